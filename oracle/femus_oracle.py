@@ -1,0 +1,828 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+CPU (numpy/scipy) restatement of the FEMuS hot path named by BASELINE.json:north_star:
+FE tables -> element Jacobian / stiffness / residual -> box mesh + uniform refinement + DOF
+numbering -> CSR assembly -> Dirichlet rows -> prolongators -> Galerkin coarse operators ->
+multiplicative V-cycle (Richardson/Jacobi) -> outer Richardson / GMRES / PCG.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this
+package; the product (femus_amd/) never does.
+
+Pinning status (see DESIGN.md "Oracle"):
+  * Gauss tables, 1-D/2-D/3-D Lagrange bases, node tables: PINNED against the reference's own
+    compiled sources (oracle/_ref/libfemus_ref_fe.so, built by oracle/Makefile from
+    /root/reference/src/02_reference_geom_elements/{00_definition,01_fe,02_quadrature}) and against
+    tests/golden/fe_tables.npz generated from that library by tests/golden/make_golden.py.
+  * Jacobian / element matrix / mesh numbering / prolongator / MG cycle: the reference code for
+    these needs boost, a cmake-generated FemusConfig.hpp and PETSc 3.20.2 (not in the image) =>
+    "parity unpinned" by a reference run; restated from the cited file:line and checked by
+    analytic properties (partition of unity, polynomial exactness, manufactured solution).
+
+All paths below are relative to /root/reference/.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+# ----------------------------------------------------------------------------------------------
+# a1. Gauss tables  (src/02_reference_geom_elements/02_quadrature/quadrature_interface.cpp:36-94,
+#     1d/quadrature_Line.cpp:10-36, 2d/quadrature_Quadrangle.cpp:11-, 3d/quadrature_Hexahedron.cpp:11-)
+# The reference stores tensor-product Gauss-Legendre rules as literals with 14 significant digits
+# (e.g. 0.57735026918963).  Rules 0..4 are reproduced as: exact rule -> tensor product -> round to
+# 14 significant digits; bit-equality with the reference literals is asserted in tests/test_oracle_ref.py.
+# ----------------------------------------------------------------------------------------------
+_ORDER_INDEX = {"zero": 0, "first": 0, "second": 1, "third": 1, "fourth": 2, "fifth": 2,
+                "sixth": 3, "seventh": 3, "eighth": 4, "ninth": 4}
+
+
+_WEIGHT_LITERAL_OVERRIDE = {("hex", 4): (0.042091477490532, 0.078911515795071, 0.14794033605678, 0.27735296695391)}
+
+
+def _round14(v):
+    v = np.asarray(v, dtype=np.float64)
+    out = np.array([float("%.14g" % x) for x in v.ravel()]).reshape(v.shape)
+    return out + 0.0  # turn -0.0 into 0.0
+
+
+def gauss_order_index(order):
+    return _ORDER_INDEX[order]
+
+
+def gauss_1d_exact(n):
+    x, w = np.polynomial.legendre.leggauss(n)
+    x = 0.5 * (x - x[::-1])  # symmetrise
+    w = 0.5 * (w + w[::-1])
+    return x, w
+
+
+def gauss_table(geom, order):
+    """returns (w[ng], x[ng, dim]) in the reference's point order (first coordinate slowest)."""
+    n = gauss_order_index(order) + 1
+    dim = {"line": 1, "quad": 2, "hex": 3}[geom]
+    x1, w1 = gauss_1d_exact(n)
+    if dim == 1:
+        w = w1.copy()
+        x = x1[:, None].copy()
+    elif dim == 2:
+        w = (w1[:, None] * w1[None, :]).ravel()
+        X, Y = np.meshgrid(x1, x1, indexing="ij")
+        x = np.stack([X.ravel(), Y.ravel()], axis=1)
+    else:
+        w = (w1[:, None, None] * w1[None, :, None] * w1[None, None, :]).ravel()
+        X, Y, Z = np.meshgrid(x1, x1, x1, indexing="ij")
+        x = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    if n == 1:  # {2},{0} / {4},{0},{0} / {8},{0},{0},{0}
+        return w, x * 0.0
+    w, x = _round14(w), _round14(x)
+    if (geom, n) in _WEIGHT_LITERAL_OVERRIDE:
+        # the reference literal differs from round14(exact product) in the last digit for this rule
+        # (3d/quadrature_Hexahedron.cpp, Gauss3): weights are classed by how many of the three 1-D
+        # indices are inner points of the 4-point rule.
+        inner = ((np.arange(n) > 0) & (np.arange(n) < n - 1)).astype(np.int64)
+        cls = (inner[:, None, None] + inner[None, :, None] + inner[None, None, :]).ravel()
+        w = np.asarray(_WEIGHT_LITERAL_OVERRIDE[(geom, n)])[cls]
+    return w, x
+
+
+# ----------------------------------------------------------------------------------------------
+# a2. 1-D Lagrange polynomials (src/02_reference_geom_elements/01_fe/1d/Edge.hpp:72-104) and the
+#     tensor-product hex / quad bases (3d/Hexahedron.cpp:95-163, 2d/Quadrilateral.cpp:68-110)
+# index i in {0,1,2}: 0 -> node at -1, 1 -> node at 0, 2 -> node at +1
+# ----------------------------------------------------------------------------------------------
+def lag_linear(x, i):
+    return (i == 0) * 0.5 * (1. - x) + (i == 2) * 0.5 * (1. + x)
+
+
+def dlag_linear(x, i):
+    return (i == 0) * (-0.5) + (i == 2) * 0.5 + 0.0 * x
+
+
+def lag_biquadratic(x, i):
+    return (i == 0) * 0.5 * x * (x - 1.) + (i == 1) * (1. - x) * (1. + x) + (i == 2) * 0.5 * x * (1. + x)
+
+
+def dlag_biquadratic(x, i):
+    return (i == 0) * (x - 0.5) + (i == 1) * (-2. * x) + (i == 2) * (x + 0.5)
+
+
+def d2lag_biquadratic(x, i):
+    return (i == 0) * 1.0 + (i == 1) * (-2.) + (i == 2) * 1.0 + 0.0 * x
+
+
+# FEMuS local node order (the convention of hex_lag::Xc / quad_lag::Xc): vertices, edge mid-points
+# (bottom ring, top ring, vertical), side-face centres (y-,x+,y+,x-), bottom, top, centre.
+XC_HEX27 = np.array(
+    [[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1],
+     [0, -1, -1], [1, 0, -1], [0, 1, -1], [-1, 0, -1], [0, -1, 1], [1, 0, 1], [0, 1, 1], [-1, 0, 1],
+     [-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0],
+     [0, -1, 0], [1, 0, 0], [0, 1, 0], [-1, 0, 0], [0, 0, -1], [0, 0, 1], [0, 0, 0]], dtype=np.float64)
+XC_QUAD9 = np.array([[-1, -1], [1, -1], [1, 1], [-1, 1], [0, -1], [1, 0], [0, 1], [-1, 0], [0, 0]],
+                    dtype=np.float64)
+
+
+def xc_table(geom):
+    return {"hex": XC_HEX27, "quad": XC_QUAD9}[geom]
+
+
+def ind_table(geom):
+    """IND[j][d] in {0,1,2} = 1-D node index of local node j along d (Hexahedron.cpp:40-47)."""
+    return (xc_table(geom) + 1).astype(np.int64)
+
+
+def ndofs(geom, fe):
+    dim = xc_table(geom).shape[1]
+    return {"linear": 2 ** dim, "biquadratic": 3 ** dim}[fe]
+
+
+def n_vertices(geom):
+    return 2 ** xc_table(geom).shape[1]
+
+
+def class_ranges(geom):
+    """local-node ranges of the three C0 Lagrange families: [0,nv) vertices, [nv,ne) edge mids,
+    [ne,nc) face/centre (elem::GetElementDofNumber(iel,k), k=0,1,2)."""
+    return {"hex": (8, 20, 27), "quad": (4, 8, 9)}[geom]
+
+
+def eval_basis(geom, fe, pts):
+    """phi[np, nc], dphi[np, nc, dim], d2phi[np, nc, ndd] at reference points pts[np, dim].
+    d2 order: 3-D (xx, yy, zz, xy, yz, zx); 2-D (xx, yy, xy)."""
+    pts = np.atleast_2d(np.asarray(pts, dtype=np.float64))
+    dim = pts.shape[1]
+    nc = ndofs(geom, fe)
+    IND = ind_table(geom)[:nc]
+    if fe == "linear":
+        L, D = lag_linear, dlag_linear
+        D2 = lambda x, i: 0.0 * x
+    else:
+        L, D, D2 = lag_biquadratic, dlag_biquadratic, d2lag_biquadratic
+    npts = pts.shape[0]
+    phi = np.empty((npts, nc))
+    dphi = np.empty((npts, nc, dim))
+    d2 = np.empty((npts, nc, 3 if dim == 2 else 6))
+    for j in range(nc):
+        l = [L(pts[:, d], IND[j, d]) for d in range(dim)]
+        dl = [D(pts[:, d], IND[j, d]) for d in range(dim)]
+        d2l = [D2(pts[:, d], IND[j, d]) for d in range(dim)]
+        if dim == 2:
+            phi[:, j] = l[0] * l[1]
+            dphi[:, j, 0] = dl[0] * l[1]
+            dphi[:, j, 1] = l[0] * dl[1]
+            d2[:, j, 0] = d2l[0] * l[1]
+            d2[:, j, 1] = l[0] * d2l[1]
+            d2[:, j, 2] = dl[0] * dl[1]
+        else:
+            phi[:, j] = l[0] * l[1] * l[2]
+            dphi[:, j, 0] = dl[0] * l[1] * l[2]
+            dphi[:, j, 1] = l[0] * dl[1] * l[2]
+            dphi[:, j, 2] = l[0] * l[1] * dl[2]
+            d2[:, j, 0] = d2l[0] * l[1] * l[2]
+            d2[:, j, 1] = l[0] * d2l[1] * l[2]
+            d2[:, j, 2] = l[0] * l[1] * d2l[2]
+            d2[:, j, 3] = dl[0] * dl[1] * l[2]
+            d2[:, j, 4] = l[0] * dl[1] * dl[2]
+            d2[:, j, 5] = dl[0] * l[1] * dl[2]
+    return phi, dphi, d2
+
+
+# ----------------------------------------------------------------------------------------------
+# a3. FE-at-quadrature tables (03_fe_evaluations_at_quadrature/ElemType.cpp:576-633, 637-741):
+#     _phi[ig][j], _dphidxi[ig][j] ... row-major [ng][nc]
+# ----------------------------------------------------------------------------------------------
+class ElemType:
+    def __init__(self, geom, fe, order="seventh"):
+        self.geom, self.fe, self.order = geom, fe, order
+        self.dim = xc_table(geom).shape[1]
+        self.nc = ndofs(geom, fe)
+        self.w, self.xg = gauss_table(geom, order)
+        self.ng = self.w.size
+        self.phi, self.dphi, self.d2phi = eval_basis(geom, fe, self.xg)
+
+    # a4. elem_type_{2,3}D::Jacobian_type<double> (ElemType.hpp:1183-1248, 1438-1537)
+    def jacobian(self, vt, ig):
+        """vt[dim][>=nc] element node coordinates (SoA).  Returns Weight, phi[nc], gradphi[nc*dim]."""
+        dim, nc = self.dim, self.nc
+        Jac = np.zeros((dim, dim))
+        for inode in range(nc):  # same accumulation order as the reference loop
+            for a in range(dim):
+                for b in range(dim):
+                    Jac[a, b] += self.dphi[ig, inode, a] * vt[b][inode]
+        if dim == 2:
+            det = Jac[0, 0] * Jac[1, 1] - Jac[0, 1] * Jac[1, 0]
+            JacI = np.array([[Jac[1, 1] / det, -Jac[0, 1] / det], [-Jac[1, 0] / det, Jac[0, 0] / det]])
+        else:
+            det = (Jac[0, 0] * (Jac[1, 1] * Jac[2, 2] - Jac[1, 2] * Jac[2, 1]) +
+                   Jac[0, 1] * (Jac[1, 2] * Jac[2, 0] - Jac[1, 0] * Jac[2, 2]) +
+                   Jac[0, 2] * (Jac[1, 0] * Jac[2, 1] - Jac[1, 1] * Jac[2, 0]))
+            JacI = np.empty((3, 3))
+            JacI[0, 0] = (-Jac[1, 2] * Jac[2, 1] + Jac[1, 1] * Jac[2, 2]) / det
+            JacI[0, 1] = (Jac[0, 2] * Jac[2, 1] - Jac[0, 1] * Jac[2, 2]) / det
+            JacI[0, 2] = (-Jac[0, 2] * Jac[1, 1] + Jac[0, 1] * Jac[1, 2]) / det
+            JacI[1, 0] = (Jac[1, 2] * Jac[2, 0] - Jac[1, 0] * Jac[2, 2]) / det
+            JacI[1, 1] = (-Jac[0, 2] * Jac[2, 0] + Jac[0, 0] * Jac[2, 2]) / det
+            JacI[1, 2] = (Jac[0, 2] * Jac[1, 0] - Jac[0, 0] * Jac[1, 2]) / det
+            JacI[2, 0] = (-Jac[1, 1] * Jac[2, 0] + Jac[1, 0] * Jac[2, 1]) / det
+            JacI[2, 1] = (Jac[0, 1] * Jac[2, 0] - Jac[0, 0] * Jac[2, 1]) / det
+            JacI[2, 2] = (-Jac[0, 1] * Jac[1, 0] + Jac[0, 0] * Jac[1, 1]) / det
+        weight = det * self.w[ig]
+        gradphi = np.empty(nc * dim)
+        for inode in range(nc):
+            for a in range(dim):
+                s = self.dphi[ig, inode, 0] * JacI[a, 0]
+                for b in range(1, dim):
+                    s = s + self.dphi[ig, inode, b] * JacI[a, b]
+                gradphi[dim * inode + a] = s
+        return weight, self.phi[ig].copy(), gradphi
+
+
+# ----------------------------------------------------------------------------------------------
+# a7. Poisson element loop (src/08_equations/assemble/
+#     00_poisson_eqn_with_all_dirichlet_bc_AD_or_nonAD_separate.hpp:111-215)
+#   Res[i] += (-f(x_g) phi_i - grad phi_i . grad u) w ;  Jac[i,j] += (grad phi_i . grad phi_j) w
+# ----------------------------------------------------------------------------------------------
+def elem_poisson(et, x, solu, rhs):
+    """x[dim][n_geom_nodes], solu[nc]; rhs(x_gss[dim]) -> float.  Pure-python loops, reference order."""
+    dim, nc = et.dim, et.nc
+    Res = np.zeros(nc)
+    Jac = np.zeros(nc * nc)
+    for ig in range(et.ng):
+        weight, phi, phi_x = et.jacobian(x, ig)
+        gradSolu = np.zeros(dim)
+        x_gss = np.zeros(dim)
+        for i in range(nc):
+            for jdim in range(dim):
+                gradSolu[jdim] += phi_x[i * dim + jdim] * solu[i]
+                x_gss[jdim] += x[jdim][i] * phi[i]
+        f = rhs(x_gss)
+        for i in range(nc):
+            weakLaplace = 0.
+            for jdim in range(dim):
+                weakLaplace += phi_x[i * dim + jdim] * gradSolu[jdim]
+            Res[i] += (-f * phi[i] - weakLaplace) * weight
+            for j in range(nc):
+                weakLaplacej = 0.
+                for kdim in range(dim):
+                    weakLaplacej += phi_x[i * dim + kdim] * phi_x[j * dim + kdim]
+                Jac[i * nc + j] += weakLaplacej * weight
+    return Jac.reshape(nc, nc), Res
+
+
+def elem_poisson_batch(et, X, U, rhs_vec):
+    """Vectorised restatement for many elements: X[nel, dim, nc_geom], U[nel, nc],
+    rhs_vec(xg[nel, ng, dim]) -> f[nel, ng].  Gauss-point sum is sequential (reference order)."""
+    nel = X.shape[0]
+    dim, nc, ng = et.dim, et.nc, et.ng
+    Jm = np.einsum("gna,ebn->egab", et.dphi, X[:, :, :nc])
+    det = np.linalg.det(Jm)
+    JI = np.linalg.inv(Jm)                       # JI[e,g,b,a] : d xi_a / d x_b  laid as inverse of J[a,b]=dx_b/dxi_a
+    grad = np.einsum("gna,egba->egnb", et.dphi, JI)   # grad[e,g,n,b] = sum_a dphi[g,n,a] * JI[b,a]
+    w = det * et.w[None, :]
+    xg = np.einsum("gn,ebn->egb", et.phi, X[:, :, :nc])
+    f = rhs_vec(xg)
+    gu = np.einsum("egnb,en->egb", grad, U)
+    K = np.zeros((nel, nc, nc))
+    F = np.zeros((nel, nc))
+    for g in range(ng):
+        G = grad[:, g]                           # [nel, nc, dim]
+        K += np.einsum("eid,ejd->eij", G, G) * w[:, g, None, None]
+        F += (-f[:, g, None] * et.phi[g][None, :] - np.einsum("eid,ed->ei", G, gu[:, g])) * w[:, g, None]
+    return K, F
+
+
+# ----------------------------------------------------------------------------------------------
+# a6. element prolongator (ElemType.cpp:439-532): for each fine node (child j, local i) of a refined
+#     element the coarse basis values |phi| >= 1e-14 at that node.
+# ----------------------------------------------------------------------------------------------
+def child_node_ref_coords(geom):
+    """X[j, i, :] = reference coordinate (coarse element) of local node i of child j.
+    child j is the sub-element at coarse vertex j (fine2CoarseVertexMapping, Hexahedron.cpp:75-83)."""
+    Xc = xc_table(geom)
+    nv = n_vertices(geom)
+    return 0.5 * (Xc[:nv, None, :] + Xc[None, :, :])
+
+
+def fine2coarse_vertex_mapping(geom):
+    """f2c[j][v] = coarse local node sitting at vertex v of child j."""
+    Xc = xc_table(geom)
+    nv = n_vertices(geom)
+    X = child_node_ref_coords(geom)[:, :nv, :]
+    out = np.empty((nv, nv), dtype=np.int64)
+    for j in range(nv):
+        for v in range(nv):
+            out[j, v] = np.where(np.all(Xc == X[j, v], axis=1))[0][0]
+    return out
+
+
+def elem_prolongator(geom, fe):
+    """P[j, i, :] coarse-basis values at (child j, local node i); entries with |.|<1e-14 set to 0
+    (they are dropped from the sparse row in the reference)."""
+    nc = ndofs(geom, fe)
+    X = child_node_ref_coords(geom)[:, :nc, :]
+    nv = n_vertices(geom)
+    phi, _, _ = eval_basis(geom, fe, X.reshape(-1, X.shape[-1]))
+    phi = phi.reshape(nv, nc, nc)
+    phi[np.abs(phi) < 1.0e-14] = 0.0
+    return phi
+
+
+# ----------------------------------------------------------------------------------------------
+# a10. meshes: box generator, uniform refinement, first-touch node renumbering (nprocs = 1)
+#   MeshGeneration.cpp:790-849 (nodes), :979-1075 (elements, boundary flags)
+#   MeshRefinement.cpp:240-294 (children, inherited vertices), :356-417 (edge mids),
+#   :513-620 (face centres, element centres) ; Mesh.cpp:517-559 (node renumbering)
+# ----------------------------------------------------------------------------------------------
+class Mesh:
+    """single-level mesh in FEMuS numbering (nprocs=1).
+    elem_dof[nel, nloc] biquadratic node ids; coords[nnode, dim]; face_flag[nel, nfaces] (<-1 boundary)."""
+
+    def __init__(self, geom, elem_dof, coords, face_flag, level=0):
+        self.geom = geom
+        self.dim = coords.shape[1]
+        self.elem_dof = elem_dof
+        self.coords = coords
+        self.face_flag = face_flag
+        self.level = level
+        self.nel = elem_dof.shape[0]
+        self.nnode = coords.shape[0]
+        self.own_size = None      # [n_vertex_nodes, +edge, +face] cumulative counts (dofOffset of families 0,1,2)
+        self.child_elem = None    # set on the coarse mesh by refine(): [nel, nchild]
+
+
+def face_nodes(geom):
+    """local nodes on each face (set semantics of hex_lag::faceDofs / quad_lag::faceDofs); face f is
+    identified by its centre node: hex 20+f, quad 4+f."""
+    Xc = xc_table(geom)
+    if geom == "hex":
+        centres = list(range(20, 26))
+    else:
+        centres = list(range(4, 8))
+    out = []
+    for c in centres:
+        d = np.nonzero(Xc[c])[0][0]
+        out.append(np.where(Xc[:, d] == Xc[c, d])[0])
+    return out
+
+
+def _first_touch_renumber(geom, elem_dof, nnode):
+    """Mesh.cpp:517-559 for nprocs=1: for class k in (vertices, edges, faces+centre): for iel: for local
+    nodes of class k: first touch gets the next id.  Returns mapping old->new and the cumulative counts."""
+    nv, ne, nc = class_ranges(geom)
+    mapping = np.full(nnode, -1, dtype=np.int64)
+    counter = 0
+    own = []
+    for (a, b) in ((0, nv), (nv, ne), (ne, nc)):
+        seq = elem_dof[:, a:b].ravel()            # element-major, local order: the visiting order
+        seq = seq[mapping[seq] < 0]               # not yet numbered by an earlier class
+        uniq, first = np.unique(seq, return_index=True)
+        order = np.argsort(first, kind="stable")
+        mapping[uniq[order]] = counter + np.arange(uniq.size)
+        counter += uniq.size
+        own.append(counter)
+    assert counter == nnode
+    return mapping, own
+
+
+def coarse_box_mesh(nx, ny, nz, lo=(0., 0., 0.), hi=(1., 1., 1.)):
+    """GenerateCoarseBoxMesh for QUAD9 (nz=0) / HEX27: lexicographic nodes (x fastest), elements i fastest,
+    FEMuS local node order, boundary face flags, then the nprocs=1 renumbering."""
+    if nz == 0:
+        geom, dim = "quad", 2
+        n = (nx, ny)
+    else:
+        geom, dim = "hex", 3
+        n = (nx, ny, nz)
+    Xc = xc_table(geom)
+    npts = [2 * m + 1 for m in n]
+    # coordinates: (i / (2 nx)) * (xmax - xmin) + xmin   (MeshGeneration.cpp:844-846)
+    axes = [(np.arange(npts[d], dtype=np.float64) / float(2 * n[d])) * (hi[d] - lo[d]) + lo[d] for d in range(dim)]
+    if dim == 2:
+        J, I = np.meshgrid(np.arange(npts[1]), np.arange(npts[0]), indexing="ij")
+        coords = np.stack([axes[0][I.ravel()], axes[1][J.ravel()]], axis=1)
+        ej, ei = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+        ei, ej = ei.ravel(), ej.ravel()
+        off = (Xc + 1).astype(np.int64)
+        elem_dof = (2 * ei[:, None] + off[None, :, 0]) + (2 * ej[:, None] + off[None, :, 1]) * npts[0]
+        face_flag = np.full((nx * ny, 4), -1, dtype=np.int64)
+        # QUAD9 (MeshGeneration.cpp 2-D branch): j==0 -> face 0 (-2 "bottom"), i==nx-1 -> face 1 (-3 "right"),
+        # j==ny-1 -> face 2 (-4 "top"), i==0 -> face 3 (-5 "left")
+        face_flag[ej == 0, 0] = -2
+        face_flag[ei == nx - 1, 1] = -3
+        face_flag[ej == ny - 1, 2] = -4
+        face_flag[ei == 0, 3] = -5
+    else:
+        K, J, I = np.meshgrid(np.arange(npts[2]), np.arange(npts[1]), np.arange(npts[0]), indexing="ij")
+        coords = np.stack([axes[0][I.ravel()], axes[1][J.ravel()], axes[2][K.ravel()]], axis=1)
+        ek, ej, ei = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+        ei, ej, ek = ei.ravel(), ej.ravel(), ek.ravel()
+        off = (Xc + 1).astype(np.int64)
+        elem_dof = ((2 * ei[:, None] + off[None, :, 0]) +
+                    npts[0] * ((2 * ej[:, None] + off[None, :, 1]) + (2 * ek[:, None] + off[None, :, 2]) * npts[1]))
+        face_flag = np.full((nx * ny * nz, 6), -1, dtype=np.int64)
+        face_flag[ek == 0, 4] = -2        # "bottom"
+        face_flag[ek == nz - 1, 5] = -7   # "top"
+        face_flag[ej == 0, 0] = -3        # "front"
+        face_flag[ej == ny - 1, 2] = -5   # "behind"
+        face_flag[ei == 0, 3] = -6        # "left"
+        face_flag[ei == nx - 1, 1] = -4   # "right"
+    nnode = coords.shape[0]
+    mapping, own = _first_touch_renumber(geom, elem_dof, nnode)
+    new_coords = np.empty_like(coords)
+    new_coords[mapping] = coords
+    m = Mesh(geom, mapping[elem_dof], new_coords, face_flag, level=0)
+    m.own_size = own
+    return m
+
+
+def refine(mc):
+    """MeshRefinement::RefineMesh for a fully refined level (nprocs=1)."""
+    geom = mc.geom
+    nv, ne, nc = class_ranges(geom)
+    nchild = nv
+    f2c = fine2coarse_vertex_mapping(geom)
+    Xc = xc_table(geom)
+    nel_f = mc.nel * nchild
+    ed = np.full((nel_f, nc), -1, dtype=np.int64)
+    # children 'nchild*iel + j', vertex v of child j = coarse node f2c[j][v]   (:240-268)
+    ed[:, :nv] = mc.elem_dof[:, f2c].reshape(nel_f, nv)
+    # boundary flags: child j inherits coarse face f iff vertex j lies on face f; same local face (:271-278)
+    nfaces = mc.face_flag.shape[1]
+    fn = face_nodes(geom)
+    ff = np.full((nel_f, nfaces), -1, dtype=np.int64)
+    ffv = ff.reshape(mc.nel, nchild, nfaces)
+    for f in range(nfaces):
+        for j in range(nchild):
+            if j in fn[f]:
+                ffv[:, j, f] = mc.face_flag[:, f]
+    nnodes = mc.nnode
+    # edge mid-points: loop elements, local edges in order; first visit creates the node (:356-417)
+    edge_v = np.empty((ne - nv, 2), dtype=np.int64)
+    for e in range(nv, ne):
+        d = np.where(Xc[e] == 0)[0][0]
+        vs = [v for v in range(nv) if all(Xc[v, k] == Xc[e, k] for k in range(Xc.shape[1]) if k != d)]
+        edge_v[e - nv] = sorted(vs)
+    a = ed[:, edge_v[:, 0]]
+    b = ed[:, edge_v[:, 1]]
+    key = (np.minimum(a, b) * np.int64(nnodes) + np.maximum(a, b)).ravel()
+    uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    rank = np.empty(uniq.size, dtype=np.int64)
+    rank[np.argsort(first, kind="stable")] = np.arange(uniq.size)
+    ed[:, nv:ne] = (nnodes + rank[inv]).reshape(nel_f, ne - nv)
+    nnodes += uniq.size
+    if geom == "hex":
+        # quad-face centres: loop elements, faces 0..5; shared faces matched by their vertices (:526-561)
+        fv = np.stack([np.sort(ed[:, [v for v in fn[f] if v < nv]], axis=1) for f in range(6)], axis=1)  # [nel,6,4]
+        base = np.int64(nnodes)
+        key = ((fv[:, :, 0] * base + fv[:, :, 1]) * base + fv[:, :, 2]).ravel()  # 3 vertices identify a face
+        uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+        rank = np.empty(uniq.size, dtype=np.int64)
+        rank[np.argsort(first, kind="stable")] = np.arange(uniq.size)
+        ed[:, 20:26] = (nnodes + rank[inv]).reshape(nel_f, 6)
+        nnodes += uniq.size
+    # element centres, one per element in element order (:598-616)
+    ed[:, nc - 1] = nnodes + np.arange(nel_f)
+    nnodes += nel_f
+    # Mesh.cpp:517-559 renumbering on the fine level
+    mapping, own = _first_touch_renumber(geom, ed, nnodes)
+    ed = mapping[ed]
+    mf = Mesh(geom, ed, np.zeros((nnodes, mc.dim)), ff, level=mc.level + 1)
+    mf.own_size = own
+    mc.child_elem = np.arange(nel_f).reshape(mc.nel, nchild)
+    # fine coordinates = mesh prolongator (biquadratic) x coarse coordinates (MeshRefinement.cpp:468-475)
+    P = build_prolongator(mc, mf, "biquadratic")
+    mf.coords = np.stack([P @ mc.coords[:, d] for d in range(mc.dim)], axis=1)
+    return mf
+
+
+def build_levels(nx, ny, nz, nlevels, lo=(0., 0., 0.), hi=(1., 1., 1.)):
+    ms = [coarse_box_mesh(nx, ny, nz, lo, hi)]
+    for _ in range(1, nlevels):
+        ms.append(refine(ms[-1]))
+    return ms
+
+
+# a8/a9: Mesh::GetSolutionDof + LinearEquation::GetSystemDof for one variable, nprocs=1:
+# biquadratic dof = node id; linear dof = node id (vertex nodes are numbered first); system row = dof.
+def n_dofs(mesh, fe):
+    return mesh.own_size[0] if fe == "linear" else mesh.nnode
+
+
+def elem_sys_dof(mesh, fe):
+    return mesh.elem_dof[:, :ndofs(mesh.geom, fe)]
+
+
+# a14. global prolongator (LinearImplicitSystem.cpp:761-909 ; fe_prolongation_matrices.cpp:232-287):
+# row = fine dof of (child j, local i), cols = coarse element dofs, INSERT semantics (duplicates identical)
+def build_prolongator(mc, mf, fe):
+    geom = mc.geom
+    nc = ndofs(geom, fe)
+    EP = elem_prolongator(geom, fe)                         # [nchild, nc, nc]
+    nchild = EP.shape[0]
+    rows = mf.elem_dof[mc.child_elem, :][:, :, :nc]          # [nel_c, nchild, nc]
+    cols = mc.elem_dof[:, :nc]                               # [nel_c, nc]
+    R = np.broadcast_to(rows[:, :, :, None], (mc.nel, nchild, nc, nc)).ravel()
+    C = np.broadcast_to(cols[:, None, None, :], (mc.nel, nchild, nc, nc)).ravel()
+    V = np.broadcast_to(EP[None], (mc.nel, nchild, nc, nc)).ravel()
+    keep = V != 0.0
+    R, C, V = R[keep], C[keep], V[keep]
+    nf, ncc = n_dofs(mf, fe), n_dofs(mc, fe)
+    key = R * np.int64(ncc) + C
+    uniq, first = np.unique(key, return_index=True)          # INSERT: keep one copy
+    P = sp.csr_matrix((V[first], (R[first], C[first])), shape=(nf, ncc))
+    P.sort_indices()
+    return P
+
+
+# a13. boundary flags (MultiLevelSolution.cpp:725-840): nodes on faces with flag < -1 are Dirichlet
+def dirichlet_dofs(mesh, fe):
+    nc = ndofs(mesh.geom, fe)
+    fn = face_nodes(mesh.geom)
+    mark = np.zeros(n_dofs(mesh, fe), dtype=bool)
+    for f, nodes in enumerate(fn):
+        nodes = nodes[nodes < nc]
+        els = np.where(mesh.face_flag[:, f] < -1)[0]
+        mark[mesh.elem_dof[els][:, nodes].ravel()] = True
+    return np.where(mark)[0]
+
+
+# a11/a12. sparsity + add_matrix_blocked / add_vector_blocked in element order
+def csr_pattern(mesh, fe):
+    ed = elem_sys_dof(mesh, fe)
+    nc = ed.shape[1]
+    n = n_dofs(mesh, fe)
+    R = np.repeat(ed, nc, axis=1).ravel()
+    C = np.tile(ed, (1, nc)).ravel()
+    A = sp.csr_matrix((np.ones(R.size, dtype=np.int8), (R, C)), shape=(n, n))
+    A.sum_duplicates()
+    A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32)
+
+
+def assemble_poisson(mesh, fe, rhs_vec, sol=None, order="seventh", chunk=4096):
+    """KK->zero; RES->zero; element loop; add_*_blocked (sequential element order for every entry)."""
+    et = ElemType(mesh.geom, fe, order)
+    ed = elem_sys_dof(mesh, fe)
+    nc = et.nc
+    n = n_dofs(mesh, fe)
+    indptr, indices = csr_pattern(mesh, fe)
+    vals = np.zeros(indices.size)
+    b = np.zeros(n)
+    if sol is None:
+        sol = np.zeros(n)
+    # position of (row, col) in CSR
+    for s in range(0, mesh.nel, chunk):
+        e = slice(s, min(s + chunk, mesh.nel))
+        X = np.transpose(mesh.coords[mesh.elem_dof[e]], (0, 2, 1))          # [ne, dim, nloc] biquadratic geometry
+        K, F = elem_poisson_batch(et, X, sol[ed[e]], rhs_vec)
+        rows = np.repeat(ed[e], nc, axis=1).ravel()
+        cols = np.tile(ed[e], (1, nc)).ravel()
+        pos = _csr_positions(indptr, indices, rows, cols)
+        # np.add.at applies in index order = element order, local (i,j) order
+        np.add.at(vals, pos, K.ravel())
+        np.add.at(b, ed[e].ravel(), F.ravel())
+    A = sp.csr_matrix((vals, indices, indptr), shape=(n, n))
+    return A, b
+
+
+def _csr_positions(indptr, indices, rows, cols):
+    key = rows.astype(np.int64) * (indices.max() + 1 if indices.size else 1)
+    # global sorted key array of the CSR (row-major, sorted columns) allows one searchsorted
+    ncol = np.int64(indices.max() + 1)
+    rowid = np.repeat(np.arange(indptr.size - 1, dtype=np.int64), np.diff(indptr))
+    gkey = rowid * ncol + indices
+    q = rows.astype(np.int64) * ncol + cols
+    pos = np.searchsorted(gkey, q)
+    assert np.all(gkey[pos] == q)
+    return pos
+
+
+# K5. MatZeroRows(KK, bdc, diag=1) keeping the pattern (LinearEquationSolverPetsc.cpp:428-436)
+def zero_rows(A, rows, diag):
+    A = A.tocsr(copy=True)
+    for r in rows:
+        A.data[A.indptr[r]:A.indptr[r + 1]] = 0.0
+    if diag != 0.0:
+        d = sp.csr_matrix((np.full(len(rows), diag), (rows, rows)), shape=A.shape)
+        A = (A + d).tocsr()
+    A.sort_indices()
+    return A
+
+
+def zero_rows_inplace_pattern(A, rows, diag):
+    """same, but strictly keeps A's pattern (needs the diagonal to be in the pattern)."""
+    A = A.tocsr(copy=True)
+    A.sort_indices()
+    for r in rows:
+        s, e = A.indptr[r], A.indptr[r + 1]
+        A.data[s:e] = 0.0
+        k = np.searchsorted(A.indices[s:e], r)
+        if diag != 0.0:
+            assert A.indices[s + k] == r
+            A.data[s + k] = diag
+    return A
+
+
+# LinearImplicitSystem::ZeroInterpolatorDirichletNodes (LinearImplicitSystem.cpp:1032-1120)
+def zero_interpolator_dirichlet(P, bdc_f, bdc_c):
+    P = P.tocsr(copy=True)
+    mf = np.ones(P.shape[0]); mf[bdc_f] = 0.0
+    mc = np.ones(P.shape[1]); mc[bdc_c] = 0.0
+    P = sp.diags(mf) @ P @ sp.diags(mc)
+    P = P.tocsr()
+    P.sort_indices()
+    return P
+
+
+# ----------------------------------------------------------------------------------------------
+# a15-a18. multigrid hierarchy + cycle.  The arithmetic of the production cycle lives in PETSc 3.20.2
+# (contrib/scripts/install_petsc.sh:12; NOT in /root/reference): PCMG multiplicative V-cycle, level
+# smoother KSPRICHARDSON(scale omega)+PCJACOBI with a fixed number of iterations, zero initial guess on
+# the way down, coarse PREONLY+LU, restriction = P^T (LinearImplicitSystem.cpp:379-382).  The in-repo
+# statement of the same cycle is LinearImplicitSystem::MGStep (LinearImplicitSystem.cpp:1397-1562).
+# ----------------------------------------------------------------------------------------------
+class Hierarchy:
+    pass
+
+
+def build_poisson_hierarchy(nx, ny, nz, nlevels, fe, rhs_vec, order="seventh", lo=(0., 0., 0.), hi=(1., 1., 1.)):
+    """MGsolve preparation (LinearImplicitSystem.cpp:318-383): assemble finest KK/RES, Galerkin chain
+    KK[l-1] = PP[l]^T KK[l] PP[l] from the un-penalised matrices, then SetPenalty on every level."""
+    H = Hierarchy()
+    H.meshes = build_levels(nx, ny, nz, nlevels, lo, hi)
+    H.fe = fe
+    H.bdc = [dirichlet_dofs(m, fe) for m in H.meshes]
+    H.P = [None]
+    for l in range(1, nlevels):
+        P = build_prolongator(H.meshes[l - 1], H.meshes[l], fe)
+        H.P.append(zero_interpolator_dirichlet(P, H.bdc[l], H.bdc[l - 1]))
+    A, b = assemble_poisson(H.meshes[-1], fe, rhs_vec, order=order)
+    H.A_raw = [None] * nlevels
+    H.A_raw[-1] = A
+    for l in range(nlevels - 1, 0, -1):
+        H.A_raw[l - 1] = (H.P[l].T @ H.A_raw[l] @ H.P[l]).tocsr()
+    H.A = []
+    for l in range(nlevels):
+        if l == nlevels - 1:
+            H.A.append(zero_rows_inplace_pattern(H.A_raw[l], H.bdc[l], 1.0))
+        else:
+            H.A.append(zero_rows(H.A_raw[l], H.bdc[l], 1.0))
+    H.b = b.copy()
+    H.b[H.bdc[-1]] = 0.0          # ZerosBoundaryResiduals (LinearEquationSolverPetsc.cpp:417-424)
+    H.b_raw = b
+    return H
+
+
+def jacobi_dinv(A):
+    d = A.diagonal().copy()
+    d[d == 0.0] = 1.0             # PCJACOBI: zero diagonal entries are replaced by 1
+    return 1.0 / d
+
+
+def smooth(A, dinv, b, x, omega, nsweeps, zero_guess):
+    """Richardson(omega) + Jacobi, fixed iteration count: x <- x + omega D^-1 (b - A x)."""
+    for it in range(nsweeps):
+        if zero_guess and it == 0:
+            x = omega * dinv * b
+        else:
+            x = x + omega * dinv * (b - A @ x)
+    return x
+
+
+def vcycle(H, level, b, omega=2. / 3., npre=2, npost=2, coarse_solve=None, x=None):
+    """One multiplicative V-cycle applied to rhs b, starting from x (None = zero)."""
+    A = H.A[level]
+    if level == 0:
+        if coarse_solve is None:
+            import scipy.sparse.linalg as spla
+            if not hasattr(H, "_lu"):
+                H._lu = spla.splu(H.A[0].tocsc())
+            return H._lu.solve(b)
+        return coarse_solve(b)
+    if not hasattr(H, "_dinv"):
+        H._dinv = [jacobi_dinv(a) for a in H.A]
+    dinv = H._dinv[level]
+    x = smooth(A, dinv, b, np.zeros_like(b) if x is None else x, omega, npre, zero_guess=(x is None))
+    r = b - A @ x
+    bc = H.P[level].T @ r
+    ec = vcycle(H, level - 1, bc, omega, npre, npost, coarse_solve)
+    x = x + H.P[level] @ ec
+    x = smooth(A, dinv, b, x, omega, npost, zero_guess=False)
+    return x
+
+
+def solve_richardson_mg(H, rtol=1e-10, maxit=100, **kw):
+    """outer Richardson with the V-cycle as the iteration (stationary MG iteration)."""
+    A, b = H.A[-1], H.b
+    x = np.zeros_like(b)
+    bn = np.linalg.norm(b)
+    hist = []
+    for it in range(maxit):
+        r = b - A @ x
+        rn = np.linalg.norm(r)
+        hist.append(rn)
+        if rn <= rtol * bn:
+            break
+        x = x + vcycle(H, len(H.A) - 1, r, **kw)
+    return x, hist
+
+
+def solve_pcg_mg(H, rtol=1e-10, maxit=100, **kw):
+    """PCG preconditioned by one V-cycle on the symmetrised system (Dirichlet rows are identity)."""
+    A, b = H.A[-1], H.b
+    L = len(H.A) - 1
+    x = np.zeros_like(b)
+    r = b - A @ x
+    z = vcycle(H, L, r, **kw)
+    p = z.copy()
+    rz = r @ z
+    bn = np.linalg.norm(b)
+    hist = [np.linalg.norm(r)]
+    for it in range(maxit):
+        if hist[-1] <= rtol * bn:
+            break
+        Ap = A @ p
+        alpha = rz / (p @ Ap)
+        x = x + alpha * p
+        r = r - alpha * Ap
+        hist.append(np.linalg.norm(r))
+        z = vcycle(H, L, r, **kw)
+        rz_new = r @ z
+        p = z + (rz_new / rz) * p
+        rz = rz_new
+    return x, hist
+
+
+def solve_gmres_mg(H, rtol=1e-10, maxit=100, restart=30, **kw):
+    """left-preconditioned restarted GMRES, preconditioner = one V-cycle, zero initial guess
+    (LinearEquationSolverPetsc.cpp:294-335; KSPGMRES default = classical Gram-Schmidt, left PC,
+    convergence on the preconditioned residual norm)."""
+    A, b = H.A[-1], H.b
+    L = len(H.A) - 1
+    M = lambda v: vcycle(H, L, v, **kw)
+    x = np.zeros_like(b)
+    hist = []
+    its = 0
+    beta0 = None
+    while its < maxit:
+        r = M(b - A @ x)
+        beta = np.linalg.norm(r)
+        if beta0 is None:
+            beta0 = np.linalg.norm(M(b))
+            hist.append(beta)
+        if beta <= rtol * beta0:
+            break
+        V = [r / beta]
+        Hm = np.zeros((restart + 1, restart))
+        g = np.zeros(restart + 1)
+        g[0] = beta
+        cs, sn = np.zeros(restart), np.zeros(restart)
+        k_used = 0
+        for k in range(restart):
+            w = M(A @ V[k])
+            h = np.array([w @ v for v in V])       # classical Gram-Schmidt
+            for hj, v in zip(h, V):
+                w = w - hj * v
+            Hm[:k + 1, k] = h
+            Hm[k + 1, k] = np.linalg.norm(w)
+            V.append(w / Hm[k + 1, k] if Hm[k + 1, k] != 0 else w)
+            for j in range(k):
+                t = cs[j] * Hm[j, k] + sn[j] * Hm[j + 1, k]
+                Hm[j + 1, k] = -sn[j] * Hm[j, k] + cs[j] * Hm[j + 1, k]
+                Hm[j, k] = t
+            d = np.hypot(Hm[k, k], Hm[k + 1, k])
+            cs[k], sn[k] = Hm[k, k] / d, Hm[k + 1, k] / d
+            Hm[k, k] = d
+            Hm[k + 1, k] = 0.0
+            g[k + 1] = -sn[k] * g[k]
+            g[k] = cs[k] * g[k]
+            its += 1
+            k_used = k + 1
+            hist.append(abs(g[k + 1]))
+            if abs(g[k + 1]) <= rtol * beta0 or its >= maxit:
+                break
+        y = np.linalg.solve(np.triu(Hm[:k_used, :k_used]), g[:k_used])
+        for j in range(k_used):
+            x = x + y[j] * V[j]
+        if abs(g[k_used]) <= rtol * beta0:
+            break
+    return x, hist
+
+
+# ----------------------------------------------------------------------------------------------
+# deterministic fills used by tests / bench (LCG, seed 12345, uniform [-1,1])
+# ----------------------------------------------------------------------------------------------
+def lcg_fill(n, seed=12345):
+    s = np.uint64(seed)
+    out = np.empty(n)
+    a, c = np.uint64(6364136223846793005), np.uint64(1442695040888963407)
+    # vectorised LCG via jump-ahead is overkill; n is small in tests
+    state = int(seed)
+    mask = (1 << 64) - 1
+    for i in range(n):
+        state = (state * 6364136223846793005 + 1442695040888963407) & mask
+        out[i] = ((state >> 11) / float(1 << 53)) * 2.0 - 1.0
+    return out
+
+
+def algorithmic_spmv_bytes(nnz, nrows, ncols):
+    """fp64 values + int32 columns + int32 row pointers, x and y touched once."""
+    return 12 * nnz + 4 * (nrows + 1) + 8 * ncols + 8 * nrows
