@@ -1,0 +1,123 @@
+"""ctypes loader for libfemus_hip.so (no fallback: fails loudly when the library is missing)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "libfemus_hip.so")
+
+
+def load_library():
+    global _LIB
+    if _LIB is None:
+        p = library_path()
+        if not os.path.exists(p):
+            raise LibraryMissing(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C femus_amd/csrc`). There is no CPU fallback." % p)
+        _LIB = ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+        _declare(_LIB)
+    return _LIB
+
+
+def _declare(L):
+    c_int, c_double, c_void_p, c_char_p = ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_char_p
+    P = ctypes.POINTER
+    L.fh_last_error.restype = c_char_p
+    L.fh_version.restype = c_char_p
+    L.fh_stream.restype = c_void_p
+    L.fh_stream.argtypes = [c_void_p]
+    L.fh_vec_dev_ptr.restype = c_void_p
+    L.fh_vec_dev_ptr.argtypes = [c_void_p]
+    L.fh_spmv_algorithmic_bytes.restype = ctypes.c_int64
+    L.fh_spmv_algorithmic_bytes.argtypes = [c_void_p]
+    if hasattr(L, "fh_mg_cycle_algorithmic_bytes"):
+        L.fh_mg_cycle_algorithmic_bytes.restype = ctypes.c_int64
+        L.fh_mg_cycle_algorithmic_bytes.argtypes = [c_void_p]
+    # everything else returns int and takes pointers/ints/doubles; set argtypes for calls with doubles
+    def sig(name, *args):
+        if hasattr(L, name):
+            f = getattr(L, name)
+            f.restype = c_int
+            f.argtypes = list(args)
+    sig("fh_init", c_int, P(c_void_p))
+    sig("fh_finalize", c_void_p)
+    sig("fh_device_name", c_void_p, c_char_p, c_int)
+    sig("fh_sync", c_void_p)
+    sig("fh_timer_start", c_void_p)
+    sig("fh_timer_stop", c_void_p, P(c_double))
+    sig("fh_set_option", c_void_p, c_char_p, c_double)
+    sig("fh_vec_create", c_void_p, c_int, c_int, c_int, c_void_p, c_int, P(c_void_p))
+    sig("fh_vec_duplicate", c_void_p, P(c_void_p))
+    sig("fh_vec_destroy", c_void_p)
+    sig("fh_vec_size", c_void_p, P(c_int), P(c_int), P(c_int), P(c_int))
+    sig("fh_vec_zero", c_void_p)
+    sig("fh_vec_fill", c_void_p, c_double)
+    sig("fh_vec_copy", c_void_p, c_void_p)
+    sig("fh_vec_upload", c_void_p, c_void_p)
+    sig("fh_vec_download", c_void_p, c_void_p)
+    sig("fh_vec_set_values", c_void_p, c_int, c_void_p, c_void_p)
+    sig("fh_vec_add_values", c_void_p, c_int, c_void_p, c_void_p)
+    sig("fh_vec_get_values", c_void_p, c_int, c_void_p, c_void_p)
+    sig("fh_vec_axpy", c_void_p, c_double, c_void_p)
+    sig("fh_vec_aypx", c_void_p, c_double, c_void_p)
+    sig("fh_vec_shift", c_void_p, c_double)
+    sig("fh_vec_scale", c_void_p, c_double)
+    sig("fh_vec_abs", c_void_p)
+    sig("fh_vec_pointwise_mult", c_void_p, c_void_p, c_void_p)
+    sig("fh_vec_dot", c_void_p, c_void_p, P(c_double))
+    sig("fh_vec_norm", c_void_p, c_int, P(c_double))
+    sig("fh_vec_reduce", c_void_p, c_int, P(c_double))
+    sig("fh_mat_create_csr", c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, P(c_void_p))
+    sig("fh_mat_destroy", c_void_p)
+    sig("fh_mat_size", c_void_p, P(c_int), P(c_int), P(c_int))
+    sig("fh_mat_zero", c_void_p)
+    sig("fh_mat_set_values_csr", c_void_p, c_void_p)
+    sig("fh_mat_get_values_csr", c_void_p, c_void_p)
+    sig("fh_mat_get_pattern", c_void_p, c_void_p, c_void_p)
+    sig("fh_mat_add_block", c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p)
+    sig("fh_mat_insert_row", c_void_p, c_int, c_int, c_void_p, c_void_p)
+    sig("fh_mat_get_row", c_void_p, c_int, P(c_int), c_void_p, c_void_p)
+    sig("fh_mat_zero_rows", c_void_p, c_int, c_void_p, c_double)
+    sig("fh_mat_zero_cols", c_void_p, c_int, c_void_p)
+    sig("fh_mat_get_diagonal", c_void_p, c_void_p)
+    sig("fh_mat_transpose", c_void_p, P(c_void_p))
+    sig("fh_mat_ptap", c_void_p, c_void_p, P(c_void_p))
+    sig("fh_mat_norm", c_void_p, c_int, P(c_double))
+    sig("fh_spmv", c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_double)
+    sig("fh_spmv_transpose", c_void_p, c_void_p, c_void_p)
+    sig("fh_fe_gauss", c_int, c_int, P(c_int), c_void_p, c_void_p)
+    sig("fh_fe_tables", c_int, c_int, c_int, P(c_int), P(c_int), c_void_p, c_void_p)
+    sig("fh_fe_elem_prolongator", c_int, c_int, P(c_int), P(c_int), c_void_p)
+    sig("fh_mesh_box", c_int, c_int, c_int, c_void_p, c_void_p, P(c_void_p))
+    sig("fh_mesh_refine", c_void_p, P(c_void_p))
+    sig("fh_mesh_destroy", c_void_p)
+    sig("fh_mesh_info", c_void_p, P(c_int), P(c_int), P(c_int), P(c_int), c_void_p, P(c_int))
+    sig("fh_mesh_get", c_void_p, c_void_p, c_void_p, c_void_p)
+    sig("fh_mesh_child_elems", c_void_p, c_void_p)
+    sig("fh_mesh_dirichlet_dofs", c_void_p, c_int, P(c_int), c_void_p)
+    sig("fh_pattern_from_elements", c_int, c_int, c_void_p, c_int, c_void_p, c_void_p)
+    sig("fh_build_prolongator", c_void_p, c_void_p, c_void_p, c_int, c_int, P(c_void_p))
+    sig("fh_assembler_create", c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, P(c_void_p))
+    sig("fh_assembler_destroy", c_void_p)
+    sig("fh_assemble_poisson", c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p)
+    sig("fh_assembler_info", c_void_p, P(c_int), P(ctypes.c_int64), P(c_double))
+    sig("fh_element_matrices_poisson", c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p)
+    sig("fh_mg_create", c_void_p, c_int, P(c_void_p))
+    sig("fh_mg_set_level", c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_int)
+    sig("fh_mg_setup", c_void_p)
+    sig("fh_mg_vcycle", c_void_p, c_void_p, c_void_p)
+    sig("fh_mg_solve", c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_double, c_int, c_int, P(c_int), P(c_double))
+    sig("fh_mg_destroy", c_void_p)
+    sig("fh_halo_unique_id", c_void_p)
+    sig("fh_halo_create", c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, P(c_void_p))
+    sig("fh_halo_update", c_void_p, c_void_p)
+    sig("fh_halo_allreduce_sum", c_void_p, c_void_p, c_int)
+    sig("fh_halo_destroy", c_void_p)

@@ -1,0 +1,502 @@
+"""Thin object wrappers over the C-ABI (include/femus_hip.h) for tests/ and bench.py.
+
+Method names follow the reference classes they stand for (NumericVector / SparseMatrix /
+LinearEquationSolver), so the parity tests read like FEMuS code.  No numerics happen here.
+"""
+import ctypes
+import numpy as np
+from ._lib import load_library
+
+GEOM = {"hex": 0, "quad": 1}
+FE = {"linear": 0, "biquadratic": 2}
+GAUSS_ORDER = {"zero": 0, "first": 0, "second": 1, "third": 1, "fourth": 2, "fifth": 2,
+               "sixth": 3, "seventh": 3, "eighth": 4, "ninth": 4}
+OUTER = {"preonly": 0, "richardson": 1, "gmres": 2, "cg": 3}
+
+
+class FemusHipError(RuntimeError):
+    pass
+
+
+def _chk(rc):
+    if rc != 0:
+        raise FemusHipError(load_library().fh_last_error().decode())
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Context:
+    """FemusInit replacement: one HIP device, a compute stream and a communication stream."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        self.h = ctypes.c_void_p()
+        _chk(self.L.fh_init(int(device), ctypes.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.L.fh_finalize(self.h)
+            self.h = ctypes.c_void_p()
+
+    def device_name(self):
+        buf = ctypes.create_string_buffer(256)
+        _chk(self.L.fh_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def sync(self):
+        _chk(self.L.fh_sync(self.h))
+
+    def set_option(self, name, value):
+        _chk(self.L.fh_set_option(self.h, name.encode(), float(value)))
+
+    def timer_start(self):
+        _chk(self.L.fh_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = ctypes.c_double()
+        _chk(self.L.fh_timer_stop(self.h, ctypes.byref(ms)))
+        return ms.value
+
+    # factories
+    def vector(self, n_global, n_local=None, first_local=0, ghost=None):
+        return Vec(self, n_global, n_global if n_local is None else n_local, first_local, ghost)
+
+    def vector_from(self, array):
+        a = _f64(array)
+        v = Vec(self, a.size, a.size, 0, None)
+        v.upload(a)
+        return v
+
+    def matrix_csr(self, m, n, rowptr, col, val=None):
+        return Mat.from_csr(self, m, n, rowptr, col, val)
+
+    def matrix_scipy(self, A):
+        A = A.tocsr()
+        A.sort_indices()
+        return Mat.from_csr(self, A.shape[0], A.shape[1], A.indptr, A.indices, A.data)
+
+
+class Vec:
+    """NumericVector (src/03_algebra/00_vectors/NumericVector.hpp:51)."""
+
+    def __init__(self, ctx, n_global, n_local, first_local=0, ghost=None, handle=None):
+        self.ctx, self.L = ctx, ctx.L
+        if handle is not None:
+            self.h = handle
+        else:
+            self.h = ctypes.c_void_p()
+            g = None if ghost is None else _i32(ghost)
+            _chk(self.L.fh_vec_create(ctx.h, int(n_global), int(n_local), int(first_local), _p(g),
+                                      0 if g is None else g.size, ctypes.byref(self.h)))
+        sz = [ctypes.c_int() for _ in range(4)]
+        _chk(self.L.fh_vec_size(self.h, *[ctypes.byref(s) for s in sz]))
+        self.n_global, self.n_local, self.first_local, self.nghost = [s.value for s in sz]
+
+    def destroy(self):
+        if self.h:
+            self.L.fh_vec_destroy(self.h)
+            self.h = None
+
+    def clone(self):
+        h = ctypes.c_void_p()
+        _chk(self.L.fh_vec_duplicate(self.h, ctypes.byref(h)))
+        return Vec(self.ctx, 0, 0, handle=h)
+
+    def size(self):
+        return self.n_global
+
+    def local_size(self):
+        return self.n_local
+
+    def zero(self):
+        _chk(self.L.fh_vec_zero(self.h))
+
+    def fill(self, s):
+        _chk(self.L.fh_vec_fill(self.h, float(s)))
+
+    def assign(self, other):
+        _chk(self.L.fh_vec_copy(self.h, other.h))
+
+    def upload(self, a):
+        a = _f64(a)
+        assert a.size == self.n_local
+        _chk(self.L.fh_vec_upload(self.h, _p(a)))
+
+    def to_numpy(self):
+        out = np.empty(self.n_local)
+        _chk(self.L.fh_vec_download(self.h, _p(out)))
+        return out
+
+    def set(self, idx, vals):
+        idx, vals = _i32(np.atleast_1d(idx)), _f64(np.atleast_1d(vals))
+        _chk(self.L.fh_vec_set_values(self.h, idx.size, _p(idx), _p(vals)))
+
+    def add_vector_blocked(self, vals, idx):
+        idx, vals = _i32(idx), _f64(vals)
+        _chk(self.L.fh_vec_add_values(self.h, idx.size, _p(idx), _p(vals)))
+
+    def get(self, idx):
+        idx = _i32(np.atleast_1d(idx))
+        out = np.empty(idx.size)
+        _chk(self.L.fh_vec_get_values(self.h, idx.size, _p(idx), _p(out)))
+        return out
+
+    def __call__(self, i):
+        return float(self.get([i])[0])
+
+    def add(self, a, v=None):
+        if v is None:
+            _chk(self.L.fh_vec_shift(self.h, float(a)))
+        else:
+            _chk(self.L.fh_vec_axpy(self.h, float(a), v.h))
+
+    def aypx(self, a, x):
+        _chk(self.L.fh_vec_aypx(self.h, float(a), x.h))
+
+    def scale(self, s):
+        _chk(self.L.fh_vec_scale(self.h, float(s)))
+
+    def abs(self):
+        _chk(self.L.fh_vec_abs(self.h))
+
+    def pointwise_mult(self, a, b):
+        _chk(self.L.fh_vec_pointwise_mult(self.h, a.h, b.h))
+
+    def dot(self, other):
+        out = ctypes.c_double()
+        _chk(self.L.fh_vec_dot(self.h, other.h, ctypes.byref(out)))
+        return out.value
+
+    def _norm(self, kind):
+        out = ctypes.c_double()
+        _chk(self.L.fh_vec_norm(self.h, kind, ctypes.byref(out)))
+        return out.value
+
+    def l1_norm(self):
+        return self._norm(1)
+
+    def l2_norm(self):
+        return self._norm(2)
+
+    def linfty_norm(self):
+        return self._norm(0)
+
+    def _reduce(self, kind):
+        out = ctypes.c_double()
+        _chk(self.L.fh_vec_reduce(self.h, kind, ctypes.byref(out)))
+        return out.value
+
+    def sum(self):
+        return self._reduce(0)
+
+    def min(self):
+        return self._reduce(1)
+
+    def max(self):
+        return self._reduce(2)
+
+    # SpMV family (NumericVector.hpp:281-284)
+    def matrix_mult(self, vec_in, mat):
+        _chk(self.L.fh_spmv(mat.h, vec_in.h, self.h, 0, None, None, 0.0))
+
+    def add_vector(self, vec_in, mat):
+        _chk(self.L.fh_spmv(mat.h, vec_in.h, self.h, 1, None, None, 0.0))
+
+    def resid(self, rhs, x, mat):
+        _chk(self.L.fh_spmv(mat.h, x.h, self.h, 2, rhs.h, None, 0.0))
+
+    def jacobi_sweep(self, rhs, x, mat, dinv, omega):
+        _chk(self.L.fh_spmv(mat.h, x.h, self.h, 3, rhs.h, dinv.h, float(omega)))
+
+    def matrix_mult_transpose(self, vec_in, mat):
+        _chk(self.L.fh_spmv_transpose(mat.h, vec_in.h, self.h))
+
+
+class Mat:
+    """SparseMatrix (src/03_algebra/01_matrices/SparseMatrix.hpp:48)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.L, self.h = ctx, ctx.L, handle
+        m, n, nnz = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _chk(self.L.fh_mat_size(self.h, ctypes.byref(m), ctypes.byref(n), ctypes.byref(nnz)))
+        self.m_, self.n_, self.nnz = m.value, n.value, nnz.value
+
+    @classmethod
+    def from_csr(cls, ctx, m, n, rowptr, col, val=None):
+        rowptr, col = _i32(rowptr), _i32(col)
+        v = None if val is None else _f64(val)
+        h = ctypes.c_void_p()
+        _chk(ctx.L.fh_mat_create_csr(ctx.h, int(m), int(n), _p(rowptr), _p(col), _p(v), ctypes.byref(h)))
+        return cls(ctx, h)
+
+    def destroy(self):
+        if self.h:
+            self.L.fh_mat_destroy(self.h)
+            self.h = None
+
+    def m(self):
+        return self.m_
+
+    def n(self):
+        return self.n_
+
+    def zero(self):
+        _chk(self.L.fh_mat_zero(self.h))
+
+    def set_values(self, val):
+        val = _f64(val)
+        assert val.size == self.nnz
+        _chk(self.L.fh_mat_set_values_csr(self.h, _p(val)))
+
+    def values(self):
+        out = np.empty(self.nnz)
+        _chk(self.L.fh_mat_get_values_csr(self.h, _p(out)))
+        return out
+
+    def pattern(self):
+        rp, col = np.empty(self.m_ + 1, np.int32), np.empty(self.nnz, np.int32)
+        _chk(self.L.fh_mat_get_pattern(self.h, _p(rp), _p(col)))
+        return rp, col
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        rp, col = self.pattern()
+        return sp.csr_matrix((self.values(), col, rp), shape=(self.m_, self.n_))
+
+    def add_matrix_blocked(self, vals, rows, cols):
+        rows, cols, vals = _i32(rows), _i32(cols), _f64(vals)
+        _chk(self.L.fh_mat_add_block(self.h, rows.size, _p(rows), cols.size, _p(cols), _p(vals)))
+
+    def insert_row(self, row, cols, vals):
+        cols, vals = _i32(cols), _f64(vals)
+        _chk(self.L.fh_mat_insert_row(self.h, int(row), cols.size, _p(cols), _p(vals)))
+
+    def get_row(self, row):
+        n = ctypes.c_int()
+        _chk(self.L.fh_mat_get_row(self.h, int(row), ctypes.byref(n), None, None))
+        cols, vals = np.empty(n.value, np.int32), np.empty(n.value)
+        _chk(self.L.fh_mat_get_row(self.h, int(row), ctypes.byref(n), _p(cols), _p(vals)))
+        return cols, vals
+
+    def mat_zero_rows(self, index, diag):
+        index = _i32(index)
+        _chk(self.L.fh_mat_zero_rows(self.h, index.size, _p(index), float(diag)))
+
+    def zero_cols(self, index):
+        index = _i32(index)
+        _chk(self.L.fh_mat_zero_cols(self.h, index.size, _p(index)))
+
+    def get_diagonal(self, dest):
+        _chk(self.L.fh_mat_get_diagonal(self.h, dest.h))
+
+    def get_transpose(self):
+        h = ctypes.c_void_p()
+        _chk(self.L.fh_mat_transpose(self.h, ctypes.byref(h)))
+        return Mat(self.ctx, h)
+
+    def matrix_PtAP(self, P, A, reuse=False):
+        """self = P^T A P ; call as C = Mat.ptap(P, A) for the first product"""
+        h = self.h if reuse else ctypes.c_void_p()
+        _chk(self.L.fh_mat_ptap(P.h, A.h, ctypes.byref(h)))
+        return self
+
+    @classmethod
+    def ptap(cls, P, A):
+        h = ctypes.c_void_p()
+        _chk(P.L.fh_mat_ptap(P.h, A.h, ctypes.byref(h)))
+        return cls(P.ctx, h)
+
+    def ptap_numeric(self, P, A):
+        h = ctypes.c_void_p(self.h.value if isinstance(self.h, ctypes.c_void_p) else self.h)
+        _chk(self.L.fh_mat_ptap(P.h, A.h, ctypes.byref(h)))
+
+    def l1_norm(self):
+        out = ctypes.c_double()
+        _chk(self.L.fh_mat_norm(self.h, 1, ctypes.byref(out)))
+        return out.value
+
+    def linfty_norm(self):
+        out = ctypes.c_double()
+        _chk(self.L.fh_mat_norm(self.h, 0, ctypes.byref(out)))
+        return out.value
+
+    def spmv_algorithmic_bytes(self):
+        return int(self.L.fh_spmv_algorithmic_bytes(self.h))
+
+
+class Mesh:
+    """box mesh + uniform refinement in FEMuS numbering (Mesh / MeshRefinement, nprocs = 1)."""
+
+    def __init__(self, L, handle):
+        self.L, self.h = L, handle
+        dim, nel, nnode, nloc, lev = [ctypes.c_int() for _ in range(5)]
+        own = (ctypes.c_int * 3)()
+        _chk(L.fh_mesh_info(self.h, ctypes.byref(dim), ctypes.byref(nel), ctypes.byref(nnode), ctypes.byref(nloc), own, ctypes.byref(lev)))
+        self.dim, self.nel, self.nnode, self.nloc, self.level = dim.value, nel.value, nnode.value, nloc.value, lev.value
+        self.own_size = list(own)
+        self.nfaces = 2 * self.dim
+        self.geom = "hex" if self.dim == 3 else "quad"
+
+    @classmethod
+    def box(cls, nx, ny, nz, lo=(0., 0., 0.), hi=(1., 1., 1.)):
+        L = load_library()
+        h = ctypes.c_void_p()
+        lo_, hi_ = _f64(lo), _f64(hi)
+        _chk(L.fh_mesh_box(nx, ny, nz, _p(lo_), _p(hi_), ctypes.byref(h)))
+        return cls(L, h)
+
+    def refine(self):
+        h = ctypes.c_void_p()
+        _chk(self.L.fh_mesh_refine(self.h, ctypes.byref(h)))
+        return Mesh(self.L, h)
+
+    def destroy(self):
+        if self.h:
+            self.L.fh_mesh_destroy(self.h)
+            self.h = None
+
+    def arrays(self):
+        ed = np.empty((self.nel, self.nloc), np.int32)
+        xy = np.empty((self.nnode, self.dim))
+        ff = np.empty((self.nel, self.nfaces), np.int32)
+        _chk(self.L.fh_mesh_get(self.h, _p(ed), _p(xy), _p(ff)))
+        return ed, xy, ff
+
+    def child_elems(self):
+        out = np.empty((self.nel, 2 ** self.dim), np.int32)
+        _chk(self.L.fh_mesh_child_elems(self.h, _p(out)))
+        return out
+
+    def n_dofs(self, fe):
+        return self.own_size[0] if fe == "linear" else self.nnode
+
+    def dirichlet_dofs(self, fe):
+        n = ctypes.c_int(self.nnode)
+        out = np.empty(self.nnode, np.int32)
+        _chk(self.L.fh_mesh_dirichlet_dofs(self.h, FE[fe], ctypes.byref(n), _p(out)))
+        return out[:n.value].copy()
+
+
+def pattern_from_elements(elem_dof, ndof):
+    L = load_library()
+    ed = _i32(elem_dof)
+    nel, nloc = ed.shape
+    rowptr = np.empty(ndof + 1, np.int32)
+    _chk(L.fh_pattern_from_elements(nel, nloc, _p(ed), ndof, _p(rowptr), None))
+    col = np.empty(rowptr[-1], np.int32)
+    _chk(L.fh_pattern_from_elements(nel, nloc, _p(ed), ndof, _p(rowptr), _p(col)))
+    return rowptr, col
+
+
+def fe_gauss(geom, order):
+    L = load_library()
+    dim = 3 if geom == "hex" else 2
+    ng = ctypes.c_int()
+    _chk(L.fh_fe_gauss(GEOM[geom], GAUSS_ORDER[order], ctypes.byref(ng), None, None))
+    w, x = np.empty(ng.value), np.empty((dim, ng.value))
+    _chk(L.fh_fe_gauss(GEOM[geom], GAUSS_ORDER[order], ctypes.byref(ng), _p(w), _p(x)))
+    return w, x.T.copy()
+
+
+def fe_tables(geom, fe, order):
+    L = load_library()
+    dim = 3 if geom == "hex" else 2
+    ng, nc = ctypes.c_int(), ctypes.c_int()
+    _chk(L.fh_fe_tables(GEOM[geom], FE[fe], GAUSS_ORDER[order], ctypes.byref(ng), ctypes.byref(nc), None, None))
+    phi, dphi = np.empty((ng.value, nc.value)), np.empty((dim, ng.value, nc.value))
+    _chk(L.fh_fe_tables(GEOM[geom], FE[fe], GAUSS_ORDER[order], ctypes.byref(ng), ctypes.byref(nc), _p(phi), _p(dphi)))
+    return phi, np.transpose(dphi, (1, 2, 0)).copy()
+
+
+def fe_elem_prolongator(geom, fe):
+    L = load_library()
+    nch, nc = ctypes.c_int(), ctypes.c_int()
+    _chk(L.fh_fe_elem_prolongator(GEOM[geom], FE[fe], ctypes.byref(nch), ctypes.byref(nc), None))
+    P = np.empty((nch.value, nc.value, nc.value))
+    _chk(L.fh_fe_elem_prolongator(GEOM[geom], FE[fe], ctypes.byref(nch), ctypes.byref(nc), _p(P)))
+    return P
+
+
+def build_prolongator(ctx, coarse, fine, fe, zero_bdc=True):
+    h = ctypes.c_void_p()
+    _chk(ctx.L.fh_build_prolongator(ctx.h, coarse.h, fine.h, FE[fe], 1 if zero_bdc else 0, ctypes.byref(h)))
+    return Mat(ctx, h)
+
+
+class Assembler:
+    """batched Poisson assembly (the element loop of 00_poisson_eqn_..._separate.hpp:106-228 as one call)."""
+
+    def __init__(self, ctx, mesh, fe, A, order="seventh", elem_dof=None, coords=None):
+        self.ctx, self.L = ctx, ctx.L
+        if elem_dof is None:
+            elem_dof, coords, _ = mesh.arrays()
+        ed, xy = _i32(elem_dof), _f64(coords)
+        geom = "hex" if xy.shape[1] == 3 else "quad"
+        self.h = ctypes.c_void_p()
+        _chk(self.L.fh_assembler_create(ctx.h, GEOM[geom], FE[fe], GAUSS_ORDER[order], ed.shape[0], ed.shape[1], _p(ed),
+                                        xy.shape[0], _p(xy), A.h, ctypes.byref(self.h)))
+        self.nel = ed.shape[0]
+        self.nc = {"linear": 2 ** xy.shape[1], "biquadratic": 3 ** xy.shape[1]}[fe]
+
+    def destroy(self):
+        if self.h:
+            self.L.fh_assembler_destroy(self.h)
+            self.h = None
+
+    def assemble(self, A, res, sol=None, source_kind=0, params=(1.0,)):
+        p = _f64(list(params) + [0.0] * (4 - len(params)))
+        _chk(self.L.fh_assemble_poisson(self.h, None if sol is None else sol.h, int(source_kind), _p(p), A.h, res.h))
+
+    def element_matrices(self, sol=None, source_kind=0, params=(1.0,)):
+        p = _f64(list(params) + [0.0] * (4 - len(params)))
+        K, F = np.empty((self.nel, self.nc, self.nc)), np.empty((self.nel, self.nc))
+        _chk(self.L.fh_element_matrices_poisson(self.h, None if sol is None else sol.h, int(source_kind), _p(p), _p(K), _p(F)))
+        return K, F
+
+    def info(self):
+        nco, by, fl = ctypes.c_int(), ctypes.c_int64(), ctypes.c_double()
+        _chk(self.L.fh_assembler_info(self.h, ctypes.byref(nco), ctypes.byref(by), ctypes.byref(fl)))
+        return {"ncolors": nco.value, "algorithmic_bytes": by.value, "flops": fl.value}
+
+
+class Multigrid:
+    """LinearEquationSolver MG interface: MGInit / MGSetLevel / MGSolve / MGClear."""
+
+    def __init__(self, ctx, nlevels):
+        self.ctx, self.L = ctx, ctx.L
+        self.h = ctypes.c_void_p()
+        _chk(self.L.fh_mg_create(ctx.h, int(nlevels), ctypes.byref(self.h)))
+
+    def set_level(self, level, A, P=None, R=None, smoother=0, omega=2. / 3., npre=2, npost=2):
+        _chk(self.L.fh_mg_set_level(self.h, int(level), A.h, None if P is None else P.h, None if R is None else R.h,
+                                    int(smoother), float(omega), int(npre), int(npost)))
+
+    def setup(self):
+        _chk(self.L.fh_mg_setup(self.h))
+
+    def vcycle(self, b, x):
+        _chk(self.L.fh_mg_vcycle(self.h, b.h, x.h))
+
+    def solve(self, b, x, outer="gmres", rtol=1e-10, atol=1e-50, dtol=1e50, maxit=100, restart=30):
+        its, rn = ctypes.c_int(), ctypes.c_double()
+        _chk(self.L.fh_mg_solve(self.h, b.h, x.h, OUTER[outer], float(rtol), float(atol), float(dtol), int(maxit), int(restart),
+                                ctypes.byref(its), ctypes.byref(rn)))
+        return its.value, rn.value
+
+    def cycle_algorithmic_bytes(self):
+        return int(self.L.fh_mg_cycle_algorithmic_bytes(self.h))
+
+    def destroy(self):
+        if self.h:
+            self.L.fh_mg_destroy(self.h)
+            self.h = None

@@ -1,0 +1,224 @@
+// Reference-element data on the host (a1, a2, a3, a6 of SURVEY 8): Gauss tables, Lagrange bases on
+// QUAD9 / HEX27, FE-at-quadrature tables, element prolongator.  Pure setup code: the tables are uploaded
+// once to the device by the assembler (fh_assemble.hip).
+//   Gauss    : src/02_reference_geom_elements/02_quadrature/quadrature_interface.cpp:36-94, 1d/quadrature_Line.cpp,
+//              2d/quadrature_Quadrangle.cpp, 3d/quadrature_Hexahedron.cpp (14-significant-digit literals)
+//   bases    : 01_fe/1d/Edge.hpp:72-104, 2d/Quadrilateral.cpp:68-110, 3d/Hexahedron.cpp:95-163
+//   tables   : 03_fe_evaluations_at_quadrature/ElemType.cpp:576-741
+//   prolong. : 03_fe_evaluations_at_quadrature/ElemType.cpp:439-532
+#include "fh_fe.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+namespace fhfe {
+
+// local node coordinates of the FEMuS HEX27 / QUAD9 ordering: 8 vertices, 12 edge mid-points (bottom ring,
+// top ring, vertical), 4 side-face centres (y-, x+, y+, x-), bottom, top, centre.
+static const signed char XC_HEX[27][3] = {
+    {-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {1, 1, 1}, {-1, 1, 1},
+    {0, -1, -1},  {1, 0, -1},  {0, 1, -1}, {-1, 0, -1}, {0, -1, 1},  {1, 0, 1},  {0, 1, 1}, {-1, 0, 1},
+    {-1, -1, 0},  {1, -1, 0},  {1, 1, 0},  {-1, 1, 0},  {0, -1, 0},  {1, 0, 0},  {0, 1, 0}, {-1, 0, 0},
+    {0, 0, -1},   {0, 0, 1},   {0, 0, 0}};
+static const signed char XC_QUAD[9][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}, {0, -1}, {1, 0}, {0, 1}, {-1, 0}, {0, 0}};
+
+int dim_of(int geom) { return geom == GEOM_HEX ? 3 : 2; }
+int nloc_of(int geom) { return geom == GEOM_HEX ? 27 : 9; }
+int nvert_of(int geom) { return geom == GEOM_HEX ? 8 : 4; }
+int nedge_end_of(int geom) { return geom == GEOM_HEX ? 20 : 8; }
+int nfaces_of(int geom) { return geom == GEOM_HEX ? 6 : 4; }
+int ndofs_of(int geom, int fe) { return fe == FE_LINEAR ? nvert_of(geom) : nloc_of(geom); }
+
+int xc(int geom, int node, int d) { return geom == GEOM_HEX ? XC_HEX[node][d] : XC_QUAD[node][d]; }
+
+// ---- Gauss-Legendre in extended precision, then the reference's 14-significant-digit rounding -----------
+static void gauss_legendre_ld(int n, long double* x, long double* w) {
+  const long double pi = 3.14159265358979323846264338327950288L;
+  for (int i = 0; i < n; i++) {
+    long double z = cosl(pi * (i + 0.75L) / (n + 0.5L));
+    long double pp = 1;
+    for (int it = 0; it < 100; it++) {
+      long double p1 = 1, p2 = 0;
+      for (int j = 0; j < n; j++) {
+        long double p3 = p2;
+        p2 = p1;
+        p1 = ((2 * j + 1) * z * p2 - j * p3) / (j + 1);
+      }
+      pp = n * (z * p1 - p2) / (z * z - 1);
+      long double z1 = z;
+      z = z1 - p1 / pp;
+      if (fabsl(z - z1) < 1e-19L) break;
+    }
+    x[n - 1 - i] = z;  // ascending
+    w[n - 1 - i] = 2 / ((1 - z * z) * pp * pp);
+  }
+  if (n % 2) x[n / 2] = 0;
+}
+
+static double round14(long double v) {
+  char buf[64];
+  snprintf(buf, sizeof(buf), "%.14Lg", v);
+  double r = strtod(buf, nullptr);
+  return r + 0.0;
+}
+
+int gauss_npoints(int geom, int order) {
+  int n = order + 1, d = (geom == GEOM_LINE) ? 1 : dim_of(geom), r = 1;
+  for (int k = 0; k < d; k++) r *= n;
+  return r;
+}
+
+// w[ng], x[d*ng + ig]; first coordinate slowest, as the reference tables
+int gauss_table(int geom, int order, double* w, double* x) {
+  if (order < 0 || order > 4) return 1;
+  const int n = order + 1;
+  const int d = (geom == GEOM_LINE) ? 1 : dim_of(geom);
+  long double x1[8], w1[8];
+  gauss_legendre_ld(n, x1, w1);
+  const int ng = gauss_npoints(geom, order);
+  // the reference's hex "seventh" literals deviate from round14(exact) in the last digit
+  // (3d/quadrature_Hexahedron.cpp Gauss3): classes by the number of inner 1-D points among (i,j,k)
+  static const double HEX4[4] = {0.042091477490532, 0.078911515795071, 0.14794033605678, 0.27735296695391};
+  for (int ig = 0; ig < ng; ig++) {
+    int idx[3] = {0, 0, 0};
+    int r = ig;
+    for (int k = d - 1; k >= 0; k--) {
+      idx[k] = r % n;
+      r /= n;
+    }
+    long double ww = 1;
+    int inner = 0;
+    for (int k = 0; k < d; k++) {
+      ww *= w1[idx[k]];
+      inner += (idx[k] > 0 && idx[k] < n - 1);
+      if (x) x[k * ng + ig] = (n == 1) ? 0.0 : round14(x1[idx[k]]);
+    }
+    if (w) {
+      if (n == 1) w[ig] = (double)ww;
+      else if (geom == GEOM_HEX && n == 4) w[ig] = HEX4[inner];
+      else w[ig] = round14(ww);
+    }
+  }
+  return 0;
+}
+
+// ---- 1-D Lagrange polynomials, same expressions as Edge.hpp:72-104 ------------------------------------
+static inline double lagL(double x, int i) { return (!i) * 0.5 * (1. - x) + !(i - 2) * 0.5 * (1. + x); }
+static inline double dlagL(double, int i) { return (!i) * (-0.5) + !(i - 2) * 0.5; }
+static inline double lagB(double x, int i) { return !i * 0.5 * x * (x - 1.) + !(i - 1) * (1. - x) * (1. + x) + !(i - 2) * 0.5 * x * (1. + x); }
+static inline double dlagB(double x, int i) { return !i * (x - 0.5) + !(i - 1) * (-2. * x) + !(i - 2) * (x + 0.5); }
+
+void eval_basis(int geom, int fe, const double* pt, double* phi, double* dphi /* [nc*dim] node-major */) {
+  const int d = dim_of(geom), nc = ndofs_of(geom, fe);
+  for (int j = 0; j < nc; j++) {
+    double l[3], dl[3];
+    for (int k = 0; k < d; k++) {
+      const int I = xc(geom, j, k) + 1;
+      l[k] = (fe == FE_LINEAR) ? lagL(pt[k], I) : lagB(pt[k], I);
+      dl[k] = (fe == FE_LINEAR) ? dlagL(pt[k], I) : dlagB(pt[k], I);
+    }
+    if (d == 2) {
+      if (phi) phi[j] = l[0] * l[1];
+      if (dphi) {
+        dphi[j * 2 + 0] = dl[0] * l[1];
+        dphi[j * 2 + 1] = l[0] * dl[1];
+      }
+    } else {
+      if (phi) phi[j] = l[0] * l[1] * l[2];
+      if (dphi) {
+        dphi[j * 3 + 0] = dl[0] * l[1] * l[2];
+        dphi[j * 3 + 1] = l[0] * dl[1] * l[2];
+        dphi[j * 3 + 2] = l[0] * l[1] * dl[2];
+      }
+    }
+  }
+}
+
+int shape_tables(int geom, int fe, int order, std::vector<double>& w, std::vector<double>& phi, std::vector<double>& dphi) {
+  const int d = dim_of(geom), nc = ndofs_of(geom, fe), ng = gauss_npoints(geom, order);
+  w.resize(ng);
+  std::vector<double> x((size_t)d * ng);
+  if (gauss_table(geom, order, w.data(), x.data())) return 1;
+  phi.resize((size_t)ng * nc);
+  dphi.resize((size_t)ng * nc * d);   // [ig][node][dim]
+  for (int ig = 0; ig < ng; ig++) {
+    double pt[3] = {0, 0, 0};
+    for (int k = 0; k < d; k++) pt[k] = x[k * ng + ig];
+    eval_basis(geom, fe, pt, &phi[(size_t)ig * nc], &dphi[(size_t)ig * nc * d]);
+  }
+  return 0;
+}
+
+// child j = sub-element at coarse vertex j; local node i of child j sits at (Xc[j] + Xc[i]) / 2
+void child_node_ref(int geom, int child, int node, double* pt) {
+  for (int k = 0; k < dim_of(geom); k++) pt[k] = 0.5 * (xc(geom, child, k) + xc(geom, node, k));
+}
+
+int fine2coarse_vertex(int geom, int child, int v) {
+  double pt[3];
+  child_node_ref(geom, child, v, pt);
+  for (int n = 0; n < nloc_of(geom); n++) {
+    bool same = true;
+    for (int k = 0; k < dim_of(geom); k++) same &= (xc(geom, n, k) == pt[k]);
+    if (same) return n;
+  }
+  return -1;
+}
+
+void elem_prolongator(int geom, int fe, std::vector<double>& P) {
+  const int nch = nvert_of(geom), nc = ndofs_of(geom, fe);
+  P.assign((size_t)nch * nc * nc, 0.0);
+  std::vector<double> phi(nc);
+  for (int j = 0; j < nch; j++)
+    for (int i = 0; i < nc; i++) {
+      double pt[3];
+      child_node_ref(geom, j, i, pt);
+      eval_basis(geom, fe, pt, phi.data(), nullptr);
+      for (int k = 0; k < nc; k++) P[((size_t)j * nc + i) * nc + k] = (fabs(phi[k]) >= 1.0e-14) ? phi[k] : 0.0;
+    }
+}
+
+}  // namespace fhfe
+
+// ---- C-ABI -------------------------------------------------------------------------------------------------
+#include "fh_internal.h"
+
+extern "C" int fh_fe_gauss(int geom, int order, int* ng, double* w, double* x) {
+  FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_gauss: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(order >= 0 && order <= 4, "fh_fe_gauss: Gauss rule index %d not supported (0..4)", order);
+  if (ng) *ng = fhfe::gauss_npoints(geom, order);
+  if (w || x) fhfe::gauss_table(geom, order, w, x);
+  return 0;
+}
+
+extern "C" int fh_fe_tables(int geom, int fe, int order, int* ng, int* nc, double* phi, double* dphi) {
+  FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_tables: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(fe == 0 || fe == 2, "fh_fe_tables: fe must be 0 (linear) or 2 (biquadratic)");
+  FH_REQUIRE(order >= 0 && order <= 4, "fh_fe_tables: Gauss rule index %d not supported (0..4)", order);
+  const int d = fhfe::dim_of(geom), n = fhfe::ndofs_of(geom, fe), g = fhfe::gauss_npoints(geom, order);
+  if (ng) *ng = g;
+  if (nc) *nc = n;
+  if (phi || dphi) {
+    std::vector<double> w, p, dp;
+    fhfe::shape_tables(geom, fe, order, w, p, dp);
+    if (phi) memcpy(phi, p.data(), p.size() * sizeof(double));
+    if (dphi)   // reference layout: one [ng][nc] table per direction (_dphidxi, _dphideta, _dphidzeta)
+      for (int k = 0; k < d; k++)
+        for (int ig = 0; ig < g; ig++)
+          for (int j = 0; j < n; j++) dphi[((size_t)k * g + ig) * n + j] = dp[((size_t)ig * n + j) * d + k];
+  }
+  return 0;
+}
+
+extern "C" int fh_fe_elem_prolongator(int geom, int fe, int* nchild, int* nc, double* P) {
+  FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_elem_prolongator: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(fe == 0 || fe == 2, "fh_fe_elem_prolongator: fe must be 0 (linear) or 2 (biquadratic)");
+  if (nchild) *nchild = fhfe::nvert_of(geom);
+  if (nc) *nc = fhfe::ndofs_of(geom, fe);
+  if (P) {
+    std::vector<double> v;
+    fhfe::elem_prolongator(geom, fe, v);
+    memcpy(P, v.data(), v.size() * sizeof(double));
+  }
+  return 0;
+}

@@ -1,0 +1,22 @@
+// host-side reference-element helpers (see fh_fe.cpp)
+#pragma once
+#include <vector>
+
+namespace fhfe {
+enum { GEOM_HEX = 0, GEOM_QUAD = 1, GEOM_LINE = 2 };
+enum { FE_LINEAR = 0, FE_BIQUADRATIC = 2 };
+int dim_of(int geom);
+int nloc_of(int geom);        // biquadratic nodes per element (27 / 9)
+int nvert_of(int geom);       // 8 / 4 (= number of children)
+int nedge_end_of(int geom);   // end of the edge-node range (20 / 8)
+int nfaces_of(int geom);
+int ndofs_of(int geom, int fe);
+int xc(int geom, int node, int d);   // local node coordinates in {-1,0,1}
+int gauss_npoints(int geom, int order);
+int gauss_table(int geom, int order, double* w, double* x);
+void eval_basis(int geom, int fe, const double* pt, double* phi, double* dphi);
+int shape_tables(int geom, int fe, int order, std::vector<double>& w, std::vector<double>& phi, std::vector<double>& dphi);
+void child_node_ref(int geom, int child, int node, double* pt);
+int fine2coarse_vertex(int geom, int child, int v);
+void elem_prolongator(int geom, int fe, std::vector<double>& P);
+}  // namespace fhfe

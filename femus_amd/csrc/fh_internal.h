@@ -1,0 +1,87 @@
+// Internal declarations shared by the translation units of libfemus_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/femus_hip.h"
+
+void fh_set_error(const char* fmt, ...);
+
+#define FH_CHECK_HIP(expr)                                                                        \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      fh_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));     \
+      return 1;                                                                                   \
+    }                                                                                             \
+  } while (0)
+
+#define FH_REQUIRE(cond, ...)                                                                     \
+  do {                                                                                            \
+    if (!(cond)) {                                                                                \
+      fh_set_error(__VA_ARGS__);                                                                  \
+      return 2;                                                                                   \
+    }                                                                                             \
+  } while (0)
+
+#define FH_TRY(expr)                                                                              \
+  do {                                                                                            \
+    int _r = (expr);                                                                              \
+    if (_r) return _r;                                                                            \
+  } while (0)
+
+struct fh_ctx_s {
+  int device = 0;
+  hipStream_t stream = nullptr;       // compute stream
+  hipStream_t comm_stream = nullptr;  // halo / collective stream
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_join = nullptr;
+  int num_cu = 256;
+  // reduction scratch
+  double* d_red = nullptr;            // device partials
+  double* h_red = nullptr;            // pinned host
+  size_t red_cap = 0;
+  // options
+  int spmv_tile = 2048;               // nnz per row block (LDS tile)
+  int spmv_xcd_remap = 1;
+  int spmv_kernel = 0;                // 0: csr-stream, 1: csr-vector
+  int assemble_emap = 1;
+  int use_graph = 1;
+};
+
+struct fh_vec_s {
+  fh_ctx_t ctx = nullptr;
+  int n_global = 0, n_local = 0, first_local = 0, nghost = 0;
+  double* d = nullptr;                // [n_local + nghost]
+  std::vector<int> ghost_idx;         // global indices of ghosts (host copy)
+  int* d_ghost_idx = nullptr;
+};
+
+struct fh_mat_s {
+  fh_ctx_t ctx = nullptr;
+  int m = 0, n = 0, nnz = 0;
+  int* d_rowptr = nullptr;
+  int* d_col = nullptr;
+  double* d_val = nullptr;
+  std::vector<int> h_rowptr, h_col;   // host copy of the pattern (setup-time integer work)
+  // CSR-stream row blocks
+  int tile = 0;
+  int nblk = 0;
+  int* d_rowblk = nullptr;
+  int max_row = 0;
+  // cached explicit transpose for matrix_mult_transpose
+  fh_mat_t At = nullptr;
+  int* d_tperm = nullptr;             // At.val[k] = val[tperm[k]]
+  bool at_valid = false;
+};
+
+// kernels / helpers implemented across TUs
+int fh_reserve_reduction(fh_ctx_t ctx, size_t ndoubles);
+int fh_mat_build_rowblocks(fh_mat_t A, int tile);
+int fh_mat_refresh_transpose(fh_mat_t A);   // re-gather values into the cached transpose
+int fh_dev_spmv(fh_mat_t A, const double* x, double* y, int mode, const double* b, const double* dinv, double omega);
+
+static inline int fh_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,527 @@
+// Device CSR matrices and the SpMV family (K7, K8, K9, K10 of SURVEY 2.1) for gfx950.
+// Replaces PetscMatrix / MatMult / MatMultAdd / MatMultTranspose / MatZeroRows
+// (src/03_algebra/01_matrices/PetscMatrix.cpp, src/03_algebra/00_vectors/PetscVector.cpp:182-247).
+//
+// SpMV design ("CSR-stream", HBM-bound): rows are grouped at setup into row blocks of <= TILE non-zeros.
+// One 256-thread workgroup per block streams its contiguous slice of (val, col) with fully coalesced
+// 16 B + 8 B loads per lane, multiplies by the gathered x entries (L1/L2/Infinity-Cache hits: x is
+// 17 MB on the 64^3 level) and parks the products in LDS; a wave-level segmented reduction (G lanes per
+// row, shuffles) then produces the rows.  The epilogue fuses residual / Jacobi-sweep forms, so a smoother
+// sweep moves the matrix exactly once.  Blocks are renumbered so that consecutive row blocks (which share
+// x lines) run on the same XCD and hit the same 4 MiB L2.
+#include "fh_internal.h"
+#include <algorithm>
+#include <cmath>
+
+// ------------------------------------------------------------------------------------------------
+// creation / destruction
+// ------------------------------------------------------------------------------------------------
+extern "C" int fh_mat_create_csr(fh_ctx_t c, int m, int n, const int* rowptr, const int* col, const double* val, fh_mat_t* out) {
+  FH_REQUIRE(c && out && rowptr, "fh_mat_create_csr: null argument");
+  FH_REQUIRE(m >= 0 && n >= 0 && rowptr[0] == 0, "fh_mat_create_csr: bad sizes");
+  const int nnz = rowptr[m];
+  FH_REQUIRE(nnz == 0 || col != nullptr, "fh_mat_create_csr: null column array");
+  fh_mat_t A = new fh_mat_s();
+  A->ctx = c;
+  A->m = m;
+  A->n = n;
+  A->nnz = nnz;
+  A->h_rowptr.assign(rowptr, rowptr + m + 1);
+  A->h_col.assign(col, col + nnz);
+  int maxrow = 0;
+  for (int i = 0; i < m; i++) {
+    FH_REQUIRE(rowptr[i + 1] >= rowptr[i], "fh_mat_create_csr: rowptr not monotone at row %d", i);
+    maxrow = std::max(maxrow, rowptr[i + 1] - rowptr[i]);
+    for (int k = rowptr[i]; k < rowptr[i + 1]; k++) {
+      FH_REQUIRE(col[k] >= 0 && col[k] < n, "fh_mat_create_csr: column %d out of range in row %d", col[k], i);
+      FH_REQUIRE(k == rowptr[i] || col[k] > col[k - 1], "fh_mat_create_csr: columns of row %d not strictly sorted", i);
+    }
+  }
+  A->max_row = maxrow;
+  // +2 padding: the streaming kernel reads (val,col) in aligned pairs and may touch one element past the end
+  FH_CHECK_HIP(hipMalloc(&A->d_rowptr, ((size_t)m + 1) * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&A->d_col, ((size_t)nnz + 2) * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&A->d_val, ((size_t)nnz + 2) * sizeof(double)));
+  FH_CHECK_HIP(hipMemsetAsync(A->d_col, 0, ((size_t)nnz + 2) * sizeof(int), c->stream));
+  FH_CHECK_HIP(hipMemsetAsync(A->d_val, 0, ((size_t)nnz + 2) * sizeof(double), c->stream));
+  FH_CHECK_HIP(hipMemcpyAsync(A->d_rowptr, rowptr, ((size_t)m + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  if (nnz) FH_CHECK_HIP(hipMemcpyAsync(A->d_col, col, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  if (val && nnz) FH_CHECK_HIP(hipMemcpyAsync(A->d_val, val, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  FH_TRY(fh_mat_build_rowblocks(A, c->spmv_tile));
+  *out = A;
+  return 0;
+}
+
+extern "C" int fh_mat_destroy(fh_mat_t A) {
+  if (!A) return 0;
+  hipStreamSynchronize(A->ctx->stream);
+  if (A->At) fh_mat_destroy(A->At);
+  if (A->d_tperm) hipFree(A->d_tperm);
+  if (A->d_rowptr) hipFree(A->d_rowptr);
+  if (A->d_col) hipFree(A->d_col);
+  if (A->d_val) hipFree(A->d_val);
+  if (A->d_rowblk) hipFree(A->d_rowblk);
+  delete A;
+  return 0;
+}
+
+extern "C" int fh_mat_size(fh_mat_t A, int* m, int* n, int* nnz) {
+  if (m) *m = A->m;
+  if (n) *n = A->n;
+  if (nnz) *nnz = A->nnz;
+  return 0;
+}
+
+extern "C" int64_t fh_spmv_algorithmic_bytes(fh_mat_t A) {
+  return 12ll * A->nnz + 4ll * (A->m + 1) + 8ll * A->n + 8ll * A->m;
+}
+
+// row blocks: greedy, <= tile non-zeros and <= 512 rows per block; a row longer than the tile is alone
+int fh_mat_build_rowblocks(fh_mat_t A, int tile) {
+  FH_REQUIRE(tile == 1024 || tile == 2048 || tile == 4096, "spmv_tile must be 1024, 2048 or 4096 (got %d)", tile);
+  std::vector<int> blk;
+  blk.push_back(0);
+  int acc = 0, rows = 0;
+  for (int i = 0; i < A->m; i++) {
+    int len = A->h_rowptr[i + 1] - A->h_rowptr[i];
+    if (rows > 0 && (acc + len > tile || rows >= 512)) {
+      blk.push_back(i);
+      acc = 0;
+      rows = 0;
+    }
+    acc += len;
+    rows++;
+  }
+  blk.push_back(A->m);
+  if (A->m == 0) blk.assign(1, 0);
+  A->nblk = (int)blk.size() - 1;
+  A->tile = tile;
+  if (A->d_rowblk) FH_CHECK_HIP(hipFree(A->d_rowblk));
+  FH_CHECK_HIP(hipMalloc(&A->d_rowblk, blk.size() * sizeof(int)));
+  FH_CHECK_HIP(hipMemcpy(A->d_rowblk, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int fh_mat_zero(fh_mat_t A) {
+  FH_CHECK_HIP(hipMemsetAsync(A->d_val, 0, (size_t)A->nnz * sizeof(double), A->ctx->stream));
+  A->at_valid = false;
+  return 0;
+}
+
+extern "C" int fh_mat_set_values_csr(fh_mat_t A, const double* val) {
+  FH_CHECK_HIP(hipMemcpyAsync(A->d_val, val, (size_t)A->nnz * sizeof(double), hipMemcpyHostToDevice, A->ctx->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(A->ctx->stream));
+  A->at_valid = false;
+  return 0;
+}
+
+extern "C" int fh_mat_get_values_csr(fh_mat_t A, double* val) {
+  FH_CHECK_HIP(hipMemcpyAsync(val, A->d_val, (size_t)A->nnz * sizeof(double), hipMemcpyDeviceToHost, A->ctx->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(A->ctx->stream));
+  return 0;
+}
+
+extern "C" int fh_mat_get_pattern(fh_mat_t A, int* rowptr, int* col) {
+  if (rowptr) memcpy(rowptr, A->h_rowptr.data(), ((size_t)A->m + 1) * sizeof(int));
+  if (col) memcpy(col, A->h_col.data(), (size_t)A->nnz * sizeof(int));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-element crossings of the reference interface (slow path; the batched assembler is the fast one)
+// ------------------------------------------------------------------------------------------------
+static int host_find(const fh_mat_t A, int row, int c) {
+  const int* b = A->h_col.data() + A->h_rowptr[row];
+  const int* e = A->h_col.data() + A->h_rowptr[row + 1];
+  const int* p = std::lower_bound(b, e, c);
+  if (p == e || *p != c) return -1;
+  return (int)(p - A->h_col.data());
+}
+
+__global__ void k_apply_entries(double* __restrict__ val, const int* __restrict__ pos, const double* __restrict__ v, int n, int add) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && pos[i] >= 0) {
+    if (add) atomicAdd(&val[pos[i]], v[i]);
+    else val[pos[i]] = v[i];
+  }
+}
+
+static int apply_entries(fh_mat_t A, const std::vector<int>& pos, const double* vals, int add) {
+  fh_ctx_t c = A->ctx;
+  int n = (int)pos.size();
+  if (!n) return 0;
+  int* d_pos = nullptr;
+  double* d_v = nullptr;
+  FH_CHECK_HIP(hipMalloc(&d_pos, n * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&d_v, n * sizeof(double)));
+  FH_CHECK_HIP(hipMemcpyAsync(d_pos, pos.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  FH_CHECK_HIP(hipMemcpyAsync(d_v, vals, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_apply_entries, dim3(fh_div_up(n, 256)), dim3(256), 0, c->stream, A->d_val, d_pos, d_v, n, add);
+  FH_CHECK_HIP(hipGetLastError());
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  hipFree(d_pos);
+  hipFree(d_v);
+  A->at_valid = false;
+  return 0;
+}
+
+extern "C" int fh_mat_add_block(fh_mat_t A, int nrow, const int* rows, int ncol, const int* cols, const double* vals) {
+  std::vector<int> pos((size_t)nrow * ncol);
+  for (int i = 0; i < nrow; i++) {
+    FH_REQUIRE(rows[i] >= 0 && rows[i] < A->m, "fh_mat_add_block: row %d out of range", rows[i]);
+    for (int j = 0; j < ncol; j++) {
+      int p = host_find(A, rows[i], cols[j]);
+      // PETSc would malloc a new entry; with a fixed device pattern this is an error unless the value is zero
+      FH_REQUIRE(p >= 0 || vals[(size_t)i * ncol + j] == 0.0, "fh_mat_add_block: entry (%d,%d) is outside the pattern", rows[i], cols[j]);
+      pos[(size_t)i * ncol + j] = p;
+    }
+  }
+  return apply_entries(A, pos, vals, 1);
+}
+
+extern "C" int fh_mat_insert_row(fh_mat_t A, int row, int ncols, const int* cols, const double* vals) {
+  FH_REQUIRE(row >= 0 && row < A->m, "fh_mat_insert_row: row %d out of range", row);
+  std::vector<int> pos(ncols);
+  for (int j = 0; j < ncols; j++) {
+    pos[j] = host_find(A, row, cols[j]);
+    FH_REQUIRE(pos[j] >= 0, "fh_mat_insert_row: entry (%d,%d) is outside the pattern", row, cols[j]);
+  }
+  return apply_entries(A, pos, vals, 0);
+}
+
+extern "C" int fh_mat_get_row(fh_mat_t A, int row, int* ncols, int* cols, double* vals) {
+  FH_REQUIRE(row >= 0 && row < A->m, "fh_mat_get_row: row %d out of range", row);
+  int s = A->h_rowptr[row], e = A->h_rowptr[row + 1];
+  if (ncols) *ncols = e - s;
+  if (cols) memcpy(cols, A->h_col.data() + s, (size_t)(e - s) * sizeof(int));
+  if (vals && e > s) {
+    FH_CHECK_HIP(hipMemcpyAsync(vals, A->d_val + s, (size_t)(e - s) * sizeof(double), hipMemcpyDeviceToHost, A->ctx->stream));
+    FH_CHECK_HIP(hipStreamSynchronize(A->ctx->stream));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: Dirichlet rows / columns
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_zero_rows(const int* __restrict__ rowptr, const int* __restrict__ col, double* __restrict__ val,
+                                                  const int* __restrict__ rows, int nrows, double diag) {
+  int r = blockIdx.x;
+  if (r >= nrows) return;
+  int row = rows[r];
+  for (int k = rowptr[row] + threadIdx.x; k < rowptr[row + 1]; k += 64) val[k] = (col[k] == row) ? diag : 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_mask_set(unsigned char* __restrict__ mask, const int* __restrict__ idx, int n) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) mask[idx[i]] = 1;
+}
+
+__global__ __launch_bounds__(256) void k_zero_cols(const int* __restrict__ col, double* __restrict__ val, const unsigned char* __restrict__ mask, int nnz) {
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < nnz; k += gridDim.x * 256)
+    if (mask[col[k]]) val[k] = 0.0;
+}
+
+extern "C" int fh_mat_zero_rows(fh_mat_t A, int n, const int* rows, double diag) {
+  if (n <= 0) return 0;
+  fh_ctx_t c = A->ctx;
+  for (int i = 0; i < n; i++) FH_REQUIRE(rows[i] >= 0 && rows[i] < A->m, "fh_mat_zero_rows: row %d out of range", rows[i]);
+  int* d_rows = nullptr;
+  FH_CHECK_HIP(hipMalloc(&d_rows, n * sizeof(int)));
+  FH_CHECK_HIP(hipMemcpyAsync(d_rows, rows, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_zero_rows, dim3(n), dim3(64), 0, c->stream, A->d_rowptr, A->d_col, A->d_val, d_rows, n, diag);
+  FH_CHECK_HIP(hipGetLastError());
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  hipFree(d_rows);
+  A->at_valid = false;
+  return 0;
+}
+
+extern "C" int fh_mat_zero_cols(fh_mat_t A, int n, const int* cols) {
+  if (n <= 0 || A->nnz == 0) return 0;
+  fh_ctx_t c = A->ctx;
+  for (int i = 0; i < n; i++) FH_REQUIRE(cols[i] >= 0 && cols[i] < A->n, "fh_mat_zero_cols: column %d out of range", cols[i]);
+  int* d_idx = nullptr;
+  unsigned char* d_mask = nullptr;
+  FH_CHECK_HIP(hipMalloc(&d_idx, n * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&d_mask, (size_t)A->n));
+  FH_CHECK_HIP(hipMemsetAsync(d_mask, 0, (size_t)A->n, c->stream));
+  FH_CHECK_HIP(hipMemcpyAsync(d_idx, cols, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_mask_set, dim3(fh_div_up(n, 256)), dim3(256), 0, c->stream, d_mask, d_idx, n);
+  int nb = std::min(fh_div_up(A->nnz, 256), c->num_cu * 8);
+  hipLaunchKernelGGL(k_zero_cols, dim3(nb), dim3(256), 0, c->stream, A->d_col, A->d_val, d_mask, A->nnz);
+  FH_CHECK_HIP(hipGetLastError());
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  hipFree(d_idx);
+  hipFree(d_mask);
+  A->at_valid = false;
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void k_get_diag(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+                                                  double* __restrict__ d, int m, int invert) {
+  int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= m) return;
+  int lo = rowptr[r], hi = rowptr[r + 1] - 1;
+  double v = 0.0;
+  while (lo <= hi) {  // sorted columns
+    int mid = (lo + hi) >> 1;
+    int cc = col[mid];
+    if (cc == r) { v = val[mid]; break; }
+    if (cc < r) lo = mid + 1; else hi = mid - 1;
+  }
+  if (invert) v = (v == 0.0) ? 1.0 : 1.0 / v;   // PCJACOBI: zero diagonal -> 1
+  d[r] = v;
+}
+
+int fh_dev_get_diag(fh_mat_t A, double* d, int invert) {
+  if (A->m == 0) return 0;
+  hipLaunchKernelGGL(k_get_diag, dim3(fh_div_up(A->m, 256)), dim3(256), 0, A->ctx->stream, A->d_rowptr, A->d_col, A->d_val, d, A->m, invert);
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int fh_mat_get_diagonal(fh_mat_t A, fh_vec_t d) {
+  FH_REQUIRE(d->n_local >= std::min(A->m, A->n), "fh_mat_get_diagonal: vector too short");
+  return fh_dev_get_diag(A, d->d, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// transpose: symbolic part on the host (integer setup work), values gathered on the device
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_perm(double* __restrict__ dst, const double* __restrict__ src, const int* __restrict__ perm, int n) {
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) dst[k] = src[perm[k]];
+}
+
+static int build_transpose(fh_mat_t A, fh_mat_t* out, int** d_perm_out) {
+  const int m = A->m, n = A->n, nnz = A->nnz;
+  std::vector<int> trp(n + 1, 0), tcol(nnz), perm(nnz);
+  for (int k = 0; k < nnz; k++) trp[A->h_col[k] + 1]++;
+  for (int j = 0; j < n; j++) trp[j + 1] += trp[j];
+  std::vector<int> cur(trp.begin(), trp.end() - 1);
+  for (int i = 0; i < m; i++)
+    for (int k = A->h_rowptr[i]; k < A->h_rowptr[i + 1]; k++) {
+      int p = cur[A->h_col[k]]++;
+      tcol[p] = i;   // rows visited in increasing order => sorted columns in the transpose
+      perm[p] = k;
+    }
+  fh_mat_t At = nullptr;
+  FH_TRY(fh_mat_create_csr(A->ctx, n, m, trp.data(), tcol.data(), nullptr, &At));
+  int* d_perm = nullptr;
+  FH_CHECK_HIP(hipMalloc(&d_perm, std::max(nnz, 1) * sizeof(int)));
+  if (nnz) FH_CHECK_HIP(hipMemcpy(d_perm, perm.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
+  *out = At;
+  *d_perm_out = d_perm;
+  return 0;
+}
+
+static int gather_transpose_values(fh_mat_t A, fh_mat_t At, const int* d_perm) {
+  if (A->nnz == 0) return 0;
+  int nb = std::min(fh_div_up(A->nnz, 256), A->ctx->num_cu * 8);
+  hipLaunchKernelGGL(k_gather_perm, dim3(nb), dim3(256), 0, A->ctx->stream, At->d_val, A->d_val, d_perm, A->nnz);
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int fh_mat_transpose(fh_mat_t A, fh_mat_t* out) {
+  int* d_perm = nullptr;
+  FH_TRY(build_transpose(A, out, &d_perm));
+  FH_TRY(gather_transpose_values(A, *out, d_perm));
+  FH_CHECK_HIP(hipStreamSynchronize(A->ctx->stream));
+  hipFree(d_perm);
+  return 0;
+}
+
+int fh_mat_refresh_transpose(fh_mat_t A) {
+  if (!A->At) FH_TRY(build_transpose(A, &A->At, &A->d_tperm));
+  if (!A->at_valid) {
+    FH_TRY(gather_transpose_values(A, A->At, A->d_tperm));
+    A->at_valid = true;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// norms (l1 = max column sum, linfty = max row sum) -- setup/diagnostic only: via the host
+// ------------------------------------------------------------------------------------------------
+extern "C" int fh_mat_norm(fh_mat_t A, int kind, double* out) {
+  std::vector<double> v(A->nnz);
+  if (A->nnz) FH_TRY(fh_mat_get_values_csr(A, v.data()));
+  double best = 0.0;
+  if (kind == 0) {
+    for (int i = 0; i < A->m; i++) {
+      double s = 0.0;
+      for (int k = A->h_rowptr[i]; k < A->h_rowptr[i + 1]; k++) s += fabs(v[k]);
+      best = std::max(best, s);
+    }
+  } else if (kind == 1) {
+    std::vector<double> cs(A->n, 0.0);
+    for (int k = 0; k < A->nnz; k++) cs[A->h_col[k]] += fabs(v[k]);
+    for (double s : cs) best = std::max(best, s);
+  } else {
+    fh_set_error("fh_mat_norm: unknown kind %d", kind);
+    return 2;
+  }
+  *out = best;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SpMV kernels
+// ------------------------------------------------------------------------------------------------
+// epilogue: MODE 0: y = s ; 1: y += s ; 2: y = b - s ; 3: y = x + omega*dinv*(b - s)
+template <int MODE>
+__device__ __forceinline__ void spmv_store(double s, int r, const double* __restrict__ x, double* __restrict__ y,
+                                           const double* __restrict__ b, const double* __restrict__ dinv, double omega) {
+  if (MODE == 0) y[r] = s;
+  else if (MODE == 1) y[r] += s;
+  else if (MODE == 2) y[r] = b[r] - s;
+  else y[r] = x[r] + omega * dinv[r] * (b[r] - s);
+}
+
+template <int TILE, int MODE>
+__global__ __launch_bounds__(256) void k_spmv_stream(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                     const double* __restrict__ val, const int* __restrict__ rowblk, int nblk, int q,
+                                                     const double* __restrict__ x, double* __restrict__ y,
+                                                     const double* __restrict__ b, const double* __restrict__ dinv, double omega) {
+  __shared__ double prod[TILE + 2];
+  // XCD-aware logical block id: physical block p runs on XCD p%8; give each XCD a contiguous range of row blocks
+  int blk = (q > 0) ? (int)(blockIdx.x & 7) * q + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (blk >= nblk) return;
+  const int tid = threadIdx.x;
+  const int r0 = rowblk[blk], r1 = rowblk[blk + 1];
+  const int s = rowptr[r0], e = rowptr[r1];
+  if (r1 - r0 == 1 && e - s > TILE) {
+    // one long row: CSR-vector over the whole workgroup
+    double acc = 0.0;
+    for (int k = s + tid; k < e; k += 256) acc += val[k] * x[col[k]];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((tid & 63) == 0) prod[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) spmv_store<MODE>(prod[0] + prod[1] + prod[2] + prod[3], r0, x, y, b, dinv, omega);
+    return;
+  }
+  // ---- stream phase: aligned (16 B val, 8 B col) pairs --------------------------------------------
+  const int s2 = s & ~1;
+  constexpr int ITER = TILE / 512 + 1;
+  double2 v[ITER];
+  int2 c[ITER];
+#pragma unroll
+  for (int k = 0; k < ITER; k++) {
+    int i = s2 + 2 * tid + k * 512;
+    if (i < e) {
+      v[k] = *reinterpret_cast<const double2*>(val + i);
+      c[k] = *reinterpret_cast<const int2*>(col + i);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < ITER; k++) {
+    int i = s2 + 2 * tid + k * 512;
+    if (i < e) {
+      double p0 = v[k].x * x[c[k].x];
+      if (i >= s) prod[i - s] = p0;
+      if (i + 1 < e) prod[i + 1 - s] = v[k].y * x[c[k].y];
+    }
+  }
+  __syncthreads();
+  // ---- segmented reduction: G lanes per row ---------------------------------------------------------
+  const int nrows = r1 - r0;
+  int G = (nrows <= 16) ? 16 : (nrows <= 32) ? 8 : (nrows <= 64) ? 4 : (nrows <= 128) ? 2 : 1;
+  const int gl = tid & (G - 1);
+  const int rows_per_pass = 256 / G;
+  const int npass = (nrows + rows_per_pass - 1) / rows_per_pass;   // uniform trip count: every lane joins the shuffles
+  for (int p = 0; p < npass; p++) {
+    const int rr = p * rows_per_pass + tid / G;
+    const bool live = rr < nrows;
+    const int r = r0 + (live ? rr : 0);
+    double acc = 0.0;
+    if (live) {
+      const int a = rowptr[r] - s, z = rowptr[r + 1] - s;
+      for (int k = a + gl; k < z; k += G) acc += prod[k];
+    }
+    for (int off = G >> 1; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (live && gl == 0) spmv_store<MODE>(acc, r, x, y, b, dinv, omega);
+  }
+}
+
+// classic CSR-vector: LANES lanes per row (kept for A/B measurements and very small matrices)
+template <int LANES, int MODE>
+__global__ __launch_bounds__(256) void k_spmv_vector(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                     const double* __restrict__ val, int m, const double* __restrict__ x,
+                                                     double* __restrict__ y, const double* __restrict__ b,
+                                                     const double* __restrict__ dinv, double omega) {
+  const int r = (blockIdx.x * 256 + threadIdx.x) / LANES;
+  const int gl = threadIdx.x & (LANES - 1);
+  const bool live = r < m;
+  double acc = 0.0;
+  if (live) {
+    const int s = rowptr[r], e = rowptr[r + 1];
+    for (int k = s + gl; k < e; k += LANES) acc += val[k] * x[col[k]];
+  }
+#pragma unroll
+  for (int off = LANES >> 1; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (live && gl == 0) spmv_store<MODE>(acc, r, x, y, b, dinv, omega);
+}
+
+template <int TILE>
+static void launch_stream(fh_mat_t A, int mode, const double* x, double* y, const double* b, const double* dinv, double omega) {
+  fh_ctx_t c = A->ctx;
+  int q = 0, grid = A->nblk;
+  if (c->spmv_xcd_remap && A->nblk >= 64) {
+    q = (A->nblk + 7) / 8;
+    grid = 8 * q;
+  }
+#define FH_LAUNCH(MODE) \
+  hipLaunchKernelGGL((k_spmv_stream<TILE, MODE>), dim3(grid), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_val, \
+                     A->d_rowblk, A->nblk, q, x, y, b, dinv, omega)
+  switch (mode) {
+    case 0: FH_LAUNCH(0); break;
+    case 1: FH_LAUNCH(1); break;
+    case 2: FH_LAUNCH(2); break;
+    default: FH_LAUNCH(3); break;
+  }
+#undef FH_LAUNCH
+}
+
+int fh_dev_spmv(fh_mat_t A, const double* x, double* y, int mode, const double* b, const double* dinv, double omega) {
+  fh_ctx_t c = A->ctx;
+  if (A->m == 0) return 0;
+  FH_REQUIRE(mode >= 0 && mode <= 3, "fh_spmv: unknown mode %d", mode);
+  FH_REQUIRE(x != y, "fh_spmv: x and y must not alias");
+  if (c->spmv_kernel == 1) {
+    const int grid = fh_div_up((int64_t)A->m * 16, 256);
+#define FH_LAUNCHV(MODE) \
+  hipLaunchKernelGGL((k_spmv_vector<16, MODE>), dim3(grid), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_val, A->m, x, y, b, dinv, omega)
+    switch (mode) {
+      case 0: FH_LAUNCHV(0); break;
+      case 1: FH_LAUNCHV(1); break;
+      case 2: FH_LAUNCHV(2); break;
+      default: FH_LAUNCHV(3); break;
+    }
+#undef FH_LAUNCHV
+  } else {
+    if (A->tile != c->spmv_tile) FH_TRY(fh_mat_build_rowblocks(A, c->spmv_tile));
+    if (A->tile == 1024) launch_stream<1024>(A, mode, x, y, b, dinv, omega);
+    else if (A->tile == 2048) launch_stream<2048>(A, mode, x, y, b, dinv, omega);
+    else launch_stream<4096>(A, mode, x, y, b, dinv, omega);
+  }
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int fh_spmv(fh_mat_t A, fh_vec_t x, fh_vec_t y, int mode, fh_vec_t b, fh_vec_t dinv, double omega) {
+  FH_REQUIRE(A && x && y, "fh_spmv: null argument");
+  FH_REQUIRE(x->n_local + x->nghost >= A->n, "fh_spmv: x has %d entries, matrix has %d columns", x->n_local + x->nghost, A->n);
+  FH_REQUIRE(y->n_local >= A->m, "fh_spmv: y has %d entries, matrix has %d rows", y->n_local, A->m);
+  FH_REQUIRE(mode < 2 || (b && b->n_local >= A->m), "fh_spmv: mode %d needs b", mode);
+  FH_REQUIRE(mode < 3 || (dinv && dinv->n_local >= A->m && A->m == A->n), "fh_spmv: mode 3 needs dinv and a square matrix");
+  return fh_dev_spmv(A, x->d, y->d, mode, b ? b->d : nullptr, dinv ? dinv->d : nullptr, omega);
+}
+
+extern "C" int fh_spmv_transpose(fh_mat_t A, fh_vec_t x, fh_vec_t y) {
+  FH_REQUIRE(x->n_local >= A->m && y->n_local >= A->n, "fh_spmv_transpose: size mismatch");
+  FH_TRY(fh_mat_refresh_transpose(A));
+  return fh_dev_spmv(A->At, x->d, y->d, 0, nullptr, nullptr, 0.0);
+}

@@ -1,0 +1,193 @@
+/*
+ * femus_hip.h -- C-ABI of libfemus_hip.so: the MI355X (gfx950) backend for the FEMuS
+ * assembly + geometric-multigrid hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  The three adapter
+ * classes in femus_amd/csrc/adapters/ (HipMatrix : SparseMatrix, HipVector : NumericVector,
+ * LinearEquationSolverHip : LinearEquationSolver) are thin shells over these entry points; a FEMuS
+ * maintainer binds them exactly the same way.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the FEMuS tree;
+ * "03_solvers/" abbreviates
+ * src/08_algebra_dependent_on_Mesh_and_Solution_but_independent_of_Systems/03_solvers_with_preconditioner/).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; fh_last_error() gives the message.
+ *     (The reference aborts on error -- CHKERRABORT / abort(); the C++ adapters do the same on !=0.)
+ *   - indices are 32-bit (PetscVector.hpp:536 asserts sizeof(PetscInt)==sizeof(int)); values are IEEE double.
+ *   - host pointers unless the name says "_dev".  All device work is queued on the context's stream;
+ *     functions that return numbers to the host synchronise that stream.
+ *   - there is NO CPU fallback: without a usable HIP device fh_init fails and nothing else works.
+ */
+#ifndef FEMUS_HIP_H
+#define FEMUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fh_ctx_s* fh_ctx_t;
+typedef struct fh_vec_s* fh_vec_t;
+typedef struct fh_mat_s* fh_mat_t;
+typedef struct fh_mg_s* fh_mg_t;
+typedef struct fh_mesh_s* fh_mesh_t;
+typedef struct fh_halo_s* fh_halo_t;
+
+/* ---- context --------------------------------------------------------------------------------
+ * replaces FemusInit (src/00_utils/00_application_initialization/FemusInit.cpp:46-74: PetscInitialize) */
+int fh_init(int device, fh_ctx_t* ctx);
+int fh_finalize(fh_ctx_t ctx);
+const char* fh_last_error(void);
+const char* fh_version(void);
+int fh_device_name(fh_ctx_t ctx, char* buf, int buflen);
+int fh_sync(fh_ctx_t ctx);
+void* fh_stream(fh_ctx_t ctx);                       /* hipStream_t of the compute stream */
+/* HIP-event timing on the compute stream (bench.py: roofline.achieved is measured with these) */
+int fh_timer_start(fh_ctx_t ctx);
+int fh_timer_stop(fh_ctx_t ctx, double* milliseconds);
+/* runtime tuning knobs (the reference honours the PETSc options DB, 03_solvers/LinearEquationSolverPetsc.cpp:251-254);
+ * names: "spmv_tile", "spmv_xcd_remap", "assemble_emap" ... returns non-zero for unknown names */
+int fh_set_option(fh_ctx_t ctx, const char* name, double value);
+
+/* ---- vectors: NumericVector (src/03_algebra/00_vectors/NumericVector.hpp:51-353, PetscVector.cpp) ----
+ * layout: [n_local owned entries | nghost ghost entries] ; ghost_idx are GLOBAL indices (PetscVector.hpp:515-569).
+ * first_local is this rank's offset into the global numbering. */
+int fh_vec_create(fh_ctx_t ctx, int n_global, int n_local, int first_local, const int* ghost_idx, int nghost, fh_vec_t* v);
+int fh_vec_duplicate(fh_vec_t src, fh_vec_t* v);                 /* NumericVector::init(other) :129 */
+int fh_vec_destroy(fh_vec_t v);
+int fh_vec_size(fh_vec_t v, int* n_global, int* n_local, int* first_local, int* nghost);
+int fh_vec_zero(fh_vec_t v);                                     /* zero() :151 */
+int fh_vec_fill(fh_vec_t v, double s);                           /* operator=(double) :153 */
+int fh_vec_copy(fh_vec_t dst, fh_vec_t src);                     /* operator=(NumericVector) :155 */
+int fh_vec_upload(fh_vec_t v, const double* host_owned);         /* operator=(std::vector) :157 (owned part) */
+int fh_vec_download(fh_vec_t v, double* host_owned);             /* localize(std::vector) :308 (owned part) */
+int fh_vec_set_values(fh_vec_t v, int n, const int* idx, const double* vals);   /* set(i,v) :146 / insert :160 */
+int fh_vec_add_values(fh_vec_t v, int n, const int* idx, const double* vals);   /* add(i,v) :148, add_vector_blocked :265 */
+int fh_vec_get_values(fh_vec_t v, int n, const int* idx, double* vals);         /* operator()(i) :224, get() :236 (owned+ghost) */
+int fh_vec_axpy(fh_vec_t y, double a, fh_vec_t x);               /* add(a,v) :262, +=, -= :243-245 */
+int fh_vec_aypx(fh_vec_t y, double a, fh_vec_t x);               /* y = a*y + x (used by resid) */
+int fh_vec_shift(fh_vec_t v, double s);                          /* add(s) :258 */
+int fh_vec_scale(fh_vec_t v, double s);                          /* scale :294 */
+int fh_vec_abs(fh_vec_t v);                                      /* abs :296 */
+int fh_vec_pointwise_mult(fh_vec_t w, fh_vec_t a, fh_vec_t b);   /* pointwise_mult :328 */
+int fh_vec_dot(fh_vec_t x, fh_vec_t y, double* out);             /* dot :298 (local part; see fh_halo_allreduce) */
+int fh_vec_norm(fh_vec_t x, int kind, double* out);              /* kind 1: l1 :200, 2: l2 :202, 0: linfty :204 */
+int fh_vec_reduce(fh_vec_t x, int kind, double* out);            /* kind 0: sum :197, 1: min :193, 2: max :195 */
+double* fh_vec_dev_ptr(fh_vec_t v);                              /* device pointer (owned then ghosts) */
+
+/* ---- matrices: SparseMatrix (src/03_algebra/01_matrices/SparseMatrix.hpp:48-282, PetscMatrix.cpp) ----
+ * device CSR, sorted columns, fixed pattern once created.  rowptr[m+1], col[nnz], val[nnz] (val may be NULL = zeros).
+ * Replaces init(m,n,m_l,n_l,d_nnz,o_nnz) :65-74 + the implicit pattern growth of MatSetValues: callers give
+ * the pattern (fh_pattern_from_elements) instead of a per-row count. */
+int fh_mat_create_csr(fh_ctx_t ctx, int m, int n, const int* rowptr, const int* col, const double* val, fh_mat_t* A);
+int fh_mat_destroy(fh_mat_t A);                                  /* clear() :59 */
+int fh_mat_size(fh_mat_t A, int* m, int* n, int* nnz);           /* m() :140, n() :143 */
+int fh_mat_zero(fh_mat_t A);                                     /* zero() :96 -- keeps the pattern */
+int fh_mat_set_values_csr(fh_mat_t A, const double* val);        /* bulk upload of all values (pattern order) */
+int fh_mat_get_values_csr(fh_mat_t A, double* val);              /* bulk download */
+int fh_mat_get_pattern(fh_mat_t A, int* rowptr, int* col);
+/* add_matrix_blocked(vals, rows, cols) :165-171 (PetscMatrix.cpp:699-729): A[rows[i],cols[j]] += vals[i*ncol+j] */
+int fh_mat_add_block(fh_mat_t A, int nrow, const int* rows, int ncol, const int* cols, const double* vals);
+/* insert_row(row, ncols, cols, vals) :162 -- INSERT semantics */
+int fh_mat_insert_row(fh_mat_t A, int row, int ncols, const int* cols, const double* vals);
+int fh_mat_get_row(fh_mat_t A, int row, int* ncols, int* cols, double* vals);    /* MatGetRowM :111 */
+/* mat_zero_rows(index, diag) :229 (PetscMatrix.cpp:1073-1077) == MatZeroRows with MAT_KEEP_NONZERO_PATTERN;
+ * also SetPenalty (03_solvers/LinearEquationSolverPetsc.cpp:428-436).  diag==0: plain zero rows. */
+int fh_mat_zero_rows(fh_mat_t A, int n, const int* rows, double diag);
+int fh_mat_zero_cols(fh_mat_t A, int n, const int* cols);        /* get_transpose+mat_zero_rows+get_transpose, LinearImplicitSystem.cpp:1101-1106 */
+int fh_mat_get_diagonal(fh_mat_t A, fh_vec_t d);                 /* get_diagonal :224 */
+int fh_mat_transpose(fh_mat_t A, fh_mat_t* At);                  /* get_transpose :227 (PetscMatrix.cpp:1031-1070) */
+/* matrix_PtAP(P, A, reuse) :183 (PetscMatrix.cpp:733-751): C = P^T A P.  *C==NULL: symbolic+numeric; else numeric reuse */
+int fh_mat_ptap(fh_mat_t P, fh_mat_t A, fh_mat_t* C);
+int fh_mat_norm(fh_mat_t A, int kind, double* out);              /* kind 1: l1_norm :211, 0: linfty_norm :214 */
+
+/* SpMV family (NumericVector::matrix_mult :283, add_vector(v,A) :281, resid :282, matrix_mult_transpose :284;
+ * PetscVector.cpp:182-247).  mode 0: y = A x ; 1: y += A x ; 2: y = b - A x (b given) ;
+ * 3: y = x + omega*dinv.*(b - A x) (one Richardson/Jacobi sweep, 03_solvers/LinearEquationSolverPetsc.cpp:516-519 + PCJACOBI) */
+int fh_spmv(fh_mat_t A, fh_vec_t x, fh_vec_t y, int mode, fh_vec_t b, fh_vec_t dinv, double omega);
+int fh_spmv_transpose(fh_mat_t A, fh_vec_t x, fh_vec_t y);       /* y = A^T x via the cached explicit transpose */
+/* algorithmic bytes of one y=Ax with this matrix: 12 nnz + 4 (m+1) + 8 n + 8 m */
+int64_t fh_spmv_algorithmic_bytes(fh_mat_t A);
+
+/* ---- FE tables (a1-a3, a6) -------------------------------------------------------------------
+ * geom: 0 = hex (HEX27 geometry), 1 = quad (QUAD9).  fe: 0 = linear (Q1), 2 = biquadratic (Q2)  (FEMuS SolType ids).
+ * gauss_order: index 0..4 of quadrature_interface.cpp:36-57 ("seventh" -> 3).
+ * Gauss: src/02_reference_geom_elements/02_quadrature/ ; basis: 01_fe/ ; tables: 03_fe_evaluations_at_quadrature/ElemType.cpp:576-741 */
+int fh_fe_gauss(int geom, int gauss_order, int* ng, double* w, double* x /* [dim*ng], x[d*ng+ig] */);
+int fh_fe_tables(int geom, int fe, int gauss_order, int* ng, int* nc, double* phi /* [ng*nc] */, double* dphi /* [dim][ng*nc] */);
+int fh_fe_elem_prolongator(int geom, int fe, int* nchild, int* nc, double* P /* [nchild*nc*nc], |.|<1e-14 -> 0 (ElemType.cpp:439-532) */);
+
+/* ---- mesh + DOF maps (a8-a10): box generator, uniform refinement, first-touch numbering, nprocs=1 ----
+ * MeshGeneration.cpp:790-849,979-1075 ; MeshRefinement.cpp:240-294,356-417,513-620 ; Mesh.cpp:517-559 */
+int fh_mesh_box(int nx, int ny, int nz, const double lo[3], const double hi[3], fh_mesh_t* mesh);
+int fh_mesh_refine(fh_mesh_t coarse, fh_mesh_t* fine);
+int fh_mesh_destroy(fh_mesh_t mesh);
+int fh_mesh_info(fh_mesh_t mesh, int* dim, int* nel, int* nnode, int* nloc, int own_size[3], int* level);
+int fh_mesh_get(fh_mesh_t mesh, int* elem_dof /* [nel*nloc] */, double* coords /* [nnode*dim] */, int* face_flag /* [nel*nfaces] */);
+int fh_mesh_child_elems(fh_mesh_t coarse, int* child /* [nel*nchild] */);
+/* boundary flags: Dirichlet dofs = nodes on faces with flag < -1 (MultiLevelSolution.cpp:725-840, value < 1.5 in
+ * 03_solvers/LinearEquationSolverPetsc.cpp:53-90).  Returns the sorted list; *n in: capacity, out: count */
+int fh_mesh_dirichlet_dofs(fh_mesh_t mesh, int fe, int* n, int* dofs);
+
+/* ---- sparsity (a11): LinearEquation::GetSparsityPatternSize (03_solvers/LinearEquation.cpp:407-548) ----
+ * CSR pattern of the element-connectivity graph: two-call protocol (rowptr first, then col). */
+int fh_pattern_from_elements(int nel, int nloc, const int* elem_dof, int ndof, int* rowptr /* [ndof+1] */, int* col /* NULL on first call */);
+
+/* ---- prolongator (a14): LinearImplicitSystem::BuildProlongatorMatrix (LinearImplicitSystem.cpp:761-909) ----
+ * builds P (fine x coarse) from the element prolongator; zero_bdc != 0 also applies
+ * ZeroInterpolatorDirichletNodes (LinearImplicitSystem.cpp:1032-1120). */
+int fh_build_prolongator(fh_ctx_t ctx, fh_mesh_t coarse, fh_mesh_t fine, int fe, int zero_bdc, fh_mat_t* P);
+
+/* ---- batched assembly (a4, a7, a12): the per-element callback of
+ * src/08_equations/assemble/00_poisson_eqn_with_all_dirichlet_bc_AD_or_nonAD_separate.hpp:106-228 as ONE call.
+ * KK->zero(); RES->zero(); element loop {Jacobian (ElemType.hpp:1183-1248,1438-1537); Res,Jac; add_*_blocked}; close.
+ * source_kind: 0 constant f=p[0]; 1: f = p[0]*prod_d sin(p[1]*x_d) ; 2: f = p[0]*prod_d cos(p[1]*x_d).
+ * sol may be NULL (= 0).  A must carry the pattern from fh_pattern_from_elements. */
+typedef struct fh_assembler_s* fh_assembler_t;
+int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int gauss_order, int nel, int nloc, const int* elem_dof,
+                        int nnode, const double* coords /* [nnode*dim] */, fh_mat_t A, fh_assembler_t* as);
+int fh_assembler_destroy(fh_assembler_t as);
+int fh_assemble_poisson(fh_assembler_t as, fh_vec_t sol, int source_kind, const double* params, fh_mat_t A, fh_vec_t res);
+int fh_assembler_info(fh_assembler_t as, int* ncolors, int64_t* algorithmic_bytes, double* flops);
+/* element-level entry (tests): K[nel*nc*nc], F[nel*nc] for the given elements, no scatter */
+int fh_element_matrices_poisson(fh_assembler_t as, fh_vec_t sol, int source_kind, const double* params, double* K, double* F);
+
+/* ---- multigrid: LinearEquationSolver (03_solvers/LinearEquationSolver.hpp:54-261, LinearEquationSolverPetsc.cpp) ----
+ * fh_mg_create      <- MGInit   (:185-215)   nlevels, outer solver
+ * fh_mg_set_level   <- MGSetLevel (:219-290) operator, interpolation PP (restriction = PP^T when R==NULL,
+ *                      LinearImplicitSystem.cpp:379-382), smoother type / omega / npre / npost, Dirichlet list (SetPenalty)
+ * fh_mg_setup       <- KSPSetUp: diagonal inverses, explicit transposes, coarse factorisation (PREONLY+LU level 0,
+ *                      LinearEquationSolverPetsc.hpp:131-134), work vectors, hipGraph capture of the cycle
+ * fh_mg_vcycle      <- one PCMG multiplicative V-cycle application x = M^-1 b
+ * fh_mg_solve       <- MGSolve (:294-353): outer solver preconditioned by the cycle
+ * fh_mg_destroy     <- MGClear (LinearEquationSolverPetsc.hpp:86-88) */
+enum { FH_SMOOTH_JACOBI = 0, FH_SMOOTH_GS_COLOR = 1 };
+enum { FH_OUTER_PREONLY = 0, FH_OUTER_RICHARDSON = 1, FH_OUTER_GMRES = 2, FH_OUTER_CG = 3 };
+int fh_mg_create(fh_ctx_t ctx, int nlevels, fh_mg_t* mg);
+int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh_mat_t R, int smoother, double omega, int npre, int npost);
+int fh_mg_setup(fh_mg_t mg);
+int fh_mg_vcycle(fh_mg_t mg, fh_vec_t b, fh_vec_t x);
+int fh_mg_solve(fh_mg_t mg, fh_vec_t b, fh_vec_t x, int outer, double rtol, double atol, double dtol, int maxit, int restart,
+                int* iterations, double* final_residual);
+int fh_mg_destroy(fh_mg_t mg);
+int64_t fh_mg_cycle_algorithmic_bytes(fh_mg_t mg);               /* SURVEY 8(d) V-cycle byte model for these levels */
+
+/* ---- multi-GPU halo (C1/C3/C4 of SURVEY 2.1): VecGhostUpdate (PetscVector.hpp:595-612), VecDot/VecNorm allreduce ----
+ * one rank per GPU.  The plan is built from each rank's ghost list; the exchange itself is neighbour
+ * send/recv over RCCL (xGMI) on the context's communication stream.  comm_id is the 128-byte ncclUniqueId
+ * created by rank 0 (fh_halo_unique_id) and distributed by the launcher (torch.distributed / MPI). */
+int fh_halo_unique_id(char id128[128]);
+int fh_halo_create(fh_ctx_t ctx, int rank, int nranks, const char id128[128],
+                   const int* send_counts /* [nranks] */, const int* send_idx /* local owned indices, grouped by dest rank */,
+                   const int* recv_counts /* [nranks] */, fh_halo_t* halo);
+int fh_halo_update(fh_halo_t halo, fh_vec_t v);                  /* owner -> ghost copies, async on comm stream + join */
+int fh_halo_allreduce_sum(fh_halo_t halo, double* vals, int n);  /* host scalars in/out */
+int fh_halo_destroy(fh_halo_t halo);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEMUS_HIP_H */

@@ -546,15 +546,13 @@ def dirichlet_dofs(mesh, fe):
 
 # a11/a12. sparsity + add_matrix_blocked / add_vector_blocked in element order
 def csr_pattern(mesh, fe):
-    ed = elem_sys_dof(mesh, fe)
+    ed = elem_sys_dof(mesh, fe).astype(np.int64)
     nc = ed.shape[1]
     n = n_dofs(mesh, fe)
-    R = np.repeat(ed, nc, axis=1).ravel()
-    C = np.tile(ed, (1, nc)).ravel()
-    A = sp.csr_matrix((np.ones(R.size, dtype=np.int8), (R, C)), shape=(n, n))
-    A.sum_duplicates()
-    A.sort_indices()
-    return A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    key = np.unique((np.repeat(ed, nc, axis=1) * n + np.tile(ed, (1, nc))).ravel())
+    rows = key // n
+    indptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))])
+    return indptr.astype(np.int32), (key % n).astype(np.int32)
 
 
 def assemble_poisson(mesh, fe, rhs_vec, sol=None, order="seventh", chunk=4096):

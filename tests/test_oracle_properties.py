@@ -1,0 +1,111 @@
+"""Oracle checks that do not need the reference: analytic properties of the restated path (CPU)."""
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+from oracle import femus_oracle as fo
+
+ONE = lambda xg: np.ones(xg.shape[:2])
+
+
+def test_partition_of_unity_and_gradient_sum():
+    for geom in ("quad", "hex"):
+        for fe in ("linear", "biquadratic"):
+            et = fo.ElemType(geom, fe, "seventh")
+            assert np.allclose(et.phi.sum(1), 1.0, atol=1e-14)
+            assert np.allclose(et.dphi.sum(1), 0.0, atol=1e-13)
+
+
+def test_jacobian_unit_cube_and_survey_probe_value():
+    et = fo.ElemType("hex", "biquadratic", "seventh")
+    h = 1.0 / 64
+    x = [(fo.XC_HEX27[:, d] + 1) / 2 * h for d in range(3)]
+    vol = sum(et.jacobian(x, g)[0] for g in range(et.ng))
+    # sum_g weight = 3.8146972656249814e-06 for h = 1/64 (14-digit Gauss literals)
+    assert vol == 3.8146972656249814e-06
+    K, F = fo.elem_poisson(et, x, np.zeros(27), lambda p: 1.0)
+    assert abs(K - K.T).max() < 1e-17
+    assert abs(K.sum(1)).max() < 1e-15
+    assert abs(K[0, 0] - 1.9444444444444e-3) < 1e-15
+
+
+def test_batch_equals_loop_on_distorted_element():
+    et = fo.ElemType("hex", "biquadratic", "seventh")
+    rng = np.random.default_rng(3)
+    x = [fo.XC_HEX27[:, d] * 0.5 + rng.uniform(-0.04, 0.04, 27) for d in range(3)]
+    u = rng.uniform(-1, 1, 27)
+    K, F = fo.elem_poisson(et, x, u, lambda p: np.sin(p[0]) + p[1])
+    Kb, Fb = fo.elem_poisson_batch(et, np.array(x)[None], u[None], lambda xg: np.sin(xg[..., 0]) + xg[..., 1])
+    assert abs(Kb[0] - K).max() <= 1e-14 * abs(K).max()
+    assert abs(Fb[0] - F).max() <= 1e-13 * abs(F).max()
+
+
+def test_mesh_counts_and_geometry():
+    ms = fo.build_levels(2, 2, 2, 3)
+    assert [m.nel for m in ms] == [8, 64, 512]
+    assert [m.nnode for m in ms] == [125, 729, 4913]
+    # vertices first, then edges, then faces/centres (Mesh.cpp:517-559)
+    assert ms[0].own_size == [27, 27 + 54, 125]
+    m = ms[-1]
+    c = m.coords[m.elem_dof]
+    assert abs(c[:, 26] - c[:, :8].mean(1)).max() == 0.0
+    assert np.unique(np.round(m.coords * 2 ** 20).astype(np.int64), axis=0).shape[0] == m.nnode
+    # first-touch numbering: element 0 holds nodes 0..7 as its vertices
+    assert m.elem_dof[0, :8].tolist() == list(range(8))
+    # the 27 nodes of a coarse element are vertices on the fine level and keep their ids (Appendix B.7)
+    mc, mf = ms[0], ms[1]
+    f2c = fo.fine2coarse_vertex_mapping("hex")
+    for j in range(8):
+        assert np.array_equal(mf.coords[mf.elem_dof[j, :8]], mc.coords[mc.elem_dof[0, f2c[j]]])
+
+
+def test_2d_config1_sizes():
+    ms = fo.build_levels(8, 8, 0, 3)
+    assert [m.nel for m in ms] == [64, 256, 1024]
+    assert [fo.n_dofs(m, "linear") for m in ms] == [81, 289, 1089]     # BASELINE config 0: 1089 DOFs
+    assert len(fo.dirichlet_dofs(ms[-1], "linear")) == 4 * 32
+
+
+def test_3d_sizes_match_baseline_table():
+    ms = fo.build_levels(2, 2, 2, 2)
+    rp, col = fo.csr_pattern(ms[-1], "biquadratic")
+    n = 4
+    assert ms[-1].nnode == (2 * n + 1) ** 3 and rp[-1] == (8 * n + 1) ** 3
+    P = fo.build_prolongator(ms[0], ms[1], "biquadratic")
+    assert P.nnz == (8 * 2 + 1) ** 3
+    assert np.allclose(np.asarray(P.sum(1)).ravel(), 1.0)                      # interpolation of constants
+
+
+def test_galerkin_equals_rediscretised_on_free_dofs():
+    H = fo.build_poisson_hierarchy(2, 2, 2, 2, "biquadratic", ONE)
+    A0, _ = fo.assemble_poisson(H.meshes[0], "biquadratic", ONE)
+    free = np.setdiff1d(np.arange(A0.shape[0]), H.bdc[0])
+    D = (A0 - H.A[0])[free][:, free]
+    assert abs(D).max() <= 1e-13 * abs(A0).max()
+
+
+@pytest.mark.parametrize("solver", ["richardson", "pcg", "gmres"])
+def test_mg_solvers_reach_direct_solution(solver):
+    H = fo.build_poisson_hierarchy(2, 2, 2, 3, "biquadratic", ONE)
+    xd = spla.spsolve(H.A[-1].tocsc(), H.b)
+    fn = {"richardson": fo.solve_richardson_mg, "pcg": fo.solve_pcg_mg, "gmres": fo.solve_gmres_mg}[solver]
+    x, hist = fn(H, rtol=1e-12)
+    assert np.linalg.norm(x - xd) <= 1e-10 * np.linalg.norm(xd)
+    assert len(hist) < 25
+
+
+def test_manufactured_solution_fourth_order():
+    f = lambda xg: -3 * np.pi ** 2 * np.prod(np.sin(np.pi * xg), axis=-1)
+    errs = []
+    for n in (2, 4):
+        H = fo.build_poisson_hierarchy(n, n, n, 2, "biquadratic", f)
+        x, _ = fo.solve_pcg_mg(H, rtol=1e-12)
+        errs.append(abs(x - np.prod(np.sin(np.pi * H.meshes[-1].coords), axis=1)).max())
+    assert errs[1] < errs[0] / 12.0
+
+
+def test_config1_2d_q1_three_level_cycle():
+    H = fo.build_poisson_hierarchy(8, 8, 0, 3, "linear", ONE)
+    xd = spla.spsolve(H.A[-1].tocsc(), H.b)
+    x, hist = fo.solve_gmres_mg(H, rtol=1e-12, npre=1, npost=1)
+    assert np.linalg.norm(x - xd) <= 1e-10 * np.linalg.norm(xd)
