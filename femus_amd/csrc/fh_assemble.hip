@@ -1,0 +1,536 @@
+// Batched Poisson assembly on gfx950 (K1-K4 of SURVEY 2.1; a4, a7, a12 of SURVEY 8).
+// Restates, as ONE device pass per element colour, the per-element callback of
+//   src/08_equations/assemble/00_poisson_eqn_with_all_dirichlet_bc_AD_or_nonAD_separate.hpp:106-228
+// with elem_type::Jacobian from src/02_reference_geom_elements/03_fe_evaluations_at_quadrature/ElemType.hpp:1183-1248
+// (2-D) and :1438-1537 (3-D):
+//   J = sum_n dphi_hat[g][n] (x) x_n over the nc SOLUTION dofs, det, adjugate/det, Weight = det * w_g,
+//   gradphi = dphi_hat . JacI ; Res_i += (-f(x_g) phi_i - grad phi_i . grad u) W ; Jac_ij += (grad phi_i . grad phi_j) W.
+//
+// Mapping (wave64): LPE lanes own one element (Q2 hex: 64 lanes, Q1 quad: 1 lane -> 64 elements per wave).
+//   phase 1  lanes = (Gauss point of the chunk) x (node part): partial J, wave shuffles, J^-1, physical gradients
+//            -> LDS gs[g][d][n] (+ weight, grad u, f) ; conflict-free ds_write_b64
+//   phase 2  lanes = (TI x TJ) register tiles of the element matrix, LDS-staged basis x basis accumulation with
+//            ds_read_b128 broadcasts; 16 FMA per 8 LDS doubles
+//   scatter  element colours make A[row,col] += K race-free without atomics (deterministic); the CSR slot of
+//            every (i,j) comes from a precomputed element->CSR map (emap, built once per pattern) or, if disabled,
+//            from a binary search in the sorted row.
+// The small dense K is FP64-VALU work, not an MFMA target (north_star); the scatter side is HBM-bound.
+#include "fh_internal.h"
+#include "fh_fe.h"
+#include <algorithm>
+
+struct fh_assembler_s {
+  fh_ctx_t ctx = nullptr;
+  int geom = 0, fe = 0, order = 0, dim = 3, nc = 27, ng = 64, nloc = 27;
+  int nel = 0, nnode = 0, ndof = 0;
+  int ncolors = 0;
+  std::vector<int> color_ptr;    // host
+  int* d_color_elems = nullptr;  // elements grouped by colour
+  int* d_elem_dof = nullptr;     // [nel*nloc]
+  double* d_coords = nullptr;    // [nnode*dim]
+  double* d_w = nullptr;         // [ng]
+  double* d_phi = nullptr;       // [ng*nc]
+  double* d_dphi = nullptr;      // [ng*nc*dim]
+  int* d_emap = nullptr;         // [nel*nc*ncp] CSR slot of (i,j), ncp = nc rounded up to 4
+  int* d_iota = nullptr;         // identity element list (for the uncoloured element-matrix entry point)
+  int ncp = 28;
+};
+
+struct AsmParams {
+  const int* elems;        // element ids of this launch
+  int nelems;
+  const int* elem_dof;
+  int nloc;
+  const double* coords;
+  const double* w;
+  const double* phi;
+  const double* dphi;
+  int ng;
+  const double* sol;       // may be null
+  int source_kind;
+  double p0, p1;
+  // scatter targets
+  const int* rowptr;
+  const int* col;
+  double* val;
+  double* res;
+  const int* emap;         // may be null -> binary search
+  int* emap_out;           // non-null: build the map instead of assembling
+  double* Kout;            // non-null: write element matrices [e][nc][nc] instead of scattering
+  double* Fout;
+};
+
+template <int DIM, int NC>
+struct AsmCfg {
+  static constexpr int TI = (NC == 9) ? 3 : 4;
+  static constexpr int TJ = TI;
+  static constexpr int NBI = (NC + TI - 1) / TI;
+  static constexpr int NBJ = (NC + TJ - 1) / TJ;
+  static constexpr int NT = NBI * NBJ;                                        // tiles per element
+  static constexpr int LPE = NT <= 1 ? 1 : NT <= 2 ? 2 : NT <= 4 ? 4 : NT <= 8 ? 8 : NT <= 16 ? 16 : NT <= 32 ? 32 : 64;
+  static constexpr int EPW = 64 / LPE;                                        // elements per wave
+  static constexpr int NSPLIT = (LPE == 64) ? 4 : 1;                          // node parts in phase 1
+  static constexpr int GC = LPE / NSPLIT;                                     // Gauss points per chunk
+  static constexpr int NPP = (NC + NSPLIT - 1) / NSPLIT;                      // nodes per part
+  static constexpr int NCP = NBI * TI;                                        // padded row length in LDS
+  static constexpr int WAVES = 4;
+  static constexpr int EPB = EPW * WAVES;                                     // elements per block
+  // per-element LDS (doubles): gradients of the chunk, weights, grad u, f, coordinates, solution
+  static constexpr int GS = GC * DIM * NCP;
+  static constexpr int LDS_RAW = GS + GC + GC * DIM + GC + NC * DIM + NC;
+  static constexpr int LDS_PER_ELEM = (LDS_RAW + 1) / 2 * 2;                  // keep every element slab 16-byte aligned
+};
+
+__device__ __forceinline__ double source_eval(int kind, double p0, double p1, const double* xg, int dim) {
+  if (kind == 0) return p0;
+  double r = p0;
+  for (int d = 0; d < dim; d++) r *= (kind == 1) ? sin(p1 * xg[d]) : cos(p1 * xg[d]);
+  return r;
+}
+
+// SRC: 0 constant source, 1 trigonometric source ; OUT: 0 scatter through emap, 1 scatter with binary search,
+// 2 build emap (symbolic pass), 3 write element matrices
+template <int DIM, int NC, int SRC, int OUT>
+__global__ __launch_bounds__(256) void k_assemble_poisson(AsmParams P) {
+  using C = AsmCfg<DIM, NC>;
+  constexpr int TI = C::TI, TJ = C::TJ, NBJ = C::NBJ, LPE = C::LPE, EPW = C::EPW, NSPLIT = C::NSPLIT, GC = C::GC, NPP = C::NPP,
+                NCP = C::NCP;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ int s_dof[C::EPB][NC];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int eiw = lane / LPE;              // element within the wave
+  const int l = lane % LPE;                // lane within the element group
+  const int slot = wave * EPW + eiw;       // element slot within the block
+  const int eidx = blockIdx.x * C::EPB + slot;
+  const bool elive = eidx < P.nelems;
+  const int e = P.elems[elive ? eidx : (P.nelems - 1)];
+
+  double* base = smem + (size_t)slot * C::LDS_PER_ELEM;
+  double* gs = base;                       // [GC][DIM][NCP]
+  double* ws = gs + C::GS;                 // [GC]
+  double* gus = ws + GC;                   // [GC][DIM]
+  double* fs = gus + GC * DIM;             // [GC]
+  double* xe = fs + GC;                    // [NC][DIM]
+  double* ue = xe + NC * DIM;              // [NC]
+
+  // ---- gather: dof ids, coordinates, solution (a8, a9: GetSolutionDof / GetSystemDof, nprocs = 1) ----------
+  for (int n = l; n < NC; n += LPE) {
+    const int dof = P.elem_dof[(size_t)e * P.nloc + n];
+    s_dof[slot][n] = dof;
+    for (int d = 0; d < DIM; d++) xe[n * DIM + d] = P.coords[(size_t)dof * DIM + d];
+    ue[n] = P.sol ? P.sol[dof] : 0.0;
+  }
+  // zero the padding columns of gs once
+  if (NCP > NC)
+    for (int k = l; k < GC * DIM * (NCP - NC); k += LPE) {
+      const int row = k / (NCP - NC), c = NC + k % (NCP - NC);
+      gs[row * NCP + c] = 0.0;
+    }
+  __syncthreads();
+
+  // tile owned by this lane in phase 2
+  const bool tlive = l < C::NT;
+  const int ib = tlive ? l / NBJ : 0, jb = tlive ? l % NBJ : 0;
+  const int i0 = ib * TI, j0 = jb * TJ;
+  double K[TI][TJ];
+  double F[TI];
+#pragma unroll
+  for (int a = 0; a < TI; a++) {
+    F[a] = 0.0;
+#pragma unroll
+    for (int b = 0; b < TJ; b++) K[a][b] = 0.0;
+  }
+
+  const int q = l / NSPLIT, part = l % NSPLIT;
+  const int n0 = part * NPP;
+  const int nchunk = (P.ng + GC - 1) / GC;
+#pragma unroll 1
+  for (int ch = 0; ch < nchunk; ch++) {
+    // ---------------- phase 1: geometry at Gauss point g = ch*GC + q -------------------------------
+    {
+      const int g = ch * GC + q;
+      const bool glive = g < P.ng;
+      const int gg = glive ? g : 0;
+      double dh[NPP][DIM];                 // reference gradients of this lane's nodes
+      double J[DIM][DIM];
+#pragma unroll
+      for (int a = 0; a < DIM; a++)
+#pragma unroll
+        for (int b = 0; b < DIM; b++) J[a][b] = 0.0;
+#pragma unroll
+      for (int k = 0; k < NPP; k++) {
+        const int n = n0 + k;
+        if (n < NC) {
+#pragma unroll
+          for (int a = 0; a < DIM; a++) {
+            dh[k][a] = P.dphi[((size_t)gg * NC + n) * DIM + a];
+#pragma unroll
+            for (int b = 0; b < DIM; b++) J[a][b] += dh[k][a] * xe[n * DIM + b];   // Jac[a][b] += dphi_a * vt[b][n]
+          }
+        } else {
+#pragma unroll
+          for (int a = 0; a < DIM; a++) dh[k][a] = 0.0;
+        }
+      }
+      if (NSPLIT > 1) {
+#pragma unroll
+        for (int off = 1; off < NSPLIT; off <<= 1)
+#pragma unroll
+          for (int a = 0; a < DIM; a++)
+#pragma unroll
+            for (int b = 0; b < DIM; b++) J[a][b] += __shfl_xor(J[a][b], off, 64);
+      }
+      double det, JI[DIM][DIM];
+      if constexpr (DIM == 2) {
+        det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+        JI[0][0] = J[1][1] / det;
+        JI[0][1] = -J[0][1] / det;
+        JI[1][0] = -J[1][0] / det;
+        JI[1][1] = J[0][0] / det;
+      } else {
+        det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[1][2] * J[2][0] - J[1][0] * J[2][2]) +
+              J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+        JI[0][0] = (-J[1][2] * J[2][1] + J[1][1] * J[2][2]) / det;
+        JI[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+        JI[0][2] = (-J[0][2] * J[1][1] + J[0][1] * J[1][2]) / det;
+        JI[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) / det;
+        JI[1][1] = (-J[0][2] * J[2][0] + J[0][0] * J[2][2]) / det;
+        JI[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+        JI[2][0] = (-J[1][1] * J[2][0] + J[1][0] * J[2][1]) / det;
+        JI[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+        JI[2][2] = (-J[0][1] * J[1][0] + J[0][0] * J[1][1]) / det;
+      }
+      const double weight = glive ? det * P.w[gg] : 0.0;
+      double gu[DIM], xg[DIM];
+#pragma unroll
+      for (int a = 0; a < DIM; a++) gu[a] = xg[a] = 0.0;
+#pragma unroll
+      for (int k = 0; k < NPP; k++) {
+        const int n = n0 + k;
+        if (n < NC) {
+          const double un = ue[n];
+          const double ph = (SRC != 0) ? P.phi[(size_t)gg * NC + n] : 0.0;
+#pragma unroll
+          for (int a = 0; a < DIM; a++) {
+            double s = dh[k][0] * JI[a][0];
+#pragma unroll
+            for (int b = 1; b < DIM; b++) s += dh[k][b] * JI[a][b];   // gradphi[a] = sum_b dphi_b * JacI[a][b]
+            gs[(q * DIM + a) * NCP + n] = glive ? s : 0.0;
+            gu[a] += s * un;
+            xg[a] += xe[n * DIM + a] * ph;
+          }
+        }
+      }
+      if (NSPLIT > 1) {
+#pragma unroll
+        for (int off = 1; off < NSPLIT; off <<= 1)
+#pragma unroll
+          for (int a = 0; a < DIM; a++) {
+            gu[a] += __shfl_xor(gu[a], off, 64);
+            xg[a] += __shfl_xor(xg[a], off, 64);
+          }
+      }
+      if (part == 0) {
+        ws[q] = weight;
+        fs[q] = (SRC == 0) ? P.p0 : source_eval(P.source_kind, P.p0, P.p1, xg, DIM);
+#pragma unroll
+        for (int a = 0; a < DIM; a++) gus[q * DIM + a] = gu[a];
+      }
+    }
+    __syncthreads();
+    // ---------------- phase 2: K += (grad phi_i . grad phi_j) W ; F += (-f phi_i - grad phi_i . grad u) W ---------
+    if (tlive) {
+#pragma unroll 2
+      for (int gq = 0; gq < GC; gq++) {
+        const double wq = ws[gq];
+        double t[TI];
+#pragma unroll
+        for (int a = 0; a < TI; a++) t[a] = 0.0;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+          const double* row = gs + (gq * DIM + d) * NCP;
+          double av[TI], bv[TJ];
+#pragma unroll
+          for (int a = 0; a < TI; a++) av[a] = row[i0 + a];
+#pragma unroll
+          for (int b = 0; b < TJ; b++) bv[b] = row[j0 + b] * wq;
+#pragma unroll
+          for (int a = 0; a < TI; a++) {
+#pragma unroll
+            for (int b = 0; b < TJ; b++) K[a][b] += av[a] * bv[b];
+            t[a] += av[a] * gus[gq * DIM + d];
+          }
+        }
+        if (jb == 0) {
+          const int g = ch * GC + gq;
+          const double fq = fs[gq];
+#pragma unroll
+          for (int a = 0; a < TI; a++) {
+            const int i = i0 + a;
+            const double ph = (i < NC && g < P.ng) ? P.phi[(size_t)g * NC + i] : 0.0;
+            F[a] += (-fq * ph - t[a]) * wq;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (!elive || !tlive) return;
+  // ---------------- output ---------------------------------------------------------------------------------------
+  if constexpr (OUT == 3) {
+#pragma unroll
+    for (int a = 0; a < TI; a++) {
+      const int i = i0 + a;
+      if (i >= NC) continue;
+#pragma unroll
+      for (int b = 0; b < TJ; b++)
+        if (j0 + b < NC) P.Kout[((size_t)eidx * NC + i) * NC + j0 + b] = K[a][b];
+      if (jb == 0) P.Fout[(size_t)eidx * NC + i] = F[a];
+    }
+    return;
+  }
+#pragma unroll
+  for (int a = 0; a < TI; a++) {
+    const int i = i0 + a;
+    if (i >= NC) continue;
+    const int row = s_dof[slot][i];
+    const int rs = P.rowptr[row], re = P.rowptr[row + 1];
+#pragma unroll
+    for (int b = 0; b < TJ; b++) {
+      const int j = j0 + b;
+      if (j >= NC) continue;
+      int pos;
+      if constexpr (OUT == 0) {
+        pos = P.emap[((size_t)e * NC + i) * NCP + j];
+      } else {
+        const int target = s_dof[slot][j];
+        int lo = rs, hi = re - 1;
+        pos = -1;
+        while (lo <= hi) {
+          const int mid = (lo + hi) >> 1;
+          const int cc = P.col[mid];
+          if (cc == target) { pos = mid; break; }
+          if (cc < target) lo = mid + 1; else hi = mid - 1;
+        }
+      }
+      if constexpr (OUT == 2) P.emap_out[((size_t)e * NC + i) * NCP + j] = pos;
+      else if (pos >= 0) P.val[pos] += K[a][b];      // add_matrix_blocked: race-free inside one colour
+    }
+    if (OUT != 2 && jb == 0) P.res[row] += F[a];     // add_vector_blocked
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+template <int DIM, int NC>
+static int launch_assemble(fh_assembler_t as, const AsmParams& P) {
+  using C = AsmCfg<DIM, NC>;
+  if (P.nelems <= 0) return 0;
+  const dim3 grid(fh_div_up(P.nelems, C::EPB)), block(256);
+  const size_t lds = (size_t)C::EPB * C::LDS_PER_ELEM * sizeof(double);
+  hipStream_t st = as->ctx->stream;
+  const int src = P.source_kind != 0;
+  const int outm = P.Kout ? 3 : P.emap_out ? 2 : P.emap ? 0 : 1;
+#define FH_ASM(SRC, OUT) hipLaunchKernelGGL((k_assemble_poisson<DIM, NC, SRC, OUT>), grid, block, lds, st, P)
+  if (outm == 2) FH_ASM(0, 2);
+  else if (outm == 3) { if (src) FH_ASM(1, 3); else FH_ASM(0, 3); }
+  else if (outm == 0) { if (src) FH_ASM(1, 0); else FH_ASM(0, 0); }
+  else { if (src) FH_ASM(1, 1); else FH_ASM(0, 1); }
+#undef FH_ASM
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+static int dispatch_assemble(fh_assembler_t as, const AsmParams& P) {
+  if (as->dim == 3 && as->nc == 27) return launch_assemble<3, 27>(as, P);
+  if (as->dim == 3 && as->nc == 8) return launch_assemble<3, 8>(as, P);
+  if (as->dim == 2 && as->nc == 9) return launch_assemble<2, 9>(as, P);
+  if (as->dim == 2 && as->nc == 4) return launch_assemble<2, 4>(as, P);
+  fh_set_error("assembler: unsupported element (dim %d, nc %d)", as->dim, as->nc);
+  return 2;
+}
+
+// greedy element colouring: elements sharing a node get different colours
+static void color_elements(int nel, int nc, int nloc, const int* elem_dof, int ndof, std::vector<int>& color_ptr,
+                           std::vector<int>& color_elems) {
+  std::vector<int> cnt(ndof + 1, 0);
+  for (int e = 0; e < nel; e++)
+    for (int l = 0; l < nc; l++) cnt[elem_dof[(size_t)e * nloc + l] + 1]++;
+  for (int i = 0; i < ndof; i++) cnt[i + 1] += cnt[i];
+  std::vector<int> adj(cnt[ndof]), cur(cnt.begin(), cnt.end() - 1);
+  for (int e = 0; e < nel; e++)
+    for (int l = 0; l < nc; l++) adj[cur[elem_dof[(size_t)e * nloc + l]]++] = e;
+  std::vector<int> color(nel, -1);
+  std::vector<unsigned long long> used;
+  int ncolors = 0;
+  for (int e = 0; e < nel; e++) {
+    unsigned long long mask = 0;   // up to 64 colours (hex meshes need 8, unstructured ones ~20-30)
+    for (int l = 0; l < nc; l++) {
+      const int d = elem_dof[(size_t)e * nloc + l];
+      for (int k = cnt[d]; k < cnt[d + 1]; k++) {
+        const int c = color[adj[k]];
+        if (c >= 0) mask |= 1ull << c;
+      }
+    }
+    int c = 0;
+    while (c < 63 && (mask >> c) & 1ull) c++;
+    color[e] = c;
+    ncolors = std::max(ncolors, c + 1);
+  }
+  color_ptr.assign(ncolors + 1, 0);
+  for (int e = 0; e < nel; e++) color_ptr[color[e] + 1]++;
+  for (int c = 0; c < ncolors; c++) color_ptr[c + 1] += color_ptr[c];
+  color_elems.resize(nel);
+  std::vector<int> pos(color_ptr.begin(), color_ptr.end() - 1);
+  for (int e = 0; e < nel; e++) color_elems[pos[color[e]]++] = e;
+}
+
+static AsmParams base_params(fh_assembler_t as) {
+  AsmParams P;
+  memset(&P, 0, sizeof(P));
+  P.elem_dof = as->d_elem_dof;
+  P.nloc = as->nloc;
+  P.coords = as->d_coords;
+  P.w = as->d_w;
+  P.phi = as->d_phi;
+  P.dphi = as->d_dphi;
+  P.ng = as->ng;
+  return P;
+}
+
+extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, int nel, int nloc, const int* elem_dof, int nnode,
+                                   const double* coords, fh_mat_t A, fh_assembler_t* out) {
+  FH_REQUIRE(ctx && elem_dof && coords && A && out, "fh_assembler_create: null argument");
+  FH_REQUIRE(geom == 0 || geom == 1, "fh_assembler_create: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(fe == 0 || fe == 2, "fh_assembler_create: fe must be 0 (linear) or 2 (biquadratic)");
+  FH_REQUIRE(nloc == fhfe::nloc_of(geom), "fh_assembler_create: nloc %d does not match the geometry (%d)", nloc, fhfe::nloc_of(geom));
+  fh_assembler_t as = new fh_assembler_s();
+  as->ctx = ctx;
+  as->geom = geom;
+  as->fe = fe;
+  as->order = order;
+  as->dim = fhfe::dim_of(geom);
+  as->nc = fhfe::ndofs_of(geom, fe);
+  as->nloc = nloc;
+  as->nel = nel;
+  as->nnode = nnode;
+  as->ndof = A->m;
+  as->ncp = ((as->nc + ((as->nc == 9) ? 2 : 3)) / ((as->nc == 9) ? 3 : 4)) * ((as->nc == 9) ? 3 : 4);
+  std::vector<double> w, phi, dphi;
+  FH_REQUIRE(fhfe::shape_tables(geom, fe, order, w, phi, dphi) == 0, "fh_assembler_create: unsupported Gauss rule %d", order);
+  as->ng = (int)w.size();
+  for (size_t k = 0; k < (size_t)nel * nloc; k++)
+    FH_REQUIRE(elem_dof[k] >= 0 && elem_dof[k] < nnode, "fh_assembler_create: node id %d out of range", elem_dof[k]);
+  auto up = [&](void** d, const void* h, size_t bytes) -> int {
+    FH_CHECK_HIP(hipMalloc(d, bytes ? bytes : 8));
+    if (bytes) FH_CHECK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+    return 0;
+  };
+  FH_TRY(up((void**)&as->d_elem_dof, elem_dof, (size_t)nel * nloc * sizeof(int)));
+  FH_TRY(up((void**)&as->d_coords, coords, (size_t)nnode * as->dim * sizeof(double)));
+  FH_TRY(up((void**)&as->d_w, w.data(), w.size() * sizeof(double)));
+  FH_TRY(up((void**)&as->d_phi, phi.data(), phi.size() * sizeof(double)));
+  FH_TRY(up((void**)&as->d_dphi, dphi.data(), dphi.size() * sizeof(double)));
+  std::vector<int> celems;
+  color_elements(nel, as->nc, nloc, elem_dof, nnode, as->color_ptr, celems);
+  as->ncolors = (int)as->color_ptr.size() - 1;
+  FH_TRY(up((void**)&as->d_color_elems, celems.data(), celems.size() * sizeof(int)));
+  std::vector<int> iota(nel);
+  for (int e = 0; e < nel; e++) iota[e] = e;
+  FH_TRY(up((void**)&as->d_iota, iota.data(), iota.size() * sizeof(int)));
+  if (ctx->assemble_emap) {
+    // symbolic phase: CSR slot of every element entry, built on the device with the same kernel
+    FH_CHECK_HIP(hipMalloc(&as->d_emap, std::max<size_t>((size_t)nel * as->nc * as->ncp, 1) * sizeof(int)));
+    AsmParams P = base_params(as);
+    P.elems = as->d_iota;
+    P.nelems = nel;
+    P.rowptr = A->d_rowptr;
+    P.col = A->d_col;
+    P.emap_out = as->d_emap;
+    P.ng = 0;   // no quadrature needed for the symbolic pass
+    FH_TRY(dispatch_assemble(as, P));
+    FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  *out = as;
+  return 0;
+}
+
+extern "C" int fh_assembler_destroy(fh_assembler_t as) {
+  if (!as) return 0;
+  hipStreamSynchronize(as->ctx->stream);
+  hipFree(as->d_color_elems);
+  hipFree(as->d_elem_dof);
+  hipFree(as->d_coords);
+  hipFree(as->d_w);
+  hipFree(as->d_phi);
+  hipFree(as->d_dphi);
+  if (as->d_emap) hipFree(as->d_emap);
+  hipFree(as->d_iota);
+  delete as;
+  return 0;
+}
+
+extern "C" int fh_assemble_poisson(fh_assembler_t as, fh_vec_t sol, int source_kind, const double* params, fh_mat_t A, fh_vec_t res) {
+  FH_REQUIRE(as && A && res, "fh_assemble_poisson: null argument");
+  FH_REQUIRE(A->m == as->ndof && res->n_local >= as->ndof, "fh_assemble_poisson: size mismatch");
+  FH_REQUIRE(source_kind >= 0 && source_kind <= 2, "fh_assemble_poisson: unknown source kind %d", source_kind);
+  FH_REQUIRE(!sol || sol->n_local + sol->nghost >= as->ndof, "fh_assemble_poisson: solution vector too short");
+  // KK->zero(); RES->zero();  (separate.hpp:106-107)
+  FH_TRY(fh_mat_zero(A));
+  FH_TRY(fh_vec_zero(res));
+  AsmParams P = base_params(as);
+  P.sol = sol ? sol->d : nullptr;
+  P.source_kind = source_kind;
+  P.p0 = params ? params[0] : 1.0;
+  P.p1 = params ? params[1] : 0.0;
+  P.rowptr = A->d_rowptr;
+  P.col = A->d_col;
+  P.val = A->d_val;
+  P.res = res->d;
+  P.emap = as->d_emap;
+  for (int c = 0; c < as->ncolors; c++) {
+    P.elems = as->d_color_elems + as->color_ptr[c];
+    P.nelems = as->color_ptr[c + 1] - as->color_ptr[c];
+    FH_TRY(dispatch_assemble(as, P));
+  }
+  A->at_valid = false;
+  return 0;
+}
+
+extern "C" int fh_element_matrices_poisson(fh_assembler_t as, fh_vec_t sol, int source_kind, const double* params, double* K, double* F) {
+  FH_REQUIRE(as && K && F, "fh_element_matrices_poisson: null argument");
+  const size_t nk = (size_t)as->nel * as->nc * as->nc, nf = (size_t)as->nel * as->nc;
+  double *dK = nullptr, *dF = nullptr;
+  FH_CHECK_HIP(hipMalloc(&dK, std::max<size_t>(nk, 1) * sizeof(double)));
+  FH_CHECK_HIP(hipMalloc(&dF, std::max<size_t>(nf, 1) * sizeof(double)));
+  AsmParams P = base_params(as);
+  P.sol = sol ? sol->d : nullptr;
+  P.source_kind = source_kind;
+  P.p0 = params ? params[0] : 1.0;
+  P.p1 = params ? params[1] : 0.0;
+  P.elems = as->d_iota;
+  P.nelems = as->nel;
+  P.Kout = dK;
+  P.Fout = dF;
+  FH_TRY(dispatch_assemble(as, P));
+  FH_CHECK_HIP(hipMemcpyAsync(K, dK, nk * sizeof(double), hipMemcpyDeviceToHost, as->ctx->stream));
+  FH_CHECK_HIP(hipMemcpyAsync(F, dF, nf * sizeof(double), hipMemcpyDeviceToHost, as->ctx->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(as->ctx->stream));
+  hipFree(dK);
+  hipFree(dF);
+  return 0;
+}
+
+extern "C" int fh_assembler_info(fh_assembler_t as, int* ncolors, int64_t* algorithmic_bytes, double* flops) {
+  if (ncolors) *ncolors = as->ncolors;
+  const int nc = as->nc, dim = as->dim, ng = as->ng;
+  // per element reads nc*dim*8 (coords) + nc*4 (dof ids) + nc*8 (u), writes nc*nc*8 (K) + nc*8 (F)
+  if (algorithmic_bytes) *algorithmic_bytes = (int64_t)as->nel * (nc * dim * 8 + nc * 4 + nc * 8 + nc * nc * 8 + nc * 8);
+  if (flops)
+    *flops = (double)as->nel * ng * (nc * dim * dim * 2.0 + 60.0 + nc * dim * dim * 2.0 + (double)nc * nc * (dim * 2.0 + 2.0) + nc * 10.0);
+  return 0;
+}

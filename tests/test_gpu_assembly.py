@@ -1,0 +1,112 @@
+"""GPU parity: batched Poisson assembly (element kernel + coloured CSR scatter) against the oracle."""
+import numpy as np
+import pytest
+
+import femus_amd
+from femus_amd import capi
+from oracle import femus_oracle as fo
+
+pytestmark = pytest.mark.gpu
+ONE = lambda xg: np.ones(xg.shape[:2])
+
+
+def levels(args, nl):
+    ms = [capi.Mesh.box(*args)]
+    for _ in range(nl - 1):
+        ms.append(ms[-1].refine())
+    return ms
+
+
+def oracle_elem(mo, fe, u, rhs):
+    et = fo.ElemType(mo.geom, fe, "seventh")
+    ed = fo.elem_sys_dof(mo, fe)
+    X = np.transpose(mo.coords[mo.elem_dof], (0, 2, 1))
+    return fo.elem_poisson_batch(et, X, u[ed], rhs)
+
+
+CASES = [((2, 2, 2), 2, "biquadratic"), ((2, 2, 2), 2, "linear"), ((4, 4, 0), 2, "biquadratic"), ((8, 8, 0), 3, "linear"),
+         ((3, 2, 1), 2, "biquadratic")]
+
+
+@pytest.mark.parametrize("args,nl,fe", CASES)
+def test_element_matrices_match_oracle(ctx, args, nl, fe):
+    m = levels(args, nl)[-1]
+    mo = fo.build_levels(*args, nl)[-1]
+    ed, xy, _ = m.arrays()
+    assert np.array_equal(ed, mo.elem_dof) and np.array_equal(xy, mo.coords)     # integer / coordinate parity first
+    n = m.n_dofs(fe)
+    rp, col = capi.pattern_from_elements(ed[:, :fo.ndofs(m.geom, fe)], n)
+    A = ctx.matrix_csr(n, n, rp, col)
+    asm = capi.Assembler(ctx, m, fe, A)
+    u = fo.lcg_fill(n, 99)
+    sol = ctx.vector_from(u)
+    # constant source
+    K, F = asm.element_matrices(sol, 0, (1.5,))
+    Ko, Fo = oracle_elem(mo, fe, u, lambda xg: 1.5 * np.ones(xg.shape[:2]))
+    assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()      # fp64, FMA contraction / summation order only
+    assert abs(F - Fo).max() <= 1e-12 * abs(Fo).max()
+    # trigonometric source f = p0 * prod sin(p1 x_d)
+    K, F = asm.element_matrices(sol, 1, (-3 * np.pi ** 2, np.pi))
+    Ko, Fo = oracle_elem(mo, fe, u, lambda xg: -3 * np.pi ** 2 * np.prod(np.sin(np.pi * xg), axis=-1))
+    assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
+    assert abs(F - Fo).max() <= 1e-12 * abs(Fo).max()
+    asm.destroy()
+    A.destroy()
+
+
+def test_distorted_hex27_geometry(ctx):
+    """curved / sheared HEX27 elements: perturb the coordinates of a 2x2x2 mesh"""
+    m = levels((2, 2, 2), 1)[0]
+    ed, xy, _ = m.arrays()
+    rng = np.random.default_rng(11)
+    xy = xy + rng.uniform(-0.03, 0.03, xy.shape)
+    n = m.nnode
+    rp, col = capi.pattern_from_elements(ed, n)
+    A = ctx.matrix_csr(n, n, rp, col)
+    asm = capi.Assembler(ctx, m, "biquadratic", A, elem_dof=ed, coords=xy)
+    u = rng.uniform(-1, 1, n)
+    K, F = asm.element_matrices(ctx.vector_from(u), 2, (2.0, 1.3))
+    et = fo.ElemType("hex", "biquadratic", "seventh")
+    X = np.transpose(xy[ed], (0, 2, 1))
+    Ko, Fo = fo.elem_poisson_batch(et, X, u[ed], lambda xg: 2.0 * np.prod(np.cos(1.3 * xg), axis=-1))
+    assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
+    assert abs(F - Fo).max() <= 1e-12 * abs(Fo).max()
+
+
+@pytest.mark.parametrize("emap", [1, 0])
+@pytest.mark.parametrize("args,nl,fe", [((2, 2, 2), 3, "biquadratic"), ((8, 8, 0), 3, "linear"), ((2, 2, 2), 2, "linear")])
+def test_global_assembly_matches_oracle(ctx, args, nl, fe, emap):
+    ctx.set_option("assemble_emap", emap)
+    try:
+        m = levels(args, nl)[-1]
+        mo = fo.build_levels(*args, nl)[-1]
+        ed, xy, _ = m.arrays()
+        n = m.n_dofs(fe)
+        nc = fo.ndofs(m.geom, fe)
+        rp, col = capi.pattern_from_elements(ed[:, :nc], n)
+        rpo, colo = fo.csr_pattern(mo, fe)
+        assert np.array_equal(rp, rpo) and np.array_equal(col, colo)          # CSR pattern: bit-exact
+        A = ctx.matrix_csr(n, n, rp, col)
+        res = ctx.vector(n)
+        asm = capi.Assembler(ctx, m, fe, A)
+        assert 1 <= asm.info()["ncolors"] <= 64
+        u = fo.lcg_fill(n, 5)
+        sol = ctx.vector_from(u)
+        Ao, bo = fo.assemble_poisson(mo, fe, ONE, sol=u)
+        for rep in range(2):                                                  # second call: zero() + reassembly
+            asm.assemble(A, res, sol, 0, (1.0,))
+            assert abs(A.values() - Ao.data).max() <= 1e-12 * abs(Ao.data).max()
+            assert abs(res.to_numpy() - bo).max() <= 1e-12 * abs(bo).max()
+        # deterministic: two assemblies give identical bits (colour order, no atomics)
+        v1 = A.values().copy()
+        asm.assemble(A, res, sol, 0, (1.0,))
+        assert np.array_equal(v1, A.values())
+        # Dirichlet rows as in MGSetLevel: SetPenalty + ZerosBoundaryResiduals
+        bdc = m.dirichlet_dofs(fe)
+        assert np.array_equal(bdc, fo.dirichlet_dofs(mo, fe))
+        A.mat_zero_rows(bdc, 1.0)
+        ref = fo.zero_rows_inplace_pattern(Ao, bdc, 1.0)
+        assert abs(A.values() - ref.data).max() <= 1e-12 * abs(ref.data).max()
+        asm.destroy()
+    finally:
+        ctx.set_option("assemble_emap", 1)
