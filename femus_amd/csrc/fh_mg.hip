@@ -1,0 +1,511 @@
+// Geometric multigrid on gfx950 (K8-K13 of SURVEY 2.1; a15-a18 of SURVEY 8).
+// Replaces the PETSc PCMG wiring of
+//   src/08_algebra.../03_solvers_with_preconditioner/LinearEquationSolverPetsc.cpp:185-353 (MGInit/MGSetLevel/MGSolve)
+// with the cycle the reference states itself in LinearImplicitSystem::MGStep (LinearImplicitSystem.cpp:1397-1562):
+//   pre-smooth -> residual -> restrict (R = PP^T, LinearImplicitSystem.cpp:379-382) -> recurse -> prolong+add -> post-smooth.
+// PETSc behaviours restated: multiplicative V-cycle, smoother = KSPRICHARDSON(scale omega) + PCJACOBI
+// with a FIXED iteration count and zero initial guess on the way down (first sweep needs no SpMV), level 0 = exact solve
+// (PREONLY + LU, LinearEquationSolverPetsc.hpp:131-134), outer KSP = PREONLY / RICHARDSON(0.99999) / left-preconditioned
+// GMRES(restart) with classical Gram-Schmidt and Knoll initial guess (:294-335) / PCG.
+//
+// MI355X design: every smoother sweep is ONE fused CSR-stream SpMV (matrix read once, x_new = x + omega*dinv*(b - A x));
+// restriction uses the explicit transpose (built once) so it is a plain coalesced SpMV; the coarse solve is a dense
+// GEMV with the inverse factored once per assembly; the whole cycle (~25 short launches, launch-bound on the coarse
+// levels) is captured in a hipGraph and replayed.
+#include "fh_internal.h"
+#include <algorithm>
+#include <cmath>
+
+int fh_dev_get_diag(fh_mat_t A, double* d, int invert);
+
+struct MgLevel {
+  fh_mat_t A = nullptr, P = nullptr, R = nullptr;
+  bool own_R = false;
+  int n = 0, smoother = 0, npre = 2, npost = 2;
+  double omega = 2.0 / 3.0;
+  double *dinv = nullptr, *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;
+};
+
+struct fh_mg_s {
+  fh_ctx_t ctx = nullptr;
+  int nlevels = 0;
+  std::vector<MgLevel> lv;
+  double* d_ainv = nullptr;   // dense inverse of the coarsest operator, row-major n0 x n0
+  bool setup_done = false;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  // Krylov workspace
+  std::vector<double*> kv;
+  int kv_n = 0;
+  int64_t cycle_bytes = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_first_sweep(double* __restrict__ x, const double* __restrict__ b, const double* __restrict__ dinv,
+                                                     double omega, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) x[i] = omega * dinv[i] * b[i];
+}
+
+// y = Ainv b, one wave per row, 16-byte loads
+__global__ __launch_bounds__(256) void k_dense_gemv(const double* __restrict__ M, const double* __restrict__ b, double* __restrict__ y, int n) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const double* m = M + (size_t)row * n;
+  double acc = 0.0;
+  for (int k = lane; k < n; k += 64) acc += m[k] * b[k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) y[row] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_csr_to_dense(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+                                                      double* __restrict__ D, int n) {
+  const int row = blockIdx.x;
+  for (int k = rowptr[row] + threadIdx.x; k < rowptr[row + 1]; k += 256) D[(size_t)row * n + col[k]] = val[k];
+}
+
+// in-place Gauss-Jordan inversion, step k (no pivoting: the coarse operator is SPD on the free dofs and identity
+// on Dirichlet rows).  Three launches per step: save column k, rank-1 update of the other rows, scale the pivot row.
+__global__ __launch_bounds__(256) void k_gj_savecol(const double* __restrict__ D, double* __restrict__ colk, int n, int k) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) colk[i] = D[(size_t)i * n + k];
+}
+
+__global__ __launch_bounds__(256) void k_gj_update(double* __restrict__ D, const double* __restrict__ colk, int n, int k) {
+  const int i = blockIdx.y;
+  if (i == k) return;
+  const double f = colk[i];
+  if (f == 0.0) return;   // row not coupled to the pivot
+  const double fp = f / colk[k];
+  const double* rk = D + (size_t)k * n;
+  double* ri = D + (size_t)i * n;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) ri[j] = (j == k) ? -fp : ri[j] - fp * rk[j];
+}
+
+__global__ __launch_bounds__(256) void k_gj_scalerow(double* __restrict__ D, const double* __restrict__ colk, int n, int k) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const double p = 1.0 / colk[k];
+  double* rk = D + (size_t)k * n;
+  rk[j] = (j == k) ? p : rk[j] * p;
+}
+
+// V^T w for nvec basis vectors (GMRES classical Gram-Schmidt): partials[j*nb + block]
+__global__ __launch_bounds__(256) void k_multidot(const double* const* __restrict__ V, const double* __restrict__ w, int nvec, int n,
+                                                  double* __restrict__ part) {
+  __shared__ double sm[4];
+  for (int j = 0; j < nvec; j++) {
+    const double* v = V[j];
+    double acc = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) acc += v[i] * w[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(size_t)j * gridDim.x + blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_multidot_final(double* __restrict__ part, int nvec, int nb) {
+  __shared__ double sm[4];
+  const int j = blockIdx.x;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) acc += part[(size_t)j * nb + i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(size_t)nvec * nb + j] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// w -= sum_j h[j] V_j   (h on the device, right behind the partials)
+__global__ __launch_bounds__(256) void k_multiaxpy(double* __restrict__ w, const double* const* __restrict__ V, const double* __restrict__ h,
+                                                   double sign, int nvec, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    double acc = w[i];
+    for (int j = 0; j < nvec; j++) acc += sign * h[j] * V[j][i];
+    w[i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_axpby2(double* y, const double* x, double a, double b, int n) {   // x may alias y
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) y[i] = a * x[i] + b * y[i];
+}
+
+static inline int sgrid(fh_ctx_t c, int n) { return std::max(1, std::min(fh_div_up(n, 256), c->num_cu * 8)); }
+
+// ------------------------------------------------------------------------------------------------
+// API
+// ------------------------------------------------------------------------------------------------
+extern "C" int fh_mg_create(fh_ctx_t ctx, int nlevels, fh_mg_t* out) {
+  FH_REQUIRE(ctx && out && nlevels >= 1, "fh_mg_create: bad arguments");
+  fh_mg_t mg = new fh_mg_s();
+  mg->ctx = ctx;
+  mg->nlevels = nlevels;
+  mg->lv.resize(nlevels);
+  *out = mg;
+  return 0;
+}
+
+extern "C" int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh_mat_t R, int smoother, double omega, int npre, int npost) {
+  FH_REQUIRE(mg && A, "fh_mg_set_level: null argument");
+  FH_REQUIRE(level >= 0 && level < mg->nlevels, "fh_mg_set_level: level %d out of range", level);
+  FH_REQUIRE(A->m == A->n, "fh_mg_set_level: operator must be square");
+  FH_REQUIRE(level == 0 || P != nullptr, "fh_mg_set_level: level %d needs an interpolation matrix", level);
+  FH_REQUIRE(!P || P->m == A->m, "fh_mg_set_level: interpolation has %d rows, operator has %d", P ? P->m : 0, A->m);
+  FH_REQUIRE(smoother == FH_SMOOTH_JACOBI, "fh_mg_set_level: only the Richardson+Jacobi smoother is implemented (got %d)", smoother);
+  FH_REQUIRE(npre >= 0 && npost >= 0, "fh_mg_set_level: negative sweep count");
+  MgLevel& L = mg->lv[level];
+  L.A = A;
+  L.P = P;
+  L.R = R;
+  L.n = A->m;
+  L.smoother = smoother;
+  L.omega = omega;
+  L.npre = npre;
+  L.npost = npost;
+  mg->setup_done = false;
+  return 0;
+}
+
+static void free_level_buffers(MgLevel& L) {
+  for (double** p : {&L.dinv, &L.x, &L.x2, &L.b, &L.r})
+    if (*p) {
+      hipFree(*p);
+      *p = nullptr;
+    }
+  if (L.own_R && L.R) {
+    fh_mat_destroy(L.R);
+    L.R = nullptr;
+    L.own_R = false;
+  }
+}
+
+static int coarse_factor(fh_mg_t mg) {
+  fh_ctx_t c = mg->ctx;
+  MgLevel& L0 = mg->lv[0];
+  const int n = L0.n;
+  FH_REQUIRE(n <= 16384, "coarse level has %d unknowns: the dense direct solve supports at most 16384", n);
+  if (mg->d_ainv) FH_CHECK_HIP(hipFree(mg->d_ainv));
+  FH_CHECK_HIP(hipMalloc(&mg->d_ainv, (size_t)n * n * sizeof(double)));
+  FH_CHECK_HIP(hipMemsetAsync(mg->d_ainv, 0, (size_t)n * n * sizeof(double), c->stream));
+  hipLaunchKernelGGL(k_csr_to_dense, dim3(n), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, mg->d_ainv, n);
+  double* colk = nullptr;
+  FH_CHECK_HIP(hipMalloc(&colk, (size_t)n * sizeof(double)));
+  const int gx = std::max(1, std::min(fh_div_up(n, 256), 8));
+  for (int k = 0; k < n; k++) {
+    hipLaunchKernelGGL(k_gj_savecol, dim3(fh_div_up(n, 256)), dim3(256), 0, c->stream, mg->d_ainv, colk, n, k);
+    hipLaunchKernelGGL(k_gj_update, dim3(gx, n), dim3(256), 0, c->stream, mg->d_ainv, colk, n, k);
+    hipLaunchKernelGGL(k_gj_scalerow, dim3(fh_div_up(n, 256)), dim3(256), 0, c->stream, mg->d_ainv, colk, n, k);
+  }
+  FH_CHECK_HIP(hipGetLastError());
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  hipFree(colk);
+  return 0;
+}
+
+static int run_cycle(fh_mg_t mg);
+
+extern "C" int fh_mg_setup(fh_mg_t mg) {
+  fh_ctx_t c = mg->ctx;
+  for (int l = 0; l < mg->nlevels; l++) FH_REQUIRE(mg->lv[l].A, "fh_mg_setup: level %d has not been set", l);
+  for (int l = 1; l < mg->nlevels; l++)
+    FH_REQUIRE(mg->lv[l].P->n == mg->lv[l - 1].n, "fh_mg_setup: interpolation of level %d has %d columns, level %d has %d rows", l,
+               mg->lv[l].P->n, l - 1, mg->lv[l - 1].n);
+  if (mg->gexec) {
+    hipGraphExecDestroy(mg->gexec);
+    mg->gexec = nullptr;
+  }
+  if (mg->graph) {
+    hipGraphDestroy(mg->graph);
+    mg->graph = nullptr;
+  }
+  mg->cycle_bytes = 0;
+  for (int l = 0; l < mg->nlevels; l++) {
+    MgLevel& L = mg->lv[l];
+    free_level_buffers(L);
+    const size_t nb = ((size_t)L.n + 2) * sizeof(double);
+    for (double** p : {&L.dinv, &L.x, &L.x2, &L.b, &L.r}) {
+      FH_CHECK_HIP(hipMalloc(p, nb));
+      FH_CHECK_HIP(hipMemsetAsync(*p, 0, nb, c->stream));
+    }
+    FH_TRY(fh_dev_get_diag(L.A, L.dinv, 1));
+    if (l > 0) {
+      if (!L.R) {   // restriction = transpose of the interpolation (LinearImplicitSystem.cpp:379-382)
+        FH_TRY(fh_mat_transpose(L.P, &L.R));
+        L.own_R = true;
+      }
+      FH_REQUIRE(L.R->m == mg->lv[l - 1].n && L.R->n == L.n, "fh_mg_setup: restriction of level %d has the wrong shape", l);
+      const int64_t bA = fh_spmv_algorithmic_bytes(L.A), n8 = 8ll * L.n;
+      // algorithmic bytes of the cycle on this level (SURVEY 8d model, zero-guess first sweep needs no SpMV):
+      if (L.npre > 0) mg->cycle_bytes += 3 * n8 + (int64_t)(L.npre - 1) * (bA + 2 * n8);
+      mg->cycle_bytes += bA + n8;                                            // residual
+      mg->cycle_bytes += fh_spmv_algorithmic_bytes(L.R) + fh_spmv_algorithmic_bytes(L.P) + n8;   // restrict, prolong+add
+      mg->cycle_bytes += (int64_t)L.npost * (bA + 2 * n8);
+    }
+  }
+  FH_TRY(coarse_factor(mg));
+  mg->cycle_bytes += 8ll * mg->lv[0].n * mg->lv[0].n + 16ll * mg->lv[0].n;
+  mg->setup_done = true;
+  FH_TRY(run_cycle(mg));   // un-captured warm-up: builds lazily created row blocks, validates the launches
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  if (c->use_graph) {
+    // capture one cycle on the internal buffers and keep it for replay
+    FH_CHECK_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    int rc = run_cycle(mg);
+    hipError_t e = hipStreamEndCapture(c->stream, &mg->graph);
+    if (rc) return rc;
+    FH_CHECK_HIP(e);
+    FH_CHECK_HIP(hipGraphInstantiate(&mg->gexec, mg->graph, nullptr, nullptr, 0));
+  }
+  return 0;
+}
+
+// one multiplicative V-cycle on the internal buffers: input lv[top].b, output lv[top].x
+static int run_cycle(fh_mg_t mg) {
+  fh_ctx_t c = mg->ctx;
+  const int top = mg->nlevels - 1;
+  for (int l = top; l >= 1; l--) {
+    MgLevel& L = mg->lv[l];
+    if (L.npre == 0) {
+      FH_CHECK_HIP(hipMemsetAsync(L.x, 0, (size_t)L.n * sizeof(double), c->stream));
+    } else {
+      // sweep 1 from a zero guess: x = omega D^-1 b ; sweeps 2..npre: fused Jacobi SpMV, ping-pong x <-> x2
+      hipLaunchKernelGGL(k_first_sweep, dim3(sgrid(c, L.n)), dim3(256), 0, c->stream, L.x, L.b, L.dinv, L.omega, L.n);
+      for (int s = 1; s < L.npre; s++) {
+        FH_TRY(fh_dev_spmv(L.A, L.x, L.x2, 3, L.b, L.dinv, L.omega));
+        std::swap(L.x, L.x2);
+      }
+    }
+    FH_TRY(fh_dev_spmv(L.A, L.x, L.r, 2, L.b, nullptr, 0.0));                       // r = b - A x
+    FH_TRY(fh_dev_spmv(L.R, L.r, mg->lv[l - 1].b, 0, nullptr, nullptr, 0.0));       // b_{l-1} = R r
+  }
+  {
+    MgLevel& L0 = mg->lv[0];
+    hipLaunchKernelGGL(k_dense_gemv, dim3(fh_div_up(L0.n, 4)), dim3(256), 0, c->stream, mg->d_ainv, L0.b, L0.x, L0.n);
+  }
+  for (int l = 1; l <= top; l++) {
+    MgLevel& L = mg->lv[l];
+    FH_TRY(fh_dev_spmv(L.P, mg->lv[l - 1].x, L.x, 1, nullptr, nullptr, 0.0));       // x += P x_{l-1}
+    for (int s = 0; s < L.npost; s++) {
+      FH_TRY(fh_dev_spmv(L.A, L.x, L.x2, 3, L.b, L.dinv, L.omega));
+      std::swap(L.x, L.x2);
+    }
+  }
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// x_out = M^-1 b_in with raw device pointers
+static int apply_cycle(fh_mg_t mg, const double* b_in, double* x_out) {
+  fh_ctx_t c = mg->ctx;
+  const int top = mg->nlevels - 1;
+  MgLevel& L = mg->lv[top];
+  FH_CHECK_HIP(hipMemcpyAsync(L.b, b_in, (size_t)L.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  if (mg->gexec) {
+    // the captured graph hard-codes the ping-pong roles: restore the parity it was captured with
+    FH_CHECK_HIP(hipGraphLaunch(mg->gexec, c->stream));
+  } else {
+    FH_TRY(run_cycle(mg));
+  }
+  FH_CHECK_HIP(hipMemcpyAsync(x_out, L.x, (size_t)L.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+extern "C" int fh_mg_vcycle(fh_mg_t mg, fh_vec_t b, fh_vec_t x) {
+  FH_REQUIRE(mg && mg->setup_done, "fh_mg_vcycle: fh_mg_setup has not been called");
+  const int n = mg->lv[mg->nlevels - 1].n;
+  FH_REQUIRE(b->n_local >= n && x->n_local >= n, "fh_mg_vcycle: vectors too short");
+  return apply_cycle(mg, b->d, x->d);
+}
+
+extern "C" int64_t fh_mg_cycle_algorithmic_bytes(fh_mg_t mg) { return mg->cycle_bytes; }
+
+extern "C" int fh_mg_destroy(fh_mg_t mg) {
+  if (!mg) return 0;
+  hipStreamSynchronize(mg->ctx->stream);
+  if (mg->gexec) hipGraphExecDestroy(mg->gexec);
+  if (mg->graph) hipGraphDestroy(mg->graph);
+  for (auto& L : mg->lv) free_level_buffers(L);
+  if (mg->d_ainv) hipFree(mg->d_ainv);
+  for (double* p : mg->kv) hipFree(p);
+  delete mg;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// outer solvers
+// ------------------------------------------------------------------------------------------------
+static int krylov_reserve(fh_mg_t mg, int nvec, int n) {
+  if ((int)mg->kv.size() >= nvec && mg->kv_n == n) return 0;
+  for (double* p : mg->kv) hipFree(p);
+  mg->kv.assign(nvec, nullptr);
+  for (int i = 0; i < nvec; i++) FH_CHECK_HIP(hipMalloc(&mg->kv[i], ((size_t)n + 2) * sizeof(double)));
+  mg->kv_n = n;
+  return 0;
+}
+
+static int dev_dot(fh_ctx_t c, const double* x, const double* y, int n, double* out) {
+  fh_vec_s vx, vy;
+  vx.ctx = vy.ctx = c;
+  vx.n_local = vy.n_local = n;
+  vx.d = const_cast<double*>(x);
+  vy.d = const_cast<double*>(y);
+  return fh_vec_dot(&vx, &vy, out);
+}
+
+static int dev_axpby(fh_ctx_t c, double* y, const double* x, double a, double b, int n) {
+  hipLaunchKernelGGL(k_axpby2, dim3(sgrid(c, n)), dim3(256), 0, c->stream, y, x, a, b, n);
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, double rtol, double atol, double dtol, int maxit, int restart,
+                           int* iterations, double* final_residual) {
+  FH_REQUIRE(mg && mg->setup_done, "fh_mg_solve: fh_mg_setup has not been called");
+  fh_ctx_t c = mg->ctx;
+  const int top = mg->nlevels - 1;
+  fh_mat_t A = mg->lv[top].A;
+  const int n = A->m;
+  FH_REQUIRE(bv->n_local >= n && xv->n_local >= n, "fh_mg_solve: vectors too short");
+  FH_REQUIRE(outer >= 0 && outer <= 3, "fh_mg_solve: unknown outer solver %d", outer);
+  double* b = bv->d;
+  double* x = xv->d;
+  int its = 0;
+  double rn = 0.0;
+
+  if (outer == FH_OUTER_PREONLY) {
+    // exactly one cycle per MGSolve (LinearEquationSolverPetsc.cpp:310-313)
+    FH_TRY(apply_cycle(mg, b, x));
+    its = 1;
+  } else if (outer == FH_OUTER_RICHARDSON) {
+    // x <- x + 0.99999 M^-1 (b - A x), x0 = 0 (MGInit: _richardsonScaleFactor = .99999, :190-193)
+    FH_TRY(krylov_reserve(mg, 2, n));
+    double *r = mg->kv[0], *z = mg->kv[1];
+    FH_CHECK_HIP(hipMemsetAsync(x, 0, (size_t)n * sizeof(double), c->stream));
+    double bn;
+    FH_TRY(dev_dot(c, b, b, n, &bn));
+    bn = sqrt(bn);
+    for (;;) {
+      FH_TRY(fh_dev_spmv(A, x, r, 2, b, nullptr, 0.0));
+      FH_TRY(dev_dot(c, r, r, n, &rn));
+      rn = sqrt(rn);
+      if (rn <= std::max(rtol * bn, atol) || its >= maxit || rn > dtol * bn) break;
+      FH_TRY(apply_cycle(mg, r, z));
+      FH_TRY(dev_axpby(c, x, z, 0.99999, 1.0, n));
+      its++;
+    }
+  } else if (outer == FH_OUTER_CG) {
+    FH_TRY(krylov_reserve(mg, 4, n));
+    double *r = mg->kv[0], *z = mg->kv[1], *p = mg->kv[2], *Ap = mg->kv[3];
+    FH_CHECK_HIP(hipMemsetAsync(x, 0, (size_t)n * sizeof(double), c->stream));
+    FH_CHECK_HIP(hipMemcpyAsync(r, b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    double bn, rz, rz_new, pAp;
+    FH_TRY(dev_dot(c, b, b, n, &bn));
+    bn = sqrt(bn);
+    rn = bn;
+    FH_TRY(apply_cycle(mg, r, z));
+    FH_CHECK_HIP(hipMemcpyAsync(p, z, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    FH_TRY(dev_dot(c, r, z, n, &rz));
+    while (rn > std::max(rtol * bn, atol) && its < maxit && rn <= dtol * bn) {
+      FH_TRY(fh_dev_spmv(A, p, Ap, 0, nullptr, nullptr, 0.0));
+      FH_TRY(dev_dot(c, p, Ap, n, &pAp));
+      const double alpha = rz / pAp;
+      FH_TRY(dev_axpby(c, x, p, alpha, 1.0, n));
+      FH_TRY(dev_axpby(c, r, Ap, -alpha, 1.0, n));
+      FH_TRY(dev_dot(c, r, r, n, &rn));
+      rn = sqrt(rn);
+      its++;
+      FH_TRY(apply_cycle(mg, r, z));
+      FH_TRY(dev_dot(c, r, z, n, &rz_new));
+      FH_TRY(dev_axpby(c, p, z, 1.0, rz_new / rz, n));
+      rz = rz_new;
+    }
+  } else {
+    // left-preconditioned GMRES(restart), classical Gram-Schmidt, Knoll guess x0 = M^-1 b
+    FH_REQUIRE(restart >= 1 && restart <= 200, "fh_mg_solve: restart %d out of range", restart);
+    FH_TRY(krylov_reserve(mg, restart + 3, n));
+    double* t = mg->kv[restart + 1];
+    double* w = mg->kv[restart + 2];
+    const int nb = sgrid(c, n);
+    FH_TRY(fh_reserve_reduction(c, (size_t)(restart + 2) * (nb + 1) + 64));
+    double** d_V = nullptr;
+    FH_CHECK_HIP(hipMalloc(&d_V, (restart + 1) * sizeof(double*)));
+    FH_CHECK_HIP(hipMemcpy(d_V, mg->kv.data(), (restart + 1) * sizeof(double*), hipMemcpyHostToDevice));
+    std::vector<double> H((size_t)(restart + 1) * restart, 0.0), g(restart + 1), cs(restart), sn(restart), y(restart);
+    // Knoll: x0 = M^-1 b ; reference norm = ||M^-1 b||
+    FH_TRY(apply_cycle(mg, b, x));
+    double beta0;
+    FH_TRY(dev_dot(c, x, x, n, &beta0));
+    beta0 = sqrt(beta0);
+    bool done = false;
+    while (!done) {
+      FH_TRY(fh_dev_spmv(A, x, t, 2, b, nullptr, 0.0));       // t = b - A x
+      FH_TRY(apply_cycle(mg, t, mg->kv[0]));                  // v0 = M^-1 t
+      double beta;
+      FH_TRY(dev_dot(c, mg->kv[0], mg->kv[0], n, &beta));
+      beta = sqrt(beta);
+      rn = beta;
+      if (beta <= std::max(rtol * beta0, atol) || its >= maxit || beta > dtol * beta0) break;
+      FH_TRY(dev_axpby(c, mg->kv[0], mg->kv[0], 0.0, 1.0 / beta, n));
+      std::fill(g.begin(), g.end(), 0.0);
+      g[0] = beta;
+      int kused = 0;
+      for (int k = 0; k < restart; k++) {
+        FH_TRY(fh_dev_spmv(A, mg->kv[k], t, 0, nullptr, nullptr, 0.0));
+        FH_TRY(apply_cycle(mg, t, w));
+        // h = V^T w (one pass), w -= V h, h_{k+1,k} = ||w||
+        hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, c->stream, (const double* const*)d_V, w, k + 1, n, c->d_red);
+        hipLaunchKernelGGL(k_multidot_final, dim3(k + 1), dim3(256), 0, c->stream, c->d_red, k + 1, nb);
+        hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, w, (const double* const*)d_V, c->d_red + (size_t)(k + 1) * nb, -1.0,
+                           k + 1, n);
+        FH_CHECK_HIP(hipMemcpyAsync(c->h_red, c->d_red + (size_t)(k + 1) * nb, (k + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+        for (int j = 0; j <= k; j++) H[(size_t)j * restart + k] = c->h_red[j];
+        double wn;
+        FH_TRY(dev_dot(c, w, w, n, &wn));
+        wn = sqrt(wn);
+        H[(size_t)(k + 1) * restart + k] = wn;
+        if (wn != 0.0) FH_TRY(dev_axpby(c, mg->kv[k + 1], w, 1.0 / wn, 0.0, n));
+        for (int j = 0; j < k; j++) {
+          const double a = H[(size_t)j * restart + k], bb = H[(size_t)(j + 1) * restart + k];
+          H[(size_t)j * restart + k] = cs[j] * a + sn[j] * bb;
+          H[(size_t)(j + 1) * restart + k] = -sn[j] * a + cs[j] * bb;
+        }
+        const double a = H[(size_t)k * restart + k], bb = H[(size_t)(k + 1) * restart + k];
+        const double d = hypot(a, bb);
+        cs[k] = a / d;
+        sn[k] = bb / d;
+        H[(size_t)k * restart + k] = d;
+        H[(size_t)(k + 1) * restart + k] = 0.0;
+        g[k + 1] = -sn[k] * g[k];
+        g[k] = cs[k] * g[k];
+        its++;
+        kused = k + 1;
+        rn = fabs(g[k + 1]);
+        if (rn <= std::max(rtol * beta0, atol) || its >= maxit) {
+          done = true;
+          break;
+        }
+      }
+      for (int i = kused - 1; i >= 0; i--) {
+        double s = g[i];
+        for (int j = i + 1; j < kused; j++) s -= H[(size_t)i * restart + j] * y[j];
+        y[i] = s / H[(size_t)i * restart + i];
+      }
+      // x += V y
+      FH_CHECK_HIP(hipMemcpyAsync(c->d_red, y.data(), kused * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, x, (const double* const*)d_V, c->d_red, 1.0, kused, n);
+      FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+    }
+    hipFree(d_V);
+  }
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  if (iterations) *iterations = its;
+  if (final_residual) *final_residual = rn;
+  return 0;
+}
