@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py -- FEMuS hot path on MI355X: fine-level Poisson assembly + one V(2,2) Jacobi cycle per step.
+
+Workload (BASELINE.json configs[1]): 3-D Poisson, Q2 (HEX27), coarse 8^3 refined to 64^3, 4-level GMG, V(2,2)
+Richardson(2/3)+Jacobi smoother, exact coarse solve, f = 1, u = 0 on the boundary; 64^3 elements PER GPU (weak scaling).
+
+One step = KK->zero / RES->zero / batched element loop / Dirichlet residual rows (the reference's "ASSEMBLY TIME"
+phase) followed by one multigrid cycle on the assembled residual (the reference's "Linear-Cycle" phase) with the
+hierarchy prepared once before the timed region (Galerkin chain + SetPenalty + smoother/coarse setup = the reference's
+"PREPARATION TIME", reported separately as prepare_ms).  Inputs are resident in HBM when the timed region starts.
+
+Prints ONE JSON line on rank 0 (contract in the task description); `roofline` is the fine-level Jacobi-sweep SpMV
+kernel, `cpu_baseline` is the oracle's C restatement timed on the host cores of this box (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6    # vendor FP64 vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--coarse", type=int, default=8, help="coarse box elements per direction (8 -> 64^3 with 4 levels)")
+    ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-reps", type=int, default=50)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    import femus_amd
+    from femus_amd.poisson import PoissonMG
+
+    ctx = femus_amd.Context(local_rank)
+    t0 = time.time()
+    pb = PoissonMG(ctx, args.coarse, args.coarse, args.coarse, args.levels, fe="biquadratic", order="seventh",
+                   omega=2. / 3., npre=2, npost=2, coarse="galerkin", source_kind=0, params=(1.0,)).init()
+    setup_s = time.time() - t0
+    ndof = pb.ndof[-1]
+    nel = pb.meshes[-1].nel
+    A = None
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+        ctx.sync()
+
+    # hierarchy preparation (outside the timed steps; timed on its own)
+    pb.assemble()
+    ctx.sync()
+    t0 = time.time()
+    pb.prepare()
+    ctx.sync()
+    prepare_first_s = time.time() - t0          # includes the one-time symbolic PtAP
+    pb.assemble()
+    ctx.sync()
+    t0 = time.time()
+    pb.prepare()                                 # numeric-only re-preparation
+    ctx.sync()
+    prepare_ms = (time.time() - t0) * 1e3
+    A = pb.A[-1]
+
+    def step():
+        pb.assemble()                            # zero + element loop (all colours)
+        pb.zero_boundary_residuals()             # ZerosBoundaryResiduals
+        pb.vcycle()                              # one V(2,2) cycle on RES -> EPSC
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = ndof * world * args.steps / elapsed
+
+    # ---- sub-phase timings with HIP events on the library's compute stream --------------------------------------
+    reps = max(3, args.steps)
+    ctx.timer_start()
+    for _ in range(reps):
+        pb.assemble()
+    asm_ms = ctx.timer_stop() / reps
+    pb.zero_boundary_residuals()
+    ctx.timer_start()
+    for _ in range(reps):
+        pb.vcycle()
+    cyc_ms = ctx.timer_stop() / reps
+    # dominant V-cycle kernel: fine-level fused Jacobi sweep (same kernel family as y=Ax / residual)
+    n = ndof
+    x, y = ctx.vector(n), ctx.vector(n)
+    x.upload(np.random.default_rng(12345).uniform(-1, 1, n))
+    dinv = ctx.vector(n)
+    A.get_diagonal(dinv)
+    dinv.upload(1.0 / np.where(dinv.to_numpy() == 0, 1.0, dinv.to_numpy()))
+    kr = args.kernel_reps
+    for _ in range(5):
+        y.jacobi_sweep(pb.RES, x, A, dinv, 2. / 3.)
+    ctx.timer_start()
+    for _ in range(kr):
+        y.jacobi_sweep(pb.RES, x, A, dinv, 2. / 3.)
+    sweep_ms = ctx.timer_stop() / kr
+    ctx.timer_start()
+    for _ in range(kr):
+        y.matrix_mult(x, A)
+    spmv_ms = ctx.timer_stop() / kr
+    spmv_bytes = A.spmv_algorithmic_bytes()
+    sweep_bytes = spmv_bytes + 3 * 8 * n       # + b, dinv, x(own row) per SURVEY 8(d) Jacobi-sweep model
+    cyc_bytes = pb.mg.cycle_algorithmic_bytes()
+    ai = pb.asm[-1].info()
+
+    out = {
+        "metric": "assembled DOFs/sec + V-cycle SpMV GB/s (% HBM peak), 3D Poisson Q2",
+        "value": value,
+        "unit": "DOF/s (assembly + one V(2,2) cycle per step)",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "3D Poisson Q2 (HEX27, 64-pt Gauss) on %d^3 box per GPU, %d-level GMG V(2,2) Jacobi(2/3), Galerkin coarse "
+                        "operators, dense exact coarse solve" % (args.coarse * 2 ** (args.levels - 1), args.levels),
+            "dofs_per_gpu": ndof,
+            "elements_per_gpu": nel,
+            "nnz_fine": A.nnz,
+            "parallelism": "1 rank per GPU" + ("" if world == 1 else "; %d independent 64^3 subdomain problems (halo exchange wired in fh_halo_*, not yet in bench)" % world),
+        },
+        "assembled_dofs_per_sec": ndof * world / (asm_ms * 1e-3),
+        "assembly_ms": asm_ms,
+        "vcycle_ms": cyc_ms,
+        "vcycles_per_sec": world / (cyc_ms * 1e-3),
+        "vcycle_GBps": cyc_bytes / cyc_ms / 1e6,
+        "vcycle_pct_hbm_peak": cyc_bytes / cyc_ms / 1e6 / HBM_PEAK_GBPS * 100.0,
+        "vcycle_spmv_GBps": spmv_bytes / spmv_ms / 1e6,
+        "vcycle_spmv_pct_hbm_peak": spmv_bytes / spmv_ms / 1e6 / HBM_PEAK_GBPS * 100.0,
+        "prepare_ms": prepare_ms,
+        "prepare_first_s": prepare_first_s,
+        "setup_s": setup_s,
+        "roofline": {
+            "kernel": "k_spmv_stream<2048,3> (fine-level fused Jacobi sweep x+w*Dinv*(b-Ax))",
+            "bound": "hbm",
+            "achieved": sweep_bytes / sweep_ms / 1e6,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": sweep_bytes / sweep_ms / 1e6 / HBM_PEAK_GBPS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": sweep_bytes,
+            "avg_launch_ms": sweep_ms,
+            "plain_spmv_ms": spmv_ms,
+        },
+        "roofline_assembly": {
+            "kernel": "k_assemble_poisson<3,27,0,0> (8 colours)",
+            "bound": "fp64-valu (also reported against hbm)",
+            "achieved_tflops": ai["flops"] / asm_ms / 1e9,
+            "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+            "frac": ai["flops"] / asm_ms / 1e9 / FP64_VALU_PEAK_TFLOPS,
+            "achieved_GBps": ai["algorithmic_bytes"] / asm_ms / 1e6,
+            "frac_hbm": ai["algorithmic_bytes"] / asm_ms / 1e6 / HBM_PEAK_GBPS,
+            "ncolors": ai["ncolors"],
+        },
+    }
+
+    # ---- CPU baseline: the oracle's C restatement on the host cores (rank 0, N = 1 only) ------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(pb, ndof, nel)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    pb.destroy()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pb, ndof, nel):
+    """`port`: oracle/oracle_kernels.c (same element loop, same CSR, same V(2,2) Jacobi cycle).  Bounded sample:
+    the element loop on a slice of elements (scaled to the full level) + full V-cycles with OpenMP over all cores."""
+    import numpy as np
+    from oracle import c_kernels as ck
+    from oracle import femus_oracle as fo
+    import scipy.sparse as sp
+    cores = ck.num_threads()
+    ed, xy, _ = pb.meshes[-1].arrays()
+    sample = min(nel, 4096)
+    rp, col = pb.A[-1].pattern()
+    val, res = np.zeros(rp[-1]), np.zeros(ndof)
+    t0 = time.perf_counter()
+    ck.assemble_poisson(ed, xy, "biquadratic", "hex", 0, sample, csr=(rp, col, val, res))
+    t_asm_sample = time.perf_counter() - t0
+    # the reference runs one rank per core with an owner-computes element split: perfect-scaling estimate over cores
+    t_asm_full = t_asm_sample * (nel / sample) / cores
+    A = [a.to_scipy() for a in pb.A]
+    P = [None] + [p.to_scipy() for p in pb.P[1:]]
+    n0 = A[0].shape[0]
+    import scipy.linalg as sla
+    lu = sla.lu_factor(A[0].toarray())
+    cyc = ck.CVcycle(A, P, 2. / 3., 2, 2, coarse_solve=lambda b: sla.lu_solve(lu, b))
+    rhs = np.ones(ndof)
+    cyc.apply(rhs)
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        cyc.apply(rhs)
+    t_cyc = (time.perf_counter() - t0) / reps
+    return {
+        "value": ndof / (t_asm_full + t_cyc),
+        "unit": "DOF/s (assembly + one V(2,2) cycle per step)",
+        "cores": cores,
+        "kind": "port",
+        "sample": "element loop on %d of %d elements single-threaded (%.2f s), scaled x%d/%d cores (owner-computes split as in the "
+                  "reference); %d full V(2,2) cycles with OpenMP on %d threads (%.3f s each)" % (sample, nel, t_asm_sample, nel // sample, cores, reps, cores, t_cyc),
+        "assembly_s_est": t_asm_full,
+        "assembled_dofs_per_sec": ndof / t_asm_full,
+        "vcycle_s": t_cyc,
+        "vcycles_per_sec": 1.0 / t_cyc,
+        "petsc": "PETSc not available -- CPU restatement only",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,128 @@
+// Multi-GPU halo exchange and scalar reductions (C1, C3, C4 of SURVEY 2.1) over RCCL / xGMI.
+// Replaces what PETSc does inside VecGhostUpdateBegin/End (src/03_algebra/00_vectors/PetscVector.hpp:595-612),
+// the MPIAIJ MatMult scatter, and VecDot/VecNorm all-reduces (Parallel.hpp:351-377).
+//
+// One rank per GPU.  The exchange is a neighbour all-to-all: a pack kernel gathers the owned interface entries
+// into one send buffer (grouped by destination), a single RCCL group of ncclSend/ncclRecv pairs moves each
+// neighbour's slice over its direct xGMI link, and the receives land straight in the ghost tail of the vector
+// ([owned | ghosts grouped by source rank]).  Communication runs on the context's second stream so interior work
+// queued on the compute stream overlaps with it; events join the two streams.
+#include "fh_internal.h"
+#include <rccl/rccl.h>
+
+struct fh_halo_s {
+  fh_ctx_t ctx = nullptr;
+  int rank = 0, nranks = 1;
+  ncclComm_t comm = nullptr;
+  std::vector<int> send_counts, recv_counts, send_off, recv_off;
+  int nsend = 0, nrecv = 0;
+  int* d_send_idx = nullptr;
+  double* d_sendbuf = nullptr;
+  double* d_scalars = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_done = nullptr;
+};
+
+#define FH_CHECK_NCCL(expr)                                                                     \
+  do {                                                                                          \
+    ncclResult_t _r = (expr);                                                                   \
+    if (_r != ncclSuccess) {                                                                    \
+      fh_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r));  \
+      return 1;                                                                                 \
+    }                                                                                           \
+  } while (0)
+
+__global__ __launch_bounds__(256) void k_pack(const double* __restrict__ v, const int* __restrict__ idx, double* __restrict__ buf, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) buf[i] = v[idx[i]];
+}
+
+extern "C" int fh_halo_unique_id(char id128[128]) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  ncclUniqueId id;
+  FH_CHECK_NCCL(ncclGetUniqueId(&id));
+  memcpy(id128, &id, 128);
+  return 0;
+}
+
+extern "C" int fh_halo_create(fh_ctx_t ctx, int rank, int nranks, const char id128[128], const int* send_counts, const int* send_idx,
+                              const int* recv_counts, fh_halo_t* out) {
+  FH_REQUIRE(ctx && out && send_counts && recv_counts, "fh_halo_create: null argument");
+  FH_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "fh_halo_create: bad rank %d of %d", rank, nranks);
+  fh_halo_t h = new fh_halo_s();
+  h->ctx = ctx;
+  h->rank = rank;
+  h->nranks = nranks;
+  h->send_counts.assign(send_counts, send_counts + nranks);
+  h->recv_counts.assign(recv_counts, recv_counts + nranks);
+  h->send_off.assign(nranks + 1, 0);
+  h->recv_off.assign(nranks + 1, 0);
+  for (int r = 0; r < nranks; r++) {
+    FH_REQUIRE(send_counts[r] >= 0 && recv_counts[r] >= 0, "fh_halo_create: negative count");
+    h->send_off[r + 1] = h->send_off[r] + send_counts[r];
+    h->recv_off[r + 1] = h->recv_off[r] + recv_counts[r];
+  }
+  h->nsend = h->send_off[nranks];
+  h->nrecv = h->recv_off[nranks];
+  FH_REQUIRE(h->nsend == 0 || send_idx, "fh_halo_create: null send index list");
+  FH_CHECK_HIP(hipMalloc(&h->d_send_idx, std::max(h->nsend, 1) * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&h->d_sendbuf, std::max(h->nsend, 1) * sizeof(double)));
+  FH_CHECK_HIP(hipMalloc(&h->d_scalars, 256 * sizeof(double)));
+  if (h->nsend) FH_CHECK_HIP(hipMemcpy(h->d_send_idx, send_idx, h->nsend * sizeof(int), hipMemcpyHostToDevice));
+  FH_CHECK_HIP(hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
+  FH_CHECK_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+  if (nranks > 1) {
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    FH_CHECK_NCCL(ncclCommInitRank(&h->comm, nranks, id, rank));
+  }
+  *out = h;
+  return 0;
+}
+
+extern "C" int fh_halo_update(fh_halo_t h, fh_vec_t v) {
+  FH_REQUIRE(h && v, "fh_halo_update: null argument");
+  FH_REQUIRE(v->nghost == h->nrecv, "fh_halo_update: vector has %d ghosts, plan receives %d", v->nghost, h->nrecv);
+  if (h->nranks == 1) return 0;
+  fh_ctx_t c = h->ctx;
+  if (h->nsend) {
+    int nb = std::max(1, std::min(fh_div_up(h->nsend, 256), c->num_cu * 4));
+    hipLaunchKernelGGL(k_pack, dim3(nb), dim3(256), 0, c->stream, v->d, h->d_send_idx, h->d_sendbuf, h->nsend);
+    FH_CHECK_HIP(hipGetLastError());
+  }
+  FH_CHECK_HIP(hipEventRecord(h->ev_packed, c->stream));
+  FH_CHECK_HIP(hipStreamWaitEvent(c->comm_stream, h->ev_packed, 0));
+  FH_CHECK_NCCL(ncclGroupStart());
+  for (int r = 0; r < h->nranks; r++) {
+    if (r == h->rank) continue;
+    if (h->send_counts[r]) FH_CHECK_NCCL(ncclSend(h->d_sendbuf + h->send_off[r], h->send_counts[r], ncclDouble, r, h->comm, c->comm_stream));
+    if (h->recv_counts[r]) FH_CHECK_NCCL(ncclRecv(v->d + v->n_local + h->recv_off[r], h->recv_counts[r], ncclDouble, r, h->comm, c->comm_stream));
+  }
+  FH_CHECK_NCCL(ncclGroupEnd());
+  FH_CHECK_HIP(hipEventRecord(h->ev_done, c->comm_stream));
+  FH_CHECK_HIP(hipStreamWaitEvent(c->stream, h->ev_done, 0));   // consumers of the ghosts on the compute stream wait here
+  return 0;
+}
+
+extern "C" int fh_halo_allreduce_sum(fh_halo_t h, double* vals, int n) {
+  FH_REQUIRE(h && vals && n >= 0 && n <= 256, "fh_halo_allreduce_sum: bad arguments (n <= 256)");
+  if (h->nranks == 1 || n == 0) return 0;
+  fh_ctx_t c = h->ctx;
+  FH_CHECK_HIP(hipMemcpyAsync(h->d_scalars, vals, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  FH_CHECK_NCCL(ncclAllReduce(h->d_scalars, h->d_scalars, n, ncclDouble, ncclSum, h->comm, c->stream));
+  FH_CHECK_HIP(hipMemcpyAsync(vals, h->d_scalars, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int fh_halo_destroy(fh_halo_t h) {
+  if (!h) return 0;
+  hipStreamSynchronize(h->ctx->stream);
+  hipStreamSynchronize(h->ctx->comm_stream);
+  if (h->comm) ncclCommDestroy(h->comm);
+  hipFree(h->d_send_idx);
+  hipFree(h->d_sendbuf);
+  hipFree(h->d_scalars);
+  hipEventDestroy(h->ev_packed);
+  hipEventDestroy(h->ev_done);
+  delete h;
+  return 0;
+}

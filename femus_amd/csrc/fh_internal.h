@@ -76,6 +76,9 @@ struct fh_mat_s {
   fh_mat_t At = nullptr;
   int* d_tperm = nullptr;             // At.val[k] = val[tperm[k]]
   bool at_valid = false;
+  // attached reusable product plan (fh_mat_ptap)
+  void* plan = nullptr;
+  void (*plan_destroy)(void*) = nullptr;
 };
 
 // kernels / helpers implemented across TUs

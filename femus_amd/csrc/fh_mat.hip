@@ -56,6 +56,7 @@ extern "C" int fh_mat_create_csr(fh_ctx_t c, int m, int n, const int* rowptr, co
 extern "C" int fh_mat_destroy(fh_mat_t A) {
   if (!A) return 0;
   hipStreamSynchronize(A->ctx->stream);
+  if (A->plan && A->plan_destroy) A->plan_destroy(A->plan);
   if (A->At) fh_mat_destroy(A->At);
   if (A->d_tperm) hipFree(A->d_tperm);
   if (A->d_rowptr) hipFree(A->d_rowptr);

@@ -1,0 +1,118 @@
+"""Host-side driver of the Poisson geometric-multigrid hot path: the calls LinearImplicitSystem makes
+(src/08_equations/00_stationary/LinearImplicitSystem.cpp), expressed over the C-ABI.
+
+    init()      <- LinearImplicitSystem::init :138-282      levels, sparsity, BuildProlongatorMatrix, ZeroInterpolatorDirichletNodes
+    assemble()  <- _assemble_system_function :325           the batched element loop (fh_assemble_poisson)
+    prepare()   <- MGsolve :347-383                         Galerkin chain KK[l-1] = PP[l]^T KK[l] PP[l] (from the un-penalised
+                                                            matrices), then MGInit / MGSetLevel (SetPenalty on every level)
+    vcycle()/mgsolve() <- Vcycle :468-497 / MGSolve        ZerosBoundaryResiduals, outer solver preconditioned by the cycle
+
+Used by tests/ and bench.py; all numerics run in libfemus_hip.so.
+"""
+import numpy as np
+
+from . import capi
+
+
+class PoissonMG:
+    def __init__(self, ctx, nx, ny, nz, nlevels, fe="biquadratic", order="seventh", lo=(0., 0., 0.), hi=(1., 1., 1.),
+                 omega=2. / 3., npre=2, npost=2, coarse="galerkin", source_kind=0, params=(1.0,)):
+        self.ctx = ctx
+        self.fe, self.order = fe, order
+        self.nlevels = nlevels
+        self.omega, self.npre, self.npost = omega, npre, npost
+        self.coarse = coarse
+        self.source_kind, self.params = source_kind, params
+        self.meshes = [capi.Mesh.box(nx, ny, nz, lo, hi)]
+        for _ in range(1, nlevels):
+            self.meshes.append(self.meshes[-1].refine())
+        self.nc = {"linear": 2 ** self.meshes[0].dim, "biquadratic": 3 ** self.meshes[0].dim}[fe]
+        self.mg = None
+
+    # ---- LinearImplicitSystem::init ---------------------------------------------------------------------------
+    def init(self):
+        ctx, fe = self.ctx, self.fe
+        top = self.nlevels - 1
+        self.ndof = [m.n_dofs(fe) for m in self.meshes]
+        self.bdc = [m.dirichlet_dofs(fe) for m in self.meshes]
+        self.P = [None] + [capi.build_prolongator(ctx, self.meshes[l - 1], self.meshes[l], fe, zero_bdc=True)
+                           for l in range(1, self.nlevels)]
+        # per-level operators: finest (and, for coarse == "rediscretise", every level) carries the element pattern
+        self.A = [None] * self.nlevels
+        self.asm = [None] * self.nlevels
+        levels = range(self.nlevels) if self.coarse == "rediscretise" else [top]
+        for l in levels:
+            ed, xy, _ = self.meshes[l].arrays()
+            rp, col = capi.pattern_from_elements(ed[:, :self.nc], self.ndof[l])
+            self.A[l] = ctx.matrix_csr(self.ndof[l], self.ndof[l], rp, col)
+            self.asm[l] = capi.Assembler(ctx, self.meshes[l], fe, self.A[l], self.order, elem_dof=ed, coords=xy)
+        n = self.ndof[top]
+        self.RES, self.EPS, self.EPSC, self.RESC = ctx.vector(n), ctx.vector(n), ctx.vector(n), ctx.vector(n)
+        self.SOL = ctx.vector(n)
+        self.sol_lvl = [None] * self.nlevels
+        self._zeros_top = np.zeros(self.bdc[top].size)
+        return self
+
+    # ---- assembly of the level to assemble (the finest) --------------------------------------------------------
+    def assemble(self, level=None):
+        l = self.nlevels - 1 if level is None else level
+        res = self.RES if l == self.nlevels - 1 else self.ctx.vector(self.ndof[l])
+        self.asm[l].assemble(self.A[l], res, self.SOL if l == self.nlevels - 1 else None, self.source_kind, self.params)
+        return res
+
+    # ---- MGsolve preparation ------------------------------------------------------------------------------------
+    def prepare(self):
+        ctx = self.ctx
+        top = self.nlevels - 1
+        if self.coarse == "galerkin":
+            for l in range(top, 0, -1):            # PtAP chain from the un-penalised operators
+                if self.A[l - 1] is None:
+                    self.A[l - 1] = capi.Mat.ptap(self.P[l], self.A[l])
+                else:
+                    self.A[l - 1].ptap_numeric(self.P[l], self.A[l])
+        else:
+            for l in range(top):
+                self.assemble(l)
+        for l in range(self.nlevels):              # MGSetLevel: BuildBdcIndex + SetPenalty
+            self.A[l].mat_zero_rows(self.bdc[l], 1.0)
+        if self.mg is None:
+            self.mg = capi.Multigrid(ctx, self.nlevels)
+        for l in range(self.nlevels):
+            self.mg.set_level(l, self.A[l], self.P[l], None, 0, self.omega, self.npre if l > 0 else 1, self.npost if l > 0 else 0)
+        self.mg.setup()
+        return self
+
+    def zero_boundary_residuals(self):
+        top = self.nlevels - 1
+        if self.bdc[top].size:
+            self.RES.set(self.bdc[top], self._zeros_top)
+
+    # ---- one preconditioner application / the MG solve ----------------------------------------------------------
+    def vcycle(self, b=None, x=None):
+        self.mg.vcycle(self.RES if b is None else b, self.EPSC if x is None else x)
+
+    def mgsolve(self, outer="gmres", rtol=1e-10, atol=1e-50, maxit=100, restart=30):
+        """MGSolve: ZerosBoundaryResiduals; KSPSolve(RES -> EPSC); RESC = KK EPSC; RES -= RESC; EPS += EPSC"""
+        self.zero_boundary_residuals()
+        its, rn = self.mg.solve(self.RES, self.EPSC, outer=outer, rtol=rtol, atol=atol, maxit=maxit, restart=restart)
+        self.RESC.matrix_mult(self.EPSC, self.A[-1])
+        self.RES.add(-1.0, self.RESC)
+        self.EPS.add(1.0, self.EPSC)
+        return its, rn
+
+    def update_sol(self):
+        """Solution::UpdateSol: Sol += Eps"""
+        self.SOL.add(1.0, self.EPS)
+        self.EPS.zero()
+
+    def destroy(self):
+        if self.mg is not None:
+            self.mg.destroy()
+        for a in self.asm:
+            if a is not None:
+                a.destroy()
+        for m in self.A + self.P:
+            if m is not None:
+                m.destroy()
+        for m in self.meshes:
+            m.destroy()

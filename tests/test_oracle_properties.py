@@ -109,3 +109,25 @@ def test_config1_2d_q1_three_level_cycle():
     xd = spla.spsolve(H.A[-1].tocsc(), H.b)
     x, hist = fo.solve_gmres_mg(H, rtol=1e-12, npre=1, npost=1)
     assert np.linalg.norm(x - xd) <= 1e-10 * np.linalg.norm(xd)
+
+
+def test_c_restatement_matches_numpy_oracle():
+    """oracle/oracle_kernels.c (the timed CPU baseline) against the numpy oracle: element kernel, scatter, cycle"""
+    from oracle import c_kernels as ck
+    H = fo.build_poisson_hierarchy(2, 2, 2, 3, "biquadratic", ONE)
+    m = H.meshes[-1]
+    u = fo.lcg_fill(m.nnode, 4)
+    K, F = ck.assemble_poisson(m.elem_dof, m.coords, "biquadratic", "hex", 0, m.nel, sol=u, source_kind=1, p0=2.0, p1=1.1)
+    et = fo.ElemType("hex", "biquadratic", "seventh")
+    X = np.transpose(m.coords[m.elem_dof], (0, 2, 1))
+    Ko, Fo = fo.elem_poisson_batch(et, X, u[m.elem_dof], lambda xg: 2.0 * np.prod(np.sin(1.1 * xg), axis=-1))
+    assert abs(K - Ko).max() <= 1e-13 * abs(Ko).max() and abs(F - Fo).max() <= 1e-12 * abs(Fo).max()
+    rp, col = fo.csr_pattern(m, "biquadratic")
+    val, res = np.zeros(rp[-1]), np.zeros(m.nnode)
+    ck.assemble_poisson(m.elem_dof, m.coords, "biquadratic", "hex", 0, m.nel, csr=(rp, col, val, res))
+    assert abs(val - H.A_raw[-1].data).max() <= 1e-13 * abs(val).max()
+    assert abs(res - H.b_raw).max() <= 1e-13 * abs(res).max()
+    cyc = ck.CVcycle(H.A, H.P)
+    rhs = fo.lcg_fill(m.nnode, 8)
+    ref = fo.vcycle(H, 2, rhs)
+    assert np.linalg.norm(cyc.apply(rhs) - ref) <= 1e-12 * np.linalg.norm(ref)
