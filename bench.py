@@ -171,7 +171,7 @@ def main():
         "prepare_first_s": prepare_first_s,
         "setup_s": setup_s,
         "roofline": {
-            "kernel": "k_spmv_stream<2048,3> (fine-level fused Jacobi sweep x+w*Dinv*(b-Ax))",
+            "kernel": "k_spmv_lx<1024,3> (fine-level fused Jacobi sweep x+w*Dinv*(b-Ax), LDS-staged x)",
             "bound": "hbm",
             "achieved": sweep_bytes / sweep_ms / 1e6,
             "peak": HBM_PEAK_GBPS,
@@ -210,10 +210,11 @@ def cpu_baseline(pb, ndof, nel):
     """`port`: oracle/oracle_kernels.c (same element loop, same CSR, same V(2,2) Jacobi cycle).  Bounded sample:
     the element loop on a slice of elements (scaled to the full level) + full V-cycles with OpenMP over all cores."""
     import numpy as np
+    os.environ["OMP_NUM_THREADS"] = str(len(os.sched_getaffinity(0)))     # before libgomp starts: threads = usable cores
     from oracle import c_kernels as ck
     from oracle import femus_oracle as fo
     import scipy.sparse as sp
-    cores = ck.num_threads()
+    cores = len(os.sched_getaffinity(0))
     ed, xy, _ = pb.meshes[-1].arrays()
     sample = min(nel, 4096)
     rp, col = pb.A[-1].pattern()

@@ -92,6 +92,7 @@ extern "C" int fh_set_option(fh_ctx_t c, const char* name, double value) {
   if (!strcmp(name, "spmv_tile")) c->spmv_tile = (int)value;
   else if (!strcmp(name, "spmv_xcd_remap")) c->spmv_xcd_remap = (int)value;
   else if (!strcmp(name, "spmv_kernel")) c->spmv_kernel = (int)value;
+  else if (!strcmp(name, "spmv_nt")) c->spmv_nt = (int)value;
   else if (!strcmp(name, "assemble_emap")) c->assemble_emap = (int)value;
   else if (!strcmp(name, "use_graph")) c->use_graph = (int)value;
   else {

@@ -45,9 +45,10 @@ struct fh_ctx_s {
   double* h_red = nullptr;            // pinned host
   size_t red_cap = 0;
   // options
-  int spmv_tile = 2048;               // nnz per row block (LDS tile)
+  int spmv_tile = 1024;               // nnz per row block (LDS tile)
   int spmv_xcd_remap = 1;
-  int spmv_kernel = 0;                // 0: csr-stream, 1: csr-vector
+  int spmv_kernel = 3;                // 0: csr-stream (workgroup tiles), 1: csr-vector, 2: csr-stream (wave tiles), 3: csr-stream with LDS-staged x
+  int spmv_nt = 0;                    // non-temporal matrix stream
   int assemble_emap = 1;
   int use_graph = 1;
 };
@@ -69,8 +70,15 @@ struct fh_mat_s {
   std::vector<int> h_rowptr, h_col;   // host copy of the pattern (setup-time integer work)
   // CSR-stream row blocks
   int tile = 0;
+  int tile_kernel = 0;
   int nblk = 0;
   int* d_rowblk = nullptr;
+  std::vector<int> h_rowblk;
+  // tile-local column compaction (spmv_kernel 3): unique columns per row block + 16-bit local indices
+  int* d_uptr = nullptr;
+  int* d_ucols = nullptr;
+  unsigned short* d_lcol = nullptr;
+  int lx_tile = 0;
   int max_row = 0;
   // cached explicit transpose for matrix_mult_transpose
   fh_mat_t At = nullptr;
@@ -84,6 +92,7 @@ struct fh_mat_s {
 // kernels / helpers implemented across TUs
 int fh_reserve_reduction(fh_ctx_t ctx, size_t ndoubles);
 int fh_mat_build_rowblocks(fh_mat_t A, int tile);
+int fh_mat_build_localcols(fh_mat_t A);
 int fh_mat_refresh_transpose(fh_mat_t A);   // re-gather values into the cached transpose
 int fh_dev_spmv(fh_mat_t A, const double* x, double* y, int mode, const double* b, const double* dinv, double omega);
 

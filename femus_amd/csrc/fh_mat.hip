@@ -12,6 +12,7 @@
 #include "fh_internal.h"
 #include <algorithm>
 #include <cmath>
+#include <thread>
 
 // ------------------------------------------------------------------------------------------------
 // creation / destruction
@@ -63,6 +64,9 @@ extern "C" int fh_mat_destroy(fh_mat_t A) {
   if (A->d_col) hipFree(A->d_col);
   if (A->d_val) hipFree(A->d_val);
   if (A->d_rowblk) hipFree(A->d_rowblk);
+  if (A->d_uptr) hipFree(A->d_uptr);
+  if (A->d_ucols) hipFree(A->d_ucols);
+  if (A->d_lcol) hipFree(A->d_lcol);
   delete A;
   return 0;
 }
@@ -80,13 +84,14 @@ extern "C" int64_t fh_spmv_algorithmic_bytes(fh_mat_t A) {
 
 // row blocks: greedy, <= tile non-zeros and <= 512 rows per block; a row longer than the tile is alone
 int fh_mat_build_rowblocks(fh_mat_t A, int tile) {
-  FH_REQUIRE(tile == 1024 || tile == 2048 || tile == 4096, "spmv_tile must be 1024, 2048 or 4096 (got %d)", tile);
+  FH_REQUIRE(tile == 256 || tile == 512 || tile == 1024 || tile == 2048 || tile == 4096, "spmv_tile must be 256..4096, power of two (got %d)", tile);
+  const int maxrows = (A->ctx->spmv_kernel == 2) ? 128 : 512;
   std::vector<int> blk;
   blk.push_back(0);
   int acc = 0, rows = 0;
   for (int i = 0; i < A->m; i++) {
     int len = A->h_rowptr[i + 1] - A->h_rowptr[i];
-    if (rows > 0 && (acc + len > tile || rows >= 512)) {
+    if (rows > 0 && (acc + len > tile || rows >= maxrows)) {
       blk.push_back(i);
       acc = 0;
       rows = 0;
@@ -98,6 +103,9 @@ int fh_mat_build_rowblocks(fh_mat_t A, int tile) {
   if (A->m == 0) blk.assign(1, 0);
   A->nblk = (int)blk.size() - 1;
   A->tile = tile;
+  A->tile_kernel = A->ctx->spmv_kernel;
+  A->h_rowblk = blk;
+  A->lx_tile = 0;   // local-column data (if any) no longer matches the row blocks
   if (A->d_rowblk) FH_CHECK_HIP(hipFree(A->d_rowblk));
   FH_CHECK_HIP(hipMalloc(&A->d_rowblk, blk.size() * sizeof(int)));
   FH_CHECK_HIP(hipMemcpy(A->d_rowblk, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -447,6 +455,232 @@ __global__ __launch_bounds__(256) void k_spmv_stream(const int* __restrict__ row
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// tile-local column compaction: for every row block the sorted list of distinct columns (ucols) and, per non-zero,
+// the 16-bit index into that list.  The SpMV then gathers each needed x entry ONCE per tile into LDS (sorted, hence
+// mostly coalesced) and the 135M per-non-zero gathers become LDS reads; the column stream shrinks from 4 to 2 bytes.
+// Integer setup work on host threads, done lazily at the first product with the matrix.
+// ------------------------------------------------------------------------------------------------
+int fh_mat_build_localcols(fh_mat_t A) {
+  const int nblk = A->nblk;
+  const std::vector<int>& blk = A->h_rowblk;
+  std::vector<int> uptr(nblk + 1, 0);
+  std::vector<unsigned short> lcol((size_t)A->nnz + 2, 0);
+  const int nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  std::vector<std::vector<int>> chunks(nthreads);
+  std::vector<int> bounds(nthreads + 1);
+  for (int t = 0; t <= nthreads; t++) bounds[t] = (int)((int64_t)nblk * t / nthreads);
+  auto work = [&](int t) {
+    std::vector<int> buf;
+    for (int b = bounds[t]; b < bounds[t + 1]; b++) {
+      const int s = A->h_rowptr[blk[b]], e = A->h_rowptr[blk[b + 1]];
+      if (e - s > A->tile) {   // single long row: handled by the global-column path
+        uptr[b + 1] = 0;
+        continue;
+      }
+      buf.assign(A->h_col.begin() + s, A->h_col.begin() + e);
+      std::sort(buf.begin(), buf.end());
+      buf.erase(std::unique(buf.begin(), buf.end()), buf.end());
+      uptr[b + 1] = (int)buf.size();
+      for (int k = s; k < e; k++)
+        lcol[k] = (unsigned short)(std::lower_bound(buf.begin(), buf.end(), A->h_col[k]) - buf.begin());
+      chunks[t].insert(chunks[t].end(), buf.begin(), buf.end());
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++) th.emplace_back(work, t);
+  for (auto& x : th) x.join();
+  for (int b = 0; b < nblk; b++) uptr[b + 1] += uptr[b];
+  std::vector<int> ucols((size_t)uptr[nblk] + 1);
+  for (int t = 0; t < nthreads; t++)
+    if (!chunks[t].empty()) std::copy(chunks[t].begin(), chunks[t].end(), ucols.begin() + uptr[bounds[t]]);
+  if (A->d_uptr) FH_CHECK_HIP(hipFree(A->d_uptr));
+  if (A->d_ucols) FH_CHECK_HIP(hipFree(A->d_ucols));
+  if (A->d_lcol) FH_CHECK_HIP(hipFree(A->d_lcol));
+  FH_CHECK_HIP(hipMalloc(&A->d_uptr, uptr.size() * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&A->d_ucols, ucols.size() * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&A->d_lcol, lcol.size() * sizeof(unsigned short)));
+  FH_CHECK_HIP(hipMemcpy(A->d_uptr, uptr.data(), uptr.size() * sizeof(int), hipMemcpyHostToDevice));
+  FH_CHECK_HIP(hipMemcpy(A->d_ucols, ucols.data(), ucols.size() * sizeof(int), hipMemcpyHostToDevice));
+  FH_CHECK_HIP(hipMemcpy(A->d_lcol, lcol.data(), lcol.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  A->lx_tile = A->tile;
+  return 0;
+}
+
+template <int TILE, int MODE>
+__global__ __launch_bounds__(256) void k_spmv_lx(const int* __restrict__ rowptr, const int* __restrict__ col, const unsigned short* __restrict__ lcol,
+                                                 const double* __restrict__ val, const int* __restrict__ rowblk, const int* __restrict__ uptr,
+                                                 const int* __restrict__ ucols, int nblk, int q, const double* __restrict__ x,
+                                                 double* __restrict__ y, const double* __restrict__ b, const double* __restrict__ dinv, double omega) {
+  __shared__ double prod[TILE + 2];
+  __shared__ double xs[TILE];
+  int blk = (q > 0) ? (int)(blockIdx.x & 7) * q + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (blk >= nblk) return;
+  const int tid = threadIdx.x;
+  const int r0 = rowblk[blk], r1 = rowblk[blk + 1];
+  const int s = rowptr[r0], e = rowptr[r1];
+  if (r1 - r0 == 1 && e - s > TILE) {
+    double acc = 0.0;
+    for (int k = s + tid; k < e; k += 256) acc += val[k] * x[col[k]];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((tid & 63) == 0) prod[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) spmv_store<MODE>(prod[0] + prod[1] + prod[2] + prod[3], r0, x, y, b, dinv, omega);
+    return;
+  }
+  // ---- matrix stream first (longest latency): 16 B of values + 4 B of local columns per lane and step ----
+  const int s2 = s & ~1;
+  constexpr int ITER = TILE / 512 + 1;
+  double2 v[ITER];
+  ushort2 lc[ITER];
+#pragma unroll
+  for (int k = 0; k < ITER; k++) {
+    const int i = s2 + 2 * tid + k * 512;
+    if (i < e) {
+      v[k] = *reinterpret_cast<const double2*>(val + i);
+      lc[k] = *reinterpret_cast<const ushort2*>(lcol + i);
+    }
+  }
+  // ---- x entries of this tile -> LDS (sorted distinct columns: neighbouring lanes share cache lines) ----
+  const int u0 = uptr[blk], nu = uptr[blk + 1] - u0;
+  for (int j = tid; j < nu; j += 256) xs[j] = x[ucols[u0 + j]];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < ITER; k++) {
+    const int i = s2 + 2 * tid + k * 512;
+    if (i < e) {
+      if (i >= s) prod[i - s] = v[k].x * xs[lc[k].x];
+      if (i + 1 < e) prod[i + 1 - s] = v[k].y * xs[lc[k].y];
+    }
+  }
+  __syncthreads();
+  const int nrows = r1 - r0;
+  const int G = (nrows <= 16) ? 16 : (nrows <= 32) ? 8 : (nrows <= 64) ? 4 : (nrows <= 128) ? 2 : 1;
+  const int gl = tid & (G - 1);
+  const int rows_per_pass = 256 / G;
+  const int npass = (nrows + rows_per_pass - 1) / rows_per_pass;
+  for (int p = 0; p < npass; p++) {
+    const int rr = p * rows_per_pass + tid / G;
+    const bool live = rr < nrows;
+    const int r = r0 + (live ? rr : 0);
+    double acc = 0.0;
+    if (live) {
+      const int a = rowptr[r] - s, z = rowptr[r + 1] - s;
+      for (int k = a + gl; k < z; k += G) acc += prod[k];
+    }
+    for (int off = G >> 1; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (live && gl == 0) spmv_store<MODE>(acc, r, x, y, b, dinv, omega);
+  }
+}
+
+template <int TILE>
+static void launch_lx(fh_mat_t A, int mode, const double* x, double* y, const double* b, const double* dinv, double omega) {
+  fh_ctx_t c = A->ctx;
+  int q = 0, grid = A->nblk;
+  if (c->spmv_xcd_remap && A->nblk >= 64) {
+    q = (A->nblk + 7) / 8;
+    grid = 8 * q;
+  }
+#define FH_LAUNCH(MODE) \
+  hipLaunchKernelGGL((k_spmv_lx<TILE, MODE>), dim3(grid), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_lcol, A->d_val, A->d_rowblk, \
+                     A->d_uptr, A->d_ucols, A->nblk, q, x, y, b, dinv, omega)
+  switch (mode) {
+    case 0: FH_LAUNCH(0); break;
+    case 1: FH_LAUNCH(1); break;
+    case 2: FH_LAUNCH(2); break;
+    default: FH_LAUNCH(3); break;
+  }
+#undef FH_LAUNCH
+}
+
+// wave-granular CSR-stream: every wave owns one row block of <= WT non-zeros and runs on its own (no workgroup
+// barrier), so slow gathers of one tile do not hold back its neighbours; NT=1 streams (val, col) with non-temporal
+// loads so the once-read matrix does not evict x from L2.
+template <int WT, int MODE, int NT>
+__global__ __launch_bounds__(256) void k_spmv_wave(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                   const double* __restrict__ val, const int* __restrict__ rowblk, int nblk, int q,
+                                                   const double* __restrict__ x, double* __restrict__ y,
+                                                   const double* __restrict__ b, const double* __restrict__ dinv, double omega) {
+  __shared__ double prod_all[4][WT + 2];
+  __shared__ int rp_all[4][132];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pb = blockIdx.x * 4 + wave;     // physical wave-tile id
+  // XCD-aware: workgroup p runs on XCD p%8; keep consecutive row blocks on one XCD
+  int blk = pb;
+  if (q > 0) {
+    const int wg = blockIdx.x;
+    blk = ((wg & 7) * q + (wg >> 3)) * 4 + wave;
+  }
+  if (blk >= nblk) return;
+  double* prod = prod_all[wave];
+  int* rp = rp_all[wave];
+  const int r0 = rowblk[blk], r1 = rowblk[blk + 1];
+  const int nrows = r1 - r0;
+  // row pointers of the tile -> LDS (also gives s, e)
+  for (int k = lane; k <= nrows; k += 64) rp[k] = rowptr[r0 + k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int s = rp[0], e = rp[nrows];
+  if (nrows == 1 && e - s > WT) {
+    double acc = 0.0;
+    for (int k = s + lane; k < e; k += 64) acc += val[k] * x[col[k]];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) spmv_store<MODE>(acc, r0, x, y, b, dinv, omega);
+    return;
+  }
+  const int s2 = s & ~1;
+  constexpr int ITER = WT / 128 + 1;
+  double2 v[ITER];
+  int2 c[ITER];
+#pragma unroll
+  for (int k = 0; k < ITER; k++) {
+    const int i = s2 + 2 * lane + k * 128;
+    if (i < e) {
+      if (NT) {
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        typedef int i2v __attribute__((ext_vector_type(2)));
+        const d2v vv = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(val + i));
+        const i2v cc = __builtin_nontemporal_load(reinterpret_cast<const i2v*>(col + i));
+        v[k] = make_double2(vv.x, vv.y);
+        c[k] = make_int2(cc.x, cc.y);
+      } else {
+        v[k] = *reinterpret_cast<const double2*>(val + i);
+        c[k] = *reinterpret_cast<const int2*>(col + i);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < ITER; k++) {
+    const int i = s2 + 2 * lane + k * 128;
+    if (i < e) {
+      const double p0 = v[k].x * x[c[k].x];
+      if (i >= s) prod[i - s] = p0;
+      if (i + 1 < e) prod[i + 1 - s] = v[k].y * x[c[k].y];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int G = (nrows <= 4) ? 16 : (nrows <= 8) ? 8 : (nrows <= 16) ? 4 : (nrows <= 32) ? 2 : 1;
+  const int gl = lane & (G - 1);
+  const int rows_per_pass = 64 / G;
+  const int npass = (nrows + rows_per_pass - 1) / rows_per_pass;
+  for (int p = 0; p < npass; p++) {
+    const int rr = p * rows_per_pass + lane / G;
+    const bool live = rr < nrows;
+    double acc = 0.0;
+    if (live) {
+      const int a = rp[rr] - s, z = rp[rr + 1] - s;
+      for (int k = a + gl; k < z; k += G) acc += prod[k];
+    }
+    for (int off = G >> 1; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (live && gl == 0) spmv_store<MODE>(acc, r0 + rr, x, y, b, dinv, omega);
+  }
+}
+
 // classic CSR-vector: LANES lanes per row (kept for A/B measurements and very small matrices)
 template <int LANES, int MODE>
 __global__ __launch_bounds__(256) void k_spmv_vector(const int* __restrict__ rowptr, const int* __restrict__ col,
@@ -502,8 +736,40 @@ int fh_dev_spmv(fh_mat_t A, const double* x, double* y, int mode, const double* 
       default: FH_LAUNCHV(3); break;
     }
 #undef FH_LAUNCHV
+  } else if (c->spmv_kernel == 2) {
+    if (A->tile != c->spmv_tile || A->tile_kernel != 2) FH_TRY(fh_mat_build_rowblocks(A, c->spmv_tile));
+    const int nwg = fh_div_up(A->nblk, 4);
+    int q = 0, grid = nwg;
+    if (c->spmv_xcd_remap && nwg >= 64) {
+      q = (nwg + 7) / 8;
+      grid = 8 * q;
+    }
+    const int nt = c->spmv_nt;
+#define FH_LW(WT, MODE, NT) \
+  hipLaunchKernelGGL((k_spmv_wave<WT, MODE, NT>), dim3(grid), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_val, A->d_rowblk, \
+                     A->nblk, q, x, y, b, dinv, omega)
+#define FH_LW_MODE(WT, NT)                 \
+  switch (mode) {                          \
+    case 0: FH_LW(WT, 0, NT); break;       \
+    case 1: FH_LW(WT, 1, NT); break;       \
+    case 2: FH_LW(WT, 2, NT); break;       \
+    default: FH_LW(WT, 3, NT); break;      \
+  }
+    FH_REQUIRE(A->tile <= 1024, "spmv_kernel 2 needs spmv_tile <= 1024");
+    if (A->tile == 256) { if (nt) { FH_LW_MODE(256, 1) } else { FH_LW_MODE(256, 0) } }
+    else if (A->tile == 512) { if (nt) { FH_LW_MODE(512, 1) } else { FH_LW_MODE(512, 0) } }
+    else { if (nt) { FH_LW_MODE(1024, 1) } else { FH_LW_MODE(1024, 0) } }
+#undef FH_LW_MODE
+#undef FH_LW
+  } else if (c->spmv_kernel == 3) {
+    FH_REQUIRE(c->spmv_tile == 1024 || c->spmv_tile == 2048, "spmv_kernel 3 needs spmv_tile 1024 or 2048");
+    if (A->tile != c->spmv_tile || A->tile_kernel != 3) FH_TRY(fh_mat_build_rowblocks(A, c->spmv_tile));
+    if (A->lx_tile != A->tile) FH_TRY(fh_mat_build_localcols(A));
+    if (A->tile == 1024) launch_lx<1024>(A, mode, x, y, b, dinv, omega);
+    else launch_lx<2048>(A, mode, x, y, b, dinv, omega);
   } else {
-    if (A->tile != c->spmv_tile) FH_TRY(fh_mat_build_rowblocks(A, c->spmv_tile));
+    if (A->tile != c->spmv_tile || A->tile_kernel != 0) FH_TRY(fh_mat_build_rowblocks(A, c->spmv_tile));
+    FH_REQUIRE(A->tile >= 1024, "spmv_kernel 0 needs spmv_tile >= 1024");
     if (A->tile == 1024) launch_stream<1024>(A, mode, x, y, b, dinv, omega);
     else if (A->tile == 2048) launch_stream<2048>(A, mode, x, y, b, dinv, omega);
     else launch_stream<4096>(A, mode, x, y, b, dinv, omega);

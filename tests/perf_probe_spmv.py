@@ -22,21 +22,27 @@ x, y, b, dinv = ctx.vector_from(xs), ctx.vector(n), ctx.vector_from(xs), ctx.vec
 import scipy.sparse as sp
 ref = sp.csr_matrix((val, col, rp), shape=(n, n)) @ xs
 by = A.spmv_algorithmic_bytes()
-for kernel in (0, 1):
-    for tile in ((1024, 2048, 4096) if kernel == 0 else (2048,)):
-        for remap in ((0, 1) if kernel == 0 else (0,)):
-            ctx.set_option("spmv_kernel", kernel); ctx.set_option("spmv_tile", tile); ctx.set_option("spmv_xcd_remap", remap)
-            y.matrix_mult(x, A); ctx.sync()
-            err = np.linalg.norm(y.to_numpy() - ref) / np.linalg.norm(ref)
-            for mode, name in ((0, "y=Ax"), (3, "jacobi")):
-                for _ in range(3):
-                    if mode == 0: y.matrix_mult(x, A)
-                    else: y.jacobi_sweep(b, x, A, dinv, 0.6)
-                ctx.timer_start()
-                reps = 20
-                for _ in range(reps):
-                    if mode == 0: y.matrix_mult(x, A)
-                    else: y.jacobi_sweep(b, x, A, dinv, 0.6)
-                ms_ = ctx.timer_stop() / reps
-                print("kernel=%d tile=%d remap=%d %-7s %.3f ms  %.1f GB/s algorithmic (%.1f%% of 8 TB/s) err=%.1e"
-                      % (kernel, tile, remap, name, ms_, by / ms_ / 1e6, by / ms_ / 1e6 / 80.0, err), flush=True)
+configs = [(0, 2048, 0, 0), (0, 4096, 1, 0), (1, 2048, 0, 0)]
+for tile in (256, 512, 1024):
+    for remap in (0, 1):
+        for nt in (0, 1):
+            configs.append((2, tile, remap, nt))
+if len(sys.argv) > 2:      # e.g. "0,2048,1,0;2,512,0,0"
+    configs = [tuple(int(v) for v in c.split(",")) for c in sys.argv[2].split(";")]
+REPS = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+for kernel, tile, remap, nt in configs:
+    ctx.set_option("spmv_kernel", kernel); ctx.set_option("spmv_tile", tile); ctx.set_option("spmv_xcd_remap", remap); ctx.set_option("spmv_nt", nt)
+    y.matrix_mult(x, A); ctx.sync()
+    err = np.linalg.norm(y.to_numpy() - ref) / np.linalg.norm(ref)
+    for mode, name in ((0, "y=Ax"), (3, "jacobi")):
+        for _ in range(3):
+            if mode == 0: y.matrix_mult(x, A)
+            else: y.jacobi_sweep(b, x, A, dinv, 0.6)
+        ctx.timer_start()
+        reps = REPS
+        for _ in range(reps):
+            if mode == 0: y.matrix_mult(x, A)
+            else: y.jacobi_sweep(b, x, A, dinv, 0.6)
+        ms_ = ctx.timer_stop() / reps
+        print("kernel=%d tile=%d remap=%d nt=%d %-7s %.3f ms  %.1f GB/s algorithmic (%.1f%% of 8 TB/s) err=%.1e"
+              % (kernel, tile, remap, nt, name, ms_, by / ms_ / 1e6, by / ms_ / 1e6 / 80.0, err), flush=True)

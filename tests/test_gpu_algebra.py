@@ -57,8 +57,7 @@ def test_vector_blas1(ctx):
     assert o.to_numpy().tolist() == (2 * np.arange(7.0)).tolist()
 
 
-@pytest.mark.parametrize("tile", [1024, 2048, 4096])
-@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("kernel,tile", [(3, 2048), (3, 1024), (0, 1024), (0, 2048), (0, 4096), (1, 2048), (2, 256), (2, 512), (2, 1024)])
 def test_spmv_family_q2_matrix(ctx, q2_matrix, tile, kernel):
     ms, A, b = q2_matrix
     ctx.set_option("spmv_tile", tile)
@@ -80,12 +79,15 @@ def test_spmv_family_q2_matrix(ctx, q2_matrix, tile, kernel):
         assert rel(y.to_numpy(), xs + 2. / 3. * fo.jacobi_dinv(A) * (b - ref)) < 1e-14
         M.destroy()
     finally:
-        ctx.set_option("spmv_tile", 2048)
-        ctx.set_option("spmv_kernel", 0)
+        ctx.set_option("spmv_tile", 1024)
+        ctx.set_option("spmv_kernel", 3)
 
 
-def test_spmv_ragged_rows_and_long_row(ctx):
+@pytest.mark.parametrize("kernel", [3, 0, 2])
+def test_spmv_ragged_rows_and_long_row(ctx, kernel):
     """empty rows, 1-entry rows, a row longer than the LDS tile, rectangular shape, odd nnz offsets"""
+    ctx.set_option("spmv_kernel", kernel)
+    ctx.set_option("spmv_tile", 1024 if kernel == 2 else 2048)
     rng = np.random.default_rng(5)
     m, n = 777, 5000
     rows, cols, vals = [], [], []
@@ -113,6 +115,8 @@ def test_spmv_ragged_rows_and_long_row(ctx):
     # empty matrix
     E = ctx.matrix_csr(0, 0, [0], [])
     assert E.nnz == 0
+    ctx.set_option("spmv_kernel", 3)
+    ctx.set_option("spmv_tile", 1024)
 
 
 def test_matrix_row_ops(ctx, q2_matrix):
