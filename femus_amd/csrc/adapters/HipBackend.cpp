@@ -1,0 +1,333 @@
+#include "HipBackend.hpp"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+
+namespace femus {
+
+void hip_check(int rc, const char* what) {
+  if (rc != 0) {   // the reference's convention: CHKERRABORT / std::cout << ...; abort();
+    std::cout << "femus_hip error in " << what << ": " << fh_last_error() << std::endl;
+    abort();
+  }
+}
+
+fh_ctx_t hip_context() {
+  static fh_ctx_t ctx = nullptr;
+  if (!ctx) {
+    const char* dev = getenv("FEMUS_HIP_DEVICE");
+    hip_check(fh_init(dev ? atoi(dev) : 0, &ctx), "fh_init");
+  }
+  return ctx;
+}
+
+// ---- factories (NumericVector.cpp:35-56, SparseMatrix.cpp:42-63, LinearEquationSolver.cpp:40-74) ----
+std::unique_ptr<NumericVector> NumericVector::build(const SolverPackage solver_package) {
+  if (solver_package != HIP_SOLVERS) {
+    std::cout << "SolverPackage solver_package:  Something is wrong here" << std::endl;
+    abort();
+  }
+  return std::unique_ptr<NumericVector>(new HipVector());
+}
+std::unique_ptr<SparseMatrix> SparseMatrix::build(const SolverPackage solver_package) {
+  if (solver_package != HIP_SOLVERS) {
+    std::cout << "SolverPackage solver_package:  Something is wrong here" << std::endl;
+    abort();
+  }
+  return std::unique_ptr<SparseMatrix>(new HipMatrix());
+}
+std::unique_ptr<LinearEquationSolver> LinearEquationSolver::build(const unsigned& igrid, const SolverPackage solver_package) {
+  if (solver_package != HIP_SOLVERS) {
+    std::cout << "SolverPackage solver_package:  Something is wrong here" << std::endl;
+    abort();
+  }
+  return std::unique_ptr<LinearEquationSolver>(new LinearEquationSolverHip(igrid));
+}
+
+static const HipVector& hv(const NumericVector& v) { return static_cast<const HipVector&>(v); }   // one backend per process,
+static const HipMatrix& hm(const SparseMatrix& A) { return static_cast<const HipMatrix&>(A); }     // as PetscMatrix.cpp:735-739
+
+// =============================== HipVector ===============================
+void HipVector::clear() {
+  if (_v) fh_vec_destroy(_v);
+  _v = nullptr;
+  _is_initialized = _is_closed = false;
+}
+std::unique_ptr<NumericVector> HipVector::clone() const {
+  HipVector* c = new HipVector();
+  c->init(*this, true);
+  c->operator=(static_cast<const NumericVector&>(*this));
+  return std::unique_ptr<NumericVector>(c);
+}
+void HipVector::init(const int N, const int n_local, const bool, const ParallelType) {
+  clear();
+  hip_check(fh_vec_create(hip_context(), N, n_local, 0, nullptr, 0, &_v), "HipVector::init");
+  _n_global = N;
+  _n_local = n_local;
+  _first = 0;
+  _is_initialized = true;
+}
+void HipVector::init(const int N, const int n_local, const std::vector<int>& ghost, const bool, const ParallelType) {
+  clear();
+  hip_check(fh_vec_create(hip_context(), N, n_local, 0, ghost.data(), (int)ghost.size(), &_v), "HipVector::init(ghosted)");
+  _n_global = N;
+  _n_local = n_local;
+  _first = 0;
+  _is_initialized = true;
+}
+void HipVector::init(const NumericVector& other, const bool) {
+  clear();
+  hip_check(fh_vec_duplicate(hv(other).handle(), &_v), "HipVector::init(other)");
+  fh_vec_size(_v, &_n_global, &_n_local, &_first, nullptr);
+  _is_initialized = true;
+}
+void HipVector::set(const int i, const double value) { hip_check(fh_vec_set_values(_v, 1, &i, &value), "HipVector::set"); _is_closed = false; }
+void HipVector::add(const int i, const double value) { hip_check(fh_vec_add_values(_v, 1, &i, &value), "HipVector::add"); _is_closed = false; }
+void HipVector::zero() { hip_check(fh_vec_zero(_v), "HipVector::zero"); }
+NumericVector& HipVector::operator=(const double s) { hip_check(fh_vec_fill(_v, s), "HipVector::operator=(double)"); return *this; }
+NumericVector& HipVector::operator=(const NumericVector& V) { hip_check(fh_vec_copy(_v, hv(V).handle()), "HipVector::operator=(vector)"); return *this; }
+NumericVector& HipVector::operator=(const std::vector<double>& v) {
+  if ((int)v.size() != _n_local) { std::cout << "HipVector::operator=(std::vector): size mismatch" << std::endl; abort(); }
+  hip_check(fh_vec_upload(_v, v.data()), "HipVector::operator=(std::vector)");
+  return *this;
+}
+double HipVector::min() const { double r; hip_check(fh_vec_reduce(_v, 1, &r), "min"); return r; }
+double HipVector::max() const { double r; hip_check(fh_vec_reduce(_v, 2, &r), "max"); return r; }
+double HipVector::sum() const { double r; hip_check(fh_vec_reduce(_v, 0, &r), "sum"); return r; }
+double HipVector::l1_norm() const { double r; hip_check(fh_vec_norm(_v, 1, &r), "l1_norm"); return r; }
+double HipVector::l2_norm() const { double r; hip_check(fh_vec_norm(_v, 2, &r), "l2_norm"); return r; }
+double HipVector::linfty_norm() const { double r; hip_check(fh_vec_norm(_v, 0, &r), "linfty_norm"); return r; }
+double HipVector::operator()(const int i) const { double r; hip_check(fh_vec_get_values(_v, 1, &i, &r), "operator()"); return r; }
+void HipVector::get(const std::vector<int>& index, std::vector<double>& values) const {
+  values.resize(index.size());
+  hip_check(fh_vec_get_values(_v, (int)index.size(), index.data(), values.data()), "HipVector::get");
+}
+void HipVector::add(const double s) { hip_check(fh_vec_shift(_v, s), "HipVector::add(s)"); }
+void HipVector::add(const double a, const NumericVector& v) { hip_check(fh_vec_axpy(_v, a, hv(v).handle()), "HipVector::add(a,v)"); }
+void HipVector::add_vector_blocked(const std::vector<double>& v, const std::vector<int>& dof) {
+  hip_check(fh_vec_add_values(_v, (int)dof.size(), dof.data(), v.data()), "add_vector_blocked");
+  _is_closed = false;
+}
+void HipVector::add_vector_blocked(const std::vector<double>& v, const std::vector<unsigned>& dof) {
+  std::vector<int> d(dof.begin(), dof.end());
+  add_vector_blocked(v, d);
+}
+void HipVector::insert_vector_blocked(const std::vector<double>& v, const std::vector<int>& dof) {
+  hip_check(fh_vec_set_values(_v, (int)dof.size(), dof.data(), v.data()), "insert_vector_blocked");
+  _is_closed = false;
+}
+void HipVector::add_vector(const NumericVector& v, const SparseMatrix& A) {
+  hip_check(fh_spmv(hm(A).handle(), hv(v).handle(), _v, 1, nullptr, nullptr, 0.), "add_vector(v,A)");
+}
+void HipVector::resid(const NumericVector& rhs, const NumericVector& v, const SparseMatrix& A) {
+  hip_check(fh_spmv(hm(A).handle(), hv(v).handle(), _v, 2, hv(rhs).handle(), nullptr, 0.), "resid");
+}
+void HipVector::matrix_mult(const NumericVector& v, const SparseMatrix& A) {
+  hip_check(fh_spmv(hm(A).handle(), hv(v).handle(), _v, 0, nullptr, nullptr, 0.), "matrix_mult");
+}
+void HipVector::matrix_mult_transpose(const NumericVector& v, const SparseMatrix& A) {
+  hip_check(fh_spmv_transpose(hm(A).handle(), hv(v).handle(), _v), "matrix_mult_transpose");
+}
+void HipVector::scale(const double f) { hip_check(fh_vec_scale(_v, f), "scale"); }
+void HipVector::abs() { hip_check(fh_vec_abs(_v), "abs"); }
+double HipVector::dot(const NumericVector& o) const { double r; hip_check(fh_vec_dot(_v, hv(o).handle(), &r), "dot"); return r; }
+void HipVector::localize(std::vector<double>& out) const {
+  out.resize(_n_local);
+  hip_check(fh_vec_download(_v, out.data()), "localize");
+}
+void HipVector::pointwise_mult(const NumericVector& a, const NumericVector& b) {
+  hip_check(fh_vec_pointwise_mult(_v, hv(a).handle(), hv(b).handle()), "pointwise_mult");
+}
+
+// =============================== HipMatrix ===============================
+void HipMatrix::clear() {
+  if (_A) fh_mat_destroy(_A);
+  _A = nullptr;
+  _stage.clear();
+  _closed = false;
+}
+void HipMatrix::init(const int m, const int n, const int, const int, const std::vector<int>&, const std::vector<int>&) {
+  clear();
+  _m = m;
+  _n = n;
+  _stage.assign(m, std::map<int, double>());   // the nnz counts are upper bounds only; the pattern grows until close()
+}
+void HipMatrix::init_pattern(const int m, const int n, const std::vector<int>& rowptr, const std::vector<int>& col) {
+  clear();
+  _m = m;
+  _n = n;
+  hip_check(fh_mat_create_csr(hip_context(), m, n, rowptr.data(), col.data(), nullptr, &_A), "HipMatrix::init_pattern");
+  _closed = true;
+}
+void HipMatrix::adopt(fh_mat_t h) {
+  clear();
+  _A = h;
+  fh_mat_size(_A, &_m, &_n, nullptr);
+  _closed = true;
+}
+void HipMatrix::close() const {
+  if (_A || _stage.empty()) {
+    _closed = true;
+    return;
+  }
+  std::vector<int> rp(_m + 1, 0), col;
+  std::vector<double> val;
+  for (int i = 0; i < _m; i++) {
+    for (auto& kv : _stage[i]) {
+      col.push_back(kv.first);
+      val.push_back(kv.second);
+    }
+    rp[i + 1] = (int)col.size();
+  }
+  hip_check(fh_mat_create_csr(hip_context(), _m, _n, rp.data(), col.data(), val.data(), &_A), "HipMatrix::close");
+  _stage.clear();
+  _stage.shrink_to_fit();
+  _closed = true;
+}
+void HipMatrix::set(const int i, const int j, const double v) {
+  if (_A) hip_check(fh_mat_insert_row(_A, i, 1, &j, &v), "HipMatrix::set");
+  else _stage[i][j] = v;
+}
+void HipMatrix::add(const int i, const int j, const double v) {
+  if (_A) hip_check(fh_mat_add_block(_A, 1, &i, 1, &j, &v), "HipMatrix::add");
+  else _stage[i][j] += v;
+}
+void HipMatrix::zero() {
+  if (_A) hip_check(fh_mat_zero(_A), "HipMatrix::zero");
+  else for (auto& r : _stage) for (auto& kv : r) kv.second = 0.;
+}
+double HipMatrix::operator()(const int i, const int j) const {
+  close();
+  int nc = 0;
+  hip_check(fh_mat_get_row(_A, i, &nc, nullptr, nullptr), "operator()");
+  std::vector<int> c(nc);
+  std::vector<double> v(nc);
+  hip_check(fh_mat_get_row(_A, i, &nc, c.data(), v.data()), "operator()");
+  auto it = std::lower_bound(c.begin(), c.end(), j);
+  return (it != c.end() && *it == j) ? v[it - c.begin()] : 0.;
+}
+int HipMatrix::MatGetRowM(const int i, int* cols, double* vals) {
+  close();
+  int nc = 0;
+  hip_check(fh_mat_get_row(_A, i, &nc, cols, vals), "MatGetRowM");
+  return nc;
+}
+void HipMatrix::insert_row(const int row, const int ncols, const std::vector<int>& cols, double* values) {
+  if (_A) hip_check(fh_mat_insert_row(_A, row, ncols, cols.data(), values), "insert_row");
+  else for (int k = 0; k < ncols; k++) _stage[row][cols[k]] = values[k];
+}
+void HipMatrix::add_matrix_blocked(const std::vector<double>& mat, const std::vector<int>& rows, const std::vector<int>& cols) {
+  if (_A) {
+    hip_check(fh_mat_add_block(_A, (int)rows.size(), rows.data(), (int)cols.size(), cols.data(), mat.data()), "add_matrix_blocked");
+  } else {
+    for (size_t i = 0; i < rows.size(); i++)
+      for (size_t j = 0; j < cols.size(); j++) _stage[rows[i]][cols[j]] += mat[i * cols.size() + j];
+  }
+}
+void HipMatrix::add_matrix_blocked(const std::vector<double>& mat, const std::vector<unsigned>& rows, const std::vector<unsigned>& cols) {
+  std::vector<int> r(rows.begin(), rows.end()), c(cols.begin(), cols.end());
+  add_matrix_blocked(mat, r, c);
+}
+void HipMatrix::matrix_PtAP(const SparseMatrix& P, const SparseMatrix& A, const bool& reuse) {
+  fh_mat_t out = (reuse && _A) ? _A : nullptr;
+  if (!reuse) clear();
+  hip_check(fh_mat_ptap(hm(P).handle(), hm(A).handle(), &out), "matrix_PtAP");
+  _A = out;
+  fh_mat_size(_A, &_m, &_n, nullptr);
+  _closed = true;
+}
+void HipMatrix::matrix_get_diagonal_values(const std::vector<int>& index, std::vector<double>& value) const {
+  value.resize(index.size());
+  for (size_t k = 0; k < index.size(); k++) value[k] = (*this)(index[k], index[k]);
+}
+double HipMatrix::l1_norm() const { close(); double r; hip_check(fh_mat_norm(_A, 1, &r), "l1_norm"); return r; }
+double HipMatrix::linfty_norm() const { close(); double r; hip_check(fh_mat_norm(_A, 0, &r), "linfty_norm"); return r; }
+void HipMatrix::get_diagonal(NumericVector& dest) const { close(); hip_check(fh_mat_get_diagonal(_A, hv(dest).handle()), "get_diagonal"); }
+void HipMatrix::get_transpose(SparseMatrix& dest) const {
+  close();
+  fh_mat_t t = nullptr;
+  hip_check(fh_mat_transpose(_A, &t), "get_transpose");
+  static_cast<HipMatrix&>(dest).adopt(t);    // also valid for dest == *this (PetscMatrix.cpp:1051-1053)
+}
+void HipMatrix::mat_zero_rows(const std::vector<int>& index, const double& diag) const {
+  close();
+  hip_check(fh_mat_zero_rows(_A, (int)index.size(), index.data(), diag), "mat_zero_rows");
+}
+
+// =============================== LinearEquationSolverHip ===============================
+LinearEquationSolverHip::~LinearEquationSolverHip() {
+  MGClear();
+  delete _KK;
+  delete _RES;
+  delete _RESC;
+  delete _EPS;
+  delete _EPSC;
+}
+void LinearEquationSolverHip::SetTolerances(const double& rtol, const double& atol, const double& divtol, const unsigned& maxits,
+                                            const unsigned& restart) {
+  _rtol = rtol;
+  _abstol = atol;
+  _dtol = divtol;
+  _maxits = (int)maxits;
+  _restart = (int)restart;
+}
+void LinearEquationSolverHip::MGInit(const MgSmootherType& mg_smoother_type, const unsigned& levelMax, const SolverType& mgSolverType) {
+  if (mg_smoother_type != MULTIPLICATIVE) {
+    std::cout << "Wrong mg_type for the HIP backend (only MULTIPLICATIVE is implemented)" << std::endl;
+    abort();
+  }
+  MGClear();
+  _levelMax = levelMax;
+  _mgSolverType = mgSolverType;
+  hip_check(fh_mg_create(hip_context(), (int)levelMax, &_mg), "MGInit");
+  _needs_setup = true;
+}
+void LinearEquationSolverHip::SetPenalty() {
+  static_cast<HipMatrix*>(_KK)->mat_zero_rows(_bdcIndex, 1.);
+}
+void LinearEquationSolverHip::ZerosBoundaryResiduals() {
+  if (_bdcIndex.empty()) return;
+  std::vector<double> zeros(_bdcIndex.size(), 0.);
+  _RES->insert_vector_blocked(zeros, _bdcIndex);
+}
+void LinearEquationSolverHip::MGSetLevel(LinearEquationSolver* LinSolver, const unsigned&, const std::vector<unsigned>&, SparseMatrix* PP,
+                                         SparseMatrix* RR, const unsigned& npre, const unsigned& npost) {
+  LinearEquationSolverHip* top = static_cast<LinearEquationSolverHip*>(LinSolver);
+  SetPenalty();
+  if (_level != 0 && _solver_type == PREONLY) {   // LinearEquationSolverPetsc.cpp:245-248
+    _solver_type = RICHARDSON;
+    _richardsonScaleFactor = 1.;
+  }
+  if (_level != 0 && _preconditioner_type != JACOBI_PRECOND) {
+    std::cout << "HIP backend: level smoother must be RICHARDSON + JACOBI_PRECOND" << std::endl;
+    abort();
+  }
+  fh_mat_t P = PP ? static_cast<HipMatrix*>(PP)->handle() : nullptr;
+  fh_mat_t R = (RR && RR != PP) ? static_cast<HipMatrix*>(RR)->handle() : nullptr;   // RR == PP means "use PP^T"
+  hip_check(fh_mg_set_level(top->_mg, (int)_level, static_cast<HipMatrix*>(_KK)->handle(), _level ? P : nullptr, _level ? R : nullptr,
+                            FH_SMOOTH_JACOBI, _richardsonScaleFactor, (int)npre, (int)npost),
+            "MGSetLevel");
+  top->_needs_setup = true;
+}
+void LinearEquationSolverHip::MGSolve(const bool) {
+  if (_needs_setup) {
+    hip_check(fh_mg_setup(_mg), "MGSolve: setup");
+    _needs_setup = false;
+  }
+  ZerosBoundaryResiduals();
+  const int outer = (_mgSolverType == PREONLY) ? FH_OUTER_PREONLY : (_mgSolverType == RICHARDSON) ? FH_OUTER_RICHARDSON
+                    : (_mgSolverType == CG) ? FH_OUTER_CG : FH_OUTER_GMRES;
+  hip_check(fh_mg_solve(_mg, static_cast<HipVector*>(_RES)->handle(), static_cast<HipVector*>(_EPSC)->handle(), outer, _rtol, _abstol, _dtol,
+                        _maxits, _restart, &_its, &_rnorm),
+            "MGSolve");
+  _RESC->matrix_mult(*_EPSC, *_KK);   // LinearEquationSolverPetsc.cpp:333-335
+  *_RES -= *_RESC;
+  *_EPS += *_EPSC;
+}
+void LinearEquationSolverHip::MGClear() {
+  if (_mg) fh_mg_destroy(_mg);
+  _mg = nullptr;
+}
+
+}  // namespace femus

@@ -1,0 +1,129 @@
+// Adapter test written the way a FEMuS application drives the algebra layer (applications/001_Poisson/main.cpp:283-609 for
+// the assembly callback, LinearImplicitSystem::MGsolve / Vcycle, LinearImplicitSystem.cpp:288-411, 468-497 for the solver):
+// everything goes through the abstract SparseMatrix / NumericVector / LinearEquationSolver interface and the factories.
+// Mesh, DOF maps and Dirichlet flags (FEMuS-owned in a real build) come from the C-ABI mesh helpers.
+//   usage: poisson_adapters nx ny nz nlevels out.bin
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <vector>
+#include "../../femus_amd/csrc/adapters/HipBackend.hpp"
+
+using namespace femus;
+
+int main(int argc, char** argv) {
+  if (argc < 6) return 2;
+  const int nx = atoi(argv[1]), ny = atoi(argv[2]), nz = atoi(argv[3]), nlev = atoi(argv[4]);
+  const int fe = 2, geom = nz ? 0 : 1;
+  const double lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1};
+  std::vector<fh_mesh_t> msh(nlev);
+  hip_check(fh_mesh_box(nx, ny, nz, lo, hi, &msh[0]), "mesh");
+  for (int l = 1; l < nlev; l++) hip_check(fh_mesh_refine(msh[l - 1], &msh[l]), "refine");
+
+  // ---- LinearImplicitSystem::init: one LinearEquationSolver per level, vectors, prolongators -----------------
+  std::vector<LinearEquationSolver*> LinSolver(nlev);
+  std::vector<SparseMatrix*> PP(nlev, nullptr);
+  std::vector<int> ndof(nlev);
+  for (int l = 0; l < nlev; l++) {
+    int dim, nel, nnode, nloc, own[3], lev;
+    fh_mesh_info(msh[l], &dim, &nel, &nnode, &nloc, own, &lev);
+    ndof[l] = nnode;
+    LinSolver[l] = LinearEquationSolver::build(l).release();
+    LinearEquationSolver* ls = LinSolver[l];
+    for (NumericVector** v : {&ls->_RES, &ls->_RESC, &ls->_EPS, &ls->_EPSC}) {
+      *v = NumericVector::build().release();
+      (*v)->init(nnode, nnode, false, SERIAL);
+    }
+    ls->_KK = SparseMatrix::build().release();
+    if (l == nlev - 1) {
+      std::vector<int> d_nnz(nnode, 125), o_nnz(nnode, 0);     // GetSparsityPatternSize upper bounds
+      ls->_KK->init(nnode, nnode, nnode, nnode, d_nnz, o_nnz);
+    }
+    int nb = nnode;
+    std::vector<int> bdc(nnode);
+    hip_check(fh_mesh_dirichlet_dofs(msh[l], fe, &nb, bdc.data()), "bdc");
+    bdc.resize(nb);
+    ls->SetBdcIndex(bdc);
+    ls->SetSolverType(RICHARDSON);
+    ls->SetPreconditionerType(JACOBI_PRECOND);
+    ls->SetRichardsonScaleFactor(2. / 3.);
+    if (l > 0) {
+      fh_mat_t P;
+      hip_check(fh_build_prolongator(hip_context(), msh[l - 1], msh[l], fe, 1, &P), "BuildProlongatorMatrix");
+      HipMatrix* hp = new HipMatrix();
+      hp->adopt(P);
+      PP[l] = hp;
+    }
+  }
+
+  // ---- the assembly callback on the finest level: per-element add_*_blocked through the virtual interface ------
+  const int top = nlev - 1;
+  int dim, nel, nnode, nloc, own[3], lev;
+  fh_mesh_info(msh[top], &dim, &nel, &nnode, &nloc, own, &lev);
+  std::vector<int> elem_dof((size_t)nel * nloc), ff((size_t)nel * 2 * dim);
+  std::vector<double> coords((size_t)nnode * dim);
+  fh_mesh_get(msh[top], elem_dof.data(), coords.data(), ff.data());
+  const int nc = nloc;
+  std::vector<double> Kall((size_t)nel * nc * nc), Fall((size_t)nel * nc);
+  {
+    // element integrals: the batched device kernel in "element matrices" mode (the reference computes them on the host)
+    std::vector<int> rp(nnode + 1), col;
+    hip_check(fh_pattern_from_elements(nel, nloc, elem_dof.data(), nnode, rp.data(), nullptr), "pattern");
+    col.resize(rp[nnode]);
+    hip_check(fh_pattern_from_elements(nel, nloc, elem_dof.data(), nnode, rp.data(), col.data()), "pattern");
+    fh_mat_t tmp;
+    hip_check(fh_mat_create_csr(hip_context(), nnode, nnode, rp.data(), col.data(), nullptr, &tmp), "tmp");
+    fh_assembler_t as;
+    hip_check(fh_assembler_create(hip_context(), geom, fe, 3, nel, nloc, elem_dof.data(), nnode, coords.data(), tmp, &as), "assembler");
+    const double params[4] = {1.0, 0, 0, 0};
+    hip_check(fh_element_matrices_poisson(as, nullptr, 0, params, Kall.data(), Fall.data()), "element matrices");
+    fh_assembler_destroy(as);
+    fh_mat_destroy(tmp);
+  }
+  SparseMatrix* KK = LinSolver[top]->_KK;
+  NumericVector* RES = LinSolver[top]->_RES;
+  KK->zero();
+  RES->zero();
+  std::vector<double> Jac(nc * nc), Res(nc);
+  std::vector<int> l2GMap(nc);
+  for (int iel = 0; iel < nel; iel++) {
+    for (int i = 0; i < nc; i++) l2GMap[i] = elem_dof[(size_t)iel * nloc + i];
+    Jac.assign(Kall.begin() + (size_t)iel * nc * nc, Kall.begin() + (size_t)(iel + 1) * nc * nc);
+    Res.assign(Fall.begin() + (size_t)iel * nc, Fall.begin() + (size_t)(iel + 1) * nc);
+    RES->add_vector_blocked(Res, l2GMap);
+    KK->add_matrix_blocked(Jac, l2GMap, l2GMap);
+  }
+  RES->close();
+  KK->close();
+
+  // ---- MGsolve: Galerkin chain, MGInit, MGSetLevel, Vcycle --------------------------------------------------------
+  for (int i = top; i > 0; i--) LinSolver[i - 1]->_KK->matrix_PtAP(*PP[i], *LinSolver[i]->_KK, false);
+  LinSolver[top]->MGInit(MULTIPLICATIVE, nlev, GMRES);
+  LinSolver[top]->SetTolerances(1e-12, 1e-50, 1e50, 40, 30);
+  std::vector<unsigned> vars(1, 0);
+  for (int i = 0; i < nlev; i++) LinSolver[i]->MGSetLevel(LinSolver[top], top, vars, PP[i], PP[i], i ? 2 : 1, i ? 2 : 0);
+  LinSolver[top]->SetEpsZero();
+  double res = 0;
+  int it = 0;
+  for (; it < 6; it++) {
+    LinSolver[top]->MGSolve(it == 0);
+    res = LinSolver[top]->_RES->l2_norm();
+    std::cout << "       *************** Linear iteration " << it + 1 << "  Linear Res  L2norm u = " << res << std::endl;
+    if (res < 1e-11) break;
+  }
+  std::vector<double> sol;
+  LinSolver[top]->_EPS->localize(sol);
+  std::cout << "||u||_2 = " << LinSolver[top]->_EPS->l2_norm() << "  max = " << LinSolver[top]->_EPS->max() << "  KK(0,0) = " << (*KK)(0, 0)
+            << std::endl;
+  FILE* f = fopen(argv[5], "wb");
+  fwrite(sol.data(), sizeof(double), sol.size(), f);
+  fclose(f);
+  LinSolver[top]->MGClear();
+  for (int l = 0; l < nlev; l++) {
+    delete LinSolver[l];
+    delete PP[l];
+    fh_mesh_destroy(msh[l]);
+  }
+  return 0;
+}
