@@ -177,7 +177,7 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": sweep_bytes / sweep_ms / 1e6 / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": measured_traffic(),
             "algorithmic_bytes_per_launch": sweep_bytes,
             "avg_launch_ms": sweep_ms,
             "plain_spmv_ms": spmv_ms,
@@ -204,6 +204,15 @@ def main():
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def measured_traffic():
+    """HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/README.md); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_spmv_traffic.json")) as f:
+            return json.load(f)["traffic_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(pb, ndof, nel):
