@@ -42,49 +42,47 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import numpy as np
     import femus_amd
+    from femus_amd import dd
     from femus_amd.poisson import PoissonMG
 
+    # setup-time rendezvous (plans, ncclUniqueId, timing maxima) over plain TCP; the data path of a cycle is RCCL
+    comm = dd.SocketComm(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")))
     ctx = femus_amd.Context(local_rank)
     t0 = time.time()
-    pb = PoissonMG(ctx, args.coarse, args.coarse, args.coarse, args.levels, fe="biquadratic", order="seventh",
-                   omega=2. / 3., npre=2, npost=2, coarse="galerkin", source_kind=0, params=(1.0,)).init()
+    parallelism = "1 rank per GPU"
+    dist_err = None
+    pb = None
+    if world > 1 and os.environ.get("FEMUS_BENCH_DD", "1") != "0":
+        try:
+            pb = dd.DistributedPoisson(ctx, comm, world, rank, nb=args.coarse, nlevels=args.levels, omega=2. / 3., npre=2, npost=2)
+            parallelism = ("mesh domain decomposition, box split %dx%dx%d (METIS unavailable), one partition per GPU, ghost DOFs "
+                           "exchanged by RCCL neighbour send/recv (fh_halo_update), replicated coarse level" % dd.GRIDS[world])
+        except Exception as e:   # report, never hide: the line says what actually ran
+            dist_err = "%s: %s" % (type(e).__name__, str(e)[:200])
+            pb = None
+    ok = comm.allgather_obj(pb is not None or world == 1)
+    if world > 1 and not all(ok):
+        pb = None
+    if pb is None:
+        pb = SerialProblem(ctx, PoissonMG, args)
+        if world > 1:
+            parallelism = "%d independent single-GPU problems (no halo exchange)%s" % (world, "" if dist_err is None else "; distributed setup failed: " + dist_err)
     setup_s = time.time() - t0
-    ndof = pb.ndof[-1]
-    nel = pb.meshes[-1].nel
-    A = None
+    ndof = pb.ndof_owned
+    nel = pb.nel_local
+    A = pb.A[-1]
 
     def barrier():
         ctx.sync()
-        if dist is not None:
-            dist.barrier()
+        comm.barrier()
         ctx.sync()
 
-    # hierarchy preparation (outside the timed steps; timed on its own)
-    pb.assemble()
-    ctx.sync()
-    t0 = time.time()
-    pb.prepare()
-    ctx.sync()
-    prepare_first_s = time.time() - t0          # includes the one-time symbolic PtAP
-    pb.assemble()
-    ctx.sync()
-    t0 = time.time()
-    pb.prepare()                                 # numeric-only re-preparation
-    ctx.sync()
-    prepare_ms = (time.time() - t0) * 1e3
-    A = pb.A[-1]
-
     def step():
-        pb.assemble()                            # zero + element loop (all colours)
+        pb.assemble()                            # KK->zero, RES->zero, batched element loop (all colours)
+        pb.set_penalty_top()                     # MGSetLevel: SetPenalty on the assembled operator
         pb.zero_boundary_residuals()             # ZerosBoundaryResiduals
         pb.vcycle()                              # one V(2,2) cycle on RES -> EPSC
 
@@ -95,33 +93,33 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = comm.allreduce_max(time.perf_counter() - t0)
     ms_per_step = elapsed / args.steps * 1e3
-    value = ndof * world * args.steps / elapsed
+    ndof_total = int(sum(comm.allgather_obj(int(ndof))))
+    value = ndof_total * args.steps / elapsed
 
     # ---- sub-phase timings with HIP events on the library's compute stream --------------------------------------
     reps = max(3, args.steps)
+    barrier()
     ctx.timer_start()
     for _ in range(reps):
         pb.assemble()
-    asm_ms = ctx.timer_stop() / reps
+    asm_ms = comm.allreduce_max(ctx.timer_stop() / reps)
+    pb.set_penalty_top()
     pb.zero_boundary_residuals()
+    barrier()
     ctx.timer_start()
     for _ in range(reps):
         pb.vcycle()
-    cyc_ms = ctx.timer_stop() / reps
+    cyc_ms = comm.allreduce_max(ctx.timer_stop() / reps)
     # dominant V-cycle kernel: fine-level fused Jacobi sweep (same kernel family as y=Ax / residual)
-    n = ndof
-    x, y = ctx.vector(n), ctx.vector(n)
+    n, ncols = A.m(), A.n()
+    ghost_ids = np.arange(n, ncols, dtype=np.int32)
+    x, y, dinv = ctx.vector(ncols, n, 0, ghost_ids), ctx.vector(ncols, n, 0, ghost_ids), ctx.vector(n)
     x.upload(np.random.default_rng(12345).uniform(-1, 1, n))
-    dinv = ctx.vector(n)
     A.get_diagonal(dinv)
-    dinv.upload(1.0 / np.where(dinv.to_numpy() == 0, 1.0, dinv.to_numpy()))
+    d = dinv.to_numpy()
+    dinv.upload(1.0 / np.where(d == 0, 1.0, d))
     kr = args.kernel_reps
     for _ in range(5):
         y.jacobi_sweep(pb.RES, x, A, dinv, 2. / 3.)
@@ -136,7 +134,7 @@ def main():
     spmv_bytes = A.spmv_algorithmic_bytes()
     sweep_bytes = spmv_bytes + 3 * 8 * n       # + b, dinv, x(own row) per SURVEY 8(d) Jacobi-sweep model
     cyc_bytes = pb.mg.cycle_algorithmic_bytes()
-    ai = pb.asm[-1].info()
+    ai = pb.asm_top.info()
 
     out = {
         "metric": "assembled DOFs/sec + V-cycle SpMV GB/s (% HBM peak), 3D Poisson Q2",
@@ -154,21 +152,23 @@ def main():
         "config": {
             "workload": "3D Poisson Q2 (HEX27, 64-pt Gauss) on %d^3 box per GPU, %d-level GMG V(2,2) Jacobi(2/3), Galerkin coarse "
                         "operators, dense exact coarse solve" % (args.coarse * 2 ** (args.levels - 1), args.levels),
-            "dofs_per_gpu": ndof,
-            "elements_per_gpu": nel,
-            "nnz_fine": A.nnz,
-            "parallelism": "1 rank per GPU" + ("" if world == 1 else "; %d independent 64^3 subdomain problems (halo exchange wired in fh_halo_*, not yet in bench)" % world),
+            "dofs_total": ndof_total,
+            "dofs_this_gpu": ndof,
+            "elements_this_gpu": nel,
+            "nnz_fine_this_gpu": A.nnz,
+            "parallelism": parallelism,
         },
-        "assembled_dofs_per_sec": ndof * world / (asm_ms * 1e-3),
+        "assembled_dofs_per_sec": ndof_total / (asm_ms * 1e-3),
         "assembly_ms": asm_ms,
         "vcycle_ms": cyc_ms,
-        "vcycles_per_sec": world / (cyc_ms * 1e-3),
+        "vcycles_per_sec": (world if "independent" in parallelism else 1.0) / (cyc_ms * 1e-3),
+        "vcycle_dofs_per_sec": ndof_total / (cyc_ms * 1e-3),
         "vcycle_GBps": cyc_bytes / cyc_ms / 1e6,
         "vcycle_pct_hbm_peak": cyc_bytes / cyc_ms / 1e6 / HBM_PEAK_GBPS * 100.0,
         "vcycle_spmv_GBps": spmv_bytes / spmv_ms / 1e6,
         "vcycle_spmv_pct_hbm_peak": spmv_bytes / spmv_ms / 1e6 / HBM_PEAK_GBPS * 100.0,
-        "prepare_ms": prepare_ms,
-        "prepare_first_s": prepare_first_s,
+        "prepare_ms": pb.prepare_ms,
+        "prepare_first_s": pb.prepare_first_s,
         "setup_s": setup_s,
         "roofline": {
             "kernel": "k_spmv_lx<1024,3> (fine-level fused Jacobi sweep x+w*Dinv*(b-Ax), LDS-staged x)",
@@ -177,13 +177,13 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": sweep_bytes / sweep_ms / 1e6 / HBM_PEAK_GBPS,
-            "traffic": measured_traffic(),
+            "traffic": measured_traffic() if world == 1 else None,
             "algorithmic_bytes_per_launch": sweep_bytes,
             "avg_launch_ms": sweep_ms,
             "plain_spmv_ms": spmv_ms,
         },
         "roofline_assembly": {
-            "kernel": "k_assemble_poisson<3,27,0,0> (8 colours)",
+            "kernel": "k_assemble_poisson<3,27,0,0> (%d colours)" % ai["ncolors"],
             "bound": "fp64-valu (also reported against hbm)",
             "achieved_tflops": ai["flops"] / asm_ms / 1e9,
             "peak_tflops": FP64_VALU_PEAK_TFLOPS,
@@ -196,14 +196,50 @@ def main():
 
     # ---- CPU baseline: the oracle's C restatement on the host cores (rank 0, N = 1 only) ------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(pb, ndof, nel)
+        out["cpu_baseline"] = cpu_baseline(pb.pb, ndof, nel)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    pb.destroy()
-    ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
+
+
+class SerialProblem:
+    """N = 1 (or N independent problems): PoissonMG with the hierarchy prepared once before the timed steps"""
+
+    def __init__(self, ctx, PoissonMG, args):
+        self.ctx = ctx
+        pb = PoissonMG(ctx, args.coarse, args.coarse, args.coarse, args.levels, fe="biquadratic", order="seventh",
+                       omega=2. / 3., npre=2, npost=2, coarse="galerkin", source_kind=0, params=(1.0,)).init()
+        pb.assemble()
+        ctx.sync()
+        t0 = time.time()
+        pb.prepare()
+        ctx.sync()
+        self.prepare_first_s = time.time() - t0          # includes the one-time symbolic PtAP
+        pb.assemble()
+        ctx.sync()
+        t0 = time.time()
+        pb.prepare()                                     # numeric-only re-preparation
+        ctx.sync()
+        self.prepare_ms = (time.time() - t0) * 1e3
+        self.pb = pb
+        self.A, self.mg, self.RES = pb.A, pb.mg, pb.RES
+        self.ndof_owned, self.nel_local = pb.ndof[-1], pb.meshes[-1].nel
+        self.asm_top = pb.asm[-1]
+        self._bdc = pb.bdc[-1]
+
+    def assemble(self):
+        self.pb.assemble()
+
+    def set_penalty_top(self):
+        self.pb.A[-1].mat_zero_rows(self._bdc, 1.0)
+
+    def zero_boundary_residuals(self):
+        self.pb.zero_boundary_residuals()
+
+    def vcycle(self):
+        self.pb.vcycle()
 
 
 def measured_traffic():

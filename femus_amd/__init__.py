@@ -7,4 +7,4 @@ by tests/ and bench.py; it never falls back to a CPU implementation: importing w
 compute call needs the built library and a HIP device.
 """
 from ._lib import load_library, library_path, LibraryMissing  # noqa: F401
-from .capi import Context, Vec, Mat, Mesh, Assembler, Multigrid, FemusHipError  # noqa: F401
+from .capi import Context, Vec, Mat, Mesh, Assembler, Multigrid, Halo, FemusHipError  # noqa: F401

@@ -99,6 +99,11 @@ def _declare(L):
     sig("fh_mesh_box", c_int, c_int, c_int, c_void_p, c_void_p, P(c_void_p))
     sig("fh_mesh_refine", c_void_p, P(c_void_p))
     sig("fh_mesh_destroy", c_void_p)
+    sig("fh_mesh_clear_boundary_faces", c_void_p, ctypes.c_uint)
+    sig("fh_mesh_set_coords", c_void_p, c_void_p)
+    sig("fh_mg_set_level_distributed", c_void_p, c_int, c_void_p, c_int)
+    sig("fh_halo_sizes", c_void_p, P(c_int), P(c_int))
+    sig("fh_halo_allreduce_vec", c_void_p, c_void_p)
     sig("fh_mesh_info", c_void_p, P(c_int), P(c_int), P(c_int), P(c_int), c_void_p, P(c_int))
     sig("fh_mesh_get", c_void_p, c_void_p, c_void_p, c_void_p)
     sig("fh_mesh_child_elems", c_void_p, c_void_p)

@@ -360,6 +360,14 @@ class Mesh:
         _chk(self.L.fh_mesh_refine(self.h, ctypes.byref(h)))
         return Mesh(self.L, h)
 
+    def clear_boundary_faces(self, mask):
+        _chk(self.L.fh_mesh_clear_boundary_faces(self.h, int(mask)))
+
+    def set_coords(self, coords):
+        c = _f64(coords)
+        assert c.shape == (self.nnode, self.dim)
+        _chk(self.L.fh_mesh_set_coords(self.h, _p(c)))
+
     def destroy(self):
         if self.h:
             self.L.fh_mesh_destroy(self.h)
@@ -441,6 +449,7 @@ class Assembler:
         if elem_dof is None:
             elem_dof, coords, _ = mesh.arrays()
         ed, xy = _i32(elem_dof), _f64(coords)
+        assert ed.min() >= 0 and ed.max() < xy.shape[0]
         geom = "hex" if xy.shape[1] == 3 else "quad"
         self.h = ctypes.c_void_p()
         _chk(self.L.fh_assembler_create(ctx.h, GEOM[geom], FE[fe], GAUSS_ORDER[order], ed.shape[0], ed.shape[1], _p(ed),
@@ -481,6 +490,9 @@ class Multigrid:
         _chk(self.L.fh_mg_set_level(self.h, int(level), A.h, None if P is None else P.h, None if R is None else R.h,
                                     int(smoother), float(omega), int(npre), int(npost)))
 
+    def set_level_distributed(self, level, halo, replicated_below=False):
+        _chk(self.L.fh_mg_set_level_distributed(self.h, int(level), None if halo is None else halo.h, 1 if replicated_below else 0))
+
     def setup(self):
         _chk(self.L.fh_mg_setup(self.h))
 
@@ -499,4 +511,34 @@ class Multigrid:
     def destroy(self):
         if self.h:
             self.L.fh_mg_destroy(self.h)
+            self.h = None
+
+
+class Halo:
+    """neighbour exchange plan over RCCL (VecGhostUpdate / MPIAIJ scatter replacement); one rank per GPU"""
+
+    def __init__(self, ctx, rank, nranks, unique_id, send_counts, send_idx, recv_counts):
+        self.ctx, self.L = ctx, ctx.L
+        sc, si, rc = _i32(send_counts), _i32(send_idx), _i32(recv_counts)
+        self.h = ctypes.c_void_p()
+        uid = ctypes.create_string_buffer(bytes(unique_id), 128)
+        _chk(self.L.fh_halo_create(ctx.h, int(rank), int(nranks), uid, _p(sc), _p(si), _p(rc), ctypes.byref(self.h)))
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        _chk(load_library().fh_halo_unique_id(buf))
+        return buf.raw
+
+    def update(self, v):
+        _chk(self.L.fh_halo_update(self.h, v.h))
+
+    def allreduce_sum(self, vals):
+        a = _f64(np.atleast_1d(vals)).copy()
+        _chk(self.L.fh_halo_allreduce_sum(self.h, _p(a), a.size))
+        return a
+
+    def destroy(self):
+        if self.h:
+            self.L.fh_halo_destroy(self.h)
             self.h = None

@@ -52,6 +52,7 @@ struct AsmParams {
   // scatter targets
   const int* rowptr;
   const int* col;
+  int nrows;               // rows of the target matrix (owned rows on a distributed level); other rows are skipped
   double* val;
   double* res;
   const int* emap;         // may be null -> binary search
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(256) void k_assemble_poisson(AsmParams P) {
     const int i = i0 + a;
     if (i >= NC) continue;
     const int row = s_dof[slot][i];
+    if (row >= P.nrows) continue;     // row owned by another rank
     const int rs = P.rowptr[row], re = P.rowptr[row + 1];
 #pragma unroll
     for (int b = 0; b < TJ; b++) {
@@ -419,6 +421,7 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
   as->nel = nel;
   as->nnode = nnode;
   as->ndof = A->m;
+  FH_REQUIRE(A->n >= 1 && A->m <= A->n, "fh_assembler_create: matrix must be square or owned-rows x local-columns");
   as->ncp = ((as->nc + ((as->nc == 9) ? 2 : 3)) / ((as->nc == 9) ? 3 : 4)) * ((as->nc == 9) ? 3 : 4);
   std::vector<double> w, phi, dphi;
   FH_REQUIRE(fhfe::shape_tables(geom, fe, order, w, phi, dphi) == 0, "fh_assembler_create: unsupported Gauss rule %d", order);
@@ -450,6 +453,7 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
     P.nelems = nel;
     P.rowptr = A->d_rowptr;
     P.col = A->d_col;
+    P.nrows = A->m;
     P.emap_out = as->d_emap;
     P.ng = 0;   // no quadrature needed for the symbolic pass
     FH_TRY(dispatch_assemble(as, P));
@@ -478,7 +482,7 @@ extern "C" int fh_assemble_poisson(fh_assembler_t as, fh_vec_t sol, int source_k
   FH_REQUIRE(as && A && res, "fh_assemble_poisson: null argument");
   FH_REQUIRE(A->m == as->ndof && res->n_local >= as->ndof, "fh_assemble_poisson: size mismatch");
   FH_REQUIRE(source_kind >= 0 && source_kind <= 2, "fh_assemble_poisson: unknown source kind %d", source_kind);
-  FH_REQUIRE(!sol || sol->n_local + sol->nghost >= as->ndof, "fh_assemble_poisson: solution vector too short");
+  FH_REQUIRE(!sol || sol->n_local + sol->nghost >= A->n, "fh_assemble_poisson: solution vector too short (needs owned + ghost entries)");
   // KK->zero(); RES->zero();  (separate.hpp:106-107)
   FH_TRY(fh_mat_zero(A));
   FH_TRY(fh_vec_zero(res));
@@ -489,6 +493,7 @@ extern "C" int fh_assemble_poisson(fh_assembler_t as, fh_vec_t sol, int source_k
   P.p1 = params ? params[1] : 0.0;
   P.rowptr = A->d_rowptr;
   P.col = A->d_col;
+  P.nrows = A->m;
   P.val = A->d_val;
   P.res = res->d;
   P.emap = as->d_emap;

@@ -78,11 +78,38 @@ extern "C" int fh_halo_create(fh_ctx_t ctx, int rank, int nranks, const char id1
   return 0;
 }
 
+extern "C" int fh_halo_sizes(fh_halo_t h, int* nsend, int* nrecv) {
+  if (nsend) *nsend = h->nsend;
+  if (nrecv) *nrecv = h->nrecv;
+  return 0;
+}
+
+int fh_halo_update_ptr(fh_halo_t h, double* vd, int n_owned);
+
 extern "C" int fh_halo_update(fh_halo_t h, fh_vec_t v) {
   FH_REQUIRE(h && v, "fh_halo_update: null argument");
   FH_REQUIRE(v->nghost == h->nrecv, "fh_halo_update: vector has %d ghosts, plan receives %d", v->nghost, h->nrecv);
+  return fh_halo_update_ptr(h, v->d, v->n_local);
+}
+
+extern "C" int fh_halo_allreduce_vec(fh_halo_t h, fh_vec_t v) {
+  FH_REQUIRE(h && v, "fh_halo_allreduce_vec: null argument");
+  if (h->nranks == 1 || v->n_local == 0) return 0;
+  FH_CHECK_NCCL(ncclAllReduce(v->d, v->d, v->n_local, ncclDouble, ncclSum, h->comm, h->ctx->stream));
+  return 0;
+}
+
+int fh_halo_allreduce_ptr(fh_halo_t h, double* d, int n) {
+  if (h->nranks == 1 || n == 0) return 0;
+  FH_CHECK_NCCL(ncclAllReduce(d, d, n, ncclDouble, ncclSum, h->comm, h->ctx->stream));
+  return 0;
+}
+
+int fh_halo_update_ptr(fh_halo_t h, double* vd, int n_owned) {
   if (h->nranks == 1) return 0;
   fh_ctx_t c = h->ctx;
+  struct { double* d; int n_local; } vv = {vd, n_owned};
+  auto* v = &vv;
   if (h->nsend) {
     int nb = std::max(1, std::min(fh_div_up(h->nsend, 256), c->num_cu * 4));
     hipLaunchKernelGGL(k_pack, dim3(nb), dim3(256), 0, c->stream, v->d, h->d_send_idx, h->d_sendbuf, h->nsend);

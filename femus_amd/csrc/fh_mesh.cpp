@@ -228,6 +228,20 @@ extern "C" int fh_mesh_refine(fh_mesh_t mc, fh_mesh_t* out) {
   return 0;
 }
 
+extern "C" int fh_mesh_clear_boundary_faces(fh_mesh_t m, unsigned face_mask) {
+  const int nf = nfaces_of(m->geom);
+  for (int iel = 0; iel < m->nel; iel++)
+    for (int f = 0; f < nf; f++)
+      if ((face_mask >> f) & 1u) m->face_flag[(size_t)iel * nf + f] = -1;
+  return 0;
+}
+
+extern "C" int fh_mesh_set_coords(fh_mesh_t m, const double* coords) {
+  FH_REQUIRE(m && coords, "fh_mesh_set_coords: null argument");
+  memcpy(m->coords.data(), coords, m->coords.size() * sizeof(double));
+  return 0;
+}
+
 extern "C" int fh_mesh_destroy(fh_mesh_t m) {
   delete m;
   return 0;

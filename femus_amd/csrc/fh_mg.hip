@@ -17,6 +17,8 @@
 #include <cmath>
 
 int fh_dev_get_diag(fh_mat_t A, double* d, int invert);
+int fh_halo_update_ptr(fh_halo_t h, double* vd, int n_owned);
+int fh_halo_allreduce_ptr(fh_halo_t h, double* d, int n);
 
 struct MgLevel {
   fh_mat_t A = nullptr, P = nullptr, R = nullptr;
@@ -24,6 +26,10 @@ struct MgLevel {
   int n = 0, smoother = 0, npre = 2, npost = 2;
   double omega = 2.0 / 3.0;
   double *dinv = nullptr, *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;
+  // distributed level: operator = owned rows over [owned | ghost] columns; halo refreshes the ghosts
+  fh_halo_t halo = nullptr;
+  bool replicated_below = false;
+  int ncols = 0;
 };
 
 struct fh_mg_s {
@@ -154,7 +160,7 @@ extern "C" int fh_mg_create(fh_ctx_t ctx, int nlevels, fh_mg_t* out) {
 extern "C" int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh_mat_t R, int smoother, double omega, int npre, int npost) {
   FH_REQUIRE(mg && A, "fh_mg_set_level: null argument");
   FH_REQUIRE(level >= 0 && level < mg->nlevels, "fh_mg_set_level: level %d out of range", level);
-  FH_REQUIRE(A->m == A->n, "fh_mg_set_level: operator must be square");
+  FH_REQUIRE(A->m <= A->n, "fh_mg_set_level: operator must be square (or owned rows x local columns on a distributed level)");
   FH_REQUIRE(level == 0 || P != nullptr, "fh_mg_set_level: level %d needs an interpolation matrix", level);
   FH_REQUIRE(!P || P->m == A->m, "fh_mg_set_level: interpolation has %d rows, operator has %d", P ? P->m : 0, A->m);
   FH_REQUIRE(smoother == FH_SMOOTH_JACOBI, "fh_mg_set_level: only the Richardson+Jacobi smoother is implemented (got %d)", smoother);
@@ -164,10 +170,19 @@ extern "C" int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh
   L.P = P;
   L.R = R;
   L.n = A->m;
+  L.ncols = A->n;
   L.smoother = smoother;
   L.omega = omega;
   L.npre = npre;
   L.npost = npost;
+  mg->setup_done = false;
+  return 0;
+}
+
+extern "C" int fh_mg_set_level_distributed(fh_mg_t mg, int level, fh_halo_t halo, int replicated_below) {
+  FH_REQUIRE(mg && level >= 0 && level < mg->nlevels, "fh_mg_set_level_distributed: bad level");
+  mg->lv[level].halo = halo;
+  mg->lv[level].replicated_below = replicated_below != 0;
   mg->setup_done = false;
   return 0;
 }
@@ -213,9 +228,16 @@ static int run_cycle(fh_mg_t mg);
 extern "C" int fh_mg_setup(fh_mg_t mg) {
   fh_ctx_t c = mg->ctx;
   for (int l = 0; l < mg->nlevels; l++) FH_REQUIRE(mg->lv[l].A, "fh_mg_setup: level %d has not been set", l);
+  bool distributed = false;
+  for (int l = 0; l < mg->nlevels; l++) {
+    MgLevel& L = mg->lv[l];
+    distributed |= (L.halo != nullptr);
+    FH_REQUIRE(L.halo || L.A->m == L.A->n, "fh_mg_setup: level %d is not square and has no halo", l);
+    FH_REQUIRE(!L.halo || L.R || l == 0, "fh_mg_setup: distributed level %d needs an explicit restriction matrix", l);
+  }
   for (int l = 1; l < mg->nlevels; l++)
-    FH_REQUIRE(mg->lv[l].P->n == mg->lv[l - 1].n, "fh_mg_setup: interpolation of level %d has %d columns, level %d has %d rows", l,
-               mg->lv[l].P->n, l - 1, mg->lv[l - 1].n);
+    FH_REQUIRE(mg->lv[l].P->n == mg->lv[l - 1].ncols, "fh_mg_setup: interpolation of level %d has %d columns, level %d has %d local entries", l,
+               mg->lv[l].P->n, l - 1, mg->lv[l - 1].ncols);
   if (mg->gexec) {
     hipGraphExecDestroy(mg->gexec);
     mg->gexec = nullptr;
@@ -228,7 +250,7 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
   for (int l = 0; l < mg->nlevels; l++) {
     MgLevel& L = mg->lv[l];
     free_level_buffers(L);
-    const size_t nb = ((size_t)L.n + 2) * sizeof(double);
+    const size_t nb = ((size_t)L.ncols + 2) * sizeof(double);
     for (double** p : {&L.dinv, &L.x, &L.x2, &L.b, &L.r}) {
       FH_CHECK_HIP(hipMalloc(p, nb));
       FH_CHECK_HIP(hipMemsetAsync(*p, 0, nb, c->stream));
@@ -239,7 +261,7 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
         FH_TRY(fh_mat_transpose(L.P, &L.R));
         L.own_R = true;
       }
-      FH_REQUIRE(L.R->m == mg->lv[l - 1].n && L.R->n == L.n, "fh_mg_setup: restriction of level %d has the wrong shape", l);
+      FH_REQUIRE(L.R->m == mg->lv[l - 1].n && (L.R->n == L.n || L.R->n == L.ncols), "fh_mg_setup: restriction of level %d has the wrong shape", l);
       const int64_t bA = fh_spmv_algorithmic_bytes(L.A), n8 = 8ll * L.n;
       // algorithmic bytes of the cycle on this level (SURVEY 8d model, zero-guess first sweep needs no SpMV):
       if (L.npre > 0) mg->cycle_bytes += 3 * n8 + (int64_t)(L.npre - 1) * (bA + 2 * n8);
@@ -253,7 +275,7 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
   mg->setup_done = true;
   FH_TRY(run_cycle(mg));   // un-captured warm-up: builds lazily created row blocks, validates the launches
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
-  if (c->use_graph) {
+  if (c->use_graph && !distributed) {
     // capture one cycle on the internal buffers and keep it for replay
     FH_CHECK_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     int rc = run_cycle(mg);
@@ -266,23 +288,28 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
 }
 
 // one multiplicative V-cycle on the internal buffers: input lv[top].b, output lv[top].x
+// distributed levels: ghosts of the operand are refreshed before every operator application (MPIAIJ MatMult semantics)
 static int run_cycle(fh_mg_t mg) {
   fh_ctx_t c = mg->ctx;
   const int top = mg->nlevels - 1;
   for (int l = top; l >= 1; l--) {
     MgLevel& L = mg->lv[l];
     if (L.npre == 0) {
-      FH_CHECK_HIP(hipMemsetAsync(L.x, 0, (size_t)L.n * sizeof(double), c->stream));
+      FH_CHECK_HIP(hipMemsetAsync(L.x, 0, (size_t)L.ncols * sizeof(double), c->stream));
     } else {
       // sweep 1 from a zero guess: x = omega D^-1 b ; sweeps 2..npre: fused Jacobi SpMV, ping-pong x <-> x2
       hipLaunchKernelGGL(k_first_sweep, dim3(sgrid(c, L.n)), dim3(256), 0, c->stream, L.x, L.b, L.dinv, L.omega, L.n);
       for (int s = 1; s < L.npre; s++) {
+        if (L.halo) FH_TRY(fh_halo_update_ptr(L.halo, L.x, L.n));
         FH_TRY(fh_dev_spmv(L.A, L.x, L.x2, 3, L.b, L.dinv, L.omega));
         std::swap(L.x, L.x2);
       }
+      if (L.halo) FH_TRY(fh_halo_update_ptr(L.halo, L.x, L.n));
     }
     FH_TRY(fh_dev_spmv(L.A, L.x, L.r, 2, L.b, nullptr, 0.0));                       // r = b - A x
+    if (L.halo && !L.replicated_below) FH_TRY(fh_halo_update_ptr(L.halo, L.r, L.n));   // restriction reads ghost residuals
     FH_TRY(fh_dev_spmv(L.R, L.r, mg->lv[l - 1].b, 0, nullptr, nullptr, 0.0));       // b_{l-1} = R r
+    if (L.halo && L.replicated_below) FH_TRY(fh_halo_allreduce_ptr(L.halo, mg->lv[l - 1].b, mg->lv[l - 1].n));
   }
   {
     MgLevel& L0 = mg->lv[0];
@@ -290,8 +317,11 @@ static int run_cycle(fh_mg_t mg) {
   }
   for (int l = 1; l <= top; l++) {
     MgLevel& L = mg->lv[l];
-    FH_TRY(fh_dev_spmv(L.P, mg->lv[l - 1].x, L.x, 1, nullptr, nullptr, 0.0));       // x += P x_{l-1}
+    MgLevel& Lc = mg->lv[l - 1];
+    if (Lc.halo) FH_TRY(fh_halo_update_ptr(Lc.halo, Lc.x, Lc.n));                    // interpolation reads ghost coarse values
+    FH_TRY(fh_dev_spmv(L.P, Lc.x, L.x, 1, nullptr, nullptr, 0.0));                   // x += P x_{l-1}
     for (int s = 0; s < L.npost; s++) {
+      if (L.halo) FH_TRY(fh_halo_update_ptr(L.halo, L.x, L.n));
       FH_TRY(fh_dev_spmv(L.A, L.x, L.x2, 3, L.b, L.dinv, L.omega));
       std::swap(L.x, L.x2);
     }
@@ -370,8 +400,20 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
   fh_ctx_t c = mg->ctx;
   const int top = mg->nlevels - 1;
   fh_mat_t A = mg->lv[top].A;
-  const int n = A->m;
-  FH_REQUIRE(bv->n_local >= n && xv->n_local >= n, "fh_mg_solve: vectors too short");
+  const int n = A->m;                       // owned rows
+  const int ncols = mg->lv[top].ncols;      // owned + ghosts on a distributed level
+  fh_halo_t HL = mg->lv[top].halo;
+  FH_REQUIRE(bv->n_local >= n && xv->n_local + xv->nghost >= ncols, "fh_mg_solve: vectors too short");
+  // distributed forms of the two global operations (MatMult with ghost refresh, VecDot with all-reduce)
+  auto spmv = [&](double* xin, double* yout, int mode, const double* bb) -> int {
+    if (HL) FH_TRY(fh_halo_update_ptr(HL, xin, n));
+    return fh_dev_spmv(A, xin, yout, mode, bb, nullptr, 0.0);
+  };
+  auto dot = [&](const double* u, const double* w2, double* out) -> int {
+    FH_TRY(dev_dot(c, u, w2, n, out));
+    if (HL) FH_TRY(fh_halo_allreduce_sum(HL, out, 1));
+    return 0;
+  };
   FH_REQUIRE(outer >= 0 && outer <= 3, "fh_mg_solve: unknown outer solver %d", outer);
   double* b = bv->d;
   double* x = xv->d;
@@ -384,15 +426,15 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
     its = 1;
   } else if (outer == FH_OUTER_RICHARDSON) {
     // x <- x + 0.99999 M^-1 (b - A x), x0 = 0 (MGInit: _richardsonScaleFactor = .99999, :190-193)
-    FH_TRY(krylov_reserve(mg, 2, n));
+    FH_TRY(krylov_reserve(mg, 2, ncols));
     double *r = mg->kv[0], *z = mg->kv[1];
     FH_CHECK_HIP(hipMemsetAsync(x, 0, (size_t)n * sizeof(double), c->stream));
     double bn;
-    FH_TRY(dev_dot(c, b, b, n, &bn));
+    FH_TRY(dot(b, b, &bn));
     bn = sqrt(bn);
     for (;;) {
-      FH_TRY(fh_dev_spmv(A, x, r, 2, b, nullptr, 0.0));
-      FH_TRY(dev_dot(c, r, r, n, &rn));
+      FH_TRY(spmv(x, r, 2, b));
+      FH_TRY(dot(r, r, &rn));
       rn = sqrt(rn);
       if (rn <= std::max(rtol * bn, atol) || its >= maxit || rn > dtol * bn) break;
       FH_TRY(apply_cycle(mg, r, z));
@@ -400,35 +442,35 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
       its++;
     }
   } else if (outer == FH_OUTER_CG) {
-    FH_TRY(krylov_reserve(mg, 4, n));
+    FH_TRY(krylov_reserve(mg, 4, ncols));
     double *r = mg->kv[0], *z = mg->kv[1], *p = mg->kv[2], *Ap = mg->kv[3];
     FH_CHECK_HIP(hipMemsetAsync(x, 0, (size_t)n * sizeof(double), c->stream));
     FH_CHECK_HIP(hipMemcpyAsync(r, b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     double bn, rz, rz_new, pAp;
-    FH_TRY(dev_dot(c, b, b, n, &bn));
+    FH_TRY(dot(b, b, &bn));
     bn = sqrt(bn);
     rn = bn;
     FH_TRY(apply_cycle(mg, r, z));
     FH_CHECK_HIP(hipMemcpyAsync(p, z, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    FH_TRY(dev_dot(c, r, z, n, &rz));
+    FH_TRY(dot(r, z, &rz));
     while (rn > std::max(rtol * bn, atol) && its < maxit && rn <= dtol * bn) {
-      FH_TRY(fh_dev_spmv(A, p, Ap, 0, nullptr, nullptr, 0.0));
-      FH_TRY(dev_dot(c, p, Ap, n, &pAp));
+      FH_TRY(spmv(p, Ap, 0, nullptr));
+      FH_TRY(dot(p, Ap, &pAp));
       const double alpha = rz / pAp;
       FH_TRY(dev_axpby(c, x, p, alpha, 1.0, n));
       FH_TRY(dev_axpby(c, r, Ap, -alpha, 1.0, n));
-      FH_TRY(dev_dot(c, r, r, n, &rn));
+      FH_TRY(dot(r, r, &rn));
       rn = sqrt(rn);
       its++;
       FH_TRY(apply_cycle(mg, r, z));
-      FH_TRY(dev_dot(c, r, z, n, &rz_new));
+      FH_TRY(dot(r, z, &rz_new));
       FH_TRY(dev_axpby(c, p, z, 1.0, rz_new / rz, n));
       rz = rz_new;
     }
   } else {
     // left-preconditioned GMRES(restart), classical Gram-Schmidt, Knoll guess x0 = M^-1 b
     FH_REQUIRE(restart >= 1 && restart <= 200, "fh_mg_solve: restart %d out of range", restart);
-    FH_TRY(krylov_reserve(mg, restart + 3, n));
+    FH_TRY(krylov_reserve(mg, restart + 3, ncols));
     double* t = mg->kv[restart + 1];
     double* w = mg->kv[restart + 2];
     const int nb = sgrid(c, n);
@@ -440,14 +482,14 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
     // Knoll: x0 = M^-1 b ; reference norm = ||M^-1 b||
     FH_TRY(apply_cycle(mg, b, x));
     double beta0;
-    FH_TRY(dev_dot(c, x, x, n, &beta0));
+    FH_TRY(dot(x, x, &beta0));
     beta0 = sqrt(beta0);
     bool done = false;
     while (!done) {
-      FH_TRY(fh_dev_spmv(A, x, t, 2, b, nullptr, 0.0));       // t = b - A x
+      FH_TRY(spmv(x, t, 2, b));                                // t = b - A x
       FH_TRY(apply_cycle(mg, t, mg->kv[0]));                  // v0 = M^-1 t
       double beta;
-      FH_TRY(dev_dot(c, mg->kv[0], mg->kv[0], n, &beta));
+      FH_TRY(dot(mg->kv[0], mg->kv[0], &beta));
       beta = sqrt(beta);
       rn = beta;
       if (beta <= std::max(rtol * beta0, atol) || its >= maxit || beta > dtol * beta0) break;
@@ -456,18 +498,19 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
       g[0] = beta;
       int kused = 0;
       for (int k = 0; k < restart; k++) {
-        FH_TRY(fh_dev_spmv(A, mg->kv[k], t, 0, nullptr, nullptr, 0.0));
+        FH_TRY(spmv(mg->kv[k], t, 0, nullptr));
         FH_TRY(apply_cycle(mg, t, w));
         // h = V^T w (one pass), w -= V h, h_{k+1,k} = ||w||
         hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, c->stream, (const double* const*)d_V, w, k + 1, n, c->d_red);
         hipLaunchKernelGGL(k_multidot_final, dim3(k + 1), dim3(256), 0, c->stream, c->d_red, k + 1, nb);
+        if (HL) FH_TRY(fh_halo_allreduce_ptr(HL, c->d_red + (size_t)(k + 1) * nb, k + 1));
         hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, w, (const double* const*)d_V, c->d_red + (size_t)(k + 1) * nb, -1.0,
                            k + 1, n);
         FH_CHECK_HIP(hipMemcpyAsync(c->h_red, c->d_red + (size_t)(k + 1) * nb, (k + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         FH_CHECK_HIP(hipStreamSynchronize(c->stream));
         for (int j = 0; j <= k; j++) H[(size_t)j * restart + k] = c->h_red[j];
         double wn;
-        FH_TRY(dev_dot(c, w, w, n, &wn));
+        FH_TRY(dot(w, w, &wn));
         wn = sqrt(wn);
         H[(size_t)(k + 1) * restart + k] = wn;
         if (wn != 0.0) FH_TRY(dev_axpby(c, mg->kv[k + 1], w, 1.0 / wn, 0.0, n));

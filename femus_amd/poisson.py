@@ -16,16 +16,19 @@ from . import capi
 
 class PoissonMG:
     def __init__(self, ctx, nx, ny, nz, nlevels, fe="biquadratic", order="seventh", lo=(0., 0., 0.), hi=(1., 1., 1.),
-                 omega=2. / 3., npre=2, npost=2, coarse="galerkin", source_kind=0, params=(1.0,)):
+                 omega=2. / 3., npre=2, npost=2, coarse="galerkin", source_kind=0, params=(1.0,), meshes=None):
         self.ctx = ctx
         self.fe, self.order = fe, order
         self.nlevels = nlevels
         self.omega, self.npre, self.npost = omega, npre, npost
         self.coarse = coarse
         self.source_kind, self.params = source_kind, params
-        self.meshes = [capi.Mesh.box(nx, ny, nz, lo, hi)]
-        for _ in range(1, nlevels):
-            self.meshes.append(self.meshes[-1].refine())
+        if meshes is not None:
+            self.meshes = list(meshes)
+        else:
+            self.meshes = [capi.Mesh.box(nx, ny, nz, lo, hi)]
+            for _ in range(1, nlevels):
+                self.meshes.append(self.meshes[-1].refine())
         self.nc = {"linear": 2 ** self.meshes[0].dim, "biquadratic": 3 ** self.meshes[0].dim}[fe]
         self.mg = None
 
@@ -81,6 +84,23 @@ class PoissonMG:
             self.mg.set_level(l, self.A[l], self.P[l], None, 0, self.omega, self.npre if l > 0 else 1, self.npost if l > 0 else 0)
         self.mg.setup()
         return self
+
+    def prepare_operators_only(self):
+        """Galerkin chain + SetPenalty without building the cycle (used by the domain-decomposition setup)"""
+        top = self.nlevels - 1
+        for l in range(top, 0, -1):
+            self.A[l - 1] = capi.Mat.ptap(self.P[l], self.A[l])
+        for l in range(self.nlevels):
+            self.A[l].mat_zero_rows(self.bdc[l], 1.0)
+
+    def destroy_device_objects(self):
+        for a in self.asm:
+            if a is not None:
+                a.destroy()
+        for m in self.A + self.P:
+            if m is not None:
+                m.destroy()
+        self.asm, self.A, self.P = [], [], []
 
     def zero_boundary_residuals(self):
         top = self.nlevels - 1

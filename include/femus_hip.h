@@ -125,6 +125,10 @@ int fh_fe_elem_prolongator(int geom, int fe, int* nchild, int* nc, double* P /* 
 int fh_mesh_box(int nx, int ny, int nz, const double lo[3], const double hi[3], fh_mesh_t* mesh);
 int fh_mesh_refine(fh_mesh_t coarse, fh_mesh_t* fine);
 int fh_mesh_destroy(fh_mesh_t mesh);
+/* domain decomposition: faces of a sub-box that are artificial cuts, not physical boundary (bit f = local face f); call on the
+ * coarse mesh before refining (flags are inherited, MeshRefinement.cpp:271-278) */
+int fh_mesh_clear_boundary_faces(fh_mesh_t mesh, unsigned face_mask);
+int fh_mesh_set_coords(fh_mesh_t mesh, const double* coords /* [nnode*dim], this mesh's numbering */);
 int fh_mesh_info(fh_mesh_t mesh, int* dim, int* nel, int* nnode, int* nloc, int own_size[3], int* level);
 int fh_mesh_get(fh_mesh_t mesh, int* elem_dof /* [nel*nloc] */, double* coords /* [nnode*dim] */, int* face_flag /* [nel*nfaces] */);
 int fh_mesh_child_elems(fh_mesh_t coarse, int* child /* [nel*nchild] */);
@@ -174,6 +178,12 @@ int fh_mg_solve(fh_mg_t mg, fh_vec_t b, fh_vec_t x, int outer, double rtol, doub
                 int* iterations, double* final_residual);
 int fh_mg_destroy(fh_mg_t mg);
 int64_t fh_mg_cycle_algorithmic_bytes(fh_mg_t mg);               /* SURVEY 8(d) V-cycle byte model for these levels */
+/* distributed levels (one mesh partition per GPU): the level's operator holds the OWNED rows only (m = n_owned) over the
+ * local [owned | ghost] column space (n = n_owned + nghost); `halo` refreshes the ghosts before every operator application
+ * (what MatMult does for MPIAIJ).  R must be given explicitly for such levels (owned coarse rows x local fine columns).
+ * replicated_below != 0: the level below is replicated on every rank (its rhs is summed with an all-reduce after the
+ * restriction; the prolongation needs no exchange).  Call before fh_mg_setup. */
+int fh_mg_set_level_distributed(fh_mg_t mg, int level, fh_halo_t halo, int replicated_below);
 
 /* ---- multi-GPU halo (C1/C3/C4 of SURVEY 2.1): VecGhostUpdate (PetscVector.hpp:595-612), VecDot/VecNorm allreduce ----
  * one rank per GPU.  The plan is built from each rank's ghost list; the exchange itself is neighbour
@@ -184,6 +194,8 @@ int fh_halo_create(fh_ctx_t ctx, int rank, int nranks, const char id128[128],
                    const int* send_counts /* [nranks] */, const int* send_idx /* local owned indices, grouped by dest rank */,
                    const int* recv_counts /* [nranks] */, fh_halo_t* halo);
 int fh_halo_update(fh_halo_t halo, fh_vec_t v);                  /* owner -> ghost copies, async on comm stream + join */
+int fh_halo_sizes(fh_halo_t halo, int* nsend, int* nrecv);
+int fh_halo_allreduce_vec(fh_halo_t halo, fh_vec_t v);            /* in-place sum over ranks of the owned part (device) */
 int fh_halo_allreduce_sum(fh_halo_t halo, double* vals, int n);  /* host scalars in/out */
 int fh_halo_destroy(fh_halo_t halo);
 
