@@ -123,6 +123,7 @@ def _declare(L):
     sig("fh_mg_destroy", c_void_p)
     sig("fh_halo_unique_id", c_void_p)
     sig("fh_halo_create", c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, P(c_void_p))
+    sig("fh_halo_create_shared", c_void_p, c_void_p, c_void_p, c_void_p, P(c_void_p))
     sig("fh_halo_update", c_void_p, c_void_p)
     sig("fh_halo_allreduce_sum", c_void_p, c_void_p, c_int)
     sig("fh_halo_destroy", c_void_p)

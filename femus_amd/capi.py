@@ -517,12 +517,15 @@ class Multigrid:
 class Halo:
     """neighbour exchange plan over RCCL (VecGhostUpdate / MPIAIJ scatter replacement); one rank per GPU"""
 
-    def __init__(self, ctx, rank, nranks, unique_id, send_counts, send_idx, recv_counts):
+    def __init__(self, ctx, rank, nranks, unique_id, send_counts, send_idx, recv_counts, parent=None):
         self.ctx, self.L = ctx, ctx.L
         sc, si, rc = _i32(send_counts), _i32(send_idx), _i32(recv_counts)
         self.h = ctypes.c_void_p()
-        uid = ctypes.create_string_buffer(bytes(unique_id), 128)
-        _chk(self.L.fh_halo_create(ctx.h, int(rank), int(nranks), uid, _p(sc), _p(si), _p(rc), ctypes.byref(self.h)))
+        if parent is not None:     # same communicator, another exchange plan
+            _chk(self.L.fh_halo_create_shared(parent.h, _p(sc), _p(si), _p(rc), ctypes.byref(self.h)))
+        else:
+            uid = ctypes.create_string_buffer(bytes(unique_id), 128)
+            _chk(self.L.fh_halo_create(ctx.h, int(rank), int(nranks), uid, _p(sc), _p(si), _p(rc), ctypes.byref(self.h)))
 
     @staticmethod
     def unique_id():

@@ -14,6 +14,7 @@ struct fh_halo_s {
   fh_ctx_t ctx = nullptr;
   int rank = 0, nranks = 1;
   ncclComm_t comm = nullptr;
+  bool owns_comm = false;
   std::vector<int> send_counts, recv_counts, send_off, recv_off;
   int nsend = 0, nrecv = 0;
   int* d_send_idx = nullptr;
@@ -43,8 +44,21 @@ extern "C" int fh_halo_unique_id(char id128[128]) {
   return 0;
 }
 
+static int halo_create(fh_ctx_t ctx, int rank, int nranks, const char* id128, ncclComm_t shared, const int* send_counts, const int* send_idx,
+                       const int* recv_counts, fh_halo_t* out);
+
 extern "C" int fh_halo_create(fh_ctx_t ctx, int rank, int nranks, const char id128[128], const int* send_counts, const int* send_idx,
                               const int* recv_counts, fh_halo_t* out) {
+  return halo_create(ctx, rank, nranks, id128, nullptr, send_counts, send_idx, recv_counts, out);
+}
+
+extern "C" int fh_halo_create_shared(fh_halo_t parent, const int* send_counts, const int* send_idx, const int* recv_counts, fh_halo_t* out) {
+  FH_REQUIRE(parent, "fh_halo_create_shared: null parent");
+  return halo_create(parent->ctx, parent->rank, parent->nranks, nullptr, parent->comm, send_counts, send_idx, recv_counts, out);
+}
+
+static int halo_create(fh_ctx_t ctx, int rank, int nranks, const char* id128, ncclComm_t shared, const int* send_counts, const int* send_idx,
+                       const int* recv_counts, fh_halo_t* out) {
   FH_REQUIRE(ctx && out && send_counts && recv_counts, "fh_halo_create: null argument");
   FH_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "fh_halo_create: bad rank %d of %d", rank, nranks);
   fh_halo_t h = new fh_halo_s();
@@ -70,9 +84,15 @@ extern "C" int fh_halo_create(fh_ctx_t ctx, int rank, int nranks, const char id1
   FH_CHECK_HIP(hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
   FH_CHECK_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
   if (nranks > 1) {
-    ncclUniqueId id;
-    memcpy(&id, id128, 128);
-    FH_CHECK_NCCL(ncclCommInitRank(&h->comm, nranks, id, rank));
+    if (shared) {
+      h->comm = shared;
+    } else {
+      FH_REQUIRE(id128 != nullptr, "fh_halo_create: null ncclUniqueId");
+      ncclUniqueId id;
+      memcpy(&id, id128, 128);
+      FH_CHECK_NCCL(ncclCommInitRank(&h->comm, nranks, id, rank));
+      h->owns_comm = true;
+    }
   }
   *out = h;
   return 0;
@@ -144,7 +164,7 @@ extern "C" int fh_halo_destroy(fh_halo_t h) {
   if (!h) return 0;
   hipStreamSynchronize(h->ctx->stream);
   hipStreamSynchronize(h->ctx->comm_stream);
-  if (h->comm) ncclCommDestroy(h->comm);
+  if (h->comm && h->owns_comm) ncclCommDestroy(h->comm);
   hipFree(h->d_send_idx);
   hipFree(h->d_sendbuf);
   hipFree(h->d_scalars);

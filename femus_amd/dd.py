@@ -471,7 +471,10 @@ class DistributedPoisson:
         full.destroy_device_objects()
         # 5. upload the restricted operators, halos, cycle
         uid = comm.bcast_obj(capi.Halo.unique_id() if rank == 0 else None)
-        self.halos = [capi.Halo(ctx, rank, nranks, uid, pl.send_counts, pl.send_idx, pl.recv_counts) for pl in H.plans]
+        self.halos = []
+        for pl in H.plans:     # one RCCL communicator, one exchange plan per level
+            self.halos.append(capi.Halo(ctx, rank, nranks, uid, pl.send_counts, pl.send_idx, pl.recv_counts,
+                                        parent=self.halos[0] if self.halos else None))
         self.A = [ctx.matrix_scipy(a) for a in H.A]
         self.P = [None] + [ctx.matrix_scipy(p) for p in H.P[1:]]
         self.R = [None] + [ctx.matrix_scipy(r) for r in H.R[1:]]

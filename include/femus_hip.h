@@ -193,6 +193,8 @@ int fh_halo_unique_id(char id128[128]);
 int fh_halo_create(fh_ctx_t ctx, int rank, int nranks, const char id128[128],
                    const int* send_counts /* [nranks] */, const int* send_idx /* local owned indices, grouped by dest rank */,
                    const int* recv_counts /* [nranks] */, fh_halo_t* halo);
+/* further exchange plans (other multigrid levels) on the communicator of an existing one (a ncclUniqueId makes ONE communicator) */
+int fh_halo_create_shared(fh_halo_t parent, const int* send_counts, const int* send_idx, const int* recv_counts, fh_halo_t* halo);
 int fh_halo_update(fh_halo_t halo, fh_vec_t v);                  /* owner -> ghost copies, async on comm stream + join */
 int fh_halo_sizes(fh_halo_t halo, int* nsend, int* nrecv);
 int fh_halo_allreduce_vec(fh_halo_t halo, fh_vec_t v);            /* in-place sum over ranks of the owned part (device) */

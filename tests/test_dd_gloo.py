@@ -100,3 +100,25 @@ def test_distributed_vcycle_matches_serial_oracle(tmp_path, world):
         assert d["n_ghost"] > 0
         seen += d["gid"].size
     assert seen == ref.size                                                              # every global node owned exactly once
+
+
+def _sock_worker(rank, world, port, out):
+    from femus_amd import dd
+    comm = dd.SocketComm(rank, world, "127.0.0.1", port)
+    got = comm.alltoallv([np.full(r + 1, rank * 10 + r, dtype=np.int64) for r in range(world)], np.int64)
+    assert [g.tolist() for g in got] == [[r * 10 + rank] * (rank + 1) for r in range(world)]
+    s = comm.allreduce_sum(np.arange(4.0) * (rank + 1))
+    assert np.array_equal(s, np.arange(4.0) * sum(range(1, world + 1)))
+    assert comm.bcast_obj(b"id" if rank == 0 else None) == b"id"
+    assert comm.allreduce_max(float(rank)) == world - 1
+    comm.barrier()
+    comm.close()
+    open(out % rank, "w").write("ok")
+
+
+def test_socket_rendezvous_three_ranks(tmp_path):
+    """the torch-free rendezvous bench.py uses for setup traffic (plans, ncclUniqueId, timing maxima)"""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "s%d")
+    mp.spawn(_sock_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    assert all(os.path.exists(out % r) for r in range(3))
