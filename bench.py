@@ -55,7 +55,7 @@ def main():
     parallelism = "1 rank per GPU"
     dist_err = None
     pb = None
-    if world > 1 and os.environ.get("FEMUS_BENCH_DD", "1") != "0":
+    if (world > 1 and os.environ.get("FEMUS_BENCH_DD", "1") != "0") or os.environ.get("FEMUS_BENCH_FORCE_DD") == "1":
         try:
             pb = dd.DistributedPoisson(ctx, comm, world, rank, nb=args.coarse, nlevels=args.levels, omega=2. / 3., npre=2, npost=2)
             parallelism = ("mesh domain decomposition, box split %dx%dx%d (METIS unavailable), one partition per GPU, ghost DOFs "

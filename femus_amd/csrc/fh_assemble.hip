@@ -34,6 +34,13 @@ struct fh_assembler_s {
   int* d_emap = nullptr;         // [nel*nc*ncp] CSR slot of (i,j), ncp = nc rounded up to 4
   int* d_iota = nullptr;         // identity element list (for the uncoloured element-matrix entry point)
   int ncp = 28;
+  // two-pass ("row gather") assembly: element matrices -> Kbuf, then every CSR row sums its <= 8 element rows in element order
+  int* d_adj_ptr = nullptr;      // [m+1]
+  int* d_adj_ei = nullptr;       // (element << 5) | local row, ascending element order
+  unsigned char* d_rowmap = nullptr;   // [nadj*nc] slot of (element row, j) inside the CSR row
+  double* d_Kbuf = nullptr;      // [nel*nc*nc]
+  double* d_Fbuf = nullptr;      // [nel*nc]
+  bool two_pass = false;
 };
 
 struct AsmParams {
@@ -57,6 +64,7 @@ struct AsmParams {
   double* res;
   const int* emap;         // may be null -> binary search
   int* emap_out;           // non-null: build the map instead of assembling
+  int debug;               // profiling aid: bit 0 skips the quadrature loop, bit 1 skips the scatter
   double* Kout;            // non-null: write element matrices [e][nc][nc] instead of scattering
   double* Fout;
 };
@@ -78,7 +86,7 @@ struct AsmCfg {
   static constexpr int EPB = EPW * WAVES;                                     // elements per block
   // per-element LDS (doubles): gradients of the chunk, weights, grad u, f, coordinates, solution
   static constexpr int GS = GC * DIM * NCP;
-  static constexpr int LDS_RAW = GS + GC + GC * DIM + GC + NC * DIM + NC;
+  static constexpr int LDS_RAW = GS + GC + GC * NCP + NC * DIM + NC;
   static constexpr int LDS_PER_ELEM = (LDS_RAW + 1) / 2 * 2;                  // keep every element slab 16-byte aligned
 };
 
@@ -111,9 +119,8 @@ __global__ __launch_bounds__(256) void k_assemble_poisson(AsmParams P) {
   double* base = smem + (size_t)slot * C::LDS_PER_ELEM;
   double* gs = base;                       // [GC][DIM][NCP]
   double* ws = gs + C::GS;                 // [GC]
-  double* gus = ws + GC;                   // [GC][DIM]
-  double* fs = gus + GC * DIM;             // [GC]
-  double* xe = fs + GC;                    // [NC][DIM]
+  double* rs = ws + GC;                    // [GC][NCP] residual integrand per (Gauss point, node)
+  double* xe = rs + GC * NCP;              // [NC][DIM]
   double* ue = xe + NC * DIM;              // [NC]
 
   // ---- gather: dof ids, coordinates, solution (a8, a9: GetSolutionDof / GetSystemDof, nprocs = 1) ----------
@@ -123,12 +130,14 @@ __global__ __launch_bounds__(256) void k_assemble_poisson(AsmParams P) {
     for (int d = 0; d < DIM; d++) xe[n * DIM + d] = P.coords[(size_t)dof * DIM + d];
     ue[n] = P.sol ? P.sol[dof] : 0.0;
   }
-  // zero the padding columns of gs once
-  if (NCP > NC)
+  // zero the padding columns of gs / rs once
+  if (NCP > NC) {
     for (int k = l; k < GC * DIM * (NCP - NC); k += LPE) {
       const int row = k / (NCP - NC), c = NC + k % (NCP - NC);
       gs[row * NCP + c] = 0.0;
     }
+    for (int k = l; k < GC * (NCP - NC); k += LPE) rs[(k / (NCP - NC)) * NCP + NC + k % (NCP - NC)] = 0.0;
+  }
   __syncthreads();
 
   // tile owned by this lane in phase 2
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(256) void k_assemble_poisson(AsmParams P) {
 
   const int q = l / NSPLIT, part = l % NSPLIT;
   const int n0 = part * NPP;
-  const int nchunk = (P.ng + GC - 1) / GC;
+  const int nchunk = (P.debug & 1) ? 0 : (P.ng + GC - 1) / GC;
 #pragma unroll 1
   for (int ch = 0; ch < nchunk; ch++) {
     // ---------------- phase 1: geometry at Gauss point g = ch*GC + q -------------------------------
@@ -183,36 +192,40 @@ __global__ __launch_bounds__(256) void k_assemble_poisson(AsmParams P) {
 #pragma unroll
             for (int b = 0; b < DIM; b++) J[a][b] += __shfl_xor(J[a][b], off, 64);
       }
+      // adjugate / det as in the reference, with ONE reciprocal (9 fp64 divisions are ~350 instructions per Gauss point)
       double det, JI[DIM][DIM];
       if constexpr (DIM == 2) {
         det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-        JI[0][0] = J[1][1] / det;
-        JI[0][1] = -J[0][1] / det;
-        JI[1][0] = -J[1][0] / det;
-        JI[1][1] = J[0][0] / det;
+        const double rd = 1.0 / det;
+        JI[0][0] = J[1][1] * rd;
+        JI[0][1] = -J[0][1] * rd;
+        JI[1][0] = -J[1][0] * rd;
+        JI[1][1] = J[0][0] * rd;
       } else {
         det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[1][2] * J[2][0] - J[1][0] * J[2][2]) +
               J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
-        JI[0][0] = (-J[1][2] * J[2][1] + J[1][1] * J[2][2]) / det;
-        JI[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
-        JI[0][2] = (-J[0][2] * J[1][1] + J[0][1] * J[1][2]) / det;
-        JI[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) / det;
-        JI[1][1] = (-J[0][2] * J[2][0] + J[0][0] * J[2][2]) / det;
-        JI[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
-        JI[2][0] = (-J[1][1] * J[2][0] + J[1][0] * J[2][1]) / det;
-        JI[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
-        JI[2][2] = (-J[0][1] * J[1][0] + J[0][0] * J[1][1]) / det;
+        const double rd = 1.0 / det;
+        JI[0][0] = (-J[1][2] * J[2][1] + J[1][1] * J[2][2]) * rd;
+        JI[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * rd;
+        JI[0][2] = (-J[0][2] * J[1][1] + J[0][1] * J[1][2]) * rd;
+        JI[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) * rd;
+        JI[1][1] = (-J[0][2] * J[2][0] + J[0][0] * J[2][2]) * rd;
+        JI[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * rd;
+        JI[2][0] = (-J[1][1] * J[2][0] + J[1][0] * J[2][1]) * rd;
+        JI[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * rd;
+        JI[2][2] = (-J[0][1] * J[1][0] + J[0][0] * J[1][1]) * rd;
       }
       const double weight = glive ? det * P.w[gg] : 0.0;
-      double gu[DIM], xg[DIM];
+      double gu[DIM], xg[DIM], ph[NPP];
 #pragma unroll
       for (int a = 0; a < DIM; a++) gu[a] = xg[a] = 0.0;
 #pragma unroll
       for (int k = 0; k < NPP; k++) {
         const int n = n0 + k;
+        ph[k] = 0.0;
         if (n < NC) {
           const double un = ue[n];
-          const double ph = (SRC != 0) ? P.phi[(size_t)gg * NC + n] : 0.0;
+          ph[k] = P.phi[(size_t)gg * NC + n];
 #pragma unroll
           for (int a = 0; a < DIM; a++) {
             double s = dh[k][0] * JI[a][0];
@@ -220,7 +233,7 @@ __global__ __launch_bounds__(256) void k_assemble_poisson(AsmParams P) {
             for (int b = 1; b < DIM; b++) s += dh[k][b] * JI[a][b];   // gradphi[a] = sum_b dphi_b * JacI[a][b]
             gs[(q * DIM + a) * NCP + n] = glive ? s : 0.0;
             gu[a] += s * un;
-            xg[a] += xe[n * DIM + a] * ph;
+            if (SRC != 0) xg[a] += xe[n * DIM + a] * ph[k];
           }
         }
       }
@@ -230,15 +243,27 @@ __global__ __launch_bounds__(256) void k_assemble_poisson(AsmParams P) {
 #pragma unroll
           for (int a = 0; a < DIM; a++) {
             gu[a] += __shfl_xor(gu[a], off, 64);
-            xg[a] += __shfl_xor(xg[a], off, 64);
+            if (SRC != 0) xg[a] += __shfl_xor(xg[a], off, 64);
           }
       }
-      if (part == 0) {
-        ws[q] = weight;
-        fs[q] = (SRC == 0) ? P.p0 : source_eval(P.source_kind, P.p0, P.p1, xg, DIM);
+      // residual integrand of this lane's nodes: (-f phi_n - grad phi_n . grad u) W  (summed over g in phase 2)
+      const double fq = (SRC == 0) ? P.p0 : source_eval(P.source_kind, P.p0, P.p1, xg, DIM);
 #pragma unroll
-        for (int a = 0; a < DIM; a++) gus[q * DIM + a] = gu[a];
+      for (int k = 0; k < NPP; k++) {
+        const int n = n0 + k;
+        if (n < NC) {
+          double wl = 0.0;
+#pragma unroll
+          for (int a = 0; a < DIM; a++) {
+            double s = dh[k][0] * JI[a][0];
+#pragma unroll
+            for (int b = 1; b < DIM; b++) s += dh[k][b] * JI[a][b];
+            wl += s * gu[a];
+          }
+          rs[q * NCP + n] = (-fq * ph[k] - wl) * weight;
+        }
       }
+      if (part == 0) ws[q] = weight;
     }
     __syncthreads();
     // ---------------- phase 2: K += (grad phi_i . grad phi_j) W ; F += (-f phi_i - grad phi_i . grad u) W ---------
@@ -246,40 +271,37 @@ __global__ __launch_bounds__(256) void k_assemble_poisson(AsmParams P) {
 #pragma unroll 2
       for (int gq = 0; gq < GC; gq++) {
         const double wq = ws[gq];
-        double t[TI];
-#pragma unroll
-        for (int a = 0; a < TI; a++) t[a] = 0.0;
 #pragma unroll
         for (int d = 0; d < DIM; d++) {
           const double* row = gs + (gq * DIM + d) * NCP;
           double av[TI], bv[TJ];
+          if constexpr (TI == 4) {   // rows are 32-byte aligned (NCP % 4 == 0, slabs 16-byte aligned): two ds_read_b128 per side
+            const double2* ra = reinterpret_cast<const double2*>(__builtin_assume_aligned(row + i0, 16));
+            const double2* rb = reinterpret_cast<const double2*>(__builtin_assume_aligned(row + j0, 16));
+            const double2 a0 = ra[0], a1 = ra[1], b0 = rb[0], b1 = rb[1];
+            av[0] = a0.x; av[1] = a0.y; av[2] = a1.x; av[3] = a1.y;
+            bv[0] = b0.x * wq; bv[1] = b0.y * wq; bv[2] = b1.x * wq; bv[3] = b1.y * wq;
+          } else {
 #pragma unroll
-          for (int a = 0; a < TI; a++) av[a] = row[i0 + a];
+            for (int a = 0; a < TI; a++) av[a] = row[i0 + a];
 #pragma unroll
-          for (int b = 0; b < TJ; b++) bv[b] = row[j0 + b] * wq;
+            for (int b = 0; b < TJ; b++) bv[b] = row[j0 + b] * wq;
+          }
 #pragma unroll
-          for (int a = 0; a < TI; a++) {
+          for (int a = 0; a < TI; a++)
 #pragma unroll
             for (int b = 0; b < TJ; b++) K[a][b] += av[a] * bv[b];
-            t[a] += av[a] * gus[gq * DIM + d];
-          }
         }
         if (jb == 0) {
-          const int g = ch * GC + gq;
-          const double fq = fs[gq];
 #pragma unroll
-          for (int a = 0; a < TI; a++) {
-            const int i = i0 + a;
-            const double ph = (i < NC && g < P.ng) ? P.phi[(size_t)g * NC + i] : 0.0;
-            F[a] += (-fq * ph - t[a]) * wq;
-          }
+          for (int a = 0; a < TI; a++) F[a] += rs[gq * NCP + i0 + a];
         }
       }
     }
     __syncthreads();
   }
 
-  if (!elive || !tlive) return;
+  if (!elive || !tlive || (P.debug & 2)) return;
   // ---------------- output ---------------------------------------------------------------------------------------
   if constexpr (OUT == 3) {
 #pragma unroll
@@ -326,8 +348,275 @@ __global__ __launch_bounds__(256) void k_assemble_poisson(AsmParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// pass 2 of the two-pass assembly: one 32-lane group per CSR row.  The row's accumulators live in LDS; for every adjacent
+// element (ascending element order = the order of the reference's sequential element loop) lane j adds K_e[i][j] into its
+// slot, then the finished row is written once, contiguously.  No colours, no atomics, no read-modify-write of HBM:
+// the coloured scatter touches 27 of the 125 entries of a row per visit and pays for whole 128-byte lines (measured 3.0 ms
+// on the 64^3 level); this pass moves each matrix value exactly once.
+// BUILD=true fills rowmap (symbolic pass, once per pattern).
+// ------------------------------------------------------------------------------------------------------------------
+template <int NC, bool BUILD>
+__global__ __launch_bounds__(256) void k_row_assemble(const int* __restrict__ rowptr, const int* __restrict__ col, int m,
+                                                      const int* __restrict__ adj_ptr, const int* __restrict__ adj_ei,
+                                                      unsigned char* __restrict__ rowmap, const int* __restrict__ elem_dof, int nloc,
+                                                      const double* __restrict__ Kbuf, const double* __restrict__ Fbuf,
+                                                      double* __restrict__ val, double* __restrict__ res) {
+  __shared__ double acc[8][256];
+  const int sub = threadIdx.x >> 5, lane = threadIdx.x & 31;
+  const int r = blockIdx.x * 8 + sub;
+  if (r >= m) return;
+  const int rs = rowptr[r], len = rowptr[r + 1] - rs;
+  if (!BUILD)
+    for (int p = lane; p < len; p += 32) acc[sub][p] = 0.0;
+  double facc = 0.0;
+  const int a0 = adj_ptr[r], a1 = adj_ptr[r + 1];
+  for (int a = a0; a < a1; a++) {
+    const int ei = adj_ei[a];
+    const int e = ei >> 5, i = ei & 31;
+    for (int j = lane; j < NC; j += 32) {
+      if (BUILD) {
+        const int target = elem_dof[(size_t)e * nloc + j];
+        int lo = rs, hi = rs + len - 1, pos = 0;
+        while (lo <= hi) {
+          const int mid = (lo + hi) >> 1;
+          const int cc = col[mid];
+          if (cc == target) { pos = mid - rs; break; }
+          if (cc < target) lo = mid + 1; else hi = mid - 1;
+        }
+        rowmap[(size_t)a * NC + j] = (unsigned char)pos;
+      } else {
+        const double k = Kbuf[((size_t)e * NC + i) * NC + j];
+        acc[sub][rowmap[(size_t)a * NC + j]] += k;      // distinct slots within one element row; waves issue LDS ops in order
+      }
+    }
+    if (!BUILD && lane == 0) facc += Fbuf[(size_t)e * NC + i];
+  }
+  if (!BUILD) {
+    for (int p = lane; p < len; p += 32) val[rs + p] = acc[sub][p];
+    if (lane == 0) res[r] = facc;
+  }
+}
+
+template <int NC>
+static int launch_rows(fh_assembler_t as, fh_mat_t A, double* res, bool build) {
+  if (A->m == 0) return 0;
+  const dim3 grid(fh_div_up(A->m, 8)), block(256);
+  if (build)
+    hipLaunchKernelGGL((k_row_assemble<NC, true>), grid, block, 0, as->ctx->stream, A->d_rowptr, A->d_col, A->m, as->d_adj_ptr, as->d_adj_ei,
+                       as->d_rowmap, as->d_elem_dof, as->nloc, nullptr, nullptr, nullptr, nullptr);
+  else
+    hipLaunchKernelGGL((k_row_assemble<NC, false>), grid, block, 0, as->ctx->stream, A->d_rowptr, A->d_col, A->m, as->d_adj_ptr, as->d_adj_ei,
+                       as->d_rowmap, as->d_elem_dof, as->nloc, as->d_Kbuf, as->d_Fbuf, A->d_val, res);
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+static int dispatch_rows(fh_assembler_t as, fh_mat_t A, double* res, bool build) {
+  switch (as->nc) {
+    case 27: return launch_rows<27>(as, A, res, build);
+    case 9: return launch_rows<9>(as, A, res, build);
+    case 8: return launch_rows<8>(as, A, res, build);
+    case 4: return launch_rows<4>(as, A, res, build);
+  }
+  fh_set_error("assembler: unsupported nc %d", as->nc);
+  return 2;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------------
+// HEX27 / Q2 element-matrix kernel for the two-pass assembly: TWO elements per wave, symmetric tiles only.
+// K_e is symmetric (the reference's Jac[i][j] = Jac[j][i] bit for bit), so only the 28 upper 4x4 tiles are accumulated and
+// mirrored on output: half the FP64 work of the full 49-tile version.  Lanes 0-31 own element A, 32-63 element B:
+//   phase 1  (8 Gauss points of the chunk) x (4 node parts) per element: partial J, shuffles, J^-1, grad phi -> LDS,
+//            residual integrand per (g, node) -> LDS
+//   phase 2  lane < 28 of each half: one upper tile, 16 FMA per 8 LDS doubles (2+2 ds_read_b128)
+// Waves are independent (own LDS slab, wave-level barriers only); one wave per workgroup.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int SRC>
+__global__ __launch_bounds__(64) void k_elem_q2hex_sym(AsmParams P) {
+  constexpr int NC = 27, NCP = 28, DIM = 3, GC = 8, NPP = 7;
+  constexpr int GS = GC * DIM * NCP;                 // 672
+  constexpr int SLAB = GS + GC * NCP + GC + NC * DIM + NC + 4;   // gs, rs, ws, xe, ue (+pad) = 1016 -> even
+  __shared__ __attribute__((aligned(16))) double smem[2 * SLAB];
+  const int lane = threadIdx.x;
+  const int half = lane >> 5, l = lane & 31;
+  const int eidx = blockIdx.x * 2 + half;
+  const bool elive = eidx < P.nelems;
+  const int e = P.elems[elive ? eidx : (P.nelems - 1)];
+  double* gs = smem + half * SLAB;
+  double* rs = gs + GS;
+  double* ws = rs + GC * NCP;
+  double* xe = ws + GC;
+  double* ue = xe + NC * DIM;
+
+  if (l < NC) {
+    const int dof = P.elem_dof[(size_t)e * P.nloc + l];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) xe[l * DIM + d] = P.coords[(size_t)dof * DIM + d];
+    ue[l] = P.sol ? P.sol[dof] : 0.0;
+  }
+  if (l < GC * DIM) gs[l * NCP + NC] = 0.0;           // padding column of the gradient rows
+  if (l < GC) rs[l * NCP + NC] = 0.0;
+  wave_lds_sync();
+
+  // upper tile (ib <= jb) owned by this lane: l = 0..27
+  int ib = 0, jb = 0;
+  {
+    int t = (l < 28) ? l : 0, row = 0;
+    while (t >= 7 - row) { t -= 7 - row; row++; }
+    ib = row;
+    jb = row + t;
+  }
+  const bool tlive = l < 28;
+  const int i0 = ib * 4, j0 = jb * 4;
+  double K[4][4], F[4];
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    F[a] = 0.0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) K[a][b] = 0.0;
+  }
+  const int q = l >> 2, part = l & 3, n0 = part * NPP;
+  const int nchunk = (P.debug & 1) ? 0 : (P.ng + GC - 1) / GC;
+#pragma unroll 1
+  for (int ch = 0; ch < nchunk; ch++) {
+    {
+      const int g = ch * GC + q;
+      const bool glive = g < P.ng;
+      const int gg = glive ? g : 0;
+      double dh[NPP][DIM], J[DIM][DIM];
+#pragma unroll
+      for (int a = 0; a < DIM; a++)
+#pragma unroll
+        for (int b = 0; b < DIM; b++) J[a][b] = 0.0;
+#pragma unroll
+      for (int k = 0; k < NPP; k++) {
+        const int n = n0 + k;
+        if (n < NC) {
+#pragma unroll
+          for (int a = 0; a < DIM; a++) {
+            dh[k][a] = P.dphi[((size_t)gg * NC + n) * DIM + a];
+#pragma unroll
+            for (int b = 0; b < DIM; b++) J[a][b] += dh[k][a] * xe[n * DIM + b];
+          }
+        } else {
+#pragma unroll
+          for (int a = 0; a < DIM; a++) dh[k][a] = 0.0;
+        }
+      }
+#pragma unroll
+      for (int off = 1; off < 4; off <<= 1)
+#pragma unroll
+        for (int a = 0; a < DIM; a++)
+#pragma unroll
+          for (int b = 0; b < DIM; b++) J[a][b] += __shfl_xor(J[a][b], off, 64);
+      const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[1][2] * J[2][0] - J[1][0] * J[2][2]) +
+                         J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+      const double rd = 1.0 / det;
+      double JI[DIM][DIM];
+      JI[0][0] = (-J[1][2] * J[2][1] + J[1][1] * J[2][2]) * rd;
+      JI[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * rd;
+      JI[0][2] = (-J[0][2] * J[1][1] + J[0][1] * J[1][2]) * rd;
+      JI[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) * rd;
+      JI[1][1] = (-J[0][2] * J[2][0] + J[0][0] * J[2][2]) * rd;
+      JI[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * rd;
+      JI[2][0] = (-J[1][1] * J[2][0] + J[1][0] * J[2][1]) * rd;
+      JI[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * rd;
+      JI[2][2] = (-J[0][1] * J[1][0] + J[0][0] * J[1][1]) * rd;
+      const double weight = glive ? det * P.w[gg] : 0.0;
+      double gr[NPP][DIM], gu[DIM] = {0.0, 0.0, 0.0}, xg[DIM] = {0.0, 0.0, 0.0}, ph[NPP];
+#pragma unroll
+      for (int k = 0; k < NPP; k++) {
+        const int n = n0 + k;
+        ph[k] = 0.0;
+#pragma unroll
+        for (int a = 0; a < DIM; a++) gr[k][a] = 0.0;
+        if (n < NC) {
+          const double un = ue[n];
+          ph[k] = P.phi[(size_t)gg * NC + n];
+#pragma unroll
+          for (int a = 0; a < DIM; a++) {
+            const double sgr = glive ? dh[k][0] * JI[a][0] + dh[k][1] * JI[a][1] + dh[k][2] * JI[a][2] : 0.0;
+            gr[k][a] = sgr;
+            gs[(q * DIM + a) * NCP + n] = sgr;
+            gu[a] += sgr * un;
+            if (SRC != 0) xg[a] += xe[n * DIM + a] * ph[k];
+          }
+        }
+      }
+#pragma unroll
+      for (int off = 1; off < 4; off <<= 1)
+#pragma unroll
+        for (int a = 0; a < DIM; a++) {
+          gu[a] += __shfl_xor(gu[a], off, 64);
+          if (SRC != 0) xg[a] += __shfl_xor(xg[a], off, 64);
+        }
+      const double fq = (SRC == 0) ? P.p0 : source_eval(P.source_kind, P.p0, P.p1, xg, DIM);
+#pragma unroll
+      for (int k = 0; k < NPP; k++) {
+        const int n = n0 + k;
+        if (n < NC) rs[q * NCP + n] = (-fq * ph[k] - (gr[k][0] * gu[0] + gr[k][1] * gu[1] + gr[k][2] * gu[2])) * weight;
+      }
+      if (part == 0) ws[q] = weight;
+    }
+    wave_lds_sync();
+    if (tlive) {
+#pragma unroll 2
+      for (int gq = 0; gq < GC; gq++) {
+        const double wq = ws[gq];
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+          const double* row = gs + (gq * DIM + d) * NCP;
+          const double2* ra = reinterpret_cast<const double2*>(__builtin_assume_aligned(row + i0, 16));
+          const double2* rb = reinterpret_cast<const double2*>(__builtin_assume_aligned(row + j0, 16));
+          const double2 a0 = ra[0], a1 = ra[1], b0 = rb[0], b1 = rb[1];
+          const double av[4] = {a0.x, a0.y, a1.x, a1.y};
+          const double bv[4] = {b0.x * wq, b0.y * wq, b1.x * wq, b1.y * wq};
+#pragma unroll
+          for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) K[a][b] += av[a] * bv[b];
+        }
+        if (ib == jb) {
+#pragma unroll
+          for (int a = 0; a < 4; a++) F[a] += rs[gq * NCP + i0 + a];
+        }
+      }
+    }
+    wave_lds_sync();
+  }
+  if (!elive || !tlive || (P.debug & 2)) return;
+  double* Ke = P.Kout + (size_t)eidx * NC * NC;
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    const int i = i0 + a;
+    if (i >= NC) continue;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int j = j0 + b;
+      if (j >= NC) continue;
+      if (ib == jb) {
+        if (b >= a) {               // diagonal tile: upper entries, mirrored
+          Ke[i * NC + j] = K[a][b];
+          if (b > a) Ke[j * NC + i] = K[a][b];
+        }
+      } else {
+        Ke[i * NC + j] = K[a][b];
+        Ke[j * NC + i] = K[a][b];
+      }
+    }
+    if (ib == jb) P.Fout[(size_t)eidx * NC + i] = F[a];
+  }
+}
+
 template <int DIM, int NC>
 static int launch_assemble(fh_assembler_t as, const AsmParams& P) {
   using C = AsmCfg<DIM, NC>;
@@ -348,6 +637,14 @@ static int launch_assemble(fh_assembler_t as, const AsmParams& P) {
 }
 
 static int dispatch_assemble(fh_assembler_t as, const AsmParams& P) {
+  if (as->dim == 3 && as->nc == 27 && P.Kout && as->ctx->assemble_sym) {
+    if (P.nelems <= 0) return 0;
+    const dim3 grid(fh_div_up(P.nelems, 2)), block(64);
+    if (P.source_kind != 0) hipLaunchKernelGGL(k_elem_q2hex_sym<1>, grid, block, 0, as->ctx->stream, P);
+    else hipLaunchKernelGGL(k_elem_q2hex_sym<0>, grid, block, 0, as->ctx->stream, P);
+    FH_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   if (as->dim == 3 && as->nc == 27) return launch_assemble<3, 27>(as, P);
   if (as->dim == 3 && as->nc == 8) return launch_assemble<3, 8>(as, P);
   if (as->dim == 2 && as->nc == 9) return launch_assemble<2, 9>(as, P);
@@ -445,7 +742,7 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
   std::vector<int> iota(nel);
   for (int e = 0; e < nel; e++) iota[e] = e;
   FH_TRY(up((void**)&as->d_iota, iota.data(), iota.size() * sizeof(int)));
-  if (ctx->assemble_emap) {
+  if (ctx->assemble_emap && !(ctx->assemble_two_pass && A->max_row <= 255)) {
     // symbolic phase: CSR slot of every element entry, built on the device with the same kernel
     FH_CHECK_HIP(hipMalloc(&as->d_emap, std::max<size_t>((size_t)nel * as->nc * as->ncp, 1) * sizeof(int)));
     AsmParams P = base_params(as);
@@ -458,6 +755,32 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
     P.ng = 0;   // no quadrature needed for the symbolic pass
     FH_TRY(dispatch_assemble(as, P));
     FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  if (ctx->assemble_two_pass && A->max_row <= 255) {
+    // row -> (element, local row) adjacency in ascending element order (host, integer setup work)
+    const int m = A->m, nc = as->nc;
+    std::vector<int> aptr(m + 1, 0);
+    for (int e = 0; e < nel; e++)
+      for (int i = 0; i < nc; i++) {
+        const int r = elem_dof[(size_t)e * nloc + i];
+        if (r < m) aptr[r + 1]++;
+      }
+    for (int r = 0; r < m; r++) aptr[r + 1] += aptr[r];
+    std::vector<int> aei(aptr[m]), cur(aptr.begin(), aptr.end() - 1);
+    for (int e = 0; e < nel; e++)
+      for (int i = 0; i < nc; i++) {
+        const int r = elem_dof[(size_t)e * nloc + i];
+        if (r < m) aei[cur[r]++] = (e << 5) | i;
+      }
+    FH_REQUIRE(nel < (1 << 26), "fh_assembler_create: too many elements for the packed adjacency");
+    FH_TRY(up((void**)&as->d_adj_ptr, aptr.data(), aptr.size() * sizeof(int)));
+    FH_TRY(up((void**)&as->d_adj_ei, aei.data(), aei.size() * sizeof(int)));
+    FH_CHECK_HIP(hipMalloc(&as->d_rowmap, std::max<size_t>((size_t)aei.size() * nc, 1)));
+    FH_CHECK_HIP(hipMalloc(&as->d_Kbuf, std::max<size_t>((size_t)nel * nc * nc, 1) * sizeof(double)));
+    FH_CHECK_HIP(hipMalloc(&as->d_Fbuf, std::max<size_t>((size_t)nel * nc, 1) * sizeof(double)));
+    FH_TRY(dispatch_rows(as, A, nullptr, true));
+    FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    as->two_pass = true;
   }
   *out = as;
   return 0;
@@ -474,6 +797,8 @@ extern "C" int fh_assembler_destroy(fh_assembler_t as) {
   hipFree(as->d_dphi);
   if (as->d_emap) hipFree(as->d_emap);
   hipFree(as->d_iota);
+  for (void* q : {(void*)as->d_adj_ptr, (void*)as->d_adj_ei, (void*)as->d_rowmap, (void*)as->d_Kbuf, (void*)as->d_Fbuf})
+    if (q) hipFree(q);
   delete as;
   return 0;
 }
@@ -483,6 +808,23 @@ extern "C" int fh_assemble_poisson(fh_assembler_t as, fh_vec_t sol, int source_k
   FH_REQUIRE(A->m == as->ndof && res->n_local >= as->ndof, "fh_assemble_poisson: size mismatch");
   FH_REQUIRE(source_kind >= 0 && source_kind <= 2, "fh_assemble_poisson: unknown source kind %d", source_kind);
   FH_REQUIRE(!sol || sol->n_local + sol->nghost >= A->n, "fh_assemble_poisson: solution vector too short (needs owned + ghost entries)");
+  if (as->two_pass) {
+    // pass 1: all element matrices (one launch, no colours) ; pass 2: rows gather their element rows (zeroing included)
+    AsmParams P = base_params(as);
+    P.sol = sol ? sol->d : nullptr;
+    P.source_kind = source_kind;
+    P.p0 = params ? params[0] : 1.0;
+    P.p1 = params ? params[1] : 0.0;
+    P.elems = as->d_iota;
+    P.nelems = as->nel;
+    P.Kout = as->d_Kbuf;
+    P.Fout = as->d_Fbuf;
+    P.debug = as->ctx->asm_debug;
+    FH_TRY(dispatch_assemble(as, P));
+    if (!(as->ctx->asm_debug & 2)) FH_TRY(dispatch_rows(as, A, res->d, false));
+    A->at_valid = false;
+    return 0;
+  }
   // KK->zero(); RES->zero();  (separate.hpp:106-107)
   FH_TRY(fh_mat_zero(A));
   FH_TRY(fh_vec_zero(res));
@@ -497,6 +839,7 @@ extern "C" int fh_assemble_poisson(fh_assembler_t as, fh_vec_t sol, int source_k
   P.val = A->d_val;
   P.res = res->d;
   P.emap = as->d_emap;
+  P.debug = as->ctx->asm_debug;
   for (int c = 0; c < as->ncolors; c++) {
     P.elems = as->d_color_elems + as->color_ptr[c];
     P.nelems = as->color_ptr[c + 1] - as->color_ptr[c];

@@ -94,6 +94,9 @@ extern "C" int fh_set_option(fh_ctx_t c, const char* name, double value) {
   else if (!strcmp(name, "spmv_kernel")) c->spmv_kernel = (int)value;
   else if (!strcmp(name, "spmv_nt")) c->spmv_nt = (int)value;
   else if (!strcmp(name, "assemble_emap")) c->assemble_emap = (int)value;
+  else if (!strcmp(name, "asm_debug")) c->asm_debug = (int)value;
+  else if (!strcmp(name, "assemble_two_pass")) c->assemble_two_pass = (int)value;
+  else if (!strcmp(name, "assemble_sym")) c->assemble_sym = (int)value;
   else if (!strcmp(name, "use_graph")) c->use_graph = (int)value;
   else {
     fh_set_error("fh_set_option: unknown option '%s'", name);

@@ -50,6 +50,9 @@ struct fh_ctx_s {
   int spmv_kernel = 3;                // 0: csr-stream (workgroup tiles), 1: csr-vector, 2: csr-stream (wave tiles), 3: csr-stream with LDS-staged x
   int spmv_nt = 0;                    // non-temporal matrix stream
   int assemble_emap = 1;
+  int asm_debug = 0;
+  int assemble_sym = 1;              // symmetric-tile HEX27/Q2 element kernel (2 elements per wave)
+  int assemble_two_pass = 1;         // 1: element matrices + row gather (default), 0: coloured scatter
   int use_graph = 1;
 };
 

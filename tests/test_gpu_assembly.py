@@ -73,9 +73,11 @@ def test_distorted_hex27_geometry(ctx):
     assert abs(F - Fo).max() <= 1e-12 * abs(Fo).max()
 
 
-@pytest.mark.parametrize("emap", [1, 0])
+@pytest.mark.parametrize("two_pass,emap", [(1, 1), (0, 1), (0, 0)])
 @pytest.mark.parametrize("args,nl,fe", [((2, 2, 2), 3, "biquadratic"), ((8, 8, 0), 3, "linear"), ((2, 2, 2), 2, "linear")])
-def test_global_assembly_matches_oracle(ctx, args, nl, fe, emap):
+def test_global_assembly_matches_oracle(ctx, args, nl, fe, two_pass, emap):
+    """two_pass=1: element matrices + row gather in element order (default); 0: coloured scatter (emap or binary search)"""
+    ctx.set_option("assemble_two_pass", two_pass)
     ctx.set_option("assemble_emap", emap)
     try:
         m = levels(args, nl)[-1]
@@ -110,3 +112,4 @@ def test_global_assembly_matches_oracle(ctx, args, nl, fe, emap):
         asm.destroy()
     finally:
         ctx.set_option("assemble_emap", 1)
+        ctx.set_option("assemble_two_pass", 1)
