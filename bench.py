@@ -171,7 +171,7 @@ def main():
         "prepare_first_s": pb.prepare_first_s,
         "setup_s": setup_s,
         "roofline": {
-            "kernel": "k_spmv_lx<1024,3> (fine-level fused Jacobi sweep x+w*Dinv*(b-Ax), LDS-staged x)",
+            "kernel": "k_spmv_lx<2048,3,true> (fine-level fused Jacobi sweep x+w*Dinv*(b-Ax), LDS-staged x)",
             "bound": "hbm",
             "achieved": sweep_bytes / sweep_ms / 1e6,
             "peak": HBM_PEAK_GBPS,

@@ -370,11 +370,11 @@ __global__ __launch_bounds__(256) void k_row_assemble(const int* __restrict__ ro
     for (int p = lane; p < len; p += 32) acc[sub][p] = 0.0;
   double facc = 0.0;
   const int a0 = adj_ptr[r], a1 = adj_ptr[r + 1];
-  for (int a = a0; a < a1; a++) {
-    const int ei = adj_ei[a];
-    const int e = ei >> 5, i = ei & 31;
-    for (int j = lane; j < NC; j += 32) {
-      if (BUILD) {
+  if (BUILD) {
+    for (int a = a0; a < a1; a++) {
+      const int ei = adj_ei[a];
+      const int e = ei >> 5;
+      for (int j = lane; j < NC; j += 32) {
         const int target = elem_dof[(size_t)e * nloc + j];
         int lo = rs, hi = rs + len - 1, pos = 0;
         while (lo <= hi) {
@@ -384,12 +384,36 @@ __global__ __launch_bounds__(256) void k_row_assemble(const int* __restrict__ ro
           if (cc < target) lo = mid + 1; else hi = mid - 1;
         }
         rowmap[(size_t)a * NC + j] = (unsigned char)pos;
-      } else {
-        const double k = Kbuf[((size_t)e * NC + i) * NC + j];
-        acc[sub][rowmap[(size_t)a * NC + j]] += k;      // distinct slots within one element row; waves issue LDS ops in order
       }
     }
-    if (!BUILD && lane == 0) facc += Fbuf[(size_t)e * NC + i];
+  } else {
+    // batches of 4 adjacent elements: all loads of a batch are issued before the (ordered) LDS accumulation
+    for (int ab = a0; ab < a1; ab += 4) {
+      double k[4];
+      int pp[4];
+      double f[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int a = ab + t;
+        k[t] = 0.0;
+        pp[t] = 0;
+        f[t] = 0.0;
+        if (a < a1) {
+          const int ei = adj_ei[a];
+          const int e = ei >> 5, i = ei & 31;
+          if (lane < NC) {
+            k[t] = Kbuf[((size_t)e * NC + i) * NC + lane];
+            pp[t] = rowmap[(size_t)a * NC + lane];
+          }
+          if (lane == 0) f[t] = Fbuf[(size_t)e * NC + i];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        if (ab + t < a1 && lane < NC) acc[sub][pp[t]] += k[t];   // distinct slots within one element row; in-order LDS per wave
+        facc += f[t];
+      }
+    }
   }
   if (!BUILD) {
     for (int p = lane; p < len; p += 32) val[rs + p] = acc[sub][p];

@@ -45,9 +45,10 @@ struct fh_ctx_s {
   double* h_red = nullptr;            // pinned host
   size_t red_cap = 0;
   // options
-  int spmv_tile = 1024;               // nnz per row block (LDS tile)
+  int spmv_tile = 2048;               // nnz per row block (LDS tile)
   int spmv_xcd_remap = 1;
   int spmv_kernel = 3;                // 0: csr-stream (workgroup tiles), 1: csr-vector, 2: csr-stream (wave tiles), 3: csr-stream with LDS-staged x
+  int spmv_share = 1;                 // kernel 3: x tile and products share one LDS buffer
   int spmv_nt = 0;                    // non-temporal matrix stream
   int assemble_emap = 1;
   int asm_debug = 0;
@@ -81,6 +82,7 @@ struct fh_mat_s {
   int* d_uptr = nullptr;
   int* d_ucols = nullptr;
   unsigned short* d_lcol = nullptr;
+  int* d_tile_s = nullptr;             // first non-zero of every row block (persistent pipelined kernel)
   int lx_tile = 0;
   int max_row = 0;
   // cached explicit transpose for matrix_mult_transpose

@@ -67,6 +67,7 @@ extern "C" int fh_mat_destroy(fh_mat_t A) {
   if (A->d_uptr) hipFree(A->d_uptr);
   if (A->d_ucols) hipFree(A->d_ucols);
   if (A->d_lcol) hipFree(A->d_lcol);
+  if (A->d_tile_s) hipFree(A->d_tile_s);
   delete A;
   return 0;
 }
@@ -85,7 +86,7 @@ extern "C" int64_t fh_spmv_algorithmic_bytes(fh_mat_t A) {
 // row blocks: greedy, <= tile non-zeros and <= 512 rows per block; a row longer than the tile is alone
 int fh_mat_build_rowblocks(fh_mat_t A, int tile) {
   FH_REQUIRE(tile == 256 || tile == 512 || tile == 1024 || tile == 2048 || tile == 4096, "spmv_tile must be 256..4096, power of two (got %d)", tile);
-  const int maxrows = (A->ctx->spmv_kernel == 2) ? 128 : 512;
+  const int maxrows = (A->ctx->spmv_kernel == 2) ? 128 : (A->ctx->spmv_kernel == 4) ? 255 : 512;
   std::vector<int> blk;
   blk.push_back(0);
   int acc = 0, rows = 0;
@@ -503,17 +504,28 @@ int fh_mat_build_localcols(fh_mat_t A) {
   FH_CHECK_HIP(hipMemcpy(A->d_uptr, uptr.data(), uptr.size() * sizeof(int), hipMemcpyHostToDevice));
   FH_CHECK_HIP(hipMemcpy(A->d_ucols, ucols.data(), ucols.size() * sizeof(int), hipMemcpyHostToDevice));
   FH_CHECK_HIP(hipMemcpy(A->d_lcol, lcol.data(), lcol.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  {
+    std::vector<int> ts(nblk + 1);
+    for (int b = 0; b <= nblk; b++) ts[b] = A->h_rowptr[blk[b]];
+    if (A->d_tile_s) FH_CHECK_HIP(hipFree(A->d_tile_s));
+    FH_CHECK_HIP(hipMalloc(&A->d_tile_s, ts.size() * sizeof(int)));
+    FH_CHECK_HIP(hipMemcpy(A->d_tile_s, ts.data(), ts.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   A->lx_tile = A->tile;
   return 0;
 }
 
-template <int TILE, int MODE>
+// SHARE: the x tile and the products use the SAME LDS buffer (one more barrier) -> half the LDS per tile, so twice the
+// matrix bytes are in flight per CU at the same residency
+template <int TILE, int MODE, bool SHARE>
 __global__ __launch_bounds__(256) void k_spmv_lx(const int* __restrict__ rowptr, const int* __restrict__ col, const unsigned short* __restrict__ lcol,
                                                  const double* __restrict__ val, const int* __restrict__ rowblk, const int* __restrict__ uptr,
                                                  const int* __restrict__ ucols, int nblk, int q, const double* __restrict__ x,
                                                  double* __restrict__ y, const double* __restrict__ b, const double* __restrict__ dinv, double omega) {
   __shared__ double prod[TILE + 2];
-  __shared__ double xs[TILE];
+  __shared__ double xs_own[SHARE ? 1 : TILE];
+  double* xs = SHARE ? prod : xs_own;
+  __shared__ int rps[516];
   int blk = (q > 0) ? (int)(blockIdx.x & 7) * q + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   if (blk >= nblk) return;
   const int tid = threadIdx.x;
@@ -529,6 +541,12 @@ __global__ __launch_bounds__(256) void k_spmv_lx(const int* __restrict__ rowptr,
     if (tid == 0) spmv_store<MODE>(prod[0] + prod[1] + prod[2] + prod[3], r0, x, y, b, dinv, omega);
     return;
   }
+  // row pointers of the tile: issued now, parked in LDS before the first barrier (no dependent global load in the reduction)
+  const int nrows = r1 - r0;
+  int rp0 = 0, rp1 = 0, rp2 = 0;
+  if (tid <= nrows) rp0 = rowptr[r0 + tid];
+  if (tid + 256 <= nrows) rp1 = rowptr[r0 + tid + 256];
+  if (tid + 512 <= nrows) rp2 = rowptr[r0 + tid + 512];
   // ---- matrix stream first (longest latency): 16 B of values + 4 B of local columns per lane and step ----
   const int s2 = s & ~1;
   constexpr int ITER = TILE / 512 + 1;
@@ -545,17 +563,41 @@ __global__ __launch_bounds__(256) void k_spmv_lx(const int* __restrict__ rowptr,
   // ---- x entries of this tile -> LDS (sorted distinct columns: neighbouring lanes share cache lines) ----
   const int u0 = uptr[blk], nu = uptr[blk + 1] - u0;
   for (int j = tid; j < nu; j += 256) xs[j] = x[ucols[u0 + j]];
+  if (tid <= nrows) rps[tid] = rp0;
+  if (tid + 256 <= nrows) rps[tid + 256] = rp1;
+  if (tid + 512 <= nrows) rps[tid + 512] = rp2;
   __syncthreads();
+  if (SHARE) {
+    double p0[ITER], p1[ITER];
 #pragma unroll
-  for (int k = 0; k < ITER; k++) {
-    const int i = s2 + 2 * tid + k * 512;
-    if (i < e) {
-      if (i >= s) prod[i - s] = v[k].x * xs[lc[k].x];
-      if (i + 1 < e) prod[i + 1 - s] = v[k].y * xs[lc[k].y];
+    for (int k = 0; k < ITER; k++) {
+      const int i = s2 + 2 * tid + k * 512;
+      p0[k] = p1[k] = 0.0;
+      if (i < e) {
+        p0[k] = v[k].x * xs[lc[k].x];
+        p1[k] = v[k].y * xs[lc[k].y];
+      }
+    }
+    __syncthreads();                      // every lane has read its x values: the buffer may now hold the products
+#pragma unroll
+    for (int k = 0; k < ITER; k++) {
+      const int i = s2 + 2 * tid + k * 512;
+      if (i < e) {
+        if (i >= s) prod[i - s] = p0[k];
+        if (i + 1 < e) prod[i + 1 - s] = p1[k];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < ITER; k++) {
+      const int i = s2 + 2 * tid + k * 512;
+      if (i < e) {
+        if (i >= s) prod[i - s] = v[k].x * xs[lc[k].x];
+        if (i + 1 < e) prod[i + 1 - s] = v[k].y * xs[lc[k].y];
+      }
     }
   }
   __syncthreads();
-  const int nrows = r1 - r0;
   const int G = (nrows <= 16) ? 16 : (nrows <= 32) ? 8 : (nrows <= 64) ? 4 : (nrows <= 128) ? 2 : 1;
   const int gl = tid & (G - 1);
   const int rows_per_pass = 256 / G;
@@ -566,7 +608,7 @@ __global__ __launch_bounds__(256) void k_spmv_lx(const int* __restrict__ rowptr,
     const int r = r0 + (live ? rr : 0);
     double acc = 0.0;
     if (live) {
-      const int a = rowptr[r] - s, z = rowptr[r + 1] - s;
+      const int a = rps[rr] - s, z = rps[rr + 1] - s;
       for (int k = a + gl; k < z; k += G) acc += prod[k];
     }
     for (int off = G >> 1; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -582,9 +624,156 @@ static void launch_lx(fh_mat_t A, int mode, const double* x, double* y, const do
     q = (A->nblk + 7) / 8;
     grid = 8 * q;
   }
-#define FH_LAUNCH(MODE) \
-  hipLaunchKernelGGL((k_spmv_lx<TILE, MODE>), dim3(grid), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_lcol, A->d_val, A->d_rowblk, \
+#define FH_LAUNCH(MODE, SH) \
+  hipLaunchKernelGGL((k_spmv_lx<TILE, MODE, SH>), dim3(grid), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_lcol, A->d_val, A->d_rowblk, \
                      A->d_uptr, A->d_ucols, A->nblk, q, x, y, b, dinv, omega)
+  if (c->spmv_share) {
+    switch (mode) {
+      case 0: FH_LAUNCH(0, true); break;
+      case 1: FH_LAUNCH(1, true); break;
+      case 2: FH_LAUNCH(2, true); break;
+      default: FH_LAUNCH(3, true); break;
+    }
+  } else {
+    switch (mode) {
+      case 0: FH_LAUNCH(0, false); break;
+      case 1: FH_LAUNCH(1, false); break;
+      case 2: FH_LAUNCH(2, false); break;
+      default: FH_LAUNCH(3, false); break;
+    }
+  }
+#undef FH_LAUNCH
+}
+
+// ------------------------------------------------------------------------------------------------
+// persistent, software-pipelined form of k_spmv_lx: every workgroup walks a contiguous range of row blocks and keeps
+// TWO tiles of matrix data in flight (the loads of tile t+1 and the column list of tile t+2 are issued before tile t is
+// reduced), so the HBM stream does not drain while a tile waits for its x gather, its barriers and its row reduction.
+// LDS is double-buffered by tile parity: two barriers per tile.
+// ------------------------------------------------------------------------------------------------
+template <int TILE, int MODE>
+__global__ __launch_bounds__(256) void k_spmv_lxp(const int* __restrict__ rowptr, const unsigned short* __restrict__ lcol,
+                                                  const double* __restrict__ val, const int* __restrict__ rowblk, const int* __restrict__ tile_s,
+                                                  const int* __restrict__ uptr, const int* __restrict__ ucols, int nblk, int tpb, int q,
+                                                  const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ b,
+                                                  const double* __restrict__ dinv, double omega) {
+  constexpr int ITER = TILE / 512 + 1;
+  constexpr int NX = TILE / 256;
+  __shared__ double prod[2][TILE + 2];
+  __shared__ double xs[2][TILE];
+  __shared__ int rps[2][260];
+  const int tid = threadIdx.x;
+  const int chunk = (q > 0) ? (int)(blockIdx.x & 7) * q + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int first = chunk * tpb;
+  const int last = min(first + tpb, nblk);
+  if (first >= last) return;
+
+  // registers of the tile being loaded ("N") and of the tile after it (column list only, "NN")
+  double2 vN[ITER];
+  ushort2 lN[ITER];
+  double xN[NX];
+  int rpN = 0, ucNN[NX];
+  int sN, eN, r0N, r1N, nuN;
+
+  auto load_ucols = [&](int t, int (&uc)[NX]) {
+    const int u0 = uptr[t], nu = uptr[t + 1] - u0;
+#pragma unroll
+    for (int k = 0; k < NX; k++) {
+      const int j = tid + k * 256;
+      uc[k] = (j < nu) ? ucols[u0 + j] : -1;
+    }
+  };
+  auto issue_tile = [&](int t, const int (&uc)[NX]) {
+    sN = tile_s[t];
+    eN = tile_s[t + 1];
+    r0N = rowblk[t];
+    r1N = rowblk[t + 1];
+    nuN = uptr[t + 1] - uptr[t];
+    const int s2 = sN & ~1;
+#pragma unroll
+    for (int k = 0; k < ITER; k++) {
+      const int i = s2 + 2 * tid + k * 512;
+      if (i < eN) {
+        vN[k] = *reinterpret_cast<const double2*>(val + i);
+        lN[k] = *reinterpret_cast<const ushort2*>(lcol + i);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NX; k++) xN[k] = (uc[k] >= 0) ? x[uc[k]] : 0.0;
+    rpN = (tid <= r1N - r0N) ? rowptr[r0N + tid] : 0;
+  };
+
+  {
+    int uc0[NX];
+    load_ucols(first, uc0);
+    issue_tile(first, uc0);
+    if (first + 1 < last) load_ucols(first + 1, ucNN);
+  }
+  for (int t = first; t < last; t++) {
+    // ---- current tile := the one in flight; start the next one ----
+    double2 vC[ITER];
+    ushort2 lC[ITER];
+    double xC[NX];
+#pragma unroll
+    for (int k = 0; k < ITER; k++) { vC[k] = vN[k]; lC[k] = lN[k]; }
+#pragma unroll
+    for (int k = 0; k < NX; k++) xC[k] = xN[k];
+    const int rpC = rpN, s = sN, e = eN, r0 = r0N, r1 = r1N, nu = nuN;
+    if (t + 1 < last) {
+      int ucT[NX];
+#pragma unroll
+      for (int k = 0; k < NX; k++) ucT[k] = ucNN[k];
+      if (t + 2 < last) load_ucols(t + 2, ucNN);
+      issue_tile(t + 1, ucT);
+    }
+    // ---- process tile t ----
+    const int par = t & 1;
+    const int nrows = r1 - r0;
+#pragma unroll
+    for (int k = 0; k < NX; k++) {
+      const int j = tid + k * 256;
+      if (j < nu) xs[par][j] = xC[k];
+    }
+    if (tid <= nrows) rps[par][tid] = rpC;
+    __syncthreads();
+    const int s2 = s & ~1;
+#pragma unroll
+    for (int k = 0; k < ITER; k++) {
+      const int i = s2 + 2 * tid + k * 512;
+      if (i < e) {
+        if (i >= s) prod[par][i - s] = vC[k].x * xs[par][lC[k].x];
+        if (i + 1 < e) prod[par][i + 1 - s] = vC[k].y * xs[par][lC[k].y];
+      }
+    }
+    __syncthreads();
+    const int G = (nrows <= 16) ? 16 : (nrows <= 32) ? 8 : (nrows <= 64) ? 4 : (nrows <= 128) ? 2 : 1;
+    const int gl = tid & (G - 1);
+    const int rr = tid / G;                       // nrows <= 255 and 256/G >= nrows for every G above: one pass
+    const bool live = rr < nrows;
+    double acc = 0.0;
+    if (live) {
+      const int a = rps[par][rr] - s, z = rps[par][rr + 1] - s;
+      for (int k = a + gl; k < z; k += G) acc += prod[par][k];
+    }
+    for (int off = G >> 1; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (live && gl == 0) spmv_store<MODE>(acc, r0 + rr, x, y, b, dinv, omega);
+  }
+}
+
+template <int TILE>
+static void launch_lxp(fh_mat_t A, int mode, const double* x, double* y, const double* b, const double* dinv, double omega) {
+  fh_ctx_t c = A->ctx;
+  const int target_blocks = c->num_cu * 5;
+  int tpb = std::max(1, (A->nblk + target_blocks - 1) / target_blocks);
+  int nchunks = (A->nblk + tpb - 1) / tpb;
+  int q = 0, grid = nchunks;
+  if (c->spmv_xcd_remap && nchunks >= 64) {
+    q = (nchunks + 7) / 8;
+    grid = 8 * q;
+  }
+#define FH_LAUNCH(MODE) \
+  hipLaunchKernelGGL((k_spmv_lxp<TILE, MODE>), dim3(grid), dim3(256), 0, c->stream, A->d_rowptr, A->d_lcol, A->d_val, A->d_rowblk, A->d_tile_s, \
+                     A->d_uptr, A->d_ucols, A->nblk, tpb, q, x, y, b, dinv, omega)
   switch (mode) {
     case 0: FH_LAUNCH(0); break;
     case 1: FH_LAUNCH(1); break;
@@ -761,12 +950,19 @@ int fh_dev_spmv(fh_mat_t A, const double* x, double* y, int mode, const double* 
     else { if (nt) { FH_LW_MODE(1024, 1) } else { FH_LW_MODE(1024, 0) } }
 #undef FH_LW_MODE
 #undef FH_LW
-  } else if (c->spmv_kernel == 3) {
-    FH_REQUIRE(c->spmv_tile == 1024 || c->spmv_tile == 2048, "spmv_kernel 3 needs spmv_tile 1024 or 2048");
-    if (A->tile != c->spmv_tile || A->tile_kernel != 3) FH_TRY(fh_mat_build_rowblocks(A, c->spmv_tile));
+  } else if (c->spmv_kernel == 4 && A->max_row <= c->spmv_tile) {
+    FH_REQUIRE(c->spmv_tile == 1024 || c->spmv_tile == 2048, "spmv_kernel 4 needs spmv_tile 1024 or 2048");
+    if (A->tile != c->spmv_tile || A->tile_kernel != 4) FH_TRY(fh_mat_build_rowblocks(A, c->spmv_tile));
+    if (A->lx_tile != A->tile) FH_TRY(fh_mat_build_localcols(A));
+    if (A->tile == 1024) launch_lxp<1024>(A, mode, x, y, b, dinv, omega);
+    else launch_lxp<2048>(A, mode, x, y, b, dinv, omega);
+  } else if (c->spmv_kernel == 3 || c->spmv_kernel == 4) {
+    FH_REQUIRE(c->spmv_tile == 1024 || c->spmv_tile == 2048 || c->spmv_tile == 4096, "spmv_kernel 3 needs spmv_tile 1024, 2048 or 4096");
+    if (A->tile != c->spmv_tile || (A->tile_kernel != 3 && A->tile_kernel != 4)) FH_TRY(fh_mat_build_rowblocks(A, c->spmv_tile));
     if (A->lx_tile != A->tile) FH_TRY(fh_mat_build_localcols(A));
     if (A->tile == 1024) launch_lx<1024>(A, mode, x, y, b, dinv, omega);
-    else launch_lx<2048>(A, mode, x, y, b, dinv, omega);
+    else if (A->tile == 2048) launch_lx<2048>(A, mode, x, y, b, dinv, omega);
+    else launch_lx<4096>(A, mode, x, y, b, dinv, omega);
   } else {
     if (A->tile != c->spmv_tile || A->tile_kernel != 0) FH_TRY(fh_mat_build_rowblocks(A, c->spmv_tile));
     FH_REQUIRE(A->tile >= 1024, "spmv_kernel 0 needs spmv_tile >= 1024");

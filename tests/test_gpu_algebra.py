@@ -57,8 +57,8 @@ def test_vector_blas1(ctx):
     assert o.to_numpy().tolist() == (2 * np.arange(7.0)).tolist()
 
 
-@pytest.mark.parametrize("kernel,tile", [(3, 2048), (3, 1024), (0, 1024), (0, 2048), (0, 4096), (1, 2048), (2, 256), (2, 512), (2, 1024)])
-def test_spmv_family_q2_matrix(ctx, q2_matrix, tile, kernel):
+@pytest.mark.parametrize("kernel,tile", [(4, 1024), (4, 2048), (3, 2048), (3, 1024), (3, 4096), (0, 1024), (0, 2048), (0, 4096), (1, 2048), (2, 256), (2, 512), (2, 1024)])
+def test_spmv_family_q2_matrix(ctx, q2_matrix, tile, kernel, share=None):
     ms, A, b = q2_matrix
     ctx.set_option("spmv_tile", tile)
     ctx.set_option("spmv_kernel", kernel)
@@ -79,11 +79,11 @@ def test_spmv_family_q2_matrix(ctx, q2_matrix, tile, kernel):
         assert rel(y.to_numpy(), xs + 2. / 3. * fo.jacobi_dinv(A) * (b - ref)) < 1e-14
         M.destroy()
     finally:
-        ctx.set_option("spmv_tile", 1024)
+        ctx.set_option("spmv_tile", 2048)
         ctx.set_option("spmv_kernel", 3)
 
 
-@pytest.mark.parametrize("kernel", [3, 0, 2])
+@pytest.mark.parametrize("kernel", [4, 3, 0, 2])
 def test_spmv_ragged_rows_and_long_row(ctx, kernel):
     """empty rows, 1-entry rows, a row longer than the LDS tile, rectangular shape, odd nnz offsets"""
     ctx.set_option("spmv_kernel", kernel)
@@ -116,7 +116,7 @@ def test_spmv_ragged_rows_and_long_row(ctx, kernel):
     E = ctx.matrix_csr(0, 0, [0], [])
     assert E.nnz == 0
     ctx.set_option("spmv_kernel", 3)
-    ctx.set_option("spmv_tile", 1024)
+    ctx.set_option("spmv_tile", 2048)
 
 
 def test_matrix_row_ops(ctx, q2_matrix):
@@ -150,3 +150,20 @@ def test_matrix_row_ops(ctx, q2_matrix):
     with pytest.raises(Exception):
         M.insert_row(0, [A.shape[0] - 1], [1.0])          # outside the pattern
     assert abs(ctx.matrix_scipy(A).l1_norm() - abs(A).sum(0).max()) < 1e-12
+
+
+def test_spmv_lds_buffer_modes(ctx, q2_matrix):
+    """kernel 3 with separate and with shared x / product LDS buffers give identical bits (same arithmetic)"""
+    ms, A, b = q2_matrix
+    n = A.shape[0]
+    xs = fo.lcg_fill(n, 77)
+    M = ctx.matrix_scipy(A)
+    x, y = ctx.vector_from(xs), ctx.vector(n)
+    outs = []
+    for share in (1, 0):
+        ctx.set_option("spmv_share", share)
+        y.matrix_mult(x, M)
+        outs.append(y.to_numpy().copy())
+    ctx.set_option("spmv_share", 1)
+    assert np.array_equal(outs[0], outs[1])
+    assert rel(outs[0], A @ xs) < 1e-14
