@@ -27,6 +27,10 @@ def num_threads():
     return int(lib().oc_num_threads())
 
 
+def set_threads(n):
+    lib().oc_set_threads(int(n))
+
+
 def assemble_poisson(mesh_elem_dof, coords, fe, geom, e0, e1, sol=None, source_kind=0, p0=1.0, p1=0.0, csr=None, order="seventh"):
     """element range [e0,e1).  csr=(rowptr, col, val, res) -> scatter (sequential, element order); else returns K, F."""
     et = fo.ElemType(geom, fe, order)

@@ -20,6 +20,12 @@
 #include <omp.h>
 #endif
 
+void oc_set_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n);
+#endif
+}
+
 int oc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
