@@ -23,6 +23,7 @@ int fh_halo_allreduce_ptr(fh_halo_t h, double* d, int n);
 struct MgLevel {
   fh_mat_t A = nullptr, P = nullptr, R = nullptr;
   bool own_R = false;
+  fh_mat_t R_of = nullptr;   // the interpolation the owned restriction was built from
   int n = 0, smoother = 0, npre = 2, npost = 2;
   double omega = 2.0 / 3.0;
   double *dinv = nullptr, *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;
@@ -73,30 +74,130 @@ __global__ __launch_bounds__(256) void k_csr_to_dense(const int* __restrict__ ro
   for (int k = rowptr[row] + threadIdx.x; k < rowptr[row + 1]; k += 256) D[(size_t)row * n + col[k]] = val[k];
 }
 
-// in-place Gauss-Jordan inversion, step k (no pivoting: the coarse operator is SPD on the free dofs and identity
-// on Dirichlet rows).  Three launches per step: save column k, rank-1 update of the other rows, scale the pivot row.
-__global__ __launch_bounds__(256) void k_gj_savecol(const double* __restrict__ D, double* __restrict__ colk, int n, int k) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) colk[i] = D[(size_t)i * n + k];
+// ------------------------------------------------------------------------------------------------
+// dense inverse of the coarsest operator: BLOCKED in-place Gauss-Jordan without pivoting (the operator is SPD on the free
+// dofs and the identity on Dirichlet rows).  Per pivot block of NB columns: save the column panel, invert the NB x NB pivot
+// in LDS, form the new row panel D^-1 A[k,:], rank-NB update of all other rows as a tiled FP64 GEMM (64x64 tiles, 4x4
+// register blocks, operands staged in LDS), and the pivot-column panel -C D^-1.  2 n^3 flops in n/NB steps of 5 launches
+// instead of 3 n launches of rank-1 updates.
+// ------------------------------------------------------------------------------------------------
+constexpr int GJ_NB = 32;
+
+__global__ __launch_bounds__(256) void k_gjb_save_panel(const double* __restrict__ D, double* __restrict__ Cp, int n, int kb, int nb) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * nb) return;
+  const int i = idx / nb, t = idx % nb;
+  Cp[(size_t)i * GJ_NB + t] = D[(size_t)i * n + kb + t];
 }
 
-__global__ __launch_bounds__(256) void k_gj_update(double* __restrict__ D, const double* __restrict__ colk, int n, int k) {
-  const int i = blockIdx.y;
-  if (i == k) return;
-  const double f = colk[i];
-  if (f == 0.0) return;   // row not coupled to the pivot
-  const double fp = f / colk[k];
-  const double* rk = D + (size_t)k * n;
-  double* ri = D + (size_t)i * n;
-  for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) ri[j] = (j == k) ? -fp : ri[j] - fp * rk[j];
+__global__ __launch_bounds__(256) void k_gjb_pivot(const double* __restrict__ D, double* __restrict__ Dinv, int n, int kb, int nb) {
+  __shared__ double M[GJ_NB][GJ_NB + 1];
+  __shared__ double colk[GJ_NB];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < nb * nb; idx += 256) M[idx / nb][idx % nb] = D[(size_t)(kb + idx / nb) * n + kb + idx % nb];
+  __syncthreads();
+  for (int k = 0; k < nb; k++) {
+    if (tid < nb) colk[tid] = M[tid][k];
+    __syncthreads();
+    const double p = 1.0 / colk[k];
+    for (int idx = tid; idx < nb * nb; idx += 256) {
+      const int i = idx / nb, j = idx % nb;
+      if (i != k) {
+        const double f = colk[i] * p;
+        M[i][j] = (j == k) ? -f : M[i][j] - f * M[k][j];
+      }
+    }
+    __syncthreads();
+    if (tid < nb) M[k][tid] = (tid == k) ? p : M[k][tid] * p;
+    __syncthreads();
+  }
+  for (int idx = tid; idx < nb * nb; idx += 256) Dinv[(idx / nb) * GJ_NB + idx % nb] = M[idx / nb][idx % nb];
 }
 
-__global__ __launch_bounds__(256) void k_gj_scalerow(double* __restrict__ D, const double* __restrict__ colk, int n, int k) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
+// rows of the pivot block: A[kb+s, j] <- sum_t Dinv[s,t] * A_old[kb+t, j] (j outside the pivot columns), Dinv inside
+__global__ __launch_bounds__(256) void k_gjb_row_panel(double* __restrict__ D, const double* __restrict__ Dinv, const double* __restrict__ Cp,
+                                                       int n, int kb, int nb) {
+  __shared__ double Ds[GJ_NB][GJ_NB + 1];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < nb * nb; idx += 256) Ds[idx / nb][idx % nb] = Dinv[(idx / nb) * GJ_NB + idx % nb];
+  __syncthreads();
+  const int j = blockIdx.x * 256 + tid;
   if (j >= n) return;
-  const double p = 1.0 / colk[k];
-  double* rk = D + (size_t)k * n;
-  rk[j] = (j == k) ? p : rk[j] * p;
+  if (j >= kb && j < kb + nb) {
+    for (int s2 = 0; s2 < nb; s2++) D[(size_t)(kb + s2) * n + j] = Ds[s2][j - kb];
+    return;
+  }
+  double old[GJ_NB];
+  for (int t = 0; t < nb; t++) old[t] = D[(size_t)(kb + t) * n + j];
+  for (int s2 = 0; s2 < nb; s2++) {
+    double acc = 0.0;
+    for (int t = 0; t < nb; t++) acc += Ds[s2][t] * old[t];
+    D[(size_t)(kb + s2) * n + j] = acc;
+  }
+}
+
+// all other rows, columns outside the pivot block: A[i,j] -= sum_t Cp[i,t] * R[t,j]   (R = the new row panel)
+__global__ __launch_bounds__(256) void k_gjb_update(double* __restrict__ D, const double* __restrict__ Cp, int n, int kb, int nb) {
+  __shared__ double Cs[64][GJ_NB + 1];
+  __shared__ double Rs[GJ_NB][64 + 2];
+  const int tid = threadIdx.x;
+  const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
+  for (int idx = tid; idx < 64 * GJ_NB; idx += 256) {
+    const int r = idx / GJ_NB, t = idx % GJ_NB;
+    const int i = ti + r;
+    Cs[r][t] = (i < n && t < nb) ? Cp[(size_t)i * GJ_NB + t] : 0.0;
+  }
+  for (int idx = tid; idx < GJ_NB * 64; idx += 256) {
+    const int t = idx / 64, c = idx % 64;
+    const int j = tj + c;
+    Rs[t][c] = (j < n && t < nb) ? D[(size_t)(kb + t) * n + j] : 0.0;
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b2 = 0; b2 < 4; b2++) acc[a][b2] = 0.0;
+#pragma unroll 8
+  for (int t = 0; t < GJ_NB; t++) {
+    double cv[4], rv[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) cv[a] = Cs[ty * 4 + a][t];
+#pragma unroll
+    for (int b2 = 0; b2 < 4; b2++) rv[b2] = Rs[t][tx * 4 + b2];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b2 = 0; b2 < 4; b2++) acc[a][b2] += cv[a] * rv[b2];
+  }
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    const int i = ti + ty * 4 + a;
+    if (i >= n || (i >= kb && i < kb + nb)) continue;
+#pragma unroll
+    for (int b2 = 0; b2 < 4; b2++) {
+      const int j = tj + tx * 4 + b2;
+      if (j >= n || (j >= kb && j < kb + nb)) continue;
+      D[(size_t)i * n + j] -= acc[a][b2];
+    }
+  }
+}
+
+// pivot columns of all other rows: A[i, kb+t] <- - sum_s Cp[i,s] * Dinv[s,t]
+__global__ __launch_bounds__(256) void k_gjb_col_panel(double* __restrict__ D, const double* __restrict__ Dinv, const double* __restrict__ Cp,
+                                                       int n, int kb, int nb) {
+  __shared__ double Ds[GJ_NB][GJ_NB + 1];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < nb * nb; idx += 256) Ds[idx / nb][idx % nb] = Dinv[(idx / nb) * GJ_NB + idx % nb];
+  __syncthreads();
+  const int idx = blockIdx.x * 256 + tid;
+  if (idx >= n * nb) return;
+  const int i = idx / nb, t = idx % nb;
+  if (i >= kb && i < kb + nb) return;
+  double acc = 0.0;
+  for (int s2 = 0; s2 < nb; s2++) acc += Cp[(size_t)i * GJ_NB + s2] * Ds[s2][t];
+  D[(size_t)i * n + kb + t] = -acc;
 }
 
 // V^T w for nvec basis vectors (GMRES classical Gram-Schmidt): partials[j*nb + block]
@@ -147,6 +248,7 @@ static inline int sgrid(fh_ctx_t c, int n) { return std::max(1, std::min(fh_div_
 // ------------------------------------------------------------------------------------------------
 // API
 // ------------------------------------------------------------------------------------------------
+static void free_level_restriction(MgLevel& L);
 extern "C" int fh_mg_create(fh_ctx_t ctx, int nlevels, fh_mg_t* out) {
   FH_REQUIRE(ctx && out && nlevels >= 1, "fh_mg_create: bad arguments");
   fh_mg_t mg = new fh_mg_s();
@@ -166,9 +268,10 @@ extern "C" int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh
   FH_REQUIRE(smoother == FH_SMOOTH_JACOBI, "fh_mg_set_level: only the Richardson+Jacobi smoother is implemented (got %d)", smoother);
   FH_REQUIRE(npre >= 0 && npost >= 0, "fh_mg_set_level: negative sweep count");
   MgLevel& L = mg->lv[level];
+  if (L.own_R && (R != nullptr || L.R_of != P)) free_level_restriction(L);
   L.A = A;
   L.P = P;
-  L.R = R;
+  if (!L.own_R) L.R = R;
   L.n = A->m;
   L.ncols = A->n;
   L.smoother = smoother;
@@ -193,10 +296,14 @@ static void free_level_buffers(MgLevel& L) {
       hipFree(*p);
       *p = nullptr;
     }
+}
+
+static void free_level_restriction(MgLevel& L) {
   if (L.own_R && L.R) {
     fh_mat_destroy(L.R);
     L.R = nullptr;
     L.own_R = false;
+    L.R_of = nullptr;
   }
 }
 
@@ -209,13 +316,18 @@ static int coarse_factor(fh_mg_t mg) {
   FH_CHECK_HIP(hipMalloc(&mg->d_ainv, (size_t)n * n * sizeof(double)));
   FH_CHECK_HIP(hipMemsetAsync(mg->d_ainv, 0, (size_t)n * n * sizeof(double), c->stream));
   hipLaunchKernelGGL(k_csr_to_dense, dim3(n), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, mg->d_ainv, n);
-  double* colk = nullptr;
-  FH_CHECK_HIP(hipMalloc(&colk, (size_t)n * sizeof(double)));
-  const int gx = std::max(1, std::min(fh_div_up(n, 256), 8));
-  for (int k = 0; k < n; k++) {
-    hipLaunchKernelGGL(k_gj_savecol, dim3(fh_div_up(n, 256)), dim3(256), 0, c->stream, mg->d_ainv, colk, n, k);
-    hipLaunchKernelGGL(k_gj_update, dim3(gx, n), dim3(256), 0, c->stream, mg->d_ainv, colk, n, k);
-    hipLaunchKernelGGL(k_gj_scalerow, dim3(fh_div_up(n, 256)), dim3(256), 0, c->stream, mg->d_ainv, colk, n, k);
+  double* colk = nullptr;   // column panel (n x NB) + pivot inverse (NB x NB)
+  FH_CHECK_HIP(hipMalloc(&colk, ((size_t)n * GJ_NB + GJ_NB * GJ_NB) * sizeof(double)));
+  double* Cp = colk;
+  double* Dinv = colk + (size_t)n * GJ_NB;
+  const int nt = fh_div_up(n, 64);
+  for (int kb = 0; kb < n; kb += GJ_NB) {
+    const int nb = std::min(GJ_NB, n - kb);
+    hipLaunchKernelGGL(k_gjb_save_panel, dim3(fh_div_up((int64_t)n * nb, 256)), dim3(256), 0, c->stream, mg->d_ainv, Cp, n, kb, nb);
+    hipLaunchKernelGGL(k_gjb_pivot, dim3(1), dim3(256), 0, c->stream, mg->d_ainv, Dinv, n, kb, nb);
+    hipLaunchKernelGGL(k_gjb_row_panel, dim3(fh_div_up(n, 256)), dim3(256), 0, c->stream, mg->d_ainv, Dinv, Cp, n, kb, nb);
+    hipLaunchKernelGGL(k_gjb_update, dim3(nt, nt), dim3(256), 0, c->stream, mg->d_ainv, Cp, n, kb, nb);
+    hipLaunchKernelGGL(k_gjb_col_panel, dim3(fh_div_up((int64_t)n * nb, 256)), dim3(256), 0, c->stream, mg->d_ainv, Dinv, Cp, n, kb, nb);
   }
   FH_CHECK_HIP(hipGetLastError());
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
@@ -257,9 +369,10 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
     }
     FH_TRY(fh_dev_get_diag(L.A, L.dinv, 1));
     if (l > 0) {
-      if (!L.R) {   // restriction = transpose of the interpolation (LinearImplicitSystem.cpp:379-382)
+      if (!L.R) {   // restriction = transpose of the interpolation (LinearImplicitSystem.cpp:379-382); kept across re-setups
         FH_TRY(fh_mat_transpose(L.P, &L.R));
         L.own_R = true;
+        L.R_of = L.P;
       }
       FH_REQUIRE(L.R->m == mg->lv[l - 1].n && (L.R->n == L.n || L.R->n == L.ncols), "fh_mg_setup: restriction of level %d has the wrong shape", l);
       const int64_t bA = fh_spmv_algorithmic_bytes(L.A), n8 = 8ll * L.n;
@@ -360,7 +473,10 @@ extern "C" int fh_mg_destroy(fh_mg_t mg) {
   hipStreamSynchronize(mg->ctx->stream);
   if (mg->gexec) hipGraphExecDestroy(mg->gexec);
   if (mg->graph) hipGraphDestroy(mg->graph);
-  for (auto& L : mg->lv) free_level_buffers(L);
+  for (auto& L : mg->lv) {
+    free_level_buffers(L);
+    free_level_restriction(L);
+  }
   if (mg->d_ainv) hipFree(mg->d_ainv);
   for (double* p : mg->kv) hipFree(p);
   delete mg;
