@@ -94,6 +94,7 @@ extern "C" int fh_set_option(fh_ctx_t c, const char* name, double value) {
   else if (!strcmp(name, "spmv_kernel")) c->spmv_kernel = (int)value;
   else if (!strcmp(name, "spmv_nt")) c->spmv_nt = (int)value;
   else if (!strcmp(name, "spmv_share")) c->spmv_share = (int)value;
+  else if (!strcmp(name, "spmv_threads")) c->spmv_threads = (int)value;
   else if (!strcmp(name, "assemble_emap")) c->assemble_emap = (int)value;
   else if (!strcmp(name, "asm_debug")) c->asm_debug = (int)value;
   else if (!strcmp(name, "assemble_two_pass")) c->assemble_two_pass = (int)value;

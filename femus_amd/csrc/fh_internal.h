@@ -48,6 +48,7 @@ struct fh_ctx_s {
   int spmv_tile = 2048;               // nnz per row block (LDS tile)
   int spmv_xcd_remap = 1;
   int spmv_kernel = 3;                // 0: csr-stream (workgroup tiles), 1: csr-vector, 2: csr-stream (wave tiles), 3: csr-stream with LDS-staged x
+  int spmv_threads = 256;             // kernel 3 workgroup size (128 or 256)
   int spmv_share = 1;                 // kernel 3: x tile and products share one LDS buffer
   int spmv_nt = 0;                    // non-temporal matrix stream
   int assemble_emap = 1;

@@ -517,15 +517,15 @@ int fh_mat_build_localcols(fh_mat_t A) {
 
 // SHARE: the x tile and the products use the SAME LDS buffer (one more barrier) -> half the LDS per tile, so twice the
 // matrix bytes are in flight per CU at the same residency
-template <int TILE, int MODE, bool SHARE>
-__global__ __launch_bounds__(256) void k_spmv_lx(const int* __restrict__ rowptr, const int* __restrict__ col, const unsigned short* __restrict__ lcol,
+template <int TILE, int MODE, bool SHARE, int NT>
+__global__ __launch_bounds__(NT) void k_spmv_lx(const int* __restrict__ rowptr, const int* __restrict__ col, const unsigned short* __restrict__ lcol,
                                                  const double* __restrict__ val, const int* __restrict__ rowblk, const int* __restrict__ uptr,
                                                  const int* __restrict__ ucols, int nblk, int q, const double* __restrict__ x,
                                                  double* __restrict__ y, const double* __restrict__ b, const double* __restrict__ dinv, double omega) {
   __shared__ double prod[TILE + 2];
   __shared__ double xs_own[SHARE ? 1 : TILE];
   double* xs = SHARE ? prod : xs_own;
-  __shared__ int rps[516];
+  __shared__ int rps[5 * NT + 4];
   int blk = (q > 0) ? (int)(blockIdx.x & 7) * q + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   if (blk >= nblk) return;
   const int tid = threadIdx.x;
@@ -533,28 +533,35 @@ __global__ __launch_bounds__(256) void k_spmv_lx(const int* __restrict__ rowptr,
   const int s = rowptr[r0], e = rowptr[r1];
   if (r1 - r0 == 1 && e - s > TILE) {
     double acc = 0.0;
-    for (int k = s + tid; k < e; k += 256) acc += val[k] * x[col[k]];
+    for (int k = s + tid; k < e; k += NT) acc += val[k] * x[col[k]];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((tid & 63) == 0) prod[tid >> 6] = acc;
     __syncthreads();
-    if (tid == 0) spmv_store<MODE>(prod[0] + prod[1] + prod[2] + prod[3], r0, x, y, b, dinv, omega);
+    if (tid == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < NT / 64; w++) tot += prod[w];
+      spmv_store<MODE>(tot, r0, x, y, b, dinv, omega);
+    }
     return;
   }
   // row pointers of the tile: issued now, parked in LDS before the first barrier (no dependent global load in the reduction)
   const int nrows = r1 - r0;
   int rp0 = 0, rp1 = 0, rp2 = 0;
   if (tid <= nrows) rp0 = rowptr[r0 + tid];
-  if (tid + 256 <= nrows) rp1 = rowptr[r0 + tid + 256];
-  if (tid + 512 <= nrows) rp2 = rowptr[r0 + tid + 512];
+  int rp3 = 0, rp4 = 0;
+  if (tid + NT <= nrows) rp1 = rowptr[r0 + tid + NT];
+  if (tid + 2 * NT <= nrows) rp2 = rowptr[r0 + tid + 2 * NT];
+  if (tid + 3 * NT <= nrows) rp3 = rowptr[r0 + tid + 3 * NT];
+  if (tid + 4 * NT <= nrows) rp4 = rowptr[r0 + tid + 4 * NT];
   // ---- matrix stream first (longest latency): 16 B of values + 4 B of local columns per lane and step ----
   const int s2 = s & ~1;
-  constexpr int ITER = TILE / 512 + 1;
+  constexpr int ITER = TILE / (2 * NT) + 1;
   double2 v[ITER];
   ushort2 lc[ITER];
 #pragma unroll
   for (int k = 0; k < ITER; k++) {
-    const int i = s2 + 2 * tid + k * 512;
+    const int i = s2 + 2 * tid + k * (2 * NT);
     if (i < e) {
       v[k] = *reinterpret_cast<const double2*>(val + i);
       lc[k] = *reinterpret_cast<const ushort2*>(lcol + i);
@@ -562,16 +569,18 @@ __global__ __launch_bounds__(256) void k_spmv_lx(const int* __restrict__ rowptr,
   }
   // ---- x entries of this tile -> LDS (sorted distinct columns: neighbouring lanes share cache lines) ----
   const int u0 = uptr[blk], nu = uptr[blk + 1] - u0;
-  for (int j = tid; j < nu; j += 256) xs[j] = x[ucols[u0 + j]];
+  for (int j = tid; j < nu; j += NT) xs[j] = x[ucols[u0 + j]];
   if (tid <= nrows) rps[tid] = rp0;
-  if (tid + 256 <= nrows) rps[tid + 256] = rp1;
-  if (tid + 512 <= nrows) rps[tid + 512] = rp2;
+  if (tid + NT <= nrows) rps[tid + NT] = rp1;
+  if (tid + 2 * NT <= nrows) rps[tid + 2 * NT] = rp2;
+  if (tid + 3 * NT <= nrows) rps[tid + 3 * NT] = rp3;
+  if (tid + 4 * NT <= nrows) rps[tid + 4 * NT] = rp4;
   __syncthreads();
   if (SHARE) {
     double p0[ITER], p1[ITER];
 #pragma unroll
     for (int k = 0; k < ITER; k++) {
-      const int i = s2 + 2 * tid + k * 512;
+      const int i = s2 + 2 * tid + k * (2 * NT);
       p0[k] = p1[k] = 0.0;
       if (i < e) {
         p0[k] = v[k].x * xs[lc[k].x];
@@ -581,7 +590,7 @@ __global__ __launch_bounds__(256) void k_spmv_lx(const int* __restrict__ rowptr,
     __syncthreads();                      // every lane has read its x values: the buffer may now hold the products
 #pragma unroll
     for (int k = 0; k < ITER; k++) {
-      const int i = s2 + 2 * tid + k * 512;
+      const int i = s2 + 2 * tid + k * (2 * NT);
       if (i < e) {
         if (i >= s) prod[i - s] = p0[k];
         if (i + 1 < e) prod[i + 1 - s] = p1[k];
@@ -590,7 +599,7 @@ __global__ __launch_bounds__(256) void k_spmv_lx(const int* __restrict__ rowptr,
   } else {
 #pragma unroll
     for (int k = 0; k < ITER; k++) {
-      const int i = s2 + 2 * tid + k * 512;
+      const int i = s2 + 2 * tid + k * (2 * NT);
       if (i < e) {
         if (i >= s) prod[i - s] = v[k].x * xs[lc[k].x];
         if (i + 1 < e) prod[i + 1 - s] = v[k].y * xs[lc[k].y];
@@ -600,7 +609,7 @@ __global__ __launch_bounds__(256) void k_spmv_lx(const int* __restrict__ rowptr,
   __syncthreads();
   const int G = (nrows <= 16) ? 16 : (nrows <= 32) ? 8 : (nrows <= 64) ? 4 : (nrows <= 128) ? 2 : 1;
   const int gl = tid & (G - 1);
-  const int rows_per_pass = 256 / G;
+  const int rows_per_pass = NT / G;
   const int npass = (nrows + rows_per_pass - 1) / rows_per_pass;
   for (int p = 0; p < npass; p++) {
     const int rr = p * rows_per_pass + tid / G;
@@ -616,7 +625,7 @@ __global__ __launch_bounds__(256) void k_spmv_lx(const int* __restrict__ rowptr,
   }
 }
 
-template <int TILE>
+template <int TILE, int NT>
 static void launch_lx(fh_mat_t A, int mode, const double* x, double* y, const double* b, const double* dinv, double omega) {
   fh_ctx_t c = A->ctx;
   int q = 0, grid = A->nblk;
@@ -625,8 +634,8 @@ static void launch_lx(fh_mat_t A, int mode, const double* x, double* y, const do
     grid = 8 * q;
   }
 #define FH_LAUNCH(MODE, SH) \
-  hipLaunchKernelGGL((k_spmv_lx<TILE, MODE, SH>), dim3(grid), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_lcol, A->d_val, A->d_rowblk, \
-                     A->d_uptr, A->d_ucols, A->nblk, q, x, y, b, dinv, omega)
+  hipLaunchKernelGGL((k_spmv_lx<TILE, MODE, SH, NT>), dim3(grid), dim3(NT), 0, c->stream, A->d_rowptr, A->d_col, A->d_lcol, A->d_val, \
+                     A->d_rowblk, A->d_uptr, A->d_ucols, A->nblk, q, x, y, b, dinv, omega)
   if (c->spmv_share) {
     switch (mode) {
       case 0: FH_LAUNCH(0, true); break;
@@ -960,9 +969,15 @@ int fh_dev_spmv(fh_mat_t A, const double* x, double* y, int mode, const double* 
     FH_REQUIRE(c->spmv_tile == 1024 || c->spmv_tile == 2048 || c->spmv_tile == 4096, "spmv_kernel 3 needs spmv_tile 1024, 2048 or 4096");
     if (A->tile != c->spmv_tile || (A->tile_kernel != 3 && A->tile_kernel != 4)) FH_TRY(fh_mat_build_rowblocks(A, c->spmv_tile));
     if (A->lx_tile != A->tile) FH_TRY(fh_mat_build_localcols(A));
-    if (A->tile == 1024) launch_lx<1024>(A, mode, x, y, b, dinv, omega);
-    else if (A->tile == 2048) launch_lx<2048>(A, mode, x, y, b, dinv, omega);
-    else launch_lx<4096>(A, mode, x, y, b, dinv, omega);
+    if (c->spmv_threads == 128) {
+      if (A->tile == 1024) launch_lx<1024, 128>(A, mode, x, y, b, dinv, omega);
+      else if (A->tile == 2048) launch_lx<2048, 128>(A, mode, x, y, b, dinv, omega);
+      else launch_lx<4096, 128>(A, mode, x, y, b, dinv, omega);
+    } else {
+      if (A->tile == 1024) launch_lx<1024, 256>(A, mode, x, y, b, dinv, omega);
+      else if (A->tile == 2048) launch_lx<2048, 256>(A, mode, x, y, b, dinv, omega);
+      else launch_lx<4096, 256>(A, mode, x, y, b, dinv, omega);
+    }
   } else {
     if (A->tile != c->spmv_tile || A->tile_kernel != 0) FH_TRY(fh_mat_build_rowblocks(A, c->spmv_tile));
     FH_REQUIRE(A->tile >= 1024, "spmv_kernel 0 needs spmv_tile >= 1024");

@@ -21,11 +21,11 @@ for name, c in (("femus", col), ("local0..len", col_local), ("banded row+k", col
     A = ctx.matrix_csr(n, n, rp, c, val)
     x, y = ctx.vector_from(xs), ctx.vector(n)
     by = A.spmv_algorithmic_bytes()
-    for kernel, tile, share in ((3, 1024, 0), (3, 1024, 1), (3, 2048, 1), (3, 4096, 1)):
-        ctx.set_option("spmv_kernel", kernel); ctx.set_option("spmv_tile", tile); ctx.set_option("spmv_share", share)
+    for kernel, tile, share, nt in ((3, 2048, 1, 256), (3, 1024, 1, 128), (3, 2048, 1, 128), (3, 1024, 1, 256)):
+        ctx.set_option("spmv_kernel", kernel); ctx.set_option("spmv_tile", tile); ctx.set_option("spmv_share", share); ctx.set_option("spmv_threads", nt)
         for _ in range(3): y.matrix_mult(x, A)
         ctx.timer_start()
         for _ in range(20): y.matrix_mult(x, A)
         ms = ctx.timer_stop() / 20
-        print("%-14s kernel=%d tile=%d share=%d  %.3f ms  %.0f GB/s" % (name, kernel, tile, share, ms, by / ms / 1e6), flush=True)
+        print("%-14s kernel=%d tile=%d share=%d nt=%d  %.3f ms  %.0f GB/s" % (name, kernel, tile, share, nt, ms, by / ms / 1e6), flush=True)
     A.destroy()
