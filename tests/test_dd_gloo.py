@@ -75,7 +75,7 @@ def _worker(rank, world, port, nb, nlevels, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_distributed_vcycle_matches_serial_oracle(tmp_path, world):
     import torch.multiprocessing as mp
     nb, nlevels = 2, 2
