@@ -90,6 +90,7 @@ def _declare(L):
     sig("fh_mat_get_diagonal", c_void_p, c_void_p)
     sig("fh_mat_transpose", c_void_p, P(c_void_p))
     sig("fh_mat_ptap", c_void_p, c_void_p, P(c_void_p))
+    sig("fh_mat_matmul", c_void_p, c_void_p, P(c_void_p))
     sig("fh_mat_norm", c_void_p, c_int, P(c_double))
     sig("fh_spmv", c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_double)
     sig("fh_spmv_transpose", c_void_p, c_void_p, c_void_p)

@@ -316,6 +316,20 @@ class Mat:
         _chk(P.L.fh_mat_ptap(P.h, A.h, ctypes.byref(h)))
         return cls(P.ctx, h)
 
+    def matmul(self, B):
+        """C = self * B (SpGEMM)"""
+        h = ctypes.c_void_p()
+        _chk(self.L.fh_mat_matmul(self.h, B.h, ctypes.byref(h)))
+        return Mat(self.ctx, h)
+
+    @classmethod
+    def matrix_ABC(cls, A, B, C):
+        """SparseMatrix::matrix_ABC (SparseMatrix.hpp:186): A*B*C"""
+        AB = A.matmul(B)
+        out = AB.matmul(C)
+        AB.destroy()
+        return out
+
     def ptap_numeric(self, P, A):
         h = ctypes.c_void_p(self.h.value if isinstance(self.h, ctypes.c_void_p) else self.h)
         _chk(self.L.fh_mat_ptap(P.h, A.h, ctypes.byref(h)))

@@ -237,6 +237,23 @@ void HipMatrix::matrix_PtAP(const SparseMatrix& P, const SparseMatrix& A, const 
   fh_mat_size(_A, &_m, &_n, nullptr);
   _closed = true;
 }
+void HipMatrix::matrix_ABC(const SparseMatrix& A, const SparseMatrix& B, const SparseMatrix& C, const bool&) {
+  fh_mat_t ab = nullptr, abc = nullptr;
+  hip_check(fh_mat_matmul(hm(A).handle(), hm(B).handle(), &ab), "matrix_ABC");
+  hip_check(fh_mat_matmul(ab, hm(C).handle(), &abc), "matrix_ABC");
+  fh_mat_destroy(ab);
+  adopt(abc);
+}
+void HipMatrix::matrix_RightMatMult(const SparseMatrix& A) {
+  fh_mat_t out = nullptr;
+  hip_check(fh_mat_matmul(handle(), hm(A).handle(), &out), "matrix_RightMatMult");
+  adopt(out);
+}
+void HipMatrix::matrix_LeftMatMult(const SparseMatrix& A) {
+  fh_mat_t out = nullptr;
+  hip_check(fh_mat_matmul(hm(A).handle(), handle(), &out), "matrix_LeftMatMult");
+  adopt(out);
+}
 void HipMatrix::matrix_get_diagonal_values(const std::vector<int>& index, std::vector<double>& value) const {
   value.resize(index.size());
   for (size_t k = 0; k < index.size(); k++) value[k] = (*this)(index[k], index[k]);
@@ -299,14 +316,15 @@ void LinearEquationSolverHip::MGSetLevel(LinearEquationSolver* LinSolver, const 
     _solver_type = RICHARDSON;
     _richardsonScaleFactor = 1.;
   }
-  if (_level != 0 && _preconditioner_type != JACOBI_PRECOND) {
-    std::cout << "HIP backend: level smoother must be RICHARDSON + JACOBI_PRECOND" << std::endl;
+  if (_level != 0 && _preconditioner_type != JACOBI_PRECOND && _preconditioner_type != SOR_PRECOND) {
+    std::cout << "HIP backend: level smoother must be RICHARDSON + JACOBI_PRECOND or SOR_PRECOND" << std::endl;
     abort();
   }
+  const int smoother = (_preconditioner_type == SOR_PRECOND) ? FH_SMOOTH_GS_COLOR : FH_SMOOTH_JACOBI;
   fh_mat_t P = PP ? static_cast<HipMatrix*>(PP)->handle() : nullptr;
   fh_mat_t R = (RR && RR != PP) ? static_cast<HipMatrix*>(RR)->handle() : nullptr;   // RR == PP means "use PP^T"
   hip_check(fh_mg_set_level(top->_mg, (int)_level, static_cast<HipMatrix*>(_KK)->handle(), _level ? P : nullptr, _level ? R : nullptr,
-                            FH_SMOOTH_JACOBI, _richardsonScaleFactor, (int)npre, (int)npost),
+                            smoother, _richardsonScaleFactor, (int)npre, (int)npost),
             "MGSetLevel");
   top->_needs_setup = true;
 }

@@ -94,6 +94,9 @@ class HipMatrix : public SparseMatrix {
   void add_matrix_blocked(const std::vector<double>& mat_value, const std::vector<int>& rows, const std::vector<int>& cols) override;
   void add_matrix_blocked(const std::vector<double>& mat_value, const std::vector<unsigned>& rows, const std::vector<unsigned>& cols) override;
   void matrix_PtAP(const SparseMatrix& mat_P, const SparseMatrix& mat_A, const bool& reuse) override;
+  void matrix_ABC(const SparseMatrix& mat_A, const SparseMatrix& mat_B, const SparseMatrix& mat_C, const bool& reuse) override;
+  void matrix_RightMatMult(const SparseMatrix& mat_A) override;
+  void matrix_LeftMatMult(const SparseMatrix& mat_A) override;
   void matrix_get_diagonal_values(const std::vector<int>& index, std::vector<double>& value) const override;
   double l1_norm() const override;
   double linfty_norm() const override;

@@ -32,6 +32,9 @@ class SparseMatrix {
   virtual void add_matrix_blocked(const std::vector<double>& mat_value, const std::vector<unsigned>& rows,
                                   const std::vector<unsigned>& cols) = 0;                                       // :169
   virtual void matrix_PtAP(const SparseMatrix& mat_P, const SparseMatrix& mat_A, const bool& reuse) = 0;        // :183
+  virtual void matrix_ABC(const SparseMatrix& mat_A, const SparseMatrix& mat_B, const SparseMatrix& mat_C, const bool& reuse) = 0;    // :186
+  virtual void matrix_RightMatMult(const SparseMatrix& mat_A) = 0;                                              // :189  this = this * A
+  virtual void matrix_LeftMatMult(const SparseMatrix& mat_A) = 0;                                               // :191  this = A * this
   virtual void matrix_get_diagonal_values(const std::vector<int>& index, std::vector<double>& value) const = 0; // :195
   virtual double l1_norm() const = 0;
   virtual double linfty_norm() const = 0;

@@ -592,7 +592,7 @@ __global__ __launch_bounds__(64) void k_elem_q2hex_sym(AsmParams P) {
       if (part == 0) ws[q] = weight;
     }
     wave_lds_sync();
-    if (tlive) {
+    if (tlive && !(P.debug & 4)) {
 #pragma unroll 2
       for (int gq = 0; gq < GC; gq++) {
         const double wq = ws[gq];

@@ -27,6 +27,10 @@ struct MgLevel {
   int n = 0, smoother = 0, npre = 2, npost = 2;
   double omega = 2.0 / 3.0;
   double *dinv = nullptr, *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;
+  // multicolour Gauss-Seidel (SOR) smoother: rows grouped by colour of the matrix graph
+  int ncolors = 0;
+  std::vector<int> color_ptr;
+  int* d_color_rows = nullptr;
   // distributed level: operator = owned rows over [owned | ghost] columns; halo refreshes the ghosts
   fh_halo_t halo = nullptr;
   bool replicated_below = false;
@@ -53,6 +57,26 @@ struct fh_mg_s {
 __global__ __launch_bounds__(256) void k_first_sweep(double* __restrict__ x, const double* __restrict__ b, const double* __restrict__ dinv,
                                                      double omega, int n) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) x[i] = omega * dinv[i] * b[i];
+}
+
+// one colour of a Gauss-Seidel sweep on A z = r: z_i = dinv_i (r_i - sum_{j != i} a_ij z_j) for the rows of the colour
+// (rows of one colour are mutually uncoupled, so the in-place update is race-free); 16 lanes per row
+__global__ __launch_bounds__(256) void k_gs_color(const int* __restrict__ rows, int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                  const double* __restrict__ val, const double* __restrict__ dinv, const double* __restrict__ r,
+                                                  double* z) {
+  const int rr = (blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int gl = threadIdx.x & 15;
+  const bool live = rr < nrows;
+  const int i = live ? rows[rr] : 0;
+  double acc = 0.0;
+  if (live)
+    for (int k = rowptr[i] + gl; k < rowptr[i + 1]; k += 16) {
+      const int j = col[k];
+      if (j != i) acc += val[k] * z[j];
+    }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (live && gl == 0) z[i] = dinv[i] * (r[i] - acc);
 }
 
 // y = Ainv b, one wave per row, 16-byte loads
@@ -265,7 +289,7 @@ extern "C" int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh
   FH_REQUIRE(A->m <= A->n, "fh_mg_set_level: operator must be square (or owned rows x local columns on a distributed level)");
   FH_REQUIRE(level == 0 || P != nullptr, "fh_mg_set_level: level %d needs an interpolation matrix", level);
   FH_REQUIRE(!P || P->m == A->m, "fh_mg_set_level: interpolation has %d rows, operator has %d", P ? P->m : 0, A->m);
-  FH_REQUIRE(smoother == FH_SMOOTH_JACOBI, "fh_mg_set_level: only the Richardson+Jacobi smoother is implemented (got %d)", smoother);
+  FH_REQUIRE(smoother == FH_SMOOTH_JACOBI || smoother == FH_SMOOTH_GS_COLOR, "fh_mg_set_level: unknown smoother %d (0 = Richardson+Jacobi, 1 = Richardson+multicolour SOR)", smoother);
   FH_REQUIRE(npre >= 0 && npost >= 0, "fh_mg_set_level: negative sweep count");
   MgLevel& L = mg->lv[level];
   if (L.own_R && (R != nullptr || L.R_of != P)) free_level_restriction(L);
@@ -296,6 +320,12 @@ static void free_level_buffers(MgLevel& L) {
       hipFree(*p);
       *p = nullptr;
     }
+}
+
+static void free_level_colors(MgLevel& L) {
+  if (L.d_color_rows) hipFree(L.d_color_rows);
+  L.d_color_rows = nullptr;
+  L.ncolors = 0;
 }
 
 static void free_level_restriction(MgLevel& L) {
@@ -337,6 +367,34 @@ static int coarse_factor(fh_mg_t mg) {
 
 static int run_cycle(fh_mg_t mg);
 
+// greedy colouring of the matrix graph (host, integer setup work): coupled rows get different colours
+static int color_rows(MgLevel& L) {
+  fh_mat_t A = L.A;
+  const int m = A->m;
+  std::vector<int> color(m, -1), mark;
+  int nc = 0;
+  for (int i = 0; i < m; i++) {
+    mark.assign(nc + 1, 0);
+    for (int k = A->h_rowptr[i]; k < A->h_rowptr[i + 1]; k++) {
+      const int j = A->h_col[k];
+      if (j < m && j != i && color[j] >= 0) mark[color[j]] = 1;
+    }
+    int c = 0;
+    while (c < nc && mark[c]) c++;
+    color[i] = c;
+    nc = std::max(nc, c + 1);
+  }
+  L.color_ptr.assign(nc + 1, 0);
+  for (int i = 0; i < m; i++) L.color_ptr[color[i] + 1]++;
+  for (int c = 0; c < nc; c++) L.color_ptr[c + 1] += L.color_ptr[c];
+  std::vector<int> rows(m), pos(L.color_ptr.begin(), L.color_ptr.end() - 1);
+  for (int i = 0; i < m; i++) rows[pos[color[i]]++] = i;
+  FH_CHECK_HIP(hipMalloc(&L.d_color_rows, std::max(m, 1) * sizeof(int)));
+  FH_CHECK_HIP(hipMemcpy(L.d_color_rows, rows.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice));
+  L.ncolors = nc;
+  return 0;
+}
+
 extern "C" int fh_mg_setup(fh_mg_t mg) {
   fh_ctx_t c = mg->ctx;
   for (int l = 0; l < mg->nlevels; l++) FH_REQUIRE(mg->lv[l].A, "fh_mg_setup: level %d has not been set", l);
@@ -368,6 +426,7 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
       FH_CHECK_HIP(hipMemsetAsync(*p, 0, nb, c->stream));
     }
     FH_TRY(fh_dev_get_diag(L.A, L.dinv, 1));
+    if (L.smoother == FH_SMOOTH_GS_COLOR && l > 0 && L.ncolors == 0) FH_TRY(color_rows(L));
     if (l > 0) {
       if (!L.R) {   // restriction = transpose of the interpolation (LinearImplicitSystem.cpp:379-382); kept across re-setups
         FH_TRY(fh_mat_transpose(L.P, &L.R));
@@ -400,6 +459,34 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
   return 0;
 }
 
+// Richardson(scale omega) + multicolour symmetric SOR: x <- x + omega * B (b - A x), B = forward then backward Gauss-Seidel
+// sweep over the colours from a zero guess (PCSOR's local symmetric sweep, PetscPreconditioner.cpp:219-222, in colour order)
+static int gs_sweeps(fh_mg_t mg, MgLevel& L, int nsweeps, bool zero_guess) {
+  fh_ctx_t c = mg->ctx;
+  for (int s = 0; s < nsweeps; s++) {
+    const bool first = zero_guess && s == 0;
+    if (first) {
+      FH_CHECK_HIP(hipMemcpyAsync(L.r, L.b, (size_t)L.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+      if (L.halo) FH_TRY(fh_halo_update_ptr(L.halo, L.x, L.n));
+      FH_TRY(fh_dev_spmv(L.A, L.x, L.r, 2, L.b, nullptr, 0.0));
+    }
+    double* z = L.x2;
+    FH_CHECK_HIP(hipMemsetAsync(z, 0, (size_t)L.ncols * sizeof(double), c->stream));
+    for (int pass = 0; pass < 2; pass++)
+      for (int k = 0; k < L.ncolors; k++) {
+        const int col = pass == 0 ? k : L.ncolors - 1 - k;
+        const int nr = L.color_ptr[col + 1] - L.color_ptr[col];
+        if (nr == 0) continue;
+        hipLaunchKernelGGL(k_gs_color, dim3(fh_div_up((int64_t)nr * 16, 256)), dim3(256), 0, c->stream, L.d_color_rows + L.color_ptr[col], nr,
+                           L.A->d_rowptr, L.A->d_col, L.A->d_val, L.dinv, L.r, z);
+      }
+    hipLaunchKernelGGL(k_axpby2, dim3(sgrid(c, L.n)), dim3(256), 0, c->stream, L.x, z, L.omega, first ? 0.0 : 1.0, L.n);
+  }
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // one multiplicative V-cycle on the internal buffers: input lv[top].b, output lv[top].x
 // distributed levels: ghosts of the operand are refreshed before every operator application (MPIAIJ MatMult semantics)
 static int run_cycle(fh_mg_t mg) {
@@ -409,6 +496,9 @@ static int run_cycle(fh_mg_t mg) {
     MgLevel& L = mg->lv[l];
     if (L.npre == 0) {
       FH_CHECK_HIP(hipMemsetAsync(L.x, 0, (size_t)L.ncols * sizeof(double), c->stream));
+    } else if (L.smoother == FH_SMOOTH_GS_COLOR) {
+      FH_TRY(gs_sweeps(mg, L, L.npre, true));
+      if (L.halo) FH_TRY(fh_halo_update_ptr(L.halo, L.x, L.n));
     } else {
       // sweep 1 from a zero guess: x = omega D^-1 b ; sweeps 2..npre: fused Jacobi SpMV, ping-pong x <-> x2
       hipLaunchKernelGGL(k_first_sweep, dim3(sgrid(c, L.n)), dim3(256), 0, c->stream, L.x, L.b, L.dinv, L.omega, L.n);
@@ -433,6 +523,10 @@ static int run_cycle(fh_mg_t mg) {
     MgLevel& Lc = mg->lv[l - 1];
     if (Lc.halo) FH_TRY(fh_halo_update_ptr(Lc.halo, Lc.x, Lc.n));                    // interpolation reads ghost coarse values
     FH_TRY(fh_dev_spmv(L.P, Lc.x, L.x, 1, nullptr, nullptr, 0.0));                   // x += P x_{l-1}
+    if (L.smoother == FH_SMOOTH_GS_COLOR) {
+      FH_TRY(gs_sweeps(mg, L, L.npost, false));
+      continue;
+    }
     for (int s = 0; s < L.npost; s++) {
       if (L.halo) FH_TRY(fh_halo_update_ptr(L.halo, L.x, L.n));
       FH_TRY(fh_dev_spmv(L.A, L.x, L.x2, 3, L.b, L.dinv, L.omega));
@@ -476,6 +570,7 @@ extern "C" int fh_mg_destroy(fh_mg_t mg) {
   for (auto& L : mg->lv) {
     free_level_buffers(L);
     free_level_restriction(L);
+    free_level_colors(L);
   }
   if (mg->d_ainv) hipFree(mg->d_ainv);
   for (double* p : mg->kv) hipFree(p);

@@ -135,3 +135,15 @@ extern "C" int fh_mat_ptap(fh_mat_t P, fh_mat_t A, fh_mat_t* Cio) {
   FH_TRY(spgemm_numeric(R, plan->AP, C));
   return 0;
 }
+
+extern "C" int fh_mat_matmul(fh_mat_t A, fh_mat_t B, fh_mat_t* Cout) {
+  FH_REQUIRE(A && B && Cout, "fh_mat_matmul: null argument");
+  FH_REQUIRE(A->n == B->m, "fh_mat_matmul: shapes do not conform (A %dx%d, B %dx%d)", A->m, A->n, B->m, B->n);
+  std::vector<int> rp, col;
+  spgemm_symbolic(A->m, B->n, A->h_rowptr, A->h_col, B->h_rowptr, B->h_col, rp, col);
+  fh_mat_t C = nullptr;
+  FH_TRY(fh_mat_create_csr(A->ctx, A->m, B->n, rp.data(), col.data(), nullptr, &C));
+  FH_TRY(spgemm_numeric(A, B, C));
+  *Cout = C;
+  return 0;
+}

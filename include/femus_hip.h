@@ -102,6 +102,9 @@ int fh_mat_get_diagonal(fh_mat_t A, fh_vec_t d);                 /* get_diagonal
 int fh_mat_transpose(fh_mat_t A, fh_mat_t* At);                  /* get_transpose :227 (PetscMatrix.cpp:1031-1070) */
 /* matrix_PtAP(P, A, reuse) :183 (PetscMatrix.cpp:733-751): C = P^T A P.  *C==NULL: symbolic+numeric; else numeric reuse */
 int fh_mat_ptap(fh_mat_t P, fh_mat_t A, fh_mat_t* C);
+/* general sparse product C = A*B (symbolic + numeric); matrix_ABC :186 (PetscMatrix.cpp:833-856), matrix_RightMatMult :189,
+ * matrix_LeftMatMult :191 are two / one of these */
+int fh_mat_matmul(fh_mat_t A, fh_mat_t B, fh_mat_t* C);
 int fh_mat_norm(fh_mat_t A, int kind, double* out);              /* kind 1: l1_norm :211, 0: linfty_norm :214 */
 
 /* SpMV family (NumericVector::matrix_mult :283, add_vector(v,A) :281, resid :282, matrix_mult_transpose :284;

@@ -685,7 +685,42 @@ def smooth(A, dinv, b, x, omega, nsweeps, zero_guess):
     return x
 
 
-def vcycle(H, level, b, omega=2. / 3., npre=2, npost=2, coarse_solve=None, x=None):
+def greedy_colors(A):
+    """greedy colouring of the matrix graph in row order: coupled rows get different colours"""
+    A = A.tocsr()
+    n = A.shape[0]
+    color = np.full(n, -1, dtype=np.int64)
+    nc = 0
+    for i in range(n):
+        cols = A.indices[A.indptr[i]:A.indptr[i + 1]]
+        used = set(color[cols[(cols != i) & (cols < n)]].tolist())
+        c = 0
+        while c in used:
+            c += 1
+        color[i] = c
+        nc = max(nc, c + 1)
+    return color, nc
+
+
+def smooth_sor_color(A, dinv, b, x, omega, nsweeps, zero_guess, color, nc):
+    """Richardson(omega) + one symmetric Gauss-Seidel sweep (PCSOR, omega_sor = 1) per iteration, colours in place of the
+    natural order: x <- x + omega * B (b - A x); B: z = 0, forward colours 0..nc-1, backward nc-1..0 of
+    z_i = dinv_i (r_i - sum_{j != i} a_ij z_j)."""
+    A = A.tocsr()
+    offd = A - sp.diags(A.diagonal())
+    rows_of = [np.where(color == c)[0] for c in range(nc)]
+    for it in range(nsweeps):
+        r = b.copy() if (zero_guess and it == 0) else b - A @ x
+        z = np.zeros_like(b)
+        for order in (range(nc), range(nc - 1, -1, -1)):
+            for c in order:
+                rows = rows_of[c]
+                z[rows] = dinv[rows] * (r[rows] - offd[rows] @ z)
+        x = omega * z if (zero_guess and it == 0) else x + omega * z
+    return x
+
+
+def vcycle(H, level, b, omega=2. / 3., npre=2, npost=2, coarse_solve=None, x=None, smoother="jacobi"):
     """One multiplicative V-cycle applied to rhs b, starting from x (None = zero)."""
     A = H.A[level]
     if level == 0:
@@ -698,12 +733,19 @@ def vcycle(H, level, b, omega=2. / 3., npre=2, npost=2, coarse_solve=None, x=Non
     if not hasattr(H, "_dinv"):
         H._dinv = [jacobi_dinv(a) for a in H.A]
     dinv = H._dinv[level]
-    x = smooth(A, dinv, b, np.zeros_like(b) if x is None else x, omega, npre, zero_guess=(x is None))
+    if smoother == "gs_color":
+        if not hasattr(H, "_colors"):
+            H._colors = [greedy_colors(a) for a in H.A]
+        col, nc = H._colors[level]
+        sm = lambda bb, xx, n, zg: smooth_sor_color(A, dinv, bb, xx, omega, n, zg, col, nc)
+    else:
+        sm = lambda bb, xx, n, zg: smooth(A, dinv, bb, xx, omega, n, zg)
+    x = sm(b, np.zeros_like(b) if x is None else x, npre, x is None)
     r = b - A @ x
     bc = H.P[level].T @ r
-    ec = vcycle(H, level - 1, bc, omega, npre, npost, coarse_solve)
+    ec = vcycle(H, level - 1, bc, omega, npre, npost, coarse_solve, smoother=smoother)
     x = x + H.P[level] @ ec
-    x = smooth(A, dinv, b, x, omega, npost, zero_guess=False)
+    x = sm(b, x, npost, False)
     return x
 
 

@@ -6,7 +6,7 @@ import femus_amd
 from femus_amd.poisson import PoissonMG
 ctx = femus_amd.Context(0)
 pb = PoissonMG(ctx, 8, 8, 8, 4).init()
-for dbg, name in ((0, "full"), (1, "gather+scatter only"), (2, "gather+quadrature only"), (3, "gather only")):
+for dbg, name in ((0, "full"), (1, "gather+scatter only"), (2, "gather+quadrature only"), (6, "gather+phase1 only"), (3, "gather only")):
     ctx.set_option("asm_debug", dbg)
     for _ in range(2): pb.assemble()
     ctx.timer_start()

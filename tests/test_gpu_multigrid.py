@@ -16,7 +16,7 @@ def rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-def device_hierarchy(ctx, H, omega=2. / 3., npre=2, npost=2):
+def device_hierarchy(ctx, H, omega=2. / 3., npre=2, npost=2, smoother=0):
     nl = len(H.A)
     mg = capi.Multigrid(ctx, nl)
     mats = []
@@ -24,7 +24,7 @@ def device_hierarchy(ctx, H, omega=2. / 3., npre=2, npost=2):
         A = ctx.matrix_scipy(H.A[l])
         P = ctx.matrix_scipy(H.P[l]) if l > 0 else None
         mats += [A, P]
-        mg.set_level(l, A, P, None, 0, omega, npre, npost)
+        mg.set_level(l, A, P, None, smoother, omega, npre, npost)
     mg.setup()
     return mg, mats
 
@@ -96,3 +96,30 @@ def test_gmres_restart_path(ctx, H3):
     b, x = ctx.vector_from(H3.b), ctx.vector(n)
     its, rn = mg.solve(b, x, outer="gmres", rtol=1e-11, maxit=200, restart=5)
     assert its > 5 and rel(x.to_numpy(), xd) < 1e-9
+
+
+def test_multicolour_sor_smoother(ctx, H3):
+    """Richardson + SOR_PRECOND level smoother (applications/001_Poisson/main.cpp:240-242) in its multicolour form:
+    cycle parity with the oracle's restatement and convergence of the outer solve"""
+    mg, mats = device_hierarchy(ctx, H3, 1.0, 1, 1, smoother=1)
+    n = H3.A[-1].shape[0]
+    rhs = fo.lcg_fill(n, 3)
+    b, x = ctx.vector_from(rhs), ctx.vector(n)
+    mg.vcycle(b, x)
+    ref = fo.vcycle(H3, len(H3.A) - 1, rhs, omega=1.0, npre=1, npost=1, smoother="gs_color")
+    assert rel(x.to_numpy(), ref) < 1e-11
+    xd = spla.spsolve(H3.A[-1].tocsc(), H3.b)
+    bb, xx = ctx.vector_from(H3.b), ctx.vector(n)
+    its, rn = mg.solve(bb, xx, outer="gmres", rtol=1e-12, maxit=40)
+    assert rel(xx.to_numpy(), xd) < 1e-10 and its <= 12
+    mg.destroy()
+
+
+def test_config1_richardson_sor_as_in_001_poisson(ctx):
+    """BASELINE configs[0] with the smoother choice of the reference application: RICHARDSON + SOR_PRECOND, npre = npost = 1"""
+    H = fo.build_poisson_hierarchy(8, 8, 0, 3, "linear", ONE)
+    mg, mats = device_hierarchy(ctx, H, 1.0, 1, 1, smoother=1)
+    xd = spla.spsolve(H.A[-1].tocsc(), H.b)
+    b, x = ctx.vector_from(H.b), ctx.vector(H.A[-1].shape[0])
+    its, rn = mg.solve(b, x, outer="gmres", rtol=1e-12, maxit=50)
+    assert rel(x.to_numpy(), xd) < 1e-10

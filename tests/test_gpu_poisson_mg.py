@@ -31,6 +31,10 @@ def test_ptap_matches_scipy(ctx):
     assert abs(C.to_scipy() - 2.0 * ref).max() <= 1e-13 * abs(ref).max()
     C.ptap_numeric(P, A)
     assert np.array_equal(v1, C.values())
+    # general products: matrix_ABC (R A P with an explicit restriction) and plain SpGEMM
+    R = P.get_transpose()
+    C3 = capi.Mat.matrix_ABC(R, A, P)
+    assert abs(C3.to_scipy() - 2.0 * ref).max() <= 1e-13 * abs(ref).max()
     # rectangular / ragged P
     rng = np.random.default_rng(2)
     import scipy.sparse as sp
