@@ -116,6 +116,8 @@ def _declare(L):
     sig("fh_assemble_poisson", c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p)
     sig("fh_assembler_info", c_void_p, P(c_int), P(ctypes.c_int64), P(c_double))
     sig("fh_element_matrices_poisson", c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p)
+    sig("fh_fe_face_nodes", c_int, c_int, c_int, P(c_int), c_void_p)
+    sig("fh_assemble_neumann_faces", c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p)
     sig("fh_mg_create", c_void_p, c_int, P(c_void_p))
     sig("fh_mg_set_level", c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_int)
     sig("fh_mg_setup", c_void_p)

@@ -449,6 +449,32 @@ def fe_elem_prolongator(geom, fe):
     return P
 
 
+def fe_face_nodes(geom, fe, face):
+    L = load_library()
+    n = ctypes.c_int()
+    out = np.empty(9, np.int32)
+    _chk(L.fh_fe_face_nodes(GEOM[geom], FE[fe], int(face), ctypes.byref(n), _p(out)))
+    return out[:n.value].copy()
+
+
+def assemble_neumann(ctx, mesh, fe, res, flux_by_flag, order="seventh"):
+    """boundary term of 001_Poisson: faces whose boundary flag is a key of flux_by_flag carry the Neumann flux tau"""
+    ed, xy, ff = mesh.arrays()
+    faces, taus = [], []
+    for f in range(mesh.nfaces):
+        loc = fe_face_nodes(mesh.geom, fe, f)
+        for flag, tau in flux_by_flag.items():
+            els = np.where(ff[:, f] == flag)[0]
+            if els.size:
+                faces.append(ed[els][:, loc])
+                taus.append(np.full(els.size, float(tau)))
+    if not faces:
+        return
+    fn, tv = _i32(np.concatenate(faces)), _f64(np.concatenate(taus))
+    xy = _f64(xy)
+    _chk(ctx.L.fh_assemble_neumann_faces(ctx.h, GEOM[mesh.geom], FE[fe], GAUSS_ORDER[order], fn.shape[0], _p(fn), _p(tv), xy.shape[0], _p(xy), res.h))
+
+
 def build_prolongator(ctx, coarse, fine, fe, zero_bdc=True):
     h = ctypes.c_void_p()
     _chk(ctx.L.fh_build_prolongator(ctx.h, coarse.h, fine.h, FE[fe], 1 if zero_bdc else 0, ctypes.byref(h)))

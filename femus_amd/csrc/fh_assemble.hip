@@ -906,3 +906,143 @@ extern "C" int fh_assembler_info(fh_assembler_t as, int* ncolors, int64_t* algor
     *flops = (double)as->nel * ng * (nc * dim * dim * 2.0 + 60.0 + nc * dim * dim * 2.0 + (double)nc * nc * (dim * 2.0 + 2.0) + nc * 10.0);
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Neumann boundary faces (a5: elem_type::JacobianSur).  One thread per boundary node: it owns the node's (face, local i)
+// pairs (ascending face order) and integrates phi_i * tau over each face with the face element's quadrature.
+// ------------------------------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ __launch_bounds__(128) void k_neumann(const int* __restrict__ node_ptr, const int* __restrict__ node_id, const int* __restrict__ pairs,
+                                                 int nbn, const int* __restrict__ face_nodes, int nfn, const double* __restrict__ tau,
+                                                 const double* __restrict__ coords, const double* __restrict__ w, const double* __restrict__ phi,
+                                                 const double* __restrict__ dphi, int ng, double* __restrict__ res) {
+  const int t = blockIdx.x * 128 + threadIdx.x;
+  if (t >= nbn) return;
+  double total = 0.0;
+  for (int p = node_ptr[t]; p < node_ptr[t + 1]; p++) {
+    const int f = pairs[p] >> 4, i = pairs[p] & 15;
+    const int* fn = face_nodes + (size_t)f * nfn;
+    double acc = 0.0;
+    for (int g = 0; g < ng; g++) {
+      double weight;
+      if (DIM == 3) {   // quad face in 3-D: tangents, normal = t1 x t2, det = |normal|  (ElemType.hpp:1330-1380)
+        double J[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+        for (int n = 0; n < nfn; n++) {
+          const double dx = dphi[((size_t)g * nfn + n) * 2 + 0], dy = dphi[((size_t)g * nfn + n) * 2 + 1];
+          const double* x = coords + (size_t)fn[n] * 3;
+          for (int d = 0; d < 3; d++) {
+            J[d][0] += dx * x[d];
+            J[d][1] += dy * x[d];
+          }
+        }
+        const double nx = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+        const double ny = J[0][1] * J[2][0] - J[2][1] * J[0][0];
+        const double nz = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+        const double inv = 1.0 / sqrt(nx * nx + ny * ny + nz * nz);
+        const double n0 = nx * inv, n1 = ny * inv, n2 = nz * inv;
+        const double det = J[0][0] * (J[1][1] * n2 - n1 * J[2][1]) + J[0][1] * (n1 * J[2][0] - J[1][0] * n2) + n0 * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+        weight = det * w[g];
+      } else {          // edge in 2-D (ElemType.hpp:1089-1138)
+        double j0 = 0.0, j1 = 0.0;
+        for (int n = 0; n < nfn; n++) {
+          const double dx = dphi[(size_t)g * nfn + n];
+          const double* x = coords + (size_t)fn[n] * 2;
+          j0 += dx * x[0];
+          j1 += dx * x[1];
+        }
+        const double modn = sqrt(j0 * j0 + j1 * j1);
+        const double n0 = j1 / modn, n1 = -j0 / modn;
+        const double det = j0 * (-n1) - (-n0) * j1;
+        weight = det * w[g];
+      }
+      acc += phi[(size_t)g * nfn + i] * tau[f] * weight;
+    }
+    total += acc;
+  }
+  res[node_id[t]] += total;
+}
+
+extern "C" int fh_assemble_neumann_faces(fh_ctx_t ctx, int geom, int fe, int order, int nfaces, const int* face_nodes, const double* tau, int nnode,
+                                         const double* coords, fh_vec_t res) {
+  FH_REQUIRE(ctx && res && (nfaces == 0 || (face_nodes && tau && coords)), "fh_assemble_neumann_faces: null argument");
+  FH_REQUIRE(geom == 0 || geom == 1, "fh_assemble_neumann_faces: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(fe == 0 || fe == 2, "fh_assemble_neumann_faces: fe must be 0 or 2");
+  if (nfaces == 0) return 0;
+  const int dim = fhfe::dim_of(geom);
+  const int fgeom = (geom == fhfe::GEOM_HEX) ? fhfe::GEOM_QUAD : fhfe::GEOM_LINE;
+  int tmp[9];
+  const int nfn = fhfe::face_nodes(geom, fe, 0, tmp);
+  // face element tables (quad: the 2-D tables; line: 1-D Lagrange at the 1-D Gauss points)
+  std::vector<double> w, phi, dphi;
+  if (fgeom == fhfe::GEOM_QUAD) {
+    FH_REQUIRE(fhfe::shape_tables(fhfe::GEOM_QUAD, fe, order, w, phi, dphi) == 0, "fh_assemble_neumann_faces: unsupported Gauss rule");
+  } else {
+    const int ng1 = order + 1;
+    w.resize(ng1);
+    std::vector<double> x1(ng1);
+    FH_REQUIRE(fhfe::gauss_table(fhfe::GEOM_LINE, order, w.data(), x1.data()) == 0, "fh_assemble_neumann_faces: unsupported Gauss rule");
+    phi.resize((size_t)ng1 * nfn);
+    dphi.resize((size_t)ng1 * nfn);
+    for (int g = 0; g < ng1; g++) {
+      const double x = x1[g];
+      if (fe == 0) {   // LineLinear: nodes -1, +1 (Edge.hpp:72-78)
+        phi[g * 2 + 0] = 0.5 * (1. - x);  phi[g * 2 + 1] = 0.5 * (1. + x);
+        dphi[g * 2 + 0] = -0.5;           dphi[g * 2 + 1] = 0.5;
+      } else {         // LineBiquadratic: nodes -1, +1, 0 (Edge.hpp:94-100)
+        phi[g * 3 + 0] = 0.5 * x * (x - 1.);  phi[g * 3 + 1] = 0.5 * x * (1. + x);  phi[g * 3 + 2] = (1. - x) * (1. + x);
+        dphi[g * 3 + 0] = x - 0.5;            dphi[g * 3 + 1] = x + 0.5;            dphi[g * 3 + 2] = -2. * x;
+      }
+    }
+  }
+  const int ng = (int)w.size();
+  // node -> (face, i) pairs, ascending face order
+  std::vector<int> cnt(nnode + 1, 0);
+  for (size_t k = 0; k < (size_t)nfaces * nfn; k++) {
+    FH_REQUIRE(face_nodes[k] >= 0 && face_nodes[k] < nnode, "fh_assemble_neumann_faces: node id out of range");
+    cnt[face_nodes[k] + 1]++;
+  }
+  std::vector<int> node_id, node_ptr(1, 0), pairs;
+  for (int n = 0; n < nnode; n++) cnt[n + 1] += cnt[n];
+  std::vector<int> cur(cnt.begin(), cnt.end() - 1), flat(cnt[nnode]);
+  FH_REQUIRE(nfaces < (1 << 27), "fh_assemble_neumann_faces: too many faces");
+  for (int f = 0; f < nfaces; f++)
+    for (int i = 0; i < nfn; i++) flat[cur[face_nodes[(size_t)f * nfn + i]]++] = (f << 4) | i;
+  for (int n = 0; n < nnode; n++)
+    if (cnt[n + 1] > cnt[n]) {
+      node_id.push_back(n);
+      pairs.insert(pairs.end(), flat.begin() + cnt[n], flat.begin() + cnt[n + 1]);
+      node_ptr.push_back((int)pairs.size());
+    }
+  const int nbn = (int)node_id.size();
+  FH_REQUIRE(res->n_local + res->nghost > node_id.back(), "fh_assemble_neumann_faces: vector too short");
+  void* dv[8] = {nullptr};
+  auto up = [&](int slot, const void* h, size_t bytes) -> int {
+    FH_CHECK_HIP(hipMalloc(&dv[slot], bytes ? bytes : 8));
+    FH_CHECK_HIP(hipMemcpyAsync(dv[slot], h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+  };
+  FH_TRY(up(0, node_ptr.data(), node_ptr.size() * sizeof(int)));
+  FH_TRY(up(1, node_id.data(), node_id.size() * sizeof(int)));
+  FH_TRY(up(2, pairs.data(), pairs.size() * sizeof(int)));
+  FH_TRY(up(3, face_nodes, (size_t)nfaces * nfn * sizeof(int)));
+  FH_TRY(up(4, tau, (size_t)nfaces * sizeof(double)));
+  FH_TRY(up(5, coords, (size_t)nnode * dim * sizeof(double)));
+  FH_TRY(up(6, w.data(), w.size() * sizeof(double)));
+  std::vector<double> tab(phi);
+  tab.insert(tab.end(), dphi.begin(), dphi.end());
+  FH_TRY(up(7, tab.data(), tab.size() * sizeof(double)));
+  const double* d_phi = (const double*)dv[7];
+  const double* d_dphi = d_phi + phi.size();
+  const dim3 grid(fh_div_up(nbn, 128)), block(128);
+  if (dim == 3)
+    hipLaunchKernelGGL(k_neumann<3>, grid, block, 0, ctx->stream, (const int*)dv[0], (const int*)dv[1], (const int*)dv[2], nbn, (const int*)dv[3], nfn,
+                       (const double*)dv[4], (const double*)dv[5], (const double*)dv[6], d_phi, d_dphi, ng, res->d);
+  else
+    hipLaunchKernelGGL(k_neumann<2>, grid, block, 0, ctx->stream, (const int*)dv[0], (const int*)dv[1], (const int*)dv[2], nbn, (const int*)dv[3], nfn,
+                       (const double*)dv[4], (const double*)dv[5], (const double*)dv[6], d_phi, d_dphi, ng, res->d);
+  FH_CHECK_HIP(hipGetLastError());
+  FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  for (void* q : dv)
+    if (q) hipFree(q);
+  return 0;
+}

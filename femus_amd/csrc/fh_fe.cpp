@@ -178,6 +178,38 @@ void elem_prolongator(int geom, int fe, std::vector<double>& P) {
     }
 }
 
+int face_nodes(int geom, int fe, int face, int* out) {
+  const int d = dim_of(geom);
+  const int centre = (geom == GEOM_HEX) ? 20 + face : 4 + face;
+  int d0 = 0;
+  for (int k = 0; k < d; k++)
+    if (xc(geom, centre, k) != 0) d0 = k;
+  const int sgn = xc(geom, centre, d0);
+  const int fgeom = (geom == GEOM_HEX) ? GEOM_QUAD : GEOM_LINE;
+  const int nfn_q2 = (geom == GEOM_HEX) ? 9 : 3, nfn_q1 = (geom == GEOM_HEX) ? 4 : 2;
+  const int nfn = (fe == FE_LINEAR) ? nfn_q1 : nfn_q2;
+  // free coordinates in cyclic order after d0
+  const int a = (d0 + 1) % d, b = (d0 + 2) % d;
+  for (int i = 0; i < nfn; i++) {
+    int xi, eta = 0;
+    if (fgeom == GEOM_QUAD) {
+      xi = XC_QUAD[i][0];
+      eta = XC_QUAD[i][1];
+    } else {
+      static const int XC_LINE[3] = {-1, 1, 0};
+      xi = XC_LINE[i];
+    }
+    out[i] = -1;
+    for (int n = 0; n < nloc_of(geom); n++) {
+      if (xc(geom, n, d0) != sgn) continue;
+      if (xc(geom, n, a) != xi) continue;
+      if (d == 3 && xc(geom, n, b) != eta) continue;
+      out[i] = n;
+    }
+  }
+  return nfn;
+}
+
 }  // namespace fhfe
 
 // ---- C-ABI -------------------------------------------------------------------------------------------------
@@ -220,5 +252,16 @@ extern "C" int fh_fe_elem_prolongator(int geom, int fe, int* nchild, int* nc, do
     fhfe::elem_prolongator(geom, fe, v);
     memcpy(P, v.data(), v.size() * sizeof(double));
   }
+  return 0;
+}
+
+extern "C" int fh_fe_face_nodes(int geom, int fe, int face, int* nfn, int* local_nodes) {
+  FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_face_nodes: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(fe == 0 || fe == 2, "fh_fe_face_nodes: fe must be 0 or 2");
+  FH_REQUIRE(face >= 0 && face < fhfe::nfaces_of(geom), "fh_fe_face_nodes: face %d out of range", face);
+  int tmp[9];
+  const int n = fhfe::face_nodes(geom, fe, face, tmp);
+  if (nfn) *nfn = n;
+  if (local_nodes) memcpy(local_nodes, tmp, n * sizeof(int));
   return 0;
 }

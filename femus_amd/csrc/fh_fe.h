@@ -19,4 +19,7 @@ int shape_tables(int geom, int fe, int order, std::vector<double>& w, std::vecto
 void child_node_ref(int geom, int child, int node, double* pt);
 int fine2coarse_vertex(int geom, int child, int v);
 void elem_prolongator(int geom, int fe, std::vector<double>& P);
+// local element nodes of face f in the face element's own node order (QUAD9 / EDGE3 parametrised by the two (one) free
+// coordinates in cyclic order); returns the number of face nodes for the FE family
+int face_nodes(int geom, int fe, int face, int* out);
 }  // namespace fhfe

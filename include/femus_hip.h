@@ -162,6 +162,14 @@ int fh_assembler_info(fh_assembler_t as, int* ncolors, int64_t* algorithmic_byte
 /* element-level entry (tests): K[nel*nc*nc], F[nel*nc] for the given elements, no scatter */
 int fh_element_matrices_poisson(fh_assembler_t as, fh_vec_t sol, int source_kind, const double* params, double* K, double* F);
 
+/* Neumann boundary term of the 001_Poisson callback (applications/001_Poisson/main.cpp:560-594): for every listed boundary face
+ * res[node_i] += int_face phi_i * tau ds with elem_type::JacobianSur (ElemType.hpp:1089-1138 edges, :1330-1380 quad faces).
+ * face_nodes[nfaces*nfn]: node ids of each face in the face element's own local order (fh_fe_face_nodes), nfn = 9/4 (hex faces,
+ * Q2/Q1) or 3/2 (quad edges); tau[nfaces]: flux per face.  Contributions to a node are summed in ascending face order. */
+int fh_fe_face_nodes(int geom, int fe, int face, int* nfn, int* local_nodes);
+int fh_assemble_neumann_faces(fh_ctx_t ctx, int geom, int fe, int gauss_order, int nfaces, const int* face_nodes, const double* tau,
+                              int nnode, const double* coords, fh_vec_t res);
+
 /* ---- multigrid: LinearEquationSolver (03_solvers/LinearEquationSolver.hpp:54-261, LinearEquationSolverPetsc.cpp) ----
  * fh_mg_create      <- MGInit   (:185-215)   nlevels, outer solver
  * fh_mg_set_level   <- MGSetLevel (:219-290) operator, interpolation PP (restriction = PP^T when R==NULL,

@@ -866,3 +866,81 @@ def lcg_fill(n, seed=12345):
 def algorithmic_spmv_bytes(nnz, nrows, ncols):
     """fp64 values + int32 columns + int32 row pointers, x and y touched once."""
     return 12 * nnz + 4 * (nrows + 1) + 8 * ncols + 8 * nrows
+
+
+# ----------------------------------------------------------------------------------------------
+# a5. elem_type::JacobianSur (ElemType.hpp:1089-1138 edges in 2-D, :1330-1380 quad faces in 3-D) and the Neumann
+#     boundary term of applications/001_Poisson/main.cpp:560-594:  F[ilocal] += phi_i * tau * weight
+# ----------------------------------------------------------------------------------------------
+def face_local_nodes(geom, fe, face, table=None):
+    """element-local nodes of `face` in the face element's own node order.  table: optional explicit order
+    (e.g. the reference's hex_lag::faceDofs row); default = parametrisation by the free coordinates in cyclic order."""
+    if table is not None:
+        nfn = {("hex", "linear"): 4, ("hex", "biquadratic"): 9, ("quad", "linear"): 2, ("quad", "biquadratic"): 3}[(geom, fe)]
+        return np.asarray(table[:nfn], dtype=np.int64)
+    Xc = xc_table(geom)
+    d = Xc.shape[1]
+    centre = (20 + face) if geom == "hex" else (4 + face)
+    d0 = int(np.nonzero(Xc[centre])[0][0])
+    sgn = Xc[centre, d0]
+    if geom == "hex":
+        ref = XC_QUAD9[:4] if fe == "linear" else XC_QUAD9
+        a, b = (d0 + 1) % 3, (d0 + 2) % 3
+        return np.array([np.where((Xc[:, d0] == sgn) & (Xc[:, a] == r[0]) & (Xc[:, b] == r[1]))[0][0] for r in ref])
+    ref = np.array([-1.0, 1.0]) if fe == "linear" else np.array([-1.0, 1.0, 0.0])
+    a = (d0 + 1) % 2
+    return np.array([np.where((Xc[:, d0] == sgn) & (Xc[:, a] == r))[0][0] for r in ref])
+
+
+def jacobian_sur(geom, fe, order, vt, ig):
+    """vt[dim][nfn] face node coordinates; returns Weight, phi[nfn], normal[dim] (reference operation order)."""
+    if geom == "hex":
+        w, xg = gauss_table("quad", order)
+        phi, dphi, _ = eval_basis("quad", fe, xg[ig:ig + 1])
+        nfn = phi.shape[1]
+        J = np.zeros((3, 3))
+        for n in range(nfn):
+            for d in range(3):
+                J[d, 0] += dphi[0, n, 0] * vt[d][n]
+                J[d, 1] += dphi[0, n, 1] * vt[d][n]
+        nx = J[1, 0] * J[2, 1] - J[1, 1] * J[2, 0]
+        ny = J[0, 1] * J[2, 0] - J[2, 1] * J[0, 0]
+        nz = J[0, 0] * J[1, 1] - J[0, 1] * J[1, 0]
+        inv = 1.0 / np.sqrt(nx * nx + ny * ny + nz * nz)
+        normal = np.array([nx * inv, ny * inv, nz * inv])
+        J[:, 2] = normal
+        det = (J[0, 0] * (J[1, 1] * J[2, 2] - J[1, 2] * J[2, 1]) + J[0, 1] * (J[1, 2] * J[2, 0] - J[1, 0] * J[2, 2]) +
+               J[0, 2] * (J[1, 0] * J[2, 1] - J[1, 1] * J[2, 0]))
+        return det * w[ig], phi[0], normal
+    w, xg = gauss_table("line", order)
+    x = xg[ig, 0]
+    if fe == "linear":
+        phi = np.array([0.5 * (1. - x), 0.5 * (1. + x)])
+        dphi = np.array([-0.5, 0.5])
+    else:
+        phi = np.array([lag_biquadratic(x, 0), lag_biquadratic(x, 2), lag_biquadratic(x, 1)])
+        dphi = np.array([dlag_biquadratic(x, 0), dlag_biquadratic(x, 2), dlag_biquadratic(x, 1)])
+    j0 = sum(dphi[n] * vt[0][n] for n in range(phi.size))
+    j1 = sum(dphi[n] * vt[1][n] for n in range(phi.size))
+    modn = np.sqrt(j0 * j0 + j1 * j1)
+    normal = np.array([j1 / modn, -j0 / modn])
+    det = j0 * (-normal[1]) - (-normal[0]) * j1
+    return det * w[ig], phi, normal
+
+
+def neumann_rhs(mesh, fe, flux_by_flag, order="seventh", face_tables=None):
+    """sum over boundary faces whose flag is in flux_by_flag of  int phi_i tau ds, scattered to the nodes"""
+    geom = mesh.geom
+    out = np.zeros(n_dofs(mesh, fe))
+    ng = gauss_table("quad" if geom == "hex" else "line", order)[0].size
+    for f in range(mesh.face_flag.shape[1]):
+        loc = face_local_nodes(geom, fe, f, None if face_tables is None else face_tables[f])
+        for flag, tau in flux_by_flag.items():
+            for iel in np.where(mesh.face_flag[:, f] == flag)[0]:
+                nodes = mesh.elem_dof[iel, loc]
+                vt = [mesh.coords[nodes, d] for d in range(mesh.dim)]
+                for ig in range(ng):
+                    weight, phi, _ = jacobian_sur(geom, fe, order, vt, ig)
+                    for i in range(nodes.size):
+                        out[nodes[i]] += phi[i] * tau * weight
+    return out
