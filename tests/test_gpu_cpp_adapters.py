@@ -33,3 +33,14 @@ def test_adapter_application_matches_oracle(tmp_path, args, nl):
     sol = np.fromfile(out)
     assert sol.size == xd.size
     assert np.linalg.norm(sol - xd) <= 1e-10 * np.linalg.norm(xd)
+
+
+def test_adapter_member_units(tmp_path):
+    """every member of HipVector / HipMatrix the path uses, against hand-computed values"""
+    lib = os.path.join(ROOT, "femus_amd", "lib")
+    exe = str(tmp_path / "adapter_units")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "femus_amd", "csrc", "adapters")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "adapter_units.cpp"), "-o", exe,
+                           "-L" + lib, "-lfemus_hip_adapters", "-lfemus_hip", "-Wl,-rpath," + lib])
+    out = subprocess.run([exe], text=True, capture_output=True)
+    assert "ADAPTER UNITS OK" in out.stdout, out.stdout + out.stderr
