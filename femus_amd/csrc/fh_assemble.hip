@@ -38,8 +38,9 @@ struct fh_assembler_s {
   int* d_adj_ptr = nullptr;      // [m+1]
   int* d_adj_ei = nullptr;       // (element << 5) | local row, ascending element order
   unsigned char* d_rowmap = nullptr;   // [nadj*nc] slot of (element row, j) inside the CSR row
-  double* d_Kbuf = nullptr;      // [nel*nc*nc]
-  double* d_Fbuf = nullptr;      // [nel*nc]
+  int* d_slot = nullptr;         // [nel*nc] adjacency slot of (element, local row), -1 when the row is not in the matrix
+  double* d_Kbuf = nullptr;      // [nadj*nc] element rows in row-gather order
+  double* d_Fbuf = nullptr;      // [nadj]
   bool two_pass = false;
 };
 
@@ -65,6 +66,7 @@ struct AsmParams {
   const int* emap;         // may be null -> binary search
   int* emap_out;           // non-null: build the map instead of assembling
   int debug;               // profiling aid: bit 0 skips the quadrature loop, bit 1 skips the scatter
+  const int* slot;         // non-null with Kout: row i of element e goes to Kout[slot[e*nc+i]*nc + j] (row-gather order), -1 = skip
   double* Kout;            // non-null: write element matrices [e][nc][nc] instead of scattering
   double* Fout;
 };
@@ -310,8 +312,22 @@ __global__ __launch_bounds__(256) void k_assemble_poisson(AsmParams P) {
       if (i >= NC) continue;
 #pragma unroll
       for (int b = 0; b < TJ; b++)
-        if (j0 + b < NC) P.Kout[((size_t)eidx * NC + i) * NC + j0 + b] = K[a][b];
-      if (jb == 0) P.Fout[(size_t)eidx * NC + i] = F[a];
+        if (j0 + b < NC) {
+          if (P.slot) {
+            const int sl = P.slot[(size_t)e * NC + i];
+            if (sl >= 0) P.Kout[(size_t)sl * NC + j0 + b] = K[a][b];
+          } else {
+            P.Kout[((size_t)eidx * NC + i) * NC + j0 + b] = K[a][b];
+          }
+        }
+      if (jb == 0) {
+        if (P.slot) {
+          const int sl = P.slot[(size_t)e * NC + i];
+          if (sl >= 0) P.Fout[sl] = F[a];
+        } else {
+          P.Fout[(size_t)eidx * NC + i] = F[a];
+        }
+      }
     }
     return;
   }
@@ -399,13 +415,11 @@ __global__ __launch_bounds__(256) void k_row_assemble(const int* __restrict__ ro
         pp[t] = 0;
         f[t] = 0.0;
         if (a < a1) {
-          const int ei = adj_ei[a];
-          const int e = ei >> 5, i = ei & 31;
           if (lane < NC) {
-            k[t] = Kbuf[((size_t)e * NC + i) * NC + lane];
+            k[t] = Kbuf[(size_t)a * NC + lane];          // slot-major: the rows of one CSR row are contiguous
             pp[t] = rowmap[(size_t)a * NC + lane];
           }
-          if (lane == 0) f[t] = Fbuf[(size_t)e * NC + i];
+          if (lane == 0) f[t] = Fbuf[a];
         }
       }
 #pragma unroll
@@ -618,7 +632,14 @@ __global__ __launch_bounds__(64) void k_elem_q2hex_sym(AsmParams P) {
     wave_lds_sync();
   }
   if (!elive || !tlive || (P.debug & 2)) return;
-  double* Ke = P.Kout + (size_t)eidx * NC * NC;
+  // output: row i of K_e -> slot of (e, i) in the row-gather buffer (or the plain [e][i][j] layout when no slot map is given)
+  int sli[4], slj[4];
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    const int i = i0 + a, j = j0 + a;
+    sli[a] = (i < NC) ? (P.slot ? P.slot[(size_t)e * NC + i] : eidx * NC + i) : -1;
+    slj[a] = (j < NC) ? (P.slot ? P.slot[(size_t)e * NC + j] : eidx * NC + j) : -1;
+  }
 #pragma unroll
   for (int a = 0; a < 4; a++) {
     const int i = i0 + a;
@@ -629,15 +650,15 @@ __global__ __launch_bounds__(64) void k_elem_q2hex_sym(AsmParams P) {
       if (j >= NC) continue;
       if (ib == jb) {
         if (b >= a) {               // diagonal tile: upper entries, mirrored
-          Ke[i * NC + j] = K[a][b];
-          if (b > a) Ke[j * NC + i] = K[a][b];
+          if (sli[a] >= 0) P.Kout[(size_t)sli[a] * NC + j] = K[a][b];
+          if (b > a && slj[b] >= 0) P.Kout[(size_t)slj[b] * NC + i] = K[a][b];
         }
       } else {
-        Ke[i * NC + j] = K[a][b];
-        Ke[j * NC + i] = K[a][b];
+        if (sli[a] >= 0) P.Kout[(size_t)sli[a] * NC + j] = K[a][b];
+        if (slj[b] >= 0) P.Kout[(size_t)slj[b] * NC + i] = K[a][b];
       }
     }
-    if (ib == jb) P.Fout[(size_t)eidx * NC + i] = F[a];
+    if (ib == jb && sli[a] >= 0) P.Fout[sli[a]] = F[a];
   }
 }
 
@@ -790,18 +811,22 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
         if (r < m) aptr[r + 1]++;
       }
     for (int r = 0; r < m; r++) aptr[r + 1] += aptr[r];
-    std::vector<int> aei(aptr[m]), cur(aptr.begin(), aptr.end() - 1);
+    std::vector<int> aei(aptr[m]), cur(aptr.begin(), aptr.end() - 1), slot((size_t)nel * nc, -1);
     for (int e = 0; e < nel; e++)
       for (int i = 0; i < nc; i++) {
         const int r = elem_dof[(size_t)e * nloc + i];
-        if (r < m) aei[cur[r]++] = (e << 5) | i;
+        if (r < m) {
+          slot[(size_t)e * nc + i] = cur[r];
+          aei[cur[r]++] = (e << 5) | i;
+        }
       }
+    FH_TRY(up((void**)&as->d_slot, slot.data(), slot.size() * sizeof(int)));
     FH_REQUIRE(nel < (1 << 26), "fh_assembler_create: too many elements for the packed adjacency");
     FH_TRY(up((void**)&as->d_adj_ptr, aptr.data(), aptr.size() * sizeof(int)));
     FH_TRY(up((void**)&as->d_adj_ei, aei.data(), aei.size() * sizeof(int)));
     FH_CHECK_HIP(hipMalloc(&as->d_rowmap, std::max<size_t>((size_t)aei.size() * nc, 1)));
-    FH_CHECK_HIP(hipMalloc(&as->d_Kbuf, std::max<size_t>((size_t)nel * nc * nc, 1) * sizeof(double)));
-    FH_CHECK_HIP(hipMalloc(&as->d_Fbuf, std::max<size_t>((size_t)nel * nc, 1) * sizeof(double)));
+    FH_CHECK_HIP(hipMalloc(&as->d_Kbuf, std::max<size_t>((size_t)aei.size() * nc, 1) * sizeof(double)));
+    FH_CHECK_HIP(hipMalloc(&as->d_Fbuf, std::max<size_t>(aei.size(), 1) * sizeof(double)));
     FH_TRY(dispatch_rows(as, A, nullptr, true));
     FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     as->two_pass = true;
@@ -821,7 +846,7 @@ extern "C" int fh_assembler_destroy(fh_assembler_t as) {
   hipFree(as->d_dphi);
   if (as->d_emap) hipFree(as->d_emap);
   hipFree(as->d_iota);
-  for (void* q : {(void*)as->d_adj_ptr, (void*)as->d_adj_ei, (void*)as->d_rowmap, (void*)as->d_Kbuf, (void*)as->d_Fbuf})
+  for (void* q : {(void*)as->d_adj_ptr, (void*)as->d_adj_ei, (void*)as->d_rowmap, (void*)as->d_Kbuf, (void*)as->d_Fbuf, (void*)as->d_slot})
     if (q) hipFree(q);
   delete as;
   return 0;
@@ -843,6 +868,7 @@ extern "C" int fh_assemble_poisson(fh_assembler_t as, fh_vec_t sol, int source_k
     P.nelems = as->nel;
     P.Kout = as->d_Kbuf;
     P.Fout = as->d_Fbuf;
+    P.slot = as->d_slot;
     P.debug = as->ctx->asm_debug;
     FH_TRY(dispatch_assemble(as, P));
     if (!(as->ctx->asm_debug & 2)) FH_TRY(dispatch_rows(as, A, res->d, false));
