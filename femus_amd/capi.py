@@ -374,6 +374,40 @@ class Mesh:
         _chk(self.L.fh_mesh_refine(self.h, ctypes.byref(h)))
         return Mesh(self.L, h)
 
+    def refine_flagged(self, flags):
+        """selective refinement (MeshRefinement::RefineMesh with an AMR flag per element)"""
+        f = np.ascontiguousarray(flags, dtype=np.uint8)
+        assert f.shape == (self.nel,)
+        h = ctypes.c_void_p()
+        _chk(self.L.fh_mesh_refine_flagged(self.h, _p(f), ctypes.byref(h)))
+        return Mesh(self.L, h)
+
+    def elem_centroids(self):
+        out = np.empty((self.nel, 3))
+        _chk(self.L.fh_mesh_elem_centroids(self.h, _p(out)))
+        return out
+
+    def elem_levels(self):
+        out = np.empty(self.nel, np.int32)
+        hom = ctypes.c_int()
+        _chk(self.L.fh_mesh_elem_levels(self.h, _p(out), ctypes.byref(hom)))
+        return out, bool(hom.value)
+
+    def flag_elements(self, fn):
+        """MeshRefinement::FlagElementsToRefine type 1: fn(x[3], level) at the vertex mean of elements of the current level"""
+        xc = self.elem_centroids()
+        lev, _ = self.elem_levels()
+        return np.array([lev[e] == self.level and bool(fn(xc[e], self.level)) for e in range(self.nel)], dtype=np.uint8)
+
+    def amr_constraints(self, fe):
+        """hanging dofs and their master weights: (hanging[n], ptr[n+1], master[nnz], weight[nnz])"""
+        n, nnz = ctypes.c_int(0), ctypes.c_int(0)
+        _chk(self.L.fh_mesh_amr_constraints(self.h, FE[fe], ctypes.byref(n), ctypes.byref(nnz), None, None, None, None))
+        hang, ptr = np.empty(n.value, np.int32), np.empty(n.value + 1, np.int32)
+        master, w = np.empty(nnz.value, np.int32), np.empty(nnz.value)
+        _chk(self.L.fh_mesh_amr_constraints(self.h, FE[fe], ctypes.byref(n), ctypes.byref(nnz), _p(hang), _p(ptr), _p(master), _p(w)))
+        return hang, ptr, master, w
+
     def clear_boundary_faces(self, mask):
         _chk(self.L.fh_mesh_clear_boundary_faces(self.h, int(mask)))
 
@@ -478,6 +512,13 @@ def assemble_neumann(ctx, mesh, fe, res, flux_by_flag, order="seventh"):
 def build_prolongator(ctx, coarse, fine, fe, zero_bdc=True):
     h = ctypes.c_void_p()
     _chk(ctx.L.fh_build_prolongator(ctx.h, coarse.h, fine.h, FE[fe], 1 if zero_bdc else 0, ctypes.byref(h)))
+    return Mat(ctx, h)
+
+
+def build_amr_prolongator(ctx, mesh, fe):
+    """LinearImplicitSystem::BuildAmrProlongatorMatrix: P_amr (n x n) of a non-homogeneous level"""
+    h = ctypes.c_void_p()
+    _chk(ctx.L.fh_build_amr_prolongator(ctx.h, mesh.h, FE[fe], ctypes.byref(h)))
     return Mat(ctx, h)
 
 

@@ -94,6 +94,16 @@ struct AsmCfg {
 
 __device__ __forceinline__ double source_eval(int kind, double p0, double p1, const double* xg, int dim) {
   if (kind == 0) return p0;
+  if (kind == 3) {   // p0 * sum_d prod_{e != d} x_e (p1 - x_e): Laplacian of -(p0/2) prod_d x_d (p1 - x_d), a Q2 polynomial
+    double sum = 0.0;
+    for (int d = 0; d < dim; d++) {
+      double pr = 1.0;
+      for (int e = 0; e < dim; e++)
+        if (e != d) pr *= xg[e] * (p1 - xg[e]);
+      sum += pr;
+    }
+    return p0 * sum;
+  }
   double r = p0;
   for (int d = 0; d < dim; d++) r *= (kind == 1) ? sin(p1 * xg[d]) : cos(p1 * xg[d]);
   return r;
@@ -855,7 +865,7 @@ extern "C" int fh_assembler_destroy(fh_assembler_t as) {
 extern "C" int fh_assemble_poisson(fh_assembler_t as, fh_vec_t sol, int source_kind, const double* params, fh_mat_t A, fh_vec_t res) {
   FH_REQUIRE(as && A && res, "fh_assemble_poisson: null argument");
   FH_REQUIRE(A->m == as->ndof && res->n_local >= as->ndof, "fh_assemble_poisson: size mismatch");
-  FH_REQUIRE(source_kind >= 0 && source_kind <= 2, "fh_assemble_poisson: unknown source kind %d", source_kind);
+  FH_REQUIRE(source_kind >= 0 && source_kind <= 3, "fh_assemble_poisson: unknown source kind %d", source_kind);
   FH_REQUIRE(!sol || sol->n_local + sol->nghost >= A->n, "fh_assemble_poisson: solution vector too short (needs owned + ghost entries)");
   if (as->two_pass) {
     // pass 1: all element matrices (one launch, no colours) ; pass 2: rows gather their element rows (zeroing included)

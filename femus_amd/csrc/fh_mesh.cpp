@@ -8,6 +8,8 @@
 #include "fh_internal.h"
 #include "fh_fe.h"
 #include <algorithm>
+#include <cmath>
+#include <functional>
 #include <unordered_map>
 
 struct fh_mesh_s {
@@ -16,7 +18,10 @@ struct fh_mesh_s {
   std::vector<int> elem_dof;      // [nel*nloc]
   std::vector<double> coords;     // [nnode*dim]
   std::vector<int> face_flag;     // [nel*nfaces]
-  std::vector<int> child;         // [nel*nchild] (set by refine on the coarse mesh)
+  std::vector<int> child;         // [nel*nchild] (set by refine on the coarse mesh; -1 padded for copied elements)
+  std::vector<char> refined;      // [nel] set by refine on the coarse mesh: element was split
+  std::vector<int> elem_level;    // [nel] refinement level of every element (Elem.hpp:372-374)
+  bool homogeneous = true;        // Mesh::GetIfHomogeneous: no element of the father level was left unrefined
 };
 
 using namespace fhfe;
@@ -92,6 +97,7 @@ extern "C" int fh_mesh_box(int nx, int ny, int nz, const double lo[3], const dou
           if (i == 0) ff[3] = -5;
         }
       }
+  m->elem_level.assign(m->nel, 0);
   first_touch_renumber(*m, nnode);
   *out = m;
   return 0;
@@ -110,7 +116,10 @@ struct Key3Hash {
   }
 };
 
-extern "C" int fh_mesh_refine(fh_mesh_t mc, fh_mesh_t* out) {
+// MeshRefinement::RefineMesh (MeshRefinement.cpp:197-493) for nprocs = 1.  flags == NULL: every element is split (uniform
+// level).  Otherwise elements of the current level with a nonzero flag are split and all the others are carried over
+// unchanged (their node ids, boundary flags and level), which makes the new level non-homogeneous (AMR).
+extern "C" int fh_mesh_refine_flagged(fh_mesh_t mc, const unsigned char* flags, fh_mesh_t* out) {
   FH_REQUIRE(mc && out, "fh_mesh_refine: null argument");
   const int geom = mc->geom, dim = mc->dim, nc = mc->nloc;
   const int nv = nvert_of(geom), ne = nedge_end_of(geom), nch = nv, nf = nfaces_of(geom);
@@ -119,9 +128,20 @@ extern "C" int fh_mesh_refine(fh_mesh_t mc, fh_mesh_t* out) {
   m->dim = dim;
   m->nloc = nc;
   m->level = mc->level + 1;
-  m->nel = mc->nel * nch;
+  if (mc->elem_level.empty()) mc->elem_level.assign(mc->nel, mc->level);
+  // only elements of the current level can be refined (Elem.hpp:358-360)
+  mc->refined.assign(mc->nel, 0);
+  std::vector<int> start(mc->nel + 1, 0);
+  for (int iel = 0; iel < mc->nel; iel++) {
+    const bool r = (mc->elem_level[iel] == mc->level) && (!flags || flags[iel]);
+    mc->refined[iel] = r;
+    if (!r) m->homogeneous = false;
+    start[iel + 1] = start[iel] + (r ? nch : 1);
+  }
+  m->nel = start[mc->nel];
   m->elem_dof.assign((size_t)m->nel * nc, -1);
   m->face_flag.assign((size_t)m->nel * nf, -1);
+  m->elem_level.assign(m->nel, 0);
   // tables derived from the node coordinates
   int f2c[8][8];
   for (int j = 0; j < nch; j++)
@@ -150,24 +170,39 @@ extern "C" int fh_mesh_refine(fh_mesh_t mc, fh_mesh_t* out) {
       if (on && cnt < 4) face_v[f][cnt++] = v;
     }
   }
-  // children: vertices and boundary flags (MeshRefinement.cpp:240-278)
-  mc->child.resize((size_t)mc->nel * nch);
-  for (int iel = 0; iel < mc->nel; iel++)
-    for (int j = 0; j < nch; j++) {
-      const int jel = iel * nch + j;
-      mc->child[(size_t)iel * nch + j] = jel;
-      for (int v = 0; v < nv; v++) m->elem_dof[(size_t)jel * nc + v] = mc->elem_dof[(size_t)iel * nc + f2c[j][v]];
+  // children: vertices and boundary flags (:240-278); copies of the elements that are not refined (:296-331)
+  mc->child.assign((size_t)mc->nel * nch, -1);
+  for (int iel = 0; iel < mc->nel; iel++) {
+    if (mc->refined[iel]) {
+      for (int j = 0; j < nch; j++) {
+        const int jel = start[iel] + j;
+        mc->child[(size_t)iel * nch + j] = jel;
+        m->elem_level[jel] = mc->elem_level[iel] + 1;
+        for (int v = 0; v < nv; v++) m->elem_dof[(size_t)jel * nc + v] = mc->elem_dof[(size_t)iel * nc + f2c[j][v]];
+        for (int f = 0; f < nf; f++) {
+          int value = mc->face_flag[(size_t)iel * nf + f];
+          if (value < -1 && child_on_face[f][j]) m->face_flag[(size_t)jel * nf + f] = value;
+        }
+      }
+    } else {
+      const int jel = start[iel];
+      mc->child[(size_t)iel * nch] = jel;
+      m->elem_level[jel] = mc->elem_level[iel];
+      for (int i = 0; i < nc; i++) m->elem_dof[(size_t)jel * nc + i] = mc->elem_dof[(size_t)iel * nc + i];
       for (int f = 0; f < nf; f++) {
         int value = mc->face_flag[(size_t)iel * nf + f];
-        if (value < -1 && child_on_face[f][j]) m->face_flag[(size_t)jel * nf + f] = value;
+        if (value < -1) m->face_flag[(size_t)jel * nf + f] = value;
       }
     }
+  }
+  auto fresh = [&](int iel) { return m->elem_level[iel] == m->level; };   // GetIfFatherHasBeenRefined
   int nnodes = mc->nnode;
   // edge mid-points (:356-417): first visit in (element, local edge) order creates the node
   {
     std::unordered_map<uint64_t, int> emap;
     emap.reserve((size_t)m->nel * 4);
-    for (int iel = 0; iel < m->nel; iel++)
+    for (int iel = 0; iel < m->nel; iel++) {
+      if (!fresh(iel)) continue;
       for (int e = nv; e < ne; e++) {
         int a = m->elem_dof[(size_t)iel * nc + edge_v[e - nv][0]], b = m->elem_dof[(size_t)iel * nc + edge_v[e - nv][1]];
         if (a > b) std::swap(a, b);
@@ -176,12 +211,14 @@ extern "C" int fh_mesh_refine(fh_mesh_t mc, fh_mesh_t* out) {
         if (it == emap.end()) it = emap.emplace(key, nnodes++).first;
         m->elem_dof[(size_t)iel * nc + e] = it->second;
       }
+    }
   }
   // quad-face centres of hexahedra (:526-561): (element, face 0..5) order
   if (geom == GEOM_HEX) {
     std::unordered_map<Key3, int, Key3Hash> fmap;
     fmap.reserve((size_t)m->nel * 4);
-    for (int iel = 0; iel < m->nel; iel++)
+    for (int iel = 0; iel < m->nel; iel++) {
+      if (!fresh(iel)) continue;
       for (int f = 0; f < 6; f++) {
         int v[4];
         for (int k = 0; k < 4; k++) v[k] = m->elem_dof[(size_t)iel * nc + face_v[f][k]];
@@ -191,9 +228,11 @@ extern "C" int fh_mesh_refine(fh_mesh_t mc, fh_mesh_t* out) {
         if (it == fmap.end()) it = fmap.emplace(key, nnodes++).first;
         m->elem_dof[(size_t)iel * nc + 20 + f] = it->second;
       }
+    }
   }
   // element centres (:598-616)
-  for (int iel = 0; iel < m->nel; iel++) m->elem_dof[(size_t)iel * nc + nc - 1] = nnodes++;
+  for (int iel = 0; iel < m->nel; iel++)
+    if (fresh(iel)) m->elem_dof[(size_t)iel * nc + nc - 1] = nnodes++;
   first_touch_renumber(*m, nnodes);
   // fine coordinates = biquadratic mesh prolongator x coarse coordinates (MeshRefinement.cpp:468-475);
   // rows are sums over the coarse element nodes in increasing global column order (CSR order)
@@ -204,10 +243,20 @@ extern "C" int fh_mesh_refine(fh_mesh_t mc, fh_mesh_t* out) {
   std::vector<int> order(nc);
   for (int iel = 0; iel < mc->nel; iel++) {
     const int* cd = &mc->elem_dof[(size_t)iel * nc];
+    if (!mc->refined[iel]) {
+      const int jel = start[iel];
+      for (int i = 0; i < nc; i++) {
+        const int row = m->elem_dof[(size_t)jel * nc + i];
+        if (done[row]) continue;
+        done[row] = 1;
+        for (int d = 0; d < dim; d++) m->coords[(size_t)row * dim + d] = mc->coords[(size_t)cd[i] * dim + d];
+      }
+      continue;
+    }
     for (int k = 0; k < nc; k++) order[k] = k;
     std::sort(order.begin(), order.end(), [&](int a, int b) { return cd[a] < cd[b]; });
     for (int j = 0; j < nch; j++) {
-      const int jel = iel * nch + j;
+      const int jel = start[iel] + j;
       for (int i = 0; i < nc; i++) {
         const int row = m->elem_dof[(size_t)jel * nc + i];
         if (done[row]) continue;
@@ -225,6 +274,29 @@ extern "C" int fh_mesh_refine(fh_mesh_t mc, fh_mesh_t* out) {
     }
   }
   *out = m;
+  return 0;
+}
+
+extern "C" int fh_mesh_refine(fh_mesh_t mc, fh_mesh_t* out) { return fh_mesh_refine_flagged(mc, nullptr, out); }
+
+// MeshRefinement::FlagElementsToRefine (:88-101): the flag function is evaluated at the mean of the element vertices
+extern "C" int fh_mesh_elem_centroids(fh_mesh_t m, double* xc3) {
+  FH_REQUIRE(m && xc3, "fh_mesh_elem_centroids: null argument");
+  const int nv = nvert_of(m->geom);
+  for (int iel = 0; iel < m->nel; iel++) {
+    double x[3] = {0, 0, 0};
+    for (int v = 0; v < nv; v++)
+      for (int d = 0; d < m->dim; d++) x[d] += m->coords[(size_t)m->elem_dof[(size_t)iel * m->nloc + v] * m->dim + d];
+    for (int d = 0; d < 3; d++) xc3[(size_t)iel * 3 + d] = x[d] / nv;
+  }
+  return 0;
+}
+
+extern "C" int fh_mesh_elem_levels(fh_mesh_t m, int* levels, int* homogeneous) {
+  FH_REQUIRE(m, "fh_mesh_elem_levels: null argument");
+  if (levels)
+    for (int iel = 0; iel < m->nel; iel++) levels[iel] = m->elem_level.empty() ? m->level : m->elem_level[iel];
+  if (homogeneous) *homogeneous = m->homogeneous ? 1 : 0;
   return 0;
 }
 
@@ -335,30 +407,41 @@ extern "C" int fh_pattern_from_elements(int nel, int nloc, const int* elem_dof, 
   return 0;
 }
 
-// a14: P (fine x coarse), INSERT semantics (first insert wins; duplicates are identical rows)
+// a14: P (fine x coarse), INSERT semantics (first insert wins; duplicates are identical rows).  Elements that were not
+// refined contribute identity rows (LinearImplicitSystem.cpp:796-806).
 extern "C" int fh_build_prolongator(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t mf, int fe, int zero_bdc, fh_mat_t* out) {
   FH_REQUIRE(ctx && mc && mf && out, "fh_build_prolongator: null argument");
   FH_REQUIRE(fe == 0 || fe == 2, "fh_build_prolongator: fe must be 0 or 2");
-  FH_REQUIRE(!mc->child.empty() && mf->nel == mc->nel * nvert_of(mc->geom), "fh_build_prolongator: fine is not the refinement of coarse");
   const int geom = mc->geom, nl = mc->nloc, nc = ndofs_of(geom, fe), nch = nvert_of(geom);
+  FH_REQUIRE(!mc->child.empty() && (int)mc->refined.size() == mc->nel, "fh_build_prolongator: fine is not the refinement of coarse");
+  {
+    int expect = 0;
+    for (int iel = 0; iel < mc->nel; iel++) expect += mc->refined[iel] ? nch : 1;
+    FH_REQUIRE(expect == mf->nel, "fh_build_prolongator: fine is not the refinement of coarse");
+  }
   const int nf = mesh_ndofs(mf, fe), ncc = mesh_ndofs(mc, fe);
   std::vector<double> EP;
   elem_prolongator(geom, fe, EP);
   std::vector<int> rowptr(nf + 1, 0);
   std::vector<char> done(nf, 0);
   // pass 1: row lengths
-  for (int iel = 0; iel < mc->nel; iel++)
-    for (int j = 0; j < nch; j++) {
+  for (int iel = 0; iel < mc->nel; iel++) {
+    const int nj = mc->refined[iel] ? nch : 1;
+    for (int j = 0; j < nj; j++) {
       const int jel = mc->child[(size_t)iel * nch + j];
       for (int i = 0; i < nc; i++) {
         const int row = mf->elem_dof[(size_t)jel * nl + i];
         if (done[row]) continue;
         done[row] = 1;
-        int cntr = 0;
-        for (int k = 0; k < nc; k++) cntr += (EP[((size_t)j * nc + i) * nc + k] != 0.0);
+        int cntr = 1;
+        if (mc->refined[iel]) {
+          cntr = 0;
+          for (int k = 0; k < nc; k++) cntr += (EP[((size_t)j * nc + i) * nc + k] != 0.0);
+        }
         rowptr[row + 1] = cntr;
       }
     }
+  }
   for (int r = 0; r < nf; r++) rowptr[r + 1] += rowptr[r];
   std::vector<int> col(rowptr[nf]);
   std::vector<double> val(rowptr[nf]);
@@ -374,28 +457,303 @@ extern "C" int fh_build_prolongator(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t mf, in
     for (int c : lc) bc[c] = 1;
   }
   std::vector<std::pair<int, double>> rowbuf;
-  for (int iel = 0; iel < mc->nel; iel++)
-    for (int j = 0; j < nch; j++) {
+  for (int iel = 0; iel < mc->nel; iel++) {
+    const int nj = mc->refined[iel] ? nch : 1;
+    for (int j = 0; j < nj; j++) {
       const int jel = mc->child[(size_t)iel * nch + j];
       for (int i = 0; i < nc; i++) {
         const int row = mf->elem_dof[(size_t)jel * nl + i];
         if (done[row]) continue;
         done[row] = 1;
         rowbuf.clear();
-        for (int k = 0; k < nc; k++) {
-          double v = EP[((size_t)j * nc + i) * nc + k];
-          if (v == 0.0) continue;
-          const int c = mc->elem_dof[(size_t)iel * nl + k];
-          if (zero_bdc && (bf[row] || bc[c])) v = 0.0;   // pattern kept, value zeroed (mat_zero_rows keeps the pattern)
-          rowbuf.emplace_back(c, v);
+        if (mc->refined[iel]) {
+          for (int k = 0; k < nc; k++) {
+            double v = EP[((size_t)j * nc + i) * nc + k];
+            if (v == 0.0) continue;
+            rowbuf.emplace_back(mc->elem_dof[(size_t)iel * nl + k], v);
+          }
+        } else {
+          rowbuf.emplace_back(mc->elem_dof[(size_t)iel * nl + i], 1.0);
         }
         std::sort(rowbuf.begin(), rowbuf.end());
         int p = rowptr[row];
         for (auto& cv : rowbuf) {
           col[p] = cv.first;
-          val[p++] = cv.second;
+          // pattern kept, value zeroed (mat_zero_rows keeps the pattern)
+          val[p++] = (zero_bdc && (bf[row] || bc[cv.first])) ? 0.0 : cv.second;
         }
       }
     }
+  }
   return fh_mat_create_csr(ctx, nf, ncc, rowptr.data(), col.data(), val.data(), out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// a22: hanging-node constraints of a non-homogeneous level (Mesh::GetAMRRestrictionAndAMRSolidMark, Mesh.cpp:1352-1830)
+// and the projection matrix built from them (LinearImplicitSystem::BuildAmrProlongatorMatrix, :912-1028).
+//
+// A face is an AMR interface when no other element shares all its vertices and it carries no boundary flag (near-face
+// index -1).  For every pair of levels (coarse Lc < fine Lf): every node of a fine interface face that lies inside a
+// coarse interface element without being one of its nodes hangs on that element; its weights are the coarse basis
+// functions of the element's interface-face nodes at that point (|w| >= 1e-10).  Masters that hang themselves are
+// resolved recursively.  A node on the interfaces with two coarser levels at once (3-D edges with a level jump of two)
+// has two mathematically identical descriptions; the one to the coarsest level is kept.
+// ---------------------------------------------------------------------------------------------------------------------
+struct AmrRows {
+  std::vector<int> hang;                 // sorted hanging dofs
+  std::vector<int> ptr;                  // CSR over hang
+  std::vector<int> master;
+  std::vector<double> w;
+};
+
+static bool inverse_map_q2(int geom, int dim, const double* xv /* [nloc*dim] */, const double* xp, double* xi) {
+  const int nl = nloc_of(geom);
+  double phi[27], dphi[81];
+  double scale = 1.0;
+  for (int k = 0; k < nl * dim; k++) scale = std::max(scale, std::fabs(xv[k]) + 1.0);
+  for (int d = 0; d < dim; d++) xi[d] = 0.0;
+  for (int it = 0; it < 30; it++) {
+    eval_basis(geom, FE_BIQUADRATIC, xi, phi, dphi);
+    double r[3] = {0, 0, 0}, J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};   // J[b][a] = d x_b / d xi_a
+    for (int j = 0; j < nl; j++)
+      for (int b = 0; b < dim; b++) {
+        r[b] += phi[j] * xv[j * dim + b];
+        for (int a = 0; a < dim; a++) J[b][a] += dphi[j * dim + a] * xv[j * dim + b];
+      }
+    for (int b = 0; b < dim; b++) r[b] -= xp[b];
+    double dx[3] = {0, 0, 0};
+    if (dim == 2) {
+      const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+      if (det == 0.0) return false;
+      dx[0] = (J[1][1] * r[0] - J[0][1] * r[1]) / det;
+      dx[1] = (-J[1][0] * r[0] + J[0][0] * r[1]) / det;
+    } else {
+      const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2],
+                   c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+      const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+      if (det == 0.0) return false;
+      const double inv[3][3] = {
+          {c00 / det, (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det, (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det},
+          {c01 / det, (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det, (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det},
+          {c02 / det, (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det, (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det}};
+      for (int a = 0; a < 3; a++) dx[a] = inv[a][0] * r[0] + inv[a][1] * r[1] + inv[a][2] * r[2];
+    }
+    double mx = 0.0;
+    for (int a = 0; a < dim; a++) {
+      xi[a] -= dx[a];
+      mx = std::max(mx, std::fabs(dx[a]));
+    }
+    if (mx < 1e-14 * scale) return true;
+  }
+  return true;
+}
+
+static void amr_constraints(const fh_mesh_s* m, int fe, AmrRows& out) {
+  const int geom = m->geom, dim = m->dim, nl = m->nloc, nv = nvert_of(geom), nf = nfaces_of(geom), nc = ndofs_of(geom, fe);
+  const int nfv = (dim == 3) ? 4 : 2;
+  out = AmrRows();
+  out.ptr.push_back(0);
+  if (m->homogeneous || m->elem_level.empty()) return;
+  // face vertices / face nodes from the local coordinates
+  int face_v[6][4], face_n[6][9], face_nn[6];
+  for (int f = 0; f < nf; f++) {
+    const int centre = (geom == GEOM_HEX) ? 20 + f : 4 + f;
+    int d0 = 0;
+    for (int d = 0; d < dim; d++)
+      if (xc(geom, centre, d) != 0) d0 = d;
+    int cv = 0, cn = 0;
+    for (int i = 0; i < nl; i++)
+      if (xc(geom, i, d0) == xc(geom, centre, d0)) {
+        if (i < nv) face_v[f][cv++] = i;
+        if (i < nc) face_n[f][cn++] = i;
+      }
+    face_nn[f] = cn;
+  }
+  // interface faces: vertex-set key seen exactly once and no boundary flag
+  std::unordered_map<Key3, int, Key3Hash> fcount;
+  fcount.reserve((size_t)m->nel * 4);
+  auto face_key = [&](int iel, int f) {
+    int v[4] = {-1, -1, -1, -1};
+    for (int k = 0; k < nfv; k++) v[k] = m->elem_dof[(size_t)iel * nl + face_v[f][k]];
+    std::sort(v, v + nfv);
+    return (dim == 3) ? Key3{v[0], v[1], v[2]} : Key3{v[0], v[1], -1};
+  };
+  for (int iel = 0; iel < m->nel; iel++)
+    for (int f = 0; f < nf; f++) fcount[face_key(iel, f)]++;
+  struct IfaceElem {
+    int iel;
+    std::vector<int> loc;   // interface-face local nodes (sorted, < nc)
+  };
+  int maxlev = 0;
+  for (int l : m->elem_level) maxlev = std::max(maxlev, l);
+  std::vector<std::vector<IfaceElem>> inter(maxlev + 1);
+  for (int iel = 0; iel < m->nel; iel++) {
+    std::vector<int> loc;
+    for (int f = 0; f < nf; f++)
+      if (m->face_flag[(size_t)iel * nf + f] == -1 && fcount[face_key(iel, f)] == 1)
+        loc.insert(loc.end(), face_n[f], face_n[f] + face_nn[f]);
+    if (loc.empty()) continue;
+    std::sort(loc.begin(), loc.end());
+    loc.erase(std::unique(loc.begin(), loc.end()), loc.end());
+    inter[m->elem_level[iel]].push_back({iel, std::move(loc)});
+  }
+  const int ndof = mesh_ndofs(m, fe);
+  std::vector<int> owner_level(ndof, -1);
+  std::unordered_map<int, std::vector<std::pair<int, double>>> raw;
+  double phi[27];
+  for (int Lc = 0; Lc <= maxlev; Lc++) {
+    if (inter[Lc].empty()) continue;
+    for (int Lf = Lc + 1; Lf <= maxlev; Lf++) {
+      if (inter[Lf].empty()) continue;
+      // fine interface nodes sorted by x for the box queries
+      std::vector<int> ids;
+      for (auto& ie : inter[Lf])
+        for (int n : ie.loc) ids.push_back(m->elem_dof[(size_t)ie.iel * nl + n]);
+      std::sort(ids.begin(), ids.end());
+      ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+      std::sort(ids.begin(), ids.end(), [&](int a, int b) {
+        const double xa = m->coords[(size_t)a * dim], xb = m->coords[(size_t)b * dim];
+        return xa < xb || (xa == xb && a < b);
+      });
+      std::vector<double> xs(ids.size());
+      for (size_t k = 0; k < ids.size(); k++) xs[k] = m->coords[(size_t)ids[k] * dim];
+      for (auto& ie : inter[Lc]) {
+        const int* ed = &m->elem_dof[(size_t)ie.iel * nl];
+        double xv[81], lo[3], hi[3];
+        for (int d = 0; d < dim; d++) lo[d] = 1e300, hi[d] = -1e300;
+        for (int i = 0; i < nl; i++)
+          for (int d = 0; d < dim; d++) {
+            const double c = m->coords[(size_t)ed[i] * dim + d];
+            xv[i * dim + d] = c;
+            lo[d] = std::min(lo[d], c);
+            hi[d] = std::max(hi[d], c);
+          }
+        for (int d = 0; d < dim; d++) {
+          const double pad = 0.01 * (hi[d] - lo[d]);
+          lo[d] -= pad;
+          hi[d] += pad;
+        }
+        const size_t k0 = std::lower_bound(xs.begin(), xs.end(), lo[0]) - xs.begin();
+        for (size_t k = k0; k < ids.size() && xs[k] <= hi[0]; k++) {
+          const int ldof = ids[k];
+          const double* xp = &m->coords[(size_t)ldof * dim];
+          bool in = true;
+          for (int d = 1; d < dim; d++) in = in && xp[d] >= lo[d] && xp[d] <= hi[d];
+          if (!in) continue;
+          bool mine = false;
+          for (int i = 0; i < nc; i++) mine = mine || ed[i] == ldof;
+          if (mine) continue;
+          double xi[3] = {0, 0, 0};
+          if (!inverse_map_q2(geom, dim, xv, xp, xi)) continue;
+          bool inside = true;
+          for (int d = 0; d < dim; d++) inside = inside && std::fabs(xi[d]) <= 1.0 + 1e-4;
+          if (!inside) continue;
+          if (owner_level[ldof] < 0) owner_level[ldof] = Lc;
+          if (owner_level[ldof] != Lc) continue;
+          eval_basis(geom, fe, xi, phi, nullptr);
+          auto& row = raw[ldof];
+          for (int n : ie.loc) {
+            if (std::fabs(phi[n]) < 1.0e-10) continue;
+            const int jd = ed[n];
+            bool found = false;
+            for (auto& e : row)
+              if (e.first == jd) {
+                e.second = phi[n];
+                found = true;
+              }
+            if (!found) row.emplace_back(jd, phi[n]);
+          }
+        }
+      }
+    }
+  }
+  // resolve masters that hang themselves (depth-first, masters in increasing dof order)
+  std::unordered_map<int, std::vector<std::pair<int, double>>> res;
+  std::function<const std::vector<std::pair<int, double>>&(int, int)> expand = [&](int l, int depth) -> const std::vector<std::pair<int, double>>& {
+    auto it = res.find(l);
+    if (it != res.end()) return it->second;
+    std::vector<std::pair<int, double>> row = raw[l];
+    std::sort(row.begin(), row.end());
+    std::vector<std::pair<int, double>> acc;
+    auto add = [&](int j, double w) {
+      for (auto& e : acc)
+        if (e.first == j) {
+          e.second += w;
+          return;
+        }
+      acc.emplace_back(j, w);
+    };
+    for (auto& e : row) {
+      if (raw.count(e.first) && depth < 16) {
+        const auto sub = expand(e.first, depth + 1);   // copy: the map may rehash below
+        for (auto& s : sub) add(s.first, e.second * s.second);
+      } else {
+        add(e.first, e.second);
+      }
+    }
+    std::sort(acc.begin(), acc.end());
+    return res.emplace(l, std::move(acc)).first->second;
+  };
+  std::vector<int> hang;
+  for (auto& kv : raw) hang.push_back(kv.first);
+  std::sort(hang.begin(), hang.end());
+  for (int l : hang) {
+    const auto& row = expand(l, 0);
+    out.hang.push_back(l);
+    for (auto& e : row) {
+      out.master.push_back(e.first);
+      out.w.push_back(e.second);
+    }
+    out.ptr.push_back((int)out.master.size());
+  }
+}
+
+extern "C" int fh_mesh_amr_constraints(fh_mesh_t m, int fe, int* n_hanging, int* nnz, int* hanging, int* ptr, int* master, double* weight) {
+  FH_REQUIRE(m && n_hanging && nnz, "fh_mesh_amr_constraints: null argument");
+  FH_REQUIRE(fe == 0 || fe == 2, "fh_mesh_amr_constraints: fe must be 0 or 2");
+  AmrRows R;
+  amr_constraints(m, fe, R);
+  if (hanging) {
+    FH_REQUIRE(*n_hanging >= (int)R.hang.size() && *nnz >= (int)R.master.size(), "fh_mesh_amr_constraints: capacity too small");
+    memcpy(hanging, R.hang.data(), R.hang.size() * sizeof(int));
+    if (ptr) memcpy(ptr, R.ptr.data(), R.ptr.size() * sizeof(int));
+    if (master) memcpy(master, R.master.data(), R.master.size() * sizeof(int));
+    if (weight) memcpy(weight, R.w.data(), R.w.size() * sizeof(double));
+  }
+  *n_hanging = (int)R.hang.size();
+  *nnz = (int)R.master.size();
+  return 0;
+}
+
+// P_amr (n x n): identity rows for regular dofs; a hanging dof's row holds its master weights and an explicit zero on
+// the diagonal (the reference inserts restriction[son][son] = 0, which keeps (son, son) in the pattern of P^T K P so
+// that SetPenalty can put its 1 there)
+extern "C" int fh_build_amr_prolongator(fh_ctx_t ctx, fh_mesh_t m, int fe, fh_mat_t* out) {
+  FH_REQUIRE(ctx && m && out, "fh_build_amr_prolongator: null argument");
+  FH_REQUIRE(fe == 0 || fe == 2, "fh_build_amr_prolongator: fe must be 0 or 2");
+  AmrRows R;
+  amr_constraints(m, fe, R);
+  const int n = mesh_ndofs(m, fe);
+  std::vector<int> rowptr(n + 1, 0), col;
+  std::vector<double> val;
+  size_t h = 0;
+  std::vector<std::pair<int, double>> row;
+  for (int i = 0; i < n; i++) {
+    if (h < R.hang.size() && R.hang[h] == i) {
+      row.clear();
+      row.emplace_back(i, 0.0);
+      for (int k = R.ptr[h]; k < R.ptr[h + 1]; k++) row.emplace_back(R.master[k], R.w[k]);
+      std::sort(row.begin(), row.end());
+      for (auto& e : row) {
+        col.push_back(e.first);
+        val.push_back(e.second);
+      }
+      h++;
+    } else {
+      col.push_back(i);
+      val.push_back(1.0);
+    }
+    rowptr[i + 1] = (int)col.size();
+  }
+  return fh_mat_create_csr(ctx, n, n, rowptr.data(), col.data(), val.data(), out);
 }

@@ -1,7 +1,8 @@
 """Host-side driver of the Poisson geometric-multigrid hot path: the calls LinearImplicitSystem makes
 (src/08_equations/00_stationary/LinearImplicitSystem.cpp), expressed over the C-ABI.
 
-    init()      <- LinearImplicitSystem::init :138-282      levels, sparsity, BuildProlongatorMatrix, ZeroInterpolatorDirichletNodes
+    init()      <- LinearImplicitSystem::init :138-282      levels, sparsity, BuildProlongatorMatrix, BuildAmrProlongatorMatrix,
+                                                            PP <- PP * PPamr, ZeroInterpolatorDirichletNodes
     assemble()  <- _assemble_system_function :325           the batched element loop (fh_assemble_poisson)
     prepare()   <- MGsolve :347-383                         Galerkin chain KK[l-1] = PP[l]^T KK[l] PP[l] (from the un-penalised
                                                             matrices), then MGInit / MGSetLevel (SetPenalty on every level)
@@ -37,18 +38,45 @@ class PoissonMG:
         ctx, fe = self.ctx, self.fe
         top = self.nlevels - 1
         self.ndof = [m.n_dofs(fe) for m in self.meshes]
-        self.bdc = [m.dirichlet_dofs(fe) for m in self.meshes]
-        self.P = [None] + [capi.build_prolongator(ctx, self.meshes[l - 1], self.meshes[l], fe, zero_bdc=True)
-                           for l in range(1, self.nlevels)]
+        # non-homogeneous (adaptively refined) levels: P_amr and the hanging dofs, which join the Dirichlet rows as
+        # "AMR artificial Dirichlet" (_Bdc = 1 < 1.5, MultiLevelSolution.cpp:725-760; LinearImplicitSystem.cpp:247-252)
+        self.Pamr = [None] * self.nlevels
+        self.hanging = [np.zeros(0, np.int32)] * self.nlevels
+        for l, m in enumerate(self.meshes):
+            if not m.elem_levels()[1]:
+                self.Pamr[l] = capi.build_amr_prolongator(ctx, m, fe)
+                self.hanging[l] = m.amr_constraints(fe)[0]
+        self.amr = any(p is not None for p in self.Pamr)
+        self.bdc = [np.union1d(m.dirichlet_dofs(fe), self.hanging[l]).astype(np.int32) for l, m in enumerate(self.meshes)]
+        if not self.amr:
+            self.P = [None] + [capi.build_prolongator(ctx, self.meshes[l - 1], self.meshes[l], fe, zero_bdc=True)
+                               for l in range(1, self.nlevels)]
+        else:
+            assert self.coarse == "galerkin", "adaptive levels use the Galerkin chain"
+            self.P = [None]
+            for l in range(1, self.nlevels):
+                P = capi.build_prolongator(ctx, self.meshes[l - 1], self.meshes[l], fe, zero_bdc=False)
+                if self.Pamr[l - 1] is not None:            # PP[l] <- PP[l] * PPamr[l-1]   (:253-258)
+                    PA = P.matmul(self.Pamr[l - 1])
+                    P.destroy()
+                    P = PA
+                P.mat_zero_rows(self.bdc[l], 0.0)           # ZeroInterpolatorDirichletNodes (:1032-1120)
+                P.zero_cols(self.bdc[l - 1])
+                self.P.append(P)
         # per-level operators: finest (and, for coarse == "rediscretise", every level) carries the element pattern
         self.A = [None] * self.nlevels
+        self.KK = [None] * self.nlevels          # assembled matrix where it differs from the operator of the cycle (AMR)
         self.asm = [None] * self.nlevels
         levels = range(self.nlevels) if self.coarse == "rediscretise" else [top]
         for l in levels:
             ed, xy, _ = self.meshes[l].arrays()
             rp, col = capi.pattern_from_elements(ed[:, :self.nc], self.ndof[l])
-            self.A[l] = ctx.matrix_csr(self.ndof[l], self.ndof[l], rp, col)
-            self.asm[l] = capi.Assembler(ctx, self.meshes[l], fe, self.A[l], self.order, elem_dof=ed, coords=xy)
+            K = ctx.matrix_csr(self.ndof[l], self.ndof[l], rp, col)
+            self.asm[l] = capi.Assembler(ctx, self.meshes[l], fe, K, self.order, elem_dof=ed, coords=xy)
+            if self.Pamr[l] is not None:
+                self.KK[l] = K
+            else:
+                self.A[l] = K
         n = self.ndof[top]
         self.RES, self.EPS, self.EPSC, self.RESC = ctx.vector(n), ctx.vector(n), ctx.vector(n), ctx.vector(n)
         self.SOL = ctx.vector(n)
@@ -60,7 +88,16 @@ class PoissonMG:
     def assemble(self, level=None):
         l = self.nlevels - 1 if level is None else level
         res = self.RES if l == self.nlevels - 1 else self.ctx.vector(self.ndof[l])
-        self.asm[l].assemble(self.A[l], res, self.SOL if l == self.nlevels - 1 else None, self.source_kind, self.params)
+        K = self.KK[l] if self.KK[l] is not None else self.A[l]
+        self.asm[l].assemble(K, res, self.SOL if l == self.nlevels - 1 else None, self.source_kind, self.params)
+        if self.Pamr[l] is not None:
+            # RES <- PPamr^T RES ; KK <- PPamr^T KK PPamr   (LinearImplicitSystem.cpp:329-335)
+            self.RESC.matrix_mult_transpose(res, self.Pamr[l])
+            res.assign(self.RESC)
+            if self.A[l] is None:
+                self.A[l] = capi.Mat.ptap(self.Pamr[l], K)
+            else:
+                self.A[l].ptap_numeric(self.Pamr[l], K)
         return res
 
     # ---- MGsolve preparation ------------------------------------------------------------------------------------
@@ -97,10 +134,10 @@ class PoissonMG:
         for a in self.asm:
             if a is not None:
                 a.destroy()
-        for m in self.A + self.P:
+        for m in self.A + self.P + self.KK + self.Pamr:
             if m is not None:
                 m.destroy()
-        self.asm, self.A, self.P = [], [], []
+        self.asm, self.A, self.P, self.KK, self.Pamr = [], [], [], [], []
 
     def zero_boundary_residuals(self):
         top = self.nlevels - 1
@@ -121,7 +158,10 @@ class PoissonMG:
         return its, rn
 
     def update_sol(self):
-        """Solution::UpdateSol: Sol += Eps"""
+        """Solution::UpdateSol: Sol += Eps (on adaptive levels EPS <- PPamr EPS first, LinearImplicitSystem.cpp:487-491)"""
+        if self.Pamr[-1] is not None:
+            self.EPSC.matrix_mult(self.EPS, self.Pamr[-1])
+            self.EPS.assign(self.EPSC)
         self.SOL.add(1.0, self.EPS)
         self.EPS.zero()
 
@@ -131,7 +171,7 @@ class PoissonMG:
         for a in self.asm:
             if a is not None:
                 a.destroy()
-        for m in self.A + self.P:
+        for m in self.A + self.P + self.KK + self.Pamr:
             if m is not None:
                 m.destroy()
         for m in self.meshes:

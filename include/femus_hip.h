@@ -127,6 +127,14 @@ int fh_fe_elem_prolongator(int geom, int fe, int* nchild, int* nc, double* P /* 
  * MeshGeneration.cpp:790-849,979-1075 ; MeshRefinement.cpp:240-294,356-417,513-620 ; Mesh.cpp:517-559 */
 int fh_mesh_box(int nx, int ny, int nz, const double lo[3], const double hi[3], fh_mesh_t* mesh);
 int fh_mesh_refine(fh_mesh_t coarse, fh_mesh_t* fine);
+/* selective (adaptive) refinement -- MeshRefinement::RefineMesh with an AMR flag per element (MeshRefinement.cpp:197-493):
+ * elements of the current level with flags[iel] != 0 are split, every other element is carried over unchanged, which
+ * makes the new level non-homogeneous.  flags == NULL refines every element of the current level. */
+int fh_mesh_refine_flagged(fh_mesh_t coarse, const unsigned char* flags /* [nel] or NULL */, fh_mesh_t* fine);
+/* the point FlagElementsToRefine evaluates the user's flag function at: mean of the element vertices (:88-101) */
+int fh_mesh_elem_centroids(fh_mesh_t mesh, double* xc /* [nel*3] */);
+/* Elem::GetElementLevel per element, Mesh::GetIfHomogeneous */
+int fh_mesh_elem_levels(fh_mesh_t mesh, int* levels /* [nel] or NULL */, int* homogeneous /* or NULL */);
 int fh_mesh_destroy(fh_mesh_t mesh);
 /* domain decomposition: faces of a sub-box that are artificial cuts, not physical boundary (bit f = local face f); call on the
  * coarse mesh before refining (flags are inherited, MeshRefinement.cpp:271-278) */
@@ -148,10 +156,24 @@ int fh_pattern_from_elements(int nel, int nloc, const int* elem_dof, int ndof, i
  * ZeroInterpolatorDirichletNodes (LinearImplicitSystem.cpp:1032-1120). */
 int fh_build_prolongator(fh_ctx_t ctx, fh_mesh_t coarse, fh_mesh_t fine, int fe, int zero_bdc, fh_mat_t* P);
 
+/* ---- adaptive refinement projection (a22) -----------------------------------------------------
+ * Hanging-node constraints of a non-homogeneous level: Mesh::GetAMRRestrictionAndAMRSolidMark (Mesh.cpp:1352-1830),
+ * source of Mesh::GetAmrRestrictionMap (Mesh.hpp:677-691).  Two-call protocol: with hanging == NULL only the counts are
+ * returned; then hanging[n] (sorted), ptr[n+1], master[nnz], weight[nnz] with chains through intermediate levels
+ * resolved.  Hanging dofs are the "AMR artificial Dirichlet" rows (flag 1 of MultiLevelSolution.cpp:725-760): the caller
+ * merges them into the Dirichlet list used by mat_zero_rows / ZeroInterpolatorDirichletNodes. */
+int fh_mesh_amr_constraints(fh_mesh_t mesh, int fe, int* n_hanging, int* nnz, int* hanging, int* ptr, int* master, double* weight);
+/* LinearImplicitSystem::BuildAmrProlongatorMatrix (LinearImplicitSystem.cpp:912-1028): P_amr (n x n), identity rows for
+ * regular dofs, master weights (+ an explicit zero diagonal) for hanging dofs.  Use sites: P[l] <- P[l] * P_amr[l-1]
+ * (:247-262, fh_mat_matmul), RES <- P_amr^T RES and KK <- P_amr^T KK P_amr (:329-342, fh_spmv_transpose / fh_mat_ptap),
+ * EPS <- P_amr EPS (:487-491, fh_spmv). */
+int fh_build_amr_prolongator(fh_ctx_t ctx, fh_mesh_t mesh, int fe, fh_mat_t* P_amr);
+
 /* ---- batched assembly (a4, a7, a12): the per-element callback of
  * src/08_equations/assemble/00_poisson_eqn_with_all_dirichlet_bc_AD_or_nonAD_separate.hpp:106-228 as ONE call.
  * KK->zero(); RES->zero(); element loop {Jacobian (ElemType.hpp:1183-1248,1438-1537); Res,Jac; add_*_blocked}; close.
- * source_kind: 0 constant f=p[0]; 1: f = p[0]*prod_d sin(p[1]*x_d) ; 2: f = p[0]*prod_d cos(p[1]*x_d).
+ * source_kind: 0 constant f=p[0]; 1: f = p[0]*prod_d sin(p[1]*x_d) ; 2: f = p[0]*prod_d cos(p[1]*x_d);
+ * 3: f = p[0]*sum_d prod_{e!=d} x_e (p[1]-x_e)  (Laplacian of the Q2 polynomial -(p[0]/2) prod_d x_d (p[1]-x_d)).
  * sol may be NULL (= 0).  A must carry the pattern from fh_pattern_from_elements. */
 typedef struct fh_assembler_s* fh_assembler_t;
 int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int gauss_order, int nel, int nloc, const int* elem_dof,

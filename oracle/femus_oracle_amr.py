@@ -1,0 +1,341 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement (numpy/scipy) of FEMuS's adaptive-refinement projection.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product path
+(femus_amd/) never does.  Parity status: *unpinned* -- the reference's AMR code cannot be linked here (PETSc-backed
+NumericVector/SparseMatrix) and its tests hold no stored numbers for this path, so correctness is anchored on the
+reference's call sites restated below and on domain properties (partition of unity, continuity across the
+coarse/fine interface, exactness for Q2 polynomials).
+
+Restated from
+  MeshRefinement.cpp:197-493   RefineMesh with a per-element AMR flag: flagged elements of the current level are split,
+                               the others are copied unchanged (their 27 node ids, face flags and level are kept)
+  Elem.hpp:358-370             GetIfElementCanBeRefined / GetIfFatherHasBeenRefined  (element level == mesh level)
+  MeshRefinement.cpp:58-131    FlagElementsToRefine: flag function evaluated at the mean of the element vertices
+  Mesh.cpp:1352-1830           GetAMRRestrictionAndAMRSolidMark: hanging nodes of the finer side of every interface
+                               face, their weights = coarse basis at the node, chains through intermediate levels resolved
+  LinearImplicitSystem.cpp:761-811   Build_Prolongation_OneElement: identity rows for elements that are not refined
+  LinearImplicitSystem.cpp:912-1028  BuildAmrProlongatorMatrix (P_amr, n x n)
+  LinearImplicitSystem.cpp:247-262   P[l] <- P[l] * P_amr[l-1]
+  LinearImplicitSystem.cpp:329-342   RES <- P_amr^T RES ; KK <- P_amr^T KK P_amr
+  LinearImplicitSystem.cpp:487-491   EPS <- P_amr EPS
+  MultiLevelSolution.cpp:725-760     GenerateBdc: hanging nodes get flag 1 ("AMR artificial Dirichlet"), which
+                                     BuildBdcIndex / ZeroInterpolatorDirichletNodes treat like Dirichlet rows (< 1.5)
+"""
+import numpy as np
+import scipy.sparse as sp
+
+from . import femus_oracle as fo
+
+
+def elem_levels(mesh):
+    lev = getattr(mesh, "elem_level", None)
+    if lev is None:
+        lev = np.full(mesh.nel, mesh.level, dtype=np.int64)
+        mesh.elem_level = lev
+    return lev
+
+
+def elem_centroids(mesh):
+    """mean of the element vertices (MeshRefinement.cpp:88-101)"""
+    nv = fo.n_vertices(mesh.geom)
+    return mesh.coords[mesh.elem_dof[:, :nv]].mean(axis=1)
+
+
+def flag_elements(mesh, fn):
+    """fn(x[3], level) -> bool evaluated on the centroid; only elements of the current level can be refined"""
+    xc = elem_centroids(mesh)
+    lev = elem_levels(mesh)
+    out = np.zeros(mesh.nel, dtype=bool)
+    for e in range(mesh.nel):
+        if lev[e] == mesh.level:
+            x = np.zeros(3)
+            x[:mesh.dim] = xc[e]
+            out[e] = bool(fn(x, mesh.level))
+    return out
+
+
+def refine_flagged(mc, flags):
+    """RefineMesh (nprocs = 1): children of the flagged elements + copies of the others, in coarse element order."""
+    geom = mc.geom
+    nv, ne, nc = fo.class_ranges(geom)
+    nchild = nv
+    f2c = fo.fine2coarse_vertex_mapping(geom)
+    Xc = fo.xc_table(geom)
+    fn = fo.face_nodes(geom)
+    nfaces = mc.face_flag.shape[1]
+    levc = elem_levels(mc)
+    flags = np.asarray(flags, dtype=bool) & (levc == mc.level)
+    cnt = np.where(flags, nchild, 1)
+    start = np.concatenate([[0], np.cumsum(cnt)])
+    nel_f = int(start[-1])
+    ed = np.full((nel_f, nc), -1, dtype=np.int64)
+    ff = np.full((nel_f, nfaces), -1, dtype=np.int64)
+    lev = np.zeros(nel_f, dtype=np.int64)
+    child = np.full((mc.nel, nchild), -1, dtype=np.int64)
+    for iel in range(mc.nel):
+        j0 = start[iel]
+        if flags[iel]:
+            for j in range(nchild):
+                ed[j0 + j, :nv] = mc.elem_dof[iel, f2c[j]]
+                for f in range(nfaces):
+                    if mc.face_flag[iel, f] < -1 and j in fn[f]:
+                        ff[j0 + j, f] = mc.face_flag[iel, f]
+                lev[j0 + j] = levc[iel] + 1
+                child[iel, j] = j0 + j
+        else:
+            ed[j0] = mc.elem_dof[iel]
+            ff[j0] = np.where(mc.face_flag[iel] < -1, mc.face_flag[iel], -1)
+            lev[j0] = levc[iel]
+            child[iel, 0] = j0
+    new_level = mc.level + 1
+    fresh = np.where(lev == new_level)[0]          # GetIfFatherHasBeenRefined
+    nnodes = mc.nnode
+    # edge mid-points of the new elements: first visit in (element, local edge) order
+    edge_v = np.empty((ne - nv, 2), dtype=np.int64)
+    for e in range(nv, ne):
+        d = np.where(Xc[e] == 0)[0][0]
+        vs = [v for v in range(nv) if all(Xc[v, k] == Xc[e, k] for k in range(Xc.shape[1]) if k != d)]
+        edge_v[e - nv] = sorted(vs)
+    seen = {}
+    for iel in fresh:
+        for e in range(nv, ne):
+            a, b = ed[iel, edge_v[e - nv, 0]], ed[iel, edge_v[e - nv, 1]]
+            key = (min(a, b), max(a, b))
+            if key not in seen:
+                seen[key] = nnodes
+                nnodes += 1
+            ed[iel, e] = seen[key]
+    if geom == "hex":
+        seen = {}
+        fverts = [[v for v in fn[f] if v < nv] for f in range(6)]
+        for iel in fresh:
+            for f in range(6):
+                key = tuple(sorted(ed[iel, fverts[f]]))
+                if key not in seen:
+                    seen[key] = nnodes
+                    nnodes += 1
+                ed[iel, 20 + f] = seen[key]
+    for iel in fresh:
+        ed[iel, nc - 1] = nnodes
+        nnodes += 1
+    mapping, own = fo._first_touch_renumber(geom, ed, nnodes)
+    ed = mapping[ed]
+    mf = fo.Mesh(geom, ed, np.zeros((nnodes, mc.dim)), ff, level=new_level)
+    mf.own_size = own
+    mf.elem_level = lev
+    mf.homogeneous = bool(np.all(flags))
+    mc.child_elem = child
+    mc.refined = flags
+    P = build_prolongator(mc, mf, "biquadratic")
+    mf.coords = np.stack([P @ mc.coords[:, d] for d in range(mc.dim)], axis=1)
+    return mf
+
+
+def build_prolongator(mc, mf, fe):
+    """element prolongator rows for refined elements, identity rows for copied ones (INSERT semantics)"""
+    geom = mc.geom
+    nc = fo.ndofs(geom, fe)
+    EP = fo.elem_prolongator(geom, fe)
+    nchild = EP.shape[0]
+    refined = getattr(mc, "refined", None)
+    if refined is None:
+        refined = np.ones(mc.nel, dtype=bool)
+    nf, ncc = fo.n_dofs(mf, fe), fo.n_dofs(mc, fe)
+    rows, cols, vals = [], [], []
+    for iel in range(mc.nel):
+        cd = mc.elem_dof[iel, :nc]
+        if refined[iel]:
+            for j in range(nchild):
+                jel = mc.child_elem[iel, j]
+                for i in range(nc):
+                    r = mf.elem_dof[jel, i]
+                    for k in range(nc):
+                        if EP[j, i, k] != 0.0:
+                            rows.append(r), cols.append(cd[k]), vals.append(EP[j, i, k])
+        else:
+            jel = mc.child_elem[iel, 0]
+            for i in range(nc):
+                rows.append(mf.elem_dof[jel, i]), cols.append(cd[i]), vals.append(1.0)
+    R, C, V = np.array(rows, dtype=np.int64), np.array(cols, dtype=np.int64), np.array(vals)
+    key = R * np.int64(ncc) + C
+    _, first = np.unique(key, return_index=True)
+    P = sp.csr_matrix((V[first], (R[first], C[first])), shape=(nf, ncc))
+    P.sort_indices()
+    return P
+
+
+def interface_faces(mesh):
+    """face (iel, f) is an AMR interface when no other element shares all its vertices and it is not a boundary
+    (elem near-face index -1, GetBoundaryIndex == 0)"""
+    nv = fo.n_vertices(mesh.geom)
+    fn = fo.face_nodes(mesh.geom)
+    nfaces = mesh.face_flag.shape[1]
+    count = {}
+    keys = {}
+    for iel in range(mesh.nel):
+        for f in range(nfaces):
+            key = tuple(sorted(mesh.elem_dof[iel, [v for v in fn[f] if v < nv]]))
+            keys[(iel, f)] = key
+            count[key] = count.get(key, 0) + 1
+    out = np.zeros((mesh.nel, nfaces), dtype=bool)
+    for (iel, f), key in keys.items():
+        out[iel, f] = count[key] == 1 and mesh.face_flag[iel, f] == -1
+    return out
+
+
+def inverse_map(geom, xv, xp, tol=1e-14, maxit=30):
+    """reference coordinate of the physical point xp in the biquadratic element with nodes xv[nloc, dim] (Newton)"""
+    dim = xv.shape[1]
+    xi = np.zeros(dim)
+    scale = np.abs(xv).max() + 1.0
+    for _ in range(maxit):
+        phi, dphi, _ = fo.eval_basis(geom, "biquadratic", xi[None, :])
+        r = phi[0] @ xv - xp
+        J = dphi[0].T @ xv                   # J[a, b] = d x_b / d xi_a
+        dx = np.linalg.solve(J.T, r)
+        xi = xi - dx
+        if np.abs(dx).max() < tol * scale:
+            break
+    return xi
+
+
+def amr_restriction(mesh, fe):
+    """hanging-node constraints of a non-homogeneous level: dict  hanging dof -> {master dof: weight}  with chains
+    through intermediate levels resolved down to real masters (Mesh.cpp:1352-1830)."""
+    geom = mesh.geom
+    nc = fo.ndofs(geom, fe)
+    fn = fo.face_nodes(geom)
+    lev = elem_levels(mesh)
+    iface = interface_faces(mesh)
+    levels = sorted(set(lev.tolist()))
+    # interface elements and their interface-face local nodes, per level
+    inter = {L: [] for L in levels}
+    for iel in range(mesh.nel):
+        fs = np.where(iface[iel])[0]
+        if fs.size:
+            loc = sorted(set(int(n) for f in fs for n in fn[f] if n < nc))
+            inter[lev[iel]].append((iel, loc))
+    raw = {}                                      # hanging dof -> {master: weight}
+    owner_level = {}                              # coarse level whose elements constrain the dof
+    for a, Lc in enumerate(levels):
+        for Lf in levels[a + 1:]:
+            fine_nodes = {}
+            for (jel, loc) in inter[Lf]:
+                for n in loc:
+                    fine_nodes[int(mesh.elem_dof[jel, n])] = mesh.coords[mesh.elem_dof[jel, n]]
+            if not fine_nodes:
+                continue
+            ids = np.array(sorted(fine_nodes), dtype=np.int64)
+            pts = np.array([fine_nodes[i] for i in ids])
+            for (iel, loc) in inter[Lc]:
+                xv = mesh.coords[mesh.elem_dof[iel]]
+                lo, hi = xv.min(axis=0), xv.max(axis=0)
+                pad = 0.01 * (hi - lo)
+                inside = np.all((pts >= lo - pad) & (pts <= hi + pad), axis=1)
+                own = set(int(d) for d in mesh.elem_dof[iel, :nc])
+                for k in np.where(inside)[0]:
+                    ldof = int(ids[k])
+                    if ldof in own:
+                        continue
+                    xi = inverse_map(geom, xv, pts[k])
+                    if np.any(np.abs(xi) > 1.0 + 1e-4):
+                        continue
+                    # A node lying on the interfaces with two coarser levels at once (3-D edges with a level jump of
+                    # two) has two mathematically identical descriptions; the one to the coarsest level is kept.
+                    if owner_level.setdefault(ldof, Lc) != Lc:
+                        continue
+                    phi, _, _ = fo.eval_basis(geom, fe, xi[None, :])
+                    for n in loc:
+                        v = phi[0, n]
+                        if abs(v) >= 1.0e-10:
+                            raw.setdefault(ldof, {})[int(mesh.elem_dof[iel, n])] = float(v)
+    # resolve masters that are themselves hanging
+    resolved = {}
+
+    def expand(l, depth=0):
+        if l in resolved:
+            return resolved[l]
+        assert depth < 16, "cyclic hanging-node constraints"
+        out = {}
+        for j, w in sorted(raw[l].items()):
+            if j in raw:
+                for jj, ww in expand(j, depth + 1).items():
+                    out[jj] = out.get(jj, 0.0) + w * ww
+            else:
+                out[j] = out.get(j, 0.0) + w
+        resolved[l] = out
+        return out
+
+    for l in sorted(raw):
+        expand(l)
+    return resolved
+
+
+def build_amr_prolongator(mesh, fe):
+    """P_amr (n x n): identity rows for regular dofs; row of a hanging dof = its master weights plus an explicit
+    zero on the diagonal (the reference inserts restriction[son][son] = 0)"""
+    n = fo.n_dofs(mesh, fe)
+    R = amr_restriction(mesh, fe)
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        if i in R:
+            rows.append(i), cols.append(i), vals.append(0.0)
+            for j, w in R[i].items():
+                rows.append(i), cols.append(j), vals.append(w)
+        else:
+            rows.append(i), cols.append(i), vals.append(1.0)
+    P = sp.csr_matrix((np.array(vals), (np.array(rows), np.array(cols))), shape=(n, n))
+    P.sort_indices()
+    return P, np.array(sorted(R), dtype=np.int64)
+
+
+class AmrHierarchy:
+    pass
+
+
+def build_amr_levels(nx, ny, nz, n_uniform, n_selective, flag_fn, lo=(0., 0., 0.), hi=(1., 1., 1.)):
+    """MultiLevelMesh::RefineMesh(n_uniform + n_selective, n_uniform, flag_fn)"""
+    ms = [fo.coarse_box_mesh(nx, ny, nz, lo, hi)]
+    ms[0].elem_level = np.zeros(ms[0].nel, dtype=np.int64)
+    ms[0].homogeneous = True
+    for l in range(1, n_uniform + n_selective):
+        mc = ms[-1]
+        flags = np.ones(mc.nel, dtype=bool) if l < n_uniform else flag_elements(mc, flag_fn)
+        ms.append(refine_flagged(mc, flags))
+    return ms
+
+
+def build_amr_hierarchy(meshes, fe, rhs_vec, order="seventh"):
+    """LinearImplicitSystem::init + one MGsolve preparation on an AMR mesh stack: returns A[l] (penalised), P[l],
+    P_amr[l] (None on homogeneous levels), bdc[l] (Dirichlet + hanging), b (projected, zeroed on bdc)"""
+    nl = len(meshes)
+    H = AmrHierarchy()
+    H.meshes = meshes
+    H.Pamr, H.hanging = [None] * nl, [np.zeros(0, dtype=np.int64)] * nl
+    for l, m in enumerate(meshes):
+        if not getattr(m, "homogeneous", True):
+            H.Pamr[l], H.hanging[l] = build_amr_prolongator(m, fe)
+    H.bdc = [np.union1d(fo.dirichlet_dofs(m, fe), H.hanging[l]) for l, m in enumerate(meshes)]
+    H.P = [None] * nl
+    for l in range(1, nl):
+        P = build_prolongator(meshes[l - 1], meshes[l], fe)
+        if H.Pamr[l - 1] is not None:
+            P = (P @ H.Pamr[l - 1]).tocsr()
+        P = fo.zero_interpolator_dirichlet(P, H.bdc[l], H.bdc[l - 1])
+        H.P[l] = P
+    top = nl - 1
+    K, b = fo.assemble_poisson(meshes[top], fe, rhs_vec, order=order)
+    if H.Pamr[top] is not None:
+        b = H.Pamr[top].T @ b
+        K = (H.Pamr[top].T @ K @ H.Pamr[top]).tocsr()
+    H.A = [None] * nl
+    H.A[top] = K
+    for l in range(top, 0, -1):
+        H.A[l - 1] = (H.P[l].T @ H.A[l] @ H.P[l]).tocsr()
+    for l in range(nl):
+        H.A[l] = fo.zero_rows(H.A[l], H.bdc[l], 1.0)
+    b = b.copy()
+    b[H.bdc[top]] = 0.0
+    H.b = b
+    H.nlevels = nl
+    return H

@@ -70,6 +70,16 @@ static void jacobian(int dim, int nc, const double* dphi_g /* [nc][dim] */, cons
 
 static double source(int kind, double p0, double p1, const double* xg, int dim) {
   if (kind == 0) return p0;
+  if (kind == 3) { /* p0 * sum_d prod_{e != d} x_e (p1 - x_e) */
+    double sum = 0.0;
+    for (int d = 0; d < dim; d++) {
+      double pr = 1.0;
+      for (int e = 0; e < dim; e++)
+        if (e != d) pr *= xg[e] * (p1 - xg[e]);
+      sum += pr;
+    }
+    return p0 * sum;
+  }
   double r = p0;
   for (int d = 0; d < dim; d++) r *= (kind == 1) ? sin(p1 * xg[d]) : cos(p1 * xg[d]);
   return r;

@@ -1,0 +1,74 @@
+"""GPU parity for the adaptive-refinement projection (BASELINE config "MGAMR"): P_amr, the projected
+prolongators, K_amr = P_amr^T K P_amr and the multigrid solve through the C-ABI against the oracle, plus the
+size-independent property that a Q2 polynomial is reproduced exactly on any adaptive box mesh."""
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+from femus_amd import capi
+from femus_amd.poisson import PoissonMG
+from oracle import femus_oracle as fo
+from oracle import femus_oracle_amr as fa
+
+from test_amr_host import CASES, ex4_flag, poly_rhs
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def amr_meshes(box, nu, ns, flag):
+    ms = [capi.Mesh.box(*box)]
+    for l in range(1, nu + ns):
+        flags = np.ones(ms[-1].nel, np.uint8) if l < nu else ms[-1].flag_elements(flag)
+        ms.append(ms[-1].refine_flagged(flags))
+    return ms
+
+
+@pytest.mark.parametrize("box,nu,ns,flag", CASES)
+@pytest.mark.parametrize("fe", ["biquadratic", "linear"])
+def test_amr_hierarchy_matches_oracle(ctx, box, nu, ns, flag, fe):
+    dim = 2 if box[2] == 0 else 3
+    mo = fa.build_amr_levels(*box, nu, ns, flag)
+    H = fa.build_amr_hierarchy(mo, fe, poly_rhs(dim))
+    nl = nu + ns
+    pb = PoissonMG(ctx, *box, nl, fe=fe, source_kind=3, params=(-2.0, 1.0), meshes=amr_meshes(box, nu, ns, flag)).init()
+    for l in range(nl):
+        assert np.array_equal(pb.bdc[l], H.bdc[l])                         # Dirichlet + hanging rows: integer, identical
+        if H.Pamr[l] is not None:
+            assert abs(pb.Pamr[l].to_scipy() - H.Pamr[l]).max() < 1e-14
+        if l > 0:
+            assert abs(pb.P[l].to_scipy() - H.P[l]).max() < 1e-14
+    pb.assemble()
+    pb.prepare()
+    for l in range(nl):
+        assert abs(pb.A[l].to_scipy() - H.A[l]).max() <= 1e-12 * abs(H.A[l]).max()   # fp64 sums in a different order
+    pb.zero_boundary_residuals()
+    assert rel(pb.RES.to_numpy(), H.b) < 1e-12
+    # parity of the FP solve: 1e-10 relative against the direct solution of the oracle system (north_star)
+    its, rn = pb.mgsolve(outer="gmres", rtol=1e-13, maxit=60)
+    pb.update_sol()
+    xd = H.Pamr[-1] @ spla.spsolve(H.A[-1].tocsc(), H.b)
+    assert rel(pb.SOL.to_numpy(), xd) < 1e-10
+    if fe == "biquadratic":
+        _, xy, _ = pb.meshes[-1].arrays()
+        assert abs(pb.SOL.to_numpy() - np.prod(xy * (1 - xy), axis=1)).max() < 1e-12
+    pb.destroy()
+
+
+def test_amr_q2_exactness_larger_mesh(ctx):
+    """8^3 coarse, one uniform + two selective levels (MGAMR-style, 3-D): 54k elements with level jumps of one and two;
+    the Q2 polynomial must come back to solver tolerance and the hanging values must equal the interpolated ones"""
+    box, nu, ns = (4, 4, 4), 2, 2
+    pb = PoissonMG(ctx, *box, nu + ns, source_kind=3, params=(-2.0, 1.0), meshes=amr_meshes(box, nu, ns, ex4_flag)).init()
+    assert pb.hanging[-1].size > 1000 and pb.hanging[-2].size > 100
+    pb.assemble()
+    pb.prepare()
+    its, rn = pb.mgsolve(outer="gmres", rtol=1e-13, maxit=60)
+    assert its <= 20
+    pb.update_sol()
+    _, xy, _ = pb.meshes[-1].arrays()
+    assert abs(pb.SOL.to_numpy() - np.prod(xy * (1 - xy), axis=1)).max() < 1e-12
+    pb.destroy()
