@@ -1,0 +1,351 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement (numpy/scipy) of FEMuS's steady Navier-Stokes Newton/multigrid path
+(BASELINE config "003_NavierStokes lid-driven cavity, Q2/Q1 Taylor-Hood, Newton + GMG-preconditioned GMRES").
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  Parity status: *unpinned*
+(the reference needs PETSc + adept to run this path and stores no numbers for it); anchored on the call sites below, on a
+finite-difference check of the hand-derived Jacobian against the residual and on domain properties.
+
+Restated from
+  src/08_equations/assemble/03_navier_stokes.hpp:330-395   Gauss loop: aResV[k][i] = (nu grad phi_i . grad u_k + phi_i (u . grad) u_k
+                                                           - p d_k phi_i) w ; aResP[i] = -(div u) psi_i w ; Res = -aRes
+  src/08_equations/assemble/Assemble_jacobian.cpp:39-72     Jac = d aRes / d sol (adept tape in the reference, derived by hand here)
+  LinearEquation.cpp:76-85, 212-237                         system dof = KKoffset[k] + mesh dof (variables stacked per rank)
+  NonLinearImplicitSystem.cpp:157-361                       nonlinear F-cycle: for every level-max: Newton iterations
+                                                           {assemble, Galerkin chain, MGInit/MGSetLevel, linear cycles, UpdateSol},
+                                                           then ProlongatorSol to the next level
+  NonLinearImplicitSystem.cpp:113-153                       HasNonLinearConverged: max_k ||Eps_k|| / ||Sol_k|| < tol
+  LinearImplicitSystem.cpp:453-464                          ProlongatorSol: Sol_f = P_mesh Sol_c per variable
+  applications/003_NavierStokes/SteadyNavierStokesParallel/main.cpp:365-390   cavity boundary conditions
+  petsc_asm/LinearEquationSolverPetscAsm.cpp:91-276         element-block (Vanka) Schwarz smoother for saddle-point systems:
+                                                           velocity dofs of the block's elements + the block's pressure dofs
+"""
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from . import femus_oracle as fo
+
+
+class NSLayout:
+    """variables U, V (, W) biquadratic and P linear; system dof = offset[k] + mesh dof (nprocs = 1)"""
+
+    def __init__(self, mesh):
+        self.dim = mesh.dim
+        self.nv = fo.ndofs(mesh.geom, "biquadratic")
+        self.npr = fo.ndofs(mesh.geom, "linear")
+        nq2, nq1 = fo.n_dofs(mesh, "biquadratic"), fo.n_dofs(mesh, "linear")
+        self.sizes = [nq2] * self.dim + [nq1]
+        self.offset = np.concatenate([[0], np.cumsum(self.sizes)])
+        self.n = int(self.offset[-1])
+        self.nd = self.dim * self.nv + self.npr
+        ed = mesh.elem_dof
+        self.elem_sys = np.concatenate([ed[:, :self.nv] + self.offset[k] for k in range(self.dim)] +
+                                       [ed[:, :self.npr] + self.offset[self.dim]], axis=1)
+
+
+def elem_ns_batch(etv, etp, X, UV, Pr, nu):
+    """X[nel, dim, nloc], UV[nel, dim, nv], Pr[nel, npr] -> Jac[nel, nd, nd], Res[nel, nd] (Res = -aRes);
+    Gauss-point sum sequential (reference order)."""
+    nel = X.shape[0]
+    dim, nv, ng = etv.dim, etv.nc, etv.ng
+    npr = etp.nc
+    nd = dim * nv + npr
+    Jm = np.einsum("gna,ebn->egab", etv.dphi, X[:, :, :nv])
+    det = np.linalg.det(Jm)
+    JI = np.linalg.inv(Jm)
+    grad = np.einsum("gna,egba->egnb", etv.dphi, JI)          # grad[e,g,n,b] = d phi_n / d x_b
+    w = det * etv.w[None, :]
+    phi, psi = etv.phi, etp.phi                               # [ng, nv], [ng, npr]
+    Jac = np.zeros((nel, nd, nd))
+    aRes = np.zeros((nel, nd))
+    for g in range(ng):
+        G = grad[:, g]                                        # [nel, nv, dim]
+        ug = np.einsum("ekn,n->ek", UV, phi[g])               # u_k
+        gu = np.einsum("ekn,enj->ekj", UV, G)                 # d_j u_k
+        pg = Pr @ psi[g]
+        wg = w[:, g]
+        lap = np.einsum("eid,ejd->eij", G, G)                 # grad phi_i . grad phi_j
+        adv = np.einsum("ej,enj->en", ug, G)                  # u . grad phi_n
+        for k in range(dim):
+            rk = slice(k * nv, (k + 1) * nv)
+            aRes[:, rk] += (nu * np.einsum("eid,ed->ei", G, gu[:, k]) + phi[g][None, :] * np.einsum("ej,ej->e", ug, gu[:, k])[:, None]
+                            - pg[:, None] * G[:, :, k]) * wg[:, None]
+            Jac[:, rk, rk] += (nu * lap + phi[g][None, :, None] * adv[:, None, :]) * wg[:, None, None]
+            for m in range(dim):
+                cm = slice(m * nv, (m + 1) * nv)
+                Jac[:, rk, cm] += (phi[g][None, :, None] * phi[g][None, None, :]) * (gu[:, k, m] * wg)[:, None, None]
+            Jac[:, rk, dim * nv:] += -(G[:, :, k][:, :, None] * psi[g][None, None, :]) * wg[:, None, None]
+            Jac[:, dim * nv:, rk] += -(psi[g][None, :, None] * G[:, :, k][:, None, :]) * wg[:, None, None]
+        div = sum(gu[:, k, k] for k in range(dim))
+        aRes[:, dim * nv:] += -(div * wg)[:, None] * psi[g][None, :]
+    return Jac, -aRes
+
+
+def assemble_ns(mesh, lay, sol, nu, order="seventh", pattern=None):
+    etv = fo.ElemType(mesh.geom, "biquadratic", order)
+    etp = fo.ElemType(mesh.geom, "linear", order)
+    X = np.transpose(mesh.coords[mesh.elem_dof], (0, 2, 1))
+    es = lay.elem_sys
+    nv, dim = lay.nv, lay.dim
+    loc = sol[es]
+    UV = loc[:, :dim * nv].reshape(mesh.nel, dim, nv)
+    Pr = loc[:, dim * nv:]
+    Jac, Res = elem_ns_batch(etv, etp, X, UV, Pr, nu)
+    if pattern is None:
+        pattern = csr_pattern_sys(lay)
+    indptr, indices = pattern
+    vals = np.zeros(indices.size)
+    rows = np.repeat(es, lay.nd, axis=1).ravel()
+    cols = np.tile(es, (1, lay.nd)).ravel()
+    pos = fo._csr_positions(indptr, indices, rows, cols)
+    np.add.at(vals, pos, Jac.ravel())
+    b = np.zeros(lay.n)
+    np.add.at(b, es.ravel(), Res.ravel())
+    return sp.csr_matrix((vals, indices, indptr), shape=(lay.n, lay.n)), b
+
+
+def csr_pattern_sys(lay):
+    es = lay.elem_sys.astype(np.int64)
+    nd, n = lay.nd, lay.n
+    key = np.unique((np.repeat(es, nd, axis=1) * n + np.tile(es, (1, nd))).ravel())
+    rows = key // n
+    indptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))])
+    return indptr.astype(np.int32), (key % n).astype(np.int32)
+
+
+# ---- boundary conditions of the cavity (main.cpp:365-390): every velocity component Dirichlet on every wall, the
+# tangential component 1 on the moving wall (open interval: the two end nodes stay 0); pressure pinned at the (lo, lo) corner
+def cavity_bc(mesh, lay, lid_flag=-5, lid_component=1, lid_value=1.0):
+    fn = fo.face_nodes(mesh.geom)
+    dim = mesh.dim
+    lo, hi = mesh.coords.min(axis=0), mesh.coords.max(axis=0)
+    bdc, val = [], []
+    mark = np.zeros(mesh.nnode, dtype=bool)
+    lid = np.zeros(mesh.nnode, dtype=bool)
+    for f, nodes in enumerate(fn):
+        els = np.where(mesh.face_flag[:, f] < -1)[0]
+        mark[mesh.elem_dof[els][:, nodes].ravel()] = True
+        els = np.where(mesh.face_flag[:, f] == lid_flag)[0]
+        lid[mesh.elem_dof[els][:, nodes].ravel()] = True
+    nodes = np.where(mark)[0]
+    tdir = lid_component
+    x = mesh.coords[nodes]
+    inside = lid[nodes] & (x[:, tdir] > lo[tdir]) & (x[:, tdir] < hi[tdir])
+    for k in range(dim):
+        bdc.append(nodes + lay.offset[k])
+        val.append(np.where(inside, lid_value, 0.0) if k == lid_component else np.zeros(nodes.size))
+    # pressure: only the corner node (x < lo + 1e-8 in every direction), reached through the boundary faces
+    nq1 = fo.n_dofs(mesh, "linear")
+    pn = nodes[(nodes < nq1) & np.all(mesh.coords[nodes] < lo + 1e-8, axis=1)]
+    bdc.append(pn + lay.offset[dim])
+    val.append(np.zeros(pn.size))
+    bdc, val = np.concatenate(bdc), np.concatenate(val)
+    o = np.argsort(bdc)
+    return bdc[o], val[o]
+
+
+def block_prolongator(mc, mf, layc, layf, bdc_f=None, bdc_c=None):
+    """blockdiag(P_Q2 x dim, P_Q1) (BuildProlongatorMatrix loops the system variables), then ZeroInterpolatorDirichletNodes"""
+    P2 = fo.build_prolongator(mc, mf, "biquadratic")
+    P1 = fo.build_prolongator(mc, mf, "linear")
+    P = sp.block_diag([P2] * layf.dim + [P1], format="csr")
+    if bdc_f is not None:
+        P = fo.zero_interpolator_dirichlet(P, bdc_f, bdc_c)
+    return P
+
+
+def vertex_patches(mesh, lay):
+    """one block per pressure dof: the pressure dof and every velocity dof of the elements sharing that vertex
+    (pressure-centred Vanka patches, the GPU form of the element-block ASM of LinearEquationSolverPetscAsm.cpp)"""
+    nq1 = fo.n_dofs(mesh, "linear")
+    elems = [[] for _ in range(nq1)]
+    for e in range(mesh.nel):
+        for v in mesh.elem_dof[e, :lay.npr]:
+            elems[v].append(e)
+    patches = []
+    for v in range(nq1):
+        nodes = np.unique(mesh.elem_dof[elems[v]][:, :lay.nv])
+        dofs = np.concatenate([nodes + lay.offset[k] for k in range(lay.dim)] + [[v + lay.offset[lay.dim]]])
+        patches.append(dofs.astype(np.int64))
+    return patches
+
+
+def color_patches(patches, n):
+    """greedy colouring in patch order: patches sharing a dof get different colours"""
+    owner = [[] for _ in range(n)]
+    for p, d in enumerate(patches):
+        for i in d:
+            owner[i].append(p)
+    color = np.full(len(patches), -1, dtype=np.int64)
+    for p, d in enumerate(patches):
+        used = set()
+        for i in d:
+            for q in owner[i]:
+                if color[q] >= 0:
+                    used.add(color[q])
+        c = 0
+        while c in used:
+            c += 1
+        color[p] = c
+    return color
+
+
+class VankaSmoother:
+    """multiplicative over colours, exact dense solve of every patch:  x_p += omega A_pp^-1 (b - A x)_p"""
+
+    def __init__(self, A, patches, color, omega=1.0):
+        self.A = A.tocsr()
+        self.patches = patches
+        self.color = color
+        self.ncolors = int(color.max()) + 1
+        self.omega = omega
+        self.inv = [np.linalg.inv(self.A[d][:, d].toarray()) for d in patches]
+
+    def sweep(self, b, x):
+        for c in range(self.ncolors):
+            for p in np.where(self.color == c)[0]:
+                d = self.patches[p]
+                r = b[d] - self.A[d] @ x
+                x[d] += self.omega * (self.inv[p] @ r)
+        return x
+
+
+class NSHierarchy:
+    pass
+
+
+def vcycle(H, level, b, x=None):
+    A = H.A[level]
+    if level == 0:
+        return H.coarse_solve(b)
+    x = np.zeros_like(b) if x is None else x
+    for _ in range(H.npre):
+        x = H.smoother[level].sweep(b, x)
+    r = b - A @ x
+    ec = vcycle(H, level - 1, H.P[level].T @ r)
+    x = x + H.P[level] @ ec
+    for _ in range(H.npost):
+        x = H.smoother[level].sweep(b, x)
+    return x
+
+
+def gmres_mg(H, top, b, rtol=1e-10, atol=1e-50, maxit=30, restart=30):
+    """left-preconditioned GMRES (classical Gram-Schmidt), preconditioner = one V-cycle, zero initial guess; same
+    iteration as femus_oracle.solve_gmres_mg"""
+    A = H.A[top]
+    M = lambda v: vcycle(H, top, v)
+    x = np.zeros_like(b)
+    hist = []
+    it = 0
+    r = M(b - A @ x)
+    beta0 = np.linalg.norm(r)
+    while True:
+        beta = np.linalg.norm(r)
+        if not hist:
+            hist.append(beta)
+        if beta <= max(rtol * beta0, atol) or it >= maxit:
+            break
+        m = restart
+        V = np.zeros((m + 1, b.size))
+        Hh = np.zeros((m + 1, m))
+        V[0] = r / beta
+        g = np.zeros(m + 1)
+        g[0] = beta
+        cs, sn = np.zeros(m), np.zeros(m)
+        k = 0
+        while k < m and it < maxit:
+            w = M(A @ V[k])
+            h = V[:k + 1] @ w
+            w = w - h @ V[:k + 1]
+            Hh[:k + 1, k] = h
+            Hh[k + 1, k] = np.linalg.norm(w)
+            if Hh[k + 1, k] > 0:
+                V[k + 1] = w / Hh[k + 1, k]
+            for i in range(k):
+                t = cs[i] * Hh[i, k] + sn[i] * Hh[i + 1, k]
+                Hh[i + 1, k] = -sn[i] * Hh[i, k] + cs[i] * Hh[i + 1, k]
+                Hh[i, k] = t
+            d = np.hypot(Hh[k, k], Hh[k + 1, k])
+            cs[k], sn[k] = Hh[k, k] / d, Hh[k + 1, k] / d
+            Hh[k, k] = d
+            Hh[k + 1, k] = 0.0
+            g[k + 1] = -sn[k] * g[k]
+            g[k] = cs[k] * g[k]
+            it += 1
+            k += 1
+            hist.append(abs(g[k]))
+            if abs(g[k]) <= max(rtol * beta0, atol):
+                break
+        y = np.linalg.solve(np.triu(Hh[:k, :k]), g[:k])
+        x = x + y @ V[:k]
+        r = M(b - A @ x)
+    return x, hist
+
+
+def build_ns_levels(nx, ny, nz, nlevels, lo, hi):
+    ms = fo.build_levels(nx, ny, nz, nlevels, lo, hi)
+    lays = [NSLayout(m) for m in ms]
+    return ms, lays
+
+
+def newton_step_operators(ms, lays, bcs, igrid, sol, nu, omega=1.0, npre=1, npost=1, order="seventh"):
+    """assemble at level igrid, Galerkin chain, penalty rows, smoothers: everything one Newton iteration prepares"""
+    H = NSHierarchy()
+    A, b = assemble_ns(ms[igrid], lays[igrid], sol, nu, order)
+    H.P = [None] * (igrid + 1)
+    for l in range(1, igrid + 1):
+        H.P[l] = block_prolongator(ms[l - 1], ms[l], lays[l - 1], lays[l], bcs[l][0], bcs[l - 1][0])
+    H.A = [None] * (igrid + 1)
+    H.A[igrid] = A
+    for l in range(igrid, 0, -1):
+        H.A[l - 1] = (H.P[l].T @ H.A[l] @ H.P[l]).tocsr()
+    for l in range(igrid + 1):
+        H.A[l] = fo.zero_rows(H.A[l], bcs[l][0], 1.0)
+    b = b.copy()
+    b[bcs[igrid][0]] = 0.0
+    H.b = b
+    H.npre, H.npost = npre, npost
+    H.smoother = [None] * (igrid + 1)
+    for l in range(1, igrid + 1):
+        patches = vertex_patches(ms[l], lays[l])
+        H.smoother[l] = VankaSmoother(H.A[l], patches, color_patches(patches, lays[l].n), omega)
+    lu = spla.splu(H.A[0].tocsc())
+    H.coarse_solve = lu.solve
+    return H
+
+
+def solve_cavity(nx, ny, nlevels, nu, lo=(-0.5, -0.5, 0.0), hi=(0.5, 0.5, 0.0), tol=1e-10, max_newton=30, linear="direct",
+                 lin_rtol=1e-10, lin_maxit=40, log=None):
+    """NonLinearImplicitSystem::MGsolve, F-cycle.  linear = "direct" (sparse LU of the Jacobian) or "gmres_mg"."""
+    ms, lays = build_ns_levels(nx, ny, 0, nlevels, lo, hi)
+    bcs = [cavity_bc(m, l) for m, l in zip(ms, lays)]
+    sols = [np.zeros(l.n) for l in lays]
+    for l in range(nlevels):
+        sols[l][bcs[l][0]] = bcs[l][1]                      # Initialize + boundary values
+    history = []
+    for igrid in range(nlevels):
+        for it in range(max_newton):
+            H = newton_step_operators(ms, lays, bcs, igrid, sols[igrid], nu)
+            if linear == "direct":
+                eps = spla.spsolve(H.A[igrid].tocsc(), H.b)
+                nlin = 0
+            else:
+                eps, hist = gmres_mg(H, igrid, H.b, rtol=lin_rtol, maxit=lin_maxit)
+                nlin = len(hist) - 1
+            sols[igrid] = sols[igrid] + eps
+            lay = lays[igrid]
+            ratios = []
+            for k in range(lay.dim + 1):
+                s = slice(lay.offset[k], lay.offset[k + 1])
+                ratios.append(np.linalg.norm(eps[s]) / (np.linalg.norm(sols[igrid][s]) + 1e-50))
+            history.append((igrid, it, max(ratios), nlin))
+            if log:
+                log("level %d newton %d eps/sol %.3e linear its %d" % (igrid, it, max(ratios), nlin))
+            if max(ratios) < tol:
+                break
+        if igrid + 1 < nlevels:
+            # ProlongatorSol: Sol_f = P_mesh Sol_c per variable (no boundary re-imposition)
+            layc, layf = lays[igrid], lays[igrid + 1]
+            P = block_prolongator(ms[igrid], ms[igrid + 1], layc, layf)
+            sols[igrid + 1] = P @ sols[igrid]
+    return ms, lays, sols, history
