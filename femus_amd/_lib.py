@@ -22,6 +22,9 @@ def load_library():
             raise LibraryMissing(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C femus_amd/csrc`). There is no CPU fallback." % p)
+        # PyTorch-ROCm ships its own HIP runtime; it has to be the first (and only) one in the process.  Loading this
+        # library before torch maps /opt/rocm's copy as well and the two tear each other down at exit (double free).
+        import torch  # noqa: F401
         _LIB = ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
         _declare(_LIB)
     return _LIB
@@ -118,6 +121,19 @@ def _declare(L):
     sig("fh_element_matrices_poisson", c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p)
     sig("fh_fe_face_nodes", c_int, c_int, c_int, P(c_int), c_void_p)
     sig("fh_assemble_neumann_faces", c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p)
+    sig("fh_mesh_refine_flagged", c_void_p, c_void_p, P(c_void_p))
+    sig("fh_mesh_elem_centroids", c_void_p, c_void_p)
+    sig("fh_mesh_elem_levels", c_void_p, c_void_p, P(c_int))
+    sig("fh_mesh_amr_constraints", c_void_p, c_int, P(c_int), P(c_int), c_void_p, c_void_p, c_void_p, c_void_p)
+    sig("fh_build_amr_prolongator", c_void_p, c_void_p, c_int, P(c_void_p))
+    sig("fh_system_elem_dofs", c_void_p, c_int, c_void_p, P(c_int), c_void_p, c_void_p)
+    sig("fh_build_system_prolongator", c_void_p, c_void_p, c_void_p, c_int, c_void_p, P(c_void_p))
+    sig("fh_mesh_vertex_patches", c_void_p, c_int, c_void_p, P(c_int), P(c_int), c_void_p, c_void_p)
+    sig("fh_ns_assembler_create", c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, P(c_void_p))
+    sig("fh_ns_assembler_destroy", c_void_p)
+    sig("fh_assemble_navier_stokes", c_void_p, c_void_p, c_double, c_void_p, c_void_p)
+    sig("fh_ns_element_matrices", c_void_p, c_void_p, c_double, c_void_p, c_void_p)
+    sig("fh_mg_set_level_patches", c_void_p, c_int, c_int, c_void_p, c_void_p)
     sig("fh_mg_create", c_void_p, c_int, P(c_void_p))
     sig("fh_mg_set_level", c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_int)
     sig("fh_mg_setup", c_void_p)

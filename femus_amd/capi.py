@@ -559,6 +559,60 @@ class Assembler:
         return {"ncolors": nco.value, "algorithmic_bytes": by.value, "flops": fl.value}
 
 
+def system_elem_dofs(mesh, fes):
+    """LinearEquation::GetSystemDof for stacked variables: (nd, offsets[nvars+1], elem_sys[nel, nd])"""
+    fe = _i32([FE[f] for f in fes])
+    nd = ctypes.c_int()
+    off = np.empty(len(fes) + 1, np.int32)
+    _chk(mesh.L.fh_system_elem_dofs(mesh.h, len(fes), _p(fe), ctypes.byref(nd), _p(off), None))
+    es = np.empty((mesh.nel, nd.value), np.int32)
+    _chk(mesh.L.fh_system_elem_dofs(mesh.h, len(fes), _p(fe), ctypes.byref(nd), _p(off), _p(es)))
+    return nd.value, off, es
+
+
+def build_system_prolongator(ctx, coarse, fine, fes):
+    fe = _i32([FE[f] for f in fes])
+    h = ctypes.c_void_p()
+    _chk(ctx.L.fh_build_system_prolongator(ctx.h, coarse.h, fine.h, len(fes), _p(fe), ctypes.byref(h)))
+    return Mat(ctx, h)
+
+
+def vertex_patches(mesh, fes):
+    """blocks of the Vanka smoother: (ptr[npatch+1], dofs)"""
+    fe = _i32([FE[f] for f in fes])
+    n, tot = ctypes.c_int(0), ctypes.c_int(0)
+    _chk(mesh.L.fh_mesh_vertex_patches(mesh.h, len(fes), _p(fe), ctypes.byref(n), ctypes.byref(tot), None, None))
+    ptr, dofs = np.empty(n.value + 1, np.int32), np.empty(tot.value, np.int32)
+    _chk(mesh.L.fh_mesh_vertex_patches(mesh.h, len(fes), _p(fe), ctypes.byref(n), ctypes.byref(tot), _p(ptr), _p(dofs)))
+    return ptr, dofs
+
+
+class NSAssembler:
+    """batched steady Navier-Stokes residual + Newton Jacobian, Taylor-Hood (03_navier_stokes.hpp:187-413 as one call)"""
+
+    def __init__(self, ctx, mesh, A, order="seventh"):
+        self.ctx, self.L = ctx, ctx.L
+        ed, xy, _ = mesh.arrays()
+        self.nel = mesh.nel
+        self.nd = mesh.dim * mesh.nloc + 2 ** mesh.dim
+        self.h = ctypes.c_void_p()
+        _chk(self.L.fh_ns_assembler_create(ctx.h, GEOM[mesh.geom], GAUSS_ORDER[order], mesh.nel, mesh.nloc, _p(ed), mesh.nnode,
+                                           mesh.own_size[0], _p(xy), A.h, ctypes.byref(self.h)))
+
+    def assemble(self, A, res, sol, nu):
+        _chk(self.L.fh_assemble_navier_stokes(self.h, None if sol is None else sol.h, ctypes.c_double(nu), A.h, res.h))
+
+    def element_matrices(self, sol, nu):
+        K, F = np.empty((self.nel, self.nd, self.nd)), np.empty((self.nel, self.nd))
+        _chk(self.L.fh_ns_element_matrices(self.h, None if sol is None else sol.h, ctypes.c_double(nu), _p(K), _p(F)))
+        return K, F
+
+    def destroy(self):
+        if self.h:
+            self.L.fh_ns_assembler_destroy(self.h)
+            self.h = None
+
+
 class Multigrid:
     """LinearEquationSolver MG interface: MGInit / MGSetLevel / MGSolve / MGClear."""
 
@@ -570,6 +624,11 @@ class Multigrid:
     def set_level(self, level, A, P=None, R=None, smoother=0, omega=2. / 3., npre=2, npost=2):
         _chk(self.L.fh_mg_set_level(self.h, int(level), A.h, None if P is None else P.h, None if R is None else R.h,
                                     int(smoother), float(omega), int(npre), int(npost)))
+
+    def set_level_patches(self, level, ptr, dofs):
+        """dof patches of the block Schwarz (Vanka) smoother of a level (smoother=2)"""
+        ptr, dofs = _i32(ptr), _i32(dofs)
+        _chk(self.L.fh_mg_set_level_patches(self.h, int(level), ptr.size - 1, _p(ptr), _p(dofs)))
 
     def set_level_distributed(self, level, halo, replicated_below=False):
         _chk(self.L.fh_mg_set_level_distributed(self.h, int(level), None if halo is None else halo.h, 1 if replicated_below else 0))

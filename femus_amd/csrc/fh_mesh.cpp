@@ -757,3 +757,115 @@ extern "C" int fh_build_amr_prolongator(fh_ctx_t ctx, fh_mesh_t m, int fe, fh_ma
   }
   return fh_mat_create_csr(ctx, n, n, rowptr.data(), col.data(), val.data(), out);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// multi-variable systems (a9, a21): LinearEquation::GetSystemDof (LinearEquation.cpp:76-85) with the nprocs = 1 offsets
+// KKoffset[k] = sum of the sizes of the variables before k (:212-237).  Variables are Lagrange families 0 (Q1) or 2 (Q2).
+// ---------------------------------------------------------------------------------------------------------------------
+static int check_vars(const char* who, int nvars, const int* fe) {
+  FH_REQUIRE(nvars >= 1 && nvars <= 8 && fe, "%s: 1..8 variables expected", who);
+  for (int k = 0; k < nvars; k++) FH_REQUIRE(fe[k] == 0 || fe[k] == 2, "%s: variable %d: fe must be 0 or 2", who, k);
+  return 0;
+}
+
+extern "C" int fh_system_elem_dofs(fh_mesh_t m, int nvars, const int* fe, int* nd_out, int* offsets, int* elem_sys) {
+  FH_REQUIRE(m, "fh_system_elem_dofs: null mesh");
+  FH_TRY(check_vars("fh_system_elem_dofs", nvars, fe));
+  int nd = 0, off = 0;
+  std::vector<int> offs(nvars + 1, 0);
+  for (int k = 0; k < nvars; k++) {
+    nd += ndofs_of(m->geom, fe[k]);
+    off += mesh_ndofs(m, fe[k]);
+    offs[k + 1] = off;
+  }
+  if (nd_out) *nd_out = nd;
+  if (offsets) memcpy(offsets, offs.data(), offs.size() * sizeof(int));
+  if (elem_sys)
+    for (int iel = 0; iel < m->nel; iel++) {
+      int p = 0;
+      for (int k = 0; k < nvars; k++)
+        for (int i = 0; i < ndofs_of(m->geom, fe[k]); i++) elem_sys[(size_t)iel * nd + p++] = offs[k] + m->elem_dof[(size_t)iel * m->nloc + i];
+    }
+  return 0;
+}
+
+// BuildProlongatorMatrix loops the system variables (LinearImplicitSystem.cpp:890-905): block-diagonal interpolation,
+// one block per variable; Dirichlet rows / columns are zeroed by the caller (fh_mat_zero_rows / fh_mat_zero_cols)
+extern "C" int fh_build_system_prolongator(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t mf, int nvars, const int* fe, fh_mat_t* out) {
+  FH_REQUIRE(ctx && mc && mf && out, "fh_build_system_prolongator: null argument");
+  FH_TRY(check_vars("fh_build_system_prolongator", nvars, fe));
+  fh_mat_t blk[3] = {nullptr, nullptr, nullptr};
+  for (int k = 0; k < nvars; k++)
+    if (!blk[fe[k]]) FH_TRY(fh_build_prolongator(ctx, mc, mf, fe[k], 0, &blk[fe[k]]));
+  int nf = 0, ncc = 0;
+  int64_t nnz = 0;
+  for (int k = 0; k < nvars; k++) {
+    nf += blk[fe[k]]->m;
+    ncc += blk[fe[k]]->n;
+    nnz += blk[fe[k]]->nnz;
+  }
+  FH_REQUIRE(nnz < 2147483647ll, "fh_build_system_prolongator: nnz overflows int32");
+  std::vector<int> rowptr(nf + 1, 0), col((size_t)nnz);
+  std::vector<double> val((size_t)nnz);
+  int r0 = 0, c0 = 0, p = 0;
+  for (int k = 0; k < nvars; k++) {
+    fh_mat_t B = blk[fe[k]];
+    std::vector<double> bv(B->nnz);
+    FH_CHECK_HIP(hipMemcpy(bv.data(), B->d_val, (size_t)B->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < B->m; i++) {
+      for (int q = B->h_rowptr[i]; q < B->h_rowptr[i + 1]; q++) {
+        col[p] = c0 + B->h_col[q];
+        val[p++] = bv[q];
+      }
+      rowptr[r0 + i + 1] = p;
+    }
+    r0 += B->m;
+    c0 += B->n;
+  }
+  for (auto b : blk)
+    if (b) fh_mat_destroy(b);
+  return fh_mat_create_csr(ctx, nf, ncc, rowptr.data(), col.data(), val.data(), out);
+}
+
+// Blocks of the Schwarz (Vanka) smoother for saddle-point systems, the GPU form of the element-block ASM of
+// petsc_asm/LinearEquationSolverPetscAsm.cpp:91-276 with one block per dof of the LAST variable (the "Schur" variable,
+// :223-256): that dof plus, for every other variable, all dofs of the elements that own it (:134-170).  Two-call
+// protocol: ptr == NULL returns the counts.
+extern "C" int fh_mesh_vertex_patches(fh_mesh_t m, int nvars, const int* fe, int* npatch, int* total, int* ptr, int* dofs) {
+  FH_REQUIRE(m && npatch && total, "fh_mesh_vertex_patches: null argument");
+  FH_TRY(check_vars("fh_mesh_vertex_patches", nvars, fe));
+  FH_REQUIRE(nvars >= 2, "fh_mesh_vertex_patches: needs at least one non-Schur variable and the Schur variable");
+  const int nl = m->nloc, ns = mesh_ndofs(m, fe[nvars - 1]), ncs = ndofs_of(m->geom, fe[nvars - 1]);
+  std::vector<int> offs(nvars + 1, 0);
+  for (int k = 0; k < nvars; k++) offs[k + 1] = offs[k] + mesh_ndofs(m, fe[k]);
+  // elements of every Schur dof
+  std::vector<int> eptr(ns + 1, 0);
+  for (int iel = 0; iel < m->nel; iel++)
+    for (int i = 0; i < ncs; i++) eptr[m->elem_dof[(size_t)iel * nl + i] + 1]++;
+  for (int v = 0; v < ns; v++) eptr[v + 1] += eptr[v];
+  std::vector<int> eadj(eptr[ns]), cur(eptr.begin(), eptr.end() - 1);
+  for (int iel = 0; iel < m->nel; iel++)
+    for (int i = 0; i < ncs; i++) eadj[cur[m->elem_dof[(size_t)iel * nl + i]]++] = iel;
+  std::vector<int> out_ptr(1, 0), out_dofs, nodes;
+  for (int v = 0; v < ns; v++) {
+    for (int k = 0; k < nvars - 1; k++) {
+      const int nck = ndofs_of(m->geom, fe[k]);
+      nodes.clear();
+      for (int q = eptr[v]; q < eptr[v + 1]; q++)
+        for (int i = 0; i < nck; i++) nodes.push_back(m->elem_dof[(size_t)eadj[q] * nl + i]);
+      std::sort(nodes.begin(), nodes.end());
+      nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
+      for (int nd : nodes) out_dofs.push_back(offs[k] + nd);
+    }
+    out_dofs.push_back(offs[nvars - 1] + v);
+    out_ptr.push_back((int)out_dofs.size());
+  }
+  if (ptr) {
+    FH_REQUIRE(*npatch >= ns && *total >= (int)out_dofs.size(), "fh_mesh_vertex_patches: capacity too small");
+    memcpy(ptr, out_ptr.data(), out_ptr.size() * sizeof(int));
+    if (dofs) memcpy(dofs, out_dofs.data(), out_dofs.size() * sizeof(int));
+  }
+  *npatch = ns;
+  *total = (int)out_dofs.size();
+  return 0;
+}

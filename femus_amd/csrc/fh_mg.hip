@@ -31,6 +31,13 @@ struct MgLevel {
   int ncolors = 0;
   std::vector<int> color_ptr;
   int* d_color_rows = nullptr;
+  // block Schwarz (Vanka) smoother: dof patches, their colours and dense inverses
+  int npatch = 0, vanka_ncolors = 0, max_patch = 0;
+  std::vector<int> h_pptr, h_pdofs, vcolor_ptr;
+  std::vector<int64_t> h_poff;
+  int *d_pptr = nullptr, *d_pdofs = nullptr, *d_porder = nullptr, *d_pflag = nullptr;
+  int64_t* d_poff = nullptr;
+  double* d_pinv = nullptr;
   // distributed level: operator = owned rows over [owned | ghost] columns; halo refreshes the ghosts
   fh_halo_t halo = nullptr;
   bool replicated_below = false;
@@ -77,6 +84,155 @@ __global__ __launch_bounds__(256) void k_gs_color(const int* __restrict__ rows, 
 #pragma unroll
   for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if (live && gl == 0) z[i] = dinv[i] * (r[i] - acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// block Schwarz (Vanka) smoother for saddle-point systems: x_p += omega A_pp^-1 (b - A x)_p for every patch p, patches of one
+// colour concurrently (patches of a colour neither share a dof nor read one another's dofs, so the order inside a colour is
+// irrelevant), colours in sequence = multiplicative Schwarz.  GPU form of the element-block ASM smoother the reference
+// selects with FEMuS_ASM (petsc_asm/LinearEquationSolverPetscAsm.cpp:91-345).
+// ------------------------------------------------------------------------------------------------
+// dense copy of A restricted to the patch, stored TRANSPOSED (column-major) so that the apply kernel reads it coalesced
+__global__ __launch_bounds__(256) void k_patch_extract(const int* __restrict__ pptr, const int* __restrict__ pdofs, const int64_t* __restrict__ poff,
+                                                       const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+                                                       double* __restrict__ M) {
+  const int p = blockIdx.x;
+  const int* d = pdofs + pptr[p];
+  const int np = pptr[p + 1] - pptr[p];
+  double* Mp = M + poff[p];
+  for (int t = threadIdx.x; t < np * np; t += 256) {
+    const int a = t / np, b = t % np;    // entry (row a, col b) of the patch matrix
+    const int r = d[a], c = d[b];
+    int lo = rowptr[r], hi = rowptr[r + 1] - 1;
+    double v = 0.0;
+    while (lo <= hi) {
+      const int mid = (lo + hi) >> 1;
+      const int cc = col[mid];
+      if (cc == c) {
+        v = val[mid];
+        break;
+      }
+      if (cc < c) lo = mid + 1; else hi = mid - 1;
+    }
+    Mp[(size_t)a * np + b] = v;
+  }
+}
+
+// in-place inverse by Gauss-Jordan with partial (row) pivoting, one workgroup per patch, row-major in global memory (the
+// patch matrix is L2-resident); on exit the matrix is transposed in place for the apply kernel.  flag[p] = 1: singular.
+__global__ __launch_bounds__(256) void k_patch_invert(const int* __restrict__ pptr, const int64_t* __restrict__ poff, double* __restrict__ M,
+                                                      int* __restrict__ flag) {
+  __shared__ int piv[512];
+  __shared__ double red_v[256];
+  __shared__ int red_i[256];
+  __shared__ double colk[512];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const int n = pptr[p + 1] - pptr[p];
+  double* A = M + poff[p];
+  bool singular = false;
+  for (int k = 0; k < n; k++) {
+    // pivot search: largest |A[i][k]|, i >= k, smallest index on ties
+    double best = -1.0;
+    int bi = k;
+    for (int i = k + tid; i < n; i += 256) {
+      const double v = fabs(A[(size_t)i * n + k]);
+      if (v > best) {
+        best = v;
+        bi = i;
+      }
+    }
+    red_v[tid] = best;
+    red_i[tid] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) {
+        const double v2 = red_v[tid + s];
+        const int i2 = red_i[tid + s];
+        if (v2 > red_v[tid] || (v2 == red_v[tid] && i2 < red_i[tid])) {
+          red_v[tid] = v2;
+          red_i[tid] = i2;
+        }
+      }
+      __syncthreads();
+    }
+    const int pr = red_i[0];
+    const double pmax = red_v[0];
+    __syncthreads();
+    if (tid == 0) piv[k] = pr;
+    if (!(pmax > 0.0)) {
+      singular = true;
+      break;
+    }
+    if (pr != k)
+      for (int j = tid; j < n; j += 256) {
+        const double t = A[(size_t)k * n + j];
+        A[(size_t)k * n + j] = A[(size_t)pr * n + j];
+        A[(size_t)pr * n + j] = t;
+      }
+    __syncthreads();
+    const double pv = 1.0 / A[(size_t)k * n + k];
+    for (int i = tid; i < n; i += 256) colk[i] = A[(size_t)i * n + k];
+    __syncthreads();
+    for (int j = tid; j < n; j += 256) A[(size_t)k * n + j] = (j == k) ? pv : A[(size_t)k * n + j] * pv;
+    __syncthreads();
+    for (int t = tid; t < n * n; t += 256) {
+      const int i = t / n, j = t % n;
+      if (i == k) continue;
+      const double f = colk[i];
+      const double akj = A[(size_t)k * n + j];
+      A[t] = (j == k) ? -f * akj : A[t] - f * akj;
+    }
+    __syncthreads();
+  }
+  if (singular) {
+    if (tid == 0) flag[p] = 1;
+    return;
+  }
+  // undo the row interchanges as column interchanges, last first
+  for (int k = n - 1; k >= 0; k--) {
+    const int pr = piv[k];
+    if (pr != k)
+      for (int i = tid; i < n; i += 256) {
+        const double t = A[(size_t)i * n + k];
+        A[(size_t)i * n + k] = A[(size_t)i * n + pr];
+        A[(size_t)i * n + pr] = t;
+      }
+    __syncthreads();
+  }
+  // transpose in place
+  for (int t = tid; t < n * n; t += 256) {
+    const int i = t / n, j = t % n;
+    if (i < j) {
+      const double a = A[(size_t)i * n + j];
+      A[(size_t)i * n + j] = A[(size_t)j * n + i];
+      A[(size_t)j * n + i] = a;
+    }
+  }
+}
+
+// one colour of the sweep; one workgroup of 64 per patch; MAXP = LDS capacity for the patch residual
+__global__ __launch_bounds__(64) void k_vanka_color(const int* __restrict__ order, int npat, const int* __restrict__ pptr, const int* __restrict__ pdofs,
+                                                    const int64_t* __restrict__ poff, const double* __restrict__ Minv, const int* __restrict__ rowptr,
+                                                    const int* __restrict__ col, const double* __restrict__ val, const double* __restrict__ b,
+                                                    double* x, double omega) {
+  extern __shared__ double rp[];
+  if ((int)blockIdx.x >= npat) return;
+  const int p = order[blockIdx.x], lane = threadIdx.x;
+  const int* d = pdofs + pptr[p];
+  const int np = pptr[p + 1] - pptr[p];
+  for (int a = lane; a < np; a += 64) {
+    const int r = d[a];
+    double s = 0.0;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; k++) s += val[k] * x[col[k]];
+    rp[a] = b[r] - s;
+  }
+  __syncthreads();
+  const double* Mi = Minv + poff[p];     // transposed inverse: Mi[b * np + a] = inv[a][b]
+  for (int a = lane; a < np; a += 64) {
+    double s = 0.0;
+    for (int c = 0; c < np; c++) s += Mi[(size_t)c * np + a] * rp[c];
+    x[d[a]] += omega * s;
+  }
 }
 
 // y = Ainv b, one wave per row, 16-byte loads
@@ -289,7 +445,8 @@ extern "C" int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh
   FH_REQUIRE(A->m <= A->n, "fh_mg_set_level: operator must be square (or owned rows x local columns on a distributed level)");
   FH_REQUIRE(level == 0 || P != nullptr, "fh_mg_set_level: level %d needs an interpolation matrix", level);
   FH_REQUIRE(!P || P->m == A->m, "fh_mg_set_level: interpolation has %d rows, operator has %d", P ? P->m : 0, A->m);
-  FH_REQUIRE(smoother == FH_SMOOTH_JACOBI || smoother == FH_SMOOTH_GS_COLOR, "fh_mg_set_level: unknown smoother %d (0 = Richardson+Jacobi, 1 = Richardson+multicolour SOR)", smoother);
+  FH_REQUIRE(smoother == FH_SMOOTH_JACOBI || smoother == FH_SMOOTH_GS_COLOR || smoother == FH_SMOOTH_VANKA,
+             "fh_mg_set_level: unknown smoother %d (0 = Richardson+Jacobi, 1 = Richardson+multicolour SOR, 2 = block Schwarz / Vanka)", smoother);
   FH_REQUIRE(npre >= 0 && npost >= 0, "fh_mg_set_level: negative sweep count");
   MgLevel& L = mg->lv[level];
   if (L.own_R && (R != nullptr || L.R_of != P)) free_level_restriction(L);
@@ -326,6 +483,129 @@ static void free_level_colors(MgLevel& L) {
   if (L.d_color_rows) hipFree(L.d_color_rows);
   L.d_color_rows = nullptr;
   L.ncolors = 0;
+}
+
+static void free_level_patches(MgLevel& L) {
+  for (void** q : {(void**)&L.d_pptr, (void**)&L.d_pdofs, (void**)&L.d_porder, (void**)&L.d_pflag, (void**)&L.d_poff, (void**)&L.d_pinv})
+    if (*q) {
+      hipFree(*q);
+      *q = nullptr;
+    }
+  L.npatch = 0;
+  L.vanka_ncolors = 0;
+}
+
+extern "C" int fh_mg_set_level_patches(fh_mg_t mg, int level, int npatch, const int* ptr, const int* dofs) {
+  FH_REQUIRE(mg && level >= 0 && level < mg->nlevels && npatch > 0 && ptr && dofs, "fh_mg_set_level_patches: bad arguments");
+  MgLevel& L = mg->lv[level];
+  free_level_patches(L);
+  L.npatch = npatch;
+  L.h_pptr.assign(ptr, ptr + npatch + 1);
+  L.h_pdofs.assign(dofs, dofs + ptr[npatch]);
+  L.h_poff.assign(npatch + 1, 0);
+  L.max_patch = 0;
+  for (int p = 0; p < npatch; p++) {
+    const int np = ptr[p + 1] - ptr[p];
+    FH_REQUIRE(np > 0 && np <= 512, "fh_mg_set_level_patches: patch %d has %d dofs (1..512 supported)", p, np);
+    L.max_patch = std::max(L.max_patch, np);
+    L.h_poff[p + 1] = L.h_poff[p] + (int64_t)np * np;
+  }
+  mg->setup_done = false;
+  return 0;
+}
+
+// greedy colouring in patch order; two patches conflict when a dof of one appears in the matrix rows of the other
+static int color_patches(MgLevel& L) {
+  const int n = L.A->m, np = L.npatch;
+  const std::vector<int>&rp = L.A->h_rowptr, &cl = L.A->h_col;
+  for (int d : L.h_pdofs) FH_REQUIRE(d >= 0 && d < n, "Vanka smoother: patch dof %d out of range", d);
+  std::vector<int> optr(n + 1, 0), rptr(n + 1, 0);
+  std::vector<std::vector<int>> reads(np);
+  std::vector<int> mark(n, -1);
+  for (int p = 0; p < np; p++) {
+    for (int q = L.h_pptr[p]; q < L.h_pptr[p + 1]; q++) {
+      const int r = L.h_pdofs[q];
+      optr[r + 1]++;
+      for (int k = rp[r]; k < rp[r + 1]; k++)
+        if (mark[cl[k]] != p) {
+          mark[cl[k]] = p;
+          reads[p].push_back(cl[k]);
+        }
+    }
+    for (int c : reads[p]) rptr[c + 1]++;
+  }
+  for (int i = 0; i < n; i++) {
+    optr[i + 1] += optr[i];
+    rptr[i + 1] += rptr[i];
+  }
+  std::vector<int> owner(optr[n]), reader(rptr[n]), oc(optr.begin(), optr.end() - 1), rc(rptr.begin(), rptr.end() - 1);
+  for (int p = 0; p < np; p++) {
+    for (int q = L.h_pptr[p]; q < L.h_pptr[p + 1]; q++) owner[oc[L.h_pdofs[q]]++] = p;
+    for (int c : reads[p]) reader[rc[c]++] = p;
+  }
+  std::vector<int> color(np, -1), used;
+  int ncol = 0;
+  for (int p = 0; p < np; p++) {
+    used.assign(ncol + 1, 0);
+    for (int c : reads[p])
+      for (int k = optr[c]; k < optr[c + 1]; k++)
+        if (color[owner[k]] >= 0) used[color[owner[k]]] = 1;
+    for (int q = L.h_pptr[p]; q < L.h_pptr[p + 1]; q++) {
+      const int d = L.h_pdofs[q];
+      for (int k = rptr[d]; k < rptr[d + 1]; k++)
+        if (color[reader[k]] >= 0) used[color[reader[k]]] = 1;
+    }
+    int c = 0;
+    while (used[c]) c++;
+    color[p] = c;
+    ncol = std::max(ncol, c + 1);
+  }
+  L.vanka_ncolors = ncol;
+  L.vcolor_ptr.assign(ncol + 1, 0);
+  for (int p = 0; p < np; p++) L.vcolor_ptr[color[p] + 1]++;
+  for (int c = 0; c < ncol; c++) L.vcolor_ptr[c + 1] += L.vcolor_ptr[c];
+  std::vector<int> order(np), pos(L.vcolor_ptr.begin(), L.vcolor_ptr.end() - 1);
+  for (int p = 0; p < np; p++) order[pos[color[p]]++] = p;
+  auto up = [&](void** d, const void* h, size_t bytes) -> int {
+    FH_CHECK_HIP(hipMalloc(d, bytes ? bytes : 8));
+    if (bytes) FH_CHECK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+    return 0;
+  };
+  FH_TRY(up((void**)&L.d_pptr, L.h_pptr.data(), L.h_pptr.size() * sizeof(int)));
+  FH_TRY(up((void**)&L.d_pdofs, L.h_pdofs.data(), L.h_pdofs.size() * sizeof(int)));
+  FH_TRY(up((void**)&L.d_poff, L.h_poff.data(), L.h_poff.size() * sizeof(int64_t)));
+  FH_TRY(up((void**)&L.d_porder, order.data(), order.size() * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&L.d_pflag, (size_t)np * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&L.d_pinv, (size_t)L.h_poff[np] * sizeof(double)));
+  return 0;
+}
+
+// numeric part of the smoother setup (every fh_mg_setup, i.e. every Newton iteration): extract and invert the patch matrices
+static int factor_patches(fh_mg_t mg, MgLevel& L) {
+  fh_ctx_t c = mg->ctx;
+  FH_CHECK_HIP(hipMemsetAsync(L.d_pflag, 0, (size_t)L.npatch * sizeof(int), c->stream));
+  hipLaunchKernelGGL(k_patch_extract, dim3(L.npatch), dim3(256), 0, c->stream, L.d_pptr, L.d_pdofs, L.d_poff, L.A->d_rowptr, L.A->d_col, L.A->d_val,
+                     L.d_pinv);
+  hipLaunchKernelGGL(k_patch_invert, dim3(L.npatch), dim3(256), 0, c->stream, L.d_pptr, L.d_poff, L.d_pinv, L.d_pflag);
+  FH_CHECK_HIP(hipGetLastError());
+  std::vector<int> flag(L.npatch);
+  FH_CHECK_HIP(hipMemcpyAsync(flag.data(), L.d_pflag, flag.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  for (int p = 0; p < L.npatch; p++) FH_REQUIRE(flag[p] == 0, "Vanka smoother: the matrix of patch %d is singular", p);
+  return 0;
+}
+
+static int vanka_sweeps(fh_mg_t mg, MgLevel& L, int nsweeps) {
+  fh_ctx_t c = mg->ctx;
+  for (int s = 0; s < nsweeps; s++)
+    for (int k = 0; k < L.vanka_ncolors; k++) {
+      const int np = L.vcolor_ptr[k + 1] - L.vcolor_ptr[k];
+      if (np == 0) continue;
+      hipLaunchKernelGGL(k_vanka_color, dim3(np), dim3(64), (size_t)L.max_patch * sizeof(double), c->stream, L.d_porder + L.vcolor_ptr[k], np,
+                         L.d_pptr, L.d_pdofs, L.d_poff, L.d_pinv, L.A->d_rowptr, L.A->d_col, L.A->d_val, L.b, L.x, L.omega);
+    }
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
 static void free_level_restriction(MgLevel& L) {
@@ -427,6 +707,11 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
     }
     FH_TRY(fh_dev_get_diag(L.A, L.dinv, 1));
     if (L.smoother == FH_SMOOTH_GS_COLOR && l > 0 && L.ncolors == 0) FH_TRY(color_rows(L));
+    if (L.smoother == FH_SMOOTH_VANKA && l > 0) {
+      FH_REQUIRE(L.npatch > 0 && !L.halo, "fh_mg_setup: level %d uses the Vanka smoother but has no patches (fh_mg_set_level_patches)", l);
+      if (!L.d_pinv) FH_TRY(color_patches(L));
+      FH_TRY(factor_patches(mg, L));
+    }
     if (l > 0) {
       if (!L.R) {   // restriction = transpose of the interpolation (LinearImplicitSystem.cpp:379-382); kept across re-setups
         FH_TRY(fh_mat_transpose(L.P, &L.R));
@@ -496,6 +781,9 @@ static int run_cycle(fh_mg_t mg) {
     MgLevel& L = mg->lv[l];
     if (L.npre == 0) {
       FH_CHECK_HIP(hipMemsetAsync(L.x, 0, (size_t)L.ncols * sizeof(double), c->stream));
+    } else if (L.smoother == FH_SMOOTH_VANKA) {
+      FH_CHECK_HIP(hipMemsetAsync(L.x, 0, (size_t)L.ncols * sizeof(double), c->stream));
+      FH_TRY(vanka_sweeps(mg, L, L.npre));
     } else if (L.smoother == FH_SMOOTH_GS_COLOR) {
       FH_TRY(gs_sweeps(mg, L, L.npre, true));
       if (L.halo) FH_TRY(fh_halo_update_ptr(L.halo, L.x, L.n));
@@ -525,6 +813,10 @@ static int run_cycle(fh_mg_t mg) {
     FH_TRY(fh_dev_spmv(L.P, Lc.x, L.x, 1, nullptr, nullptr, 0.0));                   // x += P x_{l-1}
     if (L.smoother == FH_SMOOTH_GS_COLOR) {
       FH_TRY(gs_sweeps(mg, L, L.npost, false));
+      continue;
+    }
+    if (L.smoother == FH_SMOOTH_VANKA) {
+      FH_TRY(vanka_sweeps(mg, L, L.npost));
       continue;
     }
     for (int s = 0; s < L.npost; s++) {
@@ -571,6 +863,7 @@ extern "C" int fh_mg_destroy(fh_mg_t mg) {
     free_level_buffers(L);
     free_level_restriction(L);
     free_level_colors(L);
+    free_level_patches(L);
   }
   if (mg->d_ainv) hipFree(mg->d_ainv);
   for (double* p : mg->kv) hipFree(p);

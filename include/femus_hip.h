@@ -192,6 +192,28 @@ int fh_fe_face_nodes(int geom, int fe, int face, int* nfn, int* local_nodes);
 int fh_assemble_neumann_faces(fh_ctx_t ctx, int geom, int fe, int gauss_order, int nfaces, const int* face_nodes, const double* tau,
                               int nnode, const double* coords, fh_vec_t res);
 
+/* ---- multi-variable systems and the Navier-Stokes Newton path (a9, a21) --------------------------------------------
+ * Variables are stacked per rank: system dof = KKoffset[k] + mesh dof (LinearEquation::GetSystemDof, LinearEquation.cpp:76-85,
+ * :212-237; nprocs = 1).  fe[k] in {0, 2}.  elem_sys[nel*nd] lists, per element, the dofs of variable 0, then 1, ... */
+int fh_system_elem_dofs(fh_mesh_t mesh, int nvars, const int* fe, int* nd, int* offsets /* [nvars+1] or NULL */, int* elem_sys /* or NULL */);
+/* BuildProlongatorMatrix over the system variables (LinearImplicitSystem.cpp:826-909): block-diagonal interpolation; apply
+ * ZeroInterpolatorDirichletNodes with fh_mat_zero_rows(fine bdc, 0) / fh_mat_zero_cols(coarse bdc) */
+int fh_build_system_prolongator(fh_ctx_t ctx, fh_mesh_t coarse, fh_mesh_t fine, int nvars, const int* fe, fh_mat_t* P);
+/* blocks of the Schwarz (Vanka) smoother: one per dof of the LAST variable (the Schur / pressure variable), holding that dof
+ * and all dofs of the other variables on the elements that own it (LinearEquationSolverPetscAsm.cpp:134-256).  Two-call
+ * protocol (ptr == NULL: counts only) */
+int fh_mesh_vertex_patches(fh_mesh_t mesh, int nvars, const int* fe, int* npatch, int* total, int* ptr, int* dofs);
+/* steady Navier-Stokes, Taylor-Hood Q2/Q1, variables [U | V | (W) | P]: residual and Newton Jacobian of
+ * src/08_equations/assemble/03_navier_stokes.hpp:330-409 as ONE batched call (the reference differentiates the residual with
+ * an adept tape per element, Assemble_jacobian.cpp:39-72; here the derivative is written out).  A must carry the pattern of
+ * fh_pattern_from_elements over fh_system_elem_dofs.  sol may be NULL (= 0).  nu: kinematic viscosity. */
+typedef struct fh_ns_assembler_s* fh_ns_assembler_t;
+int fh_ns_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, int n_vertex_nodes,
+                           const double* coords /* [nnode*dim] */, fh_mat_t A, fh_ns_assembler_t* as);
+int fh_ns_assembler_destroy(fh_ns_assembler_t as);
+int fh_assemble_navier_stokes(fh_ns_assembler_t as, fh_vec_t sol, double nu, fh_mat_t A, fh_vec_t res);
+int fh_ns_element_matrices(fh_ns_assembler_t as, fh_vec_t sol, double nu, double* K /* [nel*nd*nd] */, double* F /* [nel*nd] */);
+
 /* ---- multigrid: LinearEquationSolver (03_solvers/LinearEquationSolver.hpp:54-261, LinearEquationSolverPetsc.cpp) ----
  * fh_mg_create      <- MGInit   (:185-215)   nlevels, outer solver
  * fh_mg_set_level   <- MGSetLevel (:219-290) operator, interpolation PP (restriction = PP^T when R==NULL,
@@ -201,10 +223,15 @@ int fh_assemble_neumann_faces(fh_ctx_t ctx, int geom, int fe, int gauss_order, i
  * fh_mg_vcycle      <- one PCMG multiplicative V-cycle application x = M^-1 b
  * fh_mg_solve       <- MGSolve (:294-353): outer solver preconditioned by the cycle
  * fh_mg_destroy     <- MGClear (LinearEquationSolverPetsc.hpp:86-88) */
-enum { FH_SMOOTH_JACOBI = 0, FH_SMOOTH_GS_COLOR = 1 };
+enum { FH_SMOOTH_JACOBI = 0, FH_SMOOTH_GS_COLOR = 1, FH_SMOOTH_VANKA = 2 };
 enum { FH_OUTER_PREONLY = 0, FH_OUTER_RICHARDSON = 1, FH_OUTER_GMRES = 2, FH_OUTER_CG = 3 };
 int fh_mg_create(fh_ctx_t ctx, int nlevels, fh_mg_t* mg);
 int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh_mat_t R, int smoother, double omega, int npre, int npost);
+/* FH_SMOOTH_VANKA: block Schwarz smoother for saddle-point systems (the FEMuS_ASM choice of the Navier-Stokes applications,
+ * petsc_asm/LinearEquationSolverPetscAsm.cpp:91-345): x_p += omega A_pp^-1 (b - A x)_p per patch of dofs, multiplicative over
+ * conflict-free colours of patches.  Patches (fh_mesh_vertex_patches) are given per level before fh_mg_setup, which
+ * extracts and inverts the patch matrices (dense, partial pivoting) from the level's current operator. */
+int fh_mg_set_level_patches(fh_mg_t mg, int level, int npatch, const int* ptr /* [npatch+1] */, const int* dofs);
 int fh_mg_setup(fh_mg_t mg);
 int fh_mg_vcycle(fh_mg_t mg, fh_vec_t b, fh_vec_t x);
 int fh_mg_solve(fh_mg_t mg, fh_vec_t b, fh_vec_t x, int outer, double rtol, double atol, double dtol, int maxit, int restart,

@@ -170,17 +170,30 @@ def vertex_patches(mesh, lay):
     return patches
 
 
-def color_patches(patches, n):
-    """greedy colouring in patch order: patches sharing a dof get different colours"""
+def color_patches(patches, A):
+    """greedy colouring in patch order.  Two patches conflict when one writes a dof the other reads, i.e. when a dof of one
+    appears in the matrix rows of the other: patches of one colour can then be relaxed in any order (or concurrently)."""
+    A = A.tocsr()
+    n = A.shape[0]
     owner = [[] for _ in range(n)]
+    reader = [[] for _ in range(n)]
+    reads = []
     for p, d in enumerate(patches):
+        rs = np.unique(np.concatenate([A.indices[A.indptr[i]:A.indptr[i + 1]] for i in d]))
+        reads.append(rs)
         for i in d:
             owner[i].append(p)
+        for i in rs:
+            reader[i].append(p)
     color = np.full(len(patches), -1, dtype=np.int64)
     for p, d in enumerate(patches):
         used = set()
-        for i in d:
+        for i in reads[p]:
             for q in owner[i]:
+                if color[q] >= 0:
+                    used.add(color[q])
+        for i in d:
+            for q in reader[i]:
                 if color[q] >= 0:
                     used.add(color[q])
         c = 0
@@ -288,7 +301,7 @@ def build_ns_levels(nx, ny, nz, nlevels, lo, hi):
     return ms, lays
 
 
-def newton_step_operators(ms, lays, bcs, igrid, sol, nu, omega=1.0, npre=1, npost=1, order="seventh"):
+def newton_step_operators(ms, lays, bcs, igrid, sol, nu, omega=0.6, npre=2, npost=2, order="seventh"):
     """assemble at level igrid, Galerkin chain, penalty rows, smoothers: everything one Newton iteration prepares"""
     H = NSHierarchy()
     A, b = assemble_ns(ms[igrid], lays[igrid], sol, nu, order)
@@ -308,7 +321,7 @@ def newton_step_operators(ms, lays, bcs, igrid, sol, nu, omega=1.0, npre=1, npos
     H.smoother = [None] * (igrid + 1)
     for l in range(1, igrid + 1):
         patches = vertex_patches(ms[l], lays[l])
-        H.smoother[l] = VankaSmoother(H.A[l], patches, color_patches(patches, lays[l].n), omega)
+        H.smoother[l] = VankaSmoother(H.A[l], patches, color_patches(patches, H.A[l]), omega)
     lu = spla.splu(H.A[0].tocsc())
     H.coarse_solve = lu.solve
     return H

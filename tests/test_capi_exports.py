@@ -15,6 +15,7 @@ def declared_symbols():
 
 
 def test_library_exports_every_declared_symbol():
+    femus_amd.load_library()      # orders the HIP runtimes (torch first) before the raw handle below
     L = ctypes.CDLL(femus_amd.library_path())
     names = declared_symbols()
     assert len(names) > 60
