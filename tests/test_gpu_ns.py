@@ -1,0 +1,117 @@
+"""GPU parity for the Navier-Stokes Newton / multigrid path (BASELINE config "003_NavierStokes lid-driven
+cavity, Q2/Q1 Taylor-Hood, Newton + GMG-preconditioned GMRES") through the C-ABI against the oracle."""
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+from femus_amd import capi
+from femus_amd.navier_stokes import NavierStokesMG
+from oracle import femus_oracle as fo
+from oracle import femus_oracle_ns as ns
+
+pytestmark = pytest.mark.gpu
+LO, HI = (-0.5, -0.5, -0.5), (0.5, 0.5, 0.5)
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("box", [(3, 2, 0), (2, 1, 2)])
+def test_element_jacobian_and_assembly_match_oracle(ctx, box):
+    mo = fo.build_levels(*box, 1, LO, HI)[0]
+    mh = capi.Mesh.box(*box, LO, HI)
+    rng = np.random.default_rng(3)
+    mo.coords = mo.coords + 0.02 * rng.standard_normal(mo.coords.shape)     # distorted elements: full Jacobian path
+    mh.set_coords(mo.coords)
+    lay = ns.NSLayout(mo)
+    fes = ["biquadratic"] * mo.dim + ["linear"]
+    nd, off, es = capi.system_elem_dofs(mh, fes)
+    rp, col = capi.pattern_from_elements(es, lay.n)
+    ipo, ico = ns.csr_pattern_sys(lay)
+    assert np.array_equal(rp, ipo) and np.array_equal(col, ico)              # sparsity: integer, identical
+    A = ctx.matrix_csr(lay.n, lay.n, rp, col)
+    asm = capi.NSAssembler(ctx, mh, A)
+    u = 0.5 * rng.standard_normal(lay.n)
+    sol = ctx.vector_from(u)
+    nu = 0.03
+    K, F = asm.element_matrices(sol, nu)
+    etv, etp = fo.ElemType(mo.geom, "biquadratic"), fo.ElemType(mo.geom, "linear")
+    X = np.transpose(mo.coords[mo.elem_dof], (0, 2, 1))
+    loc = u[lay.elem_sys]
+    Ko, Fo = ns.elem_ns_batch(etv, etp, X, loc[:, :lay.dim * lay.nv].reshape(mo.nel, lay.dim, lay.nv), loc[:, lay.dim * lay.nv:], nu)
+    assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()                        # fp64, summation order / FMA contraction only
+    assert abs(F - Fo).max() <= 1e-12 * abs(Fo).max()
+    res = ctx.vector(lay.n)
+    asm.assemble(A, res, sol, nu)
+    Ao, bo = ns.assemble_ns(mo, lay, u, nu)
+    assert abs(A.to_scipy() - Ao).max() <= 1e-12 * abs(Ao).max()
+    assert rel(res.to_numpy(), bo) < 1e-12
+    asm.destroy(), A.destroy(), mh.destroy()
+
+
+def test_vanka_vcycle_matches_oracle(ctx):
+    """one multiplicative V(2,2) cycle with the block Schwarz smoother on the Jacobian of a non-trivial state"""
+    nu, nl = 0.01, 3
+    pb = NavierStokesMG(ctx, 4, 4, 0, nl, nu).init()
+    ms, lays = ns.build_ns_levels(4, 4, 0, nl, LO, HI)
+    bcs = [ns.cavity_bc(m, l) for m, l in zip(ms, lays)]
+    rng = np.random.default_rng(5)
+    top = nl - 1
+    state = 0.3 * rng.standard_normal(lays[top].n)
+    state[bcs[top][0]] = bcs[top][1]
+    pb.SOL[top].upload(state)
+    mg = pb.prepare(top)
+    H = ns.newton_step_operators(ms, lays, bcs, top, state, nu, omega=pb.omega, npre=pb.npre, npost=pb.npost)
+    for l in range(nl):
+        assert np.array_equal(pb.bdc[l], bcs[l][0])
+        assert abs(pb.A[(top, l)].to_scipy() - H.A[l]).max() <= 1e-11 * abs(H.A[l]).max()
+    assert rel(pb.RES[top].to_numpy(), H.b) < 1e-12
+    b = rng.standard_normal(lays[top].n)
+    b[bcs[top][0]] = 0.0
+    x = ctx.vector(lays[top].n)
+    mg.vcycle(ctx.vector_from(b), x)
+    ref = ns.vcycle(H, top, b)
+    assert rel(x.to_numpy(), ref) < 1e-9
+    pb.destroy()
+
+
+def test_cavity_newton_fcycle_matches_oracle(ctx):
+    """NonLinearImplicitSystem::MGsolve, F-cycle, Re = 100: the same Newton history as the oracle with exact linear solves and
+    the same discrete solution to 1e-8 (the FP-solve parity bar of north_star, 1e-10, holds for the linear solves inside)"""
+    nu, nl = 0.01, 3
+    pb = NavierStokesMG(ctx, 4, 4, 0, nl, nu).init()
+    assert pb.mgsolve(tol=1e-10, lin_rtol=1e-11)
+    _, lays, sols, hist = ns.solve_cavity(4, 4, nl, nu, LO, HI, linear="direct")
+    assert [h[:2] for h in pb.history] == [h[:2] for h in hist]               # same number of Newton steps on every level
+    for hg, ho in zip(pb.history, hist):
+        assert abs(hg[2] - ho[2]) <= 1e-6 * max(ho[2], 1e-9) + 1e-11
+    for l in range(nl):
+        assert rel(pb.SOL[l].to_numpy(), sols[l]) < 1e-8
+    assert max(h[3] for h in pb.history) <= 30
+    # the converged state satisfies the discrete equations: residual of the free rows vanishes
+    top = nl - 1
+    pb.prepare(top)
+    assert pb.RES[top].l2_norm() < 1e-9
+    pb.destroy()
+
+
+def test_cavity_reynolds_1000_by_continuation(ctx):
+    """BASELINE config 4 (viscosity 0.001): Newton from rest diverges at Re = 1000 on the 10 x 10 coarse grid, so the coarse
+    level is walked down in viscosity and the F-cycle then runs at the target value; checks the primary-vortex strength
+    against the published benchmark range (Ghia et al. 1982: minimum of the wall-parallel velocity on the centreline -0.38)"""
+    nl = 3
+    pb = NavierStokesMG(ctx, 10, 10, 0, nl, 0.01).init()
+    for nu in (0.01, 0.004, 0.002, 0.001):
+        pb.nu = nu
+        assert pb.newton(0, tol=1e-10, max_newton=25)
+    for ig in range(1, nl):
+        pb.prolongator_sol(ig)
+        assert pb.newton(ig, tol=1e-9, max_newton=25, lin_rtol=1e-10, lin_maxit=200)
+    _, xy, _ = pb.meshes[-1].arrays()
+    sol = pb.SOL[-1].to_numpy()
+    off = pb.offsets[-1]
+    line = np.where(abs(xy[:, 1]) < 1e-12)[0]                       # horizontal centreline y = 0; moving wall is x = -0.5
+    vmin = sol[off[1] + line].min()
+    assert -0.41 < vmin < -0.36
+    pb.destroy()

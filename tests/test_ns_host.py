@@ -1,0 +1,75 @@
+"""Navier-Stokes path on the CPU box: the oracle's own checks (finite-difference Jacobian, Newton
+convergence of the cavity, Vanka-multigrid GMRES) and the host-side integer half of the C-ABI -- system dof maps, Vanka
+patches, boundary-condition lists -- against the oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from femus_amd import capi
+from femus_amd.navier_stokes import cavity_boundary_condition, generate_bdc
+from oracle import femus_oracle as fo
+from oracle import femus_oracle_ns as ns
+
+LO, HI = (-0.5, -0.5, 0.0), (0.5, 0.5, 0.0)
+
+
+@pytest.mark.parametrize("box", [(2, 2, 0), (1, 1, 1)])
+def test_oracle_jacobian_is_the_derivative_of_the_residual(box):
+    """the hand-derived Jacobian against central differences of the residual on a distorted mesh (the reference gets the same
+    matrix from its adept tape, Assemble_jacobian.cpp:39-72)"""
+    m = fo.build_levels(*box, 1, (-.5, -.5, -.5), (.5, .5, .5))[0]
+    lay = ns.NSLayout(m)
+    rng = np.random.default_rng(0)
+    m.coords = m.coords + 0.03 * rng.standard_normal(m.coords.shape)
+    sol, d, h = rng.standard_normal(lay.n), rng.standard_normal(lay.n), 1e-6
+    A, _ = ns.assemble_ns(m, lay, sol, 0.05)
+    _, bp = ns.assemble_ns(m, lay, sol + h * d, 0.05)
+    _, bm = ns.assemble_ns(m, lay, sol - h * d, 0.05)
+    fd = -(bp - bm) / (2 * h)                    # Res = -aRes, Jac = d aRes / d sol
+    assert np.linalg.norm(A @ d - fd) <= 1e-8 * np.linalg.norm(fd)
+
+
+def test_oracle_cavity_newton_converges_quadratically_and_mg_matches_direct():
+    _, lays, sd, hd = ns.solve_cavity(4, 4, 2, 0.01, LO, HI, linear="direct")
+    last = [h for h in hd if h[0] == 1]
+    assert last[-1][2] < 1e-10 and len(last) <= 6
+    assert last[-1][2] < 10 * last[-2][2] ** 2 + 1e-12            # quadratic tail
+    _, _, sg, hg = ns.solve_cavity(4, 4, 2, 0.01, LO, HI, linear="gmres_mg", lin_rtol=1e-10)
+    assert abs(sg[-1] - sd[-1]).max() < 1e-8
+    assert max(h[3] for h in hg) <= 25                              # Vanka V(2,2) multigrid is an effective preconditioner
+
+
+@pytest.mark.parametrize("box,nl", [((3, 2, 0), 2), ((2, 2, 2), 2)])
+def test_host_system_maps_and_patches_match_oracle(box, nl):
+    lo, hi = (-0.5, -0.5, -0.5), (0.5, 0.5, 0.5)
+    mo = fo.build_levels(*box, nl, lo, hi)
+    mh = [capi.Mesh.box(*box, lo, hi)]
+    for _ in range(1, nl):
+        mh.append(mh[-1].refine())
+    for a, b in zip(mh, mo):
+        lay = ns.NSLayout(b)
+        fes = ["biquadratic"] * b.dim + ["linear"]
+        nd, off, es = capi.system_elem_dofs(a, fes)
+        assert nd == lay.nd and np.array_equal(off, lay.offset) and np.array_equal(es, lay.elem_sys)
+        ptr, dofs = capi.vertex_patches(a, fes)
+        po = ns.vertex_patches(b, lay)
+        assert ptr.size - 1 == len(po)
+        for p, d in enumerate(po):
+            assert np.array_equal(dofs[ptr[p]:ptr[p + 1]], d)
+    for a in mh:
+        a.destroy()
+
+
+def test_host_cavity_boundary_lists_match_oracle():
+    mo = fo.build_levels(4, 4, 0, 2, LO, HI)
+    mh = [capi.Mesh.box(4, 4, 0, LO, HI)]
+    mh.append(mh[0].refine())
+    lo, hi = np.array(LO[:2]), np.array(HI[:2])
+    for a, b in zip(mh, mo):
+        lay = ns.NSLayout(b)
+        idx, val = generate_bdc(a, ["U", "V", "P"], ["biquadratic", "biquadratic", "linear"], lay.offset,
+                                lambda x, name, face: cavity_boundary_condition(x, name, face, lo, hi))
+        io, vo = ns.cavity_bc(b, lay)
+        assert np.array_equal(idx, io) and np.array_equal(val, vo)
+        assert (val == 1.0).sum() == 2 * int(round(b.nel ** 0.5)) - 1      # the moving wall without its two end nodes
+    for a in mh:
+        a.destroy()
