@@ -1,0 +1,160 @@
+"""applications/001_Poisson/main.cpp over the C-ABI: reads the application's own JSON input, builds the
+box mesh, the boundary conditions and the source from their strings, and runs LinearImplicitSystem::MGsolve on the GPU.
+
+    load_config()    <- InputParser::build / JsonInputParser (src/00_file_handling/runtime_input_parsing/file/JsonInputParser.cpp;
+                        the vendored jsoncpp reader accepts // comments, so they are stripped here)
+    Poisson001       <- main.cpp:46-282: mesh (:118-141), FE order (:149), parsed boundary conditions (:158-180, names of the box
+                        faces from MeshGeneration.cpp:544-559 / 1040-1070), source string (:200-211), multigrid options (:216-257)
+    run()            <- LinearImplicitSystem::MGsolve (LinearImplicitSystem.cpp:288-411): up to max_number_linear_iteration
+                        cycles {MGSolve with the outer GMRES limited to 4 iterations (SetTolerances(1e-12,1e-20,1e50,4)),
+                        HasLinearConverged: ||RES||_2 < abs_conv_tol}, then UpdateSol
+
+Sign convention of the application (main.cpp:472-474): F = (src phi - grad phi . grad T) w, i.e. -Laplace T = src, which is the
+library kernel with f = -src.  Mesh files (.neu) need the Gambit reader and are refused.
+All numerics run in libfemus_hip.so; expressions are compiled by fh_expr_compile and evaluated on the device (source) or on the
+host at boundary nodes (Dirichlet values).
+"""
+import json
+import re
+
+import numpy as np
+
+from . import capi
+from .poisson import PoissonMG
+
+FACE_NAMES = {2: ["bottom", "right", "top", "left"], 3: ["bottom", "front", "right", "behind", "left", "top"]}
+FE_ORDER = {"first": "linear", "second": "biquadratic"}
+PREFIX = "multilevel_problem.multilevel_mesh.first.system.poisson.linear_solver."
+
+
+def load_config(path_or_text):
+    text = open(path_or_text).read() if "\n" not in path_or_text and "{" not in path_or_text else path_or_text
+    out, i, in_str = [], 0, False
+    while i < len(text):                        # drop // comments outside strings
+        c = text[i]
+        if c == '"' and (i == 0 or text[i - 1] != "\\"):
+            in_str = not in_str
+        if not in_str and text.startswith("//", i):
+            while i < len(text) and text[i] != "\n":
+                i += 1
+            continue
+        out.append(c)
+        i += 1
+    clean = re.sub(r",(\s*[}\]])", r"\1", "".join(out))
+    return json.loads(clean)
+
+
+def get(cfg, dotted, default):
+    """InputParser::getValue: value at a dotted path, or the default"""
+    node = cfg
+    for key in dotted.split("."):
+        if not isinstance(node, dict) or key not in node:
+            return default
+        node = node[key]
+    return node
+
+
+class Poisson001:
+    def __init__(self, ctx, config):
+        self.ctx = ctx
+        cfg = config if isinstance(config, dict) else load_config(config)
+        self.cfg = cfg
+        mesh_type = get(cfg, "multilevel_mesh.first.type", {})
+        if "box" not in mesh_type:
+            raise NotImplementedError("mesh files need the Gambit reader (not built); only the 'box' mesh type is served")
+        b = mesh_type["box"]
+        self.box = (int(b.get("nx", 2)), int(b.get("ny", 2)), int(b.get("nz", 0)))
+        self.lo = (float(b.get("xa", 0.)), float(b.get("ya", 0.)), float(b.get("za", 0.)))
+        self.hi = (float(b.get("xb", 1.)), float(b.get("yb", 1.)), float(b.get("zb", 0.)))
+        self.dim = 2 if self.box[2] == 0 else 3
+        if self.dim == 2:
+            self.hi = (self.hi[0], self.hi[1], 1.0)         # the box generator ignores z in 2-D
+        var = "multilevel_solution.multilevel_mesh.first.variable.first."
+        self.fe = FE_ORDER[get(cfg, var + "fe_order", "first")]
+        self.nlevels = int(get(cfg, PREFIX + "type.multigrid.nlevels", 1))
+        self.npre = int(get(cfg, PREFIX + "type.multigrid.npresmoothing", 1))
+        self.npost = int(get(cfg, PREFIX + "type.multigrid.npostmoothing", 1))        # the key the application reads (sic)
+        self.max_linear = int(get(cfg, PREFIX + "max_number_linear_iteration", 6))
+        self.abs_tol = float(get(cfg, PREFIX + "abs_conv_tol", 1.e-08))
+        assert get(cfg, PREFIX + "type.multigrid.mgtype", "V_cycle") == "V_cycle", "only the V-cycle of the shipped inputs is served"
+        # boundary conditions: default Dirichlet homogeneous on every face (InitializeBdc_with_ParsedFunction)
+        names = FACE_NAMES[self.dim]
+        self.bc_type = {n: "dirichlet" for n in names}
+        self.bc_func = {n: None for n in names}
+        for item in get(cfg, var + "boundary_conditions", []):
+            name = item.get("facename", "top")
+            if name not in names:
+                raise ValueError(" Error: the facename %s does not exist!" % name)
+            self.bc_type[name] = item.get("bdc_type", "dirichlet")
+            self.bc_func[name] = capi.Expr(item.get("bdc_func", "0."), "x,y,z,t")
+        self.source = capi.Expr(get(cfg, var + "func_source", "0."), "x,y,z,t")
+
+    def flag_of(self, name):
+        return -(FACE_NAMES[self.dim].index(name) + 2)
+
+    def dirichlet_data(self, mesh):
+        """GenerateBdc with parsed functions (MultiLevelSolution.cpp:762-800): elements and faces in order; nodes of Dirichlet
+        faces get Bdc = 0 and Sol = value(x, y, z, t = 0); a later face overwrites an earlier one"""
+        ed, xy, ff = mesh.arrays()
+        nc = {"linear": 2 ** self.dim, "biquadratic": 3 ** self.dim}[self.fe]
+        names = FACE_NAMES[self.dim]
+        val = {}
+        for iel, f in zip(*np.nonzero(ff < -1)):
+            name = names[-int(ff[iel, f]) - 2]
+            if self.bc_type[name] != "dirichlet":
+                continue
+            fn = self.bc_func[name]
+            for i in capi.fe_face_nodes(mesh.geom, "biquadratic", f):
+                if i >= nc:
+                    continue
+                node = int(ed[iel, i])
+                x4 = np.zeros(4)
+                x4[:self.dim] = xy[node]
+                val[node] = fn(x4) if fn is not None else 0.0
+        idx = np.array(sorted(val), dtype=np.int32)
+        return idx, np.array([val[i] for i in idx])
+
+    def run(self, smoother=capi.SMOOTH_GS_COLOR, omega=1.0, log=None):
+        ctx = self.ctx
+        meshes = [capi.Mesh.box(*self.box, self.lo, self.hi)]
+        for _ in range(1, self.nlevels):
+            meshes.append(meshes[-1].refine())
+        data = [self.dirichlet_data(m) for m in meshes]
+        pb = PoissonMG(ctx, *self.box, self.nlevels, fe=self.fe, omega=omega, npre=self.npre, npost=self.npost, meshes=meshes,
+                       smoother=smoother, dirichlet=[d[0] for d in data], source_expr=self.source, source_scale=-1.0)
+        pb.init()
+        top = self.nlevels - 1
+        sol0 = np.zeros(pb.ndof[top])
+        sol0[data[top][0]] = data[top][1]
+        pb.SOL.upload(sol0)
+        pb.assemble()
+        # non-homogeneous Neumann faces (main.cpp:497-553): constant flux per face, the only kind the shipped inputs use
+        flux = {}
+        for name in FACE_NAMES[self.dim]:
+            if self.bc_type[name] == "neumann" and self.bc_func[name] is not None:
+                v = self.bc_func[name](np.zeros(4))
+                if v != 0.0:
+                    flux[self.flag_of(name)] = v
+        if flux:
+            capi.assemble_neumann(ctx, meshes[top], self.fe, pb.RES, flux)
+        pb.prepare()
+        history = []
+        for it in range(self.max_linear):
+            its, _ = pb.mgsolve(outer="gmres", rtol=1e-12, atol=1e-20, maxit=4)
+            rn = pb.RES.l2_norm()
+            history.append((its, rn))
+            if log:
+                log("linear iteration %d: %d Krylov steps, Linear Res L2norm = %.6e" % (it + 1, its, rn))
+            if rn < self.abs_tol:
+                break
+        pb.update_sol()
+        _, xy, _ = meshes[top].arrays()
+        result = {"solution": pb.SOL.to_numpy(), "coords": xy[:pb.ndof[top]], "history": history, "converged": history[-1][1] < self.abs_tol,
+                  "dofs": pb.ndof[top]}
+        pb.destroy()
+        return result
+
+    def destroy(self):
+        for e in list(self.bc_func.values()) + [self.source]:
+            if e is not None:
+                e.destroy()

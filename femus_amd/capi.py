@@ -548,6 +548,10 @@ class Assembler:
         p = _f64(list(params) + [0.0] * (4 - len(params)))
         _chk(self.L.fh_assemble_poisson(self.h, None if sol is None else sol.h, int(source_kind), _p(p), A.h, res.h))
 
+    def assemble_expr(self, A, res, sol, expr, scale=1.0):
+        """source term f = scale * expr(x, y, z, t), evaluated on the device at the Gauss points"""
+        _chk(self.L.fh_assemble_poisson_expr(self.h, None if sol is None else sol.h, expr.h, float(scale), A.h, res.h))
+
     def element_matrices(self, sol=None, source_kind=0, params=(1.0,)):
         p = _f64(list(params) + [0.0] * (4 - len(params)))
         K, F = np.empty((self.nel, self.nc, self.nc)), np.empty((self.nel, self.nc))
@@ -558,6 +562,33 @@ class Assembler:
         nco, by, fl = ctypes.c_int(), ctypes.c_int64(), ctypes.c_double()
         _chk(self.L.fh_assembler_info(self.h, ctypes.byref(nco), ctypes.byref(by), ctypes.byref(fl)))
         return {"ncolors": nco.value, "algorithmic_bytes": by.value, "flops": fl.value}
+
+
+class Expr:
+    """femus::ParsedFunction: a run-time expression compiled to a postfix program (host and device evaluation)"""
+
+    def __init__(self, expression, variables="x,y,z,t"):
+        self.L = load_library()
+        self.h = ctypes.c_void_p()
+        self.nvars = len([v for v in variables.split(",") if v.strip()])
+        _chk(self.L.fh_expr_compile(expression.encode(), variables.encode(), ctypes.byref(self.h)))
+
+    def __call__(self, x):
+        x = _f64(x)
+        if x.ndim == 1:
+            out = ctypes.c_double()
+            assert x.size >= self.nvars
+            _chk(self.L.fh_expr_eval(self.h, _p(x), ctypes.byref(out)))
+            return out.value
+        assert x.shape[1] == self.nvars
+        out = np.empty(x.shape[0])
+        _chk(self.L.fh_expr_eval_many(self.h, x.shape[0], _p(x), _p(out)))
+        return out
+
+    def destroy(self):
+        if self.h:
+            self.L.fh_expr_destroy(self.h)
+            self.h = None
 
 
 def system_elem_dofs(mesh, fes):

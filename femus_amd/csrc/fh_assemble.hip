@@ -17,6 +17,7 @@
 // The small dense K is FP64-VALU work, not an MFMA target (north_star); the scatter side is HBM-bound.
 #include "fh_internal.h"
 #include "fh_fe.h"
+#include "fh_expr_device.h"
 #include <algorithm>
 
 struct fh_assembler_s {
@@ -42,6 +43,12 @@ struct fh_assembler_s {
   double* d_Kbuf = nullptr;      // [nadj*nc] element rows in row-gather order
   double* d_Fbuf = nullptr;      // [nadj]
   bool two_pass = false;
+  // source term given as a compiled expression (fh_expr): device copy of the program of the expression last used
+  int* d_prog = nullptr;
+  double* d_prog_consts = nullptr;
+  int nprog = 0;
+  std::vector<int> h_prog;
+  std::vector<double> h_prog_consts;
 };
 
 struct AsmParams {
@@ -57,6 +64,9 @@ struct AsmParams {
   const double* sol;       // may be null
   int source_kind;
   double p0, p1;
+  const int* prog;         // source_kind 4: postfix program of the source expression f = p0 * expr(x, y, z, t)
+  const double* prog_consts;
+  int nprog;
   // scatter targets
   const int* rowptr;
   const int* col;
@@ -109,7 +119,7 @@ __device__ __forceinline__ double source_eval(int kind, double p0, double p1, co
   return r;
 }
 
-// SRC: 0 constant source, 1 trigonometric source ; OUT: 0 scatter through emap, 1 scatter with binary search,
+// SRC: 0 constant source, 1 closed-form source (kinds 1-3), 2 compiled expression (kind 4) ; OUT: 0 scatter through emap, 1 scatter with binary search,
 // 2 build emap (symbolic pass), 3 write element matrices
 template <int DIM, int NC, int SRC, int OUT>
 __global__ __launch_bounds__(256) void k_assemble_poisson(AsmParams P) {
@@ -259,7 +269,15 @@ __global__ __launch_bounds__(256) void k_assemble_poisson(AsmParams P) {
           }
       }
       // residual integrand of this lane's nodes: (-f phi_n - grad phi_n . grad u) W  (summed over g in phase 2)
-      const double fq = (SRC == 0) ? P.p0 : source_eval(P.source_kind, P.p0, P.p1, xg, DIM);
+      double fq;
+      if (SRC == 0) fq = P.p0;
+      else if (SRC == 1) fq = source_eval(P.source_kind, P.p0, P.p1, xg, DIM);
+      else {
+        double x4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < DIM; a++) x4[a] = xg[a];
+        fq = P.p0 * fh_expr_device_eval(P.prog, P.nprog, P.prog_consts, x4);
+      }
 #pragma unroll
       for (int k = 0; k < NPP; k++) {
         const int n = n0 + k;
@@ -607,7 +625,15 @@ __global__ __launch_bounds__(64) void k_elem_q2hex_sym(AsmParams P) {
           gu[a] += __shfl_xor(gu[a], off, 64);
           if (SRC != 0) xg[a] += __shfl_xor(xg[a], off, 64);
         }
-      const double fq = (SRC == 0) ? P.p0 : source_eval(P.source_kind, P.p0, P.p1, xg, DIM);
+      double fq;
+      if (SRC == 0) fq = P.p0;
+      else if (SRC == 1) fq = source_eval(P.source_kind, P.p0, P.p1, xg, DIM);
+      else {
+        double x4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < DIM; a++) x4[a] = xg[a];
+        fq = P.p0 * fh_expr_device_eval(P.prog, P.nprog, P.prog_consts, x4);
+      }
 #pragma unroll
       for (int k = 0; k < NPP; k++) {
         const int n = n0 + k;
@@ -679,13 +705,15 @@ static int launch_assemble(fh_assembler_t as, const AsmParams& P) {
   const dim3 grid(fh_div_up(P.nelems, C::EPB)), block(256);
   const size_t lds = (size_t)C::EPB * C::LDS_PER_ELEM * sizeof(double);
   hipStream_t st = as->ctx->stream;
-  const int src = P.source_kind != 0;
+  const int src = P.source_kind == 0 ? 0 : P.source_kind == 4 ? 2 : 1;
   const int outm = P.Kout ? 3 : P.emap_out ? 2 : P.emap ? 0 : 1;
 #define FH_ASM(SRC, OUT) hipLaunchKernelGGL((k_assemble_poisson<DIM, NC, SRC, OUT>), grid, block, lds, st, P)
+#define FH_ASM_SRC(OUT) do { if (src == 2) FH_ASM(2, OUT); else if (src == 1) FH_ASM(1, OUT); else FH_ASM(0, OUT); } while (0)
   if (outm == 2) FH_ASM(0, 2);
-  else if (outm == 3) { if (src) FH_ASM(1, 3); else FH_ASM(0, 3); }
-  else if (outm == 0) { if (src) FH_ASM(1, 0); else FH_ASM(0, 0); }
-  else { if (src) FH_ASM(1, 1); else FH_ASM(0, 1); }
+  else if (outm == 3) FH_ASM_SRC(3);
+  else if (outm == 0) FH_ASM_SRC(0);
+  else FH_ASM_SRC(1);
+#undef FH_ASM_SRC
 #undef FH_ASM
   FH_CHECK_HIP(hipGetLastError());
   return 0;
@@ -695,7 +723,8 @@ static int dispatch_assemble(fh_assembler_t as, const AsmParams& P) {
   if (as->dim == 3 && as->nc == 27 && P.Kout && as->ctx->assemble_sym) {
     if (P.nelems <= 0) return 0;
     const dim3 grid(fh_div_up(P.nelems, 2)), block(64);
-    if (P.source_kind != 0) hipLaunchKernelGGL(k_elem_q2hex_sym<1>, grid, block, 0, as->ctx->stream, P);
+    if (P.source_kind == 4) hipLaunchKernelGGL(k_elem_q2hex_sym<2>, grid, block, 0, as->ctx->stream, P);
+    else if (P.source_kind != 0) hipLaunchKernelGGL(k_elem_q2hex_sym<1>, grid, block, 0, as->ctx->stream, P);
     else hipLaunchKernelGGL(k_elem_q2hex_sym<0>, grid, block, 0, as->ctx->stream, P);
     FH_CHECK_HIP(hipGetLastError());
     return 0;
@@ -753,6 +782,9 @@ static AsmParams base_params(fh_assembler_t as) {
   P.phi = as->d_phi;
   P.dphi = as->d_dphi;
   P.ng = as->ng;
+  P.prog = as->d_prog;
+  P.prog_consts = as->d_prog_consts;
+  P.nprog = as->nprog;
   return P;
 }
 
@@ -855,6 +887,8 @@ extern "C" int fh_assembler_destroy(fh_assembler_t as) {
   hipFree(as->d_phi);
   hipFree(as->d_dphi);
   if (as->d_emap) hipFree(as->d_emap);
+  if (as->d_prog) hipFree(as->d_prog);
+  if (as->d_prog_consts) hipFree(as->d_prog_consts);
   hipFree(as->d_iota);
   for (void* q : {(void*)as->d_adj_ptr, (void*)as->d_adj_ei, (void*)as->d_rowmap, (void*)as->d_Kbuf, (void*)as->d_Fbuf, (void*)as->d_slot})
     if (q) hipFree(q);
@@ -862,10 +896,44 @@ extern "C" int fh_assembler_destroy(fh_assembler_t as) {
   return 0;
 }
 
+static int assemble_poisson_core(fh_assembler_t as, fh_vec_t sol, int source_kind, const double* params, fh_mat_t A, fh_vec_t res);
+
 extern "C" int fh_assemble_poisson(fh_assembler_t as, fh_vec_t sol, int source_kind, const double* params, fh_mat_t A, fh_vec_t res) {
+  FH_REQUIRE(source_kind >= 0 && source_kind <= 3, "fh_assemble_poisson: unknown source kind %d", source_kind);
+  return assemble_poisson_core(as, sol, source_kind, params, A, res);
+}
+
+int fh_expr_program(fh_expr_t e, int* ncode, int* nconst, int* code, double* consts);
+
+// source term from a run-time expression: f = scale * expr(x, y, z, t) evaluated at every Gauss point on the device
+// (001_Poisson/main.cpp:472 calls the ParsedFunction on the host once per Gauss point and test function)
+extern "C" int fh_assemble_poisson_expr(fh_assembler_t as, fh_vec_t sol, fh_expr_t source, double scale, fh_mat_t A, fh_vec_t res) {
+  FH_REQUIRE(as && source, "fh_assemble_poisson_expr: null argument");
+  int nc = 0, nk = 0;
+  FH_TRY(fh_expr_program(source, &nc, &nk, nullptr, nullptr));
+  std::vector<int> code(nc);
+  std::vector<double> consts(std::max(nk, 1));
+  FH_TRY(fh_expr_program(source, &nc, &nk, code.data(), consts.data()));
+  consts.resize(nk);
+  if (code != as->h_prog || consts != as->h_prog_consts || !as->d_prog) {
+    FH_CHECK_HIP(hipStreamSynchronize(as->ctx->stream));
+    if (as->d_prog) hipFree(as->d_prog);
+    if (as->d_prog_consts) hipFree(as->d_prog_consts);
+    FH_CHECK_HIP(hipMalloc(&as->d_prog, std::max<size_t>(code.size(), 1) * sizeof(int)));
+    FH_CHECK_HIP(hipMalloc(&as->d_prog_consts, std::max<size_t>(consts.size(), 1) * sizeof(double)));
+    FH_CHECK_HIP(hipMemcpy(as->d_prog, code.data(), code.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (!consts.empty()) FH_CHECK_HIP(hipMemcpy(as->d_prog_consts, consts.data(), consts.size() * sizeof(double), hipMemcpyHostToDevice));
+    as->h_prog = code;
+    as->h_prog_consts = consts;
+    as->nprog = nc;
+  }
+  const double params[2] = {scale, 0.0};
+  return assemble_poisson_core(as, sol, 4, params, A, res);
+}
+
+static int assemble_poisson_core(fh_assembler_t as, fh_vec_t sol, int source_kind, const double* params, fh_mat_t A, fh_vec_t res) {
   FH_REQUIRE(as && A && res, "fh_assemble_poisson: null argument");
   FH_REQUIRE(A->m == as->ndof && res->n_local >= as->ndof, "fh_assemble_poisson: size mismatch");
-  FH_REQUIRE(source_kind >= 0 && source_kind <= 3, "fh_assemble_poisson: unknown source kind %d", source_kind);
   FH_REQUIRE(!sol || sol->n_local + sol->nghost >= A->n, "fh_assemble_poisson: solution vector too short (needs owned + ghost entries)");
   if (as->two_pass) {
     // pass 1: all element matrices (one launch, no colours) ; pass 2: rows gather their element rows (zeroing included)

@@ -17,13 +17,17 @@ from . import capi
 
 class PoissonMG:
     def __init__(self, ctx, nx, ny, nz, nlevels, fe="biquadratic", order="seventh", lo=(0., 0., 0.), hi=(1., 1., 1.),
-                 omega=2. / 3., npre=2, npost=2, coarse="galerkin", source_kind=0, params=(1.0,), meshes=None):
+                 omega=2. / 3., npre=2, npost=2, coarse="galerkin", source_kind=0, params=(1.0,), meshes=None,
+                 smoother=0, dirichlet=None, source_expr=None, source_scale=1.0):
         self.ctx = ctx
         self.fe, self.order = fe, order
         self.nlevels = nlevels
         self.omega, self.npre, self.npost = omega, npre, npost
         self.coarse = coarse
         self.source_kind, self.params = source_kind, params
+        self.smoother = smoother                  # capi.SMOOTH_JACOBI / SMOOTH_GS_COLOR
+        self.dirichlet = dirichlet                # per level: Dirichlet dof lists when only some faces are Dirichlet
+        self.source_expr, self.source_scale = source_expr, source_scale     # capi.Expr: f = scale * expr(x, y, z, t)
         if meshes is not None:
             self.meshes = list(meshes)
         else:
@@ -47,8 +51,9 @@ class PoissonMG:
                 self.Pamr[l] = capi.build_amr_prolongator(ctx, m, fe)
                 self.hanging[l] = m.amr_constraints(fe)[0]
         self.amr = any(p is not None for p in self.Pamr)
-        self.bdc = [np.union1d(m.dirichlet_dofs(fe), self.hanging[l]).astype(np.int32) for l, m in enumerate(self.meshes)]
-        if not self.amr:
+        phys = [m.dirichlet_dofs(fe) for m in self.meshes] if self.dirichlet is None else self.dirichlet
+        self.bdc = [np.union1d(phys[l], self.hanging[l]).astype(np.int32) for l in range(self.nlevels)]
+        if not self.amr and self.dirichlet is None:
             self.P = [None] + [capi.build_prolongator(ctx, self.meshes[l - 1], self.meshes[l], fe, zero_bdc=True)
                                for l in range(1, self.nlevels)]
         else:
@@ -89,7 +94,11 @@ class PoissonMG:
         l = self.nlevels - 1 if level is None else level
         res = self.RES if l == self.nlevels - 1 else self.ctx.vector(self.ndof[l])
         K = self.KK[l] if self.KK[l] is not None else self.A[l]
-        self.asm[l].assemble(K, res, self.SOL if l == self.nlevels - 1 else None, self.source_kind, self.params)
+        sol = self.SOL if l == self.nlevels - 1 else None
+        if self.source_expr is not None:
+            self.asm[l].assemble_expr(K, res, sol, self.source_expr, self.source_scale)
+        else:
+            self.asm[l].assemble(K, res, sol, self.source_kind, self.params)
         if self.Pamr[l] is not None:
             # RES <- PPamr^T RES ; KK <- PPamr^T KK PPamr   (LinearImplicitSystem.cpp:329-335)
             self.RESC.matrix_mult_transpose(res, self.Pamr[l])
@@ -118,7 +127,8 @@ class PoissonMG:
         if self.mg is None:
             self.mg = capi.Multigrid(ctx, self.nlevels)
         for l in range(self.nlevels):
-            self.mg.set_level(l, self.A[l], self.P[l], None, 0, self.omega, self.npre if l > 0 else 1, self.npost if l > 0 else 0)
+            self.mg.set_level(l, self.A[l], self.P[l], None, self.smoother, self.omega, self.npre if l > 0 else 1,
+                              self.npost if l > 0 else 0)
         self.mg.setup()
         return self
 

@@ -192,6 +192,21 @@ int fh_fe_face_nodes(int geom, int fe, int face, int* nfn, int* local_nodes);
 int fh_assemble_neumann_faces(fh_ctx_t ctx, int geom, int fe, int gauss_order, int nfaces, const int* face_nodes, const double* tau,
                               int nnode, const double* coords, fh_vec_t res);
 
+/* ---- run-time expressions: femus::ParsedFunction (src/02_calculus/function_parser/ParsedFunction.hpp:25-60,
+ * ParsedFunction.cpp:28-80; wraps the third-party "Function Parser for C++", not vendored).  The expression is compiled once
+ * into a postfix program; fh_expr_eval is ParsedFunction::operator()(double* x) on the host (boundary values), and
+ * fh_assemble_poisson_expr evaluates the same program on the device at every Gauss point (source term "func_source" of
+ * applications/001_Poisson/input/input.json, main.cpp:205-211, 472): f = scale * expr(x, y, z, t).  variables: comma separated,
+ * e.g. "x,y,z,t".  Constants "pi" and "e" are predefined as in the reference.  A syntax error returns nonzero with the message
+ * in fh_last_error (the reference prints it and exits). */
+typedef struct fh_expr_s* fh_expr_t;
+int fh_expr_compile(const char* expression, const char* variables, fh_expr_t* expr);
+int fh_expr_eval(fh_expr_t expr, const double* x, double* value);
+int fh_expr_eval_many(fh_expr_t expr, int npts, const double* x /* [npts*nvars] */, double* values);
+int fh_expr_program(fh_expr_t expr, int* ncode, int* nconst, int* code /* or NULL */, double* consts /* or NULL */);
+int fh_expr_destroy(fh_expr_t expr);
+int fh_assemble_poisson_expr(fh_assembler_t as, fh_vec_t sol, fh_expr_t source, double scale, fh_mat_t A, fh_vec_t res);
+
 /* ---- multi-variable systems and the Navier-Stokes Newton path (a9, a21) --------------------------------------------
  * Variables are stacked per rank: system dof = KKoffset[k] + mesh dof (LinearEquation::GetSystemDof, LinearEquation.cpp:76-85,
  * :212-237; nprocs = 1).  fe[k] in {0, 2}.  elem_sys[nel*nd] lists, per element, the dofs of variable 0, then 1, ... */

@@ -1,0 +1,93 @@
+"""applications/001_Poisson over the C-ABI: the JSON input of the application (comments, dotted paths,
+defaults), its boundary-condition strings and its source string.  CPU part: loader + host logic; GPU part: the run against the
+oracle's direct solution of the same discrete problem."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+from femus_amd import app_poisson as app
+from oracle import femus_oracle as fo
+
+# same layout and keys as applications/001_Poisson/input/input.json (own values)
+CONFIG = """
+// Configuration options
+{
+    // mesh
+    "multilevel_mesh" : { "first" : { "type" : { "box" : {
+            "nx" : 4, "ny" : 4, "nz" : 0, "xa" : 0., "xb" : 1., "ya" : 0., "yb" : 1., "za" : 0., "zb" : 0.,
+            "elem_type" : "Quad9" } } } },
+    // solution
+    "multilevel_solution" : { "multilevel_mesh" : { "first" : { "variable" : { "first" : {
+              "name" : "T",
+              "fe_order" : "second",
+              "init_func" : "0.",
+              "func_source": "10.*exp(-5.*x) - 4.*exp(-x)*y",
+              "boundary_conditions" : [
+                { "facename" : "left",   "bdc_type" : "dirichlet", "bdc_func" : "0.5+1./pi*atan(10.*(y-0.8))" },
+                { "facename" : "top",    "bdc_type" : "dirichlet", "bdc_func" : "1." },
+                { "facename" : "bottom", "bdc_type" : "neumann",   "bdc_func" : "0." },
+                { "facename" : "right",  "bdc_type" : "neumann",   "bdc_func" : "0.2" }
+              ] } } } } },
+    // multilevel problem
+    "multilevel_problem" : { "multilevel_mesh" : { "first" : { "system" : { "poisson" : { "linear_solver" : {
+                "max_number_linear_iteration" : 8,
+                "abs_conv_tol" : 1.e-10,
+                "type" : { "multigrid" : { "nlevels" : 3, "npresmoothing" : 1, "npostmoothing" : 1, "mgtype" : "V_cycle",
+                    "smoother" : { "type" : { "gmres" : { "ksp" : "gmres", "precond" : "ilu" } } } } } } } } } } }
+}
+"""
+
+
+def test_config_loader_reads_commented_json_and_defaults():
+    cfg = app.load_config(CONFIG)
+    assert app.get(cfg, "multilevel_mesh.first.type.box.nx", 2) == 4
+    assert app.get(cfg, app.PREFIX + "type.multigrid.nlevels", 1) == 3
+    assert app.get(cfg, app.PREFIX + "type.multigrid.not_there", 7) == 7
+    assert app.get(cfg, "multilevel_solution.multilevel_mesh.first.variable.first.func_source", "0.").startswith("10.*exp")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/applications/001_Poisson/input"), reason="reference tree not present")
+def test_loader_accepts_every_shipped_input_file():
+    d = "/root/reference/applications/001_Poisson/input"
+    seen = 0
+    for name in sorted(os.listdir(d)):
+        if name.endswith(".json"):
+            cfg = app.load_config(os.path.join(d, name))
+            assert "multilevel_mesh" in cfg and app.get(cfg, app.PREFIX + "type.multigrid.nlevels", 0) >= 1
+            seen += 1
+    assert seen >= 10
+
+
+@pytest.mark.gpu
+def test_run_matches_oracle_direct_solution(ctx):
+    p = app.Poisson001(ctx, CONFIG)
+    out = p.run(log=None)
+    assert out["converged"] and len(out["history"]) <= 8
+    # the same discrete problem with the oracle: F = (src phi - grad phi . grad T) w + Neumann term, Dirichlet rows penalised
+    ms = fo.build_levels(4, 4, 0, 3)
+    m = ms[-1]
+    x, y = m.coords[:, 0], m.coords[:, 1]
+    sol0 = np.zeros(m.nnode)
+    fn = fo.face_nodes("quad")
+    val = {}
+    for iel in range(m.nel):                               # GenerateBdc order: elements, then faces
+        for f in range(4):
+            if m.face_flag[iel, f] == -5:                  # left
+                for n in m.elem_dof[iel, fn[f]]:
+                    val[n] = 0.5 + 1. / np.pi * np.arctan(10. * (y[n] - 0.8))
+            elif m.face_flag[iel, f] == -4:                # top
+                for n in m.elem_dof[iel, fn[f]]:
+                    val[n] = 1.0
+    bdc = np.array(sorted(val))
+    sol0[bdc] = [val[n] for n in bdc]
+    src = lambda xg: -(10. * np.exp(-5. * xg[..., 0]) - 4. * np.exp(-xg[..., 0]) * xg[..., 1])
+    A, b = fo.assemble_poisson(m, "biquadratic", src, sol=sol0)
+    b = b + fo.neumann_rhs(m, "biquadratic", {-3: 0.2})
+    A = fo.zero_rows(A, bdc, 1.0)
+    b[bdc] = 0.0
+    ref = sol0 + spla.spsolve(A.tocsc(), b)
+    assert np.array_equal(out["coords"], m.coords)
+    assert abs(out["solution"] - ref).max() < 1e-9
+    p.destroy()

@@ -1,0 +1,46 @@
+"""The run-time expression evaluator behind ParsedFunction on the CPU box: every expression the
+reference's applications ship (001_Poisson/input/*.json, 1-D/3-D variants) plus the operator/function set of the parser
+library, against Python's own evaluation of the same formula."""
+import math
+
+import numpy as np
+import pytest
+
+from femus_amd import capi
+
+PTS = np.array([[0.3, 0.8, -0.2, 0.5], [1.7, -0.4, 0.9, 0.0], [0.0, 0.0, 0.0, 0.0], [-1.25, 2.5, 0.75, 3.0]])
+
+CASES = [
+    ("0.", lambda x, y, z, t: 0.0),
+    ("1.", lambda x, y, z, t: 1.0),
+    ("0.2", lambda x, y, z, t: 0.2),
+    ("0.5+1./pi*atan(1000.*(y-0.8))", lambda x, y, z, t: 0.5 + 1. / math.pi * math.atan(1000. * (y - 0.8))),   # input.json, "left"
+    ("10.*exp(-5.*x) - 4.*exp(-x)", lambda x, y, z, t: 10. * math.exp(-5. * x) - 4. * math.exp(-x)),           # input1D.json source
+    ("-x^2", lambda x, y, z, t: -(x ** 2)),
+    ("2^-1^2", lambda x, y, z, t: 2 ** -(1 ** 2)),
+    ("2^3^2", lambda x, y, z, t: 2.0 ** 9),
+    ("(x+y)*(z-t)/ (1+x*x)", lambda x, y, z, t: (x + y) * (z - t) / (1 + x * x)),
+    ("sin(pi*x)*cos(pi*y)+e", lambda x, y, z, t: math.sin(math.pi * x) * math.cos(math.pi * y) + math.e),
+    ("if(x<0.5 & y>=0.1, 3., -2.)", lambda x, y, z, t: 3. if (x < 0.5 and y >= 0.1) else -2.),
+    ("max(x,y)+min(z,t)*abs(x)", lambda x, y, z, t: max(x, y) + min(z, t) * abs(x)),
+    ("!(x>1) | (y=2.5)", lambda x, y, z, t: 1.0 if ((not x > 1) or y == 2.5) else 0.0),
+    ("sqrt(x*x+y*y)-hypot(x,y)+pow(2,z)+atan2(y,x)+log(exp(t))+tanh(x)+floor(y)+ceil(z)+int(2.4)+x%0.7",
+     lambda x, y, z, t: pow(2, z) + math.atan2(y, x) + t + math.tanh(x) + math.floor(y) + math.ceil(z) + 2 + math.fmod(x, 0.7)),
+    ("1e-3*x + .5e1*y + 3.E+0", lambda x, y, z, t: 1e-3 * x + 5.0 * y + 3.0),
+]
+
+
+@pytest.mark.parametrize("text,fn", CASES)
+def test_expression_matches_python(text, fn):
+    e = capi.Expr(text, "x,y,z,t")
+    ref = np.array([fn(*p) for p in PTS])
+    got = np.array([e(p) for p in PTS])
+    assert np.allclose(got, ref, rtol=1e-15, atol=1e-15)
+    assert np.array_equal(e(PTS), got)                    # batch entry point: identical
+    e.destroy()
+
+
+@pytest.mark.parametrize("bad", ["1+", "foo(x)", "x+q", "(x", "1 2", "if(x,1)", "x,y"])
+def test_syntax_errors_are_reported(bad):
+    with pytest.raises(capi.FemusHipError):
+        capi.Expr(bad, "x,y,z,t")
