@@ -30,13 +30,21 @@ PREFIX = "multilevel_problem.multilevel_mesh.first.system.poisson.linear_solver.
 def load_config(path_or_text):
     text = open(path_or_text).read() if "\n" not in path_or_text and "{" not in path_or_text else path_or_text
     out, i, in_str = [], 0, False
-    while i < len(text):                        # drop // comments outside strings
+    while i < len(text):                        # outside strings: drop // comments, make "1." / "1.e-9" / ".5" strict JSON numbers
         c = text[i]
         if c == '"' and (i == 0 or text[i - 1] != "\\"):
             in_str = not in_str
         if not in_str and text.startswith("//", i):
             while i < len(text) and text[i] != "\n":
                 i += 1
+            continue
+        if not in_str and c == "." and (i + 1 >= len(text) or not text[i + 1].isdigit()):
+            out.append(".0")                    # jsoncpp reads "1." and "1.e-09"
+            i += 1
+            continue
+        if not in_str and c == "." and (not out or not out[-1][-1].isdigit()):
+            out.append("0.")                    # ".5"
+            i += 1
             continue
         out.append(c)
         i += 1
