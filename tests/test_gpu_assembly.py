@@ -113,3 +113,24 @@ def test_global_assembly_matches_oracle(ctx, args, nl, fe, two_pass, emap):
     finally:
         ctx.set_option("assemble_emap", 1)
         ctx.set_option("assemble_two_pass", 1)
+
+
+@pytest.mark.parametrize("args,nl,fe", [((2, 2, 2), 2, "biquadratic"), ((4, 4, 0), 2, "linear")])
+def test_expression_source_equals_closed_form_source(ctx, args, nl, fe):
+    """the compiled-expression source (fh_assemble_poisson_expr, evaluated on the device at the Gauss points) against the
+    built-in closed form of the same function"""
+    m = levels(args, nl)[-1]
+    ed, xy, _ = m.arrays()
+    n = m.n_dofs(fe)
+    rp, col = capi.pattern_from_elements(ed[:, :fo.ndofs(m.geom, fe)], n)
+    A, B = ctx.matrix_csr(n, n, rp, col), ctx.matrix_csr(n, n, rp, col)
+    asm = capi.Assembler(ctx, m, fe, A)
+    u = ctx.vector_from(fo.lcg_fill(n, 7))
+    r1, r2 = ctx.vector(n), ctx.vector(n)
+    asm.assemble(A, r1, u, 1, (-2.5, 1.3))
+    text = "sin(1.3*x)*sin(1.3*y)*sin(1.3*z)" if m.dim == 3 else "sin(1.3*x)*sin(1.3*y)"
+    e = capi.Expr(text)
+    asm.assemble_expr(B, r2, u, e, -2.5)
+    assert abs(A.to_scipy() - B.to_scipy()).max() == 0.0
+    assert abs(r1.to_numpy() - r2.to_numpy()).max() <= 1e-14 * abs(r1.to_numpy()).max()
+    e.destroy(), asm.destroy(), A.destroy(), B.destroy()
