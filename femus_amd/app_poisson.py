@@ -10,11 +10,13 @@ box mesh, the boundary conditions and the source from their strings, and runs Li
                         HasLinearConverged: ||RES||_2 < abs_conv_tol}, then UpdateSol
 
 Sign convention of the application (main.cpp:472-474): F = (src phi - grad phi . grad T) w, i.e. -Laplace T = src, which is the
-library kernel with f = -src.  Mesh files (.neu) need the Gambit reader and are refused.
+library kernel with f = -src.  Mesh files ("filename" inputs, Gambit .neu) are read by fh_mesh_read_gambit
+and take the boundary conditions of the application's SetBoundaryCondition function (main.cpp:26-36).
 All numerics run in libfemus_hip.so; expressions are compiled by fh_expr_compile and evaluated on the device (source) or on the
 host at boundary nodes (Dirichlet values).
 """
 import json
+import os
 import re
 
 import numpy as np
@@ -63,20 +65,30 @@ def get(cfg, dotted, default):
 
 
 class Poisson001:
-    def __init__(self, ctx, config):
+    def __init__(self, ctx, config, base_dir=None):
+        """config: path of the JSON file, its text, or the parsed dict; base_dir: directory mesh file names are relative to
+        (the application is run from its own directory)"""
         self.ctx = ctx
         cfg = config if isinstance(config, dict) else load_config(config)
         self.cfg = cfg
         mesh_type = get(cfg, "multilevel_mesh.first.type", {})
-        if "box" not in mesh_type:
-            raise NotImplementedError("mesh files need the Gambit reader (not built); only the 'box' mesh type is served")
-        b = mesh_type["box"]
-        self.box = (int(b.get("nx", 2)), int(b.get("ny", 2)), int(b.get("nz", 0)))
-        self.lo = (float(b.get("xa", 0.)), float(b.get("ya", 0.)), float(b.get("za", 0.)))
-        self.hi = (float(b.get("xb", 1.)), float(b.get("yb", 1.)), float(b.get("zb", 0.)))
-        self.dim = 2 if self.box[2] == 0 else 3
-        if self.dim == 2:
-            self.hi = (self.hi[0], self.hi[1], 1.0)         # the box generator ignores z in 2-D
+        self.mesh_file = None
+        if "filename" in mesh_type:
+            self.mesh_file = os.path.join(base_dir, mesh_type["filename"]) if base_dir else mesh_type["filename"]
+            probe = capi.Mesh.read_gambit(self.mesh_file)
+            self.dim = probe.dim
+            probe.destroy()
+            self.box = None
+        elif "box" in mesh_type:
+            b = mesh_type["box"]
+            self.box = (int(b.get("nx", 2)), int(b.get("ny", 2)), int(b.get("nz", 0)))
+            self.lo = (float(b.get("xa", 0.)), float(b.get("ya", 0.)), float(b.get("za", 0.)))
+            self.hi = (float(b.get("xb", 1.)), float(b.get("yb", 1.)), float(b.get("zb", 0.)))
+            self.dim = 2 if self.box[2] == 0 else 3
+            if self.dim == 2:
+                self.hi = (self.hi[0], self.hi[1], 1.0)         # the box generator ignores z in 2-D
+        else:
+            raise ValueError("Error: no input mesh specified. Please check to have added the keyword mesh in the input json file! ")
         var = "multilevel_solution.multilevel_mesh.first.variable.first."
         self.fe = FE_ORDER[get(cfg, var + "fe_order", "first")]
         self.nlevels = int(get(cfg, PREFIX + "type.multigrid.nlevels", 1))
@@ -85,33 +97,43 @@ class Poisson001:
         self.max_linear = int(get(cfg, PREFIX + "max_number_linear_iteration", 6))
         self.abs_tol = float(get(cfg, PREFIX + "abs_conv_tol", 1.e-08))
         assert get(cfg, PREFIX + "type.multigrid.mgtype", "V_cycle") == "V_cycle", "only the V-cycle of the shipped inputs is served"
-        # boundary conditions: default Dirichlet homogeneous on every face (InitializeBdc_with_ParsedFunction)
-        names = FACE_NAMES[self.dim]
-        self.bc_type = {n: "dirichlet" for n in names}
-        self.bc_func = {n: None for n in names}
-        for item in get(cfg, var + "boundary_conditions", []):
-            name = item.get("facename", "top")
-            if name not in names:
-                raise ValueError(" Error: the facename %s does not exist!" % name)
-            self.bc_type[name] = item.get("bdc_type", "dirichlet")
-            self.bc_func[name] = capi.Expr(item.get("bdc_func", "0."), "x,y,z,t")
+        # boundary conditions per face flag (flag = -(face name) - 1)
+        self.bc_type, self.bc_func = {}, {}
+        if self.box is not None:
+            # default Dirichlet homogeneous on every face (InitializeBdc_with_ParsedFunction), then the listed faces
+            names = FACE_NAMES[self.dim]
+            for n in names:
+                self.bc_type[self.flag_of(n)], self.bc_func[self.flag_of(n)] = "dirichlet", None
+            for item in get(cfg, var + "boundary_conditions", []):
+                name = item.get("facename", "top")
+                if name not in names:
+                    raise ValueError(" Error: the facename %s does not exist!" % name)
+                self.bc_type[self.flag_of(name)] = item.get("bdc_type", "dirichlet")
+                self.bc_func[self.flag_of(name)] = capi.Expr(item.get("bdc_func", "0."), "x,y,z,t")
+        else:
+            # SetBoundaryCondition of the application (main.cpp:26-36): Dirichlet 0 everywhere, flux 0.2 on face name 3
+            self.file_flux = {-4: 0.2}
         self.source = capi.Expr(get(cfg, var + "func_source", "0."), "x,y,z,t")
 
     def flag_of(self, name):
         return -(FACE_NAMES[self.dim].index(name) + 2)
+
+    def face_bc(self, flag):
+        """(type, function or None) of a boundary face"""
+        if self.box is None:
+            return ("neumann", None) if flag in self.file_flux else ("dirichlet", None)
+        return self.bc_type[flag], self.bc_func[flag]
 
     def dirichlet_data(self, mesh):
         """GenerateBdc with parsed functions (MultiLevelSolution.cpp:762-800): elements and faces in order; nodes of Dirichlet
         faces get Bdc = 0 and Sol = value(x, y, z, t = 0); a later face overwrites an earlier one"""
         ed, xy, ff = mesh.arrays()
         nc = {"linear": 2 ** self.dim, "biquadratic": 3 ** self.dim}[self.fe]
-        names = FACE_NAMES[self.dim]
         val = {}
         for iel, f in zip(*np.nonzero(ff < -1)):
-            name = names[-int(ff[iel, f]) - 2]
-            if self.bc_type[name] != "dirichlet":
+            kind, fn = self.face_bc(int(ff[iel, f]))
+            if kind != "dirichlet":
                 continue
-            fn = self.bc_func[name]
             for i in capi.fe_face_nodes(mesh.geom, "biquadratic", f):
                 if i >= nc:
                     continue
@@ -124,11 +146,11 @@ class Poisson001:
 
     def run(self, smoother=capi.SMOOTH_GS_COLOR, omega=1.0, log=None):
         ctx = self.ctx
-        meshes = [capi.Mesh.box(*self.box, self.lo, self.hi)]
+        meshes = [capi.Mesh.box(*self.box, self.lo, self.hi) if self.box is not None else capi.Mesh.read_gambit(self.mesh_file)]
         for _ in range(1, self.nlevels):
             meshes.append(meshes[-1].refine())
         data = [self.dirichlet_data(m) for m in meshes]
-        pb = PoissonMG(ctx, *self.box, self.nlevels, fe=self.fe, omega=omega, npre=self.npre, npost=self.npost, meshes=meshes,
+        pb = PoissonMG(ctx, 0, 0, 0, self.nlevels, fe=self.fe, omega=omega, npre=self.npre, npost=self.npost, meshes=meshes,
                        smoother=smoother, dirichlet=[d[0] for d in data], source_expr=self.source, source_scale=-1.0)
         pb.init()
         top = self.nlevels - 1
@@ -137,12 +159,12 @@ class Poisson001:
         pb.SOL.upload(sol0)
         pb.assemble()
         # non-homogeneous Neumann faces (main.cpp:497-553): constant flux per face, the only kind the shipped inputs use
-        flux = {}
-        for name in FACE_NAMES[self.dim]:
-            if self.bc_type[name] == "neumann" and self.bc_func[name] is not None:
-                v = self.bc_func[name](np.zeros(4))
+        flux = dict(self.file_flux) if self.box is None else {}
+        for flag, kind in self.bc_type.items():
+            if kind == "neumann" and self.bc_func[flag] is not None:
+                v = self.bc_func[flag](np.zeros(4))
                 if v != 0.0:
-                    flux[self.flag_of(name)] = v
+                    flux[flag] = v
         if flux:
             capi.assemble_neumann(ctx, meshes[top], self.fe, pb.RES, flux)
         pb.prepare()

@@ -370,6 +370,14 @@ class Mesh:
         _chk(L.fh_mesh_box(nx, ny, nz, _p(lo_), _p(hi_), ctypes.byref(h)))
         return cls(L, h)
 
+    @classmethod
+    def read_gambit(cls, path, Lref=1.0):
+        """MultiLevelMesh::ReadCoarseMesh for a Gambit neutral file (HEX27 / QUAD9)"""
+        L = load_library()
+        h = ctypes.c_void_p()
+        _chk(L.fh_mesh_read_gambit(str(path).encode(), float(Lref), ctypes.byref(h)))
+        return cls(L, h)
+
     def refine(self):
         h = ctypes.c_void_p()
         _chk(self.L.fh_mesh_refine(self.h, ctypes.byref(h)))

@@ -869,3 +869,164 @@ extern "C" int fh_mesh_vertex_patches(fh_mesh_t m, int nvars, const int* fe, int
   *total = (int)out_dofs.size();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Gambit neutral files: GambitIO::read
+//   src/06_mesh/00_single_level/01_input/01_from_external_file/GambitIO.cpp:93-352
+// for the element types of this path (HEX27, QUAD9; every node of such an element is in the file, so
+// AddBiquadraticNodesNotInMeshFile, Mesh.cpp:1207-1333, has nothing to add).  The token-stream reading follows the
+// reference: control data after "NDFVL", elements after "ELEMENTS/CELLS", coordinates after "COORDINATES", groups after
+// each "GROUP:" (group and material numbers are integers), boundary sets after each "CONDITIONS" (set number n gives the
+// face flag -n-1, GambitIO.cpp:337).  Gambit's local node order is lexicographic (xi slowest, eta, zeta fastest and
+// descending) for the 27-node brick and perimeter-then-centre for the 9-node quadrilateral; its brick faces 1..6 are FEMuS
+// faces 0,4,2,5,3,1 (GambitIO.cpp:55-89).  After reading: elements sorted by (material, group, file order) as
+// Mesh::mesh_reorder_elem_quantities does (Mesh.cpp:626-690), then the first-touch node numbering (Mesh.cpp:517-559).
+// ---------------------------------------------------------------------------------------------------------------------
+#include <fstream>
+
+extern "C" int fh_mesh_read_gambit(const char* path, double Lref, fh_mesh_t* out) {
+  FH_REQUIRE(path && out && Lref != 0.0, "fh_mesh_read_gambit: bad arguments");
+  std::ifstream inf(path);
+  FH_REQUIRE((bool)inf, "Generic-mesh file %s can not read parameters", path);
+  std::vector<std::string> tok;
+  {
+    std::string t;
+    while (inf >> t) tok.push_back(t);
+  }
+  size_t p = 0;
+  auto seek = [&](const char* word, size_t from) {
+    for (size_t k = from; k < tok.size(); k++)
+      if (tok[k] == word) return k;
+    return tok.size();
+  };
+  auto num = [&](size_t k, double* v) {
+    if (k >= tok.size()) return false;
+    char* e = nullptr;
+    *v = strtod(tok[k].c_str(), &e);
+    return e != tok[k].c_str() && *e == 0;
+  };
+  p = seek("NDFVL", 0);
+  double v[6];
+  for (int k = 0; k < 6; k++) FH_REQUIRE(num(p + 1 + k, &v[k]), "fh_mesh_read_gambit: %s: error control data mesh", path);
+  FH_REQUIRE(p + 7 < tok.size() && tok[p + 7] == "ENDOFSECTION", "fh_mesh_read_gambit: %s: error control data mesh", path);
+  const int nvt = (int)v[0], nel = (int)v[1], ngroup = (int)v[2], nbcd = (int)v[3], dim = (int)v[4], dimNodes = (int)v[5];
+  FH_REQUIRE(dim == 2 || dim == 3, "fh_mesh_read_gambit: %s: %d-dimensional meshes are not served (HEX27 / QUAD9 only)", path, dim);
+  fh_mesh_s* m = new fh_mesh_s();
+  m->geom = dim == 3 ? GEOM_HEX : GEOM_QUAD;
+  m->dim = dim;
+  m->nloc = nloc_of(m->geom);
+  m->nel = nel;
+  const int nl = m->nloc, nf = nfaces_of(m->geom);
+  // Gambit local node -> FEMuS local node
+  std::vector<int> g2f(nl);
+  if (dim == 3) {
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++)
+        for (int c = 0; c < 3; c++)
+          for (int n = 0; n < nl; n++)
+            if (xc(m->geom, n, 0) == a - 1 && xc(m->geom, n, 1) == b - 1 && xc(m->geom, n, 2) == 1 - c) g2f[a * 9 + b * 3 + c] = n;
+  } else {
+    for (int g = 0; g < 8; g++) g2f[g] = (g % 2 == 0) ? g / 2 : 4 + g / 2;
+    g2f[8] = 8;
+  }
+  const int gface_hex[6] = {0, 4, 2, 5, 3, 1};
+  // elements
+  p = seek("ELEMENTS/CELLS", 0);
+  FH_REQUIRE(p < tok.size(), "fh_mesh_read_gambit: %s: no ELEMENTS/CELLS section", path);
+  p += 2;
+  std::vector<int> ed((size_t)nel * nl);
+  for (int iel = 0; iel < nel; iel++) {
+    double nve;
+    FH_REQUIRE(num(p + 2, &nve), "fh_mesh_read_gambit: %s: error element data mesh", path);
+    if ((int)nve != nl) {
+      delete m;
+      fh_set_error("Error! Invalid element type in reading Gambit File! (element %d has %d nodes; HEX27 / QUAD9 meshes are served)", iel + 1, (int)nve);
+      return 2;
+    }
+    p += 3;
+    for (int i = 0; i < nl; i++) {
+      double val;
+      FH_REQUIRE(num(p + i, &val) && val >= 1 && val <= nvt, "fh_mesh_read_gambit: %s: bad node id in element %d", path, iel + 1);
+      ed[(size_t)iel * nl + g2f[i]] = (int)val - 1;
+    }
+    p += nl;
+  }
+  FH_REQUIRE(p < tok.size() && tok[p] == "ENDOFSECTION", "fh_mesh_read_gambit: %s: error element data mesh", path);
+  // coordinates
+  p = seek("COORDINATES", 0);
+  FH_REQUIRE(p < tok.size(), "fh_mesh_read_gambit: %s: no NODAL COORDINATES section", path);
+  p += 2;
+  std::vector<double> xyz((size_t)nvt * dim);
+  for (int j = 0; j < nvt; j++) {
+    for (int d = 0; d < dimNodes; d++) {
+      double c;
+      FH_REQUIRE(num(p + 1 + d, &c), "fh_mesh_read_gambit: %s: error node data mesh", path);
+      if (d < dim) xyz[(size_t)j * dim + d] = c / Lref;
+    }
+    p += 1 + dimNodes;
+  }
+  FH_REQUIRE(p < tok.size() && tok[p] == "ENDOFSECTION", "fh_mesh_read_gambit: %s: error node data mesh 1", path);
+  // groups and materials
+  std::vector<int> group(nel, 1), material(nel, 0);
+  p = 0;
+  for (int k = 0; k < ngroup; k++) {
+    p = seek("GROUP:", p);
+    double ngel, mat, name;
+    FH_REQUIRE(p < tok.size() && num(p + 3, &ngel) && num(p + 5, &mat) && num(p + 8, &name), "fh_mesh_read_gambit: %s: error group data mesh", path);
+    p += 10;
+    for (int i = 0; i < (int)ngel; i++) {
+      double iel;
+      FH_REQUIRE(num(p + i, &iel) && iel >= 1 && iel <= nel, "fh_mesh_read_gambit: %s: error group data mesh", path);
+      group[(int)iel - 1] = (int)name;
+      material[(int)iel - 1] = (int)mat;
+    }
+    p += (size_t)ngel;
+    FH_REQUIRE(p < tok.size() && tok[p] == "ENDOFSECTION", "fh_mesh_read_gambit: %s: error group data mesh", path);
+  }
+  // boundary sets
+  std::vector<int> ff((size_t)nel * nf, -1);
+  p = 0;
+  for (int k = 0; k < nbcd; k++) {
+    p = seek("CONDITIONS", p);
+    double value, nface;
+    FH_REQUIRE(p < tok.size() && num(p + 2, &value) && num(p + 4, &nface), "fh_mesh_read_gambit: %s: error boundary data mesh", path);
+    p += 7;
+    for (int i = 0; i < (int)nface; i++) {
+      double iel, iface;
+      FH_REQUIRE(num(p, &iel) && num(p + 2, &iface) && iel >= 1 && iel <= nel && iface >= 1 && iface <= nf, "fh_mesh_read_gambit: %s: error boundary data mesh",
+                 path);
+      const int f = dim == 3 ? gface_hex[(int)iface - 1] : (int)iface - 1;
+      ff[((size_t)iel - 1) * nf + f] = -(int)value - 1;
+      p += 3;
+    }
+    FH_REQUIRE(p < tok.size() && tok[p] == "ENDOFSECTION", "fh_mesh_read_gambit: %s: error boundary data mesh", path);
+  }
+  // element order: (material, group, file order)
+  std::vector<int> order(nel);
+  for (int i = 0; i < nel; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    if (material[a] != material[b]) return material[a] < material[b];
+    return group[a] < group[b];
+  });
+  m->elem_dof.resize((size_t)nel * nl);
+  m->face_flag.resize((size_t)nel * nf);
+  for (int i = 0; i < nel; i++) {
+    memcpy(&m->elem_dof[(size_t)i * nl], &ed[(size_t)order[i] * nl], nl * sizeof(int));
+    memcpy(&m->face_flag[(size_t)i * nf], &ff[(size_t)order[i] * nf], nf * sizeof(int));
+  }
+  m->coords = xyz;
+  m->elem_level.assign(nel, 0);
+  {
+    std::vector<char> used(nvt, 0);
+    for (int x : m->elem_dof) used[x] = 1;
+    for (int j = 0; j < nvt; j++)
+      if (!used[j]) {
+        delete m;
+        fh_set_error("fh_mesh_read_gambit: %s: node %d belongs to no element", path, j + 1);
+        return 2;
+      }
+  }
+  first_touch_renumber(*m, nvt);
+  *out = m;
+  return 0;
+}

@@ -126,6 +126,11 @@ int fh_fe_elem_prolongator(int geom, int fe, int* nchild, int* nc, double* P /* 
 /* ---- mesh + DOF maps (a8-a10): box generator, uniform refinement, first-touch numbering, nprocs=1 ----
  * MeshGeneration.cpp:790-849,979-1075 ; MeshRefinement.cpp:240-294,356-417,513-620 ; Mesh.cpp:517-559 */
 int fh_mesh_box(int nx, int ny, int nz, const double lo[3], const double hi[3], fh_mesh_t* mesh);
+/* Gambit neutral file: GambitIO::read (src/06_mesh/00_single_level/01_input/01_from_external_file/GambitIO.cpp:93-352)
+ * for HEX27 / QUAD9 meshes: nodes, elements (Gambit -> FEMuS local order, :55-80), groups/materials, boundary sets (set n ->
+ * face flag -n-1, :337), then the element and node numbering of Mesh::ReadCoarseMesh (Mesh.cpp:239-250).  Lref scales the
+ * coordinates.  Errors carry the reference's messages in fh_last_error. */
+int fh_mesh_read_gambit(const char* path, double Lref, fh_mesh_t* mesh);
 int fh_mesh_refine(fh_mesh_t coarse, fh_mesh_t* fine);
 /* selective (adaptive) refinement -- MeshRefinement::RefineMesh with an AMR flag per element (MeshRefinement.cpp:197-493):
  * elements of the current level with flags[iel] != 0 are split, every other element is carried over unchanged, which

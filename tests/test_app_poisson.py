@@ -91,3 +91,44 @@ def test_run_matches_oracle_direct_solution(ctx):
     assert np.array_equal(out["coords"], m.coords)
     assert abs(out["solution"] - ref).max() < 1e-9
     p.destroy()
+
+
+FILE_CONFIG = """
+{
+    "multilevel_mesh" : { "first" : { "type" : { "filename" : "cube.neu" } } },
+    "multilevel_solution" : { "multilevel_mesh" : { "first" : { "variable" : { "first" : {
+              "name" : "T", "fe_order" : "second", "init_func" : "0.", "func_source": "1.+x*y",
+              "boundary_conditions" : [ { "facename" : "top", "bdc_type" : "dirichlet" } ] } } } } },
+    "multilevel_problem" : { "multilevel_mesh" : { "first" : { "system" : { "poisson" : { "linear_solver" : {
+                "max_number_linear_iteration" : 10, "abs_conv_tol" : 1.e-10,
+                "type" : { "multigrid" : { "nlevels" : 2, "npresmoothing" : 1, "npostmoothing" : 1, "mgtype" : "V_cycle" } } } } } } } }
+}
+"""
+
+
+@pytest.mark.gpu
+def test_mesh_file_input_matches_oracle(ctx, tmp_path):
+    """the 3-D inputs of the application: mesh from a Gambit file, SetBoundaryCondition of main.cpp:26-36 (Dirichlet 0, flux 0.2
+    through face name 3)"""
+    from gambit_writer import write_neu
+    mo = fo.coarse_box_mesh(2, 2, 2)
+    write_neu(tmp_path / "cube.neu", "hex", mo.elem_dof, mo.coords, mo.face_flag)
+    p = app.Poisson001(ctx, FILE_CONFIG, base_dir=str(tmp_path))
+    out = p.run()
+    assert out["converged"]
+    m = fo.refine(mo)
+    fn = fo.face_nodes("hex")
+    bdc = set()
+    for f in range(6):
+        els = np.where((m.face_flag[:, f] < -1) & (m.face_flag[:, f] != -4))[0]
+        bdc.update(m.elem_dof[els][:, fn[f]].ravel().tolist())
+    bdc = np.array(sorted(bdc))
+    src = lambda xg: -(1. + xg[..., 0] * xg[..., 1])
+    A, b = fo.assemble_poisson(m, "biquadratic", src)
+    b = b + fo.neumann_rhs(m, "biquadratic", {-4: 0.2})
+    A = fo.zero_rows(A, bdc, 1.0)
+    b[bdc] = 0.0
+    ref = spla.spsolve(A.tocsc(), b)
+    assert np.allclose(out["coords"], m.coords, atol=1e-10)
+    assert abs(out["solution"] - ref).max() < 1e-9
+    p.destroy()

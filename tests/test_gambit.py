@@ -1,0 +1,68 @@
+"""Gambit neutral-file reader (GambitIO::read) against meshes written by the independent writer of
+tests/gambit_writer.py, and against the reference's own input files when the reference tree is present (this container only)."""
+import os
+
+import numpy as np
+import pytest
+
+from femus_amd import capi
+from oracle import femus_oracle as fo
+
+from gambit_writer import write_neu
+
+
+@pytest.mark.parametrize("box", [(3, 2, 0), (2, 3, 2)])
+def test_reader_round_trip_of_a_box_mesh(tmp_path, box):
+    mo = fo.coarse_box_mesh(*box, lo=(-1., 0., 0.5), hi=(2., 1., 1.5))
+    path = tmp_path / "box.neu"
+    write_neu(path, mo.geom, mo.elem_dof, mo.coords, mo.face_flag)
+    m = capi.Mesh.read_gambit(path)
+    ed, xy, ff = m.arrays()
+    assert np.array_equal(ed, mo.elem_dof)                      # same elements, same first-touch numbering
+    assert np.allclose(xy, mo.coords, rtol=0, atol=1e-10)       # "%20.11e" in the file
+    assert np.array_equal(ff, mo.face_flag)
+    assert m.own_size == list(mo.own_size)
+    f = m.refine()                                              # the read mesh feeds the refinement like a generated one
+    assert f.nel == m.nel * 2 ** m.dim
+    m.destroy(), f.destroy()
+
+
+def test_reader_scales_coordinates_and_reports_errors(tmp_path):
+    mo = fo.coarse_box_mesh(2, 2, 0)
+    path = tmp_path / "q.neu"
+    write_neu(path, mo.geom, mo.elem_dof, mo.coords, mo.face_flag)
+    m = capi.Mesh.read_gambit(path, Lref=2.0)
+    assert np.allclose(m.arrays()[1], mo.coords / 2.0, atol=1e-10)
+    m.destroy()
+    with pytest.raises(capi.FemusHipError, match="can not read parameters"):
+        capi.Mesh.read_gambit(tmp_path / "missing.neu")
+    bad = tmp_path / "bad.neu"
+    bad.write_text(open(path).read().replace(" 2  9 ", " 2  8 ", 1))
+    with pytest.raises(capi.FemusHipError, match="Invalid element type"):
+        capi.Mesh.read_gambit(bad)
+
+
+REF = "/root/reference/applications"
+FILES = [("003_NavierStokes/SteadyNavierStokesParallel/input/box10x10.neu", "quad", 100, 441, {-2: 10, -3: 30}),
+         ("001_Poisson/input/cube_Hex.neu", "hex", 8, 125, {-2: 4, -3: 4, -4: 4, -5: 4, -6: 4, -7: 4})]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+@pytest.mark.parametrize("rel,geom,nel,nnode,sets", FILES)
+def test_reader_on_the_reference_input_files(rel, geom, nel, nnode, sets):
+    m = capi.Mesh.read_gambit(os.path.join(REF, rel))
+    ed, xy, ff = m.arrays()
+    assert (m.nel, m.nnode) == (nel, nnode)
+    assert {int(k): int(v) for k, v in zip(*np.unique(ff[ff < -1], return_counts=True))} == sets
+    Xc = fo.xc_table(geom).astype(float)
+    fn = fo.face_nodes(geom)
+    lo, hi = xy.min(0), xy.max(0)
+    for e in range(nel):
+        X = xy[ed[e]]
+        H = np.stack([(X[1] - X[0]) / 2, (X[3] - X[0]) / 2] + ([(X[4] - X[0]) / 2] if m.dim == 3 else []))
+        assert np.allclose(X, X[-1] + Xc @ H) and np.linalg.det(H) > 0     # FEMuS local order, right-handed
+        for f in range(ff.shape[1]):                                       # flagged faces = faces on the bounding box
+            P = xy[ed[e, fn[f]]]
+            on = any(np.allclose(P[:, k], lo[k]) or np.allclose(P[:, k], hi[k]) for k in range(m.dim))
+            assert on == (ff[e, f] < -1)
+    m.destroy()
