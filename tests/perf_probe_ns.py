@@ -1,0 +1,52 @@
+"""timing probe (not a test): BASELINE config 4 -- lid-driven cavity, 10 x 10 coarse QUAD9 mesh, 4 levels (80 x 80 Taylor-Hood
+elements, 58 242 unknowns), Newton + Vanka-multigrid-preconditioned GMRES; prints one JSON line"""
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import femus_amd
+from femus_amd.navier_stokes import NavierStokesMG
+
+
+def main():
+    nu = float(sys.argv[1]) if len(sys.argv) > 1 else 0.01
+    ctx = femus_amd.Context(0)
+    nl = 4
+    t0 = time.time()
+    pb = NavierStokesMG(ctx, 10, 10, 0, nl, 0.01).init()
+    setup_s = time.time() - t0
+    t0 = time.time()
+    for v in ([0.01] if nu >= 0.01 else [0.01, 0.004, 0.002, nu]):
+        pb.nu = v
+        assert pb.newton(0, tol=1e-10, max_newton=25)
+    for ig in range(1, nl):
+        pb.prolongator_sol(ig)
+        assert pb.newton(ig, tol=1e-10, max_newton=25, lin_rtol=1e-10, lin_maxit=200)
+    ctx.sync()
+    solve_s = time.time() - t0
+    top = nl - 1
+    # one more Newton step on the finest level, split into its parts
+    ctx.sync(); t = time.time()
+    for _ in range(5):
+        pb.asm[top].assemble(pb.KK[top], pb.RES[top], pb.SOL[top], pb.nu)
+    ctx.sync(); asm_ms = (time.time() - t) / 5 * 1e3
+    t = time.time(); mg = pb.prepare(top); ctx.sync(); prep_ms = (time.time() - t) * 1e3
+    x = ctx.vector(pb.n[top])
+    t = time.time()
+    for _ in range(20):
+        mg.vcycle(pb.RES[top], x)
+    ctx.sync(); cyc_ms = (time.time() - t) / 20 * 1e3
+    t = time.time(); its, rn = mg.solve(pb.RES[top], pb.EPS[top], outer="gmres", rtol=1e-10, maxit=200); ctx.sync()
+    lin_ms = (time.time() - t) * 1e3
+    fine = [h for h in pb.history if h[0] == top]
+    print(json.dumps({"config": "cavity Q2/Q1 80x80, 4 levels, nu=%g" % nu, "unknowns": pb.n[top], "setup_s": setup_s,
+                      "fcycle_solve_s": solve_s, "newton_steps_per_level": [sum(1 for h in pb.history if h[0] == l) for l in range(nl)],
+                      "gmres_its_finest": [h[3] for h in fine], "assembly_ms": asm_ms, "prepare_ms": prep_ms,
+                      "vcycle_ms": cyc_ms, "linear_solve_ms": lin_ms, "linear_its": its}))
+    pb.destroy()
+
+
+main()
