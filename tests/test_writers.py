@@ -1,0 +1,64 @@
+"""VTK output and binary save/load: files are parsed back and compared with what was written."""
+import base64
+import re
+import struct
+
+import numpy as np
+import pytest
+
+from femus_amd import capi, writers
+from oracle import femus_oracle as fo
+
+
+def arrays_of(text):
+    out = {}
+    for m in re.finditer(r'<DataArray type="(\w+)"([^>]*)>\s*(\S+)\s*</DataArray>', text):
+        name = re.search(r'Name="(\w+)"', m.group(2))
+        raw = m.group(3)
+        n = struct.unpack("<I", base64.b64decode(raw[:8]))[0]
+        data = base64.b64decode(raw[8:])
+        assert len(data) == n
+        out[name.group(1) if name else "points"] = np.frombuffer(data, {"Float32": "<f4", "Int32": "<i4", "UInt16": "<u2"}[m.group(1)])
+    return out
+
+
+@pytest.mark.parametrize("box", [(2, 3, 0), (2, 1, 2)])
+def test_vtu_round_trip(tmp_path, box):
+    m = capi.Mesh.box(*box)
+    m = m.refine()
+    ed, xy, _ = m.arrays()
+    u = np.sin(xy[:, 0]) + 2 * xy[:, 1]
+    p = xy[:m.own_size[0], 0] * 3 - xy[:m.own_size[0], 1]                 # a linear field, given at the vertices only
+    path = tmp_path / "sol.level2.0.biquadratic.vtu"
+    writers.write_vtu(path, m, {"U": u, "P": p})
+    a = arrays_of(open(path).read())
+    pts = a["points"].reshape(-1, 3)
+    assert np.allclose(pts[:, :m.dim], xy, atol=1e-6) and a["types"][0] == (28 if m.dim == 2 else 29)
+    nl = ed.shape[1]
+    conn = a["connectivity"].reshape(-1, nl)
+    assert np.array_equal(a["offsets"], np.arange(1, m.nel + 1) * nl)
+    # VTK node order: every cell is a valid biquadratic cell, i.e. node k sits where VTK expects it
+    xc = np.array(writers.HEX_XC if m.dim == 3 else writers.XC["quad"], float)
+    if m.dim == 3:
+        vtk = np.vstack([xc[:20], [(-1, 0, 0), (1, 0, 0), (0, -1, 0), (0, 1, 0), (0, 0, -1), (0, 0, 1), (0, 0, 0)]])
+    else:
+        vtk = xc
+    for e in range(m.nel):
+        X = pts[conn[e], :m.dim]
+        c, h = X[-1], (X[2 if m.dim == 2 else 6] - X[0]) / 2
+        assert np.allclose(X, c + vtk * h, atol=1e-5)
+    assert np.allclose(a["U"], u, atol=1e-6)
+    assert np.allclose(a["P"], 3 * xy[:, 0] - xy[:, 1], atol=1e-6)          # linear field reproduced at every biquadratic node
+    m.destroy()
+
+
+def test_save_and_load_solution(tmp_path):
+    u, p = fo.lcg_fill(100, 3), fo.lcg_fill(17, 4)
+    files = writers.save_solution(str(tmp_path / "save"), "run", 7, {"U": u, "P": p}, 3)
+    assert [f.rsplit("/", 1)[1] for f in files] == ["run_iteration7_solU_level3", "run_iteration7_solP_level3"]
+    raw = open(files[0], "rb").read()
+    assert struct.unpack(">ii", raw[:8]) == (1211214, 100) and len(raw) == 8 + 800        # PETSc binary Vec layout
+    back = writers.load_solution(str(tmp_path / "save" / "run_iteration7"), ["U", "P"], 3)
+    assert np.array_equal(back["U"], u) and np.array_equal(back["P"], p)
+    with pytest.raises(FileNotFoundError, match="cannot locate file"):
+        writers.load_solution(str(tmp_path / "save" / "run_iteration8"), ["U"], 3)
