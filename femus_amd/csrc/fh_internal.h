@@ -56,6 +56,7 @@ struct fh_ctx_s {
   int assemble_sym = 1;              // symmetric-tile HEX27/Q2 element kernel (2 elements per wave)
   int assemble_two_pass = 1;         // 1: element matrices + row gather (default), 0: coloured scatter
   int use_graph = 1;
+  int spgemm_slot_map = 1;           // Galerkin products stream a precomputed slot map instead of searching
 };
 
 struct fh_vec_s {

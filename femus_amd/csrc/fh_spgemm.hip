@@ -12,17 +12,288 @@
 #include <algorithm>
 #include <thread>
 
+// product lists of C = A*B on fixed patterns: for every entry of C the elementary products that make it up, as pairs
+// (offset of the A entry inside its row, index of the B entry), stored contiguously per C entry in increasing-k order.  Built
+// once on the device (the only place a search is needed); the numeric product is then a segmented sum with no search, no
+// atomics and a fixed summation order: 6 bytes per elementary product (6.5 GB for A*P plus 10 GB for R*(AP) at 64^3 Q2 -- HBM
+// is 288 GB) streamed per re-assembly instead of 12x as many binary searches.
+struct SlotMap {
+  unsigned short* pa = nullptr;     // [nprod] offset of the A entry in its row
+  int* pb = nullptr;                // [nprod] index of the B entry
+  long long* rowbase = nullptr;     // [m+1] first elementary product of every row
+  int* segptr = nullptr;            // [nnz(C)+m] per row: clen+1 offsets relative to rowbase[row]
+  unsigned short* slot = nullptr;   // alternative for long B rows: per elementary product, in (row, ka, kb) order, its position in the C row
+  long long nprod = 0;
+  int max_crow = 0, max_arow = 0;
+  void release() {
+    for (void** q : {(void**)&pa, (void**)&pb, (void**)&rowbase, (void**)&segptr, (void**)&slot})
+      if (*q) {
+        hipFree(*q);
+        *q = nullptr;
+      }
+  }
+};
+
 struct PtapPlan {
   fh_mat_t AP = nullptr;   // m x nc work matrix (pattern + values)
   int m = 0, n = 0, nc = 0;
   int a_nnz = 0, p_nnz = 0;
+  SlotMap map_ap, map_c;
 };
 
 static void destroy_plan(void* p) {
   PtapPlan* plan = (PtapPlan*)p;
   if (!plan) return;
   if (plan->AP) fh_mat_destroy(plan->AP);
+  plan->map_ap.release();
+  plan->map_c.release();
   delete plan;
+}
+
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int row_slot(const int* __restrict__ c_col, int cs, int clen, int c) {
+  int lo = 0, hi = clen - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (c_col[cs + mid] < c) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// pass 1: number of elementary products per row and per C entry (segptr holds counts, shifted by one, turned into offsets here)
+__global__ __launch_bounds__(256) void k_spgemm_segcount(const int* __restrict__ a_rp, const int* __restrict__ a_col, const int* __restrict__ b_rp,
+                                                         const int* __restrict__ b_col, const int* __restrict__ c_rp, const int* __restrict__ c_col,
+                                                         long long* __restrict__ rowcount, int* __restrict__ segptr, int m, int max_crow) {
+  extern __shared__ int cnts[];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= m) return;
+  int* cnt = cnts + (size_t)w * (max_crow + 1);
+  const int cs = c_rp[row], clen = c_rp[row + 1] - cs;
+  for (int t = lane; t <= clen; t += 64) cnt[t] = 0;
+  wave_sync_lds();
+  for (int ka = a_rp[row]; ka < a_rp[row + 1]; ka++) {
+    const int k = a_col[ka];
+    const int bs = b_rp[k], blen = b_rp[k + 1] - bs;
+    for (int t = lane; t < blen; t += 64) cnt[row_slot(c_col, cs, clen, b_col[bs + t]) + 1] += 1;   // distinct slots within one B row
+    wave_sync_lds();
+  }
+  if (lane == 0) {
+    int run = 0;
+    for (int t = 1; t <= clen; t++) {
+      run += cnt[t];
+      cnt[t] = run;
+    }
+    rowcount[row + 1] = run;
+  }
+  wave_sync_lds();
+  int* sp = segptr + cs + row;
+  for (int t = lane; t <= clen; t += 64) sp[t] = cnt[t];
+}
+
+// pass 2: fill the lists; A entries in sequence, so every list is in increasing-k order
+__global__ __launch_bounds__(256) void k_spgemm_segfill(const int* __restrict__ a_rp, const int* __restrict__ a_col, const int* __restrict__ b_rp,
+                                                        const int* __restrict__ b_col, const int* __restrict__ c_rp, const int* __restrict__ c_col,
+                                                        const long long* __restrict__ rowbase, const int* __restrict__ segptr,
+                                                        unsigned short* __restrict__ pa, int* __restrict__ pb, int m, int max_crow) {
+  extern __shared__ int cnts[];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= m) return;
+  int* cur = cnts + (size_t)w * (max_crow + 1);
+  const int cs = c_rp[row], clen = c_rp[row + 1] - cs;
+  const int* sp = segptr + cs + row;
+  for (int t = lane; t < clen; t += 64) cur[t] = sp[t];
+  wave_sync_lds();
+  const long long base = rowbase[row];
+  const int as = a_rp[row];
+  for (int ka = as; ka < a_rp[row + 1]; ka++) {
+    const int k = a_col[ka];
+    const int bs = b_rp[k], blen = b_rp[k + 1] - bs;
+    for (int t = lane; t < blen; t += 64) {
+      const int s = row_slot(c_col, cs, clen, b_col[bs + t]);
+      const int q = cur[s];
+      cur[s] = q + 1;
+      pa[base + q] = (unsigned short)(ka - as);
+      pb[base + q] = bs + t;
+    }
+    wave_sync_lds();
+  }
+}
+
+// numeric product: one wave per output row; every lane owns output entries and sums its list in order from a register
+__global__ __launch_bounds__(256) void k_spgemm_numeric_map(const int* __restrict__ a_rp, const double* __restrict__ a_val, const double* __restrict__ b_val,
+                                                            const int* __restrict__ c_rp, double* __restrict__ c_val,
+                                                            const long long* __restrict__ rowbase, const int* __restrict__ segptr,
+                                                            const unsigned short* __restrict__ pa, const int* __restrict__ pb, int m, int max_arow) {
+  extern __shared__ double arow[];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= m) return;
+  double* av = arow + (size_t)w * max_arow;
+  const int as = a_rp[row], alen = a_rp[row + 1] - as;
+  for (int t = lane; t < alen; t += 64) av[t] = a_val[as + t];
+  wave_sync_lds();
+  const int cs = c_rp[row], clen = c_rp[row + 1] - cs;
+  const int* sp = segptr + cs + row;
+  const long long base = rowbase[row];
+  for (int t = lane; t < clen; t += 64) {
+    double acc = 0.0;
+    const long long q1 = base + sp[t + 1];
+    for (long long q = base + sp[t]; q < q1; q++) acc += av[pa[q]] * b_val[pb[q]];
+    c_val[cs + t] = acc;
+  }
+}
+
+// ---- variant for products whose B rows are long (R * (AP): ~100 entries per row): the lanes spread over the B row, the A
+// entries are taken in sequence, the output row is accumulated in LDS; the map gives every elementary product its position in
+// the output row (2 bytes each)
+__global__ __launch_bounds__(256) void k_spgemm_count(const int* __restrict__ a_rp, const int* __restrict__ a_col, const int* __restrict__ b_rp,
+                                                      long long* __restrict__ rowcount, int m) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= m) return;
+  long long c = 0;
+  for (int ka = a_rp[row] + lane; ka < a_rp[row + 1]; ka += 64) c += b_rp[a_col[ka] + 1] - b_rp[a_col[ka]];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if (lane == 0) rowcount[row + 1] = c;
+}
+
+__global__ __launch_bounds__(256) void k_spgemm_fill(const int* __restrict__ a_rp, const int* __restrict__ a_col, const int* __restrict__ b_rp,
+                                                     const int* __restrict__ b_col, const int* __restrict__ c_rp, const int* __restrict__ c_col,
+                                                     const long long* __restrict__ rowbase, unsigned short* __restrict__ slot, int m) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= m) return;
+  const int cs = c_rp[row], clen = c_rp[row + 1] - cs;
+  long long off = rowbase[row];
+  for (int ka = a_rp[row]; ka < a_rp[row + 1]; ka++) {
+    const int k = a_col[ka];
+    const int bs = b_rp[k], blen = b_rp[k + 1] - bs;
+    for (int t = lane; t < blen; t += 64) slot[off + t] = (unsigned short)row_slot(c_col, cs, clen, b_col[bs + t]);
+    off += blen;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_spgemm_numeric_slots(const int* __restrict__ a_rp, const int* __restrict__ a_col, const double* __restrict__ a_val,
+                                                              const int* __restrict__ b_rp, const double* __restrict__ b_val,
+                                                              const int* __restrict__ c_rp, double* __restrict__ c_val,
+                                                              const long long* __restrict__ rowbase, const unsigned short* __restrict__ slot, int m,
+                                                              int max_crow) {
+  extern __shared__ double arow[];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= m) return;
+  double* acc = arow + (size_t)w * max_crow;
+  const int cs = c_rp[row], clen = c_rp[row + 1] - cs;
+  for (int t = lane; t < clen; t += 64) acc[t] = 0.0;
+  wave_sync_lds();
+  long long off = rowbase[row];
+  for (int ka = a_rp[row]; ka < a_rp[row + 1]; ka++) {
+    const int k = a_col[ka];
+    const double a = a_val[ka];
+    const int bs = b_rp[k], blen = b_rp[k + 1] - bs;
+    for (int t = lane; t < blen; t += 64) acc[slot[off + t]] += a * b_val[bs + t];
+    off += blen;
+    wave_sync_lds();
+  }
+  for (int t = lane; t < clen; t += 64) c_val[cs + t] = acc[t];
+}
+
+static int build_slot_map_long(fh_mat_t A, fh_mat_t B, fh_mat_t C, SlotMap& M) {
+  fh_ctx_t c = A->ctx;
+  const int m = C->m;
+  int max_crow = 0;
+  for (int r = 0; r < m; r++) max_crow = std::max(max_crow, C->h_rowptr[r + 1] - C->h_rowptr[r]);
+  if (m == 0 || max_crow == 0 || max_crow > 2000) return 0;
+  M.max_crow = max_crow;
+  FH_CHECK_HIP(hipMalloc(&M.rowbase, ((size_t)m + 1) * sizeof(long long)));
+  FH_CHECK_HIP(hipMemsetAsync(M.rowbase, 0, sizeof(long long), c->stream));
+  hipLaunchKernelGGL(k_spgemm_count, dim3(fh_div_up(m, 4)), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, B->d_rowptr, M.rowbase, m);
+  std::vector<long long> rb((size_t)m + 1);
+  FH_CHECK_HIP(hipMemcpyAsync(rb.data(), M.rowbase, rb.size() * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  for (int r = 0; r < m; r++) rb[r + 1] += rb[r];
+  M.nprod = rb[m];
+  size_t free_b = 0, total_b = 0;
+  hipMemGetInfo(&free_b, &total_b);
+  if (M.nprod == 0 || (size_t)M.nprod * 2 > free_b / 2) {
+    M.release();
+    return 0;
+  }
+  FH_CHECK_HIP(hipMemcpyAsync(M.rowbase, rb.data(), rb.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+  FH_CHECK_HIP(hipMalloc(&M.slot, (size_t)M.nprod * sizeof(unsigned short)));
+  hipLaunchKernelGGL(k_spgemm_fill, dim3(fh_div_up(m, 4)), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, B->d_rowptr, B->d_col, C->d_rowptr,
+                     C->d_col, M.rowbase, M.slot, m);
+  FH_CHECK_HIP(hipGetLastError());
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int build_slot_map(fh_mat_t A, fh_mat_t B, fh_mat_t C, SlotMap& M) {
+  fh_ctx_t c = A->ctx;
+  M.release();
+  if (B->m > 0 && (double)B->nnz / B->m >= 32.0) return build_slot_map_long(A, B, C, M);   // long B rows: lanes over the B row
+  const int m = C->m;
+  int max_crow = 0, max_arow = 0;
+  for (int r = 0; r < m; r++) {
+    max_crow = std::max(max_crow, C->h_rowptr[r + 1] - C->h_rowptr[r]);
+    max_arow = std::max(max_arow, A->h_rowptr[r + 1] - A->h_rowptr[r]);
+  }
+  // 4 waves x (max_crow + 1) ints / 4 waves x max_arow doubles must fit in 64 KB of LDS; A-row offsets are 16-bit
+  if (m == 0 || max_crow == 0 || max_crow > 4000 || max_arow > 2000) return 0;
+  M.max_crow = max_crow;
+  M.max_arow = std::max(max_arow, 1);
+  FH_CHECK_HIP(hipMalloc(&M.rowbase, ((size_t)m + 1) * sizeof(long long)));
+  FH_CHECK_HIP(hipMalloc(&M.segptr, ((size_t)C->nnz + m + 2) * sizeof(int)));
+  FH_CHECK_HIP(hipMemsetAsync(M.rowbase, 0, sizeof(long long), c->stream));
+  const size_t lds = (size_t)4 * (max_crow + 1) * sizeof(int);
+  hipLaunchKernelGGL(k_spgemm_segcount, dim3(fh_div_up(m, 4)), dim3(256), lds, c->stream, A->d_rowptr, A->d_col, B->d_rowptr, B->d_col, C->d_rowptr,
+                     C->d_col, M.rowbase, M.segptr, m, max_crow);
+  std::vector<long long> rb((size_t)m + 1);
+  FH_CHECK_HIP(hipMemcpyAsync(rb.data(), M.rowbase, rb.size() * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  for (int r = 0; r < m; r++) {
+    if (rb[r + 1] > 2000000000ll) {   // segment offsets inside a row are 32-bit
+      M.release();
+      return 0;
+    }
+    rb[r + 1] += rb[r];
+  }
+  M.nprod = rb[m];
+  size_t free_b = 0, total_b = 0;
+  hipMemGetInfo(&free_b, &total_b);
+  if (M.nprod == 0 || (size_t)M.nprod * 6 > free_b / 2) {   // keep the searching kernel when the lists would not fit comfortably
+    M.release();
+    return 0;
+  }
+  FH_CHECK_HIP(hipMemcpyAsync(M.rowbase, rb.data(), rb.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+  FH_CHECK_HIP(hipMalloc(&M.pa, (size_t)M.nprod * sizeof(unsigned short)));
+  FH_CHECK_HIP(hipMalloc(&M.pb, (size_t)M.nprod * sizeof(int)));
+  hipLaunchKernelGGL(k_spgemm_segfill, dim3(fh_div_up(m, 4)), dim3(256), lds, c->stream, A->d_rowptr, A->d_col, B->d_rowptr, B->d_col, C->d_rowptr,
+                     C->d_col, M.rowbase, M.segptr, M.pa, M.pb, m, max_crow);
+  FH_CHECK_HIP(hipGetLastError());
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int spgemm_numeric_map(fh_mat_t A, fh_mat_t B, fh_mat_t C, const SlotMap& M) {
+  if (M.slot) {
+    hipLaunchKernelGGL(k_spgemm_numeric_slots, dim3(fh_div_up(C->m, 4)), dim3(256), (size_t)4 * M.max_crow * sizeof(double), C->ctx->stream,
+                       A->d_rowptr, A->d_col, A->d_val, B->d_rowptr, B->d_val, C->d_rowptr, C->d_val, M.rowbase, M.slot, C->m, M.max_crow);
+    FH_CHECK_HIP(hipGetLastError());
+    C->at_valid = false;
+    return 0;
+  }
+  hipLaunchKernelGGL(k_spgemm_numeric_map, dim3(fh_div_up(C->m, 4)), dim3(256), (size_t)4 * M.max_arow * sizeof(double), C->ctx->stream, A->d_rowptr,
+                     A->d_val, B->d_val, C->d_rowptr, C->d_val, M.rowbase, M.segptr, M.pa, M.pb, C->m, M.max_arow);
+  FH_CHECK_HIP(hipGetLastError());
+  C->at_valid = false;
+  return 0;
 }
 
 // C = A*B numeric on a given pattern of C
@@ -125,14 +396,18 @@ extern "C" int fh_mat_ptap(fh_mat_t P, fh_mat_t A, fh_mat_t* Cio) {
     C->plan = plan;
     C->plan_destroy = destroy_plan;
     *Cio = C;
+    if (A->ctx->spgemm_slot_map) {
+      FH_TRY(build_slot_map(A, P, plan->AP, plan->map_ap));
+      FH_TRY(build_slot_map(R, plan->AP, C, plan->map_c));
+    }
   } else {
     plan = (PtapPlan*)C->plan;
     FH_REQUIRE(plan != nullptr, "fh_mat_ptap: the output matrix was not created by fh_mat_ptap (no reusable plan)");
     FH_REQUIRE(plan->m == A->m && plan->nc == P->n && plan->a_nnz == A->nnz && plan->p_nnz == P->nnz,
                "fh_mat_ptap: reuse with operands of a different pattern");
   }
-  FH_TRY(spgemm_numeric(A, P, plan->AP));
-  FH_TRY(spgemm_numeric(R, plan->AP, C));
+  if (plan->map_ap.pa || plan->map_ap.slot) FH_TRY(spgemm_numeric_map(A, P, plan->AP, plan->map_ap)); else FH_TRY(spgemm_numeric(A, P, plan->AP));
+  if (plan->map_c.pa || plan->map_c.slot) FH_TRY(spgemm_numeric_map(R, plan->AP, C, plan->map_c)); else FH_TRY(spgemm_numeric(R, plan->AP, C));
   return 0;
 }
 
