@@ -261,7 +261,8 @@ __global__ __launch_bounds__(256) void k_csr_to_dense(const int* __restrict__ ro
 // register blocks, operands staged in LDS), and the pivot-column panel -C D^-1.  2 n^3 flops in n/NB steps of 5 launches
 // instead of 3 n launches of rank-1 updates.
 // ------------------------------------------------------------------------------------------------
-constexpr int GJ_NB = 32;
+constexpr int GJ_NB = 32;   // pivot block (64 was measured slower: the serial pivot-block inversion and the panels grow faster than the update shrinks)
+constexpr int GJ_KS = 32;   // K slice of the update staged in LDS at a time
 
 __global__ __launch_bounds__(256) void k_gjb_save_panel(const double* __restrict__ D, double* __restrict__ Cp, int n, int kb, int nb) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -295,13 +296,13 @@ __global__ __launch_bounds__(256) void k_gjb_pivot(const double* __restrict__ D,
 }
 
 // rows of the pivot block: A[kb+s, j] <- sum_t Dinv[s,t] * A_old[kb+t, j] (j outside the pivot columns), Dinv inside
-__global__ __launch_bounds__(256) void k_gjb_row_panel(double* __restrict__ D, const double* __restrict__ Dinv, const double* __restrict__ Cp,
-                                                       int n, int kb, int nb) {
+__global__ __launch_bounds__(64) void k_gjb_row_panel(double* __restrict__ D, const double* __restrict__ Dinv, const double* __restrict__ Cp,
+                                                      int n, int kb, int nb) {
   __shared__ double Ds[GJ_NB][GJ_NB + 1];
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < nb * nb; idx += 256) Ds[idx / nb][idx % nb] = Dinv[(idx / nb) * GJ_NB + idx % nb];
+  for (int idx = tid; idx < nb * nb; idx += 64) Ds[idx / nb][idx % nb] = Dinv[(idx / nb) * GJ_NB + idx % nb];
   __syncthreads();
-  const int j = blockIdx.x * 256 + tid;
+  const int j = blockIdx.x * 64 + tid;
   if (j >= n) return;
   if (j >= kb && j < kb + nb) {
     for (int s2 = 0; s2 < nb; s2++) D[(size_t)(kb + s2) * n + j] = Ds[s2][j - kb];
@@ -318,38 +319,41 @@ __global__ __launch_bounds__(256) void k_gjb_row_panel(double* __restrict__ D, c
 
 // all other rows, columns outside the pivot block: A[i,j] -= sum_t Cp[i,t] * R[t,j]   (R = the new row panel)
 __global__ __launch_bounds__(256) void k_gjb_update(double* __restrict__ D, const double* __restrict__ Cp, int n, int kb, int nb) {
-  __shared__ double Cs[64][GJ_NB + 1];
-  __shared__ double Rs[GJ_NB][64 + 2];
+  __shared__ double Cs[64][GJ_KS + 1];
+  __shared__ double Rs[GJ_KS][64 + 2];
   const int tid = threadIdx.x;
   const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
-  for (int idx = tid; idx < 64 * GJ_NB; idx += 256) {
-    const int r = idx / GJ_NB, t = idx % GJ_NB;
-    const int i = ti + r;
-    Cs[r][t] = (i < n && t < nb) ? Cp[(size_t)i * GJ_NB + t] : 0.0;
-  }
-  for (int idx = tid; idx < GJ_NB * 64; idx += 256) {
-    const int t = idx / 64, c = idx % 64;
-    const int j = tj + c;
-    Rs[t][c] = (j < n && t < nb) ? D[(size_t)(kb + t) * n + j] : 0.0;
-  }
-  __syncthreads();
   const int ty = tid >> 4, tx = tid & 15;
   double acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; a++)
 #pragma unroll
     for (int b2 = 0; b2 < 4; b2++) acc[a][b2] = 0.0;
+  for (int t0 = 0; t0 < nb; t0 += GJ_KS) {
+    for (int idx = tid; idx < 64 * GJ_KS; idx += 256) {
+      const int r = idx / GJ_KS, t = t0 + idx % GJ_KS;
+      const int i = ti + r;
+      Cs[r][idx % GJ_KS] = (i < n && t < nb) ? Cp[(size_t)i * GJ_NB + t] : 0.0;
+    }
+    for (int idx = tid; idx < GJ_KS * 64; idx += 256) {
+      const int t = t0 + idx / 64, c = idx % 64;
+      const int j = tj + c;
+      Rs[idx / 64][c] = (j < n && t < nb) ? D[(size_t)(kb + t) * n + j] : 0.0;
+    }
+    __syncthreads();
 #pragma unroll 8
-  for (int t = 0; t < GJ_NB; t++) {
-    double cv[4], rv[4];
+    for (int t = 0; t < GJ_KS; t++) {
+      double cv[4], rv[4];
 #pragma unroll
-    for (int a = 0; a < 4; a++) cv[a] = Cs[ty * 4 + a][t];
+      for (int a = 0; a < 4; a++) cv[a] = Cs[ty * 4 + a][t];
 #pragma unroll
-    for (int b2 = 0; b2 < 4; b2++) rv[b2] = Rs[t][tx * 4 + b2];
+      for (int b2 = 0; b2 < 4; b2++) rv[b2] = Rs[t][tx * 4 + b2];
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+      for (int a = 0; a < 4; a++)
 #pragma unroll
-      for (int b2 = 0; b2 < 4; b2++) acc[a][b2] += cv[a] * rv[b2];
+        for (int b2 = 0; b2 < 4; b2++) acc[a][b2] += cv[a] * rv[b2];
+    }
+    __syncthreads();
   }
 #pragma unroll
   for (int a = 0; a < 4; a++) {
@@ -635,7 +639,7 @@ static int coarse_factor(fh_mg_t mg) {
     const int nb = std::min(GJ_NB, n - kb);
     hipLaunchKernelGGL(k_gjb_save_panel, dim3(fh_div_up((int64_t)n * nb, 256)), dim3(256), 0, c->stream, mg->d_ainv, Cp, n, kb, nb);
     hipLaunchKernelGGL(k_gjb_pivot, dim3(1), dim3(256), 0, c->stream, mg->d_ainv, Dinv, n, kb, nb);
-    hipLaunchKernelGGL(k_gjb_row_panel, dim3(fh_div_up(n, 256)), dim3(256), 0, c->stream, mg->d_ainv, Dinv, Cp, n, kb, nb);
+    hipLaunchKernelGGL(k_gjb_row_panel, dim3(fh_div_up(n, 64)), dim3(64), 0, c->stream, mg->d_ainv, Dinv, Cp, n, kb, nb);
     hipLaunchKernelGGL(k_gjb_update, dim3(nt, nt), dim3(256), 0, c->stream, mg->d_ainv, Cp, n, kb, nb);
     hipLaunchKernelGGL(k_gjb_col_panel, dim3(fh_div_up((int64_t)n * nb, 256)), dim3(256), 0, c->stream, mg->d_ainv, Dinv, Cp, n, kb, nb);
   }
