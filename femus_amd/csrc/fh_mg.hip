@@ -210,22 +210,18 @@ __global__ __launch_bounds__(256) void k_patch_invert(const int* __restrict__ pp
   }
 }
 
-// one colour of the sweep; one workgroup of 64 per patch; MAXP = LDS capacity for the patch residual
+// one colour of the sweep; one workgroup of 64 per patch.  r = b - A x of the whole level is formed once per colour by the
+// fused SpMV (patches of a colour do not read each other's dofs, so it is the exact residual for every patch of the colour);
+// the patch gathers its rows of r, applies the dense inverse and updates x
 __global__ __launch_bounds__(64) void k_vanka_color(const int* __restrict__ order, int npat, const int* __restrict__ pptr, const int* __restrict__ pdofs,
-                                                    const int64_t* __restrict__ poff, const double* __restrict__ Minv, const int* __restrict__ rowptr,
-                                                    const int* __restrict__ col, const double* __restrict__ val, const double* __restrict__ b,
+                                                    const int64_t* __restrict__ poff, const double* __restrict__ Minv, const double* __restrict__ r,
                                                     double* x, double omega) {
   extern __shared__ double rp[];
   if ((int)blockIdx.x >= npat) return;
   const int p = order[blockIdx.x], lane = threadIdx.x;
   const int* d = pdofs + pptr[p];
   const int np = pptr[p + 1] - pptr[p];
-  for (int a = lane; a < np; a += 64) {
-    const int r = d[a];
-    double s = 0.0;
-    for (int k = rowptr[r]; k < rowptr[r + 1]; k++) s += val[k] * x[col[k]];
-    rp[a] = b[r] - s;
-  }
+  for (int a = lane; a < np; a += 64) rp[a] = r[d[a]];
   __syncthreads();
   const double* Mi = Minv + poff[p];     // transposed inverse: Mi[b * np + a] = inv[a][b]
   for (int a = lane; a < np; a += 64) {
@@ -605,8 +601,9 @@ static int vanka_sweeps(fh_mg_t mg, MgLevel& L, int nsweeps) {
     for (int k = 0; k < L.vanka_ncolors; k++) {
       const int np = L.vcolor_ptr[k + 1] - L.vcolor_ptr[k];
       if (np == 0) continue;
+      FH_TRY(fh_dev_spmv(L.A, L.x, L.r, 2, L.b, nullptr, 0.0));                       // r = b - A x
       hipLaunchKernelGGL(k_vanka_color, dim3(np), dim3(64), (size_t)L.max_patch * sizeof(double), c->stream, L.d_porder + L.vcolor_ptr[k], np,
-                         L.d_pptr, L.d_pdofs, L.d_poff, L.d_pinv, L.A->d_rowptr, L.A->d_col, L.A->d_val, L.b, L.x, L.omega);
+                         L.d_pptr, L.d_pdofs, L.d_poff, L.d_pinv, L.r, L.x, L.omega);
     }
   FH_CHECK_HIP(hipGetLastError());
   return 0;
