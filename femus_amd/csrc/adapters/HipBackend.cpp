@@ -37,7 +37,9 @@ std::unique_ptr<SparseMatrix> SparseMatrix::build(const SolverPackage solver_pac
   }
   return std::unique_ptr<SparseMatrix>(new HipMatrix());
 }
-std::unique_ptr<LinearEquationSolver> LinearEquationSolver::build(const unsigned& igrid, const SolverPackage solver_package) {
+std::unique_ptr<LinearEquationSolver> LinearEquationSolver::build(const unsigned& igrid, const SolverPackage solver_package,
+                                                                  const LinearEquationSolverType smoother_type) {
+  if (solver_package == HIP_SOLVERS && smoother_type == FEMuS_ASM) return std::unique_ptr<LinearEquationSolver>(new LinearEquationSolverHipAsm(igrid));
   if (solver_package != HIP_SOLVERS) {
     std::cout << "SolverPackage solver_package:  Something is wrong here" << std::endl;
     abort();
@@ -316,17 +318,26 @@ void LinearEquationSolverHip::MGSetLevel(LinearEquationSolver* LinSolver, const 
     _solver_type = RICHARDSON;
     _richardsonScaleFactor = 1.;
   }
-  if (_level != 0 && _preconditioner_type != JACOBI_PRECOND && _preconditioner_type != SOR_PRECOND) {
-    std::cout << "HIP backend: level smoother must be RICHARDSON + JACOBI_PRECOND or SOR_PRECOND" << std::endl;
+  const int smoother = smoother_id();
+  if (_level != 0 && smoother != FH_SMOOTH_VANKA && _preconditioner_type != JACOBI_PRECOND && _preconditioner_type != SOR_PRECOND) {
+    std::cout << "HIP backend: level smoother must be RICHARDSON + JACOBI_PRECOND or SOR_PRECOND (or the FEMuS_ASM solver)" << std::endl;
     abort();
   }
-  const int smoother = (_preconditioner_type == SOR_PRECOND) ? FH_SMOOTH_GS_COLOR : FH_SMOOTH_JACOBI;
+  if (_level != 0) attach_smoother_data(top->_mg, (int)_level);
   fh_mat_t P = PP ? static_cast<HipMatrix*>(PP)->handle() : nullptr;
   fh_mat_t R = (RR && RR != PP) ? static_cast<HipMatrix*>(RR)->handle() : nullptr;   // RR == PP means "use PP^T"
   hip_check(fh_mg_set_level(top->_mg, (int)_level, static_cast<HipMatrix*>(_KK)->handle(), _level ? P : nullptr, _level ? R : nullptr,
                             smoother, _richardsonScaleFactor, (int)npre, (int)npost),
             "MGSetLevel");
   top->_needs_setup = true;
+}
+int LinearEquationSolverHip::smoother_id() const { return (_preconditioner_type == SOR_PRECOND) ? FH_SMOOTH_GS_COLOR : FH_SMOOTH_JACOBI; }
+void LinearEquationSolverHipAsm::attach_smoother_data(fh_mg_t mg, int level) {
+  if (_blockPtr.size() < 2) {
+    std::cout << "HIP backend: FEMuS_ASM level " << level << " has no blocks (SetAsmBlocks)" << std::endl;
+    abort();
+  }
+  hip_check(fh_mg_set_level_patches(mg, level, (int)_blockPtr.size() - 1, _blockPtr.data(), _blockDofs.data()), "MGSetLevel: ASM blocks");
 }
 void LinearEquationSolverHip::MGSolve(const bool) {
   if (_needs_setup) {

@@ -129,6 +129,11 @@ class LinearEquationSolverHip : public LinearEquationSolver {
   int last_iterations() const { return _its; }
   double last_residual() const { return _rnorm; }
 
+ protected:
+  // smoother of this level as handed to fh_mg_set_level; the ASM variant overrides it
+  virtual int smoother_id() const;
+  virtual void attach_smoother_data(fh_mg_t, int) {}
+
  private:
   void SetPenalty();                 // LinearEquationSolverPetsc.cpp:428-436
   void ZerosBoundaryResiduals();     // :417-424
@@ -143,6 +148,25 @@ class LinearEquationSolverHip : public LinearEquationSolver {
   bool _needs_setup = true;
   int _its = 0;
   double _rnorm = 0.;
+};
+
+// Block Schwarz smoother (LinearEquationSolverPetscAsm, petsc_asm/LinearEquationSolverPetscAsm.cpp): the blocks
+// BuildASMIndex derives from the mesh (:91-276) are handed over as dof lists, e.g. from fh_mesh_vertex_patches
+class LinearEquationSolverHipAsm : public LinearEquationSolverHip {
+ public:
+  explicit LinearEquationSolverHipAsm(const unsigned& igrid) : LinearEquationSolverHip(igrid) {}
+  void SetElementBlockNumber(const unsigned& n) override { _elementBlockNumber = n; }
+  void SetNumberOfSchurVariables(const unsigned short& n) override { _NSchurVar = n; }
+  void SetAsmBlocks(const std::vector<int>& ptr, const std::vector<int>& dofs) { _blockPtr = ptr; _blockDofs = dofs; }
+
+ protected:
+  int smoother_id() const override { return FH_SMOOTH_VANKA; }
+  void attach_smoother_data(fh_mg_t mg, int level) override;
+
+ private:
+  unsigned _elementBlockNumber = 1;
+  unsigned short _NSchurVar = 1;
+  std::vector<int> _blockPtr, _blockDofs;
 };
 
 }  // namespace femus

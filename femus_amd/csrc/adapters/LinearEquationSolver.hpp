@@ -13,11 +13,17 @@ namespace femus {
 enum MgSmootherType { FULL = 0, MULTIPLICATIVE, ADDITIVE, KASKADE };                    // MgSmootherEnum.hpp
 enum SolverType { CG = 0, GMRES = 7, RICHARDSON = 12, PREONLY = 14 };                    // SolverTypeEnum (subset, own ids)
 enum PreconditionerType { JACOBI_PRECOND = 2, SOR_PRECOND = 4, MLU_PRECOND = 14 };       // PrecondtypeEnum (subset)
+enum LinearEquationSolverType { FEMuS_DEFAULT = 0, FEMuS_ASM = 1 };                      // LinearEquationSolverEnum.hpp (subset)
 
 class LinearEquationSolver {
  public:
   virtual ~LinearEquationSolver() {}
-  static std::unique_ptr<LinearEquationSolver> build(const unsigned& igrid, const SolverPackage solver_package = HIP_SOLVERS);   // .cpp:40-74
+  // LinearEquationSolver.cpp:40-74: FEMuS_ASM returns the block Schwarz variant (LinearEquationSolverPetscAsm in the reference)
+  static std::unique_ptr<LinearEquationSolver> build(const unsigned& igrid, const SolverPackage solver_package = HIP_SOLVERS,
+                                                     const LinearEquationSolverType smoother_type = FEMuS_DEFAULT);
+  // ASM / Vanka options (LinearEquationSolver.hpp:176-204): accepted by every solver, used by the FEMuS_ASM one
+  virtual void SetElementBlockNumber(const unsigned& block_elemet_number) {}
+  virtual void SetNumberOfSchurVariables(const unsigned short& NSchurVar) {}
   // the per-level algebra objects of LinearEquation (LinearEquation.hpp): raw pointers, owned by this object
   SparseMatrix* _KK = nullptr;
   NumericVector *_RES = nullptr, *_RESC = nullptr, *_EPS = nullptr, *_EPSC = nullptr;

@@ -1,0 +1,178 @@
+// Adapter test written the way applications/003_NavierStokes drives the library: NonLinearImplicitSystem::MGsolve with F_CYCLE
+// (NonLinearImplicitSystem.cpp:157-361) over the abstract SparseMatrix / NumericVector / LinearEquationSolver interface, the
+// FEMuS_ASM solver type for the level smoothers (SteadyNavierStokesParallel/main.cpp:166-167, 187-188), the cavity boundary
+// conditions of main.cpp:365-390, and the batched Taylor-Hood residual/Jacobian call in place of the adept callback.
+// Mesh, dof maps and element blocks (FEMuS-owned in a real build) come from the C-ABI mesh helpers.
+//   usage: navier_stokes_adapters n nlevels nu out.bin
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <map>
+#include <vector>
+#include "../../femus_amd/csrc/adapters/HipBackend.hpp"
+
+using namespace femus;
+
+static bool SetBoundaryConditionCavityFlow(const double* x, const char name, double& value, const int FaceName) {
+  bool test = 1;
+  value = 0.;
+  if (name == 'V') {
+    if (4 == FaceName) {          // the x = -0.5 wall of the generated box (group 1 of box10x10.neu)
+      if (x[1] < 0.5 && x[1] > -0.5) value = 1.;
+    }
+  }
+  if (name == 'P') {
+    test = 0;
+    if (x[0] < -.5 + 1.e-08 && x[1] < -.5 + 1.e-08) test = 1;
+  }
+  return test;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 5) return 2;
+  const int n = atoi(argv[1]), nlev = atoi(argv[2]);
+  const double nu = atof(argv[3]);
+  const int geom = 1, nvars = 3, fe[3] = {2, 2, 0};
+  const char names[3] = {'U', 'V', 'P'};
+  const double lo[3] = {-0.5, -0.5, 0}, hi[3] = {0.5, 0.5, 1};
+  std::vector<fh_mesh_t> msh(nlev);
+  hip_check(fh_mesh_box(n, n, 0, lo, hi, &msh[0]), "mesh");
+  for (int l = 1; l < nlev; l++) hip_check(fh_mesh_refine(msh[l - 1], &msh[l]), "refine");
+
+  std::vector<LinearEquationSolver*> LinSolver(nlev);
+  std::vector<SparseMatrix*> PP(nlev, nullptr), PPsol(nlev, nullptr);
+  std::vector<NumericVector*> Sol(nlev);
+  std::vector<fh_ns_assembler_t> as(nlev);
+  std::vector<std::vector<int>> offs(nlev, std::vector<int>(nvars + 1)), bdc(nlev);
+  for (int l = 0; l < nlev; l++) {
+    int dim, nel, nnode, nloc, own[3], lev, nd;
+    fh_mesh_info(msh[l], &dim, &nel, &nnode, &nloc, own, &lev);
+    hip_check(fh_system_elem_dofs(msh[l], nvars, fe, &nd, offs[l].data(), nullptr), "GetSystemDof");
+    std::vector<int> es((size_t)nel * nd), ed((size_t)nel * nloc), ff((size_t)nel * 4);
+    std::vector<double> xy((size_t)nnode * dim);
+    hip_check(fh_system_elem_dofs(msh[l], nvars, fe, &nd, offs[l].data(), es.data()), "GetSystemDof");
+    fh_mesh_get(msh[l], ed.data(), xy.data(), ff.data());
+    const int ndof = offs[l][nvars];
+    // FEMuS_ASM solver: element blocks around every pressure dof
+    LinearEquationSolverHipAsm* ls = static_cast<LinearEquationSolverHipAsm*>(LinearEquationSolver::build(l, HIP_SOLVERS, FEMuS_ASM).release());
+    LinSolver[l] = ls;
+    ls->SetNumberOfSchurVariables(1);
+    ls->SetElementBlockNumber(4);
+    {
+      int np = 0, tot = 0;
+      hip_check(fh_mesh_vertex_patches(msh[l], nvars, fe, &np, &tot, nullptr, nullptr), "BuildASMIndex");
+      std::vector<int> ptr(np + 1), dofs(tot);
+      hip_check(fh_mesh_vertex_patches(msh[l], nvars, fe, &np, &tot, ptr.data(), dofs.data()), "BuildASMIndex");
+      ls->SetAsmBlocks(ptr, dofs);
+    }
+    for (NumericVector** v : {&ls->_RES, &ls->_RESC, &ls->_EPS, &ls->_EPSC, &Sol[l]}) {
+      *v = NumericVector::build().release();
+      (*v)->init(ndof, ndof, false, SERIAL);
+    }
+    // sparsity from the element couplings of the stacked variables
+    std::vector<int> rp(ndof + 1), col;
+    hip_check(fh_pattern_from_elements(nel, nd, es.data(), ndof, rp.data(), nullptr), "pattern");
+    col.resize(rp[ndof]);
+    hip_check(fh_pattern_from_elements(nel, nd, es.data(), ndof, rp.data(), col.data()), "pattern");
+    fh_mat_t K;
+    hip_check(fh_mat_create_csr(hip_context(), ndof, ndof, rp.data(), col.data(), nullptr, &K), "KK");
+    HipMatrix* hk = new HipMatrix();
+    hk->adopt(K);
+    ls->_KK = hk;
+    hip_check(fh_ns_assembler_create(hip_context(), geom, 3, nel, nloc, ed.data(), nnode, own[0], xy.data(), K, &as[l]), "assembler");
+    // GenerateBdc: boundary faces in element order, nodes of the face, boundary function at the node
+    std::map<int, double> val;
+    for (int k = 0; k < nvars; k++) {
+      const int nck = fe[k] == 2 ? 9 : 4;
+      for (int iel = 0; iel < nel; iel++)
+        for (int f = 0; f < 4; f++) {
+          const int flag = ff[(size_t)iel * 4 + f];
+          if (flag >= -1) continue;
+          int nfn = 0, loc[9];
+          hip_check(fh_fe_face_nodes(geom, 2, f, &nfn, loc), "face nodes");
+          for (int q = 0; q < nfn; q++) {
+            if (loc[q] >= nck) continue;
+            const int node = ed[(size_t)iel * nloc + loc[q]];
+            double v;
+            if (SetBoundaryConditionCavityFlow(&xy[(size_t)node * dim], names[k], v, -(flag + 1))) val[offs[l][k] + node] = v;
+          }
+        }
+    }
+    std::vector<double> vals;
+    for (auto& kv : val) {
+      bdc[l].push_back(kv.first);
+      vals.push_back(kv.second);
+    }
+    ls->SetBdcIndex(bdc[l]);
+    Sol[l]->zero();
+    Sol[l]->insert_vector_blocked(vals, bdc[l]);
+    ls->SetSolverType(RICHARDSON);
+    ls->SetRichardsonScaleFactor(0.6);
+    if (l > 0) {
+      for (int copy = 0; copy < 2; copy++) {
+        fh_mat_t P;
+        hip_check(fh_build_system_prolongator(hip_context(), msh[l - 1], msh[l], nvars, fe, &P), "BuildProlongatorMatrix");
+        HipMatrix* hp = new HipMatrix();
+        hp->adopt(P);
+        (copy ? PPsol : PP)[l] = hp;
+      }
+      PP[l]->mat_zero_rows(bdc[l], 0.);                                                       // ZeroInterpolatorDirichletNodes
+      hip_check(fh_mat_zero_cols(static_cast<HipMatrix*>(PP[l])->handle(), (int)bdc[l - 1].size(), bdc[l - 1].data()), "zero cols");
+    }
+  }
+
+  // ---- NonLinearImplicitSystem::MGsolve, F_CYCLE --------------------------------------------------------------------------
+  std::vector<unsigned> vars = {0, 1, 2};
+  int total_newton = 0, max_linear = 0;
+  for (int ig = 0; ig < nlev; ig++) {
+    for (int it = 0; it < 30; it++) {
+      LinearEquationSolver* top = LinSolver[ig];
+      top->SetResZero();
+      hip_check(fh_assemble_navier_stokes(as[ig], static_cast<HipVector*>(Sol[ig])->handle(), nu, static_cast<HipMatrix*>(top->_KK)->handle(),
+                                          static_cast<HipVector*>(top->_RES)->handle()),
+                "assemble");
+      for (int i = ig; i > 0; i--) LinSolver[i - 1]->_KK->matrix_PtAP(*PP[i], *LinSolver[i]->_KK, it > 0);
+      top->MGInit(MULTIPLICATIVE, ig + 1, GMRES);
+      top->SetTolerances(1e-11, 1e-50, 1e50, 60, 30);
+      for (int i = 0; i <= ig; i++) LinSolver[i]->MGSetLevel(top, ig, vars, PP[i], PP[i], i ? 2 : 1, i ? 2 : 0);
+      top->SetEpsZero();
+      top->MGSolve(true);
+      *Sol[ig] += *top->_EPS;                                                                  // Solution::UpdateSol
+      max_linear = std::max(max_linear, static_cast<LinearEquationSolverHip*>(top)->last_iterations());
+      top->MGClear();
+      total_newton++;
+      // HasNonLinearConverged: max over variables of ||Eps_k|| / ||Sol_k||
+      std::vector<double> eps, sol;
+      top->_EPS->localize(eps);
+      Sol[ig]->localize(sol);
+      double worst = 0.;
+      for (int k = 0; k < nvars; k++) {
+        double ne = 0., ns = 0.;
+        for (int i = offs[ig][k]; i < offs[ig][k + 1]; i++) {
+          ne += eps[i] * eps[i];
+          ns += sol[i] * sol[i];
+        }
+        worst = std::max(worst, std::sqrt(ne) / (std::sqrt(ns) + 1.e-50));
+      }
+      std::cout << "     ********* Level Max " << ig + 1 << " Nonlinear iteration " << it + 1 << " Eps_l2norm/Sol_l2norm = " << worst << std::endl;
+      if (worst < 1.e-10) break;
+    }
+    if (ig + 1 < nlev) Sol[ig + 1]->matrix_mult(*Sol[ig], *PPsol[ig + 1]);                    // ProlongatorSol
+  }
+  std::vector<double> sol;
+  Sol[nlev - 1]->localize(sol);
+  std::cout << "newton steps = " << total_newton << "  max linear iterations = " << max_linear << std::endl;
+  FILE* f = fopen(argv[4], "wb");
+  fwrite(sol.data(), sizeof(double), sol.size(), f);
+  fclose(f);
+  for (int l = 0; l < nlev; l++) {
+    fh_ns_assembler_destroy(as[l]);
+    delete LinSolver[l];
+    delete PP[l];
+    delete PPsol[l];
+    delete Sol[l];
+    fh_mesh_destroy(msh[l]);
+  }
+  return 0;
+}

@@ -44,3 +44,22 @@ def test_adapter_member_units(tmp_path):
                            "-L" + lib, "-lfemus_hip_adapters", "-lfemus_hip", "-Wl,-rpath," + lib])
     out = subprocess.run([exe], text=True, capture_output=True)
     assert "ADAPTER UNITS OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_navier_stokes_application_over_the_adapters(tmp_path):
+    """003_NavierStokes-style driver in C++: F-cycle Newton through LinearEquationSolver::build(..., FEMuS_ASM) and the batched
+    Taylor-Hood callback; same discrete solution as the oracle's Newton with exact linear solves"""
+    from oracle import femus_oracle_ns as ns
+    lib = os.path.join(ROOT, "femus_amd", "lib")
+    exe = str(tmp_path / "navier_stokes_adapters")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "femus_amd", "csrc", "adapters")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "navier_stokes_adapters.cpp"), "-o", exe,
+                           "-L" + lib, "-lfemus_hip_adapters", "-lfemus_hip", "-Wl,-rpath," + lib])
+    out = str(tmp_path / "ns.bin")
+    log = subprocess.check_output([exe, "4", "3", "0.01", out], text=True)
+    assert "Nonlinear iteration" in log
+    _, lays, sols, hist = ns.solve_cavity(4, 4, 3, 0.01, (-0.5, -0.5, 0.0), (0.5, 0.5, 0.0), linear="direct")
+    assert "newton steps = %d" % len(hist) in log
+    sol = np.fromfile(out)
+    assert sol.size == sols[-1].size
+    assert np.linalg.norm(sol - sols[-1]) <= 1e-8 * np.linalg.norm(sols[-1])
