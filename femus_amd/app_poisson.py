@@ -144,7 +144,9 @@ class Poisson001:
         idx = np.array(sorted(val), dtype=np.int32)
         return idx, np.array([val[i] for i in idx])
 
-    def run(self, smoother=capi.SMOOTH_GS_COLOR, omega=1.0, log=None):
+    def run(self, smoother=capi.SMOOTH_GS_COLOR, omega=0.5, log=None):
+        """smoother / omega: the application sets RICHARDSON + SOR_PRECOND on the fine grids (main.cpp:240-242) and leaves the
+        Richardson scale at the solver default 0.5 (LinearEquationSolverPetsc.hpp:145)"""
         ctx = self.ctx
         meshes = [capi.Mesh.box(*self.box, self.lo, self.hi) if self.box is not None else capi.Mesh.read_gambit(self.mesh_file)]
         for _ in range(1, self.nlevels):
