@@ -235,7 +235,7 @@ class SerialProblem:
         self.pb.assemble()
 
     def set_penalty_top(self):
-        self.pb.A[-1].mat_zero_rows(self._bdc, 1.0)
+        self.pb.bdc_dev[-1].zero_rows(self.pb.A[-1], 1.0)
 
     def zero_boundary_residuals(self):
         self.pb.zero_boundary_residuals()

@@ -141,6 +141,10 @@ def _declare(L):
     sig("fh_expr_program", c_void_p, P(c_int), P(c_int), c_void_p, c_void_p)
     sig("fh_expr_destroy", c_void_p)
     sig("fh_assemble_poisson_expr", c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p)
+    sig("fh_index_create", c_void_p, c_int, c_void_p, P(c_void_p))
+    sig("fh_index_destroy", c_void_p)
+    sig("fh_mat_zero_rows_index", c_void_p, c_void_p, c_double)
+    sig("fh_vec_set_index", c_void_p, c_void_p, c_double)
     sig("fh_mg_create", c_void_p, c_int, P(c_void_p))
     sig("fh_mg_set_level", c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_int)
     sig("fh_mg_setup", c_void_p)

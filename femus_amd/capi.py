@@ -572,6 +572,28 @@ class Assembler:
         return {"ncolors": nco.value, "algorithmic_bytes": by.value, "flops": fl.value}
 
 
+class Index:
+    """device-resident index list (the _bdcIndex of a level): SetPenalty / ZerosBoundaryResiduals without host traffic"""
+
+    def __init__(self, ctx, idx):
+        self.ctx, self.L = ctx, ctx.L
+        idx = _i32(idx)
+        self.n = idx.size
+        self.h = ctypes.c_void_p()
+        _chk(self.L.fh_index_create(ctx.h, idx.size, _p(idx), ctypes.byref(self.h)))
+
+    def zero_rows(self, A, diag):
+        _chk(self.L.fh_mat_zero_rows_index(A.h, self.h, float(diag)))
+
+    def set(self, v, value):
+        _chk(self.L.fh_vec_set_index(v.h, self.h, float(value)))
+
+    def destroy(self):
+        if self.h:
+            self.L.fh_index_destroy(self.h)
+            self.h = None
+
+
 class Expr:
     """femus::ParsedFunction: a run-time expression compiled to a postfix program (host and device evaluation)"""
 

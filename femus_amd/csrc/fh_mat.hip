@@ -248,6 +248,62 @@ extern "C" int fh_mat_zero_rows(fh_mat_t A, int n, const int* rows, double diag)
   return 0;
 }
 
+// ---- device-resident index list: the result of BuildBdcIndex (LinearEquationSolverPetsc.cpp:53-90) is built once per level
+// (_bdcIndexIsInitialized) and reused by SetPenalty / ZerosBoundaryResiduals at every assembly; kept on the device, these two
+// calls need no host traffic and no synchronisation
+struct fh_index_s {
+  fh_ctx_t ctx = nullptr;
+  int n = 0, max_index = -1;
+  int* d = nullptr;
+};
+
+extern "C" int fh_index_create(fh_ctx_t ctx, int n, const int* idx, fh_index_t* out) {
+  FH_REQUIRE(ctx && out && n >= 0 && (n == 0 || idx), "fh_index_create: bad arguments");
+  fh_index_s* x = new fh_index_s();
+  x->ctx = ctx;
+  x->n = n;
+  for (int i = 0; i < n; i++) {
+    FH_REQUIRE(idx[i] >= 0, "fh_index_create: negative index %d", idx[i]);
+    x->max_index = std::max(x->max_index, idx[i]);
+  }
+  FH_CHECK_HIP(hipMalloc(&x->d, std::max(n, 1) * sizeof(int)));
+  if (n) FH_CHECK_HIP(hipMemcpy(x->d, idx, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+  *out = x;
+  return 0;
+}
+
+extern "C" int fh_index_destroy(fh_index_t x) {
+  if (!x) return 0;
+  hipStreamSynchronize(x->ctx->stream);
+  hipFree(x->d);
+  delete x;
+  return 0;
+}
+
+extern "C" int fh_mat_zero_rows_index(fh_mat_t A, fh_index_t rows, double diag) {
+  FH_REQUIRE(A && rows, "fh_mat_zero_rows_index: null argument");
+  FH_REQUIRE(rows->max_index < A->m, "fh_mat_zero_rows_index: row %d out of range", rows->max_index);
+  if (rows->n == 0) return 0;
+  hipLaunchKernelGGL(k_zero_rows, dim3(rows->n), dim3(64), 0, A->ctx->stream, A->d_rowptr, A->d_col, A->d_val, rows->d, rows->n, diag);
+  FH_CHECK_HIP(hipGetLastError());
+  A->at_valid = false;
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void k_set_index(double* __restrict__ v, const int* __restrict__ idx, int n, double value) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) v[idx[i]] = value;
+}
+
+extern "C" int fh_vec_set_index(fh_vec_t v, fh_index_t idx, double value) {
+  FH_REQUIRE(v && idx, "fh_vec_set_index: null argument");
+  FH_REQUIRE(idx->max_index < v->n_local, "fh_vec_set_index: index %d is not an owned entry", idx->max_index);
+  if (idx->n == 0) return 0;
+  hipLaunchKernelGGL(k_set_index, dim3(fh_div_up(idx->n, 256)), dim3(256), 0, v->ctx->stream, v->d, idx->d, idx->n, value);
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int fh_mat_zero_cols(fh_mat_t A, int n, const int* cols) {
   if (n <= 0 || A->nnz == 0) return 0;
   fh_ctx_t c = A->ctx;

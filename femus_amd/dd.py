@@ -485,7 +485,7 @@ class DistributedPoisson:
         mk = lambda: ctx.vector(nloc, top.n_owned, 0, ghost_ids)
         self.RES, self.EPSC, self.SOL = mk(), mk(), mk()
         self.bdc_top = H.bdc_owned[-1].astype(np.int32)
-        self._zeros = np.zeros(self.bdc_top.size)
+        self.bdc_dev = capi.Index(ctx, self.bdc_top)       # BuildBdcIndex once, device-resident
         self.mg = capi.Multigrid(ctx, nlevels + 1)
         self.mg.set_level(0, self.A_rep, None, None, 0, omega, 1, 0)
         self.mg.set_level(1, self.A[0], self.P_rep, self.R_rep, 0, omega, npre, npost)
@@ -503,11 +503,10 @@ class DistributedPoisson:
         self.asm.assemble(self.A[-1], self.RES, None, 0, (1.0,))
 
     def set_penalty_top(self):
-        self.A[-1].mat_zero_rows(self.bdc_top, 1.0)
+        self.bdc_dev.zero_rows(self.A[-1], 1.0)
 
     def zero_boundary_residuals(self):
-        if self.bdc_top.size:
-            self.RES.set(self.bdc_top, self._zeros)
+        self.bdc_dev.set(self.RES, 0.0)
 
     def vcycle(self):
         self.mg.vcycle(self.RES, self.EPSC)

@@ -86,7 +86,7 @@ class PoissonMG:
         self.RES, self.EPS, self.EPSC, self.RESC = ctx.vector(n), ctx.vector(n), ctx.vector(n), ctx.vector(n)
         self.SOL = ctx.vector(n)
         self.sol_lvl = [None] * self.nlevels
-        self._zeros_top = np.zeros(self.bdc[top].size)
+        self.bdc_dev = [capi.Index(ctx, b) for b in self.bdc]      # BuildBdcIndex, once (device-resident)
         return self
 
     # ---- assembly of the level to assemble (the finest) --------------------------------------------------------
@@ -122,8 +122,8 @@ class PoissonMG:
         else:
             for l in range(top):
                 self.assemble(l)
-        for l in range(self.nlevels):              # MGSetLevel: BuildBdcIndex + SetPenalty
-            self.A[l].mat_zero_rows(self.bdc[l], 1.0)
+        for l in range(self.nlevels):              # MGSetLevel: SetPenalty
+            self.bdc_dev[l].zero_rows(self.A[l], 1.0)
         if self.mg is None:
             self.mg = capi.Multigrid(ctx, self.nlevels)
         for l in range(self.nlevels):
@@ -150,9 +150,7 @@ class PoissonMG:
         self.asm, self.A, self.P, self.KK, self.Pamr = [], [], [], [], []
 
     def zero_boundary_residuals(self):
-        top = self.nlevels - 1
-        if self.bdc[top].size:
-            self.RES.set(self.bdc[top], self._zeros_top)
+        self.bdc_dev[-1].set(self.RES, 0.0)
 
     # ---- one preconditioner application / the MG solve ----------------------------------------------------------
     def vcycle(self, b=None, x=None):
@@ -181,7 +179,7 @@ class PoissonMG:
         for a in self.asm:
             if a is not None:
                 a.destroy()
-        for m in self.A + self.P + self.KK + self.Pamr:
+        for m in self.A + self.P + self.KK + self.Pamr + self.bdc_dev:
             if m is not None:
                 m.destroy()
         for m in self.meshes:

@@ -98,6 +98,14 @@ int fh_mat_get_row(fh_mat_t A, int row, int* ncols, int* cols, double* vals);   
  * also SetPenalty (03_solvers/LinearEquationSolverPetsc.cpp:428-436).  diag==0: plain zero rows. */
 int fh_mat_zero_rows(fh_mat_t A, int n, const int* rows, double diag);
 int fh_mat_zero_cols(fh_mat_t A, int n, const int* cols);        /* get_transpose+mat_zero_rows+get_transpose, LinearImplicitSystem.cpp:1101-1106 */
+/* the Dirichlet list of a level kept on the device: BuildBdcIndex builds it once (_bdcIndexIsInitialized,
+ * LinearEquationSolverPetsc.cpp:53-90) and SetPenalty (:428-436) / ZerosBoundaryResiduals (:417-424) reuse it at every assembly;
+ * these two calls are asynchronous (no host traffic, no synchronisation) */
+typedef struct fh_index_s* fh_index_t;
+int fh_index_create(fh_ctx_t ctx, int n, const int* idx, fh_index_t* index);
+int fh_index_destroy(fh_index_t index);
+int fh_mat_zero_rows_index(fh_mat_t A, fh_index_t rows, double diag);
+int fh_vec_set_index(fh_vec_t v, fh_index_t idx, double value);   /* v[idx] = value (owned entries) */
 int fh_mat_get_diagonal(fh_mat_t A, fh_vec_t d);                 /* get_diagonal :224 */
 int fh_mat_transpose(fh_mat_t A, fh_mat_t* At);                  /* get_transpose :227 (PetscMatrix.cpp:1031-1070) */
 /* matrix_PtAP(P, A, reuse) :183 (PetscMatrix.cpp:733-751): C = P^T A P.  *C==NULL: symbolic+numeric; else numeric reuse */
