@@ -50,16 +50,23 @@ def main():
 
     # setup-time rendezvous (plans, ncclUniqueId, timing maxima) over plain TCP; the data path of a cycle is RCCL
     comm = dd.SocketComm(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")))
-    ctx = femus_amd.Context(local_rank)
+    device = local_rank
+    if os.environ.get("FEMUS_BENCH_SHARE_GPU") == "1":       # several ranks on one device (development box; host transport only)
+        import torch
+        device = local_rank % max(torch.cuda.device_count(), 1)
+    ctx = femus_amd.Context(device)
     t0 = time.time()
     parallelism = "1 rank per GPU"
     dist_err = None
     pb = None
     if (world > 1 and os.environ.get("FEMUS_BENCH_DD", "1") != "0") or os.environ.get("FEMUS_BENCH_FORCE_DD") == "1":
         try:
-            pb = dd.DistributedPoisson(ctx, comm, world, rank, nb=args.coarse, nlevels=args.levels, omega=2. / 3., npre=2, npost=2)
+            transport = os.environ.get("FEMUS_BENCH_TRANSPORT", "rccl")     # "host": host-staged exchange (debugging, shared GPUs)
+            pb = dd.DistributedPoisson(ctx, comm, world, rank, nb=args.coarse, nlevels=args.levels, omega=2. / 3., npre=2, npost=2,
+                                       transport=transport)
             parallelism = ("mesh domain decomposition, box split %dx%dx%d (METIS unavailable), one partition per GPU, ghost DOFs "
-                           "exchanged by RCCL neighbour send/recv (fh_halo_update), replicated coarse level" % dd.GRIDS[world])
+                           "exchanged by %s (fh_halo_update), replicated coarse level"
+                           % (dd.GRIDS[world] + ("RCCL neighbour send/recv" if transport == "rccl" else "the host-staged transport",)))
         except Exception as e:   # report, never hide: the line says what actually ran
             dist_err = "%s: %s" % (type(e).__name__, str(e)[:200])
             pb = None

@@ -141,6 +141,7 @@ def _declare(L):
     sig("fh_expr_program", c_void_p, P(c_int), P(c_int), c_void_p, c_void_p)
     sig("fh_expr_destroy", c_void_p)
     sig("fh_assemble_poisson_expr", c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p)
+    sig("fh_halo_create_host", c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, P(c_void_p))
     sig("fh_index_create", c_void_p, c_int, c_void_p, P(c_void_p))
     sig("fh_index_destroy", c_void_p)
     sig("fh_mat_zero_rows_index", c_void_p, c_void_p, c_double)

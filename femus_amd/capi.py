@@ -729,6 +729,55 @@ class Halo:
             uid = ctypes.create_string_buffer(bytes(unique_id), 128)
             _chk(self.L.fh_halo_create(ctx.h, int(rank), int(nranks), uid, _p(sc), _p(si), _p(rc), ctypes.byref(self.h)))
 
+    @classmethod
+    def host(cls, ctx, rank, nranks, comm, send_counts, send_idx, recv_counts, parent=None):
+        """same exchange plan over a host-staged transport: `comm` provides alltoallv(list of arrays, dtype) and
+        allreduce_sum(array) (SocketComm / TorchComm of femus_amd.dd, or an MPI wrapper)"""
+        self = cls.__new__(cls)
+        self.ctx, self.L = ctx, ctx.L
+        sc, si, rc = _i32(send_counts), _i32(send_idx), _i32(recv_counts)
+        self.h = ctypes.c_void_p()
+        if parent is not None:
+            _chk(self.L.fh_halo_create_shared(parent.h, _p(sc), _p(si), _p(rc), ctypes.byref(self.h)))
+            return self
+        EX = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int),
+                              ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int))
+        AR = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int)
+
+        def exchange(user, send, scnt, recv, rcnt):
+            try:
+                parts, off = [], 0
+                for r in range(nranks):
+                    parts.append(np.ctypeslib.as_array(send, shape=(off + scnt[r],))[off:off + scnt[r]].copy() if scnt[r] else np.zeros(0))
+                    off += scnt[r]
+                got = comm.alltoallv(parts, np.float64)
+                off = 0
+                for r in range(nranks):
+                    if rcnt[r]:
+                        assert got[r].size == rcnt[r]
+                        np.ctypeslib.as_array(recv, shape=(off + rcnt[r],))[off:off + rcnt[r]] = got[r]
+                    off += rcnt[r]
+                return 0
+            except Exception:       # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def allreduce(user, buf, n):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(n,))
+                a[:] = comm.allreduce_sum(a.copy())
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._callbacks = (EX(exchange), AR(allreduce))           # keep the trampolines alive as long as the plan
+        _chk(self.L.fh_halo_create_host(ctx.h, int(rank), int(nranks), self._callbacks[0], self._callbacks[1], None, _p(sc), _p(si), _p(rc),
+                                        ctypes.byref(self.h)))
+        return self
+
     @staticmethod
     def unique_id():
         buf = ctypes.create_string_buffer(128)

@@ -21,6 +21,11 @@ struct fh_halo_s {
   double* d_sendbuf = nullptr;
   double* d_scalars = nullptr;
   hipEvent_t ev_packed = nullptr, ev_done = nullptr;
+  // host-staged transport (fh_halo_create_host): the exchange itself is the caller's function (MPI_Neighbor_alltoallv, sockets ...)
+  fh_exchange_fn exchange = nullptr;
+  fh_allreduce_fn allreduce = nullptr;
+  void* user = nullptr;
+  double *h_send = nullptr, *h_recv = nullptr;   // pinned
 };
 
 #define FH_CHECK_NCCL(expr)                                                                     \
@@ -45,21 +50,45 @@ extern "C" int fh_halo_unique_id(char id128[128]) {
 }
 
 static int halo_create(fh_ctx_t ctx, int rank, int nranks, const char* id128, ncclComm_t shared, const int* send_counts, const int* send_idx,
-                       const int* recv_counts, fh_halo_t* out);
+                       const int* recv_counts, fh_halo_t* out, int plan_ranks = 0);
 
 extern "C" int fh_halo_create(fh_ctx_t ctx, int rank, int nranks, const char id128[128], const int* send_counts, const int* send_idx,
                               const int* recv_counts, fh_halo_t* out) {
   return halo_create(ctx, rank, nranks, id128, nullptr, send_counts, send_idx, recv_counts, out);
 }
 
+static int host_buffers(fh_halo_t h) {
+  FH_CHECK_HIP(hipHostMalloc((void**)&h->h_send, std::max<size_t>(std::max(h->nsend, 256), 1) * sizeof(double), hipHostMallocDefault));
+  FH_CHECK_HIP(hipHostMalloc((void**)&h->h_recv, std::max<size_t>(h->nrecv, 1) * sizeof(double), hipHostMallocDefault));
+  return 0;
+}
+
 extern "C" int fh_halo_create_shared(fh_halo_t parent, const int* send_counts, const int* send_idx, const int* recv_counts, fh_halo_t* out) {
   FH_REQUIRE(parent, "fh_halo_create_shared: null parent");
+  if (parent->exchange) {
+    FH_TRY(halo_create(parent->ctx, parent->rank, 1, nullptr, nullptr, send_counts, send_idx, recv_counts, out, parent->nranks));
+    (*out)->exchange = parent->exchange;
+    (*out)->allreduce = parent->allreduce;
+    (*out)->user = parent->user;
+    return host_buffers(*out);
+  }
   return halo_create(parent->ctx, parent->rank, parent->nranks, nullptr, parent->comm, send_counts, send_idx, recv_counts, out);
 }
 
-static int halo_create(fh_ctx_t ctx, int rank, int nranks, const char* id128, ncclComm_t shared, const int* send_counts, const int* send_idx,
-                       const int* recv_counts, fh_halo_t* out) {
+extern "C" int fh_halo_create_host(fh_ctx_t ctx, int rank, int nranks, fh_exchange_fn exchange, fh_allreduce_fn allreduce, void* user,
+                                   const int* send_counts, const int* send_idx, const int* recv_counts, fh_halo_t* out) {
+  FH_REQUIRE(exchange && allreduce, "fh_halo_create_host: null transport function");
+  FH_TRY(halo_create(ctx, rank, 1, nullptr, nullptr, send_counts, send_idx, recv_counts, out, nranks));   // no RCCL communicator
+  (*out)->exchange = exchange;
+  (*out)->allreduce = allreduce;
+  (*out)->user = user;
+  return host_buffers(*out);
+}
+
+static int halo_create(fh_ctx_t ctx, int rank, int comm_ranks, const char* id128, ncclComm_t shared, const int* send_counts, const int* send_idx,
+                       const int* recv_counts, fh_halo_t* out, int plan_ranks) {
   FH_REQUIRE(ctx && out && send_counts && recv_counts, "fh_halo_create: null argument");
+  const int nranks = plan_ranks > 0 ? plan_ranks : comm_ranks;     // host transport: the plan spans plan_ranks, no RCCL communicator
   FH_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "fh_halo_create: bad rank %d of %d", rank, nranks);
   fh_halo_t h = new fh_halo_s();
   h->ctx = ctx;
@@ -83,7 +112,7 @@ static int halo_create(fh_ctx_t ctx, int rank, int nranks, const char* id128, nc
   if (h->nsend) FH_CHECK_HIP(hipMemcpy(h->d_send_idx, send_idx, h->nsend * sizeof(int), hipMemcpyHostToDevice));
   FH_CHECK_HIP(hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
   FH_CHECK_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
-  if (nranks > 1) {
+  if (comm_ranks > 1) {
     if (shared) {
       h->comm = shared;
     } else {
@@ -112,15 +141,27 @@ extern "C" int fh_halo_update(fh_halo_t h, fh_vec_t v) {
   return fh_halo_update_ptr(h, v->d, v->n_local);
 }
 
+static int host_allreduce(fh_halo_t h, double* d, int n) {
+  std::vector<double> buf(n);
+  FH_CHECK_HIP(hipMemcpyAsync(buf.data(), d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->ctx->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(h->ctx->stream));
+  FH_REQUIRE(h->allreduce(h->user, buf.data(), n) == 0, "host transport: the all-reduce function failed");
+  FH_CHECK_HIP(hipMemcpyAsync(d, buf.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->ctx->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(h->ctx->stream));
+  return 0;
+}
+
 extern "C" int fh_halo_allreduce_vec(fh_halo_t h, fh_vec_t v) {
   FH_REQUIRE(h && v, "fh_halo_allreduce_vec: null argument");
   if (h->nranks == 1 || v->n_local == 0) return 0;
+  if (h->allreduce) return host_allreduce(h, v->d, v->n_local);
   FH_CHECK_NCCL(ncclAllReduce(v->d, v->d, v->n_local, ncclDouble, ncclSum, h->comm, h->ctx->stream));
   return 0;
 }
 
 int fh_halo_allreduce_ptr(fh_halo_t h, double* d, int n) {
   if (h->nranks == 1 || n == 0) return 0;
+  if (h->allreduce) return host_allreduce(h, d, n);
   FH_CHECK_NCCL(ncclAllReduce(d, d, n, ncclDouble, ncclSum, h->comm, h->ctx->stream));
   return 0;
 }
@@ -128,6 +169,19 @@ int fh_halo_allreduce_ptr(fh_halo_t h, double* d, int n) {
 int fh_halo_update_ptr(fh_halo_t h, double* vd, int n_owned) {
   if (h->nranks == 1) return 0;
   fh_ctx_t c = h->ctx;
+  if (h->exchange) {   // host-staged: pack -> pinned host -> caller's exchange -> ghost tail
+    if (h->nsend) {
+      int nb = std::max(1, std::min(fh_div_up(h->nsend, 256), c->num_cu * 4));
+      hipLaunchKernelGGL(k_pack, dim3(nb), dim3(256), 0, c->stream, vd, h->d_send_idx, h->d_sendbuf, h->nsend);
+      FH_CHECK_HIP(hipGetLastError());
+      FH_CHECK_HIP(hipMemcpyAsync(h->h_send, h->d_sendbuf, (size_t)h->nsend * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+    FH_REQUIRE(h->exchange(h->user, h->h_send, h->send_counts.data(), h->h_recv, h->recv_counts.data()) == 0,
+               "host transport: the exchange function failed");
+    if (h->nrecv) FH_CHECK_HIP(hipMemcpyAsync(vd + n_owned, h->h_recv, (size_t)h->nrecv * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return 0;
+  }
   struct { double* d; int n_local; } vv = {vd, n_owned};
   auto* v = &vv;
   if (h->nsend) {
@@ -152,6 +206,10 @@ int fh_halo_update_ptr(fh_halo_t h, double* vd, int n_owned) {
 extern "C" int fh_halo_allreduce_sum(fh_halo_t h, double* vals, int n) {
   FH_REQUIRE(h && vals && n >= 0 && n <= 256, "fh_halo_allreduce_sum: bad arguments (n <= 256)");
   if (h->nranks == 1 || n == 0) return 0;
+  if (h->allreduce) {
+    FH_REQUIRE(h->allreduce(h->user, vals, n) == 0, "host transport: the all-reduce function failed");
+    return 0;
+  }
   fh_ctx_t c = h->ctx;
   FH_CHECK_HIP(hipMemcpyAsync(h->d_scalars, vals, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
   FH_CHECK_NCCL(ncclAllReduce(h->d_scalars, h->d_scalars, n, ncclDouble, ncclSum, h->comm, c->stream));
@@ -168,6 +226,8 @@ extern "C" int fh_halo_destroy(fh_halo_t h) {
   hipFree(h->d_send_idx);
   hipFree(h->d_sendbuf);
   hipFree(h->d_scalars);
+  if (h->h_send) hipHostFree(h->h_send);
+  if (h->h_recv) hipHostFree(h->h_recv);
   hipEventDestroy(h->ev_packed);
   hipEventDestroy(h->ev_done);
   delete h;

@@ -433,7 +433,8 @@ class DistributedPoisson:
     global (px*nb, py*nb, pz*nb) box; operators hold owned rows over [owned | ghost] columns; ghosts are refreshed by
     fh_halo_update inside the cycle; one replicated level below replaces the single-GPU exact coarse solve."""
 
-    def __init__(self, ctx, comm, nranks, rank, nb=8, nlevels=4, omega=2. / 3., npre=2, npost=2, fe="biquadratic", order="seventh"):
+    def __init__(self, ctx, comm, nranks, rank, nb=8, nlevels=4, omega=2. / 3., npre=2, npost=2, fe="biquadratic", order="seventh",
+                 transport="rccl"):
         from .poisson import PoissonMG
         self.ctx, self.comm = ctx, comm
         self.part = BoxPartition(nranks, rank)
@@ -470,11 +471,16 @@ class DistributedPoisson:
         xy_new[top.newid[np.concatenate([top.owned, top.ghost])]] = xy[np.concatenate([top.owned, top.ghost])]
         full.destroy_device_objects()
         # 5. upload the restricted operators, halos, cycle
-        uid = comm.bcast_obj(capi.Halo.unique_id() if rank == 0 else None)
         self.halos = []
-        for pl in H.plans:     # one RCCL communicator, one exchange plan per level
-            self.halos.append(capi.Halo(ctx, rank, nranks, uid, pl.send_counts, pl.send_idx, pl.recv_counts,
-                                        parent=self.halos[0] if self.halos else None))
+        if transport == "host":   # host-staged exchange through `comm` (ranks sharing a GPU, launchers without RCCL peers)
+            for pl in H.plans:
+                self.halos.append(capi.Halo.host(ctx, rank, nranks, comm, pl.send_counts, pl.send_idx, pl.recv_counts,
+                                                 parent=self.halos[0] if self.halos else None))
+        else:
+            uid = comm.bcast_obj(capi.Halo.unique_id() if rank == 0 else None)
+            for pl in H.plans:     # one RCCL communicator, one exchange plan per level
+                self.halos.append(capi.Halo(ctx, rank, nranks, uid, pl.send_counts, pl.send_idx, pl.recv_counts,
+                                            parent=self.halos[0] if self.halos else None))
         self.A = [ctx.matrix_scipy(a) for a in H.A]
         self.P = [None] + [ctx.matrix_scipy(p) for p in H.P[1:]]
         self.R = [None] + [ctx.matrix_scipy(r) for r in H.R[1:]]

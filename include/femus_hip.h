@@ -283,6 +283,15 @@ int fh_halo_create(fh_ctx_t ctx, int rank, int nranks, const char id128[128],
                    const int* recv_counts /* [nranks] */, fh_halo_t* halo);
 /* further exchange plans (other multigrid levels) on the communicator of an existing one (a ncclUniqueId makes ONE communicator) */
 int fh_halo_create_shared(fh_halo_t parent, const int* send_counts, const int* send_idx, const int* recv_counts, fh_halo_t* halo);
+/* host-staged transport for the same plans (ranks without an RCCL peer-to-peer path, e.g. several ranks on one GPU, or a
+ * launcher that already has MPI): the pack kernel, the ghost layout and every caller stay the same, the bytes travel through
+ * pinned host buffers and the two functions given here (e.g. MPI_Neighbor_alltoallv and MPI_Allreduce).  exchange(user, send,
+ * send_counts[nranks], recv, recv_counts[nranks]) moves doubles grouped by destination / source rank; allreduce(user, buf, n)
+ * sums in place.  Both return 0 on success.  fh_halo_create_shared on such a plan inherits the functions. */
+typedef int (*fh_exchange_fn)(void* user, const double* send, const int* send_counts, double* recv, const int* recv_counts);
+typedef int (*fh_allreduce_fn)(void* user, double* buf, int n);
+int fh_halo_create_host(fh_ctx_t ctx, int rank, int nranks, fh_exchange_fn exchange, fh_allreduce_fn allreduce, void* user,
+                        const int* send_counts, const int* send_idx, const int* recv_counts, fh_halo_t* halo);
 int fh_halo_update(fh_halo_t halo, fh_vec_t v);                  /* owner -> ghost copies, async on comm stream + join */
 int fh_halo_sizes(fh_halo_t halo, int* nsend, int* nrecv);
 int fh_halo_allreduce_vec(fh_halo_t halo, fh_vec_t v);            /* in-place sum over ranks of the owned part (device) */

@@ -36,3 +36,64 @@ def pb_raw_values(ctx):
     pb = PoissonMG(ctx, 2, 2, 2, 3).init()
     pb.assemble()
     return pb.A[-1].values()
+
+
+# ---- several ranks on ONE GPU: the whole distributed device path (ghost-element assembly, halo updates inside the cycle,
+# replicated level all-reduce, distributed dot products of the Krylov solver) with the host-staged transport in place of RCCL,
+# which cannot connect two ranks that share a device.  Everything except the ncclSend/ncclRecv calls themselves is exercised.
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_worker(rank, world, port, nb, nlevels, out):
+    import femus_amd as fa
+    from femus_amd import dd as ddm
+    comm = ddm.SocketComm(rank, world, "127.0.0.1", port)
+    ctx = fa.Context(0)
+    dp = ddm.DistributedPoisson(ctx, comm, world, rank, nb=nb, nlevels=nlevels, transport="host")
+    dp.assemble()
+    dp.set_penalty_top()
+    dp.zero_boundary_residuals()
+    b = dp.RES.to_numpy()[:dp.n_owned]
+    dp.vcycle()
+    x = dp.EPSC.to_numpy()[:dp.n_owned].copy()
+    its, rn = dp.solve(outer="gmres", rtol=1e-12, maxit=60)
+    xs = dp.EPSC.to_numpy()[:dp.n_owned].copy()
+    top = dp.H.plans[-1]
+    np.savez(out % rank, gid=top.gid[top.owned], b=b, x=x, xs=xs, its=its, n_ghost=top.n_ghost)
+    comm.barrier()
+    comm.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_device_path_with_host_transport(tmp_path, world):
+    import scipy.sparse.linalg as spla
+    import torch.multiprocessing as mp
+    from oracle import femus_oracle as fo
+    nb, nlevels = 2, 2
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_rank_worker, args=(world, _free_port(), nb, nlevels, out), nprocs=world, join=True)
+    part = dd.BoxPartition(world, 0)
+    p = part.p
+    ONE = lambda xg: np.ones(xg.shape[:2])
+    H = fo.build_poisson_hierarchy(p[0] * nb // 2, p[1] * nb // 2, p[2] * nb // 2, nlevels + 1, "biquadratic", ONE,
+                                   hi=tuple(float(v) for v in p))
+    ref = fo.vcycle(H, nlevels, H.b)
+    xd = spla.spsolve(H.A[-1].tocsc(), H.b)
+    gid_ser, _ = dd.node_keys(H.meshes[-1].coords, nlevels - 1, nb, part)
+    srt = np.argsort(gid_ser)
+    seen = 0
+    for r in range(world):
+        d = np.load(out % r)
+        pos = srt[np.searchsorted(gid_ser[srt], d["gid"])]
+        assert np.array_equal(gid_ser[pos], d["gid"]) and d["n_ghost"] > 0
+        assert np.linalg.norm(d["b"] - H.b[pos]) <= 1e-12 * np.linalg.norm(H.b)          # distributed assembly
+        assert np.linalg.norm(d["x"] - ref[pos]) <= 1e-10 * np.linalg.norm(ref)          # distributed V-cycle
+        assert np.linalg.norm(d["xs"] - xd[pos]) <= 1e-9 * np.linalg.norm(xd)            # distributed GMRES solve
+        seen += d["gid"].size
+    assert seen == xd.size
