@@ -1050,7 +1050,10 @@ extern "C" int fh_spmv(fh_mat_t A, fh_vec_t x, fh_vec_t y, int mode, fh_vec_t b,
   FH_REQUIRE(x->n_local + x->nghost >= A->n, "fh_spmv: x has %d entries, matrix has %d columns", x->n_local + x->nghost, A->n);
   FH_REQUIRE(y->n_local >= A->m, "fh_spmv: y has %d entries, matrix has %d rows", y->n_local, A->m);
   FH_REQUIRE(mode < 2 || (b && b->n_local >= A->m), "fh_spmv: mode %d needs b", mode);
-  FH_REQUIRE(mode < 3 || (dinv && dinv->n_local >= A->m && A->m == A->n), "fh_spmv: mode 3 needs dinv and a square matrix");
+  // Jacobi sweep: x_new[i] = x[i] + omega dinv[i] (b[i] - (A x)[i]) for the rows of A; on a distributed level A holds the owned
+  // rows over [owned | ghost] columns (m <= n) and row i sits at column i
+  FH_REQUIRE(mode < 3 || (dinv && dinv->n_local >= A->m && A->m <= A->n),
+             "fh_spmv: mode 3 needs dinv and a square matrix (or owned rows over [owned | ghost] columns)");
   return fh_dev_spmv(A, x->d, y->d, mode, b ? b->d : nullptr, dinv ? dinv->d : nullptr, omega);
 }
 

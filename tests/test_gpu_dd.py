@@ -97,3 +97,24 @@ def test_multi_rank_device_path_with_host_transport(tmp_path, world):
         assert np.linalg.norm(d["xs"] - xd[pos]) <= 1e-9 * np.linalg.norm(xd)            # distributed GMRES solve
         seen += d["gid"].size
     assert seen == xd.size
+
+
+def test_bench_contract_with_two_ranks_sharing_the_gpu(tmp_path):
+    """bench.py launched as the driver launches it for N > 1 (torch.distributed.run, one process per rank), on the one GPU of
+    this box with the host-staged transport: rendezvous, distributed setup, timed steps, roofline leg and the JSON line"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FEMUS_BENCH_TRANSPORT="host", FEMUS_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--coarse", "2", "--levels", "3", "--kernel-reps", "3"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "domain decomposition" in d["config"]["parallelism"] and "host-staged" in d["config"]["parallelism"]
+    assert d["config"]["dofs_total"] == 33 * 17 * 17 and "roofline" in d and "cpu_baseline" not in d
