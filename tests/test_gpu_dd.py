@@ -70,7 +70,7 @@ def _rank_worker(rank, world, port, nb, nlevels, out):
     comm.close()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_multi_rank_device_path_with_host_transport(tmp_path, world):
     import scipy.sparse.linalg as spla
     import torch.multiprocessing as mp
