@@ -115,3 +115,40 @@ def test_cavity_reynolds_1000_by_continuation(ctx):
     vmin = sol[off[1] + line].min()
     assert -0.41 < vmin < -0.36
     pb.destroy()
+
+
+def test_three_dimensional_cavity_matches_oracle(ctx):
+    """HEX27 Taylor-Hood (89 x 89 element Jacobians, Vanka patches of up to 376 dofs): lid on the z = hi face moving in x,
+    two levels, Newton + multigrid GMRES against the oracle's Newton with exact linear solves"""
+    import scipy.sparse.linalg as spla
+    nu, nl = 0.05, 2
+    lo, hi = np.array(LO), np.array(HI)
+
+    def bc(x, name, face):
+        if name == "P":
+            return bool(np.all(x < lo + 1e-8)), 0.0
+        return True, (1.0 if (name == "U" and face == 6 and lo[0] < x[0] < hi[0]) else 0.0)
+
+    pb = NavierStokesMG(ctx, 2, 2, 2, nl, nu, boundary_condition=bc).init()
+    assert pb.mgsolve(tol=1e-10, lin_rtol=1e-11, lin_maxit=100)
+    ms = fo.build_levels(2, 2, 2, nl, LO, HI)
+    lays = [ns.NSLayout(m) for m in ms]
+    bcs = [ns.cavity_bc(m, l, lid_flag=-7, lid_component=0) for m, l in zip(ms, lays)]
+    for l in range(nl):
+        assert np.array_equal(pb.bdc[l], bcs[l][0]) and np.array_equal(pb.bdc_val[l], bcs[l][1])
+    sols = [np.zeros(l.n) for l in lays]
+    for l in range(nl):
+        sols[l][bcs[l][0]] = bcs[l][1]
+    for ig in range(nl):
+        for it in range(20):
+            A, b = ns.assemble_ns(ms[ig], lays[ig], sols[ig], nu)
+            A = fo.zero_rows(A, bcs[ig][0], 1.0)
+            b[bcs[ig][0]] = 0.0
+            eps = spla.spsolve(A.tocsc(), b)
+            sols[ig] = sols[ig] + eps
+            if np.linalg.norm(eps) < 1e-11 * np.linalg.norm(sols[ig]):
+                break
+        if ig + 1 < nl:
+            sols[ig + 1] = ns.block_prolongator(ms[ig], ms[ig + 1], lays[ig], lays[ig + 1]) @ sols[ig]
+    assert rel(pb.SOL[-1].to_numpy(), sols[-1]) < 1e-8
+    pb.destroy()
