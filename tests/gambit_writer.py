@@ -20,7 +20,8 @@ def gambit_local_order(geom):
     return [0, 4, 1, 5, 2, 6, 3, 7, 8]
 
 
-def write_neu(path, geom, elem_dof, coords, face_flag, group=5, material=2):
+def write_neu(path, geom, elem_dof, coords, face_flag, group=5, material=2, groups=None):
+    """groups: optional list of (group name, material, element ids) replacing the single group"""
     nel, nl = elem_dof.shape
     dim = coords.shape[1]
     sets = sorted(set(int(-f - 1) for f in face_flag[face_flag < -1].ravel()))
@@ -28,7 +29,8 @@ def write_neu(path, geom, elem_dof, coords, face_flag, group=5, material=2):
     with open(path, "w") as f:
         f.write("        CONTROL INFO 2.3.16\n** GAMBIT NEUTRAL FILE\ntest\nPROGRAM:                Gambit     VERSION:  2.3.16\n1 Jan 2000    00:00:00\n")
         f.write("     NUMNP     NELEM     NGRPS    NBSETS     NDFCD     NDFVL\n")
-        f.write("%10d%10d%10d%10d%10d%10d\nENDOFSECTION\n" % (coords.shape[0], nel, 1, len(sets), dim, dim))
+        glist = groups if groups is not None else [(group, material, list(range(nel)))]
+        f.write("%10d%10d%10d%10d%10d%10d\nENDOFSECTION\n" % (coords.shape[0], nel, len(glist), len(sets), dim, dim))
         f.write("   NODAL COORDINATES 2.3.16\n")
         for j, x in enumerate(coords):
             f.write("%10d" % (j + 1) + "".join("%20.11e" % v for v in x) + "\n")
@@ -38,11 +40,13 @@ def write_neu(path, geom, elem_dof, coords, face_flag, group=5, material=2):
             f.write("%8d %2d %2d " % (e + 1, 4 if geom == "hex" else 2, nl))
             for k in range(0, nl, 7):
                 f.write(("" if k == 0 else "               ") + "".join("%8d" % v for v in ids[k:k + 7]) + "\n")
-        f.write("ENDOFSECTION\n       ELEMENT GROUP 2.3.16\n")
-        f.write("GROUP: %10d ELEMENTS: %10d MATERIAL: %10d NFLAGS: %10d\n%32d\n       0\n" % (1, nel, material, 1, group))
-        for k in range(0, nel, 10):
-            f.write("".join("%8d" % (v + 1) for v in range(k, min(k + 10, nel))) + "\n")
         f.write("ENDOFSECTION\n")
+        for gi, (gname, gmat, gel) in enumerate(glist):
+            f.write("       ELEMENT GROUP 2.3.16\n")
+            f.write("GROUP: %10d ELEMENTS: %10d MATERIAL: %10d NFLAGS: %10d\n%32d\n       0\n" % (gi + 1, len(gel), gmat, 1, gname))
+            for k in range(0, len(gel), 10):
+                f.write("".join("%8d" % (v + 1) for v in gel[k:k + 10]) + "\n")
+            f.write("ENDOFSECTION\n")
         for s in sets:
             faces = [(e, fc) for e in range(nel) for fc in range(face_flag.shape[1]) if face_flag[e, fc] == -s - 1]
             f.write(" BOUNDARY CONDITIONS 2.3.16\n%32d%8d%8d%8d%8d\n" % (s, 1, len(faces), 0, 6))

@@ -66,3 +66,20 @@ def test_reader_on_the_reference_input_files(rel, geom, nel, nnode, sets):
             on = any(np.allclose(P[:, k], lo[k]) or np.allclose(P[:, k], hi[k]) for k in range(m.dim))
             assert on == (ff[e, f] < -1)
     m.destroy()
+
+
+def test_reader_orders_elements_by_material_then_group(tmp_path):
+    """Mesh::mesh_reorder_elem_quantities: elements sorted by (material, group, file order) before the node numbering"""
+    mo = fo.coarse_box_mesh(3, 2, 0)
+    groups = [(7, 4, [0, 3]), (6, 2, [1, 5]), (9, 2, [2, 4])]          # (group name, material, elements)
+    path = tmp_path / "g.neu"
+    write_neu(path, mo.geom, mo.elem_dof, mo.coords, mo.face_flag, groups=groups)
+    m = capi.Mesh.read_gambit(path)
+    ed, xy, ff = m.arrays()
+    expect = [1, 5, 2, 4, 0, 3]                                          # material 2 (groups 6, 9), then material 4
+    centre = lambda X: np.round(X[:, 8], 12)
+    assert np.allclose(xy[ed[:, 8]], mo.coords[mo.elem_dof[expect, 8]], atol=1e-10)     # element centres in the new order
+    assert np.array_equal(ff, mo.face_flag[expect])
+    # first-touch numbering of the reordered elements: vertices of the first element come first
+    assert sorted(ed[0, :4].tolist()) == [0, 1, 2, 3]
+    m.destroy()
