@@ -112,6 +112,16 @@ def main():
     for _ in range(reps):
         pb.assemble()
     asm_ms = comm.allreduce_max(ctx.timer_stop() / reps)
+    # optional fast path of the library (NOT part of `value`): affine elements through reference matrices instead of quadrature
+    ctx.set_option("assemble_affine", 1)
+    pb.assemble()
+    barrier()
+    ctx.timer_start()
+    for _ in range(reps):
+        pb.assemble()
+    asm_affine_ms = comm.allreduce_max(ctx.timer_stop() / reps)
+    ctx.set_option("assemble_affine", 0)
+    pb.assemble()
     pb.set_penalty_top()
     pb.zero_boundary_residuals()
     barrier()
@@ -188,6 +198,15 @@ def main():
             "algorithmic_bytes_per_launch": sweep_bytes,
             "avg_launch_ms": sweep_ms,
             "plain_spmv_ms": spmv_ms,
+        },
+        "optional_affine_fast_path": {
+            "note": "fh_set_option(assemble_affine, 1): elements with affine geometry (every element of this box mesh) are assembled "
+                    "from nine precomputed reference matrices instead of the 64-point quadrature loop; equal to the quadrature "
+                    "result up to summation order (tests/test_gpu_assembly.py).  Off by default and NOT used for `value`, which "
+                    "times the reference's algorithm (full quadrature on every element).",
+            "assembly_ms": asm_affine_ms,
+            "assembled_dofs_per_sec": ndof_total / (asm_affine_ms * 1e-3),
+            "step_ms_estimate": ms_per_step - asm_ms + asm_affine_ms,
         },
         "roofline_assembly": {
             "kernel": "k_elem_q2hex_sym (element matrices, symmetric tiles) + k_row_assemble<27> (row gather)",

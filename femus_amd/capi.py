@@ -556,6 +556,12 @@ class Assembler:
         p = _f64(list(params) + [0.0] * (4 - len(params)))
         _chk(self.L.fh_assemble_poisson(self.h, None if sol is None else sol.h, int(source_kind), _p(p), A.h, res.h))
 
+    def affine_count(self):
+        """(elements the affine fast path would take, elements that need quadrature)"""
+        a, g = ctypes.c_int(), ctypes.c_int()
+        _chk(self.L.fh_assembler_affine_count(self.h, ctypes.byref(a), ctypes.byref(g)))
+        return a.value, g.value
+
     def assemble_expr(self, A, res, sol, expr, scale=1.0):
         """source term f = scale * expr(x, y, z, t), evaluated on the device at the Gauss points"""
         _chk(self.L.fh_assemble_poisson_expr(self.h, None if sol is None else sol.h, expr.h, float(scale), A.h, res.h))

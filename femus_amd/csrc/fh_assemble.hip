@@ -43,6 +43,11 @@ struct fh_assembler_s {
   double* d_Kbuf = nullptr;      // [nadj*nc] element rows in row-gather order
   double* d_Fbuf = nullptr;      // [nadj]
   bool two_pass = false;
+  // optional fast path for AFFINE HEX27/Q2 elements (option assemble_affine): K_e = sum_ab det*B_ab * M_ab with the nine reference
+  // matrices M_ab = sum_g w_g d_a phi_i d_b phi_j, B = J^-1 J^-T; curved elements keep the quadrature kernel
+  int *d_aff_elems = nullptr, *d_gen_elems = nullptr;
+  int n_aff = 0, n_gen = 0;
+  double *d_Mab = nullptr, *d_mphi = nullptr;
   // source term given as a compiled expression (fh_expr): device copy of the program of the expression last used
   int* d_prog = nullptr;
   double* d_prog_consts = nullptr;
@@ -698,6 +703,117 @@ __global__ __launch_bounds__(64) void k_elem_q2hex_sym(AsmParams P) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Affine HEX27 / Q2 elements (parallelepipeds: boxes, sheared boxes): the Jacobian of the map is constant, so
+//   K_ij = sum_g w_g det grad phi_i . grad phi_j = sum_ab (det B_ab) M_ab(i,j),  B = J^-1 J^-T,  M_ab = sum_g w^_g d_a phi^_i d_b phi^_j
+// with the nine reference matrices M_ab built once from the same quadrature tables.  The result equals the quadrature loop of
+// the reference up to the order of the floating-point sums (checked against the oracle at 1e-12).  Opt-in (assemble_affine):
+// the default assembles every element by quadrature as the reference does.  16 elements per workgroup; every thread keeps the
+// M_ab values of its <= 3 matrix entries in registers and applies them to the 16 coefficient sets.
+// ------------------------------------------------------------------------------------------------------------------
+template <int SRC>
+__global__ __launch_bounds__(256) void k_elem_q2hex_affine(AsmParams P, const double* __restrict__ Mab, const double* __restrict__ mphi) {
+  constexpr int NC = 27, DIM = 3, EB = 16, NE = NC * NC;
+  __shared__ double xs[EB][NC * DIM], us[EB][NC], Jl[EB][9], Cs[EB][9], detw[EB], Ks[NE];
+  __shared__ double fgp[(SRC != 0) ? EB : 1][(SRC != 0) ? 64 : 1];
+  __shared__ int sl[EB][NC];
+  const int tid = threadIdx.x;
+  const int e0 = blockIdx.x * EB;
+  const int ne = min(EB, P.nelems - e0);
+  for (int idx = tid; idx < ne * NC; idx += 256) {
+    const int le = idx / NC, n = idx % NC;
+    const int e = P.elems[e0 + le];
+    const int dof = P.elem_dof[(size_t)e * P.nloc + n];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) xs[le][n * DIM + d] = P.coords[(size_t)dof * DIM + d];
+    us[le][n] = P.sol ? P.sol[dof] : 0.0;
+    sl[le][n] = P.slot ? P.slot[(size_t)e * NC + n] : (e0 + le) * NC + n;
+  }
+  __syncthreads();
+  {
+    const int le = tid >> 4, ab = tid & 15;
+    if (le < ne && ab < 9) {
+      const int a = ab / 3, b = ab % 3;
+      double s = 0.0;
+      for (int n = 0; n < NC; n++) s += P.dphi[(size_t)n * DIM + a] * xs[le][n * DIM + b];   // Gauss point 0
+      Jl[le][ab] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < ne) {
+    const double* J = Jl[tid];
+    const double det = J[0] * (J[4] * J[8] - J[5] * J[7]) + J[1] * (J[5] * J[6] - J[3] * J[8]) + J[2] * (J[3] * J[7] - J[4] * J[6]);
+    const double rd = 1.0 / det;
+    double JI[3][3];
+    JI[0][0] = (-J[5] * J[7] + J[4] * J[8]) * rd;
+    JI[0][1] = (J[2] * J[7] - J[1] * J[8]) * rd;
+    JI[0][2] = (-J[2] * J[4] + J[1] * J[5]) * rd;
+    JI[1][0] = (J[5] * J[6] - J[3] * J[8]) * rd;
+    JI[1][1] = (-J[2] * J[6] + J[0] * J[8]) * rd;
+    JI[1][2] = (J[2] * J[3] - J[0] * J[5]) * rd;
+    JI[2][0] = (-J[4] * J[6] + J[3] * J[7]) * rd;
+    JI[2][1] = (J[1] * J[6] - J[0] * J[7]) * rd;
+    JI[2][2] = (-J[1] * J[3] + J[0] * J[4]) * rd;
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) Cs[tid][a * 3 + b] = det * (JI[0][a] * JI[0][b] + JI[1][a] * JI[1][b] + JI[2][a] * JI[2][b]);
+    detw[tid] = det;
+  }
+  if (SRC != 0) {
+    for (int idx = tid; idx < ne * 64; idx += 256) {
+      const int le = idx >> 6, g = idx & 63;
+      double xg[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int n = 0; n < NC; n++) {
+        const double ph = P.phi[(size_t)g * NC + n];
+#pragma unroll
+        for (int d = 0; d < DIM; d++) xg[d] += xs[le][n * DIM + d] * ph;
+      }
+      const double f = (SRC == 1) ? source_eval(P.source_kind, P.p0, P.p1, xg, DIM) : P.p0 * fh_expr_device_eval(P.prog, P.nprog, P.prog_consts, xg);
+      fgp[le][g] = f * P.w[g];
+    }
+  }
+  // M_ab of this thread's entries
+  double Mr[3][9];
+  int ent[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    ent[k] = tid + k * 256;
+#pragma unroll
+    for (int ab = 0; ab < 9; ab++) Mr[k][ab] = (ent[k] < NE) ? Mab[(size_t)ab * NE + ent[k]] : 0.0;
+  }
+  __syncthreads();
+  for (int le = 0; le < ne; le++) {
+    double c[9];
+#pragma unroll
+    for (int ab = 0; ab < 9; ab++) c[ab] = Cs[le][ab];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (ent[k] >= NE) continue;
+      double v = 0.0;
+#pragma unroll
+      for (int ab = 0; ab < 9; ab++) v += c[ab] * Mr[k][ab];
+      Ks[ent[k]] = v;
+      const int i = ent[k] / NC, j = ent[k] - i * NC;
+      const int s = sl[le][i];
+      if (s >= 0) P.Kout[(size_t)s * NC + j] = v;
+    }
+    __syncthreads();
+    if (tid < NC) {
+      const int i = tid;
+      double ku = 0.0;
+      for (int j = 0; j < NC; j++) ku += Ks[i * NC + j] * us[le][j];
+      double fs;
+      if (SRC == 0) fs = P.p0 * mphi[i];
+      else {
+        fs = 0.0;
+        for (int g = 0; g < 64; g++) fs += fgp[le][g] * P.phi[(size_t)g * NC + i];
+      }
+      const int s = sl[le][i];
+      if (s >= 0) P.Fout[s] = -fs * detw[le] - ku;
+    }
+    __syncthreads();
+  }
+}
+
 template <int DIM, int NC>
 static int launch_assemble(fh_assembler_t as, const AsmParams& P) {
   using C = AsmCfg<DIM, NC>;
@@ -873,6 +989,44 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
     FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     as->two_pass = true;
   }
+  if (as->two_pass && as->dim == 3 && as->nc == 27 && as->ng == 64) {
+    // affine classification (host, geometry is fixed for the life of the assembler): every node at c + sum_a xi_a h_a
+    std::vector<int> aff, gen;
+    for (int e = 0; e < nel; e++) {
+      const int* ed = elem_dof + (size_t)e * nloc;
+      const double* x0 = coords + (size_t)ed[0] * 3;
+      double h[3][3], hmax = 0.0;
+      const int vtx[3] = {1, 3, 4};
+      for (int a = 0; a < 3; a++)
+        for (int d = 0; d < 3; d++) {
+          h[a][d] = 0.5 * (coords[(size_t)ed[vtx[a]] * 3 + d] - x0[d]);
+          hmax = std::max(hmax, std::fabs(h[a][d]));
+        }
+      bool ok = hmax > 0.0;
+      for (int n = 0; n < 27 && ok; n++)
+        for (int d = 0; d < 3; d++) {
+          double ref = x0[d];
+          for (int a = 0; a < 3; a++) ref += (fhfe::xc(geom, n, a) + 1) * h[a][d];
+          if (std::fabs(coords[(size_t)ed[n] * 3 + d] - ref) > 1e-12 * hmax) ok = false;
+        }
+      (ok ? aff : gen).push_back(e);
+    }
+    as->n_aff = (int)aff.size();
+    as->n_gen = (int)gen.size();
+    FH_TRY(up((void**)&as->d_aff_elems, aff.data(), aff.size() * sizeof(int)));
+    FH_TRY(up((void**)&as->d_gen_elems, gen.data(), gen.size() * sizeof(int)));
+    std::vector<double> Mab((size_t)9 * 729, 0.0), mphi(27, 0.0);
+    for (int g = 0; g < as->ng; g++)
+      for (int i = 0; i < 27; i++) {
+        mphi[i] += w[g] * phi[(size_t)g * 27 + i];
+        for (int j = 0; j < 27; j++)
+          for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++)
+              Mab[(size_t)(a * 3 + b) * 729 + i * 27 + j] += w[g] * dphi[((size_t)g * 27 + i) * 3 + a] * dphi[((size_t)g * 27 + j) * 3 + b];
+      }
+    FH_TRY(up((void**)&as->d_Mab, Mab.data(), Mab.size() * sizeof(double)));
+    FH_TRY(up((void**)&as->d_mphi, mphi.data(), mphi.size() * sizeof(double)));
+  }
   *out = as;
   return 0;
 }
@@ -887,6 +1041,8 @@ extern "C" int fh_assembler_destroy(fh_assembler_t as) {
   hipFree(as->d_phi);
   hipFree(as->d_dphi);
   if (as->d_emap) hipFree(as->d_emap);
+  for (void* q : {(void*)as->d_aff_elems, (void*)as->d_gen_elems, (void*)as->d_Mab, (void*)as->d_mphi})
+    if (q) hipFree(q);
   if (as->d_prog) hipFree(as->d_prog);
   if (as->d_prog_consts) hipFree(as->d_prog_consts);
   hipFree(as->d_iota);
@@ -948,6 +1104,19 @@ static int assemble_poisson_core(fh_assembler_t as, fh_vec_t sol, int source_kin
     P.Fout = as->d_Fbuf;
     P.slot = as->d_slot;
     P.debug = as->ctx->asm_debug;
+    if (as->ctx->assemble_affine && as->d_Mab && as->n_aff > 0) {
+      // affine elements through the reference-matrix kernel, the rest (curved ones) through the quadrature kernel
+      AsmParams Pa = P;
+      Pa.elems = as->d_aff_elems;
+      Pa.nelems = as->n_aff;
+      const dim3 grid(fh_div_up(as->n_aff, 16)), block(256);
+      if (P.source_kind == 4) hipLaunchKernelGGL(k_elem_q2hex_affine<2>, grid, block, 0, as->ctx->stream, Pa, as->d_Mab, as->d_mphi);
+      else if (P.source_kind != 0) hipLaunchKernelGGL(k_elem_q2hex_affine<1>, grid, block, 0, as->ctx->stream, Pa, as->d_Mab, as->d_mphi);
+      else hipLaunchKernelGGL(k_elem_q2hex_affine<0>, grid, block, 0, as->ctx->stream, Pa, as->d_Mab, as->d_mphi);
+      FH_CHECK_HIP(hipGetLastError());
+      P.elems = as->d_gen_elems;
+      P.nelems = as->n_gen;
+    }
     FH_TRY(dispatch_assemble(as, P));
     if (!(as->ctx->asm_debug & 2)) FH_TRY(dispatch_rows(as, A, res->d, false));
     A->at_valid = false;
@@ -998,6 +1167,13 @@ extern "C" int fh_element_matrices_poisson(fh_assembler_t as, fh_vec_t sol, int 
   FH_CHECK_HIP(hipStreamSynchronize(as->ctx->stream));
   hipFree(dK);
   hipFree(dF);
+  return 0;
+}
+
+extern "C" int fh_assembler_affine_count(fh_assembler_t as, int* n_affine, int* n_general) {
+  FH_REQUIRE(as, "fh_assembler_affine_count: null argument");
+  if (n_affine) *n_affine = as->d_Mab ? as->n_aff : 0;
+  if (n_general) *n_general = as->d_Mab ? as->n_gen : as->nel;
   return 0;
 }
 

@@ -196,6 +196,11 @@ int fh_assemble_poisson(fh_assembler_t as, fh_vec_t sol, int source_kind, const 
 int fh_assembler_info(fh_assembler_t as, int* ncolors, int64_t* algorithmic_bytes, double* flops);
 /* element-level entry (tests): K[nel*nc*nc], F[nel*nc] for the given elements, no scatter */
 int fh_element_matrices_poisson(fh_assembler_t as, fh_vec_t sol, int source_kind, const double* params, double* K, double* F);
+/* Optional fast path (fh_set_option(ctx, "assemble_affine", 1), default 0 = every element by quadrature as the reference does):
+ * HEX27 / Q2 elements whose geometry is affine (parallelepipeds; classified once from the coordinates, tolerance 1e-12 of the
+ * element size) are assembled from nine reference matrices M_ab = sum_g w_g d_a phi_i d_b phi_j as K = sum_ab det (J^-1 J^-T)_ab M_ab,
+ * which equals the quadrature loop up to summation order; curved elements keep the quadrature kernel.  Two-pass mode only. */
+int fh_assembler_affine_count(fh_assembler_t as, int* n_affine, int* n_general);
 
 /* Neumann boundary term of the 001_Poisson callback (applications/001_Poisson/main.cpp:560-594): for every listed boundary face
  * res[node_i] += int_face phi_i * tau ds with elem_type::JacobianSur (ElemType.hpp:1089-1138 edges, :1330-1380 quad faces).

@@ -134,3 +134,46 @@ def test_expression_source_equals_closed_form_source(ctx, args, nl, fe):
     assert abs(A.to_scipy() - B.to_scipy()).max() == 0.0
     assert abs(r1.to_numpy() - r2.to_numpy()).max() <= 1e-14 * abs(r1.to_numpy()).max()
     e.destroy(), asm.destroy(), A.destroy(), B.destroy()
+
+
+@pytest.mark.parametrize("shape", ["box", "sheared", "mixed"])
+def test_affine_fast_path_matches_oracle(ctx, shape):
+    """opt-in affine-element path (reference matrices instead of quadrature) against the oracle's quadrature loop: axis-aligned
+    boxes, a sheared (still affine) mesh, and a mesh where some elements are curved and must fall back to quadrature"""
+    args, nl = (3, 2, 2), 2
+    m = levels(args, nl)[-1]
+    mo = fo.build_levels(*args, nl)[-1]
+    ed, xy, _ = m.arrays()
+    if shape == "sheared":
+        T = np.array([[1.0, 0.3, 0.1], [0.0, 0.8, 0.25], [0.2, 0.0, 1.1]])
+        xy = xy @ T.T + np.array([0.5, -1.0, 2.0])
+    elif shape == "mixed":
+        xy = xy.copy()
+        centres = ed[::3, 26]                      # move the centre node of every third element: those become curved
+        xy[centres] += 0.01
+    m.set_coords(xy)
+    mo.coords = xy.copy()
+    n = m.nnode
+    rp, col = capi.pattern_from_elements(ed, n)
+    A = ctx.matrix_csr(n, n, rp, col)
+    asm = capi.Assembler(ctx, m, "biquadratic", A)
+    na, ng = asm.affine_count()
+    assert na + ng == m.nel and (ng == 0) == (shape != "mixed") and na > 0
+    u = fo.lcg_fill(n, 11)
+    sol, res = ctx.vector_from(u), ctx.vector(n)
+    ctx.set_option("assemble_affine", 1)
+    try:
+        for kind, params, rhs in ((0, (1.5,), lambda xg: 1.5 * np.ones(xg.shape[:2])),
+                                  (1, (-2.0, 1.3), lambda xg: -2.0 * np.prod(np.sin(1.3 * xg), axis=-1))):
+            asm.assemble(A, res, sol, kind, params)
+            Ao, bo = fo.assemble_poisson(mo, "biquadratic", rhs, sol=u)
+            assert abs(A.to_scipy() - Ao).max() <= 1e-12 * abs(Ao).max()
+            assert abs(res.to_numpy() - bo).max() <= 1e-12 * abs(bo).max()
+        e = capi.Expr("exp(x)*y - z")
+        asm.assemble_expr(A, res, sol, e, 0.7)
+        Ao, bo = fo.assemble_poisson(mo, "biquadratic", lambda xg: 0.7 * (np.exp(xg[..., 0]) * xg[..., 1] - xg[..., 2]), sol=u)
+        assert abs(res.to_numpy() - bo).max() <= 1e-12 * abs(bo).max()
+        e.destroy()
+    finally:
+        ctx.set_option("assemble_affine", 0)
+    asm.destroy(), A.destroy()
