@@ -83,3 +83,38 @@ def test_against_reference_library_directly():
             assert L.ref_eval(b"hex", b"biquadratic", 0, j, pt) == phi[p, j]
             for d in range(3):
                 assert L.ref_eval(b"hex", b"biquadratic", 1 + d, j, pt) == dphi[p, j, d]
+
+
+# ---- frozen regression vectors of the unpinned parts (SURVEY 8c items ii-vi; see tests/golden/make_regression_vectors.py) ----
+R = np.load(os.path.join(HERE, "golden", "path_small.npz"))
+
+
+@pytest.mark.parametrize("tag,box,fe", [("hex_q2", (2, 2, 2), "biquadratic"), ("quad_q1", (4, 4, 0), "linear")])
+def test_oracle_reproduces_frozen_path_vectors(tag, box, fe):
+    H = fo.build_poisson_hierarchy(*box, 2, fe, lambda xg: np.ones(xg.shape[:2]))
+    mf = H.meshes[1]
+    assert np.array_equal(mf.elem_dof, R[tag + "_elem_dof_fine"]) and np.array_equal(H.meshes[0].elem_dof, R[tag + "_elem_dof_coarse"])
+    assert np.array_equal(mf.coords, R[tag + "_coords_fine"]) and np.array_equal(mf.face_flag, R[tag + "_face_flag_fine"])
+    assert np.array_equal(H.bdc[1], R[tag + "_bdc_fine"])
+    P = H.P[1].tocoo()
+    assert np.array_equal(P.row, R[tag + "_P_row"]) and np.array_equal(P.col, R[tag + "_P_col"]) and np.array_equal(P.data, R[tag + "_P_val"])
+    A = H.A[1].tocsr()
+    assert np.array_equal(A.indptr, R[tag + "_A_indptr"]) and np.array_equal(A.indices, R[tag + "_A_indices"])
+    assert np.allclose(A.data, R[tag + "_A_data"], rtol=1e-14, atol=1e-16)
+    assert np.allclose(H.b, R[tag + "_b"], rtol=1e-14, atol=1e-18)
+    x = np.linalg.solve(A.toarray(), H.b)
+    assert np.allclose(x, R[tag + "_x_dense_lu"], rtol=1e-11, atol=1e-15)
+
+
+def test_host_mesh_layer_reproduces_frozen_vectors():
+    """the product's host mesh code (no GPU needed) against the same frozen integer tables"""
+    from femus_amd import capi
+    for tag, box in (("hex_q2", (2, 2, 2)), ("quad_q1", (4, 4, 0))):
+        m = capi.Mesh.box(*box)
+        f = m.refine()
+        ed, xy, ff = f.arrays()
+        assert np.array_equal(ed, R[tag + "_elem_dof_fine"]) and np.array_equal(xy, R[tag + "_coords_fine"])
+        assert np.array_equal(ff, R[tag + "_face_flag_fine"]) and f.own_size == R[tag + "_own_size_fine"].tolist()
+        fe = "biquadratic" if tag == "hex_q2" else "linear"
+        assert np.array_equal(f.dirichlet_dofs(fe), R[tag + "_bdc_fine"])
+        m.destroy(), f.destroy()
