@@ -88,3 +88,23 @@ def test_manufactured_solution_converges(ctx):
         errs.append(abs(pb.SOL.to_numpy() - np.prod(np.sin(np.pi * xy), axis=1)).max())
         pb.destroy()
     assert errs[1] < errs[0] / 12.0
+
+
+@pytest.mark.parametrize("tag,box,fe", [("hex_q2", (2, 2, 2), "biquadratic"), ("quad_q1", (4, 4, 0), "linear")])
+def test_against_frozen_path_vectors(ctx, tag, box, fe):
+    """the committed artefact tests/golden/path_small.npz (assembled system, right-hand side, dense-LU solution)"""
+    import os
+    R = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "path_small.npz"))
+    pb = PoissonMG(ctx, *box, 2, fe=fe).init()
+    pb.assemble()
+    assert abs(pb.RES.to_numpy() - R[tag + "_b_before_penalty"]).max() <= 1e-13 * abs(R[tag + "_b_before_penalty"]).max()
+    pb.prepare()
+    A = pb.A[1].to_scipy().tocsr()
+    A.sort_indices()
+    assert np.array_equal(A.indptr, R[tag + "_A_indptr"]) and np.array_equal(A.indices, R[tag + "_A_indices"])
+    assert abs(A.data - R[tag + "_A_data"]).max() <= 1e-12 * abs(R[tag + "_A_data"]).max()
+    pb.mgsolve(outer="gmres", rtol=1e-13, maxit=60)
+    pb.update_sol()
+    x = R[tag + "_x_dense_lu"]
+    assert np.linalg.norm(pb.SOL.to_numpy() - x) <= 1e-10 * np.linalg.norm(x)
+    pb.destroy()
