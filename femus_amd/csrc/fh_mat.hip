@@ -79,6 +79,14 @@ extern "C" int fh_mat_size(fh_mat_t A, int* m, int* n, int* nnz) {
   return 0;
 }
 
+extern "C" int fh_mat_dev_ptrs(fh_mat_t A, const int** rowptr, const int** col, const double** val) {
+  FH_REQUIRE(A, "fh_mat_dev_ptrs: null matrix");
+  if (rowptr) *rowptr = A->d_rowptr;
+  if (col) *col = A->d_col;
+  if (val) *val = A->d_val;
+  return 0;
+}
+
 extern "C" int64_t fh_spmv_algorithmic_bytes(fh_mat_t A) {
   return 12ll * A->nnz + 4ll * (A->m + 1) + 8ll * A->n + 8ll * A->m;
 }

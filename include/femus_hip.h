@@ -77,6 +77,8 @@ int fh_vec_dot(fh_vec_t x, fh_vec_t y, double* out);             /* dot :298 (lo
 int fh_vec_norm(fh_vec_t x, int kind, double* out);              /* kind 1: l1 :200, 2: l2 :202, 0: linfty :204 */
 int fh_vec_reduce(fh_vec_t x, int kind, double* out);            /* kind 0: sum :197, 1: min :193, 2: max :195 */
 double* fh_vec_dev_ptr(fh_vec_t v);                              /* device pointer (owned then ghosts) */
+/* device CSR arrays of a matrix (interoperation with other device libraries; read-only use) */
+int fh_mat_dev_ptrs(fh_mat_t A, const int** rowptr, const int** col, const double** val);
 
 /* ---- matrices: SparseMatrix (src/03_algebra/01_matrices/SparseMatrix.hpp:48-282, PetscMatrix.cpp) ----
  * device CSR, sorted columns, fixed pattern once created.  rowptr[m+1], col[nnz], val[nnz] (val may be NULL = zeros).
