@@ -30,6 +30,8 @@ for tile in (256, 512, 1024):
 if len(sys.argv) > 2:      # e.g. "0,2048,1,0;2,512,0,0"
     configs = [tuple(int(v) for v in c.split(",")) for c in sys.argv[2].split(";")]
 REPS = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+if len(sys.argv) > 4:
+    ctx.set_option("spmv_threads", int(sys.argv[4]))
 for kernel, tile, remap, nt in configs:
     ctx.set_option("spmv_kernel", kernel); ctx.set_option("spmv_tile", tile); ctx.set_option("spmv_xcd_remap", remap); ctx.set_option("spmv_nt", nt)
     y.matrix_mult(x, A); ctx.sync()
