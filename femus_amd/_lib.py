@@ -11,7 +11,8 @@ class LibraryMissing(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "lib", "libfemus_hip.so")
+    # FEMUS_HIP_LIBRARY: another build of the same library (A/B measurements of kernel variants)
+    return os.environ.get("FEMUS_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libfemus_hip.so")
 
 
 def load_library():

@@ -46,7 +46,7 @@ struct fh_ctx_s {
   size_t red_cap = 0;
   // options
   int spmv_tile = 2048;               // nnz per row block (LDS tile)
-  int spmv_xcd_remap = 1;
+  int spmv_xcd_remap = 0;             // 1: consecutive row blocks on one XCD (paid off at 7 workgroups per CU; at 8 the plain order measures ~5 % faster)
   int spmv_kernel = 3;                // 0: csr-stream (workgroup tiles), 1: csr-vector, 2: csr-stream (wave tiles), 3: csr-stream with LDS-staged x
   int spmv_threads = 256;             // kernel 3 workgroup size (128 or 256)
   int spmv_share = 1;                 // kernel 3: x tile and products share one LDS buffer
@@ -86,6 +86,7 @@ struct fh_mat_s {
   int* d_ucols = nullptr;
   unsigned short* d_lcol = nullptr;
   int* d_tile_s = nullptr;             // first non-zero of every row block (persistent pipelined kernel)
+  int* d_blkinfo = nullptr;            // 8 ints per row block: r0, r1, s, e, u0, nu (one descriptor load instead of a pointer chain)
   int lx_tile = 0;
   int max_row = 0;
   // cached explicit transpose for matrix_mult_transpose

@@ -68,6 +68,7 @@ extern "C" int fh_mat_destroy(fh_mat_t A) {
   if (A->d_ucols) hipFree(A->d_ucols);
   if (A->d_lcol) hipFree(A->d_lcol);
   if (A->d_tile_s) hipFree(A->d_tile_s);
+  if (A->d_blkinfo) hipFree(A->d_blkinfo);
   delete A;
   return 0;
 }
@@ -575,6 +576,24 @@ int fh_mat_build_localcols(fh_mat_t A) {
     FH_CHECK_HIP(hipMalloc(&A->d_tile_s, ts.size() * sizeof(int)));
     FH_CHECK_HIP(hipMemcpy(A->d_tile_s, ts.data(), ts.size() * sizeof(int), hipMemcpyHostToDevice));
   }
+  {
+    // one 32-byte descriptor per row block {first row, end row, first nnz, end nnz, first unique column, #unique columns}: the
+    // kernel starts from ONE scalar load instead of the chain rowblk -> rowptr (and uptr), i.e. one memory round trip less
+    // before the matrix stream can be issued
+    std::vector<int> info((size_t)nblk * 8 + 8, 0);
+    for (int b = 0; b < nblk; b++) {
+      int* d = &info[(size_t)b * 8];
+      d[0] = blk[b];
+      d[1] = blk[b + 1];
+      d[2] = A->h_rowptr[blk[b]];
+      d[3] = A->h_rowptr[blk[b + 1]];
+      d[4] = uptr[b];
+      d[5] = uptr[b + 1] - uptr[b];
+    }
+    if (A->d_blkinfo) FH_CHECK_HIP(hipFree(A->d_blkinfo));
+    FH_CHECK_HIP(hipMalloc(&A->d_blkinfo, info.size() * sizeof(int)));
+    FH_CHECK_HIP(hipMemcpy(A->d_blkinfo, info.data(), info.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   A->lx_tile = A->tile;
   return 0;
 }
@@ -583,18 +602,19 @@ int fh_mat_build_localcols(fh_mat_t A) {
 // matrix bytes are in flight per CU at the same residency
 template <int TILE, int MODE, bool SHARE, int NT>
 __global__ __launch_bounds__(NT) void k_spmv_lx(const int* __restrict__ rowptr, const int* __restrict__ col, const unsigned short* __restrict__ lcol,
-                                                 const double* __restrict__ val, const int* __restrict__ rowblk, const int* __restrict__ uptr,
+                                                 const double* __restrict__ val, const int* __restrict__ blkinfo,
                                                  const int* __restrict__ ucols, int nblk, int q, const double* __restrict__ x,
                                                  double* __restrict__ y, const double* __restrict__ b, const double* __restrict__ dinv, double omega) {
   __shared__ double prod[TILE + 2];
   __shared__ double xs_own[SHARE ? 1 : TILE];
   double* xs = SHARE ? prod : xs_own;
-  __shared__ int rps[5 * NT + 4];
+  __shared__ int rps[512 + 4];   // a row block holds at most 512 rows (fh_mat_build_rowblocks)
   int blk = (q > 0) ? (int)(blockIdx.x & 7) * q + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   if (blk >= nblk) return;
   const int tid = threadIdx.x;
-  const int r0 = rowblk[blk], r1 = rowblk[blk + 1];
-  const int s = rowptr[r0], e = rowptr[r1];
+  const int4 d0 = *reinterpret_cast<const int4*>(blkinfo + (size_t)blk * 8);
+  const int2 d1 = *reinterpret_cast<const int2*>(blkinfo + (size_t)blk * 8 + 4);
+  const int r0 = d0.x, r1 = d0.y, s = d0.z, e = d0.w;
   if (r1 - r0 == 1 && e - s > TILE) {
     double acc = 0.0;
     for (int k = s + tid; k < e; k += NT) acc += val[k] * x[col[k]];
@@ -632,7 +652,7 @@ __global__ __launch_bounds__(NT) void k_spmv_lx(const int* __restrict__ rowptr, 
     }
   }
   // ---- x entries of this tile -> LDS (sorted distinct columns: neighbouring lanes share cache lines) ----
-  const int u0 = uptr[blk], nu = uptr[blk + 1] - u0;
+  const int u0 = d1.x, nu = d1.y;
   for (int j = tid; j < nu; j += NT) xs[j] = x[ucols[u0 + j]];
   if (tid <= nrows) rps[tid] = rp0;
   if (tid + NT <= nrows) rps[tid + NT] = rp1;
@@ -699,7 +719,7 @@ static void launch_lx(fh_mat_t A, int mode, const double* x, double* y, const do
   }
 #define FH_LAUNCH(MODE, SH) \
   hipLaunchKernelGGL((k_spmv_lx<TILE, MODE, SH, NT>), dim3(grid), dim3(NT), 0, c->stream, A->d_rowptr, A->d_col, A->d_lcol, A->d_val, \
-                     A->d_rowblk, A->d_uptr, A->d_ucols, A->nblk, q, x, y, b, dinv, omega)
+                     A->d_blkinfo, A->d_ucols, A->nblk, q, x, y, b, dinv, omega)
   if (c->spmv_share) {
     switch (mode) {
       case 0: FH_LAUNCH(0, true); break;

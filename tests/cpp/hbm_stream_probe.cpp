@@ -17,6 +17,31 @@ __global__ __launch_bounds__(256) void k_copy(const double2* __restrict__ a, dou
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) b[i] = a[i];
 }
 
+// two concurrent read streams in the 16 B : 4 B ratio of the SpMV's value and local-column streams
+__global__ __launch_bounds__(256) void k_read2(const double2* __restrict__ a, const unsigned* __restrict__ c, size_t n2, double* __restrict__ out) {
+  double s = 0.0;
+  unsigned t = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
+    const double2 v = a[i];
+    t += c[i];
+    s += v.x + v.y;
+  }
+  if (s == 12345.678 || t == 0x12345u) out[0] = s;
+}
+// the same bytes as ONE stream: chunks of 64 lanes x (16 B + 4 B) laid out back to back
+__global__ __launch_bounds__(256) void k_read_chunked(const char* __restrict__ base, size_t nchunks, double* __restrict__ out) {
+  double s = 0.0;
+  unsigned t = 0;
+  const int lane = threadIdx.x & 63;
+  for (size_t ch = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); ch < nchunks; ch += (size_t)gridDim.x * 4) {
+    const char* p = base + ch * 1280;
+    const double2 v = *reinterpret_cast<const double2*>(p + lane * 16);
+    t += *reinterpret_cast<const unsigned*>(p + 1024 + lane * 4);
+    s += v.x + v.y;
+  }
+  if (s == 12345.678 || t == 0x12345u) out[0] = s;
+}
+
 int main() {
   const size_t bytes = 1700000000ull & ~15ull, n2 = bytes / 16;
   double2 *a, *b;
@@ -31,6 +56,31 @@ int main() {
   hipEventCreate(&e1);
   float ms;
   printf("{");
+  {
+    unsigned* c;
+    hipMalloc(&c, n2 * 4);
+    hipMemset(c, 0, n2 * 4);
+    const double tot = (double)bytes + (double)n2 * 4;
+    for (int bpc : {4, 8, 16}) {
+      const int grid = 256 * bpc;
+      for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_read2, dim3(grid), dim3(256), 0, 0, a, c, n2, out);
+      hipEventRecord(e0);
+      for (int i = 0; i < 20; i++) hipLaunchKernelGGL(k_read2, dim3(grid), dim3(256), 0, 0, a, c, n2, out);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms, e0, e1);
+      printf("\"read_two_streams_%dblk_per_cu_GBps\": %.0f, ", bpc, tot / (ms / 20) / 1e6);
+      const size_t nchunks = bytes / 1280;   // stays inside the 1.7 GB buffer
+      for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_read_chunked, dim3(grid), dim3(256), 0, 0, (const char*)b, nchunks, out);
+      hipEventRecord(e0);
+      for (int i = 0; i < 20; i++) hipLaunchKernelGGL(k_read_chunked, dim3(grid), dim3(256), 0, 0, (const char*)b, nchunks, out);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms, e0, e1);
+      printf("\"read_chunked_one_stream_%dblk_per_cu_GBps\": %.0f, ", bpc, (double)nchunks * 1280 / (ms / 20) / 1e6);
+    }
+    hipFree(c);
+  }
   for (int blocks_per_cu : {4, 8, 16, 32}) {
     const int grid = 256 * blocks_per_cu;
     for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_read, dim3(grid), dim3(256), 0, 0, a, n2, out);
