@@ -603,13 +603,20 @@ int fh_mat_build_localcols(fh_mat_t A) {
 template <int TILE, int MODE, bool SHARE, int NT>
 __global__ __launch_bounds__(NT) void k_spmv_lx(const int* __restrict__ rowptr, const int* __restrict__ col, const unsigned short* __restrict__ lcol,
                                                  const double* __restrict__ val, const int* __restrict__ blkinfo,
-                                                 const int* __restrict__ ucols, int nblk, int q, const double* __restrict__ x,
+                                                 const int* __restrict__ ucols, int nblk, int q, int chunk, const double* __restrict__ x,
                                                  double* __restrict__ y, const double* __restrict__ b, const double* __restrict__ dinv, double omega) {
   __shared__ double prod[TILE + 2];
   __shared__ double xs_own[SHARE ? 1 : TILE];
   double* xs = SHARE ? prod : xs_own;
   __shared__ int rps[512 + 4];   // a row block holds at most 512 rows (fh_mat_build_rowblocks)
-  int blk = (q > 0) ? (int)(blockIdx.x & 7) * q + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  // XCD-aware order (workgroup p runs on XCD p % 8).  q > 0: XCD k walks the row blocks in chunks of `chunk` consecutive blocks
+  // (neighbouring blocks share x lines -> L2 reuse), the chunks of the 8 XCDs interleaved so that the device as a whole still
+  // advances through the matrix front to back; chunk == q is the fully contiguous split
+  int blk = (int)blockIdx.x;
+  if (q > 0) {
+    const int xcd = (int)(blockIdx.x & 7), pos = (int)(blockIdx.x >> 3);
+    blk = ((pos / chunk) * 8 + xcd) * chunk + pos % chunk;
+  }
   if (blk >= nblk) return;
   const int tid = threadIdx.x;
   const int4 d0 = *reinterpret_cast<const int4*>(blkinfo + (size_t)blk * 8);
@@ -712,14 +719,17 @@ __global__ __launch_bounds__(NT) void k_spmv_lx(const int* __restrict__ rowptr, 
 template <int TILE, int NT>
 static void launch_lx(fh_mat_t A, int mode, const double* x, double* y, const double* b, const double* dinv, double omega) {
   fh_ctx_t c = A->ctx;
-  int q = 0, grid = A->nblk;
+  int q = 0, grid = A->nblk, chunk = 1;
   if (c->spmv_xcd_remap && A->nblk >= 64) {
-    q = (A->nblk + 7) / 8;
+    // spmv_xcd_remap: 1 = contiguous eighth per XCD, n > 1 = chunks of n consecutive row blocks per XCD, interleaved
+    chunk = (c->spmv_xcd_remap == 1) ? (A->nblk + 7) / 8 : c->spmv_xcd_remap;
+    const int per_round = 8 * chunk;
+    q = ((A->nblk + per_round - 1) / per_round) * chunk;     // positions per XCD
     grid = 8 * q;
   }
 #define FH_LAUNCH(MODE, SH) \
   hipLaunchKernelGGL((k_spmv_lx<TILE, MODE, SH, NT>), dim3(grid), dim3(NT), 0, c->stream, A->d_rowptr, A->d_col, A->d_lcol, A->d_val, \
-                     A->d_blkinfo, A->d_ucols, A->nblk, q, x, y, b, dinv, omega)
+                     A->d_blkinfo, A->d_ucols, A->nblk, q, chunk, x, y, b, dinv, omega)
   if (c->spmv_share) {
     switch (mode) {
       case 0: FH_LAUNCH(0, true); break;
