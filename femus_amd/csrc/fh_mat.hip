@@ -638,6 +638,21 @@ __global__ __launch_bounds__(NT) void k_spmv_lx(const int* __restrict__ rowptr, 
   }
   // row pointers of the tile: issued now, parked in LDS before the first barrier (no dependent global load in the reduction)
   const int nrows = r1 - r0;
+  // epilogue operands of the row this lane will finish (first reduction pass): fetched now, with the stream, instead of as a
+  // last dependent round trip after the reduction
+  const int G = (nrows <= 16) ? 16 : (nrows <= 32) ? 8 : (nrows <= 64) ? 4 : (nrows <= 128) ? 2 : 1;
+  double eb = 0.0, ed = 0.0, ex = 0.0;
+  if (MODE >= 1) {
+    const int rr0 = tid / G;
+    if (rr0 < nrows) {
+      if (MODE == 1) eb = y[r0 + rr0];
+      if (MODE >= 2) eb = b[r0 + rr0];
+      if (MODE == 3) {
+        ed = dinv[r0 + rr0];
+        ex = x[r0 + rr0];
+      }
+    }
+  }
   int rp0 = 0, rp1 = 0, rp2 = 0;
   if (tid <= nrows) rp0 = rowptr[r0 + tid];
   int rp3 = 0, rp4 = 0;
@@ -698,7 +713,6 @@ __global__ __launch_bounds__(NT) void k_spmv_lx(const int* __restrict__ rowptr, 
     }
   }
   __syncthreads();
-  const int G = (nrows <= 16) ? 16 : (nrows <= 32) ? 8 : (nrows <= 64) ? 4 : (nrows <= 128) ? 2 : 1;
   const int gl = tid & (G - 1);
   const int rows_per_pass = NT / G;
   const int npass = (nrows + rows_per_pass - 1) / rows_per_pass;
@@ -712,7 +726,15 @@ __global__ __launch_bounds__(NT) void k_spmv_lx(const int* __restrict__ rowptr, 
       for (int k = a + gl; k < z; k += G) acc += prod[k];
     }
     for (int off = G >> 1; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if (live && gl == 0) spmv_store<MODE>(acc, r, x, y, b, dinv, omega);
+    if (live && gl == 0) {
+      if (p == 0 && MODE >= 1) {
+        if (MODE == 1) y[r] = eb + acc;
+        else if (MODE == 2) y[r] = eb - acc;
+        else y[r] = ex + omega * ed * (eb - acc);
+      } else {
+        spmv_store<MODE>(acc, r, x, y, b, dinv, omega);
+      }
+    }
   }
 }
 
