@@ -147,6 +147,8 @@ def _declare(L):
     sig("fh_index_destroy", c_void_p)
     sig("fh_mat_zero_rows_index", c_void_p, c_void_p, c_double)
     sig("fh_vec_set_index", c_void_p, c_void_p, c_double)
+    sig("fh_mat_gather_values", c_void_p, c_void_p, c_void_p)
+    sig("fh_vec_gather", c_void_p, c_void_p, c_void_p)
     sig("fh_mg_create", c_void_p, c_int, P(c_void_p))
     sig("fh_mg_set_level", c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_int)
     sig("fh_mg_setup", c_void_p)

@@ -594,6 +594,13 @@ class Index:
     def set(self, v, value):
         _chk(self.L.fh_vec_set_index(v.h, self.h, float(value)))
 
+    def gather_matrix_values(self, dst, src):
+        """dst.val[k] = src.val[self[k]] (self[k] = -1: 0)"""
+        _chk(self.L.fh_mat_gather_values(dst.h, src.h, self.h))
+
+    def gather_vector(self, dst, src):
+        _chk(self.L.fh_vec_gather(dst.h, src.h, self.h))
+
     def destroy(self):
         if self.h:
             self.L.fh_index_destroy(self.h)

@@ -263,6 +263,7 @@ extern "C" int fh_mat_zero_rows(fh_mat_t A, int n, const int* rows, double diag)
 struct fh_index_s {
   fh_ctx_t ctx = nullptr;
   int n = 0, max_index = -1;
+  bool has_negative = false;     // -1 entries are allowed for gather maps ("no source": the target gets 0)
   int* d = nullptr;
 };
 
@@ -272,7 +273,8 @@ extern "C" int fh_index_create(fh_ctx_t ctx, int n, const int* idx, fh_index_t* 
   x->ctx = ctx;
   x->n = n;
   for (int i = 0; i < n; i++) {
-    FH_REQUIRE(idx[i] >= 0, "fh_index_create: negative index %d", idx[i]);
+    FH_REQUIRE(idx[i] >= -1, "fh_index_create: index %d (only -1 is allowed as 'none')", idx[i]);
+    if (idx[i] < 0) x->has_negative = true;
     x->max_index = std::max(x->max_index, idx[i]);
   }
   FH_CHECK_HIP(hipMalloc(&x->d, std::max(n, 1) * sizeof(int)));
@@ -291,6 +293,7 @@ extern "C" int fh_index_destroy(fh_index_t x) {
 
 extern "C" int fh_mat_zero_rows_index(fh_mat_t A, fh_index_t rows, double diag) {
   FH_REQUIRE(A && rows, "fh_mat_zero_rows_index: null argument");
+  FH_REQUIRE(!rows->has_negative, "fh_mat_zero_rows_index: the list holds 'none' entries");
   FH_REQUIRE(rows->max_index < A->m, "fh_mat_zero_rows_index: row %d out of range", rows->max_index);
   if (rows->n == 0) return 0;
   hipLaunchKernelGGL(k_zero_rows, dim3(rows->n), dim3(64), 0, A->ctx->stream, A->d_rowptr, A->d_col, A->d_val, rows->d, rows->n, diag);
@@ -306,9 +309,41 @@ __global__ __launch_bounds__(256) void k_set_index(double* __restrict__ v, const
 
 extern "C" int fh_vec_set_index(fh_vec_t v, fh_index_t idx, double value) {
   FH_REQUIRE(v && idx, "fh_vec_set_index: null argument");
+  FH_REQUIRE(!idx->has_negative, "fh_vec_set_index: the list holds 'none' entries");
   FH_REQUIRE(idx->max_index < v->n_local, "fh_vec_set_index: index %d is not an owned entry", idx->max_index);
   if (idx->n == 0) return 0;
   hipLaunchKernelGGL(k_set_index, dim3(fh_div_up(idx->n, 256)), dim3(256), 0, v->ctx->stream, v->d, idx->d, idx->n, value);
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// gathers along a device-resident map: dst[k] = (map[k] >= 0) ? src[map[k]] : 0.  Used to take the owned rows of an operator that
+// was assembled / projected on a rank's extended box (adaptive levels on several ranks) without host traffic.
+__global__ __launch_bounds__(256) void k_gather_map(double* __restrict__ dst, const double* __restrict__ src, const int* __restrict__ map, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int j = map[i];
+    dst[i] = (j >= 0) ? src[j] : 0.0;
+  }
+}
+
+extern "C" int fh_mat_gather_values(fh_mat_t dst, fh_mat_t src, fh_index_t map) {
+  FH_REQUIRE(dst && src && map, "fh_mat_gather_values: null argument");
+  FH_REQUIRE(map->n == dst->nnz && map->max_index < src->nnz, "fh_mat_gather_values: map has %d entries (target nnz %d), largest source %d (source nnz %d)",
+             map->n, dst->nnz, map->max_index, src->nnz);
+  if (dst->nnz == 0) return 0;
+  const int nb = std::min(fh_div_up(dst->nnz, 256), dst->ctx->num_cu * 16);
+  hipLaunchKernelGGL(k_gather_map, dim3(nb), dim3(256), 0, dst->ctx->stream, dst->d_val, src->d_val, map->d, dst->nnz);
+  FH_CHECK_HIP(hipGetLastError());
+  dst->at_valid = false;
+  return 0;
+}
+
+extern "C" int fh_vec_gather(fh_vec_t dst, fh_vec_t src, fh_index_t map) {
+  FH_REQUIRE(dst && src && map, "fh_vec_gather: null argument");
+  FH_REQUIRE(map->n <= dst->n_local + dst->nghost && map->max_index < src->n_local + src->nghost, "fh_vec_gather: map does not fit the vectors");
+  if (map->n == 0) return 0;
+  const int nb = std::min(fh_div_up(map->n, 256), dst->ctx->num_cu * 16);
+  hipLaunchKernelGGL(k_gather_map, dim3(nb), dim3(256), 0, dst->ctx->stream, dst->d, src->d, map->d, map->n);
   FH_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -69,9 +69,11 @@ class TorchComm:
         return x.numpy()
 
 
-def local_meshes(part, nb, nlevels):
+def local_meshes(part, nb, nlevels, flag_fn=None, n_uniform=None):
     """extended local box (block + ghost ring) as a FEMuS-numbered mesh hierarchy with exact global coordinates;
-    the domain is [0,px]x[0,py]x[0,pz], every rank's block is a unit cube of nb^3 coarse elements"""
+    the domain is [0,px]x[0,py]x[0,pz], every rank's block is a unit cube of nb^3 coarse elements.
+    flag_fn(x[3], level) with n_uniform < nlevels: levels n_uniform.. are refined selectively (MultiLevelMesh::RefineMesh(n, n_uniform,
+    SetRefinementFlag)); the function is evaluated on GLOBAL coordinates, so every rank flags the same elements"""
     ext_lo = [1 if part.c[d] > 0 else 0 for d in range(3)]
     ext_hi = [1 if part.c[d] < part.p[d] - 1 else 0 for d in range(3)]
     n = [nb + ext_lo[d] + ext_hi[d] for d in range(3)]
@@ -89,8 +91,11 @@ def local_meshes(part, nb, nlevels):
             mask |= 1 << fhi
     m.clear_boundary_faces(mask)
     ms = [m]
-    for _ in range(1, nlevels):
-        ms.append(ms[-1].refine())
+    for l in range(1, nlevels):
+        if flag_fn is None or n_uniform is None or l < n_uniform:
+            ms.append(ms[-1].refine())
+        else:
+            ms.append(ms[-1].refine_flagged(ms[-1].flag_elements(flag_fn)))
     return ms
 
 
@@ -434,15 +439,22 @@ class DistributedPoisson:
     fh_halo_update inside the cycle; one replicated level below replaces the single-GPU exact coarse solve."""
 
     def __init__(self, ctx, comm, nranks, rank, nb=8, nlevels=4, omega=2. / 3., npre=2, npost=2, fe="biquadratic", order="seventh",
-                 transport="rccl"):
+                 transport="rccl", flag_fn=None, n_uniform=None, source_kind=0, params=(1.0,)):
+        """flag_fn / n_uniform: adaptive levels (BASELINE config "MGAMR ... 8 GPUs"): every rank refines its extended box with the
+        same flag function on global coordinates.  The fine level is then assembled AND projected (hanging nodes) on the extended
+        box with the one-GPU code and the owned rows are gathered out on the device; uniform hierarchies keep the leaner
+        owned-rows assembler."""
         from .poisson import PoissonMG
         self.ctx, self.comm = ctx, comm
         self.part = BoxPartition(nranks, rank)
         self.nb, self.nl = nb, nlevels
+        self.source_kind, self.params = source_kind, params
         part = self.part
         # 1. full local hierarchy on the extended box (device): assemble, Galerkin chain, SetPenalty
-        meshes = local_meshes(part, nb, nlevels)
-        full = PoissonMG(ctx, 0, 0, 0, nlevels, fe=fe, order=order, omega=omega, npre=npre, npost=npost, meshes=meshes)
+        meshes = local_meshes(part, nb, nlevels, flag_fn, n_uniform)
+        self.adaptive = flag_fn is not None and not all(m.elem_levels()[1] for m in meshes)
+        full = PoissonMG(ctx, 0, 0, 0, nlevels, fe=fe, order=order, omega=omega, npre=npre, npost=npost, meshes=meshes,
+                         source_kind=source_kind, params=params)
         full.init()
         full.assemble()
         full.prepare_operators_only()
@@ -469,7 +481,26 @@ class DistributedPoisson:
         nloc = top.n_owned + top.n_ghost
         xy_new = np.zeros((nloc, 3))
         xy_new[top.newid[np.concatenate([top.owned, top.ghost])]] = xy[np.concatenate([top.owned, top.ghost])]
-        full.destroy_device_objects()
+        if self.adaptive:
+            # keep the extended-box problem: assemble() runs its assembly + hanging-node projection and gathers the owned rows
+            self.full = full
+            full.assemble()                                           # K_amr of the extended box again (prepare penalised it)
+            Kfull = full.A[-1]
+            rp_f, col_f = Kfull.pattern()
+            Aown = H.A[-1].tocsr()
+            old_of_new = np.full(nloc, -1, dtype=np.int64)
+            old_of_new[top.newid[np.concatenate([top.owned, top.ghost])]] = np.concatenate([top.owned, top.ghost])
+            rows_old = np.repeat(top.owned, np.diff(Aown.indptr))
+            cols_old = old_of_new[Aown.indices]
+            ncol = Kfull.n()
+            keys_full = np.repeat(np.arange(Kfull.m(), dtype=np.int64), np.diff(rp_f)) * ncol + col_f
+            want = rows_old.astype(np.int64) * ncol + cols_old
+            pos = np.searchsorted(keys_full, want)
+            hit = (pos < keys_full.size) & (keys_full[np.minimum(pos, keys_full.size - 1)] == want)
+            self._map_vals = np.where(hit, pos, -1).astype(np.int32)
+            self._map_rows = top.owned.astype(np.int32)
+        else:
+            full.destroy_device_objects()
         # 5. upload the restricted operators, halos, cycle
         self.halos = []
         if transport == "host":   # host-staged exchange through `comm` (ranks sharing a GPU, launchers without RCCL peers)
@@ -485,7 +516,11 @@ class DistributedPoisson:
         self.P = [None] + [ctx.matrix_scipy(p) for p in H.P[1:]]
         self.R = [None] + [ctx.matrix_scipy(r) for r in H.R[1:]]
         self.A_rep, self.P_rep, self.R_rep = ctx.matrix_scipy(H.rep["A"]), ctx.matrix_scipy(H.rep["P"]), ctx.matrix_scipy(H.rep["R"])
-        self.asm = capi.Assembler(ctx, None, fe, self.A[-1], order, elem_dof=ed_new, coords=xy_new)
+        if self.adaptive:
+            self.asm = None
+            self.map_vals, self.map_rows = capi.Index(ctx, self._map_vals), capi.Index(ctx, self._map_rows)
+        else:
+            self.asm = capi.Assembler(ctx, None, fe, self.A[-1], order, elem_dof=ed_new, coords=xy_new)
         self.n_owned, self.n_loc = top.n_owned, nloc
         ghost_ids = np.arange(top.n_owned, nloc, dtype=np.int32)
         mk = lambda: ctx.vector(nloc, top.n_owned, 0, ghost_ids)
@@ -506,7 +541,12 @@ class DistributedPoisson:
         self.prepare_ms, self.prepare_first_s = None, None
 
     def assemble(self):
-        self.asm.assemble(self.A[-1], self.RES, None, 0, (1.0,))
+        if self.adaptive:
+            res_full = self.full.assemble()                            # assembly + P_amr projection on the extended box
+            self.map_vals.gather_matrix_values(self.A[-1], self.full.A[-1])
+            self.map_rows.gather_vector(self.RES, res_full)
+            return
+        self.asm.assemble(self.A[-1], self.RES, None, self.source_kind, self.params)
 
     def set_penalty_top(self):
         self.bdc_dev.zero_rows(self.A[-1], 1.0)

@@ -108,6 +108,11 @@ int fh_index_create(fh_ctx_t ctx, int n, const int* idx, fh_index_t* index);
 int fh_index_destroy(fh_index_t index);
 int fh_mat_zero_rows_index(fh_mat_t A, fh_index_t rows, double diag);
 int fh_vec_set_index(fh_vec_t v, fh_index_t idx, double value);   /* v[idx] = value (owned entries) */
+/* device-side gathers along such a list used as a map (-1 = no source, the target gets 0): dst.val[k] = src.val[map[k]] over the
+ * non-zeros of dst, dst[i] = src[map[i]] for vectors.  They take a rank's owned rows out of an operator / residual that was
+ * assembled and projected on its extended box (adaptive levels on several ranks) without host traffic. */
+int fh_mat_gather_values(fh_mat_t dst, fh_mat_t src, fh_index_t map);
+int fh_vec_gather(fh_vec_t dst, fh_vec_t src, fh_index_t map);
 int fh_mat_get_diagonal(fh_mat_t A, fh_vec_t d);                 /* get_diagonal :224 */
 int fh_mat_transpose(fh_mat_t A, fh_mat_t* At);                  /* get_transpose :227 (PetscMatrix.cpp:1031-1070) */
 /* matrix_PtAP(P, A, reuse) :183 (PetscMatrix.cpp:733-751): C = P^T A P.  *C==NULL: symbolic+numeric; else numeric reuse */

@@ -122,3 +122,77 @@ def test_socket_rendezvous_three_ranks(tmp_path):
     out = str(tmp_path / "s%d")
     mp.spawn(_sock_worker, args=(3, _free_port(), out), nprocs=3, join=True)
     assert all(os.path.exists(out % r) for r in range(3))
+
+
+# ---- adaptive levels on several ranks (BASELINE config "MGAMR ... 8xMI355X"): every rank refines its extended box with the same
+# flag function on global coordinates; the planner works on node keys and needs nothing else
+def amr_flag(x, level):
+    return x[0] > 0.5 and (level < 2 or x[1] > 0.25)
+
+
+def oracle_amr_meshes(meshes):
+    oms = [oracle_mesh(m) for m in meshes]
+    for l, m in enumerate(meshes):
+        lev, hom = m.elem_levels()
+        oms[l].elem_level, oms[l].homogeneous = lev.astype(np.int64), hom
+        if l + 1 < len(meshes):
+            ch = m.child_elems().astype(np.int64)
+            oms[l].child_elem = ch
+            oms[l].refined = ch[:, 1] >= 0
+    return oms
+
+
+def _amr_worker(rank, world, port, nb, nlevels, n_uniform, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from femus_amd import dd
+        from oracle import femus_oracle_amr as fa
+        part = dd.BoxPartition(world, rank)
+        comm = dd.TorchComm()
+        meshes = dd.local_meshes(part, nb, nlevels, amr_flag, n_uniform)
+        oms = oracle_amr_meshes(meshes)
+        Hl = fa.build_amr_hierarchy(oms, "biquadratic", ONE)
+        m_rep, m_g0 = dd.replicated_level(part, nb)
+        om_rep, om_g0 = oracle_mesh(m_rep), oracle_mesh(m_g0)
+        om_rep.child_elem = m_rep.child_elems().astype(np.int64)
+        bdc_rep, bdc_g0 = fo.dirichlet_dofs(om_rep, "biquadratic"), fo.dirichlet_dofs(om_g0, "biquadratic")
+        P_g0 = fo.zero_interpolator_dirichlet(fo.build_prolongator(om_rep, om_g0, "biquadratic"), bdc_g0, bdc_rep)
+        H = dd.build_host_hierarchy(part, comm, nb, meshes, Hl.A, Hl.P, Hl.bdc, (m_rep, m_g0, P_g0, bdc_rep))
+        top = H.plans[-1]
+        x = dd.vcycle_numpy(comm, H, Hl.b[top.owned])
+        np.savez(out % rank, gid=top.gid[top.owned], x=x, b=Hl.b[top.owned], n_ghost=top.n_ghost,
+                 hanging=np.intersect1d(Hl.hanging[-1], top.owned).size)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_distributed_amr_vcycle_matches_serial_oracle(tmp_path, world):
+    import torch.multiprocessing as mp
+    from femus_amd import dd
+    from oracle import femus_oracle_amr as fa
+    nb, nlevels, n_uniform = 2, 3, 1
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_amr_worker, args=(world, _free_port(), nb, nlevels, n_uniform, out), nprocs=world, join=True)
+    part = dd.BoxPartition(world, 0)
+    p = part.p
+    # serial reference: the global mesh with one more (exactly solved, uniform) level below
+    ms = fa.build_amr_levels(p[0] * nb // 2, p[1] * nb // 2, p[2] * nb // 2, n_uniform + 1, nlevels - n_uniform, 
+                             lambda x, level: amr_flag(x, level - 1), hi=tuple(float(v) for v in p))
+    H = fa.build_amr_hierarchy(ms, "biquadratic", ONE)
+    ref = fo.vcycle(H, nlevels, H.b)
+    gid_ser, _ = dd.node_keys(ms[-1].coords, nlevels - 1, nb, part)
+    srt = np.argsort(gid_ser)
+    seen = hang = 0
+    for r in range(world):
+        d = np.load(out % r)
+        pos = srt[np.searchsorted(gid_ser[srt], d["gid"])]
+        assert np.array_equal(gid_ser[pos], d["gid"])
+        assert np.linalg.norm(d["b"] - H.b[pos]) <= 1e-13 * np.linalg.norm(H.b)          # same projected residual
+        assert np.linalg.norm(d["x"] - ref[pos]) <= 1e-11 * np.linalg.norm(ref)          # same cycle
+        seen += d["gid"].size
+        hang += int(d["hanging"])
+    assert seen == ref.size and hang == H.hanging[-1].size and hang > 0

@@ -118,3 +118,60 @@ def test_bench_contract_with_two_ranks_sharing_the_gpu(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "domain decomposition" in d["config"]["parallelism"] and "host-staged" in d["config"]["parallelism"]
     assert d["config"]["dofs_total"] == 33 * 17 * 17 and "roofline" in d and "cpu_baseline" not in d
+
+
+# ---- adaptive levels on several ranks (BASELINE config "MGAMR, 2 levels of AMR, 8 GPUs"), ranks sharing the one GPU -------------
+def _amr_flag(x, level):
+    return x[0] > 0.5 and (level < 2 or x[1] > 0.25)
+
+
+def _amr_rank_worker(rank, world, port, nb, nlevels, n_uniform, out):
+    import femus_amd as fa
+    from femus_amd import dd as ddm
+    comm = ddm.SocketComm(rank, world, "127.0.0.1", port)
+    ctx = fa.Context(0)
+    dp = ddm.DistributedPoisson(ctx, comm, world, rank, nb=nb, nlevels=nlevels, transport="host", flag_fn=_amr_flag, n_uniform=n_uniform)
+    dp.assemble()                                     # a rank whose box is refined everywhere keeps the homogeneous path
+    dp.set_penalty_top()
+    dp.zero_boundary_residuals()
+    b = dp.RES.to_numpy()[:dp.n_owned]
+    dp.vcycle()
+    x = dp.EPSC.to_numpy()[:dp.n_owned].copy()
+    its, rn = dp.solve(outer="gmres", rtol=1e-12, maxit=80)
+    xs = dp.EPSC.to_numpy()[:dp.n_owned].copy()
+    top = dp.H.plans[-1]
+    np.savez(out % rank, gid=top.gid[top.owned], b=b, x=x, xs=xs, its=its, adaptive=dp.adaptive)
+    comm.barrier()
+    comm.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_adaptive_levels_with_host_transport(tmp_path, world):
+    import scipy.sparse.linalg as spla
+    import torch.multiprocessing as mp
+    from oracle import femus_oracle as fo
+    from oracle import femus_oracle_amr as fam
+    nb, nlevels, n_uniform = 2, 3, 1
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_amr_rank_worker, args=(world, _free_port(), nb, nlevels, n_uniform, out), nprocs=world, join=True)
+    part = dd.BoxPartition(world, 0)
+    p = part.p
+    ONE = lambda xg: np.ones(xg.shape[:2])
+    ms = fam.build_amr_levels(p[0] * nb // 2, p[1] * nb // 2, p[2] * nb // 2, n_uniform + 1, nlevels - n_uniform,
+                              lambda x, level: _amr_flag(x, level - 1), hi=tuple(float(v) for v in p))
+    H = fam.build_amr_hierarchy(ms, "biquadratic", ONE)
+    ref = fo.vcycle(H, nlevels, H.b)
+    xd = spla.spsolve(H.A[-1].tocsc(), H.b)
+    gid_ser, _ = dd.node_keys(ms[-1].coords, nlevels - 1, nb, part)
+    srt = np.argsort(gid_ser)
+    seen, adaptive = 0, 0
+    for r in range(world):
+        d = np.load(out % r)
+        adaptive += int(d["adaptive"])
+        pos = srt[np.searchsorted(gid_ser[srt], d["gid"])]
+        assert np.array_equal(gid_ser[pos], d["gid"])
+        assert np.linalg.norm(d["b"] - H.b[pos]) <= 1e-12 * np.linalg.norm(H.b)          # assembly + projection, owned rows
+        assert np.linalg.norm(d["x"] - ref[pos]) <= 1e-10 * np.linalg.norm(ref)          # distributed V-cycle on adaptive levels
+        assert np.linalg.norm(d["xs"] - xd[pos]) <= 1e-9 * np.linalg.norm(xd)            # distributed GMRES solve
+        seen += d["gid"].size
+    assert seen == xd.size and H.hanging[-1].size > 0 and adaptive > 0
