@@ -48,6 +48,9 @@ struct fh_assembler_s {
   int *d_aff_elems = nullptr, *d_gen_elems = nullptr;
   int n_aff = 0, n_gen = 0;
   double *d_Mab = nullptr, *d_mphi = nullptr;
+  // matrix-core element kernel (k_elem_q2hex_mfma): reference gradients T[q][a][n] (q-stride 81) and
+  // shape values Phi[q][n] (stride 33)
+  double *d_mfT = nullptr, *d_mfPhi = nullptr;
   // source term given as a compiled expression (fh_expr): device copy of the program of the expression last used
   int* d_prog = nullptr;
   double* d_prog_consts = nullptr;
@@ -704,6 +707,224 @@ __global__ __launch_bounds__(64) void k_elem_q2hex_sym(AsmParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// HEX27 / Q2 element matrices on the FP64 matrix cores (v_mfma_f64_16x16x4_f64): ONE element per wave.
+//   K_e = G^T W G with G[(q,a)][i] = d phi_i / d x_a at Gauss point q (192 x 27): a symmetric rank-192 update, i.e. the three
+//   upper 16x16 tiles of a 32x32 product, 48 k-steps of 4 -> 144 MFMAs per element (the 27x27x192 FMAs of the reference's
+//   i/j/gauss loop, `00_poisson_eqn_..._separate.hpp:170-200`, executed by the matrix unit instead of ~3300 vector FMAs per lane).
+//   The A operand of a tile (row i = lane&15, k = lane>>4) and the B operand (k = lane>>4, col j = lane&15) of G^T G hold the
+//   SAME register, so a k-step costs two gradient values per lane (nodes i and i+16), their weighted copies and 3 MFMAs.
+//   Column 27 of the padded product carries w*grad u instead of w*grad phi_27 (= 0), so (K_e u)_i of the residual falls out of the
+//   same MFMAs.
+// Per element:   phase A  lane = Gauss point q: J, J^-1, det*w, grad u, source value -> per-wave LDS slab (scalar loads feed the
+//                         wave-uniform node coordinates / solution values)
+//                phase B  16 groups of the 4 Gauss points {q0, q0+16, q0+32, q0+48} x 3 directions: lanes (kk = lane>>4,
+//                         i = lane&15) form grad phi_i, grad phi_{i+16} from the reference-gradient table in LDS and J^-1 of
+//                         their q, then the 3 MFMAs
+//                phase C  source integral per node on the VALU, tiles -> LDS (mirrored) -> coalesced row stores
+// Tables (shared by the NW waves of the persistent workgroup): T[q][a][n] with q-stride 81 doubles (odd: conflict-free for
+// lane = q; 16*81 = 16 mod 32: conflict-free for the (kk, i) pattern), Phi[q][n] with stride 33.  Waves never synchronise
+// with each other after the table load.  ng == 64 only (the k-grouping is built on it); other rules keep the vector kernel.
+// ------------------------------------------------------------------------------------------------------------------
+typedef double fh_d4 __attribute__((ext_vector_type(4)));
+typedef const int __attribute__((address_space(4)))* fh_ciptr;     // read-only for the launch: uniform accesses become s_load
+constexpr int MF_TS = 81, MF_TA = 27, MF_PS = 33, MF_SS = 15, MF_KS = 29;
+constexpr int MF_SLAB = 64 * MF_SS;   // 960 doubles per wave: phase-A results, later the 27 x 29 staging of K_e
+constexpr int MF_XS = 27 * 4;         // per wave: (x, y, z, u) of the element's nodes
+constexpr size_t mf_lds_bytes(int nw) { return (size_t)(64 * MF_TS + 64 * MF_PS + nw * (MF_SLAB + MF_XS)) * sizeof(double); }
+
+template <int SRC, int NW>
+__global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const double* __restrict__ Tg, const double* __restrict__ Phig) {
+  constexpr int NC = 27, DIM = 3;
+  extern __shared__ __attribute__((aligned(16))) double mf_smem[];
+  double* T = mf_smem;
+  double* Phi = T + 64 * MF_TS;
+  for (int k = threadIdx.x; k < 64 * MF_TS; k += NW * 64) T[k] = Tg[k];
+  for (int k = threadIdx.x; k < 64 * MF_PS; k += NW * 64) Phi[k] = Phig[k];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* slab = Phi + 64 * MF_PS + wave * (MF_SLAB + MF_XS);
+  double* xs = slab + MF_SLAB;
+  const int kk = lane >> 4, li = lane & 15;
+  const int ln = lane < NC ? lane : 0;
+  const double wgauss = P.w[lane];
+  const fh_ciptr elems = (fh_ciptr)P.elems;
+  const int stride = gridDim.x * NW;
+  const int idx0 = blockIdx.x * NW + wave;
+  if (idx0 >= P.nelems) return;
+  // software pipeline over this wave's elements: node ids two elements ahead, coordinates / solution values / output slots
+  // one element ahead, so that no phase waits on an HBM round trip (the gathers are dependent loads)
+  const int last = P.nelems - 1;
+  int e_cur = elems[idx0];
+  int e_n = elems[min(idx0 + stride, last)], e_nn = elems[min(idx0 + 2 * stride, last)];
+  int sl_cur = (lane < NC) ? (P.slot ? P.slot[(size_t)e_cur * NC + lane] : idx0 * NC + lane) : -1;
+  {
+    const int dof = P.elem_dof[(size_t)e_cur * P.nloc + ln];
+    if (lane < NC) {
+      xs[lane * 4 + 0] = P.coords[(size_t)dof * DIM];
+      xs[lane * 4 + 1] = P.coords[(size_t)dof * DIM + 1];
+      xs[lane * 4 + 2] = P.coords[(size_t)dof * DIM + 2];
+      xs[lane * 4 + 3] = P.sol ? P.sol[dof] : 0.0;
+    }
+  }
+  int dof_n = P.elem_dof[(size_t)e_n * P.nloc + ln];
+  wave_lds_sync();
+#pragma unroll 1
+  for (int idx = idx0; idx < P.nelems; idx += stride) {
+    // ---- prefetch (consumed after phase B / at the next iteration) ----
+    const double nx0 = P.coords[(size_t)dof_n * DIM], nx1 = P.coords[(size_t)dof_n * DIM + 1], nx2 = P.coords[(size_t)dof_n * DIM + 2];
+    const double nu = P.sol ? P.sol[dof_n] : 0.0;
+    const int sl_n = (lane < NC) ? (P.slot ? P.slot[(size_t)e_n * NC + lane] : (idx + stride) * NC + lane) : -1;
+    const int dof_nn = P.elem_dof[(size_t)e_nn * P.nloc + ln];
+    const int e_nnn = elems[min(idx + 3 * stride, last)];
+    // ---- phase A: lane = Gauss point ----
+    {
+      const int q = lane;
+      double J[DIM][DIM] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, gh[DIM] = {0, 0, 0}, xg[DIM] = {0, 0, 0};
+      const double* Tq = T + q * MF_TS;
+#pragma unroll 9
+      for (int n = 0; n < NC; n++) {
+        const double2 xa = *reinterpret_cast<const double2*>(xs + n * 4), xb = *reinterpret_cast<const double2*>(xs + n * 4 + 2);   // broadcast reads
+        const double x0 = xa.x, x1 = xa.y, x2 = xb.x, un = xb.y;
+        const double t0 = Tq[n], t1 = Tq[MF_TA + n], t2 = Tq[2 * MF_TA + n];
+        J[0][0] += t0 * x0; J[0][1] += t0 * x1; J[0][2] += t0 * x2;
+        J[1][0] += t1 * x0; J[1][1] += t1 * x1; J[1][2] += t1 * x2;
+        J[2][0] += t2 * x0; J[2][1] += t2 * x1; J[2][2] += t2 * x2;
+        gh[0] += t0 * un; gh[1] += t1 * un; gh[2] += t2 * un;
+        if (SRC != 0) {
+          const double ph = Phi[q * MF_PS + n];
+          xg[0] += x0 * ph; xg[1] += x1 * ph; xg[2] += x2 * ph;
+        }
+      }
+      const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[1][2] * J[2][0] - J[1][0] * J[2][2]) +
+                         J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+      const double rd = 1.0 / det;
+      double JI[DIM][DIM];
+      JI[0][0] = (-J[1][2] * J[2][1] + J[1][1] * J[2][2]) * rd;
+      JI[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * rd;
+      JI[0][2] = (-J[0][2] * J[1][1] + J[0][1] * J[1][2]) * rd;
+      JI[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) * rd;
+      JI[1][1] = (-J[0][2] * J[2][0] + J[0][0] * J[2][2]) * rd;
+      JI[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * rd;
+      JI[2][0] = (-J[1][1] * J[2][0] + J[1][0] * J[2][1]) * rd;
+      JI[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * rd;
+      JI[2][2] = (-J[0][1] * J[1][0] + J[0][0] * J[1][1]) * rd;
+      const double weight = det * wgauss;
+      double fq;
+      if (SRC == 0) fq = P.p0;
+      else if (SRC == 1) fq = source_eval(P.source_kind, P.p0, P.p1, xg, DIM);
+      else {
+        double x4[4] = {xg[0], xg[1], xg[2], 0.0};
+        fq = P.p0 * fh_expr_device_eval(P.prog, P.nprog, P.prog_consts, x4);
+      }
+      double* sq = slab + q * MF_SS;
+#pragma unroll
+      for (int a = 0; a < DIM; a++) {
+#pragma unroll
+        for (int b = 0; b < DIM; b++) sq[a * 3 + b] = JI[a][b];
+        sq[10 + a] = weight * (JI[a][0] * gh[0] + JI[a][1] * gh[1] + JI[a][2] * gh[2]);
+      }
+      sq[9] = weight;
+      sq[13] = weight * fq;
+    }
+    wave_lds_sync();
+    // ---- phase B: the rank-192 update on the matrix cores ----
+    fh_d4 C00 = {0, 0, 0, 0}, C01 = C00, C11 = C00;
+    if (!(P.debug & 1)) {
+      const bool hi_live = li < 11;                           // nodes 16 + li < 27
+#pragma unroll 2
+      for (int q0 = 0; q0 < 16; q0++) {
+        const int q = q0 + 16 * kk;
+        const double* sq = slab + q * MF_SS;
+        const double* Tq = T + q * MF_TS + li;
+        const double tl0 = Tq[0], tl1 = Tq[MF_TA], tl2 = Tq[2 * MF_TA];
+        const double th0 = hi_live ? Tq[16] : 0.0, th1 = hi_live ? Tq[MF_TA + 16] : 0.0, th2 = hi_live ? Tq[2 * MF_TA + 16] : 0.0;
+        const double wq = sq[9];
+#pragma unroll
+        for (int a = 0; a < DIM; a++) {
+          const double j0 = sq[a * 3], j1 = sq[a * 3 + 1], j2 = sq[a * 3 + 2];
+          const double glo = tl0 * j0 + tl1 * j1 + tl2 * j2;
+          const double ghi = th0 * j0 + th1 * j1 + th2 * j2;   // 0 for the padding nodes 27..31
+          const double wlo = glo * wq;
+          const double wgu = sq[10 + a];
+          const double whi = (li == 11) ? wgu : ghi * wq;          // column 27: w * du/dx_a
+          C00 = __builtin_amdgcn_mfma_f64_16x16x4f64(glo, wlo, C00, 0, 0, 0);
+          C01 = __builtin_amdgcn_mfma_f64_16x16x4f64(glo, whi, C01, 0, 0, 0);
+          C11 = __builtin_amdgcn_mfma_f64_16x16x4f64(ghi, whi, C11, 0, 0, 0);
+        }
+      }
+    }
+    // ---- phase C: source integral per node (lanes i = lane&31, half of the Gauss points each) ----
+    double fsrc = 0.0;
+    {
+      const int i = lane & 31, h = lane >> 5;
+#pragma unroll 8
+      for (int g = 0; g < 32; g++) {
+        const int q = h * 32 + g;
+        fsrc += Phi[q * MF_PS + i] * slab[q * MF_SS + 13];
+      }
+      fsrc += __shfl_xor(fsrc, 32, 64);
+    }
+    if (lane < NC) {          // the next element's nodes (phase A of this element is done with xs)
+      xs[lane * 4 + 0] = nx0;
+      xs[lane * 4 + 1] = nx1;
+      xs[lane * 4 + 2] = nx2;
+      xs[lane * 4 + 3] = nu;
+    }
+    wave_lds_sync();          // every lane is done with the phase-A slab: reuse it as Ks[27][29]
+    double* Ks = slab;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = kk + 4 * r;                         // C/D layout: col = lane&15, row = (lane>>4) + 4*reg
+      Ks[row * MF_KS + li] = C00[r];
+      if (li < 12) Ks[row * MF_KS + 16 + li] = C01[r];    // columns 16..27 (27 = (K u)_row)
+      if (li < 11) Ks[(16 + li) * MF_KS + row] = C01[r];  // mirrored block (rows 16..26, columns 0..15)
+      if (row < 11 && li < 12) Ks[(16 + row) * MF_KS + 16 + li] = C11[r];
+    }
+    wave_lds_sync();
+    if (!(P.debug & 2)) {
+#pragma unroll
+      for (int t0 = 0; t0 < NC * NC; t0 += 64) {
+        const int t = t0 + lane;
+        const int row = (t < NC * NC) ? t / NC : 0;
+        const int j = t - row * NC;
+        const int s = __shfl(sl_cur, row, 64);
+        if (t < NC * NC && s >= 0) P.Kout[(size_t)s * NC + j] = Ks[row * MF_KS + j];
+      }
+      if (lane < NC && sl_cur >= 0) P.Fout[sl_cur] = -(Ks[lane * MF_KS + NC] + fsrc);
+    }
+    wave_lds_sync();          // Ks is the next element's phase-A slab
+    sl_cur = sl_n;
+    dof_n = dof_nn;
+    e_n = e_nn;
+    e_nn = e_nnn;
+  }
+}
+
+template <int SRC, int NW>
+static int launch_mfma_one(fh_assembler_t as, const AsmParams& P) {
+  constexpr size_t lds = mf_lds_bytes(NW);
+  static_assert(lds <= 160 * 1024, "k_elem_q2hex_mfma: LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_elem_q2hex_mfma<SRC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int per_cu = std::max(1, (int)((size_t)160 * 1024 / lds));
+  const int grid = std::max(1, std::min(fh_div_up(P.nelems, NW), as->ctx->num_cu * per_cu));
+  hipLaunchKernelGGL((k_elem_q2hex_mfma<SRC, NW>), dim3(grid), dim3(NW * 64), lds, as->ctx->stream, P, as->d_mfT, as->d_mfPhi);
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int NW>
+static int launch_mfma(fh_assembler_t as, const AsmParams& P) {
+  if (P.source_kind == 4) return launch_mfma_one<2, NW>(as, P);
+  if (P.source_kind != 0) return launch_mfma_one<1, NW>(as, P);
+  return launch_mfma_one<0, NW>(as, P);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Affine HEX27 / Q2 elements (parallelepipeds: boxes, sheared boxes): the Jacobian of the map is constant, so
 //   K_ij = sum_g w_g det grad phi_i . grad phi_j = sum_ab (det B_ab) M_ab(i,j),  B = J^-1 J^-T,  M_ab = sum_g w^_g d_a phi^_i d_b phi^_j
 // with the nine reference matrices M_ab built once from the same quadrature tables.  The result equals the quadrature loop of
@@ -836,6 +1057,14 @@ static int launch_assemble(fh_assembler_t as, const AsmParams& P) {
 }
 
 static int dispatch_assemble(fh_assembler_t as, const AsmParams& P) {
+  if (as->dim == 3 && as->nc == 27 && P.Kout && as->ctx->assemble_mfma && as->d_mfT && P.ng == 64) {
+    if (P.nelems <= 0) return 0;
+    switch (as->ctx->assemble_mfma) {
+      case 4: return launch_mfma<4>(as, P);
+      case 8: return launch_mfma<8>(as, P);
+      default: return launch_mfma<12>(as, P);
+    }
+  }
   if (as->dim == 3 && as->nc == 27 && P.Kout && as->ctx->assemble_sym) {
     if (P.nelems <= 0) return 0;
     const dim3 grid(fh_div_up(P.nelems, 2)), block(64);
@@ -938,6 +1167,16 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
   FH_TRY(up((void**)&as->d_w, w.data(), w.size() * sizeof(double)));
   FH_TRY(up((void**)&as->d_phi, phi.data(), phi.size() * sizeof(double)));
   FH_TRY(up((void**)&as->d_dphi, dphi.data(), dphi.size() * sizeof(double)));
+  if (as->dim == 3 && as->nc == 27 && as->ng == 64) {
+    std::vector<double> mfT((size_t)64 * MF_TS, 0.0), mfPhi((size_t)64 * MF_PS, 0.0);
+    for (int g = 0; g < 64; g++)
+      for (int n = 0; n < 27; n++) {
+        mfPhi[(size_t)g * MF_PS + n] = phi[(size_t)g * 27 + n];
+        for (int a = 0; a < 3; a++) mfT[(size_t)g * MF_TS + a * MF_TA + n] = dphi[((size_t)g * 27 + n) * 3 + a];
+      }
+    FH_TRY(up((void**)&as->d_mfT, mfT.data(), mfT.size() * sizeof(double)));
+    FH_TRY(up((void**)&as->d_mfPhi, mfPhi.data(), mfPhi.size() * sizeof(double)));
+  }
   std::vector<int> celems;
   color_elements(nel, as->nc, nloc, elem_dof, nnode, as->color_ptr, celems);
   as->ncolors = (int)as->color_ptr.size() - 1;
@@ -1041,7 +1280,7 @@ extern "C" int fh_assembler_destroy(fh_assembler_t as) {
   hipFree(as->d_phi);
   hipFree(as->d_dphi);
   if (as->d_emap) hipFree(as->d_emap);
-  for (void* q : {(void*)as->d_aff_elems, (void*)as->d_gen_elems, (void*)as->d_Mab, (void*)as->d_mphi})
+  for (void* q : {(void*)as->d_aff_elems, (void*)as->d_gen_elems, (void*)as->d_Mab, (void*)as->d_mphi, (void*)as->d_mfT, (void*)as->d_mfPhi})
     if (q) hipFree(q);
   if (as->d_prog) hipFree(as->d_prog);
   if (as->d_prog_consts) hipFree(as->d_prog_consts);
