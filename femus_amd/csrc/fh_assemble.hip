@@ -48,7 +48,7 @@ struct fh_assembler_s {
   int *d_aff_elems = nullptr, *d_gen_elems = nullptr;
   int n_aff = 0, n_gen = 0;
   double *d_Mab = nullptr, *d_mphi = nullptr;
-  // matrix-core element kernel (k_elem_q2hex_mfma): reference gradients T[q][a][n] (q-stride 81) and
+  // matrix-core element kernel (k_elem_q2hex_mfma): reference gradients T[q][c][n] (q-stride 85, c-stride 28, zero padded) and
   // shape values Phi[q][n] (stride 33)
   double *d_mfT = nullptr, *d_mfPhi = nullptr;
   // source term given as a compiled expression (fh_expr): device copy of the program of the expression last used
@@ -707,30 +707,41 @@ __global__ __launch_bounds__(64) void k_elem_q2hex_sym(AsmParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// HEX27 / Q2 element matrices on the FP64 matrix cores (v_mfma_f64_16x16x4_f64): ONE element per wave.
-//   K_e = G^T W G with G[(q,a)][i] = d phi_i / d x_a at Gauss point q (192 x 27): a symmetric rank-192 update, i.e. the three
-//   upper 16x16 tiles of a 32x32 product, 48 k-steps of 4 -> 144 MFMAs per element (the 27x27x192 FMAs of the reference's
-//   i/j/gauss loop, `00_poisson_eqn_..._separate.hpp:170-200`, executed by the matrix unit instead of ~3300 vector FMAs per lane).
-//   The A operand of a tile (row i = lane&15, k = lane>>4) and the B operand (k = lane>>4, col j = lane&15) of G^T G hold the
-//   SAME register, so a k-step costs two gradient values per lane (nodes i and i+16), their weighted copies and 3 MFMAs.
-//   Column 27 of the padded product carries w*grad u instead of w*grad phi_27 (= 0), so (K_e u)_i of the residual falls out of the
-//   same MFMAs.
-// Per element:   phase A  lane = Gauss point q: J, J^-1, det*w, grad u, source value -> per-wave LDS slab (scalar loads feed the
-//                         wave-uniform node coordinates / solution values)
-//                phase B  16 groups of the 4 Gauss points {q0, q0+16, q0+32, q0+48} x 3 directions: lanes (kk = lane>>4,
-//                         i = lane&15) form grad phi_i, grad phi_{i+16} from the reference-gradient table in LDS and J^-1 of
-//                         their q, then the 3 MFMAs
-//                phase C  source integral per node on the VALU, tiles -> LDS (mirrored) -> coalesced row stores
-// Tables (shared by the NW waves of the persistent workgroup): T[q][a][n] with q-stride 81 doubles (odd: conflict-free for
-// lane = q; 16*81 = 16 mod 32: conflict-free for the (kk, i) pattern), Phi[q][n] with stride 33.  Waves never synchronise
-// with each other after the table load.  ng == 64 only (the k-grouping is built on it); other rules keep the vector kernel.
+// HEX27 / Q2 element matrices on the FP64 matrix cores: ONE element per wave, v_mfma_f64_4x4x4_4b_f64 (four independent
+// 4x4x4 products per instruction, 16 cycles, the same 64 MAC/clk/SIMD as the 16x16x4 form but at the granularity of the
+// 27 x 27 problem).
+//   K_e = sum_q T_q^T D_q T_q,  T_q[c][i] = d phi_i / d xi_c at Gauss point q (table),  D_q = w_q det J (J^-1)^T J^-1  (3 x 3)
+//   i.e. K = A^T B with A[(q,c)][i] = T_q[c][i] read straight from the table in LDS and B[(q,c)][j] = sum_c' D_q[c][c'] T_q[c'][j]
+//   (3 FMA per value): the 27 x 27 x 192 FMAs of the reference's i/j/gauss loop (`00_poisson_eqn_..._separate.hpp:170-200`).
+//   The nodes form 7 groups of 4 (node 27 = zero padding); K_e is symmetric, so only the 28 tiles (ib <= jb) of the 7 x 7 tile grid
+//   are needed: 8 instructions of 4 tiles per k-step of 4 (schedule below), 48 k-steps -> 384 MFMAs = 6144 cycles per element.
+// Operand layout (measured, tests/cpp/mfma_f64_4x4_layout.cpp): A and B: lane = 16 k + 4 block + r ; D: lane = 16 row + 4 block + col.
+//   The lane (k, b, r) of a k-step works on Gauss point q0 + 16 k.  It forms B for its own node li = 4 b + r (column group b,
+//   "lo") and for node 16 + li (column group 4 + b, "hi"; block 3 idle) and reads A for the row group the schedule gives its block:
+//       lo-type (B = lo, columns 0..3):  t0: rows (0,0,0,0)  t1: (4,1,1,1)  t2: (5,5,2,2)  t3: (6,6,6,3)
+//       hi-type (B = hi, columns 4..6):  t4: rows (4,4,4,-)  t5: (3,5,5,-)  t6: (2,3,6,-)  t7: (1,2,3,-)
+//   which covers every unordered tile pair exactly once (tiles with ib > jb are the transposes of needed ones).
+// MFMAs do not overlap with vector instructions of other waves on gfx950 (tests/cpp/mfma_f64_overlap_probe.cpp), so the cost is
+// MFMA cycles + 4 x (vector instructions): phase B issues 18 FMAs per 24 MFMAs, A operands cost LDS reads only.
+// Per element:   phase A  lane = Gauss point q: J, J^-1, D_q, source value -> per-wave LDS slab
+//                phase B  16 groups of the 4 Gauss points {q0, q0+16, q0+32, q0+48} x 3 directions x 8 MFMAs
+//                phase C  source integral per node, tiles -> LDS (mirrored), K_e u for the residual, coalesced row stores
+// Tables (shared by the NW waves of the persistent workgroup): T[q][c][n] with q-stride 85 doubles, c-stride 28 (odd q-stride:
+// conflict-free for lane = q; 16*85 = 16 mod 32: conflict-free for the k-step pattern), Phi[q][n] with stride 33.  Waves never
+// synchronise with each other after the table load.  ng == 64 only; other rules keep the vector kernel.
 // ------------------------------------------------------------------------------------------------------------------
-typedef double fh_d4 __attribute__((ext_vector_type(4)));
 typedef const int __attribute__((address_space(4)))* fh_ciptr;     // read-only for the launch: uniform accesses become s_load
-constexpr int MF_TS = 81, MF_TA = 27, MF_PS = 33, MF_SS = 15, MF_KS = 29;
-constexpr int MF_SLAB = 64 * MF_SS;   // 960 doubles per wave: phase-A results, later the 27 x 29 staging of K_e
+constexpr int MF_TS = 85, MF_TA = 28, MF_PS = 33, MF_SS = 7, MF_KS = 29;
+constexpr int MF_SLAB = 27 * MF_KS;   // 783 doubles per wave: phase-A results (64 x 7), later the 27 x 29 staging of K_e
 constexpr int MF_XS = 27 * 4;         // per wave: (x, y, z, u) of the element's nodes
-constexpr size_t mf_lds_bytes(int nw) { return (size_t)(64 * MF_TS + 64 * MF_PS + nw * (MF_SLAB + MF_XS)) * sizeof(double); }
+constexpr int MF_WAVE = MF_SLAB + 1 + MF_XS;   // 892 doubles, even: xs stays 16-byte aligned
+constexpr size_t mf_lds_bytes(int nw) { return (size_t)(64 * MF_TS + 64 * MF_PS + nw * MF_WAVE) * sizeof(double); }
+// row group of block b in instruction t: 3 bits each
+constexpr unsigned long long mf_rows(int b0, int b1, int b2, int b3) { return (unsigned long long)(b0 | (b1 << 3) | (b2 << 6) | (b3 << 9)); }
+constexpr unsigned long long MF_SCHED_LO = mf_rows(0, 0, 0, 0) | (mf_rows(4, 1, 1, 1) << 12) | (mf_rows(5, 5, 2, 2) << 24) | (mf_rows(6, 6, 6, 3) << 36);
+constexpr unsigned long long MF_SCHED_HI = mf_rows(4, 4, 4, 4) | (mf_rows(3, 5, 5, 5) << 12) | (mf_rows(2, 3, 6, 6) << 24) | (mf_rows(1, 2, 3, 3) << 36);
+
+__device__ __forceinline__ int mf_rowg(int t, int blk) { return (int)(((t < 4 ? MF_SCHED_LO : MF_SCHED_HI) >> (12 * (t & 3) + 3 * blk)) & 7); }
 
 template <int SRC, int NW>
 __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const double* __restrict__ Tg, const double* __restrict__ Phig) {
@@ -743,10 +754,16 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double* slab = Phi + 64 * MF_PS + wave * (MF_SLAB + MF_XS);
-  double* xs = slab + MF_SLAB;
-  const int kk = lane >> 4, li = lane & 15;
+  double* slab = Phi + 64 * MF_PS + wave * MF_WAVE;
+  double* xs = slab + MF_SLAB + 1;
+  const int kk = lane >> 4, li = lane & 15, blk = (lane >> 2) & 3, r4 = lane & 3;
   const int ln = lane < NC ? lane : 0;
+  // per-lane row groups of the 8 instructions and the table offsets of the A operands
+  int offA[8];
+#pragma unroll
+  for (int t = 0; t < 8; t++) offA[t] = kk * 16 * MF_TS + 4 * mf_rowg(t, blk) + r4;
+  const int offBlo = kk * 16 * MF_TS + li;
+  const int offBhi = kk * 16 * MF_TS + (li < 12 ? 16 + li : NC);      // nodes 28..31 do not exist: read the zero padding
   const double wgauss = P.w[lane];
   const fh_ciptr elems = (fh_ciptr)P.elems;
   const int stride = gridDim.x * NW;
@@ -771,7 +788,7 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
   wave_lds_sync();
 #pragma unroll 1
   for (int idx = idx0; idx < P.nelems; idx += stride) {
-    // ---- prefetch (consumed after phase B / at the next iteration) ----
+    // ---- prefetch (consumed at the end of this iteration / in the next one) ----
     const double nx0 = P.coords[(size_t)dof_n * DIM], nx1 = P.coords[(size_t)dof_n * DIM + 1], nx2 = P.coords[(size_t)dof_n * DIM + 2];
     const double nu = P.sol ? P.sol[dof_n] : 0.0;
     const int sl_n = (lane < NC) ? (P.slot ? P.slot[(size_t)e_n * NC + lane] : (idx + stride) * NC + lane) : -1;
@@ -780,17 +797,16 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
     // ---- phase A: lane = Gauss point ----
     {
       const int q = lane;
-      double J[DIM][DIM] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, gh[DIM] = {0, 0, 0}, xg[DIM] = {0, 0, 0};
+      double J[DIM][DIM] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, xg[DIM] = {0, 0, 0};
       const double* Tq = T + q * MF_TS;
 #pragma unroll 9
       for (int n = 0; n < NC; n++) {
-        const double2 xa = *reinterpret_cast<const double2*>(xs + n * 4), xb = *reinterpret_cast<const double2*>(xs + n * 4 + 2);   // broadcast reads
-        const double x0 = xa.x, x1 = xa.y, x2 = xb.x, un = xb.y;
+        const double2 xa = *reinterpret_cast<const double2*>(xs + n * 4);   // broadcast reads
+        const double x0 = xa.x, x1 = xa.y, x2 = xs[n * 4 + 2];
         const double t0 = Tq[n], t1 = Tq[MF_TA + n], t2 = Tq[2 * MF_TA + n];
         J[0][0] += t0 * x0; J[0][1] += t0 * x1; J[0][2] += t0 * x2;
         J[1][0] += t1 * x0; J[1][1] += t1 * x1; J[1][2] += t1 * x2;
         J[2][0] += t2 * x0; J[2][1] += t2 * x1; J[2][2] += t2 * x2;
-        gh[0] += t0 * un; gh[1] += t1 * un; gh[2] += t2 * un;
         if (SRC != 0) {
           const double ph = Phi[q * MF_PS + n];
           xg[0] += x0 * ph; xg[1] += x1 * ph; xg[2] += x2 * ph;
@@ -817,40 +833,34 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
         double x4[4] = {xg[0], xg[1], xg[2], 0.0};
         fq = P.p0 * fh_expr_device_eval(P.prog, P.nprog, P.prog_consts, x4);
       }
+      // grad phi_i[a] = sum_c JI[a][c] T[c][i]  ->  D[c][c'] = w sum_a JI[a][c] JI[a][c']
       double* sq = slab + q * MF_SS;
-#pragma unroll
-      for (int a = 0; a < DIM; a++) {
-#pragma unroll
-        for (int b = 0; b < DIM; b++) sq[a * 3 + b] = JI[a][b];
-        sq[10 + a] = weight * (JI[a][0] * gh[0] + JI[a][1] * gh[1] + JI[a][2] * gh[2]);
-      }
-      sq[9] = weight;
-      sq[13] = weight * fq;
+      sq[0] = weight * (JI[0][0] * JI[0][0] + JI[1][0] * JI[1][0] + JI[2][0] * JI[2][0]);
+      sq[1] = weight * (JI[0][0] * JI[0][1] + JI[1][0] * JI[1][1] + JI[2][0] * JI[2][1]);
+      sq[2] = weight * (JI[0][0] * JI[0][2] + JI[1][0] * JI[1][2] + JI[2][0] * JI[2][2]);
+      sq[3] = weight * (JI[0][1] * JI[0][1] + JI[1][1] * JI[1][1] + JI[2][1] * JI[2][1]);
+      sq[4] = weight * (JI[0][1] * JI[0][2] + JI[1][1] * JI[1][2] + JI[2][1] * JI[2][2]);
+      sq[5] = weight * (JI[0][2] * JI[0][2] + JI[1][2] * JI[1][2] + JI[2][2] * JI[2][2]);
+      sq[6] = weight * fq;
     }
     wave_lds_sync();
     // ---- phase B: the rank-192 update on the matrix cores ----
-    fh_d4 C00 = {0, 0, 0, 0}, C01 = C00, C11 = C00;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (!(P.debug & 1)) {
-      const bool hi_live = li < 11;                           // nodes 16 + li < 27
 #pragma unroll 2
       for (int q0 = 0; q0 < 16; q0++) {
-        const int q = q0 + 16 * kk;
-        const double* sq = slab + q * MF_SS;
-        const double* Tq = T + q * MF_TS + li;
-        const double tl0 = Tq[0], tl1 = Tq[MF_TA], tl2 = Tq[2 * MF_TA];
-        const double th0 = hi_live ? Tq[16] : 0.0, th1 = hi_live ? Tq[MF_TA + 16] : 0.0, th2 = hi_live ? Tq[2 * MF_TA + 16] : 0.0;
-        const double wq = sq[9];
+        const double* sq = slab + (q0 + 16 * kk) * MF_SS;
+        const double* Tb = T + q0 * MF_TS;
+        const double d00 = sq[0], d01 = sq[1], d02 = sq[2], d11 = sq[3], d12 = sq[4], d22 = sq[5];
+        const double tl0 = Tb[offBlo], tl1 = Tb[offBlo + MF_TA], tl2 = Tb[offBlo + 2 * MF_TA];
+        const double th0 = Tb[offBhi], th1 = Tb[offBhi + MF_TA], th2 = Tb[offBhi + 2 * MF_TA];
+        const double dd[3][3] = {{d00, d01, d02}, {d01, d11, d12}, {d02, d12, d22}};
 #pragma unroll
-        for (int a = 0; a < DIM; a++) {
-          const double j0 = sq[a * 3], j1 = sq[a * 3 + 1], j2 = sq[a * 3 + 2];
-          const double glo = tl0 * j0 + tl1 * j1 + tl2 * j2;
-          const double ghi = th0 * j0 + th1 * j1 + th2 * j2;   // 0 for the padding nodes 27..31
-          const double wlo = glo * wq;
-          const double wgu = sq[10 + a];
-          const double whi = (li == 11) ? wgu : ghi * wq;          // column 27: w * du/dx_a
-          C00 = __builtin_amdgcn_mfma_f64_16x16x4f64(glo, wlo, C00, 0, 0, 0);
-          C01 = __builtin_amdgcn_mfma_f64_16x16x4f64(glo, whi, C01, 0, 0, 0);
-          C11 = __builtin_amdgcn_mfma_f64_16x16x4f64(ghi, whi, C11, 0, 0, 0);
+        for (int c = 0; c < DIM; c++) {
+          const double blo = dd[c][0] * tl0 + dd[c][1] * tl1 + dd[c][2] * tl2;
+          const double bhi = dd[c][0] * th0 + dd[c][1] * th1 + dd[c][2] * th2;
+#pragma unroll
+          for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(Tb[offA[t] + c * MF_TA], t < 4 ? blo : bhi, acc[t], 0, 0, 0);
         }
       }
     }
@@ -861,27 +871,36 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
 #pragma unroll 8
       for (int g = 0; g < 32; g++) {
         const int q = h * 32 + g;
-        fsrc += Phi[q * MF_PS + i] * slab[q * MF_SS + 13];
+        fsrc += Phi[q * MF_PS + i] * slab[q * MF_SS + 6];
       }
       fsrc += __shfl_xor(fsrc, 32, 64);
-    }
-    if (lane < NC) {          // the next element's nodes (phase A of this element is done with xs)
-      xs[lane * 4 + 0] = nx0;
-      xs[lane * 4 + 1] = nx1;
-      xs[lane * 4 + 2] = nx2;
-      xs[lane * 4 + 3] = nu;
     }
     wave_lds_sync();          // every lane is done with the phase-A slab: reuse it as Ks[27][29]
     double* Ks = slab;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int row = kk + 4 * r;                         // C/D layout: col = lane&15, row = (lane>>4) + 4*reg
-      Ks[row * MF_KS + li] = C00[r];
-      if (li < 12) Ks[row * MF_KS + 16 + li] = C01[r];    // columns 16..27 (27 = (K u)_row)
-      if (li < 11) Ks[(16 + li) * MF_KS + row] = C01[r];  // mirrored block (rows 16..26, columns 0..15)
-      if (row < 11 && li < 12) Ks[(16 + row) * MF_KS + 16 + li] = C11[r];
+    for (int t = 0; t < 8; t++) {   // D layout: row = lane>>4, block = (lane>>2)&3, col = lane&3
+      const int colg = (t < 4) ? blk : 4 + blk, rowg = mf_rowg(t, blk);
+      const int row = 4 * rowg + kk, col = 4 * colg + r4;
+      // diagonal tiles: the (i, j) and (j, i) sums differ in rounding; keep the upper entries and mirror them, so that K_e is
+      // symmetric bit for bit like the reference's Jac (products commute, same summation order)
+      const bool live = (t < 4 || blk < 3) && row < NC && col < NC && (rowg != colg || kk <= r4);
+      if (live) {
+        Ks[row * MF_KS + col] = acc[t];
+        if (row != col) Ks[col * MF_KS + row] = acc[t];
+      }
     }
     wave_lds_sync();
+    double ku = 0.0;
+    if (P.sol) {              // residual: (K_e u)_i, lanes i = lane&31, half of the columns each
+      const int i = min(lane & 31, NC - 1), h = lane >> 5;
+#pragma unroll
+      for (int g = 0; g < 14; g++) {
+        const int j = h * 14 + g;
+        const double v = (j < NC) ? Ks[i * MF_KS + min(j, NC - 1)] : 0.0;
+        ku += v * xs[min(j, NC - 1) * 4 + 3];
+      }
+      ku += __shfl_xor(ku, 32, 64);
+    }
     if (!(P.debug & 2)) {
 #pragma unroll
       for (int t0 = 0; t0 < NC * NC; t0 += 64) {
@@ -891,9 +910,16 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
         const int s = __shfl(sl_cur, row, 64);
         if (t < NC * NC && s >= 0) P.Kout[(size_t)s * NC + j] = Ks[row * MF_KS + j];
       }
-      if (lane < NC && sl_cur >= 0) P.Fout[sl_cur] = -(Ks[lane * MF_KS + NC] + fsrc);
+      if (lane < NC && sl_cur >= 0) P.Fout[sl_cur] = -(ku + fsrc);
     }
-    wave_lds_sync();          // Ks is the next element's phase-A slab
+    wave_lds_sync();          // Ks is the next element's phase-A slab, xs the next element's nodes
+    if (lane < NC) {
+      xs[lane * 4 + 0] = nx0;
+      xs[lane * 4 + 1] = nx1;
+      xs[lane * 4 + 2] = nx2;
+      xs[lane * 4 + 3] = nu;
+    }
+    wave_lds_sync();
     sl_cur = sl_n;
     dof_n = dof_nn;
     e_n = e_nn;
