@@ -209,11 +209,11 @@ def main():
             "step_ms_estimate": ms_per_step - asm_ms + asm_affine_ms,
         },
         "roofline_assembly": {
-            "kernel": "k_elem_q2hex_mfma (element matrices on the FP64 matrix cores: 384 v_mfma_f64_4x4x4_4b per element, 28 symmetric "
+            "kernel": "k_elem_q2hex_mfma (element matrices on the FP64 matrix cores: 336 v_mfma_f64_4x4x4_4b per element, 28 symmetric "
                       "tiles) + k_row_assemble<27> (row gather)",
             "bound": "fp64 (matrix and vector instructions share one issue port per SIMD on gfx950: 78.6 TFLOP/s either way; "
                      "also reported against hbm)",
-            "flops_model": "the reference's full element loop (SURVEY 8d, 4.6e5 flop/element); the kernel executes 1.97e5 MFMA flop + "
+            "flops_model": "the reference's full element loop (SURVEY 8d, 4.6e5 flop/element); the kernel executes 1.72e5 MFMA flop + "
                            "about 0.7e5 vector flop of them (symmetry), so achieved_tflops is an effective rate, not a hardware one",
             "achieved_tflops": ai["flops"] / asm_ms / 1e9,
             "peak_tflops": FP64_VALU_PEAK_TFLOPS,

@@ -40,7 +40,8 @@ struct fh_assembler_s {
   int* d_adj_ei = nullptr;       // (element << 5) | local row, ascending element order
   unsigned char* d_rowmap = nullptr;   // [nadj*nc] slot of (element row, j) inside the CSR row
   int* d_slot = nullptr;         // [nel*nc] adjacency slot of (element, local row), -1 when the row is not in the matrix
-  double* d_Kbuf = nullptr;      // [nadj*nc] element rows in row-gather order
+  double* d_Kbuf = nullptr;      // [nadj*kstride] element rows in row-gather order
+  int kstride = 27;              // doubles per element row in d_Kbuf (nc, or 32 for HEX27/Q2: whole 64-byte lines per row)
   double* d_Fbuf = nullptr;      // [nadj]
   bool two_pass = false;
   // optional fast path for AFFINE HEX27/Q2 elements (option assemble_affine): K_e = sum_ab det*B_ab * M_ab with the nine reference
@@ -86,6 +87,7 @@ struct AsmParams {
   int debug;               // profiling aid: bit 0 skips the quadrature loop, bit 1 skips the scatter
   const int* slot;         // non-null with Kout: row i of element e goes to Kout[slot[e*nc+i]*nc + j] (row-gather order), -1 = skip
   double* Kout;            // non-null: write element matrices [e][nc][nc] instead of scattering
+  int kstride;             // doubles per element row in Kout (nc; 32 = padded rows of the slot-major buffer)
   double* Fout;
 };
 
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(256) void k_assemble_poisson(AsmParams P) {
         if (j0 + b < NC) {
           if (P.slot) {
             const int sl = P.slot[(size_t)e * NC + i];
-            if (sl >= 0) P.Kout[(size_t)sl * NC + j0 + b] = K[a][b];
+            if (sl >= 0) P.Kout[(size_t)sl * P.kstride + j0 + b] = K[a][b];
           } else {
             P.Kout[((size_t)eidx * NC + i) * NC + j0 + b] = K[a][b];
           }
@@ -411,7 +413,7 @@ template <int NC, bool BUILD>
 __global__ __launch_bounds__(256) void k_row_assemble(const int* __restrict__ rowptr, const int* __restrict__ col, int m,
                                                       const int* __restrict__ adj_ptr, const int* __restrict__ adj_ei,
                                                       unsigned char* __restrict__ rowmap, const int* __restrict__ elem_dof, int nloc,
-                                                      const double* __restrict__ Kbuf, const double* __restrict__ Fbuf,
+                                                      const double* __restrict__ Kbuf, int kstride, const double* __restrict__ Fbuf,
                                                       double* __restrict__ val, double* __restrict__ res) {
   __shared__ double acc[8][256];
   const int sub = threadIdx.x >> 5, lane = threadIdx.x & 31;
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(256) void k_row_assemble(const int* __restrict__ ro
         f[t] = 0.0;
         if (a < a1) {
           if (lane < NC) {
-            k[t] = Kbuf[(size_t)a * NC + lane];          // slot-major: the rows of one CSR row are contiguous
+            k[t] = Kbuf[(size_t)a * kstride + lane];     // slot-major: the rows of one CSR row are contiguous
             pp[t] = rowmap[(size_t)a * NC + lane];
           }
           if (lane == 0) f[t] = Fbuf[a];
@@ -477,10 +479,10 @@ static int launch_rows(fh_assembler_t as, fh_mat_t A, double* res, bool build) {
   const dim3 grid(fh_div_up(A->m, 8)), block(256);
   if (build)
     hipLaunchKernelGGL((k_row_assemble<NC, true>), grid, block, 0, as->ctx->stream, A->d_rowptr, A->d_col, A->m, as->d_adj_ptr, as->d_adj_ei,
-                       as->d_rowmap, as->d_elem_dof, as->nloc, nullptr, nullptr, nullptr, nullptr);
+                       as->d_rowmap, as->d_elem_dof, as->nloc, nullptr, as->kstride, nullptr, nullptr, nullptr);
   else
     hipLaunchKernelGGL((k_row_assemble<NC, false>), grid, block, 0, as->ctx->stream, A->d_rowptr, A->d_col, A->m, as->d_adj_ptr, as->d_adj_ei,
-                       as->d_rowmap, as->d_elem_dof, as->nloc, as->d_Kbuf, as->d_Fbuf, A->d_val, res);
+                       as->d_rowmap, as->d_elem_dof, as->nloc, as->d_Kbuf, as->kstride, as->d_Fbuf, A->d_val, res);
   FH_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -694,12 +696,12 @@ __global__ __launch_bounds__(64) void k_elem_q2hex_sym(AsmParams P) {
       if (j >= NC) continue;
       if (ib == jb) {
         if (b >= a) {               // diagonal tile: upper entries, mirrored
-          if (sli[a] >= 0) P.Kout[(size_t)sli[a] * NC + j] = K[a][b];
-          if (b > a && slj[b] >= 0) P.Kout[(size_t)slj[b] * NC + i] = K[a][b];
+          if (sli[a] >= 0) P.Kout[(size_t)sli[a] * P.kstride + j] = K[a][b];
+          if (b > a && slj[b] >= 0) P.Kout[(size_t)slj[b] * P.kstride + i] = K[a][b];
         }
       } else {
-        if (sli[a] >= 0) P.Kout[(size_t)sli[a] * NC + j] = K[a][b];
-        if (slj[b] >= 0) P.Kout[(size_t)slj[b] * NC + i] = K[a][b];
+        if (sli[a] >= 0) P.Kout[(size_t)sli[a] * P.kstride + j] = K[a][b];
+        if (slj[b] >= 0) P.Kout[(size_t)slj[b] * P.kstride + i] = K[a][b];
       }
     }
     if (ib == jb && sli[a] >= 0) P.Fout[sli[a]] = F[a];
@@ -714,15 +716,18 @@ __global__ __launch_bounds__(64) void k_elem_q2hex_sym(AsmParams P) {
 //   i.e. K = A^T B with A[(q,c)][i] = T_q[c][i] read straight from the table in LDS and B[(q,c)][j] = sum_c' D_q[c][c'] T_q[c'][j]
 //   (3 FMA per value): the 27 x 27 x 192 FMAs of the reference's i/j/gauss loop (`00_poisson_eqn_..._separate.hpp:170-200`).
 //   The nodes form 7 groups of 4 (node 27 = zero padding); K_e is symmetric, so only the 28 tiles (ib <= jb) of the 7 x 7 tile grid
-//   are needed: 8 instructions of 4 tiles per k-step of 4 (schedule below), 48 k-steps -> 384 MFMAs = 6144 cycles per element.
+//   are needed: 7 instructions of 4 tiles per k-step of 4 (schedule below), 48 k-steps -> 336 MFMAs = 5376 cycles per element.
 // Operand layout (measured, tests/cpp/mfma_f64_4x4_layout.cpp): A and B: lane = 16 k + 4 block + r ; D: lane = 16 row + 4 block + col.
 //   The lane (k, b, r) of a k-step works on Gauss point q0 + 16 k.  It forms B for its own node li = 4 b + r (column group b,
-//   "lo") and for node 16 + li (column group 4 + b, "hi"; block 3 idle) and reads A for the row group the schedule gives its block:
-//       lo-type (B = lo, columns 0..3):  t0: rows (0,0,0,0)  t1: (4,1,1,1)  t2: (5,5,2,2)  t3: (6,6,6,3)
-//       hi-type (B = hi, columns 4..6):  t4: rows (4,4,4,-)  t5: (3,5,5,-)  t6: (2,3,6,-)  t7: (1,2,3,-)
-//   which covers every unordered tile pair exactly once (tiles with ib > jb are the transposes of needed ones).
+//   "lo") and for node 16 + li (column group 4 + b, "hi"; block 3 has no such node and takes column group 3 again) and reads A
+//   for the row group the schedule gives its block:
+//       lo-type (B = lo, columns 0,1,2,3):  t0: rows (0,1,2,3)  t1: (2,0,1,0)  t2: (5,4,4,1)  t3: (6,6,5,2)
+//       hi-type (B = hi, columns 4,5,6,3):  t4: rows (4,5,6,4)  t5: (6,4,5,5)  t6: (0,1,2,6)
+//   28 slots = the 28 unordered tile pairs, each exactly once (an orientation of the pair graph with in-degree 4,4,4,7,3,3,3;
+//   a tile with row > column is the transpose of the needed one).  t0 holds the diagonal tiles 0..3: its A operand is the lane's
+//   own table value.
 // MFMAs do not overlap with vector instructions of other waves on gfx950 (tests/cpp/mfma_f64_overlap_probe.cpp), so the cost is
-// MFMA cycles + 4 x (vector instructions): phase B issues 18 FMAs per 24 MFMAs, A operands cost LDS reads only.
+// MFMA cycles + 4 x (vector instructions): phase B issues 18 FMAs per 21 MFMAs, A operands cost LDS reads only.
 // Per element:   phase A  lane = Gauss point q: J, J^-1, D_q, source value -> per-wave LDS slab
 //                phase B  16 groups of the 4 Gauss points {q0, q0+16, q0+32, q0+48} x 3 directions x 8 MFMAs
 //                phase C  source integral per node, tiles -> LDS (mirrored), K_e u for the residual, coalesced row stores
@@ -738,8 +743,9 @@ constexpr int MF_WAVE = MF_SLAB + 1 + MF_XS;   // 892 doubles, even: xs stays 16
 constexpr size_t mf_lds_bytes(int nw) { return (size_t)(64 * MF_TS + 64 * MF_PS + nw * MF_WAVE) * sizeof(double); }
 // row group of block b in instruction t: 3 bits each
 constexpr unsigned long long mf_rows(int b0, int b1, int b2, int b3) { return (unsigned long long)(b0 | (b1 << 3) | (b2 << 6) | (b3 << 9)); }
-constexpr unsigned long long MF_SCHED_LO = mf_rows(0, 0, 0, 0) | (mf_rows(4, 1, 1, 1) << 12) | (mf_rows(5, 5, 2, 2) << 24) | (mf_rows(6, 6, 6, 3) << 36);
-constexpr unsigned long long MF_SCHED_HI = mf_rows(4, 4, 4, 4) | (mf_rows(3, 5, 5, 5) << 12) | (mf_rows(2, 3, 6, 6) << 24) | (mf_rows(1, 2, 3, 3) << 36);
+constexpr unsigned long long MF_SCHED_LO = mf_rows(0, 1, 2, 3) | (mf_rows(2, 0, 1, 0) << 12) | (mf_rows(5, 4, 4, 1) << 24) | (mf_rows(6, 6, 5, 2) << 36);
+constexpr unsigned long long MF_SCHED_HI = mf_rows(4, 5, 6, 4) | (mf_rows(6, 4, 5, 5) << 12) | (mf_rows(0, 1, 2, 6) << 24);
+constexpr int MF_NT = 7;              // MFMAs per k-step
 
 __device__ __forceinline__ int mf_rowg(int t, int blk) { return (int)(((t < 4 ? MF_SCHED_LO : MF_SCHED_HI) >> (12 * (t & 3) + 3 * blk)) & 7); }
 
@@ -762,11 +768,11 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
   // LDS byte addresses of this lane's operands (group 0, direction 0); the k-step loop adds immediate offsets
   const unsigned ldsT = (unsigned)(size_t)(__attribute__((address_space(3))) double*)T;
   const unsigned ldsSlab = (unsigned)(size_t)(__attribute__((address_space(3))) double*)slab;
-  unsigned aA[8];
+  unsigned aA[MF_NT];                // aA[0] unused: the A operand of t0 is the lane's own table value (rows = columns)
 #pragma unroll
-  for (int t = 0; t < 8; t++) aA[t] = ldsT + (kk * 16 * MF_TS + 4 * mf_rowg(t, blk) + r4) * 8;
+  for (int t = 0; t < MF_NT; t++) aA[t] = ldsT + (kk * 16 * MF_TS + 4 * mf_rowg(t, blk) + r4) * 8;
   const unsigned aBlo = ldsT + (kk * 16 * MF_TS + li) * 8;
-  const unsigned aBhi = ldsT + (kk * 16 * MF_TS + (li < 12 ? 16 + li : NC)) * 8;      // nodes 28..31 do not exist: read the zero padding
+  const unsigned aBhi = ldsT + (kk * 16 * MF_TS + (li < 12 ? 16 + li : li)) * 8;      // block 3 of the "hi" operand: column group 3 again
   const unsigned aD = ldsSlab + kk * 16 * MF_SS * 8;
   const double wgauss = P.w[lane];
   const fh_ciptr elems = (fh_ciptr)P.elems;
@@ -816,20 +822,18 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
           xg[0] += x0 * ph; xg[1] += x1 * ph; xg[2] += x2 * ph;
         }
       }
-      const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[1][2] * J[2][0] - J[1][0] * J[2][2]) +
-                         J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
-      const double rd = 1.0 / det;
-      double JI[DIM][DIM];
-      JI[0][0] = (-J[1][2] * J[2][1] + J[1][1] * J[2][2]) * rd;
-      JI[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * rd;
-      JI[0][2] = (-J[0][2] * J[1][1] + J[0][1] * J[1][2]) * rd;
-      JI[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) * rd;
-      JI[1][1] = (-J[0][2] * J[2][0] + J[0][0] * J[2][2]) * rd;
-      JI[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * rd;
-      JI[2][0] = (-J[1][1] * J[2][0] + J[1][0] * J[2][1]) * rd;
-      JI[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * rd;
-      JI[2][2] = (-J[0][1] * J[1][0] + J[0][0] * J[1][1]) * rd;
-      const double weight = det * wgauss;
+      // cofactors Cf = det * J^-1 (the reference's Jacobian inverse, `elem_type_template` 3-D branch, without the division)
+      double Cf[DIM][DIM];
+      Cf[0][0] = -J[1][2] * J[2][1] + J[1][1] * J[2][2];
+      Cf[0][1] = J[0][2] * J[2][1] - J[0][1] * J[2][2];
+      Cf[0][2] = -J[0][2] * J[1][1] + J[0][1] * J[1][2];
+      Cf[1][0] = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+      Cf[1][1] = -J[0][2] * J[2][0] + J[0][0] * J[2][2];
+      Cf[1][2] = J[0][2] * J[1][0] - J[0][0] * J[1][2];
+      Cf[2][0] = -J[1][1] * J[2][0] + J[1][0] * J[2][1];
+      Cf[2][1] = J[0][1] * J[2][0] - J[0][0] * J[2][1];
+      Cf[2][2] = -J[0][1] * J[1][0] + J[0][0] * J[1][1];
+      const double det = J[0][0] * Cf[0][0] + J[0][1] * Cf[1][0] + J[0][2] * Cf[2][0];
       double fq;
       if (SRC == 0) fq = P.p0;
       else if (SRC == 1) fq = source_eval(P.source_kind, P.p0, P.p1, xg, DIM);
@@ -837,27 +841,28 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
         double x4[4] = {xg[0], xg[1], xg[2], 0.0};
         fq = P.p0 * fh_expr_device_eval(P.prog, P.nprog, P.prog_consts, x4);
       }
-      // grad phi_i[a] = sum_c JI[a][c] T[c][i]  ->  D[c][c'] = w sum_a JI[a][c] JI[a][c']
+      // grad phi_i[a] = sum_c JI[a][c] T[c][i], JI = Cf / det  ->  D[c][c'] = w det sum_a JI[a][c] JI[a][c'] = (w / det) (Cf^T Cf)[c][c']
+      const double sc = wgauss / det;
       double* sq = slab + q * MF_SS;
-      sq[0] = weight * (JI[0][0] * JI[0][0] + JI[1][0] * JI[1][0] + JI[2][0] * JI[2][0]);
-      sq[1] = weight * (JI[0][0] * JI[0][1] + JI[1][0] * JI[1][1] + JI[2][0] * JI[2][1]);
-      sq[2] = weight * (JI[0][0] * JI[0][2] + JI[1][0] * JI[1][2] + JI[2][0] * JI[2][2]);
-      sq[3] = weight * (JI[0][1] * JI[0][1] + JI[1][1] * JI[1][1] + JI[2][1] * JI[2][1]);
-      sq[4] = weight * (JI[0][1] * JI[0][2] + JI[1][1] * JI[1][2] + JI[2][1] * JI[2][2]);
-      sq[5] = weight * (JI[0][2] * JI[0][2] + JI[1][2] * JI[1][2] + JI[2][2] * JI[2][2]);
-      sq[6] = weight * fq;
+      sq[0] = sc * (Cf[0][0] * Cf[0][0] + Cf[1][0] * Cf[1][0] + Cf[2][0] * Cf[2][0]);
+      sq[1] = sc * (Cf[0][0] * Cf[0][1] + Cf[1][0] * Cf[1][1] + Cf[2][0] * Cf[2][1]);
+      sq[2] = sc * (Cf[0][0] * Cf[0][2] + Cf[1][0] * Cf[1][2] + Cf[2][0] * Cf[2][2]);
+      sq[3] = sc * (Cf[0][1] * Cf[0][1] + Cf[1][1] * Cf[1][1] + Cf[2][1] * Cf[2][1]);
+      sq[4] = sc * (Cf[0][1] * Cf[0][2] + Cf[1][1] * Cf[1][2] + Cf[2][1] * Cf[2][2]);
+      sq[5] = sc * (Cf[0][2] * Cf[0][2] + Cf[1][2] * Cf[1][2] + Cf[2][2] * Cf[2][2]);
+      sq[6] = det * wgauss * fq;
     }
     wave_lds_sync();
     // ---- phase B: the rank-192 update on the matrix cores ----
     // The operand loads are issued by hand (ds_read_b64 with immediate offsets, explicit s_waitcnt): left to the compiler, pairs of
     // them become ds_read2_b64, which costs 8 LDS cycles instead of 2 + 2 (MI355X_MICROARCH.md, LDS table) and made the LDS, not
     // the matrix pipe, the bound of this phase.  Double-buffered in registers: the loads of step s+1 fly during the MFMAs of step s.
-    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double acc[MF_NT] = {0, 0, 0, 0, 0, 0, 0};
     if (!(P.debug & 1)) {
-      double Ab[2][8], TD[2][12];
+      double Ab[2][MF_NT], TD[2][12];
 #define MF_LD(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define MF_LOAD_A(p, g, c)                                                                     \
-  _Pragma("unroll") for (int t = 0; t < 8; t++) MF_LD(Ab[p][t], aA[t], ((g) * MF_TS + (c) * MF_TA) * 8)
+  _Pragma("unroll") for (int t = 1; t < MF_NT; t++) MF_LD(Ab[p][t], aA[t], ((g) * MF_TS + (c) * MF_TA) * 8)
 #define MF_LOAD_TD(p, g)                                                                       \
   _Pragma("unroll") for (int k = 0; k < 3; k++) {                                              \
     MF_LD(TD[p][k], aBlo, ((g) * MF_TS + k * MF_TA) * 8);                                      \
@@ -865,8 +870,7 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
   }                                                                                            \
   _Pragma("unroll") for (int k = 0; k < 6; k++) MF_LD(TD[p][6 + k], aD, ((g) * MF_SS + k) * 8)
 #define MF_WAIT_A(p)                                                                           \
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Ab[p][0]), "+v"(Ab[p][1]), "+v"(Ab[p][2]), "+v"(Ab[p][3]), "+v"(Ab[p][4]), "+v"(Ab[p][5]), \
-               "+v"(Ab[p][6]), "+v"(Ab[p][7]))
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Ab[p][1]), "+v"(Ab[p][2]), "+v"(Ab[p][3]), "+v"(Ab[p][4]), "+v"(Ab[p][5]), "+v"(Ab[p][6]))
 #define MF_WAIT_TD(p)                                                                          \
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(TD[p][0]), "+v"(TD[p][1]), "+v"(TD[p][2]), "+v"(TD[p][3]), "+v"(TD[p][4]), "+v"(TD[p][5]), \
                "+v"(TD[p][6]), "+v"(TD[p][7]), "+v"(TD[p][8]), "+v"(TD[p][9]), "+v"(TD[p][10]), "+v"(TD[p][11]))
@@ -889,8 +893,9 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
           }
           const double blo = dd[c][0] * TD[pg][0] + dd[c][1] * TD[pg][1] + dd[c][2] * TD[pg][2];
           const double bhi = dd[c][0] * TD[pg][3] + dd[c][1] * TD[pg][4] + dd[c][2] * TD[pg][5];
+          acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(TD[pg][c], blo, acc[0], 0, 0, 0);      // the four diagonal tiles 0..3
 #pragma unroll
-          for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(Ab[ps][t], t < 4 ? blo : bhi, acc[t], 0, 0, 0);
+          for (int t = 1; t < MF_NT; t++) acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(Ab[ps][t], t < 4 ? blo : bhi, acc[t], 0, 0, 0);
         }
       }
 #undef MF_LD
@@ -913,12 +918,12 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
     wave_lds_sync();          // every lane is done with the phase-A slab: reuse it as Ks[27][29]
     double* Ks = slab;
 #pragma unroll
-    for (int t = 0; t < 8; t++) {   // D layout: row = lane>>4, block = (lane>>2)&3, col = lane&3
-      const int colg = (t < 4) ? blk : 4 + blk, rowg = mf_rowg(t, blk);
+    for (int t = 0; t < MF_NT; t++) {   // D layout: row = lane>>4, block = (lane>>2)&3, col = lane&3
+      const int colg = (t < 4 || blk == 3) ? blk : 4 + blk, rowg = mf_rowg(t, blk);
       const int row = 4 * rowg + kk, col = 4 * colg + r4;
       // diagonal tiles: the (i, j) and (j, i) sums differ in rounding; keep the upper entries and mirror them, so that K_e is
       // symmetric bit for bit like the reference's Jac (products commute, same summation order)
-      const bool live = (t < 4 || blk < 3) && row < NC && col < NC && (rowg != colg || kk <= r4);
+      const bool live = row < NC && col < NC && (rowg != colg || kk <= r4);
       if (live) {
         Ks[row * MF_KS + col] = acc[t];
         if (row != col) Ks[col * MF_KS + row] = acc[t];
@@ -937,13 +942,27 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
       ku += __shfl_xor(ku, 32, 64);
     }
     if (!(P.debug & 2)) {
+      if (P.kstride == 32) {   // padded rows: every store instruction writes two whole 256-byte rows (zeros in the 5 pad entries)
+        // all LDS reads first, slots through v_readlane (no LDS round trip per store), then the stores back to back
+        const int j = lane & 31, hrow = lane >> 5;
+        double kv[14];
 #pragma unroll
-      for (int t0 = 0; t0 < NC * NC; t0 += 64) {
-        const int t = t0 + lane;
-        const int row = (t < NC * NC) ? t / NC : 0;
-        const int j = t - row * NC;
-        const int s = __shfl(sl_cur, row, 64);
-        if (t < NC * NC && s >= 0) P.Kout[(size_t)s * NC + j] = Ks[row * MF_KS + j];
+        for (int p = 0; p < 14; p++) kv[p] = Ks[min(2 * p + hrow, NC - 1) * MF_KS + min(j, NC)];   // column 27 of the staging is unused: any value
+#pragma unroll
+        for (int p = 0; p < 14; p++) {
+          const int s0 = __builtin_amdgcn_readlane(sl_cur, 2 * p), s1 = __builtin_amdgcn_readlane(sl_cur, min(2 * p + 1, NC - 1));
+          const int s = hrow ? s1 : s0;
+          if (2 * p + hrow < NC && s >= 0) P.Kout[(size_t)s * 32 + j] = (j < NC) ? kv[p] : 0.0;
+        }
+      } else {
+#pragma unroll
+        for (int t0 = 0; t0 < NC * NC; t0 += 64) {
+          const int t = t0 + lane;
+          const int row = (t < NC * NC) ? t / NC : 0;
+          const int j = t - row * NC;
+          const int s = __shfl(sl_cur, row, 64);
+          if (t < NC * NC && s >= 0) P.Kout[(size_t)s * NC + j] = Ks[row * MF_KS + j];
+        }
       }
       if (lane < NC && sl_cur >= 0) P.Fout[sl_cur] = -(ku + fsrc);
     }
@@ -1076,7 +1095,7 @@ __global__ __launch_bounds__(256) void k_elem_q2hex_affine(AsmParams P, const do
       Ks[ent[k]] = v;
       const int i = ent[k] / NC, j = ent[k] - i * NC;
       const int s = sl[le][i];
-      if (s >= 0) P.Kout[(size_t)s * NC + j] = v;
+      if (s >= 0) P.Kout[(size_t)s * P.kstride + j] = v;
     }
     __syncthreads();
     if (tid < NC) {
@@ -1191,6 +1210,7 @@ static AsmParams base_params(fh_assembler_t as) {
   P.prog = as->d_prog;
   P.prog_consts = as->d_prog_consts;
   P.nprog = as->nprog;
+  P.kstride = as->nc;
   return P;
 }
 
@@ -1283,7 +1303,8 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
     FH_TRY(up((void**)&as->d_adj_ptr, aptr.data(), aptr.size() * sizeof(int)));
     FH_TRY(up((void**)&as->d_adj_ei, aei.data(), aei.size() * sizeof(int)));
     FH_CHECK_HIP(hipMalloc(&as->d_rowmap, std::max<size_t>((size_t)aei.size() * nc, 1)));
-    FH_CHECK_HIP(hipMalloc(&as->d_Kbuf, std::max<size_t>((size_t)aei.size() * nc, 1) * sizeof(double)));
+    as->kstride = (nc == 27 && ctx->assemble_kpad) ? 32 : nc;
+    FH_CHECK_HIP(hipMalloc(&as->d_Kbuf, std::max<size_t>((size_t)aei.size() * as->kstride, 1) * sizeof(double)));
     FH_CHECK_HIP(hipMalloc(&as->d_Fbuf, std::max<size_t>(aei.size(), 1) * sizeof(double)));
     FH_TRY(dispatch_rows(as, A, nullptr, true));
     FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -1401,6 +1422,7 @@ static int assemble_poisson_core(fh_assembler_t as, fh_vec_t sol, int source_kin
     P.elems = as->d_iota;
     P.nelems = as->nel;
     P.Kout = as->d_Kbuf;
+    P.kstride = as->kstride;
     P.Fout = as->d_Fbuf;
     P.slot = as->d_slot;
     P.debug = as->ctx->asm_debug;
