@@ -441,13 +441,14 @@ __global__ __launch_bounds__(256) void k_row_assemble(const int* __restrict__ ro
       }
     }
   } else {
-    // batches of 4 adjacent elements: all loads of a batch are issued before the (ordered) LDS accumulation
-    for (int ab = a0; ab < a1; ab += 4) {
-      double k[4];
-      int pp[4];
-      double f[4];
+    // batches of RB adjacent elements: all loads of a batch are issued before the (ordered) LDS accumulation
+    constexpr int RB = 4;
+    for (int ab = a0; ab < a1; ab += RB) {
+      double k[RB];
+      int pp[RB];
+      double f[RB];
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
+      for (int t = 0; t < RB; t++) {
         const int a = ab + t;
         k[t] = 0.0;
         pp[t] = 0;
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(256) void k_row_assemble(const int* __restrict__ ro
         }
       }
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
+      for (int t = 0; t < RB; t++) {
         if (ab + t < a1 && lane < NC) acc[sub][pp[t]] += k[t];   // distinct slots within one element row; in-order LDS per wave
         facc += f[t];
       }
