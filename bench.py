@@ -62,6 +62,14 @@ def main():
     if (world > 1 and os.environ.get("FEMUS_BENCH_DD", "1") != "0") or os.environ.get("FEMUS_BENCH_FORCE_DD") == "1":
         try:
             transport = os.environ.get("FEMUS_BENCH_TRANSPORT", "rccl")     # "host": host-staged exchange (debugging, shared GPUs)
+            if transport == "rccl" and world > 1 and os.environ.get("FEMUS_BENCH_PREFLIGHT", "1") != "0":
+                # a ring exchange + all-reduce through fh_halo_* in a child process first: a RCCL path that fails or HANGS on this
+                # machine must end in the reported fallback below, not in a hung bench
+                from femus_amd import rccl_preflight
+                good, msg = rccl_preflight.run(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                                               int(os.environ.get("MASTER_PORT", "29500")) + 100, device)
+                if not all(comm.allgather_obj(bool(good))):
+                    raise RuntimeError(msg if not good else "RCCL preflight failed on another rank")
             pb = dd.DistributedPoisson(ctx, comm, world, rank, nb=args.coarse, nlevels=args.levels, omega=2. / 3., npre=2, npost=2,
                                        transport=transport)
             parallelism = ("mesh domain decomposition, box split %dx%dx%d (METIS unavailable), one partition per GPU, ghost DOFs "

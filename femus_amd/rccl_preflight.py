@@ -1,0 +1,66 @@
+"""RCCL preflight for multi-rank runs: a ring ghost exchange and an all-reduce through the library's own fh_halo_* calls, in a
+child process of each rank, so that a launcher (bench.py) can fall back to independent problems when the RCCL path fails OR HANGS on
+the machine at hand instead of hanging itself.
+
+    python -m femus_amd.rccl_preflight RANK WORLD ADDR PORT DEVICE        (exit code 0 = data arrived and is correct)
+
+`run(rank, world, addr, port, device, timeout)` starts that command, waits at most `timeout` seconds, kills exactly the child it
+started if it is still running, and returns (ok, message)."""
+import os
+import subprocess
+import sys
+
+
+def _child(rank, world, addr, port, device):
+    import numpy as np
+    from . import capi, Context
+    from .dd import SocketComm
+    comm = SocketComm(rank, world, addr, port, timeout=60.0)
+    ctx = Context(device)
+    uid = comm.bcast_obj(capi.Halo.unique_id() if rank == 0 else None)
+    n = 1024
+    nxt, prv = (rank + 1) % world, (rank - 1) % world
+    send_counts = np.zeros(world, dtype=np.int32)
+    recv_counts = np.zeros(world, dtype=np.int32)
+    send_counts[nxt] = n
+    recv_counts[prv] = n
+    halo = capi.Halo(ctx, rank, world, uid, send_counts, np.arange(n, dtype=np.int32), recv_counts)
+    x = ctx.vector(2 * n, n, 0, np.arange(n, 2 * n, dtype=np.int32))
+    x.upload(1000.0 * rank + np.arange(n))
+    halo.update(x)
+    # read the ghosts through an operator with one entry per row in the ghost columns: y_i = x_ghost[i]
+    A = ctx.matrix_csr(n, 2 * n, np.arange(n + 1, dtype=np.int32), np.arange(n, 2 * n, dtype=np.int32), np.ones(n))
+    y = ctx.vector(n)
+    y.matrix_mult(x, A)
+    got = y.to_numpy()
+    ok = np.array_equal(got, 1000.0 * prv + np.arange(n))
+    s = halo.allreduce_sum(np.array([1.0, float(rank)]))
+    ok = ok and s[0] == world and s[1] == world * (world - 1) / 2
+    ctx.sync()
+    oks = comm.allgather_obj(bool(ok))
+    halo.destroy()
+    comm.close()
+    return 0 if all(oks) else 3
+
+
+def run(rank, world, addr, port, device, timeout=120.0):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    p = subprocess.Popen([sys.executable, "-m", "femus_amd.rccl_preflight", str(rank), str(world), addr, str(port), str(device)],
+                         env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    try:
+        out, _ = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()                       # exactly the child started above
+        p.communicate()
+        return False, "RCCL preflight did not finish within %.0f s" % timeout
+    if p.returncode == 0:
+        return True, "ok"
+    tail = out.decode(errors="replace").strip().splitlines()[-1:] if out else []
+    return False, "RCCL preflight failed (exit %d)%s" % (p.returncode, ": " + tail[0][:160] if tail else "")
+
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    sys.exit(_child(int(a[0]), int(a[1]), a[2], int(a[3]), int(a[4])))
