@@ -257,14 +257,16 @@ __global__ __launch_bounds__(256) void k_csr_to_dense(const int* __restrict__ ro
 // register blocks, operands staged in LDS), and the pivot-column panel -C D^-1.  2 n^3 flops in n/NB steps of 5 launches
 // instead of 3 n launches of rank-1 updates.
 // ------------------------------------------------------------------------------------------------
-constexpr int GJ_NB = 32;   // pivot block (64 was measured slower: the serial pivot-block inversion and the panels grow faster than the update shrinks)
+constexpr int GJ_NB = 32;   // pivot block (64 measured slower twice, also with the MFMA update: pivot-block inversion 34 -> 192 us, row panel 38 -> 144 us per step)
 constexpr int GJ_KS = 32;   // K slice of the update staged in LDS at a time
 
-__global__ __launch_bounds__(256) void k_gjb_save_panel(const double* __restrict__ D, double* __restrict__ Cp, int n, int kb, int nb) {
+__global__ __launch_bounds__(256) void k_gjb_save_panel(const double* __restrict__ D, double* __restrict__ Cp, double* __restrict__ CpT, int n, int kb, int nb) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= n * nb) return;
   const int i = idx / nb, t = idx % nb;
-  Cp[(size_t)i * GJ_NB + t] = D[(size_t)i * n + kb + t];
+  const double v = D[(size_t)i * n + kb + t];
+  Cp[(size_t)i * GJ_NB + t] = v;
+  CpT[(size_t)t * n + i] = v;
 }
 
 __global__ __launch_bounds__(256) void k_gjb_pivot(const double* __restrict__ D, double* __restrict__ Dinv, int n, int kb, int nb) {
@@ -362,6 +364,56 @@ __global__ __launch_bounds__(256) void k_gjb_update(double* __restrict__ D, cons
       D[(size_t)i * n + j] -= acc[a][b2];
     }
   }
+}
+
+// the same update on the FP64 matrix cores (v_mfma_f64_16x16x4): 64 x 64 output tile per workgroup, 32 x 32 per wave as 2 x 2
+// MFMA tiles, K slices of 32 staged in LDS k-major (row stride 80 doubles = 16 mod 32: conflict-free fragment reads; A fragment:
+// lane = 16 k + i, B fragment: lane = 16 k + j, C: col = lane & 15, row = (lane >> 4) + 4 reg).  CpT = the saved column panel
+// transposed (t-major), so that both operands load coalesced.
+typedef double gj_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_gjb_update_mfma(double* __restrict__ D, const double* __restrict__ CpT, int n, int kb, int nb) {
+  constexpr int LD = 80;
+  __shared__ double Cs[GJ_KS][LD], Rs[GJ_KS][LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
+  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+  const int kk = lane >> 4, li = lane & 15;
+  gj_d4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = gj_d4{0.0, 0.0, 0.0, 0.0};
+  for (int t0 = 0; t0 < nb; t0 += GJ_KS) {
+    for (int idx = tid; idx < GJ_KS * 64; idx += 256) {
+      const int k = idx >> 6, c = idx & 63, t = t0 + k;
+      Cs[k][c] = (ti + c < n && t < nb) ? CpT[(size_t)t * n + ti + c] : 0.0;
+      Rs[k][c] = (tj + c < n && t < nb) ? D[(size_t)(kb + t) * n + tj + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k0 = 0; k0 < GJ_KS; k0 += 4) {
+      const double a0 = Cs[k0 + kk][wi + li], a1 = Cs[k0 + kk][wi + 16 + li];
+      const double b0 = Rs[k0 + kk][wj + li], b1 = Rs[k0 + kk][wj + 16 + li];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int i = ti + wi + a * 16 + kk + 4 * r;
+      if (i >= n || (i >= kb && i < kb + nb)) continue;
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const int j = tj + wj + b * 16 + li;
+        if (j >= n || (j >= kb && j < kb + nb)) continue;
+        D[(size_t)i * n + j] -= acc[a][b][r];
+      }
+    }
 }
 
 // pivot columns of all other rows: A[i, kb+t] <- - sum_s Cp[i,s] * Dinv[s,t]
@@ -628,16 +680,18 @@ static int coarse_factor(fh_mg_t mg) {
   FH_CHECK_HIP(hipMemsetAsync(mg->d_ainv, 0, (size_t)n * n * sizeof(double), c->stream));
   hipLaunchKernelGGL(k_csr_to_dense, dim3(n), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, mg->d_ainv, n);
   double* colk = nullptr;   // column panel (n x NB) + pivot inverse (NB x NB)
-  FH_CHECK_HIP(hipMalloc(&colk, ((size_t)n * GJ_NB + GJ_NB * GJ_NB) * sizeof(double)));
+  FH_CHECK_HIP(hipMalloc(&colk, ((size_t)2 * n * GJ_NB + GJ_NB * GJ_NB) * sizeof(double)));
   double* Cp = colk;
-  double* Dinv = colk + (size_t)n * GJ_NB;
+  double* CpT = colk + (size_t)n * GJ_NB;
+  double* Dinv = colk + (size_t)2 * n * GJ_NB;
   const int nt = fh_div_up(n, 64);
   for (int kb = 0; kb < n; kb += GJ_NB) {
     const int nb = std::min(GJ_NB, n - kb);
-    hipLaunchKernelGGL(k_gjb_save_panel, dim3(fh_div_up((int64_t)n * nb, 256)), dim3(256), 0, c->stream, mg->d_ainv, Cp, n, kb, nb);
+    hipLaunchKernelGGL(k_gjb_save_panel, dim3(fh_div_up((int64_t)n * nb, 256)), dim3(256), 0, c->stream, mg->d_ainv, Cp, CpT, n, kb, nb);
     hipLaunchKernelGGL(k_gjb_pivot, dim3(1), dim3(256), 0, c->stream, mg->d_ainv, Dinv, n, kb, nb);
     hipLaunchKernelGGL(k_gjb_row_panel, dim3(fh_div_up(n, 64)), dim3(64), 0, c->stream, mg->d_ainv, Dinv, Cp, n, kb, nb);
-    hipLaunchKernelGGL(k_gjb_update, dim3(nt, nt), dim3(256), 0, c->stream, mg->d_ainv, Cp, n, kb, nb);
+    if (c->gj_mfma) hipLaunchKernelGGL(k_gjb_update_mfma, dim3(nt, nt), dim3(256), 0, c->stream, mg->d_ainv, CpT, n, kb, nb);
+    else hipLaunchKernelGGL(k_gjb_update, dim3(nt, nt), dim3(256), 0, c->stream, mg->d_ainv, Cp, n, kb, nb);
     hipLaunchKernelGGL(k_gjb_col_panel, dim3(fh_div_up((int64_t)n * nb, 256)), dim3(256), 0, c->stream, mg->d_ainv, Dinv, Cp, n, kb, nb);
   }
   FH_CHECK_HIP(hipGetLastError());

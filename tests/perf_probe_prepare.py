@@ -1,8 +1,10 @@
-"""timing probe (not a test): hierarchy preparation (Galerkin chain, penalty rows, smoother / coarse setup) at config C2"""
+"""timing probe (not a test): hierarchy preparation (Galerkin chain, penalty rows, smoother / coarse setup) at config C2
+usage: perf_probe_prepare.py [coarse n] [gj_mfma values ...]"""
 import sys
 import time
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import femus_amd
 from femus_amd.poisson import PoissonMG
 
@@ -12,10 +14,12 @@ pb = PoissonMG(ctx, n, n, n, 4).init()
 pb.assemble()
 pb.prepare()
 ctx.sync()
-for _ in range(3):
-    pb.assemble()
-    ctx.sync()
-    t = time.time()
-    pb.prepare()
-    ctx.sync()
-    print("prepare ms", (time.time() - t) * 1e3)
+for gj in [int(v) for v in sys.argv[2:]] or [1]:
+    ctx.set_option("gj_mfma", gj)
+    for _ in range(3):
+        pb.assemble()
+        ctx.sync()
+        t = time.time()
+        pb.prepare()
+        ctx.sync()
+        print("gj_mfma %d prepare ms %.2f" % (gj, (time.time() - t) * 1e3))
