@@ -998,11 +998,12 @@ static int launch_mfma_one(fh_assembler_t as, const AsmParams& P) {
   return 0;
 }
 
-template <int NW>
-static int launch_mfma(fh_assembler_t as, const AsmParams& P) {
-  if (P.source_kind == 4) return launch_mfma_one<2, NW>(as, P);
-  if (P.source_kind != 0) return launch_mfma_one<1, NW>(as, P);
-  return launch_mfma_one<0, NW>(as, P);
+// waves per workgroup: the option for the constant source; the closed-form sources need more registers (no spills up to 8 waves)
+// and the expression evaluator with its operand stack more still (4 waves: 512 registers per lane)
+static int launch_mfma(fh_assembler_t as, const AsmParams& P, int nw) {
+  if (P.source_kind == 4) return launch_mfma_one<2, 4>(as, P);
+  if (P.source_kind != 0) return nw <= 4 ? launch_mfma_one<1, 4>(as, P) : launch_mfma_one<1, 8>(as, P);
+  return nw <= 4 ? launch_mfma_one<0, 4>(as, P) : nw <= 8 ? launch_mfma_one<0, 8>(as, P) : launch_mfma_one<0, 12>(as, P);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1140,11 +1141,7 @@ static int launch_assemble(fh_assembler_t as, const AsmParams& P) {
 static int dispatch_assemble(fh_assembler_t as, const AsmParams& P) {
   if (as->dim == 3 && as->nc == 27 && P.Kout && as->ctx->assemble_mfma && as->d_mfT && P.ng == 64) {
     if (P.nelems <= 0) return 0;
-    switch (as->ctx->assemble_mfma) {
-      case 4: return launch_mfma<4>(as, P);
-      case 8: return launch_mfma<8>(as, P);
-      default: return launch_mfma<12>(as, P);
-    }
+    return launch_mfma(as, P, as->ctx->assemble_mfma);
   }
   if (as->dim == 3 && as->nc == 27 && P.Kout && as->ctx->assemble_sym) {
     if (P.nelems <= 0) return 0;
