@@ -722,8 +722,10 @@ __global__ __launch_bounds__(64) void k_elem_q2hex_sym(AsmParams P) {
 //   The lane (k, b, r) of a k-step works on Gauss point q0 + 16 k.  It forms B for its own node li = 4 b + r (column group b,
 //   "lo") and for node 16 + li (column group 4 + b, "hi"; block 3 has no such node and takes column group 3 again) and reads A
 //   for the row group the schedule gives its block:
-//       lo-type (B = lo, columns 0,1,2,3):  t0: rows (0,1,2,3)  t1: (2,0,1,0)  t2: (5,4,4,1)  t3: (6,6,5,2)
-//       hi-type (B = hi, columns 4,5,6,3):  t4: rows (4,5,6,4)  t5: (6,4,5,5)  t6: (0,1,2,6)
+//       lo-type (B = lo, columns 0,1,2,3):  t0: rows (0,1,2,3)  t1: (2,0,1,0)  t2: (5,4,4,2)  t3: (6,6,5,4)
+//       hi-type (B = hi, columns 4,5,6,3):  t4: rows (4,5,6,5)  t5: (6,4,5,6)  t6: (0,1,2,1)
+//   (no instruction has row groups g and g + 4 in different blocks: the two Gauss points of a half-wave sit 16 doubles apart
+//   mod 32 in LDS, so such a pair would be a 2-way bank conflict of the A-operand read)
 //   28 slots = the 28 unordered tile pairs, each exactly once (an orientation of the pair graph with in-degree 4,4,4,7,3,3,3;
 //   a tile with row > column is the transpose of the needed one).  t0 holds the diagonal tiles 0..3: its A operand is the lane's
 //   own table value.
@@ -744,8 +746,8 @@ constexpr int MF_WAVE = MF_SLAB + 1 + MF_XS;   // 892 doubles, even: xs stays 16
 constexpr size_t mf_lds_bytes(int nw) { return (size_t)(64 * MF_TS + 64 * MF_PS + nw * MF_WAVE) * sizeof(double); }
 // row group of block b in instruction t: 3 bits each
 constexpr unsigned long long mf_rows(int b0, int b1, int b2, int b3) { return (unsigned long long)(b0 | (b1 << 3) | (b2 << 6) | (b3 << 9)); }
-constexpr unsigned long long MF_SCHED_LO = mf_rows(0, 1, 2, 3) | (mf_rows(2, 0, 1, 0) << 12) | (mf_rows(5, 4, 4, 1) << 24) | (mf_rows(6, 6, 5, 2) << 36);
-constexpr unsigned long long MF_SCHED_HI = mf_rows(4, 5, 6, 4) | (mf_rows(6, 4, 5, 5) << 12) | (mf_rows(0, 1, 2, 6) << 24);
+constexpr unsigned long long MF_SCHED_LO = mf_rows(0, 1, 2, 3) | (mf_rows(2, 0, 1, 0) << 12) | (mf_rows(5, 4, 4, 2) << 24) | (mf_rows(6, 6, 5, 4) << 36);
+constexpr unsigned long long MF_SCHED_HI = mf_rows(4, 5, 6, 5) | (mf_rows(6, 4, 5, 6) << 12) | (mf_rows(0, 1, 2, 1) << 24);
 constexpr int MF_NT = 7;              // MFMAs per k-step
 
 __device__ __forceinline__ int mf_rowg(int t, int blk) { return (int)(((t < 4 ? MF_SCHED_LO : MF_SCHED_HI) >> (12 * (t & 3) + 3 * blk)) & 7); }
