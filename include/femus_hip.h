@@ -49,7 +49,11 @@ void* fh_stream(fh_ctx_t ctx);                       /* hipStream_t of the compu
 int fh_timer_start(fh_ctx_t ctx);
 int fh_timer_stop(fh_ctx_t ctx, double* milliseconds);
 /* runtime tuning knobs (the reference honours the PETSc options DB, 03_solvers/LinearEquationSolverPetsc.cpp:251-254);
- * names: "spmv_tile", "spmv_xcd_remap", "assemble_emap" ... returns non-zero for unknown names */
+ * names (default): "spmv_tile" (2048), "spmv_xcd_remap" (32), "spmv_kernel" (3), "assemble_two_pass" (1), "assemble_emap" (1),
+ * "assemble_mfma" (12: HEX27/Q2 element matrices on the FP64 matrix cores, value = waves per workgroup, 0 = vector kernel),
+ * "assemble_kpad" (1: element rows of the two-pass buffer padded to 256 bytes; read when an assembler is created),
+ * "assemble_sym" (1), "assemble_affine" (0, see fh_assembler_affine_count), "gj_mfma" (1: coarse dense inverse updates on the
+ * matrix cores), "spgemm_slot_map" (1), "use_graph" (1), "asm_debug" (0).  Returns non-zero for unknown names */
 int fh_set_option(fh_ctx_t ctx, const char* name, double value);
 
 /* ---- vectors: NumericVector (src/03_algebra/00_vectors/NumericVector.hpp:51-353, PetscVector.cpp) ----
