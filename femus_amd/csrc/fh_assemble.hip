@@ -988,10 +988,11 @@ template <int SRC, int NW>
 static int launch_mfma_one(fh_assembler_t as, const AsmParams& P) {
   constexpr size_t lds = mf_lds_bytes(NW);
   static_assert(lds <= 160 * 1024, "k_elem_q2hex_mfma: LDS budget");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};      // per device: the attribute belongs to the function on the current device
+  const int dev = as->ctx->device & 63;
+  if (!attr_set[dev]) {
     FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_elem_q2hex_mfma<SRC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set[dev] = true;
   }
   const int per_cu = std::max(1, (int)((size_t)160 * 1024 / lds));
   const int grid = std::max(1, std::min(fh_div_up(P.nelems, NW), as->ctx->num_cu * per_cu));
