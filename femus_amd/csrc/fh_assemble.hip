@@ -41,6 +41,7 @@ struct fh_assembler_s {
   unsigned char* d_rowmap = nullptr;   // [nadj*nc] slot of (element row, j) inside the CSR row
   int* d_slot = nullptr;         // [nel*nc] adjacency slot of (element, local row), -1 when the row is not in the matrix
   double* d_Kbuf = nullptr;      // [nadj*kstride] element rows in row-gather order
+  size_t kbuf_bytes = 0;
   int kstride = 27;              // doubles per element row in d_Kbuf (nc, or 32 for HEX27/Q2: whole 64-byte lines per row)
   double* d_Fbuf = nullptr;      // [nadj]
   bool two_pass = false;
@@ -944,18 +945,36 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
       }
       ku += __shfl_xor(ku, 32, 64);
     }
+    // the next element's nodes: this consumes the prefetched registers (a vmcnt wait) BEFORE the hand-issued stores below, which
+    // the compiler's wait-count bookkeeping does not see; LDS operations of one wave execute in order, so the reads of xs above
+    // are done before these writes
+    if (lane < NC) {
+      xs[lane * 4 + 0] = nx0;
+      xs[lane * 4 + 1] = nx1;
+      xs[lane * 4 + 2] = nx2;
+      xs[lane * 4 + 3] = nu;
+    }
     if (!(P.debug & 2)) {
-      if (P.kstride == 32) {   // padded rows: every store instruction writes two whole 256-byte rows (zeros in the 5 pad entries)
-        // all LDS reads first, slots through v_readlane (no LDS round trip per store), then the stores back to back
+      if (P.kstride == 32) {   // padded rows: a half-wave stores one whole 256-byte row
+        // all LDS reads first; slots through v_readlane into scalar registers, and the stores written by hand so that each
+        // half-wave stores its row off a SCALAR base address (address arithmetic on the scalar unit; left to the compiler every
+        // store cost 5-9 vector instructions).  The 5 pad entries of a row receive whatever follows in the staging: the row pass
+        // never reads them.
         const int j = lane & 31, hrow = lane >> 5;
+        const unsigned joff = (unsigned)j * 8u;
         double kv[14];
 #pragma unroll
-        for (int p = 0; p < 14; p++) kv[p] = Ks[min(2 * p + hrow, NC - 1) * MF_KS + min(j, NC)];   // column 27 of the staging is unused: any value
+        for (int p = 0; p < 14; p++) kv[p] = Ks[min(2 * p + hrow, NC - 1) * MF_KS + j];
 #pragma unroll
         for (int p = 0; p < 14; p++) {
           const int s0 = __builtin_amdgcn_readlane(sl_cur, 2 * p), s1 = __builtin_amdgcn_readlane(sl_cur, min(2 * p + 1, NC - 1));
-          const int s = hrow ? s1 : s0;
-          if (2 * p + hrow < NC && s >= 0) P.Kout[(size_t)s * 32 + j] = (j < NC) ? kv[p] : 0.0;
+          const double* b0 = P.Kout + (size_t)s0 * 32;
+          const double* b1 = P.Kout + (size_t)s1 * 32;
+          if (hrow == 0) {
+            if (s0 >= 0) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(joff), "v"(kv[p]), "s"(b0) : "memory");
+          } else if (2 * p + 1 < NC) {
+            if (s1 >= 0) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(joff), "v"(kv[p]), "s"(b1) : "memory");
+          }
         }
       } else {
 #pragma unroll
@@ -969,14 +988,7 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
       }
       if (lane < NC && sl_cur >= 0) P.Fout[sl_cur] = -(ku + fsrc);
     }
-    wave_lds_sync();          // Ks is the next element's phase-A slab, xs the next element's nodes
-    if (lane < NC) {
-      xs[lane * 4 + 0] = nx0;
-      xs[lane * 4 + 1] = nx1;
-      xs[lane * 4 + 2] = nx2;
-      xs[lane * 4 + 3] = nu;
-    }
-    wave_lds_sync();
+    wave_lds_sync();          // Ks is the next element's phase-A slab, xs holds the next element's nodes
     sl_cur = sl_n;
     dof_n = dof_nn;
     e_n = e_nn;
@@ -1305,7 +1317,8 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
     FH_TRY(up((void**)&as->d_adj_ei, aei.data(), aei.size() * sizeof(int)));
     FH_CHECK_HIP(hipMalloc(&as->d_rowmap, std::max<size_t>((size_t)aei.size() * nc, 1)));
     as->kstride = (nc == 27 && ctx->assemble_kpad) ? 32 : nc;
-    FH_CHECK_HIP(hipMalloc(&as->d_Kbuf, std::max<size_t>((size_t)aei.size() * as->kstride, 1) * sizeof(double)));
+    as->kbuf_bytes = std::max<size_t>((size_t)aei.size() * as->kstride, 1) * sizeof(double);
+    FH_CHECK_HIP(hipMalloc(&as->d_Kbuf, as->kbuf_bytes));
     FH_CHECK_HIP(hipMalloc(&as->d_Fbuf, std::max<size_t>(aei.size(), 1) * sizeof(double)));
     FH_TRY(dispatch_rows(as, A, nullptr, true));
     FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
