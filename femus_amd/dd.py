@@ -348,11 +348,16 @@ class SocketComm:
             conns = {}
             while len(conns) < size - 1:
                 c, _ = srv.accept()
-                c.settimeout(timeout)
-                hello = self._recv(c)
-                if not (isinstance(hello, tuple) and hello[0] == self.MAGIC):
+                try:                                  # a stranger on this port must not stall or break the rendezvous
+                    c.settimeout(10.0)
+                    hello = self._recv(c)
+                    if not (isinstance(hello, tuple) and hello[0] == self.MAGIC):
+                        raise RuntimeError("not a rank of this job")
+                    self._send(c, (self.MAGIC, "ack"))
+                except Exception:
                     c.close()
                     continue
+                c.settimeout(timeout)
                 conns[hello[1]] = c
             self.conns = [conns[r] for r in range(1, size)]
             srv.close()
@@ -361,13 +366,20 @@ class SocketComm:
             sock = None
             while sock is None:
                 for p in ports:
+                    s = None
                     try:
                         s = socket.create_connection((addr, p), timeout=5.0)
-                        s.settimeout(timeout)
+                        s.settimeout(10.0)
                         self._send(s, (self.MAGIC, rank))
+                        ack = self._recv(s)           # only rank 0 of this job answers with the magic: any other listener is skipped
+                        if not (isinstance(ack, tuple) and ack[0] == self.MAGIC):
+                            raise OSError("foreign listener")
+                        s.settimeout(timeout)
                         sock = s
                         break
-                    except OSError:
+                    except Exception:
+                        if s is not None:
+                            s.close()
                         continue
                 if sock is None:
                     if time.time() - t0 > timeout:
