@@ -53,6 +53,8 @@ struct fh_assembler_s {
   // matrix-core element kernel (k_elem_q2hex_mfma): reference gradients T[q][c][n] (q-stride 85, c-stride 28, zero padded) and
   // shape values Phi[q][n] (stride 33)
   double *d_mfT = nullptr, *d_mfPhi = nullptr;
+  double* d_mfSFc = nullptr;     // sum-factorised map Jacobian: per-lane 1-D shape values [18][64] (null: tables are not tensor products)
+  int* d_mfSFi = nullptr;        // ... and per-lane LDS offsets [7][64]
   // source term given as a compiled expression (fh_expr): device copy of the program of the expression last used
   int* d_prog = nullptr;
   double* d_prog_consts = nullptr;
@@ -744,7 +746,8 @@ constexpr int MF_TS = 85, MF_TA = 28, MF_PS = 33, MF_SS = 7, MF_KS = 29;
 constexpr int MF_SLAB = 27 * MF_KS;   // 783 doubles per wave: phase-A results (64 x 7), later the 27 x 29 staging of K_e
 constexpr int MF_XS = 27 * 4;         // per wave: (x, y, z, u) of the element's nodes
 constexpr int MF_WAVE = MF_SLAB + 1 + MF_XS;   // 892 doubles, even: xs stays 16-byte aligned
-constexpr size_t mf_lds_bytes(int nw) { return (size_t)(64 * MF_TS + 64 * MF_PS + nw * MF_WAVE) * sizeof(double); }
+constexpr int MF_SF = 18 * 64;        // per-lane 1-D shape values of the sum-factorised Jacobian
+constexpr size_t mf_lds_bytes(int nw) { return (size_t)(64 * MF_TS + 64 * MF_PS + MF_SF + nw * MF_WAVE) * sizeof(double); }
 // row group of block b in instruction t: 3 bits each
 constexpr unsigned long long mf_rows(int b0, int b1, int b2, int b3) { return (unsigned long long)(b0 | (b1 << 3) | (b2 << 6) | (b3 << 9)); }
 constexpr unsigned long long MF_SCHED_LO = mf_rows(0, 1, 2, 3) | (mf_rows(2, 0, 1, 0) << 12) | (mf_rows(5, 4, 4, 2) << 24) | (mf_rows(6, 6, 5, 4) << 36);
@@ -754,17 +757,26 @@ constexpr int MF_NT = 7;              // MFMAs per k-step
 __device__ __forceinline__ int mf_rowg(int t, int blk) { return (int)(((t < 4 ? MF_SCHED_LO : MF_SCHED_HI) >> (12 * (t & 3) + 3 * blk)) & 7); }
 
 template <int SRC, int NW>
-__global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const double* __restrict__ Tg, const double* __restrict__ Phig) {
+__global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const double* __restrict__ Tg, const double* __restrict__ Phig, const double* __restrict__ SFc,
+                                                          const int* __restrict__ SFi) {
   constexpr int NC = 27, DIM = 3;
   extern __shared__ __attribute__((aligned(16))) double mf_smem[];
   double* T = mf_smem;
   double* Phi = T + 64 * MF_TS;
   for (int k = threadIdx.x; k < 64 * MF_TS; k += NW * 64) T[k] = Tg[k];
   for (int k = threadIdx.x; k < 64 * MF_PS; k += NW * 64) Phi[k] = Phig[k];
+  double* SFl = Phi + 64 * MF_PS;                         // [18][64] 1-D shape values per lane (sum factorisation)
+  if (SFc)
+    for (int k = threadIdx.x; k < MF_SF; k += NW * 64) SFl[k] = SFc[k];
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double* slab = Phi + 64 * MF_PS + wave * MF_WAVE;
+  double* slab = SFl + MF_SF + wave * MF_WAVE;
+  int sfi_x[3] = {0, 0, 0}, sfi_b1 = 0, sfi_b2 = 0, sfi_bv = 0, sfi_b3 = 0;
+  if (SFc) {
+    sfi_x[0] = SFi[lane]; sfi_x[1] = SFi[64 + lane]; sfi_x[2] = SFi[128 + lane];
+    sfi_b1 = SFi[192 + lane]; sfi_b2 = SFi[256 + lane]; sfi_bv = SFi[320 + lane]; sfi_b3 = SFi[384 + lane];
+  }
   double* xs = slab + MF_SLAB + 1;
   const int kk = lane >> 4, li = lane & 15, blk = (lane >> 2) & 3, r4 = lane & 3;
   const int ln = lane < NC ? lane : 0;
@@ -813,17 +825,78 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
       const int q = lane;
       double J[DIM][DIM] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, xg[DIM] = {0, 0, 0};
       const double* Tq = T + q * MF_TS;
+      if (SFc) {
+        // sum factorisation: J_q = sum_abc dl_a(q1) l_b(q2) l_c(q3) x_abc ... in three contractions through LDS (U, V alias
+        // the slab, which is written only after the last read below):
+        //   stage 1, lane = (q1, b, c) < 36:    U [b][c][q1] = sum_a l_a(q1) x_abc,   U'[b][c][q1] = sum_a dl_a(q1) x_abc
+        //   stage 2, lane = (c, q1, q2) < 48:   V [c][q12]   = sum_b l_b(q2) U,  Veta = sum_b dl_b(q2) U,  Vxi = sum_b l_b(q2) U'
+        //   stage 3, lane = Gauss point:        J[0] = sum_c l_c(q3) Vxi,  J[1] = sum_c l_c(q3) Veta,  J[2] = sum_c dl_c(q3) V
+        // 72 FMAs and ~64 LDS operations per lane instead of 243 and 135; every vector is (x, y, z, pad).
+        double* U = slab;                  // [2][3][3][4][4] = 288 doubles
+        double* V = slab + 288;            // [3][3][16][4]   = 432 doubles
+        if (lane < 36) {
+          double u[2][3] = {{0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            const double* xn = xs + sfi_x[a];
+            const double2 xa = *reinterpret_cast<const double2*>(xn);
+            const double x2 = xn[2];
+            const double la = SFl[a * 64 + lane], da = SFl[(3 + a) * 64 + lane];
+            u[0][0] += la * xa.x; u[0][1] += la * xa.y; u[0][2] += la * x2;
+            u[1][0] += da * xa.x; u[1][1] += da * xa.y; u[1][2] += da * x2;
+          }
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            *reinterpret_cast<double2*>(U + k * 144 + sfi_b1) = make_double2(u[k][0], u[k][1]);
+            U[k * 144 + sfi_b1 + 2] = u[k][2];
+          }
+        }
+        wave_lds_sync();
+        if (lane < 48) {
+          double v[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+          for (int b = 0; b < 3; b++) {
+            const double* u0 = U + b * 48 + sfi_b2;
+            const double* u1 = u0 + 144;
+            const double2 ua = *reinterpret_cast<const double2*>(u0), va = *reinterpret_cast<const double2*>(u1);
+            const double u2 = u0[2], v2 = u1[2];
+            const double lb = SFl[(6 + b) * 64 + lane], db = SFl[(9 + b) * 64 + lane];
+            v[0][0] += lb * ua.x; v[0][1] += lb * ua.y; v[0][2] += lb * u2;     // V
+            v[1][0] += db * ua.x; v[1][1] += db * ua.y; v[1][2] += db * u2;     // Veta
+            v[2][0] += lb * va.x; v[2][1] += lb * va.y; v[2][2] += lb * v2;     // Vxi
+          }
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            *reinterpret_cast<double2*>(V + k * 192 + sfi_bv) = make_double2(v[k][0], v[k][1]);
+            V[k * 192 + sfi_bv + 2] = v[k][2];
+          }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const double lc = SFl[(12 + c) * 64 + lane], dc = SFl[(15 + c) * 64 + lane];
+          const double* v0 = V + c * 64 + sfi_b3;
+          const double2 a0 = *reinterpret_cast<const double2*>(v0), a1 = *reinterpret_cast<const double2*>(v0 + 192),
+                        a2 = *reinterpret_cast<const double2*>(v0 + 384);
+          const double z0 = v0[2], z1 = v0[192 + 2], z2 = v0[384 + 2];
+          J[0][0] += lc * a2.x; J[0][1] += lc * a2.y; J[0][2] += lc * z2;
+          J[1][0] += lc * a1.x; J[1][1] += lc * a1.y; J[1][2] += lc * z1;
+          J[2][0] += dc * a0.x; J[2][1] += dc * a0.y; J[2][2] += dc * z0;
+          if (SRC != 0) { xg[0] += lc * a0.x; xg[1] += lc * a0.y; xg[2] += lc * z0; }
+        }
+      } else {
 #pragma unroll 9
-      for (int n = 0; n < NC; n++) {
-        const double2 xa = *reinterpret_cast<const double2*>(xs + n * 4);   // broadcast reads
-        const double x0 = xa.x, x1 = xa.y, x2 = xs[n * 4 + 2];
-        const double t0 = Tq[n], t1 = Tq[MF_TA + n], t2 = Tq[2 * MF_TA + n];
-        J[0][0] += t0 * x0; J[0][1] += t0 * x1; J[0][2] += t0 * x2;
-        J[1][0] += t1 * x0; J[1][1] += t1 * x1; J[1][2] += t1 * x2;
-        J[2][0] += t2 * x0; J[2][1] += t2 * x1; J[2][2] += t2 * x2;
-        if (SRC != 0) {
-          const double ph = Phi[q * MF_PS + n];
-          xg[0] += x0 * ph; xg[1] += x1 * ph; xg[2] += x2 * ph;
+        for (int n = 0; n < NC; n++) {
+          const double2 xa = *reinterpret_cast<const double2*>(xs + n * 4);   // broadcast reads
+          const double x0 = xa.x, x1 = xa.y, x2 = xs[n * 4 + 2];
+          const double t0 = Tq[n], t1 = Tq[MF_TA + n], t2 = Tq[2 * MF_TA + n];
+          J[0][0] += t0 * x0; J[0][1] += t0 * x1; J[0][2] += t0 * x2;
+          J[1][0] += t1 * x0; J[1][1] += t1 * x1; J[1][2] += t1 * x2;
+          J[2][0] += t2 * x0; J[2][1] += t2 * x1; J[2][2] += t2 * x2;
+          if (SRC != 0) {
+            const double ph = Phi[q * MF_PS + n];
+            xg[0] += x0 * ph; xg[1] += x1 * ph; xg[2] += x2 * ph;
+          }
         }
       }
       // cofactors Cf = det * J^-1 (the reference's Jacobian inverse, `elem_type_template` 3-D branch, without the division)
@@ -1008,7 +1081,8 @@ static int launch_mfma_one(fh_assembler_t as, const AsmParams& P) {
   }
   const int per_cu = std::max(1, (int)((size_t)160 * 1024 / lds));
   const int grid = std::max(1, std::min(fh_div_up(P.nelems, NW), as->ctx->num_cu * per_cu));
-  hipLaunchKernelGGL((k_elem_q2hex_mfma<SRC, NW>), dim3(grid), dim3(NW * 64), lds, as->ctx->stream, P, as->d_mfT, as->d_mfPhi);
+  hipLaunchKernelGGL((k_elem_q2hex_mfma<SRC, NW>), dim3(grid), dim3(NW * 64), lds, as->ctx->stream, P, as->d_mfT, as->d_mfPhi,
+                     as->ctx->assemble_sumfac ? as->d_mfSFc : nullptr, as->d_mfSFi);
   FH_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1270,6 +1344,89 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
       }
     FH_TRY(up((void**)&as->d_mfT, mfT.data(), mfT.size() * sizeof(double)));
     FH_TRY(up((void**)&as->d_mfPhi, mfPhi.data(), mfPhi.size() * sizeof(double)));
+    // Sum factorisation of the map Jacobian (phase A of the kernel): HEX27 shape functions are products of 1-D quadratic
+    // Lagrange polynomials and the 64-point rule is a 4 x 4 x 4 tensor grid.  Both facts are CHECKED here against the tables the
+    // reference's formulas produced (1e-13); if either fails the kernel keeps the direct 27-node loop.
+    {
+      double xi[64][3];
+      for (int g = 0; g < 64; g++)
+        for (int d = 0; d < 3; d++) {
+          xi[g][d] = 0.0;
+          for (int n = 0; n < 27; n++) xi[g][d] += phi[(size_t)g * 27 + n] * fhfe::xc(geom, n, d);
+        }
+      std::vector<double> absc;
+      for (int g = 0; g < 64; g++) {
+        bool seen = false;
+        for (double v : absc) seen |= std::fabs(v - xi[g][0]) < 1e-12;
+        if (!seen) absc.push_back(xi[g][0]);
+      }
+      std::sort(absc.begin(), absc.end());
+      bool ok = absc.size() == 4;
+      int qidx[64][3], seen_q[64] = {0}, nodeof[27];
+      for (int k = 0; k < 27; k++) nodeof[k] = -1;
+      for (int g = 0; g < 64 && ok; g++) {
+        for (int d = 0; d < 3; d++) {
+          qidx[g][d] = -1;
+          for (int k = 0; k < 4; k++)
+            if (std::fabs(absc[k] - xi[g][d]) < 1e-12) qidx[g][d] = k;
+          ok &= qidx[g][d] >= 0;
+        }
+        if (ok) seen_q[qidx[g][0] + 4 * qidx[g][1] + 16 * qidx[g][2]]++;
+      }
+      for (int k = 0; k < 64 && ok; k++) ok &= seen_q[k] == 1;
+      for (int n = 0; n < 27; n++) nodeof[(fhfe::xc(geom, n, 0) + 1) * 9 + (fhfe::xc(geom, n, 1) + 1) * 3 + fhfe::xc(geom, n, 2) + 1] = n;
+      for (int k = 0; k < 27; k++) ok &= nodeof[k] >= 0;
+      double L1[3][4], D1[3][4];
+      for (int k = 0; k < 4 && ok; k++) {
+        const double x = absc[k];
+        L1[0][k] = 0.5 * x * (x - 1.0); L1[1][k] = 1.0 - x * x; L1[2][k] = 0.5 * x * (x + 1.0);
+        D1[0][k] = x - 0.5;             D1[1][k] = -2.0 * x;    D1[2][k] = x + 0.5;
+      }
+      for (int g = 0; g < 64 && ok; g++)
+        for (int n = 0; n < 27; n++) {
+          const int a = fhfe::xc(geom, n, 0) + 1, b = fhfe::xc(geom, n, 1) + 1, c = fhfe::xc(geom, n, 2) + 1;
+          const int q1 = qidx[g][0], q2 = qidx[g][1], q3 = qidx[g][2];
+          ok &= std::fabs(phi[(size_t)g * 27 + n] - L1[a][q1] * L1[b][q2] * L1[c][q3]) <= 1e-13;
+          ok &= std::fabs(dphi[((size_t)g * 27 + n) * 3 + 0] - D1[a][q1] * L1[b][q2] * L1[c][q3]) <= 1e-13;
+          ok &= std::fabs(dphi[((size_t)g * 27 + n) * 3 + 1] - L1[a][q1] * D1[b][q2] * L1[c][q3]) <= 1e-13;
+          ok &= std::fabs(dphi[((size_t)g * 27 + n) * 3 + 2] - L1[a][q1] * L1[b][q2] * D1[c][q3]) <= 1e-13;
+        }
+      if (ok) {
+        // per-lane constants of the three stages (lane roles: see k_elem_q2hex_mfma, phase A)
+        std::vector<double> sfc((size_t)18 * 64, 0.0);
+        std::vector<int> sfi((size_t)7 * 64, 0);
+        for (int l = 0; l < 64; l++) {
+          if (l < 36) {                                  // stage 1: lane = (q1, b, c), contracts a
+            const int q1 = l & 3, bc = l >> 2, b = bc / 3, c = bc % 3;
+            for (int a = 0; a < 3; a++) {
+              sfc[(size_t)a * 64 + l] = L1[a][q1];
+              sfc[(size_t)(3 + a) * 64 + l] = D1[a][q1];
+              sfi[(size_t)a * 64 + l] = nodeof[a * 9 + b * 3 + c] * 4;      // doubles into xs
+            }
+            sfi[(size_t)3 * 64 + l] = ((b * 3 + c) * 4 + q1) * 4;
+          }
+          if (l < 48) {                                  // stage 2: lane = (c, q1, q2), contracts b
+            const int c2 = l >> 4, q12 = l & 15, q1 = q12 & 3, q2 = q12 >> 2;
+            for (int b = 0; b < 3; b++) {
+              sfc[(size_t)(6 + b) * 64 + l] = L1[b][q2];
+              sfc[(size_t)(9 + b) * 64 + l] = D1[b][q2];
+            }
+            sfi[(size_t)4 * 64 + l] = (c2 * 4 + q1) * 4;
+            sfi[(size_t)5 * 64 + l] = (c2 * 16 + q12) * 4;
+          }
+          {                                              // stage 3: lane = Gauss point, contracts c
+            const int q1 = qidx[l][0], q2 = qidx[l][1], q3 = qidx[l][2];
+            for (int c = 0; c < 3; c++) {
+              sfc[(size_t)(12 + c) * 64 + l] = L1[c][q3];
+              sfc[(size_t)(15 + c) * 64 + l] = D1[c][q3];
+            }
+            sfi[(size_t)6 * 64 + l] = (q1 + 4 * q2) * 4;
+          }
+        }
+        FH_TRY(up((void**)&as->d_mfSFc, sfc.data(), sfc.size() * sizeof(double)));
+        FH_TRY(up((void**)&as->d_mfSFi, sfi.data(), sfi.size() * sizeof(int)));
+      }
+    }
   }
   std::vector<int> celems;
   color_elements(nel, as->nc, nloc, elem_dof, nnode, as->color_ptr, celems);
@@ -1376,7 +1533,7 @@ extern "C" int fh_assembler_destroy(fh_assembler_t as) {
   hipFree(as->d_phi);
   hipFree(as->d_dphi);
   if (as->d_emap) hipFree(as->d_emap);
-  for (void* q : {(void*)as->d_aff_elems, (void*)as->d_gen_elems, (void*)as->d_Mab, (void*)as->d_mphi, (void*)as->d_mfT, (void*)as->d_mfPhi})
+  for (void* q : {(void*)as->d_aff_elems, (void*)as->d_gen_elems, (void*)as->d_Mab, (void*)as->d_mphi, (void*)as->d_mfT, (void*)as->d_mfPhi, (void*)as->d_mfSFc, (void*)as->d_mfSFi})
     if (q) hipFree(q);
   if (as->d_prog) hipFree(as->d_prog);
   if (as->d_prog_consts) hipFree(as->d_prog_consts);

@@ -52,7 +52,7 @@ int fh_timer_stop(fh_ctx_t ctx, double* milliseconds);
  * names (default): "spmv_tile" (2048), "spmv_xcd_remap" (32), "spmv_kernel" (3), "assemble_two_pass" (1), "assemble_emap" (1),
  * "assemble_mfma" (12: HEX27/Q2 element matrices on the FP64 matrix cores, value = waves per workgroup, 0 = vector kernel),
  * "assemble_kpad" (1: element rows of the two-pass buffer padded to 256 bytes; read when an assembler is created),
- * "assemble_sym" (1), "assemble_affine" (0, see fh_assembler_affine_count), "gj_mfma" (1: coarse dense inverse updates on the
+ * "assemble_sumfac" (1: map Jacobian by sum factorisation in that kernel), "assemble_sym" (1), "assemble_affine" (0, see fh_assembler_affine_count), "gj_mfma" (1: coarse dense inverse updates on the
  * matrix cores), "spgemm_slot_map" (1), "use_graph" (1), "asm_debug" (0).  Returns non-zero for unknown names */
 int fh_set_option(fh_ctx_t ctx, const char* name, double value);
 

@@ -9,7 +9,8 @@ ctx = femus_amd.Context(0)
 pb = PoissonMG(ctx, 8, 8, 8, 4).init()
 variants = [int(v) for v in sys.argv[1:]] or [12, 0]
 for nw in variants:
-    ctx.set_option("assemble_mfma", nw)
+    ctx.set_option("assemble_mfma", abs(nw))
+    ctx.set_option("assemble_sumfac", 0 if nw < 0 else 1)       # negative: direct 27-node Jacobian loop
     for dbg, name in ((0, "full"), (1, "no quadrature / MFMA phase"), (2, "no output"), (3, "neither")):
         ctx.set_option("asm_debug", dbg)
         for _ in range(2): pb.assemble()

@@ -8,7 +8,8 @@ for spec in sys.argv[1:] or ["12,1", "8,1"]:
     nw, kpad = [int(v) for v in spec.split(",")]
     ctx = femus_amd.Context(0)
     ctx.set_option("assemble_kpad", kpad)
-    ctx.set_option("assemble_mfma", nw)
+    ctx.set_option("assemble_mfma", abs(nw))
+    ctx.set_option("assemble_sumfac", 0 if nw < 0 else 1)      # negative: direct 27-node Jacobian loop
     pb = PoissonMG(ctx, 8, 8, 8, 4).init()
     for _ in range(2): pb.assemble()
     ctx.timer_start()
