@@ -747,7 +747,7 @@ constexpr int MF_SLAB = 27 * MF_KS;   // 783 doubles per wave: phase-A results (
 constexpr int MF_XS = 27 * 4;         // per wave: (x, y, z, u) of the element's nodes
 constexpr int MF_WAVE = MF_SLAB + 1 + MF_XS;   // 892 doubles, even: xs stays 16-byte aligned
 constexpr int MF_SF = 18 * 64;        // per-lane 1-D shape values of the sum-factorised Jacobian
-constexpr size_t mf_lds_bytes(int nw) { return (size_t)(64 * MF_TS + 64 * MF_PS + MF_SF + nw * MF_WAVE) * sizeof(double); }
+constexpr size_t mf_lds_bytes(int nw) { return (size_t)(64 * MF_TS + 64 * MF_PS + MF_SF + nw * MF_WAVE) * sizeof(double) + 2 * 7 * 64 * sizeof(int); }
 // row group of block b in instruction t: 3 bits each
 constexpr unsigned long long mf_rows(int b0, int b1, int b2, int b3) { return (unsigned long long)(b0 | (b1 << 3) | (b2 << 6) | (b3 << 9)); }
 constexpr unsigned long long MF_SCHED_LO = mf_rows(0, 1, 2, 3) | (mf_rows(2, 0, 1, 0) << 12) | (mf_rows(5, 4, 4, 2) << 24) | (mf_rows(6, 6, 5, 4) << 36);
@@ -768,6 +768,19 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
   double* SFl = Phi + 64 * MF_PS;                         // [18][64] 1-D shape values per lane (sum factorisation)
   if (SFc)
     for (int k = threadIdx.x; k < MF_SF; k += NW * 64) SFl[k] = SFc[k];
+  int* KsOff = reinterpret_cast<int*>(SFl + MF_SF + NW * MF_WAVE);   // [2 * MF_NT][64]: where a lane's tile entries go in the staging
+  if (threadIdx.x < 64) {
+    const int l = threadIdx.x, k4 = l >> 4, b4 = (l >> 2) & 3, r = l & 3;   // D layout: row = lane>>4, block = (lane>>2)&3, col = lane&3
+    for (int t = 0; t < MF_NT; t++) {
+      const int colg = (t < 4 || b4 == 3) ? b4 : 4 + b4, rowg = mf_rowg(t, b4);
+      const int row = 4 * rowg + k4, col = 4 * colg + r;
+      // diagonal tiles: the (i, j) and (j, i) sums differ in rounding; keep the upper entries and mirror them, so that K_e is
+      // symmetric bit for bit like the reference's Jac (products commute, same summation order)
+      const bool live = row < 27 && col < 27 && (rowg != colg || k4 <= r);
+      KsOff[(2 * t) * 64 + l] = live ? row * MF_KS + col : -1;
+      KsOff[(2 * t + 1) * 64 + l] = (live && row != col) ? col * MF_KS + row : -1;
+    }
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -994,17 +1007,13 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
     }
     wave_lds_sync();          // every lane is done with the phase-A slab: reuse it as Ks[27][29]
     double* Ks = slab;
+    // staging offsets of this lane's tile entries from the table built at kernel start (kept in LDS: as loop invariants in
+    // registers they were spilled to scratch and every reload waited on vmcnt(0))
 #pragma unroll
-    for (int t = 0; t < MF_NT; t++) {   // D layout: row = lane>>4, block = (lane>>2)&3, col = lane&3
-      const int colg = (t < 4 || blk == 3) ? blk : 4 + blk, rowg = mf_rowg(t, blk);
-      const int row = 4 * rowg + kk, col = 4 * colg + r4;
-      // diagonal tiles: the (i, j) and (j, i) sums differ in rounding; keep the upper entries and mirror them, so that K_e is
-      // symmetric bit for bit like the reference's Jac (products commute, same summation order)
-      const bool live = row < NC && col < NC && (rowg != colg || kk <= r4);
-      if (live) {
-        Ks[row * MF_KS + col] = acc[t];
-        if (row != col) Ks[col * MF_KS + row] = acc[t];
-      }
+    for (int t = 0; t < MF_NT; t++) {
+      const int od = KsOff[(2 * t) * 64 + lane], om = KsOff[(2 * t + 1) * 64 + lane];
+      if (od >= 0) Ks[od] = acc[t];
+      if (om >= 0) Ks[om] = acc[t];
     }
     wave_lds_sync();
     double ku = 0.0;
