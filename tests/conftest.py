@@ -19,3 +19,4 @@ def ctx():
     c = femus_amd.Context(0)
     yield c
     c.close()
+
