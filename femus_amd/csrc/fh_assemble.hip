@@ -87,7 +87,7 @@ struct AsmParams {
   double* res;
   const int* emap;         // may be null -> binary search
   int* emap_out;           // non-null: build the map instead of assembling
-  int debug;               // profiling aid: bit 0 skips the quadrature loop, bit 1 skips the scatter
+  int debug;               // profiling aid: bit 0 skips the quadrature loop, bit 1 skips the scatter / stores, bit 3 (host) skips the row pass
   const int* slot;         // non-null with Kout: row i of element e goes to Kout[slot[e*nc+i]*nc + j] (row-gather order), -1 = skip
   double* Kout;            // non-null: write element matrices [e][nc][nc] instead of scattering
   int kstride;             // doubles per element row in Kout (nc; 32 = padded rows of the slot-major buffer)
@@ -1620,7 +1620,7 @@ static int assemble_poisson_core(fh_assembler_t as, fh_vec_t sol, int source_kin
       P.nelems = as->n_gen;
     }
     FH_TRY(dispatch_assemble(as, P));
-    if (!(as->ctx->asm_debug & 2)) FH_TRY(dispatch_rows(as, A, res->d, false));
+    if (!(as->ctx->asm_debug & (2 | 8))) FH_TRY(dispatch_rows(as, A, res->d, false));   // bit 3: element matrices only (timing)
     A->at_valid = false;
     return 0;
   }
