@@ -389,15 +389,26 @@ __global__ __launch_bounds__(256) void k_gjb_update_mfma(double* __restrict__ D,
   const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
   const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
   const int kk = lane >> 4, li = lane & 15;
+  // the tile of D this workgroup updates is read FIRST (its HBM latency then overlaps the operand staging and the MFMAs) and
+  // serves as the accumulator: D - Cp R = D + (-Cp) R, the sign goes onto the A operand
   gj_d4 acc[2][2];
+  bool live[2][4][2];
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int b = 0; b < 2; b++) acc[a][b] = gj_d4{0.0, 0.0, 0.0, 0.0};
+    for (int r = 0; r < 4; r++) {
+      const int i = ti + wi + a * 16 + kk + 4 * r;
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const int j = tj + wj + b * 16 + li;
+        live[a][r][b] = i < n && j < n && !(i >= kb && i < kb + nb) && !(j >= kb && j < kb + nb);
+        acc[a][b][r] = live[a][r][b] ? D[(size_t)i * n + j] : 0.0;
+      }
+    }
   for (int t0 = 0; t0 < nb; t0 += GJ_KS) {
     for (int idx = tid; idx < GJ_KS * 64; idx += 256) {
       const int k = idx >> 6, c = idx & 63, t = t0 + k;
-      Cs[k][c] = (ti + c < n && t < nb) ? CpT[(size_t)t * n + ti + c] : 0.0;
+      Cs[k][c] = (ti + c < n && t < nb) ? -CpT[(size_t)t * n + ti + c] : 0.0;
       Rs[k][c] = (tj + c < n && t < nb) ? D[(size_t)(kb + t) * n + tj + c] : 0.0;
     }
     __syncthreads();
@@ -417,12 +428,10 @@ __global__ __launch_bounds__(256) void k_gjb_update_mfma(double* __restrict__ D,
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int i = ti + wi + a * 16 + kk + 4 * r;
-      if (i >= n || (i >= kb && i < kb + nb)) continue;
 #pragma unroll
       for (int b = 0; b < 2; b++) {
         const int j = tj + wj + b * 16 + li;
-        if (j >= n || (j >= kb && j < kb + nb)) continue;
-        D[(size_t)i * n + j] -= acc[a][b][r];
+        if (live[a][r][b]) D[(size_t)i * n + j] = acc[a][b][r];
       }
     }
 }
