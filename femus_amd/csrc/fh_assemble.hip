@@ -734,12 +734,18 @@ __global__ __launch_bounds__(64) void k_elem_q2hex_sym(AsmParams P) {
 //   own table value.
 // MFMAs do not overlap with vector instructions of other waves on gfx950 (tests/cpp/mfma_f64_overlap_probe.cpp), so the cost is
 // MFMA cycles + 4 x (vector instructions): phase B issues 18 FMAs per 21 MFMAs, A operands cost LDS reads only.
-// Per element:   phase A  lane = Gauss point q: J, J^-1, D_q, source value -> per-wave LDS slab
-//                phase B  16 groups of the 4 Gauss points {q0, q0+16, q0+32, q0+48} x 3 directions x 8 MFMAs
-//                phase C  source integral per node, tiles -> LDS (mirrored), K_e u for the residual, coalesced row stores
+// Per element:   phase A  map Jacobian by sum factorisation (three contractions through LDS, lanes = (q1,b,c) / (c,q1,q2) / Gauss
+//                         point; the direct 27-node loop when the tables are not tensor products), then per Gauss point the
+//                         cofactors, D_q and the source value -> per-wave LDS slab
+//                phase B  16 groups of the 4 Gauss points {q0, q0+16, q0+32, q0+48} x 3 directions x 7 MFMAs; operand loads issued
+//                         by hand (ds_read_b64 + s_waitcnt, register double buffer)
+//                phase C  source integral per node, tiles -> LDS (mirrored, offsets from a table), K_e u for the residual, one
+//                         256-byte row per half-wave store off a scalar base address
+// Node ids are prefetched two elements ahead, coordinates / solution / slots one element ahead (dependent gathers).
 // Tables (shared by the NW waves of the persistent workgroup): T[q][c][n] with q-stride 85 doubles, c-stride 28 (odd q-stride:
-// conflict-free for lane = q; 16*85 = 16 mod 32: conflict-free for the k-step pattern), Phi[q][n] with stride 33.  Waves never
-// synchronise with each other after the table load.  ng == 64 only; other rules keep the vector kernel.
+// conflict-free for lane = q; 16*85 = 16 mod 32: conflict-free for the k-step pattern), Phi[q][n] with stride 33, the per-lane 1-D
+// shape values of the sum factorisation [18][64], the staging offsets [14][64].  Waves never synchronise with each other after
+// the table load.  ng == 64 only; other rules keep the vector kernel.
 // ------------------------------------------------------------------------------------------------------------------
 typedef const int __attribute__((address_space(4)))* fh_ciptr;     // read-only for the launch: uniform accesses become s_load
 constexpr int MF_TS = 85, MF_TA = 28, MF_PS = 33, MF_SS = 7, MF_KS = 29;
