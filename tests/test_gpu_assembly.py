@@ -147,6 +147,49 @@ def test_global_assembly_matches_oracle(ctx, args, nl, fe, two_pass, emap):
         ctx.set_option("assemble_two_pass", 1)
 
 
+@pytest.mark.parametrize("sumfac,kpad,mfma", [(1, 1, 12), (0, 1, 12), (1, 0, 12), (1, 1, 0), (1, 0, 0)])
+def test_global_assembly_options_of_the_hex27_path(ctx, sumfac, kpad, mfma):
+    """HEX27/Q2 two-pass assembly with the Jacobian by sum factorisation or by the direct node loop, element rows padded to 256
+    bytes or not, matrix-core or vector element kernel: all of them against the oracle on a curved mesh, and bit-identical when
+    repeated."""
+    m = levels((3, 2, 2), 2)[-1]
+    ed, xy, _ = m.arrays()
+    rng = np.random.default_rng(17)
+    xy = xy + rng.uniform(-0.01, 0.01, xy.shape)
+    n = m.nnode
+    rp, col = capi.pattern_from_elements(ed, n)
+    A = ctx.matrix_csr(n, n, rp, col)
+    res = ctx.vector(n)
+    u = rng.uniform(-1, 1, n)
+    ctx.set_option("assemble_sumfac", sumfac)
+    ctx.set_option("assemble_kpad", kpad)
+    ctx.set_option("assemble_mfma", mfma)
+    try:
+        asm = capi.Assembler(ctx, m, "biquadratic", A, elem_dof=ed, coords=xy)      # kpad is read here
+        asm.assemble(A, res, ctx.vector_from(u), 1, (2.0, 1.3))
+        v1, f1 = A.values().copy(), res.to_numpy().copy()
+        asm.assemble(A, res, ctx.vector_from(u), 1, (2.0, 1.3))
+        assert np.array_equal(v1, A.values()) and np.array_equal(f1, res.to_numpy())
+    finally:
+        ctx.set_option("assemble_sumfac", 1)
+        ctx.set_option("assemble_kpad", 1)
+        ctx.set_option("assemble_mfma", 12)
+    et = fo.ElemType("hex", "biquadratic", "seventh")
+    Ko, Fo = fo.elem_poisson_batch(et, np.transpose(xy[ed], (0, 2, 1)), u[ed], lambda xg: 2.0 * np.prod(np.sin(1.3 * xg), axis=-1))
+    import scipy.sparse as sp
+    rows = np.repeat(ed, 27, axis=1).ravel()
+    cols = np.tile(ed, (1, 27)).ravel()
+    Ao = sp.coo_matrix((Ko.ravel(), (rows, cols)), shape=(n, n)).tocsr()
+    Ao.sort_indices()
+    bo = np.zeros(n)
+    np.add.at(bo, ed.ravel(), Fo.ravel())
+    assert np.array_equal(Ao.indptr, rp) and np.array_equal(Ao.indices, col)
+    assert abs(v1 - Ao.data).max() <= 1e-12 * abs(Ao.data).max()
+    assert abs(f1 - bo).max() <= 1e-12 * abs(bo).max()
+    asm.destroy()
+    A.destroy()
+
+
 @pytest.mark.parametrize("args,nl,fe", [((2, 2, 2), 2, "biquadratic"), ((4, 4, 0), 2, "linear")])
 def test_expression_source_equals_closed_form_source(ctx, args, nl, fe):
     """the compiled-expression source (fh_assemble_poisson_expr, evaluated on the device at the Gauss points) against the
