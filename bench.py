@@ -242,6 +242,8 @@ def main():
                            "which the kernel shortens by the symmetry of K_e and the sum-factorised Jacobian",
             "algorithmic_tflops": ai["flops"] / elem_ms / 1e9,
             "avg_launch_ms": elem_ms,
+            "traffic": measured_assembly_traffic()[0] if world == 1 else None,
+            "row_pass_traffic": measured_assembly_traffic()[1] if world == 1 else None,
             "executed_mfma_tflops": 336 * 512.0 * nel / elem_ms / 1e9,
             "row_pass_ms": asm_ms - elem_ms,
             "row_pass_GBps": (nel * 27 * (32 * 8 + 27 + 8) + A.nnz * 8.0) / max(asm_ms - elem_ms, 1e-9) / 1e6,
@@ -306,6 +308,16 @@ def measured_traffic():
             return json.load(f)["traffic_bytes_per_launch"]
     except Exception:
         return None
+
+
+def measured_assembly_traffic():
+    """HBM bytes per launch of the two assembly kernels from the committed PMC passes (profiles/README.md); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01b_assembly_traffic.json")) as f:
+            d = json.load(f)
+        return d["k_elem_q2hex_mfma<0, 12>"]["traffic_bytes_per_launch"], d["k_row_assemble<27, false>"]["traffic_bytes_per_launch"]
+    except Exception:
+        return None, None
 
 
 def usable_cores():
