@@ -59,6 +59,7 @@ struct fh_ctx_s {
   int assemble_sym = 1;              // symmetric-tile HEX27/Q2 element kernel (2 elements per wave)
   int assemble_two_pass = 1;         // 1: element matrices + row gather (default), 0: coloured scatter
   int assemble_affine = 0;           // opt-in: affine HEX27/Q2 elements through precomputed reference matrices instead of quadrature
+  int gj_symmetric = 1;              // coarse dense inverse: symmetric sweep on the upper block triangle when the operator is symmetric
   int gj_mfma = 1;                   // coarse dense inverse: rank-NB updates on the FP64 matrix cores
   int use_graph = 1;
   int spgemm_slot_map = 1;           // Galerkin products stream a precomputed slot map instead of searching

@@ -436,6 +436,183 @@ __global__ __launch_bounds__(256) void k_gjb_update_mfma(double* __restrict__ D,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// SYMMETRIC coarse operators (Poisson, AMR: checked entry by entry before use): the sweep operator on pivot blocks,
+//   A_kk <- -A_kk^-1,   A_ko <- A_kk^-1 A_ko (and its transpose),   A_oo <- A_oo - A_ok A_kk^-1 A_ko,
+// keeps the working matrix symmetric through all steps and ends in -A^-1, so only the UPPER block triangle is updated: half the
+// flops and half the HBM traffic of the general Gauss-Jordan above.  PT = the old pivot rows for ALL columns (taken from the
+// rows right of the pivot block and from the columns above it), RT = the new row panel, both k-major for the MFMA fragments.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_csr_symmetry(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val, int n,
+                                                      double tol, int* __restrict__ flag) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double dmax = 0.0;
+  for (int k = rowptr[i]; k < rowptr[i + 1]; k++) dmax = fmax(dmax, fabs(val[k]));
+  for (int k = rowptr[i]; k < rowptr[i + 1]; k++) {
+    const int j = col[k];
+    if (j == i) continue;
+    int lo = rowptr[j], hi = rowptr[j + 1] - 1;
+    double vt = 0.0;
+    while (lo <= hi) {
+      const int mid = (lo + hi) >> 1;
+      if (col[mid] == i) { vt = val[mid]; break; }
+      if (col[mid] < i) lo = mid + 1; else hi = mid - 1;
+    }
+    if (fabs(val[k] - vt) > tol * dmax) atomicOr(flag, 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gjs_gather_panel(const double* __restrict__ D, double* __restrict__ PT, int n, int kb, int nb) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * GJ_NB) return;
+  const int j = idx / GJ_NB, t = idx % GJ_NB;            // t fastest: for j < kb the 32 entries D[j][kb..] are contiguous
+  if (t >= nb) return;
+  double v;
+  if (j < kb) v = D[(size_t)j * n + kb + t];             // column above the pivot block (upper triangle)
+  else if (j < kb + nb) v = D[(size_t)(kb + min(t, j - kb)) * n + kb + max(t, j - kb)];
+  else v = D[(size_t)(kb + t) * n + j];                  // row right of the pivot block
+  PT[(size_t)t * n + j] = v;
+}
+
+__global__ __launch_bounds__(256) void k_gjs_pivot(const double* __restrict__ PT, double* __restrict__ Dinv, int n, int kb, int nb) {
+  __shared__ double M[GJ_NB][GJ_NB + 1];
+  __shared__ double colk[GJ_NB];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < GJ_NB * GJ_NB; idx += 256) {
+    const int i = idx / GJ_NB, j = idx % GJ_NB;
+    M[i][j] = (i < nb && j < nb) ? PT[(size_t)i * n + kb + j] : (i == j ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  for (int k = 0; k < nb; k++) {
+    if (tid < GJ_NB) colk[tid] = M[tid][k];
+    __syncthreads();
+    const double p = 1.0 / colk[k];
+#pragma unroll
+    for (int idx = tid; idx < GJ_NB * GJ_NB; idx += 256) {
+      const int i = idx / GJ_NB, j = idx % GJ_NB;
+      if (i != k) {
+        const double f = colk[i] * p;
+        M[i][j] = (j == k) ? -f : M[i][j] - f * M[k][j];
+      }
+    }
+    __syncthreads();
+    if (tid < GJ_NB) M[k][tid] = (tid == k) ? p : M[k][tid] * p;
+    __syncthreads();
+  }
+  for (int idx = tid; idx < nb * nb; idx += 256) Dinv[(idx / nb) * GJ_NB + idx % nb] = M[idx / nb][idx % nb];
+}
+
+// new row panel R = Dinv * PT for the columns outside the pivot block -> RT, the matrix row (j right of the block), the matrix
+// column (j above it: the transpose); -Dinv into the pivot block
+__global__ __launch_bounds__(64) void k_gjs_row_panel(double* __restrict__ D, const double* __restrict__ Dinv, const double* __restrict__ PT,
+                                                      double* __restrict__ RT, int n, int kb, int nb) {
+  __shared__ double Ds[GJ_NB][GJ_NB + 1];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < GJ_NB * GJ_NB; idx += 64) {
+    const int a = idx / GJ_NB, b = idx % GJ_NB;
+    Ds[a][b] = (a < nb && b < nb) ? Dinv[a * GJ_NB + b] : 0.0;
+  }
+  __syncthreads();
+  const int j = blockIdx.x * 64 + tid;
+  if (j >= n) return;
+  if (j >= kb && j < kb + nb) {
+    for (int s2 = 0; s2 < nb; s2++) {
+      D[(size_t)(kb + s2) * n + j] = -Ds[s2][j - kb];
+      RT[(size_t)s2 * n + j] = 0.0;
+    }
+    return;
+  }
+  double old[GJ_NB];
+#pragma unroll
+  for (int t = 0; t < GJ_NB; t++) old[t] = (t < nb) ? PT[(size_t)t * n + j] : 0.0;
+  for (int s2 = 0; s2 < nb; s2++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int t = 0; t < GJ_NB; t++) acc += Ds[s2][t] * old[t];
+    RT[(size_t)s2 * n + j] = acc;
+    if (j > kb) D[(size_t)(kb + s2) * n + j] = acc;
+    else D[(size_t)j * n + kb + s2] = acc;
+  }
+}
+
+// upper block triangle: A[i][j] -= sum_t PT[t][i] * RT[t][j]   (i, j outside the pivot block)
+__global__ __launch_bounds__(256) void k_gjs_update_mfma(double* __restrict__ D, const double* __restrict__ PT, const double* __restrict__ RT, int n,
+                                                         int kb, int nb) {
+  if (blockIdx.y > blockIdx.x) return;                    // lower block triangle: not maintained
+  constexpr int LD = 80;
+  __shared__ double Cs[GJ_KS][LD], Rs[GJ_KS][LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
+  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+  const int kk = lane >> 4, li = lane & 15;
+  gj_d4 acc[2][2];
+  bool live[2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int i = ti + wi + a * 16 + kk + 4 * r;
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const int j = tj + wj + b * 16 + li;
+        live[a][r][b] = i < n && j < n && !(i >= kb && i < kb + nb) && !(j >= kb && j < kb + nb);
+        acc[a][b][r] = live[a][r][b] ? D[(size_t)i * n + j] : 0.0;
+      }
+    }
+  for (int t0 = 0; t0 < nb; t0 += GJ_KS) {
+    for (int idx = tid; idx < GJ_KS * 64; idx += 256) {
+      const int k = idx >> 6, c = idx & 63, t = t0 + k;
+      Cs[k][c] = (ti + c < n && t < nb) ? -PT[(size_t)t * n + ti + c] : 0.0;
+      Rs[k][c] = (tj + c < n && t < nb) ? RT[(size_t)t * n + tj + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k0 = 0; k0 < GJ_KS; k0 += 4) {
+      const double a0 = Cs[k0 + kk][wi + li], a1 = Cs[k0 + kk][wi + 16 + li];
+      const double b0 = Rs[k0 + kk][wj + li], b1 = Rs[k0 + kk][wj + 16 + li];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int i = ti + wi + a * 16 + kk + 4 * r;
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const int j = tj + wj + b * 16 + li;
+        if (live[a][r][b]) D[(size_t)i * n + j] = acc[a][b][r];
+      }
+    }
+}
+
+// the upper triangle holds -A^-1: negate and mirror (64 x 64 tiles through LDS, both directions coalesced)
+__global__ __launch_bounds__(256) void k_gjs_finish(double* __restrict__ D, int n) {
+  if (blockIdx.y > blockIdx.x) return;
+  __shared__ double Ts[64][65];
+  const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
+  for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+    const int r = idx >> 6, c = idx & 63, i = ti + r, j = tj + c;
+    double v = 0.0;
+    if (i < n && j < n) {
+      v = (i <= j) ? -D[(size_t)i * n + j] : 0.0;
+      if (i <= j) D[(size_t)i * n + j] = v;
+    }
+    Ts[r][c] = v;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;              // writes D[tj + r][ti + c] = Ts[c][r]
+    const int i = tj + r, j = ti + c;
+    if (i < n && j < n && j < i) D[(size_t)i * n + j] = Ts[c][r];
+  }
+}
+
 // pivot columns of all other rows: A[i, kb+t] <- - sum_s Cp[i,s] * Dinv[s,t]
 __global__ __launch_bounds__(256) void k_gjb_col_panel(double* __restrict__ D, const double* __restrict__ Dinv, const double* __restrict__ Cp,
                                                        int n, int kb, int nb) {
@@ -700,11 +877,35 @@ static int coarse_factor(fh_mg_t mg) {
   FH_CHECK_HIP(hipMemsetAsync(mg->d_ainv, 0, (size_t)n * n * sizeof(double), c->stream));
   hipLaunchKernelGGL(k_csr_to_dense, dim3(n), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, mg->d_ainv, n);
   double* colk = nullptr;   // column panel (n x NB) + pivot inverse (NB x NB)
-  FH_CHECK_HIP(hipMalloc(&colk, ((size_t)2 * n * GJ_NB + GJ_NB * GJ_NB) * sizeof(double)));
+  FH_CHECK_HIP(hipMalloc(&colk, ((size_t)2 * n * GJ_NB + GJ_NB * GJ_NB + 8) * sizeof(double)));
   double* Cp = colk;
   double* CpT = colk + (size_t)n * GJ_NB;
   double* Dinv = colk + (size_t)2 * n * GJ_NB;
   const int nt = fh_div_up(n, 64);
+  if (c->gj_symmetric) {
+    // symmetric operator? (entry-by-entry check on the sparse form, 1e-12 of the row's largest entry)
+    int* d_flag = reinterpret_cast<int*>(Dinv + GJ_NB * GJ_NB);
+    int h_flag = 0;
+    FH_CHECK_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_csr_symmetry, dim3(fh_div_up(n, 256)), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, n, 1e-12, d_flag);
+    FH_CHECK_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (h_flag == 0) {
+      double *PT = Cp, *RT = CpT;
+      for (int kb = 0; kb < n; kb += GJ_NB) {
+        const int nb = std::min(GJ_NB, n - kb);
+        hipLaunchKernelGGL(k_gjs_gather_panel, dim3(fh_div_up((int64_t)n * GJ_NB, 256)), dim3(256), 0, c->stream, mg->d_ainv, PT, n, kb, nb);
+        hipLaunchKernelGGL(k_gjs_pivot, dim3(1), dim3(256), 0, c->stream, PT, Dinv, n, kb, nb);
+        hipLaunchKernelGGL(k_gjs_row_panel, dim3(fh_div_up(n, 64)), dim3(64), 0, c->stream, mg->d_ainv, Dinv, PT, RT, n, kb, nb);
+        hipLaunchKernelGGL(k_gjs_update_mfma, dim3(nt, nt), dim3(256), 0, c->stream, mg->d_ainv, PT, RT, n, kb, nb);
+      }
+      hipLaunchKernelGGL(k_gjs_finish, dim3(nt, nt), dim3(256), 0, c->stream, mg->d_ainv, n);
+      FH_CHECK_HIP(hipGetLastError());
+      FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+      hipFree(colk);
+      return 0;
+    }
+  }
   for (int kb = 0; kb < n; kb += GJ_NB) {
     const int nb = std::min(GJ_NB, n - kb);
     hipLaunchKernelGGL(k_gjb_save_panel, dim3(fh_div_up((int64_t)n * nb, 256)), dim3(256), 0, c->stream, mg->d_ainv, Cp, CpT, n, kb, nb);

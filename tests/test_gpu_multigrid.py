@@ -53,6 +53,30 @@ def test_vcycle_matches_oracle(ctx, H3, graph, npre, npost):
         ctx.set_option("use_graph", 1)
 
 
+@pytest.mark.parametrize("sym,mfma", [(1, 1), (0, 1), (0, 0)])
+@pytest.mark.parametrize("box", [(3, 3, 3), (5, 4, 3)])
+def test_coarse_inverse_variants(ctx, box, sym, mfma):
+    """the dense coarse inverse by the symmetric sweep on the upper block triangle (symmetric operators), by the general blocked
+    Gauss-Jordan with the rank-32 updates on the matrix cores, and by its vector form: a one-level "hierarchy" makes the cycle the
+    coarse solve itself, checked against a direct solve.  Coarse sizes 343 and 693: not multiples of the 32-wide pivot block
+    or of the 64-wide update tile."""
+    H = fo.build_poisson_hierarchy(*box, 1, "biquadratic", ONE)
+    n = H.A[0].shape[0]
+    ctx.set_option("gj_symmetric", sym)
+    ctx.set_option("gj_mfma", mfma)
+    try:
+        mg, mats = device_hierarchy(ctx, H)
+        rhs = fo.lcg_fill(n, 11)
+        b, x = ctx.vector_from(rhs), ctx.vector(n)
+        mg.vcycle(b, x)
+        ref = spla.spsolve(H.A[0].tocsc(), rhs)
+        assert rel(x.to_numpy(), ref) < 1e-11
+        mg.destroy()
+    finally:
+        ctx.set_option("gj_symmetric", 1)
+        ctx.set_option("gj_mfma", 1)
+
+
 @pytest.mark.parametrize("outer", ["richardson", "gmres", "cg"])
 def test_outer_solvers_reach_direct_solution(ctx, H3, outer):
     mg, mats = device_hierarchy(ctx, H3)
