@@ -49,6 +49,8 @@ struct fh_mg_s {
   int nlevels = 0;
   std::vector<MgLevel> lv;
   double* d_ainv = nullptr;   // dense inverse of the coarsest operator, row-major n0 x n0
+  double* d_gjwork = nullptr; // panels of the blocked inversion, kept with d_ainv across preparations
+  int ainv_n = -1;
   bool setup_done = false;
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
@@ -872,12 +874,18 @@ static int coarse_factor(fh_mg_t mg) {
   MgLevel& L0 = mg->lv[0];
   const int n = L0.n;
   FH_REQUIRE(n <= 16384, "coarse level has %d unknowns: the dense direct solve supports at most 16384", n);
-  if (mg->d_ainv) FH_CHECK_HIP(hipFree(mg->d_ainv));
-  FH_CHECK_HIP(hipMalloc(&mg->d_ainv, (size_t)n * n * sizeof(double)));
+  if (mg->ainv_n != n) {      // a repeated preparation of the same hierarchy keeps its buffers (the 193 MB allocation cost 5-10 ms)
+    if (mg->d_ainv) FH_CHECK_HIP(hipFree(mg->d_ainv));
+    if (mg->d_gjwork) FH_CHECK_HIP(hipFree(mg->d_gjwork));
+    mg->d_ainv = nullptr;
+    mg->d_gjwork = nullptr;
+    FH_CHECK_HIP(hipMalloc(&mg->d_ainv, (size_t)n * n * sizeof(double)));
+    FH_CHECK_HIP(hipMalloc(&mg->d_gjwork, ((size_t)2 * n * GJ_NB + GJ_NB * GJ_NB + 8) * sizeof(double)));
+    mg->ainv_n = n;
+  }
   FH_CHECK_HIP(hipMemsetAsync(mg->d_ainv, 0, (size_t)n * n * sizeof(double), c->stream));
   hipLaunchKernelGGL(k_csr_to_dense, dim3(n), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, mg->d_ainv, n);
-  double* colk = nullptr;   // column panel (n x NB) + pivot inverse (NB x NB)
-  FH_CHECK_HIP(hipMalloc(&colk, ((size_t)2 * n * GJ_NB + GJ_NB * GJ_NB + 8) * sizeof(double)));
+  double* colk = mg->d_gjwork;   // column panel (n x NB), its transpose / the row panel, pivot inverse (NB x NB), flag
   double* Cp = colk;
   double* CpT = colk + (size_t)n * GJ_NB;
   double* Dinv = colk + (size_t)2 * n * GJ_NB;
@@ -902,7 +910,6 @@ static int coarse_factor(fh_mg_t mg) {
       hipLaunchKernelGGL(k_gjs_finish, dim3(nt, nt), dim3(256), 0, c->stream, mg->d_ainv, n);
       FH_CHECK_HIP(hipGetLastError());
       FH_CHECK_HIP(hipStreamSynchronize(c->stream));
-      hipFree(colk);
       return 0;
     }
   }
@@ -917,7 +924,6 @@ static int coarse_factor(fh_mg_t mg) {
   }
   FH_CHECK_HIP(hipGetLastError());
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
-  hipFree(colk);
   return 0;
 }
 
@@ -1142,6 +1148,7 @@ extern "C" int fh_mg_destroy(fh_mg_t mg) {
     free_level_patches(L);
   }
   if (mg->d_ainv) hipFree(mg->d_ainv);
+  if (mg->d_gjwork) hipFree(mg->d_gjwork);
   for (double* p : mg->kv) hipFree(p);
   delete mg;
   return 0;
