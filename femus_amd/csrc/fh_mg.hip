@@ -50,6 +50,7 @@ struct fh_mg_s {
   std::vector<MgLevel> lv;
   double* d_ainv = nullptr;   // dense inverse of the coarsest operator, row-major n0 x n0
   double* d_gjwork = nullptr; // panels of the blocked inversion, kept with d_ainv across preparations
+  double* d_gjwork2 = nullptr;   // second pivot-inverse buffer (inside d_gjwork)
   int ainv_n = -1;
   bool setup_done = false;
   hipGraph_t graph = nullptr;
@@ -539,13 +540,18 @@ __global__ __launch_bounds__(64) void k_gjs_row_panel(double* __restrict__ D, co
 }
 
 // upper block triangle: A[i][j] -= sum_t PT[t][i] * RT[t][j]   (i, j outside the pivot block)
+// Look-ahead: the workgroup that owns the diagonal tile with the NEXT pivot block inverts that block right after its update
+// (the tile order is rotated so that it is scheduled first), which takes the sequential 32-step inversion (23 us) off the
+// critical path of every step but the first.
 __global__ __launch_bounds__(256) void k_gjs_update_mfma(double* __restrict__ D, const double* __restrict__ PT, const double* __restrict__ RT, int n,
-                                                         int kb, int nb) {
-  if (blockIdx.y > blockIdx.x) return;                    // lower block triangle: not maintained
+                                                         int kb, int nb, double* __restrict__ Dinv_next, int kb_next, int nb_next) {
+  const int nt = gridDim.x, t_next = (kb_next < n) ? kb_next / 64 : 0;
+  const int by = (blockIdx.y + t_next) % nt, bx = (blockIdx.x + t_next) % nt;
+  if (by > bx) return;                                    // lower block triangle: not maintained
   constexpr int LD = 80;
   __shared__ double Cs[GJ_KS][LD], Rs[GJ_KS][LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
+  const int ti = by * 64, tj = bx * 64;
   const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
   const int kk = lane >> 4, li = lane & 15;
   gj_d4 acc[2][2];
@@ -591,6 +597,43 @@ __global__ __launch_bounds__(256) void k_gjs_update_mfma(double* __restrict__ D,
         if (live[a][r][b]) D[(size_t)i * n + j] = acc[a][b][r];
       }
     }
+  if (!(kb_next < n && by == bx && by == t_next)) return;
+  // ---- this workgroup holds the updated next pivot block in its accumulators: invert it (same elimination as k_gjs_pivot) ----
+  double (*M)[GJ_NB + 1] = reinterpret_cast<double (*)[GJ_NB + 1]>(&Cs[0][0]);     // 32 x 33 doubles inside Cs (32 x 80)
+  double* colk = &Rs[0][0];
+  __syncthreads();
+  for (int idx = tid; idx < GJ_NB * GJ_NB; idx += 256) M[idx / GJ_NB][idx % GJ_NB] = (idx / GJ_NB == idx % GJ_NB) ? 1.0 : 0.0;   // identity padding
+  __syncthreads();
+  const int o = kb_next - ti;                              // offset of the block inside the tile (0 or 32)
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int il = wi + a * 16 + kk + 4 * r - o;
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const int jl = wj + b * 16 + li - o;
+        if (il >= 0 && il < nb_next && jl >= 0 && jl < nb_next) M[il][jl] = acc[a][b][r];
+      }
+    }
+  __syncthreads();
+  for (int k = 0; k < nb_next; k++) {
+    if (tid < GJ_NB) colk[tid] = M[tid][k];
+    __syncthreads();
+    const double p = 1.0 / colk[k];
+#pragma unroll
+    for (int idx = tid; idx < GJ_NB * GJ_NB; idx += 256) {
+      const int i = idx / GJ_NB, j = idx % GJ_NB;
+      if (i != k) {
+        const double f = colk[i] * p;
+        M[i][j] = (j == k) ? -f : M[i][j] - f * M[k][j];
+      }
+    }
+    __syncthreads();
+    if (tid < GJ_NB) M[k][tid] = (tid == k) ? p : M[k][tid] * p;
+    __syncthreads();
+  }
+  for (int idx = tid; idx < nb_next * nb_next; idx += 256) Dinv_next[(idx / nb_next) * GJ_NB + idx % nb_next] = M[idx / nb_next][idx % nb_next];
 }
 
 // the upper triangle holds -A^-1: negate and mirror (64 x 64 tiles through LDS, both directions coalesced)
@@ -880,7 +923,8 @@ static int coarse_factor(fh_mg_t mg) {
     mg->d_ainv = nullptr;
     mg->d_gjwork = nullptr;
     FH_CHECK_HIP(hipMalloc(&mg->d_ainv, (size_t)n * n * sizeof(double)));
-    FH_CHECK_HIP(hipMalloc(&mg->d_gjwork, ((size_t)2 * n * GJ_NB + GJ_NB * GJ_NB + 8) * sizeof(double)));
+    FH_CHECK_HIP(hipMalloc(&mg->d_gjwork, ((size_t)2 * n * GJ_NB + 2 * GJ_NB * GJ_NB + 8) * sizeof(double)));
+    mg->d_gjwork2 = mg->d_gjwork + (size_t)2 * n * GJ_NB + GJ_NB * GJ_NB + 8;
     mg->ainv_n = n;
   }
   FH_CHECK_HIP(hipMemsetAsync(mg->d_ainv, 0, (size_t)n * n * sizeof(double), c->stream));
@@ -900,12 +944,15 @@ static int coarse_factor(fh_mg_t mg) {
     FH_CHECK_HIP(hipStreamSynchronize(c->stream));
     if (h_flag == 0) {
       double *PT = Cp, *RT = CpT;
-      for (int kb = 0; kb < n; kb += GJ_NB) {
+      double* Dinv2[2] = {Dinv, mg->d_gjwork2};          // pivot inverse of this step / of the next one (look-ahead)
+      for (int kb = 0, step = 0; kb < n; kb += GJ_NB, step++) {
         const int nb = std::min(GJ_NB, n - kb);
+        const int kb_next = kb + GJ_NB, nb_next = std::max(0, std::min(GJ_NB, n - kb_next));
         hipLaunchKernelGGL(k_gjs_gather_panel, dim3(fh_div_up((int64_t)n * GJ_NB, 256)), dim3(256), 0, c->stream, mg->d_ainv, PT, n, kb, nb);
-        hipLaunchKernelGGL(k_gjs_pivot, dim3(1), dim3(256), 0, c->stream, PT, Dinv, n, kb, nb);
-        hipLaunchKernelGGL(k_gjs_row_panel, dim3(fh_div_up(n, 64)), dim3(64), 0, c->stream, mg->d_ainv, Dinv, PT, RT, n, kb, nb);
-        hipLaunchKernelGGL(k_gjs_update_mfma, dim3(nt, nt), dim3(256), 0, c->stream, mg->d_ainv, PT, RT, n, kb, nb);
+        if (step == 0) hipLaunchKernelGGL(k_gjs_pivot, dim3(1), dim3(256), 0, c->stream, PT, Dinv2[0], n, kb, nb);
+        hipLaunchKernelGGL(k_gjs_row_panel, dim3(fh_div_up(n, 64)), dim3(64), 0, c->stream, mg->d_ainv, Dinv2[step & 1], PT, RT, n, kb, nb);
+        hipLaunchKernelGGL(k_gjs_update_mfma, dim3(nt, nt), dim3(256), 0, c->stream, mg->d_ainv, PT, RT, n, kb, nb, Dinv2[(step + 1) & 1], kb_next,
+                           nb_next);
       }
       hipLaunchKernelGGL(k_gjs_finish, dim3(nt, nt), dim3(256), 0, c->stream, mg->d_ainv, n);
       FH_CHECK_HIP(hipGetLastError());
