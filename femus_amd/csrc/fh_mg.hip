@@ -508,19 +508,21 @@ __global__ __launch_bounds__(256) void k_gjs_pivot(const double* __restrict__ PT
 
 // new row panel R = Dinv * PT for the columns outside the pivot block -> RT, the matrix row (j right of the block), the matrix
 // column (j above it: the transpose); -Dinv into the pivot block
-__global__ __launch_bounds__(64) void k_gjs_row_panel(double* __restrict__ D, const double* __restrict__ Dinv, const double* __restrict__ PT,
-                                                      double* __restrict__ RT, int n, int kb, int nb) {
+__global__ __launch_bounds__(256) void k_gjs_row_panel(double* __restrict__ D, const double* __restrict__ Dinv, const double* __restrict__ PT,
+                                                       double* __restrict__ RT, int n, int kb, int nb) {
+  // 64 columns x 4 groups of 8 output rows per workgroup (one wave per group): 4x the waves of a column-per-thread layout
   __shared__ double Ds[GJ_NB][GJ_NB + 1];
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < GJ_NB * GJ_NB; idx += 64) {
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  for (int idx = tid; idx < GJ_NB * GJ_NB; idx += 256) {
     const int a = idx / GJ_NB, b = idx % GJ_NB;
     Ds[a][b] = (a < nb && b < nb) ? Dinv[a * GJ_NB + b] : 0.0;
   }
   __syncthreads();
-  const int j = blockIdx.x * 64 + tid;
+  const int j = blockIdx.x * 64 + tx;
   if (j >= n) return;
+  const int s_lo = ty * (GJ_NB / 4), s_hi = min(nb, s_lo + GJ_NB / 4);
   if (j >= kb && j < kb + nb) {
-    for (int s2 = 0; s2 < nb; s2++) {
+    for (int s2 = s_lo; s2 < s_hi; s2++) {
       D[(size_t)(kb + s2) * n + j] = -Ds[s2][j - kb];
       RT[(size_t)s2 * n + j] = 0.0;
     }
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(64) void k_gjs_row_panel(double* __restrict__ D, co
   double old[GJ_NB];
 #pragma unroll
   for (int t = 0; t < GJ_NB; t++) old[t] = (t < nb) ? PT[(size_t)t * n + j] : 0.0;
-  for (int s2 = 0; s2 < nb; s2++) {
+  for (int s2 = s_lo; s2 < s_hi; s2++) {
     double acc = 0.0;
 #pragma unroll
     for (int t = 0; t < GJ_NB; t++) acc += Ds[s2][t] * old[t];
@@ -950,7 +952,7 @@ static int coarse_factor(fh_mg_t mg) {
         const int kb_next = kb + GJ_NB, nb_next = std::max(0, std::min(GJ_NB, n - kb_next));
         hipLaunchKernelGGL(k_gjs_gather_panel, dim3(fh_div_up((int64_t)n * GJ_NB, 256)), dim3(256), 0, c->stream, mg->d_ainv, PT, n, kb, nb);
         if (step == 0) hipLaunchKernelGGL(k_gjs_pivot, dim3(1), dim3(256), 0, c->stream, PT, Dinv2[0], n, kb, nb);
-        hipLaunchKernelGGL(k_gjs_row_panel, dim3(fh_div_up(n, 64)), dim3(64), 0, c->stream, mg->d_ainv, Dinv2[step & 1], PT, RT, n, kb, nb);
+        hipLaunchKernelGGL(k_gjs_row_panel, dim3(fh_div_up(n, 64)), dim3(256), 0, c->stream, mg->d_ainv, Dinv2[step & 1], PT, RT, n, kb, nb);
         hipLaunchKernelGGL(k_gjs_update_mfma, dim3(nt, nt), dim3(256), 0, c->stream, mg->d_ainv, PT, RT, n, kb, nb, Dinv2[(step + 1) & 1], kb_next,
                            nb_next);
       }
