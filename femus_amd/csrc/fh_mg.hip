@@ -448,11 +448,13 @@ __global__ __launch_bounds__(256) void k_gjb_update_mfma(double* __restrict__ D,
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_csr_symmetry(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val, int n,
                                                       double tol, int* __restrict__ flag) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;     // one wave per row
   if (i >= n) return;
   double dmax = 0.0;
-  for (int k = rowptr[i]; k < rowptr[i + 1]; k++) dmax = fmax(dmax, fabs(val[k]));
-  for (int k = rowptr[i]; k < rowptr[i + 1]; k++) {
+  for (int k = rowptr[i] + lane; k < rowptr[i + 1]; k += 64) dmax = fmax(dmax, fabs(val[k]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
+  for (int k = rowptr[i] + lane; k < rowptr[i + 1]; k += 64) {
     const int j = col[k];
     if (j == i) continue;
     int lo = rowptr[j], hi = rowptr[j + 1] - 1;
@@ -941,7 +943,7 @@ static int coarse_factor(fh_mg_t mg) {
     int* d_flag = reinterpret_cast<int*>(Dinv + GJ_NB * GJ_NB);
     int h_flag = 0;
     FH_CHECK_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL(k_csr_symmetry, dim3(fh_div_up(n, 256)), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, n, 1e-12, d_flag);
+    hipLaunchKernelGGL(k_csr_symmetry, dim3(fh_div_up(n, 4)), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, n, 1e-12, d_flag);
     FH_CHECK_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     FH_CHECK_HIP(hipStreamSynchronize(c->stream));
     if (h_flag == 0) {
