@@ -477,6 +477,69 @@ __global__ __launch_bounds__(256) void k_row_assemble(const int* __restrict__ ro
   }
 }
 
+// The same pass for matrices whose rows have at most 128 entries (Q2 on hexes: 125): every 32-lane group works on TWO rows at
+// once -- the pass is bound by the dependent round trips adjacency -> element rows -> store of each row, so the loads of both
+// rows are issued together (twice the bytes in flight at the same LDS footprint).
+template <int NC>
+__global__ __launch_bounds__(256) void k_row_assemble2(const int* __restrict__ rowptr, int m, const int* __restrict__ adj_ptr,
+                                                       const unsigned char* __restrict__ rowmap, const double* __restrict__ Kbuf, int kstride,
+                                                       const double* __restrict__ Fbuf, double* __restrict__ val, double* __restrict__ res) {
+  __shared__ double acc[8][2][128];
+  const int sub = threadIdx.x >> 5, lane = threadIdx.x & 31;
+  const int r0 = (blockIdx.x * 8 + sub) * 2;
+  if (r0 >= m) return;
+  const bool two = r0 + 1 < m;
+  const int rsA = rowptr[r0], rsB = rowptr[r0 + 1], reB = two ? rowptr[r0 + 2] : rsB;
+  const int aA0 = adj_ptr[r0], aB0 = adj_ptr[r0 + 1], aB1 = two ? adj_ptr[r0 + 2] : aB0;
+  const int lenA = rsB - rsA, lenB = reB - rsB;
+  for (int p = lane; p < 128; p += 32) {
+    acc[sub][0][p] = 0.0;
+    acc[sub][1][p] = 0.0;
+  }
+  double fA = 0.0, fB = 0.0;
+  constexpr int RB = 4;
+  const int nA = aB0 - aA0, nB = aB1 - aB0;
+  for (int ab = 0; ab < max(nA, nB); ab += RB) {
+    double kA[RB], kB[RB], gA[RB], gB[RB];
+    int pA[RB], pB[RB];
+#pragma unroll
+    for (int t = 0; t < RB; t++) {
+      const int iA = ab + t, iB = ab + t;
+      kA[t] = kB[t] = gA[t] = gB[t] = 0.0;
+      pA[t] = pB[t] = 0;
+      if (iA < nA) {
+        const int a = aA0 + iA;
+        if (lane < NC) {
+          kA[t] = Kbuf[(size_t)a * kstride + lane];
+          pA[t] = rowmap[(size_t)a * NC + lane];
+        }
+        if (lane == 0) gA[t] = Fbuf[a];
+      }
+      if (iB < nB) {
+        const int a = aB0 + iB;
+        if (lane < NC) {
+          kB[t] = Kbuf[(size_t)a * kstride + lane];
+          pB[t] = rowmap[(size_t)a * NC + lane];
+        }
+        if (lane == 0) gB[t] = Fbuf[a];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < RB; t++) {          // ascending element order per row, as in the one-row kernel
+      if (ab + t < nA && lane < NC) acc[sub][0][pA[t]] += kA[t];
+      if (ab + t < nB && lane < NC) acc[sub][1][pB[t]] += kB[t];
+      fA += gA[t];
+      fB += gB[t];
+    }
+  }
+  for (int p = lane; p < lenA; p += 32) val[rsA + p] = acc[sub][0][p];
+  for (int p = lane; p < lenB; p += 32) val[rsB + p] = acc[sub][1][p];
+  if (lane == 0) {
+    res[r0] = fA;
+    if (two) res[r0 + 1] = fB;
+  }
+}
+
 template <int NC>
 static int launch_rows(fh_assembler_t as, fh_mat_t A, double* res, bool build) {
   if (A->m == 0) return 0;
@@ -484,6 +547,9 @@ static int launch_rows(fh_assembler_t as, fh_mat_t A, double* res, bool build) {
   if (build)
     hipLaunchKernelGGL((k_row_assemble<NC, true>), grid, block, 0, as->ctx->stream, A->d_rowptr, A->d_col, A->m, as->d_adj_ptr, as->d_adj_ei,
                        as->d_rowmap, as->d_elem_dof, as->nloc, nullptr, as->kstride, nullptr, nullptr, nullptr);
+  else if (A->max_row <= 128 && as->ctx->assemble_rows2)
+    hipLaunchKernelGGL((k_row_assemble2<NC>), dim3(fh_div_up(A->m, 16)), block, 0, as->ctx->stream, A->d_rowptr, A->m, as->d_adj_ptr, as->d_rowmap,
+                       as->d_Kbuf, as->kstride, as->d_Fbuf, A->d_val, res);
   else
     hipLaunchKernelGGL((k_row_assemble<NC, false>), grid, block, 0, as->ctx->stream, A->d_rowptr, A->d_col, A->m, as->d_adj_ptr, as->d_adj_ei,
                        as->d_rowmap, as->d_elem_dof, as->nloc, as->d_Kbuf, as->kstride, as->d_Fbuf, A->d_val, res);

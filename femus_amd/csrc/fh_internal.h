@@ -55,6 +55,7 @@ struct fh_ctx_s {
   int asm_debug = 0;
   int assemble_mfma = 12;            // HEX27/Q2, 64 Gauss points: element matrices on the FP64 matrix cores, value = waves per workgroup (0 = off)
   int assemble_sumfac = 1;           // matrix-core element kernel: map Jacobian by sum factorisation (tensor-product tables)
+  int assemble_rows2 = 1;            // row pass: two rows per 32-lane group when no row has more than 128 entries
   int assemble_kpad = 1;             // HEX27/Q2 two-pass assembly: element rows padded to 32 doubles (whole 64-byte lines per row)
   int assemble_sym = 1;              // symmetric-tile HEX27/Q2 element kernel (2 elements per wave)
   int assemble_two_pass = 1;         // 1: element matrices + row gather (default), 0: coloured scatter
