@@ -50,7 +50,30 @@ def _free_port():
     return p
 
 
+def _record_worker_failure(tag, rank, world):
+    """diagnostics only: the traceback of a failing worker process goes to gpurun_out/ (kept by the GPU harness) besides the
+    pytest output, so that an intermittent failure of these multi-process tests leaves its cause behind (open items)"""
+    import os
+    import time
+    import traceback
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "worker_failure_%s_rank%d_of_%d_%d.log" % (tag, rank, world, int(time.time()))), "w") as f:
+            f.write(traceback.format_exc())
+    except Exception:
+        pass
+
+
 def _rank_worker(rank, world, port, nb, nlevels, out):
+    try:
+        _rank_worker_body(rank, world, port, nb, nlevels, out)
+    except BaseException:
+        _record_worker_failure("uniform", rank, world)
+        raise
+
+
+def _rank_worker_body(rank, world, port, nb, nlevels, out):
     import femus_amd as fa
     from femus_amd import dd as ddm
     comm = ddm.SocketComm(rank, world, "127.0.0.1", port)
@@ -126,6 +149,14 @@ def _amr_flag(x, level):
 
 
 def _amr_rank_worker(rank, world, port, nb, nlevels, n_uniform, out):
+    try:
+        _amr_rank_worker_body(rank, world, port, nb, nlevels, n_uniform, out)
+    except BaseException:
+        _record_worker_failure("adaptive", rank, world)
+        raise
+
+
+def _amr_rank_worker_body(rank, world, port, nb, nlevels, n_uniform, out):
     import femus_amd as fa
     from femus_amd import dd as ddm
     comm = ddm.SocketComm(rank, world, "127.0.0.1", port)
