@@ -97,6 +97,7 @@ extern "C" int fh_set_option(fh_ctx_t c, const char* name, double value) {
   else if (!strcmp(name, "spmv_threads")) c->spmv_threads = (int)value;
   else if (!strcmp(name, "assemble_emap")) c->assemble_emap = (int)value;
   else if (!strcmp(name, "asm_debug")) c->asm_debug = (int)value;
+  else if (!strcmp(name, "debug_poison")) c->debug_poison = (int)value;
   else if (!strcmp(name, "assemble_two_pass")) c->assemble_two_pass = (int)value;
   else if (!strcmp(name, "assemble_sym")) c->assemble_sym = (int)value;
   else if (!strcmp(name, "assemble_mfma")) c->assemble_mfma = (int)value;
@@ -195,11 +196,12 @@ __global__ __launch_bounds__(256) void k_axpby(double* __restrict__ y, const dou
   for (; i + 1 < n; i += stride) {
     double2 xv = *reinterpret_cast<const double2*>(x + i);
     double2 yv = *reinterpret_cast<const double2*>(y + i);
-    yv.x = a * xv.x + b * yv.x;
-    yv.y = a * xv.y + b * yv.y;
+    // BLAS semantics: with b == 0 the old y is not referenced (0 * NaN of an uninitialised buffer would be NaN)
+    yv.x = (b == 0.0) ? a * xv.x : a * xv.x + b * yv.x;
+    yv.y = (b == 0.0) ? a * xv.y : a * xv.y + b * yv.y;
     *reinterpret_cast<double2*>(y + i) = yv;
   }
-  if (i < n) y[i] = a * x[i] + b * y[i];
+  if (i < n) y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];
 }
 
 template <int OP>   // 0: scale, 1: shift, 2: abs

@@ -53,6 +53,7 @@ struct fh_ctx_s {
   int spmv_nt = 0;                    // non-temporal matrix stream
   int assemble_emap = 1;
   int asm_debug = 0;
+  int debug_poison = 0;              // work buffers of the multigrid / Krylov solvers start as NaN instead of zero (tests)
   int assemble_mfma = 12;            // HEX27/Q2, 64 Gauss points: element matrices on the FP64 matrix cores, value = waves per workgroup (0 = off)
   int assemble_sumfac = 1;           // matrix-core element kernel: map Jacobian by sum factorisation (tensor-product tables)
   int assemble_rows2 = 1;            // row pass: two rows per 32-lane group when no row has more than 128 entries

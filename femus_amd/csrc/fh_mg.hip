@@ -718,7 +718,8 @@ __global__ __launch_bounds__(256) void k_multiaxpy(double* __restrict__ w, const
 }
 
 __global__ __launch_bounds__(256) void k_axpby2(double* y, const double* x, double a, double b, int n) {   // x may alias y
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) y[i] = a * x[i] + b * y[i];
+  // BLAS semantics: with b == 0 the old y is NOT referenced (it may be uninitialised memory: 0 * NaN = NaN)
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];
 }
 
 static inline int sgrid(fh_ctx_t c, int n) { return std::max(1, std::min(fh_div_up(n, 256), c->num_cu * 8)); }
@@ -1036,7 +1037,7 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
     const size_t nb = ((size_t)L.ncols + 2) * sizeof(double);
     for (double** p : {&L.dinv, &L.x, &L.x2, &L.b, &L.r}) {
       FH_CHECK_HIP(hipMalloc(p, nb));
-      FH_CHECK_HIP(hipMemsetAsync(*p, 0, nb, c->stream));
+      FH_CHECK_HIP(hipMemsetAsync(*p, (c->debug_poison && p != &L.dinv) ? 0xFF : 0, nb, c->stream));
     }
     FH_TRY(fh_dev_get_diag(L.A, L.dinv, 1));
     if (L.smoother == FH_SMOOTH_GS_COLOR && l > 0 && L.ncolors == 0) FH_TRY(color_rows(L));
@@ -1212,7 +1213,12 @@ static int krylov_reserve(fh_mg_t mg, int nvec, int n) {
   if ((int)mg->kv.size() >= nvec && mg->kv_n == n) return 0;
   for (double* p : mg->kv) hipFree(p);
   mg->kv.assign(nvec, nullptr);
-  for (int i = 0; i < nvec; i++) FH_CHECK_HIP(hipMalloc(&mg->kv[i], ((size_t)n + 2) * sizeof(double)));
+  for (int i = 0; i < nvec; i++) {
+    FH_CHECK_HIP(hipMalloc(&mg->kv[i], ((size_t)n + 2) * sizeof(double)));
+    // zero: ghost tails are read by the SpMV before any write.  debug_poison fills with NaN bit patterns instead, so that a test
+    // can show that nothing ELSE of a work vector is read before it is written (tests/test_gpu_multigrid.py)
+    FH_CHECK_HIP(hipMemsetAsync(mg->kv[i], mg->ctx->debug_poison ? 0xFF : 0, ((size_t)n + 2) * sizeof(double), mg->ctx->stream));
+  }
   mg->kv_n = n;
   return 0;
 }

@@ -78,6 +78,7 @@ def _rank_worker_body(rank, world, port, nb, nlevels, out):
     from femus_amd import dd as ddm
     comm = ddm.SocketComm(rank, world, "127.0.0.1", port)
     ctx = fa.Context(0)
+    ctx.set_option("debug_poison", 1)      # work buffers of the cycle and of GMRES start as NaN: nothing may be read before it is written / received
     dp = ddm.DistributedPoisson(ctx, comm, world, rank, nb=nb, nlevels=nlevels, transport="host")
     dp.assemble()
     dp.set_penalty_top()
@@ -161,6 +162,7 @@ def _amr_rank_worker_body(rank, world, port, nb, nlevels, n_uniform, out):
     from femus_amd import dd as ddm
     comm = ddm.SocketComm(rank, world, "127.0.0.1", port)
     ctx = fa.Context(0)
+    ctx.set_option("debug_poison", 1)      # as in _rank_worker_body
     dp = ddm.DistributedPoisson(ctx, comm, world, rank, nb=nb, nlevels=nlevels, transport="host", flag_fn=_amr_flag, n_uniform=n_uniform)
     dp.assemble()                                     # a rank whose box is refined everywhere keeps the homogeneous path
     dp.set_penalty_top()

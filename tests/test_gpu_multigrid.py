@@ -92,6 +92,27 @@ def test_outer_solvers_reach_direct_solution(ctx, H3, outer):
     mg.destroy()
 
 
+@pytest.mark.parametrize("outer", ["gmres", "cg", "richardson"])
+def test_solvers_do_not_read_uninitialised_work_memory(ctx, H3, outer):
+    """regression: the Krylov work vectors used to be raw allocations and `y = a x + 0 * y` read them -- NaN whenever the
+    allocation landed on NaN bit patterns (seen as a rare failure of GMRES solves on freshly booted boxes).  With `debug_poison`
+    the work buffers of the hierarchy and of the solvers start as NaN: the results must not change."""
+    n = H3.A[-1].shape[0]
+    xd = spla.spsolve(H3.A[-1].tocsc(), H3.b)
+    ctx.set_option("debug_poison", 1)
+    try:
+        mg, mats = device_hierarchy(ctx, H3)
+        b, x = ctx.vector_from(H3.b), ctx.vector(n)
+        mg.vcycle(b, x)
+        assert rel(x.to_numpy(), fo.vcycle(H3, len(H3.A) - 1, H3.b)) < 1e-11
+        its, rn = mg.solve(b, x, outer=outer, rtol=1e-12, maxit=60)
+    finally:
+        ctx.set_option("debug_poison", 0)
+    assert np.isfinite(x.to_numpy()).all() and np.isfinite(rn)
+    assert rel(x.to_numpy(), xd) < 1e-10
+    mg.destroy()
+
+
 def test_preonly_is_one_cycle(ctx, H3):
     mg, mats = device_hierarchy(ctx, H3)
     n = H3.A[-1].shape[0]
