@@ -1558,6 +1558,10 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
     as->kbuf_bytes = std::max<size_t>((size_t)aei.size() * as->kstride, 1) * sizeof(double);
     FH_CHECK_HIP(hipMalloc(&as->d_Kbuf, as->kbuf_bytes));
     FH_CHECK_HIP(hipMalloc(&as->d_Fbuf, std::max<size_t>(aei.size(), 1) * sizeof(double)));
+    if (ctx->debug_poison) {   // tests: the row pass must read nothing the element kernels have not written
+      FH_CHECK_HIP(hipMemset(as->d_Kbuf, 0xFF, as->kbuf_bytes));
+      FH_CHECK_HIP(hipMemset(as->d_Fbuf, 0xFF, std::max<size_t>(aei.size(), 1) * sizeof(double)));
+    }
     FH_TRY(dispatch_rows(as, A, nullptr, true));
     FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     as->two_pass = true;

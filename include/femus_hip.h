@@ -53,7 +53,9 @@ int fh_timer_stop(fh_ctx_t ctx, double* milliseconds);
  * "assemble_mfma" (12: HEX27/Q2 element matrices on the FP64 matrix cores, value = waves per workgroup, 0 = vector kernel),
  * "assemble_kpad" (1: element rows of the two-pass buffer padded to 256 bytes; read when an assembler is created),
  * "assemble_sumfac" (1: map Jacobian by sum factorisation in that kernel), "assemble_sym" (1), "assemble_affine" (0, see fh_assembler_affine_count), "gj_mfma" (1: coarse dense inverse updates on the
- * matrix cores), "gj_symmetric" (1: symmetric sweep on the upper block triangle when the coarse operator is symmetric), "spgemm_slot_map" (1), "use_graph" (1), "asm_debug" (0).  Returns non-zero for unknown names */
+ * matrix cores), "gj_symmetric" (1: symmetric sweep on the upper block triangle when the coarse operator is symmetric), "spgemm_slot_map" (1), "use_graph" (1), "asm_debug" (0),
+ * "debug_poison" (0; tests: work buffers of the solvers and the element-row buffers start as NaN bit patterns instead of zero).
+ * Returns non-zero for unknown names */
 int fh_set_option(fh_ctx_t ctx, const char* name, double value);
 
 /* ---- vectors: NumericVector (src/03_algebra/00_vectors/NumericVector.hpp:51-353, PetscVector.cpp) ----

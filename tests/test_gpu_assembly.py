@@ -164,6 +164,7 @@ def test_global_assembly_options_of_the_hex27_path(ctx, sumfac, kpad, mfma):
     ctx.set_option("assemble_sumfac", sumfac)
     ctx.set_option("assemble_kpad", kpad)
     ctx.set_option("assemble_mfma", mfma)
+    ctx.set_option("debug_poison", 1)              # element-row buffers start as NaN: the row pass may read only what was written
     try:
         asm = capi.Assembler(ctx, m, "biquadratic", A, elem_dof=ed, coords=xy)      # kpad is read here
         asm.assemble(A, res, ctx.vector_from(u), 1, (2.0, 1.3))
@@ -171,6 +172,7 @@ def test_global_assembly_options_of_the_hex27_path(ctx, sumfac, kpad, mfma):
         asm.assemble(A, res, ctx.vector_from(u), 1, (2.0, 1.3))
         assert np.array_equal(v1, A.values()) and np.array_equal(f1, res.to_numpy())
     finally:
+        ctx.set_option("debug_poison", 0)
         ctx.set_option("assemble_sumfac", 1)
         ctx.set_option("assemble_kpad", 1)
         ctx.set_option("assemble_mfma", 12)
