@@ -2,6 +2,7 @@
 // Replaces PetscVector (src/03_algebra/00_vectors/PetscVector.cpp) behind the C-ABI of include/femus_hip.h.
 // All kernels are HBM-bound streaming kernels: 16-byte accesses per lane, grid-stride, wave64 shuffles
 // for reductions, one partial per workgroup, second pass in one workgroup (deterministic order).
+#include <cstdlib>
 #include "fh_internal.h"
 #include <cstdarg>
 #include <cmath>
@@ -39,6 +40,7 @@ extern "C" int fh_init(int device, fh_ctx_t* out) {
   FH_CHECK_HIP(hipEventCreate(&c->ev0));
   FH_CHECK_HIP(hipEventCreate(&c->ev1));
   FH_CHECK_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  if (const char* e = getenv("FEMUS_HIP_POISON")) c->debug_poison = atoi(e);   // whole test suites in poison mode (see debug_poison)
   FH_TRY(fh_reserve_reduction(c, 4096));
   *out = c;
   return 0;
