@@ -299,6 +299,10 @@ extern "C" int fh_ns_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, i
   FH_TRY(up((void**)&as->d_adj_ei, aei.data(), aei.size() * sizeof(int)));
   FH_CHECK_HIP(hipMalloc(&as->d_K, std::max<size_t>((size_t)nel * nd * nd, 1) * sizeof(double)));
   FH_CHECK_HIP(hipMalloc(&as->d_F, std::max<size_t>((size_t)nel * nd, 1) * sizeof(double)));
+  if (ctx->debug_poison) {   // tests: the row pass must read nothing the element kernel has not written
+    FH_CHECK_HIP(hipMemset(as->d_K, 0xFF, std::max<size_t>((size_t)nel * nd * nd, 1) * sizeof(double)));
+    FH_CHECK_HIP(hipMemset(as->d_F, 0xFF, std::max<size_t>((size_t)nel * nd, 1) * sizeof(double)));
+  }
   *out = as;
   return 0;
 }
