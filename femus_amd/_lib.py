@@ -159,5 +159,10 @@ def _declare(L):
     sig("fh_halo_create", c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, P(c_void_p))
     sig("fh_halo_create_shared", c_void_p, c_void_p, c_void_p, c_void_p, P(c_void_p))
     sig("fh_halo_update", c_void_p, c_void_p)
+    sig("fh_halo_begin", c_void_p, c_void_p)
+    sig("fh_halo_end", c_void_p)
+    sig("fh_spmv_ghosted", c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_double)
+    sig("fh_halo_stats", c_void_p, c_int, P(ctypes.c_int64), P(ctypes.c_int64), P(c_double), P(c_double))
+    sig("fh_mat_split_info", c_void_p, c_int, P(c_int), P(c_int))
     sig("fh_halo_allreduce_sum", c_void_p, c_void_p, c_int)
     sig("fh_halo_destroy", c_void_p)

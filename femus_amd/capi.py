@@ -345,6 +345,12 @@ class Mat:
         _chk(self.L.fh_mat_norm(self.h, 0, ctypes.byref(out)))
         return out.value
 
+    def split_info(self, n_own_cols):
+        """(interior, interface) row-block counts of the overlap split for an operator over [owned | ghost] columns"""
+        a, b = ctypes.c_int(), ctypes.c_int()
+        _chk(self.L.fh_mat_split_info(self.h, int(n_own_cols), ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def spmv_algorithmic_bytes(self):
         return int(self.L.fh_spmv_algorithmic_bytes(self.h))
 
@@ -799,6 +805,27 @@ class Halo:
 
     def update(self, v):
         _chk(self.L.fh_halo_update(self.h, v.h))
+
+    def begin(self, v):
+        _chk(self.L.fh_halo_begin(self.h, v.h))
+
+    def end(self):
+        _chk(self.L.fh_halo_end(self.h))
+
+    def spmv(self, A, x, y, mode=0, b=None, dinv=None, omega=0.0):
+        """y = op(A, x) with the ghosts of x refreshed through this plan, exchange overlapped with the interior rows"""
+        _chk(self.L.fh_spmv_ghosted(A.h, self.h, x.h, y.h, int(mode), None if b is None else b.h, None if dinv is None else dinv.h, float(omega)))
+
+    def stats(self, reset=False):
+        """{'updates', 'bytes_sent', 'exchange_ms', 'exposed_ms'}; the two times need ctx.set_option('halo_profile', 1)"""
+        n, b = ctypes.c_int64(), ctypes.c_int64()
+        tx, te = ctypes.c_double(), ctypes.c_double()
+        _chk(self.L.fh_halo_stats(self.h, int(bool(reset)), ctypes.byref(n), ctypes.byref(b), ctypes.byref(tx), ctypes.byref(te)))
+        return {"updates": n.value, "bytes_sent": b.value, "exchange_ms": tx.value, "exposed_ms": te.value}
+
+    def allreduce_vec(self, v):
+        """in-place sum over the ranks of the owned part of a device vector"""
+        _chk(self.L.fh_halo_allreduce_vec(self.h, v.h))
 
     def allreduce_sum(self, vals):
         a = _f64(np.atleast_1d(vals)).copy()

@@ -111,6 +111,9 @@ extern "C" int fh_set_option(fh_ctx_t c, const char* name, double value) {
   else if (!strcmp(name, "assemble_affine")) c->assemble_affine = (int)value;
   else if (!strcmp(name, "use_graph")) c->use_graph = (int)value;
   else if (!strcmp(name, "spgemm_slot_map")) c->spgemm_slot_map = (int)value;
+  else if (!strcmp(name, "halo_overlap")) c->halo_overlap = (int)value;
+  else if (!strcmp(name, "halo_profile")) c->halo_profile = (int)value;
+  else if (!strcmp(name, "halo_self_rccl")) c->halo_self_rccl = (int)value;
   else {
     fh_set_error("fh_set_option: unknown option '%s'", name);
     return 2;

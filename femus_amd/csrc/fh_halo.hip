@@ -20,13 +20,25 @@ struct fh_halo_s {
   int* d_send_idx = nullptr;
   double* d_sendbuf = nullptr;
   double* d_scalars = nullptr;
-  hipEvent_t ev_packed = nullptr, ev_done = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_done = nullptr, ev_d2h = nullptr;
+  // begin/end pair in flight (the exchange runs on the communication stream while the caller queues interior work)
+  double* pend_vd = nullptr;
+  int pend_owned = 0;
+  bool pending = false;
+  // statistics (fh_halo_stats): exchanges started, payload sent; with the context option "halo_profile" also the duration of the
+  // exchanges (pack done -> ghosts landed) and the part of it the compute stream really waited for (exposed)
+  int64_t n_updates = 0, bytes_sent = 0;
+  double exchange_ms = 0.0, exposed_ms = 0.0;
+  hipEvent_t evt_begin = nullptr, evt_ready = nullptr;
   // host-staged transport (fh_halo_create_host): the exchange itself is the caller's function (MPI_Neighbor_alltoallv, sockets ...)
   fh_exchange_fn exchange = nullptr;
   fh_allreduce_fn allreduce = nullptr;
   void* user = nullptr;
   double *h_send = nullptr, *h_recv = nullptr;   // pinned
 };
+
+// a one-rank plan without communicator or transport has nothing to exchange
+static inline bool halo_inert(fh_halo_t h) { return h->nranks == 1 && !h->comm && !h->exchange; }
 
 #define FH_CHECK_NCCL(expr)                                                                     \
   do {                                                                                          \
@@ -111,8 +123,13 @@ static int halo_create(fh_ctx_t ctx, int rank, int comm_ranks, const char* id128
   FH_CHECK_HIP(hipMalloc(&h->d_scalars, 256 * sizeof(double)));
   if (h->nsend) FH_CHECK_HIP(hipMemcpy(h->d_send_idx, send_idx, h->nsend * sizeof(int), hipMemcpyHostToDevice));
   FH_CHECK_HIP(hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
-  FH_CHECK_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
-  if (comm_ranks > 1) {
+  FH_CHECK_HIP(hipEventCreateWithFlags(&h->ev_d2h, hipEventDisableTiming));
+  FH_CHECK_HIP(hipEventCreate(&h->ev_done));       // timing-enabled: halo_profile reads it
+  FH_CHECK_HIP(hipEventCreate(&h->evt_begin));
+  FH_CHECK_HIP(hipEventCreate(&h->evt_ready));
+  // "halo_self_rccl": a ONE-rank plan still gets a communicator and sends its interface entries to itself through
+  // ncclSend/ncclRecv -- the only way to execute the RCCL calls of this file on a box with a single GPU (hardware preflight)
+  if (comm_ranks > 1 || (plan_ranks == 0 && ctx->halo_self_rccl)) {
     if (shared) {
       h->comm = shared;
     } else {
@@ -134,6 +151,8 @@ extern "C" int fh_halo_sizes(fh_halo_t h, int* nsend, int* nrecv) {
 }
 
 int fh_halo_update_ptr(fh_halo_t h, double* vd, int n_owned);
+int fh_halo_begin_ptr(fh_halo_t h, double* vd, int n_owned);
+int fh_halo_end_ptr(fh_halo_t h);
 
 extern "C" int fh_halo_update(fh_halo_t h, fh_vec_t v) {
   FH_REQUIRE(h && v, "fh_halo_update: null argument");
@@ -153,59 +172,143 @@ static int host_allreduce(fh_halo_t h, double* d, int n) {
 
 extern "C" int fh_halo_allreduce_vec(fh_halo_t h, fh_vec_t v) {
   FH_REQUIRE(h && v, "fh_halo_allreduce_vec: null argument");
-  if (h->nranks == 1 || v->n_local == 0) return 0;
+  if (halo_inert(h) || v->n_local == 0) return 0;
   if (h->allreduce) return host_allreduce(h, v->d, v->n_local);
   FH_CHECK_NCCL(ncclAllReduce(v->d, v->d, v->n_local, ncclDouble, ncclSum, h->comm, h->ctx->stream));
   return 0;
 }
 
 int fh_halo_allreduce_ptr(fh_halo_t h, double* d, int n) {
-  if (h->nranks == 1 || n == 0) return 0;
+  if (halo_inert(h) || n == 0) return 0;
   if (h->allreduce) return host_allreduce(h, d, n);
   FH_CHECK_NCCL(ncclAllReduce(d, d, n, ncclDouble, ncclSum, h->comm, h->ctx->stream));
   return 0;
 }
 
-int fh_halo_update_ptr(fh_halo_t h, double* vd, int n_owned) {
-  if (h->nranks == 1) return 0;
+// start the exchange of the ghosts of vd ([owned | ghost]): pack on the compute stream, transfer on the communication stream.
+// Work queued on the compute stream after this call and before fh_halo_end_ptr overlaps with the exchange; it must not read
+// the ghost tail.
+int fh_halo_begin_ptr(fh_halo_t h, double* vd, int n_owned) {
+  if (halo_inert(h)) return 0;
+  FH_REQUIRE(!h->pending, "fh_halo_begin: the previous exchange of this plan has not been ended");
   fh_ctx_t c = h->ctx;
-  if (h->exchange) {   // host-staged: pack -> pinned host -> caller's exchange -> ghost tail
-    if (h->nsend) {
-      int nb = std::max(1, std::min(fh_div_up(h->nsend, 256), c->num_cu * 4));
-      hipLaunchKernelGGL(k_pack, dim3(nb), dim3(256), 0, c->stream, vd, h->d_send_idx, h->d_sendbuf, h->nsend);
-      FH_CHECK_HIP(hipGetLastError());
-      FH_CHECK_HIP(hipMemcpyAsync(h->h_send, h->d_sendbuf, (size_t)h->nsend * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    }
-    FH_CHECK_HIP(hipStreamSynchronize(c->stream));
-    FH_REQUIRE(h->exchange(h->user, h->h_send, h->send_counts.data(), h->h_recv, h->recv_counts.data()) == 0,
-               "host transport: the exchange function failed");
-    if (h->nrecv) FH_CHECK_HIP(hipMemcpyAsync(vd + n_owned, h->h_recv, (size_t)h->nrecv * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    return 0;
-  }
-  struct { double* d; int n_local; } vv = {vd, n_owned};
-  auto* v = &vv;
+  const bool prof = c->halo_profile != 0;
   if (h->nsend) {
     int nb = std::max(1, std::min(fh_div_up(h->nsend, 256), c->num_cu * 4));
-    hipLaunchKernelGGL(k_pack, dim3(nb), dim3(256), 0, c->stream, v->d, h->d_send_idx, h->d_sendbuf, h->nsend);
+    hipLaunchKernelGGL(k_pack, dim3(nb), dim3(256), 0, c->stream, vd, h->d_send_idx, h->d_sendbuf, h->nsend);
     FH_CHECK_HIP(hipGetLastError());
   }
   FH_CHECK_HIP(hipEventRecord(h->ev_packed, c->stream));
   FH_CHECK_HIP(hipStreamWaitEvent(c->comm_stream, h->ev_packed, 0));
-  FH_CHECK_NCCL(ncclGroupStart());
-  for (int r = 0; r < h->nranks; r++) {
-    if (r == h->rank) continue;
-    if (h->send_counts[r]) FH_CHECK_NCCL(ncclSend(h->d_sendbuf + h->send_off[r], h->send_counts[r], ncclDouble, r, h->comm, c->comm_stream));
-    if (h->recv_counts[r]) FH_CHECK_NCCL(ncclRecv(v->d + v->n_local + h->recv_off[r], h->recv_counts[r], ncclDouble, r, h->comm, c->comm_stream));
+  if (prof) FH_CHECK_HIP(hipEventRecord(h->evt_begin, c->comm_stream));
+  if (h->exchange) {   // host-staged: pack -> pinned host (communication stream) ; the caller's exchange runs in fh_halo_end_ptr
+    if (h->nsend) FH_CHECK_HIP(hipMemcpyAsync(h->h_send, h->d_sendbuf, (size_t)h->nsend * sizeof(double), hipMemcpyDeviceToHost, c->comm_stream));
+    FH_CHECK_HIP(hipEventRecord(h->ev_d2h, c->comm_stream));
+  } else {
+    FH_CHECK_NCCL(ncclGroupStart());
+    for (int r = 0; r < h->nranks; r++) {     // r == rank: only a self plan ("halo_self_rccl") has entries there
+      if (h->send_counts[r]) FH_CHECK_NCCL(ncclSend(h->d_sendbuf + h->send_off[r], h->send_counts[r], ncclDouble, r, h->comm, c->comm_stream));
+      if (h->recv_counts[r]) FH_CHECK_NCCL(ncclRecv(vd + n_owned + h->recv_off[r], h->recv_counts[r], ncclDouble, r, h->comm, c->comm_stream));
+    }
+    FH_CHECK_NCCL(ncclGroupEnd());
+    FH_CHECK_HIP(hipEventRecord(h->ev_done, c->comm_stream));
   }
-  FH_CHECK_NCCL(ncclGroupEnd());
-  FH_CHECK_HIP(hipEventRecord(h->ev_done, c->comm_stream));
-  FH_CHECK_HIP(hipStreamWaitEvent(c->stream, h->ev_done, 0));   // consumers of the ghosts on the compute stream wait here
+  h->pend_vd = vd;
+  h->pend_owned = n_owned;
+  h->pending = true;
+  h->n_updates++;
+  h->bytes_sent += (int64_t)h->nsend * (int64_t)sizeof(double);
+  return 0;
+}
+
+// consumers of the ghosts queued on the compute stream after this call see the received values
+int fh_halo_end_ptr(fh_halo_t h) {
+  if (halo_inert(h)) return 0;
+  FH_REQUIRE(h->pending, "fh_halo_end: no exchange in flight");
+  fh_ctx_t c = h->ctx;
+  const bool prof = c->halo_profile != 0;
+  h->pending = false;
+  if (prof) FH_CHECK_HIP(hipEventRecord(h->evt_ready, c->stream));     // the compute stream has run out of overlapped work here
+  if (h->exchange) {
+    FH_CHECK_HIP(hipEventSynchronize(h->ev_d2h));                      // only the send buffer: the overlapped kernels keep running
+    FH_REQUIRE(h->exchange(h->user, h->h_send, h->send_counts.data(), h->h_recv, h->recv_counts.data()) == 0,
+               "host transport: the exchange function failed");
+    if (h->nrecv)
+      FH_CHECK_HIP(hipMemcpyAsync(h->pend_vd + h->pend_owned, h->h_recv, (size_t)h->nrecv * sizeof(double), hipMemcpyHostToDevice, c->comm_stream));
+    FH_CHECK_HIP(hipEventRecord(h->ev_done, c->comm_stream));
+  }
+  FH_CHECK_HIP(hipStreamWaitEvent(c->stream, h->ev_done, 0));
+  if (prof) {
+    float t_x = 0.f, t_e = 0.f;
+    FH_CHECK_HIP(hipEventSynchronize(h->ev_done));
+    FH_CHECK_HIP(hipEventSynchronize(h->evt_ready));
+    FH_CHECK_HIP(hipEventElapsedTime(&t_x, h->evt_begin, h->ev_done));
+    FH_CHECK_HIP(hipEventElapsedTime(&t_e, h->evt_ready, h->ev_done));   // negative: the ghosts were there before they were needed
+    h->exchange_ms += t_x;
+    h->exposed_ms += std::max(0.f, std::min(t_e, t_x));
+  }
+  return 0;
+}
+
+int fh_halo_update_ptr(fh_halo_t h, double* vd, int n_owned) {
+  FH_TRY(fh_halo_begin_ptr(h, vd, n_owned));
+  return fh_halo_end_ptr(h);
+}
+
+// operator application on a distributed level: y = op(A, x) with x = [owned | ghost].  What MatMult does for an MPIAIJ matrix
+// behind NumericVector::matrix_mult (PetscVector.cpp:203-214): start the ghost scatter, multiply the rows that need no ghost
+// while it is in flight (compute stream), wait, multiply the rest.  n_own = owned entries of x (the operator's columns below
+// n_own are local).  h == NULL: plain product.
+int fh_dev_halo_spmv(fh_halo_t h, fh_mat_t A, double* x, int n_own, double* y, int mode, const double* b, const double* dinv, double omega) {
+  if (!h) return fh_dev_spmv(A, x, y, mode, b, dinv, omega);
+  if (!A->ctx->halo_overlap) {
+    FH_TRY(fh_halo_update_ptr(h, x, n_own));
+    return fh_dev_spmv(A, x, y, mode, b, dinv, omega);
+  }
+  FH_TRY(fh_halo_begin_ptr(h, x, n_own));
+  FH_TRY(fh_dev_spmv_part(A, n_own, 0, x, y, mode, b, dinv, omega));
+  FH_TRY(fh_halo_end_ptr(h));
+  return fh_dev_spmv_part(A, n_own, 1, x, y, mode, b, dinv, omega);
+}
+
+extern "C" int fh_spmv_ghosted(fh_mat_t A, fh_halo_t halo, fh_vec_t x, fh_vec_t y, int mode, fh_vec_t b, fh_vec_t dinv, double omega) {
+  FH_REQUIRE(A && x && y, "fh_spmv_ghosted: null argument");
+  FH_REQUIRE(x->n_local + x->nghost >= A->n, "fh_spmv_ghosted: x has %d entries, matrix has %d columns", x->n_local + x->nghost, A->n);
+  FH_REQUIRE(y->n_local >= A->m, "fh_spmv_ghosted: y has %d entries, matrix has %d rows", y->n_local, A->m);
+  FH_REQUIRE(!halo || x->nghost == halo->nrecv, "fh_spmv_ghosted: vector has %d ghosts, plan receives %d", x->nghost, halo ? halo->nrecv : 0);
+  FH_REQUIRE(mode >= 0 && mode <= 3, "fh_spmv_ghosted: unknown mode %d", mode);
+  FH_REQUIRE(mode < 2 || (b && b->n_local >= A->m), "fh_spmv_ghosted: mode %d needs b", mode);
+  FH_REQUIRE(mode < 3 || (dinv && dinv->n_local >= A->m && A->m <= A->n), "fh_spmv_ghosted: mode 3 needs dinv and owned rows over [owned | ghost] columns");
+  return fh_dev_halo_spmv(halo, A, x->d, x->n_local, y->d, mode, b ? b->d : nullptr, dinv ? dinv->d : nullptr, omega);
+}
+
+extern "C" int fh_halo_begin(fh_halo_t h, fh_vec_t v) {
+  FH_REQUIRE(h && v, "fh_halo_begin: null argument");
+  FH_REQUIRE(v->nghost == h->nrecv, "fh_halo_begin: vector has %d ghosts, plan receives %d", v->nghost, h->nrecv);
+  return fh_halo_begin_ptr(h, v->d, v->n_local);
+}
+
+extern "C" int fh_halo_end(fh_halo_t h) {
+  FH_REQUIRE(h, "fh_halo_end: null argument");
+  return fh_halo_end_ptr(h);
+}
+
+extern "C" int fh_halo_stats(fh_halo_t h, int reset, int64_t* n_updates, int64_t* bytes_sent, double* exchange_ms, double* exposed_ms) {
+  FH_REQUIRE(h, "fh_halo_stats: null argument");
+  if (n_updates) *n_updates = h->n_updates;
+  if (bytes_sent) *bytes_sent = h->bytes_sent;
+  if (exchange_ms) *exchange_ms = h->exchange_ms;
+  if (exposed_ms) *exposed_ms = h->exposed_ms;
+  if (reset) {
+    h->n_updates = h->bytes_sent = 0;
+    h->exchange_ms = h->exposed_ms = 0.0;
+  }
   return 0;
 }
 
 extern "C" int fh_halo_allreduce_sum(fh_halo_t h, double* vals, int n) {
   FH_REQUIRE(h && vals && n >= 0 && n <= 256, "fh_halo_allreduce_sum: bad arguments (n <= 256)");
-  if (h->nranks == 1 || n == 0) return 0;
+  if (halo_inert(h) || n == 0) return 0;
   if (h->allreduce) {
     FH_REQUIRE(h->allreduce(h->user, vals, n) == 0, "host transport: the all-reduce function failed");
     return 0;
@@ -228,8 +331,8 @@ extern "C" int fh_halo_destroy(fh_halo_t h) {
   hipFree(h->d_scalars);
   if (h->h_send) hipHostFree(h->h_send);
   if (h->h_recv) hipHostFree(h->h_recv);
-  hipEventDestroy(h->ev_packed);
-  hipEventDestroy(h->ev_done);
+  for (hipEvent_t e : {h->ev_packed, h->ev_done, h->ev_d2h, h->evt_begin, h->evt_ready})
+    if (e) hipEventDestroy(e);
   delete h;
   return 0;
 }

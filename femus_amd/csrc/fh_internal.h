@@ -65,6 +65,9 @@ struct fh_ctx_s {
   int gj_mfma = 1;                   // coarse dense inverse: rank-NB updates on the FP64 matrix cores
   int use_graph = 1;
   int spgemm_slot_map = 1;           // Galerkin products stream a precomputed slot map instead of searching
+  int halo_overlap = 1;              // distributed operators: rows without ghost columns run while the ghost exchange is in flight
+  int halo_profile = 0;              // time every exchange and the part of it the compute stream waited for (fh_halo_stats; synchronises)
+  int halo_self_rccl = 0;            // one-rank plans exchange with themselves through RCCL (hardware preflight on a single GPU)
 };
 
 struct fh_vec_s {
@@ -96,6 +99,12 @@ struct fh_mat_s {
   int* d_blkinfo = nullptr;            // 8 ints per row block: r0, r1, s, e, u0, nu (one descriptor load instead of a pointer chain)
   int lx_tile = 0;
   int max_row = 0;
+  // interior / interface split of the row blocks for operators over [owned | ghost] columns (fh_dev_spmv_part):
+  // descriptors permuted so that blocks without a ghost column come first
+  int split_nown = -1;                 // number of owned columns the split was built for (-1: none)
+  int split_tile = 0;
+  int nblk_int = 0;
+  int* d_blkinfo_split = nullptr;
   // cached explicit transpose for matrix_mult_transpose
   fh_mat_t At = nullptr;
   int* d_tperm = nullptr;             // At.val[k] = val[tperm[k]]
@@ -111,5 +120,10 @@ int fh_mat_build_rowblocks(fh_mat_t A, int tile);
 int fh_mat_build_localcols(fh_mat_t A);
 int fh_mat_refresh_transpose(fh_mat_t A);   // re-gather values into the cached transpose
 int fh_dev_spmv(fh_mat_t A, const double* x, double* y, int mode, const double* b, const double* dinv, double omega);
+// part 0: the row blocks that read no column >= n_own_cols (no ghost), part 1: the others; part 0 + part 1 = fh_dev_spmv
+int fh_dev_spmv_part(fh_mat_t A, int n_own_cols, int part, const double* x, double* y, int mode, const double* b, const double* dinv, double omega);
+
+// y = op(A, x) for an operator over [owned | ghost] columns: ghost exchange of x overlapped with the rows that need no ghost
+int fh_dev_halo_spmv(fh_halo_t h, fh_mat_t A, double* x, int n_own, double* y, int mode, const double* b, const double* dinv, double omega);
 
 static inline int fh_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

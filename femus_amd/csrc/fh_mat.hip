@@ -69,6 +69,7 @@ extern "C" int fh_mat_destroy(fh_mat_t A) {
   if (A->d_lcol) hipFree(A->d_lcol);
   if (A->d_tile_s) hipFree(A->d_tile_s);
   if (A->d_blkinfo) hipFree(A->d_blkinfo);
+  if (A->d_blkinfo_split) hipFree(A->d_blkinfo_split);
   delete A;
   return 0;
 }
@@ -116,6 +117,7 @@ int fh_mat_build_rowblocks(fh_mat_t A, int tile) {
   A->tile_kernel = A->ctx->spmv_kernel;
   A->h_rowblk = blk;
   A->lx_tile = 0;   // local-column data (if any) no longer matches the row blocks
+  A->split_nown = -1;
   if (A->d_rowblk) FH_CHECK_HIP(hipFree(A->d_rowblk));
   FH_CHECK_HIP(hipMalloc(&A->d_rowblk, blk.size() * sizeof(int)));
   FH_CHECK_HIP(hipMemcpy(A->d_rowblk, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -630,6 +632,7 @@ int fh_mat_build_localcols(fh_mat_t A) {
     FH_CHECK_HIP(hipMemcpy(A->d_blkinfo, info.data(), info.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   A->lx_tile = A->tile;
+  A->split_nown = -1;
   return 0;
 }
 
@@ -774,19 +777,25 @@ __global__ __launch_bounds__(NT) void k_spmv_lx(const int* __restrict__ rowptr, 
 }
 
 template <int TILE, int NT>
-static void launch_lx(fh_mat_t A, int mode, const double* x, double* y, const double* b, const double* dinv, double omega) {
+static void launch_lx(fh_mat_t A, int mode, const double* x, double* y, const double* b, const double* dinv, double omega,
+                      const int* blkinfo = nullptr, int nblk = -1) {
   fh_ctx_t c = A->ctx;
-  int q = 0, grid = A->nblk, chunk = 1;
-  if (c->spmv_xcd_remap && A->nblk >= 64) {
+  if (!blkinfo) {          // all row blocks in matrix order; otherwise a sub-list of descriptors (interior / interface split)
+    blkinfo = A->d_blkinfo;
+    nblk = A->nblk;
+  }
+  if (nblk <= 0) return;
+  int q = 0, grid = nblk, chunk = 1;
+  if (c->spmv_xcd_remap && nblk >= 64) {
     // spmv_xcd_remap: 1 = contiguous eighth per XCD, n > 1 = chunks of n consecutive row blocks per XCD, interleaved
-    chunk = (c->spmv_xcd_remap == 1) ? (A->nblk + 7) / 8 : c->spmv_xcd_remap;
+    chunk = (c->spmv_xcd_remap == 1) ? (nblk + 7) / 8 : c->spmv_xcd_remap;
     const int per_round = 8 * chunk;
-    q = ((A->nblk + per_round - 1) / per_round) * chunk;     // positions per XCD
+    q = ((nblk + per_round - 1) / per_round) * chunk;     // positions per XCD
     grid = 8 * q;
   }
 #define FH_LAUNCH(MODE, SH) \
   hipLaunchKernelGGL((k_spmv_lx<TILE, MODE, SH, NT>), dim3(grid), dim3(NT), 0, c->stream, A->d_rowptr, A->d_col, A->d_lcol, A->d_val, \
-                     A->d_blkinfo, A->d_ucols, A->nblk, q, chunk, x, y, b, dinv, omega)
+                     blkinfo, A->d_ucols, nblk, q, chunk, x, y, b, dinv, omega)
   if (c->spmv_share) {
     switch (mode) {
       case 0: FH_LAUNCH(0, true); break;
@@ -803,6 +812,38 @@ static void launch_lx(fh_mat_t A, int mode, const double* x, double* y, const do
     }
   }
 #undef FH_LAUNCH
+}
+
+// interior / interface split for an operator over [owned | ghost] columns (PETSc keeps the two column ranges of an MPIAIJ matrix
+// as two matrices so that MatMult can multiply the local part while the scatter is in flight, PetscVector.cpp:203-214 ->
+// MatMult; here the row BLOCKS are classified): the 32-byte block descriptors are copied in a permuted order, blocks whose
+// rows read no column >= n_own first.  The kernel is unchanged -- every descriptor is self-contained.
+static int build_split(fh_mat_t A, int n_own) {
+  const int nblk = A->nblk;
+  const std::vector<int>& blk = A->h_rowblk;
+  std::vector<int> info((size_t)nblk * 8 + 8, 0);
+  FH_CHECK_HIP(hipMemcpy(info.data(), A->d_blkinfo, (size_t)nblk * 8 * sizeof(int), hipMemcpyDeviceToHost));
+  std::vector<int> order;
+  order.reserve(nblk);
+  std::vector<char> ghost(nblk, 0);
+  for (int b = 0; b < nblk; b++)
+    for (int r = blk[b]; r < blk[b + 1] && !ghost[b]; r++)     // columns are sorted inside a row: its last one is its largest
+      if (A->h_rowptr[r + 1] > A->h_rowptr[r] && A->h_col[A->h_rowptr[r + 1] - 1] >= n_own) ghost[b] = 1;
+  for (int b = 0; b < nblk; b++)
+    if (!ghost[b]) order.push_back(b);
+  const int n_int = (int)order.size();
+  for (int b = 0; b < nblk; b++)
+    if (ghost[b]) order.push_back(b);
+  std::vector<int> perm((size_t)nblk * 8 + 8, 0);
+  for (int k = 0; k < nblk; k++) memcpy(&perm[(size_t)k * 8], &info[(size_t)order[k] * 8], 8 * sizeof(int));
+  if (A->d_blkinfo_split) FH_CHECK_HIP(hipFree(A->d_blkinfo_split));
+  A->d_blkinfo_split = nullptr;
+  FH_CHECK_HIP(hipMalloc(&A->d_blkinfo_split, perm.size() * sizeof(int)));
+  FH_CHECK_HIP(hipMemcpy(A->d_blkinfo_split, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice));
+  A->nblk_int = n_int;
+  A->split_nown = n_own;
+  A->split_tile = A->tile;
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1137,6 +1178,39 @@ int fh_dev_spmv(fh_mat_t A, const double* x, double* y, int mode, const double* 
     else launch_stream<4096>(A, mode, x, y, b, dinv, omega);
   }
   FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int fh_dev_spmv_part(fh_mat_t A, int n_own, int part, const double* x, double* y, int mode, const double* b, const double* dinv, double omega) {
+  fh_ctx_t c = A->ctx;
+  if (A->m == 0) return 0;
+  FH_REQUIRE(mode >= 0 && mode <= 3, "fh_spmv: unknown mode %d", mode);
+  FH_REQUIRE(x != y, "fh_spmv: x and y must not alias");
+  FH_REQUIRE(part == 0 || part == 1, "fh_dev_spmv_part: part %d", part);
+  const bool lx = (c->spmv_kernel == 3 || (c->spmv_kernel == 4 && A->max_row > c->spmv_tile)) && c->spmv_threads == 256 &&
+                  (c->spmv_tile == 1024 || c->spmv_tile == 2048 || c->spmv_tile == 4096);
+  if (!lx) return part == 0 ? 0 : fh_dev_spmv(A, x, y, mode, b, dinv, omega);     // other kernels: no split, everything after the exchange
+  if (A->tile != c->spmv_tile || (A->tile_kernel != 3 && A->tile_kernel != 4)) FH_TRY(fh_mat_build_rowblocks(A, c->spmv_tile));
+  if (A->lx_tile != A->tile) FH_TRY(fh_mat_build_localcols(A));
+  if (A->split_nown != n_own || A->split_tile != A->tile || !A->d_blkinfo_split) FH_TRY(build_split(A, n_own));
+  const int* info = A->d_blkinfo_split + (part == 0 ? 0 : (size_t)A->nblk_int * 8);
+  const int nb = part == 0 ? A->nblk_int : A->nblk - A->nblk_int;
+  if (A->tile == 1024) launch_lx<1024, 256>(A, mode, x, y, b, dinv, omega, info, nb);
+  else if (A->tile == 2048) launch_lx<2048, 256>(A, mode, x, y, b, dinv, omega, info, nb);
+  else launch_lx<4096, 256>(A, mode, x, y, b, dinv, omega, info, nb);
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+/* interior / interface block counts of the split used on distributed levels (diagnostics, tests) */
+extern "C" int fh_mat_split_info(fh_mat_t A, int n_own_cols, int* nblk_interior, int* nblk_interface) {
+  FH_REQUIRE(A, "fh_mat_split_info: null argument");
+  fh_ctx_t c = A->ctx;
+  if (A->tile != c->spmv_tile || (A->tile_kernel != 3 && A->tile_kernel != 4)) FH_TRY(fh_mat_build_rowblocks(A, c->spmv_tile));
+  if (A->lx_tile != A->tile) FH_TRY(fh_mat_build_localcols(A));
+  if (A->split_nown != n_own_cols || A->split_tile != A->tile || !A->d_blkinfo_split) FH_TRY(build_split(A, n_own_cols));
+  if (nblk_interior) *nblk_interior = A->nblk_int;
+  if (nblk_interface) *nblk_interface = A->nblk - A->nblk_int;
   return 0;
 }
 

@@ -18,6 +18,8 @@
 
 int fh_dev_get_diag(fh_mat_t A, double* d, int invert);
 int fh_halo_update_ptr(fh_halo_t h, double* vd, int n_owned);
+int fh_halo_begin_ptr(fh_halo_t h, double* vd, int n_owned);
+int fh_halo_end_ptr(fh_halo_t h);
 int fh_halo_allreduce_ptr(fh_halo_t h, double* d, int n);
 
 struct MgLevel {
@@ -724,6 +726,10 @@ __global__ __launch_bounds__(256) void k_axpby2(double* y, const double* x, doub
 
 static inline int sgrid(fh_ctx_t c, int n) { return std::max(1, std::min(fh_div_up(n, 256), c->num_cu * 8)); }
 
+static inline int halo_spmv(fh_halo_t h, fh_mat_t A, double* x, int n_own, double* y, int mode, const double* b, const double* dinv, double omega) {
+  return fh_dev_halo_spmv(h, A, x, n_own, y, mode, b, dinv, omega);
+}
+
 // ------------------------------------------------------------------------------------------------
 // API
 // ------------------------------------------------------------------------------------------------
@@ -1087,8 +1093,7 @@ static int gs_sweeps(fh_mg_t mg, MgLevel& L, int nsweeps, bool zero_guess) {
     if (first) {
       FH_CHECK_HIP(hipMemcpyAsync(L.r, L.b, (size_t)L.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     } else {
-      if (L.halo) FH_TRY(fh_halo_update_ptr(L.halo, L.x, L.n));
-      FH_TRY(fh_dev_spmv(L.A, L.x, L.r, 2, L.b, nullptr, 0.0));
+      FH_TRY(halo_spmv(L.halo, L.A, L.x, L.n, L.r, 2, L.b, nullptr, 0.0));
     }
     double* z = L.x2;
     FH_CHECK_HIP(hipMemsetAsync(z, 0, (size_t)L.ncols * sizeof(double), c->stream));
@@ -1120,20 +1125,17 @@ static int run_cycle(fh_mg_t mg) {
       FH_TRY(vanka_sweeps(mg, L, L.npre));
     } else if (L.smoother == FH_SMOOTH_GS_COLOR) {
       FH_TRY(gs_sweeps(mg, L, L.npre, true));
-      if (L.halo) FH_TRY(fh_halo_update_ptr(L.halo, L.x, L.n));
     } else {
       // sweep 1 from a zero guess: x = omega D^-1 b ; sweeps 2..npre: fused Jacobi SpMV, ping-pong x <-> x2
       hipLaunchKernelGGL(k_first_sweep, dim3(sgrid(c, L.n)), dim3(256), 0, c->stream, L.x, L.b, L.dinv, L.omega, L.n);
       for (int s = 1; s < L.npre; s++) {
-        if (L.halo) FH_TRY(fh_halo_update_ptr(L.halo, L.x, L.n));
-        FH_TRY(fh_dev_spmv(L.A, L.x, L.x2, 3, L.b, L.dinv, L.omega));
+        FH_TRY(halo_spmv(L.halo, L.A, L.x, L.n, L.x2, 3, L.b, L.dinv, L.omega));
         std::swap(L.x, L.x2);
       }
-      if (L.halo) FH_TRY(fh_halo_update_ptr(L.halo, L.x, L.n));
     }
-    FH_TRY(fh_dev_spmv(L.A, L.x, L.r, 2, L.b, nullptr, 0.0));                       // r = b - A x
-    if (L.halo && !L.replicated_below) FH_TRY(fh_halo_update_ptr(L.halo, L.r, L.n));   // restriction reads ghost residuals
-    FH_TRY(fh_dev_spmv(L.R, L.r, mg->lv[l - 1].b, 0, nullptr, nullptr, 0.0));       // b_{l-1} = R r
+    FH_TRY(halo_spmv(L.halo, L.A, L.x, L.n, L.r, 2, L.b, nullptr, 0.0));             // r = b - A x (ghosts of x refreshed)
+    // b_{l-1} = R r: the restriction reads ghost residuals, except into a replicated level (owned part, then all-reduce)
+    FH_TRY(halo_spmv(L.replicated_below ? nullptr : L.halo, L.R, L.r, L.n, mg->lv[l - 1].b, 0, nullptr, nullptr, 0.0));
     if (L.halo && L.replicated_below) FH_TRY(fh_halo_allreduce_ptr(L.halo, mg->lv[l - 1].b, mg->lv[l - 1].n));
   }
   {
@@ -1143,8 +1145,7 @@ static int run_cycle(fh_mg_t mg) {
   for (int l = 1; l <= top; l++) {
     MgLevel& L = mg->lv[l];
     MgLevel& Lc = mg->lv[l - 1];
-    if (Lc.halo) FH_TRY(fh_halo_update_ptr(Lc.halo, Lc.x, Lc.n));                    // interpolation reads ghost coarse values
-    FH_TRY(fh_dev_spmv(L.P, Lc.x, L.x, 1, nullptr, nullptr, 0.0));                   // x += P x_{l-1}
+    FH_TRY(halo_spmv(Lc.halo, L.P, Lc.x, Lc.n, L.x, 1, nullptr, nullptr, 0.0));      // x += P x_{l-1} (reads ghost coarse values)
     if (L.smoother == FH_SMOOTH_GS_COLOR) {
       FH_TRY(gs_sweeps(mg, L, L.npost, false));
       continue;
@@ -1154,8 +1155,7 @@ static int run_cycle(fh_mg_t mg) {
       continue;
     }
     for (int s = 0; s < L.npost; s++) {
-      if (L.halo) FH_TRY(fh_halo_update_ptr(L.halo, L.x, L.n));
-      FH_TRY(fh_dev_spmv(L.A, L.x, L.x2, 3, L.b, L.dinv, L.omega));
+      FH_TRY(halo_spmv(L.halo, L.A, L.x, L.n, L.x2, 3, L.b, L.dinv, L.omega));
       std::swap(L.x, L.x2);
     }
   }
@@ -1250,8 +1250,7 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
   FH_REQUIRE(bv->n_local >= n && xv->n_local + xv->nghost >= ncols, "fh_mg_solve: vectors too short");
   // distributed forms of the two global operations (MatMult with ghost refresh, VecDot with all-reduce)
   auto spmv = [&](double* xin, double* yout, int mode, const double* bb) -> int {
-    if (HL) FH_TRY(fh_halo_update_ptr(HL, xin, n));
-    return fh_dev_spmv(A, xin, yout, mode, bb, nullptr, 0.0);
+    return halo_spmv(HL, A, xin, n, yout, mode, bb, nullptr, 0.0);
   };
   auto dot = [&](const double* u, const double* w2, double* out) -> int {
     FH_TRY(dev_dot(c, u, w2, n, out));

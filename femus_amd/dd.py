@@ -317,20 +317,142 @@ def vcycle_numpy(comm, H, b_owned, omega=2. / 3., npre=2, npost=2):
 # rendezvous without torch: tiny star-topology collectives over TCP for SETUP traffic only (plans, ids, timing maxima);
 # the data path of a cycle is RCCL (fh_halo_*).  Reads RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT like torchrun sets them.
 # ---------------------------------------------------------------------------------------------------------------------
-class SocketComm:
-    MAGIC = b"femus_hip_dd_v1"
+# wire format of SocketComm: a closed set of plain values, nothing executable (never pickle: the port is reachable by others)
+_WIRE_DTYPES = ("<i4", "<i8", "<f8", "<u1", "|u1", "|b1", "<u2", "<f4")
 
-    def __init__(self, rank, size, addr="127.0.0.1", base_port=29500, timeout=300.0):
-        import pickle
+
+def wire_encode(obj, out=None):
+    import struct
+    top = out is None
+    if top:
+        out = []
+    if obj is None:
+        out.append(b"N")
+    elif isinstance(obj, (bool, np.bool_)):
+        out.append(b"T" if obj else b"F")
+    elif isinstance(obj, (int, np.integer)):
+        out.append(b"I" + struct.pack("<q", int(obj)))
+    elif isinstance(obj, (float, np.floating)):
+        out.append(b"D" + struct.pack("<d", float(obj)))
+    elif isinstance(obj, str):
+        raw = obj.encode("utf-8")
+        out.append(b"S" + struct.pack("<Q", len(raw)) + raw)
+    elif isinstance(obj, (bytes, bytearray)):
+        out.append(b"B" + struct.pack("<Q", len(obj)) + bytes(obj))
+    elif isinstance(obj, (list, tuple)):
+        out.append((b"L" if isinstance(obj, list) else b"U") + struct.pack("<Q", len(obj)))
+        for o in obj:
+            wire_encode(o, out)
+    elif isinstance(obj, np.ndarray):
+        a = np.ascontiguousarray(obj)
+        ds = a.dtype.str
+        if ds not in _WIRE_DTYPES:
+            raise TypeError("SocketComm: array dtype %s is not part of the wire format" % ds)
+        dsb = ds.encode()
+        out.append(b"A" + struct.pack("<B", len(dsb)) + dsb + struct.pack("<B", a.ndim) + struct.pack("<%dq" % a.ndim, *a.shape))
+        out.append(a.tobytes())
+    else:
+        raise TypeError("SocketComm: %s is not part of the wire format" % type(obj).__name__)
+    return b"".join(out) if top else None
+
+
+def wire_decode(buf):
+    import struct
+    mv = memoryview(buf)
+    pos = [0]
+
+    def take(n):
+        if n < 0 or pos[0] + n > len(mv):
+            raise ValueError("SocketComm: truncated or malformed message")
+        v = mv[pos[0]:pos[0] + n]
+        pos[0] += n
+        return v
+
+    def dec(depth):
+        if depth > 8:
+            raise ValueError("SocketComm: message nested too deeply")
+        t = bytes(take(1))
+        if t == b"N":
+            return None
+        if t in (b"T", b"F"):
+            return t == b"T"
+        if t == b"I":
+            return struct.unpack("<q", take(8))[0]
+        if t == b"D":
+            return struct.unpack("<d", take(8))[0]
+        if t in (b"S", b"B"):
+            (n,) = struct.unpack("<Q", take(8))
+            raw = bytes(take(n))
+            return raw.decode("utf-8") if t == b"S" else raw
+        if t in (b"L", b"U"):
+            (n,) = struct.unpack("<Q", take(8))
+            if n > len(mv):
+                raise ValueError("SocketComm: malformed list length")
+            items = [dec(depth + 1) for _ in range(n)]
+            return items if t == b"L" else tuple(items)
+        if t == b"A":
+            (nd,) = struct.unpack("<B", take(1))
+            ds = bytes(take(nd)).decode("ascii")
+            if ds not in _WIRE_DTYPES:
+                raise ValueError("SocketComm: array dtype not part of the wire format")
+            (ndim,) = struct.unpack("<B", take(1))
+            if ndim > 4:
+                raise ValueError("SocketComm: malformed array rank")
+            shape = struct.unpack("<%dq" % ndim, take(8 * ndim))
+            if any(d < 0 for d in shape):
+                raise ValueError("SocketComm: malformed array shape")
+            dt = np.dtype(ds)
+            count = int(np.prod(shape, dtype=np.int64)) if ndim else 1
+            return np.frombuffer(take(count * dt.itemsize), dtype=dt).reshape(shape).copy()
+        raise ValueError("SocketComm: unknown wire tag")
+
+    obj = dec(0)
+    if pos[0] != len(mv):
+        raise ValueError("SocketComm: trailing bytes in message")
+    return obj
+
+
+def job_token():
+    """shared secret of the ranks of ONE job for the rendezvous handshake: FEMUS_DD_TOKEN when the launcher provides one (a test
+    parent, an MPI wrapper); otherwise derived from what torchrun hands every rank of the job.  The derived token keeps strangers
+    from joining by accident; the protection against a hostile peer is the wire format above, which cannot carry code."""
+    import hashlib
+    import os
+    tok = os.environ.get("FEMUS_DD_TOKEN")
+    if tok:
+        return hashlib.sha256(tok.encode()).digest()
+    parts = [os.environ.get(k, "") for k in ("TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE")] + [str(os.getuid())]
+    return hashlib.sha256(("femus_hip_dd|" + "|".join(parts)).encode()).digest()
+
+
+class SocketComm:
+    MAGIC = b"femus_hip_dd_v2\0"          # 16 bytes
+    MAX_MESSAGE = 1 << 36                 # 64 GiB: above any setup payload, below "exhaust the host on request"
+
+    def __init__(self, rank, size, addr="127.0.0.1", base_port=29500, timeout=300.0, token=None):
+        import hmac
+        import os
         import socket
         import struct
         import time
         self.rank, self.size = rank, size
-        self._pickle, self._struct = pickle, struct
+        self._struct = struct
         self.conns = []
         if size == 1:
             return
+        token = token if token is not None else job_token()
+        mac = lambda *parts: hmac.new(token, b"".join(parts), "sha256").digest()
         ports = [base_port + 37 + k for k in range(8)]       # torchrun's own store sits on base_port
+
+        def rd(c, n):
+            buf = bytearray()
+            while len(buf) < n:
+                chunk = c.recv(n - len(buf))
+                if not chunk:
+                    raise OSError("peer closed the connection")
+                buf += chunk
+            return bytes(buf)
+
         if rank == 0:
             srv = None
             for p in ports:
@@ -348,17 +470,21 @@ class SocketComm:
             conns = {}
             while len(conns) < size - 1:
                 c, _ = srv.accept()
-                try:                                  # a stranger on this port must not stall or break the rendezvous
+                try:
+                    # handshake on raw fixed-size frames BEFORE anything is decoded: nonce -> (magic, rank, HMAC(token, nonce|rank))
                     c.settimeout(10.0)
-                    hello = self._recv(c)
-                    if not (isinstance(hello, tuple) and hello[0] == self.MAGIC):
-                        raise RuntimeError("not a rank of this job")
-                    self._send(c, (self.MAGIC, "ack"))
-                except Exception:
+                    nonce = os.urandom(16)
+                    c.sendall(nonce)
+                    hello = rd(c, 16 + 4 + 32)
+                    (r,) = struct.unpack("<i", hello[16:20])
+                    if hello[:16] != self.MAGIC or not (1 <= r < size) or r in conns or not hmac.compare_digest(hello[20:], mac(nonce, hello[16:20])):
+                        raise OSError("not a rank of this job")
+                    c.sendall(mac(nonce, b"ack"))
+                except Exception:                     # a stranger on this port must not stall or break the rendezvous
                     c.close()
                     continue
                 c.settimeout(timeout)
-                conns[hello[1]] = c
+                conns[r] = c
             self.conns = [conns[r] for r in range(1, size)]
             srv.close()
         else:
@@ -370,9 +496,10 @@ class SocketComm:
                     try:
                         s = socket.create_connection((addr, p), timeout=5.0)
                         s.settimeout(10.0)
-                        self._send(s, (self.MAGIC, rank))
-                        ack = self._recv(s)           # only rank 0 of this job answers with the magic: any other listener is skipped
-                        if not (isinstance(ack, tuple) and ack[0] == self.MAGIC):
+                        nonce = rd(s, 16)
+                        rb = struct.pack("<i", rank)
+                        s.sendall(self.MAGIC + rb + mac(nonce, rb))
+                        if not hmac.compare_digest(rd(s, 32), mac(nonce, b"ack")):      # only rank 0 of THIS job can answer
                             raise OSError("foreign listener")
                         s.settimeout(timeout)
                         sock = s
@@ -388,7 +515,7 @@ class SocketComm:
             self.conns = [sock]
 
     def _send(self, c, obj):
-        data = self._pickle.dumps(obj, protocol=4)
+        data = wire_encode(obj)
         c.sendall(self._struct.pack("<Q", len(data)) + data)
 
     def _recv(self, c):
@@ -399,9 +526,11 @@ class SocketComm:
                 if not chunk:
                     raise RuntimeError("SocketComm: peer closed the connection")
                 buf += chunk
-            return bytes(buf)
-        (n,) = self._struct.unpack("<Q", rd(8))
-        return self._pickle.loads(rd(n))
+            return buf
+        (n,) = self._struct.unpack("<Q", bytes(rd(8)))
+        if n > self.MAX_MESSAGE:
+            raise RuntimeError("SocketComm: message of %d bytes exceeds the limit" % n)
+        return wire_decode(rd(n))
 
     def allgather_obj(self, obj):
         if self.size == 1:

@@ -17,6 +17,10 @@ def _child(rank, world, addr, port, device):
     from .dd import SocketComm
     comm = SocketComm(rank, world, addr, port, timeout=60.0)
     ctx = Context(device)
+    if world == 1:
+        # one GPU: the ring neighbour is the rank itself.  "halo_self_rccl" gives the one-rank plan a real communicator, so
+        # ncclCommInitRank, the grouped ncclSend/ncclRecv and ncclAllReduce below all execute on the device
+        ctx.set_option("halo_self_rccl", 1)
     uid = comm.bcast_obj(capi.Halo.unique_id() if rank == 0 else None)
     n = 1024
     nxt, prv = (rank + 1) % world, (rank - 1) % world
@@ -27,7 +31,8 @@ def _child(rank, world, addr, port, device):
     halo = capi.Halo(ctx, rank, world, uid, send_counts, np.arange(n, dtype=np.int32), recv_counts)
     x = ctx.vector(2 * n, n, 0, np.arange(n, 2 * n, dtype=np.int32))
     x.upload(1000.0 * rank + np.arange(n))
-    halo.update(x)
+    halo.begin(x)          # the two halves, as the distributed operators use them (interior rows run in between)
+    halo.end()
     # read the ghosts through an operator with one entry per row in the ghost columns: y_i = x_ghost[i]
     A = ctx.matrix_csr(n, 2 * n, np.arange(n + 1, dtype=np.int32), np.arange(n, 2 * n, dtype=np.int32), np.ones(n))
     y = ctx.vector(n)
@@ -36,6 +41,12 @@ def _child(rank, world, addr, port, device):
     ok = np.array_equal(got, 1000.0 * prv + np.arange(n))
     s = halo.allreduce_sum(np.array([1.0, float(rank)]))
     ok = ok and s[0] == world and s[1] == world * (world - 1) / 2
+    # device-vector all-reduce (the replicated coarse level's right-hand side)
+    y.upload(np.full(n, float(rank + 1)))
+    halo.allreduce_vec(y)
+    ok = ok and np.array_equal(y.to_numpy(), np.full(n, world * (world + 1) / 2.0))
+    st = halo.stats()
+    ok = ok and st["updates"] == 1 and st["bytes_sent"] == 8 * n
     ctx.sync()
     oks = comm.allgather_obj(bool(ok))
     halo.destroy()

@@ -54,7 +54,10 @@ int fh_timer_stop(fh_ctx_t ctx, double* milliseconds);
  * "assemble_kpad" (1: element rows of the two-pass buffer padded to 256 bytes; read when an assembler is created),
  * "assemble_sumfac" (1: map Jacobian by sum factorisation in that kernel), "assemble_sym" (1), "assemble_affine" (0, see fh_assembler_affine_count), "gj_mfma" (1: coarse dense inverse updates on the
  * matrix cores), "gj_symmetric" (1: symmetric sweep on the upper block triangle when the coarse operator is symmetric), "spgemm_slot_map" (1), "use_graph" (1), "asm_debug" (0),
- * "debug_poison" (0; tests: work buffers of the solvers and the element-row buffers start as NaN bit patterns instead of zero).
+ * "debug_poison" (0; tests: work buffers of the solvers and the element-row buffers start as NaN bit patterns instead of zero),
+ * "halo_overlap" (1: on distributed levels the rows without ghost columns are multiplied while the ghost exchange is in flight),
+ * "halo_profile" (0; see fh_halo_stats), "halo_self_rccl" (0; 1: a one-rank exchange plan created afterwards gets an RCCL
+ * communicator and sends to itself -- executes ncclCommInitRank / ncclSend / ncclRecv / ncclAllReduce on a single GPU).
  * Returns non-zero for unknown names */
 int fh_set_option(fh_ctx_t ctx, const char* name, double value);
 
@@ -133,6 +136,10 @@ int fh_mat_norm(fh_mat_t A, int kind, double* out);              /* kind 1: l1_n
  * 3: y = x + omega*dinv.*(b - A x) (one Richardson/Jacobi sweep, 03_solvers/LinearEquationSolverPetsc.cpp:516-519 + PCJACOBI) */
 int fh_spmv(fh_mat_t A, fh_vec_t x, fh_vec_t y, int mode, fh_vec_t b, fh_vec_t dinv, double omega);
 int fh_spmv_transpose(fh_mat_t A, fh_vec_t x, fh_vec_t y);       /* y = A^T x via the cached explicit transpose */
+/* operators over [owned | ghost] columns (distributed levels): number of row blocks that read no column >= n_own_cols
+ * (multiplied while the ghost exchange is in flight) and of those that do (multiplied after it) -- the MPIAIJ diagonal /
+ * off-diagonal split of MatMult at row-block granularity */
+int fh_mat_split_info(fh_mat_t A, int n_own_cols, int* nblk_interior, int* nblk_interface);
 /* algorithmic bytes of one y=Ax with this matrix: 12 nnz + 4 (m+1) + 8 n + 8 m */
 int64_t fh_spmv_algorithmic_bytes(fh_mat_t A);
 
@@ -311,6 +318,20 @@ typedef int (*fh_allreduce_fn)(void* user, double* buf, int n);
 int fh_halo_create_host(fh_ctx_t ctx, int rank, int nranks, fh_exchange_fn exchange, fh_allreduce_fn allreduce, void* user,
                         const int* send_counts, const int* send_idx, const int* recv_counts, fh_halo_t* halo);
 int fh_halo_update(fh_halo_t halo, fh_vec_t v);                  /* owner -> ghost copies, async on comm stream + join */
+/* the two halves of fh_halo_update (VecGhostUpdateBegin / VecGhostUpdateEnd, PetscVector.hpp:605-608): begin packs on the compute
+ * stream and starts the transfer on the communication stream; device work queued between begin and end overlaps with it and must
+ * not read the ghost tail; consumers queued after end see the received values.  One exchange in flight per plan. */
+int fh_halo_begin(fh_halo_t halo, fh_vec_t v);
+int fh_halo_end(fh_halo_t halo);
+/* the SpMV family (modes of fh_spmv) for a GHOSTED operand: A holds this rank's rows over [owned | ghost] columns, the ghosts of x
+ * are refreshed first -- what NumericVector::matrix_mult / resid do on an MPIAIJ matrix (PetscVector.cpp:203-247): the rows that
+ * read no ghost column are multiplied while the exchange is in flight, the others after it.  halo == NULL: plain fh_spmv. */
+int fh_spmv_ghosted(fh_mat_t A, fh_halo_t halo, fh_vec_t x, fh_vec_t y, int mode, fh_vec_t b, fh_vec_t dinv, double omega);
+/* counters of a plan since creation / the last reset: exchanges started, payload bytes sent by this rank; with
+ * fh_set_option("halo_profile", 1) (synchronises every exchange -- measurement runs only) also the summed duration of the
+ * exchanges in ms (pack finished -> ghosts landed) and the part the compute stream actually waited for (exposed = not hidden
+ * behind the rows that need no ghost).  Any pointer may be NULL. */
+int fh_halo_stats(fh_halo_t halo, int reset, int64_t* n_updates, int64_t* bytes_sent, double* exchange_ms, double* exposed_ms);
 int fh_halo_sizes(fh_halo_t halo, int* nsend, int* nrecv);
 int fh_halo_allreduce_vec(fh_halo_t halo, fh_vec_t v);            /* in-place sum over ranks of the owned part (device) */
 int fh_halo_allreduce_sum(fh_halo_t halo, double* vals, int n);  /* host scalars in/out */

@@ -65,26 +65,33 @@ def _record_worker_failure(tag, rank, world):
         pass
 
 
-def _rank_worker(rank, world, port, nb, nlevels, out):
+def _rank_worker(rank, world, port, nb, nlevels, out, overlap=1):
     try:
-        _rank_worker_body(rank, world, port, nb, nlevels, out)
+        _rank_worker_body(rank, world, port, nb, nlevels, out, overlap)
     except BaseException:
         _record_worker_failure("uniform", rank, world)
         raise
 
 
-def _rank_worker_body(rank, world, port, nb, nlevels, out):
+def _rank_worker_body(rank, world, port, nb, nlevels, out, overlap=1):
     import femus_amd as fa
     from femus_amd import dd as ddm
     comm = ddm.SocketComm(rank, world, "127.0.0.1", port)
     ctx = fa.Context(0)
     ctx.set_option("debug_poison", 1)      # work buffers of the cycle and of GMRES start as NaN: nothing may be read before it is written / received
+    ctx.set_option("halo_overlap", overlap)
     dp = ddm.DistributedPoisson(ctx, comm, world, rank, nb=nb, nlevels=nlevels, transport="host")
     dp.assemble()
     dp.set_penalty_top()
     dp.zero_boundary_residuals()
     b = dp.RES.to_numpy()[:dp.n_owned]
+    for h in dp.halos:
+        h.stats(reset=True)
     dp.vcycle()
+    # V(2,2): per level one exchange per sweep after the first, one for the residual, one for the restriction (not into the
+    # replicated level), one for the interpolation from a distributed level, two post-sweeps
+    st = [h.stats()["updates"] for h in dp.halos]
+    assert st == [1 + 1 + 0 + 1 + 2] + [1 + 1 + 1 + 1 + 2] * (nlevels - 2) + [1 + 1 + 1 + 0 + 2], st
     x = dp.EPSC.to_numpy()[:dp.n_owned].copy()
     its, rn = dp.solve(outer="gmres", rtol=1e-12, maxit=60)
     xs = dp.EPSC.to_numpy()[:dp.n_owned].copy()
@@ -94,14 +101,14 @@ def _rank_worker_body(rank, world, port, nb, nlevels, out):
     comm.close()
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_multi_rank_device_path_with_host_transport(tmp_path, world):
+@pytest.mark.parametrize("world,overlap", [(2, 1), (4, 1), (8, 1), (2, 0)])
+def test_multi_rank_device_path_with_host_transport(tmp_path, world, overlap):
     import scipy.sparse.linalg as spla
     import torch.multiprocessing as mp
     from oracle import femus_oracle as fo
     nb, nlevels = 2, 2
     out = str(tmp_path / "rank%d.npz")
-    mp.spawn(_rank_worker, args=(world, _free_port(), nb, nlevels, out), nprocs=world, join=True)
+    mp.spawn(_rank_worker, args=(world, _free_port(), nb, nlevels, out, overlap), nprocs=world, join=True)
     part = dd.BoxPartition(world, 0)
     p = part.p
     ONE = lambda xg: np.ones(xg.shape[:2])
@@ -142,6 +149,9 @@ def test_bench_contract_with_two_ranks_sharing_the_gpu(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "domain decomposition" in d["config"]["parallelism"] and "host-staged" in d["config"]["parallelism"]
     assert d["config"]["dofs_total"] == 33 * 17 * 17 and "roofline" in d and "cpu_baseline" not in d
+    h = d["halo"]     # 3 distributed levels, V(2,2): 5 + 6 + 5 exchanges per cycle, some of the exchange time hidden or not, never negative
+    assert h["exchanges_per_cycle"] == 16 and h["bytes_sent_per_cycle_this_rank"] > 0
+    assert h["exchange_ms_per_cycle"] > 0 and 0 <= h["exposed_ms_per_cycle"] <= h["exchange_ms_per_cycle"]
 
 
 # ---- adaptive levels on several ranks (BASELINE config "MGAMR, 2 levels of AMR, 8 GPUs"), ranks sharing the one GPU -------------
