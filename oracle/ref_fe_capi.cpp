@@ -5,10 +5,12 @@
 //   femus::Gauss            src/02_reference_geom_elements/02_quadrature/quadrature_interface.hpp:32
 //   femus::HexBiquadratic   src/02_reference_geom_elements/01_fe/3d/Hexahedron.hpp
 //   femus::QuadBiquadratic  src/02_reference_geom_elements/01_fe/2d/Quadrilateral.hpp
+//   femus::GeomElemBase     src/02_reference_geom_elements/00_definition/GeomElemBase.hpp:32 (build), :83 (get_nodes_of_face), :97 (get_embedding_matrix)
 #include "quadrature_interface.hpp"
 #include "Hexahedron.hpp"
 #include "Quadrilateral.hpp"
 #include "Edge.hpp"
+#include "GeomElemBase.hpp"
 #include <cstring>
 #include <memory>
 
@@ -90,6 +92,34 @@ unsigned ref_fine2coarse_vertex(const char* geom, const char* fe, int child, uns
 unsigned ref_face_dof(const char* geom, const char* fe, unsigned face, unsigned j) {
   std::unique_ptr<basis> b(make_basis(geom, fe));
   return b->GetFaceDof(face, j);
+}
+
+// fine-node reference coordinates of the family (basis::GetX, Basis.hpp:251): the points set_prolongation_OneElement_All_FE
+// (ElemType.cpp:439-532) evaluates the coarse shape functions at
+void ref_xfine(const char* geom, const char* fe, int i, int dim, double* out) {
+  std::unique_ptr<basis> b(make_basis(geom, fe));
+  for (int d = 0; d < dim; d++) out[d] = b->GetX(i)[d];
+}
+
+// GeomElem* topology tables (00_definition): sizes, nodes of a face, the (deprecated) float embedding matrix of a child
+int ref_geomelem_info(const char* geom, unsigned fe_family, int* dim, int* n_nodes, int* n_nodes_linear, int* n_faces) {
+  std::unique_ptr<GeomElemBase> g = GeomElemBase::build(geom, fe_family);
+  g->set_faceNumber_offsets();
+  *dim = g->get_dimension();
+  *n_nodes = g->n_nodes();
+  *n_nodes_linear = g->n_nodes_linear();
+  *n_faces = g->n_faces_total();
+  return 0;
+}
+int ref_geomelem_face_nodes(const char* geom, unsigned fe_family, unsigned f, unsigned* out) {
+  std::unique_ptr<GeomElemBase> g = GeomElemBase::build(geom, fe_family);
+  std::vector<unsigned> v = g->get_nodes_of_face(f);
+  for (size_t k = 0; k < v.size(); k++) out[k] = v[k];
+  return (int)v.size();
+}
+double ref_geomelem_embedding(const char* geom, unsigned fe_family, unsigned child, unsigned i, unsigned j) {
+  std::unique_ptr<GeomElemBase> g = GeomElemBase::build(geom, fe_family);
+  return (double)g->get_embedding_matrix(child, i, j);
 }
 
 }  // extern "C"

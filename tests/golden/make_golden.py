@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 L = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libfemus_ref_fe.so"))
 L.ref_eval.restype = ctypes.c_double
+L.ref_geomelem_embedding.restype = ctypes.c_double
 
 out = {}
 ORDERS = ["first", "third", "fifth", "seventh", "ninth"]
@@ -65,6 +66,66 @@ for geom, dim, nv in (("quad", 2, 4), ("hex", 3, 8)):
         L.ref_kvert_ind(geom.encode(), b"biquadratic", i, b)
         kv[i] = list(b)
     out["kvert_ind_%s" % geom] = kv
+
+# element prolongator as elem_type forms it.  ElemType.cpp itself needs boost and is not compiled, so its two loops are followed
+# here on top of the COMPILED basis classes (every number below comes out of a call into the reference's object code):
+#   (1) set_fine_coordinates_in_Basis_object (ElemType.cpp:404-432): fine node i = (child, vertex) = KVERT_IND[i] of the linear
+#       element; X[i] = sum_k phi^lin_k(Xcoarse[vertex]) * Xcoarse[fine2CoarseVertexMapping[child][k]]
+#   (2) set_prolongation_OneElement_All_FE (ElemType.cpp:439-532): P[i][j] = phi_j(X[i]), entries with |.| < 1e-14 dropped
+def _xcoarse(geom, fe, i, dim):
+    b = (ctypes.c_double * 3)()
+    L.ref_xcoarse(geom.encode(), fe.encode(), i, dim, b)
+    return np.array(list(b)[:dim])
+
+
+for geom, dim in (("quad", 2), ("hex", 3)):
+    nlin = L.ref_ndofs(geom.encode(), b"linear")
+    for fe in ("linear", "biquadratic"):
+        nc = L.ref_ndofs(geom.encode(), fe.encode())
+        nf = L.ref_ndofs_fine(geom.encode(), fe.encode())
+        X = np.zeros((nf, dim))
+        P = np.zeros((nf, nc))
+        kv = np.zeros((nf, 2), dtype=np.int64)
+        for i in range(nf):
+            k2 = (ctypes.c_int * 2)()
+            L.ref_kvert_ind(geom.encode(), b"linear", i, k2)
+            child, vertex = k2[0], k2[1]
+            kv[i] = [child, vertex]
+            xvtx = _xcoarse(geom, "linear", vertex, dim)
+            pt = (ctypes.c_double * 3)(*(list(xvtx) + [0.0] * (3 - dim)))
+            xm = np.zeros(dim)
+            for k in range(nlin):
+                xv = _xcoarse(geom, "linear", L.ref_fine2coarse_vertex(geom.encode(), b"linear", child, k), dim)
+                xm += L.ref_eval(geom.encode(), b"linear", 0, k, pt) * xv
+            X[i] = xm
+            ptx = (ctypes.c_double * 3)(*(list(xm) + [0.0] * (3 - dim)))
+            for j in range(nc):
+                v = L.ref_eval(geom.encode(), fe.encode(), 0, j, ptx)
+                P[i, j] = v if abs(v) >= 1.0e-14 else 0.0
+        out["xfine_%s_%s" % (geom, fe)] = X
+        out["elem_prol_%s_%s" % (geom, fe)] = P
+        out["kvert_ind_%s_%s" % (geom, fe)] = kv
+
+# GeomElem* topology tables of the compiled 00_definition sources: sizes, face -> nodes, float embedding matrices
+for geom, fam, tag in (("hex", 2, "hex27"), ("quad", 2, "quad9")):
+    dim, nn, nl, nfc = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    L.ref_geomelem_info(geom.encode(), fam, ctypes.byref(dim), ctypes.byref(nn), ctypes.byref(nl), ctypes.byref(nfc))
+    out["geomelem_info_%s" % tag] = np.array([dim.value, nn.value, nl.value, nfc.value])
+    faces = []
+    for f in range(nfc.value):
+        buf = (ctypes.c_uint * 16)()
+        k = L.ref_geomelem_face_nodes(geom.encode(), fam, f, buf)
+        faces.append(list(buf)[:k])
+    out["geomelem_faces_%s" % tag] = np.array(faces, dtype=np.int64)
+    if tag != "quad9":      # GeomElemHex27's deprecated embedding matrix uses another coarse node numbering: not a table of this path
+        continue
+    nch = 2 ** dim.value
+    E = np.zeros((nch, nn.value, nn.value))
+    for c in range(nch):
+        for i in range(nn.value):
+            for j in range(nn.value):
+                E[c, i, j] = L.ref_geomelem_embedding(geom.encode(), fam, c, i, j)
+    out["geomelem_embedding_%s" % tag] = E
 
 np.savez_compressed(os.path.join(HERE, "fe_tables.npz"), **out)
 print("wrote", os.path.join(HERE, "fe_tables.npz"), len(out), "arrays")

@@ -1,0 +1,103 @@
+"""Product (libfemus_hip.so, host entry points: no GPU needed) against the fixture dumped from the reference's own compiled
+FE / quadrature / GeomElem sources (tests/golden/fe_tables.npz, generator tests/golden/make_golden.py): rows a1-a3, a5 (face
+nodes) and a6 of SURVEY 8 -- bit for bit.  The oracle is checked against the same new tables beside it."""
+import os
+
+import numpy as np
+import pytest
+
+from femus_amd import capi
+from oracle import femus_oracle as fo
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fe_tables.npz"))
+ORDERS = ["first", "third", "fifth", "seventh", "ninth"]
+
+
+@pytest.mark.parametrize("geom", ["quad", "hex"])
+@pytest.mark.parametrize("order", ORDERS)
+def test_product_gauss_tables_bit_exact(geom, order):
+    """a1: Gauss::Gauss + tables (quadrature_interface.cpp:36-94, quadrature_Hexahedron.cpp, quadrature_Quadrangle.cpp)"""
+    w, x = capi.fe_gauss(geom, order)
+    assert np.array_equal(w, G["gauss_w_%s_%s" % (geom, order)])
+    assert np.array_equal(x, G["gauss_x_%s_%s" % (geom, order)])
+
+
+@pytest.mark.parametrize("geom", ["quad", "hex"])
+@pytest.mark.parametrize("fe", ["linear", "biquadratic"])
+def test_product_shape_tables_at_quadrature_points_bit_exact(geom, fe):
+    """a2/a3: phi and d phi at the 'seventh' Gauss points (ElemType.cpp:576-741 fills its tables with exactly these calls)"""
+    phi, dphi = capi.fe_tables(geom, fe, "seventh")
+    ref = G["basis_%s_%s_gauss7" % (geom, fe)]
+    assert np.array_equal(phi, ref[0])
+    for d in range(dphi.shape[2]):
+        assert np.array_equal(dphi[:, :, d], ref[1 + d])
+
+
+def _rows_by_kvert(geom, fe, P):
+    """rows of a [child][local node][coarse] element prolongator in the reference's fine-node order KVERT_IND (Hexahedron.cpp:49-71)"""
+    kv = G["kvert_ind_%s_%s" % (geom, fe)]
+    return np.array([P[j, i] for (j, i) in kv])
+
+
+@pytest.mark.parametrize("geom", ["quad", "hex"])
+@pytest.mark.parametrize("fe", ["linear", "biquadratic"])
+def test_product_element_prolongator_bit_exact(geom, fe):
+    """a6: set_prolongation_OneElement_All_FE (ElemType.cpp:439-532): phi_j(GetX(i)), |.| < 1e-14 dropped"""
+    ref = G["elem_prol_%s_%s" % (geom, fe)]
+    P = capi.fe_elem_prolongator(geom, fe)
+    assert np.array_equal(_rows_by_kvert(geom, fe, P), ref)
+    Po = fo.elem_prolongator(geom, fe)
+    assert np.array_equal(_rows_by_kvert(geom, fe, Po), ref)
+    # every (child, local node) pair denotes one of the reference's fine nodes and carries that node's row
+    X = fo.child_node_ref_coords(geom)[:, :P.shape[1], :]
+    key = {tuple(x): r for x, r in zip(G["xfine_%s_%s" % (geom, fe)], ref)}
+    for j in range(P.shape[0]):
+        for i in range(P.shape[1]):
+            assert np.array_equal(P[j, i], key[tuple(X[j, i])])
+    if geom == "hex" and fe == "biquadratic":
+        assert ref.shape == (125, 27) and np.count_nonzero(ref) == 729
+
+
+@pytest.mark.parametrize("geom,tag", [("quad", "quad9")])
+def test_element_prolongator_rows_are_the_rows_of_the_geomelem_embedding_matrix(geom, tag):
+    """the compiled GeomElemQuad9 embedding matrix (float, deprecated refinement path, GeomElemQuad9.cpp:22-) numbers children and
+    their nodes differently, but describes the same 25 fine nodes over the same coarse node numbering: the SET of distinct weight
+    rows must be identical, bit for bit (the weights are dyadic, exact in float).  GeomElemHex27's matrix follows another coarse
+    node numbering (its rows are not rows of the FE prolongator under any child permutation), so it is not part of the fixture."""
+    E = G["geomelem_embedding_" + tag]
+    nc = E.shape[2]
+    rows_ref = {tuple(r) for r in E.reshape(-1, nc)}
+    for P in (capi.fe_elem_prolongator(geom, "biquadratic"), fo.elem_prolongator(geom, "biquadratic")):
+        rows = {tuple(r) for r in P.reshape(-1, nc)}
+        assert rows == rows_ref and len(rows) == (125 if geom == "hex" else 25)
+
+
+@pytest.mark.parametrize("geom,tag", [("quad", "quad9"), ("hex", "hex27")])
+def test_product_face_nodes_against_facedofs_and_geomelem_faces(geom, tag):
+    """a5: local nodes of each face -- basis::GetFaceDof (faceDofs, Hexahedron.cpp / Quadrilateral.cpp) and
+    GeomElem*::get_nodes_of_face (_faces, GeomElemHex27.cpp:15-22): same face -> same node SET, vertices first in both"""
+    faces = G["geomelem_faces_" + tag]
+    fd = G["facedofs_" + geom]
+    info = G["geomelem_info_" + tag]
+    dim = 3 if geom == "hex" else 2
+    assert info.tolist() == [dim, 3 ** dim, 2 ** dim, 2 * dim]
+    nvf = 4 if geom == "hex" else 2
+    for f in range(2 * dim):
+        got = capi.fe_face_nodes(geom, "biquadratic", f)
+        assert set(got.tolist()) == set(fd[f].tolist()) == set(faces[f].tolist())
+        assert set(got[:nvf].tolist()) == set(fd[f][:nvf].tolist())                        # vertices of the face come first
+        assert got[-1] == fd[f][-1] == faces[f][-1]                                         # the face's own centre node comes last
+        lin = capi.fe_face_nodes(geom, "linear", f)
+        assert set(lin.tolist()) == set(fd[f][:nvf].tolist())
+        assert set(fo.face_nodes(geom)[f].tolist()) == set(faces[f].tolist())
+
+
+@pytest.mark.parametrize("order", ORDERS)
+def test_tensor_rules_are_products_of_the_line_rule(order):
+    """the 1-D rules of the fixture (quadrature_Line.cpp): the product tables are tensor grids of them (what the sum-factorised
+    Jacobian of the HEX27 element kernel relies on, checked again at assembler creation)"""
+    x1 = np.sort(G["gauss_x_line_" + order][:, 0])
+    for geom in ("quad", "hex"):
+        _, x = capi.fe_gauss(geom, order)
+        for d in range(x.shape[1]):
+            assert np.allclose(np.unique(np.round(x[:, d], 13)), np.round(x1, 13), atol=1e-13)
