@@ -80,6 +80,7 @@ struct fh_vec_s {
 
 struct fh_mat_s {
   fh_ctx_t ctx = nullptr;
+  uint64_t uid = 0;                   // unique per created matrix (never reused, unlike the address): keys caches built from the pattern
   int m = 0, n = 0, nnz = 0;
   int* d_rowptr = nullptr;
   int* d_col = nullptr;

@@ -10,6 +10,7 @@
 // sweep moves the matrix exactly once.  Blocks are renumbered so that consecutive row blocks (which share
 // x lines) run on the same XCD and hit the same 4 MiB L2.
 #include "fh_internal.h"
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <thread>
@@ -23,6 +24,8 @@ extern "C" int fh_mat_create_csr(fh_ctx_t c, int m, int n, const int* rowptr, co
   const int nnz = rowptr[m];
   FH_REQUIRE(nnz == 0 || col != nullptr, "fh_mat_create_csr: null column array");
   fh_mat_t A = new fh_mat_s();
+  static std::atomic<uint64_t> next_uid{1};
+  A->uid = next_uid++;
   A->ctx = c;
   A->m = m;
   A->n = n;

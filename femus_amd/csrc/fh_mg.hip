@@ -24,8 +24,8 @@ int fh_halo_allreduce_ptr(fh_halo_t h, double* d, int n);
 
 struct MgLevel {
   fh_mat_t A = nullptr, P = nullptr, R = nullptr;
-  bool own_R = false;
-  fh_mat_t R_of = nullptr;   // the interpolation the owned restriction was built from
+  bool R_given = false;      // restriction handed in by the caller; otherwise R = the cached explicit transpose of P, refreshed at every setup
+  uint64_t A_uid = 0;        // the matrix the colourings below were built for (pattern caches: dropped when another matrix is installed)
   int n = 0, smoother = 0, npre = 2, npost = 2;
   double omega = 2.0 / 3.0;
   double *dinv = nullptr, *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;
@@ -60,6 +60,8 @@ struct fh_mg_s {
   // Krylov workspace
   std::vector<double*> kv;
   int kv_n = 0;
+  double** d_V = nullptr;     // device copy of the basis pointers (GMRES), kept with kv
+  int d_V_n = 0;
   int64_t cycle_bytes = 0;
 };
 
@@ -265,27 +267,38 @@ __global__ __launch_bounds__(256) void k_csr_to_dense(const int* __restrict__ ro
 constexpr int GJ_NB = 32;   // pivot block (64 measured slower twice, also with the MFMA update: pivot-block inversion 34 -> 192 us, row panel 38 -> 144 us per step)
 constexpr int GJ_KS = 32;   // K slice of the update staged in LDS at a time
 
-__global__ __launch_bounds__(256) void k_gjb_save_panel(const double* __restrict__ D, double* __restrict__ Cp, double* __restrict__ CpT, int n, int kb, int nb) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n * nb) return;
-  const int i = idx / nb, t = idx % nb;
-  const double v = D[(size_t)i * n + kb + t];
-  Cp[(size_t)i * GJ_NB + t] = v;
-  CpT[(size_t)t * n + i] = v;
-}
-
-// one workgroup; a single-wave version (no workgroup barriers) was measured 3x slower: 16 LDS read-modify-writes per lane and step
-// instead of 4.  Index arithmetic on the compile-time block size (the run-time nb only guards).
-__global__ __launch_bounds__(256) void k_gjb_pivot(const double* __restrict__ D, double* __restrict__ Dinv, int n, int kb, int nb) {
-  __shared__ double M[GJ_NB][GJ_NB + 1];
-  __shared__ double colk[GJ_NB];
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < GJ_NB * GJ_NB; idx += 256) {
-    const int i = idx / GJ_NB, j = idx % GJ_NB;
-    M[i][j] = (i < nb && j < nb) ? D[(size_t)(kb + i) * n + kb + j] : (i == j ? 1.0 : 0.0);   // identity padding: inert
-  }
-  __syncthreads();
+// in-place inverse of the NB x NB block M (LDS, row stride NB + 1; rows / columns >= nb are identity padding) by Gauss-Jordan with
+// PARTIAL PIVOTING, all 256 threads of the workgroup.  The inverse of a block does not depend on how it is computed, so the
+// callers (general and symmetric sweeps) are unchanged; what pivoting buys is a stable inverse of blocks that are not positive
+// definite -- saddle-point operators carry zero diagonal entries (the reference factors level 0 with a pivoted LU,
+// LinearEquationSolverPetsc.hpp:131-134).  A pivot column without any entry above 1e-300 raises *flag (singular block).
+__device__ __forceinline__ void gj_invert_block(double (*M)[GJ_NB + 1], double* colk, int* piv, int nb, int tid, int* flag) {
   for (int k = 0; k < nb; k++) {
+    if (tid < 64) {            // wave 0: largest |M[i][k]|, i in [k, nb), smallest index on ties
+      double v = (tid >= k && tid < nb) ? fabs(M[tid][k]) : -1.0;
+      int idx = tid;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double v2 = __shfl_xor(v, off, 64);
+        const int i2 = __shfl_xor(idx, off, 64);
+        if (v2 > v || (v2 == v && i2 < idx)) {
+          v = v2;
+          idx = i2;
+        }
+      }
+      if (tid == 0) {
+        piv[k] = idx;
+        if (!(v > 1e-300)) atomicOr(flag, 1);
+      }
+    }
+    __syncthreads();
+    const int pr = piv[k];
+    if (pr != k && tid < GJ_NB) {
+      const double t = M[k][tid];
+      M[k][tid] = M[pr][tid];
+      M[pr][tid] = t;
+    }
+    __syncthreads();
     if (tid < GJ_NB) colk[tid] = M[tid][k];
     __syncthreads();
     const double p = 1.0 / colk[k];
@@ -301,6 +314,45 @@ __global__ __launch_bounds__(256) void k_gjb_pivot(const double* __restrict__ D,
     if (tid < GJ_NB) M[k][tid] = (tid == k) ? p : M[k][tid] * p;
     __syncthreads();
   }
+  for (int k = nb - 1; k >= 0; k--) {      // the row interchanges come back as column interchanges, last first
+    const int pr = piv[k];
+    if (pr != k && tid < GJ_NB) {
+      const double t = M[tid][k];
+      M[tid][k] = M[tid][pr];
+      M[tid][pr] = t;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_check_finite(const double* __restrict__ D, size_t n, int* __restrict__ flag) {
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) bad |= !isfinite(D[i]);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 2);
+}
+
+__global__ __launch_bounds__(256) void k_gjb_save_panel(const double* __restrict__ D, double* __restrict__ Cp, double* __restrict__ CpT, int n, int kb, int nb) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * nb) return;
+  const int i = idx / nb, t = idx % nb;
+  const double v = D[(size_t)i * n + kb + t];
+  Cp[(size_t)i * GJ_NB + t] = v;
+  CpT[(size_t)t * n + i] = v;
+}
+
+// one workgroup; a single-wave version (no workgroup barriers) was measured 3x slower: 16 LDS read-modify-writes per lane and step
+// instead of 4.  Index arithmetic on the compile-time block size (the run-time nb only guards).
+__global__ __launch_bounds__(256) void k_gjb_pivot(const double* __restrict__ D, double* __restrict__ Dinv, int n, int kb, int nb, int* __restrict__ flag) {
+  __shared__ double M[GJ_NB][GJ_NB + 1];
+  __shared__ double colk[GJ_NB];
+  __shared__ int piv[GJ_NB];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < GJ_NB * GJ_NB; idx += 256) {
+    const int i = idx / GJ_NB, j = idx % GJ_NB;
+    M[i][j] = (i < nb && j < nb) ? D[(size_t)(kb + i) * n + kb + j] : (i == j ? 1.0 : 0.0);   // identity padding: inert
+  }
+  __syncthreads();
+  gj_invert_block(M, colk, piv, nb, tid, flag);
   for (int idx = tid; idx < nb * nb; idx += 256) Dinv[(idx / nb) * GJ_NB + idx % nb] = M[idx / nb][idx % nb];
 }
 
@@ -482,31 +534,17 @@ __global__ __launch_bounds__(256) void k_gjs_gather_panel(const double* __restri
   PT[(size_t)t * n + j] = v;
 }
 
-__global__ __launch_bounds__(256) void k_gjs_pivot(const double* __restrict__ PT, double* __restrict__ Dinv, int n, int kb, int nb) {
+__global__ __launch_bounds__(256) void k_gjs_pivot(const double* __restrict__ PT, double* __restrict__ Dinv, int n, int kb, int nb, int* __restrict__ flag) {
   __shared__ double M[GJ_NB][GJ_NB + 1];
   __shared__ double colk[GJ_NB];
+  __shared__ int piv[GJ_NB];
   const int tid = threadIdx.x;
   for (int idx = tid; idx < GJ_NB * GJ_NB; idx += 256) {
     const int i = idx / GJ_NB, j = idx % GJ_NB;
     M[i][j] = (i < nb && j < nb) ? PT[(size_t)i * n + kb + j] : (i == j ? 1.0 : 0.0);
   }
   __syncthreads();
-  for (int k = 0; k < nb; k++) {
-    if (tid < GJ_NB) colk[tid] = M[tid][k];
-    __syncthreads();
-    const double p = 1.0 / colk[k];
-#pragma unroll
-    for (int idx = tid; idx < GJ_NB * GJ_NB; idx += 256) {
-      const int i = idx / GJ_NB, j = idx % GJ_NB;
-      if (i != k) {
-        const double f = colk[i] * p;
-        M[i][j] = (j == k) ? -f : M[i][j] - f * M[k][j];
-      }
-    }
-    __syncthreads();
-    if (tid < GJ_NB) M[k][tid] = (tid == k) ? p : M[k][tid] * p;
-    __syncthreads();
-  }
+  gj_invert_block(M, colk, piv, nb, tid, flag);
   for (int idx = tid; idx < nb * nb; idx += 256) Dinv[(idx / nb) * GJ_NB + idx % nb] = M[idx / nb][idx % nb];
 }
 
@@ -550,7 +588,7 @@ __global__ __launch_bounds__(256) void k_gjs_row_panel(double* __restrict__ D, c
 // (the tile order is rotated so that it is scheduled first), which takes the sequential 32-step inversion (23 us) off the
 // critical path of every step but the first.
 __global__ __launch_bounds__(256) void k_gjs_update_mfma(double* __restrict__ D, const double* __restrict__ PT, const double* __restrict__ RT, int n,
-                                                         int kb, int nb, double* __restrict__ Dinv_next, int kb_next, int nb_next) {
+                                                         int kb, int nb, double* __restrict__ Dinv_next, int kb_next, int nb_next, int* __restrict__ flag) {
   const int nt = gridDim.x, t_next = (kb_next < n) ? kb_next / 64 : 0;
   const int by = (blockIdx.y + t_next) % nt, bx = (blockIdx.x + t_next) % nt;
   if (by > bx) return;                                    // lower block triangle: not maintained
@@ -623,22 +661,7 @@ __global__ __launch_bounds__(256) void k_gjs_update_mfma(double* __restrict__ D,
       }
     }
   __syncthreads();
-  for (int k = 0; k < nb_next; k++) {
-    if (tid < GJ_NB) colk[tid] = M[tid][k];
-    __syncthreads();
-    const double p = 1.0 / colk[k];
-#pragma unroll
-    for (int idx = tid; idx < GJ_NB * GJ_NB; idx += 256) {
-      const int i = idx / GJ_NB, j = idx % GJ_NB;
-      if (i != k) {
-        const double f = colk[i] * p;
-        M[i][j] = (j == k) ? -f : M[i][j] - f * M[k][j];
-      }
-    }
-    __syncthreads();
-    if (tid < GJ_NB) M[k][tid] = (tid == k) ? p : M[k][tid] * p;
-    __syncthreads();
-  }
+  gj_invert_block(M, colk, reinterpret_cast<int*>(&Rs[1][0]), nb_next, tid, flag);
   for (int idx = tid; idx < nb_next * nb_next; idx += 256) Dinv_next[(idx / nb_next) * GJ_NB + idx % nb_next] = M[idx / nb_next][idx % nb_next];
 }
 
@@ -733,7 +756,8 @@ static inline int halo_spmv(fh_halo_t h, fh_mat_t A, double* x, int n_own, doubl
 // ------------------------------------------------------------------------------------------------
 // API
 // ------------------------------------------------------------------------------------------------
-static void free_level_restriction(MgLevel& L);
+static void free_level_colors(MgLevel& L);
+static void free_level_patch_setup(MgLevel& L);
 extern "C" int fh_mg_create(fh_ctx_t ctx, int nlevels, fh_mg_t* out) {
   FH_REQUIRE(ctx && out && nlevels >= 1, "fh_mg_create: bad arguments");
   fh_mg_t mg = new fh_mg_s();
@@ -754,10 +778,15 @@ extern "C" int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh
              "fh_mg_set_level: unknown smoother %d (0 = Richardson+Jacobi, 1 = Richardson+multicolour SOR, 2 = block Schwarz / Vanka)", smoother);
   FH_REQUIRE(npre >= 0 && npost >= 0, "fh_mg_set_level: negative sweep count");
   MgLevel& L = mg->lv[level];
-  if (L.own_R && (R != nullptr || L.R_of != P)) free_level_restriction(L);
+  if (L.A_uid != A->uid) {   // another matrix (also one that landed on the address of a destroyed one): its graph may differ
+    free_level_colors(L);
+    free_level_patch_setup(L);
+    L.A_uid = A->uid;
+  }
   L.A = A;
   L.P = P;
-  if (!L.own_R) L.R = R;
+  L.R = R;
+  L.R_given = R != nullptr;
   L.n = A->m;
   L.ncols = A->n;
   L.smoother = smoother;
@@ -790,14 +819,19 @@ static void free_level_colors(MgLevel& L) {
   L.ncolors = 0;
 }
 
-static void free_level_patches(MgLevel& L) {
+// device side of the patch smoother (colouring by the matrix graph, inverses): rebuilt by the next setup; the patch lists stay
+static void free_level_patch_setup(MgLevel& L) {
   for (void** q : {(void**)&L.d_pptr, (void**)&L.d_pdofs, (void**)&L.d_porder, (void**)&L.d_pflag, (void**)&L.d_poff, (void**)&L.d_pinv})
     if (*q) {
       hipFree(*q);
       *q = nullptr;
     }
-  L.npatch = 0;
   L.vanka_ncolors = 0;
+}
+
+static void free_level_patches(MgLevel& L) {
+  free_level_patch_setup(L);
+  L.npatch = 0;
 }
 
 extern "C" int fh_mg_set_level_patches(fh_mg_t mg, int level, int npatch, const int* ptr, const int* dofs) {
@@ -914,15 +948,6 @@ static int vanka_sweeps(fh_mg_t mg, MgLevel& L, int nsweeps) {
   return 0;
 }
 
-static void free_level_restriction(MgLevel& L) {
-  if (L.own_R && L.R) {
-    fh_mat_destroy(L.R);
-    L.R = nullptr;
-    L.own_R = false;
-    L.R_of = nullptr;
-  }
-}
-
 static int coarse_factor(fh_mg_t mg) {
   fh_ctx_t c = mg->ctx;
   MgLevel& L0 = mg->lv[0];
@@ -945,11 +970,24 @@ static int coarse_factor(fh_mg_t mg) {
   double* CpT = colk + (size_t)n * GJ_NB;
   double* Dinv = colk + (size_t)2 * n * GJ_NB;
   const int nt = fh_div_up(n, 64);
+  int* d_flag = reinterpret_cast<int*>(Dinv + GJ_NB * GJ_NB);   // [0] unsymmetric, [1] bit 0: singular pivot block, bit 1: non-finite inverse
+  FH_CHECK_HIP(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), c->stream));
+  // the factorisation must end in a usable inverse: a pivot block without a usable pivot, or Inf / NaN anywhere in the result, is an
+  // error of fh_mg_setup, not a silent part of every later cycle
+  auto finish = [&]() -> int {
+    int h[2] = {0, 0};
+    hipLaunchKernelGGL(k_check_finite, dim3(std::min(fh_div_up((int64_t)n * n, 256), c->num_cu * 8)), dim3(256), 0, c->stream, mg->d_ainv, (size_t)n * n,
+                       d_flag + 1);
+    FH_CHECK_HIP(hipGetLastError());
+    FH_CHECK_HIP(hipMemcpyAsync(h, d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+    FH_REQUIRE(!(h[1] & 1), "fh_mg_setup: the coarsest operator (%d unknowns) is singular to working precision (no pivot in a %d x %d block)", n, GJ_NB, GJ_NB);
+    FH_REQUIRE(!(h[1] & 2), "fh_mg_setup: the inverse of the coarsest operator (%d unknowns) contains Inf / NaN", n);
+    return 0;
+  };
   if (c->gj_symmetric) {
     // symmetric operator? (entry-by-entry check on the sparse form, 1e-12 of the row's largest entry)
-    int* d_flag = reinterpret_cast<int*>(Dinv + GJ_NB * GJ_NB);
     int h_flag = 0;
-    FH_CHECK_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), c->stream));
     hipLaunchKernelGGL(k_csr_symmetry, dim3(fh_div_up(n, 4)), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, n, 1e-12, d_flag);
     FH_CHECK_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     FH_CHECK_HIP(hipStreamSynchronize(c->stream));
@@ -960,29 +998,27 @@ static int coarse_factor(fh_mg_t mg) {
         const int nb = std::min(GJ_NB, n - kb);
         const int kb_next = kb + GJ_NB, nb_next = std::max(0, std::min(GJ_NB, n - kb_next));
         hipLaunchKernelGGL(k_gjs_gather_panel, dim3(fh_div_up((int64_t)n * GJ_NB, 256)), dim3(256), 0, c->stream, mg->d_ainv, PT, n, kb, nb);
-        if (step == 0) hipLaunchKernelGGL(k_gjs_pivot, dim3(1), dim3(256), 0, c->stream, PT, Dinv2[0], n, kb, nb);
+        if (step == 0) hipLaunchKernelGGL(k_gjs_pivot, dim3(1), dim3(256), 0, c->stream, PT, Dinv2[0], n, kb, nb, d_flag + 1);
         hipLaunchKernelGGL(k_gjs_row_panel, dim3(fh_div_up(n, 64)), dim3(256), 0, c->stream, mg->d_ainv, Dinv2[step & 1], PT, RT, n, kb, nb);
         hipLaunchKernelGGL(k_gjs_update_mfma, dim3(nt, nt), dim3(256), 0, c->stream, mg->d_ainv, PT, RT, n, kb, nb, Dinv2[(step + 1) & 1], kb_next,
-                           nb_next);
+                           nb_next, d_flag + 1);
       }
       hipLaunchKernelGGL(k_gjs_finish, dim3(nt, nt), dim3(256), 0, c->stream, mg->d_ainv, n);
       FH_CHECK_HIP(hipGetLastError());
-      FH_CHECK_HIP(hipStreamSynchronize(c->stream));
-      return 0;
+      return finish();
     }
   }
   for (int kb = 0; kb < n; kb += GJ_NB) {
     const int nb = std::min(GJ_NB, n - kb);
     hipLaunchKernelGGL(k_gjb_save_panel, dim3(fh_div_up((int64_t)n * nb, 256)), dim3(256), 0, c->stream, mg->d_ainv, Cp, CpT, n, kb, nb);
-    hipLaunchKernelGGL(k_gjb_pivot, dim3(1), dim3(256), 0, c->stream, mg->d_ainv, Dinv, n, kb, nb);
+    hipLaunchKernelGGL(k_gjb_pivot, dim3(1), dim3(256), 0, c->stream, mg->d_ainv, Dinv, n, kb, nb, d_flag + 1);
     hipLaunchKernelGGL(k_gjb_row_panel, dim3(fh_div_up(n, 64)), dim3(64), 0, c->stream, mg->d_ainv, Dinv, Cp, n, kb, nb);
     if (c->gj_mfma) hipLaunchKernelGGL(k_gjb_update_mfma, dim3(nt, nt), dim3(256), 0, c->stream, mg->d_ainv, CpT, n, kb, nb);
     else hipLaunchKernelGGL(k_gjb_update, dim3(nt, nt), dim3(256), 0, c->stream, mg->d_ainv, Cp, n, kb, nb);
     hipLaunchKernelGGL(k_gjb_col_panel, dim3(fh_div_up((int64_t)n * nb, 256)), dim3(256), 0, c->stream, mg->d_ainv, Dinv, Cp, n, kb, nb);
   }
   FH_CHECK_HIP(hipGetLastError());
-  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
-  return 0;
+  return finish();
 }
 
 static int run_cycle(fh_mg_t mg);
@@ -1053,10 +1089,11 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
       FH_TRY(factor_patches(mg, L));
     }
     if (l > 0) {
-      if (!L.R) {   // restriction = transpose of the interpolation (LinearImplicitSystem.cpp:379-382); kept across re-setups
-        FH_TRY(fh_mat_transpose(L.P, &L.R));
-        L.own_R = true;
-        L.R_of = L.P;
+      if (!L.R_given) {
+        // restriction = transpose of the interpolation (LinearImplicitSystem.cpp:379-382): P's cached explicit transpose, whose
+        // values are re-gathered here whenever P was edited since (zero_rows / zero_cols / new values clear its validity flag)
+        FH_TRY(fh_mat_refresh_transpose(L.P));
+        L.R = L.P->At;
       }
       FH_REQUIRE(L.R->m == mg->lv[l - 1].n && (L.R->n == L.n || L.R->n == L.ncols), "fh_mg_setup: restriction of level %d has the wrong shape", l);
       const int64_t bA = fh_spmv_algorithmic_bytes(L.A), n8 = 8ll * L.n;
@@ -1170,7 +1207,8 @@ static int apply_cycle(fh_mg_t mg, const double* b_in, double* x_out) {
   MgLevel& L = mg->lv[top];
   FH_CHECK_HIP(hipMemcpyAsync(L.b, b_in, (size_t)L.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   if (mg->gexec) {
-    // the captured graph hard-codes the ping-pong roles: restore the parity it was captured with
+    // the graph bakes in the x / x2 roles of the capture run, and that run left L.x (host side) pointing at the buffer it ended in;
+    // run_cycle is never called un-captured while the graph exists, so the copy below reads the buffer the replay writes
     FH_CHECK_HIP(hipGraphLaunch(mg->gexec, c->stream));
   } else {
     FH_TRY(run_cycle(mg));
@@ -1195,13 +1233,13 @@ extern "C" int fh_mg_destroy(fh_mg_t mg) {
   if (mg->graph) hipGraphDestroy(mg->graph);
   for (auto& L : mg->lv) {
     free_level_buffers(L);
-    free_level_restriction(L);
     free_level_colors(L);
     free_level_patches(L);
   }
   if (mg->d_ainv) hipFree(mg->d_ainv);
   if (mg->d_gjwork) hipFree(mg->d_gjwork);
   for (double* p : mg->kv) hipFree(p);
+  if (mg->d_V) hipFree(mg->d_V);
   delete mg;
   return 0;
 }
@@ -1268,7 +1306,9 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
     FH_TRY(apply_cycle(mg, b, x));
     its = 1;
   } else if (outer == FH_OUTER_RICHARDSON) {
-    // x <- x + 0.99999 M^-1 (b - A x), x0 = 0 (MGInit: _richardsonScaleFactor = .99999, :190-193)
+    // x <- x + 0.99999 M^-1 (b - A x), x0 = 0.  The scale of the OUTER Richardson is fixed by the reference itself: MGInit sets
+    // _richardsonScaleFactor = .99999 around SetSolver(_ksp) and restores the user's value afterwards (:190-193), so
+    // SetRichardsonScaleFactor only ever reaches the level smoothers (omega of fh_mg_set_level)
     FH_TRY(krylov_reserve(mg, 2, ncols));
     double *r = mg->kv[0], *z = mg->kv[1];
     FH_CHECK_HIP(hipMemsetAsync(x, 0, (size_t)n * sizeof(double), c->stream));
@@ -1318,8 +1358,15 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
     double* w = mg->kv[restart + 2];
     const int nb = sgrid(c, n);
     FH_TRY(fh_reserve_reduction(c, (size_t)(restart + 2) * (nb + 1) + 64));
-    double** d_V = nullptr;
-    FH_CHECK_HIP(hipMalloc(&d_V, (restart + 1) * sizeof(double*)));
+    // basis pointers on the device: owned by the solver object (an early error return must not leak them)
+    if (mg->d_V_n < restart + 1) {
+      if (mg->d_V) FH_CHECK_HIP(hipFree(mg->d_V));
+      mg->d_V = nullptr;
+      mg->d_V_n = 0;
+      FH_CHECK_HIP(hipMalloc(&mg->d_V, (restart + 1) * sizeof(double*)));
+      mg->d_V_n = restart + 1;
+    }
+    double** d_V = mg->d_V;
     FH_CHECK_HIP(hipMemcpy(d_V, mg->kv.data(), (restart + 1) * sizeof(double*), hipMemcpyHostToDevice));
     std::vector<double> H((size_t)(restart + 1) * restart, 0.0), g(restart + 1), cs(restart), sn(restart), y(restart);
     // Knoll: x0 = M^-1 b ; reference norm = ||M^-1 b||
@@ -1356,7 +1403,10 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
         FH_TRY(dot(w, w, &wn));
         wn = sqrt(wn);
         H[(size_t)(k + 1) * restart + k] = wn;
+        // happy breakdown (w = 0: the Krylov space is invariant): the next basis vector is never used, but it must not stay
+        // uninitialised / stale either
         if (wn != 0.0) FH_TRY(dev_axpby(c, mg->kv[k + 1], w, 1.0 / wn, 0.0, n));
+        else FH_CHECK_HIP(hipMemsetAsync(mg->kv[k + 1], 0, (size_t)n * sizeof(double), c->stream));
         for (int j = 0; j < k; j++) {
           const double a = H[(size_t)j * restart + k], bb = H[(size_t)(j + 1) * restart + k];
           H[(size_t)j * restart + k] = cs[j] * a + sn[j] * bb;
@@ -1364,6 +1414,17 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
         }
         const double a = H[(size_t)k * restart + k], bb = H[(size_t)(k + 1) * restart + k];
         const double d = hypot(a, bb);
+        if (d == 0.0) {          // column k of the Hessenberg matrix vanished entirely: nothing to rotate, nothing more to gain
+          cs[k] = 1.0;
+          sn[k] = 0.0;
+          H[(size_t)k * restart + k] = 1.0;      // keeps the back substitution finite; g[k] stays, y[k] = g[k]
+          g[k + 1] = 0.0;
+          its++;
+          kused = k + 1;
+          rn = 0.0;
+          done = true;
+          break;
+        }
         cs[k] = a / d;
         sn[k] = bb / d;
         H[(size_t)k * restart + k] = d;
@@ -1373,7 +1434,7 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
         its++;
         kused = k + 1;
         rn = fabs(g[k + 1]);
-        if (rn <= std::max(rtol * beta0, atol) || its >= maxit) {
+        if (rn <= std::max(rtol * beta0, atol) || its >= maxit || wn == 0.0 || rn > dtol * beta0) {   // dtol: KSP_DIVERGED_DTOL at every iteration
           done = true;
           break;
         }
@@ -1388,7 +1449,6 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
       hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, x, (const double* const*)d_V, c->d_red, 1.0, kused, n);
       FH_CHECK_HIP(hipStreamSynchronize(c->stream));
     }
-    hipFree(d_V);
   }
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
   if (iterations) *iterations = its;
