@@ -168,3 +168,98 @@ def test_config1_richardson_sor_as_in_001_poisson(ctx):
     b, x = ctx.vector_from(H.b), ctx.vector(H.A[-1].shape[0])
     its, rn = mg.solve(b, x, outer="gmres", rtol=1e-12, maxit=50)
     assert rel(x.to_numpy(), xd) < 1e-10
+
+
+# ---- robustness of the setup (advisor findings, round 1) -------------------------------------------------------------------
+def _one_level(ctx, M):
+    import scipy.sparse as sp
+    A = ctx.matrix_scipy(sp.csr_matrix(M))
+    mg = capi.Multigrid(ctx, 1)
+    mg.set_level(0, A, None, None, 0, 1.0, 1, 0)
+    return mg, A
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_coarse_inverse_of_an_indefinite_operator_with_zero_diagonal(ctx, symmetric):
+    """saddle-point shape: zero diagonal entries, indefinite -- the pivot blocks are inverted with partial pivoting (the reference
+    factors level 0 with a pivoted LU, LinearEquationSolverPetsc.hpp:131-134)"""
+    rng = np.random.default_rng(4)
+    n = 150
+    M = np.zeros((n, n))
+    for k in range(0, n, 2):                      # 2 x 2 blocks [[0, 1], [1, 0]]: every diagonal entry is zero
+        M[k, k + 1] = M[k + 1, k] = 1.0 + 0.1 * rng.uniform()
+    C = 0.05 * rng.uniform(-1, 1, (n, n))
+    np.fill_diagonal(C, 0.0)
+    M += (C + C.T) if symmetric else C
+    assert np.all(np.diag(M) == 0.0)
+    mg, A = _one_level(ctx, M)
+    mg.setup()
+    rhs = rng.uniform(-1, 1, n)
+    b, x = ctx.vector_from(rhs), ctx.vector(n)
+    mg.vcycle(b, x)
+    assert rel(x.to_numpy(), np.linalg.solve(M, rhs)) < 1e-11
+    mg.destroy()
+
+
+def test_singular_coarse_operator_is_an_error_of_setup(ctx):
+    n = 96
+    M = np.eye(n)
+    M[40, 40] = 0.0                                # an empty row and column: singular
+    mg, A = _one_level(ctx, M)
+    with pytest.raises(capi.FemusHipError, match="singular|Inf"):
+        mg.setup()
+    mg.destroy()
+
+
+def test_restriction_follows_in_place_edits_of_the_interpolation(ctx, H3):
+    """R = PP^T is derived from PP at every setup: zeroing rows / columns of PP after a first setup (ZeroInterpolatorDirichletNodes,
+    LinearImplicitSystem.cpp:1032-1120, works in place) must reach the cycle"""
+    import copy
+    H = copy.copy(H3)
+    mg, mats = device_hierarchy(ctx, H3)
+    n = H3.A[-1].shape[0]
+    rhs = fo.lcg_fill(n, 5)
+    b, x = ctx.vector_from(rhs), ctx.vector(n)
+    mg.vcycle(b, x)
+    top = len(H3.A) - 1
+    rows = np.arange(0, n, 7, dtype=np.int32)
+    P_dev = mats[2 * top + 1]
+    P_dev.mat_zero_rows(rows, 0.0)
+    Pn = H3.P[top].tolil(copy=True)
+    Pn[rows, :] = 0.0
+    H.P = list(H3.P)
+    H.P[top] = Pn.tocsr()
+    mg.set_level(top, mats[2 * top], P_dev, None, 0, 2. / 3., 2, 2)
+    mg.setup()
+    mg.vcycle(b, x)
+    ref = fo.vcycle(H, top, rhs)
+    assert rel(x.to_numpy(), ref) < 1e-11
+    mg.destroy()
+
+
+def test_colouring_is_rebuilt_when_another_operator_is_installed(ctx):
+    """the multicolour SOR ordering belongs to the matrix it was computed for: installing another operator in the same solver
+    object must not reuse it"""
+    Ha = fo.build_poisson_hierarchy(2, 2, 2, 2, "biquadratic", ONE)
+    Hb = fo.build_poisson_hierarchy(2, 2, 2, 2, "biquadratic", ONE)
+    # same sizes, another graph: drop the couplings of every third row of the fine operator of Hb to all but its diagonal
+    Ab = Hb.A[1].tolil(copy=True)
+    for r in range(0, Ab.shape[0], 3):
+        d = Ab[r, r]
+        Ab[r, :] = 0.0
+        Ab[r, r] = d
+    Hb.A = [Hb.A[0], Ab.tocsr()]
+    n = Ha.A[1].shape[0]
+    rhs = fo.lcg_fill(n, 9)
+    b, x1, x2 = ctx.vector_from(rhs), ctx.vector(n), ctx.vector(n)
+    mg, mats = device_hierarchy(ctx, Ha, 1.0, 1, 1, capi.SMOOTH_GS_COLOR)
+    mg.vcycle(b, x1)
+    A2, P2, A0 = ctx.matrix_scipy(Hb.A[1]), ctx.matrix_scipy(Hb.P[1]), ctx.matrix_scipy(Hb.A[0])
+    mg.set_level(0, A0, None, None, capi.SMOOTH_GS_COLOR, 1.0, 1, 1)
+    mg.set_level(1, A2, P2, None, capi.SMOOTH_GS_COLOR, 1.0, 1, 1)
+    mg.setup()
+    mg.vcycle(b, x1)
+    fresh, mats_b = device_hierarchy(ctx, Hb, 1.0, 1, 1, capi.SMOOTH_GS_COLOR)
+    fresh.vcycle(b, x2)
+    assert rel(x1.to_numpy(), x2.to_numpy()) < 1e-13
+    mg.destroy(), fresh.destroy()
