@@ -140,6 +140,7 @@ def _declare(L):
     sig("fh_expr_eval", c_void_p, c_void_p, P(c_double))
     sig("fh_expr_eval_many", c_void_p, c_int, c_void_p, c_void_p)
     sig("fh_expr_program", c_void_p, P(c_int), P(c_int), c_void_p, c_void_p)
+    sig("fh_expr_nvars", c_void_p, P(c_int))
     sig("fh_expr_destroy", c_void_p)
     sig("fh_assemble_poisson_expr", c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p)
     sig("fh_halo_create_host", c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, P(c_void_p))

@@ -1642,6 +1642,12 @@ int fh_expr_program(fh_expr_t e, int* ncode, int* nconst, int* code, double* con
 // (001_Poisson/main.cpp:472 calls the ParsedFunction on the host once per Gauss point and test function)
 extern "C" int fh_assemble_poisson_expr(fh_assembler_t as, fh_vec_t sol, fh_expr_t source, double scale, fh_mat_t A, fh_vec_t res) {
   FH_REQUIRE(as && source, "fh_assemble_poisson_expr: null argument");
+  {
+    // the kernels hand the program a 4-entry point (x, y, z, t): a program compiled over more variables would read past it
+    int nv = 0;
+    FH_TRY(fh_expr_nvars(source, &nv));
+    FH_REQUIRE(nv <= 4, "fh_assemble_poisson_expr: the source expression has %d variables, at most 4 (x, y, z, t) are served", nv);
+  }
   int nc = 0, nk = 0;
   FH_TRY(fh_expr_program(source, &nc, &nk, nullptr, nullptr));
   std::vector<int> code(nc);

@@ -9,6 +9,8 @@
 // Grammar (fparser documentation): precedence, lowest first:  |   &   = != < <= > >=   + -   * / %   unary - !   ^ (right
 // associative, binds tighter than unary minus).  Truth is |x| >= 0.5, comparisons return 1 or 0 and use the library's default
 // epsilon 1e-12 for = and !=.  Constants "pi" and "e" are the two the reference adds (ParsedFunction.cpp:46-47).
+#include <locale>
+#include <sstream>
 #include "fh_internal.h"
 #include "fh_expr_device.h"
 #include <cctype>
@@ -31,6 +33,16 @@ struct Parser {
   fh_expr_s* out;
   std::string err;
   int depth = 0, max_depth = 0;
+  int nest = 0;                           // recursion depth of the parser itself (parentheses, unary operators, exponents)
+  static constexpr int MAX_NEST = 256;    // the expression comes from a user's JSON file: no unbounded host recursion
+  struct Nest {
+    Parser& q;
+    bool ok;
+    explicit Nest(Parser& pp) : q(pp), ok(++pp.nest <= MAX_NEST) {
+      if (!ok) q.fail("expression nested deeper than " + std::to_string(MAX_NEST) + " levels");
+    }
+    ~Nest() { q.nest--; }
+  };
 
   Parser(const std::string& str, fh_expr_s* o) : s(str), out(o) {}
   void skip() { while (p < s.size() && isspace((unsigned char)s[p])) p++; }
@@ -53,6 +65,8 @@ struct Parser {
     return false;
   }
   bool parse_or() {
+    Nest guard(*this);
+    if (!guard.ok) return false;
     if (!parse_and()) return false;
     while (true) {
       skip();
@@ -114,6 +128,8 @@ struct Parser {
     }
   }
   bool parse_unary() {
+    Nest guard(*this);
+    if (!guard.ok) return false;
     skip();
     if (p < s.size() && s[p] == '-') {
       p++;
@@ -144,6 +160,8 @@ struct Parser {
     return true;
   }
   bool parse_unary_pow() {
+    Nest guard(*this);
+    if (!guard.ok) return false;
     skip();
     if (p < s.size() && s[p] == '-') {
       p++;
@@ -164,11 +182,28 @@ struct Parser {
       return true;
     }
     if (isdigit((unsigned char)c) || c == '.') {
-      const char* b = s.c_str() + p;
-      char* e = nullptr;
-      const double v = strtod(b, &e);
-      if (e == b) return fail("bad number");
-      p += (size_t)(e - b);
+      // the literal is delimited by hand ([digits][.digits][e[+-]digits]) and converted in the classic "C" locale: strtod would
+      // follow LC_NUMERIC of the host application (a decimal comma there must not change what "0.5" means here)
+      size_t q = p;
+      while (q < s.size() && isdigit((unsigned char)s[q])) q++;
+      if (q < s.size() && s[q] == '.') {
+        q++;
+        while (q < s.size() && isdigit((unsigned char)s[q])) q++;
+      }
+      if (q < s.size() && (s[q] == 'e' || s[q] == 'E')) {
+        size_t r = q + 1;
+        if (r < s.size() && (s[r] == '+' || s[r] == '-')) r++;
+        if (r < s.size() && isdigit((unsigned char)s[r])) {
+          while (r < s.size() && isdigit((unsigned char)s[r])) r++;
+          q = r;
+        }
+      }
+      std::istringstream is(s.substr(p, q - p));
+      is.imbue(std::locale::classic());
+      double v = 0.0;
+      is >> v;
+      if (is.fail() || q == p || (q - p == 1 && s[p] == '.')) return fail("bad number");
+      p = q;
       out->consts.push_back(v);
       emit(FHX_CONST, (int)out->consts.size() - 1, 1);
       return true;
@@ -247,13 +282,14 @@ extern "C" int fh_expr_compile(const char* expression, const char* variables, fh
   if (!ok || ps.depth != 1) {
     const std::string msg = ps.err.empty() ? std::string("malformed expression") : ps.err;
     delete e;
-    fh_set_error("fh_expr_compile: \"%s\": %s", expression, msg.c_str());
+    fh_set_error("fh_expr_compile: \"%.120s%s\": %s", expression, strlen(expression) > 120 ? "..." : "", msg.c_str());
     return 2;
   }
   e->max_stack = ps.max_depth;
   if (e->max_stack > FHX_STACK) {
     delete e;
-    fh_set_error("fh_expr_compile: \"%s\" needs an evaluation stack of %d (limit %d)", expression, ps.max_depth, FHX_STACK);
+    fh_set_error("fh_expr_compile: \"%.120s%s\" needs an evaluation stack of %d (limit %d)", expression, strlen(expression) > 120 ? "..." : "",
+                 ps.max_depth, FHX_STACK);
     return 2;
   }
   *out = e;
@@ -279,6 +315,12 @@ extern "C" int fh_expr_program(fh_expr_t e, int* ncode, int* nconst, int* code, 
   if (consts) memcpy(consts, e->consts.data(), e->consts.size() * sizeof(double));
   *ncode = (int)e->code.size();
   *nconst = (int)e->consts.size();
+  return 0;
+}
+
+extern "C" int fh_expr_nvars(fh_expr_t e, int* nvars) {
+  FH_REQUIRE(e && nvars, "fh_expr_nvars: null argument");
+  *nvars = e->nvars;
   return 0;
 }
 

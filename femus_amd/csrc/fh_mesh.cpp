@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <functional>
+#include <memory>
 #include <unordered_map>
 
 struct fh_mesh_s {
@@ -884,8 +885,21 @@ extern "C" int fh_mesh_vertex_patches(fh_mesh_t m, int nvars, const int* fe, int
 // ---------------------------------------------------------------------------------------------------------------------
 #include <fstream>
 
+static int read_gambit(const char* path, double Lref, fh_mesh_t* out);
+
+// the file is untrusted input: sizes are checked before they size anything, the mesh object is owned by a guard until it is handed
+// out, and no C++ exception (bad_alloc, length_error) crosses the C boundary
 extern "C" int fh_mesh_read_gambit(const char* path, double Lref, fh_mesh_t* out) {
   FH_REQUIRE(path && out && Lref != 0.0, "fh_mesh_read_gambit: bad arguments");
+  try {
+    return read_gambit(path, Lref, out);
+  } catch (const std::exception& e) {
+    fh_set_error("fh_mesh_read_gambit: %s: %s", path, e.what());
+    return 2;
+  }
+}
+
+static int read_gambit(const char* path, double Lref, fh_mesh_t* out) {
   std::ifstream inf(path);
   FH_REQUIRE((bool)inf, "Generic-mesh file %s can not read parameters", path);
   std::vector<std::string> tok;
@@ -909,9 +923,14 @@ extern "C" int fh_mesh_read_gambit(const char* path, double Lref, fh_mesh_t* out
   double v[6];
   for (int k = 0; k < 6; k++) FH_REQUIRE(num(p + 1 + k, &v[k]), "fh_mesh_read_gambit: %s: error control data mesh", path);
   FH_REQUIRE(p + 7 < tok.size() && tok[p + 7] == "ENDOFSECTION", "fh_mesh_read_gambit: %s: error control data mesh", path);
+  // every count is bounded by the number of tokens in the file (a node, an element, a group, a boundary set each take tokens)
+  for (int k = 0; k < 6; k++)
+    FH_REQUIRE(v[k] >= 0.0 && v[k] <= (double)tok.size() && v[k] == std::floor(v[k]), "fh_mesh_read_gambit: %s: error control data mesh (count %g)", path, v[k]);
   const int nvt = (int)v[0], nel = (int)v[1], ngroup = (int)v[2], nbcd = (int)v[3], dim = (int)v[4], dimNodes = (int)v[5];
   FH_REQUIRE(dim == 2 || dim == 3, "fh_mesh_read_gambit: %s: %d-dimensional meshes are not served (HEX27 / QUAD9 only)", path, dim);
-  fh_mesh_s* m = new fh_mesh_s();
+  FH_REQUIRE(nvt >= 1 && nel >= 1 && dimNodes >= dim && dimNodes <= 3, "fh_mesh_read_gambit: %s: error control data mesh", path);
+  std::unique_ptr<fh_mesh_s> guard(new fh_mesh_s());
+  fh_mesh_s* m = guard.get();
   m->geom = dim == 3 ? GEOM_HEX : GEOM_QUAD;
   m->dim = dim;
   m->nloc = nloc_of(m->geom);
@@ -939,7 +958,6 @@ extern "C" int fh_mesh_read_gambit(const char* path, double Lref, fh_mesh_t* out
     double nve;
     FH_REQUIRE(num(p + 2, &nve), "fh_mesh_read_gambit: %s: error element data mesh", path);
     if ((int)nve != nl) {
-      delete m;
       fh_set_error("Error! Invalid element type in reading Gambit File! (element %d has %d nodes; HEX27 / QUAD9 meshes are served)", iel + 1, (int)nve);
       return 2;
     }
@@ -972,7 +990,8 @@ extern "C" int fh_mesh_read_gambit(const char* path, double Lref, fh_mesh_t* out
   for (int k = 0; k < ngroup; k++) {
     p = seek("GROUP:", p);
     double ngel, mat, name;
-    FH_REQUIRE(p < tok.size() && num(p + 3, &ngel) && num(p + 5, &mat) && num(p + 8, &name), "fh_mesh_read_gambit: %s: error group data mesh", path);
+    FH_REQUIRE(p < tok.size() && num(p + 3, &ngel) && num(p + 5, &mat) && num(p + 8, &name) && ngel >= 0 && ngel <= nel,
+               "fh_mesh_read_gambit: %s: error group data mesh", path);
     p += 10;
     for (int i = 0; i < (int)ngel; i++) {
       double iel;
@@ -989,7 +1008,8 @@ extern "C" int fh_mesh_read_gambit(const char* path, double Lref, fh_mesh_t* out
   for (int k = 0; k < nbcd; k++) {
     p = seek("CONDITIONS", p);
     double value, nface;
-    FH_REQUIRE(p < tok.size() && num(p + 2, &value) && num(p + 4, &nface), "fh_mesh_read_gambit: %s: error boundary data mesh", path);
+    FH_REQUIRE(p < tok.size() && num(p + 2, &value) && num(p + 4, &nface) && nface >= 0 && nface <= (double)nel * nf && fabs(value) < 1e9,
+               "fh_mesh_read_gambit: %s: error boundary data mesh", path);
     p += 7;
     for (int i = 0; i < (int)nface; i++) {
       double iel, iface;
@@ -1021,12 +1041,11 @@ extern "C" int fh_mesh_read_gambit(const char* path, double Lref, fh_mesh_t* out
     for (int x : m->elem_dof) used[x] = 1;
     for (int j = 0; j < nvt; j++)
       if (!used[j]) {
-        delete m;
         fh_set_error("fh_mesh_read_gambit: %s: node %d belongs to no element", path, j + 1);
         return 2;
       }
   }
   first_touch_renumber(*m, nvt);
-  *out = m;
+  *out = guard.release();
   return 0;
 }

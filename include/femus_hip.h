@@ -242,6 +242,7 @@ int fh_expr_compile(const char* expression, const char* variables, fh_expr_t* ex
 int fh_expr_eval(fh_expr_t expr, const double* x, double* value);
 int fh_expr_eval_many(fh_expr_t expr, int npts, const double* x /* [npts*nvars] */, double* values);
 int fh_expr_program(fh_expr_t expr, int* ncode, int* nconst, int* code /* or NULL */, double* consts /* or NULL */);
+int fh_expr_nvars(fh_expr_t expr, int* nvars);      /* number of variables the expression was compiled over */
 int fh_expr_destroy(fh_expr_t expr);
 int fh_assemble_poisson_expr(fh_assembler_t as, fh_vec_t sol, fh_expr_t source, double scale, fh_mat_t A, fh_vec_t res);
 

@@ -44,3 +44,29 @@ def test_expression_matches_python(text, fn):
 def test_syntax_errors_are_reported(bad):
     with pytest.raises(capi.FemusHipError):
         capi.Expr(bad, "x,y,z,t")
+
+
+def test_parser_refuses_unbounded_nesting_instead_of_overflowing_the_stack():
+    """a long run of '(' or '-' from a JSON input (advisor, round 1): an error, not a crash"""
+    from femus_amd import capi
+    for text in ("(" * 100000 + "x" + ")" * 100000, "-" * 100000 + "x", "2" + "^-2" * 50000):
+        with pytest.raises(capi.FemusHipError, match="nested deeper"):
+            capi.Expr(text)
+    e = capi.Expr("(" * 100 + "x+1" + ")" * 100)
+    assert e([2.0, 0, 0, 0]) == 3.0
+
+
+def test_numbers_do_not_depend_on_the_process_locale():
+    import locale
+    from femus_amd import capi
+    old = locale.setlocale(locale.LC_NUMERIC)
+    try:
+        for name in ("de_DE.UTF-8", "fr_FR.UTF-8", "it_IT.UTF-8"):
+            try:
+                locale.setlocale(locale.LC_NUMERIC, name)
+                break
+            except locale.Error:
+                continue
+        assert capi.Expr("0.5*x + 1.25e1 + .5 + 3.")([2.0, 0, 0, 0]) == 0.5 * 2 + 12.5 + 0.5 + 3.0
+    finally:
+        locale.setlocale(locale.LC_NUMERIC, old)
