@@ -96,6 +96,13 @@ def _declare(L):
     sig("fh_mat_ptap", c_void_p, c_void_p, P(c_void_p))
     sig("fh_mat_matmul", c_void_p, c_void_p, P(c_void_p))
     sig("fh_mat_norm", c_void_p, c_int, P(c_double))
+    sig("fh_mat_abc", c_void_p, c_void_p, c_void_p, P(c_void_p))
+    sig("fh_mat_col_mask", c_void_p, c_int, c_void_p, c_void_p)
+    sig("fh_mat_row_mask", c_void_p, c_void_p, c_void_p)
+    sig("fh_mat_restrict", c_void_p, c_int, c_void_p, c_void_p, c_int, P(c_void_p), P(c_void_p))
+    sig("fh_mat_restrict_check", c_void_p, c_int, c_void_p, c_void_p, P(c_double))
+    sig("fh_mat_value_map", c_void_p, c_void_p, c_void_p, c_void_p, P(c_void_p))
+    sig("fh_halo_allreduce_mat", c_void_p, c_void_p)
     sig("fh_spmv", c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_double)
     sig("fh_spmv_transpose", c_void_p, c_void_p, c_void_p)
     sig("fh_fe_gauss", c_int, c_int, P(c_int), c_void_p, c_void_p)

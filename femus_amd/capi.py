@@ -345,6 +345,55 @@ class Mat:
         _chk(self.L.fh_mat_norm(self.h, 0, ctypes.byref(out)))
         return out.value
 
+    # ---- owned-row operators of a domain-decomposed level (device-side cut out of the extended-box operator) ----
+    def col_mask(self, rows, mask=None):
+        """uint8 mask over the columns: 1 where one of `rows` has an entry"""
+        rows = _i32(rows)
+        if mask is None:
+            mask = np.zeros(self.n_, dtype=np.uint8)
+        _chk(self.L.fh_mat_col_mask(self.h, rows.size, _p(rows), _p(mask)))
+        return mask
+
+    def row_mask(self, colmask, mask=None):
+        """uint8 mask over the rows: 1 where the row has an entry in a masked column"""
+        cm = np.ascontiguousarray(colmask, dtype=np.uint8)
+        assert cm.size == self.n_
+        if mask is None:
+            mask = np.zeros(self.m_, dtype=np.uint8)
+        _chk(self.L.fh_mat_row_mask(self.h, _p(cm), _p(mask)))
+        return mask
+
+    def restrict(self, rows, newcol, ncols_new, check=False):
+        """(dst, map): dst = rows of self with columns renumbered by newcol (< 0: dropped); map re-gathers the values later"""
+        rows, newcol = _i32(rows), _i32(newcol)
+        assert newcol.size == self.n_
+        if check:
+            mx = ctypes.c_double()
+            _chk(self.L.fh_mat_restrict_check(self.h, rows.size, _p(rows), _p(newcol), ctypes.byref(mx)))
+            assert mx.value == 0.0, "an owned row reads a node outside the halo (|value| %g)" % mx.value
+        h, mh = ctypes.c_void_p(), ctypes.c_void_p()
+        _chk(self.L.fh_mat_restrict(self.h, rows.size, _p(rows), _p(newcol), int(ncols_new), ctypes.byref(h), ctypes.byref(mh)))
+        return Mat(self.ctx, h), Index.from_handle(self.ctx, mh, None)
+
+    def value_map(self, src, src_row=None, src_col=None):
+        """Index m with self.val[k] <- src.val[m[k]] for the entry (r, c) of self taken from (src_row[r], src_col[c]) of src"""
+        sr = None if src_row is None else _i32(src_row)
+        sc = None if src_col is None else _i32(src_col)
+        mh = ctypes.c_void_p()
+        _chk(self.L.fh_mat_value_map(self.h, src.h, _p(sr), _p(sc), ctypes.byref(mh)))
+        return Index.from_handle(self.ctx, mh, self.nnz)
+
+    @classmethod
+    def abc(cls, A, B, C):
+        """D = A B C with a reusable plan (SparseMatrix::matrix_ABC, SparseMatrix.hpp:186); repeat with D.abc_numeric(A, B, C)"""
+        h = ctypes.c_void_p()
+        _chk(A.L.fh_mat_abc(A.h, B.h, C.h, ctypes.byref(h)))
+        return cls(A.ctx, h)
+
+    def abc_numeric(self, A, B, C):
+        h = ctypes.c_void_p(self.h.value if isinstance(self.h, ctypes.c_void_p) else self.h)
+        _chk(self.L.fh_mat_abc(A.h, B.h, C.h, ctypes.byref(h)))
+
     def split_info(self, n_own_cols):
         """(interior, interface) row-block counts of the overlap split for an operator over [owned | ghost] columns"""
         a, b = ctypes.c_int(), ctypes.c_int()
@@ -594,6 +643,12 @@ class Index:
         self.h = ctypes.c_void_p()
         _chk(self.L.fh_index_create(ctx.h, idx.size, _p(idx), ctypes.byref(self.h)))
 
+    @classmethod
+    def from_handle(cls, ctx, handle, n):
+        self = cls.__new__(cls)
+        self.ctx, self.L, self.h, self.n = ctx, ctx.L, handle, n
+        return self
+
     def zero_rows(self, A, diag):
         _chk(self.L.fh_mat_zero_rows_index(A.h, self.h, float(diag)))
 
@@ -822,6 +877,10 @@ class Halo:
         tx, te = ctypes.c_double(), ctypes.c_double()
         _chk(self.L.fh_halo_stats(self.h, int(bool(reset)), ctypes.byref(n), ctypes.byref(b), ctypes.byref(tx), ctypes.byref(te)))
         return {"updates": n.value, "bytes_sent": b.value, "exchange_ms": tx.value, "exposed_ms": te.value}
+
+    def allreduce_mat(self, A):
+        """in-place sum over the ranks of the values of a matrix that has the same pattern on every rank"""
+        _chk(self.L.fh_halo_allreduce_mat(self.h, A.h))
 
     def allreduce_vec(self, v):
         """in-place sum over the ranks of the owned part of a device vector"""

@@ -178,6 +178,17 @@ extern "C" int fh_halo_allreduce_vec(fh_halo_t h, fh_vec_t v) {
   return 0;
 }
 
+// sum over the ranks of the values of a matrix with the SAME pattern on every rank (the replicated level's operator: every rank adds
+// its share P^T A_0 P; the reference gets the same sum from MatPtAP over the distributed rows, PetscMatrix.cpp:733-751)
+extern "C" int fh_halo_allreduce_mat(fh_halo_t h, fh_mat_t A) {
+  FH_REQUIRE(h && A, "fh_halo_allreduce_mat: null argument");
+  if (halo_inert(h) || A->nnz == 0) return 0;
+  A->at_valid = false;
+  if (h->allreduce) return host_allreduce(h, A->d_val, A->nnz);
+  FH_CHECK_NCCL(ncclAllReduce(A->d_val, A->d_val, A->nnz, ncclDouble, ncclSum, h->comm, h->ctx->stream));
+  return 0;
+}
+
 int fh_halo_allreduce_ptr(fh_halo_t h, double* d, int n) {
   if (halo_inert(h) || n == 0) return 0;
   if (h->allreduce) return host_allreduce(h, d, n);

@@ -343,6 +343,149 @@ extern "C" int fh_mat_gather_values(fh_mat_t dst, fh_mat_t src, fh_index_t map) 
   return 0;
 }
 
+// ---- owned-row operators of a domain-decomposed level, built on the device from the operator of the rank's extended box ----------
+// The reference's multi-rank matrices hold the rows a rank owns over [owned | ghost] columns (MPIAIJ behind PetscMatrix::init,
+// PetscMatrix.cpp:162-203; ghost lists LinearEquation.cpp:239-280).  Here the rank's complete local operator already lives on the
+// device; these entry points cut the owned rows out of it: integer pattern work on the host copies of the pattern, values by a
+// device gather along a map that is kept, so that every re-preparation (new values, same pattern) is one kernel per operator.
+
+// mask[c] = 1 for every column that one of the listed rows touches (the halo a set of owned rows reads)
+extern "C" int fh_mat_col_mask(fh_mat_t A, int nrows, const int* rows, unsigned char* mask /* [A->n], or-ed into */) {
+  FH_REQUIRE(A && mask && nrows >= 0 && (nrows == 0 || rows), "fh_mat_col_mask: bad arguments");
+  for (int i = 0; i < nrows; i++) {
+    const int r = rows[i];
+    FH_REQUIRE(r >= 0 && r < A->m, "fh_mat_col_mask: row %d out of range", r);
+    for (int k = A->h_rowptr[r]; k < A->h_rowptr[r + 1]; k++) mask[A->h_col[k]] = 1;
+  }
+  return 0;
+}
+
+// rowmask[r] = 1 for every row with an entry in a masked column (the rows a transposed operator restricted to those columns reads)
+extern "C" int fh_mat_row_mask(fh_mat_t A, const unsigned char* colmask /* [A->n] */, unsigned char* rowmask /* [A->m], or-ed into */) {
+  FH_REQUIRE(A && colmask && rowmask, "fh_mat_row_mask: null argument");
+  for (int r = 0; r < A->m; r++) {
+    if (rowmask[r]) continue;
+    for (int k = A->h_rowptr[r]; k < A->h_rowptr[r + 1]; k++)
+      if (colmask[A->h_col[k]]) {
+        rowmask[r] = 1;
+        break;
+      }
+  }
+  return 0;
+}
+
+// map[k] for every non-zero k = (r, c) of dst: position of (src_row[r], src_col[c]) in src, or -1 when src has no such entry
+// (NULL row / column lists = identity).  Feeds fh_mat_gather_values.
+extern "C" int fh_mat_value_map(fh_mat_t dst, fh_mat_t src, const int* src_row, const int* src_col, fh_index_t* out) {
+  FH_REQUIRE(dst && src && out, "fh_mat_value_map: null argument");
+  std::vector<int> map((size_t)dst->nnz, -1);
+  for (int r = 0; r < dst->m; r++) {
+    const int sr = src_row ? src_row[r] : r;
+    if (sr < 0) continue;
+    FH_REQUIRE(sr < src->m, "fh_mat_value_map: source row %d out of range", sr);
+    const int* b = src->h_col.data() + src->h_rowptr[sr];
+    const int* e = src->h_col.data() + src->h_rowptr[sr + 1];
+    for (int k = dst->h_rowptr[r]; k < dst->h_rowptr[r + 1]; k++) {
+      const int sc = src_col ? src_col[dst->h_col[k]] : dst->h_col[k];
+      if (sc < 0) continue;
+      const int* q = std::lower_bound(b, e, sc);
+      if (q != e && *q == sc) map[k] = (int)(q - src->h_col.data());
+    }
+  }
+  return fh_index_create(dst->ctx, dst->nnz, map.data(), out);
+}
+
+// dst = the listed rows of src (in list order) with columns renumbered by newcol[src->n] (entries whose new column is < 0 are
+// dropped -- they must hold zeros, which fh_mat_restrict_check verifies on the device); *map as in fh_mat_value_map, values gathered
+extern "C" int fh_mat_restrict(fh_mat_t src, int nrows, const int* rows, const int* newcol, int ncols_new, fh_mat_t* out, fh_index_t* map_out) {
+  FH_REQUIRE(src && out && map_out && newcol && nrows >= 0 && (nrows == 0 || rows) && ncols_new >= 0, "fh_mat_restrict: bad arguments");
+  std::vector<int> rp(nrows + 1, 0);
+  for (int i = 0; i < nrows; i++) {
+    const int r = rows[i];
+    FH_REQUIRE(r >= 0 && r < src->m, "fh_mat_restrict: row %d out of range", r);
+    int cnt = 0;
+    for (int k = src->h_rowptr[r]; k < src->h_rowptr[r + 1]; k++) {
+      const int c = newcol[src->h_col[k]];
+      FH_REQUIRE(c < ncols_new, "fh_mat_restrict: new column %d out of range (%d columns)", c, ncols_new);
+      cnt += c >= 0;
+    }
+    rp[i + 1] = rp[i] + cnt;
+  }
+  std::vector<int> col((size_t)rp[nrows]), map((size_t)rp[nrows]);
+  std::vector<std::pair<int, int>> buf;
+  for (int i = 0; i < nrows; i++) {
+    const int r = rows[i];
+    buf.clear();
+    for (int k = src->h_rowptr[r]; k < src->h_rowptr[r + 1]; k++) {
+      const int c = newcol[src->h_col[k]];
+      if (c >= 0) buf.emplace_back(c, k);
+    }
+    std::sort(buf.begin(), buf.end());
+    for (size_t t = 0; t < buf.size(); t++) {
+      FH_REQUIRE(t == 0 || buf[t].first != buf[t - 1].first, "fh_mat_restrict: two columns of row %d map to the same new column", r);
+      col[rp[i] + t] = buf[t].first;
+      map[rp[i] + t] = buf[t].second;
+    }
+  }
+  fh_mat_t D = nullptr;
+  FH_TRY(fh_mat_create_csr(src->ctx, nrows, ncols_new, rp.data(), col.data(), nullptr, &D));
+  fh_index_t M = nullptr;
+  int rc = fh_index_create(src->ctx, (int)map.size(), map.data(), &M);
+  if (rc) {
+    fh_mat_destroy(D);
+    return rc;
+  }
+  rc = fh_mat_gather_values(D, src, M);
+  if (rc) {
+    fh_mat_destroy(D);
+    fh_index_destroy(M);
+    return rc;
+  }
+  *out = D;
+  *map_out = M;
+  return 0;
+}
+
+// largest |value| among the entries of the listed rows of src that fh_mat_restrict drops (new column < 0): must be 0 for the owned
+// rows of a level operator -- an owned row reads nothing outside its halo
+__global__ __launch_bounds__(256) void k_dropped_max(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+                                                     const int* __restrict__ rows, int nrows, const int* __restrict__ newcol, double* __restrict__ out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  double mx = 0.0;
+  if (i < nrows) {
+    const int r = rows[i];
+    for (int k = rowptr[r] + lane; k < rowptr[r + 1]; k += 64)
+      if (newcol[col[k]] < 0) mx = fmax(mx, fabs(val[k]));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+  if (lane == 0 && mx > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(mx));   // positive doubles order like integers
+}
+
+extern "C" int fh_mat_restrict_check(fh_mat_t src, int nrows, const int* rows, const int* newcol, double* max_dropped) {
+  FH_REQUIRE(src && newcol && max_dropped && nrows >= 0 && (nrows == 0 || rows), "fh_mat_restrict_check: bad arguments");
+  *max_dropped = 0.0;
+  if (nrows == 0) return 0;
+  fh_ctx_t c = src->ctx;
+  int *d_rows = nullptr, *d_new = nullptr;
+  double* d_out = nullptr;
+  FH_CHECK_HIP(hipMalloc(&d_rows, (size_t)nrows * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&d_new, (size_t)std::max(src->n, 1) * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&d_out, sizeof(double)));
+  FH_CHECK_HIP(hipMemcpyAsync(d_rows, rows, (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  FH_CHECK_HIP(hipMemcpyAsync(d_new, newcol, (size_t)src->n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  FH_CHECK_HIP(hipMemsetAsync(d_out, 0, sizeof(double), c->stream));
+  hipLaunchKernelGGL(k_dropped_max, dim3(fh_div_up(nrows, 4)), dim3(256), 0, c->stream, src->d_rowptr, src->d_col, src->d_val, d_rows, nrows, d_new, d_out);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(max_dropped, d_out, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d_rows);
+  hipFree(d_new);
+  hipFree(d_out);
+  FH_CHECK_HIP(e);
+  return 0;
+}
+
 extern "C" int fh_vec_gather(fh_vec_t dst, fh_vec_t src, fh_index_t map) {
   FH_REQUIRE(dst && src && map, "fh_vec_gather: null argument");
   FH_REQUIRE(map->n <= dst->n_local + dst->nghost && map->max_index < src->n_local + src->nghost, "fh_vec_gather: map does not fit the vectors");

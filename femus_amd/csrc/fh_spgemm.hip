@@ -386,11 +386,9 @@ static void spgemm_symbolic(int m, int ncols, const std::vector<int>& a_rp, cons
 
 int fh_mat_refresh_transpose(fh_mat_t A);
 
-extern "C" int fh_mat_ptap(fh_mat_t P, fh_mat_t A, fh_mat_t* Cio) {
-  FH_REQUIRE(P && A && Cio, "fh_mat_ptap: null argument");
-  FH_REQUIRE(A->m == A->n && P->m == A->m, "fh_mat_ptap: shapes do not conform (A %dx%d, P %dx%d)", A->m, A->n, P->m, P->n);
-  FH_TRY(fh_mat_refresh_transpose(P));     // R = P^T with current values
-  fh_mat_t R = P->At;
+// D = R * A * P with a reusable plan attached to D: the product A*P and the two slot maps are kept, so that a repeated call with
+// operands of the same pattern is numeric only
+static int triple_product(fh_mat_t R, fh_mat_t A, fh_mat_t P, fh_mat_t* Cio, const char* who) {
   fh_mat_t C = *Cio;
   PtapPlan* plan = nullptr;
   if (!C) {
@@ -404,7 +402,7 @@ extern "C" int fh_mat_ptap(fh_mat_t P, fh_mat_t A, fh_mat_t* Cio) {
     spgemm_symbolic(A->m, P->n, A->h_rowptr, A->h_col, P->h_rowptr, P->h_col, ap_rp, ap_col);
     FH_TRY(fh_mat_create_csr(A->ctx, A->m, P->n, ap_rp.data(), ap_col.data(), nullptr, &plan->AP));
     spgemm_symbolic(R->m, P->n, R->h_rowptr, R->h_col, ap_rp, ap_col, c_rp, c_col);
-    FH_TRY(fh_mat_create_csr(A->ctx, P->n, P->n, c_rp.data(), c_col.data(), nullptr, &C));
+    FH_TRY(fh_mat_create_csr(A->ctx, R->m, P->n, c_rp.data(), c_col.data(), nullptr, &C));
     C->plan = plan;
     C->plan_destroy = destroy_plan;
     *Cio = C;
@@ -414,13 +412,26 @@ extern "C" int fh_mat_ptap(fh_mat_t P, fh_mat_t A, fh_mat_t* Cio) {
     }
   } else {
     plan = (PtapPlan*)C->plan;
-    FH_REQUIRE(plan != nullptr, "fh_mat_ptap: the output matrix was not created by fh_mat_ptap (no reusable plan)");
-    FH_REQUIRE(plan->m == A->m && plan->nc == P->n && plan->a_nnz == A->nnz && plan->p_nnz == P->nnz,
-               "fh_mat_ptap: reuse with operands of a different pattern");
+    FH_REQUIRE(plan != nullptr, "%s: the output matrix was not created by this product (no reusable plan)", who);
+    FH_REQUIRE(plan->m == A->m && plan->n == A->n && plan->nc == P->n && plan->a_nnz == A->nnz && plan->p_nnz == P->nnz && C->m == R->m,
+               "%s: reuse with operands of a different pattern", who);
   }
   if (plan->map_ap.pa || plan->map_ap.slot) FH_TRY(spgemm_numeric_map(A, P, plan->AP, plan->map_ap)); else FH_TRY(spgemm_numeric(A, P, plan->AP));
   if (plan->map_c.pa || plan->map_c.slot) FH_TRY(spgemm_numeric_map(R, plan->AP, C, plan->map_c)); else FH_TRY(spgemm_numeric(R, plan->AP, C));
   return 0;
+}
+
+extern "C" int fh_mat_ptap(fh_mat_t P, fh_mat_t A, fh_mat_t* Cio) {
+  FH_REQUIRE(P && A && Cio, "fh_mat_ptap: null argument");
+  FH_REQUIRE(A->m == A->n && P->m == A->m, "fh_mat_ptap: shapes do not conform (A %dx%d, P %dx%d)", A->m, A->n, P->m, P->n);
+  FH_TRY(fh_mat_refresh_transpose(P));     // R = P^T with current values
+  return triple_product(P->At, A, P, Cio, "fh_mat_ptap");
+}
+
+extern "C" int fh_mat_abc(fh_mat_t A, fh_mat_t B, fh_mat_t C, fh_mat_t* D) {
+  FH_REQUIRE(A && B && C && D, "fh_mat_abc: null argument");
+  FH_REQUIRE(A->n == B->m && B->n == C->m, "fh_mat_abc: shapes do not conform (A %dx%d, B %dx%d, C %dx%d)", A->m, A->n, B->m, B->n, C->m, C->n);
+  return triple_product(A, B, C, D, "fh_mat_abc");
 }
 
 extern "C" int fh_mat_matmul(fh_mat_t A, fh_mat_t B, fh_mat_t* Cout) {

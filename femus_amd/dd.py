@@ -577,18 +577,27 @@ class SocketComm:
 class DistributedPoisson:
     """weak-scaled config C3: every rank owns an nb^3-coarse-element block (64^3 fine elements for nb=8, 4 levels) of the
     global (px*nb, py*nb, pz*nb) box; operators hold owned rows over [owned | ghost] columns; ghosts are refreshed by
-    fh_halo_update inside the cycle; one replicated level below replaces the single-GPU exact coarse solve."""
+    fh_halo_* inside the cycle (overlapped with the rows that need no ghost); one replicated level below replaces the
+    single-GPU exact coarse solve.
+
+    Everything numeric stays on the device.  The rank's extended box (block + ghost ring) carries the complete local hierarchy
+    (`self.full`, the one-GPU code: assembly, Galerkin chain, SetPenalty); the owned rows of every level operator are cut out of
+    it by fh_mat_restrict (integer pattern work once, then one gather kernel per operator), the rank's share of the replicated
+    operator is the triple product fh_mat_abc summed over the ranks on the device (fh_halo_allreduce_mat).  `prepare()` repeats
+    the numeric part -- what LinearImplicitSystem::MGsolve does before every solve (LinearImplicitSystem.cpp:347-383)."""
 
     def __init__(self, ctx, comm, nranks, rank, nb=8, nlevels=4, omega=2. / 3., npre=2, npost=2, fe="biquadratic", order="seventh",
                  transport="rccl", flag_fn=None, n_uniform=None, source_kind=0, params=(1.0,)):
         """flag_fn / n_uniform: adaptive levels (BASELINE config "MGAMR ... 8 GPUs"): every rank refines its extended box with the
         same flag function on global coordinates.  The fine level is then assembled AND projected (hanging nodes) on the extended
         box with the one-GPU code and the owned rows are gathered out on the device; uniform hierarchies keep the leaner
-        owned-rows assembler."""
+        owned-rows assembler for assemble()."""
+        import time
         from .poisson import PoissonMG
         self.ctx, self.comm = ctx, comm
         self.part = BoxPartition(nranks, rank)
         self.nb, self.nl = nb, nlevels
+        self.omega, self.npre, self.npost = omega, npre, npost
         self.source_kind, self.params = source_kind, params
         part = self.part
         # 1. full local hierarchy on the extended box (device): assemble, Galerkin chain, SetPenalty
@@ -598,93 +607,153 @@ class DistributedPoisson:
                          source_kind=source_kind, params=params)
         full.init()
         full.assemble()
-        full.prepare_operators_only()
-        A_full = [a.to_scipy() for a in full.A]
-        P_full = [None] + [p.to_scipy() for p in full.P[1:]]
-        bdc_full = [np.asarray(b, dtype=np.int64) for b in full.bdc]
-        # 2. replicated level below
-        m_rep, m_g0 = replicated_level(part, nb)
-        Pg = capi.build_prolongator(ctx, m_rep, m_g0, fe, zero_bdc=True)
-        P_g0 = Pg.to_scipy()
-        Pg.destroy()
-        bdc_rep = m_rep.dirichlet_dofs(fe).astype(np.int64)
-        # 3. plans + row-restricted operators (host, integer/setup work)
-        H = build_host_hierarchy(part, comm, nb, meshes, A_full, P_full, bdc_full, (m_rep, m_g0, P_g0, bdc_rep))
+        full.level_operators()
+        self.full = full
+        # 2. exchange plans (host, integers): owners from the global grid index of the nodes, halos from the operators' patterns
+        coords = [m.arrays()[1] for m in meshes]
+        gids, owners = zip(*[node_keys(coords[l], l, nb, part) for l in range(nlevels)])
+        own_rows = [np.where(owners[l] == rank)[0].astype(np.int32) for l in range(nlevels)]
+        need = []
+        for l in range(nlevels):
+            mask = full.A[l].col_mask(own_rows[l])
+            need.append(mask)
+        for l in range(1, nlevels):
+            full.P[l].col_mask(own_rows[l], need[l - 1])                  # interpolation reads coarse ghosts
+            own_c = (owners[l - 1] == rank).astype(np.uint8)
+            full.P[l].row_mask(own_c, need[l])                            # restriction rows of owned coarse nodes read these fine nodes
+        plans = build_level_plans(part, comm, gids, owners, [m.astype(bool) for m in need])
+        H = HostHierarchy()
+        H.plans = plans
         self.H = H
-        top = H.plans[-1]
-        # 4. distributed fine-level assembler: elements touching an owned node, renumbered to [owned | ghost]
-        ed, xy, _ = meshes[-1].arrays()
-        own_mask = np.zeros(meshes[-1].nnode, dtype=bool)
-        own_mask[top.owned] = True
-        els = np.where(own_mask[ed].any(axis=1))[0]
-        ed_new = top.newid[ed[els]]
-        assert ed_new.min() >= 0
-        nloc = top.n_owned + top.n_ghost
-        xy_new = np.zeros((nloc, 3))
-        xy_new[top.newid[np.concatenate([top.owned, top.ghost])]] = xy[np.concatenate([top.owned, top.ghost])]
-        if self.adaptive:
-            # keep the extended-box problem: assemble() runs its assembly + hanging-node projection and gathers the owned rows
-            self.full = full
-            full.assemble()                                           # K_amr of the extended box again (prepare penalised it)
-            Kfull = full.A[-1]
-            rp_f, col_f = Kfull.pattern()
-            Aown = H.A[-1].tocsr()
-            old_of_new = np.full(nloc, -1, dtype=np.int64)
-            old_of_new[top.newid[np.concatenate([top.owned, top.ghost])]] = np.concatenate([top.owned, top.ghost])
-            rows_old = np.repeat(top.owned, np.diff(Aown.indptr))
-            cols_old = old_of_new[Aown.indices]
-            ncol = Kfull.n()
-            keys_full = np.repeat(np.arange(Kfull.m(), dtype=np.int64), np.diff(rp_f)) * ncol + col_f
-            want = rows_old.astype(np.int64) * ncol + cols_old
-            pos = np.searchsorted(keys_full, want)
-            hit = (pos < keys_full.size) & (keys_full[np.minimum(pos, keys_full.size - 1)] == want)
-            self._map_vals = np.where(hit, pos, -1).astype(np.int32)
-            self._map_rows = top.owned.astype(np.int32)
-        else:
-            full.destroy_device_objects()
-        # 5. upload the restricted operators, halos, cycle
+        nloc = [pl.n_owned + pl.n_ghost for pl in plans]
+        # 3. owned rows of every operator, cut out on the device; the maps re-gather the values at every preparation
+        self.A, self.mapA = [], []
+        for l in range(nlevels):
+            a, m = full.A[l].restrict(plans[l].owned, plans[l].newid, nloc[l], check=True)
+            self.A.append(a)
+            self.mapA.append(m)
+        self.P, self.R = [None], [None]
+        for l in range(1, nlevels):
+            p_, m = full.P[l].restrict(plans[l].owned, plans[l - 1].newid, nloc[l - 1])
+            m.destroy()                                                   # geometric: values never change
+            Pt = full.P[l].get_transpose()
+            r_, m = Pt.restrict(plans[l - 1].owned, plans[l].newid, nloc[l])
+            m.destroy()
+            Pt.destroy()
+            self.P.append(p_)
+            self.R.append(r_)
+        H.bdc_owned = [plans[l].newid[np.intersect1d(full.bdc[l], plans[l].owned)] for l in range(nlevels)]
+        # 4. halos
         self.halos = []
         if transport == "host":   # host-staged exchange through `comm` (ranks sharing a GPU, launchers without RCCL peers)
-            for pl in H.plans:
+            for pl in plans:
                 self.halos.append(capi.Halo.host(ctx, rank, nranks, comm, pl.send_counts, pl.send_idx, pl.recv_counts,
                                                  parent=self.halos[0] if self.halos else None))
         else:
             uid = comm.bcast_obj(capi.Halo.unique_id() if rank == 0 else None)
-            for pl in H.plans:     # one RCCL communicator, one exchange plan per level
+            for pl in plans:     # one RCCL communicator, one exchange plan per level
                 self.halos.append(capi.Halo(ctx, rank, nranks, uid, pl.send_counts, pl.send_idx, pl.recv_counts,
                                             parent=self.halos[0] if self.halos else None))
-        self.A = [ctx.matrix_scipy(a) for a in H.A]
-        self.P = [None] + [ctx.matrix_scipy(p) for p in H.P[1:]]
-        self.R = [None] + [ctx.matrix_scipy(r) for r in H.R[1:]]
-        self.A_rep, self.P_rep, self.R_rep = ctx.matrix_scipy(H.rep["A"]), ctx.matrix_scipy(H.rep["P"]), ctx.matrix_scipy(H.rep["R"])
+        # 5. replicated level below: this rank's share of P^T A_0 P as a device triple product, summed over the ranks
+        m_rep, m_g0 = replicated_level(part, nb)
+        Pg = capi.build_prolongator(ctx, m_rep, m_g0, fe, zero_bdc=True)
+        n_rep = m_rep.n_dofs(fe)
+        g0_gid, _ = node_keys(m_g0.arrays()[1], 0, nb, part)
+        srt = np.argsort(g0_gid)
+        loc = plans[0]
+        all_local = np.concatenate([loc.owned, loc.ghost])
+        rows = srt[np.searchsorted(g0_gid[srt], loc.gid[all_local])]
+        assert np.all(g0_gid[rows] == loc.gid[all_local])
+        ident = np.arange(n_rep, dtype=np.int32)
+        self.Pg_local, m = Pg.restrict(rows, ident, n_rep)                # (n_owned + n_ghost) x n_rep, [owned | ghost] order
+        m.destroy()
+        self.P_rep, m = Pg.restrict(rows[:loc.n_owned], ident, n_rep)
+        m.destroy()
+        Pg.destroy()
+        self.R_rep = self.P_rep.get_transpose()
+        self.T_rep = capi.Mat.abc(self.R_rep, self.A[0], self.Pg_local)   # plan kept: numeric-only in prepare()
+        rp, col = capi.pattern_from_elements(m_rep.arrays()[0], n_rep)    # stencil pattern of the replicated mesh (same on all ranks)
+        self.A_rep = ctx.matrix_csr(n_rep, n_rep, rp, col)
+        trp, tcol = self.T_rep.pattern()
+        pkey = np.repeat(np.arange(n_rep, dtype=np.int64), np.diff(rp)) * n_rep + col
+        tkey = np.repeat(np.arange(n_rep, dtype=np.int64), np.diff(trp)) * n_rep + tcol
+        pos = np.searchsorted(pkey, tkey)
+        assert np.all(pkey[np.minimum(pos, pkey.size - 1)] == tkey), "replicated coarse operator leaves its stencil pattern"
+        self.map_rep = self.A_rep.value_map(self.T_rep)
+        self.bdc_rep = capi.Index(ctx, m_rep.dirichlet_dofs(fe).astype(np.int32))
+        for m_ in (m_rep, m_g0):
+            m_.destroy()
+        self._replicated_operator()
+        # 6. distributed fine-level assembler: elements touching an owned node, renumbered to [owned | ghost]
+        top = plans[-1]
+        ed, xy, _ = meshes[-1].arrays()
+        own_mask = np.zeros(meshes[-1].nnode, dtype=bool)
+        own_mask[top.owned] = True
+        els = np.where(own_mask[ed].any(axis=1))[0]
+        ntop = nloc[-1]
         if self.adaptive:
+            # assemble() runs the extended-box assembly + hanging-node projection and gathers the owned rows
             self.asm = None
-            self.map_vals, self.map_rows = capi.Index(ctx, self._map_vals), capi.Index(ctx, self._map_rows)
+            self.map_rows = capi.Index(ctx, top.owned.astype(np.int32))
         else:
+            ed_new = top.newid[ed[els]]
+            assert ed_new.min() >= 0
+            xy_new = np.zeros((ntop, 3))
+            both = np.concatenate([top.owned, top.ghost])
+            xy_new[top.newid[both]] = xy[both]
             self.asm = capi.Assembler(ctx, None, fe, self.A[-1], order, elem_dof=ed_new, coords=xy_new)
-        self.n_owned, self.n_loc = top.n_owned, nloc
-        ghost_ids = np.arange(top.n_owned, nloc, dtype=np.int32)
-        mk = lambda: ctx.vector(nloc, top.n_owned, 0, ghost_ids)
+        self.n_owned, self.n_loc = top.n_owned, ntop
+        ghost_ids = np.arange(top.n_owned, ntop, dtype=np.int32)
+        mk = lambda: ctx.vector(ntop, top.n_owned, 0, ghost_ids)
         self.RES, self.EPSC, self.SOL = mk(), mk(), mk()
         self.bdc_top = H.bdc_owned[-1].astype(np.int32)
         self.bdc_dev = capi.Index(ctx, self.bdc_top)       # BuildBdcIndex once, device-resident
         self.mg = capi.Multigrid(ctx, nlevels + 1)
-        self.mg.set_level(0, self.A_rep, None, None, 0, omega, 1, 0)
-        self.mg.set_level(1, self.A[0], self.P_rep, self.R_rep, 0, omega, npre, npost)
-        self.mg.set_level_distributed(1, self.halos[0], True)
-        for l in range(1, nlevels):
-            self.mg.set_level(l + 1, self.A[l], self.P[l], self.R[l], 0, omega, npre, npost)
-            self.mg.set_level_distributed(l + 1, self.halos[l], False)
+        self._wire_cycle()
         self.mg.setup()
         self.ndof_owned = top.n_owned
         self.nel_local = els.size
         self.asm_top = self.asm
-        self.prepare_ms, self.prepare_first_s = None, None
+        self.prepare_first_s = None
+        # one numeric re-preparation, timed: what every later MGsolve pays
+        ctx.sync()
+        t0 = time.time()
+        self.prepare()
+        ctx.sync()
+        self.prepare_ms = (time.time() - t0) * 1e3
+
+    def _wire_cycle(self):
+        mg, nl = self.mg, self.nl
+        mg.set_level(0, self.A_rep, None, None, 0, self.omega, 1, 0)
+        mg.set_level(1, self.A[0], self.P_rep, self.R_rep, 0, self.omega, self.npre, self.npost)
+        mg.set_level_distributed(1, self.halos[0], True)
+        for l in range(1, nl):
+            mg.set_level(l + 1, self.A[l], self.P[l], self.R[l], 0, self.omega, self.npre, self.npost)
+            mg.set_level_distributed(l + 1, self.halos[l], False)
+
+    def _replicated_operator(self):
+        """A_rep = sum over ranks of P_rep^T A_0 Pg_local on the stencil pattern, then SetPenalty -- all on the device"""
+        self.T_rep.abc_numeric(self.R_rep, self.A[0], self.Pg_local)
+        self.map_rep.gather_matrix_values(self.A_rep, self.T_rep)
+        self.halos[0].allreduce_mat(self.A_rep)
+        self.bdc_rep.zero_rows(self.A_rep, 1.0)
+
+    def prepare(self):
+        """numeric re-preparation of the whole distributed hierarchy (MGsolve :347-383): assembly of the extended box, Galerkin
+        chain and SetPenalty there, owned rows gathered on the device, replicated operator summed over the ranks, smoother and
+        coarse factorisation -- no host round trip of any operator"""
+        full = self.full
+        full.assemble()
+        full.level_operators()
+        for l in range(self.nl):
+            self.mapA[l].gather_matrix_values(self.A[l], full.A[l])
+        self._replicated_operator()
+        self.mg.setup()
 
     def assemble(self):
         if self.adaptive:
             res_full = self.full.assemble()                            # assembly + P_amr projection on the extended box
-            self.map_vals.gather_matrix_values(self.A[-1], self.full.A[-1])
+            self.mapA[-1].gather_matrix_values(self.A[-1], self.full.A[-1])
             self.map_rows.gather_vector(self.RES, res_full)
             return
         self.asm.assemble(self.A[-1], self.RES, None, self.source_kind, self.params)

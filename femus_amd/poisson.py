@@ -110,8 +110,9 @@ class PoissonMG:
         return res
 
     # ---- MGsolve preparation ------------------------------------------------------------------------------------
-    def prepare(self):
-        ctx = self.ctx
+    def level_operators(self):
+        """the operator part of the preparation: Galerkin chain KK[l-1] = PP[l]^T KK[l] PP[l] from the un-penalised matrices
+        (symbolic once, numeric on every later call), then SetPenalty on every level"""
         top = self.nlevels - 1
         if self.coarse == "galerkin":
             for l in range(top, 0, -1):            # PtAP chain from the un-penalised operators
@@ -124,6 +125,10 @@ class PoissonMG:
                 self.assemble(l)
         for l in range(self.nlevels):              # MGSetLevel: SetPenalty
             self.bdc_dev[l].zero_rows(self.A[l], 1.0)
+
+    def prepare(self):
+        ctx = self.ctx
+        self.level_operators()
         if self.mg is None:
             self.mg = capi.Multigrid(ctx, self.nlevels)
         for l in range(self.nlevels):
@@ -134,11 +139,7 @@ class PoissonMG:
 
     def prepare_operators_only(self):
         """Galerkin chain + SetPenalty without building the cycle (used by the domain-decomposition setup)"""
-        top = self.nlevels - 1
-        for l in range(top, 0, -1):
-            self.A[l - 1] = capi.Mat.ptap(self.P[l], self.A[l])
-        for l in range(self.nlevels):
-            self.A[l].mat_zero_rows(self.bdc[l], 1.0)
+        self.level_operators()
 
     def destroy_device_objects(self):
         for a in self.asm:

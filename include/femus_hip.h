@@ -122,6 +122,19 @@ int fh_vec_set_index(fh_vec_t v, fh_index_t idx, double value);   /* v[idx] = va
  * assembled and projected on its extended box (adaptive levels on several ranks) without host traffic. */
 int fh_mat_gather_values(fh_mat_t dst, fh_mat_t src, fh_index_t map);
 int fh_vec_gather(fh_vec_t dst, fh_vec_t src, fh_index_t map);
+/* owned-row operators of a domain-decomposed level cut out of the operator of the rank's extended box on the device (the MPIAIJ
+ * row ownership of PetscMatrix::init, PetscMatrix.cpp:162-203, with the ghost lists of LinearEquation.cpp:239-280):
+ *   fh_mat_col_mask   mask[c] |= 1 for every column the listed rows touch (their halo)
+ *   fh_mat_row_mask   rowmask[r] |= 1 for every row with an entry in a masked column
+ *   fh_mat_restrict   dst = listed rows of src, columns renumbered by newcol[] (< 0: dropped, must hold zeros), values gathered;
+ *                     *map feeds fh_mat_gather_values(dst, src, map) at every re-preparation
+ *   fh_mat_restrict_check   largest |value| among the dropped entries of those rows (device reduction)
+ *   fh_mat_value_map  map of an EXISTING dst pattern into src: entry (r, c) <- (src_row[r], src_col[c]) or -1 */
+int fh_mat_col_mask(fh_mat_t A, int nrows, const int* rows, unsigned char* mask /* [n] */);
+int fh_mat_row_mask(fh_mat_t A, const unsigned char* colmask /* [n] */, unsigned char* rowmask /* [m] */);
+int fh_mat_restrict(fh_mat_t src, int nrows, const int* rows, const int* newcol /* [src n] */, int ncols_new, fh_mat_t* dst, fh_index_t* map);
+int fh_mat_restrict_check(fh_mat_t src, int nrows, const int* rows, const int* newcol, double* max_dropped);
+int fh_mat_value_map(fh_mat_t dst, fh_mat_t src, const int* src_row /* [dst m] or NULL */, const int* src_col /* [dst n] or NULL */, fh_index_t* map);
 int fh_mat_get_diagonal(fh_mat_t A, fh_vec_t d);                 /* get_diagonal :224 */
 int fh_mat_transpose(fh_mat_t A, fh_mat_t* At);                  /* get_transpose :227 (PetscMatrix.cpp:1031-1070) */
 /* matrix_PtAP(P, A, reuse) :183 (PetscMatrix.cpp:733-751): C = P^T A P.  *C==NULL: symbolic+numeric; else numeric reuse */
@@ -129,6 +142,9 @@ int fh_mat_ptap(fh_mat_t P, fh_mat_t A, fh_mat_t* C);
 /* general sparse product C = A*B (symbolic + numeric); matrix_ABC :186 (PetscMatrix.cpp:833-856), matrix_RightMatMult :189,
  * matrix_LeftMatMult :191 are two / one of these */
 int fh_mat_matmul(fh_mat_t A, fh_mat_t B, fh_mat_t* C);
+/* matrix_ABC(A, B, C, reuse) :186 (PetscMatrix.cpp:833-856): D = A B C.  *D == NULL: symbolic + numeric, the plan stays attached to D;
+ * else numeric only (operands of the same patterns) */
+int fh_mat_abc(fh_mat_t A, fh_mat_t B, fh_mat_t C, fh_mat_t* D);
 int fh_mat_norm(fh_mat_t A, int kind, double* out);              /* kind 1: l1_norm :211, 0: linfty_norm :214 */
 
 /* SpMV family (NumericVector::matrix_mult :283, add_vector(v,A) :281, resid :282, matrix_mult_transpose :284;
@@ -336,6 +352,7 @@ int fh_halo_stats(fh_halo_t halo, int reset, int64_t* n_updates, int64_t* bytes_
 int fh_halo_sizes(fh_halo_t halo, int* nsend, int* nrecv);
 int fh_halo_allreduce_vec(fh_halo_t halo, fh_vec_t v);            /* in-place sum over ranks of the owned part (device) */
 int fh_halo_allreduce_sum(fh_halo_t halo, double* vals, int n);  /* host scalars in/out */
+int fh_halo_allreduce_mat(fh_halo_t halo, fh_mat_t A);            /* in-place sum over ranks of the values of a matrix with one pattern on all ranks */
 int fh_halo_destroy(fh_halo_t halo);
 
 #ifdef __cplusplus

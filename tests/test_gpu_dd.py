@@ -41,6 +41,73 @@ def pb_raw_values(ctx):
 # ---- several ranks on ONE GPU: the whole distributed device path (ghost-element assembly, halo updates inside the cycle,
 # replicated level all-reduce, distributed dot products of the Krylov solver) with the host-staged transport in place of RCCL,
 # which cannot connect two ranks that share a device.  Everything except the ncclSend/ncclRecv calls themselves is exercised.
+def _ops_worker(rank, world, port, nb, nlevels, out):
+    try:
+        import femus_amd as fa
+        from femus_amd import dd as ddm
+        comm = ddm.SocketComm(rank, world, "127.0.0.1", port)
+        ctx = fa.Context(0)
+        dp = ddm.DistributedPoisson(ctx, comm, world, rank, nb=nb, nlevels=nlevels, transport="host")
+        assert dp.prepare_ms is not None and dp.prepare_ms > 0
+        # spoil every operator of the cycle, then re-prepare: the values must all come back from the device-side chain
+        for A in dp.A + [dp.A_rep]:
+            A.zero()
+        dp.prepare()
+        save = {"n_rep": dp.A_rep.m()}
+        Ar = dp.A_rep.to_scipy()
+        save.update(rep_data=Ar.data, rep_indices=Ar.indices, rep_indptr=Ar.indptr)
+        for l, pl in enumerate(dp.H.plans):
+            A = dp.A[l].to_scipy()
+            save.update({"rows%d" % l: pl.gid[pl.owned], "cols%d" % l: pl.gid[np.concatenate([pl.owned, pl.ghost])],
+                         "data%d" % l: A.data, "indices%d" % l: A.indices, "indptr%d" % l: A.indptr})
+        dp.assemble(); dp.set_penalty_top(); dp.zero_boundary_residuals()
+        dp.vcycle()
+        save["x"] = dp.EPSC.to_numpy()[:dp.n_owned].copy()
+        np.savez(out % rank, **save)
+        comm.barrier()
+        comm.close()
+    except BaseException:
+        _record_worker_failure("ops", rank, world)
+        raise
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_distributed_repreparation_gives_the_serial_galerkin_operators(tmp_path, world):
+    """DistributedPoisson.prepare(): extended-box assembly + Galerkin chain + SetPenalty, owned rows gathered on the device, the
+    replicated operator summed over the ranks -- every level operator equals the rows of the serial oracle chain (1e-12), as the
+    reference's distributed MatPtAP would give them (LinearImplicitSystem.cpp:347-370, PetscMatrix.cpp:733-751)"""
+    import scipy.sparse as sp
+    import torch.multiprocessing as mp
+    from oracle import femus_oracle as fo
+    nb, nlevels = 2, 3
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_ops_worker, args=(world, _free_port(), nb, nlevels, out), nprocs=world, join=True)
+    part = dd.BoxPartition(world, 0)
+    p = part.p
+    ONE = lambda xg: np.ones(xg.shape[:2])
+    H = fo.build_poisson_hierarchy(p[0] * nb // 2, p[1] * nb // 2, p[2] * nb // 2, nlevels + 1, "biquadratic", ONE,
+                                   hi=tuple(float(v) for v in p))
+    ref_cycle = fo.vcycle(H, nlevels, H.b)
+    for r in range(world):
+        d = np.load(out % r)
+        Arep = sp.csr_matrix((d["rep_data"], d["rep_indices"], d["rep_indptr"]), shape=(int(d["n_rep"]),) * 2)
+        assert abs(Arep - H.A[0]).max() <= 1e-12 * abs(H.A[0]).max()                       # replicated level: same on every rank
+        for l in range(nlevels):
+            gid_ser, _ = dd.node_keys(H.meshes[l + 1].coords, l, nb, part)
+            srt = np.argsort(gid_ser)
+            rows = srt[np.searchsorted(gid_ser[srt], d["rows%d" % l])]
+            cols = srt[np.searchsorted(gid_ser[srt], d["cols%d" % l])]
+            A = sp.csr_matrix((d["data%d" % l], d["indices%d" % l], d["indptr%d" % l]), shape=(rows.size, cols.size))
+            ref = H.A[l + 1].tocsr()[rows][:, cols]
+            assert abs(A - ref).max() <= 1e-12 * abs(ref).max(), (r, l)
+            # nothing of an owned row lies outside the [owned | ghost] columns
+            assert abs(H.A[l + 1].tocsr()[rows]).sum() == pytest.approx(abs(ref).sum(), rel=1e-14)
+        gid_top, _ = dd.node_keys(H.meshes[-1].coords, nlevels - 1, nb, part)
+        srt = np.argsort(gid_top)
+        pos = srt[np.searchsorted(gid_top[srt], d["rows%d" % (nlevels - 1)])]
+        assert np.linalg.norm(d["x"] - ref_cycle[pos]) <= 1e-10 * np.linalg.norm(ref_cycle)
+
+
 def _free_port():
     import socket
     s = socket.socket()
