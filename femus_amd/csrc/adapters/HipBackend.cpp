@@ -1,5 +1,6 @@
 #include "HipBackend.hpp"
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -22,31 +23,6 @@ fh_ctx_t hip_context() {
   return ctx;
 }
 
-// ---- factories (NumericVector.cpp:35-56, SparseMatrix.cpp:42-63, LinearEquationSolver.cpp:40-74) ----
-std::unique_ptr<NumericVector> NumericVector::build(const SolverPackage solver_package) {
-  if (solver_package != HIP_SOLVERS) {
-    std::cout << "SolverPackage solver_package:  Something is wrong here" << std::endl;
-    abort();
-  }
-  return std::unique_ptr<NumericVector>(new HipVector());
-}
-std::unique_ptr<SparseMatrix> SparseMatrix::build(const SolverPackage solver_package) {
-  if (solver_package != HIP_SOLVERS) {
-    std::cout << "SolverPackage solver_package:  Something is wrong here" << std::endl;
-    abort();
-  }
-  return std::unique_ptr<SparseMatrix>(new HipMatrix());
-}
-std::unique_ptr<LinearEquationSolver> LinearEquationSolver::build(const unsigned& igrid, const SolverPackage solver_package,
-                                                                  const LinearEquationSolverType smoother_type) {
-  if (solver_package == HIP_SOLVERS && smoother_type == FEMuS_ASM) return std::unique_ptr<LinearEquationSolver>(new LinearEquationSolverHipAsm(igrid));
-  if (solver_package != HIP_SOLVERS) {
-    std::cout << "SolverPackage solver_package:  Something is wrong here" << std::endl;
-    abort();
-  }
-  return std::unique_ptr<LinearEquationSolver>(new LinearEquationSolverHip(igrid));
-}
-
 static const HipVector& hv(const NumericVector& v) { return static_cast<const HipVector&>(v); }   // one backend per process,
 static const HipMatrix& hm(const SparseMatrix& A) { return static_cast<const HipMatrix&>(A); }     // as PetscMatrix.cpp:735-739
 
@@ -54,6 +30,7 @@ static const HipMatrix& hm(const SparseMatrix& A) { return static_cast<const Hip
 void HipVector::clear() {
   if (_v) fh_vec_destroy(_v);
   _v = nullptr;
+  _halo = nullptr;
   _is_initialized = _is_closed = false;
 }
 std::unique_ptr<NumericVector> HipVector::clone() const {
@@ -62,16 +39,18 @@ std::unique_ptr<NumericVector> HipVector::clone() const {
   c->operator=(static_cast<const NumericVector&>(*this));
   return std::unique_ptr<NumericVector>(c);
 }
-void HipVector::init(const int N, const int n_local, const bool, const ParallelType) {
+void HipVector::init(const int N, const int n_local, const bool, const ParallelType ptype) {
   clear();
+  _type = ptype;
   hip_check(fh_vec_create(hip_context(), N, n_local, 0, nullptr, 0, &_v), "HipVector::init");
   _n_global = N;
   _n_local = n_local;
   _first = 0;
   _is_initialized = true;
 }
-void HipVector::init(const int N, const int n_local, const std::vector<int>& ghost, const bool, const ParallelType) {
+void HipVector::init(const int N, const int n_local, const std::vector<int>& ghost, const bool, const ParallelType ptype) {
   clear();
+  _type = ptype;
   hip_check(fh_vec_create(hip_context(), N, n_local, 0, ghost.data(), (int)ghost.size(), &_v), "HipVector::init(ghosted)");
   _n_global = N;
   _n_local = n_local;
@@ -82,7 +61,65 @@ void HipVector::init(const NumericVector& other, const bool) {
   clear();
   hip_check(fh_vec_duplicate(hv(other).handle(), &_v), "HipVector::init(other)");
   fh_vec_size(_v, &_n_global, &_n_local, &_first, nullptr);
+  _type = hv(other).type();
+  _halo = hv(other).halo();          // same layout, same ghosts: same plan (init(other) clones the layout incl. ghosts, PetscVector.hpp:572-592)
   _is_initialized = true;
+}
+void HipVector::not_served(const char* what) {
+  std::cout << "HipVector::" << what << " is not served by the HIP backend" << std::endl;
+  abort();
+}
+void HipVector::close() {
+  if (_halo && _v) hip_check(fh_halo_update(_halo, _v), "HipVector::close (ghost refresh)");   // VecGhostUpdateBegin/End, PetscVector.hpp:604-610
+  _is_closed = true;
+}
+double HipVector::all_sum(double local) const {      // VecDot / VecNorm over the ranks (Parallel.hpp:351-377)
+  if (_halo) hip_check(fh_halo_allreduce_sum(_halo, &local, 1), "HipVector: all-reduce");
+  return local;
+}
+void HipVector::insert(const NumericVector& V, const std::vector<int>& dof) {
+  std::vector<double> v;
+  V.localize(v);
+  if (v.size() != dof.size()) { std::cout << "HipVector::insert: size mismatch" << std::endl; abort(); }
+  insert_vector_blocked(v, dof);
+}
+void HipVector::add_vector(const NumericVector& V, const std::vector<int>& dof) {
+  std::vector<double> v;
+  V.localize(v);
+  if (v.size() != dof.size()) { std::cout << "HipVector::add_vector: size mismatch" << std::endl; abort(); }
+  add_vector_blocked(v, dof);
+}
+void HipVector::swap(NumericVector& other) {
+  HipVector& o = static_cast<HipVector&>(other);
+  NumericVector::swap(other);
+  std::swap(_v, o._v);
+  std::swap(_halo, o._halo);
+  std::swap(_n_global, o._n_global);
+  std::swap(_n_local, o._n_local);
+  std::swap(_first, o._first);
+}
+void HipVector::localize(NumericVector& v_local) const {     // PetscVector.cpp: copy of the whole vector into v_local (one rank: the owned part)
+  static_cast<HipVector&>(v_local) = static_cast<const NumericVector&>(*this);
+}
+void HipVector::localize(NumericVector& v_local, const std::vector<int>& send_list) const {
+  std::vector<double> vals;
+  get(send_list, vals);
+  v_local.insert(vals, send_list);
+  v_local.close();
+}
+void HipVector::localize(const int first_local_idx, const int last_local_idx, const std::vector<int>&) {
+  if (first_local_idx != _first || last_local_idx + 1 != _first + _n_local) not_served("localize(first, last, send_list) with a new layout");
+  close();
+}
+void HipVector::localize_to_one(std::vector<double>& v_local, const int) const { localize_to_all(v_local); }
+void HipVector::localize_to_all(std::vector<double>& v_local) const {
+  // every rank gets the whole vector (PetscVector.cpp: VecScatterCreateToAll): owned part here, summed into place over the ranks
+  std::vector<double> own;
+  localize(own);
+  v_local.assign(_n_global, 0.);
+  std::copy(own.begin(), own.end(), v_local.begin() + _first);
+  if (_halo && _n_global != _n_local)
+    for (int k = 0; k < _n_global; k += 256) hip_check(fh_halo_allreduce_sum(_halo, v_local.data() + k, std::min(256, _n_global - k)), "localize_to_all");
 }
 void HipVector::set(const int i, const double value) { hip_check(fh_vec_set_values(_v, 1, &i, &value), "HipVector::set"); _is_closed = false; }
 void HipVector::add(const int i, const double value) { hip_check(fh_vec_add_values(_v, 1, &i, &value), "HipVector::add"); _is_closed = false; }
@@ -96,9 +133,9 @@ NumericVector& HipVector::operator=(const std::vector<double>& v) {
 }
 double HipVector::min() const { double r; hip_check(fh_vec_reduce(_v, 1, &r), "min"); return r; }
 double HipVector::max() const { double r; hip_check(fh_vec_reduce(_v, 2, &r), "max"); return r; }
-double HipVector::sum() const { double r; hip_check(fh_vec_reduce(_v, 0, &r), "sum"); return r; }
-double HipVector::l1_norm() const { double r; hip_check(fh_vec_norm(_v, 1, &r), "l1_norm"); return r; }
-double HipVector::l2_norm() const { double r; hip_check(fh_vec_norm(_v, 2, &r), "l2_norm"); return r; }
+double HipVector::sum() const { double r; hip_check(fh_vec_reduce(_v, 0, &r), "sum"); return all_sum(r); }
+double HipVector::l1_norm() const { double r; hip_check(fh_vec_norm(_v, 1, &r), "l1_norm"); return all_sum(r); }
+double HipVector::l2_norm() const { double r; hip_check(fh_vec_norm(_v, 2, &r), "l2_norm"); return _halo ? sqrt(all_sum(r * r)) : r; }
 double HipVector::linfty_norm() const { double r; hip_check(fh_vec_norm(_v, 0, &r), "linfty_norm"); return r; }
 double HipVector::operator()(const int i) const { double r; hip_check(fh_vec_get_values(_v, 1, &i, &r), "operator()"); return r; }
 void HipVector::get(const std::vector<int>& index, std::vector<double>& values) const {
@@ -119,21 +156,23 @@ void HipVector::insert_vector_blocked(const std::vector<double>& v, const std::v
   hip_check(fh_vec_set_values(_v, (int)dof.size(), dof.data(), v.data()), "insert_vector_blocked");
   _is_closed = false;
 }
+// the operand's exchange plan (if any) refreshes its ghosts inside the product, overlapped with the rows that need none: MatMult on
+// an MPIAIJ matrix (PetscVector.cpp:182-247)
 void HipVector::add_vector(const NumericVector& v, const SparseMatrix& A) {
-  hip_check(fh_spmv(hm(A).handle(), hv(v).handle(), _v, 1, nullptr, nullptr, 0.), "add_vector(v,A)");
+  hip_check(fh_spmv_ghosted(hm(A).handle(), hv(v).halo(), hv(v).handle(), _v, 1, nullptr, nullptr, 0.), "add_vector(v,A)");
 }
 void HipVector::resid(const NumericVector& rhs, const NumericVector& v, const SparseMatrix& A) {
-  hip_check(fh_spmv(hm(A).handle(), hv(v).handle(), _v, 2, hv(rhs).handle(), nullptr, 0.), "resid");
+  hip_check(fh_spmv_ghosted(hm(A).handle(), hv(v).halo(), hv(v).handle(), _v, 2, hv(rhs).handle(), nullptr, 0.), "resid");
 }
 void HipVector::matrix_mult(const NumericVector& v, const SparseMatrix& A) {
-  hip_check(fh_spmv(hm(A).handle(), hv(v).handle(), _v, 0, nullptr, nullptr, 0.), "matrix_mult");
+  hip_check(fh_spmv_ghosted(hm(A).handle(), hv(v).halo(), hv(v).handle(), _v, 0, nullptr, nullptr, 0.), "matrix_mult");
 }
 void HipVector::matrix_mult_transpose(const NumericVector& v, const SparseMatrix& A) {
   hip_check(fh_spmv_transpose(hm(A).handle(), hv(v).handle(), _v), "matrix_mult_transpose");
 }
 void HipVector::scale(const double f) { hip_check(fh_vec_scale(_v, f), "scale"); }
 void HipVector::abs() { hip_check(fh_vec_abs(_v), "abs"); }
-double HipVector::dot(const NumericVector& o) const { double r; hip_check(fh_vec_dot(_v, hv(o).handle(), &r), "dot"); return r; }
+double HipVector::dot(const NumericVector& o) const { double r; hip_check(fh_vec_dot(_v, hv(o).handle(), &r), "dot"); return all_sum(r); }
 void HipVector::localize(std::vector<double>& out) const {
   out.resize(_n_local);
   hip_check(fh_vec_download(_v, out.data()), "localize");
@@ -154,6 +193,138 @@ void HipMatrix::init(const int m, const int n, const int, const int, const std::
   _m = m;
   _n = n;
   _stage.assign(m, std::map<int, double>());   // the nnz counts are upper bounds only; the pattern grows until close()
+}
+void HipMatrix::not_served(const char* what) {
+  std::cout << "HipMatrix::" << what << " is not served by the HIP backend" << std::endl;
+  abort();
+}
+void HipMatrix::to_host(std::vector<int>& rp, std::vector<int>& col, std::vector<double>& val) const {
+  close();
+  int m = 0, n = 0, nnz = 0;
+  fh_mat_size(_A, &m, &n, &nnz);
+  rp.resize(m + 1);
+  col.resize(nnz);
+  val.resize(nnz);
+  hip_check(fh_mat_get_pattern(_A, rp.data(), col.data()), "HipMatrix: pattern");
+  hip_check(fh_mat_get_values_csr(_A, val.data()), "HipMatrix: values");
+}
+// block matrix of nr x nc matrices (PetscMatrix.cpp: MatCreateNest + conversion): blocks may be NULL; merged into one CSR
+void HipMatrix::init(const int nr, const int nc, const std::vector<SparseMatrix*>& P) {
+  if ((int)P.size() != nr * nc) { std::cout << "HipMatrix::init(nr, nc, blocks): wrong number of blocks" << std::endl; abort(); }
+  std::vector<int> roff(nr + 1, 0), coff(nc + 1, 0);
+  for (int i = 0; i < nr; i++)
+    for (int j = 0; j < nc; j++)
+      if (P[i * nc + j]) {
+        roff[i + 1] = P[i * nc + j]->m();
+        coff[j + 1] = P[i * nc + j]->n();
+      }
+  for (int i = 0; i < nr; i++) roff[i + 1] += roff[i];
+  for (int j = 0; j < nc; j++) coff[j + 1] += coff[j];
+  std::vector<int> rp(roff[nr] + 1, 0), col;
+  std::vector<double> val;
+  std::vector<std::vector<int>> brp(nr * nc), bcol(nr * nc);
+  std::vector<std::vector<double>> bval(nr * nc);
+  for (int b = 0; b < nr * nc; b++)
+    if (P[b]) static_cast<const HipMatrix*>(P[b])->to_host(brp[b], bcol[b], bval[b]);
+  for (int i = 0; i < nr; i++)
+    for (int r = 0; r < roff[i + 1] - roff[i]; r++) {
+      for (int j = 0; j < nc; j++) {
+        const int b = i * nc + j;
+        if (!P[b]) continue;
+        for (int k = brp[b][r]; k < brp[b][r + 1]; k++) {
+          col.push_back(coff[j] + bcol[b][k]);
+          val.push_back(bval[b][k]);
+        }
+      }
+      rp[roff[i] + r + 1] = (int)col.size();
+    }
+  clear();
+  _m = roff[nr];
+  _n = coff[nc];
+  hip_check(fh_mat_create_csr(hip_context(), _m, _n, rp.data(), col.data(), val.data(), &_A), "HipMatrix::init(blocks)");
+  _closed = true;
+}
+void HipMatrix::RemoveZeroEntries(double& tolerance) {       // PetscMatrix.cpp: entries with |value| <= tolerance leave the pattern
+  std::vector<int> rp, col, nrp, ncol;
+  std::vector<double> val, nval;
+  to_host(rp, col, val);
+  nrp.assign(_m + 1, 0);
+  for (int i = 0; i < _m; i++) {
+    for (int k = rp[i]; k < rp[i + 1]; k++)
+      if (fabs(val[k]) > tolerance) {
+        ncol.push_back(col[k]);
+        nval.push_back(val[k]);
+      }
+    nrp[i + 1] = (int)ncol.size();
+  }
+  const int m = _m, n = _n;
+  clear();
+  _m = m;
+  _n = n;
+  hip_check(fh_mat_create_csr(hip_context(), m, n, nrp.data(), ncol.data(), nval.data(), &_A), "RemoveZeroEntries");
+  _closed = true;
+}
+// this += a X (MatAXPY, PetscMatrix.cpp): the union pattern on the host, values summed
+void HipMatrix::matrix_add(const double a, SparseMatrix& X, const char[]) {
+  std::vector<int> rp, col, xrp, xcol, nrp, ncol;
+  std::vector<double> val, xval, nval;
+  to_host(rp, col, val);
+  static_cast<HipMatrix&>(X).to_host(xrp, xcol, xval);
+  if (X.m() != _m || X.n() != _n) { std::cout << "HipMatrix::matrix_add: shapes differ" << std::endl; abort(); }
+  nrp.assign(_m + 1, 0);
+  for (int i = 0; i < _m; i++) {
+    int p = rp[i], q = xrp[i];
+    while (p < rp[i + 1] || q < xrp[i + 1]) {
+      const int cp = p < rp[i + 1] ? col[p] : _n, cq = q < xrp[i + 1] ? xcol[q] : _n;
+      const int c = std::min(cp, cq);
+      double v = 0.;
+      if (cp == c) v += val[p++];
+      if (cq == c) v += a * xval[q++];
+      ncol.push_back(c);
+      nval.push_back(v);
+    }
+    nrp[i + 1] = (int)ncol.size();
+  }
+  const int m = _m, n = _n;
+  clear();
+  _m = m;
+  _n = n;
+  hip_check(fh_mat_create_csr(hip_context(), m, n, nrp.data(), ncol.data(), nval.data(), &_A), "matrix_add");
+  _closed = true;
+}
+void HipMatrix::matrix_set_off_diagonal_values_blocked(const std::vector<int>& rows, const std::vector<int>& cols, const double& value) {
+  std::vector<double> v(rows.size() * cols.size(), value);
+  matrix_set_off_diagonal_values_blocked(rows, cols, v);
+}
+void HipMatrix::matrix_set_off_diagonal_values_blocked(const std::vector<int>& rows, const std::vector<int>& cols, const std::vector<double>& value) {
+  // PetscMatrix.cpp: MatSetValuesBlocked(..., INSERT_VALUES) on the block rows x cols
+  close();
+  for (size_t i = 0; i < rows.size(); i++) {
+    std::vector<double> v(value.begin() + i * cols.size(), value.begin() + (i + 1) * cols.size());
+    hip_check(fh_mat_insert_row(_A, rows[i], (int)cols.size(), cols.data(), v.data()), "matrix_set_off_diagonal_values_blocked");
+  }
+}
+void HipMatrix::matrix_set_diagonal_values(NumericVector& D) {
+  std::vector<double> d;
+  D.localize(d);
+  std::vector<int> idx(d.size());
+  for (size_t i = 0; i < d.size(); i++) idx[i] = (int)i;
+  matrix_set_diagonal_values(idx, d);
+}
+void HipMatrix::matrix_set_diagonal_values(const std::vector<int>& index, const double& value) {
+  std::vector<double> v(index.size(), value);
+  matrix_set_diagonal_values(index, v);
+}
+void HipMatrix::matrix_set_diagonal_values(const std::vector<int>& index, const std::vector<double>& value) {
+  close();
+  for (size_t k = 0; k < index.size(); k++) hip_check(fh_mat_insert_row(_A, index[k], 1, &index[k], &value[k]), "matrix_set_diagonal_values");
+}
+void HipMatrix::print_personal(std::ostream& os) const {
+  std::vector<int> rp, col;
+  std::vector<double> val;
+  to_host(rp, col, val);
+  for (int i = 0; i < _m; i++)
+    for (int k = rp[i]; k < rp[i + 1]; k++) os << i << " " << col[k] << " " << val[k] << "\n";
 }
 void HipMatrix::init_pattern(const int m, const int n, const std::vector<int>& rowptr, const std::vector<int>& col) {
   clear();
@@ -239,12 +410,13 @@ void HipMatrix::matrix_PtAP(const SparseMatrix& P, const SparseMatrix& A, const 
   fh_mat_size(_A, &_m, &_n, nullptr);
   _closed = true;
 }
-void HipMatrix::matrix_ABC(const SparseMatrix& A, const SparseMatrix& B, const SparseMatrix& C, const bool&) {
-  fh_mat_t ab = nullptr, abc = nullptr;
-  hip_check(fh_mat_matmul(hm(A).handle(), hm(B).handle(), &ab), "matrix_ABC");
-  hip_check(fh_mat_matmul(ab, hm(C).handle(), &abc), "matrix_ABC");
-  fh_mat_destroy(ab);
-  adopt(abc);
+void HipMatrix::matrix_ABC(const SparseMatrix& A, const SparseMatrix& B, const SparseMatrix& C, const bool& reuse) {
+  fh_mat_t out = (reuse && _A) ? _A : nullptr;       // MAT_REUSE_MATRIX: numeric only (PetscMatrix.cpp:833-856)
+  if (!out) clear();
+  hip_check(fh_mat_abc(hm(A).handle(), hm(B).handle(), hm(C).handle(), &out), "matrix_ABC");
+  _A = out;
+  fh_mat_size(_A, &_m, &_n, nullptr);
+  _closed = true;
 }
 void HipMatrix::matrix_RightMatMult(const SparseMatrix& A) {
   fh_mat_t out = nullptr;
@@ -276,12 +448,9 @@ void HipMatrix::mat_zero_rows(const std::vector<int>& index, const double& diag)
 
 // =============================== LinearEquationSolverHip ===============================
 LinearEquationSolverHip::~LinearEquationSolverHip() {
-  MGClear();
-  delete _KK;
-  delete _RES;
-  delete _RESC;
-  delete _EPS;
-  delete _EPSC;
+  if (_mg) fh_mg_destroy(_mg);
+  if (_one) fh_mg_destroy(_one);
+  // _KK, _RES, ... belong to LinearEquation (DeletePde, LinearEquation.cpp:378-405)
 }
 void LinearEquationSolverHip::SetTolerances(const double& rtol, const double& atol, const double& divtol, const unsigned& maxits,
                                             const unsigned& restart) {
@@ -296,7 +465,8 @@ void LinearEquationSolverHip::MGInit(const MgSmootherType& mg_smoother_type, con
     std::cout << "Wrong mg_type for the HIP backend (only MULTIPLICATIVE is implemented)" << std::endl;
     abort();
   }
-  MGClear();
+  if (_mg) fh_mg_destroy(_mg);
+  _mg = nullptr;
   _levelMax = levelMax;
   _mgSolverType = mgSolverType;
   hip_check(fh_mg_create(hip_context(), (int)levelMax, &_mg), "MGInit");
@@ -310,12 +480,13 @@ void LinearEquationSolverHip::ZerosBoundaryResiduals() {
   std::vector<double> zeros(_bdcIndex.size(), 0.);
   _RES->insert_vector_blocked(zeros, _bdcIndex);
 }
-void LinearEquationSolverHip::MGSetLevel(LinearEquationSolver* LinSolver, const unsigned&, const std::vector<unsigned>&, SparseMatrix* PP,
-                                         SparseMatrix* RR, const unsigned& npre, const unsigned& npost) {
+void LinearEquationSolverHip::MGSetLevel(LinearEquationSolver* LinSolver, const unsigned&, const std::vector<unsigned>& variable_to_be_solved,
+                                         SparseMatrix* PP, SparseMatrix* RR, const unsigned& npre, const unsigned& npost) {
   LinearEquationSolverHip* top = static_cast<LinearEquationSolverHip*>(LinSolver);
+  if (!_bdcIndexIsInitialized) BuildBdcIndex(variable_to_be_solved);      // LinearEquationSolverPetsc.cpp:223
   SetPenalty();
-  if (_level != 0 && _solver_type == PREONLY) {   // LinearEquationSolverPetsc.cpp:245-248
-    _solver_type = RICHARDSON;
+  if (_level != 0 && _levelSolverType == PREONLY) {   // LinearEquationSolverPetsc.cpp:245-248
+    _levelSolverType = RICHARDSON;
     _richardsonScaleFactor = 1.;
   }
   const int smoother = smoother_id();
@@ -357,6 +528,28 @@ void LinearEquationSolverHip::MGSolve(const bool) {
 void LinearEquationSolverHip::MGClear() {
   if (_mg) fh_mg_destroy(_mg);
   _mg = nullptr;
+}
+void LinearEquationSolverHip::Solve(const std::vector<unsigned>& variable_to_be_solved, const bool& ksp_clean) {
+  if (!_bdcIndexIsInitialized) BuildBdcIndex(variable_to_be_solved);
+  fh_mat_t KK = static_cast<HipMatrix*>(_KK)->handle();
+  if (ksp_clean || !_one) {       // this->Clear(); SetPenalty(); this->Init(KK, KK)  (LinearEquationSolverPetsc.cpp:101-107)
+    if (_one) fh_mg_destroy(_one);
+    _one = nullptr;
+    SetPenalty();
+    KK = static_cast<HipMatrix*>(_KK)->handle();
+    // a one-level hierarchy: the "cycle" is the exact solve of this level (what the reference reaches with its default
+    // GMRES + ILU/MLU level solver at convergence); levels beyond the dense limit belong to the multigrid path
+    hip_check(fh_mg_create(hip_context(), 1, &_one), "Solve");
+    hip_check(fh_mg_set_level(_one, 0, KK, nullptr, nullptr, FH_SMOOTH_JACOBI, 1.0, 1, 0), "Solve");
+    hip_check(fh_mg_setup(_one), "Solve: factorisation of the level operator");
+  }
+  ZerosBoundaryResiduals();
+  hip_check(fh_mg_solve(_one, static_cast<HipVector*>(_RES)->handle(), static_cast<HipVector*>(_EPSC)->handle(), FH_OUTER_PREONLY, _rtol, _abstol,
+                        _dtol, _maxits, _restart, &_its, &_rnorm),
+            "Solve");
+  *_EPS += *_EPSC;                     // :123-126
+  _RESC->matrix_mult(*_EPSC, *_KK);
+  *_RES -= *_RESC;
 }
 
 }  // namespace femus

@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <iostream>
 #include <vector>
-#include "../../femus_amd/csrc/adapters/HipBackend.hpp"
+#include "HipBackend.hpp"
 
 using namespace femus;
 static int fails = 0;
@@ -127,6 +127,108 @@ int main() {
   CHECK(B->n() == 2 && (*B)(1, 0) == 1. && (*B)(1, 1) == -1.);
   B->matrix_LeftMatMult(*Pt);   // B <- P^T B (2x2)
   CHECK(B->m() == 2 && (*B)(0, 0) == 2.);
+
+  // ---- the rest of the reference's pure virtuals (NumericVector.hpp:160-169, :275-279, :301-323; SparseMatrix.hpp:81, :113, :174-207)
+  {
+    NumericVector *a = NumericVector::build().release(), *b = NumericVector::build().release();
+    a->init(5, 5, false, SERIAL);
+    b->init(5, 5, false, SERIAL);
+    *a = std::vector<double>{1, 2, 3, 4, 5};
+    b->zero();
+    b->insert(std::vector<double>{7., 8.}, std::vector<int>{4, 0});
+    CHECK((*b)(4) == 7. && (*b)(0) == 8. && (*b)(2) == 0.);
+    b->add_vector(std::vector<double>{1., 1.}, std::vector<int>{4, 1});
+    CHECK((*b)(4) == 8. && (*b)(1) == 1.);
+    b->add_vector(*a, std::vector<int>{0, 1, 2, 3, 4});
+    CHECK((*b)(0) == 9. && (*b)(3) == 4.);
+    b->insert(*a, std::vector<int>{4, 3, 2, 1, 0});
+    CHECK((*b)(4) == 1. && (*b)(0) == 5.);
+    a->swap(*b);
+    CHECK((*a)(0) == 5. && (*b)(0) == 1.);
+    b->localize(*a);
+    CHECK((*a)(4) == 5.);
+    std::vector<double> all;
+    a->localize_to_all(all);
+    CHECK(all.size() == 5 && all[2] == 3.);
+    a->localize_to_one(all, 0);
+    CHECK(all[1] == 2.);
+    *b = 0.;
+    a->localize(*b, std::vector<int>{1, 3});
+    CHECK((*b)(1) == 2. && (*b)(3) == 4. && (*b)(0) == 0.);
+    *a *= 2.;
+    *a /= 4.;
+    CHECK((*a)(3) == 2.);
+    a->close();
+    CHECK(a->closed() && a->type() == SERIAL);
+    delete a;
+    delete b;
+  }
+  {
+    HipMatrix X, Y, Z;
+    X.init_pattern(2, 2, std::vector<int>{0, 1, 3}, std::vector<int>{0, 0, 1});
+    X.set(0, 0, 1.); X.set(1, 0, 2.); X.set(1, 1, 3.);
+    Y.init_pattern(2, 2, std::vector<int>{0, 2, 3}, std::vector<int>{0, 1, 1});
+    Y.set(0, 0, 10.); Y.set(0, 1, 20.); Y.set(1, 1, 30.);
+    X.matrix_add(0.5, Y, "different_nonzero_pattern");          // union pattern
+    CHECK(X(0, 0) == 6. && X(0, 1) == 10. && X(1, 0) == 2. && X(1, 1) == 18. && X.MatGetRowM(0) == 2);
+    X.add(1.0, Y);
+    CHECK(X(0, 1) == 30.);
+    X.matrix_set_diagonal_values(std::vector<int>{0, 1}, 0.);
+    CHECK(X(0, 0) == 0. && X(1, 1) == 0. && X(1, 0) == 2.);
+    double tol = 1e-15;
+    X.RemoveZeroEntries(tol);
+    CHECK(X.MatGetRowM(0) == 1 && X.MatGetRowM(1) == 1);
+    X.matrix_set_off_diagonal_values_blocked(std::vector<int>{0}, std::vector<int>{1}, 4.5);
+    CHECK(X(0, 1) == 4.5);
+    std::vector<double> dv;
+    Y.matrix_get_diagonal_values(std::vector<int>{0, 1}, dv);
+    CHECK(dv[0] == 10. && dv[1] == 30.);
+    // 2 x 2 block matrix [[Y, 0], [0, Y]] (SparseMatrix::init(nr, nc, blocks))
+    std::vector<SparseMatrix*> blocks = {&Y, nullptr, nullptr, &Y};
+    Z.init(2, 2, blocks);
+    CHECK(Z.m() == 4 && Z.n() == 4 && Z(2, 3) == 20. && Z(0, 1) == 20. && Z(1, 2) == 0. && Z.row_start() == 0 && Z.row_stop() == 4);
+    // matrix_ABC with reuse: numeric only on the kept plan
+    HipMatrix I2, R;
+    I2.init_pattern(2, 2, std::vector<int>{0, 1, 2}, std::vector<int>{0, 1});
+    I2.set(0, 0, 1.); I2.set(1, 1, 2.);
+    R.matrix_ABC(I2, Y, I2, false);
+    CHECK(R(0, 1) == 40. && R(1, 1) == 120.);
+    Y.set(0, 1, 1.);
+    R.matrix_ABC(I2, Y, I2, true);
+    CHECK(R(0, 1) == 2.);
+  }
+  // ---- LinearEquationSolver::Solve: one-level solve of the level's system with the Dirichlet rows derived from _Bdc -----------
+  {
+    Mesh msh1;
+    for (int t = 0; t < 5; t++) msh1._dofOffset[t] = {0u, 4u};
+    Solution sol1(&msh1);
+    NumericVector* flag = NumericVector::build().release();
+    flag->init(4, 4, false, SERIAL);
+    *flag = std::vector<double>{0., 2., 2., 0.};          // ends are Dirichlet
+    sol1._Bdc.push_back(flag);
+    LinearEquationSolver* ls = LinearEquationSolver::build(0, &sol1, FEMuS_DEFAULT).release();
+    std::vector<unsigned> idx(1, 0u), typ(1, 2u), vars(1, 0u);
+    char nm[] = "u";
+    std::vector<char*> names(1, nm);
+    std::vector<bool> sp;
+    ls->InitPde(idx, typ, names, &sol1._Bdc, 1, sp);
+    CHECK(ls->KKoffset[1][0] == 4u && ls->KKIndex[1] == 4);
+    static_cast<HipMatrix*>(ls->_KK)->init_pattern(4, 4, std::vector<int>{0, 2, 5, 8, 10}, std::vector<int>{0, 1, 0, 1, 2, 1, 2, 3, 2, 3});
+    const int br[10] = {0, 0, 1, 1, 1, 2, 2, 2, 3, 3}, bc[10] = {0, 1, 0, 1, 2, 1, 2, 3, 2, 3};
+    const double bv[10] = {2, -1, -1, 2, -1, -1, 2, -1, -1, 2};
+    for (int k = 0; k < 10; k++) ls->_KK->set(br[k], bc[k], bv[k]);
+    *ls->_RES = std::vector<double>{5., 1., 1., 5.};
+    ls->SetEpsZero();
+    ls->SetTolerances(1e-12, 1e-50, 1e50, 10, 10);
+    ls->Solve(vars, true);
+    // rows 0 and 3 become identity rows with zero residual: 2 x1 - x2 = 1, -x1 + 2 x2 = 1 -> x1 = x2 = 1
+    CHECK(std::fabs((*ls->_EPS)(1) - 1.) < 1e-13 && std::fabs((*ls->_EPS)(2) - 1.) < 1e-13 && (*ls->_EPS)(0) == 0. && (*ls->_EPS)(3) == 0.);
+    CHECK(ls->_RES->linfty_norm() < 1e-13);
+    CHECK(static_cast<LinearEquationSolverHip*>(ls)->bdc_index() == (std::vector<int>{0, 3}));
+    ls->DeletePde();
+    delete ls;
+    delete flag;
+  }
 
   delete v; delete w; delete y; delete A; delete At; delete P; delete B; delete C; delete Pt; delete D;
   std::cout << (fails ? "ADAPTER UNITS FAILED" : "ADAPTER UNITS OK") << std::endl;

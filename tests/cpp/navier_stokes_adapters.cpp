@@ -10,7 +10,7 @@
 #include <iostream>
 #include <map>
 #include <vector>
-#include "../../femus_amd/csrc/adapters/HipBackend.hpp"
+#include "HipBackend.hpp"
 
 using namespace femus;
 
@@ -41,6 +41,12 @@ int main(int argc, char** argv) {
   for (int l = 1; l < nlev; l++) hip_check(fh_mesh_refine(msh[l - 1], &msh[l]), "refine");
 
   std::vector<LinearEquationSolver*> LinSolver(nlev);
+  std::vector<Mesh*> fmesh(nlev);           // FEMuS-owned in a real build: dof offsets of the families, Solution with the _Bdc flag vectors
+  std::vector<Solution*> fsol(nlev);
+  std::vector<unsigned> SolPdeIndex = {0u, 1u, 2u}, SolType = {2u, 2u, 0u};
+  char nU[] = "U", nV[] = "V", nP[] = "P";
+  std::vector<char*> SolName = {nU, nV, nP};
+  std::vector<bool> sparsity;
   std::vector<SparseMatrix*> PP(nlev, nullptr), PPsol(nlev, nullptr);
   std::vector<NumericVector*> Sol(nlev);
   std::vector<fh_ns_assembler_t> as(nlev);
@@ -55,8 +61,24 @@ int main(int argc, char** argv) {
     fh_mesh_get(msh[l], ed.data(), xy.data(), ff.data());
     const int ndof = offs[l][nvars];
     // FEMuS_ASM solver: element blocks around every pressure dof
-    LinearEquationSolverHipAsm* ls = static_cast<LinearEquationSolverHipAsm*>(LinearEquationSolver::build(l, HIP_SOLVERS, FEMuS_ASM).release());
+    fmesh[l] = new Mesh();
+    for (int t = 0; t < 5; t++) fmesh[l]->_dofOffset[t] = {0u, (unsigned)(t == 0 ? own[0] : nnode)};     // one rank
+    fsol[l] = new Solution(fmesh[l]);
+    for (int k = 0; k < nvars; k++) {
+      NumericVector* flag = NumericVector::build().release();
+      const int nk = offs[l][k + 1] - offs[l][k];
+      flag->init(nk, nk, false, SERIAL);
+      *flag = 2.;                                            // free; Dirichlet nodes get 0 below (MultiLevelSolution::GenerateBdc)
+      fsol[l]->_Bdc.push_back(flag);
+    }
+    LinearEquationSolverHipAsm* ls = static_cast<LinearEquationSolverHipAsm*>(LinearEquationSolver::build(l, fsol[l], FEMuS_ASM).release());
     LinSolver[l] = ls;
+    ls->InitPde(SolPdeIndex, SolType, SolName, &fsol[l]->_Bdc, nlev, sparsity);     // _KK, _RES, _RESC, _EPS, _EPSC; KKoffset = offs[l]
+    for (int k = 0; k <= nvars; k++)
+      if ((int)ls->KKoffset[k][0] != offs[l][k]) {
+        std::cout << "KKoffset differs from fh_system_elem_dofs" << std::endl;
+        return 3;
+      }
     ls->SetNumberOfSchurVariables(1);
     ls->SetElementBlockNumber(4);
     {
@@ -66,10 +88,8 @@ int main(int argc, char** argv) {
       hip_check(fh_mesh_vertex_patches(msh[l], nvars, fe, &np, &tot, ptr.data(), dofs.data()), "BuildASMIndex");
       ls->SetAsmBlocks(ptr, dofs);
     }
-    for (NumericVector** v : {&ls->_RES, &ls->_RESC, &ls->_EPS, &ls->_EPSC, &Sol[l]}) {
-      *v = NumericVector::build().release();
-      (*v)->init(ndof, ndof, false, SERIAL);
-    }
+    Sol[l] = NumericVector::build().release();
+    Sol[l]->init(ndof, ndof, false, SERIAL);
     // sparsity from the element couplings of the stacked variables
     std::vector<int> rp(ndof + 1), col;
     hip_check(fh_pattern_from_elements(nel, nd, es.data(), ndof, rp.data(), nullptr), "pattern");
@@ -77,9 +97,7 @@ int main(int argc, char** argv) {
     hip_check(fh_pattern_from_elements(nel, nd, es.data(), ndof, rp.data(), col.data()), "pattern");
     fh_mat_t K;
     hip_check(fh_mat_create_csr(hip_context(), ndof, ndof, rp.data(), col.data(), nullptr, &K), "KK");
-    HipMatrix* hk = new HipMatrix();
-    hk->adopt(K);
-    ls->_KK = hk;
+    static_cast<HipMatrix*>(ls->_KK)->adopt(K);
     hip_check(fh_ns_assembler_create(hip_context(), geom, 3, nel, nloc, ed.data(), nnode, own[0], xy.data(), K, &as[l]), "assembler");
     // GenerateBdc: boundary faces in element order, nodes of the face, boundary function at the node
     std::map<int, double> val;
@@ -104,10 +122,16 @@ int main(int argc, char** argv) {
       bdc[l].push_back(kv.first);
       vals.push_back(kv.second);
     }
-    ls->SetBdcIndex(bdc[l]);
+    for (int k = 0; k < nvars; k++) {                       // the flag vectors: 0 at the Dirichlet nodes of each variable
+      std::vector<int> nodes;
+      for (int row : bdc[l])
+        if (row >= offs[l][k] && row < offs[l][k + 1]) nodes.push_back(row - offs[l][k]);
+      fsol[l]->_Bdc[k]->insert(std::vector<double>(nodes.size(), 0.), nodes);
+      fsol[l]->_Bdc[k]->close();
+    }
     Sol[l]->zero();
     Sol[l]->insert_vector_blocked(vals, bdc[l]);
-    ls->SetSolverType(RICHARDSON);
+    ls->set_solver_type(RICHARDSON);
     ls->SetRichardsonScaleFactor(0.6);
     if (l > 0) {
       for (int copy = 0; copy < 2; copy++) {
@@ -168,7 +192,12 @@ int main(int argc, char** argv) {
   fclose(f);
   for (int l = 0; l < nlev; l++) {
     fh_ns_assembler_destroy(as[l]);
+    LinSolver[l]->MGClear();
+    LinSolver[l]->DeletePde();
     delete LinSolver[l];
+    for (NumericVector* f2 : fsol[l]->_Bdc) delete f2;
+    delete fsol[l];
+    delete fmesh[l];
     delete PP[l];
     delete PPsol[l];
     delete Sol[l];

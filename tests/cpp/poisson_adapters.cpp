@@ -8,7 +8,7 @@
 #include <cstdlib>
 #include <iostream>
 #include <vector>
-#include "../../femus_amd/csrc/adapters/HipBackend.hpp"
+#include "HipBackend.hpp"
 
 using namespace femus;
 
@@ -21,32 +21,48 @@ int main(int argc, char** argv) {
   hip_check(fh_mesh_box(nx, ny, nz, lo, hi, &msh[0]), "mesh");
   for (int l = 1; l < nlev; l++) hip_check(fh_mesh_refine(msh[l - 1], &msh[l]), "refine");
 
-  // ---- LinearImplicitSystem::init: one LinearEquationSolver per level, vectors, prolongators -----------------
-  std::vector<LinearEquationSolver*> LinSolver(nlev);
-  std::vector<SparseMatrix*> PP(nlev, nullptr);
+  // ---- what FEMuS owns in a real build, per level: the mesh's dof offsets, the Solution with its boundary flag vector _Bdc
+  // (2 = free, 0 = Dirichlet: MultiLevelSolution::GenerateBdc, MultiLevelSolution.cpp:725-840) --------------------------------
+  std::vector<Mesh*> fmesh(nlev);
+  std::vector<Solution*> fsol(nlev);
   std::vector<int> ndof(nlev);
   for (int l = 0; l < nlev; l++) {
     int dim, nel, nnode, nloc, own[3], lev;
     fh_mesh_info(msh[l], &dim, &nel, &nnode, &nloc, own, &lev);
     ndof[l] = nnode;
-    LinSolver[l] = LinearEquationSolver::build(l).release();
-    LinearEquationSolver* ls = LinSolver[l];
-    for (NumericVector** v : {&ls->_RES, &ls->_RESC, &ls->_EPS, &ls->_EPSC}) {
-      *v = NumericVector::build().release();
-      (*v)->init(nnode, nnode, false, SERIAL);
-    }
-    ls->_KK = SparseMatrix::build().release();
-    if (l == nlev - 1) {
-      std::vector<int> d_nnz(nnode, 125), o_nnz(nnode, 0);     // GetSparsityPatternSize upper bounds
-      ls->_KK->init(nnode, nnode, nnode, nnode, d_nnz, o_nnz);
-    }
+    fmesh[l] = new Mesh();
+    for (int t = 0; t < 5; t++) fmesh[l]->_dofOffset[t] = {0u, (unsigned)(t == 0 ? own[0] : nnode)};     // one rank
+    fsol[l] = new Solution(fmesh[l]);
+    NumericVector* flag = NumericVector::build().release();
+    flag->init(nnode, nnode, false, SERIAL);
+    *flag = 2.;
     int nb = nnode;
     std::vector<int> bdc(nnode);
     hip_check(fh_mesh_dirichlet_dofs(msh[l], fe, &nb, bdc.data()), "bdc");
     bdc.resize(nb);
-    ls->SetBdcIndex(bdc);
-    ls->SetSolverType(RICHARDSON);
-    ls->SetPreconditionerType(JACOBI_PRECOND);
+    flag->insert(std::vector<double>(nb, 0.), bdc);
+    flag->close();
+    fsol[l]->_Bdc.push_back(flag);
+  }
+
+  // ---- LinearImplicitSystem::init: one LinearEquationSolver per level through the factory, InitPde, prolongators --------------
+  std::vector<LinearEquationSolver*> LinSolver(nlev);
+  std::vector<SparseMatrix*> PP(nlev, nullptr);
+  std::vector<unsigned> SolPdeIndex(1, 0u), SolType(1, (unsigned)fe);
+  char name_u[] = "u";
+  std::vector<char*> SolName(1, name_u);
+  std::vector<bool> sparsity;
+  for (int l = 0; l < nlev; l++) {
+    const int nnode = ndof[l];
+    LinSolver[l] = LinearEquationSolver::build(l, fsol[l], FEMuS_DEFAULT).release();
+    LinearEquationSolver* ls = LinSolver[l];
+    ls->InitPde(SolPdeIndex, SolType, SolName, &fsol[l]->_Bdc, nlev, sparsity);     // creates _KK, _RES, _RESC, _EPS, _EPSC
+    if (l == nlev - 1) {
+      std::vector<int> d_nnz(nnode, 125), o_nnz(nnode, 0);     // GetSparsityPatternSize upper bounds
+      ls->_KK->init(nnode, nnode, nnode, nnode, d_nnz, o_nnz);
+    }
+    ls->set_solver_type(RICHARDSON);
+    ls->set_preconditioner_type(JACOBI_PRECOND);
     ls->SetRichardsonScaleFactor(2. / 3.);
     if (l > 0) {
       fh_mat_t P;
@@ -56,7 +72,6 @@ int main(int argc, char** argv) {
       PP[l] = hp;
     }
   }
-
   // ---- the assembly callback on the finest level: per-element add_*_blocked through the virtual interface ------
   const int top = nlev - 1;
   int dim, nel, nnode, nloc, own[3], lev;
@@ -119,10 +134,25 @@ int main(int argc, char** argv) {
   FILE* f = fopen(argv[5], "wb");
   fwrite(sol.data(), sizeof(double), sol.size(), f);
   fclose(f);
+  // BuildBdcIndex gave the rows of the mesh helper's Dirichlet list
+  {
+    int nb = ndof[top];
+    std::vector<int> bdc(nb);
+    hip_check(fh_mesh_dirichlet_dofs(msh[top], fe, &nb, bdc.data()), "bdc");
+    bdc.resize(nb);
+    if (static_cast<LinearEquationSolverHip*>(LinSolver[top])->bdc_index() != bdc) {
+      std::cout << "BuildBdcIndex: wrong Dirichlet rows" << std::endl;
+      return 3;
+    }
+  }
   LinSolver[top]->MGClear();
   for (int l = 0; l < nlev; l++) {
+    LinSolver[l]->DeletePde();
     delete LinSolver[l];
     delete PP[l];
+    delete fsol[l]->_Bdc[0];
+    delete fsol[l];
+    delete fmesh[l];
     fh_mesh_destroy(msh[l]);
   }
   return 0;

@@ -11,13 +11,16 @@ from oracle import femus_oracle as fo
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ADAPTERS = os.path.join(ROOT, "femus_amd", "csrc", "adapters")
+# the applications include the FEMuS headers by their plain names; here they resolve to the mirrored interface
+INC = ["-I" + os.path.join(ADAPTERS, "mirror"), "-I" + ADAPTERS, "-I" + os.path.join(ROOT, "include")]
 
 
 def build_app(tmp_path):
     lib = os.path.join(ROOT, "femus_amd", "lib")
     exe = str(tmp_path / "poisson_adapters")
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "femus_amd", "csrc", "adapters")], stdout=subprocess.DEVNULL)
-    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "poisson_adapters.cpp"), "-o", exe,
+    subprocess.check_call(["g++", "-O1", "-std=c++17"] + INC + [os.path.join(ROOT, "tests", "cpp", "poisson_adapters.cpp"), "-o", exe,
                            "-L" + lib, "-lfemus_hip_adapters", "-lfemus_hip", "-Wl,-rpath," + lib])
     return exe
 
@@ -40,7 +43,7 @@ def test_adapter_member_units(tmp_path):
     lib = os.path.join(ROOT, "femus_amd", "lib")
     exe = str(tmp_path / "adapter_units")
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "femus_amd", "csrc", "adapters")], stdout=subprocess.DEVNULL)
-    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "adapter_units.cpp"), "-o", exe,
+    subprocess.check_call(["g++", "-O1", "-std=c++17"] + INC + [os.path.join(ROOT, "tests", "cpp", "adapter_units.cpp"), "-o", exe,
                            "-L" + lib, "-lfemus_hip_adapters", "-lfemus_hip", "-Wl,-rpath," + lib])
     out = subprocess.run([exe], text=True, capture_output=True)
     assert "ADAPTER UNITS OK" in out.stdout, out.stdout + out.stderr
@@ -53,7 +56,7 @@ def test_navier_stokes_application_over_the_adapters(tmp_path):
     lib = os.path.join(ROOT, "femus_amd", "lib")
     exe = str(tmp_path / "navier_stokes_adapters")
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "femus_amd", "csrc", "adapters")], stdout=subprocess.DEVNULL)
-    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "navier_stokes_adapters.cpp"), "-o", exe,
+    subprocess.check_call(["g++", "-O1", "-std=c++17"] + INC + [os.path.join(ROOT, "tests", "cpp", "navier_stokes_adapters.cpp"), "-o", exe,
                            "-L" + lib, "-lfemus_hip_adapters", "-lfemus_hip", "-Wl,-rpath," + lib])
     out = str(tmp_path / "ns.bin")
     log = subprocess.check_output([exe, "4", "3", "0.01", out], text=True)
