@@ -490,8 +490,13 @@ void LinearEquationSolverHip::MGSetLevel(LinearEquationSolver* LinSolver, const 
     _richardsonScaleFactor = 1.;
   }
   const int smoother = smoother_id();
-  if (_level != 0 && smoother != FH_SMOOTH_VANKA && _preconditioner_type != JACOBI_PRECOND && _preconditioner_type != SOR_PRECOND) {
-    std::cout << "HIP backend: level smoother must be RICHARDSON + JACOBI_PRECOND or SOR_PRECOND (or the FEMuS_ASM solver)" << std::endl;
+  if (_level != 0 && smoother != FH_SMOOTH_VANKA && _preconditioner_type != JACOBI_PRECOND && _preconditioner_type != SOR_PRECOND &&
+      _preconditioner_type != ILU_PRECOND) {
+    std::cout << "HIP backend: level smoother must be RICHARDSON + JACOBI_PRECOND, SOR_PRECOND or ILU_PRECOND (or the FEMuS_ASM solver)" << std::endl;
+    abort();
+  }
+  if (_level != 0 && _levelSolverType != RICHARDSON) {     // the reference's default level solver is GMRES (a non-stationary smoother)
+    std::cout << "HIP backend: level " << _level << " runs its smoother as RICHARDSON (fixed sweeps); call SetSolverFineGrids(RICHARDSON)" << std::endl;
     abort();
   }
   if (_level != 0) attach_smoother_data(top->_mg, (int)_level);
@@ -502,7 +507,12 @@ void LinearEquationSolverHip::MGSetLevel(LinearEquationSolver* LinSolver, const 
             "MGSetLevel");
   top->_needs_setup = true;
 }
-int LinearEquationSolverHip::smoother_id() const { return (_preconditioner_type == SOR_PRECOND) ? FH_SMOOTH_GS_COLOR : FH_SMOOTH_JACOBI; }
+// PCSOR runs in the natural row order as PETSc does (level-scheduled); SetMulticolourSor(true) selects the colour order instead
+int LinearEquationSolverHip::smoother_id() const {
+  if (_preconditioner_type == SOR_PRECOND) return _multicolourSor ? FH_SMOOTH_GS_COLOR : FH_SMOOTH_SOR;
+  if (_preconditioner_type == ILU_PRECOND) return FH_SMOOTH_ILU0;
+  return FH_SMOOTH_JACOBI;
+}
 void LinearEquationSolverHipAsm::attach_smoother_data(fh_mg_t mg, int level) {
   if (_blockPtr.size() < 2) {
     std::cout << "HIP backend: FEMuS_ASM level " << level << " has no blocks (SetAsmBlocks)" << std::endl;

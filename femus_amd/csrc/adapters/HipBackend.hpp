@@ -181,6 +181,7 @@ class LinearEquationSolverHip : public LinearEquationSolver {
                   SparseMatrix* PP, SparseMatrix* RR, const unsigned& npre, const unsigned& npost) override;
   void MGSolve(const bool ksp_clean) override;
   void MGClear() override;
+  void SetMulticolourSor(const bool on) { _multicolourSor = on; }     // SOR_PRECOND in colour order (faster on the device, other history)
   int last_iterations() const { return _its; }
   double last_residual() const { return _rnorm; }
   const std::vector<int>& bdc_index() const { return _bdcIndex; }
@@ -199,6 +200,7 @@ class LinearEquationSolverHip : public LinearEquationSolver {
   unsigned _level;
   std::vector<int> _bdcIndex;
   bool _bdcIndexIsInitialized = false;
+  bool _multicolourSor = false;
   double _rtol = 1e-5, _abstol = 1e-50, _dtol = 1e5, _richardsonScaleFactor = 0.5;   // LinearEquationSolverPetsc.hpp:139-146
   int _maxits = 1000, _restart = 30;
   // top-level (the object MGInit was called on) owns the cycle

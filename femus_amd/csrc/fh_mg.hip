@@ -13,6 +13,7 @@
 // GEMV with the inverse factored once per assembly; the whole cycle (~25 short launches, launch-bound on the coarse
 // levels) is captured in a hipGraph and replayed.
 #include "fh_internal.h"
+#include "fh_trisolve.h"
 #include <algorithm>
 #include <cmath>
 
@@ -33,6 +34,8 @@ struct MgLevel {
   int ncolors = 0;
   std::vector<int> color_ptr;
   int* d_color_rows = nullptr;
+  // natural-order sweeps (FH_SMOOTH_SOR, FH_SMOOTH_ILU0): level schedules of the matrix graph, ILU(0) factors
+  fh_tri_t tri = nullptr;
   // block Schwarz (Vanka) smoother: dof patches, their colours and dense inverses
   int npatch = 0, vanka_ncolors = 0, max_patch = 0;
   std::vector<int> h_pptr, h_pdofs, vcolor_ptr;
@@ -774,13 +777,16 @@ extern "C" int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh
   FH_REQUIRE(A->m <= A->n, "fh_mg_set_level: operator must be square (or owned rows x local columns on a distributed level)");
   FH_REQUIRE(level == 0 || P != nullptr, "fh_mg_set_level: level %d needs an interpolation matrix", level);
   FH_REQUIRE(!P || P->m == A->m, "fh_mg_set_level: interpolation has %d rows, operator has %d", P ? P->m : 0, A->m);
-  FH_REQUIRE(smoother == FH_SMOOTH_JACOBI || smoother == FH_SMOOTH_GS_COLOR || smoother == FH_SMOOTH_VANKA,
-             "fh_mg_set_level: unknown smoother %d (0 = Richardson+Jacobi, 1 = Richardson+multicolour SOR, 2 = block Schwarz / Vanka)", smoother);
+  FH_REQUIRE(smoother >= FH_SMOOTH_JACOBI && smoother <= FH_SMOOTH_ILU0,
+             "fh_mg_set_level: unknown smoother %d (0 = Richardson+Jacobi, 1 = Richardson+multicolour SOR, 2 = block Schwarz / Vanka, "
+             "3 = Richardson+SOR in natural order, 4 = Richardson+ILU(0))", smoother);
   FH_REQUIRE(npre >= 0 && npost >= 0, "fh_mg_set_level: negative sweep count");
   MgLevel& L = mg->lv[level];
   if (L.A_uid != A->uid) {   // another matrix (also one that landed on the address of a destroyed one): its graph may differ
     free_level_colors(L);
     free_level_patch_setup(L);
+    fh_tri_destroy(L.tri);
+    L.tri = nullptr;
     L.A_uid = A->uid;
   }
   L.A = A;
@@ -1083,6 +1089,10 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
     }
     FH_TRY(fh_dev_get_diag(L.A, L.dinv, 1));
     if (L.smoother == FH_SMOOTH_GS_COLOR && l > 0 && L.ncolors == 0) FH_TRY(color_rows(L));
+    if ((L.smoother == FH_SMOOTH_SOR || L.smoother == FH_SMOOTH_ILU0) && l > 0) {
+      if (!L.tri) FH_TRY(fh_tri_create(L.A, &L.tri));                       // level schedules: once per pattern
+      if (L.smoother == FH_SMOOTH_ILU0) FH_TRY(fh_tri_ilu_factor(L.tri, L.A));   // numeric factorisation: every setup
+    }
     if (L.smoother == FH_SMOOTH_VANKA && l > 0) {
       FH_REQUIRE(L.npatch > 0 && !L.halo, "fh_mg_setup: level %d uses the Vanka smoother but has no patches (fh_mg_set_level_patches)", l);
       if (!L.d_pinv) FH_TRY(color_patches(L));
@@ -1121,8 +1131,9 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
   return 0;
 }
 
-// Richardson(scale omega) + multicolour symmetric SOR: x <- x + omega * B (b - A x), B = forward then backward Gauss-Seidel
-// sweep over the colours from a zero guess (PCSOR's local symmetric sweep, PetscPreconditioner.cpp:219-222, in colour order)
+// Richardson(scale omega) + a sweep preconditioner: x <- x + omega * B (b - A x).  B = forward then backward Gauss-Seidel from a
+// zero guess (PCSOR's local symmetric sweep, PetscPreconditioner.cpp:219-222) over the colours (FH_SMOOTH_GS_COLOR) or in the natural
+// row order as PETSc runs it (FH_SMOOTH_SOR), or the ILU(0) solve (FH_SMOOTH_ILU0, PetscPreconditioner.cpp:91-115)
 static int gs_sweeps(fh_mg_t mg, MgLevel& L, int nsweeps, bool zero_guess) {
   fh_ctx_t c = mg->ctx;
   for (int s = 0; s < nsweeps; s++) {
@@ -1133,6 +1144,13 @@ static int gs_sweeps(fh_mg_t mg, MgLevel& L, int nsweeps, bool zero_guess) {
       FH_TRY(halo_spmv(L.halo, L.A, L.x, L.n, L.r, 2, L.b, nullptr, 0.0));
     }
     double* z = L.x2;
+    if (L.smoother == FH_SMOOTH_SOR || L.smoother == FH_SMOOTH_ILU0) {
+      // z = B r in the natural row order, as the reference's PCSOR / PCILU apply it (level-scheduled, fh_trisolve.hip)
+      if (L.smoother == FH_SMOOTH_SOR) FH_TRY(fh_tri_ssor_apply(L.tri, L.A, L.dinv, L.r, z));
+      else FH_TRY(fh_tri_ilu_apply(L.tri, L.A, L.r, z));
+      hipLaunchKernelGGL(k_axpby2, dim3(sgrid(c, L.n)), dim3(256), 0, c->stream, L.x, z, L.omega, first ? 0.0 : 1.0, L.n);
+      continue;
+    }
     FH_CHECK_HIP(hipMemsetAsync(z, 0, (size_t)L.ncols * sizeof(double), c->stream));
     for (int pass = 0; pass < 2; pass++)
       for (int k = 0; k < L.ncolors; k++) {
@@ -1160,7 +1178,7 @@ static int run_cycle(fh_mg_t mg) {
     } else if (L.smoother == FH_SMOOTH_VANKA) {
       FH_CHECK_HIP(hipMemsetAsync(L.x, 0, (size_t)L.ncols * sizeof(double), c->stream));
       FH_TRY(vanka_sweeps(mg, L, L.npre));
-    } else if (L.smoother == FH_SMOOTH_GS_COLOR) {
+    } else if (L.smoother == FH_SMOOTH_GS_COLOR || L.smoother == FH_SMOOTH_SOR || L.smoother == FH_SMOOTH_ILU0) {
       FH_TRY(gs_sweeps(mg, L, L.npre, true));
     } else {
       // sweep 1 from a zero guess: x = omega D^-1 b ; sweeps 2..npre: fused Jacobi SpMV, ping-pong x <-> x2
@@ -1183,7 +1201,7 @@ static int run_cycle(fh_mg_t mg) {
     MgLevel& L = mg->lv[l];
     MgLevel& Lc = mg->lv[l - 1];
     FH_TRY(halo_spmv(Lc.halo, L.P, Lc.x, Lc.n, L.x, 1, nullptr, nullptr, 0.0));      // x += P x_{l-1} (reads ghost coarse values)
-    if (L.smoother == FH_SMOOTH_GS_COLOR) {
+    if (L.smoother == FH_SMOOTH_GS_COLOR || L.smoother == FH_SMOOTH_SOR || L.smoother == FH_SMOOTH_ILU0) {
       FH_TRY(gs_sweeps(mg, L, L.npost, false));
       continue;
     }
@@ -1235,6 +1253,8 @@ extern "C" int fh_mg_destroy(fh_mg_t mg) {
     free_level_buffers(L);
     free_level_colors(L);
     free_level_patches(L);
+    fh_tri_destroy(L.tri);
+    L.tri = nullptr;
   }
   if (mg->d_ainv) hipFree(mg->d_ainv);
   if (mg->d_gjwork) hipFree(mg->d_gjwork);

@@ -1,0 +1,21 @@
+// level-scheduled natural-order sweeps (fh_trisolve.hip): symmetric Gauss-Seidel (PCSOR) and ILU(0) (PCILU)
+#pragma once
+#include "fh_internal.h"
+
+struct fh_tri_s {
+  int m = 0;
+  uint64_t A_uid = 0;
+  std::vector<int> fptr, bptr;          // level pointers of the forward (rows j < i first) / backward schedule
+  std::vector<int> h_diagpos;
+  int *d_frows = nullptr, *d_brows = nullptr, *d_diagpos = nullptr;
+  double* d_lu = nullptr;               // ILU(0) factors on A's pattern: strict lower part = L (unit diagonal), rest = U
+  int* d_flag = nullptr;
+  double shift = 0.0;                   // diagonal shift the last factorisation needed (MAT_SHIFT_NONZERO)
+};
+typedef fh_tri_s* fh_tri_t;
+
+int fh_tri_create(fh_mat_t A, fh_tri_t* out);
+void fh_tri_destroy(fh_tri_t T);
+int fh_tri_ssor_apply(fh_tri_t T, fh_mat_t A, const double* dinv, const double* r, double* z);
+int fh_tri_ilu_factor(fh_tri_t T, fh_mat_t A);
+int fh_tri_ilu_apply(fh_tri_t T, fh_mat_t A, const double* r, double* z);

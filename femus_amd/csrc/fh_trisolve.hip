@@ -1,0 +1,273 @@
+// Natural-order sweeps on gfx950: the reference's PCSOR and PCILU level smoothers (a18 of SURVEY 8).
+//   PCSOR  (PetscPreconditioner.cpp:219-222; 001_Poisson/main.cpp:240-242): PETSc's default omega_sor = 1, ONE local symmetric
+//          sweep from a zero guess -- forward Gauss-Seidel over the rows in their natural order, then backward (MatSOR with
+//          SOR_LOCAL_SYMMETRIC_SWEEP | SOR_ZERO_INITIAL_GUESS); on several ranks only the rank-local diagonal block takes part.
+//   PCILU  (PetscPreconditioner.cpp:91-115): ILU(0) of the rank-local block in natural order, zero pivot 1e-16 and
+//          MAT_SHIFT_NONZERO (LinearEquationSolverPetsc.cpp:444-446): a pivot with |p| <= zeropivot * (row sum of |a_ij|) restarts the
+//          factorisation of A + shift I, shift = 100 eps first, doubled at every further restart (PETSc's MatPivotCheck_nz; PETSc
+//          3.20.2 is not under /root/reference -- restated from its documented behaviour).
+// A sequential sweep is a sparse triangular solve.  MI355X form: LEVEL SCHEDULING -- row i goes to level 1 + max(level of the rows
+// j < i it reads), all rows of a level are independent, one launch per level (captured into the cycle's hipGraph like every other
+// launch), 16 lanes per row.  The arithmetic per row is the sequential one (same operands, sum taken by 16 lanes instead of one),
+// so a sweep agrees with the sequential sweep to rounding -- unlike the multicolour ordering (FH_SMOOTH_GS_COLOR), whose iteration
+// history differs from the reference's.  Integer setup (levels, diagonal positions) on the host, once per pattern.
+#include "fh_internal.h"
+#include "fh_trisolve.h"
+#include <algorithm>
+#include <cmath>
+
+// rows of the local block only: columns >= m are ghosts (block Jacobi across ranks, as PCSOR / PCILU are local)
+static void schedule(const std::vector<int>& rp, const std::vector<int>& col, int m, bool forward, std::vector<int>& ptr, std::vector<int>& rows) {
+  std::vector<int> lev(m, 0);
+  int nlev = 0;
+  if (forward) {
+    for (int i = 0; i < m; i++) {
+      int l = 0;
+      for (int k = rp[i]; k < rp[i + 1] && col[k] < i; k++) l = std::max(l, lev[col[k]] + 1);
+      lev[i] = l;
+      nlev = std::max(nlev, l + 1);
+    }
+  } else {
+    for (int i = m - 1; i >= 0; i--) {
+      int l = 0;
+      for (int k = rp[i + 1] - 1; k >= rp[i] && col[k] > i; k--)
+        if (col[k] < m) l = std::max(l, lev[col[k]] + 1);
+      lev[i] = l;
+      nlev = std::max(nlev, l + 1);
+    }
+  }
+  ptr.assign(nlev + 1, 0);
+  for (int i = 0; i < m; i++) ptr[lev[i] + 1]++;
+  for (int l = 0; l < nlev; l++) ptr[l + 1] += ptr[l];
+  rows.resize(m);
+  std::vector<int> pos(ptr.begin(), ptr.end() - 1);
+  for (int i = 0; i < m; i++) rows[pos[lev[i]]++] = i;      // ascending row index inside a level
+}
+
+int fh_tri_create(fh_mat_t A, fh_tri_t* out) {
+  fh_tri_t T = new fh_tri_s();
+  T->m = A->m;
+  T->A_uid = A->uid;
+  std::vector<int> rows;
+  schedule(A->h_rowptr, A->h_col, A->m, true, T->fptr, rows);
+  FH_CHECK_HIP(hipMalloc(&T->d_frows, std::max(A->m, 1) * sizeof(int)));
+  FH_CHECK_HIP(hipMemcpy(T->d_frows, rows.data(), (size_t)A->m * sizeof(int), hipMemcpyHostToDevice));
+  schedule(A->h_rowptr, A->h_col, A->m, false, T->bptr, rows);
+  FH_CHECK_HIP(hipMalloc(&T->d_brows, std::max(A->m, 1) * sizeof(int)));
+  FH_CHECK_HIP(hipMemcpy(T->d_brows, rows.data(), (size_t)A->m * sizeof(int), hipMemcpyHostToDevice));
+  std::vector<int> dpos(A->m, -1);
+  for (int i = 0; i < A->m; i++) {
+    const int* b = A->h_col.data() + A->h_rowptr[i];
+    const int* e = A->h_col.data() + A->h_rowptr[i + 1];
+    const int* q = std::lower_bound(b, e, i);
+    if (q != e && *q == i) dpos[i] = (int)(q - A->h_col.data());
+  }
+  T->h_diagpos = dpos;
+  FH_CHECK_HIP(hipMalloc(&T->d_diagpos, std::max(A->m, 1) * sizeof(int)));
+  FH_CHECK_HIP(hipMemcpy(T->d_diagpos, dpos.data(), (size_t)A->m * sizeof(int), hipMemcpyHostToDevice));
+  *out = T;
+  return 0;
+}
+
+void fh_tri_destroy(fh_tri_t T) {
+  if (!T) return;
+  for (void* p : {(void*)T->d_frows, (void*)T->d_brows, (void*)T->d_diagpos, (void*)T->d_lu, (void*)T->d_flag})
+    if (p) hipFree(p);
+  delete T;
+}
+
+// ---- symmetric Gauss-Seidel ------------------------------------------------------------------------------------------------
+// forward, zero guess: z_i = dinv_i (r_i - sum_{j < i} a_ij z_j)   (entries right of the diagonal multiply zeros)
+__global__ __launch_bounds__(256) void k_gs_fwd(const int* __restrict__ rows, int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                const double* __restrict__ val, const double* __restrict__ dinv, const double* __restrict__ r,
+                                                double* z) {
+  const int rr = (blockIdx.x * 256 + threadIdx.x) >> 4, gl = threadIdx.x & 15;
+  const bool live = rr < nrows;
+  const int i = live ? rows[rr] : 0;
+  double acc = 0.0;
+  if (live)
+    for (int k = rowptr[i] + gl; k < rowptr[i + 1]; k += 16) {
+      const int j = col[k];
+      if (j < i) acc += val[k] * z[j];
+    }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (live && gl == 0) z[i] = dinv[i] * (r[i] - acc);
+}
+
+// backward: z_i = dinv_i (r_i - sum_{j != i, j local} a_ij z_j) with the newest values on both sides
+__global__ __launch_bounds__(256) void k_gs_bwd(const int* __restrict__ rows, int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                const double* __restrict__ val, const double* __restrict__ dinv, const double* __restrict__ r,
+                                                double* z, int m) {
+  const int rr = (blockIdx.x * 256 + threadIdx.x) >> 4, gl = threadIdx.x & 15;
+  const bool live = rr < nrows;
+  const int i = live ? rows[rr] : 0;
+  double acc = 0.0;
+  if (live)
+    for (int k = rowptr[i] + gl; k < rowptr[i + 1]; k += 16) {
+      const int j = col[k];
+      if (j != i && j < m) acc += val[k] * z[j];
+    }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (live && gl == 0) z[i] = dinv[i] * (r[i] - acc);
+}
+
+// z = B r, B = one symmetric Gauss-Seidel sweep of A's local block from z = 0
+int fh_tri_ssor_apply(fh_tri_t T, fh_mat_t A, const double* dinv, const double* r, double* z) {
+  hipStream_t s = A->ctx->stream;
+  const int nf = (int)T->fptr.size() - 1, nb = (int)T->bptr.size() - 1;
+  for (int l = 0; l < nf; l++) {
+    const int n = T->fptr[l + 1] - T->fptr[l];
+    hipLaunchKernelGGL(k_gs_fwd, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_frows + T->fptr[l], n, A->d_rowptr, A->d_col, A->d_val, dinv,
+                       r, z);
+  }
+  for (int l = 0; l < nb; l++) {
+    const int n = T->bptr[l + 1] - T->bptr[l];
+    hipLaunchKernelGGL(k_gs_bwd, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_brows + T->bptr[l], n, A->d_rowptr, A->d_col, A->d_val, dinv,
+                       r, z, A->m);
+  }
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- ILU(0) ----------------------------------------------------------------------------------------------------------------
+// one row per 16-lane group, rows of one level together.  Row i: for k < i in the row, ascending: l_ik = a_ik / u_kk, then
+// a_ij -= l_ik u_kj for the j > k that row k AND row i hold (IKJ form of the reference's MatLUFactorNumeric on the fixed pattern).
+__device__ __forceinline__ void tri_group_sync() {      // LDS operations of one wave execute in order; keep the compiler from reordering them
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(256) void k_ilu_factor(const int* __restrict__ rows, int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                    const int* __restrict__ diagpos, double* lu, int m, int maxrow, double zeropivot,
+                                                    int* __restrict__ flag) {
+  extern __shared__ double tri_rows[];             // [16 groups][maxrow]: the row being eliminated lives in LDS
+  const int rr = (blockIdx.x * 256 + threadIdx.x) >> 4, gl = threadIdx.x & 15;
+  if (rr >= nrows) return;
+  double* w = tri_rows + (size_t)(threadIdx.x >> 4) * maxrow;
+  const int i = rows[rr];
+  const int rs = rowptr[i], re = rowptr[i + 1];
+  for (int p = rs + gl; p < re; p += 16) w[p - rs] = lu[p];
+  tri_group_sync();
+  for (int p = rs; p < re; p++) {
+    const int k = col[p];
+    if (k >= i) break;
+    const int dk = diagpos[k];
+    const double lik = w[p - rs] / lu[dk];          // row k is final: it was factored by an earlier launch (lower level)
+    tri_group_sync();
+    if (gl == 0) w[p - rs] = lik;
+    const int ke = rowptr[k + 1];
+    for (int q = dk + 1 + gl; q < ke; q += 16) {
+      const int j = col[q];
+      if (j >= m) continue;                         // ghost column: not part of the local block
+      int lo = p + 1, hi = re - 1;
+      while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const int cc = col[mid];
+        if (cc == j) {
+          w[mid - rs] -= lik * lu[q];                // distinct j per lane: distinct slots
+          break;
+        }
+        if (cc < j) lo = mid + 1; else hi = mid - 1;
+      }
+    }
+    tri_group_sync();
+  }
+  for (int p = rs + gl; p < re; p += 16) lu[p] = w[p - rs];
+  if (gl == 0) {
+    const int di = diagpos[i];
+    double rsum = 0.0;
+    for (int p = rs; p < re; p++) rsum += fabs(w[p - rs]);
+    if (di < 0 || !(fabs(w[di - rs]) > zeropivot * rsum)) atomicOr(flag, 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ilu_shift(double* __restrict__ lu, const int* __restrict__ diagpos, int m, double shift) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m && diagpos[i] >= 0) lu[diagpos[i]] += shift;
+}
+
+int fh_tri_ilu_factor(fh_tri_t T, fh_mat_t A) {
+  fh_ctx_t c = A->ctx;
+  for (int i = 0; i < A->m; i++) FH_REQUIRE(T->h_diagpos[i] >= 0, "ILU(0): row %d has no diagonal entry in the pattern", i);
+  if (!T->d_lu) FH_CHECK_HIP(hipMalloc(&T->d_lu, ((size_t)A->nnz + 2) * sizeof(double)));
+  if (!T->d_flag) FH_CHECK_HIP(hipMalloc(&T->d_flag, sizeof(int)));
+  const int nf = (int)T->fptr.size() - 1;
+  const int maxrow = std::max(A->max_row, 1);
+  FH_REQUIRE(maxrow <= 512, "ILU(0): a row with %d entries (at most 512 are served)", maxrow);
+  const size_t lds = (size_t)16 * maxrow * sizeof(double);
+  double shift = 0.0;
+  for (int attempt = 0; attempt < 40; attempt++) {
+    FH_CHECK_HIP(hipMemcpyAsync(T->d_lu, A->d_val, (size_t)A->nnz * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (shift != 0.0) hipLaunchKernelGGL(k_ilu_shift, dim3(fh_div_up(A->m, 256)), dim3(256), 0, c->stream, T->d_lu, T->d_diagpos, A->m, shift);
+    FH_CHECK_HIP(hipMemsetAsync(T->d_flag, 0, sizeof(int), c->stream));
+    for (int l = 0; l < nf; l++) {
+      const int n = T->fptr[l + 1] - T->fptr[l];
+      hipLaunchKernelGGL(k_ilu_factor, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), lds, c->stream, T->d_frows + T->fptr[l], n, A->d_rowptr,
+                         A->d_col, T->d_diagpos, T->d_lu, A->m, maxrow, 1e-16, T->d_flag);
+    }
+    FH_CHECK_HIP(hipGetLastError());
+    int h = 0;
+    FH_CHECK_HIP(hipMemcpyAsync(&h, T->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (!h) {
+      T->shift = shift;
+      return 0;
+    }
+    shift = (shift == 0.0) ? 100.0 * 2.220446049250313e-16 : 2.0 * shift;      // MAT_SHIFT_NONZERO: restart with A + shift I
+  }
+  fh_set_error("ILU(0): zero pivot even after 40 diagonal shifts");
+  return 2;
+}
+
+// y_i = r_i - sum_{j < i} l_ij y_j
+__global__ __launch_bounds__(256) void k_ilu_lsolve(const int* __restrict__ rows, int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                    const double* __restrict__ lu, const double* __restrict__ r, double* z) {
+  const int rr = (blockIdx.x * 256 + threadIdx.x) >> 4, gl = threadIdx.x & 15;
+  const bool live = rr < nrows;
+  const int i = live ? rows[rr] : 0;
+  double acc = 0.0;
+  if (live)
+    for (int k = rowptr[i] + gl; k < rowptr[i + 1]; k += 16) {
+      const int j = col[k];
+      if (j < i) acc += lu[k] * z[j];
+    }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (live && gl == 0) z[i] = r[i] - acc;
+}
+
+// z_i = (y_i - sum_{j > i, local} u_ij z_j) / u_ii
+__global__ __launch_bounds__(256) void k_ilu_usolve(const int* __restrict__ rows, int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                    const int* __restrict__ diagpos, const double* __restrict__ lu, double* z, int m) {
+  const int rr = (blockIdx.x * 256 + threadIdx.x) >> 4, gl = threadIdx.x & 15;
+  const bool live = rr < nrows;
+  const int i = live ? rows[rr] : 0;
+  double acc = 0.0;
+  if (live)
+    for (int k = rowptr[i] + gl; k < rowptr[i + 1]; k += 16) {
+      const int j = col[k];
+      if (j > i && j < m) acc += lu[k] * z[j];
+    }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (live && gl == 0) z[i] = (z[i] - acc) / lu[diagpos[i]];
+}
+
+int fh_tri_ilu_apply(fh_tri_t T, fh_mat_t A, const double* r, double* z) {
+  hipStream_t s = A->ctx->stream;
+  const int nf = (int)T->fptr.size() - 1, nb = (int)T->bptr.size() - 1;
+  for (int l = 0; l < nf; l++) {
+    const int n = T->fptr[l + 1] - T->fptr[l];
+    hipLaunchKernelGGL(k_ilu_lsolve, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_frows + T->fptr[l], n, A->d_rowptr, A->d_col, T->d_lu, r, z);
+  }
+  for (int l = 0; l < nb; l++) {
+    const int n = T->bptr[l + 1] - T->bptr[l];
+    hipLaunchKernelGGL(k_ilu_usolve, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_brows + T->bptr[l], n, A->d_rowptr, A->d_col,
+                       T->d_diagpos, T->d_lu, z, A->m);
+  }
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -293,7 +293,17 @@ int fh_ns_element_matrices(fh_ns_assembler_t as, fh_vec_t sol, double nu, double
  * fh_mg_vcycle      <- one PCMG multiplicative V-cycle application x = M^-1 b
  * fh_mg_solve       <- MGSolve (:294-353): outer solver preconditioned by the cycle
  * fh_mg_destroy     <- MGClear (LinearEquationSolverPetsc.hpp:86-88) */
-enum { FH_SMOOTH_JACOBI = 0, FH_SMOOTH_GS_COLOR = 1, FH_SMOOTH_VANKA = 2 };
+/* level smoothers, all as Richardson(omega) with a fixed sweep count (LinearEquationSolverPetsc.cpp:516-519):
+ *   FH_SMOOTH_JACOBI    PCJACOBI (PetscPreconditioner.cpp:209-212): one fused SpMV per sweep
+ *   FH_SMOOTH_GS_COLOR  PCSOR's local symmetric sweep over the colours of the matrix graph (GPU-friendly order; converges to the same
+ *                       solution, iteration history differs from the reference's)
+ *   FH_SMOOTH_VANKA     block Schwarz on dof patches (FEMuS_ASM)
+ *   FH_SMOOTH_SOR       PCSOR exactly as PETSc applies it (:219-222; 001_Poisson/main.cpp:240-242): omega_sor = 1, one local symmetric
+ *                       Gauss-Seidel sweep in the NATURAL row order from a zero guess; level-scheduled on the device
+ *   FH_SMOOTH_ILU0      PCILU (:91-115): ILU(0) of the local block in natural order, zero pivot 1e-16 with MAT_SHIFT_NONZERO
+ *                       (LinearEquationSolverPetsc.cpp:444-446: restart on A + shift I, shift 100 eps then doubled); re-factored by
+ *                       every fh_mg_setup; level-scheduled triangular solves */
+enum { FH_SMOOTH_JACOBI = 0, FH_SMOOTH_GS_COLOR = 1, FH_SMOOTH_VANKA = 2, FH_SMOOTH_SOR = 3, FH_SMOOTH_ILU0 = 4 };
 enum { FH_OUTER_PREONLY = 0, FH_OUTER_RICHARDSON = 1, FH_OUTER_GMRES = 2, FH_OUTER_CG = 3 };
 int fh_mg_create(fh_ctx_t ctx, int nlevels, fh_mg_t* mg);
 int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh_mat_t R, int smoother, double omega, int npre, int npost);

@@ -720,6 +720,78 @@ def smooth_sor_color(A, dinv, b, x, omega, nsweeps, zero_guess, color, nc):
     return x
 
 
+def sor_symmetric_natural(A, dinv, r):
+    """z = B r, B = PCSOR as the reference selects it (PetscPreconditioner.cpp:219-222): PETSc defaults omega_sor = 1, one LOCAL
+    SYMMETRIC sweep from a zero guess, rows in their natural order (MatSOR, SOR_LOCAL_SYMMETRIC_SWEEP | SOR_ZERO_INITIAL_GUESS):
+    forward z_i = (r_i - sum_{j<i} a_ij z_j) / a_ii for i = 0..n-1, then backward z_i = (r_i - sum_{j!=i} a_ij z_j) / a_ii for
+    i = n-1..0 with the newest values.  Sequential by definition; written as two triangular solves."""
+    import scipy.sparse.linalg as spla
+    A = A.tocsr()
+    n = A.shape[0]
+    A = A[:, :n]                                   # local block (columns beyond n are ghosts)
+    D = sp.diags(1.0 / dinv)
+    L = sp.tril(A, -1).tocsr()
+    U = sp.triu(A, 1).tocsr()
+    z = spla.spsolve_triangular((L + D).tocsr(), r, lower=True)
+    z = spla.spsolve_triangular((U + D).tocsr(), r - L @ z, lower=False)
+    return z
+
+
+def ilu0_factor(A, zeropivot=1e-16):
+    """ILU(0) in natural order on A's pattern -- PCILU as the reference configures it (PetscPreconditioner.cpp:91-115;
+    PCFactorSetZeroPivot(1e-16), MAT_SHIFT_NONZERO: LinearEquationSolverPetsc.cpp:444-446).  IKJ elimination restricted to the
+    pattern; a pivot with |u_ii| <= zeropivot * sum_j |row_i| restarts the factorisation of A + shift I with shift = 100 eps,
+    doubled at every further restart (PETSc 3.20.2 MatPivotCheck_nz; not under /root/reference).  Returns (L unit lower, U, shift)."""
+    A = A.tocsr().copy()
+    n = A.shape[0]
+    A = A[:, :n].tocsr()
+    A.sort_indices()
+    ip, ix = A.indptr, A.indices
+    dpos = np.array([ip[i] + np.searchsorted(ix[ip[i]:ip[i + 1]], i) for i in range(n)])
+    assert np.all(ix[dpos] == np.arange(n)), "ILU(0): a row without diagonal entry"
+    shift = 0.0
+    while True:
+        v = A.data.copy()
+        v[dpos] += shift
+        ok = True
+        for i in range(n):
+            rs, re = ip[i], ip[i + 1]
+            cols = ix[rs:re]
+            for p in range(rs, re):
+                k = ix[p]
+                if k >= i:
+                    break
+                lik = v[p] / v[dpos[k]]
+                v[p] = lik
+                kc = ix[dpos[k] + 1:ip[k + 1]]
+                pos = np.searchsorted(cols, kc)
+                hit = (pos < cols.size) & (cols[np.minimum(pos, cols.size - 1)] == kc)
+                v[rs + pos[hit]] -= lik * v[dpos[k] + 1:ip[k + 1]][hit]
+            if not abs(v[dpos[i]]) > zeropivot * np.abs(v[rs:re]).sum():
+                ok = False
+                break
+        if ok:
+            break
+        shift = 100.0 * np.finfo(float).eps if shift == 0.0 else 2.0 * shift
+    M = sp.csr_matrix((v, ix.copy(), ip.copy()), shape=(n, n))
+    return (sp.tril(M, -1) + sp.identity(n)).tocsr(), sp.triu(M, 0).tocsr(), shift
+
+
+def ilu0_apply(LU, r):
+    import scipy.sparse.linalg as spla
+    L, U, _ = LU
+    return spla.spsolve_triangular(U, spla.spsolve_triangular(L, r, lower=True, unit_diagonal=True), lower=False)
+
+
+def smooth_precond(A, b, x, omega, nsweeps, zero_guess, apply_B):
+    """Richardson(omega) with a preconditioner application z = B r per iteration (KSPRICHARDSON, fixed iteration count)"""
+    for it in range(nsweeps):
+        first = zero_guess and it == 0
+        z = apply_B(b.copy() if first else b - A @ x)
+        x = omega * z if first else x + omega * z
+    return x
+
+
 def vcycle(H, level, b, omega=2. / 3., npre=2, npost=2, coarse_solve=None, x=None, smoother="jacobi"):
     """One multiplicative V-cycle applied to rhs b, starting from x (None = zero)."""
     A = H.A[level]
@@ -738,6 +810,14 @@ def vcycle(H, level, b, omega=2. / 3., npre=2, npost=2, coarse_solve=None, x=Non
             H._colors = [greedy_colors(a) for a in H.A]
         col, nc = H._colors[level]
         sm = lambda bb, xx, n, zg: smooth_sor_color(A, dinv, bb, xx, omega, n, zg, col, nc)
+    elif smoother == "sor":
+        sm = lambda bb, xx, n, zg: smooth_precond(A, bb, xx, omega, n, zg, lambda r: sor_symmetric_natural(A, dinv, r))
+    elif smoother == "ilu0":
+        if not hasattr(H, "_ilu"):
+            H._ilu = {}
+        if level not in H._ilu:
+            H._ilu[level] = ilu0_factor(A)
+        sm = lambda bb, xx, n, zg: smooth_precond(A, bb, xx, omega, n, zg, lambda r: ilu0_apply(H._ilu[level], r))
     else:
         sm = lambda bb, xx, n, zg: smooth(A, dinv, bb, xx, omega, n, zg)
     x = sm(b, np.zeros_like(b) if x is None else x, npre, x is None)

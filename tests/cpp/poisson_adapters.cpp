@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <string>
 #include <vector>
 #include "HipBackend.hpp"
 
@@ -62,8 +63,10 @@ int main(int argc, char** argv) {
       ls->_KK->init(nnode, nnode, nnode, nnode, d_nnz, o_nnz);
     }
     ls->set_solver_type(RICHARDSON);
-    ls->set_preconditioner_type(JACOBI_PRECOND);
-    ls->SetRichardsonScaleFactor(2. / 3.);
+    // argv[6]: "sor" = SOR_PRECOND (the choice of 001_Poisson/main.cpp:242), "ilu" = ILU_PRECOND, default JACOBI_PRECOND
+    const std::string pc = argc > 6 ? argv[6] : "jacobi";
+    ls->set_preconditioner_type(pc == "sor" ? SOR_PRECOND : pc == "ilu" ? ILU_PRECOND : JACOBI_PRECOND);
+    ls->SetRichardsonScaleFactor(pc == "jacobi" ? 2. / 3. : 0.8);
     if (l > 0) {
       fh_mat_t P;
       hip_check(fh_build_prolongator(hip_context(), msh[l - 1], msh[l], fe, 1, &P), "BuildProlongatorMatrix");

@@ -25,11 +25,11 @@ def build_app(tmp_path):
     return exe
 
 
-@pytest.mark.parametrize("args,nl", [((2, 2, 2), 3), ((4, 4, 0), 3)])
-def test_adapter_application_matches_oracle(tmp_path, args, nl):
+@pytest.mark.parametrize("args,nl,pc", [((2, 2, 2), 3, "jacobi"), ((4, 4, 0), 3, "jacobi"), ((4, 4, 0), 3, "sor"), ((2, 2, 2), 3, "ilu")])
+def test_adapter_application_matches_oracle(tmp_path, args, nl, pc):
     exe = build_app(tmp_path)
     out = str(tmp_path / "sol.bin")
-    log = subprocess.check_output([exe] + [str(a) for a in args] + [str(nl), out], text=True)
+    log = subprocess.check_output([exe] + [str(a) for a in args] + [str(nl), out, pc], text=True)
     assert "Linear iteration" in log
     H = fo.build_poisson_hierarchy(*args, nl, "biquadratic", lambda xg: np.ones(xg.shape[:2]))
     xd = spla.spsolve(H.A[-1].tocsc(), H.b)

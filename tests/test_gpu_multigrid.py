@@ -263,3 +263,78 @@ def test_colouring_is_rebuilt_when_another_operator_is_installed(ctx):
     fresh.vcycle(b, x2)
     assert rel(x1.to_numpy(), x2.to_numpy()) < 1e-13
     mg.destroy(), fresh.destroy()
+
+
+# ---- the reference's own level smoothers: PCSOR in natural order, PCILU = ILU(0) (a18) ---------------------------------------------
+@pytest.mark.parametrize("smoother,name", [(capi.SMOOTH_SOR, "sor"), (capi.SMOOTH_ILU0, "ilu0")])
+@pytest.mark.parametrize("box,fe,nl", [((2, 2, 2), "biquadratic", 3), ((8, 8, 0), "linear", 3)])
+def test_natural_order_smoothers_match_the_sequential_oracle(ctx, smoother, name, box, fe, nl):
+    """one V(2,1) cycle with Richardson(0.8) + [one symmetric Gauss-Seidel sweep in the natural row order | the ILU(0) solve]: the
+    level-scheduled device sweeps against the oracle's SEQUENTIAL sweeps (two triangular solves / IKJ elimination), 1e-11"""
+    H = fo.build_poisson_hierarchy(*box, nl, fe, ONE)
+    mg, mats = device_hierarchy(ctx, H, 0.8, 2, 1, smoother=smoother)
+    n = H.A[-1].shape[0]
+    rhs = fo.lcg_fill(n, 21)
+    b, x = ctx.vector_from(rhs), ctx.vector(n)
+    for rep in range(2):                                   # also as a replayed graph
+        mg.vcycle(b, x)
+        ref = fo.vcycle(H, nl - 1, rhs, omega=0.8, npre=2, npost=1, smoother=name)
+        assert rel(x.to_numpy(), ref) < 1e-11
+    mg.destroy()
+
+
+def test_config1_converges_within_the_budget_of_001_poisson(ctx):
+    """BASELINE configs[0] exactly as applications/001_Poisson/main.cpp:213-257 + input/input.json set it up: 2-D Q1, 8x8 refined to
+    32x32, V_CYCLE with npre = npost = 1, level solver RICHARDSON (scale 0.5, LinearEquationSolverPetsc.hpp:145) + SOR_PRECOND, outer
+    GMRES with SetTolerances(1e-12, 1e-20, 1e50, 4): at most 6 linear iterations (max_number_linear_iteration) until the residual's
+    l2 norm is below abs_conv_tol = 1e-9 (HasLinearConverged, LinearImplicitSystem.cpp:415-449)"""
+    from femus_amd.poisson import PoissonMG
+    pb = PoissonMG(ctx, 8, 8, 0, 3, fe="linear", omega=0.5, npre=1, npost=1, smoother=capi.SMOOTH_SOR).init()
+    pb.assemble()
+    pb.prepare()
+    hist = []
+    for it in range(6):
+        pb.mgsolve(outer="gmres", rtol=1e-12, atol=1e-20, maxit=4)
+        hist.append(pb.RES.l2_norm())
+        if hist[-1] < 1e-9:
+            break
+    assert hist[-1] < 1e-9 and len(hist) <= 6, hist
+    pb.update_sol()
+    H = fo.build_poisson_hierarchy(8, 8, 0, 3, "linear", ONE)
+    xd = spla.spsolve(H.A[-1].tocsc(), H.b)
+    assert rel(pb.SOL.to_numpy(), xd) < 1e-8
+    pb.destroy()
+
+
+def test_ilu0_shift_on_a_zero_pivot(ctx):
+    """MAT_SHIFT_NONZERO with zero pivot 1e-16 (LinearEquationSolverPetsc.cpp:444-446): a pivot that cancels exactly restarts the
+    factorisation of A + shift I; device and oracle take the same shift and give the same preconditioned vector"""
+    import scipy.sparse as sp
+    n = 40
+    M = sp.lil_matrix((n, n))
+    for i in range(n):
+        M[i, i] = 2.0
+        if i + 1 < n:
+            M[i, i + 1] = M[i + 1, i] = -1.0
+    M[0, 0], M[0, 1], M[1, 0], M[1, 1] = 1.0, 1.0, 1.0, 1.0            # u_11 = 1 - 1 * 1 / 1 = 0 exactly
+    M = M.tocsr()
+    Lo = fo.ilu0_factor(M)
+    assert Lo[2] > 0.0
+    A0 = ctx.matrix_scipy(sp.identity(n, format="csr"))
+    A1 = ctx.matrix_scipy(M)
+    P = ctx.matrix_scipy(sp.identity(n, format="csr"))
+    mg = capi.Multigrid(ctx, 2)
+    mg.set_level(0, A0, None, None, 0, 1.0, 1, 0)
+    mg.set_level(1, A1, P, None, capi.SMOOTH_ILU0, 1.0, 1, 0)
+    mg.setup()
+    rhs = fo.lcg_fill(n, 2)
+    b, x = ctx.vector_from(rhs), ctx.vector(n)
+    mg.vcycle(b, x)
+    # cycle = pre-smooth z = (LU)^-1 b, r = b - A z, coarse "solve" with the identity: x = z + r
+    z = fo.ilu0_apply(Lo, rhs)
+    ref = z + (rhs - M @ z)
+    # the shifted pivot is u_11 = (1 + s) - 1 / (1 + s) ~ 2 s = 4.4e-14, itself only known to eps / (2 s) ~ 0.3 %: the entries that go
+    # through it agree to that, the rest to rounding; without the shift the result would be Inf / NaN
+    got = x.to_numpy()
+    assert np.all(np.isfinite(got)) and rel(got, ref) < 1e-2 and rel(got[5:], ref[5:]) < 1e-9
+    mg.destroy()
