@@ -134,6 +134,7 @@ def _declare(L):
     sig("fh_mesh_elem_centroids", c_void_p, c_void_p)
     sig("fh_mesh_elem_levels", c_void_p, c_void_p, P(c_int))
     sig("fh_mesh_amr_constraints", c_void_p, c_int, P(c_int), P(c_int), c_void_p, c_void_p, c_void_p, c_void_p)
+    sig("fh_mesh_set_amr_mode", c_void_p, c_int)
     sig("fh_build_amr_prolongator", c_void_p, c_void_p, c_int, P(c_void_p))
     sig("fh_system_elem_dofs", c_void_p, c_int, c_void_p, P(c_int), c_void_p, c_void_p)
     sig("fh_build_system_prolongator", c_void_p, c_void_p, c_void_p, c_int, c_void_p, P(c_void_p))

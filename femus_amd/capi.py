@@ -463,6 +463,12 @@ class Mesh:
         lev, _ = self.elem_levels()
         return np.array([lev[e] == self.level and bool(fn(xc[e], self.level)) for e in range(self.nel)], dtype=np.uint8)
 
+    def set_amr_mode(self, mode):
+        """"reference" (default): the restriction map exactly as Mesh::GetAMRRestrictionAndAMRSolidMark builds it; "coarsest": the
+        consistent variant (rows sum to one).  Inherited by meshes refined from this one"""
+        _chk(self.L.fh_mesh_set_amr_mode(self.h, {"reference": 0, "coarsest": 1}[mode]))
+        return self
+
     def amr_constraints(self, fe):
         """hanging dofs and their master weights: (hanging[n], ptr[n+1], master[nnz], weight[nnz])"""
         n, nnz = ctypes.c_int(0), ctypes.c_int(0)

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <functional>
+#include <map>
 #include <memory>
 #include <unordered_map>
 
@@ -23,6 +24,10 @@ struct fh_mesh_s {
   std::vector<char> refined;      // [nel] set by refine on the coarse mesh: element was split
   std::vector<int> elem_level;    // [nel] refinement level of every element (Elem.hpp:372-374)
   bool homogeneous = true;        // Mesh::GetIfHomogeneous: no element of the father level was left unrefined
+  // hanging-node constraints: 0 = the map exactly as Mesh::GetAMRRestrictionAndAMRSolidMark builds it (default), 1 = only the
+  // description to the coarsest level for a node on two interfaces at once + full expansion of chains (rows sum to one);
+  // inherited by refined meshes (fh_mesh_set_amr_mode)
+  int amr_mode = 0;
 };
 
 using namespace fhfe;
@@ -129,6 +134,7 @@ extern "C" int fh_mesh_refine_flagged(fh_mesh_t mc, const unsigned char* flags, 
   m->dim = dim;
   m->nloc = nc;
   m->level = mc->level + 1;
+  m->amr_mode = mc->amr_mode;
   if (mc->elem_level.empty()) mc->elem_level.assign(mc->nel, mc->level);
   // only elements of the current level can be refined (Elem.hpp:358-360)
   mc->refined.assign(mc->nel, 0);
@@ -601,6 +607,7 @@ static void amr_constraints(const fh_mesh_s* m, int fe, AmrRows& out) {
   const int ndof = mesh_ndofs(m, fe);
   std::vector<int> owner_level(ndof, -1);
   std::unordered_map<int, std::vector<std::pair<int, double>>> raw;
+  std::map<int, std::map<int, double>> rest;       // reference mode: master -> {son: value}, ordered like the reference's std::map
   double phi[27];
   for (int Lc = 0; Lc <= maxlev; Lc++) {
     if (inter[Lc].empty()) continue;
@@ -649,13 +656,21 @@ static void amr_constraints(const fh_mesh_s* m, int fe, AmrRows& out) {
           bool inside = true;
           for (int d = 0; d < dim; d++) inside = inside && std::fabs(xi[d]) <= 1.0 + 1e-4;
           if (!inside) continue;
-          if (owner_level[ldof] < 0) owner_level[ldof] = Lc;
-          if (owner_level[ldof] != Lc) continue;
+          if (m->amr_mode == 1) {
+            if (owner_level[ldof] < 0) owner_level[ldof] = Lc;
+            if (owner_level[ldof] != Lc) continue;
+          }
           eval_basis(geom, fe, xi, phi, nullptr);
           auto& row = raw[ldof];
           for (int n : ie.loc) {
             if (std::fabs(phi[n]) < 1.0e-10) continue;
             const int jd = ed[n];
+            if (m->amr_mode == 0) {          // the reference's map restriction[master][son] with its diagonal marks (Mesh.cpp:1560-1567)
+              auto& mrow = rest[jd];
+              if (mrow.find(jd) == mrow.end()) mrow[jd] = 1.;
+              mrow[ldof] = phi[n];
+              rest[ldof][ldof] = 10.;
+            }
             bool found = false;
             for (auto& e : row)
               if (e.first == jd) {
@@ -667,6 +682,77 @@ static void amr_constraints(const fh_mesh_s* m, int fe, AmrRows& out) {
         }
       }
     }
+  }
+  if (m->amr_mode == 0) {
+    // second half of the reference function as written (Mesh.cpp:1711-1801): for every real master (diagonal mark < 5) a depth-first
+    // walk through sons, grandsons, ...: restriction[master][son] += value * heredity(father); a son already present in the
+    // genealogy lists of the levels above the one being filled is skipped ("alreadyFound").  For a node on the interfaces with two
+    // coarser levels this keeps the direct entry and drops the path through the intermediate hanging node, so its row does not sum to
+    // one -- that is the reference's result, reproduced here.
+    const std::map<int, std::map<int, double>> copy = rest;
+    std::map<int, std::vector<std::pair<int, double>>> hrow;        // hanging dof -> (master, weight)
+    for (auto& kv : copy)
+      if (kv.second.at(kv.first) > 5.) hrow[kv.first];
+    std::vector<std::vector<int>> genealogy;
+    std::vector<std::vector<double>> heredity;
+    std::vector<size_t> index;
+    for (auto& kv : copy) {
+      const int inode = kv.first;
+      if (!(kv.second.at(inode) < 5.)) continue;
+      std::map<int, double> acc;
+      genealogy.assign(1, std::vector<int>(1, inode));
+      heredity.assign(1, std::vector<double>(1, 1.));
+      index.assign(1, 0);
+      size_t level = 1;
+      while (level > 0) {
+        const int father = genealogy[level - 1][index[level - 1]];
+        const double hf = heredity[level - 1][index[level - 1]];
+        genealogy.resize(level + 1);
+        heredity.resize(level + 1);
+        index.resize(level + 1);
+        genealogy[level].clear();
+        heredity[level].clear();
+        index[level] = 0;
+        for (auto& e : copy.at(father)) {
+          const int son = e.first;
+          bool found = false;
+          for (size_t kl = 0; kl < level && !found; kl++)
+            for (int g : genealogy[kl])
+              if (g == son) {
+                found = true;
+                break;
+              }
+          if (found) continue;
+          genealogy[level].push_back(son);
+          heredity[level].push_back(e.second * hf);
+          acc[son] += e.second * hf;
+        }
+        if (!genealogy[level].empty()) {
+          level++;
+        } else {
+          bool test = true;
+          while (test && level > 0) {
+            index[level - 1]++;
+            test = false;
+            if (index[level - 1] == genealogy[level - 1].size()) {
+              level--;
+              test = true;
+            }
+          }
+        }
+      }
+      for (auto& e : acc) hrow[e.first].emplace_back(inode, e.second);
+    }
+    for (auto& kv : hrow) {
+      out.hang.push_back(kv.first);
+      std::sort(kv.second.begin(), kv.second.end());
+      for (auto& e : kv.second) {
+        out.master.push_back(e.first);
+        out.w.push_back(e.second);
+      }
+      out.ptr.push_back((int)out.master.size());
+    }
+    return;
   }
   // resolve masters that hang themselves (depth-first, masters in increasing dof order)
   std::unordered_map<int, std::vector<std::pair<int, double>>> res;
@@ -707,6 +793,12 @@ static void amr_constraints(const fh_mesh_s* m, int fe, AmrRows& out) {
     }
     out.ptr.push_back((int)out.master.size());
   }
+}
+
+extern "C" int fh_mesh_set_amr_mode(fh_mesh_t m, int mode) {
+  FH_REQUIRE(m && (mode == 0 || mode == 1), "fh_mesh_set_amr_mode: mode must be 0 (as the reference computes it) or 1 (coarsest level, rows sum to one)");
+  m->amr_mode = mode;
+  return 0;
 }
 
 extern "C" int fh_mesh_amr_constraints(fh_mesh_t m, int fe, int* n_hanging, int* nnz, int* hanging, int* ptr, int* master, double* weight) {

@@ -211,6 +211,14 @@ int fh_build_prolongator(fh_ctx_t ctx, fh_mesh_t coarse, fh_mesh_t fine, int fe,
  * returned; then hanging[n] (sorted), ptr[n+1], master[nnz], weight[nnz] with chains through intermediate levels
  * resolved.  Hanging dofs are the "AMR artificial Dirichlet" rows (flag 1 of MultiLevelSolution.cpp:725-760): the caller
  * merges them into the Dirichlet list used by mat_zero_rows / ZeroInterpolatorDirichletNodes. */
+/* Which map the two functions below build.  mode 0 (default): exactly the reference's -- every pair of levels (ilevel < jlevel) writes
+ * restriction[master][hanging] (Mesh.cpp:1489-1590), then the genealogy walk (:1711-1801), whose "alreadyFound" rule drops the
+ * path through an intermediate hanging node when the node is also a direct son of the master: at a node on the interfaces with two
+ * coarser levels at once (3-D edges with a level jump of two) the row does NOT sum to one.  mode 1: such a node keeps only its
+ * description to the coarsest level and chains are expanded completely, so every row sums to one and Q2 polynomials are reproduced
+ * (the consistent variant; not what the reference computes).  Both agree wherever level jumps are single.  Inherited by refined
+ * meshes; call on the coarse mesh. */
+int fh_mesh_set_amr_mode(fh_mesh_t mesh, int mode);
 int fh_mesh_amr_constraints(fh_mesh_t mesh, int fe, int* n_hanging, int* nnz, int* hanging, int* ptr, int* master, double* weight);
 /* LinearImplicitSystem::BuildAmrProlongatorMatrix (LinearImplicitSystem.cpp:912-1028): P_amr (n x n), identity rows for
  * regular dofs, master weights (+ an explicit zero diagonal) for hanging dofs.  Use sites: P[l] <- P[l] * P_amr[l-1]

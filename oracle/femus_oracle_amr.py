@@ -199,9 +199,56 @@ def inverse_map(geom, xv, xp, tol=1e-14, maxit=30):
     return xi
 
 
-def amr_restriction(mesh, fe):
+def resolve_genealogy(rest):
+    """second half of Mesh::GetAMRRestrictionAndAMRSolidMark as written (Mesh.cpp:1711-1801).  rest: the raw map
+    master dof -> {son dof: value} with the diagonal marks 1 (master) / 10 (hanging).  For every real master (diagonal < 5) a
+    depth-first walk through its sons, grandsons, ... adds value * heredity of the father to restriction[master][son]; a son is
+    skipped when it already appears in the genealogy lists of the levels above the one being filled ("alreadyFound") -- which is
+    what drops the path through an intermediate hanging node when the son is also a direct son of the master.  Returns the final
+    map master -> {son: weight} (hanging nodes: {node: 0})."""
+    copy = {m: dict(r) for m, r in rest.items()}
+    out = {m: dict(r) for m, r in rest.items()}
+    for inode in sorted(copy):
+        if copy[inode].get(inode, 0.0) < 5.0:
+            genealogy, heredity, index = [[inode]], [[1.0]], [0]
+            out[inode] = {inode: 1.0}
+            level = 1
+            while level > 0:
+                father = genealogy[level - 1][index[level - 1]]
+                del genealogy[level:], heredity[level:], index[level:]
+                gl, hl = [], []
+                for son, val in sorted(copy[father].items()):
+                    if any(son in g for g in genealogy[:level]):
+                        continue
+                    gl.append(son)
+                    hl.append(val * heredity[level - 1][index[level - 1]])
+                    out[inode][son] = out[inode].get(son, 0.0) + hl[-1]
+                    out[son] = {son: 0.0}
+                genealogy.append(gl), heredity.append(hl), index.append(0)
+                if gl:
+                    level += 1
+                else:
+                    test = True
+                    while test and level > 0:
+                        index[level - 1] += 1
+                        test = False
+                        if index[level - 1] == len(genealogy[level - 1]):
+                            level -= 1
+                            test = True
+        else:
+            out[inode] = {inode: 0.0}
+    return out
+
+
+def amr_restriction(mesh, fe, mode="reference"):
     """hanging-node constraints of a non-homogeneous level: dict  hanging dof -> {master dof: weight}  with chains
-    through intermediate levels resolved down to real masters (Mesh.cpp:1352-1830)."""
+    through intermediate levels resolved down to real masters (Mesh.cpp:1352-1830).
+    mode "reference": the map exactly as the reference builds it -- every pair of levels (ilevel < jlevel) writes
+    restriction[master][hanging] (a later pair overwrites an earlier entry of the same key), then resolve_genealogy.  Where a node
+    lies on interfaces with two coarser levels at once (3-D edges with a level jump of two) the weights of its row do not sum to
+    one; this is the reference's result.  mode "coarsest": only the description to the coarsest level is kept for such a node and
+    chains are fully expanded, which reproduces polynomials (the consistent variant; NOT what the reference computes)."""
+    assert mode in ("reference", "coarsest")
     geom = mesh.geom
     nc = fo.ndofs(geom, fe)
     fn = fo.face_nodes(geom)
@@ -216,6 +263,7 @@ def amr_restriction(mesh, fe):
             loc = sorted(set(int(n) for f in fs for n in fn[f] if n < nc))
             inter[lev[iel]].append((iel, loc))
     raw = {}                                      # hanging dof -> {master: weight}
+    rest = {}                                     # reference mode: master -> {son: value}, diagonal 1 / 10 (:1560-1567)
     owner_level = {}                              # coarse level whose elements constrain the dof
     for a, Lc in enumerate(levels):
         for Lf in levels[a + 1:]:
@@ -242,13 +290,26 @@ def amr_restriction(mesh, fe):
                         continue
                     # A node lying on the interfaces with two coarser levels at once (3-D edges with a level jump of
                     # two) has two mathematically identical descriptions; the one to the coarsest level is kept.
-                    if owner_level.setdefault(ldof, Lc) != Lc:
+                    if mode == "coarsest" and owner_level.setdefault(ldof, Lc) != Lc:
                         continue
                     phi, _, _ = fo.eval_basis(geom, fe, xi[None, :])
                     for n in loc:
                         v = phi[0, n]
                         if abs(v) >= 1.0e-10:
-                            raw.setdefault(ldof, {})[int(mesh.elem_dof[iel, n])] = float(v)
+                            jdof = int(mesh.elem_dof[iel, n])
+                            raw.setdefault(ldof, {})[jdof] = float(v)
+                            rest.setdefault(jdof, {}).setdefault(jdof, 1.0)
+                            rest[jdof][ldof] = float(v)
+                            rest.setdefault(ldof, {})[ldof] = 10.0
+    if mode == "reference":
+        final = resolve_genealogy(rest)
+        hanging = sorted(d for d, r in rest.items() if r[d] > 5.0)
+        out = {h: {} for h in hanging}
+        for m_, row in final.items():
+            for son, w in row.items():
+                if son != m_:
+                    out[son][m_] = w
+        return out
     # resolve masters that are themselves hanging
     resolved = {}
 
@@ -271,11 +332,11 @@ def amr_restriction(mesh, fe):
     return resolved
 
 
-def build_amr_prolongator(mesh, fe):
+def build_amr_prolongator(mesh, fe, mode="reference"):
     """P_amr (n x n): identity rows for regular dofs; row of a hanging dof = its master weights plus an explicit
     zero on the diagonal (the reference inserts restriction[son][son] = 0)"""
     n = fo.n_dofs(mesh, fe)
-    R = amr_restriction(mesh, fe)
+    R = amr_restriction(mesh, fe, mode)
     rows, cols, vals = [], [], []
     for i in range(n):
         if i in R:
@@ -305,7 +366,7 @@ def build_amr_levels(nx, ny, nz, n_uniform, n_selective, flag_fn, lo=(0., 0., 0.
     return ms
 
 
-def build_amr_hierarchy(meshes, fe, rhs_vec, order="seventh"):
+def build_amr_hierarchy(meshes, fe, rhs_vec, order="seventh", mode="reference"):
     """LinearImplicitSystem::init + one MGsolve preparation on an AMR mesh stack: returns A[l] (penalised), P[l],
     P_amr[l] (None on homogeneous levels), bdc[l] (Dirichlet + hanging), b (projected, zeroed on bdc)"""
     nl = len(meshes)
@@ -314,7 +375,7 @@ def build_amr_hierarchy(meshes, fe, rhs_vec, order="seventh"):
     H.Pamr, H.hanging = [None] * nl, [np.zeros(0, dtype=np.int64)] * nl
     for l, m in enumerate(meshes):
         if not getattr(m, "homogeneous", True):
-            H.Pamr[l], H.hanging[l] = build_amr_prolongator(m, fe)
+            H.Pamr[l], H.hanging[l] = build_amr_prolongator(m, fe, mode)
     H.bdc = [np.union1d(fo.dirichlet_dofs(m, fe), H.hanging[l]) for l, m in enumerate(meshes)]
     H.P = [None] * nl
     for l in range(1, nl):

@@ -37,15 +37,21 @@ def poly_rhs(dim):
 CASES = [((2, 2, 0), 1, 2, ex4_flag), ((2, 2, 2), 1, 2, ex4_flag), ((2, 2, 2), 2, 1, corner_flag), ((3, 2, 0), 2, 2, ex4_flag)]
 
 
+def edge_flag(x, level):
+    """level 0 | level 1 | level 2 meet along the line x = y = 0.5: a level-2 node there lies on interfaces with TWO coarser levels"""
+    return x[0] > 0.5 if level == 0 else (x[0] > 0.5 and x[1] > 0.5)
+
+
 @pytest.mark.parametrize("box,nu,ns,flag", CASES)
 @pytest.mark.parametrize("fe", ["biquadratic", "linear"])
 def test_oracle_partition_of_unity_and_interpolation(box, nu, ns, flag, fe):
+    """the CONSISTENT variant of the constraints (mode "coarsest"): rows sum to one, polynomials are reproduced"""
     ms = fa.build_amr_levels(*box, nu, ns, flag)
     assert not ms[-1].homogeneous
     for m in ms:
         if m.homogeneous:
             continue
-        P, hang = fa.build_amr_prolongator(m, fe)
+        P, hang = fa.build_amr_prolongator(m, fe, "coarsest")
         assert hang.size > 0
         # weights of every hanging node sum to one; its masters are regular nodes
         assert abs(np.asarray(P.sum(axis=1)).ravel() - 1.0).max() < 1e-14
@@ -66,7 +72,7 @@ def test_oracle_q2_polynomial_is_solved_exactly(box, nu, ns, flag):
     """u = prod x_d (1 - x_d) lies in the constrained Q2 space of any adaptive box mesh, so the Galerkin solution is u
     itself: a wrong hanging-node weight, a missed constraint or a discontinuity would show up at O(h^2), not 1e-13"""
     ms = fa.build_amr_levels(*box, nu, ns, flag)
-    H = fa.build_amr_hierarchy(ms, "biquadratic", poly_rhs(ms[0].dim))
+    H = fa.build_amr_hierarchy(ms, "biquadratic", poly_rhs(ms[0].dim), mode="coarsest")
     x = spla.spsolve(H.A[-1].tocsc(), H.b)
     x = H.Pamr[-1] @ x
     X = ms[-1].coords
@@ -98,17 +104,51 @@ def test_host_refinement_matches_oracle_bit_exact(box, nu, ns, flag):
         a.destroy()
 
 
-@pytest.mark.parametrize("box,nu,ns,flag", CASES)
+def test_reference_map_at_a_node_on_two_interfaces():
+    """Mesh::GetAMRRestrictionAndAMRSolidMark as written (Mesh.cpp:1352-1830): on the line where level 0, 1 and 2 meet, the pair
+    (1, 2) overwrites the entries the pair (0, 2) wrote for the masters both descriptions share, and the genealogy walk skips the path
+    through the intermediate hanging node ("alreadyFound").  Hand-computed for the Q2 node at 1/8 of a level-0 edge [a, m, b] that is
+    also at the middle of the first half [a, g, m] of a level-1 edge: kept weights w1_a = 0.375 (level-1 description), w1_m = -0.125,
+    w0_b = -0.09375 (level-0 description): sum 0.15625 -- not one.  Both variants agree on every other node."""
+    ms = fa.build_amr_levels(2, 2, 2, 1, 2, edge_flag)
+    for fe in ("linear", "biquadratic"):
+        ref, con = fa.amr_restriction(ms[-1], fe, "reference"), fa.amr_restriction(ms[-1], fe, "coarsest")
+        assert sorted(ref) == sorted(con)
+        sums = {h: sum(r.values()) for h, r in ref.items()}
+        odd = [h for h, v in sums.items() if abs(v - 1.0) > 1e-12]
+        assert all(abs(sum(r.values()) - 1.0) < 1e-13 for r in con.values())
+        X = ms[-1].coords
+        # only next to the line where the three levels meet: the node on it, and the level-2 nodes of the level-1 face y = 0.5 whose
+        # masters include a level-1 node that hangs on level 0 itself (direct entry kept, path through that node dropped)
+        assert odd and all(abs(X[h][1] - 0.5) < 1e-14 and 0.5 - 1e-14 <= X[h][0] <= 0.75 for h in odd)
+        for h in ref:
+            if h not in odd:
+                assert set(ref[h]) == set(con[h]) and max(abs(ref[h][m_] - con[h][m_]) for m_ in ref[h]) < 1e-14
+        if fe == "biquadratic":
+            assert any(abs(sums[h] - 0.15625) < 1e-14 and sorted(np.round(list(ref[h].values()), 12)) == [-0.125, -0.09375, 0.375] for h in odd)
+
+
+def test_single_level_jumps_give_the_same_map_in_both_variants():
+    ms = fa.build_amr_levels(2, 2, 2, 2, 1, corner_flag)
+    for fe in ("linear", "biquadratic"):
+        ref, con = fa.amr_restriction(ms[-1], fe, "reference"), fa.amr_restriction(ms[-1], fe, "coarsest")
+        assert sorted(ref) == sorted(con) and len(ref) > 0
+        for h in ref:
+            assert set(ref[h]) == set(con[h]) and max(abs(ref[h][m_] - con[h][m_]) for m_ in ref[h]) < 1e-14
+
+
+@pytest.mark.parametrize("mode", ["reference", "coarsest"])
+@pytest.mark.parametrize("box,nu,ns,flag", CASES + [((2, 2, 2), 1, 2, edge_flag)])
 @pytest.mark.parametrize("fe", ["biquadratic", "linear"])
-def test_host_constraints_match_oracle(box, nu, ns, flag, fe):
+def test_host_constraints_match_oracle(box, nu, ns, flag, fe, mode):
     mo = fa.build_amr_levels(*box, nu, ns, flag)
-    mh = [capi.Mesh.box(*box)]
+    mh = [capi.Mesh.box(*box).set_amr_mode(mode)]
     for l in range(1, nu + ns):
         flags = np.ones(mh[-1].nel, np.uint8) if l < nu else mh[-1].flag_elements(flag)
         mh.append(mh[-1].refine_flagged(flags))
     for a, b in zip(mh, mo):
         hang, ptr, master, w = a.amr_constraints(fe)
-        R = fa.amr_restriction(b, fe) if not b.homogeneous else {}
+        R = fa.amr_restriction(b, fe, mode) if not b.homogeneous else {}
         assert np.array_equal(hang, np.array(sorted(R), dtype=np.int64))     # integer work: identical
         for k, l in enumerate(hang):
             row = sorted(R[int(l)].items())

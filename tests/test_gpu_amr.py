@@ -10,7 +10,7 @@ from femus_amd.poisson import PoissonMG
 from oracle import femus_oracle as fo
 from oracle import femus_oracle_amr as fa
 
-from test_amr_host import CASES, ex4_flag, poly_rhs
+from test_amr_host import CASES, edge_flag, ex4_flag, poly_rhs
 
 pytestmark = pytest.mark.gpu
 
@@ -19,22 +19,26 @@ def rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-def amr_meshes(box, nu, ns, flag):
-    ms = [capi.Mesh.box(*box)]
+def amr_meshes(box, nu, ns, flag, mode="reference"):
+    ms = [capi.Mesh.box(*box).set_amr_mode(mode)]
     for l in range(1, nu + ns):
         flags = np.ones(ms[-1].nel, np.uint8) if l < nu else ms[-1].flag_elements(flag)
         ms.append(ms[-1].refine_flagged(flags))
     return ms
 
 
-@pytest.mark.parametrize("box,nu,ns,flag", CASES)
+@pytest.mark.parametrize("mode", ["reference", "coarsest"])
+@pytest.mark.parametrize("box,nu,ns,flag", CASES + [((2, 2, 2), 1, 2, edge_flag)])
 @pytest.mark.parametrize("fe", ["biquadratic", "linear"])
-def test_amr_hierarchy_matches_oracle(ctx, box, nu, ns, flag, fe):
+def test_amr_hierarchy_matches_oracle(ctx, box, nu, ns, flag, fe, mode):
+    """mode "reference": the restriction map exactly as Mesh::GetAMRRestrictionAndAMRSolidMark builds it (default of the library and of
+    the oracle); "coarsest": the consistent variant.  Every operator and the solve against the oracle in the same mode; the Q2
+    polynomial is reproduced by the consistent variant on every mesh"""
     dim = 2 if box[2] == 0 else 3
     mo = fa.build_amr_levels(*box, nu, ns, flag)
-    H = fa.build_amr_hierarchy(mo, fe, poly_rhs(dim))
+    H = fa.build_amr_hierarchy(mo, fe, poly_rhs(dim), mode=mode)
     nl = nu + ns
-    pb = PoissonMG(ctx, *box, nl, fe=fe, source_kind=3, params=(-2.0, 1.0), meshes=amr_meshes(box, nu, ns, flag)).init()
+    pb = PoissonMG(ctx, *box, nl, fe=fe, source_kind=3, params=(-2.0, 1.0), meshes=amr_meshes(box, nu, ns, flag, mode)).init()
     for l in range(nl):
         assert np.array_equal(pb.bdc[l], H.bdc[l])                         # Dirichlet + hanging rows: integer, identical
         if H.Pamr[l] is not None:
@@ -52,7 +56,7 @@ def test_amr_hierarchy_matches_oracle(ctx, box, nu, ns, flag, fe):
     pb.update_sol()
     xd = H.Pamr[-1] @ spla.spsolve(H.A[-1].tocsc(), H.b)
     assert rel(pb.SOL.to_numpy(), xd) < 1e-10
-    if fe == "biquadratic":
+    if fe == "biquadratic" and mode == "coarsest":
         _, xy, _ = pb.meshes[-1].arrays()
         assert abs(pb.SOL.to_numpy() - np.prod(xy * (1 - xy), axis=1)).max() < 1e-12
     pb.destroy()
@@ -62,7 +66,7 @@ def test_amr_q2_exactness_larger_mesh(ctx):
     """8^3 coarse, one uniform + two selective levels (MGAMR-style, 3-D): 54k elements with level jumps of one and two;
     the Q2 polynomial must come back to solver tolerance and the hanging values must equal the interpolated ones"""
     box, nu, ns = (4, 4, 4), 2, 2
-    pb = PoissonMG(ctx, *box, nu + ns, source_kind=3, params=(-2.0, 1.0), meshes=amr_meshes(box, nu, ns, ex4_flag)).init()
+    pb = PoissonMG(ctx, *box, nu + ns, source_kind=3, params=(-2.0, 1.0), meshes=amr_meshes(box, nu, ns, ex4_flag, "coarsest")).init()
     assert pb.hanging[-1].size > 1000 and pb.hanging[-2].size > 100
     pb.assemble()
     pb.prepare()
