@@ -55,6 +55,20 @@ def assemble_poisson(mesh_elem_dof, coords, fe, geom, e0, e1, sol=None, source_k
     assert rc == 0
 
 
+def assemble_poisson_all_cores(mesh_elem_dof, coords, fe, geom, csr, sol=None, source_kind=0, p0=1.0, p1=0.0, order="seventh"):
+    """the whole element loop with OpenMP over the usable cores (timed CPU baseline: owner-computes element ranges, atomic adds)"""
+    et = fo.ElemType(geom, fe, order)
+    ed = np.ascontiguousarray(mesh_elem_dof, dtype=np.int32)
+    xy = np.ascontiguousarray(coords, dtype=np.float64)
+    w, phi, dphi = np.ascontiguousarray(et.w), np.ascontiguousarray(et.phi), np.ascontiguousarray(et.dphi)
+    s = None if sol is None else np.ascontiguousarray(sol, dtype=np.float64)
+    rowptr, col, val, res = csr
+    c_d = ctypes.c_double
+    rc = lib().oc_assemble_poisson_omp(et.dim, et.nc, et.ng, _p(w), _p(phi), _p(dphi), ed.shape[0], ed.shape[1], _p(ed), _p(xy), _p(s),
+                                       int(source_kind), c_d(p0), c_d(p1), _p(rowptr), _p(col), _p(val), _p(res))
+    assert rc == 0
+
+
 def spmv(A, x, y, mode=0, b=None, dinv=None, omega=0.0):
     """A: scipy csr with int32 indices"""
     lib().oc_spmv(A.shape[0], _p(A.indptr), _p(A.indices), _p(A.data), _p(x), _p(y), int(mode), _p(b), _p(dinv), ctypes.c_double(omega))

@@ -145,6 +145,73 @@ int oc_assemble_poisson(int dim, int nc, int ng, const double* w, const double* 
   return 0;
 }
 
+/* The same loop over ALL elements [0, nel) on every core of the host (timed CPU baseline only): each thread takes a contiguous
+ * range of elements -- the owner-computes split of the reference's MPI ranks (Mesh.cpp:589-616) -- and the adds into rows shared
+ * with a neighbouring range are atomic, standing in for the stash exchange of MatAssemblyBegin/End.  The summation order is not
+ * the sequential one, so parity tests keep using oc_assemble_poisson. */
+int oc_assemble_poisson_omp(int dim, int nc, int ng, const double* w, const double* phi, const double* dphi, int nel, int nloc,
+                            const int* elem_dof, const double* coords, const double* sol, int source_kind, double p0, double p1,
+                            const int* rowptr, const int* col, double* val, double* res) {
+  int bad = 0;
+#pragma omp parallel
+  {
+    double x[27 * 3], u[27], grad[27 * 3], K[27 * 27], F[27];
+    int dofs[27];
+#pragma omp for schedule(static)
+    for (int e = 0; e < nel; e++) {
+      for (int n = 0; n < nc; n++) {
+        dofs[n] = elem_dof[(size_t)e * nloc + n];
+        for (int d = 0; d < dim; d++) x[n * dim + d] = coords[(size_t)dofs[n] * dim + d];
+        u[n] = sol ? sol[dofs[n]] : 0.0;
+      }
+      memset(K, 0, sizeof(double) * nc * nc);
+      memset(F, 0, sizeof(double) * nc);
+      for (int g = 0; g < ng; g++) {
+        double weight;
+        jacobian(dim, nc, dphi + (size_t)g * nc * dim, x, w[g], &weight, grad);
+        double gu[3] = {0, 0, 0}, xg[3] = {0, 0, 0};
+        for (int i = 0; i < nc; i++)
+          for (int d = 0; d < dim; d++) {
+            gu[d] += grad[i * dim + d] * u[i];
+            xg[d] += x[i * dim + d] * phi[g * nc + i];
+          }
+        const double f = source(source_kind, p0, p1, xg, dim);
+        for (int i = 0; i < nc; i++) {
+          double wl = 0.0;
+          for (int d = 0; d < dim; d++) wl += grad[i * dim + d] * gu[d];
+          F[i] += (-f * phi[g * nc + i] - wl) * weight;
+          for (int j = 0; j < nc; j++) {
+            double wlj = 0.0;
+            for (int d = 0; d < dim; d++) wlj += grad[i * dim + d] * grad[j * dim + d];
+            K[i * nc + j] += wlj * weight;
+          }
+        }
+      }
+      for (int i = 0; i < nc; i++) {
+        const int row = dofs[i];
+#pragma omp atomic
+        res[row] += F[i];
+        for (int j = 0; j < nc; j++) {
+          int lo = rowptr[row], hi = rowptr[row + 1] - 1, target = dofs[j], pos = -1;
+          while (lo <= hi) {
+            int mid = (lo + hi) >> 1;
+            if (col[mid] == target) { pos = mid; break; }
+            if (col[mid] < target) lo = mid + 1; else hi = mid - 1;
+          }
+          if (pos < 0) {
+#pragma omp atomic write
+            bad = 1;
+            continue;
+          }
+#pragma omp atomic
+          val[pos] += K[i * nc + j];
+        }
+      }
+    }
+  }
+  return bad;
+}
+
 /* mode 0: y = A x ; 1: y += A x ; 2: y = b - A x ; 3: y = x + omega*dinv*(b - A x) */
 void oc_spmv(int m, const int* rowptr, const int* col, const double* val, const double* x, double* y, int mode, const double* b,
              const double* dinv, double omega) {
