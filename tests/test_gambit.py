@@ -83,3 +83,33 @@ def test_reader_orders_elements_by_material_then_group(tmp_path):
     # first-touch numbering of the reordered elements: vertices of the first element come first
     assert sorted(ed[0, :4].tolist()) == [0, 1, 2, 3]
     m.destroy()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+def test_reader_on_the_curved_mesh_of_testNSSteadyDD():
+    """unittests/testNSSteadyDD/input/nsbenc.neu (the mesh behind the reference's stored norms, main.cpp:202-244): 98 curved QUAD9
+    elements around a cylinder, 3 element groups, 4 boundary sets -- every element comes out right-handed in FEMuS local order with
+    edge nodes between their vertices, every node belongs to an element, and the boundary faces are exactly the faces met once"""
+    m = capi.Mesh.read_gambit(os.path.join(os.path.dirname(REF), "unittests/testNSSteadyDD/input/nsbenc.neu"))
+    ed, xy, ff = m.arrays()
+    assert (m.nel, m.nnode, m.dim) == (98, 442, 2)
+    assert set(np.unique(ff).tolist()) == {-5, -4, -3, -2, -1}                        # sets 1..4 -> flags -2..-5 (GambitIO.cpp:337)
+    assert np.unique(ed).size == 442
+    edge_v = [(0, 1), (1, 2), (2, 3), (3, 0)]
+    seen = {}
+    for e in range(m.nel):
+        X = xy[ed[e]]
+        area = 0.5 * sum(X[a][0] * X[b][1] - X[b][0] * X[a][1] for a, b in edge_v)
+        assert area > 0                                                                # counter-clockwise
+        for k, (a, b) in enumerate(edge_v):
+            assert np.linalg.norm(X[4 + k] - 0.5 * (X[a] + X[b])) < 0.2 * np.linalg.norm(X[a] - X[b])     # mid node near the chord
+            key = tuple(sorted((int(ed[e, a]), int(ed[e, b]))))
+            seen.setdefault(key, []).append((e, k))
+    for key, uses in seen.items():
+        assert len(uses) in (1, 2)
+        for e, k in uses:
+            assert (ff[e, k] < -1) == (len(uses) == 1)                                 # boundary set <=> an edge met once
+    # refinement of the curved mesh: children keep the orientation, node count as for any QUAD9 refinement
+    f = m.refine()
+    assert f.nel == 4 * 98
+    m.destroy(), f.destroy()
