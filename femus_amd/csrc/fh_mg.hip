@@ -1119,7 +1119,11 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
   mg->setup_done = true;
   FH_TRY(run_cycle(mg));   // un-captured warm-up: builds lazily created row blocks, validates the launches
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
-  if (c->use_graph && !distributed) {
+  // distributed cycles are NOT captured: stream capture of the grouped ncclSend/ncclRecv (forked communication stream) was tried on
+  // this stack (RCCL 2.26.6 of the PyTorch wheel, one-rank self exchange) and segfaults inside the library at capture time; the
+  // launches of a distributed cycle are issued one by one
+  const bool capturable = !distributed;
+  if (c->use_graph && capturable) {
     // capture one cycle on the internal buffers and keep it for replay
     FH_CHECK_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     int rc = run_cycle(mg);

@@ -115,3 +115,16 @@ def test_rccl_calls_execute_on_one_device_by_self_exchange():
     s.close()
     ok, msg = rccl_preflight.run(0, 1, "127.0.0.1", port, 0, timeout=240.0)
     assert ok, msg
+
+
+def test_distributed_cycle_with_rccl_exchanges_on_one_device():
+    """tests/rccl_cycle_probe.py: a periodic problem as one rank's share of a distributed hierarchy, ghosts received from the rank itself
+    through ncclSend/ncclRecv, replicated coarse level through ncclAllReduce -- the whole distributed V-cycle with RCCL on this GPU,
+    with and without the interior / interface overlap, against the serial numpy cycle.  Child process with a time limit: a hang of
+    a collective must fail the test, not the box."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_cycle_probe.py")], capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0 and "PROBE OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
