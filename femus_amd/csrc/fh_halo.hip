@@ -151,7 +151,7 @@ extern "C" int fh_halo_sizes(fh_halo_t h, int* nsend, int* nrecv) {
 }
 
 int fh_halo_update_ptr(fh_halo_t h, double* vd, int n_owned);
-int fh_halo_begin_ptr(fh_halo_t h, double* vd, int n_owned);
+int fh_halo_begin_ptr(fh_halo_t h, double* vd, int n_owned, bool prepacked = false);
 int fh_halo_end_ptr(fh_halo_t h);
 
 extern "C" int fh_halo_update(fh_halo_t h, fh_vec_t v) {
@@ -199,12 +199,21 @@ int fh_halo_allreduce_ptr(fh_halo_t h, double* d, int n) {
 // start the exchange of the ghosts of vd ([owned | ghost]): pack on the compute stream, transfer on the communication stream.
 // Work queued on the compute stream after this call and before fh_halo_end_ptr overlaps with the exchange; it must not read
 // the ghost tail.
-int fh_halo_begin_ptr(fh_halo_t h, double* vd, int n_owned) {
+// the send plan of an exchange, for producers that fill the send buffer themselves (the first smoother sweep writes its interface
+// entries straight into it: one launch less per level and cycle); follow with fh_halo_begin_ptr(..., prepacked = true)
+void fh_halo_send_plan(fh_halo_t h, const int** send_idx, double** sendbuf, int* nsend) {
+  const bool live = h && !halo_inert(h);
+  *send_idx = live ? h->d_send_idx : nullptr;
+  *sendbuf = live ? h->d_sendbuf : nullptr;
+  *nsend = live ? h->nsend : 0;
+}
+
+int fh_halo_begin_ptr(fh_halo_t h, double* vd, int n_owned, bool prepacked) {
   if (halo_inert(h)) return 0;
   FH_REQUIRE(!h->pending, "fh_halo_begin: the previous exchange of this plan has not been ended");
   fh_ctx_t c = h->ctx;
   const bool prof = c->halo_profile != 0;
-  if (h->nsend) {
+  if (h->nsend && !prepacked) {
     int nb = std::max(1, std::min(fh_div_up(h->nsend, 256), c->num_cu * 4));
     hipLaunchKernelGGL(k_pack, dim3(nb), dim3(256), 0, c->stream, vd, h->d_send_idx, h->d_sendbuf, h->nsend);
     FH_CHECK_HIP(hipGetLastError());
@@ -270,13 +279,15 @@ int fh_halo_update_ptr(fh_halo_t h, double* vd, int n_owned) {
 // behind NumericVector::matrix_mult (PetscVector.cpp:203-214): start the ghost scatter, multiply the rows that need no ghost
 // while it is in flight (compute stream), wait, multiply the rest.  n_own = owned entries of x (the operator's columns below
 // n_own are local).  h == NULL: plain product.
-int fh_dev_halo_spmv(fh_halo_t h, fh_mat_t A, double* x, int n_own, double* y, int mode, const double* b, const double* dinv, double omega) {
+int fh_dev_halo_spmv(fh_halo_t h, fh_mat_t A, double* x, int n_own, double* y, int mode, const double* b, const double* dinv, double omega,
+                     bool prepacked) {
   if (!h) return fh_dev_spmv(A, x, y, mode, b, dinv, omega);
   if (!A->ctx->halo_overlap) {
-    FH_TRY(fh_halo_update_ptr(h, x, n_own));
+    FH_TRY(fh_halo_begin_ptr(h, x, n_own, prepacked));
+    FH_TRY(fh_halo_end_ptr(h));
     return fh_dev_spmv(A, x, y, mode, b, dinv, omega);
   }
-  FH_TRY(fh_halo_begin_ptr(h, x, n_own));
+  FH_TRY(fh_halo_begin_ptr(h, x, n_own, prepacked));
   FH_TRY(fh_dev_spmv_part(A, n_own, 0, x, y, mode, b, dinv, omega));
   FH_TRY(fh_halo_end_ptr(h));
   return fh_dev_spmv_part(A, n_own, 1, x, y, mode, b, dinv, omega);
@@ -290,7 +301,7 @@ extern "C" int fh_spmv_ghosted(fh_mat_t A, fh_halo_t halo, fh_vec_t x, fh_vec_t 
   FH_REQUIRE(mode >= 0 && mode <= 3, "fh_spmv_ghosted: unknown mode %d", mode);
   FH_REQUIRE(mode < 2 || (b && b->n_local >= A->m), "fh_spmv_ghosted: mode %d needs b", mode);
   FH_REQUIRE(mode < 3 || (dinv && dinv->n_local >= A->m && A->m <= A->n), "fh_spmv_ghosted: mode 3 needs dinv and owned rows over [owned | ghost] columns");
-  return fh_dev_halo_spmv(halo, A, x->d, x->n_local, y->d, mode, b ? b->d : nullptr, dinv ? dinv->d : nullptr, omega);
+  return fh_dev_halo_spmv(halo, A, x->d, x->n_local, y->d, mode, b ? b->d : nullptr, dinv ? dinv->d : nullptr, omega, false);
 }
 
 extern "C" int fh_halo_begin(fh_halo_t h, fh_vec_t v) {

@@ -125,6 +125,8 @@ int fh_dev_spmv(fh_mat_t A, const double* x, double* y, int mode, const double* 
 int fh_dev_spmv_part(fh_mat_t A, int n_own_cols, int part, const double* x, double* y, int mode, const double* b, const double* dinv, double omega);
 
 // y = op(A, x) for an operator over [owned | ghost] columns: ghost exchange of x overlapped with the rows that need no ghost
-int fh_dev_halo_spmv(fh_halo_t h, fh_mat_t A, double* x, int n_own, double* y, int mode, const double* b, const double* dinv, double omega);
+int fh_dev_halo_spmv(fh_halo_t h, fh_mat_t A, double* x, int n_own, double* y, int mode, const double* b, const double* dinv, double omega,
+                     bool prepacked = false);
+void fh_halo_send_plan(fh_halo_t h, const int** send_idx, double** sendbuf, int* nsend);
 
 static inline int fh_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -19,7 +19,6 @@
 
 int fh_dev_get_diag(fh_mat_t A, double* d, int invert);
 int fh_halo_update_ptr(fh_halo_t h, double* vd, int n_owned);
-int fh_halo_begin_ptr(fh_halo_t h, double* vd, int n_owned);
 int fh_halo_end_ptr(fh_halo_t h);
 int fh_halo_allreduce_ptr(fh_halo_t h, double* d, int n);
 
@@ -71,9 +70,15 @@ struct fh_mg_s {
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
+// sweep 1 from a zero guess; on a distributed level the interface entries go straight into the send buffer of the exchange that
+// follows (the pack kernel fused into the sweep: nsend > 0)
 __global__ __launch_bounds__(256) void k_first_sweep(double* __restrict__ x, const double* __restrict__ b, const double* __restrict__ dinv,
-                                                     double omega, int n) {
+                                                     double omega, int n, const int* __restrict__ send_idx, double* __restrict__ sendbuf, int nsend) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) x[i] = omega * dinv[i] * b[i];
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < nsend; k += gridDim.x * 256) {
+    const int i = send_idx[k];
+    sendbuf[k] = omega * dinv[i] * b[i];
+  }
 }
 
 // one colour of a Gauss-Seidel sweep on A z = r: z_i = dinv_i (r_i - sum_{j != i} a_ij z_j) for the rows of the colour
@@ -752,8 +757,9 @@ __global__ __launch_bounds__(256) void k_axpby2(double* y, const double* x, doub
 
 static inline int sgrid(fh_ctx_t c, int n) { return std::max(1, std::min(fh_div_up(n, 256), c->num_cu * 8)); }
 
-static inline int halo_spmv(fh_halo_t h, fh_mat_t A, double* x, int n_own, double* y, int mode, const double* b, const double* dinv, double omega) {
-  return fh_dev_halo_spmv(h, A, x, n_own, y, mode, b, dinv, omega);
+static inline int halo_spmv(fh_halo_t h, fh_mat_t A, double* x, int n_own, double* y, int mode, const double* b, const double* dinv, double omega,
+                            bool prepacked = false) {
+  return fh_dev_halo_spmv(h, A, x, n_own, y, mode, b, dinv, omega, prepacked);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1177,6 +1183,7 @@ static int run_cycle(fh_mg_t mg) {
   const int top = mg->nlevels - 1;
   for (int l = top; l >= 1; l--) {
     MgLevel& L = mg->lv[l];
+    bool packed = false;
     if (L.npre == 0) {
       FH_CHECK_HIP(hipMemsetAsync(L.x, 0, (size_t)L.ncols * sizeof(double), c->stream));
     } else if (L.smoother == FH_SMOOTH_VANKA) {
@@ -1186,13 +1193,19 @@ static int run_cycle(fh_mg_t mg) {
       FH_TRY(gs_sweeps(mg, L, L.npre, true));
     } else {
       // sweep 1 from a zero guess: x = omega D^-1 b ; sweeps 2..npre: fused Jacobi SpMV, ping-pong x <-> x2
-      hipLaunchKernelGGL(k_first_sweep, dim3(sgrid(c, L.n)), dim3(256), 0, c->stream, L.x, L.b, L.dinv, L.omega, L.n);
+      const int* sidx = nullptr;
+      double* sbuf = nullptr;
+      int nsend = 0;
+      if (L.halo) fh_halo_send_plan(L.halo, &sidx, &sbuf, &nsend);
+      hipLaunchKernelGGL(k_first_sweep, dim3(sgrid(c, L.n)), dim3(256), 0, c->stream, L.x, L.b, L.dinv, L.omega, L.n, sidx, sbuf, nsend);
+      packed = L.halo != nullptr;             // the exchange of this x needs no pack launch
       for (int s = 1; s < L.npre; s++) {
-        FH_TRY(halo_spmv(L.halo, L.A, L.x, L.n, L.x2, 3, L.b, L.dinv, L.omega));
+        FH_TRY(halo_spmv(L.halo, L.A, L.x, L.n, L.x2, 3, L.b, L.dinv, L.omega, packed));
+        packed = false;
         std::swap(L.x, L.x2);
       }
     }
-    FH_TRY(halo_spmv(L.halo, L.A, L.x, L.n, L.r, 2, L.b, nullptr, 0.0));             // r = b - A x (ghosts of x refreshed)
+    FH_TRY(halo_spmv(L.halo, L.A, L.x, L.n, L.r, 2, L.b, nullptr, 0.0, packed));     // r = b - A x (ghosts of x refreshed)
     // b_{l-1} = R r: the restriction reads ghost residuals, except into a replicated level (owned part, then all-reduce)
     FH_TRY(halo_spmv(L.replicated_below ? nullptr : L.halo, L.R, L.r, L.n, mg->lv[l - 1].b, 0, nullptr, nullptr, 0.0));
     if (L.halo && L.replicated_below) FH_TRY(fh_halo_allreduce_ptr(L.halo, mg->lv[l - 1].b, mg->lv[l - 1].n));
