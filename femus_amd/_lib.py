@@ -175,3 +175,9 @@ def _declare(L):
     sig("fh_mat_split_info", c_void_p, c_int, P(c_int), P(c_int))
     sig("fh_halo_allreduce_sum", c_void_p, c_void_p, c_int)
     sig("fh_halo_destroy", c_void_p)
+    sig("fh_dd_box_node_keys", c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p)
+    sig("fh_dd_plan_create", c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, P(c_void_p))
+    sig("fh_dd_plan_sizes", c_void_p, P(c_int), P(c_int), P(c_int))
+    sig("fh_dd_plan_get", c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)
+    sig("fh_dd_plan_halo", c_void_p, c_void_p, c_void_p, c_void_p, P(c_void_p))
+    sig("fh_dd_plan_destroy", c_void_p)

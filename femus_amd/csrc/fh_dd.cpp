@@ -1,0 +1,117 @@
+// Domain-decomposition planner behind the C-ABI (host-only, integer work): which nodes of a rank's local mesh it owns, which it
+// needs as ghosts, the [owned | ghost] renumbering and the send lists of the ghost exchange -- what the reference derives in
+// Mesh::dofmap_* (lowest rank touching a node owns it, Mesh.cpp:517-559; ghost node lists :767-795) and LinearEquation::InitPde
+// (KKghost_nd, LinearEquation.cpp:239-280) and hands to VecCreateGhost (PetscVector.hpp:515-569).
+// The only communication is one personalised all-to-all of 64-bit ids (every rank tells the owners which of their nodes it reads);
+// the caller provides it (MPI_Alltoallv in an MPI launcher, torch.distributed / sockets in the Python harness).
+#include "fh_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <numeric>
+
+struct fh_dd_plan_s {
+  int rank = 0, nranks = 1, n = 0;
+  std::vector<int> owned, ghost, newid, send_idx, send_counts, recv_counts;
+};
+
+// box partition of the structured hierarchy (the METIS stand-in): rank (c0, c1, c2) of a p0 x p1 x p2 grid owns the unit
+// cube [c, c + 1); a level-`level` mesh of nb coarse elements per unit has grid spacing 1 / (2 nb 2^level).  Global id = lexicographic
+// index of the (exact, dyadic) coordinates; owner = the rank whose cube holds the node, the LOWER rank on shared faces.
+extern "C" int fh_dd_box_node_keys(int n, const double* coords /* [n*3] */, int level, int nb, const int p[3], int64_t* gid, int* owner) {
+  FH_REQUIRE(n >= 0 && coords && p && gid && owner && nb >= 1 && level >= 0 && p[0] >= 1 && p[1] >= 1 && p[2] >= 1, "fh_dd_box_node_keys: bad arguments");
+  const int64_t S = (int64_t)2 * nb * ((int64_t)1 << level);
+  const int64_t G0 = p[0] * S + 1, G1 = p[1] * S + 1;
+  for (int i = 0; i < n; i++) {
+    int64_t k[3];
+    int oc[3];
+    for (int d = 0; d < 3; d++) {
+      k[d] = (int64_t)std::llround(coords[(size_t)i * 3 + d] * (double)S);
+      FH_REQUIRE(k[d] >= 0 && k[d] <= p[d] * S, "fh_dd_box_node_keys: node %d lies outside the partitioned box", i);
+      oc[d] = (int)std::min<int64_t>(k[d] / S, p[d] - 1);
+    }
+    gid[i] = k[0] + G0 * (k[1] + G1 * k[2]);
+    owner[i] = oc[0] + p[0] * (oc[1] + p[1] * oc[2]);
+  }
+  return 0;
+}
+
+extern "C" int fh_dd_plan_create(int rank, int nranks, int n, const int64_t* gid, const int* owner, const unsigned char* need,
+                                 fh_dd_alltoallv_fn alltoallv, void* user, fh_dd_plan_t* out) {
+  FH_REQUIRE(out && n >= 0 && (n == 0 || (gid && owner && need)) && nranks >= 1 && rank >= 0 && rank < nranks, "fh_dd_plan_create: bad arguments");
+  FH_REQUIRE(nranks == 1 || alltoallv, "fh_dd_plan_create: several ranks need the all-to-all function");
+  std::unique_ptr<fh_dd_plan_s> P(new fh_dd_plan_s());
+  P->rank = rank;
+  P->nranks = nranks;
+  P->n = n;
+  for (int i = 0; i < n; i++) {
+    FH_REQUIRE(owner[i] >= 0 && owner[i] < nranks, "fh_dd_plan_create: node %d has owner %d", i, owner[i]);
+    if (owner[i] == rank) P->owned.push_back(i);                 // ascending local id = the local FEMuS order
+    else if (need[i]) P->ghost.push_back(i);
+  }
+  std::sort(P->ghost.begin(), P->ghost.end(), [&](int a, int b) {   // by owner rank, then by global id
+    return owner[a] != owner[b] ? owner[a] < owner[b] : gid[a] < gid[b];
+  });
+  P->newid.assign(n, -1);
+  for (size_t k = 0; k < P->owned.size(); k++) P->newid[P->owned[k]] = (int)k;
+  for (size_t k = 0; k < P->ghost.size(); k++) P->newid[P->ghost[k]] = (int)(P->owned.size() + k);
+  P->recv_counts.assign(nranks, 0);
+  for (int g : P->ghost) P->recv_counts[owner[g]]++;
+  P->send_counts.assign(nranks, 0);
+  if (nranks > 1) {
+    // ask the owners: the global ids of my ghosts go out grouped by owner, the ids others need from me come back
+    std::vector<int64_t> req(P->ghost.size());
+    for (size_t k = 0; k < P->ghost.size(); k++) req[k] = gid[P->ghost[k]];
+    FH_REQUIRE(alltoallv(user, nullptr, P->recv_counts.data(), nullptr, P->send_counts.data()) == 0, "fh_dd_plan_create: the count exchange failed");
+    int tot = 0;
+    for (int r = 0; r < nranks; r++) {
+      FH_REQUIRE(P->send_counts[r] >= 0, "fh_dd_plan_create: negative count from rank %d", r);
+      tot += P->send_counts[r];
+    }
+    std::vector<int64_t> got(std::max(tot, 1));
+    FH_REQUIRE(alltoallv(user, req.data(), P->recv_counts.data(), got.data(), P->send_counts.data()) == 0, "fh_dd_plan_create: the id exchange failed");
+    std::vector<int> srt(P->owned.size());
+    std::iota(srt.begin(), srt.end(), 0);
+    std::sort(srt.begin(), srt.end(), [&](int a, int b) { return gid[P->owned[a]] < gid[P->owned[b]]; });
+    P->send_idx.resize(tot);
+    for (int k = 0; k < tot; k++) {
+      const int64_t g = got[k];
+      auto it = std::lower_bound(srt.begin(), srt.end(), g, [&](int a, int64_t v) { return gid[P->owned[a]] < v; });
+      FH_REQUIRE(it != srt.end() && gid[P->owned[*it]] == g, "fh_dd_plan_create: a requested node (global id %lld) is not owned by rank %d", (long long)g, rank);
+      P->send_idx[k] = *it;                                      // position among the owned entries = index into the owned part of a vector
+    }
+  }
+  *out = P.release();
+  return 0;
+}
+
+extern "C" int fh_dd_plan_sizes(fh_dd_plan_t P, int* n_owned, int* n_ghost, int* n_send) {
+  FH_REQUIRE(P, "fh_dd_plan_sizes: null plan");
+  if (n_owned) *n_owned = (int)P->owned.size();
+  if (n_ghost) *n_ghost = (int)P->ghost.size();
+  if (n_send) *n_send = (int)P->send_idx.size();
+  return 0;
+}
+
+extern "C" int fh_dd_plan_get(fh_dd_plan_t P, int* owned, int* ghost, int* newid, int* send_counts, int* send_idx, int* recv_counts) {
+  FH_REQUIRE(P, "fh_dd_plan_get: null plan");
+  if (owned) std::copy(P->owned.begin(), P->owned.end(), owned);
+  if (ghost) std::copy(P->ghost.begin(), P->ghost.end(), ghost);
+  if (newid) std::copy(P->newid.begin(), P->newid.end(), newid);
+  if (send_counts) std::copy(P->send_counts.begin(), P->send_counts.end(), send_counts);
+  if (send_idx) std::copy(P->send_idx.begin(), P->send_idx.end(), send_idx);
+  if (recv_counts) std::copy(P->recv_counts.begin(), P->recv_counts.end(), recv_counts);
+  return 0;
+}
+
+// the exchange plan of this level on the device: RCCL (id128 of rank 0 / a parent plan's communicator) or the host-staged transport
+extern "C" int fh_dd_plan_halo(fh_dd_plan_t P, fh_ctx_t ctx, const char id128[128], fh_halo_t parent, fh_halo_t* halo) {
+  FH_REQUIRE(P && ctx && halo, "fh_dd_plan_halo: null argument");
+  if (parent) return fh_halo_create_shared(parent, P->send_counts.data(), P->send_idx.data(), P->recv_counts.data(), halo);
+  return fh_halo_create(ctx, P->rank, P->nranks, id128, P->send_counts.data(), P->send_idx.data(), P->recv_counts.data(), halo);
+}
+
+extern "C" int fh_dd_plan_destroy(fh_dd_plan_t P) {
+  delete P;
+  return 0;
+}

@@ -12,7 +12,8 @@ setup.  Per level the plan holds: owned nodes (local FEMuS order), ghost nodes g
 the [owned | ghost] renumbering used by the row-restricted operators.  One extra, replicated level below the rank-local
 coarse level (global coarse mesh coarsened once, <= 4913 dofs) replaces the single-GPU exact coarse solve.
 
-Pure numpy/scipy + the host-only mesh entry points of the C-ABI: the planner runs (and is tested) without a GPU.
+The planner itself is C (fh_dd_box_node_keys, fh_dd_plan_create: host-only entry points of the C-ABI, so a C++ FEMuS build reaches the
+same code); it runs and is tested without a GPU.  This module drives it and holds the numpy executor used by the CPU (gloo) tests.
 """
 import numpy as np
 import scipy.sparse as sp
@@ -100,14 +101,17 @@ def local_meshes(part, nb, nlevels, flag_fn=None, n_uniform=None):
 
 
 def node_keys(coords, level, nb, part):
-    """global integer grid index of every node of a level-`level` mesh, the owner rank and a global id"""
-    S = 2 * nb * 2 ** level
-    k = np.rint(coords * S).astype(np.int64)
-    G = [part.p[d] * S + 1 for d in range(3)]
-    gid = k[:, 0] + G[0] * (k[:, 1] + G[1] * k[:, 2])
-    oc = [np.minimum(k[:, d] // S, part.p[d] - 1) for d in range(3)]
-    owner = part.rank_of(oc[0], oc[1], oc[2])
-    return gid, owner
+    """global integer grid index of every node of a level-`level` mesh and the owner rank (fh_dd_box_node_keys)"""
+    import ctypes
+    L = capi.load_library()
+    xy = np.ascontiguousarray(coords, dtype=np.float64)
+    if xy.shape[1] < 3:
+        xy = np.ascontiguousarray(np.hstack([xy, np.zeros((xy.shape[0], 3 - xy.shape[1]))]))
+    n = xy.shape[0]
+    gid, owner = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int32)
+    p = np.array(part.p, dtype=np.int32)
+    capi._chk(L.fh_dd_box_node_keys(n, capi._p(xy), int(level), int(nb), capi._p(p), capi._p(gid), capi._p(owner)))
+    return gid, owner.astype(np.int64)
 
 
 class LevelPlan:
@@ -115,36 +119,59 @@ class LevelPlan:
 
 
 def build_level_plans(part, comm, gids, owners, need_masks):
-    """gids/owners/need_masks: per level arrays over the local (extended box) nodes.  Returns LevelPlan per level."""
+    """gids/owners/need_masks: per level arrays over the local (extended box) nodes.  Returns LevelPlan per level.  The plan itself is
+    built by the C-ABI planner (fh_dd_plan_create, femus_amd/csrc/fh_dd.cpp) -- the same entry point a C++ FEMuS build calls; `comm`
+    only carries its one all-to-all of node ids"""
+    import ctypes
+    L = capi.load_library()
+    nr = part.nranks
+    CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int),
+                          ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int))
+
+    def alltoallv(user, send, scnt, recv, rcnt):
+        try:
+            if not send:                                   # first call: exchange the counts
+                got = comm.alltoallv([np.array([scnt[r]], dtype=np.int64) for r in range(nr)], np.int64)
+                for r in range(nr):
+                    rcnt[r] = int(got[r][0])
+                return 0
+            parts, off = [], 0
+            for r in range(nr):
+                parts.append(np.ctypeslib.as_array(send, shape=(off + scnt[r],))[off:off + scnt[r]].copy() if scnt[r] else np.zeros(0, np.int64))
+                off += scnt[r]
+            got = comm.alltoallv(parts, np.int64)
+            off = 0
+            for r in range(nr):
+                if rcnt[r]:
+                    assert got[r].size == rcnt[r]
+                    np.ctypeslib.as_array(recv, shape=(off + rcnt[r],))[off:off + rcnt[r]] = got[r]
+                off += rcnt[r]
+            return 0
+        except Exception:       # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    cb = CB(alltoallv)
     plans = []
     for gid, owner, need in zip(gids, owners, need_masks):
+        g = np.ascontiguousarray(gid, dtype=np.int64)
+        o = np.ascontiguousarray(owner, dtype=np.int32)
+        nd = np.ascontiguousarray(need, dtype=np.uint8)
+        h = ctypes.c_void_p()
+        capi._chk(L.fh_dd_plan_create(int(part.rank), int(nr), int(g.size), capi._p(g), capi._p(o), capi._p(nd), cb, None, ctypes.byref(h)))
+        a, b_, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        capi._chk(L.fh_dd_plan_sizes(h, ctypes.byref(a), ctypes.byref(b_), ctypes.byref(c)))
         P = LevelPlan()
-        me = part.rank
-        own = owner == me
-        P.owned = np.where(own)[0]                                        # local ids, ascending = local FEMuS order
-        ghost = np.where(need & ~own)[0]
-        order = np.lexsort((gid[ghost], owner[ghost]))                    # by owner rank, then by global id
-        ghost = ghost[order]
-        P.ghost = ghost
-        P.n_owned, P.n_ghost = P.owned.size, ghost.size
-        P.recv_counts = np.bincount(owner[ghost], minlength=part.nranks).astype(np.int32)
-        P.newid = np.full(gid.size, -1, dtype=np.int64)
-        P.newid[P.owned] = np.arange(P.n_owned)
-        P.newid[ghost] = P.n_owned + np.arange(P.n_ghost)
-        # ask the owners: send the global ids of my ghosts, receive the ids others need from me
-        req = [gid[ghost[owner[ghost] == r]] for r in range(part.nranks)]
-        got = comm.alltoallv(req, np.int64)
-        own_gid = gid[P.owned]
-        srt = np.argsort(own_gid)
-        send_idx, send_counts = [], []
-        for r in range(part.nranks):
-            g = got[r]
-            pos = srt[np.searchsorted(own_gid[srt], g)] if g.size else np.zeros(0, dtype=np.int64)
-            assert np.all(own_gid[pos] == g), "halo plan: a requested node is not owned here"
-            send_idx.append(pos)
-            send_counts.append(g.size)
-        P.send_idx = np.concatenate(send_idx).astype(np.int32) if send_idx else np.zeros(0, np.int32)
-        P.send_counts = np.array(send_counts, dtype=np.int32)
+        P.n_owned, P.n_ghost = a.value, b_.value
+        owned, ghost = np.empty(a.value, np.int32), np.empty(b_.value, np.int32)
+        newid, sidx = np.empty(g.size, np.int32), np.empty(c.value, np.int32)
+        sc, rc = np.empty(nr, np.int32), np.empty(nr, np.int32)
+        capi._chk(L.fh_dd_plan_get(h, capi._p(owned), capi._p(ghost), capi._p(newid), capi._p(sc), capi._p(sidx), capi._p(rc)))
+        capi._chk(L.fh_dd_plan_destroy(h))
+        P.owned, P.ghost = owned.astype(np.int64), ghost.astype(np.int64)
+        P.newid = newid.astype(np.int64)
+        P.send_idx, P.send_counts, P.recv_counts = sidx, sc, rc
         P.gid = gid
         plans.append(P)
     return plans

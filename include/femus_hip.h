@@ -373,6 +373,30 @@ int fh_halo_allreduce_sum(fh_halo_t halo, double* vals, int n);  /* host scalars
 int fh_halo_allreduce_mat(fh_halo_t halo, fh_mat_t A);            /* in-place sum over ranks of the values of a matrix with one pattern on all ranks */
 int fh_halo_destroy(fh_halo_t halo);
 
+/* ---- domain-decomposition planner (host-only, integer work) ---------------------------------------------------------
+ * Which nodes of a rank's local mesh it owns, which it needs as ghosts, the [owned | ghost] renumbering and the send lists of the
+ * ghost exchange: Mesh::dofmap_* (lowest rank touching a node owns it, Mesh.cpp:517-559; ghost lists :767-795), KKghost_nd
+ * (LinearEquation.cpp:239-280), VecCreateGhost (PetscVector.hpp:515-569).  A C++ FEMuS build reaches the multi-GPU path through
+ * these calls and HipVector::attach_halo (close() = ghost refresh, dot / norms summed over the ranks).
+ *   fh_dd_box_node_keys   box partition (the METIS stand-in): global id and owner rank of every node from its exact coordinates;
+ *                         rank (c0,c1,c2) of a p0 x p1 x p2 grid owns the unit cube [c, c+1), nb coarse elements per unit
+ *   fh_dd_plan_create     gid[n] / owner[n] / need[n] (1 = a row this rank owns reads the node: fh_mat_col_mask / fh_mat_row_mask) ->
+ *                         plan.  One personalised all-to-all of 64-bit ids through the caller's function: called twice, first with
+ *                         send == recv == NULL to exchange the counts (send_counts[r] ids go to rank r, recv_counts[r] is filled), then
+ *                         with the data (MPI_Alltoall + MPI_Alltoallv in an MPI launcher).  nranks == 1: no communication
+ *   fh_dd_plan_get        owned[] (local ids, ascending), ghost[] (by owner rank, then global id), newid[n] (-1: not part of the
+ *                         rank's vectors), send_counts / send_idx (positions among the owned entries) / recv_counts for fh_halo_create*
+ *   fh_dd_plan_halo       the device exchange plan of the level (RCCL; parent != NULL: on that plan's communicator / transport) */
+typedef struct fh_dd_plan_s* fh_dd_plan_t;
+typedef int (*fh_dd_alltoallv_fn)(void* user, const int64_t* send, const int* send_counts, int64_t* recv, int* recv_counts);
+int fh_dd_box_node_keys(int n, const double* coords /* [n*3] */, int level, int nb, const int p[3], int64_t* gid, int* owner);
+int fh_dd_plan_create(int rank, int nranks, int n, const int64_t* gid, const int* owner, const unsigned char* need,
+                      fh_dd_alltoallv_fn alltoallv, void* user, fh_dd_plan_t* plan);
+int fh_dd_plan_sizes(fh_dd_plan_t plan, int* n_owned, int* n_ghost, int* n_send);
+int fh_dd_plan_get(fh_dd_plan_t plan, int* owned, int* ghost, int* newid, int* send_counts, int* send_idx, int* recv_counts);
+int fh_dd_plan_halo(fh_dd_plan_t plan, fh_ctx_t ctx, const char id128[128], fh_halo_t parent, fh_halo_t* halo);
+int fh_dd_plan_destroy(fh_dd_plan_t plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -197,6 +197,52 @@ int main() {
     R.matrix_ABC(I2, Y, I2, true);
     CHECK(R(0, 1) == 2.);
   }
+  // ---- several ranks, seen from one: planner + a GHOSTED vector whose close() refreshes the ghosts through its exchange plan
+  // (PetscVector.hpp:595-612) and whose dot / norms go through the plan's all-reduce.  The "other rank" is this one: a host-staged
+  // transport that hands the sent entries back.
+  {
+    const int64_t gid[4] = {10, 11, 12, 13};
+    const int owner[4] = {0, 0, 0, 0};
+    const unsigned char need[4] = {1, 1, 1, 1};
+    fh_dd_plan_t plan = nullptr;
+    hip_check(fh_dd_plan_create(0, 1, 4, gid, owner, need, nullptr, nullptr, &plan), "fh_dd_plan_create");
+    int no = 0, ng = 0, ns = 0;
+    fh_dd_plan_sizes(plan, &no, &ng, &ns);
+    CHECK(no == 4 && ng == 0 && ns == 0);
+    fh_dd_plan_destroy(plan);
+    struct Self {
+      static int exchange(void*, const double* send, const int* sc, double* recv, const int* rc) {
+        for (int k = 0; k < sc[0] && k < rc[0]; k++) recv[k] = send[k];
+        return 0;
+      }
+      static int allreduce(void*, double*, int) { return 0; }
+    };
+    const int send_counts[1] = {2}, recv_counts[1] = {2}, send_idx[2] = {0, 2};
+    fh_halo_t halo = nullptr;
+    hip_check(fh_halo_create_host(hip_context(), 0, 1, Self::exchange, Self::allreduce, nullptr, send_counts, send_idx, recv_counts, &halo), "halo");
+    HipVector g;
+    g.init(8, 4, std::vector<int>{6, 7}, false, GHOSTED);     // owned global 0..3, ghosts = global 6 and 7 ("owned elsewhere")
+    g.attach_halo(halo);
+    g.set(0, 1.5); g.set(1, 2.5); g.set(2, 3.5); g.set(3, 4.5);
+    CHECK(!g.closed());
+    g.close();                                                   // ghost refresh
+    CHECK(g.closed() && g(6) == 1.5 && g(7) == 3.5 && g.type() == GHOSTED);
+    HipVector g2;
+    g2.init(g);                                                  // layout incl. ghosts and plan
+    g2 = static_cast<const NumericVector&>(g);
+    CHECK(g2.halo() == halo && std::fabs(g2.dot(g) - (1.5 * 1.5 + 2.5 * 2.5 + 3.5 * 3.5 + 4.5 * 4.5)) < 1e-14);
+    // a product with a ghosted operand refreshes the ghosts itself: y = A x, A = [0 .. | picks ghost 1]
+    HipMatrix Ag;
+    Ag.init_pattern(4, 6, std::vector<int>{0, 1, 2, 3, 4}, std::vector<int>{5, 0, 1, 4});
+    Ag.set(0, 5, 1.); Ag.set(1, 0, 1.); Ag.set(2, 1, 1.); Ag.set(3, 4, 2.);
+    g.set(2, 9.);                                                // owner value changes; the ghost copy (global 7) is stale until the product
+    HipVector yg;
+    yg.init(4, 4, false, PARALLEL);
+    yg.matrix_mult(g, Ag);
+    CHECK(yg(0) == 9. && yg(1) == 1.5 && yg(2) == 2.5 && yg(3) == 3.0);
+    g.clear(); g2.clear();
+    fh_halo_destroy(halo);
+  }
   // ---- LinearEquationSolver::Solve: one-level solve of the level's system with the Dirichlet rows derived from _Bdc -----------
   {
     Mesh msh1;
