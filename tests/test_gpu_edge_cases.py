@@ -44,7 +44,7 @@ def test_single_element_meshes_assemble_and_solve(ctx):
         pb.update_sol()
         xd = spla.spsolve(H.A[-1].tocsc(), H.b)
         assert np.allclose(pb.SOL.to_numpy(), xd, rtol=1e-10, atol=1e-14)
-        assert (pb.SOL.to_numpy() != 0).sum() == 1                # only the element centre is free
+        assert (np.abs(pb.SOL.to_numpy()) > 1e-14).sum() == 1      # only the element centre is free (pivoted inverse: Dirichlet rows to rounding)
         pb.destroy()
 
 
