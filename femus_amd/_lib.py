@@ -25,6 +25,9 @@ def load_library():
                 "(or `make -C femus_amd/csrc`). There is no CPU fallback." % p)
         # PyTorch-ROCm ships its own HIP runtime; it has to be the first (and only) one in the process.  Loading this
         # library before torch maps /opt/rocm's copy as well and the two tear each other down at exit (double free).
+        # several processes on one node exchange device memory through dmabuf IPC handles on this driver stack; without this setting
+        # RCCL's peer setup fails with "hipIpcGetMemHandle: invalid argument".  Before the HIP runtime starts; an explicit value wins.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch  # noqa: F401
         _LIB = ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
         _declare(_LIB)
