@@ -177,6 +177,8 @@ void HipVector::localize(std::vector<double>& out) const {
   out.resize(_n_local);
   hip_check(fh_vec_download(_v, out.data()), "localize");
 }
+void HipVector::BinaryPrint(const char* fileName) { hip_check(fh_vec_binary_print(_v, fileName), "BinaryPrint"); }
+void HipVector::BinaryLoad(const char* fileName) { hip_check(fh_vec_binary_load(_v, fileName), "BinaryLoad"); }
 void HipVector::pointwise_mult(const NumericVector& a, const NumericVector& b) {
   hip_check(fh_vec_pointwise_mult(_v, hv(a).handle(), hv(b).handle()), "pointwise_mult");
 }

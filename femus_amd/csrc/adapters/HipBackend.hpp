@@ -84,6 +84,9 @@ class HipVector : public NumericVector {
   void localize_to_one(std::vector<double>& v_local, const int proc_id = 0) const override;
   void localize_to_all(std::vector<double>& v_local) const override;
   void pointwise_mult(const NumericVector& vec1, const NumericVector& vec2) override;
+  // MultiLevelSolution::SaveSolution / LoadSolution (MultiLevelSolution.cpp:1070-1126): PETSc's binary Vec layout
+  void BinaryPrint(const char* fileName) override;
+  void BinaryLoad(const char* fileName) override;
   fh_vec_t handle() const { return _v; }
   // several ranks (one per GPU): the exchange plan that refreshes this vector's ghosts (built from the ghost list it was
   // initialised with, fh_halo_create*) and sums dot products / norms over the ranks.  Not owned.

@@ -93,6 +93,14 @@ class NumericVector {
   virtual void localize_to_one(std::vector<double>& v_local, const int proc_id = 0) const = 0;                   // :320
   virtual void localize_to_all(std::vector<double>& v_local) const = 0;        // :323
   virtual void pointwise_mult(const NumericVector& vec1, const NumericVector& vec2) = 0;                         // :328
+  virtual void BinaryPrint(const char* fileName) {                              // :345 (SaveSolution writes one such file per variable)
+    std::cout << "BinaryPrint is not available for this vector type\n";
+    abort();
+  }
+  virtual void BinaryLoad(const char* fileName) {                               // :350
+    std::cout << "BinaryLoad is not available for this vector type\n";
+    abort();
+  }
 
  protected:
   bool _is_closed, _is_initialized;

@@ -1,0 +1,174 @@
+// Output and restart files behind the C-ABI -- host-side, what the applications call unconditionally after the
+// solve (applications/001_Poisson/main.cpp:264-270):
+//   fh_write_vtu        VTKWriter::Write(output_path, "biquadratic", vars) (src/07_mesh_or_solution/01_multiple_levels/01_output/
+//                       VTKWriter.cpp:36-120, 460-770): one UnstructuredGrid piece, biquadratic cells (VTK types 28 / 29), Float32 points
+//                       and point data, Int32 connectivity / offsets, UInt16 types, every DataArray "binary": base64(uint32 byte count)
+//                       followed by base64(data), as print_data_array emits them; linear variables are carried to the biquadratic nodes
+//                       (mean of the vertices a node sits between); VTK's 27-node hexahedron lists its face centres x-, x+, y-, y+, z-, z+
+//                       (FEMuS: y-, x+, y+, x-, z-, z+), everything else coincides (Writer_one_level::FemusToVTKorToXDMFConn)
+//   fh_vec_binary_print / fh_vec_binary_load   NumericVector::BinaryPrint / BinaryLoad (NumericVector.hpp:345-353; PetscVector: VecView /
+//                       VecLoad on a binary viewer), the files MultiLevelSolution::SaveSolution / LoadSolution (MultiLevelSolution.cpp:
+//                       1070-1126) write per variable: big-endian int32 class id 1211214, int32 length, float64 values (PETSc's
+//                       documented binary Vec layout; PETSc itself is not under /root/reference)
+#include "fh_internal.h"
+#include "fh_fe.h"
+#include <cstdio>
+#include <memory>
+
+using namespace fhfe;
+
+int fh_mesh_host_arrays(fh_mesh_t m, int* dim, int* geom, int* nel, int* nnode, int* nloc, int* n_linear, const int** elem_dof, const double** coords);
+
+static void b64_append(std::string& out, const unsigned char* p, size_t n) {
+  static const char T[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+  for (size_t i = 0; i < n; i += 3) {
+    const unsigned b0 = p[i], b1 = i + 1 < n ? p[i + 1] : 0, b2 = i + 2 < n ? p[i + 2] : 0;
+    out.push_back(T[b0 >> 2]);
+    out.push_back(T[((b0 & 3) << 4) | (b1 >> 4)]);
+    out.push_back(i + 1 < n ? T[((b1 & 15) << 2) | (b2 >> 6)] : '=');
+    out.push_back(i + 2 < n ? T[b2 & 63] : '=');
+  }
+}
+
+static std::string b64_array(const void* data, size_t bytes) {
+  std::string out;
+  const unsigned cnt = (unsigned)bytes;                       // the reference encodes the byte count on its own, then the data
+  b64_append(out, reinterpret_cast<const unsigned char*>(&cnt), 4);
+  b64_append(out, reinterpret_cast<const unsigned char*>(data), bytes);
+  return out;
+}
+
+extern "C" int fh_write_vtu(fh_mesh_t mesh, const char* path, int nfields, const char* const* names, const int* fe, const double* const* values) {
+  FH_REQUIRE(mesh && path && nfields >= 0 && (nfields == 0 || (names && fe && values)), "fh_write_vtu: bad arguments");
+  int dim, geom, nel, nnode, nl, nlin;
+  const int* ed;
+  const double* xy;
+  FH_TRY(fh_mesh_host_arrays(mesh, &dim, &geom, &nel, &nnode, &nl, &nlin, &ed, &xy));
+  const int nv = nvert_of(geom);
+  // VTK position -> FEMuS local node
+  std::vector<int> order(nl);
+  for (int i = 0; i < nl; i++) order[i] = i;
+  if (geom == GEOM_HEX) {
+    const int fx[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+    for (int f = 0; f < 6; f++)
+      for (int n = 20; n < 26; n++)
+        if (xc(geom, n, 0) == fx[f][0] && xc(geom, n, 1) == fx[f][1] && xc(geom, n, 2) == fx[f][2]) order[20 + f] = n;
+  }
+  std::vector<float> pts((size_t)nnode * 3, 0.f);
+  for (int i = 0; i < nnode; i++)
+    for (int d = 0; d < dim; d++) pts[(size_t)i * 3 + d] = (float)xy[(size_t)i * dim + d];
+  std::vector<int> conn((size_t)nel * nl), offs(nel);
+  std::vector<unsigned short> types(nel, (unsigned short)(geom == GEOM_HEX ? 29 : 28));
+  for (int e = 0; e < nel; e++) {
+    for (int k = 0; k < nl; k++) conn[(size_t)e * nl + k] = ed[(size_t)e * nl + order[k]];
+    offs[e] = (e + 1) * nl;
+  }
+  FILE* f = fopen(path, "w");
+  FH_REQUIRE(f != nullptr, "fh_write_vtu: cannot open %s", path);
+  std::unique_ptr<FILE, int (*)(FILE*)> guard(f, fclose);
+  fprintf(f, "<?xml version=\"1.0\"?>\n<VTKFile type = \"UnstructuredGrid\" version=\"0.1\" byte_order=\"LittleEndian\">\n  <UnstructuredGrid>\n");
+  fprintf(f, "    <Piece NumberOfPoints= \"%d\" NumberOfCells= \"%d\" >\n", nnode, nel);
+  fprintf(f, "      <Points>\n        <DataArray type=\"Float32\" NumberOfComponents=\"3\" format=\"binary\">\n%s\n        </DataArray>\n      </Points>\n",
+          b64_array(pts.data(), pts.size() * sizeof(float)).c_str());
+  fprintf(f, "      <Cells>\n        <DataArray type=\"Int32\" Name=\"connectivity\" format=\"binary\">\n%s\n        </DataArray>\n",
+          b64_array(conn.data(), conn.size() * sizeof(int)).c_str());
+  fprintf(f, "        <DataArray type=\"Int32\" Name=\"offsets\" format=\"binary\">\n%s\n        </DataArray>\n", b64_array(offs.data(), offs.size() * sizeof(int)).c_str());
+  fprintf(f, "        <DataArray type=\"UInt16\" Name=\"types\" format=\"binary\">\n%s\n        </DataArray>\n      </Cells>\n",
+          b64_array(types.data(), types.size() * sizeof(unsigned short)).c_str());
+  fprintf(f, "      <PointData Scalars=\"scalars\">\n");
+  std::vector<float> fv(nnode);
+  for (int k = 0; k < nfields; k++) {
+    FH_REQUIRE(fe[k] == 0 || fe[k] == 2, "fh_write_vtu: field %d: fe must be 0 (linear) or 2 (biquadratic)", k);
+    if (fe[k] == 2) {
+      for (int i = 0; i < nnode; i++) fv[i] = (float)values[k][i];
+    } else {
+      // a Q1 field at every biquadratic node: mean of the vertices the node sits between (the element interpolation of the reference)
+      std::vector<double> full(nnode, 0.0);
+      for (int e = 0; e < nel; e++)
+        for (int i = 0; i < nl; i++) {
+          double s = 0.0;
+          int cnt = 0;
+          for (int v = 0; v < nv; v++) {
+            bool on = true;
+            for (int d = 0; d < dim; d++) on = on && (xc(geom, i, d) == 0 || xc(geom, i, d) == xc(geom, v, d));
+            if (on) {
+              s += values[k][ed[(size_t)e * nl + v]];
+              cnt++;
+            }
+          }
+          full[ed[(size_t)e * nl + i]] = s / cnt;
+        }
+      for (int i = 0; i < nnode; i++) fv[i] = (float)full[i];
+    }
+    fprintf(f, "        <DataArray type=\"Float32\" Name=\"%s\" format=\"binary\">\n%s\n        </DataArray>\n", names[k],
+            b64_array(fv.data(), fv.size() * sizeof(float)).c_str());
+  }
+  fprintf(f, "      </PointData>\n    </Piece>\n  </UnstructuredGrid>\n</VTKFile>\n");
+  return 0;
+}
+
+static void put_be32(unsigned char* p, int v) {
+  p[0] = (unsigned char)((unsigned)v >> 24), p[1] = (unsigned char)((unsigned)v >> 16), p[2] = (unsigned char)((unsigned)v >> 8), p[3] = (unsigned char)v;
+}
+static const int VEC_FILE_CLASSID = 1211214;
+
+extern "C" int fh_host_binary_print(const char* path, int n, const double* values) {
+  FH_REQUIRE(path && n >= 0 && (n == 0 || values), "fh_host_binary_print: bad arguments");
+  FILE* f = fopen(path, "wb");
+  FH_REQUIRE(f != nullptr, "fh_host_binary_print: cannot open %s", path);
+  std::unique_ptr<FILE, int (*)(FILE*)> guard(f, fclose);
+  std::vector<unsigned char> buf(8 + (size_t)n * 8);
+  put_be32(&buf[0], VEC_FILE_CLASSID);
+  put_be32(&buf[4], n);
+  for (int i = 0; i < n; i++) {
+    unsigned long long u;
+    memcpy(&u, &values[i], 8);
+    for (int b = 0; b < 8; b++) buf[8 + (size_t)i * 8 + b] = (unsigned char)(u >> (56 - 8 * b));
+  }
+  FH_REQUIRE(fwrite(buf.data(), 1, buf.size(), f) == buf.size(), "fh_host_binary_print: short write to %s", path);
+  return 0;
+}
+
+// *n in: capacity of values (0 with values == NULL: query), out: length stored in the file
+extern "C" int fh_host_binary_load(const char* path, int* n, double* values) {
+  FH_REQUIRE(path && n, "fh_host_binary_load: bad arguments");
+  FILE* f = fopen(path, "rb");
+  FH_REQUIRE(f != nullptr, "Error: cannot locate file %s", path);
+  std::unique_ptr<FILE, int (*)(FILE*)> guard(f, fclose);
+  unsigned char h[8];
+  FH_REQUIRE(fread(h, 1, 8, f) == 8, "fh_host_binary_load: %s is too short", path);
+  const int cid = (int)(((unsigned)h[0] << 24) | ((unsigned)h[1] << 16) | ((unsigned)h[2] << 8) | h[3]);
+  const int len = (int)(((unsigned)h[4] << 24) | ((unsigned)h[5] << 16) | ((unsigned)h[6] << 8) | h[7]);
+  FH_REQUIRE(cid == VEC_FILE_CLASSID && len >= 0, "%s is not a binary vector file", path);
+  if (!values) {
+    *n = len;
+    return 0;
+  }
+  FH_REQUIRE(*n >= len, "fh_host_binary_load: %s holds %d values, capacity %d", path, len, *n);
+  std::vector<unsigned char> buf((size_t)len * 8);
+  FH_REQUIRE(fread(buf.data(), 1, buf.size(), f) == buf.size(), "fh_host_binary_load: %s is truncated", path);
+  for (int i = 0; i < len; i++) {
+    unsigned long long u = 0;
+    for (int b = 0; b < 8; b++) u = (u << 8) | buf[(size_t)i * 8 + b];
+    memcpy(&values[i], &u, 8);
+  }
+  *n = len;
+  return 0;
+}
+
+extern "C" int fh_vec_binary_print(fh_vec_t v, const char* path) {
+  FH_REQUIRE(v && path, "fh_vec_binary_print: null argument");
+  std::vector<double> h(v->n_local);
+  FH_TRY(fh_vec_download(v, h.data()));
+  return fh_host_binary_print(path, v->n_local, h.data());
+}
+
+extern "C" int fh_vec_binary_load(fh_vec_t v, const char* path) {
+  FH_REQUIRE(v && path, "fh_vec_binary_load: null argument");
+  int n = 0;
+  FH_TRY(fh_host_binary_load(path, &n, nullptr));
+  FH_REQUIRE(n == v->n_local, "fh_vec_binary_load: %s holds %d values, the vector %d", path, n, v->n_local);
+  std::vector<double> h(n);
+  FH_TRY(fh_host_binary_load(path, &n, h.data()));
+  return fh_vec_upload(v, h.data());
+}

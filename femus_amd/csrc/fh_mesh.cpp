@@ -336,6 +336,20 @@ extern "C" int fh_mesh_info(fh_mesh_t m, int* dim, int* nel, int* nnode, int* nl
   return 0;
 }
 
+// host arrays of a mesh for the other translation units of the library (fh_io.cpp)
+int fh_mesh_host_arrays(fh_mesh_t m, int* dim, int* geom, int* nel, int* nnode, int* nloc, int* n_linear, const int** elem_dof, const double** coords) {
+  FH_REQUIRE(m, "null mesh");
+  *dim = m->dim;
+  *geom = m->geom;
+  *nel = m->nel;
+  *nnode = m->nnode;
+  *nloc = m->nloc;
+  *n_linear = m->own[0];
+  *elem_dof = m->elem_dof.data();
+  *coords = m->coords.data();
+  return 0;
+}
+
 extern "C" int fh_mesh_get(fh_mesh_t m, int* elem_dof, double* coords, int* face_flag) {
   if (elem_dof) memcpy(elem_dof, m->elem_dof.data(), m->elem_dof.size() * sizeof(int));
   if (coords) memcpy(coords, m->coords.data(), m->coords.size() * sizeof(double));

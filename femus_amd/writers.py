@@ -46,33 +46,24 @@ def linear_to_biquadratic(mesh_arrays, geom, xc, values):
 
 
 def write_vtu(path, mesh, fields, xc=None):
-    """fields: name -> nodal array (length nnode: biquadratic; length own_size[0]: linear)"""
-    ed, xy, _ = mesh.arrays()
-    geom = mesh.geom
-    if xc is None:
-        xc = XC["quad"] if geom == "quad" else HEX_XC
-    order = vtk_connectivity_order(geom, xc)
-    nl = ed.shape[1]
-    pts = np.zeros((mesh.nnode, 3), np.float32)
-    pts[:, :mesh.dim] = xy
-    conn = ed[:, order].astype(np.int32)
-    with open(path, "w") as f:
-        f.write('<?xml version="1.0"?>\n<VTKFile type = "UnstructuredGrid" version="0.1" byte_order="LittleEndian">\n  <UnstructuredGrid>\n')
-        f.write('    <Piece NumberOfPoints= "%d" NumberOfCells= "%d" >\n' % (mesh.nnode, mesh.nel))
-        f.write('      <Points>\n        <DataArray type="Float32" NumberOfComponents="3" format="binary">\n%s\n        </DataArray>\n      </Points>\n' % _b64(pts))
-        f.write('      <Cells>\n        <DataArray type="Int32" Name="connectivity" format="binary">\n%s\n        </DataArray>\n' % _b64(conn))
-        f.write('        <DataArray type="Int32" Name="offsets" format="binary">\n%s\n        </DataArray>\n'
-                % _b64((np.arange(1, mesh.nel + 1) * nl).astype(np.int32)))
-        f.write('        <DataArray type="UInt16" Name="types" format="binary">\n%s\n        </DataArray>\n      </Cells>\n'
-                % _b64(np.full(mesh.nel, 28 if geom == "quad" else 29, np.uint16)))
-        f.write('      <PointData Scalars="scalars">\n')
-        for name, v in fields.items():
-            v = np.asarray(v, float)
-            if v.size != mesh.nnode:
-                assert v.size == mesh.own_size[0], "field %s has neither the biquadratic nor the linear length" % name
-                v = linear_to_biquadratic((ed,), geom, xc, v)
-            f.write('        <DataArray type="Float32" Name="%s" format="binary">\n%s\n        </DataArray>\n' % (name, _b64(v.astype(np.float32))))
-        f.write('      </PointData>\n    </Piece>\n  </UnstructuredGrid>\n</VTKFile>\n')
+    """fields: name -> nodal array (length nnode: biquadratic; length own_size[0]: linear).  Written by the library (fh_write_vtu,
+    femus_amd/csrc/fh_io.cpp) -- the entry point a C++ FEMuS application calls"""
+    import ctypes
+    from . import capi
+    L = capi.load_library()
+    names = list(fields)
+    arrs = [np.ascontiguousarray(fields[k], dtype=np.float64) for k in names]
+    fe = []
+    for k, v in zip(names, arrs):
+        if v.size == mesh.nnode:
+            fe.append(2)
+        else:
+            assert v.size == mesh.own_size[0], "field %s has neither the biquadratic nor the linear length" % k
+            fe.append(0)
+    c_names = (ctypes.c_char_p * len(names))(*[k.encode() for k in names])
+    c_vals = (ctypes.c_void_p * len(names))(*[v.ctypes.data for v in arrs])
+    fe = np.array(fe, dtype=np.int32)
+    capi._chk(L.fh_write_vtu(mesh.h, os.fsencode(str(path)), len(names), c_names, capi._p(fe), c_vals))
 
 
 HEX_XC = [(-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1), (-1, -1, 1), (1, -1, 1), (1, 1, 1), (-1, 1, 1),
@@ -81,29 +72,35 @@ HEX_XC = [(-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1), (-1, -1, 1), (1, -
 
 
 def save_solution(directory, name, iteration, fields, level):
-    """fields: variable name -> array.  Returns the file names written."""
+    """fields: variable name -> array.  Returns the file names written (fh_host_binary_print: the layout of NumericVector::BinaryPrint)"""
+    from . import capi
+    L = capi.load_library()
     os.makedirs(directory, exist_ok=True)
     out = []
     for var, v in fields.items():
         fn = os.path.join(directory, "%s_iteration%d_sol%s_level%d" % (name, iteration, var, level))
-        v = np.asarray(v, float)
-        with open(fn, "wb") as f:
-            f.write(struct.pack(">ii", VEC_FILE_CLASSID, v.size))
-            f.write(v.astype(">f8").tobytes())
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        capi._chk(L.fh_host_binary_print(os.fsencode(fn), int(v.size), capi._p(v)))
         out.append(fn)
     return out
 
 
 def load_solution(prefix, variables, level):
     """prefix as passed to MultiLevelSolution::LoadSolution ("<dir>/<name>_iteration<k>"); returns name -> array"""
+    import ctypes
+    from . import capi
+    L = capi.load_library()
     out = {}
     for var in variables:
         fn = "%s_sol%s_level%d" % (prefix, var, level)
         if not os.path.exists(fn):
             raise FileNotFoundError("Error: cannot locate file " + fn)
-        raw = open(fn, "rb").read()
-        cid, n = struct.unpack(">ii", raw[:8])
-        if cid != VEC_FILE_CLASSID:
-            raise ValueError("%s is not a binary vector file" % fn)
-        out[var] = np.frombuffer(raw, ">f8", n, 8).astype(float)
+        n = ctypes.c_int(0)
+        try:
+            capi._chk(L.fh_host_binary_load(os.fsencode(fn), ctypes.byref(n), None))
+        except capi.FemusHipError as e:
+            raise ValueError(str(e))
+        v = np.empty(n.value)
+        capi._chk(L.fh_host_binary_load(os.fsencode(fn), ctypes.byref(n), capi._p(v)))
+        out[var] = v
     return out

@@ -373,6 +373,19 @@ int fh_halo_allreduce_sum(fh_halo_t halo, double* vals, int n);  /* host scalars
 int fh_halo_allreduce_mat(fh_halo_t halo, fh_mat_t A);            /* in-place sum over ranks of the values of a matrix with one pattern on all ranks */
 int fh_halo_destroy(fh_halo_t halo);
 
+/* ---- output and restart files (host-side) --------------------------------------------------------------------
+ * fh_write_vtu: VTKWriter::Write(output_path, "biquadratic", vars) (VTKWriter.cpp:36-120, 460-770): one UnstructuredGrid piece of
+ * biquadratic cells, base64 "binary" DataArrays as print_data_array emits them.  fe[k] = 2: values[k] has nnode entries; 0: the Q1
+ * dofs (vertex count), carried to the biquadratic nodes.
+ * fh_vec_binary_print / _load: NumericVector::BinaryPrint / BinaryLoad (NumericVector.hpp:345-353), the per-variable files of
+ * MultiLevelSolution::SaveSolution / LoadSolution (MultiLevelSolution.cpp:1070-1126): PETSc's binary Vec layout (big-endian class id
+ * 1211214, length, float64 values).  fh_host_binary_*: the same on host arrays (*n: capacity in / length out; values == NULL queries). */
+int fh_write_vtu(fh_mesh_t mesh, const char* path, int nfields, const char* const* names, const int* fe, const double* const* values);
+int fh_vec_binary_print(fh_vec_t v, const char* path);
+int fh_vec_binary_load(fh_vec_t v, const char* path);
+int fh_host_binary_print(const char* path, int n, const double* values);
+int fh_host_binary_load(const char* path, int* n, double* values);
+
 /* ---- domain-decomposition planner (host-only, integer work) ---------------------------------------------------------
  * Which nodes of a rank's local mesh it owns, which it needs as ghosts, the [owned | ghost] renumbering and the send lists of the
  * ghost exchange: Mesh::dofmap_* (lowest rank touching a node owns it, Mesh.cpp:517-559; ghost lists :767-795), KKghost_nd

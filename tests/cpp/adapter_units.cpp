@@ -160,6 +160,10 @@ int main() {
     CHECK((*a)(3) == 2.);
     a->close();
     CHECK(a->closed() && a->type() == SERIAL);
+    a->BinaryPrint("/tmp/femus_hip_adapter_units_vec.bin");          // SaveSolution / LoadSolution file of one variable
+    *b = 0.;
+    b->BinaryLoad("/tmp/femus_hip_adapter_units_vec.bin");
+    CHECK((*b)(3) == (*a)(3) && (*b)(0) == (*a)(0));
     delete a;
     delete b;
   }
