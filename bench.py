@@ -61,24 +61,45 @@ def main():
     dist_err = None
     pb = None
     if (world > 1 and os.environ.get("FEMUS_BENCH_DD", "1") != "0") or os.environ.get("FEMUS_BENCH_FORCE_DD") == "1":
-        try:
-            transport = os.environ.get("FEMUS_BENCH_TRANSPORT", "rccl")     # "host": host-staged exchange (debugging, shared GPUs)
-            if transport == "rccl" and world > 1 and os.environ.get("FEMUS_BENCH_PREFLIGHT", "1") != "0":
-                # a ring exchange + all-reduce through fh_halo_* in a child process first: a RCCL path that fails or HANGS on this
-                # machine must end in the reported fallback below, not in a hung bench
-                from femus_amd import rccl_preflight
-                good, msg = rccl_preflight.run(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
-                                               int(os.environ.get("MASTER_PORT", "29500")) + 100, device)
-                if not all(comm.allgather_obj(bool(good))):
-                    raise RuntimeError(msg if not good else "RCCL preflight failed on another rank")
-            pb = dd.DistributedPoisson(ctx, comm, world, rank, nb=args.coarse, nlevels=args.levels, omega=2. / 3., npre=2, npost=2,
-                                       transport=transport)
-            parallelism = ("mesh domain decomposition, box split %dx%dx%d (METIS unavailable), one partition per GPU, ghost DOFs "
-                           "exchanged by %s (fh_halo_update), replicated coarse level"
-                           % (dd.GRIDS[world] + ("RCCL neighbour send/recv" if transport == "rccl" else "the host-staged transport",)))
-        except Exception as e:   # report, never hide: the line says what actually ran
-            dist_err = "%s: %s" % (type(e).__name__, str(e)[:200])
-            pb = None
+        # transports in order of preference: "rccl" (neighbour send/recv over xGMI), then -- when the RCCL preflight fails or hangs on
+        # this machine, or when asked for -- "gloo" (the same plans and kernels, ghost bytes staged through pinned host buffers and
+        # exchanged by torch.distributed point-to-point messages): still ONE distributed problem with ghost exchange, only slower;
+        # "host" = the same through the setup sockets (development).  Independent problems are the last resort and say so.
+        want = os.environ.get("FEMUS_BENCH_TRANSPORT", "rccl")
+        order = {"rccl": ["rccl", "gloo"], "gloo": ["gloo"], "host": ["host"]}.get(want, [want])
+        for transport in order:
+            try:
+                halo_comm = None
+                if transport == "rccl" and world > 1 and os.environ.get("FEMUS_BENCH_PREFLIGHT", "1") != "0":
+                    # a ring exchange + all-reduce through fh_halo_* in a child process first: a RCCL path that fails or HANGS on this
+                    # machine must end in the reported fallback below, not in a hung bench
+                    from femus_amd import rccl_preflight
+                    good, msg = rccl_preflight.run(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                                                   int(os.environ.get("MASTER_PORT", "29500")) + 100, device)
+                    if not all(comm.allgather_obj(bool(good))):
+                        raise RuntimeError(msg if not good else "RCCL preflight failed on another rank")
+                if transport == "gloo":
+                    halo_comm = dd.TorchComm.from_env()
+                pb = dd.DistributedPoisson(ctx, comm, world, rank, nb=args.coarse, nlevels=args.levels, omega=2. / 3., npre=2, npost=2,
+                                           transport="rccl" if transport == "rccl" else "host", halo_comm=halo_comm)
+                how = {"rccl": "RCCL neighbour send/recv", "gloo": "the host-staged transport over torch.distributed (gloo)",
+                       "host": "the host-staged transport"}[transport]
+                parallelism = ("mesh domain decomposition, box split %dx%dx%d (METIS unavailable), one partition per GPU, ghost DOFs "
+                               "exchanged by %s (fh_halo_begin/end, overlapped with the interior rows), replicated coarse level"
+                               % (dd.GRIDS[world] + (how,)))
+                if dist_err is not None:
+                    parallelism += "; fell back from rccl: " + dist_err
+                err_here = None
+            except Exception as e:   # report, never hide: the line says what actually ran
+                err_here = "%s: %s" % (type(e).__name__, str(e)[:200])
+                pb = None
+            # every rank must be on the same path: one failing rank moves all of them to the next transport
+            oks = comm.allgather_obj(err_here is None)
+            if all(oks):
+                break
+            if pb is not None:
+                pb = None
+            dist_err = err_here or "the distributed setup failed on another rank"
     ok = comm.allgather_obj(pb is not None or world == 1)
     if world > 1 and not all(ok):
         pb = None

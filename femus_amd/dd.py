@@ -37,6 +37,15 @@ class BoxPartition:
 class TorchComm:
     """all-to-all of int64/float64 numpy arrays over a torch.distributed group (gloo on the host)"""
 
+    @classmethod
+    def from_env(cls, timeout_s=120):
+        """gloo group from the RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT that torchrun exports"""
+        import datetime
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=timeout_s))
+        return cls()
+
     def __init__(self, group=None):
         import torch
         import torch.distributed as dist
@@ -614,7 +623,7 @@ class DistributedPoisson:
     the numeric part -- what LinearImplicitSystem::MGsolve does before every solve (LinearImplicitSystem.cpp:347-383)."""
 
     def __init__(self, ctx, comm, nranks, rank, nb=8, nlevels=4, omega=2. / 3., npre=2, npost=2, fe="biquadratic", order="seventh",
-                 transport="rccl", flag_fn=None, n_uniform=None, source_kind=0, params=(1.0,)):
+                 transport="rccl", flag_fn=None, n_uniform=None, source_kind=0, params=(1.0,), halo_comm=None):
         """flag_fn / n_uniform: adaptive levels (BASELINE config "MGAMR ... 8 GPUs"): every rank refines its extended box with the
         same flag function on global coordinates.  The fine level is then assembled AND projected (hanging nodes) on the extended
         box with the one-GPU code and the owned rows are gathered out on the device; uniform hierarchies keep the leaner
@@ -673,8 +682,9 @@ class DistributedPoisson:
         # 4. halos
         self.halos = []
         if transport == "host":   # host-staged exchange through `comm` (ranks sharing a GPU, launchers without RCCL peers)
+            hc = halo_comm if halo_comm is not None else comm     # e.g. a gloo group for the data path, sockets for the setup
             for pl in plans:
-                self.halos.append(capi.Halo.host(ctx, rank, nranks, comm, pl.send_counts, pl.send_idx, pl.recv_counts,
+                self.halos.append(capi.Halo.host(ctx, rank, nranks, hc, pl.send_counts, pl.send_idx, pl.recv_counts,
                                                  parent=self.halos[0] if self.halos else None))
         else:
             uid = comm.bcast_obj(capi.Halo.unique_id() if rank == 0 else None)

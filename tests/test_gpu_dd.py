@@ -197,15 +197,18 @@ def test_multi_rank_device_path_with_host_transport(tmp_path, world, overlap):
     assert seen == xd.size
 
 
-def test_bench_contract_with_two_ranks_sharing_the_gpu(tmp_path):
+@pytest.mark.parametrize("transport", ["host", "gloo"])
+def test_bench_contract_with_two_ranks_sharing_the_gpu(tmp_path, transport):
     """bench.py launched as the driver launches it for N > 1 (torch.distributed.run, one process per rank), on the one GPU of
-    this box with the host-staged transport: rendezvous, distributed setup, timed steps, roofline leg and the JSON line"""
+    this box with the host-staged transport -- through the setup sockets ("host") and through torch.distributed gloo ("gloo": what
+    bench.py falls back to when the RCCL preflight fails on a machine): rendezvous, distributed setup, timed steps, roofline leg and
+    the JSON line"""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FEMUS_BENCH_TRANSPORT="host", FEMUS_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, FEMUS_BENCH_TRANSPORT=transport, FEMUS_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--coarse", "2", "--levels", "3", "--kernel-reps", "3"]
@@ -215,6 +218,7 @@ def test_bench_contract_with_two_ranks_sharing_the_gpu(tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "domain decomposition" in d["config"]["parallelism"] and "host-staged" in d["config"]["parallelism"]
+    assert ("gloo" in d["config"]["parallelism"]) == (transport == "gloo")
     assert d["config"]["dofs_total"] == 33 * 17 * 17 and "roofline" in d and "cpu_baseline" not in d
     h = d["halo"]     # 3 distributed levels, V(2,2): 5 + 6 + 5 exchanges per cycle, some of the exchange time hidden or not, never negative
     assert h["exchanges_per_cycle"] == 16 and h["bytes_sent_per_cycle_this_rank"] > 0
