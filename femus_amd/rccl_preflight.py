@@ -45,6 +45,9 @@ def _child(rank, world, addr, port, device):
     y.upload(np.full(n, float(rank + 1)))
     halo.allreduce_vec(y)
     ok = ok and np.array_equal(y.to_numpy(), np.full(n, world * (world + 1) / 2.0))
+    # values of a matrix with one pattern on all ranks (the replicated coarse operator)
+    halo.allreduce_mat(A)
+    ok = ok and np.array_equal(A.values(), np.full(n, float(world)))
     st = halo.stats()
     ok = ok and st["updates"] == 1 and st["bytes_sent"] == 8 * n
     ctx.sync()
