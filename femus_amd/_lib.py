@@ -182,6 +182,7 @@ def _declare(L):
     sig("fh_dd_plan_create", c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, P(c_void_p))
     sig("fh_dd_plan_sizes", c_void_p, P(c_int), P(c_int), P(c_int))
     sig("fh_dd_plan_get", c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)
+    sig("fh_dd_plan_global", c_void_p, c_void_p, c_void_p)
     sig("fh_dd_plan_halo", c_void_p, c_void_p, c_void_p, c_void_p, P(c_void_p))
     sig("fh_dd_plan_destroy", c_void_p)
     sig("fh_write_vtu", c_void_p, c_char_p, c_int, c_void_p, c_void_p, c_void_p)

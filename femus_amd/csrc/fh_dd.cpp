@@ -13,6 +13,10 @@
 struct fh_dd_plan_s {
   int rank = 0, nranks = 1, n = 0;
   std::vector<int> owned, ghost, newid, send_idx, send_counts, recv_counts;
+  // the reference's global numbering of the level: every rank owns one contiguous range (Mesh.cpp:735-741 _dofOffset, LinearEquation.cpp:
+  // 212-237 KKoffset), ghosts are addressed by the owner's global index (KKghost_nd, :239-280)
+  std::vector<int64_t> offsets;        // [nranks + 1] first global index of every rank
+  std::vector<int64_t> ghost_global;   // [n_ghost] global index of every ghost, in ghost order
 };
 
 // box partition of the structured hierarchy (the METIS stand-in): rank (c0, c1, c2) of a p0 x p1 x p2 grid owns the unit
@@ -80,8 +84,35 @@ extern "C" int fh_dd_plan_create(int rank, int nranks, int n, const int64_t* gid
       FH_REQUIRE(it != srt.end() && gid[P->owned[*it]] == g, "fh_dd_plan_create: a requested node (global id %lld) is not owned by rank %d", (long long)g, rank);
       P->send_idx[k] = *it;                                      // position among the owned entries = index into the owned part of a vector
     }
+    // global numbering: owned counts of all ranks (one more exchange of one number per pair), then every owner tells the requesters
+    // the GLOBAL index (offset + position) of the nodes they asked for -- the reverse of the request exchange
+    std::vector<int> ones(nranks, 1), got1(nranks, 0);
+    std::vector<int64_t> mine(nranks, (int64_t)P->owned.size()), theirs(nranks, 0);
+    FH_REQUIRE(alltoallv(user, nullptr, ones.data(), nullptr, got1.data()) == 0, "fh_dd_plan_create: the count exchange failed");
+    FH_REQUIRE(alltoallv(user, mine.data(), ones.data(), theirs.data(), got1.data()) == 0, "fh_dd_plan_create: the size exchange failed");
+    P->offsets.assign(nranks + 1, 0);
+    for (int r = 0; r < nranks; r++) P->offsets[r + 1] = P->offsets[r] + theirs[r];
+    std::vector<int64_t> reply(std::max(tot, 1));
+    for (int k = 0; k < tot; k++) reply[k] = P->offsets[rank] + P->send_idx[k];
+    std::vector<int> rc2(nranks, 0);
+    FH_REQUIRE(alltoallv(user, nullptr, P->send_counts.data(), nullptr, rc2.data()) == 0, "fh_dd_plan_create: the count exchange failed");
+    for (int r = 0; r < nranks; r++) FH_REQUIRE(rc2[r] == P->recv_counts[r], "fh_dd_plan_create: rank %d answers %d ids, %d were asked for", r, rc2[r], P->recv_counts[r]);
+    P->ghost_global.assign(std::max<size_t>(P->ghost.size(), 1), 0);
+    FH_REQUIRE(alltoallv(user, reply.data(), P->send_counts.data(), P->ghost_global.data(), rc2.data()) == 0, "fh_dd_plan_create: the reply exchange failed");
+    P->ghost_global.resize(P->ghost.size());
+  } else {
+    P->offsets = {0, (int64_t)P->owned.size()};
   }
   *out = P.release();
+  return 0;
+}
+
+// global numbering of the level as the reference keeps it: offsets[nranks + 1] (rank r owns [offsets[r], offsets[r + 1])), and the
+// global index of every ghost (the list a GHOSTED vector is initialised with, NumericVector::init(N, n_local, ghost, ...))
+extern "C" int fh_dd_plan_global(fh_dd_plan_t P, int64_t* offsets, int64_t* ghost_global) {
+  FH_REQUIRE(P, "fh_dd_plan_global: null plan");
+  if (offsets) std::copy(P->offsets.begin(), P->offsets.end(), offsets);
+  if (ghost_global) std::copy(P->ghost_global.begin(), P->ghost_global.end(), ghost_global);
   return 0;
 }
 

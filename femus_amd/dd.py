@@ -177,6 +177,9 @@ def build_level_plans(part, comm, gids, owners, need_masks):
         newid, sidx = np.empty(g.size, np.int32), np.empty(c.value, np.int32)
         sc, rc = np.empty(nr, np.int32), np.empty(nr, np.int32)
         capi._chk(L.fh_dd_plan_get(h, capi._p(owned), capi._p(ghost), capi._p(newid), capi._p(sc), capi._p(sidx), capi._p(rc)))
+        offs, gglob = np.empty(nr + 1, np.int64), np.empty(max(b_.value, 1), np.int64)
+        capi._chk(L.fh_dd_plan_global(h, capi._p(offs), capi._p(gglob)))
+        P.offsets, P.ghost_global = offs, gglob[:b_.value]          # the reference's contiguous global ranges / ghost global ids
         capi._chk(L.fh_dd_plan_destroy(h))
         P.owned, P.ghost = owned.astype(np.int64), ghost.astype(np.int64)
         P.newid = newid.astype(np.int64)
@@ -740,8 +743,9 @@ class DistributedPoisson:
             xy_new[top.newid[both]] = xy[both]
             self.asm = capi.Assembler(ctx, None, fe, self.A[-1], order, elem_dof=ed_new, coords=xy_new)
         self.n_owned, self.n_loc = top.n_owned, ntop
-        ghost_ids = np.arange(top.n_owned, ntop, dtype=np.int32)
-        mk = lambda: ctx.vector(ntop, top.n_owned, 0, ghost_ids)
+        # vectors in the reference's global numbering: this rank owns [offsets[rank], offsets[rank + 1]), ghosts carry the owners' global
+        # indices (NumericVector::init(N, n_local, ghost, fast, GHOSTED); operator()(global index) reaches owned and ghost entries)
+        mk = lambda: ctx.vector(int(top.offsets[-1]), top.n_owned, int(top.offsets[rank]), top.ghost_global.astype(np.int32))
         self.RES, self.EPSC, self.SOL = mk(), mk(), mk()
         self.bdc_top = H.bdc_owned[-1].astype(np.int32)
         self.bdc_dev = capi.Index(ctx, self.bdc_top)       # BuildBdcIndex once, device-resident

@@ -399,6 +399,9 @@ int fh_host_binary_load(const char* path, int* n, double* values);
  *                         with the data (MPI_Alltoall + MPI_Alltoallv in an MPI launcher).  nranks == 1: no communication
  *   fh_dd_plan_get        owned[] (local ids, ascending), ghost[] (by owner rank, then global id), newid[n] (-1: not part of the
  *                         rank's vectors), send_counts / send_idx (positions among the owned entries) / recv_counts for fh_halo_create*
+ *   fh_dd_plan_global     the reference's global numbering of the level: rank r owns the contiguous range [offsets[r], offsets[r+1])
+ *                         (_dofOffset, Mesh.cpp:735-741; KKoffset, LinearEquation.cpp:212-237) and every ghost's global index (KKghost_nd,
+ *                         :239-280) = the list NumericVector::init(N, n_local, ghost, fast, GHOSTED) takes
  *   fh_dd_plan_halo       the device exchange plan of the level (RCCL; parent != NULL: on that plan's communicator / transport) */
 typedef struct fh_dd_plan_s* fh_dd_plan_t;
 typedef int (*fh_dd_alltoallv_fn)(void* user, const int64_t* send, const int* send_counts, int64_t* recv, int* recv_counts);
@@ -407,6 +410,7 @@ int fh_dd_plan_create(int rank, int nranks, int n, const int64_t* gid, const int
                       fh_dd_alltoallv_fn alltoallv, void* user, fh_dd_plan_t* plan);
 int fh_dd_plan_sizes(fh_dd_plan_t plan, int* n_owned, int* n_ghost, int* n_send);
 int fh_dd_plan_get(fh_dd_plan_t plan, int* owned, int* ghost, int* newid, int* send_counts, int* send_idx, int* recv_counts);
+int fh_dd_plan_global(fh_dd_plan_t plan, int64_t* offsets /* [nranks+1] */, int64_t* ghost_global /* [n_ghost] */);
 int fh_dd_plan_halo(fh_dd_plan_t plan, fh_ctx_t ctx, const char id128[128], fh_halo_t parent, fh_halo_t* halo);
 int fh_dd_plan_destroy(fh_dd_plan_t plan);
 

@@ -69,6 +69,14 @@ def _worker(rank, world, port, nb, nlevels, out):
         v[:top.n_owned] = top.gid[top.owned].astype(np.float64)
         dd.halo_update(comm, top, v)
         assert np.array_equal(v[top.n_owned:], top.gid[top.ghost].astype(np.float64))
+        # the reference's global numbering (fh_dd_plan_global): contiguous range per rank; a ghost's global index is the owner's
+        # offset + position -- exchanging every rank's own global indices must reproduce the ghost list
+        assert top.offsets[rank + 1] - top.offsets[rank] == top.n_owned and top.offsets[0] == 0
+        v[:top.n_owned] = (top.offsets[rank] + np.arange(top.n_owned)).astype(np.float64)
+        dd.halo_update(comm, top, v)
+        assert np.array_equal(v[top.n_owned:], top.ghost_global.astype(np.float64))
+        owner_of_ghost = np.searchsorted(top.offsets, top.ghost_global, side="right") - 1
+        assert np.array_equal(owner_of_ghost, np.repeat(np.arange(world), top.recv_counts))
         x = dd.vcycle_numpy(comm, H, b[top.owned])
         np.savez(out % rank, gid=top.gid[top.owned], x=x, b=b[top.owned], n_ghost=top.n_ghost)
     finally:

@@ -163,6 +163,12 @@ def _rank_worker_body(rank, world, port, nb, nlevels, out, overlap=1):
     its, rn = dp.solve(outer="gmres", rtol=1e-12, maxit=60)
     xs = dp.EPSC.to_numpy()[:dp.n_owned].copy()
     top = dp.H.plans[-1]
+    # the vectors live in the reference's global numbering: operator()(global index) reaches owned and (refreshed) ghost entries
+    assert dp.SOL.first_local == top.offsets[rank] and dp.SOL.n_global == top.offsets[-1]
+    dp.SOL.upload((top.offsets[rank] + np.arange(dp.n_owned)).astype(np.float64))
+    dp.halos[-1].update(dp.SOL)
+    probe = np.concatenate([top.ghost_global[:5], top.offsets[rank] + np.arange(3)]).astype(np.int32)
+    assert np.array_equal(dp.SOL.get(probe), probe.astype(np.float64))
     np.savez(out % rank, gid=top.gid[top.owned], b=b, x=x, xs=xs, its=its, n_ghost=top.n_ghost)
     comm.barrier()
     comm.close()
