@@ -1,0 +1,93 @@
+"""Probe (not a pytest test): BASELINE config 5 shape on several ranks at a larger size than the unit tests -- 3-D Poisson Q2, nb^3 coarse
+elements per rank, n_uniform uniform + (nlevels - n_uniform) selectively refined levels (MGAMR/ex4-style flag), ranks sharing the one GPU
+through the host-staged transport.  Checks the distributed GMRES solution against the single-GPU solver on the same global adaptive mesh.
+usage: python tests/perf_probe_amr_dd.py [world=8] [nb=4] [nlevels=4] [n_uniform=2]"""
+import json
+import os
+import socket
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def flag(x, level):
+    return x[0] > 0.5 and (level < 2 or x[1] > 0.25)
+
+
+def worker(rank, world, port, nb, nlevels, n_uniform, out):
+    import femus_amd as fa
+    from femus_amd import dd
+    comm = dd.SocketComm(rank, world, "127.0.0.1", port)
+    ctx = fa.Context(0)
+    t0 = time.time()
+    dp = dd.DistributedPoisson(ctx, comm, world, rank, nb=nb, nlevels=nlevels, transport="host", flag_fn=flag, n_uniform=n_uniform)
+    setup = time.time() - t0
+    dp.assemble()
+    dp.set_penalty_top()
+    its, rn = dp.solve(outer="gmres", rtol=1e-12, maxit=80)
+    top = dp.H.plans[-1]
+    np.savez(out % rank, gid=top.gid[top.owned], x=dp.EPSC.to_numpy()[:dp.n_owned], its=its, adaptive=dp.adaptive, setup=setup,
+             prepare_ms=dp.prepare_ms, n_owned=dp.n_owned)
+    comm.barrier()
+    comm.close()
+
+
+def main():
+    import torch.multiprocessing as mp
+    world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    nb = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    nlevels = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    n_uniform = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = "/tmp/amr_dd_rank%d.npz"
+    t0 = time.time()
+    mp.spawn(worker, args=(world, port, nb, nlevels, n_uniform, out), nprocs=world, join=True)
+    t_dist = time.time() - t0
+    # single GPU on the global mesh: the replicated level of the distributed run is one more level below
+    import femus_amd as fa
+    from femus_amd import capi, dd
+    from femus_amd.poisson import PoissonMG
+    part = dd.BoxPartition(world, 0)
+    p = part.p
+    ctx = fa.Context(0)
+    ms = [capi.Mesh.box(p[0] * nb // 2, p[1] * nb // 2, p[2] * nb // 2, hi=tuple(float(v) for v in p))]
+    for l in range(1, nlevels + 1):
+        if l < n_uniform + 1:
+            ms.append(ms[-1].refine())
+        else:
+            ms.append(ms[-1].refine_flagged(ms[-1].flag_elements(lambda x, level: flag(x, level - 1))))
+    pb = PoissonMG(ctx, 0, 0, 0, nlevels + 1, meshes=ms).init()
+    pb.assemble()
+    pb.prepare()
+    pb.mgsolve(outer="gmres", rtol=1e-13, maxit=80)
+    xs = pb.EPS.to_numpy()
+    if pb.Pamr[-1] is not None:
+        pb.EPSC.matrix_mult(pb.EPS, pb.Pamr[-1])
+        xs_full = pb.EPSC.to_numpy()
+    gid_ser, _ = dd.node_keys(ms[-1].arrays()[1], nlevels - 1, nb, part)
+    srt = np.argsort(gid_ser)
+    worst, seen, info = 0.0, 0, []
+    for r in range(world):
+        d = np.load(out % r)
+        pos = srt[np.searchsorted(gid_ser[srt], d["gid"])]
+        assert np.array_equal(gid_ser[pos], d["gid"])
+        worst = max(worst, np.linalg.norm(d["x"] - xs[pos]) / np.linalg.norm(xs))
+        seen += d["gid"].size
+        info.append({"rank": r, "owned": int(d["n_owned"]), "adaptive": bool(d["adaptive"]), "gmres_its": int(d["its"]), "setup_s": float(d["setup"]),
+                     "prepare_ms": float(d["prepare_ms"])})
+    assert seen == xs.size
+    print(json.dumps({"config": "config-5 shape: %d ranks (box %dx%dx%d), nb=%d, %d levels (%d uniform), Q2" % ((world,) + p + (nb, nlevels, n_uniform)),
+                      "dofs": int(xs.size), "hanging_top": int(pb.hanging[-1].size), "rel_diff_vs_single_gpu": worst, "wall_s_distributed": t_dist,
+                      "ranks": info}))
+    assert worst < 1e-9
+
+
+if __name__ == "__main__":
+    main()
