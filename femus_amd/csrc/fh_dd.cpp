@@ -67,11 +67,13 @@ extern "C" int fh_dd_plan_create(int rank, int nranks, int n, const int64_t* gid
     std::vector<int64_t> req(P->ghost.size());
     for (size_t k = 0; k < P->ghost.size(); k++) req[k] = gid[P->ghost[k]];
     FH_REQUIRE(alltoallv(user, nullptr, P->recv_counts.data(), nullptr, P->send_counts.data()) == 0, "fh_dd_plan_create: the count exchange failed");
-    int tot = 0;
+    int64_t tot64 = 0;
     for (int r = 0; r < nranks; r++) {
       FH_REQUIRE(P->send_counts[r] >= 0, "fh_dd_plan_create: negative count from rank %d", r);
-      tot += P->send_counts[r];
+      tot64 += P->send_counts[r];
     }
+    FH_REQUIRE(tot64 <= (int64_t)INT32_MAX, "fh_dd_plan_create: %lld requested entries do not fit the 32-bit send list", (long long)tot64);
+    const int tot = (int)tot64;
     std::vector<int64_t> got(std::max(tot, 1));
     FH_REQUIRE(alltoallv(user, req.data(), P->recv_counts.data(), got.data(), P->send_counts.data()) == 0, "fh_dd_plan_create: the id exchange failed");
     std::vector<int> srt(P->owned.size());
@@ -104,6 +106,48 @@ extern "C" int fh_dd_plan_create(int rank, int nranks, int n, const int64_t* gid
     P->offsets = {0, (int64_t)P->owned.size()};
   }
   *out = P.release();
+  return 0;
+}
+
+// ---- system numbering of a multi-variable problem on several ranks (a9) ----------------------------------------------------------
+// The reference numbers system rows rank by rank, and inside a rank variable by variable (LinearEquation::InitPde,
+// LinearEquation.cpp:212-237):   KKoffset[0][0] = 0,  KKoffset[j][p] = KKoffset[j-1][p] + (own size of variable j-1 on rank p),
+// KKoffset[0][p] = KKoffset[nvars][p-1];  KKIndex[j] = KKIndex[j-1] + (global size of variable j-1).
+// dof_offset[k][p] = first mesh dof of variable k's family owned by rank p (Mesh::_dofOffset[solType], Mesh.cpp:735-741), [nvars][nranks+1].
+extern "C" int fh_dd_system_offsets(int nvars, int nranks, const int64_t* dof_offset, int64_t* kk_offset /* [(nvars+1)][nranks] */,
+                                    int64_t* kk_index /* [nvars+1], may be NULL */) {
+  FH_REQUIRE(nvars >= 1 && nranks >= 1 && dof_offset && kk_offset, "fh_dd_system_offsets: bad arguments");
+  for (int k = 0; k < nvars; k++)
+    for (int p = 0; p < nranks; p++)
+      FH_REQUIRE(dof_offset[(size_t)k * (nranks + 1) + p] <= dof_offset[(size_t)k * (nranks + 1) + p + 1],
+                 "fh_dd_system_offsets: the dof offsets of variable %d decrease at rank %d", k, p);
+  auto KK = [&](int j, int p) -> int64_t& { return kk_offset[(size_t)j * nranks + p]; };
+  for (int p = 0; p < nranks; p++) {
+    KK(0, p) = p == 0 ? 0 : KK(nvars, p - 1);
+    for (int j = 1; j <= nvars; j++)
+      KK(j, p) = KK(j - 1, p) + (dof_offset[(size_t)(j - 1) * (nranks + 1) + p + 1] - dof_offset[(size_t)(j - 1) * (nranks + 1) + p]);
+  }
+  if (kk_index) {
+    kk_index[0] = 0;
+    for (int j = 1; j <= nvars; j++) kk_index[j] = kk_index[j - 1] + dof_offset[(size_t)(j - 1) * (nranks + 1) + nranks];
+  }
+  return 0;
+}
+
+// LinearEquation::GetSystemDof (LinearEquation.cpp:76-85): mesh dof `idof` of variable `var` -> system row
+// KKoffset[var][p] + idof - dof_offset[var][p], p = the rank owning the dof (Mesh::BisectionSearch_find_processor_of_dof, Mesh.cpp:1004-1018)
+extern "C" int fh_dd_system_dofs(int nvars, int nranks, const int64_t* dof_offset, const int64_t* kk_offset, int var, int n, const int64_t* idof,
+                                 int64_t* sysdof, int* owner /* may be NULL */) {
+  FH_REQUIRE(nvars >= 1 && nranks >= 1 && dof_offset && kk_offset && var >= 0 && var < nvars && n >= 0 && (n == 0 || (idof && sysdof)),
+             "fh_dd_system_dofs: bad arguments");
+  const int64_t* off = dof_offset + (size_t)var * (nranks + 1);
+  for (int i = 0; i < n; i++) {
+    FH_REQUIRE(idof[i] >= off[0] && idof[i] < off[nranks], "fh_dd_system_dofs: dof %lld of variable %d lies outside [%lld, %lld)", (long long)idof[i], var,
+               (long long)off[0], (long long)off[nranks]);
+    const int p = (int)(std::upper_bound(off, off + nranks + 1, idof[i]) - off) - 1;   // off[p] <= idof < off[p + 1] (empty ranks skipped)
+    sysdof[i] = kk_offset[(size_t)var * nranks + p] + idof[i] - off[p];
+    if (owner) owner[i] = p;
+  }
   return 0;
 }
 

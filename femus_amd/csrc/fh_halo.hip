@@ -226,11 +226,15 @@ int fh_halo_begin_ptr(fh_halo_t h, double* vd, int n_owned, bool prepacked) {
     FH_CHECK_HIP(hipEventRecord(h->ev_d2h, c->comm_stream));
   } else {
     FH_CHECK_NCCL(ncclGroupStart());
-    for (int r = 0; r < h->nranks; r++) {     // r == rank: only a self plan ("halo_self_rccl") has entries there
-      if (h->send_counts[r]) FH_CHECK_NCCL(ncclSend(h->d_sendbuf + h->send_off[r], h->send_counts[r], ncclDouble, r, h->comm, c->comm_stream));
-      if (h->recv_counts[r]) FH_CHECK_NCCL(ncclRecv(vd + n_owned + h->recv_off[r], h->recv_counts[r], ncclDouble, r, h->comm, c->comm_stream));
+    ncclResult_t bad = ncclSuccess;           // a group that was opened is always closed, also when a call inside it fails
+    for (int r = 0; r < h->nranks && bad == ncclSuccess; r++) {     // r == rank: only a self plan ("halo_self_rccl") has entries there
+      if (h->send_counts[r]) bad = ncclSend(h->d_sendbuf + h->send_off[r], h->send_counts[r], ncclDouble, r, h->comm, c->comm_stream);
+      if (h->recv_counts[r] && bad == ncclSuccess)
+        bad = ncclRecv(vd + n_owned + h->recv_off[r], h->recv_counts[r], ncclDouble, r, h->comm, c->comm_stream);
     }
-    FH_CHECK_NCCL(ncclGroupEnd());
+    const ncclResult_t closed = ncclGroupEnd();
+    FH_CHECK_NCCL(bad);
+    FH_CHECK_NCCL(closed);
     FH_CHECK_HIP(hipEventRecord(h->ev_done, c->comm_stream));
   }
   h->pend_vd = vd;

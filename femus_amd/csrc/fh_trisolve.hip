@@ -44,8 +44,7 @@ static void schedule(const std::vector<int>& rp, const std::vector<int>& col, in
   for (int i = 0; i < m; i++) rows[pos[lev[i]]++] = i;      // ascending row index inside a level
 }
 
-int fh_tri_create(fh_mat_t A, fh_tri_t* out) {
-  fh_tri_t T = new fh_tri_s();
+static int tri_fill(fh_mat_t A, fh_tri_t T) {
   T->m = A->m;
   T->A_uid = A->uid;
   std::vector<int> rows;
@@ -65,6 +64,16 @@ int fh_tri_create(fh_mat_t A, fh_tri_t* out) {
   T->h_diagpos = dpos;
   FH_CHECK_HIP(hipMalloc(&T->d_diagpos, std::max(A->m, 1) * sizeof(int)));
   FH_CHECK_HIP(hipMemcpy(T->d_diagpos, dpos.data(), (size_t)A->m * sizeof(int), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int fh_tri_create(fh_mat_t A, fh_tri_t* out) {
+  fh_tri_t T = new fh_tri_s();
+  const int rc = tri_fill(A, T);
+  if (rc) {
+    fh_tri_destroy(T);
+    return rc;
+  }
   *out = T;
   return 0;
 }

@@ -123,6 +123,30 @@ def node_keys(coords, level, nb, part):
     return gid, owner.astype(np.int64)
 
 
+def system_offsets(dof_offset):
+    """KKoffset [nvars+1][nranks] and KKIndex [nvars+1] of a multi-variable system from the per-variable dof offsets [nvars][nranks+1]
+    (fh_dd_system_offsets = LinearEquation::InitPde, LinearEquation.cpp:212-237)"""
+    L = capi.load_library()
+    off = np.ascontiguousarray(dof_offset, dtype=np.int64)
+    nvars, nranks = off.shape[0], off.shape[1] - 1
+    kk = np.zeros((nvars + 1, nranks), dtype=np.int64)
+    idx = np.zeros(nvars + 1, dtype=np.int64)
+    capi._chk(L.fh_dd_system_offsets(nvars, nranks, capi._p(off), capi._p(kk), capi._p(idx)))
+    return kk, idx
+
+
+def system_dofs(dof_offset, kk_offset, var, idof):
+    """system rows and owner ranks of the mesh dofs `idof` of variable `var` (fh_dd_system_dofs = LinearEquation::GetSystemDof)"""
+    L = capi.load_library()
+    off = np.ascontiguousarray(dof_offset, dtype=np.int64)
+    kk = np.ascontiguousarray(kk_offset, dtype=np.int64)
+    ids = np.ascontiguousarray(idof, dtype=np.int64)
+    rows, owner = np.empty(ids.size, dtype=np.int64), np.empty(ids.size, dtype=np.int32)
+    capi._chk(L.fh_dd_system_dofs(off.shape[0], off.shape[1] - 1, capi._p(off), capi._p(kk), int(var), ids.size, capi._p(ids), capi._p(rows),
+                                  capi._p(owner)))
+    return rows, owner
+
+
 class LevelPlan:
     pass
 
@@ -466,7 +490,7 @@ def job_token():
 
 class SocketComm:
     MAGIC = b"femus_hip_dd_v2\0"          # 16 bytes
-    MAX_MESSAGE = 1 << 36                 # 64 GiB: above any setup payload, below "exhaust the host on request"
+    MAX_MESSAGE = 1 << 32                 # 4 GiB: above any setup payload of the planner (index lists of one level), far below host memory
 
     def __init__(self, rank, size, addr="127.0.0.1", base_port=29500, timeout=300.0, token=None):
         import hmac

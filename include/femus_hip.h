@@ -402,7 +402,12 @@ int fh_host_binary_load(const char* path, int* n, double* values);
  *   fh_dd_plan_global     the reference's global numbering of the level: rank r owns the contiguous range [offsets[r], offsets[r+1])
  *                         (_dofOffset, Mesh.cpp:735-741; KKoffset, LinearEquation.cpp:212-237) and every ghost's global index (KKghost_nd,
  *                         :239-280) = the list NumericVector::init(N, n_local, ghost, fast, GHOSTED) takes
- *   fh_dd_plan_halo       the device exchange plan of the level (RCCL; parent != NULL: on that plan's communicator / transport) */
+ *   fh_dd_plan_halo       the device exchange plan of the level (RCCL; parent != NULL: on that plan's communicator / transport)
+ *   fh_dd_system_offsets  system rows of several variables on several ranks: rank by rank, variable by variable inside a rank
+ *                         (LinearEquation::InitPde, LinearEquation.cpp:212-237): kk_offset[j][p] = first row of variable j on rank p
+ *                         (row nvars = end of the rank), kk_index[j] = global size of the variables before j
+ *   fh_dd_system_dofs     LinearEquation::GetSystemDof (LinearEquation.cpp:76-85) for a list of mesh dofs of one variable: owner rank by
+ *                         bisection of the dof offsets (Mesh.cpp:1004-1018), row = kk_offset[var][p] + idof - dof_offset[var][p] */
 typedef struct fh_dd_plan_s* fh_dd_plan_t;
 typedef int (*fh_dd_alltoallv_fn)(void* user, const int64_t* send, const int* send_counts, int64_t* recv, int* recv_counts);
 int fh_dd_box_node_keys(int n, const double* coords /* [n*3] */, int level, int nb, const int p[3], int64_t* gid, int* owner);
@@ -413,6 +418,10 @@ int fh_dd_plan_get(fh_dd_plan_t plan, int* owned, int* ghost, int* newid, int* s
 int fh_dd_plan_global(fh_dd_plan_t plan, int64_t* offsets /* [nranks+1] */, int64_t* ghost_global /* [n_ghost] */);
 int fh_dd_plan_halo(fh_dd_plan_t plan, fh_ctx_t ctx, const char id128[128], fh_halo_t parent, fh_halo_t* halo);
 int fh_dd_plan_destroy(fh_dd_plan_t plan);
+int fh_dd_system_offsets(int nvars, int nranks, const int64_t* dof_offset /* [nvars][nranks+1] */, int64_t* kk_offset /* [nvars+1][nranks] */,
+                         int64_t* kk_index /* [nvars+1] or NULL */);
+int fh_dd_system_dofs(int nvars, int nranks, const int64_t* dof_offset, const int64_t* kk_offset, int var, int n, const int64_t* idof,
+                      int64_t* sysdof, int* owner /* or NULL */);
 
 #ifdef __cplusplus
 }

@@ -930,6 +930,43 @@ def solve_gmres_mg(H, rtol=1e-10, maxit=100, restart=30, **kw):
 # ----------------------------------------------------------------------------------------------
 # deterministic fills used by tests / bench (LCG, seed 12345, uniform [-1,1])
 # ----------------------------------------------------------------------------------------------
+def system_offsets(dof_offset):
+    """KKoffset / KKIndex of LinearEquation::InitPde (LinearEquation.cpp:212-237), loop for loop: dof_offset[k][p] is the reference's
+    `_msh->_dofOffset[_SolType[_SolPdeIndex[k]]][p]`"""
+    nvars, nprocs = len(dof_offset), len(dof_offset[0]) - 1
+    KKIndex = [0] * (nvars + 1)
+    for i in range(1, nvars + 1):
+        KKIndex[i] = KKIndex[i - 1] + dof_offset[i - 1][nprocs]
+    KK = [[0] * nprocs for _ in range(nvars + 1)]
+    KK[0][0] = 0
+    for j in range(1, nvars + 1):
+        KK[j][0] = KK[j - 1][0] + (dof_offset[j - 1][1] - dof_offset[j - 1][0])
+    for i in range(1, nprocs):
+        KK[0][i] = KK[nvars][i - 1]
+        for j in range(1, nvars + 1):
+            KK[j][i] = KK[j - 1][i] + (dof_offset[j - 1][i + 1] - dof_offset[j - 1][i])
+    return KK, KKIndex
+
+
+def find_processor_of_dof(offsets, dof, iproc=0):
+    """Mesh::BisectionSearch_find_processor_of_dof (Mesh.cpp:1004-1018)"""
+    nprocs = len(offsets) - 1
+    d0, d1, d = 0, nprocs, iproc
+    while dof < offsets[d] or dof >= offsets[d + 1]:
+        if dof < offsets[d]:
+            d1 = d
+        else:
+            d0 = d + 1
+        d = (d0 + d1) // 2
+    return d
+
+
+def system_dof(dof_offset, KK, var, idof, iproc=0):
+    """LinearEquation::GetSystemDof (LinearEquation.cpp:76-85) for the mesh dof `idof` of variable `var`"""
+    p = find_processor_of_dof(dof_offset[var], idof, iproc)
+    return KK[var][p] + idof - dof_offset[var][p], p
+
+
 def lcg_fill(n, seed=12345):
     s = np.uint64(seed)
     out = np.empty(n)

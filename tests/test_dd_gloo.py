@@ -204,3 +204,39 @@ def test_distributed_amr_vcycle_matches_serial_oracle(tmp_path, world):
         seen += d["gid"].size
         hang += int(d["hanging"])
     assert seen == ref.size and hang == H.hanging[-1].size and hang > 0
+
+
+def test_system_numbering_of_several_variables_on_several_ranks():
+    """a9 on several ranks: KKoffset / KKIndex / GetSystemDof through the C-ABI against the loop-for-loop restatement of
+    LinearEquation.cpp:76-85, 212-237, plus what the numbering must satisfy (every system row hit once, ranks own contiguous ranges,
+    variables contiguous inside a rank)"""
+    from femus_amd import dd
+    rng = np.random.default_rng(7)
+    for nvars, nranks in ((1, 1), (3, 1), (1, 4), (3, 4), (4, 8)):
+        sizes = rng.integers(0, 50, size=(nvars, nranks))           # empty ranks happen on coarse levels
+        sizes[:, 0] += 1
+        # Taylor-Hood style: variables of the same family share the offsets
+        if nvars >= 3:
+            sizes[1] = sizes[0]
+        off = np.zeros((nvars, nranks + 1), dtype=np.int64)
+        off[:, 1:] = np.cumsum(sizes, axis=1)
+        kk, idx = dd.system_offsets(off)
+        KK, KKIndex = fo.system_offsets(off.tolist())
+        assert np.array_equal(kk, np.array(KK)) and np.array_equal(idx, np.array(KKIndex))
+        seen = np.zeros(int(idx[-1]), dtype=np.int32)
+        for var in range(nvars):
+            ids = np.arange(off[var, -1], dtype=np.int64)
+            rows, owner = dd.system_dofs(off, kk, var, ids)
+            for i in rng.choice(ids.size, size=min(ids.size, 40), replace=False):
+                r, p = fo.system_dof(off.tolist(), KK, var, int(ids[i]), iproc=int(rng.integers(nranks)))
+                assert (r, p) == (rows[i], owner[i])
+            seen[rows] += 1
+            # rows of a rank's share of a variable are consecutive, inside the rank's range
+            for p in range(nranks):
+                mine = rows[owner == p]
+                assert mine.size == sizes[var, p]
+                if mine.size:
+                    assert np.array_equal(mine, kk[var, p] + np.arange(mine.size)) and mine[-1] < kk[nvars, p]
+        assert np.all(seen == 1)
+    with pytest.raises(RuntimeError):
+        dd.system_dofs(off, kk, 0, np.array([off[0, -1]], dtype=np.int64))       # one past the last dof
