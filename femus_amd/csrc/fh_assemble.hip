@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void k_assemble_poisson(AsmParams P) {
         int lo = rs, hi = re - 1;
         pos = -1;
         while (lo <= hi) {
-          const int mid = (lo + hi) >> 1;
+          const int mid = lo + ((hi - lo) >> 1);   // (lo + hi) overflows beyond 2^30 non-zeros
           const int cc = P.col[mid];
           if (cc == target) { pos = mid; break; }
           if (cc < target) lo = mid + 1; else hi = mid - 1;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void k_row_assemble(const int* __restrict__ ro
         const int target = elem_dof[(size_t)e * nloc + j];
         int lo = rs, hi = rs + len - 1, pos = 0;
         while (lo <= hi) {
-          const int mid = (lo + hi) >> 1;
+          const int mid = lo + ((hi - lo) >> 1);   // (lo + hi) overflows beyond 2^30 non-zeros
           const int cc = col[mid];
           if (cc == target) { pos = mid - rs; break; }
           if (cc < target) lo = mid + 1; else hi = mid - 1;
@@ -1509,8 +1509,10 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
       }
     }
   }
+  FH_TRACE("fh_assembler_create: tables uploaded (nel %d, nnode %d)", nel, nnode);
   std::vector<int> celems;
   color_elements(nel, as->nc, nloc, elem_dof, nnode, as->color_ptr, celems);
+  FH_TRACE("fh_assembler_create: element colouring done");
   as->ncolors = (int)as->color_ptr.size() - 1;
   FH_TRY(up((void**)&as->d_color_elems, celems.data(), celems.size() * sizeof(int)));
   std::vector<int> iota(nel);
@@ -1549,6 +1551,7 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
           aei[cur[r]++] = (e << 5) | i;
         }
       }
+    FH_TRACE("fh_assembler_create: row adjacency built (%zu pairs)", aei.size());
     FH_TRY(up((void**)&as->d_slot, slot.data(), slot.size() * sizeof(int)));
     FH_REQUIRE(nel < (1 << 26), "fh_assembler_create: too many elements for the packed adjacency");
     FH_TRY(up((void**)&as->d_adj_ptr, aptr.data(), aptr.size() * sizeof(int)));
@@ -1562,8 +1565,10 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
       FH_CHECK_HIP(hipMemset(as->d_Kbuf, 0xFF, as->kbuf_bytes));
       FH_CHECK_HIP(hipMemset(as->d_Fbuf, 0xFF, std::max<size_t>(aei.size(), 1) * sizeof(double)));
     }
+    FH_TRACE("fh_assembler_create: element-row buffer allocated (%.2f GB), building the row map", as->kbuf_bytes / 1e9);
     FH_TRY(dispatch_rows(as, A, nullptr, true));
     FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    FH_TRACE("fh_assembler_create: row map built");
     as->two_pass = true;
   }
   if (as->two_pass && as->dim == 3 && as->nc == 27 && as->ng == 64) {
@@ -1603,6 +1608,7 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
       }
     FH_TRY(up((void**)&as->d_Mab, Mab.data(), Mab.size() * sizeof(double)));
     FH_TRY(up((void**)&as->d_mphi, mphi.data(), mphi.size() * sizeof(double)));
+    FH_TRACE("fh_assembler_create: affine classification done (%d affine, %d general)", as->n_aff, as->n_gen);
   }
   *out = as;
   return 0;

@@ -4,6 +4,8 @@
 // for reductions, one partial per workgroup, second pass in one workgroup (deterministic order).
 #include <cstdlib>
 #include "fh_internal.h"
+#include <chrono>
+#include <cstdlib>
 #include <cstdarg>
 #include <cmath>
 
@@ -17,6 +19,28 @@ void fh_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* fh_last_error(void) { return g_err; }
+
+bool fh_trace_on() {
+  static const bool on = [] {
+    const char* e = getenv("FEMUS_HIP_TRACE");
+    return e && *e && *e != '0';
+  }();
+  return on;
+}
+
+void fh_trace_print(const char* fmt, ...) {
+  static const auto t0 = std::chrono::steady_clock::now();
+  static double last = 0.0;
+  const double now = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  char msg[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(msg, sizeof(msg), fmt, ap);
+  va_end(ap);
+  fprintf(stderr, "[femus_hip %9.3f s, +%8.3f] %s\n", now, now - last, msg);
+  fflush(stderr);
+  last = now;
+}
 extern "C" const char* fh_version(void) { return "femus_hip 0.1 (gfx950)"; }
 
 extern "C" int fh_init(int device, fh_ctx_t* out) {

@@ -34,6 +34,14 @@ void fh_set_error(const char* fmt, ...);
     if (_r) return _r;                                                                            \
   } while (0)
 
+// setup diagnostics: FEMUS_HIP_TRACE=1 prints the stages of the (host-side) setup calls with wall-clock times to stderr
+#define FH_TRACE(...)                                                                             \
+  do {                                                                                            \
+    if (fh_trace_on()) fh_trace_print(__VA_ARGS__);                                               \
+  } while (0)
+bool fh_trace_on();
+void fh_trace_print(const char* fmt, ...);
+
 struct fh_ctx_s {
   int device = 0;
   hipStream_t stream = nullptr;       // compute stream

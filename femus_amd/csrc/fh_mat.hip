@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void k_get_diag(const int* __restrict__ rowptr
   int lo = rowptr[r], hi = rowptr[r + 1] - 1;
   double v = 0.0;
   while (lo <= hi) {  // sorted columns
-    int mid = (lo + hi) >> 1;
+    int mid = lo + ((hi - lo) >> 1);   // (lo + hi) overflows beyond 2^30 non-zeros
     int cc = col[mid];
     if (cc == r) { v = val[mid]; break; }
     if (cc < r) lo = mid + 1; else hi = mid - 1;

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_patch_extract(const int* __restrict__ p
     int lo = rowptr[r], hi = rowptr[r + 1] - 1;
     double v = 0.0;
     while (lo <= hi) {
-      const int mid = (lo + hi) >> 1;
+      const int mid = lo + ((hi - lo) >> 1);   // (lo + hi) overflows beyond 2^30 non-zeros
       const int cc = col[mid];
       if (cc == c) {
         v = val[mid];
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void k_csr_symmetry(const int* __restrict__ ro
     int lo = rowptr[j], hi = rowptr[j + 1] - 1;
     double vt = 0.0;
     while (lo <= hi) {
-      const int mid = (lo + hi) >> 1;
+      const int mid = lo + ((hi - lo) >> 1);   // (lo + hi) overflows beyond 2^30 non-zeros
       if (col[mid] == i) { vt = val[mid]; break; }
       if (col[mid] < i) lo = mid + 1; else hi = mid - 1;
     }

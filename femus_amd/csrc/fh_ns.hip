@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64) void k_sys_row_gather(const int* __restrict__ a
       const int c = es[j];
       int lo = 0, hi = len - 1;
       while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
+        const int mid = lo + ((hi - lo) >> 1);   // (lo + hi) overflows beyond 2^30 non-zeros
         if (col[rs + mid] < c) lo = mid + 1; else hi = mid;
       }
       rowacc[lo] += Kr[j];

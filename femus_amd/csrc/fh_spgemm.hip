@@ -59,7 +59,7 @@ __device__ __forceinline__ void wave_sync_lds() {
 __device__ __forceinline__ int row_slot(const int* __restrict__ c_col, int cs, int clen, int c) {
   int lo = 0, hi = clen - 1;
   while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
+    const int mid = lo + ((hi - lo) >> 1);   // (lo + hi) overflows beyond 2^30 non-zeros
     if (c_col[cs + mid] < c) lo = mid + 1; else hi = mid;
   }
   return lo;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void k_spgemm_numeric(const int* __restrict__ 
       const int k = a_col[ka];
       int lo = b_rp[k], hi = b_rp[k + 1] - 1;
       while (lo <= hi) {
-        const int mid = (lo + hi) >> 1;
+        const int mid = lo + ((hi - lo) >> 1);   // (lo + hi) overflows beyond 2^30 non-zeros
         const int cc = b_col[mid];
         if (cc == c) {
           acc += a_val[ka] * b_val[mid];

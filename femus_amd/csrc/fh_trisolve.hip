@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_ilu_factor(const int* __restrict__ rows
       if (j >= m) continue;                         // ghost column: not part of the local block
       int lo = p + 1, hi = re - 1;
       while (lo <= hi) {
-        const int mid = (lo + hi) >> 1;
+        const int mid = lo + ((hi - lo) >> 1);   // (lo + hi) overflows beyond 2^30 non-zeros
         const int cc = col[mid];
         if (cc == j) {
           w[mid - rs] -= lik * lu[q];                // distinct j per lane: distinct slots

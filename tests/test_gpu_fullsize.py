@@ -160,3 +160,21 @@ def test_sampled_csr_rows_at_full_size_match_the_c_oracle(curved_problem):
         worst_a = max(worst_a, np.abs(val[rp[r]:rp[r + 1]] - want).max() / np.abs(want).max())
         worst_b = max(worst_b, abs(res[r] - b) / babs)
     assert worst_a <= 1e-12 and worst_b <= 1e-12, (worst_a, worst_b)
+
+
+def test_one_level_beyond_the_bench_size():
+    """128^3 elements on one GPU (16 974 593 dofs, 1.08e9 non-zeros: row pointers above 2^30, a 14.5 GB element-row buffer): the size
+    where 32-bit offset arithmetic runs out -- a binary-search midpoint `(lo + hi) / 2` did, in the row-map kernel.  Run as a child
+    process with a time limit; the script checks the row sums of the assembled operator (<= 1e-14), the true residual of the GMRES
+    solve and the peak of the solution (0.056212, the same as on the 64^3 mesh)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run("ulimit -c 0; exec %s %s 5" % (sys.executable, os.path.join(here, "perf_probe_bigsize.py")), shell=True, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["dofs"] == 16974593 and out["nnz"] == 1076890625
+    assert abs(out["max_u"] - 0.056212) < 2e-5 and out["true_relres"] < 1e-6 and out["gmres_its"] <= 8
