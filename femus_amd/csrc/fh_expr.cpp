@@ -311,8 +311,8 @@ extern "C" int fh_expr_eval_many(fh_expr_t e, int npts, const double* x, double*
 
 extern "C" int fh_expr_program(fh_expr_t e, int* ncode, int* nconst, int* code, double* consts) {
   FH_REQUIRE(e && ncode && nconst, "fh_expr_program: null argument");
-  if (code) memcpy(code, e->code.data(), e->code.size() * sizeof(int));
-  if (consts) memcpy(consts, e->consts.data(), e->consts.size() * sizeof(double));
+  if (code) fh_copy_out(code, e->code);
+  if (consts) fh_copy_out(consts, e->consts);
   *ncode = (int)e->code.size();
   *nconst = (int)e->consts.size();
   return 0;

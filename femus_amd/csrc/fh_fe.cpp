@@ -233,7 +233,7 @@ extern "C" int fh_fe_tables(int geom, int fe, int order, int* ng, int* nc, doubl
   if (phi || dphi) {
     std::vector<double> w, p, dp;
     fhfe::shape_tables(geom, fe, order, w, p, dp);
-    if (phi) memcpy(phi, p.data(), p.size() * sizeof(double));
+    if (phi) fh_copy_out(phi, p);
     if (dphi)   // reference layout: one [ng][nc] table per direction (_dphidxi, _dphideta, _dphidzeta)
       for (int k = 0; k < d; k++)
         for (int ig = 0; ig < g; ig++)
@@ -250,7 +250,7 @@ extern "C" int fh_fe_elem_prolongator(int geom, int fe, int* nchild, int* nc, do
   if (P) {
     std::vector<double> v;
     fhfe::elem_prolongator(geom, fe, v);
-    memcpy(P, v.data(), v.size() * sizeof(double));
+    fh_copy_out(P, v);
   }
   return 0;
 }

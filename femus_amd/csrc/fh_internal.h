@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <vector>
 #include "../../include/femus_hip.h"
 
@@ -41,6 +42,12 @@ void fh_set_error(const char* fmt, ...);
   } while (0)
 bool fh_trace_on();
 void fh_trace_print(const char* fmt, ...);
+
+// copy of a whole host vector into a caller's array (an empty vector may have a null data(): memcpy with a null source is undefined)
+template <class T>
+static inline void fh_copy_out(T* dst, const std::vector<T>& v) {
+  if (!v.empty()) std::copy(v.begin(), v.end(), dst);
+}
 
 struct fh_ctx_s {
   int device = 0;

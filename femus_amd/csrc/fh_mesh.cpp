@@ -351,15 +351,15 @@ int fh_mesh_host_arrays(fh_mesh_t m, int* dim, int* geom, int* nel, int* nnode, 
 }
 
 extern "C" int fh_mesh_get(fh_mesh_t m, int* elem_dof, double* coords, int* face_flag) {
-  if (elem_dof) memcpy(elem_dof, m->elem_dof.data(), m->elem_dof.size() * sizeof(int));
-  if (coords) memcpy(coords, m->coords.data(), m->coords.size() * sizeof(double));
-  if (face_flag) memcpy(face_flag, m->face_flag.data(), m->face_flag.size() * sizeof(int));
+  if (elem_dof) fh_copy_out(elem_dof, m->elem_dof);
+  if (coords) fh_copy_out(coords, m->coords);
+  if (face_flag) fh_copy_out(face_flag, m->face_flag);
   return 0;
 }
 
 extern "C" int fh_mesh_child_elems(fh_mesh_t m, int* child) {
   FH_REQUIRE(!m->child.empty(), "fh_mesh_child_elems: mesh has not been refined");
-  memcpy(child, m->child.data(), m->child.size() * sizeof(int));
+  fh_copy_out(child, m->child);
   return 0;
 }
 
@@ -390,7 +390,7 @@ extern "C" int fh_mesh_dirichlet_dofs(fh_mesh_t m, int fe, int* n, int* dofs) {
   dirichlet_list(m, fe, list);
   FH_REQUIRE(*n >= (int)list.size(), "fh_mesh_dirichlet_dofs: capacity %d < %d", *n, (int)list.size());
   *n = (int)list.size();
-  memcpy(dofs, list.data(), list.size() * sizeof(int));
+  fh_copy_out(dofs, list);
   return 0;
 }
 
@@ -419,7 +419,7 @@ extern "C" int fh_pattern_from_elements(int nel, int nloc, const int* elem_dof, 
     buf.erase(std::unique(buf.begin(), buf.end()), buf.end());
     if (col) {
       FH_REQUIRE(rowptr[r] == total, "fh_pattern_from_elements: rowptr does not match (call with col=NULL first)");
-      memcpy(col + total, buf.data(), buf.size() * sizeof(int));
+      fh_copy_out(col + total, buf);
     }
     total += (int64_t)buf.size();
     FH_REQUIRE(total < 2147483647ll, "fh_pattern_from_elements: nnz overflows int32");
@@ -822,10 +822,10 @@ extern "C" int fh_mesh_amr_constraints(fh_mesh_t m, int fe, int* n_hanging, int*
   amr_constraints(m, fe, R);
   if (hanging) {
     FH_REQUIRE(*n_hanging >= (int)R.hang.size() && *nnz >= (int)R.master.size(), "fh_mesh_amr_constraints: capacity too small");
-    memcpy(hanging, R.hang.data(), R.hang.size() * sizeof(int));
-    if (ptr) memcpy(ptr, R.ptr.data(), R.ptr.size() * sizeof(int));
-    if (master) memcpy(master, R.master.data(), R.master.size() * sizeof(int));
-    if (weight) memcpy(weight, R.w.data(), R.w.size() * sizeof(double));
+    fh_copy_out(hanging, R.hang);
+    if (ptr) fh_copy_out(ptr, R.ptr);
+    if (master) fh_copy_out(master, R.master);
+    if (weight) fh_copy_out(weight, R.w);
   }
   *n_hanging = (int)R.hang.size();
   *nnz = (int)R.master.size();
@@ -886,7 +886,7 @@ extern "C" int fh_system_elem_dofs(fh_mesh_t m, int nvars, const int* fe, int* n
     offs[k + 1] = off;
   }
   if (nd_out) *nd_out = nd;
-  if (offsets) memcpy(offsets, offs.data(), offs.size() * sizeof(int));
+  if (offsets) fh_copy_out(offsets, offs);
   if (elem_sys)
     for (int iel = 0; iel < m->nel; iel++) {
       int p = 0;
@@ -969,8 +969,8 @@ extern "C" int fh_mesh_vertex_patches(fh_mesh_t m, int nvars, const int* fe, int
   }
   if (ptr) {
     FH_REQUIRE(*npatch >= ns && *total >= (int)out_dofs.size(), "fh_mesh_vertex_patches: capacity too small");
-    memcpy(ptr, out_ptr.data(), out_ptr.size() * sizeof(int));
-    if (dofs) memcpy(dofs, out_dofs.data(), out_dofs.size() * sizeof(int));
+    fh_copy_out(ptr, out_ptr);
+    if (dofs) fh_copy_out(dofs, out_dofs);
   }
   *npatch = ns;
   *total = (int)out_dofs.size();

@@ -12,7 +12,9 @@
 #include "Edge.hpp"
 #include "GeomElemBase.hpp"
 #include <cstring>
+#include <map>
 #include <memory>
+#include <string>
 
 using namespace femus;
 
@@ -32,6 +34,15 @@ static basis* make_basis(const char* geom, const char* fe) {
   return nullptr;
 }
 
+// created once per (geom, fe) and kept: the reference's `basis` has no virtual destructor, so nothing is deleted through that type
+static basis* cached_basis(const char* geom, const char* fe) {
+  static std::map<std::string, basis*> cache;
+  const std::string key = std::string(geom) + "/" + fe;
+  auto it = cache.find(key);
+  if (it == cache.end()) it = cache.emplace(key, make_basis(geom, fe)).first;
+  return it->second;
+}
+
 extern "C" {
 
 // number of Gauss points; fills w[ng] and x[dim*ng] (x[d*ng+ig]) exactly as the reference tables hold them
@@ -44,17 +55,17 @@ int ref_gauss(const char* geom, const char* order, int dim, double* w, double* x
 }
 
 int ref_ndofs(const char* geom, const char* fe) {
-  std::unique_ptr<basis> b(make_basis(geom, fe));
+  basis* b = cached_basis(geom, fe);
   return b ? b->n_dofs() : -1;
 }
 int ref_ndofs_fine(const char* geom, const char* fe) {
-  std::unique_ptr<basis> b(make_basis(geom, fe));
+  basis* b = cached_basis(geom, fe);
   return b ? b->n_dofs_fine() : -1;
 }
 
 // which: 0 phi, 1 dx, 2 dy, 3 dz, 4 dxx, 5 dyy, 6 dzz, 7 dxy, 8 dyz, 9 dzx ; evaluated for dof j at point pt
 double ref_eval(const char* geom, const char* fe, int which, int j, const double* pt) {
-  std::unique_ptr<basis> b(make_basis(geom, fe));
+  basis* b = cached_basis(geom, fe);
   const int* I = b->GetIND(j);
   switch (which) {
     case 0: return b->eval_phi(I, pt);
@@ -73,31 +84,31 @@ double ref_eval(const char* geom, const char* fe, int which, int j, const double
 
 // topology tables of the Lagrange families (coarse node coords, IND, KVERT_IND, fine2coarse vertex map, face dofs)
 void ref_xcoarse(const char* geom, const char* fe, int i, int dim, double* out) {
-  std::unique_ptr<basis> b(make_basis(geom, fe));
+  basis* b = cached_basis(geom, fe);
   for (int d = 0; d < dim; d++) out[d] = b->GetXcoarse(i)[d];
 }
 void ref_ind(const char* geom, const char* fe, int i, int dim, int* out) {
-  std::unique_ptr<basis> b(make_basis(geom, fe));
+  basis* b = cached_basis(geom, fe);
   for (int d = 0; d < dim; d++) out[d] = b->GetIND(i)[d];
 }
 void ref_kvert_ind(const char* geom, const char* fe, int i, int* out) {
-  std::unique_ptr<basis> b(make_basis(geom, fe));
+  basis* b = cached_basis(geom, fe);
   out[0] = b->GetKVERT_IND(i)[0];
   out[1] = b->GetKVERT_IND(i)[1];
 }
 unsigned ref_fine2coarse_vertex(const char* geom, const char* fe, int child, unsigned v) {
-  std::unique_ptr<basis> b(make_basis(geom, fe));
+  basis* b = cached_basis(geom, fe);
   return b->GetFine2CoarseVertexMapping(child, v);
 }
 unsigned ref_face_dof(const char* geom, const char* fe, unsigned face, unsigned j) {
-  std::unique_ptr<basis> b(make_basis(geom, fe));
+  basis* b = cached_basis(geom, fe);
   return b->GetFaceDof(face, j);
 }
 
 // fine-node reference coordinates of the family (basis::GetX, Basis.hpp:251): the points set_prolongation_OneElement_All_FE
 // (ElemType.cpp:439-532) evaluates the coarse shape functions at
 void ref_xfine(const char* geom, const char* fe, int i, int dim, double* out) {
-  std::unique_ptr<basis> b(make_basis(geom, fe));
+  basis* b = cached_basis(geom, fe);
   for (int d = 0; d < dim; d++) out[d] = b->GetX(i)[d];
 }
 
