@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
       xs[lane * 4 + 3] = nu;
     }
     if (!(P.debug & 2)) {
-      if (P.kstride == 32) {   // padded rows: a half-wave stores one whole 256-byte row
+      if (P.kstride >= 28) {   // padded rows (32: one whole 256-byte row per half-wave; 28: 224 bytes = seven whole 32-byte sectors)
         // all LDS reads first; slots through v_readlane into scalar registers, and the stores written by hand so that each
         // half-wave stores its row off a SCALAR base address (address arithmetic on the scalar unit; left to the compiler every
         // store cost 5-9 vector instructions).  The 5 pad entries of a row receive whatever follows in the staging: the row pass
@@ -1122,8 +1122,9 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_mfma(AsmParams P, const 
 #pragma unroll
         for (int p = 0; p < 14; p++) {
           const int s0 = __builtin_amdgcn_readlane(sl_cur, 2 * p), s1 = __builtin_amdgcn_readlane(sl_cur, min(2 * p + 1, NC - 1));
-          const double* b0 = P.Kout + (size_t)s0 * 32;
-          const double* b1 = P.Kout + (size_t)s1 * 32;
+          const double* b0 = P.Kout + (size_t)s0 * P.kstride;
+          const double* b1 = P.Kout + (size_t)s1 * P.kstride;
+          if (j >= P.kstride) continue;
           if (hrow == 0) {
             if (s0 >= 0) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(joff), "v"(kv[p]), "s"(b0) : "memory");
           } else if (2 * p + 1 < NC) {
@@ -1557,7 +1558,7 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
     FH_TRY(up((void**)&as->d_adj_ptr, aptr.data(), aptr.size() * sizeof(int)));
     FH_TRY(up((void**)&as->d_adj_ei, aei.data(), aei.size() * sizeof(int)));
     FH_CHECK_HIP(hipMalloc(&as->d_rowmap, std::max<size_t>((size_t)aei.size() * nc, 1)));
-    as->kstride = (nc == 27 && ctx->assemble_kpad) ? 32 : nc;
+    as->kstride = (nc == 27 && ctx->assemble_kpad) ? (ctx->assemble_kpad == 28 ? 28 : 32) : nc;
     as->kbuf_bytes = std::max<size_t>((size_t)aei.size() * as->kstride, 1) * sizeof(double);
     FH_CHECK_HIP(hipMalloc(&as->d_Kbuf, as->kbuf_bytes));
     FH_CHECK_HIP(hipMalloc(&as->d_Fbuf, std::max<size_t>(aei.size(), 1) * sizeof(double)));

@@ -102,6 +102,7 @@ static int halo_create(fh_ctx_t ctx, int rank, int comm_ranks, const char* id128
   FH_REQUIRE(ctx && out && send_counts && recv_counts, "fh_halo_create: null argument");
   const int nranks = plan_ranks > 0 ? plan_ranks : comm_ranks;     // host transport: the plan spans plan_ranks, no RCCL communicator
   FH_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "fh_halo_create: bad rank %d of %d", rank, nranks);
+  FH_CHECK_HIP(hipSetDevice(ctx->device));      // the communicator binds to the CURRENT device: make it this context's (one rank = one device)
   fh_halo_t h = new fh_halo_s();
   h->ctx = ctx;
   h->rank = rank;
