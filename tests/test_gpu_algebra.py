@@ -167,3 +167,105 @@ def test_spmv_lds_buffer_modes(ctx, q2_matrix):
     ctx.set_option("spmv_share", 1)
     assert np.array_equal(outs[0], outs[1])
     assert rel(outs[0], A @ xs) < 1e-14
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_spmv_family_random_shapes(ctx, seed):
+    """random CSR matrices of awkward shapes (one row, one column, empty rows in runs, rows longer than several LDS tiles, blocks that
+    end exactly on a tile boundary, sizes around the 256-thread and 2048-entry granularities): y = Ax, y += Ax, r = b - Ax, the fused
+    Jacobi sweep, y = A^T x and the explicit transpose against scipy"""
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 1000, 2047, 2048, 2049, 20011]))
+    n = int(rng.choice([1, 7, 64, 2048, 2049, 30011]))
+    style = seed % 5
+    lens = np.zeros(m, dtype=np.int64)
+    if style == 0:
+        lens[:] = rng.integers(0, min(n, 9) + 1, m)
+    elif style == 1:                                   # long runs of empty rows, a few heavy ones
+        heavy = rng.choice(m, size=max(1, m // 50), replace=False)
+        lens[heavy] = rng.integers(1, min(n, 7000) + 1, heavy.size)
+    elif style == 2:                                   # every row exactly 2048 / k entries: blocks end on the tile boundary
+        lens[:] = min(n, int(rng.choice([1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048])))
+    elif style == 3:
+        lens[:] = rng.integers(0, min(n, 300) + 1, m)
+        lens[rng.integers(m)] = min(n, 9000)
+    else:
+        lens[:] = min(n, 125)                          # the Q2 row length
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([np.sort(rng.choice(n, size=k, replace=False)) for k in lens] + [np.zeros(0, dtype=np.int64)]).astype(np.int32)
+    vals = rng.uniform(-1, 1, indices.size)
+    A = sp.csr_matrix((vals, indices, indptr), shape=(m, n))
+    M = ctx.matrix_scipy(A)
+    xs, bs, y0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, m), rng.uniform(-1, 1, m)
+    scale = np.abs(A) @ np.abs(xs) + np.abs(bs) + np.abs(y0) + 1e-300
+    x, b, y = ctx.vector_from(xs), ctx.vector_from(bs), ctx.vector_from(y0)
+    y.matrix_mult(x, M)
+    assert np.max(np.abs(y.to_numpy() - A @ xs) / scale) < 1e-14
+    y.assign(ctx.vector_from(y0))
+    y.add_vector(x, M)
+    assert np.max(np.abs(y.to_numpy() - (y0 + A @ xs)) / scale) < 1e-14
+    y.resid(b, x, M)
+    assert np.max(np.abs(y.to_numpy() - (bs - A @ xs)) / scale) < 1e-14
+    if m == n:
+        dinv = rng.uniform(0.5, 2.0, m)
+        y.jacobi_sweep(b, x, M, ctx.vector_from(dinv), 0.7)
+        assert np.max(np.abs(y.to_numpy() - (xs + 0.7 * dinv * (bs - A @ xs))) / (scale * 2 + np.abs(xs))) < 1e-14
+    xt = rng.uniform(-1, 1, m)
+    z = ctx.vector(n)
+    z.matrix_mult_transpose(ctx.vector_from(xt), M)
+    assert np.max(np.abs(z.to_numpy() - A.T @ xt) / (np.abs(A.T) @ np.abs(xt) + 1e-300)) < 1e-14
+    assert (M.get_transpose().to_scipy() != A.T.tocsr()).nnz == 0
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_spgemm_random_shapes(ctx, seed):
+    """C = A B, P^T A P and A B C on random sparse operands (empty rows and columns, dense-ish rows, 1 x 1, tall and wide shapes),
+    structurally and numerically against scipy; the numeric re-run on new values keeps the pattern and follows the new values"""
+    rng = np.random.default_rng(2000 + seed)
+
+    def rand(m, n, density, empty_rows=0.2):
+        A = sp.random(m, n, density=density, random_state=np.random.RandomState(int(rng.integers(1 << 30))), format="csr",
+                      data_rvs=lambda k: rng.uniform(0.5, 1.5, k) * rng.choice([-1.0, 1.0], k))
+        kill = rng.uniform(size=m) < empty_rows
+        A = sp.diags((~kill).astype(float)) @ A
+        A.eliminate_zeros()
+        A.sort_indices()
+        return A.tocsr()
+
+    nf, nc = [(1, 1), (50, 7), (300, 300), (2000, 37), (513, 1200), (4000, 500), (64, 64), (1500, 1500)][seed]
+    dens = [1.0, 0.2, 0.02, 0.01, 0.01, 0.003, 0.5, 0.004][seed]
+    A = rand(nf, nf, dens)
+    P = rand(nf, nc, min(1.0, dens * 2))
+    Ad, Pd = ctx.matrix_scipy(A), ctx.matrix_scipy(P)
+
+    def same(Md, S):
+        S = S.tocsr()
+        S.sort_indices()
+        G = Md.to_scipy()
+        # the product pattern is structural (PETSc keeps entries that cancel to zero): compare through |A| |B|
+        assert G.shape == S.shape
+        assert abs(G - S).max() <= 1e-13 * max(abs(S).max(), 1e-300) if S.nnz else G.nnz == 0 or abs(G).max() == 0.0
+        return G
+
+    C = Ad.matmul(Pd)
+    G = same(C, A @ P)
+    struct = (abs(A) @ abs(P)).tocsr()
+    assert G.nnz == struct.nnz                                     # structural pattern, no numerical dropping
+    Gal = capi_ptap(ctx, Pd, Ad)
+    same(Gal, P.T @ A @ P)
+    A2 = A.copy()
+    A2.data = rng.uniform(-2, 2, A2.nnz)
+    Ad.set_values(A2.data)
+    Gal.ptap_numeric(Pd, Ad)
+    same(Gal, P.T @ A2 @ P)
+    Rd = ctx.matrix_scipy(P.T.tocsr())
+    D = type(Ad).abc(Rd, Ad, Pd)
+    same(D, P.T @ A2 @ P)
+    Ad.set_values(A.data)
+    D.abc_numeric(Rd, Ad, Pd)
+    same(D, P.T @ A @ P)
+
+
+def capi_ptap(ctx, P, A):
+    from femus_amd import capi
+    return capi.Mat.ptap(P, A)
