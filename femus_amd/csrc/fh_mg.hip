@@ -1035,10 +1035,25 @@ static int coarse_factor(fh_mg_t mg) {
 
 static int run_cycle(fh_mg_t mg);
 
-// greedy colouring of the matrix graph (host, integer setup work): coupled rows get different colours
+// greedy colouring of the matrix graph (host, integer setup work): coupled rows get different colours.  "Coupled" is symmetric: row i
+// reading x_j keeps j out of i's colour whether or not row j reads x_i (an unsymmetric pattern -- a convection term, a one-sided
+// constraint -- would otherwise let i and j share a colour, and row i would race with row j's update)
 static int color_rows(MgLevel& L) {
   fh_mat_t A = L.A;
   const int m = A->m;
+  std::vector<int> tptr(m + 1, 0);
+  for (int i = 0; i < m; i++)
+    for (int k = A->h_rowptr[i]; k < A->h_rowptr[i + 1]; k++) {
+      const int j = A->h_col[k];
+      if (j < m && j != i) tptr[j + 1]++;
+    }
+  for (int i = 0; i < m; i++) tptr[i + 1] += tptr[i];
+  std::vector<int> trow(tptr[m]), tpos(tptr.begin(), tptr.end() - 1);
+  for (int i = 0; i < m; i++)
+    for (int k = A->h_rowptr[i]; k < A->h_rowptr[i + 1]; k++) {
+      const int j = A->h_col[k];
+      if (j < m && j != i) trow[tpos[j]++] = i;      // row i reads column j
+    }
   std::vector<int> color(m, -1), mark;
   int nc = 0;
   for (int i = 0; i < m; i++) {
@@ -1047,6 +1062,8 @@ static int color_rows(MgLevel& L) {
       const int j = A->h_col[k];
       if (j < m && j != i && color[j] >= 0) mark[color[j]] = 1;
     }
+    for (int k = tptr[i]; k < tptr[i + 1]; k++)
+      if (color[trow[k]] >= 0) mark[color[trow[k]]] = 1;
     int c = 0;
     while (c < nc && mark[c]) c++;
     color[i] = c;

@@ -10,6 +10,7 @@ struct fh_tri_s {
   int *d_frows = nullptr, *d_brows = nullptr, *d_diagpos = nullptr;
   double* d_lu = nullptr;               // ILU(0) factors on A's pattern: strict lower part = L (unit diagonal), rest = U
   int* d_flag = nullptr;
+  double* d_t = nullptr;                // symmetric sweep: t = r - L z of the forward half, read by the backward half
   double shift = 0.0;                   // diagonal shift the last factorisation needed (MAT_SHIFT_NONZERO)
 };
 typedef fh_tri_s* fh_tri_t;

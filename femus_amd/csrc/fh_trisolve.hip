@@ -64,6 +64,7 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
   T->h_diagpos = dpos;
   FH_CHECK_HIP(hipMalloc(&T->d_diagpos, std::max(A->m, 1) * sizeof(int)));
   FH_CHECK_HIP(hipMemcpy(T->d_diagpos, dpos.data(), (size_t)A->m * sizeof(int), hipMemcpyHostToDevice));
+  FH_CHECK_HIP(hipMalloc(&T->d_t, std::max(A->m, 1) * sizeof(double)));
   return 0;
 }
 
@@ -80,16 +81,16 @@ int fh_tri_create(fh_mat_t A, fh_tri_t* out) {
 
 void fh_tri_destroy(fh_tri_t T) {
   if (!T) return;
-  for (void* p : {(void*)T->d_frows, (void*)T->d_brows, (void*)T->d_diagpos, (void*)T->d_lu, (void*)T->d_flag})
+  for (void* p : {(void*)T->d_frows, (void*)T->d_brows, (void*)T->d_diagpos, (void*)T->d_lu, (void*)T->d_flag, (void*)T->d_t})
     if (p) hipFree(p);
   delete T;
 }
 
 // ---- symmetric Gauss-Seidel ------------------------------------------------------------------------------------------------
-// forward, zero guess: z_i = dinv_i (r_i - sum_{j < i} a_ij z_j)   (entries right of the diagonal multiply zeros)
+// forward, zero guess: t_i = r_i - sum_{j < i} a_ij z_j, z_i = dinv_i t_i   (entries right of the diagonal multiply zeros)
 __global__ __launch_bounds__(256) void k_gs_fwd(const int* __restrict__ rows, int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                 const double* __restrict__ val, const double* __restrict__ dinv, const double* __restrict__ r,
-                                                double* z) {
+                                                double* z, double* __restrict__ t) {
   const int rr = (blockIdx.x * 256 + threadIdx.x) >> 4, gl = threadIdx.x & 15;
   const bool live = rr < nrows;
   const int i = live ? rows[rr] : 0;
@@ -101,12 +102,18 @@ __global__ __launch_bounds__(256) void k_gs_fwd(const int* __restrict__ rows, in
     }
 #pragma unroll
   for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if (live && gl == 0) z[i] = dinv[i] * (r[i] - acc);
+  if (live && gl == 0) {
+    const double ti = r[i] - acc;
+    t[i] = ti;
+    z[i] = dinv[i] * ti;
+  }
 }
 
-// backward: z_i = dinv_i (r_i - sum_{j != i, j local} a_ij z_j) with the newest values on both sides
+// backward: z_i = dinv_i (t_i - sum_{j > i, j local} a_ij z_j): the part left of the diagonal is the forward sweep's (kept in t, as PETSc's
+// MatSOR keeps it), so a row reads nothing that a LATER row of the sweep overwrites -- with an unsymmetric pattern (a_ij != 0, a_ji == 0) row j < i
+// is not ordered after row i by the schedule, and reading z_j in place would pick up its new value
 __global__ __launch_bounds__(256) void k_gs_bwd(const int* __restrict__ rows, int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
-                                                const double* __restrict__ val, const double* __restrict__ dinv, const double* __restrict__ r,
+                                                const double* __restrict__ val, const double* __restrict__ dinv, const double* __restrict__ t,
                                                 double* z, int m) {
   const int rr = (blockIdx.x * 256 + threadIdx.x) >> 4, gl = threadIdx.x & 15;
   const bool live = rr < nrows;
@@ -115,11 +122,11 @@ __global__ __launch_bounds__(256) void k_gs_bwd(const int* __restrict__ rows, in
   if (live)
     for (int k = rowptr[i] + gl; k < rowptr[i + 1]; k += 16) {
       const int j = col[k];
-      if (j != i && j < m) acc += val[k] * z[j];
+      if (j > i && j < m) acc += val[k] * z[j];
     }
 #pragma unroll
   for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if (live && gl == 0) z[i] = dinv[i] * (r[i] - acc);
+  if (live && gl == 0) z[i] = dinv[i] * (t[i] - acc);
 }
 
 // z = B r, B = one symmetric Gauss-Seidel sweep of A's local block from z = 0
@@ -129,12 +136,12 @@ int fh_tri_ssor_apply(fh_tri_t T, fh_mat_t A, const double* dinv, const double* 
   for (int l = 0; l < nf; l++) {
     const int n = T->fptr[l + 1] - T->fptr[l];
     hipLaunchKernelGGL(k_gs_fwd, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_frows + T->fptr[l], n, A->d_rowptr, A->d_col, A->d_val, dinv,
-                       r, z);
+                       r, z, T->d_t);
   }
   for (int l = 0; l < nb; l++) {
     const int n = T->bptr[l + 1] - T->bptr[l];
     hipLaunchKernelGGL(k_gs_bwd, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_brows + T->bptr[l], n, A->d_rowptr, A->d_col, A->d_val, dinv,
-                       r, z, A->m);
+                       T->d_t, z, A->m);
   }
   FH_CHECK_HIP(hipGetLastError());
   return 0;

@@ -686,9 +686,14 @@ def smooth(A, dinv, b, x, omega, nsweeps, zero_guess):
 
 
 def greedy_colors(A):
-    """greedy colouring of the matrix graph in row order: coupled rows get different colours"""
+    """greedy colouring of the matrix graph in row order: coupled rows get different colours (coupling taken from the symmetrised
+    pattern: i reading x_j separates them whether or not j reads x_i)"""
     A = A.tocsr()
     n = A.shape[0]
+    A = A[:, :n].tocsr()
+    S = sp.csr_matrix((np.ones(A.indices.size), A.indices, A.indptr), shape=A.shape)     # the stored pattern, explicit zeros included
+    A = (S + S.T).tocsr()
+    A.sort_indices()
     color = np.full(n, -1, dtype=np.int64)
     nc = 0
     for i in range(n):

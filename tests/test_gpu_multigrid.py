@@ -338,3 +338,83 @@ def test_ilu0_shift_on_a_zero_pivot(ctx):
     got = x.to_numpy()
     assert np.all(np.isfinite(got)) and rel(got, ref) < 1e-2 and rel(got[5:], ref[5:]) < 1e-9
     mg.destroy()
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("smoother,name", [(capi.SMOOTH_SOR, "sor"), (capi.SMOOTH_ILU0, "ilu0")])
+def test_natural_order_sweeps_on_unstructured_patterns(ctx, smoother, name, seed):
+    """level scheduling on dependency graphs that are not grids: random diagonally dominant matrices with unsymmetric patterns, rows
+    without a lower (or upper) part, long rows, a dense-ish block -- PCSOR's symmetric sweep and the ILU(0) solve against the oracle's
+    sequential loops.  Two-level wrapper: pre-smooth z = B b, r = b - A z, identity coarse level: x = z + r."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(3000 + seed)
+    n = [1, 2, 37, 400, 1500, 5000][seed]
+    dens = [1.0, 1.0, 0.3, 0.03, 0.01, 0.002][seed]
+    S = sp.random(n, n, density=dens, random_state=np.random.RandomState(seed + 11), format="lil", data_rvs=lambda k: rng.uniform(-1, 1, k))
+    if n >= 400:
+        S[n // 2, :] = rng.uniform(-1, 1, n) * (rng.uniform(size=n) < min(0.2, 300.0 / n))          # a long row (<= 512 entries per row in the ILU kernel)
+        S[:, n // 3] = (rng.uniform(-1, 1, n) * (rng.uniform(size=n) < 0.05)).reshape(-1, 1)
+        for i in range(0, n, 7):                                                        # rows with nothing left / right of the diagonal
+            S[i, :i] = 0.0
+        for i in range(3, n, 11):
+            S[i, i + 1:] = 0.0
+    S = S.tocsr()
+    S.setdiag(0.0)
+    S.eliminate_zeros()
+    assert np.diff(S.indptr).max() < 500
+    M = (S + sp.diags(np.asarray(abs(S).sum(axis=1)).ravel() + 1.0)).tocsr()
+    M.sort_indices()
+    A0, A1 = ctx.matrix_scipy(sp.identity(n, format="csr")), ctx.matrix_scipy(M)
+    P = ctx.matrix_scipy(sp.identity(n, format="csr"))
+    mg = capi.Multigrid(ctx, 2)
+    mg.set_level(0, A0, None, None, 0, 1.0, 1, 0)
+    mg.set_level(1, A1, P, None, smoother, 1.0, 1, 0)
+    mg.setup()
+    rhs = rng.uniform(-1, 1, n)
+    b, x = ctx.vector_from(rhs), ctx.vector(n)
+    mg.vcycle(b, x)
+    if name == "sor":
+        z = fo.sor_symmetric_natural(M, 1.0 / M.diagonal(), rhs)
+    else:
+        LU = fo.ilu0_factor(M)
+        assert LU[2] == 0.0                                   # diagonally dominant: no shift
+        z = fo.ilu0_apply(LU, rhs)
+    ref = z + (rhs - M @ z)
+    assert rel(x.to_numpy(), ref) < 1e-12
+    mg.destroy()
+
+
+def test_multicolour_sweep_on_an_unsymmetric_pattern_is_race_free(ctx):
+    """the multicolour Gauss-Seidel smoother on a matrix whose pattern is not symmetric (row i reads x_j, row j does not read x_i): the
+    colouring works on the symmetrised graph, so no row shares a colour with a row it reads -- repeated runs are bit-identical and equal
+    to the oracle's coloured sweep"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(77)
+    n = 3000
+    S = sp.random(n, n, density=0.004, random_state=np.random.RandomState(5), format="csr", data_rvs=lambda k: rng.uniform(-1, 1, k)).tolil()
+    S.setdiag(0.0)
+    S = S.tocsr()
+    S.eliminate_zeros()
+    M = (S + sp.diags(np.asarray(abs(S).sum(axis=1)).ravel() + 1.0)).tocsr()
+    M.sort_indices()
+    assert (abs(M) - abs(M).T).nnz > 0
+    color, nc = fo.greedy_colors(M)
+    rows, cols = M.nonzero()
+    off = rows != cols
+    assert not np.any(color[rows[off]] == color[cols[off]])
+    A0, A1 = ctx.matrix_scipy(sp.identity(n, format="csr")), ctx.matrix_scipy(M)
+    P = ctx.matrix_scipy(sp.identity(n, format="csr"))
+    mg = capi.Multigrid(ctx, 2)
+    mg.set_level(0, A0, None, None, 0, 1.0, 1, 0)
+    mg.set_level(1, A1, P, None, capi.SMOOTH_GS_COLOR, 0.9, 2, 0)
+    mg.setup()
+    rhs = rng.uniform(-1, 1, n)
+    b, x = ctx.vector_from(rhs), ctx.vector(n)
+    mg.vcycle(b, x)
+    first = x.to_numpy().copy()
+    for _ in range(5):
+        mg.vcycle(b, x)
+        assert np.array_equal(x.to_numpy(), first)
+    z = fo.smooth_sor_color(M, 1.0 / M.diagonal(), rhs, np.zeros(n), 0.9, 2, True, color, nc)
+    assert rel(first, z + (rhs - M @ z)) < 1e-12
+    mg.destroy()
