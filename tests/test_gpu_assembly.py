@@ -254,3 +254,51 @@ def test_affine_fast_path_matches_oracle(ctx, shape):
     finally:
         ctx.set_option("assemble_affine", 0)
     asm.destroy(), A.destroy()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_assembly_on_shuffled_meshes(ctx, seed):
+    """unstructured numbering: the nodes and the elements of a curved mesh are renumbered at random (nothing of the box generator's
+    vertex/edge/face/centre order, element order or locality survives) -- pattern, matrix and residual against the oracle's element
+    matrices added in ascending element order, for HEX27/Q2, HEX27/Q1, QUAD9/Q2 and QUAD9/Q1, with a solution and a closed-form source"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(500 + seed)
+    geom_args, fe = [((3, 2, 2), "biquadratic"), ((5, 4, 3), "biquadratic"), ((4, 3, 2), "linear"), ((7, 5, 0), "biquadratic"),
+                     ((9, 6, 0), "linear"), ((1, 1, 1), "biquadratic")][seed]
+    m = levels(geom_args, 2)[-1]
+    ed, xy, _ = m.arrays()
+    geom = "hex" if xy.shape[1] == 3 else "quad"
+    nc = {"linear": 2 ** xy.shape[1], "biquadratic": 3 ** xy.shape[1]}[fe]
+    h = 1.0 / (2 * max(geom_args))
+    xy = xy + rng.uniform(-0.04, 0.04, xy.shape) * h
+    nn = xy.shape[0]
+    if fe == "biquadratic":
+        perm = rng.permutation(nn)                 # new id of node k
+    else:
+        # Q1 dofs are the vertex nodes, numbered first (FEMuS: dof id = node id for the vertices): shuffle inside the two classes
+        nv = int(ed[:, :nc].max()) + 1
+        perm = np.concatenate([rng.permutation(nv), nv + rng.permutation(nn - nv)])
+    xy2 = np.empty_like(xy)
+    xy2[perm] = xy
+    ed2 = perm[ed][rng.permutation(ed.shape[0])].astype(np.int32)
+    n = nn if fe == "biquadratic" else int(ed2[:, :nc].max()) + 1
+    rp, col = capi.pattern_from_elements(ed2[:, :nc], n)
+    A = ctx.matrix_csr(n, n, rp, col)
+    res = ctx.vector(n)
+    u = rng.uniform(-1, 1, n)
+    asm = capi.Assembler(ctx, None, fe, A, elem_dof=ed2, coords=xy2)
+    asm.assemble(A, res, ctx.vector_from(u), 1, (2.0, 1.3))
+    et = fo.ElemType(geom, fe, "seventh")
+    X = np.transpose(xy2[ed2], (0, 2, 1))
+    Ko, Fo = fo.elem_poisson_batch(et, X, u[ed2[:, :nc]], lambda xg: 2.0 * np.prod(np.sin(1.3 * xg), axis=-1))
+    rows = np.repeat(ed2[:, :nc], nc, axis=1).ravel()
+    cols = np.tile(ed2[:, :nc], (1, nc)).ravel()
+    Ao = sp.coo_matrix((Ko.ravel(), (rows, cols)), shape=(n, n)).tocsr()
+    Ao.sort_indices()
+    bo = np.zeros(n)
+    np.add.at(bo, ed2[:, :nc].ravel(), Fo.ravel())
+    assert np.array_equal(Ao.indptr, rp) and np.array_equal(Ao.indices, col)
+    assert abs(A.values() - Ao.data).max() <= 1e-12 * abs(Ao.data).max()
+    assert abs(res.to_numpy() - bo).max() <= 1e-12 * max(abs(bo).max(), abs(Fo).max())
+    asm.destroy()
+    A.destroy()
