@@ -168,3 +168,43 @@ def test_uniform_flags_reproduce_uniform_refinement():
     assert f.elem_levels()[1]
     hang, _, _, _ = f.amr_constraints("biquadratic")
     assert hang.size == 0
+
+
+def random_flag(seed, prob):
+    """a flag that looks random but is a function of the element centroid: the host library and the oracle evaluate it on bit-identical
+    centroids, so both refine the same elements -- scattered single elements, level jumps of two and three, islands and holes"""
+    def flag(x, level):
+        key = (int(round(x[0] * 8192)) * 73856093) ^ (int(round(x[1] * 8192)) * 19349663) ^ (int(round(x[2] * 8192)) * 83492791) ^ (level * 2654435761) ^ seed
+        return ((key * 2246822519) >> 7) % 1000 < prob * 1000
+    return flag
+
+
+@pytest.mark.parametrize("mode", ["reference", "coarsest"])
+@pytest.mark.parametrize("box,nu,ns,seed,prob", [((3, 3, 0), 1, 3, 1, 0.5), ((4, 2, 0), 1, 3, 2, 0.3), ((2, 2, 2), 1, 2, 3, 0.4), ((2, 2, 2), 1, 2, 4, 0.7),
+                                                  ((3, 2, 2), 1, 2, 5, 0.15), ((2, 2, 0), 2, 3, 6, 0.6)])
+def test_randomly_flagged_refinement_matches_oracle(box, nu, ns, seed, prob, mode):
+    """scattered flags: numbering, coordinates, child tables bit-exact; hanging-node sets identical and weights to 1e-14, both map variants,
+    Q2 and Q1"""
+    flag = random_flag(seed, prob)
+    mo = fa.build_amr_levels(*box, nu, ns, flag)
+    mh = [capi.Mesh.box(*box).set_amr_mode(mode)]
+    for l in range(1, nu + ns):
+        flags = np.ones(mh[-1].nel, np.uint8) if l < nu else mh[-1].flag_elements(flag)
+        mh.append(mh[-1].refine_flagged(flags))
+    assert not mo[-1].homogeneous and fa.elem_levels(mo[-1]).max() - fa.elem_levels(mo[-1]).min() >= 2        # jumps of two levels and more occur
+    for a, b in zip(mh, mo):
+        ed, xy, ff = a.arrays()
+        assert np.array_equal(ed, b.elem_dof) and np.array_equal(xy, b.coords) and np.array_equal(ff, b.face_flag)
+        assert np.array_equal(a.elem_levels()[0], fa.elem_levels(b))
+        for fe in ("biquadratic", "linear"):
+            hang, ptr, master, w = a.amr_constraints(fe)
+            R = fa.amr_restriction(b, fe, mode) if not b.homogeneous else {}
+            assert np.array_equal(hang, np.array(sorted(R), dtype=np.int64))
+            for k, l in enumerate(hang):
+                row = sorted(R[int(l)].items())
+                assert np.array_equal(master[ptr[k]:ptr[k + 1]], [j for j, _ in row])
+                assert abs(w[ptr[k]:ptr[k + 1]] - np.array([v for _, v in row])).max() < 1e-14
+    for a, b in zip(mh[:-1], mo[:-1]):
+        assert np.array_equal(a.child_elems(), b.child_elem)
+    for a in mh:
+        a.destroy()
