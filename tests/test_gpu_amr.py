@@ -10,7 +10,7 @@ from femus_amd.poisson import PoissonMG
 from oracle import femus_oracle as fo
 from oracle import femus_oracle_amr as fa
 
-from test_amr_host import CASES, edge_flag, ex4_flag, poly_rhs
+from test_amr_host import CASES, edge_flag, ex4_flag, poly_rhs, random_flag
 
 pytestmark = pytest.mark.gpu
 
@@ -28,7 +28,7 @@ def amr_meshes(box, nu, ns, flag, mode="reference"):
 
 
 @pytest.mark.parametrize("mode", ["reference", "coarsest"])
-@pytest.mark.parametrize("box,nu,ns,flag", CASES + [((2, 2, 2), 1, 2, edge_flag)])
+@pytest.mark.parametrize("box,nu,ns,flag", CASES + [((2, 2, 2), 1, 2, edge_flag), ((3, 3, 0), 1, 3, random_flag(1, 0.5)), ((2, 2, 2), 1, 2, random_flag(3, 0.4))])
 @pytest.mark.parametrize("fe", ["biquadratic", "linear"])
 def test_amr_hierarchy_matches_oracle(ctx, box, nu, ns, flag, fe, mode):
     """mode "reference": the restriction map exactly as Mesh::GetAMRRestrictionAndAMRSolidMark builds it (default of the library and of
