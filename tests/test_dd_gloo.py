@@ -240,3 +240,80 @@ def test_system_numbering_of_several_variables_on_several_ranks():
         assert np.all(seen == 1)
     with pytest.raises(RuntimeError):
         dd.system_dofs(off, kk, 0, np.array([off[0, -1]], dtype=np.int64))       # one past the last dof
+
+
+def test_planner_on_arbitrary_partitions():
+    """the C planner takes any ownership map (what a METIS partition gives), not only boxes: R ranks simulated as threads of this process
+    with a mailbox all-to-all; random owners, random local subsets in random local order, random need flags.  Checked: owned / ghost
+    order, a simulated ghost exchange through the send lists delivers the owners' values, the global numbering is rank-contiguous and
+    every ghost's global index is offset[owner] + its position in the owner's owned list"""
+    import threading
+    from types import SimpleNamespace
+    from femus_amd import dd
+
+    class ThreadComm:
+        def __init__(self, rank, box):
+            self.rank, self.box = rank, box
+
+        def alltoallv(self, parts, dtype):
+            R = len(parts)
+            for r in range(R):
+                self.box["mail"][r][self.rank] = np.array(parts[r], dtype=dtype, copy=True)
+            self.box["barrier"].wait()
+            got = [self.box["mail"][self.rank][r] for r in range(R)]
+            self.box["barrier"].wait()
+            return got
+
+    for R, nglob, seed in ((2, 40, 1), (3, 500, 2), (5, 3000, 3), (8, 3000, 4), (4, 7, 5)):
+        rng = np.random.default_rng(seed)
+        owner_g = rng.integers(0, R, nglob)
+        owner_g[:R] = np.arange(R) if nglob >= R else owner_g[:R]
+        vals_g = rng.uniform(-1, 1, nglob)
+        local, need = [], []
+        for r in range(R):
+            mine = np.flatnonzero(owner_g == r)
+            others = np.flatnonzero(owner_g != r)
+            extra = others[rng.uniform(size=others.size) < 0.3]
+            ids = rng.permutation(np.concatenate([mine, extra]))
+            local.append(ids)
+            nd = (rng.uniform(size=ids.size) < 0.6) | (owner_g[ids] == r)
+            need.append(nd.astype(np.uint8))
+        box = {"mail": [[None] * R for _ in range(R)], "barrier": threading.Barrier(R)}
+        plans, errs = [None] * R, []
+
+        def work(r):
+            try:
+                part = SimpleNamespace(rank=r, nranks=R)
+                plans[r] = dd.build_level_plans(part, ThreadComm(r, box), [local[r].astype(np.int64)], [owner_g[local[r]]], [need[r]])[0]
+            except Exception as e:          # a failing rank must not leave the others at the barrier
+                errs.append(repr(e))
+                box["barrier"].abort()
+
+        ts = [threading.Thread(target=work, args=(r,)) for r in range(R)]
+        [t.start() for t in ts]
+        [t.join(120) for t in ts]
+        assert not errs and all(p is not None for p in plans), errs
+        owned_gid = [local[r][plans[r].owned] for r in range(R)]
+        for r in range(R):
+            P = plans[r]
+            assert np.array_equal(np.sort(P.owned), P.owned) and np.all(owner_g[owned_gid[r]] == r)          # ascending local id
+            assert set(owned_gid[r].tolist()) == set(np.flatnonzero(owner_g == r).tolist())                  # every owned node is local here
+            gg = local[r][P.ghost]
+            want = np.flatnonzero((owner_g[local[r]] != r) & (need[r] == 1))
+            assert set(P.ghost.tolist()) == set(want.tolist())
+            key = owner_g[gg] * (nglob + 1) + gg
+            assert np.all(np.diff(key) > 0)                                                                   # by owner, then global id
+            assert np.array_equal(P.recv_counts, np.bincount(owner_g[gg], minlength=R))
+            assert np.array_equal(P.offsets, np.concatenate([[0], np.cumsum([o.size for o in owned_gid])]))
+            pos = {int(g): k for rr in range(R) for k, g in enumerate(owned_gid[rr])}
+            assert np.array_equal(P.ghost_global, [P.offsets[owner_g[g]] + pos[int(g)] for g in gg])
+        # the exchange: rank s sends values[owned][send_idx] cut by send_counts; rank r lays the segments out by source rank
+        for r in range(R):
+            got = []
+            for s in range(R):
+                Ps = plans[s]
+                so = np.concatenate([[0], np.cumsum(Ps.send_counts)])
+                seg = vals_g[owned_gid[s]][Ps.send_idx[so[r]:so[r + 1]]]
+                assert seg.size == plans[r].recv_counts[s]
+                got.append(seg)
+            assert np.array_equal(np.concatenate(got) if got else np.zeros(0), vals_g[local[r][plans[r].ghost]])
