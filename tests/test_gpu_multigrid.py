@@ -418,3 +418,36 @@ def test_multicolour_sweep_on_an_unsymmetric_pattern_is_race_free(ctx):
     z = fo.smooth_sor_color(M, 1.0 / M.diagonal(), rhs, np.zeros(n), 0.9, 2, True, color, nc)
     assert rel(first, z + (rhs - M @ z)) < 1e-12
     mg.destroy()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 33, 63, 64, 65, 97, 257, 1000])
+@pytest.mark.parametrize("kind", ["spd", "general", "permuted"])
+def test_coarse_inverse_random_sizes(ctx, n, kind):
+    """the blocked dense inverse of level 0 for sizes around the 32-wide pivot block: symmetric positive definite (the symmetric
+    sweep), a general dense matrix (Gauss-Jordan), and one whose pivot blocks need row exchanges (zero diagonal inside the blocks);
+    sparse form = dense pattern"""
+    rng = np.random.default_rng(n * 7 + len(kind))
+    G = rng.uniform(-1, 1, (n, n))
+    if kind == "spd":
+        M = G @ G.T + n * np.eye(n)
+    elif kind == "general":
+        M = G + n * 0.6 * np.eye(n)
+    else:
+        # inside every 32-block the rows are rotated by one: the diagonal is zero and the block's pivots sit off the diagonal
+        M = 0.01 * G
+        np.fill_diagonal(M, 0.0)
+        for b0 in range(0, n, 32):
+            sz = min(32, n - b0)
+            for k in range(sz):
+                M[b0 + k, b0 + (k + 1) % sz] += 1.0 + 0.1 * k / 32
+        if n % 32 == 1:
+            M[n - 1, n - 1] = 1.0            # a block of one has nothing to exchange with
+    mg, A = _one_level(ctx, M)
+    mg.setup()
+    for rep in range(2):
+        rhs = rng.uniform(-1, 1, n)
+        b, x = ctx.vector_from(rhs), ctx.vector(n)
+        mg.vcycle(b, x)
+        ref = np.linalg.solve(M, rhs)
+        assert rel(x.to_numpy(), ref) < 1e-10 * max(1.0, np.linalg.cond(M) / 1e3)
+    mg.destroy()
