@@ -1047,6 +1047,8 @@ static int read_gambit(const char* path, double Lref, fh_mesh_t* out) {
     *v = strtod(tok[k].c_str(), &e);
     return e != tok[k].c_str() && *e == 0;
   };
+  // a token used as an integer: finite, integral, inside [lo, hi] -- (int) of NaN or of 1e300 is undefined behaviour, not an error path
+  auto whole = [&](size_t k, double lo, double hi, double* v) { return num(k, v) && *v >= lo && *v <= hi && *v == std::floor(*v); };
   p = seek("NDFVL", 0);
   double v[6];
   for (int k = 0; k < 6; k++) FH_REQUIRE(num(p + 1 + k, &v[k]), "fh_mesh_read_gambit: %s: error control data mesh", path);
@@ -1084,7 +1086,7 @@ static int read_gambit(const char* path, double Lref, fh_mesh_t* out) {
   std::vector<int> ed((size_t)nel * nl);
   for (int iel = 0; iel < nel; iel++) {
     double nve;
-    FH_REQUIRE(num(p + 2, &nve), "fh_mesh_read_gambit: %s: error element data mesh", path);
+    FH_REQUIRE(whole(p + 2, 0, 1000, &nve), "fh_mesh_read_gambit: %s: error element data mesh", path);
     if ((int)nve != nl) {
       fh_set_error("Error! Invalid element type in reading Gambit File! (element %d has %d nodes; HEX27 / QUAD9 meshes are served)", iel + 1, (int)nve);
       return 2;
@@ -1092,7 +1094,7 @@ static int read_gambit(const char* path, double Lref, fh_mesh_t* out) {
     p += 3;
     for (int i = 0; i < nl; i++) {
       double val;
-      FH_REQUIRE(num(p + i, &val) && val >= 1 && val <= nvt, "fh_mesh_read_gambit: %s: bad node id in element %d", path, iel + 1);
+      FH_REQUIRE(whole(p + i, 1, nvt, &val), "fh_mesh_read_gambit: %s: bad node id in element %d", path, iel + 1);
       ed[(size_t)iel * nl + g2f[i]] = (int)val - 1;
     }
     p += nl;
@@ -1106,7 +1108,7 @@ static int read_gambit(const char* path, double Lref, fh_mesh_t* out) {
   for (int j = 0; j < nvt; j++) {
     for (int d = 0; d < dimNodes; d++) {
       double c;
-      FH_REQUIRE(num(p + 1 + d, &c), "fh_mesh_read_gambit: %s: error node data mesh", path);
+      FH_REQUIRE(num(p + 1 + d, &c) && std::isfinite(c), "fh_mesh_read_gambit: %s: error node data mesh", path);
       if (d < dim) xyz[(size_t)j * dim + d] = c / Lref;
     }
     p += 1 + dimNodes;
@@ -1118,12 +1120,12 @@ static int read_gambit(const char* path, double Lref, fh_mesh_t* out) {
   for (int k = 0; k < ngroup; k++) {
     p = seek("GROUP:", p);
     double ngel, mat, name;
-    FH_REQUIRE(p < tok.size() && num(p + 3, &ngel) && num(p + 5, &mat) && num(p + 8, &name) && ngel >= 0 && ngel <= nel,
+    FH_REQUIRE(p < tok.size() && whole(p + 3, 0, nel, &ngel) && whole(p + 5, -1e9, 1e9, &mat) && whole(p + 8, -1e9, 1e9, &name),
                "fh_mesh_read_gambit: %s: error group data mesh", path);
     p += 10;
     for (int i = 0; i < (int)ngel; i++) {
       double iel;
-      FH_REQUIRE(num(p + i, &iel) && iel >= 1 && iel <= nel, "fh_mesh_read_gambit: %s: error group data mesh", path);
+      FH_REQUIRE(whole(p + i, 1, nel, &iel), "fh_mesh_read_gambit: %s: error group data mesh", path);
       group[(int)iel - 1] = (int)name;
       material[(int)iel - 1] = (int)mat;
     }
@@ -1136,13 +1138,12 @@ static int read_gambit(const char* path, double Lref, fh_mesh_t* out) {
   for (int k = 0; k < nbcd; k++) {
     p = seek("CONDITIONS", p);
     double value, nface;
-    FH_REQUIRE(p < tok.size() && num(p + 2, &value) && num(p + 4, &nface) && nface >= 0 && nface <= (double)nel * nf && fabs(value) < 1e9,
+    FH_REQUIRE(p < tok.size() && whole(p + 2, -1e9, 1e9, &value) && whole(p + 4, 0, (double)nel * nf, &nface),
                "fh_mesh_read_gambit: %s: error boundary data mesh", path);
     p += 7;
     for (int i = 0; i < (int)nface; i++) {
       double iel, iface;
-      FH_REQUIRE(num(p, &iel) && num(p + 2, &iface) && iel >= 1 && iel <= nel && iface >= 1 && iface <= nf, "fh_mesh_read_gambit: %s: error boundary data mesh",
-                 path);
+      FH_REQUIRE(whole(p, 1, nel, &iel) && whole(p + 2, 1, nf, &iface), "fh_mesh_read_gambit: %s: error boundary data mesh", path);
       const int f = dim == 3 ? gface_hex[(int)iface - 1] : (int)iface - 1;
       ff[((size_t)iel - 1) * nf + f] = -(int)value - 1;
       p += 3;
