@@ -695,6 +695,19 @@ class Expr:
         _chk(self.L.fh_expr_eval_many(self.h, x.shape[0], _p(x), _p(out)))
         return out
 
+    def program(self):
+        """(code, consts): the postfix program the device evaluator runs (fh_expr_program)"""
+        nc, nk = ctypes.c_int(), ctypes.c_int()
+        _chk(self.L.fh_expr_program(self.h, ctypes.byref(nc), ctypes.byref(nk), None, None))
+        code, consts = np.empty(nc.value, np.int32), np.empty(nk.value)
+        _chk(self.L.fh_expr_program(self.h, ctypes.byref(nc), ctypes.byref(nk), _p(code), _p(consts)))
+        return code, consts
+
+    def n_variables(self):
+        n = ctypes.c_int()
+        _chk(self.L.fh_expr_nvars(self.h, ctypes.byref(n)))
+        return n.value
+
     def destroy(self):
         if self.h:
             self.L.fh_expr_destroy(self.h)
@@ -796,8 +809,18 @@ class Multigrid:
             self.h = None
 
 
+def version():
+    return load_library().fh_version().decode()
+
+
 class Halo:
     """neighbour exchange plan over RCCL (VecGhostUpdate / MPIAIJ scatter replacement); one rank per GPU"""
+
+    def sizes(self):
+        """(entries this rank sends, ghost entries it receives) per exchange"""
+        a, b = ctypes.c_int(), ctypes.c_int()
+        _chk(self.L.fh_halo_sizes(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def __init__(self, ctx, rank, nranks, unique_id, send_counts, send_idx, recv_counts, parent=None):
         self.ctx, self.L = ctx, ctx.L

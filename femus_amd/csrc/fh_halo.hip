@@ -146,6 +146,7 @@ static int halo_create(fh_ctx_t ctx, int rank, int comm_ranks, const char* id128
 }
 
 extern "C" int fh_halo_sizes(fh_halo_t h, int* nsend, int* nrecv) {
+  FH_REQUIRE(h, "fh_halo_sizes: null plan");
   if (nsend) *nsend = h->nsend;
   if (nrecv) *nrecv = h->nrecv;
   return 0;

@@ -70,3 +70,15 @@ def test_numbers_do_not_depend_on_the_process_locale():
         assert capi.Expr("0.5*x + 1.25e1 + .5 + 3.")([2.0, 0, 0, 0]) == 0.5 * 2 + 12.5 + 0.5 + 3.0
     finally:
         locale.setlocale(locale.LC_NUMERIC, old)
+
+
+def test_program_and_variable_count_are_exposed():
+    """fh_expr_program / fh_expr_nvars: what the device evaluator is handed (two-call size query), fh_version"""
+    f = capi.Expr("2*x+sin(y)", "x,y")
+    assert f.n_variables() == 2
+    code, consts = f.program()
+    assert code.size >= 5 and 2.0 in consts.tolist()
+    g = capi.Expr("2*x+sin(y)", "x,y,z,t")
+    assert g.n_variables() == 4 and np.array_equal(g.program()[1], consts)
+    assert capi.version().startswith("femus_hip")
+    f.destroy(), g.destroy()

@@ -128,3 +128,32 @@ def test_distributed_cycle_with_rccl_exchanges_on_one_device():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_cycle_probe.py")], capture_output=True, text=True, timeout=300, cwd=root)
     assert out.returncode == 0 and "PROBE OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_planner_output_goes_straight_into_a_device_plan(ctx):
+    """fh_dd_plan_create -> fh_dd_plan_halo -> fh_halo_sizes: the path a C++ launcher takes (no Python in between).  One rank: the plan
+    has no ghosts, the device plan is inert; the counts the planner reports are the counts the device plan holds"""
+    import ctypes
+    L = capi.load_library()
+    n = 50
+    gid = np.arange(n, dtype=np.int64)[::-1].copy()
+    owner = np.zeros(n, dtype=np.int32)
+    need = np.ones(n, dtype=np.uint8)
+    plan = ctypes.c_void_p()
+    capi._chk(L.fh_dd_plan_create(0, 1, n, capi._p(gid), capi._p(owner), capi._p(need), None, None, ctypes.byref(plan)))
+    a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    capi._chk(L.fh_dd_plan_sizes(plan, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    assert (a.value, b.value, c.value) == (n, 0, 0)
+    halo = ctypes.c_void_p()
+    capi._chk(L.fh_dd_plan_halo(plan, ctx.h, None, None, ctypes.byref(halo)))
+    ns, nr = ctypes.c_int(-1), ctypes.c_int(-1)
+    capi._chk(L.fh_halo_sizes(halo, ctypes.byref(ns), ctypes.byref(nr)))
+    assert (ns.value, nr.value) == (0, 0)
+    # an inert plan: update / begin / end are no-ops on any vector
+    v = ctx.vector_from(np.arange(float(n)))
+    capi._chk(L.fh_halo_update(halo, v.h))
+    assert np.array_equal(v.to_numpy(), np.arange(float(n)))
+    capi._chk(L.fh_halo_destroy(halo))
+    capi._chk(L.fh_dd_plan_destroy(plan))
+    with pytest.raises(capi.FemusHipError):
+        capi._chk(L.fh_dd_plan_halo(None, ctx.h, None, None, ctypes.byref(halo)))
