@@ -97,7 +97,22 @@ def main():
             mg.vcycle(b, x)
             errs.append(np.linalg.norm(x.to_numpy() - ref) / np.linalg.norm(ref))
         counts = [h.stats()["updates"] for h in halos]            # V(2,2): 5 exchanges on either distributed level
-        out.append((overlap, max(errs), counts))
+        # what one grouped ncclSend/ncclRecv costs on this stack (tiny messages: software + launch latency, no link in a self exchange)
+        import time
+        ctx.set_option("halo_profile", 1)
+        for h in halos:
+            h.stats(reset=True)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for rep in range(50):
+            mg.vcycle(b, x)
+        ctx.sync()
+        cyc_us = (time.perf_counter() - t0) / 50 * 1e6
+        st = [h.stats() for h in halos]
+        ctx.set_option("halo_profile", 0)
+        per_exchange_us = sum(s_["exchange_ms"] for s_ in st) / max(1, sum(s_["updates"] for s_ in st)) * 1e3
+        exposed_us = sum(s_["exposed_ms"] for s_ in st) / max(1, sum(s_["updates"] for s_ in st)) * 1e3
+        out.append((overlap, max(errs), counts, {"cycle_us": round(cyc_us, 1), "rccl_group_us": round(per_exchange_us, 1), "exposed_us": round(exposed_us, 1)}))
         assert max(errs) < 1e-12, (overlap, errs)
         mg.destroy()
     assert out[0][2] == [5, 5] and out[1][2] == [5, 5], out
