@@ -1385,6 +1385,7 @@ static AsmParams base_params(fh_assembler_t as) {
 
 extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, int nel, int nloc, const int* elem_dof, int nnode,
                                    const double* coords, fh_mat_t A, fh_assembler_t* out) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(ctx && elem_dof && coords && A && out, "fh_assembler_create: null argument");
   FH_REQUIRE(geom == 0 || geom == 1, "fh_assembler_create: geom must be 0 (hex) or 1 (quad)");
   FH_REQUIRE(fe == 0 || fe == 2, "fh_assembler_create: fe must be 0 (linear) or 2 (biquadratic)");
@@ -1613,6 +1614,7 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
   }
   *out = as;
   return 0;
+  FH_GUARD_END("fh_assembler_create")
 }
 
 extern "C" int fh_assembler_destroy(fh_assembler_t as) {

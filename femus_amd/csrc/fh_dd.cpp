@@ -42,6 +42,7 @@ extern "C" int fh_dd_box_node_keys(int n, const double* coords /* [n*3] */, int 
 
 extern "C" int fh_dd_plan_create(int rank, int nranks, int n, const int64_t* gid, const int* owner, const unsigned char* need,
                                  fh_dd_alltoallv_fn alltoallv, void* user, fh_dd_plan_t* out) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(out && n >= 0 && (n == 0 || (gid && owner && need)) && nranks >= 1 && rank >= 0 && rank < nranks, "fh_dd_plan_create: bad arguments");
   FH_REQUIRE(nranks == 1 || alltoallv, "fh_dd_plan_create: several ranks need the all-to-all function");
   std::unique_ptr<fh_dd_plan_s> P(new fh_dd_plan_s());
@@ -107,6 +108,7 @@ extern "C" int fh_dd_plan_create(int rank, int nranks, int n, const int64_t* gid
   }
   *out = P.release();
   return 0;
+  FH_GUARD_END("fh_dd_plan_create")
 }
 
 // ---- system numbering of a multi-variable problem on several ranks (a9) ----------------------------------------------------------

@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <algorithm>
 #include <vector>
@@ -34,6 +36,20 @@ void fh_set_error(const char* fmt, ...);
     int _r = (expr);                                                                              \
     if (_r) return _r;                                                                            \
   } while (0)
+
+// no C++ exception leaves an entry point whose host side allocates in proportion to the problem (meshes, patterns, plans, symbolic
+// products): std::bad_alloc and friends become an error code + fh_last_error, as every other failure of the C ABI
+#define FH_GUARD_BEGIN try {
+#define FH_GUARD_END(who)                                                        \
+  }                                                                              \
+  catch (const std::bad_alloc&) {                                                \
+    fh_set_error("%s: out of host memory", who);                                 \
+    return 3;                                                                    \
+  }                                                                              \
+  catch (const std::exception& e) {                                              \
+    fh_set_error("%s: %s", who, e.what());                                       \
+    return 3;                                                                    \
+  }
 
 // setup diagnostics: FEMUS_HIP_TRACE=1 prints the stages of the (host-side) setup calls with wall-clock times to stderr
 #define FH_TRACE(...)                                                                             \

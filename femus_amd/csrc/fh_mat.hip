@@ -19,6 +19,7 @@
 // creation / destruction
 // ------------------------------------------------------------------------------------------------
 extern "C" int fh_mat_create_csr(fh_ctx_t c, int m, int n, const int* rowptr, const int* col, const double* val, fh_mat_t* out) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(c && out && rowptr, "fh_mat_create_csr: null argument");
   FH_REQUIRE(m >= 0 && n >= 0 && rowptr[0] == 0, "fh_mat_create_csr: bad sizes");
   const int nnz = rowptr[m];
@@ -55,6 +56,7 @@ extern "C" int fh_mat_create_csr(fh_ctx_t c, int m, int n, const int* rowptr, co
   FH_TRY(fh_mat_build_rowblocks(A, c->spmv_tile));
   *out = A;
   return 0;
+  FH_GUARD_END("fh_mat_create_csr")
 }
 
 extern "C" int fh_mat_destroy(fh_mat_t A) {
@@ -377,6 +379,7 @@ extern "C" int fh_mat_row_mask(fh_mat_t A, const unsigned char* colmask /* [A->n
 // map[k] for every non-zero k = (r, c) of dst: position of (src_row[r], src_col[c]) in src, or -1 when src has no such entry
 // (NULL row / column lists = identity).  Feeds fh_mat_gather_values.
 extern "C" int fh_mat_value_map(fh_mat_t dst, fh_mat_t src, const int* src_row, const int* src_col, fh_index_t* out) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(dst && src && out, "fh_mat_value_map: null argument");
   std::vector<int> map((size_t)dst->nnz, -1);
   for (int r = 0; r < dst->m; r++) {
@@ -393,11 +396,13 @@ extern "C" int fh_mat_value_map(fh_mat_t dst, fh_mat_t src, const int* src_row, 
     }
   }
   return fh_index_create(dst->ctx, dst->nnz, map.data(), out);
+  FH_GUARD_END("fh_mat_value_map")
 }
 
 // dst = the listed rows of src (in list order) with columns renumbered by newcol[src->n] (entries whose new column is < 0 are
 // dropped -- they must hold zeros, which fh_mat_restrict_check verifies on the device); *map as in fh_mat_value_map, values gathered
 extern "C" int fh_mat_restrict(fh_mat_t src, int nrows, const int* rows, const int* newcol, int ncols_new, fh_mat_t* out, fh_index_t* map_out) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(src && out && map_out && newcol && nrows >= 0 && (nrows == 0 || rows) && ncols_new >= 0, "fh_mat_restrict: bad arguments");
   std::vector<int> rp(nrows + 1, 0);
   for (int i = 0; i < nrows; i++) {
@@ -444,6 +449,7 @@ extern "C" int fh_mat_restrict(fh_mat_t src, int nrows, const int* rows, const i
   *out = D;
   *map_out = M;
   return 0;
+  FH_GUARD_END("fh_mat_restrict")
 }
 
 // largest |value| among the entries of the listed rows of src that fh_mat_restrict drops (new column < 0): must be 0 for the owned

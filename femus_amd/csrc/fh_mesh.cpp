@@ -59,8 +59,14 @@ static void first_touch_renumber(fh_mesh_s& m, int nnode) {
 }
 
 extern "C" int fh_mesh_box(int nx, int ny, int nz, const double lo[3], const double hi[3], fh_mesh_t* out) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(nx > 0 && ny > 0 && nz >= 0 && out, "fh_mesh_box: bad arguments");
-  fh_mesh_s* m = new fh_mesh_s();
+  {   // 32-bit ids (the reference's, PetscVector.hpp:536): the node count and nel * 27 must fit
+    const int64_t nn = (2ll * nx + 1) * (2ll * ny + 1) * (nz ? 2ll * nz + 1 : 1), ne = (int64_t)nx * ny * (nz ? nz : 1);
+    FH_REQUIRE(nn < (1ll << 31) && ne * 27 < (1ll << 31), "fh_mesh_box: %lld nodes / %lld elements do not fit 32-bit ids", (long long)nn, (long long)ne);
+  }
+  std::unique_ptr<fh_mesh_s> holder(new fh_mesh_s());
+  fh_mesh_s* m = holder.get();
   m->geom = (nz == 0) ? GEOM_QUAD : GEOM_HEX;
   m->dim = dim_of(m->geom);
   m->nloc = nloc_of(m->geom);
@@ -107,8 +113,9 @@ extern "C" int fh_mesh_box(int nx, int ny, int nz, const double lo[3], const dou
       }
   m->elem_level.assign(m->nel, 0);
   first_touch_renumber(*m, nnode);
-  *out = m;
+  *out = holder.release();
   return 0;
+  FH_GUARD_END("fh_mesh_box")
 }
 
 struct Key3 {
@@ -128,6 +135,7 @@ struct Key3Hash {
 // level).  Otherwise elements of the current level with a nonzero flag are split and all the others are carried over
 // unchanged (their node ids, boundary flags and level), which makes the new level non-homogeneous (AMR).
 extern "C" int fh_mesh_refine_flagged(fh_mesh_t mc, const unsigned char* flags, fh_mesh_t* out) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(mc && out, "fh_mesh_refine: null argument");
   const int geom = mc->geom, dim = mc->dim, nc = mc->nloc;
   const int nv = nvert_of(geom), ne = nedge_end_of(geom), nch = nv, nf = nfaces_of(geom);
@@ -284,9 +292,12 @@ extern "C" int fh_mesh_refine_flagged(fh_mesh_t mc, const unsigned char* flags, 
   }
   *out = m;
   return 0;
+  FH_GUARD_END("fh_mesh_refine_flagged")
 }
 
-extern "C" int fh_mesh_refine(fh_mesh_t mc, fh_mesh_t* out) { return fh_mesh_refine_flagged(mc, nullptr, out); }
+extern "C" int fh_mesh_refine(fh_mesh_t mc, fh_mesh_t* out) {
+  FH_GUARD_BEGIN return fh_mesh_refine_flagged(mc, nullptr, out);   FH_GUARD_END("fh_mesh_refine")
+}
 
 // MeshRefinement::FlagElementsToRefine (:88-101): the flag function is evaluated at the mean of the element vertices
 extern "C" int fh_mesh_elem_centroids(fh_mesh_t m, double* xc3) {
@@ -398,6 +409,7 @@ extern "C" int fh_mesh_dirichlet_dofs(fh_mesh_t m, int fe, int* n, int* dofs) {
 
 // a11: union of element couplings per row, sorted
 extern "C" int fh_pattern_from_elements(int nel, int nloc, const int* elem_dof, int ndof, int* rowptr, int* col) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(nel >= 0 && nloc > 0 && ndof >= 0 && rowptr, "fh_pattern_from_elements: bad arguments");
   std::vector<int> cnt(ndof + 1, 0);
   for (size_t k = 0; k < (size_t)nel * nloc; k++) {
@@ -448,11 +460,13 @@ extern "C" int fh_pattern_from_elements(int nel, int nloc, const int* elem_dof, 
     FH_REQUIRE(!bad && rowptr[0] == 0, "fh_pattern_from_elements: rowptr does not match (call with col=NULL first)");
   }
   return 0;
+  FH_GUARD_END("fh_pattern_from_elements")
 }
 
 // a14: P (fine x coarse), INSERT semantics (first insert wins; duplicates are identical rows).  Elements that were not
 // refined contribute identity rows (LinearImplicitSystem.cpp:796-806).
 extern "C" int fh_build_prolongator(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t mf, int fe, int zero_bdc, fh_mat_t* out) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(ctx && mc && mf && out, "fh_build_prolongator: null argument");
   FH_REQUIRE(fe == 0 || fe == 2, "fh_build_prolongator: fe must be 0 or 2");
   const int geom = mc->geom, nl = mc->nloc, nc = ndofs_of(geom, fe), nch = nvert_of(geom);
@@ -529,6 +543,7 @@ extern "C" int fh_build_prolongator(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t mf, in
     }
   }
   return fh_mat_create_csr(ctx, nf, ncc, rowptr.data(), col.data(), val.data(), out);
+  FH_GUARD_END("fh_build_prolongator")
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -838,6 +853,7 @@ extern "C" int fh_mesh_set_amr_mode(fh_mesh_t m, int mode) {
 }
 
 extern "C" int fh_mesh_amr_constraints(fh_mesh_t m, int fe, int* n_hanging, int* nnz, int* hanging, int* ptr, int* master, double* weight) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(m && n_hanging && nnz, "fh_mesh_amr_constraints: null argument");
   FH_REQUIRE(fe == 0 || fe == 2, "fh_mesh_amr_constraints: fe must be 0 or 2");
   AmrRows R;
@@ -852,12 +868,14 @@ extern "C" int fh_mesh_amr_constraints(fh_mesh_t m, int fe, int* n_hanging, int*
   *n_hanging = (int)R.hang.size();
   *nnz = (int)R.master.size();
   return 0;
+  FH_GUARD_END("fh_mesh_amr_constraints")
 }
 
 // P_amr (n x n): identity rows for regular dofs; a hanging dof's row holds its master weights and an explicit zero on
 // the diagonal (the reference inserts restriction[son][son] = 0, which keeps (son, son) in the pattern of P^T K P so
 // that SetPenalty can put its 1 there)
 extern "C" int fh_build_amr_prolongator(fh_ctx_t ctx, fh_mesh_t m, int fe, fh_mat_t* out) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(ctx && m && out, "fh_build_amr_prolongator: null argument");
   FH_REQUIRE(fe == 0 || fe == 2, "fh_build_amr_prolongator: fe must be 0 or 2");
   AmrRows R;
@@ -885,6 +903,7 @@ extern "C" int fh_build_amr_prolongator(fh_ctx_t ctx, fh_mesh_t m, int fe, fh_ma
     rowptr[i + 1] = (int)col.size();
   }
   return fh_mat_create_csr(ctx, n, n, rowptr.data(), col.data(), val.data(), out);
+  FH_GUARD_END("fh_build_amr_prolongator")
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -898,6 +917,7 @@ static int check_vars(const char* who, int nvars, const int* fe) {
 }
 
 extern "C" int fh_system_elem_dofs(fh_mesh_t m, int nvars, const int* fe, int* nd_out, int* offsets, int* elem_sys) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(m, "fh_system_elem_dofs: null mesh");
   FH_TRY(check_vars("fh_system_elem_dofs", nvars, fe));
   int nd = 0, off = 0;
@@ -916,11 +936,13 @@ extern "C" int fh_system_elem_dofs(fh_mesh_t m, int nvars, const int* fe, int* n
         for (int i = 0; i < ndofs_of(m->geom, fe[k]); i++) elem_sys[(size_t)iel * nd + p++] = offs[k] + m->elem_dof[(size_t)iel * m->nloc + i];
     }
   return 0;
+  FH_GUARD_END("fh_system_elem_dofs")
 }
 
 // BuildProlongatorMatrix loops the system variables (LinearImplicitSystem.cpp:890-905): block-diagonal interpolation,
 // one block per variable; Dirichlet rows / columns are zeroed by the caller (fh_mat_zero_rows / fh_mat_zero_cols)
 extern "C" int fh_build_system_prolongator(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t mf, int nvars, const int* fe, fh_mat_t* out) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(ctx && mc && mf && out, "fh_build_system_prolongator: null argument");
   FH_TRY(check_vars("fh_build_system_prolongator", nvars, fe));
   fh_mat_t blk[3] = {nullptr, nullptr, nullptr};
@@ -954,6 +976,7 @@ extern "C" int fh_build_system_prolongator(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t
   for (auto b : blk)
     if (b) fh_mat_destroy(b);
   return fh_mat_create_csr(ctx, nf, ncc, rowptr.data(), col.data(), val.data(), out);
+  FH_GUARD_END("fh_build_system_prolongator")
 }
 
 // Blocks of the Schwarz (Vanka) smoother for saddle-point systems, the GPU form of the element-block ASM of
@@ -961,6 +984,7 @@ extern "C" int fh_build_system_prolongator(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t
 // :223-256): that dof plus, for every other variable, all dofs of the elements that own it (:134-170).  Two-call
 // protocol: ptr == NULL returns the counts.
 extern "C" int fh_mesh_vertex_patches(fh_mesh_t m, int nvars, const int* fe, int* npatch, int* total, int* ptr, int* dofs) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(m && npatch && total, "fh_mesh_vertex_patches: null argument");
   FH_TRY(check_vars("fh_mesh_vertex_patches", nvars, fe));
   FH_REQUIRE(nvars >= 2, "fh_mesh_vertex_patches: needs at least one non-Schur variable and the Schur variable");
@@ -997,6 +1021,7 @@ extern "C" int fh_mesh_vertex_patches(fh_mesh_t m, int nvars, const int* fe, int
   *npatch = ns;
   *total = (int)out_dofs.size();
   return 0;
+  FH_GUARD_END("fh_mesh_vertex_patches")
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -1081,6 +1081,7 @@ static int color_rows(MgLevel& L) {
 }
 
 extern "C" int fh_mg_setup(fh_mg_t mg) {
+  FH_GUARD_BEGIN
   fh_ctx_t c = mg->ctx;
   for (int l = 0; l < mg->nlevels; l++) FH_REQUIRE(mg->lv[l].A, "fh_mg_setup: level %d has not been set", l);
   bool distributed = false;
@@ -1156,6 +1157,7 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
     FH_CHECK_HIP(hipGraphInstantiate(&mg->gexec, mg->graph, nullptr, nullptr, 0));
   }
   return 0;
+  FH_GUARD_END("fh_mg_setup")
 }
 
 // Richardson(scale omega) + a sweep preconditioner: x <- x + omega * B (b - A x).  B = forward then backward Gauss-Seidel from a

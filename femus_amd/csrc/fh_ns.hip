@@ -229,6 +229,7 @@ __global__ __launch_bounds__(64) void k_sys_row_gather(const int* __restrict__ a
 
 extern "C" int fh_ns_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, int n_vertex_nodes,
                                       const double* coords, fh_mat_t A, fh_ns_assembler_t* out) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(ctx && elem_dof && coords && A && out, "fh_ns_assembler_create: null argument");
   FH_REQUIRE(geom == 0 || geom == 1, "fh_ns_assembler_create: geom must be 0 (hex) or 1 (quad)");
   FH_REQUIRE(nloc == fhfe::nloc_of(geom), "fh_ns_assembler_create: nloc %d does not match the geometry", nloc);
@@ -305,6 +306,7 @@ extern "C" int fh_ns_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, i
   }
   *out = as;
   return 0;
+  FH_GUARD_END("fh_ns_assembler_create")
 }
 
 extern "C" int fh_ns_assembler_destroy(fh_ns_assembler_t as) {

@@ -422,19 +422,24 @@ static int triple_product(fh_mat_t R, fh_mat_t A, fh_mat_t P, fh_mat_t* Cio, con
 }
 
 extern "C" int fh_mat_ptap(fh_mat_t P, fh_mat_t A, fh_mat_t* Cio) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(P && A && Cio, "fh_mat_ptap: null argument");
   FH_REQUIRE(A->m == A->n && P->m == A->m, "fh_mat_ptap: shapes do not conform (A %dx%d, P %dx%d)", A->m, A->n, P->m, P->n);
   FH_TRY(fh_mat_refresh_transpose(P));     // R = P^T with current values
   return triple_product(P->At, A, P, Cio, "fh_mat_ptap");
+  FH_GUARD_END("fh_mat_ptap")
 }
 
 extern "C" int fh_mat_abc(fh_mat_t A, fh_mat_t B, fh_mat_t C, fh_mat_t* D) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(A && B && C && D, "fh_mat_abc: null argument");
   FH_REQUIRE(A->n == B->m && B->n == C->m, "fh_mat_abc: shapes do not conform (A %dx%d, B %dx%d, C %dx%d)", A->m, A->n, B->m, B->n, C->m, C->n);
   return triple_product(A, B, C, D, "fh_mat_abc");
+  FH_GUARD_END("fh_mat_abc")
 }
 
 extern "C" int fh_mat_matmul(fh_mat_t A, fh_mat_t B, fh_mat_t* Cout) {
+  FH_GUARD_BEGIN
   FH_REQUIRE(A && B && Cout, "fh_mat_matmul: null argument");
   FH_REQUIRE(A->n == B->m, "fh_mat_matmul: shapes do not conform (A %dx%d, B %dx%d)", A->m, A->n, B->m, B->n);
   std::vector<int> rp, col;
@@ -444,4 +449,5 @@ extern "C" int fh_mat_matmul(fh_mat_t A, fh_mat_t B, fh_mat_t* Cout) {
   FH_TRY(spgemm_numeric(A, B, C));
   *Cout = C;
   return 0;
+  FH_GUARD_END("fh_mat_matmul")
 }

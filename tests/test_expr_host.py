@@ -82,3 +82,19 @@ def test_program_and_variable_count_are_exposed():
     assert g.n_variables() == 4 and np.array_equal(g.program()[1], consts)
     assert capi.version().startswith("femus_hip")
     f.destroy(), g.destroy()
+
+
+def test_oversized_requests_are_errors_not_crashes():
+    """no C++ exception and no 32-bit wrap-around leaves the host-side entry points: a box whose node count passes 2^31 is refused,
+    and running out of host memory inside the mesh generator comes back as an error code (child process with an address-space limit)"""
+    import subprocess
+    import sys
+    with pytest.raises(capi.FemusHipError, match="32-bit"):
+        capi.Mesh.box(1200, 1200, 1200)
+    code = ("import resource, sys\n"
+            "resource.setrlimit(resource.RLIMIT_AS, (6 << 30, 6 << 30))\n"
+            "from femus_amd import capi\n"
+            "try:\n    capi.Mesh.box(380, 380, 380)\n    print('BUILT')\n"
+            "except capi.FemusHipError as e:\n    print('ERROR', e)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+    assert r.returncode == 0 and "ERROR" in r.stdout and "out of host memory" in r.stdout, (r.stdout[-500:], r.stderr[-500:])
