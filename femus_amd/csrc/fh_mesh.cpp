@@ -139,7 +139,9 @@ extern "C" int fh_mesh_refine_flagged(fh_mesh_t mc, const unsigned char* flags, 
   FH_REQUIRE(mc && out, "fh_mesh_refine: null argument");
   const int geom = mc->geom, dim = mc->dim, nc = mc->nloc;
   const int nv = nvert_of(geom), ne = nedge_end_of(geom), nch = nv, nf = nfaces_of(geom);
-  fh_mesh_s* m = new fh_mesh_s();
+  FH_REQUIRE((int64_t)mc->nel * nch * nc < (1ll << 31), "fh_mesh_refine: the refinement of %d elements does not fit 32-bit ids", mc->nel);
+  std::unique_ptr<fh_mesh_s> holder(new fh_mesh_s());
+  fh_mesh_s* m = holder.get();
   m->geom = geom;
   m->dim = dim;
   m->nloc = nc;
@@ -290,7 +292,7 @@ extern "C" int fh_mesh_refine_flagged(fh_mesh_t mc, const unsigned char* flags, 
       }
     }
   }
-  *out = m;
+  *out = holder.release();
   return 0;
   FH_GUARD_END("fh_mesh_refine_flagged")
 }
