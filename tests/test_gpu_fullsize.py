@@ -1,9 +1,11 @@
-"""GPU parity at BASELINE.json's full size (configs[1]: 3-D Poisson Q2, 64^3, 4 levels) through size-independent properties:
-the oracle cannot assemble 262 144 elements in seconds, so the checks are identities the discretisation must satisfy."""
+"""GPU parity at BASELINE.json's full size (configs[1]: 3-D Poisson Q2, 64^3, 4 levels) through size-independent properties
+(identities the discretisation must satisfy), through samples against the single-threaded C restatement, and -- with the C restatement's
+element loop and cycle run on all host cores -- entry by entry: every value of the fine-level operator and one whole V(2,2) cycle."""
 import numpy as np
 import pytest
 
 import femus_amd
+from oracle import femus_oracle as fo
 from femus_amd.poisson import PoissonMG
 
 pytestmark = pytest.mark.gpu
@@ -160,6 +162,41 @@ def test_sampled_csr_rows_at_full_size_match_the_c_oracle(curved_problem):
         worst_a = max(worst_a, np.abs(val[rp[r]:rp[r + 1]] - want).max() / np.abs(want).max())
         worst_b = max(worst_b, abs(res[r] - b) / babs)
     assert worst_a <= 1e-12 and worst_b <= 1e-12, (worst_a, worst_b)
+
+
+def test_whole_level_matrix_and_cycle_match_the_c_oracle(ctx, curved_problem):
+    """not sampled: ALL 135 005 697 entries of the fine-level operator and all 2 146 689 residual entries (curved elements, nonzero
+    solution, sine source) against the C restatement's element loop run over every element on all host cores; then one V(2,2) cycle of
+    the whole four-level hierarchy on the device against the C restatement's cycle on the same operators (1e-10, north_star)"""
+    import os
+    import scipy.linalg as sla
+    from oracle import c_kernels as ck
+    pb, ed, xw = curved_problem
+    ck.set_threads(len(os.sched_getaffinity(0)))
+    sol = pb.SOL.to_numpy()
+    pb.assemble()
+    rp, col = pb.A[-1].pattern()
+    val, res = np.zeros(rp[-1]), np.zeros(pb.ndof[-1])
+    ck.assemble_poisson_all_cores(ed, xw, "biquadratic", "hex", (rp, col, val, res), sol=sol, source_kind=1, p0=3.0, p1=2.0)
+    got = pb.A[-1].values()
+    # row-wise scale: the entries of a row are sums of up to 8 element contributions of the size of the diagonal
+    diag_scale = np.repeat(np.maximum.reduceat(np.abs(val), rp[:-1]), np.diff(rp))
+    assert np.max(np.abs(got - val) / diag_scale) <= 1e-12
+    r_dev = pb.RES.to_numpy()
+    assert np.max(np.abs(r_dev - res)) <= 1e-12 * np.abs(res).max()
+    del got, val, diag_scale
+    # the cycle: operators of the device hierarchy (Galerkin chain + SetPenalty), C cycle on the host
+    pb.prepare()
+    A = [a.to_scipy() for a in pb.A]
+    P = [None] + [q.to_scipy() for q in pb.P[1:]]
+    lu = sla.lu_factor(A[0].toarray())
+    cyc = ck.CVcycle(A, P, 2. / 3., 2, 2, coarse_solve=lambda b: sla.lu_solve(lu, b))
+    rhs = fo.lcg_fill(pb.ndof[-1], 12345)
+    rhs[pb.bdc[-1]] = 0.0
+    want = cyc.apply(rhs)
+    b, x = ctx.vector_from(rhs), ctx.vector(pb.ndof[-1])
+    pb.vcycle(b, x)
+    assert np.linalg.norm(x.to_numpy() - want) <= 1e-10 * np.linalg.norm(want)
 
 
 def test_one_level_beyond_the_bench_size():
