@@ -191,6 +191,22 @@ def test_whole_level_matrix_and_cycle_match_the_c_oracle(ctx, curved_problem):
     P = [None] + [q.to_scipy() for q in pb.P[1:]]
     lu = sla.lu_factor(A[0].toarray())
     cyc = ck.CVcycle(A, P, 2. / 3., 2, 2, coarse_solve=lambda b: sla.lu_solve(lu, b))
+    # the Galerkin chain at full size without forming the products on the host: A_{l-1} x = P^T (A_l (P x)) on the free coarse dofs for
+    # random x (the interpolation has zero rows / columns at Dirichlet nodes, SetPenalty then puts 1 on those diagonals), C SpMV throughout
+    rng = np.random.default_rng(8)
+    for l in (3, 2, 1):
+        nc_, nf_ = pb.ndof[l - 1], pb.ndof[l]
+        for rep in range(2):
+            xc = rng.uniform(-1, 1, nc_)
+            xc[pb.bdc[l - 1]] = 0.0
+            t1, t2, lhs, rhs_ = np.zeros(nf_), np.zeros(nf_), np.zeros(nc_), np.zeros(nc_)
+            ck.spmv(cyc.P[l], xc, t1)
+            ck.spmv(cyc.A[l], t1, t2)
+            ck.spmv(cyc.R[l], t2, rhs_)
+            ck.spmv(cyc.A[l - 1], xc, lhs)
+            free = np.ones(nc_, dtype=bool)
+            free[pb.bdc[l - 1]] = False
+            assert np.max(np.abs(lhs - rhs_)[free]) <= 1e-12 * np.max(np.abs(rhs_)), l
     rhs = fo.lcg_fill(pb.ndof[-1], 12345)
     rhs[pb.bdc[-1]] = 0.0
     want = cyc.apply(rhs)
