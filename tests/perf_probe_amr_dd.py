@@ -18,13 +18,14 @@ def flag(x, level):
     return x[0] > 0.5 and (level < 2 or x[1] > 0.25)
 
 
-def worker(rank, world, port, nb, nlevels, n_uniform, out):
+def worker(rank, world, port, nb, nlevels, n_uniform, out, uniform=False):
     import femus_amd as fa
     from femus_amd import dd
     comm = dd.SocketComm(rank, world, "127.0.0.1", port)
     ctx = fa.Context(0)
     t0 = time.time()
-    dp = dd.DistributedPoisson(ctx, comm, world, rank, nb=nb, nlevels=nlevels, transport="host", flag_fn=flag, n_uniform=n_uniform)
+    dp = dd.DistributedPoisson(ctx, comm, world, rank, nb=nb, nlevels=nlevels, transport="host", flag_fn=None if uniform else flag,
+                               n_uniform=None if uniform else n_uniform)
     setup = time.time() - t0
     dp.assemble()
     dp.set_penalty_top()
@@ -42,13 +43,14 @@ def main():
     nb = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     nlevels = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     n_uniform = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+    uniform = len(sys.argv) > 5 and sys.argv[5] == "uniform"          # BASELINE config 3 shape: no adaptive levels
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     out = "/tmp/amr_dd_rank%d.npz"
     t0 = time.time()
-    mp.spawn(worker, args=(world, port, nb, nlevels, n_uniform, out), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, port, nb, nlevels, n_uniform, out, uniform), nprocs=world, join=True)
     t_dist = time.time() - t0
     # single GPU on the global mesh: the replicated level of the distributed run is one more level below
     import femus_amd as fa
@@ -59,7 +61,7 @@ def main():
     ctx = fa.Context(0)
     ms = [capi.Mesh.box(p[0] * nb // 2, p[1] * nb // 2, p[2] * nb // 2, hi=tuple(float(v) for v in p))]
     for l in range(1, nlevels + 1):
-        if l < n_uniform + 1:
+        if uniform or l < n_uniform + 1:
             ms.append(ms[-1].refine())
         else:
             ms.append(ms[-1].refine_flagged(ms[-1].flag_elements(lambda x, level: flag(x, level - 1))))
@@ -68,9 +70,6 @@ def main():
     pb.prepare()
     pb.mgsolve(outer="gmres", rtol=1e-13, maxit=80)
     xs = pb.EPS.to_numpy()
-    if pb.Pamr[-1] is not None:
-        pb.EPSC.matrix_mult(pb.EPS, pb.Pamr[-1])
-        xs_full = pb.EPSC.to_numpy()
     gid_ser, _ = dd.node_keys(ms[-1].arrays()[1], nlevels - 1, nb, part)
     srt = np.argsort(gid_ser)
     worst, seen, info = 0.0, 0, []
@@ -83,7 +82,7 @@ def main():
         info.append({"rank": r, "owned": int(d["n_owned"]), "adaptive": bool(d["adaptive"]), "gmres_its": int(d["its"]), "setup_s": float(d["setup"]),
                      "prepare_ms": float(d["prepare_ms"])})
     assert seen == xs.size
-    print(json.dumps({"config": "config-5 shape: %d ranks (box %dx%dx%d), nb=%d, %d levels (%d uniform), Q2" % ((world,) + p + (nb, nlevels, n_uniform)),
+    print(json.dumps({"config": "config-%s shape: %d ranks (box %dx%dx%d), nb=%d, %d levels (%s uniform), Q2" % (("3" if uniform else "5", world) + p + (nb, nlevels, "all" if uniform else str(n_uniform))),
                       "dofs": int(xs.size), "hanging_top": int(pb.hanging[-1].size), "rel_diff_vs_single_gpu": worst, "wall_s_distributed": t_dist,
                       "ranks": info}))
     assert worst < 1e-9

@@ -1,5 +1,7 @@
 """GPU: the distributed (domain-decomposition) code path on one rank -- row-restricted operators in [owned | ghost]
 numbering, replicated level below, halo objects, distributed assembler -- must give the single-GPU solution."""
+import os
+
 import numpy as np
 import pytest
 
@@ -295,3 +297,19 @@ def test_multi_rank_adaptive_levels_with_host_transport(tmp_path, world):
         assert np.linalg.norm(d["xs"] - xd[pos]) <= 1e-9 * np.linalg.norm(xd)            # distributed GMRES solve
         seen += d["gid"].size
     assert seen == xd.size and H.hanging[-1].size > 0 and adaptive > 0
+
+
+def test_config3_shape_at_full_size_equals_the_single_gpu_solve():
+    """BASELINE configs[2] at its real size on two ranks (64^3 elements per rank, 2 x 1 x 1 box, 4 276 737 dofs, host-staged transport, both
+    processes on this GPU): the distributed GMRES solution against the single-GPU solver on the global 128 x 64 x 64 mesh (five levels:
+    the replicated level of the distributed run is its coarsest), 1e-9 relative.  tests/perf_probe_amr_dd.py in a child process."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "perf_probe_amr_dd.py"), "2", "8", "4", "2", "uniform"], capture_output=True, text=True,
+                       timeout=900, cwd=os.path.dirname(here))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["dofs"] == 257 * 129 * 129 and out["rel_diff_vs_single_gpu"] < 1e-9
+    assert sorted(k["owned"] for k in out["ranks"]) == [128 * 129 * 129, 129 ** 3]
