@@ -32,7 +32,7 @@ extern "C" int fh_dd_box_node_keys(int n, const double* coords /* [n*3] */, int 
     for (int d = 0; d < 3; d++) {
       k[d] = (int64_t)std::llround(coords[(size_t)i * 3 + d] * (double)S);
       FH_REQUIRE(k[d] >= 0 && k[d] <= p[d] * S, "fh_dd_box_node_keys: node %d lies outside the partitioned box", i);
-      oc[d] = (int)std::min<int64_t>(k[d] / S, p[d] - 1);
+      oc[d] = k[d] == 0 ? 0 : (int)((k[d] - 1) / S);     // a node on the face between two cubes belongs to the LOWER one (Mesh.cpp:517-559)
     }
     gid[i] = k[0] + G0 * (k[1] + G1 * k[2]);
     owner[i] = oc[0] + p[0] * (oc[1] + p[1] * oc[2]);
