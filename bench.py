@@ -10,7 +10,8 @@ hierarchy prepared once before the timed region (Galerkin chain + SetPenalty + s
 "PREPARATION TIME", reported separately as prepare_ms).  Inputs are resident in HBM when the timed region starts.
 
 Prints ONE JSON line on rank 0 (contract in the task description); `roofline` is the fine-level Jacobi-sweep SpMV
-kernel, `cpu_baseline` is the oracle's C restatement timed on the host cores of this box (rank 0, N=1 only).
+kernel, `cpu_baseline` is the oracle's C restatement timed on the host cores of this box (rank 0, N=1 only).  `roofline.traffic` comes
+from hardware counters of this run: two short child runs of femus_amd/traffic_probe.py under rocprofv3 --pmc after the timed region.
 """
 import argparse
 import json
@@ -35,6 +36,7 @@ def parse():
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=50)
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic")
     return ap.parse_args()
 
 
@@ -291,6 +293,20 @@ def main():
         out["halo"] = halo_info
 
     # ---- CPU baseline: the oracle's C restatement on the host cores (rank 0, N = 1 only) ------------------------
+    if rank == 0 and world == 1 and not args.no_live_traffic and os.environ.get("FEMUS_BENCH_LIVE_TRAFFIC", "1") != "0":
+        # roofline.traffic from hardware counters of THIS run (two short child runs under rocprofv3 --pmc); when that is not possible the
+        # values of the committed counter passes stay in place and `traffic_source` says so
+        live, how = live_traffic(args.coarse, args.levels)
+        if live is not None:
+            out["roofline"]["traffic"] = live["spmv"]
+            out["roofline"]["traffic_source"] = how
+            out["roofline_assembly"]["traffic"] = live["elem"]
+            out["roofline_assembly"]["row_pass_traffic"] = live["rows"]
+            out["roofline_assembly"]["traffic_source"] = how
+        else:
+            out["roofline"]["traffic_source"] = "committed counter passes (%s); live measurement skipped: %s" % (TRAFFIC["spmv"]["source"], how)
+    elif world == 1:
+        out["roofline"]["traffic_source"] = "committed counter passes (%s)" % TRAFFIC["spmv"]["source"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pb.pb, ndof, nel)
 
@@ -381,6 +397,55 @@ def _newest_profile(suffix):
         return None, None
     raw = open(files[-1], "rb").read()
     return json.loads(raw), "%s sha256:%s" % (os.path.relpath(files[-1], ROOT), hashlib.sha256(raw).hexdigest()[:16])
+
+
+def live_traffic(coarse, levels, timeout=300):
+    """HBM bytes per launch of the roofline kernels MEASURED IN THIS RUN: femus_amd/traffic_probe.py (the bench problem, the same kernels)
+    under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and again under `--pmc WRITE_SIZE` (one counter per pass, no other trace domain, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes), child processes of rank 0 after the timed region.  Units and correction as in
+    profiles/README.md: the counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads (x 2).  Returns
+    ({"spmv": bytes, "elem": bytes, "rows": bytes}, how) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
+        return None, "this process already runs under a profiler"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="femus_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                                os.path.join(ROOT, "femus_amd", "traffic_probe.py"), str(coarse), str(levels)],
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout)
+            if "TRAFFIC PROBE DONE" not in r.stdout:
+                return None, "the %s pass failed (exit %d)" % (counter, r.returncode)
+            per = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    name = row["Kernel_Name"]
+                    key = ("spmv" if "k_spmv_lx<2048, 3" in name else "elem" if "k_elem_q2hex_mfma" in name else
+                           "rows" if "k_row_assemble" in name and "true>" not in name.split("(")[0] else None)
+                    if key:
+                        per.setdefault((key, int(row.get("Grid_Size", 0) or 0)), []).append(float(row["Counter_Value"]))
+            for key in ("spmv", "elem", "rows"):
+                grids = [g for (k, g) in per if k == key]
+                if not grids:
+                    return None, "no %s launch in the %s pass" % (key, counter)
+                v = per[(key, max(grids))]                      # the fine-level launches have the largest grid
+                got[(key, counter)] = sum(v) / len(v)
+        except subprocess.TimeoutExpired:
+            return None, "the %s pass did not finish within %d s" % (counter, timeout)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {k: got[(k, "FETCH_SIZE")] * 1024.0 * 2.0 + got[(k, "WRITE_SIZE")] * 1024.0 for k in ("spmv", "elem", "rows")}
+    return out, "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over femus_amd/traffic_probe.py (KiB counters, FETCH_SIZE x 2 on gfx950)"
 
 
 def _traffic():
