@@ -399,7 +399,7 @@ def _newest_profile(suffix):
     return json.loads(raw), "%s sha256:%s" % (os.path.relpath(files[-1], ROOT), hashlib.sha256(raw).hexdigest()[:16])
 
 
-def live_traffic(coarse, levels, timeout=300):
+def live_traffic(coarse, levels, timeout=150):
     """HBM bytes per launch of the roofline kernels MEASURED IN THIS RUN: femus_amd/traffic_probe.py (the bench problem, the same kernels)
     under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and again under `--pmc WRITE_SIZE` (one counter per pass, no other trace domain, as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes), child processes of rank 0 after the timed region.  Units and correction as in
