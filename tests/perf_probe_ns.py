@@ -14,6 +14,9 @@ from femus_amd.navier_stokes import NavierStokesMG
 def main():
     nu = float(sys.argv[1]) if len(sys.argv) > 1 else 0.01
     ctx = femus_amd.Context(0)
+    for kv in sys.argv[2:]:                      # e.g. vanka_local_residual=0
+        k, v = kv.split("=")
+        ctx.set_option(k, float(v))
     nl = 4
     t0 = time.time()
     pb = NavierStokesMG(ctx, 10, 10, 0, nl, 0.01).init()
