@@ -11,12 +11,50 @@ import subprocess
 import sys
 
 
-def _child(rank, world, addr, port, device):
+def small_problem_check(ctx, comm, rank, world, transport, nb=2, nlevels=3):
+    """the WHOLE distributed path once on a small problem (nb^3 coarse elements per rank, nlevels levels): per-level exchange plans on one
+    communicator, assembly, device-side preparation with the all-reduced replicated operator, GMRES with the overlapped cycles -- and the
+    owned part of the solution against the single-GPU solver on the global mesh, which every rank runs for itself.  Returns the relative
+    difference (max over ranks is taken by the caller)."""
+    import numpy as np
+    from . import capi, dd
+    from .poisson import PoissonMG
+    dp = dd.DistributedPoisson(ctx, comm, world, rank, nb=nb, nlevels=nlevels, transport=transport)
+    dp.assemble()
+    dp.set_penalty_top()
+    its, rn = dp.solve(outer="gmres", rtol=1e-12, maxit=60)
+    top = dp.H.plans[-1]
+    mine = dp.EPSC.to_numpy()[:dp.n_owned]
+    part = dd.BoxPartition(world, 0)
+    p = part.p
+    ms = [capi.Mesh.box(max(1, p[0] * nb // 2), max(1, p[1] * nb // 2), max(1, p[2] * nb // 2), hi=tuple(float(v) for v in p))]
+    for _ in range(nlevels):
+        ms.append(ms[-1].refine())
+    pb = PoissonMG(ctx, 0, 0, 0, nlevels + 1, meshes=ms).init()
+    pb.assemble()
+    pb.prepare()
+    pb.mgsolve(outer="gmres", rtol=1e-13, maxit=80)
+    xs = pb.EPS.to_numpy()
+    gid_ser, _ = dd.node_keys(ms[-1].arrays()[1], nlevels - 1, nb, part)
+    srt = np.argsort(gid_ser)
+    g = top.gid[top.owned]
+    pos = srt[np.searchsorted(gid_ser[srt], g)]
+    if not np.array_equal(gid_ser[pos], g) or its >= 60:
+        return 1.0
+    return float(np.linalg.norm(mine - xs[pos]) / max(np.linalg.norm(xs), 1e-300))
+
+
+def _child(rank, world, addr, port, device, transport="rccl"):
     import numpy as np
     from . import capi, Context
     from .dd import SocketComm
     comm = SocketComm(rank, world, addr, port, timeout=60.0)
     ctx = Context(device)
+    if transport != "rccl":          # the small-problem stage alone, over the host-staged transport (tests of this file's own logic)
+        diff = small_problem_check(ctx, comm, rank, world, transport)
+        oks = comm.allgather_obj(bool(diff < 1e-9))
+        comm.close()
+        return 0 if all(oks) else 4
     if world == 1:
         # one GPU: the ring neighbour is the rank itself.  "halo_self_rccl" gives the one-rank plan a real communicator, so
         # ncclCommInitRank, the grouped ncclSend/ncclRecv and ncclAllReduce below all execute on the device
@@ -53,15 +91,26 @@ def _child(rank, world, addr, port, device):
     ctx.sync()
     oks = comm.allgather_obj(bool(ok))
     halo.destroy()
+    if not all(oks):
+        comm.close()
+        return 3
+    if world > 1:
+        # second stage: everything bench.py is about to do, once, on a small problem -- a path that hangs or gives wrong numbers with
+        # RCCL on this machine ends here, in the child
+        diff = small_problem_check(ctx, comm, rank, world, "rccl")
+        oks = comm.allgather_obj(bool(diff < 1e-9))
+        if not all(oks):
+            comm.close()
+            return 4
     comm.close()
-    return 0 if all(oks) else 3
+    return 0
 
 
-def run(rank, world, addr, port, device, timeout=120.0):
+def run(rank, world, addr, port, device, timeout=180.0, transport="rccl"):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
-    p = subprocess.Popen([sys.executable, "-m", "femus_amd.rccl_preflight", str(rank), str(world), addr, str(port), str(device)],
+    p = subprocess.Popen([sys.executable, "-m", "femus_amd.rccl_preflight", str(rank), str(world), addr, str(port), str(device), transport],
                          env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     try:
         out, _ = p.communicate(timeout=timeout)
@@ -77,4 +126,4 @@ def run(rank, world, addr, port, device, timeout=120.0):
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    sys.exit(_child(int(a[0]), int(a[1]), a[2], int(a[3]), int(a[4])))
+    sys.exit(_child(int(a[0]), int(a[1]), a[2], int(a[3]), int(a[4]), a[5] if len(a) > 5 else "rccl"))

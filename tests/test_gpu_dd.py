@@ -313,3 +313,28 @@ def test_config3_shape_at_full_size_equals_the_single_gpu_solve():
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["dofs"] == 257 * 129 * 129 and out["rel_diff_vs_single_gpu"] < 1e-9
     assert sorted(k["owned"] for k in out["ranks"]) == [128 * 129 * 129, 129 ** 3]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_preflight_small_problem_stage(world):
+    """second stage of femus_amd/rccl_preflight.py (what bench.py runs in child processes before it commits to the RCCL transport): the
+    whole distributed path on a small problem against the single-GPU solve of the global mesh.  Here over the host-staged transport,
+    ranks sharing this GPU -- the stage's own logic (plans, assembly, preparation, solve, comparison, exit codes) is what is tested."""
+    import threading
+    from femus_amd import rccl_preflight
+    port = _free_port()
+    res = [None] * world
+
+    def go(r):
+        res[r] = rccl_preflight.run(r, world, "127.0.0.1", port, 0, timeout=400.0, transport="host")
+
+    ts = [threading.Thread(target=go, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(r is not None and r[0] for r in res), res
+
+
+def test_preflight_small_problem_on_one_rank(ctx):
+    """the same stage in-process on one rank with the RCCL transport selected (plans without neighbours are inert)"""
+    from femus_amd import dd, rccl_preflight
+    assert rccl_preflight.small_problem_check(ctx, dd.SocketComm(0, 1), 0, 1, "rccl") < 1e-9
