@@ -144,9 +144,10 @@ class Poisson001:
         idx = np.array(sorted(val), dtype=np.int32)
         return idx, np.array([val[i] for i in idx])
 
-    def run(self, smoother=capi.SMOOTH_GS_COLOR, omega=0.5, log=None):
+    def run(self, smoother=capi.SMOOTH_GS_COLOR, omega=0.5, log=None, output_dir=None):
         """smoother / omega: the application sets RICHARDSON + SOR_PRECOND on the fine grids (main.cpp:240-242) and leaves the
-        Richardson scale at the solver default 0.5 (LinearEquationSolverPetsc.hpp:145)"""
+        Richardson scale at the solver default 0.5 (LinearEquationSolverPetsc.hpp:145).  output_dir: write what the application writes at
+        its end (main.cpp:259-270): the VTK and the GMV file of "Sol", named as the reference names them"""
         ctx = self.ctx
         meshes = [capi.Mesh.box(*self.box, self.lo, self.hi) if self.box is not None else capi.Mesh.read_gambit(self.mesh_file)]
         for _ in range(1, self.nlevels):
@@ -183,6 +184,17 @@ class Poisson001:
         _, xy, _ = meshes[top].arrays()
         result = {"solution": pb.SOL.to_numpy(), "coords": xy[:pb.ndof[top]], "history": history, "converged": history[-1][1] < self.abs_tol,
                   "dofs": pb.ndof[top]}
+        if output_dir is not None:
+            import os
+            from . import writers
+            # VTKWriter / GMVWriter file names: <prefix>.level<gridn>.<time step>.<order>.<ext> with gridn = number of levels
+            stem = os.path.join(str(output_dir), "sol.level%d.%d.%s" % (self.nlevels, 0, "biquadratic"))
+            field = result["solution"]
+            if field.size != meshes[top].nnode:          # linear solution: the writers carry it to the nodes of the output family
+                field = field[:meshes[top].own_size[0]]
+            writers.write_vtu(stem + ".vtu", meshes[top], {"Sol": field})
+            writers.write_gmv(stem + ".gmv", meshes[top], {"Sol": field}, "biquadratic")
+            result["files"] = [stem + ".vtu", stem + ".gmv"]
         pb.destroy()
         return result
 

@@ -13,6 +13,7 @@
 #include "fh_internal.h"
 #include "fh_fe.h"
 #include <cstdio>
+#include <cstring>
 #include <memory>
 
 using namespace fhfe;
@@ -104,6 +105,98 @@ extern "C" int fh_write_vtu(fh_mesh_t mesh, const char* path, int nfields, const
             b64_array(fv.data(), fv.size() * sizeof(float)).c_str());
   }
   fprintf(f, "      </PointData>\n    </Piece>\n  </UnstructuredGrid>\n</VTKFile>\n");
+  return 0;
+}
+
+// GMVWriter::Write (src/07_mesh_or_solution/01_multiple_levels/01_output/GMVWriter.cpp:72-341), the second file 001_Poisson writes after
+// the solve (main.cpp:267-269): binary GMV, "gmvinput" "ieeei4r8", 8-byte keywords, 32-bit counts, 64-bit values.  order 0 = "linear"
+// (vertex nodes: phex8 / quad), anything else -- also "biquadratic" -- is the reference's QUADRATIC family (GMVWriter.cpp:102: vertex +
+// edge nodes, phex20 / 8quad).  Nodes of that family are the first nvt mesh nodes (FEMuS numbers vertices, then edges, then faces /
+// centres), coordinates and Lagrange variables are their nodal values (the Q_i -> Q_j projection at a node of both families is the value
+// there; a linear variable at an edge node is the mean of the edge's vertices).  One rank: the METIS_DD cell variable is 0 everywhere.
+// Keywords are written the way the reference does -- sprintf into one 10-byte buffer, 8 bytes out -- so that the bytes after a short
+// keyword are what the previous keyword left there; variable names shorter than 8 characters are padded with zeros.
+extern "C" int fh_write_gmv(fh_mesh_t mesh, const char* path, int order, int nfields, const char* const* names, const int* fe, const double* const* values) {
+  FH_REQUIRE(mesh && path && nfields >= 0 && (nfields == 0 || (names && fe && values)), "fh_write_gmv: bad arguments");
+  int dim, geom, nel, nnode, nl, nlin;
+  const int* ed;
+  const double* xy;
+  FH_TRY(fh_mesh_host_arrays(mesh, &dim, &geom, &nel, &nnode, &nl, &nlin, &ed, &xy));
+  const int index = order == 0 ? 0 : 1;
+  const int nv = nvert_of(geom), nvq = nedge_end_of(geom);           // local nodes of the linear / quadratic family
+  const int nloc_fam = index == 0 ? nv : nvq;
+  // global count of the family: the largest node id an element lists among its first nloc_fam nodes, plus one
+  int nvt_i = 0;
+  for (int e = 0; e < nel; e++)
+    for (int j = 0; j < nloc_fam; j++) nvt_i = std::max(nvt_i, ed[(size_t)e * nl + j] + 1);
+  const unsigned nvt = (unsigned)nvt_i, nelu = (unsigned)nel;
+  FILE* f = fopen(path, "wb");
+  FH_REQUIRE(f != nullptr, "fh_write_gmv: cannot open %s", path);
+  std::unique_ptr<FILE, int (*)(FILE*)> guard(f, fclose);
+  char buffer[10] = {0};
+  bool ok = true;
+  auto key = [&](const char* w) {
+    snprintf(buffer, sizeof(buffer), "%s", w);
+    ok = ok && fwrite(buffer, 1, 8, f) == 8;
+  };
+  auto put = [&](const void* p, size_t bytes) { ok = ok && (bytes == 0 || fwrite(p, 1, bytes, f) == bytes); };
+  key("gmvinput");
+  key("ieeei4r8");
+  key("nodes");
+  put(&nvt, sizeof(unsigned));
+  std::vector<double> v1(std::max<size_t>(nvt, (size_t)nel));
+  for (int d = 0; d < 3; d++) {
+    for (unsigned i = 0; i < nvt; i++) v1[i] = d < dim ? xy[(size_t)i * dim + d] : 0.0;
+    put(v1.data(), nvt * sizeof(double));
+  }
+  key("cells");
+  put(&nelu, sizeof(unsigned));
+  const unsigned nvertices = (unsigned)nloc_fam;
+  std::vector<unsigned> topo(nloc_fam);
+  for (int e = 0; e < nel; e++) {
+    if (geom == GEOM_HEX) key(index == 0 ? "phex8" : "phex20");
+    else key(index == 0 ? "quad" : "8quad");
+    put(&nvertices, sizeof(unsigned));
+    for (int j = 0; j < nloc_fam; j++) topo[j] = (unsigned)ed[(size_t)e * nl + j] + 1u;
+    put(topo.data(), topo.size() * sizeof(unsigned));
+  }
+  const unsigned zero = 0u, one = 1u;
+  key("variable");
+  key("METIS_DD");
+  put(&zero, sizeof(unsigned));
+  std::fill(v1.begin(), v1.begin() + nel, 0.0);
+  put(v1.data(), (size_t)nel * sizeof(double));
+  for (int k = 0; k < nfields; k++) {
+    FH_REQUIRE(fe[k] == 0 || fe[k] == 2, "fh_write_gmv: field %d: fe must be 0 (linear) or 2 (biquadratic)", k);
+    char name8[8] = {0};
+    strncpy(name8, names[k], 8);
+    put(name8, 8);
+    put(&one, sizeof(unsigned));
+    if (fe[k] == 2 || index == 0) {
+      put(values[k], nvt * sizeof(double));                            // nodal values at the first nvt nodes
+    } else {
+      // a linear variable at the quadratic family's nodes: vertices keep their value, an edge node takes the mean of its two vertices
+      std::vector<double> q(nvt, 0.0);
+      for (int e = 0; e < nel; e++)
+        for (int i = 0; i < nloc_fam; i++) {
+          double s = 0.0;
+          int cnt = 0;
+          for (int v = 0; v < nv; v++) {
+            bool on = true;
+            for (int d = 0; d < dim; d++) on = on && (xc(geom, i, d) == 0 || xc(geom, i, d) == xc(geom, v, d));
+            if (on) {
+              s += values[k][ed[(size_t)e * nl + v]];
+              cnt++;
+            }
+          }
+          q[ed[(size_t)e * nl + i]] = s / cnt;
+        }
+      put(q.data(), nvt * sizeof(double));
+    }
+  }
+  key("endvars");
+  key("endgmv");
+  FH_REQUIRE(ok, "fh_write_gmv: short write to %s", path);
   return 0;
 }
 

@@ -66,6 +66,27 @@ def write_vtu(path, mesh, fields, xc=None):
     capi._chk(L.fh_write_vtu(mesh.h, os.fsencode(str(path)), len(names), c_names, capi._p(fe), c_vals))
 
 
+def write_gmv(path, mesh, fields, order="biquadratic"):
+    """binary GMV file as GMVWriter::Write emits it (fh_write_gmv); order "linear" = vertex nodes, anything else = the reference's quadratic
+    family (vertex + edge nodes), which is also what "biquadratic" selects there.  fields as in write_vtu."""
+    import ctypes
+    from . import capi
+    L = capi.load_library()
+    names = list(fields)
+    arrs = [np.ascontiguousarray(fields[k], dtype=np.float64) for k in names]
+    fe = []
+    for k, v in zip(names, arrs):
+        if v.size == mesh.nnode:
+            fe.append(2)
+        else:
+            assert v.size == mesh.own_size[0], "field %s has neither the biquadratic nor the linear length" % k
+            fe.append(0)
+    c_names = (ctypes.c_char_p * len(names))(*[k.encode() for k in names])
+    c_vals = (ctypes.c_void_p * len(names))(*[v.ctypes.data for v in arrs])
+    fe = np.array(fe, dtype=np.int32)
+    capi._chk(L.fh_write_gmv(mesh.h, os.fsencode(str(path)), 0 if order == "linear" else 1, len(names), c_names, capi._p(fe), c_vals))
+
+
 HEX_XC = [(-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1), (-1, -1, 1), (1, -1, 1), (1, 1, 1), (-1, 1, 1),
           (0, -1, -1), (1, 0, -1), (0, 1, -1), (-1, 0, -1), (0, -1, 1), (1, 0, 1), (0, 1, 1), (-1, 0, 1),
           (-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0), (0, -1, 0), (1, 0, 0), (0, 1, 0), (-1, 0, 0), (0, 0, -1), (0, 0, 1), (0, 0, 0)]

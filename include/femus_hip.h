@@ -381,6 +381,10 @@ int fh_halo_destroy(fh_halo_t halo);
  * MultiLevelSolution::SaveSolution / LoadSolution (MultiLevelSolution.cpp:1070-1126): PETSc's binary Vec layout (big-endian class id
  * 1211214, length, float64 values).  fh_host_binary_*: the same on host arrays (*n: capacity in / length out; values == NULL queries). */
 int fh_write_vtu(fh_mesh_t mesh, const char* path, int nfields, const char* const* names, const int* fe, const double* const* values);
+/* fh_write_gmv: GMVWriter::Write (GMVWriter.cpp:72-341), the second output of applications/001_Poisson (main.cpp:267-269): binary GMV file
+ * ("gmvinput" "ieeei4r8", nodes, cells, the METIS_DD cell variable, node variables).  order 0 = linear (phex8 / quad cells on the vertex
+ * nodes), otherwise the reference's quadratic family (phex20 / 8quad; "biquadratic" selects it too, GMVWriter.cpp:102).  fe[k] as above. */
+int fh_write_gmv(fh_mesh_t mesh, const char* path, int order, int nfields, const char* const* names, const int* fe, const double* const* values);
 int fh_vec_binary_print(fh_vec_t v, const char* path);
 int fh_vec_binary_load(fh_vec_t v, const char* path);
 int fh_host_binary_print(const char* path, int n, const double* values);

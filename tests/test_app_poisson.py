@@ -61,10 +61,15 @@ def test_loader_accepts_every_shipped_input_file():
 
 
 @pytest.mark.gpu
-def test_run_matches_oracle_direct_solution(ctx):
+def test_run_matches_oracle_direct_solution(ctx, tmp_path):
     p = app.Poisson001(ctx, CONFIG)
-    out = p.run(log=None)
+    out = p.run(log=None, output_dir=tmp_path)
     assert out["converged"] and len(out["history"]) <= 8
+    # the two files the application writes at its end (main.cpp:259-270): VTK and GMV, named as the reference's writers name them
+    assert [os.path.basename(f) for f in out["files"]] == ["sol.level3.0.biquadratic.vtu", "sol.level3.0.biquadratic.gmv"]
+    from test_writers import read_gmv
+    xyz, cells, kinds, part, var = read_gmv(out["files"][1])
+    assert kinds == {"8quad"} and np.array_equal(var["Sol"], out["solution"][:xyz.shape[1]])
     # the same discrete problem with the oracle: F = (src phi - grad phi . grad T) w + Neumann term, Dirichlet rows penalised
     ms = fo.build_levels(4, 4, 0, 3)
     m = ms[-1]

@@ -62,3 +62,68 @@ def test_save_and_load_solution(tmp_path):
     assert np.array_equal(back["U"], u) and np.array_equal(back["P"], p)
     with pytest.raises(FileNotFoundError, match="cannot locate file"):
         writers.load_solution(str(tmp_path / "save" / "run_iteration8"), ["U"], 3)
+
+
+def read_gmv(path):
+    """minimal reader of the binary GMV layout GMVWriter.cpp writes: keywords of 8 bytes, uint32 counts, float64 values"""
+    raw = open(path, "rb").read()
+    pos = [0]
+
+    def take(n):
+        b = raw[pos[0]:pos[0] + n]
+        assert len(b) == n
+        pos[0] += n
+        return b
+
+    def word():
+        return take(8).split(b"\0")[0].decode()
+
+    assert word() == "gmvinput" and word() == "ieeei4r8"
+    kw = take(8)
+    assert kw[:6] == b"nodes\0" and kw[6:] == b"r8"            # what sprintf into the reference's one buffer leaves behind "nodes"
+    (nvt,) = struct.unpack("<I", take(4))
+    xyz = np.frombuffer(take(3 * nvt * 8), dtype="<f8").reshape(3, nvt)
+    assert word() == "cells"
+    (nel,) = struct.unpack("<I", take(4))
+    cells, kinds = [], set()
+    for _ in range(nel):
+        kinds.add(word())
+        (nv,) = struct.unpack("<I", take(4))
+        cells.append(np.frombuffer(take(4 * nv), dtype="<u4"))
+    assert word() == "variable" and word() == "METIS_DD"
+    assert struct.unpack("<I", take(4))[0] == 0
+    part = np.frombuffer(take(8 * nel), dtype="<f8")
+    var = {}
+    while True:
+        name = word()
+        if name == "endvars":
+            break
+        assert struct.unpack("<I", take(4))[0] == 1
+        var[name] = np.frombuffer(take(8 * nvt), dtype="<f8")
+    assert word() == "endgmv" and pos[0] == len(raw)
+    return xyz, np.array(cells), kinds, part, var
+
+
+@pytest.mark.parametrize("box,order", [((2, 3, 2), "biquadratic"), ((2, 3, 2), "linear"), ((3, 2, 0), "biquadratic"), ((3, 2, 0), "linear")])
+def test_gmv_file_layout_and_values(tmp_path, box, order):
+    """GMVWriter::Write (GMVWriter.cpp:72-341): header, node block of the requested family, cells with 1-based node ids, the METIS_DD cell
+    variable, node variables (a biquadratic one by its nodal values, a linear one interpolated to the edge nodes), trailer"""
+    m = capi.Mesh.box(*box)
+    ed, xy, _ = m.arrays()
+    dim = xy.shape[1]
+    u2 = np.sin(xy[:, 0]) + 2.0 * xy[:, 1] ** 2 + (xy[:, 2] if dim == 3 else 0.0)
+    nlin = m.own_size[0]
+    u1 = 1.0 + xy[:nlin, 0] - 3.0 * xy[:nlin, 1]                       # linear in x, y: the edge-midpoint mean is exact
+    path = tmp_path / "sol.gmv"
+    writers.write_gmv(path, m, {"Sol": u2, "PressureQ1": u1}, order)
+    xyz, cells, kinds, part, var = read_gmv(path)
+    nfam = m.own_size[0] if order == "linear" else m.own_size[1]
+    nloc = {("linear", 3): 8, ("biquadratic", 3): 20, ("linear", 2): 4, ("biquadratic", 2): 8}[(order, dim)]
+    assert kinds == {{("linear", 3): "phex8", ("biquadratic", 3): "phex20", ("linear", 2): "quad", ("biquadratic", 2): "8quad"}[(order, dim)]}
+    assert xyz.shape[1] == nfam and np.array_equal(xyz[:dim].T, xy[:nfam]) and (dim == 3 or not xyz[2].any())
+    assert np.array_equal(cells, ed[:, :nloc] + 1) and not part.any()
+    assert sorted(var) == ["Pressure", "Sol"]                              # names are cut to 8 characters
+    assert np.array_equal(var["Sol"], u2[:nfam])
+    want = 1.0 + xy[:nfam, 0] - 3.0 * xy[:nfam, 1]
+    assert np.allclose(var["Pressure"], want, rtol=0, atol=1e-14)
+    m.destroy()
