@@ -87,7 +87,7 @@ def main():
                 how = {"rccl": "RCCL neighbour send/recv", "gloo": "the host-staged transport over torch.distributed (gloo)",
                        "host": "the host-staged transport"}[transport]
                 parallelism = ("mesh domain decomposition, box split %dx%dx%d (METIS unavailable), one partition per GPU, ghost DOFs "
-                               "exchanged by %s (fh_halo_begin/end, overlapped with the interior rows), replicated coarse level"
+                               "exchanged by %s (fh_halo_begin/end, overlapped with the interior rows), the two coarsest levels replicated (all-reduce instead of exchanges)"
                                % (dd.GRIDS[world] + (how,)))
                 if dist_err is not None:
                     parallelism += "; fell back from rccl: " + dist_err

@@ -650,7 +650,7 @@ class DistributedPoisson:
     the numeric part -- what LinearImplicitSystem::MGsolve does before every solve (LinearImplicitSystem.cpp:347-383)."""
 
     def __init__(self, ctx, comm, nranks, rank, nb=8, nlevels=4, omega=2. / 3., npre=2, npost=2, fe="biquadratic", order="seventh",
-                 transport="rccl", flag_fn=None, n_uniform=None, source_kind=0, params=(1.0,), halo_comm=None):
+                 transport="rccl", flag_fn=None, n_uniform=None, source_kind=0, params=(1.0,), halo_comm=None, n_replicated=2):
         """flag_fn / n_uniform: adaptive levels (BASELINE config "MGAMR ... 8 GPUs"): every rank refines its extended box with the
         same flag function on global coordinates.  The fine level is then assembled AND projected (hanging nodes) on the extended
         box with the one-GPU code and the owned rows are gathered out on the device; uniform hierarchies keep the leaner
@@ -662,6 +662,10 @@ class DistributedPoisson:
         self.nb, self.nl = nb, nlevels
         self.omega, self.npre, self.npost = omega, npre, npost
         self.source_kind, self.params = source_kind, params
+        # replicated levels under the distributed ones: 1 = the global level below the coarsest local level (dense exact solve);
+        # 2 = also the coarsest local level itself as a global, replicated, SMOOTHED level (every rank sweeps all of its few thousand
+        # rows: no ghost exchange on that level, one wider all-reduce instead -- 6 exchanges per V(2,2) cycle less)
+        self.n_replicated = 2 if (n_replicated >= 2 and nlevels >= 2) else 1
         part = self.part
         # 1. full local hierarchy on the extended box (device): assemble, Galerkin chain, SetPenalty
         meshes = local_meshes(part, nb, nlevels, flag_fn, n_uniform)
@@ -745,6 +749,33 @@ class DistributedPoisson:
         assert np.all(pkey[np.minimum(pos, pkey.size - 1)] == tkey), "replicated coarse operator leaves its stencil pattern"
         self.map_rep = self.A_rep.value_map(self.T_rep)
         self.bdc_rep = capi.Index(ctx, m_rep.dirichlet_dofs(fe).astype(np.int32))
+        if self.n_replicated == 2:
+            # the coarsest local level as a replicated global level: its operator is the owned rows of every rank scattered into the global
+            # stencil pattern and summed (every row has exactly one owner); the level below is its Galerkin product, computed by every rank
+            n_g0 = m_g0.n_dofs(fe)
+            self.Pg = capi.build_prolongator(ctx, m_rep, m_g0, fe, zero_bdc=True)
+            gl_of_local = srt[np.searchsorted(g0_gid[srt], gids[0])]          # node of the extended box -> node of the global level-0 mesh
+            assert np.all(g0_gid[gl_of_local] == gids[0])
+            grp, gcol = capi.pattern_from_elements(m_g0.arrays()[0], n_g0)
+            self.A_g0 = ctx.matrix_csr(n_g0, n_g0, grp, gcol)
+            src_row = np.full(n_g0, -1, dtype=np.int32)
+            src_row[gl_of_local[loc.owned]] = np.arange(loc.n_owned, dtype=np.int32)
+            src_col = np.full(n_g0, -1, dtype=np.int32)
+            src_col[gl_of_local[all_local]] = loc.newid[all_local]
+            # nothing of the owned rows may fall outside the stencil pattern of the global mesh
+            arp, acol = self.A[0].pattern()
+            glob_of_newid = np.empty(nloc[0], dtype=np.int64)
+            glob_of_newid[loc.newid[all_local]] = gl_of_local[all_local]
+            akey = np.repeat(gl_of_local[loc.owned].astype(np.int64), np.diff(arp)) * n_g0 + glob_of_newid[acol]
+            gkey = np.repeat(np.arange(n_g0, dtype=np.int64), np.diff(grp)) * n_g0 + gcol
+            pos_ = np.searchsorted(gkey, akey)
+            assert np.all(gkey[np.minimum(pos_, gkey.size - 1)] == akey), "a level-0 operator row leaves the stencil pattern of the global mesh"
+            self.map_g0 = self.A_g0.value_map(self.A[0], src_row, src_col)
+            p1, m = full.P[1].restrict(plans[1].owned, gl_of_local.astype(np.int32), n_g0)       # owned level-1 rows x global level-0 columns
+            m.destroy()
+            self.P1_rep = p1
+            self.R1_rep = p1.get_transpose()
+            self.A_rep2 = None                                                # Galerkin product of the replicated level, built at the first preparation
         for m_ in (m_rep, m_g0):
             m_.destroy()
         self._replicated_operator()
@@ -787,8 +818,22 @@ class DistributedPoisson:
         ctx.sync()
         self.prepare_ms = (time.time() - t0) * 1e3
 
+    @property
+    def A_coarse(self):
+        """operator of the coarsest (replicated, exactly solved) level of the cycle"""
+        return self.A_rep2 if self.n_replicated == 2 else self.A_rep
+
     def _wire_cycle(self):
         mg, nl = self.mg, self.nl
+        if self.n_replicated == 2:
+            mg.set_level(0, self.A_rep2, None, None, 0, self.omega, 1, 0)
+            mg.set_level(1, self.A_g0, self.Pg, None, 0, self.omega, self.npre, self.npost)           # replicated, smoothed, no exchange
+            mg.set_level(2, self.A[1], self.P1_rep, self.R1_rep, 0, self.omega, self.npre, self.npost)
+            mg.set_level_distributed(2, self.halos[1], True)
+            for l in range(2, nl):
+                mg.set_level(l + 1, self.A[l], self.P[l], self.R[l], 0, self.omega, self.npre, self.npost)
+                mg.set_level_distributed(l + 1, self.halos[l], False)
+            return
         mg.set_level(0, self.A_rep, None, None, 0, self.omega, 1, 0)
         mg.set_level(1, self.A[0], self.P_rep, self.R_rep, 0, self.omega, self.npre, self.npost)
         mg.set_level_distributed(1, self.halos[0], True)
@@ -797,7 +842,17 @@ class DistributedPoisson:
             mg.set_level_distributed(l + 1, self.halos[l], False)
 
     def _replicated_operator(self):
-        """A_rep = sum over ranks of P_rep^T A_0 Pg_local on the stencil pattern, then SetPenalty -- all on the device"""
+        """A_rep = sum over ranks of P_rep^T A_0 Pg_local on the stencil pattern, then SetPenalty -- all on the device.  With two replicated
+        levels: A_g0 = owned rows of all ranks summed into the global pattern, A_rep2 = Pg^T A_g0 Pg computed by every rank"""
+        if self.n_replicated == 2:
+            self.map_g0.gather_matrix_values(self.A_g0, self.A[0])
+            self.halos[1].allreduce_mat(self.A_g0)
+            if self.A_rep2 is None:
+                self.A_rep2 = capi.Mat.ptap(self.Pg, self.A_g0)
+            else:
+                self.A_rep2.ptap_numeric(self.Pg, self.A_g0)
+            self.bdc_rep.zero_rows(self.A_rep2, 1.0)
+            return
         self.T_rep.abc_numeric(self.R_rep, self.A[0], self.Pg_local)
         self.map_rep.gather_matrix_values(self.A_rep, self.T_rep)
         self.halos[0].allreduce_mat(self.A_rep)

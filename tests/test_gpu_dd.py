@@ -43,21 +43,24 @@ def pb_raw_values(ctx):
 # ---- several ranks on ONE GPU: the whole distributed device path (ghost-element assembly, halo updates inside the cycle,
 # replicated level all-reduce, distributed dot products of the Krylov solver) with the host-staged transport in place of RCCL,
 # which cannot connect two ranks that share a device.  Everything except the ncclSend/ncclRecv calls themselves is exercised.
-def _ops_worker(rank, world, port, nb, nlevels, out):
+def _ops_worker(rank, world, port, nb, nlevels, out, n_replicated=2):
     try:
         import femus_amd as fa
         from femus_amd import dd as ddm
         comm = ddm.SocketComm(rank, world, "127.0.0.1", port)
         ctx = fa.Context(0)
-        dp = ddm.DistributedPoisson(ctx, comm, world, rank, nb=nb, nlevels=nlevels, transport="host")
-        assert dp.prepare_ms is not None and dp.prepare_ms > 0
+        dp = ddm.DistributedPoisson(ctx, comm, world, rank, nb=nb, nlevels=nlevels, transport="host", n_replicated=n_replicated)
+        assert dp.prepare_ms is not None and dp.prepare_ms > 0 and dp.n_replicated == n_replicated
         # spoil every operator of the cycle, then re-prepare: the values must all come back from the device-side chain
-        for A in dp.A + [dp.A_rep]:
+        for A in dp.A + [dp.A_coarse] + ([dp.A_g0] if n_replicated == 2 else []):
             A.zero()
         dp.prepare()
-        save = {"n_rep": dp.A_rep.m()}
-        Ar = dp.A_rep.to_scipy()
+        save = {"n_rep": dp.A_coarse.m()}
+        Ar = dp.A_coarse.to_scipy()
         save.update(rep_data=Ar.data, rep_indices=Ar.indices, rep_indptr=Ar.indptr)
+        if n_replicated == 2:        # the second replicated level: the whole global level-0 operator on every rank
+            Ag = dp.A_g0.to_scipy()
+            save.update(g0_data=Ag.data, g0_indices=Ag.indices, g0_indptr=Ag.indptr)
         for l, pl in enumerate(dp.H.plans):
             A = dp.A[l].to_scipy()
             save.update({"rows%d" % l: pl.gid[pl.owned], "cols%d" % l: pl.gid[np.concatenate([pl.owned, pl.ghost])],
@@ -73,8 +76,8 @@ def _ops_worker(rank, world, port, nb, nlevels, out):
         raise
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_distributed_repreparation_gives_the_serial_galerkin_operators(tmp_path, world):
+@pytest.mark.parametrize("world,n_replicated", [(2, 2), (4, 2), (2, 1)])
+def test_distributed_repreparation_gives_the_serial_galerkin_operators(tmp_path, world, n_replicated):
     """DistributedPoisson.prepare(): extended-box assembly + Galerkin chain + SetPenalty, owned rows gathered on the device, the
     replicated operator summed over the ranks -- every level operator equals the rows of the serial oracle chain (1e-12), as the
     reference's distributed MatPtAP would give them (LinearImplicitSystem.cpp:347-370, PetscMatrix.cpp:733-751)"""
@@ -83,7 +86,7 @@ def test_distributed_repreparation_gives_the_serial_galerkin_operators(tmp_path,
     from oracle import femus_oracle as fo
     nb, nlevels = 2, 3
     out = str(tmp_path / "rank%d.npz")
-    mp.spawn(_ops_worker, args=(world, _free_port(), nb, nlevels, out), nprocs=world, join=True)
+    mp.spawn(_ops_worker, args=(world, _free_port(), nb, nlevels, out, n_replicated), nprocs=world, join=True)
     part = dd.BoxPartition(world, 0)
     p = part.p
     ONE = lambda xg: np.ones(xg.shape[:2])
@@ -94,6 +97,15 @@ def test_distributed_repreparation_gives_the_serial_galerkin_operators(tmp_path,
         d = np.load(out % r)
         Arep = sp.csr_matrix((d["rep_data"], d["rep_indices"], d["rep_indptr"]), shape=(int(d["n_rep"]),) * 2)
         assert abs(Arep - H.A[0]).max() <= 1e-12 * abs(H.A[0]).max()                       # replicated level: same on every rank
+        if n_replicated == 2:
+            # the replicated smoothed level is the serial level-1 operator up to the node numbering of the two global meshes
+            n1 = H.A[1].shape[0]
+            Ag = sp.csr_matrix((d["g0_data"], d["g0_indices"], d["g0_indptr"]), shape=(n1, n1))
+            from femus_amd import capi
+            m_rep = capi.Mesh.box(p[0] * nb // 2, p[1] * nb // 2, p[2] * nb // 2, lo=(0., 0., 0.), hi=tuple(float(v) for v in p))
+            m_g0 = m_rep.refine()
+            assert np.array_equal(m_g0.arrays()[1], H.meshes[1].coords)              # same generator, same numbering
+            assert abs(Ag - H.A[1]).max() <= 1e-12 * abs(H.A[1]).max()
         for l in range(nlevels):
             gid_ser, _ = dd.node_keys(H.meshes[l + 1].coords, l, nb, part)
             srt = np.argsort(gid_ser)
@@ -160,7 +172,10 @@ def _rank_worker_body(rank, world, port, nb, nlevels, out, overlap=1):
     # V(2,2): per level one exchange per sweep after the first, one for the residual, one for the restriction (not into the
     # replicated level), one for the interpolation from a distributed level, two post-sweeps
     st = [h.stats()["updates"] for h in dp.halos]
-    assert st == [1 + 1 + 0 + 1 + 2] + [1 + 1 + 1 + 1 + 2] * (nlevels - 2) + [1 + 1 + 1 + 0 + 2], st
+    if dp.n_replicated == 2:     # the coarsest local level is replicated too: no exchange there, and none for the interpolation out of it
+        assert st == [0] + ([1 + 1 + 0 + 0 + 2] if nlevels == 2 else [1 + 1 + 0 + 1 + 2] + [1 + 1 + 1 + 1 + 2] * (nlevels - 3) + [1 + 1 + 1 + 0 + 2]), st
+    else:
+        assert st == [1 + 1 + 0 + 1 + 2] + [1 + 1 + 1 + 1 + 2] * (nlevels - 2) + [1 + 1 + 1 + 0 + 2], st
     x = dp.EPSC.to_numpy()[:dp.n_owned].copy()
     its, rn = dp.solve(outer="gmres", rtol=1e-12, maxit=60)
     xs = dp.EPSC.to_numpy()[:dp.n_owned].copy()
@@ -228,8 +243,8 @@ def test_bench_contract_with_two_ranks_sharing_the_gpu(tmp_path, transport):
     assert "domain decomposition" in d["config"]["parallelism"] and "host-staged" in d["config"]["parallelism"]
     assert ("gloo" in d["config"]["parallelism"]) == (transport == "gloo")
     assert d["config"]["dofs_total"] == 33 * 17 * 17 and "roofline" in d and "cpu_baseline" not in d
-    h = d["halo"]     # 3 distributed levels, V(2,2): 5 + 6 + 5 exchanges per cycle, some of the exchange time hidden or not, never negative
-    assert h["exchanges_per_cycle"] == 16 and h["bytes_sent_per_cycle_this_rank"] > 0
+    h = d["halo"]     # 3 local levels, the coarsest of them replicated, V(2,2): 0 + 5 + 5 exchanges per cycle, some of the exchange time hidden or not
+    assert h["exchanges_per_cycle"] == 10 and h["exchanges_per_cycle_by_level"] == [0, 5, 5] and h["bytes_sent_per_cycle_this_rank"] > 0
     assert h["exchange_ms_per_cycle"] > 0 and 0 <= h["exposed_ms_per_cycle"] <= h["exchange_ms_per_cycle"]
 
 
