@@ -146,6 +146,14 @@ class Vec:
         idx, vals = _i32(idx), _f64(vals)
         _chk(self.L.fh_vec_add_values(self.h, idx.size, _p(idx), _p(vals)))
 
+    def stage_vector_blocked(self, vals, idx):
+        """add_vector_blocked as PETSc performs it: staged until flush() (= close())"""
+        idx, vals = _i32(idx), _f64(vals)
+        _chk(self.L.fh_vec_stage_values(self.h, idx.size, _p(idx), _p(vals)))
+
+    def flush(self):
+        _chk(self.L.fh_vec_flush(self.h))
+
     def get(self, idx):
         idx = _i32(np.atleast_1d(idx))
         out = np.empty(idx.size)
@@ -277,6 +285,19 @@ class Mat:
     def add_matrix_blocked(self, vals, rows, cols):
         rows, cols, vals = _i32(rows), _i32(cols), _f64(vals)
         _chk(self.L.fh_mat_add_block(self.h, rows.size, _p(rows), cols.size, _p(cols), _p(vals)))
+
+    def stage_matrix_blocked(self, vals, rows, cols):
+        """add_matrix_blocked as PETSc performs it: staged in the pinned ring until flush() (= close())"""
+        rows, cols, vals = _i32(rows), _i32(cols), _f64(vals)
+        _chk(self.L.fh_mat_stage_block(self.h, rows.size, _p(rows), cols.size, _p(cols), _p(vals)))
+
+    def flush(self):
+        _chk(self.L.fh_mat_flush(self.h))
+
+    def stage_stats(self):
+        b, r = ctypes.c_int64(), ctypes.c_int64()
+        _chk(self.L.fh_mat_stage_stats(self.h, ctypes.byref(b), ctypes.byref(r)))
+        return b.value, r.value
 
     def insert_row(self, row, cols, vals):
         cols, vals = _i32(cols), _f64(vals)

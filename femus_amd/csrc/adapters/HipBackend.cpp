@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <thread>
 
 namespace femus {
 
@@ -31,6 +32,7 @@ void HipVector::clear() {
   if (_v) fh_vec_destroy(_v);
   _v = nullptr;
   _halo = nullptr;
+  _pending = false;
   _is_initialized = _is_closed = false;
 }
 std::unique_ptr<NumericVector> HipVector::clone() const {
@@ -65,17 +67,55 @@ void HipVector::init(const NumericVector& other, const bool) {
   _halo = hv(other).halo();          // same layout, same ghosts: same plan (init(other) clones the layout incl. ghosts, PetscVector.hpp:572-592)
   _is_initialized = true;
 }
+fh_vec_t HipVector::rv() const {
+  if (_pending) {
+    _pending = false;
+    hip_check(fh_vec_flush(_v), "HipVector: flush of the staged adds");
+  }
+  return _v;
+}
+// ownership range of this rank: the owned sizes of the ranks before it (VecGetOwnershipRange; PetscVector.hpp:683-707)
+void HipVector::attach_halo(fh_halo_t halo) {
+  _halo = halo;
+  if (!halo) return;
+  int rank = 0, nranks = 1;
+  hip_check(fh_halo_rank(halo, &rank, &nranks), "attach_halo");
+  std::vector<double> sizes(nranks, 0.);
+  sizes[rank] = _n_local;
+  hip_check(fh_halo_allreduce_sum(halo, sizes.data(), nranks), "attach_halo: owned sizes");
+  double first = 0., total = 0.;
+  for (int r = 0; r < nranks; r++) {
+    if (r < rank) first += sizes[r];
+    total += sizes[r];
+  }
+  if ((int)total != _n_global) {
+    std::cout << "HipVector::attach_halo: the owned sizes of the ranks add up to " << (long)total << ", the vector has " << _n_global << std::endl;
+    abort();
+  }
+  _first = (int)first;
+  hip_check(fh_vec_set_first(rv(), _first), "attach_halo: ownership offset");
+}
 void HipVector::not_served(const char* what) {
   std::cout << "HipVector::" << what << " is not served by the HIP backend" << std::endl;
   abort();
 }
 void HipVector::close() {
-  if (_halo && _v) hip_check(fh_halo_update(_halo, _v), "HipVector::close (ghost refresh)");   // VecGhostUpdateBegin/End, PetscVector.hpp:604-610
+  if (_v) rv();          // VecAssemblyBegin/End: the staged adds
+  if (_halo && _v) hip_check(fh_halo_update(_halo, rv()), "HipVector::close (ghost refresh)");   // VecGhostUpdateBegin/End, PetscVector.hpp:604-610
   _is_closed = true;
 }
 double HipVector::all_sum(double local) const {      // VecDot / VecNorm over the ranks (Parallel.hpp:351-377)
   if (_halo) hip_check(fh_halo_allreduce_sum(_halo, &local, 1), "HipVector: all-reduce");
   return local;
+}
+double HipVector::all_extreme(double local, bool want_max) const {   // VecMin / VecMax / NORM_INFINITY are global (PetscVector.cpp)
+  if (!_halo) return local;
+  int rank = 0, nranks = 1;
+  hip_check(fh_halo_rank(_halo, &rank, &nranks), "HipVector: reduce");
+  std::vector<double> all(nranks, 0.);
+  all[rank] = local;
+  hip_check(fh_halo_allreduce_sum(_halo, all.data(), nranks), "HipVector: reduce");
+  return want_max ? *std::max_element(all.begin(), all.end()) : *std::min_element(all.begin(), all.end());
 }
 void HipVector::insert(const NumericVector& V, const std::vector<int>& dof) {
   std::vector<double> v;
@@ -94,6 +134,7 @@ void HipVector::swap(NumericVector& other) {
   NumericVector::swap(other);
   std::swap(_v, o._v);
   std::swap(_halo, o._halo);
+  std::swap(_pending, o._pending);
   std::swap(_n_global, o._n_global);
   std::swap(_n_local, o._n_local);
   std::swap(_first, o._first);
@@ -118,34 +159,39 @@ void HipVector::localize_to_all(std::vector<double>& v_local) const {
   localize(own);
   v_local.assign(_n_global, 0.);
   std::copy(own.begin(), own.end(), v_local.begin() + _first);
-  if (_halo && _n_global != _n_local)
-    for (int k = 0; k < _n_global; k += 256) hip_check(fh_halo_allreduce_sum(_halo, v_local.data() + k, std::min(256, _n_global - k)), "localize_to_all");
+  if (_halo && _n_global != _n_local) hip_check(fh_halo_allreduce_sum(_halo, v_local.data(), _n_global), "localize_to_all");
 }
-void HipVector::set(const int i, const double value) { hip_check(fh_vec_set_values(_v, 1, &i, &value), "HipVector::set"); _is_closed = false; }
-void HipVector::add(const int i, const double value) { hip_check(fh_vec_add_values(_v, 1, &i, &value), "HipVector::add"); _is_closed = false; }
-void HipVector::zero() { hip_check(fh_vec_zero(_v), "HipVector::zero"); }
-NumericVector& HipVector::operator=(const double s) { hip_check(fh_vec_fill(_v, s), "HipVector::operator=(double)"); return *this; }
-NumericVector& HipVector::operator=(const NumericVector& V) { hip_check(fh_vec_copy(_v, hv(V).handle()), "HipVector::operator=(vector)"); return *this; }
+void HipVector::set(const int i, const double value) { hip_check(fh_vec_set_values(rv(), 1, &i, &value), "HipVector::set"); _is_closed = false; }
+void HipVector::add(const int i, const double value) {
+  hip_check(fh_vec_stage_values(_v, 1, &i, &value), "HipVector::add");
+  _pending = true;
+  _is_closed = false;
+}
+void HipVector::zero() { hip_check(fh_vec_zero(rv()), "HipVector::zero"); }
+NumericVector& HipVector::operator=(const double s) { hip_check(fh_vec_fill(rv(), s), "HipVector::operator=(double)"); return *this; }
+NumericVector& HipVector::operator=(const NumericVector& V) { hip_check(fh_vec_copy(rv(), hv(V).handle()), "HipVector::operator=(vector)"); return *this; }
 NumericVector& HipVector::operator=(const std::vector<double>& v) {
   if ((int)v.size() != _n_local) { std::cout << "HipVector::operator=(std::vector): size mismatch" << std::endl; abort(); }
-  hip_check(fh_vec_upload(_v, v.data()), "HipVector::operator=(std::vector)");
+  hip_check(fh_vec_upload(rv(), v.data()), "HipVector::operator=(std::vector)");
   return *this;
 }
-double HipVector::min() const { double r; hip_check(fh_vec_reduce(_v, 1, &r), "min"); return r; }
-double HipVector::max() const { double r; hip_check(fh_vec_reduce(_v, 2, &r), "max"); return r; }
-double HipVector::sum() const { double r; hip_check(fh_vec_reduce(_v, 0, &r), "sum"); return all_sum(r); }
-double HipVector::l1_norm() const { double r; hip_check(fh_vec_norm(_v, 1, &r), "l1_norm"); return all_sum(r); }
-double HipVector::l2_norm() const { double r; hip_check(fh_vec_norm(_v, 2, &r), "l2_norm"); return _halo ? sqrt(all_sum(r * r)) : r; }
-double HipVector::linfty_norm() const { double r; hip_check(fh_vec_norm(_v, 0, &r), "linfty_norm"); return r; }
-double HipVector::operator()(const int i) const { double r; hip_check(fh_vec_get_values(_v, 1, &i, &r), "operator()"); return r; }
+double HipVector::min() const { double r; hip_check(fh_vec_reduce(rv(), 1, &r), "min"); return all_extreme(r, false); }
+double HipVector::max() const { double r; hip_check(fh_vec_reduce(rv(), 2, &r), "max"); return all_extreme(r, true); }
+double HipVector::sum() const { double r; hip_check(fh_vec_reduce(rv(), 0, &r), "sum"); return all_sum(r); }
+double HipVector::l1_norm() const { double r; hip_check(fh_vec_norm(rv(), 1, &r), "l1_norm"); return all_sum(r); }
+double HipVector::l2_norm() const { double r; hip_check(fh_vec_norm(rv(), 2, &r), "l2_norm"); return _halo ? sqrt(all_sum(r * r)) : r; }
+double HipVector::linfty_norm() const { double r; hip_check(fh_vec_norm(rv(), 0, &r), "linfty_norm"); return all_extreme(r, true); }
+double HipVector::operator()(const int i) const { double r; hip_check(fh_vec_get_values(rv(), 1, &i, &r), "operator()"); return r; }
 void HipVector::get(const std::vector<int>& index, std::vector<double>& values) const {
   values.resize(index.size());
-  hip_check(fh_vec_get_values(_v, (int)index.size(), index.data(), values.data()), "HipVector::get");
+  hip_check(fh_vec_get_values(rv(), (int)index.size(), index.data(), values.data()), "HipVector::get");
 }
-void HipVector::add(const double s) { hip_check(fh_vec_shift(_v, s), "HipVector::add(s)"); }
-void HipVector::add(const double a, const NumericVector& v) { hip_check(fh_vec_axpy(_v, a, hv(v).handle()), "HipVector::add(a,v)"); }
+void HipVector::add(const double s) { hip_check(fh_vec_shift(rv(), s), "HipVector::add(s)"); }
+void HipVector::add(const double a, const NumericVector& v) { hip_check(fh_vec_axpy(rv(), a, hv(v).handle()), "HipVector::add(a,v)"); }
 void HipVector::add_vector_blocked(const std::vector<double>& v, const std::vector<int>& dof) {
-  hip_check(fh_vec_add_values(_v, (int)dof.size(), dof.data(), v.data()), "add_vector_blocked");
+  // staged in the pinned ring (VecSetValues into the stash); applied in call order by the next member that needs the values
+  hip_check(fh_vec_stage_values(_v, (int)dof.size(), dof.data(), v.data()), "add_vector_blocked");
+  _pending = true;
   _is_closed = false;
 }
 void HipVector::add_vector_blocked(const std::vector<double>& v, const std::vector<unsigned>& dof) {
@@ -153,34 +199,34 @@ void HipVector::add_vector_blocked(const std::vector<double>& v, const std::vect
   add_vector_blocked(v, d);
 }
 void HipVector::insert_vector_blocked(const std::vector<double>& v, const std::vector<int>& dof) {
-  hip_check(fh_vec_set_values(_v, (int)dof.size(), dof.data(), v.data()), "insert_vector_blocked");
+  hip_check(fh_vec_set_values(rv(), (int)dof.size(), dof.data(), v.data()), "insert_vector_blocked");
   _is_closed = false;
 }
 // the operand's exchange plan (if any) refreshes its ghosts inside the product, overlapped with the rows that need none: MatMult on
 // an MPIAIJ matrix (PetscVector.cpp:182-247)
 void HipVector::add_vector(const NumericVector& v, const SparseMatrix& A) {
-  hip_check(fh_spmv_ghosted(hm(A).handle(), hv(v).halo(), hv(v).handle(), _v, 1, nullptr, nullptr, 0.), "add_vector(v,A)");
+  hip_check(fh_spmv_ghosted(hm(A).handle(), hv(v).halo(), hv(v).handle(), rv(), 1, nullptr, nullptr, 0.), "add_vector(v,A)");
 }
 void HipVector::resid(const NumericVector& rhs, const NumericVector& v, const SparseMatrix& A) {
-  hip_check(fh_spmv_ghosted(hm(A).handle(), hv(v).halo(), hv(v).handle(), _v, 2, hv(rhs).handle(), nullptr, 0.), "resid");
+  hip_check(fh_spmv_ghosted(hm(A).handle(), hv(v).halo(), hv(v).handle(), rv(), 2, hv(rhs).handle(), nullptr, 0.), "resid");
 }
 void HipVector::matrix_mult(const NumericVector& v, const SparseMatrix& A) {
-  hip_check(fh_spmv_ghosted(hm(A).handle(), hv(v).halo(), hv(v).handle(), _v, 0, nullptr, nullptr, 0.), "matrix_mult");
+  hip_check(fh_spmv_ghosted(hm(A).handle(), hv(v).halo(), hv(v).handle(), rv(), 0, nullptr, nullptr, 0.), "matrix_mult");
 }
 void HipVector::matrix_mult_transpose(const NumericVector& v, const SparseMatrix& A) {
-  hip_check(fh_spmv_transpose(hm(A).handle(), hv(v).handle(), _v), "matrix_mult_transpose");
+  hip_check(fh_spmv_transpose(hm(A).handle(), hv(v).handle(), rv()), "matrix_mult_transpose");
 }
-void HipVector::scale(const double f) { hip_check(fh_vec_scale(_v, f), "scale"); }
-void HipVector::abs() { hip_check(fh_vec_abs(_v), "abs"); }
-double HipVector::dot(const NumericVector& o) const { double r; hip_check(fh_vec_dot(_v, hv(o).handle(), &r), "dot"); return all_sum(r); }
+void HipVector::scale(const double f) { hip_check(fh_vec_scale(rv(), f), "scale"); }
+void HipVector::abs() { hip_check(fh_vec_abs(rv()), "abs"); }
+double HipVector::dot(const NumericVector& o) const { double r; hip_check(fh_vec_dot(rv(), hv(o).handle(), &r), "dot"); return all_sum(r); }
 void HipVector::localize(std::vector<double>& out) const {
   out.resize(_n_local);
-  hip_check(fh_vec_download(_v, out.data()), "localize");
+  hip_check(fh_vec_download(rv(), out.data()), "localize");
 }
-void HipVector::BinaryPrint(const char* fileName) { hip_check(fh_vec_binary_print(_v, fileName), "BinaryPrint"); }
-void HipVector::BinaryLoad(const char* fileName) { hip_check(fh_vec_binary_load(_v, fileName), "BinaryLoad"); }
+void HipVector::BinaryPrint(const char* fileName) { hip_check(fh_vec_binary_print(rv(), fileName), "BinaryPrint"); }
+void HipVector::BinaryLoad(const char* fileName) { hip_check(fh_vec_binary_load(rv(), fileName), "BinaryLoad"); }
 void HipVector::pointwise_mult(const NumericVector& a, const NumericVector& b) {
-  hip_check(fh_vec_pointwise_mult(_v, hv(a).handle(), hv(b).handle()), "pointwise_mult");
+  hip_check(fh_vec_pointwise_mult(rv(), hv(a).handle(), hv(b).handle()), "pointwise_mult");
 }
 
 // =============================== HipMatrix ===============================
@@ -188,6 +234,10 @@ void HipMatrix::clear() {
   if (_A) fh_mat_destroy(_A);
   _A = nullptr;
   _stage.clear();
+  _logHdr.clear();
+  _logIdx.clear();
+  _logVal.clear();
+  _pending = false;
   _closed = false;
 }
 void HipMatrix::init(const int m, const int n, const int, const int, const std::vector<int>&, const std::vector<int>&) {
@@ -342,35 +392,113 @@ void HipMatrix::adopt(fh_mat_t h) {
   _closed = true;
 }
 void HipMatrix::close() const {
-  if (_A || _stage.empty()) {
-    _closed = true;
-    return;
+  if (!_A && !(_stage.empty() && _logHdr.empty())) first_close();
+  if (_A && _pending) {       // MatAssemblyBegin/End: the blocks staged since the last close
+    _pending = false;
+    hip_check(fh_mat_flush(_A), "HipMatrix::close (staged add_matrix_blocked calls)");
   }
-  std::vector<int> rp(_m + 1, 0), col;
-  std::vector<double> val;
-  for (int i = 0; i < _m; i++) {
-    for (auto& kv : _stage[i]) {
-      col.push_back(kv.first);
-      val.push_back(kv.second);
+  _closed = true;
+}
+// first close(): the union pattern of everything inserted and added so far (PETSc grows it inside MatSetValues), on all host cores
+void HipMatrix::first_close() const {
+  const size_t nblk = _logHdr.size() / 2;
+  std::vector<int64_t> ptr(_m + 1, 0);
+  {
+    size_t io = 0;
+    for (size_t b = 0; b < nblk; b++) {
+      const int nr = _logHdr[2 * b], nc = _logHdr[2 * b + 1];
+      for (int i = 0; i < nr; i++) {
+        const int r = _logIdx[io + i];
+        if (r < 0 || r >= _m) { std::cout << "HipMatrix::add_matrix_blocked: row " << r << " out of range" << std::endl; abort(); }
+        ptr[r + 1] += nc;
+      }
+      io += (size_t)nr + nc;
     }
-    rp[i + 1] = (int)col.size();
   }
+  for (int i = 0; i < (int)_stage.size(); i++) ptr[i + 1] += (int64_t)_stage[i].size();
+  for (int i = 0; i < _m; i++) ptr[i + 1] += ptr[i];
+  std::vector<int> cand(ptr[_m]);
+  {
+    std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
+    size_t io = 0;
+    for (size_t b = 0; b < nblk; b++) {
+      const int nr = _logHdr[2 * b], nc = _logHdr[2 * b + 1];
+      const int* cols = _logIdx.data() + io + nr;
+      for (int i = 0; i < nr; i++) {
+        const int r = _logIdx[io + i];
+        std::copy(cols, cols + nc, cand.begin() + cur[r]);
+        cur[r] += nc;
+      }
+      io += (size_t)nr + nc;
+    }
+    for (int i = 0; i < (int)_stage.size(); i++)
+      for (auto& kv : _stage[i]) cand[cur[i]++] = kv.first;
+  }
+  // sort + unique per row, rows split over the host cores
+  std::vector<int> len(_m, 0);
+  const int nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  auto work = [&](int t) {
+    const int r0 = (int)((int64_t)_m * t / nth), r1 = (int)((int64_t)_m * (t + 1) / nth);
+    for (int r = r0; r < r1; r++) {
+      int* b = cand.data() + ptr[r];
+      int* e = cand.data() + ptr[r + 1];
+      std::sort(b, e);
+      len[r] = (int)(std::unique(b, e) - b);
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nth; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& t : th) t.join();
+  }
+  std::vector<int> rp(_m + 1, 0);
+  for (int r = 0; r < _m; r++) {
+    if ((int64_t)rp[r] + len[r] > 2147483647LL) { std::cout << "HipMatrix::close: more than 2^31 non-zeros" << std::endl; abort(); }
+    rp[r + 1] = rp[r] + len[r];
+  }
+  std::vector<int> col(rp[_m]);
+  for (int r = 0; r < _m; r++) {
+    if (len[r] && (cand[ptr[r]] < 0 || cand[ptr[r] + len[r] - 1] >= _n)) { std::cout << "HipMatrix: column out of range in row " << r << std::endl; abort(); }
+    std::copy(cand.begin() + ptr[r], cand.begin() + ptr[r] + len[r], col.begin() + rp[r]);
+  }
+  std::vector<int>().swap(cand);
+  std::vector<double> val(rp[_m], 0.);
+  for (int i = 0; i < (int)_stage.size(); i++)       // inserted entries (set / insert_row before the first close)
+    for (auto& kv : _stage[i]) val[std::lower_bound(col.begin() + rp[i], col.begin() + rp[i + 1], kv.first) - col.begin()] = kv.second;
   hip_check(fh_mat_create_csr(hip_context(), _m, _n, rp.data(), col.data(), val.data(), &_A), "HipMatrix::close");
   _stage.clear();
   _stage.shrink_to_fit();
-  _closed = true;
+  // the logged blocks, in the order they were added
+  size_t io = 0, vo = 0;
+  for (size_t b = 0; b < nblk; b++) {
+    const int nr = _logHdr[2 * b], nc = _logHdr[2 * b + 1];
+    hip_check(fh_mat_stage_block(_A, nr, _logIdx.data() + io, nc, _logIdx.data() + io + nr, _logVal.data() + vo), "HipMatrix::close (replay)");
+    io += (size_t)nr + nc;
+    vo += (size_t)nr * nc;
+  }
+  if (nblk) _pending = true;
+  std::vector<int>().swap(_logHdr);
+  std::vector<int>().swap(_logIdx);
+  std::vector<double>().swap(_logVal);
 }
 void HipMatrix::set(const int i, const int j, const double v) {
-  if (_A) hip_check(fh_mat_insert_row(_A, i, 1, &j, &v), "HipMatrix::set");
+  if (_A) hip_check(fh_mat_insert_row(handle(), i, 1, &j, &v), "HipMatrix::set");
+  else if (!_logHdr.empty()) { close(); set(i, j, v); }       // an insert after adds: the adds come first
   else _stage[i][j] = v;
 }
 void HipMatrix::add(const int i, const int j, const double v) {
-  if (_A) hip_check(fh_mat_add_block(_A, 1, &i, 1, &j, &v), "HipMatrix::add");
-  else _stage[i][j] += v;
+  const std::vector<int> r(1, i), c(1, j);
+  add_matrix_blocked(std::vector<double>(1, v), r, c);
 }
 void HipMatrix::zero() {
-  if (_A) hip_check(fh_mat_zero(_A), "HipMatrix::zero");
-  else for (auto& r : _stage) for (auto& kv : r) kv.second = 0.;
+  if (_A) {
+    close();
+    hip_check(fh_mat_zero(_A), "HipMatrix::zero");
+  } else {
+    for (auto& r : _stage) for (auto& kv : r) kv.second = 0.;
+    std::fill(_logVal.begin(), _logVal.end(), 0.);       // the pattern of what was added stays (MatZeroEntries keeps it)
+  }
 }
 double HipMatrix::operator()(const int i, const int j) const {
   close();
@@ -389,16 +517,25 @@ int HipMatrix::MatGetRowM(const int i, int* cols, double* vals) {
   return nc;
 }
 void HipMatrix::insert_row(const int row, const int ncols, const std::vector<int>& cols, double* values) {
-  if (_A) hip_check(fh_mat_insert_row(_A, row, ncols, cols.data(), values), "insert_row");
+  if (!_A && !_logHdr.empty()) close();
+  if (_A) hip_check(fh_mat_insert_row(handle(), row, ncols, cols.data(), values), "insert_row");
   else for (int k = 0; k < ncols; k++) _stage[row][cols[k]] = values[k];
 }
+// the per-element crossing (PetscMatrix.cpp:699-729): nothing touches the device here.  With a device pattern the block goes into the
+// pinned ring of fh_mat_stage_block (a full ring leaves asynchronously); before the first close() it is logged on the host
 void HipMatrix::add_matrix_blocked(const std::vector<double>& mat, const std::vector<int>& rows, const std::vector<int>& cols) {
+  if (mat.size() != rows.size() * cols.size()) { std::cout << "HipMatrix::add_matrix_blocked: size mismatch" << std::endl; abort(); }
   if (_A) {
-    hip_check(fh_mat_add_block(_A, (int)rows.size(), rows.data(), (int)cols.size(), cols.data(), mat.data()), "add_matrix_blocked");
+    hip_check(fh_mat_stage_block(_A, (int)rows.size(), rows.data(), (int)cols.size(), cols.data(), mat.data()), "add_matrix_blocked");
+    _pending = true;
   } else {
-    for (size_t i = 0; i < rows.size(); i++)
-      for (size_t j = 0; j < cols.size(); j++) _stage[rows[i]][cols[j]] += mat[i * cols.size() + j];
+    _logHdr.push_back((int)rows.size());
+    _logHdr.push_back((int)cols.size());
+    _logIdx.insert(_logIdx.end(), rows.begin(), rows.end());
+    _logIdx.insert(_logIdx.end(), cols.begin(), cols.end());
+    _logVal.insert(_logVal.end(), mat.begin(), mat.end());
   }
+  _closed = false;
 }
 void HipMatrix::add_matrix_blocked(const std::vector<double>& mat, const std::vector<unsigned>& rows, const std::vector<unsigned>& cols) {
   std::vector<int> r(rows.begin(), rows.end()), c(cols.begin(), cols.end());

@@ -87,17 +87,22 @@ class HipVector : public NumericVector {
   // MultiLevelSolution::SaveSolution / LoadSolution (MultiLevelSolution.cpp:1070-1126): PETSc's binary Vec layout
   void BinaryPrint(const char* fileName) override;
   void BinaryLoad(const char* fileName) override;
-  fh_vec_t handle() const { return _v; }
+  // the device vector with every staged add applied (add_vector_blocked only stages, as VecSetValues does until VecAssemblyEnd)
+  fh_vec_t handle() const { return rv(); }
   // several ranks (one per GPU): the exchange plan that refreshes this vector's ghosts (built from the ghost list it was
-  // initialised with, fh_halo_create*) and sums dot products / norms over the ranks.  Not owned.
-  void attach_halo(fh_halo_t halo) { _halo = halo; }
+  // initialised with, fh_halo_create*) and reduces dot products / norms / min / max over the ranks.  Not owned.  Collective: the
+  // ranks exchange their owned sizes here, which gives this rank's first global index (PetscVector's ownership range)
+  void attach_halo(fh_halo_t halo);
   fh_halo_t halo() const { return _halo; }
 
  private:
   static void not_served(const char* what);
   double all_sum(double local) const;
+  double all_extreme(double local, bool want_max) const;
+  fh_vec_t rv() const;               // flushes the staged adds
   fh_vec_t _v = nullptr;
   fh_halo_t _halo = nullptr;
+  mutable bool _pending = false;     // add_vector_blocked calls staged since the last flush
   int _n_global = 0, _n_local = 0, _first = 0;
 };
 
@@ -160,11 +165,18 @@ class HipMatrix : public SparseMatrix {
   fh_mat_t handle() const { close(); return _A; }
 
  private:
-  // before the first close() entries are staged on the host (the reference relies on MatSetValues growing the
-  // pattern); close() freezes the pattern into a device CSR, after which add/insert go straight to the device
+  // before the first close() the pattern is not known (the reference relies on MatSetValues growing it): inserted entries are
+  // kept per row, added element blocks are logged as they come; close() builds the union pattern on all host cores, freezes it
+  // into a device CSR and replays the log through the staged add.  After that add_matrix_blocked stages into the pinned ring of
+  // fh_mat_stage_block and close() flushes -- no device call per element in either phase
   mutable fh_mat_t _A = nullptr;
   mutable std::vector<std::map<int, double>> _stage;
+  mutable std::vector<int> _logHdr;        // per block: nrow, ncol (rows then cols in _logIdx, values row-major in _logVal)
+  mutable std::vector<int> _logIdx;
+  mutable std::vector<double> _logVal;
+  mutable bool _pending = false;           // blocks staged on the device side since the last flush
   mutable bool _closed = false;
+  void first_close() const;
   int _row_start = 0;
   static void not_served(const char* what);
   void to_host(std::vector<int>& rp, std::vector<int>& col, std::vector<double>& val) const;

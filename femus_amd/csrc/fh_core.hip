@@ -187,6 +187,7 @@ extern "C" int fh_vec_duplicate(fh_vec_t s, fh_vec_t* out) {
 extern "C" int fh_vec_destroy(fh_vec_t v) {
   if (!v) return 0;
   hipStreamSynchronize(v->ctx->stream);
+  fh_stage_free(v->stage);
   if (v->d) hipFree(v->d);
   if (v->d_ghost_idx) hipFree(v->d_ghost_idx);
   delete v;
@@ -198,6 +199,12 @@ extern "C" int fh_vec_size(fh_vec_t v, int* n_global, int* n_local, int* first_l
   if (n_local) *n_local = v->n_local;
   if (first_local) *first_local = v->first_local;
   if (nghost) *nghost = v->nghost;
+  return 0;
+}
+
+extern "C" int fh_vec_set_first(fh_vec_t v, int first_local) {
+  FH_REQUIRE(v && first_local >= 0 && (int64_t)first_local + v->n_local <= v->n_global, "fh_vec_set_first: offset %d does not fit", first_local);
+  v->first_local = first_local;
   return 0;
 }
 
@@ -334,7 +341,11 @@ static int vec_indexed(fh_vec_t v, int n, const int* idx, const double* vals_in,
 }
 
 extern "C" int fh_vec_set_values(fh_vec_t v, int n, const int* idx, const double* vals) { return vec_indexed(v, n, idx, vals, nullptr, 0); }
-extern "C" int fh_vec_add_values(fh_vec_t v, int n, const int* idx, const double* vals) { return vec_indexed(v, n, idx, vals, nullptr, 1); }
+// immediate form of the staged add (fh_stage.hip): values added in the order given, duplicates included
+extern "C" int fh_vec_add_values(fh_vec_t v, int n, const int* idx, const double* vals) {
+  FH_TRY(fh_vec_stage_values(v, n, idx, vals));
+  return fh_vec_flush(v);
+}
 extern "C" int fh_vec_get_values(fh_vec_t v, int n, const int* idx, double* vals) { return vec_indexed(v, n, idx, nullptr, vals, 2); }
 
 extern "C" int fh_vec_axpy(fh_vec_t y, double a, fh_vec_t x) {

@@ -335,17 +335,30 @@ extern "C" int fh_halo_stats(fh_halo_t h, int reset, int64_t* n_updates, int64_t
 }
 
 extern "C" int fh_halo_allreduce_sum(fh_halo_t h, double* vals, int n) {
-  FH_REQUIRE(h && vals && n >= 0 && n <= 256, "fh_halo_allreduce_sum: bad arguments (n <= 256)");
+  FH_REQUIRE(h && vals && n >= 0, "fh_halo_allreduce_sum: bad arguments");
   if (halo_inert(h) || n == 0) return 0;
   if (h->allreduce) {
     FH_REQUIRE(h->allreduce(h->user, vals, n) == 0, "host transport: the all-reduce function failed");
     return 0;
   }
   fh_ctx_t c = h->ctx;
-  FH_CHECK_HIP(hipMemcpyAsync(h->d_scalars, vals, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  FH_CHECK_NCCL(ncclAllReduce(h->d_scalars, h->d_scalars, n, ncclDouble, ncclSum, h->comm, c->stream));
-  FH_CHECK_HIP(hipMemcpyAsync(vals, h->d_scalars, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  double* d = h->d_scalars;        // 256 doubles live with the plan (dot products, norms); longer arrays (localize_to_all) get their own
+  if (n > 256) FH_CHECK_HIP(hipMalloc(&d, (size_t)n * sizeof(double)));
+  hipError_t e = hipMemcpyAsync(d, vals, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  ncclResult_t nr = ncclSuccess;
+  if (e == hipSuccess) nr = ncclAllReduce(d, d, n, ncclDouble, ncclSum, h->comm, c->stream);
+  if (e == hipSuccess && nr == ncclSuccess) e = hipMemcpyAsync(vals, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess && nr == ncclSuccess) e = hipStreamSynchronize(c->stream);
+  if (n > 256) hipFree(d);
+  FH_REQUIRE(nr == ncclSuccess, "fh_halo_allreduce_sum: ncclAllReduce failed: %s", ncclGetErrorString(nr));
+  FH_CHECK_HIP(e);
+  return 0;
+}
+
+extern "C" int fh_halo_rank(fh_halo_t h, int* rank, int* nranks) {
+  FH_REQUIRE(h, "fh_halo_rank: null plan");
+  if (rank) *rank = h->rank;
+  if (nranks) *nranks = h->nranks;
   return 0;
 }
 

@@ -101,8 +101,13 @@ struct fh_ctx_s {
   int halo_self_rccl = 0;            // one-rank plans exchange with themselves through RCCL (hardware preflight on a single GPU)
 };
 
+// pinned staging rings of the per-element add path (fh_stage.hip); owned by the matrix / vector that staged
+struct fh_stage_s;
+void fh_stage_free(fh_stage_s* s);
+
 struct fh_vec_s {
   fh_ctx_t ctx = nullptr;
+  fh_stage_s* stage = nullptr;
   int n_global = 0, n_local = 0, first_local = 0, nghost = 0;
   double* d = nullptr;                // [n_local + nghost]
   std::vector<int> ghost_idx;         // global indices of ghosts (host copy)
@@ -111,6 +116,7 @@ struct fh_vec_s {
 
 struct fh_mat_s {
   fh_ctx_t ctx = nullptr;
+  fh_stage_s* stage = nullptr;
   uint64_t uid = 0;                   // unique per created matrix (never reused, unlike the address): keys caches built from the pattern
   int m = 0, n = 0, nnz = 0;
   int* d_rowptr = nullptr;

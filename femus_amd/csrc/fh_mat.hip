@@ -62,6 +62,7 @@ extern "C" int fh_mat_create_csr(fh_ctx_t c, int m, int n, const int* rowptr, co
 extern "C" int fh_mat_destroy(fh_mat_t A) {
   if (!A) return 0;
   hipStreamSynchronize(A->ctx->stream);
+  fh_stage_free(A->stage);
   if (A->plan && A->plan_destroy) A->plan_destroy(A->plan);
   if (A->At) fh_mat_destroy(A->At);
   if (A->d_tperm) hipFree(A->d_tperm);
@@ -192,18 +193,10 @@ static int apply_entries(fh_mat_t A, const std::vector<int>& pos, const double* 
   return 0;
 }
 
+// immediate form of the staged add (fh_stage.hip): the block is on the device when the call returns
 extern "C" int fh_mat_add_block(fh_mat_t A, int nrow, const int* rows, int ncol, const int* cols, const double* vals) {
-  std::vector<int> pos((size_t)nrow * ncol);
-  for (int i = 0; i < nrow; i++) {
-    FH_REQUIRE(rows[i] >= 0 && rows[i] < A->m, "fh_mat_add_block: row %d out of range", rows[i]);
-    for (int j = 0; j < ncol; j++) {
-      int p = host_find(A, rows[i], cols[j]);
-      // PETSc would malloc a new entry; with a fixed device pattern this is an error unless the value is zero
-      FH_REQUIRE(p >= 0 || vals[(size_t)i * ncol + j] == 0.0, "fh_mat_add_block: entry (%d,%d) is outside the pattern", rows[i], cols[j]);
-      pos[(size_t)i * ncol + j] = p;
-    }
-  }
-  return apply_entries(A, pos, vals, 1);
+  FH_TRY(fh_mat_stage_block(A, nrow, rows, ncol, cols, vals));
+  return fh_mat_flush(A);
 }
 
 extern "C" int fh_mat_insert_row(fh_mat_t A, int row, int ncols, const int* cols, const double* vals) {

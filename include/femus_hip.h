@@ -68,6 +68,7 @@ int fh_vec_create(fh_ctx_t ctx, int n_global, int n_local, int first_local, cons
 int fh_vec_duplicate(fh_vec_t src, fh_vec_t* v);                 /* NumericVector::init(other) :129 */
 int fh_vec_destroy(fh_vec_t v);
 int fh_vec_size(fh_vec_t v, int* n_global, int* n_local, int* first_local, int* nghost);
+int fh_vec_set_first(fh_vec_t v, int first_local);               /* ownership offset learnt after creation (HipVector::attach_halo) */
 int fh_vec_zero(fh_vec_t v);                                     /* zero() :151 */
 int fh_vec_fill(fh_vec_t v, double s);                           /* operator=(double) :153 */
 int fh_vec_copy(fh_vec_t dst, fh_vec_t src);                     /* operator=(NumericVector) :155 */
@@ -76,6 +77,11 @@ int fh_vec_download(fh_vec_t v, double* host_owned);             /* localize(std
 int fh_vec_set_values(fh_vec_t v, int n, const int* idx, const double* vals);   /* set(i,v) :146 / insert :160 */
 int fh_vec_add_values(fh_vec_t v, int n, const int* idx, const double* vals);   /* add(i,v) :148, add_vector_blocked :265 */
 int fh_vec_get_values(fh_vec_t v, int n, const int* idx, double* vals);         /* operator()(i) :224, get() :236 (owned+ghost) */
+/* add_vector_blocked once per element (PetscVector.cpp:132-153: VecSetValues into the stash, applied by VecAssemblyBegin/End =
+ * close(), PetscVector.hpp:595-612): fh_vec_stage_values appends to a pinned host ring, fh_vec_flush adds everything staged in
+ * the order of the calls (see fh_mat_stage_block).  fh_vec_add_values = stage + flush. */
+int fh_vec_stage_values(fh_vec_t v, int n, const int* idx, const double* vals);
+int fh_vec_flush(fh_vec_t v);
 int fh_vec_axpy(fh_vec_t y, double a, fh_vec_t x);               /* add(a,v) :262, +=, -= :243-245 */
 int fh_vec_aypx(fh_vec_t y, double a, fh_vec_t x);               /* y = a*y + x (used by resid) */
 int fh_vec_shift(fh_vec_t v, double s);                          /* add(s) :258 */
@@ -102,6 +108,17 @@ int fh_mat_get_values_csr(fh_mat_t A, double* val);              /* bulk downloa
 int fh_mat_get_pattern(fh_mat_t A, int* rowptr, int* col);
 /* add_matrix_blocked(vals, rows, cols) :165-171 (PetscMatrix.cpp:699-729): A[rows[i],cols[j]] += vals[i*ncol+j] */
 int fh_mat_add_block(fh_mat_t A, int nrow, const int* rows, int ncol, const int* cols, const double* vals);
+/* the same add as PETSc performs it for an application that calls add_matrix_blocked once per element
+ * (applications/001_Poisson/main.cpp:283-609): MatSetValues keeps the block in a stash and MatAssemblyBegin/End -- close(),
+ * PetscMatrix.hpp:237-244 -- applies it.  fh_mat_stage_block appends the block to a pinned host ring (no device call, no
+ * synchronisation; a full ring leaves for the device asynchronously while the second ring fills), fh_mat_flush applies everything
+ * staged and returns once it is on the device: one kernel per ring adds the blocks row by row IN THE ORDER OF THE CALLS, so the
+ * result has the bits of adding the elements one after the other.  An entry outside the pattern with a non-zero value is reported
+ * by the flush.  Between a stage and the flush the staged blocks are not part of the matrix: every other entry point sees the
+ * values of the last flush.  fh_mat_add_block = stage + flush. */
+int fh_mat_stage_block(fh_mat_t A, int nrow, const int* rows, int ncol, const int* cols, const double* vals);
+int fh_mat_flush(fh_mat_t A);
+int fh_mat_stage_stats(fh_mat_t A, int64_t* blocks_staged, int64_t* rings_sent);
 /* insert_row(row, ncols, cols, vals) :162 -- INSERT semantics */
 int fh_mat_insert_row(fh_mat_t A, int row, int ncols, const int* cols, const double* vals);
 int fh_mat_get_row(fh_mat_t A, int row, int* ncols, int* cols, double* vals);    /* MatGetRowM :111 */
@@ -369,7 +386,8 @@ int fh_spmv_ghosted(fh_mat_t A, fh_halo_t halo, fh_vec_t x, fh_vec_t y, int mode
 int fh_halo_stats(fh_halo_t halo, int reset, int64_t* n_updates, int64_t* bytes_sent, double* exchange_ms, double* exposed_ms);
 int fh_halo_sizes(fh_halo_t halo, int* nsend, int* nrecv);
 int fh_halo_allreduce_vec(fh_halo_t halo, fh_vec_t v);            /* in-place sum over ranks of the owned part (device) */
-int fh_halo_allreduce_sum(fh_halo_t halo, double* vals, int n);  /* host scalars in/out */
+int fh_halo_allreduce_sum(fh_halo_t halo, double* vals, int n);  /* host values in/out, any length */
+int fh_halo_rank(fh_halo_t halo, int* rank, int* nranks);
 int fh_halo_allreduce_mat(fh_halo_t halo, fh_mat_t A);            /* in-place sum over ranks of the values of a matrix with one pattern on all ranks */
 int fh_halo_destroy(fh_halo_t halo);
 
