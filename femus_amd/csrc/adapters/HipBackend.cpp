@@ -88,7 +88,7 @@ void HipVector::attach_halo(fh_halo_t halo) {
     if (r < rank) first += sizes[r];
     total += sizes[r];
   }
-  if ((int)total != _n_global) {
+  if (nranks > 1 && (int)total != _n_global) {      // (a one-rank plan may be a self exchange standing in for absent neighbours)
     std::cout << "HipVector::attach_halo: the owned sizes of the ranks add up to " << (long)total << ", the vector has " << _n_global << std::endl;
     abort();
   }

@@ -66,3 +66,14 @@ def test_navier_stokes_application_over_the_adapters(tmp_path):
     sol = np.fromfile(out)
     assert sol.size == sols[-1].size
     assert np.linalg.norm(sol - sols[-1]) <= 1e-8 * np.linalg.norm(sols[-1])
+
+
+def test_hipvector_on_two_ranks_over_the_host_transport(tmp_path):
+    """ownership offsets, global indices, ghost refresh, localize_to_all and the global reductions with two processes"""
+    lib = os.path.join(ROOT, "femus_amd", "lib")
+    exe = str(tmp_path / "adapter_two_ranks")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "femus_amd", "csrc", "adapters")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["g++", "-O1", "-std=c++17"] + INC + [os.path.join(ROOT, "tests", "cpp", "adapter_two_ranks.cpp"), "-o", exe,
+                           "-L" + lib, "-lfemus_hip_adapters", "-lfemus_hip", "-Wl,-rpath," + lib])
+    out = subprocess.run([exe], text=True, capture_output=True, timeout=120)
+    assert "TWO RANKS OK" in out.stdout, out.stdout + out.stderr
