@@ -115,6 +115,7 @@ extern "C" int fh_timer_stop(fh_ctx_t c, double* ms) {
 }
 
 extern "C" int fh_set_option(fh_ctx_t c, const char* name, double value) {
+  c->opt_gen++;
   if (!strcmp(name, "spmv_tile")) c->spmv_tile = (int)value;
   else if (!strcmp(name, "spmv_xcd_remap")) c->spmv_xcd_remap = (int)value;
   else if (!strcmp(name, "spmv_kernel")) c->spmv_kernel = (int)value;
@@ -132,8 +133,10 @@ extern "C" int fh_set_option(fh_ctx_t c, const char* name, double value) {
   else if (!strcmp(name, "assemble_sumfac")) c->assemble_sumfac = (int)value;
   else if (!strcmp(name, "gj_mfma")) c->gj_mfma = (int)value;
   else if (!strcmp(name, "gj_symmetric")) c->gj_symmetric = (int)value;
+  else if (!strcmp(name, "gj_outer")) c->gj_outer = (int)value;
   else if (!strcmp(name, "assemble_affine")) c->assemble_affine = (int)value;
   else if (!strcmp(name, "use_graph")) c->use_graph = (int)value;
+  else if (!strcmp(name, "mg_reuse_graph")) c->mg_reuse_graph = (int)value;
   else if (!strcmp(name, "spgemm_slot_map")) c->spgemm_slot_map = (int)value;
   else if (!strcmp(name, "halo_overlap")) c->halo_overlap = (int)value;
   else if (!strcmp(name, "halo_profile")) c->halo_profile = (int)value;

@@ -46,6 +46,7 @@ struct MgLevel {
   fh_halo_t halo = nullptr;
   bool replicated_below = false;
   int ncols = 0;
+  int buf_n = -1;            // size the work vectors were allocated for (kept across preparations)
 };
 
 struct fh_mg_s {
@@ -55,10 +56,12 @@ struct fh_mg_s {
   double* d_ainv = nullptr;   // dense inverse of the coarsest operator, row-major n0 x n0
   double* d_gjwork = nullptr; // panels of the blocked inversion, kept with d_ainv across preparations
   double* d_gjwork2 = nullptr;   // second pivot-inverse buffer (inside d_gjwork)
+  hipEvent_t ev_gj[2] = {nullptr, nullptr};   // two-level sweep: tiles of the next pivot block updated / its inverse ready
   int ainv_n = -1;
   bool setup_done = false;
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
+  uint64_t graph_sig = 0;     // what the captured cycle was recorded for (every pointer, size and option a launch of the cycle carries)
   // Krylov workspace
   std::vector<double*> kv;
   int kv_n = 0;
@@ -695,6 +698,211 @@ __global__ __launch_bounds__(256) void k_gjs_finish(double* __restrict__ D, int 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The symmetric sweep with pivot blocks of 128 (two-level blocking): the rank-32 form above streams the upper block triangle once
+// per 32 pivots (n/32 passes over 97 MB at n = 4913: bound by HBM at 4 flop per byte); with 128 pivots per pass the update carries
+// 16 flop per byte and runs on the matrix cores at their own speed, in a quarter of the passes.  The 128 x 128 pivot block is swept
+// inside ONE workgroup that keeps it in LDS: four inner sweeps of 32 pivots each (the same partial pivoting inside a 32-block as the
+// one-level form, so the same blocks are invertible) -- and it runs on the second stream while the first one still updates the rest
+// of the matrix: right after the row panel of step s the tiles of the NEXT pivot block are updated alone, its inversion starts, and
+// the big update follows.  PT / RT as above with 128 rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int GJ2_NB = 128;
+
+__global__ __launch_bounds__(256) void k_gjs2_gather_panel(const double* __restrict__ D, double* __restrict__ PT, int n, int kb, int nb) {
+  if (blockIdx.y == 0) {            // columns up to the end of the pivot block: t fastest (the entries D[j][kb..] are contiguous)
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int j = (int)(idx / GJ2_NB), t = (int)(idx % GJ2_NB);
+    if (j >= kb + nb || j >= n || t >= nb) return;
+    PT[(size_t)t * n + j] = (j < kb) ? D[(size_t)j * n + kb + t] : D[(size_t)(kb + min(t, j - kb)) * n + kb + max(t, j - kb)];
+  } else {                          // right of the pivot block: j fastest (rows of D)
+    const int w = n - (kb + nb);
+    if (w <= 0) return;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int t = (int)(idx / w), j = kb + nb + (int)(idx % w);
+    if (t >= nb) return;
+    PT[(size_t)t * n + j] = D[(size_t)(kb + t) * n + j];
+  }
+}
+
+// inverse of the pivot block D[kb .. kb+nb)^2 (upper triangle stored, symmetric) -> Dinv[128][128]; one workgroup, the block in LDS
+__global__ __launch_bounds__(256) void k_gjs2_invert(const double* __restrict__ D, double* __restrict__ Dinv, int n, int kb, int nb, int* __restrict__ flag) {
+  extern __shared__ __attribute__((aligned(16))) double gj2_smem[];
+  double* M = gj2_smem;                                                            // [128][128]
+  double (*Pm)[GJ_NB + 1] = reinterpret_cast<double (*)[GJ_NB + 1]>(M + GJ2_NB * GJ2_NB);   // [32][33]
+  double* colk = &Pm[0][0] + GJ_NB * (GJ_NB + 1);
+  int* piv = reinterpret_cast<int*>(colk + GJ_NB);
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < GJ2_NB * GJ2_NB; idx += 256) {
+    const int i = idx >> 7, j = idx & 127;
+    M[idx] = (i < nb && j < nb) ? D[(size_t)(kb + min(i, j)) * n + kb + max(i, j)] : (i == j ? 1.0 : 0.0);     // identity padding: inert
+  }
+  __syncthreads();
+  const int j = tid & 127, ih = tid >> 7;
+  for (int o = 0; o < GJ2_NB; o += GJ_NB) {
+    for (int idx = tid; idx < GJ_NB * GJ_NB; idx += 256) Pm[idx >> 5][idx & 31] = M[(o + (idx >> 5)) * GJ2_NB + o + (idx & 31)];
+    __syncthreads();
+    gj_invert_block(Pm, colk, piv, GJ_NB, tid, flag);      // ends with a barrier
+    // new row panel R = Pinv * (old rows o..o+32) for the columns outside the inner block; thread (j, ih) computes 16 of its 32 values
+    const bool inside = j >= o && j < o + GJ_NB;
+    double old[GJ_NB];
+#pragma unroll
+    for (int t = 0; t < GJ_NB; t++) old[t] = M[(o + t) * GJ2_NB + j];
+    __syncthreads();                                       // every old row is in registers: the rows may be overwritten
+    if (!inside) {
+#pragma unroll 4
+      for (int s = ih * 16; s < ih * 16 + 16; s++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < GJ_NB; t++) acc += Pm[s][t] * old[t];
+        M[(o + s) * GJ2_NB + j] = acc;
+      }
+    }
+    __syncthreads();
+    // A[i][j] -= sum_t A_old[i][o+t] * R[t][j] for i, j outside the inner block (columns o..o+32 still hold the old column panel)
+    if (!inside) {
+      double rp[GJ_NB];
+#pragma unroll
+      for (int t = 0; t < GJ_NB; t++) rp[t] = M[(o + t) * GJ2_NB + j];
+      for (int i = ih * 64; i < ih * 64 + 64; i++) {
+        if (i >= o && i < o + GJ_NB) continue;
+        const double* ci = M + i * GJ2_NB + o;
+        double acc = M[i * GJ2_NB + j];
+#pragma unroll
+        for (int t = 0; t < GJ_NB; t += 2) {
+          const double2 c2 = *reinterpret_cast<const double2*>(ci + t);
+          acc -= c2.x * rp[t];
+          acc -= c2.y * rp[t + 1];
+        }
+        M[i * GJ2_NB + j] = acc;
+      }
+    }
+    __syncthreads();
+    // the new column panel is the transpose of the row panel; -Pinv in the inner block
+    for (int idx = tid; idx < GJ2_NB * GJ_NB; idx += 256) {
+      const int i = idx >> 5, s = idx & 31;
+      M[i * GJ2_NB + o + s] = (i >= o && i < o + GJ_NB) ? -Pm[i - o][s] : M[(o + s) * GJ2_NB + i];
+    }
+    __syncthreads();
+  }
+  // M = -(block)^-1
+  for (int idx = tid; idx < GJ2_NB * GJ2_NB; idx += 256) Dinv[idx] = -M[idx];
+}
+
+// RT = Dinv * PT for the columns outside the pivot block (64 x 64 output tiles on the matrix cores); the matrix gets its new row
+// panel (right of the block) / column panel (above it: the transpose) and -Dinv in the block
+__global__ __launch_bounds__(256) void k_gjs2_row_panel(double* __restrict__ D, const double* __restrict__ Dinv, const double* __restrict__ PT,
+                                                        double* __restrict__ RT, int n, int kb, int nb) {
+  constexpr int LD = 80;
+  __shared__ double As[GJ_KS][LD], Bs[GJ_KS][LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ts = blockIdx.y * 64, tj = blockIdx.x * 64;
+  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+  const int kk = lane >> 4, li = lane & 15;
+  gj_d4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = gj_d4{0.0, 0.0, 0.0, 0.0};
+  for (int t0 = 0; t0 < nb; t0 += GJ_KS) {
+    for (int idx = tid; idx < GJ_KS * 64; idx += 256) {
+      const int k = idx >> 6, cc = idx & 63, t = t0 + k;
+      As[k][cc] = (ts + cc < nb && t < nb) ? Dinv[(size_t)(ts + cc) * GJ2_NB + t] : 0.0;       // A fragment (k, i) = Dinv[i][k]
+      Bs[k][cc] = (tj + cc < n && t < nb) ? PT[(size_t)t * n + tj + cc] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k0 = 0; k0 < GJ_KS; k0 += 4) {
+      const double a0 = As[k0 + kk][wi + li], a1 = As[k0 + kk][wi + 16 + li];
+      const double b0 = Bs[k0 + kk][wj + li], b1 = Bs[k0 + kk][wj + 16 + li];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int s = ts + wi + a * 16 + kk + 4 * r;
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const int j = tj + wj + b * 16 + li;
+        if (s >= nb || j >= n) continue;
+        if (j >= kb && j < kb + nb) {
+          RT[(size_t)s * n + j] = 0.0;
+          if (j - kb >= s) D[(size_t)(kb + s) * n + j] = -Dinv[(size_t)s * GJ2_NB + j - kb];
+        } else {
+          const double v = acc[a][b][r];
+          RT[(size_t)s * n + j] = v;
+          if (j > kb) D[(size_t)(kb + s) * n + j] = v;
+          else D[(size_t)j * n + kb + s] = v;
+        }
+      }
+    }
+}
+
+// upper block triangle: A[i][j] -= sum_t PT[t][i] * RT[t][j] (i, j outside the pivot block), any number of pivot rows.
+// part 0: only the tiles inside [lo, hi) x [lo, hi) (the next pivot block), part 1: all the others
+__global__ __launch_bounds__(256) void k_gjs2_update(double* __restrict__ D, const double* __restrict__ PT, const double* __restrict__ RT, int n,
+                                                     int kb, int nb, int part, int lo, int hi) {
+  const int by = part == 0 ? lo + blockIdx.y : blockIdx.y, bx = part == 0 ? lo + blockIdx.x : blockIdx.x;
+  if (by > bx) return;
+  if (part == 1 && by >= lo && by < hi && bx >= lo && bx < hi) return;
+  constexpr int LD = 80;
+  __shared__ double Cs[GJ_KS][LD], Rs[GJ_KS][LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ti = by * 64, tj = bx * 64;
+  if (ti >= n || tj >= n) return;
+  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+  const int kk = lane >> 4, li = lane & 15;
+  gj_d4 acc[2][2];
+  bool live[2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int i = ti + wi + a * 16 + kk + 4 * r;
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const int j = tj + wj + b * 16 + li;
+        live[a][r][b] = i < n && j < n && !(i >= kb && i < kb + nb) && !(j >= kb && j < kb + nb);
+        acc[a][b][r] = live[a][r][b] ? D[(size_t)i * n + j] : 0.0;
+      }
+    }
+  for (int t0 = 0; t0 < nb; t0 += GJ_KS) {
+    for (int idx = tid; idx < GJ_KS * 64; idx += 256) {
+      const int k = idx >> 6, c = idx & 63, t = t0 + k;
+      Cs[k][c] = (ti + c < n && t < nb) ? -PT[(size_t)t * n + ti + c] : 0.0;
+      Rs[k][c] = (tj + c < n && t < nb) ? RT[(size_t)t * n + tj + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k0 = 0; k0 < GJ_KS; k0 += 4) {
+      const double a0 = Cs[k0 + kk][wi + li], a1 = Cs[k0 + kk][wi + 16 + li];
+      const double b0 = Rs[k0 + kk][wj + li], b1 = Rs[k0 + kk][wj + 16 + li];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int i = ti + wi + a * 16 + kk + 4 * r;
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const int j = tj + wj + b * 16 + li;
+        if (live[a][r][b]) D[(size_t)i * n + j] = acc[a][b][r];
+      }
+    }
+}
+
 // pivot columns of all other rows: A[i, kb+t] <- - sum_s Cp[i,s] * Dinv[s,t]
 __global__ __launch_bounds__(256) void k_gjb_col_panel(double* __restrict__ D, const double* __restrict__ Dinv, const double* __restrict__ Cp,
                                                        int n, int kb, int nb) {
@@ -823,6 +1031,58 @@ static void free_level_buffers(MgLevel& L) {
       hipFree(*p);
       *p = nullptr;
     }
+  L.buf_n = -1;
+}
+
+// everything a launch of the captured cycle carries: a repeated preparation of the same hierarchy (MGsolve prepares before every
+// solve, LinearImplicitSystem.cpp:347-383) finds the same pointers, sizes and options and replays the graph it already has
+static uint64_t cycle_signature(fh_mg_t mg) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](uint64_t v) {
+    for (int k = 0; k < 8; k++) {
+      h ^= (v >> (8 * k)) & 0xff;
+      h *= 1099511628211ull;
+    }
+  };
+  auto mixp = [&](const void* p) { mix((uint64_t)(uintptr_t)p); };
+  auto mixm = [&](fh_mat_t M) {
+    mixp(M);
+    if (M) {
+      mix(M->uid);
+      mixp(M->d_val);
+      mixp(M->d_blkinfo);
+      mixp(M->d_rowblk);
+      mix((uint64_t)M->nblk);
+      mix((uint64_t)M->tile);
+      mix((uint64_t)M->lx_tile);
+    }
+  };
+  mix((uint64_t)mg->nlevels);
+  mix((uint64_t)mg->ctx->opt_gen);
+  mixp(mg->d_ainv);
+  for (int l = 0; l < mg->nlevels; l++) {
+    MgLevel& L = mg->lv[l];
+    mixm(L.A);
+    mixm(L.P);
+    mixm(L.R);
+    mix((uint64_t)L.smoother);
+    mix((uint64_t)L.npre);
+    mix((uint64_t)L.npost);
+    uint64_t ob;
+    memcpy(&ob, &L.omega, 8);
+    mix(ob);
+    mix((uint64_t)L.n);
+    mix((uint64_t)L.ncols);
+    for (double* p : {L.dinv, L.x, L.x2, L.b, L.r}) mixp(p);
+    mixp(L.tri);
+    mixp(L.d_color_rows);
+    mix((uint64_t)L.ncolors);
+    mixp(L.d_pinv);
+    mixp(L.d_porder);
+    mix((uint64_t)L.vanka_ncolors);
+    mixp(L.halo);
+  }
+  return h ? h : 1;
 }
 
 static void free_level_colors(MgLevel& L) {
@@ -971,8 +1231,9 @@ static int coarse_factor(fh_mg_t mg) {
     mg->d_ainv = nullptr;
     mg->d_gjwork = nullptr;
     FH_CHECK_HIP(hipMalloc(&mg->d_ainv, (size_t)n * n * sizeof(double)));
-    FH_CHECK_HIP(hipMalloc(&mg->d_gjwork, ((size_t)2 * n * GJ_NB + 2 * GJ_NB * GJ_NB + 8) * sizeof(double)));
-    mg->d_gjwork2 = mg->d_gjwork + (size_t)2 * n * GJ_NB + GJ_NB * GJ_NB + 8;
+    // panels: 2 x n x 128 (the two-level symmetric sweep; the one-level forms use the first 2 x n x 32), then the pivot inverses
+    FH_CHECK_HIP(hipMalloc(&mg->d_gjwork, ((size_t)2 * n * GJ2_NB + 2 * GJ2_NB * GJ2_NB + 2 * GJ_NB * GJ_NB + 16) * sizeof(double)));
+    mg->d_gjwork2 = mg->d_gjwork + (size_t)2 * n * GJ2_NB + 2 * GJ2_NB * GJ2_NB + GJ_NB * GJ_NB + 8;
     mg->ainv_n = n;
   }
   FH_CHECK_HIP(hipMemsetAsync(mg->d_ainv, 0, (size_t)n * n * sizeof(double), c->stream));
@@ -980,7 +1241,7 @@ static int coarse_factor(fh_mg_t mg) {
   double* colk = mg->d_gjwork;   // column panel (n x NB), its transpose / the row panel, pivot inverse (NB x NB), flag
   double* Cp = colk;
   double* CpT = colk + (size_t)n * GJ_NB;
-  double* Dinv = colk + (size_t)2 * n * GJ_NB;
+  double* Dinv = colk + (size_t)2 * n * GJ2_NB + 2 * GJ2_NB * GJ2_NB;
   const int nt = fh_div_up(n, 64);
   int* d_flag = reinterpret_cast<int*>(Dinv + GJ_NB * GJ_NB);   // [0] unsymmetric, [1] bit 0: singular pivot block, bit 1: non-finite inverse
   FH_CHECK_HIP(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), c->stream));
@@ -1003,6 +1264,41 @@ static int coarse_factor(fh_mg_t mg) {
     hipLaunchKernelGGL(k_csr_symmetry, dim3(fh_div_up(n, 4)), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, n, 1e-12, d_flag);
     FH_CHECK_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (h_flag == 0 && c->gj_outer >= GJ2_NB && n > 2 * GJ2_NB) {
+      // two-level blocking: pivot blocks of 128, the next block inverted on the second stream during the big update
+      double *PT = colk, *RT = colk + (size_t)n * GJ2_NB;
+      double* DinvO[2] = {colk + (size_t)2 * n * GJ2_NB, colk + (size_t)2 * n * GJ2_NB + GJ2_NB * GJ2_NB};
+      constexpr size_t lds = (size_t)(GJ2_NB * GJ2_NB + GJ_NB * (GJ_NB + 1) + GJ_NB) * sizeof(double) + GJ_NB * sizeof(int);
+      static bool attr_set[64] = {};
+      if (!attr_set[c->device & 63]) {
+        FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gjs2_invert), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[c->device & 63] = true;
+      }
+      if (!mg->ev_gj[0])
+        for (int k = 0; k < 2; k++) FH_CHECK_HIP(hipEventCreateWithFlags(&mg->ev_gj[k], hipEventDisableTiming));
+      hipStream_t s1 = c->stream, s2 = c->comm_stream;
+      hipLaunchKernelGGL(k_gjs2_invert, dim3(1), dim3(256), lds, s1, mg->d_ainv, DinvO[0], n, 0, std::min(GJ2_NB, n), d_flag + 1);
+      for (int kb = 0, step = 0; kb < n; kb += GJ2_NB, step++) {
+        const int nb = std::min(GJ2_NB, n - kb);
+        const int kb_next = kb + GJ2_NB, nb_next = std::max(0, std::min(GJ2_NB, n - kb_next));
+        const int64_t left = (int64_t)std::min(n, kb + nb) * GJ2_NB, right = (int64_t)nb * std::max(0, n - kb - nb);
+        hipLaunchKernelGGL(k_gjs2_gather_panel, dim3(fh_div_up(std::max(left, right), 256), 2), dim3(256), 0, s1, mg->d_ainv, PT, n, kb, nb);
+        if (step > 0) FH_CHECK_HIP(hipStreamWaitEvent(s1, mg->ev_gj[1], 0));      // the inverse of this pivot block (second stream)
+        hipLaunchKernelGGL(k_gjs2_row_panel, dim3(nt, fh_div_up(nb, 64)), dim3(256), 0, s1, mg->d_ainv, DinvO[step & 1], PT, RT, n, kb, nb);
+        const int lo = kb_next / 64, hi = lo + fh_div_up(std::max(nb_next, 1), 64);
+        if (nb_next > 0) {
+          hipLaunchKernelGGL(k_gjs2_update, dim3(hi - lo, hi - lo), dim3(256), 0, s1, mg->d_ainv, PT, RT, n, kb, nb, 0, lo, hi);
+          FH_CHECK_HIP(hipEventRecord(mg->ev_gj[0], s1));
+          FH_CHECK_HIP(hipStreamWaitEvent(s2, mg->ev_gj[0], 0));
+          hipLaunchKernelGGL(k_gjs2_invert, dim3(1), dim3(256), lds, s2, mg->d_ainv, DinvO[(step + 1) & 1], n, kb_next, nb_next, d_flag + 1);
+          FH_CHECK_HIP(hipEventRecord(mg->ev_gj[1], s2));
+        }
+        hipLaunchKernelGGL(k_gjs2_update, dim3(nt, nt), dim3(256), 0, s1, mg->d_ainv, PT, RT, n, kb, nb, 1, nb_next > 0 ? lo : nt, nb_next > 0 ? hi : nt);
+      }
+      hipLaunchKernelGGL(k_gjs_finish, dim3(nt, nt), dim3(256), 0, s1, mg->d_ainv, n);
+      FH_CHECK_HIP(hipGetLastError());
+      return finish();
+    }
     if (h_flag == 0) {
       double *PT = Cp, *RT = CpT;
       double* Dinv2[2] = {Dinv, mg->d_gjwork2};          // pivot inverse of this step / of the next one (look-ahead)
@@ -1094,23 +1390,17 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
   for (int l = 1; l < mg->nlevels; l++)
     FH_REQUIRE(mg->lv[l].P->n == mg->lv[l - 1].ncols, "fh_mg_setup: interpolation of level %d has %d columns, level %d has %d local entries", l,
                mg->lv[l].P->n, l - 1, mg->lv[l - 1].ncols);
-  if (mg->gexec) {
-    hipGraphExecDestroy(mg->gexec);
-    mg->gexec = nullptr;
-  }
-  if (mg->graph) {
-    hipGraphDestroy(mg->graph);
-    mg->graph = nullptr;
-  }
   mg->cycle_bytes = 0;
   for (int l = 0; l < mg->nlevels; l++) {
     MgLevel& L = mg->lv[l];
-    free_level_buffers(L);
     const size_t nb = ((size_t)L.ncols + 2) * sizeof(double);
-    for (double** p : {&L.dinv, &L.x, &L.x2, &L.b, &L.r}) {
-      FH_CHECK_HIP(hipMalloc(p, nb));
-      FH_CHECK_HIP(hipMemsetAsync(*p, (c->debug_poison && p != &L.dinv) ? 0xFF : 0, nb, c->stream));
+    if (L.buf_n != L.ncols) {      // a repeated preparation keeps its work vectors (and with them the captured cycle)
+      free_level_buffers(L);
+      for (double** p : {&L.dinv, &L.x, &L.x2, &L.b, &L.r}) FH_CHECK_HIP(hipMalloc(p, nb));
+      L.buf_n = L.ncols;
     }
+    for (double** p : {&L.dinv, &L.x, &L.x2, &L.b, &L.r})
+      FH_CHECK_HIP(hipMemsetAsync(*p, (c->debug_poison && p != &L.dinv) ? 0xFF : 0, nb, c->stream));
     FH_TRY(fh_dev_get_diag(L.A, L.dinv, 1));
     if (L.smoother == FH_SMOOTH_GS_COLOR && l > 0 && L.ncolors == 0) FH_TRY(color_rows(L));
     if ((L.smoother == FH_SMOOTH_SOR || L.smoother == FH_SMOOTH_ILU0) && l > 0) {
@@ -1141,12 +1431,23 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
   FH_TRY(coarse_factor(mg));
   mg->cycle_bytes += 8ll * mg->lv[0].n * mg->lv[0].n + 16ll * mg->lv[0].n;
   mg->setup_done = true;
+  const bool capturable = !distributed;
+  const uint64_t sig = cycle_signature(mg);
+  if (mg->gexec && mg->graph_sig == sig && c->use_graph && capturable && c->mg_reuse_graph) return 0;   // same launches: the graph stays
+  if (mg->gexec) {
+    hipGraphExecDestroy(mg->gexec);
+    mg->gexec = nullptr;
+  }
+  if (mg->graph) {
+    hipGraphDestroy(mg->graph);
+    mg->graph = nullptr;
+  }
+  mg->graph_sig = 0;
   FH_TRY(run_cycle(mg));   // un-captured warm-up: builds lazily created row blocks, validates the launches
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
   // distributed cycles are NOT captured: stream capture of the grouped ncclSend/ncclRecv (forked communication stream) was tried on
   // this stack (RCCL 2.26.6 of the PyTorch wheel, one-rank self exchange) and segfaults inside the library at capture time; the
   // launches of a distributed cycle are issued one by one
-  const bool capturable = !distributed;
   if (c->use_graph && capturable) {
     // capture one cycle on the internal buffers and keep it for replay
     FH_CHECK_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -1155,6 +1456,7 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
     if (rc) return rc;
     FH_CHECK_HIP(e);
     FH_CHECK_HIP(hipGraphInstantiate(&mg->gexec, mg->graph, nullptr, nullptr, 0));
+    mg->graph_sig = cycle_signature(mg);      // after the warm-up: lazily built row blocks exist now
   }
   return 0;
   FH_GUARD_END("fh_mg_setup")
@@ -1294,6 +1596,8 @@ extern "C" int fh_mg_destroy(fh_mg_t mg) {
   }
   if (mg->d_ainv) hipFree(mg->d_ainv);
   if (mg->d_gjwork) hipFree(mg->d_gjwork);
+  for (hipEvent_t e : mg->ev_gj)
+    if (e) hipEventDestroy(e);
   for (double* p : mg->kv) hipFree(p);
   if (mg->d_V) hipFree(mg->d_V);
   delete mg;

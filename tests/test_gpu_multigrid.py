@@ -77,6 +77,65 @@ def test_coarse_inverse_variants(ctx, box, sym, mfma):
         ctx.set_option("gj_mfma", 1)
 
 
+def test_two_level_sweep_equals_the_one_level_sweep(ctx):
+    """pivot blocks of 128 swept in LDS with the next block inverted on the second stream (default) against the rank-32 form"""
+    H = fo.build_poisson_hierarchy(5, 4, 3, 1, "biquadratic", ONE)
+    n = H.A[0].shape[0]
+    rhs = fo.lcg_fill(n, 5)
+    out = {}
+    try:
+        for outer in (128, 0):
+            ctx.set_option("gj_outer", outer)
+            mg, mats = device_hierarchy(ctx, H)
+            b, x = ctx.vector_from(rhs), ctx.vector(n)
+            mg.vcycle(b, x)
+            out[outer] = x.to_numpy().copy()
+            # a second preparation of the same object reuses the buffers and gives the same bits
+            mg.setup()
+            mg.vcycle(b, x)
+            assert np.array_equal(x.to_numpy(), out[outer])
+            mg.destroy()
+    finally:
+        ctx.set_option("gj_outer", 128)
+    ref = spla.spsolve(H.A[0].tocsc(), rhs)
+    assert rel(out[128], ref) < 1e-11 and rel(out[0], ref) < 1e-11
+    assert rel(out[128], out[0]) < 1e-12
+
+
+@pytest.mark.parametrize("reuse", [1, 0])
+def test_repeated_setup_with_new_values_keeps_or_rebuilds_the_captured_cycle(ctx, H3, reuse):
+    """MGsolve prepares before every solve: a second fh_mg_setup of the same hierarchy replays the cycle it captured the first time
+    (same pointers, sizes, options) on the NEW operator values.  All level operators times 4: every sweep, the residual and the exact
+    coarse solve scale by a power of two, so the cycle output is exactly a quarter."""
+    ctx.set_option("mg_reuse_graph", reuse)
+    try:
+        mg, mats = device_hierarchy(ctx, H3)
+        n = H3.A[-1].shape[0]
+        rhs = fo.lcg_fill(n, 9)
+        b, x = ctx.vector_from(rhs), ctx.vector(n)
+        mg.vcycle(b, x)
+        first = x.to_numpy().copy()
+        assert rel(first, fo.vcycle(H3, len(H3.A) - 1, rhs)) < 1e-11
+        for l in range(len(H3.A)):
+            mats[2 * l].set_values(4.0 * H3.A[l].tocsr().data)
+        mg.setup()
+        mg.vcycle(b, x)
+        assert np.array_equal(4.0 * x.to_numpy(), first)
+        # a changed smoother count is a different cycle: the graph must not be reused
+        mg.set_level(len(H3.A) - 1, mats[-2], mats[-1], None, 0, 2. / 3., 1, 1)
+        mg.setup()
+        mg.vcycle(b, x)
+        top = len(H3.A) - 1
+        At, dinv = H3.A[top], fo.jacobi_dinv(H3.A[top])
+        xr = fo.smooth(At, dinv, rhs, np.zeros(n), 2. / 3., 1, True)
+        xr = xr + H3.P[top] @ fo.vcycle(H3, top - 1, H3.P[top].T @ (rhs - At @ xr))
+        xr = fo.smooth(At, dinv, rhs, xr, 2. / 3., 1, False)
+        assert rel(4.0 * x.to_numpy(), xr) < 1e-11
+        mg.destroy()
+    finally:
+        ctx.set_option("mg_reuse_graph", 1)
+
+
 @pytest.mark.parametrize("outer", ["richardson", "gmres", "cg"])
 def test_outer_solvers_reach_direct_solution(ctx, H3, outer):
     mg, mats = device_hierarchy(ctx, H3)
@@ -179,12 +238,12 @@ def _one_level(ctx, M):
     return mg, A
 
 
+@pytest.mark.parametrize("n", [150, 402])
 @pytest.mark.parametrize("symmetric", [True, False])
-def test_coarse_inverse_of_an_indefinite_operator_with_zero_diagonal(ctx, symmetric):
+def test_coarse_inverse_of_an_indefinite_operator_with_zero_diagonal(ctx, symmetric, n):
     """saddle-point shape: zero diagonal entries, indefinite -- the pivot blocks are inverted with partial pivoting (the reference
     factors level 0 with a pivoted LU, LinearEquationSolverPetsc.hpp:131-134)"""
     rng = np.random.default_rng(4)
-    n = 150
     M = np.zeros((n, n))
     for k in range(0, n, 2):                      # 2 x 2 blocks [[0, 1], [1, 0]]: every diagonal entry is zero
         M[k, k + 1] = M[k + 1, k] = 1.0 + 0.1 * rng.uniform()
@@ -420,10 +479,11 @@ def test_multicolour_sweep_on_an_unsymmetric_pattern_is_race_free(ctx):
     mg.destroy()
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 33, 63, 64, 65, 97, 257, 1000])
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 33, 63, 64, 65, 97, 256, 257, 384, 511, 769, 1000])
 @pytest.mark.parametrize("kind", ["spd", "general", "permuted"])
 def test_coarse_inverse_random_sizes(ctx, n, kind):
-    """the blocked dense inverse of level 0 for sizes around the 32-wide pivot block: symmetric positive definite (the symmetric
+    """the blocked dense inverse of level 0 for sizes around the 32-wide pivot block and -- above 256 unknowns, symmetric operators --
+    around the 128-wide outer block of the two-level sweep: symmetric positive definite (the symmetric
     sweep), a general dense matrix (Gauss-Jordan), and one whose pivot blocks need row exchanges (zero diagonal inside the blocks);
     sparse form = dense pattern"""
     rng = np.random.default_rng(n * 7 + len(kind))
