@@ -40,11 +40,39 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, the environment torchrun would give
+    them) and pass rank 0's line through.  More ranks than devices is an error, never a silent 1-GPU run."""
+    import socket
+    import subprocess
+    import femus_amd
+    ndev = femus_amd.device_count()
+    share = os.environ.get("FEMUS_BENCH_SHARE_GPU") == "1"
+    if ndev < args.gpus and not share:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d HIP device(s) visible\n" % (args.gpus, ndev))
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    sys.exit(0 if all(rc == 0 for rc in rcs) else 1)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s)\n" % (args.gpus, world))
+        sys.exit(2)
 
     import numpy as np
     import femus_amd
@@ -55,8 +83,7 @@ def main():
     comm = dd.SocketComm(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")))
     device = local_rank
     if os.environ.get("FEMUS_BENCH_SHARE_GPU") == "1":       # several ranks on one device (development box; host transport only)
-        import torch
-        device = local_rank % max(torch.cuda.device_count(), 1)
+        device = local_rank % max(femus_amd.device_count(), 1)
     ctx = femus_amd.Context(device)
     t0 = time.time()
     parallelism = "1 rank per GPU"
@@ -64,11 +91,13 @@ def main():
     pb = None
     if (world > 1 and os.environ.get("FEMUS_BENCH_DD", "1") != "0") or os.environ.get("FEMUS_BENCH_FORCE_DD") == "1":
         # transports in order of preference: "rccl" (neighbour send/recv over xGMI), then -- when the RCCL preflight fails or hangs on
-        # this machine, or when asked for -- "gloo" (the same plans and kernels, ghost bytes staged through pinned host buffers and
-        # exchanged by torch.distributed point-to-point messages): still ONE distributed problem with ghost exchange, only slower;
-        # "host" = the same through the setup sockets (development).  Independent problems are the last resort and say so.
+        # this machine, or when asked for -- "host" (the same plans and kernels, ghost bytes staged through pinned host buffers and
+        # exchanged over the setup sockets): still ONE distributed problem with ghost exchange, only slower.  torch is never imported
+        # into this process: its wheel bundles its own RCCL / HIP runtime, and two runtimes next to /opt/rocm/lib/librccl.so.1 in one
+        # process are a hang waiting to happen ("gloo" = the host transport over torch.distributed stays available on request, for a
+        # launcher whose only fabric is gloo).  Independent problems are the last resort and say so.
         want = os.environ.get("FEMUS_BENCH_TRANSPORT", "rccl")
-        order = {"rccl": ["rccl", "gloo"], "gloo": ["gloo"], "host": ["host"]}.get(want, [want])
+        order = {"rccl": ["rccl", "host"], "gloo": ["gloo"], "host": ["host"]}.get(want, [want])
         for transport in order:
             try:
                 halo_comm = None
@@ -85,7 +114,7 @@ def main():
                 pb = dd.DistributedPoisson(ctx, comm, world, rank, nb=args.coarse, nlevels=args.levels, omega=2. / 3., npre=2, npost=2,
                                            transport="rccl" if transport == "rccl" else "host", halo_comm=halo_comm)
                 how = {"rccl": "RCCL neighbour send/recv", "gloo": "the host-staged transport over torch.distributed (gloo)",
-                       "host": "the host-staged transport"}[transport]
+                       "host": "the host-staged transport over TCP sockets"}[transport]
                 parallelism = ("mesh domain decomposition, box split %dx%dx%d (METIS unavailable), one partition per GPU, ghost DOFs "
                                "exchanged by %s (fh_halo_begin/end, overlapped with the interior rows), the two coarsest levels replicated (all-reduce instead of exchanges)"
                                % (dd.GRIDS[world] + (how,)))
@@ -100,6 +129,7 @@ def main():
             if all(oks):
                 break
             if pb is not None:
+                pb.destroy()       # communicator, exchange plans and the whole hierarchy of the failed attempt
                 pb = None
             dist_err = err_here or "the distributed setup failed on another rank"
     ok = comm.allgather_obj(pb is not None or world == 1)
@@ -180,7 +210,20 @@ def main():
     for _ in range(reps):
         pb.vcycle()
     cyc_ms = comm.allreduce_max(ctx.timer_stop() / reps)
+    # host time to ISSUE one cycle (no synchronisation inside): on one GPU one hipGraphLaunch, on several ranks ~60 launches + the RCCL
+    # groups one by one (a distributed cycle is not captured) -- if this exceeds vcycle_ms the host is the bound
+    barrier()
+    t_issue = time.perf_counter()
+    for _ in range(reps):
+        pb.vcycle()
+    host_issue_ms = comm.allreduce_max((time.perf_counter() - t_issue) / reps * 1e3)
+    barrier()
     halo_info = halo_report(ctx, comm, pb) if getattr(pb, "halos", None) else None
+    if halo_info is not None:
+        halo_info["host_issue_ms_per_cycle"] = host_issue_ms
+    # ---- the reference's whole MGsolve (LinearImplicitSystem.cpp:288-411): assemble, prepare (Galerkin chain, SetPenalty, smoother and
+    # coarse setup), then the multigrid-preconditioned GMRES down to 1e-10 -- a second headline next to the per-step value
+    solve = solve_report(ctx, comm, pb)
     # dominant V-cycle kernel: fine-level fused Jacobi sweep (same kernel family as y=Ax / residual)
     n, ncols = A.m(), A.n()
     ghost_ids = np.arange(n, ncols, dtype=np.int32)
@@ -238,6 +281,10 @@ def main():
         "vcycle_spmv_GBps": spmv_bytes / spmv_ms / 1e6,
         "vcycle_spmv_pct_hbm_peak": spmv_bytes / spmv_ms / 1e6 / HBM_PEAK_GBPS * 100.0,
         "prepare_ms": pb.prepare_ms,
+        "solve_ms": solve["solve_ms"],
+        "solve": solve,
+        "vcycle_host_issue_ms": host_issue_ms,
+        "runtime_libraries": femus_amd.loaded_runtimes(),
         "prepare_first_s": pb.prepare_first_s,
         "setup_s": setup_s,
         "roofline": {
@@ -293,11 +340,15 @@ def main():
         out["halo"] = halo_info
 
     # ---- CPU baseline: the oracle's C restatement on the host cores (rank 0, N = 1 only) ------------------------
-    if rank == 0 and world == 1 and not args.no_live_traffic and os.environ.get("FEMUS_BENCH_LIVE_TRAFFIC", "1") != "0":
+    if rank == 0 and not args.no_live_traffic and os.environ.get("FEMUS_BENCH_LIVE_TRAFFIC", "1") != "0":
         # roofline.traffic from hardware counters of THIS run (two short child runs under rocprofv3 --pmc); when that is not possible the
         # values of the committed counter passes stay in place and `traffic_source` says so
-        live, how = live_traffic(args.coarse, args.levels)
+        # (N > 1: the probe runs on rank 0's device while the other ranks wait at the last barrier; it is the one-GPU problem of the same
+        # local size -- the owned-rows operator of a rank has the same row blocks plus its ghost columns)
+        live, how = live_traffic(args.coarse, args.levels, device=device)
         if live is not None:
+            if world > 1:
+                how += "; one-GPU problem of the same local size on rank 0's device"
             out["roofline"]["traffic"] = live["spmv"]
             out["roofline"]["traffic_source"] = how
             out["roofline_assembly"]["traffic"] = live["elem"]
@@ -307,8 +358,24 @@ def main():
             out["roofline"]["traffic_source"] = "committed counter passes (%s); live measurement skipped: %s" % (TRAFFIC["spmv"]["source"], how)
     elif world == 1:
         out["roofline"]["traffic_source"] = "committed counter passes (%s)" % TRAFFIC["spmv"]["source"]
+    # cpu_baseline is measured on rank 0 at N = 1 only; that run leaves its object in a file on this host and the N > 1 lines of the
+    # same box (the driver runs N = 1, 2, 4, 8 back to back) carry it by reference -- per-GPU work is the same at every N
+    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "femus_amd_cpu_baseline.json")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pb.pb, ndof, nel)
+        try:
+            json.dump({"workload": out["config"]["workload"], "when": time.time(), "cpu_baseline": out["cpu_baseline"]}, open(cache, "w"))
+        except OSError:
+            pass
+    elif rank == 0 and world > 1 and not args.no_cpu_baseline:
+        try:
+            c = json.load(open(cache))
+            if c["workload"] == out["config"]["workload"]:
+                cb = dict(c["cpu_baseline"])
+                cb["by_reference"] = "measured by the N=1 run of this bench on this host %.0f s earlier (one GPU's share of the weak-scaled problem)" % (time.time() - c["when"])
+                out["cpu_baseline"] = cb
+        except (OSError, ValueError, KeyError):
+            out["cpu_baseline"] = None
 
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -322,9 +389,11 @@ def halo_report(ctx, comm, pb):
     compute stream really waits for (exposed); the rest is hidden behind the row blocks that read no ghost"""
     for h in pb.halos:
         h.stats(reset=True)
+        h.allreduce_count(reset=True)
     pb.vcycle()
     ctx.sync()
     st = [h.stats(reset=True) for h in pb.halos]
+    n_allreduce = sum(h.allreduce_count(reset=True) for h in pb.halos)
     ncyc = 3
     ctx.set_option("halo_profile", 1)
     for _ in range(ncyc):
@@ -340,7 +409,7 @@ def halo_report(ctx, comm, pb):
         "exchanges_per_cycle": int(sum(s["updates"] for s in st)),
         "exchanges_per_cycle_by_level": [int(s["updates"]) for s in st],
         "bytes_sent_per_cycle_this_rank": int(sum(s["bytes_sent"] for s in st)),
-        "allreduces_per_cycle": 1,
+        "allreduces_per_cycle": int(n_allreduce),
         "exchange_ms_per_cycle": ex,
         "exposed_ms_per_cycle": xp,
         "hidden_ms_per_cycle": max(ex - xp, 0.0),
@@ -348,6 +417,32 @@ def halo_report(ctx, comm, pb):
         "overlap": "rows without ghost columns are multiplied on the compute stream while the exchange runs on the communication "
                    "stream (fh_spmv_ghosted); times are maxima over ranks from HIP events, measured with per-exchange synchronisation",
     }
+
+
+def solve_report(ctx, comm, pb):
+    """assemble + prepare + GMRES(V(2,2)) to 1e-10 relative residual, wall clock with a synchronisation at both ends, and its parts"""
+    def timed(fn):
+        ctx.sync()
+        comm.barrier()
+        t = time.perf_counter()
+        r = fn()
+        ctx.sync()
+        return comm.allreduce_max((time.perf_counter() - t) * 1e3), r
+
+    def whole():
+        pb.assemble()
+        pb.prepare()
+        return pb.solve(rtol=1e-10)
+
+    whole()                                          # warm: Krylov workspace, graph
+    t_all, (its, rnorm) = timed(whole)
+    t_asm, _ = timed(pb.assemble)
+    t_prep, _ = timed(pb.prepare)
+    t_kry, (its2, _) = timed(lambda: pb.solve(rtol=1e-10))
+    return {"solve_ms": t_all, "assemble_ms": t_asm, "prepare_ms": t_prep, "krylov_ms": t_kry, "gmres_iterations": int(its),
+            "final_residual": float(rnorm), "rtol": 1e-10,
+            "what": "one MGsolve of the reference (LinearImplicitSystem.cpp:288-411): fine-level assembly, numeric Galerkin chain + SetPenalty + "
+                    "smoother / exact coarse factorisation, then GMRES preconditioned by one V(2,2) cycle per iteration from a zero guess"}
 
 
 class SerialProblem:
@@ -387,6 +482,13 @@ class SerialProblem:
     def vcycle(self):
         self.pb.vcycle()
 
+    def prepare(self):
+        self.pb.prepare()
+
+    def solve(self, rtol=1e-10):
+        self.pb.EPS.zero()
+        return self.pb.mgsolve(outer="gmres", rtol=rtol)
+
 
 def _newest_profile(suffix):
     """the committed PMC result of the newest round: profiles/rNN*_<suffix>; (parsed json, 'file sha256:...') or (None, None)"""
@@ -399,7 +501,7 @@ def _newest_profile(suffix):
     return json.loads(raw), "%s sha256:%s" % (os.path.relpath(files[-1], ROOT), hashlib.sha256(raw).hexdigest()[:16])
 
 
-def live_traffic(coarse, levels, timeout=150):
+def live_traffic(coarse, levels, timeout=150, device=0):
     """HBM bytes per launch of the roofline kernels MEASURED IN THIS RUN: femus_amd/traffic_probe.py (the bench problem, the same kernels)
     under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and again under `--pmc WRITE_SIZE` (one counter per pass, no other trace domain, as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes), child processes of rank 0 after the timed region.  Units and correction as in
@@ -421,7 +523,8 @@ def live_traffic(coarse, levels, timeout=150):
         try:
             r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                                 os.path.join(ROOT, "femus_amd", "traffic_probe.py"), str(coarse), str(levels)],
-                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout)
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", FEMUS_HIP_DEVICE=str(device)), capture_output=True, text=True,
+                               timeout=timeout)
             if "TRAFFIC PROBE DONE" not in r.stdout:
                 return None, "the %s pass failed (exit %d)" % (counter, r.returncode)
             per = {}

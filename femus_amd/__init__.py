@@ -8,3 +8,26 @@ compute call needs the built library and a HIP device.
 """
 from ._lib import load_library, library_path, LibraryMissing  # noqa: F401
 from .capi import Context, Vec, Mat, Mesh, Assembler, Multigrid, Halo, FemusHipError  # noqa: F401
+
+
+def device_count():
+    """HIP devices visible to this process (0 without a driver): launchers size themselves with it"""
+    import ctypes
+    n = ctypes.c_int(0)
+    load_library().fh_device_count(ctypes.byref(n))
+    return n.value
+
+
+def loaded_runtimes():
+    """which HIP runtime and which RCCL this process has mapped (paths from /proc/self/maps): the first multi-GPU run reports them"""
+    out = {}
+    try:
+        for line in open("/proc/self/maps"):
+            path = line.split()[-1]
+            base = path.rsplit("/", 1)[-1]
+            for key in ("libamdhip64", "librccl"):
+                if base.startswith(key):
+                    out.setdefault(key, set()).add(path)
+    except OSError:
+        pass
+    return {k: sorted(v) for k, v in out.items()}

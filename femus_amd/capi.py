@@ -928,6 +928,11 @@ class Halo:
         _chk(self.L.fh_halo_stats(self.h, int(bool(reset)), ctypes.byref(n), ctypes.byref(b), ctypes.byref(tx), ctypes.byref(te)))
         return {"updates": n.value, "bytes_sent": b.value, "exchange_ms": tx.value, "exposed_ms": te.value}
 
+    def allreduce_count(self, reset=False):
+        n = ctypes.c_int64()
+        _chk(self.L.fh_halo_allreduce_count(self.h, int(bool(reset)), ctypes.byref(n)))
+        return n.value
+
     def allreduce_mat(self, A):
         """in-place sum over the ranks of the values of a matrix that has the same pattern on every rank"""
         _chk(self.L.fh_halo_allreduce_mat(self.h, A.h))

@@ -43,6 +43,14 @@ void fh_trace_print(const char* fmt, ...) {
 }
 extern "C" const char* fh_version(void) { return "femus_hip 0.1 (gfx950)"; }
 
+extern "C" int fh_device_count(int* n) {
+  FH_REQUIRE(n, "fh_device_count: null output");
+  int ndev = 0;
+  const hipError_t e = hipGetDeviceCount(&ndev);
+  *n = (e == hipSuccess) ? ndev : 0;
+  return 0;
+}
+
 extern "C" int fh_init(int device, fh_ctx_t* out) {
   FH_REQUIRE(out != nullptr, "fh_init: null output");
   int ndev = 0;
@@ -133,7 +141,6 @@ extern "C" int fh_set_option(fh_ctx_t c, const char* name, double value) {
   else if (!strcmp(name, "assemble_sumfac")) c->assemble_sumfac = (int)value;
   else if (!strcmp(name, "gj_mfma")) c->gj_mfma = (int)value;
   else if (!strcmp(name, "gj_symmetric")) c->gj_symmetric = (int)value;
-  else if (!strcmp(name, "gj_outer")) c->gj_outer = (int)value;
   else if (!strcmp(name, "assemble_affine")) c->assemble_affine = (int)value;
   else if (!strcmp(name, "use_graph")) c->use_graph = (int)value;
   else if (!strcmp(name, "mg_reuse_graph")) c->mg_reuse_graph = (int)value;

@@ -80,19 +80,29 @@ extern "C" int fh_dd_plan_create(int rank, int nranks, int n, const int64_t* gid
     std::vector<int> srt(P->owned.size());
     std::iota(srt.begin(), srt.end(), 0);
     std::sort(srt.begin(), srt.end(), [&](int a, int b) { return gid[P->owned[a]] < gid[P->owned[b]]; });
-    P->send_idx.resize(tot);
+    P->send_idx.assign(tot, 0);
+    // a rank that cannot serve a request does not leave here -- the others would wait for it in the next exchange: it goes on with
+    // the size exchange, where a negative size tells every rank, and all of them return the error together
+    long long bad_gid = 0;
+    bool bad = false;
     for (int k = 0; k < tot; k++) {
       const int64_t g = got[k];
       auto it = std::lower_bound(srt.begin(), srt.end(), g, [&](int a, int64_t v) { return gid[P->owned[a]] < v; });
-      FH_REQUIRE(it != srt.end() && gid[P->owned[*it]] == g, "fh_dd_plan_create: a requested node (global id %lld) is not owned by rank %d", (long long)g, rank);
+      if (it == srt.end() || gid[P->owned[*it]] != g) {
+        if (!bad) bad_gid = (long long)g;
+        bad = true;
+        continue;
+      }
       P->send_idx[k] = *it;                                      // position among the owned entries = index into the owned part of a vector
     }
     // global numbering: owned counts of all ranks (one more exchange of one number per pair), then every owner tells the requesters
     // the GLOBAL index (offset + position) of the nodes they asked for -- the reverse of the request exchange
     std::vector<int> ones(nranks, 1), got1(nranks, 0);
-    std::vector<int64_t> mine(nranks, (int64_t)P->owned.size()), theirs(nranks, 0);
+    std::vector<int64_t> mine(nranks, bad ? (int64_t)-1 : (int64_t)P->owned.size()), theirs(nranks, 0);
     FH_REQUIRE(alltoallv(user, nullptr, ones.data(), nullptr, got1.data()) == 0, "fh_dd_plan_create: the count exchange failed");
     FH_REQUIRE(alltoallv(user, mine.data(), ones.data(), theirs.data(), got1.data()) == 0, "fh_dd_plan_create: the size exchange failed");
+    FH_REQUIRE(!bad, "fh_dd_plan_create: a requested node (global id %lld) is not owned by rank %d", bad_gid, rank);
+    for (int r = 0; r < nranks; r++) FH_REQUIRE(theirs[r] >= 0, "fh_dd_plan_create: rank %d could not serve a ghost request (inconsistent ownership map)", r);
     P->offsets.assign(nranks + 1, 0);
     for (int r = 0; r < nranks; r++) P->offsets[r + 1] = P->offsets[r] + theirs[r];
     std::vector<int64_t> reply(std::max(tot, 1));

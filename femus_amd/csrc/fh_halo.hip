@@ -27,7 +27,7 @@ struct fh_halo_s {
   bool pending = false;
   // statistics (fh_halo_stats): exchanges started, payload sent; with the context option "halo_profile" also the duration of the
   // exchanges (pack done -> ghosts landed) and the part of it the compute stream really waited for (exposed)
-  int64_t n_updates = 0, bytes_sent = 0;
+  int64_t n_updates = 0, bytes_sent = 0, n_allreduce = 0;
   double exchange_ms = 0.0, exposed_ms = 0.0;
   hipEvent_t evt_begin = nullptr, evt_ready = nullptr;
   // host-staged transport (fh_halo_create_host): the exchange itself is the caller's function (MPI_Neighbor_alltoallv, sockets ...)
@@ -175,6 +175,7 @@ static int host_allreduce(fh_halo_t h, double* d, int n) {
 extern "C" int fh_halo_allreduce_vec(fh_halo_t h, fh_vec_t v) {
   FH_REQUIRE(h && v, "fh_halo_allreduce_vec: null argument");
   if (halo_inert(h) || v->n_local == 0) return 0;
+  h->n_allreduce++;
   if (h->allreduce) return host_allreduce(h, v->d, v->n_local);
   FH_CHECK_NCCL(ncclAllReduce(v->d, v->d, v->n_local, ncclDouble, ncclSum, h->comm, h->ctx->stream));
   return 0;
@@ -185,6 +186,7 @@ extern "C" int fh_halo_allreduce_vec(fh_halo_t h, fh_vec_t v) {
 extern "C" int fh_halo_allreduce_mat(fh_halo_t h, fh_mat_t A) {
   FH_REQUIRE(h && A, "fh_halo_allreduce_mat: null argument");
   if (halo_inert(h) || A->nnz == 0) return 0;
+  h->n_allreduce++;
   A->at_valid = false;
   if (h->allreduce) return host_allreduce(h, A->d_val, A->nnz);
   FH_CHECK_NCCL(ncclAllReduce(A->d_val, A->d_val, A->nnz, ncclDouble, ncclSum, h->comm, h->ctx->stream));
@@ -193,6 +195,7 @@ extern "C" int fh_halo_allreduce_mat(fh_halo_t h, fh_mat_t A) {
 
 int fh_halo_allreduce_ptr(fh_halo_t h, double* d, int n) {
   if (halo_inert(h) || n == 0) return 0;
+  h->n_allreduce++;
   if (h->allreduce) return host_allreduce(h, d, n);
   FH_CHECK_NCCL(ncclAllReduce(d, d, n, ncclDouble, ncclSum, h->comm, h->ctx->stream));
   return 0;
@@ -294,7 +297,13 @@ int fh_dev_halo_spmv(fh_halo_t h, fh_mat_t A, double* x, int n_own, double* y, i
     return fh_dev_spmv(A, x, y, mode, b, dinv, omega);
   }
   FH_TRY(fh_halo_begin_ptr(h, x, n_own, prepacked));
-  FH_TRY(fh_dev_spmv_part(A, n_own, 0, x, y, mode, b, dinv, omega));
+  const int rc = fh_dev_spmv_part(A, n_own, 0, x, y, mode, b, dinv, omega);
+  if (rc) {                       // the exchange in flight is completed all the same: a plan left pending would refuse every later exchange
+    std::string msg = fh_last_error();
+    fh_halo_end_ptr(h);
+    fh_set_error("%s", msg.c_str());
+    return rc;
+  }
   FH_TRY(fh_halo_end_ptr(h));
   return fh_dev_spmv_part(A, n_own, 1, x, y, mode, b, dinv, omega);
 }
@@ -321,6 +330,13 @@ extern "C" int fh_halo_end(fh_halo_t h) {
   return fh_halo_end_ptr(h);
 }
 
+extern "C" int fh_halo_allreduce_count(fh_halo_t h, int reset, int64_t* n) {
+  FH_REQUIRE(h, "fh_halo_allreduce_count: null argument");
+  if (n) *n = h->n_allreduce;
+  if (reset) h->n_allreduce = 0;
+  return 0;
+}
+
 extern "C" int fh_halo_stats(fh_halo_t h, int reset, int64_t* n_updates, int64_t* bytes_sent, double* exchange_ms, double* exposed_ms) {
   FH_REQUIRE(h, "fh_halo_stats: null argument");
   if (n_updates) *n_updates = h->n_updates;
@@ -337,6 +353,7 @@ extern "C" int fh_halo_stats(fh_halo_t h, int reset, int64_t* n_updates, int64_t
 extern "C" int fh_halo_allreduce_sum(fh_halo_t h, double* vals, int n) {
   FH_REQUIRE(h && vals && n >= 0, "fh_halo_allreduce_sum: bad arguments");
   if (halo_inert(h) || n == 0) return 0;
+  h->n_allreduce++;
   if (h->allreduce) {
     FH_REQUIRE(h->allreduce(h->user, vals, n) == 0, "host transport: the all-reduce function failed");
     return 0;

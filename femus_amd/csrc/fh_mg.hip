@@ -56,7 +56,6 @@ struct fh_mg_s {
   double* d_ainv = nullptr;   // dense inverse of the coarsest operator, row-major n0 x n0
   double* d_gjwork = nullptr; // panels of the blocked inversion, kept with d_ainv across preparations
   double* d_gjwork2 = nullptr;   // second pivot-inverse buffer (inside d_gjwork)
-  hipEvent_t ev_gj[2] = {nullptr, nullptr};   // two-level sweep: tiles of the next pivot block updated / its inverse ready
   int ainv_n = -1;
   bool setup_done = false;
   hipGraph_t graph = nullptr;
@@ -698,433 +697,6 @@ __global__ __launch_bounds__(256) void k_gjs_finish(double* __restrict__ D, int 
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// The symmetric sweep with pivot blocks of 128 (two-level blocking): the rank-32 form above streams the upper block triangle once
-// per 32 pivots (n/32 passes over 97 MB at n = 4913: bound by HBM at 4 flop per byte); with 128 pivots per pass the update carries
-// 16 flop per byte and runs on the matrix cores at their own speed, in a quarter of the passes.  The 128 x 128 pivot block is swept
-// inside ONE workgroup that keeps it in LDS: four inner sweeps of 32 pivots each (the same partial pivoting inside a 32-block as the
-// one-level form, so the same blocks are invertible) -- and it runs on the second stream while the first one still updates the rest
-// of the matrix: right after the row panel of step s the tiles of the NEXT pivot block are updated alone, its inversion starts, and
-// the big update follows.  PT / RT as above with 128 rows.
-// ------------------------------------------------------------------------------------------------
-constexpr int GJ2_NB = 128;
-
-__global__ __launch_bounds__(256) void k_gjs2_gather_panel(const double* __restrict__ D, double* __restrict__ PT, int n, int kb, int nb) {
-  if (blockIdx.y == 0) {            // columns up to the end of the pivot block: t fastest (the entries D[j][kb..] are contiguous)
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int j = (int)(idx / GJ2_NB), t = (int)(idx % GJ2_NB);
-    if (j >= kb + nb || j >= n || t >= nb) return;
-    PT[(size_t)t * n + j] = (j < kb) ? D[(size_t)j * n + kb + t] : D[(size_t)(kb + min(t, j - kb)) * n + kb + max(t, j - kb)];
-  } else {                          // right of the pivot block: j fastest (rows of D)
-    const int w = n - (kb + nb);
-    if (w <= 0) return;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int t = (int)(idx / w), j = kb + nb + (int)(idx % w);
-    if (t >= nb) return;
-    PT[(size_t)t * n + j] = D[(size_t)(kb + t) * n + j];
-  }
-}
-
-// 32 x 32 inverse by ONE wave, the matrix in registers: lane (h, r) holds the columns 16 h .. 16 h + 15 of row r.  Gauss-Jordan with
-// partial pivoting as gj_invert_block, but rows are never moved: the pivot row of step k stays in its lane and remembers k, and the
-// permutation is undone when the result is written (A^-1[a][b] = R[p_a][q_b]: the explicit-swap algorithm inverts P A, whose inverse
-// is A^-1 P^T).  No workgroup barrier: what the lanes exchange (column k, the pivot row) goes through three small LDS arrays that
-// every lane reads whole -- two LDS round trips per step instead of a chain of cross-lane permutes (measured: 33 us with
-// ds_bpermute reductions, 49 us with five workgroup barriers per step).
-// In: Pm (LDS, row stride 33).  Out: the inverse in Pm.  pk: 32 ints, xch: 96 doubles of LDS.
-__device__ __forceinline__ void gj_wave_sync() {        // LDS writes of this wave before, LDS reads of this wave after
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-__device__ __forceinline__ void gj_invert32_wave(double (*Pm)[GJ_NB + 1], int* pk, double* xch, int lane, int* flag) {
-  const int r = lane & 31, h = lane >> 5;
-  double m[16];
-#pragma unroll
-  for (int c = 0; c < 16; c++) m[c] = Pm[r][16 * h + c];
-  double* colv = xch;            // [32] column k of every row (-0 for rows already used: excluded from the pivot search by its own flag)
-  double* usedv = xch + 32;      // [32] 1.0 = row already used as a pivot
-  double* prow = xch + 64;       // [32] the pivot row
-  int mystep = -1;
-  bool bad = false;
-  if (h == 0) usedv[r] = 0.0;
-  gj_wave_sync();                                    // (also orders the loads of m[] before the final stores into Pm)
-#pragma unroll
-  for (int k = 0; k < GJ_NB; k++) {
-    const int hk = k >> 4, ck = k & 15;
-    if (h == hk) colv[r] = m[ck];
-    gj_wave_sync();
-    // pivot: the unused row with the largest |M[row][k]| (smallest row on ties) -- every lane scans the 32 candidates itself
-    double best = -1.0;
-    int p = 0;
-#pragma unroll
-    for (int i = 0; i < GJ_NB; i += 2) {
-      const double2 cv = *reinterpret_cast<const double2*>(colv + i), uv = *reinterpret_cast<const double2*>(usedv + i);
-      const double a0 = uv.x != 0.0 ? -1.0 : fabs(cv.x), a1 = uv.y != 0.0 ? -1.0 : fabs(cv.y);
-      if (a0 > best) { best = a0; p = i; }
-      if (a1 > best) { best = a1; p = i + 1; }
-    }
-    p = __builtin_amdgcn_readfirstlane(p);
-    bad |= !(best > 1e-300);
-    const bool isp = (r == p);
-    if (isp) {
-#pragma unroll
-      for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2*>(prow + 16 * h + c) = make_double2(m[c], m[c + 1]);
-      if (h == 0) usedv[r] = 1.0;
-      mystep = k;
-    }
-    gj_wave_sync();
-    const double pinv = 1.0 / colv[p];
-    const double f = colv[r] * pinv;                 // multiplier of this lane's row
-#pragma unroll
-    for (int c = 0; c < 16; c += 2) {
-      const double2 pr = *reinterpret_cast<const double2*>(prow + 16 * h + c);
-      m[c] = isp ? pr.x * pinv : m[c] - f * pr.x;
-      m[c + 1] = isp ? pr.y * pinv : m[c + 1] - f * pr.y;
-    }
-    if (h == hk) m[ck] = isp ? pinv : -f;
-    gj_wave_sync();                                  // the exchange arrays are rewritten by the next step
-  }
-  if (bad && lane == 0) atomicOr(flag, 1);
-  if (h == 0) pk[mystep] = r;                       // p_k: the physical row that was the pivot of step k
-  gj_wave_sync();
-#pragma unroll
-  for (int c = 0; c < 16; c++) Pm[mystep][pk[16 * h + c]] = m[c];
-}
-
-// inverse of the pivot block D[kb .. kb+nb)^2 (upper triangle stored, symmetric) -> Dinv[128][128]; one workgroup, the block in LDS:
-// four inner sweeps of 32 pivots: wave 0 inverts the 32 x 32 pivot, then all waves form the new row panel and the rank-32 update of
-// the 128 x 128 block as register-tiled products (8 x 8 outputs per thread)
-constexpr int GJ2_LD = GJ2_NB + 2;       // LDS row stride of the pivot block: 16 bytes of padding shift consecutive rows by four banks
-constexpr size_t GJ2_INV_LDS = (size_t)(GJ2_NB * GJ2_LD + GJ_NB * (GJ_NB + 1) + 96) * sizeof(double) + GJ_NB * sizeof(int);
-__global__ __launch_bounds__(256) void k_gjs2_invert(const double* __restrict__ D, double* __restrict__ Dinv, int n, int kb, int nb, int* __restrict__ flag,
-                                                     long long* __restrict__ dbg) {
-  extern __shared__ __attribute__((aligned(16))) double gj2_smem[];
-  long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long t_prev = clock64();
-#define GJ2_TICK(k) do { if (dbg) { const long long t_now = clock64(); tk[k] += t_now - t_prev; t_prev = t_now; } } while (0)
-  double* M = gj2_smem;                                                            // [128][130]
-  double (*Pm)[GJ_NB + 1] = reinterpret_cast<double (*)[GJ_NB + 1]>(M + GJ2_NB * GJ2_LD);   // [32][33]
-  double* xch = &Pm[0][0] + GJ_NB * (GJ_NB + 1);
-  int* pk = reinterpret_cast<int*>(xch + 96);
-  const int tid = threadIdx.x;
-  // rows of the stored upper triangle, coalesced, 16 loads in flight per thread; the lower part is mirrored inside LDS
-  for (int i0 = 0; i0 < GJ2_NB; i0 += 32) {
-    double v[16];
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int i = i0 + 2 * u + (tid >> 7), j = tid & 127;
-      v[u] = (i < nb && j < nb) ? (j >= i ? D[(size_t)(kb + i) * n + kb + j] : 0.0) : (i == j ? 1.0 : 0.0);     // identity padding: inert
-    }
-#pragma unroll
-    for (int u = 0; u < 16; u++) M[(i0 + 2 * u + (tid >> 7)) * GJ2_LD + (tid & 127)] = v[u];
-  }
-  __syncthreads();
-  for (int idx = tid; idx < GJ2_NB * GJ2_NB; idx += 256) {
-    const int i = idx >> 7, j = idx & 127;
-    if (j < i) M[i * GJ2_LD + j] = M[j * GJ2_LD + i];
-  }
-  __syncthreads();
-  GJ2_TICK(0);
-  for (int o = 0; o < GJ2_NB; o += GJ_NB) {
-    for (int idx = tid; idx < GJ_NB * GJ_NB; idx += 256) Pm[idx >> 5][idx & 31] = M[(o + (idx >> 5)) * GJ2_LD + o + (idx & 31)];
-    __syncthreads();
-    GJ2_TICK(1);
-    if (tid < 64) gj_invert32_wave(Pm, pk, xch, tid, flag);
-    __syncthreads();
-    GJ2_TICK(2);
-    // new row panel R = Pinv * (old rows o..o+32): thread (ty, tx) computes rows ty + 8 a, columns 2 tx + 64 q + {0, 1}
-    {
-      const int ty = tid >> 5, tx = tid & 31;
-      double acc[4][4];
-#pragma unroll
-      for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
-#pragma unroll 4
-      for (int t = 0; t < GJ_NB; t++) {
-        const double2 o01 = *reinterpret_cast<const double2*>(M + (o + t) * GJ2_LD + 2 * tx), o23 = *reinterpret_cast<const double2*>(M + (o + t) * GJ2_LD + 2 * tx + 64);
-        const double ov[4] = {o01.x, o01.y, o23.x, o23.y};
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-          const double pv = Pm[ty + 8 * a][t];
-#pragma unroll
-          for (int b = 0; b < 4; b++) acc[a][b] += pv * ov[b];
-        }
-      }
-      __syncthreads();                                     // every old row has been read: the rows may be overwritten
-#pragma unroll
-      for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-          const int j = 2 * tx + 64 * (b >> 1) + (b & 1);
-          if (j < o || j >= o + GJ_NB) M[(o + ty + 8 * a) * GJ2_LD + j] = acc[a][b];
-        }
-    }
-    __syncthreads();
-    GJ2_TICK(3);
-    // A[i][j] -= sum_t A_old[i][o+t] * R[t][j] for i, j outside the inner block (columns o..o+32 still hold the old column panel);
-    // thread (ty, tx): rows ty + 16 a, columns 2 tx + 32 q + {0, 1}: neighbouring lanes read neighbouring 16-byte pieces
-    {
-      const int ty = tid >> 4, tx = tid & 15;
-      double acc[8][8];
-#pragma unroll
-      for (int a = 0; a < 8; a++)
-#pragma unroll
-        for (int b = 0; b < 8; b++) acc[a][b] = 0.0;
-#pragma unroll 2
-      for (int t = 0; t < GJ_NB; t += 2) {
-        double rv[2][8];
-#pragma unroll
-        for (int u = 0; u < 2; u++)
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const double2 w = *reinterpret_cast<const double2*>(M + (o + t + u) * GJ2_LD + 2 * tx + 32 * q);
-            rv[u][2 * q] = w.x;
-            rv[u][2 * q + 1] = w.y;
-          }
-#pragma unroll
-        for (int a = 0; a < 8; a++) {
-          const double2 cv = *reinterpret_cast<const double2*>(M + (ty + 16 * a) * GJ2_LD + o + t);
-#pragma unroll
-          for (int b = 0; b < 8; b++) acc[a][b] += cv.x * rv[0][b] + cv.y * rv[1][b];
-        }
-      }
-      // only entries outside the inner block's rows and columns change; they are read by nobody else in this phase
-#pragma unroll
-      for (int a = 0; a < 8; a++) {
-        const int i = ty + 16 * a;
-        if (i >= o && i < o + GJ_NB) continue;
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-          const int j = 2 * tx + 32 * (b >> 1) + (b & 1);
-          if (j < o || j >= o + GJ_NB) M[i * GJ2_LD + j] -= acc[a][b];
-        }
-      }
-    }
-    __syncthreads();
-    GJ2_TICK(4);
-    // the new column panel is the transpose of the row panel; -Pinv in the inner block
-    for (int idx = tid; idx < GJ2_NB * GJ_NB; idx += 256) {
-      const int i = idx & 127, s2 = idx >> 7;          // i fastest: the reads run along a row
-      M[i * GJ2_LD + o + s2] = (i >= o && i < o + GJ_NB) ? -Pm[i - o][s2] : M[(o + s2) * GJ2_LD + i];
-    }
-    __syncthreads();
-    GJ2_TICK(5);
-  }
-  // M = -(block)^-1
-#pragma unroll 16
-  for (int idx = tid; idx < GJ2_NB * GJ2_NB; idx += 256) Dinv[idx] = -M[(idx >> 7) * GJ2_LD + (idx & 127)];
-  GJ2_TICK(6);
-  if (dbg && tid == 0)
-    for (int k = 0; k < 7; k++) dbg[k] = tk[k];
-#undef GJ2_TICK
-}
-
-// RT = Dinv * PT for the columns outside the pivot block (64 x 64 output tiles on the matrix cores); the matrix gets its new row
-// panel (right of the block) / column panel (above it: the transpose) and -Dinv in the block
-__global__ __launch_bounds__(256) void k_gjs2_row_panel(double* __restrict__ D, const double* __restrict__ Dinv, const double* __restrict__ PT,
-                                                        double* __restrict__ RT, int n, int kb, int nb) {
-  constexpr int LD = 80;
-  __shared__ double As[GJ_KS][LD], Bs[GJ_KS][LD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ts = blockIdx.y * 64, tj = blockIdx.x * 64;
-  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
-  const int kk = lane >> 4, li = lane & 15;
-  gj_d4 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; a++)
-#pragma unroll
-    for (int b = 0; b < 2; b++) acc[a][b] = gj_d4{0.0, 0.0, 0.0, 0.0};
-  for (int t0 = 0; t0 < nb; t0 += GJ_KS) {
-    for (int idx = tid; idx < GJ_KS * 64; idx += 256) {
-      const int k = idx >> 6, cc = idx & 63, t = t0 + k;
-      As[k][cc] = (ts + cc < nb && t < nb) ? Dinv[(size_t)(ts + cc) * GJ2_NB + t] : 0.0;       // A fragment (k, i) = Dinv[i][k]
-      Bs[k][cc] = (tj + cc < n && t < nb) ? PT[(size_t)t * n + tj + cc] : 0.0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k0 = 0; k0 < GJ_KS; k0 += 4) {
-      const double a0 = As[k0 + kk][wi + li], a1 = As[k0 + kk][wi + 16 + li];
-      const double b0 = Bs[k0 + kk][wj + li], b1 = Bs[k0 + kk][wj + 16 + li];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int a = 0; a < 2; a++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int s = ts + wi + a * 16 + kk + 4 * r;
-#pragma unroll
-      for (int b = 0; b < 2; b++) {
-        const int j = tj + wj + b * 16 + li;
-        if (s >= nb || j >= n) continue;
-        if (j >= kb && j < kb + nb) {
-          RT[(size_t)s * n + j] = 0.0;
-          if (j - kb >= s) D[(size_t)(kb + s) * n + j] = -Dinv[(size_t)s * GJ2_NB + j - kb];
-        } else {
-          const double v = acc[a][b][r];
-          RT[(size_t)s * n + j] = v;
-          if (j > kb) D[(size_t)(kb + s) * n + j] = v;
-          else D[(size_t)j * n + kb + s] = v;
-        }
-      }
-    }
-}
-
-// upper block triangle: A[i][j] -= sum_t PT[t][i] * RT[t][j] (i, j outside the pivot block), any number of pivot rows.
-// part 0: only the tiles inside [lo, hi) x [lo, hi) (the next pivot block), part 1: all the others
-__global__ __launch_bounds__(256) void k_gjs2_update(double* __restrict__ D, const double* __restrict__ PT, const double* __restrict__ RT, int n,
-                                                     int kb, int nb, int part, int lo, int hi) {
-  const int by = part == 0 ? lo + blockIdx.y : blockIdx.y, bx = part == 0 ? lo + blockIdx.x : blockIdx.x;
-  if (by > bx) return;
-  if (part == 1 && by >= lo && by < hi && bx >= lo && bx < hi) return;
-  constexpr int LD = 80;
-  __shared__ double Cs[GJ_KS][LD], Rs[GJ_KS][LD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ti = by * 64, tj = bx * 64;
-  if (ti >= n || tj >= n) return;
-  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
-  const int kk = lane >> 4, li = lane & 15;
-  gj_d4 acc[2][2];
-  bool live[2][4][2];
-#pragma unroll
-  for (int a = 0; a < 2; a++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int i = ti + wi + a * 16 + kk + 4 * r;
-#pragma unroll
-      for (int b = 0; b < 2; b++) {
-        const int j = tj + wj + b * 16 + li;
-        live[a][r][b] = i < n && j < n && !(i >= kb && i < kb + nb) && !(j >= kb && j < kb + nb);
-        acc[a][b][r] = live[a][r][b] ? D[(size_t)i * n + j] : 0.0;
-      }
-    }
-  // K slices of 32 through LDS; the next slice travels from HBM into registers while the matrix cores work on the current one
-  double pc[8], pr[8];
-  auto fetch = [&](int t0) {
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int idx = tid + 256 * u, k = idx >> 6, c = idx & 63, t = t0 + k;
-      pc[u] = (ti + c < n && t < nb) ? -PT[(size_t)t * n + ti + c] : 0.0;
-      pr[u] = (tj + c < n && t < nb) ? RT[(size_t)t * n + tj + c] : 0.0;
-    }
-  };
-  fetch(0);
-  for (int t0 = 0; t0 < nb; t0 += GJ_KS) {
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int idx = tid + 256 * u;
-      Cs[idx >> 6][idx & 63] = pc[u];
-      Rs[idx >> 6][idx & 63] = pr[u];
-    }
-    __syncthreads();
-    if (t0 + GJ_KS < nb) fetch(t0 + GJ_KS);
-#pragma unroll
-    for (int k0 = 0; k0 < GJ_KS; k0 += 4) {
-      const double a0 = Cs[k0 + kk][wi + li], a1 = Cs[k0 + kk][wi + 16 + li];
-      const double b0 = Rs[k0 + kk][wj + li], b1 = Rs[k0 + kk][wj + 16 + li];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int a = 0; a < 2; a++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int i = ti + wi + a * 16 + kk + 4 * r;
-#pragma unroll
-      for (int b = 0; b < 2; b++) {
-        const int j = tj + wj + b * 16 + li;
-        if (live[a][r][b]) D[(size_t)i * n + j] = acc[a][b][r];
-      }
-    }
-}
-
-// the same update on 128 x 128 tiles: one workgroup of four waves, 64 x 64 outputs per wave as 4 x 4 matrix-core tiles (every
-// operand fragment read from LDS feeds four MFMAs instead of two, a quarter of the workgroups and barriers).  part 0: the diagonal
-// tile `next` alone (the next pivot block), part 1: all the other tiles of the upper block triangle
-__global__ __launch_bounds__(256) void k_gjs2_update128(double* __restrict__ D, const double* __restrict__ PT, const double* __restrict__ RT, int n,
-                                                        int kb, int nb, int part, int next) {
-  const int by = part == 0 ? next : blockIdx.y, bx = part == 0 ? next : blockIdx.x;
-  if (by > bx) return;
-  if (part == 1 && by == next && bx == next) return;
-  constexpr int LD = 144;
-  extern __shared__ __attribute__((aligned(16))) double gj2_smem[];
-  double (*Cs)[LD] = reinterpret_cast<double (*)[LD]>(gj2_smem);
-  double (*Rs)[LD] = reinterpret_cast<double (*)[LD]>(gj2_smem + GJ_KS * LD);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ti = by * 128, tj = bx * 128;
-  const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
-  const int kk = lane >> 4, li = lane & 15;
-  gj_d4 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int i = ti + wi + a * 16 + kk + 4 * r;
-#pragma unroll
-      for (int b = 0; b < 4; b++) {
-        const int j = tj + wj + b * 16 + li;
-        const bool live = i < n && j < n && !(i >= kb && i < kb + nb) && !(j >= kb && j < kb + nb);
-        acc[a][b][r] = live ? D[(size_t)i * n + j] : 0.0;
-      }
-    }
-  double pc[16], pr[16];
-  auto fetch = [&](int t0) {
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int idx = tid + 256 * u, k = idx >> 7, c = idx & 127, t = t0 + k;
-      pc[u] = (ti + c < n && t < nb) ? -PT[(size_t)t * n + ti + c] : 0.0;
-      pr[u] = (tj + c < n && t < nb) ? RT[(size_t)t * n + tj + c] : 0.0;
-    }
-  };
-  fetch(0);
-  for (int t0 = 0; t0 < nb; t0 += GJ_KS) {
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int idx = tid + 256 * u;
-      Cs[idx >> 7][idx & 127] = pc[u];
-      Rs[idx >> 7][idx & 127] = pr[u];
-    }
-    __syncthreads();
-    if (t0 + GJ_KS < nb) fetch(t0 + GJ_KS);
-#pragma unroll
-    for (int k0 = 0; k0 < GJ_KS; k0 += 4) {
-      double av[4], bv[4];
-#pragma unroll
-      for (int a = 0; a < 4; a++) {
-        av[a] = Cs[k0 + kk][wi + a * 16 + li];
-        bv[a] = Rs[k0 + kk][wj + a * 16 + li];
-      }
-#pragma unroll
-      for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int i = ti + wi + a * 16 + kk + 4 * r;
-#pragma unroll
-      for (int b = 0; b < 4; b++) {
-        const int j = tj + wj + b * 16 + li;
-        const bool live = i < n && j < n && !(i >= kb && i < kb + nb) && !(j >= kb && j < kb + nb);
-        if (live) D[(size_t)i * n + j] = acc[a][b][r];
-      }
-    }
-}
-
 // pivot columns of all other rows: A[i, kb+t] <- - sum_s Cp[i,s] * Dinv[s,t]
 __global__ __launch_bounds__(256) void k_gjb_col_panel(double* __restrict__ D, const double* __restrict__ Dinv, const double* __restrict__ Cp,
                                                        int n, int kb, int nb) {
@@ -1453,9 +1025,8 @@ static int coarse_factor(fh_mg_t mg) {
     mg->d_ainv = nullptr;
     mg->d_gjwork = nullptr;
     FH_CHECK_HIP(hipMalloc(&mg->d_ainv, (size_t)n * n * sizeof(double)));
-    // panels: 2 x n x 128 (the two-level symmetric sweep; the one-level forms use the first 2 x n x 32), then the pivot inverses
-    FH_CHECK_HIP(hipMalloc(&mg->d_gjwork, ((size_t)2 * n * GJ2_NB + 2 * GJ2_NB * GJ2_NB + 2 * GJ_NB * GJ_NB + 16) * sizeof(double)));
-    mg->d_gjwork2 = mg->d_gjwork + (size_t)2 * n * GJ2_NB + 2 * GJ2_NB * GJ2_NB + GJ_NB * GJ_NB + 8;
+    FH_CHECK_HIP(hipMalloc(&mg->d_gjwork, ((size_t)2 * n * GJ_NB + 2 * GJ_NB * GJ_NB + 8) * sizeof(double)));
+    mg->d_gjwork2 = mg->d_gjwork + (size_t)2 * n * GJ_NB + GJ_NB * GJ_NB + 8;
     mg->ainv_n = n;
   }
   FH_CHECK_HIP(hipMemsetAsync(mg->d_ainv, 0, (size_t)n * n * sizeof(double), c->stream));
@@ -1463,7 +1034,7 @@ static int coarse_factor(fh_mg_t mg) {
   double* colk = mg->d_gjwork;   // column panel (n x NB), its transpose / the row panel, pivot inverse (NB x NB), flag
   double* Cp = colk;
   double* CpT = colk + (size_t)n * GJ_NB;
-  double* Dinv = colk + (size_t)2 * n * GJ2_NB + 2 * GJ2_NB * GJ2_NB;
+  double* Dinv = colk + (size_t)2 * n * GJ_NB;
   const int nt = fh_div_up(n, 64);
   int* d_flag = reinterpret_cast<int*>(Dinv + GJ_NB * GJ_NB);   // [0] unsymmetric, [1] bit 0: singular pivot block, bit 1: non-finite inverse
   FH_CHECK_HIP(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), c->stream));
@@ -1486,53 +1057,6 @@ static int coarse_factor(fh_mg_t mg) {
     hipLaunchKernelGGL(k_csr_symmetry, dim3(fh_div_up(n, 4)), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, n, 1e-12, d_flag);
     FH_CHECK_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     FH_CHECK_HIP(hipStreamSynchronize(c->stream));
-    if (h_flag == 0 && c->gj_outer >= GJ2_NB && n > 2 * GJ2_NB) {
-      // two-level blocking: pivot blocks of 128, the next block inverted on the second stream during the big update
-      double *PT = colk, *RT = colk + (size_t)n * GJ2_NB;
-      double* DinvO[2] = {colk + (size_t)2 * n * GJ2_NB, colk + (size_t)2 * n * GJ2_NB + GJ2_NB * GJ2_NB};
-      constexpr size_t lds = GJ2_INV_LDS;
-      constexpr size_t lds_u = (size_t)2 * GJ_KS * 144 * sizeof(double);
-      const int ntb = fh_div_up(n, GJ2_NB);
-      static bool attr_set[64] = {};
-      if (!attr_set[c->device & 63]) {
-        FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gjs2_invert), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gjs2_update128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_u));
-        attr_set[c->device & 63] = true;
-      }
-      if (!mg->ev_gj[0])
-        for (int k = 0; k < 2; k++) FH_CHECK_HIP(hipEventCreateWithFlags(&mg->ev_gj[k], hipEventDisableTiming));
-      hipStream_t s1 = c->stream, s2 = c->comm_stream;
-      long long* d_dbg = nullptr;
-      if (fh_trace_on()) FH_CHECK_HIP(hipMalloc(&d_dbg, 8 * sizeof(long long)));
-      hipLaunchKernelGGL(k_gjs2_invert, dim3(1), dim3(256), lds, s1, mg->d_ainv, DinvO[0], n, 0, std::min(GJ2_NB, n), d_flag + 1, d_dbg);
-      if (d_dbg) {
-        long long h[8];
-        FH_CHECK_HIP(hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost));
-        FH_TRACE("k_gjs2_invert clocks (100 MHz ticks): load %lld  copy %lld  pivot %lld  panel %lld  update %lld  transpose %lld  store %lld", h[0], h[1], h[2],
-                 h[3], h[4], h[5], h[6]);
-        hipFree(d_dbg);
-      }
-      for (int kb = 0, step = 0; kb < n; kb += GJ2_NB, step++) {
-        const int nb = std::min(GJ2_NB, n - kb);
-        const int kb_next = kb + GJ2_NB, nb_next = std::max(0, std::min(GJ2_NB, n - kb_next));
-        const int64_t left = (int64_t)std::min(n, kb + nb) * GJ2_NB, right = (int64_t)nb * std::max(0, n - kb - nb);
-        hipLaunchKernelGGL(k_gjs2_gather_panel, dim3(fh_div_up(std::max(left, right), 256), 2), dim3(256), 0, s1, mg->d_ainv, PT, n, kb, nb);
-        if (step > 0) FH_CHECK_HIP(hipStreamWaitEvent(s1, mg->ev_gj[1], 0));      // the inverse of this pivot block (second stream)
-        hipLaunchKernelGGL(k_gjs2_row_panel, dim3(nt, fh_div_up(nb, 64)), dim3(256), 0, s1, mg->d_ainv, DinvO[step & 1], PT, RT, n, kb, nb);
-        const int next = nb_next > 0 ? kb_next / GJ2_NB : -1;
-        if (nb_next > 0) {
-          hipLaunchKernelGGL(k_gjs2_update128, dim3(1, 1), dim3(256), lds_u, s1, mg->d_ainv, PT, RT, n, kb, nb, 0, next);
-          FH_CHECK_HIP(hipEventRecord(mg->ev_gj[0], s1));
-          FH_CHECK_HIP(hipStreamWaitEvent(s2, mg->ev_gj[0], 0));
-          hipLaunchKernelGGL(k_gjs2_invert, dim3(1), dim3(256), lds, s2, mg->d_ainv, DinvO[(step + 1) & 1], n, kb_next, nb_next, d_flag + 1, (long long*)nullptr);
-          FH_CHECK_HIP(hipEventRecord(mg->ev_gj[1], s2));
-        }
-        hipLaunchKernelGGL(k_gjs2_update128, dim3(ntb, ntb), dim3(256), lds_u, s1, mg->d_ainv, PT, RT, n, kb, nb, 1, next);
-      }
-      hipLaunchKernelGGL(k_gjs_finish, dim3(nt, nt), dim3(256), 0, s1, mg->d_ainv, n);
-      FH_CHECK_HIP(hipGetLastError());
-      return finish();
-    }
     if (h_flag == 0) {
       double *PT = Cp, *RT = CpT;
       double* Dinv2[2] = {Dinv, mg->d_gjwork2};          // pivot inverse of this step / of the next one (look-ahead)
@@ -1830,8 +1354,6 @@ extern "C" int fh_mg_destroy(fh_mg_t mg) {
   }
   if (mg->d_ainv) hipFree(mg->d_ainv);
   if (mg->d_gjwork) hipFree(mg->d_gjwork);
-  for (hipEvent_t e : mg->ev_gj)
-    if (e) hipEventDestroy(e);
   for (double* p : mg->kv) hipFree(p);
   if (mg->d_V) hipFree(mg->d_V);
   delete mg;

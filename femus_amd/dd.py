@@ -732,22 +732,25 @@ class DistributedPoisson:
         all_local = np.concatenate([loc.owned, loc.ghost])
         rows = srt[np.searchsorted(g0_gid[srt], loc.gid[all_local])]
         assert np.all(g0_gid[rows] == loc.gid[all_local])
-        ident = np.arange(n_rep, dtype=np.int32)
-        self.Pg_local, m = Pg.restrict(rows, ident, n_rep)                # (n_owned + n_ghost) x n_rep, [owned | ghost] order
-        m.destroy()
-        self.P_rep, m = Pg.restrict(rows[:loc.n_owned], ident, n_rep)
-        m.destroy()
-        Pg.destroy()
-        self.R_rep = self.P_rep.get_transpose()
-        self.T_rep = capi.Mat.abc(self.R_rep, self.A[0], self.Pg_local)   # plan kept: numeric-only in prepare()
-        rp, col = capi.pattern_from_elements(m_rep.arrays()[0], n_rep)    # stencil pattern of the replicated mesh (same on all ranks)
-        self.A_rep = ctx.matrix_csr(n_rep, n_rep, rp, col)
-        trp, tcol = self.T_rep.pattern()
-        pkey = np.repeat(np.arange(n_rep, dtype=np.int64), np.diff(rp)) * n_rep + col
-        tkey = np.repeat(np.arange(n_rep, dtype=np.int64), np.diff(trp)) * n_rep + tcol
-        pos = np.searchsorted(pkey, tkey)
-        assert np.all(pkey[np.minimum(pos, pkey.size - 1)] == tkey), "replicated coarse operator leaves its stencil pattern"
-        self.map_rep = self.A_rep.value_map(self.T_rep)
+        if self.n_replicated == 1:        # (with two replicated levels this level's operator is the Galerkin product A_rep2 below)
+            ident = np.arange(n_rep, dtype=np.int32)
+            self.Pg_local, m = Pg.restrict(rows, ident, n_rep)                # (n_owned + n_ghost) x n_rep, [owned | ghost] order
+            m.destroy()
+            self.P_rep, m = Pg.restrict(rows[:loc.n_owned], ident, n_rep)
+            m.destroy()
+            Pg.destroy()
+            self.R_rep = self.P_rep.get_transpose()
+            self.T_rep = capi.Mat.abc(self.R_rep, self.A[0], self.Pg_local)   # plan kept: numeric-only in prepare()
+            rp, col = capi.pattern_from_elements(m_rep.arrays()[0], n_rep)    # stencil pattern of the replicated mesh (same on all ranks)
+            self.A_rep = ctx.matrix_csr(n_rep, n_rep, rp, col)
+            trp, tcol = self.T_rep.pattern()
+            pkey = np.repeat(np.arange(n_rep, dtype=np.int64), np.diff(rp)) * n_rep + col
+            tkey = np.repeat(np.arange(n_rep, dtype=np.int64), np.diff(trp)) * n_rep + tcol
+            pos = np.searchsorted(pkey, tkey)
+            assert np.all(pkey[np.minimum(pos, pkey.size - 1)] == tkey), "replicated coarse operator leaves its stencil pattern"
+            self.map_rep = self.A_rep.value_map(self.T_rep)
+        else:
+            Pg.destroy()
         self.bdc_rep = capi.Index(ctx, m_rep.dirichlet_dofs(fe).astype(np.int32))
         if self.n_replicated == 2:
             # the coarsest local level as a replicated global level: its operator is the owned rows of every rank scattered into the global
@@ -800,6 +803,7 @@ class DistributedPoisson:
         self.n_owned, self.n_loc = top.n_owned, ntop
         # vectors in the reference's global numbering: this rank owns [offsets[rank], offsets[rank + 1]), ghosts carry the owners' global
         # indices (NumericVector::init(N, n_local, ghost, fast, GHOSTED); operator()(global index) reaches owned and ghost entries)
+        assert int(top.offsets[-1]) < 2 ** 31, "global dof numbers beyond 32 bits (PetscInt is an int in the reference as well, PetscVector.hpp:536)"
         mk = lambda: ctx.vector(int(top.offsets[-1]), top.n_owned, int(top.offsets[rank]), top.ghost_global.astype(np.int32))
         self.RES, self.EPSC, self.SOL = mk(), mk(), mk()
         self.bdc_top = H.bdc_owned[-1].astype(np.int32)
@@ -869,6 +873,30 @@ class DistributedPoisson:
             self.mapA[l].gather_matrix_values(self.A[l], full.A[l])
         self._replicated_operator()
         self.mg.setup()
+
+    def destroy(self):
+        """every device object of this problem: the cycle, the owned-row operators and their value maps, the extended-box hierarchy, the
+        vectors, and last the exchange plans with their communicator (bench.py drops a problem whose setup failed on another rank)"""
+        seen = set()
+
+        def kill(o):
+            if o is None or id(o) in seen or o is self.comm or o is self.ctx:
+                return
+            seen.add(id(o))
+            if isinstance(o, (list, tuple)):
+                for x in o:
+                    kill(x)
+                return
+            d = getattr(o, "destroy", None)
+            if callable(d):
+                d()
+
+        kill(getattr(self, "mg", None))
+        for name, val in list(vars(self).items()):
+            if name not in ("comm", "ctx", "halos", "mg", "full", "part"):
+                kill(val)
+        kill(getattr(self, "full", None))
+        kill(getattr(self, "halos", None))
 
     def assemble(self):
         if self.adaptive:

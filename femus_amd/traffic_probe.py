@@ -14,7 +14,7 @@ def main():
     from femus_amd.poisson import PoissonMG
     coarse = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     levels = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-    ctx = femus_amd.Context(0)
+    ctx = femus_amd.Context(int(os.environ.get("FEMUS_HIP_DEVICE", "0")))
     pb = PoissonMG(ctx, coarse, coarse, coarse, levels, fe="biquadratic", order="seventh", omega=2. / 3., npre=2, npost=2, coarse="galerkin",
                    source_kind=0, params=(1.0,)).init()
     for _ in range(4):

@@ -38,6 +38,7 @@ typedef struct fh_halo_s* fh_halo_t;
 
 /* ---- context --------------------------------------------------------------------------------
  * replaces FemusInit (src/00_utils/00_application_initialization/FemusInit.cpp:46-74: PetscInitialize) */
+int fh_device_count(int* n);                         /* visible HIP devices (0 when there is none or no driver) */
 int fh_init(int device, fh_ctx_t* ctx);
 int fh_finalize(fh_ctx_t ctx);
 const char* fh_last_error(void);
@@ -384,6 +385,7 @@ int fh_spmv_ghosted(fh_mat_t A, fh_halo_t halo, fh_vec_t x, fh_vec_t y, int mode
  * exchanges in ms (pack finished -> ghosts landed) and the part the compute stream actually waited for (exposed = not hidden
  * behind the rows that need no ghost).  Any pointer may be NULL. */
 int fh_halo_stats(fh_halo_t halo, int reset, int64_t* n_updates, int64_t* bytes_sent, double* exchange_ms, double* exposed_ms);
+int fh_halo_allreduce_count(fh_halo_t halo, int reset, int64_t* n);   /* all-reduces issued through this plan (vectors, matrices, host scalars) */
 int fh_halo_sizes(fh_halo_t halo, int* nsend, int* nrecv);
 int fh_halo_allreduce_vec(fh_halo_t halo, fh_vec_t v);            /* in-place sum over ranks of the owned part (device) */
 int fh_halo_allreduce_sum(fh_halo_t halo, double* vals, int n);  /* host values in/out, any length */

@@ -246,6 +246,42 @@ def test_bench_contract_with_two_ranks_sharing_the_gpu(tmp_path, transport):
     h = d["halo"]     # 3 local levels, the coarsest of them replicated, V(2,2): 0 + 5 + 5 exchanges per cycle, some of the exchange time hidden or not
     assert h["exchanges_per_cycle"] == 10 and h["exchanges_per_cycle_by_level"] == [0, 5, 5] and h["bytes_sent_per_cycle_this_rank"] > 0
     assert h["exchange_ms_per_cycle"] > 0 and 0 <= h["exposed_ms_per_cycle"] <= h["exchange_ms_per_cycle"]
+    # a gradeable N > 1 line: the host time to issue a cycle, the measured number of all-reduces (restriction into the replicated level +
+    # none for the dots of a plain cycle), the roofline object of the rank's own sweep kernel, and the solve headline
+    assert h["host_issue_ms_per_cycle"] > 0 and h["allreduces_per_cycle"] >= 1
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["avg_launch_ms"] > 0
+    assert d["solve_ms"] > 0 and d["solve"]["gmres_iterations"] >= 1 and d["solve"]["final_residual"] < 1e-6
+    assert d["runtime_libraries"].get("libamdhip64") and len(d["runtime_libraries"]["libamdhip64"]) == 1       # ONE HIP runtime in the process
+
+
+def test_bench_spawns_its_own_ranks_and_never_reports_fewer(tmp_path):
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (here sharing the GPU; the RCCL preflight refuses two ranks
+    on one device, so the line must say it fell back to the host-staged transport over the setup sockets -- torch.distributed is not
+    initialised anywhere in that chain); the N = 1 run before it leaves its cpu_baseline for the N = 2 line to carry by reference; more
+    ranks than devices without the sharing switch is an error, not an n_gpus = 1 line"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    small = ["--steps", "2", "--warmup", "1", "--coarse", "2", "--levels", "3", "--kernel-reps", "3", "--no-live-traffic"]
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    env.pop("WORLD_SIZE", None)
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + small, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert d1["n_gpus"] == 1 and d1["cpu_baseline"]["cores"] >= 1 and d1["solve"]["gmres_iterations"] >= 1
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + small, env=dict(env, FEMUS_BENCH_SHARE_GPU="1"), cwd=root,
+                         capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+    d2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert d2["n_gpus"] == 2 and d2["config"]["dofs_total"] == 33 * 17 * 17
+    par = d2["config"]["parallelism"]
+    assert "fell back from rccl" in par and "TCP sockets" in par and "gloo" not in par
+    assert d2["cpu_baseline"]["by_reference"] and d2["cpu_baseline"]["value"] == d1["cpu_baseline"]["value"]
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"] + small, env=env, cwd=root, capture_output=True, text=True,
+                         timeout=300)
+    assert bad.returncode != 0 and "{" not in bad.stdout and "64" in bad.stderr
 
 
 # ---- adaptive levels on several ranks (BASELINE config "MGAMR, 2 levels of AMR, 8 GPUs"), ranks sharing the one GPU -------------

@@ -77,31 +77,6 @@ def test_coarse_inverse_variants(ctx, box, sym, mfma):
         ctx.set_option("gj_mfma", 1)
 
 
-def test_two_level_sweep_equals_the_one_level_sweep(ctx):
-    """pivot blocks of 128 swept in LDS with the next block inverted on the second stream (default) against the rank-32 form"""
-    H = fo.build_poisson_hierarchy(5, 4, 3, 1, "biquadratic", ONE)
-    n = H.A[0].shape[0]
-    rhs = fo.lcg_fill(n, 5)
-    out = {}
-    try:
-        for outer in (128, 0):
-            ctx.set_option("gj_outer", outer)
-            mg, mats = device_hierarchy(ctx, H)
-            b, x = ctx.vector_from(rhs), ctx.vector(n)
-            mg.vcycle(b, x)
-            out[outer] = x.to_numpy().copy()
-            # a second preparation of the same object reuses the buffers and gives the same bits
-            mg.setup()
-            mg.vcycle(b, x)
-            assert np.array_equal(x.to_numpy(), out[outer])
-            mg.destroy()
-    finally:
-        ctx.set_option("gj_outer", 128)
-    ref = spla.spsolve(H.A[0].tocsc(), rhs)
-    assert rel(out[128], ref) < 1e-11 and rel(out[0], ref) < 1e-11
-    assert rel(out[128], out[0]) < 1e-12
-
-
 @pytest.mark.parametrize("reuse", [1, 0])
 def test_repeated_setup_with_new_values_keeps_or_rebuilds_the_captured_cycle(ctx, H3, reuse):
     """MGsolve prepares before every solve: a second fh_mg_setup of the same hierarchy replays the cycle it captured the first time
@@ -482,8 +457,7 @@ def test_multicolour_sweep_on_an_unsymmetric_pattern_is_race_free(ctx):
 @pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 33, 63, 64, 65, 97, 256, 257, 384, 511, 769, 1000])
 @pytest.mark.parametrize("kind", ["spd", "general", "permuted"])
 def test_coarse_inverse_random_sizes(ctx, n, kind):
-    """the blocked dense inverse of level 0 for sizes around the 32-wide pivot block and -- above 256 unknowns, symmetric operators --
-    around the 128-wide outer block of the two-level sweep: symmetric positive definite (the symmetric
+    """the blocked dense inverse of level 0 for sizes around the 32-wide pivot block: symmetric positive definite (the symmetric
     sweep), a general dense matrix (Gauss-Jordan), and one whose pivot blocks need row exchanges (zero diagonal inside the blocks);
     sparse form = dense pattern"""
     rng = np.random.default_rng(n * 7 + len(kind))
