@@ -375,7 +375,7 @@ def main():
                 cb["by_reference"] = "measured by the N=1 run of this bench on this host %.0f s earlier (one GPU's share of the weak-scaled problem)" % (time.time() - c["when"])
                 out["cpu_baseline"] = cb
         except (OSError, ValueError, KeyError):
-            out["cpu_baseline"] = None
+            pass                                   # no N=1 run on this host before this one: the line carries no cpu_baseline
 
     if rank == 0:
         print(json.dumps(out), flush=True)

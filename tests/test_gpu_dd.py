@@ -231,7 +231,7 @@ def test_bench_contract_with_two_ranks_sharing_the_gpu(tmp_path, transport):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FEMUS_BENCH_TRANSPORT=transport, FEMUS_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, FEMUS_BENCH_TRANSPORT=transport, FEMUS_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", TMPDIR=str(tmp_path))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--coarse", "2", "--levels", "3", "--kernel-reps", "3"]
