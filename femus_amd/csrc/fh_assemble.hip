@@ -20,6 +20,8 @@
 #include "fh_expr_device.h"
 #include <algorithm>
 
+struct SfTab { double L[3][4], D[3][4]; };   // l_a(x_k), l'_a(x_k): 1-D quadratic Lagrange basis (nodes -1, 0, +1) at the four abscissae
+
 struct fh_assembler_s {
   fh_ctx_t ctx = nullptr;
   int geom = 0, fe = 0, order = 0, dim = 3, nc = 27, ng = 64, nloc = 27;
@@ -55,6 +57,10 @@ struct fh_assembler_s {
   double *d_mfT = nullptr, *d_mfPhi = nullptr;
   double* d_mfSFc = nullptr;     // sum-factorised map Jacobian: per-lane 1-D shape values [18][64] (null: tables are not tensor products)
   int* d_mfSFi = nullptr;        // ... and per-lane LDS offsets [7][64]
+  // sum-factorised element kernel (k_elem_q2hex_sf): 1-D basis values (uniform operands) and the per-lane tables
+  SfTab sf_tab;
+  double* d_sfLc = nullptr;      // [SF_NLC][64]
+  int* d_sfLi = nullptr;         // [SF_NLI][64]
   // source term given as a compiled expression (fh_expr): device copy of the program of the expression last used
   int* d_prog = nullptr;
   double* d_prog_consts = nullptr;
@@ -1178,6 +1184,369 @@ static int launch_mfma(fh_assembler_t as, const AsmParams& P, int nw) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// HEX27 / Q2 element matrices by SUM FACTORISATION (default for the 64-point rule when the tables are tensor products, which
+// fh_assembler_create verifies against the reference's tables): ONE element per wave, vector FP64 only.
+//   phi_i = l_a(xi) l_b(eta) l_c(zeta), Gauss point q = (q1, q2, q3), D_q = w_q det J (J^-1)(J^-1)^T in reference directions, so
+//   K[(a,b,c),(a',b',c')] = sum_q1 sum_{X1,X2 in {l, l'}} X1_a(q1) X2_a'(q1) G_{X1X2}[bb'][cc'][q1]
+//   G_{l'l'} = sum_q2 (l_b l_b')  e0                      e0 = sum_q3 D00 l_c l_c'      e1 = sum_q3 D01 l_c l_c'
+//   G_{l'l}  = sum_q2 (l_b l'_b') e1 + (l_b l_b') e2      e2 = sum_q3 D02 l_c l'_c'     e3 = sum_q3 D11 l_c l_c'
+//   G_{ll'}  = sum_q2 (l'_b l_b') e1 + (l_b l_b') e2^T    e4 = sum_q3 D12 l_c l'_c'     e5 = sum_q3 D22 l'_c l'_c'
+//   G_{ll}   = sum_q2 (l'_b l'_b') e3 + (l'_b l_b') e4 + (l_b l'_b') e4^T + (l_b l_b') e5          (^T: c and c' exchanged)
+// i.e. the i/j/Gauss loop of `00_poisson_eqn_..._separate.hpp:170-200` (27 x 27 x 64 x 3 x 3 products) contracted one direction
+// at a time: about 100 + 144 + 120 vector FMAs per lane instead of 336 matrix instructions of 16 cycles + 252 FMAs (same result
+// up to the order of the floating-point sums; parity tests at 1e-12).
+//   phase A   map Jacobian by sum factorisation (as in k_elem_q2hex_mfma; here the Gauss points sit on the lanes in tensor order
+//             q1*16 + q2*4 + q3), cofactors, D_q, source value -> Dq[7][64]
+//   stage 1   lane = (q1, q2, c): contracts q3 -> e[6][c c'][q1 q2] (and the source: sE[c][q1 q2])
+//   stage 2   lane = unordered pair {(b,c), (b',c')} (45 of the 64 lanes): contracts q2 -> 16 values G in registers
+//   stage 3   same lane: contracts q1 -> the 3 x 3 block over (a, a'), mirrored into the 27 x 29 staging (K_e symmetric bit for
+//             bit: blocks off the diagonal pair are written twice, the six upper entries of a diagonal pair are mirrored)
+//   source    f_i = sum_q phi_i s_q by the same three contractions (lanes (q1,q2,c) -> (q1,b,c) -> node)
+//   output    as k_elem_q2hex_mfma: K_e u for the residual, one 256-byte row per half-wave store
+// No table of the 3-D basis is read: the 1-D values are uniform operands (kernel argument) or per-lane constants.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int SF_ES = 18;                    // doubles per (c,c') block of e (16 + 2: the nine blocks start in distinct banks)
+constexpr int SF_NE = 6 * 9 * SF_ES;         // 972
+constexpr int SF_R = SF_NE + 48 + 36;        // e, sE[3][16], sF[9][4]; phase A's U / V and the 27 x 29 staging alias e
+constexpr int SF_DQ = 7 * 64;
+constexpr int SF_WAVE = MF_XS + SF_DQ + SF_R;   // 1612 doubles per wave (even: 16-byte alignment is kept)
+constexpr int SF_NLC = 51, SF_NLI = 20;      // rows of the per-lane tables (layout: fh_assembler_create)
+constexpr int SF_TAB = SF_NLC * 64 + SF_NLI * 32;   // doubles: both tables, shared by the waves of the workgroup
+constexpr size_t sf_lds_bytes(int nw) { return (size_t)(SF_TAB + nw * SF_WAVE) * sizeof(double); }
+static_assert(SF_R >= MF_SLAB && SF_R >= 720, "k_elem_q2hex_sf: region R holds the staging and phase A's U, V");
+
+__device__ __forceinline__ void sf_ld4(const double* p, double v[4]) {
+  const double2 a = *reinterpret_cast<const double2*>(__builtin_assume_aligned(p, 16));
+  const double2 b = *reinterpret_cast<const double2*>(__builtin_assume_aligned(p + 2, 16));
+  v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+
+template <int SRC, int NW>
+__global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab tab, const double* __restrict__ lanec, const int* __restrict__ lanei) {
+  constexpr int NC = 27, DIM = 3;
+  extern __shared__ __attribute__((aligned(16))) double sf_smem[];
+  double* SFl = sf_smem;                                  // [SF_NLC][64] doubles, then [SF_NLI][64] ints
+  int* SFi = reinterpret_cast<int*>(SFl + SF_NLC * 64);
+  for (int k = threadIdx.x; k < SF_NLC * 64; k += NW * 64) SFl[k] = lanec[k];
+  for (int k = threadIdx.x; k < SF_NLI * 64; k += NW * 64) SFi[k] = lanei[k];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* xs = SFl + SF_TAB + wave * SF_WAVE;
+  double* Dq = xs + MF_XS;
+  double* R = Dq + SF_DQ;
+  // per-lane constants: read from the workgroup's copy in LDS where they are used (conflict-free, 2 LDS cycles each) instead of
+  // holding ~120 registers across the element loop
+  const double* LCl = SFl + lane;                    // row r of the double table: LCl[r * 64]
+  const int* LIl = SFi + lane;                       // row r of the int table: LIl[r * 64]
+#define SF_I(r) LIl[(r) * 64]
+#define SF_C(r) LCl[(r) * 64]
+  const int ln = lane < NC ? lane : 0;
+  const fh_ciptr elems = (fh_ciptr)P.elems;
+  const int stride = gridDim.x * NW;
+  const int idx0 = blockIdx.x * NW + wave;
+  if (idx0 >= P.nelems) return;
+  const int last = P.nelems - 1;
+  int e_cur = elems[idx0];
+  int e_n = elems[min(idx0 + stride, last)], e_nn = elems[min(idx0 + 2 * stride, last)];
+  int sl_cur = (lane < NC) ? (P.slot ? P.slot[(size_t)e_cur * NC + lane] : idx0 * NC + lane) : -1;
+  {
+    const int dof = P.elem_dof[(size_t)e_cur * P.nloc + ln];
+    if (lane < NC) {
+      xs[lane * 4 + 0] = P.coords[(size_t)dof * DIM];
+      xs[lane * 4 + 1] = P.coords[(size_t)dof * DIM + 1];
+      xs[lane * 4 + 2] = P.coords[(size_t)dof * DIM + 2];
+      xs[lane * 4 + 3] = P.sol ? P.sol[dof] : 0.0;
+    }
+  }
+  int dof_n = P.elem_dof[(size_t)e_n * P.nloc + ln];
+  wave_lds_sync();
+#pragma unroll 1
+  for (int idx = idx0; idx < P.nelems; idx += stride) {
+    // ---- prefetch: node ids two elements ahead, coordinates / solution / slots one element ahead (dependent gathers) ----
+    const double nx0 = P.coords[(size_t)dof_n * DIM], nx1 = P.coords[(size_t)dof_n * DIM + 1], nx2 = P.coords[(size_t)dof_n * DIM + 2];
+    const double nu = P.sol ? P.sol[dof_n] : 0.0;
+    const int sl_n = (lane < NC) ? (P.slot ? P.slot[(size_t)e_n * NC + lane] : (idx + stride) * NC + lane) : -1;
+    const int dof_nn = P.elem_dof[(size_t)e_nn * P.nloc + ln];
+    const int e_nnn = elems[min(idx + 3 * stride, last)];
+    // ---- phase A: J_q by three contractions through LDS (U, V alias region R), then D_q; lane = Gauss point in tensor order ----
+    {
+      double J[DIM][DIM] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, xg[DIM] = {0, 0, 0};
+      double* U = R;                     // [2][3][3][4][4] = 288 doubles
+      const int sb1 = SF_I(3), sb2 = SF_I(4), sbv = SF_I(5), sb3 = SF_I(6);
+      double* V = R + 288;               // [3][3][16][4]   = 432 doubles
+      {
+        double u[2][3] = {{0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          const double* xn = xs + SF_I(a);
+          const double2 xa = *reinterpret_cast<const double2*>(xn);
+          const double x2 = xn[2];
+          const double la = SF_C(a), da = SF_C(3 + a);
+          u[0][0] += la * xa.x; u[0][1] += la * xa.y; u[0][2] += la * x2;
+          u[1][0] += da * xa.x; u[1][1] += da * xa.y; u[1][2] += da * x2;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          *reinterpret_cast<double2*>(U + k * 144 + sb1) = make_double2(u[k][0], u[k][1]);
+          U[k * 144 + sb1 + 2] = u[k][2];
+        }
+      }
+      wave_lds_sync();
+      {
+        double v[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+          const double* u0 = U + b * 48 + sb2;
+          const double* u1 = u0 + 144;
+          const double2 ua = *reinterpret_cast<const double2*>(u0), va = *reinterpret_cast<const double2*>(u1);
+          const double u2 = u0[2], v2 = u1[2];
+          const double lb = SF_C(6 + b), db = SF_C(9 + b);
+          v[0][0] += lb * ua.x; v[0][1] += lb * ua.y; v[0][2] += lb * u2;     // V
+          v[1][0] += db * ua.x; v[1][1] += db * ua.y; v[1][2] += db * u2;     // Veta
+          v[2][0] += lb * va.x; v[2][1] += lb * va.y; v[2][2] += lb * v2;     // Vxi
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          *reinterpret_cast<double2*>(V + k * 192 + sbv) = make_double2(v[k][0], v[k][1]);
+          V[k * 192 + sbv + 2] = v[k][2];
+        }
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const double lc = SF_C(12 + c), dc = SF_C(15 + c);
+        const double* v0 = V + c * 64 + sb3;
+        const double2 a0 = *reinterpret_cast<const double2*>(v0), a1 = *reinterpret_cast<const double2*>(v0 + 192),
+                      a2 = *reinterpret_cast<const double2*>(v0 + 384);
+        const double z0 = v0[2], z1 = v0[192 + 2], z2 = v0[384 + 2];
+        J[0][0] += lc * a2.x; J[0][1] += lc * a2.y; J[0][2] += lc * z2;
+        J[1][0] += lc * a1.x; J[1][1] += lc * a1.y; J[1][2] += lc * z1;
+        J[2][0] += dc * a0.x; J[2][1] += dc * a0.y; J[2][2] += dc * z0;
+        if (SRC != 0) { xg[0] += lc * a0.x; xg[1] += lc * a0.y; xg[2] += lc * z0; }
+      }
+      // cofactors Cf = det * J^-1 (the reference's Jacobian inverse, `elem_type_template` 3-D branch, without the division)
+      double Cf[DIM][DIM];
+      Cf[0][0] = -J[1][2] * J[2][1] + J[1][1] * J[2][2];
+      Cf[0][1] = J[0][2] * J[2][1] - J[0][1] * J[2][2];
+      Cf[0][2] = -J[0][2] * J[1][1] + J[0][1] * J[1][2];
+      Cf[1][0] = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+      Cf[1][1] = -J[0][2] * J[2][0] + J[0][0] * J[2][2];
+      Cf[1][2] = J[0][2] * J[1][0] - J[0][0] * J[1][2];
+      Cf[2][0] = -J[1][1] * J[2][0] + J[1][0] * J[2][1];
+      Cf[2][1] = J[0][1] * J[2][0] - J[0][0] * J[2][1];
+      Cf[2][2] = -J[0][1] * J[1][0] + J[0][0] * J[1][1];
+      const double det = J[0][0] * Cf[0][0] + J[0][1] * Cf[1][0] + J[0][2] * Cf[2][0];
+      double fq;
+      if (SRC == 0) fq = P.p0;
+      else if (SRC == 1) fq = source_eval(P.source_kind, P.p0, P.p1, xg, DIM);
+      else {
+        double x4[4] = {xg[0], xg[1], xg[2], 0.0};
+        fq = P.p0 * fh_expr_device_eval(P.prog, P.nprog, P.prog_consts, x4);
+      }
+      const double wgauss = SF_C(18);
+      const double sc = wgauss / det;
+      Dq[0 * 64 + lane] = sc * (Cf[0][0] * Cf[0][0] + Cf[1][0] * Cf[1][0] + Cf[2][0] * Cf[2][0]);
+      Dq[1 * 64 + lane] = sc * (Cf[0][0] * Cf[0][1] + Cf[1][0] * Cf[1][1] + Cf[2][0] * Cf[2][1]);
+      Dq[2 * 64 + lane] = sc * (Cf[0][0] * Cf[0][2] + Cf[1][0] * Cf[1][2] + Cf[2][0] * Cf[2][2]);
+      Dq[3 * 64 + lane] = sc * (Cf[0][1] * Cf[0][1] + Cf[1][1] * Cf[1][1] + Cf[2][1] * Cf[2][1]);
+      Dq[4 * 64 + lane] = sc * (Cf[0][1] * Cf[0][2] + Cf[1][1] * Cf[1][2] + Cf[2][1] * Cf[2][2]);
+      Dq[5 * 64 + lane] = sc * (Cf[0][2] * Cf[0][2] + Cf[1][2] * Cf[1][2] + Cf[2][2] * Cf[2][2]);
+      Dq[6 * 64 + lane] = det * wgauss * fq;
+    }
+    wave_lds_sync();
+    double Kb[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    double fsrc = 0.0;
+    if (!(P.debug & 1)) {
+      // ---- stage 1: lane = (q1, q2, c), contracts q3 ----
+      {
+        const double* dq = Dq + (lane >> 2) * 4;
+        double t[6][4], s4[4], zl[4], zd[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { zl[q] = SF_C(19 + q); zd[q] = SF_C(23 + q); }
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          sf_ld4(dq + k * 64, t[k]);
+#pragma unroll
+          for (int q = 0; q < 4; q++) t[k][q] *= (k == 5) ? zd[q] : zl[q];
+        }
+        sf_ld4(dq + 6 * 64, s4);
+        const int c = min(lane & 3, 2);           // lanes with c = 3 repeat c = 2 (their table rows are those of c = 2)
+        double* eo = R + c * 3 * SF_ES + (lane >> 2);
+        {
+#pragma unroll
+          for (int k = 0; k < 6; k++)
+#pragma unroll
+            for (int c2 = 0; c2 < 3; c2++) {
+              const double* z = (k == 2 || k == 4 || k == 5) ? tab.D[c2] : tab.L[c2];
+              eo[(k * 9 + c2) * SF_ES] = t[k][0] * z[0] + t[k][1] * z[1] + t[k][2] * z[2] + t[k][3] * z[3];
+            }
+          R[SF_NE + c * 16 + (lane >> 2)] = s4[0] * zl[0] + s4[1] * zl[1] + s4[2] * zl[2] + s4[3] * zl[3];
+        }
+      }
+      wave_lds_sync();
+      // ---- source, second contraction: lane = (q1, b, c), contracts q2 ----
+      {
+        double s4[4];
+        sf_ld4(R + SF_NE + SF_I(16), s4);
+        R[SF_NE + 48 + SF_I(17)] = s4[0] * SF_C(43) + s4[1] * SF_C(44) + s4[2] * SF_C(45) + s4[3] * SF_C(46);
+      }
+      // ---- stages 2 and 3: lane = pair {(b,c), (b',c')}; per q1: contract q2 into the four G values, then add their part of the
+      //      3 x 3 block over (a, a').  The loop is NOT unrolled: one iteration's operands are all that is live. ----
+      {
+        const double* e0 = R + SF_I(7);
+        const double* eT = R + SF_I(8);
+        double yLL[4], yLD[4], yDL[4], yDD[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { yLL[q] = SF_C(27 + q); yLD[q] = SF_C(31 + q); yDL[q] = SF_C(35 + q); yDD[q] = SF_C(39 + q); }
+#pragma unroll 1
+        for (int q1 = 0; q1 < 4; q1++) {
+          double v0[4], v1[4], v2[4], v2T[4], v3[4], v4[4], v4T[4], v5[4];
+          sf_ld4(e0 + 0 * 9 * SF_ES + q1 * 4, v0);
+          sf_ld4(e0 + 1 * 9 * SF_ES + q1 * 4, v1);
+          sf_ld4(e0 + 2 * 9 * SF_ES + q1 * 4, v2);
+          sf_ld4(eT + 2 * 9 * SF_ES + q1 * 4, v2T);
+          sf_ld4(e0 + 3 * 9 * SF_ES + q1 * 4, v3);
+          sf_ld4(e0 + 4 * 9 * SF_ES + q1 * 4, v4);
+          sf_ld4(eT + 4 * 9 * SF_ES + q1 * 4, v4T);
+          sf_ld4(e0 + 5 * 9 * SF_ES + q1 * 4, v5);
+          double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;     // G for (l'l'), (l'l), (ll'), (ll)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            g0 += yLL[q] * v0[q];
+            g1 += yLD[q] * v1[q]; g1 += yLL[q] * v2[q];
+            g2 += yDL[q] * v1[q]; g2 += yLL[q] * v2T[q];
+            g3 += yDD[q] * v3[q]; g3 += yDL[q] * v4[q]; g3 += yLD[q] * v4T[q]; g3 += yLL[q] * v5[q];
+          }
+          const double l0 = tab.L[0][q1], l1 = tab.L[1][q1], l2 = tab.L[2][q1], d0 = tab.D[0][q1], d1 = tab.D[1][q1], d2 = tab.D[2][q1];
+          const double la[3] = {l0, l1, l2}, da[3] = {d0, d1, d2};
+          double u[3], v[3];
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            u[a] = la[a] * g3 + da[a] * g1;
+            v[a] = la[a] * g2 + da[a] * g0;
+          }
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int a2 = 0; a2 < 3; a2++) { Kb[a][a2] += la[a2] * u[a]; Kb[a][a2] += da[a2] * v[a]; }
+        }
+      }
+      wave_lds_sync();
+      {
+        double s4[4];
+        sf_ld4(R + SF_NE + 48 + SF_I(18), s4);
+        fsrc = s4[0] * SF_C(47) + s4[1] * SF_C(48) + s4[2] * SF_C(49) + s4[3] * SF_C(50);
+      }
+    }
+    wave_lds_sync();          // every lane is done with e: reuse it as Ks[27][29]
+    double* Ks = R;
+    {
+      // no divergent branch: lanes 45..63 repeat the last pair; on a diagonal pair (kind 2) the upper entries go to both places
+      const bool diag = SF_I(15) == 2;
+      int ri[3], cj[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) { ri[a] = SF_I(9 + a); cj[a] = SF_I(12 + a); }
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int a2 = 0; a2 < 3; a2++) {
+          const double v = (a2 < a) ? (diag ? Kb[a2][a] : Kb[a][a2]) : Kb[a][a2];
+          Ks[ri[a] * MF_KS + cj[a2]] = v;
+          Ks[cj[a2] * MF_KS + ri[a]] = v;
+        }
+    }
+    wave_lds_sync();
+    double ku = 0.0;
+    if (P.sol) {              // residual: (K_e u)_i, lanes i = lane&31, half of the columns each
+      const int i = min(lane & 31, NC - 1), h = lane >> 5;
+#pragma unroll
+      for (int g = 0; g < 14; g++) {
+        const int j = h * 14 + g;
+        const double v = (j < NC) ? Ks[i * MF_KS + min(j, NC - 1)] : 0.0;
+        ku += v * xs[min(j, NC - 1) * 4 + 3];
+      }
+      ku += __shfl_xor(ku, 32, 64);
+    }
+    if (lane < NC) {          // the next element's nodes (see k_elem_q2hex_mfma)
+      xs[lane * 4 + 0] = nx0;
+      xs[lane * 4 + 1] = nx1;
+      xs[lane * 4 + 2] = nx2;
+      xs[lane * 4 + 3] = nu;
+    }
+    if (!(P.debug & 2)) {
+      if (P.kstride >= 28) {
+        const int j = lane & 31, hrow = lane >> 5;
+        const unsigned joff = (unsigned)j * 8u;
+        double kv[14];
+#pragma unroll
+        for (int p = 0; p < 14; p++) kv[p] = Ks[min(2 * p + hrow, NC - 1) * MF_KS + j];
+#pragma unroll
+        for (int p = 0; p < 14; p++) {
+          const int s0 = __builtin_amdgcn_readlane(sl_cur, 2 * p), s1 = __builtin_amdgcn_readlane(sl_cur, min(2 * p + 1, NC - 1));
+          const double* b0 = P.Kout + (size_t)s0 * P.kstride;
+          const double* b1 = P.Kout + (size_t)s1 * P.kstride;
+          if (j >= P.kstride) continue;
+          if (hrow == 0) {
+            if (s0 >= 0) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(joff), "v"(kv[p]), "s"(b0) : "memory");
+          } else if (2 * p + 1 < NC) {
+            if (s1 >= 0) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(joff), "v"(kv[p]), "s"(b1) : "memory");
+          }
+        }
+      } else {
+#pragma unroll
+        for (int t0 = 0; t0 < NC * NC; t0 += 64) {
+          const int t = t0 + lane;
+          const int row = (t < NC * NC) ? t / NC : 0;
+          const int j = t - row * NC;
+          const int s = __shfl(sl_cur, row, 64);
+          if (t < NC * NC && s >= 0) P.Kout[(size_t)s * NC + j] = Ks[row * MF_KS + j];
+        }
+      }
+      if (lane < NC && sl_cur >= 0) P.Fout[sl_cur] = -(ku + fsrc);
+    }
+    wave_lds_sync();          // Ks is the next element's phase-A scratch, xs holds the next element's nodes
+    sl_cur = sl_n;
+    dof_n = dof_nn;
+    e_n = e_nn;
+    e_nn = e_nnn;
+  }
+#undef SF_I
+#undef SF_C
+}
+
+template <int SRC, int NW>
+static int launch_sf_one(fh_assembler_t as, const AsmParams& P) {
+  constexpr size_t lds = sf_lds_bytes(NW);
+  static_assert(lds <= 160 * 1024, "k_elem_q2hex_sf: LDS budget");
+  static bool attr_set[64] = {};
+  const int dev = as->ctx->device & 63;
+  if (!attr_set[dev]) {
+    FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_elem_q2hex_sf<SRC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set[dev] = true;
+  }
+  const int per_cu = std::max(1, (int)((size_t)160 * 1024 / lds));
+  const int grid = std::max(1, std::min(fh_div_up(P.nelems, NW), as->ctx->num_cu * per_cu));
+  hipLaunchKernelGGL((k_elem_q2hex_sf<SRC, NW>), dim3(grid), dim3(NW * 64), lds, as->ctx->stream, P, as->sf_tab, as->d_sfLc, as->d_sfLi);
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int SRC>
+static int launch_sf_src(fh_assembler_t as, const AsmParams& P, int nw) {
+  if (nw <= 4) return launch_sf_one<SRC, 4>(as, P);
+  if (nw <= 5) return launch_sf_one<SRC, 5>(as, P);
+  if (nw <= 8) return launch_sf_one<SRC, 8>(as, P);
+  return launch_sf_one<SRC, 10>(as, P);
+}
+
+static int launch_sf(fh_assembler_t as, const AsmParams& P, int nw) {
+  if (P.source_kind == 4) return launch_sf_src<2>(as, P, nw);
+  if (P.source_kind != 0) return launch_sf_src<1>(as, P, nw);
+  return launch_sf_src<0>(as, P, nw);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Affine HEX27 / Q2 elements (parallelepipeds: boxes, sheared boxes): the Jacobian of the map is constant, so
 //   K_ij = sum_g w_g det grad phi_i . grad phi_j = sum_ab (det B_ab) M_ab(i,j),  B = J^-1 J^-T,  M_ab = sum_g w^_g d_a phi^_i d_b phi^_j
 // with the nine reference matrices M_ab built once from the same quadrature tables.  The result equals the quadrature loop of
@@ -1310,6 +1679,10 @@ static int launch_assemble(fh_assembler_t as, const AsmParams& P) {
 }
 
 static int dispatch_assemble(fh_assembler_t as, const AsmParams& P) {
+  if (as->dim == 3 && as->nc == 27 && P.Kout && as->ctx->assemble_sf && as->d_sfLc && P.ng == 64) {
+    if (P.nelems <= 0) return 0;
+    return launch_sf(as, P, as->ctx->assemble_sf);
+  }
   if (as->dim == 3 && as->nc == 27 && P.Kout && as->ctx->assemble_mfma && as->d_mfT && P.ng == 64) {
     if (P.nelems <= 0) return 0;
     return launch_mfma(as, P, as->ctx->assemble_mfma);
@@ -1508,6 +1881,83 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
         }
         FH_TRY(up((void**)&as->d_mfSFc, sfc.data(), sfc.size() * sizeof(double)));
         FH_TRY(up((void**)&as->d_mfSFi, sfi.data(), sfi.size() * sizeof(int)));
+        // tables of the sum-factorised element kernel (lane roles: see k_elem_q2hex_sf)
+        {
+          std::vector<double> lc((size_t)SF_NLC * 64, 0.0);
+          std::vector<int> li((size_t)SF_NLI * 64, 0);
+          int gof[64];
+          for (int g = 0; g < 64; g++) gof[qidx[g][0] * 16 + qidx[g][1] * 4 + qidx[g][2]] = g;
+          for (int a = 0; a < 3; a++)
+            for (int k = 0; k < 4; k++) { as->sf_tab.L[a][k] = L1[a][k]; as->sf_tab.D[a][k] = D1[a][k]; }
+          int pr[64][2], np = 0;
+          for (int p = 0; p < 9; p++)
+            for (int p2 = p; p2 < 9; p2++) { pr[np][0] = p; pr[np][1] = p2; np++; }
+          for (int l = 0; l < 64; l++) {
+            {                                              // phase A stage 1 and source stage 2: lane = (q1, b, c); lanes >= 36 repeat lane 35
+              const int lr = std::min(l, 35), q1 = lr & 3, bc = lr >> 2, b = bc / 3, c = bc % 3;
+              for (int a = 0; a < 3; a++) {
+                lc[(size_t)a * 64 + l] = L1[a][q1];
+                lc[(size_t)(3 + a) * 64 + l] = D1[a][q1];
+                li[(size_t)a * 64 + l] = nodeof[a * 9 + b * 3 + c] * 4;
+              }
+              li[(size_t)3 * 64 + l] = ((b * 3 + c) * 4 + q1) * 4;
+              for (int k = 0; k < 4; k++) lc[(size_t)(43 + k) * 64 + l] = L1[b][k];
+              li[(size_t)16 * 64 + l] = c * 16 + q1 * 4;
+              li[(size_t)17 * 64 + l] = (b * 3 + c) * 4 + q1;
+            }
+            {                                              // phase A stage 2: lane = (c, q1, q2); lanes >= 48 repeat lane 47
+              const int lr = std::min(l, 47), c2 = lr >> 4, q12 = lr & 15, q1 = q12 & 3, q2 = q12 >> 2;
+              for (int b = 0; b < 3; b++) {
+                lc[(size_t)(6 + b) * 64 + l] = L1[b][q2];
+                lc[(size_t)(9 + b) * 64 + l] = D1[b][q2];
+              }
+              li[(size_t)4 * 64 + l] = (c2 * 4 + q1) * 4;
+              li[(size_t)5 * 64 + l] = (c2 * 16 + q12) * 4;
+            }
+            {                                              // phase A stage 3: lane = Gauss point in tensor order
+              const int q1 = l >> 4, q2 = (l >> 2) & 3, q3 = l & 3;
+              for (int c = 0; c < 3; c++) {
+                lc[(size_t)(12 + c) * 64 + l] = L1[c][q3];
+                lc[(size_t)(15 + c) * 64 + l] = D1[c][q3];
+              }
+              li[(size_t)6 * 64 + l] = (q1 + 4 * q2) * 4;
+              lc[(size_t)18 * 64 + l] = w[gof[l]];
+            }
+            {                                              // stage 1: lane = (q1, q2, c)
+              const int c = std::min(l & 3, 2);         // c = 3 repeats c = 2
+              for (int k = 0; k < 4; k++) {
+                lc[(size_t)(19 + k) * 64 + l] = L1[c][k];
+                lc[(size_t)(23 + k) * 64 + l] = D1[c][k];
+              }
+            }
+            {                                              // stages 2, 3: lane = unordered pair {(b,c), (b',c')}
+              const int lr = std::min(l, np - 1);       // lanes >= 45 repeat the last pair
+              const int p = pr[lr][0], p2 = pr[lr][1];
+              const int b = p / 3, c = p % 3, b2 = p2 / 3, c2 = p2 % 3;
+              for (int k = 0; k < 4; k++) {
+                lc[(size_t)(27 + k) * 64 + l] = L1[b][k] * L1[b2][k];
+                lc[(size_t)(31 + k) * 64 + l] = L1[b][k] * D1[b2][k];
+                lc[(size_t)(35 + k) * 64 + l] = D1[b][k] * L1[b2][k];
+                lc[(size_t)(39 + k) * 64 + l] = D1[b][k] * D1[b2][k];
+              }
+              li[(size_t)7 * 64 + l] = (c * 3 + c2) * SF_ES;
+              li[(size_t)8 * 64 + l] = (c2 * 3 + c) * SF_ES;
+              for (int a = 0; a < 3; a++) {
+                li[(size_t)(9 + a) * 64 + l] = nodeof[a * 9 + b * 3 + c];
+                li[(size_t)(12 + a) * 64 + l] = nodeof[a * 9 + b2 * 3 + c2];
+              }
+              li[(size_t)15 * 64 + l] = p == p2 ? 2 : 1;
+            }
+            {                                              // source stage 3: lane = node; lanes >= 27 repeat node 26
+              const int n = std::min(l, 26);
+              const int a = fhfe::xc(geom, n, 0) + 1, b = fhfe::xc(geom, n, 1) + 1, c = fhfe::xc(geom, n, 2) + 1;
+              for (int k = 0; k < 4; k++) lc[(size_t)(47 + k) * 64 + l] = L1[a][k];
+              li[(size_t)18 * 64 + l] = (b * 3 + c) * 4;
+            }
+          }
+          FH_TRY(up((void**)&as->d_sfLc, lc.data(), lc.size() * sizeof(double)));
+          FH_TRY(up((void**)&as->d_sfLi, li.data(), li.size() * sizeof(int)));
+        }
       }
     }
   }
@@ -1627,7 +2077,7 @@ extern "C" int fh_assembler_destroy(fh_assembler_t as) {
   hipFree(as->d_phi);
   hipFree(as->d_dphi);
   if (as->d_emap) hipFree(as->d_emap);
-  for (void* q : {(void*)as->d_aff_elems, (void*)as->d_gen_elems, (void*)as->d_Mab, (void*)as->d_mphi, (void*)as->d_mfT, (void*)as->d_mfPhi, (void*)as->d_mfSFc, (void*)as->d_mfSFi})
+  for (void* q : {(void*)as->d_aff_elems, (void*)as->d_gen_elems, (void*)as->d_Mab, (void*)as->d_mphi, (void*)as->d_mfT, (void*)as->d_mfPhi, (void*)as->d_mfSFc, (void*)as->d_mfSFi, (void*)as->d_sfLc, (void*)as->d_sfLi})
     if (q) hipFree(q);
   if (as->d_prog) hipFree(as->d_prog);
   if (as->d_prog_consts) hipFree(as->d_prog_consts);

@@ -73,12 +73,13 @@ def test_distorted_hex27_geometry(ctx):
     assert abs(F - Fo).max() <= 1e-12 * abs(Fo).max()
 
 
-@pytest.mark.parametrize("mfma", [0, 4, 8, 12])
+@pytest.mark.parametrize("sf,mfma", [(0, 0), (0, 4), (0, 8), (0, 12), (4, 12), (5, 12), (8, 12), (10, 12)])
 @pytest.mark.parametrize("args,with_sol,kind", [((3, 1, 1), True, 2), ((5, 3, 1), False, 0), ((4, 4, 3), True, 1)])
-def test_matrix_core_and_vector_element_kernels_match_oracle(ctx, args, with_sol, kind, mfma):
-    """HEX27/Q2, 64-point rule: element matrices from the FP64 matrix-core kernel (assemble_mfma = waves per workgroup) and from the
-    vector kernel (0) on curved elements; element counts that leave waves of the persistent workgroups idle or give them several
-    elements; with and without a solution vector (the residual's K_e u term)."""
+def test_matrix_core_and_vector_element_kernels_match_oracle(ctx, args, with_sol, kind, sf, mfma):
+    """HEX27/Q2, 64-point rule: element matrices from the sum-factorised kernel (assemble_sf = waves per workgroup; the default),
+    from the FP64 matrix-core kernel (assemble_sf 0, assemble_mfma = waves per workgroup) and from the vector kernel (both 0) on
+    curved elements; element counts that leave waves of the persistent workgroups idle or give them several elements; with and
+    without a solution vector (the residual's K_e u term)."""
     m = levels(args, 1)[0]
     ed, xy, _ = m.arrays()
     rng = np.random.default_rng(5)
@@ -92,10 +93,12 @@ def test_matrix_core_and_vector_element_kernels_match_oracle(ctx, args, with_sol
     rhs = {0: lambda xg: 1.5 * np.ones(xg.shape[:2]), 1: lambda xg: 2.0 * np.prod(np.sin(1.3 * xg), axis=-1),
            2: lambda xg: 2.0 * np.prod(np.cos(1.3 * xg), axis=-1)}[kind]
     ctx.set_option("assemble_mfma", mfma)
+    ctx.set_option("assemble_sf", sf)
     try:
         K, F = asm.element_matrices(ctx.vector_from(u) if with_sol else None, kind, params)
     finally:
         ctx.set_option("assemble_mfma", 12)
+        ctx.set_option("assemble_sf", 8)
     et = fo.ElemType("hex", "biquadratic", "seventh")
     Ko, Fo = fo.elem_poisson_batch(et, np.transpose(xy[ed], (0, 2, 1)), u[ed], rhs)
     assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
@@ -147,11 +150,13 @@ def test_global_assembly_matches_oracle(ctx, args, nl, fe, two_pass, emap):
         ctx.set_option("assemble_two_pass", 1)
 
 
-@pytest.mark.parametrize("sumfac,kpad,mfma", [(1, 1, 12), (0, 1, 12), (1, 0, 12), (1, 1, 0), (1, 0, 0)])
-def test_global_assembly_options_of_the_hex27_path(ctx, sumfac, kpad, mfma):
-    """HEX27/Q2 two-pass assembly with the Jacobian by sum factorisation or by the direct node loop, element rows padded to 256
-    bytes or not, matrix-core or vector element kernel: all of them against the oracle on a curved mesh, and bit-identical when
-    repeated."""
+@pytest.mark.parametrize("sf,sumfac,kpad,mfma", [(8, 1, 1, 12), (8, 1, 0, 12), (8, 1, 28, 12), (10, 1, 1, 12), (4, 1, 1, 12),
+                                                  (0, 1, 1, 12), (0, 0, 1, 12), (0, 1, 0, 12), (0, 1, 1, 0), (0, 1, 0, 0)])
+def test_global_assembly_options_of_the_hex27_path(ctx, sf, sumfac, kpad, mfma):
+    """HEX27/Q2 two-pass assembly with the sum-factorised element kernel (sf = waves per workgroup), or (sf 0) the matrix-core /
+    vector element kernels with the Jacobian by sum factorisation or by the direct node loop; element rows padded to 256 bytes,
+    224 bytes or not at all: all of them against the oracle on a curved mesh, and bit-identical when repeated (the element-row
+    buffers start as NaN, so a row the kernel did not write shows)."""
     m = levels((3, 2, 2), 2)[-1]
     ed, xy, _ = m.arrays()
     rng = np.random.default_rng(17)
@@ -161,6 +166,7 @@ def test_global_assembly_options_of_the_hex27_path(ctx, sumfac, kpad, mfma):
     A = ctx.matrix_csr(n, n, rp, col)
     res = ctx.vector(n)
     u = rng.uniform(-1, 1, n)
+    ctx.set_option("assemble_sf", sf)
     ctx.set_option("assemble_sumfac", sumfac)
     ctx.set_option("assemble_kpad", kpad)
     ctx.set_option("assemble_mfma", mfma)
@@ -173,6 +179,7 @@ def test_global_assembly_options_of_the_hex27_path(ctx, sumfac, kpad, mfma):
         assert np.array_equal(v1, A.values()) and np.array_equal(f1, res.to_numpy())
     finally:
         ctx.set_option("debug_poison", 0)
+        ctx.set_option("assemble_sf", 8)
         ctx.set_option("assemble_sumfac", 1)
         ctx.set_option("assemble_kpad", 1)
         ctx.set_option("assemble_mfma", 12)
