@@ -1206,14 +1206,15 @@ static int launch_mfma(fh_assembler_t as, const AsmParams& P, int nw) {
 // No table of the 3-D basis is read: the 1-D values are uniform operands (kernel argument) or per-lane constants.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int SF_ES = 18;                    // doubles per (c,c') block of e (16 + 2: the nine blocks start in distinct banks)
-constexpr int SF_NE = 6 * 9 * SF_ES;         // 972
-constexpr int SF_R = SF_NE + 48 + 36;        // e, sE[3][16], sF[9][4]; phase A's U / V and the 27 x 29 staging alias e
-constexpr int SF_DQ = 7 * 64;
-constexpr int SF_WAVE = MF_XS + SF_DQ + SF_R;   // 1612 doubles per wave (even: 16-byte alignment is kept)
-constexpr int SF_NLC = 51, SF_NLI = 20;      // rows of the per-lane tables (layout: fh_assembler_create)
+constexpr int SF_NE = 56 * SF_ES;            // e: four symmetric arrays of 8 slots (6 used), two of 12 (9 used) = 1008 doubles
+constexpr int SF_R = SF_NE + 64 + 36;        // e, sE[4][16], sF[9][4]; phase A's U / V and the 27 x 29 staging alias e
+constexpr int SF_US = 40, SF_VS = 48;        // phase A: U[2][3][SF_US] then V[3][3][SF_VS], one array per coordinate (conflict-free)
+constexpr int SF_XT = 4 * 28;                // per wave: x, y, z and u of the element's nodes, 28 doubles each, in TENSOR order a*9 + b*3 + c
+constexpr int SF_WAVE = SF_XT + SF_R;   // 1220 doubles per wave (even: 16-byte alignment is kept)
+constexpr int SF_NLC = 51, SF_NLI = 16;      // rows of the per-lane tables (layout: fh_assembler_create)
 constexpr int SF_TAB = SF_NLC * 64 + SF_NLI * 32;   // doubles: both tables, shared by the waves of the workgroup
 constexpr size_t sf_lds_bytes(int nw) { return (size_t)(SF_TAB + nw * SF_WAVE) * sizeof(double); }
-static_assert(SF_R >= MF_SLAB && SF_R >= 720, "k_elem_q2hex_sf: region R holds the staging and phase A's U, V");
+static_assert(SF_R >= MF_SLAB && SF_R >= 6 * SF_US + 9 * SF_VS, "k_elem_q2hex_sf: region R holds the staging and phase A's U, V");
 
 __device__ __forceinline__ void sf_ld4(const double* p, double v[4]) {
   const double2 a = *reinterpret_cast<const double2*>(__builtin_assume_aligned(p, 16));
@@ -1221,9 +1222,9 @@ __device__ __forceinline__ void sf_ld4(const double* p, double v[4]) {
   v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
 }
 
-template <int SRC, int NW>
+template <int SRC, int NW, bool PAD>
 __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab tab, const double* __restrict__ lanec, const int* __restrict__ lanei) {
-  constexpr int NC = 27, DIM = 3;
+  constexpr int NC = 27, DIM = 3, KS = MF_KS;
   extern __shared__ __attribute__((aligned(16))) double sf_smem[];
   double* SFl = sf_smem;                                  // [SF_NLC][64] doubles, then [SF_NLI][64] ints
   int* SFi = reinterpret_cast<int*>(SFl + SF_NLC * 64);
@@ -1232,15 +1233,30 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab ta
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double* xs = SFl + SF_TAB + wave * SF_WAVE;
-  double* Dq = xs + MF_XS;
-  double* R = Dq + SF_DQ;
-  // per-lane constants: read from the workgroup's copy in LDS where they are used (conflict-free, 2 LDS cycles each) instead of
-  // holding ~120 registers across the element loop
+  double* xt = SFl + SF_TAB + wave * SF_WAVE;          // xt[0..27] x, [28..55] y, [56..83] z, [84..111] u   (tensor order)
+  double* R = xt + SF_XT;
+  // per-lane constants: the hot ones (stages 1-3, staging, output) in registers, the others are read from the workgroup's copy in
+  // LDS where they are used (conflict-free, 2 LDS cycles each)
   const double* LCl = SFl + lane;                    // row r of the double table: LCl[r * 64]
   const int* LIl = SFi + lane;                       // row r of the int table: LIl[r * 64]
 #define SF_I(r) LIl[(r) * 64]
 #define SF_C(r) LCl[(r) * 64]
+  constexpr bool REGC = NW <= 8;          // 2 waves per SIMD: 256 registers per lane, room for the per-lane constants of the hot stages
+  double rcA[19], rcZ[8], rcY[16];
+  if (REGC) {
+#pragma unroll
+    for (int r = 0; r < 19; r++) rcA[r] = lanec[r * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 8; r++) rcZ[r] = lanec[(19 + r) * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 16; r++) rcY[r] = lanec[(27 + r) * 64 + lane];
+  }
+#define SF_CA(r) (REGC ? rcA[r] : SF_C(r))
+  const int esym = lanei[5 * 64 + lane], ens = lanei[6 * 64 + lane], ensT = lanei[15 * 64 + lane], based = lanei[7 * 64 + lane], basem = lanei[8 * 64 + lane];
+  const int eout = (lane >> 4) * SF_ES + (lane & 15);
+  const bool diag = lanei[9 * 64 + lane] != 0;
+  const int tofl = lanei[13 * 64 + lane];              // tensor index of node min(lane, 26)
+  const int nodeofl = lanei[14 * 64 + lane];           // node of tensor index min(lane, 26)
   const int ln = lane < NC ? lane : 0;
   const fh_ciptr elems = (fh_ciptr)P.elems;
   const int stride = gridDim.x * NW;
@@ -1253,10 +1269,10 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab ta
   {
     const int dof = P.elem_dof[(size_t)e_cur * P.nloc + ln];
     if (lane < NC) {
-      xs[lane * 4 + 0] = P.coords[(size_t)dof * DIM];
-      xs[lane * 4 + 1] = P.coords[(size_t)dof * DIM + 1];
-      xs[lane * 4 + 2] = P.coords[(size_t)dof * DIM + 2];
-      xs[lane * 4 + 3] = P.sol ? P.sol[dof] : 0.0;
+      xt[tofl] = P.coords[(size_t)dof * DIM];
+      xt[28 + tofl] = P.coords[(size_t)dof * DIM + 1];
+      xt[56 + tofl] = P.coords[(size_t)dof * DIM + 2];
+      xt[84 + tofl] = P.sol ? P.sol[dof] : 0.0;
     }
   }
   int dof_n = P.elem_dof[(size_t)e_n * P.nloc + ln];
@@ -1269,61 +1285,69 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab ta
     const int sl_n = (lane < NC) ? (P.slot ? P.slot[(size_t)e_n * NC + lane] : (idx + stride) * NC + lane) : -1;
     const int dof_nn = P.elem_dof[(size_t)e_nn * P.nloc + ln];
     const int e_nnn = elems[min(idx + 3 * stride, last)];
-    // ---- phase A: J_q by three contractions through LDS (U, V alias region R), then D_q; lane = Gauss point in tensor order ----
+    double Dr[7];            // D_q (six entries) and the source weight at this lane's Gauss point
+    // ---- phase A: J_q by three contractions through LDS (U, V alias region R; one array per coordinate, every access is
+    //      conflict-free), then D_q; lane = Gauss point in tensor order.  Lanes beyond a stage's role count repeat its last role
+    //      (same values to the same addresses): no divergent branch in the element loop ----
     {
       double J[DIM][DIM] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, xg[DIM] = {0, 0, 0};
-      double* U = R;                     // [2][3][3][4][4] = 288 doubles
-      const int sb1 = SF_I(3), sb2 = SF_I(4), sbv = SF_I(5), sb3 = SF_I(6);
-      double* V = R + 288;               // [3][3][16][4]   = 432 doubles
+      double* U = R;                     // [2][3][SF_US]: (sum_a l_a x, sum_a l'_a x) at [(b*3+c)*4 + q1]
+      double* V = R + 6 * SF_US;         // [3][3][SF_VS]: V, Veta, Vxi at [c*16 + q1 + 4 q2]
       {
+        const double* xn = xt + SF_I(0);             // b*3 + c
         double u[2][3] = {{0, 0, 0}, {0, 0, 0}};
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-          const double* xn = xs + SF_I(a);
-          const double2 xa = *reinterpret_cast<const double2*>(xn);
-          const double x2 = xn[2];
-          const double la = SF_C(a), da = SF_C(3 + a);
-          u[0][0] += la * xa.x; u[0][1] += la * xa.y; u[0][2] += la * x2;
-          u[1][0] += da * xa.x; u[1][1] += da * xa.y; u[1][2] += da * x2;
-        }
+          const double la = SF_CA(a), da = SF_CA(3 + a);
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-          *reinterpret_cast<double2*>(U + k * 144 + sb1) = make_double2(u[k][0], u[k][1]);
-          U[k * 144 + sb1 + 2] = u[k][2];
+          for (int d = 0; d < 3; d++) {
+            const double x = xn[d * 28 + a * 9];
+            u[0][d] += la * x;
+            u[1][d] += da * x;
+          }
         }
+        double* uo = U + SF_I(1);
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+          for (int d = 0; d < 3; d++) uo[(k * 3 + d) * SF_US] = u[k][d];
       }
       wave_lds_sync();
       {
+        const double* ui = U + SF_I(2);              // c*4 + q1
         double v[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #pragma unroll
         for (int b = 0; b < 3; b++) {
-          const double* u0 = U + b * 48 + sb2;
-          const double* u1 = u0 + 144;
-          const double2 ua = *reinterpret_cast<const double2*>(u0), va = *reinterpret_cast<const double2*>(u1);
-          const double u2 = u0[2], v2 = u1[2];
-          const double lb = SF_C(6 + b), db = SF_C(9 + b);
-          v[0][0] += lb * ua.x; v[0][1] += lb * ua.y; v[0][2] += lb * u2;     // V
-          v[1][0] += db * ua.x; v[1][1] += db * ua.y; v[1][2] += db * u2;     // Veta
-          v[2][0] += lb * va.x; v[2][1] += lb * va.y; v[2][2] += lb * v2;     // Vxi
-        }
+          const double lb = SF_CA(6 + b), db = SF_CA(9 + b);
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-          *reinterpret_cast<double2*>(V + k * 192 + sbv) = make_double2(v[k][0], v[k][1]);
-          V[k * 192 + sbv + 2] = v[k][2];
+          for (int d = 0; d < 3; d++) {
+            const double u0 = ui[d * SF_US + b * 12], u1 = ui[(3 + d) * SF_US + b * 12];
+            v[0][d] += lb * u0;     // V
+            v[1][d] += db * u0;     // Veta
+            v[2][d] += lb * u1;     // Vxi
+          }
         }
+        double* vo = V + SF_I(3);
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+          for (int d = 0; d < 3; d++) vo[(k * 3 + d) * SF_VS] = v[k][d];
       }
       wave_lds_sync();
+      {
+        const double* vi = V + SF_I(4);              // q1 + 4 q2
 #pragma unroll
-      for (int c = 0; c < 3; c++) {
-        const double lc = SF_C(12 + c), dc = SF_C(15 + c);
-        const double* v0 = V + c * 64 + sb3;
-        const double2 a0 = *reinterpret_cast<const double2*>(v0), a1 = *reinterpret_cast<const double2*>(v0 + 192),
-                      a2 = *reinterpret_cast<const double2*>(v0 + 384);
-        const double z0 = v0[2], z1 = v0[192 + 2], z2 = v0[384 + 2];
-        J[0][0] += lc * a2.x; J[0][1] += lc * a2.y; J[0][2] += lc * z2;
-        J[1][0] += lc * a1.x; J[1][1] += lc * a1.y; J[1][2] += lc * z1;
-        J[2][0] += dc * a0.x; J[2][1] += dc * a0.y; J[2][2] += dc * z0;
-        if (SRC != 0) { xg[0] += lc * a0.x; xg[1] += lc * a0.y; xg[2] += lc * z0; }
+        for (int c = 0; c < 3; c++) {
+          const double lc = SF_CA(12 + c), dc = SF_CA(15 + c);
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            const double v0 = vi[d * SF_VS + c * 16], v1 = vi[(3 + d) * SF_VS + c * 16], v2 = vi[(6 + d) * SF_VS + c * 16];
+            J[0][d] += lc * v2;
+            J[1][d] += lc * v1;
+            J[2][d] += dc * v0;
+            if (SRC != 0) xg[d] += lc * v0;
+          }
+        }
       }
       // cofactors Cf = det * J^-1 (the reference's Jacobian inverse, `elem_type_template` 3-D branch, without the division)
       double Cf[DIM][DIM];
@@ -1344,79 +1368,87 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab ta
         double x4[4] = {xg[0], xg[1], xg[2], 0.0};
         fq = P.p0 * fh_expr_device_eval(P.prog, P.nprog, P.prog_consts, x4);
       }
-      const double wgauss = SF_C(18);
+      const double wgauss = SF_CA(18);
       const double sc = wgauss / det;
-      Dq[0 * 64 + lane] = sc * (Cf[0][0] * Cf[0][0] + Cf[1][0] * Cf[1][0] + Cf[2][0] * Cf[2][0]);
-      Dq[1 * 64 + lane] = sc * (Cf[0][0] * Cf[0][1] + Cf[1][0] * Cf[1][1] + Cf[2][0] * Cf[2][1]);
-      Dq[2 * 64 + lane] = sc * (Cf[0][0] * Cf[0][2] + Cf[1][0] * Cf[1][2] + Cf[2][0] * Cf[2][2]);
-      Dq[3 * 64 + lane] = sc * (Cf[0][1] * Cf[0][1] + Cf[1][1] * Cf[1][1] + Cf[2][1] * Cf[2][1]);
-      Dq[4 * 64 + lane] = sc * (Cf[0][1] * Cf[0][2] + Cf[1][1] * Cf[1][2] + Cf[2][1] * Cf[2][2]);
-      Dq[5 * 64 + lane] = sc * (Cf[0][2] * Cf[0][2] + Cf[1][2] * Cf[1][2] + Cf[2][2] * Cf[2][2]);
-      Dq[6 * 64 + lane] = det * wgauss * fq;
+      Dr[0] = sc * (Cf[0][0] * Cf[0][0] + Cf[1][0] * Cf[1][0] + Cf[2][0] * Cf[2][0]);
+      Dr[1] = sc * (Cf[0][0] * Cf[0][1] + Cf[1][0] * Cf[1][1] + Cf[2][0] * Cf[2][1]);
+      Dr[2] = sc * (Cf[0][0] * Cf[0][2] + Cf[1][0] * Cf[1][2] + Cf[2][0] * Cf[2][2]);
+      Dr[3] = sc * (Cf[0][1] * Cf[0][1] + Cf[1][1] * Cf[1][1] + Cf[2][1] * Cf[2][1]);
+      Dr[4] = sc * (Cf[0][1] * Cf[0][2] + Cf[1][1] * Cf[1][2] + Cf[2][1] * Cf[2][2]);
+      Dr[5] = sc * (Cf[0][2] * Cf[0][2] + Cf[1][2] * Cf[1][2] + Cf[2][2] * Cf[2][2]);
+      Dr[6] = det * wgauss * fq;
     }
     wave_lds_sync();
     double Kb[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     double fsrc = 0.0;
     if (!(P.debug & 1)) {
-      // ---- stage 1: lane = (q1, q2, c), contracts q3 ----
+      // ---- stage 1: contracts q3 on the FP64 matrix cores.  The Gauss points sit on the lanes as 16 q3 + 4 q1 + q2, which is
+      //      the B-operand layout of v_mfma_f64_4x4x4_4b (lane = 16 k + 4 block + column) with k = q3, block = q1, column = q2: D_q
+      //      is used where phase A left it.  A (lane = 16 k + 4 block + row) = the products l_c l_c', l_c l'_c', l'_c l'_c' at abscissa
+      //      k for four (c, c') slots (per-lane constants, the same for every block); the result lane 16 row + 4 q1 + q2 holds
+      //      e[slot][q1][q2].  Symmetric arrays (e0, e1, e3, e5) keep the six slots c <= c' (two instructions of four), e2 and e4 the
+      //      nine slots c*3 + c' (three); one more instruction contracts the source.  15 matrix instructions replace 100 vector ones,
+      //      the LDS round trip of D_q and a cross-lane sum over q3. ----
       {
-        const double* dq = Dq + (lane >> 2) * 4;
-        double t[6][4], s4[4], zl[4], zd[4];
+        double* eo = R + eout;
+        constexpr int EB[6] = {0, 8 * SF_ES, 16 * SF_ES, 28 * SF_ES, 36 * SF_ES, 48 * SF_ES};
 #pragma unroll
-        for (int q = 0; q < 4; q++) { zl[q] = SF_C(19 + q); zd[q] = SF_C(23 + q); }
+        for (int kk = 0; kk < 6; kk++) {
+          const int ng = (kk == 2 || kk == 4) ? 3 : 2;
+          const int a0 = (kk == 2 || kk == 4) ? 2 : kk == 5 ? 5 : 0;      // first constant vector: LL 0,1  LD 2,3,4  DD 5,6
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-          sf_ld4(dq + k * 64, t[k]);
-#pragma unroll
-          for (int q = 0; q < 4; q++) t[k][q] *= (k == 5) ? zd[q] : zl[q];
+          for (int g = 0; g < ng; g++) {
+            const double za = REGC ? rcZ[a0 + g] : SF_C(19 + a0 + g);
+            eo[EB[kk] + 4 * g * SF_ES] = __builtin_amdgcn_mfma_f64_4x4x4f64(za, Dr[kk], 0.0, 0, 0, 0);
+          }
         }
-        sf_ld4(dq + 6 * 64, s4);
-        const int c = min(lane & 3, 2);           // lanes with c = 3 repeat c = 2 (their table rows are those of c = 2)
-        double* eo = R + c * 3 * SF_ES + (lane >> 2);
-        {
-#pragma unroll
-          for (int k = 0; k < 6; k++)
-#pragma unroll
-            for (int c2 = 0; c2 < 3; c2++) {
-              const double* z = (k == 2 || k == 4 || k == 5) ? tab.D[c2] : tab.L[c2];
-              eo[(k * 9 + c2) * SF_ES] = t[k][0] * z[0] + t[k][1] * z[1] + t[k][2] * z[2] + t[k][3] * z[3];
-            }
-          R[SF_NE + c * 16 + (lane >> 2)] = s4[0] * zl[0] + s4[1] * zl[1] + s4[2] * zl[2] + s4[3] * zl[3];
-        }
+        const double zs = REGC ? rcZ[7] : SF_C(26);
+        R[SF_NE + lane] = __builtin_amdgcn_mfma_f64_4x4x4f64(zs, Dr[6], 0.0, 0, 0, 0);      // sE[c][q1*4 + q2], c = lane >> 4
       }
       wave_lds_sync();
       // ---- source, second contraction: lane = (q1, b, c), contracts q2 ----
       {
         double s4[4];
-        sf_ld4(R + SF_NE + SF_I(16), s4);
-        R[SF_NE + 48 + SF_I(17)] = s4[0] * SF_C(43) + s4[1] * SF_C(44) + s4[2] * SF_C(45) + s4[3] * SF_C(46);
+        sf_ld4(R + SF_NE + SF_I(10), s4);
+        R[SF_NE + 64 + SF_I(11)] = s4[0] * SF_C(43) + s4[1] * SF_C(44) + s4[2] * SF_C(45) + s4[3] * SF_C(46);
       }
       // ---- stages 2 and 3: lane = pair {(b,c), (b',c')}; per q1: contract q2 into the four G values, then add their part of the
       //      3 x 3 block over (a, a').  The loop is NOT unrolled: one iteration's operands are all that is live. ----
       {
-        const double* e0 = R + SF_I(7);
-        const double* eT = R + SF_I(8);
+        const double* es = R + esym;      // symmetric arrays: slot of (min(c,c'), max(c,c'))
+        const double* en = R + ens;       // e2, e4: slot c*3 + c'
+        const double* eT = R + ensT;      //         slot c'*3 + c
         double yLL[4], yLD[4], yDL[4], yDD[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { yLL[q] = SF_C(27 + q); yLD[q] = SF_C(31 + q); yDL[q] = SF_C(35 + q); yDD[q] = SF_C(39 + q); }
+        for (int q = 0; q < 4; q++) {
+          yLL[q] = REGC ? rcY[q] : SF_C(27 + q); yLD[q] = REGC ? rcY[4 + q] : SF_C(31 + q);
+          yDL[q] = REGC ? rcY[8 + q] : SF_C(35 + q); yDD[q] = REGC ? rcY[12 + q] : SF_C(39 + q);
+        }
 #pragma unroll 1
         for (int q1 = 0; q1 < 4; q1++) {
-          double v0[4], v1[4], v2[4], v2T[4], v3[4], v4[4], v4T[4], v5[4];
-          sf_ld4(e0 + 0 * 9 * SF_ES + q1 * 4, v0);
-          sf_ld4(e0 + 1 * 9 * SF_ES + q1 * 4, v1);
-          sf_ld4(e0 + 2 * 9 * SF_ES + q1 * 4, v2);
-          sf_ld4(eT + 2 * 9 * SF_ES + q1 * 4, v2T);
-          sf_ld4(e0 + 3 * 9 * SF_ES + q1 * 4, v3);
-          sf_ld4(e0 + 4 * 9 * SF_ES + q1 * 4, v4);
-          sf_ld4(eT + 4 * 9 * SF_ES + q1 * 4, v4T);
-          sf_ld4(e0 + 5 * 9 * SF_ES + q1 * 4, v5);
           double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;     // G for (l'l'), (l'l), (ll'), (ll)
+          {
+            double v0[4], v1[4], v2[4], v2T[4];
+            sf_ld4(es + 0 * SF_ES + q1 * 4, v0);
+            sf_ld4(es + 8 * SF_ES + q1 * 4, v1);
+            sf_ld4(en + 16 * SF_ES + q1 * 4, v2);
+            sf_ld4(eT + 16 * SF_ES + q1 * 4, v2T);
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            g0 += yLL[q] * v0[q];
-            g1 += yLD[q] * v1[q]; g1 += yLL[q] * v2[q];
-            g2 += yDL[q] * v1[q]; g2 += yLL[q] * v2T[q];
-            g3 += yDD[q] * v3[q]; g3 += yDL[q] * v4[q]; g3 += yLD[q] * v4T[q]; g3 += yLL[q] * v5[q];
+            for (int q = 0; q < 4; q++) {
+              g0 += yLL[q] * v0[q];
+              g1 += yLD[q] * v1[q]; g1 += yLL[q] * v2[q];
+              g2 += yDL[q] * v1[q]; g2 += yLL[q] * v2T[q];
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);         // the second half's operands are loaded after the first half is done with its own
+          {
+            double v3[4], v4[4], v4T[4], v5[4];
+            sf_ld4(es + 28 * SF_ES + q1 * 4, v3);
+            sf_ld4(en + 36 * SF_ES + q1 * 4, v4);
+            sf_ld4(eT + 36 * SF_ES + q1 * 4, v4T);
+            sf_ld4(es + 48 * SF_ES + q1 * 4, v5);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { g3 += yDD[q] * v3[q]; g3 += yDL[q] * v4[q]; g3 += yLD[q] * v4T[q]; g3 += yLL[q] * v5[q]; }
           }
           const double l0 = tab.L[0][q1], l1 = tab.L[1][q1], l2 = tab.L[2][q1], d0 = tab.D[0][q1], d1 = tab.D[1][q1], d2 = tab.D[2][q1];
           const double la[3] = {l0, l1, l2}, da[3] = {d0, d1, d2};
@@ -1435,61 +1467,69 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab ta
       wave_lds_sync();
       {
         double s4[4];
-        sf_ld4(R + SF_NE + 48 + SF_I(18), s4);
+        sf_ld4(R + SF_NE + 64 + SF_I(12), s4);
         fsrc = s4[0] * SF_C(47) + s4[1] * SF_C(48) + s4[2] * SF_C(49) + s4[3] * SF_C(50);
       }
     }
-    wave_lds_sync();          // every lane is done with e: reuse it as Ks[27][29]
+    wave_lds_sync();          // every lane is done with e: reuse it as the staging Ks[27][29], rows AND columns in tensor order
     double* Ks = R;
     {
-      // no divergent branch: lanes 45..63 repeat the last pair; on a diagonal pair (kind 2) the upper entries go to both places
-      const bool diag = SF_I(15) == 2;
-      int ri[3], cj[3];
-#pragma unroll
-      for (int a = 0; a < 3; a++) { ri[a] = SF_I(9 + a); cj[a] = SF_I(12 + a); }
+      // lane (p, p2) holds K[(a,p)][(a2,p2)]: entry (a*9 + p, a2*9 + p2) and its mirror; on a diagonal pair the upper entries go to
+      // both places (K_e symmetric bit for bit).  Immediate offsets only; lanes 45..63 repeat the last pair.
+      double* kd = Ks + based;       // p * KS + p2
+      double* km = Ks + basem;       // p2 * KS + p
 #pragma unroll
       for (int a = 0; a < 3; a++)
 #pragma unroll
         for (int a2 = 0; a2 < 3; a2++) {
           const double v = (a2 < a) ? (diag ? Kb[a2][a] : Kb[a][a2]) : Kb[a][a2];
-          Ks[ri[a] * MF_KS + cj[a2]] = v;
-          Ks[cj[a2] * MF_KS + ri[a]] = v;
+          kd[a * 9 * KS + a2 * 9] = v;
+          km[a2 * 9 * KS + a * 9] = v;
         }
     }
     wave_lds_sync();
     double ku = 0.0;
-    if (P.sol) {              // residual: (K_e u)_i, lanes i = lane&31, half of the columns each
-      const int i = min(lane & 31, NC - 1), h = lane >> 5;
+    if (P.sol) {              // residual: (K_e u)_i for node i = lane & 31 (row tofl), half of the columns each
+      const int h = lane >> 5;
+      const double* kr = Ks + tofl * KS + h * 14;
+      const double* ur = xt + 84 + h * 14;
 #pragma unroll
       for (int g = 0; g < 14; g++) {
-        const int j = h * 14 + g;
-        const double v = (j < NC) ? Ks[i * MF_KS + min(j, NC - 1)] : 0.0;
-        ku += v * xs[min(j, NC - 1) * 4 + 3];
+        const bool live = g < 13 || h == 0;          // tensor column h*14 + g < 27
+        const double v = live ? kr[g] : 0.0, uu = live ? ur[g] : 0.0;
+        ku += v * uu;
       }
       ku += __shfl_xor(ku, 32, 64);
     }
     if (lane < NC) {          // the next element's nodes (see k_elem_q2hex_mfma)
-      xs[lane * 4 + 0] = nx0;
-      xs[lane * 4 + 1] = nx1;
-      xs[lane * 4 + 2] = nx2;
-      xs[lane * 4 + 3] = nu;
+      xt[tofl] = nx0;
+      xt[28 + tofl] = nx1;
+      xt[56 + tofl] = nx2;
+      xt[84 + tofl] = nu;
     }
     if (!(P.debug & 2)) {
-      if (P.kstride >= 28) {
+      if (PAD) {               // P.kstride >= 28
+        // half-wave h stores the tensor rows h*14 + p, lane j = lane & 31 the column of NODE j (tensor column tofl): one whole
+        // 256-byte row per half-wave and store off a scalar base address.  The reads are issued by hand: left to the compiler, pairs
+        // of them become ds_read2_b64 (8 LDS cycles instead of 2 + 2).
         const int j = lane & 31, hrow = lane >> 5;
         const unsigned joff = (unsigned)j * 8u;
+        const unsigned kva = (unsigned)(size_t)(__attribute__((address_space(3))) double*)(Ks + hrow * 14 * KS + tofl);
         double kv[14];
 #pragma unroll
-        for (int p = 0; p < 14; p++) kv[p] = Ks[min(2 * p + hrow, NC - 1) * MF_KS + j];
+        for (int p = 0; p < 14; p++) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(kv[p]) : "v"(kva), "n"(p * KS * 8) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]), "+v"(kv[4]), "+v"(kv[5]), "+v"(kv[6]), "+v"(kv[7]),
+                     "+v"(kv[8]), "+v"(kv[9]), "+v"(kv[10]), "+v"(kv[11]), "+v"(kv[12]), "+v"(kv[13]));
 #pragma unroll
         for (int p = 0; p < 14; p++) {
-          const int s0 = __builtin_amdgcn_readlane(sl_cur, 2 * p), s1 = __builtin_amdgcn_readlane(sl_cur, min(2 * p + 1, NC - 1));
+          const int n0 = __builtin_amdgcn_readlane(nodeofl, p), n1 = __builtin_amdgcn_readlane(nodeofl, min(14 + p, NC - 1));
+          const int s0 = __builtin_amdgcn_readlane(sl_cur, n0), s1 = __builtin_amdgcn_readlane(sl_cur, n1);
           const double* b0 = P.Kout + (size_t)s0 * P.kstride;
           const double* b1 = P.Kout + (size_t)s1 * P.kstride;
           if (j >= P.kstride) continue;
           if (hrow == 0) {
             if (s0 >= 0) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(joff), "v"(kv[p]), "s"(b0) : "memory");
-          } else if (2 * p + 1 < NC) {
+          } else if (14 + p < NC) {
             if (s1 >= 0) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(joff), "v"(kv[p]), "s"(b1) : "memory");
           }
         }
@@ -1500,12 +1540,13 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab ta
           const int row = (t < NC * NC) ? t / NC : 0;
           const int j = t - row * NC;
           const int s = __shfl(sl_cur, row, 64);
-          if (t < NC * NC && s >= 0) P.Kout[(size_t)s * NC + j] = Ks[row * MF_KS + j];
+          const int tr = __shfl(tofl, row, 64), tj = __shfl(tofl, j, 64);
+          if (t < NC * NC && s >= 0) P.Kout[(size_t)s * NC + j] = Ks[tr * KS + tj];
         }
       }
       if (lane < NC && sl_cur >= 0) P.Fout[sl_cur] = -(ku + fsrc);
     }
-    wave_lds_sync();          // Ks is the next element's phase-A scratch, xs holds the next element's nodes
+    wave_lds_sync();          // Ks is the next element's phase-A scratch, xt holds the next element's nodes
     sl_cur = sl_n;
     dof_n = dof_nn;
     e_n = e_nn;
@@ -1513,37 +1554,44 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab ta
   }
 #undef SF_I
 #undef SF_C
+#undef SF_CA
 }
 
-template <int SRC, int NW>
+template <int SRC, int NW, bool PAD>
 static int launch_sf_one(fh_assembler_t as, const AsmParams& P) {
   constexpr size_t lds = sf_lds_bytes(NW);
   static_assert(lds <= 160 * 1024, "k_elem_q2hex_sf: LDS budget");
   static bool attr_set[64] = {};
   const int dev = as->ctx->device & 63;
   if (!attr_set[dev]) {
-    FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_elem_q2hex_sf<SRC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_elem_q2hex_sf<SRC, NW, PAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set[dev] = true;
   }
   const int per_cu = std::max(1, (int)((size_t)160 * 1024 / lds));
   const int grid = std::max(1, std::min(fh_div_up(P.nelems, NW), as->ctx->num_cu * per_cu));
-  hipLaunchKernelGGL((k_elem_q2hex_sf<SRC, NW>), dim3(grid), dim3(NW * 64), lds, as->ctx->stream, P, as->sf_tab, as->d_sfLc, as->d_sfLi);
+  hipLaunchKernelGGL((k_elem_q2hex_sf<SRC, NW, PAD>), dim3(grid), dim3(NW * 64), lds, as->ctx->stream, P, as->sf_tab, as->d_sfLc, as->d_sfLi);
   FH_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-template <int SRC>
+template <int SRC, bool PAD>
 static int launch_sf_src(fh_assembler_t as, const AsmParams& P, int nw) {
-  if (nw <= 4) return launch_sf_one<SRC, 4>(as, P);
-  if (nw <= 5) return launch_sf_one<SRC, 5>(as, P);
-  if (nw <= 8) return launch_sf_one<SRC, 8>(as, P);
-  return launch_sf_one<SRC, 10>(as, P);
+  if (nw <= 4) return launch_sf_one<SRC, 4, PAD>(as, P);
+  if (nw <= 8) return launch_sf_one<SRC, 8, PAD>(as, P);
+  if (nw <= 10) return launch_sf_one<SRC, 10, PAD>(as, P);
+  if (nw <= 12) return launch_sf_one<SRC, 12, PAD>(as, P);
+  return launch_sf_one<SRC, 13, PAD>(as, P);
 }
 
 static int launch_sf(fh_assembler_t as, const AsmParams& P, int nw) {
-  if (P.source_kind == 4) return launch_sf_src<2>(as, P, nw);
-  if (P.source_kind != 0) return launch_sf_src<1>(as, P, nw);
-  return launch_sf_src<0>(as, P, nw);
+  if (P.kstride >= 28) {
+    if (P.source_kind == 4) return launch_sf_src<2, true>(as, P, nw);
+    if (P.source_kind != 0) return launch_sf_src<1, true>(as, P, nw);
+    return launch_sf_src<0, true>(as, P, nw);
+  }
+  if (P.source_kind == 4) return launch_sf_src<2, false>(as, P, nw);
+  if (P.source_kind != 0) return launch_sf_src<1, false>(as, P, nw);
+  return launch_sf_src<0, false>(as, P, nw);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1881,57 +1929,66 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
         }
         FH_TRY(up((void**)&as->d_mfSFc, sfc.data(), sfc.size() * sizeof(double)));
         FH_TRY(up((void**)&as->d_mfSFi, sfi.data(), sfi.size() * sizeof(int)));
-        // tables of the sum-factorised element kernel (lane roles: see k_elem_q2hex_sf)
+        // tables of the sum-factorised element kernel (lane roles: see k_elem_q2hex_sf); lanes beyond a stage's role count repeat
+        // its last role, so that the kernel needs no divergent branch
         {
           std::vector<double> lc((size_t)SF_NLC * 64, 0.0);
           std::vector<int> li((size_t)SF_NLI * 64, 0);
-          int gof[64];
+          int gof[64], tof[27];
           for (int g = 0; g < 64; g++) gof[qidx[g][0] * 16 + qidx[g][1] * 4 + qidx[g][2]] = g;
+          for (int t = 0; t < 27; t++) tof[nodeof[t]] = t;        // nodeof[a*9 + b*3 + c] = node; tof = its inverse
           for (int a = 0; a < 3; a++)
             for (int k = 0; k < 4; k++) { as->sf_tab.L[a][k] = L1[a][k]; as->sf_tab.D[a][k] = D1[a][k]; }
           int pr[64][2], np = 0;
           for (int p = 0; p < 9; p++)
             for (int p2 = p; p2 < 9; p2++) { pr[np][0] = p; pr[np][1] = p2; np++; }
           for (int l = 0; l < 64; l++) {
-            {                                              // phase A stage 1 and source stage 2: lane = (q1, b, c); lanes >= 36 repeat lane 35
+            {                                              // phase A stage 1 and source stage 2: lane = (q1, b, c)
               const int lr = std::min(l, 35), q1 = lr & 3, bc = lr >> 2, b = bc / 3, c = bc % 3;
               for (int a = 0; a < 3; a++) {
                 lc[(size_t)a * 64 + l] = L1[a][q1];
                 lc[(size_t)(3 + a) * 64 + l] = D1[a][q1];
-                li[(size_t)a * 64 + l] = nodeof[a * 9 + b * 3 + c] * 4;
               }
-              li[(size_t)3 * 64 + l] = ((b * 3 + c) * 4 + q1) * 4;
+              li[(size_t)0 * 64 + l] = bc;
+              li[(size_t)1 * 64 + l] = lr;
               for (int k = 0; k < 4; k++) lc[(size_t)(43 + k) * 64 + l] = L1[b][k];
-              li[(size_t)16 * 64 + l] = c * 16 + q1 * 4;
-              li[(size_t)17 * 64 + l] = (b * 3 + c) * 4 + q1;
+              li[(size_t)10 * 64 + l] = c * 16 + q1 * 4;
+              li[(size_t)11 * 64 + l] = (b * 3 + c) * 4 + q1;
             }
-            {                                              // phase A stage 2: lane = (c, q1, q2); lanes >= 48 repeat lane 47
+            {                                              // phase A stage 2: lane = (c, q1, q2)
               const int lr = std::min(l, 47), c2 = lr >> 4, q12 = lr & 15, q1 = q12 & 3, q2 = q12 >> 2;
               for (int b = 0; b < 3; b++) {
                 lc[(size_t)(6 + b) * 64 + l] = L1[b][q2];
                 lc[(size_t)(9 + b) * 64 + l] = D1[b][q2];
               }
-              li[(size_t)4 * 64 + l] = (c2 * 4 + q1) * 4;
-              li[(size_t)5 * 64 + l] = (c2 * 16 + q12) * 4;
+              li[(size_t)2 * 64 + l] = c2 * 4 + q1;
+              li[(size_t)3 * 64 + l] = lr;
             }
-            {                                              // phase A stage 3: lane = Gauss point in tensor order
-              const int q1 = l >> 4, q2 = (l >> 2) & 3, q3 = l & 3;
+            {                                              // phase A stage 3: lane = Gauss point, 16 q3 + 4 q1 + q2 (the B-operand layout of stage 1)
+              const int q3 = l >> 4, q1 = (l >> 2) & 3, q2 = l & 3;
               for (int c = 0; c < 3; c++) {
                 lc[(size_t)(12 + c) * 64 + l] = L1[c][q3];
                 lc[(size_t)(15 + c) * 64 + l] = D1[c][q3];
               }
-              li[(size_t)6 * 64 + l] = (q1 + 4 * q2) * 4;
-              lc[(size_t)18 * 64 + l] = w[gof[l]];
+              li[(size_t)4 * 64 + l] = q1 + 4 * q2;
+              lc[(size_t)18 * 64 + l] = w[gof[q1 * 16 + q2 * 4 + q3]];
             }
-            {                                              // stage 1: lane = (q1, q2, c)
-              const int c = std::min(l & 3, 2);         // c = 3 repeats c = 2
-              for (int k = 0; k < 4; k++) {
-                lc[(size_t)(19 + k) * 64 + l] = L1[c][k];
-                lc[(size_t)(23 + k) * 64 + l] = D1[c][k];
+            {                                              // stage 1, A operands: lane = 16 k + 4 block + row, k = q3; eight vectors of four slots
+              const int k = l >> 4, r = l & 3;
+              static const int symc[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
+              for (int g = 0; g < 2; g++) {
+                const int sl = 4 * g + r;
+                lc[(size_t)(19 + g) * 64 + l] = sl < 6 ? L1[symc[sl][0]][k] * L1[symc[sl][1]][k] : 0.0;      // l_c l_c'
+                lc[(size_t)(24 + g) * 64 + l] = sl < 6 ? D1[symc[sl][0]][k] * D1[symc[sl][1]][k] : 0.0;      // l'_c l'_c'
               }
+              for (int g = 0; g < 3; g++) {
+                const int sl = 4 * g + r;
+                lc[(size_t)(21 + g) * 64 + l] = sl < 9 ? L1[sl / 3][k] * D1[sl % 3][k] : 0.0;                // l_c l'_c'
+              }
+              lc[(size_t)26 * 64 + l] = r < 3 ? L1[r][k] : 0.0;                                              // source: l_c
             }
             {                                              // stages 2, 3: lane = unordered pair {(b,c), (b',c')}
-              const int lr = std::min(l, np - 1);       // lanes >= 45 repeat the last pair
+              const int lr = std::min(l, np - 1);
               const int p = pr[lr][0], p2 = pr[lr][1];
               const int b = p / 3, c = p % 3, b2 = p2 / 3, c2 = p2 % 3;
               for (int k = 0; k < 4; k++) {
@@ -1940,19 +1997,24 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
                 lc[(size_t)(35 + k) * 64 + l] = D1[b][k] * L1[b2][k];
                 lc[(size_t)(39 + k) * 64 + l] = D1[b][k] * D1[b2][k];
               }
-              li[(size_t)7 * 64 + l] = (c * 3 + c2) * SF_ES;
-              li[(size_t)8 * 64 + l] = (c2 * 3 + c) * SF_ES;
-              for (int a = 0; a < 3; a++) {
-                li[(size_t)(9 + a) * 64 + l] = nodeof[a * 9 + b * 3 + c];
-                li[(size_t)(12 + a) * 64 + l] = nodeof[a * 9 + b2 * 3 + c2];
+              {
+                const int cl = std::min(c, c2), ch = std::max(c, c2);
+                const int symslot = cl == 0 ? ch : cl == 1 ? 2 + ch : 5;          // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+                li[(size_t)5 * 64 + l] = symslot * SF_ES;
               }
-              li[(size_t)15 * 64 + l] = p == p2 ? 2 : 1;
+              li[(size_t)6 * 64 + l] = (c * 3 + c2) * SF_ES;
+              li[(size_t)15 * 64 + l] = (c2 * 3 + c) * SF_ES;
+              li[(size_t)7 * 64 + l] = p * MF_KS + p2;
+              li[(size_t)8 * 64 + l] = p2 * MF_KS + p;
+              li[(size_t)9 * 64 + l] = p == p2 ? 1 : 0;
             }
-            {                                              // source stage 3: lane = node; lanes >= 27 repeat node 26
-              const int n = std::min(l, 26);
+            {                                              // source stage 3, K_e u, row stores: node l & 31 (clamped to 26)
+              const int n = std::min(l & 31, 26);
               const int a = fhfe::xc(geom, n, 0) + 1, b = fhfe::xc(geom, n, 1) + 1, c = fhfe::xc(geom, n, 2) + 1;
               for (int k = 0; k < 4; k++) lc[(size_t)(47 + k) * 64 + l] = L1[a][k];
-              li[(size_t)18 * 64 + l] = (b * 3 + c) * 4;
+              li[(size_t)12 * 64 + l] = (b * 3 + c) * 4;
+              li[(size_t)13 * 64 + l] = tof[n];
+              li[(size_t)14 * 64 + l] = nodeof[std::min(l, 26)];
             }
           }
           FH_TRY(up((void**)&as->d_sfLc, lc.data(), lc.size() * sizeof(double)));

@@ -1,0 +1,20 @@
+# PMC passes over the fine-level assembly with the sum-factorised element kernel (k_elem_q2hex_sf) and the row pass: one counter set
+# per pass, kernel trace only.     bash tests/pmc_sf.sh [nw] [out.md]      (on the GPU box)
+NW=${1:-8}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=${2:-$ROOT/gpurun_out/sf_pmc_summary.md}
+mkdir -p $(dirname $OUT)
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/pmcsf; mkdir -p /tmp/pmcsf
+i=0
+for set in "SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64" \
+           "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" \
+           "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
+           "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" \
+           "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_INSTS_FLAT" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmcsf/p$i -- python $ROOT/tests/perf_probe_sf.py $NW > /tmp/pmcsf/log$i.txt 2>&1 || echo "pass $i failed"
+done
+python $ROOT/profiles/summarize.py /tmp/pmcsf $OUT | grep "k_elem_q2hex_sf\|k_row_assemble"
