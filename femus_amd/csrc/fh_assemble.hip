@@ -44,6 +44,7 @@ struct fh_assembler_s {
   int* d_slot = nullptr;         // [nel*nc] adjacency slot of (element, local row), -1 when the row is not in the matrix
   double* d_Kbuf = nullptr;      // [nadj*kstride] element rows in row-gather order
   size_t kbuf_bytes = 0;
+  int nadj = 0;                  // element rows in d_Kbuf; row nadj is the spare one
   int kstride = 27;              // doubles per element row in d_Kbuf (nc, or 32 for HEX27/Q2: whole 64-byte lines per row)
   double* d_Fbuf = nullptr;      // [nadj]
   bool two_pass = false;
@@ -97,6 +98,7 @@ struct AsmParams {
   const int* slot;         // non-null with Kout: row i of element e goes to Kout[slot[e*nc+i]*nc + j] (row-gather order), -1 = skip
   double* Kout;            // non-null: write element matrices [e][nc][nc] instead of scattering
   int kstride;             // doubles per element row in Kout (nc; 32 = padded rows of the slot-major buffer)
+  int nsink;               // index of the spare row behind the slot-major buffer (rows the matrix does not hold)
   double* Fout;
 };
 
@@ -1211,7 +1213,7 @@ constexpr int SF_R = SF_NE + 64 + 36;        // e, sE[4][16], sF[9][4]; phase A'
 constexpr int SF_US = 40, SF_VS = 48;        // phase A: U[2][3][SF_US] then V[3][3][SF_VS], one array per coordinate (conflict-free)
 constexpr int SF_XT = 4 * 28;                // per wave: x, y, z and u of the element's nodes, 28 doubles each, in TENSOR order a*9 + b*3 + c
 constexpr int SF_WAVE = SF_XT + SF_R;   // 1220 doubles per wave (even: 16-byte alignment is kept)
-constexpr int SF_NLC = 51, SF_NLI = 16;      // rows of the per-lane tables (layout: fh_assembler_create)
+constexpr int SF_NLC = 51, SF_NLI = 18;      // rows of the per-lane tables (layout: fh_assembler_create)
 constexpr int SF_TAB = SF_NLC * 64 + SF_NLI * 32;   // doubles: both tables, shared by the waves of the workgroup
 constexpr size_t sf_lds_bytes(int nw) { return (size_t)(SF_TAB + nw * SF_WAVE) * sizeof(double); }
 static_assert(SF_R >= MF_SLAB && SF_R >= 6 * SF_US + 9 * SF_VS, "k_elem_q2hex_sf: region R holds the staging and phase A's U, V");
@@ -1255,9 +1257,12 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab ta
   const int esym = lanei[5 * 64 + lane], ens = lanei[6 * 64 + lane], ensT = lanei[15 * 64 + lane], based = lanei[7 * 64 + lane], basem = lanei[8 * 64 + lane];
   const int eout = (lane >> 4) * SF_ES + (lane & 15);
   const bool diag = lanei[9 * 64 + lane] != 0;
-  const int tofl = lanei[13 * 64 + lane];              // tensor index of node min(lane, 26)
+  // Lanes 0..26 stand for the element's nodes in TENSOR order t = a*9 + b*3 + c (node nodeofl): coordinates, solution values, output
+  // slots and the residual entries live on lane t.
+  const int tofl = lanei[13 * 64 + lane];              // tensor index of node min(lane & 31, 26)  (PAD = false: rows in node order)
   const int nodeofl = lanei[14 * 64 + lane];           // node of tensor index min(lane, 26)
-  const int ln = lane < NC ? lane : 0;
+  const size_t rowbytes = (size_t)P.kstride * sizeof(double);
+  const size_t sink = (size_t)P.nsink * rowbytes;      // rows the matrix does not hold (slot < 0) go to a spare row behind the buffer
   const fh_ciptr elems = (fh_ciptr)P.elems;
   const int stride = gridDim.x * NW;
   const int idx0 = blockIdx.x * NW + wave;
@@ -1265,25 +1270,27 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab ta
   const int last = P.nelems - 1;
   int e_cur = elems[idx0];
   int e_n = elems[min(idx0 + stride, last)], e_nn = elems[min(idx0 + 2 * stride, last)];
-  int sl_cur = (lane < NC) ? (P.slot ? P.slot[(size_t)e_cur * NC + lane] : idx0 * NC + lane) : -1;
+  int sl_cur = (lane < NC) ? (P.slot ? P.slot[(size_t)e_cur * NC + nodeofl] : idx0 * NC + nodeofl) : -1;
+  size_t ro_cur = sl_cur < 0 ? sink : (size_t)sl_cur * rowbytes;
   {
-    const int dof = P.elem_dof[(size_t)e_cur * P.nloc + ln];
+    const int dof = P.elem_dof[(size_t)e_cur * P.nloc + nodeofl];
     if (lane < NC) {
-      xt[tofl] = P.coords[(size_t)dof * DIM];
-      xt[28 + tofl] = P.coords[(size_t)dof * DIM + 1];
-      xt[56 + tofl] = P.coords[(size_t)dof * DIM + 2];
-      xt[84 + tofl] = P.sol ? P.sol[dof] : 0.0;
+      xt[lane] = P.coords[(size_t)dof * DIM];
+      xt[28 + lane] = P.coords[(size_t)dof * DIM + 1];
+      xt[56 + lane] = P.coords[(size_t)dof * DIM + 2];
+      xt[84 + lane] = P.sol ? P.sol[dof] : 0.0;
     }
   }
-  int dof_n = P.elem_dof[(size_t)e_n * P.nloc + ln];
+  int dof_n = P.elem_dof[(size_t)e_n * P.nloc + nodeofl];
+  asm volatile("" : "+v"(dof_n), "+v"(sl_cur));      // nothing pending at the loop head (see the note before the stores)
   wave_lds_sync();
 #pragma unroll 1
   for (int idx = idx0; idx < P.nelems; idx += stride) {
     // ---- prefetch: node ids two elements ahead, coordinates / solution / slots one element ahead (dependent gathers) ----
     const double nx0 = P.coords[(size_t)dof_n * DIM], nx1 = P.coords[(size_t)dof_n * DIM + 1], nx2 = P.coords[(size_t)dof_n * DIM + 2];
     const double nu = P.sol ? P.sol[dof_n] : 0.0;
-    const int sl_n = (lane < NC) ? (P.slot ? P.slot[(size_t)e_n * NC + lane] : (idx + stride) * NC + lane) : -1;
-    const int dof_nn = P.elem_dof[(size_t)e_nn * P.nloc + ln];
+    const int sl_n = (lane < NC) ? (P.slot ? P.slot[(size_t)e_n * NC + nodeofl] : (idx + stride) * NC + nodeofl) : -1;
+    const int dof_nn = P.elem_dof[(size_t)e_nn * P.nloc + nodeofl];
     const int e_nnn = elems[min(idx + 3 * stride, last)];
     double Dr[7];            // D_q (six entries) and the source weight at this lane's Gauss point
     // ---- phase A: J_q by three contractions through LDS (U, V alias region R; one array per coordinate, every access is
@@ -1467,7 +1474,7 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab ta
       wave_lds_sync();
       {
         double s4[4];
-        sf_ld4(R + SF_NE + 64 + SF_I(12), s4);
+        sf_ld4(R + SF_NE + 64 + SF_I(16), s4);
         fsrc = s4[0] * SF_C(47) + s4[1] * SF_C(48) + s4[2] * SF_C(49) + s4[3] * SF_C(50);
       }
     }
@@ -1489,9 +1496,9 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab ta
     }
     wave_lds_sync();
     double ku = 0.0;
-    if (P.sol) {              // residual: (K_e u)_i for node i = lane & 31 (row tofl), half of the columns each
+    if (P.sol) {              // residual: (K_e u)_t for tensor row t = lane & 31, half of the columns each
       const int h = lane >> 5;
-      const double* kr = Ks + tofl * KS + h * 14;
+      const double* kr = Ks + min(lane & 31, NC - 1) * KS + h * 14;
       const double* ur = xt + 84 + h * 14;
 #pragma unroll
       for (int g = 0; g < 14; g++) {
@@ -1501,36 +1508,53 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab ta
       }
       ku += __shfl_xor(ku, 32, 64);
     }
-    if (lane < NC) {          // the next element's nodes (see k_elem_q2hex_mfma)
-      xt[tofl] = nx0;
-      xt[28 + tofl] = nx1;
-      xt[56 + tofl] = nx2;
-      xt[84 + tofl] = nu;
+    if (lane < NC) {          // the next element's nodes
+      xt[lane] = nx0;
+      xt[28 + lane] = nx1;
+      xt[56 + lane] = nx2;
+      xt[84 + lane] = nu;
     }
+    // Every prefetched value is consumed HERE, before this element's stores are issued: the compiler does not see the hand-written
+    // stores in its wait-count bookkeeping, and a vmcnt wait placed after them (for a load issued before them) would also wait for
+    // all 27 row stores to reach the L2 -- once per element, at the loop head.  The residual entries go first for the same reason.
+    size_t ro_n = sl_n < 0 ? sink : (size_t)sl_n * rowbytes;
+    int dof_nn_c = dof_nn;
+    asm volatile("" : "+v"(ro_n), "+v"(dof_nn_c));
     if (!(P.debug & 2)) {
+      if (lane < NC && sl_cur >= 0) {     // by hand as well: a store the compiler tracks makes it wait for vmcnt(0) at the loop head
+        const double fv = -(ku + fsrc);
+        double* fp = P.Fout + sl_cur;
+        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(fp), "v"(fv) : "memory");
+      }
       if (PAD) {               // P.kstride >= 28
-        // half-wave h stores the tensor rows h*14 + p, lane j = lane & 31 the column of NODE j (tensor column tofl): one whole
-        // 256-byte row per half-wave and store off a scalar base address.  The reads are issued by hand: left to the compiler, pairs
-        // of them become ds_read2_b64 (8 LDS cycles instead of 2 + 2).
+        // Half-wave h stores the tensor rows h*14 + p, its lane j = lane & 31 the column of NODE j (tensor column tofl): one whole
+        // 256-byte row per half-wave and store, off a scalar base address.  No branch per row: rows without a slot go to the spare
+        // row behind the buffer; each half runs its 14 stores under one exec mask.  The LDS reads are issued by hand: left to the
+        // compiler, pairs of them become ds_read2_b64 (8 LDS cycles instead of 2 + 2).
         const int j = lane & 31, hrow = lane >> 5;
         const unsigned joff = (unsigned)j * 8u;
         const unsigned kva = (unsigned)(size_t)(__attribute__((address_space(3))) double*)(Ks + hrow * 14 * KS + tofl);
+        const unsigned rlo = (unsigned)ro_cur, rhi = (unsigned)(ro_cur >> 32);
         double kv[14];
 #pragma unroll
         for (int p = 0; p < 14; p++) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(kv[p]) : "v"(kva), "n"(p * KS * 8) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]), "+v"(kv[4]), "+v"(kv[5]), "+v"(kv[6]), "+v"(kv[7]),
                      "+v"(kv[8]), "+v"(kv[9]), "+v"(kv[10]), "+v"(kv[11]), "+v"(kv[12]), "+v"(kv[13]));
-#pragma unroll
-        for (int p = 0; p < 14; p++) {
-          const int n0 = __builtin_amdgcn_readlane(nodeofl, p), n1 = __builtin_amdgcn_readlane(nodeofl, min(14 + p, NC - 1));
-          const int s0 = __builtin_amdgcn_readlane(sl_cur, n0), s1 = __builtin_amdgcn_readlane(sl_cur, n1);
-          const double* b0 = P.Kout + (size_t)s0 * P.kstride;
-          const double* b1 = P.Kout + (size_t)s1 * P.kstride;
-          if (j >= P.kstride) continue;
+        if (j < P.kstride) {
           if (hrow == 0) {
-            if (s0 >= 0) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(joff), "v"(kv[p]), "s"(b0) : "memory");
-          } else if (14 + p < NC) {
-            if (s1 >= 0) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(joff), "v"(kv[p]), "s"(b1) : "memory");
+#pragma unroll
+            for (int p = 0; p < 14; p++) {
+              const size_t ro = ((size_t)(unsigned)__builtin_amdgcn_readlane((int)rhi, p) << 32) | (unsigned)__builtin_amdgcn_readlane((int)rlo, p);
+              const char* base = reinterpret_cast<const char*>(P.Kout) + ro;
+              asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(joff), "v"(kv[p]), "s"(base) : "memory");
+            }
+          } else {
+#pragma unroll
+            for (int p = 0; p < 13; p++) {
+              const size_t ro = ((size_t)(unsigned)__builtin_amdgcn_readlane((int)rhi, 14 + p) << 32) | (unsigned)__builtin_amdgcn_readlane((int)rlo, 14 + p);
+              const char* base = reinterpret_cast<const char*>(P.Kout) + ro;
+              asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(joff), "v"(kv[p]), "s"(base) : "memory");
+            }
           }
         }
       } else {
@@ -1539,16 +1563,16 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab ta
           const int t = t0 + lane;
           const int row = (t < NC * NC) ? t / NC : 0;
           const int j = t - row * NC;
-          const int s = __shfl(sl_cur, row, 64);
           const int tr = __shfl(tofl, row, 64), tj = __shfl(tofl, j, 64);
+          const int s = __shfl(sl_cur, tr, 64);
           if (t < NC * NC && s >= 0) P.Kout[(size_t)s * NC + j] = Ks[tr * KS + tj];
         }
       }
-      if (lane < NC && sl_cur >= 0) P.Fout[sl_cur] = -(ku + fsrc);
     }
     wave_lds_sync();          // Ks is the next element's phase-A scratch, xt holds the next element's nodes
     sl_cur = sl_n;
-    dof_n = dof_nn;
+    ro_cur = ro_n;
+    dof_n = dof_nn_c;
     e_n = e_nn;
     e_nn = e_nnn;
   }
@@ -2008,12 +2032,12 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
               li[(size_t)8 * 64 + l] = p2 * MF_KS + p;
               li[(size_t)9 * 64 + l] = p == p2 ? 1 : 0;
             }
-            {                                              // source stage 3, K_e u, row stores: node l & 31 (clamped to 26)
-              const int n = std::min(l & 31, 26);
-              const int a = fhfe::xc(geom, n, 0) + 1, b = fhfe::xc(geom, n, 1) + 1, c = fhfe::xc(geom, n, 2) + 1;
-              for (int k = 0; k < 4; k++) lc[(size_t)(47 + k) * 64 + l] = L1[a][k];
-              li[(size_t)12 * 64 + l] = (b * 3 + c) * 4;
-              li[(size_t)13 * 64 + l] = tof[n];
+            {                                              // source stage 3: lane = tensor node t = min(l & 31, 26)
+              const int t = std::min(l & 31, 26);
+              for (int k = 0; k < 4; k++) lc[(size_t)(47 + k) * 64 + l] = L1[t / 9][k];
+              li[(size_t)16 * 64 + l] = (t % 9) * 4;
+              li[(size_t)12 * 64 + l] = tof[std::min(l >> 1, 26)];           // row stores: column of node l >> 1
+              li[(size_t)13 * 64 + l] = tof[std::min(l & 31, 26)];
               li[(size_t)14 * 64 + l] = nodeof[std::min(l, 26)];
             }
           }
@@ -2072,7 +2096,8 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
     FH_TRY(up((void**)&as->d_adj_ei, aei.data(), aei.size() * sizeof(int)));
     FH_CHECK_HIP(hipMalloc(&as->d_rowmap, std::max<size_t>((size_t)aei.size() * nc, 1)));
     as->kstride = (nc == 27 && ctx->assemble_kpad) ? (ctx->assemble_kpad == 28 ? 28 : 32) : nc;
-    as->kbuf_bytes = std::max<size_t>((size_t)aei.size() * as->kstride, 1) * sizeof(double);
+    as->nadj = (int)aei.size();
+    as->kbuf_bytes = ((size_t)aei.size() + 1) * as->kstride * sizeof(double);      // + one spare row: the sink of rows without a slot
     FH_CHECK_HIP(hipMalloc(&as->d_Kbuf, as->kbuf_bytes));
     FH_CHECK_HIP(hipMalloc(&as->d_Fbuf, std::max<size_t>(aei.size(), 1) * sizeof(double)));
     if (ctx->debug_poison) {   // tests: the row pass must read nothing the element kernels have not written
@@ -2208,6 +2233,7 @@ static int assemble_poisson_core(fh_assembler_t as, fh_vec_t sol, int source_kin
     P.kstride = as->kstride;
     P.Fout = as->d_Fbuf;
     P.slot = as->d_slot;
+    P.nsink = as->nadj;
     P.debug = as->ctx->asm_debug;
     if (as->ctx->assemble_affine && as->d_Mab && as->n_aff > 0) {
       // affine elements through the reference-matrix kernel, the rest (curved ones) through the quadrature kernel
