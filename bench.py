@@ -24,7 +24,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6    # vendor FP64 vector peak = FP64 matrix peak on MI355X
-ELEM_EXECUTED_FLOPS = 336 * 512 + (339 * 2 + 121) * 64    # k_elem_q2hex_mfma, per element (PMC instruction counts)
+# k_elem_q2hex_sf, per element, from the PMC passes (profiles/r03_assembly_pmc_summary.md): 361 FMA, 51 MUL, 2 ADD FP64 vector
+# instructions on 64 lanes + 15 v_mfma_f64_4x4x4_4b of 512 flops
+ELEM_EXECUTED_FLOPS = (361 * 2 + 51 + 2) * 64 + 15 * 512
+ELEM_ALGORITHMIC_BYTES = 27 * 4 + 27 * 24 + 27 * 8 + 27 * 32 * 8 + 27 * 8    # node ids, coordinates, solution, padded element rows, residual
 
 
 def parse():
@@ -310,24 +313,28 @@ def main():
             "step_ms_estimate": ms_per_step - asm_ms + asm_affine_ms,
         },
         "roofline_assembly": {
-            "kernel": "k_elem_q2hex_mfma (element matrices on the FP64 matrix cores: 336 v_mfma_f64_4x4x4_4b per element, 28 symmetric "
-                      "tiles, sum-factorised map Jacobian); the row pass k_row_assemble<27> is reported beside it",
-            "bound": "mfma",
-            "achieved": ELEM_EXECUTED_FLOPS * nel / elem_ms / 1e9,
-            "peak": FP64_VALU_PEAK_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": ELEM_EXECUTED_FLOPS * nel / elem_ms / 1e9 / FP64_VALU_PEAK_TFLOPS,
-            "flops_model": "EXECUTED flops per element: 336 MFMA x 512 + (339 FMA x 2 + 121 MUL) x 64 lanes = 223 168 (instruction counts: "
-                           "profiles/r01b_assembly_pmc_summary.md); FP64 MFMA and FP64 vector instructions share one issue port per "
-                           "SIMD on gfx950 (78.6 TFLOP/s either way, no co-execution), so their sum is priced against that one peak. "
-                           "`algorithmic_tflops` prices the reference's full element loop instead (SURVEY 8d, 4.6e5 flop/element), "
-                           "which the kernel shortens by the symmetry of K_e and the sum-factorised Jacobian",
+            "kernel": "k_elem_q2hex_sf (element matrices by sum factorisation: K_e contracted one direction at a time, 15 FP64 matrix "
+                      "instructions + ~410 FP64 vector instructions per element instead of the 27 x 27 x 64 x 9 products of the reference's "
+                      "loop); the row pass k_row_assemble2<27> is reported beside it",
+            "bound": "hbm",
+            "achieved": ELEM_ALGORITHMIC_BYTES * nel / elem_ms / 1e6,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": ELEM_ALGORITHMIC_BYTES * nel / elem_ms / 1e6 / HBM_PEAK_GBPS,
+            "bytes_model": "per element: 27 node ids + 27 coordinates + 27 solution values read, 27 padded rows of 256 bytes + 27 residual "
+                           "entries written = %d B (the element-row buffer is the kernel's output; the row pass reads it back)" % ELEM_ALGORITHMIC_BYTES,
+            "executed_tflops": ELEM_EXECUTED_FLOPS * nel / elem_ms / 1e9,
+            "executed_frac_fp64_peak": ELEM_EXECUTED_FLOPS * nel / elem_ms / 1e9 / FP64_VALU_PEAK_TFLOPS,
+            "flops_model": "EXECUTED flops per element: (361 FMA x 2 + 51 MUL + 2 ADD) x 64 lanes + 15 MFMA x 512 = %d (instruction counts "
+                           "from the PMC passes); the kernel is bound by neither roof: LDS instruction issue and the latency of its ~15 "
+                           "dependent LDS round trips per element (DESIGN section 4).  `algorithmic_tflops` prices the reference's full "
+                           "element loop instead (SURVEY 8d, 4.6e5 flop/element): above the 78.6 TFLOP/s FP64 peak, i.e. the loop as the "
+                           "reference writes it could not run this fast on this device" % ELEM_EXECUTED_FLOPS,
             "algorithmic_tflops": ai["flops"] / elem_ms / 1e9,
             "avg_launch_ms": elem_ms,
             "traffic": TRAFFIC["asm"]["elem"] if world == 1 else None,
             "row_pass_traffic": TRAFFIC["asm"]["rows"] if world == 1 else None,
             "traffic_from_profile": TRAFFIC["asm"]["source"] if world == 1 else None,
-            "executed_mfma_tflops": 336 * 512.0 * nel / elem_ms / 1e9,
             "row_pass_ms": asm_ms - elem_ms,
             "row_pass_GBps": (nel * 27 * (32 * 8 + 27 + 8) + A.nnz * 8.0) / max(asm_ms - elem_ms, 1e-9) / 1e6,
             "assembly_achieved_tflops": ai["flops"] / asm_ms / 1e9,
@@ -533,7 +540,7 @@ def live_traffic(coarse, levels, timeout=150, device=0):
                     if row["Counter_Name"] != counter:
                         continue
                     name = row["Kernel_Name"]
-                    key = ("spmv" if "k_spmv_lx<2048, 3" in name else "elem" if "k_elem_q2hex_mfma" in name else
+                    key = ("spmv" if "k_spmv_lx<2048, 3" in name else "elem" if "k_elem_q2hex_" in name else
                            "rows" if "k_row_assemble" in name and "true>" not in name.split("(")[0] else None)
                     if key:
                         per.setdefault((key, int(row.get("Grid_Size", 0) or 0)), []).append(float(row["Counter_Value"]))
@@ -562,7 +569,7 @@ def _traffic():
         out["spmv"] = {"bytes": d.get("traffic_bytes_per_launch"), "source": src}
     d, src = _newest_profile("assembly_traffic.json")
     if d:
-        el = [v for k, v in d.items() if k.startswith("k_elem_q2hex_mfma")]
+        el = [v for k, v in d.items() if k.startswith("k_elem_q2hex_")]
         rw = [v for k, v in d.items() if k.startswith("k_row_assemble")]
         out["asm"] = {"elem": el[0]["traffic_bytes_per_launch"] if el else None, "rows": rw[0]["traffic_bytes_per_launch"] if rw else None, "source": src}
     return out

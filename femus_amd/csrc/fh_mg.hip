@@ -697,6 +697,303 @@ __global__ __launch_bounds__(256) void k_gjs_finish(double* __restrict__ D, int 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Symmetric sweep with pivot blocks of 128 (default for symmetric operators; option gj_block): the same three updates as above,
+//   A_kk <- -A_kk^-1,  A_ko <- A_kk^-1 A_ko,  A_oo <- A_oo - A_ok A_kk^-1 A_ko     (upper block triangle, ends in -A^-1)
+// in n / 128 steps of TWO launches.  With rank-32 updates every step streamed the whole upper triangle (97 MB at n = 4913) for
+// 0.8 GFLOP -- 154 steps of ~69 us; a rank-128 update does 3.1 GFLOP per pass over the same bytes, i.e. it is bound by the FP64
+// matrix cores and not by HBM, and there are 39 of them.
+//   k_inv_panel   one workgroup per 32 columns: gathers the pivot rows PT (from the upper triangle: a row right of the block, a
+//                 column above it), R = A_kk^-1 PT on the matrix cores (A_kk^-1 comes from the look-ahead below), writes PT, RT, the
+//                 row panel of D and -A_kk^-1 into the pivot block
+//   k_inv_update  128 x 128 tiles of the upper block triangle, K = 128 staged through LDS in double-buffered chunks of 16 (one
+//                 barrier per chunk), 4 waves x (4 x 4) v_mfma_f64_16x16x4 tiles; tiles of the pivot block column copy the column
+//                 panel out of RT (transposed through LDS); the workgroup that owns the NEXT pivot block inverts it right after its
+//                 update (tile order rotated so that it is scheduled first): the sequential inversion stays off the critical path
+//   inversion of a 128 x 128 block: every thread keeps an 8 x 8 sub-block in registers, pivot row and column go through a
+//                 double-buffered LDS line (one barrier per pivot), WITHOUT pivoting; a pivot below 1e-10 of the block's largest
+//                 diagonal entry raises flag bit 2 and the host repeats the whole factorisation with the pivoted 32-wide sweep.
+// ------------------------------------------------------------------------------------------------
+constexpr int IB = 128;          // pivot block and tile
+constexpr int IKC = 16;          // k rows staged per chunk
+constexpr int ILD = 144;         // LDS row stride in doubles: 2 * ILD mod 64 = 32, the two k rows a half-wave reads hit disjoint banks
+constexpr int IPN = 32;          // columns per workgroup of the panel kernel
+constexpr int IPLD = 48;         // its B stride: 2 * 48 mod 64 = 32
+
+// In-register inverse of the symmetric block src (nb x nb, upper entries valid, row stride ld, read past the L1: the caller may just
+// have written it) -> dst (row-major 128 x 128, rows / columns >= nb identity) and dstT (its transpose).  256 threads, thread
+// (ty, tx) owns rows ty*8.., columns tx*8...  lines: 2 x 2 x 128 doubles of LDS.
+__device__ __forceinline__ void inv128_block(const double* src, size_t ld, int nb, double* __restrict__ dst, double* __restrict__ dstT, double* lines,
+                                            unsigned long long* dmax_bits, int* flag) {
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  double M[8][8];
+  double dloc = 0.0;
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const int i = ty * 8 + r, j = tx * 8 + c;
+      double v = (i == j) ? 1.0 : 0.0;
+      if (i < nb && j < nb) v = __hip_atomic_load(src + (size_t)min(i, j) * ld + max(i, j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      M[r][c] = v;
+      if (i == j) dloc = fmax(dloc, fabs(v));
+    }
+  if (tid == 0) *dmax_bits = 0ull;
+  __syncthreads();
+  if (ty == tx) atomicMax(dmax_bits, (unsigned long long)__double_as_longlong(dloc));      // non-negative doubles order like their bits
+  __syncthreads();
+  const double tiny = 1e-10 * __longlong_as_double((long long)*dmax_bits);
+  bool bad = false;
+#pragma unroll 1
+  for (int k8 = 0; k8 < 16; k8++) {
+    if (k8 * 8 >= nb) break;
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+      const int k = k8 * 8 + kk;
+      double* rowb = lines + (kk & 1) * 256;       // k and kk have the same parity
+      double* colb = rowb + 128;
+      if (ty == k8) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) rowb[tx * 8 + c] = M[kk][c];
+      }
+      if (tx == k8) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) colb[ty * 8 + r] = M[r][kk];
+      }
+      __syncthreads();
+      const double piv = rowb[k];
+      bad |= !(fabs(piv) > tiny);
+      const double p = 1.0 / piv;
+      double rk[8], f[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) rk[c] = rowb[tx * 8 + c];
+#pragma unroll
+      for (int r = 0; r < 8; r++) f[r] = colb[ty * 8 + r] * p;
+#pragma unroll
+      for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) M[r][c] -= f[r] * rk[c];
+      if (tx == k8) {                               // column k of the other rows
+#pragma unroll
+        for (int r = 0; r < 8; r++) M[r][kk] = -f[r];
+      }
+      if (ty == k8) {                               // row k
+#pragma unroll
+        for (int c = 0; c < 8; c++) M[kk][c] = rk[c] * p;
+        if (tx == k8) M[kk][kk] = p;
+      }
+    }
+  }
+  if (bad) atomicOr(flag, 4);
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      dst[(ty * 8 + r) * IB + tx * 8 + c] = M[r][c];
+      dstT[(tx * 8 + c) * IB + ty * 8 + r] = M[r][c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_inv_first(const double* __restrict__ D, int n, int nb, double* __restrict__ Dinv, int* __restrict__ flag) {
+  __shared__ double lines[512];
+  __shared__ unsigned long long dmax_bits;
+  inv128_block(D, (size_t)n, nb, Dinv, Dinv + IB * IB, lines, &dmax_bits, flag);
+}
+
+// Dinv: [0, IB*IB) the inverse of the pivot block (row-major), [IB*IB, 2 IB*IB) its transpose
+__global__ __launch_bounds__(256) void k_inv_panel(double* __restrict__ D, const double* __restrict__ Dinv, double* __restrict__ PT, double* __restrict__ RT,
+                                                   int n, int kb, int nb) {
+  __shared__ double As[IKC][ILD];
+  __shared__ double Bs[IB][IPLD];              // the whole gathered panel of this workgroup: 128 x 32 (+ padding)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tj = blockIdx.x * IPN;
+  const bool inside = tj >= kb && tj < kb + IB, left = tj < kb;
+  // ---- gather PT[t][tj + jj], t < nb: a column above the block (contiguous in t), the symmetric pivot block, or a row right of it ----
+  if (left) {
+    for (int idx = tid; idx < IB * IPN; idx += 256) {
+      const int jj = idx >> 7, t = idx & 127, j = tj + jj;
+      Bs[t][jj] = (t < nb && j < n) ? D[(size_t)j * n + kb + t] : 0.0;
+    }
+  } else {
+    for (int idx = tid; idx < IB * IPN; idx += 256) {
+      const int t = idx >> 5, jj = idx & 31, j = tj + jj;
+      double v = 0.0;
+      if (t < nb && j < n) v = inside ? D[(size_t)(kb + min(t, j - kb)) * n + kb + max(t, j - kb)] : D[(size_t)(kb + t) * n + j];
+      Bs[t][jj] = v;
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < IB * IPN; idx += 256) {
+    const int t = idx >> 5, jj = idx & 31;
+    if (tj + jj < n) PT[(size_t)t * n + tj + jj] = Bs[t][jj];
+  }
+  if (inside) {               // the pivot block takes -A_kk^-1 (upper part); its columns of RT are never read
+    for (int idx = tid; idx < IB * IPN; idx += 256) {
+      const int s2 = idx >> 5, jj = idx & 31, j = tj + jj;
+      if (s2 < nb && j < kb + nb && kb + s2 <= j) D[(size_t)(kb + s2) * n + j] = -Dinv[s2 * IB + (j - kb)];
+    }
+    return;
+  }
+  // ---- R = Dinv * PT: wave w the rows 32 w .. 32 w + 31, all 32 columns; A[k][i] = Dinv^T[k][i] streamed through LDS ----
+  const int kk = lane >> 4, li = lane & 15, wi = wave * 32;
+  gj_d4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = gj_d4{0.0, 0.0, 0.0, 0.0};
+  const double* DinvT = Dinv + IB * IB;
+  const int nchunk = (nb + IKC - 1) / IKC;
+  for (int ch = 0; ch < nchunk; ch++) {
+    __syncthreads();
+    {
+      const int kr = tid >> 4, c8 = (tid & 15) * 8;
+      const double* src = DinvT + (size_t)(ch * IKC + kr) * IB + c8;
+#pragma unroll
+      for (int q = 0; q < 8; q += 2) *reinterpret_cast<double2*>(&As[kr][c8 + q]) = *reinterpret_cast<const double2*>(src + q);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k0 = 0; k0 < IKC; k0 += 4) {
+      const double a0 = As[k0 + kk][wi + li], a1 = As[k0 + kk][wi + 16 + li];
+      const double b0 = Bs[ch * IKC + k0 + kk][li], b1 = Bs[ch * IKC + k0 + kk][16 + li];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int s2 = wi + a * 16 + kk + 4 * r;
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const int j = tj + b * 16 + li;
+        if (j < n) {
+          const double v = (s2 < nb) ? acc[a][b][r] : 0.0;
+          RT[(size_t)s2 * n + j] = v;
+          if (!left && s2 < nb) D[(size_t)(kb + s2) * n + j] = v;
+        }
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_inv_update(double* __restrict__ D, const double* __restrict__ PT, const double* __restrict__ RT, int n, int kb,
+                                                    int nb, double* __restrict__ Dinv_next, int* __restrict__ flag) {
+  extern __shared__ __attribute__((aligned(16))) double iu_smem[];
+  const int nt = gridDim.x, kblk = kb / IB, kb_next = kb + IB;
+  const int t_next = (kb_next < n) ? kblk + 1 : 0;
+  const int by = (blockIdx.y + t_next) % nt, bx = (blockIdx.x + t_next) % nt;
+  if (by > bx) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ti = by * IB, tj = bx * IB;
+  if (by == kblk) return;                                  // pivot block and row panel: written by k_inv_panel
+  if (bx == kblk) {                                         // column panel above the pivot block: D[ti + i][kb + s] = RT[s][ti + i]
+    double (*Ts)[65] = reinterpret_cast<double (*)[65]>(iu_smem);
+    for (int h = 0; h < 4; h++) {                           // four 64 x 64 quarters through LDS, both directions coalesced
+      const int s0 = (h >> 1) * 64, i0 = (h & 1) * 64;
+      __syncthreads();
+      for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int s2 = s0 + (idx >> 6), i = ti + i0 + (idx & 63);
+        Ts[idx >> 6][idx & 63] = (s2 < nb && i < n) ? RT[(size_t)s2 * n + i] : 0.0;
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int i = ti + i0 + (idx >> 6), s2 = s0 + (idx & 63);
+        if (s2 < nb && i < n) D[(size_t)i * n + kb + s2] = Ts[idx & 63][idx >> 6];
+      }
+    }
+    return;
+  }
+  double* As = iu_smem;                       // [2][IKC][ILD]
+  double* Bs = iu_smem + 2 * IKC * ILD;       // [2][IKC][ILD]
+  const int kk = lane >> 4, li = lane & 15;
+  const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
+  gj_d4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int i = ti + wi + a * 16 + kk + 4 * r;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int j = tj + wj + b * 16 + li;
+        acc[a][b][r] = (i < n && j < n) ? D[(size_t)i * n + j] : 0.0;
+      }
+    }
+  // staging: thread -> k row tid >> 4, eight columns (tid & 15) * 8 of A (= -PT) and of B (= RT)
+  const int skr = tid >> 4, sc8 = (tid & 15) * 8;
+  double2 ra[4], rb[4];
+  auto gload = [&](int ch) {
+    const int t = ch * IKC + skr;
+    const double* pa = PT + (size_t)t * n + ti + sc8;
+    const double* pb = RT + (size_t)t * n + tj + sc8;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int ca = ti + sc8 + 2 * q, cb = tj + sc8 + 2 * q;
+      double2 va = make_double2(0.0, 0.0), vb = make_double2(0.0, 0.0);
+      if (t < nb) {
+        if (ca + 1 < n) { va.x = pa[2 * q]; va.y = pa[2 * q + 1]; } else if (ca < n) va.x = pa[2 * q];
+        if (cb + 1 < n) { vb.x = pb[2 * q]; vb.y = pb[2 * q + 1]; } else if (cb < n) vb.x = pb[2 * q];
+      }
+      ra[q] = make_double2(-va.x, -va.y);
+      rb[q] = vb;
+    }
+  };
+  auto lstore = [&](int buf) {
+    double* da = As + (buf * IKC + skr) * ILD + sc8;
+    double* db = Bs + (buf * IKC + skr) * ILD + sc8;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      *reinterpret_cast<double2*>(da + 2 * q) = ra[q];
+      *reinterpret_cast<double2*>(db + 2 * q) = rb[q];
+    }
+  };
+  const int nchunk = (nb + IKC - 1) / IKC;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunk; ch++) {
+    const int buf = ch & 1;
+    if (ch + 1 < nchunk) gload(ch + 1);
+    const double* A0 = As + buf * IKC * ILD + wi + li;
+    const double* B0 = Bs + buf * IKC * ILD + wj + li;
+#pragma unroll
+    for (int k0 = 0; k0 < IKC; k0 += 4) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int x = 0; x < 4; x++) {
+        av[x] = A0[(k0 + kk) * ILD + x * 16];
+        bv[x] = B0[(k0 + kk) * ILD + x * 16];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    if (ch + 1 < nchunk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int i = ti + wi + a * 16 + kk + 4 * r;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int j = tj + wj + b * 16 + li;
+        if (i < n && j < n) D[(size_t)i * n + j] = acc[a][b][r];
+      }
+    }
+  if (!(kb_next < n && by == bx && by == t_next)) return;
+  // ---- this workgroup has just written the next pivot block: invert it (off the critical path of the sweep) ----
+  __threadfence();
+  __syncthreads();
+  unsigned long long* dmax_bits = reinterpret_cast<unsigned long long*>(iu_smem + 512);
+  inv128_block(D + (size_t)kb_next * n + kb_next, (size_t)n, min(IB, n - kb_next), Dinv_next, Dinv_next + IB * IB, iu_smem, dmax_bits, flag);
+}
+
 // pivot columns of all other rows: A[i, kb+t] <- - sum_s Cp[i,s] * Dinv[s,t]
 __global__ __launch_bounds__(256) void k_gjb_col_panel(double* __restrict__ D, const double* __restrict__ Dinv, const double* __restrict__ Cp,
                                                        int n, int kb, int nb) {
@@ -1025,7 +1322,8 @@ static int coarse_factor(fh_mg_t mg) {
     mg->d_ainv = nullptr;
     mg->d_gjwork = nullptr;
     FH_CHECK_HIP(hipMalloc(&mg->d_ainv, (size_t)n * n * sizeof(double)));
-    FH_CHECK_HIP(hipMalloc(&mg->d_gjwork, ((size_t)2 * n * GJ_NB + 2 * GJ_NB * GJ_NB + 8) * sizeof(double)));
+    // panels PT, RT of the widest sweep (2 x n x 128), then the pivot inverses: 2 x (block + transpose) of 128 x 128, flags
+    FH_CHECK_HIP(hipMalloc(&mg->d_gjwork, ((size_t)2 * n * IB + 4 * IB * IB + 8) * sizeof(double)));
     mg->d_gjwork2 = mg->d_gjwork + (size_t)2 * n * GJ_NB + GJ_NB * GJ_NB + 8;
     mg->ainv_n = n;
   }
@@ -1036,7 +1334,9 @@ static int coarse_factor(fh_mg_t mg) {
   double* CpT = colk + (size_t)n * GJ_NB;
   double* Dinv = colk + (size_t)2 * n * GJ_NB;
   const int nt = fh_div_up(n, 64);
-  int* d_flag = reinterpret_cast<int*>(Dinv + GJ_NB * GJ_NB);   // [0] unsymmetric, [1] bit 0: singular pivot block, bit 1: non-finite inverse
+  // flags behind everything else in the work buffer: [0] unsymmetric, [1] bit 0: singular pivot block, bit 1: non-finite inverse, bit 2: the
+  // unpivoted 128-wide sweep met a pivot it cannot use
+  int* d_flag = reinterpret_cast<int*>(mg->d_gjwork + (size_t)2 * n * IB + 4 * IB * IB);
   FH_CHECK_HIP(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), c->stream));
   // the factorisation must end in a usable inverse: a pivot block without a usable pivot, or Inf / NaN anywhere in the result, is an
   // error of fh_mg_setup, not a silent part of every later cycle
@@ -1057,6 +1357,36 @@ static int coarse_factor(fh_mg_t mg) {
     hipLaunchKernelGGL(k_csr_symmetry, dim3(fh_div_up(n, 4)), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, n, 1e-12, d_flag);
     FH_CHECK_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (h_flag == 0 && c->gj_block >= IB) {
+      // pivot blocks of 128, two launches per step (see k_inv_update)
+      double* PT = mg->d_gjwork;
+      double* RT = PT + (size_t)n * IB;
+      double* Dv[2] = {RT + (size_t)n * IB, RT + (size_t)n * IB + 2 * IB * IB};
+      int* flg = d_flag;
+      const int ntb = fh_div_up(n, IB);
+      constexpr size_t upd_lds = (size_t)4 * IKC * ILD * sizeof(double);
+      static bool attr_set[64] = {};
+      if (!attr_set[c->device & 63]) {
+        FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inv_update), hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_lds));
+        attr_set[c->device & 63] = true;
+      }
+      hipLaunchKernelGGL(k_inv_first, dim3(1), dim3(256), 0, c->stream, mg->d_ainv, n, std::min(IB, n), Dv[0], flg + 1);
+      for (int kb = 0, step = 0; kb < n; kb += IB, step++) {
+        const int nb = std::min(IB, n - kb);
+        hipLaunchKernelGGL(k_inv_panel, dim3(fh_div_up(n, IPN)), dim3(256), 0, c->stream, mg->d_ainv, Dv[step & 1], PT, RT, n, kb, nb);
+        hipLaunchKernelGGL(k_inv_update, dim3(ntb, ntb), dim3(256), upd_lds, c->stream, mg->d_ainv, PT, RT, n, kb, nb, Dv[(step + 1) & 1], flg + 1);
+      }
+      hipLaunchKernelGGL(k_gjs_finish, dim3(nt, nt), dim3(256), 0, c->stream, mg->d_ainv, n);
+      FH_CHECK_HIP(hipGetLastError());
+      int hf[2] = {0, 0};
+      FH_CHECK_HIP(hipMemcpyAsync(hf, flg, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+      if (!(hf[1] & 4)) return finish();
+      // a pivot block without a usable diagonal pivot (the operator is symmetric but not definite): start again with the pivoted sweep
+      FH_CHECK_HIP(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), c->stream));
+      FH_CHECK_HIP(hipMemsetAsync(mg->d_ainv, 0, (size_t)n * n * sizeof(double), c->stream));
+      hipLaunchKernelGGL(k_csr_to_dense, dim3(n), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, mg->d_ainv, n);
+    }
     if (h_flag == 0) {
       double *PT = Cp, *RT = CpT;
       double* Dinv2[2] = {Dinv, mg->d_gjwork2};          // pivot inverse of this step / of the next one (look-ahead)

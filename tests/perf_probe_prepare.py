@@ -14,12 +14,12 @@ pb = PoissonMG(ctx, n, n, n, 4).init()
 pb.assemble()
 pb.prepare()
 ctx.sync()
-for gj in [int(v) for v in sys.argv[2:]] or [1]:
-    ctx.set_option("gj_mfma", gj)
+for gj in [int(v) for v in sys.argv[2:]] or [128]:
+    ctx.set_option("gj_block", gj)
     for _ in range(3):
         pb.assemble()
         ctx.sync()
         t = time.time()
         pb.prepare()
         ctx.sync()
-        print("gj_mfma %d prepare ms %.2f" % (gj, (time.time() - t) * 1e3))
+        print("gj_block %d prepare ms %.2f" % (gj, (time.time() - t) * 1e3))

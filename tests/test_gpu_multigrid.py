@@ -53,10 +53,11 @@ def test_vcycle_matches_oracle(ctx, H3, graph, npre, npost):
         ctx.set_option("use_graph", 1)
 
 
-@pytest.mark.parametrize("sym,mfma", [(1, 1), (0, 1), (0, 0)])
+@pytest.mark.parametrize("sym,mfma,block", [(1, 1, 128), (1, 1, 0), (0, 1, 128), (0, 0, 128)])
 @pytest.mark.parametrize("box", [(3, 3, 3), (5, 4, 3)])
-def test_coarse_inverse_variants(ctx, box, sym, mfma):
-    """the dense coarse inverse by the symmetric sweep on the upper block triangle (symmetric operators), by the general blocked
+def test_coarse_inverse_variants(ctx, box, sym, mfma, block):
+    """the dense coarse inverse by the symmetric sweep on the upper block triangle (symmetric operators; pivot blocks of 128 with
+    rank-128 updates, or -- gj_block 0 -- the pivoted 32-wide sweep), by the general blocked
     Gauss-Jordan with the rank-32 updates on the matrix cores, and by its vector form: a one-level "hierarchy" makes the cycle the
     coarse solve itself, checked against a direct solve.  Coarse sizes 343 and 693: not multiples of the 32-wide pivot block
     or of the 64-wide update tile."""
@@ -64,6 +65,7 @@ def test_coarse_inverse_variants(ctx, box, sym, mfma):
     n = H.A[0].shape[0]
     ctx.set_option("gj_symmetric", sym)
     ctx.set_option("gj_mfma", mfma)
+    ctx.set_option("gj_block", block)
     try:
         mg, mats = device_hierarchy(ctx, H)
         rhs = fo.lcg_fill(n, 11)
@@ -75,6 +77,7 @@ def test_coarse_inverse_variants(ctx, box, sym, mfma):
     finally:
         ctx.set_option("gj_symmetric", 1)
         ctx.set_option("gj_mfma", 1)
+        ctx.set_option("gj_block", 128)
 
 
 @pytest.mark.parametrize("reuse", [1, 0])
