@@ -147,6 +147,7 @@ def _declare(L):
     sig("fh_assemble_navier_stokes", c_void_p, c_void_p, c_double, c_void_p, c_void_p)
     sig("fh_ns_element_matrices", c_void_p, c_void_p, c_double, c_void_p, c_void_p)
     sig("fh_mg_set_level_patches", c_void_p, c_int, c_int, c_void_p, c_void_p)
+    sig("fh_mg_set_level_solver", c_void_p, c_int, c_int, c_int)
     sig("fh_expr_compile", c_char_p, c_char_p, P(c_void_p))
     sig("fh_expr_eval", c_void_p, c_void_p, P(c_double))
     sig("fh_expr_eval_many", c_void_p, c_int, c_void_p, c_void_p)

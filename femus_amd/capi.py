@@ -806,6 +806,10 @@ class Multigrid:
         ptr, dofs = _i32(ptr), _i32(dofs)
         _chk(self.L.fh_mg_set_level_patches(self.h, int(level), ptr.size - 1, _p(ptr), _p(dofs)))
 
+    def set_level_solver(self, level, solver="gmres", restart=30):
+        """level solver of the smoother: "richardson" (fixed sweeps, the default) or "gmres" (fixed iterations, left-preconditioned)"""
+        _chk(self.L.fh_mg_set_level_solver(self.h, int(level), {"richardson": 0, "gmres": 1}[solver], int(restart)))
+
     def set_level_distributed(self, level, halo, replicated_below=False):
         _chk(self.L.fh_mg_set_level_distributed(self.h, int(level), None if halo is None else halo.h, 1 if replicated_below else 0))
 

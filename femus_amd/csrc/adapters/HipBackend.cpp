@@ -634,8 +634,8 @@ void LinearEquationSolverHip::MGSetLevel(LinearEquationSolver* LinSolver, const 
     std::cout << "HIP backend: level smoother must be RICHARDSON + JACOBI_PRECOND, SOR_PRECOND or ILU_PRECOND (or the FEMuS_ASM solver)" << std::endl;
     abort();
   }
-  if (_level != 0 && _levelSolverType != RICHARDSON) {     // the reference's default level solver is GMRES (a non-stationary smoother)
-    std::cout << "HIP backend: level " << _level << " runs its smoother as RICHARDSON (fixed sweeps); call SetSolverFineGrids(RICHARDSON)" << std::endl;
+  if (_level != 0 && _levelSolverType != RICHARDSON && _levelSolverType != GMRES) {     // GMRES is the reference's default level solver
+    std::cout << "HIP backend: the level solver must be RICHARDSON or GMRES (SetSolverFineGrids)" << std::endl;
     abort();
   }
   if (_level != 0) attach_smoother_data(top->_mg, (int)_level);
@@ -644,6 +644,9 @@ void LinearEquationSolverHip::MGSetLevel(LinearEquationSolver* LinSolver, const 
   hip_check(fh_mg_set_level(top->_mg, (int)_level, static_cast<HipMatrix*>(_KK)->handle(), _level ? P : nullptr, _level ? R : nullptr,
                             smoother, _richardsonScaleFactor, (int)npre, (int)npost),
             "MGSetLevel");
+  if (_level != 0)      // KSPGMRES with KSPGMRESSetRestart(_restart) and npre / npost iterations, or KSPRICHARDSON (LinearEquationSolverPetsc.cpp:238-250, 501-519)
+    hip_check(fh_mg_set_level_solver(top->_mg, (int)_level, _levelSolverType == GMRES ? FH_LEVEL_GMRES : FH_LEVEL_RICHARDSON, _restart > 0 ? _restart : 30),
+              "MGSetLevel: level solver");
   top->_needs_setup = true;
 }
 // PCSOR runs in the natural row order as PETSc does (level-scheduled); SetMulticolourSor(true) selects the colour order instead

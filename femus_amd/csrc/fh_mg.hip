@@ -47,6 +47,12 @@ struct MgLevel {
   bool replicated_below = false;
   int ncols = 0;
   int buf_n = -1;            // size the work vectors were allocated for (kept across preparations)
+  // level solver: 0 = Richardson(omega) around the sweep preconditioner, 1 = GMRES (fixed iteration count, left-preconditioned)
+  int solver = 0, gm_restart = 30, gm_m = 0;
+  double* gm_buf = nullptr;  // (gm_m + 1) basis vectors of ncols + 2 entries
+  double** gm_dV = nullptr;  // their device pointer table
+  double* gm_small = nullptr;   // partial sums, Hessenberg matrix, reduced right-hand side, solution of the least-squares problem
+  int gm_nb = 0;             // workgroups of the dot-product launches
 };
 
 struct fh_mg_s {
@@ -1108,6 +1114,16 @@ extern "C" int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh
   return 0;
 }
 
+extern "C" int fh_mg_set_level_solver(fh_mg_t mg, int level, int solver, int restart) {
+  FH_REQUIRE(mg && level >= 0 && level < mg->nlevels, "fh_mg_set_level_solver: bad level %d", level);
+  FH_REQUIRE(solver == FH_LEVEL_RICHARDSON || solver == FH_LEVEL_GMRES, "fh_mg_set_level_solver: unknown level solver %d", solver);
+  FH_REQUIRE(restart >= 1, "fh_mg_set_level_solver: restart must be positive");
+  mg->lv[level].solver = solver;
+  mg->lv[level].gm_restart = restart;
+  mg->setup_done = false;
+  return 0;
+}
+
 extern "C" int fh_mg_set_level_distributed(fh_mg_t mg, int level, fh_halo_t halo, int replicated_below) {
   FH_REQUIRE(mg && level >= 0 && level < mg->nlevels, "fh_mg_set_level_distributed: bad level");
   mg->lv[level].halo = halo;
@@ -1116,12 +1132,23 @@ extern "C" int fh_mg_set_level_distributed(fh_mg_t mg, int level, fh_halo_t halo
   return 0;
 }
 
+static void free_level_gmres(MgLevel& L) {
+  if (L.gm_buf) hipFree(L.gm_buf);
+  if (L.gm_dV) hipFree(L.gm_dV);
+  if (L.gm_small) hipFree(L.gm_small);
+  L.gm_buf = nullptr;
+  L.gm_dV = nullptr;
+  L.gm_small = nullptr;
+  L.gm_m = 0;
+}
+
 static void free_level_buffers(MgLevel& L) {
   for (double** p : {&L.dinv, &L.x, &L.x2, &L.b, &L.r})
     if (*p) {
       hipFree(*p);
       *p = nullptr;
     }
+  free_level_gmres(L);
   L.buf_n = -1;
 }
 
@@ -1172,6 +1199,9 @@ static uint64_t cycle_signature(fh_mg_t mg) {
     mixp(L.d_porder);
     mix((uint64_t)L.vanka_ncolors);
     mixp(L.halo);
+    mix((uint64_t)L.solver);
+    mix((uint64_t)L.gm_restart);
+    mixp(L.gm_buf);
   }
   return h ? h : 1;
 }
@@ -1297,19 +1327,21 @@ static int factor_patches(fh_mg_t mg, MgLevel& L) {
   return 0;
 }
 
-static int vanka_sweeps(fh_mg_t mg, MgLevel& L, int nsweeps) {
+// multiplicative Schwarz sweeps over the colours of the patches on A x = b (x updated in place; rwork: a residual vector)
+static int vanka_apply(fh_mg_t mg, MgLevel& L, double* x, const double* b, double* rwork, double omega, int nsweeps) {
   fh_ctx_t c = mg->ctx;
   for (int s = 0; s < nsweeps; s++)
     for (int k = 0; k < L.vanka_ncolors; k++) {
       const int np = L.vcolor_ptr[k + 1] - L.vcolor_ptr[k];
       if (np == 0) continue;
-      FH_TRY(fh_dev_spmv(L.A, L.x, L.r, 2, L.b, nullptr, 0.0));                       // r = b - A x
+      FH_TRY(fh_dev_spmv(L.A, x, rwork, 2, b, nullptr, 0.0));                       // r = b - A x
       hipLaunchKernelGGL(k_vanka_color, dim3(np), dim3(64), (size_t)L.max_patch * sizeof(double), c->stream, L.d_porder + L.vcolor_ptr[k], np,
-                         L.d_pptr, L.d_pdofs, L.d_poff, L.d_pinv, L.r, L.x, L.omega);
+                         L.d_pptr, L.d_pdofs, L.d_poff, L.d_pinv, rwork, x, omega);
     }
   FH_CHECK_HIP(hipGetLastError());
   return 0;
 }
+static int vanka_sweeps(fh_mg_t mg, MgLevel& L, int nsweeps) { return vanka_apply(mg, L, L.x, L.b, L.r, L.omega, nsweeps); }
 
 static int coarse_factor(fh_mg_t mg) {
   fh_ctx_t c = mg->ctx;
@@ -1490,6 +1522,24 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
     for (double** p : {&L.dinv, &L.x, &L.x2, &L.b, &L.r})
       FH_CHECK_HIP(hipMemsetAsync(*p, (c->debug_poison && p != &L.dinv) ? 0xFF : 0, nb, c->stream));
     FH_TRY(fh_dev_get_diag(L.A, L.dinv, 1));
+    if (l > 0 && L.solver == FH_LEVEL_GMRES) {
+      const int m = std::max(1, std::min(std::max(L.npre, L.npost), L.gm_restart));
+      if (L.gm_m != m || !L.gm_buf) {
+        free_level_gmres(L);
+        const size_t vs = (size_t)L.ncols + 2;
+        L.gm_nb = sgrid(c, L.n);
+        FH_CHECK_HIP(hipMalloc(&L.gm_buf, (size_t)(m + 1) * vs * sizeof(double)));
+        FH_CHECK_HIP(hipMalloc(&L.gm_dV, (size_t)(m + 1) * sizeof(double*)));
+        FH_CHECK_HIP(hipMalloc(&L.gm_small, ((size_t)(m + 2) * L.gm_nb + m + 2 + (size_t)m * (m + 1) + (m + 1) + m + 2) * sizeof(double)));
+        std::vector<double*> tab(m + 1);
+        for (int j = 0; j <= m; j++) tab[j] = L.gm_buf + (size_t)j * vs;
+        FH_CHECK_HIP(hipMemcpy(L.gm_dV, tab.data(), tab.size() * sizeof(double*), hipMemcpyHostToDevice));
+        L.gm_m = m;
+      }
+      FH_CHECK_HIP(hipMemsetAsync(L.gm_buf, 0, (size_t)(L.gm_m + 1) * ((size_t)L.ncols + 2) * sizeof(double), c->stream));
+    } else if (L.gm_buf) {
+      free_level_gmres(L);
+    }
     if (L.smoother == FH_SMOOTH_GS_COLOR && l > 0 && L.ncolors == 0) FH_TRY(color_rows(L));
     if ((L.smoother == FH_SMOOTH_SOR || L.smoother == FH_SMOOTH_ILU0) && l > 0) {
       if (!L.tri) FH_TRY(fh_tri_create(L.A, &L.tri));                       // level schedules: once per pattern
@@ -1550,6 +1600,22 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
   FH_GUARD_END("fh_mg_setup")
 }
 
+// z = B r: forward then backward Gauss-Seidel from a zero guess over the colours of the matrix graph
+static int gs_color_apply(fh_mg_t mg, MgLevel& L, const double* r, double* z) {
+  fh_ctx_t c = mg->ctx;
+  FH_CHECK_HIP(hipMemsetAsync(z, 0, (size_t)L.ncols * sizeof(double), c->stream));
+  for (int pass = 0; pass < 2; pass++)
+    for (int k = 0; k < L.ncolors; k++) {
+      const int col = pass == 0 ? k : L.ncolors - 1 - k;
+      const int nr = L.color_ptr[col + 1] - L.color_ptr[col];
+      if (nr == 0) continue;
+      hipLaunchKernelGGL(k_gs_color, dim3(fh_div_up((int64_t)nr * 16, 256)), dim3(256), 0, c->stream, L.d_color_rows + L.color_ptr[col], nr,
+                         L.A->d_rowptr, L.A->d_col, L.A->d_val, L.dinv, r, z);
+    }
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // Richardson(scale omega) + a sweep preconditioner: x <- x + omega * B (b - A x).  B = forward then backward Gauss-Seidel from a
 // zero guess (PCSOR's local symmetric sweep, PetscPreconditioner.cpp:219-222) over the colours (FH_SMOOTH_GS_COLOR) or in the natural
 // row order as PETSc runs it (FH_SMOOTH_SOR), or the ILU(0) solve (FH_SMOOTH_ILU0, PetscPreconditioner.cpp:91-115)
@@ -1570,16 +1636,128 @@ static int gs_sweeps(fh_mg_t mg, MgLevel& L, int nsweeps, bool zero_guess) {
       hipLaunchKernelGGL(k_axpby2, dim3(sgrid(c, L.n)), dim3(256), 0, c->stream, L.x, z, L.omega, first ? 0.0 : 1.0, L.n);
       continue;
     }
-    FH_CHECK_HIP(hipMemsetAsync(z, 0, (size_t)L.ncols * sizeof(double), c->stream));
-    for (int pass = 0; pass < 2; pass++)
-      for (int k = 0; k < L.ncolors; k++) {
-        const int col = pass == 0 ? k : L.ncolors - 1 - k;
-        const int nr = L.color_ptr[col + 1] - L.color_ptr[col];
-        if (nr == 0) continue;
-        hipLaunchKernelGGL(k_gs_color, dim3(fh_div_up((int64_t)nr * 16, 256)), dim3(256), 0, c->stream, L.d_color_rows + L.color_ptr[col], nr,
-                           L.A->d_rowptr, L.A->d_col, L.A->d_val, L.dinv, L.r, z);
-      }
+    FH_TRY(gs_color_apply(mg, L, L.r, z));
     hipLaunchKernelGGL(k_axpby2, dim3(sgrid(c, L.n)), dim3(256), 0, c->stream, L.x, z, L.omega, first ? 0.0 : 1.0, L.n);
+  }
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GMRES as the level solver (FH_LEVEL_GMRES): what `SetSolverFineGrids(GMRES)` -- the reference's default `_levelSolverType`, and
+// what 003_NavierStokes sets -- makes of a level (LinearEquationSolverPetsc.cpp:238-250, 501-502): exactly npre / npost iterations
+// (PCMG skips the convergence test of its smoothers), left-preconditioned by the level's sweep preconditioner B (Jacobi, SOR,
+// ILU(0), colour sweep, one multiplicative pass over the patches), classical Gram-Schmidt, restart _restart.  Minimises
+// ||B (b - A x)||_2 over x0 + K_m(BA, B r0).  Everything stays on the device and on the stream -- dot products into device
+// scalars, the (m + 1) x m least-squares problem in one single-thread kernel -- so the cycle remains one captured graph.
+// ------------------------------------------------------------------------------------------------
+// v <- v / sqrt(s2[0]), the norm goes to *hout (a zero norm -- lucky breakdown -- gives the zero vector and a zero entry)
+__global__ __launch_bounds__(256) void k_gm_normalize(double* __restrict__ v, const double* __restrict__ s2, double* __restrict__ hout, int n) {
+  const double nrm = sqrt(fmax(s2[0], 0.0));
+  const double inv = nrm > 0.0 ? 1.0 / nrm : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *hout = nrm;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) v[i] *= inv;
+}
+__global__ void k_gm_copy(double* __restrict__ dst, const double* __restrict__ src, int k) {
+  if (threadIdx.x < k) dst[threadIdx.x] = src[threadIdx.x];
+}
+// least-squares solution of min || beta e1 - H y ||, H (m + 1) x m stored by columns of length ld (Givens rotations, one thread)
+__global__ void k_gm_solve(double* __restrict__ H, int ld, int m, const double* __restrict__ beta, double* __restrict__ g, double* __restrict__ y) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i <= m; i++) g[i] = 0.0;
+  g[0] = *beta;
+  for (int k = 0; k < m; k++) {
+    double* hk = H + (size_t)k * ld;
+    // (rotations 0 .. k-1 have been applied to this column as they were formed: see below)
+    const double a = hk[k], b2 = hk[k + 1];
+    const double d = hypot(a, b2);
+    const double cs = d > 0.0 ? a / d : 1.0, sn = d > 0.0 ? b2 / d : 0.0;
+    hk[k] = d;
+    hk[k + 1] = 0.0;
+    const double t = cs * g[k] + sn * g[k + 1];
+    g[k + 1] = -sn * g[k] + cs * g[k + 1];
+    g[k] = t;
+    for (int j = k + 1; j < m; j++) {          // the same rotation on the later columns
+      double* hj = H + (size_t)j * ld;
+      const double u = cs * hj[k] + sn * hj[k + 1];
+      hj[k + 1] = -sn * hj[k] + cs * hj[k + 1];
+      hj[k] = u;
+    }
+  }
+  for (int k = m - 1; k >= 0; k--) {
+    double acc = g[k];
+    for (int j = k + 1; j < m; j++) acc -= H[(size_t)j * ld + k] * y[j];
+    const double d = H[(size_t)k * ld + k];
+    y[k] = d != 0.0 ? acc / d : 0.0;
+  }
+}
+__global__ __launch_bounds__(256) void k_scale_by(double* __restrict__ z, const double* __restrict__ r, const double* __restrict__ dinv, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) z[i] = dinv[i] * r[i];
+}
+
+static int gs_color_apply(fh_mg_t mg, MgLevel& L, const double* r, double* z);
+
+// z = B r with the level's sweep preconditioner
+static int level_precond(fh_mg_t mg, MgLevel& L, const double* r, double* z) {
+  fh_ctx_t c = mg->ctx;
+  switch (L.smoother) {
+    case FH_SMOOTH_SOR: return fh_tri_ssor_apply(L.tri, L.A, L.dinv, r, z);
+    case FH_SMOOTH_ILU0: return fh_tri_ilu_apply(L.tri, L.A, r, z);
+    case FH_SMOOTH_GS_COLOR: return gs_color_apply(mg, L, r, z);
+    case FH_SMOOTH_VANKA:
+      FH_CHECK_HIP(hipMemsetAsync(z, 0, (size_t)L.ncols * sizeof(double), c->stream));
+      return vanka_apply(mg, L, z, r, L.x2, 1.0, 1);
+    default:
+      hipLaunchKernelGGL(k_scale_by, dim3(sgrid(c, L.n)), dim3(256), 0, c->stream, z, r, L.dinv, L.n);
+      return 0;
+  }
+}
+
+static int gmres_smooth(fh_mg_t mg, MgLevel& L, int nits, bool zero_guess) {
+  fh_ctx_t c = mg->ctx;
+  const int n = L.n, nb = L.gm_nb, ld = L.gm_m + 1;
+  const size_t vs = (size_t)L.ncols + 2;
+  double* part = L.gm_small;                               // [(gm_m + 2) * nb + gm_m + 2]
+  double* Hm = part + (size_t)(L.gm_m + 2) * nb + L.gm_m + 2;   // gm_m columns of length ld
+  double* g = Hm + (size_t)L.gm_m * ld;
+  double* y = g + ld;
+  double* beta = y + L.gm_m;
+  auto V = [&](int j) { return L.gm_buf + (size_t)j * vs; };
+  auto dots = [&](int nvec, const double* w) -> int {      // V[0..nvec)^T w -> part[nvec * nb ...]; summed over the ranks on a distributed level
+    hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, c->stream, (const double* const*)L.gm_dV, w, nvec, n, part);
+    hipLaunchKernelGGL(k_multidot_final, dim3(nvec), dim3(256), 0, c->stream, part, nvec, nb);
+    if (L.halo) FH_TRY(fh_halo_allreduce_ptr(L.halo, part + (size_t)nvec * nb, nvec));
+    return 0;
+  };
+  int done = 0;
+  while (done < nits) {
+    const int m = std::min(L.gm_m, nits - done);
+    const bool zg = zero_guess && done == 0;
+    if (zg) FH_TRY(level_precond(mg, L, L.b, V(0)));
+    else {
+      FH_TRY(halo_spmv(L.halo, L.A, L.x, n, L.r, 2, L.b, nullptr, 0.0));
+      FH_TRY(level_precond(mg, L, L.r, V(0)));
+    }
+    // beta = ||V0||, V0 <- V0 / beta : the dot kernel takes its vectors from the pointer table, so V0 . V0 = table entry 0 against V0
+    FH_TRY(dots(1, V(0)));
+    hipLaunchKernelGGL(k_gm_normalize, dim3(sgrid(c, n)), dim3(256), 0, c->stream, V(0), part + (size_t)nb, beta, n);
+    FH_CHECK_HIP(hipMemsetAsync(Hm, 0, (size_t)L.gm_m * ld * sizeof(double), c->stream));
+    for (int j = 0; j < m; j++) {
+      FH_TRY(halo_spmv(L.halo, L.A, V(j), n, L.r, 0, nullptr, nullptr, 0.0));
+      FH_TRY(level_precond(mg, L, L.r, V(j + 1)));
+      FH_TRY(dots(j + 1, V(j + 1)));                        // h = V^T w  (classical Gram-Schmidt, no refinement: PETSc's default)
+      hipLaunchKernelGGL(k_gm_copy, dim3(1), dim3(64), 0, c->stream, Hm + (size_t)j * ld, part + (size_t)(j + 1) * nb, j + 1);
+      hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, V(j + 1), (const double* const*)L.gm_dV, Hm + (size_t)j * ld, -1.0, j + 1, n);
+      // ||w||: table entry j + 1 is w itself
+      hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, c->stream, (const double* const*)(L.gm_dV + j + 1), V(j + 1), 1, n, part);
+      hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, c->stream, part, 1, nb);
+      if (L.halo) FH_TRY(fh_halo_allreduce_ptr(L.halo, part + (size_t)nb, 1));
+      hipLaunchKernelGGL(k_gm_normalize, dim3(sgrid(c, n)), dim3(256), 0, c->stream, V(j + 1), part + (size_t)nb, Hm + (size_t)j * ld + j + 1, n);
+    }
+    hipLaunchKernelGGL(k_gm_solve, dim3(1), dim3(1), 0, c->stream, Hm, ld, m, beta, g, y);
+    if (zg) FH_CHECK_HIP(hipMemsetAsync(L.x, 0, (size_t)L.ncols * sizeof(double), c->stream));
+    hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, L.x, (const double* const*)L.gm_dV, y, 1.0, m, n);
+    done += m;
   }
   FH_CHECK_HIP(hipGetLastError());
   return 0;
@@ -1595,6 +1773,8 @@ static int run_cycle(fh_mg_t mg) {
     bool packed = false;
     if (L.npre == 0) {
       FH_CHECK_HIP(hipMemsetAsync(L.x, 0, (size_t)L.ncols * sizeof(double), c->stream));
+    } else if (L.solver == FH_LEVEL_GMRES) {
+      FH_TRY(gmres_smooth(mg, L, L.npre, true));
     } else if (L.smoother == FH_SMOOTH_VANKA) {
       FH_CHECK_HIP(hipMemsetAsync(L.x, 0, (size_t)L.ncols * sizeof(double), c->stream));
       FH_TRY(vanka_sweeps(mg, L, L.npre));
@@ -1627,6 +1807,10 @@ static int run_cycle(fh_mg_t mg) {
     MgLevel& L = mg->lv[l];
     MgLevel& Lc = mg->lv[l - 1];
     FH_TRY(halo_spmv(Lc.halo, L.P, Lc.x, Lc.n, L.x, 1, nullptr, nullptr, 0.0));      // x += P x_{l-1} (reads ghost coarse values)
+    if (L.solver == FH_LEVEL_GMRES) {
+      if (L.npost > 0) FH_TRY(gmres_smooth(mg, L, L.npost, false));
+      continue;
+    }
     if (L.smoother == FH_SMOOTH_GS_COLOR || L.smoother == FH_SMOOTH_SOR || L.smoother == FH_SMOOTH_ILU0) {
       FH_TRY(gs_sweeps(mg, L, L.npost, false));
       continue;

@@ -338,6 +338,12 @@ int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh_mat_t R, i
  * conflict-free colours of patches.  Patches (fh_mesh_vertex_patches) are given per level before fh_mg_setup, which
  * extracts and inverts the patch matrices (dense, partial pivoting) from the level's current operator. */
 int fh_mg_set_level_patches(fh_mg_t mg, int level, int npatch, const int* ptr /* [npatch+1] */, const int* dofs);
+/* Level solver (`SetSolverFineGrids`, LinearImplicitSystem; `_levelSolverType`, LinearEquationSolverPetsc.cpp:238-250 and 501-519):
+ * FH_LEVEL_RICHARDSON  x <- x + omega B (b - A x), npre / npost times (KSPRICHARDSON, the smoother of fh_mg_set_level as B)
+ * FH_LEVEL_GMRES       npre / npost iterations of left-preconditioned GMRES with the same B (KSPGMRES, the reference's default
+ *                      level solver and the one 003_NavierStokes selects), classical Gram-Schmidt, restart `restart` (FEMuS: 30) */
+enum { FH_LEVEL_RICHARDSON = 0, FH_LEVEL_GMRES = 1 };
+int fh_mg_set_level_solver(fh_mg_t mg, int level, int solver, int restart);
 int fh_mg_setup(fh_mg_t mg);
 int fh_mg_vcycle(fh_mg_t mg, fh_vec_t b, fh_vec_t x);
 int fh_mg_solve(fh_mg_t mg, fh_vec_t b, fh_vec_t x, int outer, double rtol, double atol, double dtol, int maxit, int restart,

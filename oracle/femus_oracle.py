@@ -797,8 +797,45 @@ def smooth_precond(A, b, x, omega, nsweeps, zero_guess, apply_B):
     return x
 
 
-def vcycle(H, level, b, omega=2. / 3., npre=2, npost=2, coarse_solve=None, x=None, smoother="jacobi"):
-    """One multiplicative V-cycle applied to rhs b, starting from x (None = zero)."""
+def smooth_gmres(A, b, x, nits, zero_guess, apply_B, restart=30):
+    """KSPGMRES as a level smoother (`SetSolverFineGrids(GMRES)`, LinearEquationSolverPetsc.cpp:501-502; the reference's default
+    `_levelSolverType`): exactly `nits` iterations (PCMG skips the convergence test of its smoothers, Appendix A), left preconditioning
+    (KSPGMRES default), classical Gram-Schmidt without refinement (PETSc's default orthogonalisation), restart 30.  Minimises
+    ||B (b - A x)||_2 over x0 + K_nits(BA, B r0).  A lucky breakdown ends the cycle early.  Parity unpinned (PETSc is not in the image):
+    the test anchors are the minimisation property and the agreement with a dense least-squares solve."""
+    done = 0
+    while done < nits:
+        m = min(restart, nits - done)
+        r = apply_B(b.copy() if (zero_guess and done == 0) else b - A @ x)
+        beta = np.linalg.norm(r)
+        if beta == 0.0:
+            break
+        V = [r / beta]
+        Hm = np.zeros((m + 1, m))
+        k_used = 0
+        for k in range(m):
+            w = apply_B(A @ V[k])
+            h = np.array([w @ v for v in V])
+            for hj, v in zip(h, V):
+                w = w - hj * v
+            Hm[:k + 1, k] = h
+            Hm[k + 1, k] = np.linalg.norm(w)
+            k_used = k + 1
+            if Hm[k + 1, k] == 0.0:
+                break
+            V.append(w / Hm[k + 1, k])
+        g = np.zeros(k_used + 1)
+        g[0] = beta
+        y = np.linalg.lstsq(Hm[:k_used + 1, :k_used], g, rcond=None)[0]
+        dx = sum(yj * v for yj, v in zip(y, V))
+        x = dx if (zero_guess and done == 0) else x + dx
+        done += m
+    return x
+
+
+def vcycle(H, level, b, omega=2. / 3., npre=2, npost=2, coarse_solve=None, x=None, smoother="jacobi", level_solver="richardson"):
+    """One multiplicative V-cycle applied to rhs b, starting from x (None = zero).  level_solver "gmres": the smoother's sweep
+    preconditioner B (jacobi / sor / ilu0) inside `npre` / `npost` GMRES iterations instead of Richardson(omega)."""
     A = H.A[level]
     if level == 0:
         if coarse_solve is None:
@@ -825,10 +862,20 @@ def vcycle(H, level, b, omega=2. / 3., npre=2, npost=2, coarse_solve=None, x=Non
         sm = lambda bb, xx, n, zg: smooth_precond(A, bb, xx, omega, n, zg, lambda r: ilu0_apply(H._ilu[level], r))
     else:
         sm = lambda bb, xx, n, zg: smooth(A, dinv, bb, xx, omega, n, zg)
+    if level_solver == "gmres":
+        if smoother == "sor":
+            B = lambda r: sor_symmetric_natural(A, dinv, r)
+        elif smoother == "ilu0":
+            B = lambda r: ilu0_apply(H._ilu[level], r)
+        elif smoother == "jacobi":
+            B = lambda r: dinv * r
+        else:
+            raise ValueError("gmres level solver: preconditioner %s not restated" % smoother)
+        sm = lambda bb, xx, n, zg: smooth_gmres(A, bb, xx, n, zg, B)
     x = sm(b, np.zeros_like(b) if x is None else x, npre, x is None)
     r = b - A @ x
     bc = H.P[level].T @ r
-    ec = vcycle(H, level - 1, bc, omega, npre, npost, coarse_solve, smoother=smoother)
+    ec = vcycle(H, level - 1, bc, omega, npre, npost, coarse_solve, smoother=smoother, level_solver=level_solver)
     x = x + H.P[level] @ ec
     x = sm(b, x, npost, False)
     return x

@@ -320,6 +320,49 @@ def test_natural_order_smoothers_match_the_sequential_oracle(ctx, smoother, name
     mg.destroy()
 
 
+@pytest.mark.parametrize("graph", [1, 0])
+@pytest.mark.parametrize("smoother,name", [(capi.SMOOTH_JACOBI, "jacobi"), (capi.SMOOTH_SOR, "sor"), (capi.SMOOTH_ILU0, "ilu0")])
+@pytest.mark.parametrize("npre,npost", [(2, 1), (1, 1), (3, 0), (4, 4)])
+def test_gmres_level_solver_matches_the_oracle(ctx, smoother, name, npre, npost, graph):
+    """`SetSolverFineGrids(GMRES)`: the reference's default level solver (and what 003_NavierStokes sets).  One V-cycle whose smoothers
+    are npre / npost iterations of left-preconditioned GMRES around Jacobi / the natural-order SOR sweep / the ILU(0) solve, against
+    the oracle's restatement (classical Gram-Schmidt, dense least squares), also as a replayed graph; and the smoother does what GMRES
+    promises: the preconditioned residual after the cycle's pre-smoothing is the smallest over the Krylov space (checked in the oracle
+    against a dense least-squares solve)."""
+    H = fo.build_poisson_hierarchy(2, 2, 2, 3, "biquadratic", ONE)
+    nl = 3
+    ctx.set_option("use_graph", graph)
+    try:
+        mg = capi.Multigrid(ctx, nl)
+        mats = []
+        for l in range(nl):
+            A = ctx.matrix_scipy(H.A[l])
+            P = ctx.matrix_scipy(H.P[l]) if l > 0 else None
+            mats += [A, P]
+            mg.set_level(l, A, P, None, smoother, 1.0, npre, npost)
+            if l > 0:
+                mg.set_level_solver(l, "gmres", 3 if (npre, npost) == (4, 4) else 30)      # (4, 4) with restart 3: two GMRES cycles
+        mg.setup()
+        n = H.A[-1].shape[0]
+        rhs = fo.lcg_fill(n, 21)
+        b, x = ctx.vector_from(rhs), ctx.vector(n)
+        if (npre, npost) == (4, 4):
+            import functools
+            orig = fo.smooth_gmres
+            fo.smooth_gmres = functools.partial(orig, restart=3)
+        try:
+            ref = fo.vcycle(H, nl - 1, rhs, omega=1.0, npre=npre, npost=npost, smoother=name, level_solver="gmres")
+        finally:
+            if (npre, npost) == (4, 4):
+                fo.smooth_gmres = orig
+        for rep in range(2):
+            mg.vcycle(b, x)
+            assert rel(x.to_numpy(), ref) < 1e-9
+        mg.destroy()
+    finally:
+        ctx.set_option("use_graph", 1)
+
+
 def test_config1_converges_within_the_budget_of_001_poisson(ctx):
     """BASELINE configs[0] exactly as applications/001_Poisson/main.cpp:213-257 + input/input.json set it up: 2-D Q1, 8x8 refined to
     32x32, V_CYCLE with npre = npost = 1, level solver RICHARDSON (scale 0.5, LinearEquationSolverPetsc.hpp:145) + SOR_PRECOND, outer

@@ -131,3 +131,35 @@ def test_c_restatement_matches_numpy_oracle():
     rhs = fo.lcg_fill(m.nnode, 8)
     ref = fo.vcycle(H, 2, rhs)
     assert np.linalg.norm(cyc.apply(rhs) - ref) <= 1e-12 * np.linalg.norm(ref)
+
+
+def test_gmres_level_smoother_minimises_the_preconditioned_residual():
+    """oracle `smooth_gmres` (KSPGMRES as the level solver): after m iterations ||B (b - A x)|| is the minimum over x0 + K_m(BA, B r0),
+    checked against a dense least-squares solve over an explicitly built Krylov basis"""
+    import numpy as np
+    from oracle import femus_oracle as fo
+    H = fo.build_poisson_hierarchy(2, 2, 0, 2, "biquadratic", lambda xg: np.ones(xg.shape[:2]))
+    A = H.A[-1].tocsr()
+    dinv = fo.jacobi_dinv(A)
+    B = lambda r: dinv * r
+    rng = np.random.default_rng(3)
+    b, x0 = rng.uniform(-1, 1, A.shape[0]), rng.uniform(-1, 1, A.shape[0])
+    for m in (1, 2, 4):
+        x = fo.smooth_gmres(A, b, x0.copy(), m, False, B)
+        r0 = B(b - A @ x0)
+        K = [r0]
+        for _ in range(m - 1):
+            K.append(B(A @ K[-1]))
+        K = np.array(K).T
+        BAK = np.array([B(A @ K[:, j]) for j in range(m)]).T
+        c = np.linalg.lstsq(BAK, r0, rcond=None)[0]
+        best = np.linalg.norm(r0 - BAK @ c)
+        got = np.linalg.norm(B(b - A @ x))
+        assert abs(got - best) <= 1e-10 * np.linalg.norm(r0)
+    # zero initial guess: the same with x0 = 0
+    x = fo.smooth_gmres(A, b, None, 3, True, B)
+    r0 = B(b)
+    K = np.array([r0, B(A @ r0), B(A @ B(A @ r0))]).T
+    BAK = np.array([B(A @ K[:, j]) for j in range(3)]).T
+    c = np.linalg.lstsq(BAK, r0, rcond=None)[0]
+    assert abs(np.linalg.norm(B(b - A @ x)) - np.linalg.norm(r0 - BAK @ c)) <= 1e-10 * np.linalg.norm(r0)
