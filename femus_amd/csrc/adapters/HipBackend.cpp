@@ -638,7 +638,7 @@ void LinearEquationSolverHip::MGSetLevel(LinearEquationSolver* LinSolver, const 
     std::cout << "HIP backend: the level solver must be RICHARDSON or GMRES (SetSolverFineGrids)" << std::endl;
     abort();
   }
-  if (_level != 0) attach_smoother_data(top->_mg, (int)_level);
+  if (_level != 0) attach_smoother_data(top->_mg, (int)_level, variable_to_be_solved);
   fh_mat_t P = PP ? static_cast<HipMatrix*>(PP)->handle() : nullptr;
   fh_mat_t R = (RR && RR != PP) ? static_cast<HipMatrix*>(RR)->handle() : nullptr;   // RR == PP means "use PP^T"
   hip_check(fh_mg_set_level(top->_mg, (int)_level, static_cast<HipMatrix*>(_KK)->handle(), _level ? P : nullptr, _level ? R : nullptr,
@@ -655,9 +655,10 @@ int LinearEquationSolverHip::smoother_id() const {
   if (_preconditioner_type == ILU_PRECOND) return FH_SMOOTH_ILU0;
   return FH_SMOOTH_JACOBI;
 }
-void LinearEquationSolverHipAsm::attach_smoother_data(fh_mg_t mg, int level) {
+void LinearEquationSolverHipAsm::attach_smoother_data(fh_mg_t mg, int level, const std::vector<unsigned>& variable_to_be_solved) {
+  if (!_blocksGiven) BuildASMIndex(variable_to_be_solved);      // LinearEquationSolverPetscAsm::MGSetLevel builds them with the Dirichlet index
   if (_blockPtr.size() < 2) {
-    std::cout << "HIP backend: FEMuS_ASM level " << level << " has no blocks (SetAsmBlocks)" << std::endl;
+    std::cout << "HIP backend: FEMuS_ASM level " << level << " has no blocks" << std::endl;
     abort();
   }
   hip_check(fh_mg_set_level_patches(mg, level, (int)_blockPtr.size() - 1, _blockPtr.data(), _blockDofs.data()), "MGSetLevel: ASM blocks");

@@ -204,7 +204,7 @@ class LinearEquationSolverHip : public LinearEquationSolver {
  protected:
   // smoother of this level as handed to fh_mg_set_level; the ASM variant overrides it
   virtual int smoother_id() const;
-  virtual void attach_smoother_data(fh_mg_t, int) {}
+  virtual void attach_smoother_data(fh_mg_t, int, const std::vector<unsigned>&) {}
 
  private:
   // LinearEquationSolverPetsc.hpp:81 / .cpp:53-90: the sorted system rows that are Dirichlet (flag < 1.5) or belong to variables
@@ -227,21 +227,24 @@ class LinearEquationSolverHip : public LinearEquationSolver {
   double _rnorm = 0.;
 };
 
-// Block Schwarz smoother (LinearEquationSolverPetscAsm, petsc_asm/LinearEquationSolverPetscAsm.cpp): the blocks
-// BuildASMIndex derives from the mesh (:91-276) are handed over as dof lists, e.g. from fh_mesh_vertex_patches
+// Block Schwarz smoother (LinearEquationSolverPetscAsm, petsc_asm/LinearEquationSolverPetscAsm.cpp): the blocks come from the
+// reference's own setters -- SetElementBlockNumber / SetNumberOfSchurVariables -- through BuildASMIndex (HipBackendBdc.cpp, :91-276 of
+// the reference); SetAsmBlocks (not a FEMuS member) hands over other dof lists instead, e.g. fh_mesh_vertex_patches
 class LinearEquationSolverHipAsm : public LinearEquationSolverHip {
  public:
   LinearEquationSolverHipAsm(const unsigned& igrid, Solution* other_solution) : LinearEquationSolverHip(igrid, other_solution) {}
   using LinearEquationSolver::SetElementBlockNumber;
   void SetElementBlockNumber(const unsigned& n) override { _elementBlockNumber = n; }
   void SetNumberOfSchurVariables(const unsigned short& n) override { _NSchurVar = n; }
-  void SetAsmBlocks(const std::vector<int>& ptr, const std::vector<int>& dofs) { _blockPtr = ptr; _blockDofs = dofs; }
+  void SetAsmBlocks(const std::vector<int>& ptr, const std::vector<int>& dofs) { _blockPtr = ptr; _blockDofs = dofs; _blocksGiven = true; }   // not a FEMuS member: overrides BuildASMIndex
+  void BuildASMIndex(const std::vector<unsigned>& variable_to_be_solved);       // petsc_asm/LinearEquationSolverPetscAsm.cpp:91-276
 
  protected:
   int smoother_id() const override { return FH_SMOOTH_VANKA; }
-  void attach_smoother_data(fh_mg_t mg, int level) override;
+  void attach_smoother_data(fh_mg_t mg, int level, const std::vector<unsigned>& variable_to_be_solved) override;
 
  private:
+  bool _blocksGiven = false;
   unsigned _elementBlockNumber = 1;
   unsigned short _NSchurVar = 1;
   std::vector<int> _blockPtr, _blockDofs;

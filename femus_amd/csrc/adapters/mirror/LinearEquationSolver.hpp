@@ -27,11 +27,39 @@ class ParallelObject {
 
 // Mesh.hpp: _dofOffset[soltype][proc] .. [proc + 1] is the range of mesh dofs of a family a rank owns (soltype 0 linear, 1 serendipity,
 // 2 biquadratic, 3 / 4 discontinuous)
+// Elem.hpp:471-477: the elements sharing a vertex with an element, itself first (`BuildElementNearElement`, Elem.cpp:494-528)
+class elem {
+ public:
+  unsigned GetElementNearElementSize(const unsigned& iel, const unsigned& layers) const { return (layers == 0) ? 1 : (unsigned)_elementNearElement[iel].size(); }
+  unsigned GetElementNearElement(const unsigned& iel, const unsigned& j) const { return _elementNearElement[iel][j]; }
+  std::vector<std::vector<unsigned> > _elementNearElement;     // (MyMatrix <unsigned> in the FEMuS tree)
+};
+
 class Mesh {
  public:
   std::vector<unsigned> _dofOffset[5];
   unsigned GetLevel() const { return _level; }
   unsigned _level = 0;
+  // what BuildASMIndex reads (Mesh.hpp:167, 183, 211, 234, 424, 496); the element tables are filled by whoever owns the mesh
+  elem* GetMeshElements() const { return const_cast<elem*>(&_el); }
+  unsigned GetNumberOfElements() const { return (unsigned)_elementMaterial.size(); }
+  unsigned GetElementOffset(const unsigned iproc_in) const { return _elementOffset[iproc_in]; }
+  short unsigned GetElementMaterial(const unsigned& iel) const { return _elementMaterial[iel]; }
+  unsigned GetElementDofNumber(const unsigned& iel, const unsigned& type) const { return _elementDofNumber[type]; }
+  unsigned GetSolutionDof(const unsigned& i, const unsigned& iel, const short unsigned& solType) const {
+    return solType < 3 ? _elementDof[(size_t)iel * _nloc + i] : iel;       // Lagrange families share the biquadratic node ids (one rank)
+  }
+  unsigned BisectionSearch_find_processor_of_dof(const unsigned& dof, const short unsigned& solType) const {
+    unsigned p = 0;
+    while (p + 2 < _dofOffset[solType].size() && dof >= _dofOffset[solType][p + 1]) p++;
+    return p;
+  }
+  elem _el;
+  std::vector<unsigned> _elementOffset;        // [nprocs + 1]
+  std::vector<short unsigned> _elementMaterial;
+  unsigned _elementDofNumber[5] = {0, 0, 0, 1, 1};
+  std::vector<unsigned> _elementDof;           // [nel * _nloc]
+  unsigned _nloc = 0;
 };
 
 // Solution.hpp: the mesh it lives on and, per solution, the boundary flag vector (2 free, 1 AMR-constrained, 0 Dirichlet;
@@ -57,6 +85,12 @@ class LinearEquation : public ParallelObject {
                std::vector<NumericVector*>* Bdc_other, const unsigned& other_gridn, std::vector<bool>& SparsityPattern_other);
   void DeletePde();
   inline const Mesh* GetMeshFromLinEq() const { return _msh; }
+  unsigned GetSystemDof(const unsigned& index_sol, const unsigned& kkindex_sol, const unsigned& i, const unsigned& iel) const {   // LinearEquation.cpp:76-85
+    const unsigned soltype = _SolType[index_sol];
+    const unsigned idof = _msh->GetSolutionDof(i, iel, soltype);
+    const unsigned isubdom = _msh->BisectionSearch_find_processor_of_dof(idof, soltype);
+    return KKoffset[kkindex_sol][isubdom] + idof - _msh->_dofOffset[soltype][isubdom];
+  }
   std::vector<std::vector<unsigned> > KKoffset;   // [nvars + 1][nprocs]
   std::vector<int> KKIndex;                       // [nvars + 1]
   void SwapMatrices() { SparseMatrix* t = _KK; _KK = _KKamr; _KKamr = t; }

@@ -33,6 +33,7 @@ int main(int argc, char** argv) {
   if (argc < 5) return 2;
   const int n = atoi(argv[1]), nlev = atoi(argv[2]);
   const double nu = atof(argv[3]);
+  const int nschur = argc > 5 ? atoi(argv[5]) : 0, nblock = argc > 6 ? atoi(argv[6]) : 4, lsolver = argc > 7 ? atoi(argv[7]) : 0, outer_pre = argc > 8 ? atoi(argv[8]) : 0;
   const int geom = 1, nvars = 3, fe[3] = {2, 2, 0};
   const char names[3] = {'U', 'V', 'P'};
   const double lo[3] = {-0.5, -0.5, 0}, hi[3] = {0.5, 0.5, 1};
@@ -62,7 +63,27 @@ int main(int argc, char** argv) {
     const int ndof = offs[l][nvars];
     // FEMuS_ASM solver: element blocks around every pressure dof
     fmesh[l] = new Mesh();
-    for (int t = 0; t < 5; t++) fmesh[l]->_dofOffset[t] = {0u, (unsigned)(t == 0 ? own[0] : nnode)};     // one rank
+    for (int t = 0; t < 5; t++) fmesh[l]->_dofOffset[t] = {0u, (unsigned)(t == 0 ? own[0] : t < 3 ? nnode : nel)};     // one rank
+    // the element tables BuildASMIndex reads through the Mesh interface (FEMuS's own Mesh has them)
+    fmesh[l]->_elementOffset = {0u, (unsigned)nel};
+    fmesh[l]->_elementMaterial.assign(nel, 2);                                            // fluid
+    fmesh[l]->_nloc = nloc;
+    fmesh[l]->_elementDof.assign(ed.begin(), ed.end());
+    fmesh[l]->_elementDofNumber[0] = 4; fmesh[l]->_elementDofNumber[1] = 8; fmesh[l]->_elementDofNumber[2] = 9;
+    {
+      std::vector<std::vector<unsigned> > near_vertex(own[0]);                            // Elem.cpp:494-528: elements around the vertices of an element
+      for (int iel = 0; iel < nel; iel++)
+        for (int i = 0; i < 4; i++) near_vertex[ed[(size_t)iel * nloc + i]].push_back(iel);
+      fmesh[l]->_el._elementNearElement.resize(nel);
+      for (int iel = 0; iel < nel; iel++) {
+        std::map<unsigned, bool> els;
+        for (int i = 0; i < 4; i++)
+          for (unsigned jel : near_vertex[ed[(size_t)iel * nloc + i]])
+            if ((int)jel != iel) els[jel] = true;
+        fmesh[l]->_el._elementNearElement[iel].push_back(iel);
+        for (auto& kv : els) fmesh[l]->_el._elementNearElement[iel].push_back(kv.first);
+      }
+    }
     fsol[l] = new Solution(fmesh[l]);
     for (int k = 0; k < nvars; k++) {
       NumericVector* flag = NumericVector::build().release();
@@ -79,15 +100,10 @@ int main(int argc, char** argv) {
         std::cout << "KKoffset differs from fh_system_elem_dofs" << std::endl;
         return 3;
       }
-    ls->SetNumberOfSchurVariables(1);
-    ls->SetElementBlockNumber(4);
-    {
-      int np = 0, tot = 0;
-      hip_check(fh_mesh_vertex_patches(msh[l], nvars, fe, &np, &tot, nullptr, nullptr), "BuildASMIndex");
-      std::vector<int> ptr(np + 1), dofs(tot);
-      hip_check(fh_mesh_vertex_patches(msh[l], nvars, fe, &np, &tot, ptr.data(), dofs.data()), "BuildASMIndex");
-      ls->SetAsmBlocks(ptr, dofs);
-    }
+    // the smoother exactly as SteadyNavierStokesParallel/main.cpp:155-179 sets it up: blocks of `nblock` elements, `nschur` Schur variables
+    // (the application: 0 and 4), GMRES around the block-Schwarz preconditioner on every level above the coarsest
+    ls->SetNumberOfSchurVariables((unsigned short)nschur);
+    ls->SetElementBlockNumber((unsigned)nblock);
     Sol[l] = NumericVector::build().release();
     Sol[l]->init(ndof, ndof, false, SERIAL);
     // sparsity from the element couplings of the stacked variables
@@ -131,8 +147,9 @@ int main(int argc, char** argv) {
     }
     Sol[l]->zero();
     Sol[l]->insert_vector_blocked(vals, bdc[l]);
-    ls->set_solver_type(RICHARDSON);
-    ls->SetRichardsonScaleFactor(0.6);
+    ls->set_solver_type(lsolver == 0 ? GMRES : RICHARDSON);                       // SetSolverFineGrids(GMRES)
+    if (lsolver) ls->SetRichardsonScaleFactor(0.6);
+    ls->set_preconditioner_type(ILU_PRECOND);         // SetPreconditionerFineGrids(ILU_PRECOND): the sub-solve of the blocks (exact here)
     if (l > 0) {
       for (int copy = 0; copy < 2; copy++) {
         fh_mat_t P;
@@ -150,18 +167,28 @@ int main(int argc, char** argv) {
   std::vector<unsigned> vars = {0, 1, 2};
   int total_newton = 0, max_linear = 0;
   for (int ig = 0; ig < nlev; ig++) {
-    for (int it = 0; it < 30; it++) {
+    for (int it = 0; it < (outer_pre ? 90 : 30); it++) {          // SetMaxNumberOfNonLinearIterations(90) in the application
       LinearEquationSolver* top = LinSolver[ig];
       top->SetResZero();
       hip_check(fh_assemble_navier_stokes(as[ig], static_cast<HipVector*>(Sol[ig])->handle(), nu, static_cast<HipMatrix*>(top->_KK)->handle(),
                                           static_cast<HipVector*>(top->_RES)->handle()),
                 "assemble");
       for (int i = ig; i > 0; i--) LinSolver[i - 1]->_KK->matrix_PtAP(*PP[i], *LinSolver[i]->_KK, it > 0);
-      top->MGInit(MULTIPLICATIVE, ig + 1, GMRES);
-      top->SetTolerances(1e-11, 1e-50, 1e50, 60, 30);
-      for (int i = 0; i <= ig; i++) LinSolver[i]->MGSetLevel(top, ig, vars, PP[i], PP[i], i ? 2 : 1, i ? 2 : 0);
-      top->SetEpsZero();
-      top->MGSolve(true);
+      if (outer_pre) {
+        // SteadyNavierStokesParallel/main.cpp:148-185: SetOuterSolver(PREONLY), one pre- and one post-smoothing step, at most two
+        // linear iterations (V-cycles) per nonlinear one (LinearImplicitSystem.cpp:385-411)
+        top->MGInit(MULTIPLICATIVE, ig + 1, PREONLY);
+        top->SetTolerances(1e-12, 1e-20, 1e50, 4, 30);
+        for (int i = 0; i <= ig; i++) LinSolver[i]->MGSetLevel(top, ig, vars, PP[i], PP[i], 1, i ? 1 : 0);
+        top->SetEpsZero();
+        for (int lin = 0; lin < 2; lin++) top->MGSolve(lin == 0);
+      } else {
+        top->MGInit(MULTIPLICATIVE, ig + 1, GMRES);
+        top->SetTolerances(1e-11, 1e-50, 1e50, 60, 30);
+        for (int i = 0; i <= ig; i++) LinSolver[i]->MGSetLevel(top, ig, vars, PP[i], PP[i], i ? 2 : 1, i ? 2 : 0);
+        top->SetEpsZero();
+        top->MGSolve(true);
+      }
       *Sol[ig] += *top->_EPS;                                                                  // Solution::UpdateSol
       max_linear = std::max(max_linear, static_cast<LinearEquationSolverHip*>(top)->last_iterations());
       top->MGClear();
