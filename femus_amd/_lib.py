@@ -190,6 +190,8 @@ def _declare(L):
     sig("fh_dd_system_dofs", c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p)
     sig("fh_write_vtu", c_void_p, c_char_p, c_int, c_void_p, c_void_p, c_void_p)
     sig("fh_write_gmv", c_void_p, c_char_p, c_int, c_int, c_void_p, c_void_p, c_void_p)
+    sig("fh_xdmf_available")
+    sig("fh_write_xdmf", c_void_p, c_char_p, c_char_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p)
     sig("fh_vec_binary_print", c_void_p, c_char_p)
     sig("fh_vec_binary_load", c_void_p, c_char_p)
     sig("fh_host_binary_print", c_char_p, c_int, c_void_p)

@@ -87,6 +87,34 @@ def write_gmv(path, mesh, fields, order="biquadratic"):
     capi._chk(L.fh_write_gmv(mesh.h, os.fsencode(str(path)), 0 if order == "linear" else 1, len(names), c_names, capi._p(fe), c_vals))
 
 
+def xdmf_available():
+    from . import capi
+    return bool(capi.load_library().fh_xdmf_available())
+
+
+def write_xdmf(output_path, prefix, mesh, fields, level=1, time_step=0):
+    """XDMFWriter::Write(output_path, "biquadratic", vars, time_step): <prefix>.level<level>.<time_step>.biquadratic.xmf / .h5 (fh_write_xdmf,
+    HDF5 opened at run time).  fields as in write_vtu.  Returns the two paths."""
+    import ctypes
+    from . import capi
+    L = capi.load_library()
+    names = list(fields)
+    arrs = [np.ascontiguousarray(fields[k], dtype=np.float64) for k in names]
+    fe = []
+    for k, v in zip(names, arrs):
+        if v.size == mesh.nnode:
+            fe.append(2)
+        else:
+            assert v.size == mesh.own_size[0], "field %s has neither the biquadratic nor the linear length" % k
+            fe.append(0)
+    c_names = (ctypes.c_char_p * len(names))(*[k.encode() for k in names])
+    c_vals = (ctypes.c_void_p * len(names))(*[v.ctypes.data for v in arrs])
+    fe = np.array(fe, dtype=np.int32)
+    capi._chk(L.fh_write_xdmf(mesh.h, os.fsencode(str(output_path)), prefix.encode(), int(level), int(time_step), len(names), c_names, capi._p(fe), c_vals))
+    stem = os.path.join(str(output_path), "%s.level%d.%d.biquadratic" % (prefix, level, time_step))
+    return stem + ".xmf", stem + ".h5"
+
+
 HEX_XC = [(-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1), (-1, -1, 1), (1, -1, 1), (1, 1, 1), (-1, 1, 1),
           (0, -1, -1), (1, 0, -1), (0, 1, -1), (-1, 0, -1), (0, -1, 1), (1, 0, 1), (0, 1, 1), (-1, 0, 1),
           (-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0), (0, -1, 0), (1, 0, 0), (0, 1, 0), (-1, 0, 0), (0, 0, -1), (0, 0, 1), (0, 0, 0)]

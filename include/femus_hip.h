@@ -411,6 +411,12 @@ int fh_write_vtu(fh_mesh_t mesh, const char* path, int nfields, const char* cons
  * ("gmvinput" "ieeei4r8", nodes, cells, the METIS_DD cell variable, node variables).  order 0 = linear (phex8 / quad cells on the vertex
  * nodes), otherwise the reference's quadratic family (phex20 / 8quad; "biquadratic" selects it too, GMVWriter.cpp:102).  fe[k] as above. */
 int fh_write_gmv(fh_mesh_t mesh, const char* path, int order, int nfields, const char* const* names, const int* fe, const double* const* values);
+/* XDMFWriter::Write(output_path, "biquadratic", vars, time_step) (src/07_mesh_or_solution/01_multiple_levels/01_output/XDMFWriter.cpp:103-445):
+ * <prefix>.level<L>.<step>.biquadratic.xmf + .h5 with /NODES_X1..3, /CONNECTIVITY, /DOMAIN_PARTITIONS and one dataset per variable.  HDF5 is
+ * opened at run time (dlopen; FEMUS_HIP_HDF5 may name the library): fh_xdmf_available() says whether the call can work. */
+int fh_xdmf_available(void);
+int fh_write_xdmf(fh_mesh_t mesh, const char* output_path, const char* prefix, int level, int time_step, int nfields, const char* const* names,
+                  const int* fe, const double* const* values);
 int fh_vec_binary_print(fh_vec_t v, const char* path);
 int fh_vec_binary_load(fh_vec_t v, const char* path);
 int fh_host_binary_print(const char* path, int n, const double* values);

@@ -127,3 +127,50 @@ def test_gmv_file_layout_and_values(tmp_path, box, order):
     want = 1.0 + xy[:nfam, 0] - 3.0 * xy[:nfam, 1]
     assert np.allclose(var["Pressure"], want, rtol=0, atol=1e-14)
     m.destroy()
+
+
+def _h5_dataset(path, name):
+    """one dataset of an HDF5 file through h5dump (no h5py in the image): values in file order"""
+    import shutil
+    import subprocess
+    exe = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+    out = subprocess.check_output([exe, "-d", name, "-y", "-w", "0", "-m", "%.17g", str(path)], text=True)
+    i = out.index("DATA {") + 6
+    body = out[i:out.index("}", i)]
+    return np.array([float(v) for v in body.replace(",", " ").split()])
+
+
+@pytest.mark.skipif(not writers.xdmf_available(), reason="no HDF5 library to open at run time")
+@pytest.mark.parametrize("box", [(2, 3, 0), (2, 1, 2)])
+def test_xdmf_round_trip(tmp_path, box):
+    """XDMFWriter::Write: the .xmf names the datasets of the .h5 with the reference's names and dimensions; the heavy data read back
+    (h5dump) are the mesh and the fields, the connectivity in FemusToVTKorToXDMFConn order"""
+    import os
+    import xml.etree.ElementTree as ET
+    if not os.path.exists("/opt/conda/bin/h5dump"):
+        pytest.skip("h5dump not present")
+    m = capi.Mesh.box(*box).refine()
+    ed, xy, _ = m.arrays()
+    u = np.sin(xy[:, 0]) + 2 * xy[:, 1]
+    p = xy[:m.own_size[0], 0] * 3 - xy[:m.own_size[0], 1]
+    xmf, h5 = writers.write_xdmf(tmp_path, "sol", m, {"U": u, "P": p}, level=2, time_step=0)
+    assert os.path.basename(xmf) == "sol.level2.0.biquadratic.xmf"
+    root = ET.fromstring(open(xmf).read().split("\n", 2)[2])           # skip the XML and DOCTYPE lines
+    grid = root.find("Domain/Grid")
+    top = grid.find("Topology")
+    assert top.get("Type") == ("Quadrilateral_9" if m.dim == 2 else "Hexahedron_27") and int(top.get("Dimensions")) == m.nel
+    assert top.find("DataStructure").text.strip() == "sol.level2.0.biquadratic.h5:/CONNECTIVITY"
+    assert [d.text.strip().split(":/")[1] for d in grid.find("Geometry")] == ["NODES_X1", "NODES_X2", "NODES_X3"]
+    assert [a.get("Name") for a in grid.findall("Attribute")] == ["Domain_partitions", "U", "P"]
+    for d in range(3):
+        x = _h5_dataset(h5, "/NODES_X%d" % (d + 1))
+        assert np.array_equal(x, xy[:, d] if d < m.dim else np.zeros(m.nnode))
+    conn = _h5_dataset(h5, "/CONNECTIVITY").astype(int).reshape(m.nel, -1)
+    perm = list(range(ed.shape[1]))
+    if m.dim == 3:
+        perm[20:24] = [23, 21, 20, 22]
+    assert np.array_equal(conn, ed[:, perm])
+    assert np.array_equal(_h5_dataset(h5, "/U"), u)
+    pq = _h5_dataset(h5, "/P")
+    assert np.allclose(pq, xy[:, 0] * 3 - xy[:, 1], atol=1e-13)          # a linear field is reproduced at every biquadratic node
+    assert np.array_equal(_h5_dataset(h5, "/DOMAIN_PARTITIONS"), np.zeros(m.nel))
