@@ -191,6 +191,10 @@ def _declare(L):
     sig("fh_write_vtu", c_void_p, c_char_p, c_int, c_void_p, c_void_p, c_void_p)
     sig("fh_write_gmv", c_void_p, c_char_p, c_int, c_int, c_void_p, c_void_p, c_void_p)
     sig("fh_xdmf_available")
+    sig("fh_mesh_partition", c_void_p, c_int, c_void_p)
+    sig("fh_mesh_rank_elements", c_void_p, c_void_p, c_int, P(c_int), P(c_int), c_void_p)
+    sig("fh_mesh_submesh", c_void_p, c_int, c_void_p, P(c_void_p), c_void_p)
+    sig("fh_dd_topo_node_keys", c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p)
     sig("fh_write_xdmf", c_void_p, c_char_p, c_char_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p)
     sig("fh_vec_binary_print", c_void_p, c_char_p)
     sig("fh_vec_binary_load", c_void_p, c_char_p)

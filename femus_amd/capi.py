@@ -459,6 +459,40 @@ class Mesh:
         _chk(self.L.fh_mesh_refine(self.h, ctypes.byref(h)))
         return Mesh(self.L, h)
 
+    def partition(self, nparts):
+        """native k-way partition of the dual graph (the METIS_PartMeshDual of MeshMetisPartitioning.cpp:71-113): part[nel]"""
+        part = np.empty(self.nel, dtype=np.int32)
+        _chk(self.L.fh_mesh_partition(self.h, int(nparts), _p(part)))
+        return part
+
+    def rank_elements(self, part, rank):
+        """(owned elements, ring elements sharing a node with them) of a rank"""
+        part = _i32(part)
+        no, nt = ctypes.c_int(), ctypes.c_int()
+        _chk(self.L.fh_mesh_rank_elements(self.h, _p(part), int(rank), ctypes.byref(no), ctypes.byref(nt), None))
+        el = np.empty(nt.value, dtype=np.int32)
+        _chk(self.L.fh_mesh_rank_elements(self.h, _p(part), int(rank), ctypes.byref(no), ctypes.byref(nt), _p(el)))
+        return el[:no.value], el[no.value:]
+
+    def submesh(self, elems):
+        """FEMuS-numbered mesh of a list of elements; returns (mesh, node of this mesh for every node of the sub-mesh)"""
+        el = _i32(elems)
+        h = ctypes.c_void_p()
+        # the node count is not known before the call: at most nloc per element
+        gid = np.empty(el.size * self.nloc, dtype=np.int32)
+        _chk(self.L.fh_mesh_submesh(self.h, el.size, _p(el), ctypes.byref(h), _p(gid)))
+        sub = Mesh(self.L, h)
+        return sub, gid[:sub.nnode].copy()
+
+    def topo_node_keys(self, part, levels, elem_gid0, level):
+        """global id and owner of every node of levels[level] (a refinement of a sub-mesh of this coarse mesh) -- fh_dd_topo_node_keys"""
+        part, eg = _i32(part), _i32(elem_gid0)
+        hs = (ctypes.c_void_p * len(levels))(*[m.h for m in levels])
+        n = levels[level].nnode
+        gid, owner = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int32)
+        _chk(self.L.fh_dd_topo_node_keys(self.h, _p(part), len(levels), hs, _p(eg), int(level), _p(gid), _p(owner)))
+        return gid, owner.astype(np.int64)
+
     def refine_flagged(self, flags):
         """selective refinement (MeshRefinement::RefineMesh with an AMR flag per element)"""
         f = np.ascontiguousarray(flags, dtype=np.uint8)

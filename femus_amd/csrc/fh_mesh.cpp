@@ -1205,3 +1205,256 @@ static int read_gambit(const char* path, double Lref, fh_mesh_t* out) {
   *out = guard.release();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Domain decomposition of ARBITRARY coarse meshes (the reference: METIS_PartMeshDual on the coarsest level, ncommon = dim + 1 over the
+// element nodes, i.e. face neighbours; children inherit the parent's rank, MeshMetisPartitioning.cpp:71-113, 143-155).  METIS is not
+// available (and seeds its partitions randomly), so the partition is native: recursive bisection of the dual graph by breadth-first
+// growing from a pseudo-peripheral element -- balanced to one element, connected where the graph allows it, deterministic.
+//   fh_mesh_partition      part[nel] of the coarse mesh
+//   fh_mesh_rank_elements  a rank's elements: the ones it owns, then the ring of elements sharing a node with them (ascending)
+//   fh_mesh_submesh        a FEMuS-numbered mesh of a list of elements (first-touch renumbering, Mesh.cpp:517-559) + the node map
+//   fh_dd_topo_node_keys   global id and owner of every node of a refined level of such a sub-mesh, WITHOUT coordinates: a node lies
+//                          inside exactly one entity of the coarse mesh (vertex, edge, face, element = one of its 27 / 9 nodes), at
+//                          dyadic offsets measured in a frame fixed by the global ids of the entity's corners; owner = the lowest
+//                          rank among the coarse elements sharing the entity (Mesh.cpp:517-559)
+// ------------------------------------------------------------------------------------------------------------------
+static void dual_graph(const fh_mesh_s* G, std::vector<int>& ptr, std::vector<int>& adj) {
+  // two elements are face neighbours iff they share the node in the middle of a face (HEX27: local nodes 20..25, QUAD9: 4..7)
+  const int nl = G->nloc, f0 = G->geom == GEOM_HEX ? 20 : 4, f1 = G->geom == GEOM_HEX ? 26 : 8;
+  std::unordered_map<int, int> first;
+  std::vector<std::pair<int, int> > edges;
+  for (int e = 0; e < G->nel; e++)
+    for (int i = f0; i < f1; i++) {
+      const int nd = G->elem_dof[(size_t)e * nl + i];
+      auto it = first.find(nd);
+      if (it == first.end()) first[nd] = e;
+      else {
+        edges.emplace_back(it->second, e);
+        edges.emplace_back(e, it->second);
+      }
+    }
+  std::sort(edges.begin(), edges.end());
+  edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+  ptr.assign(G->nel + 1, 0);
+  for (auto& ed : edges) ptr[ed.first + 1]++;
+  for (int e = 0; e < G->nel; e++) ptr[e + 1] += ptr[e];
+  adj.resize(edges.size());
+  for (size_t k = 0; k < edges.size(); k++) adj[k] = edges[k].second;
+}
+
+static void bfs_order(const std::vector<int>& ptr, const std::vector<int>& adj, const std::vector<int>& set, const std::vector<char>& in, int start,
+                      std::vector<int>& order) {
+  std::vector<char> seen(in.size(), 0);
+  order.clear();
+  size_t next_seed = 0;
+  int seed = start;
+  while (order.size() < set.size()) {
+    if (seed < 0) {
+      while (next_seed < set.size() && seen[set[next_seed]]) next_seed++;
+      seed = set[next_seed];
+    }
+    size_t head = order.size();
+    order.push_back(seed);
+    seen[seed] = 1;
+    while (head < order.size()) {
+      const int e = order[head++];
+      for (int k = ptr[e]; k < ptr[e + 1]; k++) {
+        const int f = adj[k];
+        if (in[f] && !seen[f]) {
+          seen[f] = 1;
+          order.push_back(f);
+        }
+      }
+    }
+    seed = -1;
+  }
+}
+
+static void bisect(const std::vector<int>& ptr, const std::vector<int>& adj, std::vector<int>& set, int p0, int np, std::vector<int>& part) {
+  if (np == 1 || set.empty()) {
+    for (int e : set) part[e] = p0;
+    return;
+  }
+  std::vector<char> in(part.size(), 0);
+  for (int e : set) in[e] = 1;
+  std::vector<int> order;
+  bfs_order(ptr, adj, set, in, set[0], order);
+  const int far1 = order.back();                       // pseudo-peripheral element: the far end of a breadth-first search, twice
+  bfs_order(ptr, adj, set, in, far1, order);
+  const int far2 = order.back();
+  bfs_order(ptr, adj, set, in, far2, order);
+  const int np1 = np / 2;
+  const size_t n1 = (set.size() * (size_t)np1 + np / 2) / np;
+  std::vector<int> a(order.begin(), order.begin() + n1), b(order.begin() + n1, order.end());
+  std::sort(a.begin(), a.end());
+  std::sort(b.begin(), b.end());
+  bisect(ptr, adj, a, p0, np1, part);
+  bisect(ptr, adj, b, p0 + np1, np - np1, part);
+}
+
+extern "C" int fh_mesh_partition(fh_mesh_t G, int nparts, int* part) {
+  FH_GUARD_BEGIN
+  FH_REQUIRE(G && part && nparts >= 1, "fh_mesh_partition: bad arguments");
+  std::vector<int> ptr, adj, set(G->nel), p(G->nel, 0);
+  dual_graph(G, ptr, adj);
+  for (int e = 0; e < G->nel; e++) set[e] = e;
+  bisect(ptr, adj, set, 0, nparts, p);
+  fh_copy_out(part, p);
+  return 0;
+  FH_GUARD_END("fh_mesh_partition")
+}
+
+extern "C" int fh_mesh_rank_elements(fh_mesh_t G, const int* part, int rank, int* n_owned, int* n_total, int* elems) {
+  FH_GUARD_BEGIN
+  FH_REQUIRE(G && part && n_owned && n_total, "fh_mesh_rank_elements: bad arguments");
+  const int nl = G->nloc;
+  std::vector<char> touched(G->nnode, 0);
+  std::vector<int> own, ring;
+  for (int e = 0; e < G->nel; e++)
+    if (part[e] == rank) {
+      own.push_back(e);
+      for (int i = 0; i < nl; i++) touched[G->elem_dof[(size_t)e * nl + i]] = 1;
+    }
+  for (int e = 0; e < G->nel; e++) {
+    if (part[e] == rank) continue;
+    bool hit = false;
+    for (int i = 0; i < nl && !hit; i++) hit = touched[G->elem_dof[(size_t)e * nl + i]];
+    if (hit) ring.push_back(e);
+  }
+  *n_owned = (int)own.size();
+  *n_total = (int)(own.size() + ring.size());
+  if (elems) {
+    std::copy(own.begin(), own.end(), elems);
+    std::copy(ring.begin(), ring.end(), elems + own.size());
+  }
+  return 0;
+  FH_GUARD_END("fh_mesh_rank_elements")
+}
+
+extern "C" int fh_mesh_submesh(fh_mesh_t G, int nsel, const int* sel, fh_mesh_t* out, int* node_gid) {
+  FH_GUARD_BEGIN
+  FH_REQUIRE(G && sel && out && nsel >= 1, "fh_mesh_submesh: bad arguments");
+  const int nl = G->nloc, nf = nfaces_of(G->geom);
+  std::unique_ptr<fh_mesh_s> m(new fh_mesh_s());
+  m->geom = G->geom; m->dim = G->dim; m->nloc = nl; m->nel = nsel; m->level = G->level; m->amr_mode = G->amr_mode;
+  std::vector<int> loc(G->nnode, -1), glob;
+  m->elem_dof.resize((size_t)nsel * nl);
+  m->face_flag.resize((size_t)nsel * nf);
+  for (int k = 0; k < nsel; k++) {
+    const int e = sel[k];
+    FH_REQUIRE(e >= 0 && e < G->nel, "fh_mesh_submesh: element %d out of range", e);
+    for (int i = 0; i < nl; i++) {
+      const int g = G->elem_dof[(size_t)e * nl + i];
+      if (loc[g] < 0) {
+        loc[g] = (int)glob.size();
+        glob.push_back(g);
+      }
+      m->elem_dof[(size_t)k * nl + i] = loc[g];
+    }
+    for (int f = 0; f < nf; f++) m->face_flag[(size_t)k * nf + f] = G->face_flag[(size_t)e * nf + f];     // cut faces are interior faces of G: never boundary
+  }
+  const int nn = (int)glob.size();
+  m->coords.resize((size_t)nn * G->dim);
+  for (int i = 0; i < nn; i++)
+    for (int d = 0; d < G->dim; d++) m->coords[(size_t)i * G->dim + d] = G->coords[(size_t)glob[i] * G->dim + d];
+  m->elem_level.assign(nsel, 0);
+  // first-touch renumbering, and the same permutation on the node map
+  std::vector<int> before = m->elem_dof;
+  first_touch_renumber(*m, nn);
+  if (node_gid) {
+    for (size_t q = 0; q < before.size(); q++) node_gid[m->elem_dof[q]] = glob[before[q]];
+  }
+  *out = m.release();
+  return 0;
+  FH_GUARD_END("fh_mesh_submesh")
+}
+
+extern "C" int fh_dd_topo_node_keys(fh_mesh_t G, const int* part, int nlevels, const fh_mesh_t* levels, const int* elem_gid0, int level, int64_t* gid,
+                                    int* owner) {
+  FH_GUARD_BEGIN
+  FH_REQUIRE(G && part && levels && elem_gid0 && gid && owner && level >= 0 && level < nlevels && level <= 11, "fh_dd_topo_node_keys: bad arguments");
+  const int geom = G->geom, dim = G->dim, nl = G->nloc, nch = nvert_of(geom);
+  FH_REQUIRE(G->nnode < (1 << 24), "fh_dd_topo_node_keys: more than 2^24 coarse nodes");
+  // lowest rank among the elements around every coarse node = owner of everything inside the entity that node stands for
+  std::vector<int> minpart(G->nnode, INT32_MAX);
+  for (int e = 0; e < G->nel; e++)
+    for (int i = 0; i < nl; i++) {
+      int& mp = minpart[G->elem_dof[(size_t)e * nl + i]];
+      mp = std::min(mp, part[e]);
+    }
+  int node_at[3][3][3];                                  // local node with reference coordinates (sx-1, sy-1, sz-1)
+  for (int i = 0; i < nl; i++) node_at[xc(geom, i, 0) + 1][xc(geom, i, 1) + 1][dim == 3 ? xc(geom, i, 2) + 1 : 1] = i;
+  // every element of the level: its coarse element and the low corner of its box, in units of 2^-(level+1) of the coarse element
+  const int N = 1 << (level + 1);
+  struct Box { int ge, o[3], span; };
+  std::vector<Box> box(levels[0]->nel);
+  for (int e = 0; e < levels[0]->nel; e++) box[e] = Box{elem_gid0[e], {0, 0, 0}, N};
+  for (int l = 0; l < level; l++) {
+    const fh_mesh_s* mc = levels[l];
+    FH_REQUIRE(!mc->child.empty() && (int)box.size() == mc->nel, "fh_dd_topo_node_keys: level %d has not been refined into level %d", l, l + 1);
+    std::vector<Box> nb(levels[l + 1]->nel);
+    for (int e = 0; e < mc->nel; e++) {
+      if (!mc->refined[e]) {
+        nb[mc->child[(size_t)e * nch]] = box[e];       // copied element of an adaptive level
+        continue;
+      }
+      for (int j = 0; j < nch; j++) {                   // child j sits at the parent's vertex j
+        Box b = box[e];
+        b.span = box[e].span / 2;
+        for (int d = 0; d < dim; d++) b.o[d] += (xc(geom, j, d) > 0) ? b.span : 0;
+        nb[mc->child[(size_t)e * nch + j]] = b;
+      }
+    }
+    box.swap(nb);
+  }
+  const fh_mesh_s* mf = levels[level];
+  std::vector<char> done(mf->nnode, 0);
+  for (int e = 0; e < mf->nel; e++) {
+    const Box& b = box[e];
+    const int* gn = &G->elem_dof[(size_t)b.ge * nl];
+    for (int i = 0; i < nl; i++) {
+      const int nd = mf->elem_dof[(size_t)e * nl + i];
+      if (done[nd]) continue;
+      done[nd] = 1;
+      int p[3] = {0, 0, 0}, s[3] = {1, 1, 1};
+      for (int d = 0; d < dim; d++) {
+        p[d] = b.o[d] + (xc(geom, i, d) + 1) * b.span / 2;
+        s[d] = p[d] == 0 ? 0 : p[d] == N ? 2 : 1;
+      }
+      const int ent = gn[node_at[s[0]][s[1]][s[2]]];
+      int free_d[3], nfree = 0;
+      for (int d = 0; d < dim; d++)
+        if (s[d] == 1) free_d[nfree++] = d;
+      int64_t t[3] = {0, 0, 0};
+      auto corner = [&](int d1, int v1, int d2, int v2) {     // coarse node at the end(s) v of the free direction(s), the rest as s says
+        int q[3] = {s[0], s[1], s[2]};
+        q[d1] = v1;
+        if (d2 >= 0) q[d2] = v2;
+        return gn[node_at[q[0]][q[1]][q[2]]];
+      };
+      if (nfree == 1) {
+        const int d = free_d[0];
+        t[0] = corner(d, 0, -1, 0) < corner(d, 2, -1, 0) ? p[d] : N - p[d];
+      } else if (nfree == 2) {
+        const int d1 = free_d[0], d2 = free_d[1];
+        int m1 = 0, m2 = 0, best = INT32_MAX;
+        for (int a = 0; a < 2; a++)
+          for (int c = 0; c < 2; c++) {
+            const int g = corner(d1, 2 * a, d2, 2 * c);
+            if (g < best) { best = g; m1 = a; m2 = c; }
+          }
+        const int64_t u = m1 == 0 ? p[d1] : N - p[d1], v = m2 == 0 ? p[d2] : N - p[d2];
+        const bool first = corner(d1, 2 * (1 - m1), d2, 2 * m2) < corner(d1, 2 * m1, d2, 2 * (1 - m2));
+        t[0] = first ? u : v;
+        t[1] = first ? v : u;
+      } else if (nfree == 3) {
+        t[0] = p[0]; t[1] = p[1]; t[2] = p[2];
+      }
+      gid[nd] = ((int64_t)ent << 39) | (t[0] << 26) | (t[1] << 13) | t[2];
+      owner[nd] = minpart[ent];
+    }
+  }
+  return 0;
+  FH_GUARD_END("fh_dd_topo_node_keys")
+}

@@ -444,6 +444,16 @@ int fh_host_binary_load(const char* path, int* n, double* values);
  *                         (row nvars = end of the rank), kk_index[j] = global size of the variables before j
  *   fh_dd_system_dofs     LinearEquation::GetSystemDof (LinearEquation.cpp:76-85) for a list of mesh dofs of one variable: owner rank by
  *                         bisection of the dof offsets (Mesh.cpp:1004-1018), row = kk_offset[var][p] + idof - dof_offset[var][p] */
+/* Arbitrary coarse meshes (MeshMetisPartitioning.cpp:71-113: METIS_PartMeshDual on the coarsest level, children inherit :143-155):
+ *   fh_mesh_partition      native k-way partition of the dual graph (recursive bisection by breadth-first growing; METIS is not a dependency)
+ *   fh_mesh_rank_elements  a rank's elements: owned first, then the ring sharing a node with them
+ *   fh_mesh_submesh        FEMuS-numbered mesh of those elements + for every node the node of the coarse mesh it is
+ *   fh_dd_topo_node_keys   global id / owner (lowest rank around, Mesh.cpp:517-559) of every node of a refined level of the sub-mesh from
+ *                          the refinement tree alone (entity of the coarse mesh + dyadic offsets in a frame fixed by global ids) */
+int fh_mesh_partition(fh_mesh_t coarse, int nparts, int* part /* [nel] */);
+int fh_mesh_rank_elements(fh_mesh_t coarse, const int* part, int rank, int* n_owned, int* n_total, int* elems /* may be NULL */);
+int fh_mesh_submesh(fh_mesh_t coarse, int nsel, const int* sel, fh_mesh_t* sub, int* node_gid /* [nodes of sub], may be NULL */);
+int fh_dd_topo_node_keys(fh_mesh_t coarse, const int* part, int nlevels, const fh_mesh_t* levels, const int* elem_gid0, int level, int64_t* gid, int* owner);
 typedef struct fh_dd_plan_s* fh_dd_plan_t;
 typedef int (*fh_dd_alltoallv_fn)(void* user, const int64_t* send, const int* send_counts, int64_t* recv, int* recv_counts);
 int fh_dd_box_node_keys(int n, const double* coords /* [n*3] */, int level, int nb, const int p[3], int64_t* gid, int* owner);

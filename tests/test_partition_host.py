@@ -1,0 +1,96 @@
+"""General (non-box) domain decomposition on the host: native partitioner, sub-meshes, topological node keys (the
+reference: METIS_PartMeshDual on the coarsest level + inherited children, MeshMetisPartitioning.cpp:71-113, 143-155)."""
+import os
+import numpy as np
+import pytest
+
+from femus_amd import capi
+
+REF_INPUT = "/root/reference/applications/001_Poisson/input/cube_Hex.neu"
+
+
+def shuffled_box(n, seed):
+    """a box mesh whose elements come in a random order (sub-mesh of itself): nothing about it is structured any more"""
+    g = capi.Mesh.box(*n)
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(g.nel).astype(np.int32)
+    sub, _ = g.submesh(perm)
+    return sub
+
+
+@pytest.mark.parametrize("n,nparts", [((4, 4, 4), 2), ((4, 4, 4), 4), ((5, 3, 2), 3), ((6, 6, 0), 4), ((3, 3, 3), 8)])
+def test_partition_is_balanced_and_connected(n, nparts):
+    g = shuffled_box(n, 3)
+    part = g.partition(nparts)
+    cnt = np.bincount(part, minlength=nparts)
+    assert cnt.sum() == g.nel and cnt.max() - cnt.min() <= 1
+    ed, _, _ = g.arrays()
+    f0, f1 = (20, 26) if g.dim == 3 else (4, 8)
+    for p in range(nparts if nparts <= 4 else 0):        # few parts of a box: every part is face-connected (not guaranteed in general)
+        els = np.where(part == p)[0]
+        seen, todo = {els[0]}, [els[0]]
+        face_nodes = {e: set(ed[e, f0:f1]) for e in els}
+        while todo:
+            e = todo.pop()
+            for f in els:
+                if f not in seen and face_nodes[e] & face_nodes[f]:
+                    seen.add(f)
+                    todo.append(f)
+        assert len(seen) == els.size
+
+
+@pytest.mark.parametrize("n,nparts,nlev", [((4, 4, 4), 2, 3), ((3, 2, 2), 3, 2), ((4, 4, 0), 4, 3)])
+def test_topological_keys_agree_with_coordinates(n, nparts, nlev):
+    """on a (shuffled) box the nodes are identified by their exact dyadic coordinates as well: two nodes of two ranks' sub-meshes have the
+    same key iff they are the same point, every rank finds the same owner for it, and the owner is the lowest rank touching the node"""
+    g = shuffled_box(n, 7)
+    part = g.partition(nparts)
+    ed_g, xy_g, _ = g.arrays()
+    scale = 2 ** (nlev + 1) * np.array([max(v, 1) for v in n], dtype=float)
+    seen = {}                                            # point -> (key, owner)
+    lowest = {}                                          # point -> lowest rank with an element containing it (from the ranks' owned elements)
+    for r in range(nparts):
+        own, ring = g.rank_elements(part, r)
+        els = np.concatenate([own, ring])
+        sub, node_gid = g.submesh(els)
+        assert np.array_equal(xy_g[node_gid], sub.arrays()[1])
+        levels = [sub]
+        for _ in range(nlev - 1):
+            levels.append(levels[-1].refine())
+        for l in range(nlev):
+            gid, owner = g.topo_node_keys(part, levels, els, l)
+            ed, xy, _ = levels[l].arrays()
+            pts = [tuple(v) for v in np.rint(xy * scale[:g.dim]).astype(np.int64)]
+            assert len(set(gid.tolist())) == gid.size                     # distinct nodes, distinct keys
+            for k in range(gid.size):
+                key = (l,) + pts[k]
+                if key in seen:
+                    assert seen[key] == (gid[k], owner[k])
+                else:
+                    seen[key] = (gid[k], owner[k])
+            # lowest rank touching a node: walk the elements of this level that descend from OWNED coarse elements
+            nch = 2 ** g.dim
+            n_own_fine = own.size * nch ** l
+            for e in range(n_own_fine):
+                for nd in ed[e]:
+                    key = (l,) + pts[nd]
+                    lowest[key] = min(lowest.get(key, nparts), r)
+    for key, (gid, owner) in seen.items():
+        if key in lowest:
+            assert owner == lowest[key]
+    keys_by_level = {}
+    for (l, *_), (gid, _) in seen.items():
+        keys_by_level.setdefault(l, []).append(gid)
+    for l, ks in keys_by_level.items():
+        assert len(set(ks)) == len(ks)                                     # different points, different keys
+
+
+@pytest.mark.skipif(not os.path.exists(REF_INPUT), reason="reference inputs are only present in the build container")
+def test_gambit_mesh_can_be_partitioned_and_cut():
+    g = capi.Mesh.read_gambit(REF_INPUT)
+    part = g.partition(2)
+    assert sorted(np.bincount(part).tolist()) == [4, 4]
+    own, ring = g.rank_elements(part, 0)
+    assert own.size == 4 and ring.size == 4
+    sub, node_gid = g.submesh(np.concatenate([own, ring]))
+    assert sub.nel == 8 and sub.nnode == g.nnode
