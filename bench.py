@@ -121,6 +121,7 @@ def main():
                 parallelism = ("mesh domain decomposition, box split %dx%dx%d (METIS unavailable), one partition per GPU, ghost DOFs "
                                "exchanged by %s (fh_halo_begin/end, overlapped with the interior rows), the two coarsest levels replicated (all-reduce instead of exchanges)"
                                % (dd.GRIDS[world] + (how,)))
+                parallelism += "; partitioner: " + pb.partitioner + " (arbitrary coarse meshes: fh_mesh_partition, DistributedPoisson(coarse_mesh=...))"
                 if dist_err is not None:
                     parallelism += "; fell back from rccl: " + dist_err
                 err_here = None

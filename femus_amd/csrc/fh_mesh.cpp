@@ -1358,7 +1358,9 @@ extern "C" int fh_mesh_submesh(fh_mesh_t G, int nsel, const int* sel, fh_mesh_t*
   m->coords.resize((size_t)nn * G->dim);
   for (int i = 0; i < nn; i++)
     for (int d = 0; d < G->dim; d++) m->coords[(size_t)i * G->dim + d] = G->coords[(size_t)glob[i] * G->dim + d];
-  m->elem_level.assign(nsel, 0);
+  m->elem_level.resize(nsel);
+  for (int k = 0; k < nsel; k++) m->elem_level[k] = G->elem_level.empty() ? G->level : G->elem_level[sel[k]];
+  m->homogeneous = G->homogeneous;
   // first-touch renumbering, and the same permutation on the node map
   std::vector<int> before = m->elem_dof;
   first_touch_renumber(*m, nn);

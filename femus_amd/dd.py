@@ -650,7 +650,8 @@ class DistributedPoisson:
     the numeric part -- what LinearImplicitSystem::MGsolve does before every solve (LinearImplicitSystem.cpp:347-383)."""
 
     def __init__(self, ctx, comm, nranks, rank, nb=8, nlevels=4, omega=2. / 3., npre=2, npost=2, fe="biquadratic", order="seventh",
-                 transport="rccl", flag_fn=None, n_uniform=None, source_kind=0, params=(1.0,), halo_comm=None, n_replicated=2):
+                 transport="rccl", flag_fn=None, n_uniform=None, source_kind=0, params=(1.0,), halo_comm=None, n_replicated=2,
+                 coarse_mesh=None, partition=None):
         """flag_fn / n_uniform: adaptive levels (BASELINE config "MGAMR ... 8 GPUs"): every rank refines its extended box with the
         same flag function on global coordinates.  The fine level is then assembled AND projected (hanging nodes) on the extended
         box with the one-GPU code and the owned rows are gathered out on the device; uniform hierarchies keep the leaner
@@ -658,7 +659,21 @@ class DistributedPoisson:
         import time
         from .poisson import PoissonMG
         self.ctx, self.comm = ctx, comm
-        self.part = BoxPartition(nranks, rank)
+        # coarse_mesh: ANY HEX27 / QUAD9 coarse mesh (a Gambit file, a box whose elements come in any order), the same object on every
+        # rank.  Its elements are partitioned natively (fh_mesh_partition: the METIS_PartMeshDual of MeshMetisPartitioning.cpp:71-113;
+        # `partition` overrides it), children inherit (:143-155); a rank's extended mesh = its elements + the ring of elements sharing a
+        # node with them, numbered like any FEMuS mesh; global node ids / owners come from the refinement tree (fh_dd_topo_node_keys).
+        # The coarse mesh itself is the replicated, exactly solved level of the cycle (there is no coarser mesh to go to).
+        self.general = coarse_mesh is not None
+        if self.general:
+            assert flag_fn is None and nlevels >= 2 and fe == "biquadratic", "general partitions: uniform levels, Q2, at least two levels"
+
+            class _Part:
+                pass
+            self.part = _Part()
+            self.part.nranks, self.part.rank = nranks, rank
+        else:
+            self.part = BoxPartition(nranks, rank)
         self.nb, self.nl = nb, nlevels
         self.omega, self.npre, self.npost = omega, npre, npost
         self.source_kind, self.params = source_kind, params
@@ -668,7 +683,21 @@ class DistributedPoisson:
         self.n_replicated = 2 if (n_replicated >= 2 and nlevels >= 2) else 1
         part = self.part
         # 1. full local hierarchy on the extended box (device): assemble, Galerkin chain, SetPenalty
-        meshes = local_meshes(part, nb, nlevels, flag_fn, n_uniform)
+        if self.general:
+            G = coarse_mesh
+            self.n_replicated = 0
+            self.partition = np.asarray(partition if partition is not None else G.partition(nranks), dtype=np.int32)
+            own_e, ring_e = G.rank_elements(self.partition, rank)
+            assert own_e.size > 0, "rank %d owns no coarse element" % rank
+            els0 = np.concatenate([own_e, ring_e]).astype(np.int32)
+            sub, node_gid = G.submesh(els0)
+            meshes = [sub]
+            for l in range(1, nlevels):
+                meshes.append(meshes[-1].refine())
+            self.partitioner = "native recursive bisection of the dual graph (fh_mesh_partition), %d coarse elements" % G.nel
+        else:
+            meshes = local_meshes(part, nb, nlevels, flag_fn, n_uniform)
+            self.partitioner = "box split %dx%dx%d" % tuple(part.p)
         self.adaptive = flag_fn is not None and not all(m.elem_levels()[1] for m in meshes)
         full = PoissonMG(ctx, 0, 0, 0, nlevels, fe=fe, order=order, omega=omega, npre=npre, npost=npost, meshes=meshes,
                          source_kind=source_kind, params=params)
@@ -678,7 +707,10 @@ class DistributedPoisson:
         self.full = full
         # 2. exchange plans (host, integers): owners from the global grid index of the nodes, halos from the operators' patterns
         coords = [m.arrays()[1] for m in meshes]
-        gids, owners = zip(*[node_keys(coords[l], l, nb, part) for l in range(nlevels)])
+        if self.general:
+            gids, owners = zip(*[coarse_mesh.topo_node_keys(self.partition, meshes, els0, l) for l in range(nlevels)])
+        else:
+            gids, owners = zip(*[node_keys(coords[l], l, nb, part) for l in range(nlevels)])
         own_rows = [np.where(owners[l] == rank)[0].astype(np.int32) for l in range(nlevels)]
         need = []
         for l in range(nlevels):
@@ -722,7 +754,70 @@ class DistributedPoisson:
             for pl in plans:     # one RCCL communicator, one exchange plan per level
                 self.halos.append(capi.Halo(ctx, rank, nranks, uid, pl.send_counts, pl.send_idx, pl.recv_counts,
                                             parent=self.halos[0] if self.halos else None))
-        # 5. replicated level below: this rank's share of P^T A_0 P as a device triple product, summed over the ranks
+        if self.general:
+            # 5g. the coarse mesh as the replicated, exactly solved level: owned rows of every rank scattered into its stencil pattern and summed
+            loc = plans[0]
+            all_local = np.concatenate([loc.owned, loc.ghost])
+            n_g0 = coarse_mesh.n_dofs(fe)
+            gl_of_local = node_gid.astype(np.int64)                           # node of the extended mesh -> node of the coarse mesh
+            grp, gcol = capi.pattern_from_elements(coarse_mesh.arrays()[0], n_g0)
+            self.A_g0 = ctx.matrix_csr(n_g0, n_g0, grp, gcol)
+            src_row = np.full(n_g0, -1, dtype=np.int32)
+            src_row[gl_of_local[loc.owned]] = np.arange(loc.n_owned, dtype=np.int32)
+            src_col = np.full(n_g0, -1, dtype=np.int32)
+            src_col[gl_of_local[all_local]] = loc.newid[all_local]
+            self.map_g0 = self.A_g0.value_map(self.A[0], src_row, src_col)
+            p1, m = full.P[1].restrict(plans[1].owned, gl_of_local.astype(np.int32), n_g0)       # owned level-1 rows x coarse-mesh columns
+            m.destroy()
+            self.P1_rep = p1
+            self.R1_rep = p1.get_transpose()
+            self.bdc_rep = capi.Index(ctx, coarse_mesh.dirichlet_dofs(fe).astype(np.int32))
+            self._replicated_operator()
+        else:
+            self._init_replicated_box(ctx, full, plans, gids, nloc, fe, nb, part)
+        # 6. distributed fine-level assembler: elements touching an owned node, renumbered to [owned | ghost]
+        top = plans[-1]
+        ed, xy, _ = meshes[-1].arrays()
+        own_mask = np.zeros(meshes[-1].nnode, dtype=bool)
+        own_mask[top.owned] = True
+        els = np.where(own_mask[ed].any(axis=1))[0]
+        ntop = nloc[-1]
+        if self.adaptive:
+            # assemble() runs the extended-box assembly + hanging-node projection and gathers the owned rows
+            self.asm = None
+            self.map_rows = capi.Index(ctx, top.owned.astype(np.int32))
+        else:
+            ed_new = top.newid[ed[els]]
+            assert ed_new.min() >= 0
+            xy_new = np.zeros((ntop, 3))
+            both = np.concatenate([top.owned, top.ghost])
+            xy_new[top.newid[both]] = xy[both]
+            self.asm = capi.Assembler(ctx, None, fe, self.A[-1], order, elem_dof=ed_new, coords=xy_new)
+        self.n_owned, self.n_loc = top.n_owned, ntop
+        # vectors in the reference's global numbering: this rank owns [offsets[rank], offsets[rank + 1]), ghosts carry the owners' global
+        # indices (NumericVector::init(N, n_local, ghost, fast, GHOSTED); operator()(global index) reaches owned and ghost entries)
+        assert int(top.offsets[-1]) < 2 ** 31, "global dof numbers beyond 32 bits (PetscInt is an int in the reference as well, PetscVector.hpp:536)"
+        mk = lambda: ctx.vector(int(top.offsets[-1]), top.n_owned, int(top.offsets[rank]), top.ghost_global.astype(np.int32))
+        self.RES, self.EPSC, self.SOL = mk(), mk(), mk()
+        self.bdc_top = H.bdc_owned[-1].astype(np.int32)
+        self.bdc_dev = capi.Index(ctx, self.bdc_top)       # BuildBdcIndex once, device-resident
+        self.mg = capi.Multigrid(ctx, nlevels if self.general else nlevels + 1)
+        self._wire_cycle()
+        self.mg.setup()
+        self.ndof_owned = top.n_owned
+        self.nel_local = els.size
+        self.asm_top = self.asm
+        self.prepare_first_s = None
+        # one numeric re-preparation, timed: what every later MGsolve pays
+        ctx.sync()
+        t0 = time.time()
+        self.prepare()
+        ctx.sync()
+        self.prepare_ms = (time.time() - t0) * 1e3
+
+    def _init_replicated_box(self, ctx, full, plans, gids, nloc, fe, nb, part):
+        """5. replicated level(s) below the box hierarchy: this rank's share of P^T A_0 P as a device triple product, summed over the ranks"""
+        rank = part.rank
         m_rep, m_g0 = replicated_level(part, nb)
         Pg = capi.build_prolongator(ctx, m_rep, m_g0, fe, zero_bdc=True)
         n_rep = m_rep.n_dofs(fe)
@@ -782,53 +877,22 @@ class DistributedPoisson:
         for m_ in (m_rep, m_g0):
             m_.destroy()
         self._replicated_operator()
-        # 6. distributed fine-level assembler: elements touching an owned node, renumbered to [owned | ghost]
-        top = plans[-1]
-        ed, xy, _ = meshes[-1].arrays()
-        own_mask = np.zeros(meshes[-1].nnode, dtype=bool)
-        own_mask[top.owned] = True
-        els = np.where(own_mask[ed].any(axis=1))[0]
-        ntop = nloc[-1]
-        if self.adaptive:
-            # assemble() runs the extended-box assembly + hanging-node projection and gathers the owned rows
-            self.asm = None
-            self.map_rows = capi.Index(ctx, top.owned.astype(np.int32))
-        else:
-            ed_new = top.newid[ed[els]]
-            assert ed_new.min() >= 0
-            xy_new = np.zeros((ntop, 3))
-            both = np.concatenate([top.owned, top.ghost])
-            xy_new[top.newid[both]] = xy[both]
-            self.asm = capi.Assembler(ctx, None, fe, self.A[-1], order, elem_dof=ed_new, coords=xy_new)
-        self.n_owned, self.n_loc = top.n_owned, ntop
-        # vectors in the reference's global numbering: this rank owns [offsets[rank], offsets[rank + 1]), ghosts carry the owners' global
-        # indices (NumericVector::init(N, n_local, ghost, fast, GHOSTED); operator()(global index) reaches owned and ghost entries)
-        assert int(top.offsets[-1]) < 2 ** 31, "global dof numbers beyond 32 bits (PetscInt is an int in the reference as well, PetscVector.hpp:536)"
-        mk = lambda: ctx.vector(int(top.offsets[-1]), top.n_owned, int(top.offsets[rank]), top.ghost_global.astype(np.int32))
-        self.RES, self.EPSC, self.SOL = mk(), mk(), mk()
-        self.bdc_top = H.bdc_owned[-1].astype(np.int32)
-        self.bdc_dev = capi.Index(ctx, self.bdc_top)       # BuildBdcIndex once, device-resident
-        self.mg = capi.Multigrid(ctx, nlevels + 1)
-        self._wire_cycle()
-        self.mg.setup()
-        self.ndof_owned = top.n_owned
-        self.nel_local = els.size
-        self.asm_top = self.asm
-        self.prepare_first_s = None
-        # one numeric re-preparation, timed: what every later MGsolve pays
-        ctx.sync()
-        t0 = time.time()
-        self.prepare()
-        ctx.sync()
-        self.prepare_ms = (time.time() - t0) * 1e3
 
     @property
     def A_coarse(self):
         """operator of the coarsest (replicated, exactly solved) level of the cycle"""
-        return self.A_rep2 if self.n_replicated == 2 else self.A_rep
+        return self.A_g0 if self.general else self.A_rep2 if self.n_replicated == 2 else self.A_rep
 
     def _wire_cycle(self):
         mg, nl = self.mg, self.nl
+        if self.general:
+            mg.set_level(0, self.A_g0, None, None, 0, self.omega, 1, 0)                                  # replicated, solved exactly
+            mg.set_level(1, self.A[1], self.P1_rep, self.R1_rep, 0, self.omega, self.npre, self.npost)
+            mg.set_level_distributed(1, self.halos[1], True)
+            for l in range(2, nl):
+                mg.set_level(l, self.A[l], self.P[l], self.R[l], 0, self.omega, self.npre, self.npost)
+                mg.set_level_distributed(l, self.halos[l], False)
+            return
         if self.n_replicated == 2:
             mg.set_level(0, self.A_rep2, None, None, 0, self.omega, 1, 0)
             mg.set_level(1, self.A_g0, self.Pg, None, 0, self.omega, self.npre, self.npost)           # replicated, smoothed, no exchange
@@ -848,6 +912,11 @@ class DistributedPoisson:
     def _replicated_operator(self):
         """A_rep = sum over ranks of P_rep^T A_0 Pg_local on the stencil pattern, then SetPenalty -- all on the device.  With two replicated
         levels: A_g0 = owned rows of all ranks summed into the global pattern, A_rep2 = Pg^T A_g0 Pg computed by every rank"""
+        if self.general:
+            self.map_g0.gather_matrix_values(self.A_g0, self.A[0])
+            self.halos[1].allreduce_mat(self.A_g0)
+            self.bdc_rep.zero_rows(self.A_g0, 1.0)
+            return
         if self.n_replicated == 2:
             self.map_g0.gather_matrix_values(self.A_g0, self.A[0])
             self.halos[1].allreduce_mat(self.A_g0)

@@ -389,3 +389,83 @@ def test_preflight_small_problem_on_one_rank(ctx):
     """the same stage in-process on one rank with the RCCL transport selected (plans without neighbours are inert)"""
     from femus_amd import dd, rccl_preflight
     assert rccl_preflight.small_problem_check(ctx, dd.SocketComm(0, 1), 0, 1, "rccl") < 1e-9
+
+
+# ---- arbitrary coarse meshes: native partitioner + topological node keys (the METIS path of the reference, MeshMetisPartitioning.cpp:71-155) ----
+def _general_coarse_mesh(kind):
+    """the same coarse mesh on every rank: "shuffled" = a 4 x 3 x 2 box whose elements come in random order with perturbed (curved) interior
+    nodes; "gambit" = applications/001_Poisson/input/cube_Hex.neu (a data file of the reference, copied to tests/golden) refined once"""
+    import os
+    from femus_amd import capi
+    if kind == "gambit":
+        g0 = capi.Mesh.read_gambit(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cube_Hex.neu"))
+        g = g0.refine()
+        g0.destroy()
+        return g
+    box = capi.Mesh.box(4, 3, 2)
+    rng = np.random.default_rng(11)
+    g, _ = box.submesh(rng.permutation(box.nel).astype(np.int32))
+    box.destroy()
+    ed, xy, ff = g.arrays()
+    on_bdry = np.zeros(g.nnode, dtype=bool)
+    for f in range(6):
+        loc = capi.fe_face_nodes("hex", "biquadratic", f)
+        els = np.where(ff[:, f] < -1)[0]
+        on_bdry[ed[els][:, loc].ravel()] = True
+    xy = xy + np.where(on_bdry[:, None], 0.0, rng.uniform(-0.02, 0.02, xy.shape))
+    g.set_coords(xy)
+    return g
+
+
+def _general_worker(rank, world, port, kind, nlevels, out):
+    try:
+        import femus_amd as fa
+        from femus_amd import dd as ddm
+        comm = ddm.SocketComm(rank, world, "127.0.0.1", port)
+        ctx = fa.Context(0)
+        G = _general_coarse_mesh(kind)
+        dp = ddm.DistributedPoisson(ctx, comm, world, rank, nlevels=nlevels, transport="host", coarse_mesh=G)
+        dp.assemble(); dp.set_penalty_top()
+        its, rn = dp.solve(outer="gmres", rtol=1e-12, maxit=60)
+        top = dp.H.plans[-1]
+        xy = dp.full.meshes[-1].arrays()[1][top.owned]
+        np.savez(out % rank, x=dp.EPSC.to_numpy()[:dp.n_owned].copy(), xy=xy, its=its, part=dp.partition, n_owned=dp.n_owned)
+        comm.barrier()
+        comm.close()
+    except BaseException:
+        _record_worker_failure("general", rank, world)
+        raise
+
+
+@pytest.mark.parametrize("kind,world", [("shuffled", 2), ("shuffled", 3), ("gambit", 2), ("gambit", 4)])
+def test_general_partition_equals_the_serial_solve(ctx, tmp_path, kind, world):
+    """a coarse mesh that is no box any more (random element order + curved elements; a Gambit file), partitioned natively into 2-4 parts,
+    every rank building its extended mesh from the element adjacency and its ghost lists from the topological node keys: the distributed
+    GMRES solution equals the single-GPU solve of the same hierarchy (1e-10); every node is owned exactly once"""
+    import torch.multiprocessing as mp
+    nlevels = 3
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_general_worker, args=(world, _free_port(), kind, nlevels, out), nprocs=world, join=True)
+    G = _general_coarse_mesh(kind)
+    meshes = [G]
+    for l in range(1, nlevels):
+        meshes.append(meshes[-1].refine())
+    pb = PoissonMG(ctx, 0, 0, 0, nlevels, meshes=meshes).init()
+    pb.assemble()
+    pb.prepare()
+    pb.mgsolve(outer="gmres", rtol=1e-12)
+    ref = pb.EPSC.to_numpy()
+    xy = meshes[-1].arrays()[1]
+    key = lambda a: [tuple(v) for v in np.rint(a * 1e9).astype(np.int64)]
+    pos = {k: i for i, k in enumerate(key(xy))}
+    assert len(pos) == xy.shape[0]
+    seen = np.zeros(xy.shape[0], dtype=int)
+    for r in range(world):
+        d = np.load(out % r)
+        idx = np.array([pos[k] for k in key(d["xy"])])
+        seen[idx] += 1
+        assert np.linalg.norm(d["x"] - ref[idx]) <= 1e-10 * np.linalg.norm(ref), (r, int(d["its"]))
+        cnt = np.bincount(d["part"], minlength=world)
+        assert cnt.max() - cnt.min() <= 1
+    assert np.all(seen == 1)                               # every node has exactly one owner
+    pb.destroy()
