@@ -249,6 +249,7 @@ def main():
     spmv_ms = ctx.timer_stop() / kr
     spmv_bytes = A.spmv_algorithmic_bytes()
     sweep_bytes = spmv_bytes + 3 * 8 * n       # + b, dinv, x(own row) per SURVEY 8(d) Jacobi-sweep model
+    exp_lo, exp_hi = A.spmv_expected_bytes(3)
     cyc_bytes = pb.mg.cycle_algorithmic_bytes()
     ai = pb.asm_top.info()
 
@@ -301,6 +302,12 @@ def main():
             "traffic": TRAFFIC["spmv"]["bytes"] if world == 1 else None,
             "traffic_from_profile": TRAFFIC["spmv"]["source"] if world == 1 else None,
             "algorithmic_bytes_per_launch": sweep_bytes,
+            "expected_bytes": exp_lo,
+            "expected_bytes_no_l2_reuse": exp_hi,
+            "expected_bytes_note": "bytes of the arrays the kernel really touches (fh_spmv_expected_bytes): values 8 B + 16-bit local columns 2 B per "
+                                   "non-zero, distinct-column lists 4 B each, block descriptors, row pointers, b / D^-1 / x_row / y; x counted once "
+                                   "(`expected_bytes`) or once per row block (`..._no_l2_reuse`).  `traffic` (counters, FETCH_SIZE x 2 + WRITE_SIZE; "
+                                   "factor calibrated per access width in profiles/r03_fetch_calibration.md) should lie between the two",
             "avg_launch_ms": sweep_ms,
             "plain_spmv_ms": spmv_ms,
         },

@@ -424,6 +424,12 @@ class Mat:
     def spmv_algorithmic_bytes(self):
         return int(self.L.fh_spmv_algorithmic_bytes(self.h))
 
+    def spmv_expected_bytes(self, mode=0):
+        """(lo, hi) bytes of the arrays the product kernel touches: x counted once / once per row block (fh_spmv_expected_bytes)"""
+        lo, hi = ctypes.c_int64(), ctypes.c_int64()
+        _chk(self.L.fh_spmv_expected_bytes(self.h, int(mode), ctypes.byref(lo), ctypes.byref(hi)))
+        return lo.value, hi.value
+
 
 class Mesh:
     """box mesh + uniform refinement in FEMuS numbering (Mesh / MeshRefinement, nprocs = 1)."""

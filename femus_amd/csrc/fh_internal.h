@@ -140,6 +140,7 @@ struct fh_mat_s {
   int* d_tile_s = nullptr;             // first non-zero of every row block (persistent pipelined kernel)
   int* d_blkinfo = nullptr;            // 8 ints per row block: r0, r1, s, e, u0, nu (one descriptor load instead of a pointer chain)
   int lx_tile = 0;
+  int64_t nu_total = 0;                // sum over the row blocks of their distinct columns (entries of d_ucols)
   int max_row = 0;
   // interior / interface split of the row blocks for operators over [owned | ghost] columns (fh_dev_spmv_part):
   // descriptors permuted so that blocks without a ghost column come first

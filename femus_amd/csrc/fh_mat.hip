@@ -99,6 +99,22 @@ extern "C" int64_t fh_spmv_algorithmic_bytes(fh_mat_t A) {
   return 12ll * A->nnz + 4ll * (A->m + 1) + 8ll * A->n + 8ll * A->m;
 }
 
+// Bytes the LDS-staged kernel (spmv_kernel 3) really touches per product, from the sizes of its arrays: the value stream (8 nnz), the 16-bit
+// local columns (2 nnz), the distinct-column lists (4 per entry of ucols), the 32-byte block descriptors, the row pointers of the block's
+// rows, y (and b, D^-1, x_row for the fused forms) -- and x: `lo` counts every entry of x once (all tiles that share a column find it in the
+// L2), `hi` counts every tile's gather as a miss.  The algorithmic figure (12 B per non-zero) sits between the two for FE matrices.
+extern "C" int fh_spmv_expected_bytes(fh_mat_t A, int mode, int64_t* lo, int64_t* hi) {
+  FH_REQUIRE(A && lo && hi && mode >= 0 && mode <= 3, "fh_spmv_expected_bytes: bad arguments");
+  fh_ctx_t c = A->ctx;
+  if (A->tile != c->spmv_tile || (A->tile_kernel != 3 && A->tile_kernel != 4)) FH_TRY(fh_mat_build_rowblocks(A, c->spmv_tile));
+  if (A->lx_tile != A->tile) FH_TRY(fh_mat_build_localcols(A));
+  const int64_t fixed = 10ll * A->nnz + 4ll * A->nu_total + 32ll * A->nblk + 4ll * ((int64_t)A->m + A->nblk) + 8ll * A->m +
+                        (mode == 1 || mode == 2 ? 8ll * A->m : mode == 3 ? 24ll * A->m : 0);
+  *lo = fixed + 8ll * A->n;
+  *hi = fixed + 8ll * A->nu_total;
+  return 0;
+}
+
 // row blocks: greedy, <= tile non-zeros and <= 512 rows per block; a row longer than the tile is alone
 int fh_mat_build_rowblocks(fh_mat_t A, int tile) {
   FH_REQUIRE(tile == 256 || tile == 512 || tile == 1024 || tile == 2048 || tile == 4096, "spmv_tile must be 256..4096, power of two (got %d)", tile);
@@ -740,6 +756,7 @@ int fh_mat_build_localcols(fh_mat_t A) {
   for (auto& x : th) x.join();
   for (int b = 0; b < nblk; b++) uptr[b + 1] += uptr[b];
   std::vector<int> ucols((size_t)uptr[nblk] + 1);
+  A->nu_total = uptr[nblk];
   for (int t = 0; t < nthreads; t++)
     if (!chunks[t].empty()) std::copy(chunks[t].begin(), chunks[t].end(), ucols.begin() + uptr[bounds[t]]);
   if (A->d_uptr) FH_CHECK_HIP(hipFree(A->d_uptr));

@@ -176,6 +176,9 @@ int fh_spmv_transpose(fh_mat_t A, fh_vec_t x, fh_vec_t y);       /* y = A^T x vi
 int fh_mat_split_info(fh_mat_t A, int n_own_cols, int* nblk_interior, int* nblk_interface);
 /* algorithmic bytes of one y=Ax with this matrix: 12 nnz + 4 (m+1) + 8 n + 8 m */
 int64_t fh_spmv_algorithmic_bytes(fh_mat_t A);
+/* bytes of the arrays the LDS-staged product kernel reads and writes (mode: 0 y = Ax, 1 y += Ax, 2 r = b - Ax, 3 Jacobi sweep); lo: x counted once,
+ * hi: every row block's gather of x counted (no reuse between blocks) */
+int fh_spmv_expected_bytes(fh_mat_t A, int mode, int64_t* lo, int64_t* hi);
 
 /* ---- FE tables (a1-a3, a6) -------------------------------------------------------------------
  * geom: 0 = hex (HEX27 geometry), 1 = quad (QUAD9).  fe: 0 = linear (Q1), 2 = biquadratic (Q2)  (FEMuS SolType ids).
