@@ -117,6 +117,34 @@ def test_cavity_reynolds_1000_by_continuation(ctx):
     pb.destroy()
 
 
+def test_config4_at_its_stated_parameters_by_continuation(ctx):
+    """BASELINE config 4 exactly as stated: lid-driven cavity, Q2/Q1 Taylor-Hood, 10 x 10 coarse QUAD9 mesh, FOUR levels (80 x 80 elements,
+    58 403 unknowns), viscosity 0.001 (Re = 1000), Newton + multigrid-preconditioned GMRES on one GPU.  Newton from rest diverges at this
+    viscosity on the coarse grid, so the coarse level is walked down in viscosity first (0.01 -> 0.004 -> 0.002 -> 0.001); the F-cycle
+    then runs at the target value on every level.  Checks: every Newton solve converges, the discrete residual of the free rows vanishes
+    on the finest level, and the primary vortex has the published strength (Ghia et al. 1982: minimum of the wall-parallel velocity on
+    the centreline -0.38 at Re = 1000)."""
+    nl = 4
+    pb = NavierStokesMG(ctx, 10, 10, 0, nl, 0.01).init()
+    for nu in (0.01, 0.004, 0.002, 0.001):
+        pb.nu = nu
+        assert pb.newton(0, tol=1e-10, max_newton=25)
+    for ig in range(1, nl):
+        pb.prolongator_sol(ig)
+        assert pb.newton(ig, tol=1e-9, max_newton=25, lin_rtol=1e-10, lin_maxit=200)
+    assert pb.n[-1] == 58403
+    top = nl - 1
+    pb.prepare(top)
+    assert pb.RES[top].l2_norm() < 1e-8
+    _, xy, _ = pb.meshes[-1].arrays()
+    sol = pb.SOL[-1].to_numpy()
+    off = pb.offsets[-1]
+    line = np.where(abs(xy[:, 1]) < 1e-12)[0]
+    vmin = sol[off[1] + line].min()
+    assert -0.40 < vmin < -0.37
+    pb.destroy()
+
+
 def test_three_dimensional_cavity_matches_oracle(ctx):
     """HEX27 Taylor-Hood (89 x 89 element Jacobians, Vanka patches of up to 376 dofs): lid on the z = hi face moving in x,
     two levels, Newton + multigrid GMRES against the oracle's Newton with exact linear solves"""
