@@ -191,6 +191,7 @@ def _declare(L):
     sig("fh_write_vtu", c_void_p, c_char_p, c_int, c_void_p, c_void_p, c_void_p)
     sig("fh_write_gmv", c_void_p, c_char_p, c_int, c_int, c_void_p, c_void_p, c_void_p)
     sig("fh_xdmf_available")
+    sig("fh_assembler_galerkin", c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p)
     sig("fh_spmv_expected_bytes", c_void_p, c_int, P(ctypes.c_int64), P(ctypes.c_int64))
     sig("fh_mesh_partition", c_void_p, c_int, c_void_p)
     sig("fh_mesh_rank_elements", c_void_p, c_void_p, c_int, P(c_int), P(c_int), c_void_p)

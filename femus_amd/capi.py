@@ -678,6 +678,11 @@ class Assembler:
         p = _f64(list(params) + [0.0] * (4 - len(params)))
         _chk(self.L.fh_assemble_poisson(self.h, None if sol is None else sol.h, int(source_kind), _p(p), A.h, res.h))
 
+    def galerkin_from(self, fine, child, fine_bdc, coarse_bdc, Ac):
+        """Ac = PP^T KK PP element by element from the element matrices `fine` holds (fh_assembler_galerkin); self = the coarse level"""
+        ch, fb, cb = _i32(child), _i32(fine_bdc), _i32(coarse_bdc)
+        _chk(self.L.fh_assembler_galerkin(fine.h, self.h, _p(ch), fb.size, _p(fb), cb.size, _p(cb), Ac.h))
+
     def affine_count(self):
         """(elements the affine fast path would take, elements that need quadrature)"""
         a, g = ctypes.c_int(), ctypes.c_int()

@@ -45,6 +45,10 @@ struct fh_assembler_s {
   double* d_Kbuf = nullptr;      // [nadj*kstride] element rows in row-gather order
   size_t kbuf_bytes = 0;
   int nadj = 0;                  // element rows in d_Kbuf; row nadj is the spare one
+  // element-wise Galerkin product from the next finer level (fh_assembler_galerkin): children, child interpolation tables, Dirichlet masks
+  int* d_gal_child = nullptr;
+  unsigned char *d_gal_cnt = nullptr, *d_gal_row = nullptr, *d_gal_fb = nullptr, *d_gal_cb = nullptr;
+  double *d_gal_val = nullptr, *d_gal_res = nullptr, *d_gal_dense = nullptr;
   int kstride = 27;              // doubles per element row in d_Kbuf (nc, or 32 for HEX27/Q2: whole 64-byte lines per row)
   double* d_Fbuf = nullptr;      // [nadj]
   bool two_pass = false;
@@ -2169,7 +2173,8 @@ extern "C" int fh_assembler_destroy(fh_assembler_t as) {
   if (as->d_prog) hipFree(as->d_prog);
   if (as->d_prog_consts) hipFree(as->d_prog_consts);
   hipFree(as->d_iota);
-  for (void* q : {(void*)as->d_adj_ptr, (void*)as->d_adj_ei, (void*)as->d_rowmap, (void*)as->d_Kbuf, (void*)as->d_Fbuf, (void*)as->d_slot})
+  for (void* q : {(void*)as->d_adj_ptr, (void*)as->d_adj_ei, (void*)as->d_rowmap, (void*)as->d_Kbuf, (void*)as->d_Fbuf, (void*)as->d_slot, (void*)as->d_gal_child,
+                  (void*)as->d_gal_cnt, (void*)as->d_gal_row, (void*)as->d_gal_fb, (void*)as->d_gal_cb, (void*)as->d_gal_val, (void*)as->d_gal_res, (void*)as->d_gal_dense})
     if (q) hipFree(q);
   delete as;
   return 0;
@@ -2316,6 +2321,320 @@ extern "C" int fh_assembler_info(fh_assembler_t as, int* ncolors, int64_t* algor
   if (flops)
     *flops = (double)as->nel * ng * (nc * dim * dim * 2.0 + 60.0 + nc * dim * dim * 2.0 + (double)nc * nc * (dim * 2.0 + 2.0) + nc * 10.0);
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Galerkin coarse operator ELEMENT BY ELEMENT (uniform refinement): A = sum_e K_e and every fine element lies in one coarse element, whose
+// 27 (9) nodes interpolate its nodes by the fixed child matrix C_j (the rows of the element prolongator, ElemType.cpp:439-532), so
+//   PP^T KK PP = sum_E sum_{children j of E} C_j^T K_{child j} C_j          (LinearImplicitSystem.cpp:347-370, PetscMatrix.cpp:733-751)
+// -- coarse ELEMENT matrices from the fine ones the assembler still holds, then the same row pass as the assembly.  The general sparse triple
+// product streams ~10 elementary products per non-zero (8 ms on the 64^3 level); this reads the element-row buffer once (1.8 GB) and does
+// 7 k multiply-adds per child with the 125 non-zeros of C_j.  Rows of the interpolation at fine Dirichlet nodes and its columns at coarse
+// Dirichlet nodes are zero (ZeroInterpolatorDirichletNodes, :1032-1120): masks on K_j and on the result.  Same value as the product up to
+// the order of the sums.  One wave per coarse element.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NC, int NCH>
+__global__ __launch_bounds__(256) void k_galerkin_elem(int nelc, const int* __restrict__ child, const int* __restrict__ slot_f, const double* __restrict__ Kf, int ks_f,
+                                                       const int* __restrict__ edof_f, int nloc_f, const unsigned char* __restrict__ fb,
+                                                       const int* __restrict__ slot_c, double* __restrict__ Kc, int ks_c, const int* __restrict__ edof_c, int nloc_c,
+                                                       const unsigned char* __restrict__ cb, const unsigned char* __restrict__ tab_cnt,
+                                                       const unsigned char* __restrict__ tab_row, const double* __restrict__ tab_val) {
+  constexpr int NE = NC * NC, NT = (NE + 63) / 64, LD = NC + 1;
+  __shared__ double cval[NCH * NC * 8];
+  __shared__ unsigned char crow[NCH * NC * 8], ccnt[NCH * NC];
+  __shared__ double slab[4][2][NC * LD];
+  for (int k = threadIdx.x; k < NCH * NC * 8; k += 256) { cval[k] = tab_val[k]; crow[k] = tab_row[k]; }
+  for (int k = threadIdx.x; k < NCH * NC; k += 256) ccnt[k] = tab_cnt[k];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* Ks = slab[wave][0];
+  double* Ts = slab[wave][1];
+  for (int E = blockIdx.x * 4 + wave; E < nelc; E += gridDim.x * 4) {
+    double acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = 0.0;
+    for (int j = 0; j < NCH; j++) {
+      const int ej = child[(size_t)E * NCH + j];
+      // all gathers of the child first (independent chains in flight), then the LDS writes
+      double kin[NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const int idx = min(lane + 64 * t, NE - 1);
+        const int i = idx / NC, c = idx - i * NC;
+        const int s = slot_f[(size_t)ej * NC + i];
+        const bool dead = s < 0 || fb[edof_f[(size_t)ej * nloc_f + i]] || fb[edof_f[(size_t)ej * nloc_f + c]];
+        kin[t] = dead ? 0.0 : Kf[(size_t)max(s, 0) * ks_f + c];
+      }
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const int idx = lane + 64 * t;
+        if (idx < NE) Ks[(idx / NC) * LD + idx % NC] = kin[t];
+      }
+      wave_lds_sync();
+      // T = K_j C_j and K_E += C_j^T T: the (at most 8) non-zeros of a column of C_j, padded with zero weights -- a fixed trip count and
+      // NT independent chains per lane instead of one serial chain of dependent LDS reads per entry
+      {
+        double tv[NT];
+        int rbase[NT], cbase[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          const int idx = min(lane + 64 * t, NE - 1);
+          rbase[t] = (idx / NC) * LD;
+          cbase[t] = (j * NC + idx % NC) * 8;
+          tv[t] = 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+#pragma unroll
+          for (int t = 0; t < NT; t++) tv[t] += Ks[rbase[t] + crow[cbase[t] + q]] * cval[cbase[t] + q];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          const int idx = lane + 64 * t;
+          if (idx < NE) Ts[(idx / NC) * LD + idx % NC] = tv[t];
+        }
+      }
+      wave_lds_sync();
+      {
+        int kcol[NT], abase[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          const int idx = min(lane + 64 * t, NE - 1);
+          kcol[t] = idx % NC;
+          abase[t] = (j * NC + idx / NC) * 8;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+#pragma unroll
+          for (int t = 0; t < NT; t++) acc[t] += cval[abase[t] + q] * Ts[crow[abase[t] + q] * LD + kcol[t]];
+      }
+      wave_lds_sync();
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const int idx = lane + 64 * t;
+      if (idx < NE) {
+        const int a = idx / NC, k = idx - a * NC;
+        const int s = slot_c[(size_t)E * NC + a];
+        if (s >= 0) {
+          const bool dead = cb[edof_c[(size_t)E * nloc_c + a]] || cb[edof_c[(size_t)E * nloc_c + k]];
+          Kc[(size_t)s * ks_c + k] = dead ? 0.0 : acc[t];
+        }
+      }
+    }
+  }
+}
+
+// The same on the FP64 matrix cores (default): per child two small dense products T = K_j C_j and K_E += C_j^T T as v_mfma_f64_16x16x4 tiles
+// (27 -> 32 x 32 x 28 padded: 2 x 28 instructions of 64 cycles), operands from LDS (the eight C_j, the gathered K_j, T), the element rows of
+// the NEXT child gathered into registers while the current one is multiplied.  One wave per coarse element, one workgroup of four per CU.
+template <int NC, int NCH>
+__global__ __launch_bounds__(256) void k_galerkin_mfma(int nelc, const int* __restrict__ child, const int* __restrict__ slot_f, const double* __restrict__ Kf, int ks_f,
+                                                       const int* __restrict__ edof_f, int nloc_f, const unsigned char* __restrict__ fb,
+                                                       const int* __restrict__ slot_c, double* __restrict__ Kc, int ks_c, const int* __restrict__ edof_c, int nloc_c,
+                                                       const unsigned char* __restrict__ cb, const double* __restrict__ Cdense /* [NCH][NC][NC] */) {
+  constexpr int NE = NC * NC, NT = (NE + 63) / 64, MT = (NC + 15) / 16, KP = (NC + 3) / 4 * 4, CLD = MT * 16, KLD = KP + 1, TLD = MT * 16;
+  extern __shared__ __attribute__((aligned(16))) double gm_smem[];
+  double* Cs = gm_smem;                                   // [NCH][KP][CLD], zero padded
+  for (int k = threadIdx.x; k < NCH * KP * CLD; k += 256) {
+    const int j = k / (KP * CLD), r = (k / CLD) % KP, c = k % CLD;
+    Cs[k] = (r < NC && c < NC) ? Cdense[(j * NC + r) * NC + c] : 0.0;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* Ks = Cs + NCH * KP * CLD + wave * (MT * 16 * KLD + KP * TLD);      // [MT*16][KLD]
+  double* Ts = Ks + MT * 16 * KLD;                                            // [KP][TLD]
+  for (int k = lane; k < MT * 16 * KLD + KP * TLD; k += 64) Ks[k] = 0.0;     // the padding stays zero
+  __syncthreads();
+  const int kk = lane >> 4, li = lane & 15;
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  for (int E = blockIdx.x * 4 + wave; E < nelc; E += gridDim.x * 4) {
+    d4 KE[MT][MT];
+#pragma unroll
+    for (int a = 0; a < MT; a++)
+#pragma unroll
+      for (int b = 0; b < MT; b++) KE[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+    double kin[NT];
+    auto gather = [&](int j) {      // K_j with the rows / columns of Dirichlet nodes zeroed (kept in registers until the LDS is free)
+      const int ej = child[(size_t)E * NCH + j];
+      const int ln = min(lane, NC - 1);
+      const int sl = slot_f[(size_t)ej * NC + ln];
+      const bool dn = sl < 0 || fb[edof_f[(size_t)ej * nloc_f + ln]];
+      const unsigned long long dead = __ballot(dn && lane < NC);
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const int idx = min(lane + 64 * t, NE - 1);
+        const int i = idx / NC, c = idx - i * NC;
+        const int s = __shfl(sl, i, 64);
+        const bool d = ((dead >> i) | (dead >> c)) & 1ull;
+        kin[t] = d ? 0.0 : Kf[(size_t)max(s, 0) * ks_f + c];
+      }
+    };
+    gather(0);
+    for (int j = 0; j < NCH; j++) {
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const int idx = lane + 64 * t;
+        if (idx < NE) Ks[(idx / NC) * KLD + idx % NC] = kin[t];
+      }
+      wave_lds_sync();
+      if (j + 1 < NCH) gather(j + 1);
+      const double* Cj = Cs + j * KP * CLD;
+      d4 T[MT][MT];
+#pragma unroll
+      for (int a = 0; a < MT; a++)
+#pragma unroll
+        for (int b = 0; b < MT; b++) T[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k0 = 0; k0 < KP; k0 += 4) {
+        double av[MT], bv[MT];
+#pragma unroll
+        for (int x = 0; x < MT; x++) {
+          av[x] = Ks[(x * 16 + li) * KLD + k0 + kk];
+          bv[x] = Cj[(k0 + kk) * CLD + x * 16 + li];
+        }
+#pragma unroll
+        for (int a = 0; a < MT; a++)
+#pragma unroll
+          for (int b = 0; b < MT; b++) T[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], T[a][b], 0, 0, 0);
+      }
+#pragma unroll
+      for (int a = 0; a < MT; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = a * 16 + kk + 4 * r;
+          if (i < KP) {
+#pragma unroll
+            for (int b = 0; b < MT; b++) Ts[i * TLD + b * 16 + li] = T[a][b][r];
+          }
+        }
+      wave_lds_sync();
+#pragma unroll
+      for (int k0 = 0; k0 < KP; k0 += 4) {
+        double av[MT], bv[MT];
+#pragma unroll
+        for (int x = 0; x < MT; x++) {
+          av[x] = Cj[(k0 + kk) * CLD + x * 16 + li];        // A[row a][k i] = C_j[i][a]
+          bv[x] = Ts[(k0 + kk) * TLD + x * 16 + li];
+        }
+#pragma unroll
+        for (int a = 0; a < MT; a++)
+#pragma unroll
+          for (int b = 0; b < MT; b++) KE[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], KE[a][b], 0, 0, 0);
+      }
+      wave_lds_sync();
+    }
+    // rows / columns of coarse Dirichlet nodes are zero; rows without a slot are not stored
+    const int ln = min(lane, NC - 1);
+    const int slc = slot_c[(size_t)E * NC + ln];
+    const unsigned long long cdead = __ballot(lane < NC && cb[edof_c[(size_t)E * nloc_c + ln]]);
+#pragma unroll
+    for (int a = 0; a < MT; a++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int ra = a * 16 + kk + 4 * r;
+        const int s = __shfl(slc, min(ra, NC - 1), 64);
+#pragma unroll
+        for (int b = 0; b < MT; b++) {
+          const int k = b * 16 + li;
+          if (ra < NC && k < NC && s >= 0) {
+            const bool d = ((cdead >> ra) | (cdead >> k)) & 1ull;
+            Kc[(size_t)s * ks_c + k] = d ? 0.0 : KE[a][b][r];
+          }
+        }
+      }
+  }
+}
+
+template <int NC, int NCH>
+static size_t galerkin_mfma_lds() {
+  constexpr int MT = (NC + 15) / 16, KP = (NC + 3) / 4 * 4;
+  return ((size_t)NCH * KP * MT * 16 + 4 * ((size_t)MT * 16 * (KP + 1) + (size_t)KP * MT * 16)) * sizeof(double);
+}
+
+extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, const int* child, int nfb, const int* fbdc, int ncb, const int* cbdc, fh_mat_t Ac) {
+  FH_GUARD_BEGIN
+  FH_REQUIRE(fas && cas && child && Ac && (nfb == 0 || fbdc) && (ncb == 0 || cbdc), "fh_assembler_galerkin: null argument");
+  FH_REQUIRE(fas->two_pass && cas->two_pass && fas->nc == cas->nc && fas->geom == cas->geom && (fas->nc == 27 || fas->nc == 9),
+             "fh_assembler_galerkin: both levels need the two-pass biquadratic assembler");
+  const int nch = fhfe::nvert_of(cas->geom), nc = cas->nc;
+  FH_REQUIRE(fas->nel == cas->nel * nch, "fh_assembler_galerkin: %d fine elements are not the uniform refinement of %d coarse ones", fas->nel, cas->nel);
+  FH_REQUIRE(Ac->m == cas->ndof, "fh_assembler_galerkin: the coarse matrix does not belong to the coarse assembler");
+  fh_ctx_t c = cas->ctx;
+  auto up = [&](void** d, const void* h, size_t bytes) -> int {
+    if (*d) FH_CHECK_HIP(hipFree(*d));
+    FH_CHECK_HIP(hipMalloc(d, bytes ? bytes : 8));
+    if (bytes) FH_CHECK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+    return 0;
+  };
+  if (!cas->d_gal_child) {        // integer / table set-up, once per hierarchy
+    FH_TRY(up((void**)&cas->d_gal_child, child, (size_t)cas->nel * nch * sizeof(int)));
+    std::vector<unsigned char> cnt((size_t)nch * nc, 0), row((size_t)nch * nc * 8, 0);
+    std::vector<double> val((size_t)nch * nc * 8, 0.0), phi(nc), dphi((size_t)nc * 3);
+    for (int j = 0; j < nch; j++)
+      for (int i = 0; i < nc; i++) {                      // fine node i of child j: C_j[i][k] = phi_k at its reference point in the parent
+        double pt[3] = {0, 0, 0};
+        fhfe::child_node_ref(cas->geom, j, i, pt);
+        fhfe::eval_basis(cas->geom, fhfe::FE_BIQUADRATIC, pt, phi.data(), dphi.data());
+        for (int k = 0; k < nc; k++)
+          if (std::fabs(phi[k]) > 1e-14) {                // the threshold of ElemType.cpp:439-532
+            unsigned char& n = cnt[(size_t)j * nc + k];
+            FH_REQUIRE(n < 8, "fh_assembler_galerkin: more than 8 fine nodes of a child depend on one coarse node");
+            row[((size_t)j * nc + k) * 8 + n] = (unsigned char)i;
+            val[((size_t)j * nc + k) * 8 + n] = phi[k];
+            n++;
+          }
+      }
+    {
+      std::vector<double> dense((size_t)nch * nc * nc, 0.0);
+      for (int j = 0; j < nch; j++)
+        for (int k = 0; k < nc; k++)
+          for (int q = 0; q < cnt[(size_t)j * nc + k]; q++) dense[((size_t)j * nc + row[((size_t)j * nc + k) * 8 + q]) * nc + k] = val[((size_t)j * nc + k) * 8 + q];
+      FH_TRY(up((void**)&cas->d_gal_dense, dense.data(), dense.size() * sizeof(double)));
+    }
+    FH_TRY(up((void**)&cas->d_gal_cnt, cnt.data(), cnt.size()));
+    FH_TRY(up((void**)&cas->d_gal_row, row.data(), row.size()));
+    FH_TRY(up((void**)&cas->d_gal_val, val.data(), val.size() * sizeof(double)));
+    std::vector<unsigned char> fb(fas->nnode, 0), cb(cas->nnode, 0);
+    for (int k = 0; k < nfb; k++) {
+      FH_REQUIRE(fbdc[k] >= 0 && fbdc[k] < fas->nnode, "fh_assembler_galerkin: fine Dirichlet node %d out of range", fbdc[k]);
+      fb[fbdc[k]] = 1;
+    }
+    for (int k = 0; k < ncb; k++) {
+      FH_REQUIRE(cbdc[k] >= 0 && cbdc[k] < cas->nnode, "fh_assembler_galerkin: coarse Dirichlet node %d out of range", cbdc[k]);
+      cb[cbdc[k]] = 1;
+    }
+    FH_TRY(up((void**)&cas->d_gal_fb, fb.data(), fb.size()));
+    FH_TRY(up((void**)&cas->d_gal_cb, cb.data(), cb.size()));
+    FH_CHECK_HIP(hipMalloc(&cas->d_gal_res, std::max<size_t>(cas->ndof, 1) * sizeof(double)));
+  }
+  const int grid = std::max(1, std::min(fh_div_up(cas->nel, 4), c->num_cu * 2));
+  if (c->galerkin_mfma) {
+    const size_t lds = nc == 27 ? galerkin_mfma_lds<27, 8>() : galerkin_mfma_lds<9, 4>();
+    static bool attr_set[64] = {};
+    if (!attr_set[c->device & 63]) {
+      FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_galerkin_mfma<27, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)galerkin_mfma_lds<27, 8>()));
+      FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_galerkin_mfma<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)galerkin_mfma_lds<9, 4>()));
+      attr_set[c->device & 63] = true;
+    }
+    const int g1 = std::max(1, std::min(fh_div_up(cas->nel, 4), c->num_cu));
+    if (nc == 27)
+      hipLaunchKernelGGL((k_galerkin_mfma<27, 8>), dim3(g1), dim3(256), lds, c->stream, cas->nel, cas->d_gal_child, fas->d_slot, fas->d_Kbuf, fas->kstride, fas->d_elem_dof,
+                         fas->nloc, cas->d_gal_fb, cas->d_slot, cas->d_Kbuf, cas->kstride, cas->d_elem_dof, cas->nloc, cas->d_gal_cb, cas->d_gal_dense);
+    else
+      hipLaunchKernelGGL((k_galerkin_mfma<9, 4>), dim3(g1), dim3(256), lds, c->stream, cas->nel, cas->d_gal_child, fas->d_slot, fas->d_Kbuf, fas->kstride, fas->d_elem_dof,
+                         fas->nloc, cas->d_gal_fb, cas->d_slot, cas->d_Kbuf, cas->kstride, cas->d_elem_dof, cas->nloc, cas->d_gal_cb, cas->d_gal_dense);
+  } else if (nc == 27)
+    hipLaunchKernelGGL((k_galerkin_elem<27, 8>), dim3(grid), dim3(256), 0, c->stream, cas->nel, cas->d_gal_child, fas->d_slot, fas->d_Kbuf, fas->kstride,
+                       fas->d_elem_dof, fas->nloc, cas->d_gal_fb, cas->d_slot, cas->d_Kbuf, cas->kstride, cas->d_elem_dof, cas->nloc, cas->d_gal_cb, cas->d_gal_cnt,
+                       cas->d_gal_row, cas->d_gal_val);
+  else
+    hipLaunchKernelGGL((k_galerkin_elem<9, 4>), dim3(grid), dim3(256), 0, c->stream, cas->nel, cas->d_gal_child, fas->d_slot, fas->d_Kbuf, fas->kstride,
+                       fas->d_elem_dof, fas->nloc, cas->d_gal_fb, cas->d_slot, cas->d_Kbuf, cas->kstride, cas->d_elem_dof, cas->nloc, cas->d_gal_cb, cas->d_gal_cnt,
+                       cas->d_gal_row, cas->d_gal_val);
+  FH_CHECK_HIP(hipGetLastError());
+  FH_CHECK_HIP(hipMemsetAsync(cas->d_Fbuf, 0, std::max<size_t>(cas->nadj, 1) * sizeof(double), c->stream));
+  FH_TRY(dispatch_rows(cas, Ac, cas->d_gal_res, false));
+  return 0;
+  FH_GUARD_END("fh_assembler_galerkin")
 }
 
 // ------------------------------------------------------------------------------------------------------------------

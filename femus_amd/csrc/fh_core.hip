@@ -140,6 +140,7 @@ extern "C" int fh_set_option(fh_ctx_t c, const char* name, double value) {
   else if (!strcmp(name, "assemble_rows2")) c->assemble_rows2 = (int)value;
   else if (!strcmp(name, "assemble_sf")) c->assemble_sf = (int)value;
   else if (!strcmp(name, "assemble_sumfac")) c->assemble_sumfac = (int)value;
+  else if (!strcmp(name, "galerkin_mfma")) c->galerkin_mfma = (int)value;
   else if (!strcmp(name, "gj_block")) c->gj_block = (int)value;
   else if (!strcmp(name, "gj_mfma")) c->gj_mfma = (int)value;
   else if (!strcmp(name, "gj_symmetric")) c->gj_symmetric = (int)value;

@@ -18,7 +18,7 @@ from . import capi
 class PoissonMG:
     def __init__(self, ctx, nx, ny, nz, nlevels, fe="biquadratic", order="seventh", lo=(0., 0., 0.), hi=(1., 1., 1.),
                  omega=2. / 3., npre=2, npost=2, coarse="galerkin", source_kind=0, params=(1.0,), meshes=None,
-                 smoother=0, dirichlet=None, source_expr=None, source_scale=1.0):
+                 smoother=0, dirichlet=None, source_expr=None, source_scale=1.0, elementwise_galerkin=True):
         self.ctx = ctx
         self.fe, self.order = fe, order
         self.nlevels = nlevels
@@ -28,6 +28,7 @@ class PoissonMG:
         self.smoother = smoother                  # capi.SMOOTH_JACOBI / SMOOTH_GS_COLOR
         self.dirichlet = dirichlet                # per level: Dirichlet dof lists when only some faces are Dirichlet
         self.source_expr, self.source_scale = source_expr, source_scale     # capi.Expr: f = scale * expr(x, y, z, t)
+        self.elementwise_galerkin = elementwise_galerkin
         if meshes is not None:
             self.meshes = list(meshes)
         else:
@@ -72,7 +73,10 @@ class PoissonMG:
         self.A = [None] * self.nlevels
         self.KK = [None] * self.nlevels          # assembled matrix where it differs from the operator of the cycle (AMR)
         self.asm = [None] * self.nlevels
-        levels = range(self.nlevels) if self.coarse == "rediscretise" else [top]
+        # Galerkin chain of a uniformly refined Q2 hierarchy: element by element from the element matrices of the next finer level
+        # (fh_assembler_galerkin) instead of the sparse triple product -- every level then carries the element pattern and an assembler
+        self.gal_elem = (self.coarse == "galerkin" and self.elementwise_galerkin and not self.amr and fe == "biquadratic" and self.nlevels > 1)
+        levels = range(self.nlevels) if (self.coarse == "rediscretise" or self.gal_elem) else [top]
         for l in levels:
             ed, xy, _ = self.meshes[l].arrays()
             rp, col = capi.pattern_from_elements(ed[:, :self.nc], self.ndof[l])
@@ -87,6 +91,7 @@ class PoissonMG:
         self.SOL = ctx.vector(n)
         self.sol_lvl = [None] * self.nlevels
         self.bdc_dev = [capi.Index(ctx, b) for b in self.bdc]      # BuildBdcIndex, once (device-resident)
+        self._child = [None] * self.nlevels
         return self
 
     # ---- assembly of the level to assemble (the finest) --------------------------------------------------------
@@ -116,6 +121,11 @@ class PoissonMG:
         top = self.nlevels - 1
         if self.coarse == "galerkin":
             for l in range(top, 0, -1):            # PtAP chain from the un-penalised operators
+                if self.gal_elem:
+                    if self._child[l - 1] is None:
+                        self._child[l - 1] = self.meshes[l - 1].child_elems()
+                    self.asm[l - 1].galerkin_from(self.asm[l], self._child[l - 1], self.bdc[l], self.bdc[l - 1], self.A[l - 1])
+                    continue
                 if self.A[l - 1] is None:
                     self.A[l - 1] = capi.Mat.ptap(self.P[l], self.A[l])
                 else:

@@ -257,6 +257,11 @@ typedef struct fh_assembler_s* fh_assembler_t;
 int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int gauss_order, int nel, int nloc, const int* elem_dof,
                         int nnode, const double* coords /* [nnode*dim] */, fh_mat_t A, fh_assembler_t* as);
 int fh_assembler_destroy(fh_assembler_t as);
+/* Galerkin coarse operator PP^T KK PP of a UNIFORMLY refined level, element by element, from the element matrices the fine assembler
+ * holds since its last assembly (LinearImplicitSystem.cpp:347-370 calls the sparse product SparseMatrix::matrix_PtAP): child[nel_coarse * 2^dim]
+ * = the fine elements of every coarse element (fh_mesh_child_elems), fbdc / cbdc = the Dirichlet nodes whose interpolation rows / columns are
+ * zero (ZeroInterpolatorDirichletNodes).  Ac must carry the finite-element pattern of the coarse mesh (the pattern `coarse` was created on). */
+int fh_assembler_galerkin(fh_assembler_t fine, fh_assembler_t coarse, const int* child, int nfb, const int* fbdc, int ncb, const int* cbdc, fh_mat_t Ac);
 int fh_assemble_poisson(fh_assembler_t as, fh_vec_t sol, int source_kind, const double* params, fh_mat_t A, fh_vec_t res);
 int fh_assembler_info(fh_assembler_t as, int* ncolors, int64_t* algorithmic_bytes, double* flops);
 /* element-level entry (tests): K[nel*nc*nc], F[nel*nc] for the given elements, no scatter */
