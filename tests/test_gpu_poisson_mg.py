@@ -108,3 +108,41 @@ def test_against_frozen_path_vectors(ctx, tag, box, fe):
     x = R[tag + "_x_dense_lu"]
     assert np.linalg.norm(pb.SOL.to_numpy() - x) <= 1e-10 * np.linalg.norm(x)
     pb.destroy()
+
+
+@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("box,nl", [((2, 2, 2), 3), ((3, 2, 0), 3), ((2, 1, 2), 2)])
+def test_elementwise_galerkin_equals_the_sparse_triple_product(ctx, box, nl, mfma):
+    """PP^T KK PP of a uniformly refined Q2 hierarchy built element by element from the fine element matrices (fh_assembler_galerkin, on the
+    matrix cores or with the sparse child tables) against the sparse triple product (fh_mat_ptap) and against the oracle's chain, on curved
+    elements, 3-D and 2-D, with Dirichlet rows / columns of the interpolation zeroed: every level operator to 1e-12"""
+    from femus_amd import capi
+    rng = np.random.default_rng(9)
+    ctx.set_option("galerkin_mfma", mfma)
+    try:
+        ops = []
+        for elementwise in (True, False):
+            m0 = capi.Mesh.box(*box)
+            meshes = [m0]
+            for _ in range(1, nl):
+                meshes.append(meshes[-1].refine())
+            if elementwise:                                   # the same perturbation for both builds
+                _, xy, ff = meshes[-1].arrays()
+                ed = meshes[-1].arrays()[0]
+                onb = np.zeros(meshes[-1].nnode, dtype=bool)
+                for f in range(2 * m0.dim):
+                    loc = capi.fe_face_nodes(m0.geom, "biquadratic", f)
+                    onb[ed[np.where(ff[:, f] < -1)[0]][:, loc].ravel()] = True
+                xy_pert = xy + np.where(onb[:, None], 0.0, rng.uniform(-0.01, 0.01, xy.shape))
+            meshes[-1].set_coords(xy_pert)
+            pb = PoissonMG(ctx, 0, 0, 0, nl, meshes=meshes, elementwise_galerkin=elementwise).init()
+            assert pb.gal_elem == elementwise
+            pb.assemble()
+            pb.level_operators()
+            ops.append([pb.A[l].to_scipy() for l in range(nl)])
+            pb.destroy()
+        for l in range(nl):
+            ref = ops[1][l]
+            assert abs(ops[0][l] - ref).max() <= 1e-12 * abs(ref).max(), l
+    finally:
+        ctx.set_option("galerkin_mfma", 1)
