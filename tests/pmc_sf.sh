@@ -3,6 +3,7 @@
 NW=${1:-8}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${2:-$ROOT/gpurun_out/sf_pmc_summary.md}
+case $OUT in /*) ;; *) OUT=$PWD/$OUT ;; esac
 mkdir -p $(dirname $OUT)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmcsf; mkdir -p /tmp/pmcsf

@@ -2,7 +2,7 @@
 # SpMV sweep and of the two assembly kernels, instruction / LDS / wait counters of the element kernel).  Counter passes use
 # --kernel-trace only (never sys / hip / memory traces), one counter set per pass.
 #   bash tests/profile_round.sh r02      -> gpurun_out/r02/*   (copy the summaries worth keeping into profiles/)
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
