@@ -64,6 +64,8 @@ extern "C" int fh_write_vtu(fh_mesh_t mesh, const char* path, int nfields, const
     for (int k = 0; k < nl; k++) conn[(size_t)e * nl + k] = ed[(size_t)e * nl + order[k]];
     offs[e] = (e + 1) * nl;
   }
+  for (int k = 0; k < nfields; k++)                          // names go into XML attributes as they are
+    FH_REQUIRE(names[k] && !strpbrk(names[k], "\"&<>"), "fh_write_vtu: field %d: name with a character that an XML attribute cannot hold", k);
   FILE* f = fopen(path, "w");
   FH_REQUIRE(f != nullptr, "fh_write_vtu: cannot open %s", path);
   std::unique_ptr<FILE, int (*)(FILE*)> guard(f, fclose);
@@ -105,6 +107,9 @@ extern "C" int fh_write_vtu(fh_mesh_t mesh, const char* path, int nfields, const
             b64_array(fv.data(), fv.size() * sizeof(float)).c_str());
   }
   fprintf(f, "      </PointData>\n    </Piece>\n  </UnstructuredGrid>\n</VTKFile>\n");
+  const bool wrote = ferror(f) == 0 && fflush(f) == 0;       // a full disk shows up here or at the close
+  const bool closed = fclose(guard.release()) == 0;
+  FH_REQUIRE(wrote && closed, "fh_write_vtu: writing %s failed", path);
   return 0;
 }
 

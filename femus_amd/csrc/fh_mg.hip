@@ -39,7 +39,10 @@ struct MgLevel {
   int npatch = 0, vanka_ncolors = 0, max_patch = 0;
   std::vector<int> h_pptr, h_pdofs, vcolor_ptr;
   std::vector<int64_t> h_poff;
-  int *d_pptr = nullptr, *d_pdofs = nullptr, *d_porder = nullptr, *d_pflag = nullptr;
+  int *d_pptr = nullptr, *d_pdofs = nullptr, *d_porder = nullptr, *d_pflag = nullptr, *d_pcptr = nullptr;
+  unsigned* d_pbar = nullptr;      // arrival / exit counters of the persistent sweep
+  int vanka_maxcolor = 0;          // patches of the largest colour
+  int pbar_len = 0;
   int64_t* d_poff = nullptr;
   double* d_pinv = nullptr;
   // distributed level: operator = owned rows over [owned | ghost] columns; halo refreshes the ghosts
@@ -251,6 +254,107 @@ __global__ __launch_bounds__(64) void k_vanka_color(const int* __restrict__ orde
     double s = 0.0;
     for (int c = 0; c < np; c++) s += Mi[(size_t)c * np + a] * rp[c];
     x[d[a]] += omega * s;
+  }
+}
+
+// ALL colours of ALL sweeps in one launch (fh_set_option(vanka_persistent, 1), default): a grid of resident one-wave workgroups walks
+// the colours together, a device-wide barrier between two colours instead of a launch boundary.  Every patch forms the residual
+// of its own rows (4 lanes per row, shuffle reduction), exact for the colour because its patches do not read each other's dofs;
+// pass A of a step (patch dofs, row extents: independent of x) is issued BEFORE the barrier wait, so that after the barrier only
+// the x-dependent part is on the critical path.  The grid is sized by the host to fit the device many times over (one wave and
+// <= 4 KB of LDS per workgroup), which is what makes the spin barrier safe.  bar[0]: arrivals (monotone), bar[1]: exits; the
+// last workgroup to leave zeroes both, so the next launch finds them clean.
+// Barrier of the resident grid.  MODE 1: one arrival counter (bar[0], monotone over the launch; bar[1] counts exits and the last
+// workgroup out zeroes both).  MODE 2: one flag per workgroup (plain stores, no read-modify-write on a shared address), workgroup 0
+// polls them 64 at a time and publishes the step in bar[0]; at the end every workgroup clears its flag, workgroup 0 then bar[0].
+__device__ __forceinline__ void wave_lds_sync() {      // LDS written by one lane, read by another lane of the same wave
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int MODE>
+__device__ __forceinline__ void vanka_grid_barrier(unsigned* bar, unsigned step) {
+  __threadfence();                                   // release: this workgroup's x updates reach the other XCDs' view
+  __syncthreads();
+  if (MODE == 1) {
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = step * gridDim.x;
+      while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+  } else {
+    unsigned* flags = bar + 2;
+    if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0) {
+      if (threadIdx.x < 64) {
+        for (unsigned w = threadIdx.x; w < gridDim.x; w += 64)
+          while (__hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != step) __builtin_amdgcn_s_sleep(1);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(bar, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (threadIdx.x == 0) {
+      while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != step) __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  __threadfence();                                   // acquire: drop stale lines of x before the next colour reads it
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_vanka_persistent(const int* __restrict__ order, const int* __restrict__ cptr, int ncolors, int nsweeps,
+                                                          const int* __restrict__ pptr, const int* __restrict__ pdofs,
+                                                          const int64_t* __restrict__ poff, const double* __restrict__ Minv,
+                                                          const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+                                                          const double* __restrict__ b, double* x, double omega, unsigned* bar, int max_patch) {
+  extern __shared__ double rp_all[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & 3, rl = lane >> 2;
+  double* rp = rp_all + (size_t)wave * max_patch;     // one patch per wave
+  const int nsteps = nsweeps * ncolors;
+  for (int st = 0; st < nsteps; st++) {
+    const int k = st % ncolors;
+    const int c0 = cptr[k], npat = cptr[k + 1] - c0;
+    if (st > 0) vanka_grid_barrier<MODE>(bar, (unsigned)st);
+    for (int q = blockIdx.x * 4 + wave; q < npat; q += gridDim.x * 4) {
+      const int p = order[c0 + q];
+      const int* d = pdofs + pptr[p];
+      const int np = pptr[p + 1] - pptr[p];
+      for (int a0 = 0; a0 < np; a0 += 16) {            // 16 rows at a time, 4 lanes per row
+        const int a = a0 + rl;
+        double acc = 0.0;
+        int row = 0;
+        if (a < np) {
+          row = d[a];
+          const int ke = rowptr[row + 1];
+          for (int kk = rowptr[row] + sub; kk < ke; kk += 4) acc += val[kk] * x[col[kk]];
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (a < np && sub == 0) rp[a] = b[row] - acc;
+      }
+      wave_lds_sync();
+      const double* Mi = Minv + poff[p];               // transposed inverse: Mi[c * np + a] = inv[a][c]
+      for (int a = lane; a < np; a += 64) {
+        double s = 0.0;
+        for (int c = 0; c < np; c++) s += Mi[(size_t)c * np + a] * rp[c];
+        x[d[a]] += omega * s;
+      }
+      wave_lds_sync();
+    }
+  }
+  // leave with clean counters for the next launch
+  if (MODE == 1) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned left = __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (left == gridDim.x - 1) {
+        __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(bar + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  } else if (nsteps > 1) {
+    vanka_grid_barrier<MODE>(bar, (unsigned)nsteps);  // everybody has read the last published step ...
+    vanka_grid_barrier<MODE>(bar, 0u);                // ... and the flags and the step go back to zero
   }
 }
 
@@ -1214,7 +1318,8 @@ static void free_level_colors(MgLevel& L) {
 
 // device side of the patch smoother (colouring by the matrix graph, inverses): rebuilt by the next setup; the patch lists stay
 static void free_level_patch_setup(MgLevel& L) {
-  for (void** q : {(void**)&L.d_pptr, (void**)&L.d_pdofs, (void**)&L.d_porder, (void**)&L.d_pflag, (void**)&L.d_poff, (void**)&L.d_pinv})
+  for (void** q : {(void**)&L.d_pptr, (void**)&L.d_pdofs, (void**)&L.d_porder, (void**)&L.d_pflag, (void**)&L.d_poff, (void**)&L.d_pinv, (void**)&L.d_pcptr,
+                   (void**)&L.d_pbar})
     if (*q) {
       hipFree(*q);
       *q = nullptr;
@@ -1307,6 +1412,12 @@ static int color_patches(MgLevel& L) {
   FH_TRY(up((void**)&L.d_pdofs, L.h_pdofs.data(), L.h_pdofs.size() * sizeof(int)));
   FH_TRY(up((void**)&L.d_poff, L.h_poff.data(), L.h_poff.size() * sizeof(int64_t)));
   FH_TRY(up((void**)&L.d_porder, order.data(), order.size() * sizeof(int)));
+  FH_TRY(up((void**)&L.d_pcptr, L.vcolor_ptr.data(), L.vcolor_ptr.size() * sizeof(int)));
+  L.pbar_len = 2 + 1024;
+  FH_CHECK_HIP(hipMalloc(&L.d_pbar, L.pbar_len * sizeof(unsigned)));
+  FH_CHECK_HIP(hipMemset(L.d_pbar, 0, L.pbar_len * sizeof(unsigned)));
+  L.vanka_maxcolor = 0;
+  for (int c = 0; c < ncol; c++) L.vanka_maxcolor = std::max(L.vanka_maxcolor, L.vcolor_ptr[c + 1] - L.vcolor_ptr[c]);
   FH_CHECK_HIP(hipMalloc(&L.d_pflag, (size_t)np * sizeof(int)));
   FH_CHECK_HIP(hipMalloc(&L.d_pinv, (size_t)L.h_poff[np] * sizeof(double)));
   return 0;
@@ -1330,6 +1441,20 @@ static int factor_patches(fh_mg_t mg, MgLevel& L) {
 // multiplicative Schwarz sweeps over the colours of the patches on A x = b (x updated in place; rwork: a residual vector)
 static int vanka_apply(fh_mg_t mg, MgLevel& L, double* x, const double* b, double* rwork, double omega, int nsweeps) {
   fh_ctx_t c = mg->ctx;
+  if (c->vanka_persistent && nsweeps > 0 && L.vanka_ncolors > 0) {
+    // four waves and 4 * max_patch * 8 <= 16 KB of LDS per workgroup, at most one workgroup per CU: the whole grid is resident
+    const int grid = std::max(1, std::min(fh_div_up(L.vanka_maxcolor, 4), c->num_cu));
+    FH_REQUIRE(grid <= L.pbar_len - 2, "Vanka smoother: barrier buffer too small");
+    const size_t lds = (size_t)4 * L.max_patch * sizeof(double);
+    if (c->vanka_persistent == 1)
+      hipLaunchKernelGGL(k_vanka_persistent<1>, dim3(grid), dim3(256), lds, c->stream, L.d_porder, L.d_pcptr, L.vanka_ncolors, nsweeps, L.d_pptr, L.d_pdofs,
+                         L.d_poff, L.d_pinv, L.A->d_rowptr, L.A->d_col, L.A->d_val, b, x, omega, L.d_pbar, L.max_patch);
+    else
+      hipLaunchKernelGGL(k_vanka_persistent<2>, dim3(grid), dim3(256), lds, c->stream, L.d_porder, L.d_pcptr, L.vanka_ncolors, nsweeps, L.d_pptr, L.d_pdofs,
+                         L.d_poff, L.d_pinv, L.A->d_rowptr, L.A->d_col, L.A->d_val, b, x, omega, L.d_pbar, L.max_patch);
+    FH_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   for (int s = 0; s < nsweeps; s++)
     for (int k = 0; k < L.vanka_ncolors; k++) {
       const int np = L.vcolor_ptr[k + 1] - L.vcolor_ptr[k];

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_ilu_factor(const int* __restrict__ rows
   if (gl == 0) {
     const int di = diagpos[i];
     double rsum = 0.0;
-    for (int p = rs; p < re; p++) rsum += fabs(w[p - rs]);
+    for (int p = (di < 0 ? rs : di + 1); p < re; p++) rsum += fabs(w[p - rs]);   // the U part of the row without its diagonal (PETSc: sctx.rs)
     if (di < 0 || !(fabs(w[di - rs]) > zeropivot * rsum)) atomicOr(flag, 1);
   }
 }

@@ -745,7 +745,7 @@ def sor_symmetric_natural(A, dinv, r):
 def ilu0_factor(A, zeropivot=1e-16):
     """ILU(0) in natural order on A's pattern -- PCILU as the reference configures it (PetscPreconditioner.cpp:91-115;
     PCFactorSetZeroPivot(1e-16), MAT_SHIFT_NONZERO: LinearEquationSolverPetsc.cpp:444-446).  IKJ elimination restricted to the
-    pattern; a pivot with |u_ii| <= zeropivot * sum_j |row_i| restarts the factorisation of A + shift I with shift = 100 eps,
+    pattern; a pivot with |u_ii| <= zeropivot * sum_{j>i} |u_ij| restarts the factorisation of A + shift I with shift = 100 eps,
     doubled at every further restart (PETSc 3.20.2 MatPivotCheck_nz; not under /root/reference).  Returns (L unit lower, U, shift)."""
     A = A.tocsr().copy()
     n = A.shape[0]
@@ -772,7 +772,7 @@ def ilu0_factor(A, zeropivot=1e-16):
                 pos = np.searchsorted(cols, kc)
                 hit = (pos < cols.size) & (cols[np.minimum(pos, cols.size - 1)] == kc)
                 v[rs + pos[hit]] -= lik * v[dpos[k] + 1:ip[k + 1]][hit]
-            if not abs(v[dpos[i]]) > zeropivot * np.abs(v[rs:re]).sum():
+            if not abs(v[dpos[i]]) > zeropivot * np.abs(v[dpos[i] + 1:re]).sum():    # sctx.rs = the U part without the diagonal
                 ok = False
                 break
         if ok:

@@ -50,8 +50,11 @@ def test_element_jacobian_and_assembly_match_oracle(ctx, box):
     asm.destroy(), A.destroy(), mh.destroy()
 
 
-def test_vanka_vcycle_matches_oracle(ctx):
-    """one multiplicative V(2,2) cycle with the block Schwarz smoother on the Jacobian of a non-trivial state"""
+@pytest.mark.parametrize("persistent", [0, 1, 2])
+def test_vanka_vcycle_matches_oracle(ctx, persistent):
+    """one multiplicative V(2,2) cycle with the block Schwarz smoother on the Jacobian of a non-trivial state; the sweep as one residual + one
+    patch launch per colour (default) and as one launch with device-wide barriers between the colours (two barrier forms)"""
+    ctx.set_option("vanka_persistent", persistent)
     nu, nl = 0.01, 3
     pb = NavierStokesMG(ctx, 4, 4, 0, nl, nu).init()
     ms, lays = ns.build_ns_levels(4, 4, 0, nl, LO, HI)
@@ -74,6 +77,7 @@ def test_vanka_vcycle_matches_oracle(ctx):
     ref = ns.vcycle(H, top, b)
     assert rel(x.to_numpy(), ref) < 1e-9
     pb.destroy()
+    ctx.set_option("vanka_persistent", 0)
 
 
 def test_cavity_newton_fcycle_matches_oracle(ctx):
