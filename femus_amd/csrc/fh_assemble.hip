@@ -2633,6 +2633,7 @@ extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, con
   FH_CHECK_HIP(hipGetLastError());
   FH_CHECK_HIP(hipMemsetAsync(cas->d_Fbuf, 0, std::max<size_t>(cas->nadj, 1) * sizeof(double), c->stream));
   FH_TRY(dispatch_rows(cas, Ac, cas->d_gal_res, false));
+  Ac->at_valid = false;       // new values: a cached explicit transpose is stale
   return 0;
   FH_GUARD_END("fh_assembler_galerkin")
 }
