@@ -670,7 +670,7 @@ void LinearEquationSolverHip::MGSolve(const bool) {
   }
   ZerosBoundaryResiduals();
   const int outer = (_mgSolverType == PREONLY) ? FH_OUTER_PREONLY : (_mgSolverType == RICHARDSON) ? FH_OUTER_RICHARDSON
-                    : (_mgSolverType == CG) ? FH_OUTER_CG : FH_OUTER_GMRES;
+                    : (_mgSolverType == CG) ? FH_OUTER_CG : (_mgSolverType == FGMRES) ? FH_OUTER_FGMRES : FH_OUTER_GMRES;
   hip_check(fh_mg_solve(_mg, static_cast<HipVector*>(_RES)->handle(), static_cast<HipVector*>(_EPSC)->handle(), outer, _rtol, _abstol, _dtol,
                         _maxits, _restart, &_its, &_rnorm),
             "MGSolve");

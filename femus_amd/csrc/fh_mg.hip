@@ -2050,7 +2050,7 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
     if (HL) FH_TRY(fh_halo_allreduce_sum(HL, out, 1));
     return 0;
   };
-  FH_REQUIRE(outer >= 0 && outer <= 3, "fh_mg_solve: unknown outer solver %d", outer);
+  FH_REQUIRE(outer >= 0 && outer <= 4, "fh_mg_solve: unknown outer solver %d", outer);
   double* b = bv->d;
   double* x = xv->d;
   int its = 0;
@@ -2104,6 +2104,103 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
       FH_TRY(dot(r, z, &rz_new));
       FH_TRY(dev_axpby(c, p, z, 1.0, rz_new / rz, n));
       rz = rz_new;
+    }
+  } else if (outer == FH_OUTER_FGMRES) {
+    // flexible GMRES(restart) (KSPFGMRES, LinearEquationSolverPetsc.cpp:506-507): RIGHT preconditioning with the vectors z_k = M^-1 v_k
+    // kept, so the cycle may be a different operator at every application (GMRES level solvers); classical Gram-Schmidt, Knoll
+    // guess x0 = M^-1 b, convergence on the TRUE residual norm against ||b|| (KSPConvergedDefault with a non-zero guess)
+    FH_REQUIRE(restart >= 1 && restart <= 200, "fh_mg_solve: restart %d out of range", restart);
+    FH_TRY(krylov_reserve(mg, 2 * restart + 2, ncols));
+    double** Vv = mg->kv.data();                       // v_0 .. v_restart
+    double** Zv = mg->kv.data() + restart + 1;         // z_0 .. z_{restart-1}
+    double* w = mg->kv[2 * restart + 1];
+    const int nb = sgrid(c, n);
+    FH_TRY(fh_reserve_reduction(c, (size_t)(restart + 2) * (nb + 1) + 64));
+    if (mg->d_V_n < 2 * restart + 1) {
+      if (mg->d_V) FH_CHECK_HIP(hipFree(mg->d_V));
+      mg->d_V = nullptr;
+      mg->d_V_n = 0;
+      FH_CHECK_HIP(hipMalloc(&mg->d_V, (2 * restart + 1) * sizeof(double*)));
+      mg->d_V_n = 2 * restart + 1;
+    }
+    double** d_V = mg->d_V;
+    double** d_Z = mg->d_V + restart + 1;
+    FH_CHECK_HIP(hipMemcpy(d_V, mg->kv.data(), (2 * restart + 1) * sizeof(double*), hipMemcpyHostToDevice));
+    std::vector<double> H((size_t)(restart + 1) * restart, 0.0), g(restart + 1), cs(restart), sn(restart), y(restart);
+    FH_TRY(apply_cycle(mg, b, x));
+    double bnorm;
+    FH_TRY(dot(b, b, &bnorm));
+    bnorm = sqrt(bnorm);
+    bool done = false;
+    while (!done) {
+      FH_TRY(spmv(x, Vv[0], 2, b));                            // v0 = b - A x
+      double beta;
+      FH_TRY(dot(Vv[0], Vv[0], &beta));
+      beta = sqrt(beta);
+      rn = beta;
+      if (beta <= std::max(rtol * bnorm, atol) || its >= maxit || beta > dtol * bnorm) break;
+      FH_TRY(dev_axpby(c, Vv[0], Vv[0], 0.0, 1.0 / beta, n));
+      std::fill(g.begin(), g.end(), 0.0);
+      g[0] = beta;
+      int kused = 0;
+      for (int k = 0; k < restart; k++) {
+        FH_TRY(apply_cycle(mg, Vv[k], Zv[k]));                 // z_k = M^-1 v_k
+        FH_TRY(spmv(Zv[k], w, 0, nullptr));                    // w = A z_k
+        hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, c->stream, (const double* const*)d_V, w, k + 1, n, c->d_red);
+        hipLaunchKernelGGL(k_multidot_final, dim3(k + 1), dim3(256), 0, c->stream, c->d_red, k + 1, nb);
+        if (HL) FH_TRY(fh_halo_allreduce_ptr(HL, c->d_red + (size_t)(k + 1) * nb, k + 1));
+        hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, w, (const double* const*)d_V, c->d_red + (size_t)(k + 1) * nb, -1.0,
+                           k + 1, n);
+        FH_CHECK_HIP(hipMemcpyAsync(c->h_red, c->d_red + (size_t)(k + 1) * nb, (k + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+        for (int j = 0; j <= k; j++) H[(size_t)j * restart + k] = c->h_red[j];
+        double wn;
+        FH_TRY(dot(w, w, &wn));
+        wn = sqrt(wn);
+        H[(size_t)(k + 1) * restart + k] = wn;
+        if (wn != 0.0) FH_TRY(dev_axpby(c, Vv[k + 1], w, 1.0 / wn, 0.0, n));
+        else FH_CHECK_HIP(hipMemsetAsync(Vv[k + 1], 0, (size_t)n * sizeof(double), c->stream));
+        for (int j = 0; j < k; j++) {
+          const double a = H[(size_t)j * restart + k], bb = H[(size_t)(j + 1) * restart + k];
+          H[(size_t)j * restart + k] = cs[j] * a + sn[j] * bb;
+          H[(size_t)(j + 1) * restart + k] = -sn[j] * a + cs[j] * bb;
+        }
+        const double a = H[(size_t)k * restart + k], bb = H[(size_t)(k + 1) * restart + k];
+        const double d = hypot(a, bb);
+        if (d == 0.0) {
+          cs[k] = 1.0;
+          sn[k] = 0.0;
+          H[(size_t)k * restart + k] = 1.0;
+          g[k + 1] = 0.0;
+          its++;
+          kused = k + 1;
+          rn = 0.0;
+          done = true;
+          break;
+        }
+        cs[k] = a / d;
+        sn[k] = bb / d;
+        H[(size_t)k * restart + k] = d;
+        H[(size_t)(k + 1) * restart + k] = 0.0;
+        g[k + 1] = -sn[k] * g[k];
+        g[k] = cs[k] * g[k];
+        its++;
+        kused = k + 1;
+        rn = fabs(g[k + 1]);
+        if (rn <= std::max(rtol * bnorm, atol) || its >= maxit || wn == 0.0 || rn > dtol * bnorm) {
+          done = true;
+          break;
+        }
+      }
+      for (int i = kused - 1; i >= 0; i--) {
+        double s2 = g[i];
+        for (int j = i + 1; j < kused; j++) s2 -= H[(size_t)i * restart + j] * y[j];
+        y[i] = s2 / H[(size_t)i * restart + i];
+      }
+      // x += Z y
+      FH_CHECK_HIP(hipMemcpyAsync(c->d_red, y.data(), kused * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, x, (const double* const*)d_Z, c->d_red, 1.0, kused, n);
+      FH_CHECK_HIP(hipStreamSynchronize(c->stream));
     }
   } else {
     // left-preconditioned GMRES(restart), classical Gram-Schmidt, Knoll guess x0 = M^-1 b

@@ -338,7 +338,10 @@ int fh_ns_element_matrices(fh_ns_assembler_t as, fh_vec_t sol, double nu, double
  *                       (LinearEquationSolverPetsc.cpp:444-446: restart on A + shift I, shift 100 eps then doubled); re-factored by
  *                       every fh_mg_setup; level-scheduled triangular solves */
 enum { FH_SMOOTH_JACOBI = 0, FH_SMOOTH_GS_COLOR = 1, FH_SMOOTH_VANKA = 2, FH_SMOOTH_SOR = 3, FH_SMOOTH_ILU0 = 4 };
-enum { FH_OUTER_PREONLY = 0, FH_OUTER_RICHARDSON = 1, FH_OUTER_GMRES = 2, FH_OUTER_CG = 3 };
+/* outer solver of fh_mg_solve (`SetOuterSolver`, `_mgSolverType`; KSP types of LinearEquationSolverPetsc.cpp:455-529): one cycle,
+ * Richardson, left-preconditioned GMRES, CG, and flexible (right-preconditioned) GMRES for cycles that are not a fixed linear
+ * operator (GMRES level solvers) */
+enum { FH_OUTER_PREONLY = 0, FH_OUTER_RICHARDSON = 1, FH_OUTER_GMRES = 2, FH_OUTER_CG = 3, FH_OUTER_FGMRES = 4 };
 int fh_mg_create(fh_ctx_t ctx, int nlevels, fh_mg_t* mg);
 int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh_mat_t R, int smoother, double omega, int npre, int npost);
 /* FH_SMOOTH_VANKA: block Schwarz smoother for saddle-point systems (the FEMuS_ASM choice of the Navier-Stokes applications,

@@ -979,6 +979,63 @@ def solve_gmres_mg(H, rtol=1e-10, maxit=100, restart=30, **kw):
     return x, hist
 
 
+def solve_fgmres_mg(H, rtol=1e-10, maxit=100, restart=30, knoll=True, **kw):
+    """flexible restarted GMRES (KSPFGMRES, a case of LinearEquationSolverPetsc.cpp:506-507): right preconditioning, the preconditioned
+    vectors z_k = M v_k are kept so that M (one multigrid cycle, possibly with GMRES level solvers) may differ from application to
+    application; classical Gram-Schmidt; convergence on the true residual norm against ||b||; Knoll guess x0 = M b
+    (KSPSetInitialGuessKnoll, :308).  PETSc 3.20.2 itself is not under /root/reference: parity unpinned."""
+    A, b = H.A[-1], H.b
+    L = len(H.A) - 1
+    M = lambda v: vcycle(H, L, v, **kw)
+    x = M(b) if knoll else np.zeros_like(b)
+    bnorm = np.linalg.norm(b)
+    hist = []
+    its = 0
+    while its < maxit:
+        r = b - A @ x
+        beta = np.linalg.norm(r)
+        if not hist:
+            hist.append(beta)
+        if beta <= rtol * bnorm:
+            break
+        V, Z = [r / beta], []
+        Hm = np.zeros((restart + 1, restart))
+        g = np.zeros(restart + 1)
+        g[0] = beta
+        cs, sn = np.zeros(restart), np.zeros(restart)
+        k_used = 0
+        for k in range(restart):
+            Z.append(M(V[k]))
+            w = A @ Z[k]
+            h = np.array([w @ v for v in V])       # classical Gram-Schmidt
+            for hj, v in zip(h, V):
+                w = w - hj * v
+            Hm[:k + 1, k] = h
+            Hm[k + 1, k] = np.linalg.norm(w)
+            V.append(w / Hm[k + 1, k] if Hm[k + 1, k] != 0 else w)
+            for j in range(k):
+                t = cs[j] * Hm[j, k] + sn[j] * Hm[j + 1, k]
+                Hm[j + 1, k] = -sn[j] * Hm[j, k] + cs[j] * Hm[j + 1, k]
+                Hm[j, k] = t
+            d = np.hypot(Hm[k, k], Hm[k + 1, k])
+            cs[k], sn[k] = Hm[k, k] / d, Hm[k + 1, k] / d
+            Hm[k, k] = d
+            Hm[k + 1, k] = 0.0
+            g[k + 1] = -sn[k] * g[k]
+            g[k] = cs[k] * g[k]
+            its += 1
+            k_used = k + 1
+            hist.append(abs(g[k + 1]))
+            if abs(g[k + 1]) <= rtol * bnorm or its >= maxit:
+                break
+        y = np.linalg.solve(np.triu(Hm[:k_used, :k_used]), g[:k_used])
+        for j in range(k_used):
+            x = x + y[j] * Z[j]
+        if abs(g[k_used]) <= rtol * bnorm:
+            break
+    return x, hist
+
+
 # ----------------------------------------------------------------------------------------------
 # deterministic fills used by tests / bench (SURVEY 8d: LCG, seed 12345, uniform [-1,1])
 # ----------------------------------------------------------------------------------------------

@@ -167,14 +167,14 @@ int main(int argc, char** argv) {
   std::vector<unsigned> vars = {0, 1, 2};
   int total_newton = 0, max_linear = 0;
   for (int ig = 0; ig < nlev; ig++) {
-    for (int it = 0; it < (outer_pre ? 90 : 30); it++) {          // SetMaxNumberOfNonLinearIterations(90) in the application
+    for (int it = 0; it < (outer_pre == 1 ? 90 : 30); it++) {          // SetMaxNumberOfNonLinearIterations(90) in the application
       LinearEquationSolver* top = LinSolver[ig];
       top->SetResZero();
       hip_check(fh_assemble_navier_stokes(as[ig], static_cast<HipVector*>(Sol[ig])->handle(), nu, static_cast<HipMatrix*>(top->_KK)->handle(),
                                           static_cast<HipVector*>(top->_RES)->handle()),
                 "assemble");
       for (int i = ig; i > 0; i--) LinSolver[i - 1]->_KK->matrix_PtAP(*PP[i], *LinSolver[i]->_KK, it > 0);
-      if (outer_pre) {
+      if (outer_pre == 1) {
         // SteadyNavierStokesParallel/main.cpp:148-185: SetOuterSolver(PREONLY), one pre- and one post-smoothing step, at most two
         // linear iterations (V-cycles) per nonlinear one (LinearImplicitSystem.cpp:385-411)
         top->MGInit(MULTIPLICATIVE, ig + 1, PREONLY);
@@ -183,7 +183,7 @@ int main(int argc, char** argv) {
         top->SetEpsZero();
         for (int lin = 0; lin < 2; lin++) top->MGSolve(lin == 0);
       } else {
-        top->MGInit(MULTIPLICATIVE, ig + 1, GMRES);
+        top->MGInit(MULTIPLICATIVE, ig + 1, outer_pre == 2 ? FGMRES : GMRES);     // 2: the flexible form (cycles with GMRES level solvers)
         top->SetTolerances(1e-11, 1e-50, 1e50, 60, 30);
         for (int i = 0; i <= ig; i++) LinSolver[i]->MGSetLevel(top, ig, vars, PP[i], PP[i], i ? 2 : 1, i ? 2 : 0);
         top->SetEpsZero();

@@ -114,7 +114,7 @@ def test_repeated_setup_with_new_values_keeps_or_rebuilds_the_captured_cycle(ctx
         ctx.set_option("mg_reuse_graph", 1)
 
 
-@pytest.mark.parametrize("outer", ["richardson", "gmres", "cg"])
+@pytest.mark.parametrize("outer", ["richardson", "gmres", "cg", "fgmres"])
 def test_outer_solvers_reach_direct_solution(ctx, H3, outer):
     mg, mats = device_hierarchy(ctx, H3)
     n = H3.A[-1].shape[0]
@@ -123,13 +123,15 @@ def test_outer_solvers_reach_direct_solution(ctx, H3, outer):
     its, rn = mg.solve(b, x, outer=outer, rtol=1e-12, maxit=60)
     assert rel(x.to_numpy(), xd) < 1e-10            # north_star: 1e-10 relative on the FP solve
     assert its <= 30
-    xo, hist = {"richardson": fo.solve_richardson_mg, "gmres": fo.solve_gmres_mg, "cg": fo.solve_pcg_mg}[outer](H3, rtol=1e-12)
+    xo, hist = {"richardson": fo.solve_richardson_mg, "gmres": fo.solve_gmres_mg, "cg": fo.solve_pcg_mg, "fgmres": fo.solve_fgmres_mg}[outer](H3, rtol=1e-12)
     assert rel(x.to_numpy(), xo) < 1e-10
     assert abs(its - (len(hist) - 1)) <= 2           # same convergence behaviour as the restated algorithm
+    if outer == "fgmres":                           # the same algorithm step by step: residual estimate of the last iteration
+        assert its == len(hist) - 1 and abs(rn - hist[-1]) <= 1e-6 * hist[0]
     mg.destroy()
 
 
-@pytest.mark.parametrize("outer", ["gmres", "cg", "richardson"])
+@pytest.mark.parametrize("outer", ["gmres", "cg", "richardson", "fgmres"])
 def test_solvers_do_not_read_uninitialised_work_memory(ctx, H3, outer):
     """regression: the Krylov work vectors used to be raw allocations and `y = a x + 0 * y` read them -- NaN whenever the
     allocation landed on NaN bit patterns (seen as a rare failure of GMRES solves on freshly booted boxes).  With `debug_poison`
@@ -361,6 +363,35 @@ def test_gmres_level_solver_matches_the_oracle(ctx, smoother, name, npre, npost,
         mg.destroy()
     finally:
         ctx.set_option("use_graph", 1)
+
+
+@pytest.mark.parametrize("smoother,name", [(capi.SMOOTH_JACOBI, "jacobi"), (capi.SMOOTH_ILU0, "ilu0")])
+def test_fgmres_around_gmres_smoothed_cycles(ctx, smoother, name):
+    """a cycle whose level solvers are GMRES is not a fixed linear operator: the flexible outer solver (KSPFGMRES, right preconditioning,
+    z_k kept) is the one that converges to the direct solution at the true-residual tolerance; iteration by iteration the same as the
+    oracle's restatement"""
+    H = fo.build_poisson_hierarchy(2, 2, 2, 3, "biquadratic", ONE)
+    nl = 3
+    mg = capi.Multigrid(ctx, nl)
+    mats = []
+    for l in range(nl):
+        A = ctx.matrix_scipy(H.A[l])
+        P = ctx.matrix_scipy(H.P[l]) if l > 0 else None
+        mats += [A, P]
+        mg.set_level(l, A, P, None, smoother, 1.0, 2, 2)
+        if l > 0:
+            mg.set_level_solver(l, "gmres", 30)
+    mg.setup()
+    n = H.A[-1].shape[0]
+    xd = spla.spsolve(H.A[-1].tocsc(), H.b)
+    b, x = ctx.vector_from(H.b), ctx.vector(n)
+    its, rn = mg.solve(b, x, outer="fgmres", rtol=1e-12, maxit=40)
+    assert rel(x.to_numpy(), xd) < 1e-10
+    res = np.linalg.norm(H.b - H.A[-1] @ x.to_numpy())
+    assert res <= 2e-12 * np.linalg.norm(H.b) and abs(rn - res) <= 1e-3 * np.linalg.norm(H.b) * 1e-9 + 0.5 * res + 1e-14 * np.linalg.norm(H.b)
+    xo, hist = fo.solve_fgmres_mg(H, rtol=1e-12, maxit=40, omega=1.0, npre=2, npost=2, smoother=name, level_solver="gmres")
+    assert rel(x.to_numpy(), xo) < 1e-10 and abs(its - (len(hist) - 1)) <= 1
+    mg.destroy()
 
 
 def test_config1_converges_within_the_budget_of_001_poisson(ctx):

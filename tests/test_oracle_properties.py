@@ -94,6 +94,23 @@ def test_mg_solvers_reach_direct_solution(solver):
     assert len(hist) < 25
 
 
+@pytest.mark.parametrize("smoother", ["jacobi", "ilu0"])
+def test_flexible_gmres_is_what_gmres_smoothed_cycles_need(smoother):
+    """with GMRES level solvers the cycle changes from application to application: the flexible outer solver converges to the
+    direct solution, the non-flexible one stalls some digits short (the reason FH_OUTER_FGMRES exists); with a fixed cycle both agree"""
+    H = fo.build_poisson_hierarchy(2, 2, 2, 3, "biquadratic", ONE)
+    xd = spla.spsolve(H.A[-1].tocsc(), H.b)
+    kw = dict(omega=1.0, npre=2, npost=2, smoother=smoother, level_solver="gmres")
+    xf, hf = fo.solve_fgmres_mg(H, rtol=1e-12, maxit=40, **kw)
+    xg, _ = fo.solve_gmres_mg(H, rtol=1e-12, maxit=40, **kw)
+    assert np.linalg.norm(xf - xd) <= 1e-11 * np.linalg.norm(xd)
+    assert np.linalg.norm(H.b - H.A[-1] @ xf) <= 2e-12 * np.linalg.norm(H.b)
+    assert np.linalg.norm(xg - xd) >= 1e-8 * np.linalg.norm(xd)
+    x1, h1 = fo.solve_fgmres_mg(H, rtol=1e-12)
+    x2, h2 = fo.solve_gmres_mg(H, rtol=1e-12)
+    assert np.linalg.norm(x1 - x2) <= 1e-10 * np.linalg.norm(xd) and abs(len(h1) - len(h2)) <= 2
+
+
 def test_manufactured_solution_fourth_order():
     f = lambda xg: -3 * np.pi ** 2 * np.prod(np.sin(np.pi * xg), axis=-1)
     errs = []
