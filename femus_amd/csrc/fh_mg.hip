@@ -15,6 +15,7 @@
 #include "fh_internal.h"
 #include "fh_trisolve.h"
 #include <algorithm>
+#include <memory>
 #include <cmath>
 
 int fh_dev_get_diag(fh_mat_t A, double* d, int invert);
@@ -66,6 +67,11 @@ struct fh_mg_s {
   double* d_gjwork = nullptr; // panels of the blocked inversion, kept with d_ainv across preparations
   double* d_gjwork2 = nullptr;   // second pivot-inverse buffer (inside d_gjwork)
   int ainv_n = -1;
+  // unknowns of the coarsest level that are coupled to nothing (Dirichlet rows after SetPenalty, whose columns the Galerkin product has
+  // emptied too) are solved by their diagonal; the dense inverse holds the na remaining ones.  d_act: their indices, then the others
+  int na = -1;
+  int* d_act = nullptr;
+  std::vector<int> h_act;
   bool setup_done = false;
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
@@ -1282,6 +1288,8 @@ static uint64_t cycle_signature(fh_mg_t mg) {
   mix((uint64_t)mg->nlevels);
   mix((uint64_t)mg->ctx->opt_gen);
   mixp(mg->d_ainv);
+  mix((uint64_t)mg->na);
+  mixp(mg->d_act);
   for (int l = 0; l < mg->nlevels; l++) {
     MgLevel& L = mg->lv[l];
     mixm(L.A);
@@ -1468,11 +1476,92 @@ static int vanka_apply(fh_mg_t mg, MgLevel& L, double* x, const double* b, doubl
 }
 static int vanka_sweeps(fh_mg_t mg, MgLevel& L, int nsweeps) { return vanka_apply(mg, L, L.x, L.b, L.r, L.omega, nsweeps); }
 
+// row i is decoupled when it has a non-zero diagonal and no other non-zero entry, and no other row has a non-zero in column i
+__global__ __launch_bounds__(256) void k_coarse_coupling(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val, int n,
+                                                         int* __restrict__ rowhit, int* __restrict__ colhit) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int hit = 0;
+  double d = 0.0;
+  for (int k = rowptr[i]; k < rowptr[i + 1]; k++) {
+    const int j = col[k];
+    if (j == i) d = val[k];
+    else if (val[k] != 0.0 && j < n) {
+      hit = 1;
+      colhit[j] = 1;          // benign race: every writer stores 1
+    }
+  }
+  rowhit[i] = hit | (d == 0.0 ? 2 : 0);
+}
+
+__global__ __launch_bounds__(256) void k_csr_to_dense_sub(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+                                                          double* __restrict__ D, int na, const int* __restrict__ act, const int* __restrict__ pos) {
+  const int i = blockIdx.x, row = act[i];
+  for (int k = rowptr[row] + threadIdx.x; k < rowptr[row + 1]; k += 256) {
+    const int j = pos[col[k]];
+    if (j >= 0) D[(size_t)i * na + j] = val[k];
+  }
+}
+
+// coarse solve with decoupled unknowns: blocks [0, ceil(na / 4)): y[act[i]] = sum_k M[i][k] b[act[k]], one wave per row; the blocks
+// behind them: y[j] = dinv[j] b[j] for the n - na others (act[na ...])
+__global__ __launch_bounds__(256) void k_dense_gemv_sub(const double* __restrict__ M, const double* __restrict__ b, double* __restrict__ y, int na, int n,
+                                                        const int* __restrict__ act, const double* __restrict__ dinv) {
+  const int nbr = (na + 3) >> 2;
+  if ((int)blockIdx.x >= nbr) {
+    const int t = ((int)blockIdx.x - nbr) * 256 + threadIdx.x + na;
+    if (t < n) {
+      const int j = act[t];
+      y[j] = dinv[j] * b[j];
+    }
+    return;
+  }
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= na) return;
+  const double* m = M + (size_t)row * na;
+  double acc = 0.0;
+  for (int k = lane; k < na; k += 64) acc += m[k] * b[act[k]];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) y[act[row]] = acc;
+}
+
 static int coarse_factor(fh_mg_t mg) {
   fh_ctx_t c = mg->ctx;
   MgLevel& L0 = mg->lv[0];
-  const int n = L0.n;
-  FH_REQUIRE(n <= 16384, "coarse level has %d unknowns: the dense direct solve supports at most 16384", n);
+  const int nfull = L0.n;
+  // ---- unknowns coupled to nothing leave the dense problem (exact: the operator is block diagonal with respect to them) ----
+  int n = nfull;
+  if (c->coarse_reduce && nfull > 0) {
+    int* d_hit = nullptr;
+    FH_CHECK_HIP(hipMalloc(&d_hit, (size_t)2 * nfull * sizeof(int)));
+    std::unique_ptr<void, void (*)(void*)> guard(d_hit, [](void* q) { hipFree(q); });
+    FH_CHECK_HIP(hipMemsetAsync(d_hit, 0, (size_t)2 * nfull * sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_coarse_coupling, dim3(fh_div_up(nfull, 256)), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, nfull, d_hit,
+                       d_hit + nfull);
+    FH_CHECK_HIP(hipGetLastError());
+    std::vector<int> hit((size_t)2 * nfull);
+    FH_CHECK_HIP(hipMemcpyAsync(hit.data(), d_hit, hit.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+    std::vector<int> act, rest;
+    for (int i = 0; i < nfull; i++) (hit[i] == 0 && hit[nfull + i] == 0 ? rest : act).push_back(i);
+    n = (int)act.size();
+    act.insert(act.end(), rest.begin(), rest.end());
+    if (act != mg->h_act || !mg->d_act) {
+      if (mg->d_act) FH_CHECK_HIP(hipFree(mg->d_act));
+      mg->d_act = nullptr;
+      std::vector<int> both(act);
+      both.resize((size_t)2 * nfull, -1);                  // [nfull, 2 nfull): position of an unknown in the dense problem, -1 = not in it
+      for (int i = 0; i < n; i++) both[nfull + act[i]] = i;
+      FH_CHECK_HIP(hipMalloc(&mg->d_act, both.size() * sizeof(int)));
+      FH_CHECK_HIP(hipMemcpy(mg->d_act, both.data(), both.size() * sizeof(int), hipMemcpyHostToDevice));
+      mg->h_act = act;
+    }
+  }
+  mg->na = n;
+  FH_REQUIRE(n <= 16384, "coarse level has %d coupled unknowns: the dense direct solve supports at most 16384", n);
+  if (n == 0) return 0;
   if (mg->ainv_n != n) {      // a repeated preparation of the same hierarchy keeps its buffers (the 193 MB allocation cost 5-10 ms)
     if (mg->d_ainv) FH_CHECK_HIP(hipFree(mg->d_ainv));
     if (mg->d_gjwork) FH_CHECK_HIP(hipFree(mg->d_gjwork));
@@ -1485,7 +1574,12 @@ static int coarse_factor(fh_mg_t mg) {
     mg->ainv_n = n;
   }
   FH_CHECK_HIP(hipMemsetAsync(mg->d_ainv, 0, (size_t)n * n * sizeof(double), c->stream));
-  hipLaunchKernelGGL(k_csr_to_dense, dim3(n), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, mg->d_ainv, n);
+  auto to_dense = [&]() {
+    if (n == nfull) hipLaunchKernelGGL(k_csr_to_dense, dim3(n), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, mg->d_ainv, n);
+    else hipLaunchKernelGGL(k_csr_to_dense_sub, dim3(n), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, mg->d_ainv, n, mg->d_act,
+                            mg->d_act + nfull);
+  };
+  to_dense();
   double* colk = mg->d_gjwork;   // column panel (n x NB), its transpose / the row panel, pivot inverse (NB x NB), flag
   double* Cp = colk;
   double* CpT = colk + (size_t)n * GJ_NB;
@@ -1511,7 +1605,7 @@ static int coarse_factor(fh_mg_t mg) {
   if (c->gj_symmetric) {
     // symmetric operator? (entry-by-entry check on the sparse form, 1e-12 of the row's largest entry)
     int h_flag = 0;
-    hipLaunchKernelGGL(k_csr_symmetry, dim3(fh_div_up(n, 4)), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, n, 1e-12, d_flag);
+    hipLaunchKernelGGL(k_csr_symmetry, dim3(fh_div_up(nfull, 4)), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, nfull, 1e-12, d_flag);
     FH_CHECK_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     FH_CHECK_HIP(hipStreamSynchronize(c->stream));
     if (h_flag == 0 && c->gj_block >= IB) {
@@ -1542,7 +1636,7 @@ static int coarse_factor(fh_mg_t mg) {
       // a pivot block without a usable diagonal pivot (the operator is symmetric but not definite): start again with the pivoted sweep
       FH_CHECK_HIP(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), c->stream));
       FH_CHECK_HIP(hipMemsetAsync(mg->d_ainv, 0, (size_t)n * n * sizeof(double), c->stream));
-      hipLaunchKernelGGL(k_csr_to_dense, dim3(n), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, mg->d_ainv, n);
+      to_dense();
     }
     if (h_flag == 0) {
       double *PT = Cp, *RT = CpT;
@@ -1926,7 +2020,11 @@ static int run_cycle(fh_mg_t mg) {
   }
   {
     MgLevel& L0 = mg->lv[0];
-    hipLaunchKernelGGL(k_dense_gemv, dim3(fh_div_up(L0.n, 4)), dim3(256), 0, c->stream, mg->d_ainv, L0.b, L0.x, L0.n);
+    if (mg->na == L0.n)
+      hipLaunchKernelGGL(k_dense_gemv, dim3(fh_div_up(L0.n, 4)), dim3(256), 0, c->stream, mg->d_ainv, L0.b, L0.x, L0.n);
+    else
+      hipLaunchKernelGGL(k_dense_gemv_sub, dim3(fh_div_up(mg->na, 4) + fh_div_up(L0.n - mg->na, 256)), dim3(256), 0, c->stream, mg->d_ainv, L0.b, L0.x,
+                         mg->na, L0.n, mg->d_act, L0.dinv);
   }
   for (int l = 1; l <= top; l++) {
     MgLevel& L = mg->lv[l];
@@ -1992,6 +2090,7 @@ extern "C" int fh_mg_destroy(fh_mg_t mg) {
     L.tri = nullptr;
   }
   if (mg->d_ainv) hipFree(mg->d_ainv);
+  if (mg->d_act) hipFree(mg->d_act);
   if (mg->d_gjwork) hipFree(mg->d_gjwork);
   for (double* p : mg->kv) hipFree(p);
   if (mg->d_V) hipFree(mg->d_V);

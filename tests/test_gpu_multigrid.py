@@ -210,9 +210,14 @@ def test_config1_richardson_sor_as_in_001_poisson(ctx):
 
 
 # ---- robustness of the setup (advisor findings, round 1) -------------------------------------------------------------------
-def _one_level(ctx, M):
+def _one_level(ctx, M, stored_zeros=False):
     import scipy.sparse as sp
-    A = ctx.matrix_scipy(sp.csr_matrix(M))
+    if stored_zeros:                                           # every entry of the dense matrix is a stored entry, zeros included
+        n = M.shape[0]
+        S = sp.csr_matrix((M.ravel(), np.tile(np.arange(n), n), np.arange(0, n * n + 1, n)), shape=(n, n))
+    else:
+        S = sp.csr_matrix(M)
+    A = ctx.matrix_scipy(S)
     mg = capi.Multigrid(ctx, 1)
     mg.set_level(0, A, None, None, 0, 1.0, 1, 0)
     return mg, A
@@ -562,3 +567,34 @@ def test_coarse_inverse_random_sizes(ctx, n, kind):
         ref = np.linalg.solve(M, rhs)
         assert rel(x.to_numpy(), ref) < 1e-10 * max(1.0, np.linalg.cond(M) / 1e3)
     mg.destroy()
+
+
+@pytest.mark.parametrize("n", [5, 130, 300, 641])
+@pytest.mark.parametrize("kind", ["spd", "general", "all_decoupled", "row_only"])
+def test_coarse_solve_leaves_decoupled_unknowns_out_of_the_dense_inverse(ctx, n, kind):
+    """unknowns of the coarsest level coupled to nothing (Dirichlet rows after SetPenalty whose columns the Galerkin product emptied: non-zero
+    diagonal, zeros stored elsewhere in row and column) are solved by their diagonal and the dense inverse holds the rest (coarse_reduce,
+    default) -- same solution as the inverse of the whole operator and as numpy; an unknown whose ROW is empty but whose column is not is
+    still coupled and stays in the dense problem"""
+    rng = np.random.default_rng(n * 3 + len(kind))
+    G = rng.uniform(-1, 1, (n, n))
+    M = G @ G.T + n * np.eye(n) if kind != "general" else G + 0.6 * n * np.eye(n)
+    dec = rng.choice(n, size=n if kind == "all_decoupled" else max(1, n // 3), replace=False)
+    M[dec, :] = 0.0
+    if kind != "row_only":
+        M[:, dec] = 0.0
+    M[dec, dec] = rng.uniform(0.5, 3.0, dec.size)
+    sols = []
+    for reduce in (1, 0):
+        ctx.set_option("coarse_reduce", reduce)
+        mg, A = _one_level(ctx, M, stored_zeros=(n % 2 == 0))    # zeros as STORED entries (as after mat_zero_rows) or absent from the pattern
+        mg.setup()
+        rhs = rng.uniform(-1, 1, n)
+        b, x = ctx.vector_from(rhs), ctx.vector(n)
+        for rep in range(2):
+            mg.vcycle(b, x)
+        sols.append((x.to_numpy().copy(), np.linalg.solve(M, rhs)))
+        mg.destroy()
+    ctx.set_option("coarse_reduce", 1)
+    for got, ref in sols:
+        assert rel(got, ref) < 1e-11
