@@ -370,8 +370,16 @@ __global__ __launch_bounds__(256) void k_dense_gemv(const double* __restrict__ M
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
   const double* m = M + (size_t)row * n;
-  double acc = 0.0;
-  for (int k = lane; k < n; k += 64) acc += m[k] * b[k];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;          // four loads of the row in flight per lane
+  int k = lane;
+  for (; k + 192 < n; k += 256) {
+    a0 += m[k] * b[k];
+    a1 += m[k + 64] * b[k + 64];
+    a2 += m[k + 128] * b[k + 128];
+    a3 += m[k + 192] * b[k + 192];
+  }
+  for (; k < n; k += 64) a0 += m[k] * b[k];
+  double acc = (a0 + a1) + (a2 + a3);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if (lane == 0) y[row] = acc;
@@ -1476,22 +1484,24 @@ static int vanka_apply(fh_mg_t mg, MgLevel& L, double* x, const double* b, doubl
 }
 static int vanka_sweeps(fh_mg_t mg, MgLevel& L, int nsweeps) { return vanka_apply(mg, L, L.x, L.b, L.r, L.omega, nsweeps); }
 
-// row i is decoupled when it has a non-zero diagonal and no other non-zero entry, and no other row has a non-zero in column i
+// row i is decoupled when it has a non-zero diagonal and no other non-zero entry, and no other row has a non-zero in column i; one wave per row
 __global__ __launch_bounds__(256) void k_coarse_coupling(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val, int n,
                                                          int* __restrict__ rowhit, int* __restrict__ colhit) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
-  int hit = 0;
-  double d = 0.0;
-  for (int k = rowptr[i]; k < rowptr[i + 1]; k++) {
+  int hit = 0, diag = 0;
+  for (int k = rowptr[i] + lane; k < rowptr[i + 1]; k += 64) {
     const int j = col[k];
-    if (j == i) d = val[k];
-    else if (val[k] != 0.0 && j < n) {
+    const bool nz = val[k] != 0.0;
+    if (j == i) diag |= nz ? 1 : 0;
+    else if (nz && j < n) {
       hit = 1;
       colhit[j] = 1;          // benign race: every writer stores 1
     }
   }
-  rowhit[i] = hit | (d == 0.0 ? 2 : 0);
+  hit = __any(hit);
+  diag = __any(diag);
+  if (lane == 0) rowhit[i] = hit | (diag ? 0 : 2);
 }
 
 __global__ __launch_bounds__(256) void k_csr_to_dense_sub(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
@@ -1503,10 +1513,15 @@ __global__ __launch_bounds__(256) void k_csr_to_dense_sub(const int* __restrict_
   }
 }
 
-// coarse solve with decoupled unknowns: blocks [0, ceil(na / 4)): y[act[i]] = sum_k M[i][k] b[act[k]], one wave per row; the blocks
-// behind them: y[j] = dinv[j] b[j] for the n - na others (act[na ...])
-__global__ __launch_bounds__(256) void k_dense_gemv_sub(const double* __restrict__ M, const double* __restrict__ b, double* __restrict__ y, int na, int n,
-                                                        const int* __restrict__ act, const double* __restrict__ dinv) {
+// coarse solve with decoupled unknowns, two launches: bc = b[act[0 .. na)] (k_gather_act), then blocks [0, ceil(na / 4)): y[act[i]] = sum_k M[i][k] bc[k],
+// one wave per row; the blocks behind them: y[j] = dinv[j] b[j] for the n - na others (act[na ...])
+__global__ __launch_bounds__(256) void k_gather_act(const double* __restrict__ b, const int* __restrict__ act, int na, double* __restrict__ bc) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < na) bc[k] = b[act[k]];
+}
+
+__global__ __launch_bounds__(256) void k_dense_gemv_sub(const double* __restrict__ M, const double* __restrict__ bc, const double* __restrict__ b,
+                                                        double* __restrict__ y, int na, int n, const int* __restrict__ act, const double* __restrict__ dinv) {
   const int nbr = (na + 3) >> 2;
   if ((int)blockIdx.x >= nbr) {
     const int t = ((int)blockIdx.x - nbr) * 256 + threadIdx.x + na;
@@ -1520,8 +1535,16 @@ __global__ __launch_bounds__(256) void k_dense_gemv_sub(const double* __restrict
   const int lane = threadIdx.x & 63;
   if (row >= na) return;
   const double* m = M + (size_t)row * na;
-  double acc = 0.0;
-  for (int k = lane; k < na; k += 64) acc += m[k] * b[act[k]];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;          // four loads of the row in flight per lane
+  int k = lane;
+  for (; k + 192 < na; k += 256) {
+    a0 += m[k] * bc[k];
+    a1 += m[k + 64] * bc[k + 64];
+    a2 += m[k + 128] * bc[k + 128];
+    a3 += m[k + 192] * bc[k + 192];
+  }
+  for (; k < na; k += 64) a0 += m[k] * bc[k];
+  double acc = (a0 + a1) + (a2 + a3);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if (lane == 0) y[act[row]] = acc;
@@ -1538,7 +1561,7 @@ static int coarse_factor(fh_mg_t mg) {
     FH_CHECK_HIP(hipMalloc(&d_hit, (size_t)2 * nfull * sizeof(int)));
     std::unique_ptr<void, void (*)(void*)> guard(d_hit, [](void* q) { hipFree(q); });
     FH_CHECK_HIP(hipMemsetAsync(d_hit, 0, (size_t)2 * nfull * sizeof(int), c->stream));
-    hipLaunchKernelGGL(k_coarse_coupling, dim3(fh_div_up(nfull, 256)), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, nfull, d_hit,
+    hipLaunchKernelGGL(k_coarse_coupling, dim3(fh_div_up(nfull, 4)), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, nfull, d_hit,
                        d_hit + nfull);
     FH_CHECK_HIP(hipGetLastError());
     std::vector<int> hit((size_t)2 * nfull);
@@ -2022,9 +2045,11 @@ static int run_cycle(fh_mg_t mg) {
     MgLevel& L0 = mg->lv[0];
     if (mg->na == L0.n)
       hipLaunchKernelGGL(k_dense_gemv, dim3(fh_div_up(L0.n, 4)), dim3(256), 0, c->stream, mg->d_ainv, L0.b, L0.x, L0.n);
-    else
-      hipLaunchKernelGGL(k_dense_gemv_sub, dim3(fh_div_up(mg->na, 4) + fh_div_up(L0.n - mg->na, 256)), dim3(256), 0, c->stream, mg->d_ainv, L0.b, L0.x,
+    else {
+      hipLaunchKernelGGL(k_gather_act, dim3(fh_div_up(std::max(mg->na, 1), 256)), dim3(256), 0, c->stream, L0.b, mg->d_act, mg->na, L0.r);
+      hipLaunchKernelGGL(k_dense_gemv_sub, dim3(fh_div_up(mg->na, 4) + fh_div_up(L0.n - mg->na, 256)), dim3(256), 0, c->stream, mg->d_ainv, L0.r, L0.b, L0.x,
                          mg->na, L0.n, mg->d_act, L0.dinv);
+    }
   }
   for (int l = 1; l <= top; l++) {
     MgLevel& L = mg->lv[l];
