@@ -153,13 +153,14 @@ __global__ __launch_bounds__(256) void k_patch_extract(const int* __restrict__ p
 // in-place inverse by Gauss-Jordan with partial (row) pivoting, one workgroup per patch, row-major in global memory (the
 // patch matrix is L2-resident); on exit the matrix is transposed in place for the apply kernel.  flag[p] = 1: singular.
 __global__ __launch_bounds__(256) void k_patch_invert(const int* __restrict__ pptr, const int64_t* __restrict__ poff, double* __restrict__ M,
-                                                      int* __restrict__ flag) {
+                                                      int* __restrict__ flag, int skip_upto) {
   __shared__ int piv[512];
   __shared__ double red_v[256];
   __shared__ int red_i[256];
   __shared__ double colk[512];
   const int p = blockIdx.x, tid = threadIdx.x;
   const int n = pptr[p + 1] - pptr[p];
+  if (n <= skip_upto) return;                   // inverted by k_patch_invert_lds
   double* A = M + poff[p];
   bool singular = false;
   for (int k = 0; k < n; k++) {
@@ -240,6 +241,98 @@ __global__ __launch_bounds__(256) void k_patch_invert(const int* __restrict__ pp
       A[(size_t)j * n + i] = a;
     }
   }
+}
+
+// the same inversion for patches of at most PLDS_MAX dofs, whole matrix in LDS, ONE wave per patch (no workgroup barriers; the same
+// pivot rule -- largest |a_ik|, smallest row on ties -- and the same arithmetic per entry as k_patch_invert, so both give the same bits)
+constexpr int PLDS_MAX = 96;
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__global__ __launch_bounds__(64) void k_patch_invert_lds(const int* __restrict__ pptr, const int64_t* __restrict__ poff, double* __restrict__ M,
+                                                         int* __restrict__ flag, int nmax) {
+  extern __shared__ double pl_smem[];
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const int n = pptr[p + 1] - pptr[p];
+  if (n > PLDS_MAX) return;                      // left to k_patch_invert
+  const int ld = n | 1;
+  double* As = pl_smem;                          // [n][ld]
+  double* colk = pl_smem + nmax * (nmax | 1);    // nmax: the largest patch this launch inverts (sizes the LDS of every workgroup)
+  int* piv = reinterpret_cast<int*>(colk + nmax);
+  double* A = M + poff[p];
+  for (int t = lane; t < n * n; t += 64) As[(t / n) * ld + t % n] = A[t];
+  wave_sync_lds();
+  for (int k = 0; k < n; k++) {
+    double best = -1.0, bval = 0.0;
+    int bi = k;
+    for (int i = k + lane; i < n; i += 64) {
+      const double v = As[i * ld + k];
+      if (fabs(v) > best) {
+        best = fabs(v);
+        bval = v;
+        bi = i;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double v2 = __shfl_xor(best, off, 64), w2 = __shfl_xor(bval, off, 64);
+      const int i2 = __shfl_xor(bi, off, 64);
+      if (v2 > best || (v2 == best && i2 < bi)) {
+        best = v2;
+        bval = w2;
+        bi = i2;
+      }
+    }
+    const int pr = bi;
+    if (!(best > 0.0)) {
+      if (lane == 0) flag[p] = 1;
+      return;
+    }
+    if (lane == 0) piv[k] = pr;
+    const double pv = 1.0 / bval;
+    // column k of the other rows (after the interchange), then the interchange and the scaled pivot row, every lane its own columns
+    for (int i = lane; i < n; i += 64) colk[i] = (i == pr) ? As[k * ld + k] : As[i * ld + k];
+    wave_sync_lds();
+    for (int j = lane; j < n; j += 64) {
+      const double akj = As[pr * ld + j];
+      if (pr != k) As[pr * ld + j] = As[k * ld + j];
+      As[k * ld + j] = (j == k) ? pv : akj * pv;
+    }
+    wave_sync_lds();
+    for (int j = lane; j < n; j += 64) {
+      const double akj = As[k * ld + j];
+      for (int i0 = 0; i0 < n; i0 += 8) {          // eight rows at a time: all loads issued before the first store
+        double a[8], f[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int i = min(i0 + u, n - 1);
+          a[u] = As[i * ld + j];
+          f[u] = colk[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int i = i0 + u;
+          if (i < n && i != k) As[i * ld + j] = (j == k) ? -f[u] * akj : a[u] - f[u] * akj;
+        }
+      }
+    }
+    wave_sync_lds();
+  }
+  // undo the row interchanges as column interchanges, last first
+  for (int k = n - 1; k >= 0; k--) {
+    const int pr = piv[k];
+    if (pr != k)
+      for (int i = lane; i < n; i += 64) {
+        const double t = As[i * ld + k];
+        As[i * ld + k] = As[i * ld + pr];
+        As[i * ld + pr] = t;
+      }
+    wave_sync_lds();
+  }
+  // transposed back to global memory
+  for (int t = lane; t < n * n; t += 64) A[t] = As[(t % n) * ld + t / n];
 }
 
 // one colour of the sweep; one workgroup of 64 per patch.  r = b - A x of the whole level is formed once per colour by the
@@ -1445,7 +1538,28 @@ static int factor_patches(fh_mg_t mg, MgLevel& L) {
   FH_CHECK_HIP(hipMemsetAsync(L.d_pflag, 0, (size_t)L.npatch * sizeof(int), c->stream));
   hipLaunchKernelGGL(k_patch_extract, dim3(L.npatch), dim3(256), 0, c->stream, L.d_pptr, L.d_pdofs, L.d_poff, L.A->d_rowptr, L.A->d_col, L.A->d_val,
                      L.d_pinv);
-  hipLaunchKernelGGL(k_patch_invert, dim3(L.npatch), dim3(256), 0, c->stream, L.d_pptr, L.d_poff, L.d_pinv, L.d_pflag);
+  // patches of at most PLDS_MAX dofs: one wave each with the matrix in LDS; the others (and everything with patch_invert_lds = 0): the
+  // workgroup kernel on the matrix in global memory
+  int nsmall = 0;
+  for (int p = 0; p < L.npatch; p++) nsmall += (L.h_pptr[p + 1] - L.h_pptr[p] <= PLDS_MAX) ? 1 : 0;
+  if (c->patch_invert_lds && nsmall > 0) {
+    constexpr size_t lds_max = ((size_t)PLDS_MAX * (PLDS_MAX | 1) + PLDS_MAX) * sizeof(double) + PLDS_MAX * sizeof(int);
+    static bool attr_set[64] = {};
+    if (!attr_set[c->device & 63]) {
+      FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_patch_invert_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+      attr_set[c->device & 63] = true;
+    }
+    int nmax = 1;                                   // the LDS a launch asks for follows the largest small patch of this level
+    for (int p = 0; p < L.npatch; p++) {
+      const int np = L.h_pptr[p + 1] - L.h_pptr[p];
+      if (np <= PLDS_MAX) nmax = std::max(nmax, np);
+    }
+    const size_t lds = ((size_t)nmax * (nmax | 1) + nmax) * sizeof(double) + nmax * sizeof(int);
+    hipLaunchKernelGGL(k_patch_invert_lds, dim3(L.npatch), dim3(64), lds, c->stream, L.d_pptr, L.d_poff, L.d_pinv, L.d_pflag, nmax);
+  }
+  if (!c->patch_invert_lds || nsmall < L.npatch)
+    hipLaunchKernelGGL(k_patch_invert, dim3(L.npatch), dim3(256), 0, c->stream, L.d_pptr, L.d_poff, L.d_pinv, L.d_pflag,
+                       c->patch_invert_lds ? PLDS_MAX : 0);
   FH_CHECK_HIP(hipGetLastError());
   std::vector<int> flag(L.npatch);
   FH_CHECK_HIP(hipMemcpyAsync(flag.data(), L.d_pflag, flag.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -55,6 +55,7 @@ def test_vanka_vcycle_matches_oracle(ctx, persistent):
     """one multiplicative V(2,2) cycle with the block Schwarz smoother on the Jacobian of a non-trivial state; the sweep as one residual + one
     patch launch per colour (default) and as one launch with device-wide barriers between the colours (two barrier forms)"""
     ctx.set_option("vanka_persistent", persistent)
+    ctx.set_option("patch_invert_lds", 0 if persistent == 2 else 1)      # patch inverses by the workgroup kernel on global memory as well
     nu, nl = 0.01, 3
     pb = NavierStokesMG(ctx, 4, 4, 0, nl, nu).init()
     ms, lays = ns.build_ns_levels(4, 4, 0, nl, LO, HI)
@@ -78,6 +79,7 @@ def test_vanka_vcycle_matches_oracle(ctx, persistent):
     assert rel(x.to_numpy(), ref) < 1e-9
     pb.destroy()
     ctx.set_option("vanka_persistent", 0)
+    ctx.set_option("patch_invert_lds", 1)
 
 
 def test_cavity_newton_fcycle_matches_oracle(ctx):
