@@ -630,8 +630,8 @@ void LinearEquationSolverHip::MGSetLevel(LinearEquationSolver* LinSolver, const 
   }
   const int smoother = smoother_id();
   if (_level != 0 && smoother != FH_SMOOTH_VANKA && _preconditioner_type != JACOBI_PRECOND && _preconditioner_type != SOR_PRECOND &&
-      _preconditioner_type != ILU_PRECOND) {
-    std::cout << "HIP backend: level smoother must be RICHARDSON + JACOBI_PRECOND, SOR_PRECOND or ILU_PRECOND (or the FEMuS_ASM solver)" << std::endl;
+      _preconditioner_type != ILU_PRECOND && _preconditioner_type != IDENTITY_PRECOND) {
+    std::cout << "HIP backend: level preconditioner must be JACOBI_PRECOND, SOR_PRECOND, ILU_PRECOND or IDENTITY_PRECOND (or the FEMuS_ASM solver)" << std::endl;
     abort();
   }
   if (_level != 0 && _levelSolverType != RICHARDSON && _levelSolverType != GMRES) {     // GMRES is the reference's default level solver
@@ -653,6 +653,7 @@ void LinearEquationSolverHip::MGSetLevel(LinearEquationSolver* LinSolver, const 
 int LinearEquationSolverHip::smoother_id() const {
   if (_preconditioner_type == SOR_PRECOND) return _multicolourSor ? FH_SMOOTH_GS_COLOR : FH_SMOOTH_SOR;
   if (_preconditioner_type == ILU_PRECOND) return FH_SMOOTH_ILU0;
+  if (_preconditioner_type == IDENTITY_PRECOND) return FH_SMOOTH_IDENTITY;
   return FH_SMOOTH_JACOBI;
 }
 void LinearEquationSolverHipAsm::attach_smoother_data(fh_mg_t mg, int level, const std::vector<unsigned>& variable_to_be_solved) {

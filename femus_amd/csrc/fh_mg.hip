@@ -1299,9 +1299,9 @@ extern "C" int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh
   FH_REQUIRE(A->m <= A->n, "fh_mg_set_level: operator must be square (or owned rows x local columns on a distributed level)");
   FH_REQUIRE(level == 0 || P != nullptr, "fh_mg_set_level: level %d needs an interpolation matrix", level);
   FH_REQUIRE(!P || P->m == A->m, "fh_mg_set_level: interpolation has %d rows, operator has %d", P ? P->m : 0, A->m);
-  FH_REQUIRE(smoother >= FH_SMOOTH_JACOBI && smoother <= FH_SMOOTH_ILU0,
+  FH_REQUIRE(smoother >= FH_SMOOTH_JACOBI && smoother <= FH_SMOOTH_IDENTITY,
              "fh_mg_set_level: unknown smoother %d (0 = Richardson+Jacobi, 1 = Richardson+multicolour SOR, 2 = block Schwarz / Vanka, "
-             "3 = Richardson+SOR in natural order, 4 = Richardson+ILU(0))", smoother);
+             "3 = Richardson+SOR in natural order, 4 = Richardson+ILU(0), 5 = no preconditioner)", smoother);
   FH_REQUIRE(npre >= 0 && npost >= 0, "fh_mg_set_level: negative sweep count");
   MgLevel& L = mg->lv[level];
   if (L.A_uid != A->uid) {   // another matrix (also one that landed on the address of a destroyed one): its graph may differ
@@ -1664,6 +1664,10 @@ __global__ __launch_bounds__(256) void k_dense_gemv_sub(const double* __restrict
   if (lane == 0) y[act[row]] = acc;
 }
 
+__global__ __launch_bounds__(256) void k_fill_value(double* __restrict__ v, double a, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) v[i] = a;
+}
+
 static int coarse_factor(fh_mg_t mg) {
   fh_ctx_t c = mg->ctx;
   MgLevel& L0 = mg->lv[0];
@@ -1878,6 +1882,8 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
     for (double** p : {&L.dinv, &L.x, &L.x2, &L.b, &L.r})
       FH_CHECK_HIP(hipMemsetAsync(*p, (c->debug_poison && p != &L.dinv) ? 0xFF : 0, nb, c->stream));
     FH_TRY(fh_dev_get_diag(L.A, L.dinv, 1));
+    if (l > 0 && L.smoother == FH_SMOOTH_IDENTITY)      // PCNONE: B = I, the Jacobi kernels with a unit "inverse diagonal"
+      hipLaunchKernelGGL(k_fill_value, dim3(sgrid(c, L.n)), dim3(256), 0, c->stream, L.dinv, 1.0, L.n);
     if (l > 0 && L.solver == FH_LEVEL_GMRES) {
       const int m = std::max(1, std::min(std::max(L.npre, L.npost), L.gm_restart));
       if (L.gm_m != m || !L.gm_buf) {

@@ -336,8 +336,9 @@ int fh_ns_element_matrices(fh_ns_assembler_t as, fh_vec_t sol, double nu, double
  *                       Gauss-Seidel sweep in the NATURAL row order from a zero guess; level-scheduled on the device
  *   FH_SMOOTH_ILU0      PCILU (:91-115): ILU(0) of the local block in natural order, zero pivot 1e-16 with MAT_SHIFT_NONZERO
  *                       (LinearEquationSolverPetsc.cpp:444-446: restart on A + shift I, shift 100 eps then doubled); re-factored by
- *                       every fh_mg_setup; level-scheduled triangular solves */
-enum { FH_SMOOTH_JACOBI = 0, FH_SMOOTH_GS_COLOR = 1, FH_SMOOTH_VANKA = 2, FH_SMOOTH_SOR = 3, FH_SMOOTH_ILU0 = 4 };
+ *                       every fh_mg_setup; level-scheduled triangular solves
+ *   FH_SMOOTH_IDENTITY  PCNONE (IDENTITY_PRECOND, PetscPreconditioner.cpp:75-77): B = I */
+enum { FH_SMOOTH_JACOBI = 0, FH_SMOOTH_GS_COLOR = 1, FH_SMOOTH_VANKA = 2, FH_SMOOTH_SOR = 3, FH_SMOOTH_ILU0 = 4, FH_SMOOTH_IDENTITY = 5 };
 /* outer solver of fh_mg_solve (`SetOuterSolver`, `_mgSolverType`; KSP types of LinearEquationSolverPetsc.cpp:455-529): one cycle,
  * Richardson, left-preconditioned GMRES, CG, and flexible (right-preconditioned) GMRES for cycles that are not a fixed linear
  * operator (GMRES level solvers) */

@@ -860,6 +860,8 @@ def vcycle(H, level, b, omega=2. / 3., npre=2, npost=2, coarse_solve=None, x=Non
         if level not in H._ilu:
             H._ilu[level] = ilu0_factor(A)
         sm = lambda bb, xx, n, zg: smooth_precond(A, bb, xx, omega, n, zg, lambda r: ilu0_apply(H._ilu[level], r))
+    elif smoother == "identity":          # PCNONE (IDENTITY_PRECOND, PetscPreconditioner.cpp:75-77)
+        sm = lambda bb, xx, n, zg: smooth_precond(A, bb, xx, omega, n, zg, lambda r: r)
     else:
         sm = lambda bb, xx, n, zg: smooth(A, dinv, bb, xx, omega, n, zg)
     if level_solver == "gmres":
@@ -869,6 +871,8 @@ def vcycle(H, level, b, omega=2. / 3., npre=2, npost=2, coarse_solve=None, x=Non
             B = lambda r: ilu0_apply(H._ilu[level], r)
         elif smoother == "jacobi":
             B = lambda r: dinv * r
+        elif smoother == "identity":
+            B = lambda r: r
         else:
             raise ValueError("gmres level solver: preconditioner %s not restated" % smoother)
         sm = lambda bb, xx, n, zg: smooth_gmres(A, bb, xx, n, zg, B)

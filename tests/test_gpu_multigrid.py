@@ -328,7 +328,7 @@ def test_natural_order_smoothers_match_the_sequential_oracle(ctx, smoother, name
 
 
 @pytest.mark.parametrize("graph", [1, 0])
-@pytest.mark.parametrize("smoother,name", [(capi.SMOOTH_JACOBI, "jacobi"), (capi.SMOOTH_SOR, "sor"), (capi.SMOOTH_ILU0, "ilu0")])
+@pytest.mark.parametrize("smoother,name", [(capi.SMOOTH_JACOBI, "jacobi"), (capi.SMOOTH_SOR, "sor"), (capi.SMOOTH_ILU0, "ilu0"), (capi.SMOOTH_IDENTITY, "identity")])
 @pytest.mark.parametrize("npre,npost", [(2, 1), (1, 1), (3, 0), (4, 4)])
 def test_gmres_level_solver_matches_the_oracle(ctx, smoother, name, npre, npost, graph):
     """`SetSolverFineGrids(GMRES)`: the reference's default level solver (and what 003_NavierStokes sets).  One V-cycle whose smoothers
@@ -396,6 +396,29 @@ def test_fgmres_around_gmres_smoothed_cycles(ctx, smoother, name):
     assert res <= 2e-12 * np.linalg.norm(H.b) and abs(rn - res) <= 1e-3 * np.linalg.norm(H.b) * 1e-9 + 0.5 * res + 1e-14 * np.linalg.norm(H.b)
     xo, hist = fo.solve_fgmres_mg(H, rtol=1e-12, maxit=40, omega=1.0, npre=2, npost=2, smoother=name, level_solver="gmres")
     assert rel(x.to_numpy(), xo) < 1e-10 and abs(its - (len(hist) - 1)) <= 1
+    mg.destroy()
+
+
+@pytest.mark.parametrize("npre,npost", [(2, 2), (1, 3)])
+def test_identity_preconditioner_with_richardson(ctx, H3, npre, npost):
+    """IDENTITY_PRECOND (PCNONE): Richardson(omega) without a preconditioner as level smoother -- omega small enough for the operator's
+    spectrum -- one V-cycle against the oracle"""
+    nl = len(H3.A)
+    omega = 1.0 / max(abs(a).sum(axis=1).max() for a in H3.A[1:])
+    mg = capi.Multigrid(ctx, nl)
+    mats = []
+    for l in range(nl):
+        A = ctx.matrix_scipy(H3.A[l])
+        P = ctx.matrix_scipy(H3.P[l]) if l > 0 else None
+        mats += [A, P]
+        mg.set_level(l, A, P, None, capi.SMOOTH_IDENTITY, omega, npre, npost)
+    mg.setup()
+    n = H3.A[-1].shape[0]
+    rhs = fo.lcg_fill(n, 33)
+    b, x = ctx.vector_from(rhs), ctx.vector(n)
+    mg.vcycle(b, x)
+    ref = fo.vcycle(H3, nl - 1, rhs, omega=omega, npre=npre, npost=npost, smoother="identity")
+    assert rel(x.to_numpy(), ref) < 1e-11
     mg.destroy()
 
 
