@@ -2427,26 +2427,29 @@ __global__ __launch_bounds__(256) void k_galerkin_elem(int nelc, const int* __re
 // The same on the FP64 matrix cores (default): per child two small dense products T = K_j C_j and K_E += C_j^T T as v_mfma_f64_16x16x4 tiles
 // (27 -> 32 x 32 x 28 padded: 2 x 28 instructions of 64 cycles), operands from LDS (the eight C_j, the gathered K_j, T), the element rows of
 // the NEXT child gathered into registers while the current one is multiplied.  One wave per coarse element, one workgroup of four per CU.
+// waves per workgroup: they share the child matrices C_j in LDS; the per-wave scratch holds K_j first and T = K_j C_j afterwards (one region), so that
+// eight waves -- two per SIMD, one's LDS round trips behind the other's matrix instructions -- fit beside the 57 KB of C
+constexpr int GAL_NW = 8;
 template <int NC, int NCH>
-__global__ __launch_bounds__(256) void k_galerkin_mfma(int nelc, const int* __restrict__ child, const int* __restrict__ slot_f, const double* __restrict__ Kf, int ks_f,
+__global__ __launch_bounds__(GAL_NW * 64) void k_galerkin_mfma(int nelc, const int* __restrict__ child, const int* __restrict__ slot_f, const double* __restrict__ Kf, int ks_f,
                                                        const int* __restrict__ edof_f, int nloc_f, const unsigned char* __restrict__ fb,
                                                        const int* __restrict__ slot_c, double* __restrict__ Kc, int ks_c, const int* __restrict__ edof_c, int nloc_c,
                                                        const unsigned char* __restrict__ cb, const double* __restrict__ Cdense /* [NCH][NC][NC] */) {
   constexpr int NE = NC * NC, NT = (NE + 63) / 64, MT = (NC + 15) / 16, KP = (NC + 3) / 4 * 4, CLD = MT * 16, KLD = KP + 1, TLD = MT * 16;
   extern __shared__ __attribute__((aligned(16))) double gm_smem[];
   double* Cs = gm_smem;                                   // [NCH][KP][CLD], zero padded
-  for (int k = threadIdx.x; k < NCH * KP * CLD; k += 256) {
+  for (int k = threadIdx.x; k < NCH * KP * CLD; k += GAL_NW * 64) {
     const int j = k / (KP * CLD), r = (k / CLD) % KP, c = k % CLD;
     Cs[k] = (r < NC && c < NC) ? Cdense[(j * NC + r) * NC + c] : 0.0;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* Ks = Cs + NCH * KP * CLD + wave * (MT * 16 * KLD + KP * TLD);      // [MT*16][KLD]
-  double* Ts = Ks + MT * 16 * KLD;                                            // [KP][TLD]
-  for (int k = lane; k < MT * 16 * KLD + KP * TLD; k += 64) Ks[k] = 0.0;     // the padding stays zero
+  constexpr int WS = (MT * 16 * KLD > KP * TLD) ? MT * 16 * KLD : KP * TLD;    // doubles of scratch per wave
+  double* Ks = Cs + NCH * KP * CLD + wave * WS;      // [MT*16][KLD]
+  double* Ts = Ks;                                    // [KP][TLD]: the same region, after K_j has been consumed
   __syncthreads();
   const int kk = lane >> 4, li = lane & 15;
   typedef double d4 __attribute__((ext_vector_type(4)));
-  for (int E = blockIdx.x * 4 + wave; E < nelc; E += gridDim.x * 4) {
+  for (int E = blockIdx.x * GAL_NW + wave; E < nelc; E += gridDim.x * GAL_NW) {
     d4 KE[MT][MT];
 #pragma unroll
     for (int a = 0; a < MT; a++)
@@ -2475,6 +2478,9 @@ __global__ __launch_bounds__(256) void k_galerkin_mfma(int nelc, const int* __re
         const int idx = lane + 64 * t;
         if (idx < NE) Ks[(idx / NC) * KLD + idx % NC] = kin[t];
       }
+      // the padding of K_j (rows and columns NC .. of the operand tile) is zero: T of the previous child lived here
+      for (int q = lane; q < (MT * 16 - NC) * KLD; q += 64) Ks[NC * KLD + q] = 0.0;
+      for (int q = lane; q < NC * (KLD - NC); q += 64) Ks[(q / (KLD - NC)) * KLD + NC + q % (KLD - NC)] = 0.0;
       wave_lds_sync();
       if (j + 1 < NCH) gather(j + 1);
       const double* Cj = Cs + j * KP * CLD;
@@ -2496,6 +2502,7 @@ __global__ __launch_bounds__(256) void k_galerkin_mfma(int nelc, const int* __re
 #pragma unroll
           for (int b = 0; b < MT; b++) T[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], T[a][b], 0, 0, 0);
       }
+      wave_lds_sync();                       // every lane has read its operands of K_j: T may take the region
 #pragma unroll
       for (int a = 0; a < MT; a++)
 #pragma unroll
@@ -2547,7 +2554,8 @@ __global__ __launch_bounds__(256) void k_galerkin_mfma(int nelc, const int* __re
 template <int NC, int NCH>
 static size_t galerkin_mfma_lds() {
   constexpr int MT = (NC + 15) / 16, KP = (NC + 3) / 4 * 4;
-  return ((size_t)NCH * KP * MT * 16 + 4 * ((size_t)MT * 16 * (KP + 1) + (size_t)KP * MT * 16)) * sizeof(double);
+  const size_t ws = std::max((size_t)MT * 16 * (KP + 1), (size_t)KP * MT * 16);
+  return ((size_t)NCH * KP * MT * 16 + GAL_NW * ws) * sizeof(double);
 }
 
 extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, const int* child, int nfb, const int* fbdc, int ncb, const int* cbdc, fh_mat_t Ac) {
@@ -2615,12 +2623,12 @@ extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, con
       FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_galerkin_mfma<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)galerkin_mfma_lds<9, 4>()));
       attr_set[c->device & 63] = true;
     }
-    const int g1 = std::max(1, std::min(fh_div_up(cas->nel, 4), c->num_cu));
+    const int g1 = std::max(1, std::min(fh_div_up(cas->nel, GAL_NW), c->num_cu));
     if (nc == 27)
-      hipLaunchKernelGGL((k_galerkin_mfma<27, 8>), dim3(g1), dim3(256), lds, c->stream, cas->nel, cas->d_gal_child, fas->d_slot, fas->d_Kbuf, fas->kstride, fas->d_elem_dof,
+      hipLaunchKernelGGL((k_galerkin_mfma<27, 8>), dim3(g1), dim3(GAL_NW * 64), lds, c->stream, cas->nel, cas->d_gal_child, fas->d_slot, fas->d_Kbuf, fas->kstride, fas->d_elem_dof,
                          fas->nloc, cas->d_gal_fb, cas->d_slot, cas->d_Kbuf, cas->kstride, cas->d_elem_dof, cas->nloc, cas->d_gal_cb, cas->d_gal_dense);
     else
-      hipLaunchKernelGGL((k_galerkin_mfma<9, 4>), dim3(g1), dim3(256), lds, c->stream, cas->nel, cas->d_gal_child, fas->d_slot, fas->d_Kbuf, fas->kstride, fas->d_elem_dof,
+      hipLaunchKernelGGL((k_galerkin_mfma<9, 4>), dim3(g1), dim3(GAL_NW * 64), lds, c->stream, cas->nel, cas->d_gal_child, fas->d_slot, fas->d_Kbuf, fas->kstride, fas->d_elem_dof,
                          fas->nloc, cas->d_gal_fb, cas->d_slot, cas->d_Kbuf, cas->kstride, cas->d_elem_dof, cas->nloc, cas->d_gal_cb, cas->d_gal_dense);
   } else if (nc == 27)
     hipLaunchKernelGGL((k_galerkin_elem<27, 8>), dim3(grid), dim3(256), 0, c->stream, cas->nel, cas->d_gal_child, fas->d_slot, fas->d_Kbuf, fas->kstride,
