@@ -153,6 +153,7 @@ struct fh_mat_s {
   int split_tile = 0;
   int nblk_int = 0;
   int* d_blkinfo_split = nullptr;
+  int* d_diagpos = nullptr;            // position of every row's diagonal entry (-1: none), built by the first fh_dev_get_diag
   // cached explicit transpose for matrix_mult_transpose
   fh_mat_t At = nullptr;
   int* d_tperm = nullptr;             // At.val[k] = val[tperm[k]]

@@ -76,6 +76,7 @@ extern "C" int fh_mat_destroy(fh_mat_t A) {
   if (A->d_tile_s) hipFree(A->d_tile_s);
   if (A->d_blkinfo) hipFree(A->d_blkinfo);
   if (A->d_blkinfo_split) hipFree(A->d_blkinfo_split);
+  if (A->d_diagpos) hipFree(A->d_diagpos);
   delete A;
   return 0;
 }
@@ -532,25 +533,36 @@ extern "C" int fh_mat_zero_cols(fh_mat_t A, int n, const int* cols) {
   return 0;
 }
 
-__global__ __launch_bounds__(256) void k_get_diag(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
-                                                  double* __restrict__ d, int m, int invert) {
+// position of the diagonal entry of every row (-1: none), once per matrix: the pattern of a matrix never changes after its creation
+__global__ __launch_bounds__(256) void k_diag_pos(const int* __restrict__ rowptr, const int* __restrict__ col, int* __restrict__ pos, int m) {
   int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= m) return;
-  int lo = rowptr[r], hi = rowptr[r + 1] - 1;
-  double v = 0.0;
+  int lo = rowptr[r], hi = rowptr[r + 1] - 1, p = -1;
   while (lo <= hi) {  // sorted columns
     int mid = lo + ((hi - lo) >> 1);   // (lo + hi) overflows beyond 2^30 non-zeros
     int cc = col[mid];
-    if (cc == r) { v = val[mid]; break; }
+    if (cc == r) { p = mid; break; }
     if (cc < r) lo = mid + 1; else hi = mid - 1;
   }
+  pos[r] = p;
+}
+
+__global__ __launch_bounds__(256) void k_get_diag(const int* __restrict__ pos, const double* __restrict__ val, double* __restrict__ d, int m, int invert) {
+  int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= m) return;
+  const int p = pos[r];
+  double v = p >= 0 ? val[p] : 0.0;
   if (invert) v = (v == 0.0) ? 1.0 : 1.0 / v;   // PCJACOBI: zero diagonal -> 1
   d[r] = v;
 }
 
 int fh_dev_get_diag(fh_mat_t A, double* d, int invert) {
   if (A->m == 0) return 0;
-  hipLaunchKernelGGL(k_get_diag, dim3(fh_div_up(A->m, 256)), dim3(256), 0, A->ctx->stream, A->d_rowptr, A->d_col, A->d_val, d, A->m, invert);
+  if (!A->d_diagpos) {
+    FH_CHECK_HIP(hipMalloc(&A->d_diagpos, (size_t)A->m * sizeof(int)));
+    hipLaunchKernelGGL(k_diag_pos, dim3(fh_div_up(A->m, 256)), dim3(256), 0, A->ctx->stream, A->d_rowptr, A->d_col, A->d_diagpos, A->m);
+  }
+  hipLaunchKernelGGL(k_get_diag, dim3(fh_div_up(A->m, 256)), dim3(256), 0, A->ctx->stream, A->d_diagpos, A->d_val, d, A->m, invert);
   FH_CHECK_HIP(hipGetLastError());
   return 0;
 }
