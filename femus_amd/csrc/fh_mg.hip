@@ -1714,7 +1714,7 @@ static int coarse_factor(fh_mg_t mg) {
     mg->d_gjwork2 = mg->d_gjwork + (size_t)2 * n * GJ_NB + GJ_NB * GJ_NB + 8;
     mg->ainv_n = n;
   }
-  FH_CHECK_HIP(hipMemsetAsync(mg->d_ainv, 0, (size_t)n * n * sizeof(double), c->stream));
+  hipLaunchKernelGGL(k_fill_value, dim3(c->num_cu * 8), dim3(256), 0, c->stream, mg->d_ainv, 0.0, n * n);      // (the runtime's memset runs at 0.6 TB/s)
   auto to_dense = [&]() {
     if (n == nfull) hipLaunchKernelGGL(k_csr_to_dense, dim3(n), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, mg->d_ainv, n);
     else hipLaunchKernelGGL(k_csr_to_dense_sub, dim3(n), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, mg->d_ainv, n, mg->d_act,
@@ -1776,7 +1776,7 @@ static int coarse_factor(fh_mg_t mg) {
       if (!(hf[1] & 4)) return finish();
       // a pivot block without a usable diagonal pivot (the operator is symmetric but not definite): start again with the pivoted sweep
       FH_CHECK_HIP(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), c->stream));
-      FH_CHECK_HIP(hipMemsetAsync(mg->d_ainv, 0, (size_t)n * n * sizeof(double), c->stream));
+      hipLaunchKernelGGL(k_fill_value, dim3(c->num_cu * 8), dim3(256), 0, c->stream, mg->d_ainv, 0.0, n * n);      // (the runtime's memset runs at 0.6 TB/s)
       to_dense();
     }
     if (h_flag == 0) {
