@@ -1,7 +1,7 @@
 # Profiles of one round on the GPU box: bench line, rocprofv3 kernel trace of the bench command, PMC passes (HBM traffic of the fine-level
 # SpMV sweep and of the two assembly kernels, instruction / LDS / wait counters of the element kernel).  Counter passes use
 # --kernel-trace only (never sys / hip / memory traces), one counter set per pass.
-#   bash tests/profile_round.sh r02      -> gpurun_out/r02/*   (copy the summaries worth keeping into profiles/)
+#   bash tests/profile_round.sh r03      -> gpurun_out/r03/*   (copy the summaries worth keeping into profiles/)
 TAG=${1:-r03}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
@@ -33,4 +33,8 @@ for set in "SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY
   timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc/p$i -- python $ROOT/tests/perf_probe_kpad.py ${ASM_SPEC:-12,1} > /tmp/pmc/log$i.txt 2>&1 || echo "assembly pass $i failed"
 done
 python $ROOT/profiles/summarize.py /tmp/pmc $OUT/${TAG}_assembly_pmc_summary.md > /dev/null
+# ---- preparation: kernels of one fh_mg_setup re-preparation ----
+rm -rf /tmp/prof/prep
+PYTHONPATH=$ROOT timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/prep -- python $ROOT/tests/perf_probe_prepare.py 8 128 > /tmp/prof/prep.log 2>&1 || echo "prepare trace failed"
+python $ROOT/profiles/summarize.py /tmp/prof/prep $OUT/${TAG}_prepare_kernel_summary.md > /dev/null
 tail -c 600 $OUT/${TAG}_bench_line.json
