@@ -71,6 +71,8 @@ struct fh_mg_s {
   // emptied too) are solved by their diagonal; the dense inverse holds the na remaining ones.  d_act: their indices, then the others
   int na = -1;
   int* d_act = nullptr;
+  int* d_hit = nullptr;       // row / column coupling marks of the last test
+  int hit_n = 0;
   std::vector<int> h_act;
   bool setup_done = false;
   hipGraph_t graph = nullptr;
@@ -1675,9 +1677,14 @@ static int coarse_factor(fh_mg_t mg) {
   // ---- unknowns coupled to nothing leave the dense problem (exact: the operator is block diagonal with respect to them) ----
   int n = nfull;
   if (c->coarse_reduce && nfull > 0) {
-    int* d_hit = nullptr;
-    FH_CHECK_HIP(hipMalloc(&d_hit, (size_t)2 * nfull * sizeof(int)));
-    std::unique_ptr<void, void (*)(void*)> guard(d_hit, [](void* q) { hipFree(q); });
+    if (mg->hit_n < nfull) {           // kept across preparations (an allocation and its release cost more than the test itself)
+      if (mg->d_hit) FH_CHECK_HIP(hipFree(mg->d_hit));
+      mg->d_hit = nullptr;
+      mg->hit_n = 0;
+      FH_CHECK_HIP(hipMalloc(&mg->d_hit, (size_t)2 * nfull * sizeof(int)));
+      mg->hit_n = nfull;
+    }
+    int* d_hit = mg->d_hit;
     FH_CHECK_HIP(hipMemsetAsync(d_hit, 0, (size_t)2 * nfull * sizeof(int), c->stream));
     hipLaunchKernelGGL(k_coarse_coupling, dim3(fh_div_up(nfull, 4)), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, nfull, d_hit,
                        d_hit + nfull);
@@ -2239,6 +2246,7 @@ extern "C" int fh_mg_destroy(fh_mg_t mg) {
   }
   if (mg->d_ainv) hipFree(mg->d_ainv);
   if (mg->d_act) hipFree(mg->d_act);
+  if (mg->d_hit) hipFree(mg->d_hit);
   if (mg->d_gjwork) hipFree(mg->d_gjwork);
   for (double* p : mg->kv) hipFree(p);
   if (mg->d_V) hipFree(mg->d_V);
