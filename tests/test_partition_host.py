@@ -94,3 +94,24 @@ def test_gambit_mesh_can_be_partitioned_and_cut():
     assert own.size == 4 and ring.size == 4
     sub, node_gid = g.submesh(np.concatenate([own, ring]))
     assert sub.nel == 8 and sub.nnode == g.nnode
+
+
+def test_partition_on_random_disconnected_meshes():
+    """random subsets of box elements in random order (disconnected pieces, single elements, 2-D and 3-D), part counts from 1 to the number
+    of elements: every part non-empty, sizes within one element of each other, the rank's ring disjoint from its own elements"""
+    rng = np.random.default_rng(0)
+    for trial in range(25):
+        n = (int(rng.integers(1, 6)), int(rng.integers(1, 6)), int(rng.integers(1, 5)) if rng.integers(0, 2) else 0)
+        g = capi.Mesh.box(*n)
+        k = int(rng.integers(1, g.nel + 1))
+        sub, _ = g.submesh(rng.permutation(g.nel)[:k].astype(np.int32))
+        for nparts in sorted({1, 2, 3, int(rng.integers(1, sub.nel + 1)), sub.nel}):
+            if nparts > sub.nel:
+                continue
+            part = sub.partition(nparts)
+            cnt = np.bincount(part, minlength=nparts)
+            assert cnt.sum() == sub.nel and cnt.min() >= 1 and cnt.max() - cnt.min() <= 1 and part.min() >= 0 and part.max() < nparts
+            for r in range(min(nparts, 3)):
+                own, ring = sub.rank_elements(part, r)
+                assert set(own.tolist()) == set(np.where(part == r)[0].tolist())
+                assert not (set(own.tolist()) & set(ring.tolist()))
