@@ -241,11 +241,26 @@ def main():
     for _ in range(3):
         y.jacobi_sweep(pb.RES, x, A, dinv, 2. / 3.)
         x.jacobi_sweep(pb.RES, y, A, dinv, 2. / 3.)
+    # timed as the cycle issues them: the kr launches recorded into one hipGraph and replayed (eager launches of this kernel sit ~20 us apart,
+    # replayed ones back to back); the eager figure is kept beside it
     ctx.timer_start()
     for _ in range(kr // 2):
         y.jacobi_sweep(pb.RES, x, A, dinv, 2. / 3.)
         x.jacobi_sweep(pb.RES, y, A, dinv, 2. / 3.)
-    sweep_ms = ctx.timer_stop() / (2 * (kr // 2))
+    sweep_eager_ms = ctx.timer_stop() / (2 * (kr // 2))
+    sweep_ms = sweep_eager_ms
+    try:
+        with ctx.record() as rec:
+            for _ in range(kr // 2):
+                y.jacobi_sweep(pb.RES, x, A, dinv, 2. / 3.)
+                x.jacobi_sweep(pb.RES, y, A, dinv, 2. / 3.)
+        rec.graph.launch()
+        ctx.timer_start()
+        rec.graph.launch()
+        sweep_ms = ctx.timer_stop() / (2 * (kr // 2))
+        rec.graph.destroy()
+    except Exception as e:             # no recording on this runtime: the eager figure stands
+        sys.stderr.write("bench.py: fused sweep not timed under graph replay (%s)\n" % e)
     ctx.timer_start()
     for _ in range(kr):
         y.matrix_mult(x, A)
@@ -312,6 +327,8 @@ def main():
                                    "(`expected_bytes`) or once per row block (`..._no_l2_reuse`).  `traffic` (counters, FETCH_SIZE x 2 + WRITE_SIZE; "
                                    "factor calibrated per access width in profiles/r03_fetch_calibration.md) should lie between the two",
             "avg_launch_ms": sweep_ms,
+            "avg_launch_ms_eager": sweep_eager_ms,
+            "avg_launch_note": "avg_launch_ms: the launches recorded into one hipGraph and replayed, as the V-cycle issues them; avg_launch_ms_eager: the same launches issued one by one from the host",
             "plain_spmv_ms": spmv_ms,
         },
         "optional_affine_fast_path": {

@@ -60,6 +60,10 @@ def _declare(L):
     sig("fh_sync", c_void_p)
     sig("fh_timer_start", c_void_p)
     sig("fh_timer_stop", c_void_p, P(c_double))
+    sig("fh_graph_begin", c_void_p)
+    sig("fh_graph_end", c_void_p, P(c_void_p))
+    sig("fh_graph_launch", c_void_p)
+    sig("fh_graph_destroy", c_void_p)
     sig("fh_set_option", c_void_p, c_char_p, c_double)
     sig("fh_vec_create", c_void_p, c_int, c_int, c_int, c_void_p, c_int, P(c_void_p))
     sig("fh_vec_duplicate", c_void_p, P(c_void_p))

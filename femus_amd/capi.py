@@ -68,6 +68,11 @@ class Context:
         _chk(self.L.fh_timer_stop(self.h, ctypes.byref(ms)))
         return ms.value
 
+    def record(self):
+        """context manager: the device-only calls made inside are recorded into a hipGraph instead of executed; `.graph` replays them
+        (fh_graph_begin / fh_graph_end)"""
+        return _Recording(self)
+
     # factories
     def vector(self, n_global, n_local=None, first_local=0, ghost=None):
         return Vec(self, n_global, n_global if n_local is None else n_local, first_local, ghost)
@@ -85,6 +90,40 @@ class Context:
         A = A.tocsr()
         A.sort_indices()
         return Mat.from_csr(self, A.shape[0], A.shape[1], A.indptr, A.indices, A.data)
+
+
+class Graph:
+    """a recorded launch sequence (fh_graph_t)"""
+
+    def __init__(self, L, handle):
+        self.L, self.h = L, handle
+
+    def launch(self):
+        _chk(self.L.fh_graph_launch(self.h))
+
+    def destroy(self):
+        if self.h:
+            _chk(self.L.fh_graph_destroy(self.h))
+            self.h = None
+
+
+class _Recording:
+    def __init__(self, ctx):
+        self.ctx, self.graph = ctx, None
+
+    def __enter__(self):
+        _chk(self.ctx.L.fh_graph_begin(self.ctx.h))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        h = ctypes.c_void_p()
+        rc = self.ctx.L.fh_graph_end(self.ctx.h, ctypes.byref(h))
+        if et is None:
+            _chk(rc)
+            self.graph = Graph(self.ctx.L, h)
+        elif rc == 0 and h:
+            self.ctx.L.fh_graph_destroy(h)
+        return False
 
 
 class Vec:

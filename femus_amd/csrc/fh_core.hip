@@ -122,6 +122,76 @@ extern "C" int fh_timer_stop(fh_ctx_t c, double* ms) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// recorded launch sequences: the device-only calls made between fh_graph_begin and fh_graph_end (SpMV family, vector algebra, fh_assemble_*
+// after their first call -- nothing that synchronises, allocates or copies to the host) become one hipGraph that fh_graph_launch replays
+// ------------------------------------------------------------------------------------------------
+struct fh_graph_s {
+  fh_ctx_t ctx = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+extern "C" int fh_graph_begin(fh_ctx_t c) {
+  FH_REQUIRE(c, "fh_graph_begin: null context");
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  FH_CHECK_HIP(hipStreamIsCapturing(c->stream, &st));
+  FH_REQUIRE(st == hipStreamCaptureStatusNone, "fh_graph_begin: a recording is already open on this context");
+  FH_CHECK_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  return 0;
+}
+
+extern "C" int fh_graph_end(fh_ctx_t c, fh_graph_t* out) {
+  FH_REQUIRE(c && out, "fh_graph_end: null argument");
+  *out = nullptr;
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(c->stream, &g);
+  if (e != hipSuccess || !g) {
+    // an invalidated recording: clear the sticky error; if the runtime leaves the stream in its capture state all the same, the context
+    // gets a fresh compute stream (every call reads ctx->stream when it runs; a handle taken with fh_stream() before is stale then)
+    (void)hipGetLastError();
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    const hipError_t q = hipStreamIsCapturing(c->stream, &st);
+    (void)hipGetLastError();
+    if (q != hipSuccess || st != hipStreamCaptureStatusNone) {
+      hipStream_t fresh = nullptr;
+      if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        (void)hipGetLastError();
+        c->stream = fresh;
+      }
+    }
+  }
+  FH_REQUIRE(e == hipSuccess && g, "fh_graph_end: the recording is invalid (%s): a call inside it synchronised, allocated or copied to the host",
+             hipGetErrorString(e));
+  hipGraphExec_t ex = nullptr;
+  if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+    hipGraphDestroy(g);
+    FH_REQUIRE(false, "fh_graph_end: the graph could not be instantiated");
+  }
+  fh_graph_s* G = new fh_graph_s;
+  G->ctx = c;
+  G->graph = g;
+  G->exec = ex;
+  *out = G;
+  return 0;
+}
+
+extern "C" int fh_graph_launch(fh_graph_t g) {
+  FH_REQUIRE(g && g->exec, "fh_graph_launch: null graph");
+  FH_CHECK_HIP(hipGraphLaunch(g->exec, g->ctx->stream));
+  return 0;
+}
+
+extern "C" int fh_graph_destroy(fh_graph_t g) {
+  if (!g) return 0;
+  hipStreamSynchronize(g->ctx->stream);
+  if (g->exec) hipGraphExecDestroy(g->exec);
+  if (g->graph) hipGraphDestroy(g->graph);
+  delete g;
+  return 0;
+}
+
 extern "C" int fh_set_option(fh_ctx_t c, const char* name, double value) {
   c->opt_gen++;
   if (!strcmp(name, "spmv_tile")) c->spmv_tile = (int)value;

@@ -2223,8 +2223,16 @@ static int apply_cycle(fh_mg_t mg, const double* b_in, double* x_out) {
   return 0;
 }
 
+static int not_recording(fh_ctx_t c, const char* who) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  FH_CHECK_HIP(hipStreamIsCapturing(c->stream, &st));
+  FH_REQUIRE(st == hipStreamCaptureStatusNone, "%s: not inside fh_graph_begin / fh_graph_end (the cycle replays its own graph)", who);
+  return 0;
+}
+
 extern "C" int fh_mg_vcycle(fh_mg_t mg, fh_vec_t b, fh_vec_t x) {
   FH_REQUIRE(mg && mg->setup_done, "fh_mg_vcycle: fh_mg_setup has not been called");
+  FH_TRY(not_recording(mg->ctx, "fh_mg_vcycle"));
   const int n = mg->lv[mg->nlevels - 1].n;
   FH_REQUIRE(b->n_local >= n && x->n_local >= n, "fh_mg_vcycle: vectors too short");
   return apply_cycle(mg, b->d, x->d);

@@ -35,6 +35,7 @@ typedef struct fh_mat_s* fh_mat_t;
 typedef struct fh_mg_s* fh_mg_t;
 typedef struct fh_mesh_s* fh_mesh_t;
 typedef struct fh_halo_s* fh_halo_t;
+typedef struct fh_graph_s* fh_graph_t;
 
 /* ---- context --------------------------------------------------------------------------------
  * replaces FemusInit (src/00_utils/00_application_initialization/FemusInit.cpp:46-74: PetscInitialize) */
@@ -49,6 +50,16 @@ void* fh_stream(fh_ctx_t ctx);                       /* hipStream_t of the compu
 /* HIP-event timing on the compute stream (bench.py: roofline.achieved is measured with these) */
 int fh_timer_start(fh_ctx_t ctx);
 int fh_timer_stop(fh_ctx_t ctx, double* milliseconds);
+/* Recorded launch sequences (hipGraph): the device-only calls between fh_graph_begin and fh_graph_end -- SpMV family, vector algebra,
+ * fh_assemble_* after their first call; nothing that synchronises, allocates or copies to the host, and no fh_mg_* call (the cycle keeps
+ * its own graph) -- are recorded instead of executed; fh_graph_launch replays them on the compute stream.  No counterpart in the
+ * reference (PETSc issues every operation eagerly); bench.py times the fused sweep inside such a recording, as the cycle runs it.
+ * A recording that contains a forbidden call ends in an error of fh_graph_end; the context stays usable (it may get a new compute stream:
+ * a handle taken with fh_stream() earlier is stale then). */
+int fh_graph_begin(fh_ctx_t ctx);
+int fh_graph_end(fh_ctx_t ctx, fh_graph_t* graph);
+int fh_graph_launch(fh_graph_t graph);
+int fh_graph_destroy(fh_graph_t graph);
 /* runtime tuning knobs (the reference honours the PETSc options DB, 03_solvers/LinearEquationSolverPetsc.cpp:251-254);
  * names (default): "spmv_tile" (2048), "spmv_xcd_remap" (32), "spmv_kernel" (3), "assemble_two_pass" (1), "assemble_emap" (1),
  * "assemble_mfma" (12: HEX27/Q2 element matrices on the FP64 matrix cores, value = waves per workgroup, 0 = vector kernel),

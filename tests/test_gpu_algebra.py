@@ -269,3 +269,39 @@ def test_spgemm_random_shapes(ctx, seed):
 def capi_ptap(ctx, P, A):
     from femus_amd import capi
     return capi.Mat.ptap(P, A)
+
+
+def test_recorded_launch_sequences(ctx, q2_matrix):
+    """fh_graph_begin / fh_graph_end / fh_graph_launch: a recorded sequence of SpMV-family and vector calls replays to the bits of the eager
+    calls, any number of times; a cycle call inside a recording is refused; a recording with a host copy inside is reported as invalid"""
+    _, A, _ = q2_matrix
+    M = ctx.matrix_scipy(A)
+    n = A.shape[0]
+    rng = np.random.default_rng(3)
+    xs, bs = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    dinv = 1.0 / A.diagonal()
+
+    def sequence(x, y, b, d):
+        y.jacobi_sweep(b, x, M, d, 0.7)
+        x.jacobi_sweep(b, y, M, d, 0.7)
+        y.resid(b, x, M)
+
+    x, y, b, d = ctx.vector_from(xs), ctx.vector(n), ctx.vector_from(bs), ctx.vector_from(dinv)
+    sequence(x, y, b, d)                                   # plans built, then the eager result of TWO applications
+    sequence(x, y, b, d)
+    eager = (x.to_numpy().copy(), y.to_numpy().copy())
+    x.upload(xs)
+    with ctx.record() as rec:
+        sequence(x, y, b, d)
+    assert np.array_equal(x.to_numpy(), xs)               # recording does not execute
+    rec.graph.launch()
+    rec.graph.launch()
+    assert np.array_equal(x.to_numpy(), eager[0]) and np.array_equal(y.to_numpy(), eager[1])
+    rec.graph.destroy()
+    with pytest.raises(Exception):                         # a host read inside a recording invalidates it
+        with ctx.record():
+            y.resid(b, x, M)
+            y.l2_norm()
+    y.resid(b, x, M)                                       # the context works on
+    assert np.isfinite(y.l2_norm())
+    M.destroy()
