@@ -198,6 +198,7 @@ def _declare(L):
     sig("fh_assembler_galerkin", c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p)
     sig("fh_spmv_expected_bytes", c_void_p, c_int, P(ctypes.c_int64), P(ctypes.c_int64))
     sig("fh_mesh_partition", c_void_p, c_int, c_void_p)
+    sig("fh_mesh_partition_weighted", c_void_p, c_int, c_void_p, c_void_p)
     sig("fh_mesh_rank_elements", c_void_p, c_void_p, c_int, P(c_int), P(c_int), c_void_p)
     sig("fh_mesh_submesh", c_void_p, c_int, c_void_p, P(c_void_p), c_void_p)
     sig("fh_dd_topo_node_keys", c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p)

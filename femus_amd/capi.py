@@ -504,10 +504,16 @@ class Mesh:
         _chk(self.L.fh_mesh_refine(self.h, ctypes.byref(h)))
         return Mesh(self.L, h)
 
-    def partition(self, nparts):
-        """native k-way partition of the dual graph (the METIS_PartMeshDual of MeshMetisPartitioning.cpp:71-113): part[nel]"""
+    def partition(self, nparts, weights=None):
+        """native k-way partition of the dual graph (the METIS_PartMeshDual of MeshMetisPartitioning.cpp:71-113): part[nel];
+        weights[nel] > 0: the parts balance the weight sums (adaptive levels) instead of the element counts"""
         part = np.empty(self.nel, dtype=np.int32)
-        _chk(self.L.fh_mesh_partition(self.h, int(nparts), _p(part)))
+        if weights is None:
+            _chk(self.L.fh_mesh_partition(self.h, int(nparts), _p(part)))
+        else:
+            w = _f64(weights)
+            assert w.shape == (self.nel,)
+            _chk(self.L.fh_mesh_partition_weighted(self.h, int(nparts), _p(w), _p(part)))
         return part
 
     def rank_elements(self, part, rank):

@@ -1271,7 +1271,8 @@ static void bfs_order(const std::vector<int>& ptr, const std::vector<int>& adj, 
   }
 }
 
-static void bisect(const std::vector<int>& ptr, const std::vector<int>& adj, std::vector<int>& set, int p0, int np, std::vector<int>& part) {
+static void bisect(const std::vector<int>& ptr, const std::vector<int>& adj, std::vector<int>& set, int p0, int np, std::vector<int>& part,
+                   const double* w = nullptr) {
   if (np == 1 || set.empty()) {
     for (int e : set) part[e] = p0;
     return;
@@ -1285,12 +1286,24 @@ static void bisect(const std::vector<int>& ptr, const std::vector<int>& adj, std
   const int far2 = order.back();
   bfs_order(ptr, adj, set, in, far2, order);
   const int np1 = np / 2;
-  const size_t n1 = (set.size() * (size_t)np1 + np / 2) / np;
+  size_t n1 = (set.size() * (size_t)np1 + np / 2) / np;
+  if (w) {
+    // element weights (the work below an element after adaptive refinement): the first half takes the prefix of the breadth-first
+    // order whose weight is closest to np1 / np of the total; every side keeps at least as many elements as it has parts to fill
+    double total = 0.0;
+    for (int e : order) total += w[e];
+    const double want = total * (double)np1 / (double)np;
+    double acc = 0.0;
+    n1 = 0;
+    while (n1 < order.size() && acc + 0.5 * w[order[n1]] <= want) acc += w[order[n1++]];
+    const size_t lo = std::min(order.size(), (size_t)np1), hi = order.size() > (size_t)(np - np1) ? order.size() - (size_t)(np - np1) : 0;
+    n1 = std::max(lo, std::min(n1, std::max(lo, hi)));
+  }
   std::vector<int> a(order.begin(), order.begin() + n1), b(order.begin() + n1, order.end());
   std::sort(a.begin(), a.end());
   std::sort(b.begin(), b.end());
-  bisect(ptr, adj, a, p0, np1, part);
-  bisect(ptr, adj, b, p0 + np1, np - np1, part);
+  bisect(ptr, adj, a, p0, np1, part, w);
+  bisect(ptr, adj, b, p0 + np1, np - np1, part, w);
 }
 
 extern "C" int fh_mesh_partition(fh_mesh_t G, int nparts, int* part) {
@@ -1303,6 +1316,22 @@ extern "C" int fh_mesh_partition(fh_mesh_t G, int nparts, int* part) {
   fh_copy_out(part, p);
   return 0;
   FH_GUARD_END("fh_mesh_partition")
+}
+
+// the same bisection with element weights: the parts balance the SUM of the weights instead of the element count -- what the reference
+// gets from re-partitioning an adaptively refined level (MeshMetisPartitioning.cpp:41-113 with AMR = true) while children still inherit
+// their coarse element's rank (:143-155): weight = number of finest-level descendants of the coarse element
+extern "C" int fh_mesh_partition_weighted(fh_mesh_t G, int nparts, const double* weight, int* part) {
+  FH_GUARD_BEGIN
+  FH_REQUIRE(G && part && weight && nparts >= 1, "fh_mesh_partition_weighted: bad arguments");
+  for (int e = 0; e < G->nel; e++) FH_REQUIRE(weight[e] > 0.0 && weight[e] < 1e300, "fh_mesh_partition_weighted: weight of element %d is not positive and finite", e);
+  std::vector<int> ptr, adj, set(G->nel), p(G->nel, 0);
+  dual_graph(G, ptr, adj);
+  for (int e = 0; e < G->nel; e++) set[e] = e;
+  bisect(ptr, adj, set, 0, nparts, p, weight);
+  fh_copy_out(part, p);
+  return 0;
+  FH_GUARD_END("fh_mesh_partition_weighted")
 }
 
 extern "C" int fh_mesh_rank_elements(fh_mesh_t G, const int* part, int rank, int* n_owned, int* n_total, int* elems) {

@@ -109,6 +109,48 @@ def local_meshes(part, nb, nlevels, flag_fn=None, n_uniform=None):
     return ms
 
 
+def refine_levels(m0, nlevels, flag_fn=None, n_uniform=None):
+    """[m0, ...]: nlevels - 1 refinements of m0, uniform below n_uniform, selective (flag_fn on the coordinates the mesh carries) from there on"""
+    ms = [m0]
+    for l in range(1, nlevels):
+        if flag_fn is None or n_uniform is None or l < n_uniform:
+            ms.append(ms[-1].refine())
+        else:
+            ms.append(ms[-1].refine_flagged(ms[-1].flag_elements(flag_fn)))
+    return ms
+
+
+def amr_slice_weights(G, lo, hi, nlevels, flag_fn, n_uniform):
+    """number of finest-level descendants of the coarse elements lo .. hi-1 of G after nlevels - 1 refinements (uniform below n_uniform,
+    selective from there on).  A flag is decided from the element's own vertices, so the slice is refined in isolation"""
+    if hi <= lo:
+        return np.zeros(0, dtype=np.int64)
+    sub, _ = G.submesh(np.arange(lo, hi, dtype=np.int32))
+    ms = refine_levels(sub, nlevels, flag_fn, n_uniform)
+    anc = np.arange(sub.nel, dtype=np.int64)                      # coarse ancestor (position in the slice) of every element of the level
+    for l in range(nlevels - 1):
+        ch = ms[l].child_elems()                                  # -1 beyond the first entry of an element that was copied, not refined
+        nxt = np.empty(ms[l + 1].nel, dtype=np.int64)
+        ok = ch >= 0
+        nxt[ch[ok]] = np.broadcast_to(anc[:, None], ch.shape)[ok]
+        anc = nxt
+    w = np.bincount(anc, minlength=sub.nel).astype(np.int64)
+    for m in ms:
+        m.destroy()
+    return w
+
+
+def amr_element_weights(G, comm, nranks, rank, nlevels, flag_fn, n_uniform):
+    """work below every element of the coarse mesh G after the adaptive refinement (finest-level descendants): every rank refines a
+    contiguous slice of the coarse elements (1 / nranks of the job, the size of its later share) and the counts are gathered -- no rank
+    ever holds the refined global mesh.  Input of the weighted partition that stands for the reference's re-partition of adaptive levels."""
+    mine = amr_slice_weights(G, (G.nel * rank) // nranks, (G.nel * (rank + 1)) // nranks, nlevels, flag_fn, n_uniform)
+    parts = comm.allgather_obj(mine)
+    w = np.concatenate([np.asarray(p_, dtype=np.int64) for p_ in parts]).astype(np.float64)
+    assert w.size == G.nel and w.min() >= 1
+    return w
+
+
 def node_keys(coords, level, nb, part):
     """global integer grid index of every node of a level-`level` mesh and the owner rank (fh_dd_box_node_keys)"""
     import ctypes
@@ -666,7 +708,8 @@ class DistributedPoisson:
         # The coarse mesh itself is the replicated, exactly solved level of the cycle (there is no coarser mesh to go to).
         self.general = coarse_mesh is not None
         if self.general:
-            assert flag_fn is None and nlevels >= 2 and fe == "biquadratic", "general partitions: uniform levels, Q2, at least two levels"
+            assert nlevels >= 2 and fe == "biquadratic", "general partitions: Q2, at least two levels"
+            assert flag_fn is None or (n_uniform is not None and n_uniform >= 2), "general partitions: level 1 is the first distributed level and stays uniform"
 
             class _Part:
                 pass
@@ -686,15 +729,20 @@ class DistributedPoisson:
         if self.general:
             G = coarse_mesh
             self.n_replicated = 0
-            self.partition = np.asarray(partition if partition is not None else G.partition(nranks), dtype=np.int32)
+            # adaptive levels: the parts balance the finest-level descendants of the coarse elements (the reference re-partitions a refined
+            # level with METIS, MeshMetisPartitioning.cpp:41-113 with AMR = true; here the children keep inheriting and the coarse partition
+            # carries the weights), every rank flags with the same function on the coordinates of the mesh
+            self.elem_weights = None
+            if partition is None and flag_fn is not None:
+                self.elem_weights = amr_element_weights(G, comm, nranks, rank, nlevels, flag_fn, n_uniform)
+            self.partition = np.asarray(partition if partition is not None else G.partition(nranks, self.elem_weights), dtype=np.int32)
             own_e, ring_e = G.rank_elements(self.partition, rank)
             assert own_e.size > 0, "rank %d owns no coarse element" % rank
             els0 = np.concatenate([own_e, ring_e]).astype(np.int32)
             sub, node_gid = G.submesh(els0)
-            meshes = [sub]
-            for l in range(1, nlevels):
-                meshes.append(meshes[-1].refine())
-            self.partitioner = "native recursive bisection of the dual graph (fh_mesh_partition), %d coarse elements" % G.nel
+            meshes = refine_levels(sub, nlevels, flag_fn, n_uniform)
+            self.partitioner = "native recursive bisection of the dual graph (fh_mesh_partition%s), %d coarse elements" % (
+                "_weighted: finest-level descendants per coarse element" if self.elem_weights is not None else "", G.nel)
         else:
             meshes = local_meshes(part, nb, nlevels, flag_fn, n_uniform)
             self.partitioner = "box split %dx%dx%d" % tuple(part.p)

@@ -474,6 +474,9 @@ int fh_host_binary_load(const char* path, int* n, double* values);
  *   fh_dd_topo_node_keys   global id / owner (lowest rank around, Mesh.cpp:517-559) of every node of a refined level of the sub-mesh from
  *                          the refinement tree alone (entity of the coarse mesh + dyadic offsets in a frame fixed by global ids) */
 int fh_mesh_partition(fh_mesh_t coarse, int nparts, int* part /* [nel] */);
+/* the same with element weights (adaptive levels: weight = finest-level descendants of a coarse element; replaces the re-partition of a
+ * refined level, MeshMetisPartitioning.cpp:41-113 with AMR = true, while children inherit their coarse element's rank, :143-155) */
+int fh_mesh_partition_weighted(fh_mesh_t coarse, int nparts, const double* weight /* [nel], > 0 */, int* part /* [nel] */);
 int fh_mesh_rank_elements(fh_mesh_t coarse, const int* part, int rank, int* n_owned, int* n_total, int* elems /* may be NULL */);
 int fh_mesh_submesh(fh_mesh_t coarse, int nsel, const int* sel, fh_mesh_t* sub, int* node_gid /* [nodes of sub], may be NULL */);
 int fh_dd_topo_node_keys(fh_mesh_t coarse, const int* part, int nlevels, const fh_mesh_t* levels, const int* elem_gid0, int level, int64_t* gid, int* owner);

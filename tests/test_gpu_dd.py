@@ -469,3 +469,72 @@ def test_general_partition_equals_the_serial_solve(ctx, tmp_path, kind, world):
         assert cnt.max() - cnt.min() <= 1
     assert np.all(seen == 1)                               # every node has exactly one owner
     pb.destroy()
+
+
+# ---- adaptive levels on general partitions: weighted native partition + topological keys on selectively refined levels -------------------
+def _general_amr_flag(x, level):
+    return x[0] > 0.5 and (level < 2 or x[1] > 0.3)
+
+
+def _general_amr_worker(rank, world, port, kind, nlevels, n_uniform, out):
+    try:
+        import femus_amd as fa
+        from femus_amd import dd as ddm
+        comm = ddm.SocketComm(rank, world, "127.0.0.1", port)
+        ctx = fa.Context(0)
+        ctx.set_option("debug_poison", 1)
+        G = _general_coarse_mesh(kind)
+        dp = ddm.DistributedPoisson(ctx, comm, world, rank, nlevels=nlevels, transport="host", coarse_mesh=G, flag_fn=_general_amr_flag,
+                                    n_uniform=n_uniform)
+        dp.assemble(); dp.set_penalty_top()
+        its, rn = dp.solve(outer="gmres", rtol=1e-12, maxit=80)
+        top = dp.H.plans[-1]
+        xy = dp.full.meshes[-1].arrays()[1][top.owned]
+        np.savez(out % rank, x=dp.EPSC.to_numpy()[:dp.n_owned].copy(), xy=xy, its=its, part=dp.partition, n_owned=dp.n_owned,
+                 w=dp.elem_weights, adaptive=dp.adaptive, nel_local=dp.nel_local)
+        comm.barrier()
+        comm.close()
+    except BaseException:
+        _record_worker_failure("general_amr", rank, world)
+        raise
+
+
+@pytest.mark.parametrize("kind,world", [("shuffled", 2), ("shuffled", 3), ("gambit", 2)])
+def test_general_partition_with_adaptive_levels_equals_the_serial_solve(ctx, tmp_path, kind, world):
+    """two selectively refined levels over a coarse mesh that is no box (MGAMR on a METIS-style partition): the parts balance the
+    finest-level descendants of the coarse elements (fh_mesh_partition_weighted), every rank flags its extended mesh with the same
+    function, assembles and projects the hanging nodes there; the distributed solution equals the single-GPU solve of the same adaptive
+    hierarchy (1e-9), every node is owned once, and the weighted parts are better balanced than the element-count partition"""
+    import torch.multiprocessing as mp
+    nlevels, n_uniform = 4, 2
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_general_amr_worker, args=(world, _free_port(), kind, nlevels, n_uniform, out), nprocs=world, join=True)
+    G = _general_coarse_mesh(kind)
+    meshes = dd.refine_levels(G, nlevels, _general_amr_flag, n_uniform)
+    assert not meshes[-1].elem_levels()[1]                 # the finest level really is non-homogeneous
+    pb = PoissonMG(ctx, 0, 0, 0, nlevels, meshes=meshes).init()
+    pb.assemble()
+    pb.prepare()
+    pb.mgsolve(outer="gmres", rtol=1e-12)
+    ref = pb.EPSC.to_numpy()
+    xy = meshes[-1].arrays()[1]
+    key = lambda a: [tuple(v) for v in np.rint(a * 1e9).astype(np.int64)]
+    pos = {k: i for i, k in enumerate(key(xy))}
+    assert len(pos) == xy.shape[0]
+    seen = np.zeros(xy.shape[0], dtype=int)
+    adaptive = 0
+    for r in range(world):
+        d = np.load(out % r)
+        idx = np.array([pos[k] for k in key(d["xy"])])
+        seen[idx] += 1
+        adaptive += int(d["adaptive"])
+        assert np.linalg.norm(d["x"] - ref[idx]) <= 1e-9 * np.linalg.norm(ref), (r, int(d["its"]))
+    assert np.all(seen == 1) and adaptive > 0
+    d0 = np.load(out % 0)
+    w, part = d0["w"], d0["part"]
+    assert w.sum() == meshes[-1].nel
+    load = np.bincount(part, weights=w, minlength=world)
+    plain = np.bincount(G.partition(world), weights=w, minlength=world)
+    assert load.max() / load.mean() <= plain.max() / plain.mean() + 1e-12
+    assert load.max() / load.mean() <= 1.25, load
+    pb.destroy()

@@ -115,3 +115,91 @@ def test_partition_on_random_disconnected_meshes():
                 own, ring = sub.rank_elements(part, r)
                 assert set(own.tolist()) == set(np.where(part == r)[0].tolist())
                 assert not (set(own.tolist()) & set(ring.tolist()))
+
+
+# ---- element weights: adaptive levels on general partitions ------------------------------------------------------------------
+@pytest.mark.parametrize("n,nparts", [((6, 4, 2), 2), ((6, 4, 2), 3), ((5, 5, 0), 4), ((4, 4, 4), 8)])
+def test_weighted_partition_balances_the_weights(n, nparts):
+    """weights as adaptive refinement leaves them (1, 8 or 64 descendants, the heavy elements in one corner): every part gets its share
+    of the WEIGHT to within one heavy element, no part is empty, and unit weights reproduce the unweighted partition"""
+    g = shuffled_box(n, 5)
+    xc = g.elem_centroids()
+    w = np.where(xc[:, 0] > 0.5, np.where(xc[:, 1] > 0.5, 64.0, 8.0), 1.0)
+    part = g.partition(nparts, w)
+    assert part.min() == 0 and part.max() == nparts - 1
+    sums = np.bincount(part, weights=w, minlength=nparts)
+    assert np.bincount(part, minlength=nparts).min() >= 1
+    # recursive bisection: every cut is within half a heavy element of its target, log2(nparts) cuts deep
+    assert sums.max() - sums.min() <= 64.0 * np.ceil(np.log2(nparts)) + 1e-9, sums
+    cnt = np.bincount(g.partition(nparts), weights=w, minlength=nparts)
+    assert sums.max() <= cnt.max()                       # never worse than ignoring the weights
+    assert np.array_equal(g.partition(nparts, np.ones(g.nel)), g.partition(nparts))
+    with pytest.raises(RuntimeError):
+        g.partition(nparts, np.zeros(g.nel))
+
+
+class _OneRank:
+    """stands for the rendezvous of a one-rank job"""
+
+    def allgather_obj(self, o):
+        return [o]
+
+
+def _flag(x, level):
+    return x[0] > 0.5 and (level < 2 or x[1] > 0.25)
+
+
+def test_amr_weights_count_the_finest_descendants():
+    """the slice-wise count equals the count on the refined global mesh, whatever the number of slices"""
+    from femus_amd import dd
+    g = shuffled_box((4, 3, 2), 9)
+    nlev, n_uniform = 4, 2
+    ms = dd.refine_levels(g, nlev, _flag, n_uniform)
+    anc = np.arange(g.nel)
+    for l in range(nlev - 1):
+        ch = ms[l].child_elems()
+        nxt = np.empty(ms[l + 1].nel, dtype=np.int64)
+        ok = ch >= 0
+        nxt[ch[ok]] = np.broadcast_to(anc[:, None], ch.shape)[ok]
+        anc = nxt
+    ref = np.bincount(anc, minlength=g.nel)
+    assert ref.min() == 8 and ref.max() == 512 and ref.sum() == ms[-1].nel      # level 1 uniform, then up to two selective refinements
+    for world in (1, 3, 5):
+        got = [dd.amr_slice_weights(g, (g.nel * r) // world, (g.nel * (r + 1)) // world, nlev, _flag, n_uniform) for r in range(world)]
+        assert np.array_equal(np.concatenate(got), ref)
+    assert np.array_equal(dd.amr_element_weights(g, _OneRank(), 1, 0, nlev, _flag, n_uniform), ref.astype(float))
+
+
+@pytest.mark.parametrize("nparts", [2, 3])
+def test_topological_keys_on_adaptive_levels(nparts):
+    """selectively refined levels of the ranks' sub-meshes: a node has the same key on every rank that sees it, the keys of a level are
+    distinct points, and the union of the owned nodes of all ranks is the node set of the serially refined mesh"""
+    from femus_amd import dd
+    g = shuffled_box((4, 3, 2), 13)
+    nlev, n_uniform = 4, 2
+    ser = dd.refine_levels(g, nlev, _flag, n_uniform)
+    one = _OneRank()
+    w = dd.amr_element_weights(g, one, 1, 0, nlev, _flag, n_uniform)
+    part = g.partition(nparts, w)
+    for l in (2, 3):
+        key_of = {}
+        owned = 0
+        for r in range(nparts):
+            own, ring = g.rank_elements(part, r)
+            els = np.concatenate([own, ring]).astype(np.int32)
+            sub, _ = g.submesh(els)
+            levels = dd.refine_levels(sub, nlev, _flag, n_uniform)
+            gid, owner = g.topo_node_keys(part, levels, els, l)
+            xy = levels[l].arrays()[1]
+            assert np.unique(gid).size == gid.size
+            for k, o, x in zip(gid, owner, np.rint(xy * 4096).astype(np.int64)):
+                pt = tuple(x)
+                if pt in key_of:
+                    assert key_of[pt] == (k, o)
+                else:
+                    key_of[pt] = (k, o)
+            owned += int(np.sum(owner == r))
+        assert len(set(v[0] for v in key_of.values())) == len(key_of)
+        # every node of the serial level is owned exactly once (ring nodes of other owners may go beyond what a rank needs)
+        pts = set(tuple(x) for x in np.rint(ser[l].arrays()[1] * 4096).astype(np.int64))
+        assert pts <= set(key_of) and owned == len(pts)
