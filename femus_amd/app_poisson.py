@@ -161,13 +161,12 @@ class Poisson001:
         sol0[data[top][0]] = data[top][1]
         pb.SOL.upload(sol0)
         pb.assemble()
-        # non-homogeneous Neumann faces (main.cpp:497-553): constant flux per face, the only kind the shipped inputs use
+        # non-homogeneous Neumann faces: the parsed function of the face evaluated at every face Gauss point (box input, main.cpp:495-553);
+        # the constant flux of SetBoundaryCondition (mesh-file input, main.cpp:556-594)
         flux = dict(self.file_flux) if self.box is None else {}
         for flag, kind in self.bc_type.items():
             if kind == "neumann" and self.bc_func[flag] is not None:
-                v = self.bc_func[flag](np.zeros(4))
-                if v != 0.0:
-                    flux[flag] = v
+                flux[flag] = self.bc_func[flag]
         if flux:
             capi.assemble_neumann(ctx, meshes[top], self.fe, pb.RES, flux)
         pb.prepare()

@@ -668,21 +668,37 @@ def fe_face_nodes(geom, fe, face):
 
 
 def assemble_neumann(ctx, mesh, fe, res, flux_by_flag, order="seventh"):
-    """boundary term of 001_Poisson: faces whose boundary flag is a key of flux_by_flag carry the Neumann flux tau"""
+    """boundary term of 001_Poisson: faces whose boundary flag is a key of flux_by_flag carry the Neumann flux tau -- a number (the
+    mesh-file branch, main.cpp:556-594) or an Expr evaluated at every face Gauss point (the parsed-function branch, main.cpp:495-553)"""
     ed, xy, ff = mesh.arrays()
-    faces, taus = [], []
-    for f in range(mesh.nfaces):
-        loc = fe_face_nodes(mesh.geom, fe, f)
-        for flag, tau in flux_by_flag.items():
-            els = np.where(ff[:, f] == flag)[0]
-            if els.size:
-                faces.append(ed[els][:, loc])
-                taus.append(np.full(els.size, float(tau)))
-    if not faces:
-        return
-    fn, tv = _i32(np.concatenate(faces)), _f64(np.concatenate(taus))
     xy = _f64(xy)
-    _chk(ctx.L.fh_assemble_neumann_faces(ctx.h, GEOM[mesh.geom], FE[fe], GAUSS_ORDER[order], fn.shape[0], _p(fn), _p(tv), xy.shape[0], _p(xy), res.h))
+    for parsed in (False, True):
+        faces, taus, exprs = [], [], []
+        for f in range(mesh.nfaces):
+            loc = fe_face_nodes(mesh.geom, fe, f)
+            for flag, tau in flux_by_flag.items():
+                if isinstance(tau, Expr) != parsed:
+                    continue
+                els = np.where(ff[:, f] == flag)[0]
+                if els.size:
+                    faces.append(ed[els][:, loc])
+                    if parsed:
+                        if tau not in exprs:
+                            exprs.append(tau)
+                        taus.append(np.full(els.size, exprs.index(tau)))
+                    else:
+                        taus.append(np.full(els.size, float(tau)))
+        if not faces:
+            continue
+        fn = _i32(np.concatenate(faces))
+        if parsed:
+            fx = _i32(np.concatenate(taus))
+            hs = (ctypes.c_void_p * len(exprs))(*[e.h for e in exprs])
+            _chk(ctx.L.fh_assemble_neumann_faces_expr(ctx.h, GEOM[mesh.geom], FE[fe], GAUSS_ORDER[order], fn.shape[0], _p(fn), _p(fx), len(exprs), hs,
+                                                      xy.shape[0], _p(xy), res.h))
+        else:
+            tv = _f64(np.concatenate(taus))
+            _chk(ctx.L.fh_assemble_neumann_faces(ctx.h, GEOM[mesh.geom], FE[fe], GAUSS_ORDER[order], fn.shape[0], _p(fn), _p(tv), xy.shape[0], _p(xy), res.h))
 
 
 def build_prolongator(ctx, coarse, fine, fe, zero_bdc=True):

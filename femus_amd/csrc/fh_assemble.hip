@@ -2654,7 +2654,9 @@ template <int DIM>
 __global__ __launch_bounds__(128) void k_neumann(const int* __restrict__ node_ptr, const int* __restrict__ node_id, const int* __restrict__ pairs,
                                                  int nbn, const int* __restrict__ face_nodes, int nfn, const double* __restrict__ tau,
                                                  const double* __restrict__ coords, const double* __restrict__ w, const double* __restrict__ phi,
-                                                 const double* __restrict__ dphi, int ng, double* __restrict__ res) {
+                                                 const double* __restrict__ dphi, int ng, double* __restrict__ res,
+                                                 const int* __restrict__ face_expr, const int* __restrict__ prog, const int* __restrict__ prog_ptr,
+                                                 const double* __restrict__ pconst, const int* __restrict__ const_ptr) {
   const int t = blockIdx.x * 128 + threadIdx.x;
   if (t >= nbn) return;
   double total = 0.0;
@@ -2694,16 +2696,29 @@ __global__ __launch_bounds__(128) void k_neumann(const int* __restrict__ node_pt
         const double det = j0 * (-n1) - (-n0) * j1;
         weight = det * w[g];
       }
-      acc += phi[(size_t)g * nfn + i] * tau[f] * weight;
+      double tv;
+      if (face_expr) {       // the flux is a parsed function of the Gauss point: (*bdcfunc)(&xyzt[0]), 001_Poisson/main.cpp:524-534
+        double xg[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int n = 0; n < nfn; n++) {
+          const double ph = phi[(size_t)g * nfn + n];
+          const double* x = coords + (size_t)fn[n] * DIM;
+          for (int d = 0; d < DIM; d++) xg[d] += x[d] * ph;
+        }
+        const int ex = face_expr[f];
+        tv = fh_expr_device_eval(prog + prog_ptr[ex], prog_ptr[ex + 1] - prog_ptr[ex], pconst + const_ptr[ex], xg);
+      } else {
+        tv = tau[f];
+      }
+      acc += phi[(size_t)g * nfn + i] * tv * weight;
     }
     total += acc;
   }
   res[node_id[t]] += total;
 }
 
-extern "C" int fh_assemble_neumann_faces(fh_ctx_t ctx, int geom, int fe, int order, int nfaces, const int* face_nodes, const double* tau, int nnode,
-                                         const double* coords, fh_vec_t res) {
-  FH_REQUIRE(ctx && res && (nfaces == 0 || (face_nodes && tau && coords)), "fh_assemble_neumann_faces: null argument");
+static int neumann_faces(fh_ctx_t ctx, int geom, int fe, int order, int nfaces, const int* face_nodes, const double* tau, const int* face_expr, int nexpr,
+                         const fh_expr_t* exprs, int nnode, const double* coords, fh_vec_t res) {
+  FH_REQUIRE(ctx && res && (nfaces == 0 || (face_nodes && (tau || face_expr) && coords)), "fh_assemble_neumann_faces: null argument");
   FH_REQUIRE(geom == 0 || geom == 1, "fh_assemble_neumann_faces: geom must be 0 (hex) or 1 (quad)");
   FH_REQUIRE(fe == 0 || fe == 2, "fh_assemble_neumann_faces: fe must be 0 or 2");
   if (nfaces == 0) return 0;
@@ -2754,7 +2769,28 @@ extern "C" int fh_assemble_neumann_faces(fh_ctx_t ctx, int geom, int fe, int ord
     }
   const int nbn = (int)node_id.size();
   FH_REQUIRE(res->n_local + res->nghost > node_id.back(), "fh_assemble_neumann_faces: vector too short");
-  void* dv[8] = {nullptr};
+  // parsed fluxes: the programs of all expressions back to back
+  std::vector<int> h_prog, h_prog_ptr(1, 0), h_const_ptr(1, 0);
+  std::vector<double> h_const;
+  if (face_expr) {
+    FH_REQUIRE(nexpr >= 1 && exprs, "fh_assemble_neumann_faces_expr: no expressions");
+    for (int f = 0; f < nfaces; f++) FH_REQUIRE(face_expr[f] >= 0 && face_expr[f] < nexpr, "fh_assemble_neumann_faces_expr: face %d names expression %d of %d", f, face_expr[f], nexpr);
+    for (int k = 0; k < nexpr; k++) {
+      FH_REQUIRE(exprs[k], "fh_assemble_neumann_faces_expr: null expression");
+      int nv = 0, nc = 0, nk = 0;
+      FH_TRY(fh_expr_nvars(exprs[k], &nv));
+      FH_REQUIRE(nv <= 4, "fh_assemble_neumann_faces_expr: expression %d has %d variables, at most 4 (x, y, z, t) are served", k, nv);
+      FH_TRY(fh_expr_program(exprs[k], &nc, &nk, nullptr, nullptr));
+      std::vector<int> code(nc);
+      std::vector<double> consts(nk);
+      FH_TRY(fh_expr_program(exprs[k], &nc, &nk, code.data(), consts.data()));
+      h_prog.insert(h_prog.end(), code.begin(), code.end());
+      h_const.insert(h_const.end(), consts.begin(), consts.end());
+      h_prog_ptr.push_back((int)h_prog.size());
+      h_const_ptr.push_back((int)h_const.size());
+    }
+  }
+  void* dv[13] = {nullptr};
   auto up = [&](int slot, const void* h, size_t bytes) -> int {
     FH_CHECK_HIP(hipMalloc(&dv[slot], bytes ? bytes : 8));
     FH_CHECK_HIP(hipMemcpyAsync(dv[slot], h, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -2764,7 +2800,14 @@ extern "C" int fh_assemble_neumann_faces(fh_ctx_t ctx, int geom, int fe, int ord
   FH_TRY(up(1, node_id.data(), node_id.size() * sizeof(int)));
   FH_TRY(up(2, pairs.data(), pairs.size() * sizeof(int)));
   FH_TRY(up(3, face_nodes, (size_t)nfaces * nfn * sizeof(int)));
-  FH_TRY(up(4, tau, (size_t)nfaces * sizeof(double)));
+  if (tau) FH_TRY(up(4, tau, (size_t)nfaces * sizeof(double)));
+  if (face_expr) {
+    FH_TRY(up(8, face_expr, (size_t)nfaces * sizeof(int)));
+    FH_TRY(up(9, h_prog.data(), h_prog.size() * sizeof(int)));
+    FH_TRY(up(10, h_prog_ptr.data(), h_prog_ptr.size() * sizeof(int)));
+    FH_TRY(up(11, h_const.data(), h_const.size() * sizeof(double)));
+    FH_TRY(up(12, h_const_ptr.data(), h_const_ptr.size() * sizeof(int)));
+  }
   FH_TRY(up(5, coords, (size_t)nnode * dim * sizeof(double)));
   FH_TRY(up(6, w.data(), w.size() * sizeof(double)));
   std::vector<double> tab(phi);
@@ -2775,13 +2818,29 @@ extern "C" int fh_assemble_neumann_faces(fh_ctx_t ctx, int geom, int fe, int ord
   const dim3 grid(fh_div_up(nbn, 128)), block(128);
   if (dim == 3)
     hipLaunchKernelGGL(k_neumann<3>, grid, block, 0, ctx->stream, (const int*)dv[0], (const int*)dv[1], (const int*)dv[2], nbn, (const int*)dv[3], nfn,
-                       (const double*)dv[4], (const double*)dv[5], (const double*)dv[6], d_phi, d_dphi, ng, res->d);
+                       (const double*)dv[4], (const double*)dv[5], (const double*)dv[6], d_phi, d_dphi, ng, res->d, (const int*)dv[8], (const int*)dv[9],
+                       (const int*)dv[10], (const double*)dv[11], (const int*)dv[12]);
   else
     hipLaunchKernelGGL(k_neumann<2>, grid, block, 0, ctx->stream, (const int*)dv[0], (const int*)dv[1], (const int*)dv[2], nbn, (const int*)dv[3], nfn,
-                       (const double*)dv[4], (const double*)dv[5], (const double*)dv[6], d_phi, d_dphi, ng, res->d);
+                       (const double*)dv[4], (const double*)dv[5], (const double*)dv[6], d_phi, d_dphi, ng, res->d, (const int*)dv[8], (const int*)dv[9],
+                       (const int*)dv[10], (const double*)dv[11], (const int*)dv[12]);
   FH_CHECK_HIP(hipGetLastError());
   FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   for (void* q : dv)
     if (q) hipFree(q);
   return 0;
+}
+
+extern "C" int fh_assemble_neumann_faces(fh_ctx_t ctx, int geom, int fe, int order, int nfaces, const int* face_nodes, const double* tau, int nnode,
+                                         const double* coords, fh_vec_t res) {
+  FH_REQUIRE(nfaces == 0 || tau, "fh_assemble_neumann_faces: null argument");
+  return neumann_faces(ctx, geom, fe, order, nfaces, face_nodes, tau, nullptr, 0, nullptr, nnode, coords, res);
+}
+
+// the flux as a parsed function of the Gauss point (x, y, z, t = 0), as the parsed-boundary-condition branch of the 001_Poisson callback
+// evaluates it (`(*bdcfunc)(&xyzt[0])` inside the Gauss loop, applications/001_Poisson/main.cpp:495-553): face_expr[f] names one of `nexpr` expressions
+extern "C" int fh_assemble_neumann_faces_expr(fh_ctx_t ctx, int geom, int fe, int order, int nfaces, const int* face_nodes, const int* face_expr, int nexpr,
+                                              const fh_expr_t* exprs, int nnode, const double* coords, fh_vec_t res) {
+  FH_REQUIRE(nfaces == 0 || face_expr, "fh_assemble_neumann_faces_expr: null argument");
+  return neumann_faces(ctx, geom, fe, order, nfaces, face_nodes, nullptr, face_expr, nexpr, exprs, nnode, coords, res);
 }

@@ -306,6 +306,11 @@ int fh_expr_program(fh_expr_t expr, int* ncode, int* nconst, int* code /* or NUL
 int fh_expr_nvars(fh_expr_t expr, int* nvars);      /* number of variables the expression was compiled over */
 int fh_expr_destroy(fh_expr_t expr);
 int fh_assemble_poisson_expr(fh_assembler_t as, fh_vec_t sol, fh_expr_t source, double scale, fh_mat_t A, fh_vec_t res);
+/* Neumann term with the flux as a parsed function of the face Gauss point (x, y, z, t = 0): the parsed-boundary-condition branch of the
+ * 001_Poisson callback, `(*bdcfunc)(&xyzt[0])` inside the Gauss loop (applications/001_Poisson/main.cpp:495-553).  face_expr[f] names
+ * one of the nexpr expressions (one per boundary face name in the application); everything else as fh_assemble_neumann_faces */
+int fh_assemble_neumann_faces_expr(fh_ctx_t ctx, int geom, int fe, int gauss_order, int nfaces, const int* face_nodes, const int* face_expr,
+                                   int nexpr, const fh_expr_t* exprs, int nnode, const double* coords, fh_vec_t res);
 
 /* ---- multi-variable systems and the Navier-Stokes Newton path (a9, a21) --------------------------------------------
  * Variables are stacked per rank: system dof = KKoffset[k] + mesh dof (LinearEquation::GetSystemDof, LinearEquation.cpp:76-85,

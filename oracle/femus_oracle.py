@@ -1159,7 +1159,9 @@ def jacobian_sur(geom, fe, order, vt, ig):
 
 
 def neumann_rhs(mesh, fe, flux_by_flag, order="seventh", face_tables=None):
-    """sum over boundary faces whose flag is in flux_by_flag of  int phi_i tau ds, scattered to the nodes"""
+    """sum over boundary faces whose flag is in flux_by_flag of  int phi_i tau ds, scattered to the nodes; tau: a number
+    (applications/001_Poisson/main.cpp:556-594) or a function of the Gauss point xyzt = (sum_i x_i phi_i, t = 0) evaluated inside the
+    Gauss loop as the parsed-function branch does (`(*bdcfunc)(&xyzt[0])`, main.cpp:521-537)"""
     geom = mesh.geom
     out = np.zeros(n_dofs(mesh, fe))
     ng = gauss_table("quad" if geom == "hex" else "line", order)[0].size
@@ -1171,6 +1173,12 @@ def neumann_rhs(mesh, fe, flux_by_flag, order="seventh", face_tables=None):
                 vt = [mesh.coords[nodes, d] for d in range(mesh.dim)]
                 for ig in range(ng):
                     weight, phi, _ = jacobian_sur(geom, fe, order, vt, ig)
+                    tv = tau
+                    if callable(tau):
+                        xyzt = np.zeros(4)
+                        for d in range(mesh.dim):
+                            xyzt[d] = float(np.dot(vt[d], phi))
+                        tv = tau(xyzt)
                     for i in range(nodes.size):
-                        out[nodes[i]] += phi[i] * tau * weight
+                        out[nodes[i]] += phi[i] * tv * weight
     return out

@@ -137,3 +137,41 @@ def test_mesh_file_input_matches_oracle(ctx, tmp_path):
     assert np.allclose(out["coords"], m.coords, atol=1e-10)
     assert abs(out["solution"] - ref).max() < 1e-9
     p.destroy()
+
+
+@pytest.mark.gpu
+def test_run_with_a_parsed_neumann_function(ctx, tmp_path):
+    """a Neumann face whose bdc_func is a function of the position: evaluated at every face Gauss point as the callback does
+    (`(*bdcfunc)(&xyzt[0])`, main.cpp:521-537), not once per face"""
+    cfg = CONFIG.replace('"bdc_func" : "0.2" }', '"bdc_func" : "0.2 + 0.5*y*y - 0.1*x" }').replace('"bdc_func" : "0." }', '"bdc_func" : "sin(3.*x)" }')
+    assert cfg != CONFIG
+    p = app.Poisson001(ctx, cfg)
+    out = p.run(log=None, output_dir=tmp_path)
+    assert out["converged"]
+    m = fo.build_levels(4, 4, 0, 3)[-1]
+    x, y = m.coords[:, 0], m.coords[:, 1]
+    sol0 = np.zeros(m.nnode)
+    fn = fo.face_nodes("quad")
+    val = {}
+    for iel in range(m.nel):
+        for f in range(4):
+            if m.face_flag[iel, f] == -5:
+                for n in m.elem_dof[iel, fn[f]]:
+                    val[n] = 0.5 + 1. / np.pi * np.arctan(10. * (y[n] - 0.8))
+            elif m.face_flag[iel, f] == -4:
+                for n in m.elem_dof[iel, fn[f]]:
+                    val[n] = 1.0
+    bdc = np.array(sorted(val))
+    sol0[bdc] = [val[n] for n in bdc]
+    src = lambda xg: -(10. * np.exp(-5. * xg[..., 0]) - 4. * np.exp(-xg[..., 0]) * xg[..., 1])
+    A, b = fo.assemble_poisson(m, "biquadratic", src, sol=sol0)
+    b = b + fo.neumann_rhs(m, "biquadratic", {-3: lambda q: 0.2 + 0.5 * q[1] * q[1] - 0.1 * q[0], -2: lambda q: np.sin(3. * q[0])})
+    A = fo.zero_rows(A, bdc, 1.0)
+    b[bdc] = 0.0
+    ref = sol0 + spla.spsolve(A.tocsc(), b)
+    assert abs(out["solution"] - ref).max() < 1e-9
+    # and it differs from the flux frozen at the origin (what a constant per face would give)
+    b0 = fo.assemble_poisson(m, "biquadratic", src, sol=sol0)[1] + fo.neumann_rhs(m, "biquadratic", {-3: 0.2})
+    b0[bdc] = 0.0
+    assert abs(sol0 + spla.spsolve(A.tocsc(), b0) - ref).max() > 1e-3
+    p.destroy()
