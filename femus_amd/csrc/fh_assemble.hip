@@ -2253,6 +2253,37 @@ static int assemble_poisson_core(fh_assembler_t as, fh_vec_t sol, int source_kin
       P.elems = as->d_gen_elems;
       P.nelems = as->n_gen;
     }
+    if (as->ctx->asm_debug & 16) {
+      // TIMING PROBE ONLY (bit 4): the row pass on a second stream BESIDE the element kernel (it reads the element rows of the previous
+      // assembly): do the two kernels share the device?
+      static hipStream_t s2 = nullptr;
+      static hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (!s2) {
+        FH_CHECK_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        FH_CHECK_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+        FH_CHECK_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+      }
+      hipStream_t s1 = as->ctx->stream;
+      FH_CHECK_HIP(hipEventRecord(e0, s1));
+      FH_CHECK_HIP(hipStreamWaitEvent(s2, e0, 0));
+      if (as->ctx->asm_debug & 32) {        // bit 5: row pass issued first
+        as->ctx->stream = s2;
+        const int rc = dispatch_rows(as, A, res->d, false);
+        as->ctx->stream = s1;
+        FH_TRY(rc);
+        FH_TRY(dispatch_assemble(as, P));
+      } else {
+        FH_TRY(dispatch_assemble(as, P));
+        as->ctx->stream = s2;
+        const int rc = dispatch_rows(as, A, res->d, false);
+        as->ctx->stream = s1;
+        FH_TRY(rc);
+      }
+      FH_CHECK_HIP(hipEventRecord(e1, s2));
+      FH_CHECK_HIP(hipStreamWaitEvent(s1, e1, 0));
+      A->at_valid = false;
+      return 0;
+    }
     FH_TRY(dispatch_assemble(as, P));
     if (!(as->ctx->asm_debug & (2 | 8))) FH_TRY(dispatch_rows(as, A, res->d, false));   // bit 3: element matrices only (timing)
     A->at_valid = false;
