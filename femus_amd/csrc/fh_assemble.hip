@@ -1596,7 +1596,7 @@ static int launch_sf_one(fh_assembler_t as, const AsmParams& P) {
     attr_set[dev] = true;
   }
   const int per_cu = std::max(1, (int)((size_t)160 * 1024 / lds));
-  const int grid = std::max(1, std::min(fh_div_up(P.nelems, NW), as->ctx->num_cu * per_cu));
+  const int grid = std::max(1, std::min(fh_div_up(P.nelems, NW), as->ctx->num_cu * per_cu * as->ctx->assemble_sf_grid));
   hipLaunchKernelGGL((k_elem_q2hex_sf<SRC, NW, PAD>), dim3(grid), dim3(NW * 64), lds, as->ctx->stream, P, as->sf_tab, as->d_sfLc, as->d_sfLi);
   FH_CHECK_HIP(hipGetLastError());
   return 0;
