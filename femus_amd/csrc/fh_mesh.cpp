@@ -1271,8 +1271,44 @@ static void bfs_order(const std::vector<int>& ptr, const std::vector<int>& adj, 
   }
 }
 
+// where the prefix of an ordering is cut: np1 / np of the elements, or -- with weights (the work below an element after adaptive
+// refinement) -- the prefix whose weight is closest to np1 / np of the total; every side keeps at least as many elements as it has parts
+static size_t split_point(const std::vector<int>& order, int np, int np1, const double* w) {
+  size_t n1 = (order.size() * (size_t)np1 + np / 2) / np;
+  if (w) {
+    double total = 0.0;
+    for (int e : order) total += w[e];
+    const double want = total * (double)np1 / (double)np;
+    double acc = 0.0;
+    n1 = 0;
+    while (n1 < order.size() && acc + 0.5 * w[order[n1]] <= want) acc += w[order[n1++]];
+    const size_t lo = std::min(order.size(), (size_t)np1), hi = order.size() > (size_t)(np - np1) ? order.size() - (size_t)(np - np1) : 0;
+    n1 = std::max(lo, std::min(n1, std::max(lo, hi)));
+  }
+  return n1;
+}
+
+// faces of the dual graph cut by taking the first n1 elements of an ordering of `set`
+static long cut_of(const std::vector<int>& ptr, const std::vector<int>& adj, const std::vector<int>& order, size_t n1, const std::vector<char>& in,
+                   std::vector<char>& side) {
+  for (size_t k = 0; k < order.size(); k++) side[order[k]] = k < n1 ? 1 : 2;
+  long cut = 0;
+  for (size_t k = 0; k < n1; k++) {
+    const int e = order[k];
+    for (int q = ptr[e]; q < ptr[e + 1]; q++)
+      if (in[adj[q]] && side[adj[q]] == 2) cut++;
+  }
+  return cut;
+}
+
+// Two orderings compete at every bisection and the one that cuts fewer faces wins (ties: the first):
+//   (a) breadth-first growing from a pseudo-peripheral element -- needs nothing but the dual graph, follows bent and branched domains;
+//   (b) the elements sorted along the principal axis of their (weighted) centroids (inertial bisection) -- a plane across the short way
+//       of a compact block, where the level sets of (a) run diagonally and cut about twice as many faces.
+struct PartGeom { const double* xc; int dim; };       // element centroids [nel * dim], or null
+
 static void bisect(const std::vector<int>& ptr, const std::vector<int>& adj, std::vector<int>& set, int p0, int np, std::vector<int>& part,
-                   const double* w = nullptr) {
+                   const double* w = nullptr, const PartGeom* geo = nullptr) {
   if (np == 1 || set.empty()) {
     for (int e : set) part[e] = p0;
     return;
@@ -1286,24 +1322,78 @@ static void bisect(const std::vector<int>& ptr, const std::vector<int>& adj, std
   const int far2 = order.back();
   bfs_order(ptr, adj, set, in, far2, order);
   const int np1 = np / 2;
-  size_t n1 = (set.size() * (size_t)np1 + np / 2) / np;
-  if (w) {
-    // element weights (the work below an element after adaptive refinement): the first half takes the prefix of the breadth-first
-    // order whose weight is closest to np1 / np of the total; every side keeps at least as many elements as it has parts to fill
-    double total = 0.0;
-    for (int e : order) total += w[e];
-    const double want = total * (double)np1 / (double)np;
-    double acc = 0.0;
-    n1 = 0;
-    while (n1 < order.size() && acc + 0.5 * w[order[n1]] <= want) acc += w[order[n1++]];
-    const size_t lo = std::min(order.size(), (size_t)np1), hi = order.size() > (size_t)(np - np1) ? order.size() - (size_t)(np - np1) : 0;
-    n1 = std::max(lo, std::min(n1, std::max(lo, hi)));
+  size_t n1 = split_point(order, np, np1, w);
+  if (geo && geo->xc && set.size() > 2) {
+    const int dim = geo->dim;
+    double mean[3] = {0, 0, 0}, wsum = 0.0;
+    for (int e : set) {
+      const double we = w ? w[e] : 1.0;
+      for (int d = 0; d < dim; d++) mean[d] += we * geo->xc[(size_t)e * dim + d];
+      wsum += we;
+    }
+    for (int d = 0; d < dim; d++) mean[d] /= wsum;
+    double C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int e : set) {
+      const double we = w ? w[e] : 1.0;
+      double x[3] = {0, 0, 0};
+      for (int d = 0; d < dim; d++) x[d] = geo->xc[(size_t)e * dim + d] - mean[d];
+      for (int i = 0; i < dim; i++)
+        for (int j = 0; j < dim; j++) C[i][j] += we * x[i] * x[j];
+    }
+    // principal axis by power iteration from the diagonal's largest direction (deterministic); a cube has no preferred axis: any is a plane cut
+    double v[3] = {0, 0, 0};
+    int dmax = 0;
+    for (int d = 1; d < dim; d++)
+      if (C[d][d] > C[dmax][dmax] * (1.0 + 1e-9)) dmax = d;
+    v[dmax] = 1.0;
+    for (int it = 0; it < 60; it++) {
+      double u[3] = {0, 0, 0}, nrm = 0.0;
+      for (int i = 0; i < dim; i++)
+        for (int j = 0; j < dim; j++) u[i] += C[i][j] * v[j];
+      for (int i = 0; i < dim; i++) nrm += u[i] * u[i];
+      nrm = sqrt(nrm);
+      if (!(nrm > 0.0)) break;
+      for (int i = 0; i < dim; i++) v[i] = u[i] / nrm;
+    }
+    std::vector<std::pair<double, int> > key(set.size());
+    for (size_t k = 0; k < set.size(); k++) {
+      const int e = set[k];
+      double t = 0.0;
+      for (int d = 0; d < dim; d++) t += v[d] * (geo->xc[(size_t)e * dim + d] - mean[d]);
+      key[k] = std::make_pair(t, e);
+    }
+    // elements of one layer across the axis have equal projections up to rounding: quantised, so that the order inside a layer is the
+    // element order and the cut is the same on every machine
+    double span = 0.0;
+    for (auto& kv : key) span = std::max(span, fabs(kv.first));
+    const double q = span > 0.0 ? span * 1e-9 : 1.0;
+    for (auto& kv : key) kv.first = std::floor(kv.first / q + 0.5);
+    std::sort(key.begin(), key.end());
+    std::vector<int> order2(set.size());
+    for (size_t k = 0; k < key.size(); k++) order2[k] = key[k].second;
+    const size_t n2 = split_point(order2, np, np1, w);
+    std::vector<char> side(part.size(), 0);
+    const long cut1 = cut_of(ptr, adj, order, n1, in, side), cut2 = cut_of(ptr, adj, order2, n2, in, side);
+    if (cut2 < cut1) {
+      order.swap(order2);
+      n1 = n2;
+    }
   }
   std::vector<int> a(order.begin(), order.begin() + n1), b(order.begin() + n1, order.end());
   std::sort(a.begin(), a.end());
   std::sort(b.begin(), b.end());
-  bisect(ptr, adj, a, p0, np1, part, w);
-  bisect(ptr, adj, b, p0 + np1, np - np1, part, w);
+  bisect(ptr, adj, a, p0, np1, part, w, geo);
+  bisect(ptr, adj, b, p0 + np1, np - np1, part, w, geo);
+}
+
+static void elem_centroids_of(const fh_mesh_s* G, std::vector<double>& xc) {
+  const int nv = nvert_of(G->geom), dim = G->dim;
+  xc.assign((size_t)G->nel * dim, 0.0);
+  for (int e = 0; e < G->nel; e++)
+    for (int i = 0; i < nv; i++) {
+      const int nd = G->elem_dof[(size_t)e * G->nloc + i];
+      for (int d = 0; d < dim; d++) xc[(size_t)e * dim + d] += G->coords[(size_t)nd * dim + d] / nv;
+    }
 }
 
 extern "C" int fh_mesh_partition(fh_mesh_t G, int nparts, int* part) {
@@ -1312,7 +1402,10 @@ extern "C" int fh_mesh_partition(fh_mesh_t G, int nparts, int* part) {
   std::vector<int> ptr, adj, set(G->nel), p(G->nel, 0);
   dual_graph(G, ptr, adj);
   for (int e = 0; e < G->nel; e++) set[e] = e;
-  bisect(ptr, adj, set, 0, nparts, p);
+  std::vector<double> xc;
+  elem_centroids_of(G, xc);
+  const PartGeom geo{xc.data(), G->dim};
+  bisect(ptr, adj, set, 0, nparts, p, nullptr, &geo);
   fh_copy_out(part, p);
   return 0;
   FH_GUARD_END("fh_mesh_partition")
@@ -1328,7 +1421,10 @@ extern "C" int fh_mesh_partition_weighted(fh_mesh_t G, int nparts, const double*
   std::vector<int> ptr, adj, set(G->nel), p(G->nel, 0);
   dual_graph(G, ptr, adj);
   for (int e = 0; e < G->nel; e++) set[e] = e;
-  bisect(ptr, adj, set, 0, nparts, p, weight);
+  std::vector<double> xc;
+  elem_centroids_of(G, xc);
+  const PartGeom geo{xc.data(), G->dim};
+  bisect(ptr, adj, set, 0, nparts, p, weight, &geo);
   fh_copy_out(part, p);
   return 0;
   FH_GUARD_END("fh_mesh_partition_weighted")
