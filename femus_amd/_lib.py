@@ -169,6 +169,8 @@ def _declare(L):
     sig("fh_vec_gather", c_void_p, c_void_p, c_void_p)
     sig("fh_mg_create", c_void_p, c_int, P(c_void_p))
     sig("fh_mg_set_level", c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_int)
+    sig("fh_mg_set_coarse_coords", c_void_p, c_int, c_int, c_void_p)
+    sig("fh_mg_coarse_info", c_void_p, P(c_int), P(c_int), P(c_int), P(c_int))
     sig("fh_mg_setup", c_void_p)
     sig("fh_mg_vcycle", c_void_p, c_void_p, c_void_p)
     sig("fh_mg_solve", c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_double, c_int, c_int, P(c_int), P(c_double))

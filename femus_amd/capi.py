@@ -919,6 +919,17 @@ class Multigrid:
     def set_level_distributed(self, level, halo, replicated_below=False):
         _chk(self.L.fh_mg_set_level_distributed(self.h, int(level), None if halo is None else halo.h, 1 if replicated_below else 0))
 
+    def coarse_info(self):
+        """(unknowns in the dense coarse problem, interior blocks of its dissection -- 0: one dense inverse --, separator size, largest block)"""
+        v = [ctypes.c_int() for _ in range(4)]
+        _chk(self.L.fh_mg_coarse_info(self.h, *[ctypes.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def set_coarse_coords(self, coords):
+        """coordinates of the unknowns of level 0: the exact coarse solve then dissects its dense problem (fh_mg_set_coarse_coords)"""
+        xy = _f64(coords)
+        _chk(self.L.fh_mg_set_coarse_coords(self.h, xy.shape[1], xy.shape[0], _p(xy)))
+
     def setup(self):
         _chk(self.L.fh_mg_setup(self.h))
 

@@ -141,6 +141,9 @@ class PoissonMG:
         self.level_operators()
         if self.mg is None:
             self.mg = capi.Multigrid(ctx, self.nlevels)
+            # where the unknowns of the coarsest level lie: the exact coarse solve dissects its dense problem with it (coarse_nd)
+            xy0 = self.meshes[0].arrays()[1]
+            self.mg.set_coarse_coords(xy0[:self.ndof[0]])
         for l in range(self.nlevels):
             self.mg.set_level(l, self.A[l], self.P[l], None, self.smoother, self.omega, self.npre if l > 0 else 1,
                               self.npost if l > 0 else 0)

@@ -373,6 +373,13 @@ int fh_mg_set_level_patches(fh_mg_t mg, int level, int npatch, const int* ptr /*
 enum { FH_LEVEL_RICHARDSON = 0, FH_LEVEL_GMRES = 1 };
 int fh_mg_set_level_solver(fh_mg_t mg, int level, int solver, int restart);
 int fh_mg_setup(fh_mg_t mg);
+/* coordinates of the unknowns of level 0 ([n * dim], dim 1..3; the dofs of the coarsest mesh, Mesh::GetTopology()->_Sol[0..2]): the exact coarse
+ * solve (the reference's PCLU / MUMPS on the coarsest level, LinearEquationSolverPetsc.cpp:237-287) then dissects its dense problem -- block
+ * inverses beside each other + a separator Schur complement (option "coarse_nd", symmetric operators) instead of one dense inverse.  Optional. */
+int fh_mg_set_coarse_coords(fh_mg_t mg, int dim, int n, const double* coords);
+/* what the last fh_mg_setup made of the coarsest level: unknowns in the dense problem (the others are solved by their diagonal), interior
+ * blocks of the dissection (0 = one dense inverse), separator size, largest block; any pointer may be NULL */
+int fh_mg_coarse_info(fh_mg_t mg, int* n_dense, int* nd_blocks, int* nd_separator, int* nd_largest_block);
 int fh_mg_vcycle(fh_mg_t mg, fh_vec_t b, fh_vec_t x);
 int fh_mg_solve(fh_mg_t mg, fh_vec_t b, fh_vec_t x, int outer, double rtol, double atol, double dtol, int maxit, int restart,
                 int* iterations, double* final_residual);

@@ -6,6 +6,7 @@ import scipy.sparse.linalg as spla
 
 import femus_amd
 from femus_amd import capi
+from femus_amd.poisson import PoissonMG
 from oracle import femus_oracle as fo
 
 pytestmark = pytest.mark.gpu
@@ -621,3 +622,115 @@ def test_coarse_solve_leaves_decoupled_unknowns_out_of_the_dense_inverse(ctx, n,
     ctx.set_option("coarse_reduce", 1)
     for got, ref in sols:
         assert rel(got, ref) < 1e-11
+
+
+# ---- nested dissection of the dense coarse problem (fh_mg_set_coarse_coords + option coarse_nd) ------------------------------------------------
+def _poisson_level_operator(ctx, n, fe="biquadratic"):
+    """the Galerkin operator of the coarse level of a two-level 3-D (or 2-D) box hierarchy -- a real coarsest-level matrix: symmetric, Q2 coupling
+    through the elements, Dirichlet unknowns coupled to nothing -- and the coordinates of its unknowns"""
+    pb = PoissonMG(ctx, n[0], n[1], n[2], 2, fe=fe).init()
+    pb.assemble()
+    pb.level_operators()
+    A = pb.A[0].to_scipy().tocsr()
+    xy = pb.meshes[0].arrays()[1][:pb.ndof[0]].copy()
+    pb.destroy()
+    return A, xy
+
+
+@pytest.mark.parametrize("n,fe,nd", [((4, 4, 4), "biquadratic", 2), ((4, 4, 4), "biquadratic", 4), ((6, 4, 3), "biquadratic", 8), ((5, 5, 0), "biquadratic", 4),
+                                     ((9, 8, 7), "linear", 4)])
+def test_dissected_coarse_solve_is_the_exact_solve(ctx, n, fe, nd):
+    """the block form (interior blocks inverted beside each other, separator Schur complement, three launches per solve) gives A^-1 b like the
+    one dense inverse and like a direct solve on the host; the Dirichlet unknowns stay out of it; two preparations agree bit for bit"""
+    import scipy.sparse.linalg as spla
+    A, xy = _poisson_level_operator(ctx, n, fe)
+    rng = np.random.default_rng(7)
+    rhs = rng.uniform(-1, 1, A.shape[0])
+    ref = spla.spsolve(A.tocsc(), rhs)
+    got = {}
+    for mode in (nd, 0):
+        ctx.set_option("coarse_nd", mode)
+        ctx.set_option("coarse_nd_min", 16)
+        mg = capi.Multigrid(ctx, 1)
+        Ad = ctx.matrix_scipy(A)
+        mg.set_level(0, Ad, None, None, 0, 1.0, 1, 0)
+        mg.set_coarse_coords(xy)
+        mg.setup()
+        nden, nblk, nsep, big = mg.coarse_info()
+        if mode:
+            assert nblk >= 2 and 0 < nsep < nden and big < nden, (nden, nblk, nsep, big)
+        else:
+            assert nblk == 0
+        b, x = ctx.vector_from(rhs), ctx.vector(A.shape[0])
+        mg.vcycle(b, x)
+        first = x.to_numpy().copy()
+        mg.setup()                                      # a second preparation of the same operator
+        mg.vcycle(b, x)
+        assert np.array_equal(first, x.to_numpy())
+        got[mode] = first
+        mg.destroy()
+        Ad.destroy()
+    ctx.set_option("coarse_nd", 4)
+    ctx.set_option("coarse_nd_min", 1024)
+    assert rel(got[nd], ref) < 1e-11 and rel(got[0], ref) < 1e-11
+
+
+def test_dissection_cuts_a_q2_block_at_element_planes(ctx):
+    """the separator of the 8^3-element coarse level of the bench hierarchy (3375 coupled unknowns): four blocks of 15 x 7 x 7 unknowns and
+    the three element-boundary planes between them (225 + 2 x 105): layers of Q2 nodes at element boundaries separate, mid-planes do not"""
+    A, xy = _poisson_level_operator(ctx, (8, 8, 8))
+    mg = capi.Multigrid(ctx, 1)
+    Ad = ctx.matrix_scipy(A)
+    mg.set_level(0, Ad, None, None, 0, 1.0, 1, 0)
+    mg.set_coarse_coords(xy)
+    mg.setup()
+    assert mg.coarse_info() == (3375, 4, 435, 735)
+    mg.destroy()
+    Ad.destroy()
+
+
+def test_dissected_coarse_solve_falls_back(ctx):
+    """symmetric but indefinite (no usable unpivoted pivot in a block) and unsymmetric operators with coordinates set: the one dense inverse
+    with its pivoted fall-back serves them, the solution is still exact"""
+    rng = np.random.default_rng(3)
+    n = 160
+    xy = rng.uniform(0, 1, (n, 3))
+    M = np.zeros((n, n))
+    for k in range(0, n, 2):
+        M[k, k + 1] = M[k + 1, k] = 1.0 + 0.1 * rng.uniform()
+    C = 0.05 * rng.uniform(-1, 1, (n, n))
+    for name, Mk in (("indefinite", M + C + C.T), ("unsymmetric", M + C + 2.0 * np.eye(n))):
+        ctx.set_option("coarse_nd_min", 16)
+        mg, A = _one_level(ctx, Mk)
+        mg.set_coarse_coords(xy)
+        mg.setup()
+        assert mg.coarse_info()[1] == 0, name
+        rhs = rng.uniform(-1, 1, n)
+        b, x = ctx.vector_from(rhs), ctx.vector(n)
+        mg.vcycle(b, x)
+        assert rel(x.to_numpy(), np.linalg.solve(Mk, rhs)) < 1e-10, name
+        mg.destroy()
+    ctx.set_option("coarse_nd_min", 1024)
+
+
+def test_hierarchy_solve_with_and_without_the_dissection(ctx):
+    """a whole 3-level solve whose coarsest level (6^3 elements, 1331 coupled unknowns) is dissected: same iteration count and the same solution
+    (1e-11) as with the one dense inverse; re-preparation keeps the block form"""
+    sols = []
+    for mode in (4, 0):
+        ctx.set_option("coarse_nd", mode)
+        pb = PoissonMG(ctx, 6, 6, 6, 3).init()
+        pb.assemble()
+        pb.prepare()
+        assert (pb.mg.coarse_info()[1] >= 2) == (mode > 0)
+        its, rn = pb.mgsolve(outer="gmres", rtol=1e-12)
+        x = pb.EPSC.to_numpy().copy()
+        pb.assemble()
+        pb.prepare()
+        assert (pb.mg.coarse_info()[1] >= 2) == (mode > 0)
+        its2, _ = pb.mgsolve(outer="gmres", rtol=1e-12)
+        assert its2 == its and np.array_equal(x, pb.EPSC.to_numpy())
+        sols.append((its, x))
+        pb.destroy()
+    ctx.set_option("coarse_nd", 4)
+    assert sols[0][0] == sols[1][0] and rel(sols[0][1], sols[1][1]) < 1e-11
