@@ -217,6 +217,7 @@ extern "C" int fh_set_option(fh_ctx_t c, const char* name, double value) {
   else if (!strcmp(name, "coarse_reduce")) c->coarse_reduce = (int)value;
   else if (!strcmp(name, "coarse_nd")) c->coarse_nd = (int)value;
   else if (!strcmp(name, "coarse_nd_min")) c->coarse_nd_min = (int)value;
+  else if (!strcmp(name, "coarse_nd_streams")) c->coarse_nd_streams = (int)value;
   else if (!strcmp(name, "patch_invert_lds")) c->patch_invert_lds = (int)value;
   else if (!strcmp(name, "gj_mfma")) c->gj_mfma = (int)value;
   else if (!strcmp(name, "gj_symmetric")) c->gj_symmetric = (int)value;

@@ -2066,17 +2066,16 @@ static int nd_factor(fh_mg_t mg, int n, int nfull) {
   FH_CHECK_HIP(hipEventRecord(mg->nd_events[k], c->stream));
   for (int i = 0; i < k; i++) {
     const int nb = mg->nd_off[i + 1] - mg->nd_off[i];
-    FH_CHECK_HIP(hipStreamWaitEvent(mg->nd_streams[i], mg->nd_events[k], 0));
-    FH_TRY(invert_sym128(c, mg->nd_streams[i], mg->nd_dinv[i], nb, base + woff[i], flags + 2 * i));
-    FH_CHECK_HIP(hipEventRecord(mg->nd_events[i], mg->nd_streams[i]));
+    hipStream_t sti = c->coarse_nd_streams ? mg->nd_streams[i] : c->stream;
+    FH_CHECK_HIP(hipStreamWaitEvent(sti, mg->nd_events[k], 0));
+    FH_TRY(invert_sym128(c, sti, mg->nd_dinv[i], nb, base + woff[i], flags + 2 * i));
+    if (ns > 0)          // W of this block on its own stream as well: it needs nothing but the block inverse
+      hipLaunchKernelGGL(k_nd_w, dim3(ns), dim3(256), 0, sti, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, act, pos, mg->nd_dinv[i], mg->nd_off[i], nb,
+                         nI, ns, mg->d_nd_w, mg->d_nd_wt, flags + 2 * (k + 1));
+    FH_CHECK_HIP(hipEventRecord(mg->nd_events[i], sti));
     FH_CHECK_HIP(hipStreamWaitEvent(c->stream, mg->nd_events[i], 0));
   }
   if (ns > 0) {
-    for (int i = 0; i < k; i++) {
-      const int off = mg->nd_off[i], nb = mg->nd_off[i + 1] - off;
-      hipLaunchKernelGGL(k_nd_w, dim3(ns), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, act, pos, mg->nd_dinv[i], off, nb, nI, ns,
-                         mg->d_nd_w, mg->d_nd_wt, flags + 2 * (k + 1));
-    }
     hipLaunchKernelGGL(k_nd_schur, dim3(ns), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, act, pos, mg->d_nd_w, nI, ns, mg->d_nd_sinv,
                        flags + 2 * (k + 1));
     FH_CHECK_HIP(hipGetLastError());

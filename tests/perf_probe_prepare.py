@@ -9,6 +9,10 @@ import femus_amd
 from femus_amd.poisson import PoissonMG
 
 ctx = femus_amd.Context(0)
+if os.environ.get("FEMUS_ND"):
+    ctx.set_option("coarse_nd", int(os.environ["FEMUS_ND"]))      # interior blocks of the dissected coarse solve (0: one dense inverse)
+if os.environ.get("FEMUS_ND_STREAMS"):
+    ctx.set_option("coarse_nd_streams", int(os.environ["FEMUS_ND_STREAMS"]))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 pb = PoissonMG(ctx, n, n, n, 4).init()
 pb.assemble()
@@ -22,4 +26,4 @@ for gj in [int(v) for v in sys.argv[2:]] or [128]:
         t = time.time()
         pb.prepare()
         ctx.sync()
-        print("gj_block %d prepare ms %.2f" % (gj, (time.time() - t) * 1e3))
+        print("gj_block %d prepare ms %.2f coarse (dense unknowns, blocks, separator, largest block) %s" % (gj, (time.time() - t) * 1e3, pb.mg.coarse_info()))
