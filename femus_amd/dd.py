@@ -850,6 +850,9 @@ class DistributedPoisson:
         self.bdc_top = H.bdc_owned[-1].astype(np.int32)
         self.bdc_dev = capi.Index(ctx, self.bdc_top)       # BuildBdcIndex once, device-resident
         self.mg = capi.Multigrid(ctx, nlevels if self.general else nlevels + 1)
+        cc = coarse_mesh.arrays()[1] if self.general else getattr(self, "coarse_coords", None)
+        if cc is not None and cc.shape[0] == self.A_coarse.m():
+            self.mg.set_coarse_coords(cc)           # the exact coarse solve dissects its dense problem with them (option coarse_nd)
         self._wire_cycle()
         self.mg.setup()
         self.ndof_owned = top.n_owned
@@ -867,6 +870,7 @@ class DistributedPoisson:
         """5. replicated level(s) below the box hierarchy: this rank's share of P^T A_0 P as a device triple product, summed over the ranks"""
         rank = part.rank
         m_rep, m_g0 = replicated_level(part, nb)
+        self.coarse_coords = m_rep.arrays()[1]              # where the unknowns of the exactly solved level lie (fh_mg_set_coarse_coords)
         Pg = capi.build_prolongator(ctx, m_rep, m_g0, fe, zero_bdc=True)
         n_rep = m_rep.n_dofs(fe)
         g0_gid, _ = node_keys(m_g0.arrays()[1], 0, nb, part)
