@@ -304,6 +304,9 @@ def main():
         "vcycle_spmv_GBps": spmv_bytes / spmv_ms / 1e6,
         "vcycle_spmv_pct_hbm_peak": spmv_bytes / spmv_ms / 1e6 / HBM_PEAK_GBPS * 100.0,
         "prepare_ms": pb.prepare_ms,
+        "coarse_solve": dict(zip(("dense_unknowns", "dissection_blocks", "separator", "largest_block"), pb.mg.coarse_info()),
+                             what="exact solve of the coarsest level: unknowns coupled to nothing by their diagonal, the rest dense -- dissected into interior blocks "
+                                  "inverted beside each other + a separator Schur complement (dissection_blocks 0: one dense inverse)"),
         "solve_ms": solve["solve_ms"],
         "solve": solve,
         "vcycle_host_issue_ms": host_issue_ms,
