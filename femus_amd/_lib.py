@@ -28,11 +28,6 @@ def load_library():
         # several processes on one node exchange device memory through dmabuf IPC handles on this driver stack; without this setting
         # RCCL's peer setup fails with "hipIpcGetMemHandle: invalid argument".  Before the HIP runtime starts; an explicit value wins.
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # the HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (4 by default) and launches on one queue run
-        # one after the other: the block inverses of the dissected coarse solve (one stream each, fh_mg.hip nd_factor) run beside each other
-        # only on distinct queues -- preparation 3.7 ms with 4 queues, 3.2 ms with 8 on the bench hierarchy.  Read when the runtime starts; an
-        # explicit value wins.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         import torch  # noqa: F401
         _LIB = ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
         _declare(_LIB)

@@ -97,8 +97,8 @@ struct fh_ctx_s {
   int gj_symmetric = 1;              // coarse dense inverse: symmetric sweep on the upper block triangle when the operator is symmetric
   int galerkin_mfma = 1;             // element-wise Galerkin product on the FP64 matrix cores (0: sparse child tables on the vector ALU)
   int patch_invert_lds = 1;          // block smoother setup: patches of <= 96 dofs are inverted by one wave each in LDS (0: workgroup kernel on global memory)
-  int coarse_nd = 4;                 // coarsest level: interior blocks of the nested dissection of the coupled unknowns (block inverses beside each other + separator Schur complement); needs coordinates (fh_mg_set_coarse_coords) and a symmetric operator; 0 / 1: one dense inverse
-  int coarse_nd_streams = 1;         // ... the block inverses on their own streams (0: one after the other on the compute stream, for measurements)
+  int coarse_nd = 8;                 // coarsest level: interior blocks of the nested dissection of the coupled unknowns (block inverses beside each other + separator Schur complement); needs coordinates (fh_mg_set_coarse_coords) and a symmetric operator; 0 / 1: one dense inverse
+  int coarse_nd_streams = 0;         // ... the block inverses: 0 = one launch per step for all blocks (block index as a grid dimension), 1 = one stream per block, 2 = one after the other (measurements)
   int coarse_nd_min = 1024;          // ... only from this many coupled unknowns on
   int coarse_reduce = 1;             // coarsest level: unknowns coupled to nothing (Dirichlet rows) are solved by their diagonal, the dense inverse holds the rest
   int vanka_persistent = 0;          // block smoother: all colours of a sweep in one launch with device-wide barriers (1: arrival counter, 2: flag per

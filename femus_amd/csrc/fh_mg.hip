@@ -88,6 +88,7 @@ struct fh_mg_s {
   std::vector<double*> nd_dinv;       // per block
   int64_t* d_nd_rowoff = nullptr;     // per interior unknown: where its row of the block inverse starts (doubles from d_nd)
   int* d_nd_rowinfo = nullptr;        // per interior unknown: block offset, block size
+  void* d_nd_desc = nullptr;          // per interior block: matrix, size, work space of its inversion (InvDesc), for the batched launches
   int nd_rows_cap = 0;
   std::vector<hipStream_t> nd_streams;
   std::vector<hipEvent_t> nd_events;
@@ -1037,12 +1038,12 @@ __global__ __launch_bounds__(256) void k_inv_first(const double* __restrict__ D,
 }
 
 // Dinv: [0, IB*IB) the inverse of the pivot block (row-major), [IB*IB, 2 IB*IB) its transpose
-__global__ __launch_bounds__(256) void k_inv_panel(double* __restrict__ D, const double* __restrict__ Dinv, double* __restrict__ PT, double* __restrict__ RT,
-                                                   int n, int kb, int nb) {
+__device__ __forceinline__ void inv_panel_body(double* __restrict__ D, const double* __restrict__ Dinv, double* __restrict__ PT, double* __restrict__ RT,
+                                               int n, int kb, int nb, int bxi) {
   __shared__ double As[IKC][ILD];
   __shared__ double Bs[IB][IPLD];              // the whole gathered panel of this workgroup: 128 x 32 (+ padding)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tj = blockIdx.x * IPN;
+  const int tj = bxi * IPN;
   const bool inside = tj >= kb && tj < kb + IB, left = tj < kb;
   // ---- gather PT[t][tj + jj], t < nb: a column above the block (contiguous in t), the symmetric pivot block, or a row right of it ----
   if (left) {
@@ -1115,12 +1116,33 @@ __global__ __launch_bounds__(256) void k_inv_panel(double* __restrict__ D, const
     }
 }
 
-__global__ __launch_bounds__(256) void k_inv_update(double* __restrict__ D, const double* __restrict__ PT, const double* __restrict__ RT, int n, int kb,
-                                                    int nb, double* __restrict__ Dinv_next, int* __restrict__ flag) {
+// one dense matrix per launch (k_inv_panel / k_inv_update) or several beside each other (k_inv_panel_b / k_inv_update_b: blockIdx.z names the
+// matrix, the grid is sized for the largest; the dissected coarse solve inverts its interior blocks this way)
+struct InvDesc {
+  double* D;
+  int n;
+  double *PT, *RT, *Dv0, *Dv1;
+  int* flg;
+  int off;               // first unknown of the block in the dissected ordering (k_nd_w)
+};
+
+__global__ __launch_bounds__(256) void k_inv_panel(double* __restrict__ D, const double* __restrict__ Dinv, double* __restrict__ PT, double* __restrict__ RT,
+                                                   int n, int kb, int nb) {
+  inv_panel_body(D, Dinv, PT, RT, n, kb, nb, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void k_inv_panel_b(const InvDesc* __restrict__ desc, int kb, int odd) {
+  const InvDesc q = desc[blockIdx.z];
+  if (kb >= q.n || (int)blockIdx.x * IPN >= q.n) return;
+  inv_panel_body(q.D, odd ? q.Dv1 : q.Dv0, q.PT, q.RT, q.n, kb, min(IB, q.n - kb), blockIdx.x);
+}
+
+__device__ __forceinline__ void inv_update_body(double* __restrict__ D, const double* __restrict__ PT, const double* __restrict__ RT, int n, int kb,
+                                                int nb, double* __restrict__ Dinv_next, int* __restrict__ flag, int nt, int bxi, int byi) {
   extern __shared__ __attribute__((aligned(16))) double iu_smem[];
-  const int nt = gridDim.x, kblk = kb / IB, kb_next = kb + IB;
+  const int kblk = kb / IB, kb_next = kb + IB;
   const int t_next = (kb_next < n) ? kblk + 1 : 0;
-  const int by = (blockIdx.y + t_next) % nt, bx = (blockIdx.x + t_next) % nt;
+  const int by = (byi + t_next) % nt, bx = (bxi + t_next) % nt;
   if (by > bx) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ti = by * IB, tj = bx * IB;
@@ -1228,6 +1250,50 @@ __global__ __launch_bounds__(256) void k_inv_update(double* __restrict__ D, cons
   __syncthreads();
   unsigned long long* dmax_bits = reinterpret_cast<unsigned long long*>(iu_smem + 512);
   inv128_block(D + (size_t)kb_next * n + kb_next, (size_t)n, min(IB, n - kb_next), Dinv_next, Dinv_next + IB * IB, iu_smem, dmax_bits, flag);
+}
+
+__global__ __launch_bounds__(256) void k_inv_update(double* __restrict__ D, const double* __restrict__ PT, const double* __restrict__ RT, int n, int kb,
+                                                    int nb, double* __restrict__ Dinv_next, int* __restrict__ flag) {
+  inv_update_body(D, PT, RT, n, kb, nb, Dinv_next, flag, gridDim.x, blockIdx.x, blockIdx.y);
+}
+
+__global__ __launch_bounds__(256) void k_inv_update_b(const InvDesc* __restrict__ desc, int kb, int odd) {
+  const InvDesc q = desc[blockIdx.z];
+  const int nt = (q.n + IB - 1) / IB;
+  if (kb >= q.n || (int)blockIdx.x >= nt || (int)blockIdx.y >= nt) return;
+  inv_update_body(q.D, q.PT, q.RT, q.n, kb, min(IB, q.n - kb), odd ? q.Dv0 : q.Dv1, q.flg + 1, nt, blockIdx.x, blockIdx.y);
+}
+
+__global__ __launch_bounds__(256) void k_inv_first_b(const InvDesc* __restrict__ desc) {
+  __shared__ double lines[512];
+  __shared__ unsigned long long dmax_bits;
+  const InvDesc q = desc[blockIdx.x];
+  inv128_block(q.D, (size_t)q.n, min(IB, q.n), q.Dv0, q.Dv0 + IB * IB, lines, &dmax_bits, q.flg + 1);
+}
+
+// the upper triangle holds -A^-1: negate and mirror -- k_gjs_finish for several matrices (blockIdx.z)
+__global__ __launch_bounds__(256) void k_gjs_finish_b(const InvDesc* __restrict__ desc) {
+  const InvDesc q = desc[blockIdx.z];
+  const int n = q.n, nt = (n + 63) / 64;
+  if (blockIdx.y > blockIdx.x || (int)blockIdx.x >= nt) return;
+  double* D = q.D;
+  __shared__ double Ts[64][65];
+  const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
+  for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+    const int r = idx >> 6, c = idx & 63, i = ti + r, j = tj + c;
+    double v = 0.0;
+    if (i < n && j < n) {
+      v = (i <= j) ? -D[(size_t)i * n + j] : 0.0;
+      if (i <= j) D[(size_t)i * n + j] = v;
+    }
+    Ts[r][c] = v;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    const int i = tj + r, j = ti + c;
+    if (i < n && j < n && j < i) D[(size_t)i * n + j] = Ts[c][r];
+  }
 }
 
 // pivot columns of all other rows: A[i, kb+t] <- - sum_s Cp[i,s] * Dinv[s,t]
@@ -1814,9 +1880,9 @@ __global__ __launch_bounds__(256) void k_csr_to_dense_blk(const int* __restrict_
 
 // W[p][c] = sum over the entries (j, v) of separator row c inside interior block i of v * Binv_i[pos(j)][p]   (A_IS = A_SI^T, Binv symmetric);
 // grid (separator unknowns, blocks).  Written as W (interior x separator) and as its transpose.
-__global__ __launch_bounds__(256) void k_nd_w(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
-                                              const int* __restrict__ act, const int* __restrict__ pos, const double* __restrict__ Binv, int off, int nb,
-                                              int nI, int ns, double* __restrict__ W, double* __restrict__ WT, int* __restrict__ flag) {
+__device__ __forceinline__ void nd_w_body(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+                                          const int* __restrict__ act, const int* __restrict__ pos, const double* __restrict__ Binv, int off, int nb,
+                                          int nI, int ns, double* __restrict__ W, double* __restrict__ WT, int* __restrict__ flag) {
   __shared__ int ej[ND_ROW];
   __shared__ double ev[ND_ROW];
   __shared__ int ne;
@@ -1844,6 +1910,20 @@ __global__ __launch_bounds__(256) void k_nd_w(const int* __restrict__ rowptr, co
     W[(size_t)(off + p) * ns + c] = acc;
     WT[(size_t)c * nI + off + p] = acc;
   }
+}
+
+__global__ __launch_bounds__(256) void k_nd_w(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+                                              const int* __restrict__ act, const int* __restrict__ pos, const double* __restrict__ Binv, int off, int nb,
+                                              int nI, int ns, double* __restrict__ W, double* __restrict__ WT, int* __restrict__ flag) {
+  nd_w_body(rowptr, col, val, act, pos, Binv, off, nb, nI, ns, W, WT, flag);
+}
+
+// all interior blocks in one launch: grid (separator unknowns, blocks)
+__global__ __launch_bounds__(256) void k_nd_w_b(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+                                                const int* __restrict__ act, const int* __restrict__ pos, const InvDesc* __restrict__ desc, int nI, int ns,
+                                                double* __restrict__ W, double* __restrict__ WT, int* __restrict__ flag) {
+  const InvDesc q = desc[blockIdx.y];
+  nd_w_body(rowptr, col, val, act, pos, q.D, q.off, q.n, nI, ns, W, WT, flag);
 }
 
 // Sc[c1][c2] = A_SS[c1][c2] - sum over the interior entries (j, v) of separator row c1 of v * W[pos(j)][c2]
@@ -2039,6 +2119,16 @@ static int nd_factor(fh_mg_t mg, int n, int nfull) {
     }
     FH_CHECK_HIP(hipMemcpy(mg->d_nd_rowoff, ro.data(), ro.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     FH_CHECK_HIP(hipMemcpy(mg->d_nd_rowinfo, ri.data(), ri.size() * sizeof(int), hipMemcpyHostToDevice));
+    std::vector<InvDesc> hd(k);
+    for (int i = 0; i < k; i++) {
+      const int nb = mg->nd_off[i + 1] - mg->nd_off[i];
+      double* w = base + woff[i];
+      hd[i] = InvDesc{mg->nd_dinv[i], nb, w, w + (size_t)nb * IB, w + (size_t)2 * nb * IB, w + (size_t)2 * nb * IB + 2 * IB * IB, flags + 2 * i, mg->nd_off[i]};
+    }
+    if (mg->d_nd_desc) FH_CHECK_HIP(hipFree(mg->d_nd_desc));
+    mg->d_nd_desc = nullptr;
+    FH_CHECK_HIP(hipMalloc(&mg->d_nd_desc, hd.size() * sizeof(InvDesc)));
+    FH_CHECK_HIP(hipMemcpy(mg->d_nd_desc, hd.data(), hd.size() * sizeof(InvDesc), hipMemcpyHostToDevice));
     mg->nd_tables_valid = true;
   }
   while ((int)mg->nd_streams.size() < k) {
@@ -2062,11 +2152,34 @@ static int nd_factor(fh_mg_t mg, int n, int nfull) {
   if (ns > 0)
     hipLaunchKernelGGL(k_csr_to_dense_blk, dim3(ns), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, mg->d_nd_sinv, nI, ns, act, pos);
   FH_CHECK_HIP(hipGetLastError());
-  // the block inverses beside each other
+  // the block inverses beside each other: ONE launch per step for all of them (blockIdx.z = block; default), or one stream per block
+  // (coarse_nd_streams = 1; beside each other only where the runtime gives the streams distinct hardware queues)
+  if (c->coarse_nd_streams == 0) {
+    int nmax = 0;
+    for (int i = 0; i < k; i++) nmax = std::max(nmax, mg->nd_off[i + 1] - mg->nd_off[i]);
+    const InvDesc* desc = static_cast<const InvDesc*>(mg->d_nd_desc);
+    constexpr size_t upd_lds = (size_t)4 * IKC * ILD * sizeof(double);
+    static bool attr_set[64] = {};
+    if (!attr_set[c->device & 63]) {
+      FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inv_update_b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_lds));
+      attr_set[c->device & 63] = true;
+    }
+    const int ntb = fh_div_up(nmax, IB), nt64 = fh_div_up(nmax, 64);
+    hipLaunchKernelGGL(k_inv_first_b, dim3(k), dim3(256), 0, c->stream, desc);
+    for (int kb = 0, step = 0; kb < nmax; kb += IB, step++) {
+      hipLaunchKernelGGL(k_inv_panel_b, dim3(fh_div_up(nmax, IPN), 1, k), dim3(256), 0, c->stream, desc, kb, step & 1);
+      hipLaunchKernelGGL(k_inv_update_b, dim3(ntb, ntb, k), dim3(256), upd_lds, c->stream, desc, kb, step & 1);
+    }
+    hipLaunchKernelGGL(k_gjs_finish_b, dim3(nt64, nt64, k), dim3(256), 0, c->stream, desc);
+    if (ns > 0)
+      hipLaunchKernelGGL(k_nd_w_b, dim3(ns, k), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, act, pos, desc, nI, ns, mg->d_nd_w, mg->d_nd_wt,
+                         flags + 2 * (k + 1));
+    FH_CHECK_HIP(hipGetLastError());
+  } else {
   FH_CHECK_HIP(hipEventRecord(mg->nd_events[k], c->stream));
   for (int i = 0; i < k; i++) {
     const int nb = mg->nd_off[i + 1] - mg->nd_off[i];
-    hipStream_t sti = c->coarse_nd_streams ? mg->nd_streams[i] : c->stream;
+    hipStream_t sti = c->coarse_nd_streams == 2 ? c->stream : mg->nd_streams[i];      // 2: one block after the other on the compute stream (measurements)
     FH_CHECK_HIP(hipStreamWaitEvent(sti, mg->nd_events[k], 0));
     FH_TRY(invert_sym128(c, sti, mg->nd_dinv[i], nb, base + woff[i], flags + 2 * i));
     if (ns > 0)          // W of this block on its own stream as well: it needs nothing but the block inverse
@@ -2074,6 +2187,7 @@ static int nd_factor(fh_mg_t mg, int n, int nfull) {
                          nI, ns, mg->d_nd_w, mg->d_nd_wt, flags + 2 * (k + 1));
     FH_CHECK_HIP(hipEventRecord(mg->nd_events[i], sti));
     FH_CHECK_HIP(hipStreamWaitEvent(c->stream, mg->nd_events[i], 0));
+  }
   }
   if (ns > 0) {
     hipLaunchKernelGGL(k_nd_schur, dim3(ns), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, act, pos, mg->d_nd_w, nI, ns, mg->d_nd_sinv,
@@ -2784,6 +2898,7 @@ extern "C" int fh_mg_destroy(fh_mg_t mg) {
   if (mg->d_nd) hipFree(mg->d_nd);
   if (mg->d_nd_rowoff) hipFree(mg->d_nd_rowoff);
   if (mg->d_nd_rowinfo) hipFree(mg->d_nd_rowinfo);
+  if (mg->d_nd_desc) hipFree(mg->d_nd_desc);
   for (hipStream_t st : mg->nd_streams) hipStreamDestroy(st);
   for (hipEvent_t ev : mg->nd_events) hipEventDestroy(ev);
   for (double* p : mg->kv) hipFree(p);

@@ -670,22 +670,24 @@ def test_dissected_coarse_solve_is_the_exact_solve(ctx, n, fe, nd):
         got[mode] = first
         mg.destroy()
         Ad.destroy()
-    ctx.set_option("coarse_nd", 4)
+    ctx.set_option("coarse_nd", 8)
     ctx.set_option("coarse_nd_min", 1024)
     assert rel(got[nd], ref) < 1e-11 and rel(got[0], ref) < 1e-11
 
 
 def test_dissection_cuts_a_q2_block_at_element_planes(ctx):
     """the separator of the 8^3-element coarse level of the bench hierarchy (3375 coupled unknowns): four blocks of 15 x 7 x 7 unknowns and
-    the three element-boundary planes between them (225 + 2 x 105): layers of Q2 nodes at element boundaries separate, mid-planes do not"""
+    the three element-boundary planes between them (225 + 2 x 105), or eight blocks of 7 x 7 x 7: layers of Q2 nodes at element boundaries separate, mid-planes do not"""
     A, xy = _poisson_level_operator(ctx, (8, 8, 8))
-    mg = capi.Multigrid(ctx, 1)
     Ad = ctx.matrix_scipy(A)
-    mg.set_level(0, Ad, None, None, 0, 1.0, 1, 0)
-    mg.set_coarse_coords(xy)
-    mg.setup()
-    assert mg.coarse_info() == (3375, 4, 435, 735)
-    mg.destroy()
+    for blocks, expect in ((4, (3375, 4, 435, 735)), (8, (3375, 8, 631, 343))):       # 8 (the default): 7 x 7 x 7 blocks, 225 + 2 x 105 + 4 x 49
+        ctx.set_option("coarse_nd", blocks)
+        mg = capi.Multigrid(ctx, 1)
+        mg.set_level(0, Ad, None, None, 0, 1.0, 1, 0)
+        mg.set_coarse_coords(xy)
+        mg.setup()
+        assert mg.coarse_info() == expect
+        mg.destroy()
     Ad.destroy()
 
 
@@ -732,5 +734,35 @@ def test_hierarchy_solve_with_and_without_the_dissection(ctx):
         assert its2 == its and np.array_equal(x, pb.EPSC.to_numpy())
         sols.append((its, x))
         pb.destroy()
-    ctx.set_option("coarse_nd", 4)
+    ctx.set_option("coarse_nd", 8)
     assert sols[0][0] == sols[1][0] and rel(sols[0][1], sols[1][1]) < 1e-11
+
+
+def test_dissected_coarse_solve_of_a_disconnected_operator(ctx):
+    """two bodies that share nothing: the first cut needs no separator at all (two blocks, empty Schur complement); with more blocks the
+    separators lie inside the bodies -- exact either way"""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    A1, xy1 = _poisson_level_operator(ctx, (4, 3, 3))
+    A = sp.block_diag([A1, A1]).tocsr()
+    xy = np.vstack([xy1, xy1 + np.array([10.0, 0.0, 0.0])])
+    rng = np.random.default_rng(2)
+    rhs = rng.uniform(-1, 1, A.shape[0])
+    ref = spla.spsolve(A.tocsc(), rhs)
+    Ad = ctx.matrix_scipy(A)
+    ctx.set_option("coarse_nd_min", 16)
+    for blocks in (2, 4):
+        ctx.set_option("coarse_nd", blocks)
+        mg = capi.Multigrid(ctx, 1)
+        mg.set_level(0, Ad, None, None, 0, 1.0, 1, 0)
+        mg.set_coarse_coords(xy)
+        mg.setup()
+        nden, nblk, nsep, big = mg.coarse_info()
+        assert nblk == blocks and (nsep == 0) == (blocks == 2), (nden, nblk, nsep, big)
+        b, x = ctx.vector_from(rhs), ctx.vector(A.shape[0])
+        mg.vcycle(b, x)
+        assert rel(x.to_numpy(), ref) < 1e-11
+        mg.destroy()
+    Ad.destroy()
+    ctx.set_option("coarse_nd", 8)
+    ctx.set_option("coarse_nd_min", 1024)
