@@ -1351,6 +1351,36 @@ __global__ __launch_bounds__(256) void k_multiaxpy(double* __restrict__ w, const
   }
 }
 
+// the same with the squared norm of the new w on the way: partial sums per workgroup, then k_sum_to (one launch, one host round trip per
+// GMRES iteration instead of two)
+__global__ __launch_bounds__(256) void k_multiaxpy_norm(double* __restrict__ w, const double* const* __restrict__ V, const double* __restrict__ h,
+                                                        double sign, int nvec, int n, double* __restrict__ part) {
+  __shared__ double sm[4];
+  double sq = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    double acc = w[i];
+    for (int j = 0; j < nvec; j++) acc += sign * h[j] * V[j][i];
+    w[i] = acc;
+    sq += acc * acc;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ __launch_bounds__(256) void k_sum_to(const double* __restrict__ part, int nb, double* __restrict__ out) {
+  __shared__ double sm[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) acc += part[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
 __global__ __launch_bounds__(256) void k_axpby2(double* y, const double* x, double a, double b, int n) {   // x may alias y
   // BLAS semantics: with b == 0 the old y is NOT referenced (it may be uninitialised memory: 0 * NaN = NaN)
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];
@@ -3057,14 +3087,24 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
         hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, c->stream, (const double* const*)d_V, w, k + 1, n, c->d_red);
         hipLaunchKernelGGL(k_multidot_final, dim3(k + 1), dim3(256), 0, c->stream, c->d_red, k + 1, nb);
         if (HL) FH_TRY(fh_halo_allreduce_ptr(HL, c->d_red + (size_t)(k + 1) * nb, k + 1));
-        hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, w, (const double* const*)d_V, c->d_red + (size_t)(k + 1) * nb, -1.0,
-                           k + 1, n);
-        FH_CHECK_HIP(hipMemcpyAsync(c->h_red, c->d_red + (size_t)(k + 1) * nb, (k + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        FH_CHECK_HIP(hipStreamSynchronize(c->stream));
-        for (int j = 0; j <= k; j++) H[(size_t)j * restart + k] = c->h_red[j];
         double wn;
-        FH_TRY(dot(w, w, &wn));
-        wn = sqrt(wn);
+        if (!HL) {           // one rank: the norm of the orthogonalised w comes out of the same pass (one host round trip per iteration)
+          double* hk = c->d_red + (size_t)(k + 1) * nb;
+          hipLaunchKernelGGL(k_multiaxpy_norm, dim3(nb), dim3(256), 0, c->stream, w, (const double* const*)d_V, hk, -1.0, k + 1, n, hk + k + 2);
+          hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, c->stream, hk + k + 2, nb, hk + k + 1);
+          FH_CHECK_HIP(hipMemcpyAsync(c->h_red, hk, (k + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+          FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+          for (int j = 0; j <= k; j++) H[(size_t)j * restart + k] = c->h_red[j];
+          wn = sqrt(c->h_red[k + 1]);
+        } else {
+          hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, w, (const double* const*)d_V, c->d_red + (size_t)(k + 1) * nb, -1.0,
+                             k + 1, n);
+          FH_CHECK_HIP(hipMemcpyAsync(c->h_red, c->d_red + (size_t)(k + 1) * nb, (k + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+          FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+          for (int j = 0; j <= k; j++) H[(size_t)j * restart + k] = c->h_red[j];
+          FH_TRY(dot(w, w, &wn));
+          wn = sqrt(wn);
+        }
         H[(size_t)(k + 1) * restart + k] = wn;
         if (wn != 0.0) FH_TRY(dev_axpby(c, Vv[k + 1], w, 1.0 / wn, 0.0, n));
         else FH_CHECK_HIP(hipMemsetAsync(Vv[k + 1], 0, (size_t)n * sizeof(double), c->stream));
@@ -3154,14 +3194,24 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
         hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, c->stream, (const double* const*)d_V, w, k + 1, n, c->d_red);
         hipLaunchKernelGGL(k_multidot_final, dim3(k + 1), dim3(256), 0, c->stream, c->d_red, k + 1, nb);
         if (HL) FH_TRY(fh_halo_allreduce_ptr(HL, c->d_red + (size_t)(k + 1) * nb, k + 1));
-        hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, w, (const double* const*)d_V, c->d_red + (size_t)(k + 1) * nb, -1.0,
-                           k + 1, n);
-        FH_CHECK_HIP(hipMemcpyAsync(c->h_red, c->d_red + (size_t)(k + 1) * nb, (k + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        FH_CHECK_HIP(hipStreamSynchronize(c->stream));
-        for (int j = 0; j <= k; j++) H[(size_t)j * restart + k] = c->h_red[j];
         double wn;
-        FH_TRY(dot(w, w, &wn));
-        wn = sqrt(wn);
+        if (!HL) {           // one rank: the norm of the orthogonalised w comes out of the same pass (one host round trip per iteration)
+          double* hk = c->d_red + (size_t)(k + 1) * nb;
+          hipLaunchKernelGGL(k_multiaxpy_norm, dim3(nb), dim3(256), 0, c->stream, w, (const double* const*)d_V, hk, -1.0, k + 1, n, hk + k + 2);
+          hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, c->stream, hk + k + 2, nb, hk + k + 1);
+          FH_CHECK_HIP(hipMemcpyAsync(c->h_red, hk, (k + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+          FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+          for (int j = 0; j <= k; j++) H[(size_t)j * restart + k] = c->h_red[j];
+          wn = sqrt(c->h_red[k + 1]);
+        } else {
+          hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, w, (const double* const*)d_V, c->d_red + (size_t)(k + 1) * nb, -1.0,
+                             k + 1, n);
+          FH_CHECK_HIP(hipMemcpyAsync(c->h_red, c->d_red + (size_t)(k + 1) * nb, (k + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+          FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+          for (int j = 0; j <= k; j++) H[(size_t)j * restart + k] = c->h_red[j];
+          FH_TRY(dot(w, w, &wn));
+          wn = sqrt(wn);
+        }
         H[(size_t)(k + 1) * restart + k] = wn;
         // happy breakdown (w = 0: the Krylov space is invariant): the next basis vector is never used, but it must not stay
         // uninitialised / stale either
