@@ -51,6 +51,7 @@ struct MgLevel {
   bool replicated_below = false;
   int ncols = 0;
   int buf_n = -1;            // size the work vectors were allocated for (kept across preparations)
+  double* buf_base = nullptr;   // dinv, x, x2, b, r: one allocation
   // level solver: 0 = Richardson(omega) around the sweep preconditioner, 1 = GMRES (fixed iteration count, left-preconditioned)
   int solver = 0, gm_restart = 30, gm_m = 0;
   double* gm_buf = nullptr;  // (gm_m + 1) basis vectors of ncols + 2 entries
@@ -1351,36 +1352,6 @@ __global__ __launch_bounds__(256) void k_multiaxpy(double* __restrict__ w, const
   }
 }
 
-// the same with the squared norm of the new w on the way: partial sums per workgroup, then k_sum_to (one launch, one host round trip per
-// GMRES iteration instead of two)
-__global__ __launch_bounds__(256) void k_multiaxpy_norm(double* __restrict__ w, const double* const* __restrict__ V, const double* __restrict__ h,
-                                                        double sign, int nvec, int n, double* __restrict__ part) {
-  __shared__ double sm[4];
-  double sq = 0.0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    double acc = w[i];
-    for (int j = 0; j < nvec; j++) acc += sign * h[j] * V[j][i];
-    w[i] = acc;
-    sq += acc * acc;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = sq;
-  __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
-}
-
-__global__ __launch_bounds__(256) void k_sum_to(const double* __restrict__ part, int nb, double* __restrict__ out) {
-  __shared__ double sm[4];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < nb; i += 256) acc += part[i];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) *out = sm[0] + sm[1] + sm[2] + sm[3];
-}
-
 __global__ __launch_bounds__(256) void k_axpby2(double* y, const double* x, double a, double b, int n) {   // x may alias y
   // BLAS semantics: with b == 0 the old y is NOT referenced (it may be uninitialised memory: 0 * NaN = NaN)
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];
@@ -1469,11 +1440,9 @@ static void free_level_gmres(MgLevel& L) {
 }
 
 static void free_level_buffers(MgLevel& L) {
-  for (double** p : {&L.dinv, &L.x, &L.x2, &L.b, &L.r})
-    if (*p) {
-      hipFree(*p);
-      *p = nullptr;
-    }
+  if (L.buf_base) hipFree(L.buf_base);         // the five work vectors of the level are one allocation (one fill per preparation)
+  L.buf_base = nullptr;
+  for (double** p : {&L.dinv, &L.x, &L.x2, &L.b, &L.r}) *p = nullptr;
   free_level_gmres(L);
   L.buf_n = -1;
 }
@@ -2243,6 +2212,7 @@ static int coarse_factor(fh_mg_t mg) {
   const int nfull = L0.n;
   // ---- unknowns coupled to nothing leave the dense problem (exact: the operator is block diagonal with respect to them) ----
   int n = nfull;
+  int sym_known = -1;                  // 1 / 0: the operator passed / failed the symmetry test of this preparation
   mg->nd_active = false;
   if (!c->coarse_reduce) mg->nd_off.clear();
   if (c->coarse_reduce && nfull > 0) {
@@ -2250,17 +2220,21 @@ static int coarse_factor(fh_mg_t mg) {
       if (mg->d_hit) FH_CHECK_HIP(hipFree(mg->d_hit));
       mg->d_hit = nullptr;
       mg->hit_n = 0;
-      FH_CHECK_HIP(hipMalloc(&mg->d_hit, (size_t)2 * nfull * sizeof(int)));
+      FH_CHECK_HIP(hipMalloc(&mg->d_hit, ((size_t)2 * nfull + 2) * sizeof(int)));
       mg->hit_n = nfull;
     }
     int* d_hit = mg->d_hit;
-    FH_CHECK_HIP(hipMemsetAsync(d_hit, 0, (size_t)2 * nfull * sizeof(int), c->stream));
+    FH_CHECK_HIP(hipMemsetAsync(d_hit, 0, ((size_t)2 * nfull + 2) * sizeof(int), c->stream));
     hipLaunchKernelGGL(k_coarse_coupling, dim3(fh_div_up(nfull, 4)), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, nfull, d_hit,
                        d_hit + nfull);
+    // the symmetry test of the dissected solve in the same host round trip (flag behind the marks)
+    hipLaunchKernelGGL(k_csr_symmetry, dim3(fh_div_up(nfull, 4)), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, nfull, 1e-12,
+                       d_hit + 2 * nfull);
     FH_CHECK_HIP(hipGetLastError());
-    std::vector<int> hit((size_t)2 * nfull);
+    std::vector<int> hit((size_t)2 * nfull + 2);
     FH_CHECK_HIP(hipMemcpyAsync(hit.data(), d_hit, hit.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+    sym_known = hit[(size_t)2 * nfull] == 0 ? 1 : 0;
     std::vector<int> act, rest;
     for (int i = 0; i < nfull; i++) (hit[i] == 0 && hit[nfull + i] == 0 ? rest : act).push_back(i);
     n = (int)act.size();
@@ -2333,14 +2307,8 @@ static int coarse_factor(fh_mg_t mg) {
   mg->na = n;
   if (n == 0) return 0;
   if (!mg->nd_off.empty() && c->gj_symmetric && c->gj_block >= IB) {
-    // block form first: needs a symmetric operator (entry-by-entry check on the sparse form, as below)
-    int* d_sym = mg->d_hit;                // free again: the coupling marks are on the host
-    int h_sym = 0;
-    FH_CHECK_HIP(hipMemsetAsync(d_sym, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL(k_csr_symmetry, dim3(fh_div_up(nfull, 4)), dim3(256), 0, c->stream, L0.A->d_rowptr, L0.A->d_col, L0.A->d_val, nfull, 1e-12, d_sym);
-    FH_CHECK_HIP(hipMemcpyAsync(&h_sym, d_sym, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    FH_CHECK_HIP(hipStreamSynchronize(c->stream));
-    if (h_sym == 0) {
+    // block form first: needs a symmetric operator (entry-by-entry check on the sparse form, taken with the coupling marks above)
+    if (sym_known == 1) {
       FH_TRY(nd_factor(mg, n, nfull));
       if (mg->nd_active) return 0;
     }
@@ -2517,15 +2485,22 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
   for (int l = 0; l < mg->nlevels; l++) {
     MgLevel& L = mg->lv[l];
     const size_t nb = ((size_t)L.ncols + 2) * sizeof(double);
+    const size_t nbd = ((size_t)L.ncols + 2 + 1) & ~(size_t)1;      // doubles per vector, even: every vector stays 16-byte aligned
     if (L.buf_n != L.ncols) {      // a repeated preparation keeps its work vectors (and with them the captured cycle)
       free_level_buffers(L);
-      for (double** p : {&L.dinv, &L.x, &L.x2, &L.b, &L.r}) FH_CHECK_HIP(hipMalloc(p, nb));
+      FH_CHECK_HIP(hipMalloc(&L.buf_base, 5 * nbd * sizeof(double)));
+      int slot = 0;
+      for (double** p : {&L.dinv, &L.x, &L.x2, &L.b, &L.r}) *p = L.buf_base + (size_t)(slot++) * nbd;
       L.buf_n = L.ncols;
     }
-    for (double** p : {&L.dinv, &L.x, &L.x2, &L.b, &L.r}) {
-      if (c->debug_poison && p != &L.dinv) FH_CHECK_HIP(hipMemsetAsync(*p, 0xFF, nb, c->stream));
-      else      // zeroed by a fill kernel: the runtime's memset reaches 0.6 TB/s, five vectors of the finest level cost 0.14 ms
-        hipLaunchKernelGGL(k_fill_value, dim3(sgrid(c, L.ncols + 2)), dim3(256), 0, c->stream, *p, 0.0, L.ncols + 2);
+    if (c->debug_poison) {
+      for (double** p : {&L.dinv, &L.x, &L.x2, &L.b, &L.r}) {
+        if (p != &L.dinv) FH_CHECK_HIP(hipMemsetAsync(*p, 0xFF, nb, c->stream));
+        else hipLaunchKernelGGL(k_fill_value, dim3(sgrid(c, L.ncols + 2)), dim3(256), 0, c->stream, *p, 0.0, L.ncols + 2);
+      }
+    } else {      // zeroed by ONE fill kernel: the runtime's memset reaches 0.6 TB/s (five vectors of the finest level: 0.14 ms), five launches cost 20 us per level
+      FH_REQUIRE(5 * nbd < ((size_t)1 << 31), "fh_mg_setup: level %d is too large for the 32-bit fill", l);
+      hipLaunchKernelGGL(k_fill_value, dim3(sgrid(c, (int)std::min<size_t>(5 * nbd, (size_t)1 << 30))), dim3(256), 0, c->stream, L.buf_base, 0.0, (int)(5 * nbd));
     }
     FH_TRY(fh_dev_get_diag(L.A, L.dinv, 1));
     if (l > 0 && L.smoother == FH_SMOOTH_IDENTITY)      // PCNONE: B = I, the Jacobi kernels with a unit "inverse diagonal"
@@ -3087,24 +3062,14 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
         hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, c->stream, (const double* const*)d_V, w, k + 1, n, c->d_red);
         hipLaunchKernelGGL(k_multidot_final, dim3(k + 1), dim3(256), 0, c->stream, c->d_red, k + 1, nb);
         if (HL) FH_TRY(fh_halo_allreduce_ptr(HL, c->d_red + (size_t)(k + 1) * nb, k + 1));
+        hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, w, (const double* const*)d_V, c->d_red + (size_t)(k + 1) * nb, -1.0,
+                           k + 1, n);
+        FH_CHECK_HIP(hipMemcpyAsync(c->h_red, c->d_red + (size_t)(k + 1) * nb, (k + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+        for (int j = 0; j <= k; j++) H[(size_t)j * restart + k] = c->h_red[j];
         double wn;
-        if (!HL) {           // one rank: the norm of the orthogonalised w comes out of the same pass (one host round trip per iteration)
-          double* hk = c->d_red + (size_t)(k + 1) * nb;
-          hipLaunchKernelGGL(k_multiaxpy_norm, dim3(nb), dim3(256), 0, c->stream, w, (const double* const*)d_V, hk, -1.0, k + 1, n, hk + k + 2);
-          hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, c->stream, hk + k + 2, nb, hk + k + 1);
-          FH_CHECK_HIP(hipMemcpyAsync(c->h_red, hk, (k + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-          FH_CHECK_HIP(hipStreamSynchronize(c->stream));
-          for (int j = 0; j <= k; j++) H[(size_t)j * restart + k] = c->h_red[j];
-          wn = sqrt(c->h_red[k + 1]);
-        } else {
-          hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, w, (const double* const*)d_V, c->d_red + (size_t)(k + 1) * nb, -1.0,
-                             k + 1, n);
-          FH_CHECK_HIP(hipMemcpyAsync(c->h_red, c->d_red + (size_t)(k + 1) * nb, (k + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-          FH_CHECK_HIP(hipStreamSynchronize(c->stream));
-          for (int j = 0; j <= k; j++) H[(size_t)j * restart + k] = c->h_red[j];
-          FH_TRY(dot(w, w, &wn));
-          wn = sqrt(wn);
-        }
+        FH_TRY(dot(w, w, &wn));
+        wn = sqrt(wn);
         H[(size_t)(k + 1) * restart + k] = wn;
         if (wn != 0.0) FH_TRY(dev_axpby(c, Vv[k + 1], w, 1.0 / wn, 0.0, n));
         else FH_CHECK_HIP(hipMemsetAsync(Vv[k + 1], 0, (size_t)n * sizeof(double), c->stream));
@@ -3194,24 +3159,14 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
         hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, c->stream, (const double* const*)d_V, w, k + 1, n, c->d_red);
         hipLaunchKernelGGL(k_multidot_final, dim3(k + 1), dim3(256), 0, c->stream, c->d_red, k + 1, nb);
         if (HL) FH_TRY(fh_halo_allreduce_ptr(HL, c->d_red + (size_t)(k + 1) * nb, k + 1));
+        hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, w, (const double* const*)d_V, c->d_red + (size_t)(k + 1) * nb, -1.0,
+                           k + 1, n);
+        FH_CHECK_HIP(hipMemcpyAsync(c->h_red, c->d_red + (size_t)(k + 1) * nb, (k + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+        for (int j = 0; j <= k; j++) H[(size_t)j * restart + k] = c->h_red[j];
         double wn;
-        if (!HL) {           // one rank: the norm of the orthogonalised w comes out of the same pass (one host round trip per iteration)
-          double* hk = c->d_red + (size_t)(k + 1) * nb;
-          hipLaunchKernelGGL(k_multiaxpy_norm, dim3(nb), dim3(256), 0, c->stream, w, (const double* const*)d_V, hk, -1.0, k + 1, n, hk + k + 2);
-          hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, c->stream, hk + k + 2, nb, hk + k + 1);
-          FH_CHECK_HIP(hipMemcpyAsync(c->h_red, hk, (k + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-          FH_CHECK_HIP(hipStreamSynchronize(c->stream));
-          for (int j = 0; j <= k; j++) H[(size_t)j * restart + k] = c->h_red[j];
-          wn = sqrt(c->h_red[k + 1]);
-        } else {
-          hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, w, (const double* const*)d_V, c->d_red + (size_t)(k + 1) * nb, -1.0,
-                             k + 1, n);
-          FH_CHECK_HIP(hipMemcpyAsync(c->h_red, c->d_red + (size_t)(k + 1) * nb, (k + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-          FH_CHECK_HIP(hipStreamSynchronize(c->stream));
-          for (int j = 0; j <= k; j++) H[(size_t)j * restart + k] = c->h_red[j];
-          FH_TRY(dot(w, w, &wn));
-          wn = sqrt(wn);
-        }
+        FH_TRY(dot(w, w, &wn));
+        wn = sqrt(wn);
         H[(size_t)(k + 1) * restart + k] = wn;
         // happy breakdown (w = 0: the Krylov space is invariant): the next basis vector is never used, but it must not stay
         // uninitialised / stale either
