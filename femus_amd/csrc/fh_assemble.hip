@@ -492,8 +492,8 @@ __global__ __launch_bounds__(256) void k_row_assemble(const int* __restrict__ ro
 // The same pass for matrices whose rows have at most 128 entries (Q2 on hexes: 125): every 32-lane group works on TWO rows at
 // once -- the pass is bound by the dependent round trips adjacency -> element rows -> store of each row, so the loads of both
 // rows are issued together (twice the bytes in flight at the same LDS footprint).
-template <int NC>
-__global__ __launch_bounds__(256) void k_row_assemble2(const int* __restrict__ rowptr, int m, const int* __restrict__ adj_ptr,
+template <int NC, int NT>
+__global__ __launch_bounds__(256) void k_row_assemble2_t(const int* __restrict__ rowptr, int m, const int* __restrict__ adj_ptr,
                                                        const unsigned char* __restrict__ rowmap, const double* __restrict__ Kbuf, int kstride,
                                                        const double* __restrict__ Fbuf, double* __restrict__ val, double* __restrict__ res) {
   __shared__ double acc[8][2][128];
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void k_row_assemble2(const int* __restrict__ r
       if (iA < nA) {
         const int a = aA0 + iA;
         if (lane < NC) {
-          kA[t] = Kbuf[(size_t)a * kstride + lane];
+          kA[t] = NT ? __builtin_nontemporal_load(&Kbuf[(size_t)a * kstride + lane]) : Kbuf[(size_t)a * kstride + lane];
           pA[t] = rowmap[(size_t)a * NC + lane];
         }
         if (lane == 0) gA[t] = Fbuf[a];
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void k_row_assemble2(const int* __restrict__ r
       if (iB < nB) {
         const int a = aB0 + iB;
         if (lane < NC) {
-          kB[t] = Kbuf[(size_t)a * kstride + lane];
+          kB[t] = NT ? __builtin_nontemporal_load(&Kbuf[(size_t)a * kstride + lane]) : Kbuf[(size_t)a * kstride + lane];
           pB[t] = rowmap[(size_t)a * NC + lane];
         }
         if (lane == 0) gB[t] = Fbuf[a];
@@ -544,8 +544,13 @@ __global__ __launch_bounds__(256) void k_row_assemble2(const int* __restrict__ r
       fB += gB[t];
     }
   }
-  for (int p = lane; p < lenA; p += 32) val[rsA + p] = acc[sub][0][p];
-  for (int p = lane; p < lenB; p += 32) val[rsB + p] = acc[sub][1][p];
+  if (NT & 2) {
+    for (int p = lane; p < lenA; p += 32) __builtin_nontemporal_store(acc[sub][0][p], &val[rsA + p]);
+    for (int p = lane; p < lenB; p += 32) __builtin_nontemporal_store(acc[sub][1][p], &val[rsB + p]);
+  } else {
+    for (int p = lane; p < lenA; p += 32) val[rsA + p] = acc[sub][0][p];
+    for (int p = lane; p < lenB; p += 32) val[rsB + p] = acc[sub][1][p];
+  }
   if (lane == 0) {
     res[r0] = fA;
     if (two) res[r0 + 1] = fB;
@@ -560,8 +565,17 @@ static int launch_rows(fh_assembler_t as, fh_mat_t A, double* res, bool build) {
     hipLaunchKernelGGL((k_row_assemble<NC, true>), grid, block, 0, as->ctx->stream, A->d_rowptr, A->d_col, A->m, as->d_adj_ptr, as->d_adj_ei,
                        as->d_rowmap, as->d_elem_dof, as->nloc, nullptr, as->kstride, nullptr, nullptr, nullptr);
   else if (A->max_row <= 128 && as->ctx->assemble_rows2)
-    hipLaunchKernelGGL((k_row_assemble2<NC>), dim3(fh_div_up(A->m, 16)), block, 0, as->ctx->stream, A->d_rowptr, A->m, as->d_adj_ptr, as->d_rowmap,
-                       as->d_Kbuf, as->kstride, as->d_Fbuf, A->d_val, res);
+  {
+    const int nt = as->ctx->assemble_rows_nt;
+    const dim3 g2(fh_div_up(A->m, 16));
+#define FH_ROWS2(NTV) hipLaunchKernelGGL((k_row_assemble2_t<NC, NTV>), g2, block, 0, as->ctx->stream, A->d_rowptr, A->m, as->d_adj_ptr, as->d_rowmap, \
+                                          as->d_Kbuf, as->kstride, as->d_Fbuf, A->d_val, res)
+    if (nt == 1) FH_ROWS2(1);
+    else if (nt == 2) FH_ROWS2(2);
+    else if (nt == 3) FH_ROWS2(3);
+    else FH_ROWS2(0);
+#undef FH_ROWS2
+  }
   else
     hipLaunchKernelGGL((k_row_assemble<NC, false>), grid, block, 0, as->ctx->stream, A->d_rowptr, A->d_col, A->m, as->d_adj_ptr, as->d_adj_ei,
                        as->d_rowmap, as->d_elem_dof, as->nloc, as->d_Kbuf, as->kstride, as->d_Fbuf, A->d_val, res);
@@ -1545,6 +1559,25 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab ta
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]), "+v"(kv[4]), "+v"(kv[5]), "+v"(kv[6]), "+v"(kv[7]),
                      "+v"(kv[8]), "+v"(kv[9]), "+v"(kv[10]), "+v"(kv[11]), "+v"(kv[12]), "+v"(kv[13]));
         if (j < P.kstride) {
+          // non-temporal stores: the element rows are read once, by the row pass, long after they have left every cache (0.693 -> 0.663 ms;
+          // asm_debug bit 6 selects the plain stores for comparison)
+          if (!(P.debug & 64)) {
+            if (hrow == 0) {
+#pragma unroll
+              for (int p = 0; p < 14; p++) {
+                const size_t ro = ((size_t)(unsigned)__builtin_amdgcn_readlane((int)rhi, p) << 32) | (unsigned)__builtin_amdgcn_readlane((int)rlo, p);
+                const char* base = reinterpret_cast<const char*>(P.Kout) + ro;
+                asm volatile("global_store_dwordx2 %0, %1, %2 nt" ::"v"(joff), "v"(kv[p]), "s"(base) : "memory");
+              }
+            } else {
+#pragma unroll
+              for (int p = 0; p < 13; p++) {
+                const size_t ro = ((size_t)(unsigned)__builtin_amdgcn_readlane((int)rhi, 14 + p) << 32) | (unsigned)__builtin_amdgcn_readlane((int)rlo, 14 + p);
+                const char* base = reinterpret_cast<const char*>(P.Kout) + ro;
+                asm volatile("global_store_dwordx2 %0, %1, %2 nt" ::"v"(joff), "v"(kv[p]), "s"(base) : "memory");
+              }
+            }
+          } else
           if (hrow == 0) {
 #pragma unroll
             for (int p = 0; p < 14; p++) {
