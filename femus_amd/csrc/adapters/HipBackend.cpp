@@ -644,6 +644,8 @@ void LinearEquationSolverHip::MGSetLevel(LinearEquationSolver* LinSolver, const 
   hip_check(fh_mg_set_level(top->_mg, (int)_level, static_cast<HipMatrix*>(_KK)->handle(), _level ? P : nullptr, _level ? R : nullptr,
                             smoother, _richardsonScaleFactor, (int)npre, (int)npost),
             "MGSetLevel");
+  if (_level == 0 && _coordDim > 0 && !_coords.empty())
+    hip_check(fh_mg_set_coarse_coords(top->_mg, _coordDim, (int)(_coords.size() / (size_t)_coordDim), _coords.data()), "MGSetLevel: coordinates of the coarsest level");
   if (_level != 0)      // KSPGMRES with KSPGMRESSetRestart(_restart) and npre / npost iterations, or KSPRICHARDSON (LinearEquationSolverPetsc.cpp:238-250, 501-519)
     hip_check(fh_mg_set_level_solver(top->_mg, (int)_level, _levelSolverType == GMRES ? FH_LEVEL_GMRES : FH_LEVEL_RICHARDSON, _restart > 0 ? _restart : 30),
               "MGSetLevel: level solver");

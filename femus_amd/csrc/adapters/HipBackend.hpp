@@ -197,6 +197,10 @@ class LinearEquationSolverHip : public LinearEquationSolver {
   void MGSolve(const bool ksp_clean) override;
   void MGClear() override;
   void SetMulticolourSor(const bool on) { _multicolourSor = on; }     // SOR_PRECOND in colour order (faster on the device, other history)
+  // Backend-specific, optional: where the unknowns of THIS level's system lie (row-major [rows][dim], the rows of _KK in their order).  Given for
+  // the coarsest level, the exact coarse solve of the cycle (PCLU in the reference) dissects its dense problem with them (fh_mg_set_coarse_coords);
+  // inside FEMuS: the entries of Mesh::GetTopology()->_Sol[0..dim-1] at GetSolutionDof of every system row
+  void SetLevelCoordinates(const int dim, const std::vector<double>& xyz) { _coordDim = dim; _coords = xyz; }
   int last_iterations() const { return _its; }
   double last_residual() const { return _rnorm; }
   const std::vector<int>& bdc_index() const { return _bdcIndex; }
@@ -220,6 +224,8 @@ class LinearEquationSolverHip : public LinearEquationSolver {
   int _maxits = 1000, _restart = 30;
   // top-level (the object MGInit was called on) owns the cycle
   fh_mg_t _mg = nullptr;
+  int _coordDim = 0;
+  std::vector<double> _coords;
   fh_mg_t _one = nullptr;            // one-level solver object of Solve()
   unsigned _levelMax = 0;
   bool _needs_setup = true;

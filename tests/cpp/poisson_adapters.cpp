@@ -120,6 +120,16 @@ int main(int argc, char** argv) {
   LinSolver[top]->MGInit(MULTIPLICATIVE, nlev, GMRES);
   LinSolver[top]->SetTolerances(1e-12, 1e-50, 1e50, 40, 30);
   std::vector<unsigned> vars(1, 0);
+  {
+    // where the unknowns of the coarsest level lie (inside FEMuS: Mesh::GetTopology()->_Sol[0..dim-1]): lets the exact coarse solve dissect its
+    // dense problem when that is large enough (optional, backend-specific)
+    int d0, e0, n0, l0, o0[3], v0;
+    fh_mesh_info(msh[0], &d0, &e0, &n0, &l0, o0, &v0);
+    std::vector<int> ed0((size_t)e0 * l0), ff0((size_t)e0 * 2 * d0);
+    std::vector<double> xy0((size_t)n0 * d0);
+    fh_mesh_get(msh[0], ed0.data(), xy0.data(), ff0.data());
+    static_cast<LinearEquationSolverHip*>(LinSolver[0])->SetLevelCoordinates(d0, xy0);
+  }
   for (int i = 0; i < nlev; i++) LinSolver[i]->MGSetLevel(LinSolver[top], top, vars, PP[i], PP[i], i ? 2 : 1, i ? 2 : 0);
   LinSolver[top]->SetEpsZero();
   double res = 0;
