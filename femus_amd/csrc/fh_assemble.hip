@@ -52,6 +52,24 @@ struct fh_assembler_s {
   int kstride = 27;              // doubles per element row in d_Kbuf (nc, or 32 for HEX27/Q2: whole 64-byte lines per row)
   double* d_Fbuf = nullptr;      // [nadj]
   bool two_pass = false;
+  // fused cluster assembly (k_cluster_q2hex_sf + k_rows_partial): groups of 8 consecutive elements with one common local topology
+  // (the children of one coarse element: 125 macro nodes).  Plan = tables of the template + per-cluster destinations and maps.
+  bool fused = false;            // plan built and verified
+  bool kbuf_valid = false;       // the element-row buffer holds the matrices of the last assembly (the fused path does not write it)
+  int cl_ncl = 0, cl_nm = 0, cl_ns = 0, cl_nprow = 0;
+  size_t cl_npart = 0;           // entries of the partial-row buffer (without the sink)
+  unsigned *d_cl_dtab = nullptr, *d_cl_fdesc = nullptr, *d_cl_sinfo = nullptr;
+  unsigned short* d_cl_ovf = nullptr;
+  int *d_cl_vdst = nullptr, *d_cl_fdst = nullptr;      // [ncl][128]: >= 0 CSR offset / row of a complete row, bit 31: offset into the partial-row buffer
+  unsigned char *d_cl_map = nullptr, *d_cl_pmap = nullptr;
+  double* d_Pbuf = nullptr;
+  int *d_cl_prow = nullptr, *d_cl_padj_ptr = nullptr;
+  unsigned* d_cl_padj_off = nullptr;
+  unsigned char* d_cl_padj_len = nullptr;
+  // arguments of the last assembly (the element-wise Galerkin product re-creates the element rows from them when the fused path ran)
+  fh_vec_t last_sol = nullptr;
+  int last_source_kind = 0;
+  double last_params[2] = {1.0, 0.0};
   // optional fast path for AFFINE HEX27/Q2 elements (option assemble_affine): K_e = sum_ab det*B_ab * M_ab with the nine reference
   // matrices M_ab = sum_g w_g d_a phi_i d_b phi_j, B = J^-1 J^-T; curved elements keep the quadrature kernel
   int *d_aff_elems = nullptr, *d_gen_elems = nullptr;
@@ -1242,6 +1260,210 @@ __device__ __forceinline__ void sf_ld4(const double* p, double v[4]) {
   v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
 }
 
+// Phases A and stages 1-3 of the sum-factorised element matrix (shared by k_elem_q2hex_sf and the cluster kernel k_cluster_q2hex_sf): from the
+// element's nodes in xt (tensor order) to this lane's 3 x 3 block Kb over (a, a') and its source entry fsrc.  R is the wave's scratch region.
+template <int SRC, bool REGC>
+__device__ __forceinline__ void sf_element_blocks(const AsmParams& P, const SfTab& tab, const double* LCl, const int* LIl, const double (&rcA)[19], const double (&rcZ)[8],
+                                                  const double (&rcY)[16], const int esym, const int ens, const int ensT, const int eout, const double* xt, double* R,
+                                                  const int lane, double (&Kb)[3][3], double& fsrc) {
+  constexpr int DIM = 3;
+#define SF_I(r) LIl[(r) * 64]
+#define SF_C(r) LCl[(r) * 64]
+#define SF_CA(r) (REGC ? rcA[r] : SF_C(r))
+  double Dr[7];            // D_q (six entries) and the source weight at this lane's Gauss point
+  // ---- phase A: J_q by three contractions through LDS (U, V alias region R; one array per coordinate, every access is
+  //      conflict-free), then D_q; lane = Gauss point in tensor order.  Lanes beyond a stage's role count repeat its last role
+  //      (same values to the same addresses): no divergent branch in the element loop ----
+  {
+    double J[DIM][DIM] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, xg[DIM] = {0, 0, 0};
+    double* U = R;                     // [2][3][SF_US]: (sum_a l_a x, sum_a l'_a x) at [(b*3+c)*4 + q1]
+    double* V = R + 6 * SF_US;         // [3][3][SF_VS]: V, Veta, Vxi at [c*16 + q1 + 4 q2]
+    {
+      const double* xn = xt + SF_I(0);             // b*3 + c
+      double u[2][3] = {{0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const double la = SF_CA(a), da = SF_CA(3 + a);
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          const double x = xn[d * 28 + a * 9];
+          u[0][d] += la * x;
+          u[1][d] += da * x;
+        }
+      }
+      double* uo = U + SF_I(1);
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int d = 0; d < 3; d++) uo[(k * 3 + d) * SF_US] = u[k][d];
+    }
+    wave_lds_sync();
+    {
+      const double* ui = U + SF_I(2);              // c*4 + q1
+      double v[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        const double lb = SF_CA(6 + b), db = SF_CA(9 + b);
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          const double u0 = ui[d * SF_US + b * 12], u1 = ui[(3 + d) * SF_US + b * 12];
+          v[0][d] += lb * u0;     // V
+          v[1][d] += db * u0;     // Veta
+          v[2][d] += lb * u1;     // Vxi
+        }
+      }
+      double* vo = V + SF_I(3);
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int d = 0; d < 3; d++) vo[(k * 3 + d) * SF_VS] = v[k][d];
+    }
+    wave_lds_sync();
+    {
+      const double* vi = V + SF_I(4);              // q1 + 4 q2
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const double lc = SF_CA(12 + c), dc = SF_CA(15 + c);
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          const double v0 = vi[d * SF_VS + c * 16], v1 = vi[(3 + d) * SF_VS + c * 16], v2 = vi[(6 + d) * SF_VS + c * 16];
+          J[0][d] += lc * v2;
+          J[1][d] += lc * v1;
+          J[2][d] += dc * v0;
+          if (SRC != 0) xg[d] += lc * v0;
+        }
+      }
+    }
+    // cofactors Cf = det * J^-1 (the reference's Jacobian inverse, `elem_type_template` 3-D branch, without the division)
+    double Cf[DIM][DIM];
+    Cf[0][0] = -J[1][2] * J[2][1] + J[1][1] * J[2][2];
+    Cf[0][1] = J[0][2] * J[2][1] - J[0][1] * J[2][2];
+    Cf[0][2] = -J[0][2] * J[1][1] + J[0][1] * J[1][2];
+    Cf[1][0] = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    Cf[1][1] = -J[0][2] * J[2][0] + J[0][0] * J[2][2];
+    Cf[1][2] = J[0][2] * J[1][0] - J[0][0] * J[1][2];
+    Cf[2][0] = -J[1][1] * J[2][0] + J[1][0] * J[2][1];
+    Cf[2][1] = J[0][1] * J[2][0] - J[0][0] * J[2][1];
+    Cf[2][2] = -J[0][1] * J[1][0] + J[0][0] * J[1][1];
+    const double det = J[0][0] * Cf[0][0] + J[0][1] * Cf[1][0] + J[0][2] * Cf[2][0];
+    double fq;
+    if (SRC == 0) fq = P.p0;
+    else if (SRC == 1) fq = source_eval(P.source_kind, P.p0, P.p1, xg, DIM);
+    else {
+      double x4[4] = {xg[0], xg[1], xg[2], 0.0};
+      fq = P.p0 * fh_expr_device_eval(P.prog, P.nprog, P.prog_consts, x4);
+    }
+    const double wgauss = SF_CA(18);
+    const double sc = wgauss / det;
+    Dr[0] = sc * (Cf[0][0] * Cf[0][0] + Cf[1][0] * Cf[1][0] + Cf[2][0] * Cf[2][0]);
+    Dr[1] = sc * (Cf[0][0] * Cf[0][1] + Cf[1][0] * Cf[1][1] + Cf[2][0] * Cf[2][1]);
+    Dr[2] = sc * (Cf[0][0] * Cf[0][2] + Cf[1][0] * Cf[1][2] + Cf[2][0] * Cf[2][2]);
+    Dr[3] = sc * (Cf[0][1] * Cf[0][1] + Cf[1][1] * Cf[1][1] + Cf[2][1] * Cf[2][1]);
+    Dr[4] = sc * (Cf[0][1] * Cf[0][2] + Cf[1][1] * Cf[1][2] + Cf[2][1] * Cf[2][2]);
+    Dr[5] = sc * (Cf[0][2] * Cf[0][2] + Cf[1][2] * Cf[1][2] + Cf[2][2] * Cf[2][2]);
+    Dr[6] = det * wgauss * fq;
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int a2 = 0; a2 < 3; a2++) Kb[a][a2] = 0.0;
+  fsrc = 0.0;
+  if (!(P.debug & 1)) {
+    // ---- stage 1: contracts q3 on the FP64 matrix cores.  The Gauss points sit on the lanes as 16 q3 + 4 q1 + q2, which is
+    //      the B-operand layout of v_mfma_f64_4x4x4_4b (lane = 16 k + 4 block + column) with k = q3, block = q1, column = q2: D_q
+    //      is used where phase A left it.  A (lane = 16 k + 4 block + row) = the products l_c l_c', l_c l'_c', l'_c l'_c' at abscissa
+    //      k for four (c, c') slots (per-lane constants, the same for every block); the result lane 16 row + 4 q1 + q2 holds
+    //      e[slot][q1][q2].  Symmetric arrays (e0, e1, e3, e5) keep the six slots c <= c' (two instructions of four), e2 and e4 the
+    //      nine slots c*3 + c' (three); one more instruction contracts the source.  15 matrix instructions replace 100 vector ones,
+    //      the LDS round trip of D_q and a cross-lane sum over q3. ----
+    {
+      double* eo = R + eout;
+      constexpr int EB[6] = {0, 8 * SF_ES, 16 * SF_ES, 28 * SF_ES, 36 * SF_ES, 48 * SF_ES};
+#pragma unroll
+      for (int kk = 0; kk < 6; kk++) {
+        const int ng = (kk == 2 || kk == 4) ? 3 : 2;
+        const int a0 = (kk == 2 || kk == 4) ? 2 : kk == 5 ? 5 : 0;      // first constant vector: LL 0,1  LD 2,3,4  DD 5,6
+#pragma unroll
+        for (int g = 0; g < ng; g++) {
+          const double za = REGC ? rcZ[a0 + g] : SF_C(19 + a0 + g);
+          eo[EB[kk] + 4 * g * SF_ES] = __builtin_amdgcn_mfma_f64_4x4x4f64(za, Dr[kk], 0.0, 0, 0, 0);
+        }
+      }
+      const double zs = REGC ? rcZ[7] : SF_C(26);
+      R[SF_NE + lane] = __builtin_amdgcn_mfma_f64_4x4x4f64(zs, Dr[6], 0.0, 0, 0, 0);      // sE[c][q1*4 + q2], c = lane >> 4
+    }
+    wave_lds_sync();
+    // ---- source, second contraction: lane = (q1, b, c), contracts q2 ----
+    {
+      double s4[4];
+      sf_ld4(R + SF_NE + SF_I(10), s4);
+      R[SF_NE + 64 + SF_I(11)] = s4[0] * SF_C(43) + s4[1] * SF_C(44) + s4[2] * SF_C(45) + s4[3] * SF_C(46);
+    }
+    // ---- stages 2 and 3: lane = pair {(b,c), (b',c')}; per q1: contract q2 into the four G values, then add their part of the
+    //      3 x 3 block over (a, a').  The loop is NOT unrolled: one iteration's operands are all that is live. ----
+    {
+      const double* es = R + esym;      // symmetric arrays: slot of (min(c,c'), max(c,c'))
+      const double* en = R + ens;       // e2, e4: slot c*3 + c'
+      const double* eT = R + ensT;      //         slot c'*3 + c
+      double yLL[4], yLD[4], yDL[4], yDD[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        yLL[q] = REGC ? rcY[q] : SF_C(27 + q); yLD[q] = REGC ? rcY[4 + q] : SF_C(31 + q);
+        yDL[q] = REGC ? rcY[8 + q] : SF_C(35 + q); yDD[q] = REGC ? rcY[12 + q] : SF_C(39 + q);
+      }
+#pragma unroll 1
+      for (int q1 = 0; q1 < 4; q1++) {
+        double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;     // G for (l'l'), (l'l), (ll'), (ll)
+        {
+          double v0[4], v1[4], v2[4], v2T[4];
+          sf_ld4(es + 0 * SF_ES + q1 * 4, v0);
+          sf_ld4(es + 8 * SF_ES + q1 * 4, v1);
+          sf_ld4(en + 16 * SF_ES + q1 * 4, v2);
+          sf_ld4(eT + 16 * SF_ES + q1 * 4, v2T);
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            g0 += yLL[q] * v0[q];
+            g1 += yLD[q] * v1[q]; g1 += yLL[q] * v2[q];
+            g2 += yDL[q] * v1[q]; g2 += yLL[q] * v2T[q];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);         // the second half's operands are loaded after the first half is done with its own
+        {
+          double v3[4], v4[4], v4T[4], v5[4];
+          sf_ld4(es + 28 * SF_ES + q1 * 4, v3);
+          sf_ld4(en + 36 * SF_ES + q1 * 4, v4);
+          sf_ld4(eT + 36 * SF_ES + q1 * 4, v4T);
+          sf_ld4(es + 48 * SF_ES + q1 * 4, v5);
+#pragma unroll
+          for (int q = 0; q < 4; q++) { g3 += yDD[q] * v3[q]; g3 += yDL[q] * v4[q]; g3 += yLD[q] * v4T[q]; g3 += yLL[q] * v5[q]; }
+        }
+        const double l0 = tab.L[0][q1], l1 = tab.L[1][q1], l2 = tab.L[2][q1], d0 = tab.D[0][q1], d1 = tab.D[1][q1], d2 = tab.D[2][q1];
+        const double la[3] = {l0, l1, l2}, da[3] = {d0, d1, d2};
+        double u[3], v[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          u[a] = la[a] * g3 + da[a] * g1;
+          v[a] = la[a] * g2 + da[a] * g0;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int a2 = 0; a2 < 3; a2++) { Kb[a][a2] += la[a2] * u[a]; Kb[a][a2] += da[a2] * v[a]; }
+      }
+    }
+    wave_lds_sync();
+    {
+      double s4[4];
+      sf_ld4(R + SF_NE + 64 + SF_I(16), s4);
+      fsrc = s4[0] * SF_C(47) + s4[1] * SF_C(48) + s4[2] * SF_C(49) + s4[3] * SF_C(50);
+    }
+  }
+#undef SF_I
+#undef SF_C
+#undef SF_CA
+}
+
 template <int SRC, int NW, bool PAD>
 __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab tab, const double* __restrict__ lanec, const int* __restrict__ lanei) {
   constexpr int NC = 27, DIM = 3, KS = MF_KS;
@@ -1310,192 +1532,8 @@ __global__ __launch_bounds__(NW * 64) void k_elem_q2hex_sf(AsmParams P, SfTab ta
     const int sl_n = (lane < NC) ? (P.slot ? P.slot[(size_t)e_n * NC + nodeofl] : (idx + stride) * NC + nodeofl) : -1;
     const int dof_nn = P.elem_dof[(size_t)e_nn * P.nloc + nodeofl];
     const int e_nnn = elems[min(idx + 3 * stride, last)];
-    double Dr[7];            // D_q (six entries) and the source weight at this lane's Gauss point
-    // ---- phase A: J_q by three contractions through LDS (U, V alias region R; one array per coordinate, every access is
-    //      conflict-free), then D_q; lane = Gauss point in tensor order.  Lanes beyond a stage's role count repeat its last role
-    //      (same values to the same addresses): no divergent branch in the element loop ----
-    {
-      double J[DIM][DIM] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, xg[DIM] = {0, 0, 0};
-      double* U = R;                     // [2][3][SF_US]: (sum_a l_a x, sum_a l'_a x) at [(b*3+c)*4 + q1]
-      double* V = R + 6 * SF_US;         // [3][3][SF_VS]: V, Veta, Vxi at [c*16 + q1 + 4 q2]
-      {
-        const double* xn = xt + SF_I(0);             // b*3 + c
-        double u[2][3] = {{0, 0, 0}, {0, 0, 0}};
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-          const double la = SF_CA(a), da = SF_CA(3 + a);
-#pragma unroll
-          for (int d = 0; d < 3; d++) {
-            const double x = xn[d * 28 + a * 9];
-            u[0][d] += la * x;
-            u[1][d] += da * x;
-          }
-        }
-        double* uo = U + SF_I(1);
-#pragma unroll
-        for (int k = 0; k < 2; k++)
-#pragma unroll
-          for (int d = 0; d < 3; d++) uo[(k * 3 + d) * SF_US] = u[k][d];
-      }
-      wave_lds_sync();
-      {
-        const double* ui = U + SF_I(2);              // c*4 + q1
-        double v[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-#pragma unroll
-        for (int b = 0; b < 3; b++) {
-          const double lb = SF_CA(6 + b), db = SF_CA(9 + b);
-#pragma unroll
-          for (int d = 0; d < 3; d++) {
-            const double u0 = ui[d * SF_US + b * 12], u1 = ui[(3 + d) * SF_US + b * 12];
-            v[0][d] += lb * u0;     // V
-            v[1][d] += db * u0;     // Veta
-            v[2][d] += lb * u1;     // Vxi
-          }
-        }
-        double* vo = V + SF_I(3);
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-#pragma unroll
-          for (int d = 0; d < 3; d++) vo[(k * 3 + d) * SF_VS] = v[k][d];
-      }
-      wave_lds_sync();
-      {
-        const double* vi = V + SF_I(4);              // q1 + 4 q2
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          const double lc = SF_CA(12 + c), dc = SF_CA(15 + c);
-#pragma unroll
-          for (int d = 0; d < 3; d++) {
-            const double v0 = vi[d * SF_VS + c * 16], v1 = vi[(3 + d) * SF_VS + c * 16], v2 = vi[(6 + d) * SF_VS + c * 16];
-            J[0][d] += lc * v2;
-            J[1][d] += lc * v1;
-            J[2][d] += dc * v0;
-            if (SRC != 0) xg[d] += lc * v0;
-          }
-        }
-      }
-      // cofactors Cf = det * J^-1 (the reference's Jacobian inverse, `elem_type_template` 3-D branch, without the division)
-      double Cf[DIM][DIM];
-      Cf[0][0] = -J[1][2] * J[2][1] + J[1][1] * J[2][2];
-      Cf[0][1] = J[0][2] * J[2][1] - J[0][1] * J[2][2];
-      Cf[0][2] = -J[0][2] * J[1][1] + J[0][1] * J[1][2];
-      Cf[1][0] = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-      Cf[1][1] = -J[0][2] * J[2][0] + J[0][0] * J[2][2];
-      Cf[1][2] = J[0][2] * J[1][0] - J[0][0] * J[1][2];
-      Cf[2][0] = -J[1][1] * J[2][0] + J[1][0] * J[2][1];
-      Cf[2][1] = J[0][1] * J[2][0] - J[0][0] * J[2][1];
-      Cf[2][2] = -J[0][1] * J[1][0] + J[0][0] * J[1][1];
-      const double det = J[0][0] * Cf[0][0] + J[0][1] * Cf[1][0] + J[0][2] * Cf[2][0];
-      double fq;
-      if (SRC == 0) fq = P.p0;
-      else if (SRC == 1) fq = source_eval(P.source_kind, P.p0, P.p1, xg, DIM);
-      else {
-        double x4[4] = {xg[0], xg[1], xg[2], 0.0};
-        fq = P.p0 * fh_expr_device_eval(P.prog, P.nprog, P.prog_consts, x4);
-      }
-      const double wgauss = SF_CA(18);
-      const double sc = wgauss / det;
-      Dr[0] = sc * (Cf[0][0] * Cf[0][0] + Cf[1][0] * Cf[1][0] + Cf[2][0] * Cf[2][0]);
-      Dr[1] = sc * (Cf[0][0] * Cf[0][1] + Cf[1][0] * Cf[1][1] + Cf[2][0] * Cf[2][1]);
-      Dr[2] = sc * (Cf[0][0] * Cf[0][2] + Cf[1][0] * Cf[1][2] + Cf[2][0] * Cf[2][2]);
-      Dr[3] = sc * (Cf[0][1] * Cf[0][1] + Cf[1][1] * Cf[1][1] + Cf[2][1] * Cf[2][1]);
-      Dr[4] = sc * (Cf[0][1] * Cf[0][2] + Cf[1][1] * Cf[1][2] + Cf[2][1] * Cf[2][2]);
-      Dr[5] = sc * (Cf[0][2] * Cf[0][2] + Cf[1][2] * Cf[1][2] + Cf[2][2] * Cf[2][2]);
-      Dr[6] = det * wgauss * fq;
-    }
-    wave_lds_sync();
-    double Kb[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    double fsrc = 0.0;
-    if (!(P.debug & 1)) {
-      // ---- stage 1: contracts q3 on the FP64 matrix cores.  The Gauss points sit on the lanes as 16 q3 + 4 q1 + q2, which is
-      //      the B-operand layout of v_mfma_f64_4x4x4_4b (lane = 16 k + 4 block + column) with k = q3, block = q1, column = q2: D_q
-      //      is used where phase A left it.  A (lane = 16 k + 4 block + row) = the products l_c l_c', l_c l'_c', l'_c l'_c' at abscissa
-      //      k for four (c, c') slots (per-lane constants, the same for every block); the result lane 16 row + 4 q1 + q2 holds
-      //      e[slot][q1][q2].  Symmetric arrays (e0, e1, e3, e5) keep the six slots c <= c' (two instructions of four), e2 and e4 the
-      //      nine slots c*3 + c' (three); one more instruction contracts the source.  15 matrix instructions replace 100 vector ones,
-      //      the LDS round trip of D_q and a cross-lane sum over q3. ----
-      {
-        double* eo = R + eout;
-        constexpr int EB[6] = {0, 8 * SF_ES, 16 * SF_ES, 28 * SF_ES, 36 * SF_ES, 48 * SF_ES};
-#pragma unroll
-        for (int kk = 0; kk < 6; kk++) {
-          const int ng = (kk == 2 || kk == 4) ? 3 : 2;
-          const int a0 = (kk == 2 || kk == 4) ? 2 : kk == 5 ? 5 : 0;      // first constant vector: LL 0,1  LD 2,3,4  DD 5,6
-#pragma unroll
-          for (int g = 0; g < ng; g++) {
-            const double za = REGC ? rcZ[a0 + g] : SF_C(19 + a0 + g);
-            eo[EB[kk] + 4 * g * SF_ES] = __builtin_amdgcn_mfma_f64_4x4x4f64(za, Dr[kk], 0.0, 0, 0, 0);
-          }
-        }
-        const double zs = REGC ? rcZ[7] : SF_C(26);
-        R[SF_NE + lane] = __builtin_amdgcn_mfma_f64_4x4x4f64(zs, Dr[6], 0.0, 0, 0, 0);      // sE[c][q1*4 + q2], c = lane >> 4
-      }
-      wave_lds_sync();
-      // ---- source, second contraction: lane = (q1, b, c), contracts q2 ----
-      {
-        double s4[4];
-        sf_ld4(R + SF_NE + SF_I(10), s4);
-        R[SF_NE + 64 + SF_I(11)] = s4[0] * SF_C(43) + s4[1] * SF_C(44) + s4[2] * SF_C(45) + s4[3] * SF_C(46);
-      }
-      // ---- stages 2 and 3: lane = pair {(b,c), (b',c')}; per q1: contract q2 into the four G values, then add their part of the
-      //      3 x 3 block over (a, a').  The loop is NOT unrolled: one iteration's operands are all that is live. ----
-      {
-        const double* es = R + esym;      // symmetric arrays: slot of (min(c,c'), max(c,c'))
-        const double* en = R + ens;       // e2, e4: slot c*3 + c'
-        const double* eT = R + ensT;      //         slot c'*3 + c
-        double yLL[4], yLD[4], yDL[4], yDD[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          yLL[q] = REGC ? rcY[q] : SF_C(27 + q); yLD[q] = REGC ? rcY[4 + q] : SF_C(31 + q);
-          yDL[q] = REGC ? rcY[8 + q] : SF_C(35 + q); yDD[q] = REGC ? rcY[12 + q] : SF_C(39 + q);
-        }
-#pragma unroll 1
-        for (int q1 = 0; q1 < 4; q1++) {
-          double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;     // G for (l'l'), (l'l), (ll'), (ll)
-          {
-            double v0[4], v1[4], v2[4], v2T[4];
-            sf_ld4(es + 0 * SF_ES + q1 * 4, v0);
-            sf_ld4(es + 8 * SF_ES + q1 * 4, v1);
-            sf_ld4(en + 16 * SF_ES + q1 * 4, v2);
-            sf_ld4(eT + 16 * SF_ES + q1 * 4, v2T);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              g0 += yLL[q] * v0[q];
-              g1 += yLD[q] * v1[q]; g1 += yLL[q] * v2[q];
-              g2 += yDL[q] * v1[q]; g2 += yLL[q] * v2T[q];
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);         // the second half's operands are loaded after the first half is done with its own
-          {
-            double v3[4], v4[4], v4T[4], v5[4];
-            sf_ld4(es + 28 * SF_ES + q1 * 4, v3);
-            sf_ld4(en + 36 * SF_ES + q1 * 4, v4);
-            sf_ld4(eT + 36 * SF_ES + q1 * 4, v4T);
-            sf_ld4(es + 48 * SF_ES + q1 * 4, v5);
-#pragma unroll
-            for (int q = 0; q < 4; q++) { g3 += yDD[q] * v3[q]; g3 += yDL[q] * v4[q]; g3 += yLD[q] * v4T[q]; g3 += yLL[q] * v5[q]; }
-          }
-          const double l0 = tab.L[0][q1], l1 = tab.L[1][q1], l2 = tab.L[2][q1], d0 = tab.D[0][q1], d1 = tab.D[1][q1], d2 = tab.D[2][q1];
-          const double la[3] = {l0, l1, l2}, da[3] = {d0, d1, d2};
-          double u[3], v[3];
-#pragma unroll
-          for (int a = 0; a < 3; a++) {
-            u[a] = la[a] * g3 + da[a] * g1;
-            v[a] = la[a] * g2 + da[a] * g0;
-          }
-#pragma unroll
-          for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int a2 = 0; a2 < 3; a2++) { Kb[a][a2] += la[a2] * u[a]; Kb[a][a2] += da[a2] * v[a]; }
-        }
-      }
-      wave_lds_sync();
-      {
-        double s4[4];
-        sf_ld4(R + SF_NE + 64 + SF_I(16), s4);
-        fsrc = s4[0] * SF_C(47) + s4[1] * SF_C(48) + s4[2] * SF_C(49) + s4[3] * SF_C(50);
-      }
-    }
+    double Kb[3][3], fsrc;
+    sf_element_blocks<SRC, REGC>(P, tab, LCl, LIl, rcA, rcZ, rcY, esym, ens, ensT, eout, xt, R, lane, Kb, fsrc);
     wave_lds_sync();          // every lane is done with e: reuse it as the staging Ks[27][29], rows AND columns in tensor order
     double* Ks = R;
     {
@@ -1653,6 +1691,531 @@ static int launch_sf(fh_assembler_t as, const AsmParams& P, int nw) {
   if (P.source_kind == 4) return launch_sf_src<2, false>(as, P, nw);
   if (P.source_kind != 0) return launch_sf_src<1, false>(as, P, nw);
   return launch_sf_src<0, false>(as, P, nw);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// FUSED CLUSTER ASSEMBLY (round 4; default where the mesh offers it).  The two-pass design writes every element row to HBM (6.9 kB per
+// element) and reads it back 0.7 ms later: 3.6 GB of the 5.7 GB the assembly moves.  Here a workgroup of eight waves owns a CLUSTER of
+// eight elements that share one local topology -- the eight children of a coarse element, which the refinement numbers consecutively
+// (MeshRefinement.cpp:240-294): 125 "macro" nodes, 4913 distinct (row, column) pairs.  Every wave computes one element matrix exactly as
+// k_elem_q2hex_sf does and leaves it in its LDS staging; after a workgroup barrier the 512 threads sum, per macro entry, the 1 / 2 / 4 / 8
+// element entries that meet there IN ASCENDING ELEMENT ORDER straight out of the eight stagings and store
+//   * rows all of whose elements lie in the cluster (interior macro nodes, and boundary nodes of the domain): once, into the CSR row, in
+//     CSR order (a one-byte map per entry, built on the device when the plan is made) -- these rows never visit HBM twice;
+//   * the other macro rows: packed (template order, residual entry behind them) into the partial-row buffer, which the second pass
+//     k_rows_partial sums per CSR row in ascending cluster order (= ascending element order) and writes once.
+// Element entries are the same numbers the two-pass path produces; the sums differ from the reference's strictly sequential element order
+// only in their grouping ((e0 + e1) + (e2 + e3) across two clusters instead of ((e0 + e1) + e2) + e3), i.e. by rounding.  Deterministic: no
+// atomics, fixed order.  Nothing about the topology is assumed: the template is READ from cluster 0 (first-appearance numbering of its
+// 8 x 27 nodes in tensor order) and every other cluster must reproduce it, otherwise the assembler keeps the two-pass path.
+// Addresses inside the workgroup's LDS are 14-bit double indices; a descriptor holds the first address, the second (or the index of a
+// zero cell) and, for the 49 entries with four or eight contributions, the start of an overflow list.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int CL_NE = 8;                         // elements per cluster = waves per workgroup
+constexpr int CL_T = CL_NE * 64;                 // threads
+constexpr int CL_SPT = 10;                       // slots (macro entries) per thread
+constexpr int CL_NS_MAX = CL_T * CL_SPT;         // 5120 >= 4913
+constexpr int CL_NM_MAX = 128;                   // macro nodes (125), padded
+constexpr int CL_NOVF = 512;                     // overflow addresses
+constexpr int CL_ZC = SF_TAB + CL_NE * SF_WAVE;  // a zero cell (second operand of single-contribution entries)
+constexpr size_t cl_lds_bytes() { return (size_t)(CL_ZC + 2) * sizeof(double) + (size_t)CL_NS_MAX * 4 + CL_NM_MAX * 4 * 3 + CL_NOVF * 2; }
+static_assert(CL_ZC + 2 < (1 << 14), "cluster kernel: LDS double indices fit 14 bits");
+static_assert(cl_lds_bytes() <= 160 * 1024, "cluster kernel: LDS budget");
+
+struct ClParams {
+  int ncl, ns, nm;
+  const unsigned* dtab;        // [ns] descriptor of template entry off[r] + j
+  const unsigned* fdesc;       // [128] descriptor of the residual entry of macro row r
+  const unsigned short* ovf;   // [CL_NOVF]
+  const unsigned* sinfo;       // [CL_SPT][CL_T]: r | p << 7 | off[r] << 14 of slot tid + CL_T * i
+  const int* vdst;             // [ncl][128]
+  const int* fdst;             // [ncl][128]
+  const uint4* map;            // [ncl][CL_T]: byte i = template entry of slot tid + CL_T * i inside its row
+  double* Pbuf;
+  double* val;
+  double* res;
+};
+
+__device__ __forceinline__ double cl_sum(const double* S, const unsigned short* ovf, unsigned d) {
+  const unsigned a0 = d & 0x3fffu, a1f = (d >> 14) & 0x3fffu, nx = d >> 28;
+  unsigned a1 = a1f;
+  if (nx) a1 = ovf[a1f];
+  double v = S[a0] + S[a1];
+  for (unsigned k = 1; k < nx; k++) v += S[ovf[a1f + k]];
+  return v;
+}
+
+template <int SRC>
+__global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab tab, const double* __restrict__ lanec, const int* __restrict__ lanei, ClParams C) {
+  constexpr int NC = 27, DIM = 3, KS = MF_KS, NW = CL_NE;
+  constexpr bool REGC = true;
+  extern __shared__ __attribute__((aligned(16))) double sf_smem[];
+  double* SFl = sf_smem;
+  int* SFi = reinterpret_cast<int*>(SFl + SF_NLC * 64);
+  unsigned* dtab = reinterpret_cast<unsigned*>(sf_smem + CL_ZC + 2);
+  unsigned* fdesc = dtab + CL_NS_MAX;
+  int* rb = reinterpret_cast<int*>(fdesc + CL_NM_MAX);
+  int* fb = rb + CL_NM_MAX;
+  unsigned short* ovf = reinterpret_cast<unsigned short*>(fb + CL_NM_MAX);
+  const int tid = threadIdx.x;
+  for (int k = tid; k < SF_NLC * 64; k += CL_T) SFl[k] = lanec[k];
+  for (int k = tid; k < SF_NLI * 64; k += CL_T) SFi[k] = lanei[k];
+  for (int k = tid; k < C.ns; k += CL_T) dtab[k] = C.dtab[k];
+  if (tid < CL_NM_MAX) fdesc[tid] = C.fdesc[tid];
+  ovf[tid] = C.ovf[tid];
+  if (tid < 2) sf_smem[CL_ZC + tid] = 0.0;
+  __syncthreads();
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double* xt = SFl + SF_TAB + wave * SF_WAVE;
+  double* R = xt + SF_XT;
+  const double* LCl = SFl + lane;
+  const int* LIl = SFi + lane;
+  double rcA[19], rcZ[8], rcY[16];
+#pragma unroll
+  for (int r = 0; r < 19; r++) rcA[r] = lanec[r * 64 + lane];
+#pragma unroll
+  for (int r = 0; r < 8; r++) rcZ[r] = lanec[(19 + r) * 64 + lane];
+#pragma unroll
+  for (int r = 0; r < 16; r++) rcY[r] = lanec[(27 + r) * 64 + lane];
+  const int esym = lanei[5 * 64 + lane], ens = lanei[6 * 64 + lane], ensT = lanei[15 * 64 + lane], based = lanei[7 * 64 + lane], basem = lanei[8 * 64 + lane];
+  const int eout = (lane >> 4) * SF_ES + (lane & 15);
+  const bool diag = lanei[9 * 64 + lane] != 0;
+  const int nodeofl = lanei[14 * 64 + lane];           // node of tensor index min(lane, 26)
+  unsigned sinfo[CL_SPT];
+#pragma unroll
+  for (int i = 0; i < CL_SPT; i++) sinfo[i] = C.sinfo[i * CL_T + tid];
+  const int cstride = gridDim.x;
+  int cl = blockIdx.x;
+  if (cl >= C.ncl) return;
+  const int lastc = C.ncl - 1;
+  {
+    const int dof = P.elem_dof[(size_t)(cl * NW + wave) * P.nloc + nodeofl];
+    if (lane < NC) {
+      xt[lane] = P.coords[(size_t)dof * DIM];
+      xt[28 + lane] = P.coords[(size_t)dof * DIM + 1];
+      xt[56 + lane] = P.coords[(size_t)dof * DIM + 2];
+      xt[84 + lane] = P.sol ? P.sol[dof] : 0.0;
+    }
+  }
+  int dof_n = P.elem_dof[(size_t)(min(cl + cstride, lastc) * NW + wave) * P.nloc + nodeofl];
+  const int tm = tid & (CL_NM_MAX - 1);
+  wave_lds_sync();
+#pragma unroll 1
+  for (; cl < C.ncl; cl += cstride) {
+    // ---- prefetch (dependent gathers): coordinates / solution of the wave's next element, node ids of the one after ----
+    const int cl_nn = min(cl + 2 * cstride, lastc);
+    const double nx0 = P.coords[(size_t)dof_n * DIM], nx1 = P.coords[(size_t)dof_n * DIM + 1], nx2 = P.coords[(size_t)dof_n * DIM + 2];
+    const double nu = P.sol ? P.sol[dof_n] : 0.0;
+    const int dof_nn = P.elem_dof[(size_t)(cl_nn * NW + wave) * P.nloc + nodeofl];
+    // this cluster's destinations and maps: consumed after the element matrix, which hides the round trip
+    const int vd_cur = C.vdst[(size_t)cl * CL_NM_MAX + tm], fd_cur = C.fdst[(size_t)cl * CL_NM_MAX + tm];
+    const uint4 mp_cur = C.map[(size_t)cl * CL_T + tid];
+    double Kb[3][3], fsrc;
+    sf_element_blocks<SRC, REGC>(P, tab, LCl, LIl, rcA, rcZ, rcY, esym, ens, ensT, eout, xt, R, lane, Kb, fsrc);
+    wave_lds_sync();          // every lane is done with e: reuse it as the staging Ks[27][29], rows AND columns in tensor order
+    double* Ks = R;
+    {
+      double* kd = Ks + based;       // p * KS + p2
+      double* km = Ks + basem;       // p2 * KS + p
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int a2 = 0; a2 < 3; a2++) {
+          const double v = (a2 < a) ? (diag ? Kb[a2][a] : Kb[a][a2]) : Kb[a][a2];
+          kd[a * 9 * KS + a2 * 9] = v;
+          km[a2 * 9 * KS + a * 9] = v;
+        }
+    }
+    wave_lds_sync();
+    double ku = 0.0;
+    if (P.sol) {              // residual: (K_e u)_t for tensor row t = lane & 31, half of the columns each
+      const int h = lane >> 5;
+      const double* kr = Ks + min(lane & 31, NC - 1) * KS + h * 14;
+      const double* ur = xt + 84 + h * 14;
+#pragma unroll
+      for (int g = 0; g < 14; g++) {
+        const bool live = g < 13 || h == 0;
+        const double v = live ? kr[g] : 0.0, uu = live ? ur[g] : 0.0;
+        ku += v * uu;
+      }
+      ku += __shfl_xor(ku, 32, 64);
+    }
+    Ks[min(lane & 31, NC - 1) * KS + NC] = -(ku + fsrc);   // residual entry of tensor row t = lane & 31 in the staging's spare column (both halves hold the same value; lanes beyond 26 repeat row 26)
+    if (lane < NC) {          // the next element's nodes
+      xt[lane] = nx0;
+      xt[28 + lane] = nx1;
+      xt[56 + lane] = nx2;
+      xt[84 + lane] = nu;
+    }
+    if (tid < CL_NM_MAX) {
+      rb[tid] = vd_cur;
+      fb[tid] = fd_cur;
+    }
+    __syncthreads();
+    if (!(P.debug & 2)) {
+      const double* S = sf_smem;
+      const unsigned mw[4] = {mp_cur.x, mp_cur.y, mp_cur.z, mp_cur.w};
+#pragma unroll
+      for (int i = 0; i < CL_SPT; i++) {
+        const unsigned si = sinfo[i];
+        const int r = si & 127, p = (si >> 7) & 127, off = si >> 14;
+        const int vb = rb[r];
+        const int j = (mw[i >> 2] >> (8 * (i & 3))) & 255;
+        const double v = cl_sum(S, ovf, dtab[off + j]);
+        double* dst = (vb < 0 ? C.Pbuf + (size_t)(vb & 0x7fffffff) : C.val + (size_t)vb) + p;
+        __builtin_nontemporal_store(v, dst);
+      }
+      if (wave < CL_NM_MAX / 64) {
+        const double v = cl_sum(S, ovf, fdesc[tid]);
+        const int vb = fb[tid];
+        double* dst = vb < 0 ? C.Pbuf + (size_t)(vb & 0x7fffffff) : C.res + (size_t)vb;
+        *dst = v;
+      }
+    }
+    __syncthreads();          // the stagings are the next elements' scratch, rb / fb the next cluster's
+    dof_n = dof_nn;
+  }
+}
+
+// Second pass of the fused assembly: every CSR row that is not complete inside one cluster sums its partial macro rows (ascending cluster
+// order) in LDS and is written once; rows no element touches are written as zeros.  One 32-lane group per row.
+__global__ __launch_bounds__(256) void k_rows_partial(int nprow, const int* __restrict__ prow, const int* __restrict__ padj_ptr, const unsigned* __restrict__ padj_off,
+                                                      const unsigned char* __restrict__ padj_len, const unsigned char* __restrict__ pmap, const double* __restrict__ Pbuf,
+                                                      const int* __restrict__ rowptr, double* __restrict__ val, double* __restrict__ res) {
+  __shared__ double acc[8][128];
+  const int sub = threadIdx.x >> 5, lane = threadIdx.x & 31;
+  const int k = blockIdx.x * 8 + sub;
+  if (k >= nprow) return;
+  const int g = prow[k];
+  const int a0 = padj_ptr[k], a1 = padj_ptr[k + 1];
+  const int rs = rowptr[g], len = rowptr[g + 1] - rs;
+#pragma unroll
+  for (int q = 0; q < 4; q++) acc[sub][lane + 32 * q] = 0.0;
+  double f = 0.0;
+  constexpr int RB = 2;
+  for (int ab = a0; ab < a1; ab += RB) {
+    double v[RB][4], fv[RB];
+    int m[RB][4];
+#pragma unroll
+    for (int t = 0; t < RB; t++) {
+      const int a = ab + t;
+      const bool on = a < a1;
+      const size_t off = on ? padj_off[a] : 0;
+      const int L = on ? padj_len[a] : 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int e = lane + 32 * q;
+        const bool live = e < L;
+        v[t][q] = live ? __builtin_nontemporal_load(&Pbuf[off + e]) : 0.0;
+        m[t][q] = live ? pmap[off + e] : -1;
+      }
+      fv[t] = (on && lane == 0) ? __builtin_nontemporal_load(&Pbuf[off + L]) : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < RB; t++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (m[t][q] >= 0) acc[sub][m[t][q]] += v[t][q];
+      f += fv[t];
+    }
+  }
+  for (int p = lane; p < len; p += 32) val[rs + p] = acc[sub][p];
+  if (lane == 0) res[g] = f;
+}
+
+// Plan construction on the device: the byte maps of one cluster per workgroup.  Complete rows: for CSR position p the template entry whose
+// macro column carries the global column there; partial rows: identity in the cluster kernel's map, and in pmap the CSR position of every
+// packed entry.  An entry that cannot be placed raises err (the assembler then keeps the two-pass path).
+__global__ __launch_bounds__(256) void k_cluster_maps(int ncl, int ns, int nm, const int* __restrict__ cdof, const unsigned char* __restrict__ srow, const unsigned short* __restrict__ roff,
+                                                      const unsigned char* __restrict__ tcol, const int* __restrict__ vdst, int m, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                      unsigned char* __restrict__ map, unsigned char* __restrict__ pmap, int* __restrict__ err) {
+  __shared__ int cd[CL_NM_MAX];
+  const int c = blockIdx.x;
+  if (threadIdx.x < CL_NM_MAX) cd[threadIdx.x] = threadIdx.x < nm ? cdof[(size_t)c * CL_NM_MAX + threadIdx.x] : -1;
+  __syncthreads();
+  for (int s = threadIdx.x; s < CL_NS_MAX; s += 256) {
+    const size_t mi = ((size_t)c * CL_T + (s % CL_T)) * 16 + s / CL_T;
+    if (s >= ns) { map[mi] = 0; continue; }
+    const int r = srow[s], o = roff[r], p = s - o, len = roff[r + 1] - o;
+    const int vb = vdst[(size_t)c * CL_NM_MAX + r];
+    if (vb >= 0) {                       // complete row: CSR position p holds global column h
+      const int h = col[vb + p];
+      int j = -1;
+      for (int jj = 0; jj < len; jj++)
+        if (cd[tcol[o + jj]] == h) j = jj;
+      if (j < 0) { atomicExch(err, 1); j = 0; }
+      map[mi] = (unsigned char)j;
+    } else {
+      map[mi] = (unsigned char)p;
+      const int g = cd[r];
+      if (g < m) {                       // partial row of the matrix: where does packed entry p go in CSR row g
+        const int target = cd[tcol[s]];
+        const int rs = rowptr[g];
+        int lo = rs, hi = rowptr[g + 1] - 1, pos = -1;
+        while (lo <= hi) {
+          const int mid = lo + ((hi - lo) >> 1);
+          const int cc = col[mid];
+          if (cc == target) { pos = mid - rs; break; }
+          if (cc < target) lo = mid + 1; else hi = mid - 1;
+        }
+        if (pos < 0 || pos > 127) { atomicExch(err, 1); pos = 0; }
+        pmap[(size_t)(vb & 0x7fffffff) + p] = (unsigned char)pos;
+      }
+    }
+  }
+}
+
+
+// Plan of the fused cluster assembly (see k_cluster_q2hex_sf).  Host: template from cluster 0, verification of every cluster, completeness of
+// every (cluster, macro row), offsets of the partial rows, the lists of the second pass -- O(nel * 27) integer work; device: the byte maps.
+// Returns 0 and leaves as->fused false when the mesh does not offer the structure.
+static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof, const std::vector<int>& aptr) {
+  fh_ctx_t ctx = as->ctx;
+  const int nel = as->nel, nloc = as->nloc, m = A->m, KS = MF_KS;
+  int nodeof[27];                        // node of tensor index a*9 + b*3 + c (the staging's row / column order)
+  for (int n = 0; n < 27; n++) nodeof[(fhfe::xc(as->geom, n, 0) + 1) * 9 + (fhfe::xc(as->geom, n, 1) + 1) * 3 + fhfe::xc(as->geom, n, 2) + 1] = n;
+  if (nel < CL_NE || nel % CL_NE || A->max_row > 128 || A->h_rowptr.empty()) return 0;
+  const int ncl = nel / CL_NE;
+  // template: first-appearance numbering of the 8 x 27 nodes of cluster 0, tensor order inside an element
+  int tm[CL_NE][27], nm = 0;
+  {
+    std::vector<int> seen;
+    for (int e = 0; e < CL_NE; e++)
+      for (int t = 0; t < 27; t++) {
+        const int g = elem_dof[(size_t)e * nloc + nodeof[t]];
+        int k = -1;
+        for (int q = 0; q < (int)seen.size(); q++)
+          if (seen[q] == g) k = q;
+        if (k < 0) { k = (int)seen.size(); seen.push_back(g); }
+        tm[e][t] = k;
+      }
+    nm = (int)seen.size();
+  }
+  if (nm > CL_NM_MAX - 1) return 0;
+  int first_e[CL_NM_MAX], first_t[CL_NM_MAX], tcnt[CL_NM_MAX];
+  for (int k = 0; k < nm; k++) { first_e[k] = -1; tcnt[k] = 0; }
+  for (int e = 0; e < CL_NE; e++) {
+    bool dup[CL_NM_MAX] = {};
+    for (int t = 0; t < 27; t++) {
+      const int k = tm[e][t];
+      if (dup[k]) return 0;                      // a node twice in one element
+      dup[k] = true;
+      if (first_e[k] < 0) { first_e[k] = e; first_t[k] = t; }
+      tcnt[k]++;
+    }
+  }
+  // every cluster reproduces the template with 'nm' distinct nodes
+  std::vector<int> cdof((size_t)ncl * CL_NM_MAX, -1);
+  {
+    std::vector<int> stamp(as->nnode, -1);
+    for (int c = 0; c < ncl; c++) {
+      int* cd = &cdof[(size_t)c * CL_NM_MAX];
+      for (int k = 0; k < nm; k++) {
+        const int g = elem_dof[(size_t)(c * CL_NE + first_e[k]) * nloc + nodeof[first_t[k]]];
+        if (stamp[g] == c) return 0;             // two macro nodes, one mesh node
+        stamp[g] = c;
+        cd[k] = g;
+      }
+      for (int e = 0; e < CL_NE; e++)
+        for (int t = 0; t < 27; t++)
+          if (elem_dof[(size_t)(c * CL_NE + e) * nloc + nodeof[t]] != cd[tm[e][t]]) return 0;
+    }
+  }
+  // template rows: macro columns ascending; contributions in ascending element order
+  std::vector<unsigned short> roff(CL_NM_MAX + 1, 0);
+  std::vector<unsigned char> tcol, srow;
+  std::vector<unsigned> dtab, fdesc(CL_NM_MAX, (unsigned)CL_ZC | ((unsigned)CL_ZC << 14));
+  std::vector<unsigned short> ovf;
+  auto stag = [&](int e, int tr, int tc) { return (unsigned)(SF_TAB + e * SF_WAVE + SF_XT + tr * KS + tc); };
+  auto pack = [&](const std::vector<unsigned>& ad, unsigned* out) -> bool {
+    if (ad.size() == 1) *out = ad[0] | ((unsigned)CL_ZC << 14);
+    else if (ad.size() == 2) *out = ad[0] | (ad[1] << 14);
+    else {
+      if (ad.size() > 8 || ovf.size() + ad.size() - 1 > (size_t)CL_NOVF) return false;
+      *out = ad[0] | ((unsigned)ovf.size() << 14) | ((unsigned)(ad.size() - 1) << 28);
+      for (size_t q = 1; q < ad.size(); q++) ovf.push_back((unsigned short)ad[q]);
+    }
+    return true;
+  };
+  int tof_e[CL_NE][CL_NM_MAX];          // tensor index of macro node k in element e, -1 if absent
+  for (int e = 0; e < CL_NE; e++) {
+    for (int k = 0; k < nm; k++) tof_e[e][k] = -1;
+    for (int t = 0; t < 27; t++) tof_e[e][tm[e][t]] = t;
+  }
+  for (int r = 0; r < nm; r++) {
+    bool has[CL_NM_MAX] = {};
+    for (int e = 0; e < CL_NE; e++)
+      if (tof_e[e][r] >= 0)
+        for (int t = 0; t < 27; t++) has[tm[e][t]] = true;
+    for (int k = 0; k < nm; k++)
+      if (has[k]) {
+        std::vector<unsigned> ad;
+        for (int e = 0; e < CL_NE; e++)
+          if (tof_e[e][r] >= 0 && tof_e[e][k] >= 0) ad.push_back(stag(e, tof_e[e][r], tof_e[e][k]));
+        unsigned d;
+        if (!pack(ad, &d)) return 0;
+        dtab.push_back(d);
+        tcol.push_back((unsigned char)k);
+        srow.push_back((unsigned char)r);
+      }
+    roff[r + 1] = (unsigned short)dtab.size();
+    if (roff[r + 1] - roff[r] > 127) return 0;
+    std::vector<unsigned> ad;
+    for (int e = 0; e < CL_NE; e++)
+      if (tof_e[e][r] >= 0) ad.push_back(stag(e, tof_e[e][r], 27));
+    if (!pack(ad, &fdesc[r])) return 0;
+  }
+  for (int r = nm; r < CL_NM_MAX; r++) roff[r + 1] = roff[nm];
+  const int ns = (int)dtab.size();
+  if (ns > CL_NS_MAX || ns >= (1 << 13)) return 0;
+  ovf.resize(CL_NOVF, (unsigned short)CL_ZC);
+  std::vector<unsigned> sinfo((size_t)CL_SPT * CL_T);
+  for (int i = 0; i < CL_SPT; i++)
+    for (int t = 0; t < CL_T; t++) {
+      const int sidx = t + CL_T * i;
+      if (sidx < ns) {
+        const int r = srow[sidx];
+        sinfo[(size_t)i * CL_T + t] = (unsigned)r | ((unsigned)(sidx - roff[r]) << 7) | ((unsigned)roff[r] << 14);
+      } else
+        sinfo[(size_t)i * CL_T + t] = CL_NM_MAX - 1;         // dummy row: destination = sink
+    }
+  // destinations: a macro row is complete when all elements around its node lie in this cluster and the CSR row has exactly its columns
+  std::vector<int> vdst((size_t)ncl * CL_NM_MAX), fdst((size_t)ncl * CL_NM_MAX);
+  std::vector<char> complete(m, 0);
+  size_t npart = 0;
+  for (int c = 0; c < ncl; c++)
+    for (int r = 0; r < nm; r++) {
+      const int g = cdof[(size_t)c * CL_NM_MAX + r], len = roff[r + 1] - roff[r];
+      if (g < m && aptr[g + 1] - aptr[g] == tcnt[r] && A->h_rowptr[g + 1] - A->h_rowptr[g] == len) complete[g] = 1;
+      else if (g < m) npart += (size_t)len + 1;
+    }
+  if (npart + 128 >= ((size_t)1 << 31)) return 0;
+  const unsigned sink = 0x80000000u | (unsigned)npart;
+  std::vector<int> pcnt(m + 1, 0);
+  {
+    size_t poff = 0;
+    for (int c = 0; c < ncl; c++) {
+      for (int r = 0; r < CL_NM_MAX; r++) {
+        const size_t q = (size_t)c * CL_NM_MAX + r;
+        const int g = r < nm ? cdof[q] : -1;
+        if (g < 0 || g >= m) { vdst[q] = (int)sink; fdst[q] = (int)sink; continue; }
+        const int len = roff[r + 1] - roff[r];
+        if (complete[g]) { vdst[q] = A->h_rowptr[g]; fdst[q] = g; }
+        else {
+          vdst[q] = (int)(0x80000000u | (unsigned)poff);
+          fdst[q] = (int)(0x80000000u | (unsigned)(poff + len));
+          poff += (size_t)len + 1;
+          pcnt[g + 1]++;
+        }
+      }
+    }
+  }
+  // second pass: rows that are not complete (rows no element touches are written as zeros there), their partial rows in ascending cluster order
+  std::vector<int> prow, pptr(1, 0), rowk(m, -1);
+  for (int g = 0; g < m; g++)
+    if (!complete[g]) {
+      rowk[g] = (int)prow.size();
+      prow.push_back(g);
+      pptr.push_back(pptr.back() + pcnt[g + 1]);
+    }
+  std::vector<unsigned> padj_off(std::max<size_t>(pptr.back(), 1));
+  std::vector<unsigned char> padj_len(std::max<size_t>(pptr.back(), 1));
+  {
+    std::vector<int> cur(pptr.begin(), pptr.end() - 1);
+    for (int c = 0; c < ncl; c++)
+      for (int r = 0; r < nm; r++) {
+        const size_t q = (size_t)c * CL_NM_MAX + r;
+        const int g = cdof[q];
+        if (g < m && !complete[g]) {
+          const int a = cur[rowk[g]]++;
+          padj_off[a] = (unsigned)vdst[q] & 0x7fffffffu;
+          padj_len[a] = (unsigned char)(roff[r + 1] - roff[r]);
+        }
+      }
+  }
+  auto up = [&](void** d, const void* h, size_t bytes) -> int {
+    FH_CHECK_HIP(hipMalloc(d, bytes ? bytes : 8));
+    if (bytes) FH_CHECK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+    return 0;
+  };
+  FH_TRY(up((void**)&as->d_cl_dtab, dtab.data(), dtab.size() * 4));
+  FH_TRY(up((void**)&as->d_cl_fdesc, fdesc.data(), fdesc.size() * 4));
+  FH_TRY(up((void**)&as->d_cl_ovf, ovf.data(), ovf.size() * 2));
+  FH_TRY(up((void**)&as->d_cl_sinfo, sinfo.data(), sinfo.size() * 4));
+  FH_TRY(up((void**)&as->d_cl_vdst, vdst.data(), vdst.size() * 4));
+  FH_TRY(up((void**)&as->d_cl_fdst, fdst.data(), fdst.size() * 4));
+  FH_TRY(up((void**)&as->d_cl_prow, prow.data(), prow.size() * 4));
+  FH_TRY(up((void**)&as->d_cl_padj_ptr, pptr.data(), pptr.size() * 4));
+  FH_TRY(up((void**)&as->d_cl_padj_off, padj_off.data(), padj_off.size() * 4));
+  FH_TRY(up((void**)&as->d_cl_padj_len, padj_len.data(), padj_len.size()));
+  FH_CHECK_HIP(hipMalloc(&as->d_cl_map, (size_t)ncl * CL_T * 16));
+  FH_CHECK_HIP(hipMalloc(&as->d_cl_pmap, npart + 128));
+  FH_CHECK_HIP(hipMemset(as->d_cl_pmap, 0, npart + 128));
+  FH_CHECK_HIP(hipMalloc(&as->d_Pbuf, (npart + 128) * sizeof(double)));
+  FH_CHECK_HIP(hipMemset(as->d_Pbuf, ctx->debug_poison ? 0xFF : 0, (npart + 128) * sizeof(double)));
+  {
+    int *d_cdof = nullptr, *d_err = nullptr;
+    unsigned char *d_srow = nullptr, *d_tcol = nullptr;
+    unsigned short* d_roff = nullptr;
+    FH_TRY(up((void**)&d_cdof, cdof.data(), cdof.size() * 4));
+    FH_TRY(up((void**)&d_srow, srow.data(), srow.size()));
+    FH_TRY(up((void**)&d_tcol, tcol.data(), tcol.size()));
+    FH_TRY(up((void**)&d_roff, roff.data(), roff.size() * 2));
+    const int zero = 0;
+    FH_TRY(up((void**)&d_err, &zero, sizeof(int)));
+    hipLaunchKernelGGL(k_cluster_maps, dim3(ncl), dim3(256), 0, ctx->stream, ncl, ns, nm, d_cdof, d_srow, d_roff, d_tcol, as->d_cl_vdst, m, A->d_rowptr, A->d_col, as->d_cl_map,
+                       as->d_cl_pmap, d_err);
+    FH_CHECK_HIP(hipGetLastError());
+    int err = 0;
+    FH_CHECK_HIP(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    for (void* q : {(void*)d_cdof, (void*)d_srow, (void*)d_tcol, (void*)d_roff, (void*)d_err}) hipFree(q);
+    if (err) {
+      FH_TRACE("fh_assembler_create: cluster maps could not be placed in the matrix pattern -- two-pass assembly kept");
+      return 0;
+    }
+  }
+  as->cl_ncl = ncl;
+  as->cl_nm = nm;
+  as->cl_ns = ns;
+  as->cl_npart = npart;
+  as->cl_nprow = (int)prow.size();
+  as->fused = true;
+  FH_TRACE("fh_assembler_create: cluster plan (%d clusters, %d macro nodes, %d entries; %zu partial entries, %d rows in the second pass)", ncl, nm, ns, npart, as->cl_nprow);
+  return 0;
+}
+
+template <int SRC>
+static int launch_cluster_one(fh_assembler_t as, const AsmParams& P, const ClParams& C) {
+  constexpr size_t lds = cl_lds_bytes();
+  static bool attr_set[64] = {};
+  const int dev = as->ctx->device & 63;
+  if (!attr_set[dev]) {
+    FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster_q2hex_sf<SRC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set[dev] = true;
+  }
+  const int grid = std::max(1, std::min(C.ncl, as->ctx->num_cu * as->ctx->assemble_sf_grid));
+  hipLaunchKernelGGL((k_cluster_q2hex_sf<SRC>), dim3(grid), dim3(CL_T), lds, as->ctx->stream, P, as->sf_tab, as->d_sfLc, as->d_sfLi, C);
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+static int launch_cluster(fh_assembler_t as, const AsmParams& P, fh_mat_t A, double* res) {
+  ClParams C;
+  C.ncl = as->cl_ncl; C.ns = as->cl_ns; C.nm = as->cl_nm;
+  C.dtab = as->d_cl_dtab; C.fdesc = as->d_cl_fdesc; C.ovf = as->d_cl_ovf; C.sinfo = as->d_cl_sinfo;
+  C.vdst = as->d_cl_vdst; C.fdst = as->d_cl_fdst; C.map = reinterpret_cast<const uint4*>(as->d_cl_map);
+  C.Pbuf = as->d_Pbuf; C.val = A->d_val; C.res = res;
+  if (P.source_kind == 4) FH_TRY(launch_cluster_one<2>(as, P, C));
+  else if (P.source_kind != 0) FH_TRY(launch_cluster_one<1>(as, P, C));
+  else FH_TRY(launch_cluster_one<0>(as, P, C));
+  if (as->cl_nprow > 0 && !(as->ctx->asm_debug & (2 | 8))) {
+    hipLaunchKernelGGL(k_rows_partial, dim3(fh_div_up(as->cl_nprow, 8)), dim3(256), 0, as->ctx->stream, as->cl_nprow, as->d_cl_prow, as->d_cl_padj_ptr, as->d_cl_padj_off,
+                       as->d_cl_padj_len, as->d_cl_pmap, as->d_Pbuf, A->d_rowptr, A->d_val, res);
+    FH_CHECK_HIP(hipGetLastError());
+  }
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2146,6 +2709,7 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
     FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     FH_TRACE("fh_assembler_create: row map built");
     as->two_pass = true;
+    if (ctx->assemble_fused && as->dim == 3 && as->nc == 27 && as->ng == 64 && as->d_sfLc && ctx->assemble_sf) FH_TRY(cluster_plan_build(as, A, elem_dof, aptr));
   }
   if (as->two_pass && as->dim == 3 && as->nc == 27 && as->ng == 64) {
     // affine classification (host, geometry is fixed for the life of the assembler): every node at c + sum_a xi_a h_a
@@ -2206,6 +2770,9 @@ extern "C" int fh_assembler_destroy(fh_assembler_t as) {
   if (as->d_prog) hipFree(as->d_prog);
   if (as->d_prog_consts) hipFree(as->d_prog_consts);
   hipFree(as->d_iota);
+  for (void* q : {(void*)as->d_cl_dtab, (void*)as->d_cl_fdesc, (void*)as->d_cl_sinfo, (void*)as->d_cl_ovf, (void*)as->d_cl_vdst, (void*)as->d_cl_fdst, (void*)as->d_cl_map, (void*)as->d_cl_pmap,
+                  (void*)as->d_Pbuf, (void*)as->d_cl_prow, (void*)as->d_cl_padj_ptr, (void*)as->d_cl_padj_off, (void*)as->d_cl_padj_len})
+    if (q) hipFree(q);
   for (void* q : {(void*)as->d_adj_ptr, (void*)as->d_adj_ei, (void*)as->d_rowmap, (void*)as->d_Kbuf, (void*)as->d_Fbuf, (void*)as->d_slot, (void*)as->d_gal_child,
                   (void*)as->d_gal_cnt, (void*)as->d_gal_row, (void*)as->d_gal_fb, (void*)as->d_gal_cb, (void*)as->d_gal_val, (void*)as->d_gal_res, (void*)as->d_gal_dense})
     if (q) hipFree(q);
@@ -2273,6 +2840,18 @@ static int assemble_poisson_core(fh_assembler_t as, fh_vec_t sol, int source_kin
     P.slot = as->d_slot;
     P.nsink = as->nadj;
     P.debug = as->ctx->asm_debug;
+    as->last_sol = sol;
+    as->last_source_kind = source_kind;
+    as->last_params[0] = P.p0;
+    as->last_params[1] = P.p1;
+    if (as->fused && as->ctx->assemble_fused && as->ctx->assemble_sf && !(as->ctx->assemble_affine && as->d_Mab && as->n_aff > 0) && !(as->ctx->asm_debug & 16)) {
+      // fused cluster assembly: complete rows straight into the CSR arrays, the others through the partial-row buffer (the element-row buffer is not written)
+      as->kbuf_valid = false;
+      FH_TRY(launch_cluster(as, P, A, res->d));
+      A->at_valid = false;
+      return 0;
+    }
+    as->kbuf_valid = true;
     if (as->ctx->assemble_affine && as->d_Mab && as->n_aff > 0) {
       // affine elements through the reference-matrix kernel, the rest (curved ones) through the quadrature kernel
       AsmParams Pa = P;
@@ -2622,6 +3201,26 @@ static size_t galerkin_mfma_lds() {
   return ((size_t)NCH * KP * MT * 16 + GAL_NW * ws) * sizeof(double);
 }
 
+// element rows of the last assembly into the element-row buffer (pass 1 of the two-pass path alone)
+static int element_rows_again(fh_assembler_t as) {
+  FH_REQUIRE(as->two_pass && as->d_Kbuf, "fh_assembler_galerkin: the fine assembler holds no element rows");
+  AsmParams P = base_params(as);
+  P.sol = as->last_sol ? as->last_sol->d : nullptr;
+  P.source_kind = as->last_source_kind;
+  P.p0 = as->last_params[0];
+  P.p1 = as->last_params[1];
+  P.elems = as->d_iota;
+  P.nelems = as->nel;
+  P.Kout = as->d_Kbuf;
+  P.kstride = as->kstride;
+  P.Fout = as->d_Fbuf;
+  P.slot = as->d_slot;
+  P.nsink = as->nadj;
+  FH_TRY(dispatch_assemble(as, P));
+  as->kbuf_valid = true;
+  return 0;
+}
+
 extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, const int* child, int nfb, const int* fbdc, int ncb, const int* cbdc, fh_mat_t Ac) {
   FH_GUARD_BEGIN
   FH_REQUIRE(fas && cas && child && Ac && (nfb == 0 || fbdc) && (ncb == 0 || cbdc), "fh_assembler_galerkin: null argument");
@@ -2631,6 +3230,7 @@ extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, con
   FH_REQUIRE(fas->nel == cas->nel * nch, "fh_assembler_galerkin: %d fine elements are not the uniform refinement of %d coarse ones", fas->nel, cas->nel);
   FH_REQUIRE(Ac->m == cas->ndof, "fh_assembler_galerkin: the coarse matrix does not belong to the coarse assembler");
   fh_ctx_t c = cas->ctx;
+  if (!fas->kbuf_valid) FH_TRY(element_rows_again(fas));     // the fused assembly keeps no element rows: pass 1 of the two-pass path with the last arguments
   auto up = [&](void** d, const void* h, size_t bytes) -> int {
     if (*d) FH_CHECK_HIP(hipFree(*d));
     FH_CHECK_HIP(hipMalloc(d, bytes ? bytes : 8));
@@ -2705,6 +3305,7 @@ extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, con
   FH_CHECK_HIP(hipGetLastError());
   FH_CHECK_HIP(hipMemsetAsync(cas->d_Fbuf, 0, std::max<size_t>(cas->nadj, 1) * sizeof(double), c->stream));
   FH_TRY(dispatch_rows(cas, Ac, cas->d_gal_res, false));
+  cas->kbuf_valid = true;     // the coarse element rows this product wrote (the next coarser product reads them)
   Ac->at_valid = false;       // new values: a cached explicit transpose is stale
   return 0;
   FH_GUARD_END("fh_assembler_galerkin")

@@ -211,6 +211,7 @@ extern "C" int fh_set_option(fh_ctx_t c, const char* name, double value) {
   else if (!strcmp(name, "assemble_rows2")) c->assemble_rows2 = (int)value;
   else if (!strcmp(name, "assemble_sf")) c->assemble_sf = (int)value;
   else if (!strcmp(name, "assemble_rows_nt")) c->assemble_rows_nt = (int)value;
+  else if (!strcmp(name, "assemble_fused")) c->assemble_fused = (int)value;
   else if (!strcmp(name, "assemble_sf_grid")) c->assemble_sf_grid = std::max(1, (int)value);
   else if (!strcmp(name, "assemble_sumfac")) c->assemble_sumfac = (int)value;
   else if (!strcmp(name, "galerkin_mfma")) c->galerkin_mfma = (int)value;

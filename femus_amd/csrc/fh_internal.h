@@ -94,6 +94,7 @@ struct fh_ctx_s {
   int assemble_kpad = 1;             // HEX27/Q2 two-pass assembly: element rows padded to 32 doubles (whole 64-byte lines per row)
   int assemble_sym = 1;              // symmetric-tile HEX27/Q2 element kernel (2 elements per wave)
   int assemble_two_pass = 1;         // 1: element matrices + row gather (default), 0: coloured scatter
+  int assemble_fused = 1;            // HEX27/Q2 meshes whose elements come in sibling groups of eight: fused cluster assembly (rows complete inside a group go straight to the CSR arrays)
   int assemble_affine = 0;           // opt-in: affine HEX27/Q2 elements through precomputed reference matrices instead of quadrature
   int gj_symmetric = 1;              // coarse dense inverse: symmetric sweep on the upper block triangle when the operator is symmetric
   int galerkin_mfma = 1;             // element-wise Galerkin product on the FP64 matrix cores (0: sparse child tables on the vector ALU)
