@@ -750,6 +750,13 @@ class Assembler:
         _chk(self.L.fh_assembler_affine_count(self.h, ctypes.byref(a), ctypes.byref(g)))
         return a.value, g.value
 
+    def fused_info(self):
+        """fused cluster assembly: is it the path that runs, clusters, doubles in the partial-row buffer, rows of the second pass"""
+        a, n, r = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        pe = ctypes.c_int64()
+        _chk(self.L.fh_assembler_fused_info(self.h, ctypes.byref(a), ctypes.byref(n), ctypes.byref(pe), ctypes.byref(r)))
+        return {"active": bool(a.value), "clusters": n.value, "partial_entries": pe.value, "second_pass_rows": r.value}
+
     def assemble_expr(self, A, res, sol, expr, scale=1.0):
         """source term f = scale * expr(x, y, z, t), evaluated on the device at the Gauss points"""
         _chk(self.L.fh_assemble_poisson_expr(self.h, None if sol is None else sol.h, expr.h, float(scale), A.h, res.h))

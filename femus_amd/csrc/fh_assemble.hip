@@ -58,14 +58,15 @@ struct fh_assembler_s {
   bool kbuf_valid = false;       // the element-row buffer holds the matrices of the last assembly (the fused path does not write it)
   int cl_ncl = 0, cl_nm = 0, cl_ns = 0, cl_nprow = 0;
   size_t cl_npart = 0;           // entries of the partial-row buffer (without the sink)
-  unsigned *d_cl_dtab = nullptr, *d_cl_fdesc = nullptr, *d_cl_sinfo = nullptr;
-  unsigned short* d_cl_ovf = nullptr;
+  unsigned* d_cl_sinfo = nullptr;
+  void *d_cl_dtab = nullptr, *d_cl_fblk = nullptr, *d_cl_oblk = nullptr;      // descriptor tables of the template (see ClParams)
   int *d_cl_vdst = nullptr, *d_cl_fdst = nullptr;      // [ncl][128]: >= 0 CSR offset / row of a complete row, bit 31: offset into the partial-row buffer
+  unsigned long long* d_cl_vdst64 = nullptr;           // ... as addresses, for the value array cl_val_base
+  double* cl_val_base = nullptr;
   unsigned char *d_cl_map = nullptr, *d_cl_pmap = nullptr;
   double* d_Pbuf = nullptr;
-  int *d_cl_prow = nullptr, *d_cl_padj_ptr = nullptr;
-  unsigned* d_cl_padj_off = nullptr;
-  unsigned char* d_cl_padj_len = nullptr;
+  int* d_cl_prow = nullptr;                 // rows of the second pass
+  unsigned* d_cl_pstart = nullptr;          // [nprow + 1] their segments of the partial-row buffer
   // arguments of the last assembly (the element-wise Galerkin product re-creates the element rows from them when the fused path ran)
   fh_vec_t last_sol = nullptr;
   int last_source_kind = 0;
@@ -1716,33 +1717,42 @@ constexpr int CL_T = CL_NE * 64;                 // threads
 constexpr int CL_SPT = 10;                       // slots (macro entries) per thread
 constexpr int CL_NS_MAX = CL_T * CL_SPT;         // 5120 >= 4913
 constexpr int CL_NM_MAX = 128;                   // macro nodes (125), padded
-constexpr int CL_NOVF = 512;                     // overflow addresses
-constexpr int CL_ZC = SF_TAB + CL_NE * SF_WAVE;  // a zero cell (second operand of single-contribution entries)
-constexpr size_t cl_lds_bytes() { return (size_t)(CL_ZC + 2) * sizeof(double) + (size_t)CL_NS_MAX * 4 + CL_NM_MAX * 4 * 3 + CL_NOVF * 2; }
-static_assert(CL_ZC + 2 < (1 << 14), "cluster kernel: LDS double indices fit 14 bits");
+constexpr int CL_NBLK = 64;                      // address blocks of entries with more than two contributions (49)
+constexpr int CL_ZC = SF_TAB + CL_NE * SF_WAVE;  // a zero cell (operand of absent contributions)
+// LDS behind the element kernel's regions: zero cell, descriptors (8 B per template entry), row destinations of the cluster (8 B), residual
+// destinations (4 B), address blocks (8 x 2 B) of the residual sums and of the long sums
+constexpr size_t CL_OFF_DT = (size_t)(CL_ZC + 2) * sizeof(double);
+constexpr size_t CL_OFF_RB = CL_OFF_DT + (size_t)CL_NS_MAX * 8;
+constexpr size_t CL_OFF_FB = CL_OFF_RB + (size_t)CL_NM_MAX * 8;
+constexpr size_t CL_OFF_FL = CL_OFF_FB + (size_t)CL_NM_MAX * 4;
+constexpr size_t CL_OFF_OV = CL_OFF_FL + (size_t)CL_NM_MAX * 16;
+constexpr size_t cl_lds_bytes() { return CL_OFF_OV + (size_t)CL_NBLK * 16; }
+static_assert((CL_ZC + 2) * 8 < (1 << 17), "cluster kernel: LDS byte addresses of the stagings fit 17 bits");
 static_assert(cl_lds_bytes() <= 160 * 1024, "cluster kernel: LDS budget");
 
 struct ClParams {
   int ncl, ns, nm;
-  const unsigned* dtab;        // [ns] descriptor of template entry off[r] + j
-  const unsigned* fdesc;       // [128] descriptor of the residual entry of macro row r
-  const unsigned short* ovf;   // [CL_NOVF]
+  const uint2* dtab;           // [ns] descriptor of template entry off[r] + j: x = LDS byte address of the first contribution, y = address of the
+                               //      second (or of the zero cell) | address block << 17 | (more than two contributions) << 28
+  const uint4* fblk;           // [128] residual entry of macro row r: eight 16-bit double indices (zero cell for absent contributions)
+  const uint4* oblk;           // [CL_NBLK] contributions 3 .. 8 of the long sums, same format
   const unsigned* sinfo;       // [CL_SPT][CL_T]: r | p << 7 | off[r] << 14 of slot tid + CL_T * i
-  const int* vdst;             // [ncl][128]
-  const int* fdst;             // [ncl][128]
+  const unsigned long long* vdst;   // [ncl][128] address of the row's first entry (CSR array or partial-row buffer)
+  const int* fdst;             // [ncl][128] >= 0: row of the residual vector, bit 31: offset into the partial-row buffer
   const uint4* map;            // [ncl][CL_T]: byte i = template entry of slot tid + CL_T * i inside its row
   double* Pbuf;
-  double* val;
   double* res;
 };
 
-__device__ __forceinline__ double cl_sum(const double* S, const unsigned short* ovf, unsigned d) {
-  const unsigned a0 = d & 0x3fffu, a1f = (d >> 14) & 0x3fffu, nx = d >> 28;
-  unsigned a1 = a1f;
-  if (nx) a1 = ovf[a1f];
-  double v = S[a0] + S[a1];
-  for (unsigned k = 1; k < nx; k++) v += S[ovf[a1f + k]];
-  return v;
+__device__ __forceinline__ double cl_sum8(const char* S, const uint4 a) {       // eight contributions in ascending element order
+  const unsigned w[4] = {a.x, a.y, a.z, a.w};
+  double v[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) v[k] = *reinterpret_cast<const double*>(S + (((w[k >> 1] >> (16 * (k & 1))) & 0xffffu) << 3));
+  double t = v[0];
+#pragma unroll
+  for (int k = 1; k < 8; k++) t += v[k];
+  return t;
 }
 
 template <int SRC>
@@ -1752,17 +1762,18 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
   extern __shared__ __attribute__((aligned(16))) double sf_smem[];
   double* SFl = sf_smem;
   int* SFi = reinterpret_cast<int*>(SFl + SF_NLC * 64);
-  unsigned* dtab = reinterpret_cast<unsigned*>(sf_smem + CL_ZC + 2);
-  unsigned* fdesc = dtab + CL_NS_MAX;
-  int* rb = reinterpret_cast<int*>(fdesc + CL_NM_MAX);
-  int* fb = rb + CL_NM_MAX;
-  unsigned short* ovf = reinterpret_cast<unsigned short*>(fb + CL_NM_MAX);
+  char* Sb = reinterpret_cast<char*>(sf_smem);
+  uint2* dtab = reinterpret_cast<uint2*>(Sb + CL_OFF_DT);
+  unsigned long long* rb = reinterpret_cast<unsigned long long*>(Sb + CL_OFF_RB);
+  int* fb = reinterpret_cast<int*>(Sb + CL_OFF_FB);
+  uint4* fblk = reinterpret_cast<uint4*>(Sb + CL_OFF_FL);
+  uint4* oblk = reinterpret_cast<uint4*>(Sb + CL_OFF_OV);
   const int tid = threadIdx.x;
   for (int k = tid; k < SF_NLC * 64; k += CL_T) SFl[k] = lanec[k];
   for (int k = tid; k < SF_NLI * 64; k += CL_T) SFi[k] = lanei[k];
   for (int k = tid; k < C.ns; k += CL_T) dtab[k] = C.dtab[k];
-  if (tid < CL_NM_MAX) fdesc[tid] = C.fdesc[tid];
-  ovf[tid] = C.ovf[tid];
+  if (tid < CL_NM_MAX) fblk[tid] = C.fblk[tid];
+  if (tid < CL_NBLK) oblk[tid] = C.oblk[tid];
   if (tid < 2) sf_smem[CL_ZC + tid] = 0.0;
   __syncthreads();
   const int lane = tid & 63;
@@ -1800,6 +1811,7 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
   }
   int dof_n = P.elem_dof[(size_t)(min(cl + cstride, lastc) * NW + wave) * P.nloc + nodeofl];
   const int tm = tid & (CL_NM_MAX - 1);
+  const int frow = wave * 16 + (lane & 15);          // residual entry this lane sums (lanes 0..15 of every wave)
   wave_lds_sync();
 #pragma unroll 1
   for (; cl < C.ncl; cl += cstride) {
@@ -1809,7 +1821,8 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
     const double nu = P.sol ? P.sol[dof_n] : 0.0;
     const int dof_nn = P.elem_dof[(size_t)(cl_nn * NW + wave) * P.nloc + nodeofl];
     // this cluster's destinations and maps: consumed after the element matrix, which hides the round trip
-    const int vd_cur = C.vdst[(size_t)cl * CL_NM_MAX + tm], fd_cur = C.fdst[(size_t)cl * CL_NM_MAX + tm];
+    const unsigned long long vd_cur = C.vdst[(size_t)cl * CL_NM_MAX + tm];
+    const int fd_cur = C.fdst[(size_t)cl * CL_NM_MAX + tm];
     const uint4 mp_cur = C.map[(size_t)cl * CL_T + tid];
     double Kb[3][3], fsrc;
     sf_element_blocks<SRC, REGC>(P, tab, LCl, LIl, rcA, rcZ, rcY, esym, ens, ensT, eout, xt, R, lane, Kb, fsrc);
@@ -1854,23 +1867,48 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
     }
     __syncthreads();
     if (!(P.debug & 2)) {
-      const double* S = sf_smem;
       const unsigned mw[4] = {mp_cur.x, mp_cur.y, mp_cur.z, mp_cur.w};
+      // in stages, every stage's LDS reads independent of each other (two waves per SIMD hide little latency): descriptors and row
+      // destinations, then both operands of every entry (the zero cell for entries of one element), the rare longer sums, the stores.
+      // The phase is bound by vector-instruction issue: descriptors hold LDS BYTE addresses, destinations are whole addresses.
+      uint2 dd[CL_SPT];
+      unsigned long long vb[CL_SPT];
 #pragma unroll
       for (int i = 0; i < CL_SPT; i++) {
         const unsigned si = sinfo[i];
-        const int r = si & 127, p = (si >> 7) & 127, off = si >> 14;
-        const int vb = rb[r];
         const int j = (mw[i >> 2] >> (8 * (i & 3))) & 255;
-        const double v = cl_sum(S, ovf, dtab[off + j]);
-        double* dst = (vb < 0 ? C.Pbuf + (size_t)(vb & 0x7fffffff) : C.val + (size_t)vb) + p;
-        __builtin_nontemporal_store(v, dst);
+        dd[i] = dtab[(si >> 14) + j];
+        vb[i] = rb[si & 127];
       }
-      if (wave < CL_NM_MAX / 64) {
-        const double v = cl_sum(S, ovf, fdesc[tid]);
-        const int vb = fb[tid];
-        double* dst = vb < 0 ? C.Pbuf + (size_t)(vb & 0x7fffffff) : C.res + (size_t)vb;
-        *dst = v;
+      double vv[CL_SPT], ww[CL_SPT];
+      unsigned anyx = 0;
+#pragma unroll
+      for (int i = 0; i < CL_SPT; i++) {
+        anyx |= dd[i].y;
+        vv[i] = *reinterpret_cast<const double*>(Sb + dd[i].x);
+        ww[i] = *reinterpret_cast<const double*>(Sb + (dd[i].y & 0x1ffffu));
+      }
+#pragma unroll
+      for (int i = 0; i < CL_SPT; i++) vv[i] += ww[i];
+      if (__any((anyx >> 28) != 0)) {       // 49 of the 4913 entries have four or eight contributions: all of them read at once
+#pragma unroll
+        for (int i = 0; i < CL_SPT; i++)
+          if (__any((dd[i].y >> 28) != 0)) {
+            if (dd[i].y >> 28) vv[i] += cl_sum8(Sb, oblk[(dd[i].y >> 17) & 0x7ffu]);
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < CL_SPT; i++) {
+        double* dst = reinterpret_cast<double*>(vb[i]) + ((sinfo[i] >> 7) & 127);
+        if (P.debug & 64) *dst = vv[i];                  // bit 6: plain stores (comparison)
+        else if (!(P.debug & 4)) __builtin_nontemporal_store(vv[i], dst);
+        else if (vv[i] == 1.2345e300) *dst = vv[i];      // timing aid (bit 2): the LDS work without the stores
+      }
+      {                                     // residual entries: rows 16 w .. 16 w + 15 on the first lanes of wave w
+        const double v = cl_sum8(Sb, fblk[frow]);
+        const int fv = fb[frow];
+        double* dst = fv < 0 ? C.Pbuf + (size_t)(fv & 0x7fffffff) : C.res + (size_t)fv;
+        if (lane < 16) *dst = v;
       }
     }
     __syncthreads();          // the stagings are the next elements' scratch, rb / fb the next cluster's
@@ -1879,55 +1917,73 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
 }
 
 // Second pass of the fused assembly: every CSR row that is not complete inside one cluster sums its partial macro rows (ascending cluster
-// order) in LDS and is written once; rows no element touches are written as zeros.  One 32-lane group per row.
-__global__ __launch_bounds__(256) void k_rows_partial(int nprow, const int* __restrict__ prow, const int* __restrict__ padj_ptr, const unsigned* __restrict__ padj_off,
-                                                      const unsigned char* __restrict__ padj_len, const unsigned char* __restrict__ pmap, const double* __restrict__ Pbuf,
-                                                      const int* __restrict__ rowptr, double* __restrict__ val, double* __restrict__ res) {
-  __shared__ double acc[8][128];
+// order) in LDS and is written once; rows no element touches are written as zeros.  The partial rows of one CSR row lie BEHIND EACH OTHER in
+// the partial-row buffer (the cluster kernel scatters whole packed rows of 28 ... 126 entries there), so a 32-lane group streams one
+// contiguous segment per row, two rows at once: [prow, pstart, rowptr] -> [segments + byte maps] -> LDS adds -> store.  Order of the sums:
+// two entries of a segment meet in one CSR position only from different partial rows, i.e. >= 28 entries apart; the LDS adds are issued
+// 16 entries at a time in ascending segment order and LDS executes a wave's operations in order, so every position receives its
+// contributions in ascending cluster order -- deterministic without staging the segment.  Map byte 255 = the residual entry behind a partial row.
+constexpr int RP_Q = 7;                      // 32 * 7 = 224 >= the longest segment (8 partial rows of 27 + 1)
+template <int NT>
+__global__ __launch_bounds__(256) void k_rows_partial(int nprow, const int* __restrict__ prow, const unsigned* __restrict__ pstart, const unsigned char* __restrict__ pmap,
+                                                      const double* __restrict__ Pbuf, const int* __restrict__ rowptr, double* __restrict__ val, double* __restrict__ res, int nt) {
+  __shared__ double acc[8][2][128];
   const int sub = threadIdx.x >> 5, lane = threadIdx.x & 31;
-  const int k = blockIdx.x * 8 + sub;
-  if (k >= nprow) return;
-  const int g = prow[k];
-  const int a0 = padj_ptr[k], a1 = padj_ptr[k + 1];
-  const int rs = rowptr[g], len = rowptr[g + 1] - rs;
+  const int k0 = (blockIdx.x * 8 + sub) * 2;
+  if (k0 >= nprow) return;
+  const bool two = k0 + 1 < nprow;
+  const size_t sA = pstart[k0], sB = pstart[k0 + 1], sC = two ? pstart[k0 + 2] : sB;
+  const int TA = (int)(sB - sA), TB = (int)(sC - sB);
+  const int gA = prow[k0], gB = two ? prow[k0 + 1] : gA;
+  const int rsA = rowptr[gA], lenA = rowptr[gA + 1] - rsA, rsB = rowptr[gB], lenB = two ? rowptr[gB + 1] - rsB : 0;
+  double vA[RP_Q], vB[RP_Q];
+  int mA[RP_Q], mB[RP_Q];
 #pragma unroll
-  for (int q = 0; q < 4; q++) acc[sub][lane + 32 * q] = 0.0;
-  double f = 0.0;
-  constexpr int RB = 2;
-  for (int ab = a0; ab < a1; ab += RB) {
-    double v[RB][4], fv[RB];
-    int m[RB][4];
-#pragma unroll
-    for (int t = 0; t < RB; t++) {
-      const int a = ab + t;
-      const bool on = a < a1;
-      const size_t off = on ? padj_off[a] : 0;
-      const int L = on ? padj_len[a] : 0;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int e = lane + 32 * q;
-        const bool live = e < L;
-        v[t][q] = live ? __builtin_nontemporal_load(&Pbuf[off + e]) : 0.0;
-        m[t][q] = live ? pmap[off + e] : -1;
-      }
-      fv[t] = (on && lane == 0) ? __builtin_nontemporal_load(&Pbuf[off + L]) : 0.0;
-    }
-#pragma unroll
-    for (int t = 0; t < RB; t++) {
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-        if (m[t][q] >= 0) acc[sub][m[t][q]] += v[t][q];
-      f += fv[t];
-    }
+  for (int q = 0; q < RP_Q; q++) {
+    const int e = lane + 32 * q;
+    vA[q] = e < TA ? (NT ? __builtin_nontemporal_load(&Pbuf[sA + e]) : Pbuf[sA + e]) : 0.0;
+    mA[q] = e < TA ? (int)pmap[sA + e] : 254;
+    vB[q] = e < TB ? (NT ? __builtin_nontemporal_load(&Pbuf[sB + e]) : Pbuf[sB + e]) : 0.0;
+    mB[q] = e < TB ? (int)pmap[sB + e] : 254;
   }
-  for (int p = lane; p < len; p += 32) val[rs + p] = acc[sub][p];
-  if (lane == 0) res[g] = f;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    acc[sub][0][lane + 32 * q] = 0.0;
+    acc[sub][1][lane + 32 * q] = 0.0;
+  }
+  double fA = 0.0, fB = 0.0;
+#pragma unroll
+  for (int q = 0; q < RP_Q; q++) {
+    if (32 * q < TA || 32 * q < TB) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        if ((lane >> 4) == h && mA[q] < 128) __hip_atomic_fetch_add(&acc[sub][0][mA[q]], vA[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((lane >> 4) == h && mB[q] < 128) __hip_atomic_fetch_add(&acc[sub][1][mB[q]], vB[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    fA += mA[q] == 255 ? vA[q] : 0.0;
+    fB += mB[q] == 255 ? vB[q] : 0.0;
+  }
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) {
+    fA += __shfl_xor(fA, d, 32);
+    fB += __shfl_xor(fB, d, 32);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int p = lane; p < lenA; p += 32) val[rsA + p] = acc[sub][0][p];
+  for (int p = lane; p < lenB; p += 32) val[rsB + p] = acc[sub][1][p];
+  if (lane == 0) {
+    res[gA] = fA;
+    if (two) res[gB] = fB;
+  }
 }
 
 // Plan construction on the device: the byte maps of one cluster per workgroup.  Complete rows: for CSR position p the template entry whose
 // macro column carries the global column there; partial rows: identity in the cluster kernel's map, and in pmap the CSR position of every
 // packed entry.  An entry that cannot be placed raises err (the assembler then keeps the two-pass path).
-__global__ __launch_bounds__(256) void k_cluster_maps(int ncl, int ns, int nm, const int* __restrict__ cdof, const unsigned char* __restrict__ srow, const unsigned short* __restrict__ roff,
+__global__ __launch_bounds__(256) void k_cluster_maps(int ncl, int ns, int nm, const int* __restrict__ cdof, const unsigned* __restrict__ sinfo, const unsigned short* __restrict__ roff,
                                                       const unsigned char* __restrict__ tcol, const int* __restrict__ vdst, int m, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                       unsigned char* __restrict__ map, unsigned char* __restrict__ pmap, int* __restrict__ err) {
   __shared__ int cd[CL_NM_MAX];
@@ -1936,8 +1992,10 @@ __global__ __launch_bounds__(256) void k_cluster_maps(int ncl, int ns, int nm, c
   __syncthreads();
   for (int s = threadIdx.x; s < CL_NS_MAX; s += 256) {
     const size_t mi = ((size_t)c * CL_T + (s % CL_T)) * 16 + s / CL_T;
-    if (s >= ns) { map[mi] = 0; continue; }
-    const int r = srow[s], o = roff[r], p = s - o, len = roff[r + 1] - o;
+    const unsigned si = sinfo[s];          // slot s = tid + CL_T * i sits at [i][tid]
+    const int r = si & 127, p = (si >> 7) & 127, o = si >> 14;
+    if (r >= nm) { map[mi] = 0; continue; }
+    const int len = roff[r + 1] - o;
     const int vb = vdst[(size_t)c * CL_NM_MAX + r];
     if (vb >= 0) {                       // complete row: CSR position p holds global column h
       const int h = col[vb + p];
@@ -1950,7 +2008,7 @@ __global__ __launch_bounds__(256) void k_cluster_maps(int ncl, int ns, int nm, c
       map[mi] = (unsigned char)p;
       const int g = cd[r];
       if (g < m) {                       // partial row of the matrix: where does packed entry p go in CSR row g
-        const int target = cd[tcol[s]];
+        const int target = cd[tcol[o + p]];
         const int rs = rowptr[g];
         int lo = rs, hi = rowptr[g + 1] - 1, pos = -1;
         while (lo <= hi) {
@@ -2024,17 +2082,25 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
   }
   // template rows: macro columns ascending; contributions in ascending element order
   std::vector<unsigned short> roff(CL_NM_MAX + 1, 0);
-  std::vector<unsigned char> tcol, srow;
-  std::vector<unsigned> dtab, fdesc(CL_NM_MAX, (unsigned)CL_ZC | ((unsigned)CL_ZC << 14));
-  std::vector<unsigned short> ovf;
-  auto stag = [&](int e, int tr, int tc) { return (unsigned)(SF_TAB + e * SF_WAVE + SF_XT + tr * KS + tc); };
-  auto pack = [&](const std::vector<unsigned>& ad, unsigned* out) -> bool {
-    if (ad.size() == 1) *out = ad[0] | ((unsigned)CL_ZC << 14);
-    else if (ad.size() == 2) *out = ad[0] | (ad[1] << 14);
-    else {
-      if (ad.size() > 8 || ovf.size() + ad.size() - 1 > (size_t)CL_NOVF) return false;
-      *out = ad[0] | ((unsigned)ovf.size() << 14) | ((unsigned)(ad.size() - 1) << 28);
-      for (size_t q = 1; q < ad.size(); q++) ovf.push_back((unsigned short)ad[q]);
+  std::vector<unsigned char> tcol;
+  int nsingle[CL_NM_MAX] = {};
+  struct U2 { unsigned x, y; };
+  struct U4 { unsigned short a[8]; };
+  std::vector<U2> dtab;
+  U4 zblk;
+  for (int q = 0; q < 8; q++) zblk.a[q] = (unsigned short)CL_ZC;
+  std::vector<U4> fblk(CL_NM_MAX, zblk), oblk;
+  auto stag = [&](int e, int tr, int tc) { return (unsigned)(SF_TAB + e * SF_WAVE + SF_XT + tr * KS + tc); };      // double index into the workgroup's LDS
+  auto pack = [&](const std::vector<unsigned>& ad, U2* out) -> bool {
+    if (ad.empty() || ad.size() > 8) return false;
+    out->x = ad[0] * 8;
+    out->y = (ad.size() > 1 ? ad[1] : (unsigned)CL_ZC) * 8;
+    if (ad.size() > 2) {
+      if ((int)oblk.size() >= CL_NBLK) return false;
+      U4 b = zblk;
+      for (size_t q = 2; q < ad.size(); q++) b.a[q - 2] = (unsigned short)ad[q];
+      out->y |= ((unsigned)oblk.size() << 17) | (1u << 28);
+      oblk.push_back(b);
     }
     return true;
   };
@@ -2048,54 +2114,72 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
     for (int e = 0; e < CL_NE; e++)
       if (tof_e[e][r] >= 0)
         for (int t = 0; t < 27; t++) has[tm[e][t]] = true;
-    for (int k = 0; k < nm; k++)
-      if (has[k]) {
-        std::vector<unsigned> ad;
-        for (int e = 0; e < CL_NE; e++)
-          if (tof_e[e][r] >= 0 && tof_e[e][k] >= 0) ad.push_back(stag(e, tof_e[e][r], tof_e[e][k]));
-        unsigned d;
-        if (!pack(ad, &d)) return 0;
-        dtab.push_back(d);
-        tcol.push_back((unsigned char)k);
-        srow.push_back((unsigned char)r);
-      }
+    // entries met by ONE element first (83 %: the kernel skips the second operand for a whole wave of them), then the shared ones
+    for (int pass = 0; pass < 2; pass++) {
+      for (int k = 0; k < nm; k++)
+        if (has[k]) {
+          std::vector<unsigned> ad;
+          for (int e = 0; e < CL_NE; e++)
+            if (tof_e[e][r] >= 0 && tof_e[e][k] >= 0) ad.push_back(stag(e, tof_e[e][r], tof_e[e][k]));
+          if ((ad.size() > 1) != (pass == 1)) continue;
+          U2 d;
+          if (!pack(ad, &d)) return 0;
+          dtab.push_back(d);
+          tcol.push_back((unsigned char)k);
+        }
+      if (pass == 0) nsingle[r] = (int)dtab.size() - roff[r];
+    }
     roff[r + 1] = (unsigned short)dtab.size();
     if (roff[r + 1] - roff[r] > 127) return 0;
-    std::vector<unsigned> ad;
+    int nf = 0;
     for (int e = 0; e < CL_NE; e++)
-      if (tof_e[e][r] >= 0) ad.push_back(stag(e, tof_e[e][r], 27));
-    if (!pack(ad, &fdesc[r])) return 0;
+      if (tof_e[e][r] >= 0) fblk[r].a[nf++] = (unsigned short)stag(e, tof_e[e][r], 27);
   }
   for (int r = nm; r < CL_NM_MAX; r++) roff[r + 1] = roff[nm];
   const int ns = (int)dtab.size();
   if (ns > CL_NS_MAX || ns >= (1 << 13)) return 0;
-  ovf.resize(CL_NOVF, (unsigned short)CL_ZC);
-  std::vector<unsigned> sinfo((size_t)CL_SPT * CL_T);
-  for (int i = 0; i < CL_SPT; i++)
-    for (int t = 0; t < CL_T; t++) {
-      const int sidx = t + CL_T * i;
-      if (sidx < ns) {
-        const int r = srow[sidx];
-        sinfo[(size_t)i * CL_T + t] = (unsigned)r | ((unsigned)(sidx - roff[r]) << 7) | ((unsigned)roff[r] << 14);
-      } else
-        sinfo[(size_t)i * CL_T + t] = CL_NM_MAX - 1;         // dummy row: destination = sink
-    }
-  // destinations: a macro row is complete when all elements around its node lie in this cluster and the CSR row has exactly its columns
+  oblk.resize(CL_NBLK, zblk);
+  // slots (what thread tid does in its i-th step: slot tid + CL_T * i): the single-element ranges of all rows, then the shared ranges; a
+  // run of consecutive slots is a run of consecutive destinations (coalesced stores)
+  std::vector<unsigned> sinfo((size_t)CL_SPT * CL_T, (unsigned)(CL_NM_MAX - 1));       // default = dummy row: destination = sink
+  {
+    int sidx = 0;
+    for (int pass = 0; pass < 2; pass++)
+      for (int r = 0; r < nm; r++) {
+        const int p0 = pass ? nsingle[r] : 0, p1 = pass ? roff[r + 1] - roff[r] : nsingle[r];
+        for (int pp = p0; pp < p1; pp++) sinfo[sidx++] = (unsigned)r | ((unsigned)pp << 7) | ((unsigned)roff[r] << 14);
+      }
+  }
+  // destinations: a macro row is complete when all elements around its node lie in this cluster and the CSR row has exactly its columns.
+  // The partial rows of one CSR row follow each other in the partial-row buffer, ascending cluster (= element) order.
   std::vector<int> vdst((size_t)ncl * CL_NM_MAX), fdst((size_t)ncl * CL_NM_MAX);
   std::vector<char> complete(m, 0);
-  size_t npart = 0;
-  for (int c = 0; c < ncl; c++)
+  std::vector<unsigned> rowsz(m + 1, 0);         // entries of the segment of row g (partial rows + their residual entries)
+    for (int c = 0; c < ncl; c++)
     for (int r = 0; r < nm; r++) {
       const int g = cdof[(size_t)c * CL_NM_MAX + r], len = roff[r + 1] - roff[r];
-      if (g < m && aptr[g + 1] - aptr[g] == tcnt[r] && A->h_rowptr[g + 1] - A->h_rowptr[g] == len) complete[g] = 1;
-      else if (g < m) npart += (size_t)len + 1;
+      if (g >= m) continue;
+      if (aptr[g + 1] - aptr[g] == tcnt[r] && A->h_rowptr[g + 1] - A->h_rowptr[g] == len) complete[g] = 1;
+      else {
+        if (rowsz[g] + len + 1 > 32 * RP_Q) return 0;                // the second pass holds a segment of <= 224 entries in registers
+        rowsz[g] += (unsigned)len + 1;
+      }
     }
-  if (npart + 128 >= ((size_t)1 << 31)) return 0;
+  std::vector<int> prow, rowk(m, -1);
+  std::vector<unsigned> pstart(1, 0);
+  size_t npart = 0;
+  for (int g = 0; g < m; g++)
+    if (!complete[g]) {
+      rowk[g] = (int)prow.size();
+      prow.push_back(g);
+      npart += rowsz[g];
+      if (npart + 128 >= ((size_t)1 << 31)) return 0;
+      pstart.push_back((unsigned)npart);
+    }
   const unsigned sink = 0x80000000u | (unsigned)npart;
-  std::vector<int> pcnt(m + 1, 0);
   {
-    size_t poff = 0;
-    for (int c = 0; c < ncl; c++) {
+    std::vector<unsigned> cur(pstart.begin(), pstart.end() - 1);
+    for (int c = 0; c < ncl; c++)
       for (int r = 0; r < CL_NM_MAX; r++) {
         const size_t q = (size_t)c * CL_NM_MAX + r;
         const int g = r < nm ? cdof[q] : -1;
@@ -2103,34 +2187,10 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
         const int len = roff[r + 1] - roff[r];
         if (complete[g]) { vdst[q] = A->h_rowptr[g]; fdst[q] = g; }
         else {
-          vdst[q] = (int)(0x80000000u | (unsigned)poff);
-          fdst[q] = (int)(0x80000000u | (unsigned)(poff + len));
-          poff += (size_t)len + 1;
-          pcnt[g + 1]++;
-        }
-      }
-    }
-  }
-  // second pass: rows that are not complete (rows no element touches are written as zeros there), their partial rows in ascending cluster order
-  std::vector<int> prow, pptr(1, 0), rowk(m, -1);
-  for (int g = 0; g < m; g++)
-    if (!complete[g]) {
-      rowk[g] = (int)prow.size();
-      prow.push_back(g);
-      pptr.push_back(pptr.back() + pcnt[g + 1]);
-    }
-  std::vector<unsigned> padj_off(std::max<size_t>(pptr.back(), 1));
-  std::vector<unsigned char> padj_len(std::max<size_t>(pptr.back(), 1));
-  {
-    std::vector<int> cur(pptr.begin(), pptr.end() - 1);
-    for (int c = 0; c < ncl; c++)
-      for (int r = 0; r < nm; r++) {
-        const size_t q = (size_t)c * CL_NM_MAX + r;
-        const int g = cdof[q];
-        if (g < m && !complete[g]) {
-          const int a = cur[rowk[g]]++;
-          padj_off[a] = (unsigned)vdst[q] & 0x7fffffffu;
-          padj_len[a] = (unsigned char)(roff[r + 1] - roff[r]);
+          const int k = rowk[g];
+          vdst[q] = (int)(0x80000000u | cur[k]);
+          fdst[q] = (int)(0x80000000u | (cur[k] + (unsigned)len));
+          cur[k] += (unsigned)len + 1;
         }
       }
   }
@@ -2139,38 +2199,36 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
     if (bytes) FH_CHECK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
     return 0;
   };
-  FH_TRY(up((void**)&as->d_cl_dtab, dtab.data(), dtab.size() * 4));
-  FH_TRY(up((void**)&as->d_cl_fdesc, fdesc.data(), fdesc.size() * 4));
-  FH_TRY(up((void**)&as->d_cl_ovf, ovf.data(), ovf.size() * 2));
+  FH_TRY(up((void**)&as->d_cl_dtab, dtab.data(), dtab.size() * sizeof(U2)));
+  FH_TRY(up((void**)&as->d_cl_fblk, fblk.data(), fblk.size() * sizeof(U4)));
+  FH_TRY(up((void**)&as->d_cl_oblk, oblk.data(), oblk.size() * sizeof(U4)));
+  FH_CHECK_HIP(hipMalloc(&as->d_cl_vdst64, (size_t)ncl * CL_NM_MAX * sizeof(unsigned long long)));
   FH_TRY(up((void**)&as->d_cl_sinfo, sinfo.data(), sinfo.size() * 4));
   FH_TRY(up((void**)&as->d_cl_vdst, vdst.data(), vdst.size() * 4));
   FH_TRY(up((void**)&as->d_cl_fdst, fdst.data(), fdst.size() * 4));
   FH_TRY(up((void**)&as->d_cl_prow, prow.data(), prow.size() * 4));
-  FH_TRY(up((void**)&as->d_cl_padj_ptr, pptr.data(), pptr.size() * 4));
-  FH_TRY(up((void**)&as->d_cl_padj_off, padj_off.data(), padj_off.size() * 4));
-  FH_TRY(up((void**)&as->d_cl_padj_len, padj_len.data(), padj_len.size()));
+  FH_TRY(up((void**)&as->d_cl_pstart, pstart.data(), pstart.size() * 4));
   FH_CHECK_HIP(hipMalloc(&as->d_cl_map, (size_t)ncl * CL_T * 16));
   FH_CHECK_HIP(hipMalloc(&as->d_cl_pmap, npart + 128));
-  FH_CHECK_HIP(hipMemset(as->d_cl_pmap, 0, npart + 128));
+  FH_CHECK_HIP(hipMemset(as->d_cl_pmap, 0xFF, npart + 128));      // 255 = residual entry (the map kernel fills in the matrix entries)
   FH_CHECK_HIP(hipMalloc(&as->d_Pbuf, (npart + 128) * sizeof(double)));
   FH_CHECK_HIP(hipMemset(as->d_Pbuf, ctx->debug_poison ? 0xFF : 0, (npart + 128) * sizeof(double)));
   {
     int *d_cdof = nullptr, *d_err = nullptr;
-    unsigned char *d_srow = nullptr, *d_tcol = nullptr;
+    unsigned char* d_tcol = nullptr;
     unsigned short* d_roff = nullptr;
     FH_TRY(up((void**)&d_cdof, cdof.data(), cdof.size() * 4));
-    FH_TRY(up((void**)&d_srow, srow.data(), srow.size()));
     FH_TRY(up((void**)&d_tcol, tcol.data(), tcol.size()));
     FH_TRY(up((void**)&d_roff, roff.data(), roff.size() * 2));
     const int zero = 0;
     FH_TRY(up((void**)&d_err, &zero, sizeof(int)));
-    hipLaunchKernelGGL(k_cluster_maps, dim3(ncl), dim3(256), 0, ctx->stream, ncl, ns, nm, d_cdof, d_srow, d_roff, d_tcol, as->d_cl_vdst, m, A->d_rowptr, A->d_col, as->d_cl_map,
+    hipLaunchKernelGGL(k_cluster_maps, dim3(ncl), dim3(256), 0, ctx->stream, ncl, ns, nm, d_cdof, as->d_cl_sinfo, d_roff, d_tcol, as->d_cl_vdst, m, A->d_rowptr, A->d_col, as->d_cl_map,
                        as->d_cl_pmap, d_err);
     FH_CHECK_HIP(hipGetLastError());
     int err = 0;
     FH_CHECK_HIP(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    for (void* q : {(void*)d_cdof, (void*)d_srow, (void*)d_tcol, (void*)d_roff, (void*)d_err}) hipFree(q);
+    for (void* q : {(void*)d_cdof, (void*)d_tcol, (void*)d_roff, (void*)d_err}) hipFree(q);
     if (err) {
       FH_TRACE("fh_assembler_create: cluster maps could not be placed in the matrix pattern -- two-pass assembly kept");
       return 0;
@@ -2201,18 +2259,39 @@ static int launch_cluster_one(fh_assembler_t as, const AsmParams& P, const ClPar
   return 0;
 }
 
+// row destinations as addresses (the cluster kernel's output phase is bound by vector-instruction issue: no address arithmetic there)
+__global__ void k_cluster_vdst(size_t n, const int* __restrict__ vdst, double* Pbuf, double* val, unsigned long long* __restrict__ out) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int v = vdst[k];
+  out[k] = reinterpret_cast<unsigned long long>(v < 0 ? Pbuf + (size_t)(v & 0x7fffffff) : val + (size_t)v);
+}
+
 static int launch_cluster(fh_assembler_t as, const AsmParams& P, fh_mat_t A, double* res) {
+  if (as->cl_val_base != A->d_val) {        // first assembly, or another matrix of the same pattern
+    const size_t n = (size_t)as->cl_ncl * CL_NM_MAX;
+    hipLaunchKernelGGL(k_cluster_vdst, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as->ctx->stream, n, as->d_cl_vdst, as->d_Pbuf, A->d_val, as->d_cl_vdst64);
+    FH_CHECK_HIP(hipGetLastError());
+    as->cl_val_base = A->d_val;
+  }
   ClParams C;
   C.ncl = as->cl_ncl; C.ns = as->cl_ns; C.nm = as->cl_nm;
-  C.dtab = as->d_cl_dtab; C.fdesc = as->d_cl_fdesc; C.ovf = as->d_cl_ovf; C.sinfo = as->d_cl_sinfo;
-  C.vdst = as->d_cl_vdst; C.fdst = as->d_cl_fdst; C.map = reinterpret_cast<const uint4*>(as->d_cl_map);
-  C.Pbuf = as->d_Pbuf; C.val = A->d_val; C.res = res;
+  C.dtab = reinterpret_cast<const uint2*>(as->d_cl_dtab); C.fblk = reinterpret_cast<const uint4*>(as->d_cl_fblk); C.oblk = reinterpret_cast<const uint4*>(as->d_cl_oblk);
+  C.sinfo = as->d_cl_sinfo;
+  C.vdst = as->d_cl_vdst64; C.fdst = as->d_cl_fdst; C.map = reinterpret_cast<const uint4*>(as->d_cl_map);
+  C.Pbuf = as->d_Pbuf; C.res = res;
   if (P.source_kind == 4) FH_TRY(launch_cluster_one<2>(as, P, C));
   else if (P.source_kind != 0) FH_TRY(launch_cluster_one<1>(as, P, C));
   else FH_TRY(launch_cluster_one<0>(as, P, C));
   if (as->cl_nprow > 0 && !(as->ctx->asm_debug & (2 | 8))) {
-    hipLaunchKernelGGL(k_rows_partial, dim3(fh_div_up(as->cl_nprow, 8)), dim3(256), 0, as->ctx->stream, as->cl_nprow, as->d_cl_prow, as->d_cl_padj_ptr, as->d_cl_padj_off,
-                       as->d_cl_padj_len, as->d_cl_pmap, as->d_Pbuf, A->d_rowptr, A->d_val, res);
+    // plain loads of the partial rows: a segment starts at any multiple of 8 bytes, so neighbouring segments share cache lines -- non-temporal
+    // loads fetched those twice (measured 1.36 -> 1.33 ms per assembly; asm_debug bit 5 selects them for comparison)
+    if (!(as->ctx->asm_debug & 32))
+      hipLaunchKernelGGL(k_rows_partial<0>, dim3(fh_div_up(as->cl_nprow, 16)), dim3(256), 0, as->ctx->stream, as->cl_nprow, as->d_cl_prow, as->d_cl_pstart,
+                         as->d_cl_pmap, as->d_Pbuf, A->d_rowptr, A->d_val, res, 0);
+    else
+      hipLaunchKernelGGL(k_rows_partial<1>, dim3(fh_div_up(as->cl_nprow, 16)), dim3(256), 0, as->ctx->stream, as->cl_nprow, as->d_cl_prow, as->d_cl_pstart,
+                         as->d_cl_pmap, as->d_Pbuf, A->d_rowptr, A->d_val, res, 1);
     FH_CHECK_HIP(hipGetLastError());
   }
   return 0;
@@ -2770,8 +2849,8 @@ extern "C" int fh_assembler_destroy(fh_assembler_t as) {
   if (as->d_prog) hipFree(as->d_prog);
   if (as->d_prog_consts) hipFree(as->d_prog_consts);
   hipFree(as->d_iota);
-  for (void* q : {(void*)as->d_cl_dtab, (void*)as->d_cl_fdesc, (void*)as->d_cl_sinfo, (void*)as->d_cl_ovf, (void*)as->d_cl_vdst, (void*)as->d_cl_fdst, (void*)as->d_cl_map, (void*)as->d_cl_pmap,
-                  (void*)as->d_Pbuf, (void*)as->d_cl_prow, (void*)as->d_cl_padj_ptr, (void*)as->d_cl_padj_off, (void*)as->d_cl_padj_len})
+  for (void* q : {(void*)as->d_cl_dtab, (void*)as->d_cl_fblk, (void*)as->d_cl_sinfo, (void*)as->d_cl_oblk, (void*)as->d_cl_vdst, (void*)as->d_cl_vdst64, (void*)as->d_cl_fdst, (void*)as->d_cl_map, (void*)as->d_cl_pmap,
+                  (void*)as->d_Pbuf, (void*)as->d_cl_prow, (void*)as->d_cl_pstart})
     if (q) hipFree(q);
   for (void* q : {(void*)as->d_adj_ptr, (void*)as->d_adj_ei, (void*)as->d_rowmap, (void*)as->d_Kbuf, (void*)as->d_Fbuf, (void*)as->d_slot, (void*)as->d_gal_child,
                   (void*)as->d_gal_cnt, (void*)as->d_gal_row, (void*)as->d_gal_fb, (void*)as->d_gal_cb, (void*)as->d_gal_val, (void*)as->d_gal_res, (void*)as->d_gal_dense})
@@ -2953,6 +3032,16 @@ extern "C" int fh_assembler_affine_count(fh_assembler_t as, int* n_affine, int* 
   FH_REQUIRE(as, "fh_assembler_affine_count: null argument");
   if (n_affine) *n_affine = as->d_Mab ? as->n_aff : 0;
   if (n_general) *n_general = as->d_Mab ? as->n_gen : as->nel;
+  return 0;
+}
+
+extern "C" int fh_assembler_fused_info(fh_assembler_t as, int* active, int* nclusters, int64_t* partial_entries, int* second_pass_rows) {
+  FH_REQUIRE(as, "fh_assembler_fused_info: null argument");
+  const bool on = as->fused && as->ctx->assemble_fused && as->ctx->assemble_sf;
+  if (active) *active = on ? 1 : 0;
+  if (nclusters) *nclusters = as->fused ? as->cl_ncl : 0;
+  if (partial_entries) *partial_entries = as->fused ? (int64_t)as->cl_npart : 0;
+  if (second_pass_rows) *second_pass_rows = as->fused ? as->cl_nprow : 0;
   return 0;
 }
 

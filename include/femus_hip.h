@@ -64,7 +64,7 @@ int fh_graph_destroy(fh_graph_t graph);
  * names (default): "spmv_tile" (2048), "spmv_xcd_remap" (32), "spmv_kernel" (3), "assemble_two_pass" (1), "assemble_emap" (1),
  * "assemble_mfma" (12: HEX27/Q2 element matrices on the FP64 matrix cores, value = waves per workgroup, 0 = vector kernel),
  * "assemble_kpad" (1: element rows of the two-pass buffer padded to 256 bytes; read when an assembler is created),
- * "assemble_sumfac" (1: map Jacobian by sum factorisation in that kernel), "assemble_sym" (1), "assemble_affine" (0, see fh_assembler_affine_count), "gj_mfma" (1: coarse dense inverse updates on the
+ * "assemble_sumfac" (1: map Jacobian by sum factorisation in that kernel), "assemble_sym" (1), "assemble_affine" (0, see fh_assembler_affine_count), "assemble_fused" (1, see fh_assembler_fused_info), "gj_mfma" (1: coarse dense inverse updates on the
  * matrix cores), "gj_symmetric" (1: symmetric sweep on the upper block triangle when the coarse operator is symmetric), "spgemm_slot_map" (1), "use_graph" (1), "asm_debug" (0),
  * "debug_poison" (0; tests: work buffers of the solvers and the element-row buffers start as NaN bit patterns instead of zero),
  * "halo_overlap" (1: on distributed levels the rows without ghost columns are multiplied while the ghost exchange is in flight),
@@ -282,6 +282,14 @@ int fh_element_matrices_poisson(fh_assembler_t as, fh_vec_t sol, int source_kind
  * element size) are assembled from nine reference matrices M_ab = sum_g w_g d_a phi_i d_b phi_j as K = sum_ab det (J^-1 J^-T)_ab M_ab,
  * which equals the quadrature loop up to summation order; curved elements keep the quadrature kernel.  Two-pass mode only. */
 int fh_assembler_affine_count(fh_assembler_t as, int* n_affine, int* n_general);
+/* Fused cluster assembly (fh_set_option(ctx, "assemble_fused", 1), the default; read when an assembler is created and at every assembly):
+ * HEX27 / Q2 meshes whose elements come in groups of eight consecutive elements with one common local topology -- the children of one
+ * coarse element as MeshRefinement.cpp:240-294 numbers them -- are assembled group by group: the CSR rows whose elements all lie in the
+ * group are written once, straight from the eight element matrices; the others are summed by a second pass over a partial-row buffer.
+ * Same element matrices as the two-pass path, sums grouped per cluster (deterministic).  active = 0: the mesh does not offer the structure
+ * (or the option is off) and the two-pass path runs.  partial_entries = doubles in the partial-row buffer, second_pass_rows = CSR rows summed
+ * by the second pass (the scatter of separate.hpp:165-205 through PetscMatrix.cpp:699-729 is what both paths replace). */
+int fh_assembler_fused_info(fh_assembler_t as, int* active, int* nclusters, int64_t* partial_entries, int* second_pass_rows);
 
 /* Neumann boundary term of the 001_Poisson callback (applications/001_Poisson/main.cpp:560-594): for every listed boundary face
  * res[node_i] += int_face phi_i * tau ds with elem_type::JacobianSur (ElemType.hpp:1089-1138 edges, :1330-1380 quad faces).

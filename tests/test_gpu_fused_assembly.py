@@ -1,0 +1,150 @@
+"""GPU parity of the fused cluster assembly (k_cluster_q2hex_sf + k_rows_partial; `00_poisson_eqn_..._separate.hpp:165-205` + the scatter of
+`PetscMatrix.cpp:699-729`): against the oracle's element loop, against the two-pass path, on meshes that offer the sibling structure and on
+meshes that do not, with rows outside the matrix, after a change of the value array, and as the source of the element-wise Galerkin product."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import femus_amd
+from femus_amd import capi
+from oracle import femus_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+
+def levels(args, nl):
+    ms = [capi.Mesh.box(*args)]
+    for _ in range(nl - 1):
+        ms.append(ms[-1].refine())
+    return ms
+
+
+def oracle_global(ed, xy, u, rhs, n):
+    et = fo.ElemType("hex", "biquadratic", "seventh")
+    Ko, Fo = fo.elem_poisson_batch(et, np.transpose(xy[ed], (0, 2, 1)), u[ed], rhs)
+    rows = np.repeat(ed, 27, axis=1).ravel()
+    cols = np.tile(ed, (1, 27)).ravel()
+    Ao = sp.coo_matrix((Ko.ravel(), (rows, cols)), shape=(n, n)).tocsr()
+    Ao.sort_indices()
+    bo = np.zeros(n)
+    np.add.at(bo, ed.ravel(), Fo.ravel())
+    return Ao, bo
+
+
+KINDS = {0: ((1.5,), lambda xg: 1.5 * np.ones(xg.shape[:2])), 1: ((2.0, 1.3), lambda xg: 2.0 * np.prod(np.sin(1.3 * xg), axis=-1)),
+         2: ((2.0, 1.3), lambda xg: 2.0 * np.prod(np.cos(1.3 * xg), axis=-1))}
+
+
+@pytest.mark.parametrize("args,nl,kind,with_sol", [((1, 1, 1), 2, 0, True), ((2, 1, 1), 2, 1, True), ((3, 2, 2), 2, 2, False), ((2, 2, 2), 3, 1, True)])
+def test_fused_assembly_matches_oracle_and_two_pass(ctx, args, nl, kind, with_sol):
+    """curved refined meshes (1, 2, 12 and 64 clusters: one cluster = every row complete; boundary clusters; interior clusters): the fused path
+    runs (fused_info), equals the oracle's element loop to 1e-12 and the two-pass path to rounding, is bit-identical when repeated from
+    NaN-poisoned buffers, and writes every row (the matrix starts as NaN)."""
+    m = levels(args, nl)[-1]
+    ed, xy, _ = m.arrays()
+    rng = np.random.default_rng(3)
+    xy = xy + rng.uniform(-0.01, 0.01, xy.shape) / 2 ** (nl - 1)
+    n = m.nnode
+    rp, col = capi.pattern_from_elements(ed, n)
+    u = rng.uniform(-1, 1, n) if with_sol else np.zeros(n)
+    params, rhs = KINDS[kind]
+    out = {}
+    for fused in (1, 0):
+        ctx.set_option("assemble_fused", fused)
+        ctx.set_option("debug_poison", 1)
+        try:
+            A = ctx.matrix_csr(n, n, rp, col, np.full(col.size, np.nan))
+            res = ctx.vector_from(np.full(n, np.nan))
+            asm = capi.Assembler(ctx, m, "biquadratic", A, elem_dof=ed, coords=xy)
+            info = asm.fused_info()
+            assert info["active"] == bool(fused) and (not fused or info["clusters"] == m.nel // 8)
+            sol = ctx.vector_from(u) if with_sol else None
+            asm.assemble(A, res, sol, kind, params)
+            v1, f1 = A.values().copy(), res.to_numpy().copy()
+            asm.assemble(A, res, sol, kind, params)
+            assert np.array_equal(v1, A.values()) and np.array_equal(f1, res.to_numpy())
+            out[fused] = (v1, f1)
+            asm.destroy(), A.destroy()
+        finally:
+            ctx.set_option("debug_poison", 0)
+            ctx.set_option("assemble_fused", 1)
+    Ao, bo = oracle_global(ed, xy, u, rhs, n)
+    assert np.array_equal(Ao.indptr, rp) and np.array_equal(Ao.indices, col)
+    for fused in (1, 0):
+        v, f = out[fused]
+        assert np.isfinite(v).all() and np.isfinite(f).all()
+        assert abs(v - Ao.data).max() <= 1e-12 * abs(Ao.data).max()
+        assert abs(f - bo).max() <= 1e-12 * abs(bo).max()
+    assert abs(out[1][0] - out[0][0]).max() <= 4e-16 * abs(Ao.data).max()      # same element matrices, sums grouped per cluster
+    assert abs(out[1][1] - out[0][1]).max() <= 1e-15 * abs(bo).max()
+
+
+def test_fused_plan_is_refused_where_the_mesh_has_no_sibling_groups(ctx):
+    """an unrefined box (elements are no siblings) and a refined mesh whose elements were shuffled: the template check fails, the two-pass path
+    runs and gives the oracle's operator; a refined mesh keeps the fused path when WHOLE sibling groups are permuted"""
+    rng = np.random.default_rng(9)
+    for case in ("unrefined", "shuffled", "groups"):
+        m = levels((4, 2, 2), 1)[0] if case == "unrefined" else levels((2, 2, 1), 2)[-1]
+        ed, xy, _ = m.arrays()
+        if case == "shuffled":
+            ed = ed[rng.permutation(ed.shape[0])]
+        elif case == "groups":
+            ed = ed.reshape(-1, 8, 27)[rng.permutation(ed.shape[0] // 8)].reshape(-1, 27)
+        xy = xy + rng.uniform(-0.01, 0.01, xy.shape)
+        n = m.nnode
+        rp, col = capi.pattern_from_elements(ed, n)
+        A = ctx.matrix_csr(n, n, rp, col)
+        res = ctx.vector(n)
+        asm = capi.Assembler(ctx, m, "biquadratic", A, elem_dof=ed, coords=xy)
+        assert asm.fused_info()["active"] == (case == "groups")
+        u = rng.uniform(-1, 1, n)
+        asm.assemble(A, res, ctx.vector_from(u), 1, (2.0, 1.3))
+        Ao, bo = oracle_global(ed, xy, u, KINDS[1][1], n)
+        assert abs(A.values() - Ao.data).max() <= 1e-12 * abs(Ao.data).max()
+        assert abs(res.to_numpy() - bo).max() <= 1e-12 * abs(bo).max()
+        asm.destroy(), A.destroy()
+
+
+def test_fused_assembly_with_rows_outside_the_matrix_and_another_value_array(ctx):
+    """owned rows x local columns (what a rank of the distributed driver assembles): rows of nodes >= m go nowhere; then the same assembler
+    on a second matrix of the same pattern (the row destinations are re-based)"""
+    m = levels((2, 2, 1), 2)[-1]
+    ed, xy, _ = m.arrays()
+    rng = np.random.default_rng(21)
+    xy = xy + rng.uniform(-0.01, 0.01, xy.shape)
+    n = m.nnode
+    mrows = (2 * n) // 3
+    rp, col = capi.pattern_from_elements(ed, n)
+    rp_o, col_o = rp[:mrows + 1].copy(), col[:rp[mrows]].copy()
+    u = rng.uniform(-1, 1, n)
+    Ao, bo = oracle_global(ed, xy, u, KINDS[2][1], n)
+    A = ctx.matrix_csr(mrows, n, rp_o, col_o)
+    B = ctx.matrix_csr(mrows, n, rp_o, col_o)
+    res = ctx.vector(n)
+    asm = capi.Assembler(ctx, m, "biquadratic", A, elem_dof=ed, coords=xy)
+    assert asm.fused_info()["active"]
+    for M in (A, B, A):
+        asm.assemble(M, res, ctx.vector_from(u), 2, (2.0, 1.3))
+        assert abs(M.values() - Ao.data[:rp[mrows]]).max() <= 1e-12 * abs(Ao.data).max()
+        assert abs(res.to_numpy()[:mrows] - bo[:mrows]).max() <= 1e-12 * abs(bo).max()
+    asm.destroy(), A.destroy(), B.destroy()
+
+
+def test_elementwise_galerkin_after_a_fused_assembly(ctx):
+    """the fused path keeps no element rows: the element-wise Galerkin product re-creates them (pass 1 of the two-pass path with the last
+    arguments) and gives the same coarse operator as after a two-pass assembly"""
+    from femus_amd.poisson import PoissonMG
+    vals = {}
+    for fused in (1, 0):
+        ctx.set_option("assemble_fused", fused)
+        try:
+            pb = PoissonMG(ctx, 2, 2, 2, 3).init()
+            assert pb.asm[-1].fused_info()["active"] == bool(fused)
+            pb.assemble()
+            pb.prepare()
+            vals[fused] = [pb.A[l].to_scipy() for l in range(pb.nlevels)]
+            pb.destroy()
+        finally:
+            ctx.set_option("assemble_fused", 1)
+    for a, b in zip(vals[1], vals[0]):
+        assert abs(a - b).max() <= 1e-13 * abs(b).max()
