@@ -24,10 +24,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6    # vendor FP64 vector peak = FP64 matrix peak on MI355X
-# k_elem_q2hex_sf, per element, from the PMC passes (profiles/r03_assembly_pmc_summary.md): 361 FMA, 51 MUL, 2 ADD FP64 vector
-# instructions on 64 lanes + 15 v_mfma_f64_4x4x4_4b of 512 flops
-ELEM_EXECUTED_FLOPS = (361 * 2 + 51 + 2) * 64 + 15 * 512
-ELEM_ALGORITHMIC_BYTES = 27 * 4 + 27 * 24 + 27 * 8 + 27 * 32 * 8 + 27 * 8    # node ids, coordinates, solution, padded element rows, residual
+# k_cluster_q2hex_sf / k_elem_q2hex_sf, per element, from the PMC passes (profiles/r04_assembly_pmc_summary.md): 361 FMA, 51 MUL and 20 (fused
+# path; 2 in the two-pass kernel) ADD FP64 vector instructions on 64 lanes + 15 v_mfma_f64_4x4x4_4b of 512 flops
+ELEM_EXECUTED_FLOPS = (361 * 2 + 51 + 20) * 64 + 15 * 512
 
 
 def parse():
@@ -270,6 +269,7 @@ def main():
     exp_lo, exp_hi = A.spmv_expected_bytes(3)
     cyc_bytes = pb.mg.cycle_algorithmic_bytes()
     ai = pb.asm_top.info()
+    fused = pb.asm_top.fused_info()
 
     out = {
         "metric": "assembled DOFs/sec + V-cycle SpMV GB/s (% HBM peak), 3D Poisson Q2",
@@ -344,33 +344,31 @@ def main():
             "step_ms_estimate": ms_per_step - asm_ms + asm_affine_ms,
         },
         "roofline_assembly": {
-            "kernel": "k_elem_q2hex_sf (element matrices by sum factorisation: K_e contracted one direction at a time, 15 FP64 matrix "
-                      "instructions + ~410 FP64 vector instructions per element instead of the 27 x 27 x 64 x 9 products of the reference's "
-                      "loop); the row pass k_row_assemble2<27> is reported beside it",
+            "kernel": ("k_cluster_q2hex_sf + k_rows_partial (fused cluster assembly: eight sibling elements per workgroup, element matrices by sum factorisation, "
+                       "rows complete inside the cluster written straight into the CSR arrays, the others through the partial-row buffer and the second pass)"
+                       if fused["active"] else
+                       "k_elem_q2hex_sf + k_row_assemble2_t<27> (two-pass assembly: element matrices by sum factorisation into the element-row buffer, row gather)"),
             "bound": "hbm",
-            "achieved": ELEM_ALGORITHMIC_BYTES * nel / elem_ms / 1e6,
+            "achieved": ai["algorithmic_bytes"] / asm_ms / 1e6,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
-            "frac": ELEM_ALGORITHMIC_BYTES * nel / elem_ms / 1e6 / HBM_PEAK_GBPS,
-            "bytes_model": "per element: 27 node ids + 27 coordinates + 27 solution values read, 27 padded rows of 256 bytes + 27 residual "
-                           "entries written = %d B (the element-row buffer is the kernel's output; the row pass reads it back)" % ELEM_ALGORITHMIC_BYTES,
+            "frac": ai["algorithmic_bytes"] / asm_ms / 1e6 / HBM_PEAK_GBPS,
+            "bytes_model": "SURVEY 8(d): per element 27 node ids + 27 coordinates + 27 solution values read, 27 x 27 matrix entries + 27 residual entries "
+                           "written = 7 020 B, x %d elements = %d B per assembly, over the time of the assembly's kernels (HIP events)" % (nel, ai["algorithmic_bytes"]),
+            "avg_launch_ms": asm_ms,
+            "first_kernel_ms": elem_ms,
+            "second_pass_ms": asm_ms - elem_ms,
+            "fused": fused,
             "executed_tflops": ELEM_EXECUTED_FLOPS * nel / elem_ms / 1e9,
             "executed_frac_fp64_peak": ELEM_EXECUTED_FLOPS * nel / elem_ms / 1e9 / FP64_VALU_PEAK_TFLOPS,
-            "flops_model": "EXECUTED flops per element: (361 FMA x 2 + 51 MUL + 2 ADD) x 64 lanes + 15 MFMA x 512 = %d (instruction counts "
-                           "from the PMC passes); the kernel is bound by neither roof: LDS instruction issue and the latency of its ~15 "
-                           "dependent LDS round trips per element (DESIGN section 4).  `algorithmic_tflops` prices the reference's full "
-                           "element loop instead (SURVEY 8d, 4.6e5 flop/element): above the 78.6 TFLOP/s FP64 peak, i.e. the loop as the "
-                           "reference writes it could not run this fast on this device" % ELEM_EXECUTED_FLOPS,
+            "flops_model": "EXECUTED flops per element of the first kernel: (361 FMA x 2 + 51 MUL + 20 ADD) x 64 lanes + 15 MFMA x 512 = %d (instruction counts "
+                           "from the PMC passes).  `algorithmic_tflops` prices the reference's full element loop instead (SURVEY 8d, 4.6e5 flop/element): "
+                           "above the 78.6 TFLOP/s FP64 peak, i.e. the loop as the reference writes it could not run this fast on this device" % ELEM_EXECUTED_FLOPS,
             "algorithmic_tflops": ai["flops"] / elem_ms / 1e9,
-            "avg_launch_ms": elem_ms,
-            "traffic": TRAFFIC["asm"]["elem"] if world == 1 else None,
-            "row_pass_traffic": TRAFFIC["asm"]["rows"] if world == 1 else None,
+            "traffic": (TRAFFIC["asm"]["elem"] + TRAFFIC["asm"]["rows"]) if world == 1 and TRAFFIC["asm"]["elem"] and TRAFFIC["asm"]["rows"] else None,
+            "first_kernel_traffic": TRAFFIC["asm"]["elem"] if world == 1 else None,
+            "second_pass_traffic": TRAFFIC["asm"]["rows"] if world == 1 else None,
             "traffic_from_profile": TRAFFIC["asm"]["source"] if world == 1 else None,
-            "row_pass_ms": asm_ms - elem_ms,
-            "row_pass_GBps": (nel * 27 * (32 * 8 + 27 + 8) + A.nnz * 8.0) / max(asm_ms - elem_ms, 1e-9) / 1e6,
-            "assembly_achieved_tflops": ai["flops"] / asm_ms / 1e9,
-            "assembly_GBps": ai["algorithmic_bytes"] / asm_ms / 1e6,
-            "assembly_frac_hbm": ai["algorithmic_bytes"] / asm_ms / 1e6 / HBM_PEAK_GBPS,
         },
     }
 
@@ -389,8 +387,10 @@ def main():
                 how += "; one-GPU problem of the same local size on rank 0's device"
             out["roofline"]["traffic"] = live["spmv"]
             out["roofline"]["traffic_source"] = how
-            out["roofline_assembly"]["traffic"] = live["elem"]
-            out["roofline_assembly"]["row_pass_traffic"] = live["rows"]
+            out["roofline_assembly"]["traffic"] = live["elem"] + live["rows"]
+            out["roofline_assembly"]["first_kernel_traffic"] = live["elem"]
+            out["roofline_assembly"]["second_pass_traffic"] = live["rows"]
+            out["roofline_assembly"]["traffic_over_algorithmic"] = (live["elem"] + live["rows"]) / ai["algorithmic_bytes"]
             out["roofline_assembly"]["traffic_source"] = how
         else:
             out["roofline"]["traffic_source"] = "committed counter passes (%s); live measurement skipped: %s" % (TRAFFIC["spmv"]["source"], how)
@@ -571,8 +571,8 @@ def live_traffic(coarse, levels, timeout=150, device=0):
                     if row["Counter_Name"] != counter:
                         continue
                     name = row["Kernel_Name"]
-                    key = ("spmv" if "k_spmv_lx<2048, 3" in name else "elem" if "k_elem_q2hex_" in name else
-                           "rows" if "k_row_assemble" in name and "true>" not in name.split("(")[0] else None)
+                    key = ("spmv" if "k_spmv_lx<2048, 3" in name else "elem" if ("k_elem_q2hex_" in name or "k_cluster_q2hex_" in name) else
+                           "rows" if ("k_rows_partial" in name or ("k_row_assemble" in name and "true>" not in name.split("(")[0])) else None)
                     if key:
                         per.setdefault((key, int(row.get("Grid_Size", 0) or 0)), []).append(float(row["Counter_Value"]))
             for key in ("spmv", "elem", "rows"):
@@ -600,8 +600,8 @@ def _traffic():
         out["spmv"] = {"bytes": d.get("traffic_bytes_per_launch"), "source": src}
     d, src = _newest_profile("assembly_traffic.json")
     if d:
-        el = [v for k, v in d.items() if k.startswith("k_elem_q2hex_")]
-        rw = [v for k, v in d.items() if k.startswith("k_row_assemble")]
+        el = [v for k, v in d.items() if k.startswith("k_elem_q2hex_") or k.startswith("k_cluster_q2hex_")]
+        rw = [v for k, v in d.items() if k.startswith("k_row_assemble") or k.startswith("k_rows_partial")]
         out["asm"] = {"elem": el[0]["traffic_bytes_per_launch"] if el else None, "rows": rw[0]["traffic_bytes_per_launch"] if rw else None, "source": src}
     return out
 
