@@ -1,7 +1,7 @@
 // LinearEquationSolverHip::BuildBdcIndex -- the one member of the adapters that reads the mesh (Mesh::_dofOffset), kept in its own
 // translation unit: Mesh.hpp of the FEMuS tree pulls in the whole finite-element layer, so a FEMuS build compiles this file with
 // the rest of its library, while the interface check of tests/test_adapters_vs_reference_headers.py (no boost in this image)
-// covers HipBackend.cpp.  Same statement order as LinearEquationSolverPetsc::BuildBdcIndex (LinearEquationSolverPetsc.cpp:53-90).
+// covers HipBackend.cpp.  BuildBdcIndex serves LinearEquationSolverPetsc::BuildBdcIndex (LinearEquationSolverPetsc.cpp:53-90).
 #include "HipBackend.hpp"
 #include "Mesh.hpp"
 #include <algorithm>
@@ -9,111 +9,99 @@
 namespace femus {
 
 void LinearEquationSolverHip::BuildBdcIndex(const std::vector<unsigned>& variable_to_be_solved) {
+  // Rows the level solver keeps as identity rows (SetPenalty / ZerosBoundaryResiduals): every owned dof of a variable that is NOT solved for,
+  // and of the solved variables the dofs whose boundary flag is below 1.5 (2 = free, 1 = AMR-constrained, 0 = Dirichlet); ascending.
   _bdcIndexIsInitialized = true;
-  const int p = processor_id();
-  _bdcIndex.resize(KKoffset[KKIndex.size() - 1][p] - KKoffset[0][p]);
-  std::vector<bool> ThisSolutionIsIncluded(_SolPdeIndex.size(), false);
-  for (unsigned iind = 0; iind < variable_to_be_solved.size(); iind++) ThisSolutionIsIncluded[variable_to_be_solved[iind]] = true;
-  unsigned count0 = 0;
-  for (unsigned k = 0; k < _SolPdeIndex.size(); k++) {
-    const unsigned indexSol = _SolPdeIndex[k];
-    const unsigned soltype = _SolType[indexSol];
-    const unsigned first = GetMeshFromLinEq()->_dofOffset[soltype][p], last = GetMeshFromLinEq()->_dofOffset[soltype][p + 1];
-    if (!ThisSolutionIsIncluded[k]) {
-      for (unsigned inode = first; inode < last; inode++) _bdcIndex[count0++] = KKoffset[k][p] + (inode - first);
+  const int rank = processor_id();
+  const Mesh& mesh = *GetMeshFromLinEq();
+  std::vector<char> solved(_SolPdeIndex.size(), 0);
+  for (unsigned v : variable_to_be_solved) solved[v] = 1;
+  _bdcIndex.clear();
+  _bdcIndex.reserve(KKoffset[KKIndex.size() - 1][rank] - KKoffset[0][rank]);
+  std::vector<int> nodes;
+  std::vector<double> flag;
+  for (size_t v = 0; v < _SolPdeIndex.size(); v++) {
+    const unsigned sol = _SolPdeIndex[v], family = _SolType[sol];
+    const unsigned node0 = mesh._dofOffset[family][rank], node1 = mesh._dofOffset[family][rank + 1];
+    const int row0 = (int)KKoffset[v][rank];
+    if (!solved[v]) {
+      for (unsigned k = 0; k < node1 - node0; k++) _bdcIndex.push_back(row0 + (int)k);
       continue;
     }
     // the flag vector of this variable in one transfer instead of one host-synchronous operator()(i) per dof
-    std::vector<int> idx(last - first);
-    for (unsigned inode = first; inode < last; inode++) idx[inode - first] = (int)inode;
-    std::vector<double> flag;
-    (*_Bdc)[indexSol]->get(idx, flag);
-    for (unsigned inode = first; inode < last; inode++)
-      if (flag[inode - first] < 1.5) _bdcIndex[count0++] = KKoffset[k][p] + (inode - first);     // 2 = free, 1 = AMR-constrained, 0 = Dirichlet
+    nodes.resize(node1 - node0);
+    for (unsigned k = 0; k < node1 - node0; k++) nodes[k] = (int)(node0 + k);
+    (*_Bdc)[sol]->get(nodes, flag);
+    for (unsigned k = 0; k < node1 - node0; k++)
+      if (flag[k] < 1.5) _bdcIndex.push_back(row0 + (int)k);
   }
-  _bdcIndex.resize(count0);
   std::sort(_bdcIndex.begin(), _bdcIndex.end());
 }
 
-// Element blocks of the FEMuS_ASM solver from `SetElementBlockNumber` / `SetNumberOfSchurVariables`: the statement order of
-// LinearEquationSolverPetscAsm::BuildASMIndex (petsc_asm/LinearEquationSolverPetscAsm.cpp:91-276) with MeshASMPartitioning::DoPartition
-// (02_partitioning/MeshASMPartitioning.cpp:89-150) inlined -- runs of `_elementBlockNumber` consecutive owned elements per material class
-// (solid 4, porous 3, everything else), non-Schur variables on the elements around the block (vertex neighbours unless the Schur
-// variable is discontinuous: "FastVankaBlock"), Schur variables on the block's own elements.  The reference hands PCASM the overlapping
-// index set of a block as its subdomain (PC_ASM_BASIC: the whole subdomain is corrected); that set is the block here.
+// Element blocks of the FEMuS_ASM solver from `SetElementBlockNumber` / `SetNumberOfSchurVariables` -- what
+// LinearEquationSolverPetscAsm::BuildASMIndex (petsc_asm/LinearEquationSolverPetscAsm.cpp:91-276) and MeshASMPartitioning::DoPartition
+// (02_partitioning/MeshASMPartitioning.cpp:89-150) hand PCASM as overlapping subdomains, written from the contract:
+//   * the elements this process owns are split by material class (solid = 4, porous = 3, every other flag) and, inside a class, into runs of
+//     `_elementBlockNumber` consecutive elements: one block per run, classes in that order;
+//   * "non-Schur" variables are all variables of the system except the last `_NSchurVar` entries of the solve list; a block holds their
+//     system dofs on every OWNED element around one of its elements (the vertex neighbourhood, or only the face neighbourhood when the
+//     first Schur variable is a discontinuous family), and the Schur variables' dofs on its own elements;
+//   * every dof once, ascending; dofs of other processes that these elements carry belong to the set as well (PCASM's overlapping set).
+// PC_ASM_BASIC corrects the whole overlapping set, so that set is the block of the smoother.
 void LinearEquationSolverHipAsm::BuildASMIndex(const std::vector<unsigned>& variable_to_be_solved) {
-  const Mesh* msh = GetMeshFromLinEq();
-  bool FastVankaBlock = true;
-  if (_NSchurVar != 0)
-    FastVankaBlock = (_SolType[_SolPdeIndex[variable_to_be_solved[variable_to_be_solved.size() - _NSchurVar]]] < 3) ? false : true;   // NFE_FAMS_C_ZERO_LAGRANGE
-  const unsigned iproc = processor_id();
-  const unsigned DofOffset = KKoffset[0][iproc];
-  const unsigned DofOffsetSize = KKoffset[KKIndex.size() - 1][iproc] - KKoffset[0][iproc];
-  std::vector<unsigned> indexb(DofOffsetSize, DofOffsetSize);
-  const unsigned ElemOffset = msh->GetElementOffset(iproc), ElemOffsetp1 = msh->GetElementOffset(iproc + 1);
-  const unsigned ElemOffsetSize = ElemOffsetp1 - ElemOffset;
-  std::vector<unsigned> indexci(ElemOffsetSize), indexc(ElemOffsetSize, ElemOffsetSize);
-  // ---- DoPartition ----
-  std::vector<std::vector<unsigned> > block_elements;
-  {
-    const unsigned block_size[3] = {_elementBlockNumber, _elementBlockNumber, _elementBlockNumber};
-    const unsigned flag_block[3] = {4, 3, 2};
-    for (unsigned iMaterial = 0; iMaterial < 3; iMaterial++) {
-      std::vector<unsigned> mine;
-      for (unsigned iel = ElemOffset; iel < ElemOffsetp1; iel++) {
-        const unsigned flag_mat = msh->GetElementMaterial(iel);
-        const bool here = iMaterial < 2 ? flag_mat == flag_block[iMaterial] : (flag_mat != flag_block[0] && flag_mat != flag_block[1]);
-        if (here) mine.push_back(iel);
-      }
-      for (size_t k = 0; k < mine.size(); k += block_size[iMaterial])
-        block_elements.emplace_back(mine.begin() + k, mine.begin() + std::min(mine.size(), k + block_size[iMaterial]));
-    }
+  const Mesh& mesh = *GetMeshFromLinEq();
+  const unsigned rank = processor_id();
+  const unsigned first_elem = mesh.GetElementOffset(rank), end_elem = mesh.GetElementOffset(rank + 1);
+  const size_t nvar = _SolPdeIndex.size(), nsolve = variable_to_be_solved.size();
+
+  std::vector<char> is_schur(nvar, 0);
+  for (size_t k = nsolve - _NSchurVar; k < nsolve; k++) is_schur[variable_to_be_solved[k]] = 1;
+  // neighbourhood layer of Elem::GetElementNearElement: 1 = vertex neighbours, 0 = face neighbours (discontinuous Schur variable, family >= 3)
+  bool vertex_layer = false;
+  if (_NSchurVar != 0) vertex_layer = _SolType[_SolPdeIndex[variable_to_be_solved[nsolve - _NSchurVar]]] < 3;
+
+  // runs of consecutive owned elements per material class
+  std::vector<unsigned> of_class[3];
+  for (unsigned e = first_elem; e < end_elem; e++) {
+    const unsigned flag = mesh.GetElementMaterial(e);
+    of_class[flag == 4 ? 0 : flag == 3 ? 1 : 2].push_back(e);
   }
-  std::vector<bool> ThisVaribaleIsNonSchur(_SolPdeIndex.size(), true);
-  for (unsigned iind = variable_to_be_solved.size() - _NSchurVar; iind < variable_to_be_solved.size(); iind++)
-    ThisVaribaleIsNonSchur[variable_to_be_solved[iind]] = false;
+  const size_t run = std::max<size_t>(_elementBlockNumber, 1);
+
+  auto dofs_of = [&](unsigned elem, char schur, std::vector<int>& out) {       // system dofs of the (non-)Schur variables on one element
+    for (size_t v = 0; v < nvar; v++) {
+      if (is_schur[v] != schur) continue;
+      const unsigned sol = _SolPdeIndex[v];
+      const unsigned n = mesh.GetElementDofNumber(elem, _SolType[sol]);
+      for (unsigned i = 0; i < n; i++) out.push_back((int)GetSystemDof(sol, (unsigned)v, i, elem));
+    }
+  };
+
   _blockPtr.assign(1, 0);
   _blockDofs.clear();
-  for (size_t vb_index = 0; vb_index < block_elements.size(); vb_index++) {
-    std::vector<int> over;
-    unsigned Csize = 0;
-    for (size_t kel = 0; kel < block_elements[vb_index].size(); kel++) {
-      const unsigned iel = block_elements[vb_index][kel];
-      for (unsigned j = 0; j < msh->GetMeshElements()->GetElementNearElementSize(iel, !FastVankaBlock); j++) {
-        const unsigned jel = msh->GetMeshElements()->GetElementNearElement(iel, j);
-        if (jel < ElemOffset || jel >= ElemOffsetp1 || indexc[jel - ElemOffset] != ElemOffsetSize) continue;
-        indexci[Csize] = jel - ElemOffset;
-        indexc[jel - ElemOffset] = Csize++;
-        for (unsigned indexSol = 0; indexSol < _SolPdeIndex.size(); indexSol++) {       // non-Schur variables of the elements around
-          if (!ThisVaribaleIsNonSchur[indexSol]) continue;
-          const unsigned SolPdeIndex = _SolPdeIndex[indexSol], SolType = _SolType[SolPdeIndex];
-          for (unsigned jj = 0; jj < msh->GetElementDofNumber(jel, SolType); jj++) {
-            const unsigned kkdof = GetSystemDof(SolPdeIndex, indexSol, jj, jel);
-            if (kkdof - DofOffset < DofOffsetSize && indexb[kkdof - DofOffset] != DofOffsetSize) continue;
-            if (kkdof - DofOffset < DofOffsetSize) indexb[kkdof - DofOffset] = (unsigned)over.size();
-            over.push_back((int)kkdof);
-          }
+  std::vector<int> last_block_of(end_elem - first_elem, -1);     // block that took an owned element into its neighbourhood last
+  std::vector<int> dofs;
+  int block = 0;
+  for (const std::vector<unsigned>& elems : of_class)
+    for (size_t begin = 0; begin < elems.size(); begin += run, block++) {
+      const size_t end = std::min(elems.size(), begin + run);
+      dofs.clear();
+      for (size_t k = begin; k < end; k++) {
+        const unsigned own = elems[k];
+        const unsigned nnear = mesh.GetMeshElements()->GetElementNearElementSize(own, vertex_layer);
+        for (unsigned j = 0; j < nnear; j++) {
+          const unsigned around = mesh.GetMeshElements()->GetElementNearElement(own, j);
+          if (around < first_elem || around >= end_elem || last_block_of[around - first_elem] == block) continue;
+          last_block_of[around - first_elem] = block;
+          dofs_of(around, 0, dofs);
         }
+        dofs_of(own, 1, dofs);
       }
-      for (unsigned indexSol = 0; indexSol < _SolPdeIndex.size(); indexSol++) {         // Schur variables of the block's own elements
-        if (ThisVaribaleIsNonSchur[indexSol]) continue;
-        const unsigned SolPdeIndex = _SolPdeIndex[indexSol], SolType = _SolType[SolPdeIndex];
-        for (unsigned ii = 0; ii < msh->GetElementDofNumber(iel, SolType); ii++) {
-          const unsigned kkdof = GetSystemDof(SolPdeIndex, indexSol, ii, iel);
-          if (kkdof - DofOffset < DofOffsetSize && indexb[kkdof - DofOffset] != DofOffsetSize) continue;
-          if (kkdof - DofOffset < DofOffsetSize) indexb[kkdof - DofOffset] = (unsigned)over.size();
-          over.push_back((int)kkdof);
-        }
-      }
+      std::sort(dofs.begin(), dofs.end());
+      dofs.erase(std::unique(dofs.begin(), dofs.end()), dofs.end());
+      _blockDofs.insert(_blockDofs.end(), dofs.begin(), dofs.end());
+      _blockPtr.push_back((int)_blockDofs.size());
     }
-    for (int d : over)
-      if ((unsigned)d - DofOffset < DofOffsetSize) indexb[(unsigned)d - DofOffset] = DofOffsetSize;
-    for (unsigned i = 0; i < Csize; i++) indexc[indexci[i]] = ElemOffsetSize;
-    std::sort(over.begin(), over.end());
-    over.erase(std::unique(over.begin(), over.end()), over.end());
-    _blockDofs.insert(_blockDofs.end(), over.begin(), over.end());
-    _blockPtr.push_back((int)_blockDofs.size());
-  }
 }
 
 }  // namespace femus

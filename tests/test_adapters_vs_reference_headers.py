@@ -6,9 +6,12 @@ exact signature (no "abstract class", no "marked override but does not override"
 What the check supplies, and why it pins nothing: a FemusConfig.hpp (cmake generates it from src/00_utils/FemusConfig.hpp.in) with
 HAVE_MPI and LSOLVER, and opaque declarations of the PETSc handle types that FieldSplitTree.hpp:63-120 and
 LinearEquationSolver.hpp:132 (`KSP* GetKSP()`) name in the abstract interface -- PETSc itself is not in this image.  Nothing is
-linked or run, and nothing here is oracle evidence.  HipBackendBdc.cpp (BuildBdcIndex, reads Mesh::_dofOffset) needs Mesh.hpp, which
-pulls in boost/optional.hpp (absent): it is compiled in the stand-alone build against the mirrored headers and by a FEMuS build with
-the rest of its library."""
+linked or run, and nothing here is oracle evidence.  HipBackendBdc.cpp (BuildBdcIndex / BuildASMIndex: the members that read the real
+Mesh -- _dofOffset, GetElementOffset, GetElementMaterial, GetMeshElements()->GetElementNearElement, GetElementDofNumber) needs Mesh.hpp, whose
+include chain reaches boost/optional.hpp (absent) through ElemType.hpp only: `test_mesh_reading_members_against_the_real_mesh_header` cuts
+the chain THERE -- in the test, by pre-defining that header's include guard and forward-declaring `elem_type`, which Mesh.hpp uses through
+pointers -- and runs the front end (-fsyntax-only) over the file: every Mesh / Elem member the adapters name is checked against the real
+declarations."""
 import glob
 import os
 import subprocess
@@ -73,6 +76,35 @@ def test_adapters_derive_from_the_reference_classes(tmp_path):
     nm = subprocess.run(["nm", "-C", str(tmp_path / "hb.o")], capture_output=True, text=True).stdout
     for sym in ("U femus::NumericVector::subset_l2_norm", "U femus::SparseMatrix::read_len_hdf5", "U femus::LinearEquation::~LinearEquation"):
         assert sym in nm, sym
+
+
+def test_mesh_reading_members_against_the_real_mesh_header(tmp_path):
+    """HipBackendBdc.cpp through the compiler front end against /root/reference/src's Mesh.hpp (include chain cut at ElemType.hpp, the one header
+    that needs boost); a misspelt Mesh member must be caught by the same command"""
+    (tmp_path / "FemusConfig.hpp").write_text(
+        "#ifndef __femus_FemusConfig_hpp__\n#define __femus_FemusConfig_hpp__\n#define FEMTTU_VERSION_MAJOR 1\n#define FEMTTU_VERSION_MINOR 0\n"
+        "#define HAVE_MPI\n#define LSOLVER PETSC_SOLVERS\n#endif\n")
+    et = glob.glob(os.path.join(REF, "**", "ElemType.hpp"), recursive=True)[0]
+    guard = [l.split()[1] for l in open(et) if l.startswith("#ifndef")][0]
+    (tmp_path / "prelude.h").write_text(
+        "typedef struct _p_KSP* KSP; typedef struct _p_PC* PC; typedef struct _p_IS* IS; typedef int PetscInt;\n"
+        "#define %s\nnamespace femus { class elem_type; }\n" % guard)
+    inc = ["-I" + d for d, _, _ in os.walk(REF)]
+    mpi = [d for d in ("/opt/conda/include", "/usr/include/x86_64-linux-gnu/mpich", "/usr/lib/x86_64-linux-gnu/openmpi/include")
+           if os.path.exists(os.path.join(d, "mpi.h"))]
+    if not mpi:
+        pytest.skip("no mpi.h in this image (ParallelObject.hpp includes it)")
+    adapters = os.path.join(ROOT, "femus_amd", "csrc", "adapters")
+    base = ["g++", "-std=c++17", "-fsyntax-only", "-include", str(tmp_path / "prelude.h"), "-I" + str(tmp_path)] + inc + \
+           ["-I" + mpi[0], "-I" + os.path.join(ROOT, "include"), "-I" + adapters]
+    src = os.path.join(adapters, "HipBackendBdc.cpp")
+    out = subprocess.run(base + [src], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-4000:]
+    assert "mirror" not in out.stderr                       # no mirrored header took part
+    bad = tmp_path / "bad.cpp"
+    bad.write_text(open(src).read().replace("GetElementMaterial(", "GetElementMaterialX("))
+    out = subprocess.run(base + [str(bad)], capture_output=True, text=True)
+    assert out.returncode != 0 and "no member named" in out.stderr
 
 
 def test_mirrored_headers_declare_every_pure_virtual_of_the_reference():
