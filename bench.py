@@ -161,11 +161,14 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    ctx.marker(1)                                # phase markers (one-thread kernels) cut a kernel trace of this command: profiles/summarize.py
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = comm.allreduce_max(time.perf_counter() - t0)
+    ctx.marker(2)
     ms_per_step = elapsed / args.steps * 1e3
     ndof_total = int(sum(comm.allgather_obj(int(ndof))))
     value = ndof_total * args.steps / elapsed
@@ -209,10 +212,12 @@ def main():
     pb.set_penalty_top()
     pb.zero_boundary_residuals()
     barrier()
+    ctx.marker(3)
     ctx.timer_start()
     for _ in range(reps):
         pb.vcycle()
     cyc_ms = comm.allreduce_max(ctx.timer_stop() / reps)
+    ctx.marker(4)
     # host time to ISSUE one cycle (no synchronisation inside): on one GPU one hipGraphLaunch, on several ranks ~60 launches + the RCCL
     # groups one by one (a distributed cycle is not captured) -- if this exceeds vcycle_ms the host is the bound
     barrier()
@@ -242,11 +247,13 @@ def main():
         x.jacobi_sweep(pb.RES, y, A, dinv, 2. / 3.)
     # timed as the cycle issues them: the kr launches recorded into one hipGraph and replayed (eager launches of this kernel sit ~20 us apart,
     # replayed ones back to back); the eager figure is kept beside it
+    ctx.marker(5)
     ctx.timer_start()
     for _ in range(kr // 2):
         y.jacobi_sweep(pb.RES, x, A, dinv, 2. / 3.)
         x.jacobi_sweep(pb.RES, y, A, dinv, 2. / 3.)
     sweep_eager_ms = ctx.timer_stop() / (2 * (kr // 2))
+    ctx.marker(6)
     sweep_ms = sweep_eager_ms
     try:
         with ctx.record() as rec:
@@ -254,9 +261,11 @@ def main():
                 y.jacobi_sweep(pb.RES, x, A, dinv, 2. / 3.)
                 x.jacobi_sweep(pb.RES, y, A, dinv, 2. / 3.)
         rec.graph.launch()
+        ctx.marker(7)
         ctx.timer_start()
         rec.graph.launch()
         sweep_ms = ctx.timer_stop() / (2 * (kr // 2))
+        ctx.marker(8)
         rec.graph.destroy()
     except Exception as e:             # no recording on this runtime: the eager figure stands
         sys.stderr.write("bench.py: fused sweep not timed under graph replay (%s)\n" % e)
@@ -320,6 +329,9 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": sweep_bytes / sweep_ms / 1e6 / HBM_PEAK_GBPS,
+            "frac_is": "replayed (no kernel trace of the cycle in this run)",
+            "frac_replayed": sweep_bytes / sweep_ms / 1e6 / HBM_PEAK_GBPS,
+            "frac_eager": sweep_bytes / sweep_eager_ms / 1e6 / HBM_PEAK_GBPS,
             "traffic": TRAFFIC["spmv"]["bytes"] if world == 1 else None,
             "traffic_from_profile": TRAFFIC["spmv"]["source"] if world == 1 else None,
             "algorithmic_bytes_per_launch": sweep_bytes,
@@ -331,7 +343,11 @@ def main():
                                    "factor calibrated per access width in profiles/r03_fetch_calibration.md) should lie between the two",
             "avg_launch_ms": sweep_ms,
             "avg_launch_ms_eager": sweep_eager_ms,
-            "avg_launch_note": "avg_launch_ms: the launches recorded into one hipGraph and replayed, as the V-cycle issues them; avg_launch_ms_eager: the same launches issued one by one from the host",
+            "avg_launch_ms_replayed": sweep_ms,
+            "avg_launch_note": "avg_launch_ms (and achieved / frac): the fine-level sweeps INSIDE the V(2,2) cycle -- their durations in a rocprofv3 --kernel-trace of femus_amd/traffic_probe.py "
+                               "(the bench problem, the captured cycle replayed ten times between two marker kernels), child process of this run; avg_launch_ms_replayed / frac_replayed: "
+                               "--kernel-reps launches of the same kernel alone, recorded into one hipGraph and replayed back to back (HIP events); avg_launch_ms_eager / frac_eager: "
+                               "the same launches issued one by one from the host",
             "plain_spmv_ms": spmv_ms,
         },
         "optional_affine_fast_path": {
@@ -387,6 +403,11 @@ def main():
                 how += "; one-GPU problem of the same local size on rank 0's device"
             out["roofline"]["traffic"] = live["spmv"]
             out["roofline"]["traffic_source"] = how
+            if live.get("sweep_in_cycle_ms"):
+                t_in = live["sweep_in_cycle_ms"]
+                out["roofline"].update({"avg_launch_ms": t_in, "achieved": sweep_bytes / t_in / 1e6, "frac": sweep_bytes / t_in / 1e6 / HBM_PEAK_GBPS,
+                                        "frac_in_cycle": sweep_bytes / t_in / 1e6 / HBM_PEAK_GBPS, "in_cycle_launches": live["sweep_in_cycle_launches"],
+                                        "frac_is": "in-cycle: the fine-level fused sweeps inside the replayed V(2,2) cycle (kernel trace of this run's child process)"})
             out["roofline_assembly"]["traffic"] = live["elem"] + live["rows"]
             out["roofline_assembly"]["first_kernel_traffic"] = live["elem"]
             out["roofline_assembly"]["second_pass_traffic"] = live["rows"]
@@ -586,6 +607,29 @@ def live_traffic(coarse, levels, timeout=150, device=0):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     out = {k: got[(k, "FETCH_SIZE")] * 1024.0 * 2.0 + got[(k, "WRITE_SIZE")] * 1024.0 for k in ("spmv", "elem", "rows")}
+    # third pass, no counters: kernel trace of ten replayed cycles between two marker kernels -> duration of the fine-level sweeps in the cycle
+    d = tempfile.mkdtemp(prefix="femus_trace_", dir="/tmp")
+    try:
+        r = subprocess.run([exe, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "femus_amd", "traffic_probe.py"),
+                            str(coarse), str(levels), "cycles"], cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", FEMUS_HIP_DEVICE=str(device)),
+                           capture_output=True, text=True, timeout=timeout)
+        if "TRAFFIC PROBE DONE" in r.stdout:
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+                rows += list(csv.DictReader(open(f)))
+            t1 = [int(x["Start_Timestamp"]) for x in rows if "k_phase_marker<1>" in x["Kernel_Name"]]
+            t2 = [int(x["Start_Timestamp"]) for x in rows if "k_phase_marker<2>" in x["Kernel_Name"]]
+            if t1 and t2:
+                sw = [x for x in rows if "k_spmv_lx<2048, 3" in x["Kernel_Name"] and t1[-1] < int(x["Start_Timestamp"]) < t2[-1]]
+                if sw:
+                    gmax = max(int(x.get("Grid_Size", 0) or 0) for x in sw)
+                    du = [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e6 for x in sw if int(x.get("Grid_Size", 0) or 0) == gmax]
+                    out["sweep_in_cycle_ms"] = sum(du) / len(du)
+                    out["sweep_in_cycle_launches"] = len(du)
+    except subprocess.TimeoutExpired:
+        pass
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
     return out, "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over femus_amd/traffic_probe.py (KiB counters, FETCH_SIZE x 2 on gfx950)"
 
 

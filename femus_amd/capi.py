@@ -60,6 +60,10 @@ class Context:
     def set_option(self, name, value):
         _chk(self.L.fh_set_option(self.h, name.encode(), float(value)))
 
+    def marker(self, ident):
+        """one-thread kernel k_phase_marker<ident> on the compute stream: cuts a kernel trace into phases (profiles/summarize.py)"""
+        _chk(self.L.fh_profile_marker(self.h, int(ident)))
+
     def timer_start(self):
         _chk(self.L.fh_timer_start(self.h))
 
@@ -192,6 +196,12 @@ class Vec:
 
     def flush(self):
         _chk(self.L.fh_vec_flush(self.h))
+
+    def ghost_adds(self, nghost):
+        """the staged adds collected for this rank's ghost entries (shipped to their owners by fh_halo_reverse_add)"""
+        out = np.zeros(max(int(nghost), 1))
+        _chk(self.L.fh_vec_ghost_adds(self.h, _p(out)))
+        return out[:nghost]
 
     def get(self, idx):
         idx = _i32(np.atleast_1d(idx))
@@ -939,6 +949,10 @@ class Multigrid:
 
     def setup(self):
         _chk(self.L.fh_mg_setup(self.h))
+
+    def set_cycle_type(self, kind):
+        """PCMGSetType: "multiplicative" (default), "full", "additive", "kaskade" """
+        _chk(self.L.fh_mg_set_cycle_type(self.h, {"multiplicative": 0, "full": 1, "additive": 2, "kaskade": 3}[kind]))
 
     def vcycle(self, b, x):
         _chk(self.L.fh_mg_vcycle(self.h, b.h, x.h))

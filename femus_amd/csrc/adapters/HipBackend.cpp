@@ -100,8 +100,15 @@ void HipVector::not_served(const char* what) {
   abort();
 }
 void HipVector::close() {
-  if (_v) rv();          // VecAssemblyBegin/End: the staged adds
-  if (_halo && _v) hip_check(fh_halo_update(_halo, rv()), "HipVector::close (ghost refresh)");   // VecGhostUpdateBegin/End, PetscVector.hpp:604-610
+  if (_v) rv();          // VecAssemblyBegin/End: the staged adds of this rank
+  if (_halo && _v) {
+    // ... and the adds other ranks staged for entries this rank owns (ADD_VALUES to an off-process index is shipped to the owner and summed there,
+    // PetscVector.cpp:131-153): one flag over the ranks decides whether the reverse exchange runs at all
+    int mine = 0;
+    hip_check(fh_vec_ghost_adds_pending(rv(), &mine), "HipVector::close (ghost adds)");
+    if (all_sum((double)mine) > 0.) hip_check(fh_halo_reverse_add(_halo, rv()), "HipVector::close (ghost adds to their owners)");
+    hip_check(fh_halo_update(_halo, rv()), "HipVector::close (ghost refresh)");   // VecGhostUpdateBegin/End, PetscVector.hpp:604-610
+  }
   _is_closed = true;
 }
 double HipVector::all_sum(double local) const {      // VecDot / VecNorm over the ranks (Parallel.hpp:351-377)
@@ -600,8 +607,12 @@ void LinearEquationSolverHip::SetTolerances(const double& rtol, const double& at
   _restart = (int)restart;
 }
 void LinearEquationSolverHip::MGInit(const MgSmootherType& mg_smoother_type, const unsigned& levelMax, const SolverType& mgSolverType) {
-  if (mg_smoother_type != MULTIPLICATIVE) {
-    std::cout << "Wrong mg_type for the HIP backend (only MULTIPLICATIVE is implemented)" << std::endl;
+  int cycle = FH_CYCLE_MULTIPLICATIVE;                 // PCMGSetType, LinearEquationSolverPetsc.cpp:199-214
+  if (mg_smoother_type == FULL) cycle = FH_CYCLE_FULL;
+  else if (mg_smoother_type == ADDITIVE) cycle = FH_CYCLE_ADDITIVE;
+  else if (mg_smoother_type == KASKADE) cycle = FH_CYCLE_KASKADE;
+  else if (mg_smoother_type != MULTIPLICATIVE) {
+    std::cout << "Wrong mg_type for the HIP backend" << std::endl;
     abort();
   }
   if (_mg) fh_mg_destroy(_mg);
@@ -609,6 +620,7 @@ void LinearEquationSolverHip::MGInit(const MgSmootherType& mg_smoother_type, con
   _levelMax = levelMax;
   _mgSolverType = mgSolverType;
   hip_check(fh_mg_create(hip_context(), (int)levelMax, &_mg), "MGInit");
+  hip_check(fh_mg_set_cycle_type(_mg, cycle), "MGInit (cycle type)");
   _needs_setup = true;
 }
 void LinearEquationSolverHip::SetPenalty() {

@@ -47,6 +47,7 @@ struct fh_assembler_s {
   int nadj = 0;                  // element rows in d_Kbuf; row nadj is the spare one
   // element-wise Galerkin product from the next finer level (fh_assembler_galerkin): children, child interpolation tables, Dirichlet masks
   int* d_gal_child = nullptr;
+  uint64_t gal_key = 0;          // hash of (children, fine / coarse Dirichlet nodes) the tables below were made from
   unsigned char *d_gal_cnt = nullptr, *d_gal_row = nullptr, *d_gal_fb = nullptr, *d_gal_cb = nullptr;
   double *d_gal_val = nullptr, *d_gal_res = nullptr, *d_gal_dense = nullptr;
   int kstride = 27;              // doubles per element row in d_Kbuf (nc, or 32 for HEX27/Q2: whole 64-byte lines per row)
@@ -3326,7 +3327,19 @@ extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, con
     if (bytes) FH_CHECK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
     return 0;
   };
-  if (!cas->d_gal_child) {        // integer / table set-up, once per hierarchy
+  // integer / table set-up, once per hierarchy -- and again when the children or the Dirichlet sets differ from the ones the tables were made from
+  uint64_t key = 1469598103934665603ull;
+  {
+    auto mix = [&](const int* a, size_t n) {
+      key = (key ^ (uint64_t)n) * 1099511628211ull;
+      for (size_t k = 0; k < n; k++) key = (key ^ (uint64_t)(uint32_t)a[k]) * 1099511628211ull;
+    };
+    mix(child, (size_t)cas->nel * nch);
+    mix(fbdc, (size_t)nfb);
+    mix(cbdc, (size_t)ncb);
+  }
+  if (!cas->d_gal_child || cas->gal_key != key) {
+    cas->gal_key = key;
     FH_TRY(up((void**)&cas->d_gal_child, child, (size_t)cas->nel * nch * sizeof(int)));
     std::vector<unsigned char> cnt((size_t)nch * nc, 0), row((size_t)nch * nc * 8, 0);
     std::vector<double> val((size_t)nch * nc * 8, 0.0), phi(nc), dphi((size_t)nc * 3);
@@ -3365,7 +3378,7 @@ extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, con
     }
     FH_TRY(up((void**)&cas->d_gal_fb, fb.data(), fb.size()));
     FH_TRY(up((void**)&cas->d_gal_cb, cb.data(), cb.size()));
-    FH_CHECK_HIP(hipMalloc(&cas->d_gal_res, std::max<size_t>(cas->ndof, 1) * sizeof(double)));
+    if (!cas->d_gal_res) FH_CHECK_HIP(hipMalloc(&cas->d_gal_res, std::max<size_t>(cas->ndof, 1) * sizeof(double)));
   }
   const int grid = std::max(1, std::min(fh_div_up(cas->nel, 4), c->num_cu * 2));
   if (c->galerkin_mfma) {

@@ -109,6 +109,24 @@ extern "C" int fh_sync(fh_ctx_t c) {
 
 extern "C" void* fh_stream(fh_ctx_t c) { return (void*)c->stream; }
 
+// phase markers for kernel traces: a one-thread kernel whose NAME carries the id (k_phase_marker<3>), so that a rocprofv3 --kernel-trace of a
+// run can be cut into phases (profiles/summarize.py): which launches of a kernel ran inside the cycle, which were issued one by one ...
+template <int ID>
+__global__ void k_phase_marker(int* sink) {
+  if (sink) *sink = ID;
+}
+extern "C" int fh_profile_marker(fh_ctx_t c, int id) {
+  FH_REQUIRE(c && id >= 0 && id < 16, "fh_profile_marker: id must be 0 .. 15");
+#define FH_MARK(I) case I: hipLaunchKernelGGL(k_phase_marker<I>, dim3(1), dim3(1), 0, c->stream, (int*)nullptr); break;
+  switch (id) {
+    FH_MARK(0) FH_MARK(1) FH_MARK(2) FH_MARK(3) FH_MARK(4) FH_MARK(5) FH_MARK(6) FH_MARK(7)
+    FH_MARK(8) FH_MARK(9) FH_MARK(10) FH_MARK(11) FH_MARK(12) FH_MARK(13) FH_MARK(14) FH_MARK(15)
+  }
+#undef FH_MARK
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int fh_timer_start(fh_ctx_t c) {
   FH_CHECK_HIP(hipEventRecord(c->ev0, c->stream));
   return 0;
@@ -283,6 +301,7 @@ extern "C" int fh_vec_destroy(fh_vec_t v) {
   fh_stage_free(v->stage);
   if (v->d) hipFree(v->d);
   if (v->d_ghost_idx) hipFree(v->d_ghost_idx);
+  if (v->d_gacc) hipFree(v->d_gacc);
   delete v;
   return 0;
 }

@@ -330,6 +330,56 @@ extern "C" int fh_halo_end(fh_halo_t h) {
   return fh_halo_end_ptr(h);
 }
 
+// ghost -> owner, ADD: the accumulated adds to ghost entries (fh_vec_s::d_gacc, filled by the staged add path) travel against the direction of
+// the ghost update and are added to the owners' entries, source ranks in ascending order (an owned entry may be a ghost of several ranks:
+// one unpack launch per source rank keeps the sum deterministic).  Collective over the plan's ranks.  VecAssemblyBegin/End for the stash of
+// off-process ADD_VALUES (PetscVector.cpp:131-153, PetscVector.hpp:595-612).
+__global__ __launch_bounds__(256) void k_unpack_add(double* __restrict__ v, const int* __restrict__ idx, const double* __restrict__ buf, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) v[idx[i]] += buf[i];
+}
+
+extern "C" int fh_halo_reverse_add(fh_halo_t h, fh_vec_t v) {
+  FH_REQUIRE(h && v, "fh_halo_reverse_add: null argument");
+  if (halo_inert(h)) return 0;
+  FH_REQUIRE(!h->pending, "fh_halo_reverse_add: an exchange of this plan is in flight");
+  FH_REQUIRE(v->nghost == h->nrecv, "fh_halo_reverse_add: the vector has %d ghosts, the plan receives %d", v->nghost, h->nrecv);
+  fh_ctx_t c = h->ctx;
+  if (!v->d_gacc && v->nghost) {          // this rank staged nothing for a ghost: it sends zeros (the exchange is collective)
+    FH_CHECK_HIP(hipMalloc(&v->d_gacc, (size_t)v->nghost * sizeof(double)));
+    FH_CHECK_HIP(hipMemsetAsync(v->d_gacc, 0, (size_t)v->nghost * sizeof(double), c->stream));
+  }
+  FH_CHECK_HIP(hipEventRecord(h->ev_packed, c->stream));
+  FH_CHECK_HIP(hipStreamWaitEvent(c->comm_stream, h->ev_packed, 0));
+  if (h->exchange) {
+    if (h->nrecv) FH_CHECK_HIP(hipMemcpyAsync(h->h_recv, v->d_gacc, (size_t)h->nrecv * sizeof(double), hipMemcpyDeviceToHost, c->comm_stream));
+    FH_CHECK_HIP(hipStreamSynchronize(c->comm_stream));
+    FH_REQUIRE(h->exchange(h->user, h->h_recv, h->recv_counts.data(), h->h_send, h->send_counts.data()) == 0, "host transport: the exchange function failed");
+    if (h->nsend) FH_CHECK_HIP(hipMemcpyAsync(h->d_sendbuf, h->h_send, (size_t)h->nsend * sizeof(double), hipMemcpyHostToDevice, c->comm_stream));
+  } else {
+    FH_CHECK_NCCL(ncclGroupStart());
+    ncclResult_t bad = ncclSuccess;
+    for (int r = 0; r < h->nranks && bad == ncclSuccess; r++) {
+      if (h->recv_counts[r]) bad = ncclSend(v->d_gacc + h->recv_off[r], h->recv_counts[r], ncclDouble, r, h->comm, c->comm_stream);
+      if (h->send_counts[r] && bad == ncclSuccess) bad = ncclRecv(h->d_sendbuf + h->send_off[r], h->send_counts[r], ncclDouble, r, h->comm, c->comm_stream);
+    }
+    const ncclResult_t closed = ncclGroupEnd();
+    FH_CHECK_NCCL(bad);
+    FH_CHECK_NCCL(closed);
+  }
+  FH_CHECK_HIP(hipEventRecord(h->ev_done, c->comm_stream));
+  FH_CHECK_HIP(hipStreamWaitEvent(c->stream, h->ev_done, 0));
+  for (int r = 0; r < h->nranks; r++)
+    if (h->send_counts[r]) {
+      hipLaunchKernelGGL(k_unpack_add, dim3(fh_div_up(h->send_counts[r], 256)), dim3(256), 0, c->stream, v->d, h->d_send_idx + h->send_off[r],
+                         h->d_sendbuf + h->send_off[r], h->send_counts[r]);
+      FH_CHECK_HIP(hipGetLastError());
+    }
+  if (v->nghost) FH_CHECK_HIP(hipMemsetAsync(v->d_gacc, 0, (size_t)v->nghost * sizeof(double), c->stream));
+  v->gacc_dirty = false;
+  return 0;
+}
+
 extern "C" int fh_halo_allreduce_count(fh_halo_t h, int reset, int64_t* n) {
   FH_REQUIRE(h, "fh_halo_allreduce_count: null argument");
   if (n) *n = h->n_allreduce;

@@ -127,6 +127,10 @@ struct fh_vec_s {
   double* d = nullptr;                // [n_local + nghost]
   std::vector<int> ghost_idx;         // global indices of ghosts (host copy)
   int* d_ghost_idx = nullptr;
+  // staged ADDS to ghost entries (VecSetValues(ADD_VALUES) on an off-process index, PetscVector.cpp:131-153) collect here, not in the ghost
+  // tail: fh_halo_reverse_add ships them to the owners, which add them to their owned entries (VecAssemblyBegin/End)
+  double* d_gacc = nullptr;           // [nghost], allocated by the first such add
+  bool gacc_dirty = false;
 };
 
 struct fh_mat_s {

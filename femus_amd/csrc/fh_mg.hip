@@ -80,6 +80,9 @@ struct fh_mg_s {
   int coarse_dim = 0;
   std::vector<int> h_act_raw;         // the coupled / uncoupled lists before the dissection reordered the coupled part
   int nd_key = -1, coords_version = 0;
+  int cycle_type = 0;                 // FH_CYCLE_*: PCMGSetType
+  bool capturable = true;             // no distributed level: the cycle is replayed from a captured graph
+  uint64_t nd_A_uid = 0;              // the level-0 matrix the dissection was computed on (another pattern may not be separated by the cached separator)
   bool nd_tables_valid = false;
   std::vector<int> nd_off;            // offsets of the blocks inside the coupled unknowns, nd_off[k] = first separator unknown, nd_off[k + 1] = na
   bool nd_active = false;             // the last factorisation produced the block form (the cycle solves with it)
@@ -1411,6 +1414,16 @@ extern "C" int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh
   return 0;
 }
 
+static int capture_cycle(fh_mg_t mg);
+extern "C" int fh_mg_set_cycle_type(fh_mg_t mg, int type) {
+  FH_REQUIRE(mg, "fh_mg_set_cycle_type: null argument");
+  FH_REQUIRE(type >= FH_CYCLE_MULTIPLICATIVE && type <= FH_CYCLE_KASKADE, "fh_mg_set_cycle_type: unknown type %d (0 multiplicative, 1 full, 2 additive, 3 kaskade)", type);
+  const bool changed = mg->cycle_type != type;
+  mg->cycle_type = type;
+  if (changed && mg->setup_done) FH_TRY(capture_cycle(mg));      // the captured launch sequence is the old type's
+  return 0;
+}
+
 extern "C" int fh_mg_set_level_solver(fh_mg_t mg, int level, int solver, int restart) {
   FH_REQUIRE(mg && level >= 0 && level < mg->nlevels, "fh_mg_set_level_solver: bad level %d", level);
   FH_REQUIRE(solver == FH_LEVEL_RICHARDSON || solver == FH_LEVEL_GMRES, "fh_mg_set_level_solver: unknown level solver %d", solver);
@@ -1471,11 +1484,13 @@ static uint64_t cycle_signature(fh_mg_t mg) {
     }
   };
   mix((uint64_t)mg->nlevels);
+  mix((uint64_t)mg->cycle_type);
   mix((uint64_t)mg->ctx->opt_gen);
   mixp(mg->d_ainv);
   mixp(mg->d_nd);
   mix((uint64_t)(mg->nd_active ? mg->nd_off.size() : 0));
-  mix((uint64_t)(mg->nd_active && mg->nd_off.size() > 1 ? mg->nd_off[mg->nd_off.size() - 2] : 0));
+  if (mg->nd_active)
+    for (int o : mg->nd_off) mix((uint64_t)o);          // another dissection of the same size keeps no captured pointer
   mix((uint64_t)mg->na);
   mixp(mg->d_act);
   for (int l = 0; l < mg->nlevels; l++) {
@@ -2240,7 +2255,8 @@ static int coarse_factor(fh_mg_t mg) {
     n = (int)act.size();
     act.insert(act.end(), rest.begin(), rest.end());
     const int nd_key = c->coarse_nd * 1024 + (mg->coords_version & 1023);
-    if (act != mg->h_act_raw || !mg->d_act || nd_key != mg->nd_key) {
+    if (act != mg->h_act_raw || !mg->d_act || nd_key != mg->nd_key || mg->nd_A_uid != L0.A->uid) {
+      mg->nd_A_uid = L0.A->uid;
       if (mg->d_act) FH_CHECK_HIP(hipFree(mg->d_act));
       mg->d_act = nullptr;
       mg->h_act_raw = act;
@@ -2467,6 +2483,35 @@ static int color_rows(MgLevel& L) {
   return 0;
 }
 
+// (re)capture of the cycle: un-captured warm-up run, then one cycle recorded on the internal buffers and kept for replay
+static int capture_cycle(fh_mg_t mg) {
+  fh_ctx_t c = mg->ctx;
+  if (mg->gexec) {
+    hipGraphExecDestroy(mg->gexec);
+    mg->gexec = nullptr;
+  }
+  if (mg->graph) {
+    hipGraphDestroy(mg->graph);
+    mg->graph = nullptr;
+  }
+  mg->graph_sig = 0;
+  FH_TRY(run_cycle(mg));   // un-captured warm-up: builds lazily created row blocks, validates the launches
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  // distributed cycles are NOT captured: stream capture of the grouped ncclSend/ncclRecv (forked communication stream) was tried on
+  // this stack (RCCL 2.26.6 of the PyTorch wheel, one-rank self exchange) and segfaults inside the library at capture time; the
+  // launches of a distributed cycle are issued one by one
+  if (c->use_graph && mg->capturable) {
+    FH_CHECK_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    int rc = run_cycle(mg);
+    hipError_t e = hipStreamEndCapture(c->stream, &mg->graph);
+    if (rc) return rc;
+    FH_CHECK_HIP(e);
+    FH_CHECK_HIP(hipGraphInstantiate(&mg->gexec, mg->graph, nullptr, nullptr, 0));
+    mg->graph_sig = cycle_signature(mg);      // after the warm-up: lazily built row blocks exist now
+  }
+  return 0;
+}
+
 extern "C" int fh_mg_setup(fh_mg_t mg) {
   FH_GUARD_BEGIN
   fh_ctx_t c = mg->ctx;
@@ -2552,33 +2597,10 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
   FH_TRY(coarse_factor(mg));
   mg->cycle_bytes += 8ll * mg->lv[0].n * mg->lv[0].n + 16ll * mg->lv[0].n;
   mg->setup_done = true;
-  const bool capturable = !distributed;
+  mg->capturable = !distributed;
   const uint64_t sig = cycle_signature(mg);
-  if (mg->gexec && mg->graph_sig == sig && c->use_graph && capturable && c->mg_reuse_graph) return 0;   // same launches: the graph stays
-  if (mg->gexec) {
-    hipGraphExecDestroy(mg->gexec);
-    mg->gexec = nullptr;
-  }
-  if (mg->graph) {
-    hipGraphDestroy(mg->graph);
-    mg->graph = nullptr;
-  }
-  mg->graph_sig = 0;
-  FH_TRY(run_cycle(mg));   // un-captured warm-up: builds lazily created row blocks, validates the launches
-  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
-  // distributed cycles are NOT captured: stream capture of the grouped ncclSend/ncclRecv (forked communication stream) was tried on
-  // this stack (RCCL 2.26.6 of the PyTorch wheel, one-rank self exchange) and segfaults inside the library at capture time; the
-  // launches of a distributed cycle are issued one by one
-  if (c->use_graph && capturable) {
-    // capture one cycle on the internal buffers and keep it for replay
-    FH_CHECK_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    int rc = run_cycle(mg);
-    hipError_t e = hipStreamEndCapture(c->stream, &mg->graph);
-    if (rc) return rc;
-    FH_CHECK_HIP(e);
-    FH_CHECK_HIP(hipGraphInstantiate(&mg->gexec, mg->graph, nullptr, nullptr, 0));
-    mg->graph_sig = cycle_signature(mg);      // after the warm-up: lazily built row blocks exist now
-  }
+  if (mg->gexec && mg->graph_sig == sig && c->use_graph && mg->capturable && c->mg_reuse_graph) return 0;   // same launches: the graph stays
+  FH_TRY(capture_cycle(mg));
   return 0;
   FH_GUARD_END("fh_mg_setup")
 }
@@ -2642,7 +2664,8 @@ __global__ __launch_bounds__(256) void k_gm_normalize(double* __restrict__ v, co
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) v[i] *= inv;
 }
 __global__ void k_gm_copy(double* __restrict__ dst, const double* __restrict__ src, int k) {
-  if (threadIdx.x < k) dst[threadIdx.x] = src[threadIdx.x];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < k) dst[i] = src[i];
 }
 // least-squares solution of min || beta e1 - H y ||, H (m + 1) x m stored by columns of length ld (Givens rotations, one thread)
 __global__ void k_gm_solve(double* __restrict__ H, int ld, int m, const double* __restrict__ beta, double* __restrict__ g, double* __restrict__ y) {
@@ -2729,7 +2752,7 @@ static int gmres_smooth(fh_mg_t mg, MgLevel& L, int nits, bool zero_guess) {
       FH_TRY(halo_spmv(L.halo, L.A, V(j), n, L.r, 0, nullptr, nullptr, 0.0));
       FH_TRY(level_precond(mg, L, L.r, V(j + 1)));
       FH_TRY(dots(j + 1, V(j + 1)));                        // h = V^T w  (classical Gram-Schmidt, no refinement: PETSc's default)
-      hipLaunchKernelGGL(k_gm_copy, dim3(1), dim3(64), 0, c->stream, Hm + (size_t)j * ld, part + (size_t)(j + 1) * nb, j + 1);
+      hipLaunchKernelGGL(k_gm_copy, dim3(fh_div_up(j + 1, 64)), dim3(64), 0, c->stream, Hm + (size_t)j * ld, part + (size_t)(j + 1) * nb, j + 1);
       hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, V(j + 1), (const double* const*)L.gm_dV, Hm + (size_t)j * ld, -1.0, j + 1, n);
       // ||w||: table entry j + 1 is w itself
       hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, c->stream, (const double* const*)(L.gm_dV + j + 1), V(j + 1), 1, n, part);
@@ -2748,78 +2771,127 @@ static int gmres_smooth(fh_mg_t mg, MgLevel& L, int nits, bool zero_guess) {
 
 // one multiplicative V-cycle on the internal buffers: input lv[top].b, output lv[top].x
 // distributed levels: ghosts of the operand are refreshed before every operator application (MPIAIJ MatMult semantics)
-static int run_cycle(fh_mg_t mg) {
+// npre / npost iterations of a level's smoother on L.x for the right-hand side L.b; zero_guess: L.x is taken as zero (sweep 1 of the
+// Richardson/Jacobi smoother is then the diagonal scaling PETSc's Richardson does from a zero guess).  *packed: the send buffer of the level's
+// exchange already holds the interface entries of L.x (the first sweep writes them).
+static int smooth_level(fh_mg_t mg, MgLevel& L, int nits, bool zero_guess, bool* packed) {
   fh_ctx_t c = mg->ctx;
-  const int top = mg->nlevels - 1;
-  for (int l = top; l >= 1; l--) {
+  *packed = false;
+  if (nits == 0) {
+    if (zero_guess) FH_CHECK_HIP(hipMemsetAsync(L.x, 0, (size_t)L.ncols * sizeof(double), c->stream));
+    return 0;
+  }
+  if (L.solver == FH_LEVEL_GMRES) return gmres_smooth(mg, L, nits, zero_guess);
+  if (L.smoother == FH_SMOOTH_VANKA) {
+    if (zero_guess) FH_CHECK_HIP(hipMemsetAsync(L.x, 0, (size_t)L.ncols * sizeof(double), c->stream));
+    return vanka_sweeps(mg, L, nits);
+  }
+  if (L.smoother == FH_SMOOTH_GS_COLOR || L.smoother == FH_SMOOTH_SOR || L.smoother == FH_SMOOTH_ILU0) return gs_sweeps(mg, L, nits, zero_guess);
+  int s = 0;
+  if (zero_guess) {
+    // sweep 1 from a zero guess: x = omega D^-1 b ; the others: fused Jacobi SpMV, ping-pong x <-> x2
+    const int* sidx = nullptr;
+    double* sbuf = nullptr;
+    int nsend = 0;
+    if (L.halo) fh_halo_send_plan(L.halo, &sidx, &sbuf, &nsend);
+    hipLaunchKernelGGL(k_first_sweep, dim3(sgrid(c, L.n)), dim3(256), 0, c->stream, L.x, L.b, L.dinv, L.omega, L.n, sidx, sbuf, nsend);
+    *packed = L.halo != nullptr;             // the exchange of this x needs no pack launch
+    s = 1;
+  }
+  for (; s < nits; s++) {
+    FH_TRY(halo_spmv(L.halo, L.A, L.x, L.n, L.x2, 3, L.b, L.dinv, L.omega, *packed));
+    *packed = false;
+    std::swap(L.x, L.x2);
+  }
+  return 0;
+}
+
+// the exact solve of level 0: x = A_0^-1 b
+static int coarse_solve(fh_mg_t mg) {
+  fh_ctx_t c = mg->ctx;
+  MgLevel& L0 = mg->lv[0];
+  if (mg->nd_active) {
+    const int k = (int)mg->nd_off.size() - 2, nI = mg->nd_off[k], ns = mg->na - nI;
+    hipLaunchKernelGGL(k_gather_act, dim3(fh_div_up(std::max(mg->na, 1), 256)), dim3(256), 0, c->stream, L0.b, mg->d_act, mg->na, L0.r);
+    if (ns > 0) {
+      hipLaunchKernelGGL(k_nd_t, dim3(fh_div_up(ns, 4)), dim3(256), 0, c->stream, mg->d_nd_wt, L0.r, nI, ns, mg->d_nd_t);
+      hipLaunchKernelGGL(k_nd_xs, dim3(fh_div_up(ns, 4)), dim3(256), 0, c->stream, mg->d_nd_sinv, mg->d_nd_t, ns, nI, mg->d_act, mg->d_nd_xs, L0.x);
+    }
+    hipLaunchKernelGGL(k_nd_xi, dim3(fh_div_up(nI, 4) + fh_div_up(L0.n - mg->na, 256)), dim3(256), 0, c->stream, mg->d_nd, mg->d_nd_rowoff, mg->d_nd_rowinfo,
+                       mg->d_nd_w, L0.r, mg->d_nd_xs, L0.b, L0.x, nI, ns, mg->na, L0.n, mg->d_act, L0.dinv);
+  } else if (mg->na == L0.n)
+    hipLaunchKernelGGL(k_dense_gemv, dim3(fh_div_up(L0.n, 4)), dim3(256), 0, c->stream, mg->d_ainv, L0.b, L0.x, L0.n);
+  else {
+    hipLaunchKernelGGL(k_gather_act, dim3(fh_div_up(std::max(mg->na, 1), 256)), dim3(256), 0, c->stream, L0.b, mg->d_act, mg->na, L0.r);
+    hipLaunchKernelGGL(k_dense_gemv_sub, dim3(fh_div_up(mg->na, 4) + fh_div_up(L0.n - mg->na, 256)), dim3(256), 0, c->stream, mg->d_ainv, L0.r, L0.b, L0.x,
+                       mg->na, L0.n, mg->d_act, L0.dinv);
+  }
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// b_{l-1} = R v on level l (v = the level's residual, or its right-hand side): the restriction reads ghost entries, except into a replicated
+// level (owned part, then all-reduce)
+static int restrict_into(fh_mg_t mg, int l, double* v) {
+  MgLevel& L = mg->lv[l];
+  FH_TRY(halo_spmv(L.replicated_below ? nullptr : L.halo, L.R, v, L.n, mg->lv[l - 1].b, 0, nullptr, nullptr, 0.0));
+  if (L.halo && L.replicated_below) FH_TRY(fh_halo_allreduce_ptr(L.halo, mg->lv[l - 1].b, mg->lv[l - 1].n));
+  return 0;
+}
+
+// PCMGMCycle_Private from level `from` down (PC_MG_MULTIPLICATIVE with one cycle per level): x_from starts at zero (zero_guess) or holds a guess
+static int mcycle(fh_mg_t mg, int from, bool zero_guess) {
+  if (from == 0) return coarse_solve(mg);
+  for (int l = from; l >= 1; l--) {
     MgLevel& L = mg->lv[l];
     bool packed = false;
-    if (L.npre == 0) {
-      FH_CHECK_HIP(hipMemsetAsync(L.x, 0, (size_t)L.ncols * sizeof(double), c->stream));
-    } else if (L.solver == FH_LEVEL_GMRES) {
-      FH_TRY(gmres_smooth(mg, L, L.npre, true));
-    } else if (L.smoother == FH_SMOOTH_VANKA) {
-      FH_CHECK_HIP(hipMemsetAsync(L.x, 0, (size_t)L.ncols * sizeof(double), c->stream));
-      FH_TRY(vanka_sweeps(mg, L, L.npre));
-    } else if (L.smoother == FH_SMOOTH_GS_COLOR || L.smoother == FH_SMOOTH_SOR || L.smoother == FH_SMOOTH_ILU0) {
-      FH_TRY(gs_sweeps(mg, L, L.npre, true));
-    } else {
-      // sweep 1 from a zero guess: x = omega D^-1 b ; sweeps 2..npre: fused Jacobi SpMV, ping-pong x <-> x2
-      const int* sidx = nullptr;
-      double* sbuf = nullptr;
-      int nsend = 0;
-      if (L.halo) fh_halo_send_plan(L.halo, &sidx, &sbuf, &nsend);
-      hipLaunchKernelGGL(k_first_sweep, dim3(sgrid(c, L.n)), dim3(256), 0, c->stream, L.x, L.b, L.dinv, L.omega, L.n, sidx, sbuf, nsend);
-      packed = L.halo != nullptr;             // the exchange of this x needs no pack launch
-      for (int s = 1; s < L.npre; s++) {
-        FH_TRY(halo_spmv(L.halo, L.A, L.x, L.n, L.x2, 3, L.b, L.dinv, L.omega, packed));
-        packed = false;
-        std::swap(L.x, L.x2);
-      }
-    }
+    FH_TRY(smooth_level(mg, L, L.npre, zero_guess || l < from, &packed));
     FH_TRY(halo_spmv(L.halo, L.A, L.x, L.n, L.r, 2, L.b, nullptr, 0.0, packed));     // r = b - A x (ghosts of x refreshed)
-    // b_{l-1} = R r: the restriction reads ghost residuals, except into a replicated level (owned part, then all-reduce)
-    FH_TRY(halo_spmv(L.replicated_below ? nullptr : L.halo, L.R, L.r, L.n, mg->lv[l - 1].b, 0, nullptr, nullptr, 0.0));
-    if (L.halo && L.replicated_below) FH_TRY(fh_halo_allreduce_ptr(L.halo, mg->lv[l - 1].b, mg->lv[l - 1].n));
+    FH_TRY(restrict_into(mg, l, L.r));
   }
-  {
-    MgLevel& L0 = mg->lv[0];
-    if (mg->nd_active) {
-      const int k = (int)mg->nd_off.size() - 2, nI = mg->nd_off[k], ns = mg->na - nI;
-      hipLaunchKernelGGL(k_gather_act, dim3(fh_div_up(std::max(mg->na, 1), 256)), dim3(256), 0, c->stream, L0.b, mg->d_act, mg->na, L0.r);
-      if (ns > 0) {
-        hipLaunchKernelGGL(k_nd_t, dim3(fh_div_up(ns, 4)), dim3(256), 0, c->stream, mg->d_nd_wt, L0.r, nI, ns, mg->d_nd_t);
-        hipLaunchKernelGGL(k_nd_xs, dim3(fh_div_up(ns, 4)), dim3(256), 0, c->stream, mg->d_nd_sinv, mg->d_nd_t, ns, nI, mg->d_act, mg->d_nd_xs, L0.x);
-      }
-      hipLaunchKernelGGL(k_nd_xi, dim3(fh_div_up(nI, 4) + fh_div_up(L0.n - mg->na, 256)), dim3(256), 0, c->stream, mg->d_nd, mg->d_nd_rowoff, mg->d_nd_rowinfo,
-                         mg->d_nd_w, L0.r, mg->d_nd_xs, L0.b, L0.x, nI, ns, mg->na, L0.n, mg->d_act, L0.dinv);
-    } else if (mg->na == L0.n)
-      hipLaunchKernelGGL(k_dense_gemv, dim3(fh_div_up(L0.n, 4)), dim3(256), 0, c->stream, mg->d_ainv, L0.b, L0.x, L0.n);
-    else {
-      hipLaunchKernelGGL(k_gather_act, dim3(fh_div_up(std::max(mg->na, 1), 256)), dim3(256), 0, c->stream, L0.b, mg->d_act, mg->na, L0.r);
-      hipLaunchKernelGGL(k_dense_gemv_sub, dim3(fh_div_up(mg->na, 4) + fh_div_up(L0.n - mg->na, 256)), dim3(256), 0, c->stream, mg->d_ainv, L0.r, L0.b, L0.x,
-                         mg->na, L0.n, mg->d_act, L0.dinv);
-    }
-  }
-  for (int l = 1; l <= top; l++) {
+  FH_TRY(coarse_solve(mg));
+  for (int l = 1; l <= from; l++) {
     MgLevel& L = mg->lv[l];
     MgLevel& Lc = mg->lv[l - 1];
     FH_TRY(halo_spmv(Lc.halo, L.P, Lc.x, Lc.n, L.x, 1, nullptr, nullptr, 0.0));      // x += P x_{l-1} (reads ghost coarse values)
-    if (L.solver == FH_LEVEL_GMRES) {
-      if (L.npost > 0) FH_TRY(gmres_smooth(mg, L, L.npost, false));
-      continue;
+    bool packed = false;
+    FH_TRY(smooth_level(mg, L, L.npost, false, &packed));
+  }
+  return 0;
+}
+
+// one application of the multigrid preconditioner to lv[top].b -> lv[top].x, PCMG's four forms (PCMGSetType, LinearEquationSolverPetsc.cpp:199-214;
+// PETSc mg.c / fmg.c: PCMGMCycle_Private, PCMGACycle_Private, PCMGFCycle_Private, PCMGKCycle_Private)
+static int run_cycle(fh_mg_t mg) {
+  const int top = mg->nlevels - 1;
+  if (mg->cycle_type == FH_CYCLE_MULTIPLICATIVE) {
+    FH_TRY(mcycle(mg, top, true));
+    FH_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
+  // the other three restrict the RIGHT-HAND SIDE through all levels first
+  for (int l = top; l >= 1; l--) FH_TRY(restrict_into(mg, l, mg->lv[l].b));
+  if (mg->cycle_type == FH_CYCLE_ADDITIVE) {
+    // every level solves for itself from zero with its down smoother, the corrections are interpolated upwards and added
+    for (int l = top; l >= 1; l--) {
+      bool packed = false;
+      FH_TRY(smooth_level(mg, mg->lv[l], mg->lv[l].npre, true, &packed));
     }
-    if (L.smoother == FH_SMOOTH_GS_COLOR || L.smoother == FH_SMOOTH_SOR || L.smoother == FH_SMOOTH_ILU0) {
-      FH_TRY(gs_sweeps(mg, L, L.npost, false));
-      continue;
+    FH_TRY(coarse_solve(mg));
+    for (int l = 1; l <= top; l++) FH_TRY(halo_spmv(mg->lv[l - 1].halo, mg->lv[l].P, mg->lv[l - 1].x, mg->lv[l - 1].n, mg->lv[l].x, 1, nullptr, nullptr, 0.0));
+  } else if (mg->cycle_type == FH_CYCLE_FULL) {
+    // coarsest solve, then per level: interpolate the solution as the guess and run one multiplicative cycle from there
+    FH_TRY(coarse_solve(mg));
+    for (int l = 1; l <= top; l++) {
+      FH_TRY(halo_spmv(mg->lv[l - 1].halo, mg->lv[l].P, mg->lv[l - 1].x, mg->lv[l - 1].n, mg->lv[l].x, 0, nullptr, nullptr, 0.0));   // x_l = P x_{l-1}
+      FH_TRY(mcycle(mg, l, false));
     }
-    if (L.smoother == FH_SMOOTH_VANKA) {
-      FH_TRY(vanka_sweeps(mg, L, L.npost));
-      continue;
-    }
-    for (int s = 0; s < L.npost; s++) {
-      FH_TRY(halo_spmv(L.halo, L.A, L.x, L.n, L.x2, 3, L.b, L.dinv, L.omega));
-      std::swap(L.x, L.x2);
+  } else {   // FH_CYCLE_KASKADE: coarsest solve, then interpolate and smooth (down smoother) on the way up, no coarse-grid correction
+    FH_TRY(coarse_solve(mg));
+    for (int l = 1; l <= top; l++) {
+      FH_TRY(halo_spmv(mg->lv[l - 1].halo, mg->lv[l].P, mg->lv[l - 1].x, mg->lv[l - 1].n, mg->lv[l].x, 0, nullptr, nullptr, 0.0));
+      bool packed = false;
+      FH_TRY(smooth_level(mg, mg->lv[l], mg->lv[l].npre, false, &packed));
     }
   }
   FH_CHECK_HIP(hipGetLastError());

@@ -21,6 +21,8 @@ constexpr size_t VEC_CAP_D = 1u << 20;
 constexpr size_t VEC_CAP_I = 4u << 20;
 constexpr int ROW_CAP = 2048;             // longest row the LDS kernel keeps (24 KB of LDS per wave)
 
+extern "C" int fh_vec_flush(fh_vec_t v);
+
 struct ring_s {
   int* h_i = nullptr;        // pinned: [block chunks ... | touch lists]
   double* h_d = nullptr;     // pinned
@@ -150,14 +152,15 @@ __global__ __launch_bounds__(64) void k_stage_flush_rows(const int* __restrict__
 }
 
 // vectors: one thread per distinct target entry, its staged values added in the order of the calls
-__global__ __launch_bounds__(256) void k_stage_flush_vec(double* __restrict__ y, const int* __restrict__ ints, const double* __restrict__ vals,
-                                                          int tidx_off, int tptr_off, int tlist_off, int nt) {
+__global__ __launch_bounds__(256) void k_stage_flush_vec(double* __restrict__ y, double* __restrict__ gacc, int n_local, const int* __restrict__ ints,
+                                                          const double* __restrict__ vals, int tidx_off, int tptr_off, int tlist_off, int nt) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= nt) return;
   const int idx = ints[tidx_off + t];
-  double a = y[idx];
+  double* tgt = idx < n_local ? y + idx : gacc + (idx - n_local);      // adds to a ghost entry go to the accumulator the owner receives
+  double a = *tgt;
   for (int c = ints[tptr_off + t]; c < ints[tptr_off + t + 1]; c++) a += vals[ints[tlist_off + c]];
-  y[idx] = a;
+  *tgt = a;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -341,9 +344,18 @@ static int vec_issue(fh_vec_t v) {
   for (int k = 0; k < n; k++) tlist[tptr[s->slot[r.h_i[k]]] + s->cnt[r.h_i[k]]++] = k;
   for (int t = 0; t < nt; t++) s->cnt[s->touched[t]] = 0;
   hipStream_t st = s->ctx->stream;
+  bool to_ghost = false;
+  for (int t = 0; t < nt && !to_ghost; t++) to_ghost = tidx[t] >= v->n_local;
+  if (to_ghost) {
+    if (!v->d_gacc) {
+      FH_CHECK_HIP(hipMalloc(&v->d_gacc, (size_t)v->nghost * sizeof(double)));
+      FH_CHECK_HIP(hipMemsetAsync(v->d_gacc, 0, (size_t)v->nghost * sizeof(double), st));
+    }
+    v->gacc_dirty = true;
+  }
   FH_CHECK_HIP(hipMemcpyAsync(r.d_i, r.h_i, (tlist_off + n) * sizeof(int), hipMemcpyHostToDevice, st));
   FH_CHECK_HIP(hipMemcpyAsync(r.d_d, r.h_d, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_stage_flush_vec, dim3(fh_div_up(nt, 256)), dim3(256), 0, st, v->d, r.d_i, r.d_d, (int)tidx_off, (int)tptr_off,
+  hipLaunchKernelGGL(k_stage_flush_vec, dim3(fh_div_up(nt, 256)), dim3(256), 0, st, v->d, v->d_gacc, v->n_local, r.d_i, r.d_d, (int)tidx_off, (int)tptr_off,
                      (int)tlist_off, nt);
   return ring_issued(s, r);
 }
@@ -387,6 +399,26 @@ extern "C" int fh_vec_stage_values(fh_vec_t v, int n, const int* idx, const doub
     k0 += m;
   }
   s->n_blocks++;
+  return 0;
+}
+
+extern "C" int fh_vec_ghost_adds(fh_vec_t v, double* out) {
+  FH_REQUIRE(v && (out || v->nghost == 0), "fh_vec_ghost_adds: null argument");
+  if (v->stage && v->stage->pending) FH_TRY(fh_vec_flush(v));
+  if (!v->nghost) return 0;
+  if (!v->d_gacc) {
+    memset(out, 0, (size_t)v->nghost * sizeof(double));
+    return 0;
+  }
+  FH_CHECK_HIP(hipMemcpyAsync(out, v->d_gacc, (size_t)v->nghost * sizeof(double), hipMemcpyDeviceToHost, v->ctx->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(v->ctx->stream));
+  return 0;
+}
+
+extern "C" int fh_vec_ghost_adds_pending(fh_vec_t v, int* pending) {
+  FH_REQUIRE(v && pending, "fh_vec_ghost_adds_pending: null argument");
+  if (v->stage && v->stage->pending) FH_TRY(fh_vec_flush(v));
+  *pending = v->gacc_dirty ? 1 : 0;
   return 0;
 }
 

@@ -1,7 +1,7 @@
 """The launches whose HBM traffic `bench.py` reports: the bench problem (3-D Poisson Q2, 8^3 -> 64^3, assembled fine-level operator) and a
 few launches of the fine-level fused Jacobi sweep and of the assembly.  bench.py runs this file under `rocprofv3 --pmc <counter>
 --kernel-trace` (one counter per pass, as MI355X_MICROARCH.md prescribes) and reads the per-launch counter values of the named kernels.
-No checks, no oracle: it only has to launch the same kernels on the same data layout as the bench.   python femus_amd/traffic_probe.py [coarse] [levels]"""
+No checks, no oracle: it only has to launch the same kernels on the same data layout as the bench.   python femus_amd/traffic_probe.py [coarse] [levels] [cycles]"""
 import os
 import sys
 
@@ -28,6 +28,19 @@ def main():
     dinv.upload(1.0 / np.where(d == 0, 1.0, d))
     for _ in range(6):
         y.jacobi_sweep(pb.RES, x, A, dinv, 2. / 3.)
+    # the V(2,2) cycle as the bench runs it (hierarchy prepared, cycle replayed from its captured graph): markers 1 / 2 around the cycles let
+    # bench.py take the duration of the fine-level sweeps INSIDE the cycle from a kernel trace of this file
+    if len(sys.argv) > 3 and sys.argv[3] == "cycles":
+        pb.prepare()
+        pb.assemble()
+        pb.bdc_dev[-1].zero_rows(pb.A[-1], 1.0)
+        pb.zero_boundary_residuals()
+        for _ in range(3):
+            pb.vcycle()
+        ctx.marker(1)
+        for _ in range(10):
+            pb.vcycle()
+        ctx.marker(2)
     ctx.sync()
     print("TRAFFIC PROBE DONE", flush=True)
 

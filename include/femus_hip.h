@@ -48,6 +48,9 @@ int fh_device_name(fh_ctx_t ctx, char* buf, int buflen);
 int fh_sync(fh_ctx_t ctx);
 void* fh_stream(fh_ctx_t ctx);                       /* hipStream_t of the compute stream */
 /* HIP-event timing on the compute stream (bench.py: roofline.achieved is measured with these) */
+/* measurement aid: launches the one-thread kernel k_phase_marker<id> (id 0 .. 15) on the compute stream; a kernel trace of the run can be cut
+ * into phases at these names (profiles/summarize.py, bench.py's in-cycle sweep time) */
+int fh_profile_marker(fh_ctx_t ctx, int id);
 int fh_timer_start(fh_ctx_t ctx);
 int fh_timer_stop(fh_ctx_t ctx, double* milliseconds);
 /* Recorded launch sequences (hipGraph): the device-only calls between fh_graph_begin and fh_graph_end -- SpMV family, vector algebra,
@@ -380,6 +383,15 @@ int fh_mg_set_level_patches(fh_mg_t mg, int level, int npatch, const int* ptr /*
  *                      level solver and the one 003_NavierStokes selects), classical Gram-Schmidt, restart `restart` (FEMuS: 30) */
 enum { FH_LEVEL_RICHARDSON = 0, FH_LEVEL_GMRES = 1 };
 int fh_mg_set_level_solver(fh_mg_t mg, int level, int solver, int restart);
+/* PCMGSetType (`MgSmootherType` of MGInit, LinearEquationSolverPetsc.cpp:199-214), one application of the preconditioner to b:
+ * FH_CYCLE_MULTIPLICATIVE  V-cycle: pre-smooth, restrict the residual, recurse, interpolate-add, post-smooth (default)
+ * FH_CYCLE_FULL            b restricted through all levels; coarsest solve; per level: x = P x_coarse as the guess, then one multiplicative cycle from there
+ * FH_CYCLE_ADDITIVE        b restricted through all levels; every level solves from zero with its DOWN smoother (npre iterations), level 0 exactly;
+ *                          the corrections are interpolated upwards and added
+ * FH_CYCLE_KASKADE         b restricted through all levels; coarsest solve; per level: x = P x_coarse, then npre iterations of the down smoother
+ * (PETSc's PCMGMCycle_Private / PCMGFCycle_Private / PCMGACycle_Private / PCMGKCycle_Private).  Takes effect at the next cycle. */
+enum { FH_CYCLE_MULTIPLICATIVE = 0, FH_CYCLE_FULL = 1, FH_CYCLE_ADDITIVE = 2, FH_CYCLE_KASKADE = 3 };
+int fh_mg_set_cycle_type(fh_mg_t mg, int type);
 int fh_mg_setup(fh_mg_t mg);
 /* coordinates of the unknowns of level 0 ([n * dim], dim 1..3; the dofs of the coarsest mesh, Mesh::GetTopology()->_Sol[0..2]): the exact coarse
  * solve (the reference's PCLU / MUMPS on the coarsest level, LinearEquationSolverPetsc.cpp:237-287) then dissects its dense problem -- block
@@ -420,6 +432,14 @@ typedef int (*fh_allreduce_fn)(void* user, double* buf, int n);
 int fh_halo_create_host(fh_ctx_t ctx, int rank, int nranks, fh_exchange_fn exchange, fh_allreduce_fn allreduce, void* user,
                         const int* send_counts, const int* send_idx, const int* recv_counts, fh_halo_t* halo);
 int fh_halo_update(fh_halo_t halo, fh_vec_t v);                  /* owner -> ghost copies, async on comm stream + join */
+/* ghost -> owner, ADD_VALUES: what VecAssemblyBegin/End do with the stash of off-process adds (PetscVector.cpp:131-153, PetscVector.hpp:595-612).
+ * Staged adds (fh_vec_stage_values) whose index is a ghost of this rank are collected beside the vector; this call ships them to the owners,
+ * which add them to their entries (source ranks in ascending order: deterministic).  Collective over the ranks of the plan; a rank without
+ * such adds sends zeros.  fh_vec_ghost_adds_pending flushes the staged adds and says whether this rank has any (the caller reduces the flag
+ * over the ranks and skips the exchange when nobody has).  Follow with fh_halo_update to refresh the ghost copies. */
+int fh_halo_reverse_add(fh_halo_t halo, fh_vec_t v);
+int fh_vec_ghost_adds_pending(fh_vec_t v, int* pending);
+int fh_vec_ghost_adds(fh_vec_t v, double* out /* [nghost] the adds collected for the ghost entries since the last fh_halo_reverse_add */);
 /* the two halves of fh_halo_update (VecGhostUpdateBegin / VecGhostUpdateEnd, PetscVector.hpp:605-608): begin packs on the compute
  * stream and starts the transfer on the communication stream; device work queued between begin and end overlaps with it and must
  * not read the ghost tail; consumers queued after end see the received values.  One exchange in flight per plan. */

@@ -885,6 +885,59 @@ def vcycle(H, level, b, omega=2. / 3., npre=2, npost=2, coarse_solve=None, x=Non
     return x
 
 
+def pcmg_apply(H, b, kind="multiplicative", omega=2. / 3., npre=2, npost=2, coarse_solve=None, smoother="jacobi", level_solver="richardson"):
+    """One application of PCMG to b for the four PCMGSetType values MGInit can select (LinearEquationSolverPetsc.cpp:199-214), restated from PETSc
+    3.20's mg.c / fmg.c (parity unpinned -- PETSc is not in the image):
+      multiplicative  PCMGMCycle_Private = vcycle above
+      additive        PCMGACycle_Private: b_{l-1} = R b_l down all levels; every level x_l = smoothd(b_l) from zero (level 0: exact); x_l += P x_{l-1} upwards
+      full            PCMGFCycle_Private: b restricted down; x_0 exact; for l = 1..top: x_l = P x_{l-1}, then one multiplicative cycle on level l from that guess
+      kaskade         PCMGKCycle_Private: b restricted down; x_0 exact; for l = 1..top: x_l = P x_{l-1}, x_l = smoothd(b_l, x_l)"""
+    top = len(H.A) - 1
+    kw = dict(omega=omega, npre=npre, npost=npost, coarse_solve=coarse_solve, smoother=smoother, level_solver=level_solver)
+    if kind == "multiplicative":
+        return vcycle(H, top, b, **kw)
+    bs = [None] * (top + 1)
+    bs[top] = b
+    for l in range(top, 0, -1):
+        bs[l - 1] = H.P[l].T @ bs[l]
+    exact = lambda rhs: vcycle(H, 0, rhs, **kw)
+    # the down smoother alone = the first half of vcycle: npre iterations, no coarse correction, no post-smoothing
+    def smoothd(l, rhs, x0):
+        return exact(rhs) if l == 0 else _vcycle_presmooth_only(H, l, rhs, x0, kw)
+    if kind == "additive":
+        xs = [exact(bs[0])] + [smoothd(l, bs[l], None) for l in range(1, top + 1)]
+        x = xs[0]
+        for l in range(1, top + 1):
+            x = xs[l] + H.P[l] @ x
+        return x
+    x = exact(bs[0])
+    for l in range(1, top + 1):
+        x = H.P[l] @ x
+        if kind == "full":
+            x = vcycle(H, l, bs[l], x=x, **kw)
+        elif kind == "kaskade":
+            x = smoothd(l, bs[l], x)
+        else:
+            raise ValueError(kind)
+    return x
+
+
+def _vcycle_presmooth_only(H, level, b, x0, kw):
+    """npre iterations of the level's smoother from x0 (None = zero): vcycle with the coarse correction forced to zero on a one-level-deep view"""
+    kw2 = dict(kw)
+    kw2["npost"] = 0
+    zero = lambda r: np.zeros_like(r)
+    # levels below `level` only enter through the coarse solve: give the recursion a zero correction
+    class View:
+        pass
+    V = View()
+    V.A = [H.A[level - 1], H.A[level]]
+    V.P = [None, H.P[level]]
+    V._dinv = [H._dinv[level - 1], H._dinv[level]] if hasattr(H, "_dinv") else [jacobi_dinv(H.A[level - 1]), jacobi_dinv(H.A[level])]
+    kw2["coarse_solve"] = zero
+    return vcycle(V, 1, b, x=x0, **kw2)
+
+
 def solve_richardson_mg(H, rtol=1e-10, maxit=100, **kw):
     """outer Richardson with the V-cycle as the iteration (stationary MG iteration)."""
     A, b = H.A[-1], H.b

@@ -3,6 +3,11 @@
 The same SpMV kernel runs on every multigrid level, so the per-kernel average of `--stats` mixes fine and coarse launches;
 grouping by grid size separates the fine-level launches that bench.py's `roofline` refers to.
 
+If the run launched phase markers (fh_profile_marker -> kernels named k_phase_marker<N>; bench.py does), a second table splits every kernel's
+launches by phase: bench.py's phases are 1-2 the timed steps (assembly + cycle), 3-4 cycles alone, 5-6 the fused sweep issued launch by launch,
+7-8 the same launches replayed from one hipGraph; `steps` and `cycles` rows of the fine-level `k_spmv_lx<2048, 3, ...>` are the IN-CYCLE launches
+bench.py's `roofline.frac` is quoted on.
+
 usage: summarize.py <dir with *_kernel_trace.csv [and *_counter_collection.csv]> [out.md]
 """
 import collections
@@ -25,16 +30,38 @@ def main():
     lines = []
     traces = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
     groups = collections.defaultdict(list)
+    launches = []
     for f in traces:
         for r in csv.DictReader(open(f)):
             grid = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
             dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             groups[(short(r["Kernel_Name"]), grid)].append(dur)
+            launches.append((int(r["Start_Timestamp"]), short(r["Kernel_Name"]), grid, dur))
     tot = sum(sum(v) for v in groups.values())
     lines.append("| kernel | grid (threads) | calls | total us | avg us | min us | max us | % |")
     lines.append("|---|---|---|---|---|---|---|---|")
     for (k, g), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
         lines.append("| `%s` | %d | %d | %.1f | %.2f | %.2f | %.2f | %.1f |" % (k, g, len(v), sum(v), sum(v) / len(v), min(v), max(v), 100 * sum(v) / tot))
+    # ---- by phase (marker kernels) ----
+    PHASES = {(1, 2): "steps (assembly + cycle)", (3, 4): "cycles", (5, 6): "sweep, launch by launch", (7, 8): "sweep, graph replay"}
+    marks = {}
+    for t, k, g, dur in launches:
+        if k.startswith("k_phase_marker<"):
+            marks.setdefault(int(k[len("k_phase_marker<"):].rstrip(">")), []).append(t)
+    if marks:
+        byphase = collections.defaultdict(list)
+        for t, k, g, dur in launches:
+            if k.startswith("k_phase_marker<"):
+                continue
+            for (a, b), name in PHASES.items():
+                if a in marks and b in marks and any(ta < t < tb for ta, tb in zip(marks[a], marks[b])):
+                    byphase[(name, k, g)].append(dur)
+        lines.append("")
+        lines.append("| phase | kernel | grid (threads) | calls | avg us | min us | max us |")
+        lines.append("|---|---|---|---|---|---|---|")
+        for (name, k, g), v in sorted(byphase.items(), key=lambda kv: (kv[0][0], -sum(kv[1]))):
+            if sum(v) >= 20.0:
+                lines.append("| %s | `%s` | %d | %d | %.2f | %.2f | %.2f |" % (name, k, g, len(v), sum(v) / len(v), min(v), max(v)))
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):

@@ -65,18 +65,18 @@ static int run() {
   CHECK(y.first_local_index() == first && y.halo() == halo);
   y = static_cast<const NumericVector&>(x);
   CHECK(std::fabs(y.dot(x) - s2) < 1e-13 * s2);
-  // staged adds with global indices: owned entries and a ghost slot, applied by close(); the ghost slot is then overwritten by the
-  // owner's value (VecGhostUpdate INSERT_VALUES, SCATTER_FORWARD)
+  // staged adds with global indices: owned entries and a ghost entry, applied by close(); the add to the ghost entry is shipped to its owner
+  // and summed there (VecSetValues ADD_VALUES + VecAssemblyBegin/End), then the ghost copy is refreshed (VecGhostUpdate INSERT_VALUES, SCATTER_FORWARD)
   const int o0 = first, gh = ghosts[0];
   y.add_vector_blocked(std::vector<double>{1., 2., 100.}, std::vector<int>{o0, o0, gh});
   y.add(o0 + 1, 0.5);
   y.close();
-  CHECK(y(o0) == ref[o0] + 3. && y(o0 + 1) == ref[o0 + 1] + 0.5);
-  const double expect_ghost = ref[gh] + (gh == 7 ? 0.5 : 0.);      // global 7 is rank 1's o0 + 1; globals 2 / 5 were not changed by rank 0
+  CHECK(y(o0) == ref[o0] + 3. && y(o0 + 1) == ref[o0 + 1] + 0.5 + (g_rank == 1 ? 100. : 0.));     // rank 1's o0 + 1 = global 7 also received rank 0's 100
+  const double expect_ghost = ref[gh] + 100. + (gh == 7 ? 0.5 : 0.);      // global 7 is rank 1's o0 + 1 (its own + 0.5); global 2 got rank 1's 100 only
   CHECK(y(gh) == expect_ghost);
   std::vector<double> one;
   y.localize_to_one(one, 0);
-  CHECK((int)one.size() == N && one[0] == ref[0] + 3. && one[6] == ref[6] + 3. && one[7] == ref[7] + 0.5 && one[1] == ref[1] + 0.5);
+  CHECK((int)one.size() == N && one[0] == ref[0] + 3. && one[6] == ref[6] + 3. && one[7] == ref[7] + 100.5 && one[2] == ref[2] + 100. && one[1] == ref[1] + 0.5);
   x.clear();
   y.clear();
   fh_halo_destroy(halo);
@@ -93,6 +93,7 @@ int main() {
   g_sock = sv[g_rank];
   close(sv[1 - g_rank]);
   const int fails = run();
+  fflush(stdout);
   if (pid == 0) _exit(fails ? 1 : 0);
   int st = 0;
   waitpid(pid, &st, 0);

@@ -766,3 +766,41 @@ def test_dissected_coarse_solve_of_a_disconnected_operator(ctx):
     Ad.destroy()
     ctx.set_option("coarse_nd", 8)
     ctx.set_option("coarse_nd_min", 1024)
+
+
+@pytest.mark.parametrize("graph", [1, 0])
+@pytest.mark.parametrize("kind", ["full", "additive", "kaskade", "multiplicative"])
+@pytest.mark.parametrize("smoother,name,npre,npost", [(capi.SMOOTH_JACOBI, "jacobi", 2, 2), (capi.SMOOTH_JACOBI, "jacobi", 1, 3), (capi.SMOOTH_SOR, "sor", 1, 1)])
+def test_pcmg_types_match_the_oracle(ctx, H3, kind, smoother, name, npre, npost, graph):
+    """PCMGSetType FULL / ADDITIVE / KASKADE / MULTIPLICATIVE (MGInit's MgSmootherType, LinearEquationSolverPetsc.cpp:199-214): one application of
+    the preconditioner against the oracle's restatement of PETSc's four cycle routines, eager and replayed from the captured graph; switching
+    the type re-captures the cycle"""
+    ctx.set_option("use_graph", graph)
+    try:
+        mg, mats = device_hierarchy(ctx, H3, 2. / 3., npre, npost, smoother)
+        n = H3.A[-1].shape[0]
+        rhs = fo.lcg_fill(n, 17)
+        b, x = ctx.vector_from(rhs), ctx.vector(n)
+        for k in (kind, "multiplicative", kind):
+            mg.set_cycle_type(k)
+            ref = fo.pcmg_apply(H3, rhs, k, omega=2. / 3., npre=npre, npost=npost, smoother=name)
+            for rep in range(2):
+                mg.vcycle(b, x)
+                assert rel(x.to_numpy(), ref) < 1e-11, k
+        mg.destroy()
+    finally:
+        ctx.set_option("use_graph", 1)
+
+
+@pytest.mark.parametrize("kind", ["full", "additive", "kaskade"])
+def test_pcmg_types_as_preconditioners_of_the_outer_solver(ctx, H3, kind):
+    """every PCMG type preconditions GMRES to the direct solution (the additive and cascadic forms are no convergent iterations by themselves)"""
+    mg, mats = device_hierarchy(ctx, H3)
+    mg.set_cycle_type(kind)
+    n = H3.A[-1].shape[0]
+    xd = spla.spsolve(H3.A[-1].tocsc(), H3.b)
+    b, x = ctx.vector_from(H3.b), ctx.vector(n)
+    its, rn = mg.solve(b, x, outer="gmres", rtol=1e-12, maxit=100)
+    assert rel(x.to_numpy(), xd) < 1e-10
+    assert its <= {"full": 12, "additive": 60, "kaskade": 40}[kind]
+    mg.destroy()

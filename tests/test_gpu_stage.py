@@ -147,11 +147,17 @@ def test_staged_vector_adds_in_call_order_with_ghosts_and_repeats(ctx):
         for p, x in zip(loc, vals):
             ref[p] += x
     v.flush()
-    assert np.array_equal(v.get(glob), ref)
+    # adds to OWNED entries are applied; adds to ghost entries wait beside the vector for their owners (VecAssemblyBegin/End ships the stash of
+    # off-process ADD_VALUES, PetscVector.cpp:131-153): the ghost copies themselves are untouched
+    own = np.arange(n_local)
+    assert np.array_equal(v.get(glob[own]), ref[own])
+    assert np.array_equal(v.get(ghosts), np.zeros(ghosts.size))
+    assert np.array_equal(v.ghost_adds(ghosts.size), ref[n_local:])
     with pytest.raises(FemusHipError, match="neither owned nor a ghost"):
         v.stage_vector_blocked([1.0, 2.0], [first, 4])
     v.flush()
-    assert np.array_equal(v.get(glob), ref)                    # the failing call left nothing behind
+    assert np.array_equal(v.get(glob[own]), ref[own])          # the failing call left nothing behind
+    assert np.array_equal(v.ghost_adds(ghosts.size), ref[n_local:])
     # more values than one ring holds (1 M): several rings, same order
     big = ctx.vector(64)
     idx = rng.integers(0, 64, size=2_300_000).astype(np.int32)
