@@ -89,6 +89,7 @@ def main():
     ctx = femus_amd.Context(device)
     t0 = time.time()
     parallelism = "1 rank per GPU"
+    preflight = None
     dist_err = None
     pb = None
     if (world > 1 and os.environ.get("FEMUS_BENCH_DD", "1") != "0") or os.environ.get("FEMUS_BENCH_FORCE_DD") == "1":
@@ -107,8 +108,11 @@ def main():
                     # a ring exchange + all-reduce through fh_halo_* in a child process first: a RCCL path that fails or HANGS on this
                     # machine must end in the reported fallback below, not in a hung bench
                     from femus_amd import rccl_preflight
+                    t_pf = time.time()
                     good, msg = rccl_preflight.run(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
                                                    int(os.environ.get("MASTER_PORT", "29500")) + 100, device)
+                    preflight = [{"rank": int(g[0]), "ok": bool(g[1]), "message": g[2], "seconds": g[3]}
+                                 for g in comm.allgather_obj((rank, bool(good), str(msg)[:300], float(time.time() - t_pf)))]
                     if not all(comm.allgather_obj(bool(good))):
                         raise RuntimeError(msg if not good else "RCCL preflight failed on another rank")
                 if transport == "gloo":
@@ -390,6 +394,8 @@ def main():
 
     if halo_info is not None:
         out["halo"] = halo_info
+    if preflight is not None:
+        out["rccl_preflight"] = preflight          # what the RCCL preflight children of every rank said (ok / message / seconds)
 
     # ---- CPU baseline: the oracle's C restatement on the host cores (rank 0, N = 1 only) ------------------------
     if rank == 0 and not args.no_live_traffic and os.environ.get("FEMUS_BENCH_LIVE_TRAFFIC", "1") != "0":
@@ -454,17 +460,26 @@ def halo_report(ctx, comm, pb):
     st = [h.stats(reset=True) for h in pb.halos]
     n_allreduce = sum(h.allreduce_count(reset=True) for h in pb.halos)
     ncyc = 3
+    for h in pb.halos:
+        h.allreduce_ms(reset=True)
     ctx.set_option("halo_profile", 1)
     for _ in range(ncyc):
         pb.vcycle()
     ctx.sync()
     ctx.set_option("halo_profile", 0)
     pr = [h.stats(reset=True) for h in pb.halos]
+    ar_ms = sum(h.allreduce_ms(reset=True) for h in pb.halos) / ncyc
     top = pb.A[-1]
     n_int, n_ifc = top.split_info(top.m())
-    ex = comm.allreduce_max(sum(p["exchange_ms"] for p in pr) / ncyc)
-    xp = comm.allreduce_max(sum(p["exposed_ms"] for p in pr) / ncyc)
+    ex_me, xp_me = sum(p["exchange_ms"] for p in pr) / ncyc, sum(p["exposed_ms"] for p in pr) / ncyc
+    ex = comm.allreduce_max(ex_me)
+    xp = comm.allreduce_max(xp_me)
+    # (the setup sockets carry plain values, lists and tuples only)
+    got = comm.allgather_obj((float(ex_me), float(xp_me), float(ar_ms), [float(p["exposed_ms"] / ncyc) for p in pr]))
+    by_rank = [{"exchange_ms": g[0], "exposed_ms": g[1], "allreduce_ms": g[2], "exposed_ms_by_level": list(g[3])} for g in got]
     return {
+        "by_rank": by_rank,
+        "allreduce_ms_per_cycle": max(b["allreduce_ms"] for b in by_rank),
         "exchanges_per_cycle": int(sum(s["updates"] for s in st)),
         "exchanges_per_cycle_by_level": [int(s["updates"]) for s in st],
         "bytes_sent_per_cycle_this_rank": int(sum(s["bytes_sent"] for s in st)),

@@ -1075,6 +1075,11 @@ class Halo:
         _chk(self.L.fh_halo_allreduce_count(self.h, int(bool(reset)), ctypes.byref(n)))
         return n.value
 
+    def allreduce_ms(self, reset=False):
+        ms = ctypes.c_double()
+        _chk(self.L.fh_halo_allreduce_ms(self.h, int(bool(reset)), ctypes.byref(ms)))
+        return ms.value
+
     def allreduce_mat(self, A):
         """in-place sum over the ranks of the values of a matrix that has the same pattern on every rank"""
         _chk(self.L.fh_halo_allreduce_mat(self.h, A.h))

@@ -28,7 +28,7 @@ struct fh_halo_s {
   // statistics (fh_halo_stats): exchanges started, payload sent; with the context option "halo_profile" also the duration of the
   // exchanges (pack done -> ghosts landed) and the part of it the compute stream really waited for (exposed)
   int64_t n_updates = 0, bytes_sent = 0, n_allreduce = 0;
-  double exchange_ms = 0.0, exposed_ms = 0.0;
+  double exchange_ms = 0.0, exposed_ms = 0.0, allreduce_ms = 0.0;
   hipEvent_t evt_begin = nullptr, evt_ready = nullptr;
   // host-staged transport (fh_halo_create_host): the exchange itself is the caller's function (MPI_Neighbor_alltoallv, sockets ...)
   fh_exchange_fn exchange = nullptr;
@@ -162,6 +162,22 @@ extern "C" int fh_halo_update(fh_halo_t h, fh_vec_t v) {
   return fh_halo_update_ptr(h, v->d, v->n_local);
 }
 
+// halo_profile: wall time of a collective as the compute stream sees it (synchronises, measurement only)
+struct AllreduceTimer {
+  fh_halo_t h;
+  bool on;
+  explicit AllreduceTimer(fh_halo_t hh) : h(hh), on(hh->ctx->halo_profile != 0) {
+    if (on) hipEventRecord(h->evt_begin, h->ctx->stream);
+  }
+  ~AllreduceTimer() {
+    if (!on) return;
+    float t = 0.f;
+    if (hipEventRecord(h->evt_ready, h->ctx->stream) == hipSuccess && hipEventSynchronize(h->evt_ready) == hipSuccess &&
+        hipEventElapsedTime(&t, h->evt_begin, h->evt_ready) == hipSuccess)
+      h->allreduce_ms += t;
+  }
+};
+
 static int host_allreduce(fh_halo_t h, double* d, int n) {
   std::vector<double> buf(n);
   FH_CHECK_HIP(hipMemcpyAsync(buf.data(), d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->ctx->stream));
@@ -176,6 +192,7 @@ extern "C" int fh_halo_allreduce_vec(fh_halo_t h, fh_vec_t v) {
   FH_REQUIRE(h && v, "fh_halo_allreduce_vec: null argument");
   if (halo_inert(h) || v->n_local == 0) return 0;
   h->n_allreduce++;
+  AllreduceTimer timer(h);
   if (h->allreduce) return host_allreduce(h, v->d, v->n_local);
   FH_CHECK_NCCL(ncclAllReduce(v->d, v->d, v->n_local, ncclDouble, ncclSum, h->comm, h->ctx->stream));
   return 0;
@@ -187,6 +204,7 @@ extern "C" int fh_halo_allreduce_mat(fh_halo_t h, fh_mat_t A) {
   FH_REQUIRE(h && A, "fh_halo_allreduce_mat: null argument");
   if (halo_inert(h) || A->nnz == 0) return 0;
   h->n_allreduce++;
+  AllreduceTimer timer(h);
   A->at_valid = false;
   if (h->allreduce) return host_allreduce(h, A->d_val, A->nnz);
   FH_CHECK_NCCL(ncclAllReduce(A->d_val, A->d_val, A->nnz, ncclDouble, ncclSum, h->comm, h->ctx->stream));
@@ -196,6 +214,7 @@ extern "C" int fh_halo_allreduce_mat(fh_halo_t h, fh_mat_t A) {
 int fh_halo_allreduce_ptr(fh_halo_t h, double* d, int n) {
   if (halo_inert(h) || n == 0) return 0;
   h->n_allreduce++;
+  AllreduceTimer timer(h);
   if (h->allreduce) return host_allreduce(h, d, n);
   FH_CHECK_NCCL(ncclAllReduce(d, d, n, ncclDouble, ncclSum, h->comm, h->ctx->stream));
   return 0;
@@ -377,6 +396,13 @@ extern "C" int fh_halo_reverse_add(fh_halo_t h, fh_vec_t v) {
     }
   if (v->nghost) FH_CHECK_HIP(hipMemsetAsync(v->d_gacc, 0, (size_t)v->nghost * sizeof(double), c->stream));
   v->gacc_dirty = false;
+  return 0;
+}
+
+extern "C" int fh_halo_allreduce_ms(fh_halo_t h, int reset, double* ms) {
+  FH_REQUIRE(h && ms, "fh_halo_allreduce_ms: null argument");
+  *ms = h->allreduce_ms;
+  if (reset) h->allreduce_ms = 0.0;
   return 0;
 }
 

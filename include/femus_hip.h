@@ -455,6 +455,7 @@ int fh_spmv_ghosted(fh_mat_t A, fh_halo_t halo, fh_vec_t x, fh_vec_t y, int mode
  * behind the rows that need no ghost).  Any pointer may be NULL. */
 int fh_halo_stats(fh_halo_t halo, int reset, int64_t* n_updates, int64_t* bytes_sent, double* exchange_ms, double* exposed_ms);
 int fh_halo_allreduce_count(fh_halo_t halo, int reset, int64_t* n);   /* all-reduces issued through this plan (vectors, matrices, host scalars) */
+int fh_halo_allreduce_ms(fh_halo_t halo, int reset, double* ms);   /* with the option "halo_profile": time the compute stream spent in the all-reduces of this plan */
 int fh_halo_sizes(fh_halo_t halo, int* nsend, int* nrecv);
 int fh_halo_allreduce_vec(fh_halo_t halo, fh_vec_t v);            /* in-place sum over ranks of the owned part (device) */
 int fh_halo_allreduce_sum(fh_halo_t halo, double* vals, int n);  /* host values in/out, any length */

@@ -16,6 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+TRANSPORT = os.environ.get("FEMUS_DD_TRANSPORT", "host")                  # "rccl" on a box with one GPU per rank (tests/scale_first_run.sh)
+PER_RANK = os.environ.get("FEMUS_DD_DEVICE_PER_RANK") == "1"
+
+
+def device_of(rank):
+    return rank if PER_RANK else 0
+
+
 def flag(x, level):
     return x[0] > 0.5 and (level < 2 or x[1] > 0.25)
 
@@ -24,9 +32,9 @@ def worker(rank, world, port, nb, nlevels, n_uniform, out, uniform=False):
     import femus_amd as fa
     from femus_amd import dd
     comm = dd.SocketComm(rank, world, "127.0.0.1", port)
-    ctx = fa.Context(0)
+    ctx = fa.Context(device_of(rank))
     t0 = time.time()
-    dp = dd.DistributedPoisson(ctx, comm, world, rank, nb=nb, nlevels=nlevels, transport="host", flag_fn=None if uniform else flag,
+    dp = dd.DistributedPoisson(ctx, comm, world, rank, nb=nb, nlevels=nlevels, transport=TRANSPORT, flag_fn=None if uniform else flag,
                                n_uniform=None if uniform else n_uniform)
     setup = time.time() - t0
     dp.assemble()
@@ -49,10 +57,10 @@ def general_worker(rank, world, port, nb, nlevels, n_uniform, out):
     import femus_amd as fa
     from femus_amd import dd
     comm = dd.SocketComm(rank, world, "127.0.0.1", port)
-    ctx = fa.Context(0)
+    ctx = fa.Context(device_of(rank))
     G, _ = global_box(world, nb)
     t0 = time.time()
-    dp = dd.DistributedPoisson(ctx, comm, world, rank, nlevels=nlevels, transport="host", coarse_mesh=G, flag_fn=flag, n_uniform=n_uniform)
+    dp = dd.DistributedPoisson(ctx, comm, world, rank, nlevels=nlevels, transport=TRANSPORT, coarse_mesh=G, flag_fn=flag, n_uniform=n_uniform)
     setup = time.time() - t0
     dp.assemble()
     dp.set_penalty_top()

@@ -53,6 +53,7 @@ def _worker(rank, world, port, nb, nlevels, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from femus_amd import dd, capi
+        import dd_host_executor as hx
         part = dd.BoxPartition(world, rank)
         comm = dd.TorchComm()
         meshes = dd.local_meshes(part, nb, nlevels)
@@ -62,22 +63,22 @@ def _worker(rank, world, port, nb, nlevels, out):
         om_rep.child_elem = m_rep.child_elems().astype(np.int64)
         bdc_rep, bdc_g0 = fo.dirichlet_dofs(om_rep, "biquadratic"), fo.dirichlet_dofs(om_g0, "biquadratic")
         P_g0 = fo.zero_interpolator_dirichlet(fo.build_prolongator(om_rep, om_g0, "biquadratic"), bdc_g0, bdc_rep)
-        H = dd.build_host_hierarchy(part, comm, nb, meshes, A, P, bdc, (m_rep, m_g0, P_g0, bdc_rep))
+        H = hx.build_host_hierarchy(part, comm, nb, meshes, A, P, bdc, (m_rep, m_g0, P_g0, bdc_rep))
         top = H.plans[-1]
         # halo plan sanity: what I receive for a ghost is the owner's value of the same global node
         v = np.zeros(top.n_owned + top.n_ghost)
         v[:top.n_owned] = top.gid[top.owned].astype(np.float64)
-        dd.halo_update(comm, top, v)
+        hx.halo_update(comm, top, v)
         assert np.array_equal(v[top.n_owned:], top.gid[top.ghost].astype(np.float64))
         # the reference's global numbering (fh_dd_plan_global): contiguous range per rank; a ghost's global index is the owner's
         # offset + position -- exchanging every rank's own global indices must reproduce the ghost list
         assert top.offsets[rank + 1] - top.offsets[rank] == top.n_owned and top.offsets[0] == 0
         v[:top.n_owned] = (top.offsets[rank] + np.arange(top.n_owned)).astype(np.float64)
-        dd.halo_update(comm, top, v)
+        hx.halo_update(comm, top, v)
         assert np.array_equal(v[top.n_owned:], top.ghost_global.astype(np.float64))
         owner_of_ghost = np.searchsorted(top.offsets, top.ghost_global, side="right") - 1
         assert np.array_equal(owner_of_ghost, np.repeat(np.arange(world), top.recv_counts))
-        x = dd.vcycle_numpy(comm, H, b[top.owned])
+        x = hx.vcycle_numpy(comm, H, b[top.owned])
         np.savez(out % rank, gid=top.gid[top.owned], x=x, b=b[top.owned], n_ghost=top.n_ghost)
     finally:
         dist.destroy_process_group()
@@ -157,6 +158,7 @@ def _amr_worker(rank, world, port, nb, nlevels, n_uniform, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from femus_amd import dd
+        import dd_host_executor as hx
         from oracle import femus_oracle_amr as fa
         part = dd.BoxPartition(world, rank)
         comm = dd.TorchComm()
@@ -168,9 +170,9 @@ def _amr_worker(rank, world, port, nb, nlevels, n_uniform, out):
         om_rep.child_elem = m_rep.child_elems().astype(np.int64)
         bdc_rep, bdc_g0 = fo.dirichlet_dofs(om_rep, "biquadratic"), fo.dirichlet_dofs(om_g0, "biquadratic")
         P_g0 = fo.zero_interpolator_dirichlet(fo.build_prolongator(om_rep, om_g0, "biquadratic"), bdc_g0, bdc_rep)
-        H = dd.build_host_hierarchy(part, comm, nb, meshes, Hl.A, Hl.P, Hl.bdc, (m_rep, m_g0, P_g0, bdc_rep))
+        H = hx.build_host_hierarchy(part, comm, nb, meshes, Hl.A, Hl.P, Hl.bdc, (m_rep, m_g0, P_g0, bdc_rep))
         top = H.plans[-1]
-        x = dd.vcycle_numpy(comm, H, Hl.b[top.owned])
+        x = hx.vcycle_numpy(comm, H, Hl.b[top.owned])
         np.savez(out % rank, gid=top.gid[top.owned], x=x, b=Hl.b[top.owned], n_ghost=top.n_ghost,
                  hanging=np.intersect1d(Hl.hanging[-1], top.owned).size)
     finally:
