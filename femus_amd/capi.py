@@ -783,6 +783,38 @@ class Assembler:
         return {"ncolors": nco.value, "algorithmic_bytes": by.value, "flops": fl.value}
 
 
+class Direct:
+    """sparse exact solve of a symmetric operator (fh_direct_*: multifrontal factorisation over a nested-dissection tree)"""
+
+    def __init__(self, ctx, A, coords=None, leaf=0):
+        self.ctx, self.L, self.A = ctx, ctx.L, A
+        self.h = ctypes.c_void_p()
+        if coords is not None:
+            xy = _f64(np.ascontiguousarray(coords))
+            dim = xy.shape[1] if xy.ndim == 2 else 1
+            _chk(self.L.fh_direct_create(ctx.h, A.h, int(dim), _p(xy), int(leaf), ctypes.byref(self.h)))
+        else:
+            _chk(self.L.fh_direct_create(ctx.h, A.h, 0, None, int(leaf), ctypes.byref(self.h)))
+
+    def factor(self):
+        _chk(self.L.fh_direct_factor(self.h))
+        return self
+
+    def solve(self, b, x):
+        _chk(self.L.fh_direct_solve(self.h, b.h, x.h))
+
+    def info(self):
+        a, f, h, lf = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        fd = ctypes.c_int64()
+        _chk(self.L.fh_direct_info(self.h, ctypes.byref(a), ctypes.byref(f), ctypes.byref(h), ctypes.byref(lf), ctypes.byref(fd)))
+        return {"coupled": a.value, "fronts": f.value, "height": h.value, "largest_front": lf.value, "factor_doubles": fd.value}
+
+    def destroy(self):
+        if self.h:
+            self.L.fh_direct_destroy(self.h)
+            self.h = None
+
+
 class Index:
     """device-resident index list (the _bdcIndex of a level): SetPenalty / ZerosBoundaryResiduals without host traffic"""
 

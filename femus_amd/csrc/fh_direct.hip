@@ -1,0 +1,886 @@
+// Sparse exact solve on gfx950: multifrontal factorisation over a nested-dissection tree (round 4).
+// What it serves: the reference hands its exact solves to MUMPS through PETSc -- the coarsest multigrid level (KSPPREONLY + PCLU,
+// 03_solvers/LinearEquationSolverPetsc.hpp:131-138, LinearEquationSolverPetsc.cpp:237-287), `Solve(vars, ksp_clean)` on one level, and
+// MLU_PRECOND / LU_PRECOND as the preconditioner of a level solver (PetscPreconditioner.cpp:147-160).  Up to round 3 this library inverted
+// ONE dense matrix (<= 16 384 coupled unknowns, one dissection level at most); this file removes the limit for symmetric operators.
+//
+//   symbolic (host, once per pattern and coupled set)
+//     coupled unknowns -> coupling graph -> recursive bisection into a binary tree: leaves of <= `leaf` unknowns, inner nodes = vertex
+//     separators.  With coordinates the cut is a layer boundary across the principal axis next to the median (for Q2 unknowns: one plane
+//     of nodes at an element boundary); without, the layers are the levels of a breadth-first search from a pseudo-peripheral unknown.
+//     Unknowns are renumbered in post-order (a node's own unknowns are contiguous, ancestors come later).  Front of node t: own unknowns
+//     S_t (s) and the boundary B_t (b) = ancestors' unknowns reached by fill, from the usual recurrence
+//     struct(t) = (adj(S_t) u struct(children)) \ subtree(t).
+//   numeric (device, every factorisation; nodes of equal height in the tree batched into the same launches)
+//     D_t = A[S,S] + children's updates, E_t = A[S,B] + ..., U_t = children's updates on [B,B]      (assembly by index maps, extend-add)
+//     D_t <- D_t^-1 (the batched symmetric 128-block inverse of fh_mg.hip), W_t = D_t^-1 E_t, U_t <- U_t - E_t^T W_t   (FP64 matrix cores)
+//   solve (device, graph-capturable: fixed launch sequence and buffers), front vectors y_t = [r_t ; u_t] flow up the tree as the matrices did
+//     up:    y_t = [b[S_t] ; 0] + children's u (gather, fixed order: deterministic) ; z_t = D_t^-1 r_t ; u_t -= W_t^T r_t
+//     down:  x[S_t] = z_t - W_t x[B_t]
+// Unknowns coupled to nothing (Dirichlet rows of a penalised operator) are solved by their diagonal, as the dense path does.
+// Symmetric operators only (entry-by-entry test on the sparse form); no pivoting across fronts, a front whose own block has no usable
+// pivot fails the factorisation (the caller falls back or reports).
+#include "fh_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace {
+
+struct DNode {
+  int parent = -1, child[2] = {-1, -1};
+  int height = 0;                // 0 = leaf
+  int s = 0, b = 0;              // own unknowns, boundary unknowns
+  int own_off = 0;               // first own unknown in the permuted numbering
+  size_t D_off = 0, W_off = 0;   // into the factor buffer: D (s x s), W (s x b)
+  size_t E_off = 0, U_off = 0;   // into the transient buffer: E (s x b), U (b x b)
+  size_t y_off = 0;              // front vector [s + b]
+  size_t bidx_off = 0;           // boundary unknowns (permuted numbering, ascending)
+  std::vector<int> own, bnd;     // host: permuted indices
+};
+
+struct Graph {
+  std::vector<int> ptr, adj;
+};
+
+// ---- bisection of a set of graph vertices into (A, B, separator) --------------------------------------------------------------------
+// keys = layer index of every vertex of the set (coordinates: quantised projection on the principal axis; none: BFS levels)
+static void layer_keys(const Graph& G, const double* xyz, int dim, const std::vector<int>& set, std::vector<int>& mark /* size n, all -1 */,
+                       std::vector<std::pair<double, int> >& key) {
+  key.resize(set.size());
+  if (xyz) {
+    double mean[3] = {0, 0, 0};
+    for (int u : set)
+      for (int d = 0; d < dim; d++) mean[d] += xyz[(size_t)u * dim + d];
+    for (int d = 0; d < dim; d++) mean[d] /= (double)set.size();
+    double C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int u : set) {
+      double x[3] = {0, 0, 0};
+      for (int d = 0; d < dim; d++) x[d] = xyz[(size_t)u * dim + d] - mean[d];
+      for (int i = 0; i < dim; i++)
+        for (int j = 0; j < dim; j++) C[i][j] += x[i] * x[j];
+    }
+    double v[3] = {0, 0, 0};
+    int dmax = 0;
+    for (int d = 1; d < dim; d++)
+      if (C[d][d] > C[dmax][dmax] * (1.0 + 1e-9)) dmax = d;
+    v[dmax] = 1.0;
+    for (int it = 0; it < 60; it++) {
+      double u[3] = {0, 0, 0}, nrm = 0.0;
+      for (int i = 0; i < dim; i++)
+        for (int j = 0; j < dim; j++) u[i] += C[i][j] * v[j];
+      for (int i = 0; i < dim; i++) nrm += u[i] * u[i];
+      nrm = std::sqrt(nrm);
+      if (!(nrm > 0.0)) break;
+      for (int i = 0; i < dim; i++) v[i] = u[i] / nrm;
+    }
+    double span = 0.0;
+    for (size_t k = 0; k < set.size(); k++) {
+      double t = 0.0;
+      for (int d = 0; d < dim; d++) t += v[d] * (xyz[(size_t)set[k] * dim + d] - mean[d]);
+      key[k] = std::make_pair(t, set[k]);
+      span = std::max(span, std::fabs(t));
+    }
+    const double q = span > 0.0 ? span * 1e-9 : 1.0;
+    for (auto& kv : key) kv.first = std::floor(kv.first / q + 0.5);
+    return;
+  }
+  // graph only: breadth-first levels from a pseudo-peripheral vertex of the set (two sweeps); other components follow behind
+  for (int u : set) mark[u] = -2;                       // in the set, not reached
+  auto bfs = [&](int start, int base, std::vector<int>& order) {
+    size_t head = order.size();
+    mark[start] = base;
+    order.push_back(start);
+    while (head < order.size()) {
+      const int u = order[head++];
+      for (int e = G.ptr[u]; e < G.ptr[u + 1]; e++) {
+        const int w = G.adj[e];
+        if (mark[w] == -2) {
+          mark[w] = mark[u] + 1;
+          order.push_back(w);
+        }
+      }
+    }
+  };
+  std::vector<int> order;
+  order.reserve(set.size());
+  bfs(set[0], 0, order);
+  const int far = order.back();
+  for (int u : order) mark[u] = -2;
+  order.clear();
+  int base = 0;
+  bfs(far, 0, order);
+  for (int u : set)
+    if (mark[u] == -2) {                               // another component
+      base = mark[order.back()] + 1;
+      bfs(u, base, order);
+    }
+  for (size_t k = 0; k < set.size(); k++) key[k] = std::make_pair((double)mark[set[k]], set[k]);
+  for (int u : set) mark[u] = -1;
+}
+
+// returns false when the set cannot be cut (one layer)
+static bool bisect(const Graph& G, const double* xyz, int dim, const std::vector<int>& set, std::vector<int>& mark, std::vector<int>& side /* size n, zero */,
+                   std::vector<int>& A, std::vector<int>& B, std::vector<int>& S) {
+  std::vector<std::pair<double, int> > key;
+  layer_keys(G, xyz, dim, set, mark, key);
+  std::sort(key.begin(), key.end());
+  const size_t half = set.size() / 2;
+  size_t c_lo = half, c_hi = half;
+  while (c_lo > 0 && key[c_lo - 1].first == key[c_lo].first) c_lo--;
+  while (c_hi < set.size() && c_hi > 0 && key[c_hi - 1].first == key[c_hi].first) c_hi++;
+  size_t best_cut = 0, best_cnt = (size_t)-1;
+  int best_side = 0;
+  for (size_t cut : {c_lo, c_hi}) {
+    if (cut == 0 || cut >= set.size()) continue;
+    for (size_t k = 0; k < set.size(); k++) side[key[k].second] = k < cut ? 1 : 2;
+    size_t cnt[3] = {0, 0, 0};
+    for (size_t k = 0; k < set.size(); k++) {
+      const int u = key[k].second, mine = side[u];
+      bool touches = false;
+      for (int e = G.ptr[u]; e < G.ptr[u + 1] && !touches; e++) touches = side[G.adj[e]] == 3 - mine;
+      if (touches) cnt[mine]++;
+    }
+    for (int which = 1; which <= 2; which++) {
+      const size_t rest = (which == 1 ? cut : set.size() - cut) - cnt[which];
+      if (rest == 0) continue;
+      if (cnt[which] < best_cnt) {
+        best_cnt = cnt[which];
+        best_cut = cut;
+        best_side = which;
+      }
+    }
+    for (size_t k = 0; k < set.size(); k++) side[key[k].second] = 0;
+  }
+  if (best_side == 0) return false;
+  for (size_t k = 0; k < set.size(); k++) side[key[k].second] = k < best_cut ? 1 : 2;
+  A.clear(), B.clear(), S.clear();
+  for (size_t k = 0; k < set.size(); k++) {
+    const int u = key[k].second, mine = side[u];
+    bool touches = false;
+    if (mine == best_side)
+      for (int e = G.ptr[u]; e < G.ptr[u + 1] && !touches; e++) touches = side[G.adj[e]] == 3 - mine;
+    if (touches) S.push_back(u);
+    else (mine == 1 ? A : B).push_back(u);
+  }
+  for (size_t k = 0; k < set.size(); k++) side[key[k].second] = 0;
+  std::sort(A.begin(), A.end());
+  std::sort(B.begin(), B.end());
+  std::sort(S.begin(), S.end());
+  return !A.empty() && !B.empty();
+}
+
+static int build_tree(const Graph& G, const double* xyz, int dim, const std::vector<int>& set, int leaf, std::vector<int>& mark, std::vector<int>& side,
+                      std::vector<DNode>& nodes) {
+  std::vector<int> A, B, S;
+  if ((int)set.size() <= leaf || !bisect(G, xyz, dim, set, mark, side, A, B, S)) {
+    DNode t;
+    t.own = set;
+    nodes.push_back(std::move(t));
+    return (int)nodes.size() - 1;
+  }
+  const int ca = build_tree(G, xyz, dim, A, leaf, mark, side, nodes);
+  const int cb = build_tree(G, xyz, dim, B, leaf, mark, side, nodes);
+  DNode t;
+  t.own = S;                      // (may be empty: disconnected halves -- a node without unknowns that only joins two subtrees)
+  t.child[0] = ca;
+  t.child[1] = cb;
+  t.height = 1 + std::max(nodes[ca].height, nodes[cb].height);
+  nodes.push_back(std::move(t));
+  const int me = (int)nodes.size() - 1;
+  nodes[ca].parent = me;
+  nodes[cb].parent = me;
+  return me;
+}
+
+// ---- device kernels -------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dd_coupling(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val, int n,
+                                                     int* __restrict__ rowhit, int* __restrict__ colhit) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  int hit = 0;
+  for (int k = rowptr[i] + lane; k < rowptr[i + 1]; k += 64) {
+    const int j = col[k];
+    if (j != i && j < n && val[k] != 0.0) {
+      hit = 1;
+      colhit[j] = 1;          // benign race: every writer stores 1
+    }
+  }
+  hit = __any(hit);
+  if (lane == 0) rowhit[i] = hit;
+}
+
+__global__ __launch_bounds__(256) void k_dd_symmetry(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val, int n, double tol,
+                                                     int* __restrict__ flag) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  double dmax = 0.0;
+  for (int k = rowptr[i] + lane; k < rowptr[i + 1]; k += 64) dmax = fmax(dmax, fabs(val[k]));
+  for (int d = 32; d >= 1; d >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, d, 64));
+  int bad = 0;
+  for (int k = rowptr[i] + lane; k < rowptr[i + 1]; k += 64) {
+    const int j = col[k];
+    if (j >= n || j == i) continue;
+    int lo = rowptr[j], hi = rowptr[j + 1] - 1;
+    double t = 0.0;
+    while (lo <= hi) {
+      const int mid = lo + ((hi - lo) >> 1);
+      if (col[mid] == i) { t = val[mid]; break; }
+      if (col[mid] < i) lo = mid + 1; else hi = mid - 1;
+    }
+    if (fabs(t - val[k]) > tol * dmax) bad = 1;
+  }
+  if (__any(bad) && lane == 0) atomicExch(flag, 1);
+}
+
+// assembly of the fronts from the operator: dst[k] (offset into fac or tmp, bit 62 selects tmp) <- val[src[k]]
+__global__ __launch_bounds__(256) void k_dd_assemble(size_t n, const int* __restrict__ src, const long long* __restrict__ dst, const double* __restrict__ val,
+                                                     double* __restrict__ fac, double* __restrict__ tmp) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const long long d = dst[k];
+  const double v = val[src[k]];
+  if (d & (1ll << 62)) tmp[d & ~(1ll << 62)] = v;
+  else fac[d] = v;
+}
+
+struct EaDesc {          // extend-add of one child's update matrix into its parent's front
+  const double* U;       // child: b_c x b_c
+  int bc;
+  const int* cmap;       // [b_c] position of the child's boundary unknown in the parent's front [own | boundary]
+  double *D, *E, *Up;    // parent
+  int sp, bp;
+};
+__global__ __launch_bounds__(256) void k_dd_extend_add(const EaDesc* __restrict__ desc) {
+  const EaDesc q = desc[blockIdx.z];
+  const int i = blockIdx.y * 16 + (threadIdx.x >> 4), j = blockIdx.x * 16 + (threadIdx.x & 15);
+  if (i >= q.bc || j >= q.bc) return;
+  const int pi = q.cmap[i], pj = q.cmap[j];
+  const double v = q.U[(size_t)i * q.bc + j];
+  if (pi < q.sp) {
+    if (pj < q.sp) q.D[(size_t)pi * q.sp + pj] += v;
+    else q.E[(size_t)pi * q.bp + (pj - q.sp)] += v;
+  } else if (pj >= q.sp)
+    q.Up[(size_t)(pi - q.sp) * q.bp + (pj - q.sp)] += v;
+}
+
+// C (M x N, ldc) += alpha P^T Q with P (K x M, ldp), Q (K x N, ldq), all row-major: 64 x 64 tile per workgroup on v_mfma_f64_16x16x4 (operand
+// staging k-major with row stride 80 doubles: conflict-free fragment reads; fragments as in k_gjb_update_mfma of fh_mg.hip)
+struct GemmDesc {
+  const double *P, *Q;
+  double* C;
+  int M, N, K, ldp, ldq, ldc;
+  double alpha;
+  int upper_only;        // 1: C is symmetric and only tiles with tile column >= tile row are computed (mirrored by k_dd_mirror)
+};
+typedef double dd_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_dd_gemm_tn(const GemmDesc* __restrict__ desc) {
+  constexpr int LD = 80, KS = 16;
+  __shared__ double Ps[KS][LD], Qs[KS][LD];
+  const GemmDesc q = desc[blockIdx.z];
+  const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
+  if (ti >= q.M || tj >= q.N || (q.upper_only && tj < ti)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+  const int kk = lane >> 4, li = lane & 15;
+  dd_d4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[a][b][r] = 0.0;
+  for (int k0 = 0; k0 < q.K; k0 += KS) {
+    for (int idx = tid; idx < KS * 64; idx += 256) {
+      const int k = idx >> 6, c = idx & 63, kr = k0 + k;
+      Ps[k][c] = (kr < q.K && ti + c < q.M) ? q.P[(size_t)kr * q.ldp + ti + c] : 0.0;
+      Qs[k][c] = (kr < q.K && tj + c < q.N) ? q.Q[(size_t)kr * q.ldq + tj + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k4 = 0; k4 < KS; k4 += 4) {
+      const double a0 = Ps[k4 + kk][wi + li], a1 = Ps[k4 + kk][wi + 16 + li];
+      const double b0 = Qs[k4 + kk][wj + li], b1 = Qs[k4 + kk][wj + 16 + li];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int i = ti + wi + a * 16 + kk + 4 * r;
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const int j = tj + wj + b * 16 + li;
+        if (i < q.M && j < q.N) q.C[(size_t)i * q.ldc + j] += q.alpha * acc[a][b][r];
+      }
+    }
+}
+// lower tiles of a symmetric C from the upper ones (after k_dd_gemm_tn with upper_only)
+__global__ __launch_bounds__(256) void k_dd_mirror(const GemmDesc* __restrict__ desc) {
+  const GemmDesc q = desc[blockIdx.z];
+  const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
+  if (!q.upper_only || ti >= q.M || tj >= q.N || tj <= ti) return;          // strictly upper tiles are copied below the diagonal
+  for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+    const int i = ti + (idx >> 6), j = tj + (idx & 63);
+    if (i < q.M && j < q.N) q.C[(size_t)j * q.ldc + i] = q.C[(size_t)i * q.ldc + j];
+  }
+}
+// inside the diagonal tiles the MFMA computed both halves from the same products in a different order: make them bit-symmetric
+__global__ __launch_bounds__(256) void k_dd_mirror_diag(const GemmDesc* __restrict__ desc) {
+  const GemmDesc q = desc[blockIdx.z];
+  const int t0 = blockIdx.x * 64;
+  if (!q.upper_only || t0 >= q.M) return;
+  for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+    const int i = t0 + (idx >> 6), j = t0 + (idx & 63);
+    if (i < j && j < q.M) q.C[(size_t)j * q.ldc + i] = q.C[(size_t)i * q.ldc + j];
+  }
+}
+
+struct SolveNode {
+  const double *D, *W;
+  int s, b, own_off;
+  long long y_off;
+  const int* bidx;           // [b] boundary unknowns (permuted numbering)
+  const long long* gat[2];   // [s + b] per child: offset into y of the child's entry that lands here, -1 = none
+};
+// right-hand side into the permuted numbering / solution back, the decoupled unknowns by their diagonal
+__global__ __launch_bounds__(256) void k_dd_gather(int na, const int* __restrict__ p2o, const double* __restrict__ b, double* __restrict__ bp) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < na) bp[k] = b[p2o[k]];
+}
+__global__ __launch_bounds__(256) void k_dd_scatter(int n, int na, const int* __restrict__ p2o, const double* __restrict__ xp, const double* __restrict__ b,
+                                                    const double* __restrict__ dinv_rest, double* __restrict__ x) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int o = p2o[k];
+  x[o] = k < na ? xp[k] : b[o] * dinv_rest[k - na];
+}
+// up, step 1: y_t = [b[S_t] ; 0] + the children's u (child 0 first)
+__global__ __launch_bounds__(256) void k_dd_up_assemble(const SolveNode* __restrict__ nodes, const int* __restrict__ list, const double* __restrict__ bp,
+                                                        double* __restrict__ y) {
+  const SolveNode q = nodes[list[blockIdx.y]];
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= q.s + q.b) return;
+  double v = k < q.s ? bp[q.own_off + k] : 0.0;
+  if (q.gat[0]) {
+    const long long g = q.gat[0][k];
+    if (g >= 0) v += y[g];
+  }
+  if (q.gat[1]) {
+    const long long g = q.gat[1][k];
+    if (g >= 0) v += y[g];
+  }
+  y[q.y_off + k] = v;
+}
+// up, step 2: blocks [0, ceil(s / 4)): z_t = D^-1 r_t (one wave per row) ; blocks behind: u_t[j] -= sum_k W[k][j] r_t[k] (64 columns per block)
+__global__ __launch_bounds__(256) void k_dd_up_apply(const SolveNode* __restrict__ nodes, const int* __restrict__ list, double* __restrict__ y,
+                                                     double* __restrict__ zp) {
+  __shared__ double part[4][64];
+  const SolveNode q = nodes[list[blockIdx.y]];
+  const int nrow = (q.s + 3) / 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double* r = y + q.y_off;
+  if ((int)blockIdx.x < nrow) {
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= q.s) return;
+    const double* row = q.D + (size_t)i * q.s;
+    double a = 0.0;
+    for (int k = lane; k < q.s; k += 64) a += row[k] * r[k];
+    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+    if (lane == 0) zp[q.own_off + i] = a;
+    return;
+  }
+  const int j0 = ((int)blockIdx.x - nrow) * 64;
+  if (j0 >= q.b) return;
+  const int j = j0 + lane;
+  double a = 0.0;
+  if (j < q.b)
+    for (int k = wave; k < q.s; k += 4) a += q.W[(size_t)k * q.b + j] * r[k];
+  part[wave][lane] = a;
+  __syncthreads();
+  if (wave == 0 && j < q.b) y[q.y_off + q.s + j] -= ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+}
+// down: x[S_t] = z_t - W_t x[B_t], one wave per row
+__global__ __launch_bounds__(256) void k_dd_down(const SolveNode* __restrict__ nodes, const int* __restrict__ list, const double* __restrict__ zp,
+                                                 double* __restrict__ xp) {
+  const SolveNode q = nodes[list[blockIdx.y]];
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= q.s) return;
+  const double* row = q.W + (size_t)i * q.b;
+  double a = 0.0;
+  for (int k = lane; k < q.b; k += 64) a += row[k] * xp[q.bidx[k]];
+  for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+  if (lane == 0) xp[q.own_off + i] = zp[q.own_off + i] - a;
+}
+__global__ __launch_bounds__(256) void k_dd_fill(double* __restrict__ p, size_t n, double v) {
+  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) p[k] = v;
+}
+__global__ __launch_bounds__(256) void k_dd_diag_rest(int nrest, const int* __restrict__ rest, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                      const double* __restrict__ val, double* __restrict__ dinv, int* __restrict__ flag) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nrest) return;
+  const int i = rest[k];
+  double d = 0.0;
+  for (int e = rowptr[i]; e < rowptr[i + 1]; e++)
+    if (col[e] == i) d = val[e];
+  if (d == 0.0) atomicExch(flag, 1);
+  dinv[k] = d != 0.0 ? 1.0 / d : 0.0;
+}
+__global__ __launch_bounds__(256) void k_dd_check(const double* __restrict__ p, size_t n, int* __restrict__ flag) {
+  int bad = 0;
+  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) bad |= !isfinite(p[k]);
+  if (bad) atomicExch(flag, 1);
+}
+
+}  // namespace
+
+struct fh_direct_s {
+  fh_ctx_t ctx = nullptr;
+  fh_mat_t A = nullptr;
+  uint64_t A_uid = 0;
+  int n = 0, na = 0;               // unknowns, coupled unknowns
+  int dim = 0, leaf = 256;
+  std::vector<double> xyz;         // host copy of the coordinates ([n * dim]) or empty
+  // symbolic
+  std::vector<int> act;            // the coupled list the tree was made for (original indices), then the decoupled ones
+  std::vector<DNode> nodes;
+  std::vector<std::vector<int> > by_height;     // node ids
+  int root = -1, max_height = 0;
+  size_t fac_doubles = 0, tmp_doubles = 0, y_doubles = 0, nmap = 0;
+  // device
+  int *d_hit = nullptr, *d_p2o = nullptr, *d_flags = nullptr;
+  int* d_asm_src = nullptr;
+  long long* d_asm_dst = nullptr;
+  double *d_fac = nullptr, *d_tmp = nullptr, *d_work = nullptr, *d_y = nullptr, *d_bp = nullptr, *d_zp = nullptr, *d_xp = nullptr, *d_dinv_rest = nullptr;
+  size_t work_doubles = 0;
+  int* d_int = nullptr;            // bidx lists, cmaps, per-height node lists
+  long long* d_gat = nullptr;
+  void *d_inv = nullptr, *d_gemm = nullptr, *d_ea = nullptr, *d_snodes = nullptr;
+  std::vector<int> h_list_off;     // per height: offset of its node list in d_int
+  size_t list_base = 0;
+  std::vector<size_t> inv_off, gemm1_off, gemm2_off, ea_off[2];    // per height: first descriptor
+  std::vector<int> inv_cnt, inv_nmax, gemm_cnt, gemm_maxM1, gemm_maxN, gemm_maxM2, ea_cnt[2], ea_maxb[2], max_sb, max_s, max_b;
+  bool factored = false;
+  int n_fronts = 0, largest_front = 0;
+};
+
+static void direct_free_device(fh_direct_t d) {
+  for (void* p : {(void*)d->d_p2o, (void*)d->d_asm_src, (void*)d->d_asm_dst, (void*)d->d_fac, (void*)d->d_tmp, (void*)d->d_work, (void*)d->d_y, (void*)d->d_bp,
+                  (void*)d->d_zp, (void*)d->d_xp, (void*)d->d_dinv_rest, (void*)d->d_int, (void*)d->d_gat, d->d_inv, d->d_gemm, d->d_ea, d->d_snodes})
+    if (p) hipFree(p);
+  d->d_p2o = nullptr; d->d_asm_src = nullptr; d->d_asm_dst = nullptr; d->d_fac = d->d_tmp = d->d_work = d->d_y = d->d_bp = d->d_zp = d->d_xp = d->d_dinv_rest = nullptr;
+  d->d_int = nullptr; d->d_gat = nullptr; d->d_inv = d->d_gemm = d->d_ea = d->d_snodes = nullptr;
+}
+
+extern "C" int fh_direct_create(fh_ctx_t ctx, fh_mat_t A, int dim, const double* coords, int leaf, fh_direct_t* out) {
+  FH_GUARD_BEGIN
+  FH_REQUIRE(ctx && A && out && A->m == A->n, "fh_direct_create: a square matrix is needed");
+  FH_REQUIRE(dim == 0 || (dim >= 1 && dim <= 3 && coords), "fh_direct_create: coordinates need dim 1..3");
+  fh_direct_t d = new fh_direct_s();
+  d->ctx = ctx;
+  d->A = A;
+  d->n = A->m;
+  d->dim = coords ? dim : 0;
+  d->leaf = leaf > 0 ? leaf : 256;
+  if (coords) d->xyz.assign(coords, coords + (size_t)A->m * dim);
+  FH_CHECK_HIP(hipMalloc(&d->d_hit, ((size_t)2 * std::max(d->n, 1) + 2) * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&d->d_flags, 8 * sizeof(int)));
+  *out = d;
+  return 0;
+  FH_GUARD_END("fh_direct_create")
+}
+
+extern "C" int fh_direct_destroy(fh_direct_t d) {
+  if (!d) return 0;
+  hipStreamSynchronize(d->ctx->stream);
+  direct_free_device(d);
+  if (d->d_hit) hipFree(d->d_hit);
+  if (d->d_flags) hipFree(d->d_flags);
+  delete d;
+  return 0;
+}
+
+// tree, fronts, maps for the coupled set `act` (first na entries of d->act)
+static int direct_symbolic(fh_direct_t d) {
+  fh_mat_t A = d->A;
+  const int n = d->n, na = d->na;
+  direct_free_device(d);
+  d->nodes.clear();
+  d->by_height.clear();
+  d->factored = false;
+  std::vector<int> rp(n + 1);
+  FH_CHECK_HIP(hipMemcpy(rp.data(), A->d_rowptr, rp.size() * sizeof(int), hipMemcpyDeviceToHost));
+  std::vector<int> cl(std::max(rp[n], 1));
+  if (rp[n]) FH_CHECK_HIP(hipMemcpy(cl.data(), A->d_col, (size_t)rp[n] * sizeof(int), hipMemcpyDeviceToHost));
+  // coupling graph over the coupled unknowns (positions in act), both directions
+  std::vector<int> posn(n, -1);
+  for (int i = 0; i < na; i++) posn[d->act[i]] = i;
+  Graph G;
+  {
+    std::vector<std::pair<int, int> > ed;
+    for (int i = 0; i < na; i++)
+      for (int k = rp[d->act[i]]; k < rp[d->act[i] + 1]; k++) {
+        const int j = cl[k] < n ? posn[cl[k]] : -1;
+        if (j >= 0 && j != i) {
+          ed.emplace_back(i, j);
+          ed.emplace_back(j, i);
+        }
+      }
+    std::sort(ed.begin(), ed.end());
+    ed.erase(std::unique(ed.begin(), ed.end()), ed.end());
+    G.ptr.assign(na + 1, 0);
+    for (auto& e : ed) G.ptr[e.first + 1]++;
+    for (int i = 0; i < na; i++) G.ptr[i + 1] += G.ptr[i];
+    G.adj.resize(ed.size());
+    for (size_t k = 0; k < ed.size(); k++) G.adj[k] = ed[k].second;
+  }
+  std::vector<double> xyz;
+  if (d->dim) {
+    xyz.resize((size_t)na * d->dim);
+    for (int i = 0; i < na; i++)
+      for (int k = 0; k < d->dim; k++) xyz[(size_t)i * d->dim + k] = d->xyz[(size_t)d->act[i] * d->dim + k];
+  }
+  std::vector<int> all(na), mark(na, -1), side(na, 0);
+  std::iota(all.begin(), all.end(), 0);
+  if (na > 0) d->root = build_tree(G, d->dim ? xyz.data() : nullptr, d->dim, all, d->leaf, mark, side, d->nodes);
+  std::vector<DNode>& N = d->nodes;
+  const int nn = (int)N.size();
+  // post-order numbering: build_tree pushes children before their parent, so node order IS a post-order
+  std::vector<int> perm(na), node_of(na);          // perm[new] = position in act ; inverse below
+  {
+    int next = 0;
+    for (int t = 0; t < nn; t++) {
+      N[t].own_off = next;
+      N[t].s = (int)N[t].own.size();
+      for (int u : N[t].own) perm[next++] = u;
+    }
+    FH_REQUIRE(next == na, "fh_direct: the dissection lost unknowns (%d of %d)", next, na);
+  }
+  std::vector<int> inv(na);
+  for (int k = 0; k < na; k++) inv[perm[k]] = k;
+  for (int t = 0; t < nn; t++)
+    for (int k = 0; k < N[t].s; k++) {
+      N[t].own[k] = N[t].own_off + k;
+      node_of[N[t].own_off + k] = t;
+    }
+  // graph in the permuted numbering, boundary sets bottom-up
+  std::vector<int> pptr(na + 1, 0), padj(G.adj.size());
+  for (int k = 0; k < na; k++) pptr[k + 1] = pptr[k] + (G.ptr[perm[k] + 1] - G.ptr[perm[k]]);
+  for (int k = 0; k < na; k++) {
+    int o = pptr[k];
+    for (int e = G.ptr[perm[k]]; e < G.ptr[perm[k] + 1]; e++) padj[o++] = inv[G.adj[e]];
+    std::sort(padj.begin() + pptr[k], padj.begin() + pptr[k + 1]);
+  }
+  for (int t = 0; t < nn; t++) {
+    const int hi = N[t].own_off + N[t].s;           // everything >= hi that is reached lies in an ancestor
+    std::vector<int> st;
+    for (int k = N[t].own_off; k < hi; k++)
+      for (int e = pptr[k]; e < pptr[k + 1]; e++)
+        if (padj[e] >= hi) st.push_back(padj[e]);
+    for (int ch : N[t].child)
+      if (ch >= 0)
+        for (int v : N[ch].bnd)
+          if (v >= hi) st.push_back(v);
+    std::sort(st.begin(), st.end());
+    st.erase(std::unique(st.begin(), st.end()), st.end());
+    N[t].bnd.swap(st);
+    N[t].b = (int)N[t].bnd.size();
+  }
+  // layout
+  d->by_height.assign((size_t)(nn ? N[d->root].height : 0) + 1, std::vector<int>());
+  d->max_height = nn ? N[d->root].height : 0;
+  size_t fac = 0, tmp = 0, yo = 0, bo = 0;
+  d->largest_front = 0;
+  for (int t = 0; t < nn; t++) {
+    DNode& q = N[t];
+    d->by_height[q.height].push_back(t);
+    q.D_off = fac; fac += (size_t)q.s * q.s;
+    q.W_off = fac; fac += (size_t)q.s * q.b;
+    q.E_off = tmp; tmp += (size_t)q.s * q.b;
+    q.U_off = tmp; tmp += (size_t)q.b * q.b;
+    q.y_off = yo; yo += (size_t)q.s + q.b;
+    q.bidx_off = bo; bo += (size_t)q.b;
+    d->largest_front = std::max(d->largest_front, q.s + q.b);
+  }
+  d->n_fronts = nn;
+  d->fac_doubles = fac; d->tmp_doubles = tmp; d->y_doubles = yo;
+  // assembly map: operator entry -> front entry
+  std::vector<int> src;
+  std::vector<long long> dst;
+  for (int k = 0; k < na; k++) {
+    const int orow = d->act[perm[k]];
+    const DNode& q = N[node_of[k]];
+    const int li = k - q.own_off;
+    for (int e = rp[orow]; e < rp[orow + 1]; e++) {
+      const int pj0 = cl[e] < n ? posn[cl[e]] : -1;
+      if (pj0 < 0) continue;
+      const int pj = inv[pj0];
+      if (node_of[pj] == node_of[k]) {
+        src.push_back(e);
+        dst.push_back((long long)(q.D_off + (size_t)li * q.s + (pj - q.own_off)));
+      } else if (pj > k) {
+        const auto it = std::lower_bound(q.bnd.begin(), q.bnd.end(), pj);
+        FH_REQUIRE(it != q.bnd.end() && *it == pj, "fh_direct: an entry of the operator falls outside its front (unsymmetric pattern?)");
+        src.push_back(e);
+        dst.push_back((long long)(q.E_off + (size_t)li * q.b + (it - q.bnd.begin())) | (1ll << 62));
+      }
+    }
+  }
+  d->nmap = src.size();
+  // integer tables: boundary lists, child maps, node lists per height ; gather tables of the up sweep
+  std::vector<int> ints(bo, 0);
+  for (int t = 0; t < nn; t++) std::copy(N[t].bnd.begin(), N[t].bnd.end(), ints.begin() + N[t].bidx_off);
+  std::vector<size_t> cmap_off(nn, 0);
+  for (int t = 0; t < nn; t++) {
+    if (N[t].parent < 0) continue;
+    const DNode& p = N[N[t].parent];
+    cmap_off[t] = ints.size();
+    for (int v : N[t].bnd) {
+      int pos;
+      if (v >= p.own_off && v < p.own_off + p.s) pos = v - p.own_off;
+      else {
+        const auto it = std::lower_bound(p.bnd.begin(), p.bnd.end(), v);
+        FH_REQUIRE(it != p.bnd.end() && *it == v, "fh_direct: a child's boundary unknown is missing in its parent's front");
+        pos = p.s + (int)(it - p.bnd.begin());
+      }
+      ints.push_back(pos);
+    }
+  }
+  d->h_list_off.assign(d->max_height + 2, 0);
+  d->list_base = ints.size();
+  for (int h = 0; h <= d->max_height; h++) {
+    d->h_list_off[h] = (int)(ints.size() - d->list_base);
+    for (int t : d->by_height[h]) ints.push_back(t);
+  }
+  d->h_list_off[d->max_height + 1] = (int)(ints.size() - d->list_base);
+  std::vector<long long> gat;
+  std::vector<size_t> gat_off[2] = {std::vector<size_t>(nn, (size_t)-1), std::vector<size_t>(nn, (size_t)-1)};
+  for (int t = 0; t < nn; t++)
+    for (int w = 0; w < 2; w++) {
+      const int ch = N[t].child[w];
+      if (ch < 0 || N[ch].b == 0) continue;
+      gat_off[w][t] = gat.size();
+      gat.resize(gat.size() + (size_t)N[t].s + N[t].b, -1);
+      for (int k = 0; k < N[ch].b; k++) gat[gat_off[w][t] + ints[cmap_off[ch] + k]] = (long long)(N[ch].y_off + N[ch].s + k);
+    }
+  // ---- device ----
+  auto up = [&](void** dp, const void* h, size_t bytes) -> int {
+    FH_CHECK_HIP(hipMalloc(dp, bytes ? bytes : 8));
+    if (bytes) FH_CHECK_HIP(hipMemcpy(*dp, h, bytes, hipMemcpyHostToDevice));
+    return 0;
+  };
+  std::vector<int> p2o(n);
+  for (int k = 0; k < na; k++) p2o[k] = d->act[perm[k]];
+  for (int k = na; k < n; k++) p2o[k] = d->act[k];
+  FH_TRY(up((void**)&d->d_p2o, p2o.data(), p2o.size() * sizeof(int)));
+  FH_TRY(up((void**)&d->d_asm_src, src.data(), src.size() * sizeof(int)));
+  FH_TRY(up((void**)&d->d_asm_dst, dst.data(), dst.size() * sizeof(long long)));
+  FH_TRY(up((void**)&d->d_int, ints.data(), ints.size() * sizeof(int)));
+  FH_TRY(up((void**)&d->d_gat, gat.data(), gat.size() * sizeof(long long)));
+  FH_CHECK_HIP(hipMalloc(&d->d_fac, std::max<size_t>(fac, 1) * sizeof(double)));
+  FH_CHECK_HIP(hipMalloc(&d->d_tmp, std::max<size_t>(tmp, 1) * sizeof(double)));
+  FH_CHECK_HIP(hipMalloc(&d->d_y, std::max<size_t>(yo, 1) * sizeof(double)));
+  for (double** p : {&d->d_bp, &d->d_zp, &d->d_xp}) FH_CHECK_HIP(hipMalloc(p, std::max<size_t>(na, 1) * sizeof(double)));
+  FH_CHECK_HIP(hipMalloc(&d->d_dinv_rest, std::max<size_t>(n - na, 1) * sizeof(double)));
+  // descriptors per height
+  const int H = d->max_height + 1;
+  std::vector<InvDesc> hinv;
+  std::vector<GemmDesc> hg;
+  std::vector<EaDesc> hea;
+  std::vector<SolveNode> hs(nn);
+  d->inv_off.assign(H, 0); d->inv_cnt.assign(H, 0); d->inv_nmax.assign(H, 0);
+  d->gemm1_off.assign(H, 0); d->gemm2_off.assign(H, 0); d->gemm_cnt.assign(H, 0); d->gemm_maxM1.assign(H, 0); d->gemm_maxN.assign(H, 0); d->gemm_maxM2.assign(H, 0);
+  d->max_sb.assign(H, 0); d->max_s.assign(H, 0); d->max_b.assign(H, 0);
+  for (int w = 0; w < 2; w++) { d->ea_off[w].assign(H, 0); d->ea_cnt[w].assign(H, 0); d->ea_maxb[w].assign(H, 0); }
+  size_t work = 0;
+  for (int h = 0; h < H; h++) {
+    size_t wh = 0;
+    for (int t : d->by_height[h])
+      if (N[t].s > 0) wh += fh_inv_work_doubles(N[t].s);
+    work = std::max(work, wh);
+  }
+  d->work_doubles = work;
+  FH_CHECK_HIP(hipMalloc(&d->d_work, std::max<size_t>(work, 1) * sizeof(double)));
+  int* flags = d->d_flags;
+  for (int h = 0; h < H; h++) {
+    d->inv_off[h] = hinv.size();
+    size_t wo = 0;
+    for (int t : d->by_height[h]) {
+      const DNode& q = N[t];
+      d->max_sb[h] = std::max(d->max_sb[h], q.s + q.b);
+      d->max_s[h] = std::max(d->max_s[h], q.s);
+      d->max_b[h] = std::max(d->max_b[h], q.b);
+      if (q.s == 0) continue;
+      double* w = d->d_work + wo;
+      wo += fh_inv_work_doubles(q.s);
+      hinv.push_back(InvDesc{d->d_fac + q.D_off, q.s, w, w + (size_t)q.s * 128, w + (size_t)2 * q.s * 128, w + (size_t)2 * q.s * 128 + 2 * 128 * 128, flags + 2, 0});
+      d->inv_nmax[h] = std::max(d->inv_nmax[h], q.s);
+    }
+    d->inv_cnt[h] = (int)(hinv.size() - d->inv_off[h]);
+  }
+  for (int h = 0; h < H; h++) {            // W = D^-1 E  (D symmetric: P = D)
+    d->gemm1_off[h] = hg.size();
+    for (int t : d->by_height[h]) {
+      const DNode& q = N[t];
+      if (q.s == 0 || q.b == 0) continue;
+      hg.push_back(GemmDesc{d->d_fac + q.D_off, d->d_tmp + q.E_off, d->d_fac + q.W_off, q.s, q.b, q.s, q.s, q.b, q.b, 1.0, 0});
+      d->gemm_maxM1[h] = std::max(d->gemm_maxM1[h], q.s);
+      d->gemm_maxN[h] = std::max(d->gemm_maxN[h], q.b);
+    }
+    d->gemm_cnt[h] = (int)(hg.size() - d->gemm1_off[h]);
+  }
+  for (int h = 0; h < H; h++) {            // U -= E^T W
+    d->gemm2_off[h] = hg.size();
+    for (int t : d->by_height[h]) {
+      const DNode& q = N[t];
+      if (q.s == 0 || q.b == 0) continue;
+      hg.push_back(GemmDesc{d->d_tmp + q.E_off, d->d_fac + q.W_off, d->d_tmp + q.U_off, q.b, q.b, q.s, q.b, q.b, q.b, -1.0, 1});
+      d->gemm_maxM2[h] = std::max(d->gemm_maxM2[h], q.b);
+    }
+  }
+  for (int w = 0; w < 2; w++)
+    for (int h = 0; h < H; h++) {
+      d->ea_off[w][h] = hea.size();
+      for (int t : d->by_height[h]) {
+        const int ch = N[t].child[w];
+        if (ch < 0 || N[ch].b == 0) continue;
+        const DNode& q = N[t];
+        hea.push_back(EaDesc{d->d_tmp + N[ch].U_off, N[ch].b, d->d_int + cmap_off[ch], d->d_fac + q.D_off, d->d_tmp + q.E_off, d->d_tmp + q.U_off, q.s, q.b});
+        d->ea_maxb[w][h] = std::max(d->ea_maxb[w][h], N[ch].b);
+      }
+      d->ea_cnt[w][h] = (int)(hea.size() - d->ea_off[w][h]);
+    }
+  for (int t = 0; t < nn; t++) {
+    const DNode& q = N[t];
+    hs[t] = SolveNode{d->d_fac + q.D_off, d->d_fac + q.W_off, q.s, q.b, q.own_off, (long long)q.y_off, d->d_int + q.bidx_off,
+                      {gat_off[0][t] == (size_t)-1 ? nullptr : d->d_gat + gat_off[0][t], gat_off[1][t] == (size_t)-1 ? nullptr : d->d_gat + gat_off[1][t]}};
+  }
+  FH_TRY(up(&d->d_inv, hinv.data(), hinv.size() * sizeof(InvDesc)));
+  FH_TRY(up(&d->d_gemm, hg.data(), hg.size() * sizeof(GemmDesc)));
+  FH_TRY(up(&d->d_ea, hea.data(), hea.size() * sizeof(EaDesc)));
+  FH_TRY(up(&d->d_snodes, hs.data(), hs.size() * sizeof(SolveNode)));
+  FH_TRACE("fh_direct: %d coupled unknowns (%d decoupled), %d fronts, height %d, largest front %d, factor %.1f MB + %.1f MB transient", na, n - na, nn,
+           d->max_height, d->largest_front, fac * 8e-6, tmp * 8e-6);
+  return 0;
+}
+
+extern "C" int fh_direct_factor(fh_direct_t d) {
+  FH_GUARD_BEGIN
+  FH_REQUIRE(d, "fh_direct_factor: null argument");
+  fh_ctx_t c = d->ctx;
+  fh_mat_t A = d->A;
+  const int n = d->n;
+  d->factored = false;
+  if (n == 0) { d->factored = true; return 0; }
+  // coupled unknowns and the symmetry test, one host round trip
+  FH_CHECK_HIP(hipMemsetAsync(d->d_hit, 0, ((size_t)2 * n + 2) * sizeof(int), c->stream));
+  hipLaunchKernelGGL(k_dd_coupling, dim3(fh_div_up(n, 4)), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_val, n, d->d_hit, d->d_hit + n);
+  hipLaunchKernelGGL(k_dd_symmetry, dim3(fh_div_up(n, 4)), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_val, n, 1e-12, d->d_hit + 2 * n);
+  FH_CHECK_HIP(hipGetLastError());
+  std::vector<int> hit((size_t)2 * n + 2);
+  FH_CHECK_HIP(hipMemcpyAsync(hit.data(), d->d_hit, hit.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  FH_REQUIRE(hit[(size_t)2 * n] == 0, "fh_direct_factor: the operator is not symmetric (the sparse exact solve serves symmetric operators)");
+  std::vector<int> act, rest;
+  for (int i = 0; i < n; i++) (hit[i] == 0 && hit[n + i] == 0 ? rest : act).push_back(i);
+  const int na = (int)act.size();
+  act.insert(act.end(), rest.begin(), rest.end());
+  if (act != d->act || d->A_uid != A->uid || !d->d_p2o) {
+    d->act = act;
+    d->na = na;
+    d->A_uid = A->uid;
+    FH_TRY(direct_symbolic(d));
+  }
+  std::vector<DNode>& N = d->nodes;
+  FH_CHECK_HIP(hipMemsetAsync(d->d_flags, 0, 8 * sizeof(int), c->stream));
+  if (n > na) {
+    hipLaunchKernelGGL(k_dd_diag_rest, dim3(fh_div_up(n - na, 256)), dim3(256), 0, c->stream, n - na, d->d_p2o + na, A->d_rowptr, A->d_col, A->d_val, d->d_dinv_rest,
+                       d->d_flags);
+  }
+  const int fgrid = c->num_cu * 8;
+  hipLaunchKernelGGL(k_dd_fill, dim3(fgrid), dim3(256), 0, c->stream, d->d_fac, d->fac_doubles, 0.0);
+  hipLaunchKernelGGL(k_dd_fill, dim3(fgrid), dim3(256), 0, c->stream, d->d_tmp, d->tmp_doubles, 0.0);
+  if (d->nmap)
+    hipLaunchKernelGGL(k_dd_assemble, dim3((unsigned)((d->nmap + 255) / 256)), dim3(256), 0, c->stream, d->nmap, d->d_asm_src, d->d_asm_dst, A->d_val, d->d_fac, d->d_tmp);
+  FH_CHECK_HIP(hipGetLastError());
+  const InvDesc* inv = static_cast<const InvDesc*>(d->d_inv);
+  const GemmDesc* gm = static_cast<const GemmDesc*>(d->d_gemm);
+  const EaDesc* ea = static_cast<const EaDesc*>(d->d_ea);
+  for (int h = 0; h <= d->max_height; h++) {
+    for (int w = 0; w < 2; w++)          // children's updates, child 0 first (fixed order of the sums)
+      if (d->ea_cnt[w][h]) {
+        const int g = fh_div_up(d->ea_maxb[w][h], 16);
+        for (int z0 = 0; z0 < d->ea_cnt[w][h]; z0 += 32768)
+          hipLaunchKernelGGL(k_dd_extend_add, dim3(g, g, std::min(32768, d->ea_cnt[w][h] - z0)), dim3(256), 0, c->stream, ea + d->ea_off[w][h] + z0);
+      }
+    if (d->inv_cnt[h]) FH_TRY(fh_inv_sym_batched(c, inv + d->inv_off[h], d->inv_cnt[h], d->inv_nmax[h]));
+    if (d->gemm_cnt[h]) {
+      for (int z0 = 0; z0 < d->gemm_cnt[h]; z0 += 32768) {
+        const int kz = std::min(32768, d->gemm_cnt[h] - z0);
+        hipLaunchKernelGGL(k_dd_gemm_tn, dim3(fh_div_up(d->gemm_maxN[h], 64), fh_div_up(d->gemm_maxM1[h], 64), kz), dim3(256), 0, c->stream, gm + d->gemm1_off[h] + z0);
+        const int g2 = fh_div_up(d->gemm_maxM2[h], 64);
+        hipLaunchKernelGGL(k_dd_gemm_tn, dim3(g2, g2, kz), dim3(256), 0, c->stream, gm + d->gemm2_off[h] + z0);
+        hipLaunchKernelGGL(k_dd_mirror_diag, dim3(g2, 1, kz), dim3(256), 0, c->stream, gm + d->gemm2_off[h] + z0);
+        hipLaunchKernelGGL(k_dd_mirror, dim3(g2, g2, kz), dim3(256), 0, c->stream, gm + d->gemm2_off[h] + z0);
+      }
+    }
+    FH_CHECK_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_dd_check, dim3(fgrid), dim3(256), 0, c->stream, d->d_fac, d->fac_doubles, d->d_flags + 1);
+  FH_CHECK_HIP(hipGetLastError());
+  int hf[8];
+  FH_CHECK_HIP(hipMemcpyAsync(hf, d->d_flags, sizeof(hf), hipMemcpyDeviceToHost, c->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  FH_REQUIRE(hf[0] == 0, "fh_direct_factor: a decoupled unknown has a zero diagonal entry (singular operator)");
+  FH_REQUIRE(hf[3] == 0 && hf[1] == 0, "fh_direct_factor: a front has no usable pivot without pivoting across fronts (singular or indefinite operator)");
+  d->factored = true;
+  (void)N;
+  return 0;
+  FH_GUARD_END("fh_direct_factor")
+}
+
+// x = A^-1 b on raw device pointers (fixed launch sequence: capturable)
+int fh_direct_solve_ptr(fh_direct_t d, const double* b, double* x) {
+  FH_REQUIRE(d && d->factored, "fh_direct_solve: fh_direct_factor has not succeeded");
+  fh_ctx_t c = d->ctx;
+  const int n = d->n, na = d->na;
+  if (n == 0) return 0;
+  const SolveNode* sn = static_cast<const SolveNode*>(d->d_snodes);
+  const int* lists = d->d_int + d->list_base;
+  if (na) hipLaunchKernelGGL(k_dd_gather, dim3(fh_div_up(na, 256)), dim3(256), 0, c->stream, na, d->d_p2o, b, d->d_bp);
+  for (int h = 0; h <= d->max_height && na; h++) {
+    const int cnt = d->h_list_off[h + 1] - d->h_list_off[h];
+    if (!cnt || !d->max_sb[h]) continue;
+    const int* list = lists + d->h_list_off[h];
+    hipLaunchKernelGGL(k_dd_up_assemble, dim3(fh_div_up(d->max_sb[h], 256), cnt), dim3(256), 0, c->stream, sn, list, d->d_bp, d->d_y);
+    hipLaunchKernelGGL(k_dd_up_apply, dim3(fh_div_up(d->max_s[h], 4) + fh_div_up(d->max_b[h], 64), cnt), dim3(256), 0, c->stream, sn, list, d->d_y, d->d_zp);
+  }
+  for (int h = d->max_height; h >= 0 && na; h--) {
+    const int cnt = d->h_list_off[h + 1] - d->h_list_off[h];
+    if (!cnt || !d->max_s[h]) continue;
+    hipLaunchKernelGGL(k_dd_down, dim3(fh_div_up(d->max_s[h], 4), cnt), dim3(256), 0, c->stream, sn, lists + d->h_list_off[h], d->d_zp, d->d_xp);
+  }
+  hipLaunchKernelGGL(k_dd_scatter, dim3(fh_div_up(n, 256)), dim3(256), 0, c->stream, n, na, d->d_p2o, d->d_xp, b, d->d_dinv_rest, x);
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int fh_direct_solve(fh_direct_t d, fh_vec_t b, fh_vec_t x) {
+  FH_REQUIRE(d && b && x && b->n_local >= d->n && x->n_local >= d->n, "fh_direct_solve: vectors too short");
+  FH_REQUIRE(b->d != x->d, "fh_direct_solve: b and x must be different vectors");
+  return fh_direct_solve_ptr(d, b->d, x->d);
+}
+
+extern "C" int fh_direct_info(fh_direct_t d, int* coupled, int* fronts, int* height, int* largest_front, int64_t* factor_doubles) {
+  FH_REQUIRE(d, "fh_direct_info: null argument");
+  if (coupled) *coupled = d->na;
+  if (fronts) *fronts = d->n_fronts;
+  if (height) *height = d->max_height;
+  if (largest_front) *largest_front = d->largest_front;
+  if (factor_doubles) *factor_doubles = (int64_t)d->fac_doubles;
+  return 0;
+}

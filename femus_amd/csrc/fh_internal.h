@@ -173,6 +173,17 @@ struct fh_mat_s {
   void (*plan_destroy)(void*) = nullptr;
 };
 
+// descriptor of one dense symmetric matrix of the batched 128-block inverse (fh_mg.hip: k_inv_*_b; fh_inv_sym_batched)
+struct InvDesc {
+  double* D;             // n x n, leading dimension n; replaced by its inverse
+  int n;
+  double *PT, *RT, *Dv0, *Dv1;   // work: panels 2 x (n x 128), pivot-block inverses 2 x 2 x 128 x 128 (fh_inv_work_doubles(n) doubles from PT)
+  int* flg;              // two ints; flg[1] != 0: a pivot block had no usable diagonal pivot
+  int off;               // first unknown of the block in the dissected ordering (k_nd_w)
+};
+size_t fh_inv_work_doubles(int n);
+int fh_inv_sym_batched(fh_ctx_t c, const InvDesc* d_desc, int k, int nmax);
+
 // kernels / helpers implemented across TUs
 int fh_reserve_reduction(fh_ctx_t ctx, size_t ndoubles);
 int fh_mat_build_rowblocks(fh_mat_t A, int tile);

@@ -1122,13 +1122,7 @@ __device__ __forceinline__ void inv_panel_body(double* __restrict__ D, const dou
 
 // one dense matrix per launch (k_inv_panel / k_inv_update) or several beside each other (k_inv_panel_b / k_inv_update_b: blockIdx.z names the
 // matrix, the grid is sized for the largest; the dissected coarse solve inverts its interior blocks this way)
-struct InvDesc {
-  double* D;
-  int n;
-  double *PT, *RT, *Dv0, *Dv1;
-  int* flg;
-  int off;               // first unknown of the block in the dissected ordering (k_nd_w)
-};
+// (InvDesc: fh_internal.h)
 
 __global__ __launch_bounds__(256) void k_inv_panel(double* __restrict__ D, const double* __restrict__ Dinv, double* __restrict__ PT, double* __restrict__ RT,
                                                    int n, int kb, int nb) {
@@ -2050,6 +2044,31 @@ static int invert_sym128(fh_ctx_t c, hipStream_t st, double* D, int n, double* w
     hipLaunchKernelGGL(k_inv_update, dim3(ntb, ntb), dim3(256), upd_lds, st, D, PT, RT, n, kb, nb, Dv[(step + 1) & 1], flg + 1);
   }
   hipLaunchKernelGGL(k_gjs_finish, dim3(nt, nt), dim3(256), 0, st, D, n);
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// the batched form for other translation units (fh_direct.hip): k dense symmetric matrices (descriptors on the device) inverted beside each other
+// on the compute stream, nmax = the largest order; work per matrix: fh_inv_work_doubles(n), two flag ints per matrix (flag[1] != 0: no usable pivot)
+size_t fh_inv_work_doubles(int n) { return inv128_work_doubles(n); }
+int fh_inv_sym_batched(fh_ctx_t c, const InvDesc* desc, int k, int nmax) {
+  if (k <= 0 || nmax <= 0) return 0;
+  constexpr size_t upd_lds = (size_t)4 * IKC * ILD * sizeof(double);
+  static bool attr_set[64] = {};
+  if (!attr_set[c->device & 63]) {
+    FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inv_update_b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_lds));
+    attr_set[c->device & 63] = true;
+  }
+  const int ntb = fh_div_up(nmax, IB), nt64 = fh_div_up(nmax, 64);
+  for (int z0 = 0; z0 < k; z0 += 32768) {          // gridDim.z <= 65535
+    const int kz = std::min(k - z0, 32768);
+    hipLaunchKernelGGL(k_inv_first_b, dim3(kz), dim3(256), 0, c->stream, desc + z0);
+    for (int kb = 0, step = 0; kb < nmax; kb += IB, step++) {
+      hipLaunchKernelGGL(k_inv_panel_b, dim3(fh_div_up(nmax, IPN), 1, kz), dim3(256), 0, c->stream, desc + z0, kb, step & 1);
+      hipLaunchKernelGGL(k_inv_update_b, dim3(ntb, ntb, kz), dim3(256), upd_lds, c->stream, desc + z0, kb, step & 1);
+    }
+    hipLaunchKernelGGL(k_gjs_finish_b, dim3(nt64, nt64, kz), dim3(256), 0, c->stream, desc + z0);
+  }
   FH_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -383,6 +383,18 @@ int fh_mg_set_level_patches(fh_mg_t mg, int level, int npatch, const int* ptr /*
  *                      level solver and the one 003_NavierStokes selects), classical Gram-Schmidt, restart `restart` (FEMuS: 30) */
 enum { FH_LEVEL_RICHARDSON = 0, FH_LEVEL_GMRES = 1 };
 int fh_mg_set_level_solver(fh_mg_t mg, int level, int solver, int restart);
+/* Sparse exact solve (the reference's MUMPS / PCLU through PETSc: coarsest level LinearEquationSolverPetsc.hpp:131-138, `Solve(vars, ksp_clean)`,
+ * MLU_PRECOND / LU_PRECOND as level preconditioner PetscPreconditioner.cpp:147-160): multifrontal factorisation over a nested-dissection tree
+ * (fh_direct.hip), SYMMETRIC operators of any size.  coords ([n * dim], dim 1..3) let the dissection cut at coordinate layers (for Q2 unknowns:
+ * planes of nodes at element boundaries); dim = 0 / coords = NULL: breadth-first level sets of the matrix graph.  leaf <= 0: 256 unknowns per
+ * leaf.  fh_direct_factor reads the CURRENT values of A (symbolic work is redone only when the set of coupled unknowns or the matrix changed);
+ * unknowns coupled to nothing (penalised Dirichlet rows) are solved by their diagonal.  fh_direct_solve: x = A^-1 b (b != x). */
+typedef struct fh_direct_s* fh_direct_t;
+int fh_direct_create(fh_ctx_t ctx, fh_mat_t A, int dim, const double* coords, int leaf, fh_direct_t* out);
+int fh_direct_factor(fh_direct_t d);
+int fh_direct_solve(fh_direct_t d, fh_vec_t b, fh_vec_t x);
+int fh_direct_info(fh_direct_t d, int* coupled, int* fronts, int* height, int* largest_front, int64_t* factor_doubles);
+int fh_direct_destroy(fh_direct_t d);
 /* PCMGSetType (`MgSmootherType` of MGInit, LinearEquationSolverPetsc.cpp:199-214), one application of the preconditioner to b:
  * FH_CYCLE_MULTIPLICATIVE  V-cycle: pre-smooth, restrict the residual, recurse, interpolate-add, post-smooth (default)
  * FH_CYCLE_FULL            b restricted through all levels; coarsest solve; per level: x = P x_coarse as the guess, then one multiplicative cycle from there
