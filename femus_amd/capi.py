@@ -12,7 +12,7 @@ FE = {"linear": 0, "biquadratic": 2}
 GAUSS_ORDER = {"zero": 0, "first": 0, "second": 1, "third": 1, "fourth": 2, "fifth": 2,
                "sixth": 3, "seventh": 3, "eighth": 4, "ninth": 4}
 OUTER = {"preonly": 0, "richardson": 1, "gmres": 2, "cg": 3, "fgmres": 4}
-SMOOTH_JACOBI, SMOOTH_GS_COLOR, SMOOTH_VANKA, SMOOTH_SOR, SMOOTH_ILU0, SMOOTH_IDENTITY = 0, 1, 2, 3, 4, 5
+SMOOTH_JACOBI, SMOOTH_GS_COLOR, SMOOTH_VANKA, SMOOTH_SOR, SMOOTH_ILU0, SMOOTH_IDENTITY, SMOOTH_LU = 0, 1, 2, 3, 4, 5, 6
 
 
 class FemusHipError(RuntimeError):
@@ -979,6 +979,12 @@ class Multigrid:
         xy = _f64(coords)
         _chk(self.L.fh_mg_set_coarse_coords(self.h, xy.shape[1], xy.shape[0], _p(xy)))
 
+
+    def set_level_coords(self, level, coords):
+        """coordinates of the unknowns of a level whose preconditioner is the exact solve (SMOOTH_LU); level 0 = set_coarse_coords"""
+        xy = _f64(np.ascontiguousarray(coords))
+        dim = xy.shape[1] if xy.ndim == 2 else 1
+        _chk(self.L.fh_mg_set_level_coords(self.h, int(level), int(dim), xy.shape[0], _p(xy)))
     def setup(self):
         _chk(self.L.fh_mg_setup(self.h))
 

@@ -642,8 +642,9 @@ void LinearEquationSolverHip::MGSetLevel(LinearEquationSolver* LinSolver, const 
   }
   const int smoother = smoother_id();
   if (_level != 0 && smoother != FH_SMOOTH_VANKA && _preconditioner_type != JACOBI_PRECOND && _preconditioner_type != SOR_PRECOND &&
-      _preconditioner_type != ILU_PRECOND && _preconditioner_type != IDENTITY_PRECOND) {
-    std::cout << "HIP backend: level preconditioner must be JACOBI_PRECOND, SOR_PRECOND, ILU_PRECOND or IDENTITY_PRECOND (or the FEMuS_ASM solver)" << std::endl;
+      _preconditioner_type != ILU_PRECOND && _preconditioner_type != IDENTITY_PRECOND && _preconditioner_type != LU_PRECOND &&
+      _preconditioner_type != MLU_PRECOND) {
+    std::cout << "HIP backend: level preconditioner must be JACOBI_PRECOND, SOR_PRECOND, ILU_PRECOND, LU_PRECOND / MLU_PRECOND or IDENTITY_PRECOND (or the FEMuS_ASM solver)" << std::endl;
     abort();
   }
   if (_level != 0 && _levelSolverType != RICHARDSON && _levelSolverType != GMRES) {     // GMRES is the reference's default level solver
@@ -656,8 +657,8 @@ void LinearEquationSolverHip::MGSetLevel(LinearEquationSolver* LinSolver, const 
   hip_check(fh_mg_set_level(top->_mg, (int)_level, static_cast<HipMatrix*>(_KK)->handle(), _level ? P : nullptr, _level ? R : nullptr,
                             smoother, _richardsonScaleFactor, (int)npre, (int)npost),
             "MGSetLevel");
-  if (_level == 0 && _coordDim > 0 && !_coords.empty())
-    hip_check(fh_mg_set_coarse_coords(top->_mg, _coordDim, (int)(_coords.size() / (size_t)_coordDim), _coords.data()), "MGSetLevel: coordinates of the coarsest level");
+  if (_coordDim > 0 && !_coords.empty() && (_level == 0 || smoother == FH_SMOOTH_LU))     // the exact solves cut their dissection at coordinate layers
+    hip_check(fh_mg_set_level_coords(top->_mg, (int)_level, _coordDim, (int)(_coords.size() / (size_t)_coordDim), _coords.data()), "MGSetLevel: coordinates of the level");
   if (_level != 0)      // KSPGMRES with KSPGMRESSetRestart(_restart) and npre / npost iterations, or KSPRICHARDSON (LinearEquationSolverPetsc.cpp:238-250, 501-519)
     hip_check(fh_mg_set_level_solver(top->_mg, (int)_level, _levelSolverType == GMRES ? FH_LEVEL_GMRES : FH_LEVEL_RICHARDSON, _restart > 0 ? _restart : 30),
               "MGSetLevel: level solver");
@@ -668,6 +669,7 @@ int LinearEquationSolverHip::smoother_id() const {
   if (_preconditioner_type == SOR_PRECOND) return _multicolourSor ? FH_SMOOTH_GS_COLOR : FH_SMOOTH_SOR;
   if (_preconditioner_type == ILU_PRECOND) return FH_SMOOTH_ILU0;
   if (_preconditioner_type == IDENTITY_PRECOND) return FH_SMOOTH_IDENTITY;
+  if (_preconditioner_type == LU_PRECOND || _preconditioner_type == MLU_PRECOND) return FH_SMOOTH_LU;      // PCLU (MUMPS), PetscPreconditioner.cpp:147-160
   return FH_SMOOTH_JACOBI;
 }
 void LinearEquationSolverHipAsm::attach_smoother_data(fh_mg_t mg, int level, const std::vector<unsigned>& variable_to_be_solved) {
@@ -706,9 +708,11 @@ void LinearEquationSolverHip::Solve(const std::vector<unsigned>& variable_to_be_
     SetPenalty();
     KK = static_cast<HipMatrix*>(_KK)->handle();
     // a one-level hierarchy: the "cycle" is the exact solve of this level (what the reference reaches with its default
-    // GMRES + ILU/MLU level solver at convergence); levels beyond the dense limit belong to the multigrid path
+    // GMRES + ILU/MLU level solver at convergence): the sparse exact solve for symmetric operators of any size, the dense inverse otherwise
     hip_check(fh_mg_create(hip_context(), 1, &_one), "Solve");
     hip_check(fh_mg_set_level(_one, 0, KK, nullptr, nullptr, FH_SMOOTH_JACOBI, 1.0, 1, 0), "Solve");
+    if (_coordDim > 0 && !_coords.empty())
+      hip_check(fh_mg_set_coarse_coords(_one, _coordDim, (int)(_coords.size() / (size_t)_coordDim), _coords.data()), "Solve: coordinates of the level");
     hip_check(fh_mg_setup(_one), "Solve: factorisation of the level operator");
   }
   ZerosBoundaryResiduals();

@@ -238,6 +238,8 @@ extern "C" int fh_set_option(fh_ctx_t c, const char* name, double value) {
   else if (!strcmp(name, "coarse_reduce")) c->coarse_reduce = (int)value;
   else if (!strcmp(name, "coarse_nd")) c->coarse_nd = (int)value;
   else if (!strcmp(name, "coarse_nd_min")) c->coarse_nd_min = (int)value;
+  else if (!strcmp(name, "coarse_direct")) c->coarse_direct = (int)value;
+  else if (!strcmp(name, "coarse_direct_min")) c->coarse_direct_min = (int)value;
   else if (!strcmp(name, "coarse_nd_streams")) c->coarse_nd_streams = (int)value;
   else if (!strcmp(name, "patch_invert_lds")) c->patch_invert_lds = (int)value;
   else if (!strcmp(name, "gj_mfma")) c->gj_mfma = (int)value;

@@ -17,9 +17,11 @@
 //   solve (device, graph-capturable: fixed launch sequence and buffers), front vectors y_t = [r_t ; u_t] flow up the tree as the matrices did
 //     up:    y_t = [b[S_t] ; 0] + children's u (gather, fixed order: deterministic) ; z_t = D_t^-1 r_t ; u_t -= W_t^T r_t
 //     down:  x[S_t] = z_t - W_t x[B_t]
-// Unknowns coupled to nothing (Dirichlet rows of a penalised operator) are solved by their diagonal, as the dense path does.
-// Symmetric operators only (entry-by-entry test on the sparse form); no pivoting across fronts, a front whose own block has no usable
-// pivot fails the factorisation (the caller falls back or reports).
+// Unknowns whose ROW holds nothing but its diagonal entry (the Dirichlet rows SetPenalty leaves, LinearEquationSolverPetsc.cpp:428-436) are solved
+// first, x_d = b_d / a_dd, and their columns move to the right-hand side of the others (b_c - A_cd x_d): the operator [A_cc A_cd; 0 D] needs
+// A_cc symmetric only, whether or not the Dirichlet columns were zeroed as well.
+// Symmetric A_cc only (entry-by-entry test on the sparse form); no pivoting across fronts, a front whose own block has no usable pivot fails
+// the factorisation (the caller falls back or reports).
 #include "fh_internal.h"
 #include <algorithm>
 #include <cmath>
@@ -195,32 +197,27 @@ static int build_tree(const Graph& G, const double* xyz, int dim, const std::vec
 
 // ---- device kernels -------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_dd_coupling(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val, int n,
-                                                     int* __restrict__ rowhit, int* __restrict__ colhit) {
+                                                     int* __restrict__ rowhit) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
   int hit = 0;
-  for (int k = rowptr[i] + lane; k < rowptr[i + 1]; k += 64) {
-    const int j = col[k];
-    if (j != i && j < n && val[k] != 0.0) {
-      hit = 1;
-      colhit[j] = 1;          // benign race: every writer stores 1
-    }
-  }
+  for (int k = rowptr[i] + lane; k < rowptr[i + 1]; k += 64) hit |= (col[k] != i && col[k] < n && val[k] != 0.0) ? 1 : 0;
   hit = __any(hit);
   if (lane == 0) rowhit[i] = hit;
 }
 
+// symmetry of the coupled block: entries (i, j) with both rows coupled
 __global__ __launch_bounds__(256) void k_dd_symmetry(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val, int n, double tol,
-                                                     int* __restrict__ flag) {
+                                                     const int* __restrict__ rowhit, int* __restrict__ flag) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (i >= n) return;
+  if (i >= n || !rowhit[i]) return;
   double dmax = 0.0;
   for (int k = rowptr[i] + lane; k < rowptr[i + 1]; k += 64) dmax = fmax(dmax, fabs(val[k]));
   for (int d = 32; d >= 1; d >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, d, 64));
   int bad = 0;
   for (int k = rowptr[i] + lane; k < rowptr[i + 1]; k += 64) {
     const int j = col[k];
-    if (j >= n || j == i) continue;
+    if (j >= n || j == i || !rowhit[j]) continue;
     int lo = rowptr[j], hi = rowptr[j + 1] - 1;
     double t = 0.0;
     while (lo <= hi) {
@@ -348,17 +345,28 @@ struct SolveNode {
   const int* bidx;           // [b] boundary unknowns (permuted numbering)
   const long long* gat[2];   // [s + b] per child: offset into y of the child's entry that lands here, -1 = none
 };
-// right-hand side into the permuted numbering / solution back, the decoupled unknowns by their diagonal
-__global__ __launch_bounds__(256) void k_dd_gather(int na, const int* __restrict__ p2o, const double* __restrict__ b, double* __restrict__ bp) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k < na) bp[k] = b[p2o[k]];
+// right-hand side into the permuted numbering: b_c - A_cd (b_d / a_dd) (dinv = 1 / a_dd on the decoupled unknowns, 0 elsewhere) / solution back
+__global__ __launch_bounds__(256) void k_dd_gather(int na, const int* __restrict__ p2o, const double* __restrict__ b, const int* __restrict__ rowptr,
+                                                   const int* __restrict__ col, const double* __restrict__ val, const double* __restrict__ dinv, int n,
+                                                   double* __restrict__ bp) {
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (k >= na) return;
+  const int o = p2o[k];
+  double a = 0.0;
+  for (int e = rowptr[o] + lane; e < rowptr[o + 1]; e += 64) {
+    const int j = col[e];
+    const double dj = j < n ? dinv[j] : 0.0;
+    if (dj != 0.0) a += val[e] * (b[j] * dj);
+  }
+  for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+  if (lane == 0) bp[k] = b[o] - a;
 }
 __global__ __launch_bounds__(256) void k_dd_scatter(int n, int na, const int* __restrict__ p2o, const double* __restrict__ xp, const double* __restrict__ b,
-                                                    const double* __restrict__ dinv_rest, double* __restrict__ x) {
+                                                    const double* __restrict__ dinv, double* __restrict__ x) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= n) return;
   const int o = p2o[k];
-  x[o] = k < na ? xp[k] : b[o] * dinv_rest[k - na];
+  x[o] = k < na ? xp[k] : b[o] * dinv[o];
 }
 // up, step 1: y_t = [b[S_t] ; 0] + the children's u (child 0 first)
 __global__ __launch_bounds__(256) void k_dd_up_assemble(const SolveNode* __restrict__ nodes, const int* __restrict__ list, const double* __restrict__ bp,
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(256) void k_dd_fill(double* __restrict__ p, size_t 
   for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) p[k] = v;
 }
 __global__ __launch_bounds__(256) void k_dd_diag_rest(int nrest, const int* __restrict__ rest, const int* __restrict__ rowptr, const int* __restrict__ col,
-                                                      const double* __restrict__ val, double* __restrict__ dinv, int* __restrict__ flag) {
+                                                      const double* __restrict__ val, double* __restrict__ dinv /* [n], zeroed */, int* __restrict__ flag) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= nrest) return;
   const int i = rest[k];
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(256) void k_dd_diag_rest(int nrest, const int* __re
   for (int e = rowptr[i]; e < rowptr[i + 1]; e++)
     if (col[e] == i) d = val[e];
   if (d == 0.0) atomicExch(flag, 1);
-  dinv[k] = d != 0.0 ? 1.0 / d : 0.0;
+  dinv[i] = d != 0.0 ? 1.0 / d : 0.0;
 }
 __global__ __launch_bounds__(256) void k_dd_check(const double* __restrict__ p, size_t n, int* __restrict__ flag) {
   int bad = 0;
@@ -685,7 +693,7 @@ static int direct_symbolic(fh_direct_t d) {
   FH_CHECK_HIP(hipMalloc(&d->d_tmp, std::max<size_t>(tmp, 1) * sizeof(double)));
   FH_CHECK_HIP(hipMalloc(&d->d_y, std::max<size_t>(yo, 1) * sizeof(double)));
   for (double** p : {&d->d_bp, &d->d_zp, &d->d_xp}) FH_CHECK_HIP(hipMalloc(p, std::max<size_t>(na, 1) * sizeof(double)));
-  FH_CHECK_HIP(hipMalloc(&d->d_dinv_rest, std::max<size_t>(n - na, 1) * sizeof(double)));
+  FH_CHECK_HIP(hipMalloc(&d->d_dinv_rest, std::max<size_t>(n, 1) * sizeof(double)));        // [n]: 1 / a_dd on the decoupled unknowns, 0 elsewhere
   // descriptors per height
   const int H = d->max_height + 1;
   std::vector<InvDesc> hinv;
@@ -778,15 +786,15 @@ extern "C" int fh_direct_factor(fh_direct_t d) {
   if (n == 0) { d->factored = true; return 0; }
   // coupled unknowns and the symmetry test, one host round trip
   FH_CHECK_HIP(hipMemsetAsync(d->d_hit, 0, ((size_t)2 * n + 2) * sizeof(int), c->stream));
-  hipLaunchKernelGGL(k_dd_coupling, dim3(fh_div_up(n, 4)), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_val, n, d->d_hit, d->d_hit + n);
-  hipLaunchKernelGGL(k_dd_symmetry, dim3(fh_div_up(n, 4)), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_val, n, 1e-12, d->d_hit + 2 * n);
+  hipLaunchKernelGGL(k_dd_coupling, dim3(fh_div_up(n, 4)), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_val, n, d->d_hit);
+  hipLaunchKernelGGL(k_dd_symmetry, dim3(fh_div_up(n, 4)), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_val, n, 1e-12, d->d_hit, d->d_hit + 2 * n);
   FH_CHECK_HIP(hipGetLastError());
   std::vector<int> hit((size_t)2 * n + 2);
   FH_CHECK_HIP(hipMemcpyAsync(hit.data(), d->d_hit, hit.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
   FH_REQUIRE(hit[(size_t)2 * n] == 0, "fh_direct_factor: the operator is not symmetric (the sparse exact solve serves symmetric operators)");
   std::vector<int> act, rest;
-  for (int i = 0; i < n; i++) (hit[i] == 0 && hit[n + i] == 0 ? rest : act).push_back(i);
+  for (int i = 0; i < n; i++) (hit[i] == 0 ? rest : act).push_back(i);
   const int na = (int)act.size();
   act.insert(act.end(), rest.begin(), rest.end());
   if (act != d->act || d->A_uid != A->uid || !d->d_p2o) {
@@ -797,6 +805,7 @@ extern "C" int fh_direct_factor(fh_direct_t d) {
   }
   std::vector<DNode>& N = d->nodes;
   FH_CHECK_HIP(hipMemsetAsync(d->d_flags, 0, 8 * sizeof(int), c->stream));
+  FH_CHECK_HIP(hipMemsetAsync(d->d_dinv_rest, 0, (size_t)n * sizeof(double), c->stream));
   if (n > na) {
     hipLaunchKernelGGL(k_dd_diag_rest, dim3(fh_div_up(n - na, 256)), dim3(256), 0, c->stream, n - na, d->d_p2o + na, A->d_rowptr, A->d_col, A->d_val, d->d_dinv_rest,
                        d->d_flags);
@@ -851,7 +860,9 @@ int fh_direct_solve_ptr(fh_direct_t d, const double* b, double* x) {
   if (n == 0) return 0;
   const SolveNode* sn = static_cast<const SolveNode*>(d->d_snodes);
   const int* lists = d->d_int + d->list_base;
-  if (na) hipLaunchKernelGGL(k_dd_gather, dim3(fh_div_up(na, 256)), dim3(256), 0, c->stream, na, d->d_p2o, b, d->d_bp);
+  if (na)
+    hipLaunchKernelGGL(k_dd_gather, dim3(fh_div_up(na, 4)), dim3(256), 0, c->stream, na, d->d_p2o, b, d->A->d_rowptr, d->A->d_col, d->A->d_val, d->d_dinv_rest, n,
+                       d->d_bp);
   for (int h = 0; h <= d->max_height && na; h++) {
     const int cnt = d->h_list_off[h + 1] - d->h_list_off[h];
     if (!cnt || !d->max_sb[h]) continue;

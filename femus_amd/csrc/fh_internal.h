@@ -102,6 +102,8 @@ struct fh_ctx_s {
   int coarse_nd = 8;                 // coarsest level: interior blocks of the nested dissection of the coupled unknowns (block inverses beside each other + separator Schur complement); needs coordinates (fh_mg_set_coarse_coords) and a symmetric operator; 0 / 1: one dense inverse
   int coarse_nd_streams = 0;         // ... the block inverses: 0 = one launch per step for all blocks (block index as a grid dimension), 1 = one stream per block, 2 = one after the other (measurements)
   int coarse_nd_min = 1024;          // ... only from this many coupled unknowns on
+  int coarse_direct = 1;             // coarsest level: 1 = the sparse exact solve (fh_direct.hip) when more than coarse_direct_min unknowns are coupled, 2 = always, 0 = never (dense inverse, <= 16384)
+  int coarse_direct_min = 8192;
   int coarse_reduce = 1;             // coarsest level: unknowns coupled to nothing (Dirichlet rows) are solved by their diagonal, the dense inverse holds the rest
   int vanka_persistent = 0;          // block smoother: all colours of a sweep in one launch with device-wide barriers (1: arrival counter, 2: flag per
                                      // workgroup); measured 2.7x SLOWER than residual SpMV + patch kernel per colour, kept as an option

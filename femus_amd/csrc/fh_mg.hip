@@ -22,6 +22,7 @@ int fh_dev_get_diag(fh_mat_t A, double* d, int invert);
 int fh_halo_update_ptr(fh_halo_t h, double* vd, int n_owned);
 int fh_halo_end_ptr(fh_halo_t h);
 int fh_halo_allreduce_ptr(fh_halo_t h, double* d, int n);
+int fh_direct_solve_ptr(fh_direct_t d, const double* b, double* x);
 
 struct MgLevel {
   fh_mat_t A = nullptr, P = nullptr, R = nullptr;
@@ -52,6 +53,11 @@ struct MgLevel {
   int ncols = 0;
   int buf_n = -1;            // size the work vectors were allocated for (kept across preparations)
   double* buf_base = nullptr;   // dinv, x, x2, b, r: one allocation
+  // FH_SMOOTH_LU: B = A^-1 by the sparse exact solve (fh_direct.hip); coordinates of the level's unknowns let it cut at coordinate layers
+  fh_direct_t direct = nullptr;
+  uint64_t direct_uid = 0;
+  std::vector<double> xyz;
+  int xyz_dim = 0;
   // level solver: 0 = Richardson(omega) around the sweep preconditioner, 1 = GMRES (fixed iteration count, left-preconditioned)
   int solver = 0, gm_restart = 30, gm_m = 0;
   double* gm_buf = nullptr;  // (gm_m + 1) basis vectors of ncols + 2 entries
@@ -82,6 +88,9 @@ struct fh_mg_s {
   int nd_key = -1, coords_version = 0;
   int cycle_type = 0;                 // FH_CYCLE_*: PCMGSetType
   bool capturable = true;             // no distributed level: the cycle is replayed from a captured graph
+  fh_direct_t direct0 = nullptr;      // sparse exact solve of level 0 (more coupled unknowns than the dense inverse holds, or option coarse_direct)
+  uint64_t direct0_uid = 0;
+  bool direct0_active = false;
   uint64_t nd_A_uid = 0;              // the level-0 matrix the dissection was computed on (another pattern may not be separated by the cached separator)
   bool nd_tables_valid = false;
   std::vector<int> nd_off;            // offsets of the blocks inside the coupled unknowns, nd_off[k] = first separator unknown, nd_off[k + 1] = na
@@ -1382,9 +1391,9 @@ extern "C" int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh
   FH_REQUIRE(A->m <= A->n, "fh_mg_set_level: operator must be square (or owned rows x local columns on a distributed level)");
   FH_REQUIRE(level == 0 || P != nullptr, "fh_mg_set_level: level %d needs an interpolation matrix", level);
   FH_REQUIRE(!P || P->m == A->m, "fh_mg_set_level: interpolation has %d rows, operator has %d", P ? P->m : 0, A->m);
-  FH_REQUIRE(smoother >= FH_SMOOTH_JACOBI && smoother <= FH_SMOOTH_IDENTITY,
+  FH_REQUIRE(smoother >= FH_SMOOTH_JACOBI && smoother <= FH_SMOOTH_LU,
              "fh_mg_set_level: unknown smoother %d (0 = Richardson+Jacobi, 1 = Richardson+multicolour SOR, 2 = block Schwarz / Vanka, "
-             "3 = Richardson+SOR in natural order, 4 = Richardson+ILU(0), 5 = no preconditioner)", smoother);
+             "3 = Richardson+SOR in natural order, 4 = Richardson+ILU(0), 5 = no preconditioner, 6 = exact solve)", smoother);
   FH_REQUIRE(npre >= 0 && npost >= 0, "fh_mg_set_level: negative sweep count");
   MgLevel& L = mg->lv[level];
   if (L.A_uid != A->uid) {   // another matrix (also one that landed on the address of a destroyed one): its graph may differ
@@ -1486,6 +1495,8 @@ static uint64_t cycle_signature(fh_mg_t mg) {
   if (mg->nd_active)
     for (int o : mg->nd_off) mix((uint64_t)o);          // another dissection of the same size keeps no captured pointer
   mix((uint64_t)mg->na);
+  mix((uint64_t)mg->direct0_active);
+  mixp(mg->direct0);
   mixp(mg->d_act);
   for (int l = 0; l < mg->nlevels; l++) {
     MgLevel& L = mg->lv[l];
@@ -2341,6 +2352,23 @@ static int coarse_factor(fh_mg_t mg) {
   }
   mg->na = n;
   if (n == 0) return 0;
+  // more coupled unknowns than the dense inverse is meant for (or asked for): the sparse exact solve -- symmetric operators; anything it refuses
+  // goes on to the dense path and its own limits
+  mg->direct0_active = false;
+  if (c->coarse_direct == 2 || (c->coarse_direct == 1 && n > c->coarse_direct_min)) {
+    if (!mg->direct0 || mg->direct0_uid != L0.A->uid) {
+      if (mg->direct0) fh_direct_destroy(mg->direct0);
+      mg->direct0 = nullptr;
+      const bool have_xyz = mg->coarse_dim >= 1 && (int)mg->coarse_xyz.size() == nfull * mg->coarse_dim;
+      FH_TRY(fh_direct_create(c, L0.A, have_xyz ? mg->coarse_dim : 0, have_xyz ? mg->coarse_xyz.data() : nullptr, 0, &mg->direct0));
+      mg->direct0_uid = L0.A->uid;
+    }
+    if (fh_direct_factor(mg->direct0) == 0) {
+      mg->direct0_active = true;
+      return 0;
+    }
+    FH_TRACE("coarse_factor: the sparse exact solve refused the operator (%s); dense path", fh_last_error());
+  }
   if (!mg->nd_off.empty() && c->gj_symmetric && c->gj_block >= IB) {
     // block form first: needs a symmetric operator (entry-by-entry check on the sparse form, taken with the coupling marks above)
     if (sym_known == 1) {
@@ -2348,7 +2376,8 @@ static int coarse_factor(fh_mg_t mg) {
       if (mg->nd_active) return 0;
     }
   }
-  FH_REQUIRE(n <= 16384, "coarse level has %d coupled unknowns: the dense direct solve supports at most 16384", n);
+  FH_REQUIRE(n <= 16384, "coarse level has %d coupled unknowns: the dense direct solve supports at most 16384 (the sparse exact solve, option coarse_direct, serves symmetric operators of any size: %s)", n,
+             c->coarse_direct ? "it refused this operator" : "it is switched off");
   if (mg->ainv_n != n) {      // a repeated preparation of the same hierarchy keeps its buffers (the 193 MB allocation cost 5-10 ms)
     if (mg->d_ainv) FH_CHECK_HIP(hipFree(mg->d_ainv));
     if (mg->d_gjwork) FH_CHECK_HIP(hipFree(mg->d_gjwork));
@@ -2592,6 +2621,17 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
       if (!L.tri) FH_TRY(fh_tri_create(L.A, &L.tri));                       // level schedules: once per pattern
       if (L.smoother == FH_SMOOTH_ILU0) FH_TRY(fh_tri_ilu_factor(L.tri, L.A));   // numeric factorisation: every setup
     }
+    if (L.smoother == FH_SMOOTH_LU && l > 0) {
+      FH_REQUIRE(!L.halo, "fh_mg_setup: level %d: the exact solve as level preconditioner serves undistributed levels", l);
+      if (!L.direct || L.direct_uid != L.A->uid) {
+        if (L.direct) fh_direct_destroy(L.direct);
+        L.direct = nullptr;
+        const bool have_xyz = L.xyz_dim >= 1 && (int)L.xyz.size() == L.n * L.xyz_dim;
+        FH_TRY(fh_direct_create(c, L.A, have_xyz ? L.xyz_dim : 0, have_xyz ? L.xyz.data() : nullptr, 0, &L.direct));
+        L.direct_uid = L.A->uid;
+      }
+      FH_TRY(fh_direct_factor(L.direct));
+    }
     if (L.smoother == FH_SMOOTH_VANKA && l > 0) {
       FH_REQUIRE(L.npatch > 0 && !L.halo, "fh_mg_setup: level %d uses the Vanka smoother but has no patches (fh_mg_set_level_patches)", l);
       if (!L.d_pinv) FH_TRY(color_patches(L));
@@ -2653,9 +2693,10 @@ static int gs_sweeps(fh_mg_t mg, MgLevel& L, int nsweeps, bool zero_guess) {
       FH_TRY(halo_spmv(L.halo, L.A, L.x, L.n, L.r, 2, L.b, nullptr, 0.0));
     }
     double* z = L.x2;
-    if (L.smoother == FH_SMOOTH_SOR || L.smoother == FH_SMOOTH_ILU0) {
-      // z = B r in the natural row order, as the reference's PCSOR / PCILU apply it (level-scheduled, fh_trisolve.hip)
+    if (L.smoother == FH_SMOOTH_SOR || L.smoother == FH_SMOOTH_ILU0 || L.smoother == FH_SMOOTH_LU) {
+      // z = B r in the natural row order, as the reference's PCSOR / PCILU apply it (level-scheduled, fh_trisolve.hip); PCLU: z = A^-1 r
       if (L.smoother == FH_SMOOTH_SOR) FH_TRY(fh_tri_ssor_apply(L.tri, L.A, L.dinv, L.r, z));
+      else if (L.smoother == FH_SMOOTH_LU) FH_TRY(fh_direct_solve_ptr(L.direct, L.r, z));
       else FH_TRY(fh_tri_ilu_apply(L.tri, L.A, L.r, z));
       hipLaunchKernelGGL(k_axpby2, dim3(sgrid(c, L.n)), dim3(256), 0, c->stream, L.x, z, L.omega, first ? 0.0 : 1.0, L.n);
       continue;
@@ -2728,6 +2769,7 @@ static int level_precond(fh_mg_t mg, MgLevel& L, const double* r, double* z) {
   switch (L.smoother) {
     case FH_SMOOTH_SOR: return fh_tri_ssor_apply(L.tri, L.A, L.dinv, r, z);
     case FH_SMOOTH_ILU0: return fh_tri_ilu_apply(L.tri, L.A, r, z);
+    case FH_SMOOTH_LU: return fh_direct_solve_ptr(L.direct, r, z);
     case FH_SMOOTH_GS_COLOR: return gs_color_apply(mg, L, r, z);
     case FH_SMOOTH_VANKA:
       FH_CHECK_HIP(hipMemsetAsync(z, 0, (size_t)L.ncols * sizeof(double), c->stream));
@@ -2805,7 +2847,8 @@ static int smooth_level(fh_mg_t mg, MgLevel& L, int nits, bool zero_guess, bool*
     if (zero_guess) FH_CHECK_HIP(hipMemsetAsync(L.x, 0, (size_t)L.ncols * sizeof(double), c->stream));
     return vanka_sweeps(mg, L, nits);
   }
-  if (L.smoother == FH_SMOOTH_GS_COLOR || L.smoother == FH_SMOOTH_SOR || L.smoother == FH_SMOOTH_ILU0) return gs_sweeps(mg, L, nits, zero_guess);
+  if (L.smoother == FH_SMOOTH_GS_COLOR || L.smoother == FH_SMOOTH_SOR || L.smoother == FH_SMOOTH_ILU0 || L.smoother == FH_SMOOTH_LU)
+    return gs_sweeps(mg, L, nits, zero_guess);
   int s = 0;
   if (zero_guess) {
     // sweep 1 from a zero guess: x = omega D^-1 b ; the others: fused Jacobi SpMV, ping-pong x <-> x2
@@ -2829,6 +2872,7 @@ static int smooth_level(fh_mg_t mg, MgLevel& L, int nits, bool zero_guess, bool*
 static int coarse_solve(fh_mg_t mg) {
   fh_ctx_t c = mg->ctx;
   MgLevel& L0 = mg->lv[0];
+  if (mg->direct0_active) return fh_direct_solve_ptr(mg->direct0, L0.b, L0.x);
   if (mg->nd_active) {
     const int k = (int)mg->nd_off.size() - 2, nI = mg->nd_off[k], ns = mg->na - nI;
     hipLaunchKernelGGL(k_gather_act, dim3(fh_div_up(std::max(mg->na, 1), 256)), dim3(256), 0, c->stream, L0.b, mg->d_act, mg->na, L0.r);
@@ -2963,6 +3007,20 @@ extern "C" int fh_mg_set_coarse_coords(fh_mg_t mg, int dim, int n, const double*
 
 // what the last fh_mg_setup made of the coarsest level: unknowns in the dense problem, interior blocks of the dissection (0: one dense
 // inverse), separator size, largest block
+// coordinates of the unknowns of a level >= 1 whose preconditioner is the exact solve (FH_SMOOTH_LU): optional, as fh_mg_set_coarse_coords for level 0
+extern "C" int fh_mg_set_level_coords(fh_mg_t mg, int level, int dim, int n, const double* coords) {
+  FH_REQUIRE(mg && level >= 0 && level < mg->nlevels && dim >= 1 && dim <= 3 && n >= 0 && (coords || n == 0), "fh_mg_set_level_coords: bad arguments");
+  if (level == 0) return fh_mg_set_coarse_coords(mg, dim, n, coords);
+  MgLevel& L = mg->lv[level];
+  L.xyz.assign(coords, coords + (size_t)n * dim);
+  L.xyz_dim = dim;
+  if (L.direct) {            // the tree was cut with other (or no) coordinates
+    fh_direct_destroy(L.direct);
+    L.direct = nullptr;
+  }
+  return 0;
+}
+
 extern "C" int fh_mg_coarse_info(fh_mg_t mg, int* n_dense, int* nd_blocks, int* nd_separator, int* nd_largest_block) {
   FH_REQUIRE(mg && mg->setup_done, "fh_mg_coarse_info: fh_mg_setup has not been called");
   const int k = mg->nd_active ? (int)mg->nd_off.size() - 2 : 0;
@@ -2986,7 +3044,10 @@ extern "C" int fh_mg_destroy(fh_mg_t mg) {
     free_level_patches(L);
     fh_tri_destroy(L.tri);
     L.tri = nullptr;
+    if (L.direct) fh_direct_destroy(L.direct);
+    L.direct = nullptr;
   }
+  if (mg->direct0) fh_direct_destroy(mg->direct0);
   if (mg->d_ainv) hipFree(mg->d_ainv);
   if (mg->d_act) hipFree(mg->d_act);
   if (mg->d_hit) hipFree(mg->d_hit);

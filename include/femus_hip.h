@@ -364,8 +364,10 @@ int fh_ns_element_matrices(fh_ns_assembler_t as, fh_vec_t sol, double nu, double
  *   FH_SMOOTH_ILU0      PCILU (:91-115): ILU(0) of the local block in natural order, zero pivot 1e-16 with MAT_SHIFT_NONZERO
  *                       (LinearEquationSolverPetsc.cpp:444-446: restart on A + shift I, shift 100 eps then doubled); re-factored by
  *                       every fh_mg_setup; level-scheduled triangular solves
- *   FH_SMOOTH_IDENTITY  PCNONE (IDENTITY_PRECOND, PetscPreconditioner.cpp:75-77): B = I */
-enum { FH_SMOOTH_JACOBI = 0, FH_SMOOTH_GS_COLOR = 1, FH_SMOOTH_VANKA = 2, FH_SMOOTH_SOR = 3, FH_SMOOTH_ILU0 = 4, FH_SMOOTH_IDENTITY = 5 };
+ *   FH_SMOOTH_IDENTITY  PCNONE (IDENTITY_PRECOND, PetscPreconditioner.cpp:75-77): B = I
+ *   FH_SMOOTH_LU        PCLU (LU_PRECOND / MLU_PRECOND as the preconditioner of a level solver, PetscPreconditioner.cpp:147-160): B = A^-1 by the sparse
+ *                       exact solve (fh_direct_*; symmetric level operators), refactored at every fh_mg_setup; fh_mg_set_level_coords is optional */
+enum { FH_SMOOTH_JACOBI = 0, FH_SMOOTH_GS_COLOR = 1, FH_SMOOTH_VANKA = 2, FH_SMOOTH_SOR = 3, FH_SMOOTH_ILU0 = 4, FH_SMOOTH_IDENTITY = 5, FH_SMOOTH_LU = 6 };
 /* outer solver of fh_mg_solve (`SetOuterSolver`, `_mgSolverType`; KSP types of LinearEquationSolverPetsc.cpp:455-529): one cycle,
  * Richardson, left-preconditioned GMRES, CG, and flexible (right-preconditioned) GMRES for cycles that are not a fixed linear
  * operator (GMRES level solvers) */
@@ -409,6 +411,7 @@ int fh_mg_setup(fh_mg_t mg);
  * solve (the reference's PCLU / MUMPS on the coarsest level, LinearEquationSolverPetsc.cpp:237-287) then dissects its dense problem -- block
  * inverses beside each other + a separator Schur complement (option "coarse_nd", symmetric operators) instead of one dense inverse.  Optional. */
 int fh_mg_set_coarse_coords(fh_mg_t mg, int dim, int n, const double* coords);
+int fh_mg_set_level_coords(fh_mg_t mg, int level, int dim, int n, const double* coords);   /* level >= 1 with FH_SMOOTH_LU; level 0 = fh_mg_set_coarse_coords */
 /* what the last fh_mg_setup made of the coarsest level: unknowns in the dense problem (the others are solved by their diagonal), interior
  * blocks of the dissection (0 = one dense inverse), separator size, largest block; any pointer may be NULL */
 int fh_mg_coarse_info(fh_mg_t mg, int* n_dense, int* nd_blocks, int* nd_separator, int* nd_largest_block);

@@ -63,10 +63,11 @@ int main(int argc, char** argv) {
       ls->_KK->init(nnode, nnode, nnode, nnode, d_nnz, o_nnz);
     }
     ls->set_solver_type(RICHARDSON);
-    // argv[6]: "sor" = SOR_PRECOND (the choice of 001_Poisson/main.cpp:242), "ilu" = ILU_PRECOND, default JACOBI_PRECOND
+    // argv[6]: "sor" = SOR_PRECOND (the choice of 001_Poisson/main.cpp:242), "ilu" = ILU_PRECOND, "mlu" = MLU_PRECOND (MUMPS through PCLU, the
+    // SetPreconditionerFineGrids choice of 18 applications), default JACOBI_PRECOND
     const std::string pc = argc > 6 ? argv[6] : "jacobi";
-    ls->set_preconditioner_type(pc == "sor" ? SOR_PRECOND : pc == "ilu" ? ILU_PRECOND : JACOBI_PRECOND);
-    ls->SetRichardsonScaleFactor(pc == "jacobi" ? 2. / 3. : 0.8);
+    ls->set_preconditioner_type(pc == "sor" ? SOR_PRECOND : pc == "ilu" ? ILU_PRECOND : pc == "mlu" ? MLU_PRECOND : JACOBI_PRECOND);
+    ls->SetRichardsonScaleFactor(pc == "jacobi" ? 2. / 3. : pc == "mlu" ? 1.0 : 0.8);
     if (l > 0) {
       fh_mat_t P;
       hip_check(fh_build_prolongator(hip_context(), msh[l - 1], msh[l], fe, 1, &P), "BuildProlongatorMatrix");

@@ -25,7 +25,8 @@ def build_app(tmp_path):
     return exe
 
 
-@pytest.mark.parametrize("args,nl,pc", [((2, 2, 2), 3, "jacobi"), ((4, 4, 0), 3, "jacobi"), ((4, 4, 0), 3, "sor"), ((2, 2, 2), 3, "ilu")])
+@pytest.mark.parametrize("args,nl,pc", [((2, 2, 2), 3, "jacobi"), ((4, 4, 0), 3, "jacobi"), ((4, 4, 0), 3, "sor"), ((2, 2, 2), 3, "ilu"), ((2, 2, 2), 3, "mlu"),
+                                        ((4, 4, 0), 3, "mlu")])
 def test_adapter_application_matches_oracle(tmp_path, args, nl, pc):
     exe = build_app(tmp_path)
     out = str(tmp_path / "sol.bin")

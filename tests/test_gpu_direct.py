@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ONE = lambda xg: np.ones(xg.shape[:2])
 
 
-def poisson_operator(box, nl, fe="biquadratic", perturb=0.0):
+def poisson_operator(box, nl, fe="biquadratic", perturb=0.0, zero_columns=True):
     ms = fo.build_levels(*box, nl)
     m = ms[-1]
     if perturb:
@@ -24,10 +24,12 @@ def poisson_operator(box, nl, fe="biquadratic", perturb=0.0):
     bdc = fo.dirichlet_dofs(m, fe)
     A = fo.zero_rows_inplace_pattern(A.tocsr(), bdc, 1.0)
     # the Galerkin hierarchy also zeroes the Dirichlet COLUMNS (rows of P): symmetric, the Dirichlet unknowns coupled to nothing
-    keep = np.ones(A.shape[0])
-    keep[bdc] = 0.0
-    D = sp.diags(keep)
-    A = (D @ A @ D + sp.diags(1.0 - keep)).tocsr()
+    if zero_columns:
+        keep = np.ones(A.shape[0])
+        keep[bdc] = 0.0
+        D = sp.diags(keep)
+        A2 = (D @ A @ D + sp.diags(1.0 - keep)).tocsr()
+        A = (A2 + A * 0.0).tocsr()                 # keep the pattern (stored zeros)
     A.sort_indices()
     n = A.shape[0]
     return A, m.coords[:n] if fe == "biquadratic" else m.coords[:n], bdc
@@ -65,6 +67,24 @@ def test_sparse_exact_solve_matches_scipy(ctx, box, nl, fe, leaf, with_coords):
     d.solve(b, x)
     ref = spla.splu(A2.tocsc()).solve(rhs)
     assert np.linalg.norm(x.to_numpy() - ref) <= 1e-11 * np.linalg.norm(ref)
+    d.destroy()
+    M.destroy()
+
+
+def test_dirichlet_rows_with_their_columns_left_in_place(ctx):
+    """SetPenalty alone (rows zeroed, columns not -- what a directly assembled level holds, LinearEquationSolverPetsc.cpp:428-436): x_d = b_d and the
+    Dirichlet columns move to the right-hand side of the free unknowns, whose block is symmetric"""
+    A, xy, bdc = poisson_operator((3, 3, 3), 2, perturb=0.01, zero_columns=False)
+    n = A.shape[0]
+    assert abs(A - A.T).max() > 1e-3
+    M = ctx.matrix_scipy(A)
+    d = capi.Direct(ctx, M, xy, 80).factor()
+    rhs = np.random.default_rng(8).uniform(-1, 1, n)
+    b, x = ctx.vector_from(rhs), ctx.vector(n)
+    d.solve(b, x)
+    ref = spla.splu(A.tocsc()).solve(rhs)
+    assert np.linalg.norm(x.to_numpy() - ref) <= 1e-12 * np.linalg.norm(ref)
+    assert np.array_equal(x.to_numpy()[bdc], rhs[bdc])
     d.destroy()
     M.destroy()
 
@@ -107,3 +127,81 @@ def test_unsymmetric_and_singular_operators_are_refused(ctx):
         d.factor()
     d.destroy()
     M.destroy()
+
+
+def _hierarchy(box, nl):
+    return fo.build_poisson_hierarchy(*box, nl, "biquadratic", ONE)
+
+
+@pytest.mark.parametrize("mode", [2, 0])
+def test_coarse_level_through_the_sparse_exact_solve(ctx, mode):
+    """the multigrid's exact coarse solve through fh_direct (option coarse_direct 2 = always) gives the cycle of the dense inverse (0 = never) and
+    of the oracle; the captured cycle replays it"""
+    H = _hierarchy((2, 2, 2), 3)
+    ctx.set_option("coarse_direct", mode)
+    try:
+        nl = len(H.A)
+        mg = capi.Multigrid(ctx, nl)
+        mats = []
+        for l in range(nl):
+            A = ctx.matrix_scipy(H.A[l])
+            P = ctx.matrix_scipy(H.P[l]) if l > 0 else None
+            mats += [A, P]
+            mg.set_level(l, A, P, None, capi.SMOOTH_JACOBI, 2. / 3., 2, 2)
+        mg.set_coarse_coords(H.meshes[0].coords[:H.A[0].shape[0]])
+        mg.setup()
+        n = H.A[-1].shape[0]
+        rhs = fo.lcg_fill(n, 4)
+        b, x = ctx.vector_from(rhs), ctx.vector(n)
+        ref = fo.vcycle(H, nl - 1, rhs)
+        for rep in range(3):
+            mg.vcycle(b, x)
+            assert np.linalg.norm(x.to_numpy() - ref) <= 1e-11 * np.linalg.norm(ref)
+        mg.destroy()
+    finally:
+        ctx.set_option("coarse_direct", 1)
+
+
+def test_a_coarse_level_beyond_the_dense_limit(ctx):
+    """two-level cycle whose coarse level has 35 937 unknowns (33^3 nodes): the dense inverse would refuse it (> 16 384); GMRES around the cycle
+    reaches the direct solution of the 65^3-node problem"""
+    Hs = fo.build_poisson_hierarchy(4, 4, 4, 4, "biquadratic", ONE)
+    meshes = Hs.meshes[2:]
+    A = [Hs.A[2], Hs.A[3]]
+    P = [None, Hs.P[3]]
+    mg = capi.Multigrid(ctx, 2)
+    A0, A1, P1 = ctx.matrix_scipy(A[0]), ctx.matrix_scipy(A[1]), ctx.matrix_scipy(P[1])
+    mg.set_level(0, A0, None, None, capi.SMOOTH_JACOBI, 2. / 3., 2, 2)
+    mg.set_level(1, A1, P1, None, capi.SMOOTH_JACOBI, 2. / 3., 2, 2)
+    mg.set_coarse_coords(meshes[0].coords[:A[0].shape[0]])
+    mg.setup()
+    assert A[0].shape[0] == 33 ** 3
+    n = A[1].shape[0]
+    b, x = ctx.vector_from(Hs.b), ctx.vector(n)
+    its, rn = mg.solve(b, x, outer="fgmres", rtol=1e-11, maxit=40)          # (flexible GMRES tests the TRUE residual)
+    r = Hs.b - A[1] @ x.to_numpy()
+    assert np.linalg.norm(r) <= 1e-10 * np.linalg.norm(Hs.b), (np.linalg.norm(r) / np.linalg.norm(Hs.b), its)
+    assert its <= 14
+    mg.destroy()
+
+
+@pytest.mark.parametrize("solver", ["richardson", "gmres"])
+def test_exact_solve_as_level_preconditioner(ctx, solver):
+    """MLU_PRECOND / LU_PRECOND on a level (PetscPreconditioner.cpp:147-160): Richardson(1) around B = A^-1 makes the level exact after one
+    iteration, so a two-level cycle with it equals the direct solution of the fine system (the coarse correction of an exact iterate is zero)"""
+    H = _hierarchy((2, 2, 2), 2)
+    mg = capi.Multigrid(ctx, 2)
+    A0, A1, P1 = ctx.matrix_scipy(H.A[0]), ctx.matrix_scipy(H.A[1]), ctx.matrix_scipy(H.P[1])
+    mg.set_level(0, A0, None, None, capi.SMOOTH_JACOBI, 1.0, 1, 1)
+    mg.set_level(1, A1, P1, None, capi.SMOOTH_LU, 1.0, 1, 1)
+    if solver == "gmres":
+        mg.set_level_solver(1, "gmres", 30)
+    mg.set_level_coords(1, H.meshes[1].coords[:H.A[1].shape[0]])
+    mg.setup()
+    n = H.A[1].shape[0]
+    rhs = fo.lcg_fill(n, 9)
+    b, x = ctx.vector_from(rhs), ctx.vector(n)
+    mg.vcycle(b, x)
+    ref = spla.splu(H.A[1].tocsc()).solve(rhs)
+    assert np.linalg.norm(x.to_numpy() - ref) <= 1e-11 * np.linalg.norm(ref)
+    mg.destroy()
