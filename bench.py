@@ -637,8 +637,9 @@ def live_traffic(coarse, levels, timeout=150, device=0):
             if t1 and t2:
                 sw = [x for x in rows if "k_spmv_lx<2048, 3" in x["Kernel_Name"] and t1[-1] < int(x["Start_Timestamp"]) < t2[-1]]
                 if sw:
-                    gmax = max(int(x.get("Grid_Size", 0) or 0) for x in sw)
-                    du = [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e6 for x in sw if int(x.get("Grid_Size", 0) or 0) == gmax]
+                    grid = lambda x: int(x.get("Grid_Size", x.get("Grid_Size_X", 0)) or 0)        # (the kernel trace names the column Grid_Size_X)
+                    gmax = max(grid(x) for x in sw)
+                    du = [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e6 for x in sw if grid(x) == gmax]
                     out["sweep_in_cycle_ms"] = sum(du) / len(du)
                     out["sweep_in_cycle_launches"] = len(du)
     except subprocess.TimeoutExpired:

@@ -30,9 +30,47 @@ for set in "SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc/p$i -- python $ROOT/tests/perf_probe_kpad.py ${ASM_SPEC:-12,1} > /tmp/pmc/log$i.txt 2>&1 || echo "assembly pass $i failed"
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc/p$i -- python $ROOT/tests/perf_probe_fused_loop.py 0 > /tmp/pmc/log$i.txt 2>&1 || echo "assembly pass $i failed"
 done
 python $ROOT/profiles/summarize.py /tmp/pmc $OUT/${TAG}_assembly_pmc_summary.md > /dev/null
+# the two-pass path beside it (option assemble_fused 0): traffic of k_elem_q2hex_sf + k_row_assemble2_t for the comparison in DESIGN
+rm -rf /tmp/pmc2; mkdir -p /tmp/pmc2
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  FEMUS_FUSED=0 timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc2/p$i -- python $ROOT/tests/perf_probe_fused_loop.py 0 > /tmp/pmc2/log$i.txt 2>&1 || echo "two-pass pass $i failed"
+done
+python $ROOT/profiles/summarize.py /tmp/pmc2 $OUT/${TAG}_assembly_two_pass_pmc_summary.md > /dev/null
+# per-launch HBM traffic of the fine-level launches: (2 FETCH_SIZE + WRITE_SIZE) KiB (gfx950 correction, profiles/r03_fetch_calibration.md)
+python - <<PY
+import json
+def traffic(path, names, out, src):
+    d = json.load(open(path))
+    res = {}
+    for key, cs in d.items():
+        k, g = key.rsplit("@", 1)
+        if any(k.startswith(n) for n in names) and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            if k not in res or int(g) > res[k][0]:
+                res[k] = (int(g), {"grid": int(g), "FETCH_SIZE_KB": cs["FETCH_SIZE"], "WRITE_SIZE_KB": cs["WRITE_SIZE"],
+                                   "traffic_bytes_per_launch": (2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024.0})
+    o = {k: v[1] for k, v in res.items()}
+    o["total_bytes_per_assembly"] = sum(v["traffic_bytes_per_launch"] for v in o.values())
+    o["correction"] = "gfx950: FETCH_SIZE x 2 for every access width (profiles/r03_fetch_calibration.md); WRITE_SIZE uncorrected"
+    o["source"] = src
+    json.dump(o, open(out, "w"), indent=1)
+try:
+    traffic("$OUT/${TAG}_assembly_pmc_summary.json", ["k_cluster_q2hex_sf", "k_rows_partial"], "$OUT/${TAG}_assembly_traffic.json",
+            "bash tests/profile_round.sh $TAG (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tests/perf_probe_fused_loop.py 0)")
+    traffic("$OUT/${TAG}_assembly_two_pass_pmc_summary.json", ["k_elem_q2hex_sf", "k_row_assemble2_t"], "$OUT/${TAG}_assembly_two_pass_traffic.json",
+            "the same with FEMUS_FUSED=0 (option assemble_fused 0)")
+    d = json.load(open("$OUT/${TAG}_spmv_pmc_summary.json"))
+    key = max((k for k in d if k.startswith("k_spmv_lx<2048, 3") and "FETCH_SIZE" in d[k]), key=lambda k: int(k.rsplit("@", 1)[1]))
+    json.dump({"kernel": key, "FETCH_SIZE_KB": d[key]["FETCH_SIZE"], "WRITE_SIZE_KB": d[key]["WRITE_SIZE"],
+               "traffic_bytes_per_launch": (2 * d[key]["FETCH_SIZE"] + d[key]["WRITE_SIZE"]) * 1024.0,
+               "source": "bash tests/profile_round.sh $TAG, tests/perf_probe_spmv.py"}, open("$OUT/${TAG}_spmv_traffic.json", "w"), indent=1)
+except Exception as e:
+    print("traffic files:", e)
+PY
 # ---- preparation: kernels of one fh_mg_setup re-preparation ----
 rm -rf /tmp/prof/prep
 PYTHONPATH=$ROOT timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/prep -- python $ROOT/tests/perf_probe_prepare.py 8 128 > /tmp/prof/prep.log 2>&1 || echo "prepare trace failed"
