@@ -281,7 +281,7 @@ def main():
     sweep_bytes = spmv_bytes + 3 * 8 * n       # + b, dinv, x(own row) per SURVEY 8(d) Jacobi-sweep model
     exp_lo, exp_hi = A.spmv_expected_bytes(3)
     cyc_bytes = pb.mg.cycle_algorithmic_bytes()
-    ai = pb.asm_top.info()
+    ai = pb.asm_top.info(colors=False)
     fused = pb.asm_top.fused_info()
 
     out = {

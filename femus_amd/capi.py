@@ -90,6 +90,9 @@ class Context:
     def matrix_csr(self, m, n, rowptr, col, val=None):
         return Mat.from_csr(self, m, n, rowptr, col, val)
 
+    def matrix_from_elements(self, elem_dof, m, n=None):
+        return Mat.from_elements(self, elem_dof, m, n)
+
     def matrix_scipy(self, A):
         A = A.tocsr()
         A.sort_indices()
@@ -295,6 +298,14 @@ class Mat:
         v = None if val is None else _f64(val)
         h = ctypes.c_void_p()
         _chk(ctx.L.fh_mat_create_csr(ctx.h, int(m), int(n), _p(rowptr), _p(col), _p(v), ctypes.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_elements(cls, ctx, elem_dof, m, n=None):
+        """finite-element pattern of the element dof table, built on the device (fh_mat_create_from_elements): m owned rows over n columns"""
+        ed = _i32(np.ascontiguousarray(elem_dof))
+        h = ctypes.c_void_p()
+        _chk(ctx.L.fh_mat_create_from_elements(ctx.h, int(ed.shape[0]), int(ed.shape[1]), _p(ed), int(m), int(m if n is None else n), ctypes.byref(h)))
         return cls(ctx, h)
 
     def destroy(self):
@@ -777,10 +788,11 @@ class Assembler:
         _chk(self.L.fh_element_matrices_poisson(self.h, None if sol is None else sol.h, int(source_kind), _p(p), _p(K), _p(F)))
         return K, F
 
-    def info(self):
+    def info(self, colors=True):
+        """colors: also the number of element colours of the coloured scatter (made on demand: the default paths need none)"""
         nco, by, fl = ctypes.c_int(), ctypes.c_int64(), ctypes.c_double()
-        _chk(self.L.fh_assembler_info(self.h, ctypes.byref(nco), ctypes.byref(by), ctypes.byref(fl)))
-        return {"ncolors": nco.value, "algorithmic_bytes": by.value, "flops": fl.value}
+        _chk(self.L.fh_assembler_info(self.h, ctypes.byref(nco) if colors else None, ctypes.byref(by), ctypes.byref(fl)))
+        return {"ncolors": nco.value if colors else None, "algorithmic_bytes": by.value, "flops": fl.value}
 
 
 class Direct:

@@ -2508,6 +2508,77 @@ static AsmParams base_params(fh_assembler_t as) {
   return P;
 }
 
+// element colours for the coloured scatter (greedy; host, from the device copy of the connectivity): made at the first use
+static int ensure_colors(fh_assembler_t as) {
+  if (as->d_color_elems) return 0;
+  std::vector<int> ed((size_t)as->nel * as->nloc), celems;
+  if (!ed.empty()) FH_CHECK_HIP(hipMemcpy(ed.data(), as->d_elem_dof, ed.size() * sizeof(int), hipMemcpyDeviceToHost));
+  color_elements(as->nel, as->nc, as->nloc, ed.data(), as->nnode, as->color_ptr, celems);
+  as->ncolors = (int)as->color_ptr.size() - 1;
+  FH_CHECK_HIP(hipMalloc(&as->d_color_elems, std::max<size_t>(celems.size(), 1) * sizeof(int)));
+  if (!celems.empty()) FH_CHECK_HIP(hipMemcpy(as->d_color_elems, celems.data(), celems.size() * sizeof(int), hipMemcpyHostToDevice));
+  FH_TRACE("assembler: element colouring done (%d colours)", as->ncolors);
+  return 0;
+}
+
+// affine classification + reference matrices of the optional affine path (option assemble_affine, fh_assembler_affine_count): at the first use
+static int ensure_affine(fh_assembler_t as) {
+  if (as->d_Mab || !(as->two_pass && as->dim == 3 && as->nc == 27 && as->ng == 64)) return 0;
+  const int nel = as->nel, nloc = as->nloc, geom = as->geom;
+  std::vector<int> edv((size_t)nel * nloc);
+  std::vector<double> xv((size_t)as->nnode * 3), w, phi, dphi;
+  if (!edv.empty()) FH_CHECK_HIP(hipMemcpy(edv.data(), as->d_elem_dof, edv.size() * sizeof(int), hipMemcpyDeviceToHost));
+  if (!xv.empty()) FH_CHECK_HIP(hipMemcpy(xv.data(), as->d_coords, xv.size() * sizeof(double), hipMemcpyDeviceToHost));
+  FH_REQUIRE(fhfe::shape_tables(as->geom, as->fe, as->order, w, phi, dphi) == 0, "assembler: unsupported Gauss rule %d", as->order);
+  const int* elem_dof = edv.data();
+  const double* coords = xv.data();
+  auto up = [&](void** d, const void* h, size_t bytes) -> int {
+    FH_CHECK_HIP(hipMalloc(d, bytes ? bytes : 8));
+    if (bytes) FH_CHECK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+    return 0;
+  };
+  {
+    // affine classification (host, geometry is fixed for the life of the assembler): every node at c + sum_a xi_a h_a
+    std::vector<int> aff, gen;
+    for (int e = 0; e < nel; e++) {
+      const int* ed = elem_dof + (size_t)e * nloc;
+      const double* x0 = coords + (size_t)ed[0] * 3;
+      double h[3][3], hmax = 0.0;
+      const int vtx[3] = {1, 3, 4};
+      for (int a = 0; a < 3; a++)
+        for (int d = 0; d < 3; d++) {
+          h[a][d] = 0.5 * (coords[(size_t)ed[vtx[a]] * 3 + d] - x0[d]);
+          hmax = std::max(hmax, std::fabs(h[a][d]));
+        }
+      bool ok = hmax > 0.0;
+      for (int n = 0; n < 27 && ok; n++)
+        for (int d = 0; d < 3; d++) {
+          double ref = x0[d];
+          for (int a = 0; a < 3; a++) ref += (fhfe::xc(geom, n, a) + 1) * h[a][d];
+          if (std::fabs(coords[(size_t)ed[n] * 3 + d] - ref) > 1e-12 * hmax) ok = false;
+        }
+      (ok ? aff : gen).push_back(e);
+    }
+    as->n_aff = (int)aff.size();
+    as->n_gen = (int)gen.size();
+    FH_TRY(up((void**)&as->d_aff_elems, aff.data(), aff.size() * sizeof(int)));
+    FH_TRY(up((void**)&as->d_gen_elems, gen.data(), gen.size() * sizeof(int)));
+    std::vector<double> Mab((size_t)9 * 729, 0.0), mphi(27, 0.0);
+    for (int g = 0; g < as->ng; g++)
+      for (int i = 0; i < 27; i++) {
+        mphi[i] += w[g] * phi[(size_t)g * 27 + i];
+        for (int j = 0; j < 27; j++)
+          for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++)
+              Mab[(size_t)(a * 3 + b) * 729 + i * 27 + j] += w[g] * dphi[((size_t)g * 27 + i) * 3 + a] * dphi[((size_t)g * 27 + j) * 3 + b];
+      }
+    FH_TRY(up((void**)&as->d_Mab, Mab.data(), Mab.size() * sizeof(double)));
+    FH_TRY(up((void**)&as->d_mphi, mphi.data(), mphi.size() * sizeof(double)));
+    FH_TRACE("assembler: affine classification done (%d affine, %d general)", as->n_aff, as->n_gen);
+  }
+  return 0;
+}
+
 extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, int nel, int nloc, const int* elem_dof, int nnode,
                                    const double* coords, fh_mat_t A, fh_assembler_t* out) {
   FH_GUARD_BEGIN
@@ -2728,11 +2799,7 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
     }
   }
   FH_TRACE("fh_assembler_create: tables uploaded (nel %d, nnode %d)", nel, nnode);
-  std::vector<int> celems;
-  color_elements(nel, as->nc, nloc, elem_dof, nnode, as->color_ptr, celems);
-  FH_TRACE("fh_assembler_create: element colouring done");
-  as->ncolors = (int)as->color_ptr.size() - 1;
-  FH_TRY(up((void**)&as->d_color_elems, celems.data(), celems.size() * sizeof(int)));
+  // (element colours: made when the coloured scatter or fh_assembler_info asks for them -- ensure_colors; the default two-pass / fused paths need none)
   std::vector<int> iota(nel);
   for (int e = 0; e < nel; e++) iota[e] = e;
   FH_TRY(up((void**)&as->d_iota, iota.data(), iota.size() * sizeof(int)));
@@ -2791,45 +2858,6 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
     as->two_pass = true;
     if (ctx->assemble_fused && as->dim == 3 && as->nc == 27 && as->ng == 64 && as->d_sfLc && ctx->assemble_sf) FH_TRY(cluster_plan_build(as, A, elem_dof, aptr));
   }
-  if (as->two_pass && as->dim == 3 && as->nc == 27 && as->ng == 64) {
-    // affine classification (host, geometry is fixed for the life of the assembler): every node at c + sum_a xi_a h_a
-    std::vector<int> aff, gen;
-    for (int e = 0; e < nel; e++) {
-      const int* ed = elem_dof + (size_t)e * nloc;
-      const double* x0 = coords + (size_t)ed[0] * 3;
-      double h[3][3], hmax = 0.0;
-      const int vtx[3] = {1, 3, 4};
-      for (int a = 0; a < 3; a++)
-        for (int d = 0; d < 3; d++) {
-          h[a][d] = 0.5 * (coords[(size_t)ed[vtx[a]] * 3 + d] - x0[d]);
-          hmax = std::max(hmax, std::fabs(h[a][d]));
-        }
-      bool ok = hmax > 0.0;
-      for (int n = 0; n < 27 && ok; n++)
-        for (int d = 0; d < 3; d++) {
-          double ref = x0[d];
-          for (int a = 0; a < 3; a++) ref += (fhfe::xc(geom, n, a) + 1) * h[a][d];
-          if (std::fabs(coords[(size_t)ed[n] * 3 + d] - ref) > 1e-12 * hmax) ok = false;
-        }
-      (ok ? aff : gen).push_back(e);
-    }
-    as->n_aff = (int)aff.size();
-    as->n_gen = (int)gen.size();
-    FH_TRY(up((void**)&as->d_aff_elems, aff.data(), aff.size() * sizeof(int)));
-    FH_TRY(up((void**)&as->d_gen_elems, gen.data(), gen.size() * sizeof(int)));
-    std::vector<double> Mab((size_t)9 * 729, 0.0), mphi(27, 0.0);
-    for (int g = 0; g < as->ng; g++)
-      for (int i = 0; i < 27; i++) {
-        mphi[i] += w[g] * phi[(size_t)g * 27 + i];
-        for (int j = 0; j < 27; j++)
-          for (int a = 0; a < 3; a++)
-            for (int b = 0; b < 3; b++)
-              Mab[(size_t)(a * 3 + b) * 729 + i * 27 + j] += w[g] * dphi[((size_t)g * 27 + i) * 3 + a] * dphi[((size_t)g * 27 + j) * 3 + b];
-      }
-    FH_TRY(up((void**)&as->d_Mab, Mab.data(), Mab.size() * sizeof(double)));
-    FH_TRY(up((void**)&as->d_mphi, mphi.data(), mphi.size() * sizeof(double)));
-    FH_TRACE("fh_assembler_create: affine classification done (%d affine, %d general)", as->n_aff, as->n_gen);
-  }
   *out = as;
   return 0;
   FH_GUARD_END("fh_assembler_create")
@@ -2838,7 +2866,7 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
 extern "C" int fh_assembler_destroy(fh_assembler_t as) {
   if (!as) return 0;
   hipStreamSynchronize(as->ctx->stream);
-  hipFree(as->d_color_elems);
+  if (as->d_color_elems) hipFree(as->d_color_elems);
   hipFree(as->d_elem_dof);
   hipFree(as->d_coords);
   hipFree(as->d_w);
@@ -2924,6 +2952,7 @@ static int assemble_poisson_core(fh_assembler_t as, fh_vec_t sol, int source_kin
     as->last_source_kind = source_kind;
     as->last_params[0] = P.p0;
     as->last_params[1] = P.p1;
+    if (as->ctx->assemble_affine) FH_TRY(ensure_affine(as));
     if (as->fused && as->ctx->assemble_fused && as->ctx->assemble_sf && !(as->ctx->assemble_affine && as->d_Mab && as->n_aff > 0) && !(as->ctx->asm_debug & 16)) {
       // fused cluster assembly: complete rows straight into the CSR arrays, the others through the partial-row buffer (the element-row buffer is not written)
       as->kbuf_valid = false;
@@ -2996,6 +3025,7 @@ static int assemble_poisson_core(fh_assembler_t as, fh_vec_t sol, int source_kin
   P.res = res->d;
   P.emap = as->d_emap;
   P.debug = as->ctx->asm_debug;
+  FH_TRY(ensure_colors(as));
   for (int c = 0; c < as->ncolors; c++) {
     P.elems = as->d_color_elems + as->color_ptr[c];
     P.nelems = as->color_ptr[c + 1] - as->color_ptr[c];
@@ -3031,6 +3061,7 @@ extern "C" int fh_element_matrices_poisson(fh_assembler_t as, fh_vec_t sol, int 
 
 extern "C" int fh_assembler_affine_count(fh_assembler_t as, int* n_affine, int* n_general) {
   FH_REQUIRE(as, "fh_assembler_affine_count: null argument");
+  FH_TRY(ensure_affine(as));
   if (n_affine) *n_affine = as->d_Mab ? as->n_aff : 0;
   if (n_general) *n_general = as->d_Mab ? as->n_gen : as->nel;
   return 0;
@@ -3047,7 +3078,10 @@ extern "C" int fh_assembler_fused_info(fh_assembler_t as, int* active, int* nclu
 }
 
 extern "C" int fh_assembler_info(fh_assembler_t as, int* ncolors, int64_t* algorithmic_bytes, double* flops) {
-  if (ncolors) *ncolors = as->ncolors;
+  if (ncolors) {
+    FH_TRY(ensure_colors(as));
+    *ncolors = as->ncolors;
+  }
   const int nc = as->nc, dim = as->dim, ng = as->ng;
   // per element reads nc*dim*8 (coords) + nc*4 (dof ids) + nc*8 (u), writes nc*nc*8 (K) + nc*8 (F)
   if (algorithmic_bytes) *algorithmic_bytes = (int64_t)as->nel * (nc * dim * 8 + nc * 4 + nc * 8 + nc * nc * 8 + nc * 8);

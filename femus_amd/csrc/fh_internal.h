@@ -186,6 +186,13 @@ struct InvDesc {
 size_t fh_inv_work_doubles(int n);
 int fh_inv_sym_batched(fh_ctx_t c, const InvDesc* d_desc, int k, int nmax);
 
+// host copy of the column indices: matrices whose pattern was built on the device (fh_mat_create_from_elements) fetch it at the first host use
+int fh_mat_fetch_host_cols(fh_mat_t A);
+static inline const std::vector<int>& fh_hcol(fh_mat_t A) {
+  if (A->h_col.size() != (size_t)A->nnz) fh_mat_fetch_host_cols(A);
+  return A->h_col;
+}
+
 // kernels / helpers implemented across TUs
 int fh_reserve_reduction(fh_ctx_t ctx, size_t ndoubles);
 int fh_mat_build_rowblocks(fh_mat_t A, int tile);

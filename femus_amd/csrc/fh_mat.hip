@@ -59,6 +59,180 @@ extern "C" int fh_mat_create_csr(fh_ctx_t c, int m, int n, const int* rowptr, co
   FH_GUARD_END("fh_mat_create_csr")
 }
 
+int fh_mat_fetch_host_cols(fh_mat_t A) {
+  A->h_col.resize((size_t)A->nnz);
+  if (A->nnz) {
+    FH_CHECK_HIP(hipMemcpyAsync(A->h_col.data(), A->d_col, (size_t)A->nnz * sizeof(int), hipMemcpyDeviceToHost, A->ctx->stream));
+    FH_CHECK_HIP(hipStreamSynchronize(A->ctx->stream));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Finite-element pattern on the DEVICE (round 4; LinearEquation::GetSparsityPatternSize + SparseMatrix::init, LinearEquation.cpp:407-548): row r
+// holds the dofs of all elements around dof r.  node -> element lists by a counting pass, then one wave per row: the <= 1024 candidate
+// columns into LDS, bitonic sort, distinct keys -> length (first launch) / columns (second launch).  The host only scans the row lengths;
+// the column array never visits it unless host code asks (fh_hcol).  Same pattern as fh_pattern_from_elements (sorted, unique).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int PE_CAP = 1024;
+__global__ __launch_bounds__(256) void k_pe_count(size_t n, const int* __restrict__ elem_dof, int m, int ncols, int* __restrict__ cnt, int* __restrict__ err) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int d = elem_dof[k];
+  if (d < 0 || d >= ncols) { atomicExch(err, 1); return; }
+  if (d < m) atomicAdd(&cnt[d], 1);
+}
+__global__ __launch_bounds__(256) void k_pe_fill(size_t n, int nloc, const int* __restrict__ elem_dof, int m, int* __restrict__ cur, int* __restrict__ adj) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int d = elem_dof[k];
+  if (d >= 0 && d < m) adj[atomicAdd(&cur[d], 1)] = (int)(k / nloc);
+}
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_pe_rows(int m, const int* __restrict__ aptr, const int* __restrict__ adj, const int* __restrict__ elem_dof, int nloc,
+                                                 const int* __restrict__ rowptr, int* __restrict__ rowlen, int* __restrict__ col, int* __restrict__ err) {
+  __shared__ int keys[4][PE_CAP];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= m) return;
+  int* key = keys[wave];
+  const int a0 = aptr[r], na = aptr[r + 1] - a0, n = na * nloc;
+  if (n > PE_CAP) {
+    if (lane == 0) atomicExch(err, 2);
+    return;
+  }
+  int np = 64;
+  while (np < n) np <<= 1;
+  for (int k = lane; k < np; k += 64) key[k] = k < n ? elem_dof[(size_t)adj[a0 + k / nloc] * nloc + k % nloc] : 0x7fffffff;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int size = 2; size <= np; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = lane; t < (np >> 1); t += 64) {
+        const int lo = ((t / stride) * (stride << 1)) + (t % stride), hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const int a = key[lo], c = key[hi];
+        if ((a > c) == up) {
+          key[lo] = c;
+          key[hi] = a;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  const int per = np >> 6, k0 = lane * per;
+  int mine = 0;
+  for (int k = k0; k < k0 + per && k < n; k++) mine += (k == 0 || key[k] != key[k - 1]) ? 1 : 0;
+  int incl = mine;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += v;
+  }
+  const int total = __shfl(incl, 63, 64);
+  if (!FILL) {
+    if (lane == 0) rowlen[r] = total;
+    return;
+  }
+  int o = rowptr[r] + incl - mine;
+  for (int k = k0; k < k0 + per && k < n; k++)
+    if (k == 0 || key[k] != key[k - 1]) col[o++] = key[k];
+}
+
+extern "C" int fh_mat_create_from_elements(fh_ctx_t c, int nel, int nloc, const int* elem_dof, int m, int n, fh_mat_t* out) {
+  FH_GUARD_BEGIN
+  FH_REQUIRE(c && out && nel >= 0 && nloc > 0 && m >= 0 && n >= m && (elem_dof || nel == 0), "fh_mat_create_from_elements: bad arguments");
+  const size_t ne = (size_t)nel * nloc;
+  int *d_ed = nullptr, *d_cnt = nullptr, *d_adj = nullptr, *d_err = nullptr, *d_len = nullptr;
+  auto cleanup = [&]() {
+    for (int* p : {d_ed, d_cnt, d_adj, d_err, d_len})
+      if (p) hipFree(p);
+  };
+  FH_CHECK_HIP(hipMalloc(&d_ed, std::max<size_t>(ne, 1) * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&d_cnt, ((size_t)m + 2) * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&d_err, sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&d_len, ((size_t)m + 1) * sizeof(int)));
+  if (ne) FH_CHECK_HIP(hipMemcpyAsync(d_ed, elem_dof, ne * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  FH_CHECK_HIP(hipMemsetAsync(d_cnt, 0, ((size_t)m + 2) * sizeof(int), c->stream));
+  FH_CHECK_HIP(hipMemsetAsync(d_err, 0, sizeof(int), c->stream));
+  const unsigned gb = (unsigned)((ne + 255) / 256);
+  if (ne) hipLaunchKernelGGL(k_pe_count, dim3(gb), dim3(256), 0, c->stream, ne, d_ed, m, n, d_cnt, d_err);
+  std::vector<int> aptr((size_t)m + 1, 0);
+  if (m) FH_CHECK_HIP(hipMemcpyAsync(aptr.data() + 1, d_cnt, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  int err = 0;
+  FH_CHECK_HIP(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  if (err) {
+    cleanup();
+    fh_set_error("fh_mat_create_from_elements: a dof of an element is out of range");
+    return 2;
+  }
+  int64_t tot = 0;
+  for (int r = 0; r < m; r++) {
+    tot += aptr[r + 1];
+    aptr[r + 1] = (int)tot;
+  }
+  FH_REQUIRE(tot < 2147483647ll, "fh_mat_create_from_elements: adjacency overflows int32");
+  int* d_aptr = nullptr;
+  FH_CHECK_HIP(hipMalloc(&d_aptr, ((size_t)m + 1) * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&d_adj, std::max<size_t>((size_t)tot, 1) * sizeof(int)));
+  FH_CHECK_HIP(hipMemcpyAsync(d_aptr, aptr.data(), ((size_t)m + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  FH_CHECK_HIP(hipMemcpyAsync(d_cnt, aptr.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, c->stream));        // cursors
+  if (ne) hipLaunchKernelGGL(k_pe_fill, dim3(gb), dim3(256), 0, c->stream, ne, nloc, d_ed, m, d_cnt, d_adj);
+  if (m) hipLaunchKernelGGL(k_pe_rows<false>, dim3(fh_div_up(m, 4)), dim3(256), 0, c->stream, m, d_aptr, d_adj, d_ed, nloc, (const int*)nullptr, d_len, (int*)nullptr, d_err);
+  std::vector<int> rp((size_t)m + 1, 0);
+  if (m) FH_CHECK_HIP(hipMemcpyAsync(rp.data() + 1, d_len, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  FH_CHECK_HIP(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  if (err) {               // a node with more than PE_CAP candidate columns: the host builder serves it
+    hipFree(d_aptr);
+    cleanup();
+    std::vector<int> hrp((size_t)n + 1), hcol;
+    FH_TRY(fh_pattern_from_elements(nel, nloc, elem_dof, n, hrp.data(), nullptr));
+    hcol.resize((size_t)hrp[n]);
+    FH_TRY(fh_pattern_from_elements(nel, nloc, elem_dof, n, hrp.data(), hcol.data()));
+    return fh_mat_create_csr(c, m, n, hrp.data(), hcol.data(), nullptr, out);
+  }
+  int maxrow = 0;
+  tot = 0;
+  for (int r = 0; r < m; r++) {
+    maxrow = std::max(maxrow, rp[r + 1]);
+    tot += rp[r + 1];
+    rp[r + 1] = (int)tot;
+  }
+  if (tot >= 2147483647ll) {
+    hipFree(d_aptr);
+    cleanup();
+    fh_set_error("fh_mat_create_from_elements: nnz overflows int32");
+    return 2;
+  }
+  fh_mat_t A = new fh_mat_s();
+  static std::atomic<uint64_t> next_uid{(uint64_t)1 << 40};        // (apart from the counter of fh_mat_create_csr)
+  A->uid = next_uid++;
+  A->ctx = c;
+  A->m = m;
+  A->n = n;
+  A->nnz = (int)tot;
+  A->max_row = maxrow;
+  A->h_rowptr = rp;
+  FH_CHECK_HIP(hipMalloc(&A->d_rowptr, ((size_t)m + 1) * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&A->d_col, ((size_t)A->nnz + 2) * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&A->d_val, ((size_t)A->nnz + 2) * sizeof(double)));
+  FH_CHECK_HIP(hipMemsetAsync(A->d_col + A->nnz, 0, 2 * sizeof(int), c->stream));
+  FH_CHECK_HIP(hipMemsetAsync(A->d_val, 0, ((size_t)A->nnz + 2) * sizeof(double), c->stream));
+  FH_CHECK_HIP(hipMemcpyAsync(A->d_rowptr, rp.data(), ((size_t)m + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  if (m) hipLaunchKernelGGL(k_pe_rows<true>, dim3(fh_div_up(m, 4)), dim3(256), 0, c->stream, m, d_aptr, d_adj, d_ed, nloc, A->d_rowptr, (int*)nullptr, A->d_col, d_err);
+  FH_CHECK_HIP(hipGetLastError());
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  hipFree(d_aptr);
+  cleanup();
+  FH_TRY(fh_mat_build_rowblocks(A, c->spmv_tile));
+  *out = A;
+  return 0;
+  FH_GUARD_END("fh_mat_create_from_elements")
+}
+
 extern "C" int fh_mat_destroy(fh_mat_t A) {
   if (!A) return 0;
   hipStreamSynchronize(A->ctx->stream);
@@ -168,7 +342,7 @@ extern "C" int fh_mat_get_values_csr(fh_mat_t A, double* val) {
 
 extern "C" int fh_mat_get_pattern(fh_mat_t A, int* rowptr, int* col) {
   if (rowptr) memcpy(rowptr, A->h_rowptr.data(), ((size_t)A->m + 1) * sizeof(int));
-  if (col) memcpy(col, A->h_col.data(), (size_t)A->nnz * sizeof(int));
+  if (col) memcpy(col, fh_hcol(A).data(), (size_t)A->nnz * sizeof(int));
   return 0;
 }
 
@@ -176,11 +350,11 @@ extern "C" int fh_mat_get_pattern(fh_mat_t A, int* rowptr, int* col) {
 // per-element crossings of the reference interface (slow path; the batched assembler is the fast one)
 // ------------------------------------------------------------------------------------------------
 static int host_find(const fh_mat_t A, int row, int c) {
-  const int* b = A->h_col.data() + A->h_rowptr[row];
-  const int* e = A->h_col.data() + A->h_rowptr[row + 1];
+  const int* b = fh_hcol(A).data() + A->h_rowptr[row];
+  const int* e = fh_hcol(A).data() + A->h_rowptr[row + 1];
   const int* p = std::lower_bound(b, e, c);
   if (p == e || *p != c) return -1;
-  return (int)(p - A->h_col.data());
+  return (int)(p - fh_hcol(A).data());
 }
 
 __global__ void k_apply_entries(double* __restrict__ val, const int* __restrict__ pos, const double* __restrict__ v, int n, int add) {
@@ -230,7 +404,7 @@ extern "C" int fh_mat_get_row(fh_mat_t A, int row, int* ncols, int* cols, double
   FH_REQUIRE(row >= 0 && row < A->m, "fh_mat_get_row: row %d out of range", row);
   int s = A->h_rowptr[row], e = A->h_rowptr[row + 1];
   if (ncols) *ncols = e - s;
-  if (cols) memcpy(cols, A->h_col.data() + s, (size_t)(e - s) * sizeof(int));
+  if (cols) memcpy(cols, fh_hcol(A).data() + s, (size_t)(e - s) * sizeof(int));
   if (vals && e > s) {
     FH_CHECK_HIP(hipMemcpyAsync(vals, A->d_val + s, (size_t)(e - s) * sizeof(double), hipMemcpyDeviceToHost, A->ctx->stream));
     FH_CHECK_HIP(hipStreamSynchronize(A->ctx->stream));
@@ -367,7 +541,7 @@ extern "C" int fh_mat_col_mask(fh_mat_t A, int nrows, const int* rows, unsigned 
   for (int i = 0; i < nrows; i++) {
     const int r = rows[i];
     FH_REQUIRE(r >= 0 && r < A->m, "fh_mat_col_mask: row %d out of range", r);
-    for (int k = A->h_rowptr[r]; k < A->h_rowptr[r + 1]; k++) mask[A->h_col[k]] = 1;
+    for (int k = A->h_rowptr[r]; k < A->h_rowptr[r + 1]; k++) mask[fh_hcol(A)[k]] = 1;
   }
   return 0;
 }
@@ -378,7 +552,7 @@ extern "C" int fh_mat_row_mask(fh_mat_t A, const unsigned char* colmask /* [A->n
   for (int r = 0; r < A->m; r++) {
     if (rowmask[r]) continue;
     for (int k = A->h_rowptr[r]; k < A->h_rowptr[r + 1]; k++)
-      if (colmask[A->h_col[k]]) {
+      if (colmask[fh_hcol(A)[k]]) {
         rowmask[r] = 1;
         break;
       }
@@ -396,13 +570,13 @@ extern "C" int fh_mat_value_map(fh_mat_t dst, fh_mat_t src, const int* src_row, 
     const int sr = src_row ? src_row[r] : r;
     if (sr < 0) continue;
     FH_REQUIRE(sr < src->m, "fh_mat_value_map: source row %d out of range", sr);
-    const int* b = src->h_col.data() + src->h_rowptr[sr];
-    const int* e = src->h_col.data() + src->h_rowptr[sr + 1];
+    const int* b = fh_hcol(src).data() + src->h_rowptr[sr];
+    const int* e = fh_hcol(src).data() + src->h_rowptr[sr + 1];
     for (int k = dst->h_rowptr[r]; k < dst->h_rowptr[r + 1]; k++) {
-      const int sc = src_col ? src_col[dst->h_col[k]] : dst->h_col[k];
+      const int sc = src_col ? src_col[fh_hcol(dst)[k]] : fh_hcol(dst)[k];
       if (sc < 0) continue;
       const int* q = std::lower_bound(b, e, sc);
-      if (q != e && *q == sc) map[k] = (int)(q - src->h_col.data());
+      if (q != e && *q == sc) map[k] = (int)(q - fh_hcol(src).data());
     }
   }
   return fh_index_create(dst->ctx, dst->nnz, map.data(), out);
@@ -420,7 +594,7 @@ extern "C" int fh_mat_restrict(fh_mat_t src, int nrows, const int* rows, const i
     FH_REQUIRE(r >= 0 && r < src->m, "fh_mat_restrict: row %d out of range", r);
     int cnt = 0;
     for (int k = src->h_rowptr[r]; k < src->h_rowptr[r + 1]; k++) {
-      const int c = newcol[src->h_col[k]];
+      const int c = newcol[fh_hcol(src)[k]];
       FH_REQUIRE(c < ncols_new, "fh_mat_restrict: new column %d out of range (%d columns)", c, ncols_new);
       cnt += c >= 0;
     }
@@ -432,7 +606,7 @@ extern "C" int fh_mat_restrict(fh_mat_t src, int nrows, const int* rows, const i
     const int r = rows[i];
     buf.clear();
     for (int k = src->h_rowptr[r]; k < src->h_rowptr[r + 1]; k++) {
-      const int c = newcol[src->h_col[k]];
+      const int c = newcol[fh_hcol(src)[k]];
       if (c >= 0) buf.emplace_back(c, k);
     }
     std::sort(buf.begin(), buf.end());
@@ -582,12 +756,12 @@ __global__ __launch_bounds__(256) void k_gather_perm(double* __restrict__ dst, c
 static int build_transpose(fh_mat_t A, fh_mat_t* out, int** d_perm_out) {
   const int m = A->m, n = A->n, nnz = A->nnz;
   std::vector<int> trp(n + 1, 0), tcol(nnz), perm(nnz);
-  for (int k = 0; k < nnz; k++) trp[A->h_col[k] + 1]++;
+  for (int k = 0; k < nnz; k++) trp[fh_hcol(A)[k] + 1]++;
   for (int j = 0; j < n; j++) trp[j + 1] += trp[j];
   std::vector<int> cur(trp.begin(), trp.end() - 1);
   for (int i = 0; i < m; i++)
     for (int k = A->h_rowptr[i]; k < A->h_rowptr[i + 1]; k++) {
-      int p = cur[A->h_col[k]]++;
+      int p = cur[fh_hcol(A)[k]]++;
       tcol[p] = i;   // rows visited in increasing order => sorted columns in the transpose
       perm[p] = k;
     }
@@ -598,6 +772,7 @@ static int build_transpose(fh_mat_t A, fh_mat_t* out, int** d_perm_out) {
   if (nnz) FH_CHECK_HIP(hipMemcpy(d_perm, perm.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
   *out = At;
   *d_perm_out = d_perm;
+  FH_TRACE("build_transpose: %d x %d, %d non-zeros", m, n, nnz);
   return 0;
 }
 
@@ -642,7 +817,7 @@ extern "C" int fh_mat_norm(fh_mat_t A, int kind, double* out) {
     }
   } else if (kind == 1) {
     std::vector<double> cs(A->n, 0.0);
-    for (int k = 0; k < A->nnz; k++) cs[A->h_col[k]] += fabs(v[k]);
+    for (int k = 0; k < A->nnz; k++) cs[fh_hcol(A)[k]] += fabs(v[k]);
     for (double s : cs) best = std::max(best, s);
   } else {
     fh_set_error("fh_mat_norm: unknown kind %d", kind);
@@ -737,49 +912,111 @@ __global__ __launch_bounds__(256) void k_spmv_stream(const int* __restrict__ row
 // mostly coalesced) and the 135M per-non-zero gathers become LDS reads; the column stream shrinks from 4 to 2 bytes.
 // Integer setup work on host threads, done lazily at the first product with the matrix.
 // ------------------------------------------------------------------------------------------------
+// On the DEVICE since round 4 (the host version, 16 threads, took 0.39 s for the 135 M non-zeros of the bench's fine level -- half of the
+// first preparation): one workgroup per row block sorts the block's columns in LDS (bitonic, <= 4096 keys), marks the first of every run,
+// scans the marks and writes the distinct columns to a scratch slab and the 16-bit local index of every non-zero; the host only scans the
+// 67 k per-block counts.  Same lists, same indices as the host loop gave.
+template <int TILE>
+__global__ __launch_bounds__(256) void k_localcols(const int* __restrict__ blk, const int* __restrict__ rowptr, const int* __restrict__ col, int tile,
+                                                   int* __restrict__ uscratch, int* __restrict__ ucount, unsigned short* __restrict__ lcol) {
+  __shared__ int key[TILE];
+  __shared__ int uniq[TILE];
+  __shared__ int wsum[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int s = rowptr[blk[b]], e = rowptr[blk[b + 1]], n = e - s;
+  if (n > tile) {                       // single long row: handled by the global-column path
+    if (tid == 0) ucount[b] = 0;
+    return;
+  }
+  int np = 64;
+  while (np < n) np <<= 1;
+  for (int k = tid; k < np; k += 256) key[k] = k < n ? col[s + k] : 0x7fffffff;
+  __syncthreads();
+  for (int size = 2; size <= np; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (np >> 1); t += 256) {
+        const int lo = ((t / stride) * (stride << 1)) + (t % stride), hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const int a = key[lo], c = key[hi];
+        if ((a > c) == up) {
+          key[lo] = c;
+          key[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  // distinct keys: exclusive scan of the "first of its run" marks, 256 threads x (np / 256) consecutive entries
+  const int per = np >> 8 ? np >> 8 : 1, k0 = tid * per;
+  int mine = 0;
+  for (int k = k0; k < k0 + per && k < n; k++) mine += (k == 0 || key[k] != key[k - 1]) ? 1 : 0;
+  int incl = mine;
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += v;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = incl - mine;
+  for (int w = 0; w < wave; w++) base += wsum[w];
+  const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  for (int k = k0; k < k0 + per && k < n; k++)
+    if (k == 0 || key[k] != key[k - 1]) uniq[base++] = key[k];
+  __syncthreads();
+  for (int k = tid; k < total; k += 256) uscratch[(size_t)b * tile + k] = uniq[k];
+  if (tid == 0) ucount[b] = total;
+  for (int k = tid; k < n; k += 256) {
+    const int c = col[s + k];
+    int lo = 0, hi = total - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (uniq[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    lcol[s + k] = (unsigned short)lo;
+  }
+}
+__global__ __launch_bounds__(256) void k_localcols_compact(const int* __restrict__ uscratch, const int* __restrict__ uptr, int tile, int* __restrict__ ucols) {
+  const int b = blockIdx.x;
+  const int o = uptr[b], n = uptr[b + 1] - o;
+  for (int k = threadIdx.x; k < n; k += 256) ucols[o + k] = uscratch[(size_t)b * tile + k];
+}
+
 int fh_mat_build_localcols(fh_mat_t A) {
   const int nblk = A->nblk;
   const std::vector<int>& blk = A->h_rowblk;
+  fh_ctx_t c = A->ctx;
   std::vector<int> uptr(nblk + 1, 0);
-  std::vector<unsigned short> lcol((size_t)A->nnz + 2, 0);
-  const int nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-  std::vector<std::vector<int>> chunks(nthreads);
-  std::vector<int> bounds(nthreads + 1);
-  for (int t = 0; t <= nthreads; t++) bounds[t] = (int)((int64_t)nblk * t / nthreads);
-  auto work = [&](int t) {
-    std::vector<int> buf;
-    for (int b = bounds[t]; b < bounds[t + 1]; b++) {
-      const int s = A->h_rowptr[blk[b]], e = A->h_rowptr[blk[b + 1]];
-      if (e - s > A->tile) {   // single long row: handled by the global-column path
-        uptr[b + 1] = 0;
-        continue;
-      }
-      buf.assign(A->h_col.begin() + s, A->h_col.begin() + e);
-      std::sort(buf.begin(), buf.end());
-      buf.erase(std::unique(buf.begin(), buf.end()), buf.end());
-      uptr[b + 1] = (int)buf.size();
-      for (int k = s; k < e; k++)
-        lcol[k] = (unsigned short)(std::lower_bound(buf.begin(), buf.end(), A->h_col[k]) - buf.begin());
-      chunks[t].insert(chunks[t].end(), buf.begin(), buf.end());
-    }
-  };
-  std::vector<std::thread> th;
-  for (int t = 0; t < nthreads; t++) th.emplace_back(work, t);
-  for (auto& x : th) x.join();
-  for (int b = 0; b < nblk; b++) uptr[b + 1] += uptr[b];
-  std::vector<int> ucols((size_t)uptr[nblk] + 1);
-  A->nu_total = uptr[nblk];
-  for (int t = 0; t < nthreads; t++)
-    if (!chunks[t].empty()) std::copy(chunks[t].begin(), chunks[t].end(), ucols.begin() + uptr[bounds[t]]);
   if (A->d_uptr) FH_CHECK_HIP(hipFree(A->d_uptr));
   if (A->d_ucols) FH_CHECK_HIP(hipFree(A->d_ucols));
   if (A->d_lcol) FH_CHECK_HIP(hipFree(A->d_lcol));
-  FH_CHECK_HIP(hipMalloc(&A->d_uptr, uptr.size() * sizeof(int)));
-  FH_CHECK_HIP(hipMalloc(&A->d_ucols, ucols.size() * sizeof(int)));
-  FH_CHECK_HIP(hipMalloc(&A->d_lcol, lcol.size() * sizeof(unsigned short)));
-  FH_CHECK_HIP(hipMemcpy(A->d_uptr, uptr.data(), uptr.size() * sizeof(int), hipMemcpyHostToDevice));
-  FH_CHECK_HIP(hipMemcpy(A->d_ucols, ucols.data(), ucols.size() * sizeof(int), hipMemcpyHostToDevice));
-  FH_CHECK_HIP(hipMemcpy(A->d_lcol, lcol.data(), lcol.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  A->d_uptr = nullptr;
+  A->d_ucols = nullptr;
+  A->d_lcol = nullptr;
+  FH_CHECK_HIP(hipMalloc(&A->d_lcol, ((size_t)A->nnz + 2) * sizeof(unsigned short)));
+  FH_CHECK_HIP(hipMemsetAsync(A->d_lcol, 0, ((size_t)A->nnz + 2) * sizeof(unsigned short), c->stream));
+  {
+    int *d_scratch = nullptr, *d_count = nullptr;
+    FH_CHECK_HIP(hipMalloc(&d_scratch, std::max<size_t>((size_t)nblk * A->tile, 1) * sizeof(int)));
+    FH_CHECK_HIP(hipMalloc(&d_count, (size_t)(nblk + 1) * sizeof(int)));
+    if (nblk) {
+      hipLaunchKernelGGL(k_localcols<4096>, dim3(nblk), dim3(256), 0, c->stream, A->d_rowblk, A->d_rowptr, A->d_col, A->tile, d_scratch, d_count, A->d_lcol);
+      FH_CHECK_HIP(hipGetLastError());
+      FH_CHECK_HIP(hipMemcpyAsync(uptr.data() + 1, d_count, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+    }
+    for (int b = 0; b < nblk; b++) uptr[b + 1] += uptr[b];
+    A->nu_total = uptr[nblk];
+    FH_CHECK_HIP(hipMalloc(&A->d_uptr, uptr.size() * sizeof(int)));
+    FH_CHECK_HIP(hipMalloc(&A->d_ucols, ((size_t)uptr[nblk] + 1) * sizeof(int)));
+    FH_CHECK_HIP(hipMemcpyAsync(A->d_uptr, uptr.data(), uptr.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (nblk) {
+      hipLaunchKernelGGL(k_localcols_compact, dim3(nblk), dim3(256), 0, c->stream, d_scratch, A->d_uptr, A->tile, A->d_ucols);
+      FH_CHECK_HIP(hipGetLastError());
+    }
+    FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+    hipFree(d_scratch);
+    hipFree(d_count);
+  }
   {
     std::vector<int> ts(nblk + 1);
     for (int b = 0; b <= nblk; b++) ts[b] = A->h_rowptr[blk[b]];
@@ -807,6 +1044,7 @@ int fh_mat_build_localcols(fh_mat_t A) {
   }
   A->lx_tile = A->tile;
   A->split_nown = -1;
+  FH_TRACE("fh_mat_build_localcols: %d x %d, %d non-zeros, %d row blocks", A->m, A->n, A->nnz, nblk);
   return 0;
 }
 
@@ -1002,7 +1240,7 @@ static int build_split(fh_mat_t A, int n_own) {
   std::vector<char> ghost(nblk, 0);
   for (int b = 0; b < nblk; b++)
     for (int r = blk[b]; r < blk[b + 1] && !ghost[b]; r++)     // columns are sorted inside a row: its last one is its largest
-      if (A->h_rowptr[r + 1] > A->h_rowptr[r] && A->h_col[A->h_rowptr[r + 1] - 1] >= n_own) ghost[b] = 1;
+      if (A->h_rowptr[r + 1] > A->h_rowptr[r] && fh_hcol(A)[A->h_rowptr[r + 1] - 1] >= n_own) ghost[b] = 1;
   for (int b = 0; b < nblk; b++)
     if (!ghost[b]) order.push_back(b);
   const int n_int = (int)order.size();

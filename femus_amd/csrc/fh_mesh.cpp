@@ -967,7 +967,7 @@ extern "C" int fh_build_system_prolongator(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t
     FH_CHECK_HIP(hipMemcpy(bv.data(), B->d_val, (size_t)B->nnz * sizeof(double), hipMemcpyDeviceToHost));
     for (int i = 0; i < B->m; i++) {
       for (int q = B->h_rowptr[i]; q < B->h_rowptr[i + 1]; q++) {
-        col[p] = c0 + B->h_col[q];
+        col[p] = c0 + fh_hcol(B)[q];
         val[p++] = bv[q];
       }
       rowptr[r0 + i + 1] = p;

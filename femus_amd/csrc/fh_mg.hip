@@ -1570,7 +1570,7 @@ extern "C" int fh_mg_set_level_patches(fh_mg_t mg, int level, int npatch, const 
 // greedy colouring in patch order; two patches conflict when a dof of one appears in the matrix rows of the other
 static int color_patches(MgLevel& L) {
   const int n = L.A->m, np = L.npatch;
-  const std::vector<int>&rp = L.A->h_rowptr, &cl = L.A->h_col;
+  const std::vector<int>&rp = L.A->h_rowptr, &cl = fh_hcol(L.A);
   for (int d : L.h_pdofs) FH_REQUIRE(d >= 0 && d < n, "Vanka smoother: patch dof %d out of range", d);
   std::vector<int> optr(n + 1, 0), rptr(n + 1, 0);
   std::vector<std::vector<int>> reads(np);
@@ -2495,14 +2495,14 @@ static int color_rows(MgLevel& L) {
   std::vector<int> tptr(m + 1, 0);
   for (int i = 0; i < m; i++)
     for (int k = A->h_rowptr[i]; k < A->h_rowptr[i + 1]; k++) {
-      const int j = A->h_col[k];
+      const int j = fh_hcol(A)[k];
       if (j < m && j != i) tptr[j + 1]++;
     }
   for (int i = 0; i < m; i++) tptr[i + 1] += tptr[i];
   std::vector<int> trow(tptr[m]), tpos(tptr.begin(), tptr.end() - 1);
   for (int i = 0; i < m; i++)
     for (int k = A->h_rowptr[i]; k < A->h_rowptr[i + 1]; k++) {
-      const int j = A->h_col[k];
+      const int j = fh_hcol(A)[k];
       if (j < m && j != i) trow[tpos[j]++] = i;      // row i reads column j
     }
   std::vector<int> color(m, -1), mark;
@@ -2510,7 +2510,7 @@ static int color_rows(MgLevel& L) {
   for (int i = 0; i < m; i++) {
     mark.assign(nc + 1, 0);
     for (int k = A->h_rowptr[i]; k < A->h_rowptr[i + 1]; k++) {
-      const int j = A->h_col[k];
+      const int j = fh_hcol(A)[k];
       if (j < m && j != i && color[j] >= 0) mark[color[j]] = 1;
     }
     for (int k = tptr[i]; k < tptr[i + 1]; k++)
@@ -2545,6 +2545,7 @@ static int capture_cycle(fh_mg_t mg) {
   mg->graph_sig = 0;
   FH_TRY(run_cycle(mg));   // un-captured warm-up: builds lazily created row blocks, validates the launches
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  FH_TRACE("capture_cycle: warm-up cycle done");
   // distributed cycles are NOT captured: stream capture of the grouped ncclSend/ncclRecv (forked communication stream) was tried on
   // this stack (RCCL 2.26.6 of the PyTorch wheel, one-rank self exchange) and segfaults inside the library at capture time; the
   // launches of a distributed cycle are issued one by one
@@ -2653,7 +2654,9 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
       mg->cycle_bytes += (int64_t)L.npost * (bA + 2 * n8);
     }
   }
+  FH_TRACE("fh_mg_setup: levels set up");
   FH_TRY(coarse_factor(mg));
+  FH_TRACE("fh_mg_setup: coarse level factored");
   mg->cycle_bytes += 8ll * mg->lv[0].n * mg->lv[0].n + 16ll * mg->lv[0].n;
   mg->setup_done = true;
   mg->capturable = !distributed;

@@ -276,7 +276,7 @@ extern "C" int fh_ns_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, i
       const int r = es[(size_t)e * nd + i];
       for (int j = 0; j < nd; j++) {
         const int c = es[(size_t)e * nd + j];
-        FH_REQUIRE(std::binary_search(A->h_col.begin() + A->h_rowptr[r], A->h_col.begin() + A->h_rowptr[r + 1], c),
+        FH_REQUIRE(std::binary_search(fh_hcol(A).begin() + A->h_rowptr[r], fh_hcol(A).begin() + A->h_rowptr[r + 1], c),
                    "fh_ns_assembler_create: entry (%d, %d) is not in the matrix pattern", r, c);
       }
     }

@@ -399,9 +399,9 @@ static int triple_product(fh_mat_t R, fh_mat_t A, fh_mat_t P, fh_mat_t* Cio, con
     plan->a_nnz = A->nnz;
     plan->p_nnz = P->nnz;
     std::vector<int> ap_rp, ap_col, c_rp, c_col;
-    spgemm_symbolic(A->m, P->n, A->h_rowptr, A->h_col, P->h_rowptr, P->h_col, ap_rp, ap_col);
+    spgemm_symbolic(A->m, P->n, A->h_rowptr, fh_hcol(A), P->h_rowptr, fh_hcol(P), ap_rp, ap_col);
     FH_TRY(fh_mat_create_csr(A->ctx, A->m, P->n, ap_rp.data(), ap_col.data(), nullptr, &plan->AP));
-    spgemm_symbolic(R->m, P->n, R->h_rowptr, R->h_col, ap_rp, ap_col, c_rp, c_col);
+    spgemm_symbolic(R->m, P->n, R->h_rowptr, fh_hcol(R), ap_rp, ap_col, c_rp, c_col);
     FH_TRY(fh_mat_create_csr(A->ctx, R->m, P->n, c_rp.data(), c_col.data(), nullptr, &C));
     C->plan = plan;
     C->plan_destroy = destroy_plan;
@@ -443,7 +443,7 @@ extern "C" int fh_mat_matmul(fh_mat_t A, fh_mat_t B, fh_mat_t* Cout) {
   FH_REQUIRE(A && B && Cout, "fh_mat_matmul: null argument");
   FH_REQUIRE(A->n == B->m, "fh_mat_matmul: shapes do not conform (A %dx%d, B %dx%d)", A->m, A->n, B->m, B->n);
   std::vector<int> rp, col;
-  spgemm_symbolic(A->m, B->n, A->h_rowptr, A->h_col, B->h_rowptr, B->h_col, rp, col);
+  spgemm_symbolic(A->m, B->n, A->h_rowptr, fh_hcol(A), B->h_rowptr, fh_hcol(B), rp, col);
   fh_mat_t C = nullptr;
   FH_TRY(fh_mat_create_csr(A->ctx, A->m, B->n, rp.data(), col.data(), nullptr, &C));
   FH_TRY(spgemm_numeric(A, B, C));

@@ -48,18 +48,18 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
   T->m = A->m;
   T->A_uid = A->uid;
   std::vector<int> rows;
-  schedule(A->h_rowptr, A->h_col, A->m, true, T->fptr, rows);
+  schedule(A->h_rowptr, fh_hcol(A), A->m, true, T->fptr, rows);
   FH_CHECK_HIP(hipMalloc(&T->d_frows, std::max(A->m, 1) * sizeof(int)));
   FH_CHECK_HIP(hipMemcpy(T->d_frows, rows.data(), (size_t)A->m * sizeof(int), hipMemcpyHostToDevice));
-  schedule(A->h_rowptr, A->h_col, A->m, false, T->bptr, rows);
+  schedule(A->h_rowptr, fh_hcol(A), A->m, false, T->bptr, rows);
   FH_CHECK_HIP(hipMalloc(&T->d_brows, std::max(A->m, 1) * sizeof(int)));
   FH_CHECK_HIP(hipMemcpy(T->d_brows, rows.data(), (size_t)A->m * sizeof(int), hipMemcpyHostToDevice));
   std::vector<int> dpos(A->m, -1);
   for (int i = 0; i < A->m; i++) {
-    const int* b = A->h_col.data() + A->h_rowptr[i];
-    const int* e = A->h_col.data() + A->h_rowptr[i + 1];
+    const int* b = fh_hcol(A).data() + A->h_rowptr[i];
+    const int* e = fh_hcol(A).data() + A->h_rowptr[i + 1];
     const int* q = std::lower_bound(b, e, i);
-    if (q != e && *q == i) dpos[i] = (int)(q - A->h_col.data());
+    if (q != e && *q == i) dpos[i] = (int)(q - fh_hcol(A).data());
   }
   T->h_diagpos = dpos;
   FH_CHECK_HIP(hipMalloc(&T->d_diagpos, std::max(A->m, 1) * sizeof(int)));

@@ -79,8 +79,7 @@ class PoissonMG:
         levels = range(self.nlevels) if (self.coarse == "rediscretise" or self.gal_elem) else [top]
         for l in levels:
             ed, xy, _ = self.meshes[l].arrays()
-            rp, col = capi.pattern_from_elements(ed[:, :self.nc], self.ndof[l])
-            K = ctx.matrix_csr(self.ndof[l], self.ndof[l], rp, col)
+            K = ctx.matrix_from_elements(ed[:, :self.nc], self.ndof[l])        # GetSparsityPatternSize + init, on the device
             self.asm[l] = capi.Assembler(ctx, self.meshes[l], fe, K, self.order, elem_dof=ed, coords=xy)
             if self.Pamr[l] is not None:
                 self.KK[l] = K

@@ -234,6 +234,9 @@ int fh_mesh_dirichlet_dofs(fh_mesh_t mesh, int fe, int* n, int* dofs);
 /* ---- sparsity (a11): LinearEquation::GetSparsityPatternSize (03_solvers/LinearEquation.cpp:407-548) ----
  * CSR pattern of the element-connectivity graph: two-call protocol (rowptr first, then col). */
 int fh_pattern_from_elements(int nel, int nloc, const int* elem_dof, int ndof, int* rowptr /* [ndof+1] */, int* col /* NULL on first call */);
+/* the same pattern built ON THE DEVICE and made a matrix at once (m owned rows over n columns, values zero): node -> element lists by a counting
+ * pass, one wave per row sorts the candidate columns in LDS.  The column array stays on the device (host code that asks for it fetches it). */
+int fh_mat_create_from_elements(fh_ctx_t ctx, int nel, int nloc, const int* elem_dof, int m, int n, fh_mat_t* out);
 
 /* ---- prolongator (a14): LinearImplicitSystem::BuildProlongatorMatrix (LinearImplicitSystem.cpp:761-909) ----
  * builds P (fine x coarse) from the element prolongator; zero_bdc != 0 also applies

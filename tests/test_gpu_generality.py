@@ -76,3 +76,32 @@ def test_errors_are_reported_not_crashes(ctx):
     b, x = ctx.vector_from([1.0, 2.0, 3.0]), ctx.vector(3)
     mg.vcycle(b, x)                                                 # single level = direct solve
     assert np.allclose(x.to_numpy(), [1.0, 1.0, 1.0])
+
+
+def test_device_pattern_builder_equals_the_host_builder(ctx):
+    """fh_mat_create_from_elements (node -> element lists + one wave per row sorting its candidate columns in LDS) gives the pattern of
+    fh_pattern_from_elements on boxes, a 2-D mesh, Q1 tables, owned-rows x local-columns shapes and a shuffled element order; the tile-local
+    column lists of the SpMV (built on the device since round 4) give the product scipy computes on it"""
+    import scipy.sparse as sp
+    from femus_amd import capi
+    rng = np.random.default_rng(4)
+    for box, nl, nc in (((2, 2, 2), 2, 27), ((3, 2, 1), 2, 8), ((5, 4, 0), 2, 9), ((4, 4, 0), 1, 4), ((3, 3, 3), 2, 27)):
+        m = capi.Mesh.box(*box)
+        for _ in range(nl - 1):
+            m = m.refine()
+        ed = m.arrays()[0][:, :nc]
+        ed = ed[rng.permutation(ed.shape[0])]
+        n = int(ed.max()) + 1
+        rp, col = capi.pattern_from_elements(ed, n)
+        for rows in (n, (2 * n) // 3):
+            A = ctx.matrix_from_elements(ed, rows, n)
+            rpd, cold = A.pattern()
+            assert np.array_equal(rpd, rp[:rows + 1]) and np.array_equal(cold, col[:rp[rows]])
+            vals = rng.uniform(-1, 1, cold.size)
+            A.set_values(vals)
+            x = rng.uniform(-1, 1, n)
+            y = ctx.vector(rows)
+            y.matrix_mult(ctx.vector_from(x), A)
+            ref = sp.csr_matrix((vals, cold, rpd), shape=(rows, n)) @ x
+            assert np.abs(y.to_numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+            A.destroy()
