@@ -753,7 +753,7 @@ __global__ __launch_bounds__(256) void k_gather_perm(double* __restrict__ dst, c
   for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) dst[k] = src[perm[k]];
 }
 
-static int build_transpose(fh_mat_t A, fh_mat_t* out, int** d_perm_out) {
+static int build_transpose_host(fh_mat_t A, fh_mat_t* out, int** d_perm_out) {
   const int m = A->m, n = A->n, nnz = A->nnz;
   std::vector<int> trp(n + 1, 0), tcol(nnz), perm(nnz);
   for (int k = 0; k < nnz; k++) trp[fh_hcol(A)[k] + 1]++;
@@ -773,6 +773,114 @@ static int build_transpose(fh_mat_t A, fh_mat_t* out, int** d_perm_out) {
   *out = At;
   *d_perm_out = d_perm;
   FH_TRACE("build_transpose: %d x %d, %d non-zeros", m, n, nnz);
+  return 0;
+}
+
+// the same on the DEVICE (round 4): column counts by a counting pass, the host scans them, entries dropped into their transposed row through an
+// atomic cursor and every transposed row (<= TR_CAP entries) sorted by its column (= the source row) in LDS, the position in the source riding
+// along -- identical pattern and permutation as the host loop (which visits the rows in ascending order); longer rows: the host loop.
+constexpr int TR_CAP = 1024;
+__global__ __launch_bounds__(256) void k_tr_count(int nnz, const int* __restrict__ col, int* __restrict__ cnt) {
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < nnz; k += gridDim.x * 256) atomicAdd(&cnt[col[k]], 1);
+}
+__global__ __launch_bounds__(256) void k_tr_fill(int m, const int* __restrict__ rowptr, const int* __restrict__ col, int* __restrict__ cur, int* __restrict__ tcol,
+                                                 int* __restrict__ perm) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= m) return;
+  for (int k = rowptr[i] + lane; k < rowptr[i + 1]; k += 64) {
+    const int p = atomicAdd(&cur[col[k]], 1);
+    tcol[p] = i;
+    perm[p] = k;
+  }
+}
+__global__ __launch_bounds__(256) void k_tr_sort(int n, const int* __restrict__ trp, int* __restrict__ tcol, int* __restrict__ perm) {
+  __shared__ int keys[4][TR_CAP], pay[4][TR_CAP];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + wave;
+  if (j >= n) return;
+  const int s = trp[j], len = trp[j + 1] - s;
+  if (len <= 1) return;
+  int *key = keys[wave], *val = pay[wave];
+  int np = 64;
+  while (np < len) np <<= 1;
+  for (int k = lane; k < np; k += 64) {
+    key[k] = k < len ? tcol[s + k] : 0x7fffffff;
+    val[k] = k < len ? perm[s + k] : 0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int size = 2; size <= np; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = lane; t < (np >> 1); t += 64) {
+        const int lo = ((t / stride) * (stride << 1)) + (t % stride), hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const int a = key[lo], c = key[hi];
+        if ((a > c) == up) {
+          key[lo] = c;
+          key[hi] = a;
+          const int v = val[lo];
+          val[lo] = val[hi];
+          val[hi] = v;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  for (int k = lane; k < len; k += 64) {
+    tcol[s + k] = key[k];
+    perm[s + k] = val[k];
+  }
+}
+
+static int build_transpose(fh_mat_t A, fh_mat_t* out, int** d_perm_out) {
+  const int m = A->m, n = A->n, nnz = A->nnz;
+  fh_ctx_t c = A->ctx;
+  if (nnz == 0) return build_transpose_host(A, out, d_perm_out);
+  int* d_cnt = nullptr;
+  FH_CHECK_HIP(hipMalloc(&d_cnt, ((size_t)n + 1) * sizeof(int)));
+  FH_CHECK_HIP(hipMemsetAsync(d_cnt, 0, ((size_t)n + 1) * sizeof(int), c->stream));
+  hipLaunchKernelGGL(k_tr_count, dim3(std::min(fh_div_up(nnz, 256), c->num_cu * 16)), dim3(256), 0, c->stream, nnz, A->d_col, d_cnt);
+  std::vector<int> trp((size_t)n + 1, 0);
+  FH_CHECK_HIP(hipMemcpyAsync(trp.data() + 1, d_cnt, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  int maxrow = 0;
+  for (int j = 0; j < n; j++) {
+    maxrow = std::max(maxrow, trp[j + 1]);
+    trp[j + 1] += trp[j];
+  }
+  if (maxrow > TR_CAP) {
+    hipFree(d_cnt);
+    return build_transpose_host(A, out, d_perm_out);
+  }
+  fh_mat_t At = new fh_mat_s();
+  static std::atomic<uint64_t> next_uid{(uint64_t)1 << 41};
+  At->uid = next_uid++;
+  At->ctx = c;
+  At->m = n;
+  At->n = m;
+  At->nnz = nnz;
+  At->max_row = maxrow;
+  At->h_rowptr = trp;
+  int* d_perm = nullptr;
+  FH_CHECK_HIP(hipMalloc(&At->d_rowptr, ((size_t)n + 1) * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&At->d_col, ((size_t)nnz + 2) * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&At->d_val, ((size_t)nnz + 2) * sizeof(double)));
+  FH_CHECK_HIP(hipMalloc(&d_perm, (size_t)nnz * sizeof(int)));
+  FH_CHECK_HIP(hipMemsetAsync(At->d_col + nnz, 0, 2 * sizeof(int), c->stream));
+  FH_CHECK_HIP(hipMemsetAsync(At->d_val, 0, ((size_t)nnz + 2) * sizeof(double), c->stream));
+  FH_CHECK_HIP(hipMemcpyAsync(At->d_rowptr, trp.data(), ((size_t)n + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  FH_CHECK_HIP(hipMemcpyAsync(d_cnt, trp.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));          // cursors
+  hipLaunchKernelGGL(k_tr_fill, dim3(fh_div_up(m, 4)), dim3(256), 0, c->stream, m, A->d_rowptr, A->d_col, d_cnt, At->d_col, d_perm);
+  hipLaunchKernelGGL(k_tr_sort, dim3(fh_div_up(n, 4)), dim3(256), 0, c->stream, n, At->d_rowptr, At->d_col, d_perm);
+  FH_CHECK_HIP(hipGetLastError());
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  hipFree(d_cnt);
+  FH_TRY(fh_mat_build_rowblocks(At, c->spmv_tile));
+  *out = At;
+  *d_perm_out = d_perm;
+  FH_TRACE("build_transpose (device): %d x %d, %d non-zeros", m, n, nnz);
   return 0;
 }
 

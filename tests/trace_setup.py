@@ -26,10 +26,8 @@ A, asm = [], []
 for l in range(lv):
     ed, xy, _ = ms[l].arrays()
     t = tick("arrays() level %d" % l, t)
-    rp, col = capi.pattern_from_elements(ed[:, :27], ndof[l])
-    t = tick("pattern_from_elements level %d" % l, t)
-    K = ctx.matrix_csr(ndof[l], ndof[l], rp, col)
-    t = tick("matrix_csr level %d" % l, t)
+    K = ctx.matrix_from_elements(ed[:, :27], ndof[l])
+    t = tick("matrix_from_elements level %d" % l, t)
     asm.append(capi.Assembler(ctx, ms[l], fe, K, "seventh", elem_dof=ed, coords=xy))
     t = tick("Assembler level %d" % l, t)
     A.append(K)
