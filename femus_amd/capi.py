@@ -12,7 +12,7 @@ FE = {"linear": 0, "biquadratic": 2}
 GAUSS_ORDER = {"zero": 0, "first": 0, "second": 1, "third": 1, "fourth": 2, "fifth": 2,
                "sixth": 3, "seventh": 3, "eighth": 4, "ninth": 4}
 OUTER = {"preonly": 0, "richardson": 1, "gmres": 2, "cg": 3, "fgmres": 4}
-SMOOTH_JACOBI, SMOOTH_GS_COLOR, SMOOTH_VANKA, SMOOTH_SOR, SMOOTH_ILU0, SMOOTH_IDENTITY, SMOOTH_LU = 0, 1, 2, 3, 4, 5, 6
+SMOOTH_JACOBI, SMOOTH_GS_COLOR, SMOOTH_VANKA, SMOOTH_SOR, SMOOTH_ILU0, SMOOTH_IDENTITY, SMOOTH_LU, SMOOTH_ASM = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class FemusHipError(RuntimeError):

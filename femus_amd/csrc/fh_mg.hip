@@ -47,6 +47,11 @@ struct MgLevel {
   int pbar_len = 0;
   int64_t* d_poff = nullptr;
   double* d_pinv = nullptr;
+  // FH_SMOOTH_ASM (PCASM as the reference configures it): scratch of the block ILU(0) products and the pattern masks of the blocks; order_kind
+  // says how d_porder / d_pcptr were made (0: greedy colours, 1: dependency levels of the blocks in their index order)
+  double* d_pscr = nullptr;
+  unsigned char* d_pmask = nullptr;
+  int order_kind = -1;
   // distributed level: operator = owned rows over [owned | ghost] columns; halo refreshes the ghosts
   fh_halo_t halo = nullptr;
   bool replicated_below = false;
@@ -1391,9 +1396,9 @@ extern "C" int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh
   FH_REQUIRE(A->m <= A->n, "fh_mg_set_level: operator must be square (or owned rows x local columns on a distributed level)");
   FH_REQUIRE(level == 0 || P != nullptr, "fh_mg_set_level: level %d needs an interpolation matrix", level);
   FH_REQUIRE(!P || P->m == A->m, "fh_mg_set_level: interpolation has %d rows, operator has %d", P ? P->m : 0, A->m);
-  FH_REQUIRE(smoother >= FH_SMOOTH_JACOBI && smoother <= FH_SMOOTH_LU,
+  FH_REQUIRE(smoother >= FH_SMOOTH_JACOBI && smoother <= FH_SMOOTH_ASM,
              "fh_mg_set_level: unknown smoother %d (0 = Richardson+Jacobi, 1 = Richardson+multicolour SOR, 2 = block Schwarz / Vanka, "
-             "3 = Richardson+SOR in natural order, 4 = Richardson+ILU(0), 5 = no preconditioner, 6 = exact solve)", smoother);
+             "3 = Richardson+SOR in natural order, 4 = Richardson+ILU(0), 5 = no preconditioner, 6 = exact solve, 7 = PCASM basic / multiplicative with ILU(0) blocks)", smoother);
   FH_REQUIRE(npre >= 0 && npost >= 0, "fh_mg_set_level: negative sweep count");
   MgLevel& L = mg->lv[level];
   if (L.A_uid != A->uid) {   // another matrix (also one that landed on the address of a destroyed one): its graph may differ
@@ -1535,7 +1540,7 @@ static void free_level_colors(MgLevel& L) {
 // device side of the patch smoother (colouring by the matrix graph, inverses): rebuilt by the next setup; the patch lists stay
 static void free_level_patch_setup(MgLevel& L) {
   for (void** q : {(void**)&L.d_pptr, (void**)&L.d_pdofs, (void**)&L.d_porder, (void**)&L.d_pflag, (void**)&L.d_poff, (void**)&L.d_pinv, (void**)&L.d_pcptr,
-                   (void**)&L.d_pbar})
+                   (void**)&L.d_pbar, (void**)&L.d_pscr, (void**)&L.d_pmask})
     if (*q) {
       hipFree(*q);
       *q = nullptr;
@@ -1568,7 +1573,11 @@ extern "C" int fh_mg_set_level_patches(fh_mg_t mg, int level, int npatch, const 
 }
 
 // greedy colouring in patch order; two patches conflict when a dof of one appears in the matrix rows of the other
-static int color_patches(MgLevel& L) {
+// sequential = false: greedy colours (patches of a colour neither share nor read each other's dofs; colours in any order -- the Vanka smoother).
+// sequential = true (FH_SMOOTH_ASM): the blocks keep their INDEX ORDER, as PCASM's multiplicative composition visits them: block p gets the
+// dependency level 1 + max level of the earlier blocks it conflicts with, so a level holds blocks whose order among themselves does not matter and
+// the levels, run one after the other, give exactly the sequential sweep (level scheduling, as for the natural-order SOR / ILU sweeps)
+static int color_patches(MgLevel& L, bool sequential) {
   const int n = L.A->m, np = L.npatch;
   const std::vector<int>&rp = L.A->h_rowptr, &cl = fh_hcol(L.A);
   for (int d : L.h_pdofs) FH_REQUIRE(d >= 0 && d < n, "Vanka smoother: patch dof %d out of range", d);
@@ -1609,7 +1618,11 @@ static int color_patches(MgLevel& L) {
         if (color[reader[k]] >= 0) used[color[reader[k]]] = 1;
     }
     int c = 0;
-    while (used[c]) c++;
+    if (sequential) {
+      for (int k = 0; k < ncol; k++)
+        if (used[k]) c = k + 1;
+    } else
+      while (used[c]) c++;
     color[p] = c;
     ncol = std::max(ncol, c + 1);
   }
@@ -1636,7 +1649,89 @@ static int color_patches(MgLevel& L) {
   for (int c = 0; c < ncol; c++) L.vanka_maxcolor = std::max(L.vanka_maxcolor, L.vcolor_ptr[c + 1] - L.vcolor_ptr[c]);
   FH_CHECK_HIP(hipMalloc(&L.d_pflag, (size_t)np * sizeof(int)));
   FH_CHECK_HIP(hipMalloc(&L.d_pinv, (size_t)L.h_poff[np] * sizeof(double)));
+  if (sequential) {
+    FH_CHECK_HIP(hipMalloc(&L.d_pscr, (size_t)L.h_poff[np] * sizeof(double)));
+    FH_CHECK_HIP(hipMalloc(&L.d_pmask, (size_t)L.h_poff[np]));
+  }
+  L.order_kind = sequential ? 1 : 0;
   return 0;
+}
+
+// FH_SMOOTH_ASM: the sub-solve of a block is ONE application of ILU(0) of the block matrix in its natural (ascending dof) order with
+// PCFactorSetZeroPivot(1e-16) and MAT_SHIFT_NONZERO (LinearEquationSolverPetscAsm.cpp:278-335): the block matrix A_pp in M is replaced by the
+// product L~ U~ of its incomplete factors (restarted on A_pp + shift I, shift = 100 eps then doubled, when a pivot fails
+// |u_kk| > 1e-16 sum_{j>k} |u_kj|), which the patch inversion then turns into the dense operator (L~ U~)^-1 the sweep applies.  One workgroup
+// per block on global memory (setup); O: scratch of the same layout, mask: which entries of the block lie in the pattern of A.
+__global__ __launch_bounds__(256) void k_patch_ilu0(const int* __restrict__ pptr, const int* __restrict__ pdofs, const int64_t* __restrict__ poff,
+                                                    const int* __restrict__ rowptr, const int* __restrict__ col, double* __restrict__ M, double* __restrict__ O,
+                                                    unsigned char* __restrict__ mask, int* __restrict__ flag) {
+  __shared__ double s_shift, s_piv;
+  __shared__ int s_fail;
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const int* d = pdofs + pptr[p];
+  const int np = pptr[p + 1] - pptr[p];
+  double* Mp = M + poff[p];
+  double* Op = O + poff[p];
+  unsigned char* mk = mask + poff[p];
+  for (int t = tid; t < np * np; t += 256) {
+    const int r = d[t / np], c = d[t % np];
+    int lo = rowptr[r], hi = rowptr[r + 1] - 1, found = 0;
+    while (lo <= hi) {
+      const int mid = lo + ((hi - lo) >> 1);
+      const int cc = col[mid];
+      if (cc == c) { found = 1; break; }
+      if (cc < c) lo = mid + 1; else hi = mid - 1;
+    }
+    mk[t] = (unsigned char)found;
+    Op[t] = Mp[t];
+  }
+  if (tid == 0) s_shift = 0.0;
+  __syncthreads();
+  for (int attempt = 0; attempt < 64; attempt++) {
+    const double shift = s_shift;
+    for (int t = tid; t < np * np; t += 256) Mp[t] = Op[t] + ((t / np == t % np) ? shift : 0.0);
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    for (int k = 0; k < np; k++) {
+      if (tid == 0) {
+        const double piv = Mp[(size_t)k * np + k];
+        double rs = 0.0;
+        for (int j = k + 1; j < np; j++)
+          if (mk[(size_t)k * np + j]) rs += fabs(Mp[(size_t)k * np + j]);
+        if (!(fabs(piv) > 1e-16 * rs)) s_fail = 1;
+        s_piv = piv;
+      }
+      __syncthreads();
+      if (s_fail) break;
+      const double piv = s_piv;
+      for (int i = k + 1 + tid; i < np; i += 256)
+        if (mk[(size_t)i * np + k]) Mp[(size_t)i * np + k] /= piv;
+      __syncthreads();
+      const int w = np - k - 1;
+      for (int t = tid; t < w * w; t += 256) {
+        const int i = k + 1 + t / w, j = k + 1 + t % w;
+        if (mk[(size_t)i * np + k] && mk[(size_t)k * np + j] && mk[(size_t)i * np + j]) Mp[(size_t)i * np + j] -= Mp[(size_t)i * np + k] * Mp[(size_t)k * np + j];
+      }
+      __syncthreads();
+    }
+    if (!s_fail) break;
+    __syncthreads();
+    if (tid == 0) s_shift = shift == 0.0 ? 100.0 * 2.220446049250313e-16 : 2.0 * shift;
+    __syncthreads();
+  }
+  if (s_fail) {
+    if (tid == 0) flag[p] = 2;
+    return;
+  }
+  // M <- L~ U~ (entries outside the pattern of the factors are zero, so the dense product needs no masks)
+  for (int t = tid; t < np * np; t += 256) {
+    const int i = t / np, j = t % np, kmax = i < j ? i : j;
+    double a = 0.0;
+    for (int k = 0; k <= kmax; k++) a += (k == i ? 1.0 : Mp[(size_t)i * np + k]) * Mp[(size_t)k * np + j];
+    Op[t] = a;
+  }
+  __syncthreads();
+  for (int t = tid; t < np * np; t += 256) Mp[t] = Op[t];
 }
 
 // numeric part of the smoother setup (every fh_mg_setup, i.e. every Newton iteration): extract and invert the patch matrices
@@ -1645,6 +1740,9 @@ static int factor_patches(fh_mg_t mg, MgLevel& L) {
   FH_CHECK_HIP(hipMemsetAsync(L.d_pflag, 0, (size_t)L.npatch * sizeof(int), c->stream));
   hipLaunchKernelGGL(k_patch_extract, dim3(L.npatch), dim3(256), 0, c->stream, L.d_pptr, L.d_pdofs, L.d_poff, L.A->d_rowptr, L.A->d_col, L.A->d_val,
                      L.d_pinv);
+  if (L.smoother == FH_SMOOTH_ASM)
+    hipLaunchKernelGGL(k_patch_ilu0, dim3(L.npatch), dim3(256), 0, c->stream, L.d_pptr, L.d_pdofs, L.d_poff, L.A->d_rowptr, L.A->d_col, L.d_pinv, L.d_pscr, L.d_pmask,
+                       L.d_pflag);
   // patches of at most PLDS_MAX dofs: one wave each with the matrix in LDS; the others (and everything with patch_invert_lds = 0): the
   // workgroup kernel on the matrix in global memory
   int nsmall = 0;
@@ -1671,7 +1769,8 @@ static int factor_patches(fh_mg_t mg, MgLevel& L) {
   std::vector<int> flag(L.npatch);
   FH_CHECK_HIP(hipMemcpyAsync(flag.data(), L.d_pflag, flag.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
-  for (int p = 0; p < L.npatch; p++) FH_REQUIRE(flag[p] == 0, "Vanka smoother: the matrix of patch %d is singular", p);
+  for (int p = 0; p < L.npatch; p++)
+    FH_REQUIRE(flag[p] == 0, flag[p] == 2 ? "ASM smoother: ILU(0) of block %d found no usable pivots within 64 shifts" : "Vanka smoother: the matrix of patch %d is singular", p);
   return 0;
 }
 
@@ -2633,9 +2732,11 @@ extern "C" int fh_mg_setup(fh_mg_t mg) {
       }
       FH_TRY(fh_direct_factor(L.direct));
     }
-    if (L.smoother == FH_SMOOTH_VANKA && l > 0) {
-      FH_REQUIRE(L.npatch > 0 && !L.halo, "fh_mg_setup: level %d uses the Vanka smoother but has no patches (fh_mg_set_level_patches)", l);
-      if (!L.d_pinv) FH_TRY(color_patches(L));
+    if ((L.smoother == FH_SMOOTH_VANKA || L.smoother == FH_SMOOTH_ASM) && l > 0) {
+      FH_REQUIRE(L.npatch > 0 && !L.halo, "fh_mg_setup: level %d uses the block smoother but has no patches (fh_mg_set_level_patches)", l);
+      const int kind = L.smoother == FH_SMOOTH_ASM ? 1 : 0;
+      if (L.d_pinv && L.order_kind != kind) free_level_patch_setup(L);
+      if (!L.d_pinv) FH_TRY(color_patches(L, kind == 1));
       FH_TRY(factor_patches(mg, L));
     }
     if (l > 0) {
@@ -2696,6 +2797,13 @@ static int gs_sweeps(fh_mg_t mg, MgLevel& L, int nsweeps, bool zero_guess) {
       FH_TRY(halo_spmv(L.halo, L.A, L.x, L.n, L.r, 2, L.b, nullptr, 0.0));
     }
     double* z = L.x2;
+    if (L.smoother == FH_SMOOTH_ASM) {
+      // Richardson around PCASM: z = B r from zero (x2), the residual of the block sweep goes through dinv (unused by this smoother)
+      FH_CHECK_HIP(hipMemsetAsync(z, 0, (size_t)L.ncols * sizeof(double), c->stream));
+      FH_TRY(vanka_apply(mg, L, z, L.r, L.dinv, 1.0, 1));
+      hipLaunchKernelGGL(k_axpby2, dim3(sgrid(c, L.n)), dim3(256), 0, c->stream, L.x, z, L.omega, first ? 0.0 : 1.0, L.n);
+      continue;
+    }
     if (L.smoother == FH_SMOOTH_SOR || L.smoother == FH_SMOOTH_ILU0 || L.smoother == FH_SMOOTH_LU) {
       // z = B r in the natural row order, as the reference's PCSOR / PCILU apply it (level-scheduled, fh_trisolve.hip); PCLU: z = A^-1 r
       if (L.smoother == FH_SMOOTH_SOR) FH_TRY(fh_tri_ssor_apply(L.tri, L.A, L.dinv, L.r, z));
@@ -2775,6 +2883,7 @@ static int level_precond(fh_mg_t mg, MgLevel& L, const double* r, double* z) {
     case FH_SMOOTH_LU: return fh_direct_solve_ptr(L.direct, r, z);
     case FH_SMOOTH_GS_COLOR: return gs_color_apply(mg, L, r, z);
     case FH_SMOOTH_VANKA:
+    case FH_SMOOTH_ASM:           // PCApply_ASM: the blocks in order on the residual of r with the corrections so far, from zero
       FH_CHECK_HIP(hipMemsetAsync(z, 0, (size_t)L.ncols * sizeof(double), c->stream));
       return vanka_apply(mg, L, z, r, L.x2, 1.0, 1);
     default:
@@ -2850,7 +2959,8 @@ static int smooth_level(fh_mg_t mg, MgLevel& L, int nits, bool zero_guess, bool*
     if (zero_guess) FH_CHECK_HIP(hipMemsetAsync(L.x, 0, (size_t)L.ncols * sizeof(double), c->stream));
     return vanka_sweeps(mg, L, nits);
   }
-  if (L.smoother == FH_SMOOTH_GS_COLOR || L.smoother == FH_SMOOTH_SOR || L.smoother == FH_SMOOTH_ILU0 || L.smoother == FH_SMOOTH_LU)
+  if (L.smoother == FH_SMOOTH_GS_COLOR || L.smoother == FH_SMOOTH_SOR || L.smoother == FH_SMOOTH_ILU0 || L.smoother == FH_SMOOTH_LU ||
+      L.smoother == FH_SMOOTH_ASM)
     return gs_sweeps(mg, L, nits, zero_guess);
   int s = 0;
   if (zero_guess) {

@@ -125,7 +125,7 @@ class NavierStokesMG:
                 self.mg[ig].set_level_patches(l, *self.patches[l])
         mg = self.mg[ig]
         for l in range(ig + 1):
-            mg.set_level(l, self.A[(ig, l)], self.P[l] if l > 0 else None, None, capi.SMOOTH_VANKA, self.omega,
+            mg.set_level(l, self.A[(ig, l)], self.P[l] if l > 0 else None, None, getattr(self, "smoother", capi.SMOOTH_VANKA), self.omega,
                          self.npre if l > 0 else 1, self.npost if l > 0 else 0)
         mg.setup()
         return mg

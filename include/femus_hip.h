@@ -369,8 +369,15 @@ int fh_ns_element_matrices(fh_ns_assembler_t as, fh_vec_t sol, double nu, double
  *                       every fh_mg_setup; level-scheduled triangular solves
  *   FH_SMOOTH_IDENTITY  PCNONE (IDENTITY_PRECOND, PetscPreconditioner.cpp:75-77): B = I
  *   FH_SMOOTH_LU        PCLU (LU_PRECOND / MLU_PRECOND as the preconditioner of a level solver, PetscPreconditioner.cpp:147-160): B = A^-1 by the sparse
- *                       exact solve (fh_direct_*; symmetric level operators), refactored at every fh_mg_setup; fh_mg_set_level_coords is optional */
-enum { FH_SMOOTH_JACOBI = 0, FH_SMOOTH_GS_COLOR = 1, FH_SMOOTH_VANKA = 2, FH_SMOOTH_SOR = 3, FH_SMOOTH_ILU0 = 4, FH_SMOOTH_IDENTITY = 5, FH_SMOOTH_LU = 6 };
+ *                       exact solve (fh_direct_*; symmetric level operators), refactored at every fh_mg_setup; fh_mg_set_level_coords is optional
+ *   FH_SMOOTH_ASM       PCASM as FEMuS_ASM configures it (PetscPreconditioner.cpp:179-184: PC_ASM_BASIC + PC_COMPOSITE_MULTIPLICATIVE; sub-solves
+ *                       LinearEquationSolverPetscAsm.cpp:278-335): B r = the blocks of fh_mg_set_level_patches visited in their INDEX ORDER from a zero
+ *                       correction, block p adding (L~ U~)^-1 (r - A y)_p over its whole (overlapping) dof set, L~ U~ = ILU(0) of the block matrix in
+ *                       ascending dof order, zero pivot 1e-16, MAT_SHIFT_NONZERO.  The sequential order is kept by level scheduling (blocks that do
+ *                       not touch each other's rows run beside each other).  FH_SMOOTH_VANKA is this library's own variant of the same smoother:
+ *                       exact block inverses, damped, in colour order */
+enum { FH_SMOOTH_JACOBI = 0, FH_SMOOTH_GS_COLOR = 1, FH_SMOOTH_VANKA = 2, FH_SMOOTH_SOR = 3, FH_SMOOTH_ILU0 = 4, FH_SMOOTH_IDENTITY = 5, FH_SMOOTH_LU = 6,
+       FH_SMOOTH_ASM = 7 };
 /* outer solver of fh_mg_solve (`SetOuterSolver`, `_mgSolverType`; KSP types of LinearEquationSolverPetsc.cpp:455-529): one cycle,
  * Richardson, left-preconditioned GMRES, CG, and flexible (right-preconditioned) GMRES for cycles that are not a fixed linear
  * operator (GMRES level solvers) */

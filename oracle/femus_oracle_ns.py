@@ -223,6 +223,47 @@ class VankaSmoother:
         return x
 
 
+class AsmSmoother:
+    """PCASM as FEMuS_ASM configures it -- PC_ASM_BASIC + PC_COMPOSITE_MULTIPLICATIVE (PetscPreconditioner.cpp:179-184), sub-solves = one application
+    of ILU(0) of the block matrix in ascending dof order, zero pivot 1e-16, MAT_SHIFT_NONZERO (LinearEquationSolverPetscAsm.cpp:278-335) -- restated
+    from PETSc 3.20's PCApply_ASM (parity unpinned: PETSc is not in the image): from y = 0 the blocks in INDEX order,
+    y[d_i] += (L~ U~)_i^-1 (r - A y)[d_i] over the whole overlapping dof set d_i.  sweep = one Richardson(omega) iteration around it."""
+
+    def __init__(self, A, patches, omega=1.0, pattern=None):
+        """pattern = (rowptr, col) of the STORED entries of the level operator (the allocation the factorisation fills: element couplings on the
+        assembled level, the symbolic triple product below it -- zeros included, which a scipy product may have dropped); None: A's own"""
+        self.A = A.tocsr()
+        self.patches = [np.sort(np.asarray(d)) for d in patches]
+        self.omega = omega
+        S = self.A
+        if pattern is not None:
+            rp, col = np.asarray(pattern[0], np.int64), np.asarray(pattern[1], np.int64)
+            n = self.A.shape[0]
+            pkey = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp)) * n + col          # ascending: rows ascending, columns sorted in a row
+            C = self.A.tocoo()
+            keep = C.data != 0.0
+            akey = C.row[keep].astype(np.int64) * n + C.col[keep]
+            pos = np.searchsorted(pkey, akey)
+            assert np.all(pos < pkey.size) and np.all(pkey[np.minimum(pos, pkey.size - 1)] == akey), "the operator has entries outside the given pattern"
+            vals = np.zeros(pkey.size)
+            vals[pos] = C.data[keep]
+            S = sp.csr_matrix((vals, col, rp), shape=self.A.shape)              # explicit zeros stay (no arithmetic on S as a whole)
+        self.ilu = []
+        for d in self.patches:
+            B = S[d][:, d].tocsr()
+            self.ilu.append(fo.ilu0_factor(B))
+
+    def apply(self, r):
+        y = np.zeros_like(r)
+        for d, LU in zip(self.patches, self.ilu):
+            t = r[d] - self.A[d] @ y
+            y[d] += fo.ilu0_apply(LU, t)
+        return y
+
+    def sweep(self, b, x):
+        return x + self.omega * self.apply(b - self.A @ x)
+
+
 class NSHierarchy:
     pass
 
@@ -301,7 +342,7 @@ def build_ns_levels(nx, ny, nz, nlevels, lo, hi):
     return ms, lays
 
 
-def newton_step_operators(ms, lays, bcs, igrid, sol, nu, omega=0.6, npre=2, npost=2, order="seventh"):
+def newton_step_operators(ms, lays, bcs, igrid, sol, nu, omega=0.6, npre=2, npost=2, order="seventh", smoother="vanka", patterns=None):
     """assemble at level igrid, Galerkin chain, penalty rows, smoothers: everything one Newton iteration prepares"""
     H = NSHierarchy()
     A, b = assemble_ns(ms[igrid], lays[igrid], sol, nu, order)
@@ -321,7 +362,8 @@ def newton_step_operators(ms, lays, bcs, igrid, sol, nu, omega=0.6, npre=2, npos
     H.smoother = [None] * (igrid + 1)
     for l in range(1, igrid + 1):
         patches = vertex_patches(ms[l], lays[l])
-        H.smoother[l] = VankaSmoother(H.A[l], patches, color_patches(patches, H.A[l]), omega)
+        H.smoother[l] = (AsmSmoother(H.A[l], patches, omega, None if patterns is None else patterns[l]) if smoother == "asm" else
+                         VankaSmoother(H.A[l], patches, color_patches(patches, H.A[l]), omega))
     lu = spla.splu(H.A[0].tocsc())
     H.coarse_solve = lu.solve
     return H

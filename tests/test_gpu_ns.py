@@ -186,3 +186,45 @@ def test_three_dimensional_cavity_matches_oracle(ctx):
             sols[ig + 1] = ns.block_prolongator(ms[ig], ms[ig + 1], lays[ig], lays[ig + 1]) @ sols[ig]
     assert rel(pb.SOL[-1].to_numpy(), sols[-1]) < 1e-8
     pb.destroy()
+
+
+@pytest.mark.parametrize("level_solver", ["richardson", "gmres"])
+def test_pcasm_as_the_reference_configures_it(ctx, level_solver):
+    """FH_SMOOTH_ASM: PC_ASM_BASIC + PC_COMPOSITE_MULTIPLICATIVE over the element blocks in their index order with ILU(0) (zero pivot 1e-16,
+    MAT_SHIFT_NONZERO) sub-solves (PetscPreconditioner.cpp:179-184, LinearEquationSolverPetscAsm.cpp:278-335): one V(2,2) cycle on the
+    Jacobian of a non-trivial state against the oracle's sequential restatement, Richardson and GMRES level solvers"""
+    nu, nl = 0.01, 3
+    pb = NavierStokesMG(ctx, 4, 4, 0, nl, nu).init()
+    pb.smoother = capi.SMOOTH_ASM
+    ms, lays = ns.build_ns_levels(4, 4, 0, nl, LO, HI)
+    bcs = [ns.cavity_bc(m, l) for m, l in zip(ms, lays)]
+    rng = np.random.default_rng(5)
+    top = nl - 1
+    state = 0.3 * rng.standard_normal(lays[top].n)
+    state[bcs[top][0]] = bcs[top][1]
+    pb.SOL[top].upload(state)
+    mg = pb.prepare(top)
+    if level_solver == "gmres":
+        for l in range(1, nl):
+            mg.set_level_solver(l, "gmres", 30)
+        mg.setup()
+    # ILU(0) fills the ALLOCATED pattern (stored zeros included): the pattern is taken from the device operators, the values are the oracle's
+    H = ns.newton_step_operators(ms, lays, bcs, top, state, nu, omega=pb.omega, npre=pb.npre, npost=pb.npost, smoother="asm",
+                                 patterns=[pb.A[(top, l)].pattern() for l in range(nl)])
+    b = rng.standard_normal(lays[top].n)
+    b[bcs[top][0]] = 0.0
+    x = ctx.vector(lays[top].n)
+    mg.vcycle(ctx.vector_from(b), x)
+    if level_solver == "richardson":
+        ref = ns.vcycle(H, top, b)
+    else:
+        def cyc(level, rhs):
+            if level == 0:
+                return H.coarse_solve(rhs)
+            A, sm = H.A[level], H.smoother[level]
+            xx = fo.smooth_gmres(A, rhs, np.zeros_like(rhs), H.npre, True, sm.apply)
+            xx = xx + H.P[level] @ cyc(level - 1, H.P[level].T @ (rhs - A @ xx))
+            return fo.smooth_gmres(A, rhs, xx, H.npost, False, sm.apply)
+        ref = cyc(top, b)
+    assert rel(x.to_numpy(), ref) < 1e-9
+    pb.destroy()
