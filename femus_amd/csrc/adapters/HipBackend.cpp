@@ -641,7 +641,7 @@ void LinearEquationSolverHip::MGSetLevel(LinearEquationSolver* LinSolver, const 
     _richardsonScaleFactor = 1.;
   }
   const int smoother = smoother_id();
-  if (_level != 0 && smoother != FH_SMOOTH_VANKA && _preconditioner_type != JACOBI_PRECOND && _preconditioner_type != SOR_PRECOND &&
+  if (_level != 0 && smoother != FH_SMOOTH_VANKA && smoother != FH_SMOOTH_ASM && _preconditioner_type != JACOBI_PRECOND && _preconditioner_type != SOR_PRECOND &&
       _preconditioner_type != ILU_PRECOND && _preconditioner_type != IDENTITY_PRECOND && _preconditioner_type != LU_PRECOND &&
       _preconditioner_type != MLU_PRECOND) {
     std::cout << "HIP backend: level preconditioner must be JACOBI_PRECOND, SOR_PRECOND, ILU_PRECOND, LU_PRECOND / MLU_PRECOND or IDENTITY_PRECOND (or the FEMuS_ASM solver)" << std::endl;

@@ -243,14 +243,18 @@ class LinearEquationSolverHipAsm : public LinearEquationSolverHip {
   void SetElementBlockNumber(const unsigned& n) override { _elementBlockNumber = n; }
   void SetNumberOfSchurVariables(const unsigned short& n) override { _NSchurVar = n; }
   void SetAsmBlocks(const std::vector<int>& ptr, const std::vector<int>& dofs) { _blockPtr = ptr; _blockDofs = dofs; _blocksGiven = true; }   // not a FEMuS member: overrides BuildASMIndex
+  void SetAsmExactInColourOrder(bool on) { _exactColoured = on; }                // not a FEMuS member: see smoother_id
   void BuildASMIndex(const std::vector<unsigned>& variable_to_be_solved);       // petsc_asm/LinearEquationSolverPetscAsm.cpp:91-276
 
  protected:
-  int smoother_id() const override { return FH_SMOOTH_VANKA; }
+  // SetPreconditionerFineGrids(ILU_PRECOND) -- what the Navier-Stokes applications set -- gives PCASM as the reference configures it: basic /
+  // multiplicative over the blocks in index order, one ILU(0) application per block (FH_SMOOTH_ASM).  Any other preconditioner type, or
+  // SetAsmExactInColourOrder(true) (not a FEMuS member), gives this library's variant: exact block inverses, damped, colour order (FH_SMOOTH_VANKA)
+  int smoother_id() const override { return (_preconditioner_type == ILU_PRECOND && !_exactColoured) ? FH_SMOOTH_ASM : FH_SMOOTH_VANKA; }
   void attach_smoother_data(fh_mg_t mg, int level, const std::vector<unsigned>& variable_to_be_solved) override;
 
  private:
-  bool _blocksGiven = false;
+  bool _blocksGiven = false, _exactColoured = false;
   unsigned _elementBlockNumber = 1;
   unsigned short _NSchurVar = 1;
   std::vector<int> _blockPtr, _blockDofs;

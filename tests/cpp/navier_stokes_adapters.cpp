@@ -33,7 +33,8 @@ int main(int argc, char** argv) {
   if (argc < 5) return 2;
   const int n = atoi(argv[1]), nlev = atoi(argv[2]);
   const double nu = atof(argv[3]);
-  const int nschur = argc > 5 ? atoi(argv[5]) : 0, nblock = argc > 6 ? atoi(argv[6]) : 4, lsolver = argc > 7 ? atoi(argv[7]) : 0, outer_pre = argc > 8 ? atoi(argv[8]) : 0;
+  const int nschur = argc > 5 ? atoi(argv[5]) : 0, nblock = argc > 6 ? atoi(argv[6]) : 4, lsolver = argc > 7 ? atoi(argv[7]) : 0, outer_pre = argc > 8 ? atoi(argv[8]) : 0,
+            coloured = argc > 9 ? atoi(argv[9]) : 0;     // 1: the library's own block smoother (exact inverses in colour order) instead of PCASM as the reference sets it
   const int geom = 1, nvars = 3, fe[3] = {2, 2, 0};
   const char names[3] = {'U', 'V', 'P'};
   const double lo[3] = {-0.5, -0.5, 0}, hi[3] = {0.5, 0.5, 1};
@@ -149,7 +150,8 @@ int main(int argc, char** argv) {
     Sol[l]->insert_vector_blocked(vals, bdc[l]);
     ls->set_solver_type(lsolver == 0 ? GMRES : RICHARDSON);                       // SetSolverFineGrids(GMRES)
     if (lsolver) ls->SetRichardsonScaleFactor(0.6);
-    ls->set_preconditioner_type(ILU_PRECOND);         // SetPreconditionerFineGrids(ILU_PRECOND): the sub-solve of the blocks (exact here)
+    ls->set_preconditioner_type(ILU_PRECOND);         // SetPreconditionerFineGrids(ILU_PRECOND): one ILU(0) application per block
+    ls->SetAsmExactInColourOrder(coloured != 0);
     if (l > 0) {
       for (int copy = 0; copy < 2; copy++) {
         fh_mat_t P;

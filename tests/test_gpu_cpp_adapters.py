@@ -61,10 +61,8 @@ def test_navier_stokes_application_over_the_adapters(tmp_path, nschur, nblock, l
     non-stationary preconditioner of the (non-flexible) outer GMRES: the linear solves are a little less exact, the Newton history may be
     a few steps longer than the oracle's (exact linear solves), the discrete solution is the same; with the FLEXIBLE outer solver
     (SetOuterSolver(FGMRES), a case of the reference's switch) the linear solves are exact again, also with the application's own block
-    parameters (0, 4) and GMRES level solvers.  Not covered: the application's exact
-    combination -- blocks (0, 4) WITH the GMRES level solver and two PREONLY cycles per nonlinear step -- does not converge in this
-    restatement on the 16 x 16 test mesh (exact block solves in colour order instead of PETSc's sequential ILU sub-solves; parity
-    unpinned)."""
+    parameters (0, 4) and GMRES level solvers.  This test runs the library's own block smoother (exact block inverses in colour order,
+    SetAsmExactInColourOrder); PCASM as the reference configures it is the next test."""
     from oracle import femus_oracle_ns as ns
     lib = os.path.join(ROOT, "femus_amd", "lib")
     exe = str(tmp_path / "navier_stokes_adapters")
@@ -73,7 +71,7 @@ def test_navier_stokes_application_over_the_adapters(tmp_path, nschur, nblock, l
                            "-L" + lib, "-lfemus_hip_adapters", "-lfemus_hip", "-Wl,-rpath," + lib])
     out = str(tmp_path / "ns.bin")
     log = subprocess.check_output([exe, "4", "3", "0.01", out, str(nschur), str(nblock), "0" if level_solver == "gmres" else "1",
-                                   "2" if outer == "fgmres" else "0"], text=True)
+                                   "2" if outer == "fgmres" else "0", "1"], text=True)       # last argument 1: the library's colour-ordered exact block smoother
     assert "Nonlinear iteration" in log
     _, lays, sols, hist = ns.solve_cavity(4, 4, 3, 0.01, (-0.5, -0.5, 0.0), (0.5, 0.5, 0.0), linear="direct")
     steps = int(log.split("newton steps = ")[1].split()[0])
@@ -87,6 +85,30 @@ def test_navier_stokes_application_over_the_adapters(tmp_path, nschur, nblock, l
         assert len(hist) <= steps <= len(hist) + 6
     sol = np.fromfile(out)
     assert sol.size == sols[-1].size
+    assert np.linalg.norm(sol - sols[-1]) <= 1e-8 * np.linalg.norm(sols[-1])
+
+
+@pytest.mark.parametrize("nschur,nblock,outer", [(1, 4, "gmres"), (0, 4, "fgmres")])
+def test_navier_stokes_application_with_pcasm_as_the_reference_sets_it(tmp_path, nschur, nblock, outer):
+    """the same driver with SetPreconditionerFineGrids(ILU_PRECOND) meaning what it means in the reference: PCASM basic / multiplicative over the
+    blocks of BuildASMIndex in index order, one ILU(0) application (zero pivot 1e-16, MAT_SHIFT_NONZERO) per block (FH_SMOOTH_ASM), GMRES level
+    solvers.  Newton reaches the oracle's discrete solution with the pressure as Schur variable under GMRES and with the application's block
+    parameters (0, 4) under the flexible outer solver.  The application's remaining setting -- SetOuterSolver(PREONLY) with two cycles per Newton
+    step -- does not converge on THIS discretisation with either block smoother: SteadyNavierStokesParallel/main.cpp:96-103 solves an equal-order
+    Q1/Q1 system (its assembly callback carries the stabilisation, a non-zero pressure block), while BASELINE config 4 names Taylor-Hood Q2/Q1,
+    whose pressure block is zero (every pressure pivot of a block needs the shift)."""
+    from oracle import femus_oracle_ns as ns
+    lib = os.path.join(ROOT, "femus_amd", "lib")
+    exe = str(tmp_path / "navier_stokes_adapters")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "femus_amd", "csrc", "adapters")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["g++", "-O1", "-std=c++17"] + INC + [os.path.join(ROOT, "tests", "cpp", "navier_stokes_adapters.cpp"), "-o", exe,
+                           "-L" + lib, "-lfemus_hip_adapters", "-lfemus_hip", "-Wl,-rpath," + lib])
+    out = str(tmp_path / "ns.bin")
+    log = subprocess.check_output([exe, "4", "3", "0.01", out, str(nschur), str(nblock), "0", "2" if outer == "fgmres" else "0", "0"], text=True)
+    _, lays, sols, hist = ns.solve_cavity(4, 4, 3, 0.01, (-0.5, -0.5, 0.0), (0.5, 0.5, 0.0), linear="direct")
+    steps = int(log.split("newton steps = ")[1].split()[0])
+    assert len(hist) <= steps <= len(hist) + 8
+    sol = np.fromfile(out)
     assert np.linalg.norm(sol - sols[-1]) <= 1e-8 * np.linalg.norm(sols[-1])
 
 
