@@ -184,6 +184,7 @@ def main():
     for _ in range(reps):
         pb.assemble()
     asm_ms = comm.allreduce_max(ctx.timer_stop() / reps)
+    asm_path = pb.asm_top.last_path()
     # "one full matrix+RHS assembly into CSR (zero -> element loop -> close -> Dirichlet rows)": with SetPenalty and
     # ZerosBoundaryResiduals -- this is what assembled_dofs_per_sec is quoted on
     barrier()
@@ -379,6 +380,8 @@ def main():
             "first_kernel_ms": elem_ms,
             "second_pass_ms": asm_ms - elem_ms,
             "fused": fused,
+            "path_of_the_timed_assemblies": asm_path,
+            "path_note": "assemble_fused = 1 picks per assembly: fused, unless the element-wise Galerkin product asked for the element rows of the previous assembly (then two-pass, which keeps them: the assemblies inside `solve`)",
             "executed_tflops": ELEM_EXECUTED_FLOPS * nel / elem_ms / 1e9,
             "executed_frac_fp64_peak": ELEM_EXECUTED_FLOPS * nel / elem_ms / 1e9 / FP64_VALU_PEAK_TFLOPS,
             "flops_model": "EXECUTED flops per element of the first kernel: (361 FMA x 2 + 51 MUL + 20 ADD) x 64 lanes + 15 MFMA x 512 = %d (instruction counts "

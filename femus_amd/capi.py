@@ -771,6 +771,12 @@ class Assembler:
         _chk(self.L.fh_assembler_affine_count(self.h, ctypes.byref(a), ctypes.byref(g)))
         return a.value, g.value
 
+    def last_path(self):
+        """what the last assembly ran: "fused", "two-pass" or None"""
+        v = ctypes.c_int()
+        _chk(self.L.fh_assembler_last_path(self.h, ctypes.byref(v)))
+        return {1: "fused", 2: "two-pass"}.get(v.value)
+
     def fused_info(self):
         """fused cluster assembly: is it the path that runs, clusters, doubles in the partial-row buffer, rows of the second pass"""
         a, n, r = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

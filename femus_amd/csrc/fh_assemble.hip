@@ -57,6 +57,8 @@ struct fh_assembler_s {
   // (the children of one coarse element: 125 macro nodes).  Plan = tables of the template + per-cluster destinations and maps.
   bool fused = false;            // plan built and verified
   bool kbuf_valid = false;       // the element-row buffer holds the matrices of the last assembly (the fused path does not write it)
+  bool rows_used_since = false;  // the element-wise Galerkin product asked for the element rows since the last assembly: the next assembly keeps them (two-pass)
+  int last_path = 0;             // 1: the last assembly ran the fused path, 2: two-pass
   int cl_ncl = 0, cl_nm = 0, cl_ns = 0, cl_nprow = 0;
   size_t cl_npart = 0;           // entries of the partial-row buffer (without the sink)
   unsigned* d_cl_sinfo = nullptr;
@@ -2953,7 +2955,13 @@ static int assemble_poisson_core(fh_assembler_t as, fh_vec_t sol, int source_kin
     as->last_params[0] = P.p0;
     as->last_params[1] = P.p1;
     if (as->ctx->assemble_affine) FH_TRY(ensure_affine(as));
-    if (as->fused && as->ctx->assemble_fused && as->ctx->assemble_sf && !(as->ctx->assemble_affine && as->d_Mab && as->n_aff > 0) && !(as->ctx->asm_debug & 16)) {
+    // assemble_fused 1 (default): the fused path, unless the element rows of the PREVIOUS assembly were asked for by the element-wise Galerkin product
+    // (a solve that re-prepares after every assembly: the two-pass path leaves the rows in place, re-creating them would cost 0.66 ms at 64^3);
+    // 2: always fused; 0: never
+    const bool keep_rows = as->ctx->assemble_fused == 1 && as->rows_used_since;
+    as->rows_used_since = false;
+    if (as->fused && as->ctx->assemble_fused && !keep_rows && as->ctx->assemble_sf && !(as->ctx->assemble_affine && as->d_Mab && as->n_aff > 0) && !(as->ctx->asm_debug & 16)) {
+      as->last_path = 1;
       // fused cluster assembly: complete rows straight into the CSR arrays, the others through the partial-row buffer (the element-row buffer is not written)
       as->kbuf_valid = false;
       FH_TRY(launch_cluster(as, P, A, res->d));
@@ -2961,6 +2969,7 @@ static int assemble_poisson_core(fh_assembler_t as, fh_vec_t sol, int source_kin
       return 0;
     }
     as->kbuf_valid = true;
+    as->last_path = 2;
     if (as->ctx->assemble_affine && as->d_Mab && as->n_aff > 0) {
       // affine elements through the reference-matrix kernel, the rest (curved ones) through the quadrature kernel
       AsmParams Pa = P;
@@ -3064,6 +3073,12 @@ extern "C" int fh_assembler_affine_count(fh_assembler_t as, int* n_affine, int* 
   FH_TRY(ensure_affine(as));
   if (n_affine) *n_affine = as->d_Mab ? as->n_aff : 0;
   if (n_general) *n_general = as->d_Mab ? as->n_gen : as->nel;
+  return 0;
+}
+
+extern "C" int fh_assembler_last_path(fh_assembler_t as, int* path) {
+  FH_REQUIRE(as && path, "fh_assembler_last_path: null argument");
+  *path = as->last_path;
   return 0;
 }
 
@@ -3354,6 +3369,7 @@ extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, con
   FH_REQUIRE(fas->nel == cas->nel * nch, "fh_assembler_galerkin: %d fine elements are not the uniform refinement of %d coarse ones", fas->nel, cas->nel);
   FH_REQUIRE(Ac->m == cas->ndof, "fh_assembler_galerkin: the coarse matrix does not belong to the coarse assembler");
   fh_ctx_t c = cas->ctx;
+  fas->rows_used_since = true;                              // (the next assembly of this level keeps its element rows)
   if (!fas->kbuf_valid) FH_TRY(element_rows_again(fas));     // the fused assembly keeps no element rows: pass 1 of the two-pass path with the last arguments
   auto up = [&](void** d, const void* h, size_t bytes) -> int {
     if (*d) FH_CHECK_HIP(hipFree(*d));

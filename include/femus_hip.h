@@ -296,6 +296,10 @@ int fh_assembler_affine_count(fh_assembler_t as, int* n_affine, int* n_general);
  * (or the option is off) and the two-pass path runs.  partial_entries = doubles in the partial-row buffer, second_pass_rows = CSR rows summed
  * by the second pass (the scatter of separate.hpp:165-205 through PetscMatrix.cpp:699-729 is what both paths replace). */
 int fh_assembler_fused_info(fh_assembler_t as, int* active, int* nclusters, int64_t* partial_entries, int* second_pass_rows);
+/* "assemble_fused" = 1 chooses per assembly: the fused path, unless fh_assembler_galerkin asked for the element rows of the PREVIOUS assembly (a solve that
+ * re-prepares its hierarchy after every assembly: the two-pass path leaves the rows in place); 2 = always fused (the rows are re-created when asked for),
+ * 0 = never.  path: what the last assembly ran, 1 = fused, 2 = two-pass, 0 = none yet / another path */
+int fh_assembler_last_path(fh_assembler_t as, int* path);
 
 /* Neumann boundary term of the 001_Poisson callback (applications/001_Poisson/main.cpp:560-594): for every listed boundary face
  * res[node_i] += int_face phi_i * tau ds with elem_type::JacobianSur (ElemType.hpp:1089-1138 edges, :1330-1380 quad faces).

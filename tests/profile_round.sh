@@ -75,4 +75,7 @@ PY
 rm -rf /tmp/prof/prep
 PYTHONPATH=$ROOT timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/prep -- python $ROOT/tests/perf_probe_prepare.py 8 128 > /tmp/prof/prep.log 2>&1 || echo "prepare trace failed"
 python $ROOT/profiles/summarize.py /tmp/prof/prep $OUT/${TAG}_prepare_kernel_summary.md > /dev/null
+# ---- config 5 on one GPU (first assembly / preparation included) and the sparse exact solve ----
+python $ROOT/tests/perf_probe_amr.py 8 2> /dev/null | grep '^{' | head -1 > $OUT/${TAG}_amr_probe.json
+python $ROOT/tests/perf_probe_direct.py 1 2 3 2> /dev/null | grep '^n ' > $OUT/${TAG}_direct_probe.txt
 tail -c 600 $OUT/${TAG}_bench_line.json

@@ -148,3 +148,22 @@ def test_elementwise_galerkin_after_a_fused_assembly(ctx):
             ctx.set_option("assemble_fused", 1)
     for a, b in zip(vals[1], vals[0]):
         assert abs(a - b).max() <= 1e-13 * abs(b).max()
+    # assemble_fused = 1 picks per assembly: two-pass when the Galerkin product used the element rows of the previous assembly, fused otherwise;
+    # 2 = always fused (the product re-creates the rows every time); the operators are the same on every route
+    for mode in (1, 2):
+        ctx.set_option("assemble_fused", mode)
+        try:
+            pb = PoissonMG(ctx, 2, 2, 2, 3).init()
+            pb.assemble()
+            assert pb.asm[-1].last_path() == "fused"
+            pb.prepare()
+            pb.assemble()
+            assert pb.asm[-1].last_path() == ("two-pass" if mode == 1 else "fused")
+            pb.assemble()
+            assert pb.asm[-1].last_path() == "fused"            # nobody asked for the rows in between
+            pb.prepare()
+            for a, b in zip([pb.A[l].to_scipy() for l in range(pb.nlevels)], vals[0]):
+                assert abs(a - b).max() <= 1e-13 * abs(b).max()
+            pb.destroy()
+        finally:
+            ctx.set_option("assemble_fused", 1)
