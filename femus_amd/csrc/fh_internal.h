@@ -112,6 +112,7 @@ struct fh_ctx_s {
   int use_graph = 1;
   int mg_reuse_graph = 1;            // a repeated fh_mg_setup of an unchanged hierarchy keeps the captured cycle
   int opt_gen = 0;                   // bumped by every fh_set_option (captured launches depend on the options)
+  int spgemm_device_symbolic = 1;    // patterns of sparse products are built on the device (0: host builder)
   int spgemm_slot_map = 1;           // Galerkin products stream a precomputed slot map instead of searching
   int halo_overlap = 1;              // distributed operators: rows without ghost columns run while the ghost exchange is in flight
   int halo_profile = 0;              // time every exchange and the part of it the compute stream waited for (fh_halo_stats; synchronises)
@@ -188,6 +189,7 @@ int fh_inv_sym_batched(fh_ctx_t c, const InvDesc* d_desc, int k, int nmax);
 
 // host copy of the column indices: matrices whose pattern was built on the device (fh_mat_create_from_elements) fetch it at the first host use
 int fh_mat_fetch_host_cols(fh_mat_t A);
+int fh_mat_alloc_device_pattern(fh_ctx_t c, int m, int n, std::vector<int>&& rp, fh_mat_t* out);   // columns left to the caller's kernels
 static inline const std::vector<int>& fh_hcol(fh_mat_t A) {
   if (A->h_col.size() != (size_t)A->nnz) fh_mat_fetch_host_cols(A);
   return A->h_col;

@@ -68,6 +68,31 @@ int fh_mat_fetch_host_cols(fh_mat_t A) {
   return 0;
 }
 
+// A matrix whose pattern is produced ON THE DEVICE: row pointers (scanned on the host) are given, the column array is allocated and left to
+// the caller's kernels; values start at zero.  The host column copy is fetched only if host code asks for it (fh_hcol).  The caller
+// finishes with fh_mat_build_rowblocks once the columns are written.
+int fh_mat_alloc_device_pattern(fh_ctx_t c, int m, int n, std::vector<int>&& rp, fh_mat_t* out) {
+  fh_mat_t A = new fh_mat_s();
+  static std::atomic<uint64_t> next_uid{(uint64_t)1 << 40};        // (apart from the counter of fh_mat_create_csr)
+  A->uid = next_uid++;
+  A->ctx = c;
+  A->m = m;
+  A->n = n;
+  A->h_rowptr = std::move(rp);
+  A->nnz = A->h_rowptr[m];
+  int maxrow = 0;
+  for (int r = 0; r < m; r++) maxrow = std::max(maxrow, A->h_rowptr[r + 1] - A->h_rowptr[r]);
+  A->max_row = maxrow;
+  *out = A;
+  FH_CHECK_HIP(hipMalloc(&A->d_rowptr, ((size_t)m + 1) * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&A->d_col, ((size_t)A->nnz + 2) * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&A->d_val, ((size_t)A->nnz + 2) * sizeof(double)));
+  FH_CHECK_HIP(hipMemsetAsync(A->d_col + A->nnz, 0, 2 * sizeof(int), c->stream));
+  FH_CHECK_HIP(hipMemsetAsync(A->d_val, 0, ((size_t)A->nnz + 2) * sizeof(double), c->stream));
+  FH_CHECK_HIP(hipMemcpyAsync(A->d_rowptr, A->h_rowptr.data(), ((size_t)m + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Finite-element pattern on the DEVICE (round 4; LinearEquation::GetSparsityPatternSize + SparseMatrix::init, LinearEquation.cpp:407-548): row r
 // holds the dofs of all elements around dof r.  node -> element lists by a counting pass, then one wave per row: the <= 1024 candidate
@@ -194,10 +219,8 @@ extern "C" int fh_mat_create_from_elements(fh_ctx_t c, int nel, int nloc, const 
     FH_TRY(fh_pattern_from_elements(nel, nloc, elem_dof, n, hrp.data(), hcol.data()));
     return fh_mat_create_csr(c, m, n, hrp.data(), hcol.data(), nullptr, out);
   }
-  int maxrow = 0;
   tot = 0;
   for (int r = 0; r < m; r++) {
-    maxrow = std::max(maxrow, rp[r + 1]);
     tot += rp[r + 1];
     rp[r + 1] = (int)tot;
   }
@@ -207,21 +230,13 @@ extern "C" int fh_mat_create_from_elements(fh_ctx_t c, int nel, int nloc, const 
     fh_set_error("fh_mat_create_from_elements: nnz overflows int32");
     return 2;
   }
-  fh_mat_t A = new fh_mat_s();
-  static std::atomic<uint64_t> next_uid{(uint64_t)1 << 40};        // (apart from the counter of fh_mat_create_csr)
-  A->uid = next_uid++;
-  A->ctx = c;
-  A->m = m;
-  A->n = n;
-  A->nnz = (int)tot;
-  A->max_row = maxrow;
-  A->h_rowptr = rp;
-  FH_CHECK_HIP(hipMalloc(&A->d_rowptr, ((size_t)m + 1) * sizeof(int)));
-  FH_CHECK_HIP(hipMalloc(&A->d_col, ((size_t)A->nnz + 2) * sizeof(int)));
-  FH_CHECK_HIP(hipMalloc(&A->d_val, ((size_t)A->nnz + 2) * sizeof(double)));
-  FH_CHECK_HIP(hipMemsetAsync(A->d_col + A->nnz, 0, 2 * sizeof(int), c->stream));
-  FH_CHECK_HIP(hipMemsetAsync(A->d_val, 0, ((size_t)A->nnz + 2) * sizeof(double), c->stream));
-  FH_CHECK_HIP(hipMemcpyAsync(A->d_rowptr, rp.data(), ((size_t)m + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  fh_mat_t A = nullptr;
+  if (fh_mat_alloc_device_pattern(c, m, n, std::move(rp), &A)) {
+    hipFree(d_aptr);
+    cleanup();
+    fh_mat_destroy(A);
+    return 2;
+  }
   if (m) hipLaunchKernelGGL(k_pe_rows<true>, dim3(fh_div_up(m, 4)), dim3(256), 0, c->stream, m, d_aptr, d_adj, d_ed, nloc, A->d_rowptr, (int*)nullptr, A->d_col, d_err);
   FH_CHECK_HIP(hipGetLastError());
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));

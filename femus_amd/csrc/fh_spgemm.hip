@@ -384,6 +384,165 @@ static void spgemm_symbolic(int m, int ncols, const std::vector<int>& a_rp, cons
     if (!chunks[t].empty()) std::copy(chunks[t].begin(), chunks[t].end(), c_col.begin() + c_rp[bounds[t]]);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Pattern of A*B on the DEVICE (round 4): one wave per row.  The candidate columns (the B rows named by the A row) go through a hash set
+// in LDS (SY_TAB slots, linear probing, ds atomic compare-and-swap), which leaves the distinct columns; they are compacted, sorted (bitonic,
+// the next power of two above their count) and written.  First launch: row lengths; the host scans them; second launch: columns.  A row with
+// more than SY_CAP distinct columns raises a flag and the host builder (below) serves the product.  Short B rows (prolongators) are walked
+// one per lane, long ones (operators) with the lanes across the row.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int SY_TAB = 2048, SY_CAP = 1024, SY_EMPTY = 0x7fffffff;
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_spgemm_symbolic(int m, const int* __restrict__ a_rp, const int* __restrict__ a_col, const int* __restrict__ b_rp,
+                                                         const int* __restrict__ b_col, int lanes_over_b, const int* __restrict__ c_rp,
+                                                         int* __restrict__ rowlen, int* __restrict__ c_col, int* __restrict__ err) {
+  __shared__ int tab[4][SY_TAB];
+  __shared__ int cmp[FILL ? 4 : 1][FILL ? SY_CAP : 1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= m) return;
+  int* T = tab[wave];
+  for (int k = lane; k < SY_TAB; k += 64) T[k] = SY_EMPTY;
+  wave_sync_lds();
+  int mine = 0;
+  bool fail = false;
+  auto insert = [&](int j) {
+    unsigned h = ((unsigned)j * 2654435761u) >> 21;       // 11 bits
+    for (int p = 0; p < SY_TAB; p++) {
+      const int old = atomicCAS(&T[h], SY_EMPTY, j);
+      if (old == SY_EMPTY) {
+        mine++;
+        return;
+      }
+      if (old == j) return;
+      h = (h + 1) & (SY_TAB - 1);
+    }
+    fail = true;
+  };
+  const int as = a_rp[row], ae = a_rp[row + 1];
+  if (lanes_over_b) {
+    for (int ka = as; ka < ae; ka++) {
+      const int k = a_col[ka];
+      const int be = b_rp[k + 1];
+      for (int kb = b_rp[k] + lane; kb < be && !fail; kb += 64) insert(b_col[kb]);
+    }
+  } else {
+    for (int ka = as + lane; ka < ae; ka += 64) {
+      const int k = a_col[ka];
+      const int be = b_rp[k + 1];
+      for (int kb = b_rp[k]; kb < be && !fail; kb++) insert(b_col[kb]);
+    }
+  }
+  wave_sync_lds();
+  int incl = mine;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += v;
+  }
+  const int total = __shfl(incl, 63, 64);
+  if (__ballot(fail) != 0ull || total > SY_CAP) {
+    if (lane == 0) atomicExch(err, 2);
+    return;
+  }
+  if (!FILL) {
+    if (lane == 0) rowlen[row] = total;
+    return;
+  }
+  int* K = cmp[FILL ? wave : 0];
+  // compaction: each lane owns SY_TAB/64 consecutive slots
+  constexpr int PER = SY_TAB / 64;
+  int cnt = 0;
+  for (int k = 0; k < PER; k++) cnt += T[lane * PER + k] != SY_EMPTY ? 1 : 0;
+  int ci = cnt;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(ci, d, 64);
+    if (lane >= d) ci += v;
+  }
+  int o = ci - cnt;
+  for (int k = 0; k < PER; k++) {
+    const int v = T[lane * PER + k];
+    if (v != SY_EMPTY) K[o++] = v;
+  }
+  int np = 64;
+  while (np < total) np <<= 1;
+  for (int k = total + lane; k < np; k += 64) K[k] = SY_EMPTY;
+  wave_sync_lds();
+  for (int size = 2; size <= np; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = lane; t < (np >> 1); t += 64) {
+        const int lo = ((t / stride) * (stride << 1)) + (t % stride), hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const int a = K[lo], c = K[hi];
+        if ((a > c) == up) {
+          K[lo] = c;
+          K[hi] = a;
+        }
+      }
+      wave_sync_lds();
+    }
+  const int cs = c_rp[row];
+  for (int k = lane; k < total; k += 64) c_col[cs + k] = K[k];
+}
+
+// C = pattern(A*B) as a matrix with zero values; returns 1 (and *Cout == nullptr) when a row exceeds the device limits
+static int spgemm_symbolic_device(fh_mat_t A, fh_mat_t B, fh_mat_t* Cout) {
+  fh_ctx_t c = A->ctx;
+  const int m = A->m;
+  *Cout = nullptr;
+  if (m == 0 || A->nnz == 0 || B->nnz == 0) return 1;
+  const int lanes_over_b = (double)B->nnz / std::max(B->m, 1) >= 24.0 ? 1 : 0;
+  int *d_len = nullptr, *d_err = nullptr;
+  FH_CHECK_HIP(hipMalloc(&d_len, ((size_t)m + 1) * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&d_err, sizeof(int)));
+  FH_CHECK_HIP(hipMemsetAsync(d_err, 0, sizeof(int), c->stream));
+  hipLaunchKernelGGL(k_spgemm_symbolic<false>, dim3(fh_div_up(m, 4)), dim3(256), 0, c->stream, m, A->d_rowptr, A->d_col, B->d_rowptr, B->d_col, lanes_over_b,
+                     (const int*)nullptr, d_len, (int*)nullptr, d_err);
+  std::vector<int> rp((size_t)m + 1, 0);
+  int err = 0;
+  FH_CHECK_HIP(hipMemcpyAsync(rp.data() + 1, d_len, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  FH_CHECK_HIP(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  int64_t tot = 0;
+  for (int r = 0; r < m && !err; r++) {
+    tot += rp[r + 1];
+    if (tot >= 2147483647ll) err = 3;
+    rp[r + 1] = (int)tot;
+  }
+  if (err) {
+    hipFree(d_len);
+    hipFree(d_err);
+    return 1;
+  }
+  fh_mat_t C = nullptr;
+  if (fh_mat_alloc_device_pattern(c, m, B->n, std::move(rp), &C)) {
+    hipFree(d_len);
+    hipFree(d_err);
+    fh_mat_destroy(C);
+    return 2;
+  }
+  hipLaunchKernelGGL(k_spgemm_symbolic<true>, dim3(fh_div_up(m, 4)), dim3(256), 0, c->stream, m, A->d_rowptr, A->d_col, B->d_rowptr, B->d_col, lanes_over_b,
+                     C->d_rowptr, (int*)nullptr, C->d_col, d_err);
+  FH_CHECK_HIP(hipGetLastError());
+  FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  hipFree(d_len);
+  hipFree(d_err);
+  FH_TRY(fh_mat_build_rowblocks(C, c->spmv_tile));
+  *Cout = C;
+  return 0;
+}
+
+// pattern of A*B (zero values): on the device, or on the host when a row is beyond the device kernel's limits
+static int spgemm_pattern(fh_mat_t A, fh_mat_t B, fh_mat_t* Cout) {
+  if (A->ctx->spgemm_device_symbolic) {
+    const int rc = spgemm_symbolic_device(A, B, Cout);
+    if (rc == 0) return 0;
+    if (rc != 1) return rc;
+  }
+  std::vector<int> rp, col;
+  spgemm_symbolic(A->m, B->n, A->h_rowptr, fh_hcol(A), B->h_rowptr, fh_hcol(B), rp, col);
+  return fh_mat_create_csr(A->ctx, A->m, B->n, rp.data(), col.data(), nullptr, Cout);
+}
+
 int fh_mat_refresh_transpose(fh_mat_t A);
 
 // D = R * A * P with a reusable plan attached to D: the product A*P and the two slot maps are kept, so that a repeated call with
@@ -398,11 +557,14 @@ static int triple_product(fh_mat_t R, fh_mat_t A, fh_mat_t P, fh_mat_t* Cio, con
     plan->nc = P->n;
     plan->a_nnz = A->nnz;
     plan->p_nnz = P->nnz;
-    std::vector<int> ap_rp, ap_col, c_rp, c_col;
-    spgemm_symbolic(A->m, P->n, A->h_rowptr, fh_hcol(A), P->h_rowptr, fh_hcol(P), ap_rp, ap_col);
-    FH_TRY(fh_mat_create_csr(A->ctx, A->m, P->n, ap_rp.data(), ap_col.data(), nullptr, &plan->AP));
-    spgemm_symbolic(R->m, P->n, R->h_rowptr, fh_hcol(R), ap_rp, ap_col, c_rp, c_col);
-    FH_TRY(fh_mat_create_csr(A->ctx, R->m, P->n, c_rp.data(), c_col.data(), nullptr, &C));
+    if (int rc = spgemm_pattern(A, P, &plan->AP)) {
+      delete plan;
+      return rc;
+    }
+    if (int rc = spgemm_pattern(R, plan->AP, &C)) {
+      destroy_plan(plan);
+      return rc;
+    }
     C->plan = plan;
     C->plan_destroy = destroy_plan;
     *Cio = C;
@@ -442,10 +604,8 @@ extern "C" int fh_mat_matmul(fh_mat_t A, fh_mat_t B, fh_mat_t* Cout) {
   FH_GUARD_BEGIN
   FH_REQUIRE(A && B && Cout, "fh_mat_matmul: null argument");
   FH_REQUIRE(A->n == B->m, "fh_mat_matmul: shapes do not conform (A %dx%d, B %dx%d)", A->m, A->n, B->m, B->n);
-  std::vector<int> rp, col;
-  spgemm_symbolic(A->m, B->n, A->h_rowptr, fh_hcol(A), B->h_rowptr, fh_hcol(B), rp, col);
   fh_mat_t C = nullptr;
-  FH_TRY(fh_mat_create_csr(A->ctx, A->m, B->n, rp.data(), col.data(), nullptr, &C));
+  FH_TRY(spgemm_pattern(A, B, &C));
   FH_TRY(spgemm_numeric(A, B, C));
   *Cout = C;
   return 0;

@@ -44,6 +44,30 @@ def test_ptap_matches_scipy(ctx):
     assert abs(C2.to_scipy() - ref2).max() <= 1e-12 * max(abs(ref2).max(), 1e-300)
 
 
+def test_product_patterns_built_on_the_device_equal_the_host_builder(ctx):
+    """fh_mat_matmul / fh_mat_ptap: the pattern kernel (hash set + sort in LDS, one wave per row) against the host marker builder -- same
+    row pointers and columns; a row with more distinct columns than the kernel holds sends the whole product to the host builder"""
+    import scipy.sparse as sp
+    H = fo.build_poisson_hierarchy(2, 2, 2, 3, "biquadratic", ONE)
+    cases = [(H.A_raw[2], H.P[2]), (H.P[2].T.tocsr(), H.A_raw[2]), (H.A_raw[2], H.A_raw[2]),
+             (sp.random(300, 4000, density=0.02, random_state=1, format="csr"), sp.random(4000, 5000, density=0.01, random_state=2, format="csr")),  # > 1024 per row
+             (sp.csr_matrix((5, 7)), sp.random(7, 3, density=0.5, random_state=3, format="csr"))]
+    for Ah, Bh in cases:
+        Ah.sort_indices(); Bh.sort_indices()
+        out = {}
+        for dev in (1, 0):
+            ctx.set_option("spgemm_device_symbolic", dev)
+            A, B = ctx.matrix_scipy(Ah), ctx.matrix_scipy(Bh)
+            C = A.matmul(B).to_scipy()
+            out[dev] = (C.indptr.copy(), C.indices.copy(), C.data.copy())
+        ctx.set_option("spgemm_device_symbolic", 1)
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+        assert np.array_equal(out[0][2], out[1][2])
+        ref = (Ah @ Bh).tocsr()
+        Cd = sp.csr_matrix((out[1][2], out[1][1], out[1][0]), shape=ref.shape)
+        assert abs(Cd - ref).max() <= 1e-12 * max(abs(ref).max(), 1e-300) if ref.nnz else Cd.nnz == 0 or abs(Cd).max() == 0
+
+
 @pytest.mark.parametrize("args,nl,fe,npre,npost", [((2, 2, 2), 3, "biquadratic", 2, 2), ((8, 8, 0), 3, "linear", 1, 1)])
 @pytest.mark.parametrize("coarse", ["galerkin", "rediscretise"])
 def test_mgsolve_end_to_end(ctx, args, nl, fe, npre, npost, coarse):
