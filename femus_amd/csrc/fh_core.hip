@@ -248,6 +248,7 @@ extern "C" int fh_set_option(fh_ctx_t c, const char* name, double value) {
   else if (!strcmp(name, "use_graph")) c->use_graph = (int)value;
   else if (!strcmp(name, "mg_reuse_graph")) c->mg_reuse_graph = (int)value;
   else if (!strcmp(name, "spgemm_slot_map")) c->spgemm_slot_map = (int)value;
+  else if (!strcmp(name, "device_setup")) c->device_setup = (int)value;
   else if (!strcmp(name, "spgemm_device_symbolic")) c->spgemm_device_symbolic = (int)value;
   else if (!strcmp(name, "halo_overlap")) c->halo_overlap = (int)value;
   else if (!strcmp(name, "halo_profile")) c->halo_profile = (int)value;

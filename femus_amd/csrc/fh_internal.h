@@ -112,6 +112,7 @@ struct fh_ctx_s {
   int use_graph = 1;
   int mg_reuse_graph = 1;            // a repeated fh_mg_setup of an unchanged hierarchy keeps the captured cycle
   int opt_gen = 0;                   // bumped by every fh_set_option (captured launches depend on the options)
+  int device_setup = 1;              // prolongators are built on the device (0: host loops; identical matrices)
   int spgemm_device_symbolic = 1;    // patterns of sparse products are built on the device (0: host builder)
   int spgemm_slot_map = 1;           // Galerkin products stream a precomputed slot map instead of searching
   int halo_overlap = 1;              // distributed operators: rows without ghost columns run while the ghost exchange is in flight

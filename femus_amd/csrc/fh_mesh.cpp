@@ -131,6 +131,41 @@ struct Key3Hash {
   }
 };
 
+// open-addressing map (a, b, c) -> node id for the edge / face tables of a refinement: millions of look-ups, one allocation.  The slot index is
+// a * S + (hash bits of b, c): a is the smallest vertex of the edge / face and vertex ids follow the element order (first-touch numbering),
+// so consecutive elements probe neighbouring cache lines instead of the whole table.  S covers the keys one vertex can be the smallest of
+// (6 edges, 12 faces on a hexahedral grid; the coarse vertices, numbered first and contiguously, reach that bound all at once -- fewer slots
+// per vertex make their block overflow into one long probe chain)
+struct PairMap {
+  struct Slot {
+    int a, b, c, value;
+  };
+  std::vector<Slot> slot;
+  size_t cap = 0;
+  int per = 8, shift = 61;
+  PairMap(size_t expected, size_t n_first, int log2_per) : per(1 << log2_per), shift(64 - log2_per) {
+    cap = std::max<size_t>(std::max(expected * 2, n_first * (size_t)per), 64);
+    slot.assign(cap, Slot{-1, -1, -1, -1});
+  }
+  // the id stored for the key, or `fresh` after storing it (then *created = true)
+  int find_or_insert(int a, int b, int c, int fresh, bool* created) {
+    const uint64_t h = ((uint64_t)(uint32_t)b * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(uint32_t)(c + 1) * 0xC2B2AE3D27D4EB4Full);
+    size_t i = ((size_t)(uint32_t)a * per + (size_t)(h >> shift)) % cap;
+    for (;; i = (i + 1 == cap) ? 0 : i + 1) {
+      Slot& s = slot[i];
+      if (s.value < 0) {
+        s = Slot{a, b, c, fresh};
+        *created = true;
+        return fresh;
+      }
+      if (s.a == a && s.b == b && s.c == c) {
+        *created = false;
+        return s.value;
+      }
+    }
+  }
+};
+
 // MeshRefinement::RefineMesh (MeshRefinement.cpp:197-493) for nprocs = 1.  flags == NULL: every element is split (uniform
 // level).  Otherwise elements of the current level with a nonzero flag are split and all the others are carried over
 // unchanged (their node ids, boundary flags and level), which makes the new level non-homogeneous (AMR).
@@ -218,34 +253,30 @@ extern "C" int fh_mesh_refine_flagged(fh_mesh_t mc, const unsigned char* flags, 
   int nnodes = mc->nnode;
   // edge mid-points (:356-417): first visit in (element, local edge) order creates the node
   {
-    std::unordered_map<uint64_t, int> emap;
-    emap.reserve((size_t)m->nel * 4);
+    PairMap emap((size_t)m->nel * (size_t)(ne - nv) / 2 + 64, (size_t)mc->nnode, 3);
     for (int iel = 0; iel < m->nel; iel++) {
       if (!fresh(iel)) continue;
       for (int e = nv; e < ne; e++) {
         int a = m->elem_dof[(size_t)iel * nc + edge_v[e - nv][0]], b = m->elem_dof[(size_t)iel * nc + edge_v[e - nv][1]];
         if (a > b) std::swap(a, b);
-        uint64_t key = ((uint64_t)a << 32) | (uint32_t)b;
-        auto it = emap.find(key);
-        if (it == emap.end()) it = emap.emplace(key, nnodes++).first;
-        m->elem_dof[(size_t)iel * nc + e] = it->second;
+        bool created;
+        m->elem_dof[(size_t)iel * nc + e] = emap.find_or_insert(a, b, -1, nnodes, &created);
+        if (created) nnodes++;
       }
     }
   }
   // quad-face centres of hexahedra (:526-561): (element, face 0..5) order
   if (geom == GEOM_HEX) {
-    std::unordered_map<Key3, int, Key3Hash> fmap;
-    fmap.reserve((size_t)m->nel * 4);
+    PairMap fmap((size_t)m->nel * 4 + 64, (size_t)mc->nnode, 4);
     for (int iel = 0; iel < m->nel; iel++) {
       if (!fresh(iel)) continue;
       for (int f = 0; f < 6; f++) {
         int v[4];
         for (int k = 0; k < 4; k++) v[k] = m->elem_dof[(size_t)iel * nc + face_v[f][k]];
         std::sort(v, v + 4);
-        Key3 key{v[0], v[1], v[2]};
-        auto it = fmap.find(key);
-        if (it == fmap.end()) it = fmap.emplace(key, nnodes++).first;
-        m->elem_dof[(size_t)iel * nc + 20 + f] = it->second;
+        bool created;   // the three smallest vertices name the face
+        m->elem_dof[(size_t)iel * nc + 20 + f] = fmap.find_or_insert(v[0], v[1], v[2], nnodes, &created);
+        if (created) nnodes++;
       }
     }
   }
@@ -258,39 +289,58 @@ extern "C" int fh_mesh_refine_flagged(fh_mesh_t mc, const unsigned char* flags, 
   std::vector<double> EP;
   elem_prolongator(geom, FE_BIQUADRATIC, EP);
   m->coords.assign((size_t)m->nnode * dim, 0.0);
-  std::vector<char> done(m->nnode, 0);
-  std::vector<int> order(nc);
-  for (int iel = 0; iel < mc->nel; iel++) {
-    const int* cd = &mc->elem_dof[(size_t)iel * nc];
-    if (!mc->refined[iel]) {
-      const int jel = start[iel];
-      for (int i = 0; i < nc; i++) {
-        const int row = m->elem_dof[(size_t)jel * nc + i];
-        if (done[row]) continue;
-        done[row] = 1;
-        for (int d = 0; d < dim; d++) m->coords[(size_t)row * dim + d] = mc->coords[(size_t)cd[i] * dim + d];
+  // non-zero weights of every (child, node) row, once
+  std::vector<int> nzn((size_t)nch * nc, 0);
+  std::vector<unsigned char> nzmask((size_t)nch * nc * nc, 0);
+  for (int ji = 0; ji < nch * nc; ji++)
+    for (int k = 0; k < nc; k++) nzmask[(size_t)ji * nc + k] = EP[(size_t)ji * nc + k] != 0.0;
+  // a row shared by several coarse elements gets the same sum from each of them (same weights on the same global columns, added in
+  // increasing column order), so the coarse elements are split over threads and whoever claims a row first writes it
+  std::unique_ptr<std::atomic<unsigned char>[]> done(new std::atomic<unsigned char>[(size_t)m->nnode]);
+  for (int i = 0; i < m->nnode; i++) done[i].store(0, std::memory_order_relaxed);
+  const int nth = (mc->nel >= 4096) ? (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;
+  auto work = [&](int e0, int e1) {
+    int order[27];
+    double xs[27 * 3];
+    for (int iel = e0; iel < e1; iel++) {
+      const int* cd = &mc->elem_dof[(size_t)iel * nc];
+      if (!mc->refined[iel]) {
+        const int jel = start[iel];
+        for (int i = 0; i < nc; i++) {
+          const int row = m->elem_dof[(size_t)jel * nc + i];
+          if (done[row].exchange(1, std::memory_order_relaxed)) continue;
+          for (int d = 0; d < dim; d++) m->coords[(size_t)row * dim + d] = mc->coords[(size_t)cd[i] * dim + d];
+        }
+        continue;
       }
-      continue;
-    }
-    for (int k = 0; k < nc; k++) order[k] = k;
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return cd[a] < cd[b]; });
-    for (int j = 0; j < nch; j++) {
-      const int jel = start[iel] + j;
-      for (int i = 0; i < nc; i++) {
-        const int row = m->elem_dof[(size_t)jel * nc + i];
-        if (done[row]) continue;
-        done[row] = 1;
-        const double* pr = &EP[((size_t)j * nc + i) * nc];
-        for (int d = 0; d < dim; d++) {
-          double s = 0.0;
+      for (int k = 0; k < nc; k++) order[k] = k;
+      std::sort(order, order + nc, [&](int a, int b) { return cd[a] < cd[b]; });
+      for (int kk = 0; kk < nc; kk++)
+        for (int d = 0; d < dim; d++) xs[kk * 3 + d] = mc->coords[(size_t)cd[order[kk]] * dim + d];
+      for (int j = 0; j < nch; j++) {
+        const int jel = start[iel] + j;
+        for (int i = 0; i < nc; i++) {
+          const int row = m->elem_dof[(size_t)jel * nc + i];
+          if (done[row].exchange(1, std::memory_order_relaxed)) continue;
+          const double* pr = &EP[((size_t)j * nc + i) * nc];
+          const unsigned char* nz = &nzmask[((size_t)j * nc + i) * nc];
+          double sum[3] = {0.0, 0.0, 0.0};
           for (int kk = 0; kk < nc; kk++) {
             const int k = order[kk];
-            if (pr[k] != 0.0) s += pr[k] * mc->coords[(size_t)cd[k] * dim + d];
+            if (!nz[k]) continue;
+            for (int d = 0; d < dim; d++) sum[d] += pr[k] * xs[kk * 3 + d];
           }
-          m->coords[(size_t)row * dim + d] = s;
+          for (int d = 0; d < dim; d++) m->coords[(size_t)row * dim + d] = sum[d];
         }
       }
     }
+  };
+  if (nth == 1) {
+    work(0, mc->nel);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nth; t++) th.emplace_back(work, (int)((int64_t)mc->nel * t / nth), (int)((int64_t)mc->nel * (t + 1) / nth));
+    for (auto& x : th) x.join();
   }
   *out = holder.release();
   return 0;
@@ -465,6 +515,153 @@ extern "C" int fh_pattern_from_elements(int nel, int nloc, const int* elem_dof, 
   FH_GUARD_END("fh_pattern_from_elements")
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same prolongator built ON THE DEVICE (round 4).  The host loop above gives a fine row to the first (coarse element, child, local
+// node) that visits it; in loop order that is the MINIMUM of the linear index (iel * nch + j) * nc + i over all visits, so the owner of a
+// row is an atomicMin.  Row lengths come from a (child, node) table of non-zero counts, the host scans them, and one thread per row then
+// writes its columns at their rank among the coarse element's dofs (sorted CSR order without a sort) with the boundary rule applied.
+// Nothing but the 4-byte row lengths visits the host; the column copy there is fetched only if host code asks (fh_hcol).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PL_NONE = 0x7f7f7f7f;   // a row nobody visits (byte pattern of the memset)
+__global__ __launch_bounds__(256) void k_pl_owner(size_t n, int nc, int nl, const int* __restrict__ child, const int* __restrict__ f_ed, int* __restrict__ owner) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const int slot = (int)(t / nc), i = (int)(t % nc);
+  const int jel = child[slot];
+  if (jel < 0) return;
+  atomicMin(&owner[f_ed[(size_t)jel * nl + i]], (int)t);
+}
+__global__ __launch_bounds__(256) void k_pl_len(int nf, int nc, int nch, const int* __restrict__ owner, const char* __restrict__ refined, const int* __restrict__ cnt,
+                                                int* __restrict__ len) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= nf) return;
+  const int o = owner[r];
+  if (o == PL_NONE) {
+    len[r] = 0;
+    return;
+  }
+  const int slot = o / nc, i = o % nc, iel = slot / nch, j = slot % nch;
+  len[r] = refined[iel] ? cnt[j * nc + i] : 1;
+}
+__global__ __launch_bounds__(256) void k_pl_fill(int nf, int nc, int nch, int nl, const int* __restrict__ owner, const char* __restrict__ refined,
+                                                 const int* __restrict__ c_ed, const int* __restrict__ cnt, const int* __restrict__ nzk,
+                                                 const double* __restrict__ EP, const char* __restrict__ bf, const char* __restrict__ bc,
+                                                 const int* __restrict__ rowptr, int* __restrict__ col, double* __restrict__ val) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= nf) return;
+  const int o = owner[r];
+  if (o == PL_NONE) return;
+  const int slot = o / nc, i = o % nc, iel = slot / nch, j = slot % nch;
+  const int* cd = c_ed + (size_t)iel * nl;
+  const int p = rowptr[r];
+  const bool rowb = bf && bf[r];
+  if (!refined[iel]) {
+    const int c = cd[i];
+    col[p] = c;
+    val[p] = (rowb || (bc && bc[c])) ? 0.0 : 1.0;
+    return;
+  }
+  const int n = cnt[j * nc + i];
+  const int* nz = nzk + (size_t)(j * nc + i) * nc;
+  const double* pr = EP + (size_t)(j * nc + i) * nc;
+  for (int a = 0; a < n; a++) {
+    const int k = nz[a], c = cd[k];
+    int rank = 0;
+    for (int b = 0; b < n; b++) rank += cd[nz[b]] < c ? 1 : 0;
+    col[p + rank] = c;
+    val[p + rank] = (rowb || (bc && bc[c])) ? 0.0 : pr[k];     // pattern kept, value zeroed
+  }
+}
+
+namespace {
+struct DevBuf {   // scratch device arrays of one setup routine, freed on every exit path
+  std::vector<void*> p;
+  ~DevBuf() {
+    for (void* q : p)
+      if (q) hipFree(q);
+  }
+  template <class T>
+  int get(T** out, size_t n) {
+    void* q = nullptr;
+    if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return 1;
+    p.push_back(q);
+    *out = (T*)q;
+    return 0;
+  }
+};
+}   // namespace
+
+static int build_prolongator_device(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t mf, int fe, int zero_bdc, fh_mat_t* out) {
+  const int geom = mc->geom, nl = mc->nloc, nc = ndofs_of(geom, fe), nch = nvert_of(geom);
+  const int nf = mesh_ndofs(mf, fe), ncc = mesh_ndofs(mc, fe);
+  std::vector<double> EP;
+  elem_prolongator(geom, fe, EP);
+  std::vector<int> cnt((size_t)nch * nc, 0), nzk((size_t)nch * nc * nc, 0);
+  for (int ji = 0; ji < nch * nc; ji++)
+    for (int k = 0; k < nc; k++)
+      if (EP[(size_t)ji * nc + k] != 0.0) nzk[(size_t)ji * nc + cnt[ji]++] = k;
+  hipStream_t st = ctx->stream;
+  DevBuf B;
+  int *d_child, *d_fed, *d_ced, *d_owner, *d_len, *d_cnt, *d_nzk;
+  char *d_ref, *d_bf = nullptr, *d_bc = nullptr;
+  double* d_EP;
+  const size_t nslot = (size_t)mc->nel * nch;
+  if (B.get(&d_child, nslot) || B.get(&d_fed, mf->elem_dof.size()) || B.get(&d_ced, mc->elem_dof.size()) || B.get(&d_owner, (size_t)nf) ||
+      B.get(&d_len, (size_t)nf) || B.get(&d_cnt, cnt.size()) || B.get(&d_nzk, nzk.size()) || B.get(&d_ref, (size_t)mc->nel) || B.get(&d_EP, EP.size())) {
+    fh_set_error("fh_build_prolongator: out of device memory");
+    return 2;
+  }
+  FH_CHECK_HIP(hipMemcpyAsync(d_child, mc->child.data(), nslot * sizeof(int), hipMemcpyHostToDevice, st));
+  FH_CHECK_HIP(hipMemcpyAsync(d_fed, mf->elem_dof.data(), mf->elem_dof.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  FH_CHECK_HIP(hipMemcpyAsync(d_ced, mc->elem_dof.data(), mc->elem_dof.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  FH_CHECK_HIP(hipMemcpyAsync(d_cnt, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  FH_CHECK_HIP(hipMemcpyAsync(d_nzk, nzk.data(), nzk.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  FH_CHECK_HIP(hipMemcpyAsync(d_ref, mc->refined.data(), (size_t)mc->nel, hipMemcpyHostToDevice, st));
+  FH_CHECK_HIP(hipMemcpyAsync(d_EP, EP.data(), EP.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  FH_CHECK_HIP(hipMemsetAsync(d_owner, 0x7f, (size_t)nf * sizeof(int), st));          // PL_NONE
+  std::vector<char> bf, bc;
+  if (zero_bdc) {
+    std::vector<int> lf, lc;
+    dirichlet_list(mf, fe, lf);
+    dirichlet_list(mc, fe, lc);
+    bf.assign(nf, 0);
+    bc.assign(ncc, 0);
+    for (int r : lf) bf[r] = 1;
+    for (int c : lc) bc[c] = 1;
+    if (B.get(&d_bf, (size_t)nf) || B.get(&d_bc, (size_t)ncc)) {
+      fh_set_error("fh_build_prolongator: out of device memory");
+      return 2;
+    }
+    FH_CHECK_HIP(hipMemcpyAsync(d_bf, bf.data(), (size_t)nf, hipMemcpyHostToDevice, st));
+    FH_CHECK_HIP(hipMemcpyAsync(d_bc, bc.data(), (size_t)ncc, hipMemcpyHostToDevice, st));
+  }
+  const size_t nvis = nslot * nc;
+  FH_REQUIRE(nvis < (size_t)PL_NONE, "fh_build_prolongator: %zu visits do not fit the owner index", nvis);
+  if (nvis) hipLaunchKernelGGL(k_pl_owner, dim3((unsigned)((nvis + 255) / 256)), dim3(256), 0, st, nvis, nc, nl, d_child, d_fed, d_owner);
+  if (nf) hipLaunchKernelGGL(k_pl_len, dim3(fh_div_up(nf, 256)), dim3(256), 0, st, nf, nc, nch, d_owner, d_ref, d_cnt, d_len);
+  std::vector<int> rp((size_t)nf + 1, 0);
+  if (nf) FH_CHECK_HIP(hipMemcpyAsync(rp.data() + 1, d_len, (size_t)nf * sizeof(int), hipMemcpyDeviceToHost, st));
+  FH_CHECK_HIP(hipStreamSynchronize(st));
+  int64_t tot = 0;
+  for (int r = 0; r < nf; r++) {
+    tot += rp[r + 1];
+    rp[r + 1] = (int)tot;
+  }
+  FH_REQUIRE(tot < 2147483647ll, "fh_build_prolongator: nnz overflows int32");
+  fh_mat_t P = nullptr;
+  if (fh_mat_alloc_device_pattern(ctx, nf, ncc, std::move(rp), &P)) {
+    fh_mat_destroy(P);
+    return 2;
+  }
+  if (nf) hipLaunchKernelGGL(k_pl_fill, dim3(fh_div_up(nf, 256)), dim3(256), 0, st, nf, nc, nch, nl, d_owner, d_ref, d_ced, d_cnt, d_nzk, d_EP, d_bf, d_bc,
+                             P->d_rowptr, P->d_col, P->d_val);
+  FH_CHECK_HIP(hipGetLastError());
+  FH_CHECK_HIP(hipStreamSynchronize(st));
+  FH_TRY(fh_mat_build_rowblocks(P, ctx->spmv_tile));
+  *out = P;
+  return 0;
+}
+
 // a14: P (fine x coarse), INSERT semantics (first insert wins; duplicates are identical rows).  Elements that were not
 // refined contribute identity rows (LinearImplicitSystem.cpp:796-806).
 extern "C" int fh_build_prolongator(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t mf, int fe, int zero_bdc, fh_mat_t* out) {
@@ -478,6 +675,7 @@ extern "C" int fh_build_prolongator(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t mf, in
     for (int iel = 0; iel < mc->nel; iel++) expect += mc->refined[iel] ? nch : 1;
     FH_REQUIRE(expect == mf->nel, "fh_build_prolongator: fine is not the refinement of coarse");
   }
+  if (ctx->device_setup) return build_prolongator_device(ctx, mc, mf, fe, zero_bdc, out);
   const int nf = mesh_ndofs(mf, fe), ncc = mesh_ndofs(mc, fe);
   std::vector<double> EP;
   elem_prolongator(geom, fe, EP);

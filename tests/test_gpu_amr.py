@@ -76,3 +76,23 @@ def test_amr_q2_exactness_larger_mesh(ctx):
     _, xy, _ = pb.meshes[-1].arrays()
     assert abs(pb.SOL.to_numpy() - np.prod(xy * (1 - xy), axis=1)).max() < 1e-12
     pb.destroy()
+
+
+@pytest.mark.parametrize("box,nu,ns,flag", [((2, 2, 2), 2, 2, ex4_flag), ((3, 3, 0), 1, 3, random_flag(1, 0.5)), ((3, 2, 2), 3, 0, None)])
+@pytest.mark.parametrize("fe", ["biquadratic", "linear"])
+@pytest.mark.parametrize("zero_bdc", [True, False])
+def test_prolongator_built_on_the_device_equals_the_host_loops(ctx, box, nu, ns, flag, fe, zero_bdc):
+    """fh_build_prolongator: owner of a row by atomicMin over the visit index + rank placement (device) against the first-visit loops of
+    LinearImplicitSystem::BuildProlongatorMatrix restated on the host -- identical row pointers, columns and values"""
+    ms = amr_meshes(box, nu, ns, flag)
+    for l in range(1, len(ms)):
+        out = []
+        for dev in (1, 0):
+            ctx.set_option("device_setup", dev)
+            P = capi.build_prolongator(ctx, ms[l - 1], ms[l], fe, zero_bdc=zero_bdc)
+            S = P.to_scipy()
+            out.append((S.indptr.copy(), S.indices.copy(), S.data.copy()))
+            P.destroy()
+        ctx.set_option("device_setup", 1)
+        for a, b in zip(*out):
+            assert np.array_equal(a, b)
