@@ -722,6 +722,39 @@ def assemble_neumann(ctx, mesh, fe, res, flux_by_flag, order="seventh"):
             _chk(ctx.L.fh_assemble_neumann_faces(ctx.h, GEOM[mesh.geom], FE[fe], GAUSS_ORDER[order], fn.shape[0], _p(fn), _p(tv), xy.shape[0], _p(xy), res.h))
 
 
+def face_normals(mesh, fe, face_nodes, gauss_point=0, order="seventh", coords=None):
+    """unit normals of faces at one face Gauss point as elem_type::JacobianSur returns them (fh_fe_face_normals, host)"""
+    L = load_library()
+    xy = _f64(mesh.arrays()[1] if coords is None else coords)
+    fn = _i32(face_nodes)
+    out = np.empty((fn.shape[0], mesh.dim))
+    _chk(L.fh_fe_face_normals(GEOM[mesh.geom], FE[fe], GAUSS_ORDER[order], int(gauss_point), fn.shape[0], _p(fn), xy.shape[0], _p(xy), _p(out)))
+    return out
+
+
+def assemble_pressure_faces(ctx, mesh, res, face_nodes, tau, comp_offset, scale=-1.0, order="seventh"):
+    """open-boundary pressure term of the Navier-Stokes residual (03_navier_stokes.hpp:185-290) on the listed faces (Q2 face nodes, face element
+    order): res[comp_offset[k] + node] += scale * int_face phi tau n_k.  tau: one number per face, or a list of (Expr, face mask) pairs"""
+    xy = _f64(mesh.arrays()[1])
+    fn = _i32(face_nodes)
+    if fn.shape[0] == 0:
+        return
+    off = _i32(comp_offset)
+    if isinstance(tau, (list, tuple)) and tau and isinstance(tau[0], tuple):
+        exprs = [e for e, _ in tau]
+        fx = np.full(fn.shape[0], -1, np.int32)
+        for k, (_, mask) in enumerate(tau):
+            fx[np.asarray(mask, bool)] = k
+        assert (fx >= 0).all(), "every face needs an expression"
+        hs = (ctypes.c_void_p * len(exprs))(*[e.h for e in exprs])
+        _chk(ctx.L.fh_assemble_pressure_faces(ctx.h, GEOM[mesh.geom], GAUSS_ORDER[order], fn.shape[0], _p(fn), None, _p(fx), len(exprs), hs, xy.shape[0],
+                                              _p(xy), _p(off), float(scale), res.h))
+    else:
+        tv = _f64(np.broadcast_to(np.asarray(tau, float), (fn.shape[0],)).copy())
+        _chk(ctx.L.fh_assemble_pressure_faces(ctx.h, GEOM[mesh.geom], GAUSS_ORDER[order], fn.shape[0], _p(fn), _p(tv), None, 0, None, xy.shape[0], _p(xy),
+                                              _p(off), float(scale), res.h))
+
+
 def build_prolongator(ctx, coarse, fine, fe, zero_bdc=True):
     h = ctypes.c_void_p()
     _chk(ctx.L.fh_build_prolongator(ctx.h, coarse.h, fine.h, FE[fe], 1 if zero_bdc else 0, ctypes.byref(h)))

@@ -3467,22 +3467,24 @@ extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, con
 // Neumann boundary faces (a5: elem_type::JacobianSur).  One thread per boundary node: it owns the node's (face, local i)
 // pairs (ascending face order) and integrates phi_i * tau over each face with the face element's quadrature.
 // ------------------------------------------------------------------------------------------------------------------
-template <int DIM>
+// NORMAL: the vector form  res[off[k] + node] += scale * int_face phi_i tau n_k ds  for the DIM components (open-boundary pressure term of the
+// Navier-Stokes residual, 03_navier_stokes.hpp:185-290, normal = the one JacobianSur returns at each face Gauss point)
+template <int DIM, bool NORMAL>
 __global__ __launch_bounds__(128) void k_neumann(const int* __restrict__ node_ptr, const int* __restrict__ node_id, const int* __restrict__ pairs,
                                                  int nbn, const int* __restrict__ face_nodes, int nfn, const double* __restrict__ tau,
                                                  const double* __restrict__ coords, const double* __restrict__ w, const double* __restrict__ phi,
                                                  const double* __restrict__ dphi, int ng, double* __restrict__ res,
                                                  const int* __restrict__ face_expr, const int* __restrict__ prog, const int* __restrict__ prog_ptr,
-                                                 const double* __restrict__ pconst, const int* __restrict__ const_ptr) {
+                                                 const double* __restrict__ pconst, const int* __restrict__ const_ptr, int off0, int off1, int off2, double scale) {
   const int t = blockIdx.x * 128 + threadIdx.x;
   if (t >= nbn) return;
-  double total = 0.0;
+  double total = 0.0, totn[3] = {0.0, 0.0, 0.0};
   for (int p = node_ptr[t]; p < node_ptr[t + 1]; p++) {
     const int f = pairs[p] >> 4, i = pairs[p] & 15;
     const int* fn = face_nodes + (size_t)f * nfn;
-    double acc = 0.0;
+    double acc = 0.0, accn[3] = {0.0, 0.0, 0.0};
     for (int g = 0; g < ng; g++) {
-      double weight;
+      double weight, nrm[3] = {0.0, 0.0, 0.0};
       if (DIM == 3) {   // quad face in 3-D: tangents, normal = t1 x t2, det = |normal|  (ElemType.hpp:1330-1380)
         double J[3][2] = {{0, 0}, {0, 0}, {0, 0}};
         for (int n = 0; n < nfn; n++) {
@@ -3500,6 +3502,7 @@ __global__ __launch_bounds__(128) void k_neumann(const int* __restrict__ node_pt
         const double n0 = nx * inv, n1 = ny * inv, n2 = nz * inv;
         const double det = J[0][0] * (J[1][1] * n2 - n1 * J[2][1]) + J[0][1] * (n1 * J[2][0] - J[1][0] * n2) + n0 * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
         weight = det * w[g];
+        nrm[0] = n0; nrm[1] = n1; nrm[2] = n2;
       } else {          // edge in 2-D (ElemType.hpp:1089-1138)
         double j0 = 0.0, j1 = 0.0;
         for (int n = 0; n < nfn; n++) {
@@ -3512,6 +3515,7 @@ __global__ __launch_bounds__(128) void k_neumann(const int* __restrict__ node_pt
         const double n0 = j1 / modn, n1 = -j0 / modn;
         const double det = j0 * (-n1) - (-n0) * j1;
         weight = det * w[g];
+        nrm[0] = n0; nrm[1] = n1;
       }
       double tv;
       if (face_expr) {       // the flux is a parsed function of the Gauss point: (*bdcfunc)(&xyzt[0]), 001_Poisson/main.cpp:524-534
@@ -3526,25 +3530,32 @@ __global__ __launch_bounds__(128) void k_neumann(const int* __restrict__ node_pt
       } else {
         tv = tau[f];
       }
-      acc += phi[(size_t)g * nfn + i] * tv * weight;
+      if (NORMAL) {
+#pragma unroll
+        for (int k = 0; k < DIM; k++) accn[k] += phi[(size_t)g * nfn + i] * tv * nrm[k] * weight;
+      } else {
+        acc += phi[(size_t)g * nfn + i] * tv * weight;
+      }
     }
     total += acc;
+#pragma unroll
+    for (int k = 0; k < DIM; k++) totn[k] += accn[k];
   }
-  res[node_id[t]] += total;
+  if (NORMAL) {
+    const int off[3] = {off0, off1, off2};
+#pragma unroll
+    for (int k = 0; k < DIM; k++) res[off[k] + node_id[t]] += scale * totn[k];
+  } else {
+    res[node_id[t]] += total;
+  }
 }
 
-static int neumann_faces(fh_ctx_t ctx, int geom, int fe, int order, int nfaces, const int* face_nodes, const double* tau, const int* face_expr, int nexpr,
-                         const fh_expr_t* exprs, int nnode, const double* coords, fh_vec_t res) {
-  FH_REQUIRE(ctx && res && (nfaces == 0 || (face_nodes && (tau || face_expr) && coords)), "fh_assemble_neumann_faces: null argument");
-  FH_REQUIRE(geom == 0 || geom == 1, "fh_assemble_neumann_faces: geom must be 0 (hex) or 1 (quad)");
-  FH_REQUIRE(fe == 0 || fe == 2, "fh_assemble_neumann_faces: fe must be 0 or 2");
-  if (nfaces == 0) return 0;
-  const int dim = fhfe::dim_of(geom);
+// tables of the face element of `geom` (quad: the 2-D tables; line: 1-D Lagrange at the 1-D Gauss points): weights, phi[g][n], dphi[g][n][dim-1]
+static int face_element_tables(int geom, int fe, int order, int* nfn_out, std::vector<double>& w, std::vector<double>& phi, std::vector<double>& dphi) {
   const int fgeom = (geom == fhfe::GEOM_HEX) ? fhfe::GEOM_QUAD : fhfe::GEOM_LINE;
   int tmp[9];
   const int nfn = fhfe::face_nodes(geom, fe, 0, tmp);
-  // face element tables (quad: the 2-D tables; line: 1-D Lagrange at the 1-D Gauss points)
-  std::vector<double> w, phi, dphi;
+  *nfn_out = nfn;
   if (fgeom == fhfe::GEOM_QUAD) {
     FH_REQUIRE(fhfe::shape_tables(fhfe::GEOM_QUAD, fe, order, w, phi, dphi) == 0, "fh_assemble_neumann_faces: unsupported Gauss rule");
   } else {
@@ -3565,6 +3576,70 @@ static int neumann_faces(fh_ctx_t ctx, int geom, int fe, int order, int nfaces, 
       }
     }
   }
+  return 0;
+}
+
+// unit normals of boundary faces at one face Gauss point, as elem_type::JacobianSur returns them (host; the applications read them to decide what a
+// face contributes, e.g. 03_navier_stokes.hpp:264-275 picks the normal velocity component from the normal at Gauss point 0)
+extern "C" int fh_fe_face_normals(int geom, int fe, int order, int gauss_point, int nfaces, const int* face_nodes, int nnode, const double* coords,
+                                  double* normals /* [nfaces*dim] */) {
+  FH_GUARD_BEGIN
+  FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_face_normals: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(fe == 0 || fe == 2, "fh_fe_face_normals: fe must be 0 or 2");
+  FH_REQUIRE(nfaces == 0 || (face_nodes && coords && normals), "fh_fe_face_normals: null argument");
+  const int dim = fhfe::dim_of(geom);
+  int nfn = 0;
+  std::vector<double> w, phi, dphi;
+  FH_TRY(face_element_tables(geom, fe, order, &nfn, w, phi, dphi));
+  const int g = gauss_point;
+  FH_REQUIRE(g >= 0 && g < (int)w.size(), "fh_fe_face_normals: Gauss point %d of %d", g, (int)w.size());
+  for (int f = 0; f < nfaces; f++) {
+    const int* fn = face_nodes + (size_t)f * nfn;
+    for (int n = 0; n < nfn; n++) FH_REQUIRE(fn[n] >= 0 && fn[n] < nnode, "fh_fe_face_normals: node id out of range");
+    if (dim == 3) {
+      double J[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+      for (int n = 0; n < nfn; n++) {
+        const double dx = dphi[((size_t)g * nfn + n) * 2 + 0], dy = dphi[((size_t)g * nfn + n) * 2 + 1];
+        const double* x = coords + (size_t)fn[n] * 3;
+        for (int d = 0; d < 3; d++) {
+          J[d][0] += dx * x[d];
+          J[d][1] += dy * x[d];
+        }
+      }
+      const double nx = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+      const double ny = J[0][1] * J[2][0] - J[2][1] * J[0][0];
+      const double nz = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+      const double inv = 1.0 / sqrt(nx * nx + ny * ny + nz * nz);
+      normals[(size_t)f * 3 + 0] = nx * inv;
+      normals[(size_t)f * 3 + 1] = ny * inv;
+      normals[(size_t)f * 3 + 2] = nz * inv;
+    } else {
+      double j0 = 0.0, j1 = 0.0;
+      for (int n = 0; n < nfn; n++) {
+        const double dx = dphi[(size_t)g * nfn + n];
+        const double* x = coords + (size_t)fn[n] * 2;
+        j0 += dx * x[0];
+        j1 += dx * x[1];
+      }
+      const double modn = sqrt(j0 * j0 + j1 * j1);
+      normals[(size_t)f * 2 + 0] = j1 / modn;
+      normals[(size_t)f * 2 + 1] = -j0 / modn;
+    }
+  }
+  return 0;
+  FH_GUARD_END("fh_fe_face_normals")
+}
+
+static int neumann_faces(fh_ctx_t ctx, int geom, int fe, int order, int nfaces, const int* face_nodes, const double* tau, const int* face_expr, int nexpr,
+                         const fh_expr_t* exprs, int nnode, const double* coords, fh_vec_t res, const int* comp_offset = nullptr, double scale = 1.0) {
+  FH_REQUIRE(ctx && res && (nfaces == 0 || (face_nodes && (tau || face_expr) && coords)), "fh_assemble_neumann_faces: null argument");
+  FH_REQUIRE(geom == 0 || geom == 1, "fh_assemble_neumann_faces: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(fe == 0 || fe == 2, "fh_assemble_neumann_faces: fe must be 0 or 2");
+  if (nfaces == 0) return 0;
+  const int dim = fhfe::dim_of(geom);
+  int nfn = 0;
+  std::vector<double> w, phi, dphi;
+  FH_TRY(face_element_tables(geom, fe, order, &nfn, w, phi, dphi));
   const int ng = (int)w.size();
   // node -> (face, i) pairs, ascending face order
   std::vector<int> cnt(nnode + 1, 0);
@@ -3585,7 +3660,8 @@ static int neumann_faces(fh_ctx_t ctx, int geom, int fe, int order, int nfaces, 
       node_ptr.push_back((int)pairs.size());
     }
   const int nbn = (int)node_id.size();
-  FH_REQUIRE(res->n_local + res->nghost > node_id.back(), "fh_assemble_neumann_faces: vector too short");
+  FH_REQUIRE(res->n_local + res->nghost > node_id.back() + (comp_offset ? *std::max_element(comp_offset, comp_offset + dim) : 0),
+             "fh_assemble_neumann_faces: vector too short");
   // parsed fluxes: the programs of all expressions back to back
   std::vector<int> h_prog, h_prog_ptr(1, 0), h_const_ptr(1, 0);
   std::vector<double> h_const;
@@ -3633,14 +3709,16 @@ static int neumann_faces(fh_ctx_t ctx, int geom, int fe, int order, int nfaces, 
   const double* d_phi = (const double*)dv[7];
   const double* d_dphi = d_phi + phi.size();
   const dim3 grid(fh_div_up(nbn, 128)), block(128);
-  if (dim == 3)
-    hipLaunchKernelGGL(k_neumann<3>, grid, block, 0, ctx->stream, (const int*)dv[0], (const int*)dv[1], (const int*)dv[2], nbn, (const int*)dv[3], nfn,
-                       (const double*)dv[4], (const double*)dv[5], (const double*)dv[6], d_phi, d_dphi, ng, res->d, (const int*)dv[8], (const int*)dv[9],
-                       (const int*)dv[10], (const double*)dv[11], (const int*)dv[12]);
-  else
-    hipLaunchKernelGGL(k_neumann<2>, grid, block, 0, ctx->stream, (const int*)dv[0], (const int*)dv[1], (const int*)dv[2], nbn, (const int*)dv[3], nfn,
-                       (const double*)dv[4], (const double*)dv[5], (const double*)dv[6], d_phi, d_dphi, ng, res->d, (const int*)dv[8], (const int*)dv[9],
-                       (const int*)dv[10], (const double*)dv[11], (const int*)dv[12]);
+  const int o0 = comp_offset ? comp_offset[0] : 0, o1 = comp_offset ? comp_offset[1] : 0, o2 = (comp_offset && dim == 3) ? comp_offset[2] : 0;
+#define FH_NEUMANN_LAUNCH(D, N)                                                                                                                   \
+  hipLaunchKernelGGL((k_neumann<D, N>), grid, block, 0, ctx->stream, (const int*)dv[0], (const int*)dv[1], (const int*)dv[2], nbn, (const int*)dv[3], \
+                     nfn, (const double*)dv[4], (const double*)dv[5], (const double*)dv[6], d_phi, d_dphi, ng, res->d, (const int*)dv[8],          \
+                     (const int*)dv[9], (const int*)dv[10], (const double*)dv[11], (const int*)dv[12], o0, o1, o2, scale)
+  if (dim == 3 && comp_offset) FH_NEUMANN_LAUNCH(3, true);
+  else if (dim == 3) FH_NEUMANN_LAUNCH(3, false);
+  else if (comp_offset) FH_NEUMANN_LAUNCH(2, true);
+  else FH_NEUMANN_LAUNCH(2, false);
+#undef FH_NEUMANN_LAUNCH
   FH_CHECK_HIP(hipGetLastError());
   FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   for (void* q : dv)
@@ -3652,6 +3730,18 @@ extern "C" int fh_assemble_neumann_faces(fh_ctx_t ctx, int geom, int fe, int ord
                                          const double* coords, fh_vec_t res) {
   FH_REQUIRE(nfaces == 0 || tau, "fh_assemble_neumann_faces: null argument");
   return neumann_faces(ctx, geom, fe, order, nfaces, face_nodes, tau, nullptr, 0, nullptr, nnode, coords, res);
+}
+
+// Open-boundary pressure term of the steady Navier-Stokes residual (03_navier_stokes.hpp:185-290): on the listed boundary faces (those whose
+// normal velocity component is not Dirichlet -- the application's bdc callback decides, :236-262) aResV[k][node_i] += phi_i tau n_k weight with the
+// prescribed pressure tau (a number per face, or expression face_expr[f] at the face Gauss point) and the JacobianSur normal; the residual
+// vector takes scale * that (scale = -1: RES = -aRes, :425).  comp_offset[k]: where component k of the velocity starts in res.
+extern "C" int fh_assemble_pressure_faces(fh_ctx_t ctx, int geom, int order, int nfaces, const int* face_nodes, const double* tau, const int* face_expr,
+                                          int nexpr, const fh_expr_t* exprs, int nnode, const double* coords, const int* comp_offset, double scale,
+                                          fh_vec_t res) {
+  FH_REQUIRE(comp_offset, "fh_assemble_pressure_faces: null component offsets");
+  FH_REQUIRE(nfaces == 0 || tau || face_expr, "fh_assemble_pressure_faces: neither a pressure per face nor expressions");
+  return neumann_faces(ctx, geom, 2, order, nfaces, face_nodes, face_expr ? nullptr : tau, face_expr, nexpr, exprs, nnode, coords, res, comp_offset, scale);
 }
 
 // the flux as a parsed function of the Gauss point (x, y, z, t = 0), as the parsed-boundary-condition branch of the 001_Poisson callback

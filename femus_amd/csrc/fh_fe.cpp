@@ -7,6 +7,7 @@
 //   tables   : 03_fe_evaluations_at_quadrature/ElemType.cpp:576-741
 //   prolong. : 03_fe_evaluations_at_quadrature/ElemType.cpp:439-532
 #include "fh_fe.h"
+#include <utility>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -188,8 +189,16 @@ int face_nodes(int geom, int fe, int face, int* out) {
   const int fgeom = (geom == GEOM_HEX) ? GEOM_QUAD : GEOM_LINE;
   const int nfn_q2 = (geom == GEOM_HEX) ? 9 : 3, nfn_q1 = (geom == GEOM_HEX) ? 4 : 2;
   const int nfn = (fe == FE_LINEAR) ? nfn_q1 : nfn_q2;
-  // free coordinates in cyclic order after d0
-  const int a = (d0 + 1) % d, b = (d0 + 2) % d;
+  // free coordinates in cyclic order after d0, oriented so that the normal elem_type::JacobianSur derives from the node order (t_a x t_b on a
+  // quadrilateral face, (t_y, -t_x) on an edge) points OUT of the element, as with the reference's own face tables (hex_lag / quad_lag faceDofs;
+  // the sign matters to vector-valued boundary terms such as the pressure integral of 03_navier_stokes.hpp:185-290)
+  int a = (d0 + 1) % d, b = (d0 + 2) % d;
+  bool reverse = false;
+  if (d == 3) {
+    if (sgn < 0) std::swap(a, b);
+  } else {
+    reverse = (d0 == 0) ? (sgn < 0) : (sgn > 0);
+  }
   for (int i = 0; i < nfn; i++) {
     int xi, eta = 0;
     if (fgeom == GEOM_QUAD) {
@@ -197,7 +206,7 @@ int face_nodes(int geom, int fe, int face, int* out) {
       eta = XC_QUAD[i][1];
     } else {
       static const int XC_LINE[3] = {-1, 1, 0};
-      xi = XC_LINE[i];
+      xi = reverse ? -XC_LINE[i] : XC_LINE[i];
     }
     out[i] = -1;
     for (int n = 0; n < nloc_of(geom); n++) {

@@ -54,9 +54,43 @@ def generate_bdc(mesh, names, fes, offsets, fn):
     return idx, np.array([val[i] for i in idx])
 
 
+def open_boundary_faces(mesh, names, fn):
+    """which boundary faces carry the pressure integral of 03_navier_stokes.hpp:185-290, and the pressure on each.  Per face with a boundary flag:
+    the bdc callback of every velocity component at the mean of the Q2 face nodes (:216-262), the JacobianSur normal at face Gauss point 0, the
+    LAST component d with |n_d| >= 1e-4 as the normal velocity (:264-275); the face is kept when that component is not Dirichlet there.
+    Returns (face_nodes [nf, nfn], face_name [nf]); tau is asked per Gauss point by the caller"""
+    ed, xy, ff = mesh.arrays()
+    dim = mesh.dim
+    faces, fnames = [], []
+    for f in range(ff.shape[1]):
+        loc = capi.fe_face_nodes(mesh.geom, "biquadratic", f)
+        els = np.where(ff[:, f] < -1)[0]
+        if els.size == 0:
+            continue
+        nodes = ed[els][:, loc]
+        normals = capi.face_normals(mesh, "biquadratic", nodes, 0, coords=xy)
+        for q, iel in enumerate(els):
+            face_name = -(int(ff[iel, f]) + 1)
+            centre = np.zeros(dim)
+            for d in range(dim):
+                for n in nodes[q]:
+                    centre[d] += xy[n, d]
+                centre[d] /= nodes.shape[1]
+            is_dir = [fn(centre, names[d], face_name)[0] for d in range(dim)]
+            comp = 0
+            for d in range(dim):
+                if abs(normals[q, d]) >= 1.0e-4:
+                    comp = d
+            if not is_dir[comp]:
+                faces.append(nodes[q])
+                fnames.append(face_name)
+    nfn = 3 ** (dim - 1)
+    return (np.array(faces, np.int32).reshape(-1, nfn), np.array(fnames, np.int32))
+
+
 class NavierStokesMG:
     def __init__(self, ctx, nx, ny, nz, nlevels, nu, lo=(-0.5, -0.5, -0.5), hi=(0.5, 0.5, 0.5), omega=0.6, npre=2, npost=2,
-                 order="seventh", boundary_condition=None):
+                 order="seventh", boundary_condition=None, open_pressure=None):
         self.ctx, self.nlevels, self.nu = ctx, nlevels, nu
         self.omega, self.npre, self.npost, self.order = omega, npre, npost, order
         self.meshes = [capi.Mesh.box(nx, ny, nz, lo, hi)]
@@ -67,6 +101,9 @@ class NavierStokesMG:
         self.fes = ["biquadratic"] * self.dim + ["linear"]
         lo_, hi_ = np.array(lo[:self.dim], float), np.array(hi[:self.dim], float)
         self.bc = boundary_condition or (lambda x, name, face: cavity_boundary_condition(x, name, face, lo_, hi_))
+        # open_pressure: {face name: number or capi.Expr} -- the pressure the bdc callback prescribes for "P" on the faces whose normal velocity is
+        # free (03_navier_stokes.hpp:280); None: no face of the problem is open (the cavity) and the boundary integral is skipped
+        self.open_pressure = open_pressure
         self.history = []
 
     # ---- LinearImplicitSystem::init --------------------------------------------------------------------------------
@@ -92,6 +129,7 @@ class NavierStokesMG:
             self.SOL.append(ctx.vector_from(sol))
             self.RES.append(ctx.vector(n)), self.EPS.append(ctx.vector(n)), self.RESC.append(ctx.vector(n))
             self.patches.append(capi.vertex_patches(m, self.fes) if l > 0 else None)
+        self.open_faces = [open_boundary_faces(m, self.names, self.bc) if self.open_pressure else None for m in self.meshes]
         # interpolation of the stacked variables: Psol for ProlongatorSol (untouched), P for the cycle (Dirichlet rows/cols zeroed)
         self.Psol, self.P = [None], [None]
         for l in range(1, nl):
@@ -109,6 +147,7 @@ class NavierStokesMG:
         """assemble residual + Jacobian at the current SOL[ig]; Galerkin chain; SetPenalty; MGInit / MGSetLevel"""
         ctx = self.ctx
         self.asm[ig].assemble(self.KK[ig], self.RES[ig], self.SOL[ig], self.nu)
+        self.add_open_boundary_pressure(ig)
         self.A[(ig, ig)] = self.KK[ig]
         for l in range(ig, 0, -1):                                     # PtAP chain from the un-penalised operators
             if (ig, l - 1) not in self.A:
@@ -129,6 +168,23 @@ class NavierStokesMG:
                          self.npre if l > 0 else 1, self.npost if l > 0 else 0)
         mg.setup()
         return mg
+
+    def add_open_boundary_pressure(self, ig):
+        """RES -= int phi tau n over the open faces (data only: the Jacobian does not change)"""
+        if not self.open_pressure:
+            return
+        faces, fnames = self.open_faces[ig]
+        if faces.shape[0] == 0:
+            return
+        off = self.offsets[ig][:self.dim]
+        consts = {k: v for k, v in self.open_pressure.items() if not isinstance(v, capi.Expr)}
+        exprs = {k: v for k, v in self.open_pressure.items() if isinstance(v, capi.Expr)}
+        sel = np.isin(fnames, list(consts))
+        if sel.any():
+            capi.assemble_pressure_faces(self.ctx, self.meshes[ig], self.RES[ig], faces[sel], np.array([consts[int(k)] for k in fnames[sel]], float), off)
+        sel = np.isin(fnames, list(exprs))
+        if sel.any():
+            capi.assemble_pressure_faces(self.ctx, self.meshes[ig], self.RES[ig], faces[sel], [(e, fnames[sel] == k) for k, e in exprs.items()], off)
 
     def newton_step(self, ig, lin_rtol=1e-10, lin_maxit=60, restart=30):
         mg = self.prepare(ig)

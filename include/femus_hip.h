@@ -329,6 +329,16 @@ int fh_assemble_poisson_expr(fh_assembler_t as, fh_vec_t sol, fh_expr_t source, 
  * one of the nexpr expressions (one per boundary face name in the application); everything else as fh_assemble_neumann_faces */
 int fh_assemble_neumann_faces_expr(fh_ctx_t ctx, int geom, int fe, int gauss_order, int nfaces, const int* face_nodes, const int* face_expr,
                                    int nexpr, const fh_expr_t* exprs, int nnode, const double* coords, fh_vec_t res);
+/* Open-boundary pressure term of the steady Navier-Stokes residual (src/08_equations/assemble/03_navier_stokes.hpp:185-290): on every listed boundary
+ * face  aResV[k][node_i] += phi_i * tau * normal[k] * weight  for the dim velocity components (Q2 face nodes), tau = the prescribed pressure -- one
+ * number per face (tau) or expression face_expr[f] of the nexpr expressions evaluated at the face Gauss point, as the bdc callback is (:280) -- and
+ * normal / weight from elem_type::JacobianSur at that Gauss point.  res[comp_offset[k] + node] receives scale * the sum (scale = -1: RES = -aRes,
+ * :377-381).  Which faces: the application's decision (normal velocity component not Dirichlet, :236-276); fh_fe_face_normals returns the normals it
+ * reads for that (host arrays; Gauss point 0 in the reference). */
+int fh_assemble_pressure_faces(fh_ctx_t ctx, int geom, int gauss_order, int nfaces, const int* face_nodes, const double* tau, const int* face_expr,
+                               int nexpr, const fh_expr_t* exprs, int nnode, const double* coords, const int* comp_offset, double scale, fh_vec_t res);
+int fh_fe_face_normals(int geom, int fe, int gauss_order, int gauss_point, int nfaces, const int* face_nodes, int nnode, const double* coords,
+                       double* normals /* [nfaces*dim] */);
 
 /* ---- multi-variable systems and the Navier-Stokes Newton path (a9, a21) --------------------------------------------
  * Variables are stacked per rank: system dof = KKoffset[k] + mesh dof (LinearEquation::GetSystemDof, LinearEquation.cpp:76-85,

@@ -1166,12 +1166,18 @@ def face_local_nodes(geom, fe, face, table=None):
     centre = (20 + face) if geom == "hex" else (4 + face)
     d0 = int(np.nonzero(Xc[centre])[0][0])
     sgn = Xc[centre, d0]
+    # orientation: the JacobianSur normal of the node order points out of the element, as with the reference's faceDofs tables (the golden
+    # fixture facedofs_hex / facedofs_quad holds those; same cyclic order, possibly another starting node)
     if geom == "hex":
         ref = XC_QUAD9[:4] if fe == "linear" else XC_QUAD9
         a, b = (d0 + 1) % 3, (d0 + 2) % 3
+        if sgn < 0:
+            a, b = b, a
         return np.array([np.where((Xc[:, d0] == sgn) & (Xc[:, a] == r[0]) & (Xc[:, b] == r[1]))[0][0] for r in ref])
     ref = np.array([-1.0, 1.0]) if fe == "linear" else np.array([-1.0, 1.0, 0.0])
     a = (d0 + 1) % 2
+    if (sgn < 0) if d0 == 0 else (sgn > 0):
+        ref = -ref
     return np.array([np.where((Xc[:, d0] == sgn) & (Xc[:, a] == r))[0][0] for r in ref])
 
 

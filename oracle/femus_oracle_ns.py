@@ -104,6 +104,53 @@ def assemble_ns(mesh, lay, sol, nu, order="seventh", pattern=None):
     return sp.csr_matrix((vals, indices, indptr), shape=(lay.n, lay.n)), b
 
 
+def pressure_boundary_residual(mesh, lay, bc, order="seventh", face_tables=None):
+    """Boundary integral for the "P" part, 03_navier_stokes.hpp:185-290, loop for loop: every element, every face with a boundary flag
+    (GetFaceElementIndex < 0, :196-198; flags < -1 here: -1 is "no neighbour, no name" and the box / Gambit meshes of this tier have none on the
+    boundary); face coordinates (Q2 face nodes) and their mean (:205-229); the bdc callback of every velocity component at that mean (:232-246);
+    normal from JacobianSur at Gauss point 0 (:249-254); the last component with |n_d| >= 1e-4 is the normal velocity (:257-262); if it is not
+    Dirichlet: Gauss loop with xg = sum phi_i x_i, tau = bdc("P") at xg, aResV[k][inode] += phi_i tau n_k weight (:266-290).
+    bc(x, name, face_name) -> (is_dirichlet, value).  face_tables: the reference's faceDofs rows (GetLocalFaceVertexIndex, :223; golden fixture);
+    default = this oracle's own outward-oriented face order.  Returns aRes scattered to the system dofs (RES receives minus this, :377-381)."""
+    geom, dim = mesh.geom, mesh.dim
+    names = ["U", "V", "W"][:dim]
+    out = np.zeros(lay.n)
+    ng = fo.gauss_table("quad" if geom == "hex" else "line", order)[0].size
+    for iel in range(mesh.nel):
+        for jface in range(mesh.face_flag.shape[1]):
+            flag = int(mesh.face_flag[iel, jface])
+            if flag >= -1:
+                continue
+            face_index = -(flag + 1)
+            loc = fo.face_local_nodes(geom, "biquadratic", jface, None if face_tables is None else face_tables[jface])
+            nodes = mesh.elem_dof[iel, loc]
+            vt = [mesh.coords[nodes, d] for d in range(dim)]
+            centre = np.zeros(dim)
+            for d in range(dim):
+                for i in range(nodes.size):
+                    centre[d] += vt[d][i]
+                centre[d] /= nodes.size
+            is_dir = [bc(centre, names[d], face_index)[0] for d in range(dim)]
+            _, _, normal = fo.jacobian_sur(geom, "biquadratic", order, vt, 0)
+            comp = 0
+            for d in range(dim):
+                if abs(normal[d]) >= 1.0e-4:
+                    comp = d
+            if is_dir[comp]:
+                continue
+            for ig in range(ng):
+                weight, phi, normal = fo.jacobian_sur(geom, "biquadratic", order, vt, ig)
+                xg = np.zeros(dim)
+                for i in range(nodes.size):
+                    for k in range(dim):
+                        xg[k] += phi[i] * vt[k][i]
+                tau = bc(xg, "P", face_index)[1]
+                for i in range(nodes.size):
+                    for k in range(dim):
+                        out[lay.offset[k] + nodes[i]] += phi[i] * tau * normal[k] * weight
+    return out
+
+
 def csr_pattern_sys(lay):
     es = lay.elem_sys.astype(np.int64)
     nd, n = lay.nd, lay.n

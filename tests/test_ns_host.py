@@ -73,3 +73,40 @@ def test_host_cavity_boundary_lists_match_oracle():
         assert (val == 1.0).sum() == 2 * int(round(b.nel ** 0.5)) - 1      # the moving wall without its two end nodes
     for a in mh:
         a.destroy()
+
+
+@pytest.mark.parametrize("box", [(3, 2, 0), (2, 2, 2)])
+def test_open_boundary_pressure_integral_properties(box):
+    """03_navier_stokes.hpp:185-290 restated (oracle) + the product's host-side face selection: a constant pressure on one axis-parallel side sums
+    to tau * area * n in the normal component and to zero in the others; all sides open with one pressure sum to zero (closed surface); the
+    product's face order gives the reference's outward normals (golden faceDofs tables of the compiled reference)"""
+    import os
+    from femus_amd import capi
+    from femus_amd.navier_stokes import open_boundary_faces
+    dim = 2 if box[2] == 0 else 3
+    lo, hi = (0.0, 0.0, 0.0), (2.0, 1.0, 1.5)
+    mo = fo.build_levels(*box, 2, lo, hi)[-1]
+    lay = ns.NSLayout(mo)
+    outlet = 2 if dim == 2 else 3                                           # x = hi
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fe_tables.npz"))
+    tabs = G["facedofs_quad" if dim == 2 else "facedofs_hex"]
+    one = lambda x, name, face: ((name != "U" or face != outlet) and name != "P", 3.0)
+    r = ns.pressure_boundary_residual(mo, lay, one, face_tables=tabs)
+    area = 1.0 if dim == 2 else 1.5
+    comp = [r[lay.offset[k]:lay.offset[k + 1]].sum() for k in range(dim)]
+    assert abs(comp[0] - 3.0 * area) <= 1e-13 and all(abs(c) <= 1e-13 for c in comp[1:])       # outward normal (+1, 0, 0)
+    free = lambda x, name, face: (False, 3.0)
+    r = ns.pressure_boundary_residual(mo, lay, free, face_tables=tabs)
+    assert abs(r).max() > 0.1 and all(abs(r[lay.offset[k]:lay.offset[k + 1]].sum()) <= 1e-12 for k in range(dim))
+    # the product's own tables: same cyclic orientation as the reference's, the host-side selection picks the same faces
+    mh = capi.Mesh.box(*box, lo, hi).refine()
+    for f in range(2 * dim):
+        p = list(capi.fe_face_nodes(mh.geom, "biquadratic", f)[:2 ** (dim - 1)])
+        t = list(tabs[f][:2 ** (dim - 1)])
+        k = t.index(p[0])
+        assert t[k:] + t[:k] == p
+    faces, names = open_boundary_faces(mh, ["U", "V", "W"][:dim] + ["P"], one)
+    assert set(names.tolist()) == {outlet} and faces.shape[0] == (mo.face_flag == -(outlet + 1)).sum()
+    nrm = capi.face_normals(mh, "biquadratic", faces, 0)
+    assert abs(nrm[:, 0] - 1.0).max() <= 1e-14 and abs(nrm[:, 1:]).max() <= 1e-14
+    mh.destroy()
