@@ -114,6 +114,8 @@ def _declare(L):
     sig("fh_spmv_transpose", c_void_p, c_void_p, c_void_p)
     sig("fh_fe_gauss", c_int, c_int, P(c_int), c_void_p, c_void_p)
     sig("fh_fe_tables", c_int, c_int, c_int, P(c_int), P(c_int), c_void_p, c_void_p)
+    sig("fh_fe_tables_d2", c_int, c_int, c_int, c_void_p)
+    sig("fh_fe_jacobian", c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p)
     sig("fh_fe_elem_prolongator", c_int, c_int, P(c_int), P(c_int), c_void_p)
     sig("fh_mesh_box", c_int, c_int, c_int, c_void_p, c_void_p, P(c_void_p))
     sig("fh_mesh_refine", c_void_p, P(c_void_p))

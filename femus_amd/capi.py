@@ -671,6 +671,33 @@ def fe_tables(geom, fe, order):
     return phi, np.transpose(dphi, (1, 2, 0)).copy()
 
 
+def fe_tables_d2(geom, fe, order):
+    """second derivatives at the Gauss points, [ng, nc, nh]: (xx, yy, xy) in 2-D, (xx, yy, zz, xy, yz, zx) in 3-D"""
+    L = load_library()
+    nh = 6 if geom == "hex" else 3
+    phi, _ = fe_tables(geom, fe, order)
+    d2 = np.empty((nh,) + phi.shape)
+    _chk(L.fh_fe_tables_d2(GEOM[geom], FE[fe], GAUSS_ORDER[order], _p(d2)))
+    return np.transpose(d2, (1, 2, 0)).copy()
+
+
+def fe_jacobian(ctx, mesh, fe, order="seventh", hessians=False, elem_dof=None, coords=None):
+    """elem_type::Jacobian for every element and Gauss point (fh_fe_jacobian): weight[nel, ng], gradphi[nel, ng, nc, dim] and, when asked,
+    nablaphi[nel, ng, nc, nh]"""
+    ed, xy, _ = mesh.arrays()
+    ed = _i32(ed if elem_dof is None else elem_dof)
+    xy = _f64(xy if coords is None else coords)
+    phi, _ = fe_tables(mesh.geom, fe, order)
+    ng, nc = phi.shape
+    dim, nh = mesh.dim, (3 if mesh.dim == 2 else 6)
+    nel = ed.shape[0]
+    w, g = np.empty((nel, ng)), np.empty((nel, ng, nc, dim))
+    n = np.empty((nel, ng, nc, nh)) if hessians else None
+    _chk(ctx.L.fh_fe_jacobian(ctx.h, GEOM[mesh.geom], FE[fe], GAUSS_ORDER[order], nel, ed.shape[1], _p(ed), xy.shape[0], _p(xy), _p(w), _p(g),
+                              _p(n) if hessians else None))
+    return (w, g, n) if hessians else (w, g)
+
+
 def fe_elem_prolongator(geom, fe):
     L = load_library()
     nch, nc = ctypes.c_int(), ctypes.c_int()

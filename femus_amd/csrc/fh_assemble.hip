@@ -3464,6 +3464,141 @@ extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, con
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// a4 in full: elem_type::Jacobian (ElemType.hpp:1183-1248 2-D, :1438-1537 3-D) for every (element, Gauss point) of a mesh, with the optional
+// Hessians `nablaphi` (:1509-1534, :1232-1244): one thread per (element, Gauss point), the reference's accumulation order and bracketing.
+// The Hessian formula is the reference's: JacI^T (reference Hessian) JacI, i.e. without the second derivatives of the map (exact on affine elements).
+// ------------------------------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ __launch_bounds__(128) void k_fe_jacobian(int nel, int ng, int nc, int nloc, const int* __restrict__ ed, const double* __restrict__ coords,
+                                                     const double* __restrict__ w, const double* __restrict__ dphi, const double* __restrict__ d2phi,
+                                                     double* __restrict__ weight, double* __restrict__ gradphi, double* __restrict__ nablaphi) {
+  constexpr int NH = DIM == 2 ? 3 : 6;
+  const size_t t = (size_t)blockIdx.x * 128 + threadIdx.x;
+  if (t >= (size_t)nel * ng) return;
+  const int e = (int)(t / ng), g = (int)(t % ng);
+  const int* en = ed + (size_t)e * nloc;
+  const double* dp = dphi + (size_t)g * nc * DIM;
+  double J[DIM][DIM], I[DIM][DIM];
+  for (int a = 0; a < DIM; a++)
+    for (int b = 0; b < DIM; b++) J[a][b] = 0.0;
+  for (int n = 0; n < nc; n++) {
+    const double* x = coords + (size_t)en[n] * DIM;
+    for (int a = 0; a < DIM; a++)
+      for (int b = 0; b < DIM; b++) J[a][b] += dp[n * DIM + a] * x[b];
+  }
+  double det;
+  if (DIM == 2) {
+    det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    I[0][0] = J[1][1] / det;
+    I[0][1] = -J[0][1] / det;
+    I[1][0] = -J[1][0] / det;
+    I[1][1] = J[0][0] / det;
+  } else {
+    det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[1][2] * J[2][0] - J[1][0] * J[2][2]) + J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+    I[0][0] = (-J[1][2] * J[2][1] + J[1][1] * J[2][2]) / det;
+    I[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+    I[0][2] = (-J[0][2] * J[1][1] + J[0][1] * J[1][2]) / det;
+    I[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) / det;
+    I[1][1] = (-J[0][2] * J[2][0] + J[0][0] * J[2][2]) / det;
+    I[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+    I[2][0] = (-J[1][1] * J[2][0] + J[1][0] * J[2][1]) / det;
+    I[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+    I[2][2] = (-J[0][1] * J[1][0] + J[0][0] * J[1][1]) / det;
+  }
+  if (weight) weight[t] = det * w[g];
+  for (int n = 0; n < nc; n++) {
+    if (gradphi)
+      for (int a = 0; a < DIM; a++) {
+        double sum = dp[n * DIM + 0] * I[a][0];
+        for (int b = 1; b < DIM; b++) sum += dp[n * DIM + b] * I[a][b];
+        gradphi[(t * nc + n) * DIM + a] = sum;
+      }
+    if (nablaphi) {
+      const double* h = d2phi + ((size_t)g * nc + n) * NH;
+      double H[DIM][DIM];      // reference Hessian, symmetric
+      if (DIM == 2) {
+        H[0][0] = h[0]; H[1][1] = h[1]; H[0][1] = H[1][0] = h[2];
+      } else {
+        H[0][0] = h[0]; H[1][1] = h[1]; H[2][2] = h[2];
+        H[0][1] = H[1][0] = h[3]; H[1][2] = H[2][1] = h[4]; H[0][2] = H[2][0] = h[5];
+      }
+      auto entry = [&](int a, int b) {
+        double out = 0.0;
+        for (int r = 0; r < DIM; r++) {
+          double row = H[r][0] * I[a][0];
+          for (int c2 = 1; c2 < DIM; c2++) row += H[r][c2] * I[a][c2];
+          out += row * I[b][r];
+        }
+        return out;
+      };
+      double* o = nablaphi + (t * nc + n) * NH;
+      if (DIM == 2) {
+        o[0] = entry(0, 0); o[1] = entry(1, 1); o[2] = entry(0, 1);
+      } else {
+        o[0] = entry(0, 0); o[1] = entry(1, 1); o[2] = entry(2, 2);
+        o[3] = entry(0, 1); o[4] = entry(1, 2); o[5] = entry(2, 0);
+      }
+    }
+  }
+}
+
+extern "C" int fh_fe_tables_d2(int geom, int fe, int order, double* d2phi);
+
+extern "C" int fh_fe_jacobian(fh_ctx_t ctx, int geom, int fe, int order, int nel, int nloc, const int* elem_dof, int nnode, const double* coords,
+                              double* weight, double* gradphi, double* nablaphi) {
+  FH_GUARD_BEGIN
+  FH_REQUIRE(ctx && (nel == 0 || (elem_dof && coords)), "fh_fe_jacobian: null argument");
+  FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_jacobian: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(fe == 0 || fe == 2, "fh_fe_jacobian: fe must be 0 (linear) or 2 (biquadratic)");
+  FH_REQUIRE(nloc == fhfe::nloc_of(geom), "fh_fe_jacobian: nloc %d does not match the geometry (%d)", nloc, fhfe::nloc_of(geom));
+  if (nel == 0) return 0;
+  const int dim = fhfe::dim_of(geom), nc = fhfe::ndofs_of(geom, fe), nh = dim == 2 ? 3 : 6;
+  std::vector<double> w, phi, dphi;
+  FH_REQUIRE(fhfe::shape_tables(geom, fe, order, w, phi, dphi) == 0, "fh_fe_jacobian: unsupported Gauss rule %d", order);
+  const int ng = (int)w.size();
+  for (size_t k = 0; k < (size_t)nel * nloc; k++) FH_REQUIRE(elem_dof[k] >= 0 && elem_dof[k] < nnode, "fh_fe_jacobian: node id %d out of range", elem_dof[k]);
+  std::vector<double> d2((size_t)ng * nc * nh, 0.0);
+  if (nablaphi) {
+    std::vector<double> tab((size_t)nh * ng * nc);
+    FH_TRY(fh_fe_tables_d2(geom, fe, order, tab.data()));
+    for (int k = 0; k < nh; k++)
+      for (int g = 0; g < ng; g++)
+        for (int n = 0; n < nc; n++) d2[((size_t)g * nc + n) * nh + k] = tab[((size_t)k * ng + g) * nc + n];
+  }
+  struct Bufs {
+    std::vector<void*> p;
+    ~Bufs() { for (void* q : p) if (q) hipFree(q); }
+  } B;
+  auto dev = [&](void** d, const void* h, size_t bytes) -> int {
+    FH_CHECK_HIP(hipMalloc(d, bytes ? bytes : 8));
+    B.p.push_back(*d);
+    if (h && bytes) FH_CHECK_HIP(hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+  };
+  const size_t npt = (size_t)nel * ng;
+  int* d_ed;
+  double *d_xy, *d_w, *d_dphi, *d_d2, *d_wt = nullptr, *d_g = nullptr, *d_n = nullptr;
+  FH_TRY(dev((void**)&d_ed, elem_dof, (size_t)nel * nloc * sizeof(int)));
+  FH_TRY(dev((void**)&d_xy, coords, (size_t)nnode * dim * sizeof(double)));
+  FH_TRY(dev((void**)&d_w, w.data(), w.size() * sizeof(double)));
+  FH_TRY(dev((void**)&d_dphi, dphi.data(), dphi.size() * sizeof(double)));
+  FH_TRY(dev((void**)&d_d2, d2.data(), d2.size() * sizeof(double)));
+  if (weight) FH_TRY(dev((void**)&d_wt, nullptr, npt * sizeof(double)));
+  if (gradphi) FH_TRY(dev((void**)&d_g, nullptr, npt * nc * dim * sizeof(double)));
+  if (nablaphi) FH_TRY(dev((void**)&d_n, nullptr, npt * nc * nh * sizeof(double)));
+  const dim3 grid((unsigned)((npt + 127) / 128)), block(128);
+  if (dim == 3) hipLaunchKernelGGL(k_fe_jacobian<3>, grid, block, 0, ctx->stream, nel, ng, nc, nloc, d_ed, d_xy, d_w, d_dphi, d_d2, d_wt, d_g, d_n);
+  else hipLaunchKernelGGL(k_fe_jacobian<2>, grid, block, 0, ctx->stream, nel, ng, nc, nloc, d_ed, d_xy, d_w, d_dphi, d_d2, d_wt, d_g, d_n);
+  FH_CHECK_HIP(hipGetLastError());
+  if (weight) FH_CHECK_HIP(hipMemcpyAsync(weight, d_wt, npt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (gradphi) FH_CHECK_HIP(hipMemcpyAsync(gradphi, d_g, npt * nc * dim * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (nablaphi) FH_CHECK_HIP(hipMemcpyAsync(nablaphi, d_n, npt * nc * nh * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+  FH_GUARD_END("fh_fe_jacobian")
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Neumann boundary faces (a5: elem_type::JacobianSur).  One thread per boundary node: it owns the node's (face, local i)
 // pairs (ascending face order) and integrates phi_i * tau over each face with the face element's quadrature.
 // ------------------------------------------------------------------------------------------------------------------

@@ -109,6 +109,36 @@ static inline double dlagL(double, int i) { return (!i) * (-0.5) + !(i - 2) * 0.
 static inline double lagB(double x, int i) { return !i * 0.5 * x * (x - 1.) + !(i - 1) * (1. - x) * (1. + x) + !(i - 2) * 0.5 * x * (1. + x); }
 static inline double dlagB(double x, int i) { return !i * (x - 0.5) + !(i - 1) * (-2. * x) + !(i - 2) * (x + 0.5); }
 
+static inline double d2lagB(int i) { return !i * 1.0 + !(i - 1) * (-2.0) + !(i - 2) * 1.0; }
+
+// second derivatives, node-major [nc][nh]: 3-D (xx, yy, zz, xy, yz, zx), 2-D (xx, yy, xy) -- the order of elem_type's _d2phidxi2, _d2phideta2,
+// _d2phidzeta2, _d2phidxideta, _d2phidetadzeta, _d2phidzetadxi (ElemType.cpp:637-741).  The pure second derivatives of the (bi/tri)linear
+// family are identically zero; the mixed ones are not.
+void eval_basis_d2(int geom, int fe, const double* pt, double* d2phi) {
+  const int d = dim_of(geom), nc = ndofs_of(geom, fe);
+  for (int j = 0; j < nc; j++) {
+    double l[3], dl[3], d2l[3];
+    for (int k = 0; k < d; k++) {
+      const int I = xc(geom, j, k) + 1;
+      l[k] = (fe == FE_LINEAR) ? lagL(pt[k], I) : lagB(pt[k], I);
+      dl[k] = (fe == FE_LINEAR) ? dlagL(pt[k], I) : dlagB(pt[k], I);
+      d2l[k] = (fe == FE_LINEAR) ? 0.0 : d2lagB(I);
+    }
+    if (d == 2) {
+      d2phi[j * 3 + 0] = d2l[0] * l[1];
+      d2phi[j * 3 + 1] = l[0] * d2l[1];
+      d2phi[j * 3 + 2] = dl[0] * dl[1];
+    } else {
+      d2phi[j * 6 + 0] = d2l[0] * l[1] * l[2];
+      d2phi[j * 6 + 1] = l[0] * d2l[1] * l[2];
+      d2phi[j * 6 + 2] = l[0] * l[1] * d2l[2];
+      d2phi[j * 6 + 3] = dl[0] * dl[1] * l[2];
+      d2phi[j * 6 + 4] = l[0] * dl[1] * dl[2];
+      d2phi[j * 6 + 5] = dl[0] * l[1] * dl[2];
+    }
+  }
+}
+
 void eval_basis(int geom, int fe, const double* pt, double* phi, double* dphi /* [nc*dim] node-major */) {
   const int d = dim_of(geom), nc = ndofs_of(geom, fe);
   for (int j = 0; j < nc; j++) {
@@ -247,6 +277,23 @@ extern "C" int fh_fe_tables(int geom, int fe, int order, int* ng, int* nc, doubl
       for (int k = 0; k < d; k++)
         for (int ig = 0; ig < g; ig++)
           for (int j = 0; j < n; j++) dphi[((size_t)k * g + ig) * n + j] = dp[((size_t)ig * n + j) * d + k];
+  }
+  return 0;
+}
+
+extern "C" int fh_fe_tables_d2(int geom, int fe, int order, double* d2phi) {
+  FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_tables_d2: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(fe == 0 || fe == 2, "fh_fe_tables_d2: fe must be 0 (linear) or 2 (biquadratic)");
+  FH_REQUIRE(order >= 0 && order <= 4 && d2phi, "fh_fe_tables_d2: bad arguments");
+  const int d = fhfe::dim_of(geom), n = fhfe::ndofs_of(geom, fe), g = fhfe::gauss_npoints(geom, order), nh = d == 2 ? 3 : 6;
+  std::vector<double> w(g), x((size_t)g * d), t((size_t)n * nh);
+  fhfe::gauss_table(geom, order, w.data(), x.data());
+  for (int ig = 0; ig < g; ig++) {
+    double pt[3] = {0, 0, 0};
+    for (int k = 0; k < d; k++) pt[k] = x[(size_t)k * g + ig];
+    fhfe::eval_basis_d2(geom, fe, pt, t.data());
+    for (int k = 0; k < nh; k++)      // reference layout: one [ng][nc] table per second derivative
+      for (int j = 0; j < n; j++) d2phi[((size_t)k * g + ig) * n + j] = t[(size_t)j * nh + k];
   }
   return 0;
 }

@@ -15,6 +15,7 @@ int xc(int geom, int node, int d);   // local node coordinates in {-1,0,1}
 int gauss_npoints(int geom, int order);
 int gauss_table(int geom, int order, double* w, double* x);
 void eval_basis(int geom, int fe, const double* pt, double* phi, double* dphi);
+void eval_basis_d2(int geom, int fe, const double* pt, double* d2phi /* [nc][3 or 6] */);
 int shape_tables(int geom, int fe, int order, std::vector<double>& w, std::vector<double>& phi, std::vector<double>& dphi);
 void child_node_ref(int geom, int child, int node, double* pt);
 int fine2coarse_vertex(int geom, int child, int v);

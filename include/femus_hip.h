@@ -200,6 +200,15 @@ int fh_spmv_expected_bytes(fh_mat_t A, int mode, int64_t* lo, int64_t* hi);
  * Gauss: src/02_reference_geom_elements/02_quadrature/ ; basis: 01_fe/ ; tables: 03_fe_evaluations_at_quadrature/ElemType.cpp:576-741 */
 int fh_fe_gauss(int geom, int gauss_order, int* ng, double* w, double* x /* [dim*ng], x[d*ng+ig] */);
 int fh_fe_tables(int geom, int fe, int gauss_order, int* ng, int* nc, double* phi /* [ng*nc] */, double* dphi /* [dim][ng*nc] */);
+/* second derivatives at the Gauss points, one [ng*nc] table per derivative in the order of elem_type's members (ElemType.cpp:637-741):
+ * 3-D _d2phidxi2, _d2phideta2, _d2phidzeta2, _d2phidxideta, _d2phidetadzeta, _d2phidzetadxi; 2-D _d2phidxi2, _d2phideta2, _d2phidxideta */
+int fh_fe_tables_d2(int geom, int fe, int gauss_order, double* d2phi /* [3 or 6][ng*nc] */);
+/* elem_type::Jacobian(vt, ig, Weight, phi, gradphi, nablaphi) (ElemType.hpp:1183-1248 2-D, :1438-1537 3-D; public wrappers :675-679, :846-850) for
+ * EVERY element and Gauss point of a mesh in one launch: vt = the coordinates of the element's first nc nodes.  Host arrays in and out:
+ * weight[nel*ng]; gradphi[(e*ng + ig)*nc*dim + dim*j + d]; nablaphi[(e*ng + ig)*nc*nh + nh*j + k], nh = 3 (xx, yy, xy) or 6 (xx, yy, zz, xy,
+ * yz, zx) -- the reference's optional Hessians (:1509-1534, :1232-1244); an output passed as NULL is not computed.  phi is fh_fe_tables' */
+int fh_fe_jacobian(fh_ctx_t ctx, int geom, int fe, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, const double* coords,
+                   double* weight, double* gradphi, double* nablaphi);
 int fh_fe_elem_prolongator(int geom, int fe, int* nchild, int* nc, double* P /* [nchild*nc*nc], |.|<1e-14 -> 0 (ElemType.cpp:439-532) */);
 
 /* ---- mesh + DOF maps (a8-a10): box generator, uniform refinement, first-touch numbering, nprocs=1 ----

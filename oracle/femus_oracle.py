@@ -199,8 +199,9 @@ class ElemType:
         self.phi, self.dphi, self.d2phi = eval_basis(geom, fe, self.xg)
 
     # a4. elem_type_{2,3}D::Jacobian_type<double> (ElemType.hpp:1183-1248, 1438-1537)
-    def jacobian(self, vt, ig):
-        """vt[dim][>=nc] element node coordinates (SoA).  Returns Weight, phi[nc], gradphi[nc*dim]."""
+    def jacobian(self, vt, ig, nabla=False):
+        """vt[dim][>=nc] element node coordinates (SoA).  Returns Weight, phi[nc], gradphi[nc*dim]; with nabla=True also the optional Hessians
+        nablaphi[nc*nh] of ElemType.hpp:1232-1244 (2-D: xx, yy, xy) / :1509-1534 (3-D: xx, yy, zz, xy, yz, zx), bracketed as written there."""
         dim, nc = self.dim, self.nc
         Jac = np.zeros((dim, dim))
         for inode in range(nc):  # same accumulation order as the reference loop
@@ -232,7 +233,26 @@ class ElemType:
                 for b in range(1, dim):
                     s = s + self.dphi[ig, inode, b] * JacI[a, b]
                 gradphi[dim * inode + a] = s
-        return weight, self.phi[ig].copy(), gradphi
+        if not nabla:
+            return weight, self.phi[ig].copy(), gradphi
+        nh = 3 if dim == 2 else 6
+        nablaphi = np.empty(nc * nh)
+        pairs = [(0, 0), (1, 1), (0, 1)] if dim == 2 else [(0, 0), (1, 1), (2, 2), (0, 1), (1, 2), (2, 0)]
+        for inode in range(nc):
+            h = self.d2phi[ig, inode]
+            if dim == 2:      # rows of the reference Hessian: (dxi2, dxideta), (dxideta, deta2)
+                H = [[h[0], h[2]], [h[2], h[1]]]
+            else:             # (dxi2, dxideta, dzetadxi), (dxideta, deta2, detadzeta), (dzetadxi, detadzeta, dzeta2)
+                H = [[h[0], h[3], h[5]], [h[3], h[1], h[4]], [h[5], h[4], h[2]]]
+            for k, (a, b) in enumerate(pairs):
+                out = 0.0
+                for r in range(dim):
+                    row = H[r][0] * JacI[a, 0]
+                    for c in range(1, dim):
+                        row = row + H[r][c] * JacI[a, c]
+                    out = out + row * JacI[b, r]
+                nablaphi[nh * inode + k] = out
+        return weight, self.phi[ig].copy(), gradphi, nablaphi
 
 
 # ----------------------------------------------------------------------------------------------

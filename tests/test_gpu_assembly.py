@@ -309,3 +309,42 @@ def test_assembly_on_shuffled_meshes(ctx, seed):
     assert abs(res.to_numpy() - bo).max() <= 1e-12 * max(abs(bo).max(), abs(Fo).max())
     asm.destroy()
     A.destroy()
+
+
+@pytest.mark.parametrize("args", [(2, 2, 2), (3, 2, 0)])
+@pytest.mark.parametrize("fe", ["biquadratic", "linear"])
+def test_batched_jacobian_with_hessians_matches_oracle(ctx, args, fe):
+    """a4 in full: elem_type::Jacobian(vt, ig, Weight, phi, gradphi, nablaphi) for every element and Gauss point (fh_fe_jacobian) on curved elements
+    against the oracle's restatement (ElemType.hpp:1183-1248, :1438-1537), the optional Hessians included; on AFFINE elements the Hessians
+    reproduce the second derivatives of a quadratic exactly"""
+    m = levels(args, 1)[0]
+    ed, xy, _ = m.arrays()
+    rng = np.random.default_rng(21)
+    xyc = xy + rng.uniform(-0.03, 0.03, xy.shape)
+    w, g, h = capi.fe_jacobian(ctx, m, fe, hessians=True, coords=xyc)
+    w2, g2 = capi.fe_jacobian(ctx, m, fe, coords=xyc)
+    assert np.array_equal(w, w2) and np.array_equal(g, g2)
+    geom = "hex" if m.dim == 3 else "quad"
+    et = fo.ElemType(geom, fe, "seventh")
+    scale_g, scale_h = abs(g).max(), abs(h).max()
+    for e in range(ed.shape[0]):
+        vt = [xyc[ed[e, :et.nc], d] for d in range(m.dim)]
+        for ig in range(et.ng):
+            wo, _, go, ho = et.jacobian(vt, ig, nabla=True)
+            assert abs(w[e, ig] - wo) <= 1e-13 * abs(wo)
+            assert abs(g[e, ig].ravel() - go).max() <= 1e-12 * scale_g
+            assert abs(h[e, ig].ravel() - ho).max() <= 1e-12 * scale_h
+    if fe == "biquadratic":
+        # affine elements (a sheared box): sum_j nablaphi_j q(x_j) = Hessian of the quadratic q, sum_j gradphi_j q(x_j) = its gradient
+        dim = m.dim
+        A = np.eye(dim) + 0.2 * rng.standard_normal((dim, dim))
+        xa = xy @ A.T + 0.3
+        w, g, h = capi.fe_jacobian(ctx, m, fe, hessians=True, coords=xa)
+        Q = rng.standard_normal((dim, dim))
+        Q = Q + Q.T
+        q = 0.5 * np.einsum("ni,ij,nj->n", xa, Q, xa)
+        got = np.einsum("egjk,ej->egk", h, q[ed])
+        pairs = [(0, 0), (1, 1), (0, 1)] if dim == 2 else [(0, 0), (1, 1), (2, 2), (0, 1), (1, 2), (2, 0)]
+        want = np.array([Q[a, b] for a, b in pairs])
+        assert abs(got - want).max() <= 1e-10 * abs(Q).max()
+        assert abs(w.sum() - abs(np.linalg.det(A))) <= 1e-12          # the weights add up to the volume of the sheared unit box

@@ -33,6 +33,23 @@ def test_product_shape_tables_at_quadrature_points_bit_exact(geom, fe):
         assert np.array_equal(dphi[:, :, d], ref[1 + d])
 
 
+@pytest.mark.parametrize("geom", ["quad", "hex"])
+@pytest.mark.parametrize("fe", ["linear", "biquadratic"])
+def test_product_second_derivative_tables_bit_exact(geom, fe):
+    """a3: the _d2phi* tables elem_type fills for the optional Hessians (ElemType.cpp:637-741).  The linear families do not implement the pure
+    second derivatives in the reference (the fixture holds none); they are identically zero"""
+    d2 = capi.fe_tables_d2(geom, fe, "seventh")
+    ref = G["basis_%s_%s_gauss7" % (geom, fe)]
+    idx = [4, 5, 7] if geom == "quad" else [4, 5, 6, 7, 8, 9]
+    npure = 2 if geom == "quad" else 3
+    for k, which in enumerate(idx):
+        if fe == "linear" and k < npure:
+            assert np.all(d2[:, :, k] == 0.0)
+        else:
+            assert np.array_equal(d2[:, :, k], ref[which])
+    assert np.array_equal(d2, fo.eval_basis(geom, fe, G["gauss_x_%s_seventh" % geom])[2])
+
+
 def _rows_by_kvert(geom, fe, P):
     """rows of a [child][local node][coarse] element prolongator in the reference's fine-node order KVERT_IND (Hexahedron.cpp:49-71)"""
     kv = G["kvert_ind_%s_%s" % (geom, fe)]
