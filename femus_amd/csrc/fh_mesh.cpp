@@ -30,6 +30,9 @@ struct fh_mesh_s {
   // description to the coarsest level for a node on two interfaces at once + full expansion of chains (rows sum to one);
   // inherited by refined meshes (fh_mesh_set_amr_mode)
   int amr_mode = 0;
+  // hanging-node rows already computed for this mesh: [fe == 2], valid for amr_cache_mode (cleared when coordinates or the mode change)
+  std::shared_ptr<struct AmrRows> amr_cache[2];
+  int amr_cache_mode[2] = {-1, -1};
 };
 
 using namespace fhfe;
@@ -383,6 +386,8 @@ extern "C" int fh_mesh_clear_boundary_faces(fh_mesh_t m, unsigned face_mask) {
 extern "C" int fh_mesh_set_coords(fh_mesh_t m, const double* coords) {
   FH_REQUIRE(m && coords, "fh_mesh_set_coords: null argument");
   memcpy(m->coords.data(), coords, m->coords.size() * sizeof(double));
+  m->amr_cache[0].reset();     // the hanging-node weights are found through the coordinates
+  m->amr_cache[1].reset();
   return 0;
 }
 
@@ -806,7 +811,18 @@ static bool inverse_map_q2(int geom, int dim, const double* xv /* [nloc*dim] */,
   return true;
 }
 
-static void amr_constraints(const fh_mesh_s* m, int fe, AmrRows& out) {
+static void amr_constraints_compute(const fh_mesh_s* m, int fe, AmrRows& out);
+static void amr_constraints(fh_mesh_s* m, int fe, AmrRows& out) {
+  const int k = fe == FE_BIQUADRATIC ? 1 : 0;
+  if (!m->amr_cache[k] || m->amr_cache_mode[k] != m->amr_mode) {
+    m->amr_cache[k] = std::make_shared<AmrRows>();
+    amr_constraints_compute(m, fe, *m->amr_cache[k]);
+    m->amr_cache_mode[k] = m->amr_mode;
+  }
+  out = *m->amr_cache[k];
+}
+
+static void amr_constraints_compute(const fh_mesh_s* m, int fe, AmrRows& out) {
   const int geom = m->geom, dim = m->dim, nl = m->nloc, nv = nvert_of(geom), nf = nfaces_of(geom), nc = ndofs_of(geom, fe);
   const int nfv = (dim == 3) ? 4 : 2;
   out = AmrRows();
@@ -828,16 +844,22 @@ static void amr_constraints(const fh_mesh_s* m, int fe, AmrRows& out) {
     face_nn[f] = cn;
   }
   // interface faces: vertex-set key seen exactly once and no boundary flag
-  std::unordered_map<Key3, int, Key3Hash> fcount;
-  fcount.reserve((size_t)m->nel * 4);
-  auto face_key = [&](int iel, int f) {
-    int v[4] = {-1, -1, -1, -1};
-    for (int k = 0; k < nfv; k++) v[k] = m->elem_dof[(size_t)iel * nl + face_v[f][k]];
-    std::sort(v, v + nfv);
-    return (dim == 3) ? Key3{v[0], v[1], v[2]} : Key3{v[0], v[1], -1};
-  };
+  // (table: face key -> index into `seen`; the key's first entry is the smallest vertex, see PairMap)
+  PairMap ftab((size_t)m->nel * (size_t)nf / 2 + 64, (size_t)m->own[0] + 1, dim == 3 ? 4 : 3);
+  std::vector<int> seen;
+  seen.reserve((size_t)m->nel * nf / 2 + 64);
+  std::vector<int> fslot((size_t)m->nel * nf);
   for (int iel = 0; iel < m->nel; iel++)
-    for (int f = 0; f < nf; f++) fcount[face_key(iel, f)]++;
+    for (int f = 0; f < nf; f++) {
+      int v[4] = {-1, -1, -1, -1};
+      for (int k = 0; k < nfv; k++) v[k] = m->elem_dof[(size_t)iel * nl + face_v[f][k]];
+      std::sort(v, v + nfv);
+      bool created;
+      const int id = ftab.find_or_insert(v[0], v[1], dim == 3 ? v[2] : -1, (int)seen.size(), &created);
+      if (created) seen.push_back(0);
+      seen[id]++;
+      fslot[(size_t)iel * nf + f] = id;
+    }
   struct IfaceElem {
     int iel;
     std::vector<int> loc;   // interface-face local nodes (sorted, < nc)
@@ -848,7 +870,7 @@ static void amr_constraints(const fh_mesh_s* m, int fe, AmrRows& out) {
   for (int iel = 0; iel < m->nel; iel++) {
     std::vector<int> loc;
     for (int f = 0; f < nf; f++)
-      if (m->face_flag[(size_t)iel * nf + f] == -1 && fcount[face_key(iel, f)] == 1)
+      if (m->face_flag[(size_t)iel * nf + f] == -1 && seen[fslot[(size_t)iel * nf + f]] == 1)
         loc.insert(loc.end(), face_n[f], face_n[f] + face_nn[f]);
     if (loc.empty()) continue;
     std::sort(loc.begin(), loc.end());
@@ -859,7 +881,6 @@ static void amr_constraints(const fh_mesh_s* m, int fe, AmrRows& out) {
   std::vector<int> owner_level(ndof, -1);
   std::unordered_map<int, std::vector<std::pair<int, double>>> raw;
   std::map<int, std::map<int, double>> rest;       // reference mode: master -> {son: value}, ordered like the reference's std::map
-  double phi[27];
   for (int Lc = 0; Lc <= maxlev; Lc++) {
     if (inter[Lc].empty()) continue;
     for (int Lf = Lc + 1; Lf <= maxlev; Lf++) {
@@ -876,42 +897,72 @@ static void amr_constraints(const fh_mesh_s* m, int fe, AmrRows& out) {
       });
       std::vector<double> xs(ids.size());
       for (size_t k = 0; k < ids.size(); k++) xs[k] = m->coords[(size_t)ids[k] * dim];
-      for (auto& ie : inter[Lc]) {
-        const int* ed = &m->elem_dof[(size_t)ie.iel * nl];
-        double xv[81], lo[3], hi[3];
-        for (int d = 0; d < dim; d++) lo[d] = 1e300, hi[d] = -1e300;
-        for (int i = 0; i < nl; i++)
+      // (1) per coarse interface element, in parallel: the fine interface nodes inside it and the basis values there (box query, inverse map)
+      struct Hit {
+        int ldof;
+        double phi[27];
+      };
+      const auto& cel = inter[Lc];
+      std::vector<std::vector<Hit>> hits(cel.size());
+      auto search = [&](size_t q0, size_t q1) {
+        for (size_t q = q0; q < q1; q++) {
+          const IfaceElem& ie = cel[q];
+          const int* ed = &m->elem_dof[(size_t)ie.iel * nl];
+          double xv[81], lo[3], hi[3];
+          for (int d = 0; d < dim; d++) lo[d] = 1e300, hi[d] = -1e300;
+          for (int i = 0; i < nl; i++)
+            for (int d = 0; d < dim; d++) {
+              const double c = m->coords[(size_t)ed[i] * dim + d];
+              xv[i * dim + d] = c;
+              lo[d] = std::min(lo[d], c);
+              hi[d] = std::max(hi[d], c);
+            }
           for (int d = 0; d < dim; d++) {
-            const double c = m->coords[(size_t)ed[i] * dim + d];
-            xv[i * dim + d] = c;
-            lo[d] = std::min(lo[d], c);
-            hi[d] = std::max(hi[d], c);
+            const double pad = 0.01 * (hi[d] - lo[d]);
+            lo[d] -= pad;
+            hi[d] += pad;
           }
-        for (int d = 0; d < dim; d++) {
-          const double pad = 0.01 * (hi[d] - lo[d]);
-          lo[d] -= pad;
-          hi[d] += pad;
+          const size_t k0 = std::lower_bound(xs.begin(), xs.end(), lo[0]) - xs.begin();
+          for (size_t k = k0; k < ids.size() && xs[k] <= hi[0]; k++) {
+            const int ldof = ids[k];
+            const double* xp = &m->coords[(size_t)ldof * dim];
+            bool in = true;
+            for (int d = 1; d < dim; d++) in = in && xp[d] >= lo[d] && xp[d] <= hi[d];
+            if (!in) continue;
+            bool mine = false;
+            for (int i = 0; i < nc; i++) mine = mine || ed[i] == ldof;
+            if (mine) continue;
+            double xi[3] = {0, 0, 0};
+            if (!inverse_map_q2(geom, dim, xv, xp, xi)) continue;
+            bool inside = true;
+            for (int d = 0; d < dim; d++) inside = inside && std::fabs(xi[d]) <= 1.0 + 1e-4;
+            if (!inside) continue;
+            Hit h;
+            h.ldof = ldof;
+            eval_basis(geom, fe, xi, h.phi, nullptr);
+            hits[q].push_back(h);
+          }
         }
-        const size_t k0 = std::lower_bound(xs.begin(), xs.end(), lo[0]) - xs.begin();
-        for (size_t k = k0; k < ids.size() && xs[k] <= hi[0]; k++) {
-          const int ldof = ids[k];
-          const double* xp = &m->coords[(size_t)ldof * dim];
-          bool in = true;
-          for (int d = 1; d < dim; d++) in = in && xp[d] >= lo[d] && xp[d] <= hi[d];
-          if (!in) continue;
-          bool mine = false;
-          for (int i = 0; i < nc; i++) mine = mine || ed[i] == ldof;
-          if (mine) continue;
-          double xi[3] = {0, 0, 0};
-          if (!inverse_map_q2(geom, dim, xv, xp, xi)) continue;
-          bool inside = true;
-          for (int d = 0; d < dim; d++) inside = inside && std::fabs(xi[d]) <= 1.0 + 1e-4;
-          if (!inside) continue;
+      };
+      const int nth = cel.size() >= 256 ? (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;
+      if (nth == 1) {
+        search(0, cel.size());
+      } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nth; t++) th.emplace_back(search, cel.size() * t / nth, cel.size() * (t + 1) / nth);
+        for (auto& x : th) x.join();
+      }
+      // (2) in the order of the coarse elements: which level describes a node (mode 1), the rows, the reference's map
+      for (size_t q = 0; q < cel.size(); q++) {
+        const IfaceElem& ie = cel[q];
+        const int* ed = &m->elem_dof[(size_t)ie.iel * nl];
+        for (const Hit& hit : hits[q]) {
+          const int ldof = hit.ldof;
+          const double* phi = hit.phi;
           if (m->amr_mode == 1) {
             if (owner_level[ldof] < 0) owner_level[ldof] = Lc;
             if (owner_level[ldof] != Lc) continue;
           }
-          eval_basis(geom, fe, xi, phi, nullptr);
           auto& row = raw[ldof];
           for (int n : ie.loc) {
             if (std::fabs(phi[n]) < 1.0e-10) continue;
@@ -940,7 +991,7 @@ static void amr_constraints(const fh_mesh_s* m, int fe, AmrRows& out) {
     // genealogy lists of the levels above the one being filled is skipped ("alreadyFound").  For a node on the interfaces with two
     // coarser levels this keeps the direct entry and drops the path through the intermediate hanging node, so its row does not sum to
     // one -- that is the reference's result, reproduced here.
-    const std::map<int, std::map<int, double>> copy = rest;
+    const std::map<int, std::map<int, double>>& copy = rest;     // (read only from here on)
     std::map<int, std::vector<std::pair<int, double>>> hrow;        // hanging dof -> (master, weight)
     for (auto& kv : copy)
       if (kv.second.at(kv.first) > 5.) hrow[kv.first];
@@ -1049,6 +1100,8 @@ static void amr_constraints(const fh_mesh_s* m, int fe, AmrRows& out) {
 extern "C" int fh_mesh_set_amr_mode(fh_mesh_t m, int mode) {
   FH_REQUIRE(m && (mode == 0 || mode == 1), "fh_mesh_set_amr_mode: mode must be 0 (as the reference computes it) or 1 (coarsest level, rows sum to one)");
   m->amr_mode = mode;
+  m->amr_cache[0].reset();
+  m->amr_cache[1].reset();
   return 0;
 }
 
