@@ -1747,14 +1747,14 @@ struct ClParams {
   double* res;
 };
 
-__device__ __forceinline__ double cl_sum8(const char* S, const uint4 a) {       // eight contributions in ascending element order
+// t + eight contributions, added one after the other in ascending element order (the order of the two-pass row pass inside one cluster)
+__device__ __forceinline__ double cl_sum8(const char* S, const uint4 a, double t) {
   const unsigned w[4] = {a.x, a.y, a.z, a.w};
   double v[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) v[k] = *reinterpret_cast<const double*>(S + (((w[k >> 1] >> (16 * (k & 1))) & 0xffffu) << 3));
-  double t = v[0];
 #pragma unroll
-  for (int k = 1; k < 8; k++) t += v[k];
+  for (int k = 0; k < 8; k++) t += v[k];
   return t;
 }
 
@@ -1897,7 +1897,7 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
 #pragma unroll
         for (int i = 0; i < CL_SPT; i++)
           if (__any((dd[i].y >> 28) != 0)) {
-            if (dd[i].y >> 28) vv[i] += cl_sum8(Sb, oblk[(dd[i].y >> 17) & 0x7ffu]);
+            if (dd[i].y >> 28) vv[i] = cl_sum8(Sb, oblk[(dd[i].y >> 17) & 0x7ffu], vv[i]);
           }
       }
 #pragma unroll
@@ -1908,7 +1908,7 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
         else if (vv[i] == 1.2345e300) *dst = vv[i];      // timing aid (bit 2): the LDS work without the stores
       }
       {                                     // residual entries: rows 16 w .. 16 w + 15 on the first lanes of wave w
-        const double v = cl_sum8(Sb, fblk[frow]);
+        const double v = cl_sum8(Sb, fblk[frow], 0.0);
         const int fv = fb[frow];
         double* dst = fv < 0 ? C.Pbuf + (size_t)(fv & 0x7fffffff) : C.res + (size_t)fv;
         if (lane < 16) *dst = v;
@@ -1964,13 +1964,18 @@ __global__ __launch_bounds__(256) void k_rows_partial(int nprow, const int* __re
         if ((lane >> 4) == h && mB[q] < 128) __hip_atomic_fetch_add(&acc[sub][1][mB[q]], vB[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
-    fA += mA[q] == 255 ? vA[q] : 0.0;
-    fB += mB[q] == 255 ? vB[q] : 0.0;
-  }
-#pragma unroll
-  for (int d = 16; d >= 1; d >>= 1) {
-    fA += __shfl_xor(fA, d, 32);
-    fB += __shfl_xor(fB, d, 32);
+    {   // residual entries (one behind each partial row): added one after the other in ascending segment = cluster order, on every lane alike
+      unsigned mk = (unsigned)(__ballot(mA[q] == 255) >> (32 * (sub & 1)));
+      while (mk) {
+        fA += __shfl(vA[q], __builtin_ctz(mk), 32);
+        mk &= mk - 1;
+      }
+      mk = (unsigned)(__ballot(mB[q] == 255) >> (32 * (sub & 1)));
+      while (mk) {
+        fB += __shfl(vB[q], __builtin_ctz(mk), 32);
+        mk &= mk - 1;
+      }
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();

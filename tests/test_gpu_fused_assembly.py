@@ -77,6 +77,15 @@ def test_fused_assembly_matches_oracle_and_two_pass(ctx, args, nl, kind, with_so
         assert abs(f - bo).max() <= 1e-12 * abs(bo).max()
     assert abs(out[1][0] - out[0][0]).max() <= 4e-16 * abs(Ao.data).max()      # same element matrices, sums grouped per cluster
     assert abs(out[1][1] - out[0][1]).max() <= 1e-15 * abs(bo).max()
+    # ... and inside a cluster both paths add in ascending element order: a row all of whose elements lie in ONE cluster has the same bits
+    blocks = [set() for _ in range(n)]
+    for e in range(ed.shape[0]):
+        for nd in ed[e]:
+            blocks[nd].add(e // 8)
+    one = np.array([len(b) == 1 for b in blocks])
+    assert one.any() and np.array_equal(out[1][1][one], out[0][1][one])
+    for r in np.where(one)[0]:
+        assert np.array_equal(out[1][0][rp[r]:rp[r + 1]], out[0][0][rp[r]:rp[r + 1]])
 
 
 def test_fused_plan_is_refused_where_the_mesh_has_no_sibling_groups(ctx):

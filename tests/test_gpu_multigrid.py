@@ -727,11 +727,17 @@ def test_hierarchy_solve_with_and_without_the_dissection(ctx):
         assert (pb.mg.coarse_info()[1] >= 2) == (mode > 0)
         its, rn = pb.mgsolve(outer="gmres", rtol=1e-12)
         x = pb.EPSC.to_numpy().copy()
-        pb.assemble()
-        pb.prepare()
-        assert (pb.mg.coarse_info()[1] >= 2) == (mode > 0)
-        its2, _ = pb.mgsolve(outer="gmres", rtol=1e-12)
-        assert its2 == its and np.array_equal(x, pb.EPSC.to_numpy())
+        # (the first assembly ran the fused path; the Galerkin product then asked for element rows, so the later ones run the two-pass path, whose
+        # sums associate differently across clusters: same solution to rounding after the first re-assembly, the same bits from then on)
+        xs = []
+        for _ in range(2):
+            pb.assemble()
+            pb.prepare()
+            assert (pb.mg.coarse_info()[1] >= 2) == (mode > 0)
+            its2, _ = pb.mgsolve(outer="gmres", rtol=1e-12)
+            assert its2 == its
+            xs.append(pb.EPSC.to_numpy().copy())
+        assert rel(xs[0], x) < 1e-12 and np.array_equal(xs[0], xs[1])
         sols.append((its, x))
         pb.destroy()
     ctx.set_option("coarse_nd", 8)
