@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64) void k_vanka_color(const int* __restrict__ orde
   }
 }
 
-// ALL colours of ALL sweeps in one launch (fh_set_option(vanka_persistent, 1), default): a grid of resident one-wave workgroups walks
+// ALL colours of ALL sweeps in one launch (fh_set_option(vanka_persistent, 1 | 2); off by default): a grid of resident one-wave workgroups walks
 // the colours together, a device-wide barrier between two colours instead of a launch boundary.  Every patch forms the residual
 // of its own rows (4 lanes per row, shuffle reduction), exact for the colour because its patches do not read each other's dofs;
 // pass A of a step (patch dofs, row extents: independent of x) is issued BEFORE the barrier wait, so that after the barrier only
@@ -2204,6 +2204,7 @@ static int nd_factor(fh_mg_t mg, int n, int nfull) {
   const size_t o_sinv = tot;
   tot += (size_t)ns * ns;
   const size_t n_mat = tot;                 // everything that is zeroed before the operator is copied in
+  if (n_mat >= (size_t)2147483647) return 0;      // beyond the fill kernel's 32-bit length: the caller goes on with the other paths (sparse exact solve)
   const size_t o_w = tot;
   tot += (size_t)nI * ns;
   const size_t o_wt = tot;

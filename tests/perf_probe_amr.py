@@ -1,12 +1,13 @@
 """timing probe (not a test): BASELINE config 5 -- 3-D Poisson Q2 with two adaptively refined levels on top of two uniform ones
 (MGAMR ex4 flags on the unit cube), one GPU; prints one JSON line"""
+import os
 import json
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import femus_amd
 from femus_amd import capi
 from femus_amd.poisson import PoissonMG

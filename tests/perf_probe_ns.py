@@ -1,12 +1,13 @@
 """timing probe (not a test): BASELINE config 4 -- lid-driven cavity, 10 x 10 coarse QUAD9 mesh, 4 levels (80 x 80 Taylor-Hood
 elements, 58 242 unknowns), Newton + Vanka-multigrid-preconditioned GMRES; prints one JSON line"""
+import os
 import json
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import femus_amd
 from femus_amd.navier_stokes import NavierStokesMG
 

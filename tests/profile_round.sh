@@ -79,3 +79,4 @@ python $ROOT/profiles/summarize.py /tmp/prof/prep $OUT/${TAG}_prepare_kernel_sum
 python $ROOT/tests/perf_probe_amr.py 8 2> /dev/null | grep '^{' | head -1 > $OUT/${TAG}_amr_probe.json
 python $ROOT/tests/perf_probe_direct.py 1 2 3 2> /dev/null | grep '^n ' > $OUT/${TAG}_direct_probe.txt
 tail -c 600 $OUT/${TAG}_bench_line.json
+python $ROOT/tests/perf_probe_ns.py 0.001 2> /dev/null | grep '^{' | head -1 > $OUT/${TAG}_ns_probe.json
