@@ -557,20 +557,24 @@ static int triple_product(fh_mat_t R, fh_mat_t A, fh_mat_t P, fh_mat_t* Cio, con
     plan->nc = P->n;
     plan->a_nnz = A->nnz;
     plan->p_nnz = P->nnz;
+    FH_TRACE("%s: first product of %d x %d (%d non-zeros) with %d x %d", who, A->m, A->n, A->nnz, P->m, P->n);
     if (int rc = spgemm_pattern(A, P, &plan->AP)) {
       delete plan;
       return rc;
     }
+    FH_TRACE("%s: pattern of A P (%d non-zeros)", who, plan->AP->nnz);
     if (int rc = spgemm_pattern(R, plan->AP, &C)) {
       destroy_plan(plan);
       return rc;
     }
+    FH_TRACE("%s: pattern of R A P (%d non-zeros)", who, C->nnz);
     C->plan = plan;
     C->plan_destroy = destroy_plan;
     *Cio = C;
     if (A->ctx->spgemm_slot_map) {
       FH_TRY(build_slot_map(A, P, plan->AP, plan->map_ap));
       FH_TRY(build_slot_map(R, plan->AP, C, plan->map_c));
+      FH_TRACE("%s: slot maps (%lld + %lld products)", who, (long long)plan->map_ap.nprod, (long long)plan->map_c.nprod);
     }
   } else {
     plan = (PtapPlan*)C->plan;
