@@ -68,3 +68,39 @@ def test_device_index_equals_host_list_path(ctx):
     with pytest.raises(capi.FemusHipError):
         capi.Index(ctx, [n + 5]).zero_rows(A, 1.0)               # out of range: reported, not executed
     idx.destroy(), A.destroy(), B.destroy(), m.destroy()
+
+
+def test_round4_entry_points_with_degenerate_input(ctx):
+    """zero elements / zero faces / empty operands / bad arguments through the entry points added in round 4: no-ops or errors with a message, never a crash"""
+    import ctypes
+    L = ctx.L
+    m = capi.Mesh.box(1, 1, 1)
+    ed, xy, ff = m.arrays()
+    # batched Jacobian: no elements -> nothing written; a node id out of range -> error with the reference to the argument
+    w = np.full(3, 7.0)
+    assert L.fh_fe_jacobian(ctx.h, 0, 2, 3, 0, 27, None, 0, None, w.ctypes.data_as(ctypes.c_void_p), None, None) == 0 and np.all(w == 7.0)
+    bad = ed.copy()
+    bad[0, 5] = m.nnode + 3
+    with pytest.raises(RuntimeError, match="out of range"):
+        capi.fe_jacobian(ctx, m, "biquadratic", elem_dof=bad)
+    # one element, Gauss weights add up to the volume; Hessians of a single trilinear element: pure second derivatives vanish (to the rounding of J^-1)
+    w, g, h = capi.fe_jacobian(ctx, m, "linear", hessians=True)
+    assert abs(w.sum() - 1.0) <= 1e-14 and abs(h[..., :3]).max() <= 1e-14 and abs(h[..., 3:]).max() > 0.1
+    # pressure faces: empty list is a no-op, missing offsets / pressures are refused
+    res = ctx.vector(3 * m.nnode + 8)
+    capi.assemble_pressure_faces(ctx, m, res, np.zeros((0, 9), np.int32), 1.0, [0, m.nnode, 2 * m.nnode])
+    assert res.sum() == 0.0
+    fn = np.ascontiguousarray(ed[:1, capi.fe_face_nodes("hex", "biquadratic", 1)], dtype=np.int32)
+    assert L.fh_assemble_pressure_faces(ctx.h, 0, 3, 1, fn.ctypes.data_as(ctypes.c_void_p), None, None, 0, None, m.nnode,
+                                        xy.ctypes.data_as(ctypes.c_void_p), None, -1.0, res.h) != 0
+    capi.assemble_pressure_faces(ctx, m, res, fn, 2.0, [0, m.nnode, 2 * m.nnode], scale=1.0)
+    got = res.to_numpy()
+    assert abs(got[:m.nnode].sum() - 2.0) <= 1e-13 and abs(got[m.nnode:]).max() <= 1e-15          # face x = 1 of the unit cube: tau * area * (1, 0, 0)
+    assert capi.face_normals(m, "biquadratic", np.zeros((0, 9), np.int32)).shape == (0, 3)
+    # sparse products with an empty operand (host builder) and a product whose result is empty
+    Z = ctx.matrix_scipy(sp.csr_matrix((4, 5)))
+    B = ctx.matrix_scipy(sp.random(5, 3, density=0.6, random_state=1, format="csr"))
+    assert Z.matmul(B).to_scipy().nnz == 0
+    D = ctx.matrix_scipy(sp.csr_matrix(np.array([[0, 1.0], [0, 0]])))
+    assert abs(D.matmul(D).to_scipy()).sum() == 0.0
+    m.destroy()
