@@ -8,13 +8,13 @@ import os
 import sys
 
 root = sys.argv[1]
-f = sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True))[0]
+f = max(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getsize)      # (child processes of the command leave smaller traces)
 rows = []
 with open(f) as fh:
     for r in csv.DictReader(fh):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if "k_elem_q2hex_mfma" in r[2]]
+starts = [i for i, r in enumerate(rows) if "k_elem_q2hex_mfma" in r[2] or "k_cluster_q2hex_sf" in r[2]]
 steps = []
 for a, b in zip(starts[:-1], starts[1:]):
     seg = rows[a:b]
@@ -29,7 +29,8 @@ for a, b in zip(starts[:-1], starts[1:]):
 # the timed region of bench.py: consecutive steps with the same kernel count
 import collections
 cnt = collections.Counter(s["n_kernels"] for s in steps)
-common = cnt.most_common(1)[0][0]
+# the timed steps: the most frequent kernel count among steps with a whole cycle in them (assembly-only loops of the roofline measurement have 2-3 kernels)
+common = collections.Counter(s["n_kernels"] for s in steps if s["n_kernels"] >= 20).most_common(1)[0][0]
 timed = [s for s in steps if s["n_kernels"] == common]
 out = {"trace": os.path.basename(f), "steps_seen": len(steps), "kernels_per_step": common,
        "median_span_us": sorted(s["span_us"] for s in timed)[len(timed) // 2], "median_busy_us": sorted(s["busy_us"] for s in timed)[len(timed) // 2],
