@@ -2088,6 +2088,7 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
           if (elem_dof[(size_t)(c * CL_NE + e) * nloc + nodeof[t]] != cd[tm[e][t]]) return 0;
     }
   }
+  FH_TRACE("cluster plan: clusters verified");
   // template rows: macro columns ascending; contributions in ascending element order
   std::vector<unsigned short> roff(CL_NM_MAX + 1, 0);
   std::vector<unsigned char> tcol;
@@ -2158,6 +2159,7 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
         for (int pp = p0; pp < p1; pp++) sinfo[sidx++] = (unsigned)r | ((unsigned)pp << 7) | ((unsigned)roff[r] << 14);
       }
   }
+  FH_TRACE("cluster plan: template");
   // destinations: a macro row is complete when all elements around its node lie in this cluster and the CSR row has exactly its columns.
   // The partial rows of one CSR row follow each other in the partial-row buffer, ascending cluster (= element) order.
   std::vector<int> vdst((size_t)ncl * CL_NM_MAX), fdst((size_t)ncl * CL_NM_MAX);
@@ -2202,6 +2204,7 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
         }
       }
   }
+  FH_TRACE("cluster plan: destinations");
   auto up = [&](void** d, const void* h, size_t bytes) -> int {
     FH_CHECK_HIP(hipMalloc(d, bytes ? bytes : 8));
     if (bytes) FH_CHECK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
@@ -2221,6 +2224,7 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
   FH_CHECK_HIP(hipMemset(as->d_cl_pmap, 0xFF, npart + 128));      // 255 = residual entry (the map kernel fills in the matrix entries)
   FH_CHECK_HIP(hipMalloc(&as->d_Pbuf, (npart + 128) * sizeof(double)));
   FH_CHECK_HIP(hipMemset(as->d_Pbuf, ctx->debug_poison ? 0xFF : 0, (npart + 128) * sizeof(double)));
+  FH_TRACE("cluster plan: uploads and buffers");
   {
     int *d_cdof = nullptr, *d_err = nullptr;
     unsigned char* d_tcol = nullptr;
@@ -2586,6 +2590,36 @@ static int ensure_affine(fh_assembler_t as) {
   return 0;
 }
 
+// row -> (element, local row) adjacency on the device (fh_assembler_create)
+__global__ __launch_bounds__(256) void k_adj_count(size_t n, int nc, int nloc, const int* __restrict__ elem_dof, int m, int* __restrict__ cnt) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int r = elem_dof[(k / nc) * nloc + k % nc];
+  if (r < m) atomicAdd(&cnt[r], 1);
+}
+__global__ __launch_bounds__(256) void k_adj_fill(size_t n, int nc, int nloc, const int* __restrict__ elem_dof, int m, int* __restrict__ cur, int* __restrict__ aei) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int e = (int)(k / nc), i = (int)(k % nc);
+  const int r = elem_dof[(size_t)e * nloc + i];
+  if (r < m) aei[atomicAdd(&cur[r], 1)] = (e << 5) | i;
+}
+__global__ __launch_bounds__(256) void k_adj_sort(int m, int nc, const int* __restrict__ aptr, int* __restrict__ aei, int* __restrict__ slot) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= m) return;
+  const int a0 = aptr[r], a1 = aptr[r + 1];
+  for (int a = a0 + 1; a < a1; a++) {          // insertion sort: a row has a handful of pairs (8 on a hexahedral grid)
+    const int v = aei[a];
+    int b = a - 1;
+    while (b >= a0 && aei[b] > v) {
+      aei[b + 1] = aei[b];
+      b--;
+    }
+    aei[b + 1] = v;
+  }
+  for (int a = a0; a < a1; a++) slot[(size_t)(aei[a] >> 5) * nc + (aei[a] & 31)] = a;
+}
+
 extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, int nel, int nloc, const int* elem_dof, int nnode,
                                    const double* coords, fh_mat_t A, fh_assembler_t* out) {
   FH_GUARD_BEGIN
@@ -2825,38 +2859,54 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
     FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   }
   if (ctx->assemble_two_pass && A->max_row <= 255) {
-    // row -> (element, local row) adjacency in ascending element order (host, integer setup work)
+    // row -> (element, local row) adjacency in ascending element order, on the device (round 4): count per row, host scan of the counts, fill
+    // through per-row cursors (any order), then every row sorts its few pairs and tells each (element, local row) its slot -- the arrays the host
+    // loop produced; only the row pointers (needed by the cluster plan below) visit the host
     const int m = A->m, nc = as->nc;
+    const size_t npair = (size_t)nel * nc;
     std::vector<int> aptr(m + 1, 0);
-    for (int e = 0; e < nel; e++)
-      for (int i = 0; i < nc; i++) {
-        const int r = elem_dof[(size_t)e * nloc + i];
-        if (r < m) aptr[r + 1]++;
+    {
+      int* d_cnt = nullptr;
+      FH_CHECK_HIP(hipMalloc(&d_cnt, ((size_t)m + 1) * sizeof(int)));
+      FH_CHECK_HIP(hipMemsetAsync(d_cnt, 0, ((size_t)m + 1) * sizeof(int), ctx->stream));
+      const unsigned gb = (unsigned)((npair + 255) / 256);
+      if (npair) hipLaunchKernelGGL(k_adj_count, dim3(gb), dim3(256), 0, ctx->stream, npair, nc, nloc, as->d_elem_dof, m, d_cnt);
+      if (m) FH_CHECK_HIP(hipMemcpyAsync(aptr.data() + 1, d_cnt, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      int64_t tot = 0;
+      for (int r = 0; r < m; r++) {
+        tot += aptr[r + 1];
+        aptr[r + 1] = (int)tot;
       }
-    for (int r = 0; r < m; r++) aptr[r + 1] += aptr[r];
-    std::vector<int> aei(aptr[m]), cur(aptr.begin(), aptr.end() - 1), slot((size_t)nel * nc, -1);
-    for (int e = 0; e < nel; e++)
-      for (int i = 0; i < nc; i++) {
-        const int r = elem_dof[(size_t)e * nloc + i];
-        if (r < m) {
-          slot[(size_t)e * nc + i] = cur[r];
-          aei[cur[r]++] = (e << 5) | i;
-        }
+      if (tot >= 2147483647ll) {
+        hipFree(d_cnt);
+        fh_set_error("fh_assembler_create: the adjacency overflows int32");
+        return 2;
       }
-    FH_TRACE("fh_assembler_create: row adjacency built (%zu pairs)", aei.size());
-    FH_TRY(up((void**)&as->d_slot, slot.data(), slot.size() * sizeof(int)));
-    FH_REQUIRE(nel < (1 << 26), "fh_assembler_create: too many elements for the packed adjacency");
-    FH_TRY(up((void**)&as->d_adj_ptr, aptr.data(), aptr.size() * sizeof(int)));
-    FH_TRY(up((void**)&as->d_adj_ei, aei.data(), aei.size() * sizeof(int)));
-    FH_CHECK_HIP(hipMalloc(&as->d_rowmap, std::max<size_t>((size_t)aei.size() * nc, 1)));
+      FH_CHECK_HIP(hipMalloc(&as->d_adj_ptr, ((size_t)m + 1) * sizeof(int)));
+      FH_CHECK_HIP(hipMalloc(&as->d_adj_ei, std::max<size_t>((size_t)tot, 1) * sizeof(int)));
+      FH_CHECK_HIP(hipMalloc(&as->d_slot, std::max<size_t>(npair, 1) * sizeof(int)));
+      FH_CHECK_HIP(hipMemcpyAsync(as->d_adj_ptr, aptr.data(), ((size_t)m + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+      FH_CHECK_HIP(hipMemcpyAsync(d_cnt, aptr.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, ctx->stream));      // cursors
+      FH_CHECK_HIP(hipMemsetAsync(as->d_slot, 0xFF, std::max<size_t>(npair, 1) * sizeof(int), ctx->stream));                // -1: row not in the matrix
+      FH_REQUIRE(nel < (1 << 26), "fh_assembler_create: too many elements for the packed adjacency");
+      if (npair) hipLaunchKernelGGL(k_adj_fill, dim3(gb), dim3(256), 0, ctx->stream, npair, nc, nloc, as->d_elem_dof, m, d_cnt, as->d_adj_ei);
+      if (m) hipLaunchKernelGGL(k_adj_sort, dim3(fh_div_up(m, 256)), dim3(256), 0, ctx->stream, m, nc, as->d_adj_ptr, as->d_adj_ei, as->d_slot);
+      FH_CHECK_HIP(hipGetLastError());
+      FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      hipFree(d_cnt);
+    }
+    const size_t nadj = (size_t)aptr[m];
+    FH_TRACE("fh_assembler_create: row adjacency built (%zu pairs)", nadj);
+    FH_CHECK_HIP(hipMalloc(&as->d_rowmap, std::max<size_t>(nadj * nc, 1)));
     as->kstride = (nc == 27 && ctx->assemble_kpad) ? (ctx->assemble_kpad == 28 ? 28 : 32) : nc;
-    as->nadj = (int)aei.size();
-    as->kbuf_bytes = ((size_t)aei.size() + 1) * as->kstride * sizeof(double);      // + one spare row: the sink of rows without a slot
+    as->nadj = (int)nadj;
+    as->kbuf_bytes = (nadj + 1) * as->kstride * sizeof(double);      // + one spare row: the sink of rows without a slot
     FH_CHECK_HIP(hipMalloc(&as->d_Kbuf, as->kbuf_bytes));
-    FH_CHECK_HIP(hipMalloc(&as->d_Fbuf, std::max<size_t>(aei.size(), 1) * sizeof(double)));
+    FH_CHECK_HIP(hipMalloc(&as->d_Fbuf, std::max<size_t>(nadj, 1) * sizeof(double)));
     if (ctx->debug_poison) {   // tests: the row pass must read nothing the element kernels have not written
       FH_CHECK_HIP(hipMemset(as->d_Kbuf, 0xFF, as->kbuf_bytes));
-      FH_CHECK_HIP(hipMemset(as->d_Fbuf, 0xFF, std::max<size_t>(aei.size(), 1) * sizeof(double)));
+      FH_CHECK_HIP(hipMemset(as->d_Fbuf, 0xFF, std::max<size_t>(nadj, 1) * sizeof(double)));
     }
     FH_TRACE("fh_assembler_create: element-row buffer allocated (%.2f GB), building the row map", as->kbuf_bytes / 1e9);
     FH_TRY(dispatch_rows(as, A, nullptr, true));
