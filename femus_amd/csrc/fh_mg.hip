@@ -3076,11 +3076,13 @@ static int run_cycle(fh_mg_t mg) {
 }
 
 // x_out = M^-1 b_in with raw device pointers
+// b_in may BE the cycle's own right-hand-side buffer (lv[top].b: a caller inside this file wrote it there) and x_out may be null (the result stays
+// in lv[top].x, read there by the caller before the next cycle): the Krylov loops save the two vector copies per application that way
 static int apply_cycle(fh_mg_t mg, const double* b_in, double* x_out) {
   fh_ctx_t c = mg->ctx;
   const int top = mg->nlevels - 1;
   MgLevel& L = mg->lv[top];
-  FH_CHECK_HIP(hipMemcpyAsync(L.b, b_in, (size_t)L.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  if (b_in != L.b) FH_CHECK_HIP(hipMemcpyAsync(L.b, b_in, (size_t)L.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   if (mg->gexec) {
     // the graph bakes in the x / x2 roles of the capture run, and that run left L.x (host side) pointing at the buffer it ended in;
     // run_cycle is never called un-captured while the graph exists, so the copy below reads the buffer the replay writes
@@ -3088,7 +3090,7 @@ static int apply_cycle(fh_mg_t mg, const double* b_in, double* x_out) {
   } else {
     FH_TRY(run_cycle(mg));
   }
-  FH_CHECK_HIP(hipMemcpyAsync(x_out, L.x, (size_t)L.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  if (x_out && x_out != L.x) FH_CHECK_HIP(hipMemcpyAsync(x_out, L.x, (size_t)L.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   return 0;
 }
 
@@ -3385,8 +3387,9 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
     // left-preconditioned GMRES(restart), classical Gram-Schmidt, Knoll guess x0 = M^-1 b
     FH_REQUIRE(restart >= 1 && restart <= 200, "fh_mg_solve: restart %d out of range", restart);
     FH_TRY(krylov_reserve(mg, restart + 3, ncols));
-    double* t = mg->kv[restart + 1];
-    double* w = mg->kv[restart + 2];
+    // t = the cycle's own right-hand-side buffer (the products A v land where the cycle reads them), w = wherever the cycle leaves its result
+    double* t = mg->lv[mg->nlevels - 1].b;
+    double* w = nullptr;
     const int nb = sgrid(c, n);
     FH_TRY(fh_reserve_reduction(c, (size_t)(restart + 2) * (nb + 1) + 64));
     // basis pointers on the device: owned by the solver object (an early error return must not leak them)
@@ -3420,7 +3423,8 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
       int kused = 0;
       for (int k = 0; k < restart; k++) {
         FH_TRY(spmv(mg->kv[k], t, 0, nullptr));
-        FH_TRY(apply_cycle(mg, t, w));
+        FH_TRY(apply_cycle(mg, t, nullptr));
+        w = mg->lv[mg->nlevels - 1].x;                  // (an un-captured cycle alternates between its two buffers)
         // h = V^T w (one pass), w -= V h, h_{k+1,k} = ||w||
         hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, c->stream, (const double* const*)d_V, w, k + 1, n, c->d_red);
         hipLaunchKernelGGL(k_multidot_final, dim3(k + 1), dim3(256), 0, c->stream, c->d_red, k + 1, nb);
