@@ -430,12 +430,14 @@ extern "C" int fh_mat_get_row(fh_mat_t A, int row, int* ncols, int* cols, double
 // ------------------------------------------------------------------------------------------------
 // K5: Dirichlet rows / columns
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_zero_rows(const int* __restrict__ rowptr, const int* __restrict__ col, double* __restrict__ val,
-                                                  const int* __restrict__ rows, int nrows, double diag) {
-  int r = blockIdx.x;
+// two rows per wave (32 lanes each: a Q2 row has 27 ... 125 entries), four waves per workgroup
+__global__ __launch_bounds__(256) void k_zero_rows(const int* __restrict__ rowptr, const int* __restrict__ col, double* __restrict__ val,
+                                                   const int* __restrict__ rows, int nrows, double diag) {
+  const int r = blockIdx.x * 8 + (threadIdx.x >> 5), lane = threadIdx.x & 31;
   if (r >= nrows) return;
-  int row = rows[r];
-  for (int k = rowptr[row] + threadIdx.x; k < rowptr[row + 1]; k += 64) val[k] = (col[k] == row) ? diag : 0.0;
+  const int row = rows[r];
+  const int e = rowptr[row + 1];
+  for (int k = rowptr[row] + lane; k < e; k += 32) val[k] = (col[k] == row) ? diag : 0.0;
 }
 
 __global__ __launch_bounds__(256) void k_mask_set(unsigned char* __restrict__ mask, const int* __restrict__ idx, int n) {
@@ -455,7 +457,7 @@ extern "C" int fh_mat_zero_rows(fh_mat_t A, int n, const int* rows, double diag)
   int* d_rows = nullptr;
   FH_CHECK_HIP(hipMalloc(&d_rows, n * sizeof(int)));
   FH_CHECK_HIP(hipMemcpyAsync(d_rows, rows, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_zero_rows, dim3(n), dim3(64), 0, c->stream, A->d_rowptr, A->d_col, A->d_val, d_rows, n, diag);
+  hipLaunchKernelGGL(k_zero_rows, dim3(fh_div_up(n, 8)), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_val, d_rows, n, diag);
   FH_CHECK_HIP(hipGetLastError());
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
   hipFree(d_rows);
@@ -502,7 +504,7 @@ extern "C" int fh_mat_zero_rows_index(fh_mat_t A, fh_index_t rows, double diag) 
   FH_REQUIRE(!rows->has_negative, "fh_mat_zero_rows_index: the list holds 'none' entries");
   FH_REQUIRE(rows->max_index < A->m, "fh_mat_zero_rows_index: row %d out of range", rows->max_index);
   if (rows->n == 0) return 0;
-  hipLaunchKernelGGL(k_zero_rows, dim3(rows->n), dim3(64), 0, A->ctx->stream, A->d_rowptr, A->d_col, A->d_val, rows->d, rows->n, diag);
+  hipLaunchKernelGGL(k_zero_rows, dim3(fh_div_up(rows->n, 8)), dim3(256), 0, A->ctx->stream, A->d_rowptr, A->d_col, A->d_val, rows->d, rows->n, diag);
   FH_CHECK_HIP(hipGetLastError());
   A->at_valid = false;
   return 0;
