@@ -520,110 +520,15 @@ extern "C" int fh_pattern_from_elements(int nel, int nloc, const int* elem_dof, 
   FH_GUARD_END("fh_pattern_from_elements")
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The same prolongator built ON THE DEVICE (round 4).  The host loop above gives a fine row to the first (coarse element, child, local
-// node) that visits it; in loop order that is the MINIMUM of the linear index (iel * nch + j) * nc + i over all visits, so the owner of a
-// row is an atomicMin.  Row lengths come from a (child, node) table of non-zero counts, the host scans them, and one thread per row then
-// writes its columns at their rank among the coarse element's dofs (sorted CSR order without a sort) with the boundary rule applied.
-// Nothing but the 4-byte row lengths visits the host; the column copy there is fetched only if host code asks (fh_hcol).
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int PL_NONE = 0x7f7f7f7f;   // a row nobody visits (byte pattern of the memset)
-__global__ __launch_bounds__(256) void k_pl_owner(size_t n, int nc, int nl, const int* __restrict__ child, const int* __restrict__ f_ed, int* __restrict__ owner) {
-  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= n) return;
-  const int slot = (int)(t / nc), i = (int)(t % nc);
-  const int jel = child[slot];
-  if (jel < 0) return;
-  atomicMin(&owner[f_ed[(size_t)jel * nl + i]], (int)t);
-}
-__global__ __launch_bounds__(256) void k_pl_len(int nf, int nc, int nch, const int* __restrict__ owner, const char* __restrict__ refined, const int* __restrict__ cnt,
-                                                int* __restrict__ len) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= nf) return;
-  const int o = owner[r];
-  if (o == PL_NONE) {
-    len[r] = 0;
-    return;
-  }
-  const int slot = o / nc, i = o % nc, iel = slot / nch, j = slot % nch;
-  len[r] = refined[iel] ? cnt[j * nc + i] : 1;
-}
-__global__ __launch_bounds__(256) void k_pl_fill(int nf, int nc, int nch, int nl, const int* __restrict__ owner, const char* __restrict__ refined,
-                                                 const int* __restrict__ c_ed, const int* __restrict__ cnt, const int* __restrict__ nzk,
-                                                 const double* __restrict__ EP, const char* __restrict__ bf, const char* __restrict__ bc,
-                                                 const int* __restrict__ rowptr, int* __restrict__ col, double* __restrict__ val) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= nf) return;
-  const int o = owner[r];
-  if (o == PL_NONE) return;
-  const int slot = o / nc, i = o % nc, iel = slot / nch, j = slot % nch;
-  const int* cd = c_ed + (size_t)iel * nl;
-  const int p = rowptr[r];
-  const bool rowb = bf && bf[r];
-  if (!refined[iel]) {
-    const int c = cd[i];
-    col[p] = c;
-    val[p] = (rowb || (bc && bc[c])) ? 0.0 : 1.0;
-    return;
-  }
-  const int n = cnt[j * nc + i];
-  const int* nz = nzk + (size_t)(j * nc + i) * nc;
-  const double* pr = EP + (size_t)(j * nc + i) * nc;
-  for (int a = 0; a < n; a++) {
-    const int k = nz[a], c = cd[k];
-    int rank = 0;
-    for (int b = 0; b < n; b++) rank += cd[nz[b]] < c ? 1 : 0;
-    col[p + rank] = c;
-    val[p + rank] = (rowb || (bc && bc[c])) ? 0.0 : pr[k];     // pattern kept, value zeroed
-  }
-}
-
-namespace {
-struct DevBuf {   // scratch device arrays of one setup routine, freed on every exit path
-  std::vector<void*> p;
-  ~DevBuf() {
-    for (void* q : p)
-      if (q) hipFree(q);
-  }
-  template <class T>
-  int get(T** out, size_t n) {
-    void* q = nullptr;
-    if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return 1;
-    p.push_back(q);
-    *out = (T*)q;
-    return 0;
-  }
-};
-}   // namespace
+// the device builder lives in fh_setup.hip (this file stays plain host C++: tests/asan_host.sh); it gets the host arrays
+int fh_prolongator_device(fh_ctx_t ctx, int nl, int nc, int nch, int nel_c, const int* child, const char* refined, const int* c_ed, size_t n_fed, const int* f_ed,
+                          int nf, int ncc, const std::vector<double>& EP, const char* bf, const char* bc, fh_mat_t* out);
 
 static int build_prolongator_device(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t mf, int fe, int zero_bdc, fh_mat_t* out) {
   const int geom = mc->geom, nl = mc->nloc, nc = ndofs_of(geom, fe), nch = nvert_of(geom);
   const int nf = mesh_ndofs(mf, fe), ncc = mesh_ndofs(mc, fe);
   std::vector<double> EP;
   elem_prolongator(geom, fe, EP);
-  std::vector<int> cnt((size_t)nch * nc, 0), nzk((size_t)nch * nc * nc, 0);
-  for (int ji = 0; ji < nch * nc; ji++)
-    for (int k = 0; k < nc; k++)
-      if (EP[(size_t)ji * nc + k] != 0.0) nzk[(size_t)ji * nc + cnt[ji]++] = k;
-  hipStream_t st = ctx->stream;
-  DevBuf B;
-  int *d_child, *d_fed, *d_ced, *d_owner, *d_len, *d_cnt, *d_nzk;
-  char *d_ref, *d_bf = nullptr, *d_bc = nullptr;
-  double* d_EP;
-  const size_t nslot = (size_t)mc->nel * nch;
-  if (B.get(&d_child, nslot) || B.get(&d_fed, mf->elem_dof.size()) || B.get(&d_ced, mc->elem_dof.size()) || B.get(&d_owner, (size_t)nf) ||
-      B.get(&d_len, (size_t)nf) || B.get(&d_cnt, cnt.size()) || B.get(&d_nzk, nzk.size()) || B.get(&d_ref, (size_t)mc->nel) || B.get(&d_EP, EP.size())) {
-    fh_set_error("fh_build_prolongator: out of device memory");
-    return 2;
-  }
-  FH_CHECK_HIP(hipMemcpyAsync(d_child, mc->child.data(), nslot * sizeof(int), hipMemcpyHostToDevice, st));
-  FH_CHECK_HIP(hipMemcpyAsync(d_fed, mf->elem_dof.data(), mf->elem_dof.size() * sizeof(int), hipMemcpyHostToDevice, st));
-  FH_CHECK_HIP(hipMemcpyAsync(d_ced, mc->elem_dof.data(), mc->elem_dof.size() * sizeof(int), hipMemcpyHostToDevice, st));
-  FH_CHECK_HIP(hipMemcpyAsync(d_cnt, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice, st));
-  FH_CHECK_HIP(hipMemcpyAsync(d_nzk, nzk.data(), nzk.size() * sizeof(int), hipMemcpyHostToDevice, st));
-  FH_CHECK_HIP(hipMemcpyAsync(d_ref, mc->refined.data(), (size_t)mc->nel, hipMemcpyHostToDevice, st));
-  FH_CHECK_HIP(hipMemcpyAsync(d_EP, EP.data(), EP.size() * sizeof(double), hipMemcpyHostToDevice, st));
-  FH_CHECK_HIP(hipMemsetAsync(d_owner, 0x7f, (size_t)nf * sizeof(int), st));          // PL_NONE
   std::vector<char> bf, bc;
   if (zero_bdc) {
     std::vector<int> lf, lc;
@@ -633,38 +538,9 @@ static int build_prolongator_device(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t mf, in
     bc.assign(ncc, 0);
     for (int r : lf) bf[r] = 1;
     for (int c : lc) bc[c] = 1;
-    if (B.get(&d_bf, (size_t)nf) || B.get(&d_bc, (size_t)ncc)) {
-      fh_set_error("fh_build_prolongator: out of device memory");
-      return 2;
-    }
-    FH_CHECK_HIP(hipMemcpyAsync(d_bf, bf.data(), (size_t)nf, hipMemcpyHostToDevice, st));
-    FH_CHECK_HIP(hipMemcpyAsync(d_bc, bc.data(), (size_t)ncc, hipMemcpyHostToDevice, st));
   }
-  const size_t nvis = nslot * nc;
-  FH_REQUIRE(nvis < (size_t)PL_NONE, "fh_build_prolongator: %zu visits do not fit the owner index", nvis);
-  if (nvis) hipLaunchKernelGGL(k_pl_owner, dim3((unsigned)((nvis + 255) / 256)), dim3(256), 0, st, nvis, nc, nl, d_child, d_fed, d_owner);
-  if (nf) hipLaunchKernelGGL(k_pl_len, dim3(fh_div_up(nf, 256)), dim3(256), 0, st, nf, nc, nch, d_owner, d_ref, d_cnt, d_len);
-  std::vector<int> rp((size_t)nf + 1, 0);
-  if (nf) FH_CHECK_HIP(hipMemcpyAsync(rp.data() + 1, d_len, (size_t)nf * sizeof(int), hipMemcpyDeviceToHost, st));
-  FH_CHECK_HIP(hipStreamSynchronize(st));
-  int64_t tot = 0;
-  for (int r = 0; r < nf; r++) {
-    tot += rp[r + 1];
-    rp[r + 1] = (int)tot;
-  }
-  FH_REQUIRE(tot < 2147483647ll, "fh_build_prolongator: nnz overflows int32");
-  fh_mat_t P = nullptr;
-  if (fh_mat_alloc_device_pattern(ctx, nf, ncc, std::move(rp), &P)) {
-    fh_mat_destroy(P);
-    return 2;
-  }
-  if (nf) hipLaunchKernelGGL(k_pl_fill, dim3(fh_div_up(nf, 256)), dim3(256), 0, st, nf, nc, nch, nl, d_owner, d_ref, d_ced, d_cnt, d_nzk, d_EP, d_bf, d_bc,
-                             P->d_rowptr, P->d_col, P->d_val);
-  FH_CHECK_HIP(hipGetLastError());
-  FH_CHECK_HIP(hipStreamSynchronize(st));
-  FH_TRY(fh_mat_build_rowblocks(P, ctx->spmv_tile));
-  *out = P;
-  return 0;
+  return fh_prolongator_device(ctx, nl, nc, nch, mc->nel, mc->child.data(), mc->refined.data(), mc->elem_dof.data(), mf->elem_dof.size(), mf->elem_dof.data(), nf, ncc,
+                               EP, zero_bdc ? bf.data() : nullptr, zero_bdc ? bc.data() : nullptr, out);
 }
 
 // a14: P (fine x coarse), INSERT semantics (first insert wins; duplicates are identical rows).  Elements that were not
