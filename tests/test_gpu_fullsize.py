@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import femus_amd
+from femus_amd import capi
 from oracle import femus_oracle as fo
 from femus_amd.poisson import PoissonMG
 
@@ -89,6 +90,39 @@ def test_galerkin_chain_and_full_solve(ctx, problem):
 # The C restatement (oracle/oracle_kernels.c: the loop of 00_poisson_eqn_..._separate.hpp:111-215 over ElemType.hpp:1438-1537)
 # does a few thousand elements per second; the production launch (persistent matrix-core workgroups, 262 144 elements, nonzero
 # solution, non-constant source, curved geometry) is checked on 4096 sampled element matrices and 10 000 sampled CSR rows.
+def test_device_setup_builders_at_full_size_equal_the_host_builders(ctx, problem):
+    """BASELINE size (64^3 Q2): the prolongator of the finest level, the finite-element pattern of the finest matrix and the pattern of a sparse
+    product built on the device are identical -- row pointers, columns, values -- to what the host loops produce (options device_setup /
+    spmv patterns through fh_pattern_from_elements / spgemm_device_symbolic)"""
+    pb = problem
+    mc, mf = pb.meshes[-2], pb.meshes[-1]
+    out = []
+    for dev in (1, 0):
+        ctx.set_option("device_setup", dev)
+        P = capi.build_prolongator(ctx, mc, mf, "biquadratic", zero_bdc=True)
+        rp, col = P.pattern()
+        out.append((rp.copy(), col.copy(), P.values().copy()))
+        P.destroy()
+    ctx.set_option("device_setup", 1)
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    ed, _, _ = mf.arrays()
+    rp_h, col_h = capi.pattern_from_elements(ed, mf.nnode)            # host builder
+    rp_d, col_d = pb.A[-1].pattern()                                  # device builder (matrix_from_elements in PoissonMG.init)
+    assert np.array_equal(rp_h, rp_d) and np.array_equal(col_h, col_d)
+    # pattern of A * P on the coarser level pair (17 M x 2.1 M non-zeros)
+    A2, P2 = pb.A[-2], pb.P[-2]
+    pats = []
+    for dev in (1, 0):
+        ctx.set_option("spgemm_device_symbolic", dev)
+        C = A2.matmul(P2)
+        rp, col = C.pattern()
+        pats.append((rp.copy(), col.copy()))
+        C.destroy()
+    ctx.set_option("spgemm_device_symbolic", 1)
+    assert np.array_equal(pats[0][0], pats[1][0]) and np.array_equal(pats[0][1], pats[1][1])
+
+
 @pytest.fixture(scope="module")
 def curved_problem(ctx):
     """64^3 Q2 with a smooth non-affine map of the unit cube (every element curved), a nonzero solution and a sine source"""
