@@ -2033,6 +2033,78 @@ __global__ __launch_bounds__(256) void k_cluster_maps(int ncl, int ns, int nm, c
 }
 
 
+// Plan construction on the device, second half (round 4): what the host loops over all (cluster, macro row) pairs did.  The template of cluster 0
+// travels as a kernel argument.
+struct ClTmpl {
+  unsigned char tm[CL_NE][27];         // macro node of (element of the cluster, tensor index)
+  unsigned char first_e[CL_NM_MAX], first_t[CL_NM_MAX], tcnt[CL_NM_MAX];
+  unsigned char nodeof[27], tof[27];   // node of a tensor index and back
+  unsigned short roff[CL_NM_MAX + 1];
+  int nm;
+};
+// nodes of every cluster in template order + verification: the cluster reproduces the template with nm distinct nodes (err 1 / 2 otherwise)
+__global__ __launch_bounds__(128) void k_cl_cdof(int ncl, int nloc, const int* __restrict__ elem_dof, ClTmpl T, int* __restrict__ cdof, int* __restrict__ err) {
+  __shared__ int cd[CL_NM_MAX];
+  const int c = blockIdx.x, k = threadIdx.x;
+  cd[k] = k < T.nm ? elem_dof[(size_t)(c * CL_NE + T.first_e[k]) * nloc + T.nodeof[T.first_t[k]]] : -1;
+  __syncthreads();
+  for (int idx = k; idx < CL_NE * 27; idx += 128) {
+    const int e = idx / 27, t = idx % 27;
+    if (elem_dof[(size_t)(c * CL_NE + e) * nloc + T.nodeof[t]] != cd[T.tm[e][t]]) atomicExch(err, 1);
+  }
+  if (k < T.nm)
+    for (int j = 0; j < k; j++)
+      if (cd[j] == cd[k]) atomicExch(err, 2);          // two macro nodes, one mesh node
+  cdof[(size_t)c * CL_NM_MAX + k] = cd[k];
+}
+// a macro row is complete when all elements around its node lie in this cluster and the CSR row has exactly its columns; the others add their
+// packed length (+ the residual entry) to the segment of their CSR row
+__global__ __launch_bounds__(256) void k_cl_rows(int ncl, int m, const int* __restrict__ cdof, const int* __restrict__ aptr, const int* __restrict__ rowptr, ClTmpl T,
+                                                 unsigned char* __restrict__ complete, unsigned* __restrict__ rowsz) {
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= (size_t)ncl * CL_NM_MAX) return;
+  const int r = (int)(q & (CL_NM_MAX - 1));
+  if (r >= T.nm) return;
+  const int g = cdof[q];
+  if (g >= m) return;
+  const int len = T.roff[r + 1] - T.roff[r];
+  if (aptr[g + 1] - aptr[g] == T.tcnt[r] && rowptr[g + 1] - rowptr[g] == len) complete[g] = 1;
+  else atomicAdd(&rowsz[g], (unsigned)len + 1u);
+}
+// destinations: complete rows point into the CSR arrays; a partial row sits in the segment of its CSR row behind the partial rows of the clusters
+// before it -- found by walking the node's (element, local row) list, which is sorted by element: one step per earlier cluster
+__global__ __launch_bounds__(256) void k_cl_dst(int ncl, int m, const int* __restrict__ cdof, const int* __restrict__ aptr, const int* __restrict__ aei,
+                                                const int* __restrict__ rowptr, ClTmpl T, const unsigned char* __restrict__ complete, const unsigned* __restrict__ rowbase,
+                                                unsigned sink, int* __restrict__ vdst, int* __restrict__ fdst) {
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= (size_t)ncl * CL_NM_MAX) return;
+  const int c = (int)(q / CL_NM_MAX), r = (int)(q & (CL_NM_MAX - 1));
+  const int g = r < T.nm ? cdof[q] : -1;
+  if (g < 0 || g >= m) {
+    vdst[q] = (int)sink;
+    fdst[q] = (int)sink;
+    return;
+  }
+  if (complete[g]) {
+    vdst[q] = rowptr[g];
+    fdst[q] = g;
+    return;
+  }
+  unsigned off = rowbase[g];
+  int prev = -1;
+  for (int a = aptr[g]; a < aptr[g + 1]; a++) {
+    const int ei = aei[a], e = ei >> 5, cc = e / CL_NE;
+    if (cc >= c) break;
+    if (cc != prev) {
+      prev = cc;
+      const int r2 = T.tm[e % CL_NE][T.tof[ei & 31]];
+      off += (unsigned)(T.roff[r2 + 1] - T.roff[r2]) + 1u;
+    }
+  }
+  vdst[q] = (int)(0x80000000u | off);
+  fdst[q] = (int)(0x80000000u | (off + (unsigned)(T.roff[r + 1] - T.roff[r])));
+}
+
 // Plan of the fused cluster assembly (see k_cluster_q2hex_sf).  Host: template from cluster 0, verification of every cluster, completeness of
 // every (cluster, macro row), offsets of the partial rows, the lists of the second pass -- O(nel * 27) integer work; device: the byte maps.
 // Returns 0 and leaves as->fused false when the mesh does not offer the structure.
@@ -2071,22 +2143,40 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
       tcnt[k]++;
     }
   }
-  // every cluster reproduces the template with 'nm' distinct nodes
-  std::vector<int> cdof((size_t)ncl * CL_NM_MAX, -1);
+  // every cluster reproduces the template with 'nm' distinct nodes: checked on the device, which also lists the nodes of every cluster
+  ClTmpl T;
+  memset(&T, 0, sizeof(T));
+  T.nm = nm;
+  for (int e = 0; e < CL_NE; e++)
+    for (int t = 0; t < 27; t++) T.tm[e][t] = (unsigned char)tm[e][t];
+  for (int k = 0; k < nm; k++) {
+    T.first_e[k] = (unsigned char)first_e[k];
+    T.first_t[k] = (unsigned char)first_t[k];
+    T.tcnt[k] = (unsigned char)tcnt[k];
+  }
+  for (int t = 0; t < 27; t++) {
+    T.nodeof[t] = (unsigned char)nodeof[t];
+    T.tof[nodeof[t]] = (unsigned char)t;
+  }
+  struct Tmp {
+    std::vector<void*> p;
+    ~Tmp() { for (void* q : p) if (q) hipFree(q); }
+  } tmp;
+  auto dalloc = [&](void** d, size_t bytes) -> int {
+    FH_CHECK_HIP(hipMalloc(d, bytes ? bytes : 8));
+    tmp.p.push_back(*d);
+    return 0;
+  };
+  int *d_cdof = nullptr, *d_perr = nullptr;
+  FH_TRY(dalloc((void**)&d_cdof, (size_t)ncl * CL_NM_MAX * sizeof(int)));
+  FH_TRY(dalloc((void**)&d_perr, sizeof(int)));
+  FH_CHECK_HIP(hipMemsetAsync(d_perr, 0, sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(k_cl_cdof, dim3(ncl), dim3(128), 0, ctx->stream, ncl, nloc, as->d_elem_dof, T, d_cdof, d_perr);
   {
-    std::vector<int> stamp(as->nnode, -1);
-    for (int c = 0; c < ncl; c++) {
-      int* cd = &cdof[(size_t)c * CL_NM_MAX];
-      for (int k = 0; k < nm; k++) {
-        const int g = elem_dof[(size_t)(c * CL_NE + first_e[k]) * nloc + nodeof[first_t[k]]];
-        if (stamp[g] == c) return 0;             // two macro nodes, one mesh node
-        stamp[g] = c;
-        cd[k] = g;
-      }
-      for (int e = 0; e < CL_NE; e++)
-        for (int t = 0; t < 27; t++)
-          if (elem_dof[(size_t)(c * CL_NE + e) * nloc + nodeof[t]] != cd[tm[e][t]]) return 0;
-    }
+    int perr = 0;
+    FH_CHECK_HIP(hipMemcpyAsync(&perr, d_perr, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (perr) return 0;
   }
   FH_TRACE("cluster plan: clusters verified");
   // template rows: macro columns ascending; contributions in ascending element order
@@ -2161,49 +2251,45 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
   }
   FH_TRACE("cluster plan: template");
   // destinations: a macro row is complete when all elements around its node lie in this cluster and the CSR row has exactly its columns.
-  // The partial rows of one CSR row follow each other in the partial-row buffer, ascending cluster (= element) order.
-  std::vector<int> vdst((size_t)ncl * CL_NM_MAX), fdst((size_t)ncl * CL_NM_MAX);
-  std::vector<char> complete(m, 0);
-  std::vector<unsigned> rowsz(m + 1, 0);         // entries of the segment of row g (partial rows + their residual entries)
-    for (int c = 0; c < ncl; c++)
-    for (int r = 0; r < nm; r++) {
-      const int g = cdof[(size_t)c * CL_NM_MAX + r], len = roff[r + 1] - roff[r];
-      if (g >= m) continue;
-      if (aptr[g + 1] - aptr[g] == tcnt[r] && A->h_rowptr[g + 1] - A->h_rowptr[g] == len) complete[g] = 1;
-      else {
-        if (rowsz[g] + len + 1 > 32 * RP_Q) return 0;                // the second pass holds a segment of <= 224 entries in registers
-        rowsz[g] += (unsigned)len + 1;
-      }
-    }
-  std::vector<int> prow, rowk(m, -1);
-  std::vector<unsigned> pstart(1, 0);
+  // The partial rows of one CSR row follow each other in the partial-row buffer, ascending cluster (= element) order.  Device: completeness and
+  // segment sizes per CSR row; host: the scan over the rows (list of the second pass, segment starts); device: the destination of every macro row.
+  for (int r = 0; r <= CL_NM_MAX; r++) T.roff[r] = roff[r];
+  unsigned char* d_complete = nullptr;
+  unsigned *d_rowsz = nullptr, *d_rowbase = nullptr;
+  FH_TRY(dalloc((void**)&d_complete, (size_t)m));
+  FH_TRY(dalloc((void**)&d_rowsz, (size_t)m * sizeof(unsigned)));
+  FH_TRY(dalloc((void**)&d_rowbase, (size_t)m * sizeof(unsigned)));
+  FH_CHECK_HIP(hipMemsetAsync(d_complete, 0, (size_t)m, ctx->stream));
+  FH_CHECK_HIP(hipMemsetAsync(d_rowsz, 0, (size_t)m * sizeof(unsigned), ctx->stream));
+  const unsigned gq = (unsigned)(((size_t)ncl * CL_NM_MAX + 255) / 256);
+  hipLaunchKernelGGL(k_cl_rows, dim3(gq), dim3(256), 0, ctx->stream, ncl, m, d_cdof, as->d_adj_ptr, A->d_rowptr, T, d_complete, d_rowsz);
+  std::vector<unsigned char> complete(m, 0);
+  std::vector<unsigned> rowsz(m, 0);
+  if (m) {
+    FH_CHECK_HIP(hipMemcpyAsync(complete.data(), d_complete, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    FH_CHECK_HIP(hipMemcpyAsync(rowsz.data(), d_rowsz, (size_t)m * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<int> prow;
+  std::vector<unsigned> pstart(1, 0), rowbase(m, 0);
   size_t npart = 0;
   for (int g = 0; g < m; g++)
     if (!complete[g]) {
-      rowk[g] = (int)prow.size();
+      if (rowsz[g] > 32 * RP_Q) return 0;                // the second pass holds a segment of <= 224 entries in registers
+      rowbase[g] = (unsigned)npart;
       prow.push_back(g);
       npart += rowsz[g];
       if (npart + 128 >= ((size_t)1 << 31)) return 0;
       pstart.push_back((unsigned)npart);
     }
   const unsigned sink = 0x80000000u | (unsigned)npart;
-  {
-    std::vector<unsigned> cur(pstart.begin(), pstart.end() - 1);
-    for (int c = 0; c < ncl; c++)
-      for (int r = 0; r < CL_NM_MAX; r++) {
-        const size_t q = (size_t)c * CL_NM_MAX + r;
-        const int g = r < nm ? cdof[q] : -1;
-        if (g < 0 || g >= m) { vdst[q] = (int)sink; fdst[q] = (int)sink; continue; }
-        const int len = roff[r + 1] - roff[r];
-        if (complete[g]) { vdst[q] = A->h_rowptr[g]; fdst[q] = g; }
-        else {
-          const int k = rowk[g];
-          vdst[q] = (int)(0x80000000u | cur[k]);
-          fdst[q] = (int)(0x80000000u | (cur[k] + (unsigned)len));
-          cur[k] += (unsigned)len + 1;
-        }
-      }
-  }
+  if (m) FH_CHECK_HIP(hipMemcpyAsync(d_rowbase, rowbase.data(), (size_t)m * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+  FH_CHECK_HIP(hipMalloc(&as->d_cl_vdst, (size_t)ncl * CL_NM_MAX * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&as->d_cl_fdst, (size_t)ncl * CL_NM_MAX * sizeof(int)));
+  hipLaunchKernelGGL(k_cl_dst, dim3(gq), dim3(256), 0, ctx->stream, ncl, m, d_cdof, as->d_adj_ptr, as->d_adj_ei, A->d_rowptr, T, d_complete, d_rowbase, sink,
+                     as->d_cl_vdst, as->d_cl_fdst);
+  FH_CHECK_HIP(hipGetLastError());
+  FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   FH_TRACE("cluster plan: destinations");
   auto up = [&](void** d, const void* h, size_t bytes) -> int {
     FH_CHECK_HIP(hipMalloc(d, bytes ? bytes : 8));
@@ -2215,8 +2301,6 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
   FH_TRY(up((void**)&as->d_cl_oblk, oblk.data(), oblk.size() * sizeof(U4)));
   FH_CHECK_HIP(hipMalloc(&as->d_cl_vdst64, (size_t)ncl * CL_NM_MAX * sizeof(unsigned long long)));
   FH_TRY(up((void**)&as->d_cl_sinfo, sinfo.data(), sinfo.size() * 4));
-  FH_TRY(up((void**)&as->d_cl_vdst, vdst.data(), vdst.size() * 4));
-  FH_TRY(up((void**)&as->d_cl_fdst, fdst.data(), fdst.size() * 4));
   FH_TRY(up((void**)&as->d_cl_prow, prow.data(), prow.size() * 4));
   FH_TRY(up((void**)&as->d_cl_pstart, pstart.data(), pstart.size() * 4));
   FH_CHECK_HIP(hipMalloc(&as->d_cl_map, (size_t)ncl * CL_T * 16));
@@ -2226,10 +2310,9 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
   FH_CHECK_HIP(hipMemset(as->d_Pbuf, ctx->debug_poison ? 0xFF : 0, (npart + 128) * sizeof(double)));
   FH_TRACE("cluster plan: uploads and buffers");
   {
-    int *d_cdof = nullptr, *d_err = nullptr;
+    int* d_err = nullptr;
     unsigned char* d_tcol = nullptr;
     unsigned short* d_roff = nullptr;
-    FH_TRY(up((void**)&d_cdof, cdof.data(), cdof.size() * 4));
     FH_TRY(up((void**)&d_tcol, tcol.data(), tcol.size()));
     FH_TRY(up((void**)&d_roff, roff.data(), roff.size() * 2));
     const int zero = 0;
@@ -2240,7 +2323,7 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
     int err = 0;
     FH_CHECK_HIP(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    for (void* q : {(void*)d_cdof, (void*)d_tcol, (void*)d_roff, (void*)d_err}) hipFree(q);
+    for (void* q : {(void*)d_tcol, (void*)d_roff, (void*)d_err}) hipFree(q);
     if (err) {
       FH_TRACE("fh_assembler_create: cluster maps could not be placed in the matrix pattern -- two-pass assembly kept");
       return 0;
