@@ -159,13 +159,28 @@ def test_sampled_element_matrices_at_full_size_match_the_c_oracle(curved_problem
     assert checked >= 4096 - 256
 
 
-def test_sampled_csr_rows_at_full_size_match_the_c_oracle(curved_problem):
-    """10 000 random rows of the assembled operator and residual (two-pass path: element rows + row gather): every row equals the
-    sum of its element contributions from the C oracle, added in ascending element order as the reference's loop does"""
+PATHS = {0: "two-pass", 2: "fused"}       # option assemble_fused -> what fh_assembler_last_path must report
+
+
+def assemble_on_path(ctx, pb, fused):
+    """one assembly of the finest level on the requested path; the path that really ran is asserted"""
+    ctx.set_option("assemble_fused", fused)
+    try:
+        pb.assemble()
+    finally:
+        ctx.set_option("assemble_fused", 1)
+    assert pb.asm[-1].last_path() == PATHS[fused]
+
+
+@pytest.mark.parametrize("fused", [0, 2])
+def test_sampled_csr_rows_at_full_size_match_the_c_oracle(ctx, curved_problem, fused):
+    """10 000 random rows of the assembled operator and residual, once per assembly path (two-pass: element rows + row gather, the path of
+    every assembly that follows an element-wise Galerkin product; fused: cluster kernel + partial-row pass): every row equals the sum of its
+    element contributions from the C oracle, added in ascending element order as the reference's loop does"""
     from oracle import c_kernels as ck
     pb, ed, xw = curved_problem
     sol = pb.SOL.to_numpy()
-    pb.assemble()
+    assemble_on_path(ctx, pb, fused)
     rp, col = pb.A[-1].pattern()
     val = pb.A[-1].values()
     res = pb.RES.to_numpy()
@@ -200,24 +215,27 @@ def test_sampled_csr_rows_at_full_size_match_the_c_oracle(curved_problem):
 
 def test_whole_level_matrix_and_cycle_match_the_c_oracle(ctx, curved_problem):
     """not sampled: ALL 135 005 697 entries of the fine-level operator and all 2 146 689 residual entries (curved elements, nonzero
-    solution, sine source) against the C restatement's element loop run over every element on all host cores; then one V(2,2) cycle of
-    the whole four-level hierarchy on the device against the C restatement's cycle on the same operators (1e-10, north_star)"""
+    solution, sine source) against the C restatement's element loop run over every element on all host cores -- once per assembly path
+    (two-pass and fused, the path asserted); then one V(2,2) cycle of the whole four-level hierarchy on the device against the C
+    restatement's cycle on the same operators (1e-10, north_star)"""
     import os
     import scipy.linalg as sla
     from oracle import c_kernels as ck
     pb, ed, xw = curved_problem
     ck.set_threads(len(os.sched_getaffinity(0)))
     sol = pb.SOL.to_numpy()
-    pb.assemble()
     rp, col = pb.A[-1].pattern()
     val, res = np.zeros(rp[-1]), np.zeros(pb.ndof[-1])
     ck.assemble_poisson_all_cores(ed, xw, "biquadratic", "hex", (rp, col, val, res), sol=sol, source_kind=1, p0=3.0, p1=2.0)
-    got = pb.A[-1].values()
     # row-wise scale: the entries of a row are sums of up to 8 element contributions of the size of the diagonal
     diag_scale = np.repeat(np.maximum.reduceat(np.abs(val), rp[:-1]), np.diff(rp))
-    assert np.max(np.abs(got - val) / diag_scale) <= 1e-12
-    r_dev = pb.RES.to_numpy()
-    assert np.max(np.abs(r_dev - res)) <= 1e-12 * np.abs(res).max()
+    for fused in (2, 0):                                   # the two-pass operator last: it is the one the cycle below is prepared from
+        pb.A[-1].zero(), pb.RES.zero()
+        assemble_on_path(ctx, pb, fused)
+        got = pb.A[-1].values()
+        assert np.max(np.abs(got - val) / diag_scale) <= 1e-12, PATHS[fused]
+        r_dev = pb.RES.to_numpy()
+        assert np.max(np.abs(r_dev - res)) <= 1e-12 * np.abs(res).max(), PATHS[fused]
     del got, val, diag_scale
     # the cycle: operators of the device hierarchy (Galerkin chain + SetPenalty), C cycle on the host
     pb.prepare()
