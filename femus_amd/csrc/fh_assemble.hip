@@ -1266,77 +1266,148 @@ __device__ __forceinline__ void sf_ld4(const double* p, double v[4]) {
 
 // Phases A and stages 1-3 of the sum-factorised element matrix (shared by k_elem_q2hex_sf and the cluster kernel k_cluster_q2hex_sf): from the
 // element's nodes in xt (tensor order) to this lane's 3 x 3 block Kb over (a, a') and its source entry fsrc.  R is the wave's scratch region.
-template <int SRC, bool REGC>
-__device__ __forceinline__ void sf_element_blocks(const AsmParams& P, const SfTab& tab, const double* LCl, const int* LIl, const double (&rcA)[19], const double (&rcZ)[8],
-                                                  const double (&rcY)[16], const int esym, const int ens, const int ensT, const int eout, const double* xt, double* R,
-                                                  const int lane, double (&Kb)[3][3], double& fsrc) {
+// phase stamps of the instrumented build of the cluster kernel (asm_debug bit 7): shader clock at the phase boundaries, summed per wave in scalar registers
+struct SfStamps {
+  unsigned long long prev, acc[16];
+};
+template <bool INS>
+__device__ __forceinline__ void sf_stamp(SfStamps& st, const int k) {
+  if (INS) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    st.acc[k] += t - st.prev;
+    st.prev = t;
+  }
+}
+
+// lane l of tabv holds entry l of the 1-D table {L[3][4], D[3][4]} (sf_tab_lanes); a uniform entry is fetched with two v_readlane.  Keeping the 24 doubles
+// in scalar registers instead (the kernel argument) left the unrolled stages 2-3 with scalar spills.
+__device__ __forceinline__ double sf_tab_lanes(const SfTab& tab, const int lane) {
+  double v = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      v = (lane == a * 4 + q) ? tab.L[a][q] : v;
+      v = (lane == 12 + a * 4 + q) ? tab.D[a][q] : v;
+    }
+  return v;
+}
+__device__ __forceinline__ double sf_tab_get(const double tabv, const int entry) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(tabv), entry), hi = __builtin_amdgcn_readlane(__double2hiint(tabv), entry);
+  return __hiloint2double(hi, lo);
+}
+
+// Phase A of the sum-factorised element matrix: from the element's nodes in xt (tensor order) to D_q and the source weight at this lane's Gauss point.
+// UV = 6 * SF_US + 9 * SF_VS doubles of wave-private scratch (the callers pass region R, or a region of its own when R still holds a staging).
+struct SfIdxA {             // per-lane double indices of phase A (rows 0 .. 4 of the integer table): xt gather, U write, U read, V write, V read
+  int xn, uo, ui, vo, vi;
+};
+template <int SRC, bool REGC, bool INS = false>
+__device__ __forceinline__ void sf_phase_a(const AsmParams& P, const double* LCl, const SfIdxA ia, const double (&rcA)[19], const double* xt, double* UV, double (&Dr)[7],
+                                           SfStamps* stp = nullptr) {
   constexpr int DIM = 3;
-#define SF_I(r) LIl[(r) * 64]
+  SfStamps dummy_st;
+  SfStamps& st = INS ? *stp : dummy_st;
 #define SF_C(r) LCl[(r) * 64]
 #define SF_CA(r) (REGC ? rcA[r] : SF_C(r))
-  double Dr[7];            // D_q (six entries) and the source weight at this lane's Gauss point
-  // ---- phase A: J_q by three contractions through LDS (U, V alias region R; one array per coordinate, every access is
-  //      conflict-free), then D_q; lane = Gauss point in tensor order.  Lanes beyond a stage's role count repeat its last role
-  //      (same values to the same addresses): no divergent branch in the element loop ----
+  // ---- phase A: J_q by three contractions through LDS (U, V: one array per coordinate, every access is conflict-free), then D_q; lane = Gauss point
+  //      in tensor order.  Lanes beyond a stage's role count repeat its last role (same values to the same addresses): no divergent branch in the
+  //      element loop.  The reads are issued by hand as ds_read_b64: left to the compiler every pair became a ds_read2_b64, which costs 8 LDS cycles
+  //      instead of 2 + 2 (MI355X_MICROARCH.md, LDS table) -- and the LDS array is the busiest unit of the element phase (65 % of its cycles) ----
+#define SF_LDA(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define SF_WAIT3(n, a, b, c) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b), "+v"(c))
   {
     double J[DIM][DIM] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, xg[DIM] = {0, 0, 0};
-    double* U = R;                     // [2][3][SF_US]: (sum_a l_a x, sum_a l'_a x) at [(b*3+c)*4 + q1]
-    double* V = R + 6 * SF_US;         // [3][3][SF_VS]: V, Veta, Vxi at [c*16 + q1 + 4 q2]
+    double* U = UV;                    // [2][3][SF_US]: (sum_a l_a x, sum_a l'_a x) at [(b*3+c)*4 + q1]
+    double* V = UV + 6 * SF_US;         // [3][3][SF_VS]: V, Veta, Vxi at [c*16 + q1 + 4 q2]
     {
-      const double* xn = xt + SF_I(0);             // b*3 + c
+      const unsigned axn = (unsigned)(size_t)(__attribute__((address_space(3))) const double*)(xt + ia.xn);             // b*3 + c
+      double x[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int d = 0; d < 3; d++) SF_LDA(x[a][d], axn, (d * 28 + a * 9) * 8);
       double u[2][3] = {{0, 0, 0}, {0, 0, 0}};
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         const double la = SF_CA(a), da = SF_CA(3 + a);
+        if (a == 0) SF_WAIT3(6, x[0][0], x[0][1], x[0][2]);
+        else if (a == 1) SF_WAIT3(3, x[1][0], x[1][1], x[1][2]);
+        else SF_WAIT3(0, x[2][0], x[2][1], x[2][2]);
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-          const double x = xn[d * 28 + a * 9];
-          u[0][d] += la * x;
-          u[1][d] += da * x;
+          u[0][d] += la * x[a][d];
+          u[1][d] += da * x[a][d];
         }
       }
-      double* uo = U + SF_I(1);
+      double* uo = U + ia.uo;
 #pragma unroll
       for (int k = 0; k < 2; k++)
 #pragma unroll
         for (int d = 0; d < 3; d++) uo[(k * 3 + d) * SF_US] = u[k][d];
     }
     wave_lds_sync();
+    sf_stamp<INS>(st, 1);
     {
-      const double* ui = U + SF_I(2);              // c*4 + q1
+      const unsigned aui = (unsigned)(size_t)(__attribute__((address_space(3))) const double*)(U + ia.ui);              // c*4 + q1
+      double u0[3][3], u1[3][3];
+#pragma unroll
+      for (int b = 0; b < 3; b++)
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          SF_LDA(u0[b][d], aui, (d * SF_US + b * 12) * 8);
+          SF_LDA(u1[b][d], aui, ((3 + d) * SF_US + b * 12) * 8);
+        }
       double v[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #pragma unroll
       for (int b = 0; b < 3; b++) {
         const double lb = SF_CA(6 + b), db = SF_CA(9 + b);
+        if (b == 0) { SF_WAIT3(12, u0[0][0], u0[0][1], u0[0][2]); SF_WAIT3(12, u1[0][0], u1[0][1], u1[0][2]); }
+        else if (b == 1) { SF_WAIT3(6, u0[1][0], u0[1][1], u0[1][2]); SF_WAIT3(6, u1[1][0], u1[1][1], u1[1][2]); }
+        else { SF_WAIT3(0, u0[2][0], u0[2][1], u0[2][2]); SF_WAIT3(0, u1[2][0], u1[2][1], u1[2][2]); }
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-          const double u0 = ui[d * SF_US + b * 12], u1 = ui[(3 + d) * SF_US + b * 12];
-          v[0][d] += lb * u0;     // V
-          v[1][d] += db * u0;     // Veta
-          v[2][d] += lb * u1;     // Vxi
+          v[0][d] += lb * u0[b][d];     // V
+          v[1][d] += db * u0[b][d];     // Veta
+          v[2][d] += lb * u1[b][d];     // Vxi
         }
       }
-      double* vo = V + SF_I(3);
+      double* vo = V + ia.vo;
 #pragma unroll
       for (int k = 0; k < 3; k++)
 #pragma unroll
         for (int d = 0; d < 3; d++) vo[(k * 3 + d) * SF_VS] = v[k][d];
     }
     wave_lds_sync();
+    sf_stamp<INS>(st, 2);
     {
-      const double* vi = V + SF_I(4);              // q1 + 4 q2
+      const unsigned avi = (unsigned)(size_t)(__attribute__((address_space(3))) const double*)(V + ia.vi);              // q1 + 4 q2
+      double v0[3][3], v1[3][3], v2[3][3];
+#define SF_LDJ(c)                                                      \
+  _Pragma("unroll") for (int d = 0; d < 3; d++) {                      \
+    SF_LDA(v0[c][d], avi, (d * SF_VS + (c) * 16) * 8);                 \
+    SF_LDA(v1[c][d], avi, ((3 + d) * SF_VS + (c) * 16) * 8);           \
+    SF_LDA(v2[c][d], avi, ((6 + d) * SF_VS + (c) * 16) * 8);           \
+  }
+      SF_LDJ(0);
+      SF_LDJ(1);
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         const double lc = SF_CA(12 + c), dc = SF_CA(15 + c);
+        // nine reads per c; the reads of c = 2 go out once c = 0 has been consumed (eighteen operands live instead of twenty-seven)
+        if (c == 0) { SF_WAIT3(9, v0[0][0], v0[0][1], v0[0][2]); SF_WAIT3(9, v1[0][0], v1[0][1], v1[0][2]); SF_WAIT3(9, v2[0][0], v2[0][1], v2[0][2]); }
+        else if (c == 1) { SF_WAIT3(9, v0[1][0], v0[1][1], v0[1][2]); SF_WAIT3(9, v1[1][0], v1[1][1], v1[1][2]); SF_WAIT3(9, v2[1][0], v2[1][1], v2[1][2]); }
+        else { SF_WAIT3(0, v0[2][0], v0[2][1], v0[2][2]); SF_WAIT3(0, v1[2][0], v1[2][1], v1[2][2]); SF_WAIT3(0, v2[2][0], v2[2][1], v2[2][2]); }
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-          const double v0 = vi[d * SF_VS + c * 16], v1 = vi[(3 + d) * SF_VS + c * 16], v2 = vi[(6 + d) * SF_VS + c * 16];
-          J[0][d] += lc * v2;
-          J[1][d] += lc * v1;
-          J[2][d] += dc * v0;
-          if (SRC != 0) xg[d] += lc * v0;
+          J[0][d] += lc * v2[c][d];
+          J[1][d] += lc * v1[c][d];
+          J[2][d] += dc * v0[c][d];
+          if (SRC != 0) xg[d] += lc * v0[c][d];
         }
+        if (c == 0) { SF_LDJ(2); }
       }
+#undef SF_LDJ
     }
     // cofactors Cf = det * J^-1 (the reference's Jacobian inverse, `elem_type_template` 3-D branch, without the division)
     double Cf[DIM][DIM];
@@ -1367,7 +1438,26 @@ __device__ __forceinline__ void sf_element_blocks(const AsmParams& P, const SfTa
     Dr[5] = sc * (Cf[0][2] * Cf[0][2] + Cf[1][2] * Cf[1][2] + Cf[2][2] * Cf[2][2]);
     Dr[6] = det * wgauss * fq;
   }
-  wave_lds_sync();
+  if (INS) {                  // the stamp waits for D_q (the value is consumed by an empty asm statement)
+    asm volatile("" ::"v"(Dr[0]), "v"(Dr[5]), "v"(Dr[6]));
+    sf_stamp<INS>(st, 3);
+  }
+#undef SF_LDA
+#undef SF_WAIT3
+#undef SF_C
+#undef SF_CA
+}
+
+// Stages 1-3 (and the source integral): from D_q at this lane's Gauss point (Dr, as sf_phase_a leaves it) to this lane's 3 x 3 block Kb over (a, a') and its
+// source entry fsrc.  R is the wave's scratch region (e arrays); every lane must be done with whatever aliased it (the callers synchronise the wave first).
+template <int SRC, bool REGC, bool INS = false>
+__device__ __forceinline__ void sf_stages(const AsmParams& P, const SfTab& tab, const double* LCl, const int* LIl, const double (&rcZ)[8], const double (&rcY)[16], const int esym,
+                                          const int ens, const int ensT, const int eout, double* R, const int lane, const double (&Dr)[7], double (&Kb)[3][3], double& fsrc,
+                                          SfStamps* stp = nullptr) {
+  SfStamps dummy_st;
+  SfStamps& st = INS ? *stp : dummy_st;
+#define SF_I(r) LIl[(r) * 64]
+#define SF_C(r) LCl[(r) * 64]
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -1398,6 +1488,7 @@ __device__ __forceinline__ void sf_element_blocks(const AsmParams& P, const SfTa
       R[SF_NE + lane] = __builtin_amdgcn_mfma_f64_4x4x4f64(zs, Dr[6], 0.0, 0, 0, 0);      // sE[c][q1*4 + q2], c = lane >> 4
     }
     wave_lds_sync();
+    sf_stamp<INS>(st, 4);
     // ---- source, second contraction: lane = (q1, b, c), contracts q2 ----
     {
       double s4[4];
@@ -1416,45 +1507,72 @@ __device__ __forceinline__ void sf_element_blocks(const AsmParams& P, const SfTa
         yLL[q] = REGC ? rcY[q] : SF_C(27 + q); yLD[q] = REGC ? rcY[4 + q] : SF_C(31 + q);
         yDL[q] = REGC ? rcY[8 + q] : SF_C(35 + q); yDD[q] = REGC ? rcY[12 + q] : SF_C(39 + q);
       }
-#pragma unroll 1
-      for (int q1 = 0; q1 < 4; q1++) {
-        double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;     // G for (l'l'), (l'l), (ll'), (ll)
-        {
-          double v0[4], v1[4], v2[4], v2T[4];
-          sf_ld4(es + 0 * SF_ES + q1 * 4, v0);
-          sf_ld4(es + 8 * SF_ES + q1 * 4, v1);
-          sf_ld4(en + 16 * SF_ES + q1 * 4, v2);
-          sf_ld4(eT + 16 * SF_ES + q1 * 4, v2T);
+      {
+        // Software pipeline by hand, half a q1 at a time (the phase stamps showed a wave paying latency + 16 x 16 cycles of read return + 66 FMAs one
+        // after the other per q1): group A = the eight reads behind g0, g1, g2, group B = the eight behind g3; B(q1) is issued before A(q1)'s arithmetic,
+        // A(q1 + 1) before B(q1)'s, so eight reads are always in flight under 20 / 46 multiply-adds.  LDS reads of a wave return in order:
+        // `s_waitcnt lgkmcnt(8)` = everything but the youngest eight has arrived.  No more registers than the plain loop (sixteen operands live).
+        typedef double sf_d2 __attribute__((ext_vector_type(2)));
+        const unsigned a_es = (unsigned)(size_t)(__attribute__((address_space(3))) const double*)es;
+        const unsigned a_en = (unsigned)(size_t)(__attribute__((address_space(3))) const double*)en;
+        const unsigned a_eT = (unsigned)(size_t)(__attribute__((address_space(3))) const double*)eT;
+#define SF_LD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define SF_LOAD_A(q1)                                                                                                                     \
+  SF_LD(va[0], a_es, (0 * SF_ES + (q1) * 4) * 8); SF_LD(va[1], a_es, (0 * SF_ES + (q1) * 4) * 8 + 16);                                     \
+  SF_LD(va[2], a_es, (8 * SF_ES + (q1) * 4) * 8); SF_LD(va[3], a_es, (8 * SF_ES + (q1) * 4) * 8 + 16);                                     \
+  SF_LD(va[4], a_en, (16 * SF_ES + (q1) * 4) * 8); SF_LD(va[5], a_en, (16 * SF_ES + (q1) * 4) * 8 + 16);                                   \
+  SF_LD(va[6], a_eT, (16 * SF_ES + (q1) * 4) * 8); SF_LD(va[7], a_eT, (16 * SF_ES + (q1) * 4) * 8 + 16)
+#define SF_LOAD_B(q1)                                                                                                                     \
+  SF_LD(vb[0], a_es, (28 * SF_ES + (q1) * 4) * 8); SF_LD(vb[1], a_es, (28 * SF_ES + (q1) * 4) * 8 + 16);                                   \
+  SF_LD(vb[2], a_en, (36 * SF_ES + (q1) * 4) * 8); SF_LD(vb[3], a_en, (36 * SF_ES + (q1) * 4) * 8 + 16);                                   \
+  SF_LD(vb[4], a_eT, (36 * SF_ES + (q1) * 4) * 8); SF_LD(vb[5], a_eT, (36 * SF_ES + (q1) * 4) * 8 + 16);                                   \
+  SF_LD(vb[6], a_es, (48 * SF_ES + (q1) * 4) * 8); SF_LD(vb[7], a_es, (48 * SF_ES + (q1) * 4) * 8 + 16)
+#define SF_WAIT(v, n)                                                                                                                     \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]))
+        sf_d2 va[8], vb[8];
+        const double tabv = sf_tab_lanes(tab, lane);
+        SF_LOAD_A(0);
+#pragma unroll
+        for (int q1 = 0; q1 < 4; q1++) {
+          if (q1 == 0) { SF_LOAD_B(0); } else if (q1 == 1) { SF_LOAD_B(1); } else if (q1 == 2) { SF_LOAD_B(2); } else { SF_LOAD_B(3); }
+          SF_WAIT(va, 8);
+          double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;     // G for (l'l'), (l'l), (ll'), (ll)
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            g0 += yLL[q] * v0[q];
-            g1 += yLD[q] * v1[q]; g1 += yLL[q] * v2[q];
-            g2 += yDL[q] * v1[q]; g2 += yLL[q] * v2T[q];
+            const double v0 = va[q >> 1][q & 1], v1 = va[2 + (q >> 1)][q & 1], v2 = va[4 + (q >> 1)][q & 1], v2T = va[6 + (q >> 1)][q & 1];
+            g0 += yLL[q] * v0;
+            g1 += yLD[q] * v1; g1 += yLL[q] * v2;
+            g2 += yDL[q] * v1; g2 += yLL[q] * v2T;
           }
+          if (q1 == 0) { SF_LOAD_A(1); } else if (q1 == 1) { SF_LOAD_A(2); } else if (q1 == 2) { SF_LOAD_A(3); }
+          if (q1 < 3) { SF_WAIT(vb, 8); } else { SF_WAIT(vb, 0); }
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const double v3 = vb[q >> 1][q & 1], v4 = vb[2 + (q >> 1)][q & 1], v4T = vb[4 + (q >> 1)][q & 1], v5 = vb[6 + (q >> 1)][q & 1];
+            g3 += yDD[q] * v3; g3 += yDL[q] * v4; g3 += yLD[q] * v4T; g3 += yLL[q] * v5;
+          }
+          const double la[3] = {sf_tab_get(tabv, q1), sf_tab_get(tabv, 4 + q1), sf_tab_get(tabv, 8 + q1)};
+          const double da[3] = {sf_tab_get(tabv, 12 + q1), sf_tab_get(tabv, 16 + q1), sf_tab_get(tabv, 20 + q1)};
+          double u[3], v[3];
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            u[a] = la[a] * g3 + da[a] * g1;
+            v[a] = la[a] * g2 + da[a] * g0;
+          }
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int a2 = 0; a2 < 3; a2++) { Kb[a][a2] += la[a2] * u[a]; Kb[a][a2] += da[a2] * v[a]; }
         }
-        __builtin_amdgcn_sched_barrier(0);         // the second half's operands are loaded after the first half is done with its own
-        {
-          double v3[4], v4[4], v4T[4], v5[4];
-          sf_ld4(es + 28 * SF_ES + q1 * 4, v3);
-          sf_ld4(en + 36 * SF_ES + q1 * 4, v4);
-          sf_ld4(eT + 36 * SF_ES + q1 * 4, v4T);
-          sf_ld4(es + 48 * SF_ES + q1 * 4, v5);
-#pragma unroll
-          for (int q = 0; q < 4; q++) { g3 += yDD[q] * v3[q]; g3 += yDL[q] * v4[q]; g3 += yLD[q] * v4T[q]; g3 += yLL[q] * v5[q]; }
-        }
-        const double l0 = tab.L[0][q1], l1 = tab.L[1][q1], l2 = tab.L[2][q1], d0 = tab.D[0][q1], d1 = tab.D[1][q1], d2 = tab.D[2][q1];
-        const double la[3] = {l0, l1, l2}, da[3] = {d0, d1, d2};
-        double u[3], v[3];
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-          u[a] = la[a] * g3 + da[a] * g1;
-          v[a] = la[a] * g2 + da[a] * g0;
-        }
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-          for (int a2 = 0; a2 < 3; a2++) { Kb[a][a2] += la[a2] * u[a]; Kb[a][a2] += da[a2] * v[a]; }
+#undef SF_LD
+#undef SF_LOAD_A
+#undef SF_LOAD_B
+#undef SF_WAIT
       }
+    }
+    if (INS) {
+      asm volatile("" ::"v"(Kb[0][0]), "v"(Kb[2][2]));
+      sf_stamp<INS>(st, 5);
     }
     wave_lds_sync();
     {
@@ -1465,7 +1583,18 @@ __device__ __forceinline__ void sf_element_blocks(const AsmParams& P, const SfTa
   }
 #undef SF_I
 #undef SF_C
-#undef SF_CA
+}
+
+// Phase A and stages 1-3 in one piece (k_elem_q2hex_sf; the cluster kernel calls the two halves itself): R serves phase A's U / V first, then the e arrays.
+template <int SRC, bool REGC, bool INS = false>
+__device__ __forceinline__ void sf_element_blocks(const AsmParams& P, const SfTab& tab, const double* LCl, const int* LIl, const double (&rcA)[19], const double (&rcZ)[8],
+                                                  const double (&rcY)[16], const int esym, const int ens, const int ensT, const int eout, const double* xt, double* R,
+                                                  const int lane, double (&Kb)[3][3], double& fsrc, SfStamps* stp = nullptr) {
+  double Dr[7];            // D_q (six entries) and the source weight at this lane's Gauss point
+  const SfIdxA ia = {LIl[0], LIl[64], LIl[2 * 64], LIl[3 * 64], LIl[4 * 64]};
+  sf_phase_a<SRC, REGC, INS>(P, LCl, ia, rcA, xt, R, Dr, stp);
+  wave_lds_sync();
+  sf_stages<SRC, REGC, INS>(P, tab, LCl, LIl, rcZ, rcY, esym, ens, ensT, eout, R, lane, Dr, Kb, fsrc, stp);
 }
 
 template <int SRC, int NW, bool PAD>
@@ -1720,31 +1849,42 @@ constexpr int CL_T = CL_NE * 64;                 // threads
 constexpr int CL_SPT = 10;                       // slots (macro entries) per thread
 constexpr int CL_NS_MAX = CL_T * CL_SPT;         // 5120 >= 4913
 constexpr int CL_NM_MAX = 128;                   // macro nodes (125), padded
-constexpr int CL_NBLK = 64;                      // address blocks of entries with more than two contributions (49)
-constexpr int CL_ZC = SF_TAB + CL_NE * SF_WAVE;  // a zero cell (operand of absent contributions)
-// LDS behind the element kernel's regions: zero cell, descriptors (8 B per template entry), row destinations of the cluster (8 B), residual
-// destinations (4 B), address blocks (8 x 2 B) of the residual sums and of the long sums
-constexpr size_t CL_OFF_DT = (size_t)(CL_ZC + 2) * sizeof(double);
+constexpr int CL_NBLK = 128;                     // address blocks of the entries with more than two contributions (49 used; one per lane 16 .. 31 of the eight waves)
+// LDS of the cluster kernel (doubles): the per-lane tables it reads from LDS -- rows CL_LC0 .. SF_NLC - 1 of the constants (the others live in registers) and
+// the integer rows --, the eight wave regions (xt + R), phase A's U / V scratch of the waves that run phase A one cluster AHEAD (waves 4 .. 7: their R
+// still holds the staging of the current cluster then), a zero cell (operand of absent contributions)
+constexpr int CL_LC0 = 43;
+constexpr int CL_TAB = (SF_NLC - CL_LC0) * 64 + SF_NLI * 32;
+constexpr int CL_UVS = 6 * SF_US + 9 * SF_VS;    // 672 doubles per wave
+constexpr int CL_UV = CL_TAB + CL_NE * SF_WAVE;
+constexpr int CL_ZC = CL_UV + (CL_NE / 2) * CL_UVS;
+// behind them: the sums of the long entries (one cell each, written between the two barriers of the output phase), descriptors (8 B per template entry), row
+// destinations of the cluster (8 B), residual destinations (4 B), address blocks (8 x 2 B) of the residual sums and of the long sums
+constexpr int CL_LV = CL_ZC + 2;
+constexpr size_t CL_OFF_DT = (size_t)(CL_LV + CL_NBLK) * sizeof(double);
 constexpr size_t CL_OFF_RB = CL_OFF_DT + (size_t)CL_NS_MAX * 8;
 constexpr size_t CL_OFF_FB = CL_OFF_RB + (size_t)CL_NM_MAX * 8;
 constexpr size_t CL_OFF_FL = CL_OFF_FB + (size_t)CL_NM_MAX * 4;
 constexpr size_t CL_OFF_OV = CL_OFF_FL + (size_t)CL_NM_MAX * 16;
 constexpr size_t cl_lds_bytes() { return CL_OFF_OV + (size_t)CL_NBLK * 16; }
-static_assert((CL_ZC + 2) * 8 < (1 << 17), "cluster kernel: LDS byte addresses of the stagings fit 17 bits");
+static_assert((CL_LV + CL_NBLK) * 8 < (1 << 17), "cluster kernel: LDS byte addresses of the stagings and the long-sum cells fit 17 bits");
+static_assert(CL_ZC < (1 << 16), "cluster kernel: 16-bit double indices of the address blocks");
 static_assert(cl_lds_bytes() <= 160 * 1024, "cluster kernel: LDS budget");
+static_assert((CL_TAB % 2) == 0 && (CL_UVS % 2) == 0, "cluster kernel: 16-byte alignment of the wave regions");
 
 struct ClParams {
   int ncl, ns, nm;
-  const uint2* dtab;           // [ns] descriptor of template entry off[r] + j: x = LDS byte address of the first contribution, y = address of the
-                               //      second (or of the zero cell) | address block << 17 | (more than two contributions) << 28
+  const uint2* dtab;           // [ns] descriptor of template entry off[r] + j: x = LDS byte address of the first contribution, y = address of the second (or of
+                               //      the zero cell); an entry with more than two contributions: x = address of its long-sum cell, y = zero cell
   const uint4* fblk;           // [128] residual entry of macro row r: eight 16-bit double indices (zero cell for absent contributions)
-  const uint4* oblk;           // [CL_NBLK] contributions 3 .. 8 of the long sums, same format
+  const uint4* oblk;           // [CL_NBLK] ALL contributions of long entry k (its sum goes to cell CL_LV + k), same format
   const unsigned* sinfo;       // [CL_SPT][CL_T]: r | p << 7 | off[r] << 14 of slot tid + CL_T * i
   const unsigned long long* vdst;   // [ncl][128] address of the row's first entry (CSR array or partial-row buffer)
   const int* fdst;             // [ncl][128] >= 0: row of the residual vector, bit 31: offset into the partial-row buffer
   const uint4* map;            // [ncl][CL_T]: byte i = template entry of slot tid + CL_T * i inside its row
   double* Pbuf;
   double* res;
+  unsigned long long* stamps;  // instrumented build only (asm_debug bit 7): [workgroup][wave][16] summed phase cycles + [15] = clusters done
 };
 
 // t + eight contributions, added one after the other in ascending element order (the order of the two-pass row pass inside one cluster)
@@ -1758,13 +1898,13 @@ __device__ __forceinline__ double cl_sum8(const char* S, const uint4 a, double t
   return t;
 }
 
-template <int SRC>
+template <int SRC, bool INS = false, bool ROT = true>
 __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab tab, const double* __restrict__ lanec, const int* __restrict__ lanei, ClParams C) {
   constexpr int NC = 27, DIM = 3, KS = MF_KS, NW = CL_NE;
   constexpr bool REGC = true;
   extern __shared__ __attribute__((aligned(16))) double sf_smem[];
-  double* SFl = sf_smem;
-  int* SFi = reinterpret_cast<int*>(SFl + SF_NLC * 64);
+  double* SFl = sf_smem;                     // rows CL_LC0 .. of the per-lane constants
+  int* SFi = reinterpret_cast<int*>(SFl + (SF_NLC - CL_LC0) * 64);
   char* Sb = reinterpret_cast<char*>(sf_smem);
   uint2* dtab = reinterpret_cast<uint2*>(Sb + CL_OFF_DT);
   unsigned long long* rb = reinterpret_cast<unsigned long long*>(Sb + CL_OFF_RB);
@@ -1772,7 +1912,7 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
   uint4* fblk = reinterpret_cast<uint4*>(Sb + CL_OFF_FL);
   uint4* oblk = reinterpret_cast<uint4*>(Sb + CL_OFF_OV);
   const int tid = threadIdx.x;
-  for (int k = tid; k < SF_NLC * 64; k += CL_T) SFl[k] = lanec[k];
+  for (int k = tid; k < (SF_NLC - CL_LC0) * 64; k += CL_T) SFl[k] = lanec[CL_LC0 * 64 + k];
   for (int k = tid; k < SF_NLI * 64; k += CL_T) SFi[k] = lanei[k];
   for (int k = tid; k < C.ns; k += CL_T) dtab[k] = C.dtab[k];
   if (tid < CL_NM_MAX) fblk[tid] = C.fblk[tid];
@@ -1781,9 +1921,15 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
   __syncthreads();
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  double* xt = SFl + SF_TAB + wave * SF_WAVE;
+  // waves w and w + 4 share a SIMD (a workgroup's waves go round the four SIMDs).  Left alone, all eight waves run the same phase at the same time and the
+  // LDS-bound and the arithmetic-bound phases of an element take turns on the compute unit (measured with the phase stamps: LDS busy 54 %, vector ALU 33 %,
+  // together 87 % of the element time).  Waves 4 .. 7 therefore run phase A one cluster AHEAD -- after their staging is written, from a scratch region of
+  // their own -- so that on every SIMD one wave is in the short, latency-bound phase A while the other is in the long stages 2-3 (asm_debug bit 8: off)
+  const bool ahead = ROT && ((P.debug & 1024) ? wave >= CL_NE / 2 : wave < CL_NE / 2) && !(P.debug & 256);
+  double* xt = SFl + CL_TAB + wave * SF_WAVE;
   double* R = xt + SF_XT;
-  const double* LCl = SFl + lane;
+  double* UVa = ahead ? SFl + CL_UV + (wave & (CL_NE / 2 - 1)) * CL_UVS : R;
+  const double* LCl = SFl + lane - CL_LC0 * 64;       // row r of the constants at LCl[r * 64], r >= CL_LC0
   const int* LIl = SFi + lane;
   double rcA[19], rcZ[8], rcY[16];
 #pragma unroll
@@ -1792,13 +1938,20 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
   for (int r = 0; r < 8; r++) rcZ[r] = lanec[(19 + r) * 64 + lane];
 #pragma unroll
   for (int r = 0; r < 16; r++) rcY[r] = lanec[(27 + r) * 64 + lane];
-  const int esym = lanei[5 * 64 + lane], ens = lanei[6 * 64 + lane], ensT = lanei[15 * 64 + lane], based = lanei[7 * 64 + lane], basem = lanei[8 * 64 + lane];
-  const int eout = (lane >> 4) * SF_ES + (lane & 15);
-  const bool diag = lanei[9 * 64 + lane] != 0;
-  const int nodeofl = lanei[14 * 64 + lane];           // node of tensor index min(lane, 26)
-  unsigned sinfo[CL_SPT];
-#pragma unroll
-  for (int i = 0; i < CL_SPT; i++) sinfo[i] = C.sinfo[i * CL_T + tid];
+  // The per-lane integers of the element stages stay in registers, PACKED (the kernel runs at the 256-register limit of two waves per SIMD, and an LDS
+  // look-up each put a dependent round trip in front of every contraction): they are unpacked per cluster from values the compiler must treat as
+  // changing (cl_opaque), otherwise it would hoist the unpacked forms out of the loop again.
+  //   pk0 = esym | ens << 8 | ensT << 16 | nodeofl << 24 | diag << 29      (slot offsets inside the e arrays < 216; node of tensor index min(lane, 26))
+  //   pk1 = based | basem << 16                                           (staging offsets < 783)
+  //   pk2 = phase A's five indices, six bits each (xn <= 26, uo / ui < SF_US, vo / vi < SF_VS)
+  unsigned pk0 = (unsigned)lanei[5 * 64 + lane] | ((unsigned)lanei[6 * 64 + lane] << 8) | ((unsigned)lanei[15 * 64 + lane] << 16) | ((unsigned)lanei[14 * 64 + lane] << 24) |
+                 ((lanei[9 * 64 + lane] != 0 ? 1u : 0u) << 29);
+  unsigned pk1 = (unsigned)lanei[7 * 64 + lane] | ((unsigned)lanei[8 * 64 + lane] << 16);
+  unsigned pk2 = (unsigned)lanei[lane] | ((unsigned)lanei[64 + lane] << 6) | ((unsigned)lanei[2 * 64 + lane] << 12) | ((unsigned)lanei[3 * 64 + lane] << 18) |
+                 ((unsigned)lanei[4 * 64 + lane] << 24);
+#define CL_OPAQUE(x) asm volatile("" : "+v"(x))
+#define CL_IDXA() SfIdxA{(int)(pk2 & 63u), (int)((pk2 >> 6) & 63u), (int)((pk2 >> 12) & 63u), (int)((pk2 >> 18) & 63u), (int)(pk2 >> 24)}
+  const int nodeofl = (int)((pk0 >> 24) & 31u);
   const int cstride = gridDim.x;
   int cl = blockIdx.x;
   if (cl >= C.ncl) return;
@@ -1813,27 +1966,54 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
     }
   }
   int dof_n = P.elem_dof[(size_t)(min(cl + cstride, lastc) * NW + wave) * P.nloc + nodeofl];
-  const int tm = tid & (CL_NM_MAX - 1);
-  const int frow = wave * 16 + (lane & 15);          // residual entry this lane sums (lanes 0..15 of every wave)
   wave_lds_sync();
+  SfStamps st;
+  if (INS) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) st.acc[k] = 0;
+    st.prev = __builtin_amdgcn_s_memtime();
+  }
+  int ndone = 0;
+  double Dr[7];              // D_q and the source weight at this lane's Gauss point: phase A -> stage 1
+  if (ahead) {
+    sf_phase_a<SRC, REGC, INS>(P, LCl, CL_IDXA(), rcA, xt, UVa, Dr, &st);
+    wave_lds_sync();
+  }
 #pragma unroll 1
   for (; cl < C.ncl; cl += cstride) {
+    sf_stamp<INS>(st, 0);
+    CL_OPAQUE(pk0);
+    CL_OPAQUE(pk1);
+    CL_OPAQUE(pk2);
+    const int esym = (int)(pk0 & 255u), ens = (int)((pk0 >> 8) & 255u), ensT = (int)((pk0 >> 16) & 255u);
+    const int eout = (lane >> 4) * SF_ES + (lane & 15);
     // ---- prefetch (dependent gathers): coordinates / solution of the wave's next element, node ids of the one after ----
     const int cl_nn = min(cl + 2 * cstride, lastc);
     const double nx0 = P.coords[(size_t)dof_n * DIM], nx1 = P.coords[(size_t)dof_n * DIM + 1], nx2 = P.coords[(size_t)dof_n * DIM + 2];
     const double nu = P.sol ? P.sol[dof_n] : 0.0;
     const int dof_nn = P.elem_dof[(size_t)(cl_nn * NW + wave) * P.nloc + nodeofl];
-    // this cluster's destinations and maps: consumed after the element matrix, which hides the round trip
+    double Kb[3][3], fsrc;
+    if (!ahead) {
+      sf_phase_a<SRC, REGC, INS>(P, LCl, CL_IDXA(), rcA, xt, UVa, Dr, &st);
+      wave_lds_sync();
+    }
+    sf_stages<SRC, REGC, INS>(P, tab, LCl, LIl, rcZ, rcY, esym, ens, ensT, eout, R, lane, Dr, Kb, fsrc, &st);
+    wave_lds_sync();          // every lane is done with e: reuse it as the staging Ks[27][29], rows AND columns in tensor order
+    sf_stamp<INS>(st, 6);
+    // this cluster's destinations and maps, and the thread's slot table (the same for every cluster: an L1 / L2 hit): issued only now, behind the stages
+    // that need every register, and consumed after the workgroup barrier -- the staging, the residual and the wait at the barrier hide the round trip
+    const int tm = tid & (CL_NM_MAX - 1);
     const unsigned long long vd_cur = C.vdst[(size_t)cl * CL_NM_MAX + tm];
     const int fd_cur = C.fdst[(size_t)cl * CL_NM_MAX + tm];
     const uint4 mp_cur = C.map[(size_t)cl * CL_T + tid];
-    double Kb[3][3], fsrc;
-    sf_element_blocks<SRC, REGC>(P, tab, LCl, LIl, rcA, rcZ, rcY, esym, ens, ensT, eout, xt, R, lane, Kb, fsrc);
-    wave_lds_sync();          // every lane is done with e: reuse it as the staging Ks[27][29], rows AND columns in tensor order
+    unsigned sinfo[CL_SPT];
+#pragma unroll
+    for (int i = 0; i < CL_SPT; i++) sinfo[i] = C.sinfo[i * CL_T + tid];
     double* Ks = R;
     {
-      double* kd = Ks + based;       // p * KS + p2
-      double* km = Ks + basem;       // p2 * KS + p
+      const bool diag = ((pk0 >> 29) & 1u) != 0;
+      double* kd = Ks + (pk1 & 0xffffu);       // p * KS + p2
+      double* km = Ks + (pk1 >> 16);           // p2 * KS + p
 #pragma unroll
       for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -1844,6 +2024,7 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
         }
     }
     wave_lds_sync();
+    sf_stamp<INS>(st, 7);
     double ku = 0.0;
     if (P.sol) {              // residual: (K_e u)_t for tensor row t = lane & 31, half of the columns each
       const int h = lane >> 5;
@@ -1868,12 +2049,21 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
       rb[tid] = vd_cur;
       fb[tid] = fd_cur;
     }
+    sf_stamp<INS>(st, 8);
+    // the address block of this lane's sum of eight in the output phase (a table: read ahead of the barrier, one LDS round trip less behind it)
+    const int frow = wave * 16 + (lane & 15);
+    uint4 sumblk = (lane & 16) ? oblk[frow] : fblk[frow];
+    if (ahead) {              // phase A of the wave's NEXT element (its nodes are in xt now; behind the last cluster: the clamped element again, unused)
+      wave_lds_sync();
+      sf_phase_a<SRC, REGC, INS>(P, LCl, CL_IDXA(), rcA, xt, UVa, Dr, &st);
+    }
     __syncthreads();
+    sf_stamp<INS>(st, 9);
     if (!(P.debug & 2)) {
       const unsigned mw[4] = {mp_cur.x, mp_cur.y, mp_cur.z, mp_cur.w};
-      // in stages, every stage's LDS reads independent of each other (two waves per SIMD hide little latency): descriptors and row
-      // destinations, then both operands of every entry (the zero cell for entries of one element), the rare longer sums, the stores.
-      // The phase is bound by vector-instruction issue: descriptors hold LDS BYTE addresses, destinations are whole addresses.
+      // in stages, every stage's LDS reads independent of each other (two waves per SIMD hide little latency): descriptors and row destinations; the
+      // residual entries and the 49 entries with four or eight contributions (one sum of eight per lane, lanes 0 .. 15 / 16 .. 31 of every wave; the long
+      // sums go to their cells); a second barrier; both operands of every entry (the zero cell for entries of one element, the cell for a long one); stores.
       uint2 dd[CL_SPT];
       unsigned long long vb[CL_SPT];
 #pragma unroll
@@ -1883,22 +2073,30 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
         dd[i] = dtab[(si >> 14) + j];
         vb[i] = rb[si & 127];
       }
+      {
+        const double v = cl_sum8(Sb, sumblk, 0.0);
+        const int fv = fb[frow];
+        double* dst = fv < 0 ? C.Pbuf + (size_t)(fv & 0x7fffffff) : C.res + (size_t)fv;
+        if (lane < 16) *dst = v;
+        else if (lane < 32) sf_smem[CL_LV + frow] = v;
+      }
+      if (INS) {
+        asm volatile("" ::"v"(dd[CL_SPT - 1].x), "v"(vb[CL_SPT - 1]));
+        sf_stamp<INS>(st, 12);
+      }
+      __syncthreads();
+      sf_stamp<INS>(st, 14);
       double vv[CL_SPT], ww[CL_SPT];
-      unsigned anyx = 0;
 #pragma unroll
       for (int i = 0; i < CL_SPT; i++) {
-        anyx |= dd[i].y;
         vv[i] = *reinterpret_cast<const double*>(Sb + dd[i].x);
-        ww[i] = *reinterpret_cast<const double*>(Sb + (dd[i].y & 0x1ffffu));
+        ww[i] = *reinterpret_cast<const double*>(Sb + dd[i].y);
       }
 #pragma unroll
       for (int i = 0; i < CL_SPT; i++) vv[i] += ww[i];
-      if (__any((anyx >> 28) != 0)) {       // 49 of the 4913 entries have four or eight contributions: all of them read at once
-#pragma unroll
-        for (int i = 0; i < CL_SPT; i++)
-          if (__any((dd[i].y >> 28) != 0)) {
-            if (dd[i].y >> 28) vv[i] = cl_sum8(Sb, oblk[(dd[i].y >> 17) & 0x7ffu], vv[i]);
-          }
+      if (INS) {
+        asm volatile("" ::"v"(vv[CL_SPT - 1]), "v"(vv[0]));
+        sf_stamp<INS>(st, 13);
       }
 #pragma unroll
       for (int i = 0; i < CL_SPT; i++) {
@@ -1907,15 +2105,19 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
         else if (!(P.debug & 4)) __builtin_nontemporal_store(vv[i], dst);
         else if (vv[i] == 1.2345e300) *dst = vv[i];      // timing aid (bit 2): the LDS work without the stores
       }
-      {                                     // residual entries: rows 16 w .. 16 w + 15 on the first lanes of wave w
-        const double v = cl_sum8(Sb, fblk[frow], 0.0);
-        const int fv = fb[frow];
-        double* dst = fv < 0 ? C.Pbuf + (size_t)(fv & 0x7fffffff) : C.res + (size_t)fv;
-        if (lane < 16) *dst = v;
-      }
+      sf_stamp<INS>(st, 15);
     }
+    sf_stamp<INS>(st, 10);
     __syncthreads();          // the stagings are the next elements' scratch, rb / fb the next cluster's
+    sf_stamp<INS>(st, 11);
     dof_n = dof_nn;
+    ndone++;
+  }
+  if (INS && C.stamps && lane == 0) {
+    unsigned long long* o = C.stamps + ((size_t)blockIdx.x * NW + wave) * 20;
+#pragma unroll
+    for (int k = 0; k < 16; k++) o[k] = st.acc[k];
+    o[16] = (unsigned long long)ndone;
   }
 }
 
@@ -2189,16 +2391,17 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
   U4 zblk;
   for (int q = 0; q < 8; q++) zblk.a[q] = (unsigned short)CL_ZC;
   std::vector<U4> fblk(CL_NM_MAX, zblk), oblk;
-  auto stag = [&](int e, int tr, int tc) { return (unsigned)(SF_TAB + e * SF_WAVE + SF_XT + tr * KS + tc); };      // double index into the workgroup's LDS
+  auto stag = [&](int e, int tr, int tc) { return (unsigned)(CL_TAB + e * SF_WAVE + SF_XT + tr * KS + tc); };      // double index into the workgroup's LDS
   auto pack = [&](const std::vector<unsigned>& ad, U2* out) -> bool {
     if (ad.empty() || ad.size() > 8) return false;
     out->x = ad[0] * 8;
     out->y = (ad.size() > 1 ? ad[1] : (unsigned)CL_ZC) * 8;
-    if (ad.size() > 2) {
+    if (ad.size() > 2) {          // summed ahead of the slots, all contributions in ascending element order, into its own cell
       if ((int)oblk.size() >= CL_NBLK) return false;
       U4 b = zblk;
-      for (size_t q = 2; q < ad.size(); q++) b.a[q - 2] = (unsigned short)ad[q];
-      out->y |= ((unsigned)oblk.size() << 17) | (1u << 28);
+      for (size_t q = 0; q < ad.size(); q++) b.a[q] = (unsigned short)ad[q];
+      out->x = (unsigned)(CL_LV + (int)oblk.size()) * 8;
+      out->y = (unsigned)CL_ZC * 8;
       oblk.push_back(b);
     }
     return true;
@@ -2339,6 +2542,51 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
   return 0;
 }
 
+// Instrumented launch (asm_debug bit 7, constant source only): the same kernel with the shader clock read at twelve phase boundaries; prints the
+// average cycles per cluster and phase over all waves.  A development aid -- the stamps cost about a tenth of the wave cycles themselves.
+static int launch_cluster_stamped(fh_assembler_t as, const AsmParams& P, const ClParams& C0, int grid) {
+  constexpr size_t lds = cl_lds_bytes();
+  static bool attr_set[64] = {};
+  const int dev = as->ctx->device & 63;
+  if (!attr_set[dev]) {
+    FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster_q2hex_sf<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set[dev] = true;
+  }
+  ClParams C = C0;
+  const size_t nst = (size_t)grid * CL_NE * 20;
+  FH_CHECK_HIP(hipMalloc(&C.stamps, nst * sizeof(unsigned long long)));
+  FH_CHECK_HIP(hipMemsetAsync(C.stamps, 0, nst * sizeof(unsigned long long), as->ctx->stream));
+  hipLaunchKernelGGL((k_cluster_q2hex_sf<0, true>), dim3(grid), dim3(CL_T), lds, as->ctx->stream, P, as->sf_tab, as->d_sfLc, as->d_sfLi, C);
+  FH_CHECK_HIP(hipGetLastError());
+  std::vector<unsigned long long> h(nst);
+  FH_CHECK_HIP(hipMemcpyAsync(h.data(), C.stamps, nst * sizeof(unsigned long long), hipMemcpyDeviceToHost, as->ctx->stream));
+  FH_CHECK_HIP(hipStreamSynchronize(as->ctx->stream));
+  FH_CHECK_HIP(hipFree(C.stamps));
+  // order of the rows = order of the phases in the loop body of a wave that runs phase A in place (waves 0 .. 3)
+  static const int order[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 14, 13, 15, 10, 11};
+  static const char* name[16] = {"loop top (previous barrier exit -> stamp)", "phase A: U (gather x, first contraction, sync)", "phase A: V (second contraction, sync)",
+                                 "phase A: J, cofactors, division, D_q", "stage 1 (15 MFMA, writes, sync)", "source 2nd contraction + stages 2-3 (4 x 16 reads + 66 FMA)",
+                                 "source 3rd contraction, sync", "destination loads issued, staging writes (18), sync", "residual K_e u, next nodes, destinations",
+                                 "workgroup barrier 1 (waiting for the slowest wave)", "(end of the output phase)", "workgroup barrier 2",
+                                 "output: descriptors + destinations read, residual entries and long sums", "output: both operands read, added", "output: barrier behind the long sums", "output: stores issued"};
+  for (int half = 0; half < 2; half++) {
+    double sum[16] = {0}, ncl = 0, tot = 0;
+    for (size_t w = 0; w < (size_t)grid * CL_NE; w++) {
+      if ((int)((w % CL_NE) / (CL_NE / 2)) != half) continue;
+      for (int k = 0; k < 16; k++) sum[k] += (double)h[w * 20 + k];
+      ncl += (double)h[w * 20 + 16];
+    }
+    for (int k = 0; k < 16; k++) tot += sum[k];
+    fprintf(stderr, "k_cluster_q2hex_sf<0> phase stamps, waves %d..%d (%s): %d workgroups, %.0f wave-clusters, %.0f shader-clock ticks per cluster and wave\n", half * 4, half * 4 + 3,
+            half && !(P.debug & 256) ? "phase A one cluster ahead, i.e. rows 1-3 run behind row 8" : "phase A in place", grid, ncl, tot / std::max(ncl, 1.0));
+    for (int kk = 0; kk < 16; kk++) {
+      const int k = order[kk];
+      fprintf(stderr, "  %2d %-62s %9.1f  %5.1f %%\n", k, name[k], sum[k] / std::max(ncl, 1.0), 100.0 * sum[k] / std::max(tot, 1.0));
+    }
+  }
+  return 0;
+}
+
 template <int SRC>
 static int launch_cluster_one(fh_assembler_t as, const AsmParams& P, const ClParams& C) {
   constexpr size_t lds = cl_lds_bytes();
@@ -2349,6 +2597,7 @@ static int launch_cluster_one(fh_assembler_t as, const AsmParams& P, const ClPar
     attr_set[dev] = true;
   }
   const int grid = std::max(1, std::min(C.ncl, as->ctx->num_cu * as->ctx->assemble_sf_grid));
+  if (SRC == 0 && (as->ctx->asm_debug & 128)) return launch_cluster_stamped(as, P, C, grid);     // dev aid: phase cycles of every wave on stderr
   hipLaunchKernelGGL((k_cluster_q2hex_sf<SRC>), dim3(grid), dim3(CL_T), lds, as->ctx->stream, P, as->sf_tab, as->d_sfLc, as->d_sfLi, C);
   FH_CHECK_HIP(hipGetLastError());
   return 0;
@@ -2375,6 +2624,7 @@ static int launch_cluster(fh_assembler_t as, const AsmParams& P, fh_mat_t A, dou
   C.sinfo = as->d_cl_sinfo;
   C.vdst = as->d_cl_vdst64; C.fdst = as->d_cl_fdst; C.map = reinterpret_cast<const uint4*>(as->d_cl_map);
   C.Pbuf = as->d_Pbuf; C.res = res;
+  C.stamps = nullptr;
   if (P.source_kind == 4) FH_TRY(launch_cluster_one<2>(as, P, C));
   else if (P.source_kind != 0) FH_TRY(launch_cluster_one<1>(as, P, C));
   else FH_TRY(launch_cluster_one<0>(as, P, C));
