@@ -512,10 +512,14 @@ def solve_report(ctx, comm, pb):
         return pb.solve(rtol=1e-10)
 
     whole()                                          # warm: Krylov workspace, graph
+    ctx.marker(9)                                    # phase markers: profiles/summarize.py cuts a kernel trace of this command at them
     t_all, (its, rnorm) = timed(whole)
+    ctx.marker(10)
     t_asm, _ = timed(pb.assemble)
     t_prep, _ = timed(pb.prepare)
+    ctx.marker(11)
     t_kry, (its2, _) = timed(lambda: pb.solve(rtol=1e-10))
+    ctx.marker(12)
     return {"solve_ms": t_all, "assemble_ms": t_asm, "prepare_ms": t_prep, "krylov_ms": t_kry, "gmres_iterations": int(its),
             "final_residual": float(rnorm), "rtol": 1e-10,
             "what": "one MGsolve of the reference (LinearImplicitSystem.cpp:288-411): fine-level assembly, numeric Galerkin chain + SetPenalty + "

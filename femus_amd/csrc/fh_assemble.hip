@@ -48,6 +48,7 @@ struct fh_assembler_s {
   // element-wise Galerkin product from the next finer level (fh_assembler_galerkin): children, child interpolation tables, Dirichlet masks
   int* d_gal_child = nullptr;
   uint64_t gal_key = 0;          // hash of (children, fine / coarse Dirichlet nodes) the tables below were made from
+  bool gal_children_in_order = false;      // child j of coarse element E is fine element 8 * (its cluster) + j
   unsigned char *d_gal_cnt = nullptr, *d_gal_row = nullptr, *d_gal_fb = nullptr, *d_gal_cb = nullptr;
   double *d_gal_val = nullptr, *d_gal_res = nullptr, *d_gal_dense = nullptr;
   int kstride = 27;              // doubles per element row in d_Kbuf (nc, or 32 for HEX27/Q2: whole 64-byte lines per row)
@@ -67,6 +68,9 @@ struct fh_assembler_s {
   unsigned long long* d_cl_vdst64 = nullptr;           // ... as addresses, for the value array cl_val_base
   double* cl_val_base = nullptr;
   unsigned char *d_cl_map = nullptr, *d_cl_pmap = nullptr;
+  unsigned short* d_cl_gtab = nullptr;      // [8][27 * 27] template entry that child j OWNS at (local row, local column), 0xffff = another child's (fh_assembler_galerkin from the macro rows)
+  bool cl_all_rows = false;                 // every row of every cluster lies in the matrix (no ghost rows, no sink): the macro rows can be read back
+  bool macro_valid = false;                 // the matrix cl_val_base and the partial-row buffer hold the macro rows of the last assembly
   double* d_Pbuf = nullptr;
   int* d_cl_prow = nullptr;                 // rows of the second pass
   unsigned* d_cl_pstart = nullptr;          // [nprow + 1] their segments of the partial-row buffer
@@ -2502,6 +2506,23 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
   FH_TRY(up((void**)&as->d_cl_dtab, dtab.data(), dtab.size() * sizeof(U2)));
   FH_TRY(up((void**)&as->d_cl_fblk, fblk.data(), fblk.size() * sizeof(U4)));
   FH_TRY(up((void**)&as->d_cl_oblk, oblk.data(), oblk.size() * sizeof(U4)));
+  {   // for the Galerkin product from the macro rows: which template entry child e owns at (local row, local column) -- an entry met by several elements of
+      // the cluster belongs to the first of them, so that the eight pseudo child matrices add up to the macro matrix
+    std::vector<unsigned short> gtab((size_t)CL_NE * 27 * 27, (unsigned short)0xffff);
+    for (int e = 0; e < CL_NE; e++)
+      for (int il = 0; il < 27; il++)
+        for (int ic = 0; ic < 27; ic++) {
+          const int r = tm[e][T.tof[il]], k = tm[e][T.tof[ic]];
+          int owner = -1;
+          for (int e2 = 0; e2 < CL_NE && owner < 0; e2++)
+            if (tof_e[e2][r] >= 0 && tof_e[e2][k] >= 0) owner = e2;
+          if (owner != e) continue;
+          for (int idx = roff[r]; idx < roff[r + 1]; idx++)
+            if (tcol[idx] == k) gtab[((size_t)e * 27 + il) * 27 + ic] = (unsigned short)idx;
+        }
+    FH_TRY(up((void**)&as->d_cl_gtab, gtab.data(), gtab.size() * sizeof(unsigned short)));
+    as->cl_all_rows = (m == as->nnode);
+  }
   FH_CHECK_HIP(hipMalloc(&as->d_cl_vdst64, (size_t)ncl * CL_NM_MAX * sizeof(unsigned long long)));
   FH_TRY(up((void**)&as->d_cl_sinfo, sinfo.data(), sinfo.size() * 4));
   FH_TRY(up((void**)&as->d_cl_prow, prow.data(), prow.size() * 4));
@@ -3268,7 +3289,7 @@ extern "C" int fh_assembler_destroy(fh_assembler_t as) {
   if (as->d_prog) hipFree(as->d_prog);
   if (as->d_prog_consts) hipFree(as->d_prog_consts);
   hipFree(as->d_iota);
-  for (void* q : {(void*)as->d_cl_dtab, (void*)as->d_cl_fblk, (void*)as->d_cl_sinfo, (void*)as->d_cl_oblk, (void*)as->d_cl_vdst, (void*)as->d_cl_vdst64, (void*)as->d_cl_fdst, (void*)as->d_cl_map, (void*)as->d_cl_pmap,
+  for (void* q : {(void*)as->d_cl_dtab, (void*)as->d_cl_fblk, (void*)as->d_cl_sinfo, (void*)as->d_cl_oblk, (void*)as->d_cl_gtab, (void*)as->d_cl_vdst, (void*)as->d_cl_vdst64, (void*)as->d_cl_fdst, (void*)as->d_cl_map, (void*)as->d_cl_pmap,
                   (void*)as->d_Pbuf, (void*)as->d_cl_prow, (void*)as->d_cl_pstart})
     if (q) hipFree(q);
   for (void* q : {(void*)as->d_adj_ptr, (void*)as->d_adj_ei, (void*)as->d_rowmap, (void*)as->d_Kbuf, (void*)as->d_Fbuf, (void*)as->d_slot, (void*)as->d_gal_child,
@@ -3346,14 +3367,17 @@ static int assemble_poisson_core(fh_assembler_t as, fh_vec_t sol, int source_kin
     // assemble_fused 1 (default): the fused path, unless the element rows of the PREVIOUS assembly were asked for by the element-wise Galerkin product
     // (a solve that re-prepares after every assembly: the two-pass path leaves the rows in place, re-creating them would cost 0.66 ms at 64^3);
     // 2: always fused; 0: never
+    // (rows_used_since is only raised when the product could NOT be made from the macro rows the fused path leaves behind: fh_assembler_galerkin)
     const bool keep_rows = as->ctx->assemble_fused == 1 && as->rows_used_since;
     as->rows_used_since = false;
+    as->macro_valid = false;
     if (as->fused && as->ctx->assemble_fused && !keep_rows && as->ctx->assemble_sf && !(as->ctx->assemble_affine && as->d_Mab && as->n_aff > 0) && !(as->ctx->asm_debug & 16)) {
       as->last_path = 1;
       // fused cluster assembly: complete rows straight into the CSR arrays, the others through the partial-row buffer (the element-row buffer is not written)
       as->kbuf_valid = false;
       FH_TRY(launch_cluster(as, P, A, res->d));
       A->at_valid = false;
+      as->macro_valid = !(as->ctx->asm_debug & (2 | 4 | 8));     // (timing aids leave rows unwritten)
       return 0;
     }
     as->kbuf_valid = true;
@@ -3728,6 +3752,205 @@ static size_t galerkin_mfma_lds() {
   return ((size_t)NCH * KP * MT * 16 + GAL_NW * ws) * sizeof(double);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Element-wise Galerkin product FROM THE MACRO ROWS of a fused assembly (round 5).  The fused path keeps no element rows; what it leaves behind per cluster
+// (= per coarse element) is the 125 x 125 macro matrix K_m = sum_j S_j^T K_j S_j: complete rows in the CSR array, the others as packed rows in the
+// partial-row buffer, 4913 entries at the addresses the cluster kernel stored them to.  With C (125 x 27) the interpolation from the coarse element,
+// K_E = C^T K_m C = sum_j C_j^T K~_j C_j for ANY split of the macro entries over the children (K~_j = the entries child j owns: an entry met by several
+// children belongs to the first, table gtab).  One workgroup of eight waves per coarse element: all threads read the 4913 entries back (the loads of the
+// NEXT cluster fly during the products) into a template-ordered LDS array, wave j forms K~_j from it and runs the two 32 x 32 x 28 products of
+// k_galerkin_mfma on the matrix cores, the eight results are added in child order and leave as coarse element rows.  39 kB read per coarse element instead
+// of 55 kB, and the fused assembly stays the path of every assembly of a solve (LinearImplicitSystem.cpp:288-411: assemble -> Galerkin -> solve, every time).
+// Between the assembly and this product only Dirichlet ROWS of the fine matrix may have been replaced (SetPenalty): they are masked here anyway.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int GMAC_NW = 8, GMAC_T = GMAC_NW * 64;
+constexpr int GMAC_KP = 28, GMAC_LD = 32, GMAC_KLD = 29;
+constexpr int GMAC_WS = 32 * GMAC_KLD;                                  // scratch per wave: K~_j [32][29], then T [28][32], then the wave's result [27][28]
+constexpr int GMAC_TN = 4928;                                           // template entries (4913), padded
+constexpr size_t gmac_lds_bytes() { return ((size_t)GMAC_NW * GMAC_KP * GMAC_LD + GMAC_TN + (size_t)GMAC_NW * GMAC_WS) * sizeof(double) + CL_NM_MAX * sizeof(unsigned long long) + 32 * sizeof(int); }
+static_assert(gmac_lds_bytes() <= 160 * 1024, "k_galerkin_macro: LDS budget");
+static_assert(GMAC_WS >= GMAC_KP * GMAC_LD && GMAC_WS >= 27 * 28, "k_galerkin_macro: the wave scratch holds T and the result");
+
+__global__ __launch_bounds__(GMAC_T) void k_galerkin_macro(int nelc, const int* __restrict__ child, int nm, const unsigned* __restrict__ sinfo, const uint4* __restrict__ map,
+                                                           const unsigned long long* __restrict__ vdst, const unsigned short* __restrict__ gtab,
+                                                           const int* __restrict__ edof_f, int nloc_f, const unsigned char* __restrict__ fb,
+                                                           const int* __restrict__ slot_c, double* __restrict__ Kc, int ks_c, const int* __restrict__ edof_c, int nloc_c,
+                                                           const unsigned char* __restrict__ cb, const double* __restrict__ Cdense /* [8][27][27] */) {
+  constexpr int NC = 27, NCH = 8, NE = NC * NC, NT = (NE + 63) / 64, MT = 2, KP = GMAC_KP, CLD = GMAC_LD, KLD = GMAC_KLD, TLD = GMAC_LD;
+  extern __shared__ __attribute__((aligned(16))) double gmac_smem[];
+  double* Cs = gmac_smem;                                 // [NCH][KP][CLD], zero padded
+  double* Tm = Cs + NCH * KP * CLD;                       // the macro matrix in template order
+  double* scr = Tm + GMAC_TN;
+  unsigned long long* rbl = reinterpret_cast<unsigned long long*>(scr + GMAC_NW * GMAC_WS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int k = tid; k < NCH * KP * CLD; k += GMAC_T) {
+    const int j = k / (KP * CLD), r = (k / CLD) % KP, c = k % CLD;
+    Cs[k] = (r < NC && c < NC) ? Cdense[(j * NC + r) * NC + c] : 0.0;
+  }
+  unsigned si[CL_SPT];
+#pragma unroll
+  for (int i = 0; i < CL_SPT; i++) si[i] = sinfo[i * CL_T + tid];
+  unsigned short gt[NT];                                   // the template entries this lane fetches for its wave's child (loop invariant)
+#pragma unroll
+  for (int t = 0; t < NT; t++) gt[t] = gtab[(size_t)wave * NE + min(lane + 64 * t, NE - 1)];
+  double* Ks = scr + wave * GMAC_WS;
+  double* Ts = Ks;
+  const int kk = lane >> 4, li = lane & 15;
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int stride = gridDim.x;
+  int E = blockIdx.x;
+  if (E >= nelc) return;
+  // pipeline: values of cluster n in registers (tv), map / destinations of cluster n + 1 in registers (mp, vd)
+  const int tm = tid & (CL_NM_MAX - 1);
+  int cl = child[(size_t)E * NCH] >> 3;
+  if (tid < CL_NM_MAX) rbl[tid] = vdst[(size_t)cl * CL_NM_MAX + tm];
+  uint4 mp = map[(size_t)cl * CL_T + tid];
+  __syncthreads();
+  double tv[CL_SPT];
+#pragma unroll
+  for (int i = 0; i < CL_SPT; i++) {
+    const int r = si[i] & 127, p = (si[i] >> 7) & 127;
+    tv[i] = r < nm ? reinterpret_cast<const double*>(rbl[r])[p] : 0.0;
+  }
+  int En = min(E + stride, nelc - 1);
+  int cln = child[(size_t)En * NCH] >> 3;
+  unsigned long long vdn = vdst[(size_t)cln * CL_NM_MAX + tm];
+  uint4 mpn = map[(size_t)cln * CL_T + tid];
+  int* slds = reinterpret_cast<int*>(rbl + CL_NM_MAX);        // slots of the coarse element's 27 rows
+  const int ln = min(lane, NC - 1);
+  bool dn, dc;
+  int slc;
+  {
+    const int ej = child[(size_t)E * NCH + wave];
+    dn = fb[edof_f[(size_t)ej * nloc_f + ln]] != 0;
+    dc = cb[edof_c[(size_t)E * nloc_c + ln]] != 0;
+    slc = slot_c[(size_t)E * NC + ln];
+  }
+#pragma unroll 1
+  for (; E < nelc; E += stride) {
+    // (dn, dc, slc: Dirichlet flags of the child's and of the coarse element's nodes and the row slots of THIS element -- chains of dependent look-ups,
+    // fetched one element ahead, under the products of the previous one)
+    // ---- the macro matrix of this cluster into LDS (template order); destinations of the next cluster into rbl ----
+    {
+      const unsigned mw[4] = {mp.x, mp.y, mp.z, mp.w};
+#pragma unroll
+      for (int i = 0; i < CL_SPT; i++) {
+        const int r = si[i] & 127, j = (mw[i >> 2] >> (8 * (i & 3))) & 255;
+        if (r < nm) Tm[(si[i] >> 14) + j] = tv[i];
+      }
+    }
+    __syncthreads();                       // (also: every wave is done with rbl of this cluster -- its loads were issued one iteration ago and have landed in tv)
+    if (tid < CL_NM_MAX) rbl[tid] = vdn;
+    if (tid < NC) slds[tid] = slc;
+    __syncthreads();
+    // the NEXT cluster's values: in flight during the products below
+    mp = mpn;
+#pragma unroll
+    for (int i = 0; i < CL_SPT; i++) {
+      const int r = si[i] & 127, p = (si[i] >> 7) & 127;
+      tv[i] = r < nm ? reinterpret_cast<const double*>(rbl[r])[p] : 0.0;
+    }
+    {
+      const int Enn = min(E + 2 * stride, nelc - 1);
+      const int clnn = child[(size_t)Enn * NCH] >> 3;
+      vdn = vdst[(size_t)clnn * CL_NM_MAX + tm];
+      mpn = map[(size_t)clnn * CL_T + tid];
+    }
+    // ---- wave j: K~_j (Dirichlet rows / columns zeroed), T = K~_j C_j, R_j = C_j^T T ----
+    const unsigned long long cdead = __ballot(dc && lane < NC);
+    const unsigned long long dead = __ballot(dn && lane < NC);
+    {   // the next element's look-ups
+      const int En1 = min(E + stride, nelc - 1);
+      const int ejn = child[(size_t)En1 * NCH + wave];
+      dn = fb[edof_f[(size_t)ejn * nloc_f + ln]] != 0;
+      dc = cb[edof_c[(size_t)En1 * nloc_c + ln]] != 0;
+      slc = slot_c[(size_t)En1 * NC + ln];
+    }
+    {
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const int idx = lane + 64 * t;
+        const int ic = min(idx, NE - 1);
+        const int i = ic / NC, c = ic - i * NC;
+        const bool d = (((dead >> i) | (dead >> c)) & 1ull) || gt[t] == 0xffff;
+        const double v = Tm[min((int)gt[t], GMAC_TN - 1)];
+        if (idx < NE) Ks[i * KLD + c] = d ? 0.0 : v;
+      }
+      for (int q = lane; q < (MT * 16 - NC) * KLD; q += 64) Ks[NC * KLD + q] = 0.0;
+      for (int q = lane; q < NC * (KLD - NC); q += 64) Ks[(q / (KLD - NC)) * KLD + NC + q % (KLD - NC)] = 0.0;
+      wave_lds_sync();
+      const double* Cj = Cs + wave * KP * CLD;
+      d4 T[MT][MT], KE[MT][MT];
+#pragma unroll
+      for (int a = 0; a < MT; a++)
+#pragma unroll
+        for (int b = 0; b < MT; b++) { T[a][b] = d4{0.0, 0.0, 0.0, 0.0}; KE[a][b] = d4{0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll
+      for (int k0 = 0; k0 < KP; k0 += 4) {
+        double av[MT], bv[MT];
+#pragma unroll
+        for (int x = 0; x < MT; x++) {
+          av[x] = Ks[(x * 16 + li) * KLD + k0 + kk];
+          bv[x] = Cj[(k0 + kk) * CLD + x * 16 + li];
+        }
+#pragma unroll
+        for (int a = 0; a < MT; a++)
+#pragma unroll
+          for (int b = 0; b < MT; b++) T[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], T[a][b], 0, 0, 0);
+      }
+      wave_lds_sync();                       // every lane has read its operands of K~_j: T may take the region
+#pragma unroll
+      for (int a = 0; a < MT; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = a * 16 + kk + 4 * r;
+          if (i < KP) {
+#pragma unroll
+            for (int b = 0; b < MT; b++) Ts[i * TLD + b * 16 + li] = T[a][b][r];
+          }
+        }
+      wave_lds_sync();
+#pragma unroll
+      for (int k0 = 0; k0 < KP; k0 += 4) {
+        double av[MT], bv[MT];
+#pragma unroll
+        for (int x = 0; x < MT; x++) {
+          av[x] = Cj[(k0 + kk) * CLD + x * 16 + li];        // A[row a][k i] = C_j[i][a]
+          bv[x] = Ts[(k0 + kk) * TLD + x * 16 + li];
+        }
+#pragma unroll
+        for (int a = 0; a < MT; a++)
+#pragma unroll
+          for (int b = 0; b < MT; b++) KE[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], KE[a][b], 0, 0, 0);
+      }
+      wave_lds_sync();                       // T has been consumed: the wave's result [27][28] takes the region
+#pragma unroll
+      for (int a = 0; a < MT; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int ra = a * 16 + kk + 4 * r;
+#pragma unroll
+          for (int b = 0; b < MT; b++) {
+            const int k = b * 16 + li;
+            if (ra < NC && k < NC) Ks[ra * 28 + k] = KE[a][b][r];
+          }
+        }
+    }
+    __syncthreads();
+    // ---- the eight results added in child order; rows / columns of coarse Dirichlet nodes are zero; rows without a slot are not stored ----
+    for (int idx = tid; idx < NE; idx += GMAC_T) {
+      const int i = idx / NC, k = idx - i * NC;
+      double v = scr[i * 28 + k];
+#pragma unroll
+      for (int w = 1; w < GMAC_NW; w++) v += scr[w * GMAC_WS + i * 28 + k];
+      const int s = slds[i];
+      const bool d = ((cdead >> i) | (cdead >> k)) & 1ull;
+      if (s >= 0) Kc[(size_t)s * ks_c + k] = d ? 0.0 : v;
+    }
+    __syncthreads();                       // scratch and Tm are the next cluster's
+  }
+}
+
 // element rows of the last assembly into the element-row buffer (pass 1 of the two-pass path alone)
 static int element_rows_again(fh_assembler_t as) {
   FH_REQUIRE(as->two_pass && as->d_Kbuf, "fh_assembler_galerkin: the fine assembler holds no element rows");
@@ -3757,8 +3980,6 @@ extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, con
   FH_REQUIRE(fas->nel == cas->nel * nch, "fh_assembler_galerkin: %d fine elements are not the uniform refinement of %d coarse ones", fas->nel, cas->nel);
   FH_REQUIRE(Ac->m == cas->ndof, "fh_assembler_galerkin: the coarse matrix does not belong to the coarse assembler");
   fh_ctx_t c = cas->ctx;
-  fas->rows_used_since = true;                              // (the next assembly of this level keeps its element rows)
-  if (!fas->kbuf_valid) FH_TRY(element_rows_again(fas));     // the fused assembly keeps no element rows: pass 1 of the two-pass path with the last arguments
   auto up = [&](void** d, const void* h, size_t bytes) -> int {
     if (*d) FH_CHECK_HIP(hipFree(*d));
     FH_CHECK_HIP(hipMalloc(d, bytes ? bytes : 8));
@@ -3817,9 +4038,32 @@ extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, con
     FH_TRY(up((void**)&cas->d_gal_fb, fb.data(), fb.size()));
     FH_TRY(up((void**)&cas->d_gal_cb, cb.data(), cb.size()));
     if (!cas->d_gal_res) FH_CHECK_HIP(hipMalloc(&cas->d_gal_res, std::max<size_t>(cas->ndof, 1) * sizeof(double)));
+    // the macro rows of a fused assembly can stand in for the element rows when child j of coarse element E is element j of ONE cluster (what the
+    // refinement's numbering gives: MeshRefinement.cpp:240-294)
+    cas->gal_children_in_order = nch == CL_NE;
+    for (int E = 0; E < cas->nel && cas->gal_children_in_order; E++)
+      for (int j = 0; j < nch; j++)
+        if (child[(size_t)E * nch + j] != (child[(size_t)E * nch] / nch) * nch + j || child[(size_t)E * nch] % nch) { cas->gal_children_in_order = false; break; }
+  }
+  // source of the fine element contributions: the macro rows the fused assembly left in the fine matrix and the partial-row buffer (nothing to re-create,
+  // the fused path stays the path of the next assembly), or the element-row buffer of the two-pass path
+  const bool from_macro = nc == 27 && c->galerkin_mfma && c->galerkin_macro && fas->fused && fas->last_path == 1 && fas->macro_valid && fas->cl_all_rows &&
+                          fas->d_cl_gtab && cas->gal_children_in_order && fas->cl_ncl == cas->nel;
+  if (!from_macro) {
+    fas->rows_used_since = true;                              // (the next assembly of this level keeps its element rows)
+    if (!fas->kbuf_valid) FH_TRY(element_rows_again(fas));     // the fused assembly kept no element rows: pass 1 of the two-pass path with the last arguments
   }
   const int grid = std::max(1, std::min(fh_div_up(cas->nel, 4), c->num_cu * 2));
-  if (c->galerkin_mfma) {
+  if (from_macro) {
+    static bool attr_set_m[64] = {};
+    if (!attr_set_m[c->device & 63]) {
+      FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_galerkin_macro), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gmac_lds_bytes()));
+      attr_set_m[c->device & 63] = true;
+    }
+    hipLaunchKernelGGL(k_galerkin_macro, dim3(std::max(1, std::min(cas->nel, c->num_cu))), dim3(GMAC_T), gmac_lds_bytes(), c->stream, cas->nel, cas->d_gal_child, fas->cl_nm,
+                       fas->d_cl_sinfo, reinterpret_cast<const uint4*>(fas->d_cl_map), fas->d_cl_vdst64, fas->d_cl_gtab, fas->d_elem_dof, fas->nloc, cas->d_gal_fb, cas->d_slot,
+                       cas->d_Kbuf, cas->kstride, cas->d_elem_dof, cas->nloc, cas->d_gal_cb, cas->d_gal_dense);
+  } else if (c->galerkin_mfma) {
     const size_t lds = nc == 27 ? galerkin_mfma_lds<27, 8>() : galerkin_mfma_lds<9, 4>();
     static bool attr_set[64] = {};
     if (!attr_set[c->device & 63]) {

@@ -119,6 +119,9 @@ struct fh_mg_s {
   int kv_n = 0;
   double** d_V = nullptr;     // device copy of the basis pointers (GMRES), kept with kv
   int d_V_n = 0;
+  double* d_gm = nullptr;     // state block of the device-resident GMRES (gm_state_doubles(restart)); h_gm = pinned mirror of its header
+  double* h_gm = nullptr;
+  size_t gm_cap = 0;
   int64_t cycle_bytes = 0;
 };
 
@@ -1366,6 +1369,120 @@ __global__ __launch_bounds__(256) void k_multiaxpy(double* __restrict__ w, const
 __global__ __launch_bounds__(256) void k_axpby2(double* y, const double* x, double a, double b, int n) {   // x may alias y
   // BLAS semantics: with b == 0 the old y is NOT referenced (it may be uninitialised memory: 0 * NaN = NaN)
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];
+}
+
+// ---- device-resident GMRES (the default outer solver): the Hessenberg column, the Givens rotations, the residual estimate and the convergence test live in
+// a small state block on the device; the host reads {done, rn} back ONCE per iteration (one synchronisation instead of two, no arithmetic on the host) ----
+// state layout (doubles): [0] reference norm beta0  [1] rtol  [2] atol  [3] dtol  [4] rn  [5] scale of the next basis vector (1 / h_{k+1,k}, or 1 / beta)
+//                         [6] iterations done  [7] done flag  [8] maxit  [9] kused  [10] last norm  [11] restart   [16 ..] g, cs, sn, y, H (row-major, restart columns)
+constexpr int GM_HDR = 16;
+__device__ __forceinline__ double* gm_g(double* S) { return S + GM_HDR; }
+__device__ __forceinline__ double* gm_cs(double* S, int m) { return S + GM_HDR + (m + 1); }
+__device__ __forceinline__ double* gm_sn(double* S, int m) { return S + GM_HDR + (m + 1) + m; }
+__device__ __forceinline__ double* gm_y(double* S, int m) { return S + GM_HDR + (m + 1) + 2 * m; }
+__device__ __forceinline__ double* gm_H(double* S, int m) { return S + GM_HDR + (m + 1) + 3 * m; }
+static size_t gm_state_doubles(int m) { return (size_t)GM_HDR + (m + 1) + 3 * (size_t)m + (size_t)(m + 1) * m; }
+
+// squared norm, partial sums per block
+__global__ __launch_bounds__(256) void k_sqnorm_part(const double* __restrict__ w, int n, double* __restrict__ part) {
+  __shared__ double sm[4];
+  double acc = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) acc += w[i] * w[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+__global__ __launch_bounds__(256) void k_sum_part(const double* __restrict__ part, int nb, double* __restrict__ out) {
+  __shared__ double sm[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) acc += part[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+// y = s[0] * x (s on the device)
+__global__ __launch_bounds__(256) void k_scale_dev(double* __restrict__ y, const double* __restrict__ x, const double* __restrict__ s, int n) {
+  const double a = s[0];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) y[i] = a * x[i];
+}
+// Knoll guess done: beta0 = ||M^-1 b|| (sq = its square, summed over the ranks)
+__global__ void k_gm_begin(double* __restrict__ S, const double* __restrict__ sq, double rtol, double atol, double dtol, int maxit, int restart) {
+  S[0] = sqrt(sq[0]);
+  S[1] = rtol; S[2] = atol; S[3] = dtol;
+  S[4] = 0.0; S[5] = 0.0; S[6] = 0.0; S[7] = 0.0;
+  S[8] = (double)maxit; S[9] = 0.0; S[10] = 0.0; S[11] = (double)restart;
+}
+// start of a restart cycle: beta = ||v0|| (sq = its square); converged / diverged / out of iterations -> done, otherwise g = beta e_0 and the scale 1 / beta
+__global__ void k_gm_restart(double* __restrict__ S, const double* __restrict__ sq) {
+  const int m = (int)S[11];
+  const double beta = sqrt(sq[0]);
+  S[4] = beta;
+  S[10] = beta;
+  S[9] = 0.0;
+  double* g = gm_g(S);
+  for (int i = 0; i <= m; i++) g[i] = 0.0;
+  g[0] = beta;
+  const bool stop = beta <= fmax(S[1] * S[0], S[2]) || S[6] >= S[8] || beta > S[3] * S[0];
+  S[7] = stop ? 1.0 : 0.0;
+  S[5] = (stop || beta == 0.0) ? 0.0 : 1.0 / beta;
+}
+// iteration k: h[0..k] = V^T w (before the orthogonalisation), wsq = ||w||^2 after it -> column k of the Hessenberg matrix, rotations, residual estimate,
+// convergence test; at the end of a restart cycle (converged or k == restart - 1) the back substitution y = H^-1 g as well.  The statements follow the
+// host loop of the flexible variant below one for one (same operations in the same order).
+__global__ void k_gm_step(double* __restrict__ S, const double* __restrict__ h, const double* __restrict__ wsq, int k) {
+  const int m = (int)S[11];
+  double* g = gm_g(S);
+  double* cs = gm_cs(S, m);
+  double* sn = gm_sn(S, m);
+  double* y = gm_y(S, m);
+  double* H = gm_H(S, m);
+  const double wn = sqrt(wsq[0]);
+  for (int j = 0; j <= k; j++) H[(size_t)j * m + k] = h[j];
+  H[(size_t)(k + 1) * m + k] = wn;
+  S[10] = wn;
+  S[5] = wn != 0.0 ? 1.0 / wn : 0.0;
+  for (int j = 0; j < k; j++) {
+    const double a = H[(size_t)j * m + k], bb = H[(size_t)(j + 1) * m + k];
+    H[(size_t)j * m + k] = cs[j] * a + sn[j] * bb;
+    H[(size_t)(j + 1) * m + k] = -sn[j] * a + cs[j] * bb;
+  }
+  const double a = H[(size_t)k * m + k], bb = H[(size_t)(k + 1) * m + k];
+  const double d = hypot(a, bb);
+  bool done = false;
+  if (d == 0.0) {          // column k of the Hessenberg matrix vanished entirely: nothing to rotate, nothing more to gain
+    cs[k] = 1.0;
+    sn[k] = 0.0;
+    H[(size_t)k * m + k] = 1.0;
+    g[k + 1] = 0.0;
+    S[6] += 1.0;
+    S[4] = 0.0;
+    done = true;
+  } else {
+    cs[k] = a / d;
+    sn[k] = bb / d;
+    H[(size_t)k * m + k] = d;
+    H[(size_t)(k + 1) * m + k] = 0.0;
+    g[k + 1] = -sn[k] * g[k];
+    g[k] = cs[k] * g[k];
+    S[6] += 1.0;
+    const double rn = fabs(g[k + 1]);
+    S[4] = rn;
+    done = rn <= fmax(S[1] * S[0], S[2]) || S[6] >= S[8] || wn == 0.0 || rn > S[3] * S[0];
+  }
+  const int kused = k + 1;
+  S[9] = (double)kused;
+  S[7] = done ? 1.0 : 0.0;
+  if (done || k == m - 1) {
+    for (int i = kused - 1; i >= 0; i--) {
+      double s2 = g[i];
+      for (int j = i + 1; j < kused; j++) s2 -= H[(size_t)i * m + j] * y[j];
+      y[i] = s2 / H[(size_t)i * m + i];
+    }
+  }
 }
 
 static inline int sgrid(fh_ctx_t c, int n) { return std::max(1, std::min(fh_div_up(n, 256), c->num_cu * 8)); }
@@ -3176,6 +3293,8 @@ extern "C" int fh_mg_destroy(fh_mg_t mg) {
   for (hipEvent_t ev : mg->nd_events) hipEventDestroy(ev);
   for (double* p : mg->kv) hipFree(p);
   if (mg->d_V) hipFree(mg->d_V);
+  if (mg->d_gm) hipFree(mg->d_gm);
+  if (mg->h_gm) hipHostFree(mg->h_gm);
   delete mg;
   return 0;
 }
@@ -3383,8 +3502,95 @@ extern "C" int fh_mg_solve(fh_mg_t mg, fh_vec_t bv, fh_vec_t xv, int outer, doub
       hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, x, (const double* const*)d_Z, c->d_red, 1.0, kused, n);
       FH_CHECK_HIP(hipStreamSynchronize(c->stream));
     }
+  } else if (c->gmres_device) {
+    // left-preconditioned GMRES(restart), classical Gram-Schmidt, Knoll guess x0 = M^-1 b (LinearEquationSolverPetsc.cpp:294-335), device-resident: the
+    // Hessenberg matrix, the rotations, the residual estimate and the convergence test stay on the device (k_gm_*); per iteration the host enqueues
+    // [A v, cycle, V^T w, w -= V h, ||w||^2, k_gm_step, v_{k+1} = w / h_{k+1,k}] and reads {done, rn, iterations} back once.  Same arithmetic in the same
+    // order as the host-driven form below (option gmres_device 0), which it replaces as the default.
+    FH_REQUIRE(restart >= 1 && restart <= 200, "fh_mg_solve: restart %d out of range", restart);
+    FH_TRY(krylov_reserve(mg, restart + 3, ncols));
+    double* t = mg->lv[mg->nlevels - 1].b;
+    const int nb = sgrid(c, n);
+    FH_TRY(fh_reserve_reduction(c, (size_t)(restart + 2) * (nb + 1) + nb + 64));
+    if (mg->d_V_n < restart + 1) {
+      if (mg->d_V) FH_CHECK_HIP(hipFree(mg->d_V));
+      mg->d_V = nullptr;
+      mg->d_V_n = 0;
+      FH_CHECK_HIP(hipMalloc(&mg->d_V, (restart + 1) * sizeof(double*)));
+      mg->d_V_n = restart + 1;
+    }
+    double** d_V = mg->d_V;
+    FH_CHECK_HIP(hipMemcpyAsync(d_V, mg->kv.data(), (restart + 1) * sizeof(double*), hipMemcpyHostToDevice, c->stream));
+    if (mg->gm_cap < gm_state_doubles(restart)) {
+      if (mg->d_gm) FH_CHECK_HIP(hipFree(mg->d_gm));
+      mg->d_gm = nullptr;
+      mg->gm_cap = 0;
+      FH_CHECK_HIP(hipMalloc(&mg->d_gm, gm_state_doubles(restart) * sizeof(double)));
+      mg->gm_cap = gm_state_doubles(restart);
+    }
+    if (!mg->h_gm) FH_CHECK_HIP(hipHostMalloc(&mg->h_gm, GM_HDR * sizeof(double)));
+    double* S = mg->d_gm;
+    // scratch inside the reduction buffer: partial sums [0, (restart + 1) * nb), the projections h behind them, then the partials of ||w||^2 and its sum
+    double* hcol_of_k = nullptr;
+    double* sqp = c->d_red + (size_t)(restart + 2) * (nb + 1);
+    double* sq1 = sqp + nb;
+    auto sqnorm = [&](const double* v) -> int {          // sq1[0] = ||v||^2 over all ranks
+      hipLaunchKernelGGL(k_sqnorm_part, dim3(nb), dim3(256), 0, c->stream, v, n, sqp);
+      hipLaunchKernelGGL(k_sum_part, dim3(1), dim3(256), 0, c->stream, sqp, nb, sq1);
+      if (HL) FH_TRY(fh_halo_allreduce_ptr(HL, sq1, 1));
+      return 0;
+    };
+    auto readback = [&]() -> int {
+      FH_CHECK_HIP(hipMemcpyAsync(mg->h_gm, S, GM_HDR * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+      return 0;
+    };
+    // Knoll: x0 = M^-1 b ; reference norm = ||M^-1 b||
+    FH_TRY(apply_cycle(mg, b, x));
+    FH_TRY(sqnorm(x));
+    hipLaunchKernelGGL(k_gm_begin, dim3(1), dim3(1), 0, c->stream, S, sq1, rtol, atol, dtol, maxit, restart);
+    bool done = false;
+    while (!done) {
+      FH_TRY(spmv(x, t, 2, b));                                // t = b - A x
+      FH_TRY(apply_cycle(mg, t, mg->kv[0]));                  // v0 = M^-1 t
+      FH_TRY(sqnorm(mg->kv[0]));
+      hipLaunchKernelGGL(k_gm_restart, dim3(1), dim3(1), 0, c->stream, S, sq1);
+      hipLaunchKernelGGL(k_scale_dev, dim3(nb), dim3(256), 0, c->stream, mg->kv[0], mg->kv[0], S + 5, n);
+      FH_CHECK_HIP(hipGetLastError());
+      FH_TRY(readback());
+      rn = mg->h_gm[4];
+      if (mg->h_gm[7] != 0.0) break;
+      int kused = 0;
+      for (int k = 0; k < restart; k++) {
+        FH_TRY(spmv(mg->kv[k], t, 0, nullptr));
+        FH_TRY(apply_cycle(mg, t, nullptr));
+        double* w = mg->lv[mg->nlevels - 1].x;                // (an un-captured cycle alternates between its two buffers)
+        // h = V^T w (one pass), w -= V h, h_{k+1,k} = ||w||
+        hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, c->stream, (const double* const*)d_V, w, k + 1, n, c->d_red);
+        hipLaunchKernelGGL(k_multidot_final, dim3(k + 1), dim3(256), 0, c->stream, c->d_red, k + 1, nb);
+        hcol_of_k = c->d_red + (size_t)(k + 1) * nb;
+        if (HL) FH_TRY(fh_halo_allreduce_ptr(HL, hcol_of_k, k + 1));
+        hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, w, (const double* const*)d_V, hcol_of_k, -1.0, k + 1, n);
+        FH_TRY(sqnorm(w));
+        hipLaunchKernelGGL(k_gm_step, dim3(1), dim3(1), 0, c->stream, S, hcol_of_k, sq1, k);
+        // v_{k+1} = w / h_{k+1,k} (zero on a happy breakdown: the scale is 0 then); never used when the test above said stop
+        hipLaunchKernelGGL(k_scale_dev, dim3(nb), dim3(256), 0, c->stream, mg->kv[k + 1], w, S + 5, n);
+        FH_CHECK_HIP(hipGetLastError());
+        FH_TRY(readback());
+        its = (int)mg->h_gm[6];
+        rn = mg->h_gm[4];
+        kused = k + 1;
+        if (mg->h_gm[7] != 0.0) {
+          done = true;
+          break;
+        }
+      }
+      // x += V y (y from the back substitution inside the last k_gm_step)
+      hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, c->stream, x, (const double* const*)d_V, S + GM_HDR + (restart + 1) + 2 * restart, 1.0, kused, n);
+      FH_CHECK_HIP(hipGetLastError());
+    }
   } else {
-    // left-preconditioned GMRES(restart), classical Gram-Schmidt, Knoll guess x0 = M^-1 b
+    // the same solver driven from the host (option gmres_device 0): two synchronisations per iteration, the small dense algebra on the host
     FH_REQUIRE(restart >= 1 && restart <= 200, "fh_mg_solve: restart %d out of range", restart);
     FH_TRY(krylov_reserve(mg, restart + 3, ncols));
     // t = the cycle's own right-hand-side buffer (the products A v land where the cycle reads them), w = wherever the cycle leaves its result

@@ -141,39 +141,49 @@ def test_fused_assembly_with_rows_outside_the_matrix_and_another_value_array(ctx
 
 
 def test_elementwise_galerkin_after_a_fused_assembly(ctx):
-    """the fused path keeps no element rows: the element-wise Galerkin product re-creates them (pass 1 of the two-pass path with the last
-    arguments) and gives the same coarse operator as after a two-pass assembly"""
+    """the fused path keeps no element rows: the element-wise Galerkin product is made from the MACRO rows it left behind (complete rows in the matrix,
+    the others in the partial-row buffer: k_galerkin_macro) and gives the same coarse operators as after a two-pass assembly -- also after SetPenalty has
+    replaced the Dirichlet rows of the fine matrix, and with option galerkin_macro 0 (the element rows re-created by pass 1 of the two-pass path)"""
     from femus_amd.poisson import PoissonMG
     vals = {}
-    for fused in (1, 0):
+    for fused, macro in ((1, 1), (1, 0), (0, 1)):
         ctx.set_option("assemble_fused", fused)
+        ctx.set_option("galerkin_macro", macro)
         try:
             pb = PoissonMG(ctx, 2, 2, 2, 3).init()
             assert pb.asm[-1].fused_info()["active"] == bool(fused)
             pb.assemble()
             pb.prepare()
-            vals[fused] = [pb.A[l].to_scipy() for l in range(pb.nlevels)]
+            vals[(fused, macro)] = [pb.A[l].to_scipy() for l in range(pb.nlevels)]
+            pb.prepare()                                  # again, from the fine matrix whose Dirichlet rows SetPenalty has replaced meanwhile
+            for a, b in zip([pb.A[l].to_scipy() for l in range(pb.nlevels)], vals[(fused, macro)]):
+                assert abs(a - b).max() == 0.0
             pb.destroy()
         finally:
             ctx.set_option("assemble_fused", 1)
-    for a, b in zip(vals[1], vals[0]):
-        assert abs(a - b).max() <= 1e-13 * abs(b).max()
-    # assemble_fused = 1 picks per assembly: two-pass when the Galerkin product used the element rows of the previous assembly, fused otherwise;
-    # 2 = always fused (the product re-creates the rows every time); the operators are the same on every route
-    for mode in (1, 2):
+            ctx.set_option("galerkin_macro", 1)
+    for key in ((1, 1), (1, 0)):
+        for a, b in zip(vals[key], vals[(0, 1)]):
+            assert abs(a - b).max() <= 1e-13 * abs(b).max()
+    # the path of an assembler does not change inside a run: with the macro rows serving the product, assemble_fused 1 (default) and 2 stay fused through
+    # assemble -> prepare -> assemble (the flow of every MGsolve, LinearImplicitSystem.cpp:288-411); only with galerkin_macro 0 does mode 1 fall back to
+    # the two-pass path after a product has asked for the element rows
+    for mode, macro in ((1, 1), (2, 1), (1, 0), (2, 0)):
         ctx.set_option("assemble_fused", mode)
+        ctx.set_option("galerkin_macro", macro)
         try:
             pb = PoissonMG(ctx, 2, 2, 2, 3).init()
             pb.assemble()
             assert pb.asm[-1].last_path() == "fused"
             pb.prepare()
             pb.assemble()
-            assert pb.asm[-1].last_path() == ("two-pass" if mode == 1 else "fused")
+            assert pb.asm[-1].last_path() == ("two-pass" if (mode, macro) == (1, 0) else "fused")
             pb.assemble()
             assert pb.asm[-1].last_path() == "fused"            # nobody asked for the rows in between
             pb.prepare()
-            for a, b in zip([pb.A[l].to_scipy() for l in range(pb.nlevels)], vals[0]):
+            for a, b in zip([pb.A[l].to_scipy() for l in range(pb.nlevels)], vals[(0, 1)]):
                 assert abs(a - b).max() <= 1e-13 * abs(b).max()
             pb.destroy()
         finally:
             ctx.set_option("assemble_fused", 1)
+            ctx.set_option("galerkin_macro", 1)
