@@ -862,7 +862,8 @@ class Assembler:
 
 
 class Direct:
-    """sparse exact solve of a symmetric operator (fh_direct_*: multifrontal factorisation over a nested-dissection tree)"""
+    """sparse exact solve (fh_direct_*: multifrontal factorisation over a nested-dissection tree; symmetric operators on unpivoted fronts, unsymmetric /
+    indefinite ones on pivoted fronts)"""
 
     def __init__(self, ctx, A, coords=None, leaf=0):
         self.ctx, self.L, self.A = ctx, ctx.L, A
@@ -880,6 +881,16 @@ class Direct:
 
     def solve(self, b, x):
         _chk(self.L.fh_direct_solve(self.h, b.h, x.h))
+
+    def set_general(self, on=True):
+        """force the pivoted (general) fronts also for a symmetric operator"""
+        _chk(self.L.fh_direct_set_general(self.h, 1 if on else 0))
+        return self
+
+    def stats(self):
+        g, p, r = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _chk(self.L.fh_direct_stats(self.h, ctypes.byref(g), ctypes.byref(p), ctypes.byref(r)))
+        return {"general": bool(g.value), "perturbed_pivots": p.value, "refinement_steps": r.value}
 
     def info(self):
         a, f, h, lf = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

@@ -23,6 +23,7 @@ int fh_halo_update_ptr(fh_halo_t h, double* vd, int n_owned);
 int fh_halo_end_ptr(fh_halo_t h);
 int fh_halo_allreduce_ptr(fh_halo_t h, double* d, int n);
 int fh_direct_solve_ptr(fh_direct_t d, const double* b, double* x);
+uint64_t fh_direct_generation(fh_direct_t d);      // changes whenever the object re-analysed its operator (new device buffers, new launch shapes)
 
 struct MgLevel {
   fh_mat_t A = nullptr, P = nullptr, R = nullptr;
@@ -1619,6 +1620,7 @@ static uint64_t cycle_signature(fh_mg_t mg) {
   mix((uint64_t)mg->na);
   mix((uint64_t)mg->direct0_active);
   mixp(mg->direct0);
+  mix(fh_direct_generation(mg->direct0));     // a re-analysed sparse solve frees and reallocates every buffer the captured launches refer to
   mixp(mg->d_act);
   for (int l = 0; l < mg->nlevels; l++) {
     MgLevel& L = mg->lv[l];
@@ -1634,6 +1636,8 @@ static uint64_t cycle_signature(fh_mg_t mg) {
     mix((uint64_t)L.n);
     mix((uint64_t)L.ncols);
     for (double* p : {L.dinv, L.x, L.x2, L.b, L.r}) mixp(p);
+    mixp(L.direct);
+    mix(fh_direct_generation(L.direct));
     mixp(L.tri);
     mixp(L.d_color_rows);
     mix((uint64_t)L.ncolors);
@@ -2569,8 +2573,8 @@ static int coarse_factor(fh_mg_t mg) {
   }
   mg->na = n;
   if (n == 0) return 0;
-  // more coupled unknowns than the dense inverse is meant for (or asked for): the sparse exact solve -- symmetric operators; anything it refuses
-  // goes on to the dense path and its own limits
+  // more coupled unknowns than the dense inverse is meant for (or asked for): the sparse exact solve -- symmetric operators on its unpivoted fronts,
+  // unsymmetric / indefinite ones on pivoted fronts (round 5); only a singular operator is refused and goes on to the dense path and its own limits
   mg->direct0_active = false;
   if (c->coarse_direct == 2 || (c->coarse_direct == 1 && n > c->coarse_direct_min)) {
     if (!mg->direct0 || mg->direct0_uid != L0.A->uid) {
@@ -2593,8 +2597,8 @@ static int coarse_factor(fh_mg_t mg) {
       if (mg->nd_active) return 0;
     }
   }
-  FH_REQUIRE(n <= 16384, "coarse level has %d coupled unknowns: the dense direct solve supports at most 16384 (the sparse exact solve, option coarse_direct, serves symmetric operators of any size: %s)", n,
-             c->coarse_direct ? "it refused this operator" : "it is switched off");
+  FH_REQUIRE(n <= 16384, "coarse level has %d coupled unknowns: the dense direct solve supports at most 16384 (the sparse exact solve, option coarse_direct, serves operators of any size: %s)", n,
+             c->coarse_direct ? "it refused this operator as singular" : "it is switched off");
   if (mg->ainv_n != n) {      // a repeated preparation of the same hierarchy keeps its buffers (the 193 MB allocation cost 5-10 ms)
     if (mg->d_ainv) FH_CHECK_HIP(hipFree(mg->d_ainv));
     if (mg->d_gjwork) FH_CHECK_HIP(hipFree(mg->d_gjwork));

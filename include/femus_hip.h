@@ -426,7 +426,11 @@ enum { FH_LEVEL_RICHARDSON = 0, FH_LEVEL_GMRES = 1 };
 int fh_mg_set_level_solver(fh_mg_t mg, int level, int solver, int restart);
 /* Sparse exact solve (the reference's MUMPS / PCLU through PETSc: coarsest level LinearEquationSolverPetsc.hpp:131-138, `Solve(vars, ksp_clean)`,
  * MLU_PRECOND / LU_PRECOND as level preconditioner PetscPreconditioner.cpp:147-160): multifrontal factorisation over a nested-dissection tree
- * (fh_direct.hip), SYMMETRIC operators of any size.  coords ([n * dim], dim 1..3) let the dissection cut at coordinate layers (for Q2 unknowns:
+ * (fh_direct.hip), operators of any size: symmetric ones on unpivoted symmetric fronts, UNSYMMETRIC or INDEFINITE ones (Navier-Stokes Jacobians, saddle
+ * points with an empty diagonal block) on general fronts with partial pivoting inside the front and static perturbation of pivots that stay tiny -- what
+ * MUMPS does for the reference -- followed by two steps of iterative refinement per solve when a pivot was perturbed.  The path is chosen by an
+ * entry-by-entry symmetry test at every factorisation; fh_direct_set_general(d, 1) forces the pivoted path, fh_direct_stats reports which one ran and how
+ * many pivots were perturbed.  coords ([n * dim], dim 1..3) let the dissection cut at coordinate layers (for Q2 unknowns:
  * planes of nodes at element boundaries); dim = 0 / coords = NULL: breadth-first level sets of the matrix graph.  leaf <= 0: 256 unknowns per
  * leaf.  fh_direct_factor reads the CURRENT values of A (symbolic work is redone only when the set of coupled unknowns or the matrix changed);
  * unknowns coupled to nothing (penalised Dirichlet rows) are solved by their diagonal.  fh_direct_solve: x = A^-1 b (b != x). */
@@ -435,6 +439,8 @@ int fh_direct_create(fh_ctx_t ctx, fh_mat_t A, int dim, const double* coords, in
 int fh_direct_factor(fh_direct_t d);
 int fh_direct_solve(fh_direct_t d, fh_vec_t b, fh_vec_t x);
 int fh_direct_info(fh_direct_t d, int* coupled, int* fronts, int* height, int* largest_front, int64_t* factor_doubles);
+int fh_direct_set_general(fh_direct_t d, int on);
+int fh_direct_stats(fh_direct_t d, int* general_fronts, int* perturbed_pivots, int* refinement_steps);
 int fh_direct_destroy(fh_direct_t d);
 /* PCMGSetType (`MgSmootherType` of MGInit, LinearEquationSolverPetsc.cpp:199-214), one application of the preconditioner to b:
  * FH_CYCLE_MULTIPLICATIVE  V-cycle: pre-smooth, restrict the residual, recurse, interpolate-add, post-smooth (default)

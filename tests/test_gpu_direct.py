@@ -107,15 +107,22 @@ def test_sparse_exact_solve_beyond_the_dense_limit(ctx):
     M.destroy()
 
 
-def test_unsymmetric_and_singular_operators_are_refused(ctx):
+def test_unsymmetric_operator_is_served_and_singular_one_refused(ctx):
+    """an unsymmetric perturbation of a Poisson operator goes to the pivoted fronts (round 4 refused it); a decoupled unknown with a zero diagonal is still
+    an error"""
     A, xy, bdc = poisson_operator((2, 2, 2), 1)
     U = A.copy().tolil()
     free = np.setdiff1d(np.arange(A.shape[0]), bdc)
     U[free[0], free[1]] = U[free[0], free[1]] + 0.5
-    M = ctx.matrix_scipy(U.tocsr())
-    d = capi.Direct(ctx, M, xy)
-    with pytest.raises(capi.FemusHipError, match="not symmetric"):
-        d.factor()
+    U = U.tocsr()
+    M = ctx.matrix_scipy(U)
+    d = capi.Direct(ctx, M, xy).factor()
+    assert d.stats()["general"]
+    rhs = np.random.default_rng(3).uniform(-1, 1, U.shape[0])
+    b, x = ctx.vector_from(rhs), ctx.vector(U.shape[0])
+    d.solve(b, x)
+    ref = spla.splu(U.tocsc()).solve(rhs)
+    assert np.linalg.norm(x.to_numpy() - ref) <= 1e-12 * np.linalg.norm(ref)
     d.destroy()
     M.destroy()
     Z = A.copy().tocsr()
@@ -127,6 +134,147 @@ def test_unsymmetric_and_singular_operators_are_refused(ctx):
         d.factor()
     d.destroy()
     M.destroy()
+
+
+def _random_unsymmetric(n, per_row, seed, diag=0.3):
+    """random sparse matrix, unsymmetric in pattern and values, NOT diagonally dominant (diagonal entries of the size of the others, both signs), on top
+    of a banded part that keeps it comfortably non-singular"""
+    rng = np.random.default_rng(seed)
+    rows = np.repeat(np.arange(n), per_row)
+    cols = (rows + rng.integers(-40, 41, rows.size)) % n
+    R = sp.coo_matrix((rng.uniform(-1, 1, rows.size), (rows, cols)), shape=(n, n)).tocsr()
+    B = sp.diags([rng.uniform(0.5, 1.5, n - 1), rng.uniform(-1.5, -0.5, n - 1)], [1, -1], shape=(n, n))
+    A = (R + 2.0 * B + sp.diags(diag * rng.choice([-1.0, 1.0], n))).tocsr()
+    A.sum_duplicates()
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("n,per_row,leaf", [(300, 4, 0), (3000, 5, 96), (12000, 4, 0)])
+def test_random_unsymmetric_matrix_matches_scipy(ctx, n, per_row, leaf):
+    """threshold pivoting inside the fronts: a random unsymmetric, diagonally NON-dominant operator (what MUMPS serves for the reference:
+    PetscPreconditioner.cpp:147-160) against scipy's sparse LU, 1e-10; new values on the same pattern re-use the symbolic analysis"""
+    A = _random_unsymmetric(n, per_row, 7)
+    lu = spla.splu(A.tocsc())
+    offdiag = np.asarray(abs(A).sum(axis=1)).ravel() - abs(A.diagonal())
+    assert (abs(A.diagonal()) < offdiag).mean() > 0.9                      # not diagonally dominant
+    M = ctx.matrix_scipy(A)
+    d = capi.Direct(ctx, M, None, leaf).factor()
+    st = d.stats()
+    assert st["general"] and d.info()["coupled"] == n
+    rng = np.random.default_rng(5)
+    for rep in range(2):
+        rhs = rng.uniform(-1, 1, n)
+        b, x = ctx.vector_from(rhs), ctx.vector(n)
+        d.solve(b, x)
+        ref = lu.solve(rhs)
+        assert np.linalg.norm(x.to_numpy() - ref) <= 1e-10 * np.linalg.norm(ref), st
+    A2 = A.copy()
+    A2.data *= 1.0 + 0.05 * np.sin(np.arange(A2.nnz))
+    M.set_values(A2.data)
+    d.factor()
+    rhs = rng.uniform(-1, 1, n)
+    b, x = ctx.vector_from(rhs), ctx.vector(n)
+    d.solve(b, x)
+    xg = x.to_numpy()
+    ref = spla.splu(A2.tocsc()).solve(rhs)
+    # (the perturbed operator may be worse conditioned than the first one: residual to 1e-11, solution to 1e-9)
+    assert np.linalg.norm(A2 @ xg - rhs) <= 1e-11 * np.linalg.norm(rhs) * max(1.0, np.linalg.norm(xg, np.inf)) and np.linalg.norm(xg - ref) <= 1e-9 * np.linalg.norm(ref)
+    d.destroy()
+    M.destroy()
+
+
+def _ns_jacobian(nx, ny, nu=0.01, seed=1):
+    """Taylor-Hood Newton Jacobian of the lid-driven cavity at a non-trivial state, Dirichlet rows penalised (one pressure unknown pinned): an unsymmetric
+    saddle point with an EMPTY pressure block -- every exact solve of 003_NavierStokes is of this kind"""
+    from oracle import femus_oracle_ns as ns
+    ms, lays = ns.build_ns_levels(nx, ny, 0, 1, (-0.5, -0.5, 0.0), (0.5, 0.5, 0.0))
+    m, lay = ms[0], lays[0]
+    bc = ns.cavity_bc(m, lay)
+    rng = np.random.default_rng(seed)
+    u = 0.3 * rng.standard_normal(lay.n)
+    A, b = ns.assemble_ns(m, lay, u, nu)
+    A = fo.zero_rows(A.tocsr(), bc[0], 1.0).tocsr()
+    A.sort_indices()
+    xy = np.concatenate([m.coords[:sz, :2] for sz in lay.sizes])          # coordinates of the stacked unknowns [U | V | P]
+    return A, xy, lay
+
+
+@pytest.mark.parametrize("nx,with_coords", [(6, True), (40, True), (40, False)])
+def test_navier_stokes_jacobian_matches_scipy(ctx, nx, with_coords):
+    """the verdict's case: the Taylor-Hood Jacobian of a 40 x 40 level (14 803 unknowns, zero pressure diagonal) through the pivoted fronts, against
+    scipy's sparse LU to 1e-10, with and without coordinates"""
+    A, xy, lay = _ns_jacobian(nx, nx)
+    n = A.shape[0]
+    assert abs(A - A.T).max() > 1e-3 and (A.diagonal()[lay.offset[2]:] == 0.0).sum() > 0.9 * lay.sizes[2]
+    M = ctx.matrix_scipy(A)
+    d = capi.Direct(ctx, M, xy if with_coords else None).factor()
+    assert d.stats()["general"]
+    lu = spla.splu(A.tocsc())
+    rhs = np.random.default_rng(11).uniform(-1, 1, n)
+    b, x = ctx.vector_from(rhs), ctx.vector(n)
+    d.solve(b, x)
+    ref = lu.solve(rhs)
+    assert np.linalg.norm(x.to_numpy() - ref) <= 1e-10 * np.linalg.norm(ref), d.stats()
+    d.destroy()
+    M.destroy()
+
+
+def test_symmetric_indefinite_operator_falls_through_to_the_pivoted_fronts(ctx):
+    """a symmetric saddle point [K B; B^T 0]: the unpivoted symmetric fronts meet a zero pivot, the factorisation is repeated on the general fronts"""
+    A, xy, bdc = poisson_operator((3, 3, 0), 1)
+    n = A.shape[0]
+    rng = np.random.default_rng(4)
+    m2 = 12
+    B = sp.random(n, m2, density=0.05, random_state=5, format="csr")
+    B = (B + sp.coo_matrix((np.ones(m2), (rng.choice(n, m2, replace=False), np.arange(m2))), shape=(n, m2))).tocsr()
+    S = sp.bmat([[A, B], [B.T, None]]).tocsr()
+    S.sort_indices()
+    assert abs(S - S.T).max() == 0.0
+    M = ctx.matrix_scipy(S)
+    d = capi.Direct(ctx, M, None, 16).factor()
+    assert d.stats()["general"]
+    rhs = rng.uniform(-1, 1, n + m2)
+    b, x = ctx.vector_from(rhs), ctx.vector(n + m2)
+    d.solve(b, x)
+    ref = spla.splu(S.tocsc()).solve(rhs)
+    assert np.linalg.norm(x.to_numpy() - ref) <= 1e-10 * np.linalg.norm(ref)
+    d.destroy()
+    M.destroy()
+
+
+def test_unsymmetric_level_through_lu_smoother_and_coarse_level(ctx):
+    """FH_SMOOTH_LU (MLU_PRECOND / LU_PRECOND on a level) and the exact coarse solve accept an unsymmetric saddle point: a two-level cycle whose fine level
+    is solved exactly gives the direct solution; a one-level hierarchy with option coarse_direct 2 likewise"""
+    A, xy, lay = _ns_jacobian(8, 8)
+    n = A.shape[0]
+    ref_lu = spla.splu(A.tocsc())
+    rhs = np.random.default_rng(2).uniform(-1, 1, n)
+    ref = ref_lu.solve(rhs)
+    ctx.set_option("coarse_direct", 2)
+    try:
+        mg = capi.Multigrid(ctx, 1)
+        A0 = ctx.matrix_scipy(A)
+        mg.set_level(0, A0, None, None, capi.SMOOTH_JACOBI, 1.0, 1, 1)
+        mg.setup()
+        b, x = ctx.vector_from(rhs), ctx.vector(n)
+        for rep in range(2):
+            mg.vcycle(b, x)
+            assert np.linalg.norm(x.to_numpy() - ref) <= 1e-10 * np.linalg.norm(ref)
+        mg.destroy()
+    finally:
+        ctx.set_option("coarse_direct", 1)
+    # as level preconditioner: coarse level = a trivial 1 x 1 problem reached through a zero interpolation (the correction vanishes)
+    P = sp.csr_matrix((n, 1))
+    mg = capi.Multigrid(ctx, 2)
+    A0, A1, P1 = ctx.matrix_scipy(sp.identity(1, format="csr")), ctx.matrix_scipy(A), ctx.matrix_scipy(P)
+    mg.set_level(0, A0, None, None, capi.SMOOTH_JACOBI, 1.0, 1, 1)
+    mg.set_level(1, A1, P1, None, capi.SMOOTH_LU, 1.0, 1, 1)
+    mg.setup()
+    b, x = ctx.vector_from(rhs), ctx.vector(n)
+    mg.vcycle(b, x)
+    assert np.linalg.norm(x.to_numpy() - ref) <= 1e-10 * np.linalg.norm(ref)
+    mg.destroy()
 
 
 def _hierarchy(box, nl):
