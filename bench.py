@@ -95,10 +95,12 @@ def main():
     if (world > 1 and os.environ.get("FEMUS_BENCH_DD", "1") != "0") or os.environ.get("FEMUS_BENCH_FORCE_DD") == "1":
         # transports in order of preference: "rccl" (neighbour send/recv over xGMI), then -- when the RCCL preflight fails or hangs on
         # this machine, or when asked for -- "host" (the same plans and kernels, ghost bytes staged through pinned host buffers and
-        # exchanged over the setup sockets): still ONE distributed problem with ghost exchange, only slower.  torch is never imported
-        # into this process: its wheel bundles its own RCCL / HIP runtime, and two runtimes next to /opt/rocm/lib/librccl.so.1 in one
-        # process are a hang waiting to happen ("gloo" = the host transport over torch.distributed stays available on request, for a
-        # launcher whose only fabric is gloo).  Independent problems are the last resort and say so.
+        # exchanged over the setup sockets): still ONE distributed problem with ghost exchange, only slower.  Which runtime that is: femus_amd._lib
+        # imports torch FIRST, on purpose (torch's wheel bundles its own HIP runtime and RCCL; two HIP runtimes in one process tear each other down
+        # at exit), so the library's ncclSend / ncclRecv / ncclAllReduce bind to torch's bundled librccl.so -- same soname as the /opt/rocm copy it was
+        # linked against.  The line reports the mapped paths and ncclGetVersion (`runtime_libraries`), the preflight child runs on the same copy.
+        # ("gloo" = the host transport over torch.distributed stays available on request, for a launcher whose only fabric is gloo.)  Independent
+        # problems are the last resort and say so.
         want = os.environ.get("FEMUS_BENCH_TRANSPORT", "rccl")
         order = {"rccl": ["rccl", "host"], "gloo": ["gloo"], "host": ["host"]}.get(want, [want])
         for transport in order:

@@ -30,4 +30,14 @@ def loaded_runtimes():
                     out.setdefault(key, set()).add(path)
     except OSError:
         pass
-    return {k: sorted(v) for k, v in out.items()}
+    res = {k: sorted(v) for k, v in out.items()}
+    try:
+        import ctypes
+        v = ctypes.c_int(0)
+        if load_library().fh_rccl_version(ctypes.byref(v)) == 0:
+            res["rccl_version"] = v.value               # ncclGetVersion of the copy that is really bound
+    except Exception:
+        pass
+    res["note"] = ("femus_amd._lib imports torch BEFORE libfemus_hip.so on purpose (one HIP runtime per process: torch's wheel bundles its own), so the "
+                   "library's RCCL / HIP symbols resolve to the copies listed here, not to /opt/rocm's")
+    return res

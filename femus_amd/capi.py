@@ -1050,6 +1050,10 @@ class Multigrid:
         ptr, dofs = _i32(ptr), _i32(dofs)
         _chk(self.L.fh_mg_set_level_patches(self.h, int(level), ptr.size - 1, _p(ptr), _p(dofs)))
 
+    def set_level_patches_exact(self, level, nfirst):
+        """FH_SMOOTH_ASM: the first nfirst blocks get the exact sub-solve instead of ILU(0) (FEMuS_ASM's solid / porous blocks)"""
+        _chk(self.L.fh_mg_set_level_patches_exact(self.h, int(level), int(nfirst)))
+
     def set_level_solver(self, level, solver="gmres", restart=30):
         """level solver of the smoother: "richardson" (fixed sweeps, the default) or "gmres" (fixed iterations, left-preconditioned)"""
         _chk(self.L.fh_mg_set_level_solver(self.h, int(level), {"richardson": 0, "gmres": 1}[solver], int(restart)))

@@ -679,6 +679,7 @@ void LinearEquationSolverHipAsm::attach_smoother_data(fh_mg_t mg, int level, con
     abort();
   }
   hip_check(fh_mg_set_level_patches(mg, level, (int)_blockPtr.size() - 1, _blockPtr.data(), _blockDofs.data()), "MGSetLevel: ASM blocks");
+  if (smoother_id() == FH_SMOOTH_ASM) hip_check(fh_mg_set_level_patches_exact(mg, level, _blockExactCount), "MGSetLevel: exact ASM blocks");
 }
 void LinearEquationSolverHip::MGSolve(const bool) {
   if (_needs_setup) {

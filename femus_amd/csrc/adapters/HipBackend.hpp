@@ -242,13 +242,16 @@ class LinearEquationSolverHipAsm : public LinearEquationSolverHip {
   using LinearEquationSolver::SetElementBlockNumber;
   void SetElementBlockNumber(const unsigned& n) override { _elementBlockNumber = n; }
   void SetNumberOfSchurVariables(const unsigned short& n) override { _NSchurVar = n; }
-  void SetAsmBlocks(const std::vector<int>& ptr, const std::vector<int>& dofs) { _blockPtr = ptr; _blockDofs = dofs; _blocksGiven = true; }   // not a FEMuS member: overrides BuildASMIndex
+  void SetAsmBlocks(const std::vector<int>& ptr, const std::vector<int>& dofs, int exact_first = 0) {      // not a FEMuS member: overrides BuildASMIndex
+    _blockPtr = ptr; _blockDofs = dofs; _blockExactCount = exact_first; _blocksGiven = true;
+  }
   void SetAsmExactInColourOrder(bool on) { _exactColoured = on; }                // not a FEMuS member: see smoother_id
   void BuildASMIndex(const std::vector<unsigned>& variable_to_be_solved);       // petsc_asm/LinearEquationSolverPetscAsm.cpp:91-276
 
  protected:
   // SetPreconditionerFineGrids(ILU_PRECOND) -- what the Navier-Stokes applications set -- gives PCASM as the reference configures it: basic /
-  // multiplicative over the blocks in index order, one ILU(0) application per block (FH_SMOOTH_ASM).  Any other preconditioner type, or
+  // multiplicative over the blocks in index order, one ILU(0) application per block -- an EXACT sub-solve on the blocks of solid / porous elements,
+  // which come first (`_blockTypeRange[1]`, LinearEquationSolverPetscAsm.cpp:298-322) -- (FH_SMOOTH_ASM).  Any other preconditioner type, or
   // SetAsmExactInColourOrder(true) (not a FEMuS member), gives this library's variant: exact block inverses, damped, colour order (FH_SMOOTH_VANKA)
   int smoother_id() const override { return (_preconditioner_type == ILU_PRECOND && !_exactColoured) ? FH_SMOOTH_ASM : FH_SMOOTH_VANKA; }
   void attach_smoother_data(fh_mg_t mg, int level, const std::vector<unsigned>& variable_to_be_solved) override;
@@ -258,6 +261,7 @@ class LinearEquationSolverHipAsm : public LinearEquationSolverHip {
   unsigned _elementBlockNumber = 1;
   unsigned short _NSchurVar = 1;
   std::vector<int> _blockPtr, _blockDofs;
+  int _blockExactCount = 0;      // leading blocks with the exact sub-solve (solid + porous element blocks)
 };
 
 }  // namespace femus

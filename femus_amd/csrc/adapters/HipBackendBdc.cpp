@@ -79,10 +79,14 @@ void LinearEquationSolverHipAsm::BuildASMIndex(const std::vector<unsigned>& vari
 
   _blockPtr.assign(1, 0);
   _blockDofs.clear();
+  _blockExactCount = 0;
   std::vector<int> last_block_of(end_elem - first_elem, -1);     // block that took an owned element into its neighbourhood last
   std::vector<int> dofs;
   int block = 0;
-  for (const std::vector<unsigned>& elems : of_class)
+  for (int cls = 0; cls < 3; cls++) {
+    const std::vector<unsigned>& elems = of_class[cls];
+    // the blocks of the solid and the porous elements come first and get the exact sub-solve (`_blockTypeRange[1]`, LinearEquationSolverPetscAsm.cpp:298-307)
+    if (cls < 2) _blockExactCount += (int)((elems.size() + run - 1) / run);
     for (size_t begin = 0; begin < elems.size(); begin += run, block++) {
       const size_t end = std::min(elems.size(), begin + run);
       dofs.clear();
@@ -102,6 +106,7 @@ void LinearEquationSolverHipAsm::BuildASMIndex(const std::vector<unsigned>& vari
       _blockDofs.insert(_blockDofs.end(), dofs.begin(), dofs.end());
       _blockPtr.push_back((int)_blockDofs.size());
     }
+  }
 }
 
 }  // namespace femus

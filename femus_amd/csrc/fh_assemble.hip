@@ -75,7 +75,6 @@ struct fh_assembler_s {
   int* d_cl_prow = nullptr;                 // rows of the second pass
   unsigned* d_cl_pstart = nullptr;          // [nprow + 1] their segments of the partial-row buffer
   // arguments of the last assembly (the element-wise Galerkin product re-creates the element rows from them when the fused path ran)
-  fh_vec_t last_sol = nullptr;
   int last_source_kind = 0;
   double last_params[2] = {1.0, 0.0};
   // optional fast path for AFFINE HEX27/Q2 elements (option assemble_affine): K_e = sum_ab det*B_ab * M_ab with the nine reference
@@ -3359,7 +3358,6 @@ static int assemble_poisson_core(fh_assembler_t as, fh_vec_t sol, int source_kin
     P.slot = as->d_slot;
     P.nsink = as->nadj;
     P.debug = as->ctx->asm_debug;
-    as->last_sol = sol;
     as->last_source_kind = source_kind;
     as->last_params[0] = P.p0;
     as->last_params[1] = P.p1;
@@ -3955,7 +3953,7 @@ __global__ __launch_bounds__(GMAC_T) void k_galerkin_macro(int nelc, const int* 
 static int element_rows_again(fh_assembler_t as) {
   FH_REQUIRE(as->two_pass && as->d_Kbuf, "fh_assembler_galerkin: the fine assembler holds no element rows");
   AsmParams P = base_params(as);
-  P.sol = as->last_sol ? as->last_sol->d : nullptr;
+  P.sol = nullptr;          // only K_e is needed (the Poisson element matrix does not depend on the solution); the vector of that assembly may be gone by now
   P.source_kind = as->last_source_kind;
   P.p0 = as->last_params[0];
   P.p1 = as->last_params[1];

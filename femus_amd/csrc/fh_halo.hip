@@ -87,6 +87,16 @@ extern "C" int fh_halo_create_shared(fh_halo_t parent, const int* send_counts, c
   return halo_create(parent->ctx, parent->rank, parent->nranks, nullptr, parent->comm, send_counts, send_idx, recv_counts, out);
 }
 
+// version of the RCCL this process really calls (ncclGetVersion of whichever librccl the dynamic loader bound: the launcher reports it with the path)
+extern "C" int fh_rccl_version(int* version) {
+  FH_REQUIRE(version, "fh_rccl_version: null argument");
+  int v = 0;
+  const ncclResult_t r = ncclGetVersion(&v);
+  FH_REQUIRE(r == ncclSuccess, "fh_rccl_version: ncclGetVersion failed: %s", ncclGetErrorString(r));
+  *version = v;
+  return 0;
+}
+
 extern "C" int fh_halo_create_host(fh_ctx_t ctx, int rank, int nranks, fh_exchange_fn exchange, fh_allreduce_fn allreduce, void* user,
                                    const int* send_counts, const int* send_idx, const int* recv_counts, fh_halo_t* out) {
   FH_REQUIRE(exchange && allreduce, "fh_halo_create_host: null transport function");

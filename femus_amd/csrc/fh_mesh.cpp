@@ -380,6 +380,8 @@ extern "C" int fh_mesh_clear_boundary_faces(fh_mesh_t m, unsigned face_mask) {
   for (int iel = 0; iel < m->nel; iel++)
     for (int f = 0; f < nf; f++)
       if ((face_mask >> f) & 1u) m->face_flag[(size_t)iel * nf + f] = -1;
+  m->amr_cache[0].reset();     // interface faces of the hanging-node search are the faces flagged -1: rows cached before are stale
+  m->amr_cache[1].reset();
   return 0;
 }
 

@@ -40,6 +40,7 @@ struct MgLevel {
   fh_tri_t tri = nullptr;
   // block Schwarz (Vanka) smoother: dof patches, their colours and dense inverses
   int npatch = 0, vanka_ncolors = 0, max_patch = 0;
+  int npatch_exact = 0;       // FH_SMOOTH_ASM: the first npatch_exact blocks get the EXACT sub-solve (MLU_PRECOND on the solid / porous blocks, LinearEquationSolverPetscAsm.cpp:298-307)
   std::vector<int> h_pptr, h_pdofs, vcolor_ptr;
   std::vector<int64_t> h_poff;
   int *d_pptr = nullptr, *d_pdofs = nullptr, *d_porder = nullptr, *d_pflag = nullptr, *d_pcptr = nullptr;
@@ -1628,6 +1629,7 @@ static uint64_t cycle_signature(fh_mg_t mg) {
     mixm(L.P);
     mixm(L.R);
     mix((uint64_t)L.smoother);
+    mix((uint64_t)L.npatch_exact);
     mix((uint64_t)L.npre);
     mix((uint64_t)L.npost);
     uint64_t ob;
@@ -1689,6 +1691,16 @@ extern "C" int fh_mg_set_level_patches(fh_mg_t mg, int level, int npatch, const 
     L.max_patch = std::max(L.max_patch, np);
     L.h_poff[p + 1] = L.h_poff[p] + (int64_t)np * np;
   }
+  L.npatch_exact = 0;
+  mg->setup_done = false;
+  return 0;
+}
+
+extern "C" int fh_mg_set_level_patches_exact(fh_mg_t mg, int level, int nfirst) {
+  FH_REQUIRE(mg && level >= 0 && level < mg->nlevels, "fh_mg_set_level_patches_exact: bad arguments");
+  MgLevel& L = mg->lv[level];
+  FH_REQUIRE(nfirst >= 0 && nfirst <= L.npatch, "fh_mg_set_level_patches_exact: %d of %d blocks", nfirst, L.npatch);
+  L.npatch_exact = nfirst;
   mg->setup_done = false;
   return 0;
 }
@@ -1785,10 +1797,10 @@ static int color_patches(MgLevel& L, bool sequential) {
 // per block on global memory (setup); O: scratch of the same layout, mask: which entries of the block lie in the pattern of A.
 __global__ __launch_bounds__(256) void k_patch_ilu0(const int* __restrict__ pptr, const int* __restrict__ pdofs, const int64_t* __restrict__ poff,
                                                     const int* __restrict__ rowptr, const int* __restrict__ col, double* __restrict__ M, double* __restrict__ O,
-                                                    unsigned char* __restrict__ mask, int* __restrict__ flag) {
+                                                    unsigned char* __restrict__ mask, int* __restrict__ flag, int first) {
   __shared__ double s_shift, s_piv;
   __shared__ int s_fail;
-  const int p = blockIdx.x, tid = threadIdx.x;
+  const int p = blockIdx.x + first, tid = threadIdx.x;
   const int* d = pdofs + pptr[p];
   const int np = pptr[p + 1] - pptr[p];
   double* Mp = M + poff[p];
@@ -1861,9 +1873,10 @@ static int factor_patches(fh_mg_t mg, MgLevel& L) {
   FH_CHECK_HIP(hipMemsetAsync(L.d_pflag, 0, (size_t)L.npatch * sizeof(int), c->stream));
   hipLaunchKernelGGL(k_patch_extract, dim3(L.npatch), dim3(256), 0, c->stream, L.d_pptr, L.d_pdofs, L.d_poff, L.A->d_rowptr, L.A->d_col, L.A->d_val,
                      L.d_pinv);
-  if (L.smoother == FH_SMOOTH_ASM)
-    hipLaunchKernelGGL(k_patch_ilu0, dim3(L.npatch), dim3(256), 0, c->stream, L.d_pptr, L.d_pdofs, L.d_poff, L.A->d_rowptr, L.A->d_col, L.d_pinv, L.d_pscr, L.d_pmask,
-                       L.d_pflag);
+  // (blocks below npatch_exact keep A_pp: their sub-solve is the exact one, the reference's MLU_PRECOND on the solid / porous blocks)
+  if (L.smoother == FH_SMOOTH_ASM && L.npatch > L.npatch_exact)
+    hipLaunchKernelGGL(k_patch_ilu0, dim3(L.npatch - L.npatch_exact), dim3(256), 0, c->stream, L.d_pptr, L.d_pdofs, L.d_poff, L.A->d_rowptr, L.A->d_col, L.d_pinv, L.d_pscr,
+                       L.d_pmask, L.d_pflag, L.npatch_exact);
   // patches of at most PLDS_MAX dofs: one wave each with the matrix in LDS; the others (and everything with patch_invert_lds = 0): the
   // workgroup kernel on the matrix in global memory
   int nsmall = 0;

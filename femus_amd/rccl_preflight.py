@@ -103,6 +103,10 @@ def _child(rank, world, addr, port, device, transport="rccl"):
             comm.close()
             return 4
     comm.close()
+    if rank == 0:       # which RCCL / HIP runtime the exchange above really ran on (last line of the child's output: run() appends it to its message)
+        from . import loaded_runtimes
+        rt = loaded_runtimes()
+        print("runtime: librccl %s version %s, libamdhip64 %s" % (",".join(rt.get("librccl", ["?"])), rt.get("rccl_version", "?"), ",".join(rt.get("libamdhip64", ["?"]))))
     return 0
 
 
@@ -119,7 +123,8 @@ def run(rank, world, addr, port, device, timeout=180.0, transport="rccl"):
         p.communicate()
         return False, "RCCL preflight did not finish within %.0f s" % timeout
     if p.returncode == 0:
-        return True, "ok"
+        tail = out.decode(errors="replace").strip().splitlines()[-1:] if out else []
+        return True, "ok" + (" (" + tail[0][:200] + ")" if tail and tail[0].startswith("runtime:") else "")
     tail = out.decode(errors="replace").strip().splitlines()[-1:] if out else []
     return False, "RCCL preflight failed (exit %d)%s" % (p.returncode, ": " + tail[0][:160] if tail else "")
 

@@ -418,6 +418,10 @@ int fh_mg_set_level(fh_mg_t mg, int level, fh_mat_t A, fh_mat_t P, fh_mat_t R, i
  * conflict-free colours of patches.  Patches (fh_mesh_vertex_patches) are given per level before fh_mg_setup, which
  * extracts and inverts the patch matrices (dense, partial pivoting) from the level's current operator. */
 int fh_mg_set_level_patches(fh_mg_t mg, int level, int npatch, const int* ptr /* [npatch+1] */, const int* dofs);
+/* FH_SMOOTH_ASM only: the first `nfirst` blocks of the list get the EXACT sub-solve instead of ILU(0) -- what FEMuS_ASM gives the blocks of the solid and
+ * the porous elements, which MeshASMPartitioning::DoPartition puts first (`_blockTypeRange[1]`; MLU_PRECOND on them, LinearEquationSolverPetscAsm.cpp:298-307).
+ * After fh_mg_set_level_patches (which resets it to 0), before fh_mg_setup. */
+int fh_mg_set_level_patches_exact(fh_mg_t mg, int level, int nfirst);
 /* Level solver (`SetSolverFineGrids`, LinearImplicitSystem; `_levelSolverType`, LinearEquationSolverPetsc.cpp:238-250 and 501-519):
  * FH_LEVEL_RICHARDSON  x <- x + omega B (b - A x), npre / npost times (KSPRICHARDSON, the smoother of fh_mg_set_level as B)
  * FH_LEVEL_GMRES       npre / npost iterations of left-preconditioned GMRES with the same B (KSPGMRES, the reference's default
@@ -482,6 +486,8 @@ int fh_halo_create(fh_ctx_t ctx, int rank, int nranks, const char id128[128],
                    const int* recv_counts /* [nranks] */, fh_halo_t* halo);
 /* further exchange plans (other multigrid levels) on the communicator of an existing one (a ncclUniqueId makes ONE communicator) */
 int fh_halo_create_shared(fh_halo_t parent, const int* send_counts, const int* send_idx, const int* recv_counts, fh_halo_t* halo);
+/* ncclGetVersion of the RCCL this process is bound to (a launcher that also loads PyTorch runs on the copy PyTorch bundles: report it) */
+int fh_rccl_version(int* version);
 /* host-staged transport for the same plans (ranks without an RCCL peer-to-peer path, e.g. several ranks on one GPU, or a
  * launcher that already has MPI): the pack kernel, the ghost layout and every caller stay the same, the bytes travel through
  * pinned host buffers and the two functions given here (e.g. MPI_Neighbor_alltoallv and MPI_Allreduce).  exchange(user, send,

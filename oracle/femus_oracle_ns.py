@@ -276,8 +276,10 @@ class AsmSmoother:
     from PETSc 3.20's PCApply_ASM (parity unpinned: PETSc is not in the image): from y = 0 the blocks in INDEX order,
     y[d_i] += (L~ U~)_i^-1 (r - A y)[d_i] over the whole overlapping dof set d_i.  sweep = one Richardson(omega) iteration around it."""
 
-    def __init__(self, A, patches, omega=1.0, pattern=None):
-        """pattern = (rowptr, col) of the STORED entries of the level operator (the allocation the factorisation fills: element couplings on the
+    def __init__(self, A, patches, omega=1.0, pattern=None, n_exact=0):
+        """n_exact: the first n_exact blocks are solved EXACTLY (MLU_PRECOND on the solid / porous blocks, which DoPartition puts first:
+        `_blockTypeRange[1]`, LinearEquationSolverPetscAsm.cpp:298-307), the others by ILU(0).
+        pattern = (rowptr, col) of the STORED entries of the level operator (the allocation the factorisation fills: element couplings on the
         assembled level, the symbolic triple product below it -- zeros included, which a scipy product may have dropped); None: A's own"""
         self.A = A.tocsr()
         self.patches = [np.sort(np.asarray(d)) for d in patches]
@@ -296,15 +298,15 @@ class AsmSmoother:
             vals[pos] = C.data[keep]
             S = sp.csr_matrix((vals, col, rp), shape=self.A.shape)              # explicit zeros stay (no arithmetic on S as a whole)
         self.ilu = []
-        for d in self.patches:
+        for k, d in enumerate(self.patches):
             B = S[d][:, d].tocsr()
-            self.ilu.append(fo.ilu0_factor(B))
+            self.ilu.append(np.linalg.inv(B.toarray()) if k < n_exact else fo.ilu0_factor(B))
 
     def apply(self, r):
         y = np.zeros_like(r)
         for d, LU in zip(self.patches, self.ilu):
             t = r[d] - self.A[d] @ y
-            y[d] += fo.ilu0_apply(LU, t)
+            y[d] += LU @ t if isinstance(LU, np.ndarray) else fo.ilu0_apply(LU, t)
         return y
 
     def sweep(self, b, x):
@@ -389,7 +391,7 @@ def build_ns_levels(nx, ny, nz, nlevels, lo, hi):
     return ms, lays
 
 
-def newton_step_operators(ms, lays, bcs, igrid, sol, nu, omega=0.6, npre=2, npost=2, order="seventh", smoother="vanka", patterns=None):
+def newton_step_operators(ms, lays, bcs, igrid, sol, nu, omega=0.6, npre=2, npost=2, order="seventh", smoother="vanka", patterns=None, asm_exact=0):
     """assemble at level igrid, Galerkin chain, penalty rows, smoothers: everything one Newton iteration prepares"""
     H = NSHierarchy()
     A, b = assemble_ns(ms[igrid], lays[igrid], sol, nu, order)
@@ -409,7 +411,7 @@ def newton_step_operators(ms, lays, bcs, igrid, sol, nu, omega=0.6, npre=2, npos
     H.smoother = [None] * (igrid + 1)
     for l in range(1, igrid + 1):
         patches = vertex_patches(ms[l], lays[l])
-        H.smoother[l] = (AsmSmoother(H.A[l], patches, omega, None if patterns is None else patterns[l]) if smoother == "asm" else
+        H.smoother[l] = (AsmSmoother(H.A[l], patches, omega, None if patterns is None else patterns[l], n_exact=asm_exact) if smoother == "asm" else
                          VankaSmoother(H.A[l], patches, color_patches(patches, H.A[l]), omega))
     lu = spla.splu(H.A[0].tocsc())
     H.coarse_solve = lu.solve

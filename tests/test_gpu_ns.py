@@ -190,11 +190,12 @@ def test_three_dimensional_cavity_matches_oracle(ctx):
     pb.destroy()
 
 
-@pytest.mark.parametrize("level_solver", ["richardson", "gmres"])
-def test_pcasm_as_the_reference_configures_it(ctx, level_solver):
+@pytest.mark.parametrize("level_solver,n_exact", [("richardson", 0), ("gmres", 0), ("richardson", 5)])
+def test_pcasm_as_the_reference_configures_it(ctx, level_solver, n_exact):
     """FH_SMOOTH_ASM: PC_ASM_BASIC + PC_COMPOSITE_MULTIPLICATIVE over the element blocks in their index order with ILU(0) (zero pivot 1e-16,
     MAT_SHIFT_NONZERO) sub-solves (PetscPreconditioner.cpp:179-184, LinearEquationSolverPetscAsm.cpp:278-335): one V(2,2) cycle on the
-    Jacobian of a non-trivial state against the oracle's sequential restatement, Richardson and GMRES level solvers"""
+    Jacobian of a non-trivial state against the oracle's sequential restatement, Richardson and GMRES level solvers; n_exact: the leading blocks
+    with the EXACT sub-solve the reference gives the solid / porous blocks (`_blockTypeRange[1]`, :298-307)"""
     nu, nl = 0.01, 3
     pb = NavierStokesMG(ctx, 4, 4, 0, nl, nu).init()
     pb.smoother = capi.SMOOTH_ASM
@@ -206,13 +207,15 @@ def test_pcasm_as_the_reference_configures_it(ctx, level_solver):
     state[bcs[top][0]] = bcs[top][1]
     pb.SOL[top].upload(state)
     mg = pb.prepare(top)
-    if level_solver == "gmres":
+    if level_solver == "gmres" or n_exact:
         for l in range(1, nl):
-            mg.set_level_solver(l, "gmres", 30)
+            if level_solver == "gmres":
+                mg.set_level_solver(l, "gmres", 30)
+            mg.set_level_patches_exact(l, n_exact)
         mg.setup()
     # ILU(0) fills the ALLOCATED pattern (stored zeros included): the pattern is taken from the device operators, the values are the oracle's
     H = ns.newton_step_operators(ms, lays, bcs, top, state, nu, omega=pb.omega, npre=pb.npre, npost=pb.npost, smoother="asm",
-                                 patterns=[pb.A[(top, l)].pattern() for l in range(nl)])
+                                 patterns=[pb.A[(top, l)].pattern() for l in range(nl)], asm_exact=n_exact)
     b = rng.standard_normal(lays[top].n)
     b[bcs[top][0]] = 0.0
     x = ctx.vector(lays[top].n)
