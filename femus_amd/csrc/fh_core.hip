@@ -241,6 +241,7 @@ extern "C" int fh_set_option(fh_ctx_t c, const char* name, double value) {
   else if (!strcmp(name, "coarse_direct")) c->coarse_direct = (int)value;
   else if (!strcmp(name, "gmres_device")) c->gmres_device = (int)value;
   else if (!strcmp(name, "galerkin_macro")) c->galerkin_macro = (int)value;
+  else if (!strcmp(name, "vanka_fused")) c->vanka_fused = (int)value;
   else if (!strcmp(name, "coarse_direct_min")) c->coarse_direct_min = (int)value;
   else if (!strcmp(name, "coarse_nd_streams")) c->coarse_nd_streams = (int)value;
   else if (!strcmp(name, "patch_invert_lds")) c->patch_invert_lds = (int)value;

@@ -102,6 +102,7 @@ struct fh_ctx_s {
   int coarse_nd = 8;                 // coarsest level: interior blocks of the nested dissection of the coupled unknowns (block inverses beside each other + separator Schur complement); needs coordinates (fh_mg_set_coarse_coords) and a symmetric operator; 0 / 1: one dense inverse
   int coarse_nd_streams = 0;         // ... the block inverses: 0 = one launch per step for all blocks (block index as a grid dimension), 1 = one stream per block, 2 = one after the other (measurements)
   int coarse_nd_min = 1024;          // ... only from this many coupled unknowns on
+  int vanka_fused = 1;               // block smoothers (Vanka / PCASM): 1 = a colour in one launch, every patch forms the residual of its own rows; 0 = level residual (SpMV) + patch launch
   int galerkin_macro = 1;            // element-wise Galerkin product after a FUSED assembly: 1 = from the macro rows it left behind (k_galerkin_macro), 0 = re-create the element rows
   int gmres_device = 1;              // outer GMRES of fh_mg_solve: 1 = Hessenberg / rotations / convergence test on the device, one read-back per iteration; 0 = driven from the host
   int coarse_direct = 1;             // coarsest level: 1 = the sparse exact solve (fh_direct.hip) when more than coarse_direct_min unknowns are coupled, 2 = always, 0 = never (dense inverse, <= 16384)

@@ -44,6 +44,7 @@ struct MgLevel {
   std::vector<int> h_pptr, h_pdofs, vcolor_ptr;
   std::vector<int64_t> h_poff;
   int *d_pptr = nullptr, *d_pdofs = nullptr, *d_porder = nullptr, *d_pflag = nullptr, *d_pcptr = nullptr;
+  int4* d_pdesc = nullptr;    // per patch dof: {row, first entry, end of the row, 0} -- one load instead of the chain dof -> row pointer (k_vanka_color_fused)
   unsigned* d_pbar = nullptr;      // arrival / exit counters of the persistent sweep
   int vanka_maxcolor = 0;          // patches of the largest colour
   int pbar_len = 0;
@@ -397,6 +398,67 @@ __global__ __launch_bounds__(64) void k_vanka_color(const int* __restrict__ orde
     for (int c = 0; c < np; c++) s += Mi[(size_t)c * np + a] * rp[c];
     x[d[a]] += omega * s;
   }
+}
+
+// The same colour in ONE launch (round 5, default: option vanka_fused 1): every patch forms the residual of ITS OWN rows (4 lanes per row, 16 rows at a
+// time) instead of reading a residual of the whole level that a separate SpMV launch has just made -- exact for the colour, because its patches do not
+// read each other's dofs.  Half the launches of a sweep (the cycles of config 4 are launch-latency bound: ~380 launches of 4-9 us) and none of the
+// residual rows nobody reads.  One workgroup of four waves per patch: 8 lanes per row, the dense inverse applied a quarter of the columns per wave.
+__global__ __launch_bounds__(256) void k_patch_desc(int n, const int* __restrict__ pdofs, const int* __restrict__ rowptr, int4* __restrict__ desc) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int r = pdofs[k];
+  desc[k] = make_int4(r, rowptr[r], rowptr[r + 1], 0);
+}
+__global__ __launch_bounds__(256) void k_vanka_color_fused(const int* __restrict__ order, int npat, const int* __restrict__ pptr, const int4* __restrict__ pdesc,
+                                                           const int64_t* __restrict__ poff, const double* __restrict__ Minv, const int* __restrict__ col,
+                                                           const double* __restrict__ val, const double* __restrict__ b, double* x, double omega, int max_patch) {
+  extern __shared__ double vf_smem[];
+  double* rp = vf_smem;                          // [max_patch] residual of the patch rows
+  double* part = vf_smem + max_patch;            // [4][max_patch] partial products of the four waves
+  if ((int)blockIdx.x >= npat) return;
+  const int p = order[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = tid & 7, rl = tid >> 3;
+  const int p0 = pptr[p], np = pptr[p + 1] - p0;
+  const int4* d = pdesc + p0;
+  const double* Mi = Minv + poff[p];             // transposed inverse: Mi[c * np + a] = inv[a][c]
+  const int c0 = (np * wave) >> 2, c1 = (np * (wave + 1)) >> 2;          // this wave's quarter of the columns
+  // the step is a chain of dependent memory round trips (cycles of config 4: 192 colour steps of 15-25 us): what does not depend on x goes out first --
+  // this thread's entries of the inverse (patches of <= 64 dofs: at most sixteen), the row descriptors ({row, first, end} in one load)
+  constexpr int MR = 16;
+  double mreg[MR];
+  const bool small = np <= 64;
+  if (small) {
+#pragma unroll
+    for (int q = 0; q < MR; q++) mreg[q] = (lane < np && c0 + q < c1) ? Mi[(size_t)(c0 + q) * np + lane] : 0.0;
+  }
+  for (int a0 = 0; a0 < np; a0 += 32) {          // 32 rows at a time, 8 lanes per row (one wave per patch and 4 lanes per row was latency bound: 184 instead
+    const int a = a0 + rl;                       //  of 120 ms per linear solve of config 4)
+    double acc = 0.0, bb = 0.0;
+    if (a < np) {
+      const int4 q = d[a];
+      bb = b[q.x];
+      for (int kk = q.y + sub; kk < q.z; kk += 8) acc += val[kk] * x[col[kk]];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (a < np && sub == 0) rp[a] = bb - acc;
+  }
+  __syncthreads();
+  if (small) {
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < MR; q++) s += mreg[q] * rp[min(c0 + q, np - 1)];          // (entries beyond c1 are zero)
+    if (lane < np) part[wave * max_patch + lane] = s;
+  } else {
+    for (int a = lane; a < np; a += 64) {
+      double s = 0.0;
+      for (int c = c0; c < c1; c++) s += Mi[(size_t)c * np + a] * rp[c];
+      part[wave * max_patch + a] = s;
+    }
+  }
+  __syncthreads();
+  for (int a = tid; a < np; a += 256) x[d[a].x] += omega * (((part[a] + part[max_patch + a]) + part[2 * max_patch + a]) + part[3 * max_patch + a]);
 }
 
 // ALL colours of ALL sweeps in one launch (fh_set_option(vanka_persistent, 1 | 2); off by default): a grid of resident one-wave workgroups walks
@@ -1663,7 +1725,7 @@ static void free_level_colors(MgLevel& L) {
 // device side of the patch smoother (colouring by the matrix graph, inverses): rebuilt by the next setup; the patch lists stay
 static void free_level_patch_setup(MgLevel& L) {
   for (void** q : {(void**)&L.d_pptr, (void**)&L.d_pdofs, (void**)&L.d_porder, (void**)&L.d_pflag, (void**)&L.d_poff, (void**)&L.d_pinv, (void**)&L.d_pcptr,
-                   (void**)&L.d_pbar, (void**)&L.d_pscr, (void**)&L.d_pmask})
+                   (void**)&L.d_pbar, (void**)&L.d_pscr, (void**)&L.d_pmask, (void**)&L.d_pdesc})
     if (*q) {
       hipFree(*q);
       *q = nullptr;
@@ -1772,6 +1834,9 @@ static int color_patches(MgLevel& L, bool sequential) {
   };
   FH_TRY(up((void**)&L.d_pptr, L.h_pptr.data(), L.h_pptr.size() * sizeof(int)));
   FH_TRY(up((void**)&L.d_pdofs, L.h_pdofs.data(), L.h_pdofs.size() * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&L.d_pdesc, std::max<size_t>(L.h_pdofs.size(), 1) * sizeof(int4)));
+  hipLaunchKernelGGL(k_patch_desc, dim3(fh_div_up((int64_t)L.h_pdofs.size(), 256)), dim3(256), 0, L.A->ctx->stream, (int)L.h_pdofs.size(), L.d_pdofs, L.A->d_rowptr, L.d_pdesc);
+  FH_CHECK_HIP(hipGetLastError());
   FH_TRY(up((void**)&L.d_poff, L.h_poff.data(), L.h_poff.size() * sizeof(int64_t)));
   FH_TRY(up((void**)&L.d_porder, order.data(), order.size() * sizeof(int)));
   FH_TRY(up((void**)&L.d_pcptr, L.vcolor_ptr.data(), L.vcolor_ptr.size() * sizeof(int)));
@@ -1929,6 +1994,11 @@ static int vanka_apply(fh_mg_t mg, MgLevel& L, double* x, const double* b, doubl
     for (int k = 0; k < L.vanka_ncolors; k++) {
       const int np = L.vcolor_ptr[k + 1] - L.vcolor_ptr[k];
       if (np == 0) continue;
+      if (c->vanka_fused) {
+        hipLaunchKernelGGL(k_vanka_color_fused, dim3(np), dim3(256), (size_t)5 * L.max_patch * sizeof(double), c->stream, L.d_porder + L.vcolor_ptr[k], np, L.d_pptr,
+                           L.d_pdesc, L.d_poff, L.d_pinv, L.A->d_col, L.A->d_val, b, x, omega, L.max_patch);
+        continue;
+      }
       FH_TRY(fh_dev_spmv(L.A, x, rwork, 2, b, nullptr, 0.0));                       // r = b - A x
       hipLaunchKernelGGL(k_vanka_color, dim3(np), dim3(64), (size_t)L.max_patch * sizeof(double), c->stream, L.d_porder + L.vcolor_ptr[k], np,
                          L.d_pptr, L.d_pdofs, L.d_poff, L.d_pinv, rwork, x, omega);

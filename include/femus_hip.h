@@ -70,6 +70,8 @@ int fh_graph_destroy(fh_graph_t graph);
  * "assemble_sumfac" (1: map Jacobian by sum factorisation in that kernel), "assemble_sym" (1), "assemble_affine" (0, see fh_assembler_affine_count), "assemble_fused" (1, see fh_assembler_fused_info), "gj_mfma" (1: coarse dense inverse updates on the
  * matrix cores), "gj_symmetric" (1: symmetric sweep on the upper block triangle when the coarse operator is symmetric), "spgemm_slot_map" (1), "spgemm_device_symbolic" (1: patterns of sparse products on the device), "device_setup" (1: prolongators built on the device; 0: host loops, identical matrices), "use_graph" (1), "asm_debug" (0),
  * "debug_poison" (0; tests: work buffers of the solvers and the element-row buffers start as NaN bit patterns instead of zero),
+ * "galerkin_macro" (1: fh_assembler_galerkin after a fused assembly reads the macro rows that assembly left behind), "vanka_fused" (1: block smoothers
+ * run a colour / dependency level in one launch, every patch forming the residual of its own rows),
  * "gmres_device" (1: the outer GMRES of fh_mg_solve keeps its Hessenberg matrix, rotations and convergence test on the device and reads one status word back
  * per iteration; 0: the same solver driven from the host, two synchronisations per iteration),
  * "halo_overlap" (1: on distributed levels the rows without ghost columns are multiplied while the ghost exchange is in flight),

@@ -44,12 +44,17 @@ def main():
         mg.vcycle(pb.RES[top], x)
     ctx.sync(); cyc_ms = (time.time() - t) / 20 * 1e3
     t = time.time(); its, rn = mg.solve(pb.RES[top], pb.EPS[top], outer="gmres", rtol=1e-10, maxit=200); ctx.sync()
-    lin_ms = (time.time() - t) * 1e3
+    lin_first_ms = (time.time() - t) * 1e3           # (the first solve of this object at this restart length also allocates its Krylov workspace)
+    lin = []
+    for _ in range(3):
+        ctx.sync(); t = time.time(); its, rn = mg.solve(pb.RES[top], pb.EPS[top], outer="gmres", rtol=1e-10, maxit=200); ctx.sync()
+        lin.append((time.time() - t) * 1e3)
+    lin_ms = sorted(lin)[1]
     fine = [h for h in pb.history if h[0] == top]
     print(json.dumps({"config": "cavity Q2/Q1 80x80, 4 levels, nu=%g" % nu, "unknowns": pb.n[top], "setup_s": setup_s,
                       "fcycle_solve_s": solve_s, "newton_steps_per_level": [sum(1 for h in pb.history if h[0] == l) for l in range(nl)],
                       "gmres_its_finest": [h[3] for h in fine], "assembly_ms": asm_ms, "prepare_ms": prep_ms,
-                      "vcycle_ms": cyc_ms, "linear_solve_ms": lin_ms, "linear_its": its}))
+                      "vcycle_ms": cyc_ms, "linear_solve_ms": lin_ms, "linear_solve_first_call_ms": lin_first_ms, "linear_its": its}))
     pb.destroy()
 
 

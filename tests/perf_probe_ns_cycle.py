@@ -1,0 +1,44 @@
+"""timing probe (not a test): one Newton step of BASELINE config 4 (80 x 80 Taylor-Hood, 4 levels, nu = 0.001 state by continuation) -- the V-cycle and the
+linear solve timed after a warm-up, medians of repetitions, for the options given as name=value.  usage: perf_probe_ns_cycle.py [name=value ...]"""
+import os, sys, time, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import femus_amd
+from femus_amd.navier_stokes import NavierStokesMG
+
+ctx = femus_amd.Context(0)
+opts = {}
+for kv in sys.argv[1:]:
+    k, v = kv.split("=")
+    ctx.set_option(k, float(v))
+    opts[k] = float(v)
+nl = 4
+pb = NavierStokesMG(ctx, 10, 10, 0, nl, 0.01).init()
+for v in [0.01, 0.004, 0.002, 0.001]:
+    pb.nu = v
+    assert pb.newton(0, tol=1e-10, max_newton=25)
+for ig in range(1, nl):
+    pb.prolongator_sol(ig)
+    assert pb.newton(ig, tol=1e-10, max_newton=25, lin_rtol=1e-10, lin_maxit=200)
+top = nl - 1
+pb.asm[top].assemble(pb.KK[top], pb.RES[top], pb.SOL[top], pb.nu)
+mg = pb.prepare(top)
+x = ctx.vector(pb.n[top])
+for _ in range(5):
+    mg.vcycle(pb.RES[top], x)
+ctx.sync()
+cyc = []
+for rep in range(5):
+    ctx.sync(); t = time.perf_counter()
+    for _ in range(20):
+        mg.vcycle(pb.RES[top], x)
+    ctx.sync(); cyc.append((time.perf_counter() - t) / 20 * 1e3)
+its, rn = mg.solve(pb.RES[top], pb.EPS[top], outer="gmres", rtol=1e-10, maxit=200)
+lin = []
+for rep in range(5):
+    ctx.sync(); t = time.perf_counter()
+    its, rn = mg.solve(pb.RES[top], pb.EPS[top], outer="gmres", rtol=1e-10, maxit=200)
+    ctx.sync(); lin.append((time.perf_counter() - t) * 1e3)
+print(json.dumps({"options": opts, "unknowns": pb.n[top], "vcycle_ms_median": sorted(cyc)[2], "vcycle_ms_all": cyc, "linear_solve_ms_median": sorted(lin)[2],
+                  "linear_solve_ms_all": lin, "linear_its": its, "ms_per_iteration": sorted(lin)[2] / max(its, 1)}))
+pb.destroy()
