@@ -1033,6 +1033,24 @@ class NSAssembler:
             self.h = None
 
 
+class NSStabAssembler(NSAssembler):
+    """the callback of applications/003_NavierStokes/SteadyNavierStokesParallel (main.cpp:390-925): equal-order linear velocity / pressure on the vertex
+    nodes with the Franca-Frey stabilisation; variables [U | V | (W) | P], each `nq1` long"""
+
+    def __init__(self, ctx, mesh, A, order="seventh"):
+        self.ctx, self.L = ctx, ctx.L
+        ed, xy, _ = mesh.arrays()
+        self.nel = mesh.nel
+        self.nq1 = mesh.own_size[0]
+        self.nd = (mesh.dim + 1) * 2 ** mesh.dim
+        self.h = ctypes.c_void_p()
+        _chk(self.L.fh_ns_stab_assembler_create(ctx.h, GEOM[mesh.geom], GAUSS_ORDER[order], mesh.nel, mesh.nloc, _p(ed), mesh.nnode, self.nq1, _p(xy), A.h,
+                                                ctypes.byref(self.h)))
+
+    def assemble(self, A, res, sol, inverse_reynolds):
+        _chk(self.L.fh_assemble_navier_stokes_stab(self.h, None if sol is None else sol.h, ctypes.c_double(inverse_reynolds), A.h, res.h))
+
+
 class Multigrid:
     """LinearEquationSolver MG interface: MGInit / MGSetLevel / MGSolve / MGClear."""
 

@@ -19,6 +19,7 @@
 #include "fh_internal.h"
 #include "fh_fe.h"
 #include <algorithm>
+extern "C" int fh_fe_tables_d2(int geom, int fe, int order, double* d2phi);
 
 struct fh_ns_assembler_s {
   fh_ctx_t ctx = nullptr;
@@ -28,6 +29,8 @@ struct fh_ns_assembler_s {
   double *d_K = nullptr, *d_F = nullptr;
   int *d_adj_ptr = nullptr, *d_adj_ei = nullptr;   // row -> (element * nd + local row), ascending
   int max_row = 0;
+  int kind = 0;                 // 0: Taylor-Hood (03_navier_stokes.hpp), 1: equal-order linear with the Franca-Frey stabilisation (the application's callback)
+  double* d_d2phi = nullptr;    // kind 1: second reference derivatives [ng][nv][nh]
 };
 
 struct NsParams {
@@ -227,6 +230,243 @@ __global__ __launch_bounds__(64) void k_sys_row_gather(const int* __restrict__ a
   if (lane == 0 && res) res[r] = f;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The callback the application ships (round 5): applications/003_NavierStokes/SteadyNavierStokesParallel/main.cpp:390-925 -- equal-order LAGRANGE FIRST
+// velocity and pressure (:98-108) with the Franca-Frey stabilisation (:677-868).  Per Gauss point, with u, g_kj = d_j u_k, H_k = Hessian of u_k, p, q = grad p:
+//   Res_k = -q_k - sum_j u_j g_kj + IRe sum_j (H_k[jj] + H_j[kj])                                    strong residual (:742-755)
+//   Rek = |u| / (4 sl IRe), sl = sqrt(lambda_k) = sqrt(6) / h_k (SetLambda for LAGRANGE FIRST, :1070-1082, :1262)
+//   Rek <= 1e-15: tau = 1 / (4 sl^2 IRe), delta = 0 ; Rek < 1: tau = 1 / (4 sl^2 IRe), delta = |u|^2 / (4 sl^2 IRe) ; else tau = 1 / (|u| sl), delta = |u| / sl
+//   aRhs[k][i] = { -phi_i sum_j u_j g_kj - IRe sum_j d_j phi_i (g_kj + g_jk) + (p - delta div u) d_k phi_i + Res_k tau (u . grad phi_i)
+//                  - IRe tau [ Res_k lap phi_i + sum_n Res_n d_n d_k phi_i ] } W                     (:768-792, the two least-squares lines folded)
+//   aRhs[p][i] = { div u phi_i - tau grad phi_i . Res } W                                            (:796-803)
+// Rhs = aRhs goes to the residual vector, KKloc = -d aRhs / d Soli to the matrix (:884-910).  The reference differentiates with an adept tape; here the
+// derivative is written out (tau and delta depend on u through |u| and through the branch taken):
+//   dRes_k / d u_c[j] = -phi_j g_kc - [k = c] (u . grad phi_j) + IRe ([k = c] lap phi_j + d_k d_c phi_j) ;  dRes_k / d p[j] = -d_k phi_j
+// One workgroup of 64 threads per element; nd = 12 (QUAD4) / 32 (HEX8).
+// ------------------------------------------------------------------------------------------------------------------
+struct NsStabParams {
+  const int* elem_dof;
+  const double* coords;
+  const double *w, *phi, *dphi, *d2phi;
+  const double* sol;     // system vector [U|V|(W)|P] on the vertex nodes, or null
+  double* K;             // [nel][nd*nd]
+  double* F;             // [nel][nd]
+  int nel, nloc, ng, nq1;
+  double ire;
+};
+template <int DIM>
+__global__ __launch_bounds__(64) void k_ns_stab_elem(NsStabParams P) {
+  constexpr int NV = (DIM == 2) ? 4 : 8, NH = (DIM == 2) ? 3 : 6, ND = (DIM + 1) * NV, NT = 64, EPT = (ND * ND + NT - 1) / NT;
+  __shared__ double xv[NV * DIM], uv[(DIM + 1) * NV];
+  __shared__ double G[NV * DIM], N[NV * NH], B[NV], L[NV], Jm[DIM * DIM];
+  __shared__ double sc[64];
+  // layout of sc: u[DIM] | gu[DIM*DIM] | res[DIM] | dtau[DIM] | ddel[DIM] | p, div, tau, delta, W
+  constexpr int S_U = 0, S_GU = DIM, S_RES = DIM + DIM * DIM, S_DT = S_RES + DIM, S_DD = S_DT + DIM, S_P = S_DD + DIM, S_DIV = S_P + 1, S_TAU = S_P + 2,
+                S_DEL = S_P + 3, S_W = S_P + 4, S_HU = S_P + 5, S_GP = S_HU + DIM * NH;
+  static_assert(S_GP + DIM <= 64, "k_ns_stab_elem: scalar block");
+  const int e = blockIdx.x, tid = threadIdx.x;
+  const int* ed = P.elem_dof + (size_t)e * P.nloc;
+  for (int t = tid; t < NV * DIM; t += NT) xv[t] = P.coords[(size_t)ed[t / DIM] * DIM + t % DIM];
+  for (int t = tid; t < (DIM + 1) * NV; t += NT) uv[t] = P.sol ? P.sol[(size_t)(t / NV) * P.nq1 + ed[t % NV]] : 0.0;
+  int er[EPT], ec[EPT];
+  double acc[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; k++) {
+    const int idx = tid + k * NT;
+    er[k] = (idx < ND * ND) ? idx / ND : -1;
+    ec[k] = (idx < ND * ND) ? idx % ND : 0;
+    acc[k] = 0.0;
+  }
+  double racc = 0.0, sl = 0.0;
+  // second-derivative index of (a, b): ElemType.hpp:1232-1244 (xx, yy, xy) / :1509-1534 (xx, yy, zz, xy, yz, zx)
+  auto hidx = [](int a, int b) -> int {
+    if (a == b) return a;
+    if (DIM == 2) return 2;
+    const int s2 = a + b;
+    return s2 == 1 ? 3 : s2 == 3 ? 4 : 5;
+  };
+  __syncthreads();
+  for (int g = 0; g < P.ng; g++) {
+    const double* dph = P.dphi + (size_t)g * NV * DIM;
+    const double* ph = P.phi + (size_t)g * NV;
+    const double* d2 = P.d2phi + (size_t)g * NV * NH;
+    if (tid < DIM * DIM) {
+      const int a = tid / DIM, b = tid % DIM;
+      double s = 0.0;
+      for (int n = 0; n < NV; n++) s += dph[n * DIM + a] * xv[n * DIM + b];
+      Jm[tid] = s;
+    }
+    __syncthreads();
+    double JI[DIM][DIM], det;   // JI[b][a] = d xi_a / d x_b (the reference's JacI)
+    if (DIM == 2) {
+      det = Jm[0] * Jm[3] - Jm[1] * Jm[2];
+      const double id = 1.0 / det;
+      JI[0][0] = Jm[3] * id; JI[0][1] = -Jm[1] * id; JI[1][0] = -Jm[2] * id; JI[1][1] = Jm[0] * id;
+    } else {
+      const double a00 = Jm[0], a01 = Jm[1], a02 = Jm[2], a10 = Jm[3], a11 = Jm[4], a12 = Jm[5], a20 = Jm[6], a21 = Jm[7], a22 = Jm[8];
+      det = a00 * (a11 * a22 - a12 * a21) + a01 * (a12 * a20 - a10 * a22) + a02 * (a10 * a21 - a11 * a20);
+      const double id = 1.0 / det;
+      JI[0][0] = (a11 * a22 - a12 * a21) * id; JI[0][1] = (a02 * a21 - a01 * a22) * id; JI[0][2] = (a01 * a12 - a02 * a11) * id;
+      JI[1][0] = (a12 * a20 - a10 * a22) * id; JI[1][1] = (a00 * a22 - a02 * a20) * id; JI[1][2] = (a02 * a10 - a00 * a12) * id;
+      JI[2][0] = (a10 * a21 - a11 * a20) * id; JI[2][1] = (a01 * a20 - a00 * a21) * id; JI[2][2] = (a00 * a11 - a01 * a10) * id;
+    }
+    if (g == 0) {                  // sqrt(lambda_k) of SetLambda for LAGRANGE FIRST: hk = (scale * Weight(0) / GaussWeight(0))^(1/dim) = (scale * det)^(1/dim)
+      const double area = (DIM == 2 ? 4.0 : 8.0) * det;
+      const double hk = (DIM == 2) ? sqrt(area) : cbrt(area);
+      sl = sqrt(6.0 / (hk * hk));
+    }
+    for (int t = tid; t < NV * DIM; t += NT) {      // physical gradients
+      const int n = t / DIM, b = t % DIM;
+      double s = 0.0;
+#pragma unroll
+      for (int a = 0; a < DIM; a++) s += dph[n * DIM + a] * JI[b][a];
+      G[t] = s;
+    }
+    for (int t = tid; t < NV * NH; t += NT) {       // physical Hessians: sum_r sum_c Href[r][c] JacI[a][c] JacI[b][r] (the map's own second derivatives left out, as there)
+      const int n = t / NH, m = t % NH;
+      int a, b;
+      if (m < DIM) { a = m; b = m; }
+      else if (DIM == 2) { a = 0; b = 1; }
+      else { a = m == 3 ? 0 : m == 4 ? 1 : 2; b = m == 3 ? 1 : m == 4 ? 2 : 0; }
+      double out = 0.0;
+#pragma unroll
+      for (int r = 0; r < DIM; r++) {
+        double row = 0.0;
+#pragma unroll
+        for (int c = 0; c < DIM; c++) row += d2[n * NH + hidx(r, c)] * JI[a][c];
+        out += row * JI[b][r];
+      }
+      N[t] = out;
+    }
+    __syncthreads();
+    // solution at the Gauss point
+    if (tid < DIM) {
+      double s = 0.0;
+      for (int n = 0; n < NV; n++) s += uv[tid * NV + n] * ph[n];
+      sc[S_U + tid] = s;
+    } else if (tid < DIM + DIM * DIM) {
+      const int k = (tid - DIM) / DIM, j = (tid - DIM) % DIM;
+      double s = 0.0;
+      for (int n = 0; n < NV; n++) s += uv[k * NV + n] * G[n * DIM + j];
+      sc[S_GU + k * DIM + j] = s;
+    } else if (tid < DIM + DIM * DIM + DIM * NH) {
+      const int q = tid - DIM - DIM * DIM, k = q / NH, m = q % NH;
+      double s = 0.0;
+      for (int n = 0; n < NV; n++) s += uv[k * NV + n] * N[n * NH + m];
+      sc[S_HU + q] = s;
+    } else if (tid < DIM + DIM * DIM + DIM * NH + DIM) {
+      const int j = tid - (DIM + DIM * DIM + DIM * NH);
+      double s = 0.0;
+      for (int n = 0; n < NV; n++) s += uv[DIM * NV + n] * G[n * DIM + j];
+      sc[S_GP + j] = s;
+    } else if (tid == DIM + DIM * DIM + DIM * NH + DIM) {
+      double s = 0.0;
+      for (int n = 0; n < NV; n++) s += uv[DIM * NV + n] * ph[n];
+      sc[S_P] = s;
+      sc[S_W] = det * P.w[g];
+    }
+    __syncthreads();
+    if (tid == 0) {               // strong residual, stabilisation parameters and their derivatives with respect to u
+      const double ire = P.ire;
+      double a2 = 0.0, div = 0.0;
+      for (int k = 0; k < DIM; k++) { a2 += sc[S_U + k] * sc[S_U + k]; div += sc[S_GU + k * DIM + k]; }
+      const double an = sqrt(a2);
+      for (int k = 0; k < DIM; k++) {
+        double r = -sc[S_GP + k];
+        for (int j = 0; j < DIM; j++) r += -sc[S_U + j] * sc[S_GU + k * DIM + j] + ire * (sc[S_HU + k * NH + j] + sc[S_HU + j * NH + hidx(k, j)]);
+        sc[S_RES + k] = r;
+      }
+      const double rek = an / (4.0 * sl * ire);
+      double tau = 1.0 / (sl * sl * 4.0 * ire), del = 0.0;
+      for (int k = 0; k < DIM; k++) { sc[S_DT + k] = 0.0; sc[S_DD + k] = 0.0; }
+      if (rek > 1.0e-15) {
+        if (rek >= 1.0) {
+          tau = 1.0 / (an * sl);
+          del = an / sl;
+          for (int k = 0; k < DIM; k++) { sc[S_DT + k] = -sc[S_U + k] / (an * an * an * sl); sc[S_DD + k] = sc[S_U + k] / (an * sl); }
+        } else {                 // xi = Rek: tau = Rek / (|u| sl) = 1 / (4 sl^2 IRe), delta = Rek |u| / sl = |u|^2 / (4 sl^2 IRe)
+          tau = rek / (an * sl);
+          del = (rek * an) / sl;
+          for (int k = 0; k < DIM; k++) sc[S_DD + k] = 2.0 * sc[S_U + k] / (4.0 * sl * sl * ire);
+        }
+      }
+      sc[S_DIV] = div; sc[S_TAU] = tau; sc[S_DEL] = del;
+    }
+    if (tid >= 32 && tid < 32 + NV) {      // per node: u . grad phi and the Laplacian of phi
+      const int n = tid - 32;
+      double b = 0.0, l = 0.0;
+      for (int j = 0; j < DIM; j++) { b += sc[S_U + j] * G[n * DIM + j]; l += N[n * NH + j]; }
+      B[n] = b;
+      L[n] = l;
+    }
+    __syncthreads();
+    const double ire = P.ire, W = sc[S_W], tau = sc[S_TAU], del = sc[S_DEL], div = sc[S_DIV];
+    const double* u = sc + S_U;
+    const double* gu = sc + S_GU;
+    const double* rs = sc + S_RES;
+    const double* dt = sc + S_DT;
+    const double* dd = sc + S_DD;
+    // least-squares test factor of (component k, node i): Res_k lap phi_i + sum_n Res_n d_n d_k phi_i
+    auto lsq = [&](int k, int i, const double* r) -> double {
+      double s = r[k] * L[i];
+      for (int n = 0; n < DIM; n++) s += r[n] * N[i * NH + hidx(n, k)];
+      return s;
+    };
+#pragma unroll
+    for (int q = 0; q < EPT; q++) {
+      if (er[q] < 0) continue;
+      const int kr = er[q] / NV, i = er[q] % NV, kc = ec[q] / NV, j = ec[q] % NV;
+      double J;
+      double dres[DIM];            // d Res_n / d (this column's dof)
+      if (kc < DIM) {
+        for (int n = 0; n < DIM; n++) dres[n] = -ph[j] * gu[n * DIM + kc] + (n == kc ? -B[j] + ire * L[j] : 0.0) + ire * N[j * NH + hidx(n, kc)];
+      } else {
+        for (int n = 0; n < DIM; n++) dres[n] = -G[j * DIM + n];
+      }
+      if (kr < DIM) {
+        const int k = kr;
+        if (kc < DIM) {
+          const int c = kc;
+          double lap = 0.0;
+          for (int n = 0; n < DIM; n++) lap += G[i * DIM + n] * G[j * DIM + n];
+          J = -ph[i] * (ph[j] * gu[k * DIM + c] + (k == c ? B[j] : 0.0)) - ire * ((k == c ? lap : 0.0) + G[i * DIM + c] * G[j * DIM + k]) -
+              (dd[c] * ph[j] * div + del * G[j * DIM + c]) * G[i * DIM + k] + dres[k] * tau * B[i] +
+              rs[k] * (dt[c] * ph[j] * B[i] + tau * ph[j] * G[i * DIM + c]) - ire * dt[c] * ph[j] * lsq(k, i, rs) - ire * tau * lsq(k, i, dres);
+        } else {
+          J = ph[j] * G[i * DIM + k] + dres[k] * tau * B[i] - ire * tau * lsq(k, i, dres);
+        }
+      } else {
+        double gr = 0.0, gd = 0.0;
+        for (int n = 0; n < DIM; n++) { gr += G[i * DIM + n] * rs[n]; gd += G[i * DIM + n] * dres[n]; }
+        if (kc < DIM) J = G[j * DIM + kc] * ph[i] - dt[kc] * ph[j] * gr - tau * gd;
+        else J = -tau * gd;
+      }
+      acc[q] += -J * W;
+    }
+    if (tid < ND) {
+      const int kr = tid / NV, i = tid % NV;
+      double r;
+      if (kr < DIM) {
+        const int k = kr;
+        double adv = 0.0, lp = 0.0;
+        for (int n = 0; n < DIM; n++) { adv += u[n] * gu[k * DIM + n]; lp += G[i * DIM + n] * (gu[k * DIM + n] + gu[n * DIM + k]); }
+        r = -ph[i] * adv - ire * lp + (sc[S_P] - del * div) * G[i * DIM + k] + rs[k] * tau * B[i] - ire * tau * lsq(k, i, rs);
+      } else {
+        double gr = 0.0;
+        for (int n = 0; n < DIM; n++) gr += G[i * DIM + n] * rs[n];
+        r = div * ph[i] - tau * gr;
+      }
+      racc += r * W;
+    }
+    __syncthreads();
+  }
+  double* Ke = P.K + (size_t)e * ND * ND;
+#pragma unroll
+  for (int q = 0; q < EPT; q++)
+    if (er[q] >= 0) Ke[er[q] * ND + ec[q]] = acc[q];
+  if (tid < ND) P.F[(size_t)e * ND + tid] = racc;
+}
+
 extern "C" int fh_ns_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, int n_vertex_nodes,
                                       const double* coords, fh_mat_t A, fh_ns_assembler_t* out) {
   FH_GUARD_BEGIN
@@ -313,7 +553,7 @@ extern "C" int fh_ns_assembler_destroy(fh_ns_assembler_t as) {
   if (!as) return 0;
   hipStreamSynchronize(as->ctx->stream);
   for (void* q : {(void*)as->d_elem_dof, (void*)as->d_elem_sys, (void*)as->d_coords, (void*)as->d_w, (void*)as->d_phi, (void*)as->d_dphi,
-                  (void*)as->d_psi, (void*)as->d_K, (void*)as->d_F, (void*)as->d_adj_ptr, (void*)as->d_adj_ei})
+                  (void*)as->d_psi, (void*)as->d_K, (void*)as->d_F, (void*)as->d_adj_ptr, (void*)as->d_adj_ei, (void*)as->d_d2phi})
     if (q) hipFree(q);
   delete as;
   return 0;
@@ -343,8 +583,130 @@ static int ns_element_pass(fh_ns_assembler_t as, fh_vec_t sol, double nu) {
   return 0;
 }
 
+static int ns_stab_element_pass(fh_ns_assembler_t as, fh_vec_t sol, double ire) {
+  FH_REQUIRE(!sol || sol->n_local >= as->ndof, "navier-stokes assembly: solution vector has %d entries, the system has %d", sol ? sol->n_local : 0, as->ndof);
+  FH_REQUIRE(ire > 0.0, "navier-stokes assembly: the inverse Reynolds number must be positive");
+  NsStabParams P;
+  P.elem_dof = as->d_elem_dof;
+  P.coords = as->d_coords;
+  P.w = as->d_w;
+  P.phi = as->d_phi;
+  P.dphi = as->d_dphi;
+  P.d2phi = as->d_d2phi;
+  P.sol = sol ? sol->d : nullptr;
+  P.K = as->d_K;
+  P.F = as->d_F;
+  P.nel = as->nel;
+  P.nloc = as->nloc;
+  P.ng = as->ng;
+  P.nq1 = as->nq1;
+  P.ire = ire;
+  if (as->nel == 0) return 0;
+  if (as->dim == 2) hipLaunchKernelGGL(k_ns_stab_elem<2>, dim3(as->nel), dim3(64), 0, as->ctx->stream, P);
+  else hipLaunchKernelGGL(k_ns_stab_elem<3>, dim3(as->nel), dim3(64), 0, as->ctx->stream, P);
+  FH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// equal-order linear velocity and pressure on the vertex nodes, variables stacked [U | V | (W) | P] (each n_vertex_nodes long)
+extern "C" int fh_ns_stab_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, int n_vertex_nodes,
+                                           const double* coords, fh_mat_t A, fh_ns_assembler_t* out) {
+  FH_GUARD_BEGIN
+  FH_REQUIRE(ctx && elem_dof && coords && A && out, "fh_ns_stab_assembler_create: null argument");
+  FH_REQUIRE(geom == 0 || geom == 1, "fh_ns_stab_assembler_create: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(nloc >= fhfe::ndofs_of(geom, fhfe::FE_LINEAR), "fh_ns_stab_assembler_create: nloc %d is less than the vertices of the element", nloc);
+  fh_ns_assembler_t as = new fh_ns_assembler_s();
+  struct Guard {
+    fh_ns_assembler_t p;
+    ~Guard() { if (p) fh_ns_assembler_destroy(p); }
+  } guard{as};
+  as->ctx = ctx;
+  as->kind = 1;
+  as->geom = geom;
+  as->dim = fhfe::dim_of(geom);
+  as->nv = as->np = fhfe::ndofs_of(geom, fhfe::FE_LINEAR);
+  as->nd = (as->dim + 1) * as->nv;
+  as->nloc = nloc;
+  as->nel = nel;
+  as->nnode = nnode;
+  as->nq1 = n_vertex_nodes;
+  as->ndof = (as->dim + 1) * n_vertex_nodes;
+  FH_REQUIRE(A->m == as->ndof && A->n == as->ndof, "fh_ns_stab_assembler_create: matrix is %d x %d, the system has %d rows", A->m, A->n, as->ndof);
+  std::vector<double> w, phi, dphi;
+  FH_REQUIRE(fhfe::shape_tables(geom, fhfe::FE_LINEAR, gauss_order, w, phi, dphi) == 0, "fh_ns_stab_assembler_create: unsupported Gauss rule %d", gauss_order);
+  as->ng = (int)w.size();
+  const int nd = as->nd, nv = as->nv, nh = as->dim == 2 ? 3 : 6;
+  std::vector<double> d2t((size_t)nh * as->ng * nv), d2((size_t)as->ng * nv * nh);
+  FH_TRY(fh_fe_tables_d2(geom, fhfe::FE_LINEAR, gauss_order, d2t.data()));       // one [ng][nv] table per second derivative -> [ng][nv][nh]
+  for (int k = 0; k < nh; k++)
+    for (int g = 0; g < as->ng; g++)
+      for (int j = 0; j < nv; j++) d2[((size_t)g * nv + j) * nh + k] = d2t[((size_t)k * as->ng + g) * nv + j];
+  std::vector<int> es((size_t)nel * nd);
+  for (int e = 0; e < nel; e++) {
+    const int* ed = elem_dof + (size_t)e * nloc;
+    for (int i = 0; i < nv; i++) FH_REQUIRE(ed[i] >= 0 && ed[i] < n_vertex_nodes, "fh_ns_stab_assembler_create: vertex node %d is not a linear dof", ed[i]);
+    int p = 0;
+    for (int k = 0; k <= as->dim; k++)
+      for (int i = 0; i < nv; i++) es[(size_t)e * nd + p++] = k * n_vertex_nodes + ed[i];
+  }
+  std::vector<int> aptr(as->ndof + 1, 0);
+  for (size_t k = 0; k < es.size(); k++) aptr[es[k] + 1]++;
+  for (int r = 0; r < as->ndof; r++) aptr[r + 1] += aptr[r];
+  FH_REQUIRE((int64_t)nel * nd < 2147483647ll, "fh_ns_stab_assembler_create: too many element rows");
+  std::vector<int> aei(aptr[as->ndof]), cur(aptr.begin(), aptr.end() - 1);
+  for (int e = 0; e < nel; e++)
+    for (int i = 0; i < nd; i++) aei[cur[es[(size_t)e * nd + i]]++] = e * nd + i;
+  for (int e = 0; e < nel; e++)
+    for (int i = 0; i < nd; i++) {
+      const int r = es[(size_t)e * nd + i];
+      for (int j = 0; j < nd; j++) {
+        const int c = es[(size_t)e * nd + j];
+        FH_REQUIRE(std::binary_search(fh_hcol(A).begin() + A->h_rowptr[r], fh_hcol(A).begin() + A->h_rowptr[r + 1], c),
+                   "fh_ns_stab_assembler_create: entry (%d, %d) is not in the matrix pattern", r, c);
+      }
+    }
+  as->max_row = A->max_row;
+  if (as->max_row == 0)
+    for (int r = 0; r < A->m; r++) as->max_row = std::max(as->max_row, A->h_rowptr[r + 1] - A->h_rowptr[r]);
+  FH_REQUIRE((size_t)as->max_row * sizeof(double) <= 64 * 1024, "fh_ns_stab_assembler_create: rows of %d entries exceed the LDS accumulator", as->max_row);
+  auto up = [&](void** d, const void* h, size_t bytes) -> int {
+    FH_CHECK_HIP(hipMalloc(d, bytes ? bytes : 8));
+    if (bytes) FH_CHECK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+    return 0;
+  };
+  FH_TRY(up((void**)&as->d_elem_dof, elem_dof, (size_t)nel * nloc * sizeof(int)));
+  FH_TRY(up((void**)&as->d_elem_sys, es.data(), es.size() * sizeof(int)));
+  FH_TRY(up((void**)&as->d_coords, coords, (size_t)nnode * as->dim * sizeof(double)));
+  FH_TRY(up((void**)&as->d_w, w.data(), w.size() * sizeof(double)));
+  FH_TRY(up((void**)&as->d_phi, phi.data(), phi.size() * sizeof(double)));
+  FH_TRY(up((void**)&as->d_dphi, dphi.data(), dphi.size() * sizeof(double)));
+  FH_TRY(up((void**)&as->d_d2phi, d2.data(), d2.size() * sizeof(double)));
+  FH_TRY(up((void**)&as->d_adj_ptr, aptr.data(), aptr.size() * sizeof(int)));
+  FH_TRY(up((void**)&as->d_adj_ei, aei.data(), aei.size() * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&as->d_K, std::max<size_t>((size_t)nel * nd * nd, 1) * sizeof(double)));
+  FH_CHECK_HIP(hipMalloc(&as->d_F, std::max<size_t>((size_t)nel * nd, 1) * sizeof(double)));
+  guard.p = nullptr;
+  *out = as;
+  return 0;
+  FH_GUARD_END("fh_ns_stab_assembler_create")
+}
+
+extern "C" int fh_assemble_navier_stokes_stab(fh_ns_assembler_t as, fh_vec_t sol, double inverse_reynolds, fh_mat_t A, fh_vec_t res) {
+  FH_REQUIRE(as && A && res, "fh_assemble_navier_stokes_stab: null argument");
+  FH_REQUIRE(as->kind == 1, "fh_assemble_navier_stokes_stab: this assembler was created for the Taylor-Hood form (fh_assemble_navier_stokes)");
+  FH_REQUIRE(A->m == as->ndof && res->n_local >= as->ndof, "fh_assemble_navier_stokes_stab: size mismatch");
+  FH_TRY(ns_stab_element_pass(as, sol, inverse_reynolds));
+  if (as->ndof > 0)
+    hipLaunchKernelGGL(k_sys_row_gather, dim3(as->ndof), dim3(64), (size_t)as->max_row * sizeof(double), as->ctx->stream, as->d_adj_ptr, as->d_adj_ei,
+                       as->d_elem_sys, as->d_K, as->d_F, as->nd, A->d_rowptr, A->d_col, A->d_val, res->d, as->ndof);
+  FH_CHECK_HIP(hipGetLastError());
+  A->at_valid = false;
+  return 0;
+}
+
 extern "C" int fh_assemble_navier_stokes(fh_ns_assembler_t as, fh_vec_t sol, double nu, fh_mat_t A, fh_vec_t res) {
   FH_REQUIRE(as && A && res, "fh_assemble_navier_stokes: null argument");
+  FH_REQUIRE(as->kind == 0, "fh_assemble_navier_stokes: this assembler was created for the stabilised equal-order form (fh_assemble_navier_stokes_stab)");
   FH_REQUIRE(A->m == as->ndof && res->n_local >= as->ndof, "fh_assemble_navier_stokes: size mismatch");
   FH_TRY(ns_element_pass(as, sol, nu));
   if (as->ndof > 0)
@@ -357,7 +719,8 @@ extern "C" int fh_assemble_navier_stokes(fh_ns_assembler_t as, fh_vec_t sol, dou
 
 extern "C" int fh_ns_element_matrices(fh_ns_assembler_t as, fh_vec_t sol, double nu, double* K, double* F) {
   FH_REQUIRE(as && K && F, "fh_ns_element_matrices: null argument");
-  FH_TRY(ns_element_pass(as, sol, nu));
+  if (as->kind == 1) FH_TRY(ns_stab_element_pass(as, sol, nu));
+  else FH_TRY(ns_element_pass(as, sol, nu));
   FH_CHECK_HIP(hipMemcpyAsync(K, as->d_K, (size_t)as->nel * as->nd * as->nd * sizeof(double), hipMemcpyDeviceToHost, as->ctx->stream));
   FH_CHECK_HIP(hipMemcpyAsync(F, as->d_F, (size_t)as->nel * as->nd * sizeof(double), hipMemcpyDeviceToHost, as->ctx->stream));
   FH_CHECK_HIP(hipStreamSynchronize(as->ctx->stream));

@@ -378,6 +378,15 @@ int fh_ns_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, int nel, int
 int fh_ns_assembler_destroy(fh_ns_assembler_t as);
 int fh_assemble_navier_stokes(fh_ns_assembler_t as, fh_vec_t sol, double nu, fh_mat_t A, fh_vec_t res);
 int fh_ns_element_matrices(fh_ns_assembler_t as, fh_vec_t sol, double nu, double* K /* [nel*nd*nd] */, double* F /* [nel*nd] */);
+/* The callback applications/003_NavierStokes/SteadyNavierStokesParallel ships (main.cpp:390-925): EQUAL-ORDER LAGRANGE FIRST velocity and pressure on the
+ * vertex nodes with the Franca-Frey stabilisation (:677-868; sqrt(lambda_k) = sqrt(6) / h_k as SetLambda stores it for LAGRANGE FIRST, :1070-1082, :1262).
+ * Variables [U | V | (W) | P], each n_vertex_nodes long; elem_dof rows need the element's vertices first.  res receives Rhs = aRhs, A the matrix
+ * KKloc = -d aRhs / d Soli (:884-910; the reference's adept tape, written out here -- including the derivatives of the stabilisation parameters).
+ * inverse_reynolds = the IRe of the call; the application's continuation (:485-489) is the caller's (adapters: HipNavierStokes helpers).
+ * fh_ns_element_matrices and fh_ns_assembler_destroy serve both kinds of assembler. */
+int fh_ns_stab_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, int n_vertex_nodes,
+                                const double* coords /* [nnode*dim] */, fh_mat_t A, fh_ns_assembler_t* as);
+int fh_assemble_navier_stokes_stab(fh_ns_assembler_t as, fh_vec_t sol, double inverse_reynolds, fh_mat_t A, fh_vec_t res);
 
 /* ---- multigrid: LinearEquationSolver (03_solvers/LinearEquationSolver.hpp:54-261, LinearEquationSolverPetsc.cpp) ----
  * fh_mg_create      <- MGInit   (:185-215)   nlevels, outer solver

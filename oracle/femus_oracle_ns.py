@@ -453,3 +453,139 @@ def solve_cavity(nx, ny, nlevels, nu, lo=(-0.5, -0.5, 0.0), hi=(0.5, 0.5, 0.0), 
             P = block_prolongator(ms[igrid], ms[igrid + 1], layc, layf)
             sols[igrid + 1] = P @ sols[igrid]
     return ms, lays, sols, history
+
+
+# ================================================================================================================
+# The callback the APPLICATION ships: applications/003_NavierStokes/SteadyNavierStokesParallel/main.cpp:390-925 -- equal-order LAGRANGE FIRST
+# velocity and pressure (:98-108) with the Franca-Frey stabilisation (`FrancaAndFrey = !Tezduyare`, :677-868; the Tezduyar branch :585-676 is
+# compiled out by `bool Tezduyare = 0`).  Restated statement by statement (vectorised over the elements, Gauss points and nodes in the reference's
+# order); the Jacobian the reference takes from adept's tape (:895-910, KKloc = -d aRhs / d Soli) is taken here by COMPLEX-STEP differentiation of
+# the restated residual -- exact to rounding like the tape, and checked against central differences in tests/test_ns_host.py.
+#   sqrtlambdak (:735) = the per-element value SetLambda stores (:943-1262); for LAGRANGE FIRST its Gauss loop breaks after the first point
+#   (:1082 `if (0 == SolType) break`): lambdak = 6 / hk^2, hk = (referenceElementScale * Weight(0) / GaussWeight(0))^(1/dim)
+#   Reynolds continuation (:485-489): the callback counts its own calls, IRe = 1 / min((1 + 5 c^2)(c + 1), 10000)
+# ================================================================================================================
+class NSLayoutEqualOrder:
+    """variables U, V (, W), P all on ONE Lagrange family (the application: linear); system dof = offset[k] + mesh dof (nprocs = 1)"""
+
+    def __init__(self, mesh, fe="linear"):
+        self.dim, self.fe = mesh.dim, fe
+        self.nv = self.npr = fo.ndofs(mesh.geom, fe)
+        nq = fo.n_dofs(mesh, fe)
+        self.sizes = [nq] * (self.dim + 1)
+        self.offset = np.concatenate([[0], np.cumsum(self.sizes)])
+        self.n = int(self.offset[-1])
+        self.nd = (self.dim + 1) * self.nv
+        ed = mesh.elem_dof[:, :self.nv]
+        self.elem_sys = np.concatenate([ed + self.offset[k] for k in range(self.dim + 1)], axis=1)
+
+
+def reynolds_of_call(counter):
+    """IRe the callback uses at its `counter`-th call (main.cpp:485-489)"""
+    dre = 1 + (counter * counter) * 5
+    return 1.0 / (dre * (counter + 1)) if dre * (counter + 1) < 10000 else 1.0 / 10000.0
+
+
+def _stab_geometry(et, X):
+    """weights, gradients, Hessians (ElemType.hpp:1183-1248 / :1438-1537, geometry = the FE's own nodes), sqrt(lambda_k)"""
+    dim, nc = et.dim, et.nc
+    Jm = np.einsum("gna,ebn->egab", et.dphi, X[:, :, :nc])
+    det = np.linalg.det(Jm)
+    JacI = np.linalg.inv(Jm)                                   # the reference's JacI: gradphi[n][a] = sum_c dphi[n][c] JacI[a][c]
+    grad = np.einsum("gnc,egac->egna", et.dphi, JacI)          # d phi_n / d x_a
+    nh = 3 if dim == 2 else 6
+    pairs = [(0, 0), (1, 1), (0, 1)] if dim == 2 else [(0, 0), (1, 1), (2, 2), (0, 1), (1, 2), (2, 0)]
+    h = et.d2phi                                               # [g, n, nh]
+    if dim == 2:
+        Href = np.stack([np.stack([h[..., 0], h[..., 2]], -1), np.stack([h[..., 2], h[..., 1]], -1)], -2)          # [g, n, r, c]
+    else:
+        Href = np.stack([np.stack([h[..., 0], h[..., 3], h[..., 5]], -1), np.stack([h[..., 3], h[..., 1], h[..., 4]], -1),
+                         np.stack([h[..., 5], h[..., 4], h[..., 2]], -1)], -2)
+    nabla = np.stack([np.einsum("gnrc,egc,egr->egn", Href, JacI[:, :, a, :], JacI[:, :, b, :]) for a, b in pairs], -1)      # [e, g, n, nh]
+    w = det * et.w[None, :]
+    ref_scale = {"quad": 4.0, "hex": 8.0}[et.geom]
+    hk = (ref_scale * w[:, 0] / et.w[0]) ** (1.0 / dim)
+    return w, grad, nabla, np.sqrt(6.0 / (hk * hk)), pairs
+
+
+def _stab_residual(et, geo, U, P, IRe):
+    """aRhs of main.cpp:677-868 for all elements: U[nel, dim, nv], P[nel, nv] (real or complex) -> aRhs[nel, (dim + 1) * nv]"""
+    w, grad, nabla, sqrtlam, pairs = geo
+    dim, nv, ng = et.dim, et.nc, et.ng
+    nel = U.shape[0]
+    kv = lambda i, j: i if i == j else [p for p in range(dim, len(pairs)) if set(pairs[p]) == {i, j}][0]          # :705-709 xy / xz / yz
+    aR = np.zeros((nel, dim + 1, nv), dtype=U.dtype)
+    for g in range(ng):
+        phi = et.phi[g]
+        G, N, W = grad[:, g], nabla[:, g], w[:, g]
+        Sol = np.einsum("ekn,n->ek", U, phi)
+        Gs = np.einsum("ekn,enj->ekj", U, G)
+        Ns = np.einsum("ekn,enm->ekm", U, N)
+        Sp = P @ phi
+        Gp = np.einsum("en,enj->ej", P, G)
+        aL2 = np.sqrt(sum(Sol[:, i] * Sol[:, i] for i in range(dim)))
+        tau = 1.0 / (sqrtlam * sqrtlam * 4.0 * IRe) * np.ones(nel, dtype=U.dtype)
+        delta = np.zeros(nel, dtype=U.dtype)
+        Rek = aL2 / (4.0 * sqrtlam * IRe)
+        on = Rek.real > 1.0e-15
+        xi = np.where(Rek.real >= 1.0, 1.0, Rek)
+        safe = np.where(on, aL2, 1.0)
+        tau = np.where(on, xi / (safe * sqrtlam), tau)
+        delta = np.where(on, (xi * aL2) / sqrtlam, delta)
+        Res = np.zeros((nel, dim), dtype=U.dtype)
+        for i in range(dim):
+            Res[:, i] += 0.0 - Gp[:, i]
+            for j in range(dim):
+                Res[:, i] += -Sol[:, j] * Gs[:, i, j] + IRe * (Ns[:, i, j] + Ns[:, j, kv(i, j)])
+        div = sum(Gs[:, i, i] for i in range(dim))
+        for i in range(dim):
+            adv = sum(Sol[:, j] * Gs[:, i, j] for j in range(dim))[:, None] * phi[None, :]
+            lap = sum(IRe * G[:, :, j] * (Gs[:, i, j] + Gs[:, j, i])[:, None] for j in range(dim))
+            supg = sum(Sol[:, j][:, None] * G[:, :, j] for j in range(dim)) * tau[:, None]
+            for j in range(dim):
+                aR[:, i] += (Res[:, i] * tau * W)[:, None] * (-IRe * N[:, :, j])              # only in least square
+                aR[:, j] += (Res[:, i] * tau * W)[:, None] * (-IRe * N[:, :, kv(i, j)])
+            aR[:, i] += (-adv - lap + (Sp - delta * div)[:, None] * G[:, :, i] + Res[:, i][:, None] * supg) * W[:, None]
+        mg = sum(-G[:, :, i] * (Res[:, i] * tau)[:, None] for i in range(dim))
+        aR[:, dim] += (div[:, None] * phi[None, :] + mg) * W[:, None]
+    return aR.reshape(nel, (dim + 1) * nv)
+
+
+def elem_ns_stab_batch(et, X, U, P, IRe):
+    """element residual and matrix of the application's callback: Rhs = aRhs (added to RES, :884-893), KKloc = -d aRhs / d Soli (:895-910).
+    X[nel, dim, >= nv] node coordinates, U[nel, dim, nv], P[nel, nv] -> KK[nel, nd, nd], Rhs[nel, nd]"""
+    geo = _stab_geometry(et, X)
+    dim, nv = et.dim, et.nc
+    nd = (dim + 1) * nv
+    nel = X.shape[0]
+    Rhs = _stab_residual(et, geo, U.astype(float), P.astype(float), IRe)
+    KK = np.zeros((nel, nd, nd))
+    hstep = 1e-30
+    for c in range(nd):
+        Uc, Pc = U.astype(complex), P.astype(complex)
+        if c < dim * nv:
+            Uc[:, c // nv, c % nv] += 1j * hstep
+        else:
+            Pc[:, c - dim * nv] += 1j * hstep
+        KK[:, :, c] = -_stab_residual(et, geo, Uc, Pc, IRe).imag / hstep
+    return KK, Rhs
+
+
+def assemble_ns_stab(mesh, lay, sol, IRe, order="seventh", pattern=None):
+    et = fo.ElemType(mesh.geom, lay.fe, order)
+    X = np.transpose(mesh.coords[mesh.elem_dof], (0, 2, 1))
+    es = lay.elem_sys
+    nv, dim = lay.nv, lay.dim
+    loc = sol[es]
+    KK, Rhs = elem_ns_stab_batch(et, X, loc[:, :dim * nv].reshape(mesh.nel, dim, nv), loc[:, dim * nv:], IRe)
+    if pattern is None:
+        pattern = csr_pattern_sys(lay)
+    indptr, indices = pattern
+    vals = np.zeros(indices.size)
+    rows = np.repeat(es, lay.nd, axis=1).ravel()
+    cols = np.tile(es, (1, lay.nd)).ravel()
+    pos = fo._csr_positions(indptr, indices, rows, cols)
+    np.add.at(vals, pos, KK.ravel())
+    b = np.zeros(lay.n)
+    np.add.at(b, es.ravel(), Rhs.ravel())
+    return sp.csr_matrix((vals, indices, indptr), shape=(lay.n, lay.n)), b

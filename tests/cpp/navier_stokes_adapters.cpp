@@ -3,7 +3,10 @@
 // FEMuS_ASM solver type for the level smoothers (SteadyNavierStokesParallel/main.cpp:166-167, 187-188), the cavity boundary
 // conditions of main.cpp:365-390, and the batched Taylor-Hood residual/Jacobian call in place of the adept callback.
 // Mesh, dof maps and element blocks (FEMuS-owned in a real build) come from the C-ABI mesh helpers.
-//   usage: navier_stokes_adapters n nlevels nu out.bin
+// With the last argument `stab` = 1 the run is the application's own discretisation (main.cpp:96-108, :390-925): equal-order LAGRANGE FIRST velocity and
+// pressure, the Franca-Frey stabilised callback (fh_assemble_navier_stokes_stab) and the Reynolds continuation of the callback's call counter (:485-489;
+// `nu` is ignored).  The application erases its coarse levels (:92: ONE level, every linear solve the exact one): nlevels = 1 is its real configuration.
+//   usage: navier_stokes_adapters n nlevels nu out.bin [nschur nblock lsolver outer_pre coloured stab]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -35,7 +38,9 @@ int main(int argc, char** argv) {
   const double nu = atof(argv[3]);
   const int nschur = argc > 5 ? atoi(argv[5]) : 0, nblock = argc > 6 ? atoi(argv[6]) : 4, lsolver = argc > 7 ? atoi(argv[7]) : 0, outer_pre = argc > 8 ? atoi(argv[8]) : 0,
             coloured = argc > 9 ? atoi(argv[9]) : 0;     // 1: the library's own block smoother (exact inverses in colour order) instead of PCASM as the reference sets it
-  const int geom = 1, nvars = 3, fe[3] = {2, 2, 0};
+  const int stab = argc > 10 ? atoi(argv[10]) : 0;       // 1: the application's equal-order stabilised callback with its Reynolds continuation
+  const int geom = 1, nvars = 3;
+  const int fe[3] = {stab ? 0 : 2, stab ? 0 : 2, 0};
   const char names[3] = {'U', 'V', 'P'};
   const double lo[3] = {-0.5, -0.5, 0}, hi[3] = {0.5, 0.5, 1};
   std::vector<fh_mesh_t> msh(nlev);
@@ -45,7 +50,7 @@ int main(int argc, char** argv) {
   std::vector<LinearEquationSolver*> LinSolver(nlev);
   std::vector<Mesh*> fmesh(nlev);           // FEMuS-owned in a real build: dof offsets of the families, Solution with the _Bdc flag vectors
   std::vector<Solution*> fsol(nlev);
-  std::vector<unsigned> SolPdeIndex = {0u, 1u, 2u}, SolType = {2u, 2u, 0u};
+  std::vector<unsigned> SolPdeIndex = {0u, 1u, 2u}, SolType = {stab ? 0u : 2u, stab ? 0u : 2u, 0u};
   char nU[] = "U", nV[] = "V", nP[] = "P";
   std::vector<char*> SolName = {nU, nV, nP};
   std::vector<bool> sparsity;
@@ -115,7 +120,8 @@ int main(int argc, char** argv) {
     fh_mat_t K;
     hip_check(fh_mat_create_csr(hip_context(), ndof, ndof, rp.data(), col.data(), nullptr, &K), "KK");
     static_cast<HipMatrix*>(ls->_KK)->adopt(K);
-    hip_check(fh_ns_assembler_create(hip_context(), geom, 3, nel, nloc, ed.data(), nnode, own[0], xy.data(), K, &as[l]), "assembler");
+    if (stab) hip_check(fh_ns_stab_assembler_create(hip_context(), geom, 3, nel, nloc, ed.data(), nnode, own[0], xy.data(), K, &as[l]), "assembler");
+    else hip_check(fh_ns_assembler_create(hip_context(), geom, 3, nel, nloc, ed.data(), nnode, own[0], xy.data(), K, &as[l]), "assembler");
     // GenerateBdc: boundary faces in element order, nodes of the face, boundary function at the node
     std::map<int, double> val;
     for (int k = 0; k < nvars; k++) {
@@ -168,13 +174,24 @@ int main(int argc, char** argv) {
   // ---- NonLinearImplicitSystem::MGsolve, F_CYCLE --------------------------------------------------------------------------
   std::vector<unsigned> vars = {0, 1, 2};
   int total_newton = 0, max_linear = 0;
+  unsigned counter = 0;                  // the callback's own call counter (main.cpp:387, :485-489)
   for (int ig = 0; ig < nlev; ig++) {
     for (int it = 0; it < (outer_pre == 1 ? 90 : 30); it++) {          // SetMaxNumberOfNonLinearIterations(90) in the application
       LinearEquationSolver* top = LinSolver[ig];
       top->SetResZero();
-      hip_check(fh_assemble_navier_stokes(as[ig], static_cast<HipVector*>(Sol[ig])->handle(), nu, static_cast<HipMatrix*>(top->_KK)->handle(),
-                                          static_cast<HipVector*>(top->_RES)->handle()),
-                "assemble");
+      double IRe = nu;
+      if (stab) {
+        const double DRe = 1 + (counter * counter) * 5;
+        IRe = (DRe * (counter + 1) < 10000) ? 1. / (DRe * (counter + 1)) : 1. / 10000.;
+        std::cout << "iteration=" << counter << " Reynolds Number = " << 1. / IRe << std::endl;
+        counter++;
+        hip_check(fh_assemble_navier_stokes_stab(as[ig], static_cast<HipVector*>(Sol[ig])->handle(), IRe, static_cast<HipMatrix*>(top->_KK)->handle(),
+                                                 static_cast<HipVector*>(top->_RES)->handle()),
+                  "assemble");
+      } else
+        hip_check(fh_assemble_navier_stokes(as[ig], static_cast<HipVector*>(Sol[ig])->handle(), nu, static_cast<HipMatrix*>(top->_KK)->handle(),
+                                            static_cast<HipVector*>(top->_RES)->handle()),
+                  "assemble");
       for (int i = ig; i > 0; i--) LinSolver[i - 1]->_KK->matrix_PtAP(*PP[i], *LinSolver[i]->_KK, it > 0);
       if (outer_pre == 1) {
         // SteadyNavierStokesParallel/main.cpp:148-185: SetOuterSolver(PREONLY), one pre- and one post-smoothing step, at most two
@@ -209,7 +226,7 @@ int main(int argc, char** argv) {
         worst = std::max(worst, std::sqrt(ne) / (std::sqrt(ns) + 1.e-50));
       }
       std::cout << "     ********* Level Max " << ig + 1 << " Nonlinear iteration " << it + 1 << " Eps_l2norm/Sol_l2norm = " << worst << std::endl;
-      if (worst < 1.e-10) break;
+      if (worst < 1.e-10 && (!stab || IRe == 1. / 10000.)) break;          // (the continuation has to have reached its final Reynolds number)
     }
     if (ig + 1 < nlev) Sol[ig + 1]->matrix_mult(*Sol[ig], *PPsol[ig + 1]);                    // ProlongatorSol
   }

@@ -110,3 +110,74 @@ def test_open_boundary_pressure_integral_properties(box):
     nrm = capi.face_normals(mh, "biquadratic", faces, 0)
     assert abs(nrm[:, 0] - 1.0).max() <= 1e-14 and abs(nrm[:, 1:]).max() <= 1e-14
     mh.destroy()
+
+
+def test_stabilised_equal_order_callback_of_the_application():
+    """main.cpp:390-925 (Q1/Q1, Franca-Frey): the restated residual in vectorised form equals a plain loop restatement written beside the source, its
+    complex-step Jacobian equals central differences, both branches of the stabilisation parameter (Rek < 1 and Rek >= 1) are met, and the Reynolds
+    continuation of the callback's own counter (:485-489) gives 1, 12, 63, 184, ... capped at 10000"""
+    assert [round(1.0 / ns.reynolds_of_call(c)) for c in range(5)] == [1, 12, 63, 184, 405] and ns.reynolds_of_call(40) == 1e-4
+    for box in ((3, 2, 0), (2, 1, 2)):
+        m = fo.build_levels(*box, 1, (-0.5, -0.5, 0.0), (0.5, 0.5, 0.5))[0]
+        rng = np.random.default_rng(1)
+        m.coords = m.coords + 0.03 * rng.standard_normal(m.coords.shape)
+        et = fo.ElemType(m.geom, "linear")
+        dim, nv = et.dim, et.nc
+        X = np.transpose(m.coords[m.elem_dof], (0, 2, 1))
+        lay = ns.NSLayoutEqualOrder(m)
+        loc = (0.4 * rng.standard_normal(lay.n))[lay.elem_sys]
+        U, Pr = loc[:, :dim * nv].reshape(m.nel, dim, nv), loc[:, dim * nv:]
+        geo = ns._stab_geometry(et, X)
+        branches = set()
+        for ire in (1.0, 1e-2, 1e-4):
+            KK, Rhs = ns.elem_ns_stab_batch(et, X, U, Pr, ire)
+            # plain loops over one element, statement by statement as in the source
+            e = m.nel // 2
+            nh = 3 if dim == 2 else 6
+            aR = np.zeros((dim + 1, nv))
+            kvar = lambda i, j: i if i == j else (dim if i + j == 1 else dim + 2 if i + j == 2 else dim + 1)
+            hk = None
+            for ig in range(et.ng):
+                W, phi, gp, nb = et.jacobian(X[e], ig, nabla=True)
+                gp, nb = gp.reshape(nv, dim), nb.reshape(nv, nh)
+                if ig == 0:
+                    hk = ({"quad": 4.0, "hex": 8.0}[m.geom] * W / et.w[0]) ** (1.0 / dim)
+                sl = np.sqrt(6.0 / (hk * hk))
+                Sol = [U[e, i] @ phi for i in range(dim)] + [Pr[e] @ phi]
+                Gs = [[U[e, i] @ gp[:, j] for j in range(dim)] for i in range(dim)] + [[Pr[e] @ gp[:, j] for j in range(dim)]]
+                Ns = [[U[e, i] @ nb[:, j] for j in range(nh)] for i in range(dim)]
+                aL2 = np.sqrt(sum(Sol[i] ** 2 for i in range(dim)))
+                tau, delta = 1.0 / (sl * sl * 4.0 * ire), 0.0
+                Rek = aL2 / (4.0 * sl * ire)
+                if Rek > 1e-15:
+                    xi = 1.0 if Rek >= 1.0 else Rek
+                    branches.add(Rek >= 1.0)
+                    tau, delta = xi / (aL2 * sl), (xi * aL2) / sl
+                Res = [0.0 - Gs[dim][i] + sum(-Sol[j] * Gs[i][j] + ire * (Ns[i][j] + Ns[j][kvar(i, j)]) for j in range(dim)) for i in range(dim)]
+                div = sum(Gs[i][i] for i in range(dim))
+                for i in range(nv):
+                    for iv in range(dim):
+                        adv = lap = supg = 0.0
+                        for jv in range(dim):
+                            adv += Sol[jv] * Gs[iv][jv] * phi[i]
+                            lap += ire * gp[i, jv] * (Gs[iv][jv] + Gs[jv][iv])
+                            supg += (Sol[jv] * gp[i, jv]) * tau
+                            aR[iv, i] += Res[iv] * (-ire * nb[i, jv]) * tau * W
+                            aR[jv, i] += Res[iv] * (-ire * nb[i, kvar(iv, jv)]) * tau * W
+                        aR[iv, i] += (-adv - lap + (Sol[dim] - delta * div) * gp[i, iv] + Res[iv] * supg) * W
+                for i in range(nv):
+                    aR[dim, i] += (-(-div) * phi[i] + sum(-gp[i, iv] * Res[iv] * tau for iv in range(dim))) * W
+            assert abs(aR.ravel() - Rhs[e]).max() <= 1e-13 * abs(Rhs[e]).max()
+            h = 1e-6
+            J = np.zeros_like(KK)
+            for c in range((dim + 1) * nv):
+                Up, Pp, Um, Pm = U.copy(), Pr.copy(), U.copy(), Pr.copy()
+                if c < dim * nv:
+                    Up[:, c // nv, c % nv] += h
+                    Um[:, c // nv, c % nv] -= h
+                else:
+                    Pp[:, c - dim * nv] += h
+                    Pm[:, c - dim * nv] -= h
+                J[:, :, c] = -(ns._stab_residual(et, geo, Up, Pp, ire) - ns._stab_residual(et, geo, Um, Pm, ire)) / (2 * h)
+            assert abs(KK - J).max() <= 1e-8 * abs(KK).max()
+        assert branches == {True, False}
