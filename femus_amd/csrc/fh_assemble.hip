@@ -50,6 +50,7 @@ struct fh_assembler_s {
   uint64_t gal_key = 0;          // hash of (children, fine / coarse Dirichlet nodes) the tables below were made from
   bool gal_children_in_order = false;      // child j of coarse element E is fine element 8 * (its cluster) + j
   unsigned char *d_gal_cnt = nullptr, *d_gal_row = nullptr, *d_gal_fb = nullptr, *d_gal_cb = nullptr;
+  unsigned* d_gal_fmask = nullptr;     // [nel * 8] Dirichlet bits of the children's nodes, then [nel] of the coarse element's (k_galerkin_macro)
   double *d_gal_val = nullptr, *d_gal_res = nullptr, *d_gal_dense = nullptr;
   int kstride = 27;              // doubles per element row in d_Kbuf (nc, or 32 for HEX27/Q2: whole 64-byte lines per row)
   double* d_Fbuf = nullptr;      // [nadj]
@@ -3292,7 +3293,8 @@ extern "C" int fh_assembler_destroy(fh_assembler_t as) {
                   (void*)as->d_Pbuf, (void*)as->d_cl_prow, (void*)as->d_cl_pstart})
     if (q) hipFree(q);
   for (void* q : {(void*)as->d_adj_ptr, (void*)as->d_adj_ei, (void*)as->d_rowmap, (void*)as->d_Kbuf, (void*)as->d_Fbuf, (void*)as->d_slot, (void*)as->d_gal_child,
-                  (void*)as->d_gal_cnt, (void*)as->d_gal_row, (void*)as->d_gal_fb, (void*)as->d_gal_cb, (void*)as->d_gal_val, (void*)as->d_gal_res, (void*)as->d_gal_dense})
+                  (void*)as->d_gal_cnt, (void*)as->d_gal_row, (void*)as->d_gal_fb, (void*)as->d_gal_cb, (void*)as->d_gal_val, (void*)as->d_gal_res, (void*)as->d_gal_dense,
+                  (void*)as->d_gal_fmask})
     if (q) hipFree(q);
   delete as;
   return 0;
@@ -3762,38 +3764,69 @@ static size_t galerkin_mfma_lds() {
 // Between the assembly and this product only Dirichlet ROWS of the fine matrix may have been replaced (SetPenalty): they are masked here anyway.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int GMAC_NW = 8, GMAC_T = GMAC_NW * 64;
-constexpr int GMAC_KP = 28, GMAC_LD = 32, GMAC_KLD = 29;
-constexpr int GMAC_WS = 32 * GMAC_KLD;                                  // scratch per wave: K~_j [32][29], then T [28][32], then the wave's result [27][28]
+constexpr int GMAC_KP = 28;                                             // K of the two products, padded to the matrix instruction's 4
 constexpr int GMAC_TN = 4928;                                           // template entries (4913), padded
-constexpr size_t gmac_lds_bytes() { return ((size_t)GMAC_NW * GMAC_KP * GMAC_LD + GMAC_TN + (size_t)GMAC_NW * GMAC_WS) * sizeof(double) + CL_NM_MAX * sizeof(unsigned long long) + 32 * sizeof(int); }
+constexpr int GMAC_RS = 27 * 28;                                        // one wave's result [27][28]
+constexpr int GMAC_BUF = GMAC_NW * GMAC_RS > GMAC_TN ? GMAC_NW * GMAC_RS : GMAC_TN;      // the macro matrix, then the eight results (same region)
+constexpr size_t gmac_lds_bytes() { return (size_t)GMAC_BUF * sizeof(double) + CL_NM_MAX * sizeof(unsigned long long) + 32 * sizeof(int); }
 static_assert(gmac_lds_bytes() <= 160 * 1024, "k_galerkin_macro: LDS budget");
-static_assert(GMAC_WS >= GMAC_KP * GMAC_LD && GMAC_WS >= 27 * 28, "k_galerkin_macro: the wave scratch holds T and the result");
 
+// Operands in registers (second form of the round; the first staged K~_j, C_j and T through LDS like k_galerkin_mfma and took 1.0 ms against that kernel's
+// 0.86): wave j always serves child j, so its fragments of C_j -- B operand of T = K~_j C_j AND A operand of R = C_j^T T, the same values -- and the
+// template indices of its K~_j fragments are loop invariant (14 doubles + 14 indices per lane); T leaves the first product in exactly the lanes the second
+// product wants it as B operand (row 4 m + kk of T = accumulator m / 4, register m % 4 of lane (kk, li)): no LDS round trip between the two products.
+// Dirichlet masks of the children's and of the coarse element's 27 nodes (bit = local node), once per hierarchy: the product kernel then needs no chain
+// of dependent look-ups (children -> element dofs -> flags) per cluster
+__global__ __launch_bounds__(256) void k_gal_masks(int nelc, const int* __restrict__ child, const int* __restrict__ edof_f, int nloc_f, const unsigned char* __restrict__ fb,
+                                                    const int* __restrict__ edof_c, int nloc_c, const unsigned char* __restrict__ cb, unsigned* __restrict__ fmask,
+                                                    unsigned* __restrict__ cmask) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nelc * 9) return;
+  const int E = k / 9, j = k % 9;
+  unsigned m = 0;
+  if (j < 8) {
+    const int ej = child[(size_t)E * 8 + j];
+    for (int n = 0; n < 27; n++) m |= (fb[edof_f[(size_t)ej * nloc_f + n]] ? 1u : 0u) << n;
+    fmask[(size_t)E * 8 + j] = m;
+  } else {
+    for (int n = 0; n < 27; n++) m |= (cb[edof_c[(size_t)E * nloc_c + n]] ? 1u : 0u) << n;
+    cmask[E] = m;
+  }
+}
+
+template <bool INS>
 __global__ __launch_bounds__(GMAC_T) void k_galerkin_macro(int nelc, const int* __restrict__ child, int nm, const unsigned* __restrict__ sinfo, const uint4* __restrict__ map,
                                                            const unsigned long long* __restrict__ vdst, const unsigned short* __restrict__ gtab,
-                                                           const int* __restrict__ edof_f, int nloc_f, const unsigned char* __restrict__ fb,
-                                                           const int* __restrict__ slot_c, double* __restrict__ Kc, int ks_c, const int* __restrict__ edof_c, int nloc_c,
-                                                           const unsigned char* __restrict__ cb, const double* __restrict__ Cdense /* [8][27][27] */) {
-  constexpr int NC = 27, NCH = 8, NE = NC * NC, NT = (NE + 63) / 64, MT = 2, KP = GMAC_KP, CLD = GMAC_LD, KLD = GMAC_KLD, TLD = GMAC_LD;
-  extern __shared__ __attribute__((aligned(16))) double gmac_smem[];
-  double* Cs = gmac_smem;                                 // [NCH][KP][CLD], zero padded
-  double* Tm = Cs + NCH * KP * CLD;                       // the macro matrix in template order
-  double* scr = Tm + GMAC_TN;
-  unsigned long long* rbl = reinterpret_cast<unsigned long long*>(scr + GMAC_NW * GMAC_WS);
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int k = tid; k < NCH * KP * CLD; k += GMAC_T) {
-    const int j = k / (KP * CLD), r = (k / CLD) % KP, c = k % CLD;
-    Cs[k] = (r < NC && c < NC) ? Cdense[(j * NC + r) * NC + c] : 0.0;
+                                                           const unsigned* __restrict__ fmask, const unsigned* __restrict__ cmask,
+                                                           const int* __restrict__ slot_c, double* __restrict__ Kc, int ks_c, const double* __restrict__ Cdense /* [8][27][27] */,
+                                                           unsigned long long* __restrict__ stamps) {
+  constexpr int NC = 27, NCH = 8, NE = NC * NC, MT = 2, NK = GMAC_KP / 4;
+  SfStamps st;
+  if (INS) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) st.acc[k] = 0;
   }
+  extern __shared__ __attribute__((aligned(16))) double gmac_smem[];
+  double* Tm = gmac_smem;                                 // the macro matrix in template order; behind the products: the eight results
+  unsigned long long* rbl = reinterpret_cast<unsigned long long*>(gmac_smem + GMAC_BUF);
+  int* slds = reinterpret_cast<int*>(rbl + CL_NM_MAX);    // slots of the coarse element's 27 rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kk = lane >> 4, li = lane & 15;
   unsigned si[CL_SPT];
 #pragma unroll
   for (int i = 0; i < CL_SPT; i++) si[i] = sinfo[i * CL_T + tid];
-  unsigned short gt[NT];                                   // the template entries this lane fetches for its wave's child (loop invariant)
+  // loop-invariant fragments of child `wave`: C_j[4 m + kk][16 x + li] and the template index of K~_j[16 x + li][4 m + kk]
+  double creg[NK][MT];
+  int gidx[NK][MT];
 #pragma unroll
-  for (int t = 0; t < NT; t++) gt[t] = gtab[(size_t)wave * NE + min(lane + 64 * t, NE - 1)];
-  double* Ks = scr + wave * GMAC_WS;
-  double* Ts = Ks;
-  const int kk = lane >> 4, li = lane & 15;
+  for (int m = 0; m < NK; m++)
+#pragma unroll
+    for (int x = 0; x < MT; x++) {
+      const int r = 4 * m + kk, c = x * 16 + li;
+      creg[m][x] = (r < NC && c < NC) ? Cdense[((size_t)wave * NC + r) * NC + c] : 0.0;
+      const unsigned short g = (c < NC && r < NC) ? gtab[(size_t)wave * NE + c * NC + r] : (unsigned short)0xffff;
+      gidx[m][x] = g == 0xffff ? -1 : (int)g;
+    }
   typedef double d4 __attribute__((ext_vector_type(4)));
   const int stride = gridDim.x;
   int E = blockIdx.x;
@@ -3814,20 +3847,14 @@ __global__ __launch_bounds__(GMAC_T) void k_galerkin_macro(int nelc, const int* 
   int cln = child[(size_t)En * NCH] >> 3;
   unsigned long long vdn = vdst[(size_t)cln * CL_NM_MAX + tm];
   uint4 mpn = map[(size_t)cln * CL_T + tid];
-  int* slds = reinterpret_cast<int*>(rbl + CL_NM_MAX);        // slots of the coarse element's 27 rows
   const int ln = min(lane, NC - 1);
-  bool dn, dc;
-  int slc;
-  {
-    const int ej = child[(size_t)E * NCH + wave];
-    dn = fb[edof_f[(size_t)ej * nloc_f + ln]] != 0;
-    dc = cb[edof_c[(size_t)E * nloc_c + ln]] != 0;
-    slc = slot_c[(size_t)E * NC + ln];
-  }
+  unsigned dmask = fmask[(size_t)E * NCH + wave], cdm = cmask[E];      // Dirichlet nodes of this wave's child / of the coarse element (k_gal_masks)
+  int slc = slot_c[(size_t)E * NC + ln];
+  if (INS) st.prev = __builtin_amdgcn_s_memtime();
+  int ndone = 0;
 #pragma unroll 1
   for (; E < nelc; E += stride) {
-    // (dn, dc, slc: Dirichlet flags of the child's and of the coarse element's nodes and the row slots of THIS element -- chains of dependent look-ups,
-    // fetched one element ahead, under the products of the previous one)
+    sf_stamp<INS>(st, 0);
     // ---- the macro matrix of this cluster into LDS (template order); destinations of the next cluster into rbl ----
     {
       const unsigned mw[4] = {mp.x, mp.y, mp.z, mp.w};
@@ -3837,10 +3864,11 @@ __global__ __launch_bounds__(GMAC_T) void k_galerkin_macro(int nelc, const int* 
         if (r < nm) Tm[(si[i] >> 14) + j] = tv[i];
       }
     }
-    __syncthreads();                       // (also: every wave is done with rbl of this cluster -- its loads were issued one iteration ago and have landed in tv)
-    if (tid < CL_NM_MAX) rbl[tid] = vdn;
+    if (tid < CL_NM_MAX) rbl[tid] = vdn;      // (the loads through the previous content were issued one iteration ago and have landed in tv)
     if (tid < NC) slds[tid] = slc;
+    sf_stamp<INS>(st, 1);
     __syncthreads();
+    sf_stamp<INS>(st, 2);
     // the NEXT cluster's values: in flight during the products below
     mp = mpn;
 #pragma unroll
@@ -3854,74 +3882,55 @@ __global__ __launch_bounds__(GMAC_T) void k_galerkin_macro(int nelc, const int* 
       vdn = vdst[(size_t)clnn * CL_NM_MAX + tm];
       mpn = map[(size_t)clnn * CL_T + tid];
     }
-    // ---- wave j: K~_j (Dirichlet rows / columns zeroed), T = K~_j C_j, R_j = C_j^T T ----
-    const unsigned long long cdead = __ballot(dc && lane < NC);
-    const unsigned long long dead = __ballot(dn && lane < NC);
-    {   // the next element's look-ups
+    const unsigned long long cdead = cdm, dead = dmask;
+    {   // the next element's masks and slots (consumed one iteration later)
       const int En1 = min(E + stride, nelc - 1);
-      const int ejn = child[(size_t)En1 * NCH + wave];
-      dn = fb[edof_f[(size_t)ejn * nloc_f + ln]] != 0;
-      dc = cb[edof_c[(size_t)En1 * nloc_c + ln]] != 0;
+      dmask = fmask[(size_t)En1 * NCH + wave];
+      cdm = cmask[En1];
       slc = slot_c[(size_t)En1 * NC + ln];
     }
+    sf_stamp<INS>(st, 3);
+    // ---- wave j: T = K~_j C_j (A operand gathered from the macro matrix, rows / columns of Dirichlet nodes zeroed), R_j = C_j^T T ----
+    d4 T[MT][MT], KE[MT][MT];
+#pragma unroll
+    for (int a = 0; a < MT; a++)
+#pragma unroll
+      for (int b = 0; b < MT; b++) { T[a][b] = d4{0.0, 0.0, 0.0, 0.0}; KE[a][b] = d4{0.0, 0.0, 0.0, 0.0}; }
     {
-#pragma unroll
-      for (int t = 0; t < NT; t++) {
-        const int idx = lane + 64 * t;
-        const int ic = min(idx, NE - 1);
-        const int i = ic / NC, c = ic - i * NC;
-        const bool d = (((dead >> i) | (dead >> c)) & 1ull) || gt[t] == 0xffff;
-        const double v = Tm[min((int)gt[t], GMAC_TN - 1)];
-        if (idx < NE) Ks[i * KLD + c] = d ? 0.0 : v;
-      }
-      for (int q = lane; q < (MT * 16 - NC) * KLD; q += 64) Ks[NC * KLD + q] = 0.0;
-      for (int q = lane; q < NC * (KLD - NC); q += 64) Ks[(q / (KLD - NC)) * KLD + NC + q % (KLD - NC)] = 0.0;
-      wave_lds_sync();
-      const double* Cj = Cs + wave * KP * CLD;
-      d4 T[MT][MT], KE[MT][MT];
-#pragma unroll
-      for (int a = 0; a < MT; a++)
-#pragma unroll
-        for (int b = 0; b < MT; b++) { T[a][b] = d4{0.0, 0.0, 0.0, 0.0}; KE[a][b] = d4{0.0, 0.0, 0.0, 0.0}; }
-#pragma unroll
-      for (int k0 = 0; k0 < KP; k0 += 4) {
-        double av[MT], bv[MT];
+      double av[2][MT];                      // fragments of K~_j, one k-step ahead of the products
+      auto gather = [&](int m, double (&o)[MT]) {
 #pragma unroll
         for (int x = 0; x < MT; x++) {
-          av[x] = Ks[(x * 16 + li) * KLD + k0 + kk];
-          bv[x] = Cj[(k0 + kk) * CLD + x * 16 + li];
+          const int row = x * 16 + li, col = 4 * m + kk;
+          const bool d = gidx[m][x] < 0 || (((dead >> min(row, 63)) | (dead >> min(col, 63))) & 1ull);
+          const double v = Tm[max(gidx[m][x], 0)];
+          o[x] = d ? 0.0 : v;
         }
+      };
+      gather(0, av[0]);
+#pragma unroll
+      for (int m = 0; m < NK; m++) {
+        if (m + 1 < NK) gather(m + 1, av[(m + 1) & 1]);
 #pragma unroll
         for (int a = 0; a < MT; a++)
 #pragma unroll
-          for (int b = 0; b < MT; b++) T[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], T[a][b], 0, 0, 0);
+          for (int b = 0; b < MT; b++) T[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m & 1][a], creg[m][b], T[a][b], 0, 0, 0);
       }
-      wave_lds_sync();                       // every lane has read its operands of K~_j: T may take the region
+    }
+#pragma unroll
+    for (int m = 0; m < NK; m++)
 #pragma unroll
       for (int a = 0; a < MT; a++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int i = a * 16 + kk + 4 * r;
-          if (i < KP) {
-#pragma unroll
-            for (int b = 0; b < MT; b++) Ts[i * TLD + b * 16 + li] = T[a][b][r];
-          }
-        }
-      wave_lds_sync();
-#pragma unroll
-      for (int k0 = 0; k0 < KP; k0 += 4) {
-        double av[MT], bv[MT];
-#pragma unroll
-        for (int x = 0; x < MT; x++) {
-          av[x] = Cj[(k0 + kk) * CLD + x * 16 + li];        // A[row a][k i] = C_j[i][a]
-          bv[x] = Ts[(k0 + kk) * TLD + x * 16 + li];
-        }
-#pragma unroll
-        for (int a = 0; a < MT; a++)
-#pragma unroll
-          for (int b = 0; b < MT; b++) KE[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], KE[a][b], 0, 0, 0);
-      }
-      wave_lds_sync();                       // T has been consumed: the wave's result [27][28] takes the region
+        for (int b = 0; b < MT; b++) KE[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(creg[m][a], T[m / 4][b][m % 4], KE[a][b], 0, 0, 0);
+    if (INS) {
+      asm volatile("" ::"v"(KE[0][0][0]), "v"(KE[1][1][3]));
+      sf_stamp<INS>(st, 4);
+    }
+    __syncthreads();                       // every wave is done with the macro matrix: the results take the region
+    sf_stamp<INS>(st, 5);
+    {
+      double* Rs = Tm + wave * GMAC_RS;
 #pragma unroll
       for (int a = 0; a < MT; a++)
 #pragma unroll
@@ -3930,22 +3939,33 @@ __global__ __launch_bounds__(GMAC_T) void k_galerkin_macro(int nelc, const int* 
 #pragma unroll
           for (int b = 0; b < MT; b++) {
             const int k = b * 16 + li;
-            if (ra < NC && k < NC) Ks[ra * 28 + k] = KE[a][b][r];
+            if (ra < NC && k < NC) Rs[ra * 28 + k] = KE[a][b][r];
           }
         }
     }
+    sf_stamp<INS>(st, 6);
     __syncthreads();
+    sf_stamp<INS>(st, 7);
     // ---- the eight results added in child order; rows / columns of coarse Dirichlet nodes are zero; rows without a slot are not stored ----
     for (int idx = tid; idx < NE; idx += GMAC_T) {
       const int i = idx / NC, k = idx - i * NC;
-      double v = scr[i * 28 + k];
+      double v = Tm[i * 28 + k];
 #pragma unroll
-      for (int w = 1; w < GMAC_NW; w++) v += scr[w * GMAC_WS + i * 28 + k];
-      const int s = slds[i];
+      for (int w = 1; w < GMAC_NW; w++) v += Tm[w * GMAC_RS + i * 28 + k];
+      const int s2 = slds[i];
       const bool d = ((cdead >> i) | (cdead >> k)) & 1ull;
-      if (s >= 0) Kc[(size_t)s * ks_c + k] = d ? 0.0 : v;
+      if (s2 >= 0) Kc[(size_t)s2 * ks_c + k] = d ? 0.0 : v;
     }
-    __syncthreads();                       // scratch and Tm are the next cluster's
+    sf_stamp<INS>(st, 8);
+    __syncthreads();                       // the region is the next cluster's macro matrix
+    sf_stamp<INS>(st, 9);
+    ndone++;
+  }
+  if (INS && stamps && lane == 0) {
+    unsigned long long* o = stamps + ((size_t)blockIdx.x * GMAC_NW + wave) * 20;
+#pragma unroll
+    for (int k = 0; k < 16; k++) o[k] = st.acc[k];
+    o[16] = (unsigned long long)ndone;
   }
 }
 
@@ -4036,6 +4056,14 @@ extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, con
     FH_TRY(up((void**)&cas->d_gal_fb, fb.data(), fb.size()));
     FH_TRY(up((void**)&cas->d_gal_cb, cb.data(), cb.size()));
     if (!cas->d_gal_res) FH_CHECK_HIP(hipMalloc(&cas->d_gal_res, std::max<size_t>(cas->ndof, 1) * sizeof(double)));
+    if (nc == 27) {
+      if (cas->d_gal_fmask) FH_CHECK_HIP(hipFree(cas->d_gal_fmask));
+      cas->d_gal_fmask = nullptr;
+      FH_CHECK_HIP(hipMalloc(&cas->d_gal_fmask, ((size_t)cas->nel * 9 + 1) * sizeof(unsigned)));
+      hipLaunchKernelGGL(k_gal_masks, dim3(fh_div_up(cas->nel * 9, 256)), dim3(256), 0, c->stream, cas->nel, cas->d_gal_child, fas->d_elem_dof, fas->nloc, cas->d_gal_fb,
+                         cas->d_elem_dof, cas->nloc, cas->d_gal_cb, cas->d_gal_fmask, cas->d_gal_fmask + (size_t)cas->nel * 8);
+      FH_CHECK_HIP(hipGetLastError());
+    }
     // the macro rows of a fused assembly can stand in for the element rows when child j of coarse element E is element j of ONE cluster (what the
     // refinement's numbering gives: MeshRefinement.cpp:240-294)
     cas->gal_children_in_order = nch == CL_NE;
@@ -4055,12 +4083,37 @@ extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, con
   if (from_macro) {
     static bool attr_set_m[64] = {};
     if (!attr_set_m[c->device & 63]) {
-      FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_galerkin_macro), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gmac_lds_bytes()));
+      FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_galerkin_macro<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gmac_lds_bytes()));
+      FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_galerkin_macro<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gmac_lds_bytes()));
       attr_set_m[c->device & 63] = true;
     }
-    hipLaunchKernelGGL(k_galerkin_macro, dim3(std::max(1, std::min(cas->nel, c->num_cu))), dim3(GMAC_T), gmac_lds_bytes(), c->stream, cas->nel, cas->d_gal_child, fas->cl_nm,
-                       fas->d_cl_sinfo, reinterpret_cast<const uint4*>(fas->d_cl_map), fas->d_cl_vdst64, fas->d_cl_gtab, fas->d_elem_dof, fas->nloc, cas->d_gal_fb, cas->d_slot,
-                       cas->d_Kbuf, cas->kstride, cas->d_elem_dof, cas->nloc, cas->d_gal_cb, cas->d_gal_dense);
+    const int gm_grid = std::max(1, std::min(cas->nel, c->num_cu));          // (two workgroups per compute unit would need 128 registers per lane: 101 spilled)
+    if (c->asm_debug & 128) {             // dev aid: phase cycles of every wave on stderr (as for the cluster kernel)
+      unsigned long long* d_st = nullptr;
+      const size_t nst = (size_t)gm_grid * GMAC_NW * 20;
+      FH_CHECK_HIP(hipMalloc(&d_st, nst * sizeof(unsigned long long)));
+      FH_CHECK_HIP(hipMemsetAsync(d_st, 0, nst * sizeof(unsigned long long), c->stream));
+      hipLaunchKernelGGL(k_galerkin_macro<true>, dim3(gm_grid), dim3(GMAC_T), gmac_lds_bytes(), c->stream, cas->nel, cas->d_gal_child, fas->cl_nm, fas->d_cl_sinfo,
+                         reinterpret_cast<const uint4*>(fas->d_cl_map), fas->d_cl_vdst64, fas->d_cl_gtab, cas->d_gal_fmask, cas->d_gal_fmask + (size_t)cas->nel * 8, cas->d_slot, cas->d_Kbuf,
+                         cas->kstride, cas->d_gal_dense, d_st);
+      std::vector<unsigned long long> h(nst);
+      FH_CHECK_HIP(hipMemcpyAsync(h.data(), d_st, nst * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+      FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+      FH_CHECK_HIP(hipFree(d_st));
+      static const char* name[10] = {"loop top", "macro matrix into LDS", "barrier", "next cluster's loads issued, look-ups", "K~ fragments gathered, two products (56 MFMA)",
+                                     "barrier (all waves done with the macro matrix)", "result into LDS", "barrier", "eight results added, coarse rows stored", "barrier"};
+      double sum[10] = {0}, ncl = 0, tot = 0;
+      for (size_t w = 0; w < (size_t)gm_grid * GMAC_NW; w++) {
+        for (int k = 0; k < 10; k++) sum[k] += (double)h[w * 20 + k];
+        ncl += (double)h[w * 20 + 16];
+      }
+      for (int k = 0; k < 10; k++) tot += sum[k];
+      fprintf(stderr, "k_galerkin_macro phase stamps: %.0f shader-clock ticks per cluster and wave\n", tot / std::max(ncl, 1.0));
+      for (int k = 0; k < 10; k++) fprintf(stderr, "  %2d %-62s %9.1f  %5.1f %%\n", k, name[k], sum[k] / std::max(ncl, 1.0), 100.0 * sum[k] / std::max(tot, 1.0));
+    } else
+      hipLaunchKernelGGL(k_galerkin_macro<false>, dim3(gm_grid), dim3(GMAC_T), gmac_lds_bytes(), c->stream, cas->nel, cas->d_gal_child, fas->cl_nm, fas->d_cl_sinfo,
+                         reinterpret_cast<const uint4*>(fas->d_cl_map), fas->d_cl_vdst64, fas->d_cl_gtab, cas->d_gal_fmask, cas->d_gal_fmask + (size_t)cas->nel * 8, cas->d_slot, cas->d_Kbuf,
+                         cas->kstride, cas->d_gal_dense, (unsigned long long*)nullptr);
   } else if (c->galerkin_mfma) {
     const size_t lds = nc == 27 ? galerkin_mfma_lds<27, 8>() : galerkin_mfma_lds<9, 4>();
     static bool attr_set[64] = {};
