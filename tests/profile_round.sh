@@ -80,3 +80,10 @@ python $ROOT/tests/perf_probe_amr.py 8 2> /dev/null | grep '^{' | head -1 > $OUT
 python $ROOT/tests/perf_probe_direct.py 1 2 3 2> /dev/null | grep '^n ' > $OUT/${TAG}_direct_probe.txt
 tail -c 600 $OUT/${TAG}_bench_line.json
 python $ROOT/tests/perf_probe_ns.py 0.001 2> /dev/null | grep '^{' | head -1 > $OUT/${TAG}_ns_probe.json
+# ---- config 4 (cavity, Taylor-Hood, 80 x 80, nu = 0.001 by continuation): F-cycle Newton, cycle and linear solve; round 5: block smoother with a colour per launch ----
+python $ROOT/tests/perf_probe_ns.py 0.001 2> /dev/null | grep '^{' | tail -1 > $OUT/${TAG}_ns_probe.json
+python $ROOT/tests/perf_probe_ns_cycle.py 2> /dev/null | grep '^{' | tail -1 > $OUT/${TAG}_ns_cycle_probe.json
+python $ROOT/tests/perf_probe_ns_cycle.py vanka_fused=0 gmres_device=0 2> /dev/null | grep '^{' | tail -1 > $OUT/${TAG}_ns_cycle_probe_round4_options.json
+# ---- where the waves of the fused cluster kernel and of the macro-row Galerkin kernel spend their cycles (shader-clock stamps, asm_debug bit 7) ----
+python $ROOT/tests/perf_probe_cluster_phases.py 0 > $OUT/${TAG}_cluster_phase_stamps.txt 2>&1
+python $ROOT/tests/dev/probe12.py 2>&1 | grep -A11 "k_galerkin_macro phase" > $OUT/${TAG}_galerkin_macro_phase_stamps.txt
