@@ -93,6 +93,9 @@ class Context:
     def matrix_from_elements(self, elem_dof, m, n=None):
         return Mat.from_elements(self, elem_dof, m, n)
 
+    def matrix_from_mesh(self, mesh, fe):
+        return Mat.from_mesh(self, mesh, fe)
+
     def matrix_scipy(self, A):
         A = A.tocsr()
         A.sort_indices()
@@ -308,6 +311,13 @@ class Mat:
         _chk(ctx.L.fh_mat_create_from_elements(ctx.h, int(ed.shape[0]), int(ed.shape[1]), _p(ed), int(m), int(m if n is None else n), ctypes.byref(h)))
         return cls(ctx, h)
 
+    @classmethod
+    def from_mesh(cls, ctx, mesh, fe):
+        """the same for the square operator of one variable on a mesh, from the mesh's device copy (fh_mat_create_from_mesh)"""
+        h = ctypes.c_void_p()
+        _chk(ctx.L.fh_mat_create_from_mesh(ctx.h, mesh.h, FE[fe], ctypes.byref(h)))
+        return cls(ctx, h)
+
     def destroy(self):
         if self.h:
             self.L.fh_mat_destroy(self.h)
@@ -520,9 +530,22 @@ class Mesh:
         _chk(L.fh_mesh_read_gambit(str(path).encode(), float(Lref), ctypes.byref(h)))
         return cls(L, h)
 
-    def refine(self):
+    def refine(self, ctx=None):
+        """uniform refinement; with a context: on the device (fh_mesh_refine_device, same arrays bit for bit, the new mesh stays resident)"""
+        if ctx is not None:
+            return self.refine_device(ctx)
         h = ctypes.c_void_p()
         _chk(self.L.fh_mesh_refine(self.h, ctypes.byref(h)))
+        return Mesh(self.L, h)
+
+    def refine_device(self, ctx, flags=None):
+        """MeshRefinement::RefineMesh on the device; flags as refine_flagged (None: every element of the current level)"""
+        f = None
+        if flags is not None:
+            f = np.ascontiguousarray(flags, dtype=np.uint8)
+            assert f.shape == (self.nel,)
+        h = ctypes.c_void_p()
+        _chk(self.L.fh_mesh_refine_device(ctx.h, self.h, None if f is None else _p(f), ctypes.byref(h)))
         return Mesh(self.L, h)
 
     def partition(self, nparts, weights=None):
@@ -800,8 +823,12 @@ class Assembler:
 
     def __init__(self, ctx, mesh, fe, A, order="seventh", elem_dof=None, coords=None):
         self.ctx, self.L = ctx, ctx.L
-        if elem_dof is None:
-            elem_dof, coords, _ = mesh.arrays()
+        if elem_dof is None and mesh is not None:         # element table and coordinates from the mesh's device copy
+            self.h = ctypes.c_void_p()
+            _chk(self.L.fh_assembler_create_mesh(ctx.h, mesh.h, FE[fe], GAUSS_ORDER[order], A.h, ctypes.byref(self.h)))
+            self.nel = mesh.nel
+            self.nc = {"linear": 2 ** mesh.dim, "biquadratic": 3 ** mesh.dim}[fe]
+            return
         ed, xy = _i32(elem_dof), _f64(coords)
         assert ed.min() >= 0 and ed.max() < xy.shape[0]
         geom = "hex" if xy.shape[1] == 3 else "quad"

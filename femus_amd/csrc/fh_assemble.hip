@@ -2974,8 +2974,9 @@ __global__ __launch_bounds__(256) void k_adj_sort(int m, int nc, const int* __re
   for (int a = a0; a < a1; a++) slot[(size_t)(aei[a] >> 5) * nc + (aei[a] & 31)] = a;
 }
 
-extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, int nel, int nloc, const int* elem_dof, int nnode,
-                                   const double* coords, fh_mat_t A, fh_assembler_t* out) {
+// dev_elem_dof / dev_coords: the same two arrays already in device memory (a mesh's device copy), or null
+static int assembler_create_impl(fh_ctx_t ctx, int geom, int fe, int order, int nel, int nloc, const int* elem_dof, int nnode, const double* coords,
+                                 const int* dev_elem_dof, const double* dev_coords, fh_mat_t A, fh_assembler_t* out) {
   FH_GUARD_BEGIN
   FH_REQUIRE(ctx && elem_dof && coords && A && out, "fh_assembler_create: null argument");
   FH_REQUIRE(geom == 0 || geom == 1, "fh_assembler_create: geom must be 0 (hex) or 1 (quad)");
@@ -2997,15 +2998,26 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
   std::vector<double> w, phi, dphi;
   FH_REQUIRE(fhfe::shape_tables(geom, fe, order, w, phi, dphi) == 0, "fh_assembler_create: unsupported Gauss rule %d", order);
   as->ng = (int)w.size();
-  for (size_t k = 0; k < (size_t)nel * nloc; k++)
-    FH_REQUIRE(elem_dof[k] >= 0 && elem_dof[k] < nnode, "fh_assembler_create: node id %d out of range", elem_dof[k]);
+  if (!dev_elem_dof)      // (a mesh's own table holds ids of its own numbering)
+    for (size_t k = 0; k < (size_t)nel * nloc; k++)
+      FH_REQUIRE(elem_dof[k] >= 0 && elem_dof[k] < nnode, "fh_assembler_create: node id %d out of range", elem_dof[k]);
   auto up = [&](void** d, const void* h, size_t bytes) -> int {
     FH_CHECK_HIP(hipMalloc(d, bytes ? bytes : 8));
     if (bytes) FH_CHECK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
     return 0;
   };
-  FH_TRY(up((void**)&as->d_elem_dof, elem_dof, (size_t)nel * nloc * sizeof(int)));
-  FH_TRY(up((void**)&as->d_coords, coords, (size_t)nnode * as->dim * sizeof(double)));
+  auto dup = [&](void** d, const void* src, size_t bytes) -> int {
+    FH_CHECK_HIP(hipMalloc(d, bytes ? bytes : 8));
+    if (bytes) FH_CHECK_HIP(hipMemcpyAsync(*d, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+  };
+  if (dev_elem_dof && dev_coords) {
+    FH_TRY(dup((void**)&as->d_elem_dof, dev_elem_dof, (size_t)nel * nloc * sizeof(int)));
+    FH_TRY(dup((void**)&as->d_coords, dev_coords, (size_t)nnode * as->dim * sizeof(double)));
+  } else {
+    FH_TRY(up((void**)&as->d_elem_dof, elem_dof, (size_t)nel * nloc * sizeof(int)));
+    FH_TRY(up((void**)&as->d_coords, coords, (size_t)nnode * as->dim * sizeof(double)));
+  }
   FH_TRY(up((void**)&as->d_w, w.data(), w.size() * sizeof(double)));
   FH_TRY(up((void**)&as->d_phi, phi.data(), phi.size() * sizeof(double)));
   FH_TRY(up((void**)&as->d_dphi, dphi.data(), dphi.size() * sizeof(double)));
@@ -3272,6 +3284,24 @@ extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, in
   *out = as;
   return 0;
   FH_GUARD_END("fh_assembler_create")
+}
+
+extern "C" int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int order, int nel, int nloc, const int* elem_dof, int nnode,
+                                   const double* coords, fh_mat_t A, fh_assembler_t* out) {
+  return assembler_create_impl(ctx, geom, fe, order, nel, nloc, elem_dof, nnode, coords, nullptr, nullptr, A, out);
+}
+
+int fh_mesh_host_arrays(fh_mesh_t m, int* dim, int* geom, int* nel, int* nnode, int* nloc, int* n_linear, const int** elem_dof, const double** coords);
+
+extern "C" int fh_assembler_create_mesh(fh_ctx_t ctx, fh_mesh_t mesh, int fe, int order, fh_mat_t A, fh_assembler_t* out) {
+  FH_REQUIRE(ctx && mesh && A && out, "fh_assembler_create_mesh: null argument");
+  int dim, geom, nel, nnode, nloc, nlin;
+  const int* ed;
+  const double* xy;
+  FH_TRY(fh_mesh_host_arrays(mesh, &dim, &geom, &nel, &nnode, &nloc, &nlin, &ed, &xy));
+  fh_mesh_dev* dev = nullptr;
+  FH_TRY(fh_mesh_device(ctx, mesh, &dev));
+  return assembler_create_impl(ctx, geom, fe, order, nel, nloc, ed, nnode, xy, dev->d_elem_dof, dev->d_coords, A, out);
 }
 
 extern "C" int fh_assembler_destroy(fh_assembler_t as) {

@@ -199,6 +199,39 @@ static inline const std::vector<int>& fh_hcol(fh_mat_t A) {
   return A->h_col;
 }
 
+// device-resident copy of a mesh (fh_meshdev.hip): made by fh_mesh_refine_device (or uploaded at the first use), read by the set-up calls that
+// take a mesh -- the element table of a 64^3 level is 28 MB, its coordinates 51 MB, and every one of those calls used to upload them again
+struct fh_mesh_dev {
+  fh_ctx_t ctx = nullptr;
+  int nel = 0, nnode = 0, nloc = 0, dim = 0, nf = 0;
+  int* d_elem_dof = nullptr;      // [nel * nloc]
+  double* d_coords = nullptr;     // [nnode * dim]
+  int* d_face_flag = nullptr;     // [nel * nf]
+  int* d_elem_level = nullptr;    // [nel]
+  int* d_child = nullptr;         // [nel * nch], set when this mesh was refined on the device
+  char* d_refined = nullptr;      // [nel]
+};
+struct fh_refine_tables {         // reference-element tables of one geometry (fh_mesh.cpp: refine_tables)
+  int nv, ne, nc, nch, nf, dim;
+  int f2c[8][8], edge_v[12][2], face_v[6][4], face_diag[6][4];
+  unsigned char cof[6][8];        // child j touches face f
+  std::vector<double> EP;         // element prolongator [nch * nc][nc]
+  std::vector<int> cnt, nzk;      // non-zero weights of every row: how many, which columns
+};
+struct fh_refine_result {
+  int nel = 0, nnode = 0, own[3] = {0, 0, 0};
+  std::vector<int> elem_dof, face_flag, elem_level, child;
+  std::vector<char> refined;
+  std::vector<double> coords;
+  fh_mesh_dev* dev = nullptr;
+};
+void fh_meshdev_free(fh_mesh_dev* d);
+int fh_meshdev_upload(fh_ctx_t ctx, int nel, int nnode, int nloc, int dim, int nf, const int* elem_dof, const double* coords, const int* face_flag,
+                      const int* elem_level, fh_mesh_dev** out);
+int fh_meshdev_refine(fh_ctx_t ctx, const fh_refine_tables& tables, fh_mesh_dev* coarse, int level_c, const unsigned char* flags, fh_refine_result* out);
+// the device copy of a mesh on this context (uploaded now if the mesh has none), its host arrays beside it
+int fh_mesh_device(fh_ctx_t ctx, fh_mesh_t m, fh_mesh_dev** dev);
+
 // kernels / helpers implemented across TUs
 int fh_reserve_reduction(fh_ctx_t ctx, size_t ndoubles);
 int fh_mat_build_rowblocks(fh_mat_t A, int tile);

@@ -165,20 +165,27 @@ __global__ __launch_bounds__(256) void k_pe_rows(int m, const int* __restrict__ 
     if (k == 0 || key[k] != key[k - 1]) col[o++] = key[k];
 }
 
-extern "C" int fh_mat_create_from_elements(fh_ctx_t c, int nel, int nloc, const int* elem_dof, int m, int n, fh_mat_t* out) {
+// elem_dof: host array [nel * nloc], or null when dev_elem_dof -- the same array already in device memory (not owned) -- is given
+static int mat_create_from_elements_impl(fh_ctx_t c, int nel, int nloc, const int* elem_dof, const int* dev_elem_dof, int m, int n, fh_mat_t* out) {
   FH_GUARD_BEGIN
-  FH_REQUIRE(c && out && nel >= 0 && nloc > 0 && m >= 0 && n >= m && (elem_dof || nel == 0), "fh_mat_create_from_elements: bad arguments");
+  FH_REQUIRE(c && out && nel >= 0 && nloc > 0 && m >= 0 && n >= m && (elem_dof || dev_elem_dof || nel == 0), "fh_mat_create_from_elements: bad arguments");
   const size_t ne = (size_t)nel * nloc;
-  int *d_ed = nullptr, *d_cnt = nullptr, *d_adj = nullptr, *d_err = nullptr, *d_len = nullptr;
+  int *d_ed = nullptr, *d_ed_own = nullptr, *d_cnt = nullptr, *d_adj = nullptr, *d_err = nullptr, *d_len = nullptr;
   auto cleanup = [&]() {
-    for (int* p : {d_ed, d_cnt, d_adj, d_err, d_len})
+    for (int* p : {d_ed_own, d_cnt, d_adj, d_err, d_len})
       if (p) hipFree(p);
   };
-  FH_CHECK_HIP(hipMalloc(&d_ed, std::max<size_t>(ne, 1) * sizeof(int)));
+  std::vector<int> fetched;        // host copy of a device-only table, made only if the host builder has to serve a row
+  if (dev_elem_dof) {
+    d_ed = const_cast<int*>(dev_elem_dof);
+  } else {
+    FH_CHECK_HIP(hipMalloc(&d_ed_own, std::max<size_t>(ne, 1) * sizeof(int)));
+    d_ed = d_ed_own;
+  }
   FH_CHECK_HIP(hipMalloc(&d_cnt, ((size_t)m + 2) * sizeof(int)));
   FH_CHECK_HIP(hipMalloc(&d_err, sizeof(int)));
   FH_CHECK_HIP(hipMalloc(&d_len, ((size_t)m + 1) * sizeof(int)));
-  if (ne) FH_CHECK_HIP(hipMemcpyAsync(d_ed, elem_dof, ne * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  if (ne && !dev_elem_dof) FH_CHECK_HIP(hipMemcpyAsync(d_ed, elem_dof, ne * sizeof(int), hipMemcpyHostToDevice, c->stream));
   FH_CHECK_HIP(hipMemsetAsync(d_cnt, 0, ((size_t)m + 2) * sizeof(int), c->stream));
   FH_CHECK_HIP(hipMemsetAsync(d_err, 0, sizeof(int), c->stream));
   const unsigned gb = (unsigned)((ne + 255) / 256);
@@ -211,6 +218,11 @@ extern "C" int fh_mat_create_from_elements(fh_ctx_t c, int nel, int nloc, const 
   FH_CHECK_HIP(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
   if (err) {               // a node with more than PE_CAP candidate columns: the host builder serves it
+    if (!elem_dof) {
+      fetched.resize(ne);
+      FH_CHECK_HIP(hipMemcpy(fetched.data(), d_ed, ne * sizeof(int), hipMemcpyDeviceToHost));
+      elem_dof = fetched.data();
+    }
     hipFree(d_aptr);
     cleanup();
     std::vector<int> hrp((size_t)n + 1), hcol;
@@ -246,6 +258,34 @@ extern "C" int fh_mat_create_from_elements(fh_ctx_t c, int nel, int nloc, const 
   *out = A;
   return 0;
   FH_GUARD_END("fh_mat_create_from_elements")
+}
+
+extern "C" int fh_mat_create_from_elements(fh_ctx_t c, int nel, int nloc, const int* elem_dof, int m, int n, fh_mat_t* out) {
+  FH_REQUIRE(elem_dof || nel == 0, "fh_mat_create_from_elements: bad arguments");
+  return mat_create_from_elements_impl(c, nel, nloc, elem_dof, nullptr, m, n, out);
+}
+
+int fh_mesh_host_arrays(fh_mesh_t m, int* dim, int* geom, int* nel, int* nnode, int* nloc, int* n_linear, const int** elem_dof, const double** coords);
+
+extern "C" int fh_mat_create_from_mesh(fh_ctx_t c, fh_mesh_t mesh, int fe, fh_mat_t* out) {
+  FH_REQUIRE(c && mesh && out && (fe == 0 || fe == 2), "fh_mat_create_from_mesh: bad arguments (fe: 0 linear, 2 biquadratic)");
+  int dim, geom, nel, nnode, nloc, nlin;
+  const int* ed;
+  const double* xy;
+  FH_TRY(fh_mesh_host_arrays(mesh, &dim, &geom, &nel, &nnode, &nloc, &nlin, &ed, &xy));
+  fh_mesh_dev* dev = nullptr;
+  FH_TRY(fh_mesh_device(c, mesh, &dev));
+  if (fe == 2) return mat_create_from_elements_impl(c, nel, nloc, nullptr, dev->d_elem_dof, nnode, nnode, out);
+  // linear: the vertices are the first 2^dim local nodes of every element -- a strided copy of the table
+  const int nv = 1 << dim;
+  int* d_lin = nullptr;
+  FH_CHECK_HIP(hipMalloc(&d_lin, std::max<size_t>((size_t)nel * nv, 1) * sizeof(int)));
+  hipError_t e = nel ? hipMemcpy2DAsync(d_lin, nv * sizeof(int), dev->d_elem_dof, nloc * sizeof(int), nv * sizeof(int), nel, hipMemcpyDeviceToDevice, c->stream) : hipSuccess;
+  int rc = e == hipSuccess ? mat_create_from_elements_impl(c, nel, nv, nullptr, d_lin, nlin, nlin, out) : 1;
+  if (e != hipSuccess) fh_set_error("fh_mat_create_from_mesh: %s", hipGetErrorString(e));
+  hipStreamSynchronize(c->stream);
+  hipFree(d_lin);
+  return rc;
 }
 
 extern "C" int fh_mat_destroy(fh_mat_t A) {

@@ -33,6 +33,9 @@ struct fh_mesh_s {
   // hanging-node rows already computed for this mesh: [fe == 2], valid for amr_cache_mode (cleared when coordinates or the mode change)
   std::shared_ptr<struct AmrRows> amr_cache[2];
   int amr_cache_mode[2] = {-1, -1};
+  // the same arrays in device memory (fh_mesh_refine_device, fh_mesh_device): dropped whenever a host array they mirror is rewritten
+  fh_mesh_dev* dev = nullptr;
+  ~fh_mesh_s() { fh_meshdev_free(dev); }
 };
 
 using namespace fhfe;
@@ -186,6 +189,8 @@ extern "C" int fh_mesh_refine_flagged(fh_mesh_t mc, const unsigned char* flags, 
   m->level = mc->level + 1;
   m->amr_mode = mc->amr_mode;
   if (mc->elem_level.empty()) mc->elem_level.assign(mc->nel, mc->level);
+  fh_meshdev_free(mc->dev);     // its child table is about to change
+  mc->dev = nullptr;
   // only elements of the current level can be refined (Elem.hpp:358-360)
   mc->refined.assign(mc->nel, 0);
   std::vector<int> start(mc->nel + 1, 0);
@@ -354,6 +359,101 @@ extern "C" int fh_mesh_refine(fh_mesh_t mc, fh_mesh_t* out) {
   FH_GUARD_BEGIN return fh_mesh_refine_flagged(mc, nullptr, out);   FH_GUARD_END("fh_mesh_refine")
 }
 
+// reference-element tables of a refinement, derived from the node coordinates of the reference element as fh_mesh_refine_flagged derives them
+static void refine_tables(int geom, fh_refine_tables& T) {
+  const int dim = dim_of(geom);
+  T.nv = nvert_of(geom); T.ne = nedge_end_of(geom); T.nc = nloc_of(geom); T.nch = T.nv; T.nf = nfaces_of(geom); T.dim = dim;
+  memset(T.f2c, 0, sizeof(T.f2c)); memset(T.edge_v, 0, sizeof(T.edge_v)); memset(T.face_v, 0, sizeof(T.face_v));
+  memset(T.face_diag, 0, sizeof(T.face_diag)); memset(T.cof, 0, sizeof(T.cof));
+  for (int j = 0; j < T.nch; j++)
+    for (int v = 0; v < T.nv; v++) T.f2c[j][v] = fine2coarse_vertex(geom, j, v);
+  for (int e = T.nv; e < T.ne; e++) {
+    int cnt = 0;
+    for (int v = 0; v < T.nv && cnt < 2; v++) {
+      bool on = true;
+      for (int d = 0; d < dim; d++)
+        if (xc(geom, e, d) != 0 && xc(geom, e, d) != xc(geom, v, d)) on = false;
+      if (on) T.edge_v[e - T.nv][cnt++] = v;
+    }
+  }
+  for (int f = 0; f < T.nf; f++) {
+    const int centre = (geom == GEOM_HEX) ? 20 + f : 4 + f;
+    int d0 = 0;
+    for (int d = 0; d < dim; d++)
+      if (xc(geom, centre, d) != 0) d0 = d;
+    int cnt = 0;
+    for (int v = 0; v < T.nv; v++) {
+      const bool on = xc(geom, v, d0) == xc(geom, centre, d0);
+      T.cof[f][v] = on;
+      if (on && cnt < 4) T.face_v[f][cnt++] = v;
+    }
+    if (geom == GEOM_HEX)          // the vertex of the face that shares no edge with vertex k: both in-face coordinates differ
+      for (int k = 0; k < 4; k++)
+        for (int k2 = 0; k2 < 4; k2++) {
+          int differ = 0;
+          for (int d = 0; d < dim; d++) differ += xc(geom, T.face_v[f][k], d) != xc(geom, T.face_v[f][k2], d);
+          if (differ == 2) T.face_diag[f][k] = k2;
+        }
+  }
+  elem_prolongator(geom, FE_BIQUADRATIC, T.EP);
+  T.cnt.assign((size_t)T.nch * T.nc, 0);
+  T.nzk.assign((size_t)T.nch * T.nc * T.nc, 0);
+  for (int ji = 0; ji < T.nch * T.nc; ji++)
+    for (int k = 0; k < T.nc; k++)
+      if (T.EP[(size_t)ji * T.nc + k] != 0.0) T.nzk[(size_t)ji * T.nc + T.cnt[ji]++] = k;
+}
+
+int fh_mesh_device(fh_ctx_t ctx, fh_mesh_t m, fh_mesh_dev** dev) {
+  FH_REQUIRE(ctx && m && dev, "fh_mesh_device: null argument");
+  if (m->dev && m->dev->ctx != ctx) {
+    fh_meshdev_free(m->dev);
+    m->dev = nullptr;
+  }
+  if (!m->dev) {
+    if (m->elem_level.empty()) m->elem_level.assign(m->nel, m->level);
+    FH_TRY(fh_meshdev_upload(ctx, m->nel, m->nnode, m->nloc, m->dim, nfaces_of(m->geom), m->elem_dof.data(), m->coords.data(), m->face_flag.data(),
+                             m->elem_level.data(), &m->dev));
+  }
+  *dev = m->dev;
+  return 0;
+}
+
+// The same refinement on the device (fh_meshdev.hip): identical arrays, bit for bit; the new mesh keeps its device copy for the set-up calls
+// that follow (fh_mat_create_from_mesh, fh_assembler_create_mesh, fh_build_prolongator) and a host copy for everything else.
+extern "C" int fh_mesh_refine_device(fh_ctx_t ctx, fh_mesh_t mc, const unsigned char* flags, fh_mesh_t* out) {
+  FH_GUARD_BEGIN
+  FH_REQUIRE(ctx && mc && out, "fh_mesh_refine_device: null argument");
+  const int geom = mc->geom, nc = mc->nloc, nch = nvert_of(geom);
+  FH_REQUIRE((int64_t)mc->nel * nch * nc < (1ll << 31), "fh_mesh_refine_device: the refinement of %d elements does not fit 32-bit ids", mc->nel);
+  fh_mesh_dev* cdev = nullptr;
+  FH_TRY(fh_mesh_device(ctx, mc, &cdev));
+  fh_refine_tables T;
+  refine_tables(geom, T);
+  fh_refine_result R;
+  FH_TRY(fh_meshdev_refine(ctx, T, cdev, mc->level, flags, &R));
+  std::unique_ptr<fh_mesh_s> holder(new fh_mesh_s());
+  fh_mesh_s* m = holder.get();
+  m->dev = R.dev;
+  m->geom = geom;
+  m->dim = mc->dim;
+  m->nloc = nc;
+  m->level = mc->level + 1;
+  m->amr_mode = mc->amr_mode;
+  m->nel = R.nel;
+  m->nnode = R.nnode;
+  for (int k = 0; k < 3; k++) m->own[k] = R.own[k];
+  m->elem_dof.swap(R.elem_dof);
+  m->coords.swap(R.coords);
+  m->face_flag.swap(R.face_flag);
+  m->elem_level.swap(R.elem_level);
+  mc->child.swap(R.child);
+  mc->refined.swap(R.refined);
+  m->homogeneous = m->nel == mc->nel * nch;
+  *out = holder.release();
+  return 0;
+  FH_GUARD_END("fh_mesh_refine_device")
+}
+
 // MeshRefinement::FlagElementsToRefine (:88-101): the flag function is evaluated at the mean of the element vertices
 extern "C" int fh_mesh_elem_centroids(fh_mesh_t m, double* xc3) {
   FH_REQUIRE(m && xc3, "fh_mesh_elem_centroids: null argument");
@@ -382,6 +482,8 @@ extern "C" int fh_mesh_clear_boundary_faces(fh_mesh_t m, unsigned face_mask) {
       if ((face_mask >> f) & 1u) m->face_flag[(size_t)iel * nf + f] = -1;
   m->amr_cache[0].reset();     // interface faces of the hanging-node search are the faces flagged -1: rows cached before are stale
   m->amr_cache[1].reset();
+  fh_meshdev_free(m->dev);
+  m->dev = nullptr;
   return 0;
 }
 
@@ -390,6 +492,8 @@ extern "C" int fh_mesh_set_coords(fh_mesh_t m, const double* coords) {
   memcpy(m->coords.data(), coords, m->coords.size() * sizeof(double));
   m->amr_cache[0].reset();     // the hanging-node weights are found through the coordinates
   m->amr_cache[1].reset();
+  fh_meshdev_free(m->dev);
+  m->dev = nullptr;
   return 0;
 }
 
@@ -524,7 +628,7 @@ extern "C" int fh_pattern_from_elements(int nel, int nloc, const int* elem_dof, 
 
 // the device builder lives in fh_setup.hip (this file stays plain host C++: tests/asan_host.sh); it gets the host arrays
 int fh_prolongator_device(fh_ctx_t ctx, int nl, int nc, int nch, int nel_c, const int* child, const char* refined, const int* c_ed, size_t n_fed, const int* f_ed,
-                          int nf, int ncc, const std::vector<double>& EP, const char* bf, const char* bc, fh_mat_t* out);
+                          int nf, int ncc, const std::vector<double>& EP, const char* bf, const char* bc, fh_mat_t* out, const fh_mesh_dev* cdev, const fh_mesh_dev* fdev);
 
 static int build_prolongator_device(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t mf, int fe, int zero_bdc, fh_mat_t* out) {
   const int geom = mc->geom, nl = mc->nloc, nc = ndofs_of(geom, fe), nch = nvert_of(geom);
@@ -542,7 +646,9 @@ static int build_prolongator_device(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t mf, in
     for (int c : lc) bc[c] = 1;
   }
   return fh_prolongator_device(ctx, nl, nc, nch, mc->nel, mc->child.data(), mc->refined.data(), mc->elem_dof.data(), mf->elem_dof.size(), mf->elem_dof.data(), nf, ncc,
-                               EP, zero_bdc ? bf.data() : nullptr, zero_bdc ? bc.data() : nullptr, out);
+                               EP, zero_bdc ? bf.data() : nullptr, zero_bdc ? bc.data() : nullptr, out,
+                               // device copies made by fh_mesh_refine_device on this context: nothing to upload but the boundary marks
+                               (mc->dev && mf->dev && mc->dev->ctx == ctx && mf->dev->ctx == ctx && mc->dev->d_child) ? mc->dev : nullptr, mf->dev);
 }
 
 // a14: P (fine x coarse), INSERT semantics (first insert wins; duplicates are identical rows).  Elements that were not

@@ -81,7 +81,8 @@ struct DevBuf {   // scratch device arrays of one setup routine, freed on every 
 }   // namespace
 
 int fh_prolongator_device(fh_ctx_t ctx, int nl, int nc, int nch, int nel_c, const int* child, const char* refined, const int* c_ed, size_t n_fed, const int* f_ed,
-                          int nf, int ncc, const std::vector<double>& EP, const char* bf, const char* bc, fh_mat_t* out) {
+                          int nf, int ncc, const std::vector<double>& EP, const char* bf, const char* bc, fh_mat_t* out, const fh_mesh_dev* cdev,
+                          const fh_mesh_dev* fdev) {
   std::vector<int> cnt((size_t)nch * nc, 0), nzk((size_t)nch * nc * nc, 0);
   for (int ji = 0; ji < nch * nc; ji++)
     for (int k = 0; k < nc; k++)
@@ -92,17 +93,25 @@ int fh_prolongator_device(fh_ctx_t ctx, int nl, int nc, int nch, int nel_c, cons
   char *d_ref, *d_bf = nullptr, *d_bc = nullptr;
   double* d_EP;
   const size_t nslot = (size_t)nel_c * nch;
-  if (B.get(&d_child, nslot) || B.get(&d_fed, n_fed) || B.get(&d_ced, (size_t)nel_c * nl) || B.get(&d_owner, (size_t)nf) ||
-      B.get(&d_len, (size_t)nf) || B.get(&d_cnt, cnt.size()) || B.get(&d_nzk, nzk.size()) || B.get(&d_ref, (size_t)nel_c) || B.get(&d_EP, EP.size())) {
+  const bool resident = cdev && fdev;      // the element tables, child lists and split marks are in device memory already
+  if ((!resident && (B.get(&d_child, nslot) || B.get(&d_fed, n_fed) || B.get(&d_ced, (size_t)nel_c * nl) || B.get(&d_ref, (size_t)nel_c))) ||
+      B.get(&d_owner, (size_t)nf) || B.get(&d_len, (size_t)nf) || B.get(&d_cnt, cnt.size()) || B.get(&d_nzk, nzk.size()) || B.get(&d_EP, EP.size())) {
     fh_set_error("fh_build_prolongator: out of device memory");
     return 2;
   }
-  FH_CHECK_HIP(hipMemcpyAsync(d_child, child, nslot * sizeof(int), hipMemcpyHostToDevice, st));
-  FH_CHECK_HIP(hipMemcpyAsync(d_fed, f_ed, n_fed * sizeof(int), hipMemcpyHostToDevice, st));
-  FH_CHECK_HIP(hipMemcpyAsync(d_ced, c_ed, (size_t)nel_c * nl * sizeof(int), hipMemcpyHostToDevice, st));
+  if (resident) {
+    d_child = cdev->d_child;
+    d_ced = cdev->d_elem_dof;
+    d_ref = cdev->d_refined;
+    d_fed = fdev->d_elem_dof;
+  } else {
+    FH_CHECK_HIP(hipMemcpyAsync(d_child, child, nslot * sizeof(int), hipMemcpyHostToDevice, st));
+    FH_CHECK_HIP(hipMemcpyAsync(d_fed, f_ed, n_fed * sizeof(int), hipMemcpyHostToDevice, st));
+    FH_CHECK_HIP(hipMemcpyAsync(d_ced, c_ed, (size_t)nel_c * nl * sizeof(int), hipMemcpyHostToDevice, st));
+    FH_CHECK_HIP(hipMemcpyAsync(d_ref, refined, (size_t)nel_c, hipMemcpyHostToDevice, st));
+  }
   FH_CHECK_HIP(hipMemcpyAsync(d_cnt, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice, st));
   FH_CHECK_HIP(hipMemcpyAsync(d_nzk, nzk.data(), nzk.size() * sizeof(int), hipMemcpyHostToDevice, st));
-  FH_CHECK_HIP(hipMemcpyAsync(d_ref, refined, (size_t)nel_c, hipMemcpyHostToDevice, st));
   FH_CHECK_HIP(hipMemcpyAsync(d_EP, EP.data(), EP.size() * sizeof(double), hipMemcpyHostToDevice, st));
   FH_CHECK_HIP(hipMemsetAsync(d_owner, 0x7f, (size_t)nf * sizeof(int), st));          // PL_NONE
   if (bf) {

@@ -34,7 +34,7 @@ class PoissonMG:
         else:
             self.meshes = [capi.Mesh.box(nx, ny, nz, lo, hi)]
             for _ in range(1, nlevels):
-                self.meshes.append(self.meshes[-1].refine())
+                self.meshes.append(self.meshes[-1].refine(ctx))      # on the device; the levels stay resident for init()
         self.nc = {"linear": 2 ** self.meshes[0].dim, "biquadratic": 3 ** self.meshes[0].dim}[fe]
         self.mg = None
 
@@ -78,9 +78,8 @@ class PoissonMG:
         self.gal_elem = (self.coarse == "galerkin" and self.elementwise_galerkin and not self.amr and fe == "biquadratic" and self.nlevels > 1)
         levels = range(self.nlevels) if (self.coarse == "rediscretise" or self.gal_elem) else [top]
         for l in levels:
-            ed, xy, _ = self.meshes[l].arrays()
-            K = ctx.matrix_from_elements(ed[:, :self.nc], self.ndof[l])        # GetSparsityPatternSize + init, on the device
-            self.asm[l] = capi.Assembler(ctx, self.meshes[l], fe, K, self.order, elem_dof=ed, coords=xy)
+            K = ctx.matrix_from_mesh(self.meshes[l], fe)                       # GetSparsityPatternSize + init, on the device
+            self.asm[l] = capi.Assembler(ctx, self.meshes[l], fe, K, self.order)
             if self.Pamr[l] is not None:
                 self.KK[l] = K
             else:

@@ -228,6 +228,12 @@ int fh_mesh_refine(fh_mesh_t coarse, fh_mesh_t* fine);
  * elements of the current level with flags[iel] != 0 are split, every other element is carried over unchanged, which
  * makes the new level non-homogeneous.  flags == NULL refines every element of the current level. */
 int fh_mesh_refine_flagged(fh_mesh_t coarse, const unsigned char* flags /* [nel] or NULL */, fh_mesh_t* fine);
+/* The same refinement ON THE DEVICE (round 5; MeshRefinement.cpp:240-294, 356-417, 513-620 + Mesh.cpp:517-559): the final node numbering is
+ * the rank of every node's first touch in (class, element, local node) order, so an atomicMin per touched node (edges and faces found
+ * through a device hash table), one scan and one pass that writes ids and coordinates replace the host's ordered loops.  Same arrays as
+ * fh_mesh_refine_flagged, bit for bit (numbering, boundary flags, coordinates); the fine mesh keeps a device copy that
+ * fh_mat_create_from_mesh / fh_assembler_create_mesh / fh_build_prolongator read instead of uploading the element table again. */
+int fh_mesh_refine_device(fh_ctx_t ctx, fh_mesh_t coarse, const unsigned char* flags /* [nel] or NULL */, fh_mesh_t* fine);
 /* the point FlagElementsToRefine evaluates the user's flag function at: mean of the element vertices (:88-101) */
 int fh_mesh_elem_centroids(fh_mesh_t mesh, double* xc /* [nel*3] */);
 /* Elem::GetElementLevel per element, Mesh::GetIfHomogeneous */
@@ -250,6 +256,8 @@ int fh_pattern_from_elements(int nel, int nloc, const int* elem_dof, int ndof, i
 /* the same pattern built ON THE DEVICE and made a matrix at once (m owned rows over n columns, values zero): node -> element lists by a counting
  * pass, one wave per row sorts the candidate columns in LDS.  The column array stays on the device (host code that asks for it fetches it). */
 int fh_mat_create_from_elements(fh_ctx_t ctx, int nel, int nloc, const int* elem_dof, int m, int n, fh_mat_t* out);
+/* the same for a square operator of one variable on a mesh (fe: 0 linear, 2 biquadratic), from the mesh's device copy (made now if it has none) */
+int fh_mat_create_from_mesh(fh_ctx_t ctx, fh_mesh_t mesh, int fe, fh_mat_t* out);
 
 /* ---- prolongator (a14): LinearImplicitSystem::BuildProlongatorMatrix (LinearImplicitSystem.cpp:761-909) ----
  * builds P (fine x coarse) from the element prolongator; zero_bdc != 0 also applies
@@ -286,6 +294,8 @@ int fh_build_amr_prolongator(fh_ctx_t ctx, fh_mesh_t mesh, int fe, fh_mat_t* P_a
 typedef struct fh_assembler_s* fh_assembler_t;
 int fh_assembler_create(fh_ctx_t ctx, int geom, int fe, int gauss_order, int nel, int nloc, const int* elem_dof,
                         int nnode, const double* coords /* [nnode*dim] */, fh_mat_t A, fh_assembler_t* as);
+/* the same from a mesh: element table and coordinates come from the mesh's device copy (made now if it has none), no upload */
+int fh_assembler_create_mesh(fh_ctx_t ctx, fh_mesh_t mesh, int fe, int gauss_order, fh_mat_t A, fh_assembler_t* as);
 int fh_assembler_destroy(fh_assembler_t as);
 /* Galerkin coarse operator PP^T KK PP of a UNIFORMLY refined level, element by element, from the element matrices the fine assembler
  * holds since its last assembly (LinearImplicitSystem.cpp:347-370 calls the sparse product SparseMatrix::matrix_PtAP): child[nel_coarse * 2^dim]

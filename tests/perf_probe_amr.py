@@ -24,9 +24,9 @@ def main(mode):
     ctx = femus_amd.Context(0)
     t0 = time.time()
     ms = [capi.Mesh.box(n0, n0, n0).set_amr_mode(mode)]
-    ms.append(ms[-1].refine())
+    ms.append(ms[-1].refine(ctx))                                                   # all levels refined on the device (round 5)
     for _ in range(2):
-        ms.append(ms[-1].refine_flagged(ms[-1].flag_elements(flag)))
+        ms.append(ms[-1].refine_device(ctx, ms[-1].flag_elements(flag)))
     mesh_s = time.time() - t0
     t0 = time.time()
     pb = PoissonMG(ctx, n0, n0, n0, 4, source_kind=3, params=(-2.0, 1.0), meshes=ms).init()
