@@ -65,10 +65,13 @@ __device__ __forceinline__ int row_slot(const int* __restrict__ c_col, int cs, i
   return lo;
 }
 
-// pass 1: number of elementary products per row and per C entry (segptr holds counts, shifted by one, turned into offsets here)
+// pass 1: number of elementary products per row and per C entry (segptr holds counts, shifted by one, turned into offsets here).
+// Lanes: groups of gl = 2^k lanes, one group per A entry, the lanes of a group over that entry's B row -- B rows of a prolongator hold 1 to
+// 27 entries (8 on average), a whole wave per A entry left 7 lanes of 8 idle in the column searches, which are the cost of this pass
+// (round 5: 6.5 -> see profiles/r05_amr_probe.json for the adaptive hierarchy's first preparation).
 __global__ __launch_bounds__(256) void k_spgemm_segcount(const int* __restrict__ a_rp, const int* __restrict__ a_col, const int* __restrict__ b_rp,
                                                          const int* __restrict__ b_col, const int* __restrict__ c_rp, const int* __restrict__ c_col,
-                                                         long long* __restrict__ rowcount, int* __restrict__ segptr, int m, int max_crow) {
+                                                         long long* __restrict__ rowcount, int* __restrict__ segptr, int m, int max_crow, int gl_log2) {
   extern __shared__ int cnts[];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + w;
@@ -77,12 +80,14 @@ __global__ __launch_bounds__(256) void k_spgemm_segcount(const int* __restrict__
   const int cs = c_rp[row], clen = c_rp[row + 1] - cs;
   for (int t = lane; t <= clen; t += 64) cnt[t] = 0;
   wave_sync_lds();
-  for (int ka = a_rp[row]; ka < a_rp[row + 1]; ka++) {
+  const int gl = 1 << gl_log2, ng = 64 >> gl_log2, g = lane >> gl_log2, sub = lane & (gl - 1);
+  const int ae = a_rp[row + 1];
+  for (int ka = a_rp[row] + g; ka < ae; ka += ng) {
     const int k = a_col[ka];
     const int bs = b_rp[k], blen = b_rp[k + 1] - bs;
-    for (int t = lane; t < blen; t += 64) cnt[row_slot(c_col, cs, clen, b_col[bs + t]) + 1] += 1;   // distinct slots within one B row
-    wave_sync_lds();
+    for (int t = sub; t < blen; t += gl) atomicAdd(&cnt[row_slot(c_col, cs, clen, b_col[bs + t]) + 1], 1);
   }
+  wave_sync_lds();
   if (lane == 0) {
     int run = 0;
     for (int t = 1; t <= clen; t++) {
@@ -96,11 +101,13 @@ __global__ __launch_bounds__(256) void k_spgemm_segcount(const int* __restrict__
   for (int t = lane; t <= clen; t += 64) sp[t] = cnt[t];
 }
 
-// pass 2: fill the lists; A entries in sequence, so every list is in increasing-k order
+// pass 2: fill the lists.  The searches of ng A entries run side by side (the same lane groups as pass 1); the list positions are then handed
+// out group by group, so the order inside every list is fixed by the patterns alone (A entries in chunks of ng; inside a chunk by round of
+// gl B entries, then by A entry): the numeric product sums in a fixed order -- deterministic, bit-reproducible operators.
 __global__ __launch_bounds__(256) void k_spgemm_segfill(const int* __restrict__ a_rp, const int* __restrict__ a_col, const int* __restrict__ b_rp,
                                                         const int* __restrict__ b_col, const int* __restrict__ c_rp, const int* __restrict__ c_col,
                                                         const long long* __restrict__ rowbase, const int* __restrict__ segptr,
-                                                        unsigned short* __restrict__ pa, int* __restrict__ pb, int m, int max_crow) {
+                                                        unsigned short* __restrict__ pa, int* __restrict__ pb, int m, int max_crow, int gl_log2) {
   extern __shared__ int cnts[];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + w;
@@ -111,18 +118,30 @@ __global__ __launch_bounds__(256) void k_spgemm_segfill(const int* __restrict__ 
   for (int t = lane; t < clen; t += 64) cur[t] = sp[t];
   wave_sync_lds();
   const long long base = rowbase[row];
-  const int as = a_rp[row];
-  for (int ka = as; ka < a_rp[row + 1]; ka++) {
-    const int k = a_col[ka];
-    const int bs = b_rp[k], blen = b_rp[k + 1] - bs;
-    for (int t = lane; t < blen; t += 64) {
-      const int s = row_slot(c_col, cs, clen, b_col[bs + t]);
-      const int q = cur[s];
-      cur[s] = q + 1;
-      pa[base + q] = (unsigned short)(ka - as);
-      pb[base + q] = bs + t;
+  const int as = a_rp[row], ae = a_rp[row + 1];
+  const int gl = 1 << gl_log2, ng = 64 >> gl_log2, g = lane >> gl_log2, sub = lane & (gl - 1);
+  for (int ka0 = as; ka0 < ae; ka0 += ng) {
+    const int ka = ka0 + g;
+    int bs = 0, blen = 0;
+    if (ka < ae) {
+      const int k = a_col[ka];
+      bs = b_rp[k];
+      blen = b_rp[k + 1] - bs;
     }
-    wave_sync_lds();
+    for (int t0 = 0; __any(t0 < blen); t0 += gl) {
+      const int t = t0 + sub;
+      const bool has = t < blen;
+      const int s = has ? row_slot(c_col, cs, clen, b_col[bs + t]) : 0;
+      for (int gg = 0; gg < ng; gg++) {          // distinct slots inside one B row: the lanes of a group never meet
+        if (has && g == gg) {
+          const int q = cur[s];
+          cur[s] = q + 1;
+          pa[base + q] = (unsigned short)(ka - as);
+          pb[base + q] = bs + t;
+        }
+        wave_sync_lds();
+      }
+    }
   }
 }
 
@@ -264,8 +283,11 @@ static int build_slot_map(fh_mat_t A, fh_mat_t B, fh_mat_t C, SlotMap& M) {
   FH_CHECK_HIP(hipMalloc(&M.segptr, ((size_t)C->nnz + m + 2) * sizeof(int)));
   FH_CHECK_HIP(hipMemsetAsync(M.rowbase, 0, sizeof(long long), c->stream));
   const size_t lds = (size_t)4 * (max_crow + 1) * sizeof(int);
+  // lanes per A entry: the power of two next to the mean length of a B row, 8 to 64
+  int gl_log2 = 3;
+  while (gl_log2 < 6 && (double)(1 << gl_log2) < (double)B->nnz / std::max(B->m, 1)) gl_log2++;
   hipLaunchKernelGGL(k_spgemm_segcount, dim3(fh_div_up(m, 4)), dim3(256), lds, c->stream, A->d_rowptr, A->d_col, B->d_rowptr, B->d_col, C->d_rowptr,
-                     C->d_col, M.rowbase, M.segptr, m, max_crow);
+                     C->d_col, M.rowbase, M.segptr, m, max_crow, gl_log2);
   std::vector<long long> rb((size_t)m + 1);
   FH_CHECK_HIP(hipMemcpyAsync(rb.data(), M.rowbase, rb.size() * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
@@ -287,7 +309,7 @@ static int build_slot_map(fh_mat_t A, fh_mat_t B, fh_mat_t C, SlotMap& M) {
   FH_CHECK_HIP(hipMalloc(&M.pa, (size_t)M.nprod * sizeof(unsigned short)));
   FH_CHECK_HIP(hipMalloc(&M.pb, (size_t)M.nprod * sizeof(int)));
   hipLaunchKernelGGL(k_spgemm_segfill, dim3(fh_div_up(m, 4)), dim3(256), lds, c->stream, A->d_rowptr, A->d_col, B->d_rowptr, B->d_col, C->d_rowptr,
-                     C->d_col, M.rowbase, M.segptr, M.pa, M.pb, m, max_crow);
+                     C->d_col, M.rowbase, M.segptr, M.pa, M.pb, m, max_crow, gl_log2);
   FH_CHECK_HIP(hipGetLastError());
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
   return 0;

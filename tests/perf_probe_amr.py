@@ -59,5 +59,5 @@ def main(mode):
     pb.destroy()
 
 
-for mode in ("reference", "coarsest"):
+for mode in (sys.argv[2:] or ("reference", "coarsest")):
     main(mode)
