@@ -96,6 +96,17 @@ def test_device_setup_builders_at_full_size_equal_the_host_builders(ctx, problem
     spmv patterns through fh_pattern_from_elements / spgemm_device_symbolic)"""
     pb = problem
     mc, mf = pb.meshes[-2], pb.meshes[-1]
+    # the levels themselves: PoissonMG refines on the device (fh_mesh_refine_device); the host loops give the same 262 144 x 27 ids, boundary
+    # flags and 2 146 689 coordinates, bit for bit
+    mh = capi.Mesh.box(8, 8, 8)
+    for l in range(1, len(pb.meshes)):
+        nxt = mh.refine()
+        mh.destroy()
+        mh = nxt
+    for a, b in zip(mh.arrays(), mf.arrays()):
+        assert np.array_equal(a.view(np.int64) if a.dtype == np.float64 else a, b.view(np.int64) if b.dtype == np.float64 else b)
+    assert mh.own_size == mf.own_size
+    mh.destroy()
     out = []
     for dev in (1, 0):
         ctx.set_option("device_setup", dev)
