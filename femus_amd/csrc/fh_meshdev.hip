@@ -294,14 +294,20 @@ int fh_meshdev_refine(fh_ctx_t ctx, const fh_refine_tables& H, fh_mesh_dev* C, i
   FH_CHECK_HIP(hipMemcpyAsync(d_tab_cnt, H.cnt.data(), H.cnt.size() * sizeof(int), hipMemcpyHostToDevice, st));
   FH_CHECK_HIP(hipMemcpyAsync(d_tab_nz, H.nzk.data(), H.nzk.size() * sizeof(int), hipMemcpyHostToDevice, st));
   FH_CHECK_HIP(hipMemcpyAsync(d_EP, H.EP.data(), H.EP.size() * sizeof(double), hipMemcpyHostToDevice, st));
-  // the coarse mesh learns which of its elements were split and where their children are
-  if (C->d_child) hipFree(C->d_child);
-  if (C->d_refined) hipFree(C->d_refined);
-  C->d_child = nullptr;
-  C->d_refined = nullptr;
-  FH_CHECK_HIP(hipMalloc(&C->d_child, std::max<size_t>(nslot, 2) * sizeof(int)));
-  FH_CHECK_HIP(hipMalloc(&C->d_refined, std::max<size_t>(nel_c, 8)));
-  if (nel_c) hipLaunchKernelGGL(k_rf_mark, dim3(fh_div_up(nel_c, 256)), dim3(256), 0, st, nel_c, level_c, C->d_elem_level, d_flags, C->d_refined, d_cnt, nch);
+  // which elements are split and where their children are: handed to the coarse mesh's device copy when everything below has succeeded
+  int* d_child = nullptr;
+  char* d_refined = nullptr;
+  struct ChildGuard {
+    int*& c;
+    char*& r;
+    ~ChildGuard() {
+      if (c) hipFree(c);
+      if (r) hipFree(r);
+    }
+  } child_guard{d_child, d_refined};
+  FH_CHECK_HIP(hipMalloc(&d_child, std::max<size_t>(nslot, 2) * sizeof(int)));
+  FH_CHECK_HIP(hipMalloc(&d_refined, std::max<size_t>(nel_c, 8)));
+  if (nel_c) hipLaunchKernelGGL(k_rf_mark, dim3(fh_div_up(nel_c, 256)), dim3(256), 0, st, nel_c, level_c, C->d_elem_level, d_flags, d_refined, d_cnt, nch);
   FH_TRY(device_exclusive_scan(st, d_cnt, d_start, nel_c, d_bsum));
   int nel_f = 0;
   FH_CHECK_HIP(hipMemcpyAsync(&nel_f, d_start + nel_c, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -332,8 +338,8 @@ int fh_meshdev_refine(fh_ctx_t ctx, const fh_refine_tables& H, fh_mesh_dev* C, i
   FH_CHECK_HIP(hipMemsetAsync(d_keys, 0xFF, cap * sizeof(unsigned long long), st));
   FH_CHECK_HIP(hipMemsetAsync(d_first, 0x7f, nident * sizeof(int), st));
   if (nslot)
-    hipLaunchKernelGGL(k_rf_children, dim3((unsigned)((nslot + 255) / 256)), dim3(256), 0, st, T, nel_c, C->d_refined, d_start, C->d_elem_dof, C->d_face_flag,
-                       C->d_elem_level, C->d_child, F->d_elem_dof, F->d_face_flag, F->d_elem_level, d_parent);
+    hipLaunchKernelGGL(k_rf_children, dim3((unsigned)((nslot + 255) / 256)), dim3(256), 0, st, T, nel_c, d_refined, d_start, C->d_elem_dof, C->d_face_flag,
+                       C->d_elem_level, d_child, F->d_elem_dof, F->d_face_flag, F->d_elem_level, d_parent);
   const unsigned gb = (unsigned)((nocc + 255) / 256);
   if (nocc) {
     hipLaunchKernelGGL(k_rf_touch, dim3(gb), dim3(256), 0, st, T, nel_f, d_parent, F->d_elem_dof, d_keys, (unsigned)(cap - 1), 64 - log2cap, E0, C0, d_first, d_ident);
@@ -366,10 +372,16 @@ int fh_meshdev_refine(fh_ctx_t ctx, const fh_refine_tables& H, fh_mesh_dev* C, i
   if (nnode_f) FH_CHECK_HIP(hipMemcpyAsync(R->coords.data(), F->d_coords, R->coords.size() * sizeof(double), hipMemcpyDeviceToHost, st));
   if (nel_f) FH_CHECK_HIP(hipMemcpyAsync(R->face_flag.data(), F->d_face_flag, R->face_flag.size() * sizeof(int), hipMemcpyDeviceToHost, st));
   if (nel_f) FH_CHECK_HIP(hipMemcpyAsync(R->elem_level.data(), F->d_elem_level, (size_t)nel_f * sizeof(int), hipMemcpyDeviceToHost, st));
-  if (nslot) FH_CHECK_HIP(hipMemcpyAsync(R->child.data(), C->d_child, nslot * sizeof(int), hipMemcpyDeviceToHost, st));
-  if (nel_c) FH_CHECK_HIP(hipMemcpyAsync(R->refined.data(), C->d_refined, (size_t)nel_c, hipMemcpyDeviceToHost, st));
+  if (nslot) FH_CHECK_HIP(hipMemcpyAsync(R->child.data(), d_child, nslot * sizeof(int), hipMemcpyDeviceToHost, st));
+  if (nel_c) FH_CHECK_HIP(hipMemcpyAsync(R->refined.data(), d_refined, (size_t)nel_c, hipMemcpyDeviceToHost, st));
   FH_CHECK_HIP(hipStreamSynchronize(st));
   guard.f = nullptr;
   R->dev = F;
+  if (C->d_child) hipFree(C->d_child);
+  if (C->d_refined) hipFree(C->d_refined);
+  C->d_child = d_child;
+  C->d_refined = d_refined;
+  d_child = nullptr;
+  d_refined = nullptr;
   return 0;
 }
