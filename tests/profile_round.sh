@@ -87,3 +87,7 @@ python $ROOT/tests/perf_probe_ns_cycle.py vanka_fused=0 gmres_device=0 2> /dev/n
 # ---- where the waves of the fused cluster kernel and of the macro-row Galerkin kernel spend their cycles (shader-clock stamps, asm_debug bit 7) ----
 python $ROOT/tests/perf_probe_cluster_phases.py 0 > $OUT/${TAG}_cluster_phase_stamps.txt 2>&1
 python $ROOT/tests/dev/probe12.py 2>&1 | grep -A11 "k_galerkin_macro phase" > $OUT/${TAG}_galerkin_macro_phase_stamps.txt
+# ---- set-up of the bench problem stage by stage (levels refined on the device, round 5) and the same with the host loops ----
+python $ROOT/tests/perf_probe_setup.py --device 2> /dev/null | sed -n '/^{/,$p' > $OUT/${TAG}_setup_probe.json
+python $ROOT/tests/perf_probe_setup.py 2> /dev/null | sed -n '/^{/,$p' > $OUT/${TAG}_setup_probe_host_refinement.json
+python $ROOT/tests/perf_probe_direct_general.py > $OUT/${TAG}_direct_general_probe.txt 2>&1
