@@ -414,6 +414,8 @@ def main():
                 how += "; one-GPU problem of the same local size on rank 0's device"
             out["roofline"]["traffic"] = live["spmv"]
             out["roofline"]["traffic_source"] = how
+            out["roofline"].pop("traffic_from_profile", None)            # that label names the committed passes the live value has just replaced
+            out["roofline_assembly"].pop("traffic_from_profile", None)
             if live.get("sweep_in_cycle_ms"):
                 t_in = live["sweep_in_cycle_ms"]
                 out["roofline"].update({"avg_launch_ms": t_in, "achieved": sweep_bytes / t_in / 1e6, "frac": sweep_bytes / t_in / 1e6 / HBM_PEAK_GBPS,
