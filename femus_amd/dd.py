@@ -886,12 +886,16 @@ class DistributedPoisson:
         kill(getattr(self, "halos", None))
 
     def assemble(self):
+        # the element loop reads the state at every node of the rank's elements (Res = F - K u, as the one-GPU path does): refresh the ghost
+        # entries of SOL first (VecGhostUpdate before the assembly callback, LinearImplicitSystem.cpp:318-327).  Every rank takes part, also
+        # one whose box carries adaptive levels and assembles on its extended box: an exchange is collective over the neighbours
+        self.halos[-1].update(self.SOL)
         if self.adaptive:
             res_full = self.full.assemble()                            # assembly + P_amr projection on the extended box
             self.mapA[-1].gather_matrix_values(self.A[-1], self.full.A[-1])
             self.map_rows.gather_vector(self.RES, res_full)
             return
-        self.asm.assemble(self.A[-1], self.RES, None, self.source_kind, self.params)
+        self.asm.assemble(self.A[-1], self.RES, self.SOL, self.source_kind, self.params)
 
     def set_penalty_top(self):
         self.bdc_dev.zero_rows(self.A[-1], 1.0)

@@ -186,7 +186,12 @@ def _rank_worker_body(rank, world, port, nb, nlevels, out, overlap=1):
     dp.halos[-1].update(dp.SOL)
     probe = np.concatenate([top.ghost_global[:5], top.offsets[rank] + np.arange(3)]).astype(np.int32)
     assert np.array_equal(dp.SOL.get(probe), probe.astype(np.float64))
-    np.savez(out % rank, gid=top.gid[top.owned], b=b, x=x, xs=xs, its=its, n_ghost=top.n_ghost)
+    # assembly at a state that is not zero: the ghost entries the element loop reads arrive with the exchange inside assemble()
+    gid_own = top.gid[top.owned]
+    dp.SOL.upload(((gid_own % 97) / 97.0).astype(np.float64))
+    dp.assemble()
+    b_state = dp.RES.to_numpy()[:dp.n_owned].copy()
+    np.savez(out % rank, gid=top.gid[top.owned], b=b, x=x, xs=xs, its=its, n_ghost=top.n_ghost, b_state=b_state)
     comm.barrier()
     comm.close()
 
@@ -208,12 +213,14 @@ def test_multi_rank_device_path_with_host_transport(tmp_path, world, overlap):
     xd = spla.spsolve(H.A[-1].tocsc(), H.b)
     gid_ser, _ = dd.node_keys(H.meshes[-1].coords, nlevels - 1, nb, part)
     srt = np.argsort(gid_ser)
+    _, b_state = fo.assemble_poisson(H.meshes[-1], "biquadratic", ONE, sol=(gid_ser % 97) / 97.0)      # Res = F - K u at a state
     seen = 0
     for r in range(world):
         d = np.load(out % r)
         pos = srt[np.searchsorted(gid_ser[srt], d["gid"])]
         assert np.array_equal(gid_ser[pos], d["gid"]) and d["n_ghost"] > 0
         assert np.linalg.norm(d["b"] - H.b[pos]) <= 1e-12 * np.linalg.norm(H.b)          # distributed assembly
+        assert np.linalg.norm(d["b_state"] - b_state[pos]) <= 1e-12 * np.linalg.norm(b_state)      # ... with the state's ghost entries exchanged
         assert np.linalg.norm(d["x"] - ref[pos]) <= 1e-10 * np.linalg.norm(ref)          # distributed V-cycle
         assert np.linalg.norm(d["xs"] - xd[pos]) <= 1e-9 * np.linalg.norm(xd)            # distributed GMRES solve
         seen += d["gid"].size
