@@ -1060,6 +1060,27 @@ class NSAssembler:
             self.h = None
 
 
+class NSPwAssembler(NSAssembler):
+    """the same weak form with the DISCONTINUOUS piecewise-linear pressure of unittests/testNSSteadyDD (fh_ns_pw_assembler_create): variables
+    [U | V | (W) | P], pressure dof of local function i of element e at dim * nnode + i * nel + e"""
+
+    def __init__(self, ctx, mesh, A, order="seventh"):
+        self.ctx, self.L = ctx, ctx.L
+        ed, xy, _ = mesh.arrays()
+        self.nel = mesh.nel
+        self.nd = mesh.dim * mesh.nloc + mesh.dim + 1
+        self.h = ctypes.c_void_p()
+        _chk(self.L.fh_ns_pw_assembler_create(ctx.h, GEOM[mesh.geom], GAUSS_ORDER[order], mesh.nel, mesh.nloc, _p(ed), mesh.nnode, _p(xy), A.h,
+                                              ctypes.byref(self.h)))
+
+    @staticmethod
+    def elem_sys(mesh):
+        """[nel, nd] system dofs of every element (the table the pattern of KK is made from)"""
+        ed = mesh.arrays()[0]
+        p = np.arange(mesh.dim + 1)[None, :] * mesh.nel + np.arange(mesh.nel)[:, None] + mesh.dim * mesh.nnode
+        return np.concatenate([ed + k * mesh.nnode for k in range(mesh.dim)] + [p], axis=1).astype(np.int32)
+
+
 class NSStabAssembler(NSAssembler):
     """the callback of applications/003_NavierStokes/SteadyNavierStokesParallel (main.cpp:390-925): equal-order linear velocity / pressure on the vertex
     nodes with the Franca-Frey stabilisation; variables [U | V | (W) | P], each `nq1` long"""

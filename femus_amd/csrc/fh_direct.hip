@@ -944,18 +944,29 @@ static int direct_symbolic(fh_direct_t d) {
     std::vector<int> owner(na, -1);
     for (int t = 0; t < nn; t++)
       for (int u : N[t].own) owner[u] = t;
+    // Round 5 (the Q2 / discontinuous-pressure Jacobian of unittests/testNSSteadyDD): "no neighbour in its front" is not enough -- a front that owns the
+    // three pressure functions of an element but only some of its velocity nodes holds a singular pivot block (the element's divergence constraint reaches
+    // velocities of an ancestor).  A zero-diagonal unknown therefore goes to the HIGHEST front that owns one of its neighbours: every unknown it couples to
+    // is then eliminated in or below its own front.  An unknown and its neighbours in one row of the operator lie on one root path of the tree (the
+    // separators separate), so the destination is an ancestor and the tree stays an elimination tree.
+    std::vector<int> depth(nn, 0);
+    for (int t = nn - 1; t >= 0; t--) depth[t] = N[t].parent >= 0 ? depth[N[t].parent] + 1 : 0;      // parents are numbered after their children
     int moved = 0;
-    for (int t = 0; t < nn; t++) {            // children come before their parents: an unknown moved up is looked at again in its new front
+    for (int t = 0; t < nn; t++) {
       if (N[t].parent < 0) continue;
       std::vector<int> keep;
       for (int u : N[t].own) {
-        bool lonely = diag[d->act[u]] == 0.0;
-        for (int e = G.ptr[u]; e < G.ptr[u + 1] && lonely; e++) lonely = owner[G.adj[e]] != t;
         int dest = -1;
-        if (lonely)
-          for (int a = N[t].parent; a >= 0 && dest < 0; a = N[a].parent)
-            for (int e = G.ptr[u]; e < G.ptr[u + 1] && dest < 0; e++)
-              if (owner[G.adj[e]] == a) dest = a;
+        if (diag[d->act[u]] == 0.0) {
+          int best = t;
+          for (int e = G.ptr[u]; e < G.ptr[u + 1]; e++)
+            if (depth[owner[G.adj[e]]] < depth[best]) best = owner[G.adj[e]];
+          if (best != t) {
+            bool ancestor = false;
+            for (int a = N[t].parent; a >= 0 && !ancestor; a = N[a].parent) ancestor = a == best;
+            if (ancestor) dest = best;
+          }
+        }
         if (dest >= 0) {
           N[dest].own.push_back(u);
           owner[u] = dest;
@@ -966,7 +977,7 @@ static int direct_symbolic(fh_direct_t d) {
       N[t].own.swap(keep);
     }
     for (int t = 0; t < nn; t++) std::sort(N[t].own.begin(), N[t].own.end());
-    if (moved) FH_TRACE("fh_direct: %d unknowns with a zero diagonal entry and no neighbour in their front moved to an ancestor", moved);
+    if (moved) FH_TRACE("fh_direct: %d unknowns with a zero diagonal entry moved to the highest front among their neighbours", moved);
   }
   // post-order numbering: build_tree pushes children before their parent, so node order IS a post-order
   std::vector<int> perm(na), node_of(na);          // perm[new] = position in act ; inverse below

@@ -29,7 +29,8 @@ struct fh_ns_assembler_s {
   double *d_K = nullptr, *d_F = nullptr;
   int *d_adj_ptr = nullptr, *d_adj_ei = nullptr;   // row -> (element * nd + local row), ascending
   int max_row = 0;
-  int kind = 0;                 // 0: Taylor-Hood (03_navier_stokes.hpp), 1: equal-order linear with the Franca-Frey stabilisation (the application's callback)
+  int kind = 0;                 // 0: Taylor-Hood (03_navier_stokes.hpp), 1: equal-order linear with the Franca-Frey stabilisation (the application's callback),
+                                // 2: Q2 velocity with the discontinuous piecewise-linear pressure (unittests/testNSSteadyDD)
   double* d_d2phi = nullptr;    // kind 1: second reference derivatives [ng][nv][nh]
 };
 
@@ -44,18 +45,21 @@ struct NsParams {
   double nu;
 };
 
-template <int DIM>
+// PW = false: continuous linear pressure on the vertex nodes (Taylor-Hood, 03_navier_stokes.hpp); PW = true: DISCONTINUOUS_POLYNOMIAL FIRST, the pressure
+// space of the reference's known-answer test (unittests/testNSSteadyDD/main.cpp:97; callback :396-726, the same weak form): psi = 1, xi, eta (, zeta) in
+// REFERENCE coordinates (quadpwLinear / hexpwLinear::eval_phi, Quadrilateral.cpp:188-200), dofs owned by the element: i * nel + iel behind the velocities
+template <int DIM, bool PW = false>
 struct NsCfg {
   static constexpr int NV = (DIM == 2) ? 9 : 27;
-  static constexpr int NP = (DIM == 2) ? 4 : 8;
+  static constexpr int NP = PW ? DIM + 1 : ((DIM == 2) ? 4 : 8);
   static constexpr int ND = DIM * NV + NP;
   static constexpr int NT = (DIM == 2) ? 64 : 256;
   static constexpr int EPT = (ND * ND + NT - 1) / NT;
 };
 
-template <int DIM>
-__global__ __launch_bounds__(NsCfg<DIM>::NT) void k_ns_elem(NsParams P) {
-  using C = NsCfg<DIM>;
+template <int DIM, bool PW = false>
+__global__ __launch_bounds__((DIM == 2) ? 64 : 256) void k_ns_elem(NsParams P) {
+  using C = NsCfg<DIM, PW>;
   constexpr int NV = C::NV, NP = C::NP, ND = C::ND, NT = C::NT, EPT = C::EPT;
   __shared__ double xv[NV * DIM], uv[DIM * NV], pr[NP];
   __shared__ double G[NV * DIM], Jm[DIM * DIM], sc[DIM + DIM * DIM + 2];   // u[DIM], gu[DIM*DIM], p, w
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(NsCfg<DIM>::NT) void k_ns_elem(NsParams P) {
     xv[t] = P.coords[(size_t)ed[n] * DIM + d];
   }
   for (int t = tid; t < DIM * NV; t += NT) uv[t] = P.sol ? P.sol[(size_t)(t / NV) * P.nnode + ed[t % NV]] : 0.0;
-  for (int t = tid; t < NP; t += NT) pr[t] = P.sol ? P.sol[(size_t)DIM * P.nnode + ed[t]] : 0.0;
+  for (int t = tid; t < NP; t += NT) pr[t] = P.sol ? P.sol[(size_t)DIM * P.nnode + (PW ? (size_t)t * P.nel + e : (size_t)ed[t])] : 0.0;
   // this thread's entries of the element Jacobian: (row, col) -> (variable, node)
   int er[EPT], ec[EPT];
   double acc[EPT];
@@ -467,40 +471,50 @@ __global__ __launch_bounds__(64) void k_ns_stab_elem(NsStabParams P) {
   if (tid < ND) P.F[(size_t)e * ND + tid] = racc;
 }
 
-extern "C" int fh_ns_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, int n_vertex_nodes,
-                                      const double* coords, fh_mat_t A, fh_ns_assembler_t* out) {
+// pw: the pressure is the discontinuous piecewise-linear space (kind 2), n_vertex_nodes is not used then
+static int ns_assembler_create_impl(fh_ctx_t ctx, int geom, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, int n_vertex_nodes,
+                                    const double* coords, fh_mat_t A, bool pw, fh_ns_assembler_t* out) {
   FH_GUARD_BEGIN
   FH_REQUIRE(ctx && elem_dof && coords && A && out, "fh_ns_assembler_create: null argument");
   FH_REQUIRE(geom == 0 || geom == 1, "fh_ns_assembler_create: geom must be 0 (hex) or 1 (quad)");
   FH_REQUIRE(nloc == fhfe::nloc_of(geom), "fh_ns_assembler_create: nloc %d does not match the geometry", nloc);
   fh_ns_assembler_t as = new fh_ns_assembler_s();
   as->ctx = ctx;
+  as->kind = pw ? 2 : 0;
   as->geom = geom;
   as->dim = fhfe::dim_of(geom);
   as->nv = fhfe::ndofs_of(geom, fhfe::FE_BIQUADRATIC);
-  as->np = fhfe::ndofs_of(geom, fhfe::FE_LINEAR);
+  as->np = pw ? as->dim + 1 : fhfe::ndofs_of(geom, fhfe::FE_LINEAR);
   as->nd = as->dim * as->nv + as->np;
   as->nloc = nloc;
   as->nel = nel;
   as->nnode = nnode;
-  as->nq1 = n_vertex_nodes;
-  as->ndof = as->dim * nnode + n_vertex_nodes;
+  as->nq1 = pw ? 0 : n_vertex_nodes;
+  FH_REQUIRE((int64_t)as->dim * nnode + (pw ? (int64_t)as->np * nel : (int64_t)n_vertex_nodes) < 2147483647ll, "fh_ns_assembler_create: the system does not fit 32-bit ids");
+  as->ndof = as->dim * nnode + (pw ? as->np * nel : n_vertex_nodes);
   FH_REQUIRE(A->m == as->ndof && A->n == as->ndof, "fh_ns_assembler_create: matrix is %d x %d, the system has %d rows", A->m, A->n, as->ndof);
   std::vector<double> w, phi, dphi, w1, psi, dpsi;
   FH_REQUIRE(fhfe::shape_tables(geom, fhfe::FE_BIQUADRATIC, gauss_order, w, phi, dphi) == 0 &&
                  fhfe::shape_tables(geom, fhfe::FE_LINEAR, gauss_order, w1, psi, dpsi) == 0,
              "fh_ns_assembler_create: unsupported Gauss rule %d", gauss_order);
   as->ng = (int)w.size();
+  if (pw) {      // GetPhi(ig) of the discontinuous family: 1 and the reference coordinates of the Gauss point
+    std::vector<double> gw(as->ng), gx((size_t)as->ng * as->dim);
+    FH_REQUIRE(fhfe::gauss_table(geom, gauss_order, gw.data(), gx.data()) == 0, "fh_ns_assembler_create: unsupported Gauss rule %d", gauss_order);
+    psi.assign((size_t)as->ng * as->np, 1.0);
+    for (int g = 0; g < as->ng; g++)
+      for (int d = 0; d < as->dim; d++) psi[(size_t)g * as->np + 1 + d] = gx[(size_t)d * as->ng + g];      // gauss_table: one array per coordinate
+  }
   const int nd = as->nd;
   std::vector<int> es((size_t)nel * nd);
   for (int e = 0; e < nel; e++) {
     const int* ed = elem_dof + (size_t)e * nloc;
     for (int i = 0; i < nloc; i++) FH_REQUIRE(ed[i] >= 0 && ed[i] < nnode, "fh_ns_assembler_create: node id %d out of range", ed[i]);
-    for (int i = 0; i < as->np; i++) FH_REQUIRE(ed[i] < n_vertex_nodes, "fh_ns_assembler_create: vertex node %d is not a linear dof", ed[i]);
+    for (int i = 0; i < as->np && !pw; i++) FH_REQUIRE(ed[i] < n_vertex_nodes, "fh_ns_assembler_create: vertex node %d is not a linear dof", ed[i]);
     int p = 0;
     for (int k = 0; k < as->dim; k++)
       for (int i = 0; i < as->nv; i++) es[(size_t)e * nd + p++] = k * nnode + ed[i];
-    for (int i = 0; i < as->np; i++) es[(size_t)e * nd + p++] = as->dim * nnode + ed[i];
+    for (int i = 0; i < as->np; i++) es[(size_t)e * nd + p++] = as->dim * nnode + (pw ? i * nel + e : ed[i]);
   }
   // row -> (element, local row) adjacency in ascending element order
   std::vector<int> aptr(as->ndof + 1, 0);
@@ -549,6 +563,16 @@ extern "C" int fh_ns_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, i
   FH_GUARD_END("fh_ns_assembler_create")
 }
 
+extern "C" int fh_ns_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, int n_vertex_nodes,
+                                      const double* coords, fh_mat_t A, fh_ns_assembler_t* out) {
+  return ns_assembler_create_impl(ctx, geom, gauss_order, nel, nloc, elem_dof, nnode, n_vertex_nodes, coords, A, false, out);
+}
+
+extern "C" int fh_ns_pw_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, const double* coords,
+                                         fh_mat_t A, fh_ns_assembler_t* out) {
+  return ns_assembler_create_impl(ctx, geom, gauss_order, nel, nloc, elem_dof, nnode, 0, coords, A, true, out);
+}
+
 extern "C" int fh_ns_assembler_destroy(fh_ns_assembler_t as) {
   if (!as) return 0;
   hipStreamSynchronize(as->ctx->stream);
@@ -577,7 +601,10 @@ static int ns_element_pass(fh_ns_assembler_t as, fh_vec_t sol, double nu) {
   P.nnode = as->nnode;
   P.nu = nu;
   if (as->nel == 0) return 0;
-  if (as->dim == 2) hipLaunchKernelGGL(k_ns_elem<2>, dim3(as->nel), dim3(NsCfg<2>::NT), 0, as->ctx->stream, P);
+  if (as->kind == 2) {
+    if (as->dim == 2) hipLaunchKernelGGL((k_ns_elem<2, true>), dim3(as->nel), dim3(NsCfg<2, true>::NT), 0, as->ctx->stream, P);
+    else hipLaunchKernelGGL((k_ns_elem<3, true>), dim3(as->nel), dim3(NsCfg<3, true>::NT), 0, as->ctx->stream, P);
+  } else if (as->dim == 2) hipLaunchKernelGGL(k_ns_elem<2>, dim3(as->nel), dim3(NsCfg<2>::NT), 0, as->ctx->stream, P);
   else hipLaunchKernelGGL(k_ns_elem<3>, dim3(as->nel), dim3(NsCfg<3>::NT), 0, as->ctx->stream, P);
   FH_CHECK_HIP(hipGetLastError());
   return 0;
@@ -706,7 +733,7 @@ extern "C" int fh_assemble_navier_stokes_stab(fh_ns_assembler_t as, fh_vec_t sol
 
 extern "C" int fh_assemble_navier_stokes(fh_ns_assembler_t as, fh_vec_t sol, double nu, fh_mat_t A, fh_vec_t res) {
   FH_REQUIRE(as && A && res, "fh_assemble_navier_stokes: null argument");
-  FH_REQUIRE(as->kind == 0, "fh_assemble_navier_stokes: this assembler was created for the stabilised equal-order form (fh_assemble_navier_stokes_stab)");
+  FH_REQUIRE(as->kind == 0 || as->kind == 2, "fh_assemble_navier_stokes: this assembler was created for the stabilised equal-order form (fh_assemble_navier_stokes_stab)");
   FH_REQUIRE(A->m == as->ndof && res->n_local >= as->ndof, "fh_assemble_navier_stokes: size mismatch");
   FH_TRY(ns_element_pass(as, sol, nu));
   if (as->ndof > 0)

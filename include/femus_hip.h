@@ -385,6 +385,14 @@ int fh_mesh_vertex_patches(fh_mesh_t mesh, int nvars, const int* fe, int* npatch
 typedef struct fh_ns_assembler_s* fh_ns_assembler_t;
 int fh_ns_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, int n_vertex_nodes,
                            const double* coords /* [nnode*dim] */, fh_mat_t A, fh_ns_assembler_t* as);
+/* The same weak form with the pressure space of the reference's KNOWN-ANSWER TEST (unittests/testNSSteadyDD/main.cpp:97, callback :396-726; also
+ * 004_Boussinesq, 000_tutorial/ex08): DISCONTINUOUS_POLYNOMIAL FIRST -- psi = 1, xi, eta (, zeta) in reference coordinates (quadpwLinear /
+ * hexpwLinear, Quadrilateral.cpp:188-200), dim + 1 dofs owned by every element.  Variables stacked [U | V | (W) | P] with the pressure dof of
+ * local function i of element e at dim * nnode + i * nel + e (Mesh::GetSolutionDof for solution type 4 on one process); KK must carry the pattern of
+ * that element table (fh_mat_create_from_elements).  fh_assemble_navier_stokes assembles it.  tests/test_gpu_ns_known_answer.py reproduces the
+ * level-3 norms that test stores (1e-6 there) to 1e-9 with this assembler and the sparse exact solve. */
+int fh_ns_pw_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, const double* coords /* [nnode*dim] */,
+                              fh_mat_t KK, fh_ns_assembler_t* as);
 int fh_ns_assembler_destroy(fh_ns_assembler_t as);
 int fh_assemble_navier_stokes(fh_ns_assembler_t as, fh_vec_t sol, double nu, fh_mat_t A, fh_vec_t res);
 int fh_ns_element_matrices(fh_ns_assembler_t as, fh_vec_t sol, double nu, double* K /* [nel*nd*nd] */, double* F /* [nel*nd] */);

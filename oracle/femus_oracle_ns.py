@@ -81,9 +81,10 @@ def elem_ns_batch(etv, etp, X, UV, Pr, nu):
     return Jac, -aRes
 
 
-def assemble_ns(mesh, lay, sol, nu, order="seventh", pattern=None):
+def assemble_ns(mesh, lay, sol, nu, order="seventh", pattern=None, etp=None):
     etv = fo.ElemType(mesh.geom, "biquadratic", order)
-    etp = fo.ElemType(mesh.geom, "linear", order)
+    if etp is None:
+        etp = fo.ElemType(mesh.geom, "linear", order)
     X = np.transpose(mesh.coords[mesh.elem_dof], (0, 2, 1))
     es = lay.elem_sys
     nv, dim = lay.nv, lay.dim
@@ -589,3 +590,37 @@ def assemble_ns_stab(mesh, lay, sol, IRe, order="seventh", pattern=None):
     b = np.zeros(lay.n)
     np.add.at(b, es.ravel(), Rhs.ravel())
     return sp.csr_matrix((vals, indices, indptr), shape=(lay.n, lay.n)), b
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# Q2 velocity with the DISCONTINUOUS piecewise-linear pressure the reference's known-answer test uses (unittests/testNSSteadyDD/main.cpp:
+# AddSolution("P", DISCONTINUOUS_POLYNOMIAL, FIRST) :97, callback AssembleMatrixResNS :396-726).  The callback's weak form is the one of
+# elem_ns_batch above (nu grad u : grad phi + (u . grad u) phi - p d_k phi ; (div u) psi; full Newton Jacobian, nwtn_alg = 2, :583-600),
+# only the pressure space differs: psi = 1, xi, eta (, zeta) in REFERENCE coordinates (quadpwLinear / hexpwLinear::eval_phi with
+# IND = (0,0), (1,0), (0,1): Quadrilateral.cpp:188-200), evaluated at the Gauss points (GetPhi(ig), main.cpp:553), and its dofs belong to
+# the element: mesh dof of local function i of element iel = i * nel + iel for one process (Mesh::GetSolutionDof, solution type 4).
+# ----------------------------------------------------------------------------------------------------------------------------------
+class PwLinearPressure:
+    def __init__(self, geom, order="seventh"):
+        w, xg = fo.gauss_table(geom, order)
+        self.dim = xg.shape[1]
+        self.nc = self.dim + 1
+        self.ng = w.size
+        self.phi = np.concatenate([np.ones((w.size, 1)), xg], axis=1)
+
+
+class NSLayoutPwLinear:
+    """variables U, V (, W) biquadratic and P discontinuous piecewise linear, stacked (nprocs = 1)"""
+
+    def __init__(self, mesh):
+        self.dim = mesh.dim
+        self.nv = fo.ndofs(mesh.geom, "biquadratic")
+        self.npr = mesh.dim + 1
+        nq2 = fo.n_dofs(mesh, "biquadratic")
+        self.sizes = [nq2] * self.dim + [self.npr * mesh.nel]
+        self.offset = np.concatenate([[0], np.cumsum(self.sizes)])
+        self.n = int(self.offset[-1])
+        self.nd = self.dim * self.nv + self.npr
+        ed = mesh.elem_dof
+        pdof = np.arange(self.npr)[None, :] * mesh.nel + np.arange(mesh.nel)[:, None]
+        self.elem_sys = np.concatenate([ed[:, :self.nv] + self.offset[k] for k in range(self.dim)] + [pdof + self.offset[self.dim]], axis=1)

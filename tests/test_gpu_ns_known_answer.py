@@ -1,0 +1,97 @@
+"""The reference's known-answer test (unittests/testNSSteadyDD/main.cpp, see tests/test_ns_known_answer.py for what it stores and why level 3 is
+untouched by the adaptive levels) THROUGH THE DEVICE PATH: Gambit reader -> three refinements ON THE DEVICE -> pattern of the Q2 / discontinuous
+piecewise-linear system -> Navier-Stokes assembly kernel (fh_ns_pw_assembler_create) -> Dirichlet rows -> sparse exact solve (general fronts: the
+Jacobian has an empty pressure block) -> Newton.  The norms of U, V, P the reference asserts to 1e-6 must come out to 1e-8; and the element
+matrices of the kernel against the oracle restatement of the callback at a random state, 1e-12."""
+import os
+
+import numpy as np
+import pytest
+
+from femus_amd import capi
+from oracle import femus_oracle as fo
+from oracle import femus_oracle_ns as fns
+
+from test_ns_known_answer import CYLINDER, INFLOW, STORED, WALL, inflow_profile, nodes_on
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def hierarchy(ctx, nref):
+    m = capi.Mesh.read_gambit(os.path.join(HERE, "golden", "nsbenc.neu"))
+    for _ in range(nref):
+        m = m.refine(ctx)
+    return m
+
+
+@pytest.mark.parametrize("nref", [0, 1])
+def test_element_matrices_with_the_piecewise_linear_pressure_match_the_oracle(ctx, nref):
+    m = hierarchy(ctx, nref)
+    ed, xy, ff = m.arrays()
+    mo = fo.Mesh("quad", ed, xy, ff, level=nref)
+    lay = fns.NSLayoutPwLinear(mo)
+    es = capi.NSPwAssembler.elem_sys(m)
+    assert np.array_equal(es, lay.elem_sys)
+    KK = ctx.matrix_from_elements(es, lay.n)
+    asm = capi.NSPwAssembler(ctx, m, KK)
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, lay.n)
+    sol, res = ctx.vector_from(x), ctx.vector(lay.n)
+    K, F = asm.element_matrices(sol, 0.001)
+    loc = x[lay.elem_sys]
+    X = np.transpose(mo.coords[mo.elem_dof], (0, 2, 1))
+    Jo, Ro = fns.elem_ns_batch(fo.ElemType("quad", "biquadratic", "seventh"), fns.PwLinearPressure("quad", "seventh"), X,
+                               loc[:, :18].reshape(mo.nel, 2, 9), loc[:, 18:], 0.001)
+    assert abs(K - Jo).max() <= 1e-12 * abs(Jo).max()
+    assert abs(F - Ro).max() <= 1e-12 * max(abs(Ro).max(), 1.0)
+    # and assembled: the CSR operator and residual against the oracle's
+    asm.assemble(KK, res, sol, 0.001)
+    Ao, bo = fns.assemble_ns(mo, lay, x, 0.001, etp=fns.PwLinearPressure("quad", "seventh"))
+    assert abs(KK.to_scipy() - Ao).max() <= 1e-12 * abs(Ao).max()
+    assert np.linalg.norm(res.to_numpy() - bo) <= 1e-12 * np.linalg.norm(bo)
+    asm.destroy(); KK.destroy()
+
+
+def test_level3_norms_of_the_reference_known_answer_test_on_the_device(ctx):
+    m = hierarchy(ctx, 3)
+    assert m.nel == 98 * 64
+    ed, xy, ff = m.arrays()
+    mo = fo.Mesh("quad", ed, xy, ff, level=3)                       # node sets of the boundary only (host logic of the test)
+    nq2 = m.nnode
+    n = 2 * nq2 + 3 * m.nel
+    dn = np.unique(np.concatenate([nodes_on(mo, INFLOW), nodes_on(mo, WALL), nodes_on(mo, CYLINDER)]))
+    inflow = nodes_on(mo, INFLOW)
+    bdc = np.concatenate([dn, dn + nq2]).astype(np.int32)
+    x0 = np.zeros(n)
+    x0[:nq2] = inflow_profile(xy[:, 1])
+    x0[dn] = 0.0
+    x0[inflow] = inflow_profile(xy[inflow, 1])
+    KK = ctx.matrix_from_elements(capi.NSPwAssembler.elem_sys(m), n)
+    asm = capi.NSPwAssembler(ctx, m, KK)
+    sol, res, eps = ctx.vector_from(x0), ctx.vector(n), ctx.vector(n)
+    bidx = capi.Index(ctx, bdc)
+    # where the unknowns lie (nested dissection of the fronts): nodes for the velocities, the element centre for its three pressure functions
+    cen = xy[ed[:, 8]]
+    d = capi.Direct(ctx, KK, np.concatenate([xy, xy, cen, cen, cen]))
+    hist = []
+    for it in range(12):
+        asm.assemble(KK, res, sol, 0.001)
+        bidx.zero_rows(KK, 1.0)                                     # SetPenalty on the Dirichlet rows, their residual entries to zero
+        bidx.set(res, 0.0)
+        d.factor()
+        d.solve(res, eps)
+        sol.add(1.0, eps)
+        e, s = eps.to_numpy(), sol.to_numpy()
+        hist.append(max(np.linalg.norm(e[a:b]) / np.linalg.norm(s[a:b]) for a, b in ((0, nq2), (nq2, 2 * nq2), (2 * nq2, n))))
+        if hist[-1] < 1e-12:
+            break
+    assert hist[-1] < 1e-12, hist
+    st = d.stats()
+    assert st["general"]                                            # the pivoted fronts served it
+    s = sol.to_numpy()
+    got = {"U": np.linalg.norm(s[:nq2]), "V": np.linalg.norm(s[nq2:2 * nq2]), "P": np.linalg.norm(s[2 * nq2:])}
+    rel = {k: abs(got[k] - STORED[k]) / STORED[k] for k in got}
+    print("device path, level-3 norms", got, "relative distance to the stored numbers", rel, "Newton updates", hist, st)
+    assert max(rel.values()) < 1e-8, rel
+    d.destroy(); asm.destroy(); KK.destroy()
