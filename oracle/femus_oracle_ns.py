@@ -1,9 +1,13 @@
 """TEST INFRASTRUCTURE ONLY -- CPU restatement (numpy/scipy) of FEMuS's steady Navier-Stokes Newton/multigrid path
 (BASELINE config "003_NavierStokes lid-driven cavity, Q2/Q1 Taylor-Hood, Newton + GMG-preconditioned GMRES").
 
-Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  Parity status: *unpinned*
-(the reference needs PETSc + adept to run this path and stores no numbers for it); anchored on the call sites below, on a
-finite-difference check of the hand-derived Jacobian against the residual and on domain properties.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  Parity status: the Taylor-Hood weak form,
+its Newton linearisation, the FE tables / Jacobian on curved elements and the boundary treatment are PINNED against the reference's own
+known-answer test (unittests/testNSSteadyDD/main.cpp:202-244 stores the level-3 norms of U, V, P, T of the cylinder flow; with that test's
+pressure space -- NSLayoutPwLinear / PwLinearPressure at the end of this file -- elem_ns_batch / assemble_ns reproduce them to 4e-10,
+tests/test_ns_known_answer.py).  Unpinned (the reference needs PETSc + adept to run it and stores no numbers): the multigrid / smoother
+restatements and the stabilised equal-order form; anchored on the call sites below, on finite-difference / complex-step checks of the
+hand-derived Jacobians against the residuals and on domain properties.
 
 Restated from
   src/08_equations/assemble/03_navier_stokes.hpp:330-395   Gauss loop: aResV[k][i] = (nu grad phi_i . grad u_k + phi_i (u . grad) u_k
