@@ -137,6 +137,7 @@ def _declare(L):
     sig("fh_assembler_info", c_void_p, P(c_int), P(ctypes.c_int64), P(c_double))
     sig("fh_element_matrices_poisson", c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p)
     sig("fh_fe_face_nodes", c_int, c_int, c_int, P(c_int), c_void_p)
+    sig("fh_fe_node_ref", c_int, c_int, c_void_p)
     sig("fh_assemble_neumann_faces", c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p)
     sig("fh_assemble_neumann_faces_expr", c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p)
     sig("fh_assemble_pressure_faces", c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_double, c_void_p)

@@ -730,6 +730,14 @@ def fe_elem_prolongator(geom, fe):
     return P
 
 
+def fe_node_ref(geom, node, d=None):
+    """reference coordinates (-1, 0, 1) of a local node of the biquadratic element"""
+    dim = 3 if geom == "hex" else 2
+    out = np.zeros(3, np.int32)
+    _chk(load_library().fh_fe_node_ref(GEOM[geom], int(node), _p(out)))
+    return out[:dim].copy() if d is None else int(out[d])
+
+
 def fe_face_nodes(geom, fe, face):
     L = load_library()
     n = ctypes.c_int()

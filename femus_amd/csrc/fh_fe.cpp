@@ -311,6 +311,14 @@ extern "C" int fh_fe_elem_prolongator(int geom, int fe, int* nchild, int* nc, do
   return 0;
 }
 
+// reference coordinates (-1, 0, 1 per direction) of local node `node` of the biquadratic element (hex_lag / quad_lag X tables, Hexahedron.cpp:32-92)
+extern "C" int fh_fe_node_ref(int geom, int node, int* xi) {
+  FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_node_ref: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(node >= 0 && node < fhfe::nloc_of(geom) && xi, "fh_fe_node_ref: node %d out of range", node);
+  for (int d = 0; d < fhfe::dim_of(geom); d++) xi[d] = fhfe::xc(geom, node, d);
+  return 0;
+}
+
 extern "C" int fh_fe_face_nodes(int geom, int fe, int face, int* nfn, int* local_nodes) {
   FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_face_nodes: geom must be 0 (hex) or 1 (quad)");
   FH_REQUIRE(fe == 0 || fe == 2, "fh_fe_face_nodes: fe must be 0 or 2");

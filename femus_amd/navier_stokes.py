@@ -232,3 +232,119 @@ class NavierStokesMG:
                 m.destroy()
         for m in self.meshes:
             m.destroy()
+
+
+class NavierStokesPwMG(NavierStokesMG):
+    """The same driver for the discretisation of the reference's known-answer test (unittests/testNSSteadyDD/main.cpp): Q2 velocity with the
+    DISCONTINUOUS piecewise-linear pressure (AddSolution("P", DISCONTINUOUS_POLYNOMIAL, FIRST), :97) on given meshes, the level solver that test sets
+    (SetSolverFineGrids(GMRES) + SetPreconditionerFineGrids(ILU_PRECOND), :150-152: GMRES around ILU(0) on every level above the coarsest, exact solve
+    below) inside the nonlinear F-cycle.  Pressure dofs are owned by the elements (i * nel + iel behind the velocities); their interpolation is the
+    element prolongator of solution type 4 (ElemType.cpp:446-520: the coarse function at the child's centre for the constant, half the coarse slope for
+    the two / three linear functions)."""
+
+    def __init__(self, ctx, meshes, nu, boundary_condition, omega=1.0, npre=1, npost=1, order="seventh", level_gmres_its=4):
+        self.ctx, self.nlevels, self.nu = ctx, len(meshes), nu
+        self.omega, self.npre, self.npost, self.order = omega, npre, npost, order
+        self.meshes = list(meshes)
+        self.dim = meshes[0].dim
+        self.names = ["U", "V", "W"][:self.dim] + ["P"]
+        self.fes = ["biquadratic"] * self.dim + ["pwlinear"]
+        self.bc = boundary_condition
+        self.open_pressure = None
+        self.level_gmres_its = level_gmres_its
+        self.history = []
+
+    @staticmethod
+    def pressure_prolongator(mc, mf):
+        """[(dim + 1) nel_f] x [(dim + 1) nel_c], scipy: function f of child j of coarse element e"""
+        import scipy.sparse as sp
+        dim, nch = mc.dim, 2 ** mc.dim
+        child = mc.child_elems()                                    # [nel_c, nch], -1 for elements carried over unrefined
+        ed_c, xy_c, _ = mc.arrays()
+        ed_f, xy_f, _ = mf.arrays()
+        rows, cols, vals = [], [], []
+        centre_node = 3 ** dim - 1
+        for e in range(mc.nel):
+            kids = child[e]
+            if kids[1] < 0:                                         # not refined: the same functions on the same element
+                for f in range(dim + 1):
+                    rows.append(f * mf.nel + kids[0]); cols.append(f * mc.nel + e); vals.append(1.0)
+                continue
+            for j in range(nch):
+                jel = kids[j]
+                # centre of the child in the reference coordinates of its father: the sign pattern of the father's vertex it keeps
+                xi = [0.5 * capi.fe_node_ref(mc.geom, j, d) for d in range(dim)]
+                rows.append(jel); cols.append(e); vals.append(1.0)
+                for d in range(dim):
+                    rows.append(jel); cols.append((1 + d) * mc.nel + e); vals.append(xi[d])
+                    rows.append((1 + d) * mf.nel + jel); cols.append((1 + d) * mc.nel + e); vals.append(0.5)
+        return sp.csr_matrix((vals, (rows, cols)), shape=((dim + 1) * mf.nel, (dim + 1) * mc.nel))
+
+    def init(self):
+        import scipy.sparse as sp
+        ctx, nl, dim = self.ctx, self.nlevels, self.dim
+        self.offsets, self.elem_sys, self.n = [], [], []
+        self.bdc, self.bdc_val = [], []
+        self.KK, self.asm, self.SOL, self.RES, self.EPS, self.RESC = [], [], [], [], [], []
+        for l, m in enumerate(self.meshes):
+            es = capi.NSPwAssembler.elem_sys(m)
+            off = np.array([k * m.nnode for k in range(dim + 1)] + [dim * m.nnode + (dim + 1) * m.nel])
+            n = int(off[-1])
+            self.offsets.append(off), self.elem_sys.append(es), self.n.append(n)
+            idx, val = generate_bdc(m, self.names[:dim], self.fes[:dim], off, self.bc)       # the pressure carries no boundary condition
+            self.bdc.append(idx), self.bdc_val.append(val)
+            K = ctx.matrix_from_elements(es, n)
+            self.KK.append(K)
+            self.asm.append(capi.NSPwAssembler(ctx, m, K, self.order))
+            self.SOL.append(ctx.vector(n))
+            self.RES.append(ctx.vector(n)), self.EPS.append(ctx.vector(n)), self.RESC.append(ctx.vector(n))
+        self.open_faces = [None] * nl
+        self.Psol, self.P = [None], [None]
+        for l in range(1, nl):
+            Pq = capi.build_prolongator(ctx, self.meshes[l - 1], self.meshes[l], "biquadratic", zero_bdc=False)
+            Ps = sp.block_diag([Pq.to_scipy()] * dim + [self.pressure_prolongator(self.meshes[l - 1], self.meshes[l])]).tocsr()
+            Pq.destroy()
+            self.Psol.append(ctx.matrix_scipy(Ps))
+            P = ctx.matrix_scipy(Ps)
+            P.mat_zero_rows(self.bdc[l], 0.0)
+            P.zero_cols(self.bdc[l - 1])
+            self.P.append(P)
+        self.A, self.mg = {}, {}
+        return self
+
+    def set_state(self, level, values):
+        """Initialize(...) + the boundary values of GenerateBdc on one level"""
+        x = np.array(values, float)
+        x[self.bdc[level]] = self.bdc_val[level]
+        self.SOL[level].upload(x)
+
+    def prepare(self, ig):
+        ctx = self.ctx
+        self.asm[ig].assemble(self.KK[ig], self.RES[ig], self.SOL[ig], self.nu)
+        self.A[(ig, ig)] = self.KK[ig]
+        for l in range(ig, 0, -1):
+            if (ig, l - 1) not in self.A:
+                self.A[(ig, l - 1)] = capi.Mat.ptap(self.P[l], self.A[(ig, l)])
+            else:
+                self.A[(ig, l - 1)].ptap_numeric(self.P[l], self.A[(ig, l)])
+        for l in range(ig + 1):
+            self.A[(ig, l)].mat_zero_rows(self.bdc[l], 1.0)
+        if self.bdc[ig].size:
+            self.RES[ig].set(self.bdc[ig], np.zeros(self.bdc[ig].size))
+        if ig not in self.mg:
+            self.mg[ig] = capi.Multigrid(ctx, ig + 1)
+            for l in range(1, ig + 1):
+                self.mg[ig].set_level_solver(l, "gmres", 30)
+        mg = self.mg[ig]
+        for l in range(ig + 1):
+            its = self.level_gmres_its
+            mg.set_level(l, self.A[(ig, l)], self.P[l] if l > 0 else None, None, capi.SMOOTH_ILU0, self.omega, its * self.npre if l > 0 else 1,
+                         its * self.npost if l > 0 else 0)
+        mg.setup()
+        return mg
+
+    def newton_step(self, ig, lin_rtol=1e-10, lin_maxit=60, restart=30):
+        mg = self.prepare(ig)
+        its, rn = mg.solve(self.RES[ig], self.EPS[ig], outer="fgmres" if ig > 0 else "preonly", rtol=lin_rtol, atol=1e-50, maxit=lin_maxit, restart=restart)
+        self.SOL[ig].add(1.0, self.EPS[ig])
+        return its, rn

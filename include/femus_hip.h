@@ -333,6 +333,8 @@ int fh_assembler_last_path(fh_assembler_t as, int* path);
  * face_nodes[nfaces*nfn]: node ids of each face in the face element's own local order (fh_fe_face_nodes), nfn = 9/4 (hex faces,
  * Q2/Q1) or 3/2 (quad edges); tau[nfaces]: flux per face.  Contributions to a node are summed in ascending face order. */
 int fh_fe_face_nodes(int geom, int fe, int face, int* nfn, int* local_nodes);
+/* reference coordinates (-1, 0, 1 per direction) of a local node of the biquadratic element (the X tables of hex_lag / quad_lag) */
+int fh_fe_node_ref(int geom, int node, int* xi /* [dim] */);
 int fh_assemble_neumann_faces(fh_ctx_t ctx, int geom, int fe, int gauss_order, int nfaces, const int* face_nodes, const double* tau,
                               int nnode, const double* coords, fh_vec_t res);
 

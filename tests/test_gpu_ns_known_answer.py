@@ -95,3 +95,56 @@ def test_level3_norms_of_the_reference_known_answer_test_on_the_device(ctx):
     print("device path, level-3 norms", got, "relative distance to the stored numbers", rel, "Newton updates", hist, st)
     assert max(rel.values()) < 1e-8, rel
     d.destroy(); asm.destroy(); KK.destroy()
+
+
+def _bc(x, name, face):          # main.cpp:290-392: faces 1 inflow, 2 outflow (nothing prescribed), 3 walls, 4 cylinder
+    if face == 2:
+        return False, 0.0
+    return True, (inflow_profile(x[1]) if (name == "U" and face == 1) else 0.0)
+
+
+def test_known_answer_through_the_multigrid_path(ctx):
+    """the same numbers from the path the reference's test itself takes (main.cpp:139-160): nonlinear F-cycle over levels 0 .. 3, per Newton step the
+    Galerkin chain, an exact solve on level 0 and GMRES + ILU(0) level solvers above (SetSolverFineGrids(GMRES), SetPreconditionerFineGrids(ILU_PRECOND),
+    four iterations per smoothing step: SetTolerances(..., 4)), one pre- and one post-smoothing step, preconditioning an outer flexible GMRES.  The element-owned
+    pressures travel between the levels with the element prolongator of solution type 4 (ElemType.cpp:446-520)."""
+    from femus_amd.navier_stokes import NavierStokesPwMG
+    ms = [capi.Mesh.read_gambit(os.path.join(HERE, "golden", "nsbenc.neu"))]
+    for _ in range(3):
+        ms.append(ms[-1].refine(ctx))
+    pb = NavierStokesPwMG(ctx, ms, 0.001, _bc, level_gmres_its=4).init()
+    x = np.zeros(pb.n[0])
+    x[:ms[0].nnode] = inflow_profile(ms[0].arrays()[1][:, 1])          # Initialize("U", InitVariableU) on the coarsest level; the F-cycle prolongs from there
+    pb.set_state(0, x)
+    assert pb.mgsolve(tol=1e-10, max_newton=20, lin_rtol=1e-10, lin_maxit=100)
+    # what the reference's own limits (three Newton steps per level, stop at a relative update of 1e-4) would have kept: every level needed at most that
+    for ig in range(1, 4):
+        steps = [h for h in pb.history if h[0] == ig]
+        assert [h[2] for h in steps][min(2, len(steps) - 1)] < 1e-4
+        assert max(h[3] for h in steps) <= 30                                  # outer iterations of a linear solve
+    s = pb.SOL[3].to_numpy()
+    nq = ms[3].nnode
+    got = {"U": np.linalg.norm(s[:nq]), "V": np.linalg.norm(s[nq:2 * nq]), "P": np.linalg.norm(s[2 * nq:])}
+    rel = {k: abs(got[k] - STORED[k]) / STORED[k] for k in got}
+    print("multigrid path, level-3 norms", got, rel, pb.history)
+    assert max(rel.values()) < 1e-8, rel
+    pb.destroy()
+
+
+def test_pressure_prolongator_reproduces_a_linear_pressure(ctx):
+    """solution type 4 between two levels of an affine box mesh: p = a + b x + c y on the coarse elements arrives as the same function on their children"""
+    from femus_amd.navier_stokes import NavierStokesPwMG
+    mc = capi.Mesh.box(3, 2, 0, lo=(0., 0., 0.), hi=(3., 1., 0.))
+    mf = mc.refine(ctx)
+    P = NavierStokesPwMG.pressure_prolongator(mc, mf)
+
+    def coefficients(m, f):
+        ed, xy, _ = m.arrays()
+        xc = xy[ed[:, 8]]                                          # element centres; half sizes from the vertices (affine elements)
+        hx = 0.5 * (xy[ed[:, 1], 0] - xy[ed[:, 0], 0])
+        hy = 0.5 * (xy[ed[:, 3], 1] - xy[ed[:, 0], 1])
+        a, b, c = f
+        return np.concatenate([a + b * xc[:, 0] + c * xc[:, 1], b * hx, c * hy])      # value at the centre, slope per reference unit
+
+    f = (0.3, -1.7, 2.2)
+    assert np.allclose(P @ coefficients(mc, f), coefficients(mf, f), rtol=0, atol=1e-14)
