@@ -831,6 +831,7 @@ struct fh_direct_s {
   // general (unsymmetric / indefinite) operators
   bool general = false;            // the layout below was made for the pivoted path
   int force_general = 0;           // fh_direct_set_general: 1 = always the pivoted path
+  int zero_rule = 0;           // placement of zero-diagonal unknowns in the tree of the general fronts: 0 lowest ancestor if lonely, 1 highest neighbour front (direct_symbolic)
   int perturbed = 0;               // pivots replaced by the static perturbation in the last factorisation
   int refine = 0;                  // steps of iterative refinement in every solve (2 behind a perturbed factorisation)
   void* d_ginv = nullptr;
@@ -944,6 +945,8 @@ static int direct_symbolic(fh_direct_t d) {
     std::vector<int> owner(na, -1);
     for (int t = 0; t < nn; t++)
       for (int u : N[t].own) owner[u] = t;
+    // Two placements.  zero_rule 0 (tried first; continuous pressures are served by it with the smaller fronts): an unknown none of whose neighbours lies
+    // in its own front moves to the lowest ancestor that owns one.  zero_rule 1 (taken when the first factorisation had to perturb a pivot):
     // Round 5 (the Q2 / discontinuous-pressure Jacobian of unittests/testNSSteadyDD): "no neighbour in its front" is not enough -- a front that owns the
     // three pressure functions of an element but only some of its velocity nodes holds a singular pivot block (the element's divergence constraint reaches
     // velocities of an ancestor).  A zero-diagonal unknown therefore goes to the HIGHEST front that owns one of its neighbours: every unknown it couples to
@@ -957,7 +960,7 @@ static int direct_symbolic(fh_direct_t d) {
       std::vector<int> keep;
       for (int u : N[t].own) {
         int dest = -1;
-        if (diag[d->act[u]] == 0.0) {
+        if (diag[d->act[u]] == 0.0 && d->zero_rule == 1) {
           int best = t;
           for (int e = G.ptr[u]; e < G.ptr[u + 1]; e++)
             if (depth[owner[G.adj[e]]] < depth[best]) best = owner[G.adj[e]];
@@ -966,6 +969,13 @@ static int direct_symbolic(fh_direct_t d) {
             for (int a = N[t].parent; a >= 0 && !ancestor; a = N[a].parent) ancestor = a == best;
             if (ancestor) dest = best;
           }
+        } else if (diag[d->act[u]] == 0.0) {      // first attempt (smaller fronts): only an unknown with no neighbour in its own front moves, to the lowest ancestor that owns one
+          bool lonely = true;
+          for (int e = G.ptr[u]; e < G.ptr[u + 1] && lonely; e++) lonely = owner[G.adj[e]] != t;
+          if (lonely)
+            for (int a = N[t].parent; a >= 0 && dest < 0; a = N[a].parent)
+              for (int e = G.ptr[u]; e < G.ptr[u + 1] && dest < 0; e++)
+                if (owner[G.adj[e]] == a) dest = a;
         }
         if (dest >= 0) {
           N[dest].own.push_back(u);
@@ -1360,6 +1370,17 @@ extern "C" int fh_direct_factor(fh_direct_t d) {
   if (broke) {          // symmetric but not definite (a saddle point with symmetric blocks, a shifted operator): the pivoted path
     FH_TRACE("fh_direct: a symmetric front has no usable pivot without pivoting -- general fronts");
     d->general = true;
+    FH_TRY(direct_symbolic(d));
+    FH_TRY(direct_numeric(d, &broke));
+  }
+  if (d->general && d->perturbed > 0 && d->zero_rule == 0) {
+    // a pivot block was singular to working precision although the operator need not be: unknowns with a zero diagonal entry (element-owned
+    // pressures, multipliers) sat below velocities they constrain.  Place them in the highest front among their neighbours and factor again; the
+    // placement is kept for this object.
+    FH_TRACE("fh_direct: %d pivots perturbed -- zero-diagonal unknowns move to the highest front among their neighbours", d->perturbed);
+    d->zero_rule = 1;
+    d->perturbed = 0;
+    d->refine = 0;
     FH_TRY(direct_symbolic(d));
     FH_TRY(direct_numeric(d, &broke));
   }
