@@ -8,7 +8,7 @@ import numpy as np
 from ._lib import load_library
 
 GEOM = {"hex": 0, "quad": 1}
-FE = {"linear": 0, "biquadratic": 2}
+FE = {"linear": 0, "biquadratic": 2, "pwlinear": 4}        # 4: DISCONTINUOUS_POLYNOMIAL FIRST (system dof maps and prolongators only)
 GAUSS_ORDER = {"zero": 0, "first": 0, "second": 1, "third": 1, "fourth": 2, "fifth": 2,
                "sixth": 3, "seventh": 3, "eighth": 4, "ninth": 4}
 OUTER = {"preonly": 0, "richardson": 1, "gmres": 2, "cg": 3, "fgmres": 4}

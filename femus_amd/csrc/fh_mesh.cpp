@@ -1147,22 +1147,29 @@ extern "C" int fh_build_amr_prolongator(fh_ctx_t ctx, fh_mesh_t m, int fe, fh_ma
 // multi-variable systems (a9, a21): LinearEquation::GetSystemDof (LinearEquation.cpp:76-85) with the nprocs = 1 offsets
 // KKoffset[k] = sum of the sizes of the variables before k (:212-237).  Variables are Lagrange families 0 (Q1) or 2 (Q2).
 // ---------------------------------------------------------------------------------------------------------------------
-static int check_vars(const char* who, int nvars, const int* fe) {
+// fe: 0 LAGRANGE FIRST, 2 LAGRANGE SECOND; with_pw also 4 = DISCONTINUOUS_POLYNOMIAL FIRST (1, xi, eta (, zeta) on the reference element, dim + 1 dofs owned
+// by every element: Mesh::GetSolutionDof for solution type 4 on one process = i * nel + iel)
+static int check_vars(const char* who, int nvars, const int* fe, bool with_pw = false) {
   FH_REQUIRE(nvars >= 1 && nvars <= 8 && fe, "%s: 1..8 variables expected", who);
-  for (int k = 0; k < nvars; k++) FH_REQUIRE(fe[k] == 0 || fe[k] == 2, "%s: variable %d: fe must be 0 or 2", who, k);
+  for (int k = 0; k < nvars; k++)
+    FH_REQUIRE(fe[k] == 0 || fe[k] == 2 || (with_pw && fe[k] == 4), "%s: variable %d: fe must be 0 or 2%s", who, k, with_pw ? " (or 4, discontinuous linear)" : "");
   return 0;
 }
+static int var_elem_dofs(const fh_mesh_s* m, int fe) { return fe == 4 ? m->dim + 1 : ndofs_of(m->geom, fe); }
+static int var_mesh_dofs(const fh_mesh_s* m, int fe) { return fe == 4 ? (m->dim + 1) * m->nel : mesh_ndofs(m, fe); }
 
 extern "C" int fh_system_elem_dofs(fh_mesh_t m, int nvars, const int* fe, int* nd_out, int* offsets, int* elem_sys) {
   FH_GUARD_BEGIN
   FH_REQUIRE(m, "fh_system_elem_dofs: null mesh");
-  FH_TRY(check_vars("fh_system_elem_dofs", nvars, fe));
-  int nd = 0, off = 0;
+  FH_TRY(check_vars("fh_system_elem_dofs", nvars, fe, true));
+  int nd = 0;
+  int64_t off = 0;
   std::vector<int> offs(nvars + 1, 0);
   for (int k = 0; k < nvars; k++) {
-    nd += ndofs_of(m->geom, fe[k]);
-    off += mesh_ndofs(m, fe[k]);
-    offs[k + 1] = off;
+    nd += var_elem_dofs(m, fe[k]);
+    off += var_mesh_dofs(m, fe[k]);
+    FH_REQUIRE(off < 2147483647ll, "fh_system_elem_dofs: the system does not fit 32-bit ids");
+    offs[k + 1] = (int)off;
   }
   if (nd_out) *nd_out = nd;
   if (offsets) fh_copy_out(offsets, offs);
@@ -1170,7 +1177,8 @@ extern "C" int fh_system_elem_dofs(fh_mesh_t m, int nvars, const int* fe, int* n
     for (int iel = 0; iel < m->nel; iel++) {
       int p = 0;
       for (int k = 0; k < nvars; k++)
-        for (int i = 0; i < ndofs_of(m->geom, fe[k]); i++) elem_sys[(size_t)iel * nd + p++] = offs[k] + m->elem_dof[(size_t)iel * m->nloc + i];
+        for (int i = 0; i < var_elem_dofs(m, fe[k]); i++)
+          elem_sys[(size_t)iel * nd + p++] = offs[k] + (fe[k] == 4 ? i * m->nel + iel : m->elem_dof[(size_t)iel * m->nloc + i]);
     }
   return 0;
   FH_GUARD_END("fh_system_elem_dofs")
@@ -1181,22 +1189,73 @@ extern "C" int fh_system_elem_dofs(fh_mesh_t m, int nvars, const int* fe, int* n
 extern "C" int fh_build_system_prolongator(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t mf, int nvars, const int* fe, fh_mat_t* out) {
   FH_GUARD_BEGIN
   FH_REQUIRE(ctx && mc && mf && out, "fh_build_system_prolongator: null argument");
-  FH_TRY(check_vars("fh_build_system_prolongator", nvars, fe));
+  FH_TRY(check_vars("fh_build_system_prolongator", nvars, fe, true));
   fh_mat_t blk[3] = {nullptr, nullptr, nullptr};
   for (int k = 0; k < nvars; k++)
-    if (!blk[fe[k]]) FH_TRY(fh_build_prolongator(ctx, mc, mf, fe[k], 0, &blk[fe[k]]));
+    if (fe[k] != 4 && !blk[fe[k]]) FH_TRY(fh_build_prolongator(ctx, mc, mf, fe[k], 0, &blk[fe[k]]));
+  // the block of a discontinuous linear variable: the element prolongator of solution type 4 (ElemType.cpp:446-520) -- the coarse function at the centre of
+  // the child for its constant, half the coarse slope for its linear functions; an element carried over unrefined keeps its three / four functions
+  std::vector<int> pw_rp, pw_col;
+  std::vector<double> pw_val;
+  const int npw = mc->dim + 1, nch = nvert_of(mc->geom);
+  bool any_pw = false;
+  for (int k = 0; k < nvars; k++) any_pw |= fe[k] == 4;
+  if (any_pw) {
+    FH_REQUIRE((int)mc->child.size() == mc->nel * nch, "fh_build_system_prolongator: the coarse mesh has not been refined into the fine one");
+    std::vector<int> parent(mf->nel, -1), which(mf->nel, -1);
+    for (int e = 0; e < mc->nel; e++)
+      for (int j = 0; j < nch; j++) {
+        const int jel = mc->child[(size_t)e * nch + j];
+        if (jel < 0) continue;
+        FH_REQUIRE(jel < mf->nel, "fh_build_system_prolongator: child element %d out of range", jel);
+        parent[jel] = e;
+        which[jel] = mc->refined[e] ? j : -1;
+      }
+    for (int j = 0; j < nch; j++) FH_REQUIRE(fine2coarse_vertex(mc->geom, j, j) == j, "fh_build_system_prolongator: child %d does not sit at vertex %d of its father", j, j);
+    pw_rp.assign((size_t)npw * mf->nel + 1, 0);
+    for (int f = 0; f < npw; f++)
+      for (int jel = 0; jel < mf->nel; jel++) {
+        FH_REQUIRE(parent[jel] >= 0, "fh_build_system_prolongator: fine element %d has no father", jel);
+        const int e = parent[jel], j = which[jel];
+        if (f == 0 && j >= 0) {
+          pw_col.push_back(e);
+          pw_val.push_back(1.0);
+          for (int d = 0; d < mc->dim; d++) {
+            pw_col.push_back((1 + d) * mc->nel + e);
+            pw_val.push_back(0.5 * xc(mc->geom, j, d));      // the child's centre in the reference coordinates of its father
+          }
+        } else {
+          pw_col.push_back(f * mc->nel + e);
+          pw_val.push_back(j >= 0 ? 0.5 : 1.0);
+        }
+        pw_rp[(size_t)f * mf->nel + jel + 1] = (int)pw_col.size();
+      }
+  }
   int nf = 0, ncc = 0;
   int64_t nnz = 0;
   for (int k = 0; k < nvars; k++) {
-    nf += blk[fe[k]]->m;
-    ncc += blk[fe[k]]->n;
-    nnz += blk[fe[k]]->nnz;
+    nf += fe[k] == 4 ? npw * mf->nel : blk[fe[k]]->m;
+    ncc += fe[k] == 4 ? npw * mc->nel : blk[fe[k]]->n;
+    nnz += fe[k] == 4 ? (int64_t)pw_col.size() : blk[fe[k]]->nnz;
   }
   FH_REQUIRE(nnz < 2147483647ll, "fh_build_system_prolongator: nnz overflows int32");
   std::vector<int> rowptr(nf + 1, 0), col((size_t)nnz);
   std::vector<double> val((size_t)nnz);
   int r0 = 0, c0 = 0, p = 0;
   for (int k = 0; k < nvars; k++) {
+    if (fe[k] == 4) {
+      const int m4 = npw * mf->nel;
+      for (int i = 0; i < m4; i++) {
+        for (int q = pw_rp[i]; q < pw_rp[i + 1]; q++) {
+          col[p] = c0 + pw_col[q];
+          val[p++] = pw_val[q];
+        }
+        rowptr[r0 + i + 1] = p;
+      }
+      r0 += m4;
+      c0 += npw * mc->nel;
+      continue;
+    }
     fh_mat_t B = blk[fe[k]];
     std::vector<double> bv(B->nnz);
     FH_CHECK_HIP(hipMemcpy(bv.data(), B->d_val, (size_t)B->nnz * sizeof(double), hipMemcpyDeviceToHost));

@@ -254,41 +254,13 @@ class NavierStokesPwMG(NavierStokesMG):
         self.level_gmres_its = level_gmres_its
         self.history = []
 
-    @staticmethod
-    def pressure_prolongator(mc, mf):
-        """[(dim + 1) nel_f] x [(dim + 1) nel_c], scipy: function f of child j of coarse element e"""
-        import scipy.sparse as sp
-        dim, nch = mc.dim, 2 ** mc.dim
-        child = mc.child_elems()                                    # [nel_c, nch], -1 for elements carried over unrefined
-        ed_c, xy_c, _ = mc.arrays()
-        ed_f, xy_f, _ = mf.arrays()
-        rows, cols, vals = [], [], []
-        centre_node = 3 ** dim - 1
-        for e in range(mc.nel):
-            kids = child[e]
-            if kids[1] < 0:                                         # not refined: the same functions on the same element
-                for f in range(dim + 1):
-                    rows.append(f * mf.nel + kids[0]); cols.append(f * mc.nel + e); vals.append(1.0)
-                continue
-            for j in range(nch):
-                jel = kids[j]
-                # centre of the child in the reference coordinates of its father: the sign pattern of the father's vertex it keeps
-                xi = [0.5 * capi.fe_node_ref(mc.geom, j, d) for d in range(dim)]
-                rows.append(jel); cols.append(e); vals.append(1.0)
-                for d in range(dim):
-                    rows.append(jel); cols.append((1 + d) * mc.nel + e); vals.append(xi[d])
-                    rows.append((1 + d) * mf.nel + jel); cols.append((1 + d) * mc.nel + e); vals.append(0.5)
-        return sp.csr_matrix((vals, (rows, cols)), shape=((dim + 1) * mf.nel, (dim + 1) * mc.nel))
-
     def init(self):
-        import scipy.sparse as sp
         ctx, nl, dim = self.ctx, self.nlevels, self.dim
         self.offsets, self.elem_sys, self.n = [], [], []
         self.bdc, self.bdc_val = [], []
         self.KK, self.asm, self.SOL, self.RES, self.EPS, self.RESC = [], [], [], [], [], []
         for l, m in enumerate(self.meshes):
-            es = capi.NSPwAssembler.elem_sys(m)
-            off = np.array([k * m.nnode for k in range(dim + 1)] + [dim * m.nnode + (dim + 1) * m.nel])
+            nd, off, es = capi.system_elem_dofs(m, self.fes)               # GetSystemDof with the element-owned pressure (solution type 4)
             n = int(off[-1])
             self.offsets.append(off), self.elem_sys.append(es), self.n.append(n)
             idx, val = generate_bdc(m, self.names[:dim], self.fes[:dim], off, self.bc)       # the pressure carries no boundary condition
@@ -301,11 +273,8 @@ class NavierStokesPwMG(NavierStokesMG):
         self.open_faces = [None] * nl
         self.Psol, self.P = [None], [None]
         for l in range(1, nl):
-            Pq = capi.build_prolongator(ctx, self.meshes[l - 1], self.meshes[l], "biquadratic", zero_bdc=False)
-            Ps = sp.block_diag([Pq.to_scipy()] * dim + [self.pressure_prolongator(self.meshes[l - 1], self.meshes[l])]).tocsr()
-            Pq.destroy()
-            self.Psol.append(ctx.matrix_scipy(Ps))
-            P = ctx.matrix_scipy(Ps)
+            self.Psol.append(capi.build_system_prolongator(ctx, self.meshes[l - 1], self.meshes[l], self.fes))
+            P = capi.build_system_prolongator(ctx, self.meshes[l - 1], self.meshes[l], self.fes)
             P.mat_zero_rows(self.bdc[l], 0.0)
             P.zero_cols(self.bdc[l - 1])
             self.P.append(P)

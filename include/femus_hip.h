@@ -371,7 +371,11 @@ int fh_fe_face_normals(int geom, int fe, int gauss_order, int gauss_point, int n
 
 /* ---- multi-variable systems and the Navier-Stokes Newton path (a9, a21) --------------------------------------------
  * Variables are stacked per rank: system dof = KKoffset[k] + mesh dof (LinearEquation::GetSystemDof, LinearEquation.cpp:76-85,
- * :212-237; nprocs = 1).  fe[k] in {0, 2}.  elem_sys[nel*nd] lists, per element, the dofs of variable 0, then 1, ... */
+ * :212-237; nprocs = 1).  fe[k] in {0, 2}, and -- for these two calls -- 4 = DISCONTINUOUS_POLYNOMIAL FIRST (round 5: the pressure of
+ * unittests/testNSSteadyDD, 004_Boussinesq, tutorial ex08): dim + 1 functions 1, xi, eta (, zeta) per element, mesh dof of function i of element
+ * iel = i * nel + iel (Mesh::GetSolutionDof for solution type 4), interpolated by the element prolongator of that type (ElemType.cpp:446-520:
+ * the coarse function at the child's centre for the constant, half the coarse slope for the linear functions; an unrefined element keeps
+ * its functions).  elem_sys[nel*nd] lists, per element, the dofs of variable 0, then 1, ... */
 int fh_system_elem_dofs(fh_mesh_t mesh, int nvars, const int* fe, int* nd, int* offsets /* [nvars+1] or NULL */, int* elem_sys /* or NULL */);
 /* BuildProlongatorMatrix over the system variables (LinearImplicitSystem.cpp:826-909): block-diagonal interpolation; apply
  * ZeroInterpolatorDirichletNodes with fh_mat_zero_rows(fine bdc, 0) / fh_mat_zero_cols(coarse bdc) */

@@ -33,6 +33,7 @@ def test_element_matrices_with_the_piecewise_linear_pressure_match_the_oracle(ct
     lay = fns.NSLayoutPwLinear(mo)
     es = capi.NSPwAssembler.elem_sys(m)
     assert np.array_equal(es, lay.elem_sys)
+    assert np.array_equal(capi.system_elem_dofs(m, ["biquadratic", "biquadratic", "pwlinear"])[2], lay.elem_sys)      # the library's GetSystemDof for solution type 4
     KK = ctx.matrix_from_elements(es, lay.n)
     asm = capi.NSPwAssembler(ctx, m, KK)
     rng = np.random.default_rng(11)
@@ -131,12 +132,28 @@ def test_known_answer_through_the_multigrid_path(ctx):
     pb.destroy()
 
 
-def test_pressure_prolongator_reproduces_a_linear_pressure(ctx):
-    """solution type 4 between two levels of an affine box mesh: p = a + b x + c y on the coarse elements arrives as the same function on their children"""
-    from femus_amd.navier_stokes import NavierStokesPwMG
-    mc = capi.Mesh.box(3, 2, 0, lo=(0., 0., 0.), hi=(3., 1., 0.))
+@pytest.mark.parametrize("box", [(3, 2, 0), (2, 2, 2)])
+def test_pressure_prolongator_reproduces_a_linear_pressure(ctx, box):
+    """solution type 4 between two levels of an affine box mesh (the block fh_build_system_prolongator makes for fe = 4): p = a + b x + c y (+ d z) on the coarse
+    elements arrives as the same function on their children; the system dof map puts function i of element e at i * nel + e"""
+    dim = 2 if box[2] == 0 else 3
+    mc = capi.Mesh.box(*box, lo=(0., 0., 0.), hi=(3., 1., 2.))
     mf = mc.refine(ctx)
-    P = NavierStokesPwMG.pressure_prolongator(mc, mf)
+    nd, off, es = capi.system_elem_dofs(mf, ["pwlinear"])
+    assert nd == dim + 1 and off[-1] == (dim + 1) * mf.nel
+    assert np.array_equal(es, np.arange(dim + 1)[None, :] * mf.nel + np.arange(mf.nel)[:, None])
+    Pm = capi.build_system_prolongator(ctx, mc, mf, ["pwlinear"])
+    P = Pm.to_scipy()
+    Pm.destroy()
+    if dim == 3:
+        def coefficients3(m, f):
+            ed, xy, _ = m.arrays()
+            xc = xy[ed[:, 26]]
+            h = [0.5 * (xy[ed[:, v], d] - xy[ed[:, 0], d]) for d, v in enumerate((1, 3, 4))]
+            return np.concatenate([f[0] + xc @ np.array(f[1:])] + [f[1 + d] * h[d] for d in range(3)])
+        f3 = (0.3, -1.7, 2.2, 0.9)
+        assert np.allclose(P @ coefficients3(mc, f3), coefficients3(mf, f3), rtol=0, atol=1e-14)
+        return
 
     def coefficients(m, f):
         ed, xy, _ = m.arrays()
