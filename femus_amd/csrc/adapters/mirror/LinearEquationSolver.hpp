@@ -47,7 +47,9 @@ class Mesh {
   short unsigned GetElementMaterial(const unsigned& iel) const { return _elementMaterial[iel]; }
   unsigned GetElementDofNumber(const unsigned& iel, const unsigned& type) const { return _elementDofNumber[type]; }
   unsigned GetSolutionDof(const unsigned& i, const unsigned& iel, const short unsigned& solType) const {
-    return solType < 3 ? _elementDof[(size_t)iel * _nloc + i] : iel;       // Lagrange families share the biquadratic node ids (one rank)
+    // Lagrange families share the biquadratic node ids; the discontinuous ones belong to the element: constant = element id, linear =
+    // i * (number of elements) + iel on one rank (Mesh.cpp:1057-1070)
+    return solType < 3 ? _elementDof[(size_t)iel * _nloc + i] : (solType == 4 ? i * GetNumberOfElements() + iel : iel);
   }
   unsigned BisectionSearch_find_processor_of_dof(const unsigned& dof, const short unsigned& solType) const {
     unsigned p = 0;
