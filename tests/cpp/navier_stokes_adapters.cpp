@@ -6,7 +6,11 @@
 // With the last argument `stab` = 1 the run is the application's own discretisation (main.cpp:96-108, :390-925): equal-order LAGRANGE FIRST velocity and
 // pressure, the Franca-Frey stabilised callback (fh_assemble_navier_stokes_stab) and the Reynolds continuation of the callback's call counter (:485-489;
 // `nu` is ignored).  The application erases its coarse levels (:92: ONE level, every linear solve the exact one): nlevels = 1 is its real configuration.
-//   usage: navier_stokes_adapters n nlevels nu out.bin [nschur nblock lsolver outer_pre coloured stab]
+// With an eleventh argument -- a Gambit file -- the run is the reference's KNOWN-ANSWER TEST, unittests/testNSSteadyDD/main.cpp: that mesh (input/nsbenc.neu), Q2
+// velocity with AddSolution("P", DISCONTINUOUS_POLYNOMIAL, FIRST) (:97), its boundary conditions (:290-392) and initial velocity (:281-287), solver type
+// FEMuS_DEFAULT with SetSolverFineGrids(GMRES) + SetPreconditionerFineGrids(ILU_PRECOND) (:145-152), nonlinear F-cycle; `n` is ignored, `nlevels` = 4 gives the
+// level whose norms the test stores (:202-244).
+//   usage: navier_stokes_adapters n nlevels nu out.bin [nschur nblock lsolver outer_pre coloured stab [mesh.neu]]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -32,6 +36,16 @@ static bool SetBoundaryConditionCavityFlow(const double* x, const char name, dou
   return test;
 }
 
+// unittests/testNSSteadyDD/main.cpp:290-392 (faces: 1 inflow, 2 outflow, 3 walls, 4 cylinder) and :281-287
+static double InflowProfile(const double y) { return 1.5 * 0.2 * (4.0 / 0.1681) * y * (0.41 - y); }
+static bool SetBoundaryConditionCylinder(const double* x, const char name, double& value, const int FaceName) {
+  value = 0.;
+  if (name == 'P') return false;
+  if (FaceName == 2) return false;
+  if (name == 'U' && FaceName == 1) value = InflowProfile(x[1]);
+  return true;
+}
+
 int main(int argc, char** argv) {
   if (argc < 5) return 2;
   const int n = atoi(argv[1]), nlev = atoi(argv[2]);
@@ -39,18 +53,21 @@ int main(int argc, char** argv) {
   const int nschur = argc > 5 ? atoi(argv[5]) : 0, nblock = argc > 6 ? atoi(argv[6]) : 4, lsolver = argc > 7 ? atoi(argv[7]) : 0, outer_pre = argc > 8 ? atoi(argv[8]) : 0,
             coloured = argc > 9 ? atoi(argv[9]) : 0;     // 1: the library's own block smoother (exact inverses in colour order) instead of PCASM as the reference sets it
   const int stab = argc > 10 ? atoi(argv[10]) : 0;       // 1: the application's equal-order stabilised callback with its Reynolds continuation
+  const char* neu = argc > 11 ? argv[11] : nullptr;      // the known-answer test: Gambit mesh, discontinuous piecewise-linear pressure
+  const bool pw = neu != nullptr;
   const int geom = 1, nvars = 3;
-  const int fe[3] = {stab ? 0 : 2, stab ? 0 : 2, 0};
+  const int fe[3] = {stab ? 0 : 2, stab ? 0 : 2, pw ? 4 : 0};
   const char names[3] = {'U', 'V', 'P'};
   const double lo[3] = {-0.5, -0.5, 0}, hi[3] = {0.5, 0.5, 1};
   std::vector<fh_mesh_t> msh(nlev);
-  hip_check(fh_mesh_box(n, n, 0, lo, hi, &msh[0]), "mesh");
+  if (pw) hip_check(fh_mesh_read_gambit(neu, 1.0, &msh[0]), "ReadCoarseMesh");
+  else hip_check(fh_mesh_box(n, n, 0, lo, hi, &msh[0]), "mesh");
   for (int l = 1; l < nlev; l++) hip_check(fh_mesh_refine(msh[l - 1], &msh[l]), "refine");
 
   std::vector<LinearEquationSolver*> LinSolver(nlev);
   std::vector<Mesh*> fmesh(nlev);           // FEMuS-owned in a real build: dof offsets of the families, Solution with the _Bdc flag vectors
   std::vector<Solution*> fsol(nlev);
-  std::vector<unsigned> SolPdeIndex = {0u, 1u, 2u}, SolType = {stab ? 0u : 2u, stab ? 0u : 2u, 0u};
+  std::vector<unsigned> SolPdeIndex = {0u, 1u, 2u}, SolType = {stab ? 0u : 2u, stab ? 0u : 2u, pw ? 4u : 0u};
   char nU[] = "U", nV[] = "V", nP[] = "P";
   std::vector<char*> SolName = {nU, nV, nP};
   std::vector<bool> sparsity;
@@ -69,7 +86,8 @@ int main(int argc, char** argv) {
     const int ndof = offs[l][nvars];
     // FEMuS_ASM solver: element blocks around every pressure dof
     fmesh[l] = new Mesh();
-    for (int t = 0; t < 5; t++) fmesh[l]->_dofOffset[t] = {0u, (unsigned)(t == 0 ? own[0] : t < 3 ? nnode : nel)};     // one rank
+    for (int t = 0; t < 5; t++) fmesh[l]->_dofOffset[t] = {0u, (unsigned)(t == 0 ? own[0] : t < 3 ? nnode : t == 3 ? nel : 3 * nel)};     // one rank
+    fmesh[l]->_elementDofNumber[4] = 3;
     // the element tables BuildASMIndex reads through the Mesh interface (FEMuS's own Mesh has them)
     fmesh[l]->_elementOffset = {0u, (unsigned)nel};
     fmesh[l]->_elementMaterial.assign(nel, 2);                                            // fluid
@@ -98,7 +116,8 @@ int main(int argc, char** argv) {
       *flag = 2.;                                            // free; Dirichlet nodes get 0 below (MultiLevelSolution::GenerateBdc)
       fsol[l]->_Bdc.push_back(flag);
     }
-    LinearEquationSolverHipAsm* ls = static_cast<LinearEquationSolverHipAsm*>(LinearEquationSolver::build(l, fsol[l], FEMuS_ASM).release());
+    LinearEquationSolverHip* ls = static_cast<LinearEquationSolverHip*>(LinearEquationSolver::build(l, fsol[l], pw ? FEMuS_DEFAULT : FEMuS_ASM).release());
+    LinearEquationSolverHipAsm* lsa = pw ? nullptr : static_cast<LinearEquationSolverHipAsm*>(ls);
     LinSolver[l] = ls;
     ls->InitPde(SolPdeIndex, SolType, SolName, &fsol[l]->_Bdc, nlev, sparsity);     // _KK, _RES, _RESC, _EPS, _EPSC; KKoffset = offs[l]
     for (int k = 0; k <= nvars; k++)
@@ -108,8 +127,10 @@ int main(int argc, char** argv) {
       }
     // the smoother exactly as SteadyNavierStokesParallel/main.cpp:155-179 sets it up: blocks of `nblock` elements, `nschur` Schur variables
     // (the application: 0 and 4), GMRES around the block-Schwarz preconditioner on every level above the coarsest
-    ls->SetNumberOfSchurVariables((unsigned short)nschur);
-    ls->SetElementBlockNumber((unsigned)nblock);
+    if (lsa) {
+      lsa->SetNumberOfSchurVariables((unsigned short)nschur);
+      lsa->SetElementBlockNumber((unsigned)nblock);
+    }
     Sol[l] = NumericVector::build().release();
     Sol[l]->init(ndof, ndof, false, SERIAL);
     // sparsity from the element couplings of the stacked variables
@@ -120,11 +141,13 @@ int main(int argc, char** argv) {
     fh_mat_t K;
     hip_check(fh_mat_create_csr(hip_context(), ndof, ndof, rp.data(), col.data(), nullptr, &K), "KK");
     static_cast<HipMatrix*>(ls->_KK)->adopt(K);
-    if (stab) hip_check(fh_ns_stab_assembler_create(hip_context(), geom, 3, nel, nloc, ed.data(), nnode, own[0], xy.data(), K, &as[l]), "assembler");
+    if (pw) hip_check(fh_ns_pw_assembler_create(hip_context(), geom, 3, nel, nloc, ed.data(), nnode, xy.data(), K, &as[l]), "assembler");
+    else if (stab) hip_check(fh_ns_stab_assembler_create(hip_context(), geom, 3, nel, nloc, ed.data(), nnode, own[0], xy.data(), K, &as[l]), "assembler");
     else hip_check(fh_ns_assembler_create(hip_context(), geom, 3, nel, nloc, ed.data(), nnode, own[0], xy.data(), K, &as[l]), "assembler");
     // GenerateBdc: boundary faces in element order, nodes of the face, boundary function at the node
     std::map<int, double> val;
     for (int k = 0; k < nvars; k++) {
+      if (fe[k] == 4) continue;                             // the element-owned pressure carries no boundary condition
       const int nck = fe[k] == 2 ? 9 : 4;
       for (int iel = 0; iel < nel; iel++)
         for (int f = 0; f < 4; f++) {
@@ -136,7 +159,9 @@ int main(int argc, char** argv) {
             if (loc[q] >= nck) continue;
             const int node = ed[(size_t)iel * nloc + loc[q]];
             double v;
-            if (SetBoundaryConditionCavityFlow(&xy[(size_t)node * dim], names[k], v, -(flag + 1))) val[offs[l][k] + node] = v;
+            const bool dirichlet = pw ? SetBoundaryConditionCylinder(&xy[(size_t)node * dim], names[k], v, -(flag + 1))
+                                      : SetBoundaryConditionCavityFlow(&xy[(size_t)node * dim], names[k], v, -(flag + 1));
+            if (dirichlet) val[offs[l][k] + node] = v;
           }
         }
     }
@@ -153,11 +178,20 @@ int main(int argc, char** argv) {
       fsol[l]->_Bdc[k]->close();
     }
     Sol[l]->zero();
+    if (pw && l == 0) {                                     // Initialize("U", InitVariableU): the inflow parabola everywhere (the F-cycle prolongs upwards from here)
+      std::vector<double> u0(nnode);
+      std::vector<int> rows(nnode);
+      for (int i = 0; i < nnode; i++) {
+        rows[i] = offs[l][0] + i;
+        u0[i] = InflowProfile(xy[(size_t)i * dim + 1]);
+      }
+      Sol[l]->insert_vector_blocked(u0, rows);
+    }
     Sol[l]->insert_vector_blocked(vals, bdc[l]);
     ls->set_solver_type(lsolver == 0 ? GMRES : RICHARDSON);                       // SetSolverFineGrids(GMRES)
     if (lsolver) ls->SetRichardsonScaleFactor(0.6);
     ls->set_preconditioner_type(ILU_PRECOND);         // SetPreconditionerFineGrids(ILU_PRECOND): one ILU(0) application per block
-    ls->SetAsmExactInColourOrder(coloured != 0);
+    if (lsa) lsa->SetAsmExactInColourOrder(coloured != 0);
     if (l > 0) {
       for (int copy = 0; copy < 2; copy++) {
         fh_mat_t P;
@@ -204,7 +238,8 @@ int main(int argc, char** argv) {
       } else {
         top->MGInit(MULTIPLICATIVE, ig + 1, outer_pre == 2 ? FGMRES : GMRES);     // 2: the flexible form (cycles with GMRES level solvers)
         top->SetTolerances(1e-11, 1e-50, 1e50, 60, 30);
-        for (int i = 0; i <= ig; i++) LinSolver[i]->MGSetLevel(top, ig, vars, PP[i], PP[i], i ? 2 : 1, i ? 2 : 0);
+        // (the known-answer test: four GMRES iterations per smoothing step, SetTolerances(1.e-12, 1.e-20, 1.e+50, 4), main.cpp:153)
+        for (int i = 0; i <= ig; i++) LinSolver[i]->MGSetLevel(top, ig, vars, PP[i], PP[i], i ? (pw ? 4 : 2) : 1, i ? (pw ? 4 : 2) : 0);
         top->SetEpsZero();
         top->MGSolve(true);
       }

@@ -156,6 +156,31 @@ def test_the_shipped_navier_stokes_application_with_its_own_discretisation_and_s
             assert v.max() == 1.0 and v.min() < -0.05
 
 
+def test_the_reference_known_answer_test_over_the_cpp_adapters(tmp_path):
+    """unittests/testNSSteadyDD (the reference's stored-number test of this path) written over the C++ adapters the way its main.cpp drives FEMuS: Gambit mesh,
+    four levels, Q2 velocity + DISCONTINUOUS_POLYNOMIAL FIRST pressure (InitPde with solution type 4, KKoffset checked against fh_system_elem_dofs), its boundary
+    conditions and initial velocity, solver type FEMuS_DEFAULT with GMRES level solvers around ILU_PRECOND, Galerkin chain by matrix_PtAP, MGInit / MGSetLevel /
+    MGSolve per Newton step in a nonlinear F-cycle.  The level-3 norms the test asserts to 1e-6 (main.cpp:202-244) must come out to 1e-8."""
+    from test_ns_known_answer import STORED
+    lib = os.path.join(ROOT, "femus_amd", "lib")
+    exe = str(tmp_path / "navier_stokes_adapters")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "femus_amd", "csrc", "adapters")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["g++", "-O1", "-std=c++17"] + INC + [os.path.join(ROOT, "tests", "cpp", "navier_stokes_adapters.cpp"), "-o", exe,
+                           "-L" + lib, "-lfemus_hip_adapters", "-lfemus_hip", "-Wl,-rpath," + lib])
+    out = str(tmp_path / "nsdd.bin")
+    neu = os.path.join(ROOT, "tests", "golden", "nsbenc.neu")
+    log = subprocess.check_output([exe, "0", "4", "0.001", out, "0", "4", "0", "2", "0", "0", neu], text=True)      # GMRES level solvers, flexible outer GMRES
+    steps = int(log.split("newton steps = ")[1].split()[0])
+    assert 12 <= steps <= 30, log[-2000:]
+    sol = np.fromfile(out)
+    nel = 98 * 64
+    nq2 = (sol.size - 3 * nel) // 2
+    got = {"U": np.linalg.norm(sol[:nq2]), "V": np.linalg.norm(sol[nq2:2 * nq2]), "P": np.linalg.norm(sol[2 * nq2:])}
+    rel = {k: abs(got[k] - STORED[k]) / STORED[k] for k in got}
+    print("adapters, level-3 norms", got, rel, log[-400:])
+    assert max(rel.values()) < 1e-8, rel
+
+
 def test_hipvector_on_two_ranks_over_the_host_transport(tmp_path):
     """ownership offsets, global indices, ghost refresh, localize_to_all and the global reductions with two processes"""
     lib = os.path.join(ROOT, "femus_amd", "lib")
