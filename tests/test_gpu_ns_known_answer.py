@@ -165,3 +165,42 @@ def test_pressure_prolongator_reproduces_a_linear_pressure(ctx, box):
 
     f = (0.3, -1.7, 2.2)
     assert np.allclose(P @ coefficients(mc, f), coefficients(mf, f), rtol=0, atol=1e-14)
+
+
+def test_piecewise_linear_pressure_in_three_dimensions(ctx):
+    """the HEX27 form of the same assembler (hexpwLinear: 1, xi, eta, zeta; nd = 85) on a distorted box against the oracle restatement, and one Newton step's
+    exact solve through the pivoted fronts against scipy"""
+    import scipy.sparse.linalg as spla
+    m = capi.Mesh.box(2, 2, 2)
+    _, xy0, _ = m.arrays()
+    m.set_coords(xy0 + 0.03 * np.random.default_rng(4).uniform(-1, 1, xy0.shape))
+    m = m.refine(ctx)
+    ed, xy, ff = m.arrays()
+    mo = fo.Mesh("hex", ed, xy, ff, level=1)
+    lay = fns.NSLayoutPwLinear(mo)
+    assert lay.nd == 85
+    es = capi.system_elem_dofs(m, ["biquadratic"] * 3 + ["pwlinear"])[2]
+    assert np.array_equal(es, lay.elem_sys)
+    KK = ctx.matrix_from_elements(es, lay.n)
+    asm = capi.NSPwAssembler(ctx, m, KK)
+    x = np.random.default_rng(12).uniform(-1, 1, lay.n)
+    sol, res, eps = ctx.vector_from(x), ctx.vector(lay.n), ctx.vector(lay.n)
+    etp = fns.PwLinearPressure("hex", "seventh")
+    asm.assemble(KK, res, sol, 0.05)
+    Ao, bo = fns.assemble_ns(mo, lay, x, 0.05, etp=etp)
+    assert abs(KK.to_scipy() - Ao).max() <= 1e-12 * abs(Ao).max()
+    assert np.linalg.norm(res.to_numpy() - bo) <= 1e-12 * np.linalg.norm(bo)
+    # all velocities fixed on the boundary, the constant pressure mode removed by fixing one pressure function
+    nq2 = m.nnode
+    wall = fo.dirichlet_dofs(mo, "biquadratic")
+    bdc = np.concatenate([wall, wall + nq2, wall + 2 * nq2, [3 * nq2]]).astype(np.int32)
+    bidx = capi.Index(ctx, bdc)
+    bidx.zero_rows(KK, 1.0)
+    bidx.set(res, 0.0)
+    d = capi.Direct(ctx, KK, None).factor()
+    d.solve(res, eps)
+    A, b = KK.to_scipy(), res.to_numpy()
+    ref = spla.splu(A.tocsc()).solve(b)
+    assert np.linalg.norm(eps.to_numpy() - ref) <= 1e-10 * np.linalg.norm(ref)
+    assert d.stats()["perturbed_pivots"] == 0
+    d.destroy(); asm.destroy(); KK.destroy()
