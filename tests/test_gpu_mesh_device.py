@@ -83,10 +83,12 @@ def test_adaptive_refinement_on_the_device_equals_the_host_loops(ctx, box, nu, n
             assert np.array_equal(x, y)
 
 
-def test_gambit_mesh_refined_on_the_device(ctx):
-    path = os.path.join(HERE, "golden", "cube_Hex.neu")
-    host, dev = build(lambda: capi.Mesh.read_gambit(path), 3, None, ctx)
-    for l in range(1, 3):
+@pytest.mark.parametrize("name,nlev", [("cube_Hex.neu", 3), ("nsbenc.neu", 4)])
+def test_gambit_mesh_refined_on_the_device(ctx, name, nlev):
+    """the reference's own input meshes: the HEX27 cube of 001_Poisson and the 98 curved QUAD9 elements of its known-answer test (four boundary sets)"""
+    path = os.path.join(HERE, "golden", name)
+    host, dev = build(lambda: capi.Mesh.read_gambit(path), nlev, None, ctx)
+    for l in range(1, nlev):
         same_mesh(dev[l], host[l])
 
 
