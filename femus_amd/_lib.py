@@ -145,6 +145,7 @@ def _declare(L):
     sig("fh_mesh_read_gambit", c_char_p, c_double, P(c_void_p))
     sig("fh_mesh_refine_flagged", c_void_p, c_void_p, P(c_void_p))
     sig("fh_mesh_refine_device", c_void_p, c_void_p, c_void_p, P(c_void_p))
+    sig("fh_mesh_elem_groups", c_void_p, c_void_p, c_void_p)
     sig("fh_mat_create_from_mesh", c_void_p, c_void_p, c_int, P(c_void_p))
     sig("fh_assembler_create_mesh", c_void_p, c_void_p, c_int, c_int, c_void_p, P(c_void_p))
     sig("fh_mesh_elem_centroids", c_void_p, c_void_p)

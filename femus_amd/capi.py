@@ -601,6 +601,12 @@ class Mesh:
         _chk(self.L.fh_mesh_elem_centroids(self.h, _p(out)))
         return out
 
+    def elem_groups(self):
+        """(group, material) per element: Gambit numbers, inherited through refinements (a generated box: 1, 2)"""
+        g, mt = np.empty(self.nel, np.int32), np.empty(self.nel, np.int32)
+        _chk(self.L.fh_mesh_elem_groups(self.h, _p(g), _p(mt)))
+        return g, mt
+
     def elem_levels(self):
         out = np.empty(self.nel, np.int32)
         hom = ctypes.c_int()

@@ -25,6 +25,7 @@ struct fh_mesh_s {
   std::vector<int> child;         // [nel*nchild] (set by refine on the coarse mesh; -1 padded for copied elements)
   std::vector<char> refined;      // [nel] set by refine on the coarse mesh: element was split
   std::vector<int> elem_level;    // [nel] refinement level of every element (Elem.hpp:372-374)
+  std::vector<int> elem_group, elem_material;   // [nel] Gambit group / material number (Elem.hpp: GetElementGroup / GetElementMaterial), inherited by children; empty = group 1, material 2 ... as below
   bool homogeneous = true;        // Mesh::GetIfHomogeneous: no element of the father level was left unrefined
   // hanging-node constraints: 0 = the map exactly as Mesh::GetAMRRestrictionAndAMRSolidMark builds it (default), 1 = only the
   // description to the coarsest level for a node on two interfaces at once + full expansion of chains (rows sum to one);
@@ -171,6 +172,8 @@ struct PairMap {
     }
   }
 };
+
+static void inherit_groups(const fh_mesh_s* mc, fh_mesh_s* m);
 
 // MeshRefinement::RefineMesh (MeshRefinement.cpp:197-493) for nprocs = 1.  flags == NULL: every element is split (uniform
 // level).  Otherwise elements of the current level with a nonzero flag are split and all the others are carried over
@@ -350,9 +353,35 @@ extern "C" int fh_mesh_refine_flagged(fh_mesh_t mc, const unsigned char* flags, 
     for (int t = 0; t < nth; t++) th.emplace_back(work, (int)((int64_t)mc->nel * t / nth), (int)((int64_t)mc->nel * (t + 1) / nth));
     for (auto& x : th) x.join();
   }
+  inherit_groups(mc, m);
   *out = holder.release();
   return 0;
   FH_GUARD_END("fh_mesh_refine_flagged")
+}
+
+// children carry the group and material of their father (MeshRefinement.cpp:263-266: SetElementGroup / SetElementMaterial of the new element)
+static void inherit_groups(const fh_mesh_s* mc, fh_mesh_s* m) {
+  if (mc->elem_group.empty()) return;
+  const int nch = nvert_of(mc->geom);
+  m->elem_group.assign(m->nel, 0);
+  m->elem_material.assign(m->nel, 0);
+  for (int iel = 0; iel < mc->nel; iel++)
+    for (int j = 0; j < nch; j++) {
+      const int jel = mc->child[(size_t)iel * nch + j];
+      if (jel < 0) continue;
+      m->elem_group[jel] = mc->elem_group[iel];
+      m->elem_material[jel] = mc->elem_material[iel];
+    }
+}
+
+// Elem::GetElementGroup / GetElementMaterial per element; a generated box has one group (1) of fluid material (2), as MeshGeneration leaves it
+extern "C" int fh_mesh_elem_groups(fh_mesh_t m, int* group, int* material) {
+  FH_REQUIRE(m, "fh_mesh_elem_groups: null mesh");
+  for (int i = 0; i < m->nel; i++) {
+    if (group) group[i] = m->elem_group.empty() ? 1 : m->elem_group[i];
+    if (material) material[i] = m->elem_material.empty() ? 2 : m->elem_material[i];
+  }
+  return 0;
 }
 
 extern "C" int fh_mesh_refine(fh_mesh_t mc, fh_mesh_t* out) {
@@ -449,6 +478,7 @@ extern "C" int fh_mesh_refine_device(fh_ctx_t ctx, fh_mesh_t mc, const unsigned 
   mc->child.swap(R.child);
   mc->refined.swap(R.refined);
   m->homogeneous = m->nel == mc->nel * nch;
+  inherit_groups(mc, m);
   *out = holder.release();
   return 0;
   FH_GUARD_END("fh_mesh_refine_device")
@@ -1486,6 +1516,12 @@ static int read_gambit(const char* path, double Lref, fh_mesh_t* out) {
   }
   m->coords = xyz;
   m->elem_level.assign(nel, 0);
+  m->elem_group.resize(nel);
+  m->elem_material.resize(nel);
+  for (int i = 0; i < nel; i++) {
+    m->elem_group[i] = group[order[i]];
+    m->elem_material[i] = material[order[i]];
+  }
   {
     std::vector<char> used(nvt, 0);
     for (int x : m->elem_dof) used[x] = 1;

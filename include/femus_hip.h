@@ -238,6 +238,9 @@ int fh_mesh_refine_device(fh_ctx_t ctx, fh_mesh_t coarse, const unsigned char* f
 int fh_mesh_elem_centroids(fh_mesh_t mesh, double* xc /* [nel*3] */);
 /* Elem::GetElementLevel per element, Mesh::GetIfHomogeneous */
 int fh_mesh_elem_levels(fh_mesh_t mesh, int* levels /* [nel] or NULL */, int* homogeneous /* or NULL */);
+/* Elem::GetElementGroup / GetElementMaterial per element (Gambit group and material numbers, inherited by the children of a refinement: what a
+ * SetRefinementFlag(x, ElemGroupNumber, level) callback and MeshASMPartitioning read); a generated box: group 1, material 2 */
+int fh_mesh_elem_groups(fh_mesh_t mesh, int* group /* [nel] or NULL */, int* material /* [nel] or NULL */);
 int fh_mesh_destroy(fh_mesh_t mesh);
 /* domain decomposition: faces of a sub-box that are artificial cuts, not physical boundary (bit f = local face f); call on the
  * coarse mesh before refining (flags are inherited, MeshRefinement.cpp:271-278) */

@@ -113,3 +113,27 @@ def test_reader_on_the_curved_mesh_of_testNSSteadyDD():
     f = m.refine()
     assert f.nel == 4 * 98
     m.destroy(), f.destroy()
+
+
+def test_element_groups_of_the_known_answer_mesh_and_its_selective_levels():
+    """unittests/testNSSteadyDD: the Gambit groups 5 / 6 / 7 of nsbenc.neu drive SetRefinementFlag (main.cpp:262-280: group 5 is refined on the two
+    selective levels above the four uniform ones, main.cpp:55-82); children inherit group and material (MeshRefinement.cpp:263-266)"""
+    import os
+    m = capi.Mesh.read_gambit(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nsbenc.neu"))
+    g, mt = m.elem_groups()
+    assert dict(zip(*np.unique(g, return_counts=True))) == {5: 20, 6: 40, 7: 38} and set(mt) == {2}
+    ms = [m]
+    for l in range(1, 6):
+        g, _ = ms[-1].elem_groups()
+        lev, _ = ms[-1].elem_levels()
+        flags = np.ones(ms[-1].nel, np.uint8) if l < 4 else ((g == 5) & (lev == ms[-1].level)).astype(np.uint8)
+        nxt = ms[-1].refine_flagged(flags)
+        gn, _ = nxt.elem_groups()
+        ch = ms[-1].child_elems()
+        for e in (0, ms[-1].nel // 2, ms[-1].nel - 1):
+            kids = ch[e][ch[e] >= 0]
+            assert np.all(gn[kids] == g[e])
+        ms.append(nxt)
+    assert [x.nel for x in ms] == [98, 392, 1568, 6272, 1280 * 4 + 4992, 5120 * 4 + 4992]
+    assert ms[3].elem_levels()[1] and not ms[4].elem_levels()[1] and not ms[5].elem_levels()[1]
+    assert capi.Mesh.box(2, 1, 0).elem_groups()[0].tolist() == [1, 1]
