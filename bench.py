@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--coarse", type=int, default=8, help="coarse box elements per direction (8 -> 64^3 with 4 levels)")
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-known-answer", action="store_true", help="skip the reference's known-answer test (3 s, after the timed region)")
     ap.add_argument("--kernel-reps", type=int, default=50)
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic")
     return ap.parse_args()
@@ -402,6 +403,13 @@ def main():
     if preflight is not None:
         out["rccl_preflight"] = preflight          # what the RCCL preflight children of every rank said (ok / message / seconds)
 
+    # ---- the reference's own known-answer test through the device path (rank 0, N = 1; after the timed region, not part of `value`) --------
+    if rank == 0 and world == 1 and not args.no_known_answer:
+        try:
+            from femus_amd import known_answer as ka
+            out["known_answer"] = ka.run(ctx)
+        except Exception as e:      # reported, never hidden
+            out["known_answer"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     # ---- CPU baseline: the oracle's C restatement on the host cores (rank 0, N = 1 only) ------------------------
     if rank == 0 and not args.no_live_traffic and os.environ.get("FEMUS_BENCH_LIVE_TRAFFIC", "1") != "0":
         # roofline.traffic from hardware counters of THIS run (two short child runs under rocprofv3 --pmc); when that is not possible the

@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $ROOT/bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err
 rm -rf /tmp/prof; mkdir -p /tmp/prof
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/bench -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-live-traffic > $OUT/${TAG}_bench_line_under_rocprof.json 2> $OUT/rocprof_bench.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/bench -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-live-traffic --no-known-answer > $OUT/${TAG}_bench_line_under_rocprof.json 2> $OUT/rocprof_bench.err
 python $ROOT/profiles/summarize.py /tmp/prof/bench $OUT/${TAG}_bench_kernel_summary.md > /dev/null
 cp $(find /tmp/prof/bench -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv 2>/dev/null
 # ---- SpMV: HBM traffic of the fused Jacobi sweep (fine level) ----
