@@ -34,6 +34,9 @@ struct fh_mesh_s {
   // hanging-node rows already computed for this mesh: [fe == 2], valid for amr_cache_mode (cleared when coordinates or the mode change)
   std::shared_ptr<struct AmrRows> amr_cache[2];
   int amr_cache_mode[2] = {-1, -1};
+  // Dirichlet node list per family ([fe == 2]) once computed: the boundary flags of a mesh change only through fh_mesh_clear_boundary_faces
+  mutable std::vector<int> dir_cache[2];
+  mutable bool dir_valid[2] = {false, false};
   // the same arrays in device memory (fh_mesh_refine_device, fh_mesh_device): dropped whenever a host array they mirror is rewritten
   fh_mesh_dev* dev = nullptr;
   ~fh_mesh_s() { fh_meshdev_free(dev); }
@@ -512,6 +515,7 @@ extern "C" int fh_mesh_clear_boundary_faces(fh_mesh_t m, unsigned face_mask) {
       if ((face_mask >> f) & 1u) m->face_flag[(size_t)iel * nf + f] = -1;
   m->amr_cache[0].reset();     // interface faces of the hanging-node search are the faces flagged -1: rows cached before are stale
   m->amr_cache[1].reset();
+  m->dir_valid[0] = m->dir_valid[1] = false;
   fh_meshdev_free(m->dev);
   m->dev = nullptr;
   return 0;
@@ -572,6 +576,11 @@ extern "C" int fh_mesh_child_elems(fh_mesh_t m, int* child) {
 static int mesh_ndofs(const fh_mesh_s* m, int fe) { return fe == FE_LINEAR ? m->own[0] : m->nnode; }
 
 static void dirichlet_list(const fh_mesh_s* m, int fe, std::vector<int>& out) {
+  const int slot = fe == 2 ? 1 : 0;
+  if (m->dir_valid[slot]) {
+    out = m->dir_cache[slot];
+    return;
+  }
   const int nc = ndofs_of(m->geom, fe), nf = nfaces_of(m->geom), nl = m->nloc;
   std::vector<char> mark(mesh_ndofs(m, fe), 0);
   for (int f = 0; f < nf; f++) {
@@ -588,6 +597,8 @@ static void dirichlet_list(const fh_mesh_s* m, int fe, std::vector<int>& out) {
   out.clear();
   for (size_t i = 0; i < mark.size(); i++)
     if (mark[i]) out.push_back((int)i);
+  m->dir_cache[slot] = out;
+  m->dir_valid[slot] = true;
 }
 
 extern "C" int fh_mesh_dirichlet_dofs(fh_mesh_t m, int fe, int* n, int* dofs) {
