@@ -255,15 +255,30 @@ class NavierStokesPwMG(NavierStokesMG):
         self.history = []
 
     def init(self):
+        import scipy.sparse as sp
         ctx, nl, dim = self.ctx, self.nlevels, self.dim
         self.offsets, self.elem_sys, self.n = [], [], []
-        self.bdc, self.bdc_val = [], []
+        self.bdc, self.bdc_val, self.bdc_phys = [], [], []
         self.KK, self.asm, self.SOL, self.RES, self.EPS, self.RESC = [], [], [], [], [], []
+        # levels made by selective refinement (the two upper levels of the reference's test, main.cpp:55-82, 262-280): the velocities hang at the interfaces and are
+        # tied to their masters by PPamr, the element-owned pressures need nothing (LinearImplicitSystem.cpp:247-258, 329-335; NonLinearImplicitSystem.cpp:213-236)
+        self.Pamr, self.Aamr = [None] * nl, [None] * nl
         for l, m in enumerate(self.meshes):
             nd, off, es = capi.system_elem_dofs(m, self.fes)               # GetSystemDof with the element-owned pressure (solution type 4)
             n = int(off[-1])
             self.offsets.append(off), self.elem_sys.append(es), self.n.append(n)
             idx, val = generate_bdc(m, self.names[:dim], self.fes[:dim], off, self.bc)       # the pressure carries no boundary condition
+            self.bdc_phys.append((idx, val))
+            if not m.elem_levels()[1]:
+                Pq = capi.build_amr_prolongator(ctx, m, "biquadratic")
+                hang = m.amr_constraints("biquadratic")[0].astype(np.int64)
+                blocks = [Pq.to_scipy()] * dim + [sp.identity((dim + 1) * m.nel, format="csr")]
+                Pq.destroy()
+                self.Pamr[l] = ctx.matrix_scipy(sp.block_diag(blocks).tocsr())
+                hsys = np.concatenate([hang + off[k] for k in range(dim)])
+                hsys = np.setdiff1d(hsys, idx)
+                order = np.argsort(np.concatenate([idx, hsys]))
+                idx, val = np.concatenate([idx, hsys])[order].astype(np.int32), np.concatenate([val, np.zeros(hsys.size)])[order]
             self.bdc.append(idx), self.bdc_val.append(val)
             K = ctx.matrix_from_elements(es, n)
             self.KK.append(K)
@@ -275,6 +290,10 @@ class NavierStokesPwMG(NavierStokesMG):
         for l in range(1, nl):
             self.Psol.append(capi.build_system_prolongator(ctx, self.meshes[l - 1], self.meshes[l], self.fes))
             P = capi.build_system_prolongator(ctx, self.meshes[l - 1], self.meshes[l], self.fes)
+            if self.Pamr[l - 1] is not None:                               # PP[l] <- PP[l] PPamr[l-1]
+                PA = P.matmul(self.Pamr[l - 1])
+                P.destroy()
+                P = PA
             P.mat_zero_rows(self.bdc[l], 0.0)
             P.zero_cols(self.bdc[l - 1])
             self.P.append(P)
@@ -284,13 +303,23 @@ class NavierStokesPwMG(NavierStokesMG):
     def set_state(self, level, values):
         """Initialize(...) + the boundary values of GenerateBdc on one level"""
         x = np.array(values, float)
-        x[self.bdc[level]] = self.bdc_val[level]
+        idx, val = self.bdc_phys[level]
+        x[idx] = val
         self.SOL[level].upload(x)
 
     def prepare(self, ig):
         ctx = self.ctx
         self.asm[ig].assemble(self.KK[ig], self.RES[ig], self.SOL[ig], self.nu)
-        self.A[(ig, ig)] = self.KK[ig]
+        if self.Pamr[ig] is not None:                                      # RES <- PPamr^T RES ; KK <- PPamr^T KK PPamr
+            self.RESC[ig].matrix_mult_transpose(self.RES[ig], self.Pamr[ig])
+            self.RES[ig].assign(self.RESC[ig])
+            if self.Aamr[ig] is None:
+                self.Aamr[ig] = capi.Mat.ptap(self.Pamr[ig], self.KK[ig])
+            else:
+                self.Aamr[ig].ptap_numeric(self.Pamr[ig], self.KK[ig])
+            self.A[(ig, ig)] = self.Aamr[ig]
+        else:
+            self.A[(ig, ig)] = self.KK[ig]
         for l in range(ig, 0, -1):
             if (ig, l - 1) not in self.A:
                 self.A[(ig, l - 1)] = capi.Mat.ptap(self.P[l], self.A[(ig, l)])
@@ -315,5 +344,15 @@ class NavierStokesPwMG(NavierStokesMG):
     def newton_step(self, ig, lin_rtol=1e-10, lin_maxit=60, restart=30):
         mg = self.prepare(ig)
         its, rn = mg.solve(self.RES[ig], self.EPS[ig], outer="fgmres" if ig > 0 else "preonly", rtol=lin_rtol, atol=1e-50, maxit=lin_maxit, restart=restart)
+        if self.Pamr[ig] is not None:                                      # EPS <- PPamr EPS: the hanging velocities follow their masters (LinearImplicitSystem.cpp:487-491)
+            self.RESC[ig].matrix_mult(self.EPS[ig], self.Pamr[ig])
+            self.EPS[ig].assign(self.RESC[ig])
         self.SOL[ig].add(1.0, self.EPS[ig])
         return its, rn
+
+    def destroy(self):
+        for m in self.Pamr + self.Aamr:
+            if m is not None:
+                m.destroy()
+        self.Pamr, self.Aamr = [], []
+        super().destroy()

@@ -230,3 +230,49 @@ def test_piecewise_linear_pressure_in_three_dimensions(ctx):
     assert np.linalg.norm(eps.to_numpy() - ref) <= 1e-10 * np.linalg.norm(ref)
     assert d.stats()["perturbed_pivots"] == 0
     d.destroy(); asm.destroy(); KK.destroy()
+
+
+def test_the_whole_hierarchy_of_the_reference_test_with_its_two_selective_levels(ctx):
+    """all six levels of unittests/testNSSteadyDD (main.cpp:55-82: four uniform levels, then two made by SetRefinementFlag :262-280 -- Gambit group 5, the
+    elements around the cylinder): the nonlinear F-cycle runs through the non-homogeneous levels too (velocities hanging at the interfaces tied to their masters by
+    PPamr, NonLinearImplicitSystem.cpp:213-236; the element-owned pressures need nothing).  The reference stores no number above level 3: checked are the level-3
+    norms (untouched by what follows), convergence on every level, the hanging-node relation of the final velocities and the residual of the oracle's
+    operator on the finest level."""
+    import scipy.sparse as sp
+    from femus_amd.navier_stokes import NavierStokesPwMG
+    ms = [capi.Mesh.read_gambit(os.path.join(HERE, "golden", "nsbenc.neu"))]
+    for l in range(1, 6):
+        g, _ = ms[-1].elem_groups()
+        lev, _ = ms[-1].elem_levels()
+        flags = None if l < 4 else ((g == 5) & (lev == ms[-1].level)).astype(np.uint8)
+        ms.append(ms[-1].refine_device(ctx, flags))
+    assert [m.nel for m in ms] == [98, 392, 1568, 6272, 10112, 25472]
+    pb = NavierStokesPwMG(ctx, ms, 0.001, _bc, level_gmres_its=4).init()
+    x = np.zeros(pb.n[0])
+    x[:ms[0].nnode] = inflow_profile(ms[0].arrays()[1][:, 1])
+    pb.set_state(0, x)
+    assert pb.mgsolve(tol=1e-10, max_newton=20, lin_rtol=1e-10, lin_maxit=150)
+    s3 = pb.SOL[3].to_numpy()
+    nq = ms[3].nnode
+    got = {"U": np.linalg.norm(s3[:nq]), "V": np.linalg.norm(s3[nq:2 * nq]), "P": np.linalg.norm(s3[2 * nq:])}
+    assert max(abs(got[k] - STORED[k]) / STORED[k] for k in got) < 1e-8
+    # finest level: hanging velocities = interpolation of their masters; the oracle's discrete residual vanishes at the free unknowns after the projection
+    top = 5
+    m = ms[top]
+    s = pb.SOL[top].to_numpy()
+    hang, ptr, master, w = m.amr_constraints("biquadratic")
+    assert hang.size > 0
+    for k in range(2):
+        u = s[k * m.nnode:(k + 1) * m.nnode]
+        interp = np.array([np.dot(w[ptr[i]:ptr[i + 1]], u[master[ptr[i]:ptr[i + 1]]]) for i in range(hang.size)])
+        assert np.abs(u[hang] - interp).max() <= 1e-10 * np.abs(u).max()
+    ed, xy, ff = m.arrays()
+    mo = fo.Mesh("quad", ed, xy, ff, level=top)
+    lay = fns.NSLayoutPwLinear(mo)
+    _, b = fns.assemble_ns(mo, lay, s, 0.001, etp=fns.PwLinearPressure("quad", "seventh"))
+    Pamr = pb.Pamr[top].to_scipy()
+    r = Pamr.T @ b
+    free = np.setdiff1d(np.arange(lay.n), pb.bdc[top])
+    assert np.abs(r[free]).max() <= 1e-9 * np.abs(b).max()
+    print("six levels:", [m.nel for m in ms], "unknowns on the finest", lay.n, "newton / linear history", [(h[0], h[1], float("%.1e" % h[2]), h[3]) for h in pb.history])
+    pb.destroy()
