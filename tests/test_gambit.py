@@ -137,3 +137,31 @@ def test_element_groups_of_the_known_answer_mesh_and_its_selective_levels():
     assert [x.nel for x in ms] == [98, 392, 1568, 6272, 1280 * 4 + 4992, 5120 * 4 + 4992]
     assert ms[3].elem_levels()[1] and not ms[4].elem_levels()[1] and not ms[5].elem_levels()[1]
     assert capi.Mesh.box(2, 1, 0).elem_groups()[0].tolist() == [1, 1]
+
+
+def test_hanging_node_map_on_the_selective_levels_of_the_known_answer_mesh():
+    """the two non-homogeneous levels of unittests/testNSSteadyDD (curved elements around the cylinder): the library's hanging-node constraints
+    (Mesh::GetAMRRestrictionAndAMRSolidMark as fh_mesh_amr_constraints restates it) against the oracle's independent restatement, node by node"""
+    import os
+    from oracle import femus_oracle as fo
+    from oracle import femus_oracle_amr as fa
+    ms = [capi.Mesh.read_gambit(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nsbenc.neu"))]
+    for l in range(1, 6):
+        g, _ = ms[-1].elem_groups()
+        lev, _ = ms[-1].elem_levels()
+        ms.append(ms[-1].refine_flagged(np.ones(ms[-1].nel, np.uint8) if l < 4 else ((g == 5) & (lev == ms[-1].level)).astype(np.uint8)))
+    for l in (4, 5):
+        m = ms[l]
+        ed, xy, ff = m.arrays()
+        mo = fo.Mesh("quad", ed, xy, ff, level=l)
+        mo.elem_level = m.elem_levels()[0].astype(np.int64)
+        for fe in ("biquadratic", "linear"):
+            hang, ptr, master, w = m.amr_constraints(fe)
+            R = fa.amr_restriction(mo, fe)
+            assert hang.size > 0 and sorted(R) == hang.tolist()
+            for i, h in enumerate(hang):
+                got = dict(zip(master[ptr[i]:ptr[i + 1]].tolist(), w[ptr[i]:ptr[i + 1]].tolist()))
+                want = {k: v for k, v in R[int(h)].items() if k != int(h)}
+                got = {k: v for k, v in got.items() if k != int(h)}
+                assert set(got) == set(want), (l, fe, int(h))
+                assert max(abs(got[k] - want[k]) for k in want) <= 1e-12
