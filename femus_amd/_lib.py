@@ -158,6 +158,8 @@ def _declare(L):
     sig("fh_mesh_vertex_patches", c_void_p, c_int, c_void_p, P(c_int), P(c_int), c_void_p, c_void_p)
     sig("fh_ns_assembler_create", c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, P(c_void_p))
     sig("fh_ns_pw_assembler_create", c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, P(c_void_p))
+    sig("fh_advdiff_assembler_create", c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, P(c_void_p))
+    sig("fh_assemble_advection_diffusion", c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p)
     sig("fh_ns_assembler_destroy", c_void_p)
     sig("fh_assemble_navier_stokes", c_void_p, c_void_p, c_double, c_void_p, c_void_p)
     sig("fh_ns_element_matrices", c_void_p, c_void_p, c_double, c_void_p, c_void_p)

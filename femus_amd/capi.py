@@ -1095,6 +1095,23 @@ class NSPwAssembler(NSAssembler):
         return np.concatenate([ed + k * mesh.nnode for k in range(mesh.dim)] + [p], axis=1).astype(np.int32)
 
 
+class AdvDiffAssembler(NSAssembler):
+    """scalar LAGRANGE SECOND advection-diffusion in a given velocity field: the temperature callback of unittests/testNSSteadyDD (AssembleMatrixResT)"""
+
+    def __init__(self, ctx, mesh, A, order="seventh"):
+        self.ctx, self.L = ctx, ctx.L
+        ed, xy, _ = mesh.arrays()
+        self.nel = mesh.nel
+        self.nd = mesh.nloc
+        self.h = ctypes.c_void_p()
+        _chk(self.L.fh_advdiff_assembler_create(ctx.h, GEOM[mesh.geom], GAUSS_ORDER[order], mesh.nel, mesh.nloc, _p(ed), mesh.nnode, _p(xy), A.h,
+                                                ctypes.byref(self.h)))
+
+    def assemble(self, A, res, sol, velocity, inverse_peclet):
+        _chk(self.L.fh_assemble_advection_diffusion(self.h, None if sol is None else sol.h, None if velocity is None else velocity.h,
+                                                    ctypes.c_double(inverse_peclet), A.h, res.h))
+
+
 class NSStabAssembler(NSAssembler):
     """the callback of applications/003_NavierStokes/SteadyNavierStokesParallel (main.cpp:390-925): equal-order linear velocity / pressure on the vertex
     nodes with the Franca-Frey stabilisation; variables [U | V | (W) | P], each `nq1` long"""

@@ -30,7 +30,7 @@ struct fh_ns_assembler_s {
   int *d_adj_ptr = nullptr, *d_adj_ei = nullptr;   // row -> (element * nd + local row), ascending
   int max_row = 0;
   int kind = 0;                 // 0: Taylor-Hood (03_navier_stokes.hpp), 1: equal-order linear with the Franca-Frey stabilisation (the application's callback),
-                                // 2: Q2 velocity with the discontinuous piecewise-linear pressure (unittests/testNSSteadyDD)
+                                // 2: Q2 velocity with the discontinuous piecewise-linear pressure (unittests/testNSSteadyDD), 3: scalar advection-diffusion (its temperature system)
   double* d_d2phi = nullptr;    // kind 1: second reference derivatives [ng][nv][nh]
 };
 
@@ -199,6 +199,115 @@ __global__ __launch_bounds__((DIM == 2) ? 64 : 256) void k_ns_elem(NsParams P) {
   for (int k = 0; k < EPT; k++)
     if (er[k] >= 0) Ke[tid + k * NT] = acc[k];
   if (tid < ND) P.F[(size_t)e * ND + tid] = racc;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Scalar advection-diffusion in a given velocity field (kind 3): the temperature callback of the reference's known-answer test,
+// unittests/testNSSteadyDD/main.cpp AssembleMatrixResT (:730-880): T and the velocities are LAGRANGE SECOND,
+//   F[i]   += (-IPe grad phi_i . grad T - (u . grad T) phi_i) w          (:851)
+//   B[i,j] += (IPe grad phi_i . grad phi_j + (u . grad phi_j) phi_i) w  (:854-864)
+// One workgroup per element as k_ns_elem; the velocity is read from a stacked vector [U | V | (W) | ...] of stride nnode.
+// ------------------------------------------------------------------------------------------------------------------
+struct AdvDiffParams {
+  const int* elem_dof;
+  const double* coords;
+  const double *w, *phi, *dphi;
+  const double* sol;     // T [nnode] or null
+  const double* vel;     // [dim * nnode (+ ...)] or null (pure diffusion)
+  double* K;             // [nel][nv*nv]
+  double* F;             // [nel][nv]
+  int nel, nloc, ng, nnode;
+  double ipe;
+};
+template <int DIM>
+__global__ __launch_bounds__((DIM == 2) ? 64 : 256) void k_advdiff_elem(AdvDiffParams P) {
+  constexpr int NV = (DIM == 2) ? 9 : 27, NT = (DIM == 2) ? 64 : 256, EPT = (NV * NV + NT - 1) / NT;
+  __shared__ double xv[NV * DIM], uv[DIM * NV], tv[NV];
+  __shared__ double G[NV * DIM], Jm[DIM * DIM], sc[2 * DIM];   // u[DIM], grad T[DIM]
+  const int e = blockIdx.x, tid = threadIdx.x;
+  const int* ed = P.elem_dof + (size_t)e * P.nloc;
+  for (int t = tid; t < NV * DIM; t += NT) xv[t] = P.coords[(size_t)ed[t / DIM] * DIM + t % DIM];
+  for (int t = tid; t < DIM * NV; t += NT) uv[t] = P.vel ? P.vel[(size_t)(t / NV) * P.nnode + ed[t % NV]] : 0.0;
+  for (int t = tid; t < NV; t += NT) tv[t] = P.sol ? P.sol[ed[t]] : 0.0;
+  double acc[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; k++) acc[k] = 0.0;
+  double racc = 0.0;
+  __syncthreads();
+  for (int g = 0; g < P.ng; g++) {
+    const double* dph = P.dphi + (size_t)g * NV * DIM;
+    const double* ph = P.phi + (size_t)g * NV;
+    if (tid < DIM * DIM) {
+      const int a = tid / DIM, b = tid % DIM;
+      double s = 0.0;
+      for (int n = 0; n < NV; n++) s += dph[n * DIM + a] * xv[n * DIM + b];
+      Jm[tid] = s;
+    }
+    __syncthreads();
+    double JI[DIM][DIM], det;
+    if (DIM == 2) {
+      det = Jm[0] * Jm[3] - Jm[1] * Jm[2];
+      const double id = 1.0 / det;
+      JI[0][0] = Jm[3] * id; JI[0][1] = -Jm[1] * id; JI[1][0] = -Jm[2] * id; JI[1][1] = Jm[0] * id;
+    } else {
+      const double a00 = Jm[0], a01 = Jm[1], a02 = Jm[2], a10 = Jm[3], a11 = Jm[4], a12 = Jm[5], a20 = Jm[6], a21 = Jm[7], a22 = Jm[8];
+      det = a00 * (a11 * a22 - a12 * a21) + a01 * (a12 * a20 - a10 * a22) + a02 * (a10 * a21 - a11 * a20);
+      const double id = 1.0 / det;
+      JI[0][0] = (a11 * a22 - a12 * a21) * id; JI[0][1] = (a02 * a21 - a01 * a22) * id; JI[0][2] = (a01 * a12 - a02 * a11) * id;
+      JI[1][0] = (a12 * a20 - a10 * a22) * id; JI[1][1] = (a00 * a22 - a02 * a20) * id; JI[1][2] = (a02 * a10 - a00 * a12) * id;
+      JI[2][0] = (a10 * a21 - a11 * a20) * id; JI[2][1] = (a01 * a20 - a00 * a21) * id; JI[2][2] = (a00 * a11 - a01 * a10) * id;
+    }
+    for (int t = tid; t < NV * DIM; t += NT) {
+      const int n = t / DIM, b = t % DIM;
+      double s = 0.0;
+#pragma unroll
+      for (int a = 0; a < DIM; a++) s += dph[n * DIM + a] * JI[b][a];
+      G[t] = s;
+    }
+    __syncthreads();
+    if (tid < DIM) {
+      double s = 0.0;
+      for (int n = 0; n < NV; n++) s += uv[tid * NV + n] * ph[n];
+      sc[tid] = s;
+    } else if (tid < 2 * DIM) {
+      const int d = tid - DIM;
+      double s = 0.0;
+      for (int n = 0; n < NV; n++) s += tv[n] * G[n * DIM + d];
+      sc[tid] = s;
+    }
+    __syncthreads();
+    const double wq = det * P.w[g];
+    const double* ug = sc;
+    const double* gt = sc + DIM;
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+      const int idx = tid + k * NT;
+      if (idx >= NV * NV) continue;
+      const int i = idx / NV, j = idx % NV;
+      double lap = 0.0, adv = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) {
+        lap += G[i * DIM + d] * G[j * DIM + d];
+        adv += ug[d] * G[j * DIM + d];
+      }
+      acc[k] += (P.ipe * lap + adv * ph[i]) * wq;
+    }
+    if (tid < NV) {
+      double lap = 0.0, adv = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) {
+        lap += G[tid * DIM + d] * gt[d];
+        adv += ug[d] * gt[d];
+      }
+      racc += (-P.ipe * lap - adv * ph[tid]) * wq;
+    }
+    __syncthreads();
+  }
+  double* Ke = P.K + (size_t)e * NV * NV;
+#pragma unroll
+  for (int k = 0; k < EPT; k++)
+    if (tid + k * NT < NV * NV) Ke[tid + k * NT] = acc[k];
+  if (tid < NV) P.F[(size_t)e * NV + tid] = racc;
 }
 
 // pass 2: CSR row r <- sum over (element, local row) in ascending element order; one wave per row, LDS accumulator
@@ -473,25 +582,25 @@ __global__ __launch_bounds__(64) void k_ns_stab_elem(NsStabParams P) {
 
 // pw: the pressure is the discontinuous piecewise-linear space (kind 2), n_vertex_nodes is not used then
 static int ns_assembler_create_impl(fh_ctx_t ctx, int geom, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, int n_vertex_nodes,
-                                    const double* coords, fh_mat_t A, bool pw, fh_ns_assembler_t* out) {
+                                    const double* coords, fh_mat_t A, bool pw, fh_ns_assembler_t* out, bool scalar = false) {
   FH_GUARD_BEGIN
   FH_REQUIRE(ctx && elem_dof && coords && A && out, "fh_ns_assembler_create: null argument");
   FH_REQUIRE(geom == 0 || geom == 1, "fh_ns_assembler_create: geom must be 0 (hex) or 1 (quad)");
   FH_REQUIRE(nloc == fhfe::nloc_of(geom), "fh_ns_assembler_create: nloc %d does not match the geometry", nloc);
   fh_ns_assembler_t as = new fh_ns_assembler_s();
   as->ctx = ctx;
-  as->kind = pw ? 2 : 0;
+  as->kind = scalar ? 3 : pw ? 2 : 0;
   as->geom = geom;
   as->dim = fhfe::dim_of(geom);
   as->nv = fhfe::ndofs_of(geom, fhfe::FE_BIQUADRATIC);
-  as->np = pw ? as->dim + 1 : fhfe::ndofs_of(geom, fhfe::FE_LINEAR);
-  as->nd = as->dim * as->nv + as->np;
+  as->np = scalar ? 0 : pw ? as->dim + 1 : fhfe::ndofs_of(geom, fhfe::FE_LINEAR);
+  as->nd = scalar ? as->nv : as->dim * as->nv + as->np;
   as->nloc = nloc;
   as->nel = nel;
   as->nnode = nnode;
   as->nq1 = pw ? 0 : n_vertex_nodes;
   FH_REQUIRE((int64_t)as->dim * nnode + (pw ? (int64_t)as->np * nel : (int64_t)n_vertex_nodes) < 2147483647ll, "fh_ns_assembler_create: the system does not fit 32-bit ids");
-  as->ndof = as->dim * nnode + (pw ? as->np * nel : n_vertex_nodes);
+  as->ndof = scalar ? nnode : as->dim * nnode + (pw ? as->np * nel : n_vertex_nodes);
   FH_REQUIRE(A->m == as->ndof && A->n == as->ndof, "fh_ns_assembler_create: matrix is %d x %d, the system has %d rows", A->m, A->n, as->ndof);
   std::vector<double> w, phi, dphi, w1, psi, dpsi;
   FH_REQUIRE(fhfe::shape_tables(geom, fhfe::FE_BIQUADRATIC, gauss_order, w, phi, dphi) == 0 &&
@@ -512,7 +621,7 @@ static int ns_assembler_create_impl(fh_ctx_t ctx, int geom, int gauss_order, int
     for (int i = 0; i < nloc; i++) FH_REQUIRE(ed[i] >= 0 && ed[i] < nnode, "fh_ns_assembler_create: node id %d out of range", ed[i]);
     for (int i = 0; i < as->np && !pw; i++) FH_REQUIRE(ed[i] < n_vertex_nodes, "fh_ns_assembler_create: vertex node %d is not a linear dof", ed[i]);
     int p = 0;
-    for (int k = 0; k < as->dim; k++)
+    for (int k = 0; k < (scalar ? 1 : as->dim); k++)
       for (int i = 0; i < as->nv; i++) es[(size_t)e * nd + p++] = k * nnode + ed[i];
     for (int i = 0; i < as->np; i++) es[(size_t)e * nd + p++] = as->dim * nnode + (pw ? i * nel + e : ed[i]);
   }
@@ -566,6 +675,37 @@ static int ns_assembler_create_impl(fh_ctx_t ctx, int geom, int gauss_order, int
 extern "C" int fh_ns_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, int n_vertex_nodes,
                                       const double* coords, fh_mat_t A, fh_ns_assembler_t* out) {
   return ns_assembler_create_impl(ctx, geom, gauss_order, nel, nloc, elem_dof, nnode, n_vertex_nodes, coords, A, false, out);
+}
+
+extern "C" int fh_advdiff_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, const double* coords,
+                                          fh_mat_t A, fh_ns_assembler_t* out) {
+  return ns_assembler_create_impl(ctx, geom, gauss_order, nel, nloc, elem_dof, nnode, 0, coords, A, false, out, true);
+}
+
+extern "C" int fh_assemble_advection_diffusion(fh_ns_assembler_t as, fh_vec_t sol, fh_vec_t velocity, double inverse_peclet, fh_mat_t A, fh_vec_t res) {
+  FH_REQUIRE(as && A && res, "fh_assemble_advection_diffusion: null argument");
+  FH_REQUIRE(as->kind == 3, "fh_assemble_advection_diffusion: this assembler was not created by fh_advdiff_assembler_create");
+  FH_REQUIRE(A->m == as->ndof && res->n_local >= as->ndof, "fh_assemble_advection_diffusion: size mismatch");
+  FH_REQUIRE(!sol || sol->n_local >= as->nnode, "fh_assemble_advection_diffusion: the state has %d entries, the mesh %d nodes", sol ? sol->n_local : 0, as->nnode);
+  FH_REQUIRE(!velocity || velocity->n_local >= as->dim * as->nnode, "fh_assemble_advection_diffusion: the velocity vector has %d entries, %d x %d are needed",
+             velocity ? velocity->n_local : 0, as->dim, as->nnode);
+  AdvDiffParams P;
+  P.elem_dof = as->d_elem_dof; P.coords = as->d_coords; P.w = as->d_w; P.phi = as->d_phi; P.dphi = as->d_dphi;
+  P.sol = sol ? sol->d : nullptr;
+  P.vel = velocity ? velocity->d : nullptr;
+  P.K = as->d_K; P.F = as->d_F;
+  P.nel = as->nel; P.nloc = as->nloc; P.ng = as->ng; P.nnode = as->nnode;
+  P.ipe = inverse_peclet;
+  if (as->nel) {
+    if (as->dim == 2) hipLaunchKernelGGL(k_advdiff_elem<2>, dim3(as->nel), dim3(64), 0, as->ctx->stream, P);
+    else hipLaunchKernelGGL(k_advdiff_elem<3>, dim3(as->nel), dim3(256), 0, as->ctx->stream, P);
+  }
+  if (as->ndof > 0)
+    hipLaunchKernelGGL(k_sys_row_gather, dim3(as->ndof), dim3(64), (size_t)as->max_row * sizeof(double), as->ctx->stream, as->d_adj_ptr, as->d_adj_ei,
+                       as->d_elem_sys, as->d_K, as->d_F, as->nd, A->d_rowptr, A->d_col, A->d_val, res->d, as->ndof);
+  FH_CHECK_HIP(hipGetLastError());
+  A->at_valid = false;
+  return 0;
 }
 
 extern "C" int fh_ns_pw_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, const double* coords,

@@ -400,6 +400,12 @@ int fh_ns_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, int nel, int
  * local function i of element e at dim * nnode + i * nel + e (Mesh::GetSolutionDof for solution type 4 on one process); KK must carry the pattern of
  * that element table (fh_mat_create_from_elements).  fh_assemble_navier_stokes assembles it.  tests/test_gpu_ns_known_answer.py reproduces the
  * level-3 norms that test stores (1e-6 there) to 1e-9 with this assembler and the sparse exact solve. */
+/* The temperature system of the same test (AssembleMatrixResT, main.cpp:730-880): LAGRANGE SECOND scalar advected by a given velocity field,
+ * Res = (-IPe grad phi . grad T - (u . grad T) phi) w, KK = (IPe grad phi_i . grad phi_j + (u . grad phi_j) phi_i) w.  KK: pattern of the mesh
+ * (fh_mat_create_from_mesh, fe 2); velocity: a stacked vector [U | V | (W) | ...] of stride nnode (the Navier-Stokes state), or NULL. */
+int fh_advdiff_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, const double* coords /* [nnode*dim] */,
+                                fh_mat_t KK, fh_ns_assembler_t* as);
+int fh_assemble_advection_diffusion(fh_ns_assembler_t as, fh_vec_t T /* or NULL */, fh_vec_t velocity /* or NULL */, double inverse_peclet, fh_mat_t KK, fh_vec_t RES);
 int fh_ns_pw_assembler_create(fh_ctx_t ctx, int geom, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, const double* coords /* [nnode*dim] */,
                               fh_mat_t KK, fh_ns_assembler_t* as);
 int fh_ns_assembler_destroy(fh_ns_assembler_t as);

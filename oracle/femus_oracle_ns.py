@@ -628,3 +628,47 @@ class NSLayoutPwLinear:
         ed = mesh.elem_dof
         pdof = np.arange(self.npr)[None, :] * mesh.nel + np.arange(mesh.nel)[:, None]
         self.elem_sys = np.concatenate([ed[:, :self.nv] + self.offset[k] for k in range(self.dim)] + [pdof + self.offset[self.dim]], axis=1)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# The temperature system of the same test: AssembleMatrixResT (unittests/testNSSteadyDD/main.cpp:730-880).  T and the velocities are
+# LAGRANGE SECOND; per Gauss point  F[i] += (-IPe grad phi_i . grad T - (u . grad T) phi_i) w  (:851),
+# B[i, j] += (IPe grad phi_i . grad phi_j + (u . grad phi_j) phi_i) w  (:854-864); IPe = 1 / Peclet (:741).
+# ----------------------------------------------------------------------------------------------------------------------------------
+def elem_advdiff_batch(et, X, T, UV, ipe):
+    """X[nel, dim, nv], T[nel, nv], UV[nel, dim, nv] -> B[nel, nv, nv], F[nel, nv]; Gauss-point sum sequential"""
+    nel, nv = X.shape[0], et.nc
+    Jm = np.einsum("gna,ebn->egab", et.dphi, X[:, :, :nv])
+    det = np.linalg.det(Jm)
+    JI = np.linalg.inv(Jm)
+    grad = np.einsum("gna,egba->egnb", et.dphi, JI)
+    w = det * et.w[None, :]
+    B, F = np.zeros((nel, nv, nv)), np.zeros((nel, nv))
+    for g in range(et.ng):
+        G = grad[:, g]
+        ug = np.einsum("ekn,n->ek", UV, et.phi[g])
+        gt = np.einsum("en,enj->ej", T, G)
+        lap = np.einsum("eid,ejd->eij", G, G)
+        adv = np.einsum("ej,enj->en", ug, G)                       # u . grad phi_n
+        B += (ipe * lap + et.phi[g][None, :, None] * adv[:, None, :]) * w[:, g][:, None, None]
+        F += (-ipe * np.einsum("eid,ed->ei", G, gt) - et.phi[g][None, :] * np.einsum("ej,ej->e", ug, gt)[:, None]) * w[:, g][:, None]
+    return B, F
+
+
+def assemble_advdiff(mesh, sol, vel, ipe, order="seventh"):
+    """KK, RES of the temperature system on a mesh: sol[nnode] (T), vel[dim * nnode (+ ...)] the stacked velocity state"""
+    et = fo.ElemType(mesh.geom, "biquadratic", order)
+    ed = mesh.elem_dof
+    nn = mesh.nnode
+    X = np.transpose(mesh.coords[ed], (0, 2, 1))
+    UV = np.stack([vel[k * nn:(k + 1) * nn][ed] for k in range(mesh.dim)], axis=1)
+    B, F = elem_advdiff_batch(et, X, sol[ed], UV, ipe)
+    indptr, indices = fo.csr_pattern(mesh, "biquadratic")
+    vals = np.zeros(indices.size)
+    nv = et.nc
+    rows = np.repeat(ed, nv, axis=1).ravel()
+    cols = np.tile(ed, (1, nv)).ravel()
+    np.add.at(vals, fo._csr_positions(indptr, indices, rows, cols), B.ravel())
+    b = np.zeros(nn)
+    np.add.at(b, ed.ravel(), F.ravel())
+    return sp.csr_matrix((vals, indices, indptr), shape=(nn, nn)), b

@@ -276,3 +276,101 @@ def test_the_whole_hierarchy_of_the_reference_test_with_its_two_selective_levels
     assert np.abs(r[free]).max() <= 1e-9 * np.abs(b).max()
     print("six levels:", [m.nel for m in ms], "unknowns on the finest", lay.n, "newton / linear history", [(h[0], h[1], float("%.1e" % h[2]), h[3]) for h in pb.history])
     pb.destroy()
+
+
+def _t_bc(mo):
+    """main.cpp:375-391: T = 1 on the inflow, 5 on the cylinder, nothing prescribed on the walls and the outflow"""
+    inflow, cyl = nodes_on(mo, INFLOW), nodes_on(mo, CYLINDER)
+    idx = np.concatenate([inflow, cyl])
+    val = np.concatenate([np.ones(inflow.size), 5.0 * np.ones(cyl.size)])
+    o = np.argsort(idx)
+    return idx[o].astype(np.int32), val[o]
+
+
+def test_temperature_system_of_the_reference_test(ctx):
+    """the second system of unittests/testNSSteadyDD (AssembleMatrixResT, main.cpp:730-880: LAGRANGE SECOND advection-diffusion in the computed velocity field,
+    IPe = 1 / 1000 for Fluid(par, 0.001, 1, "Newtonian", 0.001, 1.): Prandtl 1) on level 3: element matrices and the assembled operator against the oracle
+    restatement at a random state, then the solve -- exact, and by the cycle the test configures (V-cycle, GMRES + ILU(0) level solvers :186-200) -- against scipy
+    on the oracle's operator.  The reference stores only the boundary values of T on this level (its V-cycle runs on the finest level, :186); here the field itself
+    is checked."""
+    import scipy.sparse.linalg as spla
+    from femus_amd import known_answer as ka
+    ms = [capi.Mesh.read_gambit(os.path.join(HERE, "golden", "nsbenc.neu"))]
+    for _ in range(3):
+        ms.append(ms[-1].refine(ctx))
+    m = ms[3]
+    ed, xy, ff = m.arrays()
+    mo = fo.Mesh("quad", ed, xy, ff, level=3)
+    nn = m.nnode
+    KK = ctx.matrix_from_mesh(m, "biquadratic")
+    asm = capi.AdvDiffAssembler(ctx, m, KK)
+    rng = np.random.default_rng(21)
+    t0, v0 = rng.uniform(-1, 1, nn), rng.uniform(-1, 1, 2 * nn)
+    T, V, res = ctx.vector_from(t0), ctx.vector_from(v0), ctx.vector(nn)
+    asm.assemble(KK, res, T, V, 1e-3)
+    Ao, bo = fns.assemble_advdiff(mo, t0, v0, 1e-3)
+    assert abs(KK.to_scipy() - Ao).max() <= 1e-12 * abs(Ao).max()
+    assert np.linalg.norm(res.to_numpy() - bo) <= 1e-12 * np.linalg.norm(bo)
+    # the velocity field of the flow (level 3, exact Newton as in the known-answer run), then T from its boundary values
+    pbn = NavierStokesPwMG_single(ctx, m)
+    vel = pbn.SOL[0]
+    idx, val = _t_bc(mo)
+    t_init = np.zeros(nn)
+    t_init[idx] = val
+    T.upload(t_init)
+    asm.assemble(KK, res, T, vel, 1e-3)
+    Ao, bo = fns.assemble_advdiff(mo, t_init, vel.to_numpy(), 1e-3)
+    free = np.setdiff1d(np.arange(nn), idx)
+    d_ref = np.zeros(nn)
+    d_ref[free] = spla.splu(Ao.tocsr()[free][:, free].tocsc()).solve(bo[free])
+    t_ref = t_init + d_ref
+    bidx = capi.Index(ctx, idx)
+    bidx.zero_rows(KK, 1.0)
+    bidx.set(res, 0.0)
+    eps = ctx.vector(nn)
+    d = capi.Direct(ctx, KK, xy).factor()
+    d.solve(res, eps)
+    assert np.linalg.norm(eps.to_numpy() - d_ref) <= 1e-10 * np.linalg.norm(d_ref)
+    d.destroy()
+    # the cycle of the test: Galerkin chain over levels 0 .. 3, exact solve below, GMRES + ILU(0) level solvers, one smoothing step before and after
+    bdc = []
+    for l, ml in enumerate(ms):
+        e_l, x_l, f_l = ml.arrays()
+        bdc.append(_t_bc(fo.Mesh("quad", e_l, x_l, f_l, level=l))[0])
+    A = {3: KK}
+    Ps = {}
+    for l in range(3, 0, -1):
+        P = capi.build_prolongator(ctx, ms[l - 1], ms[l], "biquadratic", zero_bdc=False)
+        P.mat_zero_rows(bdc[l], 0.0)
+        P.zero_cols(bdc[l - 1])
+        Ps[l] = P
+        A[l - 1] = capi.Mat.ptap(P, A[l])
+        bdc_dev = capi.Index(ctx, bdc[l - 1])
+        bdc_dev.zero_rows(A[l - 1], 1.0)
+    mg = capi.Multigrid(ctx, 4)
+    for l in range(1, 4):
+        mg.set_level_solver(l, "gmres", 30)
+    for l in range(4):
+        mg.set_level(l, A[l], Ps.get(l), None, capi.SMOOTH_ILU0, 1.0, 4 if l else 1, 4 if l else 0)
+    mg.setup()
+    its, rn = mg.solve(res, eps, outer="fgmres", rtol=1e-12, maxit=60)
+    assert its <= 30
+    assert np.linalg.norm(eps.to_numpy() - d_ref) <= 1e-9 * np.linalg.norm(d_ref)
+    t_dev = t_init + eps.to_numpy()
+    assert t_dev.min() > 1.0 - 0.35 and t_dev.max() < 5.0 + 0.35             # no spurious extrema beyond the usual Galerkin wiggles at Pe = 1000
+    print("temperature on level 3: outer iterations", its, "range", t_dev.min(), t_dev.max(), "||T||", np.linalg.norm(t_dev), "distance to scipy on the oracle's operator",
+          np.linalg.norm(t_dev - t_ref) / np.linalg.norm(t_ref))
+    mg.destroy(); pbn.destroy(); asm.destroy()
+
+
+def NavierStokesPwMG_single(ctx, m):
+    """the converged flow on one level (exact Newton), as femus_amd.known_answer.run does it"""
+    from femus_amd import known_answer as ka
+    from femus_amd.navier_stokes import NavierStokesPwMG
+    pb = NavierStokesPwMG(ctx, [m], 0.001, ka.boundary_condition).init()
+    x = np.zeros(pb.n[0])
+    x[:m.nnode] = ka.inflow_profile(m.arrays()[1][:, 1])
+    pb.set_state(0, x)
+    assert pb.mgsolve(tol=1e-10, max_newton=20)
+    pb.meshes = []            # the mesh belongs to the caller
+    return pb
