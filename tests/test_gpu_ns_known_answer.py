@@ -374,3 +374,14 @@ def NavierStokesPwMG_single(ctx, m):
     assert pb.mgsolve(tol=1e-10, max_newton=20)
     pb.meshes = []            # the mesh belongs to the caller
     return pb
+
+
+def test_the_reference_unit_test_as_an_application(ctx):
+    """femus_amd/app_ns_steady_dd.py = unittests/testNSSteadyDD/main.cpp over the C-ABI, all of it: six levels (two selective), the Navier-Stokes system under
+    the test's own iteration limits, the temperature system on the finest level, and the test's four assertions (main.cpp:202-244)"""
+    from femus_amd import app_ns_steady_dd as app
+    r = app.run(ctx, verbose=False)
+    assert r["passed"] and r["elements"] == [98, 392, 1568, 6272, 10112, 25472]
+    assert max(r["relative_distance"].values()) < 1e-8, r["relative_distance"]
+    lo, hi = r["temperature_range"]
+    assert 0.9 < lo <= 1.0 + 1e-9 and 5.0 - 1e-9 <= hi < 5.1
