@@ -212,8 +212,11 @@ int fh_tri_ilu_factor(fh_tri_t T, fh_mat_t A) {
   if (!T->d_flag) FH_CHECK_HIP(hipMalloc(&T->d_flag, sizeof(int)));
   const int nf = (int)T->fptr.size() - 1;
   const int maxrow = std::max(A->max_row, 1);
-  FH_REQUIRE(maxrow <= 512, "ILU(0): a row with %d entries (at most 512 are served)", maxrow);
+  // the row being eliminated lives in LDS, sixteen rows per workgroup: 128 bytes per entry of the longest row.  512 entries fit the 64 kB a kernel gets
+  // without asking; up to 1 200 (stacked three-dimensional systems after a Galerkin product) the kernel asks for more of the CU's 160 kB
+  FH_REQUIRE(maxrow <= 1200, "ILU(0): a row with %d entries (at most 1200 are served)", maxrow);
   const size_t lds = (size_t)16 * maxrow * sizeof(double);
+  if (lds > 64 * 1024) FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ilu_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   double shift = 0.0;
   for (int attempt = 0; attempt < 40; attempt++) {
     FH_CHECK_HIP(hipMemcpyAsync(T->d_lu, A->d_val, (size_t)A->nnz * sizeof(double), hipMemcpyDeviceToDevice, c->stream));

@@ -385,3 +385,48 @@ def test_the_reference_unit_test_as_an_application(ctx):
     assert max(r["relative_distance"].values()) < 1e-8, r["relative_distance"]
     lo, hi = r["temperature_range"]
     assert 0.9 < lo <= 1.0 + 1e-9 and 5.0 - 1e-9 <= hi < 5.1
+
+
+def test_three_dimensional_flow_with_a_selective_level(ctx):
+    """HEX27 / hexpwLinear through the same driver: lid-driven box, two uniform levels and one selective level above them (an octant refined), nonlinear F-cycle
+    with GMRES + ILU(0) level solvers; the final velocities satisfy the hanging-node relation and the oracle's discrete residual vanishes"""
+    from femus_amd.navier_stokes import NavierStokesPwMG
+    ms = [capi.Mesh.box(2, 2, 2, lo=(0., 0., 0.), hi=(1., 1., 1.))]
+    ms.append(ms[-1].refine(ctx))
+    xc = ms[-1].elem_centroids()
+    ms.append(ms[-1].refine_device(ctx, ((xc[:, 0] > 0.5) & (xc[:, 1] > 0.5) & (xc[:, 2] > 0.5)).astype(np.uint8)))
+    assert not ms[2].elem_levels()[1]
+
+    def bc(x, name, face):                       # every face a wall; the top (z = 1, face name 6 of the box generator) moves in x; the pressure level is fixed below
+        return True, (1.0 if (name == "U" and face == 6 and 0.0 < x[0] < 1.0 and 0.0 < x[1] < 1.0) else 0.0)
+
+    pb = NavierStokesPwMG(ctx, ms, 0.05, bc, level_gmres_its=4).init()
+    # all-Dirichlet velocities leave the pressure defined up to a constant: fix the constant function of element 0 on every level (FixSolutionAtOnePoint)
+    for l in range(3):
+        p0 = np.int32(3 * ms[l].nnode)
+        pb.bdc[l] = np.sort(np.append(pb.bdc[l], p0)).astype(np.int32)
+        pb.bdc_val[l] = np.zeros(pb.bdc[l].size)
+    for l in range(1, 3):                        # the cycle's interpolation must not touch the fixed pressure function
+        pb.P[l].mat_zero_rows(np.array([3 * ms[l].nnode], np.int32), 0.0)
+        pb.P[l].zero_cols(np.array([3 * ms[l - 1].nnode], np.int32))
+    pb.set_state(0, np.zeros(pb.n[0]))
+    assert pb.mgsolve(tol=1e-10, max_newton=20, lin_rtol=1e-10, lin_maxit=150)
+    top = 2
+    m = ms[top]
+    s = pb.SOL[top].to_numpy()
+    hang, ptr, master, w = m.amr_constraints("biquadratic")
+    assert hang.size > 0
+    for k in range(3):
+        u = s[k * m.nnode:(k + 1) * m.nnode]
+        interp = np.array([np.dot(w[ptr[i]:ptr[i + 1]], u[master[ptr[i]:ptr[i + 1]]]) for i in range(hang.size)])
+        assert np.abs(u[hang] - interp).max() <= 1e-10 * max(np.abs(u).max(), 1e-30)
+    ed, xy, ff = m.arrays()
+    mo = fo.Mesh("hex", ed, xy, ff, level=top)
+    lay = fns.NSLayoutPwLinear(mo)
+    _, b = fns.assemble_ns(mo, lay, s, 0.05, etp=fns.PwLinearPressure("hex", "seventh"))
+    r = pb.Pamr[top].to_scipy().T @ b
+    free = np.setdiff1d(np.arange(lay.n), pb.bdc[top])
+    assert np.abs(r[free]).max() <= 1e-9 * np.abs(b).max()
+    # the lid drives a recirculation (hanging nodes ON the lid interpolate its discontinuous data: up to 1.125^2 there)
+    assert 1.0 <= np.abs(s[:m.nnode]).max() <= 1.125 ** 2 + 1e-12 and s[:m.nnode].min() < -0.01
+    pb.destroy()
