@@ -8,6 +8,10 @@ struct fh_tri_s {
   std::vector<int> fptr, bptr;          // level pointers of the forward (rows j < i first) / backward schedule
   std::vector<int> h_diagpos;
   int *d_frows = nullptr, *d_brows = nullptr, *d_diagpos = nullptr;
+  // runs of consecutive SMALL levels go to one workgroup each (fh_trisolve.hip: k_tri_run): level pointers on the device, and per sweep direction the
+  // segments {first level, number of levels, 1 = run of small levels / 0 = one large level}
+  int *d_fptr = nullptr, *d_bptr = nullptr;
+  std::vector<int> fseg, bseg;
   double* d_lu = nullptr;               // ILU(0) factors on A's pattern: strict lower part = L (unit diagonal), rest = U
   int* d_flag = nullptr;
   double* d_t = nullptr;                // symmetric sweep: t = r - L z of the forward half, read by the backward half

@@ -16,6 +16,12 @@
 #include <algorithm>
 #include <cmath>
 
+// A level of at most TRI_SMALL rows is "small": a launch per level then costs more than the level's work (a two-dimensional stacked system of 70 000 unknowns
+// has 1 500 levels of 46 rows on average: 3 000 launches of 5 us per triangular solve).  Consecutive small levels are swept by ONE workgroup of 1 024 threads
+// (64 rows at a time, 16 lanes each) with a workgroup barrier between the levels: all its waves sit on one CU and share its L1, so the barrier's
+// workgroup-scope release / acquire is all the ordering the rows of the next level need (round 5).
+constexpr int TRI_SMALL = 256;
+
 // rows of the local block only: columns >= m are ghosts (block Jacobi across ranks, as PCSOR / PCILU are local)
 static void schedule(const std::vector<int>& rp, const std::vector<int>& col, int m, bool forward, std::vector<int>& ptr, std::vector<int>& rows) {
   std::vector<int> lev(m, 0);
@@ -54,6 +60,27 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
   schedule(A->h_rowptr, fh_hcol(A), A->m, false, T->bptr, rows);
   FH_CHECK_HIP(hipMalloc(&T->d_brows, std::max(A->m, 1) * sizeof(int)));
   FH_CHECK_HIP(hipMemcpy(T->d_brows, rows.data(), (size_t)A->m * sizeof(int), hipMemcpyHostToDevice));
+  auto segments = [](const std::vector<int>& ptr, std::vector<int>& seg) {
+    seg.clear();
+    const int nl = (int)ptr.size() - 1;
+    for (int l = 0; l < nl;) {
+      if (ptr[l + 1] - ptr[l] > TRI_SMALL) {
+        seg.insert(seg.end(), {l, 1, 0});
+        l++;
+        continue;
+      }
+      int e = l;
+      while (e < nl && ptr[e + 1] - ptr[e] <= TRI_SMALL) e++;
+      seg.insert(seg.end(), {l, e - l, 1});
+      l = e;
+    }
+  };
+  segments(T->fptr, T->fseg);
+  segments(T->bptr, T->bseg);
+  FH_CHECK_HIP(hipMalloc(&T->d_fptr, T->fptr.size() * sizeof(int)));
+  FH_CHECK_HIP(hipMemcpy(T->d_fptr, T->fptr.data(), T->fptr.size() * sizeof(int), hipMemcpyHostToDevice));
+  FH_CHECK_HIP(hipMalloc(&T->d_bptr, T->bptr.size() * sizeof(int)));
+  FH_CHECK_HIP(hipMemcpy(T->d_bptr, T->bptr.data(), T->bptr.size() * sizeof(int), hipMemcpyHostToDevice));
   std::vector<int> dpos(A->m, -1);
   for (int i = 0; i < A->m; i++) {
     const int* b = fh_hcol(A).data() + A->h_rowptr[i];
@@ -81,7 +108,7 @@ int fh_tri_create(fh_mat_t A, fh_tri_t* out) {
 
 void fh_tri_destroy(fh_tri_t T) {
   if (!T) return;
-  for (void* p : {(void*)T->d_frows, (void*)T->d_brows, (void*)T->d_diagpos, (void*)T->d_lu, (void*)T->d_flag, (void*)T->d_t})
+  for (void* p : {(void*)T->d_frows, (void*)T->d_brows, (void*)T->d_diagpos, (void*)T->d_lu, (void*)T->d_flag, (void*)T->d_t, (void*)T->d_fptr, (void*)T->d_bptr})
     if (p) hipFree(p);
   delete T;
 }
@@ -129,19 +156,79 @@ __global__ __launch_bounds__(256) void k_gs_bwd(const int* __restrict__ rows, in
   if (live && gl == 0) z[i] = dinv[i] * (t[i] - acc);
 }
 
+// ---- runs of small levels in one workgroup: the row bodies of the four kernels above / below, levels separated by a workgroup barrier ----
+struct TriRun {
+  const int *rows, *lptr, *rowptr, *col, *diagpos;
+  const double *val, *dinv, *r, *t_in;
+  double *z, *t_out;
+  int l0, nl, m;
+};
+template <int KIND>      // 0: Gauss-Seidel forward, 1: backward, 2: ILU lower, 3: ILU upper
+__global__ __launch_bounds__(1024) void k_tri_run(TriRun P) {
+  const int gl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  for (int l = P.l0; l < P.l0 + P.nl; l++) {
+    const int base = P.lptr[l], n = P.lptr[l + 1] - base;
+    for (int r0 = 0; r0 < n; r0 += 64) {
+      const int rr = r0 + grp;
+      const bool live = rr < n;
+      const int i = live ? P.rows[base + rr] : 0;
+      double acc = 0.0;
+      if (live)
+        for (int k = P.rowptr[i] + gl; k < P.rowptr[i + 1]; k += 16) {
+          const int j = P.col[k];
+          if (KIND == 0 || KIND == 2) {
+            if (j < i) acc += P.val[k] * P.z[j];
+          } else {
+            if (j > i && j < P.m) acc += P.val[k] * P.z[j];
+          }
+        }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+      if (live && gl == 0) {
+        if (KIND == 0) {
+          const double ti = P.r[i] - acc;
+          P.t_out[i] = ti;
+          P.z[i] = P.dinv[i] * ti;
+        } else if (KIND == 1) {
+          P.z[i] = P.dinv[i] * (P.t_in[i] - acc);
+        } else if (KIND == 2) {
+          P.z[i] = P.r[i] - acc;
+        } else {
+          P.z[i] = (P.z[i] - acc) / P.val[P.diagpos[i]];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // z = B r, B = one symmetric Gauss-Seidel sweep of A's local block from z = 0
 int fh_tri_ssor_apply(fh_tri_t T, fh_mat_t A, const double* dinv, const double* r, double* z) {
   hipStream_t s = A->ctx->stream;
   const int nf = (int)T->fptr.size() - 1, nb = (int)T->bptr.size() - 1;
-  for (int l = 0; l < nf; l++) {
-    const int n = T->fptr[l + 1] - T->fptr[l];
-    hipLaunchKernelGGL(k_gs_fwd, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_frows + T->fptr[l], n, A->d_rowptr, A->d_col, A->d_val, dinv,
-                       r, z, T->d_t);
+  (void)nf; (void)nb;
+  TriRun P = {nullptr, nullptr, A->d_rowptr, A->d_col, T->d_diagpos, A->d_val, dinv, r, T->d_t, z, T->d_t, 0, 0, A->m};
+  for (size_t q = 0; q < T->fseg.size(); q += 3) {
+    const int l = T->fseg[q];
+    if (T->fseg[q + 2]) {
+      P.rows = T->d_frows; P.lptr = T->d_fptr; P.l0 = l; P.nl = T->fseg[q + 1];
+      hipLaunchKernelGGL(k_tri_run<0>, dim3(1), dim3(1024), 0, s, P);
+    } else {
+      const int n = T->fptr[l + 1] - T->fptr[l];
+      hipLaunchKernelGGL(k_gs_fwd, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_frows + T->fptr[l], n, A->d_rowptr, A->d_col, A->d_val, dinv,
+                         r, z, T->d_t);
+    }
   }
-  for (int l = 0; l < nb; l++) {
-    const int n = T->bptr[l + 1] - T->bptr[l];
-    hipLaunchKernelGGL(k_gs_bwd, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_brows + T->bptr[l], n, A->d_rowptr, A->d_col, A->d_val, dinv,
-                       T->d_t, z, A->m);
+  for (size_t q = 0; q < T->bseg.size(); q += 3) {
+    const int l = T->bseg[q];
+    if (T->bseg[q + 2]) {
+      P.rows = T->d_brows; P.lptr = T->d_bptr; P.l0 = l; P.nl = T->bseg[q + 1];
+      hipLaunchKernelGGL(k_tri_run<1>, dim3(1), dim3(1024), 0, s, P);
+    } else {
+      const int n = T->bptr[l + 1] - T->bptr[l];
+      hipLaunchKernelGGL(k_gs_bwd, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_brows + T->bptr[l], n, A->d_rowptr, A->d_col, A->d_val, dinv,
+                         T->d_t, z, A->m);
+    }
   }
   FH_CHECK_HIP(hipGetLastError());
   return 0;
@@ -278,14 +365,28 @@ __global__ __launch_bounds__(256) void k_ilu_usolve(const int* __restrict__ rows
 int fh_tri_ilu_apply(fh_tri_t T, fh_mat_t A, const double* r, double* z) {
   hipStream_t s = A->ctx->stream;
   const int nf = (int)T->fptr.size() - 1, nb = (int)T->bptr.size() - 1;
-  for (int l = 0; l < nf; l++) {
-    const int n = T->fptr[l + 1] - T->fptr[l];
-    hipLaunchKernelGGL(k_ilu_lsolve, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_frows + T->fptr[l], n, A->d_rowptr, A->d_col, T->d_lu, r, z);
+  (void)nf; (void)nb;
+  TriRun P = {nullptr, nullptr, A->d_rowptr, A->d_col, T->d_diagpos, T->d_lu, nullptr, r, nullptr, z, nullptr, 0, 0, A->m};
+  for (size_t q = 0; q < T->fseg.size(); q += 3) {
+    const int l = T->fseg[q];
+    if (T->fseg[q + 2]) {
+      P.rows = T->d_frows; P.lptr = T->d_fptr; P.l0 = l; P.nl = T->fseg[q + 1];
+      hipLaunchKernelGGL(k_tri_run<2>, dim3(1), dim3(1024), 0, s, P);
+    } else {
+      const int n = T->fptr[l + 1] - T->fptr[l];
+      hipLaunchKernelGGL(k_ilu_lsolve, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_frows + T->fptr[l], n, A->d_rowptr, A->d_col, T->d_lu, r, z);
+    }
   }
-  for (int l = 0; l < nb; l++) {
-    const int n = T->bptr[l + 1] - T->bptr[l];
-    hipLaunchKernelGGL(k_ilu_usolve, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_brows + T->bptr[l], n, A->d_rowptr, A->d_col,
-                       T->d_diagpos, T->d_lu, z, A->m);
+  for (size_t q = 0; q < T->bseg.size(); q += 3) {
+    const int l = T->bseg[q];
+    if (T->bseg[q + 2]) {
+      P.rows = T->d_brows; P.lptr = T->d_bptr; P.l0 = l; P.nl = T->bseg[q + 1];
+      hipLaunchKernelGGL(k_tri_run<3>, dim3(1), dim3(1024), 0, s, P);
+    } else {
+      const int n = T->bptr[l + 1] - T->bptr[l];
+      hipLaunchKernelGGL(k_ilu_usolve, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_brows + T->bptr[l], n, A->d_rowptr, A->d_col,
+                         T->d_diagpos, T->d_lu, z, A->m);
+    }
   }
   FH_CHECK_HIP(hipGetLastError());
   return 0;
