@@ -163,12 +163,81 @@ struct TriRun {
   double *z, *t_out;
   int l0, nl, m;
 };
+// What a level costs inside the run is its chain of dependent loads (level pointer -> row id -> row pointers -> columns / values -> z).  Only the last link
+// depends on the level before: everything else of the NEXT level's first 64 rows -- row id, bounds, the first TRI_PF entries per lane, the right-hand side and the
+// diagonal -- is loaded while the current level is computed (two register sets), so that after the barrier a level is one gather of z, the sum and a store.  The
+// lane's entries are added in the same order as in the one-launch-per-level kernels: the same bits.
+constexpr int TRI_PF = 6;
+struct TriPre {
+  int i, rs, re, c[TRI_PF];
+  double v[TRI_PF], e0, e1;
+};
+template <int KIND>
+__device__ __forceinline__ void tri_prefetch(const TriRun& P, int base, int n, int grp, int gl, TriPre& Q) {
+  Q.i = -1;
+  Q.rs = Q.re = 0;
+  if (grp >= n) return;
+  const int i = P.rows[base + grp];
+  Q.i = i;
+  Q.rs = P.rowptr[i];
+  Q.re = P.rowptr[i + 1];
+#pragma unroll
+  for (int q = 0; q < TRI_PF; q++) {
+    const int k = Q.rs + gl + 16 * q;
+    Q.c[q] = k < Q.re ? P.col[k] : -1;
+    Q.v[q] = k < Q.re ? P.val[k] : 0.0;
+  }
+  if (gl == 0) {
+    Q.e0 = KIND == 1 ? P.t_in[i] : KIND == 3 ? P.z[i] : P.r[i];
+    Q.e1 = (KIND == 0 || KIND == 1) ? P.dinv[i] : KIND == 3 ? P.val[P.diagpos[i]] : 1.0;
+  }
+}
+template <int KIND>
+__device__ __forceinline__ bool tri_takes(int j, int i, int m) {
+  return (KIND == 0 || KIND == 2) ? (j < i) : (j > i && j < m);
+}
+template <int KIND>
+__device__ __forceinline__ void tri_store(const TriRun& P, int i, double acc, double e0, double e1) {
+  if (KIND == 0) {
+    const double ti = e0 - acc;
+    P.t_out[i] = ti;
+    P.z[i] = e1 * ti;
+  } else if (KIND == 1) {
+    P.z[i] = e1 * (e0 - acc);
+  } else if (KIND == 2) {
+    P.z[i] = e0 - acc;
+  } else {
+    P.z[i] = (e0 - acc) / e1;
+  }
+}
+
 template <int KIND>      // 0: Gauss-Seidel forward, 1: backward, 2: ILU lower, 3: ILU upper
 __global__ __launch_bounds__(1024) void k_tri_run(TriRun P) {
   const int gl = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  for (int l = P.l0; l < P.l0 + P.nl; l++) {
-    const int base = P.lptr[l], n = P.lptr[l + 1] - base;
-    for (int r0 = 0; r0 < n; r0 += 64) {
+  const int lend = P.l0 + P.nl;
+  int base = P.lptr[P.l0], nxt = P.lptr[P.l0 + 1];
+  TriPre Q;
+  tri_prefetch<KIND>(P, base, nxt - base, grp, gl, Q);
+  for (int l = P.l0; l < lend; l++) {
+    const int n = nxt - base;
+    const int base2 = nxt, nxt2 = (l + 1 < lend) ? P.lptr[l + 2] : nxt;
+    TriPre N;
+    tri_prefetch<KIND>(P, base2, nxt2 - base2, grp, gl, N);          // next level (nothing of it depends on this level's z)
+    if (Q.i >= 0) {                                                     // first 64 rows: from the registers loaded one level ago
+      const int i = Q.i;
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < TRI_PF; q++)
+        if (Q.c[q] >= 0 && tri_takes<KIND>(Q.c[q], i, P.m)) acc += Q.v[q] * P.z[Q.c[q]];
+      for (int k = Q.rs + gl + 16 * TRI_PF; k < Q.re; k += 16) {
+        const int j = P.col[k];
+        if (tri_takes<KIND>(j, i, P.m)) acc += P.val[k] * P.z[j];
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+      if (gl == 0) tri_store<KIND>(P, i, acc, Q.e0, Q.e1);
+    }
+    for (int r0 = 64; r0 < n; r0 += 64) {                               // the rest of a level of more than 64 rows
       const int rr = r0 + grp;
       const bool live = rr < n;
       const int i = live ? P.rows[base + rr] : 0;
@@ -176,29 +245,20 @@ __global__ __launch_bounds__(1024) void k_tri_run(TriRun P) {
       if (live)
         for (int k = P.rowptr[i] + gl; k < P.rowptr[i + 1]; k += 16) {
           const int j = P.col[k];
-          if (KIND == 0 || KIND == 2) {
-            if (j < i) acc += P.val[k] * P.z[j];
-          } else {
-            if (j > i && j < P.m) acc += P.val[k] * P.z[j];
-          }
+          if (tri_takes<KIND>(j, i, P.m)) acc += P.val[k] * P.z[j];
         }
 #pragma unroll
       for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
       if (live && gl == 0) {
-        if (KIND == 0) {
-          const double ti = P.r[i] - acc;
-          P.t_out[i] = ti;
-          P.z[i] = P.dinv[i] * ti;
-        } else if (KIND == 1) {
-          P.z[i] = P.dinv[i] * (P.t_in[i] - acc);
-        } else if (KIND == 2) {
-          P.z[i] = P.r[i] - acc;
-        } else {
-          P.z[i] = (P.z[i] - acc) / P.val[P.diagpos[i]];
-        }
+        const double e0 = KIND == 1 ? P.t_in[i] : KIND == 3 ? P.z[i] : P.r[i];
+        const double e1 = (KIND == 0 || KIND == 1) ? P.dinv[i] : KIND == 3 ? P.val[P.diagpos[i]] : 1.0;
+        tri_store<KIND>(P, i, acc, e0, e1);
       }
     }
     __syncthreads();
+    Q = N;
+    base = base2;
+    nxt = nxt2;
   }
 }
 
