@@ -135,3 +135,18 @@ def test_setup_calls_read_the_device_copy(ctx, fe, box):
         assert np.array_equal(r0.to_numpy(), r1.to_numpy())
         for o in (as0, as1, A0, A1):
             o.destroy()
+
+
+@pytest.mark.parametrize("box", [(1, 1, 0), (1, 1, 1), (3, 2, 0)])
+def test_edge_cases_of_the_device_refinement(ctx, box):
+    """no element flagged (the new level is a copy, non-homogeneous), a single element, every element flagged through a flag array"""
+    for flags_of in (lambda m: np.zeros(m.nel, np.uint8), lambda m: np.ones(m.nel, np.uint8),
+                     lambda m: (np.arange(m.nel) % 2 == 0).astype(np.uint8)):
+        h, d = capi.Mesh.box(*box), capi.Mesh.box(*box)
+        fl = flags_of(h)
+        h2, d2 = h.refine_flagged(fl), d.refine_device(ctx, fl)
+        same_mesh(d2, h2)
+        assert np.array_equal(d.child_elems(), h.child_elems())
+        # and once more on top of it (elements of older levels are never split again)
+        fl2 = np.ones(h2.nel, np.uint8)
+        same_mesh(d2.refine_device(ctx, fl2), h2.refine_flagged(fl2))
