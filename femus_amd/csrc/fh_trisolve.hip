@@ -303,6 +303,9 @@ __device__ __forceinline__ void tri_group_sync() {      // LDS operations of one
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// LCOL: the columns of the row live in LDS beside its values (rows of up to 800 entries): the position search of every update -- seven dependent loads per
+// entry of row k -- then runs at LDS latency instead of cache latency (round 5: the factorisation is a chain of such searches, 120 us per level of 46 rows before)
+template <bool LCOL>
 __global__ __launch_bounds__(256) void k_ilu_factor(const int* __restrict__ rows, int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                     const int* __restrict__ diagpos, double* lu, int m, int maxrow, double zeropivot,
                                                     int* __restrict__ flag) {
@@ -310,33 +313,49 @@ __global__ __launch_bounds__(256) void k_ilu_factor(const int* __restrict__ rows
   const int rr = (blockIdx.x * 256 + threadIdx.x) >> 4, gl = threadIdx.x & 15;
   if (rr >= nrows) return;
   double* w = tri_rows + (size_t)(threadIdx.x >> 4) * maxrow;
+  int* wc = reinterpret_cast<int*>(tri_rows + (size_t)16 * maxrow) + (size_t)(threadIdx.x >> 4) * maxrow;
   const int i = rows[rr];
   const int rs = rowptr[i], re = rowptr[i + 1];
-  for (int p = rs + gl; p < re; p += 16) w[p - rs] = lu[p];
+  for (int p = rs + gl; p < re; p += 16) {
+    w[p - rs] = lu[p];
+    if (LCOL) wc[p - rs] = col[p];
+  }
   tri_group_sync();
+  // what step p + 1 needs of its pivot row k' (final since an earlier launch: its diagonal position, u_k'k', its end, the lane's first entry right of the
+  // diagonal) is loaded while step p updates the row -- the chain diagpos[k] -> lu[dk] -> col / lu[q] is otherwise paid once per lower entry
+  int k = rs < re ? (LCOL ? wc[0] : col[rs]) : i;
+  int dk = k < i ? diagpos[k] : 0, ke = k < i ? rowptr[k + 1] : 0;
+  double ukk = k < i ? lu[dk] : 1.0;
+  int jq = (k < i && dk + 1 + gl < ke) ? col[dk + 1 + gl] : -1;
+  double uq = (k < i && dk + 1 + gl < ke) ? lu[dk + 1 + gl] : 0.0;
   for (int p = rs; p < re; p++) {
-    const int k = col[p];
     if (k >= i) break;
-    const int dk = diagpos[k];
-    const double lik = w[p - rs] / lu[dk];          // row k is final: it was factored by an earlier launch (lower level)
+    const int k2 = p + 1 < re ? (LCOL ? wc[p + 1 - rs] : col[p + 1]) : i;
+    const int dk2 = k2 < i ? diagpos[k2] : 0, ke2 = k2 < i ? rowptr[k2 + 1] : 0;
+    const double ukk2 = k2 < i ? lu[dk2] : 1.0;
+    const int jq2 = (k2 < i && dk2 + 1 + gl < ke2) ? col[dk2 + 1 + gl] : -1;
+    const double uq2 = (k2 < i && dk2 + 1 + gl < ke2) ? lu[dk2 + 1 + gl] : 0.0;
+    const double lik = w[p - rs] / ukk;             // row k is final: it was factored by an earlier launch (lower level)
     tri_group_sync();
     if (gl == 0) w[p - rs] = lik;
-    const int ke = rowptr[k + 1];
     for (int q = dk + 1 + gl; q < ke; q += 16) {
-      const int j = col[q];
+      const bool first = q == dk + 1 + gl;
+      const int j = first ? jq : col[q];
+      const double u = first ? uq : lu[q];
       if (j >= m) continue;                         // ghost column: not part of the local block
       int lo = p + 1, hi = re - 1;
       while (lo <= hi) {
         const int mid = lo + ((hi - lo) >> 1);   // (lo + hi) overflows beyond 2^30 non-zeros
-        const int cc = col[mid];
+        const int cc = LCOL ? wc[mid - rs] : col[mid];
         if (cc == j) {
-          w[mid - rs] -= lik * lu[q];                // distinct j per lane: distinct slots
+          w[mid - rs] -= lik * u;                    // distinct j per lane: distinct slots
           break;
         }
         if (cc < j) lo = mid + 1; else hi = mid - 1;
       }
     }
     tri_group_sync();
+    k = k2; dk = dk2; ke = ke2; ukk = ukk2; jq = jq2; uq = uq2;
   }
   for (int p = rs + gl; p < re; p += 16) lu[p] = w[p - rs];
   if (gl == 0) {
@@ -362,8 +381,11 @@ int fh_tri_ilu_factor(fh_tri_t T, fh_mat_t A) {
   // the row being eliminated lives in LDS, sixteen rows per workgroup: 128 bytes per entry of the longest row.  512 entries fit the 64 kB a kernel gets
   // without asking; up to 1 200 (stacked three-dimensional systems after a Galerkin product) the kernel asks for more of the CU's 160 kB
   FH_REQUIRE(maxrow <= 1200, "ILU(0): a row with %d entries (at most 1200 are served)", maxrow);
-  const size_t lds = (size_t)16 * maxrow * sizeof(double);
-  if (lds > 64 * 1024) FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ilu_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const bool lcol = maxrow <= 800;
+  const size_t lds = (size_t)16 * maxrow * (sizeof(double) + (lcol ? sizeof(int) : 0));
+  if (lds > 64 * 1024)
+    FH_CHECK_HIP(hipFuncSetAttribute(lcol ? reinterpret_cast<const void*>(&k_ilu_factor<true>) : reinterpret_cast<const void*>(&k_ilu_factor<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   double shift = 0.0;
   for (int attempt = 0; attempt < 40; attempt++) {
     FH_CHECK_HIP(hipMemcpyAsync(T->d_lu, A->d_val, (size_t)A->nnz * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -371,8 +393,12 @@ int fh_tri_ilu_factor(fh_tri_t T, fh_mat_t A) {
     FH_CHECK_HIP(hipMemsetAsync(T->d_flag, 0, sizeof(int), c->stream));
     for (int l = 0; l < nf; l++) {
       const int n = T->fptr[l + 1] - T->fptr[l];
-      hipLaunchKernelGGL(k_ilu_factor, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), lds, c->stream, T->d_frows + T->fptr[l], n, A->d_rowptr,
-                         A->d_col, T->d_diagpos, T->d_lu, A->m, maxrow, 1e-16, T->d_flag);
+      if (lcol)
+        hipLaunchKernelGGL(k_ilu_factor<true>, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), lds, c->stream, T->d_frows + T->fptr[l], n, A->d_rowptr,
+                           A->d_col, T->d_diagpos, T->d_lu, A->m, maxrow, 1e-16, T->d_flag);
+      else
+        hipLaunchKernelGGL(k_ilu_factor<false>, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), lds, c->stream, T->d_frows + T->fptr[l], n, A->d_rowptr,
+                           A->d_col, T->d_diagpos, T->d_lu, A->m, maxrow, 1e-16, T->d_flag);
     }
     FH_CHECK_HIP(hipGetLastError());
     int h = 0;
