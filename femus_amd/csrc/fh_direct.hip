@@ -1390,7 +1390,9 @@ extern "C" int fh_direct_factor(fh_direct_t d) {
 }
 
 // internal: identifies the device buffers and launch shapes a captured solve refers to (fh_mg.hip's cycle signature)
-uint64_t fh_direct_generation(fh_direct_t d) { return d ? d->generation : 0; }
+// The number of refinement steps is part of the launch sequence of a solve and is set by every NUMERIC factorisation (a later Jacobian of the same
+// pattern may perturb a pivot where the captured one did not, or the other way round): it is part of the identity a captured cycle compares.
+uint64_t fh_direct_generation(fh_direct_t d) { return d ? (d->generation << 3) | (uint64_t)(d->refine & 7) : 0; }
 extern "C" int fh_direct_stats(fh_direct_t d, int* general_fronts, int* perturbed_pivots, int* refinement_steps) {
   FH_REQUIRE(d, "fh_direct_stats: null argument");
   if (general_fronts) *general_fronts = d->general ? 1 : 0;
