@@ -8,7 +8,7 @@ import numpy as np
 from ._lib import load_library
 
 GEOM = {"hex": 0, "quad": 1}
-FE = {"linear": 0, "biquadratic": 2, "pwlinear": 4}        # 4: DISCONTINUOUS_POLYNOMIAL FIRST (system dof maps and prolongators only)
+FE = {"linear": 0, "serendipity": 1, "biquadratic": 2, "constant": 3, "pwlinear": 4}        # 4: DISCONTINUOUS_POLYNOMIAL FIRST (system dof maps and prolongators only)
 GAUSS_ORDER = {"zero": 0, "first": 0, "second": 1, "third": 1, "fourth": 2, "fifth": 2,
                "sixth": 3, "seventh": 3, "eighth": 4, "ninth": 4}
 OUTER = {"preonly": 0, "richardson": 1, "gmres": 2, "cg": 3, "fgmres": 4}
@@ -660,7 +660,8 @@ class Mesh:
         return out
 
     def n_dofs(self, fe):
-        return self.own_size[0] if fe == "linear" else self.nnode
+        """Mesh::GetSolutionDof on one process: the linear / serendipity families own the leading vertex / vertex + edge node ids, the piecewise constant one the elements"""
+        return {"linear": self.own_size[0], "serendipity": self.own_size[1], "biquadratic": self.nnode, "constant": self.nel}[fe]
 
     def dirichlet_dofs(self, fe):
         n = ctypes.c_int(self.nnode)
@@ -883,7 +884,10 @@ class Assembler:
         a, n, r = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         pe = ctypes.c_int64()
         _chk(self.L.fh_assembler_fused_info(self.h, ctypes.byref(a), ctypes.byref(n), ctypes.byref(pe), ctypes.byref(r)))
-        return {"active": bool(a.value), "clusters": n.value, "partial_entries": pe.value, "second_pass_rows": r.value}
+        cs, ce = ctypes.c_int(), ctypes.c_int64()
+        _chk(self.L.fh_assembler_carry_info(self.h, ctypes.byref(cs), ctypes.byref(ce)))
+        return {"active": bool(a.value), "clusters": n.value, "partial_entries": pe.value, "second_pass_rows": r.value,
+                "clusters_per_super": cs.value, "carried_entries": ce.value}
 
     def assemble_expr(self, A, res, sol, expr, scale=1.0):
         """source term f = scale * expr(x, y, z, t), evaluated on the device at the Gauss points"""

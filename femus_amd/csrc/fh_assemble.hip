@@ -62,6 +62,9 @@ struct fh_assembler_s {
   bool rows_used_since = false;  // the element-wise Galerkin product asked for the element rows since the last assembly: the next assembly keeps them (two-pass)
   int last_path = 0;             // 1: the last assembly ran the fused path, 2: two-pass
   int cl_ncl = 0, cl_nm = 0, cl_ns = 0, cl_nprow = 0;
+  int cl_sup_shift = 0;          // log2 of the clusters per super-cluster whose inner rows are carried in the CSR array (0: none)
+  int cl_walk_shift = 0;         // log2 of the consecutive clusters a workgroup of the cluster kernel serves one after the other (= cl_sup_shift; measurements: assemble_carry 100 + k walks 2^k clusters with nothing carried)
+  size_t cl_ncarried = 0;        // CSR entries of carried rows
   size_t cl_npart = 0;           // entries of the partial-row buffer (without the sink)
   unsigned* d_cl_sinfo = nullptr;
   void *d_cl_dtab = nullptr, *d_cl_fblk = nullptr, *d_cl_oblk = nullptr;      // descriptor tables of the template (see ClParams)
@@ -69,6 +72,7 @@ struct fh_assembler_s {
   unsigned long long* d_cl_vdst64 = nullptr;           // ... as addresses, for the value array cl_val_base
   double* cl_val_base = nullptr;
   unsigned char *d_cl_map = nullptr, *d_cl_pmap = nullptr;
+  unsigned char* d_cl_mapb = nullptr;       // carried plans: destination positions of the slots (k_cluster_maps)
   unsigned short* d_cl_gtab = nullptr;      // [8][27 * 27] template entry that child j OWNS at (local row, local column), 0xffff = another child's (fh_assembler_galerkin from the macro rows)
   bool cl_all_rows = false;                 // every row of every cluster lies in the matrix (no ghost rows, no sink): the macro rows can be read back
   bool macro_valid = false;                 // the matrix cl_val_base and the partial-row buffer hold the macro rows of the last assembly
@@ -612,6 +616,7 @@ static int launch_rows(fh_assembler_t as, fh_mat_t A, double* res, bool build) {
 static int dispatch_rows(fh_assembler_t as, fh_mat_t A, double* res, bool build) {
   switch (as->nc) {
     case 27: return launch_rows<27>(as, A, res, build);
+    case 20: return launch_rows<20>(as, A, res, build);
     case 9: return launch_rows<9>(as, A, res, build);
     case 8: return launch_rows<8>(as, A, res, build);
     case 4: return launch_rows<4>(as, A, res, build);
@@ -1878,14 +1883,16 @@ static_assert((CL_TAB % 2) == 0 && (CL_UVS % 2) == 0, "cluster kernel: 16-byte a
 
 struct ClParams {
   int ncl, ns, nm;
+  int sup_shift;               // CARRY kernels: log2 of the clusters per super-cluster (a workgroup walks whole super-clusters, ascending cluster order)
   const uint2* dtab;           // [ns] descriptor of template entry off[r] + j: x = LDS byte address of the first contribution, y = address of the second (or of
                                //      the zero cell); an entry with more than two contributions: x = address of its long-sum cell, y = zero cell
   const uint4* fblk;           // [128] residual entry of macro row r: eight 16-bit double indices (zero cell for absent contributions)
   const uint4* oblk;           // [CL_NBLK] ALL contributions of long entry k (its sum goes to cell CL_LV + k), same format
   const unsigned* sinfo;       // [CL_SPT][CL_T]: r | p << 7 | off[r] << 14 of slot tid + CL_T * i
   const unsigned long long* vdst;   // [ncl][128] address of the row's first entry (CSR array or partial-row buffer)
-  const int* fdst;             // [ncl][128] >= 0: row of the residual vector, bit 31: offset into the partial-row buffer
-  const uint4* map;            // [ncl][CL_T]: byte i = template entry of slot tid + CL_T * i inside its row
+  const int* fdst;             // [ncl][128] >= 0: row of the residual vector (bit 30: carried row an earlier cluster stored to -- add), bit 31: offset into the partial-row buffer
+  const uint4* map;            // [ncl][CL_T]: byte i = template entry of slot tid + CL_T * i inside its row; bits 16 + i of word 2: carried entry to add to (k_cluster_maps)
+  const uint4* mapb;           // CARRY kernels: [ncl][CL_T] byte i = position of the slot in its destination row
   double* Pbuf;
   double* res;
   unsigned long long* stamps;  // instrumented build only (asm_debug bit 7): [workgroup][wave][16] summed phase cycles + [15] = clusters done
@@ -1902,7 +1909,12 @@ __device__ __forceinline__ double cl_sum8(const char* S, const uint4 a, double t
   return t;
 }
 
-template <int SRC, bool INS = false, bool ROT = true>
+// CARRY: the workgroup walks super-clusters (1 << C.sup_shift consecutive clusters, one after the other); a row whose elements all lie in the super-cluster is
+// accumulated in the CSR array itself -- the first cluster that holds an entry stores it, the later ones load, add and store (same workgroup, a barrier in
+// between; ascending cluster order = the order of the second pass, so the bits are the ones the partial-row buffer gives) -- and only the rows on the surface
+// of the super-cluster go through the partial-row buffer.  (Measured and dropped: the add as a floating-point atomic without return, global_atomic_add_f64 --
+// same bits, no round trip for the wave, but 17 M of them per assembly took 1.2 ms.)
+template <int SRC, bool INS = false, bool ROT = true, bool CARRY = false>
 __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab tab, const double* __restrict__ lanec, const int* __restrict__ lanei, ClParams C) {
   constexpr int NC = 27, DIM = 3, KS = MF_KS, NW = CL_NE;
   constexpr bool REGC = true;
@@ -1957,9 +1969,16 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
 #define CL_IDXA() SfIdxA{(int)(pk2 & 63u), (int)((pk2 >> 6) & 63u), (int)((pk2 >> 12) & 63u), (int)((pk2 >> 18) & 63u), (int)(pk2 >> 24)}
   const int nodeofl = (int)((pk0 >> 24) & 31u);
   const int cstride = gridDim.x;
-  int cl = blockIdx.x;
-  if (cl >= C.ncl) return;
-  const int lastc = C.ncl - 1;
+  // iteration `it` of this workgroup serves cluster ((blockIdx.x + (it >> sh) * gridDim.x) << sh) + (it & ((1 << sh) - 1)); sh = 0 without CARRY
+  const int sh = CARRY ? C.sup_shift : 0;
+  const int nsup = C.ncl >> sh;
+  if ((int)blockIdx.x >= nsup) return;
+  const int nit = ((nsup - 1 - (int)blockIdx.x) / cstride + 1) << sh;
+  auto cl_at = [&](int it) {
+    it = min(it, nit - 1);
+    return ((((int)blockIdx.x + (it >> sh) * cstride)) << sh) + (it & ((1 << sh) - 1));
+  };
+  int cl = cl_at(0);
   {
     const int dof = P.elem_dof[(size_t)(cl * NW + wave) * P.nloc + nodeofl];
     if (lane < NC) {
@@ -1969,7 +1988,7 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
       xt[84 + lane] = P.sol ? P.sol[dof] : 0.0;
     }
   }
-  int dof_n = P.elem_dof[(size_t)(min(cl + cstride, lastc) * NW + wave) * P.nloc + nodeofl];
+  int dof_n = P.elem_dof[(size_t)(cl_at(1) * NW + wave) * P.nloc + nodeofl];
   wave_lds_sync();
   SfStamps st;
   if (INS) {
@@ -1984,7 +2003,8 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
     wave_lds_sync();
   }
 #pragma unroll 1
-  for (; cl < C.ncl; cl += cstride) {
+  for (int it = 0; it < nit; it++) {
+    cl = cl_at(it);
     sf_stamp<INS>(st, 0);
     CL_OPAQUE(pk0);
     CL_OPAQUE(pk1);
@@ -1992,7 +2012,7 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
     const int esym = (int)(pk0 & 255u), ens = (int)((pk0 >> 8) & 255u), ensT = (int)((pk0 >> 16) & 255u);
     const int eout = (lane >> 4) * SF_ES + (lane & 15);
     // ---- prefetch (dependent gathers): coordinates / solution of the wave's next element, node ids of the one after ----
-    const int cl_nn = min(cl + 2 * cstride, lastc);
+    const int cl_nn = cl_at(it + 2);
     const double nx0 = P.coords[(size_t)dof_n * DIM], nx1 = P.coords[(size_t)dof_n * DIM + 1], nx2 = P.coords[(size_t)dof_n * DIM + 2];
     const double nu = P.sol ? P.sol[dof_n] : 0.0;
     const int dof_nn = P.elem_dof[(size_t)(cl_nn * NW + wave) * P.nloc + nodeofl];
@@ -2010,6 +2030,9 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
     const unsigned long long vd_cur = C.vdst[(size_t)cl * CL_NM_MAX + tm];
     const int fd_cur = C.fdst[(size_t)cl * CL_NM_MAX + tm];
     const uint4 mp_cur = C.map[(size_t)cl * CL_T + tid];
+    // CARRY: positions of the slots in their rows; residual destination of the row this lane sums in the output phase (wave * 16 + lane % 16)
+    const uint4 mq_cur = CARRY ? C.mapb[(size_t)cl * CL_T + tid] : make_uint4(0u, 0u, 0u, 0u);
+    const int fv_own = CARRY ? C.fdst[(size_t)cl * CL_NM_MAX + wave * 16 + (lane & 15)] : 0;
     unsigned sinfo[CL_SPT];
 #pragma unroll
     for (int i = 0; i < CL_SPT; i++) sinfo[i] = C.sinfo[i * CL_T + tid];
@@ -2057,6 +2080,8 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
     // the address block of this lane's sum of eight in the output phase (a table: read ahead of the barrier, one LDS round trip less behind it)
     const int frow = wave * 16 + (lane & 15);
     uint4 sumblk = (lane & 16) ? oblk[frow] : fblk[frow];
+    // CARRY: the residual entry of a carried row that an earlier cluster of the super-cluster stored (same workgroup, a barrier ago): on its way before the barrier
+    typedef __attribute__((address_space(1))) double cl_gdouble;      // global address space: a generic (flat) access would also count as an LDS operation
     if (ahead) {              // phase A of the wave's NEXT element (its nodes are in xt now; behind the last cluster: the clamped element again, unused)
       wave_lds_sync();
       sf_phase_a<SRC, REGC, INS>(P, LCl, CL_IDXA(), rcA, xt, UVa, Dr, &st);
@@ -2065,24 +2090,44 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
     sf_stamp<INS>(st, 9);
     if (!(P.debug & 2)) {
       const unsigned mw[4] = {mp_cur.x, mp_cur.y, mp_cur.z, mp_cur.w};
+      const unsigned mq[4] = {mq_cur.x, mq_cur.y, mq_cur.z, mq_cur.w};
+      // CARRY: the residual entry of a carried row that an earlier cluster of the super-cluster stored (same workgroup, a barrier ago); consumed behind the stores
+      double fold = 0.0;
+      if (CARRY && lane < 16 && fv_own >= 0 && (fv_own & 0x40000000))
+        fold = __hip_atomic_load((const cl_gdouble*)(C.res + (size_t)(fv_own & 0x3fffffff)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // in stages, every stage's LDS reads independent of each other (two waves per SIMD hide little latency): descriptors and row destinations; the
       // residual entries and the 49 entries with four or eight contributions (one sum of eight per lane, lanes 0 .. 15 / 16 .. 31 of every wave; the long
       // sums go to their cells); a second barrier; both operands of every entry (the zero cell for entries of one element, the cell for a long one); stores.
       uint2 dd[CL_SPT];
-      unsigned long long vb[CL_SPT];
+      unsigned long long vb[CL_SPT];       // destination of the slot (address of the row, plus the position)
+      double accv[CARRY ? CL_SPT : 1];     // CARRY: what the earlier clusters of the super-cluster left at a carried entry
 #pragma unroll
       for (int i = 0; i < CL_SPT; i++) {
         const unsigned si = sinfo[i];
         const int j = (mw[i >> 2] >> (8 * (i & 3))) & 255;
+        const int p = (si >> 7) & 127;
+        const int pos = CARRY ? (int)((mq[i >> 2] >> (8 * (i & 3))) & 255) : p;
         dd[i] = dtab[(si >> 14) + j];
-        vb[i] = rb[si & 127];
+        vb[i] = rb[si & 127] + (unsigned long long)(pos * 8);
       }
+      if (CARRY) {      // (issuing these ahead of the descriptor reads was measured: the loads cost 0.05 instead of 0.07 ms, the rest of the phase 0.02 more; skipping the
+                        // block by a wave-uniform test of the flags: 0.96 -> 1.45 ms, the ten values then live in scratch)
+#pragma unroll
+        for (int i = 0; i < CL_SPT; i++) {
+          accv[i] = 0.0;
+          if (((mw[2] >> (16 + i)) & 1u) && !(P.debug & 512)) accv[i] = __hip_atomic_load((const cl_gdouble*)vb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (bit 9: timing aid, WRONG values)
+        }
+      }
+      double fsum;
+      int fvv;
       {
         const double v = cl_sum8(Sb, sumblk, 0.0);
-        const int fv = fb[frow];
-        double* dst = fv < 0 ? C.Pbuf + (size_t)(fv & 0x7fffffff) : C.res + (size_t)fv;
-        if (lane < 16) *dst = v;
-        else if (lane < 32) sf_smem[CL_LV + frow] = v;
+        const int fv = CARRY ? fv_own : fb[frow];
+        double* dst = fv < 0 ? C.Pbuf + (size_t)(fv & 0x7fffffff) : C.res + (size_t)(CARRY ? (fv & 0x3fffffff) : fv);
+        if (!CARRY) { if (lane < 16) *dst = v; }       // CARRY: stored behind the second barrier (waiting for `fold` here would wait for the carried entries too)
+        if (lane >= 16 && lane < 32) sf_smem[CL_LV + frow] = v;
+        fsum = v;
+        fvv = fv;
       }
       if (INS) {
         asm volatile("" ::"v"(dd[CL_SPT - 1].x), "v"(vb[CL_SPT - 1]));
@@ -2098,16 +2143,24 @@ __global__ __launch_bounds__(CL_T) void k_cluster_q2hex_sf(AsmParams P, SfTab ta
       }
 #pragma unroll
       for (int i = 0; i < CL_SPT; i++) vv[i] += ww[i];
+      if (CARRY) {
+#pragma unroll
+        for (int i = 0; i < CL_SPT; i++) vv[i] = accv[i] + vv[i];      // (earlier clusters, or 0) + this cluster: the second pass's order
+      }
       if (INS) {
         asm volatile("" ::"v"(vv[CL_SPT - 1]), "v"(vv[0]));
         sf_stamp<INS>(st, 13);
       }
 #pragma unroll
       for (int i = 0; i < CL_SPT; i++) {
-        double* dst = reinterpret_cast<double*>(vb[i]) + ((sinfo[i] >> 7) & 127);
+        cl_gdouble* dst = (cl_gdouble*)vb[i];
         if (P.debug & 64) *dst = vv[i];                  // bit 6: plain stores (comparison)
         else if (!(P.debug & 4)) __builtin_nontemporal_store(vv[i], dst);
         else if (vv[i] == 1.2345e300) *dst = vv[i];      // timing aid (bit 2): the LDS work without the stores
+      }
+      if (CARRY && lane < 16) {
+        cl_gdouble* dst = (cl_gdouble*)(fvv < 0 ? C.Pbuf + (size_t)(fvv & 0x7fffffff) : C.res + (size_t)(fvv & 0x3fffffff));
+        *dst = (fvv >= 0 && (fvv & 0x40000000)) ? fold + fsum : fsum;
       }
       sf_stamp<INS>(st, 15);
     }
@@ -2194,48 +2247,99 @@ __global__ __launch_bounds__(256) void k_rows_partial(int nprow, const int* __re
   }
 }
 
-// Plan construction on the device: the byte maps of one cluster per workgroup.  Complete rows: for CSR position p the template entry whose
-// macro column carries the global column there; partial rows: identity in the cluster kernel's map, and in pmap the CSR position of every
-// packed entry.  An entry that cannot be placed raises err (the assembler then keeps the two-pass path).
+// Plan construction on the device: the map words of one cluster per workgroup; a thread writes the 16-byte words of one thread of the cluster kernel.
+// Slot i of a thread (slot tid + CL_T * i = macro row r, position p) computes template entry `e` of the row and stores it at position `q` of the row's destination:
+//   complete row: e = the entry whose macro column carries the global column at CSR position p, q = p (the row is written in CSR order)
+//   carried row:  e = p, q = the CSR position of that entry's column (stored, or added to what the earlier clusters of the super-cluster left there)
+//   partial row:  e = q = p (packed row in the partial-row buffer; pmap gets the CSR position for the second pass)
+//   map  (always):        bytes 0 .. 9 = e of slot i; bits 16 + i of word 2: carried entry that an EARLIER cluster has stored already (load, add, store)
+//   mapb (carried plans): bytes 0 .. 9 = q of slot i; bits 16 + i of word 2: carried entry to which a LATER cluster still adds (the Galerkin product reads an
+//                         entry in the cluster that made the last contribution)
+// An entry that cannot be placed raises err (the assembler then keeps the two-pass path).  first_cnt[g] counts the first contributions to carried row g: the
+// caller checks that they cover the whole CSR row (a position nobody stores to would keep stale values).
 __global__ __launch_bounds__(256) void k_cluster_maps(int ncl, int ns, int nm, const int* __restrict__ cdof, const unsigned* __restrict__ sinfo, const unsigned short* __restrict__ roff,
                                                       const unsigned char* __restrict__ tcol, const int* __restrict__ vdst, int m, const int* __restrict__ rowptr, const int* __restrict__ col,
-                                                      unsigned char* __restrict__ map, unsigned char* __restrict__ pmap, int* __restrict__ err) {
+                                                      const unsigned char* __restrict__ rowcls, const int* __restrict__ aptr, const int* __restrict__ aei,
+                                                      const int* __restrict__ elem_dof, int nloc, uint4* __restrict__ map, uint4* __restrict__ mapb, unsigned char* __restrict__ pmap,
+                                                      unsigned* __restrict__ first_cnt, int* __restrict__ err) {
   __shared__ int cd[CL_NM_MAX];
   const int c = blockIdx.x;
   if (threadIdx.x < CL_NM_MAX) cd[threadIdx.x] = threadIdx.x < nm ? cdof[(size_t)c * CL_NM_MAX + threadIdx.x] : -1;
   __syncthreads();
-  for (int s = threadIdx.x; s < CL_NS_MAX; s += 256) {
-    const size_t mi = ((size_t)c * CL_T + (s % CL_T)) * 16 + s / CL_T;
-    const unsigned si = sinfo[s];          // slot s = tid + CL_T * i sits at [i][tid]
-    const int r = si & 127, p = (si >> 7) & 127, o = si >> 14;
-    if (r >= nm) { map[mi] = 0; continue; }
-    const int len = roff[r + 1] - o;
-    const int vb = vdst[(size_t)c * CL_NM_MAX + r];
-    if (vb >= 0) {                       // complete row: CSR position p holds global column h
-      const int h = col[vb + p];
-      int j = -1;
-      for (int jj = 0; jj < len; jj++)
-        if (cd[tcol[o + jj]] == h) j = jj;
-      if (j < 0) { atomicExch(err, 1); j = 0; }
-      map[mi] = (unsigned char)j;
-    } else {
-      map[mi] = (unsigned char)p;
-      const int g = cd[r];
-      if (g < m) {                       // partial row of the matrix: where does packed entry p go in CSR row g
-        const int target = cd[tcol[o + p]];
-        const int rs = rowptr[g];
-        int lo = rs, hi = rowptr[g + 1] - 1, pos = -1;
-        while (lo <= hi) {
-          const int mid = lo + ((hi - lo) >> 1);
-          const int cc = col[mid];
-          if (cc == target) { pos = mid - rs; break; }
-          if (cc < target) lo = mid + 1; else hi = mid - 1;
-        }
-        if (pos < 0 || pos > 127) { atomicExch(err, 1); pos = 0; }
-        pmap[(size_t)(vb & 0x7fffffff) + p] = (unsigned char)pos;
-      }
+  auto find_pos = [&](int g, int target) {       // position of column `target` in CSR row g, -1 if absent
+    const int rs = rowptr[g];
+    int lo = rs, hi = rowptr[g + 1] - 1;
+    while (lo <= hi) {
+      const int mid = lo + ((hi - lo) >> 1);
+      const int cc = col[mid];
+      if (cc == target) return mid - rs;
+      if (cc < target) lo = mid + 1; else hi = mid - 1;
     }
+    return -1;
+  };
+  for (int tid = threadIdx.x; tid < CL_T; tid += 256) {
+    unsigned w[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
+    for (int i = 0; i < CL_SPT; i++) {
+      const unsigned si = sinfo[i * CL_T + tid];
+      const int r = si & 127, p = (si >> 7) & 127, o = si >> 14;
+      unsigned byte = (unsigned)p, pos_b = (unsigned)p, cls = 0, acc = 0, last = 1;
+      if (r < nm) {
+        const int len = roff[r + 1] - o;
+        const int vb = vdst[(size_t)c * CL_NM_MAX + r];
+        if (vb >= 0) {
+          const int g = cd[r];
+          cls = rowcls[g];
+          if (cls != 2) {                    // complete row: CSR position p holds global column h
+            cls = 1;
+            const int h = col[vb + p];
+            int j = -1;
+            for (int jj = 0; jj < len; jj++)
+              if (cd[tcol[o + jj]] == h) j = jj;
+            if (j < 0) { atomicExch(err, 1); j = 0; }
+            byte = (unsigned)j;
+          } else {                           // carried row: entry p goes to (is added at) the CSR position of its column
+            const int target = cd[tcol[o + p]];
+            int pos = find_pos(g, target);
+            if (pos < 0 || pos > 127) { atomicExch(err, 1); pos = 0; }
+            pos_b = (unsigned)pos;
+            bool later = false;
+            for (int a = aptr[g]; a < aptr[g + 1]; a++) {     // the other clusters around node g: does one of their elements hold `target` too?
+              const int e = aei[a] >> 5, cc = e / CL_NE;
+              if (cc == c) continue;
+              bool has = false;
+              for (int n = 0; n < 27; n++) has = has || elem_dof[(size_t)e * nloc + n] == target;
+              if (has) { if (cc < c) acc = 1; else later = true; }
+            }
+            last = later ? 0u : 1u;
+            if (!acc) atomicAdd(&first_cnt[g], 1u);
+          }
+        } else {
+          byte = (unsigned)p;
+          const int g = cd[r];
+          if (g < m) {                       // partial row of the matrix: where does packed entry p go in CSR row g
+            int pos = find_pos(g, cd[tcol[o + p]]);
+            if (pos < 0 || pos > 127) { atomicExch(err, 1); pos = 0; }
+            pmap[(size_t)(vb & 0x7fffffff) + p] = (unsigned char)pos;
+          }
+        }
+      }
+      w[i >> 2] |= byte << (8 * (i & 3));
+      wb[i >> 2] |= pos_b << (8 * (i & 3));
+      w[2] |= acc << (16 + i);
+      wb[2] |= (last ? 0u : 1u) << (16 + i);
+    }
+    map[(size_t)c * CL_T + tid] = make_uint4(w[0], w[1], w[2], w[3]);
+    if (mapb) mapb[(size_t)c * CL_T + tid] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
   }
+}
+// every position of a carried CSR row must receive exactly one first contribution
+__global__ __launch_bounds__(256) void k_cl_cover(int m, const int* __restrict__ rowptr, const unsigned char* __restrict__ rowcls, const unsigned* __restrict__ first_cnt,
+                                                  int* __restrict__ err, unsigned long long* __restrict__ ncarried) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= m || rowcls[g] != 2) return;
+  const unsigned len = (unsigned)(rowptr[g + 1] - rowptr[g]);
+  if (first_cnt[g] != len) atomicExch(err, 1);
+  atomicAdd(ncarried, (unsigned long long)len);
 }
 
 
@@ -2263,18 +2367,22 @@ __global__ __launch_bounds__(128) void k_cl_cdof(int ncl, int nloc, const int* _
       if (cd[j] == cd[k]) atomicExch(err, 2);          // two macro nodes, one mesh node
   cdof[(size_t)c * CL_NM_MAX + k] = cd[k];
 }
-// a macro row is complete when all elements around its node lie in this cluster and the CSR row has exactly its columns; the others add their
+// a macro row is complete (class 1) when all elements around its node lie in this cluster and the CSR row has exactly its columns; carried (class 2) when
+// they all lie in this cluster's super-cluster (the clusters c >> sup_shift: one workgroup walks them in ascending order); the others add their
 // packed length (+ the residual entry) to the segment of their CSR row
-__global__ __launch_bounds__(256) void k_cl_rows(int ncl, int m, const int* __restrict__ cdof, const int* __restrict__ aptr, const int* __restrict__ rowptr, ClTmpl T,
-                                                 unsigned char* __restrict__ complete, unsigned* __restrict__ rowsz) {
+__global__ __launch_bounds__(256) void k_cl_rows(int ncl, int m, const int* __restrict__ cdof, const int* __restrict__ aptr, const int* __restrict__ aei, const int* __restrict__ rowptr,
+                                                 ClTmpl T, int sup_shift, unsigned char* __restrict__ complete, unsigned* __restrict__ rowsz) {
   const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (q >= (size_t)ncl * CL_NM_MAX) return;
-  const int r = (int)(q & (CL_NM_MAX - 1));
+  const int c = (int)(q / CL_NM_MAX), r = (int)(q & (CL_NM_MAX - 1));
   if (r >= T.nm) return;
   const int g = cdof[q];
   if (g >= m) return;
   const int len = T.roff[r + 1] - T.roff[r];
-  if (aptr[g + 1] - aptr[g] == T.tcnt[r] && rowptr[g + 1] - rowptr[g] == len) complete[g] = 1;
+  if (aptr[g + 1] - aptr[g] == T.tcnt[r] && rowptr[g + 1] - rowptr[g] == len) { complete[g] = 1; return; }
+  bool carried = sup_shift > 0;
+  for (int a = aptr[g]; a < aptr[g + 1] && carried; a++) carried = (((aei[a] >> 5) / CL_NE) >> sup_shift) == (c >> sup_shift);
+  if (carried) complete[g] = 2;          // (every cluster around g arrives at the same answer)
   else atomicAdd(&rowsz[g], (unsigned)len + 1u);
 }
 // destinations: complete rows point into the CSR arrays; a partial row sits in the segment of its CSR row behind the partial rows of the clusters
@@ -2291,9 +2399,9 @@ __global__ __launch_bounds__(256) void k_cl_dst(int ncl, int m, const int* __res
     fdst[q] = (int)sink;
     return;
   }
-  if (complete[g]) {
+  if (complete[g]) {       // complete or carried: the CSR row itself; bit 30 of the residual destination: an earlier cluster has stored there already (add)
     vdst[q] = rowptr[g];
-    fdst[q] = g;
+    fdst[q] = g | ((complete[g] == 2 && ((aei[aptr[g]] >> 5) / CL_NE) < c) ? 0x40000000 : 0);
     return;
   }
   unsigned off = rowbase[g];
@@ -2314,7 +2422,7 @@ __global__ __launch_bounds__(256) void k_cl_dst(int ncl, int m, const int* __res
 // Plan of the fused cluster assembly (see k_cluster_q2hex_sf).  Host: template from cluster 0, verification of every cluster, completeness of
 // every (cluster, macro row), offsets of the partial rows, the lists of the second pass -- O(nel * 27) integer work; device: the byte maps.
 // Returns 0 and leaves as->fused false when the mesh does not offer the structure.
-static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof, const std::vector<int>& aptr) {
+static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof, const std::vector<int>& aptr, bool allow_carry = true) {
   fh_ctx_t ctx = as->ctx;
   const int nel = as->nel, nloc = as->nloc, m = A->m, KS = MF_KS;
   int nodeof[27];                        // node of tensor index a*9 + b*3 + c (the staging's row / column order)
@@ -2469,7 +2577,26 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
   FH_CHECK_HIP(hipMemsetAsync(d_complete, 0, (size_t)m, ctx->stream));
   FH_CHECK_HIP(hipMemsetAsync(d_rowsz, 0, (size_t)m * sizeof(unsigned), ctx->stream));
   const unsigned gq = (unsigned)(((size_t)ncl * CL_NM_MAX + 255) / 256);
-  hipLaunchKernelGGL(k_cl_rows, dim3(gq), dim3(256), 0, ctx->stream, ncl, m, d_cdof, as->d_adj_ptr, A->d_rowptr, T, d_complete, d_rowsz);
+  // super-clusters (assemble_carry): 8^k consecutive clusters = the descendants of one ancestor k levels up in a refined mesh.  Rows all of whose elements lie in
+  // one super-cluster never visit the partial-row buffer.  Automatic choice: the largest k <= 2 that still gives every workgroup of the persistent grid two
+  // super-clusters (a workgroup walks a super-cluster alone, in ascending cluster order).  Nothing about the topology is assumed: the classes come from the
+  // adjacency lists; a mesh whose consecutive clusters are not neighbours simply has few carried rows.
+  int sup_shift = 0;
+  {
+    const int want = ctx->assemble_carry;
+    const int wgs = std::max(1, ctx->num_cu * ctx->assemble_sf_grid);
+    if (want < 0) {
+      for (int sh : {6, 3})
+        if (sup_shift == 0 && ncl % (1 << sh) == 0 && (ncl >> sh) >= 2 * wgs) sup_shift = sh;
+    } else if (want > 0) {
+      sup_shift = std::min(want % 100, 12);
+      while (sup_shift > 0 && ncl % (1 << sup_shift)) sup_shift--;
+    }
+    as->cl_walk_shift = sup_shift;
+    if (want >= 100) sup_shift = 0;               // measurement aid: the walk order of the carried plan, nothing carried
+    if (m >= (1 << 30) || !allow_carry) sup_shift = 0;          // bit 30 of a residual destination marks "add"
+  }
+  hipLaunchKernelGGL(k_cl_rows, dim3(gq), dim3(256), 0, ctx->stream, ncl, m, d_cdof, as->d_adj_ptr, as->d_adj_ei, A->d_rowptr, T, sup_shift, d_complete, d_rowsz);
   std::vector<unsigned char> complete(m, 0);
   std::vector<unsigned> rowsz(m, 0);
   if (m) {
@@ -2528,6 +2655,7 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
   FH_TRY(up((void**)&as->d_cl_prow, prow.data(), prow.size() * 4));
   FH_TRY(up((void**)&as->d_cl_pstart, pstart.data(), pstart.size() * 4));
   FH_CHECK_HIP(hipMalloc(&as->d_cl_map, (size_t)ncl * CL_T * 16));
+  if (sup_shift > 0 || ctx->assemble_carry >= 200) FH_CHECK_HIP(hipMalloc(&as->d_cl_mapb, (size_t)ncl * CL_T * 16));
   FH_CHECK_HIP(hipMalloc(&as->d_cl_pmap, npart + 128));
   FH_CHECK_HIP(hipMemset(as->d_cl_pmap, 0xFF, npart + 128));      // 255 = residual entry (the map kernel fills in the matrix entries)
   FH_CHECK_HIP(hipMalloc(&as->d_Pbuf, (npart + 128) * sizeof(double)));
@@ -2537,17 +2665,38 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
     int* d_err = nullptr;
     unsigned char* d_tcol = nullptr;
     unsigned short* d_roff = nullptr;
+    unsigned* d_first = nullptr;
+    unsigned long long* d_ncar = nullptr;
     FH_TRY(up((void**)&d_tcol, tcol.data(), tcol.size()));
     FH_TRY(up((void**)&d_roff, roff.data(), roff.size() * 2));
     const int zero = 0;
     FH_TRY(up((void**)&d_err, &zero, sizeof(int)));
-    hipLaunchKernelGGL(k_cluster_maps, dim3(ncl), dim3(256), 0, ctx->stream, ncl, ns, nm, d_cdof, as->d_cl_sinfo, d_roff, d_tcol, as->d_cl_vdst, m, A->d_rowptr, A->d_col, as->d_cl_map,
-                       as->d_cl_pmap, d_err);
+    FH_TRY(dalloc((void**)&d_first, (size_t)m * sizeof(unsigned)));
+    FH_TRY(dalloc((void**)&d_ncar, sizeof(unsigned long long)));
+    FH_CHECK_HIP(hipMemsetAsync(d_first, 0, (size_t)m * sizeof(unsigned), ctx->stream));
+    FH_CHECK_HIP(hipMemsetAsync(d_ncar, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k_cluster_maps, dim3(ncl), dim3(256), 0, ctx->stream, ncl, ns, nm, d_cdof, as->d_cl_sinfo, d_roff, d_tcol, as->d_cl_vdst, m, A->d_rowptr, A->d_col, d_complete,
+                       as->d_adj_ptr, as->d_adj_ei, as->d_elem_dof, nloc, reinterpret_cast<uint4*>(as->d_cl_map), reinterpret_cast<uint4*>(as->d_cl_mapb), as->d_cl_pmap, d_first, d_err);
+    if (sup_shift > 0 && m > 0)
+      hipLaunchKernelGGL(k_cl_cover, dim3(fh_div_up(m, 256)), dim3(256), 0, ctx->stream, m, A->d_rowptr, d_complete, d_first, d_err, d_ncar);
     FH_CHECK_HIP(hipGetLastError());
     int err = 0;
+    unsigned long long ncar = 0;
     FH_CHECK_HIP(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    FH_CHECK_HIP(hipMemcpyAsync(&ncar, d_ncar, sizeof(ncar), hipMemcpyDeviceToHost, ctx->stream));
     FH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    as->cl_ncarried = (size_t)ncar;
     for (void* q : {(void*)d_tcol, (void*)d_roff, (void*)d_err}) hipFree(q);
+    if (err && sup_shift > 0) {
+      // (a pattern with positions no element contributes to: a carried row would keep stale values there) -- the plan without carried rows
+      FH_TRACE("fh_assembler_create: carried rows do not cover their CSR rows -- cluster plan without them");
+      for (void** q : {(void**)&as->d_cl_dtab, (void**)&as->d_cl_fblk, (void**)&as->d_cl_sinfo, (void**)&as->d_cl_oblk, (void**)&as->d_cl_gtab, (void**)&as->d_cl_vdst, (void**)&as->d_cl_vdst64,
+                       (void**)&as->d_cl_fdst, (void**)&as->d_cl_map, (void**)&as->d_cl_mapb, (void**)&as->d_cl_pmap, (void**)&as->d_Pbuf, (void**)&as->d_cl_prow, (void**)&as->d_cl_pstart}) {
+        if (*q) FH_CHECK_HIP(hipFree(*q));
+        *q = nullptr;
+      }
+      return cluster_plan_build(as, A, elem_dof, aptr, false);
+    }
     if (err) {
       FH_TRACE("fh_assembler_create: cluster maps could not be placed in the matrix pattern -- two-pass assembly kept");
       return 0;
@@ -2558,26 +2707,30 @@ static int cluster_plan_build(fh_assembler_t as, fh_mat_t A, const int* elem_dof
   as->cl_ns = ns;
   as->cl_npart = npart;
   as->cl_nprow = (int)prow.size();
+  as->cl_sup_shift = sup_shift;
+  if (sup_shift > 0 || ctx->assemble_carry < 100) as->cl_walk_shift = sup_shift;
   as->fused = true;
-  FH_TRACE("fh_assembler_create: cluster plan (%d clusters, %d macro nodes, %d entries; %zu partial entries, %d rows in the second pass)", ncl, nm, ns, npart, as->cl_nprow);
+  FH_TRACE("fh_assembler_create: cluster plan (%d clusters, %d macro nodes, %d entries; super-clusters of %d: %zu carried entries; %zu partial entries, %d rows in the second pass)", ncl,
+           nm, ns, 1 << sup_shift, as->cl_ncarried, npart, as->cl_nprow);
   return 0;
 }
 
 // Instrumented launch (asm_debug bit 7, constant source only): the same kernel with the shader clock read at twelve phase boundaries; prints the
 // average cycles per cluster and phase over all waves.  A development aid -- the stamps cost about a tenth of the wave cycles themselves.
+template <bool CARRY>
 static int launch_cluster_stamped(fh_assembler_t as, const AsmParams& P, const ClParams& C0, int grid) {
   constexpr size_t lds = cl_lds_bytes();
   static bool attr_set[64] = {};
   const int dev = as->ctx->device & 63;
   if (!attr_set[dev]) {
-    FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster_q2hex_sf<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster_q2hex_sf<0, true, true, CARRY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set[dev] = true;
   }
   ClParams C = C0;
   const size_t nst = (size_t)grid * CL_NE * 20;
   FH_CHECK_HIP(hipMalloc(&C.stamps, nst * sizeof(unsigned long long)));
   FH_CHECK_HIP(hipMemsetAsync(C.stamps, 0, nst * sizeof(unsigned long long), as->ctx->stream));
-  hipLaunchKernelGGL((k_cluster_q2hex_sf<0, true>), dim3(grid), dim3(CL_T), lds, as->ctx->stream, P, as->sf_tab, as->d_sfLc, as->d_sfLi, C);
+  hipLaunchKernelGGL((k_cluster_q2hex_sf<0, true, true, CARRY>), dim3(grid), dim3(CL_T), lds, as->ctx->stream, P, as->sf_tab, as->d_sfLc, as->d_sfLi, C);
   FH_CHECK_HIP(hipGetLastError());
   std::vector<unsigned long long> h(nst);
   FH_CHECK_HIP(hipMemcpyAsync(h.data(), C.stamps, nst * sizeof(unsigned long long), hipMemcpyDeviceToHost, as->ctx->stream));
@@ -2608,18 +2761,18 @@ static int launch_cluster_stamped(fh_assembler_t as, const AsmParams& P, const C
   return 0;
 }
 
-template <int SRC>
+template <int SRC, bool CARRY>
 static int launch_cluster_one(fh_assembler_t as, const AsmParams& P, const ClParams& C) {
   constexpr size_t lds = cl_lds_bytes();
   static bool attr_set[64] = {};
   const int dev = as->ctx->device & 63;
   if (!attr_set[dev]) {
-    FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster_q2hex_sf<SRC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster_q2hex_sf<SRC, false, true, CARRY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set[dev] = true;
   }
-  const int grid = std::max(1, std::min(C.ncl, as->ctx->num_cu * as->ctx->assemble_sf_grid));
-  if (SRC == 0 && (as->ctx->asm_debug & 128)) return launch_cluster_stamped(as, P, C, grid);     // dev aid: phase cycles of every wave on stderr
-  hipLaunchKernelGGL((k_cluster_q2hex_sf<SRC>), dim3(grid), dim3(CL_T), lds, as->ctx->stream, P, as->sf_tab, as->d_sfLc, as->d_sfLi, C);
+  const int grid = std::max(1, std::min(C.ncl >> (CARRY ? C.sup_shift : 0), as->ctx->num_cu * as->ctx->assemble_sf_grid));
+  if (SRC == 0 && (as->ctx->asm_debug & 128)) return launch_cluster_stamped<CARRY>(as, P, C, grid);     // dev aid: phase cycles of every wave on stderr
+  hipLaunchKernelGGL((k_cluster_q2hex_sf<SRC, false, true, CARRY>), dim3(grid), dim3(CL_T), lds, as->ctx->stream, P, as->sf_tab, as->d_sfLc, as->d_sfLi, C);
   FH_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -2643,12 +2796,17 @@ static int launch_cluster(fh_assembler_t as, const AsmParams& P, fh_mat_t A, dou
   C.ncl = as->cl_ncl; C.ns = as->cl_ns; C.nm = as->cl_nm;
   C.dtab = reinterpret_cast<const uint2*>(as->d_cl_dtab); C.fblk = reinterpret_cast<const uint4*>(as->d_cl_fblk); C.oblk = reinterpret_cast<const uint4*>(as->d_cl_oblk);
   C.sinfo = as->d_cl_sinfo;
-  C.vdst = as->d_cl_vdst64; C.fdst = as->d_cl_fdst; C.map = reinterpret_cast<const uint4*>(as->d_cl_map);
+  C.vdst = as->d_cl_vdst64; C.fdst = as->d_cl_fdst; C.map = reinterpret_cast<const uint4*>(as->d_cl_map); C.mapb = reinterpret_cast<const uint4*>(as->d_cl_mapb);
   C.Pbuf = as->d_Pbuf; C.res = res;
   C.stamps = nullptr;
-  if (P.source_kind == 4) FH_TRY(launch_cluster_one<2>(as, P, C));
-  else if (P.source_kind != 0) FH_TRY(launch_cluster_one<1>(as, P, C));
-  else FH_TRY(launch_cluster_one<0>(as, P, C));
+  C.sup_shift = as->cl_walk_shift;
+  if (as->cl_sup_shift > 0 || (as->ctx->assemble_carry >= 200 && as->d_cl_mapb)) {      // (>= 200: measurement aid, the CARRY kernel on a plan without carried rows)
+    if (P.source_kind == 4) FH_TRY((launch_cluster_one<2, true>(as, P, C)));
+    else if (P.source_kind != 0) FH_TRY((launch_cluster_one<1, true>(as, P, C)));
+    else FH_TRY((launch_cluster_one<0, true>(as, P, C)));
+  } else if (P.source_kind == 4) FH_TRY((launch_cluster_one<2, false>(as, P, C)));
+  else if (P.source_kind != 0) FH_TRY((launch_cluster_one<1, false>(as, P, C)));
+  else FH_TRY((launch_cluster_one<0, false>(as, P, C)));
   if (as->cl_nprow > 0 && !(as->ctx->asm_debug & (2 | 8))) {
     // plain loads of the partial rows: a segment starts at any multiple of 8 bytes, so neighbouring segments share cache lines -- non-temporal
     // loads fetched those twice (measured 1.36 -> 1.33 ms per assembly; asm_debug bit 5 selects them for comparison)
@@ -2814,6 +2972,8 @@ static int dispatch_assemble(fh_assembler_t as, const AsmParams& P) {
     return 0;
   }
   if (as->dim == 3 && as->nc == 27) return launch_assemble<3, 27>(as, P);
+  if (as->dim == 3 && as->nc == 20) return launch_assemble<3, 20>(as, P);      // serendipity (HexQuadratic / QuadQuadratic): the generic tile kernel
+  if (as->dim == 2 && as->nc == 8) return launch_assemble<2, 8>(as, P);
   if (as->dim == 3 && as->nc == 8) return launch_assemble<3, 8>(as, P);
   if (as->dim == 2 && as->nc == 9) return launch_assemble<2, 9>(as, P);
   if (as->dim == 2 && as->nc == 4) return launch_assemble<2, 4>(as, P);
@@ -2980,7 +3140,7 @@ static int assembler_create_impl(fh_ctx_t ctx, int geom, int fe, int order, int 
   FH_GUARD_BEGIN
   FH_REQUIRE(ctx && elem_dof && coords && A && out, "fh_assembler_create: null argument");
   FH_REQUIRE(geom == 0 || geom == 1, "fh_assembler_create: geom must be 0 (hex) or 1 (quad)");
-  FH_REQUIRE(fe == 0 || fe == 2, "fh_assembler_create: fe must be 0 (linear) or 2 (biquadratic)");
+  FH_REQUIRE(fe == 0 || fe == 1 || fe == 2, "fh_assembler_create: fe must be 0 (linear), 1 (serendipity) or 2 (biquadratic)");
   FH_REQUIRE(nloc == fhfe::nloc_of(geom), "fh_assembler_create: nloc %d does not match the geometry (%d)", nloc, fhfe::nloc_of(geom));
   fh_assembler_t as = new fh_assembler_s();
   as->ctx = ctx;
@@ -3319,7 +3479,7 @@ extern "C" int fh_assembler_destroy(fh_assembler_t as) {
   if (as->d_prog) hipFree(as->d_prog);
   if (as->d_prog_consts) hipFree(as->d_prog_consts);
   hipFree(as->d_iota);
-  for (void* q : {(void*)as->d_cl_dtab, (void*)as->d_cl_fblk, (void*)as->d_cl_sinfo, (void*)as->d_cl_oblk, (void*)as->d_cl_gtab, (void*)as->d_cl_vdst, (void*)as->d_cl_vdst64, (void*)as->d_cl_fdst, (void*)as->d_cl_map, (void*)as->d_cl_pmap,
+  for (void* q : {(void*)as->d_cl_dtab, (void*)as->d_cl_fblk, (void*)as->d_cl_sinfo, (void*)as->d_cl_oblk, (void*)as->d_cl_gtab, (void*)as->d_cl_vdst, (void*)as->d_cl_vdst64, (void*)as->d_cl_fdst, (void*)as->d_cl_map, (void*)as->d_cl_mapb, (void*)as->d_cl_pmap,
                   (void*)as->d_Pbuf, (void*)as->d_cl_prow, (void*)as->d_cl_pstart})
     if (q) hipFree(q);
   for (void* q : {(void*)as->d_adj_ptr, (void*)as->d_adj_ei, (void*)as->d_rowmap, (void*)as->d_Kbuf, (void*)as->d_Fbuf, (void*)as->d_slot, (void*)as->d_gal_child,
@@ -3531,6 +3691,14 @@ extern "C" int fh_assembler_fused_info(fh_assembler_t as, int* active, int* nclu
   if (nclusters) *nclusters = as->fused ? as->cl_ncl : 0;
   if (partial_entries) *partial_entries = as->fused ? (int64_t)as->cl_npart : 0;
   if (second_pass_rows) *second_pass_rows = as->fused ? as->cl_nprow : 0;
+  return 0;
+}
+
+extern "C" int fh_assembler_carry_info(fh_assembler_t as, int* clusters_per_super, int64_t* carried_entries) {
+  FH_REQUIRE(as, "fh_assembler_carry_info: null argument");
+  const bool on = as->fused && as->ctx->assemble_fused && as->ctx->assemble_sf;
+  if (clusters_per_super) *clusters_per_super = on ? 1 << as->cl_sup_shift : 0;
+  if (carried_entries) *carried_entries = on ? (int64_t)as->cl_ncarried : 0;
   return 0;
 }
 
@@ -3826,7 +3994,7 @@ __global__ __launch_bounds__(256) void k_gal_masks(int nelc, const int* __restri
 
 template <bool INS>
 __global__ __launch_bounds__(GMAC_T) void k_galerkin_macro(int nelc, const int* __restrict__ child, int nm, const unsigned* __restrict__ sinfo, const uint4* __restrict__ map,
-                                                           const unsigned long long* __restrict__ vdst, const unsigned short* __restrict__ gtab,
+                                                           const uint4* __restrict__ mapb /* carried plans, else null */, const unsigned long long* __restrict__ vdst, const unsigned short* __restrict__ gtab,
                                                            const unsigned* __restrict__ fmask, const unsigned* __restrict__ cmask,
                                                            const int* __restrict__ slot_c, double* __restrict__ Kc, int ks_c, const double* __restrict__ Cdense /* [8][27][27] */,
                                                            unsigned long long* __restrict__ stamps) {
@@ -3868,15 +4036,28 @@ __global__ __launch_bounds__(GMAC_T) void k_galerkin_macro(int nelc, const int* 
   uint4 mp = map[(size_t)cl * CL_T + tid];
   __syncthreads();
   double tv[CL_SPT];
+  // where slot i of a cluster's macro matrix is read: position p of the row (complete / partial rows), or -- a row carried in the CSR array across the clusters of a
+  // super-cluster -- the CSR position the map byte names, and only in the cluster that made the LAST contribution (the entry holds the sum of all of them there;
+  // the pseudo child matrices still add up to the assembled matrix, which is all the coarse operator depends on); -1: nothing to read
+  auto slot_pos = [&](const uint4& q4, int i) {
+    const unsigned mq[4] = {q4.x, q4.y, q4.z, q4.w};
+    const int r = si[i] & 127, p = (si[i] >> 7) & 127;
+    if (r >= nm) return -1;
+    if (!mapb) return p;
+    return ((mq[2] >> (16 + i)) & 1u) ? -1 : (int)((mq[i >> 2] >> (8 * (i & 3))) & 255);
+  };
+  const uint4 qzero = make_uint4(0u, 0u, 0u, 0u);
+  uint4 mq = mapb ? mapb[(size_t)cl * CL_T + tid] : qzero;
 #pragma unroll
   for (int i = 0; i < CL_SPT; i++) {
-    const int r = si[i] & 127, p = (si[i] >> 7) & 127;
-    tv[i] = r < nm ? reinterpret_cast<const double*>(rbl[r])[p] : 0.0;
+    const int r = si[i] & 127, pos = slot_pos(mq, i);
+    tv[i] = pos >= 0 ? reinterpret_cast<const double*>(rbl[r])[pos] : 0.0;
   }
   int En = min(E + stride, nelc - 1);
   int cln = child[(size_t)En * NCH] >> 3;
   unsigned long long vdn = vdst[(size_t)cln * CL_NM_MAX + tm];
   uint4 mpn = map[(size_t)cln * CL_T + tid];
+  uint4 mqn = mapb ? mapb[(size_t)cln * CL_T + tid] : qzero;
   const int ln = min(lane, NC - 1);
   unsigned dmask = fmask[(size_t)E * NCH + wave], cdm = cmask[E];      // Dirichlet nodes of this wave's child / of the coarse element (k_gal_masks)
   int slc = slot_c[(size_t)E * NC + ln];
@@ -3901,16 +4082,18 @@ __global__ __launch_bounds__(GMAC_T) void k_galerkin_macro(int nelc, const int* 
     sf_stamp<INS>(st, 2);
     // the NEXT cluster's values: in flight during the products below
     mp = mpn;
+    mq = mqn;
 #pragma unroll
     for (int i = 0; i < CL_SPT; i++) {
-      const int r = si[i] & 127, p = (si[i] >> 7) & 127;
-      tv[i] = r < nm ? reinterpret_cast<const double*>(rbl[r])[p] : 0.0;
+      const int r = si[i] & 127, pos = slot_pos(mq, i);
+      tv[i] = pos >= 0 ? reinterpret_cast<const double*>(rbl[r])[pos] : 0.0;
     }
     {
       const int Enn = min(E + 2 * stride, nelc - 1);
       const int clnn = child[(size_t)Enn * NCH] >> 3;
       vdn = vdst[(size_t)clnn * CL_NM_MAX + tm];
       mpn = map[(size_t)clnn * CL_T + tid];
+      if (mapb) mqn = mapb[(size_t)clnn * CL_T + tid];
     }
     const unsigned long long cdead = cdm, dead = dmask;
     {   // the next element's masks and slots (consumed one iteration later)
@@ -4124,7 +4307,7 @@ extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, con
       FH_CHECK_HIP(hipMalloc(&d_st, nst * sizeof(unsigned long long)));
       FH_CHECK_HIP(hipMemsetAsync(d_st, 0, nst * sizeof(unsigned long long), c->stream));
       hipLaunchKernelGGL(k_galerkin_macro<true>, dim3(gm_grid), dim3(GMAC_T), gmac_lds_bytes(), c->stream, cas->nel, cas->d_gal_child, fas->cl_nm, fas->d_cl_sinfo,
-                         reinterpret_cast<const uint4*>(fas->d_cl_map), fas->d_cl_vdst64, fas->d_cl_gtab, cas->d_gal_fmask, cas->d_gal_fmask + (size_t)cas->nel * 8, cas->d_slot, cas->d_Kbuf,
+                         reinterpret_cast<const uint4*>(fas->d_cl_map), reinterpret_cast<const uint4*>(fas->d_cl_mapb), fas->d_cl_vdst64, fas->d_cl_gtab, cas->d_gal_fmask, cas->d_gal_fmask + (size_t)cas->nel * 8, cas->d_slot, cas->d_Kbuf,
                          cas->kstride, cas->d_gal_dense, d_st);
       std::vector<unsigned long long> h(nst);
       FH_CHECK_HIP(hipMemcpyAsync(h.data(), d_st, nst * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -4142,7 +4325,7 @@ extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, con
       for (int k = 0; k < 10; k++) fprintf(stderr, "  %2d %-62s %9.1f  %5.1f %%\n", k, name[k], sum[k] / std::max(ncl, 1.0), 100.0 * sum[k] / std::max(tot, 1.0));
     } else
       hipLaunchKernelGGL(k_galerkin_macro<false>, dim3(gm_grid), dim3(GMAC_T), gmac_lds_bytes(), c->stream, cas->nel, cas->d_gal_child, fas->cl_nm, fas->d_cl_sinfo,
-                         reinterpret_cast<const uint4*>(fas->d_cl_map), fas->d_cl_vdst64, fas->d_cl_gtab, cas->d_gal_fmask, cas->d_gal_fmask + (size_t)cas->nel * 8, cas->d_slot, cas->d_Kbuf,
+                         reinterpret_cast<const uint4*>(fas->d_cl_map), reinterpret_cast<const uint4*>(fas->d_cl_mapb), fas->d_cl_vdst64, fas->d_cl_gtab, cas->d_gal_fmask, cas->d_gal_fmask + (size_t)cas->nel * 8, cas->d_slot, cas->d_Kbuf,
                          cas->kstride, cas->d_gal_dense, (unsigned long long*)nullptr);
   } else if (c->galerkin_mfma) {
     const size_t lds = nc == 27 ? galerkin_mfma_lds<27, 8>() : galerkin_mfma_lds<9, 4>();
@@ -4262,7 +4445,7 @@ extern "C" int fh_fe_jacobian(fh_ctx_t ctx, int geom, int fe, int order, int nel
   FH_GUARD_BEGIN
   FH_REQUIRE(ctx && (nel == 0 || (elem_dof && coords)), "fh_fe_jacobian: null argument");
   FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_jacobian: geom must be 0 (hex) or 1 (quad)");
-  FH_REQUIRE(fe == 0 || fe == 2, "fh_fe_jacobian: fe must be 0 (linear) or 2 (biquadratic)");
+  FH_REQUIRE(fe == 0 || fe == 1 || fe == 2, "fh_fe_jacobian: fe must be 0 (linear), 1 (serendipity) or 2 (biquadratic)");
   FH_REQUIRE(nloc == fhfe::nloc_of(geom), "fh_fe_jacobian: nloc %d does not match the geometry (%d)", nloc, fhfe::nloc_of(geom));
   if (nel == 0) return 0;
   const int dim = fhfe::dim_of(geom), nc = fhfe::ndofs_of(geom, fe), nh = dim == 2 ? 3 : 6;
@@ -4433,7 +4616,7 @@ extern "C" int fh_fe_face_normals(int geom, int fe, int order, int gauss_point, 
                                   double* normals /* [nfaces*dim] */) {
   FH_GUARD_BEGIN
   FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_face_normals: geom must be 0 (hex) or 1 (quad)");
-  FH_REQUIRE(fe == 0 || fe == 2, "fh_fe_face_normals: fe must be 0 or 2");
+  FH_REQUIRE(fe == 0 || fe == 1 || fe == 2, "fh_fe_face_normals: fe must be 0, 1 or 2");
   FH_REQUIRE(nfaces == 0 || (face_nodes && coords && normals), "fh_fe_face_normals: null argument");
   const int dim = fhfe::dim_of(geom);
   int nfn = 0;
@@ -4482,7 +4665,7 @@ static int neumann_faces(fh_ctx_t ctx, int geom, int fe, int order, int nfaces, 
                          const fh_expr_t* exprs, int nnode, const double* coords, fh_vec_t res, const int* comp_offset = nullptr, double scale = 1.0) {
   FH_REQUIRE(ctx && res && (nfaces == 0 || (face_nodes && (tau || face_expr) && coords)), "fh_assemble_neumann_faces: null argument");
   FH_REQUIRE(geom == 0 || geom == 1, "fh_assemble_neumann_faces: geom must be 0 (hex) or 1 (quad)");
-  FH_REQUIRE(fe == 0 || fe == 2, "fh_assemble_neumann_faces: fe must be 0 or 2");
+  FH_REQUIRE(fe == 0 || fe == 1 || fe == 2, "fh_assemble_neumann_faces: fe must be 0, 1 or 2");
   if (nfaces == 0) return 0;
   const int dim = fhfe::dim_of(geom);
   int nfn = 0;

@@ -3,7 +3,8 @@
 // once to the device by the assembler (fh_assemble.hip).
 //   Gauss    : src/02_reference_geom_elements/02_quadrature/quadrature_interface.cpp:36-94, 1d/quadrature_Line.cpp,
 //              2d/quadrature_Quadrangle.cpp, 3d/quadrature_Hexahedron.cpp (14-significant-digit literals)
-//   bases    : 01_fe/1d/Edge.hpp:72-104, 2d/Quadrilateral.cpp:68-110, 3d/Hexahedron.cpp:95-163
+//   bases    : 01_fe/1d/Edge.hpp:72-104, 2d/Quadrilateral.cpp:68-110, 3d/Hexahedron.cpp:95-163; serendipity (QuadQuadratic, Quadrilateral.cpp:113-161;
+//              HexQuadratic, Hexahedron.cpp:167-256) and piecewise constant (quad0 / hex0, Quadrilateral.hpp:173-, Hexahedron.hpp:196-)
 //   tables   : 03_fe_evaluations_at_quadrature/ElemType.cpp:576-741
 //   prolong. : 03_fe_evaluations_at_quadrature/ElemType.cpp:439-532
 #include "fh_fe.h"
@@ -28,7 +29,7 @@ int nloc_of(int geom) { return geom == GEOM_HEX ? 27 : 9; }
 int nvert_of(int geom) { return geom == GEOM_HEX ? 8 : 4; }
 int nedge_end_of(int geom) { return geom == GEOM_HEX ? 20 : 8; }
 int nfaces_of(int geom) { return geom == GEOM_HEX ? 6 : 4; }
-int ndofs_of(int geom, int fe) { return fe == FE_LINEAR ? nvert_of(geom) : nloc_of(geom); }
+int ndofs_of(int geom, int fe) { return fe == FE_LINEAR ? nvert_of(geom) : fe == FE_SERENDIPITY ? nedge_end_of(geom) : fe == FE_CONSTANT ? 1 : nloc_of(geom); }
 
 int xc(int geom, int node, int d) { return geom == GEOM_HEX ? XC_HEX[node][d] : XC_QUAD[node][d]; }
 
@@ -110,12 +111,91 @@ static inline double lagB(double x, int i) { return !i * 0.5 * x * (x - 1.) + !(
 static inline double dlagB(double x, int i) { return !i * (x - 0.5) + !(i - 1) * (-2. * x) + !(i - 2) * (x + 0.5); }
 
 static inline double d2lagB(int i) { return !i * 1.0 + !(i - 1) * (-2.0) + !(i - 2) * 1.0; }
+// "quadratic" 1-D factors of the serendipity families (Edge.hpp:81-91): linear at the end nodes, the bubble at the middle one
+static inline double lagQ(double x, int i) { return !i * (0.5) * (1. - x) + !(i - 1) * (1. - x) * (1. + x) + !(i - 2) * (0.5) * (1. + x); }
+static inline double dlagQ(double x, int i) { return (!i) * (-0.5) + !(i - 1) * (-2. * x) + !(i - 2) * (0.5); }
+static inline double d2lagQ(int i) { return !(i - 1) * (-2.); }
+
+// Serendipity bases, the expressions of QuadQuadratic / HexQuadratic term by term and in their order (the tables are compared bit for bit with the ones the
+// reference's compiled classes give): a vertex function is the product of the three (two) linear factors times (-2 + ix x + jx y + kx z) ((-1 + ...) in 2-D),
+// an edge function the plain product.  out: phi, d/dx, d/dy, d/dz, then xx, yy, zz, xy, yz, zx (2-D: phi, dx, dy, -, xx, yy, -, xy)
+static void serendipity_node(int geom, int j, const double* x, double out[10]) {
+  const int d = dim_of(geom);
+  int I[3] = {1, 1, 1};
+  for (int k = 0; k < d; k++) I[k] = xc(geom, j, k) + 1;
+  for (int k = 0; k < 10; k++) out[k] = 0.0;
+  if (d == 2) {
+    const double ix = I[0] - 1., jx = I[1] - 1.;
+    const double l0 = lagQ(x[0], I[0]), l1 = lagQ(x[1], I[1]), d0 = dlagQ(x[0], I[0]), d1 = dlagQ(x[1], I[1]), s0 = d2lagQ(I[0]), s1 = d2lagQ(I[1]);
+    if (fabs(ix * jx) == 0) {
+      out[0] = l0 * l1;
+      out[1] = d0 * l1;
+      out[2] = l0 * d1;
+      out[4] = s0 * l1;
+      out[5] = l0 * s1;
+      out[7] = d0 * d1;
+    } else {
+      const double s = -1. + ix * x[0] + jx * x[1];
+      out[0] = s * l0 * l1;
+      out[1] = l1 * (ix * l0 + s * d0);
+      out[2] = l0 * (jx * l1 + s * d1);
+      out[4] = l1 * (2. * ix * d0 + s * s0);
+      out[5] = l0 * (2. * jx * d1 + s * s1);
+      out[7] = ix * l0 * d1 + jx * l1 * d0 + s * d0 * d1;
+    }
+    return;
+  }
+  const double ix = I[0] - 1., jx = I[1] - 1., kx = I[2] - 1.;
+  const double l0 = lagQ(x[0], I[0]), l1 = lagQ(x[1], I[1]), l2 = lagQ(x[2], I[2]);
+  const double d0 = dlagQ(x[0], I[0]), d1 = dlagQ(x[1], I[1]), d2 = dlagQ(x[2], I[2]);
+  const double s0 = d2lagQ(I[0]), s1 = d2lagQ(I[1]), s2 = d2lagQ(I[2]);
+  if (fabs(ix * jx * kx) == 0) {
+    out[0] = l0 * l1 * l2;
+    out[1] = d0 * l1 * l2;
+    out[2] = l0 * d1 * l2;
+    out[3] = l0 * l1 * d2;
+    out[4] = s0 * l1 * l2;
+    out[5] = l0 * s1 * l2;
+    out[6] = l0 * l1 * s2;
+    out[7] = d0 * d1 * l2;
+    out[8] = l0 * d1 * d2;
+    out[9] = d0 * l1 * d2;
+  } else {
+    const double s = -2. + ix * x[0] + jx * x[1] + kx * x[2];
+    out[0] = s * l0 * l1 * l2;
+    out[1] = l1 * l2 * (ix * l0 + s * d0);
+    out[2] = l0 * l2 * (jx * l1 + s * d1);
+    out[3] = l0 * l1 * (kx * l2 + s * d2);
+    out[4] = l1 * l2 * (2. * ix * d0 + s * s0);
+    out[5] = l2 * l0 * (2. * jx * d1 + s * s1);
+    out[6] = l0 * l1 * (2. * kx * d2 + s * s2);
+    out[7] = l2 * (ix * l0 * d1 + jx * l1 * d0 + s * d0 * d1);
+    out[8] = l0 * (jx * l1 * d2 + kx * l2 * d1 + s * d1 * d2);
+    out[9] = l1 * (kx * l2 * d0 + ix * l0 * d2 + s * d2 * d0);
+  }
+}
 
 // second derivatives, node-major [nc][nh]: 3-D (xx, yy, zz, xy, yz, zx), 2-D (xx, yy, xy) -- the order of elem_type's _d2phidxi2, _d2phideta2,
 // _d2phidzeta2, _d2phidxideta, _d2phidetadzeta, _d2phidzetadxi (ElemType.cpp:637-741).  The pure second derivatives of the (bi/tri)linear
 // family are identically zero; the mixed ones are not.
 void eval_basis_d2(int geom, int fe, const double* pt, double* d2phi) {
   const int d = dim_of(geom), nc = ndofs_of(geom, fe);
+  if (fe == FE_CONSTANT) {
+    for (int k = 0; k < (d == 2 ? 3 : 6); k++) d2phi[k] = 0.0;
+    return;
+  }
+  if (fe == FE_SERENDIPITY) {
+    for (int j = 0; j < nc; j++) {
+      double v[10];
+      serendipity_node(geom, j, pt, v);
+      if (d == 2) {
+        d2phi[j * 3 + 0] = v[4]; d2phi[j * 3 + 1] = v[5]; d2phi[j * 3 + 2] = v[7];
+      } else {
+        for (int k = 0; k < 6; k++) d2phi[j * 6 + k] = v[4 + k];
+      }
+    }
+    return;
+  }
   for (int j = 0; j < nc; j++) {
     double l[3], dl[3], d2l[3];
     for (int k = 0; k < d; k++) {
@@ -141,6 +221,22 @@ void eval_basis_d2(int geom, int fe, const double* pt, double* d2phi) {
 
 void eval_basis(int geom, int fe, const double* pt, double* phi, double* dphi /* [nc*dim] node-major */) {
   const int d = dim_of(geom), nc = ndofs_of(geom, fe);
+  if (fe == FE_CONSTANT) {        // quad0 / hex0: the constant one
+    if (phi) phi[0] = 1.;
+    if (dphi)
+      for (int k = 0; k < d; k++) dphi[k] = 0.;
+    return;
+  }
+  if (fe == FE_SERENDIPITY) {
+    for (int j = 0; j < nc; j++) {
+      double v[10];
+      serendipity_node(geom, j, pt, v);
+      if (phi) phi[j] = v[0];
+      if (dphi)
+        for (int k = 0; k < d; k++) dphi[j * d + k] = v[1 + k];
+    }
+    return;
+  }
   for (int j = 0; j < nc; j++) {
     double l[3], dl[3];
     for (int k = 0; k < d; k++) {
@@ -217,8 +313,8 @@ int face_nodes(int geom, int fe, int face, int* out) {
     if (xc(geom, centre, k) != 0) d0 = k;
   const int sgn = xc(geom, centre, d0);
   const int fgeom = (geom == GEOM_HEX) ? GEOM_QUAD : GEOM_LINE;
-  const int nfn_q2 = (geom == GEOM_HEX) ? 9 : 3, nfn_q1 = (geom == GEOM_HEX) ? 4 : 2;
-  const int nfn = (fe == FE_LINEAR) ? nfn_q1 : nfn_q2;
+  const int nfn_q2 = (geom == GEOM_HEX) ? 9 : 3, nfn_q1 = (geom == GEOM_HEX) ? 4 : 2, nfn_ser = (geom == GEOM_HEX) ? 8 : 3;
+  const int nfn = (fe == FE_LINEAR) ? nfn_q1 : (fe == FE_SERENDIPITY) ? nfn_ser : (fe == FE_CONSTANT) ? 0 : nfn_q2;
   // free coordinates in cyclic order after d0, oriented so that the normal elem_type::JacobianSur derives from the node order (t_a x t_b on a
   // quadrilateral face, (t_y, -t_x) on an edge) points OUT of the element, as with the reference's own face tables (hex_lag / quad_lag faceDofs;
   // the sign matters to vector-valued boundary terms such as the pressure integral of 03_navier_stokes.hpp:185-290)
@@ -264,7 +360,7 @@ extern "C" int fh_fe_gauss(int geom, int order, int* ng, double* w, double* x) {
 
 extern "C" int fh_fe_tables(int geom, int fe, int order, int* ng, int* nc, double* phi, double* dphi) {
   FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_tables: geom must be 0 (hex) or 1 (quad)");
-  FH_REQUIRE(fe == 0 || fe == 2, "fh_fe_tables: fe must be 0 (linear) or 2 (biquadratic)");
+  FH_REQUIRE(fhfe::fe_known(fe), "fh_fe_tables: fe must be 0 (linear), 1 (serendipity), 2 (biquadratic) or 3 (piecewise constant)");
   FH_REQUIRE(order >= 0 && order <= 4, "fh_fe_tables: Gauss rule index %d not supported (0..4)", order);
   const int d = fhfe::dim_of(geom), n = fhfe::ndofs_of(geom, fe), g = fhfe::gauss_npoints(geom, order);
   if (ng) *ng = g;
@@ -283,7 +379,7 @@ extern "C" int fh_fe_tables(int geom, int fe, int order, int* ng, int* nc, doubl
 
 extern "C" int fh_fe_tables_d2(int geom, int fe, int order, double* d2phi) {
   FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_tables_d2: geom must be 0 (hex) or 1 (quad)");
-  FH_REQUIRE(fe == 0 || fe == 2, "fh_fe_tables_d2: fe must be 0 (linear) or 2 (biquadratic)");
+  FH_REQUIRE(fhfe::fe_known(fe), "fh_fe_tables_d2: fe must be 0 (linear), 1 (serendipity), 2 (biquadratic) or 3 (piecewise constant)");
   FH_REQUIRE(order >= 0 && order <= 4 && d2phi, "fh_fe_tables_d2: bad arguments");
   const int d = fhfe::dim_of(geom), n = fhfe::ndofs_of(geom, fe), g = fhfe::gauss_npoints(geom, order), nh = d == 2 ? 3 : 6;
   std::vector<double> w(g), x((size_t)g * d), t((size_t)n * nh);
@@ -300,7 +396,7 @@ extern "C" int fh_fe_tables_d2(int geom, int fe, int order, double* d2phi) {
 
 extern "C" int fh_fe_elem_prolongator(int geom, int fe, int* nchild, int* nc, double* P) {
   FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_elem_prolongator: geom must be 0 (hex) or 1 (quad)");
-  FH_REQUIRE(fe == 0 || fe == 2, "fh_fe_elem_prolongator: fe must be 0 (linear) or 2 (biquadratic)");
+  FH_REQUIRE(fhfe::fe_known(fe), "fh_fe_elem_prolongator: fe must be 0 (linear), 1 (serendipity), 2 (biquadratic) or 3 (piecewise constant)");
   if (nchild) *nchild = fhfe::nvert_of(geom);
   if (nc) *nc = fhfe::ndofs_of(geom, fe);
   if (P) {
@@ -321,7 +417,7 @@ extern "C" int fh_fe_node_ref(int geom, int node, int* xi) {
 
 extern "C" int fh_fe_face_nodes(int geom, int fe, int face, int* nfn, int* local_nodes) {
   FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_face_nodes: geom must be 0 (hex) or 1 (quad)");
-  FH_REQUIRE(fe == 0 || fe == 2, "fh_fe_face_nodes: fe must be 0 or 2");
+  FH_REQUIRE(fhfe::fe_known(fe), "fh_fe_face_nodes: fe must be 0 .. 3");
   FH_REQUIRE(face >= 0 && face < fhfe::nfaces_of(geom), "fh_fe_face_nodes: face %d out of range", face);
   int tmp[9];
   const int n = fhfe::face_nodes(geom, fe, face, tmp);

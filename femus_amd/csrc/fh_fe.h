@@ -4,7 +4,8 @@
 
 namespace fhfe {
 enum { GEOM_HEX = 0, GEOM_QUAD = 1, GEOM_LINE = 2 };
-enum { FE_LINEAR = 0, FE_BIQUADRATIC = 2 };
+enum { FE_LINEAR = 0, FE_SERENDIPITY = 1, FE_BIQUADRATIC = 2, FE_CONSTANT = 3 };      // FEFamily order of the reference (CONTINUOUS_LINEAR, _SERENDIPITY, _BIQUADRATIC, DISCONTINUOUS_CONSTANT; 4 = DISCONTINUOUS_LINEAR lives in fh_mesh.cpp / fh_ns.hip)
+inline bool fe_known(int fe) { return fe >= 0 && fe <= 3; }
 int dim_of(int geom);
 int nloc_of(int geom);        // biquadratic nodes per element (27 / 9)
 int nvert_of(int geom);       // 8 / 4 (= number of children)

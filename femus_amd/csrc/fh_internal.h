@@ -95,6 +95,9 @@ struct fh_ctx_s {
   int assemble_sym = 1;              // symmetric-tile HEX27/Q2 element kernel (2 elements per wave)
   int assemble_two_pass = 1;         // 1: element matrices + row gather (default), 0: coloured scatter
   int assemble_fused = 1;            // HEX27/Q2 meshes whose elements come in sibling groups of eight: fused cluster assembly (rows complete inside a group go straight to the CSR arrays)
+  int assemble_carry = -1;           // fused cluster assembly: rows whose elements all lie in one SUPER-cluster of 8^k consecutive clusters (k = value / 3) are accumulated in the CSR array
+                                     // itself by the one workgroup that walks the super-cluster (store / load-add-store, ascending cluster order), not through the partial-row buffer;
+                                     // -1 = 64 or 8 clusters where every workgroup gets at least two super-clusters, 0 = off, 3 / 6 = forced (read when an assembler is created)
   int assemble_affine = 0;           // opt-in: affine HEX27/Q2 elements through precomputed reference matrices instead of quadrature
   int gj_symmetric = 1;              // coarse dense inverse: symmetric sweep on the upper block triangle when the operator is symmetric
   int galerkin_mfma = 1;             // element-wise Galerkin product on the FP64 matrix cores (0: sparse child tables on the vector ALU)

@@ -268,16 +268,25 @@ extern "C" int fh_mat_create_from_elements(fh_ctx_t c, int nel, int nloc, const 
 int fh_mesh_host_arrays(fh_mesh_t m, int* dim, int* geom, int* nel, int* nnode, int* nloc, int* n_linear, const int** elem_dof, const double** coords);
 
 extern "C" int fh_mat_create_from_mesh(fh_ctx_t c, fh_mesh_t mesh, int fe, fh_mat_t* out) {
-  FH_REQUIRE(c && mesh && out && (fe == 0 || fe == 2), "fh_mat_create_from_mesh: bad arguments (fe: 0 linear, 2 biquadratic)");
+  FH_REQUIRE(c && mesh && out && fe >= 0 && fe <= 3, "fh_mat_create_from_mesh: bad arguments (fe: 0 linear, 1 serendipity, 2 biquadratic, 3 piecewise constant)");
   int dim, geom, nel, nnode, nloc, nlin;
   const int* ed;
   const double* xy;
   FH_TRY(fh_mesh_host_arrays(mesh, &dim, &geom, &nel, &nnode, &nloc, &nlin, &ed, &xy));
+  if (fe == 3) {       // element-owned dofs: every element couples with itself only
+    std::vector<int> iota(nel);
+    for (int e = 0; e < nel; e++) iota[e] = e;
+    return mat_create_from_elements_impl(c, nel, 1, iota.data(), nullptr, nel, nel, out);
+  }
   fh_mesh_dev* dev = nullptr;
   FH_TRY(fh_mesh_device(c, mesh, &dev));
   if (fe == 2) return mat_create_from_elements_impl(c, nel, nloc, nullptr, dev->d_elem_dof, nnode, nnode, out);
-  // linear: the vertices are the first 2^dim local nodes of every element -- a strided copy of the table
-  const int nv = 1 << dim;
+  // linear / serendipity: the family's nodes are the first 2^dim (4 / 8) resp. vertex + edge (8 / 20) local nodes of every element -- a strided copy of the
+  // table -- and own the leading node ids (Mesh::GetSolutionDof, Mesh.cpp:1026-1050)
+  int own[3] = {0, 0, 0};
+  FH_TRY(fh_mesh_info(mesh, nullptr, nullptr, nullptr, nullptr, own, nullptr));
+  const int nv = fe == 0 ? 1 << dim : (dim == 3 ? 20 : 8);
+  if (fe == 1) nlin = own[1];
   int* d_lin = nullptr;
   FH_CHECK_HIP(hipMalloc(&d_lin, std::max<size_t>((size_t)nel * nv, 1) * sizeof(int)));
   hipError_t e = nel ? hipMemcpy2DAsync(d_lin, nv * sizeof(int), dev->d_elem_dof, nloc * sizeof(int), nv * sizeof(int), nel, hipMemcpyDeviceToDevice, c->stream) : hipSuccess;

@@ -35,8 +35,8 @@ struct fh_mesh_s {
   std::shared_ptr<struct AmrRows> amr_cache[2];
   int amr_cache_mode[2] = {-1, -1};
   // Dirichlet node list per family ([fe == 2]) once computed: the boundary flags of a mesh change only through fh_mesh_clear_boundary_faces
-  mutable std::vector<int> dir_cache[2];
-  mutable bool dir_valid[2] = {false, false};
+  mutable std::vector<int> dir_cache[4];      // per FE family 0 .. 3
+  mutable bool dir_valid[4] = {false, false, false, false};
   // the same arrays in device memory (fh_mesh_refine_device, fh_mesh_device): dropped whenever a host array they mirror is rewritten
   fh_mesh_dev* dev = nullptr;
   ~fh_mesh_s() { fh_meshdev_free(dev); }
@@ -515,7 +515,7 @@ extern "C" int fh_mesh_clear_boundary_faces(fh_mesh_t m, unsigned face_mask) {
       if ((face_mask >> f) & 1u) m->face_flag[(size_t)iel * nf + f] = -1;
   m->amr_cache[0].reset();     // interface faces of the hanging-node search are the faces flagged -1: rows cached before are stale
   m->amr_cache[1].reset();
-  m->dir_valid[0] = m->dir_valid[1] = false;
+  for (bool& v : m->dir_valid) v = false;
   fh_meshdev_free(m->dev);
   m->dev = nullptr;
   return 0;
@@ -573,10 +573,17 @@ extern "C" int fh_mesh_child_elems(fh_mesh_t m, int* child) {
   return 0;
 }
 
-static int mesh_ndofs(const fh_mesh_s* m, int fe) { return fe == FE_LINEAR ? m->own[0] : m->nnode; }
+// dofs of a scalar variable of the family on this mesh (one process): Mesh::GetSolutionDof (Mesh.cpp:1021-1074) maps local node i of an element to the mesh node
+// for the three Lagrange families -- nodes are numbered vertices, edge mid-points, the rest, so the linear and the serendipity family own the leading
+// own[0] / own[1] ids (:1026-1050) -- and to the element for the piecewise constant one (:1056-1059)
+static int mesh_ndofs(const fh_mesh_s* m, int fe) { return fe == FE_LINEAR ? m->own[0] : fe == FE_SERENDIPITY ? m->own[1] : fe == FE_CONSTANT ? m->nel : m->nnode; }
 
 static void dirichlet_list(const fh_mesh_s* m, int fe, std::vector<int>& out) {
-  const int slot = fe == 2 ? 1 : 0;
+  const int slot = fe;
+  if (fe == FE_CONSTANT) {          // element-owned: no dof lies on a face
+    out.clear();
+    return;
+  }
   if (m->dir_valid[slot]) {
     out = m->dir_cache[slot];
     return;
@@ -602,7 +609,7 @@ static void dirichlet_list(const fh_mesh_s* m, int fe, std::vector<int>& out) {
 }
 
 extern "C" int fh_mesh_dirichlet_dofs(fh_mesh_t m, int fe, int* n, int* dofs) {
-  FH_REQUIRE(fe == 0 || fe == 2, "fh_mesh_dirichlet_dofs: fe must be 0 or 2");
+  FH_REQUIRE(fe_known(fe), "fh_mesh_dirichlet_dofs: fe must be 0 .. 3");
   std::vector<int> list;
   dirichlet_list(m, fe, list);
   FH_REQUIRE(*n >= (int)list.size(), "fh_mesh_dirichlet_dofs: capacity %d < %d", *n, (int)list.size());
@@ -697,13 +704,28 @@ static int build_prolongator_device(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t mf, in
 extern "C" int fh_build_prolongator(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t mf, int fe, int zero_bdc, fh_mat_t* out) {
   FH_GUARD_BEGIN
   FH_REQUIRE(ctx && mc && mf && out, "fh_build_prolongator: null argument");
-  FH_REQUIRE(fe == 0 || fe == 2, "fh_build_prolongator: fe must be 0 or 2");
+  FH_REQUIRE(fe_known(fe), "fh_build_prolongator: fe must be 0 (linear), 1 (serendipity), 2 (biquadratic) or 3 (piecewise constant)");
   const int geom = mc->geom, nl = mc->nloc, nc = ndofs_of(geom, fe), nch = nvert_of(geom);
   FH_REQUIRE(!mc->child.empty() && (int)mc->refined.size() == mc->nel, "fh_build_prolongator: fine is not the refinement of coarse");
   {
     int expect = 0;
     for (int iel = 0; iel < mc->nel; iel++) expect += mc->refined[iel] ? nch : 1;
     FH_REQUIRE(expect == mf->nel, "fh_build_prolongator: fine is not the refinement of coarse");
+  }
+  if (fe == FE_CONSTANT) {
+    // quad0 / hex0 (set_prolongation_OneElement_All_FE with the one function 1 at the centres of the children, ElemType.cpp:439-532): every child -- and an
+    // element carried over unrefined -- takes the value of its father
+    std::vector<int> rowptr(mf->nel + 1), col(mf->nel, -1);
+    std::vector<double> val(mf->nel, 1.0);
+    for (int r = 0; r <= mf->nel; r++) rowptr[r] = r;
+    for (int iel = 0; iel < mc->nel; iel++)
+      for (int j = 0; j < (mc->refined[iel] ? nch : 1); j++) {
+        const int jel = mc->child[(size_t)iel * nch + j];
+        FH_REQUIRE(jel >= 0 && jel < mf->nel, "fh_build_prolongator: child element %d out of range", jel);
+        col[jel] = iel;
+      }
+    for (int jel = 0; jel < mf->nel; jel++) FH_REQUIRE(col[jel] >= 0, "fh_build_prolongator: fine element %d has no father", jel);
+    return fh_mat_create_csr(ctx, mf->nel, mc->nel, rowptr.data(), col.data(), val.data(), out);
   }
   if (ctx->device_setup) return build_prolongator_device(ctx, mc, mf, fe, zero_bdc, out);
   const int nf = mesh_ndofs(mf, fe), ncc = mesh_ndofs(mc, fe);
@@ -1193,7 +1215,7 @@ extern "C" int fh_build_amr_prolongator(fh_ctx_t ctx, fh_mesh_t m, int fe, fh_ma
 static int check_vars(const char* who, int nvars, const int* fe, bool with_pw = false) {
   FH_REQUIRE(nvars >= 1 && nvars <= 8 && fe, "%s: 1..8 variables expected", who);
   for (int k = 0; k < nvars; k++)
-    FH_REQUIRE(fe[k] == 0 || fe[k] == 2 || (with_pw && fe[k] == 4), "%s: variable %d: fe must be 0 or 2%s", who, k, with_pw ? " (or 4, discontinuous linear)" : "");
+    FH_REQUIRE(fe_known(fe[k]) || (with_pw && fe[k] == 4), "%s: variable %d: fe must be 0 .. 3%s", who, k, with_pw ? " (or 4, discontinuous linear)" : "");
   return 0;
 }
 static int var_elem_dofs(const fh_mesh_s* m, int fe) { return fe == 4 ? m->dim + 1 : ndofs_of(m->geom, fe); }
@@ -1219,7 +1241,7 @@ extern "C" int fh_system_elem_dofs(fh_mesh_t m, int nvars, const int* fe, int* n
       int p = 0;
       for (int k = 0; k < nvars; k++)
         for (int i = 0; i < var_elem_dofs(m, fe[k]); i++)
-          elem_sys[(size_t)iel * nd + p++] = offs[k] + (fe[k] == 4 ? i * m->nel + iel : m->elem_dof[(size_t)iel * m->nloc + i]);
+          elem_sys[(size_t)iel * nd + p++] = offs[k] + (fe[k] == 4 ? i * m->nel + iel : fe[k] == FE_CONSTANT ? iel : m->elem_dof[(size_t)iel * m->nloc + i]);
     }
   return 0;
   FH_GUARD_END("fh_system_elem_dofs")
@@ -1231,7 +1253,7 @@ extern "C" int fh_build_system_prolongator(fh_ctx_t ctx, fh_mesh_t mc, fh_mesh_t
   FH_GUARD_BEGIN
   FH_REQUIRE(ctx && mc && mf && out, "fh_build_system_prolongator: null argument");
   FH_TRY(check_vars("fh_build_system_prolongator", nvars, fe, true));
-  fh_mat_t blk[3] = {nullptr, nullptr, nullptr};
+  fh_mat_t blk[4] = {nullptr, nullptr, nullptr, nullptr};
   for (int k = 0; k < nvars; k++)
     if (fe[k] != 4 && !blk[fe[k]]) FH_TRY(fh_build_prolongator(ctx, mc, mf, fe[k], 0, &blk[fe[k]]));
   // the block of a discontinuous linear variable: the element prolongator of solution type 4 (ElemType.cpp:446-520) -- the coarse function at the centre of

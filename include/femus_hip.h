@@ -67,7 +67,7 @@ int fh_graph_destroy(fh_graph_t graph);
  * names (default): "spmv_tile" (2048), "spmv_xcd_remap" (32), "spmv_kernel" (3), "assemble_two_pass" (1), "assemble_emap" (1),
  * "assemble_mfma" (12: HEX27/Q2 element matrices on the FP64 matrix cores, value = waves per workgroup, 0 = vector kernel),
  * "assemble_kpad" (1: element rows of the two-pass buffer padded to 256 bytes; read when an assembler is created),
- * "assemble_sumfac" (1: map Jacobian by sum factorisation in that kernel), "assemble_sym" (1), "assemble_affine" (0, see fh_assembler_affine_count), "assemble_fused" (1, see fh_assembler_fused_info), "gj_mfma" (1: coarse dense inverse updates on the
+ * "assemble_sumfac" (1: map Jacobian by sum factorisation in that kernel), "assemble_sym" (1), "assemble_affine" (0, see fh_assembler_affine_count), "assemble_fused" (1, see fh_assembler_fused_info), "assemble_carry" (-1, see fh_assembler_carry_info), "gj_mfma" (1: coarse dense inverse updates on the
  * matrix cores), "gj_symmetric" (1: symmetric sweep on the upper block triangle when the coarse operator is symmetric), "spgemm_slot_map" (1), "spgemm_device_symbolic" (1: patterns of sparse products on the device), "device_setup" (1: prolongators built on the device; 0: host loops, identical matrices), "use_graph" (1), "asm_debug" (0),
  * "debug_poison" (0; tests: work buffers of the solvers and the element-row buffers start as NaN bit patterns instead of zero),
  * "galerkin_macro" (1: fh_assembler_galerkin after a fused assembly reads the macro rows that assembly left behind), "vanka_fused" (1: block smoothers
@@ -322,6 +322,15 @@ int fh_assembler_affine_count(fh_assembler_t as, int* n_affine, int* n_general);
  * (or the option is off) and the two-pass path runs.  partial_entries = doubles in the partial-row buffer, second_pass_rows = CSR rows summed
  * by the second pass (the scatter of separate.hpp:165-205 through PetscMatrix.cpp:699-729 is what both paths replace). */
 int fh_assembler_fused_info(fh_assembler_t as, int* active, int* nclusters, int64_t* partial_entries, int* second_pass_rows);
+/* Carried rows of the fused cluster assembly (fh_set_option(ctx, "assemble_carry", v), read when an assembler is created; -1 = automatic, the default):
+ * the persistent workgroups of the cluster kernel walk SUPER-clusters of 8^k consecutive clusters (v = 3 k: 3 -> 8 clusters = 64 elements, 6 -> 64 clusters
+ * = 512 elements; in a refined mesh the descendants of one ancestor k + 1 levels up) one cluster after the other.  A CSR row all of whose elements lie in one
+ * super-cluster is accumulated IN the CSR array by that one workgroup -- the first cluster that holds an entry stores it, the later ones load, add, store,
+ * in ascending cluster order, which is the order of the second pass: the values have the bits the partial-row buffer gives -- and only the rows on the
+ * surface of a super-cluster go through the partial-row buffer (64 clusters: 33 % of the entries that go there with 0).  Automatic: the largest k <= 2 that
+ * leaves every workgroup at least two super-clusters, else 0.  The classes are read from the element lists; nothing about the mesh is assumed beyond the
+ * cluster structure itself.  clusters_per_super = 1: nothing is carried; carried_entries = CSR entries of the carried rows. */
+int fh_assembler_carry_info(fh_assembler_t as, int* clusters_per_super, int64_t* carried_entries);
 /* "assemble_fused" = 1 chooses per assembly: the fused path, unless fh_assembler_galerkin asked for the element rows of the PREVIOUS assembly (a solve that
  * re-prepares its hierarchy after every assembly: the two-pass path leaves the rows in place); 2 = always fused (the rows are re-created when asked for),
  * 0 = never.  path: what the last assembly ran, 1 = fused, 2 = two-pass, 0 = none yet / another path.

@@ -109,6 +109,19 @@ def d2lag_biquadratic(x, i):
     return (i == 0) * 1.0 + (i == 1) * (-2.) + (i == 2) * 1.0 + 0.0 * x
 
 
+# "quadratic" 1-D factors of the serendipity families (Edge.hpp:81-91): linear at the end nodes, the bubble at the middle one
+def lag_quadratic(x, i):
+    return (i == 0) * 0.5 * (1. - x) + (i == 1) * (1. - x) * (1. + x) + (i == 2) * 0.5 * (1. + x)
+
+
+def dlag_quadratic(x, i):
+    return (i == 0) * (-0.5) + (i == 1) * (-2. * x) + (i == 2) * 0.5
+
+
+def d2lag_quadratic(x, i):
+    return (i == 1) * (-2.) + 0.0 * x
+
+
 # FEMuS local node order (the convention of hex_lag::Xc / quad_lag::Xc): vertices, edge mid-points
 # (bottom ring, top ring, vertical), side-face centres (y-,x+,y+,x-), bottom, top, centre.
 XC_HEX27 = np.array(
@@ -130,8 +143,9 @@ def ind_table(geom):
 
 
 def ndofs(geom, fe):
+    """basis::n_dofs of the element families: Lagrange linear / serendipity ("quadratic") / biquadratic, piecewise constant (quad0 / hex0)"""
     dim = xc_table(geom).shape[1]
-    return {"linear": 2 ** dim, "biquadratic": 3 ** dim}[fe]
+    return {"linear": 2 ** dim, "serendipity": {2: 8, 3: 20}[dim], "biquadratic": 3 ** dim, "constant": 1}[fe]
 
 
 def n_vertices(geom):
@@ -151,6 +165,11 @@ def eval_basis(geom, fe, pts):
     dim = pts.shape[1]
     nc = ndofs(geom, fe)
     IND = ind_table(geom)[:nc]
+    if fe == "constant":          # quad0 / hex0 (Quadrilateral.hpp:173-, Hexahedron.hpp:196-): the constant one, every derivative zero
+        npts = pts.shape[0]
+        return np.ones((npts, 1)), np.zeros((npts, 1, dim)), np.zeros((npts, 1, 3 if dim == 2 else 6))
+    if fe == "serendipity":
+        return _eval_serendipity(geom, pts)
     if fe == "linear":
         L, D = lag_linear, dlag_linear
         D2 = lambda x, i: 0.0 * x
@@ -182,6 +201,67 @@ def eval_basis(geom, fe, pts):
             d2[:, j, 3] = dl[0] * dl[1] * l[2]
             d2[:, j, 4] = l[0] * dl[1] * dl[2]
             d2[:, j, 5] = dl[0] * l[1] * dl[2]
+    return phi, dphi, d2
+
+
+def _eval_serendipity(geom, pts):
+    """QuadQuadratic (Quadrilateral.cpp:113-161) / HexQuadratic (Hexahedron.cpp:167-256), the expressions term by term and in their order: an edge
+    function is the plain product of the 1-D "quadratic" factors, a vertex function that product times (-1 + ix x + jx y) resp. (-2 + ix x + jx y + kx z)"""
+    dim = pts.shape[1]
+    nc = ndofs(geom, "serendipity")
+    IND = ind_table(geom)[:nc]
+    npts = pts.shape[0]
+    phi = np.empty((npts, nc))
+    dphi = np.empty((npts, nc, dim))
+    d2 = np.empty((npts, nc, 3 if dim == 2 else 6))
+    x = [pts[:, d] for d in range(dim)]
+    for j in range(nc):
+        I = IND[j]
+        l = [lag_quadratic(x[d], I[d]) for d in range(dim)]
+        dl = [dlag_quadratic(x[d], I[d]) for d in range(dim)]
+        sl = [d2lag_quadratic(x[d], I[d]) for d in range(dim)]
+        if dim == 2:
+            ix, jx = I[0] - 1., I[1] - 1.
+            if abs(ix * jx) == 0:
+                phi[:, j] = l[0] * l[1]
+                dphi[:, j, 0] = dl[0] * l[1]
+                dphi[:, j, 1] = l[0] * dl[1]
+                d2[:, j, 0] = sl[0] * l[1]
+                d2[:, j, 1] = l[0] * sl[1]
+                d2[:, j, 2] = dl[0] * dl[1]
+            else:
+                s = -1. + ix * x[0] + jx * x[1]
+                phi[:, j] = s * l[0] * l[1]
+                dphi[:, j, 0] = l[1] * (ix * l[0] + s * dl[0])
+                dphi[:, j, 1] = l[0] * (jx * l[1] + s * dl[1])
+                d2[:, j, 0] = l[1] * (2. * ix * dl[0] + s * sl[0])
+                d2[:, j, 1] = l[0] * (2. * jx * dl[1] + s * sl[1])
+                d2[:, j, 2] = ix * l[0] * dl[1] + jx * l[1] * dl[0] + s * dl[0] * dl[1]
+            continue
+        ix, jx, kx = I[0] - 1., I[1] - 1., I[2] - 1.
+        if abs(ix * jx * kx) == 0:
+            phi[:, j] = l[0] * l[1] * l[2]
+            dphi[:, j, 0] = dl[0] * l[1] * l[2]
+            dphi[:, j, 1] = l[0] * dl[1] * l[2]
+            dphi[:, j, 2] = l[0] * l[1] * dl[2]
+            d2[:, j, 0] = sl[0] * l[1] * l[2]
+            d2[:, j, 1] = l[0] * sl[1] * l[2]
+            d2[:, j, 2] = l[0] * l[1] * sl[2]
+            d2[:, j, 3] = dl[0] * dl[1] * l[2]
+            d2[:, j, 4] = l[0] * dl[1] * dl[2]
+            d2[:, j, 5] = dl[0] * l[1] * dl[2]
+        else:
+            s = -2. + ix * x[0] + jx * x[1] + kx * x[2]
+            phi[:, j] = s * l[0] * l[1] * l[2]
+            dphi[:, j, 0] = l[1] * l[2] * (ix * l[0] + s * dl[0])
+            dphi[:, j, 1] = l[0] * l[2] * (jx * l[1] + s * dl[1])
+            dphi[:, j, 2] = l[0] * l[1] * (kx * l[2] + s * dl[2])
+            d2[:, j, 0] = l[1] * l[2] * (2. * ix * dl[0] + s * sl[0])
+            d2[:, j, 1] = l[2] * l[0] * (2. * jx * dl[1] + s * sl[1])
+            d2[:, j, 2] = l[0] * l[1] * (2. * kx * dl[2] + s * sl[2])
+            d2[:, j, 3] = l[2] * (ix * l[0] * dl[1] + jx * l[1] * dl[0] + s * dl[0] * dl[1])
+            d2[:, j, 4] = l[0] * (jx * l[1] * dl[2] + kx * l[2] * dl[1] + s * dl[1] * dl[2])
+            d2[:, j, 5] = l[1] * (kx * l[2] * dl[0] + ix * l[0] * dl[2] + s * dl[2] * dl[0])
     return phi, dphi, d2
 
 
@@ -523,10 +603,16 @@ def build_levels(nx, ny, nz, nlevels, lo=(0., 0., 0.), hi=(1., 1., 1.)):
 # a8/a9: Mesh::GetSolutionDof + LinearEquation::GetSystemDof for one variable, nprocs=1:
 # biquadratic dof = node id; linear dof = node id (vertex nodes are numbered first); system row = dof.
 def n_dofs(mesh, fe):
-    return mesh.own_size[0] if fe == "linear" else mesh.nnode
+    """dofs of one variable of the family (nprocs = 1): nodes are numbered vertices, edge mid-points, the rest, so the linear / serendipity families own the
+    leading own_size[0] / own_size[1] node ids; the piecewise constant family owns the elements (Mesh::GetSolutionDof, Mesh.cpp:1021-1074)"""
+    return {"linear": mesh.own_size[0], "serendipity": mesh.own_size[1], "biquadratic": mesh.nnode, "constant": mesh.nel}[fe]
 
 
 def elem_sys_dof(mesh, fe):
+    """Mesh::GetSolutionDof(i, iel, solType) for all elements (Mesh.cpp:1021-1074, nprocs = 1): the element's i-th node for the Lagrange families
+    (:1026-1054), the element itself for the piecewise constant one (:1056-1059)"""
+    if fe == "constant":
+        return np.arange(mesh.nel, dtype=mesh.elem_dof.dtype)[:, None]
     return mesh.elem_dof[:, :ndofs(mesh.geom, fe)]
 
 
@@ -537,8 +623,8 @@ def build_prolongator(mc, mf, fe):
     nc = ndofs(geom, fe)
     EP = elem_prolongator(geom, fe)                         # [nchild, nc, nc]
     nchild = EP.shape[0]
-    rows = mf.elem_dof[mc.child_elem, :][:, :, :nc]          # [nel_c, nchild, nc]
-    cols = mc.elem_dof[:, :nc]                               # [nel_c, nc]
+    rows = elem_sys_dof(mf, fe)[mc.child_elem, :]            # [nel_c, nchild, nc]
+    cols = elem_sys_dof(mc, fe)                              # [nel_c, nc]
     R = np.broadcast_to(rows[:, :, :, None], (mc.nel, nchild, nc, nc)).ravel()
     C = np.broadcast_to(cols[:, None, None, :], (mc.nel, nchild, nc, nc)).ravel()
     V = np.broadcast_to(EP[None], (mc.nel, nchild, nc, nc)).ravel()
@@ -1179,7 +1265,7 @@ def face_local_nodes(geom, fe, face, table=None):
     """element-local nodes of `face` in the face element's own node order.  table: optional explicit order
     (e.g. the reference's hex_lag::faceDofs row); default = parametrisation by the free coordinates in cyclic order."""
     if table is not None:
-        nfn = {("hex", "linear"): 4, ("hex", "biquadratic"): 9, ("quad", "linear"): 2, ("quad", "biquadratic"): 3}[(geom, fe)]
+        nfn = {("hex", "linear"): 4, ("hex", "serendipity"): 8, ("hex", "biquadratic"): 9, ("quad", "linear"): 2, ("quad", "serendipity"): 3, ("quad", "biquadratic"): 3}[(geom, fe)]
         return np.asarray(table[:nfn], dtype=np.int64)
     Xc = xc_table(geom)
     d = Xc.shape[1]
@@ -1189,7 +1275,7 @@ def face_local_nodes(geom, fe, face, table=None):
     # orientation: the JacobianSur normal of the node order points out of the element, as with the reference's faceDofs tables (the golden
     # fixture facedofs_hex / facedofs_quad holds those; same cyclic order, possibly another starting node)
     if geom == "hex":
-        ref = XC_QUAD9[:4] if fe == "linear" else XC_QUAD9
+        ref = XC_QUAD9[:4] if fe == "linear" else XC_QUAD9[:8] if fe == "serendipity" else XC_QUAD9
         a, b = (d0 + 1) % 3, (d0 + 2) % 3
         if sgn < 0:
             a, b = b, a

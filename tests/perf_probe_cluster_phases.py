@@ -8,6 +8,7 @@ extra = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 stamps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = femus_amd.Context(0)
 ctx.set_option("assemble_fused", 2)
+if os.environ.get("FEMUS_CARRY"): ctx.set_option("assemble_carry", int(os.environ["FEMUS_CARRY"]))
 pb = PoissonMG(ctx, 8, 8, 8, 4).init()
 for _ in range(3): pb.assemble()
 for dbg, what in ((2, "element phase only"), (8, "cluster kernel alone"), (0, "cluster kernel + second pass")):

@@ -187,3 +187,107 @@ def test_elementwise_galerkin_after_a_fused_assembly(ctx):
         finally:
             ctx.set_option("assemble_fused", 1)
             ctx.set_option("galerkin_macro", 1)
+
+
+@pytest.mark.parametrize("args,nl,carry,kind,with_sol", [((2, 2, 2), 3, 3, 1, True), ((2, 2, 2), 3, 6, 0, True), ((3, 2, 2), 3, 6, 2, False), ((1, 1, 1), 3, 3, 1, True),
+                                                         ((4, 2, 2), 2, 3, 1, True)])
+def test_carried_rows_have_the_bits_of_the_partial_row_buffer(ctx, args, nl, carry, kind, with_sol):
+    """assemble_carry: rows all of whose elements lie in one super-cluster (8 / 64 / -- where the cluster count is no multiple -- 32 consecutive clusters) are
+    accumulated in the CSR array by the one workgroup that walks the super-cluster: store, then load-add-store in ascending cluster order, which is the order
+    of the second pass -- matrix and residual are BIT-IDENTICAL to the plan without carried rows, from NaN-poisoned arrays, twice; fewer entries visit the
+    partial-row buffer; and both equal the oracle's element loop to 1e-12.  (4, 2, 2) refined once: consecutive clusters that are no siblings of each other."""
+    m = levels(args, nl)[-1]
+    ed, xy, _ = m.arrays()
+    rng = np.random.default_rng(5)
+    xy = xy + rng.uniform(-0.01, 0.01, xy.shape) / 2 ** (nl - 1)
+    n = m.nnode
+    rp, col = capi.pattern_from_elements(ed, n)
+    u = rng.uniform(-1, 1, n) if with_sol else np.zeros(n)
+    params, rhs = KINDS[kind]
+    out, info = {}, {}
+    for c in (0, carry):
+        ctx.set_option("assemble_carry", c)
+        ctx.set_option("debug_poison", 1)
+        try:
+            A = ctx.matrix_csr(n, n, rp, col, np.full(col.size, np.nan))
+            res = ctx.vector_from(np.full(n, np.nan))
+            asm = capi.Assembler(ctx, m, "biquadratic", A, elem_dof=ed, coords=xy)
+            info[c] = asm.fused_info()
+            assert info[c]["active"]
+            sol = ctx.vector_from(u) if with_sol else None
+            asm.assemble(A, res, sol, kind, params)
+            v1, f1 = A.values().copy(), res.to_numpy().copy()
+            A.set_values(np.full(col.size, np.nan))
+            asm.assemble(A, res, sol, kind, params)
+            assert np.array_equal(v1, A.values()) and np.array_equal(f1, res.to_numpy())
+            out[c] = (v1, f1)
+            asm.destroy(), A.destroy()
+        finally:
+            ctx.set_option("debug_poison", 0)
+            ctx.set_option("assemble_carry", -1)
+    assert info[0]["clusters_per_super"] == 1 and info[0]["carried_entries"] == 0
+    assert info[carry]["clusters_per_super"] > 1 and info[carry]["carried_entries"] > 0
+    assert info[carry]["partial_entries"] < info[0]["partial_entries"] and info[carry]["second_pass_rows"] < info[0]["second_pass_rows"]
+    assert np.isfinite(out[carry][0]).all() and np.isfinite(out[carry][1]).all()
+    assert np.array_equal(out[0][0], out[carry][0]) and np.array_equal(out[0][1], out[carry][1])
+    Ao, bo = oracle_global(ed, xy, u, rhs, n)
+    row_scale = np.repeat(np.maximum.reduceat(abs(Ao.data), rp[:-1]), np.diff(rp))
+    assert (abs(out[carry][0] - Ao.data) / row_scale).max() <= 1e-12
+    assert abs(out[carry][1] - bo).max() <= 1e-12 * abs(bo).max()
+
+
+def test_carried_rows_with_a_pattern_that_holds_more_than_the_element_couplings(ctx):
+    """a CSR row with a position no element contributes to cannot be carried (nobody would store there): the plan is made again without carried rows (the second
+    pass writes whole rows) and gives the oracle's operator with zeros at the extra positions"""
+    m = levels((2, 2, 2), 3)[-1]
+    ed, xy, _ = m.arrays()
+    n = m.nnode
+    rp, col = capi.pattern_from_elements(ed, n)
+    P = sp.csr_matrix((np.ones(col.size), col, rp), shape=(n, n))
+    extra = sp.coo_matrix((np.ones(n - 1), (np.arange(n - 1), (np.arange(n - 1) * 7 + 3) % n)), shape=(n, n)).tocsr()
+    P = (P + extra).tocsr()
+    P.sort_indices()
+    ctx.set_option("assemble_carry", 3)
+    try:
+        A = ctx.matrix_csr(n, n, P.indptr.astype(np.int32), P.indices.astype(np.int32), np.full(P.nnz, np.nan))
+        res = ctx.vector(n)
+        asm = capi.Assembler(ctx, m, "biquadratic", A, elem_dof=ed, coords=xy)
+        fi = asm.fused_info()
+        assert fi["active"] and fi["clusters_per_super"] == 1
+        u = np.random.default_rng(2).uniform(-1, 1, n)
+        asm.assemble(A, res, ctx.vector_from(u), 1, (2.0, 1.3))
+        Ao, bo = oracle_global(ed, xy, u, KINDS[1][1], n)
+        got = sp.csr_matrix((A.values(), P.indices, P.indptr), shape=(n, n))
+        assert np.isfinite(got.data).all()
+        assert abs(got - Ao).max() <= 1e-12 * abs(Ao.data).max()
+        assert abs(res.to_numpy() - bo).max() <= 1e-12 * abs(bo).max()
+        asm.destroy(), A.destroy()
+    finally:
+        ctx.set_option("assemble_carry", -1)
+
+
+@pytest.mark.parametrize("carry", [3, 6])
+def test_elementwise_galerkin_from_carried_rows(ctx, carry):
+    """k_galerkin_macro reads a carried entry in the cluster that made the last contribution (the sum of all of them): the pseudo child matrices still add
+    up to the assembled operator, so the coarse operators equal the ones made without carried rows to rounding -- also after SetPenalty"""
+    from femus_amd.poisson import PoissonMG
+    vals = {}
+    for c in (0, carry):
+        ctx.set_option("assemble_carry", c)
+        try:
+            pb = PoissonMG(ctx, 2, 2, 2, 4).init()
+            fi = pb.asm[-1].fused_info()
+            assert fi["active"] and (fi["clusters_per_super"] > 1) == (c > 0)
+            pb.assemble()
+            pb.prepare()
+            assert pb.asm[-1].last_path() == "fused"
+            vals[c] = [pb.A[l].to_scipy() for l in range(pb.nlevels)]
+            pb.prepare()
+            for a, b in zip([pb.A[l].to_scipy() for l in range(pb.nlevels)], vals[c]):
+                assert abs(a - b).max() == 0.0
+            pb.destroy()
+        finally:
+            ctx.set_option("assemble_carry", -1)
+    assert abs(vals[0][-1] - vals[carry][-1]).max() == 0.0
+    for a, b in zip(vals[0][:-1], vals[carry][:-1]):
+        assert abs(a - b).max() <= 1e-13 * abs(b).max()
