@@ -25,7 +25,7 @@ from . import capi
 from .poisson import PoissonMG
 
 FACE_NAMES = {2: ["bottom", "right", "top", "left"], 3: ["bottom", "front", "right", "behind", "left", "top"]}
-FE_ORDER = {"first": "linear", "second": "biquadratic"}
+FE_ORDER = {"first": "linear", "serendipity": "serendipity", "second": "biquadratic"}       # FEOrder of the input (main.cpp:149) -> Lagrange family
 PREFIX = "multilevel_problem.multilevel_mesh.first.system.poisson.linear_solver."
 
 
@@ -128,7 +128,7 @@ class Poisson001:
         """GenerateBdc with parsed functions (MultiLevelSolution.cpp:762-800): elements and faces in order; nodes of Dirichlet
         faces get Bdc = 0 and Sol = value(x, y, z, t = 0); a later face overwrites an earlier one"""
         ed, xy, ff = mesh.arrays()
-        nc = {"linear": 2 ** self.dim, "biquadratic": 3 ** self.dim}[self.fe]
+        nc = {"linear": 2 ** self.dim, "serendipity": 8 if self.dim == 2 else 20, "biquadratic": 3 ** self.dim}[self.fe]
         val = {}
         for iel, f in zip(*np.nonzero(ff < -1)):
             kind, fn = self.face_bc(int(ff[iel, f]))
@@ -189,7 +189,7 @@ class Poisson001:
             # VTKWriter / GMVWriter file names: <prefix>.level<gridn>.<time step>.<order>.<ext> with gridn = number of levels
             stem = os.path.join(str(output_dir), "sol.level%d.%d.%s" % (self.nlevels, 0, "biquadratic"))
             field = result["solution"]
-            if field.size != meshes[top].nnode:          # linear solution: the writers carry it to the nodes of the output family
+            if field.size != meshes[top].nnode:          # linear / serendipity solution: the writers carry the vertex values to the nodes of the output family
                 field = field[:meshes[top].own_size[0]]
             writers.write_vtu(stem + ".vtu", meshes[top], {"Sol": field})
             writers.write_gmv(stem + ".gmv", meshes[top], {"Sol": field}, "biquadratic")

@@ -842,7 +842,7 @@ class Assembler:
             self.h = ctypes.c_void_p()
             _chk(self.L.fh_assembler_create_mesh(ctx.h, mesh.h, FE[fe], GAUSS_ORDER[order], A.h, ctypes.byref(self.h)))
             self.nel = mesh.nel
-            self.nc = {"linear": 2 ** mesh.dim, "biquadratic": 3 ** mesh.dim}[fe]
+            self.nc = {"linear": 2 ** mesh.dim, "serendipity": 8 if mesh.dim == 2 else 20, "biquadratic": 3 ** mesh.dim}[fe]
             return
         ed, xy = _i32(elem_dof), _f64(coords)
         assert ed.min() >= 0 and ed.max() < xy.shape[0]
@@ -851,7 +851,7 @@ class Assembler:
         _chk(self.L.fh_assembler_create(ctx.h, GEOM[geom], FE[fe], GAUSS_ORDER[order], ed.shape[0], ed.shape[1], _p(ed),
                                         xy.shape[0], _p(xy), A.h, ctypes.byref(self.h)))
         self.nel = ed.shape[0]
-        self.nc = {"linear": 2 ** xy.shape[1], "biquadratic": 3 ** xy.shape[1]}[fe]
+        self.nc = {"linear": 2 ** xy.shape[1], "serendipity": 8 if xy.shape[1] == 2 else 20, "biquadratic": 3 ** xy.shape[1]}[fe]
 
     def destroy(self):
         if self.h:

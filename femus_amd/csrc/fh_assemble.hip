@@ -145,7 +145,7 @@ struct AsmCfg {
   static constexpr int NT = NBI * NBJ;                                        // tiles per element
   static constexpr int LPE = NT <= 1 ? 1 : NT <= 2 ? 2 : NT <= 4 ? 4 : NT <= 8 ? 8 : NT <= 16 ? 16 : NT <= 32 ? 32 : 64;
   static constexpr int EPW = 64 / LPE;                                        // elements per wave
-  static constexpr int NSPLIT = (LPE == 64) ? 4 : 1;                          // node parts in phase 1
+  static constexpr int NSPLIT = (LPE == 64 || NC == 20) ? 4 : 1;              // node parts in phase 1 (HEX20: 8 Gauss points per chunk instead of 32, 47 kB of LDS per workgroup instead of 171)
   static constexpr int GC = LPE / NSPLIT;                                     // Gauss points per chunk
   static constexpr int NPP = (NC + NSPLIT - 1) / NSPLIT;                      // nodes per part
   static constexpr int NCP = NBI * TI;                                        // padded row length in LDS

@@ -35,7 +35,8 @@ class PoissonMG:
             self.meshes = [capi.Mesh.box(nx, ny, nz, lo, hi)]
             for _ in range(1, nlevels):
                 self.meshes.append(self.meshes[-1].refine(ctx))      # on the device; the levels stay resident for init()
-        self.nc = {"linear": 2 ** self.meshes[0].dim, "biquadratic": 3 ** self.meshes[0].dim}[fe]
+        dim = self.meshes[0].dim
+        self.nc = {"linear": 2 ** dim, "serendipity": 8 if dim == 2 else 20, "biquadratic": 3 ** dim}[fe]
         self.mg = None
 
     # ---- LinearImplicitSystem::init ---------------------------------------------------------------------------

@@ -199,7 +199,12 @@ int64_t fh_spmv_algorithmic_bytes(fh_mat_t A);
 int fh_spmv_expected_bytes(fh_mat_t A, int mode, int64_t* lo, int64_t* hi);
 
 /* ---- FE tables (a1-a3, a6) -------------------------------------------------------------------
- * geom: 0 = hex (HEX27 geometry), 1 = quad (QUAD9).  fe: 0 = linear (Q1), 2 = biquadratic (Q2)  (FEMuS SolType ids).
+ * geom: 0 = hex (HEX27 geometry), 1 = quad (QUAD9).  fe = FEMuS SolType ids (FEFamily order): 0 = linear (Q1), 1 = serendipity (QuadQuadratic / HexQuadratic,
+ * 8 / 20 nodes: Quadrilateral.cpp:113-161, Hexahedron.cpp:167-256), 2 = biquadratic (Q2), 3 = piecewise constant (quad0 / hex0, one dof per element).
+ * Dofs of one variable on one process (Mesh::GetSolutionDof, Mesh.cpp:1021-1074): local node i of the element for 0 / 1 / 2 -- nodes are numbered vertices, edge
+ * mid-points, the rest, so families 0 and 1 own the leading own[0] / own[1] node ids of fh_mesh_info --, the element itself for 3 (and i * nel + iel for 4,
+ * discontinuous linear: fh_system_elem_dofs / fh_build_system_prolongator only).  Tables, element prolongators, patterns, prolongators and system dof maps serve
+ * 0 .. 3; the Poisson assembler, the Neumann faces and fh_fe_jacobian serve the Lagrange families 0 .. 2; the adaptive-refinement constraints 0 and 2.
  * gauss_order: index 0..4 of quadrature_interface.cpp:36-57 ("seventh" -> 3).
  * Gauss: src/02_reference_geom_elements/02_quadrature/ ; basis: 01_fe/ ; tables: 03_fe_evaluations_at_quadrature/ElemType.cpp:576-741 */
 int fh_fe_gauss(int geom, int gauss_order, int* ng, double* w, double* x /* [dim*ng], x[d*ng+ig] */);
@@ -259,7 +264,7 @@ int fh_pattern_from_elements(int nel, int nloc, const int* elem_dof, int ndof, i
 /* the same pattern built ON THE DEVICE and made a matrix at once (m owned rows over n columns, values zero): node -> element lists by a counting
  * pass, one wave per row sorts the candidate columns in LDS.  The column array stays on the device (host code that asks for it fetches it). */
 int fh_mat_create_from_elements(fh_ctx_t ctx, int nel, int nloc, const int* elem_dof, int m, int n, fh_mat_t* out);
-/* the same for a square operator of one variable on a mesh (fe: 0 linear, 2 biquadratic), from the mesh's device copy (made now if it has none) */
+/* the same for a square operator of one variable on a mesh (fe 0 .. 3), from the mesh's device copy (made now if it has none) */
 int fh_mat_create_from_mesh(fh_ctx_t ctx, fh_mesh_t mesh, int fe, fh_mat_t* out);
 
 /* ---- prolongator (a14): LinearImplicitSystem::BuildProlongatorMatrix (LinearImplicitSystem.cpp:761-909) ----

@@ -605,7 +605,11 @@ def build_levels(nx, ny, nz, nlevels, lo=(0., 0., 0.), hi=(1., 1., 1.)):
 def n_dofs(mesh, fe):
     """dofs of one variable of the family (nprocs = 1): nodes are numbered vertices, edge mid-points, the rest, so the linear / serendipity families own the
     leading own_size[0] / own_size[1] node ids; the piecewise constant family owns the elements (Mesh::GetSolutionDof, Mesh.cpp:1021-1074)"""
-    return {"linear": mesh.own_size[0], "serendipity": mesh.own_size[1], "biquadratic": mesh.nnode, "constant": mesh.nel}[fe]
+    if fe == "biquadratic":
+        return mesh.nnode
+    if fe == "constant":
+        return mesh.nel
+    return mesh.own_size[{"linear": 0, "serendipity": 1}[fe]]
 
 
 def elem_sys_dof(mesh, fe):

@@ -5,6 +5,7 @@
 //   femus::Gauss            src/02_reference_geom_elements/02_quadrature/quadrature_interface.hpp:32
 //   femus::HexBiquadratic   src/02_reference_geom_elements/01_fe/3d/Hexahedron.hpp
 //   femus::QuadBiquadratic  src/02_reference_geom_elements/01_fe/2d/Quadrilateral.hpp
+//   femus::HexQuadratic / QuadQuadratic (serendipity), hex0 / quad0 (piecewise constant), hexpwLinear / quadpwLinear: same headers
 //   femus::GeomElemBase     src/02_reference_geom_elements/00_definition/GeomElemBase.hpp:32 (build), :83 (get_nodes_of_face), :97 (get_embedding_matrix)
 #include "quadrature_interface.hpp"
 #include "Hexahedron.hpp"
@@ -23,10 +24,14 @@ static basis* make_basis(const char* geom, const char* fe) {
     if (!strcmp(fe, "linear")) return new HexLinear();
     if (!strcmp(fe, "quadratic")) return new HexQuadratic();
     if (!strcmp(fe, "biquadratic")) return new HexBiquadratic();
+    if (!strcmp(fe, "constant")) return new hex0();
+    if (!strcmp(fe, "pwlinear")) return new hexpwLinear();
   } else if (!strcmp(geom, "quad")) {
     if (!strcmp(fe, "linear")) return new QuadLinear();
     if (!strcmp(fe, "quadratic")) return new QuadQuadratic();
     if (!strcmp(fe, "biquadratic")) return new QuadBiquadratic();
+    if (!strcmp(fe, "constant")) return new quad0();
+    if (!strcmp(fe, "pwlinear")) return new quadpwLinear();
   } else if (!strcmp(geom, "line")) {
     if (!strcmp(fe, "linear")) return new LineLinear();
     if (!strcmp(fe, "biquadratic")) return new LineBiquadratic();

@@ -24,12 +24,14 @@ for geom, dim in (("line", 1), ("quad", 2), ("hex", 3)):
         out["gauss_w_%s_%s" % (geom, order)] = w
         out["gauss_x_%s_%s" % (geom, order)] = x.T.copy()
 
+REFNAME = {"serendipity": "quadratic"}
 rng = np.random.default_rng(20260929)
 for geom, dim, nv in (("quad", 2, 4), ("hex", 3, 8)):
     sample = rng.uniform(-1, 1, (7, dim))
     out["sample_pts_%s" % geom] = sample
-    for fe in ("linear", "biquadratic"):
-        nc = L.ref_ndofs(geom.encode(), fe.encode())
+    for fe in ("linear", "biquadratic", "serendipity", "constant"):
+        rfe = REFNAME.get(fe, fe)          # the reference calls the serendipity family "quadratic"
+        nc = L.ref_ndofs(geom.encode(), rfe.encode())
         for tag, pts in (("gauss7", out["gauss_x_%s_seventh" % geom]), ("sample", sample)):
             vals = np.zeros((10, pts.shape[0], nc))
             for p in range(pts.shape[0]):
@@ -42,7 +44,7 @@ for geom, dim, nv in (("quad", 2, 4), ("hex", 3, 8)):
                             continue  # HexLinear does not implement pure second derivatives
                         if fe == "linear" and which in (4, 5) and dim == 2:
                             continue
-                        vals[which, p, j] = L.ref_eval(geom.encode(), fe.encode(), which, j, pt)
+                        vals[which, p, j] = L.ref_eval(geom.encode(), rfe.encode(), which, j, pt)
             out["basis_%s_%s_%s" % (geom, fe, tag)] = vals
     nloc = 3 ** dim
     xc = np.zeros((nloc, dim))
@@ -59,6 +61,8 @@ for geom, dim, nv in (("quad", 2, 4), ("hex", 3, 8)):
     out["f2c_%s" % geom] = np.array([[L.ref_fine2coarse_vertex(geom.encode(), b"linear", j, v) for v in range(nv)] for j in range(nv)])
     nfd = 9 if geom == "hex" else 3
     out["facedofs_%s" % geom] = np.array([[L.ref_face_dof(geom.encode(), b"biquadratic", f, k) for k in range(nfd)] for f in range(2 * dim)])
+    nfs = 8 if geom == "hex" else 3        # face nodes of the serendipity family (QUAD8 / EDGE3)
+    out["facedofs_%s_serendipity" % geom] = np.array([[L.ref_face_dof(geom.encode(), b"quadratic", f, k) for k in range(nfs)] for f in range(2 * dim)])
     nf = L.ref_ndofs_fine(geom.encode(), b"biquadratic")
     kv = np.zeros((nf, 2), dtype=np.int64)
     for i in range(nf):
@@ -80,9 +84,10 @@ def _xcoarse(geom, fe, i, dim):
 
 for geom, dim in (("quad", 2), ("hex", 3)):
     nlin = L.ref_ndofs(geom.encode(), b"linear")
-    for fe in ("linear", "biquadratic"):
-        nc = L.ref_ndofs(geom.encode(), fe.encode())
-        nf = L.ref_ndofs_fine(geom.encode(), fe.encode())
+    for fe in ("linear", "biquadratic", "serendipity"):
+        rfe = REFNAME.get(fe, fe)
+        nc = L.ref_ndofs(geom.encode(), rfe.encode())
+        nf = L.ref_ndofs_fine(geom.encode(), rfe.encode())
         X = np.zeros((nf, dim))
         P = np.zeros((nf, nc))
         kv = np.zeros((nf, 2), dtype=np.int64)
@@ -100,11 +105,30 @@ for geom, dim in (("quad", 2), ("hex", 3)):
             X[i] = xm
             ptx = (ctypes.c_double * 3)(*(list(xm) + [0.0] * (3 - dim)))
             for j in range(nc):
-                v = L.ref_eval(geom.encode(), fe.encode(), 0, j, ptx)
+                v = L.ref_eval(geom.encode(), rfe.encode(), 0, j, ptx)
                 P[i, j] = v if abs(v) >= 1.0e-14 else 0.0
         out["xfine_%s_%s" % (geom, fe)] = X
         out["elem_prol_%s_%s" % (geom, fe)] = P
         out["kvert_ind_%s_%s" % (geom, fe)] = kv
+    # the discontinuous families carry their own fine points (hex_const::X, quad_const::X) and (child, function) table; the piecewise constant one:
+    # P[i][0] = phi_0(X[i]) = 1 for each of the 2^dim children
+    nf0 = L.ref_ndofs_fine(geom.encode(), b"constant")
+    X0 = np.zeros((nf0, dim))
+    kv0 = np.zeros((nf0, 2), dtype=np.int64)
+    P0 = np.zeros((nf0, 1))
+    for i in range(nf0):
+        b = (ctypes.c_double * 3)()
+        L.ref_xfine(geom.encode(), b"constant", i, dim, b)
+        X0[i] = list(b)[:dim]
+        k2 = (ctypes.c_int * 2)()
+        L.ref_kvert_ind(geom.encode(), b"constant", i, k2)
+        kv0[i] = [k2[0], k2[1]]
+        ptx = (ctypes.c_double * 3)(*(list(X0[i]) + [0.0] * (3 - dim)))
+        v = L.ref_eval(geom.encode(), b"constant", 0, 0, ptx)
+        P0[i, 0] = v if abs(v) >= 1.0e-14 else 0.0
+    out["xfine_%s_constant" % geom] = X0
+    out["elem_prol_%s_constant" % geom] = P0
+    out["kvert_ind_%s_constant" % geom] = kv0
 
 # GeomElem* topology tables of the compiled 00_definition sources: sizes, face -> nodes, float embedding matrices
 for geom, fam, tag in (("hex", 2, "hex27"), ("quad", 2, "quad9")):

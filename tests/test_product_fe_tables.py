@@ -23,7 +23,7 @@ def test_product_gauss_tables_bit_exact(geom, order):
 
 
 @pytest.mark.parametrize("geom", ["quad", "hex"])
-@pytest.mark.parametrize("fe", ["linear", "biquadratic"])
+@pytest.mark.parametrize("fe", ["linear", "serendipity", "biquadratic", "constant"])
 def test_product_shape_tables_at_quadrature_points_bit_exact(geom, fe):
     """a2/a3: phi and d phi at the 'seventh' Gauss points (ElemType.cpp:576-741 fills its tables with exactly these calls)"""
     phi, dphi = capi.fe_tables(geom, fe, "seventh")
@@ -34,7 +34,7 @@ def test_product_shape_tables_at_quadrature_points_bit_exact(geom, fe):
 
 
 @pytest.mark.parametrize("geom", ["quad", "hex"])
-@pytest.mark.parametrize("fe", ["linear", "biquadratic"])
+@pytest.mark.parametrize("fe", ["linear", "serendipity", "biquadratic", "constant"])
 def test_product_second_derivative_tables_bit_exact(geom, fe):
     """a3: the _d2phi* tables elem_type fills for the optional Hessians (ElemType.cpp:637-741).  The linear families do not implement the pure
     second derivatives in the reference (the fixture holds none); they are identically zero"""
@@ -57,7 +57,33 @@ def _rows_by_kvert(geom, fe, P):
 
 
 @pytest.mark.parametrize("geom", ["quad", "hex"])
-@pytest.mark.parametrize("fe", ["linear", "biquadratic"])
+def test_product_piecewise_constant_element_prolongator(geom):
+    """a6 for quad0 / hex0 (Quadrilateral.hpp:173-, Hexahedron.hpp:196-): the family's own fine-point table hex_const::X / KVERT_IND (Hexahedron.cpp:258-278)
+    lists one (child, function 0) pair per child; P[i][0] = 1 at every one of them"""
+    ref, kv = G["elem_prol_%s_constant" % geom], G["kvert_ind_%s_constant" % geom]
+    nch = 8 if geom == "hex" else 4
+    assert kv.tolist() == [[j, 0] for j in range(nch)] and np.array_equal(ref, np.ones((nch, 1)))
+    for P in (capi.fe_elem_prolongator(geom, "constant"), fo.elem_prolongator(geom, "constant")):
+        assert P.shape == (nch, 1, 1) and np.array_equal(_rows_by_kvert(geom, "constant", P), ref)
+    # the fine points are the centres of the children: half the reference coordinates of the coarse vertex the child sits at
+    assert np.array_equal(G["xfine_%s_constant" % geom], 0.5 * fo.xc_table(geom)[:nch])
+
+
+@pytest.mark.parametrize("geom", ["quad", "hex"])
+def test_product_serendipity_face_nodes(geom):
+    """a5 for the serendipity family: basis::GetFaceDof of QuadQuadratic / HexQuadratic -- EDGE3 / QUAD8 faces, vertices first"""
+    fd = G["facedofs_%s_serendipity" % geom]
+    nvf = 4 if geom == "hex" else 2
+    for f in range(fd.shape[0]):
+        got = capi.fe_face_nodes(geom, "serendipity", f)
+        assert got.size == fd.shape[1] and set(got.tolist()) == set(fd[f].tolist())
+        assert set(got[:nvf].tolist()) == set(fd[f][:nvf].tolist())
+        assert set(fo.face_local_nodes(geom, "serendipity", f).tolist()) == set(fd[f].tolist())
+        assert capi.fe_face_nodes(geom, "constant", f).size == 0
+
+
+@pytest.mark.parametrize("geom", ["quad", "hex"])
+@pytest.mark.parametrize("fe", ["linear", "serendipity", "biquadratic"])
 def test_product_element_prolongator_bit_exact(geom, fe):
     """a6: set_prolongation_OneElement_All_FE (ElemType.cpp:439-532): phi_j(GetX(i)), |.| < 1e-14 dropped"""
     ref = G["elem_prol_%s_%s" % (geom, fe)]
@@ -73,6 +99,8 @@ def test_product_element_prolongator_bit_exact(geom, fe):
             assert np.array_equal(P[j, i], key[tuple(X[j, i])])
     if geom == "hex" and fe == "biquadratic":
         assert ref.shape == (125, 27) and np.count_nonzero(ref) == 729
+    if fe == "serendipity":
+        assert ref.shape == ((81, 20) if geom == "hex" else (21, 8))          # HexQuadratic(20, 81), QuadQuadratic(8, 21)
 
 
 @pytest.mark.parametrize("geom,tag", [("quad", "quad9")])
