@@ -104,6 +104,9 @@ class NavierStokesMG:
         # open_pressure: {face name: number or capi.Expr} -- the pressure the bdc callback prescribes for "P" on the faces whose normal velocity is
         # free (03_navier_stokes.hpp:280); None: no face of the problem is open (the cavity) and the boundary integral is skipped
         self.open_pressure = open_pressure
+        # coarsest level of the cycles (the reference's EraseCoarseLevels, MultiLevelMesh.cpp; SteadyNavierStokesParallel/main.cpp:92 uses it): the levels below are
+        # still meshes of the nonlinear F-cycle, but a cycle at level-max ig stops at min(coarse_level, ig) and solves there exactly (sparse LU on general fronts)
+        self.coarse_level = 0
         self.history = []
 
     # ---- LinearImplicitSystem::init --------------------------------------------------------------------------------
@@ -149,23 +152,24 @@ class NavierStokesMG:
         self.asm[ig].assemble(self.KK[ig], self.RES[ig], self.SOL[ig], self.nu)
         self.add_open_boundary_pressure(ig)
         self.A[(ig, ig)] = self.KK[ig]
-        for l in range(ig, 0, -1):                                     # PtAP chain from the un-penalised operators
+        c = min(self.coarse_level, ig)
+        for l in range(ig, c, -1):                                     # PtAP chain from the un-penalised operators
             if (ig, l - 1) not in self.A:
                 self.A[(ig, l - 1)] = capi.Mat.ptap(self.P[l], self.A[(ig, l)])
             else:
                 self.A[(ig, l - 1)].ptap_numeric(self.P[l], self.A[(ig, l)])
-        for l in range(ig + 1):
+        for l in range(c, ig + 1):
             self.A[(ig, l)].mat_zero_rows(self.bdc[l], 1.0)
         if self.bdc[ig].size:                                          # ZerosBoundaryResiduals
             self.RES[ig].set(self.bdc[ig], np.zeros(self.bdc[ig].size))
         if ig not in self.mg:
-            self.mg[ig] = capi.Multigrid(ctx, ig + 1)
-            for l in range(1, ig + 1):
-                self.mg[ig].set_level_patches(l, *self.patches[l])
+            self.mg[ig] = capi.Multigrid(ctx, ig - c + 1)
+            for l in range(c + 1, ig + 1):
+                self.mg[ig].set_level_patches(l - c, *self.patches[l])
         mg = self.mg[ig]
-        for l in range(ig + 1):
-            mg.set_level(l, self.A[(ig, l)], self.P[l] if l > 0 else None, None, getattr(self, "smoother", capi.SMOOTH_VANKA), self.omega,
-                         self.npre if l > 0 else 1, self.npost if l > 0 else 0)
+        for l in range(c, ig + 1):
+            mg.set_level(l - c, self.A[(ig, l)], self.P[l] if l > c else None, None, getattr(self, "smoother", capi.SMOOTH_VANKA), self.omega,
+                         self.npre if l > c else 1, self.npost if l > c else 0)
         mg.setup()
         return mg
 

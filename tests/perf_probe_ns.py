@@ -20,7 +20,9 @@ def main():
         ctx.set_option(k, float(v))
     nl = 4
     t0 = time.time()
-    pb = NavierStokesMG(ctx, 10, 10, 0, nl, 0.01).init()
+    pb = NavierStokesMG(ctx, 10, 10, 0, nl, 0.01)
+    pb.coarse_level = int(os.environ.get("FEMUS_NS_COARSE_LEVEL", "0"))
+    pb.init()
     setup_s = time.time() - t0
     t0 = time.time()
     for v in ([0.01] if nu >= 0.01 else [0.01, 0.004, 0.002, nu]):
@@ -54,7 +56,8 @@ def main():
     print(json.dumps({"config": "cavity Q2/Q1 80x80, 4 levels, nu=%g" % nu, "unknowns": pb.n[top], "setup_s": setup_s,
                       "fcycle_solve_s": solve_s, "newton_steps_per_level": [sum(1 for h in pb.history if h[0] == l) for l in range(nl)],
                       "gmres_its_finest": [h[3] for h in fine], "assembly_ms": asm_ms, "prepare_ms": prep_ms,
-                      "vcycle_ms": cyc_ms, "linear_solve_ms": lin_ms, "linear_solve_first_call_ms": lin_first_ms, "linear_its": its}))
+                      "vcycle_ms": cyc_ms, "linear_solve_ms": lin_ms, "linear_solve_first_call_ms": lin_first_ms, "linear_its": its, "ms_per_iteration": lin_ms / max(its, 1),
+                      "coarse_level": pb.coarse_level, "coarse_unknowns": pb.n[min(pb.coarse_level, top)]}))
     pb.destroy()
 
 

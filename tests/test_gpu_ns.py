@@ -153,6 +153,31 @@ def test_config4_at_its_stated_parameters_by_continuation(ctx):
     pb.destroy()
 
 
+def test_config4_with_the_coarse_levels_erased_from_the_cycles(ctx):
+    """the cycles of config 4 stopped at the 40 x 40 level (coarse_level 2: 14 803 unknowns solved exactly on the pivoted fronts, the reference's
+    EraseCoarseLevels) instead of running three more levels of colour steps: the same nonlinear F-cycle -- same Newton steps per level, same
+    flow -- with fewer GMRES iterations per Newton step (profiles/r06_ns_probe.json: 89 -> 24 ms per linear solve)"""
+    nl = 4
+    runs = {}
+    for c in (0, 2):
+        pb = NavierStokesMG(ctx, 10, 10, 0, nl, 0.01)
+        pb.coarse_level = c
+        pb.init()
+        for nu in (0.01, 0.004, 0.002, 0.001):
+            pb.nu = nu
+            assert pb.newton(0, tol=1e-10, max_newton=25)
+        for ig in range(1, nl):
+            pb.prolongator_sol(ig)
+            assert pb.newton(ig, tol=1e-9, max_newton=25, lin_rtol=1e-10, lin_maxit=200)
+        runs[c] = ([sum(1 for h in pb.history if h[0] == l) for l in range(nl)], [h[3] for h in pb.history if h[0] == nl - 1], pb.SOL[-1].to_numpy().copy())
+        pb.prepare(nl - 1)
+        assert pb.RES[nl - 1].l2_norm() < 1e-8
+        pb.destroy()
+    assert runs[0][0] == runs[2][0]                                          # Newton steps per level
+    assert max(runs[2][1]) < min(runs[0][1])                                 # GMRES iterations per Newton step on the finest level
+    assert np.linalg.norm(runs[0][2] - runs[2][2]) <= 1e-8 * np.linalg.norm(runs[0][2])
+
+
 def test_three_dimensional_cavity_matches_oracle(ctx):
     """HEX27 Taylor-Hood (89 x 89 element Jacobians, Vanka patches of up to 376 dofs): lid on the z = hi face moving in x,
     two levels, Newton + multigrid GMRES against the oracle's Newton with exact linear solves"""
