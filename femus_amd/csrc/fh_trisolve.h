@@ -12,6 +12,10 @@ struct fh_tri_s {
   // segments {first level, number of levels, 1 = run of small levels / 0 = one large level}
   int *d_fptr = nullptr, *d_bptr = nullptr;
   std::vector<int> fseg, bseg;
+  // where an entry's operand z_j comes from inside a run (round 6): >= 0 the column j itself (global memory), < 0: -(rank + 1) of row j in the level just before --
+  // the run kernel keeps the values of the previous level in LDS, so the one link of a level's dependency chain that cannot be loaded ahead is an LDS read
+  int *d_fsrc = nullptr, *d_bsrc = nullptr;
+  int *d_flv = nullptr, *d_blv = nullptr;      // per row in level order: {row, first entry, end, diagonal position} (one 16-byte load instead of a chain of three)
   double* d_lu = nullptr;               // ILU(0) factors on A's pattern: strict lower part = L (unit diagonal), rest = U
   int* d_flag = nullptr;
   double* d_t = nullptr;                // symmetric sweep: t = r - L z of the forward half, read by the backward half

@@ -23,8 +23,8 @@
 constexpr int TRI_SMALL = 256;
 
 // rows of the local block only: columns >= m are ghosts (block Jacobi across ranks, as PCSOR / PCILU are local)
-static void schedule(const std::vector<int>& rp, const std::vector<int>& col, int m, bool forward, std::vector<int>& ptr, std::vector<int>& rows) {
-  std::vector<int> lev(m, 0);
+static void schedule(const std::vector<int>& rp, const std::vector<int>& col, int m, bool forward, std::vector<int>& ptr, std::vector<int>& rows, std::vector<int>& lev) {
+  lev.assign(m, 0);
   int nlev = 0;
   if (forward) {
     for (int i = 0; i < m; i++) {
@@ -53,13 +53,13 @@ static void schedule(const std::vector<int>& rp, const std::vector<int>& col, in
 static int tri_fill(fh_mat_t A, fh_tri_t T) {
   T->m = A->m;
   T->A_uid = A->uid;
-  std::vector<int> rows;
-  schedule(A->h_rowptr, fh_hcol(A), A->m, true, T->fptr, rows);
+  std::vector<int> rows, brows, flev, blev;
+  schedule(A->h_rowptr, fh_hcol(A), A->m, true, T->fptr, rows, flev);
   FH_CHECK_HIP(hipMalloc(&T->d_frows, std::max(A->m, 1) * sizeof(int)));
   FH_CHECK_HIP(hipMemcpy(T->d_frows, rows.data(), (size_t)A->m * sizeof(int), hipMemcpyHostToDevice));
-  schedule(A->h_rowptr, fh_hcol(A), A->m, false, T->bptr, rows);
+  schedule(A->h_rowptr, fh_hcol(A), A->m, false, T->bptr, brows, blev);
   FH_CHECK_HIP(hipMalloc(&T->d_brows, std::max(A->m, 1) * sizeof(int)));
-  FH_CHECK_HIP(hipMemcpy(T->d_brows, rows.data(), (size_t)A->m * sizeof(int), hipMemcpyHostToDevice));
+  FH_CHECK_HIP(hipMemcpy(T->d_brows, brows.data(), (size_t)A->m * sizeof(int), hipMemcpyHostToDevice));
   auto segments = [](const std::vector<int>& ptr, std::vector<int>& seg) {
     seg.clear();
     const int nl = (int)ptr.size() - 1;
@@ -77,6 +77,44 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
   };
   segments(T->fptr, T->fseg);
   segments(T->bptr, T->bseg);
+  // operand sources of the run kernel: an entry whose column was computed in the level JUST BEFORE, inside the same run, reads the workgroup's LDS copy of that
+  // level (rank of the column among the level's rows); every other entry reads z in global memory -- written at least two barriers earlier, or by another launch
+  auto sources = [&](const std::vector<int>& ptr, const std::vector<int>& seg, const std::vector<int>& lvrows, const std::vector<int>& lev, bool forward, int** d_src) -> int {
+    const int m = A->m, nl = (int)ptr.size() - 1;
+    std::vector<char> lds_ok(std::max(nl, 1), 0);          // level l may read level l - 1 from LDS: both in one run, l not the run's first level
+    for (size_t q = 0; q < seg.size(); q += 3)
+      if (seg[q + 2])
+        for (int l = seg[q] + 1; l < seg[q] + seg[q + 1]; l++) lds_ok[l] = 1;
+    std::vector<int> rank(m, 0);
+    for (int l = 0; l < nl; l++)
+      for (int k = ptr[l]; k < ptr[l + 1]; k++) rank[lvrows[k]] = k - ptr[l];
+    const std::vector<int>& col = fh_hcol(A);
+    std::vector<int> src(std::max<size_t>(col.size(), 1));
+    for (int i = 0; i < m; i++)
+      for (int k = A->h_rowptr[i]; k < A->h_rowptr[i + 1]; k++) {
+        const int j = col[k];
+        const bool takes = forward ? j < i : (j > i && j < m);
+        src[k] = (takes && lds_ok[lev[i]] && lev[j] == lev[i] - 1) ? -(rank[j] + 1) : j;
+      }
+    FH_CHECK_HIP(hipMalloc(d_src, src.size() * sizeof(int)));
+    FH_CHECK_HIP(hipMemcpy(*d_src, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+  };
+  auto level_rows = [&](const std::vector<int>& lvrows, const std::vector<int>& dp, int** d_lv) -> int {
+    std::vector<int> lv((size_t)std::max(A->m, 1) * 4, 0);
+    for (int k = 0; k < A->m; k++) {
+      const int i = lvrows[k];
+      lv[(size_t)k * 4 + 0] = i;
+      lv[(size_t)k * 4 + 1] = A->h_rowptr[i];
+      lv[(size_t)k * 4 + 2] = A->h_rowptr[i + 1];
+      lv[(size_t)k * 4 + 3] = std::max(dp[i], 0);
+    }
+    FH_CHECK_HIP(hipMalloc(d_lv, lv.size() * sizeof(int)));
+    FH_CHECK_HIP(hipMemcpy(*d_lv, lv.data(), lv.size() * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+  };
+  FH_TRY(sources(T->fptr, T->fseg, rows, flev, true, &T->d_fsrc));
+  FH_TRY(sources(T->bptr, T->bseg, brows, blev, false, &T->d_bsrc));
   FH_CHECK_HIP(hipMalloc(&T->d_fptr, T->fptr.size() * sizeof(int)));
   FH_CHECK_HIP(hipMemcpy(T->d_fptr, T->fptr.data(), T->fptr.size() * sizeof(int), hipMemcpyHostToDevice));
   FH_CHECK_HIP(hipMalloc(&T->d_bptr, T->bptr.size() * sizeof(int)));
@@ -89,6 +127,8 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
     if (q != e && *q == i) dpos[i] = (int)(q - fh_hcol(A).data());
   }
   T->h_diagpos = dpos;
+  FH_TRY(level_rows(rows, dpos, &T->d_flv));
+  FH_TRY(level_rows(brows, dpos, &T->d_blv));
   FH_CHECK_HIP(hipMalloc(&T->d_diagpos, std::max(A->m, 1) * sizeof(int)));
   FH_CHECK_HIP(hipMemcpy(T->d_diagpos, dpos.data(), (size_t)A->m * sizeof(int), hipMemcpyHostToDevice));
   FH_CHECK_HIP(hipMalloc(&T->d_t, std::max(A->m, 1) * sizeof(double)));
@@ -108,7 +148,7 @@ int fh_tri_create(fh_mat_t A, fh_tri_t* out) {
 
 void fh_tri_destroy(fh_tri_t T) {
   if (!T) return;
-  for (void* p : {(void*)T->d_frows, (void*)T->d_brows, (void*)T->d_diagpos, (void*)T->d_lu, (void*)T->d_flag, (void*)T->d_t, (void*)T->d_fptr, (void*)T->d_bptr})
+  for (void* p : {(void*)T->d_frows, (void*)T->d_brows, (void*)T->d_diagpos, (void*)T->d_lu, (void*)T->d_flag, (void*)T->d_t, (void*)T->d_fptr, (void*)T->d_bptr, (void*)T->d_fsrc, (void*)T->d_bsrc, (void*)T->d_flv, (void*)T->d_blv})
     if (p) hipFree(p);
   delete T;
 }
@@ -158,108 +198,153 @@ __global__ __launch_bounds__(256) void k_gs_bwd(const int* __restrict__ rows, in
 
 // ---- runs of small levels in one workgroup: the row bodies of the four kernels above / below, levels separated by a workgroup barrier ----
 struct TriRun {
-  const int *rows, *lptr, *rowptr, *col, *diagpos;
+  const int *rows, *lptr, *rowptr, *src, *diagpos;
+  const int4* lv;
   const double *val, *dinv, *r, *t_in;
   double *z, *t_out;
   int l0, nl, m;
 };
-// What a level costs inside the run is its chain of dependent loads (level pointer -> row id -> row pointers -> columns / values -> z).  Only the last link
-// depends on the level before: everything else of the NEXT level's first 64 rows -- row id, bounds, the first TRI_PF entries per lane, the right-hand side and the
-// diagonal -- is loaded while the current level is computed (two register sets), so that after the barrier a level is one gather of z, the sum and a store.  The
-// lane's entries are added in the same order as in the one-launch-per-level kernels: the same bits.
-constexpr int TRI_PF = 6;
-struct TriPre {
-  int i, rs, re, c[TRI_PF];
-  double v[TRI_PF], e0, e1;
+// What a level costs inside the run is its chain of dependent loads: level pointer -> row id -> row pointers -> operand sources / values -> z.  A two-dimensional
+// stacked system streams 25 MB of rows per sweep through ONE compute unit, so every link is a trip to the L2 or beyond (0.25 us), and a chain loaded one level
+// ahead (round 5) made a level cost the whole chain: 0.7 us.  Round 6: the row id, its bounds and its diagonal position come in ONE 16-byte load from a table in
+// level order (fh_tri_s::d_flv), and a software pipeline THREE levels deep -- in the iteration that computes level l the workgroup also loads that table's rows of
+// level l + 3, the first TRI_PF entries per lane / right-hand side / diagonal of level l + 2 and the global operands of level l + 1 (written two barriers ago or
+// earlier), each from what the previous iteration brought in, into three register sets used round robin (the loop is unrolled by three: no register moves).  The
+// operands computed by the level JUST BEFORE cannot be loaded ahead; they are read from the workgroup's LDS copy of that level (two buffers of TRI_SMALL values;
+// P.src < 0).  After the barrier a level is: LDS reads, the sum, a store.  The lane's entries are added in the same order as in the one-launch-per-level kernels:
+// the same bits.
+constexpr int TRI_PF = 4;
+constexpr int TRI_NONE = -2147483647 - 1;          // no entry (beyond the end of the row)
+struct TriSlot {
+  int i, rs, re, dp, active, c[TRI_PF];
+  double v[TRI_PF], zq[TRI_PF], e0, e1;
 };
-template <int KIND>
-__device__ __forceinline__ void tri_prefetch(const TriRun& P, int base, int n, int grp, int gl, TriPre& Q) {
-  Q.i = -1;
-  Q.rs = Q.re = 0;
-  if (grp >= n) return;
-  const int i = P.rows[base + grp];
-  Q.i = i;
-  Q.rs = P.rowptr[i];
-  Q.re = P.rowptr[i + 1];
-#pragma unroll
-  for (int q = 0; q < TRI_PF; q++) {
-    const int k = Q.rs + gl + 16 * q;
-    Q.c[q] = k < Q.re ? P.col[k] : -1;
-    Q.v[q] = k < Q.re ? P.val[k] : 0.0;
-  }
-  if (gl == 0) {
-    Q.e0 = KIND == 1 ? P.t_in[i] : KIND == 3 ? P.z[i] : P.r[i];
-    Q.e1 = (KIND == 0 || KIND == 1) ? P.dinv[i] : KIND == 3 ? P.val[P.diagpos[i]] : 1.0;
-  }
-}
 template <int KIND>
 __device__ __forceinline__ bool tri_takes(int j, int i, int m) {
   return (KIND == 0 || KIND == 2) ? (j < i) : (j > i && j < m);
 }
+// stage A: this lane group's row of level L (clamped to the run; a group beyond the level repeats its last row and stores nothing)
+__device__ __forceinline__ void tri_stage_a(const TriRun& P, int L, int lend, int grp, TriSlot& S) {
+  const int Lc = min(L, lend - 1);
+  const int b = P.lptr[Lc], n = P.lptr[Lc + 1] - b;
+  S.active = (L < lend && grp < n) ? 1 : 0;
+  const int4 q = P.lv[b + min(grp, n - 1)];
+  S.i = q.x; S.rs = q.y; S.re = q.z; S.dp = q.w;
+}
+// stage C: the lane's first entries, the right-hand side and the diagonal
 template <int KIND>
-__device__ __forceinline__ void tri_store(const TriRun& P, int i, double acc, double e0, double e1) {
+__device__ __forceinline__ void tri_stage_c(const TriRun& P, int gl, TriSlot& S) {
+  if (__builtin_amdgcn_ballot_w64(S.active != 0) == 0ull) return;        // a wave without a row in that level (levels hold 46 rows on average, the workgroup 64 groups)
+  const int i = S.i;
+#pragma unroll
+  for (int q = 0; q < TRI_PF; q++) {
+    const int k = S.rs + gl + 16 * q;
+    const int kk = min(k, max(S.re - 1, S.rs));
+    const int c = P.src[kk];
+    S.c[q] = k < S.re ? c : TRI_NONE;
+    S.v[q] = P.val[kk];
+  }
+  S.e0 = KIND == 1 ? P.t_in[i] : KIND == 3 ? P.z[i] : P.r[i];
+  S.e1 = (KIND == 0 || KIND == 1) ? P.dinv[i] : KIND == 3 ? P.val[S.dp] : 1.0;
+}
+// stage Z: operands from global memory (entries of levels at least two back, or of another launch)
+template <int KIND>
+__device__ __forceinline__ void tri_stage_z(const TriRun& P, TriSlot& S) {
+  if (__builtin_amdgcn_ballot_w64(S.active != 0) == 0ull) return;
+#pragma unroll
+  for (int q = 0; q < TRI_PF; q++) S.zq[q] = P.z[max(S.c[q], 0)];
+}
+template <int KIND>
+__device__ __forceinline__ double tri_store(const TriRun& P, int i, double acc, double e0, double e1) {
+  double zi;
   if (KIND == 0) {
     const double ti = e0 - acc;
     P.t_out[i] = ti;
-    P.z[i] = e1 * ti;
+    zi = e1 * ti;
   } else if (KIND == 1) {
-    P.z[i] = e1 * (e0 - acc);
+    zi = e1 * (e0 - acc);
   } else if (KIND == 2) {
-    P.z[i] = e0 - acc;
+    zi = e0 - acc;
   } else {
-    P.z[i] = (e0 - acc) / e1;
+    zi = (e0 - acc) / e1;
+  }
+  P.z[i] = zi;
+  return zi;
+}
+// level l from slot S; zp / zc: LDS copies of the previous / of this level
+template <int KIND>
+__device__ __forceinline__ void tri_level(const TriRun& P, int l, int gl, int grp, const TriSlot& S, const double* zp, double* zc) {
+  if (S.active) {                                                       // first 64 rows: from the registers the pipeline filled
+    const int i = S.i;
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < TRI_PF; q++) {
+      if (S.c[q] == TRI_NONE) continue;
+      if (S.c[q] < 0) acc += S.v[q] * zp[-S.c[q] - 1];
+      else if (tri_takes<KIND>(S.c[q], i, P.m)) acc += S.v[q] * S.zq[q];
+    }
+    for (int k = S.rs + gl + 16 * TRI_PF; k < S.re; k += 16) {
+      const int j = P.src[k];
+      if (j < 0) acc += P.val[k] * zp[-j - 1];
+      else if (tri_takes<KIND>(j, i, P.m)) acc += P.val[k] * P.z[j];
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (gl == 0) zc[grp] = tri_store<KIND>(P, i, acc, S.e0, S.e1);
+  }
+  const int base = P.lptr[l], n = P.lptr[l + 1] - base;
+  for (int r0 = 64; r0 < n; r0 += 64) {                                 // the rest of a level of more than 64 rows
+    const int rr = r0 + grp;
+    const bool live = rr < n;
+    const int i = live ? P.rows[base + rr] : 0;
+    double acc = 0.0;
+    if (live)
+      for (int k = P.rowptr[i] + gl; k < P.rowptr[i + 1]; k += 16) {
+        const int j = P.src[k];
+        if (j < 0) acc += P.val[k] * zp[-j - 1];
+        else if (tri_takes<KIND>(j, i, P.m)) acc += P.val[k] * P.z[j];
+      }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (live && gl == 0) {
+      const double e0 = KIND == 1 ? P.t_in[i] : KIND == 3 ? P.z[i] : P.r[i];
+      const double e1 = (KIND == 0 || KIND == 1) ? P.dinv[i] : KIND == 3 ? P.val[P.diagpos[i]] : 1.0;
+      zc[rr] = tri_store<KIND>(P, i, acc, e0, e1);
+    }
   }
 }
 
 template <int KIND>      // 0: Gauss-Seidel forward, 1: backward, 2: ILU lower, 3: ILU upper
 __global__ __launch_bounds__(1024) void k_tri_run(TriRun P) {
+  __shared__ double zl[2][TRI_SMALL];             // z of the rows of the previous / of this level, by rank inside the level
   const int gl = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  const int lend = P.l0 + P.nl;
-  int base = P.lptr[P.l0], nxt = P.lptr[P.l0 + 1];
-  TriPre Q;
-  tri_prefetch<KIND>(P, base, nxt - base, grp, gl, Q);
-  for (int l = P.l0; l < lend; l++) {
-    const int n = nxt - base;
-    const int base2 = nxt, nxt2 = (l + 1 < lend) ? P.lptr[l + 2] : nxt;
-    TriPre N;
-    tri_prefetch<KIND>(P, base2, nxt2 - base2, grp, gl, N);          // next level (nothing of it depends on this level's z)
-    if (Q.i >= 0) {                                                     // first 64 rows: from the registers loaded one level ago
-      const int i = Q.i;
-      double acc = 0.0;
-#pragma unroll
-      for (int q = 0; q < TRI_PF; q++)
-        if (Q.c[q] >= 0 && tri_takes<KIND>(Q.c[q], i, P.m)) acc += Q.v[q] * P.z[Q.c[q]];
-      for (int k = Q.rs + gl + 16 * TRI_PF; k < Q.re; k += 16) {
-        const int j = P.col[k];
-        if (tri_takes<KIND>(j, i, P.m)) acc += P.val[k] * P.z[j];
-      }
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-      if (gl == 0) tri_store<KIND>(P, i, acc, Q.e0, Q.e1);
-    }
-    for (int r0 = 64; r0 < n; r0 += 64) {                               // the rest of a level of more than 64 rows
-      const int rr = r0 + grp;
-      const bool live = rr < n;
-      const int i = live ? P.rows[base + rr] : 0;
-      double acc = 0.0;
-      if (live)
-        for (int k = P.rowptr[i] + gl; k < P.rowptr[i + 1]; k += 16) {
-          const int j = P.col[k];
-          if (tri_takes<KIND>(j, i, P.m)) acc += P.val[k] * P.z[j];
-        }
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-      if (live && gl == 0) {
-        const double e0 = KIND == 1 ? P.t_in[i] : KIND == 3 ? P.z[i] : P.r[i];
-        const double e1 = (KIND == 0 || KIND == 1) ? P.dinv[i] : KIND == 3 ? P.val[P.diagpos[i]] : 1.0;
-        tri_store<KIND>(P, i, acc, e0, e1);
-      }
-    }
-    __syncthreads();
-    Q = N;
-    base = base2;
-    nxt = nxt2;
+  const int l0 = P.l0, lend = P.l0 + P.nl;
+  TriSlot S0, S1, S2;
+  // prologue: level l0 complete, l0 + 1 up to its entries, l0 + 2 its rows
+  tri_stage_a(P, l0, lend, grp, S0); tri_stage_a(P, l0 + 1, lend, grp, S1); tri_stage_a(P, l0 + 2, lend, grp, S2);
+  tri_stage_c<KIND>(P, gl, S0); tri_stage_c<KIND>(P, gl, S1);
+  tri_stage_z<KIND>(P, S0);
+  // iteration for level l in slot CUR: operands of l + 1 (Z), entries of l + 2 (C), the level itself, rows of l + 3 (A, into CUR, behind the level's arithmetic).
+  // The LDS buffers alternate with the level, the slots with a period of three: six steps per trip.  (Measured: the kernel is bound by vector-instruction issue --
+  // sixteen waves run the whole step for at most four rows each -- not by the load chain: asking for the rows a full step earlier, through one more register
+  // set, cost 10 %.)
+#define TRI_STEP(PH, CUR, NZ, NC)                                                      \
+  if (l + PH < lend) {                                                                 \
+    tri_stage_z<KIND>(P, NZ);                                                          \
+    tri_stage_c<KIND>(P, gl, NC);                                                      \
+    tri_level<KIND>(P, l + PH, gl, grp, CUR, zl[(PH + 1) & 1], zl[PH & 1]);            \
+    tri_stage_a(P, l + PH + 3, lend, grp, CUR);                                        \
+    __syncthreads();                                                                   \
   }
+  for (int l = l0; l < lend; l += 6) {
+    TRI_STEP(0, S0, S1, S2)
+    TRI_STEP(1, S1, S2, S0)
+    TRI_STEP(2, S2, S0, S1)
+    TRI_STEP(3, S0, S1, S2)
+    TRI_STEP(4, S1, S2, S0)
+    TRI_STEP(5, S2, S0, S1)
+  }
+#undef TRI_STEP
 }
 
 // z = B r, B = one symmetric Gauss-Seidel sweep of A's local block from z = 0
@@ -267,11 +352,11 @@ int fh_tri_ssor_apply(fh_tri_t T, fh_mat_t A, const double* dinv, const double* 
   hipStream_t s = A->ctx->stream;
   const int nf = (int)T->fptr.size() - 1, nb = (int)T->bptr.size() - 1;
   (void)nf; (void)nb;
-  TriRun P = {nullptr, nullptr, A->d_rowptr, A->d_col, T->d_diagpos, A->d_val, dinv, r, T->d_t, z, T->d_t, 0, 0, A->m};
+  TriRun P = {nullptr, nullptr, A->d_rowptr, nullptr, T->d_diagpos, nullptr, A->d_val, dinv, r, T->d_t, z, T->d_t, 0, 0, A->m};
   for (size_t q = 0; q < T->fseg.size(); q += 3) {
     const int l = T->fseg[q];
     if (T->fseg[q + 2]) {
-      P.rows = T->d_frows; P.lptr = T->d_fptr; P.l0 = l; P.nl = T->fseg[q + 1];
+      P.rows = T->d_frows; P.lptr = T->d_fptr; P.src = T->d_fsrc; P.lv = reinterpret_cast<const int4*>(T->d_flv); P.l0 = l; P.nl = T->fseg[q + 1];
       hipLaunchKernelGGL(k_tri_run<0>, dim3(1), dim3(1024), 0, s, P);
     } else {
       const int n = T->fptr[l + 1] - T->fptr[l];
@@ -282,7 +367,7 @@ int fh_tri_ssor_apply(fh_tri_t T, fh_mat_t A, const double* dinv, const double* 
   for (size_t q = 0; q < T->bseg.size(); q += 3) {
     const int l = T->bseg[q];
     if (T->bseg[q + 2]) {
-      P.rows = T->d_brows; P.lptr = T->d_bptr; P.l0 = l; P.nl = T->bseg[q + 1];
+      P.rows = T->d_brows; P.lptr = T->d_bptr; P.src = T->d_bsrc; P.lv = reinterpret_cast<const int4*>(T->d_blv); P.l0 = l; P.nl = T->bseg[q + 1];
       hipLaunchKernelGGL(k_tri_run<1>, dim3(1), dim3(1024), 0, s, P);
     } else {
       const int n = T->bptr[l + 1] - T->bptr[l];
@@ -452,11 +537,11 @@ int fh_tri_ilu_apply(fh_tri_t T, fh_mat_t A, const double* r, double* z) {
   hipStream_t s = A->ctx->stream;
   const int nf = (int)T->fptr.size() - 1, nb = (int)T->bptr.size() - 1;
   (void)nf; (void)nb;
-  TriRun P = {nullptr, nullptr, A->d_rowptr, A->d_col, T->d_diagpos, T->d_lu, nullptr, r, nullptr, z, nullptr, 0, 0, A->m};
+  TriRun P = {nullptr, nullptr, A->d_rowptr, nullptr, T->d_diagpos, nullptr, T->d_lu, nullptr, r, nullptr, z, nullptr, 0, 0, A->m};
   for (size_t q = 0; q < T->fseg.size(); q += 3) {
     const int l = T->fseg[q];
     if (T->fseg[q + 2]) {
-      P.rows = T->d_frows; P.lptr = T->d_fptr; P.l0 = l; P.nl = T->fseg[q + 1];
+      P.rows = T->d_frows; P.lptr = T->d_fptr; P.src = T->d_fsrc; P.lv = reinterpret_cast<const int4*>(T->d_flv); P.l0 = l; P.nl = T->fseg[q + 1];
       hipLaunchKernelGGL(k_tri_run<2>, dim3(1), dim3(1024), 0, s, P);
     } else {
       const int n = T->fptr[l + 1] - T->fptr[l];
@@ -466,7 +551,7 @@ int fh_tri_ilu_apply(fh_tri_t T, fh_mat_t A, const double* r, double* z) {
   for (size_t q = 0; q < T->bseg.size(); q += 3) {
     const int l = T->bseg[q];
     if (T->bseg[q + 2]) {
-      P.rows = T->d_brows; P.lptr = T->d_bptr; P.l0 = l; P.nl = T->bseg[q + 1];
+      P.rows = T->d_brows; P.lptr = T->d_bptr; P.src = T->d_bsrc; P.lv = reinterpret_cast<const int4*>(T->d_blv); P.l0 = l; P.nl = T->bseg[q + 1];
       hipLaunchKernelGGL(k_tri_run<3>, dim3(1), dim3(1024), 0, s, P);
     } else {
       const int n = T->bptr[l + 1] - T->bptr[l];
