@@ -73,6 +73,7 @@ extern "C" int fh_init(int device, fh_ctx_t* out) {
   FH_CHECK_HIP(hipEventCreate(&c->ev1));
   FH_CHECK_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   if (const char* e = getenv("FEMUS_HIP_COARSE_ND")) c->coarse_nd = atoi(e);   // A/B measurements of the dissected coarse solve (blocks; 0: one dense inverse)
+  if (const char* e = getenv("FEMUS_HIP_CARRY")) c->assemble_carry = atoi(e);   // A/B measurements of the carried rows of the fused assembly (0: none)
   if (const char* e = getenv("FEMUS_HIP_POISON")) c->debug_poison = atoi(e);   // whole test suites in poison mode (see debug_poison)
   FH_TRY(fh_reserve_reduction(c, 4096));
   *out = c;
