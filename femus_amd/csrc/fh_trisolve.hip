@@ -466,8 +466,16 @@ int fh_tri_ilu_factor(fh_tri_t T, fh_mat_t A) {
   // the row being eliminated lives in LDS, sixteen rows per workgroup: 128 bytes per entry of the longest row.  512 entries fit the 64 kB a kernel gets
   // without asking; up to 1 200 (stacked three-dimensional systems after a Galerkin product) the kernel asks for more of the CU's 160 kB
   FH_REQUIRE(maxrow <= 1200, "ILU(0): a row with %d entries (at most 1200 are served)", maxrow);
-  const bool lcol = maxrow <= 800;
+  // what the device grants a workgroup on request (160 kB on MI355X): the columns join the values in LDS only where both fit, and a row too long even for the
+  // values alone is refused with the limit in the message
+  int lds_max = 0, lds_optin = 0;
+  if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess) lds_max = 0;
+  if (hipDeviceGetAttribute(&lds_optin, hipDeviceAttributeSharedMemPerBlockOptin, c->device) != hipSuccess) lds_optin = 0;
+  (void)hipGetLastError();
+  lds_max = std::max(std::max(lds_max, lds_optin), 64 * 1024);
+  const bool lcol = maxrow <= 800 && (size_t)16 * maxrow * (sizeof(double) + sizeof(int)) <= (size_t)lds_max;
   const size_t lds = (size_t)16 * maxrow * (sizeof(double) + (lcol ? sizeof(int) : 0));
+  FH_REQUIRE(lds <= (size_t)lds_max, "ILU(0): a row with %d entries needs %zu bytes of LDS per workgroup, the device grants %d", maxrow, lds, lds_max);
   if (lds > 64 * 1024)
     FH_CHECK_HIP(hipFuncSetAttribute(lcol ? reinterpret_cast<const void*>(&k_ilu_factor<true>) : reinterpret_cast<const void*>(&k_ilu_factor<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
