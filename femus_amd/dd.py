@@ -255,6 +255,63 @@ def build_level_plans(part, comm, gids, owners, need_masks):
     return plans
 
 
+def stack_plan(plan, nv, nranks):
+    """The exchange plan of `nv` variables of one family stacked as the reference stacks a system -- rank by rank, variable by variable inside a rank
+    (KKoffset, LinearEquation.cpp:212-237; fh_dd_system_offsets / fh_dd_system_dofs) -- from the plan of ONE variable.  Local layout of a stacked vector:
+    owned = [var 0 | var 1 | ...] (n_owned each), ghosts grouped by source rank and, inside a rank, by variable: exactly what the sender's stacked owned
+    block delivers, so the plan is again {send_counts, send_idx, recv_counts} and runs through the same fh_halo_* objects.  Returns a LevelPlan with, in
+    addition, col_of[k] = stacked local index of every scalar local index ([owned | ghost] numbering) of variable k."""
+    S = LevelPlan()
+    n0, ng = plan.n_owned, plan.n_ghost
+    sc, rc = np.asarray(plan.send_counts, dtype=np.int64), np.asarray(plan.recv_counts, dtype=np.int64)
+    soff, goff = np.concatenate([[0], np.cumsum(sc)]), np.concatenate([[0], np.cumsum(rc)])
+    S.nv, S.base = nv, plan
+    S.n_owned, S.n_ghost = nv * n0, nv * ng
+    S.send_counts, S.recv_counts = (sc * nv).astype(np.int32), (rc * nv).astype(np.int32)
+    S.send_idx = np.concatenate([np.asarray(plan.send_idx[soff[r]:soff[r + 1]], dtype=np.int64) + k * n0 for r in range(nranks) for k in range(nv)]
+                                + [np.zeros(0, np.int64)]).astype(np.int32)
+    src = np.repeat(np.arange(nranks), rc)                              # source rank of every scalar ghost
+    q = np.arange(ng, dtype=np.int64)
+    S.col_of = []
+    for k in range(nv):
+        c = np.empty(n0 + ng, dtype=np.int64)
+        c[:n0] = k * n0 + np.arange(n0)
+        c[n0:] = nv * n0 + nv * goff[src] + k * rc[src] + (q - goff[src])
+        S.col_of.append(c)
+    # the reference's global system numbering: every variable has the dof offsets of the one plan
+    dof_offset = np.tile(np.asarray(plan.offsets, dtype=np.int64), (nv, 1))
+    kk, idx = system_offsets(dof_offset)
+    S.kk_offset, S.kk_index = kk, idx
+    S.offsets = np.concatenate([kk[0], [kk[nv][nranks - 1]]]).astype(np.int64)            # rank r owns the system rows [KKoffset[0][r], KKoffset[nv][r])
+    gg = np.empty(nv * ng, dtype=np.int64)
+    for k in range(nv):
+        rows, owner = system_dofs(dof_offset, kk, k, plan.ghost_global)
+        assert np.array_equal(owner, src)
+        gg[S.col_of[k][n0:] - nv * n0] = rows
+    S.ghost_global = gg
+    return S
+
+
+def stack_matrix(M, row_plan, col_plan, nv, coupling=None):
+    """block matrix of a stacked system in the stacked local numbering from the scalar owned-rows matrix M (scipy CSR, row_plan.n_owned x (col_plan.n_owned +
+    col_plan.n_ghost)): block (k, k2) = coupling[k][k2] * M (default: the identity -- nv uncoupled copies)"""
+    import scipy.sparse as sp
+    C = M.tocoo()
+    n0r = row_plan.base.n_owned
+    rows, cols, vals = [], [], []
+    for k in range(nv):
+        for k2 in range(nv):
+            w = (1.0 if k == k2 else 0.0) if coupling is None else float(coupling[k][k2])
+            if w == 0.0:
+                continue
+            rows.append(C.row + k * n0r)
+            cols.append(col_plan.col_of[k2][C.col])
+            vals.append(w * C.data)
+    S = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nv * n0r, col_plan.n_owned + col_plan.n_ghost))
+    S.sort_indices()
+    return S
+
+
 def needed_columns(A_full, P_full, owners, me):
     """per level: the non-owned local nodes whose values the owned rows of A_l, P_{l+1}, R_l read"""
     nl = len(A_full)
@@ -567,6 +624,7 @@ class DistributedPoisson:
         import time
         from .poisson import PoissonMG
         self.ctx, self.comm = ctx, comm
+        self.transport, self.halo_comm = transport, halo_comm
         # coarse_mesh: ANY HEX27 / QUAD9 coarse mesh (a Gambit file, a box whose elements come in any order), the same object on every
         # rank.  Its elements are partitioned natively (fh_mesh_partition: the METIS_PartMeshDual of MeshMetisPartitioning.cpp:71-113;
         # `partition` overrides it), children inherit (:143-155); a rank's extended mesh = its elements + the ring of elements sharing a
@@ -909,3 +967,98 @@ class DistributedPoisson:
     def solve(self, outer="gmres", rtol=1e-10, maxit=60):
         self.zero_boundary_residuals()
         return self.mg.solve(self.RES, self.EPSC, outer=outer, rtol=rtol, maxit=maxit)
+
+
+class DistributedStacked:
+    """`nv` variables stacked the way LinearEquation stacks a system on several ranks (rank by rank, variable by variable inside a rank: KKoffset,
+    LinearEquation.cpp:212-237) and driven through the SAME device machinery as DistributedPoisson: exchange plans (fh_halo_*), owned-rows operators over
+    [owned | ghost] columns, replicated levels below, distributed cycle and Krylov solver (fh_mg_*).  Built from a prepared DistributedPoisson `dp` (box
+    partition): block (k, k) of every operator = scale[k] times the scalar one -- `nv` Poisson variables; the plans, the numbering and the cycle do not care
+    what couples the blocks.  What a multi-variable application (Navier-Stokes: Missing in DESIGN section 8) adds is its own assembly, not another decomposition."""
+
+    def __init__(self, dp, nv=2, scale=None):
+        import scipy.sparse as sp
+        assert not dp.general, "stacked systems: box partitions"
+        ctx, comm = dp.ctx, dp.comm
+        rank, nranks = dp.part.rank, dp.part.nranks
+        self.dp, self.nv, self.ctx = dp, nv, ctx
+        w = [1.0] * nv if scale is None else [float(v) for v in scale]
+        coup = [[(w[k] if k == k2 else 0.0) for k2 in range(nv)] for k in range(nv)]
+        nl = dp.nl
+        self.plans = [stack_plan(pl, nv, nranks) for pl in dp.H.plans]
+        pl = self.plans
+        self.A = [ctx.matrix_scipy(stack_matrix(dp.A[l].to_scipy(), pl[l], pl[l], nv, coup)) for l in range(nl)]
+        self.P = [None] + [ctx.matrix_scipy(stack_matrix(dp.P[l].to_scipy(), pl[l], pl[l - 1], nv)) for l in range(1, nl)]
+        self.R = [None] + [ctx.matrix_scipy(stack_matrix(dp.R[l].to_scipy(), pl[l - 1], pl[l], nv)) for l in range(1, nl)]
+        self.halos = []
+        if dp.transport == "host":
+            hc = dp.halo_comm if dp.halo_comm is not None else comm
+            for q in pl:
+                self.halos.append(capi.Halo.host(ctx, rank, nranks, hc, q.send_counts, q.send_idx, q.recv_counts, parent=self.halos[0] if self.halos else None))
+        else:
+            uid = comm.bcast_obj(capi.Halo.unique_id() if rank == 0 else None)
+            for q in pl:
+                self.halos.append(capi.Halo(ctx, rank, nranks, uid, q.send_counts, q.send_idx, q.recv_counts, parent=self.halos[0] if self.halos else None))
+
+        def rows_by_var(M, n_rows_one, n_cols_one):          # owned rows of every variable x replicated (global) columns [var 0 | var 1 | ...]
+            C = M.to_scipy().tocoo()
+            r = np.concatenate([C.row + k * n_rows_one for k in range(nv)])
+            c = np.concatenate([C.col + k * n_cols_one for k in range(nv)])
+            return sp.csr_matrix((np.tile(C.data, nv), (r, c)), shape=(nv * n_rows_one, nv * n_cols_one))
+
+        bd = lambda M: sp.block_diag([w[k] * M.to_scipy() for k in range(nv)]).tocsr()
+        self.mg = capi.Multigrid(ctx, nl + 1)
+        mg = self.mg
+        self.rep = []
+        if dp.n_replicated == 2:
+            n_g0 = dp.A_g0.m()
+            A2, Ag = ctx.matrix_scipy(bd(dp.A_rep2)), ctx.matrix_scipy(bd(dp.A_g0))
+            Pg = ctx.matrix_scipy(sp.block_diag([dp.Pg.to_scipy()] * nv).tocsr())
+            P1 = rows_by_var(dp.P1_rep, dp.H.plans[1].n_owned, n_g0)
+            P1d, R1d = ctx.matrix_scipy(P1), ctx.matrix_scipy(P1.T.tocsr())
+            self.rep = [A2, Ag, Pg, P1d, R1d]
+            mg.set_level(0, A2, None, None, 0, dp.omega, 1, 0)
+            mg.set_level(1, Ag, Pg, None, 0, dp.omega, dp.npre, dp.npost)
+            mg.set_level(2, self.A[1], P1d, R1d, 0, dp.omega, dp.npre, dp.npost)
+            mg.set_level_distributed(2, self.halos[1], True)
+            for l in range(2, nl):
+                mg.set_level(l + 1, self.A[l], self.P[l], self.R[l], 0, dp.omega, dp.npre, dp.npost)
+                mg.set_level_distributed(l + 1, self.halos[l], False)
+        else:
+            n_rep = dp.A_rep.m()
+            Ar = ctx.matrix_scipy(bd(dp.A_rep))
+            P0 = rows_by_var(dp.P_rep, dp.H.plans[0].n_owned, n_rep)
+            P0d, R0d = ctx.matrix_scipy(P0), ctx.matrix_scipy(P0.T.tocsr())
+            self.rep = [Ar, P0d, R0d]
+            mg.set_level(0, Ar, None, None, 0, dp.omega, 1, 0)
+            mg.set_level(1, self.A[0], P0d, R0d, 0, dp.omega, dp.npre, dp.npost)
+            mg.set_level_distributed(1, self.halos[0], True)
+            for l in range(1, nl):
+                mg.set_level(l + 1, self.A[l], self.P[l], self.R[l], 0, dp.omega, dp.npre, dp.npost)
+                mg.set_level_distributed(l + 1, self.halos[l], False)
+        mg.setup()
+        top = pl[-1]
+        self.n_owned = top.n_owned
+        assert int(top.offsets[-1]) < 2 ** 31
+        mk = lambda: ctx.vector(int(top.offsets[-1]), top.n_owned, int(top.offsets[rank]), top.ghost_global.astype(np.int32))
+        self.RES, self.EPSC = mk(), mk()
+
+    def set_rhs(self, parts):
+        """the owned entries of every variable's right-hand side, one array per variable"""
+        n0 = self.dp.n_owned
+        v = np.zeros(self.plans[-1].n_owned)
+        for k, b in enumerate(parts):
+            v[k * n0:(k + 1) * n0] = b
+        self.RES.upload(v)
+
+    def solve(self, outer="gmres", rtol=1e-10, maxit=60):
+        return self.mg.solve(self.RES, self.EPSC, outer=outer, rtol=rtol, maxit=maxit)
+
+    def vcycle(self):
+        self.mg.vcycle(self.RES, self.EPSC)
+
+    def destroy(self):
+        self.mg.destroy()
+        for m in self.A + self.P + self.R + self.rep + [self.RES, self.EPSC] + self.halos:
+            if m is not None:
+                m.destroy()

@@ -144,3 +144,24 @@ def vcycle_numpy(comm, H, b_owned, omega=2. / 3., npre=2, npost=2):
     return x[nl - 1][:H.plans[nl - 1].n_owned].copy()
 
 
+
+
+def stack_hierarchy(H, nv, nranks, scale=None):
+    """the host hierarchy of `nv` stacked variables (femus_amd.dd.stack_plan / stack_matrix: the reference's rank-by-rank, variable-by-variable system
+    numbering) from the hierarchy of one: block-diagonal operators and transfers (variable k's operator scaled by scale[k]), the replicated level stacked
+    [var 0 | var 1 | ...] on every rank.  The executor above runs it unchanged."""
+    from femus_amd.dd import stack_plan, stack_matrix
+    nl = len(H.A)
+    S = HostHierarchy()
+    S.plans = [stack_plan(pl, nv, nranks) for pl in H.plans]
+    coup = None if scale is None else [[(scale[k] if k == k2 else 0.0) for k2 in range(nv)] for k in range(nv)]
+    S.A = [stack_matrix(H.A[l], S.plans[l], S.plans[l], nv, coup) for l in range(nl)]
+    S.P = [None] + [stack_matrix(H.P[l], S.plans[l], S.plans[l - 1], nv) for l in range(1, nl)]
+    S.R = [None] + [stack_matrix(H.R[l], S.plans[l - 1], S.plans[l], nv) for l in range(1, nl)]
+    S.bdc_owned = [np.concatenate([H.bdc_owned[l] + k * H.plans[l].n_owned for k in range(nv)]) for l in range(nl)]
+    S.rep = None
+    if H.rep is not None:
+        w = [1.0] * nv if scale is None else list(scale)
+        S.rep = {"A": sp.block_diag([w[k] * H.rep["A"] for k in range(nv)]).tocsr(), "P": sp.block_diag([H.rep["P"]] * nv).tocsr(),
+                 "R": sp.block_diag([H.rep["R"]] * nv).tocsr(), "n": nv * H.rep["n"]}
+    return S

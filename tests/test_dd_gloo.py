@@ -111,6 +111,72 @@ def test_distributed_vcycle_matches_serial_oracle(tmp_path, world):
     assert seen == ref.size                                                              # every global node owned exactly once
 
 
+def _stacked_worker(rank, world, port, nb, nlevels, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from femus_amd import dd
+        import dd_host_executor as hx
+        part = dd.BoxPartition(world, rank)
+        comm = dd.TorchComm()
+        meshes = dd.local_meshes(part, nb, nlevels)
+        oms, A, P, bdc, b = full_local_operators(meshes)
+        m_rep, m_g0 = dd.replicated_level(part, nb)
+        om_rep, om_g0 = oracle_mesh(m_rep), oracle_mesh(m_g0)
+        om_rep.child_elem = m_rep.child_elems().astype(np.int64)
+        bdc_rep, bdc_g0 = fo.dirichlet_dofs(om_rep, "biquadratic"), fo.dirichlet_dofs(om_g0, "biquadratic")
+        P_g0 = fo.zero_interpolator_dirichlet(fo.build_prolongator(om_rep, om_g0, "biquadratic"), bdc_g0, bdc_rep)
+        H = hx.build_host_hierarchy(part, comm, nb, meshes, A, P, bdc, (m_rep, m_g0, P_g0, bdc_rep))
+        nv = 2
+        S = hx.stack_hierarchy(H, nv, world, scale=[1.0, 0.5])
+        top, stop = H.plans[-1], S.plans[-1]
+        n0, ng = top.n_owned, top.n_ghost
+        # the system numbering is the reference's (LinearEquation.cpp:212-237, restated loop for loop in the oracle): rank by rank, variable by variable
+        KK, KKIndex = fo.system_offsets([list(top.offsets)] * nv)
+        assert np.array_equal(np.array(KK), stop.kk_offset) and list(stop.kk_index) == KKIndex
+        assert stop.offsets[rank + 1] - stop.offsets[rank] == nv * n0 and stop.offsets[-1] == nv * top.offsets[-1]
+        for k in range(nv):          # GetSystemDof of every ghost of every variable (LinearEquation.cpp:76-85)
+            for q in range(0, ng, max(1, ng // 7)):
+                assert stop.ghost_global[stop.col_of[k][n0 + q] - nv * n0] == fo.system_dof([list(top.offsets)] * nv, KK, k, int(top.ghost_global[q]))[0]
+        # the stacked exchange delivers, for every ghost, the owner's entry of the same system row
+        v = np.zeros(stop.n_owned + stop.n_ghost)
+        v[:stop.n_owned] = (stop.offsets[rank] + np.arange(stop.n_owned)).astype(np.float64)
+        hx.halo_update(comm, stop, v)
+        assert np.array_equal(v[stop.n_owned:], stop.ghost_global.astype(np.float64))
+        # one V-cycle of the stacked system [A u = b, 0.5 A w = 2.5 b]
+        bs = np.concatenate([b[top.owned], 2.5 * b[top.owned]])
+        x = hx.vcycle_numpy(comm, S, bs)
+        np.savez(out % rank, gid=top.gid[top.owned], x0=x[:n0], x1=x[n0:], n_ghost=stop.n_ghost)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_stacked_two_variable_system_through_the_decomposition(tmp_path, world):
+    """two variables stacked as LinearEquation stacks them (KKoffset per rank, LinearEquation.cpp:212-237): the planner's exchange plan, operators and transfers
+    of ONE variable carried to the stacked numbering (femus_amd.dd.stack_plan / stack_matrix), the distributed cycle run on the stacked system -- every
+    variable's part equals the serial oracle cycle of its own equation"""
+    import torch.multiprocessing as mp
+    nb, nlevels = 2, 2
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_stacked_worker, args=(world, _free_port(), nb, nlevels, out), nprocs=world, join=True)
+    from femus_amd import dd
+    part = dd.BoxPartition(world, 0)
+    p = part.p
+    H = fo.build_poisson_hierarchy(p[0] * nb // 2, p[1] * nb // 2, p[2] * nb // 2, nlevels + 1, "biquadratic", ONE, hi=tuple(float(v) for v in p))
+    ref = fo.vcycle(H, nlevels, H.b)                    # A u = b; the second variable solves 0.5 A w = 2.5 b: its cycle gives 5 times the first's
+    gid_ser, _ = dd.node_keys(H.meshes[-1].coords, nlevels - 1, nb, part)
+    srt = np.argsort(gid_ser)
+    for r in range(world):
+        d = np.load(out % r)
+        pos = srt[np.searchsorted(gid_ser[srt], d["gid"])]
+        assert np.linalg.norm(d["x0"] - ref[pos]) <= 1e-11 * np.linalg.norm(ref)
+        assert np.linalg.norm(d["x1"] - 5.0 * ref[pos]) <= 1e-11 * np.linalg.norm(5.0 * ref)
+        assert d["n_ghost"] > 0
+
+
 def _sock_worker(rank, world, port, out):
     from femus_amd import dd
     comm = dd.SocketComm(rank, world, "127.0.0.1", port)

@@ -122,6 +122,56 @@ def test_distributed_repreparation_gives_the_serial_galerkin_operators(tmp_path,
         assert np.linalg.norm(d["x"] - ref_cycle[pos]) <= 1e-10 * np.linalg.norm(ref_cycle)
 
 
+def _stacked_worker(rank, world, port, nb, nlevels, out, n_replicated):
+    try:
+        import femus_amd as fa
+        from femus_amd import dd as ddm
+        comm = ddm.SocketComm(rank, world, "127.0.0.1", port)
+        ctx = fa.Context(0)
+        dp = ddm.DistributedPoisson(ctx, comm, world, rank, nb=nb, nlevels=nlevels, transport="host", n_replicated=n_replicated)
+        dp.assemble(); dp.set_penalty_top(); dp.zero_boundary_residuals()
+        b = dp.RES.to_numpy()[:dp.n_owned].copy()
+        ds = ddm.DistributedStacked(dp, nv=2, scale=[1.0, 0.5])
+        top = ds.plans[-1]
+        # the vectors carry the reference's system numbering: this rank owns [KKoffset[0][rank], KKoffset[2][rank]), a ghost is reached by its system row
+        assert ds.RES.size() == 2 * int(dp.H.plans[-1].offsets[-1]) and ds.RES.local_size() == 2 * dp.n_owned
+        its_s, _ = dp.solve(outer="gmres", rtol=1e-12)
+        x = dp.EPSC.to_numpy()[:dp.n_owned].copy()
+        ds.set_rhs([b, 2.5 * b])
+        its, rn = ds.solve(outer="gmres", rtol=1e-12)
+        xs = ds.EPSC.to_numpy()[:2 * dp.n_owned]
+        # ghost refresh of the stacked vector through the device exchange plan: every ghost gets its owner's entry of the same system row
+        v = ctx.vector(int(top.offsets[-1]), top.n_owned, int(top.offsets[rank]), top.ghost_global.astype(np.int32))
+        v.upload((top.offsets[rank] + np.arange(top.n_owned)).astype(np.float64))
+        ds.halos[-1].update(v)
+        ghosts = v.to_numpy_with_ghosts()[top.n_owned:] if hasattr(v, "to_numpy_with_ghosts") else None
+        np.savez(out % rank, x=x, x0=xs[:dp.n_owned], x1=xs[dp.n_owned:], its=its, its_s=its_s, n_ghost=top.n_ghost,
+                 ghosts=np.zeros(0) if ghosts is None else ghosts, ghost_global=top.ghost_global)
+        comm.barrier()
+        comm.close()
+    except BaseException:
+        _record_worker_failure("stacked", rank, world)
+        raise
+
+
+@pytest.mark.parametrize("world,n_replicated", [(2, 2), (4, 2), (2, 1)])
+def test_stacked_two_variable_system_on_the_distributed_device_path(tmp_path, world, n_replicated):
+    """two variables stacked as LinearEquation stacks a system over the ranks (KKoffset, LinearEquation.cpp:212-237; fh_dd_system_offsets) run through the
+    device machinery of the decomposition -- stacked exchange plans in fh_halo_*, owned-rows block operators, replicated levels, distributed GMRES around the
+    distributed V-cycle: the solve of [A u = b, 0.5 A w = 2.5 b] gives u = the scalar distributed solve and w = 5 u on every rank"""
+    import torch.multiprocessing as mp
+    nb, nlevels = 2, 3
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_stacked_worker, args=(world, _free_port(), nb, nlevels, out, n_replicated), nprocs=world, join=True)
+    for r in range(world):
+        d = np.load(out % r)
+        assert d["n_ghost"] > 0
+        assert np.linalg.norm(d["x0"] - d["x"]) <= 1e-9 * np.linalg.norm(d["x"])
+        assert np.linalg.norm(d["x1"] - 5.0 * d["x"]) <= 1e-9 * np.linalg.norm(5.0 * d["x"])
+        if d["ghosts"].size:
+            assert np.array_equal(d["ghosts"], d["ghost_global"].astype(np.float64))
+
+
 def _free_port():
     import socket
     s = socket.socket()
