@@ -76,6 +76,8 @@ struct fh_assembler_s {
   unsigned short* d_cl_gtab = nullptr;      // [8][27 * 27] template entry that child j OWNS at (local row, local column), 0xffff = another child's (fh_assembler_galerkin from the macro rows)
   bool cl_all_rows = false;                 // every row of every cluster lies in the matrix (no ghost rows, no sink): the macro rows can be read back
   bool macro_valid = false;                 // the matrix cl_val_base and the partial-row buffer hold the macro rows of the last assembly
+  fh_mat_t cl_mat_of_macro = nullptr;       // the matrix of that assembly
+  uint64_t macro_val_gen = 0;               // ... as long as nobody but SetPenalty has written the matrix since (fh_mat_s::val_gen)
   double* d_Pbuf = nullptr;
   int* d_cl_prow = nullptr;                 // rows of the second pass
   unsigned* d_cl_pstart = nullptr;          // [nprow + 1] their segments of the partial-row buffer
@@ -3568,6 +3570,8 @@ static int assemble_poisson_core(fh_assembler_t as, fh_vec_t sol, int source_kin
       FH_TRY(launch_cluster(as, P, A, res->d));
       A->at_valid = false;
       as->macro_valid = !(as->ctx->asm_debug & (2 | 4 | 8));     // (timing aids leave rows unwritten)
+      as->macro_val_gen = ++A->val_gen;
+      as->cl_mat_of_macro = A;
       return 0;
     }
     as->kbuf_valid = true;
@@ -4286,8 +4290,11 @@ extern "C" int fh_assembler_galerkin(fh_assembler_t fas, fh_assembler_t cas, con
   }
   // source of the fine element contributions: the macro rows the fused assembly left in the fine matrix and the partial-row buffer (nothing to re-create,
   // the fused path stays the path of the next assembly), or the element-row buffer of the two-pass path
+  // (the macro rows live in the user-visible fine matrix: any writer of its values since the assembly other than the Dirichlet-row replacement -- a scaling, an
+  //  in-place product, staged adds -- sends the product back to the element rows, which are re-created from the arguments of the last assembly)
   const bool from_macro = nc == 27 && c->galerkin_mfma && c->galerkin_macro && fas->fused && fas->last_path == 1 && fas->macro_valid && fas->cl_all_rows &&
-                          fas->d_cl_gtab && cas->gal_children_in_order && fas->cl_ncl == cas->nel;
+                          fas->d_cl_gtab && cas->gal_children_in_order && fas->cl_ncl == cas->nel && fas->cl_mat_of_macro != nullptr &&
+                          fas->cl_mat_of_macro->d_val == fas->cl_val_base && fas->cl_mat_of_macro->val_gen == fas->macro_val_gen;
   if (!from_macro) {
     fas->rows_used_since = true;                              // (the next assembly of this level keeps its element rows)
     if (!fas->kbuf_valid) FH_TRY(element_rows_again(fas));     // the fused assembly kept no element rows: pass 1 of the two-pass path with the last arguments

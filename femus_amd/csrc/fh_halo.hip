@@ -211,6 +211,7 @@ extern "C" int fh_halo_allreduce_vec(fh_halo_t h, fh_vec_t v) {
 // sum over the ranks of the values of a matrix with the SAME pattern on every rank (the replicated level's operator: every rank adds
 // its share P^T A_0 P; the reference gets the same sum from MatPtAP over the distributed rows, PetscMatrix.cpp:733-751)
 extern "C" int fh_halo_allreduce_mat(fh_halo_t h, fh_mat_t A) {
+  if (A) A->val_gen++;
   FH_REQUIRE(h && A, "fh_halo_allreduce_mat: null argument");
   if (halo_inert(h) || A->nnz == 0) return 0;
   h->n_allreduce++;

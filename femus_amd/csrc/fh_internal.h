@@ -147,6 +147,8 @@ struct fh_mat_s {
   fh_ctx_t ctx = nullptr;
   fh_stage_s* stage = nullptr;
   uint64_t uid = 0;                   // unique per created matrix (never reused, unlike the address): keys caches built from the pattern
+  uint64_t val_gen = 0;               // bumped by every writer of the values except the Dirichlet-row replacement (fh_mat_zero_rows*): whoever keeps something derived from
+                                      // the values of one moment (the macro rows of a fused assembly, read back by fh_assembler_galerkin) compares it
   int m = 0, n = 0, nnz = 0;
   int* d_rowptr = nullptr;
   int* d_col = nullptr;

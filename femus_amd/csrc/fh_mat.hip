@@ -386,12 +386,14 @@ int fh_mat_build_rowblocks(fh_mat_t A, int tile) {
 }
 
 extern "C" int fh_mat_zero(fh_mat_t A) {
+  if (A) A->val_gen++;
   FH_CHECK_HIP(hipMemsetAsync(A->d_val, 0, (size_t)A->nnz * sizeof(double), A->ctx->stream));
   A->at_valid = false;
   return 0;
 }
 
 extern "C" int fh_mat_set_values_csr(fh_mat_t A, const double* val) {
+  if (A) A->val_gen++;
   FH_CHECK_HIP(hipMemcpyAsync(A->d_val, val, (size_t)A->nnz * sizeof(double), hipMemcpyHostToDevice, A->ctx->stream));
   FH_CHECK_HIP(hipStreamSynchronize(A->ctx->stream));
   A->at_valid = false;
@@ -450,11 +452,13 @@ static int apply_entries(fh_mat_t A, const std::vector<int>& pos, const double* 
 
 // immediate form of the staged add (fh_stage.hip): the block is on the device when the call returns
 extern "C" int fh_mat_add_block(fh_mat_t A, int nrow, const int* rows, int ncol, const int* cols, const double* vals) {
+  if (A) A->val_gen++;
   FH_TRY(fh_mat_stage_block(A, nrow, rows, ncol, cols, vals));
   return fh_mat_flush(A);
 }
 
 extern "C" int fh_mat_insert_row(fh_mat_t A, int row, int ncols, const int* cols, const double* vals) {
+  if (A) A->val_gen++;
   FH_REQUIRE(row >= 0 && row < A->m, "fh_mat_insert_row: row %d out of range", row);
   std::vector<int> pos(ncols);
   for (int j = 0; j < ncols; j++) {
@@ -584,6 +588,7 @@ __global__ __launch_bounds__(256) void k_gather_map(double* __restrict__ dst, co
 }
 
 extern "C" int fh_mat_gather_values(fh_mat_t dst, fh_mat_t src, fh_index_t map) {
+  if (dst) dst->val_gen++;
   FH_REQUIRE(dst && src && map, "fh_mat_gather_values: null argument");
   FH_REQUIRE(map->n == dst->nnz && map->max_index < src->nnz, "fh_mat_gather_values: map has %d entries (target nnz %d), largest source %d (source nnz %d)",
              map->n, dst->nnz, map->max_index, src->nnz);
@@ -753,6 +758,7 @@ extern "C" int fh_vec_gather(fh_vec_t dst, fh_vec_t src, fh_index_t map) {
 }
 
 extern "C" int fh_mat_zero_cols(fh_mat_t A, int n, const int* cols) {
+  if (A) A->val_gen++;
   if (n <= 0 || A->nnz == 0) return 0;
   fh_ctx_t c = A->ctx;
   for (int i = 0; i < n; i++) FH_REQUIRE(cols[i] >= 0 && cols[i] < A->n, "fh_mat_zero_cols: column %d out of range", cols[i]);

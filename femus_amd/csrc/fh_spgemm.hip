@@ -606,6 +606,7 @@ static int triple_product(fh_mat_t R, fh_mat_t A, fh_mat_t P, fh_mat_t* Cio, con
   }
   if (plan->map_ap.pa || plan->map_ap.slot) FH_TRY(spgemm_numeric_map(A, P, plan->AP, plan->map_ap)); else FH_TRY(spgemm_numeric(A, P, plan->AP));
   if (plan->map_c.pa || plan->map_c.slot) FH_TRY(spgemm_numeric_map(R, plan->AP, C, plan->map_c)); else FH_TRY(spgemm_numeric(R, plan->AP, C));
+  C->val_gen++;
   return 0;
 }
 

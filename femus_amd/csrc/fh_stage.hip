@@ -301,6 +301,7 @@ static int stage_finish(fh_stage_s* s, const char* who) {
 }
 
 extern "C" int fh_mat_flush(fh_mat_t A) {
+  if (A) A->val_gen++;
   FH_REQUIRE(A, "fh_mat_flush: null matrix");
   if (!A->stage || !A->stage->pending) return 0;
   FH_TRY(mat_issue(A));

@@ -291,3 +291,22 @@ def test_elementwise_galerkin_from_carried_rows(ctx, carry):
     assert abs(vals[0][-1] - vals[carry][-1]).max() == 0.0
     for a, b in zip(vals[0][:-1], vals[carry][:-1]):
         assert abs(a - b).max() <= 1e-13 * abs(b).max()
+
+
+def test_galerkin_product_does_not_read_macro_rows_somebody_else_has_written(ctx):
+    """the macro rows of a fused assembly live in the user-visible fine matrix: after any writer of its values other than SetPenalty (here: the values
+    replaced by twice themselves) the element-wise Galerkin product goes back to the element rows of the assembly -- the coarse operators are the ones of
+    the assembled operator, not of what the matrix holds now (fh_mat_s::val_gen)"""
+    from femus_amd.poisson import PoissonMG
+    pb = PoissonMG(ctx, 2, 2, 2, 3).init()
+    pb.assemble()
+    pb.prepare()
+    ref = [pb.A[l].to_scipy() for l in range(pb.nlevels - 1)]
+    pb.assemble()
+    assert pb.asm[-1].last_path() == "fused"
+    top = pb.A[-1]
+    top.set_values(2.0 * top.values())
+    pb.level_operators()
+    for l in range(pb.nlevels - 1):
+        assert abs(pb.A[l].to_scipy() - ref[l]).max() <= 1e-13 * abs(ref[l]).max()
+    pb.destroy()
