@@ -2305,12 +2305,28 @@ __global__ __launch_bounds__(256) void k_cluster_maps(int ncl, int ns, int nm, c
             if (pos < 0 || pos > 127) { atomicExch(err, 1); pos = 0; }
             pos_b = (unsigned)pos;
             bool later = false;
-            for (int a = aptr[g]; a < aptr[g + 1]; a++) {     // the other clusters around node g: does one of their elements hold `target` too?
-              const int e = aei[a] >> 5, cc = e / CL_NE;
-              if (cc == c) continue;
-              bool has = false;
-              for (int n = 0; n < 27; n++) has = has || elem_dof[(size_t)e * nloc + n] == target;
-              if (has) { if (cc < c) acc = 1; else later = true; }
+            if (target < m) {        // the elements that hold BOTH nodes: the two element lists are sorted, a merge finds the common ones (<= 8 + 8 steps)
+              int a = aptr[g], b = aptr[target];
+              const int ae = aptr[g + 1], be = aptr[target + 1];
+              while (a < ae && b < be) {
+                const int ea = aei[a] >> 5, eb = aei[b] >> 5;
+                if (ea == eb) {
+                  const int cc = ea / CL_NE;
+                  if (cc < c) acc = 1;
+                  else if (cc > c) later = true;
+                  a++;
+                  b++;
+                } else if (ea < eb) a++;
+                else b++;
+              }
+            } else {                 // a column outside the matrix (ghost) has no element list: look into the elements around g
+              for (int a = aptr[g]; a < aptr[g + 1]; a++) {
+                const int e = aei[a] >> 5, cc = e / CL_NE;
+                if (cc == c) continue;
+                bool has = false;
+                for (int n = 0; n < 27; n++) has = has || elem_dof[(size_t)e * nloc + n] == target;
+                if (has) { if (cc < c) acc = 1; else later = true; }
+              }
             }
             last = later ? 0u : 1u;
             if (!acc) atomicAdd(&first_cnt[g], 1u);

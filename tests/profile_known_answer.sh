@@ -15,8 +15,8 @@ rows = list(csv.DictReader(open(f[0])))
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open("$OUT/${TAG}_known_answer_kernel_summary.md", "w") as o:
-    o.write("kernels of `python tests/perf_probe_known_answer.py fcycle` (testNSSteadyDD, four uniform levels, nonlinear F-cycle to convergence; rocprofv3 --kernel-trace --stats)\n\n")
+    o.write("kernels of python tests/perf_probe_known_answer.py fcycle (testNSSteadyDD, four uniform levels, nonlinear F-cycle to convergence; rocprofv3 --kernel-trace --stats)\n\n")
     o.write("total kernel time %.1f ms in %d launches\n\n| kernel | calls | total ms | avg us | %% |\n|---|---|---|---|---|\n" % (tot / 1e6, sum(int(r["Calls"]) for r in rows)))
     for r in rows[:25]:
-        o.write("| \`%s\` | %s | %.2f | %.2f | %.1f |\n" % (r["Name"][:70], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
+        o.write("| %s | %s | %.2f | %.2f | %.1f |\n" % (r["Name"][:70], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
 PY

@@ -79,13 +79,25 @@ python $ROOT/profiles/summarize.py /tmp/prof/prep $OUT/${TAG}_prepare_kernel_sum
 python $ROOT/tests/perf_probe_amr.py 8 2> /dev/null | grep '^{' | head -1 > $OUT/${TAG}_amr_probe.json
 python $ROOT/tests/perf_probe_direct.py 1 2 3 2> /dev/null | grep '^n ' > $OUT/${TAG}_direct_probe.txt
 tail -c 600 $OUT/${TAG}_bench_line.json
-python $ROOT/tests/perf_probe_ns.py 0.001 2> /dev/null | grep '^{' | head -1 > $OUT/${TAG}_ns_probe.json
-# ---- config 4 (cavity, Taylor-Hood, 80 x 80, nu = 0.001 by continuation): F-cycle Newton, cycle and linear solve; round 5: block smoother with a colour per launch ----
-python $ROOT/tests/perf_probe_ns.py 0.001 2> /dev/null | grep '^{' | tail -1 > $OUT/${TAG}_ns_probe.json
+# ---- config 4 (cavity, Taylor-Hood, 80 x 80, nu = 0.001 by continuation): F-cycle Newton, cycle and linear solve; round 5: block smoother with a colour per launch;
+#      round 6: the cycles stop at the 40 x 40 level (FEMUS_NS_COARSE_LEVEL=2: exact solve there), beside the full hierarchy ----
+FEMUS_NS_COARSE_LEVEL=2 python $ROOT/tests/perf_probe_ns.py 0.001 2> /dev/null | grep '^{' | tail -1 > $OUT/${TAG}_ns_probe.json
+FEMUS_NS_COARSE_LEVEL=0 python $ROOT/tests/perf_probe_ns.py 0.001 2> /dev/null | grep '^{' | tail -1 > $OUT/${TAG}_ns_probe_full_hierarchy.json
 python $ROOT/tests/perf_probe_ns_cycle.py 2> /dev/null | grep '^{' | tail -1 > $OUT/${TAG}_ns_cycle_probe.json
 python $ROOT/tests/perf_probe_ns_cycle.py vanka_fused=0 gmres_device=0 2> /dev/null | grep '^{' | tail -1 > $OUT/${TAG}_ns_cycle_probe_round4_options.json
 # ---- where the waves of the fused cluster kernel and of the macro-row Galerkin kernel spend their cycles (shader-clock stamps, asm_debug bit 7) ----
 python $ROOT/tests/perf_probe_cluster_phases.py 0 > $OUT/${TAG}_cluster_phase_stamps.txt 2>&1
+FEMUS_CARRY=0 python $ROOT/tests/perf_probe_cluster_phases.py 0 > $OUT/${TAG}_cluster_phase_stamps_no_carried_rows.txt 2>&1
+python $ROOT/tests/perf_probe_carry.py 4 2> /dev/null | tail -1 > $OUT/${TAG}_carry_probe.json
+# the assembly without carried rows (assemble_carry 0: round 5's plan) beside it: traffic of the two kernels
+rm -rf /tmp/pmc3; mkdir -p /tmp/pmc3
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  FEMUS_HIP_CARRY=0 timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc3/p$i -- python $ROOT/tests/perf_probe_fused_loop.py 0 > /tmp/pmc3/log$i.txt 2>&1 || echo "no-carry pass $i failed"
+done
+python $ROOT/profiles/summarize.py /tmp/pmc3 $OUT/${TAG}_assembly_no_carried_rows_pmc_summary.md > /dev/null
+bash $ROOT/tests/profile_known_answer.sh $TAG
 python $ROOT/tests/dev/probe12.py 2>&1 | grep -A11 "k_galerkin_macro phase" > $OUT/${TAG}_galerkin_macro_phase_stamps.txt
 # ---- set-up of the bench problem stage by stage (levels refined on the device, round 5) and the same with the host loops ----
 python $ROOT/tests/perf_probe_setup.py --device 2> /dev/null | sed -n '/^{/,$p' > $OUT/${TAG}_setup_probe.json
