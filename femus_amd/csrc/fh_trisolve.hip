@@ -21,6 +21,7 @@
 // (64 rows at a time, 16 lanes each) with a workgroup barrier between the levels: all its waves sit on one CU and share its L1, so the barrier's
 // workgroup-scope release / acquire is all the ordering the rows of the next level need (round 5).
 constexpr int TRI_SMALL = 256;
+constexpr int64_t TRI_SMALL_WORK = 32768;      // entries of a small level (all of its rows, both triangles)
 
 // rows of the local block only: columns >= m are ghosts (block Jacobi across ranks, as PCSOR / PCILU are local)
 static void schedule(const std::vector<int>& rp, const std::vector<int>& col, int m, bool forward, std::vector<int>& ptr, std::vector<int>& rows, std::vector<int>& lev) {
@@ -60,23 +61,31 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
   schedule(A->h_rowptr, fh_hcol(A), A->m, false, T->bptr, brows, blev);
   FH_CHECK_HIP(hipMalloc(&T->d_brows, std::max(A->m, 1) * sizeof(int)));
   FH_CHECK_HIP(hipMemcpy(T->d_brows, brows.data(), (size_t)A->m * sizeof(int), hipMemcpyHostToDevice));
-  auto segments = [](const std::vector<int>& ptr, std::vector<int>& seg) {
+  // small = few rows AND little work: a level of 256 rows with 1 200 entries each (stacked three-dimensional systems) would keep ONE compute unit busy for
+  // four passes of 75 steps where a launch spreads it over sixteen workgroups
+  auto segments = [&](const std::vector<int>& ptr, const std::vector<int>& lrows, std::vector<int>& seg) {
     seg.clear();
     const int nl = (int)ptr.size() - 1;
+    auto small = [&](int l) {
+      if (!A->ctx->tri_runs || ptr[l + 1] - ptr[l] > TRI_SMALL) return false;
+      int64_t work = 0;
+      for (int q = ptr[l]; q < ptr[l + 1]; q++) work += A->h_rowptr[lrows[q] + 1] - A->h_rowptr[lrows[q]];
+      return work <= TRI_SMALL_WORK;
+    };
     for (int l = 0; l < nl;) {
-      if (ptr[l + 1] - ptr[l] > TRI_SMALL) {
+      if (!small(l)) {
         seg.insert(seg.end(), {l, 1, 0});
         l++;
         continue;
       }
       int e = l;
-      while (e < nl && ptr[e + 1] - ptr[e] <= TRI_SMALL) e++;
+      while (e < nl && small(e)) e++;
       seg.insert(seg.end(), {l, e - l, 1});
       l = e;
     }
   };
-  segments(T->fptr, T->fseg);
-  segments(T->bptr, T->bseg);
+  segments(T->fptr, rows, T->fseg);
+  segments(T->bptr, brows, T->bseg);
   // operand sources of the run kernel: an entry whose column was computed in the level JUST BEFORE, inside the same run, reads the workgroup's LDS copy of that
   // level (rank of the column among the level's rows); every other entry reads z in global memory -- written at least two barriers earlier, or by another launch
   auto sources = [&](const std::vector<int>& ptr, const std::vector<int>& seg, const std::vector<int>& lvrows, const std::vector<int>& lev, bool forward, int** d_src) -> int {
@@ -100,14 +109,26 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
     FH_CHECK_HIP(hipMemcpy(*d_src, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice));
     return 0;
   };
-  auto level_rows = [&](const std::vector<int>& lvrows, const std::vector<int>& dp, int** d_lv) -> int {
+  // per row in level order: {row, first entry of the sweep's triangle, its end, w}; forward: the entries left of the diagonal, w = position of the diagonal;
+  // backward: the entries right of the diagonal without the ghost columns, w = start of the whole row (the lanes keep the entries they have in the
+  // one-launch-per-level kernels, which walk the whole row: the same partial sums, the same bits -- the run kernel just does not load the other triangle)
+  auto level_rows = [&](const std::vector<int>& lvrows, const std::vector<int>& dp, bool forward, int** d_lv) -> int {
     std::vector<int> lv((size_t)std::max(A->m, 1) * 4, 0);
+    const std::vector<int>& col = fh_hcol(A);
     for (int k = 0; k < A->m; k++) {
       const int i = lvrows[k];
+      const int* b = col.data() + A->h_rowptr[i];
+      const int* e = col.data() + A->h_rowptr[i + 1];
       lv[(size_t)k * 4 + 0] = i;
-      lv[(size_t)k * 4 + 1] = A->h_rowptr[i];
-      lv[(size_t)k * 4 + 2] = A->h_rowptr[i + 1];
-      lv[(size_t)k * 4 + 3] = std::max(dp[i], 0);
+      if (forward) {
+        lv[(size_t)k * 4 + 1] = A->h_rowptr[i];
+        lv[(size_t)k * 4 + 2] = (int)(std::lower_bound(b, e, i) - col.data());
+        lv[(size_t)k * 4 + 3] = std::max(dp[i], 0);
+      } else {
+        lv[(size_t)k * 4 + 1] = (int)(std::upper_bound(b, e, i) - col.data());
+        lv[(size_t)k * 4 + 2] = (int)(std::lower_bound(b, e, A->m) - col.data());
+        lv[(size_t)k * 4 + 3] = A->h_rowptr[i];
+      }
     }
     FH_CHECK_HIP(hipMalloc(d_lv, lv.size() * sizeof(int)));
     FH_CHECK_HIP(hipMemcpy(*d_lv, lv.data(), lv.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -127,8 +148,8 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
     if (q != e && *q == i) dpos[i] = (int)(q - fh_hcol(A).data());
   }
   T->h_diagpos = dpos;
-  FH_TRY(level_rows(rows, dpos, &T->d_flv));
-  FH_TRY(level_rows(brows, dpos, &T->d_blv));
+  FH_TRY(level_rows(rows, dpos, true, &T->d_flv));
+  FH_TRY(level_rows(brows, dpos, false, &T->d_blv));
   FH_CHECK_HIP(hipMalloc(&T->d_diagpos, std::max(A->m, 1) * sizeof(int)));
   FH_CHECK_HIP(hipMemcpy(T->d_diagpos, dpos.data(), (size_t)A->m * sizeof(int), hipMemcpyHostToDevice));
   FH_CHECK_HIP(hipMalloc(&T->d_t, std::max(A->m, 1) * sizeof(double)));
@@ -214,45 +235,61 @@ struct TriRun {
 // P.src < 0).  After the barrier a level is: LDS reads, the sum, a store.  The lane's entries are added in the same order as in the one-launch-per-level kernels:
 // the same bits.
 constexpr int TRI_PF = 4;
-constexpr int TRI_NONE = -2147483647 - 1;          // no entry (beyond the end of the row)
+#ifndef TRI_SKIP
+#define TRI_SKIP 1
+#endif
+// A slot = what the pipeline holds of one level for this lane.  Nothing in it is TESTED in the step that loads it (a select on a value a step too early is a wait for
+// the load just issued, with every other load of the step queued behind it -- the ISA of the first version of this pipeline showed two such full round trips per
+// level: the `k < re ? c : none` select of stage C, and register copies of stage A's row behind the barrier, put there by the guards around the unrolled steps):
+// c[] holds the sources as loaded (of a clamped, existing entry), nv says how many of them belong to the row.
 struct TriSlot {
-  int i, rs, re, dp, active, c[TRI_PF];
+  int i, lo, hi, w, active, nv, first, b, n, c[TRI_PF];      // lo, hi: the triangle's entries; w: see level_rows; first: this lane's first entry; b, n: first row / rows of the level (wave-uniform)
   double v[TRI_PF], zq[TRI_PF], e0, e1;
 };
 template <int KIND>
 __device__ __forceinline__ bool tri_takes(int j, int i, int m) {
   return (KIND == 0 || KIND == 2) ? (j < i) : (j > i && j < m);
 }
-// stage A: this lane group's row of level L (clamped to the run; a group beyond the level repeats its last row and stores nothing)
-__device__ __forceinline__ void tri_stage_a(const TriRun& P, int L, int lend, int grp, TriSlot& S) {
-  const int Lc = min(L, lend - 1);
-  const int b = P.lptr[Lc], n = P.lptr[Lc + 1] - b;
-  S.active = (L < lend && grp < n) ? 1 : 0;
+// stage A: this lane group's row of a level whose pointer pair (b, b + n) is at hand (loaded a step ahead); a group beyond the level repeats its last row and stores nothing
+__device__ __forceinline__ void tri_stage_a(const TriRun& P, bool in_run, int b, int n, int grp, TriSlot& S) {
+  S.active = (in_run && grp < n) ? 1 : 0;
+  S.b = b;
+  S.n = in_run ? n : 0;
   const int4 q = P.lv[b + min(grp, n - 1)];
-  S.i = q.x; S.rs = q.y; S.re = q.z; S.dp = q.w;
+  S.i = q.x; S.lo = q.y; S.hi = q.z; S.w = q.w;
 }
-// stage C: the lane's first entries, the right-hand side and the diagonal
+// stage C: the lane's first entries (only those the row has: a load instruction costs the memory pipe of the ONE compute unit its cycles whether its lanes
+// carry an entry or repeat the last one, and that pipe is what bounds a level), the right-hand side and the diagonal
 template <int KIND>
 __device__ __forceinline__ void tri_stage_c(const TriRun& P, int gl, TriSlot& S) {
+#if TRI_SKIP
   if (__builtin_amdgcn_ballot_w64(S.active != 0) == 0ull) return;        // a wave without a row in that level (levels hold 46 rows on average, the workgroup 64 groups)
+#endif
   const int i = S.i;
+  // the lane's entries are those at positions = gl (mod 16) counted from the start of the whole row, as in the kernels that walk the whole row
+  S.first = (KIND == 0 || KIND == 2) ? S.lo + gl : S.lo + ((S.w + gl - S.lo) & 15);
+  const int len = S.active ? S.hi - S.first : 0;
+  S.nv = len <= 0 ? 0 : min((len + 15) >> 4, TRI_PF);
 #pragma unroll
-  for (int q = 0; q < TRI_PF; q++) {
-    const int k = S.rs + gl + 16 * q;
-    const int kk = min(k, max(S.re - 1, S.rs));
-    const int c = P.src[kk];
-    S.c[q] = k < S.re ? c : TRI_NONE;
-    S.v[q] = P.val[kk];
+  for (int q = 0; q < TRI_PF; q++)
+    if (q < S.nv) {
+      S.c[q] = P.src[S.first + 16 * q];
+      S.v[q] = P.val[S.first + 16 * q];
+    }
+  if (S.active) {
+    S.e0 = KIND == 1 ? P.t_in[i] : KIND == 3 ? P.z[i] : P.r[i];
+    S.e1 = (KIND == 0 || KIND == 1) ? P.dinv[i] : KIND == 3 ? P.val[S.lo - 1] : 1.0;      // the diagonal of U sits just before the row's upper entries
   }
-  S.e0 = KIND == 1 ? P.t_in[i] : KIND == 3 ? P.z[i] : P.r[i];
-  S.e1 = (KIND == 0 || KIND == 1) ? P.dinv[i] : KIND == 3 ? P.val[S.dp] : 1.0;
 }
 // stage Z: operands from global memory (entries of levels at least two back, or of another launch)
 template <int KIND>
 __device__ __forceinline__ void tri_stage_z(const TriRun& P, TriSlot& S) {
+#if TRI_SKIP
   if (__builtin_amdgcn_ballot_w64(S.active != 0) == 0ull) return;
+#endif
 #pragma unroll
-  for (int q = 0; q < TRI_PF; q++) S.zq[q] = P.z[max(S.c[q], 0)];
+  for (int q = 0; q < TRI_PF; q++)
+    if (q < S.nv && S.c[q] >= 0) S.zq[q] = P.z[S.c[q]];
 }
 template <int KIND>
 __device__ __forceinline__ double tri_store(const TriRun& P, int i, double acc, double e0, double e1) {
@@ -271,32 +308,49 @@ __device__ __forceinline__ double tri_store(const TriRun& P, int i, double acc, 
   P.z[i] = zi;
   return zi;
 }
-// level l from slot S; zp / zc: LDS copies of the previous / of this level
+// sum over the 16 lanes of a row group into its lane 0: the tree of `for (off = 8; off; off >>= 1) acc += __shfl_down(acc, off)` (same operands, same order, same bits)
+// with the lane exchange as DPP row shifts -- a row of the DPP unit IS 16 lanes -- instead of four dependent ds_bpermute round trips through the LDS pipe on
+// the critical path of every level
+template <int N>
+__device__ __forceinline__ double tri_row_from(double v) {      // lane i <- lane i + N of the same 16 lanes (lanes past the row end read zero: their sums are not used)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + N, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + N, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double tri_reduce16(double acc) {
+  acc += tri_row_from<8>(acc);
+  acc += tri_row_from<4>(acc);
+  acc += tri_row_from<2>(acc);
+  acc += tri_row_from<1>(acc);
+  return acc;
+}
+// the level held by slot S; zp / zc: LDS copies of the previous / of this level
 template <int KIND>
-__device__ __forceinline__ void tri_level(const TriRun& P, int l, int gl, int grp, const TriSlot& S, const double* zp, double* zc) {
+__device__ __forceinline__ void tri_level(const TriRun& P, int gl, int grp, const TriSlot& S, const double* zp, double* zc) {
   if (S.active) {                                                       // first 64 rows: from the registers the pipeline filled
     const int i = S.i;
+    double zz[TRI_PF];
+#pragma unroll
+    for (int q = 0; q < TRI_PF; q++)
+      if (q < S.nv && S.c[q] < 0) zz[q] = zp[-S.c[q] - 1];      // all LDS reads at once, one wait (the operands of the level just before)
     double acc = 0.0;
 #pragma unroll
     for (int q = 0; q < TRI_PF; q++) {
-      if (S.c[q] == TRI_NONE) continue;
-      if (S.c[q] < 0) acc += S.v[q] * zp[-S.c[q] - 1];
-      else if (tri_takes<KIND>(S.c[q], i, P.m)) acc += S.v[q] * S.zq[q];
+      const int c = S.c[q];
+      const double op = c < 0 ? zz[q] : S.zq[q];
+      if (q < S.nv) acc += S.v[q] * op;
     }
-    for (int k = S.rs + gl + 16 * TRI_PF; k < S.re; k += 16) {
+    for (int k = S.first + 16 * TRI_PF; k < S.hi; k += 16) {
       const int j = P.src[k];
-      if (j < 0) acc += P.val[k] * zp[-j - 1];
-      else if (tri_takes<KIND>(j, i, P.m)) acc += P.val[k] * P.z[j];
+      acc += P.val[k] * (j < 0 ? zp[-j - 1] : P.z[j]);
     }
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    acc = tri_reduce16(acc);
     if (gl == 0) zc[grp] = tri_store<KIND>(P, i, acc, S.e0, S.e1);
   }
-  const int base = P.lptr[l], n = P.lptr[l + 1] - base;
-  for (int r0 = 64; r0 < n; r0 += 64) {                                 // the rest of a level of more than 64 rows
+  for (int r0 = 64; r0 < S.n; r0 += 64) {                               // the rest of a level of more than 64 rows
     const int rr = r0 + grp;
-    const bool live = rr < n;
-    const int i = live ? P.rows[base + rr] : 0;
+    const bool live = rr < S.n;
+    const int i = live ? P.rows[S.b + rr] : 0;
     double acc = 0.0;
     if (live)
       for (int k = P.rowptr[i] + gl; k < P.rowptr[i + 1]; k += 16) {
@@ -304,8 +358,7 @@ __device__ __forceinline__ void tri_level(const TriRun& P, int l, int gl, int gr
         if (j < 0) acc += P.val[k] * zp[-j - 1];
         else if (tri_takes<KIND>(j, i, P.m)) acc += P.val[k] * P.z[j];
       }
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    acc = tri_reduce16(acc);
     if (live && gl == 0) {
       const double e0 = KIND == 1 ? P.t_in[i] : KIND == 3 ? P.z[i] : P.r[i];
       const double e1 = (KIND == 0 || KIND == 1) ? P.dinv[i] : KIND == 3 ? P.val[P.diagpos[i]] : 1.0;
@@ -320,20 +373,31 @@ __global__ __launch_bounds__(1024) void k_tri_run(TriRun P) {
   const int gl = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int l0 = P.l0, lend = P.l0 + P.nl;
   TriSlot S0, S1, S2;
-  // prologue: level l0 complete, l0 + 1 up to its entries, l0 + 2 its rows
-  tri_stage_a(P, l0, lend, grp, S0); tri_stage_a(P, l0 + 1, lend, grp, S1); tri_stage_a(P, l0 + 2, lend, grp, S2);
+  auto lp = [&](int L) { return P.lptr[min(L, lend)]; };        // level pointers, clamped to the run (lend itself is the end of the last level)
+  // prologue: level l0 complete, l0 + 1 up to its entries, l0 + 2 its rows, the pointer pair of l0 + 3
+  {
+    const int p0 = lp(l0), p1 = lp(l0 + 1), p2 = lp(l0 + 2), p3 = lp(l0 + 3);
+    tri_stage_a(P, true, p0, p1 - p0, grp, S0);
+    tri_stage_a(P, l0 + 1 < lend, l0 + 1 < lend ? p1 : p0, l0 + 1 < lend ? p2 - p1 : p1 - p0, grp, S1);
+    tri_stage_a(P, l0 + 2 < lend, l0 + 2 < lend ? p2 : p0, l0 + 2 < lend ? p3 - p2 : p1 - p0, grp, S2);
+  }
   tri_stage_c<KIND>(P, gl, S0); tri_stage_c<KIND>(P, gl, S1);
   tri_stage_z<KIND>(P, S0);
-  // iteration for level l in slot CUR: operands of l + 1 (Z), entries of l + 2 (C), the level itself, rows of l + 3 (A, into CUR, behind the level's arithmetic).
-  // The LDS buffers alternate with the level, the slots with a period of three: six steps per trip.  (Measured: the kernel is bound by vector-instruction issue --
-  // sixteen waves run the whole step for at most four rows each -- not by the load chain: asking for the rows a full step earlier, through one more register
-  // set, cost 10 %.)
+  int nb = lp(l0 + 3), ne = lp(l0 + 4);             // pointer pair of the level stage A takes next; the pair after it is asked for a step ahead
+  const int fb = lp(l0), fn = lp(l0 + 1) - fb;      // what stage A repeats beyond the end of the run (an existing level, nothing stored)
+  // iteration for level l in slot CUR: operands of l + 1 (Z), entries of l + 2 (C), the level itself, rows of l + 3 (A, into CUR, behind the level's arithmetic),
+  // pointer pair of l + 4.  The LDS buffers alternate with the level, the slots with a period of three: six steps per trip, NOT guarded one by one -- the steps
+  // past the end of the run find inactive slots and only meet at the barriers -- so that the trip is straight-line code and stage A's load lands in the slot's own
+  // registers (with a guard per step the compiler copied it there behind the barrier: a wait for a load just issued, every level).
 #define TRI_STEP(PH, CUR, NZ, NC)                                                      \
-  if (l + PH < lend) {                                                                 \
+  {                                                                                    \
     tri_stage_z<KIND>(P, NZ);                                                          \
     tri_stage_c<KIND>(P, gl, NC);                                                      \
-    tri_level<KIND>(P, l + PH, gl, grp, CUR, zl[(PH + 1) & 1], zl[PH & 1]);            \
-    tri_stage_a(P, l + PH + 3, lend, grp, CUR);                                        \
+    tri_level<KIND>(P, gl, grp, CUR, zl[(PH + 1) & 1], zl[PH & 1]);                    \
+    const bool in = l + PH + 3 < lend;                                                 \
+    tri_stage_a(P, in, in ? nb : fb, in ? ne - nb : fn, grp, CUR);                     \
+    nb = ne;                                                                           \
+    ne = lp(l + PH + 5);                                                               \
     __syncthreads();                                                                   \
   }
   for (int l = l0; l < lend; l += 6) {

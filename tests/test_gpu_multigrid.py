@@ -328,6 +328,30 @@ def test_natural_order_smoothers_match_the_sequential_oracle(ctx, smoother, name
     mg.destroy()
 
 
+@pytest.mark.parametrize("smoother", [capi.SMOOTH_SOR, capi.SMOOTH_ILU0])
+@pytest.mark.parametrize("box,fe,nl", [((24, 24, 0), "biquadratic", 2), ((3, 3, 3), "biquadratic", 2)])
+def test_runs_of_small_levels_give_the_bits_of_a_launch_per_level(ctx, smoother, box, fe, nl):
+    """the natural-order sweeps take runs of consecutive small levels in ONE workgroup (software pipeline over the levels, the previous level's values in LDS,
+    the 16-lane sums by DPP row shifts); option tri_runs = 0 sweeps every level with a launch of its own (sums by wave shuffles): same operands in the same
+    order, so one V(2,1) cycle gives the same bits either way.  2-D: 97 levels of <= 49 rows (all in runs); 3-D: levels beyond the run limits in between"""
+    H = fo.build_poisson_hierarchy(*box, nl, fe, ONE)
+    n = H.A[-1].shape[0]
+    rhs = fo.lcg_fill(n, 33)
+    out = []
+    for runs in (1, 0):
+        ctx.set_option("tri_runs", runs)
+        try:
+            mg, mats = device_hierarchy(ctx, H, 0.8, 2, 1, smoother=smoother)
+            b, x = ctx.vector_from(rhs), ctx.vector(n)
+            mg.vcycle(b, x)
+            out.append(x.to_numpy().copy())
+            mg.destroy()
+        finally:
+            ctx.set_option("tri_runs", 1)
+    assert np.isfinite(out[0]).all() and np.abs(out[0]).max() > 0
+    assert np.array_equal(out[0], out[1])
+
+
 @pytest.mark.parametrize("graph", [1, 0])
 @pytest.mark.parametrize("smoother,name", [(capi.SMOOTH_JACOBI, "jacobi"), (capi.SMOOTH_SOR, "sor"), (capi.SMOOTH_ILU0, "ilu0"), (capi.SMOOTH_IDENTITY, "identity")])
 @pytest.mark.parametrize("npre,npost", [(2, 1), (1, 1), (3, 0), (4, 4)])
