@@ -16,6 +16,7 @@ struct fh_tri_s {
   // the run kernel keeps the values of the previous level in LDS, so the one link of a level's dependency chain that cannot be loaded ahead is an LDS read
   int *d_fsrc = nullptr, *d_bsrc = nullptr;
   int *d_flv = nullptr, *d_blv = nullptr;      // per row in level order: {row, first entry, end, diagonal position} (one 16-byte load instead of a chain of three)
+  unsigned long long* d_prog = nullptr;  // progress word of the run kernel's main workgroup, read by its prefetching workgroup (fh_trisolve.hip)
   double* d_lu = nullptr;               // ILU(0) factors on A's pattern: strict lower part = L (unit diagonal), rest = U
   int* d_flag = nullptr;
   double* d_t = nullptr;                // symmetric sweep: t = r - L z of the forward half, read by the backward half

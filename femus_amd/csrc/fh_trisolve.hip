@@ -13,6 +13,15 @@
 // history differs from the reference's.  Integer setup (levels, diagonal positions) on the host, once per pattern.
 #include "fh_internal.h"
 #include "fh_trisolve.h"
+#ifndef TRI_STAMP
+#define TRI_STAMP 0      // dev builds: shader-clock stamps of two waves over 32 steps of a long run (FEMUS_TRI_STAMP=1), printed when a plan is destroyed
+#endif
+// dev builds (TRI_STAMP 1): FEMUS_TRI_DBG switches stages of the run kernel off -- 1 no operand gathers, 4 no arithmetic, 8 no row-table loads; wrong results, timing only
+#define TRI_ON(bit) (!TRI_STAMP || !(P.dbg & (bit)))
+#if TRI_STAMP
+static long long* g_tri_stamp = nullptr;
+static void tri_stamp_report();
+#endif
 #include <algorithm>
 #include <cmath>
 
@@ -148,6 +157,8 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
     if (q != e && *q == i) dpos[i] = (int)(q - fh_hcol(A).data());
   }
   T->h_diagpos = dpos;
+  FH_CHECK_HIP(hipMalloc(&T->d_prog, 2 * sizeof(unsigned long long)));
+  FH_CHECK_HIP(hipMemset(T->d_prog, 0, 2 * sizeof(unsigned long long)));
   FH_TRY(level_rows(rows, dpos, true, &T->d_flv));
   FH_TRY(level_rows(brows, dpos, false, &T->d_blv));
   FH_CHECK_HIP(hipMalloc(&T->d_diagpos, std::max(A->m, 1) * sizeof(int)));
@@ -157,6 +168,12 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
 }
 
 int fh_tri_create(fh_mat_t A, fh_tri_t* out) {
+#if TRI_STAMP
+  if (getenv("FEMUS_TRI_STAMP") && !g_tri_stamp) {
+    hipMalloc(&g_tri_stamp, 512 * sizeof(long long));
+    hipMemset(g_tri_stamp, 0, 512 * sizeof(long long));
+  }
+#endif
   fh_tri_t T = new fh_tri_s();
   const int rc = tri_fill(A, T);
   if (rc) {
@@ -169,7 +186,10 @@ int fh_tri_create(fh_mat_t A, fh_tri_t* out) {
 
 void fh_tri_destroy(fh_tri_t T) {
   if (!T) return;
-  for (void* p : {(void*)T->d_frows, (void*)T->d_brows, (void*)T->d_diagpos, (void*)T->d_lu, (void*)T->d_flag, (void*)T->d_t, (void*)T->d_fptr, (void*)T->d_bptr, (void*)T->d_fsrc, (void*)T->d_bsrc, (void*)T->d_flv, (void*)T->d_blv})
+#if TRI_STAMP
+  tri_stamp_report();
+#endif
+  for (void* p : {(void*)T->d_frows, (void*)T->d_brows, (void*)T->d_diagpos, (void*)T->d_lu, (void*)T->d_flag, (void*)T->d_t, (void*)T->d_fptr, (void*)T->d_bptr, (void*)T->d_fsrc, (void*)T->d_bsrc, (void*)T->d_flv, (void*)T->d_blv, (void*)T->d_prog})
     if (p) hipFree(p);
   delete T;
 }
@@ -218,13 +238,60 @@ __global__ __launch_bounds__(256) void k_gs_bwd(const int* __restrict__ rows, in
 }
 
 // ---- runs of small levels in one workgroup: the row bodies of the four kernels above / below, levels separated by a workgroup barrier ----
+constexpr int TRI_AHEAD = 1024, TRI_PF_POLLS = 1 << 15;
+static unsigned tri_launch_id = 0;
+// the prefetching workgroup pays for runs of many levels (env FEMUS_TRI_PREFETCH: 0 never, else the block count to launch)
+static int tri_blocks(int nl) {
+  static int v = -1;
+  if (v < 0) v = getenv("FEMUS_TRI_PREFETCH") ? atoi(getenv("FEMUS_TRI_PREFETCH")) : 9;
+  return (v > 1 && nl >= 64) ? v : 1;
+}
+static int tri_ahead() {
+  static int v = -1;
+  if (v < 0) v = getenv("FEMUS_TRI_AHEAD") ? atoi(getenv("FEMUS_TRI_AHEAD")) : TRI_AHEAD;
+  return v;
+}
+static int tri_dbg() {
+  static int v = -1;
+  if (v < 0) v = getenv("FEMUS_TRI_DBG") ? atoi(getenv("FEMUS_TRI_DBG")) : 0;
+  return v;
+}
 struct TriRun {
   const int *rows, *lptr, *rowptr, *src, *diagpos;
   const int4* lv;
   const double *val, *dinv, *r, *t_in;
   double *z, *t_out;
   int l0, nl, m;
+  long long* stamp;        // dev builds (TRI_STAMP): shader-clock stamps of two waves over 32 steps
+  unsigned long long* prog;      // progress of the main workgroup: (launch id << 32) | first table row of the level in work, ~0 in the low half when done
+  unsigned id;
+  int ahead;               // table rows the prefetching workgroup keeps in front of the level in work
+  int nblk;                // workgroups of the launch: 1, or TRI_PF_BLOCK + 1 with the prefetching one
+  int dbg;                 // timing aids (FEMUS_TRI_DBG, wrong results): 1 no operand gathers, 2 no entry loads, 4 no arithmetic, 8 no row-table loads
 };
+
+#if TRI_STAMP
+static void tri_stamp_report() {
+  if (!g_tri_stamp) return;
+  long long h[512];
+  hipDeviceSynchronize();
+  hipMemcpy(h, g_tri_stamp, sizeof(h), hipMemcpyDeviceToHost);
+  for (int w = 0; w < 2; w++) {
+    double d[6] = {0, 0, 0, 0, 0, 0};
+    int cnt = 0;
+    for (int st = 0; st < 31; st++) {
+      const long long* a = h + w * 256 + st * 8;
+      if (!a[0] || !a[8]) continue;
+      for (int k = 0; k < 5; k++) d[k] += (double)(a[k + 1] - a[k]);
+      d[5] += (double)(a[8] - a[0]);
+      cnt++;
+    }
+    if (cnt) fprintf(stderr, "[tri stamp] wave %d, %d steps: Z issue %.0f, C issue %.0f, level %.0f, A issue %.0f, barrier %.0f; step %.0f (s_memtime ticks)\n", w * 8, cnt, d[0] / cnt, d[1] / cnt, d[2] / cnt,
+                     d[3] / cnt, d[4] / cnt, d[5] / cnt);
+  }
+  hipMemset(g_tri_stamp, 0, 512 * sizeof(long long));
+}
+#endif
 // What a level costs inside the run is its chain of dependent loads: level pointer -> row id -> row pointers -> operand sources / values -> z.  A two-dimensional
 // stacked system streams 25 MB of rows per sweep through ONE compute unit, so every link is a trip to the L2 or beyond (0.25 us), and a chain loaded one level
 // ahead (round 5) made a level cost the whole chain: 0.7 us.  Round 6: the row id, its bounds and its diagonal position come in ONE 16-byte load from a table in
@@ -234,6 +301,11 @@ struct TriRun {
 // operands computed by the level JUST BEFORE cannot be loaded ahead; they are read from the workgroup's LDS copy of that level (two buffers of TRI_SMALL values;
 // P.src < 0).  After the barrier a level is: LDS reads, the sum, a store.  The lane's entries are added in the same order as in the one-launch-per-level kernels:
 // the same bits.
+#if TRI_STAMP
+#define TRI_T(k) if (stamping) { P.stamp[sbase + (size_t)(l + PHV - P.l0 - 200) * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime(); }
+#else
+#define TRI_T(k)
+#endif
 constexpr int TRI_PF = 4;
 #ifndef TRI_SKIP
 #define TRI_SKIP 1
@@ -278,7 +350,7 @@ __device__ __forceinline__ void tri_stage_c(const TriRun& P, int gl, TriSlot& S)
     }
   if (S.active) {
     S.e0 = KIND == 1 ? P.t_in[i] : KIND == 3 ? P.z[i] : P.r[i];
-    S.e1 = (KIND == 0 || KIND == 1) ? P.dinv[i] : KIND == 3 ? P.val[S.lo - 1] : 1.0;      // the diagonal of U sits just before the row's upper entries
+    S.e1 = (KIND == 0 || KIND == 1) ? P.dinv[i] : KIND == 3 ? P.val[S.lo - 1] : 1.0;      // the diagonal of U sits just before the row's upper entries (inverted in stage Z, a step later: off the level's critical path)
   }
 }
 // stage Z: operands from global memory (entries of levels at least two back, or of another launch)
@@ -290,6 +362,7 @@ __device__ __forceinline__ void tri_stage_z(const TriRun& P, TriSlot& S) {
 #pragma unroll
   for (int q = 0; q < TRI_PF; q++)
     if (q < S.nv && S.c[q] >= 0) S.zq[q] = P.z[S.c[q]];
+  if (KIND == 3 && S.active) S.e1 = 1.0 / S.e1;
 }
 template <int KIND>
 __device__ __forceinline__ double tri_store(const TriRun& P, int i, double acc, double e0, double e1) {
@@ -303,7 +376,7 @@ __device__ __forceinline__ double tri_store(const TriRun& P, int i, double acc, 
   } else if (KIND == 2) {
     zi = e0 - acc;
   } else {
-    zi = (e0 - acc) / e1;
+    zi = (e0 - acc) * e1;        // e1 = 1 / u_ii, formed a step ahead (PETSc's factored matrices store the inverted diagonal and multiply, MatSolve_SeqAIJ)
   }
   P.z[i] = zi;
   return zi;
@@ -361,10 +434,57 @@ __device__ __forceinline__ void tri_level(const TriRun& P, int gl, int grp, cons
     acc = tri_reduce16(acc);
     if (live && gl == 0) {
       const double e0 = KIND == 1 ? P.t_in[i] : KIND == 3 ? P.z[i] : P.r[i];
-      const double e1 = (KIND == 0 || KIND == 1) ? P.dinv[i] : KIND == 3 ? P.val[P.diagpos[i]] : 1.0;
+      const double e1 = (KIND == 0 || KIND == 1) ? P.dinv[i] : KIND == 3 ? 1.0 / P.val[P.diagpos[i]] : 1.0;
       zc[rr] = tri_store<KIND>(P, i, acc, e0, e1);
     }
   }
+}
+
+// The run's rows stream 25 MB per sweep through ONE compute unit with a look-ahead of a level or two: what the pipeline cannot hide is the distance to HBM.  A second
+// workgroup of the same launch -- workgroups go round the eight XCDs in turn, so number 8 shares the L2 of number 0 -- walks the level-ordered row table ahead of
+// the main one and touches the lines of the rows' entries (values and sources) TRI_AHEAD table rows in front of the level in work, which it reads from a progress
+// word the main workgroup stores once per level.  It never holds the main workgroup up (nothing waits for it), leaves when the main one is done or when it sees no
+// progress for a few milliseconds, and nothing it loads is used.
+
+__device__ void tri_prefetch(const TriRun& P) {
+  const int first = P.lptr[P.l0], end = P.lptr[P.l0 + P.nl];
+  int pos = first, polls = 0;
+  double acc = 0.0;
+  int iacc = 0;
+  while (pos < end) {
+    const unsigned long long w = __hip_atomic_load(P.prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int cur = first;
+    if ((unsigned)(w >> 32) == P.id) {
+      if ((unsigned)w == 0xffffffffu) break;
+      cur = (int)(unsigned)w;
+    }
+    const int limit = min(end, cur + P.ahead);
+    if (pos >= limit) {
+      if (++polls > TRI_PF_POLLS) break;
+      __builtin_amdgcn_s_sleep(8);
+      continue;
+    }
+    const int e = pos + (int)threadIdx.x;
+    if (e < limit) {
+      const int4 q = P.lv[e];
+      for (int k0 = q.y & ~7; k0 < q.z; k0 += 64) {          // one load per 64-byte line, eight lines in flight
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (k0 + 8 * u < q.z) ? P.val[k0 + 8 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += v[u];
+      }
+      for (int k0 = q.y & ~15; k0 < q.z; k0 += 64) {
+        int c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) c[u] = (k0 + 16 * u < q.z) ? P.src[k0 + 16 * u] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) iacc ^= c[u];
+      }
+    }
+    pos = min(pos + (int)blockDim.x, limit);
+  }
+  if (acc == 1.2345678e-301 && iacc == 0x7fffffff) P.prog[1] = 0;      // never: keeps the loads alive
 }
 
 template <int KIND>      // 0: Gauss-Seidel forward, 1: backward, 2: ILU lower, 3: ILU upper
@@ -372,6 +492,10 @@ __global__ __launch_bounds__(1024) void k_tri_run(TriRun P) {
   __shared__ double zl[2][TRI_SMALL];             // z of the rows of the previous / of this level, by rank inside the level
   const int gl = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int l0 = P.l0, lend = P.l0 + P.nl;
+  if (blockIdx.x != 0) {
+    if ((int)blockIdx.x == P.nblk - 1) tri_prefetch(P);
+    return;
+  }
   TriSlot S0, S1, S2;
   auto lp = [&](int L) { return P.lptr[min(L, lend)]; };        // level pointers, clamped to the run (lend itself is the end of the last level)
   // prologue: level l0 complete, l0 + 1 up to its entries, l0 + 2 its rows, the pointer pair of l0 + 3
@@ -391,14 +515,24 @@ __global__ __launch_bounds__(1024) void k_tri_run(TriRun P) {
   // registers (with a guard per step the compiler copied it there behind the barrier: a wait for a load just issued, every level).
 #define TRI_STEP(PH, CUR, NZ, NC)                                                      \
   {                                                                                    \
-    tri_stage_z<KIND>(P, NZ);                                                          \
-    tri_stage_c<KIND>(P, gl, NC);                                                      \
-    tri_level<KIND>(P, gl, grp, CUR, zl[(PH + 1) & 1], zl[PH & 1]);                    \
+    [[maybe_unused]] constexpr int PHV = PH;                                           \
+    [[maybe_unused]] const bool stamping = TRI_STAMP && P.stamp && (threadIdx.x == 0 || threadIdx.x == 512) && l + PH - P.l0 >= 200 && l + PH - P.l0 < 232; \
+    [[maybe_unused]] const size_t sbase = threadIdx.x == 0 ? 0 : 256;                                   \
+    TRI_T(0)                                                                           \
+    if (threadIdx.x == 0 && P.nblk > 1) __hip_atomic_store(P.prog, ((unsigned long long)P.id << 32) | (unsigned)CUR.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    if (TRI_ON(1)) tri_stage_z<KIND>(P, NZ);                                        \
+    TRI_T(1)                                                                           \
+    if (TRI_ON(2)) tri_stage_c<KIND>(P, gl, NC);                                    \
+    TRI_T(2)                                                                           \
+    if (TRI_ON(4)) tri_level<KIND>(P, gl, grp, CUR, zl[(PH + 1) & 1], zl[PH & 1]);  \
+    TRI_T(3)                                                                           \
     const bool in = l + PH + 3 < lend;                                                 \
-    tri_stage_a(P, in, in ? nb : fb, in ? ne - nb : fn, grp, CUR);                     \
+    if (TRI_ON(8)) tri_stage_a(P, in, in ? nb : fb, in ? ne - nb : fn, grp, CUR);   \
     nb = ne;                                                                           \
     ne = lp(l + PH + 5);                                                               \
+    TRI_T(4)                                                                           \
     __syncthreads();                                                                   \
+    TRI_T(5)                                                                           \
   }
   for (int l = l0; l < lend; l += 6) {
     TRI_STEP(0, S0, S1, S2)
@@ -409,6 +543,7 @@ __global__ __launch_bounds__(1024) void k_tri_run(TriRun P) {
     TRI_STEP(5, S2, S0, S1)
   }
 #undef TRI_STEP
+  if (threadIdx.x == 0 && P.nblk > 1) __hip_atomic_store(P.prog, ((unsigned long long)P.id << 32) | 0xffffffffull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // z = B r, B = one symmetric Gauss-Seidel sweep of A's local block from z = 0
@@ -416,12 +551,13 @@ int fh_tri_ssor_apply(fh_tri_t T, fh_mat_t A, const double* dinv, const double* 
   hipStream_t s = A->ctx->stream;
   const int nf = (int)T->fptr.size() - 1, nb = (int)T->bptr.size() - 1;
   (void)nf; (void)nb;
-  TriRun P = {nullptr, nullptr, A->d_rowptr, nullptr, T->d_diagpos, nullptr, A->d_val, dinv, r, T->d_t, z, T->d_t, 0, 0, A->m};
+  TriRun P = {nullptr, nullptr, A->d_rowptr, nullptr, T->d_diagpos, nullptr, A->d_val, dinv, r, T->d_t, z, T->d_t, 0, 0, A->m, nullptr, T->d_prog, 0u, tri_ahead(), 1, tri_dbg()};
   for (size_t q = 0; q < T->fseg.size(); q += 3) {
     const int l = T->fseg[q];
     if (T->fseg[q + 2]) {
       P.rows = T->d_frows; P.lptr = T->d_fptr; P.src = T->d_fsrc; P.lv = reinterpret_cast<const int4*>(T->d_flv); P.l0 = l; P.nl = T->fseg[q + 1];
-      hipLaunchKernelGGL(k_tri_run<0>, dim3(1), dim3(1024), 0, s, P);
+      P.id = ++tri_launch_id; P.nblk = tri_blocks(P.nl);
+      hipLaunchKernelGGL(k_tri_run<0>, dim3(P.nblk), dim3(1024), 0, s, P);
     } else {
       const int n = T->fptr[l + 1] - T->fptr[l];
       hipLaunchKernelGGL(k_gs_fwd, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_frows + T->fptr[l], n, A->d_rowptr, A->d_col, A->d_val, dinv,
@@ -432,7 +568,8 @@ int fh_tri_ssor_apply(fh_tri_t T, fh_mat_t A, const double* dinv, const double* 
     const int l = T->bseg[q];
     if (T->bseg[q + 2]) {
       P.rows = T->d_brows; P.lptr = T->d_bptr; P.src = T->d_bsrc; P.lv = reinterpret_cast<const int4*>(T->d_blv); P.l0 = l; P.nl = T->bseg[q + 1];
-      hipLaunchKernelGGL(k_tri_run<1>, dim3(1), dim3(1024), 0, s, P);
+      P.id = ++tri_launch_id; P.nblk = tri_blocks(P.nl);
+      hipLaunchKernelGGL(k_tri_run<1>, dim3(P.nblk), dim3(1024), 0, s, P);
     } else {
       const int n = T->bptr[l + 1] - T->bptr[l];
       hipLaunchKernelGGL(k_gs_bwd, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_brows + T->bptr[l], n, A->d_rowptr, A->d_col, A->d_val, dinv,
@@ -602,19 +739,23 @@ __global__ __launch_bounds__(256) void k_ilu_usolve(const int* __restrict__ rows
     }
 #pragma unroll
   for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if (live && gl == 0) z[i] = (z[i] - acc) / lu[diagpos[i]];
+  if (live && gl == 0) z[i] = (z[i] - acc) * (1.0 / lu[diagpos[i]]);      // as the run kernel: times the inverted diagonal
 }
 
 int fh_tri_ilu_apply(fh_tri_t T, fh_mat_t A, const double* r, double* z) {
   hipStream_t s = A->ctx->stream;
   const int nf = (int)T->fptr.size() - 1, nb = (int)T->bptr.size() - 1;
   (void)nf; (void)nb;
-  TriRun P = {nullptr, nullptr, A->d_rowptr, nullptr, T->d_diagpos, nullptr, T->d_lu, nullptr, r, nullptr, z, nullptr, 0, 0, A->m};
+  TriRun P = {nullptr, nullptr, A->d_rowptr, nullptr, T->d_diagpos, nullptr, T->d_lu, nullptr, r, nullptr, z, nullptr, 0, 0, A->m, nullptr, T->d_prog, 0u, tri_ahead(), 1, tri_dbg()};
   for (size_t q = 0; q < T->fseg.size(); q += 3) {
     const int l = T->fseg[q];
     if (T->fseg[q + 2]) {
       P.rows = T->d_frows; P.lptr = T->d_fptr; P.src = T->d_fsrc; P.lv = reinterpret_cast<const int4*>(T->d_flv); P.l0 = l; P.nl = T->fseg[q + 1];
-      hipLaunchKernelGGL(k_tri_run<2>, dim3(1), dim3(1024), 0, s, P);
+#if TRI_STAMP
+      P.stamp = (g_tri_stamp && P.nl > 300) ? g_tri_stamp : nullptr;
+#endif
+      P.id = ++tri_launch_id; P.nblk = tri_blocks(P.nl);
+      hipLaunchKernelGGL(k_tri_run<2>, dim3(P.nblk), dim3(1024), 0, s, P);
     } else {
       const int n = T->fptr[l + 1] - T->fptr[l];
       hipLaunchKernelGGL(k_ilu_lsolve, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_frows + T->fptr[l], n, A->d_rowptr, A->d_col, T->d_lu, r, z);
@@ -624,7 +765,8 @@ int fh_tri_ilu_apply(fh_tri_t T, fh_mat_t A, const double* r, double* z) {
     const int l = T->bseg[q];
     if (T->bseg[q + 2]) {
       P.rows = T->d_brows; P.lptr = T->d_bptr; P.src = T->d_bsrc; P.lv = reinterpret_cast<const int4*>(T->d_blv); P.l0 = l; P.nl = T->bseg[q + 1];
-      hipLaunchKernelGGL(k_tri_run<3>, dim3(1), dim3(1024), 0, s, P);
+      P.id = ++tri_launch_id; P.nblk = tri_blocks(P.nl);
+      hipLaunchKernelGGL(k_tri_run<3>, dim3(P.nblk), dim3(1024), 0, s, P);
     } else {
       const int n = T->bptr[l + 1] - T->bptr[l];
       hipLaunchKernelGGL(k_ilu_usolve, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_brows + T->bptr[l], n, A->d_rowptr, A->d_col,
