@@ -17,6 +17,7 @@ struct fh_tri_s {
   int *d_fsrc = nullptr, *d_bsrc = nullptr;
   int *d_flv = nullptr, *d_blv = nullptr;      // per row in level order: {row, first entry, end, diagonal position} (one 16-byte load instead of a chain of three)
   unsigned long long* d_prog = nullptr;  // progress word of the run kernel's main workgroup, read by its prefetching workgroup (fh_trisolve.hip)
+  int run_pf = 2;                       // register slots per lane of the run kernel: 2 while the mean triangle of a row has at most 32 entries, else 4
   double* d_lu = nullptr;               // ILU(0) factors on A's pattern: strict lower part = L (unit diagonal), rest = U
   int* d_flag = nullptr;
   double* d_t = nullptr;                // symmetric sweep: t = r - L z of the forward half, read by the backward half

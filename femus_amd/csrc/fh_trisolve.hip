@@ -121,6 +121,7 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
   // per row in level order: {row, first entry of the sweep's triangle, its end, w}; forward: the entries left of the diagonal, w = position of the diagonal;
   // backward: the entries right of the diagonal without the ghost columns, w = start of the whole row (the lanes keep the entries they have in the
   // one-launch-per-level kernels, which walk the whole row: the same partial sums, the same bits -- the run kernel just does not load the other triangle)
+  int64_t tri_len_sum = 0;
   auto level_rows = [&](const std::vector<int>& lvrows, const std::vector<int>& dp, bool forward, int** d_lv) -> int {
     std::vector<int> lv((size_t)std::max(A->m, 1) * 4, 0);
     const std::vector<int>& col = fh_hcol(A);
@@ -129,6 +130,8 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
       const int* b = col.data() + A->h_rowptr[i];
       const int* e = col.data() + A->h_rowptr[i + 1];
       lv[(size_t)k * 4 + 0] = i;
+      const int lower = (int)(std::lower_bound(b, e, i) - b), upper = (int)(std::lower_bound(b, e, A->m) - std::upper_bound(b, e, i));
+      tri_len_sum += forward ? lower : upper;
       if (forward) {
         lv[(size_t)k * 4 + 1] = A->h_rowptr[i];
         lv[(size_t)k * 4 + 2] = (int)(std::lower_bound(b, e, i) - col.data());
@@ -159,8 +162,13 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
   T->h_diagpos = dpos;
   FH_CHECK_HIP(hipMalloc(&T->d_prog, 2 * sizeof(unsigned long long)));
   FH_CHECK_HIP(hipMemset(T->d_prog, 0, 2 * sizeof(unsigned long long)));
+  T->run_pf = 2;
   FH_TRY(level_rows(rows, dpos, true, &T->d_flv));
   FH_TRY(level_rows(brows, dpos, false, &T->d_blv));
+  // two slots (32 entries of the triangle per row in registers) while the MEAN triangle is within them: measured on the stacked two-dimensional system, a third of
+  // whose rows have 37 lower entries, two slots with those rows' tails in the loop beat four by 8 %
+  T->run_pf = (tri_len_sum <= (int64_t)32 * 2 * std::max(A->m, 1)) ? 2 : 4;
+  if (const char* e = getenv("FEMUS_TRI_PF")) T->run_pf = atoi(e) == 2 ? 2 : 4;      // measurements
   FH_CHECK_HIP(hipMalloc(&T->d_diagpos, std::max(A->m, 1) * sizeof(int)));
   FH_CHECK_HIP(hipMemcpy(T->d_diagpos, dpos.data(), (size_t)A->m * sizeof(int), hipMemcpyHostToDevice));
   FH_CHECK_HIP(hipMalloc(&T->d_t, std::max(A->m, 1) * sizeof(double)));
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(256) void k_gs_bwd(const int* __restrict__ rows, in
 }
 
 // ---- runs of small levels in one workgroup: the row bodies of the four kernels above / below, levels separated by a workgroup barrier ----
-constexpr int TRI_AHEAD = 1024, TRI_PF_POLLS = 1 << 15;
+constexpr int TRI_AHEAD = 1024, TRI_POLL_CAP = 1 << 15;
 static unsigned tri_launch_id = 0;
 // the prefetching workgroup pays for runs of many levels (env FEMUS_TRI_PREFETCH: 0 never, else the block count to launch)
 static int tri_blocks(int nl) {
@@ -306,7 +314,8 @@ static void tri_stamp_report() {
 #else
 #define TRI_T(k)
 #endif
-constexpr int TRI_PF = 4;
+// PF: entries per lane held in registers (16 PF entries of the triangle per row, the rest in a loop): 2 while the mean triangle of the plan's rows has at most 32 entries
+// (two-dimensional systems), else 4 -- every slot is instructions in every step whether a row fills it or not (measured: 4 -> 2 is 7 % of a sweep)
 #ifndef TRI_SKIP
 #define TRI_SKIP 1
 #endif
@@ -314,16 +323,18 @@ constexpr int TRI_PF = 4;
 // the load just issued, with every other load of the step queued behind it -- the ISA of the first version of this pipeline showed two such full round trips per
 // level: the `k < re ? c : none` select of stage C, and register copies of stage A's row behind the barrier, put there by the guards around the unrolled steps):
 // c[] holds the sources as loaded (of a clamped, existing entry), nv says how many of them belong to the row.
+template <int PF>
 struct TriSlot {
-  int i, lo, hi, w, active, nv, first, b, n, c[TRI_PF];      // lo, hi: the triangle's entries; w: see level_rows; first: this lane's first entry; b, n: first row / rows of the level (wave-uniform)
-  double v[TRI_PF], zq[TRI_PF], e0, e1;
+  int i, lo, hi, w, active, nv, first, b, n, c[PF];      // lo, hi: the triangle's entries; w: see level_rows; first: this lane's first entry; b, n: first row / rows of the level (wave-uniform)
+  double v[PF], zq[PF], e0, e1;
 };
 template <int KIND>
 __device__ __forceinline__ bool tri_takes(int j, int i, int m) {
   return (KIND == 0 || KIND == 2) ? (j < i) : (j > i && j < m);
 }
 // stage A: this lane group's row of a level whose pointer pair (b, b + n) is at hand (loaded a step ahead); a group beyond the level repeats its last row and stores nothing
-__device__ __forceinline__ void tri_stage_a(const TriRun& P, bool in_run, int b, int n, int grp, TriSlot& S) {
+template <int PF>
+__device__ __forceinline__ void tri_stage_a(const TriRun& P, bool in_run, int b, int n, int grp, TriSlot<PF>& S) {
   S.active = (in_run && grp < n) ? 1 : 0;
   S.b = b;
   S.n = in_run ? n : 0;
@@ -332,8 +343,8 @@ __device__ __forceinline__ void tri_stage_a(const TriRun& P, bool in_run, int b,
 }
 // stage C: the lane's first entries (only those the row has: a load instruction costs the memory pipe of the ONE compute unit its cycles whether its lanes
 // carry an entry or repeat the last one, and that pipe is what bounds a level), the right-hand side and the diagonal
-template <int KIND>
-__device__ __forceinline__ void tri_stage_c(const TriRun& P, int gl, TriSlot& S) {
+template <int KIND, int PF>
+__device__ __forceinline__ void tri_stage_c(const TriRun& P, int gl, TriSlot<PF>& S) {
 #if TRI_SKIP
   if (__builtin_amdgcn_ballot_w64(S.active != 0) == 0ull) return;        // a wave without a row in that level (levels hold 46 rows on average, the workgroup 64 groups)
 #endif
@@ -341,9 +352,9 @@ __device__ __forceinline__ void tri_stage_c(const TriRun& P, int gl, TriSlot& S)
   // the lane's entries are those at positions = gl (mod 16) counted from the start of the whole row, as in the kernels that walk the whole row
   S.first = (KIND == 0 || KIND == 2) ? S.lo + gl : S.lo + ((S.w + gl - S.lo) & 15);
   const int len = S.active ? S.hi - S.first : 0;
-  S.nv = len <= 0 ? 0 : min((len + 15) >> 4, TRI_PF);
+  S.nv = len <= 0 ? 0 : min((len + 15) >> 4, PF);
 #pragma unroll
-  for (int q = 0; q < TRI_PF; q++)
+  for (int q = 0; q < PF; q++)
     if (q < S.nv) {
       S.c[q] = P.src[S.first + 16 * q];
       S.v[q] = P.val[S.first + 16 * q];
@@ -354,13 +365,13 @@ __device__ __forceinline__ void tri_stage_c(const TriRun& P, int gl, TriSlot& S)
   }
 }
 // stage Z: operands from global memory (entries of levels at least two back, or of another launch)
-template <int KIND>
-__device__ __forceinline__ void tri_stage_z(const TriRun& P, TriSlot& S) {
+template <int KIND, int PF>
+__device__ __forceinline__ void tri_stage_z(const TriRun& P, TriSlot<PF>& S) {
 #if TRI_SKIP
   if (__builtin_amdgcn_ballot_w64(S.active != 0) == 0ull) return;
 #endif
 #pragma unroll
-  for (int q = 0; q < TRI_PF; q++)
+  for (int q = 0; q < PF; q++)
     if (q < S.nv && S.c[q] >= 0) S.zq[q] = P.z[S.c[q]];
   if (KIND == 3 && S.active) S.e1 = 1.0 / S.e1;
 }
@@ -398,22 +409,22 @@ __device__ __forceinline__ double tri_reduce16(double acc) {
   return acc;
 }
 // the level held by slot S; zp / zc: LDS copies of the previous / of this level
-template <int KIND>
-__device__ __forceinline__ void tri_level(const TriRun& P, int gl, int grp, const TriSlot& S, const double* zp, double* zc) {
+template <int KIND, int PF>
+__device__ __forceinline__ void tri_level(const TriRun& P, int gl, int grp, const TriSlot<PF>& S, const double* zp, double* zc) {
   if (S.active) {                                                       // first 64 rows: from the registers the pipeline filled
     const int i = S.i;
-    double zz[TRI_PF];
+    double zz[PF];
 #pragma unroll
-    for (int q = 0; q < TRI_PF; q++)
+    for (int q = 0; q < PF; q++)
       if (q < S.nv && S.c[q] < 0) zz[q] = zp[-S.c[q] - 1];      // all LDS reads at once, one wait (the operands of the level just before)
     double acc = 0.0;
 #pragma unroll
-    for (int q = 0; q < TRI_PF; q++) {
+    for (int q = 0; q < PF; q++) {
       const int c = S.c[q];
       const double op = c < 0 ? zz[q] : S.zq[q];
       if (q < S.nv) acc += S.v[q] * op;
     }
-    for (int k = S.first + 16 * TRI_PF; k < S.hi; k += 16) {
+    for (int k = S.first + 16 * PF; k < S.hi; k += 16) {
       const int j = P.src[k];
       acc += P.val[k] * (j < 0 ? zp[-j - 1] : P.z[j]);
     }
@@ -460,7 +471,7 @@ __device__ void tri_prefetch(const TriRun& P) {
     }
     const int limit = min(end, cur + P.ahead);
     if (pos >= limit) {
-      if (++polls > TRI_PF_POLLS) break;
+      if (++polls > TRI_POLL_CAP) break;
       __builtin_amdgcn_s_sleep(8);
       continue;
     }
@@ -487,7 +498,7 @@ __device__ void tri_prefetch(const TriRun& P) {
   if (acc == 1.2345678e-301 && iacc == 0x7fffffff) P.prog[1] = 0;      // never: keeps the loads alive
 }
 
-template <int KIND>      // 0: Gauss-Seidel forward, 1: backward, 2: ILU lower, 3: ILU upper
+template <int KIND, int PF>      // 0: Gauss-Seidel forward, 1: backward, 2: ILU lower, 3: ILU upper
 __global__ __launch_bounds__(1024) void k_tri_run(TriRun P) {
   __shared__ double zl[2][TRI_SMALL];             // z of the rows of the previous / of this level, by rank inside the level
   const int gl = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(1024) void k_tri_run(TriRun P) {
     if ((int)blockIdx.x == P.nblk - 1) tri_prefetch(P);
     return;
   }
-  TriSlot S0, S1, S2;
+  TriSlot<PF> S0, S1, S2;
   auto lp = [&](int L) { return P.lptr[min(L, lend)]; };        // level pointers, clamped to the run (lend itself is the end of the last level)
   // prologue: level l0 complete, l0 + 1 up to its entries, l0 + 2 its rows, the pointer pair of l0 + 3
   {
@@ -505,8 +516,8 @@ __global__ __launch_bounds__(1024) void k_tri_run(TriRun P) {
     tri_stage_a(P, l0 + 1 < lend, l0 + 1 < lend ? p1 : p0, l0 + 1 < lend ? p2 - p1 : p1 - p0, grp, S1);
     tri_stage_a(P, l0 + 2 < lend, l0 + 2 < lend ? p2 : p0, l0 + 2 < lend ? p3 - p2 : p1 - p0, grp, S2);
   }
-  tri_stage_c<KIND>(P, gl, S0); tri_stage_c<KIND>(P, gl, S1);
-  tri_stage_z<KIND>(P, S0);
+  tri_stage_c<KIND, PF>(P, gl, S0); tri_stage_c<KIND, PF>(P, gl, S1);
+  tri_stage_z<KIND, PF>(P, S0);
   int nb = lp(l0 + 3), ne = lp(l0 + 4);             // pointer pair of the level stage A takes next; the pair after it is asked for a step ahead
   const int fb = lp(l0), fn = lp(l0 + 1) - fb;      // what stage A repeats beyond the end of the run (an existing level, nothing stored)
   // iteration for level l in slot CUR: operands of l + 1 (Z), entries of l + 2 (C), the level itself, rows of l + 3 (A, into CUR, behind the level's arithmetic),
@@ -520,11 +531,11 @@ __global__ __launch_bounds__(1024) void k_tri_run(TriRun P) {
     [[maybe_unused]] const size_t sbase = threadIdx.x == 0 ? 0 : 256;                                   \
     TRI_T(0)                                                                           \
     if (threadIdx.x == 0 && P.nblk > 1) __hip_atomic_store(P.prog, ((unsigned long long)P.id << 32) | (unsigned)CUR.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-    if (TRI_ON(1)) tri_stage_z<KIND>(P, NZ);                                        \
+    if (TRI_ON(1)) tri_stage_z<KIND, PF>(P, NZ);                                        \
     TRI_T(1)                                                                           \
-    if (TRI_ON(2)) tri_stage_c<KIND>(P, gl, NC);                                    \
+    if (TRI_ON(2)) tri_stage_c<KIND, PF>(P, gl, NC);                                    \
     TRI_T(2)                                                                           \
-    if (TRI_ON(4)) tri_level<KIND>(P, gl, grp, CUR, zl[(PH + 1) & 1], zl[PH & 1]);  \
+    if (TRI_ON(4)) tri_level<KIND, PF>(P, gl, grp, CUR, zl[(PH + 1) & 1], zl[PH & 1]);  \
     TRI_T(3)                                                                           \
     const bool in = l + PH + 3 < lend;                                                 \
     if (TRI_ON(8)) tri_stage_a(P, in, in ? nb : fb, in ? ne - nb : fn, grp, CUR);   \
@@ -557,7 +568,8 @@ int fh_tri_ssor_apply(fh_tri_t T, fh_mat_t A, const double* dinv, const double* 
     if (T->fseg[q + 2]) {
       P.rows = T->d_frows; P.lptr = T->d_fptr; P.src = T->d_fsrc; P.lv = reinterpret_cast<const int4*>(T->d_flv); P.l0 = l; P.nl = T->fseg[q + 1];
       P.id = ++tri_launch_id; P.nblk = tri_blocks(P.nl);
-      hipLaunchKernelGGL(k_tri_run<0>, dim3(P.nblk), dim3(1024), 0, s, P);
+      if (T->run_pf == 2) hipLaunchKernelGGL((k_tri_run<0, 2>), dim3(P.nblk), dim3(1024), 0, s, P);
+      else hipLaunchKernelGGL((k_tri_run<0, 4>), dim3(P.nblk), dim3(1024), 0, s, P);
     } else {
       const int n = T->fptr[l + 1] - T->fptr[l];
       hipLaunchKernelGGL(k_gs_fwd, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_frows + T->fptr[l], n, A->d_rowptr, A->d_col, A->d_val, dinv,
@@ -569,7 +581,8 @@ int fh_tri_ssor_apply(fh_tri_t T, fh_mat_t A, const double* dinv, const double* 
     if (T->bseg[q + 2]) {
       P.rows = T->d_brows; P.lptr = T->d_bptr; P.src = T->d_bsrc; P.lv = reinterpret_cast<const int4*>(T->d_blv); P.l0 = l; P.nl = T->bseg[q + 1];
       P.id = ++tri_launch_id; P.nblk = tri_blocks(P.nl);
-      hipLaunchKernelGGL(k_tri_run<1>, dim3(P.nblk), dim3(1024), 0, s, P);
+      if (T->run_pf == 2) hipLaunchKernelGGL((k_tri_run<1, 2>), dim3(P.nblk), dim3(1024), 0, s, P);
+      else hipLaunchKernelGGL((k_tri_run<1, 4>), dim3(P.nblk), dim3(1024), 0, s, P);
     } else {
       const int n = T->bptr[l + 1] - T->bptr[l];
       hipLaunchKernelGGL(k_gs_bwd, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_brows + T->bptr[l], n, A->d_rowptr, A->d_col, A->d_val, dinv,
@@ -755,7 +768,8 @@ int fh_tri_ilu_apply(fh_tri_t T, fh_mat_t A, const double* r, double* z) {
       P.stamp = (g_tri_stamp && P.nl > 300) ? g_tri_stamp : nullptr;
 #endif
       P.id = ++tri_launch_id; P.nblk = tri_blocks(P.nl);
-      hipLaunchKernelGGL(k_tri_run<2>, dim3(P.nblk), dim3(1024), 0, s, P);
+      if (T->run_pf == 2) hipLaunchKernelGGL((k_tri_run<2, 2>), dim3(P.nblk), dim3(1024), 0, s, P);
+      else hipLaunchKernelGGL((k_tri_run<2, 4>), dim3(P.nblk), dim3(1024), 0, s, P);
     } else {
       const int n = T->fptr[l + 1] - T->fptr[l];
       hipLaunchKernelGGL(k_ilu_lsolve, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_frows + T->fptr[l], n, A->d_rowptr, A->d_col, T->d_lu, r, z);
@@ -766,7 +780,8 @@ int fh_tri_ilu_apply(fh_tri_t T, fh_mat_t A, const double* r, double* z) {
     if (T->bseg[q + 2]) {
       P.rows = T->d_brows; P.lptr = T->d_bptr; P.src = T->d_bsrc; P.lv = reinterpret_cast<const int4*>(T->d_blv); P.l0 = l; P.nl = T->bseg[q + 1];
       P.id = ++tri_launch_id; P.nblk = tri_blocks(P.nl);
-      hipLaunchKernelGGL(k_tri_run<3>, dim3(P.nblk), dim3(1024), 0, s, P);
+      if (T->run_pf == 2) hipLaunchKernelGGL((k_tri_run<3, 2>), dim3(P.nblk), dim3(1024), 0, s, P);
+      else hipLaunchKernelGGL((k_tri_run<3, 4>), dim3(P.nblk), dim3(1024), 0, s, P);
     } else {
       const int n = T->bptr[l + 1] - T->bptr[l];
       hipLaunchKernelGGL(k_ilu_usolve, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), 0, s, T->d_brows + T->bptr[l], n, A->d_rowptr, A->d_col,
