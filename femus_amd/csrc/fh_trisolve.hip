@@ -30,6 +30,8 @@ static void tri_stamp_report();
 // (64 rows at a time, 16 lanes each) with a workgroup barrier between the levels: all its waves sit on one CU and share its L1, so the barrier's
 // workgroup-scope release / acquire is all the ordering the rows of the next level need (round 5).
 constexpr int TRI_SMALL = 256;
+constexpr int TRI_RING = 2;                     // levels whose values the run kernel keeps in LDS (a ring indexed by the level number): this level and the one before.  (Eight levels, so that
+                                                // most operands come from LDS instead of the gather, measured the same: the level is bound by the L1's requests for the rows' own lines)
 constexpr int64_t TRI_SMALL_WORK = 32768;      // entries of a small level (all of its rows, both triangles)
 
 // rows of the local block only: columns >= m are ghosts (block Jacobi across ranks, as PCSOR / PCILU are local)
@@ -76,7 +78,7 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
     seg.clear();
     const int nl = (int)ptr.size() - 1;
     auto small = [&](int l) {
-      if (!A->ctx->tri_runs || ptr[l + 1] - ptr[l] > TRI_SMALL) return false;
+      if (!A->ctx->tri_runs || A->nnz >= (1 << 28) || ptr[l + 1] - ptr[l] > TRI_SMALL) return false;
       int64_t work = 0;
       for (int q = ptr[l]; q < ptr[l + 1]; q++) work += A->h_rowptr[lrows[q] + 1] - A->h_rowptr[lrows[q]];
       return work <= TRI_SMALL_WORK;
@@ -99,10 +101,10 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
   // level (rank of the column among the level's rows); every other entry reads z in global memory -- written at least two barriers earlier, or by another launch
   auto sources = [&](const std::vector<int>& ptr, const std::vector<int>& seg, const std::vector<int>& lvrows, const std::vector<int>& lev, bool forward, int** d_src) -> int {
     const int m = A->m, nl = (int)ptr.size() - 1;
-    std::vector<char> lds_ok(std::max(nl, 1), 0);          // level l may read level l - 1 from LDS: both in one run, l not the run's first level
+    std::vector<int> run_first(std::max(nl, 1), -1);       // first level of the run a level belongs to (-1: a level with a launch of its own)
     for (size_t q = 0; q < seg.size(); q += 3)
       if (seg[q + 2])
-        for (int l = seg[q] + 1; l < seg[q] + seg[q + 1]; l++) lds_ok[l] = 1;
+        for (int l = seg[q]; l < seg[q] + seg[q + 1]; l++) run_first[l] = seg[q];
     std::vector<int> rank(m, 0);
     for (int l = 0; l < nl; l++)
       for (int k = ptr[l]; k < ptr[l + 1]; k++) rank[lvrows[k]] = k - ptr[l];
@@ -112,7 +114,9 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
       for (int k = A->h_rowptr[i]; k < A->h_rowptr[i + 1]; k++) {
         const int j = col[k];
         const bool takes = forward ? j < i : (j > i && j < m);
-        src[k] = (takes && lds_ok[lev[i]] && lev[j] == lev[i] - 1) ? -(rank[j] + 1) : j;
+        // from LDS: the column was computed at most TRI_RING - 1 levels before, inside the same run (the ring slot of a level is its number modulo TRI_RING)
+        const bool lds = takes && run_first[lev[i]] >= 0 && lev[j] < lev[i] && lev[i] - lev[j] < TRI_RING && lev[j] >= run_first[lev[i]];
+        src[k] = lds ? -((lev[j] % TRI_RING) * TRI_SMALL + rank[j] + 1) : j;
       }
     FH_CHECK_HIP(hipMalloc(d_src, src.size() * sizeof(int)));
     FH_CHECK_HIP(hipMemcpy(*d_src, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -168,7 +172,7 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
   // two slots (32 entries of the triangle per row in registers) while the MEAN triangle is within them: measured on the stacked two-dimensional system, a third of
   // whose rows have 37 lower entries, two slots with those rows' tails in the loop beat four by 8 %
   T->run_pf = (tri_len_sum <= (int64_t)32 * 2 * std::max(A->m, 1)) ? 2 : 4;
-  if (const char* e = getenv("FEMUS_TRI_PF")) T->run_pf = atoi(e) == 2 ? 2 : 4;      // measurements
+  if (const char* e = getenv("FEMUS_TRI_PF")) T->run_pf = atoi(e) == 2 ? 2 : atoi(e) == 3 ? 3 : 4;      // measurements
   FH_CHECK_HIP(hipMalloc(&T->d_diagpos, std::max(A->m, 1) * sizeof(int)));
   FH_CHECK_HIP(hipMemcpy(T->d_diagpos, dpos.data(), (size_t)A->m * sizeof(int), hipMemcpyHostToDevice));
   FH_CHECK_HIP(hipMalloc(&T->d_t, std::max(A->m, 1) * sizeof(double)));
@@ -323,6 +327,12 @@ static void tri_stamp_report() {
 // the load just issued, with every other load of the step queued behind it -- the ISA of the first version of this pipeline showed two such full round trips per
 // level: the `k < re ? c : none` select of stage C, and register copies of stage A's row behind the barrier, put there by the guards around the unrolled steps):
 // c[] holds the sources as loaded (of a clamped, existing entry), nv says how many of them belong to the row.
+// byte offsets as unsigned 32-bit values on a uniform base: one shift per address instead of a sign extension and a 64-bit multiply-add (runs are only planned
+// for matrices of less than 2^28 entries)
+template <class T>
+__device__ __forceinline__ T tri_ld(const T* base, int idx) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)((unsigned)idx * (unsigned)sizeof(T)));
+}
 template <int PF>
 struct TriSlot {
   int i, lo, hi, w, active, nv, first, b, n, c[PF];      // lo, hi: the triangle's entries; w: see level_rows; first: this lane's first entry; b, n: first row / rows of the level (wave-uniform)
@@ -332,19 +342,25 @@ template <int KIND>
 __device__ __forceinline__ bool tri_takes(int j, int i, int m) {
   return (KIND == 0 || KIND == 2) ? (j < i) : (j > i && j < m);
 }
-// stage A: this lane group's row of a level whose pointer pair (b, b + n) is at hand (loaded a step ahead); a group beyond the level repeats its last row and stores nothing
-template <int PF>
-__device__ __forceinline__ void tri_stage_a(const TriRun& P, bool in_run, int b, int n, int grp, TriSlot<PF>& S) {
-  S.active = (in_run && grp < n) ? 1 : 0;
-  S.b = b;
-  S.n = in_run ? n : 0;
+// stage A: this lane group's row of a level whose pointer pair (b, b + n) is at hand (loaded a step ahead); a group beyond the level repeats its last row and stores
+// nothing.  The row goes into a register set of its own (two of them, alternating): it is asked for at the START of a step and used at the start of the next one,
+// a whole step later -- loaded straight into the slot that the step's level still computes from, it could only be asked for at the step's end and was waited for,
+// a round trip to the L2, every level
+struct TriRow {
+  int i, lo, hi, w, active, b, n;
+};
+__device__ __forceinline__ void tri_stage_a(const TriRun& P, bool in_run, int b, int n, int grp, TriRow& R) {
+  R.active = (in_run && grp < n) ? 1 : 0;
+  R.b = b;
+  R.n = in_run ? n : 0;
   const int4 q = P.lv[b + min(grp, n - 1)];
-  S.i = q.x; S.lo = q.y; S.hi = q.z; S.w = q.w;
+  R.i = q.x; R.lo = q.y; R.hi = q.z; R.w = q.w;
 }
 // stage C: the lane's first entries (only those the row has: a load instruction costs the memory pipe of the ONE compute unit its cycles whether its lanes
 // carry an entry or repeat the last one, and that pipe is what bounds a level), the right-hand side and the diagonal
 template <int KIND, int PF>
-__device__ __forceinline__ void tri_stage_c(const TriRun& P, int gl, TriSlot<PF>& S) {
+__device__ __forceinline__ void tri_stage_c(const TriRun& P, int gl, const TriRow& R, TriSlot<PF>& S) {
+  S.i = R.i; S.lo = R.lo; S.hi = R.hi; S.w = R.w; S.active = R.active; S.b = R.b; S.n = R.n;
 #if TRI_SKIP
   if (__builtin_amdgcn_ballot_w64(S.active != 0) == 0ull) return;        // a wave without a row in that level (levels hold 46 rows on average, the workgroup 64 groups)
 #endif
@@ -356,12 +372,12 @@ __device__ __forceinline__ void tri_stage_c(const TriRun& P, int gl, TriSlot<PF>
 #pragma unroll
   for (int q = 0; q < PF; q++)
     if (q < S.nv) {
-      S.c[q] = P.src[S.first + 16 * q];
-      S.v[q] = P.val[S.first + 16 * q];
+      S.c[q] = tri_ld(P.src, S.first + 16 * q);
+      S.v[q] = tri_ld(P.val, S.first + 16 * q);
     }
   if (S.active) {
-    S.e0 = KIND == 1 ? P.t_in[i] : KIND == 3 ? P.z[i] : P.r[i];
-    S.e1 = (KIND == 0 || KIND == 1) ? P.dinv[i] : KIND == 3 ? P.val[S.lo - 1] : 1.0;      // the diagonal of U sits just before the row's upper entries (inverted in stage Z, a step later: off the level's critical path)
+    S.e0 = KIND == 1 ? tri_ld(P.t_in, i) : KIND == 3 ? tri_ld((const double*)P.z, i) : tri_ld(P.r, i);
+    S.e1 = (KIND == 0 || KIND == 1) ? tri_ld(P.dinv, i) : KIND == 3 ? tri_ld(P.val, S.lo - 1) : 1.0;      // the diagonal of U sits just before the row's upper entries (inverted in stage Z, a step later: off the level's critical path)
   }
 }
 // stage Z: operands from global memory (entries of levels at least two back, or of another launch)
@@ -372,7 +388,7 @@ __device__ __forceinline__ void tri_stage_z(const TriRun& P, TriSlot<PF>& S) {
 #endif
 #pragma unroll
   for (int q = 0; q < PF; q++)
-    if (q < S.nv && S.c[q] >= 0) S.zq[q] = P.z[S.c[q]];
+    if (q < S.nv && S.c[q] >= 0) S.zq[q] = tri_ld((const double*)P.z, S.c[q]);
   if (KIND == 3 && S.active) S.e1 = 1.0 / S.e1;
 }
 template <int KIND>
@@ -500,7 +516,7 @@ __device__ void tri_prefetch(const TriRun& P) {
 
 template <int KIND, int PF>      // 0: Gauss-Seidel forward, 1: backward, 2: ILU lower, 3: ILU upper
 __global__ __launch_bounds__(1024) void k_tri_run(TriRun P) {
-  __shared__ double zl[2][TRI_SMALL];             // z of the rows of the previous / of this level, by rank inside the level
+  __shared__ double zl[TRI_RING * TRI_SMALL];     // z of the rows of the last TRI_RING levels, by level number modulo TRI_RING and rank inside the level
   const int gl = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int l0 = P.l0, lend = P.l0 + P.nl;
   if (blockIdx.x != 0) {
@@ -508,50 +524,57 @@ __global__ __launch_bounds__(1024) void k_tri_run(TriRun P) {
     return;
   }
   TriSlot<PF> S0, S1, S2;
+  TriRow R0, R1;
   auto lp = [&](int L) { return P.lptr[min(L, lend)]; };        // level pointers, clamped to the run (lend itself is the end of the last level)
-  // prologue: level l0 complete, l0 + 1 up to its entries, l0 + 2 its rows, the pointer pair of l0 + 3
+  const int fb = lp(l0), fn = lp(l0 + 1) - fb;      // what stage A repeats beyond the end of the run (an existing level, nothing stored)
+  auto rows_of = [&](int L, int b, int e, TriRow& R) {         // stage A of level L with its pointer pair (b, e)
+    const bool in = L < lend;
+    tri_stage_a(P, in, in ? b : fb, in ? e - b : fn, grp, R);
+  };
+  // prologue: level l0 complete, l0 + 1 up to its entries, l0 + 2 its rows (in R0: l0 + 2 is even from l0), the pointer pair of l0 + 3
+  int nb, ne;
   {
     const int p0 = lp(l0), p1 = lp(l0 + 1), p2 = lp(l0 + 2), p3 = lp(l0 + 3);
-    tri_stage_a(P, true, p0, p1 - p0, grp, S0);
-    tri_stage_a(P, l0 + 1 < lend, l0 + 1 < lend ? p1 : p0, l0 + 1 < lend ? p2 - p1 : p1 - p0, grp, S1);
-    tri_stage_a(P, l0 + 2 < lend, l0 + 2 < lend ? p2 : p0, l0 + 2 < lend ? p3 - p2 : p1 - p0, grp, S2);
+    rows_of(l0, p0, p1, R0);
+    rows_of(l0 + 1, p1, p2, R1);
+    tri_stage_c<KIND, PF>(P, gl, R0, S0);
+    tri_stage_c<KIND, PF>(P, gl, R1, S1);
+    rows_of(l0 + 2, p2, p3, R0);
+    nb = p3;
+    ne = lp(l0 + 4);
   }
-  tri_stage_c<KIND, PF>(P, gl, S0); tri_stage_c<KIND, PF>(P, gl, S1);
   tri_stage_z<KIND, PF>(P, S0);
-  int nb = lp(l0 + 3), ne = lp(l0 + 4);             // pointer pair of the level stage A takes next; the pair after it is asked for a step ahead
-  const int fb = lp(l0), fn = lp(l0 + 1) - fb;      // what stage A repeats beyond the end of the run (an existing level, nothing stored)
-  // iteration for level l in slot CUR: operands of l + 1 (Z), entries of l + 2 (C), the level itself, rows of l + 3 (A, into CUR, behind the level's arithmetic),
-  // pointer pair of l + 4.  The LDS buffers alternate with the level, the slots with a period of three: six steps per trip, NOT guarded one by one -- the steps
-  // past the end of the run find inactive slots and only meet at the barriers -- so that the trip is straight-line code and stage A's load lands in the slot's own
-  // registers (with a guard per step the compiler copied it there behind the barrier: a wait for a load just issued, every level).
-#define TRI_STEP(PH, CUR, NZ, NC)                                                      \
+  // step for level l in slot CUR: entries of l + 2 (C, from the rows asked for a step ago), rows of l + 3 (A), operands of l + 1 (Z), the level itself, pointer pair
+  // of l + 5.  EVERYTHING a step asks for is asked for at its start, behind one wait for what the step before asked for: every load has a whole step to come back.
+  // The LDS buffers alternate with the level, the row sets too, the slots with a period of three: six steps per trip, NOT guarded one by one -- the steps past the
+  // end of the run find inactive slots and only meet at the barriers -- so that the trip is straight-line code.
+#define TRI_STEP(PH, CUR, NZ, NC, RC, RA)                                              \
   {                                                                                    \
     [[maybe_unused]] constexpr int PHV = PH;                                           \
     [[maybe_unused]] const bool stamping = TRI_STAMP && P.stamp && (threadIdx.x == 0 || threadIdx.x == 512) && l + PH - P.l0 >= 200 && l + PH - P.l0 < 232; \
-    [[maybe_unused]] const size_t sbase = threadIdx.x == 0 ? 0 : 256;                                   \
+    [[maybe_unused]] const size_t sbase = threadIdx.x == 0 ? 0 : 256;                  \
     TRI_T(0)                                                                           \
     if (threadIdx.x == 0 && P.nblk > 1) __hip_atomic_store(P.prog, ((unsigned long long)P.id << 32) | (unsigned)CUR.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-    if (TRI_ON(1)) tri_stage_z<KIND, PF>(P, NZ);                                        \
+    if (TRI_ON(2)) tri_stage_c<KIND, PF>(P, gl, RC, NC);                               \
     TRI_T(1)                                                                           \
-    if (TRI_ON(2)) tri_stage_c<KIND, PF>(P, gl, NC);                                    \
-    TRI_T(2)                                                                           \
-    if (TRI_ON(4)) tri_level<KIND, PF>(P, gl, grp, CUR, zl[(PH + 1) & 1], zl[PH & 1]);  \
-    TRI_T(3)                                                                           \
-    const bool in = l + PH + 3 < lend;                                                 \
-    if (TRI_ON(8)) tri_stage_a(P, in, in ? nb : fb, in ? ne - nb : fn, grp, CUR);   \
+    if (TRI_ON(8)) rows_of(l + PH + 3, nb, ne, RA);                                    \
     nb = ne;                                                                           \
     ne = lp(l + PH + 5);                                                               \
+    if (TRI_ON(1)) tri_stage_z<KIND, PF>(P, NZ);                                       \
+    TRI_T(2)                                                                           \
+    if (TRI_ON(4)) tri_level<KIND, PF>(P, gl, grp, CUR, zl, zl + ((l + PH) % TRI_RING) * TRI_SMALL); \
+    TRI_T(3)                                                                           \
     TRI_T(4)                                                                           \
     __syncthreads();                                                                   \
     TRI_T(5)                                                                           \
   }
   for (int l = l0; l < lend; l += 6) {
-    TRI_STEP(0, S0, S1, S2)
-    TRI_STEP(1, S1, S2, S0)
-    TRI_STEP(2, S2, S0, S1)
-    TRI_STEP(3, S0, S1, S2)
-    TRI_STEP(4, S1, S2, S0)
-    TRI_STEP(5, S2, S0, S1)
+    TRI_STEP(0, S0, S1, S2, R0, R1)
+    TRI_STEP(1, S1, S2, S0, R1, R0)
+    TRI_STEP(2, S2, S0, S1, R0, R1)
+    TRI_STEP(3, S0, S1, S2, R1, R0)
+    TRI_STEP(4, S1, S2, S0, R0, R1)
+    TRI_STEP(5, S2, S0, S1, R1, R0)
   }
 #undef TRI_STEP
   if (threadIdx.x == 0 && P.nblk > 1) __hip_atomic_store(P.prog, ((unsigned long long)P.id << 32) | 0xffffffffull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -569,6 +592,7 @@ int fh_tri_ssor_apply(fh_tri_t T, fh_mat_t A, const double* dinv, const double* 
       P.rows = T->d_frows; P.lptr = T->d_fptr; P.src = T->d_fsrc; P.lv = reinterpret_cast<const int4*>(T->d_flv); P.l0 = l; P.nl = T->fseg[q + 1];
       P.id = ++tri_launch_id; P.nblk = tri_blocks(P.nl);
       if (T->run_pf == 2) hipLaunchKernelGGL((k_tri_run<0, 2>), dim3(P.nblk), dim3(1024), 0, s, P);
+      else if (T->run_pf == 3) hipLaunchKernelGGL((k_tri_run<0, 3>), dim3(P.nblk), dim3(1024), 0, s, P);
       else hipLaunchKernelGGL((k_tri_run<0, 4>), dim3(P.nblk), dim3(1024), 0, s, P);
     } else {
       const int n = T->fptr[l + 1] - T->fptr[l];
@@ -582,6 +606,7 @@ int fh_tri_ssor_apply(fh_tri_t T, fh_mat_t A, const double* dinv, const double* 
       P.rows = T->d_brows; P.lptr = T->d_bptr; P.src = T->d_bsrc; P.lv = reinterpret_cast<const int4*>(T->d_blv); P.l0 = l; P.nl = T->bseg[q + 1];
       P.id = ++tri_launch_id; P.nblk = tri_blocks(P.nl);
       if (T->run_pf == 2) hipLaunchKernelGGL((k_tri_run<1, 2>), dim3(P.nblk), dim3(1024), 0, s, P);
+      else if (T->run_pf == 3) hipLaunchKernelGGL((k_tri_run<1, 3>), dim3(P.nblk), dim3(1024), 0, s, P);
       else hipLaunchKernelGGL((k_tri_run<1, 4>), dim3(P.nblk), dim3(1024), 0, s, P);
     } else {
       const int n = T->bptr[l + 1] - T->bptr[l];
@@ -769,6 +794,7 @@ int fh_tri_ilu_apply(fh_tri_t T, fh_mat_t A, const double* r, double* z) {
 #endif
       P.id = ++tri_launch_id; P.nblk = tri_blocks(P.nl);
       if (T->run_pf == 2) hipLaunchKernelGGL((k_tri_run<2, 2>), dim3(P.nblk), dim3(1024), 0, s, P);
+      else if (T->run_pf == 3) hipLaunchKernelGGL((k_tri_run<2, 3>), dim3(P.nblk), dim3(1024), 0, s, P);
       else hipLaunchKernelGGL((k_tri_run<2, 4>), dim3(P.nblk), dim3(1024), 0, s, P);
     } else {
       const int n = T->fptr[l + 1] - T->fptr[l];
@@ -781,6 +807,7 @@ int fh_tri_ilu_apply(fh_tri_t T, fh_mat_t A, const double* r, double* z) {
       P.rows = T->d_brows; P.lptr = T->d_bptr; P.src = T->d_bsrc; P.lv = reinterpret_cast<const int4*>(T->d_blv); P.l0 = l; P.nl = T->bseg[q + 1];
       P.id = ++tri_launch_id; P.nblk = tri_blocks(P.nl);
       if (T->run_pf == 2) hipLaunchKernelGGL((k_tri_run<3, 2>), dim3(P.nblk), dim3(1024), 0, s, P);
+      else if (T->run_pf == 3) hipLaunchKernelGGL((k_tri_run<3, 3>), dim3(P.nblk), dim3(1024), 0, s, P);
       else hipLaunchKernelGGL((k_tri_run<3, 4>), dim3(P.nblk), dim3(1024), 0, s, P);
     } else {
       const int n = T->bptr[l + 1] - T->bptr[l];

@@ -29,3 +29,4 @@ for _ in range(10):
     mg.vcycle(ns.RES[3], x)
 ctx.sync()
 print(json.dumps({"dbg": os.environ.get("FEMUS_TRI_DBG", "0"), "cycle_ms": (time.time() - t) / 10 * 1e3}))
+ns.destroy()          # (a TRI_STAMP dev build prints its clock stamps when the plans go)

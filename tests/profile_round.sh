@@ -98,6 +98,8 @@ for set in "FETCH_SIZE" "WRITE_SIZE"; do
 done
 python $ROOT/profiles/summarize.py /tmp/pmc3 $OUT/${TAG}_assembly_no_carried_rows_pmc_summary.md > /dev/null
 bash $ROOT/tests/profile_known_answer.sh $TAG
+bash $ROOT/tests/pmc_trisweep.sh $TAG > /dev/null 2>&1        # counters of the sweeps' run kernel -> ${TAG}_trisweep_pmc_summary.md
+python $ROOT/tests/perf_probe_trisweep.py 2> /dev/null | grep cycle_ms > $OUT/${TAG}_trisweep_probe.json
 python $ROOT/tests/dev/probe12.py 2>&1 | grep -A11 "k_galerkin_macro phase" > $OUT/${TAG}_galerkin_macro_phase_stamps.txt
 # ---- set-up of the bench problem stage by stage (levels refined on the device, round 5) and the same with the host loops ----
 python $ROOT/tests/perf_probe_setup.py --device 2> /dev/null | sed -n '/^{/,$p' > $OUT/${TAG}_setup_probe.json
