@@ -18,4 +18,8 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_tri/p$i -- python $ROOT/tests/perf_probe_trisweep.py > /tmp/pmc_tri/log$i.txt 2>&1 || { echo "pass $i ($set) failed"; tail -2 /tmp/pmc_tri/log$i.txt; }
 done
-python $ROOT/profiles/summarize.py /tmp/pmc_tri $OUT/${TAG}_trisweep_pmc_summary.md | grep "k_tri_run" | head -40
+python $ROOT/profiles/summarize.py /tmp/pmc_tri /tmp/pmc_tri/all.md > /dev/null
+# keep the rows of the sweeps' kernels only (the run holds the whole set-up of the problem)
+{ echo "counters of tests/perf_probe_trisweep.py (rocprofv3 --pmc, separate passes, --kernel-trace only), per launch on average; k_tri_run<kind, register slots>: kind 2 = ILU lower, 3 = ILU upper"; echo; grep -E "^\| kernel|^\|---|k_tri_run|k_ilu_" /tmp/pmc_tri/all.md; } > $OUT/${TAG}_trisweep_pmc_summary.md
+rm -f $OUT/${TAG}_trisweep_pmc_summary.json
+grep "k_tri_run" $OUT/${TAG}_trisweep_pmc_summary.md | head -60
