@@ -251,6 +251,7 @@ extern "C" int fh_set_option(fh_ctx_t c, const char* name, double value) {
   else if (!strcmp(name, "assemble_affine")) c->assemble_affine = (int)value;
   else if (!strcmp(name, "assemble_carry")) c->assemble_carry = (int)value;
   else if (!strcmp(name, "tri_runs")) c->tri_runs = (int)value;
+  else if (!strcmp(name, "ilu_ahead")) c->ilu_ahead = (int)value;
   else if (!strcmp(name, "use_graph")) c->use_graph = (int)value;
   else if (!strcmp(name, "mg_reuse_graph")) c->mg_reuse_graph = (int)value;
   else if (!strcmp(name, "spgemm_slot_map")) c->spgemm_slot_map = (int)value;

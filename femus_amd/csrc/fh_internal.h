@@ -95,6 +95,7 @@ struct fh_ctx_s {
   int assemble_sym = 1;              // symmetric-tile HEX27/Q2 element kernel (2 elements per wave)
   int assemble_two_pass = 1;         // 1: element matrices + row gather (default), 0: coloured scatter
   int assemble_fused = 1;            // HEX27/Q2 meshes whose elements come in sibling groups of eight: fused cluster assembly (rows complete inside a group go straight to the CSR arrays)
+  int ilu_ahead = 2;                 // ILU(0) factorisation with the pivot rows asked for ahead of the elimination chain: 2 with the positions from a plan built once per pattern (k_ilu_factor_plan), 1 searched (k_ilu_factor_ahead); 0: the round-5 kernel (A/B of the bitwise test)
   int tri_runs = 1;                  // natural-order sweeps: runs of small levels in one workgroup (fh_trisolve.hip k_tri_run); 0: one launch per level (the A/B of the bitwise test)
   int assemble_carry = -1;           // fused cluster assembly: rows whose elements all lie in one SUPER-cluster of 8^k consecutive clusters (k = value / 3) are accumulated in the CSR array
                                      // itself by the one workgroup that walks the super-cluster (store / load-add-store, ascending cluster order), not through the partial-row buffer;

@@ -16,6 +16,11 @@ struct fh_tri_s {
   // the run kernel keeps the values of the previous level in LDS, so the one link of a level's dependency chain that cannot be loaded ahead is an LDS read
   int *d_fsrc = nullptr, *d_bsrc = nullptr;
   int *d_flv = nullptr, *d_blv = nullptr;      // per row in level order: {row, first entry, end, diagonal position} (one 16-byte load instead of a chain of three)
+  // elimination plan of the ILU(0) factorisation (built at the first factorisation): for every entry left of a diagonal (a pivot of its row) where the pivot row's
+  // entries right of ITS diagonal land in the row -- one byte each (255: nowhere), d_ppofs[p] = first byte of the pivot at entry p
+  int* d_ppofs = nullptr;
+  unsigned char* d_ppos = nullptr;
+  int plan_state = 0;                    // 0 not tried, 1 built, -1 not served (rows of more than 254 entries, or more than 2^31 bytes)
   unsigned long long* d_prog = nullptr;  // progress word of the run kernel's main workgroup, read by its prefetching workgroup (fh_trisolve.hip)
   int run_pf = 2;                       // register slots per lane of the run kernel: 2 while the mean triangle of a row has at most 32 entries, else 4
   double* d_lu = nullptr;               // ILU(0) factors on A's pattern: strict lower part = L (unit diagonal), rest = U

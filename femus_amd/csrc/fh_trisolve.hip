@@ -201,7 +201,7 @@ void fh_tri_destroy(fh_tri_t T) {
 #if TRI_STAMP
   tri_stamp_report();
 #endif
-  for (void* p : {(void*)T->d_frows, (void*)T->d_brows, (void*)T->d_diagpos, (void*)T->d_lu, (void*)T->d_flag, (void*)T->d_t, (void*)T->d_fptr, (void*)T->d_bptr, (void*)T->d_fsrc, (void*)T->d_bsrc, (void*)T->d_flv, (void*)T->d_blv, (void*)T->d_prog})
+  for (void* p : {(void*)T->d_frows, (void*)T->d_brows, (void*)T->d_diagpos, (void*)T->d_lu, (void*)T->d_flag, (void*)T->d_t, (void*)T->d_fptr, (void*)T->d_bptr, (void*)T->d_fsrc, (void*)T->d_bsrc, (void*)T->d_flv, (void*)T->d_blv, (void*)T->d_prog, (void*)T->d_ppofs, (void*)T->d_ppos})
     if (p) hipFree(p);
   delete T;
 }
@@ -690,6 +690,206 @@ __global__ __launch_bounds__(256) void k_ilu_factor(const int* __restrict__ rows
   }
 }
 
+// The same elimination with the pivot rows asked for AHEAD of the chain (round 6).  What a pivot costs above is two dependent trips to memory -- diagpos[k] /
+// rowptr[k + 1], then u_kk and the row's entries -- behind a look-ahead of one pivot: 2.8 us per lower entry, 89 us for a level of 46 rows of 31 lower entries.
+// The pivot rows are final (earlier launches), so nothing but the arithmetic depends on the order: first the descriptors of ALL pivots of the row (diagonal
+// position, end, u_kk) go into LDS, sixteen pivots per trip; then the elimination runs over them with the lane's first two entries of pivots p + 1 .. p + 3 in three
+// register sets (loop unrolled by three), asked for three steps before they are used.  Same operations on every entry in the same order: the same bits.
+struct IluPivot {
+  int j0, j1;
+  double u0, u1;
+};
+__global__ __launch_bounds__(256) void k_ilu_factor_ahead(const int* __restrict__ rows, int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                          const int* __restrict__ diagpos, double* lu, int m, int maxrow, double zeropivot,
+                                                          int* __restrict__ flag) {
+  extern __shared__ double tri_rows[];             // per group: the row's values, the pivots' u_kk; then its columns, the pivots' diagonal positions and ends
+  const int rr = (blockIdx.x * 256 + threadIdx.x) >> 4, gl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  if (rr >= nrows) return;
+  double* w = tri_rows + (size_t)g * maxrow;
+  double* pu = tri_rows + (size_t)(16 + g) * maxrow;
+  int* ibase = reinterpret_cast<int*>(tri_rows + (size_t)32 * maxrow);
+  int* wc = ibase + (size_t)g * maxrow;
+  int* pd = ibase + (size_t)(16 + g) * maxrow;
+  int* pe = ibase + (size_t)(32 + g) * maxrow;
+  const int i = rows[rr];
+  const int rs = rowptr[i], re = rowptr[i + 1], di = diagpos[i];
+  const int nlow = max(di - rs, 0);                 // entries left of the diagonal = pivots (the columns are sorted)
+  for (int p = rs + gl; p < re; p += 16) {
+    w[p - rs] = lu[p];
+    wc[p - rs] = col[p];
+  }
+  tri_group_sync();
+  for (int t = gl; t < nlow; t += 16) {
+    const int k = wc[t], dk = diagpos[k];
+    pd[t] = dk;
+    pe[t] = rowptr[k + 1];
+    pu[t] = lu[dk];
+  }
+  tri_group_sync();
+  auto fetch = [&](int t, IluPivot& v) {            // the lane's first two entries right of pivot t's diagonal
+    v.j0 = v.j1 = -1;
+    v.u0 = v.u1 = 0.0;
+    if (t < nlow) {
+      const int q0 = pd[t] + 1 + gl, ke = pe[t];
+      if (q0 < ke) {
+        v.j0 = col[q0];
+        v.u0 = lu[q0];
+      }
+      if (q0 + 16 < ke) {
+        v.j1 = col[q0 + 16];
+        v.u1 = lu[q0 + 16];
+      }
+    }
+  };
+  const int nrow = re - rs;
+  auto update = [&](int t, int j, double u, double lik) {      // a_ij -= l_ik u_kj where row i holds column j (right of the pivot's position)
+    if (j < 0 || j >= m) return;                               // no entry / ghost column: not part of the local block
+    int lo = t + 1, hi = nrow - 1;
+    while (lo <= hi) {
+      const int mid = (lo + hi) >> 1;
+      const int cc = wc[mid];
+      if (cc == j) {
+        w[mid] -= lik * u;                                     // distinct j per lane: distinct slots
+        break;
+      }
+      if (cc < j) lo = mid + 1; else hi = mid - 1;
+    }
+  };
+  IluPivot v0, v1, v2;
+  fetch(0, v0);
+  fetch(1, v1);
+  fetch(2, v2);
+#define ILU_STEP(T, V)                                                                     \
+  if ((T) < nlow) {                                                                        \
+    const double lik = w[T] / pu[T];                                                       \
+    tri_group_sync();                                                                      \
+    if (gl == 0) w[T] = lik;                                                               \
+    update(T, V.j0, V.u0, lik);                                                            \
+    update(T, V.j1, V.u1, lik);                                                            \
+    for (int q = pd[T] + 33 + gl; q < pe[T]; q += 16) update(T, col[q], lu[q], lik);       \
+    tri_group_sync();                                                                      \
+    fetch((T) + 3, V);                                                                     \
+  }
+  for (int t = 0; t < nlow; t += 3) {
+    ILU_STEP(t, v0)
+    ILU_STEP(t + 1, v1)
+    ILU_STEP(t + 2, v2)
+  }
+#undef ILU_STEP
+  for (int p = rs + gl; p < re; p += 16) lu[p] = w[p - rs];
+  if (gl == 0) {
+    double rsum = 0.0;
+    for (int p = (di < 0 ? rs : di + 1); p < re; p++) rsum += fabs(w[p - rs]);   // the U part of the row without its diagonal (PETSc: sctx.rs)
+    if (di < 0 || !(fabs(w[di - rs]) > zeropivot * rsum)) atomicOr(flag, 1);
+  }
+}
+
+// The elimination with a PLAN (round 6): what is left per pivot above is the position search -- six dependent LDS reads per entry of the pivot row, two or three
+// entries per lane, every one of the row's ~ 30 pivots: 2.5 us per pivot.  Where an entry of pivot row k lands in row i depends on the pattern alone, so the
+// searches are done once (k_ilu_plan, all rows at once, when the first factorisation of a pattern is asked for) and kept as one byte per (pivot, entry): the
+// factorisation then reads u_kj and a byte and updates w[byte].  Same operations on every entry in the same order as the searching kernels: the same bits.
+__global__ __launch_bounds__(256) void k_ilu_plan(int m, const int* __restrict__ rowptr, const int* __restrict__ col, const int* __restrict__ diagpos,
+                                                  const int* __restrict__ ppofs, unsigned char* __restrict__ ppos) {
+  const int i = (blockIdx.x * 256 + threadIdx.x) >> 4, gl = threadIdx.x & 15;
+  if (i >= m) return;
+  const int rs = rowptr[i], re = rowptr[i + 1], nlow = max(diagpos[i] - rs, 0);
+  for (int t = 0; t < nlow; t++) {
+    const int k = col[rs + t], dk = diagpos[k], ke = rowptr[k + 1], o = ppofs[rs + t];
+    for (int q = dk + 1 + gl; q < ke; q += 16) {
+      const int j = col[q];
+      int pos = 255;
+      if (j < m) {
+        int lo = rs + t + 1, hi = re - 1;
+        while (lo <= hi) {
+          const int mid = lo + ((hi - lo) >> 1);
+          const int cc = col[mid];
+          if (cc == j) {
+            pos = mid - rs;
+            break;
+          }
+          if (cc < j) lo = mid + 1; else hi = mid - 1;
+        }
+      }
+      ppos[o + (q - dk - 1)] = (unsigned char)pos;
+    }
+  }
+}
+struct IluPlanned {
+  int b0, b1;
+  double u0, u1;
+};
+__global__ __launch_bounds__(256) void k_ilu_factor_plan(const int* __restrict__ rows, int nrows, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                         const int* __restrict__ diagpos, const int* __restrict__ ppofs,
+                                                         const unsigned char* __restrict__ ppos, double* lu, int maxrow, double zeropivot,
+                                                         int* __restrict__ flag) {
+  extern __shared__ double tri_rows[];             // per group: the row's values, the pivots' u_kk; then the pivots' diagonal positions, ends and plan offsets
+  const int rr = (blockIdx.x * 256 + threadIdx.x) >> 4, gl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  if (rr >= nrows) return;
+  double* w = tri_rows + (size_t)g * maxrow;
+  double* pu = tri_rows + (size_t)(16 + g) * maxrow;
+  int* ibase = reinterpret_cast<int*>(tri_rows + (size_t)32 * maxrow);
+  int* pd = ibase + (size_t)g * maxrow;
+  int* pe = ibase + (size_t)(16 + g) * maxrow;
+  int* po = ibase + (size_t)(32 + g) * maxrow;
+  const int i = rows[rr];
+  const int rs = rowptr[i], re = rowptr[i + 1], di = diagpos[i];
+  const int nlow = max(di - rs, 0);                 // entries left of the diagonal = pivots (the columns are sorted)
+  for (int p = rs + gl; p < re; p += 16) w[p - rs] = lu[p];
+  for (int t = gl; t < nlow; t += 16) {
+    const int k = col[rs + t], dk = diagpos[k];
+    pd[t] = dk;
+    pe[t] = rowptr[k + 1];
+    po[t] = ppofs[rs + t];
+    pu[t] = lu[dk];
+  }
+  tri_group_sync();
+  auto fetch = [&](int t, IluPlanned& v) {          // the lane's first two entries right of pivot t's diagonal: value and place in this row
+    v.b0 = v.b1 = 255;
+    v.u0 = v.u1 = 0.0;
+    if (t < nlow) {
+      const int q0 = pd[t] + 1 + gl, ke = pe[t], o = po[t] + gl;
+      if (q0 < ke) {
+        v.b0 = ppos[o];
+        v.u0 = lu[q0];
+      }
+      if (q0 + 16 < ke) {
+        v.b1 = ppos[o + 16];
+        v.u1 = lu[q0 + 16];
+      }
+    }
+  };
+  IluPlanned v0, v1, v2;
+  fetch(0, v0);
+  fetch(1, v1);
+  fetch(2, v2);
+#define ILU_STEP(T, V)                                                                     \
+  if ((T) < nlow) {                                                                        \
+    const double lik = w[T] / pu[T];                                                       \
+    tri_group_sync();                                                                      \
+    if (gl == 0) w[T] = lik;                                                               \
+    if (V.b0 != 255) w[V.b0] -= lik * V.u0;                                                \
+    if (V.b1 != 255) w[V.b1] -= lik * V.u1;                                                \
+    for (int q = pd[T] + 33 + gl; q < pe[T]; q += 16) {                                    \
+      const int b = ppos[po[T] + (q - pd[T] - 1)];                                         \
+      if (b != 255) w[b] -= lik * lu[q];                                                   \
+    }                                                                                      \
+    tri_group_sync();                                                                      \
+    fetch((T) + 3, V);                                                                     \
+  }
+  for (int t = 0; t < nlow; t += 3) {
+    ILU_STEP(t, v0)
+    ILU_STEP(t + 1, v1)
+    ILU_STEP(t + 2, v2)
+  }
+#undef ILU_STEP
+  for (int p = rs + gl; p < re; p += 16) lu[p] = w[p - rs];
+  if (gl == 0) {
+    double rsum = 0.0;
+    for (int p = (di < 0 ? rs : di + 1); p < re; p++) rsum += fabs(w[p - rs]);   // the U part of the row without its diagonal (PETSc: sctx.rs)
+    if (di < 0 || !(fabs(w[di - rs]) > zeropivot * rsum)) atomicOr(flag, 1);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_ilu_shift(double* __restrict__ lu, const int* __restrict__ diagpos, int m, double shift) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < m && diagpos[i] >= 0) lu[diagpos[i]] += shift;
@@ -713,10 +913,38 @@ int fh_tri_ilu_factor(fh_tri_t T, fh_mat_t A) {
   (void)hipGetLastError();
   lds_max = std::max(std::max(lds_max, lds_optin), 64 * 1024);
   const bool lcol = maxrow <= 800 && (size_t)16 * maxrow * (sizeof(double) + sizeof(int)) <= (size_t)lds_max;
-  const size_t lds = (size_t)16 * maxrow * (sizeof(double) + (lcol ? sizeof(int) : 0));
+  // pivot descriptors in LDS too (k_ilu_factor_ahead): 28 bytes per entry of the longest row and group
+  const bool ahead = c->ilu_ahead && (size_t)16 * maxrow * 28 <= (size_t)lds_max;
+  if (ahead && c->ilu_ahead >= 2 && T->plan_state == 0) {       // the elimination plan of this pattern, once
+    T->plan_state = -1;
+    if (maxrow <= 254) {
+      const std::vector<int>& hc = fh_hcol(A);
+      std::vector<int> pofs((size_t)std::max(A->nnz, 1), 0);
+      int64_t total = 0;
+      for (int i = 0; i < A->m; i++)
+        for (int p = A->h_rowptr[i]; p < T->h_diagpos[i]; p++) {
+          const int k = hc[p];
+          pofs[p] = (int)std::min<int64_t>(total, 2147483647);
+          total += A->h_rowptr[k + 1] - T->h_diagpos[k] - 1;
+        }
+      if (total < 2147483647ll) {
+        FH_CHECK_HIP(hipMalloc(&T->d_ppofs, pofs.size() * sizeof(int)));
+        FH_CHECK_HIP(hipMemcpyAsync(T->d_ppofs, pofs.data(), pofs.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        FH_CHECK_HIP(hipMalloc(&T->d_ppos, (size_t)std::max<int64_t>(total, 1) + 64));
+        hipLaunchKernelGGL(k_ilu_plan, dim3(fh_div_up((int64_t)A->m * 16, 256)), dim3(256), 0, c->stream, A->m, A->d_rowptr, A->d_col, T->d_diagpos, T->d_ppofs,
+                           T->d_ppos);
+        FH_CHECK_HIP(hipGetLastError());
+        FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+        T->plan_state = 1;
+        FH_TRACE("fh_tri_ilu_factor: elimination plan of %d rows, %lld bytes", A->m, (long long)total);
+      }
+    }
+  }
+  const bool planned = ahead && c->ilu_ahead >= 2 && T->plan_state == 1;
+  const size_t lds = ahead ? (size_t)16 * maxrow * 28 : (size_t)16 * maxrow * (sizeof(double) + (lcol ? sizeof(int) : 0));
   FH_REQUIRE(lds <= (size_t)lds_max, "ILU(0): a row with %d entries needs %zu bytes of LDS per workgroup, the device grants %d", maxrow, lds, lds_max);
   if (lds > 64 * 1024)
-    FH_CHECK_HIP(hipFuncSetAttribute(lcol ? reinterpret_cast<const void*>(&k_ilu_factor<true>) : reinterpret_cast<const void*>(&k_ilu_factor<false>),
+    FH_CHECK_HIP(hipFuncSetAttribute(planned ? reinterpret_cast<const void*>(&k_ilu_factor_plan) : ahead ? reinterpret_cast<const void*>(&k_ilu_factor_ahead) : lcol ? reinterpret_cast<const void*>(&k_ilu_factor<true>) : reinterpret_cast<const void*>(&k_ilu_factor<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   double shift = 0.0;
   for (int attempt = 0; attempt < 40; attempt++) {
@@ -725,7 +953,13 @@ int fh_tri_ilu_factor(fh_tri_t T, fh_mat_t A) {
     FH_CHECK_HIP(hipMemsetAsync(T->d_flag, 0, sizeof(int), c->stream));
     for (int l = 0; l < nf; l++) {
       const int n = T->fptr[l + 1] - T->fptr[l];
-      if (lcol)
+      if (planned)
+        hipLaunchKernelGGL(k_ilu_factor_plan, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), lds, c->stream, T->d_frows + T->fptr[l], n, A->d_rowptr, A->d_col,
+                           T->d_diagpos, T->d_ppofs, T->d_ppos, T->d_lu, maxrow, 1e-16, T->d_flag);
+      else if (ahead)
+        hipLaunchKernelGGL(k_ilu_factor_ahead, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), lds, c->stream, T->d_frows + T->fptr[l], n, A->d_rowptr,
+                           A->d_col, T->d_diagpos, T->d_lu, A->m, maxrow, 1e-16, T->d_flag);
+      else if (lcol)
         hipLaunchKernelGGL(k_ilu_factor<true>, dim3(fh_div_up((int64_t)n * 16, 256)), dim3(256), lds, c->stream, T->d_frows + T->fptr[l], n, A->d_rowptr,
                            A->d_col, T->d_diagpos, T->d_lu, A->m, maxrow, 1e-16, T->d_flag);
       else

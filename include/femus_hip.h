@@ -67,7 +67,7 @@ int fh_graph_destroy(fh_graph_t graph);
  * names (default): "spmv_tile" (2048), "spmv_xcd_remap" (32), "spmv_kernel" (3), "assemble_two_pass" (1), "assemble_emap" (1),
  * "assemble_mfma" (12: HEX27/Q2 element matrices on the FP64 matrix cores, value = waves per workgroup, 0 = vector kernel),
  * "assemble_kpad" (1: element rows of the two-pass buffer padded to 256 bytes; read when an assembler is created),
- * "assemble_sumfac" (1: map Jacobian by sum factorisation in that kernel), "assemble_sym" (1), "assemble_affine" (0, see fh_assembler_affine_count), "assemble_fused" (1, see fh_assembler_fused_info), "assemble_carry" (-1, see fh_assembler_carry_info), "tri_runs" (1: natural-order sweeps take runs of small levels in one workgroup; 0: one launch per level -- read when a level solver is set up), "gj_mfma" (1: coarse dense inverse updates on the
+ * "assemble_sumfac" (1: map Jacobian by sum factorisation in that kernel), "assemble_sym" (1), "assemble_affine" (0, see fh_assembler_affine_count), "assemble_fused" (1, see fh_assembler_fused_info), "assemble_carry" (-1, see fh_assembler_carry_info), "ilu_ahead" (2: ILU(0) factorisation with the pivot rows loaded ahead of the elimination chain and the update positions from a plan built once per pattern; 1: positions searched; 0: the one-pivot look-ahead), "tri_runs" (1: natural-order sweeps take runs of small levels in one workgroup; 0: one launch per level -- read when a level solver is set up), "gj_mfma" (1: coarse dense inverse updates on the
  * matrix cores), "gj_symmetric" (1: symmetric sweep on the upper block triangle when the coarse operator is symmetric), "spgemm_slot_map" (1), "spgemm_device_symbolic" (1: patterns of sparse products on the device), "device_setup" (1: prolongators built on the device; 0: host loops, identical matrices), "use_graph" (1), "asm_debug" (0),
  * "debug_poison" (0; tests: work buffers of the solvers and the element-row buffers start as NaN bit patterns instead of zero),
  * "galerkin_macro" (1: fh_assembler_galerkin after a fused assembly reads the macro rows that assembly left behind), "vanka_fused" (1: block smoothers

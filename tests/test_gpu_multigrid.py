@@ -328,6 +328,30 @@ def test_natural_order_smoothers_match_the_sequential_oracle(ctx, smoother, name
     mg.destroy()
 
 
+@pytest.mark.parametrize("box,fe,nl", [((24, 24, 0), "biquadratic", 2), ((3, 3, 3), "biquadratic", 2), ((16, 16, 0), "linear", 3)])
+def test_ilu_factorisation_with_the_pivot_rows_asked_for_ahead_gives_the_same_bits(ctx, box, fe, nl):
+    """k_ilu_factor_plan (update positions from a plan built once per pattern; option ilu_ahead = 2, the default) and k_ilu_factor_ahead (descriptors of all pivots of a
+    row in LDS first, the entries of three pivots ahead in registers, positions searched; 1) do the operations of the kernel with a one-pivot look-ahead (0) in the same order: one V(2,1) cycle with the ILU(0) level solves gives the same bits, and the sequential oracle's
+    to 1e-11"""
+    H = fo.build_poisson_hierarchy(*box, nl, fe, ONE)
+    n = H.A[-1].shape[0]
+    rhs = fo.lcg_fill(n, 35)
+    out = []
+    for ahead in (2, 1, 0):
+        ctx.set_option("ilu_ahead", ahead)
+        try:
+            mg, mats = device_hierarchy(ctx, H, 0.8, 2, 1, smoother=capi.SMOOTH_ILU0)
+            b, x = ctx.vector_from(rhs), ctx.vector(n)
+            mg.vcycle(b, x)
+            out.append(x.to_numpy().copy())
+            mg.destroy()
+        finally:
+            ctx.set_option("ilu_ahead", 2)
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+    ref = fo.vcycle(H, nl - 1, rhs, omega=0.8, npre=2, npost=1, smoother="ilu0")
+    assert rel(out[0], ref) < 1e-11
+
+
 @pytest.mark.parametrize("smoother", [capi.SMOOTH_SOR, capi.SMOOTH_ILU0])
 @pytest.mark.parametrize("box,fe,nl", [((24, 24, 0), "biquadratic", 2), ((3, 3, 3), "biquadratic", 2)])
 def test_runs_of_small_levels_give_the_bits_of_a_launch_per_level(ctx, smoother, box, fe, nl):
