@@ -22,7 +22,7 @@ struct fh_tri_s {
   unsigned char* d_ppos = nullptr;
   int plan_state = 0;                    // 0 not tried, 1 built, -1 not served (rows of more than 254 entries, or more than 2^31 bytes)
   unsigned long long* d_prog = nullptr;  // progress word of the run kernel's main workgroup, read by its prefetching workgroup (fh_trisolve.hip)
-  int run_pf = 2;                       // register slots per lane of the run kernel: 2 while the mean triangle of a row has at most 32 entries, else 4
+  int run_pf = 2, run_pb = 2;           // register slots per lane of the run kernel, forward / backward sweep: 2 while 90 % of the lower / upper triangles have at most 32 entries, else 4
   double* d_lu = nullptr;               // ILU(0) factors on A's pattern: strict lower part = L (unit diagonal), rest = U
   int* d_flag = nullptr;
   double* d_t = nullptr;                // symmetric sweep: t = r - L z of the forward half, read by the backward half

@@ -125,7 +125,8 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
   // per row in level order: {row, first entry of the sweep's triangle, its end, w}; forward: the entries left of the diagonal, w = position of the diagonal;
   // backward: the entries right of the diagonal without the ghost columns, w = start of the whole row (the lanes keep the entries they have in the
   // one-launch-per-level kernels, which walk the whole row: the same partial sums, the same bits -- the run kernel just does not load the other triangle)
-  int64_t tri_len_sum = 0;
+  int64_t tri_len_f = 0, tri_len_b = 0;
+  std::vector<int> hist_f(1024, 0), hist_b(1024, 0);
   auto level_rows = [&](const std::vector<int>& lvrows, const std::vector<int>& dp, bool forward, int** d_lv) -> int {
     std::vector<int> lv((size_t)std::max(A->m, 1) * 4, 0);
     const std::vector<int>& col = fh_hcol(A);
@@ -135,7 +136,8 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
       const int* e = col.data() + A->h_rowptr[i + 1];
       lv[(size_t)k * 4 + 0] = i;
       const int lower = (int)(std::lower_bound(b, e, i) - b), upper = (int)(std::lower_bound(b, e, A->m) - std::upper_bound(b, e, i));
-      tri_len_sum += forward ? lower : upper;
+      (forward ? tri_len_f : tri_len_b) += forward ? lower : upper;
+      (forward ? hist_f : hist_b)[std::min(forward ? lower : upper, 1023)]++;
       if (forward) {
         lv[(size_t)k * 4 + 1] = A->h_rowptr[i];
         lv[(size_t)k * 4 + 2] = (int)(std::lower_bound(b, e, i) - col.data());
@@ -166,13 +168,26 @@ static int tri_fill(fh_mat_t A, fh_tri_t T) {
   T->h_diagpos = dpos;
   FH_CHECK_HIP(hipMalloc(&T->d_prog, 2 * sizeof(unsigned long long)));
   FH_CHECK_HIP(hipMemset(T->d_prog, 0, 2 * sizeof(unsigned long long)));
-  T->run_pf = 2;
   FH_TRY(level_rows(rows, dpos, true, &T->d_flv));
   FH_TRY(level_rows(brows, dpos, false, &T->d_blv));
-  // two slots (32 entries of the triangle per row in registers) while the MEAN triangle is within them: measured on the stacked two-dimensional system, a third of
-  // whose rows have 37 lower entries, two slots with those rows' tails in the loop beat four by 8 %
-  T->run_pf = (tri_len_sum <= (int64_t)32 * 2 * std::max(A->m, 1)) ? 2 : 4;
-  if (const char* e = getenv("FEMUS_TRI_PF")) T->run_pf = atoi(e) == 2 ? 2 : atoi(e) == 3 ? 3 : 4;      // measurements
+  // register slots per lane and direction by the 90th percentile of the lengths of the direction's triangles (measured on the stacked two-dimensional system of the
+  // known-answer test -- lower triangles: median 18, 90 % within 26, longest 33; upper: 12, 34, 76 --: lower sweep 0.62 / 0.65 / 0.69 ms with 2 / 3 / 4 slots, upper
+  // sweep 0.73 / 0.67 / 0.64: a slot is instructions in every step whether a row fills it or not, a tail in the loop is a round trip to the L2 that the whole level
+  // waits for)
+  const double mean_f = (double)tri_len_f / std::max(A->m, 1), mean_b = (double)tri_len_b / std::max(A->m, 1);
+  auto pct = [&](const std::vector<int>& h, double f) {
+    int64_t acc = 0;
+    for (int v = 0; v < 1024; v++) {
+      acc += h[v];
+      if ((double)acc >= f * A->m) return v;
+    }
+    return 1023;
+  };
+  FH_TRACE("fh_tri_create: lower p50 / p75 / p90 / max %d / %d / %d / %d, upper %d / %d / %d / %d", pct(hist_f, 0.5), pct(hist_f, 0.75), pct(hist_f, 0.9), pct(hist_f, 1.0), pct(hist_b, 0.5), pct(hist_b, 0.75), pct(hist_b, 0.9), pct(hist_b, 1.0));
+  T->run_pf = pct(hist_f, 0.9) <= 32 ? 2 : 4;
+  T->run_pb = pct(hist_b, 0.9) <= 32 ? 2 : 4;
+  FH_TRACE("fh_tri_create: %d rows, mean lower / upper triangle %.1f / %.1f entries, %d / %d register slots per lane", A->m, mean_f, mean_b, T->run_pf, T->run_pb);
+  if (const char* e = getenv("FEMUS_TRI_PF")) T->run_pf = T->run_pb = atoi(e) == 2 ? 2 : atoi(e) == 3 ? 3 : 4;      // measurements
   FH_CHECK_HIP(hipMalloc(&T->d_diagpos, std::max(A->m, 1) * sizeof(int)));
   FH_CHECK_HIP(hipMemcpy(T->d_diagpos, dpos.data(), (size_t)A->m * sizeof(int), hipMemcpyHostToDevice));
   FH_CHECK_HIP(hipMalloc(&T->d_t, std::max(A->m, 1) * sizeof(double)));
@@ -605,8 +620,8 @@ int fh_tri_ssor_apply(fh_tri_t T, fh_mat_t A, const double* dinv, const double* 
     if (T->bseg[q + 2]) {
       P.rows = T->d_brows; P.lptr = T->d_bptr; P.src = T->d_bsrc; P.lv = reinterpret_cast<const int4*>(T->d_blv); P.l0 = l; P.nl = T->bseg[q + 1];
       P.id = ++tri_launch_id; P.nblk = tri_blocks(P.nl);
-      if (T->run_pf == 2) hipLaunchKernelGGL((k_tri_run<1, 2>), dim3(P.nblk), dim3(1024), 0, s, P);
-      else if (T->run_pf == 3) hipLaunchKernelGGL((k_tri_run<1, 3>), dim3(P.nblk), dim3(1024), 0, s, P);
+      if (T->run_pb == 2) hipLaunchKernelGGL((k_tri_run<1, 2>), dim3(P.nblk), dim3(1024), 0, s, P);
+      else if (T->run_pb == 3) hipLaunchKernelGGL((k_tri_run<1, 3>), dim3(P.nblk), dim3(1024), 0, s, P);
       else hipLaunchKernelGGL((k_tri_run<1, 4>), dim3(P.nblk), dim3(1024), 0, s, P);
     } else {
       const int n = T->bptr[l + 1] - T->bptr[l];
@@ -1040,8 +1055,8 @@ int fh_tri_ilu_apply(fh_tri_t T, fh_mat_t A, const double* r, double* z) {
     if (T->bseg[q + 2]) {
       P.rows = T->d_brows; P.lptr = T->d_bptr; P.src = T->d_bsrc; P.lv = reinterpret_cast<const int4*>(T->d_blv); P.l0 = l; P.nl = T->bseg[q + 1];
       P.id = ++tri_launch_id; P.nblk = tri_blocks(P.nl);
-      if (T->run_pf == 2) hipLaunchKernelGGL((k_tri_run<3, 2>), dim3(P.nblk), dim3(1024), 0, s, P);
-      else if (T->run_pf == 3) hipLaunchKernelGGL((k_tri_run<3, 3>), dim3(P.nblk), dim3(1024), 0, s, P);
+      if (T->run_pb == 2) hipLaunchKernelGGL((k_tri_run<3, 2>), dim3(P.nblk), dim3(1024), 0, s, P);
+      else if (T->run_pb == 3) hipLaunchKernelGGL((k_tri_run<3, 3>), dim3(P.nblk), dim3(1024), 0, s, P);
       else hipLaunchKernelGGL((k_tri_run<3, 4>), dim3(P.nblk), dim3(1024), 0, s, P);
     } else {
       const int n = T->bptr[l + 1] - T->bptr[l];
