@@ -248,6 +248,7 @@ static int build_slot_map_long(fh_mat_t A, fh_mat_t B, fh_mat_t C, SlotMap& M) {
   std::vector<long long> rb((size_t)m + 1);
   FH_CHECK_HIP(hipMemcpyAsync(rb.data(), M.rowbase, rb.size() * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  FH_TRACE("slot map (long rows): products counted");
   for (int r = 0; r < m; r++) rb[r + 1] += rb[r];
   M.nprod = rb[m];
   size_t free_b = 0, total_b = 0;
@@ -262,6 +263,7 @@ static int build_slot_map_long(fh_mat_t A, fh_mat_t B, fh_mat_t C, SlotMap& M) {
                      C->d_col, M.rowbase, M.slot, m);
   FH_CHECK_HIP(hipGetLastError());
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  FH_TRACE("slot map (long rows): slots filled (%lld products)", (long long)M.nprod);
   return 0;
 }
 
@@ -291,6 +293,7 @@ static int build_slot_map(fh_mat_t A, fh_mat_t B, fh_mat_t C, SlotMap& M) {
   std::vector<long long> rb((size_t)m + 1);
   FH_CHECK_HIP(hipMemcpyAsync(rb.data(), M.rowbase, rb.size() * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  FH_TRACE("slot map: products counted");
   for (int r = 0; r < m; r++) {
     if (rb[r + 1] > 2000000000ll) {   // segment offsets inside a row are 32-bit
       M.release();
@@ -306,12 +309,14 @@ static int build_slot_map(fh_mat_t A, fh_mat_t B, fh_mat_t C, SlotMap& M) {
     return 0;
   }
   FH_CHECK_HIP(hipMemcpyAsync(M.rowbase, rb.data(), rb.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+  FH_TRACE("slot map: scanned");
   FH_CHECK_HIP(hipMalloc(&M.pa, (size_t)M.nprod * sizeof(unsigned short)));
   FH_CHECK_HIP(hipMalloc(&M.pb, (size_t)M.nprod * sizeof(int)));
   hipLaunchKernelGGL(k_spgemm_segfill, dim3(fh_div_up(m, 4)), dim3(256), lds, c->stream, A->d_rowptr, A->d_col, B->d_rowptr, B->d_col, C->d_rowptr,
                      C->d_col, M.rowbase, M.segptr, M.pa, M.pb, m, max_crow, gl_log2);
   FH_CHECK_HIP(hipGetLastError());
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  FH_TRACE("slot map: lists filled (%lld products)", (long long)M.nprod);
   return 0;
 }
 
@@ -524,6 +529,7 @@ static int spgemm_symbolic_device(fh_mat_t A, fh_mat_t B, fh_mat_t* Cout) {
   FH_CHECK_HIP(hipMemcpyAsync(rp.data() + 1, d_len, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   FH_CHECK_HIP(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  FH_TRACE("spgemm symbolic: row lengths counted (%d rows)", m);
   int64_t tot = 0;
   for (int r = 0; r < m && !err; r++) {
     tot += rp[r + 1];
@@ -542,13 +548,16 @@ static int spgemm_symbolic_device(fh_mat_t A, fh_mat_t B, fh_mat_t* Cout) {
     fh_mat_destroy(C);
     return 2;
   }
+  FH_TRACE("spgemm symbolic: scanned, pattern allocated");
   hipLaunchKernelGGL(k_spgemm_symbolic<true>, dim3(fh_div_up(m, 4)), dim3(256), 0, c->stream, m, A->d_rowptr, A->d_col, B->d_rowptr, B->d_col, lanes_over_b,
                      C->d_rowptr, (int*)nullptr, C->d_col, d_err);
   FH_CHECK_HIP(hipGetLastError());
   FH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  FH_TRACE("spgemm symbolic: columns filled");
   hipFree(d_len);
   hipFree(d_err);
   FH_TRY(fh_mat_build_rowblocks(C, c->spmv_tile));
+  FH_TRACE("spgemm symbolic: row blocks");
   *Cout = C;
   return 0;
 }
