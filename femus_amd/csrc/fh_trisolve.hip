@@ -664,17 +664,17 @@ __global__ __launch_bounds__(256) void k_ilu_factor(const int* __restrict__ rows
   // diagonal) is loaded while step p updates the row -- the chain diagpos[k] -> lu[dk] -> col / lu[q] is otherwise paid once per lower entry
   int k = rs < re ? (LCOL ? wc[0] : col[rs]) : i;
   int dk = k < i ? diagpos[k] : 0, ke = k < i ? rowptr[k + 1] : 0;
-  double ukk = k < i ? lu[dk] : 1.0;
+  double ukk = k < i ? 1.0 / lu[dk] : 1.0;          // the INVERTED pivot, formed ahead of the chain: the multiplier is a product, as in MatLUFactorNumeric_SeqAIJ
   int jq = (k < i && dk + 1 + gl < ke) ? col[dk + 1 + gl] : -1;
   double uq = (k < i && dk + 1 + gl < ke) ? lu[dk + 1 + gl] : 0.0;
   for (int p = rs; p < re; p++) {
     if (k >= i) break;
     const int k2 = p + 1 < re ? (LCOL ? wc[p + 1 - rs] : col[p + 1]) : i;
     const int dk2 = k2 < i ? diagpos[k2] : 0, ke2 = k2 < i ? rowptr[k2 + 1] : 0;
-    const double ukk2 = k2 < i ? lu[dk2] : 1.0;
+    const double ukk2 = k2 < i ? 1.0 / lu[dk2] : 1.0;
     const int jq2 = (k2 < i && dk2 + 1 + gl < ke2) ? col[dk2 + 1 + gl] : -1;
     const double uq2 = (k2 < i && dk2 + 1 + gl < ke2) ? lu[dk2 + 1 + gl] : 0.0;
-    const double lik = w[p - rs] / ukk;             // row k is final: it was factored by an earlier launch (lower level)
+    const double lik = w[p - rs] * ukk;             // row k is final: it was factored by an earlier launch (lower level)
     tri_group_sync();
     if (gl == 0) w[p - rs] = lik;
     for (int q = dk + 1 + gl; q < ke; q += 16) {
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(256) void k_ilu_factor_ahead(const int* __restrict_
     const int k = wc[t], dk = diagpos[k];
     pd[t] = dk;
     pe[t] = rowptr[k + 1];
-    pu[t] = lu[dk];
+    pu[t] = 1.0 / lu[dk];      // the inverted pivot (PETSc keeps the diagonal of the factor inverted and multiplies)
   }
   tri_group_sync();
   auto fetch = [&](int t, IluPivot& v) {            // the lane's first two entries right of pivot t's diagonal
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256) void k_ilu_factor_ahead(const int* __restrict_
   fetch(2, v2);
 #define ILU_STEP(T, V)                                                                     \
   if ((T) < nlow) {                                                                        \
-    const double lik = w[T] / pu[T];                                                       \
+    const double lik = w[T] * pu[T];                                                       \
     tri_group_sync();                                                                      \
     if (gl == 0) w[T] = lik;                                                               \
     update(T, V.j0, V.u0, lik);                                                            \
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256) void k_ilu_factor_plan(const int* __restrict__
     pd[t] = dk;
     pe[t] = rowptr[k + 1];
     po[t] = ppofs[rs + t];
-    pu[t] = lu[dk];
+    pu[t] = 1.0 / lu[dk];      // the inverted pivot (PETSc keeps the diagonal of the factor inverted and multiplies)
   }
   tri_group_sync();
   auto fetch = [&](int t, IluPlanned& v) {          // the lane's first two entries right of pivot t's diagonal: value and place in this row
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(256) void k_ilu_factor_plan(const int* __restrict__
   fetch(2, v2);
 #define ILU_STEP(T, V)                                                                     \
   if ((T) < nlow) {                                                                        \
-    const double lik = w[T] / pu[T];                                                       \
+    const double lik = w[T] * pu[T];                                                       \
     tri_group_sync();                                                                      \
     if (gl == 0) w[T] = lik;                                                               \
     if (V.b0 != 255) w[V.b0] -= lik * V.u0;                                                \
