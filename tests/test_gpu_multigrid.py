@@ -494,6 +494,42 @@ def test_config1_converges_within_the_budget_of_001_poisson(ctx):
     pb.destroy()
 
 
+def test_ilu0_with_rows_beyond_the_plan_of_one_byte_positions(ctx):
+    """the elimination plan keeps positions inside a row as one byte (rows of at most 254 entries); a matrix with a row of 300 entries is factorised by the
+    searching kernel instead -- same factors: one preconditioned vector against the sequential oracle"""
+    import scipy.sparse as sp
+    n = 320
+    rng = np.random.default_rng(5)
+    M = sp.lil_matrix((n, n))
+    for i in range(n):
+        M[i, i] = 8.0 + 0.01 * i
+        for j in (i - 2, i - 1, i + 1, i + 2):
+            if 0 <= j < n:
+                M[i, j] = -1.0 + 0.1 * rng.random()
+    wide = 200
+    cols = np.sort(rng.choice(np.delete(np.arange(n), wide), 299, replace=False))
+    for j in cols:                                             # one row (and its column, for a symmetric pattern) with 300 entries
+        M[wide, j] = 0.01 * (1 + rng.random())
+        M[j, wide] = 0.01 * (1 + rng.random())
+    M = M.tocsr()
+    assert np.diff(M.indptr).max() >= 300
+    Lo = fo.ilu0_factor(M)
+    A0 = ctx.matrix_scipy(sp.identity(n, format="csr"))
+    A1 = ctx.matrix_scipy(M)
+    P = ctx.matrix_scipy(sp.identity(n, format="csr"))
+    mg = capi.Multigrid(ctx, 2)
+    mg.set_level(0, A0, None, None, 0, 1.0, 1, 0)
+    mg.set_level(1, A1, P, None, capi.SMOOTH_ILU0, 1.0, 1, 0)
+    mg.setup()
+    rhs = fo.lcg_fill(n, 4)
+    b, x = ctx.vector_from(rhs), ctx.vector(n)
+    mg.vcycle(b, x)
+    z = fo.ilu0_apply(Lo, rhs)
+    ref = z + (rhs - M @ z)
+    assert rel(x.to_numpy(), ref) < 1e-11
+    mg.destroy()
+
+
 def test_ilu0_shift_on_a_zero_pivot(ctx):
     """MAT_SHIFT_NONZERO with zero pivot 1e-16 (LinearEquationSolverPetsc.cpp:444-446): a pivot that cancels exactly restarts the
     factorisation of A + shift I; device and oracle take the same shift and give the same preconditioned vector"""
