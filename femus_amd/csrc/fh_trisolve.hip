@@ -313,35 +313,37 @@ static void tri_stamp_report() {
       d[5] += (double)(a[8] - a[0]);
       cnt++;
     }
-    if (cnt) fprintf(stderr, "[tri stamp] wave %d, %d steps: Z issue %.0f, C issue %.0f, level %.0f, A issue %.0f, barrier %.0f; step %.0f (s_memtime ticks)\n", w * 8, cnt, d[0] / cnt, d[1] / cnt, d[2] / cnt,
+    if (cnt) fprintf(stderr, "[tri stamp] wave %d, %d steps: wait + C issue %.0f, A + Z issue %.0f, level %.0f, - %.0f, barrier %.0f; step %.0f (s_memtime ticks; the stamps themselves slow the stamped steps)\n", w * 8, cnt, d[0] / cnt, d[1] / cnt, d[2] / cnt,
                      d[3] / cnt, d[4] / cnt, d[5] / cnt);
   }
   hipMemset(g_tri_stamp, 0, 512 * sizeof(long long));
 }
 #endif
-// What a level costs inside the run is its chain of dependent loads: level pointer -> row id -> row pointers -> operand sources / values -> z.  A two-dimensional
-// stacked system streams 25 MB of rows per sweep through ONE compute unit, so every link is a trip to the L2 or beyond (0.25 us), and a chain loaded one level
-// ahead (round 5) made a level cost the whole chain: 0.7 us.  Round 6: the row id, its bounds and its diagonal position come in ONE 16-byte load from a table in
-// level order (fh_tri_s::d_flv), and a software pipeline THREE levels deep -- in the iteration that computes level l the workgroup also loads that table's rows of
-// level l + 3, the first TRI_PF entries per lane / right-hand side / diagonal of level l + 2 and the global operands of level l + 1 (written two barriers ago or
-// earlier), each from what the previous iteration brought in, into three register sets used round robin (the loop is unrolled by three: no register moves).  The
-// operands computed by the level JUST BEFORE cannot be loaded ahead; they are read from the workgroup's LDS copy of that level (two buffers of TRI_SMALL values;
-// P.src < 0).  After the barrier a level is: LDS reads, the sum, a store.  The lane's entries are added in the same order as in the one-launch-per-level kernels:
-// the same bits.
+// The run kernel (round 6).  A two-dimensional stacked system of 70 000 unknowns has 1 500 levels of 46 rows; a level that loads its rows when it gets to them
+// costs the chain level pointer -> row -> entries -> operands, four trips to the L2 (0.7 us, round 5).  Here:
+//  * the row, the bounds of the sweep's triangle and the lane phase come in ONE 16-byte load from a table in level order (fh_tri_s::d_flv / d_blv), and only the
+//    sweep's triangle is loaded at all;
+//  * a software pipeline: in the step that computes level l the workgroup asks for the table rows of level l + 3 (stage A, into a register set of their own), the
+//    first 16 PF entries per row / right-hand side / diagonal of level l + 2 (stage C) and the global operands of level l + 1 (stage Z: written two barriers ago
+//    or earlier) -- all at the START of the step, behind one wait for what the step before asked for -- into three slot sets used round robin (six steps per
+//    trip, straight-line code: no register moves);
+//  * operands computed by the level JUST BEFORE cannot be loaded ahead: they are read from the workgroup's LDS copy of that level (P.src < 0);
+//  * after the barrier a level is: LDS reads, the sums (sixteen lanes per row, the tree by DPP row shifts), a store;
+//  * a second workgroup of the launch on the same XCD touches the rows' lines TRI_AHEAD table rows ahead (tri_prefetch).
+// The lane's entries are added in the order of the one-launch-per-level kernels: the same bits (option tri_runs = 0, tests/test_gpu_multigrid.py).
 #if TRI_STAMP
 #define TRI_T(k) if (stamping) { P.stamp[sbase + (size_t)(l + PHV - P.l0 - 200) * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime(); }
 #else
 #define TRI_T(k)
 #endif
-// PF: entries per lane held in registers (16 PF entries of the triangle per row, the rest in a loop): 2 while the mean triangle of the plan's rows has at most 32 entries
-// (two-dimensional systems), else 4 -- every slot is instructions in every step whether a row fills it or not (measured: 4 -> 2 is 7 % of a sweep)
+// PF: entries per lane held in registers (16 PF entries of the triangle per row, the rest in a loop): 2 or 4 per direction, chosen in tri_fill
 #ifndef TRI_SKIP
 #define TRI_SKIP 1
 #endif
 // A slot = what the pipeline holds of one level for this lane.  Nothing in it is TESTED in the step that loads it (a select on a value a step too early is a wait for
 // the load just issued, with every other load of the step queued behind it -- the ISA of the first version of this pipeline showed two such full round trips per
 // level: the `k < re ? c : none` select of stage C, and register copies of stage A's row behind the barrier, put there by the guards around the unrolled steps):
-// c[] holds the sources as loaded (of a clamped, existing entry), nv says how many of them belong to the row.
+// c[] holds the sources as loaded, nv says how many of the slots belong to the row (the others are not loaded).
 // byte offsets as unsigned 32-bit values on a uniform base: one shift per address instead of a sign extension and a 64-bit multiply-add (runs are only planned
 // for matrices of less than 2^28 entries)
 template <class T>
