@@ -7,7 +7,7 @@ import ctypes
 import numpy as np
 from ._lib import load_library
 
-GEOM = {"hex": 0, "quad": 1}
+GEOM = {"hex": 0, "quad": 1, "line": 2}
 FE = {"linear": 0, "serendipity": 1, "biquadratic": 2, "constant": 3, "pwlinear": 4}        # 4: DISCONTINUOUS_POLYNOMIAL FIRST (system dof maps and prolongators only)
 GAUSS_ORDER = {"zero": 0, "first": 0, "second": 1, "third": 1, "fourth": 2, "fifth": 2,
                "sixth": 3, "seventh": 3, "eighth": 4, "ninth": 4}
@@ -681,9 +681,12 @@ def pattern_from_elements(elem_dof, ndof):
     return rowptr, col
 
 
+_DIM = {"hex": 3, "quad": 2, "line": 1}
+
+
 def fe_gauss(geom, order):
     L = load_library()
-    dim = 3 if geom == "hex" else 2
+    dim = _DIM[geom]
     ng = ctypes.c_int()
     _chk(L.fh_fe_gauss(GEOM[geom], GAUSS_ORDER[order], ctypes.byref(ng), None, None))
     w, x = np.empty(ng.value), np.empty((dim, ng.value))
@@ -693,7 +696,7 @@ def fe_gauss(geom, order):
 
 def fe_tables(geom, fe, order):
     L = load_library()
-    dim = 3 if geom == "hex" else 2
+    dim = _DIM[geom]
     ng, nc = ctypes.c_int(), ctypes.c_int()
     _chk(L.fh_fe_tables(GEOM[geom], FE[fe], GAUSS_ORDER[order], ctypes.byref(ng), ctypes.byref(nc), None, None))
     phi, dphi = np.empty((ng.value, nc.value)), np.empty((dim, ng.value, nc.value))
@@ -702,9 +705,9 @@ def fe_tables(geom, fe, order):
 
 
 def fe_tables_d2(geom, fe, order):
-    """second derivatives at the Gauss points, [ng, nc, nh]: (xx, yy, xy) in 2-D, (xx, yy, zz, xy, yz, zx) in 3-D"""
+    """second derivatives at the Gauss points, [ng, nc, nh]: (xx) in 1-D, (xx, yy, xy) in 2-D, (xx, yy, zz, xy, yz, zx) in 3-D"""
     L = load_library()
-    nh = 6 if geom == "hex" else 3
+    nh = {"hex": 6, "quad": 3, "line": 1}[geom]
     phi, _ = fe_tables(geom, fe, order)
     d2 = np.empty((nh,) + phi.shape)
     _chk(L.fh_fe_tables_d2(GEOM[geom], FE[fe], GAUSS_ORDER[order], _p(d2)))

@@ -23,15 +23,20 @@ static const signed char XC_HEX[27][3] = {
     {-1, -1, 0},  {1, -1, 0},  {1, 1, 0},  {-1, 1, 0},  {0, -1, 0},  {1, 0, 0},  {0, 1, 0}, {-1, 0, 0},
     {0, 0, -1},   {0, 0, 1},   {0, 0, 0}};
 static const signed char XC_QUAD[9][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}, {0, -1}, {1, 0}, {0, 1}, {-1, 0}, {0, 0}};
+// EDGE3 (1d/Edge.cpp:22-30): the two end points, then the middle
+static const signed char XC_LINE[3][1] = {{-1}, {1}, {0}};
 
-int dim_of(int geom) { return geom == GEOM_HEX ? 3 : 2; }
-int nloc_of(int geom) { return geom == GEOM_HEX ? 27 : 9; }
-int nvert_of(int geom) { return geom == GEOM_HEX ? 8 : 4; }
-int nedge_end_of(int geom) { return geom == GEOM_HEX ? 20 : 8; }
-int nfaces_of(int geom) { return geom == GEOM_HEX ? 6 : 4; }
-int ndofs_of(int geom, int fe) { return fe == FE_LINEAR ? nvert_of(geom) : fe == FE_SERENDIPITY ? nedge_end_of(geom) : fe == FE_CONSTANT ? 1 : nloc_of(geom); }
+int dim_of(int geom) { return geom == GEOM_HEX ? 3 : geom == GEOM_QUAD ? 2 : 1; }
+int nloc_of(int geom) { return geom == GEOM_HEX ? 27 : geom == GEOM_QUAD ? 9 : 3; }
+int nvert_of(int geom) { return geom == GEOM_HEX ? 8 : geom == GEOM_QUAD ? 4 : 2; }
+int nedge_end_of(int geom) { return geom == GEOM_HEX ? 20 : geom == GEOM_QUAD ? 8 : 2; }
+int nfaces_of(int geom) { return geom == GEOM_HEX ? 6 : geom == GEOM_QUAD ? 4 : 2; }
+// (on the line the "quadratic" family IS the three-node one: NVE[5] = {2, 3, 3, 1, 2}, GeomElTypeEnum)
+int ndofs_of(int geom, int fe) {
+  return fe == FE_LINEAR ? nvert_of(geom) : fe == FE_SERENDIPITY ? (geom == GEOM_LINE ? 3 : nedge_end_of(geom)) : fe == FE_CONSTANT ? 1 : nloc_of(geom);
+}
 
-int xc(int geom, int node, int d) { return geom == GEOM_HEX ? XC_HEX[node][d] : XC_QUAD[node][d]; }
+int xc(int geom, int node, int d) { return geom == GEOM_HEX ? XC_HEX[node][d] : geom == GEOM_QUAD ? XC_QUAD[node][d] : XC_LINE[node][d]; }
 
 // ---- Gauss-Legendre in extended precision, then the reference's 14-significant-digit rounding -----------
 static void gauss_legendre_ld(int n, long double* x, long double* w) {
@@ -181,10 +186,10 @@ static void serendipity_node(int geom, int j, const double* x, double out[10]) {
 void eval_basis_d2(int geom, int fe, const double* pt, double* d2phi) {
   const int d = dim_of(geom), nc = ndofs_of(geom, fe);
   if (fe == FE_CONSTANT) {
-    for (int k = 0; k < (d == 2 ? 3 : 6); k++) d2phi[k] = 0.0;
+    for (int k = 0; k < (d == 1 ? 1 : d == 2 ? 3 : 6); k++) d2phi[k] = 0.0;
     return;
   }
-  if (fe == FE_SERENDIPITY) {
+  if (fe == FE_SERENDIPITY && d > 1) {
     for (int j = 0; j < nc; j++) {
       double v[10];
       serendipity_node(geom, j, pt, v);
@@ -204,7 +209,9 @@ void eval_basis_d2(int geom, int fe, const double* pt, double* d2phi) {
       dl[k] = (fe == FE_LINEAR) ? dlagL(pt[k], I) : dlagB(pt[k], I);
       d2l[k] = (fe == FE_LINEAR) ? 0.0 : d2lagB(I);
     }
-    if (d == 2) {
+    if (d == 1) {
+      d2phi[j] = d2l[0];
+    } else if (d == 2) {
       d2phi[j * 3 + 0] = d2l[0] * l[1];
       d2phi[j * 3 + 1] = l[0] * d2l[1];
       d2phi[j * 3 + 2] = dl[0] * dl[1];
@@ -227,7 +234,7 @@ void eval_basis(int geom, int fe, const double* pt, double* phi, double* dphi /*
       for (int k = 0; k < d; k++) dphi[k] = 0.;
     return;
   }
-  if (fe == FE_SERENDIPITY) {
+  if (fe == FE_SERENDIPITY && d > 1) {
     for (int j = 0; j < nc; j++) {
       double v[10];
       serendipity_node(geom, j, pt, v);
@@ -244,7 +251,10 @@ void eval_basis(int geom, int fe, const double* pt, double* phi, double* dphi /*
       l[k] = (fe == FE_LINEAR) ? lagL(pt[k], I) : lagB(pt[k], I);
       dl[k] = (fe == FE_LINEAR) ? dlagL(pt[k], I) : dlagB(pt[k], I);
     }
-    if (d == 2) {
+    if (d == 1) {
+      if (phi) phi[j] = l[0];
+      if (dphi) dphi[j] = dl[0];
+    } else if (d == 2) {
       if (phi) phi[j] = l[0] * l[1];
       if (dphi) {
         dphi[j * 2 + 0] = dl[0] * l[1];
@@ -306,6 +316,11 @@ void elem_prolongator(int geom, int fe, std::vector<double>& P) {
 }
 
 int face_nodes(int geom, int fe, int face, int* out) {
+  if (geom == GEOM_LINE) {        // the "faces" of a line element are its end points (line_lag faceDofs)
+    if (fe == FE_CONSTANT) return 0;
+    out[0] = face;
+    return 1;
+  }
   const int d = dim_of(geom);
   const int centre = (geom == GEOM_HEX) ? 20 + face : 4 + face;
   int d0 = 0;
@@ -351,7 +366,7 @@ int face_nodes(int geom, int fe, int face, int* out) {
 #include "fh_internal.h"
 
 extern "C" int fh_fe_gauss(int geom, int order, int* ng, double* w, double* x) {
-  FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_gauss: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(geom >= 0 && geom <= 2, "fh_fe_gauss: geom must be 0 (hex), 1 (quad) or 2 (line)");
   FH_REQUIRE(order >= 0 && order <= 4, "fh_fe_gauss: Gauss rule index %d not supported (0..4)", order);
   if (ng) *ng = fhfe::gauss_npoints(geom, order);
   if (w || x) fhfe::gauss_table(geom, order, w, x);
@@ -359,7 +374,7 @@ extern "C" int fh_fe_gauss(int geom, int order, int* ng, double* w, double* x) {
 }
 
 extern "C" int fh_fe_tables(int geom, int fe, int order, int* ng, int* nc, double* phi, double* dphi) {
-  FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_tables: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(geom >= 0 && geom <= 2, "fh_fe_tables: geom must be 0 (hex), 1 (quad) or 2 (line)");
   FH_REQUIRE(fhfe::fe_known(fe), "fh_fe_tables: fe must be 0 (linear), 1 (serendipity), 2 (biquadratic) or 3 (piecewise constant)");
   FH_REQUIRE(order >= 0 && order <= 4, "fh_fe_tables: Gauss rule index %d not supported (0..4)", order);
   const int d = fhfe::dim_of(geom), n = fhfe::ndofs_of(geom, fe), g = fhfe::gauss_npoints(geom, order);
@@ -378,10 +393,10 @@ extern "C" int fh_fe_tables(int geom, int fe, int order, int* ng, int* nc, doubl
 }
 
 extern "C" int fh_fe_tables_d2(int geom, int fe, int order, double* d2phi) {
-  FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_tables_d2: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(geom >= 0 && geom <= 2, "fh_fe_tables_d2: geom must be 0 (hex), 1 (quad) or 2 (line)");
   FH_REQUIRE(fhfe::fe_known(fe), "fh_fe_tables_d2: fe must be 0 (linear), 1 (serendipity), 2 (biquadratic) or 3 (piecewise constant)");
   FH_REQUIRE(order >= 0 && order <= 4 && d2phi, "fh_fe_tables_d2: bad arguments");
-  const int d = fhfe::dim_of(geom), n = fhfe::ndofs_of(geom, fe), g = fhfe::gauss_npoints(geom, order), nh = d == 2 ? 3 : 6;
+  const int d = fhfe::dim_of(geom), n = fhfe::ndofs_of(geom, fe), g = fhfe::gauss_npoints(geom, order), nh = d == 1 ? 1 : d == 2 ? 3 : 6;
   std::vector<double> w(g), x((size_t)g * d), t((size_t)n * nh);
   fhfe::gauss_table(geom, order, w.data(), x.data());
   for (int ig = 0; ig < g; ig++) {
@@ -395,7 +410,7 @@ extern "C" int fh_fe_tables_d2(int geom, int fe, int order, double* d2phi) {
 }
 
 extern "C" int fh_fe_elem_prolongator(int geom, int fe, int* nchild, int* nc, double* P) {
-  FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_elem_prolongator: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(geom >= 0 && geom <= 2, "fh_fe_elem_prolongator: geom must be 0 (hex), 1 (quad) or 2 (line)");
   FH_REQUIRE(fhfe::fe_known(fe), "fh_fe_elem_prolongator: fe must be 0 (linear), 1 (serendipity), 2 (biquadratic) or 3 (piecewise constant)");
   if (nchild) *nchild = fhfe::nvert_of(geom);
   if (nc) *nc = fhfe::ndofs_of(geom, fe);
@@ -409,14 +424,14 @@ extern "C" int fh_fe_elem_prolongator(int geom, int fe, int* nchild, int* nc, do
 
 // reference coordinates (-1, 0, 1 per direction) of local node `node` of the biquadratic element (hex_lag / quad_lag X tables, Hexahedron.cpp:32-92)
 extern "C" int fh_fe_node_ref(int geom, int node, int* xi) {
-  FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_node_ref: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(geom >= 0 && geom <= 2, "fh_fe_node_ref: geom must be 0 (hex), 1 (quad) or 2 (line)");
   FH_REQUIRE(node >= 0 && node < fhfe::nloc_of(geom) && xi, "fh_fe_node_ref: node %d out of range", node);
   for (int d = 0; d < fhfe::dim_of(geom); d++) xi[d] = fhfe::xc(geom, node, d);
   return 0;
 }
 
 extern "C" int fh_fe_face_nodes(int geom, int fe, int face, int* nfn, int* local_nodes) {
-  FH_REQUIRE(geom == 0 || geom == 1, "fh_fe_face_nodes: geom must be 0 (hex) or 1 (quad)");
+  FH_REQUIRE(geom >= 0 && geom <= 2, "fh_fe_face_nodes: geom must be 0 (hex), 1 (quad) or 2 (line)");
   FH_REQUIRE(fhfe::fe_known(fe), "fh_fe_face_nodes: fe must be 0 .. 3");
   FH_REQUIRE(face >= 0 && face < fhfe::nfaces_of(geom), "fh_fe_face_nodes: face %d out of range", face);
   int tmp[9];

@@ -71,6 +71,26 @@ for geom, dim, nv in (("quad", 2, 4), ("hex", 3, 8)):
         kv[i] = list(b)
     out["kvert_ind_%s" % geom] = kv
 
+# EDGE3 (round 6: the one-dimensional input of 001_Poisson): LineLinear / LineBiquadratic at the line Gauss points and at sample points: phi, d/dx, d2/dx2
+sample1 = rng.uniform(-1, 1, (7, 1))
+out["sample_pts_line"] = sample1
+for fe in ("linear", "biquadratic"):
+    nc = L.ref_ndofs(b"line", fe.encode())
+    for tag, pts in (("gauss7", out["gauss_x_line_seventh"]), ("sample", sample1)):
+        vals = np.zeros((3, pts.shape[0], nc))
+        for p in range(pts.shape[0]):
+            pt = (ctypes.c_double * 3)(float(pts[p, 0]), 0.0, 0.0)
+            for j in range(nc):
+                for k, which in enumerate((0, 1, 4)):
+                    vals[k, p, j] = L.ref_eval(b"line", fe.encode(), which, j, pt)
+        out["basis_line_%s_%s" % (fe, tag)] = vals
+xc1 = np.zeros((3, 1))
+for i in range(3):
+    b = (ctypes.c_double * 3)()
+    L.ref_xcoarse(b"line", b"biquadratic", i, 1, b)
+    xc1[i, 0] = b[0]
+out["xc_line"] = xc1
+
 # element prolongator as elem_type forms it.  ElemType.cpp itself needs boost and is not compiled, so its two loops are followed
 # here on top of the COMPILED basis classes (every number below comes out of a call into the reference's object code):
 #   (1) set_fine_coordinates_in_Basis_object (ElemType.cpp:404-432): fine node i = (child, vertex) = KVERT_IND[i] of the linear

@@ -50,6 +50,23 @@ def test_product_second_derivative_tables_bit_exact(geom, fe):
     assert np.array_equal(d2, fo.eval_basis(geom, fe, G["gauss_x_%s_seventh" % geom])[2])
 
 
+@pytest.mark.parametrize("fe", ["linear", "biquadratic"])
+def test_product_line_tables_bit_exact(fe):
+    """EDGE3 (round 6, the one-dimensional input of 001_Poisson): LineLinear / LineBiquadratic (1d/Edge.hpp:72-104) at the 'seventh' line Gauss points -- phi, d/dx,
+    d2/dx2 -- and the Gauss table itself, against the reference's compiled classes; the serendipity family of a line is the three-node one"""
+    w, x = capi.fe_gauss("line", "seventh")
+    assert np.array_equal(w, G["gauss_w_line_seventh"]) and np.array_equal(x, G["gauss_x_line_seventh"])
+    ref = G["basis_line_%s_gauss7" % fe]
+    phi, dphi = capi.fe_tables("line", fe, "seventh")
+    d2 = capi.fe_tables_d2("line", fe, "seventh")
+    assert np.array_equal(phi, ref[0]) and np.array_equal(dphi[:, :, 0], ref[1]) and np.array_equal(d2[:, :, 0], ref[2])
+    if fe == "biquadratic":
+        ps, ds = capi.fe_tables("line", "serendipity", "seventh")
+        assert np.array_equal(ps, phi) and np.array_equal(ds, dphi)
+    assert np.array_equal(G["xc_line"][:, 0], [-1.0, 1.0, 0.0])
+    assert [capi.fe_face_nodes("line", fe, f).tolist() for f in range(2)] == [[0], [1]]
+
+
 def _rows_by_kvert(geom, fe, P):
     """rows of a [child][local node][coarse] element prolongator in the reference's fine-node order KVERT_IND (Hexahedron.cpp:49-71)"""
     kv = G["kvert_ind_%s_%s" % (geom, fe)]
