@@ -24,7 +24,7 @@ import numpy as np
 from . import capi
 from .poisson import PoissonMG
 
-FACE_NAMES = {2: ["bottom", "right", "top", "left"], 3: ["bottom", "front", "right", "behind", "left", "top"]}
+FACE_NAMES = {1: ["left", "right"], 2: ["bottom", "right", "top", "left"], 3: ["bottom", "front", "right", "behind", "left", "top"]}   # MeshGeneration.cpp:248-253 (EDGE3 box)
 FE_ORDER = {"first": "linear", "serendipity": "serendipity", "second": "biquadratic"}       # FEOrder of the input (main.cpp:149) -> Lagrange family
 PREFIX = "multilevel_problem.multilevel_mesh.first.system.poisson.linear_solver."
 
@@ -84,9 +84,11 @@ class Poisson001:
             self.box = (int(b.get("nx", 2)), int(b.get("ny", 2)), int(b.get("nz", 0)))
             self.lo = (float(b.get("xa", 0.)), float(b.get("ya", 0.)), float(b.get("za", 0.)))
             self.hi = (float(b.get("xb", 1.)), float(b.get("yb", 1.)), float(b.get("zb", 0.)))
-            self.dim = 2 if self.box[2] == 0 else 3
+            self.dim = 1 if (self.box[1] == 0 and self.box[2] == 0) else 2 if self.box[2] == 0 else 3
             if self.dim == 2:
                 self.hi = (self.hi[0], self.hi[1], 1.0)         # the box generator ignores z in 2-D
+            if self.dim == 1:
+                assert b.get("elem_type", "Edge3") == "Edge3", "the one-dimensional box is made of EDGE3 elements (MeshGeneration.cpp:90)"
         else:
             raise ValueError("Error: no input mesh specified. Please check to have added the keyword mesh in the input json file! ")
         var = "multilevel_solution.multilevel_mesh.first.variable.first."
@@ -128,7 +130,7 @@ class Poisson001:
         """GenerateBdc with parsed functions (MultiLevelSolution.cpp:762-800): elements and faces in order; nodes of Dirichlet
         faces get Bdc = 0 and Sol = value(x, y, z, t = 0); a later face overwrites an earlier one"""
         ed, xy, ff = mesh.arrays()
-        nc = {"linear": 2 ** self.dim, "serendipity": 8 if self.dim == 2 else 20, "biquadratic": 3 ** self.dim}[self.fe]
+        nc = {"linear": 2 ** self.dim, "serendipity": {1: 3, 2: 8, 3: 20}[self.dim], "biquadratic": 3 ** self.dim}[self.fe]
         val = {}
         for iel, f in zip(*np.nonzero(ff < -1)):
             kind, fn = self.face_bc(int(ff[iel, f]))
@@ -149,6 +151,8 @@ class Poisson001:
         Richardson scale at the solver default 0.5 (LinearEquationSolverPetsc.hpp:145).  output_dir: write what the application writes at
         its end (main.cpp:259-270): the VTK and the GMV file of "Sol", named as the reference names them"""
         ctx = self.ctx
+        if self.dim == 1:
+            return self.run_line(log)
         meshes = [capi.Mesh.box(*self.box, self.lo, self.hi) if self.box is not None else capi.Mesh.read_gambit(self.mesh_file)]
         for _ in range(1, self.nlevels):
             meshes.append(meshes[-1].refine())
@@ -195,6 +199,84 @@ class Poisson001:
             writers.write_gmv(stem + ".gmv", meshes[top], {"Sol": field}, "biquadratic")
             result["files"] = [stem + ".vtu", stem + ".gmv"]
         pb.destroy()
+        return result
+
+    # ---- the one-dimensional input (input/input1D.json: EDGE3 box) -------------------------------------------------------------------------------
+    NU_1D, V_1D = 0.01, 1.0                      # main.cpp:392-395: in one dimension the callback is advection-diffusion with V = 1, nu = 0.01
+
+    def line_mesh(self):
+        """MeshGeneration.cpp:78-262 (nodes i / (2 nx), element i = {2 i, 2 i + 2, 2 i + 1}, face 0 of the first element "left", face 1 of the last
+        "right") and the numbering every FEMuS mesh gets: vertices first, then the middles, each in order of first appearance"""
+        nx, (xa, xb) = self.box[0], (self.lo[0], self.hi[0])
+        x = np.array([(i / (2.0 * nx)) * (xb - xa) + xa for i in range(2 * nx + 1)])
+        ed = np.array([[2 * i, 2 * i + 2, 2 * i + 1] for i in range(nx)])
+        new = np.full(2 * nx + 1, -1)
+        k = 0
+        for cls in ((0, 1), (2,)):
+            for e in range(nx):
+                for l in cls:
+                    if new[ed[e, l]] < 0:
+                        new[ed[e, l]] = k
+                        k += 1
+        xs = np.empty_like(x)
+        xs[new] = x
+        faces = {-2: (0, 0), -3: (nx - 1, 1)}                 # flag -> (element, local face = local node)
+        return new[ed], xs, faces, nx + 1
+
+    def run_line(self, log=None):
+        """LinearImplicitSystem::MGsolve on the EDGE3 box with the callback's one-dimensional form (fh_assemble_advdiff_line): one level (the shipped input has
+        nlevels = 1), i.e. the exact solve of KK EPS = RES per linear iteration, Sol += EPS"""
+        if self.nlevels != 1:
+            raise NotImplementedError("the one-dimensional box is served on one level (input/input1D.json: nlevels = 1)")
+        ctx = self.ctx
+        ed, xs, faces, nv = self.line_mesh()
+        nc = 2 if self.fe == "linear" else 3
+        ndof = nv if self.fe == "linear" else xs.size
+        pairs = sorted({(int(a), int(b)) for e in ed for a in e[:nc] for b in e[:nc]})
+        rows = np.array([p[0] for p in pairs])
+        indptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=ndof))])
+        K = capi.Mat.from_csr(ctx, ndof, ndof, indptr, np.array([p[1] for p in pairs]))
+        SOL, RES, EPS = ctx.vector(ndof), ctx.vector(ndof), ctx.vector(ndof)
+        sol0 = np.zeros(ndof)
+        idx, point_flux = [], []
+        for flag, (e, f) in faces.items():
+            kind, fn = self.face_bc(flag)
+            node = int(ed[e, f])
+            x4 = np.array([xs[node], 0.0, 0.0, 0.0])
+            if kind == "dirichlet":
+                idx.append(node)
+                sol0[node] = fn(x4) if fn is not None else 0.0
+            elif fn is not None:                              # non-homogeneous Neumann: the side "element" is a point, F[node] += g(x) (main.cpp:540-549)
+                point_flux.append((node, fn(x4)))
+        idx = np.array(sorted(idx), dtype=np.int32)
+        SOL.upload(sol0)
+        mg = capi.Multigrid(ctx, 1)
+        history = []
+        for it in range(self.max_linear):
+            capi.assemble_advdiff_line(ctx, self.fe, ed, xs, K, RES, self.NU_1D, self.V_1D, sol=SOL, source=self.source)
+            if point_flux:
+                r = RES.to_numpy()
+                for node, g in point_flux:
+                    r[node] += g
+                RES.upload(r)
+            if idx.size:
+                K.mat_zero_rows(idx, 1.0)
+                RES.set(idx, np.zeros(idx.size))
+            rn = RES.l2_norm()
+            history.append((0 if it == 0 else 1, rn))
+            if log:
+                log("linear iteration %d: Linear Res L2norm = %.6e" % (it, rn))
+            if it > 0 and rn < self.abs_tol:
+                break
+            mg.set_level(0, K, None, None, capi.SMOOTH_JACOBI, 1.0, 1, 0)
+            mg.setup()
+            EPS.zero()
+            mg.solve(RES, EPS, outer="preonly")
+            SOL.add(1.0, EPS)
+        mg.destroy()
+        result = {"solution": SOL.to_numpy(), "coords": xs[:ndof].reshape(-1, 1), "history": history, "converged": history[-1][1] < self.abs_tol, "dofs": ndof,
+                  "elem_dof": ed, "nodes": xs}
+        K.destroy()
         return result
 
     def destroy(self):

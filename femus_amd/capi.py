@@ -756,6 +756,14 @@ def fe_face_nodes(geom, fe, face):
     return out[:n.value].copy()
 
 
+def assemble_advdiff_line(ctx, fe, elem_dof, coords, K, res, nu, velocity, sol=None, source=None, order="seventh"):
+    """the 001_Poisson callback on a one-dimensional EDGE3 mesh (main.cpp:355-480 with dim == 1: advection-diffusion with its streamline-upwind terms):
+    K <- Jacobian, res <- residual.  elem_dof[nel, 3] node ids (ends, then middle; vertices numbered first), coords[nnode]"""
+    ed, x = _i32(elem_dof), _f64(coords)
+    _chk(ctx.L.fh_assemble_advdiff_line(ctx.h, FE[fe], GAUSS_ORDER[order], ed.shape[0], _p(ed), x.size, _p(x), sol.h if sol is not None else None, float(nu),
+                                        float(velocity), source.h if source is not None else None, K.h, res.h))
+
+
 def assemble_neumann(ctx, mesh, fe, res, flux_by_flag, order="seventh"):
     """boundary term of 001_Poisson: faces whose boundary flag is a key of flux_by_flag carry the Neumann flux tau -- a number (the
     mesh-file branch, main.cpp:556-594) or an Expr evaluated at every face Gauss point (the parsed-function branch, main.cpp:495-553)"""

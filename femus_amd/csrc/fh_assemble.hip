@@ -4805,3 +4805,157 @@ extern "C" int fh_assemble_neumann_faces_expr(fh_ctx_t ctx, int geom, int fe, in
   FH_REQUIRE(nfaces == 0 || face_expr, "fh_assemble_neumann_faces_expr: null argument");
   return neumann_faces(ctx, geom, fe, order, nfaces, face_nodes, nullptr, face_expr, nexpr, exprs, nnode, coords, res);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The application's callback on a ONE-DIMENSIONAL mesh (applications/001_Poisson/main.cpp:355-480 with dim == 1; its shipped input/input1D.json, an EDGE3
+// box): there the callback is not a Poisson problem -- main.cpp:392-395 sets V = 1, nu = 0.01 -- but advection-diffusion with the streamline-upwind terms the
+// same loop carries in every dimension (tau = 0 where V = 0, which is why the 2-D / 3-D kernels above never see them):
+//   tau   = barNu / V^2,  barNu = (coth(Pe) - 1 / Pe) V h / 2,  Pe = V h / (2 nu),  h = x[1] - x[0]  (directions_of_reference_element, Elem.hpp:149-167)
+//   F_i  += (f phi_i - nu phi_i' u' - V u' phi_i + (f - (-nu u'' + V u')) s_i) w,   s_i = (V phi_i' + nu phi_i'') tau
+//   B_ij += (nu (phi_i' phi_j' - phi_j'' s_i) + V phi_j' (phi_i + s_i)) w
+// with elem_type_1D::Jacobian (ElemType.hpp:994-1035): Jac = sum dphi_n x_n, w = Jac w_g, phi' = dphi / Jac, phi'' = d2phi / Jac^2.
+// One thread per ROW: it walks the elements of its node in ascending order, forms its row of each element matrix over the Gauss points and adds it -- the
+// grouping of the reference's add_matrix_blocked / add_vector_blocked, no atomics.  The problem sizes of a one-dimensional mesh make everything else moot.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_line_advdiff(int ndof, int nc, int ng, const int* __restrict__ adj_ptr, const int* __restrict__ adj,
+                                                     const int* __restrict__ elem_dof, const double* __restrict__ coords, const double* __restrict__ sol,
+                                                     const double* __restrict__ w, const double* __restrict__ phi, const double* __restrict__ dphi,
+                                                     const double* __restrict__ d2phi, double nu, double V, const int* __restrict__ prog, int nprog,
+                                                     const double* __restrict__ pconst, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                     double* __restrict__ val, double* __restrict__ res) {
+  const int r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= ndof) return;
+  const int rs = rowptr[r], re = rowptr[r + 1];
+  for (int k = rs; k < re; k++) val[k] = 0.0;
+  double racc = 0.0;
+  for (int a = adj_ptr[r]; a < adj_ptr[r + 1]; a++) {
+    const int e = adj[a] >> 2, i = adj[a] & 3;
+    double x[3], u[3];
+    int dof[3];
+    for (int n = 0; n < nc; n++) {
+      dof[n] = elem_dof[e * 3 + n];
+      x[n] = coords[dof[n]];
+      u[n] = sol ? sol[dof[n]] : 0.0;
+    }
+    // stabilisation parameter of the element (main.cpp:397-428)
+    const double VxiHxi = (x[1] - x[0]) * V;
+    const double PeXi = VxiHxi / (2. * nu);
+    const double barXi = (fabs(PeXi) < 1.0e-10) ? 0. : 1. / tanh(PeXi) - 1. / PeXi;
+    const double barNu = barXi * VxiHxi / 2.;
+    const double vL2Norm2 = V * V;
+    const double supgTau = (vL2Norm2 > 1.0e-15) ? barNu / vL2Norm2 : 0.;
+    double F = 0.0, B[3] = {0.0, 0.0, 0.0};
+    for (int g = 0; g < ng; g++) {
+      double Jac = 0.0;
+      for (int n = 0; n < nc; n++) Jac += dphi[g * nc + n] * x[n];
+      const double weight = Jac * w[g], JacI = 1 / Jac;
+      double ph[3], gr[3], nb[3], gradSol = 0.0, nablaSol = 0.0, xg[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int n = 0; n < nc; n++) {
+        ph[n] = phi[g * nc + n];
+        gr[n] = dphi[g * nc + n] * JacI;
+        nb[n] = d2phi[g * nc + n] * JacI * JacI;
+        xg[0] += x[n] * ph[n];
+        gradSol += gr[n] * u[n];
+        nablaSol += nb[n] * u[n];
+      }
+      const double lapRhs = nu * gr[i] * gradSol;
+      const double advRhs = V * gradSol * ph[i];
+      const double resRhs = -nu * nablaSol + V * gradSol;
+      const double supgPhi = (V * gr[i] + nu * nb[i]) * supgTau;
+      const double src = prog ? fh_expr_device_eval(prog, nprog, pconst, xg) : 0.0;
+      F += (src * ph[i] - lapRhs - advRhs + (src - resRhs) * supgPhi) * weight;
+      for (int j = 0; j < nc; j++) {
+        const double lap = nu * (gr[i] * gr[j] - nb[j] * supgPhi) * weight;
+        const double adv = V * gr[j] * (ph[i] + supgPhi) * weight;
+        B[j] += lap + adv;
+      }
+    }
+    racc += F;
+    for (int j = 0; j < nc; j++)
+      for (int k = rs; k < re; k++)
+        if (col[k] == dof[j]) {
+          val[k] += B[j];
+          break;
+        }
+  }
+  res[r] = racc;
+}
+
+extern "C" int fh_assemble_advdiff_line(fh_ctx_t ctx, int fe, int order, int nel, const int* elem_dof, int nnode, const double* coords, fh_vec_t sol, double nu,
+                                        double velocity, fh_expr_t source, fh_mat_t KK, fh_vec_t RES) {
+  FH_GUARD_BEGIN
+  FH_REQUIRE(ctx && elem_dof && coords && KK && RES && nel >= 1 && nnode >= 2, "fh_assemble_advdiff_line: null or empty argument");
+  FH_REQUIRE(fe == fhfe::FE_LINEAR || fe == fhfe::FE_SERENDIPITY || fe == fhfe::FE_BIQUADRATIC, "fh_assemble_advdiff_line: fe must be 0, 1 or 2");
+  FH_REQUIRE(nu > 0.0, "fh_assemble_advdiff_line: the diffusivity must be positive");
+  const int nc = fhfe::ndofs_of(fhfe::GEOM_LINE, fe), ndof = KK->m;
+  FH_REQUIRE(KK->n == ndof && RES->n_local >= ndof && (!sol || sol->n_local >= ndof), "fh_assemble_advdiff_line: size mismatch");
+  std::vector<int> cnt(ndof + 1, 0);
+  for (int e = 0; e < nel; e++)
+    for (int n = 0; n < nc; n++) {
+      const int d = elem_dof[e * 3 + n];
+      FH_REQUIRE(d >= 0 && d < ndof && d < nnode, "fh_assemble_advdiff_line: element %d, node %d: dof %d outside the system (the vertices are numbered first)", e, n, d);
+      cnt[d + 1]++;
+    }
+  for (int d = 0; d < ndof; d++) cnt[d + 1] += cnt[d];
+  std::vector<int> adj(cnt[ndof]), fill(cnt.begin(), cnt.end() - 1);
+  for (int e = 0; e < nel; e++)                         // ascending element order per dof
+    for (int n = 0; n < nc; n++) adj[fill[elem_dof[e * 3 + n]]++] = e * 4 + n;
+  std::vector<double> w, phi, dphi;
+  FH_REQUIRE(fhfe::shape_tables(fhfe::GEOM_LINE, fe, order, w, phi, dphi) == 0, "fh_assemble_advdiff_line: unsupported Gauss rule");
+  const int ng = (int)w.size();
+  std::vector<double> d2((size_t)ng * nc), x1(ng), t(nc);
+  fhfe::gauss_table(fhfe::GEOM_LINE, order, nullptr, x1.data());
+  for (int g = 0; g < ng; g++) {
+    const double pt[3] = {x1[g], 0.0, 0.0};
+    fhfe::eval_basis_d2(fhfe::GEOM_LINE, fe, pt, t.data());
+    for (int n = 0; n < nc; n++) d2[(size_t)g * nc + n] = t[n];
+  }
+  std::vector<int> code;
+  std::vector<double> consts;
+  if (source) {
+    int nv = 0, ncode = 0, nk = 0;
+    FH_TRY(fh_expr_nvars(source, &nv));
+    FH_REQUIRE(nv <= 4, "fh_assemble_advdiff_line: the source expression has %d variables, at most 4 (x, y, z, t) are served", nv);
+    FH_TRY(fh_expr_program(source, &ncode, &nk, nullptr, nullptr));
+    code.resize(ncode);
+    consts.resize(std::max(nk, 1));
+    FH_TRY(fh_expr_program(source, &ncode, &nk, code.data(), consts.data()));
+  }
+  hipStream_t st = ctx->stream;
+  std::vector<void*> dv;
+  auto up = [&](const void* h, size_t bytes) -> void* {
+    void* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr;
+    dv.push_back(d);
+    if (bytes) hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st);
+    return d;
+  };
+  int* d_ptr = (int*)up(cnt.data(), cnt.size() * sizeof(int));
+  int* d_adj = (int*)up(adj.data(), adj.size() * sizeof(int));
+  int* d_ed = (int*)up(elem_dof, (size_t)nel * 3 * sizeof(int));
+  double* d_x = (double*)up(coords, (size_t)nnode * sizeof(double));
+  double* d_w = (double*)up(w.data(), w.size() * sizeof(double));
+  double* d_phi = (double*)up(phi.data(), phi.size() * sizeof(double));
+  double* d_dphi = (double*)up(dphi.data(), dphi.size() * sizeof(double));
+  double* d_d2 = (double*)up(d2.data(), d2.size() * sizeof(double));
+  int* d_code = source ? (int*)up(code.data(), code.size() * sizeof(int)) : nullptr;
+  double* d_k = source ? (double*)up(consts.data(), consts.size() * sizeof(double)) : nullptr;
+  int rc = 0;
+  if (!d_ptr || !d_adj || !d_ed || !d_x || !d_w || !d_phi || !d_dphi || !d_d2 || (source && (!d_code || !d_k))) {
+    fh_set_error("fh_assemble_advdiff_line: out of device memory");
+    rc = 2;
+  } else {
+    hipLaunchKernelGGL(k_line_advdiff, dim3(fh_div_up(ndof, 64)), dim3(64), 0, st, ndof, nc, ng, d_ptr, d_adj, d_ed, d_x, sol ? sol->d : nullptr, d_w, d_phi, d_dphi,
+                       d_d2, nu, velocity, d_code, (int)code.size(), d_k, KK->d_rowptr, KK->d_col, KK->d_val, RES->d);
+    if (hipGetLastError() != hipSuccess) {
+      fh_set_error("fh_assemble_advdiff_line: launch failed");
+      rc = 2;
+    }
+    KK->val_gen++;
+    KK->at_valid = false;
+  }
+  hipStreamSynchronize(st);
+  for (void* q : dv) hipFree(q);
+  return rc;
+  FH_GUARD_END("fh_assemble_advdiff_line")
+}

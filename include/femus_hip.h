@@ -375,6 +375,14 @@ int fh_assemble_poisson_expr(fh_assembler_t as, fh_vec_t sol, fh_expr_t source, 
  * one of the nexpr expressions (one per boundary face name in the application); everything else as fh_assemble_neumann_faces */
 int fh_assemble_neumann_faces_expr(fh_ctx_t ctx, int geom, int fe, int gauss_order, int nfaces, const int* face_nodes, const int* face_expr,
                                    int nexpr, const fh_expr_t* exprs, int nnode, const double* coords, fh_vec_t res);
+
+/* The callback of applications/001_Poisson on a ONE-DIMENSIONAL mesh (main.cpp:355-480 with dim == 1; the shipped input/input1D.json: an EDGE3 box with
+ * V = 1, nu = 0.01, main.cpp:392-395): advection-diffusion with the streamline-upwind terms of that loop.  elem_dof[nel*3]: the nodes of every element in
+ * EDGE3 order (the two ends, then the middle: MeshGeneration.cpp:231-233), vertices numbered first so that a node id is its dof id in both families;
+ * coords[nnode]; fe 0 (two dofs per element) or 1 / 2 (three); sol NULL = 0; source NULL = 0.  KK (pattern holding every (i, j) of every element) and RES are
+ * OVERWRITTEN: KK = the Jacobian, RES = the residual, as the callback leaves them before the boundary rows are treated. */
+int fh_assemble_advdiff_line(fh_ctx_t ctx, int fe, int gauss_order, int nel, const int* elem_dof, int nnode, const double* coords, fh_vec_t sol, double nu,
+                             double velocity, fh_expr_t source, fh_mat_t KK, fh_vec_t RES);
 /* Open-boundary pressure term of the steady Navier-Stokes residual (src/08_equations/assemble/03_navier_stokes.hpp:185-290): on every listed boundary
  * face  aResV[k][node_i] += phi_i * tau * normal[k] * weight  for the dim velocity components (Q2 face nodes), tau = the prescribed pressure -- one
  * number per face (tau) or expression face_expr[f] of the nexpr expressions evaluated at the face Gauss point, as the bdc callback is (:280) -- and

@@ -1,0 +1,108 @@
+"""TEST INFRASTRUCTURE ONLY (oracle).  CPU restatement of the one-dimensional case of applications/001_Poisson (its shipped input/input1D.json): the EDGE3
+box, its numbering, the callback's advection-diffusion form with the streamline-upwind terms, the boundary rows and the solve -- numpy, loops as the reference
+writes them.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+
+  box_mesh      MeshGeneration.cpp:78-262 (case 1: nodes i / (2 nx), element i = {2 i, 2 i + 2, 2 i + 1}, face 0 of the first element "left" = -2, face 1 of the
+                last "right" = -3) + the renumbering every FEMuS mesh goes through (vertices first, then the middles, each class in order of first appearance)
+  tables        1d/Edge.hpp:72-104 (LineLinear, LineBiquadratic) at the line Gauss points: pinned bit for bit by tests/golden/fe_tables.npz (oracle/_ref)
+  assemble      main.cpp:355-480 with dim == 1 (V = 1, nu = 0.01 at :392-395); elem_type_1D::Jacobian, ElemType.hpp:994-1035
+  solve         LinearImplicitSystem::MGsolve with one level: exact solve of KK EPS = RES, Sol += EPS (boundary rows: MatZeroRows with 1 on the diagonal, RES = 0)
+"""
+import numpy as np
+
+from . import femus_oracle as fo
+
+
+def box_mesh(nx, xa=0.0, xb=1.0):
+    x = np.array([(i / (2.0 * nx)) * (xb - xa) + xa for i in range(2 * nx + 1)])
+    ed = np.array([[2 * i, 2 * i + 2, 2 * i + 1] for i in range(nx)])
+    face = np.full((nx, 2), -1)
+    face[0, 0] = -2            # "left"
+    face[nx - 1, 1] = -3       # "right"
+    # renumbering: vertices (local nodes 0, 1) first, then the middles, first appearance walking the elements
+    new = np.full(2 * nx + 1, -1)
+    k = 0
+    for cls in ((0, 1), (2,)):
+        for e in range(nx):
+            for l in cls:
+                if new[ed[e, l]] < 0:
+                    new[ed[e, l]] = k
+                    k += 1
+    xs = np.empty_like(x)
+    xs[new] = x
+    return new[ed], xs, face, nx + 1          # elem_dof, coords, face flags, number of vertices
+
+
+def line_tables(fe, order="seventh"):
+    w, xg = fo.gauss_table("line", order)
+    xg = np.asarray(xg).reshape(-1)
+    nodes = (0, 2) if fe == "linear" else (0, 2, 1)          # 1-D index I = xc + 1 of the local nodes (ends -1, +1, middle 0)
+    lag, dlag = (fo.lag_linear, fo.dlag_linear) if fe == "linear" else (fo.lag_biquadratic, fo.dlag_biquadratic)
+    phi = np.array([[lag(x, I) for I in nodes] for x in xg])
+    dphi = np.array([[dlag(x, I) for I in nodes] for x in xg])
+    d2phi = np.zeros_like(phi) if fe == "linear" else np.array([[fo.d2lag_biquadratic(x, I) for I in nodes] for x in xg])
+    return np.asarray(w), phi, dphi, d2phi
+
+
+def assemble(elem_dof, coords, fe, sol, source, nu=0.01, V=1.0, order="seventh"):
+    """dense KK and RES as the callback leaves them (before the boundary rows)"""
+    nc = 2 if fe == "linear" else 3
+    ndof = int(elem_dof[:, :nc].max()) + 1
+    w, PHI, DPHI, D2PHI = line_tables(fe, order)
+    KK = np.zeros((ndof, ndof))
+    RES = np.zeros(ndof)
+    for e in range(elem_dof.shape[0]):
+        dof = elem_dof[e, :nc]
+        x = coords[dof]
+        u = sol[dof]
+        VxiHxi = (x[1] - x[0]) * V
+        PeXi = VxiHxi / (2. * nu)
+        barXi = 0. if abs(PeXi) < 1.0e-10 else 1. / np.tanh(PeXi) - 1. / PeXi
+        barNu = barXi * VxiHxi / 2.
+        vL2Norm2 = V * V
+        supgTau = barNu / vL2Norm2 if vL2Norm2 > 1.0e-15 else 0.
+        F = np.zeros(nc)
+        B = np.zeros((nc, nc))
+        for g in range(w.size):
+            Jac = 0.0
+            for n in range(nc):
+                Jac += DPHI[g, n] * x[n]
+            weight = Jac * w[g]
+            JacI = 1 / Jac
+            phi = PHI[g]
+            gradphi = DPHI[g] * JacI
+            nablaphi = D2PHI[g] * JacI * JacI
+            xg = gradSol = nablaSol = 0.0
+            for n in range(nc):
+                xg += x[n] * phi[n]
+                gradSol += gradphi[n] * u[n]
+                nablaSol += nablaphi[n] * u[n]
+            src = source(xg)
+            for i in range(nc):
+                lapRhs = nu * gradphi[i] * gradSol
+                advRhs = V * gradSol * phi[i]
+                resRhs = -nu * nablaSol + V * gradSol
+                supgPhi = (V * gradphi[i] + nu * nablaphi[i]) * supgTau
+                F[i] += (src * phi[i] - lapRhs - advRhs + (src - resRhs) * supgPhi) * weight
+                for j in range(nc):
+                    lap = nu * (gradphi[i] * gradphi[j] - nablaphi[j] * supgPhi) * weight
+                    adv = V * gradphi[j] * (phi[i] + supgPhi) * weight
+                    B[i, j] += lap + adv
+        RES[dof] += F
+        KK[np.ix_(dof, dof)] += B
+    return KK, RES
+
+
+def solve(nx, fe, source, dirichlet_left=0.0, xa=0.0, xb=1.0, nu=0.01, V=1.0):
+    """input1D.json: Dirichlet on "left", homogeneous Neumann on "right" (no boundary term), one level"""
+    ed, xs, face, nv = box_mesh(nx, xa, xb)
+    nc = 2 if fe == "linear" else 3
+    ndof = nv if fe == "linear" else xs.size
+    sol = np.zeros(ndof)
+    left = int(ed[0, 0])                                   # local node 0 of the element whose face 0 carries the flag
+    sol[left] = dirichlet_left
+    KK, RES = assemble(ed, xs, fe, sol, source, nu, V)
+    KK[left, :] = 0.0
+    KK[left, left] = 1.0
+    RES[left] = 0.0
+    return sol + np.linalg.solve(KK, RES), xs[:ndof], (KK, RES)
