@@ -283,3 +283,20 @@ class Poisson001:
         for e in list(self.bc_func.values()) + [self.source]:
             if e is not None:
                 e.destroy()
+
+
+if __name__ == "__main__":
+    # python -m femus_amd.app_poisson input/input.json [output directory]   -- run from the application's directory, as the reference's executable is
+    import sys
+    import femus_amd
+    if len(sys.argv) < 2:
+        sys.exit("usage: python -m femus_amd.app_poisson <input.json> [output directory]")
+    path = sys.argv[1]
+    app = Poisson001(femus_amd.Context(0), path, base_dir=os.getcwd())
+    out = app.run(log=print, output_dir=sys.argv[2] if len(sys.argv) > 2 else None) if app.dim > 1 else app.run(log=print)
+    print("%d dofs, %d linear iteration(s), Linear Res L2norm %.3e, %s; max |Sol| = %.12g" % (out["dofs"], len(out["history"]), out["history"][-1][1],
+                                                                                              "converged" if out["converged"] else "NOT converged",
+                                                                                              float(np.abs(out["solution"]).max())))
+    for f in out.get("files", []):
+        print("wrote", f)
+    app.destroy()
