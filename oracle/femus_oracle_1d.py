@@ -93,8 +93,9 @@ def assemble(elem_dof, coords, fe, sol, source, nu=0.01, V=1.0, order="seventh")
     return KK, RES
 
 
-def solve(nx, fe, source, dirichlet_left=0.0, xa=0.0, xb=1.0, nu=0.01, V=1.0):
-    """input1D.json: Dirichlet on "left", homogeneous Neumann on "right" (no boundary term), one level"""
+def solve(nx, fe, source, dirichlet_left=0.0, xa=0.0, xb=1.0, nu=0.01, V=1.0, flux_right=None):
+    """input1D.json: Dirichlet on "left", Neumann on "right" -- homogeneous there (no boundary term); a parsed flux g adds g(x) to the row of the end
+    point, the side "element" being a point (main.cpp:540-549) --, one level"""
     ed, xs, face, nv = box_mesh(nx, xa, xb)
     nc = 2 if fe == "linear" else 3
     ndof = nv if fe == "linear" else xs.size
@@ -102,6 +103,9 @@ def solve(nx, fe, source, dirichlet_left=0.0, xa=0.0, xb=1.0, nu=0.01, V=1.0):
     left = int(ed[0, 0])                                   # local node 0 of the element whose face 0 carries the flag
     sol[left] = dirichlet_left
     KK, RES = assemble(ed, xs, fe, sol, source, nu, V)
+    if flux_right is not None:
+        right = int(ed[nx - 1, 1])
+        RES[right] += flux_right(xs[right])
     KK[left, :] = 0.0
     KK[left, left] = 1.0
     RES[left] = 0.0
