@@ -223,60 +223,133 @@ class Poisson001:
         faces = {-2: (0, 0), -3: (nx - 1, 1)}                 # flag -> (element, local face = local node)
         return new[ed], xs, faces, nx + 1
 
-    def run_line(self, log=None):
-        """LinearImplicitSystem::MGsolve on the EDGE3 box with the callback's one-dimensional form (fh_assemble_advdiff_line): one level (the shipped input has
-        nlevels = 1), i.e. the exact solve of KK EPS = RES per linear iteration, Sol += EPS"""
-        if self.nlevels != 1:
-            raise NotImplementedError("the one-dimensional box is served on one level (input/input1D.json: nlevels = 1)")
-        ctx = self.ctx
-        ed, xs, faces, nv = self.line_mesh()
+    @staticmethod
+    def refine_line(ed, xs, faces):
+        """MeshRefinement::RefineMesh on EDGE3: element e -> children 2 e (at vertex 0) and 2 e + 1 (at vertex 1); vertex v of child j = coarse node
+        fine2CoarseVertexMapping[j][v] ({0, 2}, {2, 1}); every child gets a new middle whose coordinate is the element prolongator's row (the quadratic map at
+        xi = -1/2, +1/2); a child inherits the flag of the face its vertex lies on; then the numbering of every FEMuS mesh (vertices first, then middles, first touch)"""
+        nel = ed.shape[0]
+        f2c = ((0, 2), (2, 1))
+        EP = capi.fe_elem_prolongator("line", "biquadratic")          # [child][local node][coarse function]
+        raw = np.zeros((2 * nel, 3), dtype=np.int64)
+        x = list(xs)
+        for e in range(nel):
+            for j in range(2):
+                raw[2 * e + j, 0], raw[2 * e + j, 1] = ed[e, f2c[j][0]], ed[e, f2c[j][1]]
+                raw[2 * e + j, 2] = len(x)
+                x.append(sum(EP[j, 2, k] * xs[ed[e, k]] for k in range(3)))
+        x = np.array(x)
+        new = np.full(x.size, -1)
+        k = 0
+        for cls in ((0, 1), (2,)):
+            for e in range(2 * nel):
+                for l in cls:
+                    if new[raw[e, l]] < 0:
+                        new[raw[e, l]] = k
+                        k += 1
+        xf = np.empty_like(x)
+        xf[new] = x
+        ffaces = {flag: (2 * e + f, f) for flag, (e, f) in faces.items()}
+        return new[raw], xf, ffaces, nel * 2 + 1
+
+    def line_prolongator(self, ed_c, ed_f, ndof_c, ndof_f):
+        """PP of a level (Mesh / FE prolongator, ElemType.cpp:439-532 on the line): row of fine dof = coarse shape functions at its reference point in the father"""
         nc = 2 if self.fe == "linear" else 3
-        ndof = nv if self.fe == "linear" else xs.size
+        EP = capi.fe_elem_prolongator("line", self.fe)
+        P = {}
+        for e in range(ed_c.shape[0]):
+            for j in range(2):
+                for n in range(nc):
+                    row = int(ed_f[2 * e + j, n])
+                    for k in range(nc):
+                        if EP[j, n, k] != 0.0:
+                            P[(row, int(ed_c[e, k]))] = EP[j, n, k]
+        keys = sorted(P)
+        rows = np.array([q[0] for q in keys])
+        indptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=ndof_f))])
+        return capi.Mat.from_csr(self.ctx, ndof_f, ndof_c, indptr, np.array([q[1] for q in keys]), np.array([P[q] for q in keys]))
+
+    def run_line(self, log=None, smoother=capi.SMOOTH_SOR, omega=1.0):
+        """LinearImplicitSystem::MGsolve on the EDGE3 box with the callback's one-dimensional form (fh_assemble_advdiff_line) on the finest level, Galerkin
+        operators below it (PP^T KK PP), V-cycles under GMRES limited to 4 iterations per linear iteration; one level (the shipped input): the exact solve.
+        smoother / omega: Richardson + SOR_PRECOND as main.cpp:240-242 sets them (scale 1 here: the natural-order sweep of a one-dimensional operator)"""
+        ctx = self.ctx
+        levels = [self.line_mesh()]
+        for _ in range(1, self.nlevels):
+            levels.append(self.refine_line(*levels[-1][:3]))
+        nc = 2 if self.fe == "linear" else 3
+        ndofs = [(nv if self.fe == "linear" else xs.size) for (_, xs, _, nv) in levels]
+        top = self.nlevels - 1
+        ed, xs, faces, nv = levels[top]
+        ndof = ndofs[top]
         pairs = sorted({(int(a), int(b)) for e in ed for a in e[:nc] for b in e[:nc]})
         rows = np.array([p[0] for p in pairs])
         indptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=ndof))])
         K = capi.Mat.from_csr(ctx, ndof, ndof, indptr, np.array([p[1] for p in pairs]))
         SOL, RES, EPS = ctx.vector(ndof), ctx.vector(ndof), ctx.vector(ndof)
         sol0 = np.zeros(ndof)
-        idx, point_flux = [], []
-        for flag, (e, f) in faces.items():
+        bdc, point_flux = [[] for _ in levels], []
+        for flag in faces:
             kind, fn = self.face_bc(flag)
-            node = int(ed[e, f])
-            x4 = np.array([xs[node], 0.0, 0.0, 0.0])
-            if kind == "dirichlet":
-                idx.append(node)
-                sol0[node] = fn(x4) if fn is not None else 0.0
-            elif fn is not None:                              # non-homogeneous Neumann: the side "element" is a point, F[node] += g(x) (main.cpp:540-549)
-                point_flux.append((node, fn(x4)))
-        idx = np.array(sorted(idx), dtype=np.int32)
+            for l, (edl, xl, fl, _) in enumerate(levels):
+                e, f = fl[flag]
+                node = int(edl[e, f])
+                if kind == "dirichlet":
+                    bdc[l].append(node)
+                if l == top:
+                    x4 = np.array([xl[node], 0.0, 0.0, 0.0])
+                    if kind == "dirichlet":
+                        sol0[node] = fn(x4) if fn is not None else 0.0
+                    elif fn is not None:                      # non-homogeneous Neumann: the side "element" is a point, F[node] += g(x) (main.cpp:540-549)
+                        point_flux.append((node, fn(x4)))
+        bdc = [np.array(sorted(b), dtype=np.int32) for b in bdc]
+        P = [None] + [self.line_prolongator(levels[l - 1][0], levels[l][0], ndofs[l - 1], ndofs[l]) for l in range(1, self.nlevels)]
+        for l in range(1, self.nlevels):                      # rows of fine Dirichlet dofs and columns of coarse ones carry nothing (ZeroInterpolatorDirichletNodes)
+            if bdc[l].size:
+                P[l].mat_zero_rows(bdc[l], 0.0)
+            if bdc[l - 1].size:
+                P[l].zero_cols(bdc[l - 1])
         SOL.upload(sol0)
-        mg = capi.Multigrid(ctx, 1)
+        mg = capi.Multigrid(ctx, self.nlevels)
+        A = [None] * self.nlevels
+        A[top] = K
         history = []
-        for it in range(self.max_linear):
+        for it in range(self.max_linear + 1):
             capi.assemble_advdiff_line(ctx, self.fe, ed, xs, K, RES, self.NU_1D, self.V_1D, sol=SOL, source=self.source)
             if point_flux:
                 r = RES.to_numpy()
                 for node, g in point_flux:
                     r[node] += g
                 RES.upload(r)
-            if idx.size:
-                K.mat_zero_rows(idx, 1.0)
-                RES.set(idx, np.zeros(idx.size))
+            if bdc[top].size:
+                K.mat_zero_rows(bdc[top], 1.0)
+                RES.set(bdc[top], np.zeros(bdc[top].size))
             rn = RES.l2_norm()
-            history.append((0 if it == 0 else 1, rn))
+            history.append((0, rn) if it == 0 else (its, rn))
             if log:
                 log("linear iteration %d: Linear Res L2norm = %.6e" % (it, rn))
-            if it > 0 and rn < self.abs_tol:
+            if (it > 0 and rn < self.abs_tol) or it == self.max_linear:
                 break
-            mg.set_level(0, K, None, None, capi.SMOOTH_JACOBI, 1.0, 1, 0)
+            for l in range(top, 0, -1):                       # Galerkin chain, then the boundary rows of every level
+                if A[l - 1] is None:
+                    A[l - 1] = capi.Mat.ptap(P[l], A[l])
+                else:
+                    A[l - 1].ptap_numeric(P[l], A[l])
+            for l in range(top):
+                if bdc[l].size:
+                    A[l].mat_zero_rows(bdc[l], 1.0)
+            for l in range(self.nlevels):
+                mg.set_level(l, A[l], P[l], None, smoother, omega, self.npre if l > 0 else 1, self.npost if l > 0 else 0)
             mg.setup()
             EPS.zero()
-            mg.solve(RES, EPS, outer="preonly")
+            its, _ = mg.solve(RES, EPS, outer="gmres" if self.nlevels > 1 else "preonly", rtol=1e-12, atol=1e-20, maxit=4)
             SOL.add(1.0, EPS)
         mg.destroy()
         result = {"solution": SOL.to_numpy(), "coords": xs[:ndof].reshape(-1, 1), "history": history, "converged": history[-1][1] < self.abs_tol, "dofs": ndof,
-                  "elem_dof": ed, "nodes": xs}
-        K.destroy()
+                  "elem_dof": ed, "nodes": xs, "levels": [(l[0], l[1]) for l in levels]}
+        for m in A + P:
+            if m is not None:
+                m.destroy()
         return result
 
     def destroy(self):

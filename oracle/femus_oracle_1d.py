@@ -110,3 +110,53 @@ def solve(nx, fe, source, dirichlet_left=0.0, xa=0.0, xb=1.0, nu=0.01, V=1.0, fl
     KK[left, left] = 1.0
     RES[left] = 0.0
     return sol + np.linalg.solve(KK, RES), xs[:ndof], (KK, RES)
+
+
+def refine(ed, xs, face):
+    """MeshRefinement::RefineMesh on EDGE3 (the rules of femus_oracle.refine on the line): children 2 e + j, vertex v of child j = coarse node
+    fine2CoarseVertexMapping[j][v], a new middle per child at the image of xi = -1/2 / +1/2 under the father's quadratic map (the element prolongator's rows
+    0.375, -0.125, 0.75), child j inherits the flag of face j; numbering: vertices first, then middles, first touch"""
+    nel = ed.shape[0]
+    f2c = np.array([[0, 2], [2, 1]])
+    rows = {0: (fo.lag_biquadratic(-0.5, 0), fo.lag_biquadratic(-0.5, 2), fo.lag_biquadratic(-0.5, 1)),       # weights of (end 0, end 1, middle)
+            1: (fo.lag_biquadratic(0.5, 0), fo.lag_biquadratic(0.5, 2), fo.lag_biquadratic(0.5, 1))}
+    raw = np.zeros((2 * nel, 3), dtype=np.int64)
+    x = list(xs)
+    ff = np.full((2 * nel, 2), -1)
+    for e in range(nel):
+        for j in range(2):
+            c = 2 * e + j
+            raw[c, :2] = ed[e, f2c[j]]
+            raw[c, 2] = len(x)
+            w = rows[j]
+            x.append(w[0] * xs[ed[e, 0]] + w[1] * xs[ed[e, 1]] + w[2] * xs[ed[e, 2]])
+            ff[c, j] = face[e, j]
+    x = np.array(x)
+    new = np.full(x.size, -1)
+    k = 0
+    for a, b in ((0, 2), (2, 3)):
+        for c in range(2 * nel):
+            for l in range(a, b):
+                if new[raw[c, l]] < 0:
+                    new[raw[c, l]] = k
+                    k += 1
+    xf = np.empty_like(x)
+    xf[new] = x
+    return new[raw], xf, ff, 2 * nel + 1
+
+
+def solve_levels(nx, nlevels, fe, source, dirichlet_left=0.0, xa=0.0, xb=1.0, nu=0.01, V=1.0):
+    """the discrete problem of the FINEST of nlevels levels, solved directly (what the multigrid iteration of the application converges to), and the meshes"""
+    meshes = [box_mesh(nx, xa, xb)]
+    for _ in range(1, nlevels):
+        meshes.append(refine(*meshes[-1][:3]))
+    ed, xs, face, nv = meshes[-1]
+    ndof = nv if fe == "linear" else xs.size
+    sol = np.zeros(ndof)
+    left = int(ed[np.where(face[:, 0] == -2)[0][0], 0])
+    sol[left] = dirichlet_left
+    KK, RES = assemble(ed, xs, fe, sol, source, nu, V)
+    KK[left, :] = 0.0
+    KK[left, left] = 1.0
+    RES[left] = 0.0
+    return sol + np.linalg.solve(KK, RES), meshes

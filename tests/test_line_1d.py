@@ -50,6 +50,19 @@ def test_oracle_without_velocity_is_the_poisson_form():
     assert np.allclose(K, K.T) and np.allclose(K.sum(axis=1), 0.0, atol=1e-12) and np.isclose(F.sum(), 1.0)
 
 
+def test_oracle_refinement_of_the_edge3_box():
+    """children at the father's vertices, new middles at the quarter points, flags inherited by the end children, vertices numbered first"""
+    ed, xs, face, nv = o1.box_mesh(3, 0.0, 3.0)
+    ef, xf, ff, nvf = o1.refine(ed, xs, face)
+    assert nvf == 7 and np.allclose(np.sort(xf[:nvf]), np.arange(7) * 0.5) and np.allclose(np.sort(xf[nvf:]), 0.25 + 0.5 * np.arange(6))
+    assert np.allclose(xf[ef[:, 2]], 0.5 * (xf[ef[:, 0]] + xf[ef[:, 1]])) and np.all(xf[ef[:, 0]] < xf[ef[:, 1]])
+    assert ff[0].tolist() == [-2, -1] and ff[-1].tolist() == [-1, -3] and (ff[1:-1] == -1).all()
+    u2, meshes = o1.solve_levels(10, 2, "biquadratic", source)
+    u1, x1, _ = o1.solve(20, "biquadratic", source)            # the refined ten-element box IS the twenty-element box, numbered differently
+    xs2 = meshes[-1][1]
+    assert np.allclose(u2[np.argsort(xs2)], u1[np.argsort(x1)], atol=1e-12)
+
+
 gpu = pytest.mark.gpu
 
 
@@ -143,4 +156,27 @@ def test_one_dimensional_input_with_boundary_values_and_a_flux(ctx, fe):
     ref, x, _ = o1.solve(23, ofe, source, dirichlet_left=0.75 - 0.5, xa=-0.5, xb=1.5, flux_right=lambda x: 0.02 * x)
     assert out["dofs"] == ref.size and np.abs(out["solution"] - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
     assert abs(out["solution"][0] - 0.25) < 1e-14
+    p.destroy()
+
+
+@gpu
+@pytest.mark.parametrize("fe,nlevels", [("second", 3), ("first", 3), ("second", 4)])
+def test_one_dimensional_input_on_several_levels(ctx, fe, nlevels):
+    """input1D.json with "nlevels" raised: EDGE3 refinement (meshes equal to the oracle's, integers and coordinates), Galerkin operators, V-cycles with the
+    natural-order sweep under GMRES(4): converges under the input's own limits to the direct solve of the finest level's problem"""
+    from femus_amd import app_poisson as app
+    cfg = app.load_config(SHIPPED_1D_INPUT)
+    cfg["multilevel_solution"]["multilevel_mesh"]["first"]["variable"]["first"]["fe_order"] = fe
+    cfg["multilevel_problem"]["multilevel_mesh"]["first"]["system"]["poisson"]["linear_solver"]["type"]["multigrid"]["nlevels"] = nlevels
+    p = app.Poisson001(ctx, cfg)
+    out = p.run()
+    ofe = "linear" if fe == "first" else "biquadratic"
+    ref, meshes = o1.solve_levels(10, nlevels, ofe, source)
+    for (ed_p, xs_p), (ed_o, xs_o, _, _) in zip(out["levels"], meshes):
+        assert np.array_equal(ed_p, ed_o) and np.allclose(xs_p, xs_o, rtol=0, atol=1e-15)
+    assert out["converged"] and len(out["history"]) <= 7, out["history"]
+    assert np.abs(out["solution"] - ref).max() < 1e-8                       # what ||RES|| < 1e-9 leaves
+    p.max_linear, p.abs_tol = 30, 1e-13
+    out = p.run()
+    assert out["converged"] and np.abs(out["solution"] - ref).max() < 1e-10
     p.destroy()
