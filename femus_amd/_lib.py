@@ -138,6 +138,7 @@ def _declare(L):
     sig("fh_element_matrices_poisson", c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p)
     sig("fh_fe_face_nodes", c_int, c_int, c_int, P(c_int), c_void_p)
     sig("fh_fe_node_ref", c_int, c_int, c_void_p)
+    sig("fh_fe_node_ref_coords", c_int, c_int, c_void_p)
     sig("fh_assemble_neumann_faces", c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p)
     sig("fh_assemble_neumann_faces_expr", c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p)
     sig("fh_assemble_advdiff_line", c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_double, c_double, c_void_p, c_void_p, c_void_p)

@@ -25,18 +25,27 @@ static const signed char XC_HEX[27][3] = {
 static const signed char XC_QUAD[9][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}, {0, -1}, {1, 0}, {0, 1}, {-1, 0}, {0, 0}};
 // EDGE3 (1d/Edge.cpp:22-30): the two end points, then the middle
 static const signed char XC_LINE[3][1] = {{-1}, {1}, {0}};
+// TRI7 (2d/Triangle.cpp:27-37): vertices, edge middles, centre; TRI_IND = the (i, j) selectors of the basis polynomials (0, 1, 2 along an edge, 7 the bubble);
+// children (Triangle.cpp:48-53): three at the vertices, the fourth the middle triangle {4, 5, 3}; faces (:55-59)
+static const double XC_TRI[7][2] = {{0, 0}, {1, 0}, {0, 1}, {0.5, 0}, {0.5, 0.5}, {0, 0.5}, {1. / 3., 1. / 3.}};
+static const int TRI_IND[7][2] = {{0, 0}, {2, 0}, {0, 2}, {1, 0}, {1, 1}, {0, 1}, {7, 7}};
+static const int TRI_F2C[4][3] = {{0, 3, 5}, {3, 1, 4}, {5, 4, 2}, {4, 5, 3}};
+static const int TRI_FACE[3][3] = {{0, 1, 3}, {1, 2, 4}, {2, 0, 5}};
 
-int dim_of(int geom) { return geom == GEOM_HEX ? 3 : geom == GEOM_QUAD ? 2 : 1; }
-int nloc_of(int geom) { return geom == GEOM_HEX ? 27 : geom == GEOM_QUAD ? 9 : 3; }
-int nvert_of(int geom) { return geom == GEOM_HEX ? 8 : geom == GEOM_QUAD ? 4 : 2; }
-int nedge_end_of(int geom) { return geom == GEOM_HEX ? 20 : geom == GEOM_QUAD ? 8 : 2; }
-int nfaces_of(int geom) { return geom == GEOM_HEX ? 6 : geom == GEOM_QUAD ? 4 : 2; }
+int dim_of(int geom) { return geom == GEOM_HEX ? 3 : (geom == GEOM_QUAD || geom == GEOM_TRI) ? 2 : 1; }
+int nloc_of(int geom) { return geom == GEOM_HEX ? 27 : geom == GEOM_QUAD ? 9 : geom == GEOM_TRI ? 7 : 3; }
+int nvert_of(int geom) { return geom == GEOM_HEX ? 8 : geom == GEOM_QUAD ? 4 : geom == GEOM_TRI ? 3 : 2; }
+int nedge_end_of(int geom) { return geom == GEOM_HEX ? 20 : geom == GEOM_QUAD ? 8 : geom == GEOM_TRI ? 6 : 2; }
+int nfaces_of(int geom) { return geom == GEOM_HEX ? 6 : geom == GEOM_QUAD ? 4 : geom == GEOM_TRI ? 3 : 2; }
 // (on the line the "quadratic" family IS the three-node one: NVE[5] = {2, 3, 3, 1, 2}, GeomElTypeEnum)
 int ndofs_of(int geom, int fe) {
   return fe == FE_LINEAR ? nvert_of(geom) : fe == FE_SERENDIPITY ? (geom == GEOM_LINE ? 3 : nedge_end_of(geom)) : fe == FE_CONSTANT ? 1 : nloc_of(geom);
 }
 
 int xc(int geom, int node, int d) { return geom == GEOM_HEX ? XC_HEX[node][d] : geom == GEOM_QUAD ? XC_QUAD[node][d] : XC_LINE[node][d]; }
+void node_ref(int geom, int node, double* pt) {
+  for (int k = 0; k < dim_of(geom); k++) pt[k] = geom == GEOM_TRI ? XC_TRI[node][k] : (double)xc(geom, node, k);
+}
 
 // ---- Gauss-Legendre in extended precision, then the reference's 14-significant-digit rounding -----------
 static void gauss_legendre_ld(int n, long double* x, long double* w) {
@@ -69,7 +78,32 @@ static double round14(long double v) {
   return r + 0.0;
 }
 
+// triangle rules (2d/quadrature_Triangle.cpp): symmetric rules with the barycentre, 1 / 4 / 7 / 13 / 19 points; first row the weights (the reference
+// triangle has area 1/2), then x, y -- the numbers as the reference's tables hold them (14 significant digits, the last rule 7)
+static const int TRI_NG[5] = {1, 4, 7, 13, 19};
+static const double TRI_G0[3][1] = {{0.5}, {0.33333333333333}, {0.33333333333333}};
+static const double TRI_G1[3][4] = {{-0.28125, 0.26041666666667, 0.26041666666667, 0.26041666666667}, {0.33333333333333, 0.6, 0.2, 0.2}, {0.33333333333333, 0.2, 0.6, 0.2}};
+static const double TRI_G2[3][7] = {{0.1125, 0.062969590272414, 0.062969590272414, 0.062969590272414, 0.066197076394253, 0.066197076394253, 0.066197076394253},
+                                    {0.33333333333333, 0.79742698535309, 0.10128650732346, 0.10128650732346, 0.05971587178977, 0.47014206410511, 0.47014206410511},
+                                    {0.33333333333333, 0.10128650732346, 0.79742698535309, 0.10128650732346, 0.47014206410511, 0.05971587178977, 0.47014206410511}};
+static const double TRI_G3[3][13] = {
+    {-0.074785022233835, 0.087807628716602, 0.087807628716602, 0.087807628716602, 0.026673617804419, 0.026673617804419, 0.026673617804419, 0.038556880445128,
+     0.038556880445128, 0.038556880445128, 0.038556880445128, 0.038556880445128, 0.038556880445128},
+    {0.33333333333333, 0.47930806784192, 0.26034596607904, 0.26034596607904, 0.86973979419557, 0.065130102902216, 0.065130102902216, 0.63844418856981,
+     0.63844418856981, 0.048690315425316, 0.048690315425316, 0.31286549600488, 0.31286549600488},
+    {0.33333333333333, 0.26034596607904, 0.47930806784192, 0.26034596607904, 0.065130102902216, 0.86973979419557, 0.065130102902216, 0.048690315425316,
+     0.31286549600488, 0.63844418856981, 0.31286549600488, 0.63844418856981, 0.048690315425316}};
+static const double TRI_G4[3][19] = {
+    {0.0485679, 0.01566735, 0.01566735, 0.01566735, 0.03891377, 0.03891377, 0.03891377, 0.03982387, 0.03982387, 0.03982387, 0.01278884, 0.01278884, 0.01278884,
+     0.02164177, 0.02164177, 0.02164177, 0.02164177, 0.02164177, 0.02164177},
+    {0.3333333, 0.02063496, 0.4896825, 0.4896825, 0.1258208, 0.4370896, 0.4370896, 0.6235929, 0.1882035, 0.1882035, 0.910541, 0.04472951, 0.04472951, 0.03683841,
+     0.03683841, 0.7411986, 0.7411986, 0.221963, 0.221963},
+    {0.3333333, 0.4896825, 0.02063496, 0.4896825, 0.4370896, 0.1258208, 0.4370896, 0.1882035, 0.6235929, 0.1882035, 0.04472951, 0.910541, 0.04472951, 0.7411986,
+     0.221963, 0.03683841, 0.221963, 0.03683841, 0.7411986}};
+static const double* TRI_G[5] = {TRI_G0[0], TRI_G1[0], TRI_G2[0], TRI_G3[0], TRI_G4[0]};
+
 int gauss_npoints(int geom, int order) {
+  if (geom == GEOM_TRI) return TRI_NG[order];
   int n = order + 1, d = (geom == GEOM_LINE) ? 1 : dim_of(geom), r = 1;
   for (int k = 0; k < d; k++) r *= n;
   return r;
@@ -78,6 +112,17 @@ int gauss_npoints(int geom, int order) {
 // w[ng], x[d*ng + ig]; first coordinate slowest, as the reference tables
 int gauss_table(int geom, int order, double* w, double* x) {
   if (order < 0 || order > 4) return 1;
+  if (geom == GEOM_TRI) {
+    const int ng = TRI_NG[order];
+    for (int ig = 0; ig < ng; ig++) {
+      if (w) w[ig] = TRI_G[order][ig];
+      if (x) {
+        x[ig] = TRI_G[order][ng + ig];
+        x[ng + ig] = TRI_G[order][2 * ng + ig];
+      }
+    }
+    return 0;
+  }
   const int n = order + 1;
   const int d = (geom == GEOM_LINE) ? 1 : dim_of(geom);
   long double x1[8], w1[8];
@@ -120,6 +165,41 @@ static inline double d2lagB(int i) { return !i * 1.0 + !(i - 1) * (-2.0) + !(i -
 static inline double lagQ(double x, int i) { return !i * (0.5) * (1. - x) + !(i - 1) * (1. - x) * (1. + x) + !(i - 2) * (0.5) * (1. + x); }
 static inline double dlagQ(double x, int i) { return (!i) * (-0.5) + !(i - 1) * (-2. * x) + !(i - 2) * (0.5); }
 static inline double d2lagQ(int i) { return !(i - 1) * (-2.); }
+
+// Triangle families (2d/Triangle.hpp:69-181): P1, P2 and P2 enriched with the cubic bubble (TRI7), selected by the (i, j) pair of the node as the 1-D factors
+// above are by their index; the terms in the reference's order (the tables are compared bit for bit with the ones its compiled classes give).
+// out: phi, d/dx, d/dy, d2/dx2, d2/dy2, d2/dxdy
+static void tri_node(int fe, int i, int j, double x, double y, double out[6]) {
+  for (int k = 0; k < 6; k++) out[k] = 0.0;
+  if (fe == FE_LINEAR) {
+    out[0] = (!i * !j) * (1. - x - y) + !(i - 2) * x + !(j - 2) * y;
+    out[1] = -(!i * !j) + !(i - 2);
+    out[2] = -(!i * !j) + !(j - 2);
+  } else if (fe == FE_SERENDIPITY) {
+    out[0] = !i * (!j * (1. - x - y) * (1. - 2. * x - 2. * y) + !(j - 1) * 4. * y * (1. - x - y) + !(j - 2) * (-y + 2. * y * y)) +
+             !(i - 1) * (!j * 4. * x * (1. - x - y) + !(j - 1) * 4. * x * y) + !(i - 2) * (!j * (-x + 2. * x * x));
+    out[1] = !i * (!j * (-3. + 4. * x + 4. * y) + !(j - 1) * y * (-4.)) + !(i - 1) * (!j * 4. * (1. - 2. * x - y) + !(j - 1) * y * (4.)) + !(i - 2) * (!j * (-1 + 4. * x));
+    out[2] = !j * (!i * (-3. + 4. * y + 4. * x) + !(i - 1) * x * (-4.)) + !(j - 1) * (!i * 4. * (1. - 2. * y - x) + !(i - 1) * x * (4.)) + !(j - 2) * (!i * (-1 + 4. * y));
+    out[3] = !j * ((!i) * 4. + !(i - 1) * (-8.) + !(i - 2) * 4.);
+    out[4] = !i * ((!j) * 4. + !(j - 1) * (-8.) + !(j - 2) * 4.);
+    out[5] = ((!i) * (!j) + !(i - 1) * !(j - 1)) * 4. + (!(i - 1) * (!j) + (!i) * !(j - 1)) * (-4.);
+  } else {
+    const double b3 = 3. * x * y * (1 - x - y), bx = y - 2. * x * y - y * y, by = x - x * x - 2. * x * y, bxy = 1 - 2. * x - 2. * y;      // (the products associate as in the reference's inline terms)
+    out[0] = !i * (!j * ((1. - x - y) * (1. - 2. * x - 2. * y) + b3) + !(j - 1) * 4. * (y * (1. - x - y) - b3) + !(j - 2) * (-y + 2. * y * y + b3)) +
+             !(i - 1) * (!j * 4. * (x * (1. - x - y) - b3) + !(j - 1) * 4. * (x * y - b3)) + !(i - 2) * (!j * (-x + 2. * x * x + b3)) +
+             !(i - 7) * (!(j - 7) * 27. * x * y * (1 - x - y));
+    out[1] = !i * (!j * (-3. + 4. * x + 4. * y + 3. * bx) + !(j - 1) * 4. * (-y - 3. * bx) + !(j - 2) * 3. * bx) +
+             !(i - 1) * (!j * 4. * (1. - 2. * x - y - 3. * bx) + !(j - 1) * 4. * (y - 3. * bx)) + !(i - 2) * (!j * (-1 + 4. * x + 3. * bx)) + !(i - 7) * (!(j - 7) * 27. * bx);
+    out[2] = !j * (!i * (-3. + 4. * y + 4. * x + 3. * by) + !(i - 1) * 4. * (-x - 3. * by) + !(i - 2) * 3. * by) +
+             !(j - 1) * (!i * 4. * (1. - 2. * y - x - 3. * by) + !(i - 1) * 4. * (x - 3. * by)) + !(j - 2) * (!i * (-1 + 4. * y + 3. * by)) + !(j - 7) * (!(i - 7) * 27. * by);
+    out[3] = !i * (!j * (4. - 6. * y) + !(j - 1) * 4. * (6. * y) + !(j - 2) * (-6. * y)) + !(i - 1) * (!j * 4. * (-2. + 6. * y) + !(j - 1) * 4. * (6. * y)) +
+             !(i - 2) * (!j * (4. - 6. * y)) + !(i - 7) * (!(j - 7) * (-54. * y));
+    out[4] = !j * (!i * (4. - 6. * x) + !(i - 1) * 4. * (6. * x) + !(i - 2) * (-6. * x)) + !(j - 1) * (!i * 4. * (-2. + 6. * x) + !(i - 1) * 4. * (6. * x)) +
+             !(j - 2) * (!i * (4. - 6. * x)) + !(j - 7) * (!(i - 7) * (-54. * x));
+    out[5] = !j * (!i * (4. + 3. * bxy) + !(i - 1) * 4. * (-1. - 3. * bxy) + !(i - 2) * 3. * bxy) +
+             !(j - 1) * (!i * 4. * (-1. - 3. * bxy) + !(i - 1) * 4. * (1. - 3. * bxy)) + !(j - 2) * (!i * (3. * bxy)) + !(j - 7) * (!(i - 7) * 27. * bxy);
+  }
+}
 
 // Serendipity bases, the expressions of QuadQuadratic / HexQuadratic term by term and in their order (the tables are compared bit for bit with the ones the
 // reference's compiled classes give): a vertex function is the product of the three (two) linear factors times (-2 + ix x + jx y + kx z) ((-1 + ...) in 2-D),
@@ -189,6 +269,16 @@ void eval_basis_d2(int geom, int fe, const double* pt, double* d2phi) {
     for (int k = 0; k < (d == 1 ? 1 : d == 2 ? 3 : 6); k++) d2phi[k] = 0.0;
     return;
   }
+  if (geom == GEOM_TRI) {        // (xx, yy, xy)
+    for (int j = 0; j < nc; j++) {
+      double v[6];
+      tri_node(fe, TRI_IND[j][0], TRI_IND[j][1], pt[0], pt[1], v);
+      d2phi[j * 3 + 0] = v[3];
+      d2phi[j * 3 + 1] = v[4];
+      d2phi[j * 3 + 2] = v[5];
+    }
+    return;
+  }
   if (fe == FE_SERENDIPITY && d > 1) {
     for (int j = 0; j < nc; j++) {
       double v[10];
@@ -228,6 +318,18 @@ void eval_basis_d2(int geom, int fe, const double* pt, double* d2phi) {
 
 void eval_basis(int geom, int fe, const double* pt, double* phi, double* dphi /* [nc*dim] node-major */) {
   const int d = dim_of(geom), nc = ndofs_of(geom, fe);
+  if (geom == GEOM_TRI && fe != FE_CONSTANT) {
+    for (int j = 0; j < nc; j++) {
+      double v[6];
+      tri_node(fe, TRI_IND[j][0], TRI_IND[j][1], pt[0], pt[1], v);
+      if (phi) phi[j] = v[0];
+      if (dphi) {
+        dphi[j * 2 + 0] = v[1];
+        dphi[j * 2 + 1] = v[2];
+      }
+    }
+    return;
+  }
   if (fe == FE_CONSTANT) {        // quad0 / hex0: the constant one
     if (phi) phi[0] = 1.;
     if (dphi)
@@ -288,10 +390,18 @@ int shape_tables(int geom, int fe, int order, std::vector<double>& w, std::vecto
 
 // child j = sub-element at coarse vertex j; local node i of child j sits at (Xc[j] + Xc[i]) / 2
 void child_node_ref(int geom, int child, int node, double* pt) {
+  if (geom == GEOM_TRI) {       // the child's reference triangle mapped affinely onto its three vertices in the father (the fourth child is the rotated middle one)
+    const double* v0 = XC_TRI[TRI_F2C[child][0]];
+    const double* v1 = XC_TRI[TRI_F2C[child][1]];
+    const double* v2 = XC_TRI[TRI_F2C[child][2]];
+    for (int k = 0; k < 2; k++) pt[k] = v0[k] + (v1[k] - v0[k]) * XC_TRI[node][0] + (v2[k] - v0[k]) * XC_TRI[node][1];
+    return;
+  }
   for (int k = 0; k < dim_of(geom); k++) pt[k] = 0.5 * (xc(geom, child, k) + xc(geom, node, k));
 }
 
 int fine2coarse_vertex(int geom, int child, int v) {
+  if (geom == GEOM_TRI) return TRI_F2C[child][v];
   double pt[3];
   child_node_ref(geom, child, v, pt);
   for (int n = 0; n < nloc_of(geom); n++) {
@@ -303,7 +413,7 @@ int fine2coarse_vertex(int geom, int child, int v) {
 }
 
 void elem_prolongator(int geom, int fe, std::vector<double>& P) {
-  const int nch = nvert_of(geom), nc = ndofs_of(geom, fe);
+  const int nch = geom == GEOM_TRI ? 4 : nvert_of(geom), nc = ndofs_of(geom, fe);
   P.assign((size_t)nch * nc * nc, 0.0);
   std::vector<double> phi(nc);
   for (int j = 0; j < nch; j++)
@@ -316,6 +426,11 @@ void elem_prolongator(int geom, int fe, std::vector<double>& P) {
 }
 
 int face_nodes(int geom, int fe, int face, int* out) {
+  if (geom == GEOM_TRI) {         // edges: the two ends, then the middle (tri_lag faceDofs)
+    const int n = fe == FE_CONSTANT ? 0 : fe == FE_LINEAR ? 2 : 3;
+    for (int k = 0; k < n; k++) out[k] = TRI_FACE[face][k];
+    return n;
+  }
   if (geom == GEOM_LINE) {        // the "faces" of a line element are its end points (line_lag faceDofs)
     if (fe == FE_CONSTANT) return 0;
     out[0] = face;
@@ -366,7 +481,7 @@ int face_nodes(int geom, int fe, int face, int* out) {
 #include "fh_internal.h"
 
 extern "C" int fh_fe_gauss(int geom, int order, int* ng, double* w, double* x) {
-  FH_REQUIRE(geom >= 0 && geom <= 2, "fh_fe_gauss: geom must be 0 (hex), 1 (quad) or 2 (line)");
+  FH_REQUIRE(geom >= 0 && geom <= 3, "fh_fe_gauss: geom must be 0 (hex), 1 (quad), 2 (line) or 3 (triangle)");
   FH_REQUIRE(order >= 0 && order <= 4, "fh_fe_gauss: Gauss rule index %d not supported (0..4)", order);
   if (ng) *ng = fhfe::gauss_npoints(geom, order);
   if (w || x) fhfe::gauss_table(geom, order, w, x);
@@ -374,7 +489,7 @@ extern "C" int fh_fe_gauss(int geom, int order, int* ng, double* w, double* x) {
 }
 
 extern "C" int fh_fe_tables(int geom, int fe, int order, int* ng, int* nc, double* phi, double* dphi) {
-  FH_REQUIRE(geom >= 0 && geom <= 2, "fh_fe_tables: geom must be 0 (hex), 1 (quad) or 2 (line)");
+  FH_REQUIRE(geom >= 0 && geom <= 3, "fh_fe_tables: geom must be 0 (hex), 1 (quad), 2 (line) or 3 (triangle)");
   FH_REQUIRE(fhfe::fe_known(fe), "fh_fe_tables: fe must be 0 (linear), 1 (serendipity), 2 (biquadratic) or 3 (piecewise constant)");
   FH_REQUIRE(order >= 0 && order <= 4, "fh_fe_tables: Gauss rule index %d not supported (0..4)", order);
   const int d = fhfe::dim_of(geom), n = fhfe::ndofs_of(geom, fe), g = fhfe::gauss_npoints(geom, order);
@@ -393,7 +508,7 @@ extern "C" int fh_fe_tables(int geom, int fe, int order, int* ng, int* nc, doubl
 }
 
 extern "C" int fh_fe_tables_d2(int geom, int fe, int order, double* d2phi) {
-  FH_REQUIRE(geom >= 0 && geom <= 2, "fh_fe_tables_d2: geom must be 0 (hex), 1 (quad) or 2 (line)");
+  FH_REQUIRE(geom >= 0 && geom <= 3, "fh_fe_tables_d2: geom must be 0 (hex), 1 (quad), 2 (line) or 3 (triangle)");
   FH_REQUIRE(fhfe::fe_known(fe), "fh_fe_tables_d2: fe must be 0 (linear), 1 (serendipity), 2 (biquadratic) or 3 (piecewise constant)");
   FH_REQUIRE(order >= 0 && order <= 4 && d2phi, "fh_fe_tables_d2: bad arguments");
   const int d = fhfe::dim_of(geom), n = fhfe::ndofs_of(geom, fe), g = fhfe::gauss_npoints(geom, order), nh = d == 1 ? 1 : d == 2 ? 3 : 6;
@@ -410,9 +525,9 @@ extern "C" int fh_fe_tables_d2(int geom, int fe, int order, double* d2phi) {
 }
 
 extern "C" int fh_fe_elem_prolongator(int geom, int fe, int* nchild, int* nc, double* P) {
-  FH_REQUIRE(geom >= 0 && geom <= 2, "fh_fe_elem_prolongator: geom must be 0 (hex), 1 (quad) or 2 (line)");
+  FH_REQUIRE(geom >= 0 && geom <= 3, "fh_fe_elem_prolongator: geom must be 0 (hex), 1 (quad), 2 (line) or 3 (triangle)");
   FH_REQUIRE(fhfe::fe_known(fe), "fh_fe_elem_prolongator: fe must be 0 (linear), 1 (serendipity), 2 (biquadratic) or 3 (piecewise constant)");
-  if (nchild) *nchild = fhfe::nvert_of(geom);
+  if (nchild) *nchild = geom == fhfe::GEOM_TRI ? 4 : fhfe::nvert_of(geom);
   if (nc) *nc = fhfe::ndofs_of(geom, fe);
   if (P) {
     std::vector<double> v;
@@ -424,14 +539,22 @@ extern "C" int fh_fe_elem_prolongator(int geom, int fe, int* nchild, int* nc, do
 
 // reference coordinates (-1, 0, 1 per direction) of local node `node` of the biquadratic element (hex_lag / quad_lag X tables, Hexahedron.cpp:32-92)
 extern "C" int fh_fe_node_ref(int geom, int node, int* xi) {
-  FH_REQUIRE(geom >= 0 && geom <= 2, "fh_fe_node_ref: geom must be 0 (hex), 1 (quad) or 2 (line)");
+  FH_REQUIRE(geom >= 0 && geom <= 2, "fh_fe_node_ref: geom must be 0 (hex), 1 (quad) or 2 (line) (integer coordinates; the triangle: fh_fe_node_ref_coords)");
   FH_REQUIRE(node >= 0 && node < fhfe::nloc_of(geom) && xi, "fh_fe_node_ref: node %d out of range", node);
   for (int d = 0; d < fhfe::dim_of(geom); d++) xi[d] = fhfe::xc(geom, node, d);
   return 0;
 }
 
+// reference coordinates of a local node as doubles (any element: the triangle's are 0, 1/2, 1, 1/3)
+extern "C" int fh_fe_node_ref_coords(int geom, int node, double* xi) {
+  FH_REQUIRE(geom >= 0 && geom <= 3 && xi, "fh_fe_node_ref_coords: bad arguments");
+  FH_REQUIRE(node >= 0 && node < fhfe::nloc_of(geom), "fh_fe_node_ref_coords: node %d out of range", node);
+  fhfe::node_ref(geom, node, xi);
+  return 0;
+}
+
 extern "C" int fh_fe_face_nodes(int geom, int fe, int face, int* nfn, int* local_nodes) {
-  FH_REQUIRE(geom >= 0 && geom <= 2, "fh_fe_face_nodes: geom must be 0 (hex), 1 (quad) or 2 (line)");
+  FH_REQUIRE(geom >= 0 && geom <= 3, "fh_fe_face_nodes: geom must be 0 (hex), 1 (quad), 2 (line) or 3 (triangle)");
   FH_REQUIRE(fhfe::fe_known(fe), "fh_fe_face_nodes: fe must be 0 .. 3");
   FH_REQUIRE(face >= 0 && face < fhfe::nfaces_of(geom), "fh_fe_face_nodes: face %d out of range", face);
   int tmp[9];

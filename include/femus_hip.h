@@ -352,6 +352,8 @@ int fh_assembler_last_path(fh_assembler_t as, int* path);
 int fh_fe_face_nodes(int geom, int fe, int face, int* nfn, int* local_nodes);
 /* reference coordinates (-1, 0, 1 per direction) of a local node of the biquadratic element (the X tables of hex_lag / quad_lag) */
 int fh_fe_node_ref(int geom, int node, int* xi /* [dim] */);
+/* the same as doubles, for every element (geom 3 = the triangle TRI7 of 2d/Triangle.cpp: vertices, edge middles, centre at 0, 1/2, 1, 1/3) */
+int fh_fe_node_ref_coords(int geom, int node, double* xi /* [dim] */);
 int fh_assemble_neumann_faces(fh_ctx_t ctx, int geom, int fe, int gauss_order, int nfaces, const int* face_nodes, const double* tau,
                               int nnode, const double* coords, fh_vec_t res);
 

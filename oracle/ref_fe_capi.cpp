@@ -5,11 +5,13 @@
 //   femus::Gauss            src/02_reference_geom_elements/02_quadrature/quadrature_interface.hpp:32
 //   femus::HexBiquadratic   src/02_reference_geom_elements/01_fe/3d/Hexahedron.hpp
 //   femus::QuadBiquadratic  src/02_reference_geom_elements/01_fe/2d/Quadrilateral.hpp
+//   femus::TriLinear / TriQuadratic / TriBiquadratic  src/02_reference_geom_elements/01_fe/2d/Triangle.hpp (round 6)
 //   femus::HexQuadratic / QuadQuadratic (serendipity), hex0 / quad0 (piecewise constant), hexpwLinear / quadpwLinear: same headers
 //   femus::GeomElemBase     src/02_reference_geom_elements/00_definition/GeomElemBase.hpp:32 (build), :83 (get_nodes_of_face), :97 (get_embedding_matrix)
 #include "quadrature_interface.hpp"
 #include "Hexahedron.hpp"
 #include "Quadrilateral.hpp"
+#include "Triangle.hpp"
 #include "Edge.hpp"
 #include "GeomElemBase.hpp"
 #include <cstring>
@@ -32,6 +34,10 @@ static basis* make_basis(const char* geom, const char* fe) {
     if (!strcmp(fe, "biquadratic")) return new QuadBiquadratic();
     if (!strcmp(fe, "constant")) return new quad0();
     if (!strcmp(fe, "pwlinear")) return new quadpwLinear();
+  } else if (!strcmp(geom, "tri")) {
+    if (!strcmp(fe, "linear")) return new TriLinear();
+    if (!strcmp(fe, "quadratic")) return new TriQuadratic();
+    if (!strcmp(fe, "biquadratic")) return new TriBiquadratic();
   } else if (!strcmp(geom, "line")) {
     if (!strcmp(fe, "linear")) return new LineLinear();
     if (!strcmp(fe, "biquadratic")) return new LineBiquadratic();

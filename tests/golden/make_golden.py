@@ -91,6 +91,44 @@ for i in range(3):
     xc1[i, 0] = b[0]
 out["xc_line"] = xc1
 
+# TRI7 (round 6): the triangle's Gauss rules, TriLinear / TriQuadratic / TriBiquadratic at the 'seventh' points and at sample points (phi, dx, dy, dxx, dyy, dxy),
+# node table, selectors, children, edge nodes
+for order in ORDERS:
+    ng = L.ref_gauss(b"tri", order.encode(), 2, None, None)
+    w = np.zeros(ng)
+    x = np.zeros((2, ng))
+    L.ref_gauss(b"tri", order.encode(), 2, w.ctypes.data_as(ctypes.c_void_p), x.ctypes.data_as(ctypes.c_void_p))
+    out["gauss_w_tri_%s" % order] = w
+    out["gauss_x_tri_%s" % order] = x.T.copy()
+sample_t = rng.uniform(0, 0.5, (7, 2))
+out["sample_pts_tri"] = sample_t
+for fe in ("linear", "serendipity", "biquadratic"):
+    rfe = REFNAME.get(fe, fe)
+    nc = L.ref_ndofs(b"tri", rfe.encode())
+    for tag, pts in (("gauss7", out["gauss_x_tri_seventh"]), ("sample", sample_t)):
+        vals = np.zeros((6, pts.shape[0], nc))
+        for p in range(pts.shape[0]):
+            pt = (ctypes.c_double * 3)(float(pts[p, 0]), float(pts[p, 1]), 0.0)
+            for j in range(nc):
+                for k, which in enumerate((0, 1, 2, 4, 5, 7)):
+                    if fe == "linear" and which in (4, 5, 7):
+                        continue               # TriLinear implements no second derivatives
+                    vals[k, p, j] = L.ref_eval(b"tri", rfe.encode(), which, j, pt)
+        out["basis_tri_%s_%s" % (fe, tag)] = vals
+xct = np.zeros((7, 2))
+indt = np.zeros((7, 2), dtype=np.int64)
+for i in range(7):
+    b = (ctypes.c_double * 3)()
+    L.ref_xcoarse(b"tri", b"biquadratic", i, 2, b)
+    xct[i] = list(b)[:2]
+    ii = (ctypes.c_int * 3)()
+    L.ref_ind(b"tri", b"biquadratic", i, 2, ii)
+    indt[i] = list(ii)[:2]
+out["xc_tri"] = xct
+out["ind_tri"] = indt
+out["f2c_tri"] = np.array([[L.ref_fine2coarse_vertex(b"tri", b"linear", j, v) for v in range(3)] for j in range(4)])
+out["facedofs_tri"] = np.array([[L.ref_face_dof(b"tri", b"biquadratic", f, k) for k in range(3)] for f in range(3)])
+
 # element prolongator as elem_type forms it.  ElemType.cpp itself needs boost and is not compiled, so its two loops are followed
 # here on top of the COMPILED basis classes (every number below comes out of a call into the reference's object code):
 #   (1) set_fine_coordinates_in_Basis_object (ElemType.cpp:404-432): fine node i = (child, vertex) = KVERT_IND[i] of the linear

@@ -67,6 +67,39 @@ def test_product_line_tables_bit_exact(fe):
     assert [capi.fe_face_nodes("line", fe, f).tolist() for f in range(2)] == [[0], [1]]
 
 
+@pytest.mark.parametrize("order", ORDERS)
+def test_product_triangle_gauss_tables_bit_exact(order):
+    """2d/quadrature_Triangle.cpp: the five symmetric rules (1 / 4 / 7 / 13 / 19 points)"""
+    w, x = capi.fe_gauss("tri", order)
+    assert np.array_equal(w, G["gauss_w_tri_%s" % order]) and np.array_equal(x, G["gauss_x_tri_%s" % order])
+
+
+@pytest.mark.parametrize("fe", ["linear", "serendipity", "biquadratic"])
+def test_product_triangle_tables_bit_exact(fe):
+    """TRI7 (round 6): TriLinear / TriQuadratic / TriBiquadratic (2d/Triangle.hpp:69-181) at the 'seventh' points: phi, the two first and the three second
+    derivatives against the reference's compiled classes; children, edge nodes and the element prolongator (coarse functions at the children's nodes)"""
+    ref = G["basis_tri_%s_gauss7" % fe]
+    phi, dphi = capi.fe_tables("tri", fe, "seventh")
+    d2 = capi.fe_tables_d2("tri", fe, "seventh")
+    assert np.array_equal(phi, ref[0]) and np.array_equal(dphi[:, :, 0], ref[1]) and np.array_equal(dphi[:, :, 1], ref[2])
+    for k in range(3):
+        assert np.array_equal(d2[:, :, k], ref[3 + k])
+    assert np.allclose(phi.sum(axis=1), 1.0, atol=1e-14) and np.allclose(dphi.sum(axis=1), 0.0, atol=1e-13)
+    nfn = 2 if fe == "linear" else 3
+    assert [capi.fe_face_nodes("tri", fe, f).tolist() for f in range(3)] == [G["facedofs_tri"][f][:nfn].tolist() for f in range(3)]
+    P = capi.fe_elem_prolongator("tri", fe)
+    nc = phi.shape[1]
+    assert P.shape == (4, nc, nc)
+    f2c = G["f2c_tri"]
+    for j in range(4):
+        for i in range(3):                                # a child's vertex is a node of the father: the row is a unit vector (for the families that hold that node)
+            if f2c[j][i] < nc:
+                e = np.zeros(nc)
+                e[f2c[j][i]] = 1.0
+                assert np.allclose(P[j, i], e, atol=1e-14)
+        assert np.allclose(P[j].sum(axis=1), 1.0, atol=1e-14)     # partition of unity at every child node
+
+
 def _rows_by_kvert(geom, fe, P):
     """rows of a [child][local node][coarse] element prolongator in the reference's fine-node order KVERT_IND (Hexahedron.cpp:49-71)"""
     kv = G["kvert_ind_%s_%s" % (geom, fe)]
