@@ -756,6 +756,14 @@ def fe_face_nodes(geom, fe, face):
     return out[:n.value].copy()
 
 
+def assemble_poisson_rows(ctx, geom, fe, elem_dof, coords, K, res, sol=None, source=None, scale=1.0, order="seventh"):
+    """the Poisson callback through the generic (dim, nc, ng) kernel (fh_assemble_poisson_rows): K_ij = sum grad phi_i . grad phi_j w, res_i = sum (scale f phi_i -
+    grad phi_i . grad sol) w; elem_dof[nel, nloc] in the family's local order, node classes numbered one after the other"""
+    ed, x = _i32(elem_dof), _f64(coords)
+    _chk(ctx.L.fh_assemble_poisson_rows(ctx.h, GEOM[geom], FE[fe], GAUSS_ORDER[order], ed.shape[0], ed.shape[1], _p(ed), x.shape[0], _p(x),
+                                        sol.h if sol is not None else None, source.h if source is not None else None, float(scale), K.h, res.h))
+
+
 def assemble_advdiff_line(ctx, fe, elem_dof, coords, K, res, nu, velocity, sol=None, source=None, order="seventh"):
     """the 001_Poisson callback on a one-dimensional EDGE3 mesh (main.cpp:355-480 with dim == 1: advection-diffusion with its streamline-upwind terms):
     K <- Jacobian, res <- residual.  elem_dof[nel, 3] node ids (ends, then middle; vertices numbered first), coords[nnode]"""

@@ -4959,3 +4959,168 @@ extern "C" int fh_assemble_advdiff_line(fh_ctx_t ctx, int fe, int order, int nel
   return rc;
   FH_GUARD_END("fh_assemble_advdiff_line")
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The Poisson callback through a GENERIC (dim, nc, ng) kernel (round 6): any element family fh_fe has tables for -- the triangle (geom 3) first, whose meshes
+// do not go through the tensor-product mesh layer -- with the element table given by the caller (nloc nodes per element in the family's local order; dof id =
+// node id, the classes numbered one after the other as every FEMuS mesh is).  One thread per ROW walks the elements of its node in ascending order and forms its
+// row of each element matrix over the Gauss points (elem_type::Jacobian: Jac[a][b] = sum_n dphi_n/dxi_a x_n[b], grad phi_n = Jac^-1 dphi_n, w = det w_g):
+//   K_ij += grad phi_i . grad phi_j w,   RES_i += (scale f phi_i - grad phi_i . grad u) w        (main.cpp:430-470 with V = 0)
+// The grouping of the reference's add_matrix_blocked / add_vector_blocked, no atomics; meant for the sizes such meshes have here, not for the bench (the
+// hexahedral paths above are the fast ones).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int GEN_NC = 27;
+__global__ __launch_bounds__(64) void k_poisson_rows_generic(int ndof, int dim, int nc, int ng, int nloc, const int* __restrict__ adj_ptr, const int* __restrict__ adj,
+                                                             const int* __restrict__ elem_dof, const double* __restrict__ coords, const double* __restrict__ sol,
+                                                             const double* __restrict__ w, const double* __restrict__ phi, const double* __restrict__ dphi,
+                                                             double scale, const int* __restrict__ prog, int nprog, const double* __restrict__ pconst,
+                                                             const int* __restrict__ rowptr, const int* __restrict__ col, double* __restrict__ val,
+                                                             double* __restrict__ res) {
+  const int r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= ndof) return;
+  const int rs = rowptr[r], re = rowptr[r + 1];
+  for (int k = rs; k < re; k++) val[k] = 0.0;
+  double racc = 0.0;
+  for (int a = adj_ptr[r]; a < adj_ptr[r + 1]; a++) {
+    const int e = adj[a] / GEN_NC, i = adj[a] % GEN_NC;
+    double x[GEN_NC][3], u[GEN_NC], B[GEN_NC], gr[GEN_NC][3];
+    int dof[GEN_NC];
+    for (int n = 0; n < nc; n++) {
+      dof[n] = elem_dof[(size_t)e * nloc + n];
+      for (int d = 0; d < dim; d++) x[n][d] = coords[(size_t)dof[n] * dim + d];
+      u[n] = sol ? sol[dof[n]] : 0.0;
+      B[n] = 0.0;
+    }
+    double F = 0.0;
+    for (int g = 0; g < ng; g++) {
+      const double* dp = dphi + (size_t)g * nc * dim;
+      double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Ji[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, det;
+      for (int n = 0; n < nc; n++)
+        for (int p = 0; p < dim; p++)
+          for (int q = 0; q < dim; q++) J[p][q] += dp[n * dim + p] * x[n][q];
+      if (dim == 1) {
+        det = J[0][0];
+        Ji[0][0] = 1 / det;
+      } else if (dim == 2) {
+        det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+        Ji[0][0] = J[1][1] / det;
+        Ji[0][1] = -J[0][1] / det;
+        Ji[1][0] = -J[1][0] / det;
+        Ji[1][1] = J[0][0] / det;
+      } else {
+        det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[1][2] * J[2][0] - J[1][0] * J[2][2]) + J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+        Ji[0][0] = (-J[1][2] * J[2][1] + J[1][1] * J[2][2]) / det;
+        Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+        Ji[0][2] = (-J[0][2] * J[1][1] + J[0][1] * J[1][2]) / det;
+        Ji[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) / det;
+        Ji[1][1] = (-J[0][2] * J[2][0] + J[0][0] * J[2][2]) / det;
+        Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+        Ji[2][0] = (-J[1][1] * J[2][0] + J[1][0] * J[2][1]) / det;
+        Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+        Ji[2][2] = (-J[0][1] * J[1][0] + J[0][0] * J[1][1]) / det;
+      }
+      const double weight = det * w[g];
+      double gu[3] = {0, 0, 0}, xq[4] = {0, 0, 0, 0};
+      for (int n = 0; n < nc; n++) {
+        const double ph = phi[(size_t)g * nc + n];
+        for (int q = 0; q < dim; q++) {
+          double s = 0.0;
+          for (int p = 0; p < dim; p++) s += Ji[q][p] * dp[n * dim + p];
+          gr[n][q] = s;
+          gu[q] += s * u[n];
+          xq[q] += x[n][q] * ph;
+        }
+      }
+      const double f = prog ? scale * fh_expr_device_eval(prog, nprog, pconst, xq) : 0.0;
+      double lap = 0.0;
+      for (int q = 0; q < dim; q++) lap += gr[i][q] * gu[q];
+      F += (f * phi[(size_t)g * nc + i] - lap) * weight;
+      for (int j = 0; j < nc; j++) {
+        double s = 0.0;
+        for (int q = 0; q < dim; q++) s += gr[i][q] * gr[j][q];
+        B[j] += s * weight;
+      }
+    }
+    racc += F;
+    for (int j = 0; j < nc; j++)
+      for (int k = rs; k < re; k++)
+        if (col[k] == dof[j]) {
+          val[k] += B[j];
+          break;
+        }
+  }
+  res[r] = racc;
+}
+
+extern "C" int fh_assemble_poisson_rows(fh_ctx_t ctx, int geom, int fe, int order, int nel, int nloc, const int* elem_dof, int nnode, const double* coords,
+                                        fh_vec_t sol, fh_expr_t source, double scale, fh_mat_t KK, fh_vec_t RES) {
+  FH_GUARD_BEGIN
+  FH_REQUIRE(ctx && elem_dof && coords && KK && RES && nel >= 1 && nnode >= 1, "fh_assemble_poisson_rows: null or empty argument");
+  FH_REQUIRE(geom >= 0 && geom <= 3, "fh_assemble_poisson_rows: geom must be 0 (hex), 1 (quad), 2 (line) or 3 (triangle)");
+  FH_REQUIRE(fe == fhfe::FE_LINEAR || fe == fhfe::FE_SERENDIPITY || fe == fhfe::FE_BIQUADRATIC, "fh_assemble_poisson_rows: fe must be 0, 1 or 2");
+  const int dim = fhfe::dim_of(geom), nc = fhfe::ndofs_of(geom, fe), ndof = KK->m;
+  FH_REQUIRE(nloc >= nc && nc <= GEN_NC, "fh_assemble_poisson_rows: %d nodes per element given, the family has %d", nloc, nc);
+  FH_REQUIRE(KK->n == ndof && RES->n_local >= ndof && (!sol || sol->n_local >= ndof), "fh_assemble_poisson_rows: size mismatch");
+  std::vector<int> cnt(ndof + 1, 0);
+  for (int e = 0; e < nel; e++)
+    for (int n = 0; n < nc; n++) {
+      const int d = elem_dof[(size_t)e * nloc + n];
+      FH_REQUIRE(d >= 0 && d < ndof && d < nnode, "fh_assemble_poisson_rows: element %d, node %d: dof %d outside the system (the classes are numbered one after the other)", e, n, d);
+      cnt[d + 1]++;
+    }
+  for (int d = 0; d < ndof; d++) cnt[d + 1] += cnt[d];
+  std::vector<int> adj(cnt[ndof]), fill(cnt.begin(), cnt.end() - 1);
+  FH_REQUIRE((int64_t)nel * GEN_NC < 2147483647ll, "fh_assemble_poisson_rows: too many elements");
+  for (int e = 0; e < nel; e++)                         // ascending element order per dof
+    for (int n = 0; n < nc; n++) adj[fill[elem_dof[(size_t)e * nloc + n]]++] = e * GEN_NC + n;
+  std::vector<double> w, phi, dphi;
+  FH_REQUIRE(fhfe::shape_tables(geom, fe, order, w, phi, dphi) == 0, "fh_assemble_poisson_rows: unsupported Gauss rule");
+  const int ng = (int)w.size();
+  std::vector<int> code;
+  std::vector<double> consts;
+  if (source) {
+    int nv = 0, ncode = 0, nk = 0;
+    FH_TRY(fh_expr_nvars(source, &nv));
+    FH_REQUIRE(nv <= 4, "fh_assemble_poisson_rows: the source expression has %d variables, at most 4 (x, y, z, t) are served", nv);
+    FH_TRY(fh_expr_program(source, &ncode, &nk, nullptr, nullptr));
+    code.resize(ncode);
+    consts.resize(std::max(nk, 1));
+    FH_TRY(fh_expr_program(source, &ncode, &nk, code.data(), consts.data()));
+  }
+  hipStream_t st = ctx->stream;
+  std::vector<void*> dv;
+  auto up = [&](const void* h, size_t bytes) -> void* {
+    void* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr;
+    dv.push_back(d);
+    if (bytes) hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st);
+    return d;
+  };
+  int* d_ptr = (int*)up(cnt.data(), cnt.size() * sizeof(int));
+  int* d_adj = (int*)up(adj.data(), adj.size() * sizeof(int));
+  int* d_ed = (int*)up(elem_dof, (size_t)nel * nloc * sizeof(int));
+  double* d_x = (double*)up(coords, (size_t)nnode * dim * sizeof(double));
+  double* d_w = (double*)up(w.data(), w.size() * sizeof(double));
+  double* d_phi = (double*)up(phi.data(), phi.size() * sizeof(double));
+  double* d_dphi = (double*)up(dphi.data(), dphi.size() * sizeof(double));
+  int* d_code = source ? (int*)up(code.data(), code.size() * sizeof(int)) : nullptr;
+  double* d_k = source ? (double*)up(consts.data(), consts.size() * sizeof(double)) : nullptr;
+  int rc = 0;
+  if (!d_ptr || !d_adj || !d_ed || !d_x || !d_w || !d_phi || !d_dphi || (source && (!d_code || !d_k))) {
+    fh_set_error("fh_assemble_poisson_rows: out of device memory");
+    rc = 2;
+  } else {
+    hipLaunchKernelGGL(k_poisson_rows_generic, dim3(fh_div_up(ndof, 64)), dim3(64), 0, st, ndof, dim, nc, ng, nloc, d_ptr, d_adj, d_ed, d_x, sol ? sol->d : nullptr, d_w,
+                       d_phi, d_dphi, scale, d_code, (int)code.size(), d_k, KK->d_rowptr, KK->d_col, KK->d_val, RES->d);
+    if (hipGetLastError() != hipSuccess) {
+      fh_set_error("fh_assemble_poisson_rows: launch failed");
+      rc = 2;
+    }
+    KK->val_gen++;
+    KK->at_valid = false;
+  }
+  hipStreamSynchronize(st);
+  for (void* q : dv) hipFree(q);
+  return rc;
+  FH_GUARD_END("fh_assemble_poisson_rows")
+}
