@@ -87,6 +87,7 @@ class Poisson001:
             self.dim = 1 if (self.box[1] == 0 and self.box[2] == 0) else 2 if self.box[2] == 0 else 3
             if self.dim == 2:
                 self.hi = (self.hi[0], self.hi[1], 1.0)         # the box generator ignores z in 2-D
+            self.tri = self.dim == 2 and b.get("elem_type", "Quad9") == "Tri6"            # MeshGeneration.cpp:568-: the box cut into triangles
             if self.dim == 1:
                 assert b.get("elem_type", "Edge3") == "Edge3", "the one-dimensional box is made of EDGE3 elements (MeshGeneration.cpp:90)"
         else:
@@ -153,6 +154,8 @@ class Poisson001:
         ctx = self.ctx
         if self.dim == 1:
             return self.run_line(log)
+        if getattr(self, "tri", False):
+            return self.run_tri(log)
         meshes = [capi.Mesh.box(*self.box, self.lo, self.hi) if self.box is not None else capi.Mesh.read_gambit(self.mesh_file)]
         for _ in range(1, self.nlevels):
             meshes.append(meshes[-1].refine())
@@ -200,6 +203,121 @@ class Poisson001:
             result["files"] = [stem + ".vtu", stem + ".gmv"]
         pb.destroy()
         return result
+
+    # ---- a two-dimensional box of triangles ("elem_type" : "Tri6") ---------------------------------------------------------------------------------
+    def run_tri(self, log=None, smoother=capi.SMOOTH_SOR, omega=1.0):
+        """LinearImplicitSystem::MGsolve on the TRI6 box (TRI7 inside, femus_amd/tri_mesh.py): the Poisson callback through the generic kernel on the finest
+        level (fh_assemble_poisson_rows; all three Lagrange families), Galerkin operators below it, V-cycles under GMRES limited to 4 iterations per linear
+        iteration.  Boundary conditions and source as for the quadrilateral box (same face names and flags)"""
+        from . import tri_mesh
+        ctx = self.ctx
+        levels = [tri_mesh.box(self.box[0], self.box[1], self.lo[:2], self.hi[:2])]
+        for _ in range(1, self.nlevels):
+            levels.append(tri_mesh.refine(*levels[-1][:3]))
+        fam = {"linear": 0, "serendipity": 1, "biquadratic": 2}[self.fe]
+        nc = (3, 6, 7)[fam]
+        ndofs = [own[fam] for (_, _, _, own) in levels]
+        fnodes = [capi.fe_face_nodes("tri", self.fe, f) for f in range(3)]
+        top = self.nlevels - 1
+        ed, xs, ff, _ = levels[top]
+        ndof = ndofs[top]
+        K = self._pattern_from_elements(ed[:, :nc], ndof)
+        SOL, RES, EPS = ctx.vector(ndof), ctx.vector(ndof), ctx.vector(ndof)
+        sol0 = np.zeros(ndof)
+        bdc = []
+        flux_faces, flux_idx, flux_exprs = [], [], []
+        for l, (edl, xl, ffl, _) in enumerate(levels):
+            val = {}
+            for iel, f in zip(*np.nonzero(ffl < -1)):               # elements and faces in order; a later face overwrites an earlier one (GenerateBdc)
+                kind, fn = self.face_bc(int(ffl[iel, f]))
+                nodes = edl[iel, fnodes[f]]
+                if kind == "dirichlet":
+                    for node in nodes:
+                        x4 = np.array([xl[node, 0], xl[node, 1], 0.0, 0.0])
+                        val[int(node)] = fn(x4) if (fn is not None and l == top) else 0.0
+                elif fn is not None and l == top:
+                    if fn not in flux_exprs:
+                        flux_exprs.append(fn)
+                    flux_faces.append(nodes)
+                    flux_idx.append(flux_exprs.index(fn))
+            idx = np.array(sorted(val), dtype=np.int32)
+            bdc.append(idx)
+            if l == top:
+                sol0[idx] = [val[i] for i in idx]
+        P = [None] + [self._prolongator_from_children("tri", levels[l - 1][0], levels[l][0], nc, ndofs[l - 1], ndofs[l]) for l in range(1, self.nlevels)]
+        for l in range(1, self.nlevels):
+            if bdc[l].size:
+                P[l].mat_zero_rows(bdc[l], 0.0)
+            if bdc[l - 1].size:
+                P[l].zero_cols(bdc[l - 1])
+        SOL.upload(sol0)
+        mg = capi.Multigrid(ctx, self.nlevels)
+        A = [None] * self.nlevels
+        A[top] = K
+        history = []
+        its = 0
+        for it in range(self.max_linear + 1):
+            capi.assemble_poisson_rows(ctx, "tri", self.fe, ed, xs, K, RES, sol=SOL, source=self.source, scale=1.0)
+            if flux_faces:
+                capi.assemble_neumann_edges(ctx, self.fe, np.array(flux_faces), np.array(flux_idx), flux_exprs, xs, RES)
+            if bdc[top].size:
+                K.mat_zero_rows(bdc[top], 1.0)
+                RES.set(bdc[top], np.zeros(bdc[top].size))
+            rn = RES.l2_norm()
+            history.append((its, rn))
+            if log:
+                log("linear iteration %d: Linear Res L2norm = %.6e" % (it, rn))
+            if (it > 0 and rn < self.abs_tol) or it == self.max_linear:
+                break
+            for l in range(top, 0, -1):
+                if A[l - 1] is None:
+                    A[l - 1] = capi.Mat.ptap(P[l], A[l])
+                else:
+                    A[l - 1].ptap_numeric(P[l], A[l])
+            for l in range(top):
+                if bdc[l].size:
+                    A[l].mat_zero_rows(bdc[l], 1.0)
+            for l in range(self.nlevels):
+                mg.set_level(l, A[l], P[l], None, smoother, omega, self.npre if l > 0 else 1, self.npost if l > 0 else 0)
+            mg.setup()
+            EPS.zero()
+            its, _ = mg.solve(RES, EPS, outer="gmres" if self.nlevels > 1 else "preonly", rtol=1e-12, atol=1e-20, maxit=4)
+            SOL.add(1.0, EPS)
+        mg.destroy()
+        result = {"solution": SOL.to_numpy(), "coords": xs[:ndof], "history": history, "converged": history[-1][1] < self.abs_tol, "dofs": ndof,
+                  "levels": [(l[0], l[1], l[2]) for l in levels]}
+        for m in A + P:
+            if m is not None:
+                m.destroy()
+        return result
+
+    def _pattern_from_elements(self, ed, ndof):
+        """CSR pattern holding every (i, j) of every element"""
+        nc = ed.shape[1]
+        r = np.repeat(ed, nc, axis=1).ravel().astype(np.int64)
+        c = np.tile(ed, (1, nc)).ravel().astype(np.int64)
+        key = np.unique(r * ndof + c)
+        rows, cols = key // ndof, key % ndof
+        indptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=ndof))])
+        return capi.Mat.from_csr(self.ctx, ndof, ndof, indptr, cols)
+
+    def _prolongator_from_children(self, geom, ed_c, ed_f, nc, ndof_c, ndof_f):
+        """PP of a level from the element prolongator (ElemType.cpp:439-532): fine element nchild e + j is child j of coarse element e; the row of a fine dof
+        holds the coarse shape functions at its place in the father (the same row from every element that shares the dof)"""
+        EP = capi.fe_elem_prolongator(geom, self.fe)
+        nch = EP.shape[0]
+        P = {}
+        for j in range(nch):
+            for n in range(nc):
+                rows = ed_f[j::nch, n]
+                for k in range(nc):
+                    if EP[j, n, k] != 0.0:
+                        for r, c in zip(rows.tolist(), ed_c[:, k].tolist()):
+                            P[(r, c)] = EP[j, n, k]
+        keys = sorted(P)
+        rows = np.array([q[0] for q in keys])
+        indptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=ndof_f))])
+        return capi.Mat.from_csr(self.ctx, ndof_f, ndof_c, indptr, np.array([q[1] for q in keys]), np.array([P[q] for q in keys]))
 
     # ---- the one-dimensional input (input/input1D.json: EDGE3 box) -------------------------------------------------------------------------------
     NU_1D, V_1D = 0.01, 1.0                      # main.cpp:392-395: in one dimension the callback is advection-diffusion with V = 1, nu = 0.01

@@ -806,6 +806,18 @@ def assemble_neumann(ctx, mesh, fe, res, flux_by_flag, order="seventh"):
             _chk(ctx.L.fh_assemble_neumann_faces(ctx.h, GEOM[mesh.geom], FE[fe], GAUSS_ORDER[order], fn.shape[0], _p(fn), _p(tv), xy.shape[0], _p(xy), res.h))
 
 
+def assemble_neumann_edges(ctx, fe, face_nodes, face_expr, exprs, coords, res, order="seventh"):
+    """edge integrals of a parsed flux on explicitly listed EDGES of a two-dimensional mesh of any element shape (triangles: the caller keeps the mesh):
+    face_nodes[nfaces, nfn] in the line element's order (ends, then middle), face_expr[nfaces] an index into exprs; fh_assemble_neumann_faces_expr with the
+    quadrilateral's face geometry (a line)"""
+    fn, fx, xy = _i32(face_nodes), _i32(face_expr), _f64(coords)
+    if fn.shape[0] == 0:
+        return
+    hs = (ctypes.c_void_p * len(exprs))(*[e.h for e in exprs])
+    _chk(ctx.L.fh_assemble_neumann_faces_expr(ctx.h, GEOM["quad"], FE[fe], GAUSS_ORDER[order], fn.shape[0], _p(fn), _p(fx), len(exprs), hs, xy.shape[0], _p(xy),
+                                              res.h))
+
+
 def face_normals(mesh, fe, face_nodes, gauss_point=0, order="seventh", coords=None):
     """unit normals of faces at one face Gauss point as elem_type::JacobianSur returns them (fh_fe_face_normals, host)"""
     L = load_library()

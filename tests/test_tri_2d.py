@@ -108,3 +108,44 @@ def test_generic_kernel_on_tensor_product_elements_matches_their_oracle(ctx, box
     Ad = A.toarray()
     assert np.abs(K.to_scipy().toarray() - Ad).max() <= 1e-12 * np.abs(Ad).max()
     K.destroy()
+
+
+TRI_INPUT = """
+{
+    "multilevel_mesh" : { "first" : { "type" : { "box" : { "nx" : 4, "ny" : 3, "nz" : 0, "xa" : 0., "xb" : 1., "ya" : 0., "yb" : 1., "za" : 0., "zb" : 0.,
+                                                            "elem_type" : "Tri6" } } } },
+    "multilevel_solution" : { "multilevel_mesh" : { "first" : { "variable" : { "first" : {
+              "name" : "T", "fe_order" : "second", "init_func" : "0.", "func_source": "1. + x*y",
+              "boundary_conditions" : [ { "facename" : "left", "bdc_type" : "dirichlet", "bdc_func" : "0.5+1./pi*atan(10.*(y-0.8))" },
+                                        { "facename" : "top", "bdc_type" : "dirichlet", "bdc_func" : "1." },
+                                        { "facename" : "bottom", "bdc_type" : "neumann", "bdc_func" : "0." },
+                                        { "facename" : "right", "bdc_type" : "neumann", "bdc_func" : "0.3*y" } ] } } } } },
+    "multilevel_problem" : { "multilevel_mesh" : { "first" : { "system" : { "poisson" : { "linear_solver" : {
+                "max_number_linear_iteration" : 6, "abs_conv_tol" : 1.e-09,
+                "type" : { "multigrid" : { "nlevels" : 3, "npresmoothing" : 1, "npostsmoothing" : 1, "mgtype" : "V_cycle" } } } } } } } }
+}
+"""
+
+
+@gpu
+@pytest.mark.parametrize("fe_order,fe", [("second", "biquadratic"), ("first", "linear"), ("serendipity", "serendipity")])
+def test_the_application_on_a_box_of_triangles(ctx, fe_order, fe):
+    """applications/001_Poisson with the boundary conditions of its shipped input.json (a parsed Dirichlet profile on "left", 1 on "top", fluxes on the others;
+    the profile softened) on a TRI6 box, three levels: meshes equal to the oracle's (integers; coordinates to rounding), converged under the input's limits,
+    and -- iterated on -- the direct solve of the finest level's problem to 1e-10"""
+    from femus_amd import app_poisson as app
+    cfg = app.load_config(TRI_INPUT)
+    cfg["multilevel_solution"]["multilevel_mesh"]["first"]["variable"]["first"]["fe_order"] = fe_order
+    p = app.Poisson001(ctx, cfg)
+    assert p.tri and p.fe == fe and p.nlevels == 3
+    out = p.run()
+    ref, meshes = ot.solve(4, 3, 3, fe, lambda x: 1. + x[0] * x[1], dirichlet_flags=(-5, -4), flux_by_flag={-3: lambda x: 0.3 * x[1], -2: lambda x: 0.0},
+                           values=lambda x: 0.5 + 1. / np.pi * np.arctan(10. * (x[1] - 0.8)) if x[0] == 0.0 else 1.0)      # the corner: "left" is face 2 of its element, after "top" (face 1)
+    for (ed_p, xs_p, ff_p), (ed_o, xs_o, ff_o, _) in zip(out["levels"], meshes):
+        assert np.array_equal(ed_p, ed_o) and np.array_equal(ff_p, ff_o) and np.abs(xs_p - xs_o).max() < 1e-14
+    assert out["dofs"] == ref.size and out["converged"] and len(out["history"]) <= 7, out["history"]
+    assert np.abs(out["solution"] - ref).max() < 1e-8
+    p.max_linear, p.abs_tol = 40, 1e-13
+    out = p.run()
+    assert out["converged"] and np.abs(out["solution"] - ref).max() < 1e-10
+    p.destroy()
