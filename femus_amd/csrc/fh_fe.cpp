@@ -31,12 +31,18 @@ static const double XC_TRI[7][2] = {{0, 0}, {1, 0}, {0, 1}, {0.5, 0}, {0.5, 0.5}
 static const int TRI_IND[7][2] = {{0, 0}, {2, 0}, {0, 2}, {1, 0}, {1, 1}, {0, 1}, {7, 7}};
 static const int TRI_F2C[4][3] = {{0, 3, 5}, {3, 1, 4}, {5, 4, 2}, {4, 5, 3}};
 static const int TRI_FACE[3][3] = {{0, 1, 3}, {1, 2, 4}, {2, 0, 5}};
+// TET10 (3d/Tetrahedron.cpp:24-100; the four face nodes and the centre of the reference's TET15 are not served): vertices, edge middles; selectors; the eight
+// children (four at the vertices, four out of the inner octahedron); faces = (three vertices, three middles)
+static const double XC_TET[10][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0.5, 0, 0}, {0.5, 0.5, 0}, {0, 0.5, 0}, {0., 0, 0.5}, {0.5, 0., 0.5}, {0, 0.5, 0.5}};
+static const int TET_IND[10][3] = {{0, 0, 0}, {2, 0, 0}, {0, 2, 0}, {0, 0, 2}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {0, 1, 1}};
+static const int TET_F2C[8][4] = {{0, 4, 6, 7}, {4, 1, 5, 8}, {6, 5, 2, 9}, {7, 8, 9, 3}, {5, 6, 4, 7}, {8, 7, 5, 4}, {7, 9, 8, 5}, {9, 5, 7, 6}};
+static const int TET_FACE[4][6] = {{0, 2, 1, 6, 5, 4}, {0, 1, 3, 4, 8, 7}, {1, 2, 3, 5, 9, 8}, {2, 0, 3, 6, 7, 9}};
 
-int dim_of(int geom) { return geom == GEOM_HEX ? 3 : (geom == GEOM_QUAD || geom == GEOM_TRI) ? 2 : 1; }
-int nloc_of(int geom) { return geom == GEOM_HEX ? 27 : geom == GEOM_QUAD ? 9 : geom == GEOM_TRI ? 7 : 3; }
-int nvert_of(int geom) { return geom == GEOM_HEX ? 8 : geom == GEOM_QUAD ? 4 : geom == GEOM_TRI ? 3 : 2; }
-int nedge_end_of(int geom) { return geom == GEOM_HEX ? 20 : geom == GEOM_QUAD ? 8 : geom == GEOM_TRI ? 6 : 2; }
-int nfaces_of(int geom) { return geom == GEOM_HEX ? 6 : geom == GEOM_QUAD ? 4 : geom == GEOM_TRI ? 3 : 2; }
+int dim_of(int geom) { return (geom == GEOM_HEX || geom == GEOM_TET) ? 3 : (geom == GEOM_QUAD || geom == GEOM_TRI) ? 2 : 1; }
+int nloc_of(int geom) { return geom == GEOM_HEX ? 27 : geom == GEOM_QUAD ? 9 : geom == GEOM_TRI ? 7 : geom == GEOM_TET ? 10 : 3; }
+int nvert_of(int geom) { return geom == GEOM_HEX ? 8 : (geom == GEOM_QUAD || geom == GEOM_TET) ? 4 : geom == GEOM_TRI ? 3 : 2; }
+int nedge_end_of(int geom) { return geom == GEOM_HEX ? 20 : geom == GEOM_QUAD ? 8 : geom == GEOM_TRI ? 6 : geom == GEOM_TET ? 10 : 2; }
+int nfaces_of(int geom) { return geom == GEOM_HEX ? 6 : (geom == GEOM_QUAD || geom == GEOM_TET) ? 4 : geom == GEOM_TRI ? 3 : 2; }
 // (on the line the "quadratic" family IS the three-node one: NVE[5] = {2, 3, 3, 1, 2}, GeomElTypeEnum)
 int ndofs_of(int geom, int fe) {
   return fe == FE_LINEAR ? nvert_of(geom) : fe == FE_SERENDIPITY ? (geom == GEOM_LINE ? 3 : nedge_end_of(geom)) : fe == FE_CONSTANT ? 1 : nloc_of(geom);
@@ -44,7 +50,7 @@ int ndofs_of(int geom, int fe) {
 
 int xc(int geom, int node, int d) { return geom == GEOM_HEX ? XC_HEX[node][d] : geom == GEOM_QUAD ? XC_QUAD[node][d] : XC_LINE[node][d]; }
 void node_ref(int geom, int node, double* pt) {
-  for (int k = 0; k < dim_of(geom); k++) pt[k] = geom == GEOM_TRI ? XC_TRI[node][k] : (double)xc(geom, node, k);
+  for (int k = 0; k < dim_of(geom); k++) pt[k] = geom == GEOM_TRI ? XC_TRI[node][k] : geom == GEOM_TET ? XC_TET[node][k] : (double)xc(geom, node, k);
 }
 
 // ---- Gauss-Legendre in extended precision, then the reference's 14-significant-digit rounding -----------
@@ -101,9 +107,71 @@ static const double TRI_G4[3][19] = {
     {0.3333333, 0.4896825, 0.02063496, 0.4896825, 0.4370896, 0.1258208, 0.4370896, 0.1882035, 0.6235929, 0.1882035, 0.04472951, 0.910541, 0.04472951, 0.7411986,
      0.221963, 0.03683841, 0.221963, 0.03683841, 0.7411986}};
 static const double* TRI_G[5] = {TRI_G0[0], TRI_G1[0], TRI_G2[0], TRI_G3[0], TRI_G4[0]};
+// tetrahedron rules (3d/quadrature_Tetrahedron.cpp): 1 / 5 / 15 / 31 / 45 points; weights (the reference tetrahedron has volume 1/6), then x, y, z -- the numbers
+// as the reference's tables hold them
+static const int TET_NG[5] = {1, 5, 15, 31, 45};
+static const double TET_G0[4][1] = {
+    {0.16666666666667},
+    {0.25},
+    {0.25},
+    {0.25}};
+static const double TET_G1[4][5] = {
+    {-0.13333333333333, 0.075, 0.075, 0.075, 0.075},
+    {0.25, 0.5, 0.16666666666667, 0.16666666666667, 0.16666666666667},
+    {0.25, 0.16666666666667, 0.5, 0.16666666666667, 0.16666666666667},
+    {0.25, 0.16666666666667, 0.16666666666667, 0.5, 0.16666666666667}};
+static const double TET_G2[4][15] = {
+    {0.030283678097089, 0.006026785714286, 0.006026785714286, 0.006026785714286, 0.006026785714286, 0.011645249086029, 0.011645249086029, 0.011645249086029, 0.011645249086029, 0.010949141561386,
+     0.010949141561386, 0.010949141561386, 0.010949141561386, 0.010949141561386, 0.010949141561386},
+    {0.25, 0, 0.33333333333333, 0.33333333333333, 0.33333333333333, 0.72727272727273, 0.090909090909091, 0.090909090909091, 0.090909090909091, 0.43344984642634,
+     0.43344984642634, 0.43344984642634, 0.066550153573664, 0.066550153573664, 0.066550153573664},
+    {0.25, 0.33333333333333, 0, 0.33333333333333, 0.33333333333333, 0.090909090909091, 0.72727272727273, 0.090909090909091, 0.090909090909091, 0.43344984642634,
+     0.066550153573664, 0.066550153573664, 0.43344984642634, 0.43344984642634, 0.066550153573664},
+    {0.25, 0.33333333333333, 0.33333333333333, 0, 0.33333333333333, 0.090909090909091, 0.090909090909091, 0.72727272727273, 0.090909090909091, 0.066550153573664,
+     0.43344984642634, 0.066550153573664, 0.43344984642634, 0.066550153573664, 0.43344984642634}};
+static const double TET_G3[4][31] = {
+    {0.01826422, 0.01059994, 0.01059994, 0.01059994, 0.01059994, -0.06251774, -0.06251774, -0.06251774, -0.06251774, 0.004891425,
+     0.004891425, 0.004891425, 0.004891425, 0.0009700176, 0.0009700176, 0.0009700176, 0.0009700176, 0.0009700176, 0.0009700176, 0.02755732,
+     0.02755732, 0.02755732, 0.02755732, 0.02755732, 0.02755732, 0.02755732, 0.02755732, 0.02755732, 0.02755732, 0.02755732,
+     0.02755732},
+    {0.25, 0.7653604, 0.07821319, 0.07821319, 0.07821319, 0.6344704, 0.1218432, 0.1218432, 0.1218432, 0.002382507,
+     0.3325392, 0.3325392, 0.3325392, 0, 0, 0, 0.5, 0.5, 0.5, 0.6,
+     0.6, 0.6, 0.2, 0.2, 0.2, 0.1, 0.1, 0.1, 0.1, 0.1,
+     0.1},
+    {0.25, 0.07821319, 0.7653604, 0.07821319, 0.07821319, 0.1218432, 0.6344704, 0.1218432, 0.1218432, 0.3325392,
+     0.002382507, 0.3325392, 0.3325392, 0, 0.5, 0.5, 0, 0, 0.5, 0.2,
+     0.1, 0.1, 0.6, 0.1, 0.1, 0.6, 0.6, 0.2, 0.2, 0.1,
+     0.1},
+    {0.25, 0.07821319, 0.07821319, 0.7653604, 0.07821319, 0.1218432, 0.1218432, 0.6344704, 0.1218432, 0.3325392,
+     0.3325392, 0.002382507, 0.3325392, 0.5, 0, 0.5, 0, 0.5, 0, 0.1,
+     0.2, 0.1, 0.1, 0.6, 0.1, 0.2, 0.1, 0.6, 0.1, 0.6,
+     0.2}};
+static const double TET_G4[4][45] = {
+    {-0.03932701, 0.004081316, 0.004081316, 0.004081316, 0.004081316, 0.0006580868, 0.0006580868, 0.0006580868, 0.0006580868, 0.004384259,
+     0.004384259, 0.004384259, 0.004384259, 0.004384259, 0.004384259, 0.01383006, 0.01383006, 0.01383006, 0.01383006, 0.01383006,
+     0.01383006, 0.004240437, 0.004240437, 0.004240437, 0.004240437, 0.004240437, 0.004240437, 0.004240437, 0.004240437, 0.004240437,
+     0.004240437, 0.004240437, 0.004240437, 0.00223874, 0.00223874, 0.00223874, 0.00223874, 0.00223874, 0.00223874, 0.00223874,
+     0.00223874, 0.00223874, 0.00223874, 0.00223874, 0.00223874},
+    {0.25, 0.6175872, 0.1274709, 0.1274709, 0.1274709, 0.9037635, 0.03207883, 0.03207883, 0.03207883, 0.4502229,
+     0.4502229, 0.4502229, 0.0497771, 0.0497771, 0.0497771, 0.3162696, 0.3162696, 0.3162696, 0.1837304, 0.1837304,
+     0.1837304, 0.51328, 0.51328, 0.51328, 0.02291779, 0.02291779, 0.02291779, 0.2319011, 0.2319011, 0.2319011,
+     0.2319011, 0.2319011, 0.2319011, 0.1937465, 0.1937465, 0.1937465, 0.7303134, 0.7303134, 0.7303134, 0.03797005,
+     0.03797005, 0.03797005, 0.03797005, 0.03797005, 0.03797005},
+    {0.25, 0.1274709, 0.6175872, 0.1274709, 0.1274709, 0.03207883, 0.9037635, 0.03207883, 0.03207883, 0.4502229,
+     0.0497771, 0.0497771, 0.4502229, 0.4502229, 0.0497771, 0.3162696, 0.1837304, 0.1837304, 0.3162696, 0.3162696,
+     0.1837304, 0.02291779, 0.2319011, 0.2319011, 0.51328, 0.2319011, 0.2319011, 0.51328, 0.51328, 0.02291779,
+     0.02291779, 0.2319011, 0.2319011, 0.7303134, 0.03797005, 0.03797005, 0.1937465, 0.03797005, 0.03797005, 0.1937465,
+     0.1937465, 0.7303134, 0.7303134, 0.03797005, 0.03797005},
+    {0.25, 0.1274709, 0.1274709, 0.6175872, 0.1274709, 0.03207883, 0.03207883, 0.9037635, 0.03207883, 0.0497771,
+     0.4502229, 0.0497771, 0.4502229, 0.0497771, 0.4502229, 0.1837304, 0.3162696, 0.1837304, 0.3162696, 0.1837304,
+     0.3162696, 0.2319011, 0.02291779, 0.2319011, 0.2319011, 0.51328, 0.2319011, 0.02291779, 0.2319011, 0.51328,
+     0.2319011, 0.51328, 0.02291779, 0.03797005, 0.7303134, 0.03797005, 0.03797005, 0.1937465, 0.03797005, 0.7303134,
+     0.03797005, 0.1937465, 0.03797005, 0.1937465, 0.7303134}};
+static const double* TET_G[5] = {TET_G0[0], TET_G1[0], TET_G2[0], TET_G3[0], TET_G4[0]};
 
 int gauss_npoints(int geom, int order) {
   if (geom == GEOM_TRI) return TRI_NG[order];
+  if (geom == GEOM_TET) return TET_NG[order];
   int n = order + 1, d = (geom == GEOM_LINE) ? 1 : dim_of(geom), r = 1;
   for (int k = 0; k < d; k++) r *= n;
   return r;
@@ -112,6 +180,15 @@ int gauss_npoints(int geom, int order) {
 // w[ng], x[d*ng + ig]; first coordinate slowest, as the reference tables
 int gauss_table(int geom, int order, double* w, double* x) {
   if (order < 0 || order > 4) return 1;
+  if (geom == GEOM_TET) {
+    const int ng = TET_NG[order];
+    for (int ig = 0; ig < ng; ig++) {
+      if (w) w[ig] = TET_G[order][ig];
+      if (x)
+        for (int k = 0; k < 3; k++) x[k * ng + ig] = TET_G[order][(k + 1) * ng + ig];
+    }
+    return 0;
+  }
   if (geom == GEOM_TRI) {
     const int ng = TRI_NG[order];
     for (int ig = 0; ig < ng; ig++) {
@@ -201,6 +278,46 @@ static void tri_node(int fe, int i, int j, double x, double y, double out[6]) {
   }
 }
 
+// Tetrahedron families (3d/Tetrahedron.cpp: TetLinear, TetQuadratic), selected by the (i, j, k) triple of the node; the terms in the reference's order.
+// out: phi, d/dx, d/dy, d/dz, then xx, yy, zz, xy, yz, zx (the second derivatives of P2 are the constants 4, -8, -4 of its barycentric products)
+static void tet_node(int fe, int i, int j, int k, double x, double y, double z, double out[10]) {
+  for (int q = 0; q < 10; q++) out[q] = 0.0;
+  if (fe == FE_LINEAR) {
+    out[0] = (!i * !j * !k) * (1. - x - y - z) + !(i - 2) * x + !(j - 2) * y + !(k - 2) * z;
+    out[1] = -(!i * !j * !k) + !(i - 2);
+    out[2] = -(!i * !j * !k) + !(j - 2);
+    out[3] = -(!i * !j * !k) + !(k - 2);
+    return;
+  }
+  const double t = 1. - (x + y + z);
+  out[0] = !i * (!j * (!k * t * (2. * t - 1.) + !(k - 1) * 4. * z * t + !(k - 2) * (-z + 2. * z * z)) + !(j - 1) * (!k * 4. * y * t + !(k - 1) * 4. * y * z) +
+                 !(j - 2) * (!k * (-y + 2. * y * y))) +
+           !(i - 1) * (!j * (!k * 4. * x * t + !(k - 1) * 4. * x * z) + !(j - 1) * (!k * 4. * x * y)) + !(i - 2) * (!j * (!k * (-x + 2. * x * x)));
+  out[1] = !i * (!j * (!k * (-4. * t + 1.) + !(k - 1) * (-4.) * z) + !(j - 1) * (!k * (-4.) * y)) +
+           !(i - 1) * (!j * (!k * 4. * (t - x) + !(k - 1) * 4. * z) + !(j - 1) * (!k * 4. * y)) + !(i - 2) * (!j * (!k * (-1. + 4. * x)));
+  out[2] = !i * (!j * (!k * (-4. * t + 1.) + !(k - 1) * (-4.) * z) + !(j - 1) * (!k * 4. * (t - y) + !(k - 1) * 4. * z) + !(j - 2) * (!k * (-1. + 4. * y))) +
+           !(i - 1) * (!j * (!k * (-4.) * x) + !(j - 1) * (!k * 4. * x));
+  out[3] = !i * (!j * (!k * (-4. * t + 1.) + !(k - 1) * 4. * (t - z) + !(k - 2) * (-1 + 4. * z)) + !(j - 1) * (!k * (-4.) * y + !(k - 1) * 4. * y)) +
+           !(i - 1) * (!j * (!k * (-4.) * x + !(k - 1) * 4. * x));
+  // Hessian of P2: node (i, j, k) -> barycentric pair; phi = L_a (2 L_a - 1) at a vertex, 4 L_a L_b on an edge; L_0 = t has gradient (-1, -1, -1), L_m the unit vector e_m
+  int a = -1, b = -1;                                   // barycentric indices 0 (t), 1 (x), 2 (y), 3 (z) of the node's one or two factors
+  const int idx[3] = {i, j, k};
+  for (int m = 0; m < 3; m++)
+    if (idx[m] == 2) a = b = m + 1;
+  if (a < 0) {
+    for (int m = 0; m < 3; m++)
+      if (idx[m] == 1) (a < 0 ? a : b) = m + 1;
+    if (a < 0) a = b = 0;                               // (0, 0, 0): the vertex at the origin
+    else if (b < 0) b = 0;                              // one index 1: the edge towards the origin
+  }
+  auto g = [](int L, int d) { return L == 0 ? -1.0 : (L == d + 1 ? 1.0 : 0.0); };
+  const int pr[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {1, 2}, {2, 0}};
+  for (int q = 0; q < 6; q++) {
+    const int p = pr[q][0], r = pr[q][1];
+    out[4 + q] = (a == b) ? 4.0 * g(a, p) * g(a, r) : 4.0 * (g(a, p) * g(b, r) + g(b, p) * g(a, r));
+  }
+}
+
 // Serendipity bases, the expressions of QuadQuadratic / HexQuadratic term by term and in their order (the tables are compared bit for bit with the ones the
 // reference's compiled classes give): a vertex function is the product of the three (two) linear factors times (-2 + ix x + jx y + kx z) ((-1 + ...) in 2-D),
 // an edge function the plain product.  out: phi, d/dx, d/dy, d/dz, then xx, yy, zz, xy, yz, zx (2-D: phi, dx, dy, -, xx, yy, -, xy)
@@ -269,6 +386,14 @@ void eval_basis_d2(int geom, int fe, const double* pt, double* d2phi) {
     for (int k = 0; k < (d == 1 ? 1 : d == 2 ? 3 : 6); k++) d2phi[k] = 0.0;
     return;
   }
+  if (geom == GEOM_TET) {        // (xx, yy, zz, xy, yz, zx)
+    for (int j = 0; j < nc; j++) {
+      double v[10];
+      tet_node(fe, TET_IND[j][0], TET_IND[j][1], TET_IND[j][2], pt[0], pt[1], pt[2], v);
+      for (int q = 0; q < 6; q++) d2phi[j * 6 + q] = v[4 + q];
+    }
+    return;
+  }
   if (geom == GEOM_TRI) {        // (xx, yy, xy)
     for (int j = 0; j < nc; j++) {
       double v[6];
@@ -318,6 +443,16 @@ void eval_basis_d2(int geom, int fe, const double* pt, double* d2phi) {
 
 void eval_basis(int geom, int fe, const double* pt, double* phi, double* dphi /* [nc*dim] node-major */) {
   const int d = dim_of(geom), nc = ndofs_of(geom, fe);
+  if (geom == GEOM_TET && fe != FE_CONSTANT) {
+    for (int j = 0; j < nc; j++) {
+      double v[10];
+      tet_node(fe, TET_IND[j][0], TET_IND[j][1], TET_IND[j][2], pt[0], pt[1], pt[2], v);
+      if (phi) phi[j] = v[0];
+      if (dphi)
+        for (int q = 0; q < 3; q++) dphi[j * 3 + q] = v[1 + q];
+    }
+    return;
+  }
   if (geom == GEOM_TRI && fe != FE_CONSTANT) {
     for (int j = 0; j < nc; j++) {
       double v[6];
@@ -390,6 +525,14 @@ int shape_tables(int geom, int fe, int order, std::vector<double>& w, std::vecto
 
 // child j = sub-element at coarse vertex j; local node i of child j sits at (Xc[j] + Xc[i]) / 2
 void child_node_ref(int geom, int child, int node, double* pt) {
+  if (geom == GEOM_TET) {       // the child's reference tetrahedron mapped affinely onto its four vertices in the father
+    const double* v0 = XC_TET[TET_F2C[child][0]];
+    for (int k = 0; k < 3; k++) {
+      pt[k] = v0[k];
+      for (int m = 0; m < 3; m++) pt[k] += (XC_TET[TET_F2C[child][m + 1]][k] - v0[k]) * XC_TET[node][m];
+    }
+    return;
+  }
   if (geom == GEOM_TRI) {       // the child's reference triangle mapped affinely onto its three vertices in the father (the fourth child is the rotated middle one)
     const double* v0 = XC_TRI[TRI_F2C[child][0]];
     const double* v1 = XC_TRI[TRI_F2C[child][1]];
@@ -402,6 +545,7 @@ void child_node_ref(int geom, int child, int node, double* pt) {
 
 int fine2coarse_vertex(int geom, int child, int v) {
   if (geom == GEOM_TRI) return TRI_F2C[child][v];
+  if (geom == GEOM_TET) return TET_F2C[child][v];
   double pt[3];
   child_node_ref(geom, child, v, pt);
   for (int n = 0; n < nloc_of(geom); n++) {
@@ -413,7 +557,7 @@ int fine2coarse_vertex(int geom, int child, int v) {
 }
 
 void elem_prolongator(int geom, int fe, std::vector<double>& P) {
-  const int nch = geom == GEOM_TRI ? 4 : nvert_of(geom), nc = ndofs_of(geom, fe);
+  const int nch = geom == GEOM_TRI ? 4 : geom == GEOM_TET ? 8 : nvert_of(geom), nc = ndofs_of(geom, fe);
   P.assign((size_t)nch * nc * nc, 0.0);
   std::vector<double> phi(nc);
   for (int j = 0; j < nch; j++)
@@ -426,6 +570,11 @@ void elem_prolongator(int geom, int fe, std::vector<double>& P) {
 }
 
 int face_nodes(int geom, int fe, int face, int* out) {
+  if (geom == GEOM_TET) {         // triangles: the three vertices, then the three middles (tet_lag faceDofs; TRI6 order)
+    const int n = fe == FE_CONSTANT ? 0 : fe == FE_LINEAR ? 3 : 6;
+    for (int k = 0; k < n; k++) out[k] = TET_FACE[face][k];
+    return n;
+  }
   if (geom == GEOM_TRI) {         // edges: the two ends, then the middle (tri_lag faceDofs)
     const int n = fe == FE_CONSTANT ? 0 : fe == FE_LINEAR ? 2 : 3;
     for (int k = 0; k < n; k++) out[k] = TRI_FACE[face][k];
@@ -481,7 +630,7 @@ int face_nodes(int geom, int fe, int face, int* out) {
 #include "fh_internal.h"
 
 extern "C" int fh_fe_gauss(int geom, int order, int* ng, double* w, double* x) {
-  FH_REQUIRE(geom >= 0 && geom <= 3, "fh_fe_gauss: geom must be 0 (hex), 1 (quad), 2 (line) or 3 (triangle)");
+  FH_REQUIRE(geom >= 0 && geom <= 4, "fh_fe_gauss: geom must be 0 (hex), 1 (quad), 2 (line), 3 (triangle) or 4 (tetrahedron)");
   FH_REQUIRE(order >= 0 && order <= 4, "fh_fe_gauss: Gauss rule index %d not supported (0..4)", order);
   if (ng) *ng = fhfe::gauss_npoints(geom, order);
   if (w || x) fhfe::gauss_table(geom, order, w, x);
@@ -489,7 +638,8 @@ extern "C" int fh_fe_gauss(int geom, int order, int* ng, double* w, double* x) {
 }
 
 extern "C" int fh_fe_tables(int geom, int fe, int order, int* ng, int* nc, double* phi, double* dphi) {
-  FH_REQUIRE(geom >= 0 && geom <= 3, "fh_fe_tables: geom must be 0 (hex), 1 (quad), 2 (line) or 3 (triangle)");
+  FH_REQUIRE(geom >= 0 && geom <= 4, "fh_fe_tables: geom must be 0 (hex), 1 (quad), 2 (line), 3 (triangle) or 4 (tetrahedron)");
+  FH_REQUIRE(geom != 4 || fe <= 1, "fh_fe_tables: on the tetrahedron the families 0 (P1) and 1 (P2, TET10) are served, not the P2 + bubble one (TET15)");
   FH_REQUIRE(fhfe::fe_known(fe), "fh_fe_tables: fe must be 0 (linear), 1 (serendipity), 2 (biquadratic) or 3 (piecewise constant)");
   FH_REQUIRE(order >= 0 && order <= 4, "fh_fe_tables: Gauss rule index %d not supported (0..4)", order);
   const int d = fhfe::dim_of(geom), n = fhfe::ndofs_of(geom, fe), g = fhfe::gauss_npoints(geom, order);
@@ -508,7 +658,8 @@ extern "C" int fh_fe_tables(int geom, int fe, int order, int* ng, int* nc, doubl
 }
 
 extern "C" int fh_fe_tables_d2(int geom, int fe, int order, double* d2phi) {
-  FH_REQUIRE(geom >= 0 && geom <= 3, "fh_fe_tables_d2: geom must be 0 (hex), 1 (quad), 2 (line) or 3 (triangle)");
+  FH_REQUIRE(geom >= 0 && geom <= 4, "fh_fe_tables_d2: geom must be 0 (hex), 1 (quad), 2 (line), 3 (triangle) or 4 (tetrahedron)");
+  FH_REQUIRE(geom != 4 || fe <= 1, "fh_fe_tables_d2: on the tetrahedron the families 0 (P1) and 1 (P2, TET10) are served, not the P2 + bubble one (TET15)");
   FH_REQUIRE(fhfe::fe_known(fe), "fh_fe_tables_d2: fe must be 0 (linear), 1 (serendipity), 2 (biquadratic) or 3 (piecewise constant)");
   FH_REQUIRE(order >= 0 && order <= 4 && d2phi, "fh_fe_tables_d2: bad arguments");
   const int d = fhfe::dim_of(geom), n = fhfe::ndofs_of(geom, fe), g = fhfe::gauss_npoints(geom, order), nh = d == 1 ? 1 : d == 2 ? 3 : 6;
@@ -525,9 +676,10 @@ extern "C" int fh_fe_tables_d2(int geom, int fe, int order, double* d2phi) {
 }
 
 extern "C" int fh_fe_elem_prolongator(int geom, int fe, int* nchild, int* nc, double* P) {
-  FH_REQUIRE(geom >= 0 && geom <= 3, "fh_fe_elem_prolongator: geom must be 0 (hex), 1 (quad), 2 (line) or 3 (triangle)");
+  FH_REQUIRE(geom >= 0 && geom <= 4, "fh_fe_elem_prolongator: geom must be 0 (hex), 1 (quad), 2 (line), 3 (triangle) or 4 (tetrahedron)");
+  FH_REQUIRE(geom != 4 || fe <= 1, "fh_fe_elem_prolongator: on the tetrahedron the families 0 (P1) and 1 (P2, TET10) are served, not the P2 + bubble one (TET15)");
   FH_REQUIRE(fhfe::fe_known(fe), "fh_fe_elem_prolongator: fe must be 0 (linear), 1 (serendipity), 2 (biquadratic) or 3 (piecewise constant)");
-  if (nchild) *nchild = geom == fhfe::GEOM_TRI ? 4 : fhfe::nvert_of(geom);
+  if (nchild) *nchild = geom == fhfe::GEOM_TRI ? 4 : geom == fhfe::GEOM_TET ? 8 : fhfe::nvert_of(geom);
   if (nc) *nc = fhfe::ndofs_of(geom, fe);
   if (P) {
     std::vector<double> v;
@@ -547,14 +699,15 @@ extern "C" int fh_fe_node_ref(int geom, int node, int* xi) {
 
 // reference coordinates of a local node as doubles (any element: the triangle's are 0, 1/2, 1, 1/3)
 extern "C" int fh_fe_node_ref_coords(int geom, int node, double* xi) {
-  FH_REQUIRE(geom >= 0 && geom <= 3 && xi, "fh_fe_node_ref_coords: bad arguments");
+  FH_REQUIRE(geom >= 0 && geom <= 4 && xi, "fh_fe_node_ref_coords: bad arguments");
   FH_REQUIRE(node >= 0 && node < fhfe::nloc_of(geom), "fh_fe_node_ref_coords: node %d out of range", node);
   fhfe::node_ref(geom, node, xi);
   return 0;
 }
 
 extern "C" int fh_fe_face_nodes(int geom, int fe, int face, int* nfn, int* local_nodes) {
-  FH_REQUIRE(geom >= 0 && geom <= 3, "fh_fe_face_nodes: geom must be 0 (hex), 1 (quad), 2 (line) or 3 (triangle)");
+  FH_REQUIRE(geom >= 0 && geom <= 4, "fh_fe_face_nodes: geom must be 0 (hex), 1 (quad), 2 (line), 3 (triangle) or 4 (tetrahedron)");
+  FH_REQUIRE(geom != 4 || fe <= 1, "fh_fe_face_nodes: on the tetrahedron the families 0 (P1) and 1 (P2, TET10) are served, not the P2 + bubble one (TET15)");
   FH_REQUIRE(fhfe::fe_known(fe), "fh_fe_face_nodes: fe must be 0 .. 3");
   FH_REQUIRE(face >= 0 && face < fhfe::nfaces_of(geom), "fh_fe_face_nodes: face %d out of range", face);
   int tmp[9];

@@ -12,6 +12,7 @@
 #include "Hexahedron.hpp"
 #include "Quadrilateral.hpp"
 #include "Triangle.hpp"
+#include "Tetrahedron.hpp"
 #include "Edge.hpp"
 #include "GeomElemBase.hpp"
 #include <cstring>
@@ -34,6 +35,10 @@ static basis* make_basis(const char* geom, const char* fe) {
     if (!strcmp(fe, "biquadratic")) return new QuadBiquadratic();
     if (!strcmp(fe, "constant")) return new quad0();
     if (!strcmp(fe, "pwlinear")) return new quadpwLinear();
+  } else if (!strcmp(geom, "tet")) {
+    if (!strcmp(fe, "linear")) return new TetLinear();
+    if (!strcmp(fe, "quadratic")) return new TetQuadratic();
+    if (!strcmp(fe, "biquadratic")) return new TetBiquadratic();
   } else if (!strcmp(geom, "tri")) {
     if (!strcmp(fe, "linear")) return new TriLinear();
     if (!strcmp(fe, "quadratic")) return new TriQuadratic();

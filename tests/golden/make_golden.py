@@ -129,6 +129,44 @@ out["ind_tri"] = indt
 out["f2c_tri"] = np.array([[L.ref_fine2coarse_vertex(b"tri", b"linear", j, v) for v in range(3)] for j in range(4)])
 out["facedofs_tri"] = np.array([[L.ref_face_dof(b"tri", b"biquadratic", f, k) for k in range(3)] for f in range(3)])
 
+# TET10 (round 6): the tetrahedron's Gauss rules, TetLinear / TetQuadratic at the 'seventh' points and at sample points (all ten derivatives slots), node table,
+# selectors, children, face nodes (the first six of faceDofs: TRI6 order)
+for order in ORDERS:
+    ng = L.ref_gauss(b"tet", order.encode(), 3, None, None)
+    w = np.zeros(ng)
+    x = np.zeros((3, ng))
+    L.ref_gauss(b"tet", order.encode(), 3, w.ctypes.data_as(ctypes.c_void_p), x.ctypes.data_as(ctypes.c_void_p))
+    out["gauss_w_tet_%s" % order] = w
+    out["gauss_x_tet_%s" % order] = x.T.copy()
+sample_q = rng.uniform(0, 0.3, (7, 3))
+out["sample_pts_tet"] = sample_q
+for fe in ("linear", "serendipity"):
+    rfe = REFNAME.get(fe, fe)
+    nc = L.ref_ndofs(b"tet", rfe.encode())
+    for tag, pts in (("gauss7", out["gauss_x_tet_seventh"]), ("sample", sample_q)):
+        vals = np.zeros((10, pts.shape[0], nc))
+        for p in range(pts.shape[0]):
+            pt = (ctypes.c_double * 3)(*[float(v) for v in pts[p]])
+            for j in range(nc):
+                for which in range(10):
+                    if fe == "linear" and which >= 4:
+                        continue
+                    vals[which, p, j] = L.ref_eval(b"tet", rfe.encode(), which, j, pt)
+        out["basis_tet_%s_%s" % (fe, tag)] = vals
+xcq = np.zeros((10, 3))
+indq = np.zeros((10, 3), dtype=np.int64)
+for i in range(10):
+    b = (ctypes.c_double * 3)()
+    L.ref_xcoarse(b"tet", b"quadratic", i, 3, b)
+    xcq[i] = list(b)
+    ii = (ctypes.c_int * 3)()
+    L.ref_ind(b"tet", b"quadratic", i, 3, ii)
+    indq[i] = list(ii)
+out["xc_tet"] = xcq
+out["ind_tet"] = indq
+out["f2c_tet"] = np.array([[L.ref_fine2coarse_vertex(b"tet", b"linear", j, v) for v in range(4)] for j in range(8)])
+out["facedofs_tet"] = np.array([[L.ref_face_dof(b"tet", b"quadratic", f, k) for k in range(6)] for f in range(4)])
+
 # element prolongator as elem_type forms it.  ElemType.cpp itself needs boost and is not compiled, so its two loops are followed
 # here on top of the COMPILED basis classes (every number below comes out of a call into the reference's object code):
 #   (1) set_fine_coordinates_in_Basis_object (ElemType.cpp:404-432): fine node i = (child, vertex) = KVERT_IND[i] of the linear

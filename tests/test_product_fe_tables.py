@@ -100,6 +100,42 @@ def test_product_triangle_tables_bit_exact(fe):
         assert np.allclose(P[j].sum(axis=1), 1.0, atol=1e-14)     # partition of unity at every child node
 
 
+@pytest.mark.parametrize("order", ORDERS)
+def test_product_tetrahedron_gauss_tables_bit_exact(order):
+    """3d/quadrature_Tetrahedron.cpp: the five rules (1 / 5 / 15 / 31 / 45 points)"""
+    w, x = capi.fe_gauss("tet", order)
+    assert np.array_equal(w, G["gauss_w_tet_%s" % order]) and np.array_equal(x, G["gauss_x_tet_%s" % order])
+
+
+@pytest.mark.parametrize("fe", ["linear", "serendipity"])
+def test_product_tetrahedron_tables_bit_exact(fe):
+    """TET10 (round 6): TetLinear / TetQuadratic (3d/Tetrahedron.cpp) at the 'seventh' points: phi, the three first and the six second derivatives against the
+    reference's compiled classes; children, face nodes, element prolongator; the P2 + bubble family (TET15) is refused"""
+    ref = G["basis_tet_%s_gauss7" % fe]
+    phi, dphi = capi.fe_tables("tet", fe, "seventh")
+    d2 = capi.fe_tables_d2("tet", fe, "seventh")
+    assert np.array_equal(phi, ref[0])
+    for d in range(3):
+        assert np.array_equal(dphi[:, :, d], ref[1 + d])
+    for k in range(6):
+        assert np.array_equal(d2[:, :, k], ref[4 + k])
+    nfn = 3 if fe == "linear" else 6
+    assert [capi.fe_face_nodes("tet", fe, f).tolist() for f in range(4)] == [G["facedofs_tet"][f][:nfn].tolist() for f in range(4)]
+    P = capi.fe_elem_prolongator("tet", fe)
+    nc = phi.shape[1]
+    assert P.shape == (8, nc, nc)
+    f2c = G["f2c_tet"]
+    for j in range(8):
+        for i in range(4):
+            if f2c[j][i] < nc:
+                e = np.zeros(nc)
+                e[f2c[j][i]] = 1.0
+                assert np.allclose(P[j, i], e, atol=1e-14)
+        assert np.allclose(P[j].sum(axis=1), 1.0, atol=1e-14)
+    with pytest.raises(capi.FemusHipError):
+        capi.fe_tables("tet", "biquadratic", "seventh")
+
+
 def _rows_by_kvert(geom, fe, P):
     """rows of a [child][local node][coarse] element prolongator in the reference's fine-node order KVERT_IND (Hexahedron.cpp:49-71)"""
     kv = G["kvert_ind_%s_%s" % (geom, fe)]
