@@ -75,9 +75,13 @@ class Poisson001:
         self.mesh_file = None
         if "filename" in mesh_type:
             self.mesh_file = os.path.join(base_dir, mesh_type["filename"]) if base_dir else mesh_type["filename"]
-            probe = capi.Mesh.read_gambit(self.mesh_file)
-            self.dim = probe.dim
-            probe.destroy()
+            self.tet = self._gambit_is_tet10(self.mesh_file)               # cube_Tet.neu of input3D_Tet_*.json: served by the host-side tetrahedral mesh code
+            if self.tet:
+                self.dim = 3
+            else:
+                probe = capi.Mesh.read_gambit(self.mesh_file)
+                self.dim = probe.dim
+                probe.destroy()
             self.box = None
         elif "box" in mesh_type:
             b = mesh_type["box"]
@@ -156,6 +160,8 @@ class Poisson001:
             return self.run_line(log)
         if getattr(self, "tri", False):
             return self.run_tri(log)
+        if getattr(self, "tet", False):
+            return self.run_tet(log)
         meshes = [capi.Mesh.box(*self.box, self.lo, self.hi) if self.box is not None else capi.Mesh.read_gambit(self.mesh_file)]
         for _ in range(1, self.nlevels):
             meshes.append(meshes[-1].refine())
@@ -206,18 +212,44 @@ class Poisson001:
 
     # ---- a two-dimensional box of triangles ("elem_type" : "Tri6") ---------------------------------------------------------------------------------
     def run_tri(self, log=None, smoother=capi.SMOOTH_SOR, omega=1.0):
-        """LinearImplicitSystem::MGsolve on the TRI6 box (TRI7 inside, femus_amd/tri_mesh.py): the Poisson callback through the generic kernel on the finest
-        level (fh_assemble_poisson_rows; all three Lagrange families), Galerkin operators below it, V-cycles under GMRES limited to 4 iterations per linear
-        iteration.  Boundary conditions and source as for the quadrilateral box (same face names and flags)"""
+        """a TRI6 box (TRI7 inside, femus_amd/tri_mesh.py): all three Lagrange families; boundary conditions and source as for the quadrilateral box"""
         from . import tri_mesh
-        ctx = self.ctx
         levels = [tri_mesh.box(self.box[0], self.box[1], self.lo[:2], self.hi[:2])]
         for _ in range(1, self.nlevels):
             levels.append(tri_mesh.refine(*levels[-1][:3]))
         fam = {"linear": 0, "serendipity": 1, "biquadratic": 2}[self.fe]
-        nc = (3, 6, 7)[fam]
-        ndofs = [own[fam] for (_, _, _, own) in levels]
-        fnodes = [capi.fe_face_nodes("tri", self.fe, f) for f in range(3)]
+        return self._run_simplex("tri", levels, (3, 6, 7)[fam], [own[fam] for (_, _, _, own) in levels], log, smoother, omega)
+
+    @staticmethod
+    def _gambit_is_tet10(path):
+        """the first element of the file's ELEMENTS/CELLS section: Gambit type 6 with 10 nodes"""
+        with open(path) as f:
+            tok = f.read().split()
+        if "ELEMENTS/CELLS" not in tok:
+            return False
+        p = tok.index("ELEMENTS/CELLS") + 2
+        return tok[p + 1] == "6" and tok[p + 2] == "10"
+
+    def run_tet(self, log=None, smoother=capi.SMOOTH_SOR, omega=1.0):
+        """a Gambit mesh of TET10 elements (input3D_Tet_first / _serendipity.json with input/cube_Tet.neu; femus_amd/tet_mesh.py): P1 and P2; the boundary
+        conditions of the application's SetBoundaryCondition (Dirichlet 0, flux 0.2 on face name 3)"""
+        from . import tet_mesh
+        if self.fe == "biquadratic":
+            raise NotImplementedError("tetrahedra are served with \"fe_order\" first and serendipity (P1, P2); FEMuS's TET15 family (face nodes and centre) is not built")
+        levels = [tet_mesh.read_gambit(self.mesh_file)]
+        for _ in range(1, self.nlevels):
+            levels.append(tet_mesh.refine(*levels[-1][:3]))
+        fam = {"linear": 0, "serendipity": 1}[self.fe]
+        return self._run_simplex("tet", levels, (4, 10)[fam], [own[fam] for (_, _, _, own) in levels], log, smoother, omega)
+
+    def _run_simplex(self, geom, levels, nc, ndofs, log, smoother, omega):
+        """LinearImplicitSystem::MGsolve on meshes this module keeps (triangles, tetrahedra): the Poisson callback through the generic kernel on the finest
+        level (fh_assemble_poisson_rows), transfers from the element prolongator, Galerkin operators below, V-cycles under GMRES limited to 4 iterations per
+        linear iteration"""
+        ctx = self.ctx
+        dim = 2 if geom == "tri" else 3
+        nf = 3 if geom == "tri" else 4
+        fnodes = [capi.fe_face_nodes(geom, self.fe, f) for f in range(nf)]
         top = self.nlevels - 1
         ed, xs, ff, _ = levels[top]
         ndof = ndofs[top]
@@ -225,26 +257,32 @@ class Poisson001:
         SOL, RES, EPS = ctx.vector(ndof), ctx.vector(ndof), ctx.vector(ndof)
         sol0 = np.zeros(ndof)
         bdc = []
-        flux_faces, flux_idx, flux_exprs = [], [], []
+        flux_faces, flux_idx, flux_exprs, tau_faces, tau_vals = [], [], [], [], []
         for l, (edl, xl, ffl, _) in enumerate(levels):
             val = {}
             for iel, f in zip(*np.nonzero(ffl < -1)):               # elements and faces in order; a later face overwrites an earlier one (GenerateBdc)
-                kind, fn = self.face_bc(int(ffl[iel, f]))
+                flag = int(ffl[iel, f])
+                kind, fn = self.face_bc(flag)
                 nodes = edl[iel, fnodes[f]]
                 if kind == "dirichlet":
                     for node in nodes:
-                        x4 = np.array([xl[node, 0], xl[node, 1], 0.0, 0.0])
+                        x4 = np.zeros(4)
+                        x4[:dim] = xl[node]
                         val[int(node)] = fn(x4) if (fn is not None and l == top) else 0.0
-                elif fn is not None and l == top:
-                    if fn not in flux_exprs:
-                        flux_exprs.append(fn)
-                    flux_faces.append(nodes)
-                    flux_idx.append(flux_exprs.index(fn))
+                elif l == top:
+                    if fn is not None:                              # parsed flux (box inputs)
+                        if fn not in flux_exprs:
+                            flux_exprs.append(fn)
+                        flux_faces.append(nodes)
+                        flux_idx.append(flux_exprs.index(fn))
+                    elif self.box is None and flag in self.file_flux:      # the constant flux of SetBoundaryCondition (mesh-file inputs)
+                        tau_faces.append(nodes)
+                        tau_vals.append(self.file_flux[flag])
             idx = np.array(sorted(val), dtype=np.int32)
             bdc.append(idx)
             if l == top:
                 sol0[idx] = [val[i] for i in idx]
-        P = [None] + [self._prolongator_from_children("tri", levels[l - 1][0], levels[l][0], nc, ndofs[l - 1], ndofs[l]) for l in range(1, self.nlevels)]
+        P = [None] + [self._prolongator_from_children(geom, levels[l - 1][0], levels[l][0], nc, ndofs[l - 1], ndofs[l]) for l in range(1, self.nlevels)]
         for l in range(1, self.nlevels):
             if bdc[l].size:
                 P[l].mat_zero_rows(bdc[l], 0.0)
@@ -257,9 +295,11 @@ class Poisson001:
         history = []
         its = 0
         for it in range(self.max_linear + 1):
-            capi.assemble_poisson_rows(ctx, "tri", self.fe, ed, xs, K, RES, sol=SOL, source=self.source, scale=1.0)
+            capi.assemble_poisson_rows(ctx, geom, self.fe, ed, xs, K, RES, sol=SOL, source=self.source, scale=1.0)
             if flux_faces:
                 capi.assemble_neumann_edges(ctx, self.fe, np.array(flux_faces), np.array(flux_idx), flux_exprs, xs, RES)
+            if tau_faces:
+                capi.assemble_neumann_faces(ctx, geom, self.fe, np.array(tau_faces), np.array(tau_vals), xs, RES)
             if bdc[top].size:
                 K.mat_zero_rows(bdc[top], 1.0)
                 RES.set(bdc[top], np.zeros(bdc[top].size))

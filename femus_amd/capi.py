@@ -740,6 +740,14 @@ def fe_elem_prolongator(geom, fe):
     return P
 
 
+def fe_node_ref_coords(geom, node):
+    """reference coordinates of a local node as doubles (any element: the simplices' are 0, 1/2, 1, 1/3)"""
+    L = load_library()
+    out = np.zeros(3)
+    _chk(L.fh_fe_node_ref_coords(GEOM[geom], int(node), _p(out)))
+    return out[:_DIM[geom]]
+
+
 def fe_node_ref(geom, node, d=None):
     """reference coordinates (-1, 0, 1) of a local node of the biquadratic element"""
     dim = 3 if geom == "hex" else 2
@@ -816,6 +824,15 @@ def assemble_neumann_edges(ctx, fe, face_nodes, face_expr, exprs, coords, res, o
     hs = (ctypes.c_void_p * len(exprs))(*[e.h for e in exprs])
     _chk(ctx.L.fh_assemble_neumann_faces_expr(ctx.h, GEOM["quad"], FE[fe], GAUSS_ORDER[order], fn.shape[0], _p(fn), _p(fx), len(exprs), hs, xy.shape[0], _p(xy),
                                               res.h))
+
+
+def assemble_neumann_faces(ctx, geom, fe, face_nodes, tau, coords, res, order="seventh"):
+    """face integrals of a constant flux per face on explicitly listed faces of a mesh the caller keeps (tetrahedra: TRI3 / TRI6 faces in the face element's
+    order, vertices then middles): res[node] += int phi tau dS (fh_assemble_neumann_faces)"""
+    fn, tv, xy = _i32(face_nodes), _f64(tau), _f64(coords)
+    if fn.shape[0] == 0:
+        return
+    _chk(ctx.L.fh_assemble_neumann_faces(ctx.h, GEOM[geom], FE[fe], GAUSS_ORDER[order], fn.shape[0], _p(fn), _p(tv), xy.shape[0], _p(xy), res.h))
 
 
 def face_normals(mesh, fe, face_nodes, gauss_point=0, order="seventh", coords=None):

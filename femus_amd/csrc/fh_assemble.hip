@@ -4606,11 +4606,13 @@ __global__ __launch_bounds__(128) void k_neumann(const int* __restrict__ node_pt
 
 // tables of the face element of `geom` (quad: the 2-D tables; line: 1-D Lagrange at the 1-D Gauss points): weights, phi[g][n], dphi[g][n][dim-1]
 static int face_element_tables(int geom, int fe, int order, int* nfn_out, std::vector<double>& w, std::vector<double>& phi, std::vector<double>& dphi) {
-  const int fgeom = (geom == fhfe::GEOM_HEX) ? fhfe::GEOM_QUAD : fhfe::GEOM_LINE;
+  const int fgeom = (geom == fhfe::GEOM_HEX) ? fhfe::GEOM_QUAD : (geom == fhfe::GEOM_TET) ? fhfe::GEOM_TRI : fhfe::GEOM_LINE;
   int tmp[9];
   const int nfn = fhfe::face_nodes(geom, fe, 0, tmp);
   *nfn_out = nfn;
-  if (fgeom == fhfe::GEOM_QUAD) {
+  if (fgeom == fhfe::GEOM_TRI) {        // the faces of a tetrahedron: TRI3 / TRI6 with the triangle's rule of the same order
+    FH_REQUIRE(fhfe::shape_tables(fhfe::GEOM_TRI, fe, order, w, phi, dphi) == 0, "fh_assemble_neumann_faces: unsupported Gauss rule");
+  } else if (fgeom == fhfe::GEOM_QUAD) {
     FH_REQUIRE(fhfe::shape_tables(fhfe::GEOM_QUAD, fe, order, w, phi, dphi) == 0, "fh_assemble_neumann_faces: unsupported Gauss rule");
   } else {
     const int ng1 = order + 1;
@@ -4687,8 +4689,8 @@ extern "C" int fh_fe_face_normals(int geom, int fe, int order, int gauss_point, 
 static int neumann_faces(fh_ctx_t ctx, int geom, int fe, int order, int nfaces, const int* face_nodes, const double* tau, const int* face_expr, int nexpr,
                          const fh_expr_t* exprs, int nnode, const double* coords, fh_vec_t res, const int* comp_offset = nullptr, double scale = 1.0) {
   FH_REQUIRE(ctx && res && (nfaces == 0 || (face_nodes && (tau || face_expr) && coords)), "fh_assemble_neumann_faces: null argument");
-  FH_REQUIRE(geom == 0 || geom == 1, "fh_assemble_neumann_faces: geom must be 0 (hex) or 1 (quad)");
-  FH_REQUIRE(fe == 0 || fe == 1 || fe == 2, "fh_assemble_neumann_faces: fe must be 0, 1 or 2");
+  FH_REQUIRE(geom == 0 || geom == 1 || geom == 3 || geom == 4, "fh_assemble_neumann_faces: geom must be 0 (hex), 1 (quad), 3 (triangle) or 4 (tetrahedron)");
+  FH_REQUIRE(fe == 0 || fe == 1 || (fe == 2 && geom != 4), "fh_assemble_neumann_faces: fe must be 0, 1 or 2 (tetrahedron: 0 or 1)");
   if (nfaces == 0) return 0;
   const int dim = fhfe::dim_of(geom);
   int nfn = 0;
