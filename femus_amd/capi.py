@@ -7,7 +7,7 @@ import ctypes
 import numpy as np
 from ._lib import load_library
 
-GEOM = {"hex": 0, "quad": 1, "line": 2, "tri": 3, "tet": 4}
+GEOM = {"hex": 0, "quad": 1, "line": 2, "tri": 3, "tet": 4, "wedge": 5}
 FE = {"linear": 0, "serendipity": 1, "biquadratic": 2, "constant": 3, "pwlinear": 4}        # 4: DISCONTINUOUS_POLYNOMIAL FIRST (system dof maps and prolongators only)
 GAUSS_ORDER = {"zero": 0, "first": 0, "second": 1, "third": 1, "fourth": 2, "fifth": 2,
                "sixth": 3, "seventh": 3, "eighth": 4, "ninth": 4}
@@ -681,7 +681,7 @@ def pattern_from_elements(elem_dof, ndof):
     return rowptr, col
 
 
-_DIM = {"hex": 3, "quad": 2, "line": 1, "tri": 2, "tet": 3}
+_DIM = {"hex": 3, "quad": 2, "line": 1, "tri": 2, "tet": 3, "wedge": 3}
 
 
 def fe_gauss(geom, order):
@@ -707,7 +707,7 @@ def fe_tables(geom, fe, order):
 def fe_tables_d2(geom, fe, order):
     """second derivatives at the Gauss points, [ng, nc, nh]: (xx) in 1-D, (xx, yy, xy) in 2-D, (xx, yy, zz, xy, yz, zx) in 3-D"""
     L = load_library()
-    nh = {"hex": 6, "quad": 3, "line": 1, "tri": 3, "tet": 6}[geom]
+    nh = {"hex": 6, "quad": 3, "line": 1, "tri": 3, "tet": 6, "wedge": 6}[geom]
     phi, _ = fe_tables(geom, fe, order)
     d2 = np.empty((nh,) + phi.shape)
     _chk(L.fh_fe_tables_d2(GEOM[geom], FE[fe], GAUSS_ORDER[order], _p(d2)))

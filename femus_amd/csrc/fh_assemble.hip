@@ -5058,7 +5058,7 @@ extern "C" int fh_assemble_poisson_rows(fh_ctx_t ctx, int geom, int fe, int orde
                                         fh_vec_t sol, fh_expr_t source, double scale, fh_mat_t KK, fh_vec_t RES) {
   FH_GUARD_BEGIN
   FH_REQUIRE(ctx && elem_dof && coords && KK && RES && nel >= 1 && nnode >= 1, "fh_assemble_poisson_rows: null or empty argument");
-  FH_REQUIRE(geom >= 0 && geom <= 4, "fh_assemble_poisson_rows: geom must be 0 (hex), 1 (quad), 2 (line), 3 (triangle) or 4 (tetrahedron)");
+  FH_REQUIRE(geom >= 0 && geom <= 5, "fh_assemble_poisson_rows: geom must be 0 (hex), 1 (quad), 2 (line), 3 (triangle), 4 (tetrahedron) or 5 (prism)");
   FH_REQUIRE(geom != 4 || fe <= 1, "fh_assemble_poisson_rows: on the tetrahedron the families 0 (P1) and 1 (P2, TET10) are served");
   FH_REQUIRE(fe == fhfe::FE_LINEAR || fe == fhfe::FE_SERENDIPITY || fe == fhfe::FE_BIQUADRATIC, "fh_assemble_poisson_rows: fe must be 0, 1 or 2");
   const int dim = fhfe::dim_of(geom), nc = fhfe::ndofs_of(geom, fe), ndof = KK->m;

@@ -3,7 +3,7 @@
 #include <vector>
 
 namespace fhfe {
-enum { GEOM_HEX = 0, GEOM_QUAD = 1, GEOM_LINE = 2, GEOM_TRI = 3, GEOM_TET = 4 };
+enum { GEOM_HEX = 0, GEOM_QUAD = 1, GEOM_LINE = 2, GEOM_TRI = 3, GEOM_TET = 4, GEOM_WEDGE = 5 };
 enum { FE_LINEAR = 0, FE_SERENDIPITY = 1, FE_BIQUADRATIC = 2, FE_CONSTANT = 3 };      // FEFamily order of the reference (CONTINUOUS_LINEAR, _SERENDIPITY, _BIQUADRATIC, DISCONTINUOUS_CONSTANT; 4 = DISCONTINUOUS_LINEAR lives in fh_mesh.cpp / fh_ns.hip)
 inline bool fe_known(int fe) { return fe >= 0 && fe <= 3; }
 int dim_of(int geom);

@@ -13,6 +13,7 @@
 #include "Quadrilateral.hpp"
 #include "Triangle.hpp"
 #include "Tetrahedron.hpp"
+#include "Wedge.hpp"
 #include "Edge.hpp"
 #include "GeomElemBase.hpp"
 #include <cstring>
@@ -35,6 +36,10 @@ static basis* make_basis(const char* geom, const char* fe) {
     if (!strcmp(fe, "biquadratic")) return new QuadBiquadratic();
     if (!strcmp(fe, "constant")) return new quad0();
     if (!strcmp(fe, "pwlinear")) return new quadpwLinear();
+  } else if (!strcmp(geom, "wedge")) {
+    if (!strcmp(fe, "linear")) return new WedgeLinear();
+    if (!strcmp(fe, "quadratic")) return new WedgeQuadratic();
+    if (!strcmp(fe, "biquadratic")) return new WedgeBiquadratic();
   } else if (!strcmp(geom, "tet")) {
     if (!strcmp(fe, "linear")) return new TetLinear();
     if (!strcmp(fe, "quadratic")) return new TetQuadratic();

@@ -167,6 +167,44 @@ out["ind_tet"] = indq
 out["f2c_tet"] = np.array([[L.ref_fine2coarse_vertex(b"tet", b"linear", j, v) for v in range(4)] for j in range(8)])
 out["facedofs_tet"] = np.array([[L.ref_face_dof(b"tet", b"quadratic", f, k) for k in range(6)] for f in range(4)])
 
+# WEDGE21 (round 6): the prism's Gauss rules, WedgeLinear / WedgeQuadratic / WedgeBiquadratic at the 'seventh' points and at sample points, node table, selectors,
+# children, face nodes
+for order in ORDERS:
+    ng = L.ref_gauss(b"wedge", order.encode(), 3, None, None)
+    w = np.zeros(ng)
+    x = np.zeros((3, ng))
+    L.ref_gauss(b"wedge", order.encode(), 3, w.ctypes.data_as(ctypes.c_void_p), x.ctypes.data_as(ctypes.c_void_p))
+    out["gauss_w_wedge_%s" % order] = w
+    out["gauss_x_wedge_%s" % order] = x.T.copy()
+sample_w = np.concatenate([rng.uniform(0, 0.45, (7, 2)), rng.uniform(-1, 1, (7, 1))], axis=1)
+out["sample_pts_wedge"] = sample_w
+for fe in ("linear", "serendipity", "biquadratic"):
+    rfe = REFNAME.get(fe, fe)
+    nc = L.ref_ndofs(b"wedge", rfe.encode())
+    for tag, pts in (("gauss7", out["gauss_x_wedge_seventh"]), ("sample", sample_w)):
+        vals = np.zeros((10, pts.shape[0], nc))
+        for p in range(pts.shape[0]):
+            pt = (ctypes.c_double * 3)(*[float(v) for v in pts[p]])
+            for j in range(nc):
+                for which in range(10):
+                    if fe != "biquadratic" and which >= 4:
+                        continue
+                    vals[which, p, j] = L.ref_eval(b"wedge", rfe.encode(), which, j, pt)
+        out["basis_wedge_%s_%s" % (fe, tag)] = vals
+xcw = np.zeros((21, 3))
+indw = np.zeros((21, 3), dtype=np.int64)
+for i in range(21):
+    b = (ctypes.c_double * 3)()
+    L.ref_xcoarse(b"wedge", b"biquadratic", i, 3, b)
+    xcw[i] = list(b)
+    ii = (ctypes.c_int * 3)()
+    L.ref_ind(b"wedge", b"biquadratic", i, 3, ii)
+    indw[i] = list(ii)
+out["xc_wedge"] = xcw
+out["ind_wedge"] = indw
+out["f2c_wedge"] = np.array([[L.ref_fine2coarse_vertex(b"wedge", b"linear", j, v) for v in range(6)] for j in range(8)])
+out["facedofs_wedge"] = np.array([[L.ref_face_dof(b"wedge", b"biquadratic", f, k) if (f < 3 or k < 7) else -1 for k in range(9)] for f in range(5)])
+
 # element prolongator as elem_type forms it.  ElemType.cpp itself needs boost and is not compiled, so its two loops are followed
 # here on top of the COMPILED basis classes (every number below comes out of a call into the reference's object code):
 #   (1) set_fine_coordinates_in_Basis_object (ElemType.cpp:404-432): fine node i = (child, vertex) = KVERT_IND[i] of the linear

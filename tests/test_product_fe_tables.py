@@ -136,6 +136,43 @@ def test_product_tetrahedron_tables_bit_exact(fe):
         capi.fe_tables("tet", "biquadratic", "seventh")
 
 
+@pytest.mark.parametrize("order", ORDERS)
+def test_product_prism_gauss_tables_bit_exact(order):
+    """3d/quadrature_Wedge.cpp: the five rules (1 / 8 / 21 / 52 / 95 points)"""
+    w, x = capi.fe_gauss("wedge", order)
+    assert np.array_equal(w, G["gauss_w_wedge_%s" % order]) and np.array_equal(x, G["gauss_x_wedge_%s" % order])
+
+
+@pytest.mark.parametrize("fe", ["linear", "serendipity", "biquadratic"])
+def test_product_prism_tables_bit_exact(fe):
+    """WEDGE21 (round 6): WedgeLinear / WedgeQuadratic / WedgeBiquadratic (3d/Wedge.cpp) at the 'seventh' points: phi and the three first derivatives against the
+    reference's compiled classes (biquadratic: the six second derivatives too); children, face nodes, element prolongator"""
+    ref = G["basis_wedge_%s_gauss7" % fe]
+    phi, dphi = capi.fe_tables("wedge", fe, "seventh")
+    assert np.array_equal(phi, ref[0])
+    for d in range(3):
+        assert np.array_equal(dphi[:, :, d], ref[1 + d])
+    if fe == "biquadratic":
+        d2 = capi.fe_tables_d2("wedge", fe, "seventh")
+        for k in range(6):
+            assert np.array_equal(d2[:, :, k], ref[4 + k])
+    assert np.allclose(phi.sum(axis=1), 1.0, atol=1e-13)
+    nq, nt = {"linear": (4, 3), "serendipity": (8, 6), "biquadratic": (9, 7)}[fe]
+    for f in range(5):
+        assert capi.fe_face_nodes("wedge", fe, f).tolist() == G["facedofs_wedge"][f][:(nq if f < 3 else nt)].tolist()
+    P = capi.fe_elem_prolongator("wedge", fe)
+    nc = phi.shape[1]
+    assert P.shape == (8, nc, nc)
+    f2c = G["f2c_wedge"]
+    for j in range(8):
+        for i in range(6):
+            if f2c[j][i] < nc:
+                e = np.zeros(nc)
+                e[f2c[j][i]] = 1.0
+                assert np.allclose(P[j, i], e, atol=1e-14)
+        assert np.allclose(P[j].sum(axis=1), 1.0, atol=1e-13)
+
+
 def _rows_by_kvert(geom, fe, P):
     """rows of a [child][local node][coarse] element prolongator in the reference's fine-node order KVERT_IND (Hexahedron.cpp:49-71)"""
     kv = G["kvert_ind_%s_%s" % (geom, fe)]
