@@ -75,8 +75,9 @@ class Poisson001:
         self.mesh_file = None
         if "filename" in mesh_type:
             self.mesh_file = os.path.join(base_dir, mesh_type["filename"]) if base_dir else mesh_type["filename"]
-            self.tet = self._gambit_is_tet10(self.mesh_file)               # cube_Tet.neu of input3D_Tet_*.json: served by the host-side tetrahedral mesh code
-            if self.tet:
+            kind = self._gambit_kind(self.mesh_file)                       # cube_Tet.neu / cube_Wedge.neu of input3D_Tet_* / _Wedge_*.json: host-side mesh code
+            self.tet, self.wedge = kind == "tet10", kind == "wedge18"
+            if self.tet or self.wedge:
                 self.dim = 3
             else:
                 probe = capi.Mesh.read_gambit(self.mesh_file)
@@ -162,6 +163,8 @@ class Poisson001:
             return self.run_tri(log)
         if getattr(self, "tet", False):
             return self.run_tet(log)
+        if getattr(self, "wedge", False):
+            return self.run_wedge(log)
         meshes = [capi.Mesh.box(*self.box, self.lo, self.hi) if self.box is not None else capi.Mesh.read_gambit(self.mesh_file)]
         for _ in range(1, self.nlevels):
             meshes.append(meshes[-1].refine())
@@ -221,14 +224,24 @@ class Poisson001:
         return self._run_simplex("tri", levels, (3, 6, 7)[fam], [own[fam] for (_, _, _, own) in levels], log, smoother, omega)
 
     @staticmethod
-    def _gambit_is_tet10(path):
-        """the first element of the file's ELEMENTS/CELLS section: Gambit type 6 with 10 nodes"""
+    def _gambit_kind(path):
+        """the first element of the file's ELEMENTS/CELLS section: Gambit type 6 with 10 nodes (TET10), type 5 with 18 (WEDGE18)"""
         with open(path) as f:
             tok = f.read().split()
         if "ELEMENTS/CELLS" not in tok:
-            return False
+            return None
         p = tok.index("ELEMENTS/CELLS") + 2
-        return tok[p + 1] == "6" and tok[p + 2] == "10"
+        return {("6", "10"): "tet10", ("5", "18"): "wedge18"}.get((tok[p + 1], tok[p + 2]))
+
+    def run_wedge(self, log=None, smoother=capi.SMOOTH_SOR, omega=1.0):
+        """a Gambit mesh of WEDGE18 elements (input3D_Wedge_first / _second / _serendipity.json with input/cube_Wedge.neu; femus_amd/wedge_mesh.py: WEDGE21
+        inside): the three Lagrange families; the boundary conditions of the application's SetBoundaryCondition"""
+        from . import wedge_mesh
+        levels = [wedge_mesh.read_gambit(self.mesh_file)]
+        for _ in range(1, self.nlevels):
+            levels.append(wedge_mesh.refine(*levels[-1][:3]))
+        fam = {"linear": 0, "serendipity": 1, "biquadratic": 2}[self.fe]
+        return self._run_simplex("wedge", levels, (6, 15, 21)[fam], [own[fam] for (_, _, _, own) in levels], log, smoother, omega)
 
     def run_tet(self, log=None, smoother=capi.SMOOTH_SOR, omega=1.0):
         """a Gambit mesh of TET10 elements (input3D_Tet_first / _serendipity.json with input/cube_Tet.neu; femus_amd/tet_mesh.py): P1 and P2; the boundary
@@ -248,7 +261,7 @@ class Poisson001:
         linear iteration"""
         ctx = self.ctx
         dim = 2 if geom == "tri" else 3
-        nf = 3 if geom == "tri" else 4
+        nf = {"tri": 3, "tet": 4, "wedge": 5}[geom]
         fnodes = [capi.fe_face_nodes(geom, self.fe, f) for f in range(nf)]
         top = self.nlevels - 1
         ed, xs, ff, _ = levels[top]
@@ -298,8 +311,11 @@ class Poisson001:
             capi.assemble_poisson_rows(ctx, geom, self.fe, ed, xs, K, RES, sol=SOL, source=self.source, scale=1.0)
             if flux_faces:
                 capi.assemble_neumann_edges(ctx, self.fe, np.array(flux_faces), np.array(flux_idx), flux_exprs, xs, RES)
-            if tau_faces:
-                capi.assemble_neumann_faces(ctx, geom, self.fe, np.array(tau_faces), np.array(tau_vals), xs, RES)
+            if tau_faces:                                             # by kind of face (a prism has quadrilaterals and triangles): the face element named
+                for nn in sorted({len(f) for f in tau_faces}):
+                    sel = [k for k, f in enumerate(tau_faces) if len(f) == nn]
+                    fgeom = "triface" if nn in (3, 6, 7) else "quadface"
+                    capi.assemble_neumann_faces(ctx, fgeom, self.fe, np.array([tau_faces[k] for k in sel]), np.array([tau_vals[k] for k in sel]), xs, RES)
             if bdc[top].size:
                 K.mat_zero_rows(bdc[top], 1.0)
                 RES.set(bdc[top], np.zeros(bdc[top].size))

@@ -832,7 +832,8 @@ def assemble_neumann_faces(ctx, geom, fe, face_nodes, tau, coords, res, order="s
     fn, tv, xy = _i32(face_nodes), _f64(tau), _f64(coords)
     if fn.shape[0] == 0:
         return
-    _chk(ctx.L.fh_assemble_neumann_faces(ctx.h, GEOM[geom], FE[fe], GAUSS_ORDER[order], fn.shape[0], _p(fn), _p(tv), xy.shape[0], _p(xy), res.h))
+    g = {"quadface": 101, "lineface": 102, "triface": 103}.get(geom)           # the face element itself named (prisms have faces of two kinds)
+    _chk(ctx.L.fh_assemble_neumann_faces(ctx.h, GEOM[geom] if g is None else g, FE[fe], GAUSS_ORDER[order], fn.shape[0], _p(fn), _p(tv), xy.shape[0], _p(xy), res.h))
 
 
 def face_normals(mesh, fe, face_nodes, gauss_point=0, order="seventh", coords=None):

@@ -4606,9 +4606,10 @@ __global__ __launch_bounds__(128) void k_neumann(const int* __restrict__ node_pt
 
 // tables of the face element of `geom` (quad: the 2-D tables; line: 1-D Lagrange at the 1-D Gauss points): weights, phi[g][n], dphi[g][n][dim-1]
 static int face_element_tables(int geom, int fe, int order, int* nfn_out, std::vector<double>& w, std::vector<double>& phi, std::vector<double>& dphi) {
-  const int fgeom = (geom == fhfe::GEOM_HEX) ? fhfe::GEOM_QUAD : (geom == fhfe::GEOM_TET) ? fhfe::GEOM_TRI : fhfe::GEOM_LINE;
+  // geom >= 100: the FACE element itself is named (100 + its geometry: 101 quadrilateral, 103 triangle, 102 line) -- prisms have faces of two kinds
+  const int fgeom = geom >= 100 ? geom - 100 : (geom == fhfe::GEOM_HEX) ? fhfe::GEOM_QUAD : (geom == fhfe::GEOM_TET) ? fhfe::GEOM_TRI : fhfe::GEOM_LINE;
   int tmp[9];
-  const int nfn = fhfe::face_nodes(geom, fe, 0, tmp);
+  const int nfn = geom >= 100 ? fhfe::ndofs_of(fgeom, fe) : fhfe::face_nodes(geom, fe, 0, tmp);
   *nfn_out = nfn;
   if (fgeom == fhfe::GEOM_TRI) {        // the faces of a tetrahedron: TRI3 / TRI6 with the triangle's rule of the same order
     FH_REQUIRE(fhfe::shape_tables(fhfe::GEOM_TRI, fe, order, w, phi, dphi) == 0, "fh_assemble_neumann_faces: unsupported Gauss rule");
@@ -4689,10 +4690,11 @@ extern "C" int fh_fe_face_normals(int geom, int fe, int order, int gauss_point, 
 static int neumann_faces(fh_ctx_t ctx, int geom, int fe, int order, int nfaces, const int* face_nodes, const double* tau, const int* face_expr, int nexpr,
                          const fh_expr_t* exprs, int nnode, const double* coords, fh_vec_t res, const int* comp_offset = nullptr, double scale = 1.0) {
   FH_REQUIRE(ctx && res && (nfaces == 0 || (face_nodes && (tau || face_expr) && coords)), "fh_assemble_neumann_faces: null argument");
-  FH_REQUIRE(geom == 0 || geom == 1 || geom == 3 || geom == 4, "fh_assemble_neumann_faces: geom must be 0 (hex), 1 (quad), 3 (triangle) or 4 (tetrahedron)");
+  FH_REQUIRE(geom == 0 || geom == 1 || geom == 3 || geom == 4 || geom == 101 || geom == 102 || geom == 103,
+             "fh_assemble_neumann_faces: geom must be 0 (hex), 1 (quad), 3 (triangle), 4 (tetrahedron), or 100 + the face element's own geometry (101 / 102 / 103)");
   FH_REQUIRE(fe == 0 || fe == 1 || (fe == 2 && geom != 4), "fh_assemble_neumann_faces: fe must be 0, 1 or 2 (tetrahedron: 0 or 1)");
   if (nfaces == 0) return 0;
-  const int dim = fhfe::dim_of(geom);
+  const int dim = geom >= 100 ? fhfe::dim_of(geom - 100) + 1 : fhfe::dim_of(geom);
   int nfn = 0;
   std::vector<double> w, phi, dphi;
   FH_TRY(face_element_tables(geom, fe, order, &nfn, w, phi, dphi));

@@ -353,7 +353,8 @@ int fh_fe_face_nodes(int geom, int fe, int face, int* nfn, int* local_nodes);
 /* reference coordinates (-1, 0, 1 per direction) of a local node of the biquadratic element (the X tables of hex_lag / quad_lag) */
 int fh_fe_node_ref(int geom, int node, int* xi /* [dim] */);
 /* the same as doubles, for every element (geom 3 = the triangle TRI7 of 2d/Triangle.cpp: vertices, edge middles, centre at 0, 1/2, 1, 1/3) */
-int fh_fe_node_ref_coords(int geom, int node, double* xi /* [dim] */);
+int fh_fe_node_ref_coords(int geom, int node, double* xi /* [dim]  geom 3 / 4: edges of triangles / faces of tetrahedra (TRI3, TRI6); geom 100 + g names the FACE element itself (101 quadrilateral, 103 triangle, 102 line:
+ * prisms have faces of two kinds). */);
 int fh_assemble_neumann_faces(fh_ctx_t ctx, int geom, int fe, int gauss_order, int nfaces, const int* face_nodes, const double* tau,
                               int nnode, const double* coords, fh_vec_t res);
 
