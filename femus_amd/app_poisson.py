@@ -244,16 +244,14 @@ class Poisson001:
         return self._run_simplex("wedge", levels, (6, 15, 21)[fam], [own[fam] for (_, _, _, own) in levels], log, smoother, omega)
 
     def run_tet(self, log=None, smoother=capi.SMOOTH_SOR, omega=1.0):
-        """a Gambit mesh of TET10 elements (input3D_Tet_first / _serendipity.json with input/cube_Tet.neu; femus_amd/tet_mesh.py): P1 and P2; the boundary
-        conditions of the application's SetBoundaryCondition (Dirichlet 0, flux 0.2 on face name 3)"""
+        """a Gambit mesh of TET10 elements (input3D_Tet_first / _serendipity / _second.json with input/cube_Tet.neu; femus_amd/tet_mesh.py): P1, P2 and P2 with
+        face and volume bubbles (TET15); the boundary conditions of the application's SetBoundaryCondition (Dirichlet 0, flux 0.2 on face name 3)"""
         from . import tet_mesh
-        if self.fe == "biquadratic":
-            raise NotImplementedError("tetrahedra are served with \"fe_order\" first and serendipity (P1, P2); FEMuS's TET15 family (face nodes and centre) is not built")
         levels = [tet_mesh.read_gambit(self.mesh_file)]
         for _ in range(1, self.nlevels):
             levels.append(tet_mesh.refine(*levels[-1][:3]))
-        fam = {"linear": 0, "serendipity": 1}[self.fe]
-        return self._run_simplex("tet", levels, (4, 10)[fam], [own[fam] for (_, _, _, own) in levels], log, smoother, omega)
+        fam = {"linear": 0, "serendipity": 1, "biquadratic": 2}[self.fe]
+        return self._run_simplex("tet", levels, (4, 10, 15)[fam], [own[fam] for (_, _, _, own) in levels], log, smoother, omega)
 
     def _run_simplex(self, geom, levels, nc, ndofs, log, smoother, omega):
         """LinearImplicitSystem::MGsolve on meshes this module keeps (triangles, tetrahedra): the Poisson callback through the generic kernel on the finest

@@ -4692,7 +4692,7 @@ static int neumann_faces(fh_ctx_t ctx, int geom, int fe, int order, int nfaces, 
   FH_REQUIRE(ctx && res && (nfaces == 0 || (face_nodes && (tau || face_expr) && coords)), "fh_assemble_neumann_faces: null argument");
   FH_REQUIRE(geom == 0 || geom == 1 || geom == 3 || geom == 4 || geom == 101 || geom == 102 || geom == 103,
              "fh_assemble_neumann_faces: geom must be 0 (hex), 1 (quad), 3 (triangle), 4 (tetrahedron), or 100 + the face element's own geometry (101 / 102 / 103)");
-  FH_REQUIRE(fe == 0 || fe == 1 || (fe == 2 && geom != 4), "fh_assemble_neumann_faces: fe must be 0, 1 or 2 (tetrahedron: 0 or 1)");
+  FH_REQUIRE(fe == 0 || fe == 1 || fe == 2, "fh_assemble_neumann_faces: fe must be 0, 1 or 2");
   if (nfaces == 0) return 0;
   const int dim = geom >= 100 ? fhfe::dim_of(geom - 100) + 1 : fhfe::dim_of(geom);
   int nfn = 0;
@@ -5061,7 +5061,6 @@ extern "C" int fh_assemble_poisson_rows(fh_ctx_t ctx, int geom, int fe, int orde
   FH_GUARD_BEGIN
   FH_REQUIRE(ctx && elem_dof && coords && KK && RES && nel >= 1 && nnode >= 1, "fh_assemble_poisson_rows: null or empty argument");
   FH_REQUIRE(geom >= 0 && geom <= 5, "fh_assemble_poisson_rows: geom must be 0 (hex), 1 (quad), 2 (line), 3 (triangle), 4 (tetrahedron) or 5 (prism)");
-  FH_REQUIRE(geom != 4 || fe <= 1, "fh_assemble_poisson_rows: on the tetrahedron the families 0 (P1) and 1 (P2, TET10) are served");
   FH_REQUIRE(fe == fhfe::FE_LINEAR || fe == fhfe::FE_SERENDIPITY || fe == fhfe::FE_BIQUADRATIC, "fh_assemble_poisson_rows: fe must be 0, 1 or 2");
   const int dim = fhfe::dim_of(geom), nc = fhfe::ndofs_of(geom, fe), ndof = KK->m;
   FH_REQUIRE(nloc >= nc && nc <= GEN_NC, "fh_assemble_poisson_rows: %d nodes per element given, the family has %d", nloc, nc);

@@ -1,25 +1,40 @@
 """Tetrahedral meshes of applications/001_Poisson on the host (integers and coordinates only; all numerics run in libfemus_hip.so): the Gambit reader for
-TET10, refinement, numbering.  The families served on tetrahedra are P1 and P2 (the application's "first" and "serendipity"): the face nodes and the centre
-FEMuS adds for its TET15 are not built.
+TET10, the face and centre nodes FEMuS adds (TET15), refinement, numbering.
 
     read_gambit   GambitIO.cpp:101-330: ten nodes per element in Gambit's order -> FEMuS's through GambitToFemusVertexIndex[1] (:66-69), boundary sets
-                  "element, type, face" with the faces as numbered in the file (GambitToFemusFaceIndex[1], :85), flag = -(set name) - 1
+                  "element, type, face" with the faces as numbered in the file (GambitToFemusFaceIndex[1], :85), flag = -(set name) - 1;
+                  Mesh::AddBiquadraticNodesNotInMeshFile (Mesh.cpp:1207-1333): one node per face (shared by the two tetrahedra it separates), one centre per
+                  element, coordinates with the weights of Mesh.cpp:107-113 (faces -1/9, 4/9; centre -1/8, 1/4)
     refine        MeshRefinement::RefineMesh: children 8 e + j, their vertices through tet_lag::fine2CoarseVertexMapping (read off the element prolongator the
-                  library builds from it), new middles shared between neighbours, coordinates by the P2 element prolongator; a child face all of whose
-                  vertices lie on a face of the father carries that face's flag
-    numbering     vertices, then middles, each class in order of first appearance walking the elements
+                  library builds from it), new middles and face centres shared between neighbours, a centre per child, coordinates by the TET15 element
+                  prolongator; a child face all of whose vertices lie on a face of the father carries that face's flag
+    numbering     vertices, then middles, then face centres and centres, each class in order of first appearance walking the elements
 """
 import numpy as np
 
 from . import capi
 
 G2F = (0, 4, 1, 6, 5, 2, 7, 8, 9, 3)
+# Mesh.cpp:107-113: weights of the ten file nodes in the four face nodes and in the centre
+WGT = np.array([[-1. / 9., -1. / 9., -1. / 9., 0, 4. / 9., 4. / 9., 4. / 9., 0, 0, 0], [-1. / 9., -1. / 9., 0, -1. / 9., 4. / 9., 0, 0, 4. / 9., 4. / 9., 0],
+                [0, -1. / 9., -1. / 9., -1. / 9., 0, 4. / 9., 0, 0, 4. / 9., 4. / 9.], [-1. / 9., 0, -1. / 9., -1. / 9., 0, 0, 4. / 9., 4. / 9., 0, 4. / 9.],
+                [-1. / 8.] * 4 + [1. / 4.] * 6])
+
+
+def _first_touch(keys):
+    """one id per distinct key, numbered by first appearance; returns (id per key, index of the creating entry per id)"""
+    uniq, first, inv = np.unique(keys, axis=0, return_index=True, return_inverse=True)
+    rank = np.empty(uniq.shape[0], dtype=np.int64)
+    rank[np.argsort(first, kind="stable")] = np.arange(uniq.shape[0])
+    owner = np.empty(uniq.shape[0], dtype=np.int64)
+    owner[rank] = first
+    return rank[inv.ravel()], owner
 
 
 def _renumber(raw, nnode):
     new = np.full(nnode, -1, dtype=np.int64)
     k, own = 0, []
-    for lo, hi in ((0, 4), (4, 10)):
+    for lo, hi in ((0, 4), (4, 10), (10, 15)):
         seq = raw[:, lo:hi].ravel()
         seq = seq[new[seq] < 0]
         uniq, first = np.unique(seq, return_index=True)
@@ -43,7 +58,7 @@ def read_gambit(path, Lref=1.0):
     cells = np.array(tok[p:p + 13 * nel], dtype=object).reshape(nel, 13)
     if not (np.all(cells[:, 1].astype(int) == 6) and np.all(cells[:, 2].astype(int) == 10)):
         raise ValueError("%s: TET10 elements only (element type 6 with 10 nodes)" % path)
-    raw = np.zeros((nel, 10), dtype=np.int64)
+    raw = np.full((nel, 15), -1, dtype=np.int64)
     raw[:, list(G2F)] = cells[:, 3:].astype(np.int64) - 1
     ff = np.full((nel, 4), -1, dtype=np.int64)
     q = 0
@@ -54,19 +69,32 @@ def read_gambit(path, Lref=1.0):
         sets = np.array(tok[q:q + 3 * nface], dtype=np.int64).reshape(nface, 3)
         ff[sets[:, 0] - 1, sets[:, 2] - 1] = -name - 1
         q += 3 * nface
-    new, own = _renumber(raw, nvt)
-    xs = np.empty_like(xyz)
-    xs[new] = xyz
+    faces = [capi.fe_face_nodes("tet", "biquadratic", f) for f in range(4)]
+    keys = np.sort(np.stack([raw[:, faces[f][:3]] for f in range(4)], axis=1).reshape(4 * nel, 3), axis=1)
+    ids, _ = _first_touch(keys)                                           # element by element, face by face: the first tetrahedron that holds a face creates its node
+    raw[:, 10:14] = (nvt + ids).reshape(nel, 4)
+    nface_nodes = int(ids.max()) + 1
+    raw[:, 14] = nvt + nface_nodes + np.arange(nel)
+    coords = np.concatenate([xyz, np.zeros((nface_nodes + nel, 3))])
+    acc = np.zeros((nel, 5, 3))
+    for j in range(10, 15):
+        for i in range(10):                                               # the sum in the order of Mesh.cpp:1316-1324
+            acc[:, j - 10] += coords[raw[:, i]] * WGT[j - 10][i]
+    for e in range(nel):                                                  # element by element as the reference does: a shared face node keeps the later element's sum
+        coords[raw[e, 10:15]] = acc[e]
+    new, own = _renumber(raw, coords.shape[0])
+    xs = np.empty_like(coords)
+    xs[new] = coords
     return new[raw], xs, ff, own
 
 
 def refine(ed, xs, ff):
     nel = ed.shape[0]
-    EP = capi.fe_elem_prolongator("tet", "serendipity")                   # [child][local node][coarse function]
+    EP = capi.fe_elem_prolongator("tet", "biquadratic")                   # [child][local node][coarse function]
     f2c = np.array([[int(np.argmax(EP[j, v])) for v in range(4)] for j in range(8)])
-    faces = [capi.fe_face_nodes("tet", "serendipity", f) for f in range(4)]      # three vertices, three middles
+    faces = [capi.fe_face_nodes("tet", "biquadratic", f) for f in range(4)]      # three vertices, three middles, the centre
     edge_v = _edge_vertices()
-    raw = np.full((8 * nel, 10), -1, dtype=np.int64)
+    raw = np.full((8 * nel, 15), -1, dtype=np.int64)
     fff = np.full((8 * nel, 4), -1, dtype=np.int64)
     for j in range(8):
         raw[j::8, :4] = ed[:, f2c[j]]
@@ -74,23 +102,39 @@ def refine(ed, xs, ff):
             for f in range(4):
                 if all(int(f2c[j][v]) in faces[f].tolist() for v in faces[lf][:3]):
                     fff[j::8, lf] = ff[:, f]
+    ch = np.arange(8 * nel)
+    coords = [xs]
+    nnew = xs.shape[0]
+
+    def create(keys, locals_per_key):
+        """new shared nodes for the keys [8 nel, n, width] (first appearance in element order, then local order); locals_per_key[k] = local node index"""
+        nonlocal nnew
+        n = keys.shape[1]
+        ids, owner = _first_touch(keys.reshape(-1, keys.shape[2]))
+        c, k = owner // n, owner % n
+        loc = np.array(locals_per_key)[k]
+        pos = np.zeros((owner.size, 3))
+        for m in range(15):
+            pos += EP[c % 8, loc, m][:, None] * xs[ed[c // 8, m]]
+        coords.append(pos)
+        out = (nnew + ids).reshape(-1, n)
+        nnew += owner.size
+        return out
+
     a = np.stack([raw[:, e[0]] for e in edge_v], axis=1)
     b = np.stack([raw[:, e[1]] for e in edge_v], axis=1)
-    key = (np.minimum(a, b) * np.int64(xs.shape[0]) + np.maximum(a, b)).ravel()
-    uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
-    rank = np.empty(uniq.size, dtype=np.int64)
-    rank[np.argsort(first, kind="stable")] = np.arange(uniq.size)
-    raw[:, 4:] = (xs.shape[0] + rank[inv]).reshape(-1, 6)
-    owner = np.empty(uniq.size, dtype=np.int64)
-    owner[rank] = first                                                    # (child element * 6 + local edge) that created the node
-    c, k = owner // 6, owner % 6
-    mid = np.zeros((uniq.size, 3))
-    for m in range(10):
-        mid += EP[c % 8, 4 + k, m][:, None] * xs[ed[c // 8, m]]
-    coords = np.concatenate([xs, mid])
+    raw[:, 4:10] = create(np.stack([np.minimum(a, b), np.maximum(a, b)], axis=2), list(range(4, 10)))
+    tri = np.sort(np.stack([raw[:, faces[f][:3]] for f in range(4)], axis=1), axis=2)
+    raw[:, 10:14] = create(tri, [10, 11, 12, 13])
+    raw[:, 14] = nnew + ch
+    cen = np.zeros((8 * nel, 3))
+    for m in range(15):
+        cen += EP[ch % 8, 14, m][:, None] * xs[ed[ch // 8, m]]
+    coords.append(cen)
+    coords = np.concatenate(coords)
     new, own = _renumber(raw, coords.shape[0])
     used = new >= 0
-    xf = np.empty((own[1], 3))
+    xf = np.empty((own[2], 3))
     xf[new[used]] = coords[used]
     return new[raw], xf, fff, own
 

@@ -81,12 +81,13 @@ def read_gambit(path, Lref=1.0):
     raw[:, 20] = nvt + ntri + np.arange(nel)
     coords = np.concatenate([xyz, np.zeros((ntri + nel, 3))])
     W = {18: ([0, 1, 2], [6, 7, 8]), 19: ([3, 4, 5], [9, 10, 11]), 20: ([12, 13, 14], [15, 16, 17])}
+    acc = np.zeros((nel, 3, 3))
     for j, (neg, pos) in W.items():
-        s = np.zeros((nel, 3))
         for i in range(18):                                  # the sum in the order of Mesh.cpp:1316-1324
             wgt = -1. / 9. if i in neg else 4. / 9. if i in pos else 0.0
-            s += coords[raw[:, i]] * wgt
-        coords[raw[:, j]] = s
+            acc[:, j - 18] += coords[raw[:, i]] * wgt
+    for e in range(nel):                                     # element by element as the reference does: a shared face node keeps the later element's sum
+        coords[raw[e, 18:21]] = acc[e]
     new, own = _renumber(raw, coords.shape[0])
     xs = np.empty_like(coords)
     xs[new] = coords

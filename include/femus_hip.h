@@ -199,7 +199,9 @@ int64_t fh_spmv_algorithmic_bytes(fh_mat_t A);
 int fh_spmv_expected_bytes(fh_mat_t A, int mode, int64_t* lo, int64_t* hi);
 
 /* ---- FE tables (a1-a3, a6) -------------------------------------------------------------------
- * geom: 0 = hex (HEX27 geometry), 1 = quad (QUAD9).  fe = FEMuS SolType ids (FEFamily order): 0 = linear (Q1), 1 = serendipity (QuadQuadratic / HexQuadratic,
+ * geom: 0 = hex (HEX27 geometry), 1 = quad (QUAD9), 2 = line (EDGE3), 3 = triangle (TRI7), 4 = tetrahedron (TET15: 3d/Tetrahedron.cpp; TetBiquadratic is summed
+ * from barycentric products and agrees with the reference's expanded polynomials to rounding, every other table bit for bit; no second derivatives for it),
+ * 5 = prism (WEDGE21; no serendipity second derivatives).  fe = FEMuS SolType ids (FEFamily order): 0 = linear (Q1), 1 = serendipity (QuadQuadratic / HexQuadratic,
  * 8 / 20 nodes: Quadrilateral.cpp:113-161, Hexahedron.cpp:167-256), 2 = biquadratic (Q2), 3 = piecewise constant (quad0 / hex0, one dof per element).
  * Dofs of one variable on one process (Mesh::GetSolutionDof, Mesh.cpp:1021-1074): local node i of the element for 0 / 1 / 2 -- nodes are numbered vertices, edge
  * mid-points, the rest, so families 0 and 1 own the leading own[0] / own[1] node ids of fh_mesh_info --, the element itself for 3 (and i * nel + iel for 4,

@@ -166,6 +166,22 @@ out["xc_tet"] = xcq
 out["ind_tet"] = indq
 out["f2c_tet"] = np.array([[L.ref_fine2coarse_vertex(b"tet", b"linear", j, v) for v in range(4)] for j in range(8)])
 out["facedofs_tet"] = np.array([[L.ref_face_dof(b"tet", b"quadratic", f, k) for k in range(6)] for f in range(4)])
+# TET15 (round 6): TetBiquadratic (values and first derivatives), the fifteen nodes, the seven nodes of a face
+for tag, pts in (("gauss7", out["gauss_x_tet_seventh"]), ("sample", sample_q)):
+    vals = np.zeros((4, pts.shape[0], 15))
+    for p in range(pts.shape[0]):
+        pt = (ctypes.c_double * 3)(*[float(v) for v in pts[p]])
+        for j in range(15):
+            for which in range(4):
+                vals[which, p, j] = L.ref_eval(b"tet", b"biquadratic", which, j, pt)
+    out["basis_tet_biquadratic_%s" % tag] = vals
+xcq15 = np.zeros((15, 3))
+for i in range(15):
+    b = (ctypes.c_double * 3)()
+    L.ref_xcoarse(b"tet", b"biquadratic", i, 3, b)
+    xcq15[i] = list(b)
+out["xc_tet15"] = xcq15
+out["facedofs_tet15"] = np.array([[L.ref_face_dof(b"tet", b"biquadratic", f, k) for k in range(7)] for f in range(4)])
 
 # WEDGE21 (round 6): the prism's Gauss rules, WedgeLinear / WedgeQuadratic / WedgeBiquadratic at the 'seventh' points and at sample points, node table, selectors,
 # children, face nodes

@@ -132,8 +132,30 @@ def test_product_tetrahedron_tables_bit_exact(fe):
                 e[f2c[j][i]] = 1.0
                 assert np.allclose(P[j, i], e, atol=1e-14)
         assert np.allclose(P[j].sum(axis=1), 1.0, atol=1e-14)
+
+
+def test_product_tetrahedron_p2_bubble_tables():
+    """TET15: TetBiquadratic (3d/Tetrahedron.cpp:325-600) in the product's hierarchical form (vertex / edge / face / centre terms summed in another order than the
+    reference's expanded polynomials): values and first derivatives to 1e-14 at the 'seventh' points; the fifteen nodes and the seven nodes of a
+    face bit for bit; Kronecker property at the nodes; the element prolongator a partition of unity; the second derivatives are refused"""
+    ref = G["basis_tet_biquadratic_gauss7"]
+    phi, dphi = capi.fe_tables("tet", "biquadratic", "seventh")
+    assert np.allclose(phi, ref[0], rtol=0, atol=1e-14)
+    for d in range(3):
+        assert np.allclose(dphi[:, :, d], ref[1 + d], rtol=0, atol=2e-14)
+    xc = np.array([capi.fe_node_ref_coords("tet", i) for i in range(15)])
+    assert np.array_equal(xc, G["xc_tet15"])
+    assert [capi.fe_face_nodes("tet", "biquadratic", f).tolist() for f in range(4)] == G["facedofs_tet15"].tolist()
+    P = capi.fe_elem_prolongator("tet", "biquadratic")
+    assert P.shape == (8, 15, 15)
+    for j in range(8):
+        assert np.allclose(P[j].sum(axis=1), 1.0, atol=1e-13)
+        for i in range(4):
+            e = np.zeros(15)
+            e[G["f2c_tet"][j][i]] = 1.0
+            assert np.allclose(P[j, i], e, atol=1e-14)
     with pytest.raises(capi.FemusHipError):
-        capi.fe_tables("tet", "biquadratic", "seventh")
+        capi.fe_tables_d2("tet", "biquadratic", "seventh")
 
 
 @pytest.mark.parametrize("order", ORDERS)

@@ -1,4 +1,4 @@
-"""Tetrahedra (the TET10 meshes of applications/001_Poisson: input3D_Tet_first / _serendipity.json with input/cube_Tet.neu, a data file of the application kept in
+"""Tetrahedra (the TET10 meshes of applications/001_Poisson: input3D_Tet_first / _serendipity / _second.json with input/cube_Tet.neu, a data file of the application kept in
 tests/golden).  CPU: the oracle restatement (oracle/femus_oracle_tet.py) -- basis against the fixture of the reference's compiled classes, reader / refinement
 properties, the product's host-side mesh code equal to it.  GPU: the generic kernel and the triangle-face integrals against the oracle entry for entry, and
 the shipped inputs through app_poisson against the oracle's direct solve."""
@@ -19,13 +19,16 @@ def volumes(ed, xs):
     return np.einsum("ij,ij->i", np.cross(xs[ed[:, 1]] - xs[ed[:, 0]], xs[ed[:, 2]] - xs[ed[:, 0]]), xs[ed[:, 3]] - xs[ed[:, 0]]) / 6
 
 
-@pytest.mark.parametrize("fe", ["linear", "serendipity"])
+@pytest.mark.parametrize("fe", ["linear", "serendipity", "biquadratic"])
 def test_oracle_tetrahedron_basis_is_the_reference_s(fe):
     for tag, pts in (("sample", G["sample_pts_tet"]), ("gauss7", G["gauss_x_tet_seventh"])):
-        ref = G["basis_tet_%s_%s" % (fe, tag)]
+        ref = G["basis_tet_%s_%s" % (fe, tag)][:4]
         phi, dphi = oq.basis(fe, pts)
         assert np.abs(phi - ref[0]).max() < 4e-15 and max(np.abs(dphi[:, :, d] - ref[1 + d]).max() for d in range(3)) < 4e-15
-    assert np.array_equal(oq.XC, G["xc_tet"]) and np.array_equal(oq.F2C, G["f2c_tet"]) and np.array_equal(oq.FACE, G["facedofs_tet"])
+    assert np.array_equal(oq.XC, G["xc_tet15"]) and np.array_equal(oq.F2C, G["f2c_tet"]) and np.array_equal(oq.FACE, G["facedofs_tet15"])
+    assert np.array_equal(oq.XC[:10], G["xc_tet"]) and np.array_equal(oq.FACE[:, :6], G["facedofs_tet"])
+    P = oq.elem_prolongator(fe)
+    assert np.allclose(P.sum(axis=2), 1.0, atol=1e-13)
 
 
 def test_the_mesh_file_is_the_application_s():
@@ -36,18 +39,25 @@ def test_the_mesh_file_is_the_application_s():
 
 
 def test_oracle_reader_and_refinement_and_the_product_s_mesh_code():
-    """cube_Tet.neu: 105 positively oriented TET10 elements filling the unit cube, middles at the middles, six boundary sets of eight faces; refined: eight times
+    """cube_Tet.neu: 105 positively oriented TET10 elements filling the unit cube, middles at the middles, the added face nodes at the faces' centres (234 of
+    them: every inner face shared) and the added centres at the centres, six boundary sets of eight faces; refined: eight times
     the elements, the same volume, four times the faces per set, flagged faces on the cube's surface; femus_amd/tet_mesh.py gives the same integers and
     coordinates on three levels"""
     from femus_amd import tet_mesh
     ed, xs, ff, own = oq.read_gambit(MESH)
-    assert ed.shape == (105, 10) and own == [39, 206] and np.isclose(volumes(ed, xs).sum(), 1.0) and volumes(ed, xs).min() > 0
+    assert ed.shape == (105, 15) and own == [39, 206, 545] and np.isclose(volumes(ed, xs).sum(), 1.0) and volumes(ed, xs).min() > 0
+    assert np.unique(ed[:, 10:14]).size == (105 * 4 + 48) // 2 and np.unique(ed[:, 14]).size == 105
+    for f in range(4):
+        assert np.allclose(xs[ed[:, 10 + f]], xs[ed[:, oq.FACE[f][:3]]].mean(axis=1), atol=1e-15)
+    assert np.allclose(xs[ed[:, 14]], xs[ed[:, :4]].mean(axis=1), atol=1e-15)
     for m, (a, b) in enumerate(oq.EDGE):
         assert np.allclose(xs[ed[:, 4 + m]], 0.5 * (xs[ed[:, a]] + xs[ed[:, b]]))
     assert [(ff == f).sum() for f in range(-7, -1)] == [8] * 6
     a, b = tet_mesh.read_gambit(MESH), (ed, xs, ff, own)
     for level in range(3):
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+        # file level: the same bits; refined levels: the TET15 element prolongator of the library and the oracle's agree to rounding (other order of the sums)
+        assert np.array_equal(a[1], b[1]) if level == 0 else np.abs(a[1] - b[1]).max() < 2e-15
         if level == 2:
             break
         a, b = tet_mesh.refine(*a[:3]), oq.refine(*b[:3])
@@ -60,10 +70,10 @@ def test_oracle_reader_and_refinement_and_the_product_s_mesh_code():
 
 
 @gpu
-@pytest.mark.parametrize("fe", ["linear", "serendipity"])
+@pytest.mark.parametrize("fe", ["linear", "serendipity", "biquadratic"])
 def test_generic_kernel_and_face_integrals_on_tetrahedra_match_the_oracle(ctx, fe):
     """fh_assemble_poisson_rows on the refined cube of tetrahedra, nodes moved (curved P2 geometry), at a non-trivial state; fh_assemble_neumann_faces on its
-    flagged TRI3 / TRI6 faces: against the oracle's loops, 1e-12"""
+    flagged TRI3 / TRI6 / TRI7 faces: against the oracle's loops, 1e-12"""
     from femus_amd import capi
     from test_tri_2d import _pattern
     ed, xs, ff, own = oq.refine(*oq.read_gambit(MESH)[:3])
@@ -79,7 +89,7 @@ def test_generic_kernel_and_face_integrals_on_tetrahedra_match_the_oracle(ctx, f
     assert abs(Kd - Ka).max() <= 1e-12 * abs(Ka).max()
     assert np.abs(RES.to_numpy() - Fo).max() <= 1e-12 * np.abs(Fo).max()
     fno = oq.neumann(ed, xs, ff, fe, {-4: 0.2, -6: -1.5})
-    nfn = 3 if fe == "linear" else 6
+    nfn = oq.NFACE[fe]
     faces, taus = [], []
     for e, fl in zip(*np.nonzero(ff < -1)):
         if ff[e, fl] in (-4, -6):
@@ -109,7 +119,7 @@ def _shipped(fe_order, nlevels=4):
 """ % (fe_order, nlevels)
 
 
-@pytest.mark.parametrize("name,fe_order", [("input3D_Tet_first.json", "first"), ("input3D_Tet_serendipity.json", "serendipity")])
+@pytest.mark.parametrize("name,fe_order", [("input3D_Tet_first.json", "first"), ("input3D_Tet_serendipity.json", "serendipity"), ("input3D_Tet_second.json", "second")])
 def test_the_configurations_below_are_the_shipped_files(name, fe_order):
     from femus_amd import app_poisson as app
     ref_file = "/root/reference/applications/001_Poisson/input/" + name
@@ -119,10 +129,10 @@ def test_the_configurations_below_are_the_shipped_files(name, fe_order):
 
 
 @gpu
-@pytest.mark.parametrize("fe_order,fe,nlevels", [("first", "linear", 4), ("serendipity", "serendipity", 3)])
+@pytest.mark.parametrize("fe_order,fe,nlevels", [("first", "linear", 4), ("serendipity", "serendipity", 3), ("second", "biquadratic", 3)])
 def test_the_shipped_tetrahedral_inputs_of_001_poisson(ctx, tmp_path, fe_order, fe, nlevels):
-    """applications/001_Poisson/input/input3D_Tet_first.json (four levels, as shipped) and input3D_Tet_serendipity.json (on three of its four levels: the oracle's
-    direct solve of the fourth takes minutes) with input/cube_Tet.neu through app_poisson on the GPU -- SetBoundaryCondition of main.cpp:26-36: Dirichlet 0
+    """applications/001_Poisson/input/input3D_Tet_first.json (four levels, as shipped), input3D_Tet_serendipity.json and input3D_Tet_second.json (on three of
+    their four levels: the oracle's direct solve of the fourth takes minutes) with input/cube_Tet.neu through app_poisson on the GPU -- SetBoundaryCondition of main.cpp:26-36: Dirichlet 0
     everywhere but face 3, which carries the flux 0.2 -- against the oracle's direct solve of the finest level's problem"""
     from femus_amd import app_poisson as app
     os.makedirs(tmp_path / "input")
@@ -133,7 +143,7 @@ def test_the_shipped_tetrahedral_inputs_of_001_poisson(ctx, tmp_path, fe_order, 
     assert out["converged"] and len(out["history"]) <= 7, out["history"]
     ref, meshes = oq.solve(oq.read_gambit(MESH), nlevels, fe, lambda x: 0.0, dirichlet_flags=(-2, -3, -5, -6, -7), flux_by_flag={-4: 0.2})
     for (ed_p, xs_p, ff_p), (ed_o, xs_o, ff_o, _) in zip(out["levels"], meshes):
-        assert np.array_equal(ed_p, ed_o) and np.array_equal(ff_p, ff_o) and np.array_equal(xs_p, xs_o)
+        assert np.array_equal(ed_p, ed_o) and np.array_equal(ff_p, ff_o) and np.abs(xs_p - xs_o).max() < 2e-15
     assert out["dofs"] == ref.size and np.abs(ref).max() > 1e-3
     assert np.abs(out["solution"] - ref).max() < 1e-8
     p.max_linear, p.abs_tol = 40, 1e-13
@@ -143,17 +153,18 @@ def test_the_shipped_tetrahedral_inputs_of_001_poisson(ctx, tmp_path, fe_order, 
 
 
 @gpu
-def test_the_shipped_serendipity_input_on_all_of_its_four_levels(ctx, tmp_path):
-    """input3D_Tet_serendipity.json exactly as shipped (four levels: 53 760 TET10 elements): converges under the input's own limits; its solution at the nodes of
+@pytest.mark.parametrize("fe_order", ["serendipity", "second"])
+def test_the_shipped_quadratic_inputs_on_all_of_their_four_levels(ctx, tmp_path, fe_order):
+    """input3D_Tet_serendipity.json / input3D_Tet_second.json exactly as shipped (four levels: 53 760 elements): converges under the input's own limits; its solution at the nodes of
     the three-level problem stays within the discretisation error of that problem's solution (the oracle comparison proper is the three-level test above)"""
     from femus_amd import app_poisson as app
     os.makedirs(tmp_path / "input")
     (tmp_path / "input" / "cube_Tet.neu").write_bytes(open(MESH, "rb").read())
-    p4 = app.Poisson001(ctx, _shipped("serendipity", 4), base_dir=str(tmp_path))
+    p4 = app.Poisson001(ctx, _shipped(fe_order, 4), base_dir=str(tmp_path))
     out4 = p4.run()
     assert out4["converged"] and len(out4["history"]) <= 7, out4["history"]
     assert out4["levels"][-1][0].shape[0] == 105 * 8 ** 3
-    p3 = app.Poisson001(ctx, _shipped("serendipity", 3), base_dir=str(tmp_path))
+    p3 = app.Poisson001(ctx, _shipped(fe_order, 3), base_dir=str(tmp_path))
     out3 = p3.run()
     n3 = out3["dofs"]                                             # the nodes of level 3 are the first vertices of level 4 (vertices are numbered first, fathers' nodes first)
     x3, x4 = out3["coords"], out4["coords"]
