@@ -143,6 +143,7 @@ def _declare(L):
     sig("fh_assemble_neumann_faces_expr", c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p)
     sig("fh_assemble_advdiff_line", c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_double, c_double, c_void_p, c_void_p, c_void_p)
     sig("fh_assemble_poisson_rows", c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p)
+    sig("fh_assemble_poisson_mixed", c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p)
     sig("fh_assemble_pressure_faces", c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_double, c_void_p)
     sig("fh_fe_face_normals", c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p)
     sig("fh_mesh_read_gambit", c_char_p, c_double, P(c_void_p))

@@ -76,8 +76,8 @@ class Poisson001:
         if "filename" in mesh_type:
             self.mesh_file = os.path.join(base_dir, mesh_type["filename"]) if base_dir else mesh_type["filename"]
             kind = self._gambit_kind(self.mesh_file)                       # cube_Tet.neu / cube_Wedge.neu of input3D_Tet_* / _Wedge_*.json: host-side mesh code
-            self.tet, self.wedge = kind == "tet10", kind == "wedge18"
-            if self.tet or self.wedge:
+            self.tet, self.wedge, self.mixed = kind == "tet10", kind == "wedge18", kind == "mixed"
+            if self.tet or self.wedge or self.mixed:
                 self.dim = 3
             else:
                 probe = capi.Mesh.read_gambit(self.mesh_file)
@@ -165,6 +165,8 @@ class Poisson001:
             return self.run_tet(log)
         if getattr(self, "wedge", False):
             return self.run_wedge(log)
+        if getattr(self, "mixed", False):
+            return self.run_mixed(log)
         meshes = [capi.Mesh.box(*self.box, self.lo, self.hi) if self.box is not None else capi.Mesh.read_gambit(self.mesh_file)]
         for _ in range(1, self.nlevels):
             meshes.append(meshes[-1].refine())
@@ -225,13 +227,31 @@ class Poisson001:
 
     @staticmethod
     def _gambit_kind(path):
-        """the first element of the file's ELEMENTS/CELLS section: Gambit type 6 with 10 nodes (TET10), type 5 with 18 (WEDGE18)"""
+        """the elements of the file's ELEMENTS/CELLS section: Gambit type 6 with 10 nodes (TET10), type 5 with 18 (WEDGE18), more than one shape ("mixed":
+        cube_all_shapes*.neu); None: the hexahedral / quadrilateral files the library's reader takes"""
         with open(path) as f:
             tok = f.read().split()
-        if "ELEMENTS/CELLS" not in tok:
+        if "ELEMENTS/CELLS" not in tok or "NDFVL" not in tok:
             return None
+        nel = int(tok[tok.index("NDFVL") + 2])
         p = tok.index("ELEMENTS/CELLS") + 2
-        return {("6", "10"): "tet10", ("5", "18"): "wedge18"}.get((tok[p + 1], tok[p + 2]))
+        seen = set()
+        for _ in range(nel):
+            seen.add((tok[p + 1], tok[p + 2]))
+            p += 3 + int(tok[p + 2])
+        if len(seen) > 1:
+            return "mixed"
+        return {("6", "10"): "tet10", ("5", "18"): "wedge18"}.get(seen.pop())
+
+    def run_mixed(self, log=None, smoother=capi.SMOOTH_SOR, omega=1.0):
+        """a Gambit mesh of mixed shapes (input3D.json / input3D_All_first.json with input/cube_all_shapes_Six_boundary_groups.neu: tetrahedra, prisms and
+        hexahedra; femus_amd/mixed_mesh.py): the three Lagrange families; the boundary conditions of the application's SetBoundaryCondition"""
+        from . import mixed_mesh
+        levels = [mixed_mesh.read_gambit(self.mesh_file)]
+        for _ in range(1, self.nlevels):
+            levels.append(mixed_mesh.refine(*levels[-1][:4]))
+        fam = {"linear": 0, "serendipity": 1, "biquadratic": 2}[self.fe]
+        return self._run_simplex("mixed", [l[1:] for l in levels], None, [l[4][fam] for l in levels], log, smoother, omega, kinds=[l[0] for l in levels])
 
     def run_wedge(self, log=None, smoother=capi.SMOOTH_SOR, omega=1.0):
         """a Gambit mesh of WEDGE18 elements (input3D_Wedge_first / _second / _serendipity.json with input/cube_Wedge.neu; femus_amd/wedge_mesh.py: WEDGE21
@@ -253,18 +273,23 @@ class Poisson001:
         fam = {"linear": 0, "serendipity": 1, "biquadratic": 2}[self.fe]
         return self._run_simplex("tet", levels, (4, 10, 15)[fam], [own[fam] for (_, _, _, own) in levels], log, smoother, omega)
 
-    def _run_simplex(self, geom, levels, nc, ndofs, log, smoother, omega):
-        """LinearImplicitSystem::MGsolve on meshes this module keeps (triangles, tetrahedra): the Poisson callback through the generic kernel on the finest
-        level (fh_assemble_poisson_rows), transfers from the element prolongator, Galerkin operators below, V-cycles under GMRES limited to 4 iterations per
-        linear iteration"""
+    def _run_simplex(self, geom, levels, nc, ndofs, log, smoother, omega, kinds=None):
+        """LinearImplicitSystem::MGsolve on meshes this module keeps (triangles, tetrahedra, prisms, mixed shapes): the Poisson callback through the generic kernel
+        on the finest level (fh_assemble_poisson_rows / _mixed), transfers from the element prolongator, Galerkin operators below, V-cycles under GMRES limited to
+        4 iterations per linear iteration.  kinds[l][e] (mixed meshes): the shape of every element of level l; elem_dof rows padded with -1"""
         ctx = self.ctx
         dim = 2 if geom == "tri" else 3
-        nf = {"tri": 3, "tet": 4, "wedge": 5}[geom]
-        fnodes = [capi.fe_face_nodes(geom, self.fe, f) for f in range(nf)]
+        fam = {"linear": 0, "serendipity": 1, "biquadratic": 2}[self.fe]
+        NF = {"tri": 3, "tet": 4, "wedge": 5, "hex": 6}
+        CL = {"tri": (3, 6, 7), "tet": (4, 10, 15), "wedge": (6, 15, 21), "hex": (8, 20, 27)}
+        shapes = [geom] if kinds is None else sorted(set(kinds[0].tolist()))
+        fn_by = {s: [capi.fe_face_nodes(s, self.fe, f) for f in range(NF[s])] for s in shapes}
+        shape_of = (lambda l, e: geom) if kinds is None else (lambda l, e: kinds[l][e])
+        groups = [[(geom, np.arange(lv[0].shape[0]))] if kinds is None else [(s, np.nonzero(kinds[l] == s)[0]) for s in shapes] for l, lv in enumerate(levels)]
         top = self.nlevels - 1
         ed, xs, ff, _ = levels[top]
         ndof = ndofs[top]
-        K = self._pattern_from_elements(ed[:, :nc], ndof)
+        K = self._pattern_from_elements([ed[idx][:, :CL[s][fam]] for s, idx in groups[top]], ndof)
         SOL, RES, EPS = ctx.vector(ndof), ctx.vector(ndof), ctx.vector(ndof)
         sol0 = np.zeros(ndof)
         bdc = []
@@ -274,7 +299,7 @@ class Poisson001:
             for iel, f in zip(*np.nonzero(ffl < -1)):               # elements and faces in order; a later face overwrites an earlier one (GenerateBdc)
                 flag = int(ffl[iel, f])
                 kind, fn = self.face_bc(flag)
-                nodes = edl[iel, fnodes[f]]
+                nodes = edl[iel, fn_by[shape_of(l, iel)][f]]
                 if kind == "dirichlet":
                     for node in nodes:
                         x4 = np.zeros(4)
@@ -293,7 +318,8 @@ class Poisson001:
             bdc.append(idx)
             if l == top:
                 sol0[idx] = [val[i] for i in idx]
-        P = [None] + [self._prolongator_from_children(geom, levels[l - 1][0], levels[l][0], nc, ndofs[l - 1], ndofs[l]) for l in range(1, self.nlevels)]
+        P = [None] + [self._prolongator_from_children([(s, idx, CL[s][fam]) for s, idx in groups[l - 1]], levels[l - 1][0], levels[l][0], ndofs[l - 1], ndofs[l])
+                      for l in range(1, self.nlevels)]
         for l in range(1, self.nlevels):
             if bdc[l].size:
                 P[l].mat_zero_rows(bdc[l], 0.0)
@@ -306,7 +332,10 @@ class Poisson001:
         history = []
         its = 0
         for it in range(self.max_linear + 1):
-            capi.assemble_poisson_rows(ctx, geom, self.fe, ed, xs, K, RES, sol=SOL, source=self.source, scale=1.0)
+            if kinds is None:
+                capi.assemble_poisson_rows(ctx, geom, self.fe, ed, xs, K, RES, sol=SOL, source=self.source, scale=1.0)
+            else:
+                capi.assemble_poisson_mixed(ctx, self.fe, kinds[top], ed, xs, K, RES, sol=SOL, source=self.source, scale=1.0)
             if flux_faces:
                 capi.assemble_neumann_edges(ctx, self.fe, np.array(flux_faces), np.array(flux_idx), flux_exprs, xs, RES)
             if tau_faces:                                             # by kind of face (a prism has quadrilaterals and triangles): the face element named
@@ -345,29 +374,34 @@ class Poisson001:
                 m.destroy()
         return result
 
-    def _pattern_from_elements(self, ed, ndof):
-        """CSR pattern holding every (i, j) of every element"""
-        nc = ed.shape[1]
-        r = np.repeat(ed, nc, axis=1).ravel().astype(np.int64)
-        c = np.tile(ed, (1, nc)).ravel().astype(np.int64)
-        key = np.unique(r * ndof + c)
+    def _pattern_from_elements(self, eds, ndof):
+        """CSR pattern holding every (i, j) of every element; eds: one elem_dof array per shape"""
+        keys = []
+        for ed in eds:
+            nc = ed.shape[1]
+            r = np.repeat(ed, nc, axis=1).ravel().astype(np.int64)
+            c = np.tile(ed, (1, nc)).ravel().astype(np.int64)
+            keys.append(r * ndof + c)
+        key = np.unique(np.concatenate(keys))
         rows, cols = key // ndof, key % ndof
         indptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=ndof))])
         return capi.Mat.from_csr(self.ctx, ndof, ndof, indptr, cols)
 
-    def _prolongator_from_children(self, geom, ed_c, ed_f, nc, ndof_c, ndof_f):
-        """PP of a level from the element prolongator (ElemType.cpp:439-532): fine element nchild e + j is child j of coarse element e; the row of a fine dof
-        holds the coarse shape functions at its place in the father (the same row from every element that shares the dof)"""
-        EP = capi.fe_elem_prolongator(geom, self.fe)
-        nch = EP.shape[0]
+    def _prolongator_from_children(self, groups, ed_c, ed_f, ndof_c, ndof_f):
+        """PP of a level from the element prolongators (ElemType.cpp:439-532): fine element nchild e + j is child j of coarse element e; the row of a fine dof
+        holds the coarse shape functions at its place in the father (the same row from every element that shares the dof).  groups: (shape, coarse elements of
+        that shape, dofs per element)"""
         P = {}
-        for j in range(nch):
-            for n in range(nc):
-                rows = ed_f[j::nch, n]
-                for k in range(nc):
-                    if EP[j, n, k] != 0.0:
-                        for r, c in zip(rows.tolist(), ed_c[:, k].tolist()):
-                            P[(r, c)] = EP[j, n, k]
+        for geom, idx, nc in groups:
+            EP = capi.fe_elem_prolongator(geom, self.fe)
+            nch = EP.shape[0]
+            for j in range(nch):
+                for n in range(nc):
+                    rows = ed_f[nch * idx + j, n]
+                    for k in range(nc):
+                        if EP[j, n, k] != 0.0:
+                            for r, c in zip(rows.tolist(), ed_c[idx, k].tolist()):
+                                P[(r, c)] = EP[j, n, k]
         keys = sorted(P)
         rows = np.array([q[0] for q in keys])
         indptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=ndof_f))])

@@ -772,6 +772,14 @@ def assemble_poisson_rows(ctx, geom, fe, elem_dof, coords, K, res, sol=None, sou
                                         sol.h if sol is not None else None, source.h if source is not None else None, float(scale), K.h, res.h))
 
 
+def assemble_poisson_mixed(ctx, fe, elem_geom, elem_dof, coords, K, res, sol=None, source=None, scale=1.0, order="seventh"):
+    """the same on a mesh of mixed shapes (fh_assemble_poisson_mixed): elem_geom[nel] names of GEOM per element, elem_dof[nel, nloc] padded (the padding is not read)"""
+    eg = _i32(np.array([GEOM[g] for g in elem_geom]))
+    ed, x = _i32(np.where(np.asarray(elem_dof) < 0, 0, elem_dof)), _f64(coords)
+    _chk(ctx.L.fh_assemble_poisson_mixed(ctx.h, FE[fe], GAUSS_ORDER[order], ed.shape[0], ed.shape[1], _p(eg), _p(ed), x.shape[0], _p(x),
+                                         sol.h if sol is not None else None, source.h if source is not None else None, float(scale), K.h, res.h))
+
+
 def assemble_advdiff_line(ctx, fe, elem_dof, coords, K, res, nu, velocity, sol=None, source=None, order="seventh"):
     """the 001_Poisson callback on a one-dimensional EDGE3 mesh (main.cpp:355-480 with dim == 1: advection-diffusion with its streamline-upwind terms):
     K <- Jacobian, res <- residual.  elem_dof[nel, 3] node ids (ends, then middle; vertices numbered first), coords[nnode]"""

@@ -4974,9 +4974,16 @@ extern "C" int fh_assemble_advdiff_line(fh_ctx_t ctx, int fe, int order, int nel
 // hexahedral paths above are the fast ones).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int GEN_NC = 27;
-__global__ __launch_bounds__(64) void k_poisson_rows_generic(int ndof, int dim, int nc, int ng, int nloc, const int* __restrict__ adj_ptr, const int* __restrict__ adj,
+struct GenTab {              // the tables of one element shape: a mesh of mixed shapes (hexahedra, tetrahedra, prisms; quadrilaterals, triangles) names one per element
+  int nc, ng;
+  const double *w, *phi, *dphi;
+};
+struct GenTabs {
+  GenTab t[3];
+};
+__global__ __launch_bounds__(64) void k_poisson_rows_generic(int ndof, int dim, GenTabs tabs, const unsigned char* __restrict__ etab, int nloc,
+                                                             const int* __restrict__ adj_ptr, const int* __restrict__ adj,
                                                              const int* __restrict__ elem_dof, const double* __restrict__ coords, const double* __restrict__ sol,
-                                                             const double* __restrict__ w, const double* __restrict__ phi, const double* __restrict__ dphi,
                                                              double scale, const int* __restrict__ prog, int nprog, const double* __restrict__ pconst,
                                                              const int* __restrict__ rowptr, const int* __restrict__ col, double* __restrict__ val,
                                                              double* __restrict__ res) {
@@ -4987,6 +4994,9 @@ __global__ __launch_bounds__(64) void k_poisson_rows_generic(int ndof, int dim, 
   double racc = 0.0;
   for (int a = adj_ptr[r]; a < adj_ptr[r + 1]; a++) {
     const int e = adj[a] / GEN_NC, i = adj[a] % GEN_NC;
+    const GenTab& T = tabs.t[etab ? etab[e] : 0];
+    const int nc = T.nc, ng = T.ng;
+    const double *w = T.w, *phi = T.phi, *dphi = T.dphi;
     double x[GEN_NC][3], u[GEN_NC], B[GEN_NC], gr[GEN_NC][3];
     int dof[GEN_NC];
     for (int n = 0; n < nc; n++) {
@@ -5056,18 +5066,30 @@ __global__ __launch_bounds__(64) void k_poisson_rows_generic(int ndof, int dim, 
   res[r] = racc;
 }
 
-extern "C" int fh_assemble_poisson_rows(fh_ctx_t ctx, int geom, int fe, int order, int nel, int nloc, const int* elem_dof, int nnode, const double* coords,
-                                        fh_vec_t sol, fh_expr_t source, double scale, fh_mat_t KK, fh_vec_t RES) {
-  FH_GUARD_BEGIN
-  FH_REQUIRE(ctx && elem_dof && coords && KK && RES && nel >= 1 && nnode >= 1, "fh_assemble_poisson_rows: null or empty argument");
-  FH_REQUIRE(geom >= 0 && geom <= 5, "fh_assemble_poisson_rows: geom must be 0 (hex), 1 (quad), 2 (line), 3 (triangle), 4 (tetrahedron) or 5 (prism)");
-  FH_REQUIRE(fe == fhfe::FE_LINEAR || fe == fhfe::FE_SERENDIPITY || fe == fhfe::FE_BIQUADRATIC, "fh_assemble_poisson_rows: fe must be 0, 1 or 2");
-  const int dim = fhfe::dim_of(geom), nc = fhfe::ndofs_of(geom, fe), ndof = KK->m;
-  FH_REQUIRE(nloc >= nc && nc <= GEN_NC, "fh_assemble_poisson_rows: %d nodes per element given, the family has %d", nloc, nc);
+// shapes[ns] (ns <= 3, one dimension), elem_shape[nel] = index into shapes per element (nullptr: every element is shapes[0])
+static int poisson_rows_impl(fh_ctx_t ctx, int ns, const int* shapes, const int* elem_shape, int fe, int order, int nel, int nloc, const int* elem_dof, int nnode,
+                             const double* coords, fh_vec_t sol, fh_expr_t source, double scale, fh_mat_t KK, fh_vec_t RES) {
+  const int dim = fhfe::dim_of(shapes[0]), ndof = KK->m;
+  int ncs[3] = {0, 0, 0};
+  for (int k = 0; k < ns; k++) {
+    FH_REQUIRE(shapes[k] >= 0 && shapes[k] <= 5, "fh_assemble_poisson_rows: geom must be 0 (hex), 1 (quad), 2 (line), 3 (triangle), 4 (tetrahedron) or 5 (prism)");
+    FH_REQUIRE(fhfe::dim_of(shapes[k]) == dim, "fh_assemble_poisson_mixed: the shapes of one mesh have one dimension");
+    ncs[k] = fhfe::ndofs_of(shapes[k], fe);
+    FH_REQUIRE(nloc >= ncs[k] && ncs[k] <= GEN_NC, "fh_assemble_poisson_rows: %d nodes per element given, the family has %d", nloc, ncs[k]);
+  }
   FH_REQUIRE(KK->n == ndof && RES->n_local >= ndof && (!sol || sol->n_local >= ndof), "fh_assemble_poisson_rows: size mismatch");
+  std::vector<unsigned char> etab;
+  if (elem_shape) {
+    etab.resize(nel);
+    for (int e = 0; e < nel; e++) {
+      FH_REQUIRE(elem_shape[e] >= 0 && elem_shape[e] < ns, "fh_assemble_poisson_mixed: element %d names shape %d of %d", e, elem_shape[e], ns);
+      etab[e] = (unsigned char)elem_shape[e];
+    }
+  }
+  auto nc_of = [&](int e) { return ncs[elem_shape ? elem_shape[e] : 0]; };
   std::vector<int> cnt(ndof + 1, 0);
   for (int e = 0; e < nel; e++)
-    for (int n = 0; n < nc; n++) {
+    for (int n = 0; n < nc_of(e); n++) {
       const int d = elem_dof[(size_t)e * nloc + n];
       FH_REQUIRE(d >= 0 && d < ndof && d < nnode, "fh_assemble_poisson_rows: element %d, node %d: dof %d outside the system (the classes are numbered one after the other)", e, n, d);
       cnt[d + 1]++;
@@ -5076,10 +5098,9 @@ extern "C" int fh_assemble_poisson_rows(fh_ctx_t ctx, int geom, int fe, int orde
   std::vector<int> adj(cnt[ndof]), fill(cnt.begin(), cnt.end() - 1);
   FH_REQUIRE((int64_t)nel * GEN_NC < 2147483647ll, "fh_assemble_poisson_rows: too many elements");
   for (int e = 0; e < nel; e++)                         // ascending element order per dof
-    for (int n = 0; n < nc; n++) adj[fill[elem_dof[(size_t)e * nloc + n]]++] = e * GEN_NC + n;
-  std::vector<double> w, phi, dphi;
-  FH_REQUIRE(fhfe::shape_tables(geom, fe, order, w, phi, dphi) == 0, "fh_assemble_poisson_rows: unsupported Gauss rule");
-  const int ng = (int)w.size();
+    for (int n = 0; n < nc_of(e); n++) adj[fill[elem_dof[(size_t)e * nloc + n]]++] = e * GEN_NC + n;
+  std::vector<double> w[3], phi[3], dphi[3];
+  for (int k = 0; k < ns; k++) FH_REQUIRE(fhfe::shape_tables(shapes[k], fe, order, w[k], phi[k], dphi[k]) == 0, "fh_assemble_poisson_rows: unsupported Gauss rule");
   std::vector<int> code;
   std::vector<double> consts;
   if (source) {
@@ -5093,9 +5114,13 @@ extern "C" int fh_assemble_poisson_rows(fh_ctx_t ctx, int geom, int fe, int orde
   }
   hipStream_t st = ctx->stream;
   std::vector<void*> dv;
+  bool oom = false;
   auto up = [&](const void* h, size_t bytes) -> void* {
     void* d = nullptr;
-    if (hipMalloc(&d, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr;
+    if (hipMalloc(&d, std::max<size_t>(bytes, 8)) != hipSuccess) {
+      oom = true;
+      return nullptr;
+    }
     dv.push_back(d);
     if (bytes) hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st);
     return d;
@@ -5104,18 +5129,21 @@ extern "C" int fh_assemble_poisson_rows(fh_ctx_t ctx, int geom, int fe, int orde
   int* d_adj = (int*)up(adj.data(), adj.size() * sizeof(int));
   int* d_ed = (int*)up(elem_dof, (size_t)nel * nloc * sizeof(int));
   double* d_x = (double*)up(coords, (size_t)nnode * dim * sizeof(double));
-  double* d_w = (double*)up(w.data(), w.size() * sizeof(double));
-  double* d_phi = (double*)up(phi.data(), phi.size() * sizeof(double));
-  double* d_dphi = (double*)up(dphi.data(), dphi.size() * sizeof(double));
+  GenTabs tabs;
+  for (int k = 0; k < 3; k++) tabs.t[k] = GenTab{0, 0, nullptr, nullptr, nullptr};
+  for (int k = 0; k < ns; k++)
+    tabs.t[k] = GenTab{ncs[k], (int)w[k].size(), (const double*)up(w[k].data(), w[k].size() * sizeof(double)), (const double*)up(phi[k].data(), phi[k].size() * sizeof(double)),
+                       (const double*)up(dphi[k].data(), dphi[k].size() * sizeof(double))};
+  unsigned char* d_etab = elem_shape ? (unsigned char*)up(etab.data(), etab.size()) : nullptr;
   int* d_code = source ? (int*)up(code.data(), code.size() * sizeof(int)) : nullptr;
   double* d_k = source ? (double*)up(consts.data(), consts.size() * sizeof(double)) : nullptr;
   int rc = 0;
-  if (!d_ptr || !d_adj || !d_ed || !d_x || !d_w || !d_phi || !d_dphi || (source && (!d_code || !d_k))) {
+  if (oom) {
     fh_set_error("fh_assemble_poisson_rows: out of device memory");
     rc = 2;
   } else {
-    hipLaunchKernelGGL(k_poisson_rows_generic, dim3(fh_div_up(ndof, 64)), dim3(64), 0, st, ndof, dim, nc, ng, nloc, d_ptr, d_adj, d_ed, d_x, sol ? sol->d : nullptr, d_w,
-                       d_phi, d_dphi, scale, d_code, (int)code.size(), d_k, KK->d_rowptr, KK->d_col, KK->d_val, RES->d);
+    hipLaunchKernelGGL(k_poisson_rows_generic, dim3(fh_div_up(ndof, 64)), dim3(64), 0, st, ndof, dim, tabs, d_etab, nloc, d_ptr, d_adj, d_ed, d_x, sol ? sol->d : nullptr, scale,
+                       d_code, (int)code.size(), d_k, KK->d_rowptr, KK->d_col, KK->d_val, RES->d);
     if (hipGetLastError() != hipSuccess) {
       fh_set_error("fh_assemble_poisson_rows: launch failed");
       rc = 2;
@@ -5126,5 +5154,38 @@ extern "C" int fh_assemble_poisson_rows(fh_ctx_t ctx, int geom, int fe, int orde
   hipStreamSynchronize(st);
   for (void* q : dv) hipFree(q);
   return rc;
+}
+
+extern "C" int fh_assemble_poisson_rows(fh_ctx_t ctx, int geom, int fe, int order, int nel, int nloc, const int* elem_dof, int nnode, const double* coords,
+                                        fh_vec_t sol, fh_expr_t source, double scale, fh_mat_t KK, fh_vec_t RES) {
+  FH_GUARD_BEGIN
+  FH_REQUIRE(ctx && elem_dof && coords && KK && RES && nel >= 1 && nnode >= 1, "fh_assemble_poisson_rows: null or empty argument");
+  FH_REQUIRE(geom >= 0 && geom <= 5, "fh_assemble_poisson_rows: geom must be 0 (hex), 1 (quad), 2 (line), 3 (triangle), 4 (tetrahedron) or 5 (prism)");
+  FH_REQUIRE(fe == fhfe::FE_LINEAR || fe == fhfe::FE_SERENDIPITY || fe == fhfe::FE_BIQUADRATIC, "fh_assemble_poisson_rows: fe must be 0, 1 or 2");
+  return poisson_rows_impl(ctx, 1, &geom, nullptr, fe, order, nel, nloc, elem_dof, nnode, coords, sol, source, scale, KK, RES);
   FH_GUARD_END("fh_assemble_poisson_rows")
+}
+
+// The same on a mesh of MIXED shapes (cube_all_shapes*.neu of applications/001_Poisson: hexahedra, tetrahedra and prisms in one file): elem_geom[nel] names the
+// shape of every element (at most three different ones, of one dimension); rows of elem_dof padded to nloc.  The entries of a row are summed in ascending element
+// order whatever the shapes, as the reference's element loop does.
+extern "C" int fh_assemble_poisson_mixed(fh_ctx_t ctx, int fe, int order, int nel, int nloc, const int* elem_geom, const int* elem_dof, int nnode, const double* coords,
+                                         fh_vec_t sol, fh_expr_t source, double scale, fh_mat_t KK, fh_vec_t RES) {
+  FH_GUARD_BEGIN
+  FH_REQUIRE(ctx && elem_geom && elem_dof && coords && KK && RES && nel >= 1 && nnode >= 1, "fh_assemble_poisson_mixed: null or empty argument");
+  FH_REQUIRE(fe == fhfe::FE_LINEAR || fe == fhfe::FE_SERENDIPITY || fe == fhfe::FE_BIQUADRATIC, "fh_assemble_poisson_mixed: fe must be 0, 1 or 2");
+  int shapes[3], ns = 0;
+  std::vector<int> idx(nel);
+  for (int e = 0; e < nel; e++) {
+    int k = 0;
+    while (k < ns && shapes[k] != elem_geom[e]) k++;
+    if (k == ns) {
+      FH_REQUIRE(ns < 3, "fh_assemble_poisson_mixed: more than three shapes in one mesh");
+      FH_REQUIRE(elem_geom[e] >= 0 && elem_geom[e] <= 5, "fh_assemble_poisson_mixed: element %d: shape %d", e, elem_geom[e]);
+      shapes[ns++] = elem_geom[e];
+    }
+    idx[e] = k;
+  }
+  return poisson_rows_impl(ctx, ns, shapes, idx.data(), fe, order, nel, nloc, elem_dof, nnode, coords, sol, source, scale, KK, RES);
+  FH_GUARD_END("fh_assemble_poisson_mixed")
 }

@@ -1,0 +1,179 @@
+"""Meshes of mixed shapes (applications/001_Poisson: input3D.json / input3D_All_first.json with input/cube_all_shapes_Six_boundary_groups.neu -- ten tetrahedra, six
+prisms and four hexahedra in one Gambit file, a data file of the application kept in tests/golden).  CPU: the oracle restatement
+(oracle/femus_oracle_mixed.py) -- reader / refinement properties, the product's host-side mesh code equal to it.  GPU: the mixed generic kernel and the face integrals
+against the oracle entry for entry, and the shipped inputs through app_poisson against the oracle's direct solve."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import femus_oracle_mixed as om
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MESH = os.path.join(HERE, "golden", "cube_all_shapes_Six_boundary_groups.neu")
+gpu = pytest.mark.gpu
+
+
+def volume(kind, ed, xs):
+    """the integral of 1 with each element's own tables (the reference's tetrahedron weights sum to 1/6 - 1.07e-9: the cube of tetrahedra alone would miss 6.4e-9)"""
+    vol = 0.0
+    for s in set(kind.tolist()):
+        w, _, DPHI = om.tables(s, "biquadratic")
+        for e in np.nonzero(kind == s)[0]:
+            x = xs[ed[e, :om.NLOC[s]]]
+            dets = np.array([np.linalg.det(DPHI[g].T @ x) for g in range(len(w))])
+            assert dets.min() > 0
+            vol += float(dets @ w)
+    return vol
+
+
+def test_the_mesh_file_is_the_application_s():
+    ref_file = "/root/reference/applications/001_Poisson/input/cube_all_shapes_Six_boundary_groups.neu"
+    if not os.path.exists(ref_file):
+        pytest.skip("the reference tree is not here")
+    assert open(ref_file, "rb").read() == open(MESH, "rb").read()
+
+
+def test_oracle_reader_and_refinement_and_the_product_s_mesh_code():
+    """the file: 10 TET10 + 6 WEDGE18 + 4 HEX27 elements filling the unit cube, positively oriented, 131 nodes + 32 triangle-face nodes (those between a tetrahedron
+    and a prism shared) + 16 centres, six boundary sets of five faces; edge nodes at the middles; refined twice: eight times the elements, the same volume, four
+    times the faces per set, flagged faces on the cube's surface; femus_amd/mixed_mesh.py gives the same integers (and coordinates to rounding) on three levels"""
+    from femus_amd import mixed_mesh
+    kind, ed, xs, ff, own = om.read_gambit(MESH)
+    assert [(kind == s).sum() for s in ("tet", "wedge", "hex")] == [10, 6, 4] and own == [28, 97, 179]
+    assert abs(volume(kind, ed, xs) - 1.0) < 1e-8
+    for e in range(20):
+        s = kind[e]
+        nv = om.CLASSES[s][0]
+        assert np.all(ed[e, :om.NLOC[s]] >= 0) and np.all(ed[e, om.NLOC[s]:] == -1)
+        for m, (a, b) in enumerate(om.EDGE[s]):
+            assert np.allclose(xs[ed[e, nv + m]], 0.5 * (xs[ed[e, a]] + xs[ed[e, b]]), atol=1e-11)
+        for f in range(len(om.FACE[s])):
+            assert np.allclose(xs[ed[e, om.FACE_LOCAL[s][f]]], xs[ed[e, om.FACE[s][f][:om.NVF[s][f]]]].mean(axis=0), atol=1e-11)
+    # a triangle between a tetrahedron and a prism carries ONE node
+    tri_nodes = {}
+    for e in range(20):
+        for f in range(len(om.FACE[kind[e]])):
+            if om.NVF[kind[e]][f] == 3:
+                tri_nodes.setdefault(int(ed[e, om.FACE_LOCAL[kind[e]][f]]), set()).add(kind[e])
+    assert len(tri_nodes) == 32 and any(v == {"tet", "wedge"} for v in tri_nodes.values())
+    assert [(ff == f).sum() for f in range(-7, -1)] == [5] * 6
+    a, b = mixed_mesh.read_gambit(MESH), (kind, ed, xs, ff, own)
+    for level in range(3):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3]) and a[4] == b[4]
+        assert np.array_equal(a[2], b[2]) if level == 0 else np.abs(a[2] - b[2]).max() < 2e-15
+        if level == 2:
+            break
+        a, b = mixed_mesh.refine(*a[:4]), om.refine(*b[:4])
+        kf, ef, xf, fff, _ = b
+        assert ef.shape[0] == 20 * 8 ** (level + 1) and abs(volume(kf, ef, xf) - 1.0) < 1e-8
+        assert [(fff == f).sum() for f in range(-7, -1)] == [5 * 4 ** (level + 1)] * 6
+        for e, f in zip(*np.nonzero(fff < -1)):
+            x = xf[ef[e, om.FACE[kf[e]][f][:om.NVF[kf[e]][f]]]]
+            assert any(np.all(np.abs(x[:, d] - v) < 1e-14) for d in range(3) for v in (0.0, 1.0))
+
+
+@gpu
+@pytest.mark.parametrize("fe", ["linear", "serendipity", "biquadratic"])
+def test_mixed_kernel_and_face_integrals_match_the_oracle(ctx, fe):
+    """fh_assemble_poisson_mixed on the refined mesh of three shapes, nodes moved (curved geometry), at a non-trivial state; fh_assemble_neumann_faces on its flagged
+    triangles and quadrilaterals: against the oracle's loops, 1e-12"""
+    from femus_amd import capi
+    kind, ed, xs, ff, own = om.refine(*om.read_gambit(MESH)[:4])
+    xs = xs + 0.01 * np.sin(5 * xs[:, [1, 2, 0]]) * (xs * (1 - xs)).prod(axis=1, keepdims=True) * 60
+    ndof = om.n_dofs(own, fe)
+    u = np.random.default_rng(11).uniform(-1, 1, ndof)
+    Ko, Fo = om.assemble(kind, ed, xs, fe, lambda x: np.exp(x[0]) * (1 + x[1]) - x[2], u)
+    import scipy.sparse as sp
+    pat = sp.csr_matrix(Ko)
+    pat.sort_indices()
+    K = capi.Mat.from_csr(ctx, ndof, ndof, pat.indptr, pat.indices)
+    RES, SOL = ctx.vector(ndof), ctx.vector_from(u)
+    f = capi.Expr("exp(x)*(1+y)-z", "x,y,z,t")
+    capi.assemble_poisson_mixed(ctx, fe, kind, ed, xs, K, RES, sol=SOL, source=f)
+    assert abs(K.to_scipy() - Ko).max() <= 1e-12 * abs(Ko).max()
+    assert np.abs(RES.to_numpy() - Fo).max() <= 1e-12 * np.abs(Fo).max()
+    fno = om.neumann(kind, ed, xs, ff, fe, {-4: 0.2, -6: -1.5}, ndof)
+    R2 = ctx.vector(ndof)
+    for nv, name in ((3, "triface"), (4, "quadface")):
+        faces, taus = [], []
+        for e, fl in zip(*np.nonzero(ff < -1)):
+            if ff[e, fl] in (-4, -6) and om.NVF[kind[e]][fl] == nv:
+                faces.append(ed[e, om.FACE[kind[e]][fl][:om.NFN[nv][fe]]])
+                taus.append(0.2 if ff[e, fl] == -4 else -1.5)
+        if faces:
+            capi.assemble_neumann_faces(ctx, name, fe, np.array(faces), np.array(taus), xs, R2)
+    assert np.abs(R2.to_numpy() - fno).max() <= 1e-13 * np.abs(fno).max() + 1e-16
+    f.destroy()
+    K.destroy()
+
+
+def _shipped(fe_order, nlevels=4):
+    return """
+{
+    "multilevel_mesh" : { "first" : { "type" : { "filename" : "input/cube_all_shapes_Six_boundary_groups.neu" } } },
+    "multilevel_solution" : { "multilevel_mesh" : { "first" : { "variable" : { "first" : {
+              "name" : "T", "fe_order" : "%s", "init_func" : "0.", "func_source": "0.",
+              "boundary_conditions" : [ { "facename" : "top", "bdc_type" : "dirichlet" },
+                                        { "facename" : "right", "bdc_type" : "neumann", "bdc_func" : "0.2" } ] } } } } },
+    "multilevel_problem" : { "multilevel_mesh" : { "first" : { "system" : { "poisson" : { "linear_solver" : {
+                "max_number_linear_iteration" : 6, "abs_conv_tol" : 1.e-09,
+                "type" : { "multigrid" : { "nlevels" : %d, "npresmoothing" : 1, "npostsmoothing" : 1, "mgtype" : "V_cycle",
+                    "smoother" : { "type" : { "gmres" : { "ksp" : "gmres", "precond" : "ilu", "rtol" : 1.e-12, "atol" : 1.e-20, "divtol" : 1.e+50,
+                                                          "max_its" : 4 } } } } } } } } } } }
+}
+""" % (fe_order, nlevels)
+
+
+@pytest.mark.parametrize("name,fe_order", [("input3D_All_first.json", "first"), ("input3D.json", "second")])
+def test_the_configurations_below_are_the_shipped_files(name, fe_order):
+    from femus_amd import app_poisson as app
+    ref_file = "/root/reference/applications/001_Poisson/input/" + name
+    if not os.path.exists(ref_file):
+        pytest.skip("the reference tree is not here")
+    assert app.load_config(ref_file) == app.load_config(_shipped(fe_order))
+
+
+@gpu
+@pytest.mark.parametrize("fe_order,fe,nlevels", [("first", "linear", 4), ("serendipity", "serendipity", 3), ("second", "biquadratic", 3)])
+def test_the_shipped_mixed_shape_inputs_of_001_poisson(ctx, tmp_path, fe_order, fe, nlevels):
+    """applications/001_Poisson/input/input3D_All_first.json (four levels, as shipped) and input3D.json (second order; compared on three of its four levels: the
+    oracle's direct solve of the fourth takes minutes), and the serendipity family on the same mesh, through app_poisson on the GPU -- SetBoundaryCondition of
+    main.cpp:26-36: Dirichlet 0 everywhere but face 3, which carries the flux 0.2 -- against the oracle's direct solve of the finest level's problem"""
+    from femus_amd import app_poisson as app
+    os.makedirs(tmp_path / "input")
+    (tmp_path / "input" / os.path.basename(MESH)).write_bytes(open(MESH, "rb").read())
+    p = app.Poisson001(ctx, _shipped(fe_order, nlevels), base_dir=str(tmp_path))
+    assert p.mixed and p.fe == fe and p.nlevels == nlevels
+    out = p.run()
+    assert out["converged"] and len(out["history"]) <= 7, out["history"]
+    ref, meshes = om.solve(om.read_gambit(MESH), nlevels, fe, lambda x: 0.0, dirichlet_flags=(-2, -3, -5, -6, -7), flux_by_flag={-4: 0.2})
+    for (ed_p, xs_p, ff_p), (_, ed_o, xs_o, ff_o, _) in zip(out["levels"], meshes):
+        assert np.array_equal(ed_p, ed_o) and np.array_equal(ff_p, ff_o) and np.abs(xs_p - xs_o).max() < 2e-15
+    assert out["dofs"] == ref.size and np.abs(ref).max() > 1e-3
+    assert np.abs(out["solution"] - ref).max() < 1e-8
+    p.max_linear, p.abs_tol = 40, 1e-13
+    out = p.run()
+    assert out["converged"] and np.abs(out["solution"] - ref).max() < 1e-10
+    p.destroy()
+
+
+@gpu
+def test_input3d_json_on_all_of_its_four_levels(ctx, tmp_path):
+    """input3D.json exactly as shipped (second order, four levels: 10 240 elements of three shapes): converges under the input's own limits; its solution at the nodes
+    of the three-level problem stays within the discretisation error of that problem's solution"""
+    from femus_amd import app_poisson as app
+    import scipy.spatial
+    os.makedirs(tmp_path / "input")
+    (tmp_path / "input" / os.path.basename(MESH)).write_bytes(open(MESH, "rb").read())
+    p4 = app.Poisson001(ctx, _shipped("second", 4), base_dir=str(tmp_path))
+    out4 = p4.run()
+    assert out4["converged"] and len(out4["history"]) <= 7, out4["history"]
+    assert out4["levels"][-1][0].shape[0] == 20 * 8 ** 3
+    p3 = app.Poisson001(ctx, _shipped("second", 3), base_dir=str(tmp_path))
+    out3 = p3.run()
+    d, idx = scipy.spatial.cKDTree(out4["coords"]).query(out3["coords"])
+    assert d.max() < 1e-12
+    assert np.abs(out4["solution"][idx] - out3["solution"]).max() < 0.1 * np.abs(out3["solution"]).max()
+    p3.destroy()
+    p4.destroy()
