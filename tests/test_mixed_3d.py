@@ -177,3 +177,57 @@ def test_input3d_json_on_all_of_its_four_levels(ctx, tmp_path):
     assert np.abs(out4["solution"][idx] - out3["solution"]).max() < 0.1 * np.abs(out3["solution"]).max()
     p3.destroy()
     p4.destroy()
+
+
+@gpu
+@pytest.mark.parametrize("fe", ["linear", "serendipity", "biquadratic"])
+def test_mixed_kernel_in_two_dimensions_a_quadrilateral_beside_two_triangles(ctx, fe):
+    """fh_assemble_poisson_mixed with geom 1 (QUAD9) and 3 (TRI7) in one mesh -- the unit square as one quadrilateral and two triangles sharing curved edges --
+    against an element loop over the oracles' tables of each shape (1e-12); then the shapes the call refuses"""
+    from femus_amd import capi
+    from oracle import femus_oracle as fo, femus_oracle_tri as ot
+    xs = np.array([[0, 0], [.5, 0], [.5, 1], [0, 1], [1, 0], [1, 1], [.25, 0], [.53, .5], [.25, 1], [0, .5], [.75, 0], [.77, .52], [1, .5], [.75, 1],
+                   [.26, .51], [.68, .17], [.84, .66]], dtype=float)
+    kind = np.array(["quad", "tri", "tri"])
+    ed = np.full((3, 9), -1, dtype=np.int64)
+    ed[0] = [0, 1, 2, 3, 6, 7, 8, 9, 14]
+    ed[1, :7] = [1, 4, 2, 10, 11, 7, 15]
+    ed[2, :7] = [4, 5, 2, 12, 13, 11, 16]
+    fam = {"linear": 0, "serendipity": 1, "biquadratic": 2}[fe]
+    ncs = {"quad": (4, 8, 9)[fam], "tri": (3, 6, 7)[fam]}
+    ndof = (6, 14, 17)[fam]
+    wq, xq = fo.gauss_table("quad", "seventh")
+    xq = np.asarray(xq)
+    xq = xq.T if (xq.shape[0] == 2 and xq.shape[1] != 2) else xq
+    outq = fo.eval_basis("quad", fe, xq)
+    wt, xt = ot.gauss("seventh")
+    T = {"quad": (np.asarray(wq), outq[0], outq[1]), "tri": (wt,) + tuple(ot.basis(fe, xt))}
+    u = np.random.default_rng(5).uniform(-1, 1, ndof)
+    src = lambda x: 1.0 + x[0] * x[1]
+    Ko, Fo = np.zeros((ndof, ndof)), np.zeros(ndof)
+    for e in range(3):
+        w, PHI, DPHI = T[kind[e]]
+        dof = ed[e, :ncs[kind[e]]]
+        x = xs[dof]
+        for g in range(len(w)):
+            J = DPHI[g].T @ x
+            det = np.linalg.det(J)
+            assert det > 0
+            grad = DPHI[g] @ np.linalg.inv(J).T
+            Ko[np.ix_(dof, dof)] += (grad @ grad.T) * det * w[g]
+            Fo[dof] += (src(PHI[g] @ x) * PHI[g] - grad @ (grad.T @ u[dof])) * det * w[g]
+    import scipy.sparse as sp
+    pat = sp.csr_matrix((np.abs(Ko) > 0).astype(float) + np.eye(ndof))
+    pat.sort_indices()
+    K = capi.Mat.from_csr(ctx, ndof, ndof, pat.indptr, pat.indices)
+    RES, SOL = ctx.vector(ndof), ctx.vector_from(u)
+    f = capi.Expr("1+x*y", "x,y,z,t")
+    capi.assemble_poisson_mixed(ctx, fe, kind, ed, xs, K, RES, sol=SOL, source=f)
+    assert abs(K.to_scipy().toarray() - Ko).max() <= 1e-12 * abs(Ko).max()
+    assert np.abs(RES.to_numpy() - Fo).max() <= 1e-12 * np.abs(Fo).max()
+    with pytest.raises(capi.FemusHipError, match="one dimension"):
+        capi.assemble_poisson_mixed(ctx, fe, np.array(["quad", "tet", "tri"]), ed, xs, K, RES)
+    with pytest.raises(capi.FemusHipError, match="more than three shapes"):
+        capi.assemble_poisson_mixed(ctx, fe, np.array(["hex", "tet", "wedge", "quad"]), np.zeros((4, 27), dtype=np.int64), np.zeros((40, 3)), K, RES)
+    f.destroy()
+    K.destroy()
