@@ -12,7 +12,7 @@ extra = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 ctx = femus_amd.Context(0)
 out = {}
 ref = None
-for carry in (0, 3, 6, -1):
+for carry in ([int(c) for c in os.environ["CARRY_LIST"].split(",")] if "CARRY_LIST" in os.environ else (0, 3, 6, -1)):
     ctx.set_option("assemble_carry", carry)
     pb = PoissonMG(ctx, 8, 8, 8, levels).init()
     fi = pb.asm[-1].fused_info()

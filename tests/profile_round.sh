@@ -105,3 +105,4 @@ python $ROOT/tests/dev/probe12.py 2>&1 | grep -A11 "k_galerkin_macro phase" > $O
 python $ROOT/tests/perf_probe_setup.py --device 2> /dev/null | sed -n '/^{/,$p' > $OUT/${TAG}_setup_probe.json
 python $ROOT/tests/perf_probe_setup.py 2> /dev/null | sed -n '/^{/,$p' > $OUT/${TAG}_setup_probe_host_refinement.json
 python $ROOT/tests/perf_probe_direct_general.py > $OUT/${TAG}_direct_general_probe.txt 2>&1
+python $ROOT/tests/perf_probe_shipped_inputs.py 2> /dev/null | sed -n '/^{/,$p' > $OUT/${TAG}_shipped_inputs_probe.json
