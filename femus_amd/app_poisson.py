@@ -391,21 +391,23 @@ class Poisson001:
         """PP of a level from the element prolongators (ElemType.cpp:439-532): fine element nchild e + j is child j of coarse element e; the row of a fine dof
         holds the coarse shape functions at its place in the father (the same row from every element that shares the dof).  groups: (shape, coarse elements of
         that shape, dofs per element)"""
-        P = {}
-        for geom, idx, nc in groups:
+        rows_l, cols_l, vals_l = [], [], []
+        for geom, idx, nc in groups:                                # the order of ElemType.cpp's insertions: child, fine node, coarse function, element
             EP = capi.fe_elem_prolongator(geom, self.fe)
             nch = EP.shape[0]
             for j in range(nch):
                 for n in range(nc):
                     rows = ed_f[nch * idx + j, n]
-                    for k in range(nc):
-                        if EP[j, n, k] != 0.0:
-                            for r, c in zip(rows.tolist(), ed_c[idx, k].tolist()):
-                                P[(r, c)] = EP[j, n, k]
-        keys = sorted(P)
-        rows = np.array([q[0] for q in keys])
+                    for k in np.nonzero(EP[j, n, :nc])[0]:
+                        rows_l.append(rows)
+                        cols_l.append(ed_c[idx, k])
+                        vals_l.append(np.full(rows.size, EP[j, n, k]))
+        rows, cols, vals = np.concatenate(rows_l).astype(np.int64), np.concatenate(cols_l).astype(np.int64), np.concatenate(vals_l)
+        key = (rows * ndof_c + cols)[::-1]                          # INSERT_VALUES: the last insertion of an entry stays
+        uniq, last = np.unique(key, return_index=True)
+        rows, cols, vals = uniq // ndof_c, uniq % ndof_c, vals[::-1][last]
         indptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=ndof_f))])
-        return capi.Mat.from_csr(self.ctx, ndof_f, ndof_c, indptr, np.array([q[1] for q in keys]), np.array([P[q] for q in keys]))
+        return capi.Mat.from_csr(self.ctx, ndof_f, ndof_c, indptr, cols, vals)
 
     # ---- the one-dimensional input (input/input1D.json: EDGE3 box) -------------------------------------------------------------------------------
     NU_1D, V_1D = 0.01, 1.0                      # main.cpp:392-395: in one dimension the callback is advection-diffusion with V = 1, nu = 0.01
