@@ -4931,7 +4931,7 @@ extern "C" int fh_assemble_advdiff_line(fh_ctx_t ctx, int fe, int order, int nel
     void* d = nullptr;
     if (hipMalloc(&d, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr;
     dv.push_back(d);
-    if (bytes) hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st);
+    if (bytes && h) hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st);
     return d;
   };
   int* d_ptr = (int*)up(cnt.data(), cnt.size() * sizeof(int));
@@ -4967,8 +4967,9 @@ extern "C" int fh_assemble_advdiff_line(fh_ctx_t ctx, int fe, int order, int nel
 // ------------------------------------------------------------------------------------------------------------------
 // The Poisson callback through a GENERIC (dim, nc, ng) kernel (round 6): any element family fh_fe has tables for -- the triangle (geom 3) first, whose meshes
 // do not go through the tensor-product mesh layer -- with the element table given by the caller (nloc nodes per element in the family's local order; dof id =
-// node id, the classes numbered one after the other as every FEMuS mesh is).  One thread per ROW walks the elements of its node in ascending order and forms its
-// row of each element matrix over the Gauss points (elem_type::Jacobian: Jac[a][b] = sum_n dphi_n/dxi_a x_n[b], grad phi_n = Jac^-1 dphi_n, w = det w_g):
+// node id, the classes numbered one after the other as every FEMuS mesh is).  Two passes: one thread per (element, local row) forms that row of the element
+// matrix over the Gauss points (elem_type::Jacobian: Jac[a][b] = sum_n dphi_n/dxi_a x_n[b], grad phi_n = Jac^-1 dphi_n, w = det w_g) into a buffer; one thread per
+// ROW then adds the rows of its node's elements in ascending element order (first version: the row thread formed them itself -- 80 instead of 37 ms per call on 54 k TET15 elements, host preparation included):
 //   K_ij += grad phi_i . grad phi_j w,   RES_i += (scale f phi_i - grad phi_i . grad u) w        (main.cpp:430-470 with V = 0)
 // The grouping of the reference's add_matrix_blocked / add_vector_blocked, no atomics; meant for the sizes such meshes have here, not for the bench (the
 // hexahedral paths above are the fast ones).
@@ -4981,12 +4982,85 @@ struct GenTab {              // the tables of one element shape: a mesh of mixed
 struct GenTabs {
   GenTab t[3];
 };
-__global__ __launch_bounds__(64) void k_poisson_rows_generic(int ndof, int dim, GenTabs tabs, const unsigned char* __restrict__ etab, int nloc,
-                                                             const int* __restrict__ adj_ptr, const int* __restrict__ adj,
-                                                             const int* __restrict__ elem_dof, const double* __restrict__ coords, const double* __restrict__ sol,
-                                                             double scale, const int* __restrict__ prog, int nprog, const double* __restrict__ pconst,
-                                                             const int* __restrict__ rowptr, const int* __restrict__ col, double* __restrict__ val,
-                                                             double* __restrict__ res) {
+// First pass: one thread per (element, local row i) -- row i of the element matrix into Kb[(e * ncmax + i) * ncmax + j], its residual entry into Fb[e * ncmax + i].
+__global__ __launch_bounds__(64) void k_poisson_pairs_generic(int nel, int ncmax, int dim, GenTabs tabs, const unsigned char* __restrict__ etab, int nloc,
+                                                              const int* __restrict__ elem_dof, const double* __restrict__ coords, const double* __restrict__ sol,
+                                                              double scale, const int* __restrict__ prog, int nprog, const double* __restrict__ pconst,
+                                                              double* __restrict__ Kb, double* __restrict__ Fb) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= nel * ncmax) return;
+  const int e = t / ncmax, i = t - e * ncmax;
+  const GenTab& T = tabs.t[etab ? etab[e] : 0];
+  const int nc = T.nc, ng = T.ng;
+  if (i >= nc) return;
+  const double *w = T.w, *phi = T.phi, *dphi = T.dphi;
+  double x[GEN_NC][3], u[GEN_NC], B[GEN_NC], gr[GEN_NC][3];
+  for (int n = 0; n < nc; n++) {
+    const int dof = elem_dof[(size_t)e * nloc + n];
+    for (int d = 0; d < dim; d++) x[n][d] = coords[(size_t)dof * dim + d];
+    u[n] = sol ? sol[dof] : 0.0;
+    B[n] = 0.0;
+  }
+  double F = 0.0;
+  for (int g = 0; g < ng; g++) {
+    const double* dp = dphi + (size_t)g * nc * dim;
+    double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Ji[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, det;
+    for (int n = 0; n < nc; n++)
+      for (int p = 0; p < dim; p++)
+        for (int q = 0; q < dim; q++) J[p][q] += dp[n * dim + p] * x[n][q];
+    if (dim == 1) {
+      det = J[0][0];
+      Ji[0][0] = 1 / det;
+    } else if (dim == 2) {
+      det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+      Ji[0][0] = J[1][1] / det;
+      Ji[0][1] = -J[0][1] / det;
+      Ji[1][0] = -J[1][0] / det;
+      Ji[1][1] = J[0][0] / det;
+    } else {
+      det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[1][2] * J[2][0] - J[1][0] * J[2][2]) + J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+      Ji[0][0] = (-J[1][2] * J[2][1] + J[1][1] * J[2][2]) / det;
+      Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+      Ji[0][2] = (-J[0][2] * J[1][1] + J[0][1] * J[1][2]) / det;
+      Ji[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) / det;
+      Ji[1][1] = (-J[0][2] * J[2][0] + J[0][0] * J[2][2]) / det;
+      Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+      Ji[2][0] = (-J[1][1] * J[2][0] + J[1][0] * J[2][1]) / det;
+      Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+      Ji[2][2] = (-J[0][1] * J[1][0] + J[0][0] * J[1][1]) / det;
+    }
+    const double weight = det * w[g];
+    double gu[3] = {0, 0, 0}, xq[4] = {0, 0, 0, 0};
+    for (int n = 0; n < nc; n++) {
+      const double ph = phi[(size_t)g * nc + n];
+      for (int q = 0; q < dim; q++) {
+        double sacc = 0.0;
+        for (int p = 0; p < dim; p++) sacc += Ji[q][p] * dp[n * dim + p];
+        gr[n][q] = sacc;
+        gu[q] += sacc * u[n];
+        xq[q] += x[n][q] * ph;
+      }
+    }
+    const double f = prog ? scale * fh_expr_device_eval(prog, nprog, pconst, xq) : 0.0;
+    double lap = 0.0;
+    for (int q = 0; q < dim; q++) lap += gr[i][q] * gu[q];
+    F += (f * phi[(size_t)g * nc + i] - lap) * weight;
+    for (int j = 0; j < nc; j++) {
+      double sacc = 0.0;
+      for (int q = 0; q < dim; q++) sacc += gr[i][q] * gr[j][q];
+      B[j] += sacc * weight;
+    }
+  }
+  double* out = Kb + (size_t)t * ncmax;
+  for (int j = 0; j < nc; j++) out[j] = B[j];
+  Fb[t] = F;
+}
+
+// Second pass: one thread per row, its (element, local row) pairs in ascending element order -- the order of the reference's element loop.
+__global__ __launch_bounds__(64) void k_poisson_rows_generic(int ndof, int ncmax, GenTabs tabs, const unsigned char* __restrict__ etab, int nloc,
+                                                             const int* __restrict__ adj_ptr, const int* __restrict__ adj, const int* __restrict__ elem_dof,
+                                                             const double* __restrict__ Kb, const double* __restrict__ Fb, const int* __restrict__ rowptr,
+                                                             const int* __restrict__ col, double* __restrict__ val, double* __restrict__ res) {
   const int r = blockIdx.x * 64 + threadIdx.x;
   if (r >= ndof) return;
   const int rs = rowptr[r], re = rowptr[r + 1];
@@ -4994,74 +5068,18 @@ __global__ __launch_bounds__(64) void k_poisson_rows_generic(int ndof, int dim, 
   double racc = 0.0;
   for (int a = adj_ptr[r]; a < adj_ptr[r + 1]; a++) {
     const int e = adj[a] / GEN_NC, i = adj[a] % GEN_NC;
-    const GenTab& T = tabs.t[etab ? etab[e] : 0];
-    const int nc = T.nc, ng = T.ng;
-    const double *w = T.w, *phi = T.phi, *dphi = T.dphi;
-    double x[GEN_NC][3], u[GEN_NC], B[GEN_NC], gr[GEN_NC][3];
-    int dof[GEN_NC];
-    for (int n = 0; n < nc; n++) {
-      dof[n] = elem_dof[(size_t)e * nloc + n];
-      for (int d = 0; d < dim; d++) x[n][d] = coords[(size_t)dof[n] * dim + d];
-      u[n] = sol ? sol[dof[n]] : 0.0;
-      B[n] = 0.0;
-    }
-    double F = 0.0;
-    for (int g = 0; g < ng; g++) {
-      const double* dp = dphi + (size_t)g * nc * dim;
-      double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Ji[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, det;
-      for (int n = 0; n < nc; n++)
-        for (int p = 0; p < dim; p++)
-          for (int q = 0; q < dim; q++) J[p][q] += dp[n * dim + p] * x[n][q];
-      if (dim == 1) {
-        det = J[0][0];
-        Ji[0][0] = 1 / det;
-      } else if (dim == 2) {
-        det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-        Ji[0][0] = J[1][1] / det;
-        Ji[0][1] = -J[0][1] / det;
-        Ji[1][0] = -J[1][0] / det;
-        Ji[1][1] = J[0][0] / det;
-      } else {
-        det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[1][2] * J[2][0] - J[1][0] * J[2][2]) + J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
-        Ji[0][0] = (-J[1][2] * J[2][1] + J[1][1] * J[2][2]) / det;
-        Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
-        Ji[0][2] = (-J[0][2] * J[1][1] + J[0][1] * J[1][2]) / det;
-        Ji[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) / det;
-        Ji[1][1] = (-J[0][2] * J[2][0] + J[0][0] * J[2][2]) / det;
-        Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
-        Ji[2][0] = (-J[1][1] * J[2][0] + J[1][0] * J[2][1]) / det;
-        Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
-        Ji[2][2] = (-J[0][1] * J[1][0] + J[0][0] * J[1][1]) / det;
-      }
-      const double weight = det * w[g];
-      double gu[3] = {0, 0, 0}, xq[4] = {0, 0, 0, 0};
-      for (int n = 0; n < nc; n++) {
-        const double ph = phi[(size_t)g * nc + n];
-        for (int q = 0; q < dim; q++) {
-          double s = 0.0;
-          for (int p = 0; p < dim; p++) s += Ji[q][p] * dp[n * dim + p];
-          gr[n][q] = s;
-          gu[q] += s * u[n];
-          xq[q] += x[n][q] * ph;
-        }
-      }
-      const double f = prog ? scale * fh_expr_device_eval(prog, nprog, pconst, xq) : 0.0;
-      double lap = 0.0;
-      for (int q = 0; q < dim; q++) lap += gr[i][q] * gu[q];
-      F += (f * phi[(size_t)g * nc + i] - lap) * weight;
-      for (int j = 0; j < nc; j++) {
-        double s = 0.0;
-        for (int q = 0; q < dim; q++) s += gr[i][q] * gr[j][q];
-        B[j] += s * weight;
-      }
-    }
-    racc += F;
-    for (int j = 0; j < nc; j++)
+    const int nc = tabs.t[etab ? etab[e] : 0].nc;
+    const size_t pr = (size_t)e * ncmax + i;
+    racc += Fb[pr];
+    const double* B = Kb + pr * ncmax;
+    for (int j = 0; j < nc; j++) {
+      const int dj = elem_dof[(size_t)e * nloc + j];
       for (int k = rs; k < re; k++)
-        if (col[k] == dof[j]) {
+        if (col[k] == dj) {
           val[k] += B[j];
           break;
         }
+    }
   }
   res[r] = racc;
 }
@@ -5122,7 +5140,7 @@ static int poisson_rows_impl(fh_ctx_t ctx, int ns, const int* shapes, const int*
       return nullptr;
     }
     dv.push_back(d);
-    if (bytes) hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st);
+    if (bytes && h) hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st);
     return d;
   };
   int* d_ptr = (int*)up(cnt.data(), cnt.size() * sizeof(int));
@@ -5137,13 +5155,19 @@ static int poisson_rows_impl(fh_ctx_t ctx, int ns, const int* shapes, const int*
   unsigned char* d_etab = elem_shape ? (unsigned char*)up(etab.data(), etab.size()) : nullptr;
   int* d_code = source ? (int*)up(code.data(), code.size() * sizeof(int)) : nullptr;
   double* d_k = source ? (double*)up(consts.data(), consts.size() * sizeof(double)) : nullptr;
+  const int ncmax = std::max(ncs[0], std::max(ncs[1], ncs[2]));
+  FH_REQUIRE((int64_t)nel * ncmax < 2147483647ll, "fh_assemble_poisson_rows: too many elements");
+  double* d_Kb = (double*)up(nullptr, (size_t)nel * ncmax * ncmax * sizeof(double));      // element rows between the two passes
+  double* d_Fb = (double*)up(nullptr, (size_t)nel * ncmax * sizeof(double));
   int rc = 0;
   if (oom) {
     fh_set_error("fh_assemble_poisson_rows: out of device memory");
     rc = 2;
   } else {
-    hipLaunchKernelGGL(k_poisson_rows_generic, dim3(fh_div_up(ndof, 64)), dim3(64), 0, st, ndof, dim, tabs, d_etab, nloc, d_ptr, d_adj, d_ed, d_x, sol ? sol->d : nullptr, scale,
-                       d_code, (int)code.size(), d_k, KK->d_rowptr, KK->d_col, KK->d_val, RES->d);
+    hipLaunchKernelGGL(k_poisson_pairs_generic, dim3(fh_div_up((int64_t)nel * ncmax, 64)), dim3(64), 0, st, nel, ncmax, dim, tabs, d_etab, nloc, d_ed, d_x,
+                       sol ? sol->d : nullptr, scale, d_code, (int)code.size(), d_k, d_Kb, d_Fb);
+    hipLaunchKernelGGL(k_poisson_rows_generic, dim3(fh_div_up(ndof, 64)), dim3(64), 0, st, ndof, ncmax, tabs, d_etab, nloc, d_ptr, d_adj, d_ed, d_Kb, d_Fb, KK->d_rowptr,
+                       KK->d_col, KK->d_val, RES->d);
     if (hipGetLastError() != hipSuccess) {
       fh_set_error("fh_assemble_poisson_rows: launch failed");
       rc = 2;
