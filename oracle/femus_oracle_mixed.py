@@ -7,6 +7,9 @@ them, on top of the single-shape oracles.  Only tests/, __graft_entry__.smoke() 
                 Mesh::AddBiquadraticNodesNotInMeshFile (Mesh.cpp:1207-1333) over elements of both shapes with triangle faces; weights Mesh.cpp:105-122
   refine        MeshRefinement::RefineMesh: children 8 e + j, shape of the father; shared edge / face nodes through dictionaries
   assemble      main.cpp:355-480: el->GetElementType(iel) picks the tables of every element
+  PIN           bases and Gauss rules through the single-shape oracles: tests/golden/fe_tables.npz (written by the reference's compiled classes); the reader, the added
+                nodes, refinement and numbering are restated from the cited lines -- "parity unpinned" for that integer half (the mesh layer of the reference does
+                not build here: DESIGN section 5), anchored on the product's independent implementation giving the same integers and on geometric invariants
 """
 import os
 
