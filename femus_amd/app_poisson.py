@@ -152,21 +152,23 @@ class Poisson001:
         idx = np.array(sorted(val), dtype=np.int32)
         return idx, np.array([val[i] for i in idx])
 
-    def run(self, smoother=capi.SMOOTH_GS_COLOR, omega=0.5, log=None, output_dir=None):
+    def run(self, smoother=capi.SMOOTH_GS_COLOR, omega=0.5, log=None, output_dir=None, simplex_smoother=capi.SMOOTH_GS_COLOR, simplex_omega=1.0):
         """smoother / omega: the application sets RICHARDSON + SOR_PRECOND on the fine grids (main.cpp:240-242) and leaves the
         Richardson scale at the solver default 0.5 (LinearEquationSolverPetsc.hpp:145).  output_dir: write what the application writes at
         its end (main.cpp:259-270): the VTK and the GMV file of "Sol", named as the reference names them"""
         ctx = self.ctx
         if self.dim == 1:
             return self.run_line(log)
+        # triangles, tetrahedra, prisms, mixed shapes: multicolour Gauss-Seidel by default -- the iteration counts of the natural-order symmetric sweep the
+        # application sets (SOR_PRECOND; simplex_smoother=capi.SMOOTH_SOR runs that one) at half the time on 240 k unknowns (tests/dev/probe_simplex_smoother.py)
         if getattr(self, "tri", False):
-            return self.run_tri(log)
+            return self.run_tri(log, simplex_smoother, simplex_omega)
         if getattr(self, "tet", False):
-            return self.run_tet(log)
+            return self.run_tet(log, simplex_smoother, simplex_omega)
         if getattr(self, "wedge", False):
-            return self.run_wedge(log)
+            return self.run_wedge(log, simplex_smoother, simplex_omega)
         if getattr(self, "mixed", False):
-            return self.run_mixed(log)
+            return self.run_mixed(log, simplex_smoother, simplex_omega)
         meshes = [capi.Mesh.box(*self.box, self.lo, self.hi) if self.box is not None else capi.Mesh.read_gambit(self.mesh_file)]
         for _ in range(1, self.nlevels):
             meshes.append(meshes[-1].refine())
@@ -216,7 +218,7 @@ class Poisson001:
         return result
 
     # ---- a two-dimensional box of triangles ("elem_type" : "Tri6") ---------------------------------------------------------------------------------
-    def run_tri(self, log=None, smoother=capi.SMOOTH_SOR, omega=1.0):
+    def run_tri(self, log=None, smoother=capi.SMOOTH_GS_COLOR, omega=1.0):
         """a TRI6 box (TRI7 inside, femus_amd/tri_mesh.py): all three Lagrange families; boundary conditions and source as for the quadrilateral box"""
         from . import tri_mesh
         levels = [tri_mesh.box(self.box[0], self.box[1], self.lo[:2], self.hi[:2])]
@@ -243,7 +245,7 @@ class Poisson001:
             return "mixed"
         return {("6", "10"): "tet10", ("5", "18"): "wedge18"}.get(seen.pop())
 
-    def run_mixed(self, log=None, smoother=capi.SMOOTH_SOR, omega=1.0):
+    def run_mixed(self, log=None, smoother=capi.SMOOTH_GS_COLOR, omega=1.0):
         """a Gambit mesh of mixed shapes (input3D.json / input3D_All_first.json with input/cube_all_shapes_Six_boundary_groups.neu: tetrahedra, prisms and
         hexahedra; femus_amd/mixed_mesh.py): the three Lagrange families; the boundary conditions of the application's SetBoundaryCondition"""
         from . import mixed_mesh
@@ -253,7 +255,7 @@ class Poisson001:
         fam = {"linear": 0, "serendipity": 1, "biquadratic": 2}[self.fe]
         return self._run_simplex("mixed", [l[1:] for l in levels], None, [l[4][fam] for l in levels], log, smoother, omega, kinds=[l[0] for l in levels])
 
-    def run_wedge(self, log=None, smoother=capi.SMOOTH_SOR, omega=1.0):
+    def run_wedge(self, log=None, smoother=capi.SMOOTH_GS_COLOR, omega=1.0):
         """a Gambit mesh of WEDGE18 elements (input3D_Wedge_first / _second / _serendipity.json with input/cube_Wedge.neu; femus_amd/wedge_mesh.py: WEDGE21
         inside): the three Lagrange families; the boundary conditions of the application's SetBoundaryCondition"""
         from . import wedge_mesh
@@ -263,7 +265,7 @@ class Poisson001:
         fam = {"linear": 0, "serendipity": 1, "biquadratic": 2}[self.fe]
         return self._run_simplex("wedge", levels, (6, 15, 21)[fam], [own[fam] for (_, _, _, own) in levels], log, smoother, omega)
 
-    def run_tet(self, log=None, smoother=capi.SMOOTH_SOR, omega=1.0):
+    def run_tet(self, log=None, smoother=capi.SMOOTH_GS_COLOR, omega=1.0):
         """a Gambit mesh of TET10 elements (input3D_Tet_first / _serendipity / _second.json with input/cube_Tet.neu; femus_amd/tet_mesh.py): P1, P2 and P2 with
         face and volume bubbles (TET15); the boundary conditions of the application's SetBoundaryCondition (Dirichlet 0, flux 0.2 on face name 3)"""
         from . import tet_mesh
