@@ -4967,9 +4967,9 @@ extern "C" int fh_assemble_advdiff_line(fh_ctx_t ctx, int fe, int order, int nel
 // ------------------------------------------------------------------------------------------------------------------
 // The Poisson callback through a GENERIC (dim, nc, ng) kernel (round 6): any element family fh_fe has tables for -- the triangle (geom 3) first, whose meshes
 // do not go through the tensor-product mesh layer -- with the element table given by the caller (nloc nodes per element in the family's local order; dof id =
-// node id, the classes numbered one after the other as every FEMuS mesh is).  Two passes: one thread per (element, local row) forms that row of the element
-// matrix over the Gauss points (elem_type::Jacobian: Jac[a][b] = sum_n dphi_n/dxi_a x_n[b], grad phi_n = Jac^-1 dphi_n, w = det w_g) into a buffer; one thread per
-// ROW then adds the rows of its node's elements in ascending element order (first version: the row thread formed them itself -- 80 instead of 37 ms per call on 54 k TET15 elements, host preparation included):
+// node id, the classes numbered one after the other as every FEMuS mesh is).  Two passes: one wave per element forms the element
+// matrix over the Gauss points (elem_type::Jacobian: Jac[a][b] = sum_n dphi_n/dxi_a x_n[b], grad phi_n = Jac^-1 dphi_n, w = det w_g) into a buffer, with the place of every entry in the matrix beside it; one thread per
+// ROW then adds the rows of its node's elements in ascending element order (first version: the row thread formed them itself -- 80 ms per call on 54 k TET15 elements, host preparation included):
 //   K_ij += grad phi_i . grad phi_j w,   RES_i += (scale f phi_i - grad phi_i . grad u) w        (main.cpp:430-470 with V = 0)
 // The grouping of the reference's add_matrix_blocked / add_vector_blocked, no atomics; meant for the sizes such meshes have here, not for the bench (the
 // hexahedral paths above are the fast ones).
@@ -4982,85 +4982,171 @@ struct GenTab {              // the tables of one element shape: a mesh of mixed
 struct GenTabs {
   GenTab t[3];
 };
-// First pass: one thread per (element, local row i) -- row i of the element matrix into Kb[(e * ncmax + i) * ncmax + j], its residual entry into Fb[e * ncmax + i].
+// First pass: one WAVE per element.  The Gauss points are taken GEN_GC at a time through LDS: (A) lane = Gauss point: Jacobian, its inverse, weight, source value;
+// (B) lanes over (Gauss point, node): the node's gradient; (C) lane = Gauss point: grad u; (D) lanes over the pairs i <= j of the element matrix (K_ji = K_ij
+// bit for bit: the products commute) and over the residual entries, Gauss points in ascending order.  Every sum is taken in the order of the one-thread-per-row
+// kernel this replaces (nodes ascending inside a Gauss point, Gauss points ascending); 53 760 TET15 elements: 26 + 8.5 ms (element rows by one thread each +
+// searching row pass) -> 4.7 + 0.8 ms (profiles/r06_shipped_inputs_kernel_summary.md).
+// Row i of the element matrix goes to Kb[(e * ncmax + i) * ncmax + j], its residual entry to Fb[e * ncmax + i].
+constexpr int GEN_GC = 32;
+constexpr int GEN_LDS = GEN_NC * 3 + GEN_NC + GEN_GC * 9 + GEN_GC * 2 + GEN_GC * 3 + GEN_GC * GEN_NC * 3;
 __global__ __launch_bounds__(64) void k_poisson_pairs_generic(int nel, int ncmax, int dim, GenTabs tabs, const unsigned char* __restrict__ etab, int nloc,
                                                               const int* __restrict__ elem_dof, const double* __restrict__ coords, const double* __restrict__ sol,
                                                               double scale, const int* __restrict__ prog, int nprog, const double* __restrict__ pconst,
-                                                              double* __restrict__ Kb, double* __restrict__ Fb) {
-  const int t = blockIdx.x * 64 + threadIdx.x;
-  if (t >= nel * ncmax) return;
-  const int e = t / ncmax, i = t - e * ncmax;
+                                                              const int* __restrict__ rowptr, const int* __restrict__ col, double* __restrict__ Kb,
+                                                              int* __restrict__ Pos, double* __restrict__ Fb) {
+  __shared__ double S[GEN_LDS];
+  __shared__ int DOF[GEN_NC];
+  double* X = S;                          // [nc][3]
+  double* U = X + GEN_NC * 3;             // [nc]
+  double* JI = U + GEN_NC;                // [GC][9]
+  double* WG = JI + GEN_GC * 9;           // [GC] det w
+  double* FS = WG + GEN_GC;               // [GC] scale f(x_g)
+  double* GU = FS + GEN_GC;               // [GC][3]
+  double* G = GU + GEN_GC * 3;            // [GC][nc][3]
+  const int e = blockIdx.x, lane = threadIdx.x;
   const GenTab& T = tabs.t[etab ? etab[e] : 0];
   const int nc = T.nc, ng = T.ng;
-  if (i >= nc) return;
   const double *w = T.w, *phi = T.phi, *dphi = T.dphi;
-  double x[GEN_NC][3], u[GEN_NC], B[GEN_NC], gr[GEN_NC][3];
-  for (int n = 0; n < nc; n++) {
-    const int dof = elem_dof[(size_t)e * nloc + n];
-    for (int d = 0; d < dim; d++) x[n][d] = coords[(size_t)dof * dim + d];
-    u[n] = sol ? sol[dof] : 0.0;
-    B[n] = 0.0;
+  if (lane < nc) {
+    const int dof = elem_dof[(size_t)e * nloc + lane];
+    DOF[lane] = dof;
+    for (int d = 0; d < 3; d++) X[lane * 3 + d] = d < dim ? coords[(size_t)dof * dim + d] : 0.0;
+    U[lane] = sol ? sol[dof] : 0.0;
+  }
+  // this lane's pairs (i <= j), GEN_NC (GEN_NC + 1) / 2 = 378 at most: six per lane
+  constexpr int NPL = (GEN_NC * (GEN_NC + 1) / 2 + 63) / 64;
+  const int npair = nc * (nc + 1) / 2;
+  int pi[NPL], pj[NPL];
+  double acc[NPL];
+#pragma unroll
+  for (int k = 0; k < NPL; k++) {
+    int p = lane + 64 * k, i = 0;
+    if (p < npair) {
+      while (p >= nc - i) {
+        p -= nc - i;
+        i++;
+      }
+      pi[k] = i;
+      pj[k] = i + p;
+    } else {
+      pi[k] = pj[k] = -1;
+    }
+    acc[k] = 0.0;
   }
   double F = 0.0;
-  for (int g = 0; g < ng; g++) {
-    const double* dp = dphi + (size_t)g * nc * dim;
-    double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Ji[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, det;
-    for (int n = 0; n < nc; n++)
-      for (int p = 0; p < dim; p++)
-        for (int q = 0; q < dim; q++) J[p][q] += dp[n * dim + p] * x[n][q];
-    if (dim == 1) {
-      det = J[0][0];
-      Ji[0][0] = 1 / det;
-    } else if (dim == 2) {
-      det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-      Ji[0][0] = J[1][1] / det;
-      Ji[0][1] = -J[0][1] / det;
-      Ji[1][0] = -J[1][0] / det;
-      Ji[1][1] = J[0][0] / det;
-    } else {
-      det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[1][2] * J[2][0] - J[1][0] * J[2][2]) + J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
-      Ji[0][0] = (-J[1][2] * J[2][1] + J[1][1] * J[2][2]) / det;
-      Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
-      Ji[0][2] = (-J[0][2] * J[1][1] + J[0][1] * J[1][2]) / det;
-      Ji[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) / det;
-      Ji[1][1] = (-J[0][2] * J[2][0] + J[0][0] * J[2][2]) / det;
-      Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
-      Ji[2][0] = (-J[1][1] * J[2][0] + J[1][0] * J[2][1]) / det;
-      Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
-      Ji[2][2] = (-J[0][1] * J[1][0] + J[0][0] * J[1][1]) / det;
+  __syncthreads();
+  for (int g0 = 0; g0 < ng; g0 += GEN_GC) {
+    const int gc = min(GEN_GC, ng - g0);
+    if (lane < gc) {                      // (A)
+      const int g = g0 + lane;
+      const double* dp = dphi + (size_t)g * nc * dim;
+      double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Ji[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, det;
+      for (int n = 0; n < nc; n++)
+        for (int p = 0; p < dim; p++)
+          for (int q = 0; q < dim; q++) J[p][q] += dp[n * dim + p] * X[n * 3 + q];
+      if (dim == 1) {
+        det = J[0][0];
+        Ji[0][0] = 1 / det;
+      } else if (dim == 2) {
+        det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+        Ji[0][0] = J[1][1] / det;
+        Ji[0][1] = -J[0][1] / det;
+        Ji[1][0] = -J[1][0] / det;
+        Ji[1][1] = J[0][0] / det;
+      } else {
+        det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[1][2] * J[2][0] - J[1][0] * J[2][2]) + J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+        Ji[0][0] = (-J[1][2] * J[2][1] + J[1][1] * J[2][2]) / det;
+        Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+        Ji[0][2] = (-J[0][2] * J[1][1] + J[0][1] * J[1][2]) / det;
+        Ji[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) / det;
+        Ji[1][1] = (-J[0][2] * J[2][0] + J[0][0] * J[2][2]) / det;
+        Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+        Ji[2][0] = (-J[1][1] * J[2][0] + J[1][0] * J[2][1]) / det;
+        Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+        Ji[2][2] = (-J[0][1] * J[1][0] + J[0][0] * J[1][1]) / det;
+      }
+      for (int q = 0; q < 3; q++)
+        for (int p = 0; p < 3; p++) JI[lane * 9 + q * 3 + p] = Ji[q][p];
+      WG[lane] = det * w[g];
+      double xq[4] = {0, 0, 0, 0};
+      for (int n = 0; n < nc; n++) {
+        const double ph = phi[(size_t)g * nc + n];
+        for (int q = 0; q < dim; q++) xq[q] += X[n * 3 + q] * ph;
+      }
+      FS[lane] = prog ? scale * fh_expr_device_eval(prog, nprog, pconst, xq) : 0.0;
     }
-    const double weight = det * w[g];
-    double gu[3] = {0, 0, 0}, xq[4] = {0, 0, 0, 0};
-    for (int n = 0; n < nc; n++) {
-      const double ph = phi[(size_t)g * nc + n];
+    __syncthreads();
+    for (int t = lane; t < gc * nc; t += 64) {                      // (B)
+      const int l = t / nc, n = t - l * nc;
+      const double* dp = dphi + ((size_t)(g0 + l) * nc + n) * dim;
       for (int q = 0; q < dim; q++) {
         double sacc = 0.0;
-        for (int p = 0; p < dim; p++) sacc += Ji[q][p] * dp[n * dim + p];
-        gr[n][q] = sacc;
-        gu[q] += sacc * u[n];
-        xq[q] += x[n][q] * ph;
+        for (int p = 0; p < dim; p++) sacc += JI[l * 9 + q * 3 + p] * dp[p];
+        G[(l * GEN_NC + n) * 3 + q] = sacc;
       }
     }
-    const double f = prog ? scale * fh_expr_device_eval(prog, nprog, pconst, xq) : 0.0;
-    double lap = 0.0;
-    for (int q = 0; q < dim; q++) lap += gr[i][q] * gu[q];
-    F += (f * phi[(size_t)g * nc + i] - lap) * weight;
-    for (int j = 0; j < nc; j++) {
-      double sacc = 0.0;
-      for (int q = 0; q < dim; q++) sacc += gr[i][q] * gr[j][q];
-      B[j] += sacc * weight;
+    __syncthreads();
+    if (lane < gc) {                      // (C)
+      double gu[3] = {0, 0, 0};
+      for (int n = 0; n < nc; n++)
+        for (int q = 0; q < dim; q++) gu[q] += G[(lane * GEN_NC + n) * 3 + q] * U[n];
+      for (int q = 0; q < 3; q++) GU[lane * 3 + q] = gu[q];
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NPL; k++)         // (D)
+      if (pi[k] >= 0) {
+        double a = acc[k];
+        for (int l = 0; l < gc; l++) {
+          const double *gi = G + (l * GEN_NC + pi[k]) * 3, *gj = G + (l * GEN_NC + pj[k]) * 3;
+          double sacc = 0.0;
+          for (int q = 0; q < dim; q++) sacc += gi[q] * gj[q];
+          a += sacc * WG[l];
+        }
+        acc[k] = a;
+      }
+    if (lane < nc)
+      for (int l = 0; l < gc; l++) {
+        const double* gi = G + (l * GEN_NC + lane) * 3;
+        double lap = 0.0;
+        for (int q = 0; q < dim; q++) lap += gi[q] * GU[l * 3 + q];
+        F += (FS[l] * phi[(size_t)(g0 + l) * nc + lane] - lap) * WG[l];
+      }
+    __syncthreads();
   }
-  double* out = Kb + (size_t)t * ncmax;
-  for (int j = 0; j < nc; j++) out[j] = B[j];
-  Fb[t] = F;
+  // the entry's place in the matrix beside its value (-1: the pattern does not hold it), so that the row pass adds without searching
+  double* out = Kb + (size_t)e * ncmax * ncmax;
+  int* pos = Pos + (size_t)e * ncmax * ncmax;
+  auto place = [&](int i, int j) {
+    const int r = DOF[i], c = DOF[j];
+    int at = -1;
+    for (int k = rowptr[r], re = rowptr[r + 1]; k < re; k++)
+      if (col[k] == c) {
+        at = k;
+        break;
+      }
+    return at;
+  };
+#pragma unroll
+  for (int k = 0; k < NPL; k++)
+    if (pi[k] >= 0) {
+      out[(size_t)pi[k] * ncmax + pj[k]] = acc[k];
+      pos[(size_t)pi[k] * ncmax + pj[k]] = place(pi[k], pj[k]);
+      if (pi[k] != pj[k]) {
+        out[(size_t)pj[k] * ncmax + pi[k]] = acc[k];
+        pos[(size_t)pj[k] * ncmax + pi[k]] = place(pj[k], pi[k]);
+      }
+    }
+  if (lane < nc) Fb[(size_t)e * ncmax + lane] = F;
 }
 
-// Second pass: one thread per row, its (element, local row) pairs in ascending element order -- the order of the reference's element loop.
-__global__ __launch_bounds__(64) void k_poisson_rows_generic(int ndof, int ncmax, GenTabs tabs, const unsigned char* __restrict__ etab, int nloc,
-                                                             const int* __restrict__ adj_ptr, const int* __restrict__ adj, const int* __restrict__ elem_dof,
-                                                             const double* __restrict__ Kb, const double* __restrict__ Fb, const int* __restrict__ rowptr,
-                                                             const int* __restrict__ col, double* __restrict__ val, double* __restrict__ res) {
+// Second pass: one thread per row, its (element, local row) pairs in ascending element order -- the order of the reference's element loop --, every entry added
+// at the place the first pass found for it.
+__global__ __launch_bounds__(64) void k_poisson_rows_generic(int ndof, int ncmax, GenTabs tabs, const unsigned char* __restrict__ etab,
+                                                             const int* __restrict__ adj_ptr, const int* __restrict__ adj, const double* __restrict__ Kb,
+                                                             const int* __restrict__ Pos, const double* __restrict__ Fb, const int* __restrict__ rowptr,
+                                                             double* __restrict__ val, double* __restrict__ res) {
   const int r = blockIdx.x * 64 + threadIdx.x;
   if (r >= ndof) return;
   const int rs = rowptr[r], re = rowptr[r + 1];
@@ -5072,14 +5158,9 @@ __global__ __launch_bounds__(64) void k_poisson_rows_generic(int ndof, int ncmax
     const size_t pr = (size_t)e * ncmax + i;
     racc += Fb[pr];
     const double* B = Kb + pr * ncmax;
-    for (int j = 0; j < nc; j++) {
-      const int dj = elem_dof[(size_t)e * nloc + j];
-      for (int k = rs; k < re; k++)
-        if (col[k] == dj) {
-          val[k] += B[j];
-          break;
-        }
-    }
+    const int* at = Pos + pr * ncmax;
+    for (int j = 0; j < nc; j++)
+      if (at[j] >= 0) val[at[j]] += B[j];
   }
   res[r] = racc;
 }
@@ -5159,15 +5240,16 @@ static int poisson_rows_impl(fh_ctx_t ctx, int ns, const int* shapes, const int*
   FH_REQUIRE((int64_t)nel * ncmax < 2147483647ll, "fh_assemble_poisson_rows: too many elements");
   double* d_Kb = (double*)up(nullptr, (size_t)nel * ncmax * ncmax * sizeof(double));      // element rows between the two passes
   double* d_Fb = (double*)up(nullptr, (size_t)nel * ncmax * sizeof(double));
+  int* d_Pos = (int*)up(nullptr, (size_t)nel * ncmax * ncmax * sizeof(int));
   int rc = 0;
   if (oom) {
     fh_set_error("fh_assemble_poisson_rows: out of device memory");
     rc = 2;
   } else {
-    hipLaunchKernelGGL(k_poisson_pairs_generic, dim3(fh_div_up((int64_t)nel * ncmax, 64)), dim3(64), 0, st, nel, ncmax, dim, tabs, d_etab, nloc, d_ed, d_x,
-                       sol ? sol->d : nullptr, scale, d_code, (int)code.size(), d_k, d_Kb, d_Fb);
-    hipLaunchKernelGGL(k_poisson_rows_generic, dim3(fh_div_up(ndof, 64)), dim3(64), 0, st, ndof, ncmax, tabs, d_etab, nloc, d_ptr, d_adj, d_ed, d_Kb, d_Fb, KK->d_rowptr,
-                       KK->d_col, KK->d_val, RES->d);
+    hipLaunchKernelGGL(k_poisson_pairs_generic, dim3(nel), dim3(64), 0, st, nel, ncmax, dim, tabs, d_etab, nloc, d_ed, d_x,
+                       sol ? sol->d : nullptr, scale, d_code, (int)code.size(), d_k, KK->d_rowptr, KK->d_col, d_Kb, d_Pos, d_Fb);
+    hipLaunchKernelGGL(k_poisson_rows_generic, dim3(fh_div_up(ndof, 64)), dim3(64), 0, st, ndof, ncmax, tabs, d_etab, d_ptr, d_adj, d_Kb, d_Pos, d_Fb, KK->d_rowptr,
+                       KK->d_val, RES->d);
     if (hipGetLastError() != hipSuccess) {
       fh_set_error("fh_assemble_poisson_rows: launch failed");
       rc = 2;

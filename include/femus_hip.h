@@ -392,7 +392,7 @@ int fh_assemble_advdiff_line(fh_ctx_t ctx, int fe, int gauss_order, int nel, con
 /* The Poisson callback (main.cpp:355-480 with V = 0) through a GENERIC (dim, nc, ng) kernel, for element families whose meshes the caller keeps -- the triangle
  * (geom 3: TRI7 node order of 2d/Triangle.cpp: vertices, edge middles, centre) first: elem_dof[nel*nloc] in the family's local order with the node classes
  * numbered one after the other (a node id is its dof id), coords[nnode*dim].  KK and RES are OVERWRITTEN: KK_ij = sum grad phi_i . grad phi_j w,
- * RES_i = sum (scale f phi_i - grad phi_i . grad Sol) w.  Element rows first (one thread per element and local row), then one thread per row adding them in
+ * RES_i = sum (scale f phi_i - grad phi_i . grad Sol) w.  Element matrices first (one wave per element, the entries' places in KK beside them), then one thread per row adding them in
  * ascending element order; geom 0 .. 2 are served too (a cross-check of the
  * tensor-product assemblers on small meshes). */
 int fh_assemble_poisson_rows(fh_ctx_t ctx, int geom, int fe, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, const double* coords, fh_vec_t sol,
