@@ -1,9 +1,10 @@
 """TEST INFRASTRUCTURE ONLY (oracle).  CPU restatement of the MIXED-SHAPE path of applications/001_Poisson (its shipped input3D.json / input3D_All_first.json with
-input/cube_all_shapes_Six_boundary_groups.neu: tetrahedra, prisms and hexahedra in one Gambit file): reader, the nodes FEMuS adds, numbering, refinement, the
+input/cube_all_shapes_Six_boundary_groups.neu: tetrahedra, prisms and hexahedra in one Gambit file; and the two-dimensional Gambit files of the reference tree
+with QUAD9 and / or TRI6 elements): reader, the nodes FEMuS adds, numbering, refinement, the
 Poisson callback element by element with each element's own shape, face integrals on triangles and quadrilaterals, solve -- loops as the reference writes
 them, on top of the single-shape oracles.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
 
-  read_gambit   GambitIO.cpp:101-330 (types 4 / 6 / 5 = HEX27 / TET10 / WEDGE18; GambitToFemusVertexIndex :55-69, GambitToFemusFaceIndex :84-86);
+  read_gambit   GambitIO.cpp:101-330 (types 4 / 6 / 5 / 2 / 3 = HEX27 / TET10 / WEDGE18 / QUAD9 / TRI6; GambitToFemusVertexIndex :55-69, GambitToFemusFaceIndex :84-86);
                 Mesh::AddBiquadraticNodesNotInMeshFile (Mesh.cpp:1207-1333) over elements of both shapes with triangle faces; weights Mesh.cpp:105-122
   refine        MeshRefinement::RefineMesh: children 8 e + j, shape of the father; shared edge / face nodes through dictionaries
   assemble      main.cpp:355-480: el->GetElementType(iel) picks the tables of every element
@@ -21,43 +22,49 @@ from . import femus_oracle_tri as ot
 from . import femus_oracle_wedge as ow
 
 _G = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "fe_tables.npz"))
-NLOC = {"hex": 27, "tet": 15, "wedge": 21}
-CLASSES = {"hex": (8, 20, 27), "tet": (4, 10, 15), "wedge": (6, 15, 21)}
-FACE = {"hex": [list(r) for r in _G["facedofs_hex"]], "tet": [list(r) for r in oq.FACE], "wedge": [list(r) for r in ow.FACE]}
-NVF = {"hex": [4] * 6, "tet": [3] * 4, "wedge": [4, 4, 4, 3, 3]}
-FACE_LOCAL = {"hex": [20, 21, 22, 23, 24, 25], "tet": [10, 11, 12, 13], "wedge": [15, 16, 17, 18, 19]}
+NLOC = {"hex": 27, "tet": 15, "wedge": 21, "quad": 9, "tri": 7}
+CLASSES = {"hex": (8, 20, 27), "tet": (4, 10, 15), "wedge": (6, 15, 21), "quad": (4, 8, 9), "tri": (3, 6, 7)}
+FACE = {"hex": [list(r) for r in _G["facedofs_hex"]], "tet": [list(r) for r in oq.FACE], "wedge": [list(r) for r in ow.FACE],
+        "quad": [list(r) for r in _G["facedofs_quad"]], "tri": [list(r) for r in ot.FACE]}
+NVF = {"hex": [4] * 6, "tet": [3] * 4, "wedge": [4, 4, 4, 3, 3], "quad": [2] * 4, "tri": [2] * 3}
+FACE_LOCAL = {"hex": [20, 21, 22, 23, 24, 25], "tet": [10, 11, 12, 13], "wedge": [15, 16, 17, 18, 19], "quad": [4, 5, 6, 7], "tri": [3, 4, 5]}
 HEX_EDGE = [(0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7)]      # local nodes 8 .. 19 (Hexahedron.cpp: XC rows)
-EDGE = {"hex": HEX_EDGE, "tet": list(oq.EDGE), "wedge": list(ow.EDGE)}
-GAMBIT = {4: ("hex", 27), 6: ("tet", 10), 5: ("wedge", 18)}
-G2F = {"hex": (4, 16, 0, 15, 23, 11, 7, 19, 3, 12, 20, 8, 25, 26, 24, 14, 22, 10, 5, 17, 1, 13, 21, 9, 6, 18, 2), "tet": oq.G2F, "wedge": ow.G2F}
-GFACE = {"hex": (0, 4, 2, 5, 3, 1), "tet": (0, 1, 2, 3), "wedge": ow.GFACE}
+EDGE = {"hex": HEX_EDGE, "tet": list(oq.EDGE), "wedge": list(ow.EDGE), "quad": [(0, 1), (1, 2), (2, 3), (3, 0)], "tri": [(0, 1), (1, 2), (2, 0)]}
+GAMBIT = {(4, 27): "hex", (6, 10): "tet", (5, 18): "wedge", (2, 9): "quad", (3, 6): "tri"}
+G2F = {"hex": (4, 16, 0, 15, 23, 11, 7, 19, 3, 12, 20, 8, 25, 26, 24, 14, 22, 10, 5, 17, 1, 13, 21, 9, 6, 18, 2), "tet": oq.G2F, "wedge": ow.G2F,
+       "quad": (0, 4, 1, 5, 2, 6, 3, 7, 8), "tri": (0, 3, 1, 4, 2, 5)}
+GFACE = {"hex": (0, 4, 2, 5, 3, 1), "tet": (0, 1, 2, 3), "wedge": ow.GFACE, "quad": (0, 1, 2, 3), "tri": (0, 1, 2)}
 WEDGE_W = np.zeros((3, 18))
 WEDGE_W[0, [0, 1, 2]], WEDGE_W[0, [6, 7, 8]] = -1. / 9., 4. / 9.
 WEDGE_W[1, [3, 4, 5]], WEDGE_W[1, [9, 10, 11]] = -1. / 9., 4. / 9.
 WEDGE_W[2, [12, 13, 14]], WEDGE_W[2, [15, 16, 17]] = -1. / 9., 4. / 9.
-ADDED = {"tet": oq.WGT, "wedge": WEDGE_W}
+ADDED = {"tet": oq.WGT, "wedge": WEDGE_W, "tri": np.array([[-1. / 9.] * 3 + [4. / 9.] * 3])}
+COMPLETE = ("hex", "quad")
 NDOF = {s: {"linear": CLASSES[s][0], "serendipity": CLASSES[s][1], "biquadratic": CLASSES[s][2]} for s in NLOC}
-NFN = {3: {"linear": 3, "serendipity": 6, "biquadratic": 7}, 4: {"linear": 4, "serendipity": 8, "biquadratic": 9}}
+NFN = {2: {"linear": 2, "serendipity": 3, "biquadratic": 3}, 3: {"linear": 3, "serendipity": 6, "biquadratic": 7}, 4: {"linear": 4, "serendipity": 8, "biquadratic": 9}}
 
 
 def f2c(shape):
-    return {"hex": fo.fine2coarse_vertex_mapping("hex"), "tet": oq.F2C, "wedge": ow.F2C}[shape]
+    if shape in ("hex", "quad"):
+        return fo.fine2coarse_vertex_mapping(shape)
+    return {"tet": oq.F2C, "wedge": ow.F2C, "tri": ot.F2C}[shape]
 
 
 def elem_prolongator(shape, fe):
-    return fo.elem_prolongator("hex", fe) if shape == "hex" else (oq if shape == "tet" else ow).elem_prolongator(fe)
+    return fo.elem_prolongator(shape, fe) if shape in ("hex", "quad") else {"tet": oq, "wedge": ow, "tri": ot}[shape].elem_prolongator(fe)
 
 
 def tables(shape, fe, order="seventh"):
-    """(w[ng], phi[ng, nc], dphi[ng, nc, 3]) of a shape"""
-    if shape == "hex":
-        w, x = fo.gauss_table("hex", order)
+    """(w[ng], phi[ng, nc], dphi[ng, nc, dim]) of a shape"""
+    if shape in ("hex", "quad"):
+        d = 3 if shape == "hex" else 2
+        w, x = fo.gauss_table(shape, order)
         x = np.asarray(x)
-        if x.shape[0] == 3 and x.shape[1] != 3:
+        if x.shape[0] == d and x.shape[1] != d:
             x = x.T
-        out = fo.eval_basis("hex", fe, x)
+        out = fo.eval_basis(shape, fe, x)
         return np.asarray(w), out[0], out[1]
-    m = oq if shape == "tet" else ow
+    m = {"tet": oq, "wedge": ow, "tri": ot}[shape]
     w, x = m.gauss(order)
     phi, dphi = m.basis(fe, x)
     return w, phi, dphi
@@ -90,18 +97,18 @@ def read_gambit(path):
     tok = open(path).read().split()
     p = tok.index("NDFVL") + 1
     nvt, nel, ngroup, nbcd, dim, _ = (int(t) for t in tok[p:p + 6])
-    assert dim == 3 and ngroup == 1
+    assert dim in (2, 3) and ngroup == 1
     p = tok.index("COORDINATES") + 2
-    xyz = np.zeros((nvt, 3))
+    xyz = np.zeros((nvt, dim))
     for n in range(nvt):
-        xyz[n] = [float(t) for t in tok[p + 1:p + 4]]
-        p += 4
+        xyz[n] = [float(t) for t in tok[p + 1:p + 1 + dim]]
+        p += 1 + dim
     p = tok.index("ELEMENTS/CELLS") + 2
     kind = []
     raw = np.full((nel, 27), -1, dtype=np.int64)
     for e in range(nel):
-        s, nn = GAMBIT[int(tok[p + 1])]
-        assert int(tok[p + 2]) == nn
+        nn = int(tok[p + 2])
+        s = GAMBIT[(int(tok[p + 1]), nn)]
         kind.append(s)
         for i in range(nn):
             raw[e, G2F[s][i]] = int(tok[p + 3 + i]) - 1
@@ -119,7 +126,7 @@ def read_gambit(path):
     # Mesh.cpp:1228-1270: triangle faces of tetrahedra and prisms, the first element that holds one creates its node and hands it to the first later element that
     # holds the same three vertices; :1273-1287: then a centre per tetrahedron / prism
     nn = nvt
-    tri = {s: [f for f in range(len(FACE[s])) if NVF[s][f] == 3] for s in NLOC}
+    tri = {s: [f for f in range(len(FACE[s])) if NVF[s][f] == 3 and dim == 3] for s in NLOC}
     for e in range(nel):
         for f in tri[kind[e]]:
             l = FACE_LOCAL[kind[e]][f]
@@ -138,17 +145,17 @@ def read_gambit(path):
                         break
                 nn += 1
     for e in range(nel):
-        if kind[e] != "hex":
+        if kind[e] not in COMPLETE:
             raw[e, NLOC[kind[e]] - 1] = nn
             nn += 1
-    coords = np.concatenate([xyz, np.zeros((nn - nvt, 3))])
+    coords = np.concatenate([xyz, np.zeros((nn - nvt, dim))])
     for e in range(nel):
-        if kind[e] == "hex":
+        if kind[e] in COMPLETE:
             continue
         W = ADDED[kind[e]]
         j0 = NLOC[kind[e]] - W.shape[0]
         for j in range(W.shape[0]):
-            acc = np.zeros(3)
+            acc = np.zeros(dim)
             for i in range(j0):
                 acc += coords[raw[e, i]] * W[j][i]
             coords[raw[e, j0 + j]] = acc
@@ -160,10 +167,11 @@ def read_gambit(path):
 
 
 def refine(kind, ed, xs, ff):
-    nel = ed.shape[0]
-    ck = np.repeat(kind, 8)
-    raw = np.full((8 * nel, 27), -1, dtype=np.int64)
-    fff = np.full((8 * nel, 6), -1, dtype=np.int64)
+    nel, dim = ed.shape[0], xs.shape[1]
+    nch = 8 if dim == 3 else 4
+    ck = np.repeat(kind, nch)
+    raw = np.full((nch * nel, 27), -1, dtype=np.int64)
+    fff = np.full((nch * nel, 6), -1, dtype=np.int64)
     coords = list(xs)
     shared = {}
     EPs = {s: elem_prolongator(s, "biquadratic") for s in set(kind.tolist())}
@@ -175,8 +183,8 @@ def refine(kind, ed, xs, ff):
         def place(j, local):
             return sum(EP[j, local, m] * xs[ed[e, m]] for m in range(nl))
 
-        for j in range(8):
-            c = 8 * e + j
+        for j in range(nch):
+            c = nch * e + j
             cn = F2C[j]
             raw[c, :nv] = ed[e, cn]
             for lf in range(len(FACE[s])):                     # a child face all of whose vertices lie on a face of the father carries that face's flag
@@ -184,7 +192,8 @@ def refine(kind, ed, xs, ff):
                     if NVF[s][lf] == NVF[s][f] and all(int(cn[v]) in FACE[s][f] for v in FACE[s][lf][:NVF[s][lf]]):
                         fff[c, lf] = ff[e, f]
             todo = [(nv + k, tuple(sorted((int(raw[c, a]), int(raw[c, b]))))) for k, (a, b) in enumerate(EDGE[s])]
-            todo += [(FACE_LOCAL[s][f], tuple(sorted(int(v) for v in raw[c, FACE[s][f][:NVF[s][f]]]))) for f in range(len(FACE[s]))]
+            if dim == 3:                                       # (in two dimensions the faces are the edges)
+                todo += [(FACE_LOCAL[s][f], tuple(sorted(int(v) for v in raw[c, FACE[s][f][:NVF[s][f]]]))) for f in range(len(FACE[s]))]
             for local, key in sorted(todo):                    # local order
                 if key not in shared:
                     shared[key] = len(coords)
@@ -195,7 +204,7 @@ def refine(kind, ed, xs, ff):
     coords = np.array(coords)
     new, own = _renumber(ck, raw, coords.shape[0])
     used = new >= 0
-    xf = np.empty((own[2], 3))
+    xf = np.empty((own[2], dim))
     xf[new[used]] = coords[used]
     return ck, _apply(new, raw), xf, fff, own
 
@@ -236,6 +245,14 @@ def assemble(kind, ed, xs, fe, source, sol=None, order="seventh"):
 
 
 def _face_tables(nv, fe, order):
+    if nv == 2:                                              # line elements: ends, then middle
+        w, xg = fo.gauss_table("line", order)
+        xg = np.asarray(xg).reshape(-1)
+        nodes = (0, 2) if fe == "linear" else (0, 2, 1)
+        lag, dlag = (fo.lag_linear, fo.dlag_linear) if fe == "linear" else (fo.lag_biquadratic, fo.dlag_biquadratic)
+        ph = np.array([[lag(x, I) for I in nodes] for x in xg])
+        dp = np.array([[[dlag(x, I)] for I in nodes] for x in xg])
+        return np.asarray(w), ph, dp
     if nv == 4:
         w, x = fo.gauss_table("quad", order)
         x = np.asarray(x)
@@ -249,7 +266,7 @@ def _face_tables(nv, fe, order):
 
 
 def neumann(kind, ed, xs, ff, fe, flux_by_flag, ndof, order="seventh"):
-    FT = {nv: _face_tables(nv, fe, order) for nv in (3, 4)}
+    FT = {nv: _face_tables(nv, fe, order) for nv in ((3, 4) if xs.shape[1] == 3 else (2,))}
     F = np.zeros(ndof)
     for e, f in zip(*np.nonzero(ff < -1)):
         if ff[e, f] not in flux_by_flag:
@@ -260,7 +277,7 @@ def neumann(kind, ed, xs, ff, fe, flux_by_flag, ndof, order="seventh"):
         w, PH, DP = FT[nv]
         for g in range(len(w)):
             t = DP[g].T @ x
-            area = np.linalg.norm(np.cross(t[0], t[1]))
+            area = np.linalg.norm(np.cross(t[0], t[1])) if nv > 2 else np.hypot(t[0][0], t[0][1])
             tau = flux_by_flag[ff[e, f]]
             tv = tau(PH[g] @ x) if callable(tau) else tau
             F[fn] += PH[g] * tv * area * w[g]

@@ -1,7 +1,8 @@
 """Meshes of mixed shapes (applications/001_Poisson: input3D.json / input3D_All_first.json with input/cube_all_shapes_Six_boundary_groups.neu -- ten tetrahedra, six
 prisms and four hexahedra in one Gambit file, a data file of the application kept in tests/golden).  CPU: the oracle restatement
 (oracle/femus_oracle_mixed.py) -- reader / refinement properties, the product's host-side mesh code equal to it.  GPU: the mixed generic kernel and the face integrals
-against the oracle entry for entry, and the shipped inputs through app_poisson against the oracle's direct solve."""
+against the oracle entry for entry, and the shipped inputs through app_poisson against the oracle's direct solve.  Below: the two-dimensional Gambit files
+(QUAD9 + TRI6, TRI6 alone) through the same reader, refinement and kernel."""
 import os
 
 import numpy as np
@@ -245,3 +246,91 @@ def test_the_application_tells_the_mesh_files_apart(tmp_path):
     bad.write_text(text)
     with pytest.raises(ValueError, match="element 1 of Gambit type 7"):
         mixed_mesh.read_gambit(str(bad))
+
+
+# ---- two dimensions: the Gambit files of QUAD9 and TRI6 elements the reference tree holds (59 files mix the two, 73 hold triangles alone) ------------------------
+MESH_2D = {"square_mixed.neu": "applications/MPM_FEM/ex11/input/square_mixed.neu", "tri2.neu": "applications/ISM/ex1/input/tri2.neu"}
+
+
+@pytest.mark.parametrize("name", sorted(MESH_2D))
+def test_two_dimensional_gambit_files_reader_refinement_and_the_product_s_mesh_code(name):
+    """square_mixed.neu (two QUAD9 + four TRI6 elements on [-1/2, 1/2]^2) and tri2.neu (two TRI6 on the unit square), data files of the reference tree kept in
+    tests/golden: the centre FEMuS adds to every triangle at the mean of its vertices, edge nodes at the middles, the area kept by two refinements, boundary edges
+    doubled per level and lying on the boundary; femus_amd/mixed_mesh.py gives the oracle's integers (coordinates to rounding) on three levels"""
+    from femus_amd import mixed_mesh
+    path = os.path.join(HERE, "golden", name)
+    ref_file = "/root/reference/" + MESH_2D[name]
+    if os.path.exists(ref_file):
+        assert open(ref_file, "rb").read() == open(path, "rb").read()
+    kind, ed, xs, ff, own = om.read_gambit(path)
+    assert xs.shape[1] == 2 and set(kind.tolist()) <= {"quad", "tri"}
+    for e in np.nonzero(kind == "tri")[0]:
+        assert np.allclose(xs[ed[e, 6]], xs[ed[e, :3]].mean(axis=0), atol=1e-15) and np.all(ed[e, 7:] == -1)
+    nb0 = int((ff < -1).sum())
+
+    def area(k, e_, x_):
+        tot = 0.0
+        for s in set(k.tolist()):
+            w, _, DPHI = om.tables(s, "biquadratic")
+            for e in np.nonzero(k == s)[0]:
+                xe = x_[e_[e, :om.NLOC[s]]]
+                dets = np.array([np.linalg.det(DPHI[g].T @ xe) for g in range(len(w))])
+                assert dets.min() > 0
+                tot += float(dets @ w)
+        return tot
+
+    a0 = area(kind, ed, xs)
+    assert abs(a0 - 1.0) < 1e-9
+    lo, hi = xs.min(axis=0), xs.max(axis=0)
+    a, b = mixed_mesh.read_gambit(path), (kind, ed, xs, ff, own)
+    for level in range(3):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3]) and a[4] == b[4]
+        assert np.array_equal(a[2], b[2]) if level == 0 else np.abs(a[2] - b[2]).max() < 2e-15
+        if level == 2:
+            break
+        a, b = mixed_mesh.refine(*a[:4]), om.refine(*b[:4])
+        kf, ef, xf, fff, _ = b
+        assert ef.shape[0] == ed.shape[0] * 4 ** (level + 1) and abs(area(kf, ef, xf) - a0) < 1e-12 and int((fff < -1).sum()) == nb0 * 2 ** (level + 1)
+        for e, f in zip(*np.nonzero(fff < -1)):
+            x = xf[ef[e, om.FACE[kf[e]][f][:2]]]
+            assert any(np.all(np.abs(x[:, d] - v[d]) < 1e-14) for d in range(2) for v in (lo, hi))
+
+
+def _config_2d(name, fe_order, nlevels):
+    return """
+{
+    "multilevel_mesh" : { "first" : { "type" : { "filename" : "input/%s" } } },
+    "multilevel_solution" : { "multilevel_mesh" : { "first" : { "variable" : { "first" : {
+              "name" : "T", "fe_order" : "%s", "init_func" : "0.", "func_source": "1.+x*y",
+              "boundary_conditions" : [ { "facename" : "top", "bdc_type" : "dirichlet" } ] } } } } },
+    "multilevel_problem" : { "multilevel_mesh" : { "first" : { "system" : { "poisson" : { "linear_solver" : {
+                "max_number_linear_iteration" : 8, "abs_conv_tol" : 1.e-10,
+                "type" : { "multigrid" : { "nlevels" : %d, "npresmoothing" : 1, "npostsmoothing" : 1, "mgtype" : "V_cycle",
+                    "smoother" : { "type" : { "gmres" : { "ksp" : "gmres", "precond" : "ilu", "rtol" : 1.e-12, "atol" : 1.e-20, "divtol" : 1.e+50,
+                                                          "max_its" : 4 } } } } } } } } } } }
+}
+""" % (name, fe_order, nlevels)
+
+
+@gpu
+@pytest.mark.parametrize("name", sorted(MESH_2D))
+@pytest.mark.parametrize("fe_order,fe", [("first", "linear"), ("serendipity", "serendipity"), ("second", "biquadratic")])
+def test_001_poisson_on_the_two_dimensional_gambit_files(ctx, tmp_path, name, fe_order, fe):
+    """applications/001_Poisson with a two-dimensional Gambit file of quadrilaterals and triangles (and of triangles alone) on four levels, source 1 + x y, the
+    boundary set of the file held at zero (SetBoundaryCondition: every face name but 3 is Dirichlet): through app_poisson on the GPU against the oracle's direct
+    solve of the finest level's problem, 1e-10; meshes equal to the oracle's on every level"""
+    from femus_amd import app_poisson as app
+    path = os.path.join(HERE, "golden", name)
+    os.makedirs(tmp_path / "input")
+    (tmp_path / "input" / name).write_bytes(open(path, "rb").read())
+    p = app.Poisson001(ctx, _config_2d(name, fe_order, 4), base_dir=str(tmp_path))
+    assert p.mixed and p.dim == 2 and p.fe == fe
+    p.max_linear, p.abs_tol = 40, 1e-13
+    out = p.run()
+    assert out["converged"], out["history"]
+    ref, meshes = om.solve(om.read_gambit(path), 4, fe, lambda x: 1.0 + x[0] * x[1], dirichlet_flags=(-2,), flux_by_flag=None)
+    for (ed_p, xs_p, ff_p), (_, ed_o, xs_o, ff_o, _) in zip(out["levels"], meshes):
+        assert np.array_equal(ed_p, ed_o) and np.array_equal(ff_p, ff_o) and np.abs(xs_p - xs_o).max() < 2e-15
+    assert out["dofs"] == ref.size and np.abs(ref).max() > 1e-3
+    assert np.abs(out["solution"] - ref).max() < 1e-10
+    p.destroy()
