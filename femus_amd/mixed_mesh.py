@@ -87,6 +87,8 @@ def read_gambit(path, Lref=1.0):
     nvt, nel, ngroup, nbcd, dim, _ = (int(t) for t in tok[p:p + 6])
     if dim not in (2, 3):
         raise ValueError("%s: a %d-dimensional mesh" % (path, dim))
+    if ngroup != 1:          # several groups: Mesh.cpp:626-690 orders the elements by (material, group, index) -- not built here, refused rather than mis-ordered
+        raise ValueError("%s: %d element groups; this reader keeps the file's element order, which is the reference's only for one group" % (path, ngroup))
     p = tok.index("COORDINATES") + 2
     xyz = np.array(tok[p:p + (1 + dim) * nvt], dtype=object).reshape(nvt, 1 + dim)[:, 1:].astype(float) / Lref
     p = tok.index("ELEMENTS/CELLS") + 2

@@ -49,6 +49,8 @@ def read_gambit(path, Lref=1.0):
     tok = open(path).read().split()
     p = tok.index("NDFVL") + 1
     nvt, nel, ngroup, nbcd, dim, _ = (int(t) for t in tok[p:p + 6])
+    if ngroup != 1:          # several groups: Mesh.cpp:626-690 orders the elements by (material, group, index) -- not built here, refused rather than mis-ordered
+        raise ValueError("%s: %d element groups; this reader keeps the file's element order, which is the reference's only for one group" % (path, ngroup))
     if dim != 3:
         raise ValueError("%s: a %d-dimensional mesh where tetrahedra are expected" % (path, dim))
     p = tok.index("COORDINATES") + 2

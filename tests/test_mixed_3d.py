@@ -246,6 +246,15 @@ def test_the_application_tells_the_mesh_files_apart(tmp_path):
     bad.write_text(text)
     with pytest.raises(ValueError, match="element 1 of Gambit type 7"):
         mixed_mesh.read_gambit(str(bad))
+    two = tmp_path / "two_groups.neu"
+    lines = open(MESH).read().split("\n")
+    k = [i for i, l in enumerate(lines) if "NGRPS" in l][0] + 1
+    t = lines[k].split()
+    t[2] = "2"
+    lines[k] = " ".join(t)
+    two.write_text("\n".join(lines))
+    with pytest.raises(ValueError, match="2 element groups"):
+        mixed_mesh.read_gambit(str(two))
 
 
 # ---- two dimensions: the Gambit files of QUAD9 and TRI6 elements the reference tree holds (59 files mix the two, 73 hold triangles alone) ------------------------
