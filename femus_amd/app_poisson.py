@@ -237,7 +237,7 @@ class Poisson001:
             tok = f.read().split()
         if "ELEMENTS/CELLS" not in tok or "NDFVL" not in tok:
             return None
-        nel = int(tok[tok.index("NDFVL") + 2])
+        nel, ngroup = int(tok[tok.index("NDFVL") + 2]), int(tok[tok.index("NDFVL") + 3])
         p = tok.index("ELEMENTS/CELLS") + 2
         seen = set()
         for _ in range(nel):
@@ -245,7 +245,8 @@ class Poisson001:
             p += 3 + int(tok[p + 2])
         if len(seen) > 1:
             return "mixed"
-        return {("6", "10"): "tet10", ("5", "18"): "wedge18", ("3", "6"): "mixed"}.get(seen.pop())         # (TRI6 files go through the mixed-shape reader)
+        kind = {("6", "10"): "tet10", ("5", "18"): "wedge18", ("3", "6"): "mixed"}.get(seen.pop())         # (TRI6 files go through the mixed-shape reader)
+        return "mixed" if (kind is not None and ngroup > 1) else kind       # (and so do files with several element groups: it orders the elements by them)
 
     def run_mixed(self, log=None, smoother=capi.SMOOTH_GS_COLOR, omega=1.0):
         """a Gambit mesh of mixed shapes (input3D.json / input3D_All_first.json with input/cube_all_shapes_Six_boundary_groups.neu: tetrahedra, prisms and

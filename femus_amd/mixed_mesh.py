@@ -3,7 +3,7 @@ Gambit files of quadrilaterals and / or triangles the reference tree holds (QUAD
 numerics run in libfemus_hip.so.  A mesh is (kind[nel] of "hex" / "tet" / "wedge" / "quad" / "tri", ed[nel, 27] padded with -1, xs[nnode, dim], ff[nel, 6] padded
 with -1, own[3]).
 
-    read_gambit   GambitIO.cpp:101-330: HEX27 (type 4), TET10 (type 6), WEDGE18 (type 5), QUAD9 (type 2), TRI6 (type 3) in the file's order (one group: Mesh.cpp:626-690 keeps it), nodes through
+    read_gambit   GambitIO.cpp:101-330: HEX27 (type 4), TET10 (type 6), WEDGE18 (type 5), QUAD9 (type 2), TRI6 (type 3) ordered by (material, group, file index) as Mesh.cpp:626-690 orders them, nodes through
                   GambitToFemusVertexIndex (:55-69), faces through GambitToFemusFaceIndex (:84-86), flag = -(set name) - 1;
                   Mesh::AddBiquadraticNodesNotInMeshFile (Mesh.cpp:1207-1333): a node per TRIANGLE face -- shared between a tetrahedron and a prism as well --,
                   created by the first element that holds it, then a centre per tetrahedron / prism / triangle; coordinates with the weights of Mesh.cpp:105-122
@@ -81,14 +81,12 @@ def _apply(new, raw):
     return np.where(raw >= 0, new[np.maximum(raw, 0)], -1)
 
 
-def read_gambit(path, Lref=1.0):
+def read_gambit(path, Lref=1.0, groups=False):
     tok = open(path).read().split()
     p = tok.index("NDFVL") + 1
     nvt, nel, ngroup, nbcd, dim, _ = (int(t) for t in tok[p:p + 6])
     if dim not in (2, 3):
         raise ValueError("%s: a %d-dimensional mesh" % (path, dim))
-    if ngroup != 1:          # several groups: Mesh.cpp:626-690 orders the elements by (material, group, index) -- not built here, refused rather than mis-ordered
-        raise ValueError("%s: %d element groups; this reader keeps the file's element order, which is the reference's only for one group" % (path, ngroup))
     p = tok.index("COORDINATES") + 2
     xyz = np.array(tok[p:p + (1 + dim) * nvt], dtype=object).reshape(nvt, 1 + dim)[:, 1:].astype(float) / Lref
     p = tok.index("ELEMENTS/CELLS") + 2
@@ -140,10 +138,23 @@ def read_gambit(path, Lref=1.0):
                     acc += coords[raw[e, i]] * W[j][i]
                 coords[raw[e, j0 + j]] = acc
     kind = np.array(kind)
+    # GambitIO.cpp:290-321: group = the integer on the line under "GROUP:", material = its MATERIAL field; Mesh.cpp:626-690: the elements ordered by
+    # (material, group, file index) -- after the added nodes were made in file order, before the nodes are numbered
+    group, material = np.ones(nel, dtype=np.int64), np.zeros(nel, dtype=np.int64)
+    q = 0
+    for _ in range(ngroup):
+        q = tok.index("GROUP:", q)
+        ngel, mat, name = int(tok[q + 3]), int(tok[q + 5]), int(tok[q + 8])
+        ids = np.array(tok[q + 10:q + 10 + ngel], dtype=np.int64) - 1
+        group[ids], material[ids] = name, mat
+        q += 10 + ngel
+    order = np.lexsort((np.arange(nel), group, material))
+    kind, raw, ff, group, material = kind[order], raw[order], ff[order], group[order], material[order]
     new, own = _renumber(kind, raw, nn)
     xs = np.empty_like(coords)
     xs[new] = coords
-    return kind, _apply(new, raw), xs, ff, own
+    out = (kind, _apply(new, raw), xs, ff, own)
+    return out + (group, material) if groups else out
 
 
 def refine(kind, ed, xs, ff):

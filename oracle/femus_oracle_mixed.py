@@ -97,7 +97,7 @@ def read_gambit(path):
     tok = open(path).read().split()
     p = tok.index("NDFVL") + 1
     nvt, nel, ngroup, nbcd, dim, _ = (int(t) for t in tok[p:p + 6])
-    assert dim in (2, 3) and ngroup == 1
+    assert dim in (2, 3)
     p = tok.index("COORDINATES") + 2
     xyz = np.zeros((nvt, dim))
     for n in range(nvt):
@@ -160,6 +160,27 @@ def read_gambit(path):
                 acc += coords[raw[e, i]] * W[j][i]
             coords[raw[e, j0 + j]] = acc
     kind = np.array(kind)
+    # GambitIO.cpp:298-320: "GROUP:" k "ELEMENTS:" n "MATERIAL:" m "NFLAGS:" f, the group's name (read as its number), the flags, the n elements;
+    # Mesh.cpp:626-690 (mesh_reorder_elem_quantities): a bubble sort of the elements by material, then group, then index
+    group, material = [1] * nel, [0] * nel
+    q = 0
+    for _ in range(ngroup):
+        q = tok.index("GROUP:", q)
+        ngel, mat, name = int(tok[q + 3]), int(tok[q + 5]), int(tok[q + 8])
+        for i in range(ngel):
+            group[int(tok[q + 10 + i]) - 1], material[int(tok[q + 10 + i]) - 1] = name, mat
+        q += 10 + ngel
+    inv = list(range(nel))
+    n = nel
+    while n > 1:
+        newn = 0
+        for j in range(1, n):
+            a, b = inv[j - 1], inv[j]
+            if material[b] < material[a] or (material[b] == material[a] and (group[b] < group[a] or (group[b] == group[a] and b < a))):
+                inv[j - 1], inv[j] = b, a
+                newn = j
+        n = newn
+    kind, raw, ff = kind[inv], raw[inv], ff[inv]
     new, own = _renumber(kind, raw, nn)
     xs = np.empty_like(coords)
     xs[new] = coords

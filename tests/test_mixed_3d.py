@@ -246,19 +246,46 @@ def test_the_application_tells_the_mesh_files_apart(tmp_path):
     bad.write_text(text)
     with pytest.raises(ValueError, match="element 1 of Gambit type 7"):
         mixed_mesh.read_gambit(str(bad))
-    two = tmp_path / "two_groups.neu"
-    lines = open(MESH).read().split("\n")
+    # several element groups: the single-shape readers refuse (they keep the file's order), the application sends such a file to the mixed reader, which orders
+    # the elements by (material, group, index)
+    from femus_amd import tet_mesh
+    tet = os.path.join(g, "cube_Tet.neu")
+    lines = open(tet).read().split("\n")
     k = [i for i, l in enumerate(lines) if "NGRPS" in l][0] + 1
     t = lines[k].split()
     t[2] = "2"
     lines[k] = " ".join(t)
+    two = tmp_path / "two_groups.neu"
     two.write_text("\n".join(lines))
     with pytest.raises(ValueError, match="2 element groups"):
-        mixed_mesh.read_gambit(str(two))
+        tet_mesh.read_gambit(str(two))
+    assert app.Poisson001._gambit_kind(str(two)) == "mixed"
+
+
+def test_element_groups_order_the_elements():
+    """triAMR.neu (applications/MGAMR/ex4/input: eight TRI6 elements in four groups named 5 .. 8, one material): Mesh.cpp:626-690 orders the elements by material,
+    group, file index -- file elements 7 8 3 4 5 6 1 2 --, after the triangle centres were added in file order; the oracle's literal bubble sort and the product's
+    key sort agree, and the boundary sets follow their elements (set 3: four edges)"""
+    from femus_amd import mixed_mesh
+    path = os.path.join(HERE, "golden", "triAMR.neu")
+    kind, ed, xs, ff, own, group, material = mixed_mesh.read_gambit(path, groups=True)
+    assert group.tolist() == [5, 5, 6, 6, 7, 7, 8, 8] and set(material.tolist()) == {2}
+    ko, eo, xo, fo_, oo = om.read_gambit(path)
+    assert np.array_equal(ed, eo) and np.array_equal(xs, xo) and np.array_equal(ff, fo_) and own == oo
+    # the first element of the ordered mesh is element 7 of the file: its vertices are the file's nodes of that line
+    tok = open(path).read().split()
+    p = tok.index("ELEMENTS/CELLS") + 2 + 6 * 9
+    assert tok[p] == "7"
+    filenodes = np.array(tok[p + 3:p + 9], dtype=np.int64) - 1
+    q = tok.index("COORDINATES") + 2
+    xyz = np.array(tok[q:q + 3 * 25], dtype=object).reshape(25, 3)[:, 1:].astype(float)
+    assert np.array_equal(xs[ed[0, [0, 3, 1, 4, 2, 5]]], xyz[filenodes])
+    assert [(ff == f).sum() for f in (-2, -3, -4)] == [2, 2, 4]
 
 
 # ---- two dimensions: the Gambit files of QUAD9 and TRI6 elements the reference tree holds (59 files mix the two, 73 hold triangles alone) ------------------------
-MESH_2D = {"square_mixed.neu": "applications/MPM_FEM/ex11/input/square_mixed.neu", "tri2.neu": "applications/ISM/ex1/input/tri2.neu"}
+MESH_2D = {"square_mixed.neu": "applications/MPM_FEM/ex11/input/square_mixed.neu", "tri2.neu": "applications/ISM/ex1/input/tri2.neu",
+           "triAMR.neu": "applications/MGAMR/ex4/input/triAMR.neu"}
 
 
 @pytest.mark.parametrize("name", sorted(MESH_2D))
@@ -326,7 +353,8 @@ def _config_2d(name, fe_order, nlevels):
 @pytest.mark.parametrize("fe_order,fe", [("first", "linear"), ("serendipity", "serendipity"), ("second", "biquadratic")])
 def test_001_poisson_on_the_two_dimensional_gambit_files(ctx, tmp_path, name, fe_order, fe):
     """applications/001_Poisson with a two-dimensional Gambit file of quadrilaterals and triangles (and of triangles alone) on four levels, source 1 + x y, the
-    boundary set of the file held at zero (SetBoundaryCondition: every face name but 3 is Dirichlet): through app_poisson on the GPU against the oracle's direct
+    boundary sets of the file as SetBoundaryCondition treats them (every face name but 3 held at zero, name 3 -- triAMR.neu has it -- with the flux 0.2; that file
+    also orders its elements by their four groups): through app_poisson on the GPU against the oracle's direct
     solve of the finest level's problem, 1e-10; meshes equal to the oracle's on every level"""
     from femus_amd import app_poisson as app
     path = os.path.join(HERE, "golden", name)
@@ -337,7 +365,9 @@ def test_001_poisson_on_the_two_dimensional_gambit_files(ctx, tmp_path, name, fe
     p.max_linear, p.abs_tol = 40, 1e-13
     out = p.run()
     assert out["converged"], out["history"]
-    ref, meshes = om.solve(om.read_gambit(path), 4, fe, lambda x: 1.0 + x[0] * x[1], dirichlet_flags=(-2,), flux_by_flag=None)
+    flags = set(np.unique(om.read_gambit(path)[3]).tolist()) - {-1}
+    ref, meshes = om.solve(om.read_gambit(path), 4, fe, lambda x: 1.0 + x[0] * x[1], dirichlet_flags=tuple(flags - {-4}),
+                           flux_by_flag={-4: 0.2} if -4 in flags else None)
     for (ed_p, xs_p, ff_p), (_, ed_o, xs_o, ff_o, _) in zip(out["levels"], meshes):
         assert np.array_equal(ed_p, ed_o) and np.array_equal(ff_p, ff_o) and np.abs(xs_p - xs_o).max() < 2e-15
     assert out["dofs"] == ref.size and np.abs(ref).max() > 1e-3
