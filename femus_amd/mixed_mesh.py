@@ -84,9 +84,11 @@ def _apply(new, raw):
 def read_gambit(path, Lref=1.0, groups=False):
     tok = open(path).read().split()
     p = tok.index("NDFVL") + 1
-    nvt, nel, ngroup, nbcd, dim, _ = (int(t) for t in tok[p:p + 6])
+    nvt, nel, ngroup, nbcd, dim, dim_nodes = (int(t) for t in tok[p:p + 6])
     if dim not in (2, 3):
         raise ValueError("%s: a %d-dimensional mesh" % (path, dim))
+    if dim_nodes != dim:     # GambitIO.cpp:128, 246-270: the nodes carry NDFVL coordinates -- a surface in space (the Willmore / conformal applications)
+        raise ValueError("%s: %d-dimensional elements with %d coordinates per node (a surface in space): not served" % (path, dim, dim_nodes))
     p = tok.index("COORDINATES") + 2
     xyz = np.array(tok[p:p + (1 + dim) * nvt], dtype=object).reshape(nvt, 1 + dim)[:, 1:].astype(float) / Lref
     p = tok.index("ELEMENTS/CELLS") + 2

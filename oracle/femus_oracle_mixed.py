@@ -96,8 +96,8 @@ def _apply(new, raw):
 def read_gambit(path):
     tok = open(path).read().split()
     p = tok.index("NDFVL") + 1
-    nvt, nel, ngroup, nbcd, dim, _ = (int(t) for t in tok[p:p + 6])
-    assert dim in (2, 3)
+    nvt, nel, ngroup, nbcd, dim, dim_nodes = (int(t) for t in tok[p:p + 6])
+    assert dim in (2, 3) and dim_nodes == dim
     p = tok.index("COORDINATES") + 2
     xyz = np.zeros((nvt, dim))
     for n in range(nvt):

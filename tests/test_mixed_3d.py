@@ -373,3 +373,47 @@ def test_001_poisson_on_the_two_dimensional_gambit_files(ctx, tmp_path, name, fe
     assert out["dofs"] == ref.size and np.abs(ref).max() > 1e-3
     assert np.abs(out["solution"] - ref).max() < 1e-10
     p.destroy()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/applications"), reason="the reference tree is not here")
+def test_the_reader_on_the_small_gambit_files_of_the_reference_tree():
+    """every distinct Gambit file of the reference tree up to 40 kB that holds other shapes than HEX27 / QUAD9 alone (the whole tree: tests/dev/sweep_reference_neu.py,
+    profiles/r06_gambit_reader_sweep.txt): read and refined once by femus_amd/mixed_mesh.py -- the measure is kept, the boundary faces are multiplied by 4 (edges by
+    2); a surface in space is refused with its message"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sweep", os.path.join(HERE, "dev", "sweep_reference_neu.py"))
+    sw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sw)
+    from femus_amd import mixed_mesh
+    seen, done, refused = set(), 0, 0
+    for root, _, files in os.walk("/root/reference"):
+        for f in sorted(files):
+            p = os.path.join(root, f)
+            if not f.endswith(".neu") or os.path.getsize(p) > 40000:
+                continue
+            raw = open(p, "rb").read()
+            if hash(raw) in seen:
+                continue
+            seen.add(hash(raw))
+            tok = raw.decode(errors="ignore").split()
+            q = tok.index("NDFVL") + 1
+            k = tok.index("ELEMENTS/CELLS") + 2
+            types = set()
+            for _ in range(int(tok[q + 1])):
+                types.add((int(tok[k + 1]), int(tok[k + 2])))
+                k += 3 + int(tok[k + 2])
+            if types <= {(4, 27)} or types <= {(2, 9)}:
+                continue
+            if int(tok[q + 4]) != int(tok[q + 5]):
+                with pytest.raises(ValueError, match="a surface in space"):
+                    mixed_mesh.read_gambit(p)
+                refused += 1
+                continue
+            m = mixed_mesh.read_gambit(p)
+            v0, _ = sw.measure(m[0], m[1], m[2])
+            m1 = mixed_mesh.refine(*m[:4])
+            v1, _ = sw.measure(m1[0], m1[1], m1[2])
+            assert v0 > 0 and abs(v1 - v0) <= 1e-9 * v0, p
+            assert int((m1[3] < -1).sum()) == int((m[3] < -1).sum()) * (4 if m[2].shape[1] == 3 else 2), p
+            done += 1
+    assert done >= 20
