@@ -397,7 +397,8 @@ int fh_assemble_advdiff_line(fh_ctx_t ctx, int fe, int gauss_order, int nel, con
  * tensor-product assemblers on small meshes). */
 int fh_assemble_poisson_rows(fh_ctx_t ctx, int geom, int fe, int gauss_order, int nel, int nloc, const int* elem_dof, int nnode, const double* coords, fh_vec_t sol,
                              fh_expr_t source, double scale, fh_mat_t KK, fh_vec_t RES);
-/* The same on a mesh of MIXED shapes (applications/001_Poisson/input/cube_all_shapes*.neu: hexahedra, tetrahedra and prisms in one file; the element loop of
+/* The same on a mesh of MIXED shapes (applications/001_Poisson/input/cube_all_shapes*.neu: hexahedra, tetrahedra and prisms in one file; quadrilaterals and
+ * triangles in two dimensions; the element loop of
  * main.cpp:355-480 asks every element for its own type): elem_geom[nel] = the geom id of every element (at most three different ones, of one dimension), rows of
  * elem_dof padded to nloc.  A row's entries are summed in ascending element order whatever the shapes. */
 int fh_assemble_poisson_mixed(fh_ctx_t ctx, int fe, int gauss_order, int nel, int nloc, const int* elem_geom, const int* elem_dof, int nnode, const double* coords,
