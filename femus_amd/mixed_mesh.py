@@ -13,7 +13,7 @@ with -1, own[3]).
 """
 import numpy as np
 
-from . import capi
+from . import _mesh_keys, capi
 
 SHAPES = ("hex", "tet", "wedge", "quad", "tri")
 NLOC = {"hex": 27, "tet": 15, "wedge": 21, "quad": 9, "tri": 7}
@@ -49,14 +49,7 @@ def tables(shape):
     return _T[shape]
 
 
-def _first_touch(keys):
-    """one id per distinct key, numbered by first appearance; returns (id per key, index of the creating entry per id)"""
-    uniq, first, inv = np.unique(keys, axis=0, return_index=True, return_inverse=True)
-    rank = np.empty(uniq.shape[0], dtype=np.int64)
-    rank[np.argsort(first, kind="stable")] = np.arange(uniq.shape[0])
-    owner = np.empty(uniq.shape[0], dtype=np.int64)
-    owner[rank] = first
-    return rank[inv.ravel()], owner
+_first_touch = _mesh_keys.first_touch
 
 
 def _renumber(kind, raw, nnode):

@@ -12,7 +12,7 @@ TET10, the face and centre nodes FEMuS adds (TET15), refinement, numbering.
 """
 import numpy as np
 
-from . import capi
+from . import _mesh_keys, capi
 
 G2F = (0, 4, 1, 6, 5, 2, 7, 8, 9, 3)
 # Mesh.cpp:107-113: weights of the ten file nodes in the four face nodes and in the centre
@@ -21,14 +21,7 @@ WGT = np.array([[-1. / 9., -1. / 9., -1. / 9., 0, 4. / 9., 4. / 9., 4. / 9., 0, 
                 [-1. / 8.] * 4 + [1. / 4.] * 6])
 
 
-def _first_touch(keys):
-    """one id per distinct key, numbered by first appearance; returns (id per key, index of the creating entry per id)"""
-    uniq, first, inv = np.unique(keys, axis=0, return_index=True, return_inverse=True)
-    rank = np.empty(uniq.shape[0], dtype=np.int64)
-    rank[np.argsort(first, kind="stable")] = np.arange(uniq.shape[0])
-    owner = np.empty(uniq.shape[0], dtype=np.int64)
-    owner[rank] = first
-    return rank[inv.ravel()], owner
+_first_touch = _mesh_keys.first_touch
 
 
 def _renumber(raw, nnode):

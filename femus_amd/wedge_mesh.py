@@ -12,7 +12,7 @@ triangle-face and centre nodes FEMuS adds (WEDGE21), refinement, numbering.
 """
 import numpy as np
 
-from . import capi
+from . import _mesh_keys, capi
 
 G2F = (3, 11, 5, 9, 10, 4, 12, 17, 14, 15, 16, 13, 0, 8, 2, 6, 7, 1)
 GFACE = (2, 1, 0, 4, 3)
@@ -41,14 +41,7 @@ def _tables():
     return faces, edges
 
 
-def _first_touch(keys):
-    """one id per distinct key, numbered by first appearance; returns (id per key, index of the creating entry per id)"""
-    uniq, first, inv = np.unique(keys, axis=0, return_index=True, return_inverse=True)
-    rank = np.empty(uniq.shape[0], dtype=np.int64)
-    rank[np.argsort(first, kind="stable")] = np.arange(uniq.shape[0])
-    owner = np.empty(uniq.shape[0], dtype=np.int64)
-    owner[rank] = first
-    return rank[inv.ravel()], owner
+_first_touch = _mesh_keys.first_touch
 
 
 def read_gambit(path, Lref=1.0):
