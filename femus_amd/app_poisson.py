@@ -381,7 +381,15 @@ class Poisson001:
         return result
 
     def _pattern_from_elements(self, eds, ndof):
-        """CSR pattern holding every (i, j) of every element; eds: one elem_dof array per shape"""
+        """CSR pattern holding every (i, j) of every element; eds: one elem_dof array per shape.  Built on the device (fh_mat_create_from_elements) from one table
+        padded to the widest shape with each element's first dof (a repeated dof adds no entry); the array version below serves rows the device builder's
+        candidate lists do not hold"""
+        width = max(ed.shape[1] for ed in eds)
+        table = np.concatenate([np.concatenate([ed, np.broadcast_to(ed[:, :1], (ed.shape[0], width - ed.shape[1]))], axis=1) for ed in eds])
+        try:
+            return capi.Mat.from_elements(self.ctx, table, ndof)
+        except capi.FemusHipError:
+            pass
         keys = []
         for ed in eds:
             nc = ed.shape[1]
